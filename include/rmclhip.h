@@ -1,0 +1,261 @@
+/*
+ * rmclhip.h -- C ABI of librmclhip.so: the MI355X (gfx950) implementation of
+ * RMCL / MICP-L's ray-casting-correspondence + pose-correction hot path.
+ *
+ * This is the drop-in boundary.  Every entry point names the
+ * reference interface it replaces (paths relative to the uos/rmcl tree).  The
+ * C++ adapters in include/rmcl_hip/ present it with the reference's class
+ * shapes (Correspondences_<MemT>, SensorUpdater<MemT>); INTEGRATION.md shows the
+ * reference-side glue.
+ *
+ * Conventions
+ *  - plain pointers + sizes, no C++ / torch types; all structs are PODs with the
+ *    reference's in-memory layouts (rmagine::Transform = {Quaternion{x,y,z,w},
+ *    Vector{x,y,z}, uint32 stamp} = 32 B, pinned by
+ *    rmcl_ros/src/nodes/rmcl_localization.cpp:245-249).
+ *  - every function returns rmclhip_status (0 = OK) and never throws; the text
+ *    of the last error on the calling thread is rmclhip_last_error().
+ *    (The reference throws std::runtime_error -- micp_localization.cpp:613,
+ *    PCDSensorUpdaterOptix.cpp:179-192 -- the C++ adapters rethrow.)
+ *  - there is NO CPU fallback: without a HIP device every compute call fails
+ *    with RMCLHIP_ERR_NO_DEVICE.
+ *  - a handle is thread-compatible (no concurrent calls on one handle); each
+ *    rcc / pf handle owns one HIP stream; calls are synchronous on return unless
+ *    suffixed _async.
+ *  - pointers suffixed _dev are device pointers (hipMalloc'd, e.g. a torch
+ *    tensor's data_ptr()); all other pointers are host memory.
+ */
+#ifndef RMCLHIP_H
+#define RMCLHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RMCLHIP_VERSION_MAJOR 0
+#define RMCLHIP_VERSION_MINOR 1
+
+typedef int rmclhip_status;
+enum {
+  RMCLHIP_OK = 0,
+  RMCLHIP_ERR_INVALID = 1,    /* bad argument / state (reference: std::runtime_error) */
+  RMCLHIP_ERR_NO_DEVICE = 2,  /* no HIP device: the product has no CPU path */
+  RMCLHIP_ERR_HIP = 3,        /* a HIP runtime call failed (reference: RM_CUDA_CHECK throw) */
+  RMCLHIP_ERR_NOMEM = 4,
+  RMCLHIP_ERR_UNSUPPORTED = 5
+};
+
+/* ---- PODs ------------------------------------------------------------------ */
+typedef struct { float x, y, z; } rmclhip_vec3;
+typedef struct { float x, y, z, w; } rmclhip_quat;
+/* rmagine::Transform (rmcl_localization.cpp:245-249) */
+typedef struct { rmclhip_quat R; rmclhip_vec3 t; uint32_t stamp; } rmclhip_transform;
+typedef struct { float min, inc; uint32_t size; } rmclhip_discrete_interval;
+typedef struct { float min, max; } rmclhip_interval;
+/* rmagine::SphericalModel; field meaning pinned by rmcl_ros/src/util/conversions.cpp:22-34
+ * (phi = vertical/rows/height, theta = horizontal/cols/width) */
+typedef struct {
+  rmclhip_discrete_interval phi;
+  rmclhip_discrete_interval theta;
+  rmclhip_interval range;
+} rmclhip_spherical_model;
+/* rmagine::CrossStatistics (members pinned by micp_localization.cpp:87-105,934,1010-1011).
+ * covariance is row-major, C(r,c) = 1/n sum (m_i - model_mean)_r (d_i - dataset_mean)_c */
+typedef struct {
+  rmclhip_vec3 dataset_mean;
+  rmclhip_vec3 model_mean;
+  float covariance[9];
+  uint32_t n_meas;
+} rmclhip_cross_statistics;
+/* rmagine::Gaussian1D + rmcl::ParticleAttributes (ParticleAttributes.hpp:18-34), 36 B */
+typedef struct { float mean, sigma; uint32_t n_meas; } rmclhip_gaussian1d;
+typedef struct { rmclhip_gaussian1d likelihood; float state_sigma[6]; } rmclhip_particle_attributes;
+/* rmcl::RangeMeasurement (RangeMeasurement.hpp:10-21), 64 B; cov row-major */
+typedef struct { rmclhip_vec3 orig, dir; float range; float cov[9]; } rmclhip_range_measurement;
+/* sensor_update.* parameters, defaults PCDSensorUpdaterEmbree.cpp:122-134
+ * (== optix/EvaluationDataOptix.hpp:62-81 minus pointers) */
+typedef struct {
+  float dist_sigma;                 /* 2.0  */
+  float real_hit_sim_miss_error;    /* 100  */
+  float real_miss_sim_hit_error;    /* 100  */
+  float real_miss_sim_miss_error;   /* 0    */
+  rmclhip_interval sensor_range;    /* [0.05, 80] */
+  uint32_t max_n_meas;              /* MAX_N_MEAS = 10000, ParticleAttributes.hpp:34 */
+} rmclhip_pf_params;
+
+typedef struct {
+  uint32_t n_faces, n_vertices;
+  uint32_t n_nodes;        /* BVH4 nodes (128 B each) */
+  uint32_t n_tri_records;  /* == n_faces (64 B each, leaf order) */
+  uint32_t max_depth;      /* BVH4 depth */
+  uint32_t stack_need;     /* worst-case traversal stack entries */
+  uint64_t device_bytes;
+  float bbox_min[3], bbox_max[3];
+} rmclhip_map_info;
+
+typedef struct rmclhip_ctx rmclhip_ctx;
+typedef struct rmclhip_map rmclhip_map;
+typedef struct rmclhip_rcc rmclhip_rcc;
+typedef struct rmclhip_pf rmclhip_pf;
+
+/* ---- library ------------------------------------------------------------------ */
+const char* rmclhip_last_error(void);
+const char* rmclhip_version(void);
+
+/* context = one device (+ default resources). device index as seen by HIP. */
+rmclhip_status rmclhip_ctx_create(int device, rmclhip_ctx** out);
+void rmclhip_ctx_destroy(rmclhip_ctx* ctx);
+rmclhip_status rmclhip_ctx_device_name(rmclhip_ctx* ctx, char* buf, size_t n);
+
+/* ---- map ------------------------------------------------------------------------
+ * replaces rm::import_embree_map / import_optix_map + scene commit
+ * (micp_localization.cpp:187-195; PCDSensorUpdaterEmbree.cpp:143-174): copies the
+ * indexed triangle mesh, builds the BVH on the host, uploads; immutable afterwards.
+ * Ref-counted so it can live in an rm::MapMap-like registry under "<name>.hip". */
+rmclhip_status rmclhip_map_create(rmclhip_ctx* ctx, const float* vertices_xyz, uint32_t n_vertices,
+                                  const uint32_t* faces_ijk, uint32_t n_faces, rmclhip_map** out);
+rmclhip_status rmclhip_map_retain(rmclhip_map* map);
+void rmclhip_map_release(rmclhip_map* map);
+rmclhip_status rmclhip_map_get_info(const rmclhip_map* map, rmclhip_map_info* out);
+
+/* Host-only BVH build (no device needed): fills caller buffers with the exact
+ * arrays map_create uploads.  nodes: n_nodes*32 dwords, tris: n_faces*16 dwords.
+ * Pass NULL buffers to query sizes via info.  Used by the CPU tests to check the
+ * builder's invariants without a GPU. */
+rmclhip_status rmclhip_bvh_build_host(const float* vertices_xyz, uint32_t n_vertices,
+                                      const uint32_t* faces_ijk, uint32_t n_faces,
+                                      rmclhip_map_info* info, uint32_t* nodes_out, size_t nodes_cap_dwords,
+                                      uint32_t* tris_out, size_t tris_cap_dwords);
+
+/* ---- ray-casting correspondences (MICP-L) ------------------------------------------
+ * rmcl::RCCEmbreeSpherical / RCCEmbreeO1Dn / RCCOptixSpherical
+ * (rmcl/include/rmcl/registration/RCCEmbree.hpp:18-83, RCCOptix.hpp:18-93) on top of
+ * rmcl::Correspondences_<MemT> (Correspondences.hpp:16-88). */
+rmclhip_status rmclhip_rcc_create(rmclhip_ctx* ctx, rmclhip_map* map, rmclhip_rcc** out);
+void rmclhip_rcc_destroy(rmclhip_rcc* rcc);
+/* Correspondences_::setTsb (Correspondences.hpp:31-34; RCCEmbree.cpp:15-19) */
+rmclhip_status rmclhip_rcc_set_tsb(rmclhip_rcc* rcc, const rmclhip_transform* Tsb);
+/* rm::ModelSetter<SphericalModel>::setModel (RCCEmbree.cpp:21-24) */
+rmclhip_status rmclhip_rcc_set_model_spherical(rmclhip_rcc* rcc, const rmclhip_spherical_model* model);
+/* rm::ModelSetter<O1DnModel>::setModel (RCCEmbree.cpp:84-87; fields conversions.cpp:74-94):
+ * dirs_xyz is width*height*3 floats, row-major buffer id = vid*width + hid */
+rmclhip_status rmclhip_rcc_set_model_o1dn(rmclhip_rcc* rcc, uint32_t width, uint32_t height,
+                                          rmclhip_interval range, rmclhip_vec3 orig, const float* dirs_xyz);
+/* public members Correspondences_::params.max_dist / adaptive_max_dist_min
+ * (written by the node: micp_localization.cpp:608-609) */
+rmclhip_status rmclhip_rcc_set_params(rmclhip_rcc* rcc, float max_dist, float adaptive_max_dist_min);
+/* Correspondences_::dataset {points, mask} (filled by MICPSphericalSensorCPU::unpackMessage,
+ * MICPSphericalSensorCPU.cpp:181-233).  src_is_device != 0: pointers are device memory.
+ * mask may be NULL (all valid). */
+rmclhip_status rmclhip_rcc_set_dataset(rmclhip_rcc* rcc, const float* points_xyz, const uint8_t* mask,
+                                       uint32_t n, int src_is_device);
+/* convenience mirror of unpackMessage: ranges -> dataset points = dir(vid,hid)*range (+orig for
+ * O1Dn), mask = range in [range.min, range.max]; returns valid count */
+rmclhip_status rmclhip_rcc_set_dataset_from_ranges(rmclhip_rcc* rcc, const float* ranges, uint32_t n,
+                                                   uint32_t* n_valid_out);
+/* RCC*::find(Tbm_est) (RCCEmbree.cpp:26-36, RCCOptix.cpp:28-43): grow-only model buffers,
+ * simulate {points, normals, hits} (+ ranges, face ids) in the SENSOR frame. No-op on an empty model. */
+rmclhip_status rmclhip_rcc_find(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est);
+rmclhip_status rmclhip_rcc_find_async(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est);
+rmclhip_status rmclhip_rcc_sync(rmclhip_rcc* rcc);
+/* Correspondences{CPU,CUDA}::computeCrossStatistics (CorrespondencesCPU.cpp:10-39):
+ * max_dist' = max_dist (1-p) + adaptive_max_dist_min p; rm::statistics_p2l(T_snew_sold, ...) */
+rmclhip_status rmclhip_rcc_compute_cross_statistics(rmclhip_rcc* rcc, const rmclhip_transform* T_snew_sold,
+                                                    double convergence_progress,
+                                                    rmclhip_cross_statistics* out);
+/* modelView() read-back (Correspondences.hpp:47-55) + ranges / face ids. Any pointer may be NULL.
+ * Sizes: n = model size of the last find. */
+rmclhip_status rmclhip_rcc_download(rmclhip_rcc* rcc, uint8_t* hits, float* ranges, float* points_xyz,
+                                    float* normals_xyz, uint32_t* face_ids);
+/* borrowed device views of the model buffers (valid until the next find that grows them) */
+rmclhip_status rmclhip_rcc_device_views(rmclhip_rcc* rcc, const uint8_t** hits_dev, const float** ranges_dev,
+                                        const float** points_dev, const float** normals_dev,
+                                        const uint32_t** face_ids_dev, uint32_t* n);
+/* MICPLocalizationNode::correctOnce inner loop for ONE sensor, entirely on the device
+ * (micp_localization.cpp:900-964 with MICPSensor.hpp:146-184): find(Tom*Tbo) once, then n_iter x
+ * { T_bnew_bold = ~Tbo T_onew_oold Tbo; T_snew_sold = ~Tsb T_bnew_bold Tsb; reduce; Tsb*, Tbo*;
+ *   umeyama; T_onew_oold *= T_inner }.  Outputs T_onew_oold and the last merged statistics (odom frame). */
+rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* rcc, const rmclhip_transform* Tom,
+                                        const rmclhip_transform* Tbo, uint32_t n_iter,
+                                        double convergence_progress, int refind_each_iteration,
+                                        rmclhip_transform* T_onew_oold_out,
+                                        rmclhip_cross_statistics* stats_o_out);
+/* stale v1 SphereCorrector API (lidar_corrector_embree_benchmark.cpp:86-133): nposes hypotheses share
+ * the dataset; one raycast + reduction + Umeyama per pose; Tdelta_out[i] such that
+ * T_new[i] = Tbm[i] * Tdelta_out[i]. */
+rmclhip_status rmclhip_rcc_correct_batch(rmclhip_rcc* rcc, const rmclhip_transform* Tbm, uint32_t nposes,
+                                         rmclhip_transform* Tdelta_out, rmclhip_cross_statistics* stats_out);
+
+/* kernel timing of the last find / reduction on the handle's stream (hipEvent, ms) */
+rmclhip_status rmclhip_rcc_last_kernel_ms(rmclhip_rcc* rcc, float* find_ms, float* reduce_ms);
+/* benchmarking hook: run `iters` back-to-back find launches on the handle's stream bracketed by
+ * hipEvents on THAT stream; returns the mean kernel-to-kernel time per launch in ms */
+rmclhip_status rmclhip_rcc_time_find(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est, uint32_t iters,
+                                     float* ms_per_launch);
+rmclhip_status rmclhip_rcc_time_reduce(rmclhip_rcc* rcc, const rmclhip_transform* T_snew_sold, uint32_t iters,
+                                       float* ms_per_launch);
+/* kernel variant selection (0 = default packet traversal) */
+rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* rcc, int variant);
+
+/* ---- host-side algebra (rmagine math the callers of the hot path use) -------------- */
+/* rm::umeyama_transform(CrossStatistics) (micp_localization.cpp:952-953) */
+rmclhip_status rmclhip_umeyama_transform(const rmclhip_cross_statistics* stats, rmclhip_transform* out);
+/* CrossStatistics::operator+= (micp_localization.cpp:936-937) */
+rmclhip_status rmclhip_cross_statistics_merge(const rmclhip_cross_statistics* a,
+                                              const rmclhip_cross_statistics* b,
+                                              rmclhip_cross_statistics* out);
+/* Transform * CrossStatistics (MICPSensor.hpp:182, micp_localization.cpp:931) */
+rmclhip_status rmclhip_cross_statistics_transform(const rmclhip_transform* T,
+                                                  const rmclhip_cross_statistics* s,
+                                                  rmclhip_cross_statistics* out);
+/* Transform::operator*, operator~ (micp_localization.cpp:926,963) */
+rmclhip_status rmclhip_transform_mult(const rmclhip_transform* a, const rmclhip_transform* b,
+                                      rmclhip_transform* out);
+rmclhip_status rmclhip_transform_inv(const rmclhip_transform* a, rmclhip_transform* out);
+
+/* ---- particle-filter sensor update (RMCL) --------------------------------------------
+ * rmcl::PCDSensorUpdaterEmbree / PCDSensorUpdaterOptix
+ * (rmcl_ros/src/rmcl/PCDSensorUpdaterEmbree.cpp:244-352, PCDSensorUpdaterOptix.cpp:174-350,
+ *  kernels optix/BeamEvaluateProgram.cu:15-130) behind SensorUpdater<MemT>::update
+ * (rmcl_ros/include/rmcl_ros/rmcl/SensorUpdater.hpp:18-42, ParticleUpdater.hpp:24-44). */
+rmclhip_status rmclhip_pf_create(rmclhip_ctx* ctx, rmclhip_map* map, rmclhip_pf** out);
+void rmclhip_pf_destroy(rmclhip_pf* pf);
+rmclhip_status rmclhip_pf_set_params(rmclhip_pf* pf, const rmclhip_pf_params* params);
+/* update(poses, attrs): all `n_beams` sampled measurements (sensor frame) are applied to every
+ * particle IN ORDER, in one launch; attrs are updated in place on the device.
+ * poses_dev / attrs_dev: device arrays of n_particles rmclhip_transform / rmclhip_particle_attributes. */
+rmclhip_status rmclhip_pf_update(rmclhip_pf* pf, const rmclhip_transform* poses_dev,
+                                 rmclhip_particle_attributes* attrs_dev, uint32_t n_particles,
+                                 const rmclhip_range_measurement* beams, uint32_t n_beams,
+                                 const rmclhip_transform* Tsb);
+rmclhip_status rmclhip_pf_update_async(rmclhip_pf* pf, const rmclhip_transform* poses_dev,
+                                       rmclhip_particle_attributes* attrs_dev, uint32_t n_particles,
+                                       const rmclhip_range_measurement* beams, uint32_t n_beams,
+                                       const rmclhip_transform* Tsb);
+rmclhip_status rmclhip_pf_sync(rmclhip_pf* pf);
+/* optional debug/parity output of the next update: per (particle, beam) error in metres
+ * (device buffer of n_particles*n_beams floats, or NULL to disable) */
+rmclhip_status rmclhip_pf_set_error_output(rmclhip_pf* pf, float* errors_dev);
+/* gather likelihood.mean of every particle into a dense float array (the payload of the
+ * multi-GPU all-gather) */
+rmclhip_status rmclhip_pf_extract_weights(rmclhip_pf* pf, const rmclhip_particle_attributes* attrs_dev,
+                                          uint32_t n_particles, float* weights_dev);
+rmclhip_status rmclhip_pf_time_update(rmclhip_pf* pf, const rmclhip_transform* poses_dev,
+                                      rmclhip_particle_attributes* attrs_dev, uint32_t n_particles,
+                                      const rmclhip_range_measurement* beams, uint32_t n_beams,
+                                      const rmclhip_transform* Tsb, uint32_t iters, float* ms_per_launch);
+rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* pf, int variant);
+
+/* ---- device memory helpers for hosts without their own allocator ---------------------- */
+rmclhip_status rmclhip_malloc(rmclhip_ctx* ctx, size_t bytes, void** out_dev);
+rmclhip_status rmclhip_free(rmclhip_ctx* ctx, void* ptr_dev);
+rmclhip_status rmclhip_memcpy_h2d(rmclhip_ctx* ctx, void* dst_dev, const void* src, size_t bytes);
+rmclhip_status rmclhip_memcpy_d2h(rmclhip_ctx* ctx, void* dst, const void* src_dev, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RMCLHIP_H */

@@ -1,0 +1,393 @@
+"""ctypes front-end of the CPU oracle (oracle/rmcl_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  May be imported by tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg -- never by anything under rmcl_amd/.
+PARITY UNPINNED: see oracle/rmcl_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "librmcl_oracle.so")
+
+# numpy mirrors of the POD structs (identical layout to rmcl_amd.types)
+VEC3 = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4")])
+QUAT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("w", "<f4")])
+TRANSFORM = np.dtype([("R", QUAT), ("t", VEC3), ("stamp", "<u4")])
+CROSS_STATISTICS = np.dtype([("dataset_mean", VEC3), ("model_mean", VEC3),
+                             ("covariance", "<f4", (9,)), ("n_meas", "<u4")])
+GAUSSIAN1D = np.dtype([("mean", "<f4"), ("sigma", "<f4"), ("n_meas", "<u4")])
+PARTICLE_ATTRIBUTES = np.dtype([("likelihood", GAUSSIAN1D), ("state_sigma", "<f4", (6,))])
+RANGE_MEASUREMENT = np.dtype([("orig", VEC3), ("dir", VEC3), ("range", "<f4"), ("cov", "<f4", (9,))])
+assert TRANSFORM.itemsize == 32 and CROSS_STATISTICS.itemsize == 64
+assert PARTICLE_ATTRIBUTES.itemsize == 36 and RANGE_MEASUREMENT.itemsize == 64
+
+
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class Quat(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("w", C.c_float)]
+
+
+class Transform(C.Structure):
+    _fields_ = [("R", Quat), ("t", Vec3), ("stamp", C.c_uint32)]
+
+
+class DiscreteInterval(C.Structure):
+    _fields_ = [("min", C.c_float), ("inc", C.c_float), ("size", C.c_uint32)]
+
+
+class Interval(C.Structure):
+    _fields_ = [("min", C.c_float), ("max", C.c_float)]
+
+
+class SphericalModel(C.Structure):
+    _fields_ = [("phi", DiscreteInterval), ("theta", DiscreteInterval), ("range", Interval)]
+
+
+class CrossStatistics(C.Structure):
+    _fields_ = [("dataset_mean", Vec3), ("model_mean", Vec3), ("covariance", C.c_float * 9),
+                ("n_meas", C.c_uint32)]
+
+
+class Gaussian1D(C.Structure):
+    _fields_ = [("mean", C.c_float), ("sigma", C.c_float), ("n_meas", C.c_uint32)]
+
+
+class PFParams(C.Structure):
+    _fields_ = [("dist_sigma", C.c_float), ("real_hit_sim_miss_error", C.c_float),
+                ("real_miss_sim_hit_error", C.c_float), ("real_miss_sim_miss_error", C.c_float),
+                ("sensor_range", Interval), ("max_n_meas", C.c_uint32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("rays", C.c_uint64)]
+
+
+def build(force=False):
+    """Compile the C restatement (gcc). Called by __graft_entry__.build()."""
+    src = os.path.join(_HERE, "rmcl_oracle.c")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src),
+                                                    os.path.getmtime(os.path.join(_HERE, "rmcl_oracle.h")))):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-B", "librmcl_oracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        build()
+    with open("/proc/cpuinfo") as f:
+        if " fma" not in f.read():
+            raise RuntimeError("oracle is compiled with -mfma but this CPU has no FMA")
+    L = C.CDLL(_LIB_PATH)
+    vp, u32, f32, i32 = C.c_void_p, C.c_uint32, C.c_float, C.c_int
+    L.orc_quat_mult.restype = Quat
+    L.orc_quat_mult.argtypes = [Quat, Quat]
+    L.orc_quat_rotate.restype = Vec3
+    L.orc_quat_rotate.argtypes = [Quat, Vec3]
+    L.orc_transform_mult.restype = Transform
+    L.orc_transform_mult.argtypes = [Transform, Transform]
+    L.orc_transform_inv.restype = Transform
+    L.orc_transform_inv.argtypes = [Transform]
+    L.orc_transform_apply.restype = Vec3
+    L.orc_transform_apply.argtypes = [Transform, Vec3]
+    L.orc_euler_to_quat.restype = Quat
+    L.orc_euler_to_quat.argtypes = [f32, f32, f32]
+    L.orc_mesh_create.restype = vp
+    L.orc_mesh_create.argtypes = [vp, u32, vp, u32, u32]
+    L.orc_mesh_destroy.argtypes = [vp]
+    L.orc_mesh_num_nodes.restype = u32
+    L.orc_mesh_num_nodes.argtypes = [vp]
+    L.orc_mesh_face_normals.argtypes = [vp, vp]
+    L.orc_intersect_brute.restype = i32
+    L.orc_intersect_brute.argtypes = [vp, Vec3, Vec3, f32, f32, C.POINTER(f32), C.POINTER(u32)]
+    L.orc_intersect_bvh.restype = i32
+    L.orc_intersect_bvh.argtypes = [vp, Vec3, Vec3, f32, f32, C.POINTER(f32), C.POINTER(u32), vp]
+    L.orc_trace_bvh4.restype = i32
+    L.orc_trace_bvh4.argtypes = [vp, u32, vp, u32, Vec3, Vec3, f32, f32, C.POINTER(f32), C.POINTER(u32)]
+    L.orc_mesh_tri_records.argtypes = [vp, vp]
+    L.orc_spherical_directions.argtypes = [vp, vp]
+    L.orc_simulate_spherical.restype = i32
+    L.orc_simulate_spherical.argtypes = [vp, vp, vp, vp, u32, i32, i32,
+                                         vp, vp, vp, vp, vp, vp]
+    L.orc_simulate_o1dn.restype = i32
+    L.orc_simulate_o1dn.argtypes = [vp, u32, u32, Interval, Vec3, vp, vp, vp, u32, i32, i32,
+                                    vp, vp, vp, vp, vp, vp]
+    L.orc_statistics_p2l_f32.argtypes = [vp, vp, vp, vp, vp, vp, u32, f32, vp]
+    L.orc_statistics_p2l_f64.argtypes = [vp, vp, vp, vp, vp, vp, u32, f32, vp, vp]
+    L.orc_adaptive_max_dist.restype = f32
+    L.orc_adaptive_max_dist.argtypes = [f32, f32, C.c_double]
+    L.orc_cross_statistics_merge.restype = CrossStatistics
+    L.orc_cross_statistics_merge.argtypes = [CrossStatistics, CrossStatistics]
+    L.orc_cross_statistics_transform.restype = CrossStatistics
+    L.orc_cross_statistics_transform.argtypes = [Transform, CrossStatistics]
+    L.orc_umeyama_transform.restype = Transform
+    L.orc_umeyama_transform.argtypes = [vp]
+    L.orc_svd3.argtypes = [vp, vp, vp, vp]
+    L.orc_gaussian1d_add.restype = Gaussian1D
+    L.orc_gaussian1d_add.argtypes = [Gaussian1D, Gaussian1D]
+    L.orc_evaluate_rcc.restype = f32
+    L.orc_evaluate_rcc.argtypes = [vp, vp, vp, i32]
+    L.orc_pf_update.restype = i32
+    L.orc_pf_update.argtypes = [vp, vp, vp, u32, vp, u32, vp, vp, i32, i32, vp]
+    _lib = L
+    return L
+
+
+# ---------------------------------------------------------------- helpers --
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def transform(q=(0, 0, 0, 1), t=(0, 0, 0)):
+    T = np.zeros((), dtype=TRANSFORM)
+    T["R"]["x"], T["R"]["y"], T["R"]["z"], T["R"]["w"] = q
+    T["t"]["x"], T["t"]["y"], T["t"]["z"] = t
+    return T
+
+
+def _ct_T(T):
+    T = np.ascontiguousarray(T, dtype=TRANSFORM).reshape(())
+    return Transform.from_buffer_copy(T.tobytes())
+
+
+def _np_T(ct):
+    return np.frombuffer(bytes(ct), dtype=TRANSFORM)[0].copy()
+
+
+def euler_to_quat(roll, pitch, yaw):
+    q = lib().orc_euler_to_quat(roll, pitch, yaw)
+    return (q.x, q.y, q.z, q.w)
+
+
+def transform_from_rpy(t, rpy):
+    return transform(euler_to_quat(*rpy), t)
+
+
+def tmult(a, b):
+    return _np_T(lib().orc_transform_mult(_ct_T(a), _ct_T(b)))
+
+
+def tinv(a):
+    return _np_T(lib().orc_transform_inv(_ct_T(a)))
+
+
+def tapply(T, p):
+    v = lib().orc_transform_apply(_ct_T(T), Vec3(*[float(x) for x in p]))
+    return np.array([v.x, v.y, v.z], dtype=np.float32)
+
+
+def _ct_cs(s):
+    s = np.ascontiguousarray(s, dtype=CROSS_STATISTICS).reshape(())
+    return CrossStatistics.from_buffer_copy(s.tobytes())
+
+
+def _np_cs(ct):
+    return np.frombuffer(bytes(ct), dtype=CROSS_STATISTICS)[0].copy()
+
+
+def cs_identity():
+    return np.zeros((), dtype=CROSS_STATISTICS)
+
+
+def cs_merge(a, b):
+    return _np_cs(lib().orc_cross_statistics_merge(_ct_cs(a), _ct_cs(b)))
+
+
+def cs_transform(T, s):
+    return _np_cs(lib().orc_cross_statistics_transform(_ct_T(T), _ct_cs(s)))
+
+
+def umeyama(s):
+    s = np.ascontiguousarray(s, dtype=CROSS_STATISTICS).reshape(1)
+    return _np_T(lib().orc_umeyama_transform(_p(s)))
+
+
+def svd3(A):
+    A = np.ascontiguousarray(A, dtype=np.float64).reshape(9)
+    U = np.zeros(9); w = np.zeros(3); V = np.zeros(9)
+    lib().orc_svd3(_p(A), _p(U), _p(w), _p(V))
+    return U.reshape(3, 3), w, V.reshape(3, 3)
+
+
+def adaptive_max_dist(max_dist, adaptive_min, p):
+    return float(lib().orc_adaptive_max_dist(max_dist, adaptive_min, p))
+
+
+def spherical_model(phi_min, phi_inc, phi_n, theta_min, theta_inc, theta_n, range_min, range_max):
+    m = SphericalModel()
+    m.phi.min, m.phi.inc, m.phi.size = phi_min, phi_inc, phi_n
+    m.theta.min, m.theta.inc, m.theta.size = theta_min, theta_inc, theta_n
+    m.range.min, m.range.max = range_min, range_max
+    return m
+
+
+def pf_params(dist_sigma=2.0, real_hit_sim_miss_error=100.0, real_miss_sim_hit_error=100.0,
+              real_miss_sim_miss_error=0.0, range_min=0.05, range_max=80.0, max_n_meas=10000):
+    """Defaults: PCDSensorUpdaterEmbree.cpp:122-134."""
+    p = PFParams()
+    p.dist_sigma = dist_sigma
+    p.real_hit_sim_miss_error = real_hit_sim_miss_error
+    p.real_miss_sim_hit_error = real_miss_sim_hit_error
+    p.real_miss_sim_miss_error = real_miss_sim_miss_error
+    p.sensor_range.min, p.sensor_range.max = range_min, range_max
+    p.max_n_meas = max_n_meas
+    return p
+
+
+class Mesh:
+    def __init__(self, verts, faces, max_leaf=4):
+        self.verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+        self.faces = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
+        self.h = lib().orc_mesh_create(_p(self.verts), len(self.verts), _p(self.faces), len(self.faces), max_leaf)
+        if not self.h:
+            raise ValueError("orc_mesh_create failed")
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().orc_mesh_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    @property
+    def num_nodes(self):
+        return lib().orc_mesh_num_nodes(self.h)
+
+    def face_normals(self):
+        out = np.zeros((len(self.faces), 3), dtype=np.float32)
+        lib().orc_mesh_face_normals(self.h, _p(out))
+        return out
+
+    def tri_records(self):
+        out = np.zeros((len(self.faces), 15), dtype=np.float32)
+        lib().orc_mesh_tri_records(self.h, _p(out))
+        return out
+
+    def intersect(self, O, D, tnear=0.0, tfar=np.inf, bvh=False):
+        t = C.c_float(0)
+        f = C.c_uint32(0)
+        Ov = Vec3(*[float(x) for x in O])
+        Dv = Vec3(*[float(x) for x in D])
+        if bvh:
+            r = lib().orc_intersect_bvh(self.h, Ov, Dv, tnear, tfar, C.byref(t), C.byref(f), None)
+        else:
+            r = lib().orc_intersect_brute(self.h, Ov, Dv, tnear, tfar, C.byref(t), C.byref(f))
+        return (True, t.value, f.value) if r > 0 else (False, None, None)
+
+    def _alloc(self, n, want):
+        out = {}
+        out["hits"] = np.zeros(n, dtype=np.uint8) if "hits" in want else None
+        out["ranges"] = np.zeros(n, dtype=np.float32) if "ranges" in want else None
+        out["points"] = np.zeros((n, 3), dtype=np.float32) if "points" in want else None
+        out["normals"] = np.zeros((n, 3), dtype=np.float32) if "normals" in want else None
+        out["face_ids"] = np.zeros(n, dtype=np.uint32) if "face_ids" in want else None
+        return out
+
+    def simulate_spherical(self, model, Tsb, Tbm, bvh=True, nthreads=1,
+                           want=("hits", "ranges", "points", "normals", "face_ids"), counters=False):
+        Tbm = np.ascontiguousarray(Tbm, dtype=TRANSFORM).reshape(-1)
+        Tsb = np.ascontiguousarray(Tsb, dtype=TRANSFORM).reshape(1)
+        n = model.phi.size * model.theta.size * len(Tbm)
+        out = self._alloc(n, want)
+        cnt = Counters()
+        lib().orc_simulate_spherical(self.h, C.byref(model), _p(Tsb), _p(Tbm), len(Tbm), int(bvh), nthreads,
+                                     _p(out["hits"]), _p(out["ranges"]), _p(out["points"]), _p(out["normals"]),
+                                     _p(out["face_ids"]), C.addressof(cnt) if counters else None)
+        if counters:
+            out["counters"] = dict(nodes_visited=cnt.nodes_visited, tris_tested=cnt.tris_tested, rays=cnt.rays)
+        return out
+
+    def simulate_o1dn(self, width, height, range_min, range_max, orig, dirs, Tsb, Tbm, bvh=True, nthreads=1,
+                      want=("hits", "ranges", "points", "normals", "face_ids"), counters=False):
+        Tbm = np.ascontiguousarray(Tbm, dtype=TRANSFORM).reshape(-1)
+        Tsb = np.ascontiguousarray(Tsb, dtype=TRANSFORM).reshape(1)
+        dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        assert len(dirs) == width * height
+        n = width * height * len(Tbm)
+        out = self._alloc(n, want)
+        cnt = Counters()
+        rng = Interval(range_min, range_max)
+        lib().orc_simulate_o1dn(self.h, width, height, rng, Vec3(*[float(x) for x in orig]), _p(dirs),
+                                _p(Tsb), _p(Tbm), len(Tbm), int(bvh), nthreads,
+                                _p(out["hits"]), _p(out["ranges"]), _p(out["points"]), _p(out["normals"]),
+                                _p(out["face_ids"]), C.addressof(cnt) if counters else None)
+        if counters:
+            out["counters"] = dict(nodes_visited=cnt.nodes_visited, tris_tested=cnt.tris_tested, rays=cnt.rays)
+        return out
+
+    def pf_update(self, poses, attrs, beams, Tsb, params, bvh=True, nthreads=1, want_errors=False):
+        """In-place update of attrs (returns errors if asked)."""
+        poses = np.ascontiguousarray(poses, dtype=TRANSFORM).reshape(-1)
+        assert attrs.dtype == PARTICLE_ATTRIBUTES and attrs.flags.c_contiguous
+        beams = np.ascontiguousarray(beams, dtype=RANGE_MEASUREMENT).reshape(-1)
+        Tsb = np.ascontiguousarray(Tsb, dtype=TRANSFORM).reshape(1)
+        err = np.zeros((len(poses), len(beams)), dtype=np.float32) if want_errors else None
+        lib().orc_pf_update(self.h, _p(poses), _p(attrs), len(poses), _p(beams), len(beams), _p(Tsb),
+                            C.byref(params), int(bvh), nthreads, _p(err))
+        return err
+
+
+def statistics_p2l(Tpre, dataset_points, dataset_mask, model_points, model_normals, model_mask, max_dist):
+    Tpre = np.ascontiguousarray(Tpre, dtype=TRANSFORM).reshape(1)
+    dp = np.ascontiguousarray(dataset_points, dtype=np.float32).reshape(-1, 3)
+    mp = np.ascontiguousarray(model_points, dtype=np.float32).reshape(-1, 3)
+    mn = np.ascontiguousarray(model_normals, dtype=np.float32).reshape(-1, 3)
+    dm = None if dataset_mask is None else np.ascontiguousarray(dataset_mask, dtype=np.uint8)
+    mm = None if model_mask is None else np.ascontiguousarray(model_mask, dtype=np.uint8)
+    out = np.zeros(1, dtype=CROSS_STATISTICS)
+    lib().orc_statistics_p2l_f32(_p(Tpre), _p(dp), _p(dm), _p(mp), _p(mn), _p(mm), len(dp), max_dist, _p(out))
+    return out[0].copy()
+
+
+def statistics_p2l_f64(Tpre, dataset_points, dataset_mask, model_points, model_normals, model_mask, max_dist):
+    Tpre = np.ascontiguousarray(Tpre, dtype=TRANSFORM).reshape(1)
+    dp = np.ascontiguousarray(dataset_points, dtype=np.float32).reshape(-1, 3)
+    mp = np.ascontiguousarray(model_points, dtype=np.float32).reshape(-1, 3)
+    mn = np.ascontiguousarray(model_normals, dtype=np.float32).reshape(-1, 3)
+    dm = None if dataset_mask is None else np.ascontiguousarray(dataset_mask, dtype=np.uint8)
+    mm = None if model_mask is None else np.ascontiguousarray(model_mask, dtype=np.uint8)
+    out = np.zeros(15, dtype=np.float64)
+    n = np.zeros(1, dtype=np.uint32)
+    lib().orc_statistics_p2l_f64(_p(Tpre), _p(dp), _p(dm), _p(mp), _p(mn), _p(mm), len(dp), max_dist, _p(out), _p(n))
+    return dict(dataset_mean=out[0:3].copy(), model_mean=out[3:6].copy(), covariance=out[6:15].reshape(3, 3).copy(),
+                n_meas=int(n[0]))
+
+
+def gaussian1d_add(a, b):
+    r = lib().orc_gaussian1d_add(Gaussian1D(*a), Gaussian1D(*b))
+    return (r.mean, r.sigma, r.n_meas)
+
+
+def trace_bvh4(nodes, tris, O, D, tnear=0.0, tfar=np.inf):
+    """Closest hit through the PRODUCT's exported BVH4 arrays, with the oracle's intersector."""
+    nodes = np.ascontiguousarray(nodes, dtype=np.uint32)
+    tris = np.ascontiguousarray(tris, dtype=np.uint32)
+    t = C.c_float(0)
+    f = C.c_uint32(0)
+    r = lib().orc_trace_bvh4(_p(nodes), nodes.size // 32, _p(tris), tris.size // 16, Vec3(*[float(x) for x in O]),
+                             Vec3(*[float(x) for x in D]), tnear, tfar, C.byref(t), C.byref(f))
+    if r < 0:
+        raise RuntimeError("malformed BVH4 (code %d)" % r)
+    return (True, t.value, f.value) if r > 0 else (False, None, None)
+
+
+def spherical_directions(model):
+    """(H*W, 3) float32 sensor-frame directions, exactly the values the simulate restatement uses."""
+    out = np.zeros((model.phi.size * model.theta.size, 3), dtype=np.float32)
+    lib().orc_spherical_directions(C.byref(model), _p(out))
+    return out

@@ -1,0 +1,972 @@
+/*
+ * rmcl_oracle.c -- CPU restatement of the RMCL / MICP-L hot path.
+ * TEST INFRASTRUCTURE ONLY (see rmcl_oracle.h).  PARITY UNPINNED (see header).
+ *
+ * Build: gcc -O2 -ffp-contract=off -mfma -fPIC -shared -pthread (oracle/Makefile).
+ * -ffp-contract=off: every fused multiply-add below is an explicit fmaf().
+ */
+#define _GNU_SOURCE
+#include "rmcl_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+/* ------------------------------------------------------------------------- */
+/* vector helpers with a fixed operation order                                */
+/* ------------------------------------------------------------------------- */
+
+static inline orc_vec3 v3(float x, float y, float z) { orc_vec3 r = {x, y, z}; return r; }
+static inline orc_vec3 v_add(orc_vec3 a, orc_vec3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline orc_vec3 v_sub(orc_vec3 a, orc_vec3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline orc_vec3 v_scale(orc_vec3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+/* rmagine Vector3::dot: plain left-to-right sum of products */
+static inline float v_dot_plain(orc_vec3 a, orc_vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+/* Embree's dot/cross on FMA hardware: madd(a.x,b.x,madd(a.y,b.y,a.z*b.z)), msub(...)
+ * (embree4 common/math/vec3.h, kernels/geometry/triangle_intersector_moeller.h) */
+static inline float v_dot_fma(orc_vec3 a, orc_vec3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+static inline orc_vec3 v_cross_fma(orc_vec3 a, orc_vec3 b)
+{
+  return v3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+
+/* ------------------------------------------------------------------------- */
+/* rmagine Quaternion / Transform (external; recollected upstream semantics,  */
+/* SURVEY.md Appendix A): Hamilton product, q*p = q (p,0) q^-1, T*v = R v + t */
+/* ------------------------------------------------------------------------- */
+
+orc_quat orc_quat_mult(orc_quat a, orc_quat b)
+{
+  orc_quat r;
+  r.w = ((a.w * b.w - a.x * b.x) - a.y * b.y) - a.z * b.z;
+  r.x = ((a.w * b.x + a.x * b.w) + a.y * b.z) - a.z * b.y;
+  r.y = ((a.w * b.y - a.x * b.z) + a.y * b.w) + a.z * b.x;
+  r.z = ((a.w * b.z + a.x * b.y) - a.y * b.x) + a.z * b.w;
+  return r;
+}
+
+orc_quat orc_quat_inv(orc_quat q)
+{
+  orc_quat r = {-q.x, -q.y, -q.z, q.w};
+  return r;
+}
+
+orc_vec3 orc_quat_rotate(orc_quat q, orc_vec3 p)
+{
+  const orc_quat P = {p.x, p.y, p.z, 0.0f};
+  const orc_quat PT = orc_quat_mult(orc_quat_mult(q, P), orc_quat_inv(q));
+  return v3(PT.x, PT.y, PT.z);
+}
+
+orc_vec3 orc_transform_apply(orc_transform T, orc_vec3 p)
+{
+  return v_add(orc_quat_rotate(T.R, p), T.t);
+}
+
+orc_transform orc_transform_mult(orc_transform a, orc_transform b)
+{
+  /* P' = R1 (R2 P + t2) + t1 */
+  orc_transform r;
+  r.t = v_add(orc_quat_rotate(a.R, b.t), a.t);
+  r.R = orc_quat_mult(a.R, b.R);
+  r.stamp = a.stamp;
+  return r;
+}
+
+orc_transform orc_transform_inv(orc_transform a)
+{
+  orc_transform r;
+  r.R = orc_quat_inv(a.R);
+  const orc_vec3 rt = orc_quat_rotate(r.R, a.t);
+  r.t = v3(-rt.x, -rt.y, -rt.z);
+  r.stamp = a.stamp;
+  return r;
+}
+
+orc_transform orc_transform_identity(void)
+{
+  orc_transform r;
+  r.R.x = 0; r.R.y = 0; r.R.z = 0; r.R.w = 1;
+  r.t = v3(0, 0, 0);
+  r.stamp = 0;
+  return r;
+}
+
+/* rmagine EulerAngles -> Quaternion (ZYX, used by rmcl_localization.cpp:315) */
+orc_quat orc_euler_to_quat(float roll, float pitch, float yaw)
+{
+  const float cr = cosf(roll / 2.0f), sr = sinf(roll / 2.0f);
+  const float cp = cosf(pitch / 2.0f), sp = sinf(pitch / 2.0f);
+  const float cy = cosf(yaw / 2.0f), sy = sinf(yaw / 2.0f);
+  orc_quat q;
+  q.w = cr * cp * cy + sr * sp * sy;
+  q.x = sr * cp * cy - cr * sp * sy;
+  q.y = cr * sp * cy + sr * cp * sy;
+  q.z = cr * cp * sy - sr * sp * cy;
+  return q;
+}
+
+/* ------------------------------------------------------------------------- */
+/* mesh: triangle records + the oracle's own BVH2                             */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+  orc_vec3 v0, e1, e2, Ng, n; /* e1 = v0-v1, e2 = v2-v0, Ng = cross(e2,e1) (Embree Triangle4) */
+} orc_tri;
+
+typedef struct {
+  float bmin[3];
+  float bmax[3];
+  uint32_t left_first; /* inner: index of left child (right = left+1); leaf: first prim */
+  uint32_t count;      /* 0 = inner */
+} orc_node;            /* 32 B: the "reference tree" of SURVEY.md 8(d) */
+
+struct orc_mesh {
+  uint32_t nf;
+  orc_tri* tris;       /* indexed by ORIGINAL face id */
+  uint32_t* prim;      /* BVH leaf order -> face id */
+  orc_node* nodes;
+  uint32_t n_nodes;
+  uint32_t max_leaf;
+  float pad;
+};
+
+static void tri_setup(orc_tri* T, orc_vec3 a, orc_vec3 b, orc_vec3 c)
+{
+  T->v0 = a;
+  T->e1 = v_sub(a, b);
+  T->e2 = v_sub(c, a);
+  T->Ng = v_cross_fma(T->e2, T->e1);
+  /* rmagine normalizeInplace: d = sqrt(x*x+y*y+z*z); x/=d ... */
+  const float d = sqrtf((T->Ng.x * T->Ng.x + T->Ng.y * T->Ng.y) + T->Ng.z * T->Ng.z);
+  if (d > 0.0f) T->n = v3(T->Ng.x / d, T->Ng.y / d, T->Ng.z / d);
+  else T->n = v3(0, 0, 0);
+}
+
+/* Moeller-Trumbore in Embree's formulation (triangle_intersector_moeller.h):
+ * scaled barycentrics, sign-adjusted, rejection tests before the single division.
+ * Two-sided (no back-face culling).  Returns 1 and t on a hit in [tnear,tfar]. */
+static inline int tri_intersect(const orc_tri* T, orc_vec3 O, orc_vec3 D, float tnear, float tfar, float* t_out)
+{
+  const orc_vec3 C = v_sub(T->v0, O);
+  const orc_vec3 R = v_cross_fma(C, D);
+  const float den = v_dot_fma(T->Ng, D);
+  const float aden = fabsf(den);
+  float U = v_dot_fma(R, T->e2);
+  float V = v_dot_fma(R, T->e1);
+  float Tt = v_dot_fma(T->Ng, C);
+  if (den < 0.0f) { U = -U; V = -V; Tt = -Tt; }
+  if (!(den != 0.0f)) return 0;
+  if (!(U >= 0.0f && V >= 0.0f && (U + V) <= aden)) return 0;
+  const float t = Tt / aden;
+  if (!(t >= tnear && t <= tfar)) return 0;
+  *t_out = t;
+  return 1;
+}
+
+/* --- BVH2 builder: binned SAH, top-down ---------------------------------- */
+
+typedef struct { float bmin[3], bmax[3], c[3]; } prim_info;
+
+typedef struct {
+  orc_mesh* m;
+  prim_info* info; /* indexed by face id */
+  uint32_t n_alloc;
+} build_ctx;
+
+static inline void box_init(float* bmin, float* bmax)
+{
+  for (int k = 0; k < 3; ++k) { bmin[k] = FLT_MAX; bmax[k] = -FLT_MAX; }
+}
+static inline void box_grow(float* bmin, float* bmax, const float* omin, const float* omax)
+{
+  for (int k = 0; k < 3; ++k) { if (omin[k] < bmin[k]) bmin[k] = omin[k]; if (omax[k] > bmax[k]) bmax[k] = omax[k]; }
+}
+static inline float box_area(const float* bmin, const float* bmax)
+{
+  const float dx = bmax[0] - bmin[0], dy = bmax[1] - bmin[1], dz = bmax[2] - bmin[2];
+  if (dx < 0 || dy < 0 || dz < 0) return 0.0f;
+  return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+
+#define ORC_BINS 16
+
+static void build_rec(build_ctx* bc, uint32_t node_id, uint32_t first, uint32_t count)
+{
+  orc_mesh* m = bc->m;
+  orc_node* node = &m->nodes[node_id];
+  float cmin[3], cmax[3];
+  box_init(node->bmin, node->bmax);
+  box_init(cmin, cmax);
+  for (uint32_t i = first; i < first + count; ++i) {
+    const prim_info* p = &bc->info[m->prim[i]];
+    box_grow(node->bmin, node->bmax, p->bmin, p->bmax);
+    box_grow(cmin, cmax, p->c, p->c);
+  }
+  for (int k = 0; k < 3; ++k) { node->bmin[k] -= m->pad; node->bmax[k] += m->pad; }
+  if (count <= m->max_leaf) {
+    node->left_first = first; node->count = count;
+    return;
+  }
+  /* choose split */
+  int best_axis = -1; int best_bin = -1; float best_cost = FLT_MAX;
+  for (int axis = 0; axis < 3; ++axis) {
+    const float ext = cmax[axis] - cmin[axis];
+    if (!(ext > 0.0f)) continue;
+    float bbmin[ORC_BINS][3], bbmax[ORC_BINS][3]; uint32_t bcnt[ORC_BINS];
+    for (int b = 0; b < ORC_BINS; ++b) { box_init(bbmin[b], bbmax[b]); bcnt[b] = 0; }
+    const float scale = (float)ORC_BINS / ext;
+    for (uint32_t i = first; i < first + count; ++i) {
+      const prim_info* p = &bc->info[m->prim[i]];
+      int b = (int)((p->c[axis] - cmin[axis]) * scale);
+      if (b >= ORC_BINS) b = ORC_BINS - 1;
+      if (b < 0) b = 0;
+      bcnt[b]++; box_grow(bbmin[b], bbmax[b], p->bmin, p->bmax);
+    }
+    float la[ORC_BINS - 1], ra[ORC_BINS - 1]; uint32_t lc[ORC_BINS - 1], rc[ORC_BINS - 1];
+    float lmin[3], lmax[3], rmin[3], rmax[3]; uint32_t c = 0;
+    box_init(lmin, lmax);
+    for (int b = 0; b < ORC_BINS - 1; ++b) { box_grow(lmin, lmax, bbmin[b], bbmax[b]); c += bcnt[b]; la[b] = box_area(lmin, lmax); lc[b] = c; }
+    box_init(rmin, rmax); c = 0;
+    for (int b = ORC_BINS - 1; b > 0; --b) { box_grow(rmin, rmax, bbmin[b], bbmax[b]); c += bcnt[b]; ra[b - 1] = box_area(rmin, rmax); rc[b - 1] = c; }
+    for (int b = 0; b < ORC_BINS - 1; ++b) {
+      if (lc[b] == 0 || rc[b] == 0) continue;
+      const float cost = la[b] * (float)lc[b] + ra[b] * (float)rc[b];
+      if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+    }
+  }
+  uint32_t mid;
+  if (best_axis < 0) {
+    /* all centroids coincide: split in the middle */
+    mid = first + count / 2;
+  } else {
+    const float ext = cmax[best_axis] - cmin[best_axis];
+    const float scale = (float)ORC_BINS / ext;
+    uint32_t i = first, j = first + count;
+    while (i < j) {
+      const prim_info* p = &bc->info[m->prim[i]];
+      int b = (int)((p->c[best_axis] - cmin[best_axis]) * scale);
+      if (b >= ORC_BINS) b = ORC_BINS - 1;
+      if (b < 0) b = 0;
+      if (b <= best_bin) { ++i; } else { --j; uint32_t tmp = m->prim[i]; m->prim[i] = m->prim[j]; m->prim[j] = tmp; }
+    }
+    mid = i;
+    if (mid == first || mid == first + count) mid = first + count / 2;
+  }
+  const uint32_t left = m->n_nodes; m->n_nodes += 2;
+  node->left_first = left; node->count = 0;
+  build_rec(bc, left, first, mid - first);
+  build_rec(bc, left + 1, mid, first + count - mid);
+}
+
+orc_mesh* orc_mesh_create(const float* verts, uint32_t nv, const uint32_t* faces, uint32_t nf, uint32_t max_leaf)
+{
+  if (nf == 0 || max_leaf == 0) return NULL;
+  orc_mesh* m = (orc_mesh*)calloc(1, sizeof(orc_mesh));
+  m->nf = nf; m->max_leaf = max_leaf;
+  m->tris = (orc_tri*)malloc(sizeof(orc_tri) * nf);
+  m->prim = (uint32_t*)malloc(sizeof(uint32_t) * nf);
+  m->nodes = (orc_node*)malloc(sizeof(orc_node) * (2 * (size_t)nf));
+  prim_info* info = (prim_info*)malloc(sizeof(prim_info) * nf);
+  float smin[3], smax[3]; box_init(smin, smax);
+  for (uint32_t f = 0; f < nf; ++f) {
+    orc_vec3 p[3];
+    for (int k = 0; k < 3; ++k) {
+      const uint32_t vi = faces[3 * f + k];
+      if (vi >= nv) { free(info); orc_mesh_destroy(m); return NULL; }
+      p[k] = v3(verts[3 * vi], verts[3 * vi + 1], verts[3 * vi + 2]);
+    }
+    tri_setup(&m->tris[f], p[0], p[1], p[2]);
+    prim_info* pi = &info[f];
+    box_init(pi->bmin, pi->bmax);
+    for (int k = 0; k < 3; ++k) {
+      const float q[3] = {p[k].x, p[k].y, p[k].z};
+      box_grow(pi->bmin, pi->bmax, q, q);
+    }
+    for (int k = 0; k < 3; ++k) pi->c[k] = 0.5f * (pi->bmin[k] + pi->bmax[k]);
+    box_grow(smin, smax, pi->bmin, pi->bmax);
+    m->prim[f] = f;
+  }
+  float diag = 0.0f;
+  for (int k = 0; k < 3; ++k) { const float d = smax[k] - smin[k]; if (d > diag) diag = d; }
+  float amax = 0.0f;
+  for (int k = 0; k < 3; ++k) { if (fabsf(smin[k]) > amax) amax = fabsf(smin[k]); if (fabsf(smax[k]) > amax) amax = fabsf(smax[k]); }
+  m->pad = 1e-4f * (diag > amax ? diag : amax) + 1e-6f;
+  build_ctx bc = {m, info, 0};
+  m->n_nodes = 1;
+  build_rec(&bc, 0, 0, nf);
+  free(info);
+  return m;
+}
+
+void orc_mesh_destroy(orc_mesh* m)
+{
+  if (!m) return;
+  free(m->tris); free(m->prim); free(m->nodes); free(m);
+}
+
+uint32_t orc_mesh_num_nodes(const orc_mesh* m) { return m->n_nodes; }
+
+void orc_mesh_face_normals(const orc_mesh* m, float* out)
+{
+  for (uint32_t f = 0; f < m->nf; ++f) { out[3 * f] = m->tris[f].n.x; out[3 * f + 1] = m->tris[f].n.y; out[3 * f + 2] = m->tris[f].n.z; }
+}
+
+/* closest hit with the documented deterministic tie-break: min t, then min face id.
+ * This brute-force loop is the bit-exact face-id authority. */
+int orc_intersect_brute(const orc_mesh* m, orc_vec3 O, orc_vec3 D, float tnear, float tfar, float* t_out, uint32_t* face_out)
+{
+  float best_t = 0.0f; uint32_t best_f = 0xFFFFFFFFu; int found = 0;
+  for (uint32_t f = 0; f < m->nf; ++f) {
+    float t;
+    if (tri_intersect(&m->tris[f], O, D, tnear, tfar, &t)) {
+      if (!found || t < best_t || (t == best_t && f < best_f)) { best_t = t; best_f = f; found = 1; }
+    }
+  }
+  if (found) { *t_out = best_t; *face_out = best_f; }
+  return found;
+}
+
+static inline float safe_inv(float d)
+{
+  if (fabsf(d) < 1e-30f) d = copysignf(1e-30f, d);
+  return 1.0f / d;
+}
+
+static inline int box_hit(const orc_node* n, const float* o, const float* inv, float tnear, float tfar, float* tn_out)
+{
+  float tn = tnear, tf = tfar;
+  for (int k = 0; k < 3; ++k) {
+    float t0 = (n->bmin[k] - o[k]) * inv[k];
+    float t1 = (n->bmax[k] - o[k]) * inv[k];
+    if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }
+    if (t0 > tn) tn = t0;
+    if (t1 < tf) tf = t1;
+  }
+  *tn_out = tn;
+  return tn <= tf * 1.0000004f;
+}
+
+int orc_intersect_bvh(const orc_mesh* m, orc_vec3 O, orc_vec3 D, float tnear, float tfar, float* t_out, uint32_t* face_out, orc_counters* cnt)
+{
+  const float o[3] = {O.x, O.y, O.z};
+  const float inv[3] = {safe_inv(D.x), safe_inv(D.y), safe_inv(D.z)};
+  float best_t = tfar; uint32_t best_f = 0xFFFFFFFFu; int found = 0;
+  uint32_t stack[128]; int sp = 0;
+  uint64_t nv = 0, nt = 0;
+  float tn;
+  if (!(D.x == D.x && D.y == D.y && D.z == D.z)) goto done; /* NaN direction: miss */
+  nv++;
+  if (!box_hit(&m->nodes[0], o, inv, tnear, best_t, &tn)) goto done;
+  stack[sp++] = 0;
+  while (sp > 0) {
+    const orc_node* n = &m->nodes[stack[--sp]];
+    if (n->count > 0) {
+      for (uint32_t i = 0; i < n->count; ++i) {
+        const uint32_t f = m->prim[n->left_first + i];
+        float t; nt++;
+        if (tri_intersect(&m->tris[f], O, D, tnear, tfar, &t)) {
+          if (!found || t < best_t || (t == best_t && f < best_f)) { best_t = t; best_f = f; found = 1; }
+        }
+      }
+      continue;
+    }
+    const uint32_t l = n->left_first, r = l + 1;
+    float tl, tr;
+    nv += 2;
+    const int hl = box_hit(&m->nodes[l], o, inv, tnear, best_t, &tl);
+    const int hr = box_hit(&m->nodes[r], o, inv, tnear, best_t, &tr);
+    if (hl && hr) {
+      if (sp + 2 > 128) return -1;
+      if (tl <= tr) { stack[sp++] = r; stack[sp++] = l; } else { stack[sp++] = l; stack[sp++] = r; }
+    } else if (hl) { stack[sp++] = l; }
+    else if (hr) { stack[sp++] = r; }
+  }
+done:
+  if (cnt) { cnt->nodes_visited += nv; cnt->tris_tested += nt; cnt->rays += 1; }
+  if (found) { *t_out = best_t; *face_out = best_f; }
+  return found;
+}
+
+/* ------------------------------------------------------------------------- */
+/* simulate                                                                   */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+  const orc_mesh* m;
+  int kind; /* 0 spherical, 1 o1dn */
+  const orc_spherical_model* sph;
+  uint32_t width, height;
+  orc_interval range;
+  orc_vec3 orig;
+  const float* dirs;
+  const orc_transform* Tsb;
+  const orc_transform* Tbm;
+  uint32_t nposes;
+  int use_bvh;
+  uint8_t* hits; float* ranges; float* points; float* normals; uint32_t* face_ids;
+  /* work distribution */
+  volatile uint64_t next;
+  uint64_t total;
+  pthread_mutex_t mtx;
+  orc_counters cnt;
+} sim_job;
+
+static void sim_range(sim_job* J, uint64_t begin, uint64_t end, orc_counters* cnt)
+{
+  const uint64_t per_pose = (uint64_t)J->width * J->height;
+  const float nanv = NAN;
+  uint32_t cur_pid = 0xFFFFFFFFu;
+  orc_transform Tsm = orc_transform_identity(), Tms = Tsm;
+  for (uint64_t g = begin; g < end; ++g) {
+    const uint32_t pid = (uint32_t)(g / per_pose);
+    const uint32_t loc = (uint32_t)(g % per_pose);
+    const uint32_t vid = loc / J->width, hid = loc % J->width;
+    if (pid != cur_pid) {
+      Tsm = orc_transform_mult(J->Tbm[pid], *J->Tsb);
+      Tms = orc_transform_inv(Tsm);
+      cur_pid = pid;
+    }
+    orc_vec3 dir_s, orig_s, org_m;
+    if (J->kind == 0) {
+      /* rmagine SphericalModel::getDirection = polar2cartesian(phi, theta)
+       * (convention pinned by rmcl_ros/src/util/conversions.cpp:174-188) */
+      const float phi = J->sph->phi.min + (float)vid * J->sph->phi.inc;
+      const float theta = J->sph->theta.min + (float)hid * J->sph->theta.inc;
+      const float cp = cosf(phi), sp = sinf(phi), ct = cosf(theta), st = sinf(theta);
+      dir_s = v3(cp * ct, cp * st, sp);
+      orig_s = v3(0, 0, 0);
+      org_m = Tsm.t;
+    } else {
+      dir_s = v3(J->dirs[3 * loc], J->dirs[3 * loc + 1], J->dirs[3 * loc + 2]);
+      orig_s = J->orig;
+      org_m = orc_transform_apply(Tsm, orig_s);
+    }
+    const orc_vec3 dir_m = orc_quat_rotate(Tsm.R, dir_s);
+    float t = 0; uint32_t face = 0xFFFFFFFFu;
+    int hit;
+    if (J->use_bvh) hit = orc_intersect_bvh(J->m, org_m, dir_m, 0.0f, J->range.max, &t, &face, cnt);
+    else hit = orc_intersect_brute(J->m, org_m, dir_m, 0.0f, J->range.max, &t, &face);
+    if (hit > 0) {
+      if (J->hits) J->hits[g] = 1;
+      if (J->ranges) J->ranges[g] = t;
+      if (J->points) {
+        orc_vec3 p = v_scale(dir_s, t);
+        if (J->kind == 1) p = v_add(p, orig_s);
+        J->points[3 * g] = p.x; J->points[3 * g + 1] = p.y; J->points[3 * g + 2] = p.z;
+      }
+      if (J->normals) {
+        orc_vec3 n = orc_quat_rotate(Tms.R, J->m->tris[face].n);
+        /* flip towards the sensor */
+        if (v_dot_plain(dir_s, n) > 0.0f) n = v3(-n.x, -n.y, -n.z);
+        J->normals[3 * g] = n.x; J->normals[3 * g + 1] = n.y; J->normals[3 * g + 2] = n.z;
+      }
+      if (J->face_ids) J->face_ids[g] = face;
+    } else {
+      if (J->hits) J->hits[g] = 0;
+      if (J->ranges) J->ranges[g] = J->range.max + 1.0f;
+      if (J->points) { J->points[3 * g] = nanv; J->points[3 * g + 1] = nanv; J->points[3 * g + 2] = nanv; }
+      if (J->normals) { J->normals[3 * g] = nanv; J->normals[3 * g + 1] = nanv; J->normals[3 * g + 2] = nanv; }
+      if (J->face_ids) J->face_ids[g] = 0xFFFFFFFFu;
+    }
+  }
+}
+
+#define ORC_GRAIN 128 /* the reference's TBB grain (PCDSensorUpdaterEmbree.cpp:331) */
+
+static void* sim_worker(void* arg)
+{
+  sim_job* J = (sim_job*)arg;
+  orc_counters local = {0, 0, 0};
+  for (;;) {
+    const uint64_t b = __sync_fetch_and_add(&J->next, (uint64_t)ORC_GRAIN);
+    if (b >= J->total) break;
+    uint64_t e = b + ORC_GRAIN; if (e > J->total) e = J->total;
+    sim_range(J, b, e, &local);
+  }
+  pthread_mutex_lock(&J->mtx);
+  J->cnt.nodes_visited += local.nodes_visited; J->cnt.tris_tested += local.tris_tested; J->cnt.rays += local.rays;
+  pthread_mutex_unlock(&J->mtx);
+  return NULL;
+}
+
+static int run_sim(sim_job* J, int nthreads, orc_counters* cnt)
+{
+  J->next = 0; J->total = (uint64_t)J->width * J->height * J->nposes;
+  pthread_mutex_init(&J->mtx, NULL);
+  memset(&J->cnt, 0, sizeof(J->cnt));
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads == 1) { sim_worker(J); }
+  else {
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * nthreads);
+    for (int i = 0; i < nthreads; ++i) pthread_create(&th[i], NULL, sim_worker, J);
+    for (int i = 0; i < nthreads; ++i) pthread_join(th[i], NULL);
+    free(th);
+  }
+  pthread_mutex_destroy(&J->mtx);
+  if (cnt) *cnt = J->cnt;
+  return 0;
+}
+
+int orc_simulate_spherical(const orc_mesh* m, const orc_spherical_model* model, const orc_transform* Tsb,
+                           const orc_transform* Tbm, uint32_t nposes, int use_bvh, int nthreads,
+                           uint8_t* hits, float* ranges, float* points, float* normals, uint32_t* face_ids,
+                           orc_counters* cnt)
+{
+  sim_job J; memset(&J, 0, sizeof(J));
+  J.m = m; J.kind = 0; J.sph = model; J.width = model->theta.size; J.height = model->phi.size;
+  J.range = model->range; J.Tsb = Tsb; J.Tbm = Tbm; J.nposes = nposes; J.use_bvh = use_bvh;
+  J.hits = hits; J.ranges = ranges; J.points = points; J.normals = normals; J.face_ids = face_ids;
+  return run_sim(&J, nthreads, cnt);
+}
+
+int orc_simulate_o1dn(const orc_mesh* m, uint32_t width, uint32_t height, orc_interval range, orc_vec3 orig,
+                      const float* dirs, const orc_transform* Tsb, const orc_transform* Tbm, uint32_t nposes,
+                      int use_bvh, int nthreads, uint8_t* hits, float* ranges, float* points, float* normals,
+                      uint32_t* face_ids, orc_counters* cnt)
+{
+  sim_job J; memset(&J, 0, sizeof(J));
+  J.m = m; J.kind = 1; J.width = width; J.height = height; J.range = range; J.orig = orig; J.dirs = dirs;
+  J.Tsb = Tsb; J.Tbm = Tbm; J.nposes = nposes; J.use_bvh = use_bvh;
+  J.hits = hits; J.ranges = ranges; J.points = points; J.normals = normals; J.face_ids = face_ids;
+  return run_sim(&J, nthreads, cnt);
+}
+
+/* ------------------------------------------------------------------------- */
+/* statistics_p2l + CrossStatistics algebra + umeyama                         */
+/* ------------------------------------------------------------------------- */
+
+float orc_adaptive_max_dist(float max_dist, float adaptive_max_dist_min, double p)
+{
+  /* CorrespondencesCPU.cpp:21-23: float operands promoted to double, stored to float */
+  return (float)((double)max_dist * (1.0 - p) + (double)adaptive_max_dist_min * p);
+}
+
+orc_cross_statistics orc_cross_statistics_identity(void)
+{
+  orc_cross_statistics s; memset(&s, 0, sizeof(s)); return s;
+}
+
+/* rm::CrossStatistics::operator+= : count-weighted (Chan) merge; covariance is
+ * normalised by n and oriented model x dataset^T. */
+orc_cross_statistics orc_cross_statistics_merge(orc_cross_statistics a, orc_cross_statistics b)
+{
+  orc_cross_statistics r;
+  r.n_meas = a.n_meas + b.n_meas;
+  if (r.n_meas == 0) return orc_cross_statistics_identity();
+  const float w1 = (float)a.n_meas / (float)r.n_meas;
+  const float w2 = (float)b.n_meas / (float)r.n_meas;
+  r.dataset_mean = v_add(v_scale(a.dataset_mean, w1), v_scale(b.dataset_mean, w2));
+  r.model_mean = v_add(v_scale(a.model_mean, w1), v_scale(b.model_mean, w2));
+  const orc_vec3 m1 = v_sub(a.model_mean, r.model_mean), d1 = v_sub(a.dataset_mean, r.dataset_mean);
+  const orc_vec3 m2 = v_sub(b.model_mean, r.model_mean), d2 = v_sub(b.dataset_mean, r.dataset_mean);
+  const float mm1[3] = {m1.x, m1.y, m1.z}, dd1[3] = {d1.x, d1.y, d1.z};
+  const float mm2[3] = {m2.x, m2.y, m2.z}, dd2[3] = {d2.x, d2.y, d2.z};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      const float P1 = a.covariance[3 * i + j] * w1 + b.covariance[3 * i + j] * w2;
+      const float P2 = (mm1[i] * dd1[j]) * w1 + (mm2[i] * dd2[j]) * w2;
+      r.covariance[3 * i + j] = P1 + P2;
+    }
+  return r;
+}
+
+static void quat_to_mat(orc_quat q, float* M)
+{
+  /* rmagine Matrix3x3 <- Quaternion */
+  M[0] = 2.0f * (q.w * q.w + q.x * q.x) - 1.0f; M[1] = 2.0f * (q.x * q.y - q.w * q.z); M[2] = 2.0f * (q.x * q.z + q.w * q.y);
+  M[3] = 2.0f * (q.x * q.y + q.w * q.z); M[4] = 2.0f * (q.w * q.w + q.y * q.y) - 1.0f; M[5] = 2.0f * (q.y * q.z - q.w * q.x);
+  M[6] = 2.0f * (q.x * q.z - q.w * q.y); M[7] = 2.0f * (q.y * q.z + q.w * q.x); M[8] = 2.0f * (q.w * q.w + q.z * q.z) - 1.0f;
+}
+
+/* Transform * CrossStatistics: means transformed, covariance rotated R C R^T */
+orc_cross_statistics orc_cross_statistics_transform(orc_transform T, orc_cross_statistics s)
+{
+  orc_cross_statistics r;
+  r.dataset_mean = orc_transform_apply(T, s.dataset_mean);
+  r.model_mean = orc_transform_apply(T, s.model_mean);
+  float R[9], tmp[9];
+  quat_to_mat(T.R, R);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+    float acc = 0.0f; for (int k = 0; k < 3; ++k) acc += R[3 * i + k] * s.covariance[3 * k + j];
+    tmp[3 * i + j] = acc;
+  }
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+    float acc = 0.0f; for (int k = 0; k < 3; ++k) acc += tmp[3 * i + k] * R[3 * j + k];
+    r.covariance[3 * i + j] = acc;
+  }
+  r.n_meas = s.n_meas;
+  return r;
+}
+
+/* gate + projection exactly as restated in-repo at rmcl_ros/src/micpl/MICPSensorCPU.cpp:70-84,
+ * with Tpre applied to the dataset point first (rm::statistics_p2l). Returns 1 if kept. */
+static inline int p2l_element(const orc_transform* Tpre, const float* dp, const float* mp, const float* mn,
+                              float max_dist, orc_vec3* Di_out, orc_vec3* Mi_out)
+{
+  const orc_vec3 Di = orc_transform_apply(*Tpre, v3(dp[0], dp[1], dp[2]));
+  const orc_vec3 Ii = v3(mp[0], mp[1], mp[2]);
+  const orc_vec3 Ni = v3(mn[0], mn[1], mn[2]);
+  const float spd = v_dot_plain(v_sub(Ii, Di), Ni);
+  if (fabsf(spd) < max_dist) {
+    *Di_out = Di;
+    *Mi_out = v_add(Di, v_scale(Ni, spd));
+    return 1;
+  }
+  return 0;
+}
+
+void orc_statistics_p2l_f32(const orc_transform* Tpre, const float* dp, const uint8_t* dm, const float* mp,
+                            const float* mn, const uint8_t* mm, uint32_t n, float max_dist,
+                            orc_cross_statistics* out)
+{
+  orc_cross_statistics s = orc_cross_statistics_identity();
+  for (uint32_t i = 0; i < n; ++i) {
+    if ((dm == NULL || dm[i] > 0) && (mm == NULL || mm[i] > 0)) {
+      orc_vec3 Di, Mi;
+      if (p2l_element(Tpre, dp + 3 * i, mp + 3 * i, mn + 3 * i, max_dist, &Di, &Mi)) {
+        orc_cross_statistics one = orc_cross_statistics_identity();
+        one.dataset_mean = Di; one.model_mean = Mi; one.n_meas = 1;
+        s = orc_cross_statistics_merge(s, one);
+      }
+    }
+  }
+  *out = s;
+}
+
+void orc_statistics_p2l_f64(const orc_transform* Tpre, const float* dp, const uint8_t* dm, const float* mp,
+                            const float* mn, const uint8_t* mm, uint32_t n, float max_dist, double* out15,
+                            uint32_t* n_out)
+{
+  double sd[3] = {0, 0, 0}, sm[3] = {0, 0, 0}; uint32_t cnt = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if ((dm == NULL || dm[i] > 0) && (mm == NULL || mm[i] > 0)) {
+      orc_vec3 Di, Mi;
+      if (p2l_element(Tpre, dp + 3 * i, mp + 3 * i, mn + 3 * i, max_dist, &Di, &Mi)) {
+        sd[0] += Di.x; sd[1] += Di.y; sd[2] += Di.z; sm[0] += Mi.x; sm[1] += Mi.y; sm[2] += Mi.z; cnt++;
+      }
+    }
+  }
+  memset(out15, 0, sizeof(double) * 15);
+  *n_out = cnt;
+  if (cnt == 0) return;
+  double md[3], mmn[3];
+  for (int k = 0; k < 3; ++k) { md[k] = sd[k] / cnt; mmn[k] = sm[k] / cnt; }
+  double C[9] = {0};
+  for (uint32_t i = 0; i < n; ++i) {
+    if ((dm == NULL || dm[i] > 0) && (mm == NULL || mm[i] > 0)) {
+      orc_vec3 Di, Mi;
+      if (p2l_element(Tpre, dp + 3 * i, mp + 3 * i, mn + 3 * i, max_dist, &Di, &Mi)) {
+        const double d[3] = {Di.x - md[0], Di.y - md[1], Di.z - md[2]};
+        const double m_[3] = {Mi.x - mmn[0], Mi.y - mmn[1], Mi.z - mmn[2]};
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) C[3 * r + c] += m_[r] * d[c];
+      }
+    }
+  }
+  for (int k = 0; k < 3; ++k) { out15[k] = md[k]; out15[3 + k] = mmn[k]; }
+  for (int k = 0; k < 9; ++k) out15[6 + k] = C[k] / cnt;
+}
+
+/* symmetric 3x3 Jacobi eigen-decomposition (double). A = V diag(e) V^T */
+static void jacobi_eig3(const double* Ain, double* V, double* e)
+{
+  double A[9]; memcpy(A, Ain, sizeof(A));
+  for (int i = 0; i < 9; ++i) V[i] = 0;
+  V[0] = V[4] = V[8] = 1;
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    const double dg = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
+    if (off <= 1e-34 * dg || off == 0.0) break;
+    for (int p = 0; p < 2; ++p) for (int q = p + 1; q < 3; ++q) {
+      const double apq = A[3 * p + q];
+      if (apq == 0.0) continue;
+      const double theta = (A[3 * q + q] - A[3 * p + p]) / (2.0 * apq);
+      const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+      const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+      for (int k = 0; k < 3; ++k) { /* A <- A J */
+        const double akp = A[3 * k + p], akq = A[3 * k + q];
+        A[3 * k + p] = c * akp - s * akq; A[3 * k + q] = s * akp + c * akq;
+      }
+      for (int k = 0; k < 3; ++k) { /* A <- J^T A */
+        const double apk = A[3 * p + k], aqk = A[3 * q + k];
+        A[3 * p + k] = c * apk - s * aqk; A[3 * q + k] = s * apk + c * aqk;
+      }
+      for (int k = 0; k < 3; ++k) {
+        const double vkp = V[3 * k + p], vkq = V[3 * k + q];
+        V[3 * k + p] = c * vkp - s * vkq; V[3 * k + q] = s * vkp + c * vkq;
+      }
+    }
+  }
+  e[0] = A[0]; e[1] = A[4]; e[2] = A[8];
+}
+
+void orc_svd3(const double* A, double* U, double* w, double* V)
+{
+  /* B = A^T A = V S^2 V^T ; u_i = A v_i / s_i */
+  double B[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+    double acc = 0; for (int k = 0; k < 3; ++k) acc += A[3 * k + i] * A[3 * k + j];
+    B[3 * i + j] = acc;
+  }
+  double Vr[9], e[3];
+  jacobi_eig3(B, Vr, e);
+  int idx[3] = {0, 1, 2};
+  for (int i = 0; i < 2; ++i) for (int j = i + 1; j < 3; ++j) if (e[idx[j]] > e[idx[i]]) { int t = idx[i]; idx[i] = idx[j]; idx[j] = t; }
+  for (int c = 0; c < 3; ++c) {
+    for (int r = 0; r < 3; ++r) V[3 * r + c] = Vr[3 * r + idx[c]];
+    w[c] = e[idx[c]] > 0 ? sqrt(e[idx[c]]) : 0.0;
+  }
+  const double tol = 1e-9 * (w[0] > 0 ? w[0] : 1.0);
+  double u[3][3];
+  int have[3] = {0, 0, 0};
+  for (int c = 0; c < 3; ++c) {
+    if (w[c] > tol) {
+      for (int r = 0; r < 3; ++r) { double acc = 0; for (int k = 0; k < 3; ++k) acc += A[3 * r + k] * V[3 * k + c]; u[c][r] = acc / w[c]; }
+      /* re-orthonormalise against previous */
+      for (int p = 0; p < c; ++p) if (have[p]) { double d = 0; for (int r = 0; r < 3; ++r) d += u[c][r] * u[p][r]; for (int r = 0; r < 3; ++r) u[c][r] -= d * u[p][r]; }
+      double nrm = 0; for (int r = 0; r < 3; ++r) nrm += u[c][r] * u[c][r]; nrm = sqrt(nrm);
+      if (nrm > 0) { for (int r = 0; r < 3; ++r) u[c][r] /= nrm; have[c] = 1; }
+    }
+  }
+  if (!have[0]) { u[0][0] = 1; u[0][1] = 0; u[0][2] = 0; have[0] = 1; }
+  if (!have[1]) {
+    /* any unit vector orthogonal to u0 */
+    int k = 0; if (fabs(u[0][1]) < fabs(u[0][k])) k = 1; if (fabs(u[0][2]) < fabs(u[0][k])) k = 2;
+    double a[3] = {0, 0, 0}; a[k] = 1;
+    double d = u[0][k];
+    double nrm = 0;
+    for (int r = 0; r < 3; ++r) { u[1][r] = a[r] - d * u[0][r]; nrm += u[1][r] * u[1][r]; }
+    nrm = sqrt(nrm); for (int r = 0; r < 3; ++r) u[1][r] /= nrm;
+    have[1] = 1;
+  }
+  if (!have[2]) {
+    u[2][0] = u[0][1] * u[1][2] - u[0][2] * u[1][1];
+    u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2];
+    u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
+  }
+  for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) U[3 * r + c] = u[c][r];
+}
+
+static double det3(const double* M)
+{
+  return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+static orc_quat mat_to_quat(const double* R)
+{
+  /* Shepperd's method */
+  double q[4]; /* x y z w */
+  const double tr = R[0] + R[4] + R[8];
+  if (tr > 0) {
+    const double s = sqrt(tr + 1.0) * 2.0;
+    q[3] = 0.25 * s; q[0] = (R[7] - R[5]) / s; q[1] = (R[2] - R[6]) / s; q[2] = (R[3] - R[1]) / s;
+  } else if (R[0] > R[4] && R[0] > R[8]) {
+    const double s = sqrt(1.0 + R[0] - R[4] - R[8]) * 2.0;
+    q[3] = (R[7] - R[5]) / s; q[0] = 0.25 * s; q[1] = (R[1] + R[3]) / s; q[2] = (R[2] + R[6]) / s;
+  } else if (R[4] > R[8]) {
+    const double s = sqrt(1.0 + R[4] - R[0] - R[8]) * 2.0;
+    q[3] = (R[2] - R[6]) / s; q[0] = (R[1] + R[3]) / s; q[1] = 0.25 * s; q[2] = (R[5] + R[7]) / s;
+  } else {
+    const double s = sqrt(1.0 + R[8] - R[0] - R[4]) * 2.0;
+    q[3] = (R[3] - R[1]) / s; q[0] = (R[2] + R[6]) / s; q[1] = (R[5] + R[7]) / s; q[2] = 0.25 * s;
+  }
+  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  orc_quat r = {(float)(q[0] / n), (float)(q[1] / n), (float)(q[2] / n), (float)(q[3] / n)};
+  return r;
+}
+
+/* rm::umeyama_transform: C = U S V^T, R = U diag(1,1,sign(det U det V)) V^T,
+ * t = model_mean - R dataset_mean; identity when n_meas == 0. */
+orc_transform orc_umeyama_transform(const orc_cross_statistics* s)
+{
+  orc_transform T = orc_transform_identity();
+  if (s->n_meas == 0) return T;
+  double C[9], U[9], w[3], V[9];
+  for (int i = 0; i < 9; ++i) C[i] = s->covariance[i];
+  orc_svd3(C, U, w, V);
+  double S[3] = {1, 1, 1};
+  if (det3(U) * det3(V) < 0) S[2] = -1;
+  double R[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+    double acc = 0; for (int k = 0; k < 3; ++k) acc += U[3 * i + k] * S[k] * V[3 * j + k];
+    R[3 * i + j] = acc;
+  }
+  T.R = mat_to_quat(R);
+  const orc_vec3 Rd = orc_quat_rotate(T.R, s->dataset_mean);
+  T.t = v_sub(s->model_mean, Rd);
+  return T;
+}
+
+/* ------------------------------------------------------------------------- */
+/* particle filter                                                            */
+/* ------------------------------------------------------------------------- */
+
+/* rm::Gaussian1D::operator+= : 1-D count-weighted merge (parity unpinned) */
+orc_gaussian1d orc_gaussian1d_add(orc_gaussian1d a, orc_gaussian1d b)
+{
+  orc_gaussian1d r;
+  r.n_meas = a.n_meas + b.n_meas;
+  const float w1 = (float)a.n_meas / (float)r.n_meas;
+  const float w2 = (float)b.n_meas / (float)r.n_meas;
+  r.mean = a.mean * w1 + b.mean * w2;
+  const float P1 = a.sigma * w1 + b.sigma * w2;
+  const float P2 = ((a.mean - r.mean) * (a.mean - r.mean)) * w1 + ((b.mean - r.mean) * (b.mean - r.mean)) * w2;
+  r.sigma = P1 + P2;
+  return r;
+}
+
+/* evaluate_rcc, PCDSensorUpdaterEmbree.cpp:18-86, with UNIT face normals
+ * (== optix/BeamEvaluateProgram.cu:77-120; SURVEY.md Appendix B.1 recommendation). */
+float orc_evaluate_rcc(const orc_mesh* m, const orc_range_measurement* meas, const orc_pf_params* p, int use_bvh)
+{
+  const int real_hit = (meas->range >= p->sensor_range.min && meas->range <= p->sensor_range.max);
+  float t = 0; uint32_t face = 0;
+  int hit;
+  if (use_bvh) hit = orc_intersect_bvh(m, meas->orig, meas->dir, 0.0f, INFINITY, &t, &face, NULL);
+  else hit = orc_intersect_brute(m, meas->orig, meas->dir, 0.0f, INFINITY, &t, &face);
+  const int sim_hit = (hit > 0) && (t > p->sensor_range.min);
+  float error;
+  if (sim_hit) {
+    if (real_hit) {
+      const orc_vec3 preal = v_add(meas->orig, v_scale(meas->dir, meas->range));
+      const orc_vec3 pint = v_add(meas->orig, v_scale(meas->dir, t));
+      error = fabsf(v_dot_plain(v_sub(pint, preal), m->tris[face].n));
+    } else error = p->real_miss_sim_hit_error;
+  } else {
+    error = real_hit ? p->real_hit_sim_miss_error : p->real_miss_sim_miss_error;
+  }
+  return error;
+}
+
+typedef struct {
+  const orc_mesh* m; const orc_transform* poses; orc_particle_attributes* attrs; uint32_t n;
+  const orc_range_measurement* beams; uint32_t nbeams; const orc_transform* Tsb; const orc_pf_params* p;
+  int use_bvh; float* errors;
+  volatile uint64_t next;
+} pf_job;
+
+static void pf_particle(pf_job* J, uint32_t i)
+{
+  const orc_pf_params* p = J->p;
+  const float sq = p->dist_sigma * p->dist_sigma;
+  const orc_transform Tsm = orc_transform_mult(J->poses[i], *J->Tsb);
+  orc_particle_attributes a = J->attrs[i];
+  for (uint32_t b = 0; b < J->nbeams; ++b) {
+    /* meas_m = Tsm * meas_s (RangeMeasurement.hpp:28-42) */
+    orc_range_measurement mm = J->beams[b];
+    mm.dir = orc_quat_rotate(Tsm.R, J->beams[b].dir);
+    mm.orig = orc_transform_apply(Tsm, J->beams[b].orig);
+    const float error = orc_evaluate_rcc(J->m, &mm, p, J->use_bvh);
+    if (J->errors) J->errors[(size_t)i * J->nbeams + b] = error;
+    /* PCDSensorUpdaterEmbree.cpp:224: float argument, double exp/sqrt, float result */
+    const float arg = -(error * error) / sq / 2;
+    const float eval = (float)(exp((double)arg) / sqrt((double)(2 * sq) * M_PI));
+    orc_gaussian1d meas = {eval, 0.0f, 1};
+    a.likelihood = orc_gaussian1d_add(a.likelihood, meas);
+    if (a.likelihood.n_meas > p->max_n_meas) a.likelihood.n_meas = p->max_n_meas;
+  }
+  J->attrs[i] = a;
+}
+
+static void* pf_worker(void* arg)
+{
+  pf_job* J = (pf_job*)arg;
+  for (;;) {
+    const uint64_t b = __sync_fetch_and_add(&J->next, (uint64_t)ORC_GRAIN);
+    if (b >= J->n) break;
+    uint64_t e = b + ORC_GRAIN; if (e > J->n) e = J->n;
+    for (uint64_t i = b; i < e; ++i) pf_particle(J, (uint32_t)i);
+  }
+  return NULL;
+}
+
+int orc_pf_update(const orc_mesh* m, const orc_transform* poses, orc_particle_attributes* attrs, uint32_t n,
+                  const orc_range_measurement* beams, uint32_t nbeams, const orc_transform* Tsb,
+                  const orc_pf_params* p, int use_bvh, int nthreads, float* errors_out)
+{
+  pf_job J = {m, poses, attrs, n, beams, nbeams, Tsb, p, use_bvh, errors_out, 0};
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads == 1) { pf_worker(&J); return 0; }
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * nthreads);
+  for (int i = 0; i < nthreads; ++i) pthread_create(&th[i], NULL, pf_worker, &J);
+  for (int i = 0; i < nthreads; ++i) pthread_join(th[i], NULL);
+  free(th);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* checker for the PRODUCT's BVH arrays (layout: rmcl_amd/csrc/layout.h):    */
+/* walks the exported Node4 / TriRec dwords with the oracle's intersector so */
+/* the CPU suite can prove the builder never loses a triangle.               */
+/* ------------------------------------------------------------------------- */
+int orc_trace_bvh4(const uint32_t* nodes, uint32_t n_nodes, const uint32_t* tris, uint32_t n_tris,
+                   orc_vec3 O, orc_vec3 D, float tnear, float tfar, float* t_out, uint32_t* face_out)
+{
+  const float o[3] = {O.x, O.y, O.z};
+  const float inv[3] = {safe_inv(D.x), safe_inv(D.y), safe_inv(D.z)};
+  float best_t = tfar; uint32_t best_f = 0xFFFFFFFFu; int found = 0;
+  uint32_t stack[256]; int sp = 0;
+  stack[sp++] = 0;
+  while (sp > 0) {
+    const uint32_t ref = stack[--sp];
+    if (ref & 0x80000000u) {
+      const uint32_t first = ref & 0x0FFFFFFFu, cnt = ((ref >> 28) & 7u) + 1u;
+      for (uint32_t i = 0; i < cnt; ++i) {
+        if (first + i >= n_tris) return -2;
+        const float* r = (const float*)(tris + 16u * (first + i));
+        orc_tri T;
+        T.v0 = v3(r[0], r[1], r[2]); T.e1 = v3(r[3], r[4], r[5]); T.e2 = v3(r[6], r[7], r[8]);
+        T.Ng = v3(r[9], r[10], r[11]); T.n = v3(r[12], r[13], r[14]);
+        const uint32_t f = tris[16u * (first + i) + 15u];
+        float t;
+        if (tri_intersect(&T, O, D, tnear, tfar, &t)) {
+          if (!found || t < best_t || (t == best_t && f < best_f)) { best_t = t; best_f = f; found = 1; }
+        }
+      }
+      continue;
+    }
+    if (ref >= n_nodes) return -2;
+    const float* nd = (const float*)(nodes + 32u * ref);
+    const uint32_t* ch = nodes + 32u * ref + 24u;
+    for (int c = 0; c < 4; ++c) {
+      if (ch[c] == 0xFFFFFFFFu) continue;
+      orc_node bx;
+      bx.bmin[0] = nd[0 + c]; bx.bmin[1] = nd[4 + c]; bx.bmin[2] = nd[8 + c];
+      bx.bmax[0] = nd[12 + c]; bx.bmax[1] = nd[16 + c]; bx.bmax[2] = nd[20 + c];
+      float tn;
+      if (box_hit(&bx, o, inv, tnear, best_t, &tn)) { if (sp >= 256) return -1; stack[sp++] = ch[c]; }
+    }
+  }
+  if (found) { *t_out = best_t; *face_out = best_f; }
+  return found;
+}
+
+/* rmagine SphericalModel::getDirection(vid, hid) for the whole image, buffer order vid*W + hid
+ * (convention pinned by rmcl_ros/src/util/conversions.cpp:174-188) */
+void orc_spherical_directions(const orc_spherical_model* model, float* out)
+{
+  const uint32_t H = model->phi.size, W = model->theta.size;
+  for (uint32_t vid = 0; vid < H; ++vid) {
+    const float phi = model->phi.min + (float)vid * model->phi.inc;
+    const float cp = cosf(phi), sp = sinf(phi);
+    for (uint32_t hid = 0; hid < W; ++hid) {
+      const float theta = model->theta.min + (float)hid * model->theta.inc;
+      float* o = out + 3u * ((size_t)vid * W + hid);
+      o[0] = cp * cosf(theta); o[1] = cp * sinf(theta); o[2] = sp;
+    }
+  }
+}
+
+/* triangle records exactly as the oracle derives them, face-id order, 15 floats each */
+void orc_mesh_tri_records(const orc_mesh* m, float* out)
+{
+  for (uint32_t f = 0; f < m->nf; ++f) {
+    const orc_tri* T = &m->tris[f];
+    float* o = out + 15u * f;
+    o[0] = T->v0.x; o[1] = T->v0.y; o[2] = T->v0.z; o[3] = T->e1.x; o[4] = T->e1.y; o[5] = T->e1.z;
+    o[6] = T->e2.x; o[7] = T->e2.y; o[8] = T->e2.z; o[9] = T->Ng.x; o[10] = T->Ng.y; o[11] = T->Ng.z;
+    o[12] = T->n.x; o[13] = T->n.y; o[14] = T->n.z;
+  }
+}

@@ -1,0 +1,13 @@
+"""rmcl_amd -- MI355X (gfx950) implementation of RMCL / MICP-L's ray-casting-correspondence +
+pose-correction hot path.  Host-side mirror of the reference's operator interfaces over the C ABI
+of librmclhip.so (include/rmclhip.h).  No CPU fallback: importing works anywhere the shared
+library is built, computing needs a HIP device.
+"""
+from . import _capi, types, synthetic  # noqa: F401
+from ._capi import NoDeviceError, RmclHipError  # noqa: F401
+from .micp import MICPLocalization, MICPSensor  # noqa: F401
+from .pf import PCDSensorUpdaterHip, beams_from_points, sample_beams  # noqa: F401
+from .registration import (Context, CorrespondencesHIP, DeviceArray, HipMap, MapMap, RCCHipO1Dn,  # noqa: F401
+                           RCCHipSpherical, build_bvh_host, import_hip_map)
+
+__version__ = "0.1.0"

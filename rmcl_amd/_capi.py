@@ -1,0 +1,137 @@
+"""ctypes binding of librmclhip.so (include/rmclhip.h).
+
+The library is the product; this module only loads it.  It fails loudly when the
+shared object is missing -- there is no Python/CPU fallback of the hot path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librmclhip.so")
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED = range(6)
+
+
+class RmclHipError(RuntimeError):
+    """Mirrors the std::runtime_error the reference throws (micp_localization.cpp:613)."""
+
+    def __init__(self, status, msg):
+        super().__init__("rmclhip status %d: %s" % (status, msg))
+        self.status = status
+
+
+class NoDeviceError(RmclHipError):
+    pass
+
+
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class Interval(C.Structure):
+    _fields_ = [("min", C.c_float), ("max", C.c_float)]
+
+
+class DiscreteInterval(C.Structure):
+    _fields_ = [("min", C.c_float), ("inc", C.c_float), ("size", C.c_uint32)]
+
+
+class SphericalModel(C.Structure):
+    _fields_ = [("phi", DiscreteInterval), ("theta", DiscreteInterval), ("range", Interval)]
+
+
+class PFParams(C.Structure):
+    _fields_ = [("dist_sigma", C.c_float), ("real_hit_sim_miss_error", C.c_float),
+                ("real_miss_sim_hit_error", C.c_float), ("real_miss_sim_miss_error", C.c_float),
+                ("sensor_range", Interval), ("max_n_meas", C.c_uint32)]
+
+
+class MapInfo(C.Structure):
+    _fields_ = [("n_faces", C.c_uint32), ("n_vertices", C.c_uint32), ("n_nodes", C.c_uint32),
+                ("n_tri_records", C.c_uint32), ("max_depth", C.c_uint32), ("stack_need", C.c_uint32),
+                ("device_bytes", C.c_uint64), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/rmclhip.h
+_vp, _u32, _f32, _i32, _sz, _dbl = C.c_void_p, C.c_uint32, C.c_float, C.c_int, C.c_size_t, C.c_double
+_pp = C.POINTER(C.c_void_p)
+SIGNATURES = {
+    "rmclhip_last_error": (C.c_char_p, []),
+    "rmclhip_version": (C.c_char_p, []),
+    "rmclhip_ctx_create": (_i32, [_i32, _pp]),
+    "rmclhip_ctx_destroy": (None, [_vp]),
+    "rmclhip_ctx_device_name": (_i32, [_vp, C.c_char_p, _sz]),
+    "rmclhip_map_create": (_i32, [_vp, _vp, _u32, _vp, _u32, _pp]),
+    "rmclhip_map_retain": (_i32, [_vp]),
+    "rmclhip_map_release": (None, [_vp]),
+    "rmclhip_map_get_info": (_i32, [_vp, C.POINTER(MapInfo)]),
+    "rmclhip_bvh_build_host": (_i32, [_vp, _u32, _vp, _u32, C.POINTER(MapInfo), _vp, _sz, _vp, _sz]),
+    "rmclhip_rcc_create": (_i32, [_vp, _vp, _pp]),
+    "rmclhip_rcc_destroy": (None, [_vp]),
+    "rmclhip_rcc_set_tsb": (_i32, [_vp, _vp]),
+    "rmclhip_rcc_set_model_spherical": (_i32, [_vp, C.POINTER(SphericalModel)]),
+    "rmclhip_rcc_set_model_o1dn": (_i32, [_vp, _u32, _u32, Interval, Vec3, _vp]),
+    "rmclhip_rcc_set_params": (_i32, [_vp, _f32, _f32]),
+    "rmclhip_rcc_set_dataset": (_i32, [_vp, _vp, _vp, _u32, _i32]),
+    "rmclhip_rcc_set_dataset_from_ranges": (_i32, [_vp, _vp, _u32, C.POINTER(_u32)]),
+    "rmclhip_rcc_find": (_i32, [_vp, _vp]),
+    "rmclhip_rcc_find_async": (_i32, [_vp, _vp]),
+    "rmclhip_rcc_sync": (_i32, [_vp]),
+    "rmclhip_rcc_compute_cross_statistics": (_i32, [_vp, _vp, _dbl, _vp]),
+    "rmclhip_rcc_download": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "rmclhip_rcc_device_views": (_i32, [_vp, _pp, _pp, _pp, _pp, _pp, C.POINTER(_u32)]),
+    "rmclhip_rcc_correct_once": (_i32, [_vp, _vp, _vp, _u32, _dbl, _i32, _vp, _vp]),
+    "rmclhip_rcc_correct_batch": (_i32, [_vp, _vp, _u32, _vp, _vp]),
+    "rmclhip_rcc_last_kernel_ms": (_i32, [_vp, C.POINTER(_f32), C.POINTER(_f32)]),
+    "rmclhip_rcc_time_find": (_i32, [_vp, _vp, _u32, C.POINTER(_f32)]),
+    "rmclhip_rcc_time_reduce": (_i32, [_vp, _vp, _u32, C.POINTER(_f32)]),
+    "rmclhip_rcc_set_variant": (_i32, [_vp, _i32]),
+    "rmclhip_umeyama_transform": (_i32, [_vp, _vp]),
+    "rmclhip_cross_statistics_merge": (_i32, [_vp, _vp, _vp]),
+    "rmclhip_cross_statistics_transform": (_i32, [_vp, _vp, _vp]),
+    "rmclhip_transform_mult": (_i32, [_vp, _vp, _vp]),
+    "rmclhip_transform_inv": (_i32, [_vp, _vp]),
+    "rmclhip_pf_create": (_i32, [_vp, _vp, _pp]),
+    "rmclhip_pf_destroy": (None, [_vp]),
+    "rmclhip_pf_set_params": (_i32, [_vp, C.POINTER(PFParams)]),
+    "rmclhip_pf_update": (_i32, [_vp, _vp, _vp, _u32, _vp, _u32, _vp]),
+    "rmclhip_pf_update_async": (_i32, [_vp, _vp, _vp, _u32, _vp, _u32, _vp]),
+    "rmclhip_pf_sync": (_i32, [_vp]),
+    "rmclhip_pf_set_error_output": (_i32, [_vp, _vp]),
+    "rmclhip_pf_extract_weights": (_i32, [_vp, _vp, _u32, _vp]),
+    "rmclhip_pf_time_update": (_i32, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32, C.POINTER(_f32)]),
+    "rmclhip_pf_set_variant": (_i32, [_vp, _i32]),
+    "rmclhip_malloc": (_i32, [_vp, _sz, _pp]),
+    "rmclhip_free": (_i32, [_vp, _vp]),
+    "rmclhip_memcpy_h2d": (_i32, [_vp, _vp, _vp, _sz]),
+    "rmclhip_memcpy_d2h": (_i32, [_vp, _vp, _vp, _sz]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load librmclhip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "librmclhip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C rmcl_amd/csrc`. rmcl_amd has no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the ABI symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(status):
+    if status == OK:
+        return
+    msg = lib().rmclhip_last_error().decode("utf-8", "replace")
+    if status == ERR_NO_DEVICE:
+        raise NoDeviceError(status, msg)
+    raise RmclHipError(status, msg)

@@ -1,0 +1,271 @@
+// bvh_build.cpp -- see bvh_build.h.  Compiled with -ffp-contract=off: the triangle
+// records must be bit-identical to what the parity oracle derives from the same mesh.
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <deque>
+
+namespace rmclhip {
+namespace {
+
+struct Box {
+  float mn[3], mx[3];
+  void reset() {
+    for (int k = 0; k < 3; ++k) { mn[k] = FLT_MAX; mx[k] = -FLT_MAX; }
+  }
+  void grow(const Box& o) {
+    for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], o.mn[k]); mx[k] = std::max(mx[k], o.mx[k]); }
+  }
+  void grow(const float* p) {
+    for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], p[k]); mx[k] = std::max(mx[k], p[k]); }
+  }
+  float area() const {
+    const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    if (dx < 0 || dy < 0 || dz < 0) return 0.f;
+    return 2.f * (dx * dy + dy * dz + dz * dx);
+  }
+};
+
+struct Prim { Box b; float c[3]; };
+
+struct Node2 {
+  Box b;
+  int32_t left = -1, right = -1;  // children (inner)
+  uint32_t first = 0, count = 0;  // prims (leaf)
+  bool leaf() const { return left < 0; }
+};
+
+constexpr int kBins = 16;
+
+struct Builder {
+  const std::vector<Prim>& prims;
+  std::vector<uint32_t>& order;
+  std::vector<Node2> nodes;
+
+  Builder(const std::vector<Prim>& p, std::vector<uint32_t>& o) : prims(p), order(o) {}
+
+  int bin_of(float c, float cmin, float scale) const {
+    int b = static_cast<int>((c - cmin) * scale);
+    return std::min(kBins - 1, std::max(0, b));
+  }
+
+  // iterative top-down build
+  void build() {
+    struct Task { int32_t node; uint32_t first, count; };
+    nodes.reserve(order.size() * 2);
+    nodes.emplace_back();
+    std::vector<Task> stack;
+    stack.push_back({0, 0, static_cast<uint32_t>(order.size())});
+    while (!stack.empty()) {
+      const Task t = stack.back();
+      stack.pop_back();
+      Box nb, cb;
+      nb.reset(); cb.reset();
+      for (uint32_t i = t.first; i < t.first + t.count; ++i) {
+        const Prim& p = prims[order[i]];
+        nb.grow(p.b);
+        cb.grow(p.c);
+      }
+      nodes[t.node].b = nb;
+      if (t.count <= kMaxLeafTris) {
+        nodes[t.node].first = t.first;
+        nodes[t.node].count = t.count;
+        continue;
+      }
+      int best_axis = -1, best_bin = -1;
+      float best_cost = FLT_MAX;
+      for (int axis = 0; axis < 3; ++axis) {
+        const float ext = cb.mx[axis] - cb.mn[axis];
+        if (!(ext > 0.f)) continue;
+        Box bb[kBins];
+        uint32_t bc[kBins];
+        for (int b = 0; b < kBins; ++b) { bb[b].reset(); bc[b] = 0; }
+        const float scale = static_cast<float>(kBins) / ext;
+        for (uint32_t i = t.first; i < t.first + t.count; ++i) {
+          const Prim& p = prims[order[i]];
+          const int b = bin_of(p.c[axis], cb.mn[axis], scale);
+          bc[b]++;
+          bb[b].grow(p.b);
+        }
+        float la[kBins - 1], ra[kBins - 1];
+        uint32_t lc[kBins - 1], rc[kBins - 1];
+        Box acc;
+        acc.reset();
+        uint32_t c = 0;
+        for (int b = 0; b < kBins - 1; ++b) { acc.grow(bb[b]); c += bc[b]; la[b] = acc.area(); lc[b] = c; }
+        acc.reset();
+        c = 0;
+        for (int b = kBins - 1; b > 0; --b) { acc.grow(bb[b]); c += bc[b]; ra[b - 1] = acc.area(); rc[b - 1] = c; }
+        for (int b = 0; b < kBins - 1; ++b) {
+          if (lc[b] == 0 || rc[b] == 0) continue;
+          const float cost = la[b] * static_cast<float>(lc[b]) + ra[b] * static_cast<float>(rc[b]);
+          if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+        }
+      }
+      uint32_t mid;
+      if (best_axis < 0) {
+        mid = t.first + t.count / 2;
+      } else {
+        const float ext = cb.mx[best_axis] - cb.mn[best_axis];
+        const float scale = static_cast<float>(kBins) / ext;
+        const float cmin = cb.mn[best_axis];
+        auto it = std::partition(order.begin() + t.first, order.begin() + t.first + t.count, [&](uint32_t id) {
+          return bin_of(prims[id].c[best_axis], cmin, scale) <= best_bin;
+        });
+        mid = static_cast<uint32_t>(it - order.begin());
+        if (mid == t.first || mid == t.first + t.count) mid = t.first + t.count / 2;
+      }
+      const int32_t l = static_cast<int32_t>(nodes.size());
+      nodes.emplace_back();
+      nodes.emplace_back();
+      nodes[t.node].left = l;
+      nodes[t.node].right = l + 1;
+      stack.push_back({l + 1, mid, t.first + t.count - mid});
+      stack.push_back({l, t.first, mid - t.first});
+    }
+  }
+};
+
+inline void cross_fma(const float* a, const float* b, float* r) {
+  r[0] = std::fmaf(a[1], b[2], -(a[2] * b[1]));
+  r[1] = std::fmaf(a[2], b[0], -(a[0] * b[2]));
+  r[2] = std::fmaf(a[0], b[1], -(a[1] * b[0]));
+}
+
+}  // namespace
+
+std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, uint32_t nf, BvhHost& out) {
+  if (!verts || !faces) return "null mesh pointers";
+  if (nf == 0 || nv == 0) return "empty mesh";
+  if (nf > 0x0FFFFFFFu) return "too many faces (max 2^28-1)";
+  for (uint32_t i = 0; i < 3u * nf; ++i)
+    if (faces[i] >= nv) return "face index out of range";
+  for (size_t i = 0; i < 3 * static_cast<size_t>(nv); ++i)
+    if (!std::isfinite(verts[i])) return "non-finite vertex coordinate";
+
+  // triangle records (by face id) + primitive boxes
+  std::vector<TriRec> recs(nf);
+  std::vector<Prim> prims(nf);
+  Box scene;
+  scene.reset();
+  for (uint32_t f = 0; f < nf; ++f) {
+    const float* a = verts + 3 * static_cast<size_t>(faces[3 * f + 0]);
+    const float* b = verts + 3 * static_cast<size_t>(faces[3 * f + 1]);
+    const float* c = verts + 3 * static_cast<size_t>(faces[3 * f + 2]);
+    TriRec& r = recs[f];
+    for (int k = 0; k < 3; ++k) {
+      r.v0[k] = a[k];
+      r.e1[k] = a[k] - b[k];
+      r.e2[k] = c[k] - a[k];
+    }
+    cross_fma(r.e2, r.e1, r.Ng);
+    const float d = std::sqrt((r.Ng[0] * r.Ng[0] + r.Ng[1] * r.Ng[1]) + r.Ng[2] * r.Ng[2]);
+    for (int k = 0; k < 3; ++k) r.n[k] = (d > 0.f) ? r.Ng[k] / d : 0.f;
+    r.face_id = f;
+    Prim& p = prims[f];
+    p.b.reset();
+    p.b.grow(a);
+    p.b.grow(b);
+    p.b.grow(c);
+    for (int k = 0; k < 3; ++k) p.c[k] = 0.5f * (p.b.mn[k] + p.b.mx[k]);
+    scene.grow(p.b);
+  }
+
+  std::vector<uint32_t> order(nf);
+  for (uint32_t f = 0; f < nf; ++f) order[f] = f;
+  Builder bld(prims, order);
+  bld.build();
+  const std::vector<Node2>& n2 = bld.nodes;
+
+  // conservative padding of every stored box: the slab test runs in fp32 with fused ops and must
+  // never cull a box whose triangle the (exact-spec) intersector would accept.
+  float diag = 0.f, amax = 0.f;
+  for (int k = 0; k < 3; ++k) {
+    diag = std::max(diag, scene.mx[k] - scene.mn[k]);
+    amax = std::max(amax, std::max(std::fabs(scene.mn[k]), std::fabs(scene.mx[k])));
+  }
+  const float pad = 1e-4f * std::max(diag, amax) + 1e-6f;
+
+  // collapse BVH2 -> BVH4, breadth-first emission
+  out.nodes.clear();
+  out.tris.resize(nf);
+  for (uint32_t i = 0; i < nf; ++i) out.tris[i] = recs[order[i]];
+
+  struct QItem { int32_t n2; uint32_t depth; uint32_t stack_before; };
+  std::deque<QItem> queue;
+  // the root is always an inner Node4, even for tiny meshes
+  queue.push_back({0, 1, 0});
+  std::vector<std::pair<uint32_t, int>> patch;  // (node4 index, slot) -> child n2 id to resolve later
+  std::vector<int32_t> n2_of_node4;
+  uint32_t max_depth = 0, stack_need = 0;
+
+  // first pass: assign Node4 ids in BFS order
+  while (!queue.empty()) {
+    const QItem it = queue.front();
+    queue.pop_front();
+    const uint32_t my = static_cast<uint32_t>(out.nodes.size());
+    out.nodes.emplace_back();
+    Node4& nd = out.nodes.back();
+    std::memset(&nd, 0, sizeof(nd));
+    max_depth = std::max(max_depth, it.depth);
+
+    int32_t kids[4];
+    int nk = 0;
+    if (n2[it.n2].leaf()) {
+      kids[nk++] = it.n2;
+    } else {
+      kids[nk++] = n2[it.n2].left;
+      kids[nk++] = n2[it.n2].right;
+      while (nk < 4) {
+        int best = -1;
+        float best_area = -1.f;
+        for (int i = 0; i < nk; ++i) {
+          if (n2[kids[i]].leaf()) continue;
+          const float a = n2[kids[i]].b.area();
+          if (a > best_area) { best_area = a; best = i; }
+        }
+        if (best < 0) break;
+        const int32_t k = kids[best];
+        kids[best] = n2[k].left;
+        kids[nk++] = n2[k].right;
+      }
+    }
+    const uint32_t stack_here = it.stack_before + static_cast<uint32_t>(nk - 1);
+    stack_need = std::max(stack_need, stack_here);
+    for (int s = 0; s < 4; ++s) {
+      if (s < nk) {
+        const Node2& ch = n2[kids[s]];
+        nd.minx[s] = ch.b.mn[0] - pad; nd.miny[s] = ch.b.mn[1] - pad; nd.minz[s] = ch.b.mn[2] - pad;
+        nd.maxx[s] = ch.b.mx[0] + pad; nd.maxy[s] = ch.b.mx[1] + pad; nd.maxz[s] = ch.b.mx[2] + pad;
+        if (ch.leaf()) {
+          nd.child[s] = make_leaf_ref(ch.first, ch.count);
+        } else {
+          // id resolved when the child is dequeued: BFS => ids are assigned in queue order
+          nd.child[s] = 0;
+          patch.emplace_back(my, s);
+          queue.push_back({kids[s], it.depth + 1, stack_here});
+        }
+      } else {
+        nd.minx[s] = nd.miny[s] = nd.minz[s] = INFINITY;
+        nd.maxx[s] = nd.maxy[s] = nd.maxz[s] = -INFINITY;
+        nd.child[s] = kEmptyRef;
+      }
+    }
+  }
+  // BFS: the i-th pushed inner child receives Node4 id (i+1)
+  for (size_t i = 0; i < patch.size(); ++i) out.nodes[patch[i].first].child[patch[i].second] = static_cast<uint32_t>(i + 1);
+
+  out.info.n_faces = nf;
+  out.info.n_vertices = nv;
+  out.info.n_nodes = static_cast<uint32_t>(out.nodes.size());
+  out.info.max_depth = max_depth;
+  out.info.stack_need = stack_need + 1;
+  out.info.pad = pad;
+  for (int k = 0; k < 3; ++k) { out.info.bbox_min[k] = scene.mn[k]; out.info.bbox_max[k] = scene.mx[k]; }
+  return std::string();
+}
+
+}  // namespace rmclhip

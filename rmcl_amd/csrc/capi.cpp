@@ -1,0 +1,913 @@
+// capi.cpp -- implementation of the C ABI declared in include/rmclhip.h.
+// Host-side orchestration only: device memory, streams, launches.  There is no CPU compute
+// path here: without a HIP device every compute entry point fails with RMCLHIP_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rmclhip.h"
+#include "bvh_build.h"
+#include "devmath.h"
+#include "kernels.h"
+
+using namespace rmclhip;
+
+static_assert(sizeof(rmclhip_transform) == sizeof(xform), "Transform layout");
+static_assert(sizeof(rmclhip_cross_statistics) == sizeof(cstats), "CrossStatistics layout");
+static_assert(sizeof(rmclhip_particle_attributes) == 36, "ParticleAttributes layout");
+static_assert(sizeof(rmclhip_range_measurement) == 64, "RangeMeasurement layout");
+static_assert(sizeof(rmclhip_spherical_model) == 32, "SphericalModel layout");
+
+namespace {
+
+thread_local std::string g_err;
+
+rmclhip_status fail(rmclhip_status st, const std::string& msg) {
+  g_err = msg;
+  return st;
+}
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return fail(RMCLHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+  } while (0)
+
+inline xform to_x(const rmclhip_transform* T) {
+  xform r;
+  std::memcpy(&r, T, sizeof(r));
+  return r;
+}
+inline void from_x(const xform& x, rmclhip_transform* T) { std::memcpy(T, &x, sizeof(x)); }
+inline cstats to_cs(const rmclhip_cross_statistics* s) {
+  cstats r;
+  std::memcpy(&r, s, sizeof(r));
+  return r;
+}
+inline void from_cs(const cstats& c, rmclhip_cross_statistics* s) { std::memcpy(s, &c, sizeof(c)); }
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;  // elements
+  // grow-only (RCCEmbree.cpp:28-33)
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
+    if (e == hipSuccess) cap = n;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace
+
+struct rmclhip_ctx {
+  int device = 0;
+  hipDeviceProp_t props;
+};
+
+struct rmclhip_map {
+  rmclhip_ctx* ctx = nullptr;
+  std::atomic<int> refs{1};
+  BvhInfo info;
+  uint32_t* d_nodes = nullptr;
+  uint32_t* d_tris = nullptr;
+  uint64_t bytes = 0;
+};
+
+struct rmclhip_rcc {
+  rmclhip_ctx* ctx = nullptr;
+  rmclhip_map* map = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  xform Tsb = xidentity();
+  // model
+  ModelKind kind = kModelNone;
+  uint32_t W = 0, H = 0;
+  rmclhip_interval range{0.f, 0.f};
+  f3 orig{0.f, 0.f, 0.f};
+  DevBuf<float> d_model_tab;
+  // params
+  float max_dist = 1.0f, adaptive_max_dist_min = 1.0f;
+  // dataset
+  DevBuf<float> d_ds_points;
+  DevBuf<uint8_t> d_ds_mask;
+  uint32_t n_dataset = 0;
+  bool ds_has_mask = false;
+  // model buffers
+  DevBuf<uint8_t> d_hits;
+  DevBuf<float> d_ranges, d_points, d_normals;
+  DevBuf<uint32_t> d_face_ids;
+  uint32_t n_model = 0;      // per pose
+  uint32_t nposes_last = 0;
+  // reduction
+  DevBuf<double> d_partials;
+  cstats* h_stats = nullptr;       // pinned, host-mapped
+  cstats* h_stats_dev = nullptr;   // device alias of h_stats
+  MicpState* d_state = nullptr;
+  MicpState* h_state = nullptr;    // pinned
+  uint32_t* d_counter = nullptr;
+  // batch
+  DevBuf<xform> d_Tbm, d_Tsm, d_Tms, d_Tdelta;
+  DevBuf<cstats> d_bstats;
+  int variant = 0;
+  float last_find_ms = 0.f, last_reduce_ms = 0.f;
+};
+
+struct rmclhip_pf {
+  rmclhip_ctx* ctx = nullptr;
+  rmclhip_map* map = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  rmclhip_pf_params params{2.0f, 100.0f, 100.0f, 0.0f, {0.05f, 80.0f}, 10000u};
+  DevBuf<float> d_beams;
+  float* h_beams = nullptr;  // pinned staging
+  size_t h_beams_cap = 0;
+  float* errors_dev = nullptr;
+  int variant = 0;
+};
+
+extern "C" {
+
+const char* rmclhip_last_error(void) { return g_err.c_str(); }
+const char* rmclhip_version(void) { return "rmclhip 0.1 (gfx950)"; }
+
+// ---- context ---------------------------------------------------------------------------------
+rmclhip_status rmclhip_ctx_create(int device, rmclhip_ctx** out) {
+  if (!out) return fail(RMCLHIP_ERR_INVALID, "ctx_create: out is null");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(RMCLHIP_ERR_NO_DEVICE, "no HIP device available (librmclhip has no CPU fallback)");
+  if (device < 0 || device >= count) return fail(RMCLHIP_ERR_INVALID, "ctx_create: device index out of range");
+  HIPCHK(hipSetDevice(device));
+  rmclhip_ctx* c = new rmclhip_ctx();
+  c->device = device;
+  e = hipGetDeviceProperties(&c->props, device);
+  if (e != hipSuccess) {
+    delete c;
+    return fail(RMCLHIP_ERR_HIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+  }
+  *out = c;
+  return RMCLHIP_OK;
+}
+
+void rmclhip_ctx_destroy(rmclhip_ctx* ctx) { delete ctx; }
+
+rmclhip_status rmclhip_ctx_device_name(rmclhip_ctx* ctx, char* buf, size_t n) {
+  if (!ctx || !buf || n == 0) return fail(RMCLHIP_ERR_INVALID, "ctx_device_name: bad arguments");
+  std::snprintf(buf, n, "%s (%s, %d CUs)", ctx->props.name, ctx->props.gcnArchName, ctx->props.multiProcessorCount);
+  return RMCLHIP_OK;
+}
+
+// ---- map -------------------------------------------------------------------------------------
+static void fill_info(const BvhInfo& bi, uint64_t bytes, rmclhip_map_info* out) {
+  std::memset(out, 0, sizeof(*out));
+  out->n_faces = bi.n_faces;
+  out->n_vertices = bi.n_vertices;
+  out->n_nodes = bi.n_nodes;
+  out->n_tri_records = bi.n_faces;
+  out->max_depth = bi.max_depth;
+  out->stack_need = bi.stack_need;
+  out->device_bytes = bytes;
+  for (int k = 0; k < 3; ++k) { out->bbox_min[k] = bi.bbox_min[k]; out->bbox_max[k] = bi.bbox_max[k]; }
+}
+
+rmclhip_status rmclhip_bvh_build_host(const float* v, uint32_t nv, const uint32_t* f, uint32_t nf,
+                                      rmclhip_map_info* info, uint32_t* nodes_out, size_t nodes_cap,
+                                      uint32_t* tris_out, size_t tris_cap) {
+  BvhHost bvh;
+  const std::string err = build_bvh(v, nv, f, nf, bvh);
+  if (!err.empty()) return fail(RMCLHIP_ERR_INVALID, "bvh_build_host: " + err);
+  const size_t nd = bvh.nodes.size() * kNodeDwords, td = bvh.tris.size() * kTriDwords;
+  if (info) fill_info(bvh.info, (nd + td) * 4, info);
+  if (nodes_out) {
+    if (nodes_cap < nd) return fail(RMCLHIP_ERR_INVALID, "bvh_build_host: nodes buffer too small");
+    std::memcpy(nodes_out, bvh.nodes.data(), nd * 4);
+  }
+  if (tris_out) {
+    if (tris_cap < td) return fail(RMCLHIP_ERR_INVALID, "bvh_build_host: tris buffer too small");
+    std::memcpy(tris_out, bvh.tris.data(), td * 4);
+  }
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_map_create(rmclhip_ctx* ctx, const float* v, uint32_t nv, const uint32_t* f, uint32_t nf,
+                                  rmclhip_map** out) {
+  if (!out) return fail(RMCLHIP_ERR_INVALID, "map_create: out is null");
+  *out = nullptr;
+  if (!ctx) return fail(RMCLHIP_ERR_INVALID, "map_create: ctx is null");
+  BvhHost bvh;
+  const std::string err = build_bvh(v, nv, f, nf, bvh);
+  if (!err.empty()) return fail(RMCLHIP_ERR_INVALID, "map_create: " + err);
+  if (bvh.info.stack_need > 64)
+    return fail(RMCLHIP_ERR_UNSUPPORTED, "map_create: BVH needs a traversal stack deeper than 64 entries");
+  HIPCHK(hipSetDevice(ctx->device));
+  rmclhip_map* m = new rmclhip_map();
+  m->ctx = ctx;
+  m->info = bvh.info;
+  const size_t nb = bvh.nodes.size() * sizeof(Node4), tb = bvh.tris.size() * sizeof(TriRec);
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->d_nodes), nb);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_tris), tb);
+  if (e == hipSuccess) e = hipMemcpy(m->d_nodes, bvh.nodes.data(), nb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(m->d_tris, bvh.tris.data(), tb, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (m->d_nodes) (void)hipFree(m->d_nodes);
+    if (m->d_tris) (void)hipFree(m->d_tris);
+    delete m;
+    return fail(e == hipErrorOutOfMemory ? RMCLHIP_ERR_NOMEM : RMCLHIP_ERR_HIP,
+                std::string("map_create upload: ") + hipGetErrorString(e));
+  }
+  m->bytes = nb + tb;
+  *out = m;
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_map_retain(rmclhip_map* map) {
+  if (!map) return fail(RMCLHIP_ERR_INVALID, "map_retain: null");
+  map->refs.fetch_add(1);
+  return RMCLHIP_OK;
+}
+
+void rmclhip_map_release(rmclhip_map* map) {
+  if (!map) return;
+  if (map->refs.fetch_sub(1) == 1) {
+    (void)hipSetDevice(map->ctx->device);
+    if (map->d_nodes) (void)hipFree(map->d_nodes);
+    if (map->d_tris) (void)hipFree(map->d_tris);
+    delete map;
+  }
+}
+
+rmclhip_status rmclhip_map_get_info(const rmclhip_map* map, rmclhip_map_info* out) {
+  if (!map || !out) return fail(RMCLHIP_ERR_INVALID, "map_get_info: null");
+  fill_info(map->info, map->bytes, out);
+  return RMCLHIP_OK;
+}
+
+// ---- rcc -------------------------------------------------------------------------------------
+rmclhip_status rmclhip_rcc_create(rmclhip_ctx* ctx, rmclhip_map* map, rmclhip_rcc** out) {
+  if (!out) return fail(RMCLHIP_ERR_INVALID, "rcc_create: out is null");
+  *out = nullptr;
+  if (!ctx || !map) return fail(RMCLHIP_ERR_INVALID, "rcc_create: NO MAP");
+  HIPCHK(hipSetDevice(ctx->device));
+  rmclhip_rcc* r = new rmclhip_rcc();
+  r->ctx = ctx;
+  r->map = map;
+  rmclhip_map_retain(map);
+  hipError_t e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&r->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&r->ev1);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_stats), sizeof(cstats) * 2, hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&r->h_stats_dev), r->h_stats, 0);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_state), sizeof(MicpState), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->d_state), sizeof(MicpState));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->d_counter), sizeof(uint32_t));
+  if (e != hipSuccess) {
+    rmclhip_rcc_destroy(r);
+    return fail(RMCLHIP_ERR_HIP, std::string("rcc_create: ") + hipGetErrorString(e));
+  }
+  *out = r;
+  return RMCLHIP_OK;
+}
+
+void rmclhip_rcc_destroy(rmclhip_rcc* r) {
+  if (!r) return;
+  (void)hipSetDevice(r->ctx->device);
+  if (r->stream) (void)hipStreamSynchronize(r->stream);
+  r->d_model_tab.release(); r->d_ds_points.release(); r->d_ds_mask.release();
+  r->d_hits.release(); r->d_ranges.release(); r->d_points.release(); r->d_normals.release(); r->d_face_ids.release();
+  r->d_partials.release(); r->d_Tbm.release(); r->d_Tsm.release(); r->d_Tms.release(); r->d_Tdelta.release();
+  r->d_bstats.release();
+  if (r->h_stats) (void)hipHostFree(r->h_stats);
+  if (r->h_state) (void)hipHostFree(r->h_state);
+  if (r->d_state) (void)hipFree(r->d_state);
+  if (r->d_counter) (void)hipFree(r->d_counter);
+  if (r->ev0) (void)hipEventDestroy(r->ev0);
+  if (r->ev1) (void)hipEventDestroy(r->ev1);
+  if (r->stream) (void)hipStreamDestroy(r->stream);
+  rmclhip_map_release(r->map);
+  delete r;
+}
+
+rmclhip_status rmclhip_rcc_set_tsb(rmclhip_rcc* r, const rmclhip_transform* Tsb) {
+  if (!r || !Tsb) return fail(RMCLHIP_ERR_INVALID, "rcc_set_tsb: null");
+  r->Tsb = to_x(Tsb);
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_set_model_spherical(rmclhip_rcc* r, const rmclhip_spherical_model* m) {
+  if (!r || !m) return fail(RMCLHIP_ERR_INVALID, "rcc_set_model_spherical: null");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  const uint32_t H = m->phi.size, W = m->theta.size;
+  r->kind = kModelSpherical;
+  r->W = W; r->H = H;
+  r->range = m->range;
+  r->orig = mk3(0.f, 0.f, 0.f);
+  if (W == 0 || H == 0) return RMCLHIP_OK;
+  // trig tables with the host libm, exactly what rmagine's getDirection evaluates per ray:
+  // phi = phi.min + float(vid) * phi.inc, theta likewise
+  std::vector<float> tab(2 * static_cast<size_t>(H) + 2 * static_cast<size_t>(W));
+  for (uint32_t v = 0; v < H; ++v) {
+    const float phi = m->phi.min + static_cast<float>(v) * m->phi.inc;
+    tab[v] = cosf(phi);
+    tab[H + v] = sinf(phi);
+  }
+  for (uint32_t h = 0; h < W; ++h) {
+    const float th = m->theta.min + static_cast<float>(h) * m->theta.inc;
+    tab[2 * H + h] = cosf(th);
+    tab[2 * H + W + h] = sinf(th);
+  }
+  HIPCHK(r->d_model_tab.reserve(tab.size()));
+  HIPCHK(hipMemcpy(r->d_model_tab.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_set_model_o1dn(rmclhip_rcc* r, uint32_t width, uint32_t height, rmclhip_interval range,
+                                          rmclhip_vec3 orig, const float* dirs) {
+  if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_set_model_o1dn: null");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  r->kind = kModelO1Dn;
+  r->W = width; r->H = height;
+  r->range = range;
+  r->orig = mk3(orig.x, orig.y, orig.z);
+  const size_t n = static_cast<size_t>(width) * height;
+  if (n == 0) return RMCLHIP_OK;
+  if (!dirs) return fail(RMCLHIP_ERR_INVALID, "rcc_set_model_o1dn: dirs is null");
+  HIPCHK(r->d_model_tab.reserve(3 * n));
+  HIPCHK(hipMemcpy(r->d_model_tab.p, dirs, 3 * n * sizeof(float), hipMemcpyHostToDevice));
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_set_params(rmclhip_rcc* r, float max_dist, float adaptive_max_dist_min) {
+  if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_set_params: null");
+  r->max_dist = max_dist;
+  r->adaptive_max_dist_min = adaptive_max_dist_min;
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_set_dataset(rmclhip_rcc* r, const float* pts, const uint8_t* mask, uint32_t n,
+                                       int src_is_device) {
+  if (!r || (!pts && n > 0)) return fail(RMCLHIP_ERR_INVALID, "rcc_set_dataset: null");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  r->n_dataset = n;
+  r->ds_has_mask = (mask != nullptr);
+  if (n == 0) return RMCLHIP_OK;
+  const hipMemcpyKind kind = src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  HIPCHK(r->d_ds_points.reserve(3 * static_cast<size_t>(n)));
+  HIPCHK(hipMemcpy(r->d_ds_points.p, pts, 3 * static_cast<size_t>(n) * sizeof(float), kind));
+  if (mask) {
+    HIPCHK(r->d_ds_mask.reserve(n));
+    HIPCHK(hipMemcpy(r->d_ds_mask.p, mask, n, kind));
+  }
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_set_dataset_from_ranges(rmclhip_rcc* r, const float* ranges, uint32_t n,
+                                                   uint32_t* n_valid_out) {
+  if (!r || !ranges) return fail(RMCLHIP_ERR_INVALID, "rcc_set_dataset_from_ranges: null");
+  if (r->kind == kModelNone) return fail(RMCLHIP_ERR_INVALID, "rcc_set_dataset_from_ranges: no sensor model set");
+  if (n != r->W * r->H) return fail(RMCLHIP_ERR_INVALID, "rcc_set_dataset_from_ranges: n != model size");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  r->n_dataset = n;
+  r->ds_has_mask = true;
+  if (n_valid_out) *n_valid_out = 0;
+  if (n == 0) return RMCLHIP_OK;
+  HIPCHK(r->d_ds_points.reserve(3 * static_cast<size_t>(n)));
+  HIPCHK(r->d_ds_mask.reserve(n));
+  // stage the ranges in the (not yet used) ranges model buffer region of a scratch allocation
+  DevBuf<float> d_r;
+  HIPCHK(d_r.reserve(n));
+  hipError_t e = hipMemcpy(d_r.p, ranges, n * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemsetAsync(r->d_counter, 0, sizeof(uint32_t), r->stream);
+  if (e == hipSuccess)
+    e = launch_dataset_from_ranges(d_r.p, r->d_model_tab.p, r->kind, r->W, r->H, r->orig, r->range.min, r->range.max,
+                                   r->d_ds_points.p, r->d_ds_mask.p, r->d_counter, r->stream);
+  uint32_t nv = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&nv, r->d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+  d_r.release();
+  if (e != hipSuccess) return fail(RMCLHIP_ERR_HIP, std::string("dataset_from_ranges: ") + hipGetErrorString(e));
+  if (n_valid_out) *n_valid_out = nv;
+  return RMCLHIP_OK;
+}
+
+static uint32_t pick_tile_w_log2(uint32_t H) {
+  // 8x8 tiles for images at least 8 rows tall; flatter tiles for 2-D scanners
+  uint32_t th = 1;
+  while (th < H && th < 8) th <<= 1;
+  uint32_t twl = 0;
+  while ((64u >> twl) > th) ++twl;
+  return twl;  // tile = 2^twl wide, 64 >> twl tall
+}
+
+static rmclhip_status ensure_model_buffers(rmclhip_rcc* r, size_t n_total) {
+  HIPCHK(r->d_hits.reserve(n_total));
+  HIPCHK(r->d_ranges.reserve(n_total));
+  HIPCHK(r->d_points.reserve(3 * n_total));
+  HIPCHK(r->d_normals.reserve(3 * n_total));
+  HIPCHK(r->d_face_ids.reserve(n_total));
+  return RMCLHIP_OK;
+}
+
+static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
+  std::memset(&p, 0, sizeof(p));
+  p.nodes = r->map->d_nodes;
+  p.tris = r->map->d_tris;
+  p.model_tab = r->d_model_tab.p;
+  p.W = r->W; p.H = r->H;
+  p.tile_w_log2 = pick_tile_w_log2(r->H);
+  const uint32_t tw = 1u << p.tile_w_log2, th = 64u >> p.tile_w_log2;
+  p.tiles_x = (r->W + tw - 1) / tw;
+  p.tiles_y = (r->H + th - 1) / th;
+  p.tfar = r->range.max;
+  p.orig_s = r->orig;
+  p.nposes = nposes;
+  p.hits = r->d_hits.p; p.ranges = r->d_ranges.p; p.points = r->d_points.p; p.normals = r->d_normals.p;
+  p.face_ids = r->d_face_ids.p;
+}
+
+static rmclhip_status find_enqueue(rmclhip_rcc* r, const xform& Tbm) {
+  const size_t n = static_cast<size_t>(r->W) * r->H;
+  r->n_model = static_cast<uint32_t>(n);
+  r->nposes_last = 1;
+  if (rmclhip_status st = ensure_model_buffers(r, n)) return st;
+  FindParams p;
+  fill_find_params(r, p, 1);
+  p.Tsm = xmul(Tbm, r->Tsb);
+  p.Tms = xinv(p.Tsm);
+  HIPCHK(launch_find(p, r->kind, r->variant, r->stream));
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_find_async(rmclhip_rcc* r, const rmclhip_transform* Tbm_est) {
+  if (!r || !Tbm_est) return fail(RMCLHIP_ERR_INVALID, "rcc_find: null");
+  // RCCOptix.cpp:30-34: nothing to do for an empty model
+  if (r->kind == kModelNone || r->W == 0 || r->H == 0) return RMCLHIP_OK;
+  HIPCHK(hipSetDevice(r->ctx->device));
+  return find_enqueue(r, to_x(Tbm_est));
+}
+
+rmclhip_status rmclhip_rcc_find(rmclhip_rcc* r, const rmclhip_transform* Tbm_est) {
+  if (!r || !Tbm_est) return fail(RMCLHIP_ERR_INVALID, "rcc_find: null");
+  if (r->kind == kModelNone || r->W == 0 || r->H == 0) return RMCLHIP_OK;
+  HIPCHK(hipSetDevice(r->ctx->device));
+  HIPCHK(hipEventRecord(r->ev0, r->stream));
+  if (rmclhip_status st = find_enqueue(r, to_x(Tbm_est))) return st;
+  HIPCHK(hipEventRecord(r->ev1, r->stream));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  HIPCHK(hipEventElapsedTime(&r->last_find_ms, r->ev0, r->ev1));
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_sync(rmclhip_rcc* r) {
+  if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_sync: null");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  return RMCLHIP_OK;
+}
+
+static rmclhip_status reduce_enqueue(rmclhip_rcc* r, const xform& Tpre, const xform* Tpre_dev, float max_dist,
+                                     uint32_t nposes, uint32_t* nblocks_out) {
+  const uint32_t n = (r->n_dataset < r->n_model) ? r->n_dataset : r->n_model;
+  if (n == 0) return fail(RMCLHIP_ERR_INVALID, "computeCrossStatistics: empty dataset or model (call find first)");
+  const uint32_t nb = reduce_num_blocks(n);
+  HIPCHK(r->d_partials.reserve(static_cast<size_t>(nposes) * nb * 16));
+  ReduceParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.dataset_points = r->d_ds_points.p;
+  p.dataset_mask = r->ds_has_mask ? r->d_ds_mask.p : nullptr;
+  p.model_points = r->d_points.p;
+  p.model_normals = r->d_normals.p;
+  p.model_mask = r->d_hits.p;
+  p.n = n;
+  p.nposes = nposes;
+  p.max_dist = max_dist;
+  p.Tpre = Tpre;
+  p.Tpre_dev = Tpre_dev;
+  p.partials = r->d_partials.p;
+  p.nblocks = nb;
+  if (r->n_model != n && nposes > 1) return fail(RMCLHIP_ERR_INVALID, "batch reduction needs dataset size == model size");
+  HIPCHK(launch_reduce_partials(p, r->stream));
+  *nblocks_out = nb;
+  return RMCLHIP_OK;
+}
+
+static float adaptive_max_dist(const rmclhip_rcc* r, double p) {
+  // CorrespondencesCPU.cpp:21-23 (float operands, double arithmetic, float store)
+  return static_cast<float>(static_cast<double>(r->max_dist) * (1.0 - p) +
+                            static_cast<double>(r->adaptive_max_dist_min) * p);
+}
+
+rmclhip_status rmclhip_rcc_compute_cross_statistics(rmclhip_rcc* r, const rmclhip_transform* T_snew_sold,
+                                                    double convergence_progress, rmclhip_cross_statistics* out) {
+  if (!r || !T_snew_sold || !out) return fail(RMCLHIP_ERR_INVALID, "computeCrossStatistics: null");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  if (r->nposes_last != 1) return fail(RMCLHIP_ERR_INVALID, "computeCrossStatistics: last find was a batch");
+  uint32_t nb = 0;
+  HIPCHK(hipEventRecord(r->ev0, r->stream));
+  if (rmclhip_status st = reduce_enqueue(r, to_x(T_snew_sold), nullptr, adaptive_max_dist(r, convergence_progress), 1, &nb))
+    return st;
+  HIPCHK(launch_reduce_finalize(r->d_partials.p, nb, 1, r->h_stats_dev, r->stream));
+  HIPCHK(hipEventRecord(r->ev1, r->stream));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  HIPCHK(hipEventElapsedTime(&r->last_reduce_ms, r->ev0, r->ev1));
+  from_cs(r->h_stats[0], out);
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_download(rmclhip_rcc* r, uint8_t* hits, float* ranges, float* points, float* normals,
+                                    uint32_t* face_ids) {
+  if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_download: null");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  const size_t n = static_cast<size_t>(r->n_model) * (r->nposes_last ? r->nposes_last : 1);
+  if (n == 0) return RMCLHIP_OK;
+  if (hits) HIPCHK(hipMemcpy(hits, r->d_hits.p, n, hipMemcpyDeviceToHost));
+  if (ranges) HIPCHK(hipMemcpy(ranges, r->d_ranges.p, n * sizeof(float), hipMemcpyDeviceToHost));
+  if (points) HIPCHK(hipMemcpy(points, r->d_points.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+  if (normals) HIPCHK(hipMemcpy(normals, r->d_normals.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+  if (face_ids) HIPCHK(hipMemcpy(face_ids, r->d_face_ids.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_device_views(rmclhip_rcc* r, const uint8_t** hits, const float** ranges,
+                                        const float** points, const float** normals, const uint32_t** face_ids,
+                                        uint32_t* n) {
+  if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_device_views: null");
+  if (hits) *hits = r->d_hits.p;
+  if (ranges) *ranges = r->d_ranges.p;
+  if (points) *points = r->d_points.p;
+  if (normals) *normals = r->d_normals.p;
+  if (face_ids) *face_ids = r->d_face_ids.p;
+  if (n) *n = r->n_model * (r->nposes_last ? r->nposes_last : 1);
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform* Tom_, const rmclhip_transform* Tbo_,
+                                        uint32_t n_iter, double convergence_progress, int refind_each_iteration,
+                                        rmclhip_transform* T_out, rmclhip_cross_statistics* stats_out) {
+  if (!r || !Tom_ || !Tbo_ || !T_out) return fail(RMCLHIP_ERR_INVALID, "correct_once: null");
+  if (r->kind == kModelNone || r->W == 0 || r->H == 0) return fail(RMCLHIP_ERR_INVALID, "correct_once: no sensor model");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  const xform Tom = to_x(Tom_), Tbo = to_x(Tbo_);
+  const float maxd = adaptive_max_dist(r, convergence_progress);
+  if (!refind_each_iteration) {
+    // schedule (R), micp_localization.cpp:900-964: 1 find, n_iter x (reduce + solve); nothing returns
+    // to the host until the end: the pre-transform of iteration i+1 is produced on the device.
+    if (rmclhip_status st = find_enqueue(r, xmul(Tom, Tbo))) return st;
+    HIPCHK(launch_micp_init(r->d_state, r->stream));
+    for (uint32_t i = 0; i < n_iter; ++i) {
+      uint32_t nb = 0;
+      if (rmclhip_status st = reduce_enqueue(r, xidentity(), &r->d_state->T_snew_sold, maxd, 1, &nb)) return st;
+      HIPCHK(launch_micp_step(r->d_partials.p, nb, r->Tsb, Tbo, r->d_state, r->stream));
+    }
+    HIPCHK(hipMemcpyAsync(r->h_state, r->d_state, sizeof(MicpState), hipMemcpyDeviceToHost, r->stream));
+    HIPCHK(hipStreamSynchronize(r->stream));
+    from_x(r->h_state->T_onew_oold, T_out);
+    if (stats_out) from_cs(r->h_state->stats_o, stats_out);
+    return RMCLHIP_OK;
+  }
+  // schedule (B), lidar_corrector_embree_benchmark.cpp:127-135: re-raycast from the corrected pose every iteration
+  xform T_onew_oold = xidentity();
+  cstats last = cs_identity();
+  for (uint32_t i = 0; i < n_iter; ++i) {
+    const xform Tom_cur = xmul(Tom, T_onew_oold);
+    if (rmclhip_status st = find_enqueue(r, xmul(Tom_cur, Tbo))) return st;
+    uint32_t nb = 0;
+    if (rmclhip_status st = reduce_enqueue(r, xidentity(), nullptr, maxd, 1, &nb)) return st;
+    HIPCHK(launch_reduce_finalize(r->d_partials.p, nb, 1, r->h_stats_dev, r->stream));
+    HIPCHK(hipStreamSynchronize(r->stream));
+    const cstats Cs_o = cs_transform(Tbo, cs_transform(r->Tsb, r->h_stats[0]));
+    last = cs_merge(cs_identity(), Cs_o);
+    T_onew_oold = xmul(T_onew_oold, umeyama(last));
+  }
+  from_x(T_onew_oold, T_out);
+  if (stats_out) from_cs(last, stats_out);
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_correct_batch(rmclhip_rcc* r, const rmclhip_transform* Tbm, uint32_t nposes,
+                                         rmclhip_transform* Tdelta_out, rmclhip_cross_statistics* stats_out) {
+  if (!r || !Tbm || !Tdelta_out) return fail(RMCLHIP_ERR_INVALID, "correct_batch: null");
+  if (nposes == 0) return RMCLHIP_OK;
+  if (r->kind == kModelNone || r->W == 0 || r->H == 0) return fail(RMCLHIP_ERR_INVALID, "correct_batch: no sensor model");
+  if (nposes > 32768) return fail(RMCLHIP_ERR_UNSUPPORTED, "correct_batch: at most 32768 poses per call");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  const size_t n = static_cast<size_t>(r->W) * r->H;
+  if (r->n_dataset != n) return fail(RMCLHIP_ERR_INVALID, "correct_batch: dataset size != model size");
+  if (rmclhip_status st = ensure_model_buffers(r, n * nposes)) return st;
+  HIPCHK(r->d_Tbm.reserve(nposes)); HIPCHK(r->d_Tsm.reserve(nposes)); HIPCHK(r->d_Tms.reserve(nposes));
+  HIPCHK(r->d_Tdelta.reserve(nposes)); HIPCHK(r->d_bstats.reserve(nposes));
+  HIPCHK(hipMemcpyAsync(r->d_Tbm.p, Tbm, sizeof(xform) * nposes, hipMemcpyHostToDevice, r->stream));
+  HIPCHK(launch_compose_poses(r->d_Tbm.p, r->Tsb, r->d_Tsm.p, r->d_Tms.p, nposes, r->stream));
+  r->n_model = static_cast<uint32_t>(n);
+  r->nposes_last = nposes;
+  FindParams p;
+  fill_find_params(r, p, nposes);
+  p.Tsm_arr = r->d_Tsm.p;
+  p.Tms_arr = r->d_Tms.p;
+  HIPCHK(launch_find(p, r->kind, r->variant, r->stream));
+  uint32_t nb = 0;
+  if (rmclhip_status st = reduce_enqueue(r, xidentity(), nullptr, r->max_dist, nposes, &nb)) return st;
+  HIPCHK(launch_batch_solve(r->d_partials.p, nb, nposes, r->Tsb, r->d_Tdelta.p, r->d_bstats.p, r->stream));
+  HIPCHK(hipMemcpyAsync(Tdelta_out, r->d_Tdelta.p, sizeof(xform) * nposes, hipMemcpyDeviceToHost, r->stream));
+  if (stats_out)
+    HIPCHK(hipMemcpyAsync(stats_out, r->d_bstats.p, sizeof(cstats) * nposes, hipMemcpyDeviceToHost, r->stream));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_last_kernel_ms(rmclhip_rcc* r, float* find_ms, float* reduce_ms) {
+  if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_last_kernel_ms: null");
+  if (find_ms) *find_ms = r->last_find_ms;
+  if (reduce_ms) *reduce_ms = r->last_reduce_ms;
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_time_find(rmclhip_rcc* r, const rmclhip_transform* Tbm_est, uint32_t iters, float* ms) {
+  if (!r || !Tbm_est || !ms || iters == 0) return fail(RMCLHIP_ERR_INVALID, "rcc_time_find: bad arguments");
+  if (r->kind == kModelNone || r->W == 0 || r->H == 0) return fail(RMCLHIP_ERR_INVALID, "rcc_time_find: no sensor model");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  const xform T = to_x(Tbm_est);
+  if (rmclhip_status st = find_enqueue(r, T)) return st;  // warm-up + allocation
+  HIPCHK(hipStreamSynchronize(r->stream));
+  HIPCHK(hipEventRecord(r->ev0, r->stream));
+  for (uint32_t i = 0; i < iters; ++i)
+    if (rmclhip_status st = find_enqueue(r, T)) return st;
+  HIPCHK(hipEventRecord(r->ev1, r->stream));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  float total = 0.f;
+  HIPCHK(hipEventElapsedTime(&total, r->ev0, r->ev1));
+  *ms = total / static_cast<float>(iters);
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_time_reduce(rmclhip_rcc* r, const rmclhip_transform* Tpre, uint32_t iters, float* ms) {
+  if (!r || !Tpre || !ms || iters == 0) return fail(RMCLHIP_ERR_INVALID, "rcc_time_reduce: bad arguments");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  const xform T = to_x(Tpre);
+  uint32_t nb = 0;
+  if (rmclhip_status st = reduce_enqueue(r, T, nullptr, r->max_dist, 1, &nb)) return st;
+  HIPCHK(hipStreamSynchronize(r->stream));
+  HIPCHK(hipEventRecord(r->ev0, r->stream));
+  for (uint32_t i = 0; i < iters; ++i) {
+    if (rmclhip_status st = reduce_enqueue(r, T, nullptr, r->max_dist, 1, &nb)) return st;
+    HIPCHK(launch_reduce_finalize(r->d_partials.p, nb, 1, r->h_stats_dev + 1, r->stream));
+  }
+  HIPCHK(hipEventRecord(r->ev1, r->stream));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  float total = 0.f;
+  HIPCHK(hipEventElapsedTime(&total, r->ev0, r->ev1));
+  *ms = total / static_cast<float>(iters);
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
+  if (!r || variant < 0 || variant > 1) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: bad arguments");
+  r->variant = variant;
+  return RMCLHIP_OK;
+}
+
+// ---- host-side algebra ---------------------------------------------------------------------------
+rmclhip_status rmclhip_umeyama_transform(const rmclhip_cross_statistics* s, rmclhip_transform* out) {
+  if (!s || !out) return fail(RMCLHIP_ERR_INVALID, "umeyama_transform: null");
+  from_x(umeyama(to_cs(s)), out);
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_cross_statistics_merge(const rmclhip_cross_statistics* a, const rmclhip_cross_statistics* b,
+                                              rmclhip_cross_statistics* out) {
+  if (!a || !b || !out) return fail(RMCLHIP_ERR_INVALID, "cross_statistics_merge: null");
+  from_cs(cs_merge(to_cs(a), to_cs(b)), out);
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_cross_statistics_transform(const rmclhip_transform* T, const rmclhip_cross_statistics* s,
+                                                  rmclhip_cross_statistics* out) {
+  if (!T || !s || !out) return fail(RMCLHIP_ERR_INVALID, "cross_statistics_transform: null");
+  from_cs(cs_transform(to_x(T), to_cs(s)), out);
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_transform_mult(const rmclhip_transform* a, const rmclhip_transform* b, rmclhip_transform* out) {
+  if (!a || !b || !out) return fail(RMCLHIP_ERR_INVALID, "transform_mult: null");
+  from_x(xmul(to_x(a), to_x(b)), out);
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_transform_inv(const rmclhip_transform* a, rmclhip_transform* out) {
+  if (!a || !out) return fail(RMCLHIP_ERR_INVALID, "transform_inv: null");
+  from_x(xinv(to_x(a)), out);
+  return RMCLHIP_OK;
+}
+
+// ---- particle filter -------------------------------------------------------------------------------
+rmclhip_status rmclhip_pf_create(rmclhip_ctx* ctx, rmclhip_map* map, rmclhip_pf** out) {
+  if (!out) return fail(RMCLHIP_ERR_INVALID, "pf_create: out is null");
+  *out = nullptr;
+  if (!ctx || !map) return fail(RMCLHIP_ERR_INVALID, "pf_create: NO MAP");
+  HIPCHK(hipSetDevice(ctx->device));
+  rmclhip_pf* f = new rmclhip_pf();
+  f->ctx = ctx;
+  f->map = map;
+  rmclhip_map_retain(map);
+  hipError_t e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&f->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&f->ev1);
+  if (e != hipSuccess) {
+    rmclhip_pf_destroy(f);
+    return fail(RMCLHIP_ERR_HIP, std::string("pf_create: ") + hipGetErrorString(e));
+  }
+  *out = f;
+  return RMCLHIP_OK;
+}
+
+void rmclhip_pf_destroy(rmclhip_pf* f) {
+  if (!f) return;
+  (void)hipSetDevice(f->ctx->device);
+  if (f->stream) (void)hipStreamSynchronize(f->stream);
+  f->d_beams.release();
+  if (f->h_beams) (void)hipHostFree(f->h_beams);
+  if (f->ev0) (void)hipEventDestroy(f->ev0);
+  if (f->ev1) (void)hipEventDestroy(f->ev1);
+  if (f->stream) (void)hipStreamDestroy(f->stream);
+  rmclhip_map_release(f->map);
+  delete f;
+}
+
+rmclhip_status rmclhip_pf_set_params(rmclhip_pf* f, const rmclhip_pf_params* p) {
+  if (!f || !p) return fail(RMCLHIP_ERR_INVALID, "pf_set_params: null");
+  if (!(p->dist_sigma > 0.f)) return fail(RMCLHIP_ERR_INVALID, "pf_set_params: dist_sigma must be > 0");
+  f->params = *p;
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_pf_set_error_output(rmclhip_pf* f, float* errors_dev) {
+  if (!f) return fail(RMCLHIP_ERR_INVALID, "pf_set_error_output: null");
+  f->errors_dev = errors_dev;
+  return RMCLHIP_OK;
+}
+
+static rmclhip_status pf_upload_beams(rmclhip_pf* f, const rmclhip_range_measurement* beams, uint32_t n_beams) {
+  const size_t nf = static_cast<size_t>(n_beams) * 16;
+  HIPCHK(f->d_beams.reserve(nf));
+  if (f->h_beams_cap < nf) {
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (f->h_beams) (void)hipHostFree(f->h_beams);
+    f->h_beams = nullptr;
+    f->h_beams_cap = 0;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&f->h_beams), nf * sizeof(float), hipHostMallocDefault));
+    f->h_beams_cap = nf;
+  } else {
+    HIPCHK(hipStreamSynchronize(f->stream));  // the staging buffer may still be in flight
+  }
+  std::memcpy(f->h_beams, beams, nf * sizeof(float));
+  HIPCHK(hipMemcpyAsync(f->d_beams.p, f->h_beams, nf * sizeof(float), hipMemcpyHostToDevice, f->stream));
+  return RMCLHIP_OK;
+}
+
+static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, rmclhip_particle_attributes* attrs,
+                                 uint32_t n, uint32_t n_beams, const rmclhip_transform* Tsb) {
+  PfParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.nodes = f->map->d_nodes;
+  p.tris = f->map->d_tris;
+  p.poses = reinterpret_cast<const xform*>(poses);
+  p.attrs = attrs;
+  p.n_particles = n;
+  p.beams = f->d_beams.p;
+  p.n_beams = n_beams;
+  p.Tsb = to_x(Tsb);
+  p.dist_sigma = f->params.dist_sigma;
+  p.rhsm = f->params.real_hit_sim_miss_error;
+  p.rmsh = f->params.real_miss_sim_hit_error;
+  p.rmsm = f->params.real_miss_sim_miss_error;
+  p.range_min = f->params.sensor_range.min;
+  p.range_max = f->params.sensor_range.max;
+  p.max_n_meas = f->params.max_n_meas;
+  p.errors = f->errors_dev;
+  // particles per workgroup: ~4096 rays per block, at most 64 particles, evals must fit 32 KB of LDS
+  uint32_t pb = 4096u / n_beams;
+  if (pb < 1u) pb = 1u;
+  if (pb > 64u) pb = 64u;
+  if (static_cast<size_t>(pb) * n_beams > 8192u) return fail(RMCLHIP_ERR_UNSUPPORTED, "pf_update: more than 8192 beams");
+  p.particles_per_block = pb;
+  const int variant = (f->map->info.stack_need > 32) ? 1 : f->variant;
+  HIPCHK(launch_pf_update(p, variant, f->stream));
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_pf_update_async(rmclhip_pf* f, const rmclhip_transform* poses, rmclhip_particle_attributes* attrs,
+                                       uint32_t n, const rmclhip_range_measurement* beams, uint32_t n_beams,
+                                       const rmclhip_transform* Tsb) {
+  if (!f || !Tsb) return fail(RMCLHIP_ERR_INVALID, "pf_update: null");
+  if (n == 0 || n_beams == 0) return RMCLHIP_OK;
+  if (!poses || !attrs || !beams) return fail(RMCLHIP_ERR_INVALID, "pf_update: null buffers");
+  HIPCHK(hipSetDevice(f->ctx->device));
+  if (rmclhip_status st = pf_upload_beams(f, beams, n_beams)) return st;
+  return pf_enqueue(f, poses, attrs, n, n_beams, Tsb);
+}
+
+rmclhip_status rmclhip_pf_update(rmclhip_pf* f, const rmclhip_transform* poses, rmclhip_particle_attributes* attrs,
+                                 uint32_t n, const rmclhip_range_measurement* beams, uint32_t n_beams,
+                                 const rmclhip_transform* Tsb) {
+  if (rmclhip_status st = rmclhip_pf_update_async(f, poses, attrs, n, beams, n_beams, Tsb)) return st;
+  HIPCHK(hipStreamSynchronize(f->stream));
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_pf_sync(rmclhip_pf* f) {
+  if (!f) return fail(RMCLHIP_ERR_INVALID, "pf_sync: null");
+  HIPCHK(hipSetDevice(f->ctx->device));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_pf_extract_weights(rmclhip_pf* f, const rmclhip_particle_attributes* attrs, uint32_t n,
+                                          float* weights_dev) {
+  if (!f || (!attrs && n) || (!weights_dev && n)) return fail(RMCLHIP_ERR_INVALID, "pf_extract_weights: null");
+  HIPCHK(hipSetDevice(f->ctx->device));
+  HIPCHK(launch_pf_extract_weights(attrs, n, weights_dev, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_pf_time_update(rmclhip_pf* f, const rmclhip_transform* poses, rmclhip_particle_attributes* attrs,
+                                      uint32_t n, const rmclhip_range_measurement* beams, uint32_t n_beams,
+                                      const rmclhip_transform* Tsb, uint32_t iters, float* ms) {
+  if (!f || !ms || iters == 0 || !Tsb || !poses || !attrs || !beams || n == 0 || n_beams == 0)
+    return fail(RMCLHIP_ERR_INVALID, "pf_time_update: bad arguments");
+  HIPCHK(hipSetDevice(f->ctx->device));
+  if (rmclhip_status st = pf_upload_beams(f, beams, n_beams)) return st;
+  if (rmclhip_status st = pf_enqueue(f, poses, attrs, n, n_beams, Tsb)) return st;
+  HIPCHK(hipStreamSynchronize(f->stream));
+  HIPCHK(hipEventRecord(f->ev0, f->stream));
+  for (uint32_t i = 0; i < iters; ++i)
+    if (rmclhip_status st = pf_enqueue(f, poses, attrs, n, n_beams, Tsb)) return st;
+  HIPCHK(hipEventRecord(f->ev1, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  float total = 0.f;
+  HIPCHK(hipEventElapsedTime(&total, f->ev0, f->ev1));
+  *ms = total / static_cast<float>(iters);
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* f, int variant) {
+  if (!f || variant < 0 || variant > 1) return fail(RMCLHIP_ERR_INVALID, "pf_set_variant: bad arguments");
+  f->variant = variant;
+  return RMCLHIP_OK;
+}
+
+// ---- device memory helpers ---------------------------------------------------------------------------
+rmclhip_status rmclhip_malloc(rmclhip_ctx* ctx, size_t bytes, void** out) {
+  if (!ctx || !out) return fail(RMCLHIP_ERR_INVALID, "malloc: null");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+  if (e != hipSuccess)
+    return fail(e == hipErrorOutOfMemory ? RMCLHIP_ERR_NOMEM : RMCLHIP_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_free(rmclhip_ctx* ctx, void* p) {
+  if (!ctx) return fail(RMCLHIP_ERR_INVALID, "free: null ctx");
+  if (!p) return RMCLHIP_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipFree(p));
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_memcpy_h2d(rmclhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx || (bytes && (!dst || !src))) return fail(RMCLHIP_ERR_INVALID, "memcpy_h2d: null");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_memcpy_d2h(rmclhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx || (bytes && (!dst || !src))) return fail(RMCLHIP_ERR_INVALID, "memcpy_d2h: null");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return RMCLHIP_OK;
+}
+
+}  // extern "C"

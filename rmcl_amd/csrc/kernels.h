@@ -1,0 +1,97 @@
+// kernels.h -- launch interface between the C ABI (capi.cpp) and the HIP kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "devmath.h"
+#include "layout.h"
+
+namespace rmclhip {
+
+enum ModelKind : uint32_t { kModelNone = 0, kModelSpherical = 1, kModelO1Dn = 2 };
+
+// one find() launch: every ray of (nposes x H x W)
+struct FindParams {
+  const uint32_t* nodes;   // Node4[]
+  const uint32_t* tris;    // TriRec[]
+  // spherical: [cos(phi_v) (H) | sin(phi_v) (H) | cos(theta_h) (W) | sin(theta_h) (W)], host libm values
+  // o1dn:      dirs xyz (W*H*3)
+  const float* model_tab;
+  uint32_t W, H;
+  uint32_t tile_w_log2;    // wave = 2^tile_w_log2 x (64 >> tile_w_log2) rays of the scan image
+  uint32_t tiles_x, tiles_y;
+  float tfar;              // model.range.max
+  f3 orig_s;               // sensor-frame ray origin (0 for spherical)
+  // pose(s): Tsm = Tbm * Tsb. Single pose: by value; batch: device arrays (pose = blockIdx.y)
+  xform Tsm, Tms;
+  const xform* Tsm_arr;
+  const xform* Tms_arr;
+  uint32_t nposes;
+  // outputs (nullable), sensor frame, index = pose*W*H + vid*W + hid
+  uint8_t* hits;
+  float* ranges;
+  float* points;
+  float* normals;
+  uint32_t* face_ids;
+};
+
+struct ReduceParams {
+  const float* dataset_points;
+  const uint8_t* dataset_mask;   // nullable
+  const float* model_points;
+  const float* model_normals;
+  const uint8_t* model_mask;
+  uint32_t n;                    // elements per pose
+  uint32_t nposes;               // model buffers hold nposes*n elements; dataset is shared
+  float max_dist;
+  xform Tpre;                    // used when Tpre_dev == nullptr
+  const xform* Tpre_dev;         // per-pose pre-transform (device), nullable
+  double* partials;              // [nposes][nblocks][16]
+  uint32_t nblocks;
+};
+
+struct PfParams {
+  const uint32_t* nodes;
+  const uint32_t* tris;
+  const xform* poses;            // Tbm per particle
+  void* attrs;                   // rmclhip_particle_attributes[n]
+  uint32_t n_particles;
+  const float* beams;            // rmclhip_range_measurement[n_beams] (16 floats each), device
+  uint32_t n_beams;
+  xform Tsb;
+  float dist_sigma, rhsm, rmsh, rmsm, range_min, range_max;
+  uint32_t max_n_meas;
+  float* errors;                 // nullable [n_particles*n_beams]
+  uint32_t particles_per_block;
+};
+
+// MICP-L inner-loop state kept on the device between launches (correct_once)
+struct MicpState {
+  xform T_onew_oold;
+  xform T_snew_sold;             // pre-transform for the next reduction
+  cstats stats_o;                // last merged statistics, odom frame
+};
+
+hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStream_t s);
+hipError_t launch_compose_poses(const xform* Tbm_dev, xform Tsb, xform* Tsm_out, xform* Tms_out, uint32_t n,
+                                hipStream_t s);
+uint32_t reduce_num_blocks(uint32_t n);
+hipError_t launch_reduce_partials(const ReduceParams& p, hipStream_t s);
+// finalize one pose's partials into CrossStatistics (writes to out, which may be host-mapped memory)
+hipError_t launch_reduce_finalize(const double* partials, uint32_t nblocks, uint32_t nposes, cstats* out,
+                                  hipStream_t s);
+// finalize + (Tsb*, Tbo*) + umeyama + compose; advances MicpState on the device
+hipError_t launch_micp_step(const double* partials, uint32_t nblocks, xform Tsb, xform Tbo, MicpState* state,
+                            hipStream_t s);
+hipError_t launch_micp_init(MicpState* state, hipStream_t s);
+// batch: per pose finalize + umeyama -> Tdelta (sensor->base conjugated), stats
+hipError_t launch_batch_solve(const double* partials, uint32_t nblocks, uint32_t nposes, xform Tsb,
+                              xform* Tdelta_out, cstats* stats_out, hipStream_t s);
+hipError_t launch_dataset_from_ranges(const float* ranges, const float* model_tab, uint32_t kind, uint32_t W,
+                                      uint32_t H, f3 orig, float rmin, float rmax, float* points, uint8_t* mask,
+                                      uint32_t* n_valid, hipStream_t s);
+hipError_t launch_pf_update(const PfParams& p, int variant, hipStream_t s);
+hipError_t launch_pf_extract_weights(const void* attrs, uint32_t n, float* weights, hipStream_t s);
+
+}  // namespace rmclhip

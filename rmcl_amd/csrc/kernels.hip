@@ -1,0 +1,648 @@
+// kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the RMCL / MICP-L hot path.
+//
+//  k_find            ray-casting correspondences: rm::*Simulator*::simulate as called by
+//                    RCC*::find (rmcl/src/rmcl/registration/RCCEmbree.cpp:26-36,89-99)
+//  k_reduce_partials rm::statistics_p2l (CorrespondencesCPU.cpp:26-30; gate MICPSensorCPU.cpp:70-84)
+//  k_micp_step       one inner iteration of MICPLocalizationNode::correctOnce
+//                    (rmcl_ros/src/nodes/micp_localization.cpp:915-964) + rm::umeyama_transform
+//  k_pf_update       PCDSensorUpdater{Embree,Optix}::update, all beams fused
+//                    (PCDSensorUpdaterEmbree.cpp:290-342, optix/BeamEvaluateProgram.cu:15-130)
+//
+// Wave64 design notes (DESIGN.md has the long form):
+//  * packet traversal: one wave = one 8x8 (configurable) tile of the scan image.  The current
+//    BVH4 node is WAVE-UNIFORM, so its 128 B are fetched with scalar loads (s_load_dwordx*)
+//    into SGPRs and the per-lane slab tests read them as SGPR operands; triangles likewise.
+//    The traversal stack is wave-uniform too and lives in ONE VGPR, one entry per lane,
+//    pushed / popped with v_writelane / v_readlane.  Descent decisions are v_cmp ballots.
+//  * per-lane traversal (incoherent particle-filter rays): per-lane stack in LDS laid out
+//    [depth][lane] (bank-conflict free), nodes via global_load_dwordx4.
+//  * the ray/triangle arithmetic (tri_accept) is an exact-order fp32 spec shared with the
+//    parity oracle; the slab test is free-form but conservative (boxes are padded at build).
+#include "kernels.h"
+
+namespace rmclhip {
+
+namespace {
+
+typedef const __attribute__((address_space(4))) uint32_t* cu32p;  // constant AS: uniform loads -> SMEM
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(4))) u32x16* cu32x16p;
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+struct RayHit {
+  float t;
+  uint32_t face;
+  uint32_t rec;
+};
+
+__device__ __forceinline__ float asf(uint32_t u) { return __uint_as_float(u); }
+
+__device__ __forceinline__ float safe_inv(float d) {
+  const float ad = fabsf(d);
+  const float s = (ad < 1e-30f) ? copysignf(1e-30f, d) : d;
+  return 1.0f / s;
+}
+
+// Moeller-Trumbore in Embree's formulation; must match oracle/rmcl_oracle.c:tri_intersect op for op.
+// Returns the barycentric acceptance; T/aden is left to the caller (so a packet can skip the divide).
+__device__ __forceinline__ bool tri_accept(f3 v0, f3 e1, f3 e2, f3 Ng, f3 O, f3 D, float& Tt, float& aden) {
+  const f3 C = sub3(v0, O);
+  const f3 R = cross_fma(C, D);
+  const float den = dot_fma(Ng, D);
+  aden = fabsf(den);
+  float U = dot_fma(R, e2);
+  float V = dot_fma(R, e1);
+  Tt = dot_fma(Ng, C);
+  if (den < 0.0f) { U = -U; V = -V; Tt = -Tt; }
+  return (den != 0.0f) && (U >= 0.0f) && (V >= 0.0f) && ((U + V) <= aden);
+}
+
+__device__ __forceinline__ void slab(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, f3 inv,
+                                     f3 noi, float best_t, float& tn, float& tf) {
+  const float ax = fmaf(mnx, inv.x, noi.x), bx = fmaf(mxx, inv.x, noi.x);
+  const float ay = fmaf(mny, inv.y, noi.y), by = fmaf(mxy, inv.y, noi.y);
+  const float az = fmaf(mnz, inv.z, noi.z), bz = fmaf(mxz, inv.z, noi.z);
+  tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+  tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best_t));
+}
+
+#define RMCL_CSWAP(i, j)                                   \
+  {                                                        \
+    const bool sw_ = key[j] < key[i];                      \
+    const uint32_t ka_ = sw_ ? key[j] : key[i];            \
+    const uint32_t kb_ = sw_ ? key[i] : key[j];            \
+    const uint32_t ra_ = sw_ ? ref[j] : ref[i];            \
+    const uint32_t rb_ = sw_ ? ref[i] : ref[j];            \
+    key[i] = ka_; key[j] = kb_; ref[i] = ra_; ref[j] = rb_; \
+  }
+
+// ---------------------------------------------------------------------------------------------
+// packet traversal: wave-uniform node, scalar loads, stack in a VGPR (needs stack_need <= 64)
+// ray_tfar < 0 marks an inactive lane.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void trace_packet(cu32p nodes, cu32p tris, f3 O, f3 D, float ray_tfar, uint32_t lane, RayHit& h) {
+  const f3 inv = mk3(safe_inv(D.x), safe_inv(D.y), safe_inv(D.z));
+  const f3 noi = mk3(-(O.x * inv.x), -(O.y * inv.y), -(O.z * inv.z));
+  float best_t = ray_tfar;
+  uint32_t best_face = kInvalidFace, best_rec = 0;
+
+  int stk = 0;       // 64 wave-uniform entries, entry i in lane i
+  uint32_t sp = 0;   // uniform
+  uint32_t cur = 0;  // uniform; root is always an inner node
+  for (;;) {
+    if (!(cur & kLeafBit)) {
+      // whole node in two s_load_dwordx16: dwords 0..15 = minx miny minz maxx, 16..31 = maxy maxz child rsvd
+      const cu32x16p np = reinterpret_cast<cu32x16p>(nodes + cur * kNodeDwords);
+      const u32x16 lo = np[0], hi = np[1];
+      uint32_t key[4], ref[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float tn, tf;
+        slab(asf(lo[0 + c]), asf(lo[4 + c]), asf(lo[8 + c]), asf(lo[12 + c]), asf(hi[0 + c]), asf(hi[4 + c]), inv, noi,
+             best_t, tn, tf);
+        const uint64_t m = __ballot(tn <= tf);
+        ref[c] = hi[8 + c];
+        uint32_t k = kNone;
+        if (m != 0) {
+          const int first = __builtin_ctzll(m);
+          k = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(__float_as_uint(tn)), first));
+        }
+        key[c] = k;
+      }
+      RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
+      if (key[3] != kNone) { stk = (lane == sp) ? static_cast<int>(ref[3]) : stk; ++sp; }
+      if (key[2] != kNone) { stk = (lane == sp) ? static_cast<int>(ref[2]) : stk; ++sp; }
+      if (key[1] != kNone) { stk = (lane == sp) ? static_cast<int>(ref[1]) : stk; ++sp; }
+      if (key[0] != kNone) { cur = ref[0]; continue; }
+    } else {
+      const uint32_t first = cur & 0x0FFFFFFFu;
+      const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
+      for (uint32_t i = 0; i < cnt; ++i) {
+        const u32x16 tr = *reinterpret_cast<cu32x16p>(tris + (first + i) * kTriDwords);  // one s_load_dwordx16
+        const f3 v0 = mk3(asf(tr[0]), asf(tr[1]), asf(tr[2]));
+        const f3 e1 = mk3(asf(tr[3]), asf(tr[4]), asf(tr[5]));
+        const f3 e2 = mk3(asf(tr[6]), asf(tr[7]), asf(tr[8]));
+        const f3 Ng = mk3(asf(tr[9]), asf(tr[10]), asf(tr[11]));
+        const uint32_t face = tr[15];
+        float Tt, aden;
+        const bool ok = tri_accept(v0, e1, e2, Ng, O, D, Tt, aden);
+        if (__ballot(ok) != 0) {
+          const float t = Tt / aden;
+          const bool acc = ok && (t >= 0.0f) && (t <= ray_tfar);
+          const bool closer = acc && ((t < best_t) || ((t == best_t) && (face < best_face)));
+          best_t = closer ? t : best_t;
+          best_face = closer ? face : best_face;
+          best_rec = closer ? (first + i) : best_rec;
+        }
+      }
+    }
+    if (sp == 0) break;
+    --sp;
+    cur = static_cast<uint32_t>(__builtin_amdgcn_readlane(stk, sp));
+  }
+  h.t = best_t;
+  h.face = best_face;
+  h.rec = best_rec;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-lane traversal: every lane walks its own path; stack in LDS [depth][blockDim]
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void trace_lane(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris,
+                                           f3 O, f3 D, float ray_tfar, uint32_t* __restrict__ lds_stack,
+                                           uint32_t lds_stride, RayHit& h) {
+  const f3 inv = mk3(safe_inv(D.x), safe_inv(D.y), safe_inv(D.z));
+  const f3 noi = mk3(-(O.x * inv.x), -(O.y * inv.y), -(O.z * inv.z));
+  float best_t = ray_tfar;
+  uint32_t best_face = kInvalidFace, best_rec = 0;
+  constexpr uint32_t kDone = 0x7FFFFFFFu;
+  uint32_t sp = 0;
+  uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
+  while (cur != kDone) {
+    if (!(cur & kLeafBit)) {
+      const uint4* np = reinterpret_cast<const uint4*>(nodes) + static_cast<size_t>(cur) * 8u;
+      const uint4 qmnx = np[0], qmny = np[1], qmnz = np[2], qmxx = np[3], qmxy = np[4], qmxz = np[5], qch = np[6];
+      const uint32_t amnx[4] = {qmnx.x, qmnx.y, qmnx.z, qmnx.w}, amny[4] = {qmny.x, qmny.y, qmny.z, qmny.w};
+      const uint32_t amnz[4] = {qmnz.x, qmnz.y, qmnz.z, qmnz.w}, amxx[4] = {qmxx.x, qmxx.y, qmxx.z, qmxx.w};
+      const uint32_t amxy[4] = {qmxy.x, qmxy.y, qmxy.z, qmxy.w}, amxz[4] = {qmxz.x, qmxz.y, qmxz.z, qmxz.w};
+      uint32_t ref[4] = {qch.x, qch.y, qch.z, qch.w};
+      uint32_t key[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float tn, tf;
+        slab(asf(amnx[c]), asf(amny[c]), asf(amnz[c]), asf(amxx[c]), asf(amxy[c]), asf(amxz[c]), inv, noi, best_t, tn, tf);
+        key[c] = (tn <= tf) ? __float_as_uint(tn) : kNone;
+      }
+      RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
+      if (key[3] != kNone) { lds_stack[sp * lds_stride] = ref[3]; ++sp; }
+      if (key[2] != kNone) { lds_stack[sp * lds_stride] = ref[2]; ++sp; }
+      if (key[1] != kNone) { lds_stack[sp * lds_stride] = ref[1]; ++sp; }
+      if (key[0] != kNone) { cur = ref[0]; continue; }
+    } else {
+      const uint32_t first = cur & 0x0FFFFFFFu;
+      const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
+      for (uint32_t i = 0; i < cnt; ++i) {
+        const uint4* tp = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(first + i) * 4u;
+        const uint4 a = tp[0], b = tp[1], c = tp[2], d = tp[3];
+        const f3 v0 = mk3(asf(a.x), asf(a.y), asf(a.z));
+        const f3 e1 = mk3(asf(a.w), asf(b.x), asf(b.y));
+        const f3 e2 = mk3(asf(b.z), asf(b.w), asf(c.x));
+        const f3 Ng = mk3(asf(c.y), asf(c.z), asf(c.w));
+        const uint32_t face = d.w;
+        float Tt, aden;
+        const bool ok = tri_accept(v0, e1, e2, Ng, O, D, Tt, aden);
+        if (ok) {
+          const float t = Tt / aden;
+          const bool acc = (t >= 0.0f) && (t <= ray_tfar);
+          const bool closer = acc && ((t < best_t) || ((t == best_t) && (face < best_face)));
+          best_t = closer ? t : best_t;
+          best_face = closer ? face : best_face;
+          best_rec = closer ? (first + i) : best_rec;
+        }
+      }
+    }
+    if (sp == 0) { cur = kDone; }
+    else { --sp; cur = lds_stack[sp * lds_stride]; }
+  }
+  h.t = best_t;
+  h.face = best_face;
+  h.rec = best_rec;
+}
+
+// ---------------------------------------------------------------------------------------------
+// find
+// ---------------------------------------------------------------------------------------------
+template <uint32_t kModel, bool kPacket>
+__global__ void __launch_bounds__(256) k_find(const FindParams p) {
+  extern __shared__ uint32_t lds_dyn[];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  // XCD-aware remap: the dispatcher places block b on XCD b%8; give every XCD a contiguous range of
+  // tiles so neighbouring tiles (which walk the same subtrees) share one L2.  gridDim.x % 8 == 0.
+  const uint32_t chunk = gridDim.x >> 3;
+  const uint32_t vb = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+  const uint32_t tile = vb * 4u + wave;
+  const uint32_t ntiles = p.tiles_x * p.tiles_y;
+  if (tile >= ntiles) return;
+  const uint32_t pose = blockIdx.y;
+  const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+  const uint32_t twl = p.tile_w_log2;
+  const uint32_t lx = lane & ((1u << twl) - 1u), ly = lane >> twl;
+  const uint32_t vid = (ty << (6u - twl)) + ly, hid = (tx << twl) + lx;
+  const bool valid = (vid < p.H) && (hid < p.W);
+  const uint32_t cv = valid ? vid : 0u, ch = valid ? hid : 0u;
+  const uint32_t loc = cv * p.W + ch;
+
+  xform Tsm, Tms;
+  if (p.Tsm_arr != nullptr) { Tsm = p.Tsm_arr[pose]; Tms = p.Tms_arr[pose]; }
+  else { Tsm = p.Tsm; Tms = p.Tms; }
+
+  f3 dir_s, org_m;
+  if (kModel == kModelSpherical) {
+    // rmagine SphericalModel::getDirection (convention pinned by rmcl_ros/src/util/conversions.cpp:174-188);
+    // the four trig tables hold the host libm values of cos/sin(phi_v), cos/sin(theta_h)
+    const float cp = p.model_tab[cv], sp = p.model_tab[p.H + cv];
+    const float ct = p.model_tab[2u * p.H + ch], st = p.model_tab[2u * p.H + p.W + ch];
+    dir_s = mk3(cp * ct, cp * st, sp);
+    org_m = Tsm.t;
+  } else {
+    dir_s = mk3(p.model_tab[3u * loc], p.model_tab[3u * loc + 1u], p.model_tab[3u * loc + 2u]);
+    org_m = xapply(Tsm, p.orig_s);
+  }
+  const f3 dir_m = qrot(Tsm.R, dir_s);
+  const bool finite = (dir_m.x == dir_m.x) && (dir_m.y == dir_m.y) && (dir_m.z == dir_m.z);
+  const float ray_tfar = (valid && finite) ? p.tfar : -1.0f;
+
+  RayHit h;
+  if (kPacket) {
+    trace_packet((cu32p)(p.nodes), (cu32p)(p.tris), org_m, dir_m, ray_tfar, lane, h);
+  } else {
+    trace_lane(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
+  }
+
+  if (!valid) return;
+  const size_t g = static_cast<size_t>(pose) * p.W * p.H + loc;
+  const bool found = (h.face != kInvalidFace);
+  if (found) {
+    if (p.hits) p.hits[g] = 1;
+    if (p.ranges) p.ranges[g] = h.t;
+    if (p.points) {
+      f3 pt = scale3(dir_s, h.t);
+      if (kModel == kModelO1Dn) pt = add3(pt, p.orig_s);
+      p.points[3 * g] = pt.x; p.points[3 * g + 1] = pt.y; p.points[3 * g + 2] = pt.z;
+    }
+    if (p.normals) {
+      const uint4 nrec = reinterpret_cast<const uint4*>(p.tris)[static_cast<size_t>(h.rec) * 4u + 3u];
+      f3 n = qrot(Tms.R, mk3(asf(nrec.x), asf(nrec.y), asf(nrec.z)));
+      if (dot_plain(dir_s, n) > 0.0f) n = neg3(n);  // flip towards the sensor
+      p.normals[3 * g] = n.x; p.normals[3 * g + 1] = n.y; p.normals[3 * g + 2] = n.z;
+    }
+    if (p.face_ids) p.face_ids[g] = h.face;
+  } else {
+    const float qn = __uint_as_float(0x7FC00000u);
+    if (p.hits) p.hits[g] = 0;
+    if (p.ranges) p.ranges[g] = p.tfar + 1.0f;
+    if (p.points) { p.points[3 * g] = qn; p.points[3 * g + 1] = qn; p.points[3 * g + 2] = qn; }
+    if (p.normals) { p.normals[3 * g] = qn; p.normals[3 * g + 1] = qn; p.normals[3 * g + 2] = qn; }
+    if (p.face_ids) p.face_ids[g] = kInvalidFace;
+  }
+}
+
+__global__ void k_compose_poses(const xform* __restrict__ Tbm, xform Tsb, xform* __restrict__ Tsm,
+                                xform* __restrict__ Tms, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const xform T = xmul(Tbm[i], Tsb);
+  Tsm[i] = T;
+  Tms[i] = xinv(T);
+}
+
+// ---------------------------------------------------------------------------------------------
+// statistics_p2l
+// ---------------------------------------------------------------------------------------------
+constexpr int kAcc = 16;  // sd[3] sm[3] smd[9] cnt
+
+__global__ void __launch_bounds__(256) k_reduce_partials(const ReduceParams p) {
+  __shared__ double red[4][kAcc];
+  const uint32_t pose = blockIdx.y;
+  const xform Tpre = (p.Tpre_dev != nullptr) ? p.Tpre_dev[pose] : p.Tpre;
+  double acc[kAcc];
+#pragma unroll
+  for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
+  const size_t mbase = static_cast<size_t>(pose) * p.n;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < p.n; i += gridDim.x * 256u) {
+    const bool dok = (p.dataset_mask == nullptr) || (p.dataset_mask[i] > 0);
+    if (dok && p.model_mask[mbase + i] > 0) {
+      const float* dp = p.dataset_points + 3 * static_cast<size_t>(i);
+      const float* mp = p.model_points + 3 * (mbase + i);
+      const float* mn = p.model_normals + 3 * (mbase + i);
+      const f3 Di = xapply(Tpre, mk3(dp[0], dp[1], dp[2]));
+      const f3 Ii = mk3(mp[0], mp[1], mp[2]);
+      const f3 Ni = mk3(mn[0], mn[1], mn[2]);
+      const float spd = dot_plain(sub3(Ii, Di), Ni);
+      if (fabsf(spd) < p.max_dist) {
+        const f3 Mi = add3(Di, scale3(Ni, spd));
+        const double d[3] = {Di.x, Di.y, Di.z}, m[3] = {Mi.x, Mi.y, Mi.z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { acc[k] += d[k]; acc[3 + k] += m[k]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) acc[6 + 3 * r + c] += m[r] * d[c];
+        acc[15] += 1.0;
+      }
+    }
+  }
+  // wave64 shuffle tree, then 4 waves through LDS
+#pragma unroll
+  for (int k = 0; k < kAcc; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    acc[k] = v;
+  }
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < kAcc; ++k) red[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < kAcc) {
+    const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    p.partials[(static_cast<size_t>(pose) * p.nblocks + blockIdx.x) * kAcc + threadIdx.x] = v;
+  }
+}
+
+// sum the per-block partials of one pose (one wave) and turn the raw moments into CrossStatistics
+__device__ __forceinline__ cstats finalize_pose(const double* __restrict__ partials, uint32_t nblocks) {
+  const uint32_t lane = threadIdx.x & 63u;
+  double acc[kAcc];
+#pragma unroll
+  for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
+  for (uint32_t b = lane; b < nblocks; b += 64u) {
+#pragma unroll
+    for (int k = 0; k < kAcc; ++k) acc[k] += partials[static_cast<size_t>(b) * kAcc + k];
+  }
+#pragma unroll
+  for (int k = 0; k < kAcc; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    acc[k] = v;
+  }
+  cstats s = cs_identity();
+  const double n = acc[15];
+  if (n > 0.0) {
+    const double md[3] = {acc[0] / n, acc[1] / n, acc[2] / n};
+    const double mm[3] = {acc[3] / n, acc[4] / n, acc[5] / n};
+    s.dataset_mean = mk3(static_cast<float>(md[0]), static_cast<float>(md[1]), static_cast<float>(md[2]));
+    s.model_mean = mk3(static_cast<float>(mm[0]), static_cast<float>(mm[1]), static_cast<float>(mm[2]));
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) s.covariance[3 * r + c] = static_cast<float>(acc[6 + 3 * r + c] / n - mm[r] * md[c]);
+    s.n_meas = static_cast<uint32_t>(n);
+  }
+  return s;
+}
+
+__global__ void __launch_bounds__(64) k_reduce_finalize(const double* __restrict__ partials, uint32_t nblocks,
+                                                       cstats* __restrict__ out) {
+  const uint32_t pose = blockIdx.x;
+  const cstats s = finalize_pose(partials + static_cast<size_t>(pose) * nblocks * kAcc, nblocks);
+  if (threadIdx.x == 0) out[pose] = s;
+}
+
+__global__ void k_micp_init(MicpState* st) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    st->T_onew_oold = xidentity();
+    st->T_snew_sold = xidentity();
+    st->stats_o = cs_identity();
+  }
+}
+
+// micp_localization.cpp:915-964 for one sensor (merge_weight_multiplier == 1):
+//   Cs_b = Tsb * stats_s (MICPSensor.hpp:182); Cs_o = Tbo * Cs_b (:931); Cmerged = Identity += Cs_o (:936)
+//   T_inner = umeyama(Cmerged) (:952); T_onew_oold = T_onew_oold * T_inner (:963)
+//   next T_bnew_bold = ~Tbo * T_onew_oold * Tbo (:926); T_snew_sold = ~Tsb * T_bnew_bold * Tsb (MICPSensor.hpp:178)
+__global__ void __launch_bounds__(64) k_micp_step(const double* __restrict__ partials, uint32_t nblocks, xform Tsb,
+                                                  xform Tbo, MicpState* st) {
+  const cstats stats_s = finalize_pose(partials, nblocks);
+  if (threadIdx.x == 0) {
+    const cstats Cs_b = cs_transform(Tsb, stats_s);
+    const cstats Cs_o = cs_transform(Tbo, Cs_b);
+    const cstats Cmerged = cs_merge(cs_identity(), Cs_o);
+    const xform T_inner = umeyama(Cmerged);
+    const xform T_onew_oold = xmul(st->T_onew_oold, T_inner);
+    const xform T_bnew_bold = xmul(xmul(xinv(Tbo), T_onew_oold), Tbo);
+    st->T_onew_oold = T_onew_oold;
+    st->T_snew_sold = xmul(xmul(xinv(Tsb), T_bnew_bold), Tsb);
+    st->stats_o = Cmerged;
+  }
+}
+
+// stale v1 corrector (lidar_corrector_embree_benchmark.cpp:127-135): per pose, Tdelta_b = Tsb * T_s * ~Tsb
+__global__ void __launch_bounds__(64) k_batch_solve(const double* __restrict__ partials, uint32_t nblocks, xform Tsb,
+                                                    xform* __restrict__ Tdelta, cstats* __restrict__ stats) {
+  const uint32_t pose = blockIdx.x;
+  const cstats s = finalize_pose(partials + static_cast<size_t>(pose) * nblocks * kAcc, nblocks);
+  if (threadIdx.x == 0) {
+    const xform Ts = umeyama(s);
+    Tdelta[pose] = xmul(xmul(Tsb, Ts), xinv(Tsb));
+    if (stats) stats[pose] = s;
+  }
+}
+
+// MICPSphericalSensorCPU::unpackMessage / MICPO1DnSensorCPU::unpackMessage (dataset construction)
+__global__ void k_dataset_from_ranges(const float* __restrict__ ranges, const float* __restrict__ tab, uint32_t kind,
+                                      uint32_t W, uint32_t H, f3 orig, float rmin, float rmax,
+                                      float* __restrict__ points, uint8_t* __restrict__ mask,
+                                      uint32_t* __restrict__ n_valid) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= W * H) return;
+  const uint32_t vid = i / W, hid = i - vid * W;
+  const float r = ranges[i];
+  f3 dir;
+  if (kind == kModelSpherical) {
+    const float cp = tab[vid], sp = tab[H + vid], ct = tab[2u * H + hid], st = tab[2u * H + W + hid];
+    dir = mk3(cp * ct, cp * st, sp);
+  } else {
+    dir = mk3(tab[3u * i], tab[3u * i + 1u], tab[3u * i + 2u]);
+  }
+  f3 pt = scale3(dir, r);
+  if (kind == kModelO1Dn) pt = add3(pt, orig);
+  points[3u * i] = pt.x; points[3u * i + 1u] = pt.y; points[3u * i + 2u] = pt.z;
+  const bool out_of_range = (r < rmin) || (r > rmax);
+  mask[i] = out_of_range ? 0 : 1;
+  if (!out_of_range) atomicAdd(n_valid, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// particle filter: all beams of all particles in one launch
+// ---------------------------------------------------------------------------------------------
+struct g1d { float mean, sigma; uint32_t n_meas; };
+struct pattrs { g1d likelihood; float state_sigma[6]; };
+static_assert(sizeof(pattrs) == 36, "ParticleAttributes must be 36 B");
+
+// rm::Gaussian1D::operator+= (1-D count-weighted merge)
+__device__ __forceinline__ g1d g1d_add(g1d a, g1d b) {
+  g1d r;
+  r.n_meas = a.n_meas + b.n_meas;
+  const float w1 = static_cast<float>(a.n_meas) / static_cast<float>(r.n_meas);
+  const float w2 = static_cast<float>(b.n_meas) / static_cast<float>(r.n_meas);
+  r.mean = a.mean * w1 + b.mean * w2;
+  const float P1 = a.sigma * w1 + b.sigma * w2;
+  const float P2 = ((a.mean - r.mean) * (a.mean - r.mean)) * w1 + ((b.mean - r.mean) * (b.mean - r.mean)) * w2;
+  r.sigma = P1 + P2;
+  return r;
+}
+
+template <int kStackDepth>
+__global__ void __launch_bounds__(256) k_pf_update(const PfParams p) {
+  // LDS: [ per-lane stacks kStackDepth*256 | Tsm (PB xforms) | evals (PB*n_beams floats) ]
+  extern __shared__ uint32_t lds_dyn[];
+  uint32_t* stacks = lds_dyn;
+  xform* s_Tsm = reinterpret_cast<xform*>(lds_dyn + kStackDepth * 256);
+  float* s_eval = reinterpret_cast<float*>(s_Tsm + p.particles_per_block);
+
+  const uint32_t PB = p.particles_per_block;
+  const uint32_t p0 = blockIdx.x * PB;
+  if (p0 >= p.n_particles) return;
+  const uint32_t np = min(PB, p.n_particles - p0);
+  if (threadIdx.x < np) s_Tsm[threadIdx.x] = xmul(p.poses[p0 + threadIdx.x], p.Tsb);
+  __syncthreads();
+
+  const float sq = p.dist_sigma * p.dist_sigma;
+  const uint32_t nrays = np * p.n_beams;
+  for (uint32_t r = threadIdx.x; r < ((nrays + 255u) & ~255u); r += 256u) {
+    const bool live = r < nrays;
+    const uint32_t rr = live ? r : 0u;
+    const uint32_t pi = rr / p.n_beams, b = rr - pi * p.n_beams;
+    const xform Tsm = s_Tsm[pi];
+    const float* bm = p.beams + 16u * b;
+    // meas_m = Tsm * meas_s (RangeMeasurement.hpp:28-42)
+    const f3 dir = qrot(Tsm.R, mk3(bm[3], bm[4], bm[5]));
+    const f3 org = xapply(Tsm, mk3(bm[0], bm[1], bm[2]));
+    const float range = bm[6];
+    const bool finite = (dir.x == dir.x) && (dir.y == dir.y) && (dir.z == dir.z);
+    RayHit h;
+    trace_lane(p.nodes, p.tris, org, dir, (live && finite) ? __builtin_inff() : -1.0f, stacks + threadIdx.x, 256u, h);
+    if (live) {
+      // evaluate_rcc (PCDSensorUpdaterEmbree.cpp:18-86) with unit face normals (BeamEvaluateProgram.cu:104-113)
+      const bool real_hit = (range >= p.range_min) && (range <= p.range_max);
+      const bool sim_hit = (h.face != kInvalidFace) && (h.t > p.range_min);
+      float error;
+      if (sim_hit) {
+        if (real_hit) {
+          const uint4 nrec = reinterpret_cast<const uint4*>(p.tris)[static_cast<size_t>(h.rec) * 4u + 3u];
+          const f3 n = mk3(asf(nrec.x), asf(nrec.y), asf(nrec.z));
+          const f3 preal = add3(org, scale3(dir, range));
+          const f3 pint = add3(org, scale3(dir, h.t));
+          error = fabsf(dot_plain(sub3(pint, preal), n));
+        } else {
+          error = p.rmsh;
+        }
+      } else {
+        error = real_hit ? p.rhsm : p.rmsm;
+      }
+      if (p.errors) p.errors[static_cast<size_t>(p0 + pi) * p.n_beams + b] = error;
+      // PCDSensorUpdaterEmbree.cpp:224 : float argument, double exp / sqrt, float result
+      const float arg = -(error * error) / sq / 2;
+      const float eval = static_cast<float>(exp(static_cast<double>(arg)) /
+                                            sqrt(static_cast<double>(2 * sq) * 3.14159265358979323846));
+      s_eval[rr] = eval;
+    }
+  }
+  __syncthreads();
+  // in-order merge, one lane per particle (sequential semantics of sensorUpdate, :232-238)
+  if (threadIdx.x < np) {
+    pattrs* A = reinterpret_cast<pattrs*>(p.attrs) + (p0 + threadIdx.x);
+    g1d L = A->likelihood;
+    const float* ev = s_eval + threadIdx.x * p.n_beams;
+    for (uint32_t b = 0; b < p.n_beams; ++b) {
+      g1d m; m.mean = ev[b]; m.sigma = 0.0f; m.n_meas = 1;
+      L = g1d_add(L, m);
+      L.n_meas = min(L.n_meas, p.max_n_meas);
+    }
+    A->likelihood = L;
+  }
+}
+
+__global__ void k_pf_extract_weights(const pattrs* __restrict__ attrs, uint32_t n, float* __restrict__ w) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) w[i] = attrs[i].likelihood.mean;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStream_t s) {
+  const uint32_t ntiles = p.tiles_x * p.tiles_y;
+  uint32_t nblocks = (ntiles + 3u) / 4u;
+  nblocks = (nblocks + 7u) & ~7u;  // the XCD remap in k_find needs gridDim.x % 8 == 0
+  dim3 grid(nblocks, p.nposes, 1), block(256, 1, 1);
+  if (variant == 0) {  // packet traversal (needs map stack_need <= 64, checked by the caller)
+    if (kind == kModelSpherical) hipLaunchKernelGGL((k_find<kModelSpherical, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((k_find<kModelO1Dn, true>), grid, block, 0, s, p);
+  } else {             // per-lane traversal, 64-deep LDS stack
+    const size_t lds = 64u * 256u * sizeof(uint32_t);
+    if (kind == kModelSpherical) hipLaunchKernelGGL((k_find<kModelSpherical, false>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((k_find<kModelO1Dn, false>), grid, block, lds, s, p);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_compose_poses(const xform* Tbm_dev, xform Tsb, xform* Tsm_out, xform* Tms_out, uint32_t n,
+                                hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_compose_poses, dim3((n + 255u) / 256u), dim3(256), 0, s, Tbm_dev, Tsb, Tsm_out, Tms_out, n);
+  return hipGetLastError();
+}
+
+uint32_t reduce_num_blocks(uint32_t n) {
+  // two elements per thread keeps >= 256 workgroups in flight for a 128x1024 scan
+  uint32_t nb = (n + 511u) / 512u;
+  if (nb < 1u) nb = 1u;
+  if (nb > 1024u) nb = 1024u;
+  return nb;
+}
+
+hipError_t launch_reduce_partials(const ReduceParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_partials, dim3(p.nblocks, p.nposes), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce_finalize(const double* partials, uint32_t nblocks, uint32_t nposes, cstats* out,
+                                  hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_finalize, dim3(nposes), dim3(64), 0, s, partials, nblocks, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_micp_init(MicpState* state, hipStream_t s) {
+  hipLaunchKernelGGL(k_micp_init, dim3(1), dim3(64), 0, s, state);
+  return hipGetLastError();
+}
+
+hipError_t launch_micp_step(const double* partials, uint32_t nblocks, xform Tsb, xform Tbo, MicpState* state,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(k_micp_step, dim3(1), dim3(64), 0, s, partials, nblocks, Tsb, Tbo, state);
+  return hipGetLastError();
+}
+
+hipError_t launch_batch_solve(const double* partials, uint32_t nblocks, uint32_t nposes, xform Tsb,
+                              xform* Tdelta_out, cstats* stats_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_batch_solve, dim3(nposes), dim3(64), 0, s, partials, nblocks, Tsb, Tdelta_out, stats_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_dataset_from_ranges(const float* ranges, const float* model_tab, uint32_t kind, uint32_t W,
+                                      uint32_t H, f3 orig, float rmin, float rmax, float* points, uint8_t* mask,
+                                      uint32_t* n_valid, hipStream_t s) {
+  const uint32_t n = W * H;
+  hipLaunchKernelGGL(k_dataset_from_ranges, dim3((n + 255u) / 256u), dim3(256), 0, s, ranges, model_tab, kind, W, H,
+                     orig, rmin, rmax, points, mask, n_valid);
+  return hipGetLastError();
+}
+
+hipError_t launch_pf_update(const PfParams& p, int variant, hipStream_t s) {
+  const uint32_t nblocks = (p.n_particles + p.particles_per_block - 1u) / p.particles_per_block;
+  const size_t tail = sizeof(xform) * p.particles_per_block +
+                      sizeof(float) * static_cast<size_t>(p.particles_per_block) * p.n_beams;
+  if (variant == 1) {
+    const size_t lds = 64u * 256u * sizeof(uint32_t) + tail;
+    hipLaunchKernelGGL((k_pf_update<64>), dim3(nblocks), dim3(256), lds, s, p);
+  } else {
+    const size_t lds = 32u * 256u * sizeof(uint32_t) + tail;
+    hipLaunchKernelGGL((k_pf_update<32>), dim3(nblocks), dim3(256), lds, s, p);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_pf_extract_weights(const void* attrs, uint32_t n, float* weights, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_pf_extract_weights, dim3((n + 255u) / 256u), dim3(256), 0, s,
+                     reinterpret_cast<const pattrs*>(attrs), n, weights);
+  return hipGetLastError();
+}
+
+}  // namespace rmclhip

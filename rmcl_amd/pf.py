@@ -1,0 +1,125 @@
+"""Particle-filter sensor update, mirror of rmcl::SensorUpdater<MemT> over the C ABI.
+
+Reference: SensorUpdaterBase{init,reset} + ParticleUpdater<MemT>::update(poses, attrs, cfg)
+(rmcl_ros/include/rmcl_ros/rmcl/SensorUpdater.hpp:18-42, ParticleUpdater.hpp:24-44), implemented by
+PCDSensorUpdaterEmbree / PCDSensorUpdaterOptix (rmcl_ros/src/rmcl/PCDSensorUpdater*.cpp).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from .registration import _as_ptr
+from .types import RANGE_MEASUREMENT, TRANSFORM, _ptr, pf_params
+
+
+def beams_from_points(points):
+    """PCDSensorUpdaterEmbree.cpp:313-327: meas_s = {orig 0, dir = p/|p|, range = |p|, cov = 0.1 I}."""
+    p = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros(len(p), dtype=RANGE_MEASUREMENT)
+    # rmagine Vector3::l2norm / normalize in float32
+    nrm = np.sqrt((p[:, 0] * p[:, 0] + p[:, 1] * p[:, 1]) + p[:, 2] * p[:, 2]).astype(np.float32)
+    out["dir"]["x"], out["dir"]["y"], out["dir"]["z"] = p[:, 0] / nrm, p[:, 1] / nrm, p[:, 2] / nrm
+    out["range"] = nrm
+    out["cov"][:, 0] = out["cov"][:, 4] = out["cov"][:, 8] = np.float32(0.1)
+    return out
+
+
+def sample_beams(cloud_xyz, samples, seed):
+    """Beam sampling of PCDSensorUpdaterEmbree.cpp:290-311 with an explicit seed:
+    uniform random indices, up to 100 retries for a finite point."""
+    pts = np.ascontiguousarray(cloud_xyz, dtype=np.float32).reshape(-1, 3)
+    rng = np.random.RandomState(seed)
+    chosen = []
+    for _ in range(samples):
+        for _try in range(100):
+            i = rng.randint(0, len(pts))
+            if np.all(np.isfinite(pts[i])):
+                chosen.append(i)
+                break
+        else:
+            break  # "Point invalid": the reference returns early
+    return beams_from_points(pts[chosen])
+
+
+class PCDSensorUpdaterHip:
+    """rmcl::PCDSensorUpdaterOptix on gfx950: update() mutates attrs in place on the device."""
+
+    def __init__(self, hip_map):
+        if hip_map is None:
+            raise RuntimeError("NO MAP")  # PCDSensorUpdaterOptix.cpp:179-182
+        self.map = hip_map
+        self.ctx = hip_map.ctx
+        self.config = pf_params()
+        self._h = C.c_void_p()
+        self._beams = None
+        self._Tsb = None
+
+    def init(self):
+        """SensorUpdaterBase::init (PCDSensorUpdaterEmbree.cpp:107-114)."""
+        if not self._h:
+            _capi.check(_capi.lib().rmclhip_pf_create(self.ctx.handle, self.map.handle, C.byref(self._h)))
+        self._push_params()
+
+    def reset(self):
+        """SensorUpdaterBase::reset (PCDSensorUpdaterEmbree.cpp:116-119): nothing to reset."""
+
+    def setInput(self, beams, Tsb):
+        """Input<>::setInput analogue: the sampled measurements (sensor frame) and the sensor->base TF."""
+        self._beams = np.ascontiguousarray(beams, dtype=RANGE_MEASUREMENT).reshape(-1)
+        self._Tsb = np.ascontiguousarray(Tsb, dtype=TRANSFORM).reshape(1)
+
+    def update(self, particle_poses, particle_attrs, n_particles=None, sync=True):
+        """ParticleUpdater::update(poses, attrs): device views of n Transform / ParticleAttributes."""
+        if not self._h:
+            self.init()
+        if self._beams is None:
+            raise RuntimeError("setInput() first")
+        if n_particles is None:
+            n_particles = particle_poses.count if hasattr(particle_poses, "count") else particle_poses.shape[0]
+        self._push_params()
+        fn = _capi.lib().rmclhip_pf_update if sync else _capi.lib().rmclhip_pf_update_async
+        _capi.check(fn(self._h, _as_ptr(particle_poses), _as_ptr(particle_attrs), int(n_particles),
+                       _ptr(self._beams), len(self._beams), _ptr(self._Tsb)))
+        return {}
+
+    def sync(self):
+        _capi.check(_capi.lib().rmclhip_pf_sync(self._h))
+
+    def set_error_output(self, errors_dev):
+        if not self._h:
+            self.init()
+        _capi.check(_capi.lib().rmclhip_pf_set_error_output(self._h, _as_ptr(errors_dev)))
+
+    def extract_weights(self, particle_attrs, n_particles, weights_dev):
+        _capi.check(_capi.lib().rmclhip_pf_extract_weights(self._h, _as_ptr(particle_attrs), int(n_particles),
+                                                           _as_ptr(weights_dev)))
+
+    def time_update(self, particle_poses, particle_attrs, n_particles, iters=5):
+        if not self._h:
+            self.init()
+        self._push_params()
+        ms = C.c_float(0)
+        _capi.check(_capi.lib().rmclhip_pf_time_update(self._h, _as_ptr(particle_poses), _as_ptr(particle_attrs),
+                                                       int(n_particles), _ptr(self._beams), len(self._beams),
+                                                       _ptr(self._Tsb), int(iters), C.byref(ms)))
+        return ms.value
+
+    def set_variant(self, v):
+        if not self._h:
+            self.init()
+        _capi.check(_capi.lib().rmclhip_pf_set_variant(self._h, int(v)))
+
+    def _push_params(self):
+        _capi.check(_capi.lib().rmclhip_pf_set_params(self._h, C.byref(self.config)))
+
+    def close(self):
+        if self._h:
+            _capi.lib().rmclhip_pf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

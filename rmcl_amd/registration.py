@@ -1,0 +1,321 @@
+"""Host-side mirror of the reference's correspondence-operator interface, over the C ABI.
+
+Reference classes mirrored (names, argument meaning and error behaviour kept):
+  rmcl::Correspondences_<MemT>            rmcl/include/rmcl/registration/Correspondences.hpp:16-88
+  rmcl::CorrespondencesCUDA               rmcl/include/rmcl/registration/CorrespondencesCUDA.hpp:10-17
+  rmcl::RCCOptixSpherical / RCCEmbreeO1Dn rmcl/include/rmcl/registration/RCCOptix.hpp:18-93, RCCEmbree.hpp:18-83
+  rm::import_*_map + rm::MapMap           rmcl_ros/src/rmcl/PCDSensorUpdaterEmbree.cpp:143-174
+
+Everything here is plumbing: arithmetic happens in librmclhip.so (HIP kernels); a missing
+library or device raises instead of falling back.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from .types import CROSS_STATISTICS, TRANSFORM, _ptr
+
+
+def _as_ptr(x):
+    """device pointer from an int, a torch tensor or a DeviceArray"""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    if hasattr(x, "ptr"):
+        return C.c_void_p(x.ptr)
+    raise TypeError("expected a device pointer, torch tensor or DeviceArray")
+
+
+class Context:
+    """One HIP device (rmclhip_ctx)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _capi.check(_capi.lib().rmclhip_ctx_create(int(device), C.byref(self._h)))
+        self.device = int(device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        _capi.check(_capi.lib().rmclhip_ctx_device_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    def close(self):
+        if self._h:
+            _capi.lib().rmclhip_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class DeviceArray:
+    """Minimal owning device buffer for hosts without torch (rmagine::Memory<T, VRAM_HIP> analogue)."""
+
+    def __init__(self, ctx, dtype, count):
+        self.ctx, self.dtype, self.count = ctx, np.dtype(dtype), int(count)
+        p = C.c_void_p()
+        _capi.check(_capi.lib().rmclhip_malloc(ctx.handle, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    @property
+    def nbytes(self):
+        return self.dtype.itemsize * self.count
+
+    @classmethod
+    def from_host(cls, ctx, arr):
+        arr = np.ascontiguousarray(arr)
+        d = cls(ctx, arr.dtype, arr.size)
+        d.upload(arr)
+        return d
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert arr.size == self.count
+        _capi.check(_capi.lib().rmclhip_memcpy_h2d(self.ctx.handle, C.c_void_p(self.ptr), _ptr(arr), self.nbytes))
+
+    def download(self):
+        out = np.zeros(self.count, dtype=self.dtype)
+        _capi.check(_capi.lib().rmclhip_memcpy_d2h(self.ctx.handle, _ptr(out), C.c_void_p(self.ptr), self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            _capi.lib().rmclhip_free(self.ctx.handle, C.c_void_p(self.ptr))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class HipMap:
+    """Immutable triangle mesh + BVH on the device (rm::EmbreeMap / rm::OptixMap analogue)."""
+
+    def __init__(self, ctx, vertices, faces):
+        self.ctx = ctx
+        v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+        f = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
+        self._h = C.c_void_p()
+        _capi.check(_capi.lib().rmclhip_map_create(ctx.handle, _ptr(v), len(v), _ptr(f), len(f), C.byref(self._h)))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self):
+        mi = _capi.MapInfo()
+        _capi.check(_capi.lib().rmclhip_map_get_info(self._h, C.byref(mi)))
+        return {k: (list(getattr(mi, k)) if k.startswith("bbox") else getattr(mi, k)) for k, _ in mi._fields_}
+
+    def release(self):
+        if self._h:
+            _capi.lib().rmclhip_map_release(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def import_hip_map(ctx, vertices, faces):
+    """rm::import_embree_map analogue for in-memory meshes (micp_localization.cpp:187-195)."""
+    return HipMap(ctx, vertices, faces)
+
+
+class MapMap(dict):
+    """rm::MapMap: registry keyed '<name>.hip' (PCDSensorUpdaterEmbree.cpp:143-174)."""
+
+
+def build_bvh_host(vertices, faces):
+    """Host-only BVH build (no device): returns (info dict, nodes[n,32] u32, tris[nf,16] u32)."""
+    v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+    f = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
+    mi = _capi.MapInfo()
+    L = _capi.lib()
+    _capi.check(L.rmclhip_bvh_build_host(_ptr(v), len(v), _ptr(f), len(f), C.byref(mi), None, 0, None, 0))
+    nodes = np.zeros((mi.n_nodes, 32), dtype=np.uint32)
+    tris = np.zeros((mi.n_tri_records, 16), dtype=np.uint32)
+    _capi.check(L.rmclhip_bvh_build_host(_ptr(v), len(v), _ptr(f), len(f), C.byref(mi), _ptr(nodes), nodes.size,
+                                         _ptr(tris), tris.size))
+    info = {k: (list(getattr(mi, k)) if k.startswith("bbox") else getattr(mi, k)) for k, _ in mi._fields_}
+    return info, nodes, tris
+
+
+class UmeyamaReductionConstraints:
+    """rmagine::UmeyamaReductionConstraints (only max_dist is used, micp_localization.cpp:525-526)."""
+
+    def __init__(self, max_dist=1.0):
+        self.max_dist = float(max_dist)
+
+
+class CorrespondencesHIP:
+    """rmcl::Correspondences_<VRAM_HIP> + CorrespondencesCUDA::computeCrossStatistics.
+
+    Public attributes as in Correspondences.hpp:19-29: params, adaptive_max_dist_min, outdated;
+    the dataset is handed over with set_dataset()/set_dataset_from_ranges().
+    """
+
+    def __init__(self, hip_map):
+        if hip_map is None:
+            raise RuntimeError("NO MAP")  # PCDSensorUpdaterOptix.cpp:179-182 error convention
+        self.map = hip_map
+        self.ctx = hip_map.ctx
+        self.params = UmeyamaReductionConstraints(1.0)
+        self.adaptive_max_dist_min = 1.0
+        self.outdated = True
+        self._h = C.c_void_p()
+        _capi.check(_capi.lib().rmclhip_rcc_create(self.ctx.handle, hip_map.handle, C.byref(self._h)))
+        self._model_shape = (0, 0)
+        self._last_nposes = 1
+
+    # -- Correspondences_ interface --------------------------------------------------------
+    def setTsb(self, Tsb):
+        T = np.ascontiguousarray(Tsb, dtype=TRANSFORM).reshape(1)
+        _capi.check(_capi.lib().rmclhip_rcc_set_tsb(self._h, _ptr(T)))
+
+    def find(self, Tbm_est):
+        """RCC*::find (RCCEmbree.cpp:26-36): fills the model buffers; returns None."""
+        T = np.ascontiguousarray(Tbm_est, dtype=TRANSFORM).reshape(1)
+        _capi.check(_capi.lib().rmclhip_rcc_find(self._h, _ptr(T)))
+        self._last_nposes = 1
+
+    def computeCrossStatistics(self, T_snew_sold, convergence_progress=0.0):
+        """CorrespondencesCPU.cpp:10-39; returns CrossStatistics by value on the host."""
+        self._push_params()
+        T = np.ascontiguousarray(T_snew_sold, dtype=TRANSFORM).reshape(1)
+        out = np.zeros(1, dtype=CROSS_STATISTICS)
+        _capi.check(_capi.lib().rmclhip_rcc_compute_cross_statistics(self._h, _ptr(T), float(convergence_progress),
+                                                                     _ptr(out)))
+        return out[0].copy()
+
+    def modelView(self):
+        """host copy of {points, mask(hits), normals} (+ ranges, face_ids) of the last find"""
+        H, W = self._model_shape
+        n = H * W * self._last_nposes
+        out = dict(hits=np.zeros(n, np.uint8), ranges=np.zeros(n, np.float32), points=np.zeros((n, 3), np.float32),
+                   normals=np.zeros((n, 3), np.float32), face_ids=np.zeros(n, np.uint32))
+        if n:
+            _capi.check(_capi.lib().rmclhip_rcc_download(self._h, _ptr(out["hits"]), _ptr(out["ranges"]),
+                                                         _ptr(out["points"]), _ptr(out["normals"]),
+                                                         _ptr(out["face_ids"])))
+        out["mask"] = out["hits"]
+        return out
+
+    # -- dataset ------------------------------------------------------------------------------
+    def set_dataset(self, points, mask=None, device=False):
+        """dataset {points, mask} (MICPSphericalSensorCPU.cpp:181-233 fills these)."""
+        if device:
+            n = int(points.numel() // 3) if hasattr(points, "numel") else points.count // 3
+            _capi.check(_capi.lib().rmclhip_rcc_set_dataset(self._h, _as_ptr(points), _as_ptr(mask), n, 1))
+        else:
+            p = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+            m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).reshape(-1)
+            _capi.check(_capi.lib().rmclhip_rcc_set_dataset(self._h, _ptr(p), _ptr(m), len(p), 0))
+        self.outdated = True
+
+    def set_dataset_from_ranges(self, ranges):
+        """unpackMessage mirror: points = dir*range (+orig), mask = range within model.range"""
+        r = np.ascontiguousarray(ranges, dtype=np.float32).reshape(-1)
+        nv = C.c_uint32(0)
+        _capi.check(_capi.lib().rmclhip_rcc_set_dataset_from_ranges(self._h, _ptr(r), len(r), C.byref(nv)))
+        self.outdated = True
+        return nv.value
+
+    # -- extras (fast paths) --------------------------------------------------------------------
+    def correct_once(self, Tom, Tbo, n_iter, convergence_progress=0.0, refind_each_iteration=False):
+        """MICP-L inner loop for this one sensor on the device (micp_localization.cpp:900-964)."""
+        self._push_params()
+        a = np.ascontiguousarray(Tom, dtype=TRANSFORM).reshape(1)
+        b = np.ascontiguousarray(Tbo, dtype=TRANSFORM).reshape(1)
+        T = np.zeros(1, dtype=TRANSFORM)
+        s = np.zeros(1, dtype=CROSS_STATISTICS)
+        _capi.check(_capi.lib().rmclhip_rcc_correct_once(self._h, _ptr(a), _ptr(b), int(n_iter),
+                                                         float(convergence_progress), int(bool(refind_each_iteration)),
+                                                         _ptr(T), _ptr(s)))
+        self._last_nposes = 1
+        return T[0].copy(), s[0].copy()
+
+    def correct_batch(self, Tbm):
+        """v1 SphereCorrector::correct (lidar_corrector_embree_benchmark.cpp:127-135): Tdelta per pose."""
+        self._push_params()
+        T = np.ascontiguousarray(Tbm, dtype=TRANSFORM).reshape(-1)
+        out = np.zeros(len(T), dtype=TRANSFORM)
+        st = np.zeros(len(T), dtype=CROSS_STATISTICS)
+        _capi.check(_capi.lib().rmclhip_rcc_correct_batch(self._h, _ptr(T), len(T), _ptr(out), _ptr(st)))
+        self._last_nposes = len(T)
+        return out, st
+
+    def time_find(self, Tbm_est, iters=20):
+        T = np.ascontiguousarray(Tbm_est, dtype=TRANSFORM).reshape(1)
+        ms = C.c_float(0)
+        _capi.check(_capi.lib().rmclhip_rcc_time_find(self._h, _ptr(T), int(iters), C.byref(ms)))
+        self._last_nposes = 1
+        return ms.value
+
+    def time_reduce(self, T_snew_sold, iters=20):
+        self._push_params()
+        T = np.ascontiguousarray(T_snew_sold, dtype=TRANSFORM).reshape(1)
+        ms = C.c_float(0)
+        _capi.check(_capi.lib().rmclhip_rcc_time_reduce(self._h, _ptr(T), int(iters), C.byref(ms)))
+        return ms.value
+
+    def find_async(self, Tbm_est):
+        T = np.ascontiguousarray(Tbm_est, dtype=TRANSFORM).reshape(1)
+        _capi.check(_capi.lib().rmclhip_rcc_find_async(self._h, _ptr(T)))
+        self._last_nposes = 1
+
+    def sync(self):
+        _capi.check(_capi.lib().rmclhip_rcc_sync(self._h))
+
+    def last_kernel_ms(self):
+        a, b = C.c_float(0), C.c_float(0)
+        _capi.check(_capi.lib().rmclhip_rcc_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def set_variant(self, variant):
+        _capi.check(_capi.lib().rmclhip_rcc_set_variant(self._h, int(variant)))
+
+    def _push_params(self):
+        _capi.check(_capi.lib().rmclhip_rcc_set_params(self._h, float(self.params.max_dist),
+                                                       float(self.adaptive_max_dist_min)))
+
+    def close(self):
+        if self._h:
+            _capi.lib().rmclhip_rcc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RCCHipSpherical(CorrespondencesHIP):
+    """rmcl::RCCOptixSpherical / RCCEmbreeSpherical on gfx950 (RCCEmbree.cpp:8-36)."""
+
+    def setModel(self, sensor_model):
+        _capi.check(_capi.lib().rmclhip_rcc_set_model_spherical(self._h, C.byref(sensor_model)))
+        self._model_shape = (int(sensor_model.phi.size), int(sensor_model.theta.size))
+
+
+class RCCHipO1Dn(CorrespondencesHIP):
+    """rmcl::RCCEmbreeO1Dn / RCCOptixO1Dn on gfx950 (RCCEmbree.cpp:71-99)."""
+
+    def setModel(self, width, height, range_min, range_max, orig, dirs):
+        d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        if len(d) != width * height:
+            raise ValueError("dirs must hold width*height directions")
+        rng = _capi.Interval(range_min, range_max)
+        o = _capi.Vec3(*[float(x) for x in orig])
+        _capi.check(_capi.lib().rmclhip_rcc_set_model_o1dn(self._h, int(width), int(height), rng, o, _ptr(d)))
+        self._model_shape = (int(height), int(width))

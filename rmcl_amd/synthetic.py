@@ -1,0 +1,197 @@
+"""Procedural, seeded inputs for tests and bench.py: meshes, sensor models, poses,
+particle clouds.  Pure input generation -- no hot-path arithmetic lives here.
+"""
+import math
+
+import numpy as np
+
+from .types import PARTICLE_ATTRIBUTES, TRANSFORM, euler_to_quat, spherical_model, transform_from_rpy
+
+
+def find_abc(C):
+    """Factorisation rule of the reference's benchmark (lidar_corrector_embree_benchmark.cpp:17-36)."""
+    A = int(math.sqrt(C))
+    B = A
+    res = A * B
+    while res != C and B > 0 and A <= C:
+        if res > C:
+            B -= 1
+        else:
+            A += 1
+        res = A * B
+    if not (B > 0 and A <= C and res == C):
+        raise ValueError("could not factorise %d" % C)
+    return A, B
+
+
+def uv_sphere(n_faces, radius=10.0):
+    """UV sphere with exactly n_faces triangles (A x B quads, 2 triangles each; the two triangle fans at
+    the poles contain zero-area triangles, which never intersect).  Normals point outward."""
+    if n_faces % 2:
+        raise ValueError("n_faces must be even")
+    A, B = find_abc(n_faces // 2)  # A columns (longitude), B rows (latitude)
+    lon = (np.arange(A + 1, dtype=np.float64) / A) * 2.0 * np.pi
+    lat = (np.arange(B + 1, dtype=np.float64) / B) * np.pi - np.pi / 2
+    LON, LAT = np.meshgrid(lon, lat)  # (B+1, A+1)
+    v = np.stack([radius * np.cos(LAT) * np.cos(LON), radius * np.cos(LAT) * np.sin(LON), radius * np.sin(LAT)], -1)
+    verts = v.reshape(-1, 3).astype(np.float32)
+    j, i = np.meshgrid(np.arange(B), np.arange(A), indexing="ij")
+    p00 = (j * (A + 1) + i).ravel()
+    p01 = p00 + 1
+    p10 = p00 + (A + 1)
+    p11 = p10 + 1
+    faces = np.empty((2 * A * B, 3), dtype=np.uint32)
+    faces[0::2] = np.stack([p00, p01, p11], -1)
+    faces[1::2] = np.stack([p00, p11, p10], -1)
+    return verts, faces
+
+
+def cube_room(side=10.0, grid=9):
+    """Axis-aligned cube room centred at the origin, each wall a grid x grid quad mesh:
+    6 * grid^2 * 2 triangles (972 for grid=9), normals inward."""
+    h = side / 2.0
+    lin = np.linspace(-h, h, grid + 1)
+    verts, faces = [], []
+    for axis in range(3):
+        for sign in (-1.0, 1.0):
+            base = len(verts)
+            u_ax, v_ax = [(1, 2), (2, 0), (0, 1)][axis]
+            for b in lin:
+                for a in lin:
+                    p = [0.0, 0.0, 0.0]
+                    p[axis] = sign * h
+                    p[u_ax] = a
+                    p[v_ax] = b
+                    verts.append(p)
+            for jj in range(grid):
+                for ii in range(grid):
+                    p00 = base + jj * (grid + 1) + ii
+                    p01, p10, p11 = p00 + 1, p00 + grid + 1, p00 + grid + 2
+                    if sign > 0:  # inward normal = -axis
+                        faces.append([p00, p11, p01])
+                        faces.append([p00, p10, p11])
+                    else:
+                        faces.append([p00, p01, p11])
+                        faces.append([p00, p11, p10])
+    return np.asarray(verts, dtype=np.float32), np.asarray(faces, dtype=np.uint32)
+
+
+def noisy_room(n_faces_target=100000, side=20.0, height=6.0, noise=0.02, seed=1234, boxes=6):
+    """Room with interior boxes and seeded vertex noise: a less symmetric mesh than the sphere, with
+    occlusion and rays that miss (open ceiling).  Returns about n_faces_target triangles."""
+    rng = np.random.RandomState(seed)
+    quads = []  # (origin, u, v) rectangles
+    hx, hz = side / 2.0, height
+    quads.append((np.array([-hx, -hx, 0.0]), np.array([side, 0, 0.0]), np.array([0, side, 0.0])))  # floor
+    quads.append((np.array([-hx, -hx, 0.0]), np.array([side, 0, 0.0]), np.array([0, 0, hz])))
+    quads.append((np.array([-hx, hx, 0.0]), np.array([side, 0, 0.0]), np.array([0, 0, hz])))
+    quads.append((np.array([-hx, -hx, 0.0]), np.array([0, side, 0.0]), np.array([0, 0, hz])))
+    quads.append((np.array([hx, -hx, 0.0]), np.array([0, side, 0.0]), np.array([0, 0, hz])))
+    for _ in range(boxes):
+        c = rng.uniform(-hx * 0.8, hx * 0.8, size=2)
+        s = rng.uniform(0.5, 2.0, size=3)
+        o = np.array([c[0] - s[0] / 2, c[1] - s[1] / 2, 0.0])
+        ex, ey, ez = np.array([s[0], 0, 0.0]), np.array([0, s[1], 0.0]), np.array([0, 0, s[2]])
+        quads += [(o, ex, ez), (o + ey, ex, ez), (o, ey, ez), (o + ex, ey, ez), (o + ez, ex, ey)]
+    area = np.array([np.linalg.norm(np.cross(u, v)) for _, u, v in quads])
+    per_area = n_faces_target / 2.0 / area.sum()
+    verts, faces = [], []
+    for (o, u, v), a in zip(quads, area):
+        lu, lv = np.linalg.norm(u), np.linalg.norm(v)
+        nu = max(1, int(round(math.sqrt(a * per_area) * math.sqrt(lu / lv))))
+        nv = max(1, int(round(a * per_area / nu)))
+        base = len(verts)
+        for jj in range(nv + 1):
+            for ii in range(nu + 1):
+                verts.append(o + u * (ii / nu) + v * (jj / nv))
+        for jj in range(nv):
+            for ii in range(nu):
+                p00 = base + jj * (nu + 1) + ii
+                p01, p10, p11 = p00 + 1, p00 + nu + 1, p00 + nu + 2
+                faces.append([p00, p01, p11])
+                faces.append([p00, p11, p10])
+    verts = np.asarray(verts, dtype=np.float64)
+    verts += rng.uniform(-noise, noise, size=verts.shape)
+    return verts.astype(np.float32), np.asarray(faces, dtype=np.uint32)
+
+
+# ---- sensor models -----------------------------------------------------------
+def model_c1():
+    """32x32, phi in [-45,45] deg, theta full circle, range [0.1, 100]."""
+    f = np.float32
+    return spherical_model(f(-math.pi / 4), f((math.pi / 2) / 31), 32, f(-math.pi), f(2 * math.pi / 32), 32, f(0.1), f(100.0))
+
+
+def model_c2():
+    """128x1024, phi in [-22.5,22.5] deg, theta full circle, range [0.3, 120]."""
+    f = np.float32
+    return spherical_model(f(-math.pi / 8), f((math.pi / 4) / 127), 128, f(-math.pi), f(2 * math.pi / 1024), 1024,
+                           f(0.3), f(120.0))
+
+
+def model_vlp16_900(range_min=0.0):
+    """rmagine vlp16_900(): 16x900, phi in [-15,15] deg (lidar_corrector_embree_benchmark.cpp:91-93 sets range.min=0)."""
+    f = np.float32
+    return spherical_model(f(-15.0 * math.pi / 180), f((30.0 * math.pi / 180) / 15), 16, f(-math.pi), f(2 * math.pi / 900),
+                           900, f(range_min), f(130.0))
+
+
+def model_pf16(range_min=0.05, range_max=80.0):
+    """16x16 particle-filter sensor: phi in [-15,15] deg, theta full circle."""
+    f = np.float32
+    return spherical_model(f(-15.0 * math.pi / 180), f((30.0 * math.pi / 180) / 15), 16, f(-math.pi), f(2 * math.pi / 16),
+                           16, f(range_min), f(range_max))
+
+
+def model_directions(model):
+    """(H*W, 3) float32 directions of a spherical model in buffer order (vid*W + hid); used to turn a
+    spherical scan into an O1Dn model / PF beams.  float32 trig of float32 angles, like the kernels' tables."""
+    H, W = model.phi.size, model.theta.size
+    phi = (np.float32(model.phi.min) + np.arange(H, dtype=np.float32) * np.float32(model.phi.inc)).astype(np.float32)
+    th = (np.float32(model.theta.min) + np.arange(W, dtype=np.float32) * np.float32(model.theta.inc)).astype(np.float32)
+    cp, sp = np.cos(phi).astype(np.float32), np.sin(phi).astype(np.float32)
+    ct, st = np.cos(th).astype(np.float32), np.sin(th).astype(np.float32)
+    d = np.empty((H, W, 3), dtype=np.float32)
+    d[..., 0] = cp[:, None] * ct[None, :]
+    d[..., 1] = cp[:, None] * st[None, :]
+    d[..., 2] = sp[:, None] * np.ones((1, W), np.float32)
+    return d.reshape(-1, 3)
+
+
+# ---- poses -----------------------------------------------------------------------------------------
+def pose_c2_truth():
+    s = math.sqrt(2.0)
+    return transform_from_rpy((0.37 * s, -0.21 * s, 0.13 * s), (0.02, -0.03, 0.4))
+
+
+def pose_c2_perturbation():
+    return transform_from_rpy((0.2, 0.1, 0.05), (0.0, 0.0, 2.0 * math.pi / 180))
+
+
+def tsb_offset():
+    """the one non-identity Tsb of SURVEY.md 8(d): t=(0.1,0,0.3), yaw 10 deg"""
+    return transform_from_rpy((0.1, 0.0, 0.3), (0.0, 0.0, 10.0 * math.pi / 180))
+
+
+def uniform_particles(n, seed=42, bb_min=(-8, -8, -1, 0, 0, -math.pi), bb_max=(8, 8, 1, 0, 0, math.pi)):
+    """RmclNode::initSamplesUniform (rmcl_localization.cpp:277-342): uniform poses in a 6-D box,
+    attrs = Gaussian1D::Identity() with mean 1."""
+    rng = np.random.RandomState(seed)
+    lo, hi = np.asarray(bb_min, dtype=np.float64), np.asarray(bb_max, dtype=np.float64)
+    u = rng.uniform(size=(n, 6)) * (hi - lo) + lo
+    poses = np.zeros(n, dtype=TRANSFORM)
+    cr, sr = np.cos(u[:, 3] / 2), np.sin(u[:, 3] / 2)
+    cp, sp = np.cos(u[:, 4] / 2), np.sin(u[:, 4] / 2)
+    cy, sy = np.cos(u[:, 5] / 2), np.sin(u[:, 5] / 2)
+    poses["R"]["x"] = sr * cp * cy - cr * sp * sy
+    poses["R"]["y"] = cr * sp * cy + sr * cp * sy
+    poses["R"]["z"] = cr * cp * sy - sr * sp * cy
+    poses["R"]["w"] = cr * cp * cy + sr * sp * sy
+    poses["t"]["x"], poses["t"]["y"], poses["t"]["z"] = u[:, 0], u[:, 1], u[:, 2]
+    attrs = np.zeros(n, dtype=PARTICLE_ATTRIBUTES)
+    attrs["likelihood"]["mean"] = 1.0
+    return poses, attrs
+
+
+__all__ = [n for n in dir() if not n.startswith("_")]
+_ = euler_to_quat  # re-exported for callers

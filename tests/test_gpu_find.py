@@ -1,0 +1,221 @@
+"""GPU parity: RCC*::find (ray-casting correspondences) through the C ABI vs the CPU oracle.
+
+Reads like the reference's call pattern: setTsb, setModel, find(Tbm_est), modelView()
+(rmcl/src/rmcl/registration/RCCEmbree.cpp:8-36).  Bar: hits / face ids bit-exact; ranges, points,
+normals within 1e-5 relative (BASELINE.json north_star).
+"""
+import hashlib
+import json
+import math
+
+import numpy as np
+import pytest
+
+from conftest import assert_close_rel, golden_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(gpu, ref, what):
+    assert np.array_equal(gpu["hits"], ref["hits"]), what + ": hits differ"
+    bad = gpu["face_ids"] != ref["face_ids"]
+    assert not bad.any(), "%s: %d of %d face ids differ" % (what, bad.sum(), bad.size)
+    assert_close_rel(gpu["ranges"], ref["ranges"], 1e-5, 0, what + " ranges")
+    assert_close_rel(gpu["points"], ref["points"], 1e-5, 1e-6, what + " points")
+    assert_close_rel(gpu["normals"], ref["normals"], 1e-5, 1e-6, what + " normals")
+
+
+def _poses(syn, T):
+    return [
+        syn.pose_c2_truth(),
+        T.transform_from_rpy((-2.1, 1.3, -0.7), (0.3, -0.2, 2.5)),
+        T.transform_from_rpy((3.9, -3.3, 2.2), (-0.1, 0.25, -1.2)),
+    ]
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_c1_cube_32x32(ra, orc, ctx, meshes, variant):
+    """config C1: 32x32 scan, 972-triangle cube, every output attribute, 3 poses, Tsb != I."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("cube")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    model = syn.model_c1()
+    for Tsb in (T.identity(), syn.tsb_offset()):
+        rcc = ra.RCCHipSpherical(hm)
+        rcc.set_variant(variant)
+        rcc.setTsb(Tsb)
+        rcc.setModel(model)
+        for i, Tbm in enumerate(_poses(syn, T)):
+            rcc.find(Tbm)
+            gpu = rcc.modelView()
+            ref = m.simulate_spherical(model, Tsb, Tbm, bvh=False)
+            _compare(gpu, ref, "cube pose %d" % i)
+            assert gpu["hits"].all()
+        rcc.close()
+
+
+def test_c1_matches_committed_golden(ra, ctx, meshes):
+    """GPU vs the committed fixture (tests/golden/g2_cube_32x32.npz, made by tests/golden/make_golden.py)."""
+    from rmcl_amd import synthetic as syn, types as T
+    g = np.load(golden_path("g2_cube_32x32.npz"))
+    v, f = meshes("cube")
+    hm = ra.import_hip_map(ctx, v, f)
+    rcc = ra.RCCHipSpherical(hm)
+    rcc.setTsb(g["Tsb"].view(T.TRANSFORM)[0])
+    rcc.setModel(syn.model_c1())
+    poses = g["Tbm"].view(T.TRANSFORM)
+    n = 32 * 32
+    for i in range(len(poses)):
+        rcc.find(poses[i])
+        gpu = rcc.modelView()
+        ref = {k: g[k][i * n:(i + 1) * n] for k in ("hits", "ranges", "points", "normals", "face_ids")}
+        _compare(gpu, ref, "golden pose %d" % i)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_c2_sphere100k_full_size(ra, orc, ctx, meshes, variant):
+    """config C2 at BASELINE.json's full size: 128x1024 rays, 100k triangles; oracle BVH on all rays,
+    brute force on a sample, and the committed SHA-256 of the face-id array (G7)."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("sphere100k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    model = syn.model_c2()
+    rcc = ra.RCCHipSpherical(hm)
+    rcc.set_variant(variant)
+    rcc.setTsb(T.identity())
+    rcc.setModel(model)
+    Tbm = syn.pose_c2_truth()
+    rcc.find(Tbm)
+    gpu = rcc.modelView()
+    ref = m.simulate_spherical(model, T.identity(), Tbm, bvh=True, nthreads=8)
+    _compare(gpu, ref, "C2")
+    assert gpu["hits"].all()
+    with open(golden_path("g7_digests.json")) as fh:
+        dig = json.load(fh)
+    assert hashlib.sha256(gpu["face_ids"].tobytes()).hexdigest() == dig["c2_sphere100k_face_ids_sha256"]
+    # size-independent property: every hit point lies on the radius-10 sphere seen from the sensor
+    Tsm = Tbm
+    t = np.array([Tsm["t"]["x"], Tsm["t"]["y"], Tsm["t"]["z"]], dtype=np.float64)
+    # |R p_s + t| == 10 up to faceting (chord sag of a 250x200 UV sphere < 1 cm at 10 m)
+    from scipy.spatial.transform import Rotation
+    R = Rotation.from_quat([Tsm["R"]["x"], Tsm["R"]["y"], Tsm["R"]["z"], Tsm["R"]["w"]]).as_matrix()
+    pm = gpu["points"].astype(np.float64) @ R.T + t
+    r = np.linalg.norm(pm, axis=1)
+    assert np.all(r <= 10.0 + 1e-4) and np.all(r >= 10.0 - 0.02)
+
+
+def test_ragged_and_tiny_models(ra, orc, ctx, meshes):
+    """edge cases: 1x1, 1x360 (2-D scanner), 7x33 (ragged tiles), empty model (find is a no-op,
+    RCCOptix.cpp:30-34)."""
+    from rmcl_amd import types as T
+    v, f = meshes("room30k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    Tbm = T.transform_from_rpy((0.5, -0.4, 1.2), (0.05, -0.02, 0.7))
+    Tsb = T.identity()
+    f32 = np.float32
+    for (H, W) in [(1, 1), (1, 360), (7, 33), (65, 9)]:
+        model = T.spherical_model(f32(-0.3), f32(0.6 / max(H - 1, 1)), H, f32(-math.pi), f32(2 * math.pi / W), W,
+                                  f32(0.1), f32(30.0))
+        rcc = ra.RCCHipSpherical(hm)
+        rcc.setTsb(Tsb)
+        rcc.setModel(model)
+        rcc.find(Tbm)
+        gpu = rcc.modelView()
+        ref = m.simulate_spherical(model, Tsb, Tbm, bvh=False)
+        _compare(gpu, ref, "ragged %dx%d" % (H, W))
+        rcc.close()
+    rcc = ra.RCCHipSpherical(hm)
+    rcc.setTsb(Tsb)
+    rcc.setModel(T.spherical_model(f32(0), f32(0), 0, f32(0), f32(0), 0, f32(0.1), f32(30.0)))
+    rcc.find(Tbm)  # must not raise
+    assert rcc.modelView()["hits"].size == 0
+
+
+def test_misses_and_range_limit(ra, orc, ctx, meshes):
+    """rays leaving through the open ceiling and hits beyond range.max are misses:
+    hits 0, range = range.max + 1, NaN point/normal, face id 0xFFFFFFFF."""
+    from rmcl_amd import types as T
+    v, f = meshes("room30k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    f32 = np.float32
+    model = T.spherical_model(f32(-0.6), f32(1.8 / 47), 48, f32(-math.pi), f32(2 * math.pi / 200), 200, f32(0.1), f32(6.0))
+    Tbm = T.transform_from_rpy((1.0, 2.0, 1.5), (0.0, 0.1, -0.3))
+    rcc = ra.RCCHipSpherical(hm)
+    rcc.setTsb(T.identity())
+    rcc.setModel(model)
+    rcc.find(Tbm)
+    gpu = rcc.modelView()
+    ref = m.simulate_spherical(model, T.identity(), Tbm, bvh=False)
+    _compare(gpu, ref, "misses")
+    miss = gpu["hits"] == 0
+    assert miss.any() and (~miss).any()
+    assert np.all(gpu["ranges"][miss] == f32(7.0))
+    assert np.all(gpu["face_ids"][miss] == 0xFFFFFFFF)
+    assert np.isnan(gpu["points"][miss]).all() and np.isnan(gpu["normals"][miss]).all()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_o1dn_model(ra, orc, ctx, meshes, variant):
+    """RCCEmbreeO1Dn::find (RCCEmbree.cpp:89-99): one origin, N explicit directions, with NaN
+    directions (invalid points of an organised cloud) which must come back as misses."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room30k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    base = syn.model_pf16()
+    W, H = 64, 24
+    rng = np.random.RandomState(5)
+    f32 = np.float32
+    sm = T.spherical_model(f32(-0.4), f32(0.9 / (H - 1)), H, f32(-math.pi), f32(2 * math.pi / W), W, f32(0.2), f32(40.0))
+    dirs = syn.model_directions(sm).copy()
+    dirs[rng.randint(0, len(dirs), 20)] = np.nan
+    orig = (0.05, -0.02, 0.11)
+    Tsb = syn.tsb_offset()
+    Tbm = T.transform_from_rpy((-1.0, 0.7, 1.1), (0.02, 0.03, 1.9))
+    rcc = ra.RCCHipO1Dn(hm)
+    rcc.set_variant(variant)
+    rcc.setTsb(Tsb)
+    rcc.setModel(W, H, 0.2, 40.0, orig, dirs)
+    rcc.find(Tbm)
+    gpu = rcc.modelView()
+    ref = m.simulate_o1dn(W, H, 0.2, 40.0, orig, dirs, Tsb, Tbm, bvh=False)
+    _compare(gpu, ref, "o1dn")
+    assert (gpu["hits"] == 0).sum() >= 20
+    _ = base
+
+
+def test_grow_only_buffers_and_refind(ra, orc, ctx, meshes):
+    """model buffers are grow-only (RCCEmbree.cpp:28-33): big model, then small, then big again."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("cube")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    rcc = ra.RCCHipSpherical(hm)
+    rcc.setTsb(T.identity())
+    Tbm = syn.pose_c2_truth()
+    for model in (syn.model_c1(), syn.model_pf16(), syn.model_c1()):
+        rcc.setModel(model)
+        rcc.find(Tbm)
+        _compare(rcc.modelView(), m.simulate_spherical(model, T.identity(), Tbm, bvh=False), "regrow")
+
+
+def test_far_from_origin_mesh(ra, orc, ctx):
+    """conservative slab test: a mesh 5 km from the origin (large absolute coordinates) must still
+    give brute-force-identical face ids."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = syn.uv_sphere(5000, radius=8.0)
+    off = np.array([5000.0, -3000.0, 120.0], dtype=np.float32)
+    v = (v + off).astype(np.float32)
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    rcc = ra.RCCHipSpherical(hm)
+    rcc.setTsb(T.identity())
+    model = syn.model_c1()
+    rcc.setModel(model)
+    Tbm = T.transform_from_rpy(tuple(off + np.array([0.4, -0.3, 0.2], dtype=np.float32)), (0.1, 0.2, 0.3))
+    rcc.find(Tbm)
+    _compare(rcc.modelView(), m.simulate_spherical(model, T.identity(), Tbm, bvh=False), "far mesh")
