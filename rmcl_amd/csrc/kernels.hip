@@ -101,8 +101,9 @@ __device__ __forceinline__ void trace_packet(cu32p nodes, cu32p tris, f3 O, f3 D
         float tn, tf;
         slab(asf(lo[0 + c]), asf(lo[4 + c]), asf(lo[8 + c]), asf(lo[12 + c]), asf(hi[0 + c]), asf(hi[4 + c]), inv, noi,
              best_t, tn, tf);
-        const uint64_t m = __ballot(tn <= tf);
         ref[c] = hi[8 + c];
+        // empty slots carry an inverted box, which a min/max slab test reads as infinite: mask them
+        const uint64_t m = (ref[c] != kEmptyRef) ? __ballot(tn <= tf) : 0ull;
         uint32_t k = kNone;
         if (m != 0) {
           const int first = __builtin_ctzll(m);
@@ -172,7 +173,7 @@ __device__ __forceinline__ void trace_lane(const uint32_t* __restrict__ nodes, c
       for (int c = 0; c < 4; ++c) {
         float tn, tf;
         slab(asf(amnx[c]), asf(amny[c]), asf(amnz[c]), asf(amxx[c]), asf(amxy[c]), asf(amxz[c]), inv, noi, best_t, tn, tf);
-        key[c] = (tn <= tf) ? __float_as_uint(tn) : kNone;
+        key[c] = ((tn <= tf) && (ref[c] != kEmptyRef)) ? __float_as_uint(tn) : kNone;
       }
       RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
       if (key[3] != kNone) { lds_stack[sp * lds_stride] = ref[3]; ++sp; }
