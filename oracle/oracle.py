@@ -391,3 +391,18 @@ def spherical_directions(model):
     out = np.zeros((model.phi.size * model.theta.size, 3), dtype=np.float32)
     lib().orc_spherical_directions(C.byref(model), _p(out))
     return out
+
+
+def statistics_p2l_exact(Tpre, dataset_points, dataset_mask, model_points, model_normals, model_mask, max_dist):
+    """statistics_p2l evaluated in double (two-pass) and rounded once to the f32 CrossStatistics struct:
+    the order-independent value of the reference's formula on the given f32 inputs.  This is the parity
+    authority for reductions; statistics_p2l() (f32 sequential merge, the single-thread order of the
+    reference) drifts by ~1e-4 over 10^5 elements, as do the reference's own OpenMP / CUDA orders."""
+    r = statistics_p2l_f64(Tpre, dataset_points, dataset_mask, model_points, model_normals, model_mask, max_dist)
+    s = np.zeros((), dtype=CROSS_STATISTICS)
+    for i, k in enumerate("xyz"):
+        s["dataset_mean"][k] = r["dataset_mean"][i]
+        s["model_mean"][k] = r["model_mean"][i]
+    s["covariance"] = r["covariance"].reshape(9)
+    s["n_meas"] = r["n_meas"]
+    return s

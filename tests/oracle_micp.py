@@ -24,7 +24,7 @@ def dataset_from_ranges(model, ranges):
 def compute_cross_statistics_b(sim, ds_points, ds_mask, Tsb, T_bnew_bold, max_dist):
     """MICPSensor_::computeCrossStatistics (MICPSensor.hpp:159-184), stats in the base frame."""
     T_snew_sold = orc.tmult(orc.tmult(orc.tinv(Tsb), T_bnew_bold), Tsb)
-    stats_s = orc.statistics_p2l(T_snew_sold, ds_points, ds_mask, sim["points"], sim["normals"], sim["hits"], max_dist)
+    stats_s = orc.statistics_p2l_exact(T_snew_sold, ds_points, ds_mask, sim["points"], sim["normals"], sim["hits"], max_dist)
     return orc.cs_transform(Tsb, stats_s)
 
 
@@ -63,7 +63,7 @@ def correct_batch(mesh, model, Tsb, Tbm, ds_points, ds_mask, max_dist, nthreads=
     ident = orc.transform()
     for i in range(len(Tbm)):
         sim = mesh.simulate_spherical(model, Tsb, Tbm[i], bvh=True, nthreads=nthreads)
-        s = orc.statistics_p2l(ident, ds_points, ds_mask, sim["points"], sim["normals"], sim["hits"], max_dist)
+        s = orc.statistics_p2l_exact(ident, ds_points, ds_mask, sim["points"], sim["normals"], sim["hits"], max_dist)
         Ts = orc.umeyama(s)
         out[i] = orc.tmult(orc.tmult(Tsb, Ts), orc.tinv(Tsb))
         stats[i] = s

@@ -1,0 +1,128 @@
+"""GPU parity of the particle-filter sensor update: PCDSensorUpdater{Embree,Optix}::update
+(rmcl_ros/src/rmcl/PCDSensorUpdaterEmbree.cpp:18-86,197-241,290-342; optix/BeamEvaluateProgram.cu:15-130)
+through rmclhip_pf_update vs the oracle.  Errors (metres) within 1e-5 relative, n_meas bit-exact,
+likelihood mean / sigma within 1e-5 relative.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import assert_close_rel, golden_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ra, ctx, hm, poses, attrs, beams, Tsb, params=None, variant=0):
+    upd = ra.PCDSensorUpdaterHip(hm)
+    if params is not None:
+        upd.config = params
+    upd.init()
+    upd.set_variant(variant)
+    upd.setInput(beams, Tsb)
+    d_poses = ra.DeviceArray.from_host(ctx, poses)
+    d_attrs = ra.DeviceArray.from_host(ctx, attrs)
+    d_err = ra.DeviceArray(ctx, np.float32, len(poses) * len(beams))
+    upd.set_error_output(d_err)
+    upd.update(d_poses, d_attrs)
+    out = d_attrs.download(), d_err.download().reshape(len(poses), len(beams))
+    upd.close()
+    return out
+
+
+def _check(a_gpu, e_gpu, a_ref, e_ref, what):
+    assert_close_rel(e_gpu, e_ref, 1e-5, 1e-6, what + " errors")
+    assert np.array_equal(a_gpu["likelihood"]["n_meas"], a_ref["likelihood"]["n_meas"]), what + " n_meas"
+    assert_close_rel(a_gpu["likelihood"]["mean"], a_ref["likelihood"]["mean"], 1e-5, 1e-12, what + " mean")
+    assert_close_rel(a_gpu["likelihood"]["sigma"], a_ref["likelihood"]["sigma"], 1e-4, 1e-10, what + " sigma")
+    assert np.array_equal(a_gpu["state_sigma"], a_ref["state_sigma"]), what + " state_sigma must be untouched"
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_golden_g6_cube(ra, ctx, meshes, variant):
+    """committed fixture G6: 64 particles x 16 beams on the cube; beams outside the sensor range
+    (real miss) and the MAX_N_MEAS clamp included."""
+    from rmcl_amd import types as T
+    g = np.load(golden_path("g6_pf_cube.npz"))
+    v, f = meshes("cube")
+    hm = ra.import_hip_map(ctx, v, f)
+    poses = g["poses"].view(T.TRANSFORM)
+    attrs = g["attrs_in"].view(T.PARTICLE_ATTRIBUTES)
+    beams = g["beams"].view(T.RANGE_MEASUREMENT)
+    Tsb = g["Tsb"].view(T.TRANSFORM)[0]
+    a_gpu, e_gpu = _run(ra, ctx, hm, poses, attrs.copy(), beams, Tsb, variant=variant)
+    _check(a_gpu, e_gpu, g["attrs_out"].view(T.PARTICLE_ATTRIBUTES), g["errors"], "G6")
+
+
+@pytest.mark.parametrize("n_particles,n_beams", [(1000, 100), (257, 7), (4099, 256)])
+def test_room_random_particles(ra, orc, ctx, meshes, n_particles, n_beams):
+    """random hypotheses in a room with occluders and an open ceiling (sim misses), reference default of
+    100 random beams and ragged sizes; beams sampled from a simulated cloud like update() does."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room30k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    model = syn.model_c1()
+    truth = T.transform_from_rpy((1.0, -1.5, 1.2), (0.0, 0.0, 0.5))
+    cloud = m.simulate_spherical(model, T.identity(), truth, bvh=True)["points"]  # NaN where the scan missed
+    beams = ra.sample_beams(cloud, n_beams, seed=99)
+    assert len(beams) == n_beams
+    poses, attrs = syn.uniform_particles(n_particles, seed=5, bb_min=(-9, -9, 0.2, 0, 0, -math.pi),
+                                         bb_max=(9, 9, 3.0, 0, 0, math.pi))
+    Tsb = syn.tsb_offset()
+    a_gpu, e_gpu = _run(ra, ctx, hm, poses, attrs.copy(), beams, Tsb)
+    a_ref = attrs.copy()
+    e_ref = m.pf_update(poses, a_ref, beams, Tsb, orc.pf_params(), bvh=True, nthreads=8, want_errors=True)
+    _check(a_gpu, e_gpu, a_ref, e_ref, "room %dx%d" % (n_particles, n_beams))
+    assert (e_ref == 100.0).any() and (e_ref < 1.0).any()
+
+
+def test_repeated_updates_accumulate_and_clamp(ra, orc, ctx, meshes):
+    """likelihood accumulates over successive update() calls and n_meas saturates at MAX_N_MEAS = 10000
+    (PCDSensorUpdaterEmbree.cpp:237-238): start at 9900, apply 3 x 64 beams."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("cube")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    poses, attrs = syn.uniform_particles(300, seed=21, bb_min=(-4, -4, -2, 0, 0, -math.pi), bb_max=(4, 4, 2, 0, 0, math.pi))
+    attrs["likelihood"]["n_meas"] = 9900
+    attrs["likelihood"]["sigma"] = 0.002
+    beams = ra.beams_from_points(syn.model_directions(syn.model_pf16())[::4] * np.float32(4.0))
+    upd = ra.PCDSensorUpdaterHip(hm)
+    upd.init()
+    upd.setInput(beams, T.identity())
+    d_poses, d_attrs = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
+    a_ref = attrs.copy()
+    for _ in range(3):
+        upd.update(d_poses, d_attrs)
+        m.pf_update(poses, a_ref, beams, T.identity(), orc.pf_params(), bvh=False)
+    a_gpu = d_attrs.download()
+    assert np.all(a_gpu["likelihood"]["n_meas"] == 10000)
+    assert np.array_equal(a_gpu["likelihood"]["n_meas"], a_ref["likelihood"]["n_meas"])
+    assert_close_rel(a_gpu["likelihood"]["mean"], a_ref["likelihood"]["mean"], 1e-5, 1e-12, "accumulated mean")
+    w = ra.DeviceArray(ctx, np.float32, len(poses))
+    upd.extract_weights(d_attrs, len(poses), w)
+    assert np.array_equal(w.download(), a_gpu["likelihood"]["mean"])
+
+
+def test_custom_parameters_and_empty_inputs(ra, orc, ctx, meshes):
+    """non-default sensor_update.* parameters; zero particles / zero beams are no-ops."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room30k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    poses, attrs = syn.uniform_particles(128, seed=2, bb_min=(-9, -9, 0.2, 0, 0, -math.pi), bb_max=(9, 9, 3.0, 0, 0, math.pi))
+    beams = ra.beams_from_points(syn.model_directions(syn.model_pf16())[3::7] * np.float32(6.0))
+    kw = dict(dist_sigma=0.5, real_hit_sim_miss_error=7.0, real_miss_sim_hit_error=3.0, real_miss_sim_miss_error=0.25,
+              range_min=0.5, range_max=5.5, max_n_meas=50)
+    a_gpu, e_gpu = _run(ra, ctx, hm, poses, attrs.copy(), beams, syn.tsb_offset(), params=T.pf_params(**kw))
+    a_ref = attrs.copy()
+    e_ref = m.pf_update(poses, a_ref, beams, syn.tsb_offset(), orc.pf_params(**kw), bvh=False, want_errors=True)
+    _check(a_gpu, e_gpu, a_ref, e_ref, "custom params")
+    assert set(np.unique(e_ref)) >= {np.float32(3.0), np.float32(0.25)} or (e_ref == 3.0).any()
+    upd = ra.PCDSensorUpdaterHip(hm)
+    upd.init()
+    upd.setInput(beams, T.identity())
+    d_poses, d_attrs = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
+    upd.update(d_poses, d_attrs, n_particles=0)
+    assert np.array_equal(d_attrs.download().view(np.uint8), attrs.view(np.uint8))
