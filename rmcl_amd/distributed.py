@@ -1,0 +1,74 @@
+"""Multi-GPU particle-filter sensor update: one process per GPU, particles block-partitioned, mesh + BVH
+replicated, ONE collective per update -- an all-gather of the per-particle likelihood means over
+RCCL/xGMI.  The reference has no distributed code at all; this is new.
+
+The all-gather payload is 4 B x N (1 M particles: 4 MB total, 0.5 MB per rank on 8 GPUs): with 7
+point-to-point xGMI links per GPU this is latency-bound (tens of microseconds), so it is issued as a
+single collective on equal-sized (padded) shards, never bucketed or split.
+
+Works with backend "nccl" (= RCCL) on GPUs and "gloo" on CPU (tests).
+"""
+import numpy as np
+
+
+def shard_bounds(n, rank, world):
+    """contiguous block partition of [0, n): the first n % world ranks own one extra particle."""
+    base, rem = divmod(int(n), int(world))
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def shard_capacity(n, world):
+    """padded per-rank shard length (equal on all ranks, as all_gather requires)."""
+    return (int(n) + int(world) - 1) // int(world)
+
+
+def allgather_weights(local_weights, n_total, group=None):
+    """local_weights: 1-D float32 torch tensor holding this rank's shard (device tensor for RCCL).
+    Returns the dense [n_total] weight vector, identical on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    cap = shard_capacity(n_total, world)
+    send = torch.zeros(cap, dtype=torch.float32, device=local_weights.device)
+    send[: local_weights.numel()] = local_weights
+    recv = [torch.empty(cap, dtype=torch.float32, device=local_weights.device) for _ in range(world)]
+    dist.all_gather(recv, send, group=group)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_bounds(n_total, r, world)
+        parts.append(recv[r][: hi - lo])
+    return torch.cat(parts)
+
+
+def allreduce_sum_max(local_weights, group=None):
+    """global {sum, max} of the weights: the distributed form of the reference's simple_stats_kernel
+    (rmcl_ros/src/rmcl/resampling.cu:41-92), two tiny all-reduces."""
+    import torch
+    import torch.distributed as dist
+    s = local_weights.to(torch.float64).sum().reshape(1)
+    m = local_weights.max().reshape(1).clone() if local_weights.numel() else torch.full((1,), -np.inf, device=local_weights.device)
+    dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+    return float(s.item()), float(m.item())
+
+
+class ShardedSensorUpdate:
+    """rank-local PCDSensorUpdaterHip over this rank's block of the particle cloud + the weight all-gather."""
+
+    def __init__(self, updater, n_total, rank, world):
+        self.updater = updater
+        self.n_total, self.rank, self.world = int(n_total), int(rank), int(world)
+        self.lo, self.hi = shard_bounds(n_total, rank, world)
+
+    @property
+    def n_local(self):
+        return self.hi - self.lo
+
+    def update(self, poses_dev, attrs_dev, weights_local):
+        """poses_dev / attrs_dev: this rank's shard on the device; weights_local: float32 torch CUDA tensor
+        of n_local elements that receives likelihood.mean.  Returns the gathered [n_total] tensor."""
+        self.updater.update(poses_dev, attrs_dev, n_particles=self.n_local)
+        self.updater.extract_weights(attrs_dev, self.n_local, weights_local.data_ptr())
+        return allgather_weights(weights_local, self.n_total)

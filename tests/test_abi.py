@@ -1,0 +1,164 @@
+"""CPU tests of the drop-in boundary: librmclhip.so loads, exports every symbol include/rmclhip.h declares,
+fails loudly (no CPU fallback) without a device, and its host-side pieces (transform algebra, Umeyama,
+BVH builder) agree with the oracle.  No compute entry point is called here.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    with open(os.path.join(ROOT, "include", "rmclhip.h")) as fh:
+        src = fh.read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rmclhip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(ra):
+    names = _declared_symbols()
+    assert len(names) >= 45
+    L = C.CDLL(ra._capi.LIB_PATH)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    # and the Python binding covers exactly the header
+    assert sorted(ra._capi.SIGNATURES) == names
+
+
+def test_pod_layouts(ra):
+    T = ra.types
+    assert T.TRANSFORM.itemsize == 32 and T.TRANSFORM.fields["t"][1] == 16 and T.TRANSFORM.fields["stamp"][1] == 28
+    assert T.CROSS_STATISTICS.itemsize == 64 and T.CROSS_STATISTICS.fields["n_meas"][1] == 60
+    assert T.PARTICLE_ATTRIBUTES.itemsize == 36 and T.RANGE_MEASUREMENT.itemsize == 64
+    assert C.sizeof(ra._capi.SphericalModel) == 32 and C.sizeof(ra._capi.PFParams) == 28
+
+
+def test_no_device_is_a_loud_error_not_a_fallback(ra):
+    """In a GPU-less container ctx_create must fail with RMCLHIP_ERR_NO_DEVICE (on a GPU box it succeeds);
+    null handles are rejected with RMCLHIP_ERR_INVALID and a message."""
+    L = ra._capi.lib()
+    h = C.c_void_p()
+    st = L.rmclhip_ctx_create(0, C.byref(h))
+    if st != ra._capi.OK:
+        assert st == ra._capi.ERR_NO_DEVICE
+        assert b"no CPU fallback" in L.rmclhip_last_error()
+        with pytest.raises(ra.NoDeviceError):
+            ra.Context(0)
+    else:
+        L.rmclhip_ctx_destroy(h)
+    out = C.c_void_p()
+    assert L.rmclhip_rcc_create(None, None, C.byref(out)) == ra._capi.ERR_INVALID
+    assert b"NO MAP" in L.rmclhip_last_error()
+    assert L.rmclhip_pf_create(None, None, C.byref(out)) == ra._capi.ERR_INVALID
+    assert L.rmclhip_rcc_find(None, None) == ra._capi.ERR_INVALID
+    assert L.rmclhip_version().startswith(b"rmclhip")
+
+
+def test_host_algebra_bit_exact_with_oracle(ra, orc):
+    """rmclhip_transform_mult / _inv / cross_statistics_* are the same operation-order spec as the oracle."""
+    T = ra.types
+    rng = np.random.RandomState(0)
+    for _ in range(30):
+        qa, qb = rng.normal(size=4), rng.normal(size=4)
+        A = T.transform(qa / np.linalg.norm(qa), rng.uniform(-5, 5, 3))
+        B = T.transform(qb / np.linalg.norm(qb), rng.uniform(-5, 5, 3))
+        assert T.mult(A, B).tobytes() == orc.tmult(A, B).tobytes()
+        assert T.inv(A).tobytes() == orc.tinv(A).tobytes()
+        s1, s2 = np.zeros((), T.CROSS_STATISTICS), np.zeros((), T.CROSS_STATISTICS)
+        for s in (s1, s2):
+            for k in "xyz":
+                s["dataset_mean"][k], s["model_mean"][k] = rng.uniform(-3, 3, 2)
+            s["covariance"] = rng.normal(size=9)
+            s["n_meas"] = rng.randint(1, 1000)
+        assert T.cross_statistics_merge(s1, s2).tobytes() == orc.cs_merge(s1, s2).tobytes()
+        assert T.cross_statistics_transform(A, s1).tobytes() == orc.cs_transform(A, s1).tobytes()
+        tu, to = T.umeyama_transform(s1), orc.umeyama(s1)
+        assert np.allclose([tu["R"][k] for k in "xyzw"], [to["R"][k] for k in "xyzw"], atol=1e-6)
+        assert np.allclose([tu["t"][k] for k in "xyz"], [to["t"][k] for k in "xyz"], atol=1e-5)
+    ident = T.cross_statistics_merge(T.cross_statistics_identity(), T.cross_statistics_identity())
+    assert int(ident["n_meas"]) == 0 and not np.isnan(ident["covariance"]).any()
+
+
+@pytest.mark.parametrize("name", ["cube", "sphere20k", "room30k"])
+def test_bvh_builder_invariants(ra, orc, meshes, name):
+    """Host-only build (rmclhip_bvh_build_host): every face in exactly one leaf, triangle records bit-equal
+    to the oracle's, every child box contains its subtree, BFS node order, stack bound respected, and the
+    oracle's intersector walking THESE arrays reproduces brute force."""
+    v, f = meshes(name)
+    info, nodes, tris = ra.build_bvh_host(v, f)
+    m = orc.Mesh(v, f)
+    nf = len(f)
+    assert info["n_faces"] == nf and nodes.shape == (info["n_nodes"], 32) and tris.shape == (nf, 16)
+    fid = tris[:, 15]
+    assert np.array_equal(np.sort(fid), np.arange(nf, dtype=np.uint32))
+    assert np.array_equal(tris.view(np.float32)[:, :15].view(np.uint32), m.tri_records()[fid].view(np.uint32))
+    fl = nodes.view(np.float32)
+    leaf_seen = np.zeros(nf, dtype=np.int32)
+    v0 = tris.view(np.float32)[:, 0:3]
+    v1 = v0 - tris.view(np.float32)[:, 3:6]
+    v2 = v0 + tris.view(np.float32)[:, 6:9]
+
+    def subtree_bounds(ref, depth, stack):
+        if ref & 0x80000000:
+            first, cnt = ref & 0x0FFFFFFF, ((ref >> 28) & 7) + 1
+            assert cnt <= 4
+            leaf_seen[first:first + cnt] += 1
+            pts = np.concatenate([v0[first:first + cnt], v1[first:first + cnt], v2[first:first + cnt]])
+            return pts.min(0), pts.max(0), depth, stack
+        assert ref < info["n_nodes"]
+        lo, hi, dmax, smax = np.full(3, np.inf), np.full(3, -np.inf), depth, stack
+        kids = [c for c in range(4) if nodes[ref, 24 + c] != 0xFFFFFFFF]
+        assert len(kids) >= 1
+        for c in range(4):
+            child = int(nodes[ref, 24 + c])
+            if child == 0xFFFFFFFF:
+                continue
+            if not child & 0x80000000:
+                assert child > ref  # breadth-first order: children come later
+            clo, chi, d, s = subtree_bounds(child, depth + 1, stack + len(kids) - 1)
+            bmin = np.array([fl[ref, 0 + c], fl[ref, 4 + c], fl[ref, 8 + c]])
+            bmax = np.array([fl[ref, 12 + c], fl[ref, 16 + c], fl[ref, 20 + c]])
+            assert np.all(bmin <= clo) and np.all(bmax >= chi)       # (padded) box contains the subtree
+            lo, hi, dmax, smax = np.minimum(lo, clo), np.maximum(hi, chi), max(dmax, d), max(smax, s)
+        return lo, hi, dmax, smax
+
+    import sys
+    sys.setrecursionlimit(10000)
+    lo, hi, dmax, smax = subtree_bounds(0, 1, 0)
+    assert np.all(leaf_seen == 1)
+    assert smax + 1 <= info["stack_need"] <= 64
+    assert np.allclose(lo, info["bbox_min"], atol=1e-5) and np.allclose(hi, info["bbox_max"], atol=1e-5)
+    rng = np.random.RandomState(1)
+    for _ in range(200):
+        O = rng.uniform(-3, 3, 3).astype(np.float32)
+        O[2] = abs(O[2]) + 0.1
+        D = rng.normal(size=3).astype(np.float32)
+        D /= np.linalg.norm(D)
+        assert orc.trace_bvh4(nodes, tris, O, D, 0.0, 1e4) == m.intersect(O, D, 0.0, 1e4)
+
+
+def test_bvh_builder_rejects_bad_meshes(ra):
+    L = ra._capi.lib()
+    v = np.zeros((3, 3), np.float32)
+    bad = np.array([[0, 1, 7]], np.uint32)
+    with pytest.raises(ra.RmclHipError):
+        ra.build_bvh_host(v, bad)
+    v[0, 0] = np.nan
+    with pytest.raises(ra.RmclHipError):
+        ra.build_bvh_host(v, np.array([[0, 1, 2]], np.uint32))
+    assert b"bvh_build_host" in L.rmclhip_last_error()
+
+
+def test_tiny_meshes_build(ra, orc):
+    """1 triangle and 5 triangles: the root is still an inner Node4."""
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0.5], [2, 2, 2], [3, 1, 0]], np.float32)
+    for f in (np.array([[0, 1, 2]], np.uint32), np.array([[0, 1, 2], [1, 3, 2], [2, 3, 4], [3, 5, 4], [0, 2, 4]], np.uint32)):
+        info, nodes, tris = ra.build_bvh_host(v, f)
+        assert info["n_nodes"] >= 1 and not (nodes[0, 24] == 0xFFFFFFFF)
+        m = orc.Mesh(v, f)
+        for O, D in (((0.2, 0.2, 3), (0, 0, -1)), ((0.7, 0.7, 3), (0, 0, -1)), ((5, 5, 5), (1, 0, 0))):
+            assert orc.trace_bvh4(nodes, tris, O, D) == m.intersect(O, D)

@@ -1,0 +1,134 @@
+"""CPU tests of the product's HOST logic (rmcl_amd.micp, rmcl_amd.pf helpers, rmcl_amd.synthetic): the
+correction loop is driven with a test-only correspondence operator backed by the oracle, so the loop
+itself (frame conjugation, merge, weighted merge, Umeyama, composition, convergence heuristic) is checked
+against the oracle-side restatement and the committed G5 trajectory without a GPU.
+"""
+import math
+
+import numpy as np
+
+import oracle_micp as om
+from conftest import golden_path
+
+
+class OracleCorrespondences:
+    """TEST STUB with the Correspondences_ interface (setTsb / find / computeCrossStatistics), CPU oracle inside."""
+
+    def __init__(self, orc, mesh, model, ds, mask, max_dist, adaptive_min):
+        self.orc, self.mesh, self.model, self.ds, self.mask = orc, mesh, model, ds, mask
+        self.max_dist, self.adaptive_min = max_dist, adaptive_min
+        self.outdated = True
+        self.Tsb = orc.transform()
+        self.sim = None
+        self.n_find = 0
+
+    def setTsb(self, Tsb):
+        self.Tsb = Tsb
+
+    def find(self, Tbm):
+        self.sim = self.mesh.simulate_spherical(self.model, self.Tsb, Tbm, bvh=True, nthreads=4)
+        self.n_find += 1
+
+    def computeCrossStatistics(self, T_snew_sold, convergence_progress=0.0):
+        md = self.orc.adaptive_max_dist(self.max_dist, self.adaptive_min, convergence_progress)
+        return self.orc.statistics_p2l_exact(T_snew_sold, self.ds, self.mask, self.sim["points"], self.sim["normals"],
+                                             self.sim["hits"], md)
+
+
+def test_correct_once_host_loop_matches_oracle_and_golden(ra, orc, meshes):
+    from rmcl_amd import synthetic as syn, types as T
+    g = np.load(golden_path("g5_micp_sphere20k.npz"))
+    v, f = meshes("sphere20k")
+    m = orc.Mesh(v, f)
+    model = syn.model_vlp16_900(0.0)
+    Tsb, Tbo, Tom2 = (g[k].view(T.TRANSFORM)[0] for k in ("Tsb", "Tbo", "Tom2"))
+    meas = m.simulate_spherical(model, Tsb, T.mult(T.identity(), Tbo), bvh=True, nthreads=4)
+    ds, mask = om.dataset_from_ranges(model, meas["ranges"])
+    corr = OracleCorrespondences(orc, m, model, ds, mask, 1.0, 0.15)
+    sensor = ra.MICPSensor("lidar", corr, Tsb=Tsb, Tbo=Tbo)
+    sensor.valid_dataset_measurements = int(mask.sum())
+    loc = ra.MICPLocalization([sensor], optimization_iterations=10)
+    loc.Tom_ = Tom2
+    loc.convergence_progress_ = 0.3
+    rec = []
+    loc.correctOnce(record=rec)
+    assert corr.n_find == 1                                   # inner iterations do not re-raycast (App. B.4)
+    traj = g["traj_frames"].view(T.TRANSFORM)
+    assert np.array(rec, dtype=T.TRANSFORM).tobytes() == traj.tobytes()
+    # state update: Tom' = Tom * T_onew_oold, quaternion renormalised (micp_localization.cpp:972-984)
+    exp = T.mult(Tom2, rec[-1])
+    assert np.allclose([loc.Tom_["t"][k] for k in "xyz"], [exp["t"][k] for k in "xyz"], atol=1e-7)
+    q = np.array([loc.Tom_["R"][k] for k in "xyzw"], dtype=np.float64)
+    assert abs(np.linalg.norm(q) - 1.0) < 1e-6
+    # convergence heuristic (:988-1007)
+    t = np.array([exp["t"][k] for k in "xyz"], dtype=np.float64)
+    n_meas = loc.correction_stats_latest_["valid_matches"]
+    expect = (1.0 / math.exp(10.0 * np.linalg.norm(t))) * float(exp["R"]["w"]) ** 2 * (n_meas / mask.sum())
+    assert abs(loc.convergence_progress_ - expect) < 1e-6
+    assert loc.correction_stats_latest_["cov_trace"] > 0
+
+
+def test_two_sensors_merge_and_weights(ra, orc, meshes):
+    """two sensors with different Tsb and merge weights: the merged statistics are the count-weighted merge
+    of both (micp_localization.cpp:931-937); weight 0 on one sensor removes its influence from the solve."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("cube")
+    m = orc.Mesh(v, f)
+    model = syn.model_c1()
+    truth = syn.pose_c2_truth()
+    est = T.mult(truth, syn.pose_c2_perturbation())
+    sensors = []
+    for name, Tsb in (("a", T.identity()), ("b", syn.tsb_offset())):
+        meas = m.simulate_spherical(model, Tsb, truth, bvh=False)
+        ds, mask = om.dataset_from_ranges(model, meas["ranges"])
+        corr = OracleCorrespondences(orc, m, model, ds, mask, 1.0, 1.0)
+        s = ra.MICPSensor(name, corr, Tsb=Tsb, Tbo=T.identity())
+        s.valid_dataset_measurements = int(mask.sum())
+        sensors.append(s)
+    loc = ra.MICPLocalization(sensors, optimization_iterations=3, adaptive_max_dist=False)
+    loc.Tom_ = est
+    d_both = loc.correctOnce()
+    assert loc.correction_stats_latest_["valid_matches"] > 1500     # both sensors contributed
+    assert loc.convergence_progress_ == 0.0                         # adaptive_max_dist off
+    sensors[1].merge_weight_multiplier = 0.0
+    loc2 = ra.MICPLocalization(sensors, optimization_iterations=3, adaptive_max_dist=False)
+    loc2.Tom_ = est
+    d_a = loc2.correctOnce()
+    To, _, _ = om.correct_once(m, model, T.identity(), T.identity(), est, sensors[0].correspondences_.ds,
+                               sensors[0].correspondences_.mask, 3, 1.0, nthreads=1)
+    assert np.allclose([d_a["t"][k] for k in "xyz"], [To["t"][k] for k in "xyz"], atol=1e-6)
+    assert not np.allclose([d_a["t"][k] for k in "xyz"], [d_both["t"][k] for k in "xyz"], atol=1e-6)
+    # disable_correction: state untouched
+    loc3 = ra.MICPLocalization(sensors, optimization_iterations=3, disable_correction=True)
+    loc3.Tom_ = est
+    loc3.correctOnce()
+    assert loc3.Tom_.tobytes() == np.asarray(est).tobytes()
+
+
+def test_beam_helpers(ra):
+    """beams_from_points == PCDSensorUpdaterEmbree.cpp:313-327; sample_beams skips NaN points and is seeded."""
+    pts = np.array([[3, 0, 4], [0, 0, 2], [np.nan, 1, 1], [1, 1, 1]], dtype=np.float32)
+    b = ra.beams_from_points(pts[[0, 1]])
+    assert np.allclose(b["range"], [5, 2]) and np.allclose([b["dir"]["x"][0], b["dir"]["z"][0]], [0.6, 0.8])
+    assert np.allclose(b["cov"][0], np.eye(3).ravel() * 0.1) and np.all(b["orig"]["x"] == 0)
+    s1, s2 = ra.sample_beams(pts, 50, seed=1), ra.sample_beams(pts, 50, seed=1)
+    assert len(s1) == 50 and s1.tobytes() == s2.tobytes() and np.isfinite(s1["range"]).all()
+    assert ra.sample_beams(pts, 50, seed=2).tobytes() != s1.tobytes()
+
+
+def test_synthetic_generators(ra):
+    from rmcl_amd import synthetic as syn
+    v, f = syn.uv_sphere(100000)
+    assert len(f) == 100000 and np.allclose(np.linalg.norm(v, axis=1), 10.0, atol=1e-4)
+    assert syn.find_abc(50000) == (250, 200)        # the reference's factorisation rule
+    v, f = syn.cube_room()
+    assert len(f) == 972 and np.abs(v).max() == 5.0
+    v, f = syn.noisy_room(30000)
+    assert 25000 < len(f) < 36000 and f.max() < len(v)
+    m = syn.model_c2()
+    assert (m.phi.size, m.theta.size) == (128, 1024) and abs(m.theta.inc * 1024 - 2 * math.pi) < 1e-5
+    poses, attrs = syn.uniform_particles(1000, seed=42)
+    q = np.stack([poses["R"][k] for k in "xyzw"], -1)
+    assert np.allclose(np.linalg.norm(q, axis=1), 1, atol=1e-6) and np.all(q[:, 0] == 0) and np.all(q[:, 1] == 0)
+    assert np.all(attrs["likelihood"]["mean"] == 1.0) and np.all(attrs["likelihood"]["n_meas"] == 0)
+    assert syn.uniform_particles(10, seed=42)[0].tobytes() == syn.uniform_particles(10, seed=42)[0].tobytes()
