@@ -86,6 +86,8 @@ SIGNATURES = {
     "rmclhip_rcc_time_find": (_i32, [_vp, _vp, _u32, C.POINTER(_f32)]),
     "rmclhip_rcc_time_reduce": (_i32, [_vp, _vp, _u32, C.POINTER(_f32)]),
     "rmclhip_rcc_set_variant": (_i32, [_vp, _i32]),
+    "rmclhip_rcc_find_batch": (_i32, [_vp, _vp, _u32]),
+    "rmclhip_rcc_time_find_batch": (_i32, [_vp, _vp, _u32, _u32, C.POINTER(_f32)]),
     "rmclhip_umeyama_transform": (_i32, [_vp, _vp]),
     "rmclhip_cross_statistics_merge": (_i32, [_vp, _vp, _vp]),
     "rmclhip_cross_statistics_transform": (_i32, [_vp, _vp, _vp]),

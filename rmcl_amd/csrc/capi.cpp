@@ -124,7 +124,8 @@ struct rmclhip_rcc {
   // batch
   DevBuf<xform> d_Tbm, d_Tsm, d_Tms, d_Tdelta;
   DevBuf<cstats> d_bstats;
-  int variant = 0;
+  int variant = 0;        // traversal kind: 0 wave-packet, 1 per-lane
+  int tile_override = 0;  // 1 + log2(tile width), 0 = automatic
   float last_find_ms = 0.f, last_reduce_ms = 0.f;
 };
 
@@ -435,7 +436,7 @@ static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
   p.tris = r->map->d_tris;
   p.model_tab = r->d_model_tab.p;
   p.W = r->W; p.H = r->H;
-  p.tile_w_log2 = pick_tile_w_log2(r->H);
+  p.tile_w_log2 = (r->tile_override > 0) ? static_cast<uint32_t>(r->tile_override - 1) : pick_tile_w_log2(r->H);
   const uint32_t tw = 1u << p.tile_w_log2, th = 64u >> p.tile_w_log2;
   p.tiles_x = (r->W + tw - 1) / tw;
   p.tiles_y = (r->H + th - 1) / th;
@@ -606,6 +607,8 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
   return RMCLHIP_OK;
 }
 
+static rmclhip_status find_batch_enqueue(rmclhip_rcc* r, const rmclhip_transform* Tbm, uint32_t nposes);
+
 rmclhip_status rmclhip_rcc_correct_batch(rmclhip_rcc* r, const rmclhip_transform* Tbm, uint32_t nposes,
                                          rmclhip_transform* Tdelta_out, rmclhip_cross_statistics* stats_out) {
   if (!r || !Tbm || !Tdelta_out) return fail(RMCLHIP_ERR_INVALID, "correct_batch: null");
@@ -615,18 +618,8 @@ rmclhip_status rmclhip_rcc_correct_batch(rmclhip_rcc* r, const rmclhip_transform
   HIPCHK(hipSetDevice(r->ctx->device));
   const size_t n = static_cast<size_t>(r->W) * r->H;
   if (r->n_dataset != n) return fail(RMCLHIP_ERR_INVALID, "correct_batch: dataset size != model size");
-  if (rmclhip_status st = ensure_model_buffers(r, n * nposes)) return st;
-  HIPCHK(r->d_Tbm.reserve(nposes)); HIPCHK(r->d_Tsm.reserve(nposes)); HIPCHK(r->d_Tms.reserve(nposes));
   HIPCHK(r->d_Tdelta.reserve(nposes)); HIPCHK(r->d_bstats.reserve(nposes));
-  HIPCHK(hipMemcpyAsync(r->d_Tbm.p, Tbm, sizeof(xform) * nposes, hipMemcpyHostToDevice, r->stream));
-  HIPCHK(launch_compose_poses(r->d_Tbm.p, r->Tsb, r->d_Tsm.p, r->d_Tms.p, nposes, r->stream));
-  r->n_model = static_cast<uint32_t>(n);
-  r->nposes_last = nposes;
-  FindParams p;
-  fill_find_params(r, p, nposes);
-  p.Tsm_arr = r->d_Tsm.p;
-  p.Tms_arr = r->d_Tms.p;
-  HIPCHK(launch_find(p, r->kind, r->variant, r->stream));
+  if (rmclhip_status st = find_batch_enqueue(r, Tbm, nposes)) return st;
   uint32_t nb = 0;
   if (rmclhip_status st = reduce_enqueue(r, xidentity(), nullptr, r->max_dist, nposes, &nb)) return st;
   HIPCHK(launch_batch_solve(r->d_partials.p, nb, nposes, r->Tsb, r->d_Tdelta.p, r->d_bstats.p, r->stream));
@@ -683,8 +676,58 @@ rmclhip_status rmclhip_rcc_time_reduce(rmclhip_rcc* r, const rmclhip_transform* 
 }
 
 rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
-  if (!r || variant < 0 || variant > 1) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: bad arguments");
-  r->variant = variant;
+  if (!r || variant < 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: bad arguments");
+  const int kind = variant & 0xF, tile = (variant >> 4) & 0xF;
+  if (kind > 1 || tile > 7) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
+  r->variant = kind;
+  r->tile_override = tile;
+  return RMCLHIP_OK;
+}
+
+static rmclhip_status find_batch_enqueue(rmclhip_rcc* r, const rmclhip_transform* Tbm, uint32_t nposes) {
+  if (nposes > 32768) return fail(RMCLHIP_ERR_UNSUPPORTED, "find_batch: at most 32768 poses per call");
+  const size_t n = static_cast<size_t>(r->W) * r->H;
+  if (rmclhip_status st = ensure_model_buffers(r, n * nposes)) return st;
+  HIPCHK(r->d_Tbm.reserve(nposes)); HIPCHK(r->d_Tsm.reserve(nposes)); HIPCHK(r->d_Tms.reserve(nposes));
+  HIPCHK(hipMemcpyAsync(r->d_Tbm.p, Tbm, sizeof(xform) * nposes, hipMemcpyHostToDevice, r->stream));
+  HIPCHK(launch_compose_poses(r->d_Tbm.p, r->Tsb, r->d_Tsm.p, r->d_Tms.p, nposes, r->stream));
+  r->n_model = static_cast<uint32_t>(n);
+  r->nposes_last = nposes;
+  FindParams p;
+  fill_find_params(r, p, nposes);
+  p.Tsm_arr = r->d_Tsm.p;
+  p.Tms_arr = r->d_Tms.p;
+  HIPCHK(launch_find(p, r->kind, r->variant, r->stream));
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_find_batch(rmclhip_rcc* r, const rmclhip_transform* Tbm, uint32_t nposes) {
+  if (!r || (!Tbm && nposes)) return fail(RMCLHIP_ERR_INVALID, "find_batch: null");
+  if (nposes == 0 || r->kind == kModelNone || r->W == 0 || r->H == 0) return RMCLHIP_OK;
+  HIPCHK(hipSetDevice(r->ctx->device));
+  if (rmclhip_status st = find_batch_enqueue(r, Tbm, nposes)) return st;
+  HIPCHK(hipStreamSynchronize(r->stream));
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_time_find_batch(rmclhip_rcc* r, const rmclhip_transform* Tbm, uint32_t nposes,
+                                           uint32_t iters, float* ms) {
+  if (!r || !Tbm || !ms || iters == 0 || nposes == 0) return fail(RMCLHIP_ERR_INVALID, "time_find_batch: bad arguments");
+  if (r->kind == kModelNone || r->W == 0 || r->H == 0) return fail(RMCLHIP_ERR_INVALID, "time_find_batch: no sensor model");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  if (rmclhip_status st = find_batch_enqueue(r, Tbm, nposes)) return st;
+  HIPCHK(hipStreamSynchronize(r->stream));
+  FindParams p;
+  fill_find_params(r, p, nposes);
+  p.Tsm_arr = r->d_Tsm.p;
+  p.Tms_arr = r->d_Tms.p;
+  HIPCHK(hipEventRecord(r->ev0, r->stream));
+  for (uint32_t i = 0; i < iters; ++i) HIPCHK(launch_find(p, r->kind, r->variant, r->stream));
+  HIPCHK(hipEventRecord(r->ev1, r->stream));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  float total = 0.f;
+  HIPCHK(hipEventElapsedTime(&total, r->ev0, r->ev1));
+  *ms = total / static_cast<float>(iters);
   return RMCLHIP_OK;
 }
 

@@ -254,6 +254,19 @@ class CorrespondencesHIP:
         self._last_nposes = len(T)
         return out, st
 
+    def find_batch(self, Tbm):
+        """Simulator::simulate(Memory<Transform>, Bundle&): pose-major model buffers."""
+        T = np.ascontiguousarray(Tbm, dtype=TRANSFORM).reshape(-1)
+        _capi.check(_capi.lib().rmclhip_rcc_find_batch(self._h, _ptr(T), len(T)))
+        self._last_nposes = len(T)
+
+    def time_find_batch(self, Tbm, iters=10):
+        T = np.ascontiguousarray(Tbm, dtype=TRANSFORM).reshape(-1)
+        ms = C.c_float(0)
+        _capi.check(_capi.lib().rmclhip_rcc_time_find_batch(self._h, _ptr(T), len(T), int(iters), C.byref(ms)))
+        self._last_nposes = len(T)
+        return ms.value
+
     def time_find(self, Tbm_est, iters=20):
         T = np.ascontiguousarray(Tbm_est, dtype=TRANSFORM).reshape(1)
         ms = C.c_float(0)
