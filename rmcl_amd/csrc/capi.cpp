@@ -224,7 +224,10 @@ rmclhip_status rmclhip_map_create(rmclhip_ctx* ctx, const float* v, uint32_t nv,
   m->info = bvh.info;
   const size_t nb = bvh.nodes.size() * sizeof(Node4), tb = bvh.tris.size() * sizeof(TriRec);
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->d_nodes), nb);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_tris), tb);
+  // + 3 zeroed records: the packet kernel always requests a full 4-record leaf
+  const size_t tb_pad = (kMaxLeafTris - 1) * sizeof(TriRec);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_tris), tb + tb_pad);
+  if (e == hipSuccess) e = hipMemset(reinterpret_cast<char*>(m->d_tris) + tb, 0, tb_pad);
   if (e == hipSuccess) e = hipMemcpy(m->d_nodes, bvh.nodes.data(), nb, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(m->d_tris, bvh.tris.data(), tb, hipMemcpyHostToDevice);
   if (e != hipSuccess) {

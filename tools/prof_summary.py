@@ -26,7 +26,7 @@ def main(path):
             "%sx%s/%s" % (r[9], r[10], r[11])))
     try:
         pm = cur.execute(
-            "select k.name, p.counter_name, avg(p.value), count(*) from pmc_events p join kernels k "
+            "select k.name, p.counter_name, avg(p.counter_value), count(*) from pmc_events p join kernels k "
             "on p.dispatch_id = k.dispatch_id group by k.name, p.counter_name order by k.name").fetchall()
     except sqlite3.Error:
         pm = []
