@@ -1,0 +1,127 @@
+// micp_cpp_example.cpp -- the C++ adapters of include/rmcl_hip/rmcl_hip.hpp driven the way the reference's
+// callers drive their operators: MICPSensor_::findCorrespondences / computeCrossStatistics
+// (rmcl_ros/include/rmcl_ros/micpl/MICPSensor.hpp:146-184), the correctOnce inner loop
+// (rmcl_ros/src/nodes/micp_localization.cpp:915-964) and SensorUpdater::update.
+//
+//   g++ -std=c++17 -Iinclude examples/micp_cpp_example.cpp -Lrmcl_amd -lrmclhip -Wl,-rpath,$PWD/rmcl_amd -o micp_example
+//   ./micp_example mesh.bin       (mesh.bin: u32 nv, u32 nf, nv*3 f32, nf*3 u32)
+//
+// Prints one "key value" pair per line; tests/test_cpp_adapters.py compares them with the Python path.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "rmcl_hip/rmcl_hip.hpp"
+
+using namespace rmcl_hip;
+
+static Transform from_rpy(float x, float y, float z, double roll, double pitch, double yaw) {
+  const double cr = std::cos(roll / 2), sr = std::sin(roll / 2), cp = std::cos(pitch / 2), sp = std::sin(pitch / 2);
+  const double cy = std::cos(yaw / 2), sy = std::sin(yaw / 2);
+  Transform T = identity();
+  T.R.x = static_cast<float>(sr * cp * cy - cr * sp * sy);
+  T.R.y = static_cast<float>(cr * sp * cy + sr * cp * sy);
+  T.R.z = static_cast<float>(cr * cp * sy - sr * sp * cy);
+  T.R.w = static_cast<float>(cr * cp * cy + sr * sp * sy);
+  T.t = {x, y, z};
+  return T;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) { std::fprintf(stderr, "usage: %s mesh.bin\n", argv[0]); return 2; }
+  std::FILE* fh = std::fopen(argv[1], "rb");
+  if (!fh) { std::perror("mesh"); return 2; }
+  uint32_t nv = 0, nf = 0;
+  if (std::fread(&nv, 4, 1, fh) != 1 || std::fread(&nf, 4, 1, fh) != 1) return 2;
+  std::vector<float> verts(3 * static_cast<size_t>(nv));
+  std::vector<uint32_t> faces(3 * static_cast<size_t>(nf));
+  if (std::fread(verts.data(), 4, verts.size(), fh) != verts.size()) return 2;
+  if (std::fread(faces.data(), 4, faces.size(), fh) != faces.size()) return 2;
+  std::fclose(fh);
+
+  try {
+    auto ctx = std::make_shared<Context>(0);
+    auto map = std::make_shared<HipMap>(ctx, verts.data(), nv, faces.data(), nf);
+
+    // sensor: 32x32 spherical scanner (config C1), mounted with an offset
+    const float pi = 3.14159265358979323846f;
+    SphericalModel model{};
+    model.phi = {-pi / 4, (pi / 2) / 31, 32};
+    model.theta = {-pi, 2 * pi / 32, 32};
+    model.range = {0.1f, 100.0f};
+    const Transform Tsb = from_rpy(0.1f, 0.0f, 0.3f, 0, 0, 10.0 * pi / 180);
+    const Transform Tbo = identity();
+    const Transform truth = from_rpy(0.5f, -0.3f, 0.2f, 0.02, -0.03, 0.4);
+    const Transform Tom_est = truth * from_rpy(0.2f, 0.1f, 0.05f, 0, 0, 2.0 * pi / 180);
+
+    RCCHipSpherical rcc(map);
+    rcc.setTsb(Tsb);
+    rcc.setModel(model);
+    rcc.params.max_dist = 1.0f;
+    rcc.adaptive_max_dist_min = 0.15f;
+
+    // "measured" scan: simulate at the true pose, then unpackMessage-style dataset from the ranges
+    const uint32_t n = model.phi.size * model.theta.size;
+    rcc.find(truth * Tbo);
+    std::vector<float> ranges(n);
+    std::vector<uint32_t> face_ids(n);
+    std::vector<uint8_t> hits(n);
+    rcc.download(hits.data(), ranges.data(), nullptr, nullptr, face_ids.data());
+    const uint32_t valid = rcc.setDatasetFromRanges(ranges.data(), n);
+    uint64_t face_sum = 0, hit_sum = 0;
+    for (uint32_t i = 0; i < n; ++i) { face_sum += hits[i] ? face_ids[i] : 0; hit_sum += hits[i]; }
+    std::printf("hits %llu\nface_sum %llu\nvalid %u\n", (unsigned long long)hit_sum, (unsigned long long)face_sum, valid);
+
+    // MICPSensor_::findCorrespondences + the correctOnce inner loop on the host, 5 iterations
+    rcc.find(Tom_est * Tbo);
+    Transform T_onew_oold = identity();
+    CrossStatistics Cmerged = cross_statistics_identity();
+    for (int i = 0; i < 5; ++i) {
+      const Transform T_bnew_bold = ~Tbo * T_onew_oold * Tbo;
+      const Transform T_snew_sold = ~Tsb * T_bnew_bold * Tsb;
+      const CrossStatistics stats_s = rcc.computeCrossStatistics(T_snew_sold, 0.0);
+      const CrossStatistics Cs_o = Tbo * (Tsb * stats_s);
+      Cmerged = cross_statistics_identity();
+      Cmerged += Cs_o;
+      T_onew_oold = T_onew_oold * umeyama_transform(Cmerged);
+    }
+    std::printf("host_loop_n_meas %u\nhost_loop_t %.9g %.9g %.9g\nhost_loop_q %.9g %.9g %.9g %.9g\n", Cmerged.n_meas,
+                T_onew_oold.t.x, T_onew_oold.t.y, T_onew_oold.t.z, T_onew_oold.R.x, T_onew_oold.R.y, T_onew_oold.R.z,
+                T_onew_oold.R.w);
+    // the same loop resident on the device
+    CrossStatistics sdev{};
+    const Transform Tdev = rcc.correctOnce(Tom_est, Tbo, 5, 0.0, false, &sdev);
+    std::printf("device_loop_n_meas %u\ndevice_loop_t %.9g %.9g %.9g\n", sdev.n_meas, Tdev.t.x, Tdev.t.y, Tdev.t.z);
+
+    // particle filter: 4 hypotheses, 3 beams
+    std::vector<Transform> poses = {truth, Tom_est, from_rpy(1, 1, 0, 0, 0, 1.0), from_rpy(-2, 0.5f, 0.3f, 0, 0, -2.0)};
+    std::vector<ParticleAttributes> attrs(poses.size());
+    for (auto& a : attrs) { a = ParticleAttributes{}; a.likelihood.mean = 1.0f; }
+    std::vector<RangeMeasurement> beams(3);
+    const float dirs[3][3] = {{1, 0, 0}, {0, 1, 0}, {0.6f, 0, 0.8f}};
+    for (int b = 0; b < 3; ++b) {
+      beams[b] = RangeMeasurement{};
+      beams[b].dir = {dirs[b][0], dirs[b][1], dirs[b][2]};
+      beams[b].range = 3.0f + b;
+    }
+    void *d_poses = nullptr, *d_attrs = nullptr;
+    check(rmclhip_malloc(ctx->handle(), poses.size() * sizeof(Transform), &d_poses));
+    check(rmclhip_malloc(ctx->handle(), attrs.size() * sizeof(ParticleAttributes), &d_attrs));
+    check(rmclhip_memcpy_h2d(ctx->handle(), d_poses, poses.data(), poses.size() * sizeof(Transform)));
+    check(rmclhip_memcpy_h2d(ctx->handle(), d_attrs, attrs.data(), attrs.size() * sizeof(ParticleAttributes)));
+    PCDSensorUpdaterHip upd(map);
+    upd.init();
+    upd.setInput(beams, Tsb);
+    upd.update({static_cast<Transform*>(d_poses), poses.size()}, {static_cast<ParticleAttributes*>(d_attrs), attrs.size()});
+    check(rmclhip_memcpy_d2h(ctx->handle(), attrs.data(), d_attrs, attrs.size() * sizeof(ParticleAttributes)));
+    for (size_t i = 0; i < attrs.size(); ++i)
+      std::printf("pf_%zu %.9g %.9g %u\n", i, attrs[i].likelihood.mean, attrs[i].likelihood.sigma, attrs[i].likelihood.n_meas);
+    check(rmclhip_free(ctx->handle(), d_poses));
+    check(rmclhip_free(ctx->handle(), d_attrs));
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -1,0 +1,290 @@
+// rmcl_hip.hpp -- header-only C++17 adapters that present librmclhip's C ABI (include/rmclhip.h) with the
+// class shapes of the reference, so MICP-L / RMCL callers keep their code:
+//
+//   rmcl::Correspondences_<MemT>            rmcl/include/rmcl/registration/Correspondences.hpp:16-88
+//   rmcl::CorrespondencesCUDA               rmcl/include/rmcl/registration/CorrespondencesCUDA.hpp:10-17
+//   rmcl::RCCOptixSpherical / RCCEmbreeO1Dn rmcl/include/rmcl/registration/RCCOptix.hpp:18-93, RCCEmbree.hpp:60-83
+//   rmcl::SensorUpdater<MemT>               rmcl_ros/include/rmcl_ros/rmcl/SensorUpdater.hpp:18-42
+//   rmcl::ParticleUpdater<MemT>::update     rmcl_ros/include/rmcl_ros/rmcl/ParticleUpdater.hpp:24-44
+//
+// rmagine is not a dependency: the few PODs the hot path needs are restated here with rmagine's member
+// names and memory layouts (INTEGRATION.md shows the two-line conversions to/from the rmagine types).
+// Errors: the C ABI returns status codes; these adapters rethrow std::runtime_error like the reference
+// (micp_localization.cpp:613, PCDSensorUpdaterOptix.cpp:179-192).
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../rmclhip.h"
+
+namespace rmcl_hip {
+
+struct VRAM_HIP {};  // memory-space tag, sibling of rmagine::RAM / VRAM_CUDA
+
+using Vector = rmclhip_vec3;
+using Quaternion = rmclhip_quat;
+using Transform = rmclhip_transform;
+using SphericalModel = rmclhip_spherical_model;
+using CrossStatistics = rmclhip_cross_statistics;
+using ParticleAttributes = rmclhip_particle_attributes;
+using RangeMeasurement = rmclhip_range_measurement;
+using Interval = rmclhip_interval;
+
+inline void check(rmclhip_status st) {
+  if (st != RMCLHIP_OK) throw std::runtime_error(std::string("rmclhip: ") + rmclhip_last_error());
+}
+
+inline Transform identity() { return Transform{{0.f, 0.f, 0.f, 1.f}, {0.f, 0.f, 0.f}, 0u}; }
+// Transform::operator* / operator~ (micp_localization.cpp:926,963)
+inline Transform operator*(const Transform& a, const Transform& b) {
+  Transform r;
+  check(rmclhip_transform_mult(&a, &b, &r));
+  return r;
+}
+inline Transform operator~(const Transform& a) {
+  Transform r;
+  check(rmclhip_transform_inv(&a, &r));
+  return r;
+}
+// Transform * CrossStatistics (MICPSensor.hpp:182)
+inline CrossStatistics operator*(const Transform& T, const CrossStatistics& s) {
+  CrossStatistics r;
+  check(rmclhip_cross_statistics_transform(&T, &s, &r));
+  return r;
+}
+// CrossStatistics::operator+= (micp_localization.cpp:936-937)
+inline CrossStatistics& operator+=(CrossStatistics& a, const CrossStatistics& b) {
+  CrossStatistics r;
+  check(rmclhip_cross_statistics_merge(&a, &b, &r));
+  a = r;
+  return a;
+}
+inline CrossStatistics cross_statistics_identity() { return CrossStatistics{}; }
+// rm::umeyama_transform (micp_localization.cpp:952-953)
+inline Transform umeyama_transform(const CrossStatistics& s) {
+  Transform r;
+  check(rmclhip_umeyama_transform(&s, &r));
+  return r;
+}
+
+struct UmeyamaReductionConstraints { float max_dist = 1.0f; };
+
+// one HIP device
+class Context {
+ public:
+  explicit Context(int device = 0) { check(rmclhip_ctx_create(device, &h_)); }
+  ~Context() { rmclhip_ctx_destroy(h_); }
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+  rmclhip_ctx* handle() const { return h_; }
+
+ private:
+  rmclhip_ctx* h_ = nullptr;
+};
+using ContextPtr = std::shared_ptr<Context>;
+
+// rm::EmbreeMap / rm::OptixMap analogue; shared via shared_ptr like EmbreeMapPtr (PCDSensorUpdaterEmbree.cpp:143-174)
+class HipMap {
+ public:
+  HipMap(ContextPtr ctx, const float* vertices_xyz, uint32_t n_vertices, const uint32_t* faces_ijk, uint32_t n_faces)
+      : ctx_(std::move(ctx)) {
+    check(rmclhip_map_create(ctx_->handle(), vertices_xyz, n_vertices, faces_ijk, n_faces, &h_));
+  }
+  ~HipMap() { rmclhip_map_release(h_); }
+  HipMap(const HipMap&) = delete;
+  HipMap& operator=(const HipMap&) = delete;
+  rmclhip_map* handle() const { return h_; }
+  const ContextPtr& context() const { return ctx_; }
+
+ private:
+  ContextPtr ctx_;
+  rmclhip_map* h_ = nullptr;
+};
+using HipMapPtr = std::shared_ptr<HipMap>;
+
+// non-owning device view (rmagine::MemoryView<T, VRAM_HIP>)
+template <typename T>
+struct DeviceView {
+  T* ptr = nullptr;
+  size_t n = 0;
+  T* raw() const { return ptr; }
+  size_t size() const { return n; }
+};
+
+template <typename MemT>
+class Correspondences_;
+
+// rmcl::Correspondences_<VRAM_HIP> + CorrespondencesCUDA::computeCrossStatistics
+template <>
+class Correspondences_<VRAM_HIP> {
+ public:
+  // public attributes that have to be filled (Correspondences.hpp:19-29)
+  UmeyamaReductionConstraints params;
+  float adaptive_max_dist_min = 1.0f;
+  bool outdated = true;
+
+  explicit Correspondences_(HipMapPtr map) : map_(std::move(map)) {
+    if (!map_) throw std::runtime_error("NO MAP");
+    check(rmclhip_rcc_create(map_->context()->handle(), map_->handle(), &h_));
+  }
+  virtual ~Correspondences_() { rmclhip_rcc_destroy(h_); }
+  Correspondences_(const Correspondences_&) = delete;
+  Correspondences_& operator=(const Correspondences_&) = delete;
+
+  virtual void setTsb(const Transform& Tsb) {
+    Tsb_ = Tsb;
+    check(rmclhip_rcc_set_tsb(h_, &Tsb));
+  }
+  // finds and fills the model buffers
+  virtual void find(const Transform& Tbm_est) { check(rmclhip_rcc_find(h_, &Tbm_est)); }
+  virtual CrossStatistics computeCrossStatistics(const Transform& T_snew_sold, double convergence_progress = 0.0) const {
+    check(rmclhip_rcc_set_params(h_, params.max_dist, adaptive_max_dist_min));
+    CrossStatistics out;
+    check(rmclhip_rcc_compute_cross_statistics(h_, &T_snew_sold, convergence_progress, &out));
+    return out;
+  }
+  // dataset {points, mask}: host or device source (the CUDA sensors upload once per scan,
+  // MICPSphericalSensorCUDA.cpp:231-232)
+  void setDataset(const float* points_xyz, const uint8_t* mask, uint32_t n, bool src_is_device = false) {
+    check(rmclhip_rcc_set_dataset(h_, points_xyz, mask, n, src_is_device ? 1 : 0));
+    outdated = true;
+  }
+  uint32_t setDatasetFromRanges(const float* ranges, uint32_t n) {
+    uint32_t valid = 0;
+    check(rmclhip_rcc_set_dataset_from_ranges(h_, ranges, n, &valid));
+    outdated = true;
+    return valid;
+  }
+  // modelView(): borrowed device views of {points, hits(mask), normals} (+ ranges, face ids)
+  struct ModelView {
+    const float* points;
+    const uint8_t* mask;
+    const float* normals;
+    const float* ranges;
+    const uint32_t* face_ids;
+    uint32_t n;
+  };
+  ModelView modelView() const {
+    ModelView v{};
+    check(rmclhip_rcc_device_views(h_, &v.mask, &v.ranges, &v.points, &v.normals, &v.face_ids, &v.n));
+    return v;
+  }
+  void download(uint8_t* hits, float* ranges, float* points, float* normals, uint32_t* face_ids) const {
+    check(rmclhip_rcc_download(h_, hits, ranges, points, normals, face_ids));
+  }
+  // device-resident MICP-L inner loop for this sensor (micp_localization.cpp:900-964)
+  Transform correctOnce(const Transform& Tom, const Transform& Tbo, uint32_t iterations, double convergence_progress,
+                        bool refind_each_iteration, CrossStatistics* stats_o = nullptr) {
+    check(rmclhip_rcc_set_params(h_, params.max_dist, adaptive_max_dist_min));
+    Transform T;
+    check(rmclhip_rcc_correct_once(h_, &Tom, &Tbo, iterations, convergence_progress, refind_each_iteration ? 1 : 0, &T,
+                                   stats_o));
+    return T;
+  }
+  // v1 SphereCorrector::correct (lidar_corrector_embree_benchmark.cpp:127-135)
+  std::vector<Transform> correctBatch(const std::vector<Transform>& Tbm, std::vector<CrossStatistics>* stats = nullptr) {
+    check(rmclhip_rcc_set_params(h_, params.max_dist, adaptive_max_dist_min));
+    std::vector<Transform> out(Tbm.size());
+    if (stats) stats->resize(Tbm.size());
+    check(rmclhip_rcc_correct_batch(h_, Tbm.data(), static_cast<uint32_t>(Tbm.size()), out.data(),
+                                    stats ? stats->data() : nullptr));
+    return out;
+  }
+  rmclhip_rcc* handle() const { return h_; }
+
+ protected:
+  HipMapPtr map_;
+  rmclhip_rcc* h_ = nullptr;
+  Transform Tsb_ = identity();
+};
+using CorrespondencesHIP = Correspondences_<VRAM_HIP>;
+
+// rmagine::ModelSetter<ModelT>
+template <typename ModelT>
+struct ModelSetter {
+  virtual ~ModelSetter() = default;
+  virtual void setModel(const ModelT&) = 0;
+};
+
+// rmagine::O1DnModel (fields: rmcl_ros/src/util/conversions.cpp:74-94)
+struct O1DnModel {
+  uint32_t width = 0, height = 0;
+  Interval range{0.f, 0.f};
+  Vector orig{0.f, 0.f, 0.f};
+  std::vector<Vector> dirs;
+};
+
+class RCCHipSpherical : public CorrespondencesHIP, public ModelSetter<SphericalModel> {
+ public:
+  explicit RCCHipSpherical(HipMapPtr map) : CorrespondencesHIP(std::move(map)) {}
+  void setModel(const SphericalModel& m) override { check(rmclhip_rcc_set_model_spherical(h_, &m)); }
+};
+
+class RCCHipO1Dn : public CorrespondencesHIP, public ModelSetter<O1DnModel> {
+ public:
+  explicit RCCHipO1Dn(HipMapPtr map) : CorrespondencesHIP(std::move(map)) {}
+  void setModel(const O1DnModel& m) override {
+    if (m.dirs.size() != static_cast<size_t>(m.width) * m.height) throw std::runtime_error("O1DnModel: dirs.size() != width*height");
+    check(rmclhip_rcc_set_model_o1dn(h_, m.width, m.height, m.range, m.orig, reinterpret_cast<const float*>(m.dirs.data())));
+  }
+};
+
+// ---- particle filter -----------------------------------------------------------------------------------
+struct ParticleUpdateConfig {};
+struct ParticleUpdateResults {};
+
+struct SensorUpdaterBase {
+  virtual ~SensorUpdaterBase() = default;
+  virtual void init() {}
+  virtual void reset() {}
+};
+
+template <typename MemT>
+struct ParticleUpdater;
+template <>
+struct ParticleUpdater<VRAM_HIP> {
+  virtual ~ParticleUpdater() = default;
+  virtual ParticleUpdateResults update(DeviceView<Transform> particle_poses, DeviceView<ParticleAttributes> particle_attrs,
+                                       const ParticleUpdateConfig& config = {}) = 0;
+};
+
+// rmcl::PCDSensorUpdaterOptix on gfx950.  setInput() takes the already sampled measurements (sensor frame)
+// and Tsb; sampling from a PointCloud2 and the TF lookup stay with the ROS-side caller
+// (PCDSensorUpdaterEmbree.cpp:249-327).
+class PCDSensorUpdaterHip : public SensorUpdaterBase, public ParticleUpdater<VRAM_HIP> {
+ public:
+  rmclhip_pf_params config_{2.0f, 100.0f, 100.0f, 0.0f, {0.05f, 80.0f}, 10000u};
+
+  explicit PCDSensorUpdaterHip(HipMapPtr map) : map_(std::move(map)) {
+    if (!map_) throw std::runtime_error("NO MAP");
+  }
+  ~PCDSensorUpdaterHip() override { rmclhip_pf_destroy(h_); }
+  void init() override {
+    if (!h_) check(rmclhip_pf_create(map_->context()->handle(), map_->handle(), &h_));
+  }
+  void setInput(std::vector<RangeMeasurement> beams, const Transform& Tsb) {
+    beams_ = std::move(beams);
+    Tsb_ = Tsb;
+  }
+  ParticleUpdateResults update(DeviceView<Transform> poses, DeviceView<ParticleAttributes> attrs,
+                               const ParticleUpdateConfig& = {}) override {
+    init();
+    check(rmclhip_pf_set_params(h_, &config_));
+    check(rmclhip_pf_update(h_, poses.raw(), attrs.raw(), static_cast<uint32_t>(poses.size()), beams_.data(),
+                            static_cast<uint32_t>(beams_.size()), &Tsb_));
+    return {};
+  }
+  rmclhip_pf* handle() const { return h_; }
+
+ private:
+  HipMapPtr map_;
+  rmclhip_pf* h_ = nullptr;
+  std::vector<RangeMeasurement> beams_;
+  Transform Tsb_ = identity();
+};
+
+}  // namespace rmcl_hip

@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""GPU perf exploration of the particle-filter update (config C4 and smaller)."""
+import math
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import rmcl_amd as ra
+from rmcl_amd import synthetic as syn, types as T
+
+mesh = sys.argv[1] if len(sys.argv) > 1 else "sphere"
+ctx = ra.Context(0)
+v, f = syn.uv_sphere(100000) if mesh == "sphere" else syn.noisy_room(100000)
+hm = ra.import_hip_map(ctx, v, f)
+print("map", hm.info())
+dirs = syn.model_directions(syn.model_pf16())
+for n_particles, n_beams in ((10000, 100), (100000, 100), (100000, 256)):
+    if mesh == "sphere":
+        poses, attrs = syn.uniform_particles(n_particles, seed=42, bb_min=(-5, -5, -1, 0, 0, -math.pi), bb_max=(5, 5, 1, 0, 0, math.pi))
+    else:
+        poses, attrs = syn.uniform_particles(n_particles, seed=42, bb_min=(-9, -9, 0.3, 0, 0, -math.pi), bb_max=(9, 9, 3, 0, 0, math.pi))
+    sel = np.linspace(0, len(dirs) - 1, n_beams).astype(int)
+    beams = ra.beams_from_points(dirs[sel] * np.float32(6.0))
+    d_poses, d_attrs = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
+    for variant in (0,):
+        upd = ra.PCDSensorUpdaterHip(hm)
+        upd.init()
+        upd.set_variant(variant)
+        upd.setInput(beams, T.identity())
+        ms = upd.time_update(d_poses, d_attrs, n_particles, iters=3)
+        rays = n_particles * n_beams
+        print("particles=%7d beams=%4d variant=%d: %9.3f ms  %7.3f Grays/s  %9.1f particle-updates/s" %
+              (n_particles, n_beams, variant, ms, rays / ms / 1e6, n_particles / ms * 1e3), flush=True)
+        upd.close()
