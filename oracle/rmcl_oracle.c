@@ -678,7 +678,7 @@ static void jacobi_eig3(const double* Ain, double* V, double* e)
   for (int sweep = 0; sweep < 64; ++sweep) {
     const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
     const double dg = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
-    if (off <= 1e-34 * dg || off == 0.0) break;
+    if (off <= 1e-30 * dg || off == 0.0) break;
     for (int p = 0; p < 2; ++p) for (int q = p + 1; q < 3; ++q) {
       const double apq = A[3 * p + q];
       if (apq == 0.0) continue;

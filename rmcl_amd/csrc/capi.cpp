@@ -6,6 +6,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -51,6 +52,19 @@ inline cstats to_cs(const rmclhip_cross_statistics* s) {
   return r;
 }
 inline void from_cs(const cstats& c, rmclhip_cross_statistics* s) { std::memcpy(s, &c, sizeof(c)); }
+
+// RMCLHIP_DEBUG=1: report which API call leaves a HIP error behind
+struct ApiGuard {
+  const char* name;
+  explicit ApiGuard(const char* n) : name(n) {}
+  ~ApiGuard() {
+    static const bool on = std::getenv("RMCLHIP_DEBUG") != nullptr;
+    if (on) {
+      const hipError_t e = hipPeekAtLastError();
+      if (e != hipSuccess) std::fprintf(stderr, "[rmclhip debug] %s leaves HIP error: %s\n", name, hipGetErrorString(e));
+    }
+  }
+};
 
 template <typename T>
 struct DevBuf {
@@ -121,6 +135,22 @@ struct rmclhip_rcc {
   MicpState* d_state = nullptr;
   MicpState* h_state = nullptr;    // pinned
   uint32_t* d_counter = nullptr;
+  uint32_t* d_tickets = nullptr;   // one arrival counter per pose for the fused reduction tail
+  // device-resident MICP loop as a static hipGraph: per-call inputs travel in one 256-B H2D copy
+  MicpCall* h_call = nullptr;      // pinned
+  MicpCall* d_call = nullptr;
+  hipGraphExec_t micp_exec = nullptr;
+  hipGraph_t micp_graph = nullptr;
+  struct MicpKey {
+    uint32_t n_iter = 0, W = 0, H = 0, n_dataset = 0;
+    int kind = 0, variant = 0, tile = 0, fused = 0, has_mask = 0;
+    const void* ptrs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool operator==(const MicpKey& o) const { return std::memcmp(this, &o, sizeof(MicpKey)) == 0; }
+  } micp_key;
+  bool use_graph = true;
+  bool graph_dirty = true;         // set by setModel / set_variant: by-value launch arguments changed
+  size_t tickets_cap = 0;
+  bool fused_tail = false;         // true: last-block tail inside the reduction kernel (measured slower, A/B only)
   // batch
   DevBuf<xform> d_Tbm, d_Tsm, d_Tms, d_Tdelta;
   DevBuf<cstats> d_bstats;
@@ -149,6 +179,7 @@ const char* rmclhip_version(void) { return "rmclhip 0.1 (gfx950)"; }
 
 // ---- context ---------------------------------------------------------------------------------
 rmclhip_status rmclhip_ctx_create(int device, rmclhip_ctx** out) {
+  ApiGuard guard_("rmclhip_ctx_create");
   if (!out) return fail(RMCLHIP_ERR_INVALID, "ctx_create: out is null");
   *out = nullptr;
   int count = 0;
@@ -171,6 +202,7 @@ rmclhip_status rmclhip_ctx_create(int device, rmclhip_ctx** out) {
 void rmclhip_ctx_destroy(rmclhip_ctx* ctx) { delete ctx; }
 
 rmclhip_status rmclhip_ctx_device_name(rmclhip_ctx* ctx, char* buf, size_t n) {
+  ApiGuard guard_("rmclhip_ctx_device_name");
   if (!ctx || !buf || n == 0) return fail(RMCLHIP_ERR_INVALID, "ctx_device_name: bad arguments");
   std::snprintf(buf, n, "%s (%s, %d CUs)", ctx->props.name, ctx->props.gcnArchName, ctx->props.multiProcessorCount);
   return RMCLHIP_OK;
@@ -192,6 +224,7 @@ static void fill_info(const BvhInfo& bi, uint64_t bytes, rmclhip_map_info* out) 
 rmclhip_status rmclhip_bvh_build_host(const float* v, uint32_t nv, const uint32_t* f, uint32_t nf,
                                       rmclhip_map_info* info, uint32_t* nodes_out, size_t nodes_cap,
                                       uint32_t* tris_out, size_t tris_cap) {
+  ApiGuard guard_("rmclhip_bvh_build_host");
   BvhHost bvh;
   const std::string err = build_bvh(v, nv, f, nf, bvh);
   if (!err.empty()) return fail(RMCLHIP_ERR_INVALID, "bvh_build_host: " + err);
@@ -210,6 +243,7 @@ rmclhip_status rmclhip_bvh_build_host(const float* v, uint32_t nv, const uint32_
 
 rmclhip_status rmclhip_map_create(rmclhip_ctx* ctx, const float* v, uint32_t nv, const uint32_t* f, uint32_t nf,
                                   rmclhip_map** out) {
+  ApiGuard guard_("rmclhip_map_create");
   if (!out) return fail(RMCLHIP_ERR_INVALID, "map_create: out is null");
   *out = nullptr;
   if (!ctx) return fail(RMCLHIP_ERR_INVALID, "map_create: ctx is null");
@@ -243,12 +277,14 @@ rmclhip_status rmclhip_map_create(rmclhip_ctx* ctx, const float* v, uint32_t nv,
 }
 
 rmclhip_status rmclhip_map_retain(rmclhip_map* map) {
+  ApiGuard guard_("rmclhip_map_retain");
   if (!map) return fail(RMCLHIP_ERR_INVALID, "map_retain: null");
   map->refs.fetch_add(1);
   return RMCLHIP_OK;
 }
 
 void rmclhip_map_release(rmclhip_map* map) {
+  ApiGuard guard_("rmclhip_map_release");
   if (!map) return;
   if (map->refs.fetch_sub(1) == 1) {
     (void)hipSetDevice(map->ctx->device);
@@ -259,6 +295,7 @@ void rmclhip_map_release(rmclhip_map* map) {
 }
 
 rmclhip_status rmclhip_map_get_info(const rmclhip_map* map, rmclhip_map_info* out) {
+  ApiGuard guard_("rmclhip_map_get_info");
   if (!map || !out) return fail(RMCLHIP_ERR_INVALID, "map_get_info: null");
   fill_info(map->info, map->bytes, out);
   return RMCLHIP_OK;
@@ -266,6 +303,7 @@ rmclhip_status rmclhip_map_get_info(const rmclhip_map* map, rmclhip_map_info* ou
 
 // ---- rcc -------------------------------------------------------------------------------------
 rmclhip_status rmclhip_rcc_create(rmclhip_ctx* ctx, rmclhip_map* map, rmclhip_rcc** out) {
+  ApiGuard guard_("rmclhip_rcc_create");
   if (!out) return fail(RMCLHIP_ERR_INVALID, "rcc_create: out is null");
   *out = nullptr;
   if (!ctx || !map) return fail(RMCLHIP_ERR_INVALID, "rcc_create: NO MAP");
@@ -282,6 +320,8 @@ rmclhip_status rmclhip_rcc_create(rmclhip_ctx* ctx, rmclhip_map* map, rmclhip_rc
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_state), sizeof(MicpState), hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->d_state), sizeof(MicpState));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->d_counter), sizeof(uint32_t));
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_call), sizeof(MicpCall), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->d_call), sizeof(MicpCall));
   if (e != hipSuccess) {
     rmclhip_rcc_destroy(r);
     return fail(RMCLHIP_ERR_HIP, std::string("rcc_create: ") + hipGetErrorString(e));
@@ -291,36 +331,51 @@ rmclhip_status rmclhip_rcc_create(rmclhip_ctx* ctx, rmclhip_map* map, rmclhip_rc
 }
 
 void rmclhip_rcc_destroy(rmclhip_rcc* r) {
+  ApiGuard guard_("rmclhip_rcc_destroy");
   if (!r) return;
   (void)hipSetDevice(r->ctx->device);
-  if (r->stream) (void)hipStreamSynchronize(r->stream);
+#define DBG_STEP(x)                                                                                       \
+  do {                                                                                                  \
+    const hipError_t e_ = (x);                                                                          \
+    if (e_ != hipSuccess && std::getenv("RMCLHIP_DEBUG")) std::fprintf(stderr, "[rmclhip debug] %s -> %s\n", #x, hipGetErrorString(e_)); \
+  } while (0)
+  if (r->stream) DBG_STEP(hipStreamSynchronize(r->stream));
   r->d_model_tab.release(); r->d_ds_points.release(); r->d_ds_mask.release();
   r->d_hits.release(); r->d_ranges.release(); r->d_points.release(); r->d_normals.release(); r->d_face_ids.release();
   r->d_partials.release(); r->d_Tbm.release(); r->d_Tsm.release(); r->d_Tms.release(); r->d_Tdelta.release();
   r->d_bstats.release();
-  if (r->h_stats) (void)hipHostFree(r->h_stats);
-  if (r->h_state) (void)hipHostFree(r->h_state);
-  if (r->d_state) (void)hipFree(r->d_state);
-  if (r->d_counter) (void)hipFree(r->d_counter);
-  if (r->ev0) (void)hipEventDestroy(r->ev0);
-  if (r->ev1) (void)hipEventDestroy(r->ev1);
-  if (r->stream) (void)hipStreamDestroy(r->stream);
+  DBG_STEP(hipPeekAtLastError());
+  if (r->h_stats) DBG_STEP(hipHostFree(r->h_stats));
+  if (r->h_state) DBG_STEP(hipHostFree(r->h_state));
+  if (r->d_state) DBG_STEP(hipFree(r->d_state));
+  if (r->d_counter) DBG_STEP(hipFree(r->d_counter));
+  if (r->d_tickets) DBG_STEP(hipFree(r->d_tickets));
+  if (r->micp_exec) DBG_STEP(hipGraphExecDestroy(r->micp_exec));
+  if (r->micp_graph) DBG_STEP(hipGraphDestroy(r->micp_graph));
+  if (r->h_call) DBG_STEP(hipHostFree(r->h_call));
+  if (r->d_call) DBG_STEP(hipFree(r->d_call));
+  if (r->ev0) DBG_STEP(hipEventDestroy(r->ev0));
+  if (r->ev1) DBG_STEP(hipEventDestroy(r->ev1));
+  if (r->stream) DBG_STEP(hipStreamDestroy(r->stream));
   rmclhip_map_release(r->map);
   delete r;
 }
 
 rmclhip_status rmclhip_rcc_set_tsb(rmclhip_rcc* r, const rmclhip_transform* Tsb) {
+  ApiGuard guard_("rmclhip_rcc_set_tsb");
   if (!r || !Tsb) return fail(RMCLHIP_ERR_INVALID, "rcc_set_tsb: null");
   r->Tsb = to_x(Tsb);
   return RMCLHIP_OK;
 }
 
 rmclhip_status rmclhip_rcc_set_model_spherical(rmclhip_rcc* r, const rmclhip_spherical_model* m) {
+  ApiGuard guard_("rmclhip_rcc_set_model_spherical");
   if (!r || !m) return fail(RMCLHIP_ERR_INVALID, "rcc_set_model_spherical: null");
   HIPCHK(hipSetDevice(r->ctx->device));
   HIPCHK(hipStreamSynchronize(r->stream));
   const uint32_t H = m->phi.size, W = m->theta.size;
   r->kind = kModelSpherical;
+  r->graph_dirty = true;
   r->W = W; r->H = H;
   r->range = m->range;
   r->orig = mk3(0.f, 0.f, 0.f);
@@ -345,10 +400,12 @@ rmclhip_status rmclhip_rcc_set_model_spherical(rmclhip_rcc* r, const rmclhip_sph
 
 rmclhip_status rmclhip_rcc_set_model_o1dn(rmclhip_rcc* r, uint32_t width, uint32_t height, rmclhip_interval range,
                                           rmclhip_vec3 orig, const float* dirs) {
+  ApiGuard guard_("rmclhip_rcc_set_model_o1dn");
   if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_set_model_o1dn: null");
   HIPCHK(hipSetDevice(r->ctx->device));
   HIPCHK(hipStreamSynchronize(r->stream));
   r->kind = kModelO1Dn;
+  r->graph_dirty = true;
   r->W = width; r->H = height;
   r->range = range;
   r->orig = mk3(orig.x, orig.y, orig.z);
@@ -361,6 +418,7 @@ rmclhip_status rmclhip_rcc_set_model_o1dn(rmclhip_rcc* r, uint32_t width, uint32
 }
 
 rmclhip_status rmclhip_rcc_set_params(rmclhip_rcc* r, float max_dist, float adaptive_max_dist_min) {
+  ApiGuard guard_("rmclhip_rcc_set_params");
   if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_set_params: null");
   r->max_dist = max_dist;
   r->adaptive_max_dist_min = adaptive_max_dist_min;
@@ -369,6 +427,7 @@ rmclhip_status rmclhip_rcc_set_params(rmclhip_rcc* r, float max_dist, float adap
 
 rmclhip_status rmclhip_rcc_set_dataset(rmclhip_rcc* r, const float* pts, const uint8_t* mask, uint32_t n,
                                        int src_is_device) {
+  ApiGuard guard_("rmclhip_rcc_set_dataset");
   if (!r || (!pts && n > 0)) return fail(RMCLHIP_ERR_INVALID, "rcc_set_dataset: null");
   HIPCHK(hipSetDevice(r->ctx->device));
   HIPCHK(hipStreamSynchronize(r->stream));
@@ -387,6 +446,7 @@ rmclhip_status rmclhip_rcc_set_dataset(rmclhip_rcc* r, const float* pts, const u
 
 rmclhip_status rmclhip_rcc_set_dataset_from_ranges(rmclhip_rcc* r, const float* ranges, uint32_t n,
                                                    uint32_t* n_valid_out) {
+  ApiGuard guard_("rmclhip_rcc_set_dataset_from_ranges");
   if (!r || !ranges) return fail(RMCLHIP_ERR_INVALID, "rcc_set_dataset_from_ranges: null");
   if (r->kind == kModelNone) return fail(RMCLHIP_ERR_INVALID, "rcc_set_dataset_from_ranges: no sensor model set");
   if (n != r->W * r->H) return fail(RMCLHIP_ERR_INVALID, "rcc_set_dataset_from_ranges: n != model size");
@@ -464,6 +524,7 @@ static rmclhip_status find_enqueue(rmclhip_rcc* r, const xform& Tbm) {
 }
 
 rmclhip_status rmclhip_rcc_find_async(rmclhip_rcc* r, const rmclhip_transform* Tbm_est) {
+  ApiGuard guard_("rmclhip_rcc_find_async");
   if (!r || !Tbm_est) return fail(RMCLHIP_ERR_INVALID, "rcc_find: null");
   // RCCOptix.cpp:30-34: nothing to do for an empty model
   if (r->kind == kModelNone || r->W == 0 || r->H == 0) return RMCLHIP_OK;
@@ -472,6 +533,7 @@ rmclhip_status rmclhip_rcc_find_async(rmclhip_rcc* r, const rmclhip_transform* T
 }
 
 rmclhip_status rmclhip_rcc_find(rmclhip_rcc* r, const rmclhip_transform* Tbm_est) {
+  ApiGuard guard_("rmclhip_rcc_find");
   if (!r || !Tbm_est) return fail(RMCLHIP_ERR_INVALID, "rcc_find: null");
   if (r->kind == kModelNone || r->W == 0 || r->H == 0) return RMCLHIP_OK;
   HIPCHK(hipSetDevice(r->ctx->device));
@@ -484,18 +546,37 @@ rmclhip_status rmclhip_rcc_find(rmclhip_rcc* r, const rmclhip_transform* Tbm_est
 }
 
 rmclhip_status rmclhip_rcc_sync(rmclhip_rcc* r) {
+  ApiGuard guard_("rmclhip_rcc_sync");
   if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_sync: null");
   HIPCHK(hipSetDevice(r->ctx->device));
   HIPCHK(hipStreamSynchronize(r->stream));
   return RMCLHIP_OK;
 }
 
+struct ReduceTail {
+  uint32_t mode = kTailNone;
+  const MicpCall* call = nullptr;
+  cstats* stats_out = nullptr;
+  xform Tbo = xidentity();
+  MicpState* state = nullptr;
+  xform* Tdelta_out = nullptr;
+};
+
 static rmclhip_status reduce_enqueue(rmclhip_rcc* r, const xform& Tpre, const xform* Tpre_dev, float max_dist,
-                                     uint32_t nposes, uint32_t* nblocks_out) {
+                                     uint32_t nposes, const ReduceTail& tail) {
   const uint32_t n = (r->n_dataset < r->n_model) ? r->n_dataset : r->n_model;
   if (n == 0) return fail(RMCLHIP_ERR_INVALID, "computeCrossStatistics: empty dataset or model (call find first)");
+  if (r->n_model != n && nposes > 1) return fail(RMCLHIP_ERR_INVALID, "batch reduction needs dataset size == model size");
   const uint32_t nb = reduce_num_blocks(n);
   HIPCHK(r->d_partials.reserve(static_cast<size_t>(nposes) * nb * 16));
+  if (r->tickets_cap < nposes) {
+    if (r->d_tickets) (void)hipFree(r->d_tickets);
+    r->d_tickets = nullptr;
+    r->tickets_cap = 0;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&r->d_tickets), sizeof(uint32_t) * nposes));
+    HIPCHK(hipMemset(r->d_tickets, 0, sizeof(uint32_t) * nposes));
+    r->tickets_cap = nposes;
+  }
   ReduceParams p;
   std::memset(&p, 0, sizeof(p));
   p.dataset_points = r->d_ds_points.p;
@@ -510,9 +591,21 @@ static rmclhip_status reduce_enqueue(rmclhip_rcc* r, const xform& Tpre, const xf
   p.Tpre_dev = Tpre_dev;
   p.partials = r->d_partials.p;
   p.nblocks = nb;
-  if (r->n_model != n && nposes > 1) return fail(RMCLHIP_ERR_INVALID, "batch reduction needs dataset size == model size");
+  p.tickets = r->d_tickets;
+  p.call = tail.call;
+  p.Tsb = r->Tsb;
+  p.Tbo = tail.Tbo;
+  p.state = tail.state;
+  p.stats_out = tail.stats_out;
+  p.Tdelta_out = tail.Tdelta_out;
+  p.tail_mode = r->fused_tail ? tail.mode : static_cast<uint32_t>(kTailNone);
   HIPCHK(launch_reduce_partials(p, r->stream));
-  *nblocks_out = nb;
+  if (!r->fused_tail) {
+    if (tail.mode == kTailStats) HIPCHK(launch_reduce_finalize(r->d_partials.p, nb, nposes, tail.stats_out, r->stream));
+    else if (tail.mode == kTailMicp) HIPCHK(launch_micp_step(r->d_partials.p, nb, r->Tsb, tail.Tbo, tail.call, tail.state, r->stream));
+    else if (tail.mode == kTailBatchSolve)
+      HIPCHK(launch_batch_solve(r->d_partials.p, nb, nposes, r->Tsb, tail.Tdelta_out, tail.stats_out, r->stream));
+  }
   return RMCLHIP_OK;
 }
 
@@ -524,14 +617,16 @@ static float adaptive_max_dist(const rmclhip_rcc* r, double p) {
 
 rmclhip_status rmclhip_rcc_compute_cross_statistics(rmclhip_rcc* r, const rmclhip_transform* T_snew_sold,
                                                     double convergence_progress, rmclhip_cross_statistics* out) {
+  ApiGuard guard_("rmclhip_rcc_compute_cross_statistics");
   if (!r || !T_snew_sold || !out) return fail(RMCLHIP_ERR_INVALID, "computeCrossStatistics: null");
   HIPCHK(hipSetDevice(r->ctx->device));
   if (r->nposes_last != 1) return fail(RMCLHIP_ERR_INVALID, "computeCrossStatistics: last find was a batch");
-  uint32_t nb = 0;
+  ReduceTail tail;
+  tail.mode = kTailStats;
+  tail.stats_out = r->h_stats_dev;  // host-mapped: the last block writes the 64-B result straight to the host
   HIPCHK(hipEventRecord(r->ev0, r->stream));
-  if (rmclhip_status st = reduce_enqueue(r, to_x(T_snew_sold), nullptr, adaptive_max_dist(r, convergence_progress), 1, &nb))
+  if (rmclhip_status st = reduce_enqueue(r, to_x(T_snew_sold), nullptr, adaptive_max_dist(r, convergence_progress), 1, tail))
     return st;
-  HIPCHK(launch_reduce_finalize(r->d_partials.p, nb, 1, r->h_stats_dev, r->stream));
   HIPCHK(hipEventRecord(r->ev1, r->stream));
   HIPCHK(hipStreamSynchronize(r->stream));
   HIPCHK(hipEventElapsedTime(&r->last_reduce_ms, r->ev0, r->ev1));
@@ -541,6 +636,7 @@ rmclhip_status rmclhip_rcc_compute_cross_statistics(rmclhip_rcc* r, const rmclhi
 
 rmclhip_status rmclhip_rcc_download(rmclhip_rcc* r, uint8_t* hits, float* ranges, float* points, float* normals,
                                     uint32_t* face_ids) {
+  ApiGuard guard_("rmclhip_rcc_download");
   if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_download: null");
   HIPCHK(hipSetDevice(r->ctx->device));
   HIPCHK(hipStreamSynchronize(r->stream));
@@ -557,6 +653,7 @@ rmclhip_status rmclhip_rcc_download(rmclhip_rcc* r, uint8_t* hits, float* ranges
 rmclhip_status rmclhip_rcc_device_views(rmclhip_rcc* r, const uint8_t** hits, const float** ranges,
                                         const float** points, const float** normals, const uint32_t** face_ids,
                                         uint32_t* n) {
+  ApiGuard guard_("rmclhip_rcc_device_views");
   if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_device_views: null");
   if (hits) *hits = r->d_hits.p;
   if (ranges) *ranges = r->d_ranges.p;
@@ -570,6 +667,7 @@ rmclhip_status rmclhip_rcc_device_views(rmclhip_rcc* r, const uint8_t** hits, co
 rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform* Tom_, const rmclhip_transform* Tbo_,
                                         uint32_t n_iter, double convergence_progress, int refind_each_iteration,
                                         rmclhip_transform* T_out, rmclhip_cross_statistics* stats_out) {
+  ApiGuard guard_("rmclhip_rcc_correct_once");
   if (!r || !Tom_ || !Tbo_ || !T_out) return fail(RMCLHIP_ERR_INVALID, "correct_once: null");
   if (r->kind == kModelNone || r->W == 0 || r->H == 0) return fail(RMCLHIP_ERR_INVALID, "correct_once: no sensor model");
   HIPCHK(hipSetDevice(r->ctx->device));
@@ -578,14 +676,76 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
   if (!refind_each_iteration) {
     // schedule (R), micp_localization.cpp:900-964: 1 find, n_iter x (reduce + solve); nothing returns
     // to the host until the end: the pre-transform of iteration i+1 is produced on the device.
-    if (rmclhip_status st = find_enqueue(r, xmul(Tom, Tbo))) return st;
-    HIPCHK(launch_micp_init(r->d_state, r->stream));
-    for (uint32_t i = 0; i < n_iter; ++i) {
-      uint32_t nb = 0;
-      if (rmclhip_status st = reduce_enqueue(r, xidentity(), &r->d_state->T_snew_sold, maxd, 1, &nb)) return st;
-      HIPCHK(launch_micp_step(r->d_partials.p, nb, r->Tsb, Tbo, r->d_state, r->stream));
+    // The launch chain is captured ONCE into a hipGraph (the kernels read the per-call pose / frames /
+    // max_dist from d_call, refreshed by the graph's first node), so a correction costs one graph launch
+    // instead of 2 + 2*n_iter host launches (~5 us each, which left the GPU idle between these tiny kernels).
+    const size_t n = static_cast<size_t>(r->W) * r->H;
+    r->n_model = static_cast<uint32_t>(n);
+    r->nposes_last = 1;
+    if (rmclhip_status st = ensure_model_buffers(r, n)) return st;
+    const uint32_t nred = (r->n_dataset < r->n_model) ? r->n_dataset : r->n_model;
+    if (nred == 0) return fail(RMCLHIP_ERR_INVALID, "correct_once: empty dataset");
+    HIPCHK(r->d_partials.reserve(static_cast<size_t>(reduce_num_blocks(nred)) * 16));
+    {
+      ReduceTail none;  // allocates the ticket buffer outside the capture
+      (void)none;
+      if (r->tickets_cap < 1) {
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&r->d_tickets), sizeof(uint32_t)));
+        HIPCHK(hipMemset(r->d_tickets, 0, sizeof(uint32_t)));
+        r->tickets_cap = 1;
+      }
     }
-    HIPCHK(hipMemcpyAsync(r->h_state, r->d_state, sizeof(MicpState), hipMemcpyDeviceToHost, r->stream));
+    r->h_call->Tsm = xmul(xmul(Tom, Tbo), r->Tsb);
+    r->h_call->Tms = xinv(r->h_call->Tsm);
+    r->h_call->Tsb = r->Tsb;
+    r->h_call->Tbo = Tbo;
+    r->h_call->max_dist = maxd;
+    auto enqueue_chain = [&]() -> rmclhip_status {
+      HIPCHK(hipMemcpyAsync(r->d_call, r->h_call, sizeof(MicpCall), hipMemcpyHostToDevice, r->stream));
+      FindParams p;
+      fill_find_params(r, p, 1);
+      p.Tsm_arr = &r->d_call->Tsm;
+      p.Tms_arr = &r->d_call->Tms;
+      HIPCHK(launch_find(p, r->kind, r->variant, r->stream));
+      HIPCHK(launch_micp_init(r->d_state, r->stream));
+      for (uint32_t i = 0; i < n_iter; ++i) {
+        ReduceTail tail;
+        tail.mode = kTailMicp;
+        tail.Tbo = Tbo;
+        tail.state = r->d_state;
+        tail.call = r->d_call;
+        if (rmclhip_status st = reduce_enqueue(r, xidentity(), &r->d_state->T_snew_sold, maxd, 1, tail)) return st;
+      }
+      HIPCHK(hipMemcpyAsync(r->h_state, r->d_state, sizeof(MicpState), hipMemcpyDeviceToHost, r->stream));
+      return RMCLHIP_OK;
+    };
+    if (r->use_graph) {
+      rmclhip_rcc::MicpKey key;
+      std::memset(&key, 0, sizeof(key));
+      key.n_iter = n_iter; key.W = r->W; key.H = r->H; key.n_dataset = r->n_dataset;
+      key.kind = static_cast<int>(r->kind); key.variant = r->variant; key.tile = r->tile_override;
+      key.fused = r->fused_tail ? 1 : 0; key.has_mask = r->ds_has_mask ? 1 : 0;
+      key.ptrs[0] = r->d_points.p; key.ptrs[1] = r->d_ds_points.p; key.ptrs[2] = r->d_partials.p;
+      key.ptrs[3] = r->d_model_tab.p; key.ptrs[4] = r->d_ds_mask.p; key.ptrs[5] = r->d_hits.p;
+      if (!r->micp_exec || r->graph_dirty || !(key == r->micp_key)) {
+        if (r->micp_exec) { (void)hipGraphExecDestroy(r->micp_exec); r->micp_exec = nullptr; }
+        if (r->micp_graph) { (void)hipGraphDestroy(r->micp_graph); r->micp_graph = nullptr; }
+        HIPCHK(hipStreamSynchronize(r->stream));
+        HIPCHK(hipStreamBeginCapture(r->stream, hipStreamCaptureModeThreadLocal));
+        const rmclhip_status cst = enqueue_chain();
+        hipGraph_t g = nullptr;
+        const hipError_t ce = hipStreamEndCapture(r->stream, &g);
+        if (cst != RMCLHIP_OK) { if (g) (void)hipGraphDestroy(g); return cst; }
+        if (ce != hipSuccess) return fail(RMCLHIP_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+        r->micp_graph = g;
+        HIPCHK(hipGraphInstantiate(&r->micp_exec, g, nullptr, nullptr, 0));
+        r->micp_key = key;
+        r->graph_dirty = false;
+      }
+      HIPCHK(hipGraphLaunch(r->micp_exec, r->stream));
+    } else {
+      if (rmclhip_status st = enqueue_chain()) return st;
+    }
     HIPCHK(hipStreamSynchronize(r->stream));
     from_x(r->h_state->T_onew_oold, T_out);
     if (stats_out) from_cs(r->h_state->stats_o, stats_out);
@@ -597,9 +757,10 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
   for (uint32_t i = 0; i < n_iter; ++i) {
     const xform Tom_cur = xmul(Tom, T_onew_oold);
     if (rmclhip_status st = find_enqueue(r, xmul(Tom_cur, Tbo))) return st;
-    uint32_t nb = 0;
-    if (rmclhip_status st = reduce_enqueue(r, xidentity(), nullptr, maxd, 1, &nb)) return st;
-    HIPCHK(launch_reduce_finalize(r->d_partials.p, nb, 1, r->h_stats_dev, r->stream));
+    ReduceTail tail;
+    tail.mode = kTailStats;
+    tail.stats_out = r->h_stats_dev;
+    if (rmclhip_status st = reduce_enqueue(r, xidentity(), nullptr, maxd, 1, tail)) return st;
     HIPCHK(hipStreamSynchronize(r->stream));
     const cstats Cs_o = cs_transform(Tbo, cs_transform(r->Tsb, r->h_stats[0]));
     last = cs_merge(cs_identity(), Cs_o);
@@ -614,6 +775,7 @@ static rmclhip_status find_batch_enqueue(rmclhip_rcc* r, const rmclhip_transform
 
 rmclhip_status rmclhip_rcc_correct_batch(rmclhip_rcc* r, const rmclhip_transform* Tbm, uint32_t nposes,
                                          rmclhip_transform* Tdelta_out, rmclhip_cross_statistics* stats_out) {
+  ApiGuard guard_("rmclhip_rcc_correct_batch");
   if (!r || !Tbm || !Tdelta_out) return fail(RMCLHIP_ERR_INVALID, "correct_batch: null");
   if (nposes == 0) return RMCLHIP_OK;
   if (r->kind == kModelNone || r->W == 0 || r->H == 0) return fail(RMCLHIP_ERR_INVALID, "correct_batch: no sensor model");
@@ -623,9 +785,11 @@ rmclhip_status rmclhip_rcc_correct_batch(rmclhip_rcc* r, const rmclhip_transform
   if (r->n_dataset != n) return fail(RMCLHIP_ERR_INVALID, "correct_batch: dataset size != model size");
   HIPCHK(r->d_Tdelta.reserve(nposes)); HIPCHK(r->d_bstats.reserve(nposes));
   if (rmclhip_status st = find_batch_enqueue(r, Tbm, nposes)) return st;
-  uint32_t nb = 0;
-  if (rmclhip_status st = reduce_enqueue(r, xidentity(), nullptr, r->max_dist, nposes, &nb)) return st;
-  HIPCHK(launch_batch_solve(r->d_partials.p, nb, nposes, r->Tsb, r->d_Tdelta.p, r->d_bstats.p, r->stream));
+  ReduceTail tail;
+  tail.mode = kTailBatchSolve;
+  tail.Tdelta_out = r->d_Tdelta.p;
+  tail.stats_out = r->d_bstats.p;
+  if (rmclhip_status st = reduce_enqueue(r, xidentity(), nullptr, r->max_dist, nposes, tail)) return st;
   HIPCHK(hipMemcpyAsync(Tdelta_out, r->d_Tdelta.p, sizeof(xform) * nposes, hipMemcpyDeviceToHost, r->stream));
   if (stats_out)
     HIPCHK(hipMemcpyAsync(stats_out, r->d_bstats.p, sizeof(cstats) * nposes, hipMemcpyDeviceToHost, r->stream));
@@ -634,6 +798,7 @@ rmclhip_status rmclhip_rcc_correct_batch(rmclhip_rcc* r, const rmclhip_transform
 }
 
 rmclhip_status rmclhip_rcc_last_kernel_ms(rmclhip_rcc* r, float* find_ms, float* reduce_ms) {
+  ApiGuard guard_("rmclhip_rcc_last_kernel_ms");
   if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_last_kernel_ms: null");
   if (find_ms) *find_ms = r->last_find_ms;
   if (reduce_ms) *reduce_ms = r->last_reduce_ms;
@@ -641,6 +806,7 @@ rmclhip_status rmclhip_rcc_last_kernel_ms(rmclhip_rcc* r, float* find_ms, float*
 }
 
 rmclhip_status rmclhip_rcc_time_find(rmclhip_rcc* r, const rmclhip_transform* Tbm_est, uint32_t iters, float* ms) {
+  ApiGuard guard_("rmclhip_rcc_time_find");
   if (!r || !Tbm_est || !ms || iters == 0) return fail(RMCLHIP_ERR_INVALID, "rcc_time_find: bad arguments");
   if (r->kind == kModelNone || r->W == 0 || r->H == 0) return fail(RMCLHIP_ERR_INVALID, "rcc_time_find: no sensor model");
   HIPCHK(hipSetDevice(r->ctx->device));
@@ -659,17 +825,18 @@ rmclhip_status rmclhip_rcc_time_find(rmclhip_rcc* r, const rmclhip_transform* Tb
 }
 
 rmclhip_status rmclhip_rcc_time_reduce(rmclhip_rcc* r, const rmclhip_transform* Tpre, uint32_t iters, float* ms) {
+  ApiGuard guard_("rmclhip_rcc_time_reduce");
   if (!r || !Tpre || !ms || iters == 0) return fail(RMCLHIP_ERR_INVALID, "rcc_time_reduce: bad arguments");
   HIPCHK(hipSetDevice(r->ctx->device));
   const xform T = to_x(Tpre);
-  uint32_t nb = 0;
-  if (rmclhip_status st = reduce_enqueue(r, T, nullptr, r->max_dist, 1, &nb)) return st;
+  ReduceTail tail;
+  tail.mode = kTailStats;
+  tail.stats_out = r->h_stats_dev + 1;
+  if (rmclhip_status st = reduce_enqueue(r, T, nullptr, r->max_dist, 1, tail)) return st;
   HIPCHK(hipStreamSynchronize(r->stream));
   HIPCHK(hipEventRecord(r->ev0, r->stream));
-  for (uint32_t i = 0; i < iters; ++i) {
-    if (rmclhip_status st = reduce_enqueue(r, T, nullptr, r->max_dist, 1, &nb)) return st;
-    HIPCHK(launch_reduce_finalize(r->d_partials.p, nb, 1, r->h_stats_dev + 1, r->stream));
-  }
+  for (uint32_t i = 0; i < iters; ++i)
+    if (rmclhip_status st = reduce_enqueue(r, T, nullptr, r->max_dist, 1, tail)) return st;
   HIPCHK(hipEventRecord(r->ev1, r->stream));
   HIPCHK(hipStreamSynchronize(r->stream));
   float total = 0.f;
@@ -679,11 +846,15 @@ rmclhip_status rmclhip_rcc_time_reduce(rmclhip_rcc* r, const rmclhip_transform* 
 }
 
 rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
+  ApiGuard guard_("rmclhip_rcc_set_variant");
   if (!r || variant < 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: bad arguments");
   const int kind = variant & 0xF, tile = (variant >> 4) & 0xF;
-  if (kind > 1 || tile > 7) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
+  if (kind > 1 || tile > 7 || (variant >> 10) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
   r->variant = kind;
   r->tile_override = tile;
+  r->fused_tail = ((variant >> 8) & 1) != 0;
+  r->use_graph = ((variant >> 9) & 1) == 0;
+  r->graph_dirty = true;
   return RMCLHIP_OK;
 }
 
@@ -705,6 +876,7 @@ static rmclhip_status find_batch_enqueue(rmclhip_rcc* r, const rmclhip_transform
 }
 
 rmclhip_status rmclhip_rcc_find_batch(rmclhip_rcc* r, const rmclhip_transform* Tbm, uint32_t nposes) {
+  ApiGuard guard_("rmclhip_rcc_find_batch");
   if (!r || (!Tbm && nposes)) return fail(RMCLHIP_ERR_INVALID, "find_batch: null");
   if (nposes == 0 || r->kind == kModelNone || r->W == 0 || r->H == 0) return RMCLHIP_OK;
   HIPCHK(hipSetDevice(r->ctx->device));
@@ -715,6 +887,7 @@ rmclhip_status rmclhip_rcc_find_batch(rmclhip_rcc* r, const rmclhip_transform* T
 
 rmclhip_status rmclhip_rcc_time_find_batch(rmclhip_rcc* r, const rmclhip_transform* Tbm, uint32_t nposes,
                                            uint32_t iters, float* ms) {
+  ApiGuard guard_("rmclhip_rcc_time_find_batch");
   if (!r || !Tbm || !ms || iters == 0 || nposes == 0) return fail(RMCLHIP_ERR_INVALID, "time_find_batch: bad arguments");
   if (r->kind == kModelNone || r->W == 0 || r->H == 0) return fail(RMCLHIP_ERR_INVALID, "time_find_batch: no sensor model");
   HIPCHK(hipSetDevice(r->ctx->device));
@@ -736,6 +909,7 @@ rmclhip_status rmclhip_rcc_time_find_batch(rmclhip_rcc* r, const rmclhip_transfo
 
 // ---- host-side algebra ---------------------------------------------------------------------------
 rmclhip_status rmclhip_umeyama_transform(const rmclhip_cross_statistics* s, rmclhip_transform* out) {
+  ApiGuard guard_("rmclhip_umeyama_transform");
   if (!s || !out) return fail(RMCLHIP_ERR_INVALID, "umeyama_transform: null");
   from_x(umeyama(to_cs(s)), out);
   return RMCLHIP_OK;
@@ -743,6 +917,7 @@ rmclhip_status rmclhip_umeyama_transform(const rmclhip_cross_statistics* s, rmcl
 
 rmclhip_status rmclhip_cross_statistics_merge(const rmclhip_cross_statistics* a, const rmclhip_cross_statistics* b,
                                               rmclhip_cross_statistics* out) {
+  ApiGuard guard_("rmclhip_cross_statistics_merge");
   if (!a || !b || !out) return fail(RMCLHIP_ERR_INVALID, "cross_statistics_merge: null");
   from_cs(cs_merge(to_cs(a), to_cs(b)), out);
   return RMCLHIP_OK;
@@ -750,18 +925,21 @@ rmclhip_status rmclhip_cross_statistics_merge(const rmclhip_cross_statistics* a,
 
 rmclhip_status rmclhip_cross_statistics_transform(const rmclhip_transform* T, const rmclhip_cross_statistics* s,
                                                   rmclhip_cross_statistics* out) {
+  ApiGuard guard_("rmclhip_cross_statistics_transform");
   if (!T || !s || !out) return fail(RMCLHIP_ERR_INVALID, "cross_statistics_transform: null");
   from_cs(cs_transform(to_x(T), to_cs(s)), out);
   return RMCLHIP_OK;
 }
 
 rmclhip_status rmclhip_transform_mult(const rmclhip_transform* a, const rmclhip_transform* b, rmclhip_transform* out) {
+  ApiGuard guard_("rmclhip_transform_mult");
   if (!a || !b || !out) return fail(RMCLHIP_ERR_INVALID, "transform_mult: null");
   from_x(xmul(to_x(a), to_x(b)), out);
   return RMCLHIP_OK;
 }
 
 rmclhip_status rmclhip_transform_inv(const rmclhip_transform* a, rmclhip_transform* out) {
+  ApiGuard guard_("rmclhip_transform_inv");
   if (!a || !out) return fail(RMCLHIP_ERR_INVALID, "transform_inv: null");
   from_x(xinv(to_x(a)), out);
   return RMCLHIP_OK;
@@ -769,6 +947,7 @@ rmclhip_status rmclhip_transform_inv(const rmclhip_transform* a, rmclhip_transfo
 
 // ---- particle filter -------------------------------------------------------------------------------
 rmclhip_status rmclhip_pf_create(rmclhip_ctx* ctx, rmclhip_map* map, rmclhip_pf** out) {
+  ApiGuard guard_("rmclhip_pf_create");
   if (!out) return fail(RMCLHIP_ERR_INVALID, "pf_create: out is null");
   *out = nullptr;
   if (!ctx || !map) return fail(RMCLHIP_ERR_INVALID, "pf_create: NO MAP");
@@ -789,6 +968,7 @@ rmclhip_status rmclhip_pf_create(rmclhip_ctx* ctx, rmclhip_map* map, rmclhip_pf*
 }
 
 void rmclhip_pf_destroy(rmclhip_pf* f) {
+  ApiGuard guard_("rmclhip_pf_destroy");
   if (!f) return;
   (void)hipSetDevice(f->ctx->device);
   if (f->stream) (void)hipStreamSynchronize(f->stream);
@@ -802,6 +982,7 @@ void rmclhip_pf_destroy(rmclhip_pf* f) {
 }
 
 rmclhip_status rmclhip_pf_set_params(rmclhip_pf* f, const rmclhip_pf_params* p) {
+  ApiGuard guard_("rmclhip_pf_set_params");
   if (!f || !p) return fail(RMCLHIP_ERR_INVALID, "pf_set_params: null");
   if (!(p->dist_sigma > 0.f)) return fail(RMCLHIP_ERR_INVALID, "pf_set_params: dist_sigma must be > 0");
   f->params = *p;
@@ -809,6 +990,7 @@ rmclhip_status rmclhip_pf_set_params(rmclhip_pf* f, const rmclhip_pf_params* p) 
 }
 
 rmclhip_status rmclhip_pf_set_error_output(rmclhip_pf* f, float* errors_dev) {
+  ApiGuard guard_("rmclhip_pf_set_error_output");
   if (!f) return fail(RMCLHIP_ERR_INVALID, "pf_set_error_output: null");
   f->errors_dev = errors_dev;
   return RMCLHIP_OK;
@@ -866,6 +1048,7 @@ static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, 
 rmclhip_status rmclhip_pf_update_async(rmclhip_pf* f, const rmclhip_transform* poses, rmclhip_particle_attributes* attrs,
                                        uint32_t n, const rmclhip_range_measurement* beams, uint32_t n_beams,
                                        const rmclhip_transform* Tsb) {
+  ApiGuard guard_("rmclhip_pf_update_async");
   if (!f || !Tsb) return fail(RMCLHIP_ERR_INVALID, "pf_update: null");
   if (n == 0 || n_beams == 0) return RMCLHIP_OK;
   if (!poses || !attrs || !beams) return fail(RMCLHIP_ERR_INVALID, "pf_update: null buffers");
@@ -877,12 +1060,14 @@ rmclhip_status rmclhip_pf_update_async(rmclhip_pf* f, const rmclhip_transform* p
 rmclhip_status rmclhip_pf_update(rmclhip_pf* f, const rmclhip_transform* poses, rmclhip_particle_attributes* attrs,
                                  uint32_t n, const rmclhip_range_measurement* beams, uint32_t n_beams,
                                  const rmclhip_transform* Tsb) {
+  ApiGuard guard_("rmclhip_pf_update");
   if (rmclhip_status st = rmclhip_pf_update_async(f, poses, attrs, n, beams, n_beams, Tsb)) return st;
   HIPCHK(hipStreamSynchronize(f->stream));
   return RMCLHIP_OK;
 }
 
 rmclhip_status rmclhip_pf_sync(rmclhip_pf* f) {
+  ApiGuard guard_("rmclhip_pf_sync");
   if (!f) return fail(RMCLHIP_ERR_INVALID, "pf_sync: null");
   HIPCHK(hipSetDevice(f->ctx->device));
   HIPCHK(hipStreamSynchronize(f->stream));
@@ -891,6 +1076,7 @@ rmclhip_status rmclhip_pf_sync(rmclhip_pf* f) {
 
 rmclhip_status rmclhip_pf_extract_weights(rmclhip_pf* f, const rmclhip_particle_attributes* attrs, uint32_t n,
                                           float* weights_dev) {
+  ApiGuard guard_("rmclhip_pf_extract_weights");
   if (!f || (!attrs && n) || (!weights_dev && n)) return fail(RMCLHIP_ERR_INVALID, "pf_extract_weights: null");
   HIPCHK(hipSetDevice(f->ctx->device));
   HIPCHK(launch_pf_extract_weights(attrs, n, weights_dev, f->stream));
@@ -901,6 +1087,7 @@ rmclhip_status rmclhip_pf_extract_weights(rmclhip_pf* f, const rmclhip_particle_
 rmclhip_status rmclhip_pf_time_update(rmclhip_pf* f, const rmclhip_transform* poses, rmclhip_particle_attributes* attrs,
                                       uint32_t n, const rmclhip_range_measurement* beams, uint32_t n_beams,
                                       const rmclhip_transform* Tsb, uint32_t iters, float* ms) {
+  ApiGuard guard_("rmclhip_pf_time_update");
   if (!f || !ms || iters == 0 || !Tsb || !poses || !attrs || !beams || n == 0 || n_beams == 0)
     return fail(RMCLHIP_ERR_INVALID, "pf_time_update: bad arguments");
   HIPCHK(hipSetDevice(f->ctx->device));
@@ -919,6 +1106,7 @@ rmclhip_status rmclhip_pf_time_update(rmclhip_pf* f, const rmclhip_transform* po
 }
 
 rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* f, int variant) {
+  ApiGuard guard_("rmclhip_pf_set_variant");
   if (!f || variant < 0 || variant > 1) return fail(RMCLHIP_ERR_INVALID, "pf_set_variant: bad arguments");
   f->variant = variant;
   return RMCLHIP_OK;
@@ -926,6 +1114,7 @@ rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* f, int variant) {
 
 // ---- device memory helpers ---------------------------------------------------------------------------
 rmclhip_status rmclhip_malloc(rmclhip_ctx* ctx, size_t bytes, void** out) {
+  ApiGuard guard_("rmclhip_malloc");
   if (!ctx || !out) return fail(RMCLHIP_ERR_INVALID, "malloc: null");
   HIPCHK(hipSetDevice(ctx->device));
   hipError_t e = hipMalloc(out, bytes ? bytes : 1);
@@ -935,6 +1124,7 @@ rmclhip_status rmclhip_malloc(rmclhip_ctx* ctx, size_t bytes, void** out) {
 }
 
 rmclhip_status rmclhip_free(rmclhip_ctx* ctx, void* p) {
+  ApiGuard guard_("rmclhip_free");
   if (!ctx) return fail(RMCLHIP_ERR_INVALID, "free: null ctx");
   if (!p) return RMCLHIP_OK;
   HIPCHK(hipSetDevice(ctx->device));
@@ -943,6 +1133,7 @@ rmclhip_status rmclhip_free(rmclhip_ctx* ctx, void* p) {
 }
 
 rmclhip_status rmclhip_memcpy_h2d(rmclhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  ApiGuard guard_("rmclhip_memcpy_h2d");
   if (!ctx || (bytes && (!dst || !src))) return fail(RMCLHIP_ERR_INVALID, "memcpy_h2d: null");
   HIPCHK(hipSetDevice(ctx->device));
   if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
@@ -950,6 +1141,7 @@ rmclhip_status rmclhip_memcpy_h2d(rmclhip_ctx* ctx, void* dst, const void* src, 
 }
 
 rmclhip_status rmclhip_memcpy_d2h(rmclhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  ApiGuard guard_("rmclhip_memcpy_d2h");
   if (!ctx || (bytes && (!dst || !src))) return fail(RMCLHIP_ERR_INVALID, "memcpy_d2h: null");
   HIPCHK(hipSetDevice(ctx->device));
   if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));

@@ -36,6 +36,10 @@ struct FindParams {
   uint32_t* face_ids;
 };
 
+struct MicpState;
+struct MicpCall;
+enum TailMode : uint32_t { kTailNone = 0, kTailStats = 1, kTailMicp = 2, kTailBatchSolve = 3 };
+
 struct ReduceParams {
   const float* dataset_points;
   const uint8_t* dataset_mask;   // nullable
@@ -45,10 +49,18 @@ struct ReduceParams {
   uint32_t n;                    // elements per pose
   uint32_t nposes;               // model buffers hold nposes*n elements; dataset is shared
   float max_dist;
+  const MicpCall* call;          // nullable: when set, max_dist / Tsb / Tbo are read from it (graph replay)
   xform Tpre;                    // used when Tpre_dev == nullptr
   const xform* Tpre_dev;         // per-pose pre-transform (device), nullable
   double* partials;              // [nposes][nblocks][16]
   uint32_t nblocks;
+  // fused tail executed by the last block of each pose (kTailNone: partials only)
+  uint32_t tail_mode;
+  uint32_t* tickets;             // [nposes], zero before the first launch; re-armed by the kernel
+  cstats* stats_out;             // kTailStats / kTailBatchSolve (nullable there)
+  xform Tsb, Tbo;                // kTailMicp / kTailBatchSolve
+  MicpState* state;              // kTailMicp
+  xform* Tdelta_out;             // kTailBatchSolve
 };
 
 struct PfParams {
@@ -64,6 +76,15 @@ struct PfParams {
   uint32_t max_n_meas;
   float* errors;                 // nullable [n_particles*n_beams]
   uint32_t particles_per_block;
+};
+
+// per-call inputs of the device-resident MICP loop: written by ONE H2D copy so that the whole loop can be a
+// static hipGraph (kernel arguments never change between replays)
+struct MicpCall {
+  xform Tsm, Tms;   // find pose: Tom * Tbo * Tsb and its inverse
+  xform Tsb, Tbo;
+  float max_dist;
+  uint32_t pad[7];
 };
 
 // MICP-L inner-loop state kept on the device between launches (correct_once)
@@ -82,8 +103,8 @@ hipError_t launch_reduce_partials(const ReduceParams& p, hipStream_t s);
 hipError_t launch_reduce_finalize(const double* partials, uint32_t nblocks, uint32_t nposes, cstats* out,
                                   hipStream_t s);
 // finalize + (Tsb*, Tbo*) + umeyama + compose; advances MicpState on the device
-hipError_t launch_micp_step(const double* partials, uint32_t nblocks, xform Tsb, xform Tbo, MicpState* state,
-                            hipStream_t s);
+hipError_t launch_micp_step(const double* partials, uint32_t nblocks, xform Tsb, xform Tbo, const MicpCall* call,
+                            MicpState* state, hipStream_t s);
 hipError_t launch_micp_init(MicpState* state, hipStream_t s);
 // batch: per pose finalize + umeyama -> Tdelta (sensor->base conjugated), stats
 hipError_t launch_batch_solve(const double* partials, uint32_t nblocks, uint32_t nposes, xform Tsb,

@@ -310,10 +310,64 @@ __global__ void k_compose_poses(const xform* __restrict__ Tbm, xform Tsb, xform*
 // ---------------------------------------------------------------------------------------------
 constexpr int kAcc = 16;  // sd[3] sm[3] smd[9] cnt
 
+// sum the per-block partials of one pose (one wave) and turn the raw moments into CrossStatistics
+template <bool kAgentLoads = false>
+__device__ __forceinline__ cstats finalize_pose(const double* partials, uint32_t nblocks) {
+  const uint32_t lane = threadIdx.x & 63u;
+  double acc[kAcc];
+#pragma unroll
+  for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
+  for (uint32_t b = lane; b < nblocks; b += 64u) {
+#pragma unroll
+    for (int k = 0; k < kAcc; ++k) {
+      const double* q = partials + static_cast<size_t>(b) * kAcc + k;
+      acc[k] += kAgentLoads ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kAcc; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    acc[k] = v;
+  }
+  cstats s = cs_identity();
+  const double n = acc[15];
+  if (n > 0.0) {
+    const double md[3] = {acc[0] / n, acc[1] / n, acc[2] / n};
+    const double mm[3] = {acc[3] / n, acc[4] / n, acc[5] / n};
+    s.dataset_mean = mk3(static_cast<float>(md[0]), static_cast<float>(md[1]), static_cast<float>(md[2]));
+    s.model_mean = mk3(static_cast<float>(mm[0]), static_cast<float>(mm[1]), static_cast<float>(mm[2]));
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) s.covariance[3 * r + c] = static_cast<float>(acc[6 + 3 * r + c] / n - mm[r] * md[c]);
+    s.n_meas = static_cast<uint32_t>(n);
+  }
+  return s;
+}
+
+
+// one MICP inner iteration from the reduced statistics, executed by ONE lane
+// micp_localization.cpp:915-964 for one sensor (merge_weight_multiplier == 1):
+//   Cs_b = Tsb * stats_s (MICPSensor.hpp:182); Cs_o = Tbo * Cs_b (:931); Cmerged = Identity += Cs_o (:936)
+//   T_inner = umeyama(Cmerged) (:952); T_onew_oold = T_onew_oold * T_inner (:963)
+//   next T_bnew_bold = ~Tbo * T_onew_oold * Tbo (:926); T_snew_sold = ~Tsb * T_bnew_bold * Tsb (MICPSensor.hpp:178)
+__device__ __forceinline__ void micp_advance(const cstats& stats_s, const xform& Tsb, const xform& Tbo, MicpState* st) {
+  const cstats Cs_b = cs_transform(Tsb, stats_s);
+  const cstats Cs_o = cs_transform(Tbo, Cs_b);
+  const cstats Cmerged = cs_merge(cs_identity(), Cs_o);
+  const xform T_inner = umeyama(Cmerged);
+  const xform T_onew_oold = xmul(st->T_onew_oold, T_inner);
+  const xform T_bnew_bold = xmul(xmul(xinv(Tbo), T_onew_oold), Tbo);
+  st->T_onew_oold = T_onew_oold;
+  st->T_snew_sold = xmul(xmul(xinv(Tsb), T_bnew_bold), Tsb);
+  st->stats_o = Cmerged;
+}
+
 __global__ void __launch_bounds__(256) k_reduce_partials(const ReduceParams p) {
   __shared__ double red[4][kAcc];
   const uint32_t pose = blockIdx.y;
   const xform Tpre = (p.Tpre_dev != nullptr) ? p.Tpre_dev[pose] : p.Tpre;
+  const float max_dist = (p.call != nullptr) ? p.call->max_dist : p.max_dist;
   double acc[kAcc];
 #pragma unroll
   for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
@@ -328,7 +382,7 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const ReduceParams p) {
       const f3 Ii = mk3(mp[0], mp[1], mp[2]);
       const f3 Ni = mk3(mn[0], mn[1], mn[2]);
       const float spd = dot_plain(sub3(Ii, Di), Ni);
-      if (fabsf(spd) < p.max_dist) {
+      if (fabsf(spd) < max_dist) {
         const f3 Mi = add3(Di, scale3(Ni, spd));
         const double d[3] = {Di.x, Di.y, Di.z}, m[3] = {Mi.x, Mi.y, Mi.z};
 #pragma unroll
@@ -357,39 +411,39 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const ReduceParams p) {
   __syncthreads();
   if (threadIdx.x < kAcc) {
     const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-    p.partials[(static_cast<size_t>(pose) * p.nblocks + blockIdx.x) * kAcc + threadIdx.x] = v;
+    // agent-scope relaxed store = write-through (sc1) 8-B store: visible to the last arriver without an L2
+    // write-back fence (MI355X_MICROARCH.md, hand-off forms)
+    __hip_atomic_store(p.partials + (static_cast<size_t>(pose) * p.nblocks + blockIdx.x) * kAcc + threadIdx.x, v,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-}
-
-// sum the per-block partials of one pose (one wave) and turn the raw moments into CrossStatistics
-__device__ __forceinline__ cstats finalize_pose(const double* __restrict__ partials, uint32_t nblocks) {
-  const uint32_t lane = threadIdx.x & 63u;
-  double acc[kAcc];
-#pragma unroll
-  for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
-  for (uint32_t b = lane; b < nblocks; b += 64u) {
-#pragma unroll
-    for (int k = 0; k < kAcc; ++k) acc[k] += partials[static_cast<size_t>(b) * kAcc + k];
+  if (p.tail_mode == kTailNone) return;
+  // ---- fused tail: the LAST block of this pose to arrive finalizes.  Hand-off without fences: write-through
+  // (sc1) partial stores -> every wave s_waitcnt vmcnt(0) -> barrier -> relaxed agent-scope ticket; the last
+  // arriver reads the partials with sc1 loads (L1-bypassing).  A release fence per block (256 x buffer_wbl2)
+  // measured SLOWER than the kernel boundary it replaces (reduce 14.5 us vs 10.7 us for two launches).
+  __shared__ uint32_t s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t ticket = __hip_atomic_fetch_add(p.tickets + pose, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (ticket == gridDim.x - 1u) ? 1u : 0u;
   }
-#pragma unroll
-  for (int k = 0; k < kAcc; ++k) {
-    double v = acc[k];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    acc[k] = v;
+  __syncthreads();
+  if (s_last == 0u) return;
+  if (threadIdx.x >= 64u) return;
+  const cstats st = finalize_pose<true>(p.partials + static_cast<size_t>(pose) * p.nblocks * kAcc, p.nblocks);
+  if (threadIdx.x == 0) {
+    p.tickets[pose] = 0u;  // re-armed for the next launch on this stream
+    if (p.tail_mode == kTailStats) {
+      p.stats_out[pose] = st;
+    } else if (p.tail_mode == kTailMicp) {
+      micp_advance(st, p.call ? p.call->Tsb : p.Tsb, p.call ? p.call->Tbo : p.Tbo, p.state);
+    } else {  // kTailBatchSolve: v1 corrector, Tdelta_b = Tsb * T_s * ~Tsb
+      const xform Ts = umeyama(st);
+      p.Tdelta_out[pose] = xmul(xmul(p.Tsb, Ts), xinv(p.Tsb));
+      if (p.stats_out) p.stats_out[pose] = st;
+    }
   }
-  cstats s = cs_identity();
-  const double n = acc[15];
-  if (n > 0.0) {
-    const double md[3] = {acc[0] / n, acc[1] / n, acc[2] / n};
-    const double mm[3] = {acc[3] / n, acc[4] / n, acc[5] / n};
-    s.dataset_mean = mk3(static_cast<float>(md[0]), static_cast<float>(md[1]), static_cast<float>(md[2]));
-    s.model_mean = mk3(static_cast<float>(mm[0]), static_cast<float>(mm[1]), static_cast<float>(mm[2]));
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) s.covariance[3 * r + c] = static_cast<float>(acc[6 + 3 * r + c] / n - mm[r] * md[c]);
-    s.n_meas = static_cast<uint32_t>(n);
-  }
-  return s;
 }
 
 __global__ void __launch_bounds__(64) k_reduce_finalize(const double* __restrict__ partials, uint32_t nblocks,
@@ -407,24 +461,11 @@ __global__ void k_micp_init(MicpState* st) {
   }
 }
 
-// micp_localization.cpp:915-964 for one sensor (merge_weight_multiplier == 1):
-//   Cs_b = Tsb * stats_s (MICPSensor.hpp:182); Cs_o = Tbo * Cs_b (:931); Cmerged = Identity += Cs_o (:936)
-//   T_inner = umeyama(Cmerged) (:952); T_onew_oold = T_onew_oold * T_inner (:963)
-//   next T_bnew_bold = ~Tbo * T_onew_oold * Tbo (:926); T_snew_sold = ~Tsb * T_bnew_bold * Tsb (MICPSensor.hpp:178)
+// unfused form of the MICP step (kept for A/B against the fused tail of k_reduce_partials)
 __global__ void __launch_bounds__(64) k_micp_step(const double* __restrict__ partials, uint32_t nblocks, xform Tsb,
-                                                  xform Tbo, MicpState* st) {
+                                                  xform Tbo, const MicpCall* call, MicpState* st) {
   const cstats stats_s = finalize_pose(partials, nblocks);
-  if (threadIdx.x == 0) {
-    const cstats Cs_b = cs_transform(Tsb, stats_s);
-    const cstats Cs_o = cs_transform(Tbo, Cs_b);
-    const cstats Cmerged = cs_merge(cs_identity(), Cs_o);
-    const xform T_inner = umeyama(Cmerged);
-    const xform T_onew_oold = xmul(st->T_onew_oold, T_inner);
-    const xform T_bnew_bold = xmul(xmul(xinv(Tbo), T_onew_oold), Tbo);
-    st->T_onew_oold = T_onew_oold;
-    st->T_snew_sold = xmul(xmul(xinv(Tsb), T_bnew_bold), Tsb);
-    st->stats_o = Cmerged;
-  }
+  if (threadIdx.x == 0) micp_advance(stats_s, call ? call->Tsb : Tsb, call ? call->Tbo : Tbo, st);
 }
 
 // stale v1 corrector (lidar_corrector_embree_benchmark.cpp:127-135): per pose, Tdelta_b = Tsb * T_s * ~Tsb
@@ -611,9 +652,9 @@ hipError_t launch_micp_init(MicpState* state, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_micp_step(const double* partials, uint32_t nblocks, xform Tsb, xform Tbo, MicpState* state,
-                            hipStream_t s) {
-  hipLaunchKernelGGL(k_micp_step, dim3(1), dim3(64), 0, s, partials, nblocks, Tsb, Tbo, state);
+hipError_t launch_micp_step(const double* partials, uint32_t nblocks, xform Tsb, xform Tbo, const MicpCall* call,
+                            MicpState* state, hipStream_t s) {
+  hipLaunchKernelGGL(k_micp_step, dim3(1), dim3(64), 0, s, partials, nblocks, Tsb, Tbo, call, state);
   return hipGetLastError();
 }
 
