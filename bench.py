@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--variant", type=int, default=0, help="0 packet traversal, 1 per-lane traversal")
+    ap.add_argument("--variant", type=int, default=1, help="find traversal: 1 per-lane while-while (default), 0 wave-packet")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extras", action="store_true", help="also time C3 (MICP loop), batch and C4 (particle filter)")
     args = ap.parse_args()

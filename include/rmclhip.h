@@ -197,8 +197,9 @@ rmclhip_status rmclhip_rcc_time_find(rmclhip_rcc* rcc, const rmclhip_transform* 
                                      float* ms_per_launch);
 rmclhip_status rmclhip_rcc_time_reduce(rmclhip_rcc* rcc, const rmclhip_transform* T_snew_sold, uint32_t iters,
                                        float* ms_per_launch);
-/* kernel variant selection: bits 0..3 traversal (0 = wave-packet, 1 = per-lane),
- * bits 4..7 = 1 + log2(tile width) of the wave's scan-image tile (0 = automatic, 8x8 for tall images) */
+/* kernel variant selection: bits 0..3 traversal (1 = per-lane while-while, the default;
+ * 0 = wave-packet), bits 4..7 = 1 + log2(tile width) of the wave's scan-image tile (0 = automatic, 8x8 for
+ * tall images), bit 8 = fused last-block reduction tail (A/B), bit 9 = disable the hipGraph MICP loop (A/B) */
 rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* rcc, int variant);
 /* rm::Simulator::simulate(Memory<Transform>, Bundle&) (batch form, lidar_corrector_embree_benchmark.cpp:117):
  * one launch for nposes x H x W rays; model buffers become pose-major [pose][vid][hid]. */

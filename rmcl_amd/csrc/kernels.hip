@@ -219,6 +219,82 @@ __device__ __forceinline__ void trace_lane(const uint32_t* __restrict__ nodes, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// per-lane traversal, "while-while" form (Aila & Laine): every lane first descends through inner nodes
+// until it holds a leaf; only then does the wave run the (expensive) triangle tests, with most lanes
+// active.  kScratchStack: the per-lane stack lives in private (scratch) memory instead of LDS, which frees
+// the LDS for occupancy (a 64-deep LDS stack costs 64 KB per 256-thread block = 2 blocks per CU).
+// ---------------------------------------------------------------------------------------------
+template <bool kScratchStack>
+__device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris,
+                                              f3 O, f3 D, float ray_tfar, uint32_t* __restrict__ lds_stack,
+                                              uint32_t lds_stride, RayHit& h) {
+  const f3 inv = mk3(safe_inv(D.x), safe_inv(D.y), safe_inv(D.z));
+  const f3 noi = mk3(-(O.x * inv.x), -(O.y * inv.y), -(O.z * inv.z));
+  float best_t = ray_tfar;
+  uint32_t best_face = kInvalidFace, best_rec = 0;
+  constexpr uint32_t kDone = 0x7FFFFFFFu;
+  uint32_t priv[kScratchStack ? 64 : 1];
+  uint32_t sp = 0;
+  uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
+#define RMCL_PUSH(v) { if (kScratchStack) priv[sp] = (v); else lds_stack[sp * lds_stride] = (v); ++sp; }
+#define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; cur = kScratchStack ? priv[sp] : lds_stack[sp * lds_stride]; } }
+  while (__any(cur != kDone)) {
+    // phase 1: inner nodes
+    while ((cur != kDone) && !(cur & kLeafBit)) {
+      const uint4* np = reinterpret_cast<const uint4*>(nodes) + static_cast<size_t>(cur) * 8u;
+      const uint4 qmnx = np[0], qmny = np[1], qmnz = np[2], qmxx = np[3], qmxy = np[4], qmxz = np[5], qch = np[6];
+      const uint32_t amnx[4] = {qmnx.x, qmnx.y, qmnx.z, qmnx.w}, amny[4] = {qmny.x, qmny.y, qmny.z, qmny.w};
+      const uint32_t amnz[4] = {qmnz.x, qmnz.y, qmnz.z, qmnz.w}, amxx[4] = {qmxx.x, qmxx.y, qmxx.z, qmxx.w};
+      const uint32_t amxy[4] = {qmxy.x, qmxy.y, qmxy.z, qmxy.w}, amxz[4] = {qmxz.x, qmxz.y, qmxz.z, qmxz.w};
+      uint32_t ref[4] = {qch.x, qch.y, qch.z, qch.w};
+      uint32_t key[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float tn, tf;
+        slab(asf(amnx[c]), asf(amny[c]), asf(amnz[c]), asf(amxx[c]), asf(amxy[c]), asf(amxz[c]), inv, noi, best_t, tn, tf);
+        key[c] = ((tn <= tf) && (ref[c] != kEmptyRef)) ? __float_as_uint(tn) : kNone;
+      }
+      RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
+      if (key[3] != kNone) RMCL_PUSH(ref[3])
+      if (key[2] != kNone) RMCL_PUSH(ref[2])
+      if (key[1] != kNone) RMCL_PUSH(ref[1])
+      if (key[0] != kNone) cur = ref[0];
+      else RMCL_POP()
+    }
+    // phase 2: this lane's leaf (if any)
+    if (cur != kDone) {
+      const uint32_t first = cur & 0x0FFFFFFFu;
+      const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
+      for (uint32_t i = 0; i < cnt; ++i) {
+        const uint4* tp = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(first + i) * 4u;
+        const uint4 a = tp[0], b = tp[1], c = tp[2], d = tp[3];
+        const f3 v0 = mk3(asf(a.x), asf(a.y), asf(a.z));
+        const f3 e1 = mk3(asf(a.w), asf(b.x), asf(b.y));
+        const f3 e2 = mk3(asf(b.z), asf(b.w), asf(c.x));
+        const f3 Ng = mk3(asf(c.y), asf(c.z), asf(c.w));
+        const uint32_t face = d.w;
+        float Tt, aden;
+        const bool ok = tri_accept(v0, e1, e2, Ng, O, D, Tt, aden);
+        if (ok) {
+          const float t = Tt / aden;
+          const bool acc = (t >= 0.0f) && (t <= ray_tfar);
+          const bool closer = acc && ((t < best_t) || ((t == best_t) && (face < best_face)));
+          best_t = closer ? t : best_t;
+          best_face = closer ? face : best_face;
+          best_rec = closer ? (first + i) : best_rec;
+        }
+      }
+      RMCL_POP()
+    }
+  }
+#undef RMCL_PUSH
+#undef RMCL_POP
+  h.t = best_t;
+  h.face = best_face;
+  h.rec = best_rec;
+}
+
+// ---------------------------------------------------------------------------------------------
 // find
 // ---------------------------------------------------------------------------------------------
 template <uint32_t kModel, bool kPacket>
@@ -265,7 +341,7 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   if (kPacket) {
     trace_packet((cu32p)(p.nodes), (cu32p)(p.tris), org_m, dir_m, ray_tfar, lane, h);
   } else {
-    trace_lane(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
+    trace_lane_ww<true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, nullptr, 0u, h);
   }
 
   if (!valid) return;
@@ -524,12 +600,15 @@ __device__ __forceinline__ g1d g1d_add(g1d a, g1d b) {
   return r;
 }
 
-template <int kStackDepth>
+// kTrav: 0 = while-while traversal, per-lane stack in scratch (no LDS stack; default)
+//        1 = while-while traversal, per-lane stack in LDS
+//        2 = original single-loop traversal, stack in LDS (A/B)
+template <int kStackDepth, int kTrav>
 __global__ void __launch_bounds__(256) k_pf_update(const PfParams p) {
-  // LDS: [ per-lane stacks kStackDepth*256 | Tsm (PB xforms) | evals (PB*n_beams floats) ]
+  // LDS: [ per-lane stacks kStackDepth*256 (kTrav != 0) | Tsm (PB xforms) | evals (PB*n_beams floats) ]
   extern __shared__ uint32_t lds_dyn[];
   uint32_t* stacks = lds_dyn;
-  xform* s_Tsm = reinterpret_cast<xform*>(lds_dyn + kStackDepth * 256);
+  xform* s_Tsm = reinterpret_cast<xform*>(lds_dyn + (kTrav == 0 ? 0 : kStackDepth * 256));
   float* s_eval = reinterpret_cast<float*>(s_Tsm + p.particles_per_block);
 
   const uint32_t PB = p.particles_per_block;
@@ -553,7 +632,10 @@ __global__ void __launch_bounds__(256) k_pf_update(const PfParams p) {
     const float range = bm[6];
     const bool finite = (dir.x == dir.x) && (dir.y == dir.y) && (dir.z == dir.z);
     RayHit h;
-    trace_lane(p.nodes, p.tris, org, dir, (live && finite) ? __builtin_inff() : -1.0f, stacks + threadIdx.x, 256u, h);
+    const float rtf = (live && finite) ? __builtin_inff() : -1.0f;
+    if (kTrav == 0) trace_lane_ww<true>(p.nodes, p.tris, org, dir, rtf, nullptr, 0u, h);
+    else if (kTrav == 1) trace_lane_ww<false>(p.nodes, p.tris, org, dir, rtf, stacks + threadIdx.x, 256u, h);
+    else trace_lane(p.nodes, p.tris, org, dir, rtf, stacks + threadIdx.x, 256u, h);
     if (live) {
       // evaluate_rcc (PCDSensorUpdaterEmbree.cpp:18-86) with unit face normals (BeamEvaluateProgram.cu:104-113)
       const bool real_hit = (range >= p.range_min) && (range <= p.range_max);
@@ -613,8 +695,8 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
   if (variant == 0) {  // packet traversal (needs map stack_need <= 64, checked by the caller)
     if (kind == kModelSpherical) hipLaunchKernelGGL((k_find<kModelSpherical, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((k_find<kModelO1Dn, true>), grid, block, 0, s, p);
-  } else {             // per-lane traversal, 64-deep LDS stack
-    const size_t lds = 64u * 256u * sizeof(uint32_t);
+  } else {             // per-lane while-while traversal, stack in scratch
+    const size_t lds = 0;
     if (kind == kModelSpherical) hipLaunchKernelGGL((k_find<kModelSpherical, false>), grid, block, lds, s, p);
     else hipLaunchKernelGGL((k_find<kModelO1Dn, false>), grid, block, lds, s, p);
   }
@@ -677,13 +759,15 @@ hipError_t launch_pf_update(const PfParams& p, int variant, hipStream_t s) {
   const uint32_t nblocks = (p.n_particles + p.particles_per_block - 1u) / p.particles_per_block;
   const size_t tail = sizeof(xform) * p.particles_per_block +
                       sizeof(float) * static_cast<size_t>(p.particles_per_block) * p.n_beams;
-  if (variant == 1) {
-    const size_t lds = 64u * 256u * sizeof(uint32_t) + tail;
-    hipLaunchKernelGGL((k_pf_update<64>), dim3(nblocks), dim3(256), lds, s, p);
-  } else {
-    const size_t lds = 32u * 256u * sizeof(uint32_t) + tail;
-    hipLaunchKernelGGL((k_pf_update<32>), dim3(nblocks), dim3(256), lds, s, p);
-  }
+  const int trav = variant & 3;        // see k_pf_update
+  const bool deep = (variant & 4) != 0;  // 64-deep LDS stack instead of 32 (maps with stack_need > 32)
+  const size_t stack_lds = (trav == 0) ? 0u : (deep ? 64u : 32u) * 256u * sizeof(uint32_t);
+  const size_t lds = stack_lds + tail;
+  if (trav == 0) hipLaunchKernelGGL((k_pf_update<64, 0>), dim3(nblocks), dim3(256), lds, s, p);
+  else if (trav == 1 && deep) hipLaunchKernelGGL((k_pf_update<64, 1>), dim3(nblocks), dim3(256), lds, s, p);
+  else if (trav == 1) hipLaunchKernelGGL((k_pf_update<32, 1>), dim3(nblocks), dim3(256), lds, s, p);
+  else if (deep) hipLaunchKernelGGL((k_pf_update<64, 2>), dim3(nblocks), dim3(256), lds, s, p);
+  else hipLaunchKernelGGL((k_pf_update<32, 2>), dim3(nblocks), dim3(256), lds, s, p);
   return hipGetLastError();
 }
 

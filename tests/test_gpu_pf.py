@@ -38,7 +38,7 @@ def _check(a_gpu, e_gpu, a_ref, e_ref, what):
     assert np.array_equal(a_gpu["state_sigma"], a_ref["state_sigma"]), what + " state_sigma must be untouched"
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_golden_g6_cube(ra, ctx, meshes, variant):
     """committed fixture G6: 64 particles x 16 beams on the cube; beams outside the sensor range
     (real miss) and the MAX_N_MEAS clamp included."""
@@ -55,7 +55,8 @@ def test_golden_g6_cube(ra, ctx, meshes, variant):
 
 
 @pytest.mark.parametrize("n_particles,n_beams", [(1000, 100), (257, 7), (4099, 256)])
-def test_room_random_particles(ra, orc, ctx, meshes, n_particles, n_beams):
+@pytest.mark.parametrize("variant", [0, 2])
+def test_room_random_particles(ra, orc, ctx, meshes, n_particles, n_beams, variant):
     """random hypotheses in a room with occluders and an open ceiling (sim misses), reference default of
     100 random beams and ragged sizes; beams sampled from a simulated cloud like update() does."""
     from rmcl_amd import synthetic as syn, types as T
@@ -70,7 +71,7 @@ def test_room_random_particles(ra, orc, ctx, meshes, n_particles, n_beams):
     poses, attrs = syn.uniform_particles(n_particles, seed=5, bb_min=(-9, -9, 0.2, 0, 0, -math.pi),
                                          bb_max=(9, 9, 3.0, 0, 0, math.pi))
     Tsb = syn.tsb_offset()
-    a_gpu, e_gpu = _run(ra, ctx, hm, poses, attrs.copy(), beams, Tsb)
+    a_gpu, e_gpu = _run(ra, ctx, hm, poses, attrs.copy(), beams, Tsb, variant=variant)
     a_ref = attrs.copy()
     e_ref = m.pf_update(poses, a_ref, beams, Tsb, orc.pf_params(), bvh=True, nthreads=8, want_errors=True)
     _check(a_gpu, e_gpu, a_ref, e_ref, "room %dx%d" % (n_particles, n_beams))
