@@ -2,19 +2,23 @@
 """bench.py -- headline benchmark of the RMCL / MICP-L hot path on MI355X.
 
 Metric (BASELINE.json): ray-mesh intersections/s (+ derived pose-corrections/s), 100k-triangle mesh,
-128x1024 spherical scan.  Workload at every N: config C2 = one pose x 131 072 rays against the
-sphere-100k mesh per step, i.e. one RCC find() launch (rmcl/src/rmcl/registration/RCCEmbree.cpp:26-36)
-with all five output attributes written.  A single MICP pose does not shard:
---gpus N runs N independent replicas, one process per GPU, different pose per rank, no data-path
-collective ("replicas only", weak scaling).
+128x1024 spherical scan.
+
+Default workload (every N): config C2 = one pose x 131 072 rays against the sphere-100k mesh per step, i.e.
+one RCC find() launch (rmcl/src/rmcl/registration/RCCEmbree.cpp:26-36) with all five output attributes
+written.  A single MICP pose does not shard: --gpus N runs N independent replicas, one
+process per GPU, a different pose per rank, no data-path collective ("replicas only", weak scaling).
+
+--workload pf: config C4 per GPU (100k particles x 256 beams, sphere-100k), particles block-partitioned over
+the ranks (weak scaling: 100k per GPU) and ONE RCCL all-gather of the 4 B x N weights per step.
 
   python bench.py --gpus 1 --steps 200 --warmup 20
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events on the stream the kernel
-runs on (rmclhip_rcc_time_find); `cpu_baseline` times the CPU oracle (a port -- the reference's Embree
-path cannot be built here) on the host cores, rank 0, N=1 only.
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events on the stream the kernel runs on
+(rmclhip_rcc_time_find / rmclhip_pf_time_update); `cpu_baseline` times the CPU oracle (a port -- the
+reference's Embree path cannot be built here) on the host cores, rank 0, N=1 only.
 """
 import argparse
 import json
@@ -35,14 +39,32 @@ def algorithmic_bytes_raycast(n_rays, n_tri, n_poses):
     return n_rays * 33 + n_tri * 36 + (2 * n_tri - 1) * 32 + n_poses * 32
 
 
+def algorithmic_bytes_pf(n_particles, n_beams):
+    """SURVEY.md 8(d) B_pf: pose 32 B read + attrs 36 B read + 36 B written per particle, 64 B per beam."""
+    return n_particles * (32 + 36 + 36) + n_beams * 64
+
+
+def measured_traffic(kernel_key):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, produced by
+    tools/pmc_find.sh + tools/traffic_from_pmc.py: separate FETCH_SIZE / WRITE_SIZE passes, KiB -> bytes;
+    gfx950's 2x FETCH_SIZE under-count applies to wide 16 B/lane streams only and is noted there)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        d = json.load(fh)
+    return d.get(kernel_key, {}).get("hbm_bytes_per_launch")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", choices=("c2", "pf"), default="c2")
     ap.add_argument("--variant", type=int, default=1, help="find traversal: 1 per-lane while-while (default), 0 wave-packet")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extras", action="store_true", help="also time C3 (MICP loop), batch and C4 (particle filter)")
+    ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
 
     import numpy as np
@@ -53,119 +75,191 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
     dist = None
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-
-    ctx = ra.Context(local_rank)
-    v, f = syn.uv_sphere(100000)
-    hm = ra.import_hip_map(ctx, v, f)
-    model = syn.model_c2()
-    n_rays = model.phi.size * model.theta.size
-    rcc = ra.RCCHipSpherical(hm)
-    rcc.set_variant(args.variant)
-    rcc.setTsb(T.identity())
-    rcc.setModel(model)
-    # replicas: rank r localises a scan from a different pose inside the same map
-    Tbm = T.mult(syn.pose_c2_truth(), T.transform_from_rpy((0.05 * rank, -0.03 * rank, 0.0), (0.0, 0.0, 0.11 * rank)))
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(max(args.warmup, 1)):
-        rcc.find_async(Tbm)
-    rcc.sync()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rcc.find_async(Tbm)
-    rcc.sync()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        return float(tt.item())
 
-    # dominant kernel, measured live: HIP events on the rcc's own stream around back-to-back launches
-    kernel_ms = rcc.time_find(Tbm, iters=max(50, min(args.steps, 500)))
-    b_rc = algorithmic_bytes_raycast(n_rays, len(f), 1)
-    achieved = b_rc / (kernel_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_find<spherical,%s>" % ("packet" if args.variant == 0 else "lane"),
-                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
-                "algorithmic_bytes_per_launch": b_rc, "kernel_ms": round(kernel_ms, 5),
-                "kernel_rays_per_s": round(n_rays / (kernel_ms * 1e-3), 1)}
-
+    ctx = ra.Context(local_rank)
+    v, f = syn.uv_sphere(100000)
+    hm = ra.import_hip_map(ctx, v, f)
+    cores = os.cpu_count() or 1
     extras = {}
-    if rank == 0:
-        # C3: MICP-L inner loop, schedule (R) 1 find + 10 x (reduce + solve) and (B) 10 x (find + reduce + solve)
-        # measured scan = the product's own simulation at the ground-truth pose (no oracle involved)
-        rcc.find(syn.pose_c2_truth())
-        rcc.set_dataset_from_ranges(rcc.modelView()["ranges"])
-        rcc.params.max_dist = 1.0
-        rcc.adaptive_max_dist_min = 0.15
-        est = T.mult(syn.pose_c2_truth(), syn.pose_c2_perturbation())
-        for name, refind in (("R", False), ("B", True)):
-            rcc.correct_once(est, T.identity(), 10, 0.0, refind)
-            reps = 20
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                rcc.correct_once(est, T.identity(), 10, 0.0, refind)
-            dt = (time.perf_counter() - t1) / reps
-            extras["c3_schedule_%s_ms" % name] = round(dt * 1e3, 4)
-            extras["c3_schedule_%s_pose_corrections_per_s" % name] = round(1.0 / dt, 1)
-            extras["c3_schedule_%s_icp_iterations_per_s" % name] = round(10.0 / dt, 1)
-        red_ms = rcc.time_reduce(T.identity(), iters=100)
-        extras["reduce_kernel_ms"] = round(red_ms, 5)
-        extras["reduce_GBps"] = round((n_rays * 38 + 64) / (red_ms * 1e-3) / 1e9, 1)
-
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle as orc  # cpu_baseline leg only: the oracle is the thing timed, never the product path
-        m = orc.Mesh(v, f)
-        cores = os.cpu_count() or 1
-        m.simulate_spherical(model, T.identity(), Tbm, bvh=True, nthreads=cores, want=("hits", "ranges", "points", "normals", "face_ids"))
-        reps, t1 = 0, time.perf_counter()
-        while time.perf_counter() - t1 < 10.0 and reps < 200:
-            m.simulate_spherical(model, T.identity(), Tbm, bvh=True, nthreads=cores)
-            reps += 1
-        dt = time.perf_counter() - t1
-        cpu = {"value": round(reps * n_rays / dt, 1), "unit": "rays/s", "cores": cores, "kind": "port",
-               "sample": "%d x the same 128x1024 / 100k-triangle scan, CPU oracle (BVH2 + same intersector), %d threads"
-                         % (reps, cores)}
 
+    if args.workload == "c2":
+        model = syn.model_c2()
+        n_rays = model.phi.size * model.theta.size
+        rcc = ra.RCCHipSpherical(hm)
+        rcc.set_variant(args.variant)
+        rcc.setTsb(T.identity())
+        rcc.setModel(model)
+        # replicas: rank r localises a scan from a different pose inside the same map
+        Tbm = T.mult(syn.pose_c2_truth(), T.transform_from_rpy((0.05 * rank, -0.03 * rank, 0.0), (0.0, 0.0, 0.11 * rank)))
+        for _ in range(max(args.warmup, 1)):
+            rcc.find_async(Tbm)
+        rcc.sync()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            rcc.find_async(Tbm)
+        rcc.sync()
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        units_per_step = n_rays
+
+        # dominant kernel, measured live: HIP events on the rcc's own stream around back-to-back launches
+        kernel_ms = rcc.time_find(Tbm, iters=max(50, min(args.steps, 500)))
+        b_alg = algorithmic_bytes_raycast(n_rays, len(f), 1)
+        kname = "k_find<spherical,%s>" % ("packet" if (args.variant & 0xF) == 0 else "lane")
+        traffic = measured_traffic("k_find_packet" if (args.variant & 0xF) == 0 else "k_find_lane")
+
+        if rank == 0 and not args.no_extras:
+            # C3: MICP-L inner loop: (R) 1 find + 10 x (reduce + solve), (B) 10 x (find + reduce + solve).
+            # The measured scan is the product's own simulation at the ground-truth pose (no oracle involved).
+            rcc.find(syn.pose_c2_truth())
+            rcc.set_dataset_from_ranges(rcc.modelView()["ranges"])
+            rcc.params.max_dist = 1.0
+            rcc.adaptive_max_dist_min = 0.15
+            est = T.mult(syn.pose_c2_truth(), syn.pose_c2_perturbation())
+            for name, refind in (("R", False), ("B", True)):
+                rcc.correct_once(est, T.identity(), 10, 0.0, refind)
+                reps = 20
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    rcc.correct_once(est, T.identity(), 10, 0.0, refind)
+                dt = (time.perf_counter() - t1) / reps
+                extras["c3_schedule_%s_ms" % name] = round(dt * 1e3, 4)
+                extras["c3_schedule_%s_pose_corrections_per_s" % name] = round(1.0 / dt, 1)
+                extras["c3_schedule_%s_icp_iterations_per_s" % name] = round(10.0 / dt, 1)
+            red_ms = rcc.time_reduce(T.identity(), iters=100)
+            extras["reduce_ms"] = round(red_ms, 5)
+            extras["reduce_GBps"] = round((n_rays * 38 + 64) / (red_ms * 1e-3) / 1e9, 1)
+            # pose batches (v1 corrector shape): 64 poses x 128x1024 rays in one launch
+            rng = np.random.RandomState(0)
+            poses = np.array([T.mult(syn.pose_c2_truth(), T.transform_from_rpy(tuple(rng.uniform(-0.5, 0.5, 3)), (0, 0, rng.uniform(-3, 3))))
+                              for _ in range(64)], dtype=T.TRANSFORM)
+            bms = rcc.time_find_batch(poses, iters=5)
+            extras["find_batch64_ms"] = round(bms, 4)
+            extras["find_batch64_rays_per_s"] = round(64 * n_rays / (bms * 1e-3), 1)
+            rcc.correct_batch(poses)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                rcc.correct_batch(poses)
+            dt = (time.perf_counter() - t1) / 3
+            extras["correct_batch64_ms"] = round(dt * 1e3, 4)
+            extras["correct_batch64_pose_corrections_per_s"] = round(64 / dt, 1)
+            # C4: particle filter, 100k particles x 256 beams
+            pms, prays = _pf_c4(ra, syn, T, np, ctx, hm, 100000, 256, iters=3)
+            extras["c4_pf_update_ms"] = round(pms, 4)
+            extras["c4_particle_beam_evals_per_s"] = round(prays / (pms * 1e-3), 1)
+            extras["c4_particle_updates_per_s"] = round(100000 / (pms * 1e-3), 1)
+            extras["c4_pf_algorithmic_GBps"] = round(algorithmic_bytes_pf(100000, 256) / (pms * 1e-3) / 1e9, 2)
+
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle as orc  # cpu_baseline leg only: the oracle is the thing timed, never the product path
+            m = orc.Mesh(v, f)
+            m.simulate_spherical(model, T.identity(), Tbm, bvh=True, nthreads=cores)
+            reps, t1 = 0, time.perf_counter()
+            while time.perf_counter() - t1 < 10.0:
+                m.simulate_spherical(model, T.identity(), Tbm, bvh=True, nthreads=cores)
+                reps += 1
+            dt = time.perf_counter() - t1
+            cpu = {"value": round(reps * n_rays / dt, 1), "unit": "rays/s", "cores": cores, "kind": "port",
+                   "sample": "%d x the same 128x1024 / 100k-triangle scan in %.1f s, CPU oracle (BVH2, same intersector), "
+                             "%d threads" % (reps, dt, cores)}
+        metric = "ray-mesh intersections/s (128x1024 scan, 100k-tri mesh)"
+        unit = "rays/s"
+        workload = ("C2: 1 pose x 128x1024 spherical LiDAR, UV-sphere 100k triangles, find() only, 5 output "
+                    "attributes; N>1 = independent replicas")
+        parallelism = "replicas%d" % world
+    else:
+        # ---- particle filter, weak scaling: 100k particles per GPU, one all-gather of the weights per step
+        from rmcl_amd import distributed as D
+        n_local, n_beams = 100000, 256
+        n_total = n_local * world
+        poses_all, attrs_all = syn.uniform_particles(n_total, seed=42, bb_min=(-5, -5, -1, 0, 0, -math.pi), bb_max=(5, 5, 1, 0, 0, math.pi))
+        lo, hi = D.shard_bounds(n_total, rank, world)
+        dirs = syn.model_directions(syn.model_pf16())
+        beams = ra.beams_from_points(dirs * np.float32(6.0))
+        upd = ra.PCDSensorUpdaterHip(hm)
+        upd.init()
+        upd.setInput(beams, T.identity())
+        d_poses = ra.DeviceArray.from_host(ctx, poses_all[lo:hi])
+        d_attrs = ra.DeviceArray.from_host(ctx, attrs_all[lo:hi])
+        w_local = torch.empty(hi - lo, dtype=torch.float32, device="cuda")
+        sharded = D.ShardedSensorUpdate(upd, n_total, rank, world)
+
+        def step():
+            if dist is not None:
+                return sharded.update(d_poses, d_attrs, w_local)
+            upd.update(d_poses, d_attrs, n_particles=hi - lo)
+            upd.extract_weights(d_attrs, hi - lo, w_local.data_ptr())
+            return w_local
+
+        for _ in range(max(args.warmup, 1)):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        units_per_step = n_local * n_beams
+        kernel_ms = upd.time_update(d_poses, d_attrs, hi - lo, iters=5)
+        b_alg = algorithmic_bytes_pf(hi - lo, n_beams)
+        kname = "k_pf_update"
+        traffic = measured_traffic("k_pf_update")
+        extras["particle_updates_per_s"] = round(world * args.steps * n_local / elapsed, 1)
+        extras["allgather_bytes"] = 4 * n_total
+        metric = "particle-beam evaluations/s (100k particles x 256 beams per GPU, 100k-tri mesh)"
+        unit = "rays/s"
+        workload = "C4 per GPU: 100k particles x 16x16 beams, UV-sphere 100k triangles, fused update + weight all-gather"
+        parallelism = "particles-sharded dp%d + all_gather(4B x N)" % world
+        n_rays = units_per_step
+
+    achieved = b_alg / (kernel_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": b_alg, "kernel_ms": round(kernel_ms, 5),
+                "kernel_units_per_s": round(units_per_step / (kernel_ms * 1e-3), 1)}
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
         out = {
-            "metric": "ray-mesh intersections/s (128x1024 scan, 100k-tri mesh)",
-            "value": round(world * args.steps * n_rays / elapsed, 1),
-            "unit": "rays/s",
+            "metric": metric,
+            "value": round(world * args.steps * units_per_step / elapsed, 1),
+            "unit": unit,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 5),
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "C2: 1 pose x 128x1024 spherical LiDAR, UV-sphere 100k triangles, find() only, "
-                                   "5 output attributes; N>1 = independent replicas",
-                       "rays_per_step": n_rays, "triangles": int(len(f)), "parallelism": "replicas%d" % world,
-                       "kernel_variant": args.variant},
+            "config": {"workload": workload, "units_per_step_per_gpu": units_per_step, "triangles": int(len(f)),
+                       "parallelism": parallelism, "kernel_variant": args.variant},
             "pose_corrections_per_s": extras.get("c3_schedule_R_pose_corrections_per_s"),
             "roofline": roofline,
             "cpu_baseline": cpu,
@@ -175,6 +269,20 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _pf_c4(ra, syn, T, np, ctx, hm, n_particles, n_beams, iters):
+    poses, attrs = syn.uniform_particles(n_particles, seed=42, bb_min=(-5, -5, -1, 0, 0, -math.pi), bb_max=(5, 5, 1, 0, 0, math.pi))
+    dirs = syn.model_directions(syn.model_pf16())
+    sel = np.linspace(0, len(dirs) - 1, n_beams).astype(int)
+    beams = ra.beams_from_points(dirs[sel] * np.float32(6.0))
+    upd = ra.PCDSensorUpdaterHip(hm)
+    upd.init()
+    upd.setInput(beams, T.identity())
+    d_poses, d_attrs = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
+    ms = upd.time_update(d_poses, d_attrs, n_particles, iters=iters)
+    upd.close()
+    return ms, n_particles * n_beams
 
 
 if __name__ == "__main__":

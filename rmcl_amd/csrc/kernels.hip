@@ -221,10 +221,12 @@ __device__ __forceinline__ void trace_lane(const uint32_t* __restrict__ nodes, c
 // ---------------------------------------------------------------------------------------------
 // per-lane traversal, "while-while" form (Aila & Laine): every lane first descends through inner nodes
 // until it holds a leaf; only then does the wave run the (expensive) triangle tests, with most lanes
-// active.  kScratchStack: the per-lane stack lives in private (scratch) memory instead of LDS, which frees
-// the LDS for occupancy (a 64-deep LDS stack costs 64 KB per 256-thread block = 2 blocks per CU).
+// active.  The per-lane stack is split: the first kLdsEntries live in LDS ([entry][lane], conflict free), deeper
+// entries spill to private (scratch) memory.  A full 64-deep LDS stack costs 64 KB per 256-thread block (2 blocks
+// per CU); a pure scratch stack keeps occupancy but measured 272 MB of HBM-side write traffic per C4 update; 16
+// LDS entries (16 KB per block) catch almost every push.
 // ---------------------------------------------------------------------------------------------
-template <bool kScratchStack>
+template <int kLdsEntries>  // stack entries kept in LDS ([entry][lane]); the rest (up to 64 total) in scratch
 __device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris,
                                               f3 O, f3 D, float ray_tfar, uint32_t* __restrict__ lds_stack,
                                               uint32_t lds_stride, RayHit& h) {
@@ -233,11 +235,11 @@ __device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes
   float best_t = ray_tfar;
   uint32_t best_face = kInvalidFace, best_rec = 0;
   constexpr uint32_t kDone = 0x7FFFFFFFu;
-  uint32_t priv[kScratchStack ? 64 : 1];
+  uint32_t priv[(kLdsEntries < 64) ? (64 - kLdsEntries) : 1];
   uint32_t sp = 0;
   uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
-#define RMCL_PUSH(v) { if (kScratchStack) priv[sp] = (v); else lds_stack[sp * lds_stride] = (v); ++sp; }
-#define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; cur = kScratchStack ? priv[sp] : lds_stack[sp * lds_stride]; } }
+#define RMCL_PUSH(v) { if (kLdsEntries >= 64 || sp < kLdsEntries) lds_stack[sp * lds_stride] = (v); else priv[sp - kLdsEntries] = (v); ++sp; }
+#define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; cur = (kLdsEntries >= 64 || sp < kLdsEntries) ? lds_stack[sp * lds_stride] : priv[sp - kLdsEntries]; } }
   while (__any(cur != kDone)) {
     // phase 1: inner nodes
     while ((cur != kDone) && !(cur & kLeafBit)) {
@@ -341,7 +343,7 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   if (kPacket) {
     trace_packet((cu32p)(p.nodes), (cu32p)(p.tris), org_m, dir_m, ray_tfar, lane, h);
   } else {
-    trace_lane_ww<true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, nullptr, 0u, h);
+    trace_lane_ww<16>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
   }
 
   if (!valid) return;
@@ -600,15 +602,15 @@ __device__ __forceinline__ g1d g1d_add(g1d a, g1d b) {
   return r;
 }
 
-// kTrav: 0 = while-while traversal, per-lane stack in scratch (no LDS stack; default)
-//        1 = while-while traversal, per-lane stack in LDS
+// kTrav: 0 = while-while traversal, per-lane stack 16 entries in LDS + scratch overflow (default)
+//        1 = while-while traversal, per-lane stack entirely in LDS
 //        2 = original single-loop traversal, stack in LDS (A/B)
 template <int kStackDepth, int kTrav>
 __global__ void __launch_bounds__(256) k_pf_update(const PfParams p) {
   // LDS: [ per-lane stacks kStackDepth*256 (kTrav != 0) | Tsm (PB xforms) | evals (PB*n_beams floats) ]
   extern __shared__ uint32_t lds_dyn[];
   uint32_t* stacks = lds_dyn;
-  xform* s_Tsm = reinterpret_cast<xform*>(lds_dyn + (kTrav == 0 ? 0 : kStackDepth * 256));
+  xform* s_Tsm = reinterpret_cast<xform*>(lds_dyn + (kTrav == 0 ? 16 : kStackDepth) * 256);
   float* s_eval = reinterpret_cast<float*>(s_Tsm + p.particles_per_block);
 
   const uint32_t PB = p.particles_per_block;
@@ -633,8 +635,8 @@ __global__ void __launch_bounds__(256) k_pf_update(const PfParams p) {
     const bool finite = (dir.x == dir.x) && (dir.y == dir.y) && (dir.z == dir.z);
     RayHit h;
     const float rtf = (live && finite) ? __builtin_inff() : -1.0f;
-    if (kTrav == 0) trace_lane_ww<true>(p.nodes, p.tris, org, dir, rtf, nullptr, 0u, h);
-    else if (kTrav == 1) trace_lane_ww<false>(p.nodes, p.tris, org, dir, rtf, stacks + threadIdx.x, 256u, h);
+    if (kTrav == 0) trace_lane_ww<16>(p.nodes, p.tris, org, dir, rtf, stacks + threadIdx.x, 256u, h);
+    else if (kTrav == 1) trace_lane_ww<64>(p.nodes, p.tris, org, dir, rtf, stacks + threadIdx.x, 256u, h);
     else trace_lane(p.nodes, p.tris, org, dir, rtf, stacks + threadIdx.x, 256u, h);
     if (live) {
       // evaluate_rcc (PCDSensorUpdaterEmbree.cpp:18-86) with unit face normals (BeamEvaluateProgram.cu:104-113)
@@ -696,7 +698,7 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
     if (kind == kModelSpherical) hipLaunchKernelGGL((k_find<kModelSpherical, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((k_find<kModelO1Dn, true>), grid, block, 0, s, p);
   } else {             // per-lane while-while traversal, stack in scratch
-    const size_t lds = 0;
+    const size_t lds = 16u * 256u * sizeof(uint32_t);
     if (kind == kModelSpherical) hipLaunchKernelGGL((k_find<kModelSpherical, false>), grid, block, lds, s, p);
     else hipLaunchKernelGGL((k_find<kModelO1Dn, false>), grid, block, lds, s, p);
   }
@@ -761,7 +763,7 @@ hipError_t launch_pf_update(const PfParams& p, int variant, hipStream_t s) {
                       sizeof(float) * static_cast<size_t>(p.particles_per_block) * p.n_beams;
   const int trav = variant & 3;        // see k_pf_update
   const bool deep = (variant & 4) != 0;  // 64-deep LDS stack instead of 32 (maps with stack_need > 32)
-  const size_t stack_lds = (trav == 0) ? 0u : (deep ? 64u : 32u) * 256u * sizeof(uint32_t);
+  const size_t stack_lds = ((trav == 0) ? 16u : (deep ? 64u : 32u)) * 256u * sizeof(uint32_t);
   const size_t lds = stack_lds + tail;
   if (trav == 0) hipLaunchKernelGGL((k_pf_update<64, 0>), dim3(nblocks), dim3(256), lds, s, p);
   else if (trav == 1 && deep) hipLaunchKernelGGL((k_pf_update<64, 1>), dim3(nblocks), dim3(256), lds, s, p);

@@ -1,0 +1,21 @@
+#!/bin/bash
+# HBM traffic passes (rocprofv3 PMC, one counter group per run, kernel-trace only) for the three hot kernels.
+# usage (on the GPU box, via gpurun): bash tools/pmc_traffic.sh <tag>
+set -u
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/traffic_$1
+mkdir -p $OUT
+run() { # name counters... -- cmd
+  name=$1; shift; ctr=$1; shift
+  timeout 300 rocprofv3 --kernel-trace --pmc $ctr -d $OUT -o $name -- "$@" > $OUT/$name.stdout 2>&1 || echo "$name failed" >> $OUT/errors.txt
+}
+for v in 1 0; do
+  run find_v${v}_fetch FETCH_SIZE python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras --variant $v
+  run find_v${v}_write WRITE_SIZE python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras --variant $v
+done
+run pf_fetch FETCH_SIZE python bench.py --workload pf --steps 3 --warmup 1
+run pf_write WRITE_SIZE python bench.py --workload pf --steps 3 --warmup 1
+run red_fetch FETCH_SIZE python bench.py --steps 5 --warmup 2 --no-cpu-baseline
+run red_write WRITE_SIZE python bench.py --steps 5 --warmup 2 --no-cpu-baseline
+ls $OUT

@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""profiles/traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh.
+
+FETCH_SIZE / WRITE_SIZE are in KiB per dispatch (rocprofv3, derived from TCC_EA0_RDREQ / _WRREQ).  On gfx950
+FETCH_SIZE reads exactly 1/2 of the bytes of a WIDE coalesced streaming read (16 B/lane) -- that correction
+(x2) is applied to the streaming reduction kernel only; BVH traversal reads are 16-B gathers / scalar 64-B
+requests for which the counter is uncalibrated, so they are reported as measured, with the x2 bound alongside.
+"""
+import json
+import sqlite3
+import sys
+
+
+def avg(db, kernel_like, counter):
+    con = sqlite3.connect(db)
+    row = con.execute(
+        "select avg(v), count(*) from (select sum(p.counter_value) as v from pmc_events p join kernels k on p.dispatch_id = k.dispatch_id "
+        "where k.name like ? and p.counter_name = ? group by p.dispatch_id)", (kernel_like, counter)).fetchone()
+    return (row[0] or 0.0), row[1]
+
+
+def main(d, out):
+    res = {}
+    for key, like, pre, wide in (("k_find_lane", "%k_find<1u, false>%", "find_v1", False), ("k_find_packet", "%k_find<1u, true>%", "find_v0", False),
+                                 ("k_pf_update", "%k_pf_update%", "pf", False), ("k_reduce_partials", "%k_reduce_partials%", "red", True)):
+        f, nf = avg("%s/%s_fetch_results.db" % (d, pre), like, "FETCH_SIZE")
+        w, nw = avg("%s/%s_write_results.db" % (d, pre), like, "WRITE_SIZE")
+        fb, wb = f * 1024.0, w * 1024.0
+        res[key] = {"fetch_bytes_measured": round(fb), "write_bytes_measured": round(wb),
+                    "fetch_correction": 2.0 if wide else 1.0,
+                    "hbm_bytes_per_launch": round(fb * (2.0 if wide else 1.0) + wb),
+                    "hbm_bytes_per_launch_upper_bound_x2_fetch": round(2 * fb + wb), "dispatches": [nf, nw]}
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1, sort_keys=True)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
