@@ -274,22 +274,66 @@ RM_HD quat mat_to_quat(const double* R) {
   return r;
 }
 
+// Orthogonal polar factor of a well-conditioned 3x3 matrix with positive determinant (scaled Newton iteration,
+// Higham).  Returns false -- leaving the decision to the SVD path -- for det <= 0, near-singular input or slow
+// convergence.
+RM_HD bool polar3(const double* A, double* R) {
+  double X[9];
+  double fro2 = 0.0;
+  for (int i = 0; i < 9; ++i) { X[i] = A[i]; fro2 += A[i] * A[i]; }
+  const double fro = sqrt(fro2);
+  if (!(fro > 0.0) || !(det3(A) > 1e-9 * fro * fro * fro)) return false;
+  for (int it = 0; it < 24; ++it) {
+    // Y = X^-T via cofactors: inv(X) = adj(X) / det  =>  X^-T = cof(X) / det
+    double Cf[9];
+    Cf[0] = X[4] * X[8] - X[5] * X[7]; Cf[1] = X[5] * X[6] - X[3] * X[8]; Cf[2] = X[3] * X[7] - X[4] * X[6];
+    Cf[3] = X[2] * X[7] - X[1] * X[8]; Cf[4] = X[0] * X[8] - X[2] * X[6]; Cf[5] = X[1] * X[6] - X[0] * X[7];
+    Cf[6] = X[1] * X[5] - X[2] * X[4]; Cf[7] = X[2] * X[3] - X[0] * X[5]; Cf[8] = X[0] * X[4] - X[1] * X[3];
+    const double det = X[0] * Cf[0] + X[1] * Cf[1] + X[2] * Cf[2];
+    if (!(det > 0.0)) return false;
+    const double idet = 1.0 / det;
+    double nx = 0.0, ny = 0.0;
+    for (int i = 0; i < 9; ++i) { Cf[i] *= idet; nx += X[i] * X[i]; ny += Cf[i] * Cf[i]; }
+    const double g = sqrt(sqrt(ny / nx));  // (|X^-1|_F / |X|_F)^(1/2)
+    const double a = 0.5 * g, b = 0.5 / g;
+    double diff = 0.0;
+    for (int i = 0; i < 9; ++i) {
+      const double xn = a * X[i] + b * Cf[i];
+      const double d = xn - X[i];
+      diff += d * d;
+      X[i] = xn;
+    }
+    if (diff <= 1e-28 * 3.0) {  // |X_{k+1} - X_k|_F <= 1e-14 |R|_F
+      for (int i = 0; i < 9; ++i) R[i] = X[i];
+      return true;
+    }
+  }
+  return false;
+}
+
 // rm::umeyama_transform: C = U S V^T, R = U diag(1,1,sign(det U det V)) V^T, t = mm - R dm
 RM_HD xform umeyama(const cstats& s) {
   xform T = xidentity();
   if (s.n_meas == 0) return T;
-  double C[9], U[9], w[3], V[9];
+  double C[9], R[9];
   for (int i = 0; i < 9; ++i) C[i] = static_cast<double>(s.covariance[i]);
-  svd3(C, U, w, V);
-  double S[3] = {1, 1, 1};
-  if (det3(U) * det3(V) < 0) S[2] = -1;
-  double R[9];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) {
-      double acc = 0;
-      for (int k = 0; k < 3; ++k) acc += U[3 * i + k] * S[k] * V[3 * j + k];
-      R[3 * i + j] = acc;
-    }
+  // Fast path: for det(C) > 0 the Kabsch/Umeyama rotation U diag(1,1,+1) V^T IS the orthogonal polar factor of
+  // C, which a scaled Newton iteration X <- (g X + X^-T / g) / 2 delivers in ~6 steps of ~60 fp64 operations --
+  // an order of magnitude fewer dependent fp64 instructions than the Jacobi SVD (a lone lane issues one fp64
+  // instruction per ~8 cycles: the SVD solve measured ~9 us of the 14 us k_micp_step).  Reflection (det < 0),
+  // rank-deficient or slowly converging inputs take the SVD path below, which defines the semantics.
+  if (!polar3(C, R)) {
+    double U[9], w[3], V[9];
+    svd3(C, U, w, V);
+    double S[3] = {1, 1, 1};
+    if (det3(U) * det3(V) < 0) S[2] = -1;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double acc = 0;
+        for (int k = 0; k < 3; ++k) acc += U[3 * i + k] * S[k] * V[3 * j + k];
+        R[3 * i + j] = acc;
+      }
+  }
   T.R = mat_to_quat(R);
   T.t = sub3(s.model_mean, qrot(T.R, s.dataset_mean));
   return T;

@@ -391,24 +391,33 @@ constexpr int kAcc = 16;  // sd[3] sm[3] smd[9] cnt
 // sum the per-block partials of one pose (one wave) and turn the raw moments into CrossStatistics
 template <bool kAgentLoads = false>
 __device__ __forceinline__ cstats finalize_pose(const double* partials, uint32_t nblocks) {
+  // transposed reduction: lane = 16*g + k sums moment k over the blocks b = g, g+4, ... (16 lanes read one
+  // 128-B partial: coalesced), then only TWO cross-lane steps (xor 16, 32) for one double per lane and 16
+  // v_readlane broadcasts -- instead of 16 moments x 6 butterfly steps = 192 dependent ds_bpermute (measured
+  // ~4.5 us of the 14 us k_micp_step)
   const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t k0 = lane & 15u, g = lane >> 4;
+  // 8 loads in flight per lane (a one-load-per-iteration loop serialises ~64 L2 round trips: measured +12 us)
+  double a = 0.0;
+  uint32_t b = g;
+  for (; b + 28u < nblocks; b += 32u) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double* q = partials + static_cast<size_t>(b + 4u * u) * kAcc + k0;
+      v[u] = kAgentLoads ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+    }
+    a += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  }
+  for (; b < nblocks; b += 4u) {
+    const double* q = partials + static_cast<size_t>(b) * kAcc + k0;
+    a += kAgentLoads ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+  }
+  a += __shfl_xor(a, 16, 64);
+  a += __shfl_xor(a, 32, 64);
   double acc[kAcc];
 #pragma unroll
-  for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
-  for (uint32_t b = lane; b < nblocks; b += 64u) {
-#pragma unroll
-    for (int k = 0; k < kAcc; ++k) {
-      const double* q = partials + static_cast<size_t>(b) * kAcc + k;
-      acc[k] += kAgentLoads ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < kAcc; ++k) {
-    double v = acc[k];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    acc[k] = v;
-  }
+  for (int k = 0; k < kAcc; ++k) acc[k] = __shfl(a, k, 64);
   cstats s = cs_identity();
   const double n = acc[15];
   if (n > 0.0) {
@@ -441,6 +450,9 @@ __device__ __forceinline__ void micp_advance(const cstats& stats_s, const xform&
   st->stats_o = Cmerged;
 }
 
+// kTail == kTailNone keeps the streaming kernel lean (the solve code of the fused tails costs registers and
+// scratch: with it compiled in, this kernel went from 96 to 192 VGPRs + 80 B scratch and 2.3x slower launches)
+template <uint32_t kTail>
 __global__ void __launch_bounds__(256) k_reduce_partials(const ReduceParams p) {
   __shared__ double red[4][kAcc];
   const uint32_t pose = blockIdx.y;
@@ -473,19 +485,23 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const ReduceParams p) {
       }
     }
   }
-  // wave64 shuffle tree, then 4 waves through LDS
-#pragma unroll
-  for (int k = 0; k < kAcc; ++k) {
-    double v = acc[k];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    acc[k] = v;
-  }
+  // wave64 reduction of 16 moments: halving butterfly -- at xor distance 32/16/8/4 each lane hands the half of
+  // its moments it no longer owns to its partner (8+4+2+1 exchanges), then two plain steps: 17 double shuffles
+  // instead of 16 x 6 = 96.  Afterwards lane L holds the wave total of moment L >> 2.
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  if (lane == 0) {
 #pragma unroll
-    for (int k = 0; k < kAcc; ++k) red[wave][k] = acc[k];
+  for (int half = 8, off = 32; half >= 1; half >>= 1, off >>= 1) {
+    const bool hi = (lane & static_cast<uint32_t>(off)) != 0u;
+#pragma unroll
+    for (int j = 0; j < half; ++j) {
+      const double send = hi ? acc[j] : acc[j + half];
+      const double keep = hi ? acc[j + half] : acc[j];
+      acc[j] = keep + __shfl_xor(send, off, 64);
+    }
   }
+  acc[0] += __shfl_xor(acc[0], 2, 64);
+  acc[0] += __shfl_xor(acc[0], 1, 64);
+  if ((lane & 3u) == 0u) red[wave][lane >> 2] = acc[0];
   __syncthreads();
   if (threadIdx.x < kAcc) {
     const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
@@ -494,7 +510,7 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const ReduceParams p) {
     __hip_atomic_store(p.partials + (static_cast<size_t>(pose) * p.nblocks + blockIdx.x) * kAcc + threadIdx.x, v,
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (p.tail_mode == kTailNone) return;
+  if constexpr (kTail != kTailNone) {
   // ---- fused tail: the LAST block of this pose to arrive finalizes.  Hand-off without fences: write-through
   // (sc1) partial stores -> every wave s_waitcnt vmcnt(0) -> barrier -> relaxed agent-scope ticket; the last
   // arriver reads the partials with sc1 loads (L1-bypassing).  A release fence per block (256 x buffer_wbl2)
@@ -512,9 +528,9 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const ReduceParams p) {
   const cstats st = finalize_pose<true>(p.partials + static_cast<size_t>(pose) * p.nblocks * kAcc, p.nblocks);
   if (threadIdx.x == 0) {
     p.tickets[pose] = 0u;  // re-armed for the next launch on this stream
-    if (p.tail_mode == kTailStats) {
+    if (kTail == kTailStats) {
       p.stats_out[pose] = st;
-    } else if (p.tail_mode == kTailMicp) {
+    } else if (kTail == kTailMicp) {
       micp_advance(st, p.call ? p.call->Tsb : p.Tsb, p.call ? p.call->Tbo : p.Tbo, p.state);
     } else {  // kTailBatchSolve: v1 corrector, Tdelta_b = Tsb * T_s * ~Tsb
       const xform Ts = umeyama(st);
@@ -522,6 +538,7 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const ReduceParams p) {
       if (p.stats_out) p.stats_out[pose] = st;
     }
   }
+  }  // kTail != kTailNone
 }
 
 __global__ void __launch_bounds__(64) k_reduce_finalize(const double* __restrict__ partials, uint32_t nblocks,
@@ -721,7 +738,11 @@ uint32_t reduce_num_blocks(uint32_t n) {
 }
 
 hipError_t launch_reduce_partials(const ReduceParams& p, hipStream_t s) {
-  hipLaunchKernelGGL(k_reduce_partials, dim3(p.nblocks, p.nposes), dim3(256), 0, s, p);
+  const dim3 grid(p.nblocks, p.nposes), block(256);
+  if (p.tail_mode == kTailStats) hipLaunchKernelGGL((k_reduce_partials<kTailStats>), grid, block, 0, s, p);
+  else if (p.tail_mode == kTailMicp) hipLaunchKernelGGL((k_reduce_partials<kTailMicp>), grid, block, 0, s, p);
+  else if (p.tail_mode == kTailBatchSolve) hipLaunchKernelGGL((k_reduce_partials<kTailBatchSolve>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((k_reduce_partials<kTailNone>), grid, block, 0, s, p);
   return hipGetLastError();
 }
 

@@ -159,3 +159,55 @@ def test_correct_batch_v1_api(ra, orc, ctx, meshes):
     # z contracts slowly for a +-15 deg sensor but must not grow
     assert np.abs(t1[:, :2]).max() < 2e-2
     assert np.all(np.abs(t1[:, 2]) <= np.abs(t0[:, 2]) + 1e-3)
+
+
+@pytest.mark.parametrize("variant_bits", [0, 1 << 8, 1 << 9, (1 << 8) | (1 << 9)])
+def test_loop_variants_agree(ra, orc, ctx, meshes, variant_bits):
+    """A/B code paths of the MICP loop (fused last-block reduction tail, hipGraph replay on/off) give the same
+    statistics and pose as the default path; repeated calls with changing inputs exercise graph replay with
+    fresh per-call parameters (pose, Tbo, max_dist, Tsb)."""
+    from rmcl_amd import synthetic as syn, types as T
+    m, hm, model = _sphere_setup(ra, orc, ctx, meshes)
+    ident = T.identity()
+    meas = m.simulate_spherical(model, ident, ident, bvh=True, nthreads=8)
+    ds, mask = om.dataset_from_ranges(model, meas["ranges"])
+    rcc = ra.RCCHipSpherical(hm)
+    rcc.set_variant(1 | variant_bits)
+    rcc.setTsb(ident)
+    rcc.setModel(model)
+    rcc.set_dataset(ds, mask)
+    cases = [(T.transform((0, 0, 0, 1), (0.0, 0.0, 0.2)), ident, 1.0, 0.0, ident),
+             (T.transform_from_rpy((0.1, -0.05, 0.1), (0, 0, 0.02)), T.transform_from_rpy((0.2, 0.1, 0.0), (0, 0, 0.3)), 0.7, 0.4, syn.tsb_offset()),
+             (T.transform((0, 0, 0, 1), (0.05, 0.0, -0.1)), ident, 1.0, 0.0, ident)]
+    for Tom, Tbo, md, p, Tsb in cases:
+        rcc.setTsb(Tsb)
+        rcc.params.max_dist, rcc.adaptive_max_dist_min = md, 0.15
+        Tg, sg = rcc.correct_once(Tom, Tbo, 4, p, False)
+        To, so, _ = om.correct_once(m, model, Tsb, Tbo, Tom, ds, mask, 4, md, adaptive_min=0.15, convergence_progress=p, nthreads=8)
+        _transform_close(Tg, To, 1e-5)
+        assert int(sg["n_meas"]) == int(so["n_meas"])
+        s1 = rcc.computeCrossStatistics(ident, p)
+        assert int(s1["n_meas"]) > 0
+    Td, st = rcc.correct_batch(np.array([c[0] for c in cases], dtype=T.TRANSFORM))
+    assert len(Td) == 3 and int(st[0]["n_meas"]) > 0
+
+
+def test_find_batch_o1dn_pose_major(ra, orc, ctx, meshes):
+    """Simulator::simulate(Memory<Transform>, Bundle&) for an O1Dn model: pose-major buffers == single finds."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room30k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    sm = syn.model_pf16()
+    dirs = syn.model_directions(sm)
+    rcc = ra.RCCHipO1Dn(hm)
+    rcc.setTsb(syn.tsb_offset())
+    rcc.setModel(16, 16, 0.05, 80.0, (0.01, 0.02, 0.03), dirs)
+    poses, _ = syn.uniform_particles(33, seed=9, bb_min=(-8, -8, 0.5, 0, 0, -3), bb_max=(8, 8, 2.5, 0, 0, 3))
+    for variant in (1, 0):
+        rcc.set_variant(variant)
+        rcc.find_batch(poses)
+        mv = rcc.modelView()
+        ref = m.simulate_o1dn(16, 16, 0.05, 80.0, (0.01, 0.02, 0.03), dirs, syn.tsb_offset(), poses, bvh=True, nthreads=4)
+        assert np.array_equal(mv["face_ids"], ref["face_ids"]) and np.array_equal(mv["hits"], ref["hits"])
+        assert np.allclose(mv["ranges"], ref["ranges"], rtol=1e-5)
