@@ -219,3 +219,38 @@ def test_far_from_origin_mesh(ra, orc, ctx):
     Tbm = T.transform_from_rpy(tuple(off + np.array([0.4, -0.3, 0.2], dtype=np.float32)), (0.1, 0.2, 0.3))
     rcc.find(Tbm)
     _compare(rcc.modelView(), m.simulate_spherical(model, T.identity(), Tbm, bvh=False), "far mesh")
+
+
+def test_c5_mesh_one_million_triangles(ra, orc, ctx):
+    """config C5's map size: 1M-triangle sphere (BVH4 depth 15, traversal stack 46 -> LDS + scratch spill path),
+    a 128x1024 scan and a small particle-filter update against the oracle."""
+    import math
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = syn.uv_sphere(1000000)
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    info = hm.info()
+    assert info["n_faces"] == 1000000 and info["stack_need"] <= 64
+    model = syn.model_c2()
+    Tbm = syn.pose_c2_truth()
+    ref = m.simulate_spherical(model, T.identity(), Tbm, bvh=True, nthreads=8)
+    for variant in (1, 0):
+        rcc = ra.RCCHipSpherical(hm)
+        rcc.set_variant(variant)
+        rcc.setTsb(T.identity())
+        rcc.setModel(model)
+        rcc.find(Tbm)
+        _compare(rcc.modelView(), ref, "sphere-1M variant %d" % variant)
+        rcc.close()
+    poses, attrs = syn.uniform_particles(2000, seed=4, bb_min=(-6, -6, -2, 0, 0, -math.pi), bb_max=(6, 6, 2, 0, 0, math.pi))
+    beams = ra.beams_from_points(syn.model_directions(syn.model_pf16())[::4] * np.float32(7.0))
+    upd = ra.PCDSensorUpdaterHip(hm)
+    upd.init()
+    upd.setInput(beams, T.identity())
+    d_poses, d_attrs = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
+    upd.update(d_poses, d_attrs)
+    a_ref = attrs.copy()
+    m.pf_update(poses, a_ref, beams, T.identity(), orc.pf_params(), bvh=True, nthreads=8)
+    a_gpu = d_attrs.download()
+    assert np.array_equal(a_gpu["likelihood"]["n_meas"], a_ref["likelihood"]["n_meas"])
+    assert_close_rel(a_gpu["likelihood"]["mean"], a_ref["likelihood"]["mean"], 1e-5, 1e-12, "1M pf mean")
