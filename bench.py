@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--variant", type=int, default=1, help="find traversal: 1 per-lane while-while (default), 0 wave-packet")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing tests)")
+    ap.add_argument("--all-on-device0", action="store_true", help="testing only: every rank uses GPU 0")
     args = ap.parse_args()
 
     import numpy as np
@@ -78,12 +80,17 @@ def main():
     if world == 1 and args.gpus > 1:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
     dist = None
+    if args.all_on_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     def barrier():
         if dist is not None:
