@@ -233,6 +233,40 @@ class RCCHipO1Dn : public CorrespondencesHIP, public ModelSetter<O1DnModel> {
   }
 };
 
+// rmagine::PinholeModel (fields: rmcl_ros/src/util/conversions.cpp:36-60)
+struct PinholeModel {
+  uint32_t width = 0, height = 0;
+  Interval range{0.f, 0.f};
+  float f[2] = {1.f, 1.f};
+  float c[2] = {0.f, 0.f};
+};
+
+// rmagine::OnDnModel (fields: rmcl_ros/src/util/conversions.cpp:96-120)
+struct OnDnModel {
+  uint32_t width = 0, height = 0;
+  Interval range{0.f, 0.f};
+  std::vector<Vector> origs, dirs;
+};
+
+class RCCHipPinhole : public CorrespondencesHIP, public ModelSetter<PinholeModel> {
+ public:
+  explicit RCCHipPinhole(HipMapPtr map) : CorrespondencesHIP(std::move(map)) {}
+  void setModel(const PinholeModel& m) override {
+    check(rmclhip_rcc_set_model_pinhole(h_, m.width, m.height, m.range, m.f[0], m.f[1], m.c[0], m.c[1]));
+  }
+};
+
+class RCCHipOnDn : public CorrespondencesHIP, public ModelSetter<OnDnModel> {
+ public:
+  explicit RCCHipOnDn(HipMapPtr map) : CorrespondencesHIP(std::move(map)) {}
+  void setModel(const OnDnModel& m) override {
+    const size_t n = static_cast<size_t>(m.width) * m.height;
+    if (m.dirs.size() != n || m.origs.size() != n) throw std::runtime_error("OnDnModel: origs/dirs size != width*height");
+    check(rmclhip_rcc_set_model_ondn(h_, m.width, m.height, m.range, reinterpret_cast<const float*>(m.origs.data()),
+                                     reinterpret_cast<const float*>(m.dirs.data())));
+  }
+};
+
 // ---- particle filter -----------------------------------------------------------------------------------
 struct ParticleUpdateConfig {};
 struct ParticleUpdateResults {};

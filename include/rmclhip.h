@@ -144,6 +144,14 @@ rmclhip_status rmclhip_rcc_set_model_spherical(rmclhip_rcc* rcc, const rmclhip_s
  * dirs_xyz is width*height*3 floats, row-major buffer id = vid*width + hid */
 rmclhip_status rmclhip_rcc_set_model_o1dn(rmclhip_rcc* rcc, uint32_t width, uint32_t height,
                                           rmclhip_interval range, rmclhip_vec3 orig, const float* dirs_xyz);
+/* rm::ModelSetter<PinholeModel>::setModel (RCCEmbreePinhole, RCCEmbree.cpp:39-68; f = {fx, fy}, c = {cx, cy}:
+ * conversions.cpp:36-60): direction = normalize((hid-cx)/fx, (vid-cy)/fy, 1) mapped optical -> x-forward frame */
+rmclhip_status rmclhip_rcc_set_model_pinhole(rmclhip_rcc* rcc, uint32_t width, uint32_t height,
+                                             rmclhip_interval range, float fx, float fy, float cx, float cy);
+/* rm::ModelSetter<OnDnModel>::setModel (RCCEmbreeOnDn, RCCEmbree.cpp:102-130; fields conversions.cpp:96-120):
+ * one origin AND one direction per ray, width*height*3 floats each, buffer id = vid*width + hid */
+rmclhip_status rmclhip_rcc_set_model_ondn(rmclhip_rcc* rcc, uint32_t width, uint32_t height,
+                                          rmclhip_interval range, const float* origs_xyz, const float* dirs_xyz);
 /* public members Correspondences_::params.max_dist / adaptive_max_dist_min
  * (written by the node: micp_localization.cpp:608-609) */
 rmclhip_status rmclhip_rcc_set_params(rmclhip_rcc* rcc, float max_dist, float adaptive_max_dist_min);

@@ -123,6 +123,11 @@ def lib():
     L.orc_simulate_spherical.restype = i32
     L.orc_simulate_spherical.argtypes = [vp, vp, vp, vp, u32, i32, i32,
                                          vp, vp, vp, vp, vp, vp]
+    L.orc_simulate_pinhole.restype = i32
+    L.orc_simulate_pinhole.argtypes = [vp, u32, u32, Interval, vp, vp, vp, vp, u32, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.orc_simulate_ondn.restype = i32
+    L.orc_simulate_ondn.argtypes = [vp, u32, u32, Interval, vp, vp, vp, vp, u32, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.orc_pinhole_directions.argtypes = [u32, u32, vp, vp, vp]
     L.orc_simulate_o1dn.restype = i32
     L.orc_simulate_o1dn.argtypes = [vp, u32, u32, Interval, Vec3, vp, vp, vp, u32, i32, i32,
                                     vp, vp, vp, vp, vp, vp]
@@ -330,6 +335,30 @@ class Mesh:
             out["counters"] = dict(nodes_visited=cnt.nodes_visited, tris_tested=cnt.tris_tested, rays=cnt.rays)
         return out
 
+    def simulate_pinhole(self, width, height, range_min, range_max, f, c, Tsb, Tbm, bvh=True, nthreads=1,
+                         want=("hits", "ranges", "points", "normals", "face_ids")):
+        Tbm = np.ascontiguousarray(Tbm, dtype=TRANSFORM).reshape(-1)
+        Tsb = np.ascontiguousarray(Tsb, dtype=TRANSFORM).reshape(1)
+        fa, ca = np.asarray(f, dtype=np.float32), np.asarray(c, dtype=np.float32)
+        out = self._alloc(width * height * len(Tbm), want)
+        lib().orc_simulate_pinhole(self.h, width, height, Interval(range_min, range_max), _p(fa), _p(ca), _p(Tsb), _p(Tbm),
+                                   len(Tbm), int(bvh), nthreads, _p(out["hits"]), _p(out["ranges"]), _p(out["points"]),
+                                   _p(out["normals"]), _p(out["face_ids"]), None)
+        return out
+
+    def simulate_ondn(self, width, height, range_min, range_max, origs, dirs, Tsb, Tbm, bvh=True, nthreads=1,
+                      want=("hits", "ranges", "points", "normals", "face_ids")):
+        Tbm = np.ascontiguousarray(Tbm, dtype=TRANSFORM).reshape(-1)
+        Tsb = np.ascontiguousarray(Tsb, dtype=TRANSFORM).reshape(1)
+        origs = np.ascontiguousarray(origs, dtype=np.float32).reshape(-1, 3)
+        dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        assert len(origs) == len(dirs) == width * height
+        out = self._alloc(width * height * len(Tbm), want)
+        lib().orc_simulate_ondn(self.h, width, height, Interval(range_min, range_max), _p(origs), _p(dirs), _p(Tsb), _p(Tbm),
+                                len(Tbm), int(bvh), nthreads, _p(out["hits"]), _p(out["ranges"]), _p(out["points"]),
+                                _p(out["normals"]), _p(out["face_ids"]), None)
+        return out
+
     def pf_update(self, poses, attrs, beams, Tsb, params, bvh=True, nthreads=1, want_errors=False):
         """In-place update of attrs (returns errors if asked)."""
         poses = np.ascontiguousarray(poses, dtype=TRANSFORM).reshape(-1)
@@ -406,3 +435,11 @@ def statistics_p2l_exact(Tpre, dataset_points, dataset_mask, model_points, model
     s["covariance"] = r["covariance"].reshape(9)
     s["n_meas"] = r["n_meas"]
     return s
+
+
+def pinhole_directions(width, height, f, c):
+    """(H*W, 3) sensor-frame directions of a pinhole model (rmagine PinholeModel::getDirection)."""
+    fa, ca = np.asarray(f, dtype=np.float32), np.asarray(c, dtype=np.float32)
+    out = np.zeros((width * height, 3), dtype=np.float32)
+    lib().orc_pinhole_directions(width, height, _p(fa), _p(ca), _p(out))
+    return out

@@ -390,13 +390,27 @@ done:
   return found;
 }
 
+/* rmagine PinholeModel::getDirection (external; fields f = {fx, fy}, c = {cx, cy} pinned by
+ * rmcl_ros/src/util/conversions.cpp:36-60): optical ray ((hid - cx)/fx, (vid - cy)/fy, 1) normalised, then
+ * optical (x right, y down, z forward) -> sensor frame (x forward, y left, z up). */
+orc_vec3 orc_pinhole_direction(const float* f, const float* c, uint32_t vid, uint32_t hid)
+{
+  const float pX = ((float)hid - c[0]) / f[0];
+  const float pY = ((float)vid - c[1]) / f[1];
+  const float d = sqrtf((pX * pX + pY * pY) + 1.0f * 1.0f);
+  const orc_vec3 o = v3(pX / d, pY / d, 1.0f / d);
+  return v3(o.z, -o.x, -o.y);
+}
+
 /* ------------------------------------------------------------------------- */
 /* simulate                                                                   */
 /* ------------------------------------------------------------------------- */
 
 typedef struct {
   const orc_mesh* m;
-  int kind; /* 0 spherical, 1 o1dn */
+  int kind; /* 0 spherical, 1 o1dn, 2 pinhole, 3 ondn */
+  float pin_f[2], pin_c[2];
+  const float* origs;
   const orc_spherical_model* sph;
   uint32_t width, height;
   orc_interval range;
@@ -439,9 +453,18 @@ static void sim_range(sim_job* J, uint64_t begin, uint64_t end, orc_counters* cn
       dir_s = v3(cp * ct, cp * st, sp);
       orig_s = v3(0, 0, 0);
       org_m = Tsm.t;
-    } else {
+    } else if (J->kind == 1) {
       dir_s = v3(J->dirs[3 * loc], J->dirs[3 * loc + 1], J->dirs[3 * loc + 2]);
       orig_s = J->orig;
+      org_m = orc_transform_apply(Tsm, orig_s);
+    } else if (J->kind == 2) {
+      dir_s = orc_pinhole_direction(J->pin_f, J->pin_c, vid, hid);
+      orig_s = v3(0, 0, 0);
+      org_m = Tsm.t;
+    } else {
+      /* OnDn: per-ray origin and direction (RCCEmbreeOnDn, RCCEmbree.cpp:102-130) */
+      dir_s = v3(J->dirs[3 * loc], J->dirs[3 * loc + 1], J->dirs[3 * loc + 2]);
+      orig_s = v3(J->origs[3 * loc], J->origs[3 * loc + 1], J->origs[3 * loc + 2]);
       org_m = orc_transform_apply(Tsm, orig_s);
     }
     const orc_vec3 dir_m = orc_quat_rotate(Tsm.R, dir_s);
@@ -454,7 +477,7 @@ static void sim_range(sim_job* J, uint64_t begin, uint64_t end, orc_counters* cn
       if (J->ranges) J->ranges[g] = t;
       if (J->points) {
         orc_vec3 p = v_scale(dir_s, t);
-        if (J->kind == 1) p = v_add(p, orig_s);
+        if (J->kind == 1 || J->kind == 3) p = v_add(p, orig_s);
         J->points[3 * g] = p.x; J->points[3 * g + 1] = p.y; J->points[3 * g + 2] = p.z;
       }
       if (J->normals) {
@@ -969,4 +992,39 @@ void orc_mesh_tri_records(const orc_mesh* m, float* out)
     o[6] = T->e2.x; o[7] = T->e2.y; o[8] = T->e2.z; o[9] = T->Ng.x; o[10] = T->Ng.y; o[11] = T->Ng.z;
     o[12] = T->n.x; o[13] = T->n.y; o[14] = T->n.z;
   }
+}
+
+int orc_simulate_pinhole(const orc_mesh* m, uint32_t width, uint32_t height, orc_interval range, const float* f,
+                         const float* c, const orc_transform* Tsb, const orc_transform* Tbm, uint32_t nposes,
+                         int use_bvh, int nthreads, uint8_t* hits, float* ranges, float* points, float* normals,
+                         uint32_t* face_ids, orc_counters* cnt)
+{
+  sim_job J; memset(&J, 0, sizeof(J));
+  J.m = m; J.kind = 2; J.width = width; J.height = height; J.range = range;
+  J.pin_f[0] = f[0]; J.pin_f[1] = f[1]; J.pin_c[0] = c[0]; J.pin_c[1] = c[1];
+  J.Tsb = Tsb; J.Tbm = Tbm; J.nposes = nposes; J.use_bvh = use_bvh;
+  J.hits = hits; J.ranges = ranges; J.points = points; J.normals = normals; J.face_ids = face_ids;
+  return run_sim(&J, nthreads, cnt);
+}
+
+int orc_simulate_ondn(const orc_mesh* m, uint32_t width, uint32_t height, orc_interval range, const float* origs,
+                      const float* dirs, const orc_transform* Tsb, const orc_transform* Tbm, uint32_t nposes,
+                      int use_bvh, int nthreads, uint8_t* hits, float* ranges, float* points, float* normals,
+                      uint32_t* face_ids, orc_counters* cnt)
+{
+  sim_job J; memset(&J, 0, sizeof(J));
+  J.m = m; J.kind = 3; J.width = width; J.height = height; J.range = range; J.origs = origs; J.dirs = dirs;
+  J.Tsb = Tsb; J.Tbm = Tbm; J.nposes = nposes; J.use_bvh = use_bvh;
+  J.hits = hits; J.ranges = ranges; J.points = points; J.normals = normals; J.face_ids = face_ids;
+  return run_sim(&J, nthreads, cnt);
+}
+
+void orc_pinhole_directions(uint32_t width, uint32_t height, const float* f, const float* c, float* out)
+{
+  for (uint32_t vid = 0; vid < height; ++vid)
+    for (uint32_t hid = 0; hid < width; ++hid) {
+      const orc_vec3 d = orc_pinhole_direction(f, c, vid, hid);
+      float* o = out + 3u * ((size_t)vid * width + hid);
+      o[0] = d.x; o[1] = d.y; o[2] = d.z;
+    }
 }

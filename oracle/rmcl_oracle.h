@@ -114,6 +114,18 @@ int orc_simulate_o1dn(const orc_mesh* m, uint32_t width, uint32_t height, orc_in
                       uint8_t* hits, float* ranges, float* points, float* normals,
                       uint32_t* face_ids, orc_counters* cnt);
 
+/* RCCEmbreePinhole / RCCEmbreeOnDn (RCCEmbree.cpp:39-68,102-130): same intersector, other ray generators */
+orc_vec3 orc_pinhole_direction(const float* f, const float* c, uint32_t vid, uint32_t hid);
+void orc_pinhole_directions(uint32_t width, uint32_t height, const float* f, const float* c, float* out);
+int orc_simulate_pinhole(const orc_mesh* m, uint32_t width, uint32_t height, orc_interval range, const float* f,
+                         const float* c, const orc_transform* Tsb, const orc_transform* Tbm, uint32_t nposes,
+                         int use_bvh, int nthreads, uint8_t* hits, float* ranges, float* points, float* normals,
+                         uint32_t* face_ids, orc_counters* cnt);
+int orc_simulate_ondn(const orc_mesh* m, uint32_t width, uint32_t height, orc_interval range, const float* origs,
+                      const float* dirs, const orc_transform* Tsb, const orc_transform* Tbm, uint32_t nposes,
+                      int use_bvh, int nthreads, uint8_t* hits, float* ranges, float* points, float* normals,
+                      uint32_t* face_ids, orc_counters* cnt);
+
 /* ---- rm::statistics_p2l (CorrespondencesCPU.cpp:26-30; gate pinned by MICPSensorCPU.cpp:70-84) ---- */
 void orc_statistics_p2l_f32(const orc_transform* Tpre,
                             const float* dataset_points, const uint8_t* dataset_mask,

@@ -8,6 +8,6 @@ from ._capi import NoDeviceError, RmclHipError  # noqa: F401
 from .micp import MICPLocalization, MICPSensor  # noqa: F401
 from .pf import PCDSensorUpdaterHip, beams_from_points, sample_beams  # noqa: F401
 from .registration import (Context, CorrespondencesHIP, DeviceArray, HipMap, MapMap, RCCHipO1Dn,  # noqa: F401
-                           RCCHipSpherical, build_bvh_host, import_hip_map)
+                           RCCHipOnDn, RCCHipPinhole, RCCHipSpherical, build_bvh_host, import_hip_map)
 
 __version__ = "0.1.0"

@@ -71,6 +71,8 @@ SIGNATURES = {
     "rmclhip_rcc_set_tsb": (_i32, [_vp, _vp]),
     "rmclhip_rcc_set_model_spherical": (_i32, [_vp, C.POINTER(SphericalModel)]),
     "rmclhip_rcc_set_model_o1dn": (_i32, [_vp, _u32, _u32, Interval, Vec3, _vp]),
+    "rmclhip_rcc_set_model_pinhole": (_i32, [_vp, _u32, _u32, Interval, _f32, _f32, _f32, _f32]),
+    "rmclhip_rcc_set_model_ondn": (_i32, [_vp, _u32, _u32, Interval, _vp, _vp]),
     "rmclhip_rcc_set_params": (_i32, [_vp, _f32, _f32]),
     "rmclhip_rcc_set_dataset": (_i32, [_vp, _vp, _vp, _u32, _i32]),
     "rmclhip_rcc_set_dataset_from_ranges": (_i32, [_vp, _vp, _u32, C.POINTER(_u32)]),

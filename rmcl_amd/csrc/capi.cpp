@@ -114,6 +114,7 @@ struct rmclhip_rcc {
   uint32_t W = 0, H = 0;
   rmclhip_interval range{0.f, 0.f};
   f3 orig{0.f, 0.f, 0.f};
+  float pin_fc[4] = {1.f, 1.f, 0.f, 0.f};  // pinhole fx, fy, cx, cy
   DevBuf<float> d_model_tab;
   // params
   float max_dist = 1.0f, adaptive_max_dist_min = 1.0f;
@@ -418,6 +419,42 @@ rmclhip_status rmclhip_rcc_set_model_o1dn(rmclhip_rcc* r, uint32_t width, uint32
   return RMCLHIP_OK;
 }
 
+rmclhip_status rmclhip_rcc_set_model_pinhole(rmclhip_rcc* r, uint32_t width, uint32_t height, rmclhip_interval range,
+                                             float fx, float fy, float cx, float cy) {
+  ApiGuard guard_("rmclhip_rcc_set_model_pinhole");
+  if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_set_model_pinhole: null");
+  if (!(fx != 0.f) || !(fy != 0.f)) return fail(RMCLHIP_ERR_INVALID, "rcc_set_model_pinhole: zero focal length");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  r->kind = kModelPinhole;
+  r->graph_dirty = true;
+  r->W = width; r->H = height;
+  r->range = range;
+  r->orig = mk3(0.f, 0.f, 0.f);
+  r->pin_fc[0] = fx; r->pin_fc[1] = fy; r->pin_fc[2] = cx; r->pin_fc[3] = cy;
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_set_model_ondn(rmclhip_rcc* r, uint32_t width, uint32_t height, rmclhip_interval range,
+                                          const float* origs, const float* dirs) {
+  ApiGuard guard_("rmclhip_rcc_set_model_ondn");
+  if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_set_model_ondn: null");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  r->kind = kModelOnDn;
+  r->graph_dirty = true;
+  r->W = width; r->H = height;
+  r->range = range;
+  r->orig = mk3(0.f, 0.f, 0.f);
+  const size_t n = static_cast<size_t>(width) * height;
+  if (n == 0) return RMCLHIP_OK;
+  if (!origs || !dirs) return fail(RMCLHIP_ERR_INVALID, "rcc_set_model_ondn: origs / dirs is null");
+  HIPCHK(r->d_model_tab.reserve(6 * n));
+  HIPCHK(hipMemcpy(r->d_model_tab.p, origs, 3 * n * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(r->d_model_tab.p + 3 * n, dirs, 3 * n * sizeof(float), hipMemcpyHostToDevice));
+  return RMCLHIP_OK;
+}
+
 rmclhip_status rmclhip_rcc_set_params(rmclhip_rcc* r, float max_dist, float adaptive_max_dist_min) {
   ApiGuard guard_("rmclhip_rcc_set_params");
   if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_set_params: null");
@@ -465,7 +502,7 @@ rmclhip_status rmclhip_rcc_set_dataset_from_ranges(rmclhip_rcc* r, const float* 
   hipError_t e = hipMemcpy(d_r.p, ranges, n * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemsetAsync(r->d_counter, 0, sizeof(uint32_t), r->stream);
   if (e == hipSuccess)
-    e = launch_dataset_from_ranges(d_r.p, r->d_model_tab.p, r->kind, r->W, r->H, r->orig, r->range.min, r->range.max,
+    e = launch_dataset_from_ranges(d_r.p, r->d_model_tab.p, r->kind, r->W, r->H, r->orig, r->pin_fc, r->range.min, r->range.max,
                                    r->d_ds_points.p, r->d_ds_mask.p, r->d_counter, r->stream);
   uint32_t nv = 0;
   if (e == hipSuccess) e = hipMemcpyAsync(&nv, r->d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream);
@@ -506,6 +543,7 @@ static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
   p.tiles_y = (r->H + th - 1) / th;
   p.tfar = r->range.max;
   p.orig_s = r->orig;
+  p.pin_f[0] = r->pin_fc[0]; p.pin_f[1] = r->pin_fc[1]; p.pin_c[0] = r->pin_fc[2]; p.pin_c[1] = r->pin_fc[3];
   p.nposes = nposes;
   p.hits = r->d_hits.p; p.ranges = r->d_ranges.p; p.points = r->d_points.p; p.normals = r->d_normals.p;
   p.face_ids = r->d_face_ids.p;

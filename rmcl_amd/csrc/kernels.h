@@ -9,7 +9,7 @@
 
 namespace rmclhip {
 
-enum ModelKind : uint32_t { kModelNone = 0, kModelSpherical = 1, kModelO1Dn = 2 };
+enum ModelKind : uint32_t { kModelNone = 0, kModelSpherical = 1, kModelO1Dn = 2, kModelPinhole = 3, kModelOnDn = 4 };
 
 // one find() launch: every ray of (nposes x H x W)
 struct FindParams {
@@ -17,7 +17,10 @@ struct FindParams {
   const uint32_t* tris;    // TriRec[]
   // spherical: [cos(phi_v) (H) | sin(phi_v) (H) | cos(theta_h) (W) | sin(theta_h) (W)], host libm values
   // o1dn:      dirs xyz (W*H*3)
+  // ondn:      [origs xyz (W*H*3) | dirs xyz (W*H*3)]
+  // pinhole:   none (procedural from pin_f = {fx, fy}, pin_c = {cx, cy})
   const float* model_tab;
+  float pin_f[2], pin_c[2];
   uint32_t W, H;
   uint32_t tile_w_log2;    // wave = 2^tile_w_log2 x (64 >> tile_w_log2) rays of the scan image
   uint32_t tiles_x, tiles_y;
@@ -110,8 +113,8 @@ hipError_t launch_micp_init(MicpState* state, hipStream_t s);
 hipError_t launch_batch_solve(const double* partials, uint32_t nblocks, uint32_t nposes, xform Tsb,
                               xform* Tdelta_out, cstats* stats_out, hipStream_t s);
 hipError_t launch_dataset_from_ranges(const float* ranges, const float* model_tab, uint32_t kind, uint32_t W,
-                                      uint32_t H, f3 orig, float rmin, float rmax, float* points, uint8_t* mask,
-                                      uint32_t* n_valid, hipStream_t s);
+                                      uint32_t H, f3 orig, const float* pin_fc, float rmin, float rmax, float* points,
+                                      uint8_t* mask, uint32_t* n_valid, hipStream_t s);
 hipError_t launch_pf_update(const PfParams& p, int variant, hipStream_t s);
 hipError_t launch_pf_extract_weights(const void* attrs, uint32_t n, float* weights, hipStream_t s);
 

@@ -304,6 +304,16 @@ __device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes
   h.rec = best_rec;
 }
 
+// rmagine PinholeModel::getDirection: optical ray ((hid - cx)/fx, (vid - cy)/fy, 1) normalised (Vector::normalize
+// = divide by sqrt(x*x + y*y + z*z)), then optical (x right, y down, z forward) -> sensor (x forward, y left, z up).
+// Same operation order as oracle/rmcl_oracle.c:orc_pinhole_direction (IEEE division / sqrt on both sides).
+__device__ __forceinline__ f3 pinhole_direction(float fx, float fy, float cx, float cy, uint32_t vid, uint32_t hid) {
+  const float pX = (static_cast<float>(hid) - cx) / fx;
+  const float pY = (static_cast<float>(vid) - cy) / fy;
+  const float d = sqrtf((pX * pX + pY * pY) + 1.0f * 1.0f);
+  return mk3(1.0f / d, -(pX / d), -(pY / d));
+}
+
 // ---------------------------------------------------------------------------------------------
 // find
 // ---------------------------------------------------------------------------------------------
@@ -331,7 +341,7 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   if (p.Tsm_arr != nullptr) { Tsm = p.Tsm_arr[pose]; Tms = p.Tms_arr[pose]; }
   else { Tsm = p.Tsm; Tms = p.Tms; }
 
-  f3 dir_s, org_m;
+  f3 dir_s, org_m, orig_s = p.orig_s;
   if (kModel == kModelSpherical) {
     // rmagine SphericalModel::getDirection (convention pinned by rmcl_ros/src/util/conversions.cpp:174-188);
     // the four trig tables hold the host libm values of cos/sin(phi_v), cos/sin(theta_h)
@@ -339,9 +349,18 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
     const float ct = p.model_tab[2u * p.H + ch], st = p.model_tab[2u * p.H + p.W + ch];
     dir_s = mk3(cp * ct, cp * st, sp);
     org_m = Tsm.t;
+  } else if (kModel == kModelPinhole) {
+    dir_s = pinhole_direction(p.pin_f[0], p.pin_f[1], p.pin_c[0], p.pin_c[1], cv, ch);
+    org_m = Tsm.t;
+  } else if (kModel == kModelOnDn) {
+    const float* og = p.model_tab + 3u * static_cast<size_t>(loc);
+    const float* dr = p.model_tab + 3u * (static_cast<size_t>(p.W) * p.H + loc);
+    orig_s = mk3(og[0], og[1], og[2]);
+    dir_s = mk3(dr[0], dr[1], dr[2]);
+    org_m = xapply(Tsm, orig_s);
   } else {
     dir_s = mk3(p.model_tab[3u * loc], p.model_tab[3u * loc + 1u], p.model_tab[3u * loc + 2u]);
-    org_m = xapply(Tsm, p.orig_s);
+    org_m = xapply(Tsm, orig_s);
   }
   const f3 dir_m = qrot(Tsm.R, dir_s);
   const bool finite = (dir_m.x == dir_m.x) && (dir_m.y == dir_m.y) && (dir_m.z == dir_m.z);
@@ -362,7 +381,7 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
     if (p.ranges) p.ranges[g] = h.t;
     if (p.points) {
       f3 pt = scale3(dir_s, h.t);
-      if (kModel == kModelO1Dn) pt = add3(pt, p.orig_s);
+      if (kModel == kModelO1Dn || kModel == kModelOnDn) pt = add3(pt, orig_s);
       p.points[3 * g] = pt.x; p.points[3 * g + 1] = pt.y; p.points[3 * g + 2] = pt.z;
     }
     if (p.normals) {
@@ -585,22 +604,29 @@ __global__ void __launch_bounds__(64) k_batch_solve(const double* __restrict__ p
 
 // MICPSphericalSensorCPU::unpackMessage / MICPO1DnSensorCPU::unpackMessage (dataset construction)
 __global__ void k_dataset_from_ranges(const float* __restrict__ ranges, const float* __restrict__ tab, uint32_t kind,
-                                      uint32_t W, uint32_t H, f3 orig, float rmin, float rmax,
-                                      float* __restrict__ points, uint8_t* __restrict__ mask,
-                                      uint32_t* __restrict__ n_valid) {
+                                      uint32_t W, uint32_t H, f3 orig, float fx, float fy, float cx, float cy,
+                                      float rmin, float rmax, float* __restrict__ points,
+                                      uint8_t* __restrict__ mask, uint32_t* __restrict__ n_valid) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= W * H) return;
   const uint32_t vid = i / W, hid = i - vid * W;
   const float r = ranges[i];
-  f3 dir;
+  f3 dir, o = orig;
   if (kind == kModelSpherical) {
     const float cp = tab[vid], sp = tab[H + vid], ct = tab[2u * H + hid], st = tab[2u * H + W + hid];
     dir = mk3(cp * ct, cp * st, sp);
+  } else if (kind == kModelPinhole) {
+    dir = pinhole_direction(fx, fy, cx, cy, vid, hid);
+  } else if (kind == kModelOnDn) {
+    o = mk3(tab[3u * i], tab[3u * i + 1u], tab[3u * i + 2u]);
+    const float* dr = tab + 3u * (static_cast<size_t>(W) * H + i);
+    dir = mk3(dr[0], dr[1], dr[2]);
   } else {
     dir = mk3(tab[3u * i], tab[3u * i + 1u], tab[3u * i + 2u]);
   }
+  // unpackMessage: spherical adds no origin (MICPSphericalSensorCPU.cpp:218), the others do (MICPO1DnSensorCPU.cpp:211-213)
   f3 pt = scale3(dir, r);
-  if (kind == kModelO1Dn) pt = add3(pt, orig);
+  if (kind != kModelSpherical) pt = add3(pt, o);
   points[3u * i] = pt.x; points[3u * i + 1u] = pt.y; points[3u * i + 2u] = pt.z;
   const bool out_of_range = (r < rmin) || (r > rmax);
   mask[i] = out_of_range ? 0 : 1;
@@ -719,14 +745,21 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
   uint32_t nblocks = (ntiles + 3u) / 4u;
   nblocks = (nblocks + 7u) & ~7u;  // the XCD remap in k_find needs gridDim.x % 8 == 0
   dim3 grid(nblocks, p.nposes, 1), block(256, 1, 1);
-  if (variant == 0) {  // packet traversal (needs map stack_need <= 64, checked by the caller)
-    if (kind == kModelSpherical) hipLaunchKernelGGL((k_find<kModelSpherical, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((k_find<kModelO1Dn, true>), grid, block, 0, s, p);
-  } else {             // per-lane while-while traversal, stack in scratch
-    const size_t lds = 16u * 256u * sizeof(uint32_t);
-    if (kind == kModelSpherical) hipLaunchKernelGGL((k_find<kModelSpherical, false>), grid, block, lds, s, p);
-    else hipLaunchKernelGGL((k_find<kModelO1Dn, false>), grid, block, lds, s, p);
+#define RMCL_LAUNCH_FIND(PACKET, LDS)                                                                          \
+  switch (kind) {                                                                                              \
+    case kModelSpherical: hipLaunchKernelGGL((k_find<kModelSpherical, PACKET>), grid, block, LDS, s, p); break; \
+    case kModelO1Dn: hipLaunchKernelGGL((k_find<kModelO1Dn, PACKET>), grid, block, LDS, s, p); break;           \
+    case kModelPinhole: hipLaunchKernelGGL((k_find<kModelPinhole, PACKET>), grid, block, LDS, s, p); break;     \
+    case kModelOnDn: hipLaunchKernelGGL((k_find<kModelOnDn, PACKET>), grid, block, LDS, s, p); break;           \
+    default: return hipErrorInvalidValue;                                                                      \
   }
+  if (variant == 0) {  // wave-packet traversal (needs map stack_need <= 64, checked at map creation)
+    RMCL_LAUNCH_FIND(true, 0)
+  } else {             // per-lane while-while traversal: 16 stack entries per lane in LDS, the rest in scratch
+    const size_t lds = 16u * 256u * sizeof(uint32_t);
+    RMCL_LAUNCH_FIND(false, lds)
+  }
+#undef RMCL_LAUNCH_FIND
   return hipGetLastError();
 }
 
@@ -778,11 +811,11 @@ hipError_t launch_batch_solve(const double* partials, uint32_t nblocks, uint32_t
 }
 
 hipError_t launch_dataset_from_ranges(const float* ranges, const float* model_tab, uint32_t kind, uint32_t W,
-                                      uint32_t H, f3 orig, float rmin, float rmax, float* points, uint8_t* mask,
-                                      uint32_t* n_valid, hipStream_t s) {
+                                      uint32_t H, f3 orig, const float* pin_fc, float rmin, float rmax, float* points,
+                                      uint8_t* mask, uint32_t* n_valid, hipStream_t s) {
   const uint32_t n = W * H;
   hipLaunchKernelGGL(k_dataset_from_ranges, dim3((n + 255u) / 256u), dim3(256), 0, s, ranges, model_tab, kind, W, H,
-                     orig, rmin, rmax, points, mask, n_valid);
+                     orig, pin_fc[0], pin_fc[1], pin_fc[2], pin_fc[3], rmin, rmax, points, mask, n_valid);
   return hipGetLastError();
 }
 

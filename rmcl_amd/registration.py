@@ -332,3 +332,26 @@ class RCCHipO1Dn(CorrespondencesHIP):
         o = _capi.Vec3(*[float(x) for x in orig])
         _capi.check(_capi.lib().rmclhip_rcc_set_model_o1dn(self._h, int(width), int(height), rng, o, _ptr(d)))
         self._model_shape = (int(height), int(width))
+
+
+class RCCHipPinhole(CorrespondencesHIP):
+    """rmcl::RCCEmbreePinhole / RCCOptixPinhole on gfx950 (RCCEmbree.cpp:39-68): depth camera."""
+
+    def setModel(self, width, height, range_min, range_max, fx, fy, cx, cy):
+        rng = _capi.Interval(range_min, range_max)
+        _capi.check(_capi.lib().rmclhip_rcc_set_model_pinhole(self._h, int(width), int(height), rng, float(fx), float(fy),
+                                                              float(cx), float(cy)))
+        self._model_shape = (int(height), int(width))
+
+
+class RCCHipOnDn(CorrespondencesHIP):
+    """rmcl::RCCEmbreeOnDn / RCCOptixOnDn on gfx950 (RCCEmbree.cpp:102-130): N origins, N directions."""
+
+    def setModel(self, width, height, range_min, range_max, origs, dirs):
+        o = np.ascontiguousarray(origs, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        if len(o) != width * height or len(d) != width * height:
+            raise ValueError("origs / dirs must hold width*height entries")
+        rng = _capi.Interval(range_min, range_max)
+        _capi.check(_capi.lib().rmclhip_rcc_set_model_ondn(self._h, int(width), int(height), rng, _ptr(o), _ptr(d)))
+        self._model_shape = (int(height), int(width))
