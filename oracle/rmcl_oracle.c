@@ -953,11 +953,13 @@ int orc_trace_bvh4(const uint32_t* nodes, uint32_t n_nodes, const uint32_t* tris
     if (ref >= n_nodes) return -2;
     const float* nd = (const float*)(nodes + 32u * ref);
     const uint32_t* ch = nodes + 32u * ref + 24u;
-    for (int c = 0; c < 4; ++c) {
-      if (ch[c] == 0xFFFFFFFFu) continue;
+    const uint32_t nk = nodes[32u * ref + 28u];   /* number of valid children; unused slots are skipped */
+    if (nk < 1 || nk > 4) return -2;
+    for (uint32_t c = 0; c < nk; ++c) {
       orc_node bx;
-      bx.bmin[0] = nd[0 + c]; bx.bmin[1] = nd[4 + c]; bx.bmin[2] = nd[8 + c];
-      bx.bmax[0] = nd[12 + c]; bx.bmax[1] = nd[16 + c]; bx.bmax[2] = nd[20 + c];
+      bx.bmin[0] = nd[0 + 2 * c]; bx.bmax[0] = nd[1 + 2 * c];
+      bx.bmin[1] = nd[8 + 2 * c]; bx.bmax[1] = nd[9 + 2 * c];
+      bx.bmin[2] = nd[16 + 2 * c]; bx.bmax[2] = nd[17 + 2 * c];
       float tn;
       if (box_hit(&bx, o, inv, tnear, best_t, &tn)) { if (sp >= 256) return -1; stack[sp++] = ch[c]; }
     }

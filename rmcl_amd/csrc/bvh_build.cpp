@@ -235,11 +235,13 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
     }
     const uint32_t stack_here = it.stack_before + static_cast<uint32_t>(nk - 1);
     stack_need = std::max(stack_need, stack_here);
+    nd.n_children = static_cast<uint32_t>(nk);
     for (int s = 0; s < 4; ++s) {
       if (s < nk) {
         const Node2& ch = n2[kids[s]];
-        nd.minx[s] = ch.b.mn[0] - pad; nd.miny[s] = ch.b.mn[1] - pad; nd.minz[s] = ch.b.mn[2] - pad;
-        nd.maxx[s] = ch.b.mx[0] + pad; nd.maxy[s] = ch.b.mx[1] + pad; nd.maxz[s] = ch.b.mx[2] + pad;
+        nd.x[2 * s] = ch.b.mn[0] - pad; nd.x[2 * s + 1] = ch.b.mx[0] + pad;
+        nd.y[2 * s] = ch.b.mn[1] - pad; nd.y[2 * s + 1] = ch.b.mx[1] + pad;
+        nd.z[2 * s] = ch.b.mn[2] - pad; nd.z[2 * s + 1] = ch.b.mx[2] + pad;
         if (ch.leaf()) {
           nd.child[s] = make_leaf_ref(ch.first, ch.count);
         } else {
@@ -249,9 +251,11 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
           queue.push_back({kids[s], it.depth + 1, stack_here});
         }
       } else {
-        nd.minx[s] = nd.miny[s] = nd.minz[s] = INFINITY;
-        nd.maxx[s] = nd.maxy[s] = nd.maxz[s] = -INFINITY;
-        nd.child[s] = kEmptyRef;
+        // unused slot: unreachable point box + a harmless leaf reference (layout.h)
+        nd.x[2 * s] = nd.x[2 * s + 1] = kFarPoint[0];
+        nd.y[2 * s] = nd.y[2 * s + 1] = kFarPoint[1];
+        nd.z[2 * s] = nd.z[2 * s + 1] = kFarPoint[2];
+        nd.child[s] = make_leaf_ref(0, 1);
       }
     }
   }

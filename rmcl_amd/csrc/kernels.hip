@@ -62,13 +62,18 @@ __device__ __forceinline__ bool tri_accept(f3 v0, f3 e1, f3 e2, f3 Ng, f3 O, f3 
   return (den != 0.0f) && (U >= 0.0f) && (V >= 0.0f) && ((U + V) <= aden);
 }
 
-__device__ __forceinline__ void slab(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, f3 inv,
-                                     f3 noi, float best_t, float& tn, float& tf) {
-  const float ax = fmaf(mnx, inv.x, noi.x), bx = fmaf(mxx, inv.x, noi.x);
-  const float ay = fmaf(mny, inv.y, noi.y), by = fmaf(mxy, inv.y, noi.y);
-  const float az = fmaf(mnz, inv.z, noi.z), bz = fmaf(mxz, inv.z, noi.z);
-  tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-  tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best_t));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// One child's slab test.  px/py/pz = (min, max) plane pair of the child per axis; both plane distances of an
+// axis are ONE packed FMA (v_pk_fma_f32).  Free-form arithmetic: conservative because the boxes are padded.
+__device__ __forceinline__ void slab(f2 px, f2 py, f2 pz, f3 inv, f3 noi, float best_t, float& tn, float& tf) {
+  const f2 ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+  const f2 nx = {noi.x, noi.x}, ny = {noi.y, noi.y}, nz = {noi.z, noi.z};
+  const f2 tx = __builtin_elementwise_fma(px, ix, nx);
+  const f2 ty = __builtin_elementwise_fma(py, iy, ny);
+  const f2 tz = __builtin_elementwise_fma(pz, iz, nz);
+  tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), 0.0f));
+  tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), best_t));
 }
 
 #define RMCL_CSWAP(i, j)                                   \
@@ -96,18 +101,18 @@ __device__ __forceinline__ void trace_packet(cu32p nodes, cu32p tris, f3 O, f3 D
   uint32_t cur = 0;  // uniform; root is always an inner node
   for (;;) {
     if (!(cur & kLeafBit)) {
-      // whole node in two s_load_dwordx16: dwords 0..15 = minx miny minz maxx, 16..31 = maxy maxz child rsvd
+      // whole node in two s_load_dwordx16: dwords 0..15 = x pairs, y pairs; 16..31 = z pairs, child[4], count
       const cu32x16p np = reinterpret_cast<cu32x16p>(nodes + cur * kNodeDwords);
       const u32x16 lo = np[0], hi = np[1];
       uint32_t key[4], ref[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         float tn, tf;
-        slab(asf(lo[0 + c]), asf(lo[4 + c]), asf(lo[8 + c]), asf(lo[12 + c]), asf(hi[0 + c]), asf(hi[4 + c]), inv, noi,
-             best_t, tn, tf);
+        const f2 px = {asf(lo[2 * c]), asf(lo[2 * c + 1])}, py = {asf(lo[8 + 2 * c]), asf(lo[9 + 2 * c])};
+        const f2 pz = {asf(hi[2 * c]), asf(hi[2 * c + 1])};
+        slab(px, py, pz, inv, noi, best_t, tn, tf);
         ref[c] = hi[8 + c];
-        // empty slots carry an inverted box, which a min/max slab test reads as infinite: mask them
-        const uint64_t m = (ref[c] != kEmptyRef) ? __ballot(tn <= tf) : 0ull;
+        const uint64_t m = __ballot(tn <= tf);  // unused slots hold an unreachable box (layout.h)
         uint32_t k = kNone;
         if (m != 0) {
           const int first = __builtin_ctzll(m);
@@ -173,18 +178,19 @@ __device__ __forceinline__ void trace_lane(const uint32_t* __restrict__ nodes, c
   uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
   while (cur != kDone) {
     if (!(cur & kLeafBit)) {
+      // 7 x global_load_dwordx4: x pairs (children 0-1, 2-3), y pairs, z pairs, child[4]
       const uint4* np = reinterpret_cast<const uint4*>(nodes) + static_cast<size_t>(cur) * 8u;
-      const uint4 qmnx = np[0], qmny = np[1], qmnz = np[2], qmxx = np[3], qmxy = np[4], qmxz = np[5], qch = np[6];
-      const uint32_t amnx[4] = {qmnx.x, qmnx.y, qmnx.z, qmnx.w}, amny[4] = {qmny.x, qmny.y, qmny.z, qmny.w};
-      const uint32_t amnz[4] = {qmnz.x, qmnz.y, qmnz.z, qmnz.w}, amxx[4] = {qmxx.x, qmxx.y, qmxx.z, qmxx.w};
-      const uint32_t amxy[4] = {qmxy.x, qmxy.y, qmxy.z, qmxy.w}, amxz[4] = {qmxz.x, qmxz.y, qmxz.z, qmxz.w};
+      const uint4 qx0 = np[0], qx1 = np[1], qy0 = np[2], qy1 = np[3], qz0 = np[4], qz1 = np[5], qch = np[6];
+      const f2 bx[4] = {{asf(qx0.x), asf(qx0.y)}, {asf(qx0.z), asf(qx0.w)}, {asf(qx1.x), asf(qx1.y)}, {asf(qx1.z), asf(qx1.w)}};
+      const f2 by[4] = {{asf(qy0.x), asf(qy0.y)}, {asf(qy0.z), asf(qy0.w)}, {asf(qy1.x), asf(qy1.y)}, {asf(qy1.z), asf(qy1.w)}};
+      const f2 bz[4] = {{asf(qz0.x), asf(qz0.y)}, {asf(qz0.z), asf(qz0.w)}, {asf(qz1.x), asf(qz1.y)}, {asf(qz1.z), asf(qz1.w)}};
       uint32_t ref[4] = {qch.x, qch.y, qch.z, qch.w};
       uint32_t key[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         float tn, tf;
-        slab(asf(amnx[c]), asf(amny[c]), asf(amnz[c]), asf(amxx[c]), asf(amxy[c]), asf(amxz[c]), inv, noi, best_t, tn, tf);
-        key[c] = ((tn <= tf) && (ref[c] != kEmptyRef)) ? __float_as_uint(tn) : kNone;
+        slab(bx[c], by[c], bz[c], inv, noi, best_t, tn, tf);
+        key[c] = (tn <= tf) ? __float_as_uint(tn) : kNone;  // unused slots hold an unreachable box (layout.h)
       }
       RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
       if (key[3] != kNone) { lds_stack[sp * lds_stride] = ref[3]; ++sp; }
@@ -247,18 +253,19 @@ __device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes
   while (__any(cur != kDone)) {
     // phase 1: inner nodes
     while ((cur != kDone) && !(cur & kLeafBit)) {
+      // 7 x global_load_dwordx4: x pairs (children 0-1, 2-3), y pairs, z pairs, child[4]
       const uint4* np = reinterpret_cast<const uint4*>(nodes) + static_cast<size_t>(cur) * 8u;
-      const uint4 qmnx = np[0], qmny = np[1], qmnz = np[2], qmxx = np[3], qmxy = np[4], qmxz = np[5], qch = np[6];
-      const uint32_t amnx[4] = {qmnx.x, qmnx.y, qmnx.z, qmnx.w}, amny[4] = {qmny.x, qmny.y, qmny.z, qmny.w};
-      const uint32_t amnz[4] = {qmnz.x, qmnz.y, qmnz.z, qmnz.w}, amxx[4] = {qmxx.x, qmxx.y, qmxx.z, qmxx.w};
-      const uint32_t amxy[4] = {qmxy.x, qmxy.y, qmxy.z, qmxy.w}, amxz[4] = {qmxz.x, qmxz.y, qmxz.z, qmxz.w};
+      const uint4 qx0 = np[0], qx1 = np[1], qy0 = np[2], qy1 = np[3], qz0 = np[4], qz1 = np[5], qch = np[6];
+      const f2 bx[4] = {{asf(qx0.x), asf(qx0.y)}, {asf(qx0.z), asf(qx0.w)}, {asf(qx1.x), asf(qx1.y)}, {asf(qx1.z), asf(qx1.w)}};
+      const f2 by[4] = {{asf(qy0.x), asf(qy0.y)}, {asf(qy0.z), asf(qy0.w)}, {asf(qy1.x), asf(qy1.y)}, {asf(qy1.z), asf(qy1.w)}};
+      const f2 bz[4] = {{asf(qz0.x), asf(qz0.y)}, {asf(qz0.z), asf(qz0.w)}, {asf(qz1.x), asf(qz1.y)}, {asf(qz1.z), asf(qz1.w)}};
       uint32_t ref[4] = {qch.x, qch.y, qch.z, qch.w};
       uint32_t key[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         float tn, tf;
-        slab(asf(amnx[c]), asf(amny[c]), asf(amnz[c]), asf(amxx[c]), asf(amxy[c]), asf(amxz[c]), inv, noi, best_t, tn, tf);
-        key[c] = ((tn <= tf) && (ref[c] != kEmptyRef)) ? __float_as_uint(tn) : kNone;
+        slab(bx[c], by[c], bz[c], inv, noi, best_t, tn, tf);
+        key[c] = (tn <= tf) ? __float_as_uint(tn) : kNone;  // unused slots hold an unreachable box (layout.h)
       }
 #ifdef RMCL_FULL_SORT
       RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)

@@ -2,17 +2,23 @@
 //
 // BVH4 node, 128 B (32 dwords), 128-B aligned: one wave fetches a whole node with two
 // s_load_dwordx16 (packet traversal) or seven global_load_dwordx4 per lane (per-lane
-// traversal).  Child boxes are SoA so that child c's six bounds sit at dword c of six
-// consecutive 16-B vectors.
+// traversal).  Per axis the four children's bounds are interleaved (min, max) pairs, so a
+// child's two planes of one axis sit in ONE 64-bit register pair and the slab distances of both
+// planes are ONE packed FMA (v_pk_fma_f32):
 //
-//   dword  0.. 3  minx[4]      dword 12..15  maxx[4]     dword 24..27  child[4]
-//   dword  4.. 7  miny[4]      dword 16..19  maxy[4]     dword 28..31  reserved
-//   dword  8..11  minz[4]      dword 20..23  maxz[4]
+//   dword  0.. 7  x: mn0 mx0 mn1 mx1 mn2 mx2 mn3 mx3
+//   dword  8..15  y: mn0 mx0 ... mn3 mx3
+//   dword 16..23  z: mn0 mx0 ... mn3 mx3
+//   dword 24..27  child[4]
+//   dword 28      number of valid children (1..4)        dword 29..31 reserved
 //
 // child reference: bit31 = 0 -> index of another Node4
 //                  bit31 = 1 -> leaf: bits 28..30 = count-1 (1..8 triangles),
 //                                     bits  0..27 = index of the first TriRec
-//                  0xFFFFFFFF   -> empty slot (its box is inverted: never hit)
+// Unused slots hold a degenerate box far outside any scene (min = max = kFarPoint: the slab test can never
+// accept it for a finite search interval) and a reference to leaf {record 0, count 1}, so that no kernel
+// needs an "is this slot empty" test; should a pathological ray ever pass the box test, it only re-tests
+// triangle 0.
 //
 // Triangle record, 64 B (16 dwords), stored in leaf order:
 //   v0.xyz | e1.xyz (= v0-v1) | e2.xyz (= v2-v0) | Ng.xyz (= cross(e2,e1)) | n.xyz (unit) | face_id
@@ -24,17 +30,17 @@
 namespace rmclhip {
 
 constexpr uint32_t kLeafBit = 0x80000000u;
-constexpr uint32_t kEmptyRef = 0xFFFFFFFFu;
 constexpr uint32_t kNodeDwords = 32;
 constexpr uint32_t kTriDwords = 16;
 constexpr uint32_t kMaxLeafTris = 4;
 constexpr uint32_t kInvalidFace = 0xFFFFFFFFu;
+constexpr float kFarPoint[3] = {1.0e30f, 2.0e30f, 3.0e30f};
 
 struct alignas(128) Node4 {
-  float minx[4], miny[4], minz[4];
-  float maxx[4], maxy[4], maxz[4];
+  float x[8], y[8], z[8];  // per axis: mn0 mx0 mn1 mx1 mn2 mx2 mn3 mx3
   uint32_t child[4];
-  uint32_t reserved[4];
+  uint32_t n_children;
+  uint32_t reserved[3];
 };
 static_assert(sizeof(Node4) == 128, "Node4 must be 128 B");
 

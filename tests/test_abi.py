@@ -111,17 +111,18 @@ def test_bvh_builder_invariants(ra, orc, meshes, name):
             return pts.min(0), pts.max(0), depth, stack
         assert ref < info["n_nodes"]
         lo, hi, dmax, smax = np.full(3, np.inf), np.full(3, -np.inf), depth, stack
-        kids = [c for c in range(4) if nodes[ref, 24 + c] != 0xFFFFFFFF]
-        assert len(kids) >= 1
-        for c in range(4):
+        nk = int(nodes[ref, 28])
+        assert 1 <= nk <= 4
+        kids = list(range(nk))
+        for c in range(nk, 4):   # unused slots: unreachable point box + harmless leaf reference
+            assert fl[ref, 2 * c] == fl[ref, 2 * c + 1] >= 1e30 and nodes[ref, 24 + c] == 0x80000000
+        for c in kids:
             child = int(nodes[ref, 24 + c])
-            if child == 0xFFFFFFFF:
-                continue
             if not child & 0x80000000:
                 assert child > ref  # breadth-first order: children come later
             clo, chi, d, s = subtree_bounds(child, depth + 1, stack + len(kids) - 1)
-            bmin = np.array([fl[ref, 0 + c], fl[ref, 4 + c], fl[ref, 8 + c]])
-            bmax = np.array([fl[ref, 12 + c], fl[ref, 16 + c], fl[ref, 20 + c]])
+            bmin = np.array([fl[ref, 0 + 2 * c], fl[ref, 8 + 2 * c], fl[ref, 16 + 2 * c]])
+            bmax = np.array([fl[ref, 1 + 2 * c], fl[ref, 9 + 2 * c], fl[ref, 17 + 2 * c]])
             assert np.all(bmin <= clo) and np.all(bmax >= chi)       # (padded) box contains the subtree
             lo, hi, dmax, smax = np.minimum(lo, clo), np.maximum(hi, chi), max(dmax, d), max(smax, s)
         return lo, hi, dmax, smax
@@ -158,7 +159,7 @@ def test_tiny_meshes_build(ra, orc):
     v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0.5], [2, 2, 2], [3, 1, 0]], np.float32)
     for f in (np.array([[0, 1, 2]], np.uint32), np.array([[0, 1, 2], [1, 3, 2], [2, 3, 4], [3, 5, 4], [0, 2, 4]], np.uint32)):
         info, nodes, tris = ra.build_bvh_host(v, f)
-        assert info["n_nodes"] >= 1 and not (nodes[0, 24] == 0xFFFFFFFF)
+        assert info["n_nodes"] >= 1 and 1 <= nodes[0, 28] <= 4
         m = orc.Mesh(v, f)
         for O, D in (((0.2, 0.2, 3), (0, 0, -1)), ((0.7, 0.7, 3), (0, 0, -1)), ((5, 5, 5), (1, 0, 0))):
             assert orc.trace_bvh4(nodes, tris, O, D) == m.intersect(O, D)
