@@ -254,6 +254,14 @@ rmclhip_status rmclhip_pf_sync(rmclhip_pf* pf);
 /* optional debug/parity output of the next update: per (particle, beam) error in metres
  * (device buffer of n_particles*n_beams floats, or NULL to disable) */
 rmclhip_status rmclhip_pf_set_error_output(rmclhip_pf* pf, float* errors_dev);
+/* MotionUpdater<MemT>::update inner loop: TFMotionUpdaterGPU / particle_move_and_forget_kernel
+ * (rmcl_ros/src/rmcl/particle_motion.cu:11-46) and, with check_collision != 0, the wall-collision test the CPU
+ * updater adds (TFMotionUpdaterCPU.cpp:17-50,207-221): pose <- pose * T_bnew_bold;
+ * n_meas -= forget_rate * n_meas; a particle whose step crosses the mesh gets likelihood {0, 0, MAX_N_MEAS}.
+ * forget_rate is the already combined rate (TFMotionUpdaterCPU.cpp:172-174). */
+rmclhip_status rmclhip_pf_motion_update(rmclhip_pf* pf, rmclhip_transform* poses_dev,
+                                        rmclhip_particle_attributes* attrs_dev, uint32_t n_particles,
+                                        const rmclhip_transform* T_bnew_bold, double forget_rate, int check_collision);
 /* gather likelihood.mean of every particle into a dense float array (the payload of the
  * multi-GPU all-gather) */
 rmclhip_status rmclhip_pf_extract_weights(rmclhip_pf* pf, const rmclhip_particle_attributes* attrs_dev,

@@ -148,6 +148,7 @@ def lib():
     L.orc_evaluate_rcc.argtypes = [vp, vp, vp, i32]
     L.orc_pf_update.restype = i32
     L.orc_pf_update.argtypes = [vp, vp, vp, u32, vp, u32, vp, vp, i32, i32, vp]
+    L.orc_pf_motion_update.argtypes = [vp, vp, vp, u32, vp, C.c_double, u32, i32]
     _lib = L
     return L
 
@@ -358,6 +359,13 @@ class Mesh:
                                 len(Tbm), int(bvh), nthreads, _p(out["hits"]), _p(out["ranges"]), _p(out["points"]),
                                 _p(out["normals"]), _p(out["face_ids"]), None)
         return out
+
+    def pf_motion_update(self, poses, attrs, T_bnew_bold, forget_rate, collision=True, max_n_meas=10000, bvh=True):
+        """In-place TFMotionUpdaterCPU inner loop (poses, attrs are modified)."""
+        assert poses.dtype == TRANSFORM and attrs.dtype == PARTICLE_ATTRIBUTES
+        T = np.ascontiguousarray(T_bnew_bold, dtype=TRANSFORM).reshape(1)
+        lib().orc_pf_motion_update(self.h if collision else None, _p(poses), _p(attrs), len(poses), _p(T), float(forget_rate),
+                                   int(max_n_meas), int(bvh))
 
     def pf_update(self, poses, attrs, beams, Tsb, params, bvh=True, nthreads=1, want_errors=False):
         """In-place update of attrs (returns errors if asked)."""

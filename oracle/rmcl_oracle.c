@@ -1030,3 +1030,38 @@ void orc_pinhole_directions(uint32_t width, uint32_t height, const float* f, con
       o[0] = d.x; o[1] = d.y; o[2] = d.z;
     }
 }
+
+/* ------------------------------------------------------------------------- */
+/* particle-filter motion update: TFMotionUpdaterCPU::update inner loop        */
+/* (rmcl_ros/src/rmcl/TFMotionUpdaterCPU.cpp:184-224) == particle_motion.cu:11-34 */
+/* plus the wall-collision test collision_in_between (:17-50)                   */
+/* ------------------------------------------------------------------------- */
+int orc_collision_in_between(const orc_mesh* m, orc_vec3 p1, orc_vec3 p2, int use_bvh)
+{
+  orc_vec3 vec = v_sub(p2, p1);
+  const float length = sqrtf((vec.x * vec.x + vec.y * vec.y) + vec.z * vec.z);
+  if (length < 0.00001) return 0;
+  vec = v3(vec.x / length, vec.y / length, vec.z / length);
+  float t; uint32_t face;
+  const int hit = use_bvh ? orc_intersect_bvh(m, p1, vec, 0.0f, length, &t, &face, NULL)
+                          : orc_intersect_brute(m, p1, vec, 0.0f, length, &t, &face);
+  return hit > 0;
+}
+
+void orc_pf_motion_update(const orc_mesh* m /* NULL: no collision test */, orc_transform* poses,
+                          orc_particle_attributes* attrs, uint32_t n, const orc_transform* T_bnew_bold,
+                          double forget_rate, uint32_t max_n_meas, int use_bvh)
+{
+  for (uint32_t i = 0; i < n; ++i) {
+    const orc_transform pose_old = poses[i];
+    orc_particle_attributes attr = attrs[i];
+    const orc_transform pose_new = orc_transform_mult(pose_old, *T_bnew_bold);
+    /* `n_meas -= forget_rate * n_meas` on a uint32: double arithmetic, truncating store */
+    attr.likelihood.n_meas = (uint32_t)((double)attr.likelihood.n_meas - forget_rate * (double)attr.likelihood.n_meas);
+    if (m && orc_collision_in_between(m, pose_old.t, pose_new.t, use_bvh)) {
+      attr.likelihood.mean = 0.0f; attr.likelihood.sigma = 0.0f; attr.likelihood.n_meas = max_n_meas;
+    }
+    poses[i] = pose_new;
+    attrs[i] = attr;
+  }
+}

@@ -159,6 +159,11 @@ int orc_pf_update(const orc_mesh* m, const orc_transform* poses, orc_particle_at
                   const orc_transform* Tsb, const orc_pf_params* p, int use_bvh, int nthreads,
                   float* errors_out /* nullable, n*nbeams */);
 
+/* ---- particle-filter motion update (TFMotionUpdaterCPU.cpp:17-50,184-224; particle_motion.cu:11-34) ---- */
+int orc_collision_in_between(const orc_mesh* m, orc_vec3 p1, orc_vec3 p2, int use_bvh);
+void orc_pf_motion_update(const orc_mesh* m, orc_transform* poses, orc_particle_attributes* attrs, uint32_t n,
+                          const orc_transform* T_bnew_bold, double forget_rate, uint32_t max_n_meas, int use_bvh);
+
 #ifdef __cplusplus
 }
 #endif

@@ -102,6 +102,7 @@ SIGNATURES = {
     "rmclhip_pf_update_async": (_i32, [_vp, _vp, _vp, _u32, _vp, _u32, _vp]),
     "rmclhip_pf_sync": (_i32, [_vp]),
     "rmclhip_pf_set_error_output": (_i32, [_vp, _vp]),
+    "rmclhip_pf_motion_update": (_i32, [_vp, _vp, _vp, _u32, _vp, _dbl, _i32]),
     "rmclhip_pf_extract_weights": (_i32, [_vp, _vp, _u32, _vp]),
     "rmclhip_pf_time_update": (_i32, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32, C.POINTER(_f32)]),
     "rmclhip_pf_set_variant": (_i32, [_vp, _i32]),

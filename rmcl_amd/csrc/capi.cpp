@@ -1113,6 +1113,20 @@ rmclhip_status rmclhip_pf_sync(rmclhip_pf* f) {
   return RMCLHIP_OK;
 }
 
+rmclhip_status rmclhip_pf_motion_update(rmclhip_pf* f, rmclhip_transform* poses_dev, rmclhip_particle_attributes* attrs_dev,
+                                        uint32_t n, const rmclhip_transform* T_bnew_bold, double forget_rate,
+                                        int check_collision) {
+  ApiGuard guard_("rmclhip_pf_motion_update");
+  if (!f || !T_bnew_bold) return fail(RMCLHIP_ERR_INVALID, "pf_motion_update: null");
+  if (n == 0) return RMCLHIP_OK;
+  if (!poses_dev || !attrs_dev) return fail(RMCLHIP_ERR_INVALID, "pf_motion_update: null buffers");
+  HIPCHK(hipSetDevice(f->ctx->device));
+  HIPCHK(launch_pf_motion(f->map->d_nodes, f->map->d_tris, reinterpret_cast<xform*>(poses_dev), attrs_dev, n,
+                          to_x(T_bnew_bold), forget_rate, f->params.max_n_meas, check_collision != 0, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  return RMCLHIP_OK;
+}
+
 rmclhip_status rmclhip_pf_extract_weights(rmclhip_pf* f, const rmclhip_particle_attributes* attrs, uint32_t n,
                                           float* weights_dev) {
   ApiGuard guard_("rmclhip_pf_extract_weights");

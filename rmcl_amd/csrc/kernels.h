@@ -117,5 +117,7 @@ hipError_t launch_dataset_from_ranges(const float* ranges, const float* model_ta
                                       uint8_t* mask, uint32_t* n_valid, hipStream_t s);
 hipError_t launch_pf_update(const PfParams& p, int variant, hipStream_t s);
 hipError_t launch_pf_extract_weights(const void* attrs, uint32_t n, float* weights, hipStream_t s);
+hipError_t launch_pf_motion(const uint32_t* nodes, const uint32_t* tris, xform* poses, void* attrs, uint32_t n,
+                            xform T_bnew_bold, double forget_rate, uint32_t max_n_meas, bool collision, hipStream_t s);
 
 }  // namespace rmclhip

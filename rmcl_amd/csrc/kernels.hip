@@ -737,6 +737,37 @@ __global__ void __launch_bounds__(256) k_pf_update(const PfParams p) {
   }
 }
 
+// particle_move_and_forget_kernel (rmcl_ros/src/rmcl/particle_motion.cu:11-34) + the wall-collision test of the
+// CPU updater (collision_in_between, TFMotionUpdaterCPU.cpp:17-50,207-221): one lane per particle; the occlusion
+// ray runs from the old to the new particle position with tfar = segment length.
+template <bool kCollision>
+__global__ void __launch_bounds__(256) k_pf_motion(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris,
+                                                   xform* __restrict__ poses, pattrs* __restrict__ attrs, uint32_t n,
+                                                   xform T_bnew_bold, double forget_rate, uint32_t max_n_meas) {
+  extern __shared__ uint32_t lds_dyn[];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < n;
+  const uint32_t ii = live ? i : 0u;
+  const xform pose_old = poses[ii];
+  g1d L = attrs[ii].likelihood;
+  const xform pose_new = xmul(pose_old, T_bnew_bold);
+  // `n_meas -= forget_rate * n_meas` on a uint32: double arithmetic, truncating store
+  L.n_meas = static_cast<uint32_t>(static_cast<double>(L.n_meas) - forget_rate * static_cast<double>(L.n_meas));
+  if (kCollision) {
+    f3 vec = sub3(pose_new.t, pose_old.t);
+    const float length = sqrtf((vec.x * vec.x + vec.y * vec.y) + vec.z * vec.z);
+    const bool moving = !(static_cast<double>(length) < 0.00001);
+    vec = mk3(vec.x / length, vec.y / length, vec.z / length);
+    RayHit h;
+    trace_lane_ww<16>(nodes, tris, pose_old.t, vec, (live && moving) ? length : -1.0f, lds_dyn + threadIdx.x, blockDim.x, h);
+    if (moving && h.face != kInvalidFace) { L.mean = 0.0f; L.sigma = 0.0f; L.n_meas = max_n_meas; }
+  }
+  if (live) {
+    poses[i] = pose_new;
+    attrs[i].likelihood = L;
+  }
+}
+
 __global__ void k_pf_extract_weights(const pattrs* __restrict__ attrs, uint32_t n, float* __restrict__ w) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) w[i] = attrs[i].likelihood.mean;
@@ -839,6 +870,19 @@ hipError_t launch_pf_update(const PfParams& p, int variant, hipStream_t s) {
   else if (trav == 1) hipLaunchKernelGGL((k_pf_update<32, 1>), dim3(nblocks), dim3(256), lds, s, p);
   else if (deep) hipLaunchKernelGGL((k_pf_update<64, 2>), dim3(nblocks), dim3(256), lds, s, p);
   else hipLaunchKernelGGL((k_pf_update<32, 2>), dim3(nblocks), dim3(256), lds, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_pf_motion(const uint32_t* nodes, const uint32_t* tris, xform* poses, void* attrs, uint32_t n,
+                            xform T_bnew_bold, double forget_rate, uint32_t max_n_meas, bool collision, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const dim3 grid((n + 255u) / 256u), block(256);
+  if (collision)
+    hipLaunchKernelGGL((k_pf_motion<true>), grid, block, 16u * 256u * sizeof(uint32_t), s, nodes, tris, poses,
+                       reinterpret_cast<pattrs*>(attrs), n, T_bnew_bold, forget_rate, max_n_meas);
+  else
+    hipLaunchKernelGGL((k_pf_motion<false>), grid, block, 0, s, nodes, tris, poses, reinterpret_cast<pattrs*>(attrs), n,
+                       T_bnew_bold, forget_rate, max_n_meas);
   return hipGetLastError();
 }
 

@@ -5,6 +5,7 @@ Reference: SensorUpdaterBase{init,reset} + ParticleUpdater<MemT>::update(poses, 
 PCDSensorUpdaterEmbree / PCDSensorUpdaterOptix (rmcl_ros/src/rmcl/PCDSensorUpdater*.cpp).
 """
 import ctypes as C
+import math
 
 import numpy as np
 
@@ -40,6 +41,49 @@ def sample_beams(cloud_xyz, samples, seed):
         else:
             break  # "Point invalid": the reference returns early
     return beams_from_points(pts[chosen])
+
+
+def combined_forget_rate(forget_rate_per_meter, forget_rate_per_second, dist_travelled, dt):
+    """TFMotionUpdaterCPU.cpp:172-174: per-meter and per-second rates turned absolute (exponential) and multiplied."""
+    space = 1.0 - math.pow(1.0 - forget_rate_per_meter, dist_travelled)
+    tim = 1.0 - math.pow(1.0 - forget_rate_per_second, dt)
+    return space * tim
+
+
+class TFMotionUpdaterHip:
+    """rmcl::TFMotionUpdaterGPU on gfx950 + the wall-collision test of TFMotionUpdaterCPU (MotionUpdater<MemT>)."""
+
+    def __init__(self, hip_map, check_collision=True):
+        if hip_map is None:
+            raise RuntimeError("NO MAP")
+        self.map, self.ctx, self.check_collision = hip_map, hip_map.ctx, check_collision
+        self._h = C.c_void_p()
+
+    def init(self):
+        if not self._h:
+            _capi.check(_capi.lib().rmclhip_pf_create(self.ctx.handle, self.map.handle, C.byref(self._h)))
+
+    def reset(self):
+        """TFMotionUpdaterCPU::reset forgets the previous odometry pose (host-side state of the caller)."""
+
+    def update(self, particle_poses, particle_attrs, n_particles, T_bnew_bold, forget_rate):
+        self.init()
+        T = np.ascontiguousarray(T_bnew_bold, dtype=TRANSFORM).reshape(1)
+        _capi.check(_capi.lib().rmclhip_pf_motion_update(self._h, _as_ptr(particle_poses), _as_ptr(particle_attrs),
+                                                         int(n_particles), _ptr(T), float(forget_rate),
+                                                         int(bool(self.check_collision))))
+        return {}
+
+    def close(self):
+        if self._h:
+            _capi.lib().rmclhip_pf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class PCDSensorUpdaterHip:
