@@ -267,6 +267,16 @@ class RCCHipOnDn : public CorrespondencesHIP, public ModelSetter<OnDnModel> {
   }
 };
 
+// rmcl::CPCEmbree (rmcl/include/rmcl/registration/CPCEmbree.hpp): closest-point correspondences
+class CPCHip : public CorrespondencesHIP {
+ public:
+  explicit CPCHip(HipMapPtr map) : CorrespondencesHIP(std::move(map)) {}
+  void find(const Transform& Tbm_est) override {
+    check(rmclhip_rcc_set_params(h_, params.max_dist, adaptive_max_dist_min));
+    check(rmclhip_rcc_find_cpc(h_, &Tbm_est));
+  }
+};
+
 // ---- particle filter -----------------------------------------------------------------------------------
 struct ParticleUpdateConfig {};
 struct ParticleUpdateResults {};

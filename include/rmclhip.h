@@ -169,6 +169,11 @@ rmclhip_status rmclhip_rcc_set_dataset_from_ranges(rmclhip_rcc* rcc, const float
 rmclhip_status rmclhip_rcc_find(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est);
 rmclhip_status rmclhip_rcc_find_async(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est);
 rmclhip_status rmclhip_rcc_sync(rmclhip_rcc* rcc);
+/* rmcl::CPCEmbree::find (rmcl/src/rmcl/registration/CPCEmbree.cpp:18-44), closest-point correspondences (`type: CP`):
+ * for every dataset point Pm = Tsm * d_i the nearest surface point of the map; model buffers (sized like the
+ * dataset) receive hits = (distance <= params.max_dist), points = Tms * p_closest, normals = Tms.R * n_face
+ * (+ ranges = distance, face ids).  computeCrossStatistics then works unchanged. */
+rmclhip_status rmclhip_rcc_find_cpc(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est);
 /* Correspondences{CPU,CUDA}::computeCrossStatistics (CorrespondencesCPU.cpp:10-39):
  * max_dist' = max_dist (1-p) + adaptive_max_dist_min p; rm::statistics_p2l(T_snew_sold, ...) */
 rmclhip_status rmclhip_rcc_compute_cross_statistics(rmclhip_rcc* rcc, const rmclhip_transform* T_snew_sold,

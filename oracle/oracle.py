@@ -148,6 +148,9 @@ def lib():
     L.orc_evaluate_rcc.argtypes = [vp, vp, vp, i32]
     L.orc_pf_update.restype = i32
     L.orc_pf_update.argtypes = [vp, vp, vp, u32, vp, u32, vp, vp, i32, i32, vp]
+    L.orc_closest_point.restype = i32
+    L.orc_closest_point.argtypes = [vp, Vec3, i32, C.POINTER(f32), C.POINTER(Vec3), C.POINTER(u32)]
+    L.orc_cpc_find.argtypes = [vp, vp, vp, vp, u32, f32, i32, vp, vp, vp, vp, vp]
     L.orc_pf_motion_update.argtypes = [vp, vp, vp, u32, vp, C.c_double, u32, i32]
     _lib = L
     return L
@@ -358,6 +361,21 @@ class Mesh:
         lib().orc_simulate_ondn(self.h, width, height, Interval(range_min, range_max), _p(origs), _p(dirs), _p(Tsb), _p(Tbm),
                                 len(Tbm), int(bvh), nthreads, _p(out["hits"]), _p(out["ranges"]), _p(out["points"]),
                                 _p(out["normals"]), _p(out["face_ids"]), None)
+        return out
+
+    def closest_point(self, P, bvh=False):
+        d, cp, f = C.c_float(0), Vec3(), C.c_uint32(0)
+        r = lib().orc_closest_point(self.h, Vec3(*[float(x) for x in P]), int(bvh), C.byref(d), C.byref(cp), C.byref(f))
+        return (d.value, np.array([cp.x, cp.y, cp.z], np.float32), f.value) if r > 0 else None
+
+    def cpc_find(self, Tsb, Tbm, dataset_points, max_dist, bvh=True):
+        """CPCEmbree::find: dict(hits, ranges (= distance), points, normals, face_ids), sensor frame."""
+        Tsb = np.ascontiguousarray(Tsb, dtype=TRANSFORM).reshape(1)
+        Tbm = np.ascontiguousarray(Tbm, dtype=TRANSFORM).reshape(1)
+        dp = np.ascontiguousarray(dataset_points, dtype=np.float32).reshape(-1, 3)
+        out = self._alloc(len(dp), ("hits", "ranges", "points", "normals", "face_ids"))
+        lib().orc_cpc_find(self.h, _p(Tsb), _p(Tbm), _p(dp), len(dp), float(max_dist), int(bvh), _p(out["hits"]),
+                           _p(out["ranges"]), _p(out["points"]), _p(out["normals"]), _p(out["face_ids"]))
         return out
 
     def pf_motion_update(self, poses, attrs, T_bnew_bold, forget_rate, collision=True, max_n_meas=10000, bvh=True):

@@ -1065,3 +1065,122 @@ void orc_pf_motion_update(const orc_mesh* m /* NULL: no collision test */, orc_t
     attrs[i] = attr;
   }
 }
+
+/* ------------------------------------------------------------------------- */
+/* closest-point correspondences: CPCEmbree::find (rmcl/src/rmcl/registration/ */
+/* CPCEmbree.cpp:18-44) -> rm::EmbreeMap::closestPoint (external; Embree point   */
+/* query + the closest-point-on-triangle routine of Embree's closest_point      */
+/* tutorial, i.e. Ericson, Real-Time Collision Detection 5.1.5).                */
+/* a = v0, ab = -e1, ac = e2, b = a + ab, c = a + ac (record form).             */
+/* Tie-break of equidistant triangles: min squared distance, then min face id.  */
+/* ------------------------------------------------------------------------- */
+static inline orc_vec3 closest_point_triangle(const orc_tri* T, orc_vec3 p)
+{
+  const orc_vec3 a = T->v0;
+  const orc_vec3 ab = v3(-T->e1.x, -T->e1.y, -T->e1.z), ac = T->e2;
+  const orc_vec3 b = v_add(a, ab), c = v_add(a, ac);
+  const orc_vec3 ap = v_sub(p, a);
+  const float d1 = v_dot_plain(ab, ap), d2 = v_dot_plain(ac, ap);
+  if (d1 <= 0.f && d2 <= 0.f) return a;
+  const orc_vec3 bp = v_sub(p, b);
+  const float d3 = v_dot_plain(ab, bp), d4 = v_dot_plain(ac, bp);
+  if (d3 >= 0.f && d4 <= d3) return b;
+  const orc_vec3 cp = v_sub(p, c);
+  const float d5 = v_dot_plain(ab, cp), d6 = v_dot_plain(ac, cp);
+  if (d6 >= 0.f && d5 <= d6) return c;
+  const float vc = d1 * d4 - d3 * d2;
+  if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { const float v = d1 / (d1 - d3); return v_add(a, v_scale(ab, v)); }
+  const float vb = d5 * d2 - d1 * d6;
+  if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { const float v = d2 / (d2 - d6); return v_add(a, v_scale(ac, v)); }
+  const float va = d3 * d6 - d5 * d4;
+  if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {
+    const float v = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    return v_add(b, v_scale(v_sub(c, b), v));
+  }
+  const float denom = 1.f / ((va + vb) + vc);
+  const float v = vb * denom, w = vc * denom;
+  return v_add(v_add(a, v_scale(ab, v)), v_scale(ac, w));
+}
+
+static inline float dist2(orc_vec3 a, orc_vec3 b)
+{
+  const orc_vec3 d = v_sub(a, b);
+  return (d.x * d.x + d.y * d.y) + d.z * d.z;
+}
+
+static inline float box_dist2(const orc_node* n, const float* p)
+{
+  float acc = 0.f;
+  for (int k = 0; k < 3; ++k) {
+    float d = 0.f;
+    if (p[k] < n->bmin[k]) d = n->bmin[k] - p[k]; else if (p[k] > n->bmax[k]) d = p[k] - n->bmax[k];
+    acc += d * d;
+  }
+  return acc;
+}
+
+int orc_closest_point(const orc_mesh* m, orc_vec3 P, int use_bvh, float* d_out, orc_vec3* cp_out, uint32_t* face_out)
+{
+  float best = INFINITY; uint32_t best_f = 0xFFFFFFFFu; orc_vec3 best_p = v3(0, 0, 0);
+  if (!(P.x == P.x && P.y == P.y && P.z == P.z)) return 0;
+  if (!use_bvh) {
+    for (uint32_t f = 0; f < m->nf; ++f) {
+      const orc_vec3 q = closest_point_triangle(&m->tris[f], P);
+      const float d2 = dist2(P, q);
+      if (d2 < best || (d2 == best && f < best_f)) { best = d2; best_f = f; best_p = q; }
+    }
+  } else {
+    const float p[3] = {P.x, P.y, P.z};
+    uint32_t stack[128]; int sp = 0;
+    stack[sp++] = 0;
+    while (sp > 0) {
+      const orc_node* n = &m->nodes[stack[--sp]];
+      if (box_dist2(n, p) * 0.999999f > best) continue;
+      if (n->count > 0) {
+        for (uint32_t i = 0; i < n->count; ++i) {
+          const uint32_t f = m->prim[n->left_first + i];
+          const orc_vec3 q = closest_point_triangle(&m->tris[f], P);
+          const float d2 = dist2(P, q);
+          if (d2 < best || (d2 == best && f < best_f)) { best = d2; best_f = f; best_p = q; }
+        }
+        continue;
+      }
+      const uint32_t l = n->left_first, r = l + 1;
+      const float dl = box_dist2(&m->nodes[l], p), dr = box_dist2(&m->nodes[r], p);
+      if (sp + 2 > 128) return -1;
+      if (dl <= dr) { stack[sp++] = r; stack[sp++] = l; } else { stack[sp++] = l; stack[sp++] = r; }
+    }
+  }
+  if (best_f == 0xFFFFFFFFu) return 0;
+  *d_out = sqrtf(best); *cp_out = best_p; *face_out = best_f;
+  return 1;
+}
+
+/* CPCEmbree::find: model buffers sized like the dataset; hits = (d <= max_dist); point / normal back in the
+ * sensor frame.  Non-finite dataset points give hits = 0 and NaN outputs. */
+void orc_cpc_find(const orc_mesh* m, const orc_transform* Tsb, const orc_transform* Tbm, const float* dataset_points,
+                  uint32_t n, float max_dist, int use_bvh, uint8_t* hits, float* dists, float* points, float* normals,
+                  uint32_t* face_ids)
+{
+  const orc_transform Tsm = orc_transform_mult(*Tbm, *Tsb);
+  const orc_transform Tms = orc_transform_inv(Tsm);
+  for (uint32_t i = 0; i < n; ++i) {
+    const orc_vec3 Pm = orc_transform_apply(Tsm, v3(dataset_points[3 * i], dataset_points[3 * i + 1], dataset_points[3 * i + 2]));
+    float d; orc_vec3 cp; uint32_t face;
+    if (orc_closest_point(m, Pm, use_bvh, &d, &cp, &face) > 0) {
+      const orc_vec3 ps = orc_transform_apply(Tms, cp);
+      const orc_vec3 ns = orc_quat_rotate(Tms.R, m->tris[face].n);
+      if (hits) hits[i] = (d <= max_dist) ? 1 : 0;
+      if (dists) dists[i] = d;
+      if (points) { points[3 * i] = ps.x; points[3 * i + 1] = ps.y; points[3 * i + 2] = ps.z; }
+      if (normals) { normals[3 * i] = ns.x; normals[3 * i + 1] = ns.y; normals[3 * i + 2] = ns.z; }
+      if (face_ids) face_ids[i] = face;
+    } else {
+      if (hits) hits[i] = 0;
+      if (dists) dists[i] = NAN;
+      if (points) { points[3 * i] = NAN; points[3 * i + 1] = NAN; points[3 * i + 2] = NAN; }
+      if (normals) { normals[3 * i] = NAN; normals[3 * i + 1] = NAN; normals[3 * i + 2] = NAN; }
+      if (face_ids) face_ids[i] = 0xFFFFFFFFu;
+    }
+  }
+}

@@ -159,6 +159,12 @@ int orc_pf_update(const orc_mesh* m, const orc_transform* poses, orc_particle_at
                   const orc_transform* Tsb, const orc_pf_params* p, int use_bvh, int nthreads,
                   float* errors_out /* nullable, n*nbeams */);
 
+/* ---- closest-point correspondences (CPCEmbree.cpp:18-44; rm::EmbreeMap::closestPoint) ---- */
+int orc_closest_point(const orc_mesh* m, orc_vec3 P, int use_bvh, float* d_out, orc_vec3* cp_out, uint32_t* face_out);
+void orc_cpc_find(const orc_mesh* m, const orc_transform* Tsb, const orc_transform* Tbm, const float* dataset_points,
+                  uint32_t n, float max_dist, int use_bvh, uint8_t* hits, float* dists, float* points, float* normals,
+                  uint32_t* face_ids);
+
 /* ---- particle-filter motion update (TFMotionUpdaterCPU.cpp:17-50,184-224; particle_motion.cu:11-34) ---- */
 int orc_collision_in_between(const orc_mesh* m, orc_vec3 p1, orc_vec3 p2, int use_bvh);
 void orc_pf_motion_update(const orc_mesh* m, orc_transform* poses, orc_particle_attributes* attrs, uint32_t n,

@@ -8,7 +8,7 @@ from ._capi import NoDeviceError, RmclHipError  # noqa: F401
 from .micp import MICPLocalization, MICPSensor  # noqa: F401
 from .pf import (PCDSensorUpdaterHip, TFMotionUpdaterHip, beams_from_points, combined_forget_rate,  # noqa: F401
                  sample_beams)
-from .registration import (Context, CorrespondencesHIP, DeviceArray, HipMap, MapMap, RCCHipO1Dn,  # noqa: F401
+from .registration import (CPCHip, Context, CorrespondencesHIP, DeviceArray, HipMap, MapMap, RCCHipO1Dn,  # noqa: F401
                            RCCHipOnDn, RCCHipPinhole, RCCHipSpherical, build_bvh_host, import_hip_map)
 
 __version__ = "0.1.0"

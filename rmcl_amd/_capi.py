@@ -79,6 +79,7 @@ SIGNATURES = {
     "rmclhip_rcc_find": (_i32, [_vp, _vp]),
     "rmclhip_rcc_find_async": (_i32, [_vp, _vp]),
     "rmclhip_rcc_sync": (_i32, [_vp]),
+    "rmclhip_rcc_find_cpc": (_i32, [_vp, _vp]),
     "rmclhip_rcc_compute_cross_statistics": (_i32, [_vp, _vp, _dbl, _vp]),
     "rmclhip_rcc_download": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "rmclhip_rcc_device_views": (_i32, [_vp, _pp, _pp, _pp, _pp, _pp, C.POINTER(_u32)]),

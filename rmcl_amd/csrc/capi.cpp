@@ -584,6 +584,23 @@ rmclhip_status rmclhip_rcc_find(rmclhip_rcc* r, const rmclhip_transform* Tbm_est
   return RMCLHIP_OK;
 }
 
+rmclhip_status rmclhip_rcc_find_cpc(rmclhip_rcc* r, const rmclhip_transform* Tbm_est) {
+  ApiGuard guard_("rmclhip_rcc_find_cpc");
+  if (!r || !Tbm_est) return fail(RMCLHIP_ERR_INVALID, "rcc_find_cpc: null");
+  if (r->n_dataset == 0) return RMCLHIP_OK;
+  HIPCHK(hipSetDevice(r->ctx->device));
+  // CPCEmbree.cpp:20-25: model buffers are sized like the DATASET (grow-only)
+  const size_t n = r->n_dataset;
+  if (rmclhip_status st = ensure_model_buffers(r, n)) return st;
+  r->n_model = r->n_dataset;
+  r->nposes_last = 1;
+  const xform Tsm = xmul(to_x(Tbm_est), r->Tsb);
+  HIPCHK(launch_cpc_find(r->map->d_nodes, r->map->d_tris, r->d_ds_points.p, r->n_dataset, r->max_dist, Tsm, xinv(Tsm),
+                         r->d_hits.p, r->d_ranges.p, r->d_points.p, r->d_normals.p, r->d_face_ids.p, r->stream));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  return RMCLHIP_OK;
+}
+
 rmclhip_status rmclhip_rcc_sync(rmclhip_rcc* r) {
   ApiGuard guard_("rmclhip_rcc_sync");
   if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_sync: null");

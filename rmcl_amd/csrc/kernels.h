@@ -98,6 +98,9 @@ struct MicpState {
 };
 
 hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStream_t s);
+hipError_t launch_cpc_find(const uint32_t* nodes, const uint32_t* tris, const float* dataset_points, uint32_t n,
+                           float max_dist, xform Tsm, xform Tms, uint8_t* hits, float* dists, float* points,
+                           float* normals, uint32_t* face_ids, hipStream_t s);
 hipError_t launch_compose_poses(const xform* Tbm_dev, xform Tsb, xform* Tsm_out, xform* Tms_out, uint32_t n,
                                 hipStream_t s);
 uint32_t reduce_num_blocks(uint32_t n);

@@ -311,6 +311,155 @@ __device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes
   h.rec = best_rec;
 }
 
+// ---------------------------------------------------------------------------------------------
+// closest-point query (CPCEmbree::find -> rm::EmbreeMap::closestPoint): per-lane while-while traversal ordered
+// by box distance, closest point on triangle = Embree closest_point tutorial / Ericson RTCD 5.1.5, in the exact
+// operation order of oracle/rmcl_oracle.c:closest_point_triangle (a = v0, ab = -e1, ac = e2, b = a+ab, c = a+ac).
+// Equidistant triangles: min squared distance, then min face id.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f3 closest_point_triangle(f3 a, f3 e1, f3 e2, f3 p) {
+  const f3 ab = neg3(e1), ac = e2;
+  const f3 b = add3(a, ab), c = add3(a, ac);
+  const f3 ap = sub3(p, a);
+  const float d1 = dot_plain(ab, ap), d2 = dot_plain(ac, ap);
+  if (d1 <= 0.f && d2 <= 0.f) return a;
+  const f3 bp = sub3(p, b);
+  const float d3 = dot_plain(ab, bp), d4 = dot_plain(ac, bp);
+  if (d3 >= 0.f && d4 <= d3) return b;
+  const f3 cp = sub3(p, c);
+  const float d5 = dot_plain(ab, cp), d6 = dot_plain(ac, cp);
+  if (d6 >= 0.f && d5 <= d6) return c;
+  const float vc = d1 * d4 - d3 * d2;
+  if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { const float v = d1 / (d1 - d3); return add3(a, scale3(ab, v)); }
+  const float vb = d5 * d2 - d1 * d6;
+  if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { const float v = d2 / (d2 - d6); return add3(a, scale3(ac, v)); }
+  const float va = d3 * d6 - d5 * d4;
+  if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {
+    const float v = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    return add3(b, scale3(sub3(c, b), v));
+  }
+  const float denom = 1.f / ((va + vb) + vc);
+  const float v = vb * denom, w = vc * denom;
+  return add3(add3(a, scale3(ab, v)), scale3(ac, w));
+}
+
+struct NearHit {
+  float d2;
+  uint32_t face;
+  uint32_t rec;
+  f3 p;
+};
+
+template <int kLdsEntries>
+__device__ __forceinline__ void nearest_lane_ww(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris,
+                                                f3 P, bool active, uint32_t* __restrict__ lds_stack,
+                                                uint32_t lds_stride, NearHit& h) {
+  float best = 3.0e38f;  // finite: unused node slots (box at 1e30 -> d2 = inf) never pass `d2 <= best`
+  uint32_t best_face = kInvalidFace, best_rec = 0;
+  f3 best_p = mk3(0.f, 0.f, 0.f);
+  constexpr uint32_t kDone = 0x7FFFFFFFu;
+  uint32_t priv[(kLdsEntries < 64) ? (64 - kLdsEntries) : 1];
+  uint32_t sp = 0;
+  uint32_t cur = active ? 0u : kDone;
+#define RMCL_PUSH(v) { if (kLdsEntries >= 64 || sp < kLdsEntries) lds_stack[sp * lds_stride] = (v); else priv[sp - kLdsEntries] = (v); ++sp; }
+#define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; cur = (kLdsEntries >= 64 || sp < kLdsEntries) ? lds_stack[sp * lds_stride] : priv[sp - kLdsEntries]; } }
+  while (__any(cur != kDone)) {
+    while ((cur != kDone) && !(cur & kLeafBit)) {
+      const uint4* np = reinterpret_cast<const uint4*>(nodes) + static_cast<size_t>(cur) * 8u;
+      const uint4 qx0 = np[0], qx1 = np[1], qy0 = np[2], qy1 = np[3], qz0 = np[4], qz1 = np[5], qch = np[6];
+      const f2 bx[4] = {{asf(qx0.x), asf(qx0.y)}, {asf(qx0.z), asf(qx0.w)}, {asf(qx1.x), asf(qx1.y)}, {asf(qx1.z), asf(qx1.w)}};
+      const f2 by[4] = {{asf(qy0.x), asf(qy0.y)}, {asf(qy0.z), asf(qy0.w)}, {asf(qy1.x), asf(qy1.y)}, {asf(qy1.z), asf(qy1.w)}};
+      const f2 bz[4] = {{asf(qz0.x), asf(qz0.y)}, {asf(qz0.z), asf(qz0.w)}, {asf(qz1.x), asf(qz1.y)}, {asf(qz1.z), asf(qz1.w)}};
+      uint32_t ref[4] = {qch.x, qch.y, qch.z, qch.w};
+      uint32_t key[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        // squared distance to the (padded) child box: a conservative lower bound of any triangle inside
+        const float dx = fmaxf(fmaxf(bx[c].x - P.x, P.x - bx[c].y), 0.f);
+        const float dy = fmaxf(fmaxf(by[c].x - P.y, P.y - by[c].y), 0.f);
+        const float dz = fmaxf(fmaxf(bz[c].x - P.z, P.z - bz[c].y), 0.f);
+        const float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+        key[c] = (d2 <= best) ? __float_as_uint(d2) : kNone;
+      }
+      RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
+      if (key[3] != kNone) RMCL_PUSH(ref[3])
+      if (key[2] != kNone) RMCL_PUSH(ref[2])
+      if (key[1] != kNone) RMCL_PUSH(ref[1])
+      if (key[0] != kNone) cur = ref[0];
+      else RMCL_POP()
+    }
+    if (cur != kDone) {
+      const uint32_t first = cur & 0x0FFFFFFFu;
+      const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
+      for (uint32_t i = 0; i < cnt; ++i) {
+        const uint4* tp = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(first + i) * 4u;
+        const uint4 a = tp[0], b = tp[1], c = tp[2], d = tp[3];
+        const f3 v0 = mk3(asf(a.x), asf(a.y), asf(a.z));
+        const f3 e1 = mk3(asf(a.w), asf(b.x), asf(b.y));
+        const f3 e2 = mk3(asf(b.z), asf(b.w), asf(c.x));
+        const uint32_t face = d.w;
+        const f3 q = closest_point_triangle(v0, e1, e2, P);
+        const f3 df = sub3(P, q);
+        const float d2 = (df.x * df.x + df.y * df.y) + df.z * df.z;
+        const bool closer = (d2 < best) || ((d2 == best) && (face < best_face));
+        if (closer) { best = d2; best_face = face; best_rec = first + i; best_p = q; }
+      }
+      RMCL_POP()
+    }
+  }
+#undef RMCL_PUSH
+#undef RMCL_POP
+  h.d2 = best;
+  h.face = best_face;
+  h.rec = best_rec;
+  h.p = best_p;
+}
+
+struct CpcParams {
+  const uint32_t* nodes;
+  const uint32_t* tris;
+  const float* dataset_points;
+  uint32_t n;
+  float max_dist;
+  xform Tsm, Tms;
+  uint8_t* hits;
+  float* dists;
+  float* points;
+  float* normals;
+  uint32_t* face_ids;
+};
+
+__global__ void __launch_bounds__(256) k_cpc_find(const CpcParams p) {
+  extern __shared__ uint32_t lds_dyn[];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < p.n;
+  const uint32_t ii = live ? i : 0u;
+  const float* dp = p.dataset_points + 3 * static_cast<size_t>(ii);
+  const f3 Pm = xapply(p.Tsm, mk3(dp[0], dp[1], dp[2]));
+  const bool finite = (Pm.x == Pm.x) && (Pm.y == Pm.y) && (Pm.z == Pm.z);
+  NearHit h;
+  nearest_lane_ww<16>(p.nodes, p.tris, Pm, live && finite, lds_dyn + threadIdx.x, blockDim.x, h);
+  if (!live) return;
+  if (h.face != kInvalidFace) {
+    const float d = sqrtf(h.d2);
+    const uint4 nrec = reinterpret_cast<const uint4*>(p.tris)[static_cast<size_t>(h.rec) * 4u + 3u];
+    const f3 ps = xapply(p.Tms, h.p);
+    const f3 ns = qrot(p.Tms.R, mk3(asf(nrec.x), asf(nrec.y), asf(nrec.z)));
+    if (p.hits) p.hits[i] = (d <= p.max_dist) ? 1 : 0;
+    if (p.dists) p.dists[i] = d;
+    if (p.points) { p.points[3 * i] = ps.x; p.points[3 * i + 1] = ps.y; p.points[3 * i + 2] = ps.z; }
+    if (p.normals) { p.normals[3 * i] = ns.x; p.normals[3 * i + 1] = ns.y; p.normals[3 * i + 2] = ns.z; }
+    if (p.face_ids) p.face_ids[i] = h.face;
+  } else {
+    const float qn = __uint_as_float(0x7FC00000u);
+    if (p.hits) p.hits[i] = 0;
+    if (p.dists) p.dists[i] = qn;
+    if (p.points) { p.points[3 * i] = qn; p.points[3 * i + 1] = qn; p.points[3 * i + 2] = qn; }
+    if (p.normals) { p.normals[3 * i] = qn; p.normals[3 * i + 1] = qn; p.normals[3 * i + 2] = qn; }
+    if (p.face_ids) p.face_ids[i] = kInvalidFace;
+  }
+}
+
 // rmagine PinholeModel::getDirection: optical ray ((hid - cx)/fx, (vid - cy)/fy, 1) normalised (Vector::normalize
 // = divide by sqrt(x*x + y*y + z*z)), then optical (x right, y down, z forward) -> sensor (x forward, y left, z up).
 // Same operation order as oracle/rmcl_oracle.c:orc_pinhole_direction (IEEE division / sqrt on both sides).
@@ -798,6 +947,17 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
     RMCL_LAUNCH_FIND(false, lds)
   }
 #undef RMCL_LAUNCH_FIND
+  return hipGetLastError();
+}
+
+hipError_t launch_cpc_find(const uint32_t* nodes, const uint32_t* tris, const float* dataset_points, uint32_t n,
+                           float max_dist, xform Tsm, xform Tms, uint8_t* hits, float* dists, float* points,
+                           float* normals, uint32_t* face_ids, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  CpcParams p;
+  p.nodes = nodes; p.tris = tris; p.dataset_points = dataset_points; p.n = n; p.max_dist = max_dist;
+  p.Tsm = Tsm; p.Tms = Tms; p.hits = hits; p.dists = dists; p.points = points; p.normals = normals; p.face_ids = face_ids;
+  hipLaunchKernelGGL(k_cpc_find, dim3((n + 255u) / 256u), dim3(256), 16u * 256u * sizeof(uint32_t), s, p);
   return hipGetLastError();
 }
 

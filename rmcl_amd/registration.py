@@ -355,3 +355,19 @@ class RCCHipOnDn(CorrespondencesHIP):
         rng = _capi.Interval(range_min, range_max)
         _capi.check(_capi.lib().rmclhip_rcc_set_model_ondn(self._h, int(width), int(height), rng, _ptr(o), _ptr(d)))
         self._model_shape = (int(height), int(width))
+
+
+class CPCHip(CorrespondencesHIP):
+    """rmcl::CPCEmbree on gfx950 (CPCEmbree.cpp:11-44): closest-point correspondences; find() pairs every
+    dataset point with the nearest surface point of the map (no sensor model needed)."""
+
+    def find(self, Tbm_est):
+        self._push_params()   # hits = (distance <= params.max_dist)
+        T = np.ascontiguousarray(Tbm_est, dtype=TRANSFORM).reshape(1)
+        _capi.check(_capi.lib().rmclhip_rcc_find_cpc(self._h, _ptr(T)))
+        self._last_nposes = 1
+
+    def set_dataset(self, points, mask=None, device=False):
+        super().set_dataset(points, mask, device)
+        n = (points.count // 3) if hasattr(points, "count") else int(np.asarray(points).size // 3)
+        self._model_shape = (1, n)

@@ -1,0 +1,68 @@
+"""GPU parity of closest-point correspondences: CPCEmbree::find
+(rmcl/src/rmcl/registration/CPCEmbree.cpp:18-44) vs the oracle (brute-force nearest triangle, Ericson's
+closest point on triangle).  Face ids bit-exact, distances / points / normals within 1e-5."""
+import numpy as np
+import pytest
+
+import oracle_micp as om
+from conftest import assert_close_rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _cmp(gpu, ref, what):
+    assert np.array_equal(gpu["hits"], ref["hits"]), what
+    assert np.array_equal(gpu["face_ids"], ref["face_ids"]), what
+    assert_close_rel(gpu["ranges"], ref["ranges"], 1e-5, 1e-7, what + " distances")
+    assert_close_rel(gpu["points"], ref["points"], 1e-5, 1e-6, what + " points")
+    assert_close_rel(gpu["normals"], ref["normals"], 1e-5, 1e-6, what + " normals")
+
+
+@pytest.mark.parametrize("mesh_name", ["cube", "room30k"])
+def test_cpc_find_matches_oracle(ra, orc, ctx, meshes, mesh_name):
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes(mesh_name)
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    model = syn.model_c1()
+    Tsb = syn.tsb_offset()
+    truth = T.transform_from_rpy((0.5, -0.3, 1.2), (0.02, -0.03, 0.4))
+    est = T.mult(truth, syn.pose_c2_perturbation())
+    meas = m.simulate_spherical(model, Tsb, truth, bvh=True)
+    ds, mask = om.dataset_from_ranges(model, meas["ranges"])
+    ds[5] = np.nan                                # invalid point of an organised cloud
+    cpc = ra.CPCHip(hm)
+    cpc.setTsb(Tsb)
+    cpc.params.max_dist = 0.3
+    cpc.adaptive_max_dist_min = 0.3
+    cpc.set_dataset(ds, mask)
+    cpc.find(est)
+    gpu = cpc.modelView()
+    ref = m.cpc_find(Tsb, est, ds, 0.3, bvh=False)
+    _cmp(gpu, ref, "cpc " + mesh_name)
+    assert gpu["hits"].any() and (gpu["hits"] == 0).any()
+    # the reduction + Umeyama on closest-point correspondences (classic ICP step)
+    s = cpc.computeCrossStatistics(T.identity())
+    r = orc.statistics_p2l_f64(T.identity(), ds, mask, ref["points"], ref["normals"], ref["hits"], 0.3)
+    assert int(s["n_meas"]) == r["n_meas"] > 50
+    assert np.allclose(s["covariance"].reshape(3, 3), r["covariance"], rtol=1e-5, atol=1e-6)
+
+
+def test_cpc_points_on_surface_and_ties(ra, orc, ctx, meshes):
+    """query points exactly on shared edges / vertices (distance 0, several equidistant triangles): the
+    (min distance, min face id) tie-break must agree with the brute-force oracle."""
+    from rmcl_amd import types as T
+    v, f = meshes("cube")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    pts = np.concatenate([v[::7], (v[f[::11, 0]] + v[f[::11, 1]]) * np.float32(0.5), np.zeros((1, 3), np.float32)]).astype(np.float32)
+    cpc = ra.CPCHip(hm)
+    cpc.setTsb(T.identity())
+    cpc.params.max_dist = 10.0
+    cpc.set_dataset(pts, None)
+    cpc.find(T.identity())
+    gpu = cpc.modelView()
+    ref = m.cpc_find(T.identity(), T.identity(), pts, 10.0, bvh=False)
+    _cmp(gpu, ref, "ties")
+    assert np.sum(gpu["ranges"] == 0) > 50
+    assert abs(gpu["ranges"][-1] - 5.0) < 1e-6     # centre of the 10 m cube room
