@@ -301,7 +301,7 @@ struct ParticleUpdater<VRAM_HIP> {
 // (PCDSensorUpdaterEmbree.cpp:249-327).
 class PCDSensorUpdaterHip : public SensorUpdaterBase, public ParticleUpdater<VRAM_HIP> {
  public:
-  rmclhip_pf_params config_{2.0f, 100.0f, 100.0f, 0.0f, {0.05f, 80.0f}, 10000u};
+  rmclhip_pf_params config_{2.0f, 100.0f, 100.0f, 0.0f, {0.05f, 80.0f}, 10000u, 0u};
 
   explicit PCDSensorUpdaterHip(HipMapPtr map) : map_(std::move(map)) {
     if (!map_) throw std::runtime_error("NO MAP");

@@ -84,6 +84,7 @@ typedef struct {
   float real_miss_sim_miss_error;   /* 0    */
   rmclhip_interval sensor_range;    /* [0.05, 80] */
   uint32_t max_n_meas;              /* MAX_N_MEAS = 10000, ParticleAttributes.hpp:34 */
+  uint32_t correspondence_type;     /* 0 = RCC (evaluate_rcc, :18-86), 1 = CPC (evaluate_cpc, :88-95) */
 } rmclhip_pf_params;
 
 typedef struct {

@@ -62,7 +62,8 @@ class Gaussian1D(C.Structure):
 class PFParams(C.Structure):
     _fields_ = [("dist_sigma", C.c_float), ("real_hit_sim_miss_error", C.c_float),
                 ("real_miss_sim_hit_error", C.c_float), ("real_miss_sim_miss_error", C.c_float),
-                ("sensor_range", Interval), ("max_n_meas", C.c_uint32)]
+                ("sensor_range", Interval), ("max_n_meas", C.c_uint32),
+                ("correspondence_type", C.c_uint32)]
 
 
 class Counters(C.Structure):
@@ -245,7 +246,8 @@ def spherical_model(phi_min, phi_inc, phi_n, theta_min, theta_inc, theta_n, rang
 
 
 def pf_params(dist_sigma=2.0, real_hit_sim_miss_error=100.0, real_miss_sim_hit_error=100.0,
-              real_miss_sim_miss_error=0.0, range_min=0.05, range_max=80.0, max_n_meas=10000):
+              real_miss_sim_miss_error=0.0, range_min=0.05, range_max=80.0, max_n_meas=10000,
+              correspondence_type=0):
     """Defaults: PCDSensorUpdaterEmbree.cpp:122-134."""
     p = PFParams()
     p.dist_sigma = dist_sigma
@@ -254,6 +256,7 @@ def pf_params(dist_sigma=2.0, real_hit_sim_miss_error=100.0, real_miss_sim_hit_e
     p.real_miss_sim_miss_error = real_miss_sim_miss_error
     p.sensor_range.min, p.sensor_range.max = range_min, range_max
     p.max_n_meas = max_n_meas
+    p.correspondence_type = correspondence_type
     return p
 
 

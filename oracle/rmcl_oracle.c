@@ -881,7 +881,15 @@ static void pf_particle(pf_job* J, uint32_t i)
     orc_range_measurement mm = J->beams[b];
     mm.dir = orc_quat_rotate(Tsm.R, J->beams[b].dir);
     mm.orig = orc_transform_apply(Tsm, J->beams[b].orig);
-    const float error = orc_evaluate_rcc(J->m, &mm, p, J->use_bvh);
+    float error;
+    if (p->correspondence_type == 1) {
+      /* evaluate_cpc (PCDSensorUpdaterEmbree.cpp:88-95): distance of meas_m.mean() (RangeMeasurement.hpp:17-20) */
+      const orc_vec3 mean = v_add(mm.orig, v_scale(mm.dir, mm.range));
+      float d; orc_vec3 cp; uint32_t face;
+      error = (orc_closest_point(J->m, mean, J->use_bvh, &d, &cp, &face) > 0) ? d : NAN;
+    } else {
+      error = orc_evaluate_rcc(J->m, &mm, p, J->use_bvh);
+    }
     if (J->errors) J->errors[(size_t)i * J->nbeams + b] = error;
     /* PCDSensorUpdaterEmbree.cpp:224: float argument, double exp/sqrt, float result */
     const float arg = -(error * error) / sq / 2;

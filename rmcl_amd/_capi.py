@@ -43,7 +43,8 @@ class SphericalModel(C.Structure):
 class PFParams(C.Structure):
     _fields_ = [("dist_sigma", C.c_float), ("real_hit_sim_miss_error", C.c_float),
                 ("real_miss_sim_hit_error", C.c_float), ("real_miss_sim_miss_error", C.c_float),
-                ("sensor_range", Interval), ("max_n_meas", C.c_uint32)]
+                ("sensor_range", Interval), ("max_n_meas", C.c_uint32),
+                ("correspondence_type", C.c_uint32)]
 
 
 class MapInfo(C.Structure):

@@ -166,7 +166,7 @@ struct rmclhip_pf {
   rmclhip_map* map = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  rmclhip_pf_params params{2.0f, 100.0f, 100.0f, 0.0f, {0.05f, 80.0f}, 10000u};
+  rmclhip_pf_params params{2.0f, 100.0f, 100.0f, 0.0f, {0.05f, 80.0f}, 10000u, 0u};
   DevBuf<float> d_beams;
   float* h_beams = nullptr;  // pinned staging
   size_t h_beams_cap = 0;
@@ -1041,6 +1041,7 @@ rmclhip_status rmclhip_pf_set_params(rmclhip_pf* f, const rmclhip_pf_params* p) 
   ApiGuard guard_("rmclhip_pf_set_params");
   if (!f || !p) return fail(RMCLHIP_ERR_INVALID, "pf_set_params: null");
   if (!(p->dist_sigma > 0.f)) return fail(RMCLHIP_ERR_INVALID, "pf_set_params: dist_sigma must be > 0");
+  if (p->correspondence_type > 1u) return fail(RMCLHIP_ERR_INVALID, "pf_set_params: correspondence_type must be 0 (RCC) or 1 (CPC)");
   f->params = *p;
   return RMCLHIP_OK;
 }
@@ -1096,7 +1097,7 @@ static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, 
   if (pb > 64u) pb = 64u;
   if (static_cast<size_t>(pb) * n_beams > 8192u) return fail(RMCLHIP_ERR_UNSUPPORTED, "pf_update: more than 8192 beams");
   p.particles_per_block = pb;
-  const int variant = (f->variant & 3) | ((f->map->info.stack_need > 32) ? 4 : 0);
+  const int variant = (f->variant & 3) | ((f->map->info.stack_need > 32) ? 4 : 0) | (f->params.correspondence_type == 1u ? 8 : 0);
   HIPCHK(launch_pf_update(p, variant, f->stream));
   return RMCLHIP_OK;
 }

@@ -812,12 +812,13 @@ __device__ __forceinline__ g1d g1d_add(g1d a, g1d b) {
 // kTrav: 0 = while-while traversal, per-lane stack 16 entries in LDS + scratch overflow (default)
 //        1 = while-while traversal, per-lane stack entirely in LDS
 //        2 = original single-loop traversal, stack in LDS (A/B)
+//        3 = closest-point correspondences (correspondence_type 1): nearest-point query instead of a ray
 template <int kStackDepth, int kTrav>
 __global__ void __launch_bounds__(256) k_pf_update(const PfParams p) {
   // LDS: [ per-lane stacks kStackDepth*256 (kTrav != 0) | Tsm (PB xforms) | evals (PB*n_beams floats) ]
   extern __shared__ uint32_t lds_dyn[];
   uint32_t* stacks = lds_dyn;
-  xform* s_Tsm = reinterpret_cast<xform*>(lds_dyn + (kTrav == 0 ? 16 : kStackDepth) * 256);
+  xform* s_Tsm = reinterpret_cast<xform*>(lds_dyn + ((kTrav == 0 || kTrav == 3) ? 16 : kStackDepth) * 256);
   float* s_eval = reinterpret_cast<float*>(s_Tsm + p.particles_per_block);
 
   const uint32_t PB = p.particles_per_block;
@@ -840,6 +841,21 @@ __global__ void __launch_bounds__(256) k_pf_update(const PfParams p) {
     const f3 org = xapply(Tsm, mk3(bm[0], bm[1], bm[2]));
     const float range = bm[6];
     const bool finite = (dir.x == dir.x) && (dir.y == dir.y) && (dir.z == dir.z);
+    if (kTrav == 3) {
+      // evaluate_cpc (PCDSensorUpdaterEmbree.cpp:88-95): distance of meas_m.mean() = orig + dir * range to the surface
+      const f3 mean = add3(org, scale3(dir, range));
+      const bool ok = (mean.x == mean.x) && (mean.y == mean.y) && (mean.z == mean.z);
+      NearHit nh;
+      nearest_lane_ww<16>(p.nodes, p.tris, mean, live && ok, stacks + threadIdx.x, 256u, nh);
+      if (live) {
+        const float error = (nh.face != kInvalidFace) ? sqrtf(nh.d2) : __uint_as_float(0x7FC00000u);
+        if (p.errors) p.errors[static_cast<size_t>(p0 + pi) * p.n_beams + b] = error;
+        const float arg = -(error * error) / sq / 2;
+        s_eval[rr] = static_cast<float>(exp(static_cast<double>(arg)) /
+                                        sqrt(static_cast<double>(2 * sq) * 3.14159265358979323846));
+      }
+      continue;
+    }
     RayHit h;
     const float rtf = (live && finite) ? __builtin_inff() : -1.0f;
     if (kTrav == 0) trace_lane_ww<16>(p.nodes, p.tris, org, dir, rtf, stacks + threadIdx.x, 256u, h);
@@ -1023,9 +1039,11 @@ hipError_t launch_pf_update(const PfParams& p, int variant, hipStream_t s) {
                       sizeof(float) * static_cast<size_t>(p.particles_per_block) * p.n_beams;
   const int trav = variant & 3;        // see k_pf_update
   const bool deep = (variant & 4) != 0;  // 64-deep LDS stack instead of 32 (maps with stack_need > 32)
-  const size_t stack_lds = ((trav == 0) ? 16u : (deep ? 64u : 32u)) * 256u * sizeof(uint32_t);
+  const bool cpc = (variant & 8) != 0;   // correspondence_type 1
+  const size_t stack_lds = ((trav == 0 || cpc) ? 16u : (deep ? 64u : 32u)) * 256u * sizeof(uint32_t);
   const size_t lds = stack_lds + tail;
-  if (trav == 0) hipLaunchKernelGGL((k_pf_update<64, 0>), dim3(nblocks), dim3(256), lds, s, p);
+  if (cpc) hipLaunchKernelGGL((k_pf_update<64, 3>), dim3(nblocks), dim3(256), lds, s, p);
+  else if (trav == 0) hipLaunchKernelGGL((k_pf_update<64, 0>), dim3(nblocks), dim3(256), lds, s, p);
   else if (trav == 1 && deep) hipLaunchKernelGGL((k_pf_update<64, 1>), dim3(nblocks), dim3(256), lds, s, p);
   else if (trav == 1) hipLaunchKernelGGL((k_pf_update<32, 1>), dim3(nblocks), dim3(256), lds, s, p);
   else if (deep) hipLaunchKernelGGL((k_pf_update<64, 2>), dim3(nblocks), dim3(256), lds, s, p);

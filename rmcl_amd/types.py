@@ -108,7 +108,8 @@ def spherical_model(phi_min, phi_inc, phi_n, theta_min, theta_inc, theta_n, rang
 
 
 def pf_params(dist_sigma=2.0, real_hit_sim_miss_error=100.0, real_miss_sim_hit_error=100.0,
-              real_miss_sim_miss_error=0.0, range_min=0.05, range_max=80.0, max_n_meas=MAX_N_MEAS):
+              real_miss_sim_miss_error=0.0, range_min=0.05, range_max=80.0, max_n_meas=MAX_N_MEAS,
+              correspondence_type=0):
     """sensor_update.* defaults of PCDSensorUpdaterEmbree.cpp:122-134."""
     p = _capi.PFParams()
     p.dist_sigma = dist_sigma
@@ -117,4 +118,5 @@ def pf_params(dist_sigma=2.0, real_hit_sim_miss_error=100.0, real_miss_sim_hit_e
     p.real_miss_sim_miss_error = real_miss_sim_miss_error
     p.sensor_range.min, p.sensor_range.max = range_min, range_max
     p.max_n_meas = max_n_meas
+    p.correspondence_type = correspondence_type
     return p

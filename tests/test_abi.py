@@ -34,7 +34,7 @@ def test_pod_layouts(ra):
     assert T.TRANSFORM.itemsize == 32 and T.TRANSFORM.fields["t"][1] == 16 and T.TRANSFORM.fields["stamp"][1] == 28
     assert T.CROSS_STATISTICS.itemsize == 64 and T.CROSS_STATISTICS.fields["n_meas"][1] == 60
     assert T.PARTICLE_ATTRIBUTES.itemsize == 36 and T.RANGE_MEASUREMENT.itemsize == 64
-    assert C.sizeof(ra._capi.SphericalModel) == 32 and C.sizeof(ra._capi.PFParams) == 28
+    assert C.sizeof(ra._capi.SphericalModel) == 32 and C.sizeof(ra._capi.PFParams) == 32
 
 
 def test_no_device_is_a_loud_error_not_a_fallback(ra):

@@ -66,3 +66,38 @@ def test_cpc_points_on_surface_and_ties(ra, orc, ctx, meshes):
     _cmp(gpu, ref, "ties")
     assert np.sum(gpu["ranges"] == 0) > 50
     assert abs(gpu["ranges"][-1] - 5.0) < 1e-6     # centre of the 10 m cube room
+
+
+@pytest.mark.parametrize("n_particles,n_beams", [(500, 100), (131, 9)])
+def test_pf_update_with_closest_point_errors(ra, orc, ctx, meshes, n_particles, n_beams):
+    """sensor_update.correspondence_type = 1 (evaluate_cpc, PCDSensorUpdaterEmbree.cpp:88-95,219-222): the beam
+    error is the distance of the measured point to the surface."""
+    import math
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room30k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    truth = T.transform_from_rpy((1.0, -1.5, 1.2), (0.0, 0.0, 0.5))
+    cloud = m.simulate_spherical(syn.model_c1(), T.identity(), truth, bvh=True)["points"]
+    beams = ra.sample_beams(cloud, n_beams, seed=7)
+    poses, attrs = syn.uniform_particles(n_particles, seed=6, bb_min=(-9, -9, 0.2, 0, 0, -math.pi), bb_max=(9, 9, 3.0, 0, 0, math.pi))
+    Tsb = syn.tsb_offset()
+    upd = ra.PCDSensorUpdaterHip(hm)
+    upd.config = T.pf_params(correspondence_type=1)
+    upd.init()
+    upd.setInput(beams, Tsb)
+    d_poses, d_attrs = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
+    d_err = ra.DeviceArray(ctx, np.float32, n_particles * n_beams)
+    upd.set_error_output(d_err)
+    upd.update(d_poses, d_attrs)
+    a_gpu, e_gpu = d_attrs.download(), d_err.download().reshape(n_particles, n_beams)
+    a_ref = attrs.copy()
+    e_ref = m.pf_update(poses, a_ref, beams, Tsb, orc.pf_params(correspondence_type=1), bvh=True, nthreads=8, want_errors=True)
+    assert_close_rel(e_gpu, e_ref, 1e-5, 1e-6, "cpc errors")
+    assert np.array_equal(a_gpu["likelihood"]["n_meas"], a_ref["likelihood"]["n_meas"])
+    assert_close_rel(a_gpu["likelihood"]["mean"], a_ref["likelihood"]["mean"], 1e-5, 1e-12, "cpc mean")
+    assert_close_rel(a_gpu["likelihood"]["sigma"], a_ref["likelihood"]["sigma"], 1e-4, 1e-10, "cpc sigma")
+    assert e_ref.max() < 20 and e_ref.min() >= 0       # distances, never the 100 m miss penalty
+    with pytest.raises(ra.RmclHipError):
+        upd.config = T.pf_params(correspondence_type=2)
+        upd.update(d_poses, d_attrs)
