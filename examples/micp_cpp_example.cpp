@@ -117,6 +117,28 @@ int main(int argc, char** argv) {
     check(rmclhip_memcpy_d2h(ctx->handle(), attrs.data(), d_attrs, attrs.size() * sizeof(ParticleAttributes)));
     for (size_t i = 0; i < attrs.size(); ++i)
       std::printf("pf_%zu %.9g %.9g %u\n", i, attrs[i].likelihood.mean, attrs[i].likelihood.sigma, attrs[i].likelihood.n_meas);
+    // motion update (30 cm forward, 1 % forgetting, wall-collision test) and one gladiator tournament
+    TFMotionUpdaterHip motion(map);
+    const DeviceView<Transform> vposes{static_cast<Transform*>(d_poses), poses.size()};
+    const DeviceView<ParticleAttributes> vattrs{static_cast<ParticleAttributes*>(d_attrs), attrs.size()};
+    motion.update(vposes, vattrs, from_rpy(0.3f, 0, 0, 0, 0, 0.05f), 0.01);
+    void *d_poses_new = nullptr, *d_attrs_new = nullptr;
+    check(rmclhip_malloc(ctx->handle(), poses.size() * sizeof(Transform), &d_poses_new));
+    check(rmclhip_malloc(ctx->handle(), attrs.size() * sizeof(ParticleAttributes), &d_attrs_new));
+    GladiatorResamplerHip resampler(ctx);
+    resampler.seed = 42;
+    const rmclhip_likelihood_stats st = resampler.computeStats(vattrs);
+    std::printf("stats %.9g %.9g\n", st.sum, st.max);
+    const auto res = resampler.update(vposes, vattrs, {static_cast<Transform*>(d_poses_new), poses.size()},
+                                      {static_cast<ParticleAttributes*>(d_attrs_new), attrs.size()});
+    check(rmclhip_memcpy_d2h(ctx->handle(), poses.data(), d_poses_new, poses.size() * sizeof(Transform)));
+    check(rmclhip_memcpy_d2h(ctx->handle(), attrs.data(), d_attrs_new, attrs.size() * sizeof(ParticleAttributes)));
+    std::printf("resampled %zu\n", res.n_particles);
+    for (size_t i = 0; i < attrs.size(); ++i)
+      std::printf("rs_%zu %.9g %u %.9g %.9g %.9g\n", i, attrs[i].likelihood.mean, attrs[i].likelihood.n_meas, poses[i].t.x,
+                  poses[i].t.y, poses[i].t.z);
+    check(rmclhip_free(ctx->handle(), d_poses_new));
+    check(rmclhip_free(ctx->handle(), d_attrs_new));
     check(rmclhip_free(ctx->handle(), d_poses));
     check(rmclhip_free(ctx->handle(), d_attrs));
   } catch (const std::exception& e) {

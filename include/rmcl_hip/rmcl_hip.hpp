@@ -331,4 +331,68 @@ class PCDSensorUpdaterHip : public SensorUpdaterBase, public ParticleUpdater<VRA
   Transform Tsb_ = identity();
 };
 
+// rmcl::TFMotionUpdaterGPU (+ the wall-collision test of TFMotionUpdaterCPU) on gfx950: MotionUpdater<MemT>.
+// The odometry lookup (TF) and the forget rate (TFMotionUpdaterCPU.cpp:172-174) stay with the caller.
+class TFMotionUpdaterHip : public SensorUpdaterBase {
+ public:
+  bool check_collision = true;
+  explicit TFMotionUpdaterHip(HipMapPtr map) : map_(std::move(map)) {
+    if (!map_) throw std::runtime_error("NO MAP");
+  }
+  ~TFMotionUpdaterHip() override { rmclhip_pf_destroy(h_); }
+  void init() override {
+    if (!h_) check(rmclhip_pf_create(map_->context()->handle(), map_->handle(), &h_));
+  }
+  ParticleUpdateResults update(DeviceView<Transform> poses, DeviceView<ParticleAttributes> attrs,
+                               const Transform& T_bnew_bold, double forget_rate) {
+    init();
+    check(rmclhip_pf_motion_update(h_, poses.raw(), attrs.raw(), static_cast<uint32_t>(poses.size()), &T_bnew_bold,
+                                   forget_rate, check_collision ? 1 : 0));
+    return {};
+  }
+
+ private:
+  HipMapPtr map_;
+  rmclhip_pf* h_ = nullptr;
+};
+
+// rmcl::GladiatorResamplerGPU on gfx950: Resampler<MemT>::update(poses, attrs, poses_new, attrs_new)
+// (GladiatorResamplerGPU.cpp:46-81).  Out of place; `seed` + the running step select the Philox stream.
+struct ParticleUpdateDynamicConfig {};
+struct ParticleUpdateDynamicResults { size_t n_particles = 0; };
+class GladiatorResamplerHip : public SensorUpdaterBase {
+ public:
+  rmclhip_gladiator_config config_{0.03f, 0.03f, 0.0f, 0.0f, 0.0f, 0.01f, 0.3f, 0.2f, 0u};
+  uint64_t seed = 1234;
+
+  explicit GladiatorResamplerHip(ContextPtr ctx) : ctx_(std::move(ctx)) {
+    if (!ctx_) throw std::runtime_error("NO CONTEXT");
+  }
+  ~GladiatorResamplerHip() override { rmclhip_resampler_destroy(h_); }
+  void init() override {
+    if (!h_) check(rmclhip_resampler_create(ctx_->handle(), &h_));
+  }
+  void reset() override { step_ = 0; }
+  rmclhip_likelihood_stats computeStats(DeviceView<ParticleAttributes> attrs) {
+    init();
+    rmclhip_likelihood_stats s{};
+    check(rmclhip_resampler_compute_stats(h_, attrs.raw(), static_cast<uint32_t>(attrs.size()), &s));
+    return s;
+  }
+  ParticleUpdateDynamicResults update(DeviceView<Transform> poses, DeviceView<ParticleAttributes> attrs,
+                                      DeviceView<Transform> poses_new, DeviceView<ParticleAttributes> attrs_new,
+                                      const ParticleUpdateDynamicConfig& = {}) {
+    init();
+    const uint32_t n_new = static_cast<uint32_t>(poses_new.size());
+    check(rmclhip_resampler_gladiator(h_, poses.raw(), attrs.raw(), static_cast<uint32_t>(poses.size()), poses_new.raw(),
+                                      attrs_new.raw(), 0u, n_new, &config_, seed, step_++));
+    return {n_new};
+  }
+
+ private:
+  ContextPtr ctx_;
+  rmclhip_resampler* h_ = nullptr;
+  uint32_t step_ = 0;
+};
+
 }  // namespace rmcl_hip

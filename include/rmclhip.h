@@ -87,6 +87,17 @@ typedef struct {
   uint32_t correspondence_type;     /* 0 = RCC (evaluate_rcc, :18-86), 1 = CPC (evaluate_cpc, :88-95) */
 } rmclhip_pf_params;
 
+/* rmcl::GladiatorResamplerConfig (GladiatorResamplerConfig.hpp:7-20), defaults GladiatorResamplerGPU.cpp:34-44 */
+typedef struct {
+  float min_noise_tx, min_noise_ty, min_noise_tz;        /* 0.03 0.03 0 */
+  float min_noise_roll, min_noise_pitch, min_noise_yaw;  /* 0 0 0.01 */
+  float likelihood_forget_per_meter;                     /* 0.3 */
+  float likelihood_forget_per_radian;                    /* 0.2 */
+  uint32_t trans_dist_metric; /* 0 = |t| (resampling.cu:179), 1 = |t|^2 (GladiatorResamplerCPU.cpp:156) */
+} rmclhip_gladiator_config;
+/* rmcl::SimpleLikelihoodStats (resampling.cuh:26-30) */
+typedef struct { float sum, max; } rmclhip_likelihood_stats;
+
 typedef struct {
   uint32_t n_faces, n_vertices;
   uint32_t n_nodes;        /* BVH4 nodes (128 B each) */
@@ -101,6 +112,7 @@ typedef struct rmclhip_ctx rmclhip_ctx;
 typedef struct rmclhip_map rmclhip_map;
 typedef struct rmclhip_rcc rmclhip_rcc;
 typedef struct rmclhip_pf rmclhip_pf;
+typedef struct rmclhip_resampler rmclhip_resampler;
 
 /* ---- library ------------------------------------------------------------------ */
 const char* rmclhip_last_error(void);
@@ -277,6 +289,24 @@ rmclhip_status rmclhip_pf_time_update(rmclhip_pf* pf, const rmclhip_transform* p
                                       const rmclhip_range_measurement* beams, uint32_t n_beams,
                                       const rmclhip_transform* Tsb, uint32_t iters, float* ms_per_launch);
 rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* pf, int variant);
+
+
+/* ---- resampling: rmcl::GladiatorResamplerGPU (GladiatorResamplerGPU.cpp:46-81, resampling.cu:41-219) ----
+ * compute_stats: {sum, max} of likelihood.mean over n particles (simple_stats_kernel), returned to the host.
+ * gladiator: champions first .. first+count-1 each fight one random enemy out of ALL n_particles; the winner
+ * (enemy: copied, perturbed by the min_noise_* Gaussians, n_meas *= remember_rate) lands in
+ * poses_new_dev / attrs_new_dev [0 .. count).  first/count let one GPU resample its shard of an all-gathered
+ * cloud.  Random numbers: Philox4x32-10, key = seed, counter = (champion index, step, draw, 0) -- reproducible
+ * and independent of the sharding (the reference's cuRAND / mt19937 streams are not reproducible). */
+rmclhip_status rmclhip_resampler_create(rmclhip_ctx* ctx, rmclhip_resampler** out);
+void rmclhip_resampler_destroy(rmclhip_resampler* rs);
+rmclhip_status rmclhip_resampler_compute_stats(rmclhip_resampler* rs, const rmclhip_particle_attributes* attrs_dev,
+                                               uint32_t n, rmclhip_likelihood_stats* out);
+rmclhip_status rmclhip_resampler_gladiator(rmclhip_resampler* rs, const rmclhip_transform* poses_dev,
+                                           const rmclhip_particle_attributes* attrs_dev, uint32_t n_particles,
+                                           rmclhip_transform* poses_new_dev, rmclhip_particle_attributes* attrs_new_dev,
+                                           uint32_t first, uint32_t count, const rmclhip_gladiator_config* config,
+                                           uint64_t seed, uint32_t step);
 
 /* ---- device memory helpers for hosts without their own allocator ---------------------- */
 rmclhip_status rmclhip_malloc(rmclhip_ctx* ctx, size_t bytes, void** out_dev);

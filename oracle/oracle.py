@@ -59,6 +59,17 @@ class Gaussian1D(C.Structure):
     _fields_ = [("mean", C.c_float), ("sigma", C.c_float), ("n_meas", C.c_uint32)]
 
 
+class GladiatorConfig(C.Structure):
+    _fields_ = [("min_noise_tx", C.c_float), ("min_noise_ty", C.c_float), ("min_noise_tz", C.c_float),
+                ("min_noise_roll", C.c_float), ("min_noise_pitch", C.c_float), ("min_noise_yaw", C.c_float),
+                ("likelihood_forget_per_meter", C.c_float), ("likelihood_forget_per_radian", C.c_float),
+                ("trans_dist_metric", C.c_uint32)]
+
+
+class LikelihoodStats(C.Structure):
+    _fields_ = [("sum", C.c_float), ("max", C.c_float)]
+
+
 class PFParams(C.Structure):
     _fields_ = [("dist_sigma", C.c_float), ("real_hit_sim_miss_error", C.c_float),
                 ("real_miss_sim_hit_error", C.c_float), ("real_miss_sim_miss_error", C.c_float),
@@ -153,6 +164,11 @@ def lib():
     L.orc_closest_point.argtypes = [vp, Vec3, i32, C.POINTER(f32), C.POINTER(Vec3), C.POINTER(u32)]
     L.orc_cpc_find.argtypes = [vp, vp, vp, vp, u32, f32, i32, vp, vp, vp, vp, vp]
     L.orc_pf_motion_update.argtypes = [vp, vp, vp, u32, vp, C.c_double, u32, i32]
+    L.orc_philox4x32_10.argtypes = [vp, vp, vp]
+    L.orc_likelihood_stats_compute.restype = LikelihoodStats
+    L.orc_likelihood_stats_compute.argtypes = [vp, u32]
+    L.orc_quat_to_euler.argtypes = [Quat, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32)]
+    L.orc_gladiator_resample.argtypes = [vp, vp, u32, vp, vp, u32, u32, C.POINTER(GladiatorConfig), C.c_uint64, u32]
     _lib = L
     return L
 
@@ -472,3 +488,45 @@ def pinhole_directions(width, height, f, c):
     out = np.zeros((width * height, 3), dtype=np.float32)
     lib().orc_pinhole_directions(width, height, _p(fa), _p(ca), _p(out))
     return out
+
+
+# ------------------------------------------------------------ resampling --
+def gladiator_config(min_noise_tx=0.03, min_noise_ty=0.03, min_noise_tz=0.0, min_noise_roll=0.0, min_noise_pitch=0.0,
+                     min_noise_yaw=0.01, likelihood_forget_per_meter=0.3, likelihood_forget_per_radian=0.2,
+                     trans_dist_metric=0):
+    """GladiatorResamplerGPU::updateParams defaults (GladiatorResamplerGPU.cpp:34-44)."""
+    return GladiatorConfig(min_noise_tx, min_noise_ty, min_noise_tz, min_noise_roll, min_noise_pitch, min_noise_yaw,
+                           likelihood_forget_per_meter, likelihood_forget_per_radian, trans_dist_metric)
+
+
+def philox4x32_10(ctr, key):
+    c = np.ascontiguousarray(ctr, dtype=np.uint32)
+    k = np.ascontiguousarray(key, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib().orc_philox4x32_10(_p(c), _p(k), _p(out))
+    return out
+
+
+def likelihood_stats(attrs):
+    assert attrs.dtype == PARTICLE_ATTRIBUTES
+    r = lib().orc_likelihood_stats_compute(_p(attrs), len(attrs))
+    return {"sum": r.sum, "max": r.max}
+
+
+def quat_to_euler(q):
+    r, p, y = C.c_float(), C.c_float(), C.c_float()
+    xyzw = [float(v) for v in q] if isinstance(q, (tuple, list)) else [float(q[k]) for k in "xyzw"]
+    lib().orc_quat_to_euler(Quat(*xyzw), C.byref(r), C.byref(p), C.byref(y))
+    return r.value, p.value, y.value
+
+
+def gladiator_resample(poses, attrs, cfg, seed, step, first=0, count=None):
+    """returns (poses_new, attrs_new) of champions first..first+count-1."""
+    poses = np.ascontiguousarray(poses, dtype=TRANSFORM).reshape(-1)
+    assert attrs.dtype == PARTICLE_ATTRIBUTES and len(attrs) == len(poses)
+    if count is None:
+        count = len(poses) - first
+    pn, an = np.zeros(count, TRANSFORM), np.zeros(count, PARTICLE_ATTRIBUTES)
+    lib().orc_gladiator_resample(_p(poses), _p(attrs), len(poses), _p(pn), _p(an), int(first), int(count),
+                                 C.byref(cfg), int(seed), int(step))
+    return pn, an

@@ -1192,3 +1192,117 @@ void orc_cpc_find(const orc_mesh* m, const orc_transform* Tsb, const orc_transfo
     }
   }
 }
+
+/* ------------------------------------------------------------------------- */
+/* gladiator resampling (resampling.cu:41-219, GladiatorResamplerCPU.cpp)    */
+/* ------------------------------------------------------------------------- */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* simple_stats_kernel (resampling.cu:41-81): {sum, max} of likelihood.mean, max seeded with 0 like the kernel's
+ * shared-memory init (:52-53); the sum is accumulated in double (order independent to float precision). */
+orc_likelihood_stats orc_likelihood_stats_compute(const orc_particle_attributes* attrs, uint32_t n)
+{
+  double sum = 0.0; float mx = 0.0f;
+  for (uint32_t i = 0; i < n; ++i) {
+    const float L = attrs[i].likelihood.mean;
+    sum += (double)L;
+    if (L > mx) mx = L;
+  }
+  orc_likelihood_stats r = {(float)sum, mx};
+  return r;
+}
+
+/* rmagine EulerAngles::set(Quaternion) (EXTERNAL; the textbook ZYX extraction) */
+void orc_quat_to_euler(orc_quat q, float* roll, float* pitch, float* yaw)
+{
+  const float sinr_cosp = 2.0f * (q.w * q.x + q.y * q.z);
+  const float cosr_cosp = 1.0f - 2.0f * (q.x * q.x + q.y * q.y);
+  const float sinp = 2.0f * (q.w * q.y - q.z * q.x);
+  const float siny_cosp = 2.0f * (q.w * q.z + q.x * q.y);
+  const float cosy_cosp = 1.0f - 2.0f * (q.y * q.y + q.z * q.z);
+  *roll = (float)atan2((double)sinr_cosp, (double)cosr_cosp);
+  if (fabsf(sinp) >= 1.0f) *pitch = copysignf((float)(M_PI / 2.0), sinp);
+  else *pitch = (float)asin((double)sinp);
+  *yaw = (float)atan2((double)siny_cosp, (double)cosy_cosp);
+}
+
+static orc_quat euler_to_quat_d(float roll, float pitch, float yaw)
+{
+  const float cr = (float)cos((double)(roll / 2.0f)), sr = (float)sin((double)(roll / 2.0f));
+  const float cp = (float)cos((double)(pitch / 2.0f)), sp = (float)sin((double)(pitch / 2.0f));
+  const float cy = (float)cos((double)(yaw / 2.0f)), sy = (float)sin((double)(yaw / 2.0f));
+  orc_quat q;
+  q.w = cr * cp * cy + sr * sp * sy;
+  q.x = sr * cp * cy - cr * sp * sy;
+  q.y = cr * sp * cy + sr * cp * sy;
+  q.z = cr * cp * sy - sr * sp * cy;
+  return q;
+}
+
+static void box_muller(uint32_t a, uint32_t b, float* z0, float* z1)
+{
+  const double u1 = ((double)a + 0.5) * (1.0 / 4294967296.0), u2 = ((double)b + 0.5) * (1.0 / 4294967296.0);
+  const double r = sqrt(-2.0 * log(u1)), ang = 6.283185307179586476925 * u2;
+  *z0 = (float)(r * cos(ang));
+  *z1 = (float)(r * sin(ang));
+}
+
+void orc_gladiator_resample(const orc_transform* poses, const orc_particle_attributes* attrs, uint32_t n,
+                            orc_transform* poses_new, orc_particle_attributes* attrs_new, uint32_t first,
+                            uint32_t count, const orc_gladiator_config* cfg, uint64_t seed, uint32_t step)
+{
+  const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  for (uint32_t k = 0; k < count; ++k) {
+    const uint32_t champion = first + k;
+    uint32_t ra[4], rb[4];
+    const uint32_t c0[4] = {champion, step, 0u, 0u}, c1[4] = {champion, step, 1u, 0u};
+    orc_philox4x32_10(c0, key, ra);
+    orc_philox4x32_10(c1, key, rb);
+    const uint32_t enemy = ra[0] % n;
+    float Nd_tx, Nd_ty, Nd_tz, Nd_rx, Nd_ry, Nd_rz;
+    box_muller(ra[1], ra[2], &Nd_tx, &Nd_ty);
+    box_muller(ra[3], rb[0], &Nd_tz, &Nd_rx);
+    box_muller(rb[1], rb[2], &Nd_ry, &Nd_rz);
+    const float Lc = attrs[champion].likelihood.mean, Le = attrs[enemy].likelihood.mean;
+    if (Le > Lc) {
+      const orc_transform pose = poses[enemy];
+      orc_transform pose_new = pose;
+      orc_particle_attributes attrs_n = attrs[enemy];
+      pose_new.t.x = pose_new.t.x + Nd_tx * cfg->min_noise_tx;
+      pose_new.t.y = pose_new.t.y + Nd_ty * cfg->min_noise_ty;
+      pose_new.t.z = pose_new.t.z + Nd_tz * cfg->min_noise_tz;
+      float roll, pitch, yaw;
+      orc_quat_to_euler(pose_new.R, &roll, &pitch, &yaw);
+      roll = roll + Nd_rx * cfg->min_noise_roll;
+      pitch = pitch + Nd_ry * cfg->min_noise_pitch;
+      yaw = yaw + Nd_rz * cfg->min_noise_yaw;
+      pose_new.R = euler_to_quat_d(roll, pitch, yaw);
+      const orc_transform diff = orc_transform_mult(orc_transform_inv(pose), pose_new);
+      const float t2 = (diff.t.x * diff.t.x + diff.t.y * diff.t.y) + diff.t.z * diff.t.z;
+      const float trans_dist = (cfg->trans_dist_metric == 1u) ? t2 : sqrtf(t2);
+      /* rmagine Quaternion::l2norm (EXTERNAL): the 4-vector norm, i.e. ~1 for a unit quaternion */
+      const float rot_dist = sqrtf(((diff.R.w * diff.R.w + diff.R.x * diff.R.x) + diff.R.y * diff.R.y) + diff.R.z * diff.R.z);
+      const float frs = (float)(1.0 - pow(1.0 - (double)cfg->likelihood_forget_per_meter, (double)trans_dist));
+      const float frr = (float)(1.0 - pow(1.0 - (double)cfg->likelihood_forget_per_radian, (double)rot_dist));
+      const float forget_rate = (frs > frr) ? frs : frr;
+      const float remember_rate = (float)(1.0 - (double)forget_rate);
+      attrs_n.likelihood.n_meas = (uint32_t)((float)attrs_n.likelihood.n_meas * remember_rate);
+      poses_new[k] = pose_new;
+      attrs_new[k] = attrs_n;
+    } else {
+      poses_new[k] = poses[champion];
+      attrs_new[k] = attrs[champion];
+    }
+  }
+}

@@ -171,6 +171,28 @@ int orc_collision_in_between(const orc_mesh* m, orc_vec3 p1, orc_vec3 p2, int us
 void orc_pf_motion_update(const orc_mesh* m, orc_transform* poses, orc_particle_attributes* attrs, uint32_t n,
                           const orc_transform* T_bnew_bold, double forget_rate, uint32_t max_n_meas, int use_bvh);
 
+/* ---- gladiator resampling (resampling.cu:41-219, GladiatorResamplerCPU.cpp:71-176) ----
+ * The reference draws from cuRAND (GPU) / per-TBB-thread mt19937 (CPU, schedule dependent): neither stream can
+ * be reproduced, so the restatement pins a counter-based generator instead: Philox4x32-10 (Salmon et al. 2011),
+ * key = seed, counter = (champion index, step, draw, 0).  Normals: Box-Muller in double.  Every transcendental
+ * (log, sin, cos, atan2, asin, pow) is evaluated in double and rounded to float, so that host and device agree. */
+typedef struct {
+  float min_noise_tx, min_noise_ty, min_noise_tz;         /* GladiatorResamplerGPU.cpp:34-40 defaults .03 .03 0 */
+  float min_noise_roll, min_noise_pitch, min_noise_yaw;   /* 0 0 .01 */
+  float likelihood_forget_per_meter;                      /* 0.3 */
+  float likelihood_forget_per_radian;                     /* 0.2 */
+  uint32_t trans_dist_metric;   /* 0 = l2norm (resampling.cu:179), 1 = l2normSquared (GladiatorResamplerCPU.cpp:156) */
+} orc_gladiator_config;
+typedef struct { float sum, max; } orc_likelihood_stats;
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+orc_likelihood_stats orc_likelihood_stats_compute(const orc_particle_attributes* attrs, uint32_t n);
+void orc_quat_to_euler(orc_quat q, float* roll, float* pitch, float* yaw);
+/* champions first .. first+count-1 fight a random enemy out of the n particles; the winners land in
+ * poses_new / attrs_new [0 .. count) */
+void orc_gladiator_resample(const orc_transform* poses, const orc_particle_attributes* attrs, uint32_t n,
+                            orc_transform* poses_new, orc_particle_attributes* attrs_new, uint32_t first,
+                            uint32_t count, const orc_gladiator_config* cfg, uint64_t seed, uint32_t step);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,17 @@ class PFParams(C.Structure):
                 ("correspondence_type", C.c_uint32)]
 
 
+class GladiatorConfig(C.Structure):
+    _fields_ = [("min_noise_tx", C.c_float), ("min_noise_ty", C.c_float), ("min_noise_tz", C.c_float),
+                ("min_noise_roll", C.c_float), ("min_noise_pitch", C.c_float), ("min_noise_yaw", C.c_float),
+                ("likelihood_forget_per_meter", C.c_float), ("likelihood_forget_per_radian", C.c_float),
+                ("trans_dist_metric", C.c_uint32)]
+
+
+class LikelihoodStats(C.Structure):
+    _fields_ = [("sum", C.c_float), ("max", C.c_float)]
+
+
 class MapInfo(C.Structure):
     _fields_ = [("n_faces", C.c_uint32), ("n_vertices", C.c_uint32), ("n_nodes", C.c_uint32),
                 ("n_tri_records", C.c_uint32), ("max_depth", C.c_uint32), ("stack_need", C.c_uint32),
@@ -108,6 +119,11 @@ SIGNATURES = {
     "rmclhip_pf_extract_weights": (_i32, [_vp, _vp, _u32, _vp]),
     "rmclhip_pf_time_update": (_i32, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32, C.POINTER(_f32)]),
     "rmclhip_pf_set_variant": (_i32, [_vp, _i32]),
+    "rmclhip_resampler_create": (_i32, [_vp, _pp]),
+    "rmclhip_resampler_destroy": (None, [_vp]),
+    "rmclhip_resampler_compute_stats": (_i32, [_vp, _vp, _u32, C.POINTER(LikelihoodStats)]),
+    "rmclhip_resampler_gladiator": (_i32, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, C.POINTER(GladiatorConfig),
+                                            C.c_uint64, _u32]),
     "rmclhip_malloc": (_i32, [_vp, _sz, _pp]),
     "rmclhip_free": (_i32, [_vp, _vp]),
     "rmclhip_memcpy_h2d": (_i32, [_vp, _vp, _vp, _sz]),

@@ -174,6 +174,15 @@ struct rmclhip_pf {
   int variant = 0;
 };
 
+// GladiatorResamplerGPU analogue: owns a stream and the scratch of the {sum, max} reduction
+struct rmclhip_resampler {
+  rmclhip_ctx* ctx = nullptr;
+  hipStream_t stream = nullptr;
+  DevBuf<double> d_psum;
+  DevBuf<float> d_pmax, d_out;
+  float* h_out = nullptr;  // pinned {sum, max}
+};
+
 extern "C" {
 
 const char* rmclhip_last_error(void) { return g_err.c_str(); }
@@ -1180,6 +1189,81 @@ rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* f, int variant) {
   ApiGuard guard_("rmclhip_pf_set_variant");
   if (!f || variant < 0 || variant > 2) return fail(RMCLHIP_ERR_INVALID, "pf_set_variant: bad arguments");
   f->variant = variant;
+  return RMCLHIP_OK;
+}
+
+
+// ---- resampling --------------------------------------------------------------------------------
+rmclhip_status rmclhip_resampler_create(rmclhip_ctx* ctx, rmclhip_resampler** out) {
+  ApiGuard guard_("rmclhip_resampler_create");
+  if (!out) return fail(RMCLHIP_ERR_INVALID, "resampler_create: out is null");
+  *out = nullptr;
+  if (!ctx) return fail(RMCLHIP_ERR_INVALID, "resampler_create: null context");
+  HIPCHK(hipSetDevice(ctx->device));
+  rmclhip_resampler* r = new rmclhip_resampler();
+  r->ctx = ctx;
+  hipError_t e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = r->d_psum.reserve(256);
+  if (e == hipSuccess) e = r->d_pmax.reserve(256);
+  if (e == hipSuccess) e = r->d_out.reserve(2);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_out), 2 * sizeof(float), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    rmclhip_resampler_destroy(r);
+    return fail(RMCLHIP_ERR_HIP, std::string("resampler_create: ") + hipGetErrorString(e));
+  }
+  *out = r;
+  return RMCLHIP_OK;
+}
+
+void rmclhip_resampler_destroy(rmclhip_resampler* r) {
+  ApiGuard guard_("rmclhip_resampler_destroy");
+  if (!r) return;
+  (void)hipSetDevice(r->ctx->device);
+  if (r->stream) (void)hipStreamSynchronize(r->stream);
+  r->d_psum.release();
+  r->d_pmax.release();
+  r->d_out.release();
+  if (r->h_out) (void)hipHostFree(r->h_out);
+  if (r->stream) (void)hipStreamDestroy(r->stream);
+  delete r;
+}
+
+rmclhip_status rmclhip_resampler_compute_stats(rmclhip_resampler* r, const rmclhip_particle_attributes* attrs_dev,
+                                               uint32_t n, rmclhip_likelihood_stats* out) {
+  ApiGuard guard_("rmclhip_resampler_compute_stats");
+  if (!r || !out || (!attrs_dev && n)) return fail(RMCLHIP_ERR_INVALID, "resampler_compute_stats: null");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  HIPCHK(launch_likelihood_stats(attrs_dev, n, r->d_psum.p, r->d_pmax.p, r->d_out.p, r->stream));
+  HIPCHK(hipMemcpyAsync(r->h_out, r->d_out.p, 2 * sizeof(float), hipMemcpyDeviceToHost, r->stream));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  out->sum = r->h_out[0];
+  out->max = r->h_out[1];
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_resampler_gladiator(rmclhip_resampler* r, const rmclhip_transform* poses_dev,
+                                           const rmclhip_particle_attributes* attrs_dev, uint32_t n_particles,
+                                           rmclhip_transform* poses_new_dev, rmclhip_particle_attributes* attrs_new_dev,
+                                           uint32_t first, uint32_t count, const rmclhip_gladiator_config* cfg,
+                                           uint64_t seed, uint32_t step) {
+  ApiGuard guard_("rmclhip_resampler_gladiator");
+  if (!r || !cfg) return fail(RMCLHIP_ERR_INVALID, "resampler_gladiator: null");
+  if (count == 0) return RMCLHIP_OK;
+  if (!poses_dev || !attrs_dev || !poses_new_dev || !attrs_new_dev || n_particles == 0)
+    return fail(RMCLHIP_ERR_INVALID, "resampler_gladiator: null particle buffers");
+  if (static_cast<uint64_t>(first) + count > n_particles)
+    return fail(RMCLHIP_ERR_INVALID, "resampler_gladiator: champion range exceeds the particle count");
+  if (cfg->trans_dist_metric > 1u) return fail(RMCLHIP_ERR_INVALID, "resampler_gladiator: trans_dist_metric must be 0 or 1");
+  if (poses_new_dev == poses_dev || attrs_new_dev == attrs_dev)
+    return fail(RMCLHIP_ERR_INVALID, "resampler_gladiator: the tournament is out of place (double buffers)");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  const float c8[8] = {cfg->min_noise_tx, cfg->min_noise_ty, cfg->min_noise_tz, cfg->min_noise_roll,
+                       cfg->min_noise_pitch, cfg->min_noise_yaw, cfg->likelihood_forget_per_meter,
+                       cfg->likelihood_forget_per_radian};
+  HIPCHK(launch_gladiator_resample(reinterpret_cast<const xform*>(poses_dev), attrs_dev, n_particles,
+                                   reinterpret_cast<xform*>(poses_new_dev), attrs_new_dev, first, count, c8,
+                                   cfg->trans_dist_metric, seed, step, r->stream));
+  HIPCHK(hipStreamSynchronize(r->stream));
   return RMCLHIP_OK;
 }
 

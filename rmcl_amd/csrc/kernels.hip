@@ -938,6 +938,142 @@ __global__ void k_pf_extract_weights(const pattrs* __restrict__ attrs, uint32_t 
   if (i < n) w[i] = attrs[i].likelihood.mean;
 }
 
+// ---------------------------------------------------------------------------------------------
+// gladiator resampling (resampling.cu:41-219).  Random stream = Philox4x32-10 keyed by the seed with counter
+// (champion index, step, draw, 0): reproducible, independent of the launch shape and of how the particle range
+// is sharded across GPUs.  Transcendentals are evaluated in double and rounded to float (see oracle).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
+  const double u1 = (static_cast<double>(a) + 0.5) * (1.0 / 4294967296.0);
+  const double u2 = (static_cast<double>(b) + 0.5) * (1.0 / 4294967296.0);
+  const double r = sqrt(-2.0 * log(u1)), ang = 6.283185307179586476925 * u2;
+  z0 = static_cast<float>(r * cos(ang));
+  z1 = static_cast<float>(r * sin(ang));
+}
+
+struct GladiatorConfig {
+  float min_noise_tx, min_noise_ty, min_noise_tz, min_noise_roll, min_noise_pitch, min_noise_yaw;
+  float likelihood_forget_per_meter, likelihood_forget_per_radian;
+  uint32_t trans_dist_metric;
+};
+
+__global__ void __launch_bounds__(256) k_gladiator_resample(const xform* __restrict__ poses, const pattrs* __restrict__ attrs,
+                                                            uint32_t n, xform* __restrict__ poses_new,
+                                                            pattrs* __restrict__ attrs_new, uint32_t first, uint32_t count,
+                                                            GladiatorConfig cfg, uint32_t key0, uint32_t key1,
+                                                            uint32_t step) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  const uint32_t champion = first + k;
+  uint32_t ra[4], rb[4];
+  philox4x32_10(champion, step, 0u, 0u, key0, key1, ra);
+  philox4x32_10(champion, step, 1u, 0u, key0, key1, rb);
+  const uint32_t enemy = ra[0] % n;
+  const float Lc = attrs[champion].likelihood.mean, Le = attrs[enemy].likelihood.mean;
+  if (Le > Lc) {
+    float Nd_tx, Nd_ty, Nd_tz, Nd_rx, Nd_ry, Nd_rz;
+    box_muller(ra[1], ra[2], Nd_tx, Nd_ty);
+    box_muller(ra[3], rb[0], Nd_tz, Nd_rx);
+    box_muller(rb[1], rb[2], Nd_ry, Nd_rz);
+    const xform pose = poses[enemy];
+    xform pn = pose;
+    pattrs an = attrs[enemy];
+    pn.t.x = pn.t.x + Nd_tx * cfg.min_noise_tx;
+    pn.t.y = pn.t.y + Nd_ty * cfg.min_noise_ty;
+    pn.t.z = pn.t.z + Nd_tz * cfg.min_noise_tz;
+    // EulerAngles e = pose_new.R (textbook ZYX extraction)
+    const quat q = pn.R;
+    const float sinr_cosp = 2.0f * (q.w * q.x + q.y * q.z);
+    const float cosr_cosp = 1.0f - 2.0f * (q.x * q.x + q.y * q.y);
+    const float sinp = 2.0f * (q.w * q.y - q.z * q.x);
+    const float siny_cosp = 2.0f * (q.w * q.z + q.x * q.y);
+    const float cosy_cosp = 1.0f - 2.0f * (q.y * q.y + q.z * q.z);
+    float roll = static_cast<float>(atan2(static_cast<double>(sinr_cosp), static_cast<double>(cosr_cosp)));
+    float pitch = (fabsf(sinp) >= 1.0f) ? copysignf(static_cast<float>(3.14159265358979323846 / 2.0), sinp)
+                                        : static_cast<float>(asin(static_cast<double>(sinp)));
+    float yaw = static_cast<float>(atan2(static_cast<double>(siny_cosp), static_cast<double>(cosy_cosp)));
+    roll = roll + Nd_rx * cfg.min_noise_roll;
+    pitch = pitch + Nd_ry * cfg.min_noise_pitch;
+    yaw = yaw + Nd_rz * cfg.min_noise_yaw;
+    // pose_new.R = e
+    const float cr = static_cast<float>(cos(static_cast<double>(roll / 2.0f))), sr = static_cast<float>(sin(static_cast<double>(roll / 2.0f)));
+    const float cp = static_cast<float>(cos(static_cast<double>(pitch / 2.0f))), sp = static_cast<float>(sin(static_cast<double>(pitch / 2.0f)));
+    const float cy = static_cast<float>(cos(static_cast<double>(yaw / 2.0f))), sy = static_cast<float>(sin(static_cast<double>(yaw / 2.0f)));
+    pn.R.w = cr * cp * cy + sr * sp * sy;
+    pn.R.x = sr * cp * cy - cr * sp * sy;
+    pn.R.y = cr * sp * cy + sr * cp * sy;
+    pn.R.z = cr * cp * sy - sr * sp * cy;
+    const xform diff = xmul(xinv(pose), pn);
+    const float t2 = (diff.t.x * diff.t.x + diff.t.y * diff.t.y) + diff.t.z * diff.t.z;
+    const float trans_dist = (cfg.trans_dist_metric == 1u) ? t2 : sqrtf(t2);
+    const float rot_dist = sqrtf(((diff.R.w * diff.R.w + diff.R.x * diff.R.x) + diff.R.y * diff.R.y) + diff.R.z * diff.R.z);
+    const float frs = static_cast<float>(1.0 - pow(1.0 - static_cast<double>(cfg.likelihood_forget_per_meter), static_cast<double>(trans_dist)));
+    const float frr = static_cast<float>(1.0 - pow(1.0 - static_cast<double>(cfg.likelihood_forget_per_radian), static_cast<double>(rot_dist)));
+    const float forget_rate = (frs > frr) ? frs : frr;
+    const float remember_rate = static_cast<float>(1.0 - static_cast<double>(forget_rate));
+    an.likelihood.n_meas = static_cast<uint32_t>(static_cast<float>(an.likelihood.n_meas) * remember_rate);
+    poses_new[k] = pn;
+    attrs_new[k] = an;
+  } else {
+    poses_new[k] = poses[champion];
+    attrs_new[k] = attrs[champion];
+  }
+}
+
+// simple_stats_kernel (resampling.cu:41-81): {sum, max} of likelihood.mean; max seeded with 0 like the reference's
+// shared-memory init, sum accumulated in double.  Stage 1: <=256 blocks of grid-stride partials; stage 2: one wave.
+__global__ void __launch_bounds__(256) k_likelihood_stats_partial(const pattrs* __restrict__ attrs, uint32_t n,
+                                                                  double* __restrict__ psum, float* __restrict__ pmax) {
+  __shared__ double s_sum[4];
+  __shared__ float s_max[4];
+  double sum = 0.0;
+  float mx = 0.0f;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float L = attrs[i].likelihood.mean;
+    sum += static_cast<double>(L);
+    mx = (L > mx) ? L : mx;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    sum += __shfl_down(sum, off);
+    const float o = __shfl_down(mx, off);
+    mx = (o > mx) ? o : mx;
+  }
+  if ((threadIdx.x & 63u) == 0u) { s_sum[threadIdx.x >> 6] = sum; s_max[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    psum[blockIdx.x] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
+    pmax[blockIdx.x] = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+  }
+}
+
+__global__ void __launch_bounds__(64) k_likelihood_stats_final(const double* __restrict__ psum, const float* __restrict__ pmax,
+                                                               uint32_t nblocks, float* __restrict__ out) {
+  double sum = 0.0;
+  float mx = 0.0f;
+  for (uint32_t i = threadIdx.x; i < nblocks; i += 64u) {
+    sum += psum[i];
+    mx = fmaxf(mx, pmax[i]);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    sum += __shfl_down(sum, off);
+    mx = fmaxf(mx, __shfl_down(mx, off));
+  }
+  if (threadIdx.x == 0) { out[0] = static_cast<float>(sum); out[1] = mx; }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1068,6 +1204,27 @@ hipError_t launch_pf_extract_weights(const void* attrs, uint32_t n, float* weigh
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_pf_extract_weights, dim3((n + 255u) / 256u), dim3(256), 0, s,
                      reinterpret_cast<const pattrs*>(attrs), n, weights);
+  return hipGetLastError();
+}
+
+hipError_t launch_gladiator_resample(const xform* poses, const void* attrs, uint32_t n, xform* poses_new, void* attrs_new,
+                                     uint32_t first, uint32_t count, const float* cfg8, uint32_t trans_dist_metric,
+                                     uint64_t seed, uint32_t step, hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  GladiatorConfig c{cfg8[0], cfg8[1], cfg8[2], cfg8[3], cfg8[4], cfg8[5], cfg8[6], cfg8[7], trans_dist_metric};
+  hipLaunchKernelGGL(k_gladiator_resample, dim3((count + 255u) / 256u), dim3(256), 0, s, poses,
+                     reinterpret_cast<const pattrs*>(attrs), n, poses_new, reinterpret_cast<pattrs*>(attrs_new), first,
+                     count, c, static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), step);
+  return hipGetLastError();
+}
+
+hipError_t launch_likelihood_stats(const void* attrs, uint32_t n, double* psum, float* pmax, float* out2, hipStream_t s) {
+  uint32_t nblocks = (n + 1023u) / 1024u;
+  if (nblocks < 1u) nblocks = 1u;
+  if (nblocks > 256u) nblocks = 256u;
+  hipLaunchKernelGGL(k_likelihood_stats_partial, dim3(nblocks), dim3(256), 0, s, reinterpret_cast<const pattrs*>(attrs), n,
+                     psum, pmax);
+  hipLaunchKernelGGL(k_likelihood_stats_final, dim3(1), dim3(64), 0, s, psum, pmax, nblocks, out2);
   return hipGetLastError();
 }
 

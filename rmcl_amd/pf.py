@@ -11,7 +11,7 @@ import numpy as np
 
 from . import _capi
 from .registration import _as_ptr
-from .types import RANGE_MEASUREMENT, TRANSFORM, _ptr, pf_params
+from .types import RANGE_MEASUREMENT, TRANSFORM, _ptr, gladiator_config, pf_params
 
 
 def beams_from_points(points):
@@ -160,6 +160,59 @@ class PCDSensorUpdaterHip:
     def close(self):
         if self._h:
             _capi.lib().rmclhip_pf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GladiatorResamplerHip:
+    """rmcl::GladiatorResamplerGPU on gfx950 (Resampler<MemT>: init / reset / update(poses, attrs, poses_new,
+    attrs_new) -> {n_particles}; GladiatorResamplerGPU.cpp:46-81).  The tournament is out of place (the node's
+    particle double buffer, rmcl_localization.cpp:600-640); `seed` and the running step counter select the
+    Philox stream, so a run is reproducible."""
+
+    def __init__(self, ctx, seed=1234):
+        self.ctx = ctx
+        self.config = gladiator_config()
+        self.seed = int(seed)
+        self.step = 0
+        self._h = C.c_void_p()
+
+    def init(self):
+        if not self._h:
+            _capi.check(_capi.lib().rmclhip_resampler_create(self.ctx.handle, C.byref(self._h)))
+
+    def reset(self):
+        self.step = 0
+
+    def compute_stats(self, particle_attrs, n_particles):
+        """compute_stats (resampling.cu:83-92): {sum, max} of the particle likelihoods."""
+        self.init()
+        out = _capi.LikelihoodStats()
+        _capi.check(_capi.lib().rmclhip_resampler_compute_stats(self._h, _as_ptr(particle_attrs), int(n_particles),
+                                                                C.byref(out)))
+        return {"sum": out.sum, "max": out.max}
+
+    def update(self, particle_poses, particle_attrs, particle_poses_new, particle_attrs_new, n_particles,
+               first=0, count=None):
+        """champions first..first+count-1 (default: all) vs random enemies out of all n_particles; results in
+        particle_*_new[0..count)."""
+        self.init()
+        if count is None:
+            count = int(n_particles) - int(first)
+        _capi.check(_capi.lib().rmclhip_resampler_gladiator(
+            self._h, _as_ptr(particle_poses), _as_ptr(particle_attrs), int(n_particles), _as_ptr(particle_poses_new),
+            _as_ptr(particle_attrs_new), int(first), int(count), C.byref(self.config), self.seed, self.step))
+        self.step += 1
+        return {"n_particles": int(count)}
+
+    def close(self):
+        if self._h:
+            _capi.lib().rmclhip_resampler_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

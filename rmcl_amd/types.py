@@ -120,3 +120,13 @@ def pf_params(dist_sigma=2.0, real_hit_sim_miss_error=100.0, real_miss_sim_hit_e
     p.max_n_meas = max_n_meas
     p.correspondence_type = correspondence_type
     return p
+
+
+def gladiator_config(min_noise_tx=0.03, min_noise_ty=0.03, min_noise_tz=0.0, min_noise_roll=0.0, min_noise_pitch=0.0,
+                     min_noise_yaw=0.01, likelihood_forget_per_meter=0.3, likelihood_forget_per_radian=0.2,
+                     trans_dist_metric=0):
+    """resampling.* parameters with the defaults of GladiatorResamplerGPU::updateParams (GladiatorResamplerGPU.cpp:34-44);
+    trans_dist_metric 0 = |t| like the reference's GPU kernel, 1 = |t|^2 like its CPU implementation."""
+    return _capi.GladiatorConfig(min_noise_tx, min_noise_ty, min_noise_tz, min_noise_roll, min_noise_pitch,
+                                 min_noise_yaw, likelihood_forget_per_meter, likelihood_forget_per_radian,
+                                 trans_dist_metric)

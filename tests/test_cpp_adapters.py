@@ -86,3 +86,14 @@ def test_cpp_example_matches_python_and_oracle(ra, orc, ctx, meshes, tmp_path):
         mean, sigma, n = out["pf_%d" % i]
         assert int(n) == int(attrs["likelihood"]["n_meas"][i])
         assert abs(float(mean) - float(attrs["likelihood"]["mean"][i])) <= 1e-5 * abs(float(attrs["likelihood"]["mean"][i])) + 1e-12
+    # motion update + gladiator tournament on the updated cloud
+    m.pf_motion_update(poses, attrs, T.transform_from_rpy((0.3, 0, 0), (0, 0, 0.05)), 0.01, collision=True, bvh=False)
+    st = orc.likelihood_stats(attrs)
+    assert abs(float(out["stats"][0]) - st["sum"]) <= 1e-6 * st["sum"] and abs(float(out["stats"][1]) - st["max"]) <= 1e-6 * st["max"]
+    pn, an = orc.gladiator_resample(poses, attrs, orc.gladiator_config(), seed=42, step=0)
+    assert int(out["resampled"][0]) == 4
+    for i in range(4):
+        mean, n, x, y, z = out["rs_%d" % i]
+        assert int(n) == int(an["likelihood"]["n_meas"][i])
+        assert abs(float(mean) - float(an["likelihood"]["mean"][i])) <= 1e-5 * abs(float(an["likelihood"]["mean"][i])) + 1e-12
+        assert np.allclose([float(x), float(y), float(z)], [float(pn["t"][k][i]) for k in "xyz"], atol=1e-5)

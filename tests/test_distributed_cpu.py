@@ -53,6 +53,21 @@ def _worker(rank, world, port, n_total, out_dir):
         ok &= abs(ssum - float(ref["likelihood"]["mean"].astype(np.float64).sum())) < 1e-6
         ok &= smax == float(ref["likelihood"]["mean"].max())
         ok &= gathered.numel() == n_total
+        # distributed gladiator tournament == the unsharded one (Philox counter = global champion index)
+        cfg = orc.gladiator_config(min_noise_roll=0.01)
+
+        def resample(poses_all, attrs_all, n, first, count):
+            pa = poses_all.numpy().reshape(-1).view(orc.TRANSFORM)
+            aa = attrs_all.numpy().reshape(-1).view(orc.PARTICLE_ATTRIBUTES)
+            pn, an = orc.gladiator_resample(pa, aa, cfg, seed=77, step=3, first=first, count=count)
+            return pn, an
+
+        full = ref.copy()
+        lp = torch.from_numpy(poses[lo:hi].copy().view(np.uint8).reshape(hi - lo, 32))
+        la = torch.from_numpy(full[lo:hi].copy().view(np.uint8).reshape(hi - lo, 36))
+        pn, an = D.ShardedResample(resample, n_total, rank, world).update(lp, la)
+        pn_ref, an_ref = orc.gladiator_resample(poses, full, cfg, seed=77, step=3)
+        ok &= pn.tobytes() == pn_ref[lo:hi].tobytes() and an.tobytes() == an_ref[lo:hi].tobytes()
         with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as fh:
             fh.write("OK" if ok else "MISMATCH")
     finally:
