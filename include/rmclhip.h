@@ -87,6 +87,15 @@ typedef struct {
   uint32_t correspondence_type;     /* 0 = RCC (evaluate_rcc, :18-86), 1 = CPC (evaluate_cpc, :88-95) */
 } rmclhip_pf_params;
 
+/* sensor_msgs/PointCloud2 layout of the fields this path reads (datatype: PointField FLOAT32 = 7, FLOAT64 = 8) and
+ * the row / column sub-sampling of rmcl::FilterOptions2D (scan_operations.cpp:41-52) */
+typedef struct {
+  uint32_t width, height, point_step, row_step;
+  uint32_t offset_x, offset_y, offset_z;
+  uint32_t datatype;
+} rmclhip_pointcloud2_layout;
+typedef struct { uint32_t skip_begin, skip_end, increment; } rmclhip_filter1d;
+
 /* rmcl::GladiatorResamplerConfig (GladiatorResamplerConfig.hpp:7-20), defaults GladiatorResamplerGPU.cpp:34-44 */
 typedef struct {
   float min_noise_tx, min_noise_ty, min_noise_tz;        /* 0.03 0.03 0 */
@@ -182,6 +191,18 @@ rmclhip_status rmclhip_rcc_set_dataset_from_ranges(rmclhip_rcc* rcc, const float
 rmclhip_status rmclhip_rcc_find(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est);
 rmclhip_status rmclhip_rcc_find_async(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est);
 rmclhip_status rmclhip_rcc_sync(rmclhip_rcc* rcc);
+/* Wire-format input: the bytes of a sensor_msgs/PointCloud2 become the O1Dn sensor model AND the dataset in one
+ * device pass -- estimateModelAndData (rmcl_ros/src/util/conversions.cpp:869-1002: range = |p|, dir = p / range,
+ * non-finite -> 0) + filter (scan_operations.cpp:41-116; NULL = keep every row / column) +
+ * MICPO1DnSensorCPU::unpackMessage (MICPO1DnSensorCPU.cpp:176-227: point = dir * range + orig,
+ * mask = range within `range`).  Replaces set_model_o1dn + set_dataset for clouds; `data` may be a host or a
+ * device pointer.  Returns the filtered image size and the number of valid measurements. */
+rmclhip_status rmclhip_rcc_set_input_pointcloud2(rmclhip_rcc* rcc, const uint8_t* data, size_t nbytes,
+                                                 const rmclhip_pointcloud2_layout* layout,
+                                                 const rmclhip_filter1d* filter_height,
+                                                 const rmclhip_filter1d* filter_width, rmclhip_interval range,
+                                                 int src_is_device, uint32_t* out_width, uint32_t* out_height,
+                                                 uint32_t* n_valid);
 /* rmcl::CPCEmbree::find (rmcl/src/rmcl/registration/CPCEmbree.cpp:18-44), closest-point correspondences (`type: CP`):
  * for every dataset point Pm = Tsm * d_i the nearest surface point of the map; model buffers (sized like the
  * dataset) receive hits = (distance <= params.max_dist), points = Tms * p_closest, normals = Tms.R * n_face

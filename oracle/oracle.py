@@ -59,6 +59,10 @@ class Gaussian1D(C.Structure):
     _fields_ = [("mean", C.c_float), ("sigma", C.c_float), ("n_meas", C.c_uint32)]
 
 
+class Filter1D(C.Structure):
+    _fields_ = [("skip_begin", C.c_uint32), ("skip_end", C.c_uint32), ("increment", C.c_uint32)]
+
+
 class GladiatorConfig(C.Structure):
     _fields_ = [("min_noise_tx", C.c_float), ("min_noise_ty", C.c_float), ("min_noise_tz", C.c_float),
                 ("min_noise_roll", C.c_float), ("min_noise_pitch", C.c_float), ("min_noise_yaw", C.c_float),
@@ -164,6 +168,8 @@ def lib():
     L.orc_closest_point.argtypes = [vp, Vec3, i32, C.POINTER(f32), C.POINTER(Vec3), C.POINTER(u32)]
     L.orc_cpc_find.argtypes = [vp, vp, vp, vp, u32, f32, i32, vp, vp, vp, vp, vp]
     L.orc_pf_motion_update.argtypes = [vp, vp, vp, u32, vp, C.c_double, u32, i32]
+    L.orc_pointcloud2_unpack.argtypes = [vp, u32, u32, u32, u32, u32, u32, u32, u32, Filter1D, Filter1D, f32, f32,
+                                         C.POINTER(u32), C.POINTER(u32), vp, vp, vp, vp, C.POINTER(u32)]
     L.orc_philox4x32_10.argtypes = [vp, vp, vp]
     L.orc_likelihood_stats_compute.restype = LikelihoodStats
     L.orc_likelihood_stats_compute.argtypes = [vp, u32]
@@ -530,3 +536,22 @@ def gladiator_resample(poses, attrs, cfg, seed, step, first=0, count=None):
     lib().orc_gladiator_resample(_p(poses), _p(attrs), len(poses), _p(pn), _p(an), int(first), int(count),
                                  C.byref(cfg), int(seed), int(step))
     return pn, an
+
+
+# ------------------------------------------------------------ wire formats --
+def pointcloud2_unpack(data, width, height, point_step, row_step, off_x, off_y, off_z, datatype=7,
+                       filter_h=(0, 0, 1), filter_w=(0, 0, 1), range_min=0.0, range_max=1e30):
+    """PointCloud2 bytes -> {width, height, dirs, ranges, points, mask, n_valid} (O1Dn model + dataset)."""
+    buf = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data.view(np.uint8).reshape(-1))
+    fh, fw = Filter1D(*filter_h), Filter1D(*filter_w)
+    ow, oh, nv = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    args = [_p(buf), width, height, point_step, row_step, off_x, off_y, off_z, datatype, fh, fw, range_min, range_max]
+    rc = lib().orc_pointcloud2_unpack(*args, C.byref(ow), C.byref(oh), None, None, None, None, C.byref(nv))
+    if rc != 0:
+        raise ValueError("pointcloud2_unpack: rc %d" % rc)
+    n = ow.value * oh.value
+    dirs, pts = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    rng, mask = np.zeros(n, np.float32), np.zeros(n, np.uint8)
+    lib().orc_pointcloud2_unpack(*args, C.byref(ow), C.byref(oh), _p(dirs), _p(rng), _p(pts), _p(mask), C.byref(nv))
+    return {"width": ow.value, "height": oh.value, "dirs": dirs, "ranges": rng, "points": pts, "mask": mask,
+            "n_valid": nv.value}

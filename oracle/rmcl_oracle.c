@@ -1306,3 +1306,53 @@ void orc_gladiator_resample(const orc_transform* poses, const orc_particle_attri
     }
   }
 }
+
+/* ------------------------------------------------------------------------- */
+/* PointCloud2 -> O1Dn model + dataset (conversions.cpp:869-1002 etc.)       */
+/* ------------------------------------------------------------------------- */
+int orc_pointcloud2_unpack(const uint8_t* data, uint32_t width, uint32_t height, uint32_t point_step, uint32_t row_step,
+                           uint32_t off_x, uint32_t off_y, uint32_t off_z, uint32_t datatype, orc_filter1d fh,
+                           orc_filter1d fw, float range_min, float range_max, uint32_t* out_w, uint32_t* out_h,
+                           float* dirs, float* ranges, float* points, uint8_t* mask, uint32_t* n_valid)
+{
+  if (datatype != 7u && datatype != 8u) return -1;     /* "Field X has unknown DataType" */
+  if (fh.increment == 0 || fw.increment == 0) return -2;
+  if (fw.skip_begin + fw.skip_end > width || fh.skip_begin + fh.skip_end > height) return -2;
+  const uint32_t ow = (width - fw.skip_begin - fw.skip_end) / fw.increment;
+  const uint32_t oh = (height - fh.skip_begin - fh.skip_end) / fh.increment;
+  *out_w = ow; *out_h = oh;
+  uint32_t nv = 0;
+  if (!dirs) { if (n_valid) *n_valid = 0; return 0; }  /* size query */
+  for (uint32_t ti = 0; ti < oh; ++ti) {
+    const size_t si = (size_t)ti * fh.increment + fh.skip_begin;
+    for (uint32_t tj = 0; tj < ow; ++tj) {
+      const size_t sj = (size_t)tj * fw.increment + fw.skip_begin;
+      const uint8_t* ptr = data + si * row_step + sj * point_step;
+      float x, y, z;
+      if (datatype == 7u) {
+        memcpy(&x, ptr + off_x, 4); memcpy(&y, ptr + off_y, 4); memcpy(&z, ptr + off_z, 4);
+      } else {
+        double dx, dy, dz;
+        memcpy(&dx, ptr + off_x, 8); memcpy(&dy, ptr + off_y, 8); memcpy(&dz, ptr + off_z, 8);
+        x = (float)dx; y = (float)dy; z = (float)dz;
+      }
+      const size_t id = (size_t)ti * ow + tj;
+      float range; orc_vec3 d;
+      if (isfinite(x) && isfinite(y) && isfinite(z)) {
+        range = sqrtf((x * x + y * y) + z * z);
+        d = v3(x / range, y / range, z / range);
+      } else {
+        range = 0.0f; d = v3(0, 0, 0);
+      }
+      dirs[3 * id] = d.x; dirs[3 * id + 1] = d.y; dirs[3 * id + 2] = d.z;
+      ranges[id] = range;
+      /* unpackMessage: real_point = dir * range + orig (orig = 0 for a cloud in its own frame) */
+      points[3 * id] = d.x * range + 0.0f; points[3 * id + 1] = d.y * range + 0.0f; points[3 * id + 2] = d.z * range + 0.0f;
+      const int out = (range < range_min) || (range > range_max);
+      mask[id] = out ? 0 : 1;
+      if (!out) ++nv;
+    }
+  }
+  if (n_valid) *n_valid = nv;
+  return 0;
+}

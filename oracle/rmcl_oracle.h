@@ -193,6 +193,18 @@ void orc_gladiator_resample(const orc_transform* poses, const orc_particle_attri
                             orc_transform* poses_new, orc_particle_attributes* attrs_new, uint32_t first,
                             uint32_t count, const orc_gladiator_config* cfg, uint64_t seed, uint32_t step);
 
+/* ---- PointCloud2 wire format -> O1Dn model + dataset --------------------------------------------------
+ * estimateModelAndData (rmcl_ros/src/util/conversions.cpp:869-1002: per point range = |p|, dir = p / range;
+ * non-finite -> dir 0, range 0) + filter (scan_operations.cpp:41-116: skip_begin / skip_end / increment
+ * sub-sampling of rows and columns) + MICPO1DnSensorCPU::unpackMessage (MICPO1DnSensorCPU.cpp:176-227:
+ * point = dir * range + orig, mask = range within [range_min, range_max]).  datatype: 7 = FLOAT32, 8 = FLOAT64
+ * (sensor_msgs/PointField).  Outputs have out_w * out_h entries. */
+typedef struct { uint32_t skip_begin, skip_end, increment; } orc_filter1d;
+int orc_pointcloud2_unpack(const uint8_t* data, uint32_t width, uint32_t height, uint32_t point_step, uint32_t row_step,
+                           uint32_t off_x, uint32_t off_y, uint32_t off_z, uint32_t datatype, orc_filter1d fh,
+                           orc_filter1d fw, float range_min, float range_max, uint32_t* out_w, uint32_t* out_h,
+                           float* dirs, float* ranges, float* points, uint8_t* mask, uint32_t* n_valid);
+
 #ifdef __cplusplus
 }
 #endif

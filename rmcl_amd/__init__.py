@@ -3,7 +3,7 @@ pose-correction hot path.  Host-side mirror of the reference's operator interfac
 of librmclhip.so (include/rmclhip.h).  No CPU fallback: importing works anywhere the shared
 library is built, computing needs a HIP device.
 """
-from . import _capi, types, synthetic  # noqa: F401
+from . import _capi, types, synthetic, wire  # noqa: F401
 from ._capi import NoDeviceError, RmclHipError  # noqa: F401
 from .micp import MICPLocalization, MICPSensor  # noqa: F401
 from .pf import (GladiatorResamplerHip, PCDSensorUpdaterHip, TFMotionUpdaterHip, beams_from_points, combined_forget_rate,  # noqa: F401

@@ -47,6 +47,15 @@ class PFParams(C.Structure):
                 ("correspondence_type", C.c_uint32)]
 
 
+class PointCloud2Layout(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("point_step", C.c_uint32), ("row_step", C.c_uint32),
+                ("offset_x", C.c_uint32), ("offset_y", C.c_uint32), ("offset_z", C.c_uint32), ("datatype", C.c_uint32)]
+
+
+class Filter1D(C.Structure):
+    _fields_ = [("skip_begin", C.c_uint32), ("skip_end", C.c_uint32), ("increment", C.c_uint32)]
+
+
 class GladiatorConfig(C.Structure):
     _fields_ = [("min_noise_tx", C.c_float), ("min_noise_ty", C.c_float), ("min_noise_tz", C.c_float),
                 ("min_noise_roll", C.c_float), ("min_noise_pitch", C.c_float), ("min_noise_yaw", C.c_float),
@@ -92,6 +101,9 @@ SIGNATURES = {
     "rmclhip_rcc_find_async": (_i32, [_vp, _vp]),
     "rmclhip_rcc_sync": (_i32, [_vp]),
     "rmclhip_rcc_find_cpc": (_i32, [_vp, _vp]),
+    "rmclhip_rcc_set_input_pointcloud2": (_i32, [_vp, _vp, _sz, C.POINTER(PointCloud2Layout), C.POINTER(Filter1D),
+                                                  C.POINTER(Filter1D), Interval, _i32, C.POINTER(_u32),
+                                                  C.POINTER(_u32), C.POINTER(_u32)]),
     "rmclhip_rcc_compute_cross_statistics": (_i32, [_vp, _vp, _dbl, _vp]),
     "rmclhip_rcc_download": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "rmclhip_rcc_device_views": (_i32, [_vp, _pp, _pp, _pp, _pp, _pp, C.POINTER(_u32)]),

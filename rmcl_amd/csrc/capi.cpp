@@ -3,6 +3,7 @@
 // path here: without a HIP device every compute entry point fails with RMCLHIP_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -153,6 +154,7 @@ struct rmclhip_rcc {
   size_t tickets_cap = 0;
   bool fused_tail = false;         // true: last-block tail inside the reduction kernel (measured slower, A/B only)
   // batch
+  DevBuf<uint8_t> d_raw;           // staged PointCloud2 bytes (set_input_pointcloud2)
   DevBuf<xform> d_Tbm, d_Tsm, d_Tms, d_Tdelta;
   DevBuf<cstats> d_bstats;
   int variant = 1;        // traversal kind: 0 wave-packet, 1 per-lane while-while (default: measured faster on
@@ -355,6 +357,7 @@ void rmclhip_rcc_destroy(rmclhip_rcc* r) {
   r->d_hits.release(); r->d_ranges.release(); r->d_points.release(); r->d_normals.release(); r->d_face_ids.release();
   r->d_partials.release(); r->d_Tbm.release(); r->d_Tsm.release(); r->d_Tms.release(); r->d_Tdelta.release();
   r->d_bstats.release();
+  r->d_raw.release();
   DBG_STEP(hipPeekAtLastError());
   if (r->h_stats) DBG_STEP(hipHostFree(r->h_stats));
   if (r->h_state) DBG_STEP(hipHostFree(r->h_state));
@@ -518,6 +521,63 @@ rmclhip_status rmclhip_rcc_set_dataset_from_ranges(rmclhip_rcc* r, const float* 
   if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
   d_r.release();
   if (e != hipSuccess) return fail(RMCLHIP_ERR_HIP, std::string("dataset_from_ranges: ") + hipGetErrorString(e));
+  if (n_valid_out) *n_valid_out = nv;
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_set_input_pointcloud2(rmclhip_rcc* r, const uint8_t* data, size_t nbytes,
+                                                 const rmclhip_pointcloud2_layout* L, const rmclhip_filter1d* fh,
+                                                 const rmclhip_filter1d* fw, rmclhip_interval range, int src_is_device,
+                                                 uint32_t* out_width, uint32_t* out_height, uint32_t* n_valid_out) {
+  ApiGuard guard_("rmclhip_rcc_set_input_pointcloud2");
+  if (!r || !L) return fail(RMCLHIP_ERR_INVALID, "rcc_set_input_pointcloud2: null");
+  if (L->datatype != 7u && L->datatype != 8u)
+    return fail(RMCLHIP_ERR_UNSUPPORTED, "rcc_set_input_pointcloud2: Field X has unknown DataType (FLOAT32 / FLOAT64 only)");
+  const rmclhip_filter1d none{0u, 0u, 1u};
+  const rmclhip_filter1d h = fh ? *fh : none, w = fw ? *fw : none;
+  if (h.increment == 0u || w.increment == 0u || static_cast<uint64_t>(h.skip_begin) + h.skip_end > L->height ||
+      static_cast<uint64_t>(w.skip_begin) + w.skip_end > L->width)
+    return fail(RMCLHIP_ERR_INVALID, "rcc_set_input_pointcloud2: bad filter options");
+  const uint32_t ow = (L->width - w.skip_begin - w.skip_end) / w.increment;
+  const uint32_t oh = (L->height - h.skip_begin - h.skip_end) / h.increment;
+  const size_t n = static_cast<size_t>(ow) * oh;
+  const uint32_t fsz = (L->datatype == 8u) ? 8u : 4u;
+  if (n) {
+    if (!data) return fail(RMCLHIP_ERR_INVALID, "rcc_set_input_pointcloud2: data is null");
+    const uint32_t max_off = std::max(L->offset_x, std::max(L->offset_y, L->offset_z));
+    const uint64_t last = static_cast<uint64_t>((oh - 1u) * h.increment + h.skip_begin) * L->row_step +
+                          static_cast<uint64_t>((ow - 1u) * w.increment + w.skip_begin) * L->point_step + max_off + fsz;
+    if (last > nbytes) return fail(RMCLHIP_ERR_INVALID, "rcc_set_input_pointcloud2: cloud data shorter than its layout");
+  }
+  HIPCHK(hipSetDevice(r->ctx->device));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  r->kind = kModelO1Dn;
+  r->graph_dirty = true;
+  r->W = ow; r->H = oh;
+  r->range = range;
+  r->orig = mk3(0.f, 0.f, 0.f);
+  r->n_dataset = static_cast<uint32_t>(n);
+  r->ds_has_mask = true;
+  if (out_width) *out_width = ow;
+  if (out_height) *out_height = oh;
+  if (n_valid_out) *n_valid_out = 0;
+  if (n == 0) return RMCLHIP_OK;
+  HIPCHK(r->d_model_tab.reserve(3 * n));
+  HIPCHK(r->d_ds_points.reserve(3 * n));
+  HIPCHK(r->d_ds_mask.reserve(n));
+  const uint8_t* d_data = data;
+  if (!src_is_device) {
+    HIPCHK(r->d_raw.reserve(nbytes));
+    HIPCHK(hipMemcpyAsync(r->d_raw.p, data, nbytes, hipMemcpyHostToDevice, r->stream));
+    d_data = r->d_raw.p;
+  }
+  HIPCHK(hipMemsetAsync(r->d_counter, 0, sizeof(uint32_t), r->stream));
+  HIPCHK(launch_pointcloud2_unpack(d_data, L->point_step, L->row_step, L->offset_x, L->offset_y, L->offset_z, L->datatype == 8u,
+                                   h.skip_begin, h.increment, w.skip_begin, w.increment, ow, oh, range.min, range.max,
+                                   r->d_model_tab.p, r->d_ds_points.p, r->d_ds_mask.p, r->d_counter, r->stream));
+  uint32_t nv = 0;
+  HIPCHK(hipMemcpyAsync(&nv, r->d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+  HIPCHK(hipStreamSynchronize(r->stream));
   if (n_valid_out) *n_valid_out = nv;
   return RMCLHIP_OK;
 }

@@ -789,6 +789,46 @@ __global__ void k_dataset_from_ranges(const float* __restrict__ ranges, const fl
   if (!out_of_range) atomicAdd(n_valid, 1u);
 }
 
+// sensor_msgs/PointCloud2 bytes -> O1Dn model (dirs) + dataset (points, mask) in one pass:
+// estimateModelAndData (conversions.cpp:869-1002) + filter (scan_operations.cpp:41-116) + MICPO1DnSensorCPU::unpackMessage
+struct Pc2Params {
+  const uint8_t* data;
+  uint32_t point_step, row_step, off_x, off_y, off_z, is_f64;
+  uint32_t h_skip, h_inc, w_skip, w_inc;
+  uint32_t out_w, out_h;
+  float range_min, range_max;
+  float* dirs;
+  float* points;
+  uint8_t* mask;
+  uint32_t* n_valid;
+};
+
+__device__ __forceinline__ float pc2_load(const uint8_t* p, bool f64) {
+  if (f64) { double d; __builtin_memcpy(&d, p, 8); return static_cast<float>(d); }
+  float f; __builtin_memcpy(&f, p, 4); return f;
+}
+
+__global__ void __launch_bounds__(256) k_pointcloud2_unpack(const Pc2Params p) {
+  const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= p.out_w * p.out_h) return;
+  const uint32_t ti = id / p.out_w, tj = id - ti * p.out_w;
+  const size_t si = static_cast<size_t>(ti) * p.h_inc + p.h_skip, sj = static_cast<size_t>(tj) * p.w_inc + p.w_skip;
+  const uint8_t* ptr = p.data + si * p.row_step + sj * p.point_step;
+  const float x = pc2_load(ptr + p.off_x, p.is_f64), y = pc2_load(ptr + p.off_y, p.is_f64), z = pc2_load(ptr + p.off_z, p.is_f64);
+  const bool fin = (fabsf(x) <= 3.402823466e38f) && (fabsf(y) <= 3.402823466e38f) && (fabsf(z) <= 3.402823466e38f);
+  float range = 0.0f;
+  f3 d = mk3(0.f, 0.f, 0.f);
+  if (fin) {
+    range = sqrtf((x * x + y * y) + z * z);
+    d = mk3(x / range, y / range, z / range);
+  }
+  p.dirs[3u * id] = d.x; p.dirs[3u * id + 1u] = d.y; p.dirs[3u * id + 2u] = d.z;
+  p.points[3u * id] = d.x * range + 0.0f; p.points[3u * id + 1u] = d.y * range + 0.0f; p.points[3u * id + 2u] = d.z * range + 0.0f;
+  const bool out_of_range = (range < p.range_min) || (range > p.range_max);
+  p.mask[id] = out_of_range ? 0 : 1;
+  if (!out_of_range) atomicAdd(p.n_valid, 1u);
+}
+
 // ---------------------------------------------------------------------------------------------
 // particle filter: all beams of all particles in one launch
 // ---------------------------------------------------------------------------------------------
@@ -1225,6 +1265,19 @@ hipError_t launch_likelihood_stats(const void* attrs, uint32_t n, double* psum, 
   hipLaunchKernelGGL(k_likelihood_stats_partial, dim3(nblocks), dim3(256), 0, s, reinterpret_cast<const pattrs*>(attrs), n,
                      psum, pmax);
   hipLaunchKernelGGL(k_likelihood_stats_final, dim3(1), dim3(64), 0, s, psum, pmax, nblocks, out2);
+  return hipGetLastError();
+}
+
+hipError_t launch_pointcloud2_unpack(const uint8_t* data, uint32_t point_step, uint32_t row_step, uint32_t off_x,
+                                     uint32_t off_y, uint32_t off_z, bool is_f64, uint32_t h_skip, uint32_t h_inc,
+                                     uint32_t w_skip, uint32_t w_inc, uint32_t out_w, uint32_t out_h, float range_min,
+                                     float range_max, float* dirs, float* points, uint8_t* mask, uint32_t* n_valid,
+                                     hipStream_t s) {
+  const uint32_t n = out_w * out_h;
+  if (n == 0) return hipSuccess;
+  Pc2Params p{data, point_step, row_step, off_x, off_y, off_z, is_f64 ? 1u : 0u, h_skip, h_inc, w_skip, w_inc,
+              out_w, out_h, range_min, range_max, dirs, points, mask, n_valid};
+  hipLaunchKernelGGL(k_pointcloud2_unpack, dim3((n + 255u) / 256u), dim3(256), 0, s, p);
   return hipGetLastError();
 }
 

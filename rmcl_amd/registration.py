@@ -333,6 +333,32 @@ class RCCHipO1Dn(CorrespondencesHIP):
         _capi.check(_capi.lib().rmclhip_rcc_set_model_o1dn(self._h, int(width), int(height), rng, o, _ptr(d)))
         self._model_shape = (int(height), int(width))
 
+    def setInputPointCloud2(self, data, width, height, point_step, row_step, offset_x, offset_y, offset_z,
+                            datatype=7, range_min=0.0, range_max=1e30, filter_height=None, filter_width=None,
+                            device=False, nbytes=None):
+        """A sensor_msgs/PointCloud2 as received (bytes / uint8 array, or a device pointer with device=True and
+        nbytes) becomes the O1Dn model and the dataset in one device pass: estimateModelAndData
+        (conversions.cpp:869-1002) + filter (scan_operations.cpp:41-116) + MICPO1DnSensorCPU::unpackMessage.
+        filter_*: (skip_begin, skip_end, increment) or None.  Returns (width, height, n_valid) after filtering."""
+        L = _capi.PointCloud2Layout(int(width), int(height), int(point_step), int(row_step), int(offset_x),
+                                    int(offset_y), int(offset_z), int(datatype))
+        fh = _capi.Filter1D(*filter_height) if filter_height is not None else None
+        fw = _capi.Filter1D(*filter_width) if filter_width is not None else None
+        if device:
+            ptr, nb = _as_ptr(data), int(nbytes)
+        else:
+            buf = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8)) if isinstance(data, (bytes, bytearray, memoryview)) \
+                else np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+            ptr, nb = _ptr(buf), buf.size
+        ow, oh, nv = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        _capi.check(_capi.lib().rmclhip_rcc_set_input_pointcloud2(
+            self._h, ptr, nb, C.byref(L), C.byref(fh) if fh is not None else None,
+            C.byref(fw) if fw is not None else None, _capi.Interval(range_min, range_max), int(bool(device)),
+            C.byref(ow), C.byref(oh), C.byref(nv)))
+        self._model_shape = (oh.value, ow.value)
+        self.outdated = True
+        return ow.value, oh.value, nv.value
+
 
 class RCCHipPinhole(CorrespondencesHIP):
     """rmcl::RCCEmbreePinhole / RCCOptixPinhole on gfx950 (RCCEmbree.cpp:39-68): depth camera."""
