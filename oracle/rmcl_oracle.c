@@ -1356,3 +1356,60 @@ int orc_pointcloud2_unpack(const uint8_t* data, uint32_t width, uint32_t height,
   if (n_valid) *n_valid = nv;
   return 0;
 }
+
+int orc_trace_bvh4_ordered(const uint32_t* nodes, const uint32_t* tris, orc_vec3 O, orc_vec3 D, float tnear, float tfar,
+                           int mode, uint64_t counters[5], float* t_out, uint32_t* face_out)
+{
+  const float o[3] = {O.x, O.y, O.z};
+  const float inv[3] = {safe_inv(D.x), safe_inv(D.y), safe_inv(D.z)};
+  float best_t = tfar; uint32_t best_f = 0xFFFFFFFFu; int found = 0;
+  uint32_t stack[256]; float stack_t[256]; int sp = 0;
+  uint32_t cur = 0; int have = 1;
+  while (have) {
+    if (!(cur & 0x80000000u)) {
+      counters[0]++;
+      const float* nd = (const float*)(nodes + 32u * cur);
+      const uint32_t* ch = nodes + 32u * cur + 24u;
+      float key[4]; uint32_t ref[4]; int nh = 0;
+      for (uint32_t c = 0; c < 4; ++c) {
+        orc_node bx;
+        bx.bmin[0] = nd[0 + 2 * c]; bx.bmax[0] = nd[1 + 2 * c];
+        bx.bmin[1] = nd[8 + 2 * c]; bx.bmax[1] = nd[9 + 2 * c];
+        bx.bmin[2] = nd[16 + 2 * c]; bx.bmax[2] = nd[17 + 2 * c];
+        float tn;
+        if (bx.bmin[0] < 1e29f && box_hit(&bx, o, inv, tnear, best_t, &tn)) { key[nh] = tn; ref[nh] = ch[c]; nh++; }
+      }
+      if (nh == 0) counters[1]++;
+      /* nearest first; deferred ones sorted (mode bit1) or in slot order */
+      for (int i = 0; i < nh; ++i) for (int j = i + 1; j < nh; ++j)
+        if (key[j] < key[i] && (i == 0 || (mode & 2))) { float tk = key[i]; key[i] = key[j]; key[j] = tk; uint32_t tr = ref[i]; ref[i] = ref[j]; ref[j] = tr; }
+      for (int i = nh - 1; i >= 1; --i) { stack[sp] = ref[i]; stack_t[sp] = key[i]; sp++; }
+      if (sp > (int)counters[4]) counters[4] = (uint64_t)sp;
+      if (nh > 0) { cur = ref[0]; continue; }
+    } else {
+      counters[2]++;
+      const uint32_t first = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
+      for (uint32_t i = 0; i < cnt; ++i) {
+        counters[3]++;
+        const float* r = (const float*)(tris + 16u * (first + i));
+        orc_tri T;
+        T.v0 = v3(r[0], r[1], r[2]); T.e1 = v3(r[3], r[4], r[5]); T.e2 = v3(r[6], r[7], r[8]);
+        T.Ng = v3(r[9], r[10], r[11]); T.n = v3(r[12], r[13], r[14]);
+        const uint32_t f = tris[16u * (first + i) + 15u];
+        float t;
+        if (tri_intersect(&T, O, D, tnear, tfar, &t)) {
+          if (!found || t < best_t || (t == best_t && f < best_f)) { best_t = t; best_f = f; found = 1; }
+        }
+      }
+    }
+    /* pop */
+    have = 0;
+    while (sp > 0) {
+      --sp;
+      if ((mode & 1) && stack_t[sp] > best_t) continue;
+      cur = stack[sp]; have = 1; break;
+    }
+  }
+  if (found) { *t_out = best_t; *face_out = best_f; }
+  return found;
+}

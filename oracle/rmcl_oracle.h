@@ -193,6 +193,13 @@ void orc_gladiator_resample(const orc_transform* poses, const orc_particle_attri
                             orc_transform* poses_new, orc_particle_attributes* attrs_new, uint32_t first,
                             uint32_t count, const orc_gladiator_config* cfg, uint64_t seed, uint32_t step);
 
+/* instrumented walk of the PRODUCT's BVH4 in the product's traversal order (nearest child first, deferred
+ * children on a stack): counts inner-node visits, visits whose four children all fail, leaf visits, triangle
+ * tests and the stack high-water mark.  mode bit0: cull popped entries with their stored entry distance;
+ * bit1: fully sort the deferred children.  BVH-quality / traversal-policy measurements only. */
+int orc_trace_bvh4_ordered(const uint32_t* nodes, const uint32_t* tris, orc_vec3 O, orc_vec3 D, float tnear, float tfar,
+                           int mode, uint64_t counters[5], float* t_out, uint32_t* face_out);
+
 /* ---- PointCloud2 wire format -> O1Dn model + dataset --------------------------------------------------
  * estimateModelAndData (rmcl_ros/src/util/conversions.cpp:869-1002: per point range = |p|, dir = p / range;
  * non-finite -> dir 0, range 0) + filter (scan_operations.cpp:41-116: skip_begin / skip_end / increment

@@ -157,8 +157,9 @@ struct rmclhip_rcc {
   DevBuf<uint8_t> d_raw;           // staged PointCloud2 bytes (set_input_pointcloud2)
   DevBuf<xform> d_Tbm, d_Tsm, d_Tms, d_Tdelta;
   DevBuf<cstats> d_bstats;
-  int variant = 1;        // traversal kind: 0 wave-packet, 1 per-lane while-while (default: measured faster on
-                          // occluded scenes and single scans; the packet wins only on smooth pose batches)
+  int variant = 15;       // traversal kind: 0 wave-packet, 1 one lane per ray (while-while), 2 four lanes per ray
+                          // (quad-cooperative), 15 automatic: quad while the launch is bound by the slowest ray's
+                          // chain of dependent fetches (few rays in flight), one lane per ray once the chip is full
   int tile_override = 0;  // 1 + log2(tile width), 0 = automatic
   float last_find_ms = 0.f, last_reduce_ms = 0.f;
 };
@@ -600,6 +601,14 @@ static rmclhip_status ensure_model_buffers(rmclhip_rcc* r, size_t n_total) {
   return RMCLHIP_OK;
 }
 
+// traversal kind of a launch of `nposes` scans (tools/latency_explore.py: the quad traversal wins up to ~64 k rays
+// in flight, above that four lanes per ray cost more issue slots than the shorter chains save)
+static int find_variant(const rmclhip_rcc* r, uint32_t nposes) {
+  if (r->variant != 15) return r->variant;
+  const uint64_t rays = static_cast<uint64_t>(r->W) * r->H * nposes;
+  return (rays <= 65536u) ? 2 : 1;
+}
+
 static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
   std::memset(&p, 0, sizeof(p));
   p.nodes = r->map->d_nodes;
@@ -627,7 +636,7 @@ static rmclhip_status find_enqueue(rmclhip_rcc* r, const xform& Tbm) {
   fill_find_params(r, p, 1);
   p.Tsm = xmul(Tbm, r->Tsb);
   p.Tms = xinv(p.Tsm);
-  HIPCHK(launch_find(p, r->kind, r->variant, r->stream));
+  HIPCHK(launch_find(p, r->kind, find_variant(r, p.nposes), r->stream));
   return RMCLHIP_OK;
 }
 
@@ -831,7 +840,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
       fill_find_params(r, p, 1);
       p.Tsm_arr = &r->d_call->Tsm;
       p.Tms_arr = &r->d_call->Tms;
-      HIPCHK(launch_find(p, r->kind, r->variant, r->stream));
+      HIPCHK(launch_find(p, r->kind, find_variant(r, p.nposes), r->stream));
       HIPCHK(launch_micp_init(r->d_state, r->stream));
       for (uint32_t i = 0; i < n_iter; ++i) {
         ReduceTail tail;
@@ -974,7 +983,7 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
   ApiGuard guard_("rmclhip_rcc_set_variant");
   if (!r || variant < 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: bad arguments");
   const int kind = variant & 0xF, tile = (variant >> 4) & 0xF;
-  if (kind > 1 || tile > 7 || (variant >> 10) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
+  if ((kind > 2 && kind != 15) || tile > 7 || (variant >> 10) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
   r->variant = kind;
   r->tile_override = tile;
   r->fused_tail = ((variant >> 8) & 1) != 0;
@@ -996,7 +1005,7 @@ static rmclhip_status find_batch_enqueue(rmclhip_rcc* r, const rmclhip_transform
   fill_find_params(r, p, nposes);
   p.Tsm_arr = r->d_Tsm.p;
   p.Tms_arr = r->d_Tms.p;
-  HIPCHK(launch_find(p, r->kind, r->variant, r->stream));
+  HIPCHK(launch_find(p, r->kind, find_variant(r, p.nposes), r->stream));
   return RMCLHIP_OK;
 }
 
@@ -1023,7 +1032,7 @@ rmclhip_status rmclhip_rcc_time_find_batch(rmclhip_rcc* r, const rmclhip_transfo
   p.Tsm_arr = r->d_Tsm.p;
   p.Tms_arr = r->d_Tms.p;
   HIPCHK(hipEventRecord(r->ev0, r->stream));
-  for (uint32_t i = 0; i < iters; ++i) HIPCHK(launch_find(p, r->kind, r->variant, r->stream));
+  for (uint32_t i = 0; i < iters; ++i) HIPCHK(launch_find(p, r->kind, find_variant(r, p.nposes), r->stream));
   HIPCHK(hipEventRecord(r->ev1, r->stream));
   HIPCHK(hipStreamSynchronize(r->stream));
   float total = 0.f;

@@ -312,6 +312,113 @@ __device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes
 }
 
 // ---------------------------------------------------------------------------------------------
+// quad-cooperative traversal: FOUR lanes per ray, lane c of the quad owns child slot c of the current node and
+// triangle c of the current leaf (leaves hold <= 4 triangles).  A single scan is bound by the slowest ray's chain
+// of dependent node fetches (tools/latency_explore.py: one wave alone takes 2/3 of the full scan's time), so the
+// work of one step is spread over four lanes: one slab test instead of four, a rank computation over DPP
+// quad_perm instead of a sorting network, up to four triangle tests at once.  The quad's stack (64 entries, the
+// builder's bound) lives in LDS.  Same acceptance rules and tie-break as trace_lane_ww: identical results.
+// ---------------------------------------------------------------------------------------------
+template <int kCtrl>
+__device__ __forceinline__ uint32_t quad_dpp(uint32_t v) {
+  return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), kCtrl, 0xF, 0xF, true));
+}
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kQuadXor3 = 0x1B;  // quad_perm [1,0,3,2] [2,3,0,1] [3,2,1,0]
+
+__device__ __forceinline__ void trace_quad(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris, f3 O,
+                                           f3 D, float ray_tfar, uint32_t c, uint32_t ray, uint32_t* __restrict__ lds,
+                                           RayHit& h) {
+  const f3 inv = mk3(safe_inv(D.x), safe_inv(D.y), safe_inv(D.z));
+  const f3 noi = mk3(-(O.x * inv.x), -(O.y * inv.y), -(O.z * inv.z));
+  float best_t = ray_tfar;
+  uint32_t best_face = kInvalidFace, best_rec = 0;
+  constexpr uint32_t kDone = 0x7FFFFFFFu;
+  uint32_t sp = 0;
+  uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
+  // stack entry e of ray r sits at e*64 + ((r + e) & 63): the <= 3 pushes of one quad and the pops of the 16 rays
+  // of a wave fall into distinct LDS banks
+#define RMCL_QSLOT(e) (((e) << 6) + ((ray + (e)) & 63u))
+  while (__any(cur != kDone)) {
+    while ((cur != kDone) && !(cur & kLeafBit)) {
+      const uint32_t* nd = nodes + static_cast<size_t>(cur) * kNodeDwords;
+      const f2 px = *reinterpret_cast<const f2*>(nd + 2u * c);
+      const f2 py = *reinterpret_cast<const f2*>(nd + 8u + 2u * c);
+      const f2 pz = *reinterpret_cast<const f2*>(nd + 16u + 2u * c);
+      const uint32_t ref = nd[24u + c];
+      float tn, tf;
+      slab(px, py, pz, inv, noi, best_t, tn, tf);
+      const uint32_t hit = (tn <= tf) ? 1u : 0u;  // unused slots hold an unreachable box (layout.h)
+      // unique keys: entry distance with the slot number in the two low mantissa bits; misses sort last
+      const uint32_t key = (hit ? (__float_as_uint(tn) & ~3u) : 0xFFFFFFFCu) | c;
+      const uint32_t k1 = quad_dpp<kQuadXor1>(key), k2 = quad_dpp<kQuadXor2>(key), k3 = quad_dpp<kQuadXor3>(key);
+      const uint32_t rank = (k1 < key ? 1u : 0u) + (k2 < key ? 1u : 0u) + (k3 < key ? 1u : 0u);
+      const uint32_t h1 = hit + quad_dpp<kQuadXor1>(hit);
+      const uint32_t nh = h1 + quad_dpp<kQuadXor2>(h1);
+      const uint32_t sel = (hit && rank == 0u) ? ref : 0u;
+      const uint32_t s1 = sel | quad_dpp<kQuadXor1>(sel);
+      const uint32_t nearest = s1 | quad_dpp<kQuadXor2>(s1);
+      if (hit && rank != 0u) {
+        const uint32_t e = sp + (nh - 1u - rank);  // second nearest on top
+        lds[RMCL_QSLOT(e)] = ref;
+      }
+      if (nh != 0u) {
+        sp += nh - 1u;
+        cur = nearest;
+      } else if (sp == 0u) {
+        cur = kDone;
+      } else {
+        --sp;
+        cur = lds[RMCL_QSLOT(sp)];
+      }
+    }
+    if (cur != kDone) {
+      const uint32_t first = cur & 0x0FFFFFFFu;
+      const uint32_t cnt = ((cur >> 28) & 7u) + 1u;  // <= kMaxLeafTris = 4
+      const uint32_t idx = first + ((c < cnt) ? c : (cnt - 1u));
+      const uint4* tp = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(idx) * 4u;
+      const uint4 a = tp[0], b = tp[1], cc = tp[2], d = tp[3];
+      const f3 v0 = mk3(asf(a.x), asf(a.y), asf(a.z));
+      const f3 e1 = mk3(asf(a.w), asf(b.x), asf(b.y));
+      const f3 e2 = mk3(asf(b.z), asf(b.w), asf(cc.x));
+      const f3 Ng = mk3(asf(cc.y), asf(cc.z), asf(cc.w));
+      float Tt, aden;
+      const bool ok = tri_accept(v0, e1, e2, Ng, O, D, Tt, aden);
+      const float t = Tt / aden;
+      const bool acc = ok && (c < cnt) && (t >= 0.0f) && (t <= ray_tfar);
+      // quad minimum of (t, face): candidates that fail carry (+inf, invalid face) and never win
+      float ct = acc ? t : __builtin_inff();
+      uint32_t cf = acc ? d.w : kInvalidFace, cr = idx;
+      {
+        const float ot = __uint_as_float(quad_dpp<kQuadXor1>(__float_as_uint(ct)));
+        const uint32_t of = quad_dpp<kQuadXor1>(cf), orr = quad_dpp<kQuadXor1>(cr);
+        const bool take = (ot < ct) || ((ot == ct) && (of < cf));
+        ct = take ? ot : ct; cf = take ? of : cf; cr = take ? orr : cr;
+      }
+      {
+        const float ot = __uint_as_float(quad_dpp<kQuadXor2>(__float_as_uint(ct)));
+        const uint32_t of = quad_dpp<kQuadXor2>(cf), orr = quad_dpp<kQuadXor2>(cr);
+        const bool take = (ot < ct) || ((ot == ct) && (of < cf));
+        ct = take ? ot : ct; cf = take ? of : cf; cr = take ? orr : cr;
+      }
+      const bool closer = (cf != kInvalidFace) && ((ct < best_t) || ((ct == best_t) && (cf < best_face)));
+      best_t = closer ? ct : best_t;
+      best_face = closer ? cf : best_face;
+      best_rec = closer ? cr : best_rec;
+      if (sp == 0u) {
+        cur = kDone;
+      } else {
+        --sp;
+        cur = lds[RMCL_QSLOT(sp)];
+      }
+    }
+  }
+#undef RMCL_QSLOT
+  h.t = best_t;
+  h.face = best_face;
+  h.rec = best_rec;
+}
+
+// ---------------------------------------------------------------------------------------------
 // closest-point query (CPCEmbree::find -> rm::EmbreeMap::closestPoint): per-lane while-while traversal ordered
 // by box distance, closest point on triangle = Embree closest_point tutorial / Ericson RTCD 5.1.5, in the exact
 // operation order of oracle/rmcl_oracle.c:closest_point_triangle (a = v0, ab = -e1, ac = e2, b = a+ab, c = a+ac).
@@ -473,15 +580,19 @@ __device__ __forceinline__ f3 pinhole_direction(float fx, float fy, float cx, fl
 // ---------------------------------------------------------------------------------------------
 // find
 // ---------------------------------------------------------------------------------------------
-template <uint32_t kModel, bool kPacket>
+// kTrav: 0 = wave packet, 1 = one lane per ray (while-while), 2 = four lanes per ray (quad-cooperative; the block
+// of 256 threads then covers ONE 64-ray tile instead of four)
+template <uint32_t kModel, int kTrav>
 __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   extern __shared__ uint32_t lds_dyn[];
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  constexpr bool kPacket = (kTrav == 0), kQuad = (kTrav == 2);
+  const uint32_t lane = kQuad ? (threadIdx.x >> 2) : (threadIdx.x & 63u), wave = threadIdx.x >> 6;
+  const uint32_t sub = threadIdx.x & 3u;  // quad mode: child slot / triangle slot / output role of this lane
   // XCD-aware remap: the dispatcher places block b on XCD b%8; give every XCD a contiguous range of
   // tiles so neighbouring tiles (which walk the same subtrees) share one L2.  gridDim.x % 8 == 0.
   const uint32_t chunk = gridDim.x >> 3;
   const uint32_t vb = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
-  const uint32_t tile = vb * 4u + wave;
+  const uint32_t tile = kQuad ? vb : (vb * 4u + wave);
   const uint32_t ntiles = p.tiles_x * p.tiles_y;
   if (tile >= ntiles) return;
   const uint32_t pose = blockIdx.y;
@@ -525,6 +636,8 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   RayHit h;
   if (kPacket) {
     trace_packet((cu32p)(p.nodes), (cu32p)(p.tris), org_m, dir_m, ray_tfar, lane, h);
+  } else if (kQuad) {
+    trace_quad(p.nodes, p.tris, org_m, dir_m, ray_tfar, sub, lane, lds_dyn, h);
   } else {
     trace_lane_ww<16>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
   }
@@ -532,28 +645,31 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   if (!valid) return;
   const size_t g = static_cast<size_t>(pose) * p.W * p.H + loc;
   const bool found = (h.face != kInvalidFace);
+  // quad mode: the four lanes of a ray hold the same result and share the stores (0: hits/ranges/face ids, 1: points,
+  // 2: normals)
+  const bool w0 = !kQuad || sub == 0u, w1 = !kQuad || sub == 1u, w2 = !kQuad || sub == 2u;
   if (found) {
-    if (p.hits) p.hits[g] = 1;
-    if (p.ranges) p.ranges[g] = h.t;
-    if (p.points) {
+    if (p.hits && w0) p.hits[g] = 1;
+    if (p.ranges && w0) p.ranges[g] = h.t;
+    if (p.points && w1) {
       f3 pt = scale3(dir_s, h.t);
       if (kModel == kModelO1Dn || kModel == kModelOnDn) pt = add3(pt, orig_s);
       p.points[3 * g] = pt.x; p.points[3 * g + 1] = pt.y; p.points[3 * g + 2] = pt.z;
     }
-    if (p.normals) {
+    if (p.normals && w2) {
       const uint4 nrec = reinterpret_cast<const uint4*>(p.tris)[static_cast<size_t>(h.rec) * 4u + 3u];
       f3 n = qrot(Tms.R, mk3(asf(nrec.x), asf(nrec.y), asf(nrec.z)));
       if (dot_plain(dir_s, n) > 0.0f) n = neg3(n);  // flip towards the sensor
       p.normals[3 * g] = n.x; p.normals[3 * g + 1] = n.y; p.normals[3 * g + 2] = n.z;
     }
-    if (p.face_ids) p.face_ids[g] = h.face;
+    if (p.face_ids && w0) p.face_ids[g] = h.face;
   } else {
     const float qn = __uint_as_float(0x7FC00000u);
-    if (p.hits) p.hits[g] = 0;
-    if (p.ranges) p.ranges[g] = p.tfar + 1.0f;
-    if (p.points) { p.points[3 * g] = qn; p.points[3 * g + 1] = qn; p.points[3 * g + 2] = qn; }
-    if (p.normals) { p.normals[3 * g] = qn; p.normals[3 * g + 1] = qn; p.normals[3 * g + 2] = qn; }
-    if (p.face_ids) p.face_ids[g] = kInvalidFace;
+    if (p.hits && w0) p.hits[g] = 0;
+    if (p.ranges && w0) p.ranges[g] = p.tfar + 1.0f;
+    if (p.points && w1) { p.points[3 * g] = qn; p.points[3 * g + 1] = qn; p.points[3 * g + 2] = qn; }
+    if (p.normals && w2) { p.normals[3 * g] = qn; p.normals[3 * g + 1] = qn; p.normals[3 * g + 2] = qn; }
+    if (p.face_ids && w0) p.face_ids[g] = kInvalidFace;
   }
 }
 
@@ -1121,22 +1237,25 @@ __global__ void __launch_bounds__(64) k_likelihood_stats_final(const double* __r
 // ---------------------------------------------------------------------------------------------
 hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStream_t s) {
   const uint32_t ntiles = p.tiles_x * p.tiles_y;
-  uint32_t nblocks = (ntiles + 3u) / 4u;
+  uint32_t nblocks = (variant == 2) ? ntiles : (ntiles + 3u) / 4u;
   nblocks = (nblocks + 7u) & ~7u;  // the XCD remap in k_find needs gridDim.x % 8 == 0
   dim3 grid(nblocks, p.nposes, 1), block(256, 1, 1);
-#define RMCL_LAUNCH_FIND(PACKET, LDS)                                                                          \
-  switch (kind) {                                                                                              \
-    case kModelSpherical: hipLaunchKernelGGL((k_find<kModelSpherical, PACKET>), grid, block, LDS, s, p); break; \
-    case kModelO1Dn: hipLaunchKernelGGL((k_find<kModelO1Dn, PACKET>), grid, block, LDS, s, p); break;           \
-    case kModelPinhole: hipLaunchKernelGGL((k_find<kModelPinhole, PACKET>), grid, block, LDS, s, p); break;     \
-    case kModelOnDn: hipLaunchKernelGGL((k_find<kModelOnDn, PACKET>), grid, block, LDS, s, p); break;           \
-    default: return hipErrorInvalidValue;                                                                      \
+#define RMCL_LAUNCH_FIND(TRAV, LDS)                                                                          \
+  switch (kind) {                                                                                            \
+    case kModelSpherical: hipLaunchKernelGGL((k_find<kModelSpherical, TRAV>), grid, block, LDS, s, p); break; \
+    case kModelO1Dn: hipLaunchKernelGGL((k_find<kModelO1Dn, TRAV>), grid, block, LDS, s, p); break;           \
+    case kModelPinhole: hipLaunchKernelGGL((k_find<kModelPinhole, TRAV>), grid, block, LDS, s, p); break;     \
+    case kModelOnDn: hipLaunchKernelGGL((k_find<kModelOnDn, TRAV>), grid, block, LDS, s, p); break;           \
+    default: return hipErrorInvalidValue;                                                                    \
   }
   if (variant == 0) {  // wave-packet traversal (needs map stack_need <= 64, checked at map creation)
-    RMCL_LAUNCH_FIND(true, 0)
+    RMCL_LAUNCH_FIND(0, 0)
+  } else if (variant == 2) {  // quad-cooperative: 64 rays per block, 64 stack entries per ray in LDS
+    const size_t lds = 64u * 64u * sizeof(uint32_t);
+    RMCL_LAUNCH_FIND(2, lds)
   } else {             // per-lane while-while traversal: 16 stack entries per lane in LDS, the rest in scratch
     const size_t lds = 16u * 256u * sizeof(uint32_t);
-    RMCL_LAUNCH_FIND(false, lds)
+    RMCL_LAUNCH_FIND(1, lds)
   }
 #undef RMCL_LAUNCH_FIND
   return hipGetLastError();
