@@ -137,7 +137,8 @@ struct rmclhip_rcc {
   MicpState* d_state = nullptr;
   MicpState* h_state = nullptr;    // pinned
   uint32_t* d_counter = nullptr;
-  uint32_t* d_tickets = nullptr;   // one arrival counter per pose for the fused reduction tail
+  uint32_t* d_tickets = nullptr;
+  uint32_t* d_loop_barrier = nullptr;  // counter of the persistent-loop grid barrier   // one arrival counter per pose for the fused reduction tail
   // device-resident MICP loop as a static hipGraph: per-call inputs travel in one 256-B H2D copy
   MicpCall* h_call = nullptr;      // pinned
   MicpCall* d_call = nullptr;
@@ -152,6 +153,8 @@ struct rmclhip_rcc {
   bool use_graph = true;
   bool graph_dirty = true;         // set by setModel / set_variant: by-value launch arguments changed
   size_t tickets_cap = 0;
+  int loop_blocks = 0;             // MICP loop form (schedule R): 0 one launch per iteration (k_micp_iter), -1 classic
+                                   // reduce + solve launches, > 0 persistent k_micp_loop with this many blocks
   bool fused_tail = false;         // true: last-block tail inside the reduction kernel (measured slower, A/B only)
   // batch
   DevBuf<uint8_t> d_raw;           // staged PointCloud2 bytes (set_input_pointcloud2)
@@ -332,7 +335,7 @@ rmclhip_status rmclhip_rcc_create(rmclhip_ctx* ctx, rmclhip_map* map, rmclhip_rc
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_stats), sizeof(cstats) * 2, hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&r->h_stats_dev), r->h_stats, 0);
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_state), sizeof(MicpState), hipHostMallocDefault);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->d_state), sizeof(MicpState));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->d_state), 2 * sizeof(MicpState));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->d_counter), sizeof(uint32_t));
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_call), sizeof(MicpCall), hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->d_call), sizeof(MicpCall));
@@ -363,6 +366,7 @@ void rmclhip_rcc_destroy(rmclhip_rcc* r) {
   if (r->h_stats) DBG_STEP(hipHostFree(r->h_stats));
   if (r->h_state) DBG_STEP(hipHostFree(r->h_state));
   if (r->d_state) DBG_STEP(hipFree(r->d_state));
+  if (r->d_loop_barrier) DBG_STEP(hipFree(r->d_loop_barrier));
   if (r->d_counter) DBG_STEP(hipFree(r->d_counter));
   if (r->d_tickets) DBG_STEP(hipFree(r->d_tickets));
   if (r->micp_exec) DBG_STEP(hipGraphExecDestroy(r->micp_exec));
@@ -819,7 +823,11 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
     if (rmclhip_status st = ensure_model_buffers(r, n)) return st;
     const uint32_t nred = (r->n_dataset < r->n_model) ? r->n_dataset : r->n_model;
     if (nred == 0) return fail(RMCLHIP_ERR_INVALID, "correct_once: empty dataset");
-    HIPCHK(r->d_partials.reserve(static_cast<size_t>(reduce_num_blocks(nred)) * 16));
+    HIPCHK(r->d_partials.reserve(std::max<size_t>(static_cast<size_t>(reduce_num_blocks(nred)) * 32, 2u * 256u * 16u)));
+    if (!r->d_loop_barrier) {
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&r->d_loop_barrier), sizeof(uint32_t)));
+      HIPCHK(hipMemset(r->d_loop_barrier, 0, sizeof(uint32_t)));
+    }
     {
       ReduceTail none;  // allocates the ticket buffer outside the capture
       (void)none;
@@ -841,7 +849,27 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
       p.Tsm_arr = &r->d_call->Tsm;
       p.Tms_arr = &r->d_call->Tms;
       HIPCHK(launch_find(p, r->kind, find_variant(r, p.nposes), r->stream));
-      HIPCHK(launch_micp_init(r->d_state, r->stream));
+      HIPCHK(launch_micp_init(r->d_state, r->d_loop_barrier, r->stream));
+      MicpState* final_state = r->d_state;
+      const uint8_t* dmask = r->ds_has_mask ? r->d_ds_mask.p : nullptr;
+      if (r->loop_blocks > 0) {
+        // persistent loop: every iteration inside ONE launch (k_micp_loop); A/B only -- a device-wide barrier
+        // across the 8 XCDs costs more than the launch boundaries it replaces
+        HIPCHK(launch_micp_loop(r->d_ds_points.p, dmask, r->d_points.p, r->d_normals.p, r->d_hits.p, nred, n_iter,
+                                r->d_call, r->d_partials.p, r->d_loop_barrier, r->d_state,
+                                static_cast<uint32_t>(r->loop_blocks), r->stream));
+      } else if (r->loop_blocks == 0 && !r->fused_tail && n_iter > 0) {
+        // default: ONE launch per iteration (k_micp_iter solves the previous iteration in its prologue) + one
+        // closing solve: n_iter + 1 launches instead of 2 * n_iter
+        const uint32_t nb = reduce_num_blocks(nred);
+        double* part[2] = {r->d_partials.p, r->d_partials.p + static_cast<size_t>(nb) * 16};
+        for (uint32_t i = 0; i < n_iter; ++i)
+          HIPCHK(launch_micp_iter(r->d_ds_points.p, dmask, r->d_points.p, r->d_normals.p, r->d_hits.p, nred, nb, r->d_call,
+                                  part[(i + 1u) & 1u], part[i & 1u], r->d_state + (i & 1u), r->d_state + ((i + 1u) & 1u),
+                                  i == 0, r->stream));
+        final_state = r->d_state + (n_iter & 1u);
+        HIPCHK(launch_micp_step(part[(n_iter - 1u) & 1u], nb, r->Tsb, Tbo, r->d_call, final_state, r->stream));
+      } else
       for (uint32_t i = 0; i < n_iter; ++i) {
         ReduceTail tail;
         tail.mode = kTailMicp;
@@ -850,7 +878,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
         tail.call = r->d_call;
         if (rmclhip_status st = reduce_enqueue(r, xidentity(), &r->d_state->T_snew_sold, maxd, 1, tail)) return st;
       }
-      HIPCHK(hipMemcpyAsync(r->h_state, r->d_state, sizeof(MicpState), hipMemcpyDeviceToHost, r->stream));
+      HIPCHK(hipMemcpyAsync(r->h_state, final_state, sizeof(MicpState), hipMemcpyDeviceToHost, r->stream));
       return RMCLHIP_OK;
     };
     if (r->use_graph) {
@@ -858,7 +886,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
       std::memset(&key, 0, sizeof(key));
       key.n_iter = n_iter; key.W = r->W; key.H = r->H; key.n_dataset = r->n_dataset;
       key.kind = static_cast<int>(r->kind); key.variant = r->variant; key.tile = r->tile_override;
-      key.fused = r->fused_tail ? 1 : 0; key.has_mask = r->ds_has_mask ? 1 : 0;
+      key.fused = (r->fused_tail ? 1 : 0) | (r->loop_blocks << 1); key.has_mask = r->ds_has_mask ? 1 : 0;
       key.ptrs[0] = r->d_points.p; key.ptrs[1] = r->d_ds_points.p; key.ptrs[2] = r->d_partials.p;
       key.ptrs[3] = r->d_model_tab.p; key.ptrs[4] = r->d_ds_mask.p; key.ptrs[5] = r->d_hits.p;
       if (!r->micp_exec || r->graph_dirty || !(key == r->micp_key)) {
@@ -983,11 +1011,16 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
   ApiGuard guard_("rmclhip_rcc_set_variant");
   if (!r || variant < 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: bad arguments");
   const int kind = variant & 0xF, tile = (variant >> 4) & 0xF;
-  if ((kind > 2 && kind != 15) || tile > 7 || (variant >> 10) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
+  if ((kind > 2 && kind != 15) || tile > 7 || (variant >> 13) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
   r->variant = kind;
   r->tile_override = tile;
   r->fused_tail = ((variant >> 8) & 1) != 0;
   r->use_graph = ((variant >> 9) & 1) == 0;
+  {  // bits 10..12: MICP loop form -- 0 default (one launch per iteration, solve in the prologue), 1 classic
+     // (reduce + solve launches), 2..6 persistent loop kernel with 16..256 blocks
+    static const int kLoopBlocks[8] = {0, -1, 16, 32, 64, 128, 256, 0};
+    r->loop_blocks = kLoopBlocks[(variant >> 10) & 7];
+  }
   r->graph_dirty = true;
   return RMCLHIP_OK;
 }

@@ -121,7 +121,20 @@ hipError_t launch_reduce_finalize(const double* partials, uint32_t nblocks, uint
 // finalize + (Tsb*, Tbo*) + umeyama + compose; advances MicpState on the device
 hipError_t launch_micp_step(const double* partials, uint32_t nblocks, xform Tsb, xform Tbo, const MicpCall* call,
                             MicpState* state, hipStream_t s);
-hipError_t launch_micp_init(MicpState* state, hipStream_t s);
+// state: TWO MicpState slots (ping-pong of k_micp_iter); both initialised
+hipError_t launch_micp_init(MicpState* state, uint32_t* barrier, hipStream_t s);
+// one launch per MICP iteration: finishes the previous iteration (finalize + solve, redundantly in every block)
+// and streams the next reduction; a final launch_micp_step closes the last iteration
+hipError_t launch_micp_iter(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
+                            const float* model_normals, const uint8_t* model_mask, uint32_t n, uint32_t nblocks,
+                            const MicpCall* call, const double* partials_prev, double* partials_out,
+                            const MicpState* state_in, MicpState* state_out, bool first, hipStream_t s);
+// persistent loop: n_iter x (reduce, barrier, finalize + solve) in one launch; nblocks <= number of CUs (the grid
+// must be co-resident); partials: 2 * nblocks * 16 doubles; barrier: one uint32, zeroed by launch_micp_init
+hipError_t launch_micp_loop(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
+                            const float* model_normals, const uint8_t* model_mask, uint32_t n, uint32_t n_iter,
+                            const MicpCall* call, double* partials, uint32_t* barrier, MicpState* state,
+                            uint32_t nblocks, hipStream_t s);
 // batch: per pose finalize + umeyama -> Tdelta (sensor->base conjugated), stats
 hipError_t launch_batch_solve(const double* partials, uint32_t nblocks, uint32_t nposes, xform Tsb,
                               xform* Tdelta_out, cstats* stats_out, hipStream_t s);

@@ -324,6 +324,7 @@ __device__ __forceinline__ uint32_t quad_dpp(uint32_t v) {
   return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), kCtrl, 0xF, 0xF, true));
 }
 constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kQuadXor3 = 0x1B;  // quad_perm [1,0,3,2] [2,3,0,1] [3,2,1,0]
+constexpr uint32_t kQuadStackEntries = 1u + 64u + 4u;            // sentinel + the builder's bound + scratch rows
 
 __device__ __forceinline__ void trace_quad(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris, f3 O,
                                            f3 D, float ray_tfar, uint32_t c, uint32_t ray, uint32_t* __restrict__ lds,
@@ -333,43 +334,46 @@ __device__ __forceinline__ void trace_quad(const uint32_t* __restrict__ nodes, c
   float best_t = ray_tfar;
   uint32_t best_face = kInvalidFace, best_rec = 0;
   constexpr uint32_t kDone = 0x7FFFFFFFu;
-  uint32_t sp = 0;
+  // The quad's stack: entry e of ray r at byte (e*64 + r)*4 of `lds` (kQuadStackEntries rows).  Row 0 holds the
+  // sentinel kDone, so that popping an empty stack ends the ray without a test; rows above the top are scratch:
+  // every lane stores its child reference every step (deferred children below the new top, the rest above it)
+  // and the top of the stack is fetched speculatively together with the node -- no branch in a node step.
+  const char* nbase = reinterpret_cast<const char*>(nodes);
+  char* sbase = reinterpret_cast<char*>(lds) + ray * 4u;
+  if (c == 0u) *reinterpret_cast<uint32_t*>(sbase) = kDone;
+  uint32_t spb = 256u;  // byte offset of the first free row
   uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
-  // stack entry e of ray r sits at e*64 + ((r + e) & 63): the <= 3 pushes of one quad and the pops of the 16 rays
-  // of a wave fall into distinct LDS banks
-#define RMCL_QSLOT(e) (((e) << 6) + ((ray + (e)) & 63u))
+  const uint32_t coff = c * 8u;
   while (__any(cur != kDone)) {
-    while ((cur != kDone) && !(cur & kLeafBit)) {
-      const uint32_t* nd = nodes + static_cast<size_t>(cur) * kNodeDwords;
-      const f2 px = *reinterpret_cast<const f2*>(nd + 2u * c);
-      const f2 py = *reinterpret_cast<const f2*>(nd + 8u + 2u * c);
-      const f2 pz = *reinterpret_cast<const f2*>(nd + 16u + 2u * c);
-      const uint32_t ref = nd[24u + c];
+    while (cur < kDone) {  // inner node (leaf references have bit 31 set)
+      const char* nd = nbase + (cur << 7) + coff;
+      const f2 px = *reinterpret_cast<const f2*>(nd);
+      const f2 py = *reinterpret_cast<const f2*>(nd + 32);
+      const f2 pz = *reinterpret_cast<const f2*>(nd + 64);
+      const uint32_t ref = *reinterpret_cast<const uint32_t*>(nbase + (cur << 7) + 96u + c * 4u);
+      const uint32_t top = *reinterpret_cast<const uint32_t*>(sbase + (spb - 256u));
       float tn, tf;
       slab(px, py, pz, inv, noi, best_t, tn, tf);
-      const uint32_t hit = (tn <= tf) ? 1u : 0u;  // unused slots hold an unreachable box (layout.h)
-      // unique keys: entry distance with the slot number in the two low mantissa bits; misses sort last
-      const uint32_t key = (hit ? (__float_as_uint(tn) & ~3u) : 0xFFFFFFFCu) | c;
+      // unique keys: entry distance with the slot number in the two low mantissa bits; misses (unused slots hold
+      // an unreachable box, layout.h) sort last
+      const uint32_t key = ((tn <= tf) ? (__float_as_uint(tn) & ~3u) : 0xFFFFFFFCu) | c;
       const uint32_t k1 = quad_dpp<kQuadXor1>(key), k2 = quad_dpp<kQuadXor2>(key), k3 = quad_dpp<kQuadXor3>(key);
       const uint32_t rank = (k1 < key ? 1u : 0u) + (k2 < key ? 1u : 0u) + (k3 < key ? 1u : 0u);
-      const uint32_t h1 = hit + quad_dpp<kQuadXor1>(hit);
-      const uint32_t nh = h1 + quad_dpp<kQuadXor2>(h1);
-      const uint32_t sel = (hit && rank == 0u) ? ref : 0u;
+      const uint32_t kmax = max(max(key, k1), max(k2, k3)), kmin = min(min(key, k1), min(k2, k3));
+      // number of hits = 4 - misses; all four keys are known to every lane
+      const uint32_t nh = (key < 0xFFFFFFFCu ? 1u : 0u) + (k1 < 0xFFFFFFFCu ? 1u : 0u) + (k2 < 0xFFFFFFFCu ? 1u : 0u) +
+                          (k3 < 0xFFFFFFFCu ? 1u : 0u);
+      (void)kmax;
+      const uint32_t sel = (key == kmin) ? ref : 0u;
       const uint32_t s1 = sel | quad_dpp<kQuadXor1>(sel);
       const uint32_t nearest = s1 | quad_dpp<kQuadXor2>(s1);
-      if (hit && rank != 0u) {
-        const uint32_t e = sp + (nh - 1u - rank);  // second nearest on top
-        lds[RMCL_QSLOT(e)] = ref;
-      }
-      if (nh != 0u) {
-        sp += nh - 1u;
-        cur = nearest;
-      } else if (sp == 0u) {
-        cur = kDone;
-      } else {
-        --sp;
-        cur = lds[RMCL_QSLOT(sp)];
-      }
+      // rows: deferred hits (rank 1..nh-1) at spb + (nh-1-rank), second nearest on top; rank 0 and the misses land
+      // in the scratch rows at or above the new top
+      const uint32_t row = (rank < nh) ? (nh - 1u - rank) : rank;
+      *reinterpret_cast<uint32_t*>(sbase + spb + (row << 8)) = ref;
+      const bool any = nh != 0u;
+      cur = any ? nearest : top;
+      spb = any ? (spb + ((nh - 1u) << 8)) : (spb - 256u);
     }
     if (cur != kDone) {
       const uint32_t first = cur & 0x0FFFFFFFu;
@@ -377,6 +381,7 @@ __device__ __forceinline__ void trace_quad(const uint32_t* __restrict__ nodes, c
       const uint32_t idx = first + ((c < cnt) ? c : (cnt - 1u));
       const uint4* tp = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(idx) * 4u;
       const uint4 a = tp[0], b = tp[1], cc = tp[2], d = tp[3];
+      const uint32_t top = *reinterpret_cast<const uint32_t*>(sbase + (spb - 256u));
       const f3 v0 = mk3(asf(a.x), asf(a.y), asf(a.z));
       const f3 e1 = mk3(asf(a.w), asf(b.x), asf(b.y));
       const f3 e2 = mk3(asf(b.z), asf(b.w), asf(cc.x));
@@ -404,15 +409,10 @@ __device__ __forceinline__ void trace_quad(const uint32_t* __restrict__ nodes, c
       best_t = closer ? ct : best_t;
       best_face = closer ? cf : best_face;
       best_rec = closer ? cr : best_rec;
-      if (sp == 0u) {
-        cur = kDone;
-      } else {
-        --sp;
-        cur = lds[RMCL_QSLOT(sp)];
-      }
+      cur = top;
+      spb -= 256u;
     }
   }
-#undef RMCL_QSLOT
   h.t = best_t;
   h.face = best_face;
   h.rec = best_rec;
@@ -696,9 +696,21 @@ __device__ __forceinline__ cstats finalize_pose(const double* partials, uint32_t
   // ~4.5 us of the 14 us k_micp_step)
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t k0 = lane & 15u, g = lane >> 4;
-  // 8 loads in flight per lane (a one-load-per-iteration loop serialises ~64 L2 round trips: measured +12 us)
+  // 32 loads in flight per lane: every batch is one L2 round trip (~0.8 us) for this lone wave, so 256 partials
+  // cost two round trips (8 in flight: 8 round trips, measured 6 us of the 11 us solve step; one load per
+  // iteration serialised 64 round trips)
   double a = 0.0;
   uint32_t b = g;
+  for (; b + 124u < nblocks; b += 128u) {
+    double v[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      const double* q = partials + static_cast<size_t>(b + 4u * u) * kAcc + k0;
+      v[u] = kAgentLoads ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+    }
+#pragma unroll
+    for (int u = 0; u < 32; u += 8) a += ((v[u] + v[u + 1]) + (v[u + 2] + v[u + 3])) + ((v[u + 4] + v[u + 5]) + (v[u + 6] + v[u + 7]));
+  }
   for (; b + 28u < nblocks; b += 32u) {
     double v[8];
 #pragma unroll
@@ -847,11 +859,206 @@ __global__ void __launch_bounds__(64) k_reduce_finalize(const double* __restrict
   if (threadIdx.x == 0) out[pose] = s;
 }
 
-__global__ void k_micp_init(MicpState* st) {
+// ---------------------------------------------------------------------------------------------
+// persistent MICP loop: ALL optimization iterations of one correction in ONE launch.
+// The per-iteration chain "reduce (grid) -> finalize + solve (one lane) -> next pre-transform" is bound by launch
+// boundaries (two ~5 us launches per iteration for ~1 us of HBM/L2 streaming).  Here a small co-resident grid
+// (gridDim.x <= number of CUs, 512 threads) keeps iterating: each block reduces its contiguous slice of the
+// correspondences (which stay L2-resident), publishes a 128-B partial with write-through stores, meets the other
+// blocks at a counter barrier, and then EVERY block finalizes and solves redundantly (same partials, same
+// order, same code => identical state) -- one barrier per iteration and no broadcast step.
+// ---------------------------------------------------------------------------------------------
+struct MicpLoopParams {
+  const float* dataset_points;
+  const uint8_t* dataset_mask;  // nullable
+  const float* model_points;
+  const float* model_normals;
+  const uint8_t* model_mask;
+  uint32_t n, n_iter;
+  const MicpCall* call;  // Tsb, Tbo, max_dist of this correction
+  double* partials;      // [2][gridDim.x][16] (double-buffered across iterations)
+  uint32_t* barrier;     // zero at launch (k_micp_init)
+  MicpState* state;      // result, written by block 0
+};
+
+__global__ void __launch_bounds__(512) k_micp_loop(const MicpLoopParams p) {
+  __shared__ double red[8][kAcc];
+  __shared__ MicpState s_state;
+  __shared__ xform s_Tsb, s_Tbo;
+  const uint32_t G = gridDim.x, b = blockIdx.x;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) {
+    s_state.T_onew_oold = xidentity();
+    s_state.T_snew_sold = xidentity();
+    s_state.stats_o = cs_identity();
+    s_Tsb = p.call->Tsb;
+    s_Tbo = p.call->Tbo;
+  }
+  const float max_dist = p.call->max_dist;
+  // contiguous slice of this block, a multiple of the block size
+  const uint32_t per = ((p.n + G - 1u) / G + 511u) & ~511u;
+  const uint32_t i0 = b * per, i1 = min(p.n, i0 + per);
+  __syncthreads();
+  for (uint32_t it = 0; it < p.n_iter; ++it) {
+    const xform Tpre = s_state.T_snew_sold;
+    double acc[kAcc];
+#pragma unroll
+    for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += 512u) {
+      const bool dok = (p.dataset_mask == nullptr) || (p.dataset_mask[i] > 0);
+      if (dok && p.model_mask[i] > 0) {
+        const float* dp = p.dataset_points + 3 * static_cast<size_t>(i);
+        const float* mp = p.model_points + 3 * static_cast<size_t>(i);
+        const float* mn = p.model_normals + 3 * static_cast<size_t>(i);
+        const f3 Di = xapply(Tpre, mk3(dp[0], dp[1], dp[2]));
+        const f3 Ii = mk3(mp[0], mp[1], mp[2]);
+        const f3 Ni = mk3(mn[0], mn[1], mn[2]);
+        const float spd = dot_plain(sub3(Ii, Di), Ni);
+        if (fabsf(spd) < max_dist) {
+          const f3 Mi = add3(Di, scale3(Ni, spd));
+          const double d[3] = {Di.x, Di.y, Di.z}, m[3] = {Mi.x, Mi.y, Mi.z};
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { acc[k] += d[k]; acc[3 + k] += m[k]; }
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[6 + 3 * r + c] += m[r] * d[c];
+          acc[15] += 1.0;
+        }
+      }
+    }
+    // wave reduction (halving butterfly, see k_reduce_partials), then the 8 waves through LDS
+#pragma unroll
+    for (int half = 8, off = 32; half >= 1; half >>= 1, off >>= 1) {
+      const bool hi = (lane & static_cast<uint32_t>(off)) != 0u;
+#pragma unroll
+      for (int j = 0; j < half; ++j) {
+        const double send = hi ? acc[j] : acc[j + half];
+        const double keep = hi ? acc[j + half] : acc[j];
+        acc[j] = keep + __shfl_xor(send, off, 64);
+      }
+    }
+    acc[0] += __shfl_xor(acc[0], 2, 64);
+    acc[0] += __shfl_xor(acc[0], 1, 64);
+    if ((lane & 3u) == 0u) red[wave][lane >> 2] = acc[0];
+    __syncthreads();
+    double* part = p.partials + static_cast<size_t>(it & 1u) * G * kAcc;
+    if (threadIdx.x < kAcc) {
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += red[w][threadIdx.x];
+      __hip_atomic_store(part + static_cast<size_t>(b) * kAcc + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // grid barrier: write-through partial stores complete (vmcnt) -> arrive -> spin on the monotonic counter
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(p.barrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t target = (it + 1u) * G;
+      while (__hip_atomic_load(p.barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    if (wave == 0u) {
+      const cstats st = finalize_pose<true>(part, G);
+      if (lane == 0u) micp_advance(st, s_Tsb, s_Tbo, &s_state);
+    }
+    __syncthreads();
+  }
+  if (b == 0u && threadIdx.x == 0u) *p.state = s_state;
+}
+
+// One MICP iteration per launch (instead of reduce + solve = two): the launch of iteration i first finishes
+// iteration i-1 -- wave 0 of EVERY block sums the previous partials and solves redundantly (same inputs, same
+// order => the same pre-transform in every block; block 0 records the advanced state) -- and then streams the
+// correspondences with that pre-transform.  Partials and state ping-pong between two buffers so that no block
+// reads what another block of the same launch writes.
+struct MicpIterParams {
+  const float* dataset_points;
+  const uint8_t* dataset_mask;  // nullable
+  const float* model_points;
+  const float* model_normals;
+  const uint8_t* model_mask;
+  uint32_t n, nblocks;
+  const MicpCall* call;
+  const double* partials_prev;  // of the previous launch (unused when first)
+  double* partials_out;
+  const MicpState* state_in;    // state before finishing the previous iteration
+  MicpState* state_out;
+  uint32_t first;
+};
+
+__global__ void __launch_bounds__(256) k_micp_iter(const MicpIterParams p) {
+  __shared__ double red[4][kAcc];
+  __shared__ xform s_Tpre;
+  if (threadIdx.x < 64u) {
+    if (p.first) {
+      if (threadIdx.x == 0) s_Tpre = xidentity();
+    } else {
+      const cstats st = finalize_pose(p.partials_prev, p.nblocks);
+      if (threadIdx.x == 0) {
+        MicpState local = *p.state_in;
+        micp_advance(st, p.call->Tsb, p.call->Tbo, &local);
+        s_Tpre = local.T_snew_sold;
+        if (blockIdx.x == 0) *p.state_out = local;
+      }
+    }
+  }
+  __syncthreads();
+  const xform Tpre = s_Tpre;
+  const float max_dist = p.call->max_dist;
+  double acc[kAcc];
+#pragma unroll
+  for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < p.n; i += gridDim.x * 256u) {
+    const bool dok = (p.dataset_mask == nullptr) || (p.dataset_mask[i] > 0);
+    if (dok && p.model_mask[i] > 0) {
+      const float* dp = p.dataset_points + 3 * static_cast<size_t>(i);
+      const float* mp = p.model_points + 3 * static_cast<size_t>(i);
+      const float* mn = p.model_normals + 3 * static_cast<size_t>(i);
+      const f3 Di = xapply(Tpre, mk3(dp[0], dp[1], dp[2]));
+      const f3 Ii = mk3(mp[0], mp[1], mp[2]);
+      const f3 Ni = mk3(mn[0], mn[1], mn[2]);
+      const float spd = dot_plain(sub3(Ii, Di), Ni);
+      if (fabsf(spd) < max_dist) {
+        const f3 Mi = add3(Di, scale3(Ni, spd));
+        const double d[3] = {Di.x, Di.y, Di.z}, m[3] = {Mi.x, Mi.y, Mi.z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { acc[k] += d[k]; acc[3 + k] += m[k]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) acc[6 + 3 * r + c] += m[r] * d[c];
+        acc[15] += 1.0;
+      }
+    }
+  }
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int half = 8, off = 32; half >= 1; half >>= 1, off >>= 1) {
+    const bool hi = (lane & static_cast<uint32_t>(off)) != 0u;
+#pragma unroll
+    for (int j = 0; j < half; ++j) {
+      const double send = hi ? acc[j] : acc[j + half];
+      const double keep = hi ? acc[j + half] : acc[j];
+      acc[j] = keep + __shfl_xor(send, off, 64);
+    }
+  }
+  acc[0] += __shfl_xor(acc[0], 2, 64);
+  acc[0] += __shfl_xor(acc[0], 1, 64);
+  if ((lane & 3u) == 0u) red[wave][lane >> 2] = acc[0];
+  __syncthreads();
+  if (threadIdx.x < kAcc)
+    p.partials_out[static_cast<size_t>(blockIdx.x) * kAcc + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+__global__ void k_micp_init(MicpState* st, uint32_t* barrier) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     st->T_onew_oold = xidentity();
     st->T_snew_sold = xidentity();
     st->stats_o = cs_identity();
+    st[1] = st[0];  // the state ping-pongs between two slots (k_micp_iter)
+    if (barrier) *barrier = 0u;
   }
 }
 
@@ -1251,7 +1458,7 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
   if (variant == 0) {  // wave-packet traversal (needs map stack_need <= 64, checked at map creation)
     RMCL_LAUNCH_FIND(0, 0)
   } else if (variant == 2) {  // quad-cooperative: 64 rays per block, 64 stack entries per ray in LDS
-    const size_t lds = 64u * 64u * sizeof(uint32_t);
+    const size_t lds = kQuadStackEntries * 64u * sizeof(uint32_t);
     RMCL_LAUNCH_FIND(2, lds)
   } else {             // per-lane while-while traversal: 16 stack entries per lane in LDS, the rest in scratch
     const size_t lds = 16u * 256u * sizeof(uint32_t);
@@ -1302,8 +1509,28 @@ hipError_t launch_reduce_finalize(const double* partials, uint32_t nblocks, uint
   return hipGetLastError();
 }
 
-hipError_t launch_micp_init(MicpState* state, hipStream_t s) {
-  hipLaunchKernelGGL(k_micp_init, dim3(1), dim3(64), 0, s, state);
+hipError_t launch_micp_loop(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
+                            const float* model_normals, const uint8_t* model_mask, uint32_t n, uint32_t n_iter,
+                            const MicpCall* call, double* partials, uint32_t* barrier, MicpState* state,
+                            uint32_t nblocks, hipStream_t s) {
+  MicpLoopParams p{dataset_points, dataset_mask, model_points, model_normals, model_mask, n, n_iter, call, partials,
+                   barrier, state};
+  hipLaunchKernelGGL(k_micp_loop, dim3(nblocks), dim3(512), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_micp_iter(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
+                            const float* model_normals, const uint8_t* model_mask, uint32_t n, uint32_t nblocks,
+                            const MicpCall* call, const double* partials_prev, double* partials_out,
+                            const MicpState* state_in, MicpState* state_out, bool first, hipStream_t s) {
+  MicpIterParams p{dataset_points, dataset_mask, model_points, model_normals, model_mask, n, nblocks, call,
+                   partials_prev, partials_out, state_in, state_out, first ? 1u : 0u};
+  hipLaunchKernelGGL(k_micp_iter, dim3(nblocks), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_micp_init(MicpState* state, uint32_t* barrier, hipStream_t s) {
+  hipLaunchKernelGGL(k_micp_init, dim3(1), dim3(64), 0, s, state, barrier);
   return hipGetLastError();
 }
 

@@ -161,9 +161,11 @@ def test_correct_batch_v1_api(ra, orc, ctx, meshes):
     assert np.all(np.abs(t1[:, 2]) <= np.abs(t0[:, 2]) + 1e-3)
 
 
-@pytest.mark.parametrize("variant_bits", [0, 1 << 8, 1 << 9, (1 << 8) | (1 << 9)])
+@pytest.mark.parametrize("variant_bits", [0, 1 << 8, 1 << 9, (1 << 8) | (1 << 9), 1 << 10, (1 << 10) | (1 << 9), 4 << 10,
+                                          (6 << 10) | (1 << 8)])
 def test_loop_variants_agree(ra, orc, ctx, meshes, variant_bits):
-    """A/B code paths of the MICP loop (fused last-block reduction tail, hipGraph replay on/off) give the same
+    """A/B code paths of the MICP loop (fused last-block reduction tail, hipGraph replay on/off, loop form: one
+    launch per iteration / reduce + solve launches / persistent kernel with a grid barrier) give the same
     statistics and pose as the default path; repeated calls with changing inputs exercise graph replay with
     fresh per-call parameters (pose, Tbo, max_dist, Tsb)."""
     from rmcl_amd import synthetic as syn, types as T
