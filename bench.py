@@ -62,7 +62,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=("c2", "pf"), default="c2")
-    ap.add_argument("--variant", type=int, default=1, help="find traversal: 1 per-lane while-while (default), 0 wave-packet")
+    ap.add_argument("--variant", type=int, default=15,
+                    help="find traversal: 15 automatic (default), 1 one lane per ray, 2 four lanes per ray, 0 wave packet")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing tests)")

@@ -1202,8 +1202,9 @@ static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, 
   p.range_max = f->params.sensor_range.max;
   p.max_n_meas = f->params.max_n_meas;
   p.errors = f->errors_dev;
-  // particles per workgroup: ~4096 rays per block, at most 64 particles, evals must fit 32 KB of LDS
-  uint32_t pb = 4096u / n_beams;
+  // particles per workgroup: ~2048 rays per block (measured 4-6 % faster than 4096: shorter tail per block, more
+  // blocks to balance), at most 64 particles, evals must fit 32 KB of LDS
+  uint32_t pb = 2048u / n_beams;
   if (pb < 1u) pb = 1u;
   if (pb > 64u) pb = 64u;
   if (static_cast<size_t>(pb) * n_beams > 8192u) return fail(RMCLHIP_ERR_UNSUPPORTED, "pf_update: more than 8192 beams");
