@@ -359,11 +359,10 @@ __device__ __forceinline__ void trace_quad(const uint32_t* __restrict__ nodes, c
       const uint32_t key = ((tn <= tf) ? (__float_as_uint(tn) & ~3u) : 0xFFFFFFFCu) | c;
       const uint32_t k1 = quad_dpp<kQuadXor1>(key), k2 = quad_dpp<kQuadXor2>(key), k3 = quad_dpp<kQuadXor3>(key);
       const uint32_t rank = (k1 < key ? 1u : 0u) + (k2 < key ? 1u : 0u) + (k3 < key ? 1u : 0u);
-      const uint32_t kmax = max(max(key, k1), max(k2, k3)), kmin = min(min(key, k1), min(k2, k3));
+      const uint32_t kmin = min(min(key, k1), min(k2, k3));
       // number of hits = 4 - misses; all four keys are known to every lane
       const uint32_t nh = (key < 0xFFFFFFFCu ? 1u : 0u) + (k1 < 0xFFFFFFFCu ? 1u : 0u) + (k2 < 0xFFFFFFFCu ? 1u : 0u) +
                           (k3 < 0xFFFFFFFCu ? 1u : 0u);
-      (void)kmax;
       const uint32_t sel = (key == kmin) ? ref : 0u;
       const uint32_t s1 = sel | quad_dpp<kQuadXor1>(sel);
       const uint32_t nearest = s1 | quad_dpp<kQuadXor2>(s1);
