@@ -244,9 +244,12 @@ rmclhip_status rmclhip_rcc_time_find(rmclhip_rcc* rcc, const rmclhip_transform* 
                                      float* ms_per_launch);
 rmclhip_status rmclhip_rcc_time_reduce(rmclhip_rcc* rcc, const rmclhip_transform* T_snew_sold, uint32_t iters,
                                        float* ms_per_launch);
-/* kernel variant selection: bits 0..3 traversal (1 = per-lane while-while, the default;
- * 0 = wave-packet), bits 4..7 = 1 + log2(tile width) of the wave's scan-image tile (0 = automatic, 8x8 for
- * tall images), bit 8 = fused last-block reduction tail (A/B), bit 9 = disable the hipGraph MICP loop (A/B) */
+/* kernel variant selection: bits 0..3 traversal (15 = automatic, the default: four lanes per ray
+ * up to 65536 rays in flight, one lane per ray above; 0 = wave packet, 1 = one lane per ray, 2 = four lanes per
+ * ray), bits 4..7 = 1 + log2(tile width) of the wave's scan-image tile (0 = automatic, 8x8 for tall images),
+ * bit 8 = fused last-block reduction tail (A/B), bit 9 = disable the hipGraph MICP loop (A/B), bits 10..12 = form
+ * of the MICP loop (0 = one launch per iteration, the default; 1 = reduce + solve launches; 2..6 = persistent
+ * kernel with 16..256 blocks and a grid barrier, A/B) */
 rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* rcc, int variant);
 /* rm::Simulator::simulate(Memory<Transform>, Bundle&) (batch form, lidar_corrector_embree_benchmark.cpp:117):
  * one launch for nposes x H x W rays; model buffers become pose-major [pose][vid][hid]. */
@@ -309,6 +312,9 @@ rmclhip_status rmclhip_pf_time_update(rmclhip_pf* pf, const rmclhip_transform* p
                                       rmclhip_particle_attributes* attrs_dev, uint32_t n_particles,
                                       const rmclhip_range_measurement* beams, uint32_t n_beams,
                                       const rmclhip_transform* Tsb, uint32_t iters, float* ms_per_launch);
+/* bits 0..3: traversal (0 = while-while with the hybrid LDS + scratch stack, 1 = stack entirely in LDS, 2 = single
+ * loop, A/B); bits 4..6: ray scheduling (0 = rounds of one ray per lane; 1..4 = persistent lanes that fetch the
+ * next ray when 8 / 16 / 32 / 48 lanes of their wave are idle).  A fresh handle uses traversal 0, refill at 32. */
 rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* pf, int variant);
 
 

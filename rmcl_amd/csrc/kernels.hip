@@ -1264,6 +1264,174 @@ __global__ void __launch_bounds__(256) k_pf_update(const PfParams p) {
   }
 }
 
+// Persistent-lane variant of k_pf_update ("dynamic ray fetch", Aila & Laine 2009).  The beams of a particle point in
+// all directions, so the 64 rays of a wave diverge almost immediately and with one ray per lane per round the
+// wave waits for its slowest ray: PMC showed 52 % of the lanes active in VALU instructions.  Here a lane that has
+// finished its ray takes the next one from the block's queue as soon as kRefill lanes of its wave are idle; every
+// result is stored under its ray index, so the outcome does not depend on the schedule.  Traversal, acceptance
+// rules and beam evaluation are those of trace_lane_ww / k_pf_update (bit-identical results).
+template <int kLdsEntries, int kRefill>
+__global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
+  // LDS: [ per-lane stacks kLdsEntries*256 | Tsm (PB xforms) | evals (PB*n_beams floats) ]
+  extern __shared__ uint32_t lds_dyn[];
+  __shared__ uint32_t s_next;
+  uint32_t* lds_stack = lds_dyn + threadIdx.x;
+  constexpr uint32_t lds_stride = 256u;
+  xform* s_Tsm = reinterpret_cast<xform*>(lds_dyn + kLdsEntries * 256);
+  float* s_eval = reinterpret_cast<float*>(s_Tsm + p.particles_per_block);
+
+  const uint32_t PB = p.particles_per_block;
+  const uint32_t p0 = blockIdx.x * PB;
+  if (p0 >= p.n_particles) return;
+  const uint32_t np = min(PB, p.n_particles - p0);
+  if (threadIdx.x < np) s_Tsm[threadIdx.x] = xmul(p.poses[p0 + threadIdx.x], p.Tsb);
+  if (threadIdx.x == 0) s_next = 0u;
+  __syncthreads();
+
+  const float sq = p.dist_sigma * p.dist_sigma;
+  const uint32_t nrays = np * p.n_beams;
+  const uint32_t lane = threadIdx.x & 63u;
+  constexpr uint32_t kDone = 0x7FFFFFFFu;
+  // per-lane ray state
+  uint32_t rr = 0;
+  bool has_ray = false, exhausted = false;
+  f3 O = mk3(0.f, 0.f, 0.f), D = O, inv = O, noi = O;
+  float range = 0.f, best_t = 0.f;
+  uint32_t best_face = kInvalidFace, best_rec = 0;
+  uint32_t priv[(kLdsEntries < 64) ? (64 - kLdsEntries) : 1];
+  uint32_t sp = 0, cur = kDone;
+#define RMCL_PUSH(v) { if (kLdsEntries >= 64 || sp < kLdsEntries) lds_stack[sp * lds_stride] = (v); else priv[sp - kLdsEntries] = (v); ++sp; }
+#define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; cur = (kLdsEntries >= 64 || sp < kLdsEntries) ? lds_stack[sp * lds_stride] : priv[sp - kLdsEntries]; } }
+  for (;;) {
+    const bool idle = (cur == kDone) && !exhausted;
+    const uint64_t want = __ballot(idle);
+    const uint64_t busy = __ballot(cur != kDone);
+    if (want == 0 && busy == 0) break;
+    if (want != 0 && (busy == 0 || __popcll(want) >= kRefill)) {
+      if (idle) {
+        if (has_ray) {
+          // evaluate_rcc (PCDSensorUpdaterEmbree.cpp:18-86) with unit face normals (BeamEvaluateProgram.cu:104-113)
+          const uint32_t pi = rr / p.n_beams, b = rr - pi * p.n_beams;
+          const bool real_hit = (range >= p.range_min) && (range <= p.range_max);
+          const bool sim_hit = (best_face != kInvalidFace) && (best_t > p.range_min);
+          float error;
+          if (sim_hit) {
+            if (real_hit) {
+              const uint4 nrec = reinterpret_cast<const uint4*>(p.tris)[static_cast<size_t>(best_rec) * 4u + 3u];
+              const f3 n = mk3(asf(nrec.x), asf(nrec.y), asf(nrec.z));
+              const f3 preal = add3(O, scale3(D, range));
+              const f3 pint = add3(O, scale3(D, best_t));
+              error = fabsf(dot_plain(sub3(pint, preal), n));
+            } else {
+              error = p.rmsh;
+            }
+          } else {
+            error = real_hit ? p.rhsm : p.rmsm;
+          }
+          if (p.errors) p.errors[static_cast<size_t>(p0 + pi) * p.n_beams + b] = error;
+          // PCDSensorUpdaterEmbree.cpp:224 : float argument, double exp / sqrt, float result
+          const float arg = -(error * error) / sq / 2;
+          s_eval[rr] = static_cast<float>(exp(static_cast<double>(arg)) /
+                                          sqrt(static_cast<double>(2 * sq) * 3.14159265358979323846));
+          has_ray = false;
+        }
+      }
+      // next rays for the idle lanes: one LDS atomic per wave and refill
+      const uint32_t nwant = static_cast<uint32_t>(__popcll(want));
+      const int leader = __builtin_ctzll(want);
+      uint32_t base = 0;
+      if (static_cast<int>(lane) == leader) base = atomicAdd(&s_next, nwant);
+      base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(base), leader));
+      if (idle) {
+        const uint32_t mine = base + static_cast<uint32_t>(__popcll(want & ((1ull << lane) - 1ull)));
+        if (mine < nrays) {
+          rr = mine;
+          const uint32_t pi = rr / p.n_beams, b = rr - pi * p.n_beams;
+          const xform Tsm = s_Tsm[pi];
+          const float* bm = p.beams + 16u * b;
+          // meas_m = Tsm * meas_s (RangeMeasurement.hpp:28-42)
+          D = qrot(Tsm.R, mk3(bm[3], bm[4], bm[5]));
+          O = xapply(Tsm, mk3(bm[0], bm[1], bm[2]));
+          range = bm[6];
+          inv = mk3(safe_inv(D.x), safe_inv(D.y), safe_inv(D.z));
+          noi = mk3(-(O.x * inv.x), -(O.y * inv.y), -(O.z * inv.z));
+          best_t = __builtin_inff();
+          best_face = kInvalidFace;
+          best_rec = 0;
+          sp = 0;
+          has_ray = true;
+          const bool finite = (D.x == D.x) && (D.y == D.y) && (D.z == D.z);
+          cur = finite ? 0u : kDone;  // a non-finite beam is a miss: evaluated at the next refill
+        } else {
+          exhausted = true;
+        }
+      }
+    }
+    // phase 1: inner nodes (see trace_lane_ww)
+    while ((cur != kDone) && !(cur & kLeafBit)) {
+      const uint4* np4 = reinterpret_cast<const uint4*>(p.nodes) + static_cast<size_t>(cur) * 8u;
+      const uint4 qx0 = np4[0], qx1 = np4[1], qy0 = np4[2], qy1 = np4[3], qz0 = np4[4], qz1 = np4[5], qch = np4[6];
+      const f2 bx[4] = {{asf(qx0.x), asf(qx0.y)}, {asf(qx0.z), asf(qx0.w)}, {asf(qx1.x), asf(qx1.y)}, {asf(qx1.z), asf(qx1.w)}};
+      const f2 by[4] = {{asf(qy0.x), asf(qy0.y)}, {asf(qy0.z), asf(qy0.w)}, {asf(qy1.x), asf(qy1.y)}, {asf(qy1.z), asf(qy1.w)}};
+      const f2 bz[4] = {{asf(qz0.x), asf(qz0.y)}, {asf(qz0.z), asf(qz0.w)}, {asf(qz1.x), asf(qz1.y)}, {asf(qz1.z), asf(qz1.w)}};
+      uint32_t ref[4] = {qch.x, qch.y, qch.z, qch.w};
+      uint32_t key[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float tn, tf;
+        slab(bx[c], by[c], bz[c], inv, noi, best_t, tn, tf);
+        key[c] = (tn <= tf) ? __float_as_uint(tn) : kNone;
+      }
+      RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
+      if (key[3] != kNone) RMCL_PUSH(ref[3])
+      if (key[2] != kNone) RMCL_PUSH(ref[2])
+      if (key[1] != kNone) RMCL_PUSH(ref[1])
+      if (key[0] != kNone) cur = ref[0];
+      else RMCL_POP()
+    }
+    // phase 2: this lane's leaf (if any)
+    if (cur != kDone) {
+      const uint32_t first = cur & 0x0FFFFFFFu;
+      const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
+      for (uint32_t i = 0; i < cnt; ++i) {
+        const uint4* tp = reinterpret_cast<const uint4*>(p.tris) + static_cast<size_t>(first + i) * 4u;
+        const uint4 a = tp[0], b = tp[1], c = tp[2], d = tp[3];
+        const f3 v0 = mk3(asf(a.x), asf(a.y), asf(a.z));
+        const f3 e1 = mk3(asf(a.w), asf(b.x), asf(b.y));
+        const f3 e2 = mk3(asf(b.z), asf(b.w), asf(c.x));
+        const f3 Ng = mk3(asf(c.y), asf(c.z), asf(c.w));
+        const uint32_t face = d.w;
+        float Tt, aden;
+        const bool ok = tri_accept(v0, e1, e2, Ng, O, D, Tt, aden);
+        if (ok) {
+          const float t = Tt / aden;
+          const bool acc = (t >= 0.0f);  // tfar = infinity
+          const bool closer = acc && ((t < best_t) || ((t == best_t) && (face < best_face)));
+          best_t = closer ? t : best_t;
+          best_face = closer ? face : best_face;
+          best_rec = closer ? (first + i) : best_rec;
+        }
+      }
+      RMCL_POP()
+    }
+  }
+#undef RMCL_PUSH
+#undef RMCL_POP
+  __syncthreads();
+  // in-order merge, one lane per particle (sequential semantics of sensorUpdate, :232-238)
+  if (threadIdx.x < np) {
+    pattrs* A = reinterpret_cast<pattrs*>(p.attrs) + (p0 + threadIdx.x);
+    g1d L = A->likelihood;
+    const float* ev = s_eval + threadIdx.x * p.n_beams;
+    for (uint32_t b = 0; b < p.n_beams; ++b) {
+      g1d m; m.mean = ev[b]; m.sigma = 0.0f; m.n_meas = 1;
+      L = g1d_add(L, m);
+      L.n_meas = min(L.n_meas, p.max_n_meas);
+    }
+    A->likelihood = L;
+  }
+}
+
 // particle_move_and_forget_kernel (rmcl_ros/src/rmcl/particle_motion.cu:11-34) + the wall-collision test of the
 // CPU updater (collision_in_between, TFMotionUpdaterCPU.cpp:17-50,207-221): one lane per particle; the occlusion
 // ray runs from the old to the new particle position with tfar = segment length.
@@ -1563,6 +1731,14 @@ hipError_t launch_pf_update(const PfParams& p, int variant, hipStream_t s) {
   const bool cpc = (variant & 8) != 0;   // correspondence_type 1
   const size_t stack_lds = ((trav == 0 || cpc) ? 16u : (deep ? 64u : 32u)) * 256u * sizeof(uint32_t);
   const size_t lds = stack_lds + tail;
+  const int refill = (variant >> 4) & 7;  // 0 = rounds of one ray per lane; 1..4 = persistent lanes, refill at 8/16/32/48 idle
+  if (!cpc && trav == 0 && refill != 0) {
+    if (refill == 1) hipLaunchKernelGGL((k_pf_update_persist<16, 8>), dim3(nblocks), dim3(256), lds, s, p);
+    else if (refill == 2) hipLaunchKernelGGL((k_pf_update_persist<16, 16>), dim3(nblocks), dim3(256), lds, s, p);
+    else if (refill == 3) hipLaunchKernelGGL((k_pf_update_persist<16, 32>), dim3(nblocks), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((k_pf_update_persist<16, 48>), dim3(nblocks), dim3(256), lds, s, p);
+    return hipGetLastError();
+  }
   if (cpc) hipLaunchKernelGGL((k_pf_update<64, 3>), dim3(nblocks), dim3(256), lds, s, p);
   else if (trav == 0) hipLaunchKernelGGL((k_pf_update<64, 0>), dim3(nblocks), dim3(256), lds, s, p);
   else if (trav == 1 && deep) hipLaunchKernelGGL((k_pf_update<64, 1>), dim3(nblocks), dim3(256), lds, s, p);

@@ -16,7 +16,7 @@ v, f = syn.uv_sphere(100000) if mesh == "sphere" else syn.noisy_room(100000)
 hm = ra.import_hip_map(ctx, v, f)
 print("map", hm.info())
 dirs = syn.model_directions(syn.model_pf16())
-for n_particles, n_beams in ((10000, 100), (100000, 100), (100000, 256)):
+for n_particles, n_beams in ((100000, 100), (100000, 256)):
     if mesh == "sphere":
         poses, attrs = syn.uniform_particles(n_particles, seed=42, bb_min=(-5, -5, -1, 0, 0, -math.pi), bb_max=(5, 5, 1, 0, 0, math.pi))
     else:
@@ -24,7 +24,7 @@ for n_particles, n_beams in ((10000, 100), (100000, 100), (100000, 256)):
     sel = np.linspace(0, len(dirs) - 1, n_beams).astype(int)
     beams = ra.beams_from_points(dirs[sel] * np.float32(6.0))
     d_poses, d_attrs = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
-    for variant in (0, 1, 2):
+    for variant in (0, 16, 32, 48, 64):
         upd = ra.PCDSensorUpdaterHip(hm)
         upd.init()
         upd.set_variant(variant)
