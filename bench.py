@@ -182,6 +182,30 @@ def main():
             extras["c4_particle_beam_evals_per_s"] = round(prays / (pms * 1e-3), 1)
             extras["c4_particle_updates_per_s"] = round(100000 / (pms * 1e-3), 1)
             extras["c4_pf_algorithmic_GBps"] = round(algorithmic_bytes_pf(100000, 256) / (pms * 1e-3) / 1e9, 2)
+            extras.update(_pf_cycle(ra, syn, T, np, ctx, hm, 100000))
+            # closest-point correspondences on the C2 dataset, and a 16x900 scan (rays in flight below the chip's
+            # width: the four-lanes-per-ray traversal is selected automatically)
+            cpc = ra.CPCHip(hm)
+            cpc.setTsb(T.identity())
+            cpc.params.max_dist = 1.0
+            rcc.find(syn.pose_c2_truth())
+            mv = rcc.modelView()
+            cpc.set_dataset(mv["points"].reshape(-1, 3), mv["hits"].reshape(-1))
+            cpc.find(est)
+            t1 = time.perf_counter()
+            for _ in range(20):
+                cpc.find(est)
+            dt = (time.perf_counter() - t1) / 20
+            extras["cpc_find_ms"] = round(dt * 1e3, 4)
+            extras["cpc_closest_points_per_s"] = round(n_rays / dt, 1)
+            cpc.close()
+            small = ra.RCCHipSpherical(hm)
+            small.setTsb(T.identity())
+            small.setModel(syn.model_vlp16_900())
+            sms = small.time_find(Tbm, iters=100)
+            extras["find_16x900_ms"] = round(sms, 5)
+            extras["find_16x900_rays_per_s"] = round(16 * 900 / (sms * 1e-3), 1)
+            small.close()
 
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -291,6 +315,38 @@ def _pf_c4(ra, syn, T, np, ctx, hm, n_particles, n_beams, iters):
     ms = upd.time_update(d_poses, d_attrs, n_particles, iters=iters)
     upd.close()
     return ms, n_particles * n_beams
+
+
+def _pf_cycle(ra, syn, T, np, ctx, hm, n_particles):
+    """one particle-filter cycle besides the sensor update: motion update (with the wall-collision ray),
+    likelihood statistics and the gladiator tournament, wall-clock per call (synchronous ABI calls)."""
+    poses, attrs = syn.uniform_particles(n_particles, seed=43, bb_min=(-5, -5, -1, 0, 0, -math.pi), bb_max=(5, 5, 1, 0, 0, math.pi))
+    attrs["likelihood"]["mean"] = np.random.RandomState(1).uniform(0, 1, n_particles)
+    attrs["likelihood"]["n_meas"] = 5000
+    d_p, d_a = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
+    d_pn, d_an = ra.DeviceArray(ctx, T.TRANSFORM, n_particles), ra.DeviceArray(ctx, T.PARTICLE_ATTRIBUTES, n_particles)
+    out = {}
+    step = T.transform_from_rpy((0.05, 0.0, 0.0), (0.0, 0.0, 0.01))
+    for coll in (False, True):
+        mo = ra.TFMotionUpdaterHip(hm, check_collision=coll)
+        mo.update(d_p, d_a, n_particles, step, 0.001)
+        t1 = time.perf_counter()
+        for _ in range(20):
+            mo.update(d_p, d_a, n_particles, step, 0.001)
+        out["pf_motion_update%s_ms" % ("_collision" if coll else "")] = round((time.perf_counter() - t1) / 20 * 1e3, 4)
+        mo.close()
+    rs = ra.GladiatorResamplerHip(ctx)
+    rs.update(d_p, d_a, d_pn, d_an, n_particles)
+    t1 = time.perf_counter()
+    for _ in range(20):
+        rs.update(d_p, d_a, d_pn, d_an, n_particles)
+    out["pf_resample_gladiator_ms"] = round((time.perf_counter() - t1) / 20 * 1e3, 4)
+    t1 = time.perf_counter()
+    for _ in range(20):
+        rs.compute_stats(d_a, n_particles)
+    out["pf_likelihood_stats_ms"] = round((time.perf_counter() - t1) / 20 * 1e3, 4)
+    rs.close()
+    return out
 
 
 if __name__ == "__main__":
