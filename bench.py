@@ -205,6 +205,23 @@ def main():
             sms = small.time_find(Tbm, iters=100)
             extras["find_16x900_ms"] = round(sms, 5)
             extras["find_16x900_rays_per_s"] = round(16 * 900 / (sms * 1e-3), 1)
+            # the reference's own (stale) benchmark shape: 1000 poses x vlp16_900 per correct() call, sphere with
+            # 100k faces (lidar_corrector_{embree,optix}_benchmark.cpp; BASELINE.md: OptiX 73.7 k, Embree 5.5 k
+            # corrections/s on the authors' hardware)
+            rng = np.random.RandomState(1)
+            v1poses = np.array([T.transform_from_rpy(tuple(rng.uniform(-1.0, 1.0, 3) * (1, 1, 0.3)), (0, 0, rng.uniform(-3, 3)))
+                                for _ in range(1000)], dtype=T.TRANSFORM)
+            small.find(T.identity())
+            small.set_dataset_from_ranges(small.modelView()["ranges"])
+            small.params.max_dist = 1.0
+            small.correct_batch(v1poses)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                small.correct_batch(v1poses)
+            dt = (time.perf_counter() - t1) / 3
+            extras["v1_bench_1000x16x900_ms"] = round(dt * 1e3, 4)
+            extras["v1_bench_rays_per_s"] = round(1000 * 16 * 900 / dt, 1)
+            extras["v1_bench_pose_corrections_per_s"] = round(1000 / dt, 1)
             small.close()
 
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
