@@ -965,9 +965,9 @@ int orc_trace_bvh4(const uint32_t* nodes, uint32_t n_nodes, const uint32_t* tris
     if (nk < 1 || nk > 4) return -2;
     for (uint32_t c = 0; c < nk; ++c) {
       orc_node bx;
-      bx.bmin[0] = nd[0 + 2 * c]; bx.bmax[0] = nd[1 + 2 * c];
-      bx.bmin[1] = nd[8 + 2 * c]; bx.bmax[1] = nd[9 + 2 * c];
-      bx.bmin[2] = nd[16 + 2 * c]; bx.bmax[2] = nd[17 + 2 * c];
+      bx.bmin[0] = nd[0 + c]; bx.bmax[0] = nd[4 + c];
+      bx.bmin[1] = nd[8 + c]; bx.bmax[1] = nd[12 + c];
+      bx.bmin[2] = nd[16 + c]; bx.bmax[2] = nd[20 + c];
       float tn;
       if (box_hit(&bx, o, inv, tnear, best_t, &tn)) { if (sp >= 256) return -1; stack[sp++] = ch[c]; }
     }
@@ -1373,9 +1373,9 @@ int orc_trace_bvh4_ordered(const uint32_t* nodes, const uint32_t* tris, orc_vec3
       float key[4]; uint32_t ref[4]; int nh = 0;
       for (uint32_t c = 0; c < 4; ++c) {
         orc_node bx;
-        bx.bmin[0] = nd[0 + 2 * c]; bx.bmax[0] = nd[1 + 2 * c];
-        bx.bmin[1] = nd[8 + 2 * c]; bx.bmax[1] = nd[9 + 2 * c];
-        bx.bmin[2] = nd[16 + 2 * c]; bx.bmax[2] = nd[17 + 2 * c];
+        bx.bmin[0] = nd[0 + c]; bx.bmax[0] = nd[4 + c];
+        bx.bmin[1] = nd[8 + c]; bx.bmax[1] = nd[12 + c];
+        bx.bmin[2] = nd[16 + c]; bx.bmax[2] = nd[20 + c];
         float tn;
         if (bx.bmin[0] < 1e29f && box_hit(&bx, o, inv, tnear, best_t, &tn)) { key[nh] = tn; ref[nh] = ch[c]; nh++; }
       }

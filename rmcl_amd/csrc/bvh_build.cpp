@@ -239,9 +239,9 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
     for (int s = 0; s < 4; ++s) {
       if (s < nk) {
         const Node2& ch = n2[kids[s]];
-        nd.x[2 * s] = ch.b.mn[0] - pad; nd.x[2 * s + 1] = ch.b.mx[0] + pad;
-        nd.y[2 * s] = ch.b.mn[1] - pad; nd.y[2 * s + 1] = ch.b.mx[1] + pad;
-        nd.z[2 * s] = ch.b.mn[2] - pad; nd.z[2 * s + 1] = ch.b.mx[2] + pad;
+        nd.x[s] = ch.b.mn[0] - pad; nd.x[4 + s] = ch.b.mx[0] + pad;
+        nd.y[s] = ch.b.mn[1] - pad; nd.y[4 + s] = ch.b.mx[1] + pad;
+        nd.z[s] = ch.b.mn[2] - pad; nd.z[4 + s] = ch.b.mx[2] + pad;
         if (ch.leaf()) {
           nd.child[s] = make_leaf_ref(ch.first, ch.count);
         } else {
@@ -252,9 +252,9 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
         }
       } else {
         // unused slot: unreachable point box + a harmless leaf reference (layout.h)
-        nd.x[2 * s] = nd.x[2 * s + 1] = kFarPoint[0];
-        nd.y[2 * s] = nd.y[2 * s + 1] = kFarPoint[1];
-        nd.z[2 * s] = nd.z[2 * s + 1] = kFarPoint[2];
+        nd.x[s] = nd.x[4 + s] = kFarPoint[0];
+        nd.y[s] = nd.y[4 + s] = kFarPoint[1];
+        nd.z[s] = nd.z[4 + s] = kFarPoint[2];
         nd.child[s] = make_leaf_ref(0, 1);
       }
     }

@@ -76,6 +76,54 @@ __device__ __forceinline__ void slab(f2 px, f2 py, f2 pz, f3 inv, f3 noi, float 
   tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), best_t));
 }
 
+// Per-ray constants of the sign-selected node fetch (layout.h): byte offsets, inside a 128-B node, of the group of
+// four planes the ray ENTERS through and of the group it leaves through, per axis.
+struct RaySlab {
+  f3 inv, noi;
+  uint32_t onx, ofx, ony, ofy, onz, ofz;
+};
+
+__device__ __forceinline__ RaySlab make_ray_slab(f3 O, f3 D) {
+  RaySlab r;
+  r.inv = mk3(safe_inv(D.x), safe_inv(D.y), safe_inv(D.z));
+  r.noi = mk3(-(O.x * r.inv.x), -(O.y * r.inv.y), -(O.z * r.inv.z));
+  r.onx = (r.inv.x < 0.0f) ? 16u : 0u;  r.ofx = 16u - r.onx;
+  r.ony = (r.inv.y < 0.0f) ? 48u : 32u; r.ofy = 80u - r.ony;
+  r.onz = (r.inv.z < 0.0f) ? 80u : 64u; r.ofz = 144u - r.onz;
+  return r;
+}
+
+// The four children of inner node `cur` for one lane: seven global_load_dwordx4 (near / far plane groups of the
+// three axes + child references), twelve packed FMAs (two children per instruction), then per child one
+// max3 / min3 pair.  key = entry distance bits (>= 0, so they order like the floats) or kNone for a miss; unused
+// slots hold an unreachable box (layout.h).  Free-form arithmetic: conservative because the boxes are padded.
+__device__ __forceinline__ void node_keys(const uint32_t* __restrict__ nodes, uint32_t cur, const RaySlab& rs, float best_t,
+                                          uint32_t (&key)[4], uint32_t (&ref)[4]) {
+  const char* nb = reinterpret_cast<const char*>(nodes) + (static_cast<size_t>(cur) << 7);
+  const uint4 qnx = *reinterpret_cast<const uint4*>(nb + rs.onx), qfx = *reinterpret_cast<const uint4*>(nb + rs.ofx);
+  const uint4 qny = *reinterpret_cast<const uint4*>(nb + rs.ony), qfy = *reinterpret_cast<const uint4*>(nb + rs.ofy);
+  const uint4 qnz = *reinterpret_cast<const uint4*>(nb + rs.onz), qfz = *reinterpret_cast<const uint4*>(nb + rs.ofz);
+  const uint4 qch = *reinterpret_cast<const uint4*>(nb + 96);
+  const f2 ix = {rs.inv.x, rs.inv.x}, iy = {rs.inv.y, rs.inv.y}, iz = {rs.inv.z, rs.inv.z};
+  const f2 nx = {rs.noi.x, rs.noi.x}, ny = {rs.noi.y, rs.noi.y}, nz = {rs.noi.z, rs.noi.z};
+  const f2 nx01 = __builtin_elementwise_fma(f2{asf(qnx.x), asf(qnx.y)}, ix, nx), nx23 = __builtin_elementwise_fma(f2{asf(qnx.z), asf(qnx.w)}, ix, nx);
+  const f2 fx01 = __builtin_elementwise_fma(f2{asf(qfx.x), asf(qfx.y)}, ix, nx), fx23 = __builtin_elementwise_fma(f2{asf(qfx.z), asf(qfx.w)}, ix, nx);
+  const f2 ny01 = __builtin_elementwise_fma(f2{asf(qny.x), asf(qny.y)}, iy, ny), ny23 = __builtin_elementwise_fma(f2{asf(qny.z), asf(qny.w)}, iy, ny);
+  const f2 fy01 = __builtin_elementwise_fma(f2{asf(qfy.x), asf(qfy.y)}, iy, ny), fy23 = __builtin_elementwise_fma(f2{asf(qfy.z), asf(qfy.w)}, iy, ny);
+  const f2 nz01 = __builtin_elementwise_fma(f2{asf(qnz.x), asf(qnz.y)}, iz, nz), nz23 = __builtin_elementwise_fma(f2{asf(qnz.z), asf(qnz.w)}, iz, nz);
+  const f2 fz01 = __builtin_elementwise_fma(f2{asf(qfz.x), asf(qfz.y)}, iz, nz), fz23 = __builtin_elementwise_fma(f2{asf(qfz.z), asf(qfz.w)}, iz, nz);
+  const float tnx[4] = {nx01.x, nx01.y, nx23.x, nx23.y}, tfx[4] = {fx01.x, fx01.y, fx23.x, fx23.y};
+  const float tny[4] = {ny01.x, ny01.y, ny23.x, ny23.y}, tfy[4] = {fy01.x, fy01.y, fy23.x, fy23.y};
+  const float tnz[4] = {nz01.x, nz01.y, nz23.x, nz23.y}, tfz[4] = {fz01.x, fz01.y, fz23.x, fz23.y};
+  ref[0] = qch.x; ref[1] = qch.y; ref[2] = qch.z; ref[3] = qch.w;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float tn = fmaxf(fmaxf(fmaxf(tnx[c], tny[c]), tnz[c]), 0.0f);
+    const float tf = fminf(fminf(fminf(tfx[c], tfy[c]), tfz[c]), best_t);
+    key[c] = (tn <= tf) ? __float_as_uint(tn) : kNone;
+  }
+}
+
 #define RMCL_CSWAP(i, j)                                   \
   {                                                        \
     const bool sw_ = key[j] < key[i];                      \
@@ -101,15 +149,15 @@ __device__ __forceinline__ void trace_packet(cu32p nodes, cu32p tris, f3 O, f3 D
   uint32_t cur = 0;  // uniform; root is always an inner node
   for (;;) {
     if (!(cur & kLeafBit)) {
-      // whole node in two s_load_dwordx16: dwords 0..15 = x pairs, y pairs; 16..31 = z pairs, child[4], count
+      // whole node in two s_load_dwordx16: dwords 0..15 = x and y plane groups; 16..31 = z groups, child[4], count
       const cu32x16p np = reinterpret_cast<cu32x16p>(nodes + cur * kNodeDwords);
       const u32x16 lo = np[0], hi = np[1];
       uint32_t key[4], ref[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         float tn, tf;
-        const f2 px = {asf(lo[2 * c]), asf(lo[2 * c + 1])}, py = {asf(lo[8 + 2 * c]), asf(lo[9 + 2 * c])};
-        const f2 pz = {asf(hi[2 * c]), asf(hi[2 * c + 1])};
+        const f2 px = {asf(lo[c]), asf(lo[4 + c])}, py = {asf(lo[8 + c]), asf(lo[12 + c])};
+        const f2 pz = {asf(hi[c]), asf(hi[4 + c])};
         slab(px, py, pz, inv, noi, best_t, tn, tf);
         ref[c] = hi[8 + c];
         const uint64_t m = __ballot(tn <= tf);  // unused slots hold an unreachable box (layout.h)
@@ -169,8 +217,7 @@ __device__ __forceinline__ void trace_packet(cu32p nodes, cu32p tris, f3 O, f3 D
 __device__ __forceinline__ void trace_lane(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris,
                                            f3 O, f3 D, float ray_tfar, uint32_t* __restrict__ lds_stack,
                                            uint32_t lds_stride, RayHit& h) {
-  const f3 inv = mk3(safe_inv(D.x), safe_inv(D.y), safe_inv(D.z));
-  const f3 noi = mk3(-(O.x * inv.x), -(O.y * inv.y), -(O.z * inv.z));
+  const RaySlab rs = make_ray_slab(O, D);
   float best_t = ray_tfar;
   uint32_t best_face = kInvalidFace, best_rec = 0;
   constexpr uint32_t kDone = 0x7FFFFFFFu;
@@ -178,20 +225,8 @@ __device__ __forceinline__ void trace_lane(const uint32_t* __restrict__ nodes, c
   uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
   while (cur != kDone) {
     if (!(cur & kLeafBit)) {
-      // 7 x global_load_dwordx4: x pairs (children 0-1, 2-3), y pairs, z pairs, child[4]
-      const uint4* np = reinterpret_cast<const uint4*>(nodes) + static_cast<size_t>(cur) * 8u;
-      const uint4 qx0 = np[0], qx1 = np[1], qy0 = np[2], qy1 = np[3], qz0 = np[4], qz1 = np[5], qch = np[6];
-      const f2 bx[4] = {{asf(qx0.x), asf(qx0.y)}, {asf(qx0.z), asf(qx0.w)}, {asf(qx1.x), asf(qx1.y)}, {asf(qx1.z), asf(qx1.w)}};
-      const f2 by[4] = {{asf(qy0.x), asf(qy0.y)}, {asf(qy0.z), asf(qy0.w)}, {asf(qy1.x), asf(qy1.y)}, {asf(qy1.z), asf(qy1.w)}};
-      const f2 bz[4] = {{asf(qz0.x), asf(qz0.y)}, {asf(qz0.z), asf(qz0.w)}, {asf(qz1.x), asf(qz1.y)}, {asf(qz1.z), asf(qz1.w)}};
-      uint32_t ref[4] = {qch.x, qch.y, qch.z, qch.w};
-      uint32_t key[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float tn, tf;
-        slab(bx[c], by[c], bz[c], inv, noi, best_t, tn, tf);
-        key[c] = (tn <= tf) ? __float_as_uint(tn) : kNone;  // unused slots hold an unreachable box (layout.h)
-      }
+      uint32_t key[4], ref[4];
+      node_keys(nodes, cur, rs, best_t, key, ref);
       RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
       if (key[3] != kNone) { lds_stack[sp * lds_stride] = ref[3]; ++sp; }
       if (key[2] != kNone) { lds_stack[sp * lds_stride] = ref[2]; ++sp; }
@@ -240,8 +275,7 @@ template <int kLdsEntries>  // stack entries kept in LDS ([entry][lane]); the re
 __device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris,
                                               f3 O, f3 D, float ray_tfar, uint32_t* __restrict__ lds_stack,
                                               uint32_t lds_stride, RayHit& h) {
-  const f3 inv = mk3(safe_inv(D.x), safe_inv(D.y), safe_inv(D.z));
-  const f3 noi = mk3(-(O.x * inv.x), -(O.y * inv.y), -(O.z * inv.z));
+  const RaySlab rs = make_ray_slab(O, D);
   float best_t = ray_tfar;
   uint32_t best_face = kInvalidFace, best_rec = 0;
   constexpr uint32_t kDone = 0x7FFFFFFFu;
@@ -253,20 +287,8 @@ __device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes
   while (__any(cur != kDone)) {
     // phase 1: inner nodes
     while ((cur != kDone) && !(cur & kLeafBit)) {
-      // 7 x global_load_dwordx4: x pairs (children 0-1, 2-3), y pairs, z pairs, child[4]
-      const uint4* np = reinterpret_cast<const uint4*>(nodes) + static_cast<size_t>(cur) * 8u;
-      const uint4 qx0 = np[0], qx1 = np[1], qy0 = np[2], qy1 = np[3], qz0 = np[4], qz1 = np[5], qch = np[6];
-      const f2 bx[4] = {{asf(qx0.x), asf(qx0.y)}, {asf(qx0.z), asf(qx0.w)}, {asf(qx1.x), asf(qx1.y)}, {asf(qx1.z), asf(qx1.w)}};
-      const f2 by[4] = {{asf(qy0.x), asf(qy0.y)}, {asf(qy0.z), asf(qy0.w)}, {asf(qy1.x), asf(qy1.y)}, {asf(qy1.z), asf(qy1.w)}};
-      const f2 bz[4] = {{asf(qz0.x), asf(qz0.y)}, {asf(qz0.z), asf(qz0.w)}, {asf(qz1.x), asf(qz1.y)}, {asf(qz1.z), asf(qz1.w)}};
-      uint32_t ref[4] = {qch.x, qch.y, qch.z, qch.w};
-      uint32_t key[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float tn, tf;
-        slab(bx[c], by[c], bz[c], inv, noi, best_t, tn, tf);
-        key[c] = (tn <= tf) ? __float_as_uint(tn) : kNone;  // unused slots hold an unreachable box (layout.h)
-      }
+      uint32_t key[4], ref[4];
+      node_keys(nodes, cur, rs, best_t, key, ref);
 #ifdef RMCL_FULL_SORT
       RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
 #else
@@ -329,8 +351,7 @@ constexpr uint32_t kQuadStackEntries = 1u + 64u + 4u;            // sentinel + t
 __device__ __forceinline__ void trace_quad(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris, f3 O,
                                            f3 D, float ray_tfar, uint32_t c, uint32_t ray, uint32_t* __restrict__ lds,
                                            RayHit& h) {
-  const f3 inv = mk3(safe_inv(D.x), safe_inv(D.y), safe_inv(D.z));
-  const f3 noi = mk3(-(O.x * inv.x), -(O.y * inv.y), -(O.z * inv.z));
+  const RaySlab rs = make_ray_slab(O, D);
   float best_t = ray_tfar;
   uint32_t best_face = kInvalidFace, best_rec = 0;
   constexpr uint32_t kDone = 0x7FFFFFFFu;
@@ -343,17 +364,19 @@ __device__ __forceinline__ void trace_quad(const uint32_t* __restrict__ nodes, c
   if (c == 0u) *reinterpret_cast<uint32_t*>(sbase) = kDone;
   uint32_t spb = 256u;  // byte offset of the first free row
   uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
-  const uint32_t coff = c * 8u;
+  // this lane's planes inside a node: near / far group of each axis (sign-selected, layout.h) + its slot
+  const uint32_t onx = rs.onx + c * 4u, ofx = rs.ofx + c * 4u, ony = rs.ony + c * 4u, ofy = rs.ofy + c * 4u;
+  const uint32_t onz = rs.onz + c * 4u, ofz = rs.ofz + c * 4u, och = 96u + c * 4u;
   while (__any(cur != kDone)) {
     while (cur < kDone) {  // inner node (leaf references have bit 31 set)
-      const char* nd = nbase + (cur << 7) + coff;
-      const f2 px = *reinterpret_cast<const f2*>(nd);
-      const f2 py = *reinterpret_cast<const f2*>(nd + 32);
-      const f2 pz = *reinterpret_cast<const f2*>(nd + 64);
-      const uint32_t ref = *reinterpret_cast<const uint32_t*>(nbase + (cur << 7) + 96u + c * 4u);
+      const char* nd = nbase + (cur << 7);
+      const float pnx = *reinterpret_cast<const float*>(nd + onx), pfx = *reinterpret_cast<const float*>(nd + ofx);
+      const float pny = *reinterpret_cast<const float*>(nd + ony), pfy = *reinterpret_cast<const float*>(nd + ofy);
+      const float pnz = *reinterpret_cast<const float*>(nd + onz), pfz = *reinterpret_cast<const float*>(nd + ofz);
+      const uint32_t ref = *reinterpret_cast<const uint32_t*>(nd + och);
       const uint32_t top = *reinterpret_cast<const uint32_t*>(sbase + (spb - 256u));
-      float tn, tf;
-      slab(px, py, pz, inv, noi, best_t, tn, tf);
+      const float tn = fmaxf(fmaxf(fmaxf(fmaf(pnx, rs.inv.x, rs.noi.x), fmaf(pny, rs.inv.y, rs.noi.y)), fmaf(pnz, rs.inv.z, rs.noi.z)), 0.0f);
+      const float tf = fminf(fminf(fminf(fmaf(pfx, rs.inv.x, rs.noi.x), fmaf(pfy, rs.inv.y, rs.noi.y)), fmaf(pfz, rs.inv.z, rs.noi.z)), best_t);
       // unique keys: entry distance with the slot number in the two low mantissa bits; misses (unused slots hold
       // an unreachable box, layout.h) sort last
       const uint32_t key = ((tn <= tf) ? (__float_as_uint(tn) & ~3u) : 0xFFFFFFFCu) | c;
@@ -473,9 +496,10 @@ __device__ __forceinline__ void nearest_lane_ww(const uint32_t* __restrict__ nod
     while ((cur != kDone) && !(cur & kLeafBit)) {
       const uint4* np = reinterpret_cast<const uint4*>(nodes) + static_cast<size_t>(cur) * 8u;
       const uint4 qx0 = np[0], qx1 = np[1], qy0 = np[2], qy1 = np[3], qz0 = np[4], qz1 = np[5], qch = np[6];
-      const f2 bx[4] = {{asf(qx0.x), asf(qx0.y)}, {asf(qx0.z), asf(qx0.w)}, {asf(qx1.x), asf(qx1.y)}, {asf(qx1.z), asf(qx1.w)}};
-      const f2 by[4] = {{asf(qy0.x), asf(qy0.y)}, {asf(qy0.z), asf(qy0.w)}, {asf(qy1.x), asf(qy1.y)}, {asf(qy1.z), asf(qy1.w)}};
-      const f2 bz[4] = {{asf(qz0.x), asf(qz0.y)}, {asf(qz0.z), asf(qz0.w)}, {asf(qz1.x), asf(qz1.y)}, {asf(qz1.z), asf(qz1.w)}};
+      // (lower, upper) plane of child c per axis: q*0 hold the four lower planes, q*1 the four upper planes
+      const f2 bx[4] = {{asf(qx0.x), asf(qx1.x)}, {asf(qx0.y), asf(qx1.y)}, {asf(qx0.z), asf(qx1.z)}, {asf(qx0.w), asf(qx1.w)}};
+      const f2 by[4] = {{asf(qy0.x), asf(qy1.x)}, {asf(qy0.y), asf(qy1.y)}, {asf(qy0.z), asf(qy1.z)}, {asf(qy0.w), asf(qy1.w)}};
+      const f2 bz[4] = {{asf(qz0.x), asf(qz1.x)}, {asf(qz0.y), asf(qz1.y)}, {asf(qz0.z), asf(qz1.z)}, {asf(qz0.w), asf(qz1.w)}};
       uint32_t ref[4] = {qch.x, qch.y, qch.z, qch.w};
       uint32_t key[4];
 #pragma unroll
@@ -1295,7 +1319,8 @@ __global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
   // per-lane ray state
   uint32_t rr = 0;
   bool has_ray = false, exhausted = false;
-  f3 O = mk3(0.f, 0.f, 0.f), D = O, inv = O, noi = O;
+  f3 O = mk3(0.f, 0.f, 0.f), D = O;
+  RaySlab rs = make_ray_slab(O, mk3(1.f, 1.f, 1.f));
   float range = 0.f, best_t = 0.f;
   uint32_t best_face = kInvalidFace, best_rec = 0;
   uint32_t priv[(kLdsEntries < 64) ? (64 - kLdsEntries) : 1];
@@ -1353,8 +1378,7 @@ __global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
           D = qrot(Tsm.R, mk3(bm[3], bm[4], bm[5]));
           O = xapply(Tsm, mk3(bm[0], bm[1], bm[2]));
           range = bm[6];
-          inv = mk3(safe_inv(D.x), safe_inv(D.y), safe_inv(D.z));
-          noi = mk3(-(O.x * inv.x), -(O.y * inv.y), -(O.z * inv.z));
+          rs = make_ray_slab(O, D);
           best_t = __builtin_inff();
           best_face = kInvalidFace;
           best_rec = 0;
@@ -1369,19 +1393,8 @@ __global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
     }
     // phase 1: inner nodes (see trace_lane_ww)
     while ((cur != kDone) && !(cur & kLeafBit)) {
-      const uint4* np4 = reinterpret_cast<const uint4*>(p.nodes) + static_cast<size_t>(cur) * 8u;
-      const uint4 qx0 = np4[0], qx1 = np4[1], qy0 = np4[2], qy1 = np4[3], qz0 = np4[4], qz1 = np4[5], qch = np4[6];
-      const f2 bx[4] = {{asf(qx0.x), asf(qx0.y)}, {asf(qx0.z), asf(qx0.w)}, {asf(qx1.x), asf(qx1.y)}, {asf(qx1.z), asf(qx1.w)}};
-      const f2 by[4] = {{asf(qy0.x), asf(qy0.y)}, {asf(qy0.z), asf(qy0.w)}, {asf(qy1.x), asf(qy1.y)}, {asf(qy1.z), asf(qy1.w)}};
-      const f2 bz[4] = {{asf(qz0.x), asf(qz0.y)}, {asf(qz0.z), asf(qz0.w)}, {asf(qz1.x), asf(qz1.y)}, {asf(qz1.z), asf(qz1.w)}};
-      uint32_t ref[4] = {qch.x, qch.y, qch.z, qch.w};
-      uint32_t key[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float tn, tf;
-        slab(bx[c], by[c], bz[c], inv, noi, best_t, tn, tf);
-        key[c] = (tn <= tf) ? __float_as_uint(tn) : kNone;
-      }
+      uint32_t key[4], ref[4];
+      node_keys(p.nodes, cur, rs, best_t, key, ref);
       RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
       if (key[3] != kNone) RMCL_PUSH(ref[3])
       if (key[2] != kNone) RMCL_PUSH(ref[2])

@@ -2,15 +2,20 @@
 //
 // BVH4 node, 128 B (32 dwords), 128-B aligned: one wave fetches a whole node with two
 // s_load_dwordx16 (packet traversal) or seven global_load_dwordx4 per lane (per-lane
-// traversal).  Per axis the four children's bounds are interleaved (min, max) pairs, so a
-// child's two planes of one axis sit in ONE 64-bit register pair and the slab distances of both
-// planes are ONE packed FMA (v_pk_fma_f32):
+// traversal).  Per axis the four children's lower planes and upper planes are two separate
+// 16-B groups:
 //
-//   dword  0.. 7  x: mn0 mx0 mn1 mx1 mn2 mx2 mn3 mx3
-//   dword  8..15  y: mn0 mx0 ... mn3 mx3
-//   dword 16..23  z: mn0 mx0 ... mn3 mx3
+//   dword  0.. 3  x lower planes of children 0..3     dword  4.. 7  x upper planes
+//   dword  8..11  y lower planes                      dword 12..15  y upper planes
+//   dword 16..19  z lower planes                      dword 20..23  z upper planes
 //   dword 24..27  child[4]
 //   dword 28      number of valid children (1..4)        dword 29..31 reserved
+//
+// A ray knows from the sign of its direction which plane of an axis it enters through, so a lane
+// fetches "the four near planes" and "the four far planes" of an axis with two dwordx4 loads whose
+// offsets (0 / 16 B inside the axis group) are per-ray constants: the slab test needs no min / max to
+// order the two planes, the plane distances of two children are ONE packed FMA (v_pk_fma_f32), and the
+// entry / exit distance of a child is one v_max3 / v_min3.
 //
 // child reference: bit31 = 0 -> index of another Node4
 //                  bit31 = 1 -> leaf: bits 28..30 = count-1 (1..8 triangles),
@@ -37,7 +42,7 @@ constexpr uint32_t kInvalidFace = 0xFFFFFFFFu;
 constexpr float kFarPoint[3] = {1.0e30f, 2.0e30f, 3.0e30f};
 
 struct alignas(128) Node4 {
-  float x[8], y[8], z[8];  // per axis: mn0 mx0 mn1 mx1 mn2 mx2 mn3 mx3
+  float x[8], y[8], z[8];  // per axis: lower planes of children 0..3, then upper planes of children 0..3
   uint32_t child[4];
   uint32_t n_children;
   uint32_t reserved[3];

@@ -115,14 +115,14 @@ def test_bvh_builder_invariants(ra, orc, meshes, name):
         assert 1 <= nk <= 4
         kids = list(range(nk))
         for c in range(nk, 4):   # unused slots: unreachable point box + harmless leaf reference
-            assert fl[ref, 2 * c] == fl[ref, 2 * c + 1] >= 1e30 and nodes[ref, 24 + c] == 0x80000000
+            assert fl[ref, c] == fl[ref, 4 + c] >= 1e30 and nodes[ref, 24 + c] == 0x80000000
         for c in kids:
             child = int(nodes[ref, 24 + c])
             if not child & 0x80000000:
                 assert child > ref  # breadth-first order: children come later
             clo, chi, d, s = subtree_bounds(child, depth + 1, stack + len(kids) - 1)
-            bmin = np.array([fl[ref, 0 + 2 * c], fl[ref, 8 + 2 * c], fl[ref, 16 + 2 * c]])
-            bmax = np.array([fl[ref, 1 + 2 * c], fl[ref, 9 + 2 * c], fl[ref, 17 + 2 * c]])
+            bmin = np.array([fl[ref, 0 + c], fl[ref, 8 + c], fl[ref, 16 + c]])
+            bmax = np.array([fl[ref, 4 + c], fl[ref, 12 + c], fl[ref, 20 + c]])
             assert np.all(bmin <= clo) and np.all(bmax >= chi)       # (padded) box contains the subtree
             lo, hi, dmax, smax = np.minimum(lo, clo), np.maximum(hi, chi), max(dmax, d), max(smax, s)
         return lo, hi, dmax, smax
