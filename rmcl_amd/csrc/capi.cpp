@@ -680,7 +680,8 @@ rmclhip_status rmclhip_rcc_find_cpc(rmclhip_rcc* r, const rmclhip_transform* Tbm
   r->nposes_last = 1;
   const xform Tsm = xmul(to_x(Tbm_est), r->Tsb);
   HIPCHK(launch_cpc_find(r->map->d_nodes, r->map->d_tris, r->d_ds_points.p, r->n_dataset, r->max_dist, Tsm, xinv(Tsm),
-                         r->d_hits.p, r->d_ranges.p, r->d_points.p, r->d_normals.p, r->d_face_ids.p, r->stream));
+                         r->d_hits.p, r->d_ranges.p, r->d_points.p, r->d_normals.p, r->d_face_ids.p,
+                         (r->variant == 15) ? true : (r->variant == 2), r->stream));
   HIPCHK(hipStreamSynchronize(r->stream));
   return RMCLHIP_OK;
 }

@@ -545,6 +545,90 @@ __device__ __forceinline__ void nearest_lane_ww(const uint32_t* __restrict__ nod
   h.p = best_p;
 }
 
+// closest-point query with FOUR lanes per point (see trace_quad): lane c measures the distance to child box c and
+// runs Ericson's closest-point-on-triangle for triangle c of a leaf -- the expensive, branchy part of this query is
+// done for up to four triangles at once; (d2, face id) ties resolve exactly like nearest_lane_ww.
+__device__ __forceinline__ void nearest_quad(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris, f3 P,
+                                             bool active, uint32_t c, uint32_t ray, uint32_t* __restrict__ lds, NearHit& h) {
+  float best = 3.0e38f;
+  uint32_t best_face = kInvalidFace, best_rec = 0;
+  f3 best_p = mk3(0.f, 0.f, 0.f);
+  constexpr uint32_t kDone = 0x7FFFFFFFu;
+  const char* nbase = reinterpret_cast<const char*>(nodes);
+  char* sbase = reinterpret_cast<char*>(lds) + ray * 4u;
+  if (c == 0u) *reinterpret_cast<uint32_t*>(sbase) = kDone;  // sentinel row (see trace_quad)
+  uint32_t spb = 256u;
+  uint32_t cur = active ? 0u : kDone;
+  const uint32_t coff = c * 4u;
+  while (__any(cur != kDone)) {
+    while (cur < kDone) {
+      const char* nd = nbase + (cur << 7) + coff;
+      const float lx = *reinterpret_cast<const float*>(nd), hx = *reinterpret_cast<const float*>(nd + 16);
+      const float ly = *reinterpret_cast<const float*>(nd + 32), hy = *reinterpret_cast<const float*>(nd + 48);
+      const float lz = *reinterpret_cast<const float*>(nd + 64), hz = *reinterpret_cast<const float*>(nd + 80);
+      const uint32_t ref = *reinterpret_cast<const uint32_t*>(nd + 96);
+      const uint32_t top = *reinterpret_cast<const uint32_t*>(sbase + (spb - 256u));
+      const float dx = fmaxf(fmaxf(lx - P.x, P.x - hx), 0.f);
+      const float dy = fmaxf(fmaxf(ly - P.y, P.y - hy), 0.f);
+      const float dz = fmaxf(fmaxf(lz - P.z, P.z - hz), 0.f);
+      const float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+      const uint32_t key = ((d2 <= best) ? (__float_as_uint(d2) & ~3u) : 0xFFFFFFFCu) | c;
+      const uint32_t k1 = quad_dpp<kQuadXor1>(key), k2 = quad_dpp<kQuadXor2>(key), k3 = quad_dpp<kQuadXor3>(key);
+      const uint32_t rank = (k1 < key ? 1u : 0u) + (k2 < key ? 1u : 0u) + (k3 < key ? 1u : 0u);
+      const uint32_t kmin = min(min(key, k1), min(k2, k3));
+      const uint32_t nh = (key < 0xFFFFFFFCu ? 1u : 0u) + (k1 < 0xFFFFFFFCu ? 1u : 0u) + (k2 < 0xFFFFFFFCu ? 1u : 0u) +
+                          (k3 < 0xFFFFFFFCu ? 1u : 0u);
+      const uint32_t sel = (key == kmin) ? ref : 0u;
+      const uint32_t s1 = sel | quad_dpp<kQuadXor1>(sel);
+      const uint32_t nearest = s1 | quad_dpp<kQuadXor2>(s1);
+      const uint32_t row = (rank < nh) ? (nh - 1u - rank) : rank;
+      *reinterpret_cast<uint32_t*>(sbase + spb + (row << 8)) = ref;
+      const bool any = nh != 0u;
+      cur = any ? nearest : top;
+      spb = any ? (spb + ((nh - 1u) << 8)) : (spb - 256u);
+    }
+    if (cur != kDone) {
+      const uint32_t first = cur & 0x0FFFFFFFu;
+      const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
+      const uint32_t idx = first + ((c < cnt) ? c : (cnt - 1u));
+      const uint4* tp = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(idx) * 4u;
+      const uint4 a = tp[0], b = tp[1], cc = tp[2], d = tp[3];
+      const uint32_t top = *reinterpret_cast<const uint32_t*>(sbase + (spb - 256u));
+      const f3 v0 = mk3(asf(a.x), asf(a.y), asf(a.z));
+      const f3 e1 = mk3(asf(a.w), asf(b.x), asf(b.y));
+      const f3 e2 = mk3(asf(b.z), asf(b.w), asf(cc.x));
+      f3 cq = closest_point_triangle(v0, e1, e2, P);
+      const f3 df = sub3(P, cq);
+      const float d2 = (df.x * df.x + df.y * df.y) + df.z * df.z;
+      const bool valid = c < cnt;
+      float cd = valid ? d2 : __builtin_inff();
+      uint32_t cf = valid ? d.w : kInvalidFace, cr = idx;
+#define RMCL_QMIN(CTRL)                                                                               \
+      {                                                                                               \
+        const float od = __uint_as_float(quad_dpp<CTRL>(__float_as_uint(cd)));                        \
+        const uint32_t of = quad_dpp<CTRL>(cf), orr = quad_dpp<CTRL>(cr);                             \
+        const float ox = __uint_as_float(quad_dpp<CTRL>(__float_as_uint(cq.x)));                      \
+        const float oy = __uint_as_float(quad_dpp<CTRL>(__float_as_uint(cq.y)));                      \
+        const float oz = __uint_as_float(quad_dpp<CTRL>(__float_as_uint(cq.z)));                      \
+        const bool take = (od < cd) || ((od == cd) && (of < cf));                                     \
+        cd = take ? od : cd; cf = take ? of : cf; cr = take ? orr : cr;                               \
+        cq.x = take ? ox : cq.x; cq.y = take ? oy : cq.y; cq.z = take ? oz : cq.z;                    \
+      }
+      RMCL_QMIN(kQuadXor1)
+      RMCL_QMIN(kQuadXor2)
+#undef RMCL_QMIN
+      const bool closer = (cf != kInvalidFace) && ((cd < best) || ((cd == best) && (cf < best_face)));
+      if (closer) { best = cd; best_face = cf; best_rec = cr; best_p = cq; }
+      cur = top;
+      spb -= 256u;
+    }
+  }
+  h.d2 = best;
+  h.face = best_face;
+  h.rec = best_rec;
+  h.p = best_p;
+}
+
 struct CpcParams {
   const uint32_t* nodes;
   const uint32_t* tris;
@@ -559,34 +643,44 @@ struct CpcParams {
   uint32_t* face_ids;
 };
 
+// kQuad: four lanes per dataset point (64 points per block) instead of one
+template <bool kQuad>
 __global__ void __launch_bounds__(256) k_cpc_find(const CpcParams p) {
   extern __shared__ uint32_t lds_dyn[];
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t sub = threadIdx.x & 3u;
+  const uint32_t i = kQuad ? (blockIdx.x * 64u + (threadIdx.x >> 2)) : (blockIdx.x * blockDim.x + threadIdx.x);
   const bool live = i < p.n;
   const uint32_t ii = live ? i : 0u;
   const float* dp = p.dataset_points + 3 * static_cast<size_t>(ii);
   const f3 Pm = xapply(p.Tsm, mk3(dp[0], dp[1], dp[2]));
   const bool finite = (Pm.x == Pm.x) && (Pm.y == Pm.y) && (Pm.z == Pm.z);
   NearHit h;
-  nearest_lane_ww<16>(p.nodes, p.tris, Pm, live && finite, lds_dyn + threadIdx.x, blockDim.x, h);
+  if (kQuad) nearest_quad(p.nodes, p.tris, Pm, live && finite, sub, threadIdx.x >> 2, lds_dyn, h);
+  else nearest_lane_ww<16>(p.nodes, p.tris, Pm, live && finite, lds_dyn + threadIdx.x, blockDim.x, h);
   if (!live) return;
+  // quad: the four lanes of a point hold the same result and share the stores
+  const bool w0 = !kQuad || sub == 0u, w1 = !kQuad || sub == 1u, w2 = !kQuad || sub == 2u;
   if (h.face != kInvalidFace) {
     const float d = sqrtf(h.d2);
-    const uint4 nrec = reinterpret_cast<const uint4*>(p.tris)[static_cast<size_t>(h.rec) * 4u + 3u];
-    const f3 ps = xapply(p.Tms, h.p);
-    const f3 ns = qrot(p.Tms.R, mk3(asf(nrec.x), asf(nrec.y), asf(nrec.z)));
-    if (p.hits) p.hits[i] = (d <= p.max_dist) ? 1 : 0;
-    if (p.dists) p.dists[i] = d;
-    if (p.points) { p.points[3 * i] = ps.x; p.points[3 * i + 1] = ps.y; p.points[3 * i + 2] = ps.z; }
-    if (p.normals) { p.normals[3 * i] = ns.x; p.normals[3 * i + 1] = ns.y; p.normals[3 * i + 2] = ns.z; }
-    if (p.face_ids) p.face_ids[i] = h.face;
+    if (p.hits && w0) p.hits[i] = (d <= p.max_dist) ? 1 : 0;
+    if (p.dists && w0) p.dists[i] = d;
+    if (p.points && w1) {
+      const f3 ps = xapply(p.Tms, h.p);
+      p.points[3 * i] = ps.x; p.points[3 * i + 1] = ps.y; p.points[3 * i + 2] = ps.z;
+    }
+    if (p.normals && w2) {
+      const uint4 nrec = reinterpret_cast<const uint4*>(p.tris)[static_cast<size_t>(h.rec) * 4u + 3u];
+      const f3 ns = qrot(p.Tms.R, mk3(asf(nrec.x), asf(nrec.y), asf(nrec.z)));
+      p.normals[3 * i] = ns.x; p.normals[3 * i + 1] = ns.y; p.normals[3 * i + 2] = ns.z;
+    }
+    if (p.face_ids && w0) p.face_ids[i] = h.face;
   } else {
     const float qn = __uint_as_float(0x7FC00000u);
-    if (p.hits) p.hits[i] = 0;
-    if (p.dists) p.dists[i] = qn;
-    if (p.points) { p.points[3 * i] = qn; p.points[3 * i + 1] = qn; p.points[3 * i + 2] = qn; }
-    if (p.normals) { p.normals[3 * i] = qn; p.normals[3 * i + 1] = qn; p.normals[3 * i + 2] = qn; }
-    if (p.face_ids) p.face_ids[i] = kInvalidFace;
+    if (p.hits && w0) p.hits[i] = 0;
+    if (p.dists && w0) p.dists[i] = qn;
+    if (p.points && w1) { p.points[3 * i] = qn; p.points[3 * i + 1] = qn; p.points[3 * i + 2] = qn; }
+    if (p.normals && w2) { p.normals[3 * i] = qn; p.normals[3 * i + 1] = qn; p.normals[3 * i + 2] = qn; }
+    if (p.face_ids && w0) p.face_ids[i] = kInvalidFace;
   }
 }
 
@@ -1650,12 +1744,13 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
 
 hipError_t launch_cpc_find(const uint32_t* nodes, const uint32_t* tris, const float* dataset_points, uint32_t n,
                            float max_dist, xform Tsm, xform Tms, uint8_t* hits, float* dists, float* points,
-                           float* normals, uint32_t* face_ids, hipStream_t s) {
+                           float* normals, uint32_t* face_ids, bool quad, hipStream_t s) {
   if (n == 0) return hipSuccess;
   CpcParams p;
   p.nodes = nodes; p.tris = tris; p.dataset_points = dataset_points; p.n = n; p.max_dist = max_dist;
   p.Tsm = Tsm; p.Tms = Tms; p.hits = hits; p.dists = dists; p.points = points; p.normals = normals; p.face_ids = face_ids;
-  hipLaunchKernelGGL(k_cpc_find, dim3((n + 255u) / 256u), dim3(256), 16u * 256u * sizeof(uint32_t), s, p);
+  if (quad) hipLaunchKernelGGL((k_cpc_find<true>), dim3((n + 63u) / 64u), dim3(256), kQuadStackEntries * 64u * sizeof(uint32_t), s, p);
+  else hipLaunchKernelGGL((k_cpc_find<false>), dim3((n + 255u) / 256u), dim3(256), 16u * 256u * sizeof(uint32_t), s, p);
   return hipGetLastError();
 }
 

@@ -18,8 +18,9 @@ def _cmp(gpu, ref, what):
     assert_close_rel(gpu["normals"], ref["normals"], 1e-5, 1e-6, what + " normals")
 
 
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("mesh_name", ["cube", "room30k"])
-def test_cpc_find_matches_oracle(ra, orc, ctx, meshes, mesh_name):
+def test_cpc_find_matches_oracle(ra, orc, ctx, meshes, mesh_name, variant):
     from rmcl_amd import synthetic as syn, types as T
     v, f = meshes(mesh_name)
     m = orc.Mesh(v, f)
@@ -32,6 +33,7 @@ def test_cpc_find_matches_oracle(ra, orc, ctx, meshes, mesh_name):
     ds, mask = om.dataset_from_ranges(model, meas["ranges"])
     ds[5] = np.nan                                # invalid point of an organised cloud
     cpc = ra.CPCHip(hm)
+    cpc.set_variant(variant)          # 1: one lane per point, 2: four lanes per point
     cpc.setTsb(Tsb)
     cpc.params.max_dist = 0.3
     cpc.adaptive_max_dist_min = 0.3
@@ -48,7 +50,8 @@ def test_cpc_find_matches_oracle(ra, orc, ctx, meshes, mesh_name):
     assert np.allclose(s["covariance"].reshape(3, 3), r["covariance"], rtol=1e-5, atol=1e-6)
 
 
-def test_cpc_points_on_surface_and_ties(ra, orc, ctx, meshes):
+@pytest.mark.parametrize("variant", [1, 2])
+def test_cpc_points_on_surface_and_ties(ra, orc, ctx, meshes, variant):
     """query points exactly on shared edges / vertices (distance 0, several equidistant triangles): the
     (min distance, min face id) tie-break must agree with the brute-force oracle."""
     from rmcl_amd import types as T
@@ -57,6 +60,7 @@ def test_cpc_points_on_surface_and_ties(ra, orc, ctx, meshes):
     hm = ra.import_hip_map(ctx, v, f)
     pts = np.concatenate([v[::7], (v[f[::11, 0]] + v[f[::11, 1]]) * np.float32(0.5), np.zeros((1, 3), np.float32)]).astype(np.float32)
     cpc = ra.CPCHip(hm)
+    cpc.set_variant(variant)
     cpc.setTsb(T.identity())
     cpc.params.max_dist = 10.0
     cpc.set_dataset(pts, None)
