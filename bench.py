@@ -334,9 +334,21 @@ def _pf_c4(ra, syn, T, np, ctx, hm, n_particles, n_beams, iters):
     return ms, n_particles * n_beams
 
 
+def _median_call_ms(fn, reps=25, warm=3):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t1 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t1)
+    ts.sort()
+    return ts[len(ts) // 2] * 1e3
+
+
 def _pf_cycle(ra, syn, T, np, ctx, hm, n_particles):
     """one particle-filter cycle besides the sensor update: motion update (with the wall-collision ray),
-    likelihood statistics and the gladiator tournament, wall-clock per call (synchronous ABI calls)."""
+    likelihood statistics and the gladiator tournament; median wall clock of the synchronous ABI calls."""
     poses, attrs = syn.uniform_particles(n_particles, seed=43, bb_min=(-5, -5, -1, 0, 0, -math.pi), bb_max=(5, 5, 1, 0, 0, math.pi))
     attrs["likelihood"]["mean"] = np.random.RandomState(1).uniform(0, 1, n_particles)
     attrs["likelihood"]["n_meas"] = 5000
@@ -346,22 +358,12 @@ def _pf_cycle(ra, syn, T, np, ctx, hm, n_particles):
     step = T.transform_from_rpy((0.05, 0.0, 0.0), (0.0, 0.0, 0.01))
     for coll in (False, True):
         mo = ra.TFMotionUpdaterHip(hm, check_collision=coll)
-        mo.update(d_p, d_a, n_particles, step, 0.001)
-        t1 = time.perf_counter()
-        for _ in range(20):
-            mo.update(d_p, d_a, n_particles, step, 0.001)
-        out["pf_motion_update%s_ms" % ("_collision" if coll else "")] = round((time.perf_counter() - t1) / 20 * 1e3, 4)
+        out["pf_motion_update%s_ms" % ("_collision" if coll else "")] = round(
+            _median_call_ms(lambda: mo.update(d_p, d_a, n_particles, step, 0.001)), 4)
         mo.close()
     rs = ra.GladiatorResamplerHip(ctx)
-    rs.update(d_p, d_a, d_pn, d_an, n_particles)
-    t1 = time.perf_counter()
-    for _ in range(20):
-        rs.update(d_p, d_a, d_pn, d_an, n_particles)
-    out["pf_resample_gladiator_ms"] = round((time.perf_counter() - t1) / 20 * 1e3, 4)
-    t1 = time.perf_counter()
-    for _ in range(20):
-        rs.compute_stats(d_a, n_particles)
-    out["pf_likelihood_stats_ms"] = round((time.perf_counter() - t1) / 20 * 1e3, 4)
+    out["pf_resample_gladiator_ms"] = round(_median_call_ms(lambda: rs.update(d_p, d_a, d_pn, d_an, n_particles)), 4)
+    out["pf_likelihood_stats_ms"] = round(_median_call_ms(lambda: rs.compute_stats(d_a, n_particles)), 4)
     rs.close()
     return out
 

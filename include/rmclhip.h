@@ -151,6 +151,10 @@ rmclhip_status rmclhip_bvh_build_host(const float* vertices_xyz, uint32_t n_vert
                                       const uint32_t* faces_ijk, uint32_t n_faces,
                                       rmclhip_map_info* info, uint32_t* nodes_out, size_t nodes_cap_dwords,
                                       uint32_t* tris_out, size_t tris_cap_dwords);
+/* the 64-B quantised twins of the nodes (layout.h: Node4Q, 16 dwords each, same indices and child references as the
+ * Node4 array of rmclhip_bvh_build_host): what the incoherent traversals (particle filter, pose batches) read */
+rmclhip_status rmclhip_bvh_build_host_quantised(const float* vertices_xyz, uint32_t n_vertices, const uint32_t* faces_ijk,
+                                                uint32_t n_faces, uint32_t* qnodes_out, size_t qnodes_capacity_dwords);
 
 /* ---- ray-casting correspondences (MICP-L) ------------------------------------------
  * rmcl::RCCEmbreeSpherical / RCCEmbreeO1Dn / RCCOptixSpherical
@@ -245,8 +249,9 @@ rmclhip_status rmclhip_rcc_time_find(rmclhip_rcc* rcc, const rmclhip_transform* 
 rmclhip_status rmclhip_rcc_time_reduce(rmclhip_rcc* rcc, const rmclhip_transform* T_snew_sold, uint32_t iters,
                                        float* ms_per_launch);
 /* kernel variant selection: bits 0..3 traversal (15 = automatic, the default: four lanes per ray
- * up to 65536 rays in flight, one lane per ray above; 0 = wave packet, 1 = one lane per ray, 2 = four lanes per
- * ray), bits 4..7 = 1 + log2(tile width) of the wave's scan-image tile (0 = automatic, 8x8 for tall images),
+ * up to 65536 rays in flight, one lane per ray up to 262144, one lane per ray on the 64-B quantised nodes above;
+ * 0 = wave packet, 1 = one lane per ray, 2 = four lanes per ray, 4 = one lane per ray on quantised nodes),
+ * bits 4..7 = 1 + log2(tile width) of the wave's scan-image tile (0 = automatic, 8x8 for tall images),
  * bit 8 = fused last-block reduction tail (A/B), bit 9 = disable the hipGraph MICP loop (A/B), bits 10..12 = form
  * of the MICP loop (0 = one launch per iteration, the default; 1 = reduce + solve launches; 2..6 = persistent
  * kernel with 16..256 blocks and a grid barrier, A/B) */
@@ -314,7 +319,8 @@ rmclhip_status rmclhip_pf_time_update(rmclhip_pf* pf, const rmclhip_transform* p
                                       const rmclhip_transform* Tsb, uint32_t iters, float* ms_per_launch);
 /* bits 0..3: traversal (0 = while-while with the hybrid LDS + scratch stack, 1 = stack entirely in LDS, 2 = single
  * loop, A/B); bits 4..6: ray scheduling (0 = rounds of one ray per lane; 1..4 = persistent lanes that fetch the
- * next ray when 8 / 16 / 32 / 48 lanes of their wave are idle).  A fresh handle uses traversal 0, refill at 32. */
+ * next ray when 8 / 16 / 32 / 48 lanes of their wave are idle); bit 7: persistent lanes on the 128-B nodes instead
+ * of their 64-B quantised twins (A/B).  A fresh handle uses traversal 0, refill at 32, quantised nodes. */
 rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* pf, int variant);
 
 

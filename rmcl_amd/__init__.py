@@ -9,6 +9,7 @@ from .micp import MICPLocalization, MICPSensor  # noqa: F401
 from .pf import (GladiatorResamplerHip, PCDSensorUpdaterHip, TFMotionUpdaterHip, beams_from_points, combined_forget_rate,  # noqa: F401
                  sample_beams)
 from .registration import (CPCHip, Context, CorrespondencesHIP, DeviceArray, HipMap, MapMap, RCCHipO1Dn,  # noqa: F401
-                           RCCHipOnDn, RCCHipPinhole, RCCHipSpherical, build_bvh_host, import_hip_map)
+                           RCCHipOnDn, RCCHipPinhole, RCCHipSpherical, build_bvh_host, build_bvh_host_quantised,
+                           import_hip_map)
 
 __version__ = "0.1.0"

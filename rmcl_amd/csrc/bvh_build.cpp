@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstring>
 #include <deque>
+#include <limits>
 
 namespace rmclhip {
 namespace {
@@ -261,6 +262,46 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
   }
   // BFS: the i-th pushed inner child receives Node4 id (i+1)
   for (size_t i = 0; i < patch.size(); ++i) out.nodes[patch[i].first].child[patch[i].second] = static_cast<uint32_t>(i + 1);
+
+  // quantised twins (layout.h): per node, corner + step of an 8-bit grid that covers all (padded) child boxes; lower
+  // planes round down, upper planes up, checked in the arithmetic the decode uses
+  out.qnodes.resize(out.nodes.size());
+  for (size_t i = 0; i < out.nodes.size(); ++i) {
+    const Node4& nd = out.nodes[i];
+    Node4Q& q = out.qnodes[i];
+    std::memset(&q, 0, sizeof(q));
+    const float* lohi[3] = {nd.x, nd.y, nd.z};
+    uint32_t* qlo[3] = {&q.qx_lo, &q.qy_lo, &q.qz_lo};
+    uint32_t* qhi[3] = {&q.qx_hi, &q.qy_hi, &q.qz_hi};
+    for (int a = 0; a < 3; ++a) {
+      float mn = std::numeric_limits<float>::infinity(), mx = -std::numeric_limits<float>::infinity();
+      for (uint32_t c = 0; c < nd.n_children; ++c) { mn = std::min(mn, lohi[a][c]); mx = std::max(mx, lohi[a][4 + c]); }
+      float sc = (mx - mn) / 255.0f;
+      if (!(sc > 1e-30f)) sc = 1e-30f;
+      while (mn + 255.0f * sc < mx) sc = std::nextafter(sc, std::numeric_limits<float>::infinity());
+      q.origin[a] = mn;
+      q.scale[a] = sc;
+      uint32_t lo_word = 0, hi_word = 0;
+      for (uint32_t c = 0; c < 4; ++c) {
+        uint32_t l = 255u, h = 0u;  // unused slot: inverted
+        if (c < nd.n_children) {
+          const double dl = (static_cast<double>(lohi[a][c]) - mn) / sc, dh = (static_cast<double>(lohi[a][4 + c]) - mn) / sc;
+          int il = static_cast<int>(std::floor(dl)), ih = static_cast<int>(std::ceil(dh));
+          il = std::max(0, std::min(255, il));
+          ih = std::max(0, std::min(255, ih));
+          while (il > 0 && mn + static_cast<float>(il) * sc > lohi[a][c]) --il;
+          while (ih < 255 && mn + static_cast<float>(ih) * sc < lohi[a][4 + c]) ++ih;
+          l = static_cast<uint32_t>(il);
+          h = static_cast<uint32_t>(ih);
+        }
+        lo_word |= l << (8u * c);
+        hi_word |= h << (8u * c);
+      }
+      *qlo[a] = lo_word;
+      *qhi[a] = hi_word;
+    }
+    for (int c = 0; c < 4; ++c) q.child[c] = nd.child[c];
+  }
 
   out.info.n_faces = nf;
   out.info.n_vertices = nv;

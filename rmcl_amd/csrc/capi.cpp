@@ -100,6 +100,7 @@ struct rmclhip_map {
   std::atomic<int> refs{1};
   BvhInfo info;
   uint32_t* d_nodes = nullptr;
+  uint32_t* d_qnodes = nullptr;  // Node4Q twins
   uint32_t* d_tris = nullptr;
   uint64_t bytes = 0;
 };
@@ -178,6 +179,7 @@ struct rmclhip_pf {
   size_t h_beams_cap = 0;
   float* errors_dev = nullptr;
   int variant = 0;
+  bool full_nodes = false;  // A/B: persistent lanes on the 128-B nodes instead of their 64-B quantised twins
   int refill = 3;  // 0: rounds of one ray per lane; 1..4: persistent lanes (dynamic ray fetch), refill when 8/16/32/48
                    // lanes of a wave are idle (default 32: measured 5 % / 10 % faster than rounds on sphere / room)
 };
@@ -260,6 +262,19 @@ rmclhip_status rmclhip_bvh_build_host(const float* v, uint32_t nv, const uint32_
   return RMCLHIP_OK;
 }
 
+rmclhip_status rmclhip_bvh_build_host_quantised(const float* v, uint32_t nv, const uint32_t* f, uint32_t nf,
+                                                uint32_t* qnodes_out, size_t qnodes_cap) {
+  ApiGuard guard_("rmclhip_bvh_build_host_quantised");
+  if (!qnodes_out) return fail(RMCLHIP_ERR_INVALID, "bvh_build_host_quantised: null");
+  BvhHost bvh;
+  const std::string err = build_bvh(v, nv, f, nf, bvh);
+  if (!err.empty()) return fail(RMCLHIP_ERR_INVALID, "bvh_build_host_quantised: " + err);
+  const size_t qd = bvh.qnodes.size() * (sizeof(Node4Q) / 4);
+  if (qnodes_cap < qd) return fail(RMCLHIP_ERR_INVALID, "bvh_build_host_quantised: buffer too small");
+  std::memcpy(qnodes_out, bvh.qnodes.data(), qd * 4);
+  return RMCLHIP_OK;
+}
+
 rmclhip_status rmclhip_map_create(rmclhip_ctx* ctx, const float* v, uint32_t nv, const uint32_t* f, uint32_t nf,
                                   rmclhip_map** out) {
   ApiGuard guard_("rmclhip_map_create");
@@ -282,15 +297,19 @@ rmclhip_status rmclhip_map_create(rmclhip_ctx* ctx, const float* v, uint32_t nv,
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_tris), tb + tb_pad);
   if (e == hipSuccess) e = hipMemset(reinterpret_cast<char*>(m->d_tris) + tb, 0, tb_pad);
   if (e == hipSuccess) e = hipMemcpy(m->d_nodes, bvh.nodes.data(), nb, hipMemcpyHostToDevice);
+  const size_t qb = bvh.qnodes.size() * sizeof(Node4Q);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_qnodes), qb);
+  if (e == hipSuccess) e = hipMemcpy(m->d_qnodes, bvh.qnodes.data(), qb, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(m->d_tris, bvh.tris.data(), tb, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     if (m->d_nodes) (void)hipFree(m->d_nodes);
+    if (m->d_qnodes) (void)hipFree(m->d_qnodes);
     if (m->d_tris) (void)hipFree(m->d_tris);
     delete m;
     return fail(e == hipErrorOutOfMemory ? RMCLHIP_ERR_NOMEM : RMCLHIP_ERR_HIP,
                 std::string("map_create upload: ") + hipGetErrorString(e));
   }
-  m->bytes = nb + tb;
+  m->bytes = nb + qb + tb;
   *out = m;
   return RMCLHIP_OK;
 }
@@ -308,6 +327,7 @@ void rmclhip_map_release(rmclhip_map* map) {
   if (map->refs.fetch_sub(1) == 1) {
     (void)hipSetDevice(map->ctx->device);
     if (map->d_nodes) (void)hipFree(map->d_nodes);
+    if (map->d_qnodes) (void)hipFree(map->d_qnodes);
     if (map->d_tris) (void)hipFree(map->d_tris);
     delete map;
   }
@@ -607,17 +627,19 @@ static rmclhip_status ensure_model_buffers(rmclhip_rcc* r, size_t n_total) {
   return RMCLHIP_OK;
 }
 
-// traversal kind of a launch of `nposes` scans (tools/latency_explore.py: the quad traversal wins up to ~64 k rays
-// in flight, above that four lanes per ray cost more issue slots than the shorter chains save)
+// traversal kind of a launch of `nposes` scans (tools/latency_explore.py, tools/perf_explore.py)
 static int find_variant(const rmclhip_rcc* r, uint32_t nposes) {
   if (r->variant != 15) return r->variant;
   const uint64_t rays = static_cast<uint64_t>(r->W) * r->H * nposes;
-  return (rays <= 65536u) ? 2 : 1;
+  if (rays <= 65536u) return 2;   // bound by the slowest ray's fetch chain: four lanes per ray
+  if (rays <= 262144u) return 1;  // one scan fills the chip once: one lane per ray, full-precision nodes
+  return 4;                       // batches are bound by L1 accesses: one lane per ray on the 64-B quantised nodes
 }
 
 static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
   std::memset(&p, 0, sizeof(p));
   p.nodes = r->map->d_nodes;
+  p.qnodes = r->map->d_qnodes;
   p.tris = r->map->d_tris;
   p.model_tab = r->d_model_tab.p;
   p.W = r->W; p.H = r->H;
@@ -1014,7 +1036,7 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
   ApiGuard guard_("rmclhip_rcc_set_variant");
   if (!r || variant < 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: bad arguments");
   const int kind = variant & 0xF, tile = (variant >> 4) & 0xF;
-  if ((kind > 2 && kind != 15) || tile > 7 || (variant >> 13) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
+  if ((kind > 4 && kind != 15) || kind == 3 || tile > 7 || (variant >> 13) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
   r->variant = kind;
   r->tile_override = tile;
   r->fused_tail = ((variant >> 8) & 1) != 0;
@@ -1190,6 +1212,7 @@ static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, 
   PfParams p;
   std::memset(&p, 0, sizeof(p));
   p.nodes = f->map->d_nodes;
+  p.qnodes = f->map->d_qnodes;
   p.tris = f->map->d_tris;
   p.poses = reinterpret_cast<const xform*>(poses);
   p.attrs = attrs;
@@ -1213,7 +1236,7 @@ static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, 
   if (static_cast<size_t>(pb) * n_beams > 8192u) return fail(RMCLHIP_ERR_UNSUPPORTED, "pf_update: more than 8192 beams");
   p.particles_per_block = pb;
   const int variant = (f->variant & 3) | ((f->map->info.stack_need > 32) ? 4 : 0) | (f->params.correspondence_type == 1u ? 8 : 0) |
-                      (f->refill << 4);
+                      (f->refill << 4) | (f->full_nodes ? 128 : 0);
   HIPCHK(launch_pf_update(p, variant, f->stream));
   return RMCLHIP_OK;
 }
@@ -1255,7 +1278,7 @@ rmclhip_status rmclhip_pf_motion_update(rmclhip_pf* f, rmclhip_transform* poses_
   if (n == 0) return RMCLHIP_OK;
   if (!poses_dev || !attrs_dev) return fail(RMCLHIP_ERR_INVALID, "pf_motion_update: null buffers");
   HIPCHK(hipSetDevice(f->ctx->device));
-  HIPCHK(launch_pf_motion(f->map->d_nodes, f->map->d_tris, reinterpret_cast<xform*>(poses_dev), attrs_dev, n,
+  HIPCHK(launch_pf_motion(f->map->d_qnodes, f->map->d_tris, reinterpret_cast<xform*>(poses_dev), attrs_dev, n,
                           to_x(T_bnew_bold), forget_rate, f->params.max_n_meas, check_collision != 0, f->stream));
   HIPCHK(hipStreamSynchronize(f->stream));
   return RMCLHIP_OK;
@@ -1294,9 +1317,10 @@ rmclhip_status rmclhip_pf_time_update(rmclhip_pf* f, const rmclhip_transform* po
 
 rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* f, int variant) {
   ApiGuard guard_("rmclhip_pf_set_variant");
-  if (!f || variant < 0 || (variant & 15) > 2 || (variant >> 4) > 4) return fail(RMCLHIP_ERR_INVALID, "pf_set_variant: bad arguments");
+  if (!f || variant < 0 || (variant & 15) > 2 || ((variant >> 4) & 7) > 4 || (variant >> 8) != 0) return fail(RMCLHIP_ERR_INVALID, "pf_set_variant: bad arguments");
   f->variant = variant & 15;
-  f->refill = variant >> 4;
+  f->refill = (variant >> 4) & 7;
+  f->full_nodes = ((variant >> 7) & 1) != 0;
   return RMCLHIP_OK;
 }
 

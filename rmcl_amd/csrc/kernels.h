@@ -14,6 +14,7 @@ enum ModelKind : uint32_t { kModelNone = 0, kModelSpherical = 1, kModelO1Dn = 2,
 // one find() launch: every ray of (nposes x H x W)
 struct FindParams {
   const uint32_t* nodes;   // Node4[]
+  const uint32_t* qnodes;  // Node4Q[] (quantised twins)
   const uint32_t* tris;    // TriRec[]
   // spherical: [cos(phi_v) (H) | sin(phi_v) (H) | cos(theta_h) (W) | sin(theta_h) (W)], host libm values
   // o1dn:      dirs xyz (W*H*3)
@@ -68,6 +69,7 @@ struct ReduceParams {
 
 struct PfParams {
   const uint32_t* nodes;
+  const uint32_t* qnodes;         // quantised twins (Node4Q), nullable
   const uint32_t* tris;
   const xform* poses;            // Tbm per particle
   void* attrs;                   // rmclhip_particle_attributes[n]

@@ -124,6 +124,31 @@ __device__ __forceinline__ void node_keys(const uint32_t* __restrict__ nodes, ui
   }
 }
 
+// node_keys on the quantised twin of the node (layout.h: Node4Q): FOUR loads instead of seven.  The plane distance
+// t = (origin + q*scale - O) * inv is evaluated as q * (scale*inv) + (origin*inv - O*inv): six per-node
+// instructions, then one (packed) FMA per plane as before; the bytes are widened with v_cvt_f32_ubyteN.
+__device__ __forceinline__ void node_keys_q(const uint32_t* __restrict__ qnodes, uint32_t cur, const RaySlab& rs, float best_t,
+                                            uint32_t (&key)[4], uint32_t (&ref)[4]) {
+  const uint4* nb = reinterpret_cast<const uint4*>(qnodes) + static_cast<size_t>(cur) * 4u;
+  const uint4 qa = nb[0], qb = nb[1], qc = nb[2], qch = nb[3];
+  const float sx = asf(qa.w) * rs.inv.x, sy = asf(qb.x) * rs.inv.y, sz = asf(qb.y) * rs.inv.z;
+  const float bx = fmaf(asf(qa.x), rs.inv.x, rs.noi.x), by = fmaf(asf(qa.y), rs.inv.y, rs.noi.y), bz = fmaf(asf(qa.z), rs.inv.z, rs.noi.z);
+  const bool ngx = rs.inv.x < 0.0f, ngy = rs.inv.y < 0.0f, ngz = rs.inv.z < 0.0f;
+  const uint32_t qnx = ngx ? qb.w : qb.z, qfx = ngx ? qb.z : qb.w;
+  const uint32_t qny = ngy ? qc.y : qc.x, qfy = ngy ? qc.x : qc.y;
+  const uint32_t qnz = ngz ? qc.w : qc.z, qfz = ngz ? qc.z : qc.w;
+  ref[0] = qch.x; ref[1] = qch.y; ref[2] = qch.z; ref[3] = qch.w;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float tnx = fmaf(static_cast<float>((qnx >> (8 * c)) & 0xFFu), sx, bx), tfx = fmaf(static_cast<float>((qfx >> (8 * c)) & 0xFFu), sx, bx);
+    const float tny = fmaf(static_cast<float>((qny >> (8 * c)) & 0xFFu), sy, by), tfy = fmaf(static_cast<float>((qfy >> (8 * c)) & 0xFFu), sy, by);
+    const float tnz = fmaf(static_cast<float>((qnz >> (8 * c)) & 0xFFu), sz, bz), tfz = fmaf(static_cast<float>((qfz >> (8 * c)) & 0xFFu), sz, bz);
+    const float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), 0.0f);
+    const float tf = fminf(fminf(fminf(tfx, tfy), tfz), best_t);
+    key[c] = (tn <= tf) ? __float_as_uint(tn) : kNone;
+  }
+}
+
 #define RMCL_CSWAP(i, j)                                   \
   {                                                        \
     const bool sw_ = key[j] < key[i];                      \
@@ -271,7 +296,8 @@ __device__ __forceinline__ void trace_lane(const uint32_t* __restrict__ nodes, c
 // per CU); a pure scratch stack keeps occupancy but measured 272 MB of HBM-side write traffic per C4 update; 16
 // LDS entries (16 KB per block) catch almost every push.
 // ---------------------------------------------------------------------------------------------
-template <int kLdsEntries>  // stack entries kept in LDS ([entry][lane]); the rest (up to 64 total) in scratch
+// kQuant: `nodes` points to the quantised Node4Q twins (four loads per node visit instead of seven)
+template <int kLdsEntries, bool kQuant = false>  // stack entries kept in LDS ([entry][lane]); the rest (up to 64 total) in scratch
 __device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris,
                                               f3 O, f3 D, float ray_tfar, uint32_t* __restrict__ lds_stack,
                                               uint32_t lds_stride, RayHit& h) {
@@ -288,7 +314,8 @@ __device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes
     // phase 1: inner nodes
     while ((cur != kDone) && !(cur & kLeafBit)) {
       uint32_t key[4], ref[4];
-      node_keys(nodes, cur, rs, best_t, key, ref);
+      if (kQuant) node_keys_q(nodes, cur, rs, best_t, key, ref);
+      else node_keys(nodes, cur, rs, best_t, key, ref);
 #ifdef RMCL_FULL_SORT
       RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
 #else
@@ -697,7 +724,8 @@ __device__ __forceinline__ f3 pinhole_direction(float fx, float fy, float cx, fl
 // ---------------------------------------------------------------------------------------------
 // find
 // ---------------------------------------------------------------------------------------------
-// kTrav: 0 = wave packet, 1 = one lane per ray (while-while), 2 = four lanes per ray (quad-cooperative; the block
+// kTrav: 0 = wave packet, 1 = one lane per ray (while-while), 4 = the same on the quantised 64-B nodes,
+// 2 = four lanes per ray (quad-cooperative; the block
 // of 256 threads then covers ONE 64-ray tile instead of four)
 template <uint32_t kModel, int kTrav>
 __global__ void __launch_bounds__(256) k_find(const FindParams p) {
@@ -756,7 +784,8 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   } else if (kQuad) {
     trace_quad(p.nodes, p.tris, org_m, dir_m, ray_tfar, sub, lane, lds_dyn, h);
   } else {
-    trace_lane_ww<16>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
+    if (kTrav == 4) trace_lane_ww<16, true>(p.qnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
+    else trace_lane_ww<16>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
   }
 
   if (!valid) return;
@@ -1388,7 +1417,7 @@ __global__ void __launch_bounds__(256) k_pf_update(const PfParams p) {
 // finished its ray takes the next one from the block's queue as soon as kRefill lanes of its wave are idle; every
 // result is stored under its ray index, so the outcome does not depend on the schedule.  Traversal, acceptance
 // rules and beam evaluation are those of trace_lane_ww / k_pf_update (bit-identical results).
-template <int kLdsEntries, int kRefill>
+template <int kLdsEntries, int kRefill, bool kQuant>
 __global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
   // LDS: [ per-lane stacks kLdsEntries*256 | Tsm (PB xforms) | evals (PB*n_beams floats) ]
   extern __shared__ uint32_t lds_dyn[];
@@ -1488,7 +1517,8 @@ __global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
     // phase 1: inner nodes (see trace_lane_ww)
     while ((cur != kDone) && !(cur & kLeafBit)) {
       uint32_t key[4], ref[4];
-      node_keys(p.nodes, cur, rs, best_t, key, ref);
+      if (kQuant) node_keys_q(p.qnodes, cur, rs, best_t, key, ref);
+      else node_keys(p.nodes, cur, rs, best_t, key, ref);
       RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
       if (key[3] != kNone) RMCL_PUSH(ref[3])
       if (key[2] != kNone) RMCL_PUSH(ref[2])
@@ -1561,7 +1591,7 @@ __global__ void __launch_bounds__(256) k_pf_motion(const uint32_t* __restrict__ 
     const bool moving = !(static_cast<double>(length) < 0.00001);
     vec = mk3(vec.x / length, vec.y / length, vec.z / length);
     RayHit h;
-    trace_lane_ww<16>(nodes, tris, pose_old.t, vec, (live && moving) ? length : -1.0f, lds_dyn + threadIdx.x, blockDim.x, h);
+    trace_lane_ww<16, true>(nodes, tris, pose_old.t, vec, (live && moving) ? length : -1.0f, lds_dyn + threadIdx.x, blockDim.x, h);
     if (moving && h.face != kInvalidFace) { L.mean = 0.0f; L.sigma = 0.0f; L.n_meas = max_n_meas; }
   }
   if (live) {
@@ -1734,6 +1764,9 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
   } else if (variant == 2) {  // quad-cooperative: 64 rays per block, 64 stack entries per ray in LDS
     const size_t lds = kQuadStackEntries * 64u * sizeof(uint32_t);
     RMCL_LAUNCH_FIND(2, lds)
+  } else if (variant == 4) {  // one lane per ray on the 64-B quantised nodes
+    const size_t lds = 16u * 256u * sizeof(uint32_t);
+    RMCL_LAUNCH_FIND(4, lds)
   } else {             // per-lane while-while traversal: 16 stack entries per lane in LDS, the rest in scratch
     const size_t lds = 16u * 256u * sizeof(uint32_t);
     RMCL_LAUNCH_FIND(1, lds)
@@ -1841,10 +1874,18 @@ hipError_t launch_pf_update(const PfParams& p, int variant, hipStream_t s) {
   const size_t lds = stack_lds + tail;
   const int refill = (variant >> 4) & 7;  // 0 = rounds of one ray per lane; 1..4 = persistent lanes, refill at 8/16/32/48 idle
   if (!cpc && trav == 0 && refill != 0) {
-    if (refill == 1) hipLaunchKernelGGL((k_pf_update_persist<16, 8>), dim3(nblocks), dim3(256), lds, s, p);
-    else if (refill == 2) hipLaunchKernelGGL((k_pf_update_persist<16, 16>), dim3(nblocks), dim3(256), lds, s, p);
-    else if (refill == 3) hipLaunchKernelGGL((k_pf_update_persist<16, 32>), dim3(nblocks), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((k_pf_update_persist<16, 48>), dim3(nblocks), dim3(256), lds, s, p);
+    const bool quant = ((variant >> 7) & 1) == 0 && p.qnodes != nullptr;  // bit 7: full-precision nodes (A/B)
+    if (quant) {
+      if (refill == 1) hipLaunchKernelGGL((k_pf_update_persist<16, 8, true>), dim3(nblocks), dim3(256), lds, s, p);
+      else if (refill == 2) hipLaunchKernelGGL((k_pf_update_persist<16, 16, true>), dim3(nblocks), dim3(256), lds, s, p);
+      else if (refill == 3) hipLaunchKernelGGL((k_pf_update_persist<16, 32, true>), dim3(nblocks), dim3(256), lds, s, p);
+      else hipLaunchKernelGGL((k_pf_update_persist<16, 48, true>), dim3(nblocks), dim3(256), lds, s, p);
+    } else {
+      if (refill == 1) hipLaunchKernelGGL((k_pf_update_persist<16, 8, false>), dim3(nblocks), dim3(256), lds, s, p);
+      else if (refill == 2) hipLaunchKernelGGL((k_pf_update_persist<16, 16, false>), dim3(nblocks), dim3(256), lds, s, p);
+      else if (refill == 3) hipLaunchKernelGGL((k_pf_update_persist<16, 32, false>), dim3(nblocks), dim3(256), lds, s, p);
+      else hipLaunchKernelGGL((k_pf_update_persist<16, 48, false>), dim3(nblocks), dim3(256), lds, s, p);
+    }
     return hipGetLastError();
   }
   if (cpc) hipLaunchKernelGGL((k_pf_update<64, 3>), dim3(nblocks), dim3(256), lds, s, p);

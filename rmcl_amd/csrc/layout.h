@@ -49,6 +49,23 @@ struct alignas(128) Node4 {
 };
 static_assert(sizeof(Node4) == 128, "Node4 must be 128 B");
 
+// Quantised twin of a Node4, 64 B (16 dwords), same index and same child references: the children's (padded) boxes
+// as 8-bit offsets from the node's own corner, rounded outwards.  A lane reads it with FOUR dwordx4 loads
+// instead of seven -- the incoherent traversals (particle filter, pose batches) are bound by the number of L1
+// cache-line accesses, i.e. by load instructions per node visit, not by bytes or arithmetic.
+//   dword  0.. 2  origin xyz         dword 3..5  scale xyz (plane = origin + q * scale)
+//   dword  6      x lower q of children 0..3 (one byte each)   dword  7  x upper q
+//   dword  8 / 9  y lower / upper                              dword 10 / 11  z lower / upper
+//   dword 12..15  child[4]
+// Unused slots: lower q = 255, upper q = 0 (an inverted box is never entered) + the harmless leaf reference.
+struct alignas(64) Node4Q {
+  float origin[3];
+  float scale[3];
+  uint32_t qx_lo, qx_hi, qy_lo, qy_hi, qz_lo, qz_hi;
+  uint32_t child[4];
+};
+static_assert(sizeof(Node4Q) == 64, "Node4Q must be 64 B");
+
 struct alignas(64) TriRec {
   float v0[3];
   float e1[3];

@@ -150,6 +150,15 @@ def build_bvh_host(vertices, faces):
     return info, nodes, tris
 
 
+def build_bvh_host_quantised(vertices, faces, n_nodes):
+    """the 64-B quantised twins of the nodes of build_bvh_host (host only): qnodes[n_nodes, 16] u32."""
+    v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+    f = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
+    q = np.zeros((int(n_nodes), 16), dtype=np.uint32)
+    _capi.check(_capi.lib().rmclhip_bvh_build_host_quantised(_ptr(v), len(v), _ptr(f), len(f), _ptr(q), q.size))
+    return q
+
+
 class UmeyamaReductionConstraints:
     """rmagine::UmeyamaReductionConstraints (only max_dist is used, micp_localization.cpp:525-526)."""
 

@@ -142,6 +142,30 @@ def test_bvh_builder_invariants(ra, orc, meshes, name):
         assert orc.trace_bvh4(nodes, tris, O, D, 0.0, 1e4) == m.intersect(O, D, 0.0, 1e4)
 
 
+@pytest.mark.parametrize("name", ["cube", "sphere20k", "room30k"])
+def test_quantised_nodes_contain_the_full_precision_boxes(ra, meshes, name):
+    """Node4Q twins (layout.h): same child references; the 8-bit boxes decode (origin + q * scale, fp32) to boxes
+    that contain the padded Node4 boxes -- culling on them is conservative, so results cannot change --, and lose
+    little (at most two grid steps per plane); unused slots are inverted."""
+    v, f = meshes(name)
+    info, nodes, _ = ra.build_bvh_host(v, f)
+    q = ra.build_bvh_host_quantised(v, f, info["n_nodes"])
+    fl, qf = nodes.view(np.float32), q.view(np.float32)
+    assert np.array_equal(q[:, 12:16], nodes[:, 24:28])
+    for a in range(3):
+        origin, scale = qf[:, a], qf[:, 3 + a]
+        assert np.all(scale > 0)
+        for c in range(4):
+            valid = nodes[:, 28] > c
+            ql = ((q[:, 6 + 2 * a] >> (8 * c)) & 0xFF).astype(np.float32)
+            qh = ((q[:, 7 + 2 * a] >> (8 * c)) & 0xFF).astype(np.float32)
+            lo, hi = fl[:, 8 * a + c], fl[:, 8 * a + 4 + c]
+            dlo, dhi = origin + ql * scale, origin + qh * scale
+            assert np.all(dlo[valid] <= lo[valid]) and np.all(dhi[valid] >= hi[valid])
+            assert np.all(lo[valid] - dlo[valid] <= 2.0001 * scale[valid]) and np.all(dhi[valid] - hi[valid] <= 2.0001 * scale[valid])
+            assert np.all(ql[~valid] == 255) and np.all(qh[~valid] == 0)
+
+
 def test_bvh_builder_rejects_bad_meshes(ra):
     L = ra._capi.lib()
     v = np.zeros((3, 3), np.float32)

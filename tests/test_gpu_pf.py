@@ -38,7 +38,7 @@ def _check(a_gpu, e_gpu, a_ref, e_ref, what):
     assert np.array_equal(a_gpu["state_sigma"], a_ref["state_sigma"]), what + " state_sigma must be untouched"
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 16, 48])
+@pytest.mark.parametrize("variant", [0, 1, 2, 16, 48, 48 | 128])
 def test_golden_g6_cube(ra, ctx, meshes, variant):
     """committed fixture G6: 64 particles x 16 beams on the cube; beams outside the sensor range
     (real miss) and the MAX_N_MEAS clamp included."""
@@ -55,7 +55,7 @@ def test_golden_g6_cube(ra, ctx, meshes, variant):
 
 
 @pytest.mark.parametrize("n_particles,n_beams", [(1000, 100), (257, 7), (4099, 256)])
-@pytest.mark.parametrize("variant", [0, 2, 16, 32, 64])
+@pytest.mark.parametrize("variant", [0, 2, 16, 32, 64, 48 | 128])
 def test_room_random_particles(ra, orc, ctx, meshes, n_particles, n_beams, variant):
     """random hypotheses in a room with occluders and an open ceiling (sim misses), reference default of
     100 random beams and ragged sizes; beams sampled from a simulated cloud like update() does."""
