@@ -320,7 +320,7 @@ rmclhip_status rmclhip_pf_time_update(rmclhip_pf* pf, const rmclhip_transform* p
 /* bits 0..3: traversal (0 = while-while with the hybrid LDS + scratch stack, 1 = stack entirely in LDS, 2 = single
  * loop, A/B); bits 4..6: ray scheduling (0 = rounds of one ray per lane; 1..4 = persistent lanes that fetch the
  * next ray when 8 / 16 / 32 / 48 lanes of their wave are idle); bit 7: persistent lanes on the 128-B nodes instead
- * of their 64-B quantised twins (A/B).  A fresh handle uses traversal 0, refill at 32, quantised nodes. */
+ * of their 64-B quantised twins (A/B).  A fresh handle uses traversal 0, refill at 48, quantised nodes. */
 rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* pf, int variant);
 
 

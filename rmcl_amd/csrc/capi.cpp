@@ -180,8 +180,9 @@ struct rmclhip_pf {
   float* errors_dev = nullptr;
   int variant = 0;
   bool full_nodes = false;  // A/B: persistent lanes on the 128-B nodes instead of their 64-B quantised twins
-  int refill = 3;  // 0: rounds of one ray per lane; 1..4: persistent lanes (dynamic ray fetch), refill when 8/16/32/48
-                   // lanes of a wave are idle (default 32: measured 5 % / 10 % faster than rounds on sphere / room)
+  int refill = 4;  // 0: rounds of one ray per lane; 1..4: persistent lanes (dynamic ray fetch), refill when 8/16/32/48
+                   // lanes of a wave are idle (default 48: the refill block also evaluates the finished beams, which
+                   // pays off with many lanes at once; measured best on sphere and room)
 };
 
 // GladiatorResamplerGPU analogue: owns a stream and the scratch of the {sum, max} reduction

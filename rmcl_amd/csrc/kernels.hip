@@ -138,13 +138,23 @@ __device__ __forceinline__ void node_keys_q(const uint32_t* __restrict__ qnodes,
   const uint32_t qny = ngy ? qc.y : qc.x, qfy = ngy ? qc.x : qc.y;
   const uint32_t qnz = ngz ? qc.w : qc.z, qfz = ngz ? qc.z : qc.w;
   ref[0] = qch.x; ref[1] = qch.y; ref[2] = qch.z; ref[3] = qch.w;
+  // bytes -> floats (v_cvt_f32_ubyteN), two children per packed FMA
+#define RMCL_Q2(w, a, b) f2{static_cast<float>(((w) >> (8 * (a))) & 0xFFu), static_cast<float>(((w) >> (8 * (b))) & 0xFFu)}
+  const f2 sx2 = {sx, sx}, sy2 = {sy, sy}, sz2 = {sz, sz}, bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
+  const f2 nx01 = __builtin_elementwise_fma(RMCL_Q2(qnx, 0, 1), sx2, bx2), nx23 = __builtin_elementwise_fma(RMCL_Q2(qnx, 2, 3), sx2, bx2);
+  const f2 fx01 = __builtin_elementwise_fma(RMCL_Q2(qfx, 0, 1), sx2, bx2), fx23 = __builtin_elementwise_fma(RMCL_Q2(qfx, 2, 3), sx2, bx2);
+  const f2 ny01 = __builtin_elementwise_fma(RMCL_Q2(qny, 0, 1), sy2, by2), ny23 = __builtin_elementwise_fma(RMCL_Q2(qny, 2, 3), sy2, by2);
+  const f2 fy01 = __builtin_elementwise_fma(RMCL_Q2(qfy, 0, 1), sy2, by2), fy23 = __builtin_elementwise_fma(RMCL_Q2(qfy, 2, 3), sy2, by2);
+  const f2 nz01 = __builtin_elementwise_fma(RMCL_Q2(qnz, 0, 1), sz2, bz2), nz23 = __builtin_elementwise_fma(RMCL_Q2(qnz, 2, 3), sz2, bz2);
+  const f2 fz01 = __builtin_elementwise_fma(RMCL_Q2(qfz, 0, 1), sz2, bz2), fz23 = __builtin_elementwise_fma(RMCL_Q2(qfz, 2, 3), sz2, bz2);
+#undef RMCL_Q2
+  const float tnx[4] = {nx01.x, nx01.y, nx23.x, nx23.y}, tfx[4] = {fx01.x, fx01.y, fx23.x, fx23.y};
+  const float tny[4] = {ny01.x, ny01.y, ny23.x, ny23.y}, tfy[4] = {fy01.x, fy01.y, fy23.x, fy23.y};
+  const float tnz[4] = {nz01.x, nz01.y, nz23.x, nz23.y}, tfz[4] = {fz01.x, fz01.y, fz23.x, fz23.y};
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const float tnx = fmaf(static_cast<float>((qnx >> (8 * c)) & 0xFFu), sx, bx), tfx = fmaf(static_cast<float>((qfx >> (8 * c)) & 0xFFu), sx, bx);
-    const float tny = fmaf(static_cast<float>((qny >> (8 * c)) & 0xFFu), sy, by), tfy = fmaf(static_cast<float>((qfy >> (8 * c)) & 0xFFu), sy, by);
-    const float tnz = fmaf(static_cast<float>((qnz >> (8 * c)) & 0xFFu), sz, bz), tfz = fmaf(static_cast<float>((qfz >> (8 * c)) & 0xFFu), sz, bz);
-    const float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), 0.0f);
-    const float tf = fminf(fminf(fminf(tfx, tfy), tfz), best_t);
+    const float tn = fmaxf(fmaxf(fmaxf(tnx[c], tny[c]), tnz[c]), 0.0f);
+    const float tf = fminf(fminf(fminf(tfx[c], tfy[c]), tfz[c]), best_t);
     key[c] = (tn <= tf) ? __float_as_uint(tn) : kNone;
   }
 }
@@ -309,7 +319,7 @@ __device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes
   uint32_t sp = 0;
   uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
 #define RMCL_PUSH(v) { if (kLdsEntries >= 64 || sp < kLdsEntries) lds_stack[sp * lds_stride] = (v); else priv[sp - kLdsEntries] = (v); ++sp; }
-#define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; cur = (kLdsEntries >= 64 || sp < kLdsEntries) ? lds_stack[sp * lds_stride] : priv[sp - kLdsEntries]; } }
+#define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; if (kLdsEntries >= 64 || sp < kLdsEntries) cur = lds_stack[sp * lds_stride]; else cur = priv[sp - kLdsEntries]; } }
   while (__any(cur != kDone)) {
     // phase 1: inner nodes
     while ((cur != kDone) && !(cur & kLeafBit)) {
@@ -518,7 +528,7 @@ __device__ __forceinline__ void nearest_lane_ww(const uint32_t* __restrict__ nod
   uint32_t sp = 0;
   uint32_t cur = active ? 0u : kDone;
 #define RMCL_PUSH(v) { if (kLdsEntries >= 64 || sp < kLdsEntries) lds_stack[sp * lds_stride] = (v); else priv[sp - kLdsEntries] = (v); ++sp; }
-#define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; cur = (kLdsEntries >= 64 || sp < kLdsEntries) ? lds_stack[sp * lds_stride] : priv[sp - kLdsEntries]; } }
+#define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; if (kLdsEntries >= 64 || sp < kLdsEntries) cur = lds_stack[sp * lds_stride]; else cur = priv[sp - kLdsEntries]; } }
   while (__any(cur != kDone)) {
     while ((cur != kDone) && !(cur & kLeafBit)) {
       const uint4* np = reinterpret_cast<const uint4*>(nodes) + static_cast<size_t>(cur) * 8u;
@@ -1449,7 +1459,7 @@ __global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
   uint32_t priv[(kLdsEntries < 64) ? (64 - kLdsEntries) : 1];
   uint32_t sp = 0, cur = kDone;
 #define RMCL_PUSH(v) { if (kLdsEntries >= 64 || sp < kLdsEntries) lds_stack[sp * lds_stride] = (v); else priv[sp - kLdsEntries] = (v); ++sp; }
-#define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; cur = (kLdsEntries >= 64 || sp < kLdsEntries) ? lds_stack[sp * lds_stride] : priv[sp - kLdsEntries]; } }
+#define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; if (kLdsEntries >= 64 || sp < kLdsEntries) cur = lds_stack[sp * lds_stride]; else cur = priv[sp - kLdsEntries]; } }
   for (;;) {
     const bool idle = (cur == kDone) && !exhausted;
     const uint64_t want = __ballot(idle);

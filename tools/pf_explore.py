@@ -24,7 +24,7 @@ for n_particles, n_beams in ((100000, 100), (100000, 256)):
     sel = np.linspace(0, len(dirs) - 1, n_beams).astype(int)
     beams = ra.beams_from_points(dirs[sel] * np.float32(6.0))
     d_poses, d_attrs = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
-    for variant in (0, 48 | 128, 48):
+    for variant in (16, 32, 48, 64):
         upd = ra.PCDSensorUpdaterHip(hm)
         upd.init()
         upd.set_variant(variant)
