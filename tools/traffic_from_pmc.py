@@ -21,7 +21,7 @@ def avg(db, kernel_like, counter):
 
 def main(d, out):
     res = {}
-    for key, like, pre, wide in (("k_find_lane", "%k_find<1u, false>%", "find_v1", False), ("k_find_packet", "%k_find<1u, true>%", "find_v0", False),
+    for key, like, pre, wide in (("k_find_lane", "%k_find<1u, 1>%", "find_v1", False), ("k_find_packet", "%k_find<1u, 0>%", "find_v0", False),
                                  ("k_pf_update", "%k_pf_update%", "pf", False), ("k_reduce_partials", "%k_reduce_partials%", "red", True)):
         f, nf = avg("%s/%s_fetch_results.db" % (d, pre), like, "FETCH_SIZE")
         w, nw = avg("%s/%s_write_results.db" % (d, pre), like, "WRITE_SIZE")
