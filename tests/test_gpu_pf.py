@@ -127,3 +127,48 @@ def test_custom_parameters_and_empty_inputs(ra, orc, ctx, meshes):
     d_poses, d_attrs = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
     upd.update(d_poses, d_attrs, n_particles=0)
     assert np.array_equal(d_attrs.download().view(np.uint8), attrs.view(np.uint8))
+
+
+def test_c4_full_size_properties(ra, orc, ctx, meshes):
+    """BASELINE config C4 at full size (100 000 particles x 256 beams, sphere-100k): far beyond what the oracle
+    finishes in seconds, so size-independent properties are checked instead --
+    (1) a particle at the sphere's centre sees every beam at the radius: beams of exactly that range evaluate to
+        (nearly) zero error, whatever the particle's yaw; the first 1000 particles are such particles;
+    (2) the result does not depend on the ray schedule: persistent lanes (two thresholds, both node forms) and
+        rounds give bit-identical attributes for all 100 000 particles;
+    (3) a 257-particle prefix agrees with the oracle."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("sphere100k")
+    hm = ra.import_hip_map(ctx, v, f)
+    n, radius = 100000, 10.0
+    poses, attrs = syn.uniform_particles(n, seed=42, bb_min=(-5, -5, -1, 0, 0, -math.pi), bb_max=(5, 5, 1, 0, 0, math.pi))
+    rng = np.random.RandomState(3)
+    for i in range(1000):   # at the centre, generic orientation (beams must not run along the mesh's meridians / rings:
+        poses[i] = T.transform_from_rpy((0, 0, 0), (0.011, 0.007, rng.uniform(-3, 3)))   # the intersector is not watertight)
+    beams = ra.beams_from_points(syn.model_directions(syn.model_pf16()) * np.float32(radius))
+    assert len(beams) == 256
+    results = []
+    for variant in (64, 16, 48 | 128, 0):
+        upd = ra.PCDSensorUpdaterHip(hm)
+        upd.init()
+        upd.set_variant(variant)
+        upd.setInput(beams, T.identity())
+        d_poses, d_attrs = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
+        upd.update(d_poses, d_attrs)
+        results.append(d_attrs.download())
+        upd.close()
+    a = results[0]
+    for other in results[1:]:
+        assert other.tobytes() == a.tobytes()                                   # (2)
+    assert np.all(a["likelihood"]["n_meas"] == 256)
+    peak = 1.0 / math.sqrt(2 * 4.0 * math.pi)                                   # eval at zero error, dist_sigma 2
+    centre = a["likelihood"]["mean"][:1000]
+    # starting from mean 1 with n_meas 0, 256 merges of ~peak leave exactly the average of the evals
+    assert np.all(np.abs(centre - peak) < 2e-5 * peak + 1e-7)                   # (1): faceting error << sigma
+    assert a["likelihood"]["mean"][1000:].mean() < 0.9 * peak                   # off-centre particles are less likely
+    m = orc.Mesh(v, f)
+    sub = slice(900, 1157)                                                      # centre and off-centre particles
+    ref = attrs[sub].copy()
+    m.pf_update(poses[sub], ref, beams, T.identity(), orc.pf_params(), bvh=True, nthreads=8)
+    assert np.array_equal(a["likelihood"]["n_meas"][sub], ref["likelihood"]["n_meas"])
+    assert_close_rel(a["likelihood"]["mean"][sub], ref["likelihood"]["mean"], 1e-5, 1e-12, "C4 prefix mean")   # (3)
