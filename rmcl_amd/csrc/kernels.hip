@@ -1524,20 +1524,29 @@ __global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
         }
       }
     }
-    // phase 1: inner nodes (see trace_lane_ww)
-    while ((cur != kDone) && !(cur & kLeafBit)) {
-      uint32_t key[4], ref[4];
-      if (kQuant) node_keys_q(p.qnodes, cur, rs, best_t, key, ref);
-      else node_keys(p.nodes, cur, rs, best_t, key, ref);
-      RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
-      if (key[3] != kNone) RMCL_PUSH(ref[3])
-      if (key[2] != kNone) RMCL_PUSH(ref[2])
-      if (key[1] != kNone) RMCL_PUSH(ref[1])
-      if (key[0] != kNone) cur = ref[0];
-      else RMCL_POP()
+    // phase 1: inner nodes (see trace_lane_ww) -- left EARLY once at most kTailLanes lanes are still descending while
+    // others already hold a leaf: the stragglers resume in the next round and the leaf holders do not idle through
+    // the tail (measured 7 % / 5 % faster on sphere / room; for coherent scans the plain loop of trace_lane_ww wins)
+    constexpr int kTailLanes = 8;
+    for (;;) {
+      const bool inner = (cur != kDone) && !(cur & kLeafBit);
+      const uint64_t m_inner = __ballot(inner);
+      if (m_inner == 0) break;
+      if (__popcll(m_inner) <= kTailLanes && __ballot((cur != kDone) && (cur & kLeafBit)) != 0) break;
+      if (inner) {
+        uint32_t key[4], ref[4];
+        if (kQuant) node_keys_q(p.qnodes, cur, rs, best_t, key, ref);
+        else node_keys(p.nodes, cur, rs, best_t, key, ref);
+        RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
+        if (key[3] != kNone) RMCL_PUSH(ref[3])
+        if (key[2] != kNone) RMCL_PUSH(ref[2])
+        if (key[1] != kNone) RMCL_PUSH(ref[1])
+        if (key[0] != kNone) cur = ref[0];
+        else RMCL_POP()
+      }
     }
     // phase 2: this lane's leaf (if any)
-    if (cur != kDone) {
+    if ((cur != kDone) && (cur & kLeafBit)) {
       const uint32_t first = cur & 0x0FFFFFFFu;
       const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
       for (uint32_t i = 0; i < cnt; ++i) {
