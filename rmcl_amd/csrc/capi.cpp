@@ -875,7 +875,8 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
       p.Tsm_arr = &r->d_call->Tsm;
       p.Tms_arr = &r->d_call->Tms;
       HIPCHK(launch_find(p, r->kind, find_variant(r, p.nposes), r->stream));
-      HIPCHK(launch_micp_init(r->d_state, r->d_loop_barrier, r->stream));
+      const bool iter_form = r->loop_blocks == 0 && !r->fused_tail && n_iter > 0;
+      if (!iter_form) HIPCHK(launch_micp_init(r->d_state, r->d_loop_barrier, r->stream));  // k_micp_iter initialises itself
       MicpState* final_state = r->d_state;
       const uint8_t* dmask = r->ds_has_mask ? r->d_ds_mask.p : nullptr;
       if (r->loop_blocks > 0) {
@@ -884,7 +885,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
         HIPCHK(launch_micp_loop(r->d_ds_points.p, dmask, r->d_points.p, r->d_normals.p, r->d_hits.p, nred, n_iter,
                                 r->d_call, r->d_partials.p, r->d_loop_barrier, r->d_state,
                                 static_cast<uint32_t>(r->loop_blocks), r->stream));
-      } else if (r->loop_blocks == 0 && !r->fused_tail && n_iter > 0) {
+      } else if (iter_form) {
         // default: ONE launch per iteration (k_micp_iter solves the previous iteration in its prologue) + one
         // closing solve: n_iter + 1 launches instead of 2 * n_iter
         const uint32_t nb = reduce_num_blocks(nred);

@@ -1148,7 +1148,16 @@ __global__ void __launch_bounds__(256) k_micp_iter(const MicpIterParams p) {
   __shared__ xform s_Tpre;
   if (threadIdx.x < 64u) {
     if (p.first) {
-      if (threadIdx.x == 0) s_Tpre = xidentity();
+      if (threadIdx.x == 0) {
+        s_Tpre = xidentity();
+        if (blockIdx.x == 0) {  // the state before any iteration (replaces a separate init launch)
+          MicpState init;
+          init.T_onew_oold = xidentity();
+          init.T_snew_sold = xidentity();
+          init.stats_o = cs_identity();
+          *p.state_out = init;
+        }
+      }
     } else {
       const cstats st = finalize_pose(p.partials_prev, p.nblocks);
       if (threadIdx.x == 0) {
