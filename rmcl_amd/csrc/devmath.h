@@ -275,74 +275,108 @@ RM_HD quat mat_to_quat(const double* R) {
 }
 
 
-// reciprocal for the Newton iteration below: on the device one v_rcp_f64 plus two Newton-Raphson steps (full
-// double accuracy, ~5 dependent instructions instead of the ~35 of an IEEE division); exact division on the host
-RM_HD double polar_rcp(double x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(fma(-x, r, 1.0), r, r);
-  r = fma(fma(-x, r, 1.0), r, r);
-  return r;
-#else
-  return 1.0 / x;
-#endif
+// Rotation of the Kabsch / Umeyama problem as a unit quaternion, without an SVD: the optimal proper rotation
+// R (m ~ R d) is the eigenvector of the largest eigenvalue of Horn's symmetric, traceless 4x4 matrix K built from
+// the cross-covariance (Horn 1987); that eigenvalue is the largest root of the quartic
+// P(l) = l^4 + c2 l^2 + c1 l + c0 and is found by Newton's method from the upper bound sqrt(trace K^2) (monotone
+// convergence; Theobald 2005, "QCP"); the eigenvector is a column of adj(K - l I).  The reflection case of the
+// SVD formulation (det < 0 -> diag(1,1,-1)) needs no special handling: the eigenvector IS the best proper
+// rotation.  ~350 dependent fp64 operations instead of ~900 for the scaled-Newton polar iteration used before (a
+// lone lane retires one dependent instruction per ~5 cycles, so this is what the MICP step costs).  Returns false
+// for (nearly) degenerate inputs -- repeated largest eigenvalue, zero matrix --, where the caller falls back to
+// the Jacobi SVD, which defines the semantics.  q = (x, y, z, w), normalised.
+// determinant and adjugate of a symmetric 4x4 matrix from its ten entries, by 2x2 sub-determinants (Laplace expansion);
+// written with scalars only -- indexed local arrays would live in scratch memory on the device
+struct sym4 {
+  double k00, k01, k02, k03, k11, k12, k13, k22, k23, k33;
+};
+struct sym4_minors {
+  double s0, s1, s2, s3, s4, s5, c0, c1, c2, c3, c4, c5;
+};
+RM_HD sym4_minors sym4_sub(const sym4& K) {
+  sym4_minors m;
+  // rows 0,1 (k10 = k01): s*; rows 2,3 (k20 = k02, k21 = k12, k30 = k03, k31 = k13, k32 = k23): c*
+  m.s0 = K.k00 * K.k11 - K.k01 * K.k01; m.s1 = K.k00 * K.k12 - K.k01 * K.k02; m.s2 = K.k00 * K.k13 - K.k01 * K.k03;
+  m.s3 = K.k01 * K.k12 - K.k11 * K.k02; m.s4 = K.k01 * K.k13 - K.k11 * K.k03; m.s5 = K.k02 * K.k13 - K.k12 * K.k03;
+  m.c5 = K.k22 * K.k33 - K.k23 * K.k23; m.c4 = K.k12 * K.k33 - K.k13 * K.k23; m.c3 = K.k12 * K.k23 - K.k13 * K.k22;
+  m.c2 = K.k02 * K.k33 - K.k03 * K.k23; m.c1 = K.k02 * K.k23 - K.k03 * K.k22; m.c0 = K.k02 * K.k13 - K.k03 * K.k12;
+  return m;
+}
+RM_HD double sym4_det(const sym4_minors& m) {
+  return m.s0 * m.c5 - m.s1 * m.c4 + m.s2 * m.c3 + m.s3 * m.c2 - m.s4 * m.c1 + m.s5 * m.c0;
 }
 
-// Rotation factor of the polar decomposition A = R*H by the scaled Newton iteration X <- (g X + X^-T / g) / 2
-// (Higham).  Only valid for det A > 0 (a proper rotation is wanted); returns false for reflections, rank
-// deficiency or slow convergence -- the caller falls back to the Jacobi SVD.  The iteration runs on ONE lane, so
-// its cost is the length of the dependent fp64 chain: the scaling factor g (any positive value works, it only
-// steers convergence) is computed in fp32 and snapped to exactly 1 near convergence (so that the fixed point is
-// exactly orthogonal), the inverse uses polar_rcp, and the loop stops when the step is below 1e-7: Newton
-// converges quadratically, the iterate just computed is then accurate to ~1e-14.
-RM_HD bool polar3(const double* A, double* R) {
-  double X[9];
-  double fro2 = 0.0;
-  for (int i = 0; i < 9; ++i) { X[i] = A[i]; fro2 += A[i] * A[i]; }
-  const double fro = sqrt(fro2);
-  if (!(fro > 0.0) || !(det3(A) > 1e-9 * fro * fro * fro)) return false;
-  for (int it = 0; it < 24; ++it) {
-    // Y = X^-T via cofactors: inv(X) = adj(X) / det  =>  X^-T = cof(X) / det
-    double Cf[9];
-    Cf[0] = X[4] * X[8] - X[5] * X[7]; Cf[1] = X[5] * X[6] - X[3] * X[8]; Cf[2] = X[3] * X[7] - X[4] * X[6];
-    Cf[3] = X[2] * X[7] - X[1] * X[8]; Cf[4] = X[0] * X[8] - X[2] * X[6]; Cf[5] = X[1] * X[6] - X[0] * X[7];
-    Cf[6] = X[1] * X[5] - X[2] * X[4]; Cf[7] = X[2] * X[3] - X[0] * X[5]; Cf[8] = X[0] * X[4] - X[1] * X[3];
-    const double det = X[0] * Cf[0] + X[1] * Cf[1] + X[2] * Cf[2];
-    if (!(det > 0.0)) return false;
-    const double idet = polar_rcp(det);
-    double nx = 0.0, ny = 0.0;
-    for (int i = 0; i < 9; ++i) { Cf[i] *= idet; nx += X[i] * X[i]; ny += Cf[i] * Cf[i]; }
-    float gf = sqrtf(sqrtf(static_cast<float>(ny) / static_cast<float>(nx)));  // (|X^-1|_F / |X|_F)^(1/2)
-    if (!(gf > 0.0f) || !(gf < 3.0e38f) || fabsf(gf - 1.0f) < 1.0e-3f) gf = 1.0f;
-    const double a = 0.5 * static_cast<double>(gf), b = static_cast<double>(0.5f / gf);
-    double diff = 0.0;
-    for (int i = 0; i < 9; ++i) {
-      const double xn = a * X[i] + b * Cf[i];
-      const double d = xn - X[i];
-      diff += d * d;
-      X[i] = xn;
-    }
-    if (diff <= 1e-14 * 3.0) {  // |X_{k+1} - X_k|_F <= 1e-7 |R|_F  =>  |X_{k+1} - R| ~ 1e-14
-      for (int i = 0; i < 9; ++i) R[i] = X[i];
-      return true;
-    }
+RM_HD bool horn_quaternion(const double* C, double* q) {
+  // C[3*r + c] = sum m_r d_c  =>  S_ab = sum d_a m_b = C[3*b + a]
+  const double Sxx = C[0], Sxy = C[3], Sxz = C[6], Syx = C[1], Syy = C[4], Syz = C[7], Szx = C[2], Szy = C[5], Szz = C[8];
+  sym4 K;
+  K.k00 = Sxx + Syy + Szz; K.k01 = Syz - Szy; K.k02 = Szx - Sxz; K.k03 = Sxy - Syx;
+  K.k11 = Sxx - Syy - Szz; K.k12 = Sxy + Syx; K.k13 = Szx + Sxz;
+  K.k22 = -Sxx + Syy - Szz; K.k23 = Syz + Szy;
+  K.k33 = -Sxx - Syy + Szz;
+  const double ss = ((Sxx * Sxx + Sxy * Sxy + Sxz * Sxz) + (Syx * Syx + Syy * Syy + Syz * Syz)) + (Szx * Szx + Szy * Szy + Szz * Szz);
+  if (!(ss > 0.0)) return false;
+  const double c2 = -2.0 * ss;
+  const double c1 = -8.0 * det3(C);
+  const double c0 = sym4_det(sym4_sub(K));
+  const double lam0 = sqrt(4.0 * ss);  // sqrt(trace K^2) = sqrt(-2 c2) >= largest eigenvalue
+  double lam = lam0;
+  bool converged = false;
+  for (int it = 0; it < 60; ++it) {
+    const double l2 = lam * lam;
+    const double P = (l2 + c2) * l2 + c1 * lam + c0;
+    const double dP = (4.0 * l2 + 2.0 * c2) * lam + c1;
+    if (!(dP > 0.0)) break;
+    const double step = P / dP;
+    lam -= step;
+    if (step <= 1e-14 * lam0) { converged = true; break; }
   }
-  return false;
+  if (!converged) return false;
+  K.k00 -= lam; K.k11 -= lam; K.k22 -= lam; K.k33 -= lam;
+  const sym4_minors m = sym4_sub(K);
+  // adj(K - l I) = const * v v^T (symmetric): diagonal entries ~ v_c^2, take the column of the largest one
+  const double a00 = K.k11 * m.c5 - K.k12 * m.c4 + K.k13 * m.c3;
+  const double a11 = K.k00 * m.c5 - K.k02 * m.c2 + K.k03 * m.c1;
+  const double a22 = K.k03 * m.s4 - K.k13 * m.s2 + K.k33 * m.s0;
+  const double a33 = K.k02 * m.s3 - K.k12 * m.s1 + K.k22 * m.s0;
+  const double a01 = -K.k01 * m.c5 + K.k02 * m.c4 - K.k03 * m.c3;
+  const double a02 = K.k13 * m.s5 - K.k23 * m.s4 + K.k33 * m.s3;
+  const double a03 = -K.k12 * m.s5 + K.k22 * m.s4 - K.k23 * m.s3;
+  const double a12 = -K.k03 * m.s5 + K.k23 * m.s2 - K.k33 * m.s1;
+  const double a13 = K.k02 * m.s5 - K.k22 * m.s2 + K.k23 * m.s1;
+  const double a23 = -K.k02 * m.s4 + K.k12 * m.s2 - K.k23 * m.s0;
+  double v0 = a00, v1 = a01, v2 = a02, v3 = a03, dbest = fabs(a00);
+  if (fabs(a11) > dbest) { v0 = a01; v1 = a11; v2 = a12; v3 = a13; dbest = fabs(a11); }
+  if (fabs(a22) > dbest) { v0 = a02; v1 = a12; v2 = a22; v3 = a23; dbest = fabs(a22); }
+  if (fabs(a33) > dbest) { v0 = a03; v1 = a13; v2 = a23; v3 = a33; dbest = fabs(a33); }
+  if (!(dbest > 1e-10 * lam0 * lam0 * lam0)) return false;  // repeated largest eigenvalue
+  const double n = sqrt((v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3));
+  if (!(n > 0.0)) return false;
+  double w = v0 / n, x = v1 / n, y = v2 / n, z = v3 / n;
+  // sign convention of mat_to_quat (Shepperd): w > 0 when trace R > 0 (|w| > 1/2), else the largest of x, y, z positive
+  double lead = w;
+  if (!(fabs(w) > 0.5)) {
+    if (x * x > y * y && x * x > z * z) lead = x;
+    else if (y * y > z * z) lead = y;
+    else lead = z;
+  }
+  if (lead < 0.0) { w = -w; x = -x; y = -y; z = -z; }
+  q[0] = x; q[1] = y; q[2] = z; q[3] = w;
+  return true;
 }
 
-// rm::umeyama_transform: C = U S V^T, R = U diag(1,1,sign(det U det V)) V^T, t = mm - R dm
 RM_HD xform umeyama(const cstats& s) {
   xform T = xidentity();
   if (s.n_meas == 0) return T;
-  double C[9], R[9];
+  double C[9];
   for (int i = 0; i < 9; ++i) C[i] = static_cast<double>(s.covariance[i]);
-  // Fast path: for det(C) > 0 the Kabsch/Umeyama rotation U diag(1,1,+1) V^T IS the orthogonal polar factor of
-  // C, which a scaled Newton iteration X <- (g X + X^-T / g) / 2 delivers in ~6 steps of ~60 fp64 operations --
-  // an order of magnitude fewer dependent fp64 instructions than the Jacobi SVD (a lone lane issues one fp64
-  // instruction per ~8 cycles: the SVD solve measured ~9 us of the 14 us k_micp_step).  Reflection (det < 0),
-  // rank-deficient or slowly converging inputs take the SVD path below, which defines the semantics.
-  if (!polar3(C, R)) {
-    double U[9], w[3], V[9];
+  double q[4];
+  if (horn_quaternion(C, q)) {
+    T.R.x = static_cast<float>(q[0]); T.R.y = static_cast<float>(q[1]);
+    T.R.z = static_cast<float>(q[2]); T.R.w = static_cast<float>(q[3]);
+  } else {
+    // Jacobi SVD: R = U diag(1, 1, sign(det U det V)) V^T (defines the semantics; degenerate inputs only)
+    double U[9], w[3], V[9], R[9];
     svd3(C, U, w, V);
     double S[3] = {1, 1, 1};
     if (det3(U) * det3(V) < 0) S[2] = -1;
@@ -352,8 +386,8 @@ RM_HD xform umeyama(const cstats& s) {
         for (int k = 0; k < 3; ++k) acc += U[3 * i + k] * S[k] * V[3 * j + k];
         R[3 * i + j] = acc;
       }
+    T.R = mat_to_quat(R);
   }
-  T.R = mat_to_quat(R);
   T.t = sub3(s.model_mean, qrot(T.R, s.dataset_mean));
   return T;
 }

@@ -3,6 +3,7 @@ fails loudly (no CPU fallback) without a device, and its host-side pieces (trans
 BVH builder) agree with the oracle.  No compute entry point is called here.
 """
 import ctypes as C
+import math
 import os
 import re
 
@@ -187,3 +188,57 @@ def test_tiny_meshes_build(ra, orc):
         m = orc.Mesh(v, f)
         for O, D in (((0.2, 0.2, 3), (0, 0, -1)), ((0.7, 0.7, 3), (0, 0, -1)), ((5, 5, 5), (1, 0, 0))):
             assert orc.trace_bvh4(nodes, tris, O, D) == m.intersect(O, D)
+
+
+def test_umeyama_special_cases_match_the_svd_definition(ra, orc):
+    """rmclhip_umeyama_transform solves the rotation through Horn's quaternion eigenproblem (largest root of a
+    quartic by Newton, eigenvector from the adjugate) and falls back to the Jacobi SVD for degenerate inputs; the
+    oracle is the SVD definition R = U diag(1, 1, det) V^T.  Half turns (w ~ 0), reflections (det < 0), planar and
+    collinear point sets, noise-free data and tiny / huge scales must all agree."""
+    T = ra.types
+    rng = np.random.RandomState(5)
+
+    def stats(C, dm=(0.3, -0.2, 0.1), mm=(1.0, 2.0, -0.5), n=100):
+        s = np.zeros((), T.CROSS_STATISTICS)
+        for k, a, b in zip("xyz", dm, mm):
+            s["dataset_mean"][k], s["model_mean"][k] = a, b
+        s["covariance"] = np.asarray(C, np.float64).reshape(9)
+        s["n_meas"] = n
+        return s
+
+    def rot(axis, angle):
+        axis = np.asarray(axis, float) / np.linalg.norm(axis)
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        return np.eye(3) + math.sin(angle) * K + (1 - math.cos(angle)) * K @ K
+
+    cases = []
+    for angle in (0.0, 1e-4, 0.5, math.pi / 2, math.pi - 1e-3, math.pi):
+        for axis in ((1, 0, 0), (0, 0, 1), (1, 2, 3), (-1, 1, 0.1)):
+            d = rng.normal(size=(60, 3)) * (2.0, 1.0, 0.5)
+            R = rot(axis, angle)
+            m = d @ R.T
+            for noise in (0.0, 0.02):
+                mn = m + rng.normal(size=m.shape) * noise
+                cases.append(((mn - mn.mean(0)).T @ (d - d.mean(0))) / len(d))
+    planar = rng.normal(size=(40, 3)) * (1.0, 1.0, 0.0)
+    cases.append(((planar @ rot((0, 0, 1), 0.7).T).T @ planar) / 40)                 # rank 2
+    line = np.outer(rng.normal(size=40), (1.0, 2.0, -1.0))
+    cases.append((line.T @ line) / 40)                                               # rank 1: rotation not unique
+    cases += [c * s for c in cases[:6] for s in (1e-8, 1e6)]                         # scales
+    cases += [rng.normal(size=(3, 3)) * (1, 1, -1) for _ in range(20)]               # arbitrary, many with det < 0
+    n_checked = 0
+    for C in cases:
+        s = stats(C)
+        tu, to = T.umeyama_transform(s), orc.umeyama(s)
+        qu = np.array([tu["R"][k] for k in "xyzw"], np.float64)
+        qo = np.array([to["R"][k] for k in "xyzw"], np.float64)
+        assert abs(np.linalg.norm(qu) - 1.0) < 1e-6
+        sv = np.linalg.svd(np.asarray(C, np.float64).reshape(3, 3), compute_uv=False)
+        if sv[1] < 1e-6 * sv[0]:
+            continue                                                                  # rotation not unique: only unit norm is required
+        assert min(np.abs(qu - qo).max(), np.abs(qu + qo).max()) < 2e-6, (C, qu, qo)
+        assert np.allclose([tu["t"][k] for k in "xyz"], [to["t"][k] for k in "xyz"], atol=2e-5)
+        n_checked += 1
+    assert n_checked > 60
+    z = T.umeyama_transform(stats(np.zeros((3, 3))))                                  # zero covariance: SVD fallback, unit quaternion
+    assert abs(np.linalg.norm([z["R"][k] for k in "xyzw"]) - 1.0) < 1e-6
