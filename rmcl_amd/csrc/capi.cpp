@@ -731,7 +731,7 @@ static rmclhip_status reduce_enqueue(rmclhip_rcc* r, const xform& Tpre, const xf
   const uint32_t n = (r->n_dataset < r->n_model) ? r->n_dataset : r->n_model;
   if (n == 0) return fail(RMCLHIP_ERR_INVALID, "computeCrossStatistics: empty dataset or model (call find first)");
   if (r->n_model != n && nposes > 1) return fail(RMCLHIP_ERR_INVALID, "batch reduction needs dataset size == model size");
-  const uint32_t nb = reduce_num_blocks(n);
+  const uint32_t nb = reduce_num_blocks(n, nposes);
   HIPCHK(r->d_partials.reserve(static_cast<size_t>(nposes) * nb * 16));
   if (r->tickets_cap < nposes) {
     if (r->d_tickets) (void)hipFree(r->d_tickets);
@@ -849,7 +849,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
     if (rmclhip_status st = ensure_model_buffers(r, n)) return st;
     const uint32_t nred = (r->n_dataset < r->n_model) ? r->n_dataset : r->n_model;
     if (nred == 0) return fail(RMCLHIP_ERR_INVALID, "correct_once: empty dataset");
-    HIPCHK(r->d_partials.reserve(std::max<size_t>(static_cast<size_t>(reduce_num_blocks(nred)) * 32, 2u * 256u * 16u)));
+    HIPCHK(r->d_partials.reserve(std::max<size_t>(static_cast<size_t>(reduce_num_blocks(nred, 1)) * 32, 2u * 256u * 16u)));
     if (!r->d_loop_barrier) {
       HIPCHK(hipMalloc(reinterpret_cast<void**>(&r->d_loop_barrier), sizeof(uint32_t)));
       HIPCHK(hipMemset(r->d_loop_barrier, 0, sizeof(uint32_t)));
@@ -888,7 +888,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
       } else if (iter_form) {
         // default: ONE launch per iteration (k_micp_iter solves the previous iteration in its prologue) + one
         // closing solve: n_iter + 1 launches instead of 2 * n_iter
-        const uint32_t nb = reduce_num_blocks(nred);
+        const uint32_t nb = reduce_num_blocks(nred, 1);
         double* part[2] = {r->d_partials.p, r->d_partials.p + static_cast<size_t>(nb) * 16};
         for (uint32_t i = 0; i < n_iter; ++i)
           HIPCHK(launch_micp_iter(r->d_ds_points.p, dmask, r->d_points.p, r->d_normals.p, r->d_hits.p, nred, nb, r->d_call,

@@ -115,7 +115,7 @@ hipError_t launch_pointcloud2_unpack(const uint8_t* data, uint32_t point_step, u
                                      hipStream_t s);
 hipError_t launch_compose_poses(const xform* Tbm_dev, xform Tsb, xform* Tsm_out, xform* Tms_out, uint32_t n,
                                 hipStream_t s);
-uint32_t reduce_num_blocks(uint32_t n);
+uint32_t reduce_num_blocks(uint32_t n, uint32_t nposes);
 hipError_t launch_reduce_partials(const ReduceParams& p, hipStream_t s);
 // finalize one pose's partials into CrossStatistics (writes to out, which may be host-mapped memory)
 hipError_t launch_reduce_finalize(const double* partials, uint32_t nblocks, uint32_t nposes, cstats* out,
