@@ -228,15 +228,30 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle as orc  # cpu_baseline leg only: the oracle is the thing timed, never the product path
             m = orc.Mesh(v, f)
-            m.simulate_spherical(model, T.identity(), Tbm, bvh=True, nthreads=cores)
+            # 16 scans per call: the oracle spawns its worker threads per call (pthread_create x cores), which would
+            # otherwise dominate a single 131 072-ray scan on a many-core host
+            per_call = 16
+            Tb = np.array([Tbm] * per_call, dtype=T.TRANSFORM)
+            buf = m.simulate_spherical(model, T.identity(), Tb, bvh=True, nthreads=cores)   # outputs reused below
+            # the thread count that serves the oracle best on this host (it does not scale to every SMT thread of a
+            # two-socket box): short trial per candidate, then the 10 s sample with the winner
+            best_nt, best_rate = cores, 0.0
+            for nt in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8)}, reverse=True):
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    m.simulate_spherical(model, T.identity(), Tb, bvh=True, nthreads=nt, out=buf)
+                rate = 2 * per_call * n_rays / (time.perf_counter() - t1)
+                if rate > best_rate:
+                    best_nt, best_rate = nt, rate
             reps, t1 = 0, time.perf_counter()
             while time.perf_counter() - t1 < 10.0:
-                m.simulate_spherical(model, T.identity(), Tbm, bvh=True, nthreads=cores)
-                reps += 1
+                m.simulate_spherical(model, T.identity(), Tb, bvh=True, nthreads=best_nt, out=buf)
+                reps += per_call
             dt = time.perf_counter() - t1
-            cpu = {"value": round(reps * n_rays / dt, 1), "unit": "rays/s", "cores": cores, "kind": "port",
-                   "sample": "%d x the same 128x1024 / 100k-triangle scan in %.1f s, CPU oracle (BVH2, same intersector), "
-                             "%d threads" % (reps, dt, cores)}
+            cpu = {"value": round(reps * n_rays / dt, 1), "unit": "rays/s", "cores": best_nt, "kind": "port",
+                   "sample": "%d x the same 128x1024 / 100k-triangle scan (16 per call) in %.1f s, CPU oracle (BVH2, same "
+                             "intersector, five output attributes), %d threads (best of %d/%d/%d/%d on a %d-thread host)"
+                             % (reps, dt, best_nt, cores, cores // 2, cores // 4, cores // 8, cores)}
         metric = "ray-mesh intersections/s (128x1024 scan, 100k-tri mesh)"
         unit = "rays/s"
         workload = ("C2: 1 pose x 128x1024 spherical LiDAR, UV-sphere 100k triangles, find() only, 5 output "

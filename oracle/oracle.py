@@ -333,11 +333,14 @@ class Mesh:
         return out
 
     def simulate_spherical(self, model, Tsb, Tbm, bvh=True, nthreads=1,
-                           want=("hits", "ranges", "points", "normals", "face_ids"), counters=False):
+                           want=("hits", "ranges", "points", "normals", "face_ids"), counters=False, out=None):
+        """out: reuse the output arrays of an earlier call of the same size (timing loops: fresh arrays cost
+        first-touch page faults in every worker thread)."""
         Tbm = np.ascontiguousarray(Tbm, dtype=TRANSFORM).reshape(-1)
         Tsb = np.ascontiguousarray(Tsb, dtype=TRANSFORM).reshape(1)
         n = model.phi.size * model.theta.size * len(Tbm)
-        out = self._alloc(n, want)
+        if out is None:
+            out = self._alloc(n, want)
         cnt = Counters()
         lib().orc_simulate_spherical(self.h, C.byref(model), _p(Tsb), _p(Tbm), len(Tbm), int(bvh), nthreads,
                                      _p(out["hits"]), _p(out["ranges"]), _p(out["points"]), _p(out["normals"]),

@@ -424,6 +424,7 @@ typedef struct {
   /* work distribution */
   volatile uint64_t next;
   uint64_t total;
+  uint64_t grain;
   pthread_mutex_t mtx;
   orc_counters cnt;
 } sim_job;
@@ -502,12 +503,16 @@ static void sim_range(sim_job* J, uint64_t begin, uint64_t end, orc_counters* cn
 static void* sim_worker(void* arg)
 {
   sim_job* J = (sim_job*)arg;
+  /* private copy of the (read-only) job description: the shared struct's cache line is written by every worker's
+   * fetch-and-add on `next`, and reading the job fields from it for every ray made 256 threads run no faster
+   * than 7 */
+  sim_job Jl = *J;
   orc_counters local = {0, 0, 0};
   for (;;) {
-    const uint64_t b = __sync_fetch_and_add(&J->next, (uint64_t)ORC_GRAIN);
-    if (b >= J->total) break;
-    uint64_t e = b + ORC_GRAIN; if (e > J->total) e = J->total;
-    sim_range(J, b, e, &local);
+    const uint64_t b = __sync_fetch_and_add(&J->next, Jl.grain);
+    if (b >= Jl.total) break;
+    uint64_t e = b + Jl.grain; if (e > Jl.total) e = Jl.total;
+    sim_range(&Jl, b, e, &local);
   }
   pthread_mutex_lock(&J->mtx);
   J->cnt.nodes_visited += local.nodes_visited; J->cnt.tris_tested += local.tris_tested; J->cnt.rays += local.rays;
@@ -518,6 +523,12 @@ static void* sim_worker(void* arg)
 static int run_sim(sim_job* J, int nthreads, orc_counters* cnt)
 {
   J->next = 0; J->total = (uint64_t)J->width * J->height * J->nposes;
+  if (nthreads < 1) nthreads = 1;
+  /* the reference's grain of 128 rays belongs to TBB's work-stealing deques; with ONE shared counter it makes 256
+   * threads fight over a cache line (measured: 256 threads slower than 32), so the chunks grow with the job:
+   * about 16 per thread */
+  J->grain = J->total / ((uint64_t)nthreads * 16u);
+  if (J->grain < ORC_GRAIN) J->grain = ORC_GRAIN;
   pthread_mutex_init(&J->mtx, NULL);
   memset(&J->cnt, 0, sizeof(J->cnt));
   if (nthreads < 1) nthreads = 1;
@@ -868,6 +879,7 @@ typedef struct {
   const orc_range_measurement* beams; uint32_t nbeams; const orc_transform* Tsb; const orc_pf_params* p;
   int use_bvh; float* errors;
   volatile uint64_t next;
+  uint64_t grain;
 } pf_job;
 
 static void pf_particle(pf_job* J, uint32_t i)
@@ -904,11 +916,12 @@ static void pf_particle(pf_job* J, uint32_t i)
 static void* pf_worker(void* arg)
 {
   pf_job* J = (pf_job*)arg;
+  pf_job Jl = *J;  /* private copy of the read-only fields (see sim_worker) */
   for (;;) {
-    const uint64_t b = __sync_fetch_and_add(&J->next, (uint64_t)ORC_GRAIN);
-    if (b >= J->n) break;
-    uint64_t e = b + ORC_GRAIN; if (e > J->n) e = J->n;
-    for (uint64_t i = b; i < e; ++i) pf_particle(J, (uint32_t)i);
+    const uint64_t b = __sync_fetch_and_add(&J->next, Jl.grain);
+    if (b >= Jl.n) break;
+    uint64_t e = b + Jl.grain; if (e > Jl.n) e = Jl.n;
+    for (uint64_t i = b; i < e; ++i) pf_particle(&Jl, (uint32_t)i);
   }
   return NULL;
 }
@@ -917,8 +930,11 @@ int orc_pf_update(const orc_mesh* m, const orc_transform* poses, orc_particle_at
                   const orc_range_measurement* beams, uint32_t nbeams, const orc_transform* Tsb,
                   const orc_pf_params* p, int use_bvh, int nthreads, float* errors_out)
 {
-  pf_job J = {m, poses, attrs, n, beams, nbeams, Tsb, p, use_bvh, errors_out, 0};
+  pf_job J = {m, poses, attrs, n, beams, nbeams, Tsb, p, use_bvh, errors_out, 0, ORC_GRAIN};
   if (nthreads < 1) nthreads = 1;
+  J.grain = (uint64_t)n / ((uint64_t)nthreads * 16u);   /* particles per fetch (see run_sim) */
+  if (J.grain < 1) J.grain = 1;
+  if (J.grain > ORC_GRAIN) J.grain = ORC_GRAIN;
   if (nthreads == 1) { pf_worker(&J); return 0; }
   pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * nthreads);
   for (int i = 0; i < nthreads; ++i) pthread_create(&th[i], NULL, pf_worker, &J);
