@@ -136,7 +136,8 @@ struct rmclhip_rcc {
   cstats* h_stats = nullptr;       // pinned, host-mapped
   cstats* h_stats_dev = nullptr;   // device alias of h_stats
   MicpState* d_state = nullptr;
-  MicpState* h_state = nullptr;    // pinned
+  MicpState* h_state = nullptr;    // pinned, host-mapped
+  MicpState* h_state_dev = nullptr;  // device alias of h_state
   uint32_t* d_counter = nullptr;
   uint32_t* d_tickets = nullptr;
   uint32_t* d_loop_barrier = nullptr;  // counter of the persistent-loop grid barrier   // one arrival counter per pose for the fused reduction tail
@@ -357,7 +358,8 @@ rmclhip_status rmclhip_rcc_create(rmclhip_ctx* ctx, rmclhip_map* map, rmclhip_rc
   if (e == hipSuccess) e = hipEventCreate(&r->ev1);
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_stats), sizeof(cstats) * 2, hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&r->h_stats_dev), r->h_stats, 0);
-  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_state), sizeof(MicpState), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_state), sizeof(MicpState), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&r->h_state_dev), r->h_state, 0);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->d_state), 2 * sizeof(MicpState));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->d_counter), sizeof(uint32_t));
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_call), sizeof(MicpCall), hipHostMallocDefault);
@@ -766,7 +768,7 @@ static rmclhip_status reduce_enqueue(rmclhip_rcc* r, const xform& Tpre, const xf
   HIPCHK(launch_reduce_partials(p, r->stream));
   if (!r->fused_tail) {
     if (tail.mode == kTailStats) HIPCHK(launch_reduce_finalize(r->d_partials.p, nb, nposes, tail.stats_out, r->stream));
-    else if (tail.mode == kTailMicp) HIPCHK(launch_micp_step(r->d_partials.p, nb, r->Tsb, tail.Tbo, tail.call, tail.state, r->stream));
+    else if (tail.mode == kTailMicp) HIPCHK(launch_micp_step(r->d_partials.p, nb, r->Tsb, tail.Tbo, tail.call, tail.state, tail.state, r->stream));
     else if (tail.mode == kTailBatchSolve)
       HIPCHK(launch_batch_solve(r->d_partials.p, nb, nposes, r->Tsb, tail.Tdelta_out, tail.stats_out, r->stream));
   }
@@ -894,8 +896,10 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
           HIPCHK(launch_micp_iter(r->d_ds_points.p, dmask, r->d_points.p, r->d_normals.p, r->d_hits.p, nred, nb, r->d_call,
                                   part[(i + 1u) & 1u], part[i & 1u], r->d_state + (i & 1u), r->d_state + ((i + 1u) & 1u),
                                   i == 0, r->stream));
-        final_state = r->d_state + (n_iter & 1u);
-        HIPCHK(launch_micp_step(part[(n_iter - 1u) & 1u], nb, r->Tsb, Tbo, r->d_call, final_state, r->stream));
+        // the closing step writes the result straight into host-mapped memory (no copy node)
+        HIPCHK(launch_micp_step(part[(n_iter - 1u) & 1u], nb, r->Tsb, Tbo, r->d_call, r->d_state + (n_iter & 1u),
+                                r->h_state_dev, r->stream));
+        final_state = nullptr;
       } else
       for (uint32_t i = 0; i < n_iter; ++i) {
         ReduceTail tail;
@@ -905,7 +909,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
         tail.call = r->d_call;
         if (rmclhip_status st = reduce_enqueue(r, xidentity(), &r->d_state->T_snew_sold, maxd, 1, tail)) return st;
       }
-      HIPCHK(hipMemcpyAsync(r->h_state, final_state, sizeof(MicpState), hipMemcpyDeviceToHost, r->stream));
+      if (final_state) HIPCHK(hipMemcpyAsync(r->h_state, final_state, sizeof(MicpState), hipMemcpyDeviceToHost, r->stream));
       return RMCLHIP_OK;
     };
     if (r->use_graph) {

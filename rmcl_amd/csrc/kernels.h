@@ -122,7 +122,7 @@ hipError_t launch_reduce_finalize(const double* partials, uint32_t nblocks, uint
                                   hipStream_t s);
 // finalize + (Tsb*, Tbo*) + umeyama + compose; advances MicpState on the device
 hipError_t launch_micp_step(const double* partials, uint32_t nblocks, xform Tsb, xform Tbo, const MicpCall* call,
-                            MicpState* state, hipStream_t s);
+                            const MicpState* state, MicpState* state_out, hipStream_t s);
 // state: TWO MicpState slots (ping-pong of k_micp_iter); both initialised
 hipError_t launch_micp_init(MicpState* state, uint32_t* barrier, hipStream_t s);
 // one launch per MICP iteration: finishes the previous iteration (finalize + solve, redundantly in every block)

@@ -1228,10 +1228,16 @@ __global__ void k_micp_init(MicpState* st, uint32_t* barrier) {
 }
 
 // unfused form of the MICP step (kept for A/B against the fused tail of k_reduce_partials)
+// st_out may alias st (in place) or point to host-mapped memory: the closing step of a correction then delivers the
+// result without a device-to-host copy node
 __global__ void __launch_bounds__(64) k_micp_step(const double* __restrict__ partials, uint32_t nblocks, xform Tsb,
-                                                  xform Tbo, const MicpCall* call, MicpState* st) {
+                                                  xform Tbo, const MicpCall* call, const MicpState* st, MicpState* st_out) {
   const cstats stats_s = finalize_pose(partials, nblocks);
-  if (threadIdx.x == 0) micp_advance(stats_s, call ? call->Tsb : Tsb, call ? call->Tbo : Tbo, st);
+  if (threadIdx.x == 0) {
+    MicpState local = *st;
+    micp_advance(stats_s, call ? call->Tsb : Tsb, call ? call->Tbo : Tbo, &local);
+    *st_out = local;
+  }
 }
 
 // stale v1 corrector (lidar_corrector_embree_benchmark.cpp:127-135): per pose, Tdelta_b = Tsb * T_s * ~Tsb
@@ -1875,8 +1881,8 @@ hipError_t launch_micp_init(MicpState* state, uint32_t* barrier, hipStream_t s) 
 }
 
 hipError_t launch_micp_step(const double* partials, uint32_t nblocks, xform Tsb, xform Tbo, const MicpCall* call,
-                            MicpState* state, hipStream_t s) {
-  hipLaunchKernelGGL(k_micp_step, dim3(1), dim3(64), 0, s, partials, nblocks, Tsb, Tbo, call, state);
+                            const MicpState* state, MicpState* state_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_micp_step, dim3(1), dim3(64), 0, s, partials, nblocks, Tsb, Tbo, call, state, state_out);
   return hipGetLastError();
 }
 
