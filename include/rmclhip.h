@@ -248,6 +248,11 @@ rmclhip_status rmclhip_rcc_time_find(rmclhip_rcc* rcc, const rmclhip_transform* 
                                      float* ms_per_launch);
 rmclhip_status rmclhip_rcc_time_reduce(rmclhip_rcc* rcc, const rmclhip_transform* T_snew_sold, uint32_t iters,
                                        float* ms_per_launch);
+/* host-clock time of one complete synchronous rmclhip_rcc_correct_once as a C caller sees it (mean over `iters` calls
+ * after one untimed call); measurement aid like time_find / time_reduce */
+rmclhip_status rmclhip_rcc_time_correct_once(rmclhip_rcc* rcc, const rmclhip_transform* Tom, const rmclhip_transform* Tbo,
+                                             uint32_t n_iter, double convergence_progress, int refind_each_iteration,
+                                             uint32_t iters, float* ms_per_call);
 /* kernel variant selection: bits 0..3 traversal (15 = automatic, the default: four lanes per ray
  * up to 65536 rays in flight, one lane per ray up to 262144, one lane per ray on the 64-B quantised nodes above;
  * 0 = wave packet, 1 = one lane per ray, 2 = four lanes per ray, 4 = one lane per ray on quantised nodes),

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1035,6 +1036,23 @@ rmclhip_status rmclhip_rcc_time_reduce(rmclhip_rcc* r, const rmclhip_transform* 
   float total = 0.f;
   HIPCHK(hipEventElapsedTime(&total, r->ev0, r->ev1));
   *ms = total / static_cast<float>(iters);
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_time_correct_once(rmclhip_rcc* r, const rmclhip_transform* Tom, const rmclhip_transform* Tbo,
+                                             uint32_t n_iter, double convergence_progress, int refind_each_iteration,
+                                             uint32_t iters, float* ms_per_call) {
+  if (!r || !Tom || !Tbo || !ms_per_call || iters == 0) return fail(RMCLHIP_ERR_INVALID, "rcc_time_correct_once: bad arguments");
+  rmclhip_transform T;
+  rmclhip_cross_statistics S;
+  // one untimed call (graph capture / allocation), then `iters` complete synchronous corrections on the host clock:
+  // what a C or C++ caller of this ABI sees per rmclhip_rcc_correct_once
+  if (rmclhip_status st = rmclhip_rcc_correct_once(r, Tom, Tbo, n_iter, convergence_progress, refind_each_iteration, &T, &S)) return st;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t i = 0; i < iters; ++i)
+    if (rmclhip_status st = rmclhip_rcc_correct_once(r, Tom, Tbo, n_iter, convergence_progress, refind_each_iteration, &T, &S)) return st;
+  const auto t1 = std::chrono::steady_clock::now();
+  *ms_per_call = static_cast<float>(std::chrono::duration<double, std::milli>(t1 - t0).count() / iters);
   return RMCLHIP_OK;
 }
 

@@ -253,6 +253,17 @@ class CorrespondencesHIP:
         self._last_nposes = 1
         return T[0].copy(), s[0].copy()
 
+    def time_correct_once(self, Tom, Tbo, n_iter, convergence_progress=0.0, refind_each_iteration=False, iters=20):
+        """mean host-clock ms of one synchronous correct_once at the C ABI (no Python in the timed loop)"""
+        self._push_params()
+        a = np.ascontiguousarray(Tom, dtype=TRANSFORM).reshape(1)
+        b = np.ascontiguousarray(Tbo, dtype=TRANSFORM).reshape(1)
+        ms = C.c_float(0)
+        _capi.check(_capi.lib().rmclhip_rcc_time_correct_once(self._h, _ptr(a), _ptr(b), int(n_iter), float(convergence_progress),
+                                                              int(bool(refind_each_iteration)), int(iters), C.byref(ms)))
+        self._last_nposes = 1
+        return ms.value
+
     def correct_batch(self, Tbm):
         """v1 SphereCorrector::correct (lidar_corrector_embree_benchmark.cpp:127-135): Tdelta per pose."""
         self._push_params()
