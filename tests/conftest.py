@@ -59,6 +59,8 @@ def meshes():
                 cache[name] = syn.noisy_room(30000)
             elif name == "room100k":
                 cache[name] = syn.noisy_room(100000)
+            elif name == "sphere1m":
+                cache[name] = syn.uv_sphere(1000000)
             else:
                 raise KeyError(name)
         return cache[name]
