@@ -303,6 +303,18 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
     for (int c = 0; c < 4; ++c) q.child[c] = nd.child[c];
   }
 
+  out.cnodes.resize(out.nodes.size());
+  for (size_t i = 0; i < out.nodes.size(); ++i) {
+    const Node4& nd = out.nodes[i];
+    Node4C& cn = out.cnodes[i];
+    for (int c = 0; c < 4; ++c) {
+      cn.c[c].lo[0] = nd.x[c]; cn.c[c].lo[1] = nd.y[c]; cn.c[c].lo[2] = nd.z[c];
+      cn.c[c].hix = nd.x[4 + c]; cn.c[c].hiy = nd.y[4 + c]; cn.c[c].hiz = nd.z[4 + c];
+      cn.c[c].ref = nd.child[c];
+      cn.c[c].pad = 0;
+    }
+  }
+
   out.info.n_faces = nf;
   out.info.n_vertices = nv;
   out.info.n_nodes = static_cast<uint32_t>(out.nodes.size());

@@ -20,6 +20,7 @@ struct BvhInfo {
 struct BvhHost {
   std::vector<Node4> nodes;
   std::vector<Node4Q> qnodes;  // quantised twins, same indices
+  std::vector<Node4C> cnodes;  // child-major twins, same indices
   std::vector<TriRec> tris;  // leaf order
   BvhInfo info;
 };

@@ -102,6 +102,7 @@ struct rmclhip_map {
   BvhInfo info;
   uint32_t* d_nodes = nullptr;
   uint32_t* d_qnodes = nullptr;  // Node4Q twins
+  uint32_t* d_cnodes = nullptr;  // Node4C twins
   uint32_t* d_tris = nullptr;
   uint64_t bytes = 0;
 };
@@ -303,16 +304,20 @@ rmclhip_status rmclhip_map_create(rmclhip_ctx* ctx, const float* v, uint32_t nv,
   const size_t qb = bvh.qnodes.size() * sizeof(Node4Q);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_qnodes), qb);
   if (e == hipSuccess) e = hipMemcpy(m->d_qnodes, bvh.qnodes.data(), qb, hipMemcpyHostToDevice);
+  const size_t cb = bvh.cnodes.size() * sizeof(Node4C);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_cnodes), cb);
+  if (e == hipSuccess) e = hipMemcpy(m->d_cnodes, bvh.cnodes.data(), cb, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(m->d_tris, bvh.tris.data(), tb, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     if (m->d_nodes) (void)hipFree(m->d_nodes);
     if (m->d_qnodes) (void)hipFree(m->d_qnodes);
+    if (m->d_cnodes) (void)hipFree(m->d_cnodes);
     if (m->d_tris) (void)hipFree(m->d_tris);
     delete m;
     return fail(e == hipErrorOutOfMemory ? RMCLHIP_ERR_NOMEM : RMCLHIP_ERR_HIP,
                 std::string("map_create upload: ") + hipGetErrorString(e));
   }
-  m->bytes = nb + qb + tb;
+  m->bytes = nb + qb + cb + tb;
   *out = m;
   return RMCLHIP_OK;
 }
@@ -331,6 +336,7 @@ void rmclhip_map_release(rmclhip_map* map) {
     (void)hipSetDevice(map->ctx->device);
     if (map->d_nodes) (void)hipFree(map->d_nodes);
     if (map->d_qnodes) (void)hipFree(map->d_qnodes);
+    if (map->d_cnodes) (void)hipFree(map->d_cnodes);
     if (map->d_tris) (void)hipFree(map->d_tris);
     delete map;
   }
@@ -644,6 +650,7 @@ static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
   std::memset(&p, 0, sizeof(p));
   p.nodes = r->map->d_nodes;
   p.qnodes = r->map->d_qnodes;
+  p.cnodes = r->map->d_cnodes;
   p.tris = r->map->d_tris;
   p.model_tab = r->d_model_tab.p;
   p.W = r->W; p.H = r->H;
@@ -705,9 +712,10 @@ rmclhip_status rmclhip_rcc_find_cpc(rmclhip_rcc* r, const rmclhip_transform* Tbm
   r->n_model = r->n_dataset;
   r->nposes_last = 1;
   const xform Tsm = xmul(to_x(Tbm_est), r->Tsb);
-  HIPCHK(launch_cpc_find(r->map->d_nodes, r->map->d_tris, r->d_ds_points.p, r->n_dataset, r->max_dist, Tsm, xinv(Tsm),
-                         r->d_hits.p, r->d_ranges.p, r->d_points.p, r->d_normals.p, r->d_face_ids.p,
-                         (r->variant == 15) ? true : (r->variant == 2), r->stream));
+  const bool quad = (r->variant == 15) ? true : (r->variant == 2);  // four lanes per point read the child-major nodes
+  HIPCHK(launch_cpc_find(quad ? r->map->d_cnodes : r->map->d_nodes, r->map->d_tris, r->d_ds_points.p, r->n_dataset,
+                         r->max_dist, Tsm, xinv(Tsm), r->d_hits.p, r->d_ranges.p, r->d_points.p, r->d_normals.p,
+                         r->d_face_ids.p, quad, r->stream));
   HIPCHK(hipStreamSynchronize(r->stream));
   return RMCLHIP_OK;
 }

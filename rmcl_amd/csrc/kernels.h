@@ -15,6 +15,7 @@ enum ModelKind : uint32_t { kModelNone = 0, kModelSpherical = 1, kModelO1Dn = 2,
 struct FindParams {
   const uint32_t* nodes;   // Node4[]
   const uint32_t* qnodes;  // Node4Q[] (quantised twins)
+  const uint32_t* cnodes;  // Node4C[] (child-major twins)
   const uint32_t* tris;    // TriRec[]
   // spherical: [cos(phi_v) (H) | sin(phi_v) (H) | cos(theta_h) (W) | sin(theta_h) (W)], host libm values
   // o1dn:      dirs xyz (W*H*3)

@@ -401,17 +401,18 @@ __device__ __forceinline__ void trace_quad(const uint32_t* __restrict__ nodes, c
   if (c == 0u) *reinterpret_cast<uint32_t*>(sbase) = kDone;
   uint32_t spb = 256u;  // byte offset of the first free row
   uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
-  // this lane's planes inside a node: near / far group of each axis (sign-selected, layout.h) + its slot
-  const uint32_t onx = rs.onx + c * 4u, ofx = rs.ofx + c * 4u, ony = rs.ony + c * 4u, ofy = rs.ofy + c * 4u;
-  const uint32_t onz = rs.onz + c * 4u, ofz = rs.ofz + c * 4u, och = 96u + c * 4u;
+  // this lane's child inside a child-major node (layout.h: Node4C): 32 B = two dwordx4
+  const uint32_t coff = c * 32u;
+  const bool ngx = rs.inv.x < 0.0f, ngy = rs.inv.y < 0.0f, ngz = rs.inv.z < 0.0f;
   while (__any(cur != kDone)) {
     while (cur < kDone) {  // inner node (leaf references have bit 31 set)
-      const char* nd = nbase + (cur << 7);
-      const float pnx = *reinterpret_cast<const float*>(nd + onx), pfx = *reinterpret_cast<const float*>(nd + ofx);
-      const float pny = *reinterpret_cast<const float*>(nd + ony), pfy = *reinterpret_cast<const float*>(nd + ofy);
-      const float pnz = *reinterpret_cast<const float*>(nd + onz), pfz = *reinterpret_cast<const float*>(nd + ofz);
-      const uint32_t ref = *reinterpret_cast<const uint32_t*>(nd + och);
+      const uint4* nd = reinterpret_cast<const uint4*>(nbase + (cur << 7) + coff);
+      const uint4 q0 = nd[0], q1 = nd[1];  // lo.x lo.y lo.z hi.x | hi.y hi.z ref pad
       const uint32_t top = *reinterpret_cast<const uint32_t*>(sbase + (spb - 256u));
+      const float pnx = ngx ? asf(q0.w) : asf(q0.x), pfx = ngx ? asf(q0.x) : asf(q0.w);
+      const float pny = ngy ? asf(q1.x) : asf(q0.y), pfy = ngy ? asf(q0.y) : asf(q1.x);
+      const float pnz = ngz ? asf(q1.y) : asf(q0.z), pfz = ngz ? asf(q0.z) : asf(q1.y);
+      const uint32_t ref = q1.z;
       const float tn = fmaxf(fmaxf(fmaxf(fmaf(pnx, rs.inv.x, rs.noi.x), fmaf(pny, rs.inv.y, rs.noi.y)), fmaf(pnz, rs.inv.z, rs.noi.z)), 0.0f);
       const float tf = fminf(fminf(fminf(fmaf(pfx, rs.inv.x, rs.noi.x), fmaf(pfy, rs.inv.y, rs.noi.y)), fmaf(pfz, rs.inv.z, rs.noi.z)), best_t);
       // unique keys: entry distance with the slot number in the two low mantissa bits; misses (unused slots hold
@@ -596,14 +597,13 @@ __device__ __forceinline__ void nearest_quad(const uint32_t* __restrict__ nodes,
   if (c == 0u) *reinterpret_cast<uint32_t*>(sbase) = kDone;  // sentinel row (see trace_quad)
   uint32_t spb = 256u;
   uint32_t cur = active ? 0u : kDone;
-  const uint32_t coff = c * 4u;
+  const uint32_t coff = c * 32u;  // this lane's child inside a child-major node (layout.h: Node4C)
   while (__any(cur != kDone)) {
     while (cur < kDone) {
-      const char* nd = nbase + (cur << 7) + coff;
-      const float lx = *reinterpret_cast<const float*>(nd), hx = *reinterpret_cast<const float*>(nd + 16);
-      const float ly = *reinterpret_cast<const float*>(nd + 32), hy = *reinterpret_cast<const float*>(nd + 48);
-      const float lz = *reinterpret_cast<const float*>(nd + 64), hz = *reinterpret_cast<const float*>(nd + 80);
-      const uint32_t ref = *reinterpret_cast<const uint32_t*>(nd + 96);
+      const uint4* nd = reinterpret_cast<const uint4*>(nbase + (cur << 7) + coff);
+      const uint4 q0 = nd[0], q1 = nd[1];  // lo.x lo.y lo.z hi.x | hi.y hi.z ref pad
+      const float lx = asf(q0.x), ly = asf(q0.y), lz = asf(q0.z), hx = asf(q0.w), hy = asf(q1.x), hz = asf(q1.y);
+      const uint32_t ref = q1.z;
       const uint32_t top = *reinterpret_cast<const uint32_t*>(sbase + (spb - 256u));
       const float dx = fmaxf(fmaxf(lx - P.x, P.x - hx), 0.f);
       const float dy = fmaxf(fmaxf(ly - P.y, P.y - hy), 0.f);
@@ -792,7 +792,7 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   if (kPacket) {
     trace_packet((cu32p)(p.nodes), (cu32p)(p.tris), org_m, dir_m, ray_tfar, lane, h);
   } else if (kQuad) {
-    trace_quad(p.nodes, p.tris, org_m, dir_m, ray_tfar, sub, lane, lds_dyn, h);
+    trace_quad(p.cnodes, p.tris, org_m, dir_m, ray_tfar, sub, lane, lds_dyn, h);
   } else {
     if (kTrav == 4) trace_lane_ww<16, true>(p.qnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
     else trace_lane_ww<16>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);

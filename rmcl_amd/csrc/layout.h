@@ -66,6 +66,14 @@ struct alignas(64) Node4Q {
 };
 static_assert(sizeof(Node4Q) == 64, "Node4Q must be 64 B");
 
+// Child-major twin of a Node4, 128 B, same index: child c occupies 32 B = {lo.x lo.y lo.z hi.x | hi.y hi.z ref pad}.
+// The quad-cooperative traversals give each of a ray's four lanes ONE child: two dwordx4 loads per lane and node
+// visit instead of seven dword loads.
+struct alignas(128) Node4C {
+  struct Child { float lo[3]; float hix; float hiy, hiz; uint32_t ref; uint32_t pad; } c[4];
+};
+static_assert(sizeof(Node4C) == 128, "Node4C must be 128 B");
+
 struct alignas(64) TriRec {
   float v0[3];
   float e1[3];
