@@ -1,0 +1,105 @@
+"""GPU parity on adversarial meshes: random triangle soups (intersecting, sliver, zero-area triangles), exact duplicates
+of faces under different ids (every hit is a tie -> the (min t, min face id) rule decides), coplanar overlapping
+triangles and coordinates far from the origin.  Every traversal of find (wave packet, one lane per ray, quantised
+nodes, four lanes per ray), the closest-point query and the particle filter must agree with the BRUTE-FORCE oracle:
+no BVH on the checker's side, so builder, node twins and all traversal orders are covered end to end."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import assert_close_rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _soup(seed, n_tri, offset=(0.0, 0.0, 0.0), scale=8.0):
+    rng = np.random.RandomState(seed)
+    c = rng.uniform(-scale, scale, (n_tri, 1, 3))
+    tri = c + rng.normal(size=(n_tri, 3, 3)) * rng.uniform(0.05, 0.7, (n_tri, 1, 1))
+    tri[::17, 2] = tri[::17, 1]                                     # zero-area triangles (two equal vertices)
+    tri[::23] = tri[::23] * (1.0, 1.0, 0.0) + (0.0, 0.0, 0.5)       # a stack of coplanar, overlapping triangles in z = 0.5
+    v = (tri.reshape(-1, 3) + np.asarray(offset)).astype(np.float32)
+    f = np.arange(3 * n_tri, dtype=np.uint32).reshape(-1, 3)
+    return v, f
+
+
+def _duplicate_faces(v, f, seed):
+    """every face twice, ids shuffled: all hits tie exactly"""
+    rng = np.random.RandomState(seed)
+    ff = np.concatenate([f, f])
+    return v, ff[rng.permutation(len(ff))]
+
+
+@pytest.mark.parametrize("case", ["soup", "duplicates", "far_from_origin"])
+def test_find_all_traversals_vs_brute_force(ra, orc, ctx, case):
+    from rmcl_amd import synthetic as syn, types as T
+    if case == "soup":
+        v, f = _soup(1, 3000)
+    elif case == "duplicates":
+        v, f = _duplicate_faces(*_soup(2, 1500), seed=3)
+    else:
+        v, f = _soup(4, 2000, offset=(5000.0, -3000.0, 800.0))
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    model = syn.model_c1()
+    origin = (0.3, -0.2, 0.1) if case != "far_from_origin" else (5000.3, -3000.2, 800.1)
+    pose = T.transform_from_rpy(origin, (0.13, -0.27, 0.9))
+    Tsb = syn.tsb_offset()
+    ref = m.simulate_spherical(model, Tsb, pose, bvh=False)          # brute force over all triangles
+    assert 100 < int(ref["hits"].sum()) < 1024, int(ref["hits"].sum())   # hits and misses
+    for variant in (0, 1, 2, 4):
+        rcc = ra.RCCHipSpherical(hm)
+        rcc.set_variant(variant)
+        rcc.setTsb(Tsb)
+        rcc.setModel(model)
+        rcc.find(pose)
+        g = rcc.modelView()
+        what = "%s variant %d" % (case, variant)
+        assert np.array_equal(g["hits"].reshape(-1), ref["hits"]), what
+        assert np.array_equal(g["face_ids"].reshape(-1), ref["face_ids"]), what
+        assert_close_rel(g["ranges"].reshape(-1), ref["ranges"], 1e-5, 0, what + " ranges")
+        rcc.close()
+    if case == "duplicates":                                        # ties are everywhere: the smaller id of each pair must win
+        hit_ids = ref["face_ids"][ref["hits"] > 0]
+        assert len(np.unique(hit_ids)) > 50
+
+
+def test_cpc_and_pf_vs_brute_force_on_a_soup(ra, orc, ctx):
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = _duplicate_faces(*_soup(7, 1200), seed=8)
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    rng = np.random.RandomState(9)
+    pts = rng.uniform(-9, 9, (700, 3)).astype(np.float32)
+    I = T.identity()
+    for variant in (1, 2):
+        cpc = ra.CPCHip(hm)
+        cpc.set_variant(variant)
+        cpc.setTsb(I)
+        cpc.params.max_dist = 0.7
+        cpc.set_dataset(pts, None)
+        cpc.find(I)
+        g = cpc.modelView()
+        ref = m.cpc_find(I, I, pts, 0.7, bvh=False)
+        assert np.array_equal(g["face_ids"].reshape(-1), ref["face_ids"]) and np.array_equal(g["hits"].reshape(-1), ref["hits"])
+        assert_close_rel(g["ranges"].reshape(-1), ref["ranges"], 1e-5, 1e-7, "soup cpc distances")
+        cpc.close()
+    poses, attrs = syn.uniform_particles(300, seed=10, bb_min=(-7, -7, -7, -0.3, -0.3, -math.pi), bb_max=(7, 7, 7, 0.3, 0.3, math.pi))
+    beams = ra.beams_from_points(syn.model_directions(syn.model_pf16())[::5] * np.float32(2.5))
+    a_ref = attrs.copy()
+    e_ref = m.pf_update(poses, a_ref, beams, I, orc.pf_params(), bvh=False, want_errors=True)
+    for variant in (0, 64, 64 | 128):
+        upd = ra.PCDSensorUpdaterHip(hm)
+        upd.init()
+        upd.set_variant(variant)
+        upd.setInput(beams, I)
+        d_p, d_a = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
+        d_e = ra.DeviceArray(ctx, np.float32, len(poses) * len(beams))
+        upd.set_error_output(d_e)
+        upd.update(d_p, d_a)
+        assert_close_rel(d_e.download().reshape(e_ref.shape), e_ref, 1e-5, 1e-6, "soup pf errors variant %d" % variant)
+        a = d_a.download()
+        assert np.array_equal(a["likelihood"]["n_meas"], a_ref["likelihood"]["n_meas"])
+        assert_close_rel(a["likelihood"]["mean"], a_ref["likelihood"]["mean"], 1e-5, 1e-12, "soup pf mean")
+        upd.close()
