@@ -138,7 +138,7 @@ def main():
         # dominant kernel, measured live: HIP events on the rcc's own stream around back-to-back launches
         kernel_ms = rcc.time_find(Tbm, iters=max(50, min(args.steps, 500)))
         b_alg = algorithmic_bytes_raycast(n_rays, len(f), 1)
-        kname = "k_find<spherical,%s>" % ("packet" if (args.variant & 0xF) == 0 else "lane")
+        kname = "k_find<spherical,%s>" % ("packet" if (args.variant & 0xF) == 0 else "lane")  # 15 / 1 / 5: one lane per ray
         traffic = measured_traffic("k_find_packet" if (args.variant & 0xF) == 0 else "k_find_lane")
 
         if rank == 0 and not args.no_extras:

@@ -254,8 +254,9 @@ rmclhip_status rmclhip_rcc_time_correct_once(rmclhip_rcc* rcc, const rmclhip_tra
                                              uint32_t n_iter, double convergence_progress, int refind_each_iteration,
                                              uint32_t iters, float* ms_per_call);
 /* kernel variant selection: bits 0..3 traversal (15 = automatic, the default: four lanes per ray
- * up to 65536 rays in flight, one lane per ray up to 262144, one lane per ray on the 64-B quantised nodes above;
- * 0 = wave packet, 1 = one lane per ray, 2 = four lanes per ray, 4 = one lane per ray on quantised nodes),
+ * up to 65536 rays in flight, one lane per ray with a quad-finished tail up to 262144, one lane per ray on the 64-B
+ * quantised nodes above; 0 = wave packet, 1 = one lane per ray, 2 = four lanes per ray, 4 = one lane per ray on
+ * quantised nodes, 5 = one lane per ray whose last <= 16 rays per wave are handed to four lanes each),
  * bits 4..7 = 1 + log2(tile width) of the wave's scan-image tile (0 = automatic, 8x8 for tall images),
  * bit 8 = fused last-block reduction tail (A/B), bit 9 = disable the hipGraph MICP loop (A/B), bits 10..12 = form
  * of the MICP loop (0 = one launch per iteration, the default; 1 = reduce + solve launches; 2..6 = persistent

@@ -642,7 +642,7 @@ static int find_variant(const rmclhip_rcc* r, uint32_t nposes) {
   if (r->variant != 15) return r->variant;
   const uint64_t rays = static_cast<uint64_t>(r->W) * r->H * nposes;
   if (rays <= 65536u) return 2;   // bound by the slowest ray's fetch chain: four lanes per ray
-  if (rays <= 262144u) return 1;  // one scan fills the chip once: one lane per ray, full-precision nodes
+  if (rays <= 262144u) return 5;  // one scan fills the chip once: one lane per ray, the tail of every wave finished by quads
   return 4;                       // batches are bound by L1 accesses: one lane per ray on the 64-B quantised nodes
 }
 
@@ -1068,7 +1068,7 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
   ApiGuard guard_("rmclhip_rcc_set_variant");
   if (!r || variant < 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: bad arguments");
   const int kind = variant & 0xF, tile = (variant >> 4) & 0xF;
-  if ((kind > 4 && kind != 15) || kind == 3 || tile > 7 || (variant >> 13) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
+  if ((kind > 5 && kind != 15) || kind == 3 || tile > 7 || (variant >> 13) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
   r->variant = kind;
   r->tile_override = tile;
   r->fused_tail = ((variant >> 8) & 1) != 0;

@@ -385,12 +385,21 @@ __device__ __forceinline__ uint32_t quad_dpp(uint32_t v) {
 constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kQuadXor3 = 0x1B;  // quad_perm [1,0,3,2] [2,3,0,1] [3,2,1,0]
 constexpr uint32_t kQuadStackEntries = 1u + 64u + 4u;            // sentinel + the builder's bound + scratch rows
 
+// A traversal in progress, handed from one lane to a quad (see trace_lane_ww_tail): current node, number of stack
+// entries already stored in rows 1..n_stack of the quad's column, and the best hit so far.
+struct QuadResume {
+  uint32_t cur, n_stack;
+  float best_t;
+  uint32_t best_face, best_rec;
+};
+
+template <bool kResume = false>
 __device__ __forceinline__ void trace_quad(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris, f3 O,
                                            f3 D, float ray_tfar, uint32_t c, uint32_t ray, uint32_t* __restrict__ lds,
-                                           RayHit& h) {
+                                           RayHit& h, const QuadResume* resume = nullptr) {
   const RaySlab rs = make_ray_slab(O, D);
-  float best_t = ray_tfar;
-  uint32_t best_face = kInvalidFace, best_rec = 0;
+  float best_t = kResume ? resume->best_t : ray_tfar;
+  uint32_t best_face = kResume ? resume->best_face : kInvalidFace, best_rec = kResume ? resume->best_rec : 0u;
   constexpr uint32_t kDone = 0x7FFFFFFFu;
   // The quad's stack: entry e of ray r at byte (e*64 + r)*4 of `lds` (kQuadStackEntries rows).  Row 0 holds the
   // sentinel kDone, so that popping an empty stack ends the ray without a test; rows above the top are scratch:
@@ -399,8 +408,8 @@ __device__ __forceinline__ void trace_quad(const uint32_t* __restrict__ nodes, c
   const char* nbase = reinterpret_cast<const char*>(nodes);
   char* sbase = reinterpret_cast<char*>(lds) + ray * 4u;
   if (c == 0u) *reinterpret_cast<uint32_t*>(sbase) = kDone;
-  uint32_t spb = 256u;  // byte offset of the first free row
-  uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
+  uint32_t spb = kResume ? ((resume->n_stack + 1u) << 8) : 256u;  // byte offset of the first free row
+  uint32_t cur = (ray_tfar >= 0.0f) ? (kResume ? resume->cur : 0u) : kDone;
   // this lane's child inside a child-major node (layout.h: Node4C): 32 B = two dwordx4
   const uint32_t coff = c * 32u;
   const bool ngx = rs.inv.x < 0.0f, ngy = rs.inv.y < 0.0f, ngz = rs.inv.z < 0.0f;
@@ -473,6 +482,117 @@ __device__ __forceinline__ void trace_quad(const uint32_t* __restrict__ nodes, c
       spb -= 256u;
     }
   }
+  h.t = best_t;
+  h.face = best_face;
+  h.rec = best_rec;
+}
+
+// trace_lane_ww whose LAST rays are finished by quads.  A single scan ends when its slowest ray ends, and that ray sits
+// in a wave whose other lanes have long been idle: once at most kTailRays rays of the wave are still walking, each of
+// them is handed to four lanes (state through LDS, its stack copied into a quad-layout column) and finishes with
+// trace_quad -- shorter node steps, four triangles per leaf step -- instead of crawling on alone.  Same visits per
+// ray up to ordering, same results.  LDS: lane stacks | quad-tail stacks (64 columns x kQuadStackEntries rows) | hand-over
+// slots (4 waves x kTailRays x 12 dwords).
+constexpr uint32_t kTailRays = 16;
+constexpr uint32_t kTailXferDwords = 12;
+
+template <int kLdsEntries>
+__device__ __forceinline__ void trace_lane_ww_tail(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ cnodes,
+                                                   const uint32_t* __restrict__ tris, f3 O, f3 D, float ray_tfar,
+                                                   uint32_t* __restrict__ lds_stack, uint32_t lds_stride,
+                                                   uint32_t* __restrict__ qstack, uint32_t* __restrict__ xfer_wave,
+                                                   RayHit& h) {
+  const RaySlab rs = make_ray_slab(O, D);
+  float best_t = ray_tfar;
+  uint32_t best_face = kInvalidFace, best_rec = 0;
+  constexpr uint32_t kDone = 0x7FFFFFFFu;
+  uint32_t priv[(kLdsEntries < 64) ? (64 - kLdsEntries) : 1];
+  uint32_t sp = 0;
+  uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#define RMCL_PUSH(v) { if (kLdsEntries >= 64 || sp < kLdsEntries) lds_stack[sp * lds_stride] = (v); else priv[sp - kLdsEntries] = (v); ++sp; }
+#define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; if (kLdsEntries >= 64 || sp < kLdsEntries) cur = lds_stack[sp * lds_stride]; else cur = priv[sp - kLdsEntries]; } }
+  for (;;) {
+    const uint64_t m_act = __ballot(cur != kDone);
+    if (m_act == 0) break;
+    const uint32_t na = static_cast<uint32_t>(__popcll(m_act));
+    if (na <= kTailRays) {
+      // ---- hand the remaining rays to quads ----
+      const bool mine = cur != kDone;
+      const uint32_t j = static_cast<uint32_t>(__popcll(m_act & ((1ull << lane) - 1ull)));
+      if (mine) {
+        uint32_t* x = xfer_wave + j * kTailXferDwords;
+        x[0] = __float_as_uint(O.x); x[1] = __float_as_uint(O.y); x[2] = __float_as_uint(O.z);
+        x[3] = __float_as_uint(D.x); x[4] = __float_as_uint(D.y); x[5] = __float_as_uint(D.z);
+        x[6] = __float_as_uint(ray_tfar); x[7] = __float_as_uint(best_t); x[8] = best_face; x[9] = best_rec;
+        x[10] = cur; x[11] = sp;
+        // the stack, bottom to top, into rows 1..sp of column (wave*16 + j) of the quad-layout region
+        uint32_t* col = qstack + (wave * kTailRays + j);
+        for (uint32_t e = 0; e < sp; ++e) {
+          const uint32_t v = (kLdsEntries >= 64 || e < kLdsEntries) ? lds_stack[e * lds_stride] : priv[e - kLdsEntries];
+          col[(e + 1u) * 64u] = v;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // the hand-over slots and stack columns are read by OTHER lanes of this wave
+      const uint32_t q = lane >> 2, c = lane & 3u;
+      const bool have = q < na;
+      const uint32_t* x = xfer_wave + (have ? q : 0u) * kTailXferDwords;
+      const f3 Oq = mk3(asf(x[0]), asf(x[1]), asf(x[2])), Dq = mk3(asf(x[3]), asf(x[4]), asf(x[5]));
+      QuadResume rsm;
+      rsm.cur = x[10]; rsm.n_stack = x[11]; rsm.best_t = asf(x[7]); rsm.best_face = x[8]; rsm.best_rec = x[9];
+      const float tfq = have ? asf(x[6]) : -1.0f;
+      RayHit hq;
+      trace_quad<true>(cnodes, tris, Oq, Dq, tfq, c, wave * kTailRays + q, qstack, hq, &rsm);
+      if (have && c == 0u) {
+        uint32_t* y = xfer_wave + q * kTailXferDwords;
+        y[7] = __float_as_uint(hq.t); y[8] = hq.face; y[9] = hq.rec;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (mine) {
+        const uint32_t* y = xfer_wave + j * kTailXferDwords;
+        best_t = asf(y[7]); best_face = y[8]; best_rec = y[9];
+      }
+      break;
+    }
+    // phase 1: inner nodes
+    while ((cur != kDone) && !(cur & kLeafBit)) {
+      uint32_t key[4], ref[4];
+      node_keys(nodes, cur, rs, best_t, key, ref);
+      RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
+      if (key[3] != kNone) RMCL_PUSH(ref[3])
+      if (key[2] != kNone) RMCL_PUSH(ref[2])
+      if (key[1] != kNone) RMCL_PUSH(ref[1])
+      if (key[0] != kNone) cur = ref[0];
+      else RMCL_POP()
+    }
+    // phase 2: this lane's leaf (if any)
+    if (cur != kDone) {
+      const uint32_t first = cur & 0x0FFFFFFFu;
+      const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
+      for (uint32_t i = 0; i < cnt; ++i) {
+        const uint4* tp = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(first + i) * 4u;
+        const uint4 a = tp[0], b = tp[1], c = tp[2], d = tp[3];
+        const f3 v0 = mk3(asf(a.x), asf(a.y), asf(a.z));
+        const f3 e1 = mk3(asf(a.w), asf(b.x), asf(b.y));
+        const f3 e2 = mk3(asf(b.z), asf(b.w), asf(c.x));
+        const f3 Ng = mk3(asf(c.y), asf(c.z), asf(c.w));
+        const uint32_t face = d.w;
+        float Tt, aden;
+        const bool ok = tri_accept(v0, e1, e2, Ng, O, D, Tt, aden);
+        if (ok) {
+          const float t = Tt / aden;
+          const bool acc = (t >= 0.0f) && (t <= ray_tfar);
+          const bool closer = acc && ((t < best_t) || ((t == best_t) && (face < best_face)));
+          best_t = closer ? t : best_t;
+          best_face = closer ? face : best_face;
+          best_rec = closer ? (first + i) : best_rec;
+        }
+      }
+      RMCL_POP()
+    }
+  }
+#undef RMCL_PUSH
+#undef RMCL_POP
   h.t = best_t;
   h.face = best_face;
   h.rec = best_rec;
@@ -734,7 +854,8 @@ __device__ __forceinline__ f3 pinhole_direction(float fx, float fy, float cx, fl
 // ---------------------------------------------------------------------------------------------
 // find
 // ---------------------------------------------------------------------------------------------
-// kTrav: 0 = wave packet, 1 = one lane per ray (while-while), 4 = the same on the quantised 64-B nodes,
+// kTrav: 0 = wave packet, 1 = one lane per ray (while-while), 4 = the same on the quantised 64-B nodes, 5 = one lane
+// per ray with the tail of every wave handed to quads,
 // 2 = four lanes per ray (quad-cooperative; the block
 // of 256 threads then covers ONE 64-ray tile instead of four)
 template <uint32_t kModel, int kTrav>
@@ -795,6 +916,9 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
     trace_quad(p.cnodes, p.tris, org_m, dir_m, ray_tfar, sub, lane, lds_dyn, h);
   } else {
     if (kTrav == 4) trace_lane_ww<16, true>(p.qnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
+    else if (kTrav == 5)
+      trace_lane_ww_tail<16>(p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x,
+                             lds_dyn + 16u * 256u, lds_dyn + 16u * 256u + kQuadStackEntries * 64u + (threadIdx.x >> 6) * (kTailRays * kTailXferDwords), h);
     else trace_lane_ww<16>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
   }
 
@@ -1801,6 +1925,9 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
   } else if (variant == 4) {  // one lane per ray on the 64-B quantised nodes
     const size_t lds = 16u * 256u * sizeof(uint32_t);
     RMCL_LAUNCH_FIND(4, lds)
+  } else if (variant == 5) {  // one lane per ray, the last rays of every wave finished by quads
+    const size_t lds = (16u * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords) * sizeof(uint32_t);
+    RMCL_LAUNCH_FIND(5, lds)
   } else {             // per-lane while-while traversal: 16 stack entries per lane in LDS, the rest in scratch
     const size_t lds = 16u * 256u * sizeof(uint32_t);
     RMCL_LAUNCH_FIND(1, lds)
