@@ -14,7 +14,7 @@ ctx = ra.Context(0)
 v, f = syn.uv_sphere(100000) if mesh == "sphere" else syn.noisy_room(100000)
 hm = ra.import_hip_map(ctx, v, f)
 base = syn.pose_c2_truth() if mesh == "sphere" else T.transform_from_rpy((1.5, -2.0, 1.6), (0.02, -0.03, 0.4))
-for kind in (1, 5):
+for kind in (1, 5, 2):
     for H, W in ((128, 1024), (64, 1024), (64, 2048), (16, 900)):
         m = syn.model_c2()
         m.phi.inc = m.phi.inc * 128.0 / H
