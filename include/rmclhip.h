@@ -127,7 +127,9 @@ typedef struct rmclhip_resampler rmclhip_resampler;
 const char* rmclhip_last_error(void);
 const char* rmclhip_version(void);
 
-/* context = one device (+ default resources). device index as seen by HIP. */
+/* context = one device (+ default resources). device index as seen by HIP.  The context is reference counted:
+ * every map / rcc / pf / resampler handle created from it holds a reference, rmclhip_ctx_destroy drops the
+ * creator's, and the context is freed with its last holder -- destroy order does not matter. */
 rmclhip_status rmclhip_ctx_create(int device, rmclhip_ctx** out);
 void rmclhip_ctx_destroy(rmclhip_ctx* ctx);
 rmclhip_status rmclhip_ctx_device_name(rmclhip_ctx* ctx, char* buf, size_t n);
@@ -256,12 +258,20 @@ rmclhip_status rmclhip_rcc_time_correct_once(rmclhip_rcc* rcc, const rmclhip_tra
 /* kernel variant selection: bits 0..3 traversal (15 = automatic, the default: four lanes per ray
  * up to 65536 rays in flight, one lane per ray with a quad-finished tail up to 262144, one lane per ray on the 64-B
  * quantised nodes above; 0 = wave packet, 1 = one lane per ray, 2 = four lanes per ray, 4 = one lane per ray on
- * quantised nodes, 5 = one lane per ray whose last <= 16 rays per wave are handed to four lanes each),
+ * quantised nodes, 5 = one lane per ray whose last <= 16 rays per wave are handed to four lanes each; 6 / 7 = 5 with
+ * the top 85 / 341 nodes of the tree resident in LDS, 8 = 5 with one-round-trip leaves, 9 / 10 = 8 with the LDS top),
  * bits 4..7 = 1 + log2(tile width) of the wave's scan-image tile (0 = automatic, 8x8 for tall images),
  * bit 8 = fused last-block reduction tail (A/B), bit 9 = disable the hipGraph MICP loop (A/B), bits 10..12 = form
  * of the MICP loop (0 = one launch per iteration, the default; 1 = reduce + solve launches; 2..6 = persistent
  * kernel with 16..256 blocks and a grid barrier, A/B) */
 rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* rcc, int variant);
+/* the traversal (bits 0..3 above, never 15) a find of `nposes` scans of the current model would launch */
+rmclhip_status rmclhip_rcc_find_variant(const rmclhip_rcc* rcc, uint32_t nposes, int* variant_out);
+/* DIAGNOSTICS (tools/probe_find.py; not part of the reference interface): one spherical find() through an instrumented
+ * copy of the one-lane-per-ray traversal that stamps s_memtime around every node / leaf step of every wave.
+ * mode: bit 0 = one-round-trip leaves, bit 1 = LDS-resident top of the tree.  log_out: n_tiles x 512 dwords (host). */
+rmclhip_status rmclhip_debug_probe_find(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est, int mode, uint32_t* log_out,
+                                        size_t log_cap_dwords, uint32_t* n_tiles_out);
 /* rm::Simulator::simulate(Memory<Transform>, Bundle&) (batch form, lidar_corrector_embree_benchmark.cpp:117):
  * one launch for nposes x H x W rays; model buffers become pose-major [pose][vid][hid]. */
 rmclhip_status rmclhip_rcc_find_batch(rmclhip_rcc* rcc, const rmclhip_transform* Tbm, uint32_t nposes);

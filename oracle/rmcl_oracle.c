@@ -147,7 +147,8 @@ static void tri_setup(orc_tri* T, orc_vec3 a, orc_vec3 b, orc_vec3 c)
 
 /* Moeller-Trumbore in Embree's formulation (triangle_intersector_moeller.h):
  * scaled barycentrics, sign-adjusted, rejection tests before the single division.
- * Two-sided (no back-face culling).  Returns 1 and t on a hit in [tnear,tfar]. */
+ * Two-sided (no back-face culling).  Returns 1 and t on a hit in (tnear,tfar]: Embree's depth test is strict on
+ * the near side (absDen * tnear < T), so a ray that starts exactly on a triangle does not hit it. */
 static inline int tri_intersect(const orc_tri* T, orc_vec3 O, orc_vec3 D, float tnear, float tfar, float* t_out)
 {
   const orc_vec3 C = v_sub(T->v0, O);
@@ -161,7 +162,7 @@ static inline int tri_intersect(const orc_tri* T, orc_vec3 O, orc_vec3 D, float 
   if (!(den != 0.0f)) return 0;
   if (!(U >= 0.0f && V >= 0.0f && (U + V) <= aden)) return 0;
   const float t = Tt / aden;
-  if (!(t >= tnear && t <= tfar)) return 0;
+  if (!(aden * tnear < Tt && t <= tfar)) return 0;
   *t_out = t;
   return 1;
 }
@@ -500,45 +501,99 @@ static void sim_range(sim_job* J, uint64_t begin, uint64_t end, orc_counters* cn
 
 #define ORC_GRAIN 128 /* the reference's TBB grain (PCDSensorUpdaterEmbree.cpp:331) */
 
-static void* sim_worker(void* arg)
+/* --- persistent worker pool -------------------------------------------------------------------------------
+ * The reference parallelises with TBB (a process-wide pool of work-stealing workers).  The oracle keeps ONE pool
+ * of pthreads alive across calls (spawning 256 threads per 131 072-ray scan cost more than the scan) and hands
+ * worker w the chunks w, w + N, w + 2N, ... of the job: no shared counter, no contended cache line, every worker
+ * writes its own slice of the outputs.  Chunks of 512 rays = 4 TBB grains keep neighbouring rays (same subtrees) in
+ * one core's cache while giving every one of 256 workers >= 1 chunk of a 128x1024 scan. */
+typedef void (*orc_pool_fn)(void* job, int worker, int nworkers);
+static struct {
+  pthread_mutex_t mtx;
+  pthread_cond_t go, done;
+  pthread_t* th;
+  int n_alive;        /* threads created so far (ids 1..n_alive; the caller is worker 0) */
+  int n_active;       /* workers taking part in the current job (including the caller) */
+  uint64_t epoch;     /* bumped per job */
+  int pending;        /* pool threads still running the current job */
+  orc_pool_fn fn;
+  void* job;
+  int inited;
+} g_pool;
+static pthread_mutex_t g_pool_call = PTHREAD_MUTEX_INITIALIZER; /* one parallel region at a time */
+
+static void* pool_thread(void* arg)
+{
+  const int id = (int)(intptr_t)arg;
+  uint64_t seen = 0;
+  pthread_mutex_lock(&g_pool.mtx);
+  for (;;) {
+    while (g_pool.epoch == seen) pthread_cond_wait(&g_pool.go, &g_pool.mtx);
+    seen = g_pool.epoch;
+    if (id < g_pool.n_active) {
+      orc_pool_fn fn = g_pool.fn; void* job = g_pool.job; const int n = g_pool.n_active;
+      pthread_mutex_unlock(&g_pool.mtx);
+      fn(job, id, n);
+      pthread_mutex_lock(&g_pool.mtx);
+      if (--g_pool.pending == 0) pthread_cond_signal(&g_pool.done);
+    }
+  }
+  return NULL;
+}
+
+static void pool_run(orc_pool_fn fn, void* job, int nthreads)
+{
+  if (nthreads <= 1) { fn(job, 0, 1); return; }
+  pthread_mutex_lock(&g_pool_call);
+  if (!g_pool.inited) {
+    pthread_mutex_init(&g_pool.mtx, NULL);
+    pthread_cond_init(&g_pool.go, NULL);
+    pthread_cond_init(&g_pool.done, NULL);
+    g_pool.inited = 1;
+  }
+  pthread_mutex_lock(&g_pool.mtx);
+  if (g_pool.n_alive < nthreads - 1) {
+    g_pool.th = (pthread_t*)realloc(g_pool.th, sizeof(pthread_t) * (size_t)(nthreads - 1));
+    for (int i = g_pool.n_alive; i < nthreads - 1; ++i) {
+      /* a thread born now has seen = 0 < epoch only if epoch > 0: give it the current epoch by creating it while
+       * we hold the mutex and letting it wait for the NEXT bump */
+      pthread_create(&g_pool.th[i], NULL, pool_thread, (void*)(intptr_t)(i + 1));
+    }
+    g_pool.n_alive = nthreads - 1;
+  }
+  g_pool.fn = fn; g_pool.job = job; g_pool.n_active = nthreads; g_pool.pending = nthreads - 1;
+  g_pool.epoch++;
+  pthread_cond_broadcast(&g_pool.go);
+  pthread_mutex_unlock(&g_pool.mtx);
+  fn(job, 0, nthreads);
+  pthread_mutex_lock(&g_pool.mtx);
+  while (g_pool.pending != 0) pthread_cond_wait(&g_pool.done, &g_pool.mtx);
+  pthread_mutex_unlock(&g_pool.mtx);
+  pthread_mutex_unlock(&g_pool_call);
+}
+
+static void sim_worker(void* arg, int worker, int nworkers)
 {
   sim_job* J = (sim_job*)arg;
-  /* private copy of the (read-only) job description: the shared struct's cache line is written by every worker's
-   * fetch-and-add on `next`, and reading the job fields from it for every ray made 256 threads run no faster
-   * than 7 */
-  sim_job Jl = *J;
+  sim_job Jl = *J; /* private copy of the read-only job description */
   orc_counters local = {0, 0, 0};
-  for (;;) {
-    const uint64_t b = __sync_fetch_and_add(&J->next, Jl.grain);
-    if (b >= Jl.total) break;
+  for (uint64_t b = (uint64_t)worker * Jl.grain; b < Jl.total; b += (uint64_t)nworkers * Jl.grain) {
     uint64_t e = b + Jl.grain; if (e > Jl.total) e = Jl.total;
     sim_range(&Jl, b, e, &local);
   }
   pthread_mutex_lock(&J->mtx);
   J->cnt.nodes_visited += local.nodes_visited; J->cnt.tris_tested += local.tris_tested; J->cnt.rays += local.rays;
   pthread_mutex_unlock(&J->mtx);
-  return NULL;
 }
 
 static int run_sim(sim_job* J, int nthreads, orc_counters* cnt)
 {
   J->next = 0; J->total = (uint64_t)J->width * J->height * J->nposes;
   if (nthreads < 1) nthreads = 1;
-  /* the reference's grain of 128 rays belongs to TBB's work-stealing deques; with ONE shared counter it makes 256
-   * threads fight over a cache line (measured: 256 threads slower than 32), so the chunks grow with the job:
-   * about 16 per thread */
-  J->grain = J->total / ((uint64_t)nthreads * 16u);
-  if (J->grain < ORC_GRAIN) J->grain = ORC_GRAIN;
+  J->grain = 4 * ORC_GRAIN;
   pthread_mutex_init(&J->mtx, NULL);
   memset(&J->cnt, 0, sizeof(J->cnt));
-  if (nthreads < 1) nthreads = 1;
-  if (nthreads == 1) { sim_worker(J); }
-  else {
-    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * nthreads);
-    for (int i = 0; i < nthreads; ++i) pthread_create(&th[i], NULL, sim_worker, J);
-    for (int i = 0; i < nthreads; ++i) pthread_join(th[i], NULL);
-    free(th);
-  }
+  pool_run(sim_worker, J, nthreads);
   pthread_mutex_destroy(&J->mtx);
   if (cnt) *cnt = J->cnt;
   return 0;
@@ -913,17 +968,14 @@ static void pf_particle(pf_job* J, uint32_t i)
   J->attrs[i] = a;
 }
 
-static void* pf_worker(void* arg)
+static void pf_worker(void* arg, int worker, int nworkers)
 {
   pf_job* J = (pf_job*)arg;
   pf_job Jl = *J;  /* private copy of the read-only fields (see sim_worker) */
-  for (;;) {
-    const uint64_t b = __sync_fetch_and_add(&J->next, Jl.grain);
-    if (b >= Jl.n) break;
+  for (uint64_t b = (uint64_t)worker * Jl.grain; b < Jl.n; b += (uint64_t)nworkers * Jl.grain) {
     uint64_t e = b + Jl.grain; if (e > Jl.n) e = Jl.n;
     for (uint64_t i = b; i < e; ++i) pf_particle(&Jl, (uint32_t)i);
   }
-  return NULL;
 }
 
 int orc_pf_update(const orc_mesh* m, const orc_transform* poses, orc_particle_attributes* attrs, uint32_t n,
@@ -935,11 +987,7 @@ int orc_pf_update(const orc_mesh* m, const orc_transform* poses, orc_particle_at
   J.grain = (uint64_t)n / ((uint64_t)nthreads * 16u);   /* particles per fetch (see run_sim) */
   if (J.grain < 1) J.grain = 1;
   if (J.grain > ORC_GRAIN) J.grain = ORC_GRAIN;
-  if (nthreads == 1) { pf_worker(&J); return 0; }
-  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * nthreads);
-  for (int i = 0; i < nthreads; ++i) pthread_create(&th[i], NULL, pf_worker, &J);
-  for (int i = 0; i < nthreads; ++i) pthread_join(th[i], NULL);
-  free(th);
+  pool_run(pf_worker, &J, nthreads);
   return 0;
 }
 

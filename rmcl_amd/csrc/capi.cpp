@@ -94,7 +94,17 @@ struct DevBuf {
 struct rmclhip_ctx {
   int device = 0;
   hipDeviceProp_t props;
+  // map / rcc / pf / resampler handles keep a pointer to their context: each holds a reference, and
+  // rmclhip_ctx_destroy only drops the creator's, so destroying the context before its children is safe
+  std::atomic<int> refs{1};
 };
+
+namespace {
+inline void ctx_retain(rmclhip_ctx* c) { c->refs.fetch_add(1); }
+inline void ctx_release(rmclhip_ctx* c) {
+  if (c && c->refs.fetch_sub(1) == 1) delete c;
+}
+}  // namespace
 
 struct rmclhip_map {
   rmclhip_ctx* ctx = nullptr;
@@ -224,7 +234,7 @@ rmclhip_status rmclhip_ctx_create(int device, rmclhip_ctx** out) {
   return RMCLHIP_OK;
 }
 
-void rmclhip_ctx_destroy(rmclhip_ctx* ctx) { delete ctx; }
+void rmclhip_ctx_destroy(rmclhip_ctx* ctx) { ctx_release(ctx); }
 
 rmclhip_status rmclhip_ctx_device_name(rmclhip_ctx* ctx, char* buf, size_t n) {
   ApiGuard guard_("rmclhip_ctx_device_name");
@@ -318,6 +328,7 @@ rmclhip_status rmclhip_map_create(rmclhip_ctx* ctx, const float* v, uint32_t nv,
                 std::string("map_create upload: ") + hipGetErrorString(e));
   }
   m->bytes = nb + qb + cb + tb;
+  ctx_retain(ctx);
   *out = m;
   return RMCLHIP_OK;
 }
@@ -338,6 +349,7 @@ void rmclhip_map_release(rmclhip_map* map) {
     if (map->d_qnodes) (void)hipFree(map->d_qnodes);
     if (map->d_cnodes) (void)hipFree(map->d_cnodes);
     if (map->d_tris) (void)hipFree(map->d_tris);
+    ctx_release(map->ctx);
     delete map;
   }
 }
@@ -358,6 +370,7 @@ rmclhip_status rmclhip_rcc_create(rmclhip_ctx* ctx, rmclhip_map* map, rmclhip_rc
   HIPCHK(hipSetDevice(ctx->device));
   rmclhip_rcc* r = new rmclhip_rcc();
   r->ctx = ctx;
+  ctx_retain(ctx);
   r->map = map;
   rmclhip_map_retain(map);
   hipError_t e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
@@ -409,6 +422,7 @@ void rmclhip_rcc_destroy(rmclhip_rcc* r) {
   if (r->ev1) DBG_STEP(hipEventDestroy(r->ev1));
   if (r->stream) DBG_STEP(hipStreamDestroy(r->stream));
   rmclhip_map_release(r->map);
+  ctx_release(r->ctx);
   delete r;
 }
 
@@ -652,6 +666,7 @@ static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
   p.qnodes = r->map->d_qnodes;
   p.cnodes = r->map->d_cnodes;
   p.tris = r->map->d_tris;
+  p.n_nodes = r->map->info.n_nodes;
   p.model_tab = r->d_model_tab.p;
   p.W = r->W; p.H = r->H;
   p.tile_w_log2 = (r->tile_override > 0) ? static_cast<uint32_t>(r->tile_override - 1) : pick_tile_w_log2(r->H);
@@ -1068,7 +1083,7 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
   ApiGuard guard_("rmclhip_rcc_set_variant");
   if (!r || variant < 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: bad arguments");
   const int kind = variant & 0xF, tile = (variant >> 4) & 0xF;
-  if ((kind > 5 && kind != 15) || kind == 3 || tile > 7 || (variant >> 13) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
+  if ((kind > 10 && kind != 15) || kind == 3 || tile > 7 || (variant >> 13) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
   r->variant = kind;
   r->tile_override = tile;
   r->fused_tail = ((variant >> 8) & 1) != 0;
@@ -1079,6 +1094,41 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
     r->loop_blocks = kLoopBlocks[(variant >> 10) & 7];
   }
   r->graph_dirty = true;
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_find_variant(const rmclhip_rcc* r, uint32_t nposes, int* variant_out) {
+  if (!r || !variant_out) return fail(RMCLHIP_ERR_INVALID, "rcc_find_variant: null");
+  *variant_out = find_variant(r, nposes ? nposes : 1u);
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_debug_probe_find(rmclhip_rcc* r, const rmclhip_transform* Tbm_est, int mode, uint32_t* log_out,
+                                        size_t log_cap_dwords, uint32_t* n_tiles_out) {
+  ApiGuard guard_("rmclhip_debug_probe_find");
+  if (!r || !Tbm_est || !log_out) return fail(RMCLHIP_ERR_INVALID, "debug_probe_find: null");
+  if (r->kind != kModelSpherical || r->W == 0 || r->H == 0) return fail(RMCLHIP_ERR_INVALID, "debug_probe_find: spherical model only");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  const size_t n = static_cast<size_t>(r->W) * r->H;
+  r->n_model = static_cast<uint32_t>(n);
+  r->nposes_last = 1;
+  if (rmclhip_status st = ensure_model_buffers(r, n)) return st;
+  FindParams p;
+  fill_find_params(r, p, 1);
+  p.Tsm = xmul(to_x(Tbm_est), r->Tsb);
+  p.Tms = xinv(p.Tsm);
+  const size_t ntiles = static_cast<size_t>(p.tiles_x) * p.tiles_y, dwords = ntiles * 512u;
+  if (n_tiles_out) *n_tiles_out = static_cast<uint32_t>(ntiles);
+  if (log_cap_dwords < dwords) return fail(RMCLHIP_ERR_INVALID, "debug_probe_find: log buffer too small");
+  uint32_t* d_log = nullptr;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_log), dwords * sizeof(uint32_t)));
+  hipError_t e = hipMemsetAsync(d_log, 0, dwords * sizeof(uint32_t), r->stream);
+  // a few launches first: the timeline of a warm launch (map in L2) is the one of interest
+  for (int i = 0; i < 3 && e == hipSuccess; ++i) e = launch_find_probe(p, mode, d_log, r->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(log_out, d_log, dwords * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+  (void)hipFree(d_log);
+  if (e != hipSuccess) return fail(RMCLHIP_ERR_HIP, std::string("debug_probe_find: ") + hipGetErrorString(e));
   return RMCLHIP_OK;
 }
 
@@ -1178,6 +1228,7 @@ rmclhip_status rmclhip_pf_create(rmclhip_ctx* ctx, rmclhip_map* map, rmclhip_pf*
   HIPCHK(hipSetDevice(ctx->device));
   rmclhip_pf* f = new rmclhip_pf();
   f->ctx = ctx;
+  ctx_retain(ctx);
   f->map = map;
   rmclhip_map_retain(map);
   hipError_t e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
@@ -1202,6 +1253,7 @@ void rmclhip_pf_destroy(rmclhip_pf* f) {
   if (f->ev1) (void)hipEventDestroy(f->ev1);
   if (f->stream) (void)hipStreamDestroy(f->stream);
   rmclhip_map_release(f->map);
+  ctx_release(f->ctx);
   delete f;
 }
 
@@ -1366,6 +1418,7 @@ rmclhip_status rmclhip_resampler_create(rmclhip_ctx* ctx, rmclhip_resampler** ou
   HIPCHK(hipSetDevice(ctx->device));
   rmclhip_resampler* r = new rmclhip_resampler();
   r->ctx = ctx;
+  ctx_retain(ctx);
   hipError_t e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = r->d_psum.reserve(256);
   if (e == hipSuccess) e = r->d_pmax.reserve(256);
@@ -1389,6 +1442,7 @@ void rmclhip_resampler_destroy(rmclhip_resampler* r) {
   r->d_out.release();
   if (r->h_out) (void)hipHostFree(r->h_out);
   if (r->stream) (void)hipStreamDestroy(r->stream);
+  ctx_release(r->ctx);
   delete r;
 }
 

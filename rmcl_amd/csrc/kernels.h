@@ -17,6 +17,7 @@ struct FindParams {
   const uint32_t* qnodes;  // Node4Q[] (quantised twins)
   const uint32_t* cnodes;  // Node4C[] (child-major twins)
   const uint32_t* tris;    // TriRec[]
+  uint32_t n_nodes;        // number of Node4 (the LDS-resident top of the tree copies min(kTop, n_nodes) of them)
   // spherical: [cos(phi_v) (H) | sin(phi_v) (H) | cos(theta_h) (W) | sin(theta_h) (W)], host libm values
   // o1dn:      dirs xyz (W*H*3)
   // ondn:      [origs xyz (W*H*3) | dirs xyz (W*H*3)]
@@ -101,6 +102,8 @@ struct MicpState {
 };
 
 hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStream_t s);
+// diagnostics (tools/probe_find.py): per-wave step timeline of one spherical scan; probe_log: tiles x 512 dwords
+hipError_t launch_find_probe(const FindParams& p, int mode, uint32_t* probe_log, hipStream_t s);
 hipError_t launch_cpc_find(const uint32_t* nodes, const uint32_t* tris, const float* dataset_points, uint32_t n,
                            float max_dist, xform Tsm, xform Tms, uint8_t* hits, float* dists, float* points,
                            float* normals, uint32_t* face_ids, bool quad, hipStream_t s);

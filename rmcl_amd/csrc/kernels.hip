@@ -50,6 +50,8 @@ __device__ __forceinline__ float safe_inv(float d) {
 
 // Moeller-Trumbore in Embree's formulation; must match oracle/rmcl_oracle.c:tri_intersect op for op.
 // Returns the barycentric acceptance; T/aden is left to the caller (so a packet can skip the divide).
+// Depth test of the callers: Embree's near side is STRICT (absDen * tnear < T, tnear = 0 => T > 0): a ray that starts
+// exactly on a triangle does not hit it; far side t <= tfar.
 __device__ __forceinline__ bool tri_accept(f3 v0, f3 e1, f3 e2, f3 Ng, f3 O, f3 D, float& Tt, float& aden) {
   const f3 C = sub3(v0, O);
   const f3 R = cross_fma(C, D);
@@ -97,9 +99,7 @@ __device__ __forceinline__ RaySlab make_ray_slab(f3 O, f3 D) {
 // three axes + child references), twelve packed FMAs (two children per instruction), then per child one
 // max3 / min3 pair.  key = entry distance bits (>= 0, so they order like the floats) or kNone for a miss; unused
 // slots hold an unreachable box (layout.h).  Free-form arithmetic: conservative because the boxes are padded.
-__device__ __forceinline__ void node_keys(const uint32_t* __restrict__ nodes, uint32_t cur, const RaySlab& rs, float best_t,
-                                          uint32_t (&key)[4], uint32_t (&ref)[4]) {
-  const char* nb = reinterpret_cast<const char*>(nodes) + (static_cast<size_t>(cur) << 7);
+__device__ __forceinline__ void node_keys_at(const char* nb, const RaySlab& rs, float best_t, uint32_t (&key)[4], uint32_t (&ref)[4]) {
   const uint4 qnx = *reinterpret_cast<const uint4*>(nb + rs.onx), qfx = *reinterpret_cast<const uint4*>(nb + rs.ofx);
   const uint4 qny = *reinterpret_cast<const uint4*>(nb + rs.ony), qfy = *reinterpret_cast<const uint4*>(nb + rs.ofy);
   const uint4 qnz = *reinterpret_cast<const uint4*>(nb + rs.onz), qfz = *reinterpret_cast<const uint4*>(nb + rs.ofz);
@@ -122,6 +122,72 @@ __device__ __forceinline__ void node_keys(const uint32_t* __restrict__ nodes, ui
     const float tf = fminf(fminf(fminf(tfx[c], tfy[c]), tfz[c]), best_t);
     key[c] = (tn <= tf) ? __float_as_uint(tn) : kNone;
   }
+}
+
+__device__ __forceinline__ void node_keys(const uint32_t* __restrict__ nodes, uint32_t cur, const RaySlab& rs, float best_t,
+                                          uint32_t (&key)[4], uint32_t (&ref)[4]) {
+  node_keys_at(reinterpret_cast<const char*>(nodes) + (static_cast<size_t>(cur) << 7), rs, best_t, key, ref);
+}
+
+// LDS-resident top of the tree (north_star: "LDS-staged node tiles"): the nodes are stored breadth-first, so the first
+// kTop of them ARE the top levels; every block copies that prefix into its LDS once, and a lane whose current node
+// index is below kTop reads it from there.  The choice is per lane and per step, so the node address is a FLAT
+// pointer -- LDS aperture or global -- and the seven plane-group loads become flat_load_dwordx4: lanes still in the
+// top levels are served by the LDS (~64 cycles), the others by L1/L2 as before, in one instruction stream.
+template <int kTop>
+__device__ __forceinline__ const char* node_address(const uint32_t* __restrict__ nodes, const uint32_t* lds_top, uint32_t cur) {
+  const char* g = reinterpret_cast<const char*>(nodes);
+  if (kTop == 0) return g + (static_cast<size_t>(cur) << 7);
+  const char* l = reinterpret_cast<const char*>(lds_top);
+  return ((cur < static_cast<uint32_t>(kTop)) ? l : g) + (static_cast<size_t>(cur) << 7);
+}
+
+// One triangle test of the per-lane traversals from the three dwordx4 of its record + its face id (same
+// arithmetic and acceptance as the loop bodies above: tri_accept, Tt > 0, t <= tfar, (min t, min face id)).
+__device__ __forceinline__ void tri_update(uint4 a, uint4 b, uint4 c, uint32_t face, uint32_t rec, f3 O, f3 D, float ray_tfar,
+                                           float& best_t, uint32_t& best_face, uint32_t& best_rec) {
+  const f3 v0 = mk3(asf(a.x), asf(a.y), asf(a.z));
+  const f3 e1 = mk3(asf(a.w), asf(b.x), asf(b.y));
+  const f3 e2 = mk3(asf(b.z), asf(b.w), asf(c.x));
+  const f3 Ng = mk3(asf(c.y), asf(c.z), asf(c.w));
+  float Tt, aden;
+  const bool ok = tri_accept(v0, e1, e2, Ng, O, D, Tt, aden);
+  if (ok) {
+    const float t = Tt / aden;
+    const bool acc = (Tt > 0.0f) && (t <= ray_tfar);
+    const bool closer = acc && ((t < best_t) || ((t == best_t) && (face < best_face)));
+    best_t = closer ? t : best_t;
+    best_face = closer ? face : best_face;
+    best_rec = closer ? rec : best_rec;
+  }
+}
+
+// A whole leaf (<= 4 records) in ONE memory round trip: the loop form above waits for triangle i before it requests
+// triangle i+1 -- up to four dependent round trips per leaf visit, and the wave runs as many as its fullest leaf has
+// triangles.  Here the records of all (wave-uniform maximum) slots are requested together; a lane whose leaf is
+// shorter re-requests its last record (same line, and a repeated test cannot change (best_t, best_face)), then the
+// tests run in record order: results identical to the loop.
+__device__ __forceinline__ void leaf_batch(const uint32_t* __restrict__ tris, uint32_t cur, f3 O, f3 D, float ray_tfar,
+                                           float& best_t, uint32_t& best_face, uint32_t& best_rec) {
+  const uint32_t first = cur & 0x0FFFFFFFu;
+  const uint32_t last = first + ((cur >> 28) & 7u);
+  const bool w2 = __any(last > first), w3 = __any(last > first + 1u), w4 = __any(last > first + 2u);
+  const uint32_t i1 = min(first + 1u, last), i2 = min(first + 2u, last), i3 = min(first + 3u, last);
+  const uint4* t0 = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(first) * 4u;
+  const uint4* t1 = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(i1) * 4u;
+  const uint4* t2 = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(i2) * 4u;
+  const uint4* t3 = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(i3) * 4u;
+  const uint4 a0 = t0[0], b0 = t0[1], c0 = t0[2];
+  const uint32_t f0 = reinterpret_cast<const uint32_t*>(t0)[15];
+  uint4 a1 = a0, b1 = b0, c1 = c0, a2 = a0, b2 = b0, c2 = c0, a3 = a0, b3 = b0, c3 = c0;
+  uint32_t f1 = f0, f2 = f0, f3_ = f0;
+  if (w2) { a1 = t1[0]; b1 = t1[1]; c1 = t1[2]; f1 = reinterpret_cast<const uint32_t*>(t1)[15]; }
+  if (w3) { a2 = t2[0]; b2 = t2[1]; c2 = t2[2]; f2 = reinterpret_cast<const uint32_t*>(t2)[15]; }
+  if (w4) { a3 = t3[0]; b3 = t3[1]; c3 = t3[2]; f3_ = reinterpret_cast<const uint32_t*>(t3)[15]; }
+  tri_update(a0, b0, c0, f0, first, O, D, ray_tfar, best_t, best_face, best_rec);
+  if (w2) tri_update(a1, b1, c1, f1, i1, O, D, ray_tfar, best_t, best_face, best_rec);
+  if (w3) tri_update(a2, b2, c2, f2, i2, O, D, ray_tfar, best_t, best_face, best_rec);
+  if (w4) tri_update(a3, b3, c3, f3_, i3, O, D, ray_tfar, best_t, best_face, best_rec);
 }
 
 // node_keys on the quantised twin of the node (layout.h: Node4Q): FOUR loads instead of seven.  The plane distance
@@ -228,7 +294,7 @@ __device__ __forceinline__ void trace_packet(cu32p nodes, cu32p tris, f3 O, f3 D
           const bool ok = tri_accept(v0, e1, e2, Ng, O, D, Tt, aden);
           if (__ballot(ok) != 0) {
             const float t = Tt / aden;
-            const bool acc = ok && (t >= 0.0f) && (t <= ray_tfar);
+            const bool acc = ok && (Tt > 0.0f) && (t <= ray_tfar);
             const bool closer = acc && ((t < best_t) || ((t == best_t) && (face < best_face)));
             best_t = closer ? t : best_t;
             best_face = closer ? face : best_face;
@@ -282,7 +348,7 @@ __device__ __forceinline__ void trace_lane(const uint32_t* __restrict__ nodes, c
         const bool ok = tri_accept(v0, e1, e2, Ng, O, D, Tt, aden);
         if (ok) {
           const float t = Tt / aden;
-          const bool acc = (t >= 0.0f) && (t <= ray_tfar);
+          const bool acc = (Tt > 0.0f) && (t <= ray_tfar);
           const bool closer = acc && ((t < best_t) || ((t == best_t) && (face < best_face)));
           best_t = closer ? t : best_t;
           best_face = closer ? face : best_face;
@@ -353,7 +419,7 @@ __device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes
         const bool ok = tri_accept(v0, e1, e2, Ng, O, D, Tt, aden);
         if (ok) {
           const float t = Tt / aden;
-          const bool acc = (t >= 0.0f) && (t <= ray_tfar);
+          const bool acc = (Tt > 0.0f) && (t <= ray_tfar);
           const bool closer = acc && ((t < best_t) || ((t == best_t) && (face < best_face)));
           best_t = closer ? t : best_t;
           best_face = closer ? face : best_face;
@@ -458,7 +524,7 @@ __device__ __forceinline__ void trace_quad(const uint32_t* __restrict__ nodes, c
       float Tt, aden;
       const bool ok = tri_accept(v0, e1, e2, Ng, O, D, Tt, aden);
       const float t = Tt / aden;
-      const bool acc = ok && (c < cnt) && (t >= 0.0f) && (t <= ray_tfar);
+      const bool acc = ok && (c < cnt) && (Tt > 0.0f) && (t <= ray_tfar);
       // quad minimum of (t, face): candidates that fail carry (+inf, invalid face) and never win
       float ct = acc ? t : __builtin_inff();
       uint32_t cf = acc ? d.w : kInvalidFace, cr = idx;
@@ -496,12 +562,12 @@ __device__ __forceinline__ void trace_quad(const uint32_t* __restrict__ nodes, c
 constexpr uint32_t kTailRays = 16;
 constexpr uint32_t kTailXferDwords = 12;
 
-template <int kLdsEntries>
+template <int kLdsEntries, int kTop = 0, bool kLeafBatch = false>
 __device__ __forceinline__ void trace_lane_ww_tail(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ cnodes,
                                                    const uint32_t* __restrict__ tris, f3 O, f3 D, float ray_tfar,
                                                    uint32_t* __restrict__ lds_stack, uint32_t lds_stride,
                                                    uint32_t* __restrict__ qstack, uint32_t* __restrict__ xfer_wave,
-                                                   RayHit& h) {
+                                                   RayHit& h, const uint32_t* lds_top = nullptr) {
   const RaySlab rs = make_ray_slab(O, D);
   float best_t = ray_tfar;
   uint32_t best_face = kInvalidFace, best_rec = 0;
@@ -557,7 +623,7 @@ __device__ __forceinline__ void trace_lane_ww_tail(const uint32_t* __restrict__ 
     // phase 1: inner nodes
     while ((cur != kDone) && !(cur & kLeafBit)) {
       uint32_t key[4], ref[4];
-      node_keys(nodes, cur, rs, best_t, key, ref);
+      node_keys_at(node_address<kTop>(nodes, lds_top, cur), rs, best_t, key, ref);
       RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
       if (key[3] != kNone) RMCL_PUSH(ref[3])
       if (key[2] != kNone) RMCL_PUSH(ref[2])
@@ -566,6 +632,12 @@ __device__ __forceinline__ void trace_lane_ww_tail(const uint32_t* __restrict__ 
       else RMCL_POP()
     }
     // phase 2: this lane's leaf (if any)
+    if (kLeafBatch) {
+      if (cur != kDone) {
+        leaf_batch(tris, cur, O, D, ray_tfar, best_t, best_face, best_rec);
+        RMCL_POP()
+      }
+    } else
     if (cur != kDone) {
       const uint32_t first = cur & 0x0FFFFFFFu;
       const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
@@ -581,7 +653,7 @@ __device__ __forceinline__ void trace_lane_ww_tail(const uint32_t* __restrict__ 
         const bool ok = tri_accept(v0, e1, e2, Ng, O, D, Tt, aden);
         if (ok) {
           const float t = Tt / aden;
-          const bool acc = (t >= 0.0f) && (t <= ray_tfar);
+          const bool acc = (Tt > 0.0f) && (t <= ray_tfar);
           const bool closer = acc && ((t < best_t) || ((t == best_t) && (face < best_face)));
           best_t = closer ? t : best_t;
           best_face = closer ? face : best_face;
@@ -858,12 +930,38 @@ __device__ __forceinline__ f3 pinhole_direction(float fx, float fy, float cx, fl
 // per ray with the tail of every wave handed to quads,
 // 2 = four lanes per ray (quad-cooperative; the block
 // of 256 threads then covers ONE 64-ray tile instead of four)
+// kTrav 5..10 share the tail traversal: 6 / 7 add the LDS-resident top of the tree (85 / 341 nodes = levels 0-3 / 0-4 of a
+// full BVH4), 8 adds the one-round-trip leaf, 9 / 10 both
+constexpr int find_top_nodes(int trav) { return (trav == 6 || trav == 9) ? 85 : ((trav == 7 || trav == 10) ? 341 : 0); }
+constexpr bool find_leaf_batch(int trav) { return trav >= 8 && trav <= 10; }
+constexpr uint32_t kFindTailLdsDwords = 16u * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords;
+
 template <uint32_t kModel, int kTrav>
 __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   extern __shared__ uint32_t lds_dyn[];
   constexpr bool kPacket = (kTrav == 0), kQuad = (kTrav == 2);
+  constexpr int kTop = find_top_nodes(kTrav);
   const uint32_t lane = kQuad ? (threadIdx.x >> 2) : (threadIdx.x & 63u), wave = threadIdx.x >> 6;
   const uint32_t sub = threadIdx.x & 3u;  // quad mode: child slot / triangle slot / output role of this lane
+  if constexpr (kTop > 0) {
+    // the block's copy of the top of the tree: coalesced 16-B pieces, all requested before the first LDS write
+    uint4* dst = reinterpret_cast<uint4*>(lds_dyn + kFindTailLdsDwords);
+    const uint4* src = reinterpret_cast<const uint4*>(p.nodes);
+    const uint32_t n16 = min(static_cast<uint32_t>(kTop), p.n_nodes) * 8u;
+    constexpr int kRounds = (kTop > 0) ? (kTop * 8 + 255) / 256 : 1;
+    uint4 v[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const uint32_t i = static_cast<uint32_t>(r) * 256u + threadIdx.x;
+      if (i < n16) v[r] = src[i];
+    }
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const uint32_t i = static_cast<uint32_t>(r) * 256u + threadIdx.x;
+      if (i < n16) dst[i] = v[r];
+    }
+    __syncthreads();
+  }
   // XCD-aware remap: the dispatcher places block b on XCD b%8; give every XCD a contiguous range of
   // tiles so neighbouring tiles (which walk the same subtrees) share one L2.  gridDim.x % 8 == 0.
   const uint32_t chunk = gridDim.x >> 3;
@@ -916,9 +1014,11 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
     trace_quad(p.cnodes, p.tris, org_m, dir_m, ray_tfar, sub, lane, lds_dyn, h);
   } else {
     if (kTrav == 4) trace_lane_ww<16, true>(p.qnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
-    else if (kTrav == 5)
-      trace_lane_ww_tail<16>(p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x,
-                             lds_dyn + 16u * 256u, lds_dyn + 16u * 256u + kQuadStackEntries * 64u + (threadIdx.x >> 6) * (kTailRays * kTailXferDwords), h);
+    else if (kTrav >= 5)
+      trace_lane_ww_tail<16, kTop, find_leaf_batch(kTrav)>(
+          p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, lds_dyn + 16u * 256u,
+          lds_dyn + 16u * 256u + kQuadStackEntries * 64u + (threadIdx.x >> 6) * (kTailRays * kTailXferDwords), h,
+          lds_dyn + kFindTailLdsDwords);
     else trace_lane_ww<16>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
   }
 
@@ -950,6 +1050,193 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
     if (p.points && w1) { p.points[3 * g] = qn; p.points[3 * g + 1] = qn; p.points[3 * g + 2] = qn; }
     if (p.normals && w2) { p.normals[3 * g] = qn; p.normals[3 * g + 1] = qn; p.normals[3 * g + 2] = qn; }
     if (p.face_ids && w0) p.face_ids[g] = kInvalidFace;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// DIAGNOSTIC kernel (tools/probe_find.py; never on the product path): the per-lane while-while traversal of k_find<spherical>
+// with s_memtime stamps around every node step and every leaf step of every wave, so that the cost of a step can be
+// split into "loads issued -> data arrived" and "arithmetic + stack traffic" per tree depth.
+// Log entry (2 dwords): {cycles since wave start, kind | active lanes << 8 | uniform << 16 | step << 20}; kinds: 1 node step
+// begins, 2 its node data arrived, 3 it ends, 4 leaf step begins, 5 its records arrived, 6 it ends, 7 traversal done, 8 stores
+// issued.  probe_log[wave][0] = {number of entries, XCC id}.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kProbeEntries = 255;
+
+__device__ __forceinline__ uint32_t probe_clock(bool drain) {
+  uint64_t t;
+  if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  else asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  return static_cast<uint32_t>(t);
+}
+
+template <bool kLeafBatch, int kTop>
+__global__ void __launch_bounds__(256) k_find_probe(const FindParams p, uint32_t* __restrict__ probe_log) {
+  extern __shared__ uint32_t lds_dyn[];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if constexpr (kTop > 0) {
+    uint4* dst = reinterpret_cast<uint4*>(lds_dyn + 16u * 256u);
+    const uint4* src = reinterpret_cast<const uint4*>(p.nodes);
+    const uint32_t n16 = min(static_cast<uint32_t>(kTop), p.n_nodes) * 8u;
+    for (uint32_t i = threadIdx.x; i < n16; i += 256u) dst[i] = src[i];
+    __syncthreads();
+  }
+  const uint32_t chunk = gridDim.x >> 3;
+  const uint32_t vb = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+  const uint32_t tile = vb * 4u + wave;
+  const uint32_t ntiles = p.tiles_x * p.tiles_y;
+  if (tile >= ntiles) return;
+  const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+  const uint32_t twl = p.tile_w_log2;
+  const uint32_t lx = lane & ((1u << twl) - 1u), ly = lane >> twl;
+  const uint32_t vid = (ty << (6u - twl)) + ly, hid = (tx << twl) + lx;
+  const bool valid = (vid < p.H) && (hid < p.W);
+  const uint32_t cv = valid ? vid : 0u, ch = valid ? hid : 0u;
+  const uint32_t loc = cv * p.W + ch;
+  const xform Tsm = p.Tsm, Tms = p.Tms;
+  uint32_t* log = probe_log + static_cast<size_t>(tile) * (2u * (kProbeEntries + 1u));
+  uint32_t nlog = 0;
+  const uint32_t t_begin = probe_clock(false);
+#define RMCL_PROBE(KIND, DRAIN, ACTIVE_MASK, UNIFORM, STEP)                                                              \
+  {                                                                                                                      \
+    const uint32_t tc_ = probe_clock(DRAIN) - t_begin;                                                                    \
+    if (nlog < kProbeEntries && lane == 0u) {                                                                            \
+      log[2u * (nlog + 1u)] = tc_;                                                                                       \
+      log[2u * (nlog + 1u) + 1u] = (KIND) | (static_cast<uint32_t>(__popcll(ACTIVE_MASK)) << 8) | ((UNIFORM) ? 0x10000u : 0u) | ((STEP) << 20); \
+    }                                                                                                                    \
+    ++nlog;                                                                                                              \
+  }
+  const float cp = p.model_tab[cv], sp_ = p.model_tab[p.H + cv];
+  const float ct = p.model_tab[2u * p.H + ch], st = p.model_tab[2u * p.H + p.W + ch];
+  const f3 dir_s = mk3(cp * ct, cp * st, sp_);
+  const f3 O = Tsm.t;
+  const f3 D = qrot(Tsm.R, dir_s);
+  const bool finite = (D.x == D.x) && (D.y == D.y) && (D.z == D.z);
+  const float ray_tfar = (valid && finite) ? p.tfar : -1.0f;
+
+  const RaySlab rs = make_ray_slab(O, D);
+  float best_t = ray_tfar;
+  uint32_t best_face = kInvalidFace, best_rec = 0;
+  constexpr uint32_t kDone = 0x7FFFFFFFu;
+  uint32_t* lds_stack = lds_dyn + threadIdx.x;
+  constexpr uint32_t lds_stride = 256u;
+  uint32_t priv[48];
+  uint32_t sp = 0;
+  uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
+  uint32_t step = 0;
+#define RMCL_PUSH(v) { if (sp < 16u) lds_stack[sp * lds_stride] = (v); else priv[sp - 16u] = (v); ++sp; }
+#define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; if (sp < 16u) cur = lds_stack[sp * lds_stride]; else cur = priv[sp - 16u]; } }
+  while (__any(cur != kDone)) {
+    for (;;) {
+      const bool inner = (cur != kDone) && !(cur & kLeafBit);
+      const uint64_t m = __ballot(inner);
+      if (m == 0) break;
+      const uint32_t c0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cur), __builtin_ctzll(m)));
+      const bool uni = __ballot(inner && cur != c0) == 0;
+      RMCL_PROBE(1u, true, m, uni, step)
+      if (inner) {
+        const char* nb = node_address<kTop>(p.nodes, lds_dyn + 16u * 256u, cur);
+        const uint4 qnx = *reinterpret_cast<const uint4*>(nb + rs.onx), qfx = *reinterpret_cast<const uint4*>(nb + rs.ofx);
+        const uint4 qny = *reinterpret_cast<const uint4*>(nb + rs.ony), qfy = *reinterpret_cast<const uint4*>(nb + rs.ofy);
+        const uint4 qnz = *reinterpret_cast<const uint4*>(nb + rs.onz), qfz = *reinterpret_cast<const uint4*>(nb + rs.ofz);
+        const uint4 qch = *reinterpret_cast<const uint4*>(nb + 96);
+        // keep the loads above the stamp: the asm below has a memory clobber and waits for them
+        uint32_t sink = qnx.x ^ qfx.x ^ qny.x ^ qfy.x ^ qnz.x ^ qfz.x ^ qch.x;
+        asm volatile("" : "+v"(sink));
+        RMCL_PROBE(2u, true, m, uni, step)
+        const f2 ix = {rs.inv.x, rs.inv.x}, iy = {rs.inv.y, rs.inv.y}, iz = {rs.inv.z, rs.inv.z};
+        const f2 nx = {rs.noi.x, rs.noi.x}, ny = {rs.noi.y, rs.noi.y}, nz = {rs.noi.z, rs.noi.z};
+        const f2 nx01 = __builtin_elementwise_fma(f2{asf(qnx.x), asf(qnx.y)}, ix, nx), nx23 = __builtin_elementwise_fma(f2{asf(qnx.z), asf(qnx.w)}, ix, nx);
+        const f2 fx01 = __builtin_elementwise_fma(f2{asf(qfx.x), asf(qfx.y)}, ix, nx), fx23 = __builtin_elementwise_fma(f2{asf(qfx.z), asf(qfx.w)}, ix, nx);
+        const f2 ny01 = __builtin_elementwise_fma(f2{asf(qny.x), asf(qny.y)}, iy, ny), ny23 = __builtin_elementwise_fma(f2{asf(qny.z), asf(qny.w)}, iy, ny);
+        const f2 fy01 = __builtin_elementwise_fma(f2{asf(qfy.x), asf(qfy.y)}, iy, ny), fy23 = __builtin_elementwise_fma(f2{asf(qfy.z), asf(qfy.w)}, iy, ny);
+        const f2 nz01 = __builtin_elementwise_fma(f2{asf(qnz.x), asf(qnz.y)}, iz, nz), nz23 = __builtin_elementwise_fma(f2{asf(qnz.z), asf(qnz.w)}, iz, nz);
+        const f2 fz01 = __builtin_elementwise_fma(f2{asf(qfz.x), asf(qfz.y)}, iz, nz), fz23 = __builtin_elementwise_fma(f2{asf(qfz.z), asf(qfz.w)}, iz, nz);
+        const float tnx[4] = {nx01.x, nx01.y, nx23.x, nx23.y}, tfx[4] = {fx01.x, fx01.y, fx23.x, fx23.y};
+        const float tny[4] = {ny01.x, ny01.y, ny23.x, ny23.y}, tfy[4] = {fy01.x, fy01.y, fy23.x, fy23.y};
+        const float tnz[4] = {nz01.x, nz01.y, nz23.x, nz23.y}, tfz[4] = {fz01.x, fz01.y, fz23.x, fz23.y};
+        uint32_t key[4], ref[4] = {qch.x, qch.y, qch.z, qch.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float tn = fmaxf(fmaxf(fmaxf(tnx[c], tny[c]), tnz[c]), 0.0f);
+          const float tf = fminf(fminf(fminf(tfx[c], tfy[c]), tfz[c]), best_t);
+          key[c] = (tn <= tf) ? __float_as_uint(tn) : kNone;
+        }
+        RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
+        if (key[3] != kNone) RMCL_PUSH(ref[3])
+        if (key[2] != kNone) RMCL_PUSH(ref[2])
+        if (key[1] != kNone) RMCL_PUSH(ref[1])
+        if (key[0] != kNone) cur = ref[0];
+        else RMCL_POP()
+      }
+      RMCL_PROBE(3u, true, m, uni, step)
+      ++step;
+    }
+    {
+      const bool leaf = (cur != kDone);
+      const uint64_t m = __ballot(leaf);
+      if (m != 0) {
+        if (kLeafBatch) {
+          RMCL_PROBE(4u, true, m, false, step)
+          if (leaf) {
+            leaf_batch(p.tris, cur, O, D, ray_tfar, best_t, best_face, best_rec);
+            RMCL_POP()
+          }
+          RMCL_PROBE(6u, true, m, false, step)
+        } else {
+          const uint32_t first = cur & 0x0FFFFFFFu;
+          const uint32_t cnt = leaf ? (((cur >> 28) & 7u) + 1u) : 0u;
+          for (uint32_t i = 0; __any(i < cnt); ++i) {
+            const uint64_t mi = __ballot(i < cnt);
+            RMCL_PROBE(4u, true, mi, false, step)
+            if (i < cnt) {
+              const uint4* tp = reinterpret_cast<const uint4*>(p.tris) + static_cast<size_t>(first + i) * 4u;
+              const uint4 a = tp[0], b = tp[1], c = tp[2], d = tp[3];
+              uint32_t sink = a.x ^ b.x ^ c.x ^ d.x;
+              asm volatile("" : "+v"(sink));
+              RMCL_PROBE(5u, true, mi, false, step)
+              tri_update(a, b, c, d.w, first + i, O, D, ray_tfar, best_t, best_face, best_rec);
+            }
+            RMCL_PROBE(6u, true, mi, false, step)
+          }
+          if (leaf) RMCL_POP()
+        }
+        ++step;
+      }
+    }
+  }
+#undef RMCL_PUSH
+#undef RMCL_POP
+  RMCL_PROBE(7u, true, __ballot(true), false, step)
+  if (valid) {
+    const size_t g = loc;
+    const bool found = (best_face != kInvalidFace);
+    if (found) {
+      p.hits[g] = 1;
+      p.ranges[g] = best_t;
+      const f3 pt = scale3(dir_s, best_t);
+      p.points[3 * g] = pt.x; p.points[3 * g + 1] = pt.y; p.points[3 * g + 2] = pt.z;
+      const uint4 nrec = reinterpret_cast<const uint4*>(p.tris)[static_cast<size_t>(best_rec) * 4u + 3u];
+      f3 n = qrot(Tms.R, mk3(asf(nrec.x), asf(nrec.y), asf(nrec.z)));
+      if (dot_plain(dir_s, n) > 0.0f) n = neg3(n);
+      p.normals[3 * g] = n.x; p.normals[3 * g + 1] = n.y; p.normals[3 * g + 2] = n.z;
+      p.face_ids[g] = best_face;
+    } else {
+      const float qn = __uint_as_float(0x7FC00000u);
+      p.hits[g] = 0;
+      p.ranges[g] = p.tfar + 1.0f;
+      p.points[3 * g] = qn; p.points[3 * g + 1] = qn; p.points[3 * g + 2] = qn;
+      p.normals[3 * g] = qn; p.normals[3 * g + 1] = qn; p.normals[3 * g + 2] = qn;
+      p.face_ids[g] = kInvalidFace;
+    }
+  }
+  RMCL_PROBE(8u, true, __ballot(true), false, step)
+#undef RMCL_PROBE
+  if (lane == 0u) {
+    log[0] = min(nlog, kProbeEntries);
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    log[1] = xcc;
   }
 }
 
@@ -1700,7 +1987,7 @@ __global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
         const bool ok = tri_accept(v0, e1, e2, Ng, O, D, Tt, aden);
         if (ok) {
           const float t = Tt / aden;
-          const bool acc = (t >= 0.0f);  // tfar = infinity
+          const bool acc = (Tt > 0.0f);  // tnear = 0 exclusive, tfar = infinity
           const bool closer = acc && ((t < best_t) || ((t == best_t) && (face < best_face)));
           best_t = closer ? t : best_t;
           best_face = closer ? face : best_face;
@@ -1909,13 +2196,25 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
   uint32_t nblocks = (variant == 2) ? ntiles : (ntiles + 3u) / 4u;
   nblocks = (nblocks + 7u) & ~7u;  // the XCD remap in k_find needs gridDim.x % 8 == 0
   dim3 grid(nblocks, p.nposes, 1), block(256, 1, 1);
-#define RMCL_LAUNCH_FIND(TRAV, LDS)                                                                          \
-  switch (kind) {                                                                                            \
-    case kModelSpherical: hipLaunchKernelGGL((k_find<kModelSpherical, TRAV>), grid, block, LDS, s, p); break; \
-    case kModelO1Dn: hipLaunchKernelGGL((k_find<kModelO1Dn, TRAV>), grid, block, LDS, s, p); break;           \
-    case kModelPinhole: hipLaunchKernelGGL((k_find<kModelPinhole, TRAV>), grid, block, LDS, s, p); break;     \
-    case kModelOnDn: hipLaunchKernelGGL((k_find<kModelOnDn, TRAV>), grid, block, LDS, s, p); break;           \
-    default: return hipErrorInvalidValue;                                                                    \
+  // more than 64 KB of dynamic LDS per block must be granted once per kernel
+  static bool lds_granted[16][8] = {};
+#define RMCL_FIND_ONE(KIND, TRAV, LDS)                                                                               \
+  {                                                                                                                  \
+    if ((LDS) > 65536u && !lds_granted[TRAV][KIND]) {                                                                \
+      const hipError_t ge = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_find<KIND, TRAV>),                  \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(LDS)); \
+      if (ge != hipSuccess) return ge;                                                                               \
+      lds_granted[TRAV][KIND] = true;                                                                                \
+    }                                                                                                                \
+    hipLaunchKernelGGL((k_find<KIND, TRAV>), grid, block, LDS, s, p);                                                \
+  }
+#define RMCL_LAUNCH_FIND(TRAV, LDS)                             \
+  switch (kind) {                                               \
+    case kModelSpherical: RMCL_FIND_ONE(kModelSpherical, TRAV, LDS) break; \
+    case kModelO1Dn: RMCL_FIND_ONE(kModelO1Dn, TRAV, LDS) break;           \
+    case kModelPinhole: RMCL_FIND_ONE(kModelPinhole, TRAV, LDS) break;     \
+    case kModelOnDn: RMCL_FIND_ONE(kModelOnDn, TRAV, LDS) break;           \
+    default: return hipErrorInvalidValue;                       \
   }
   if (variant == 0) {  // wave-packet traversal (needs map stack_need <= 64, checked at map creation)
     RMCL_LAUNCH_FIND(0, 0)
@@ -1925,14 +2224,34 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
   } else if (variant == 4) {  // one lane per ray on the 64-B quantised nodes
     const size_t lds = 16u * 256u * sizeof(uint32_t);
     RMCL_LAUNCH_FIND(4, lds)
-  } else if (variant == 5) {  // one lane per ray, the last rays of every wave finished by quads
-    const size_t lds = (16u * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords) * sizeof(uint32_t);
-    RMCL_LAUNCH_FIND(5, lds)
+  } else if (variant >= 5 && variant <= 10) {  // one lane per ray, the last rays of every wave finished by quads
+    const size_t lds = (kFindTailLdsDwords + static_cast<uint32_t>(find_top_nodes(variant)) * kNodeDwords) * sizeof(uint32_t);
+    switch (variant) {
+      case 5: RMCL_LAUNCH_FIND(5, lds) break;
+      case 6: RMCL_LAUNCH_FIND(6, lds) break;
+      case 7: RMCL_LAUNCH_FIND(7, lds) break;
+      case 8: RMCL_LAUNCH_FIND(8, lds) break;
+      case 9: RMCL_LAUNCH_FIND(9, lds) break;
+      default: RMCL_LAUNCH_FIND(10, lds) break;
+    }
   } else {             // per-lane while-while traversal: 16 stack entries per lane in LDS, the rest in scratch
     const size_t lds = 16u * 256u * sizeof(uint32_t);
     RMCL_LAUNCH_FIND(1, lds)
   }
 #undef RMCL_LAUNCH_FIND
+#undef RMCL_FIND_ONE
+  return hipGetLastError();
+}
+
+hipError_t launch_find_probe(const FindParams& p, int mode, uint32_t* probe_log, hipStream_t s) {
+  const uint32_t ntiles = p.tiles_x * p.tiles_y;
+  uint32_t nblocks = ((ntiles + 3u) / 4u + 7u) & ~7u;
+  const dim3 grid(nblocks, 1, 1), block(256, 1, 1);
+  const size_t lds0 = 16u * 256u * sizeof(uint32_t);
+  if (mode == 0) hipLaunchKernelGGL((k_find_probe<false, 0>), grid, block, lds0, s, p, probe_log);
+  else if (mode == 1) hipLaunchKernelGGL((k_find_probe<true, 0>), grid, block, lds0, s, p, probe_log);
+  else if (mode == 2) hipLaunchKernelGGL((k_find_probe<false, 85>), grid, block, lds0 + 85u * 128u, s, p, probe_log);
+  else hipLaunchKernelGGL((k_find_probe<true, 85>), grid, block, lds0 + 85u * 128u, s, p, probe_log);
   return hipGetLastError();
 }
 

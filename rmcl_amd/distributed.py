@@ -24,22 +24,49 @@ def shard_capacity(n, world):
     return (int(n) + int(world) - 1) // int(world)
 
 
+class _GatherBuffers:
+    """send / receive / dense buffers of one (n_total, world, device, dtype) all-gather, allocated ONCE: a 4 MB
+    latency-bound collective must not pay three allocations and a torch.cat per step."""
+
+    _cache = {}
+
+    def __init__(self, n_total, world, device, dtype, rec):
+        import torch
+        self.cap = shard_capacity(n_total, world)
+        shape = (self.cap,) if rec == 0 else (self.cap, rec)
+        self.send = torch.zeros(shape, dtype=dtype, device=device)
+        self.recv = torch.empty((world * self.cap,) + shape[1:], dtype=dtype, device=device)
+        self.ragged = (n_total % world) != 0
+        self.dense = torch.empty((n_total,) + shape[1:], dtype=dtype, device=device) if self.ragged else None
+        self.bounds = [shard_bounds(n_total, r, world) for r in range(world)]
+
+    @classmethod
+    def get(cls, n_total, world, device, dtype, rec=0):
+        key = (int(n_total), int(world), str(device), dtype, int(rec))
+        b = cls._cache.get(key)
+        if b is None:
+            b = cls._cache[key] = cls(int(n_total), int(world), device, dtype, int(rec))
+        return b
+
+    def gather(self, local, group):
+        import torch.distributed as dist
+        self.send[: local.shape[0]].copy_(local)
+        dist.all_gather_into_tensor(self.recv, self.send, group=group)
+        if not self.ragged:
+            return self.recv          # equal shards: the receive buffer IS the dense vector (no copy)
+        for r, (lo, hi) in enumerate(self.bounds):
+            self.dense[lo:hi].copy_(self.recv[r * self.cap: r * self.cap + (hi - lo)])
+        return self.dense
+
+
 def allgather_weights(local_weights, n_total, group=None):
     """local_weights: 1-D float32 torch tensor holding this rank's shard (device tensor for RCCL).
-    Returns the dense [n_total] weight vector, identical on every rank."""
+    Returns the dense [n_total] weight vector, identical on every rank.  ONE all_gather_into_tensor on equal-sized
+    (padded) shards into preallocated buffers; the result aliases a cached buffer that the next call overwrites."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    cap = shard_capacity(n_total, world)
-    send = torch.zeros(cap, dtype=torch.float32, device=local_weights.device)
-    send[: local_weights.numel()] = local_weights
-    recv = [torch.empty(cap, dtype=torch.float32, device=local_weights.device) for _ in range(world)]
-    dist.all_gather(recv, send, group=group)
-    parts = []
-    for r in range(world):
-        lo, hi = shard_bounds(n_total, r, world)
-        parts.append(recv[r][: hi - lo])
-    return torch.cat(parts)
+    return _GatherBuffers.get(n_total, world, local_weights.device, torch.float32).gather(local_weights, group)
 
 
 def allreduce_sum_max(local_weights, group=None):
@@ -77,21 +104,12 @@ class ShardedSensorUpdate:
 def allgather_records(local_records, n_total, group=None):
     """All-gather of fixed-size records (poses 32 B, attributes 36 B): local_records is a [n_local, rec_bytes]
     uint8 torch tensor holding this rank's shard; returns the dense [n_total, rec_bytes] tensor, identical on every
-    rank.  One collective on equal-sized padded shards (C5: 68 MB over 8 ranks, 8.5 MB per rank contribution)."""
+    rank.  One collective on equal-sized padded shards (C5: 68 MB over 8 ranks, 8.5 MB per rank contribution) into
+    preallocated buffers (the result aliases a cached buffer that the next call with the same shape overwrites)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    cap = shard_capacity(n_total, world)
-    rec = local_records.shape[1]
-    send = torch.zeros((cap, rec), dtype=torch.uint8, device=local_records.device)
-    send[: local_records.shape[0]] = local_records
-    recv = torch.empty((world * cap, rec), dtype=torch.uint8, device=local_records.device)
-    dist.all_gather_into_tensor(recv, send, group=group)
-    parts = []
-    for r in range(world):
-        lo, hi = shard_bounds(n_total, r, world)
-        parts.append(recv[r * cap: r * cap + (hi - lo)])
-    return torch.cat(parts)
+    return _GatherBuffers.get(n_total, world, local_records.device, torch.uint8, local_records.shape[1]).gather(local_records, group)
 
 
 class ShardedResample:

@@ -28,14 +28,14 @@ def beams_from_points(points):
 
 def sample_beams(cloud_xyz, samples, seed):
     """Beam sampling of PCDSensorUpdaterEmbree.cpp:290-311 with an explicit seed:
-    uniform random indices, up to 100 retries for a finite point."""
+    uniform random indices, up to 100 retries for a point without NaN."""
     pts = np.ascontiguousarray(cloud_xyz, dtype=np.float32).reshape(-1, 3)
     rng = np.random.RandomState(seed)
     chosen = []
     for _ in range(samples):
         for _try in range(100):
             i = rng.randint(0, len(pts))
-            if np.all(np.isfinite(pts[i])):
+            if not np.isnan(pts[i]).any():   # x==x && y==y && z==z (PCDSensorUpdaterEmbree.cpp:303): +-inf passes
                 chosen.append(i)
                 break
         else:

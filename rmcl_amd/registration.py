@@ -317,6 +317,24 @@ class CorrespondencesHIP:
     def set_variant(self, variant):
         _capi.check(_capi.lib().rmclhip_rcc_set_variant(self._h, int(variant)))
 
+    def find_variant(self, nposes=1):
+        """the traversal the automatic rule (variant 15) launches for `nposes` scans of the current model"""
+        v = C.c_int(0)
+        _capi.check(_capi.lib().rmclhip_rcc_find_variant(self._h, int(nposes), C.byref(v)))
+        return v.value
+
+    def debug_probe_find(self, Tbm_est, mode=0):
+        """diagnostics: per-wave step timeline of one spherical scan -> uint32 array [n_tiles, 256, 2]"""
+        T = np.ascontiguousarray(Tbm_est, dtype=TRANSFORM).reshape(1)
+        H, W = self._model_shape
+        cap = ((H + 7) // 8 + 1) * ((W + 7) // 8 + 1) * 64 * 512   # any tile shape
+        cap = min(cap, (H * W + 64 * 64) * 8 * 2)
+        buf = np.zeros(max(cap, 512), np.uint32)
+        nt = C.c_uint32(0)
+        _capi.check(_capi.lib().rmclhip_debug_probe_find(self._h, _ptr(T), int(mode), _ptr(buf), buf.size, C.byref(nt)))
+        self._last_nposes = 1
+        return buf[: nt.value * 512].reshape(nt.value, 256, 2)
+
     def _push_params(self):
         _capi.check(_capi.lib().rmclhip_rcc_set_params(self._h, float(self.params.max_dist),
                                                        float(self.adaptive_max_dist_min)))
@@ -414,6 +432,10 @@ class CPCHip(CorrespondencesHIP):
         self._last_nposes = 1
 
     def set_dataset(self, points, mask=None, device=False):
+        # element count exactly as the base class derives it (torch tensor / DeviceArray / host array)
+        if device:
+            n = int(points.numel() // 3) if hasattr(points, "numel") else int(points.count // 3)
+        else:
+            n = int(np.asarray(points).size // 3)
         super().set_dataset(points, mask, device)
-        n = (points.count // 3) if hasattr(points, "count") else int(np.asarray(points).size // 3)
         self._model_shape = (1, n)

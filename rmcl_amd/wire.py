@@ -61,14 +61,14 @@ def xyz_from_pointcloud2(data, n_points, point_step, offset_x, offset_y, offset_
 
 def sample_beams_pointcloud2(data, n_points, point_step, offset_x, offset_y, offset_z, samples, seed, datatype=FLOAT32):
     """PCDSensorUpdaterEmbree.cpp:290-327 on the raw message bytes: `samples` uniformly random points (each with up
-    to 100 retries for a finite one) become RangeMeasurements {orig 0, dir = p / |p|, range = |p|}."""
+    to 100 retries for one without NaN) become RangeMeasurements {orig 0, dir = p / |p|, range = |p|}."""
     pts = xyz_from_pointcloud2(data, n_points, point_step, offset_x, offset_y, offset_z, datatype)
     rng = np.random.RandomState(seed)
     chosen = []
     for _ in range(samples):
         for _try in range(100):
             i = rng.randint(0, n_points)
-            if np.all(np.isfinite(pts[i])):
+            if not np.isnan(pts[i]).any():   # x==x && y==y && z==z (PCDSensorUpdaterEmbree.cpp:303): +-inf passes
                 chosen.append(i)
                 break
         else:

@@ -41,10 +41,26 @@ def _worker(rank, world, port, n_total, out_dir):
         Tsb = syn.tsb_offset()
         lo, hi = D.shard_bounds(n_total, rank, world)
         local_attrs = attrs[lo:hi].copy()
-        if hi > lo:
-            m.pf_update(poses[lo:hi], local_attrs, beams, Tsb, orc.pf_params(), bvh=True)
-        w_local = torch.from_numpy(np.ascontiguousarray(local_attrs["likelihood"]["mean"]))
-        gathered = D.allgather_weights(w_local, n_total)
+
+        class OracleUpdater:
+            """TEST STUB with the PCDSensorUpdaterHip call surface ShardedSensorUpdate drives (update /
+            extract_weights); the rank-local beam evaluation is the CPU oracle's."""
+
+            def update(self, poses_dev, attrs_dev, n_particles=None):
+                if n_particles:
+                    m.pf_update(poses_dev[:n_particles], attrs_dev[:n_particles], beams, Tsb, orc.pf_params(), bvh=True)
+
+            def extract_weights(self, attrs_dev, n, weights_ptr):
+                import ctypes
+                w = np.ascontiguousarray(attrs_dev["likelihood"]["mean"][:n])
+                ctypes.memmove(weights_ptr, w.ctypes.data, 4 * n)
+
+        sharded = D.ShardedSensorUpdate(OracleUpdater(), n_total, rank, world)
+        assert (sharded.lo, sharded.hi, sharded.n_local) == (lo, hi, hi - lo)
+        w_local = torch.zeros(hi - lo, dtype=torch.float32)
+        for _ in range(2):   # twice: the preallocated gather buffers are reused
+            local_attrs = attrs[lo:hi].copy()
+            gathered = sharded.update(poses[lo:hi], local_attrs, w_local)
         ssum, smax = D.allreduce_sum_max(w_local)
         # unsharded reference on every rank
         ref = attrs.copy()

@@ -254,3 +254,170 @@ def test_c5_mesh_one_million_triangles(ra, orc, ctx):
     a_gpu = d_attrs.download()
     assert np.array_equal(a_gpu["likelihood"]["n_meas"], a_ref["likelihood"]["n_meas"])
     assert_close_rel(a_gpu["likelihood"]["mean"], a_ref["likelihood"]["mean"], 1e-5, 1e-12, "1M pf mean")
+
+
+ROOM_POSE_RPY = ((1.5, -2.0, 1.6), (0.02, -0.03, 0.4))   # the pose of tests/golden/make_golden.py:g7_digests
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6, 15])
+def test_c2_room100k_full_size(ra, orc, ctx, meshes, variant):
+    """config C2's scan on a REALISTIC map (room-100k: occluders, vertex noise, open ceiling => misses): every
+    traversal incl. the automatic one (15) vs the oracle on all 131 072 rays + the committed G7 digests
+    (face ids, hits, hit count).  RCCEmbree.cpp:26-36 / RCCOptix.cpp:28-43."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room100k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    model = syn.model_c2()
+    rcc = ra.RCCHipSpherical(hm)
+    rcc.set_variant(variant)
+    rcc.setTsb(T.identity())
+    rcc.setModel(model)
+    Tbm = T.transform_from_rpy(*ROOM_POSE_RPY)
+    rcc.find(Tbm)
+    gpu = rcc.modelView()
+    ref = m.simulate_spherical(model, T.identity(), Tbm, bvh=True, nthreads=8)
+    _compare(gpu, ref, "C2 room-100k variant %d" % variant)
+    with open(golden_path("g7_digests.json")) as fh:
+        dig = json.load(fh)
+    assert hashlib.sha256(gpu["face_ids"].tobytes()).hexdigest() == dig["c2_room100k_face_ids_sha256"]
+    assert hashlib.sha256(gpu["hits"].tobytes()).hexdigest() == dig["c2_room100k_hits_sha256"]
+    assert int(gpu["hits"].sum()) == dig["c2_room100k_n_hits"]
+    assert 0 < int(gpu["hits"].sum()) < gpu["hits"].size   # the scan really contains misses
+    rcc.close()
+
+
+def _o1dn_c2(syn, n_nan=37, seed=11):
+    """the documented deployment model: C2's 128x1024 directions as DATA (+12 B/ray read), a few NaNs"""
+    model = syn.model_c2()
+    dirs = syn.model_directions(model).copy()
+    rng = np.random.RandomState(seed)
+    dirs[rng.randint(0, len(dirs), n_nan)] = np.nan
+    return model, dirs
+
+
+@pytest.mark.parametrize("mesh,variant", [("sphere100k", 15), ("room100k", 15), ("room100k", 1), ("room100k", 2)])
+def test_o1dn_c2_size_single_pose(ra, orc, ctx, meshes, mesh, variant):
+    """RCCEmbreeO1Dn::find (RCCEmbree.cpp:89-99) at C2's full size: 131 072 explicit directions, sensor origin and
+    Tsb != identity, NaN directions come back as misses."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes(mesh)
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    model, dirs = _o1dn_c2(syn)
+    W, H = model.theta.size, model.phi.size
+    orig = (0.03, -0.01, 0.08)
+    Tsb = syn.tsb_offset()
+    Tbm = syn.pose_c2_truth() if mesh == "sphere100k" else T.transform_from_rpy(*ROOM_POSE_RPY)
+    rcc = ra.RCCHipO1Dn(hm)
+    rcc.set_variant(variant)
+    rcc.setTsb(Tsb)
+    rcc.setModel(W, H, float(model.range.min), float(model.range.max), orig, dirs)
+    rcc.find(Tbm)
+    gpu = rcc.modelView()
+    ref = m.simulate_o1dn(W, H, float(model.range.min), float(model.range.max), orig, dirs, Tsb, Tbm, bvh=True, nthreads=8)
+    _compare(gpu, ref, "o1dn C2 %s variant %d" % (mesh, variant))
+    assert (gpu["hits"] == 0).sum() >= 30
+    rcc.close()
+
+
+def test_o1dn_c2_size_pose_batch(ra, orc, ctx, meshes):
+    """8 poses x 131 072 explicit directions in one launch (pose-major model buffers), automatic traversal
+    (> 262 144 rays in flight => quantised nodes)."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room100k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    model, dirs = _o1dn_c2(syn, seed=12)
+    W, H = model.theta.size, model.phi.size
+    orig = (0.0, 0.02, 0.05)
+    Tsb = syn.tsb_offset()
+    rng = np.random.RandomState(3)
+    base = T.transform_from_rpy(*ROOM_POSE_RPY)
+    poses = np.array([T.mult(base, T.transform_from_rpy(tuple(rng.uniform(-1.5, 1.5, 3) * (1, 1, 0.2)),
+                                                        (0.0, 0.0, rng.uniform(-3, 3)))) for _ in range(8)],
+                     dtype=T.TRANSFORM)
+    rcc = ra.RCCHipO1Dn(hm)
+    rcc.setTsb(Tsb)
+    rcc.setModel(W, H, float(model.range.min), float(model.range.max), orig, dirs)
+    rcc.find_batch(poses)
+    gpu = rcc.modelView()
+    ref = m.simulate_o1dn(W, H, float(model.range.min), float(model.range.max), orig, dirs, Tsb, poses, bvh=True, nthreads=8)
+    _compare(gpu, ref, "o1dn C2 batch")
+    rcc.close()
+
+
+@pytest.mark.parametrize("mesh", ["sphere100k", "room100k"])
+def test_automatic_variant_in_every_size_bracket(ra, orc, ctx, meshes, mesh):
+    """variant 15 (the default) picks a different traversal per rays-in-flight bracket (capi.cpp:find_variant):
+    <= 65 536 four lanes per ray, <= 262 144 one lane per ray with the tail of every wave finished by quads,
+    larger: one lane per ray on the quantised nodes.  Each bracket is run explicitly with variant 15."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes(mesh)
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    base = syn.pose_c2_truth() if mesh == "sphere100k" else T.transform_from_rpy(*ROOM_POSE_RPY)
+    f32 = np.float32
+    brackets = [(16, 900, 1), (64, 1024, 1), (96, 1024, 1), (128, 1024, 1), (128, 2048, 1), (128, 1024, 3), (16, 900, 40)]
+    for (H, W, nposes) in brackets:
+        model = T.spherical_model(f32(-0.39), f32(0.78 / (H - 1)), H, f32(-math.pi), f32(2 * math.pi / W), W, f32(0.3), f32(120.0))
+        rng = np.random.RandomState(H + W + nposes)
+        poses = np.array([T.mult(base, T.transform_from_rpy(tuple(rng.uniform(-0.5, 0.5, 3)), (0.0, 0.0, rng.uniform(-3, 3))))
+                          for _ in range(nposes)], dtype=T.TRANSFORM)
+        rcc = ra.RCCHipSpherical(hm)
+        rcc.set_variant(15)
+        rcc.setTsb(T.identity())
+        rcc.setModel(model)
+        if nposes == 1:
+            rcc.find(poses[0])
+        else:
+            rcc.find_batch(poses)
+        gpu = rcc.modelView()
+        ref = m.simulate_spherical(model, T.identity(), poses, bvh=True, nthreads=8)
+        _compare(gpu, ref, "auto %s %dx%dx%d" % (mesh, H, W, nposes))
+        rcc.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6])
+def test_sensor_origin_on_a_face(ra, orc, ctx, meshes, variant):
+    """Embree's depth test is strict on the near side (absDen * tnear < T with tnear = 0): a ray that starts exactly ON a
+    wall triangle does not hit that triangle -- the sensor sees the room, not t = 0 everywhere."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("cube")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    model = syn.model_c1()
+    Tbm = T.transform_from_rpy((5.0, 0.3, 0.2), (0.0, 0.0, 0.0))     # x = +5 is the wall plane of the side-10 cube
+    rcc = ra.RCCHipSpherical(hm)
+    rcc.set_variant(variant)
+    rcc.setTsb(T.identity())
+    rcc.setModel(model)
+    rcc.find(Tbm)
+    gpu = rcc.modelView()
+    ref = m.simulate_spherical(model, T.identity(), Tbm, bvh=False)
+    _compare(gpu, ref, "origin on a face")
+    hit = gpu["hits"] > 0
+    assert hit.any() and (~hit).any()               # inward rays see the room, outward rays leave the cube
+    assert gpu["ranges"][hit].min() > 1e-3          # nobody reports the wall it stands on at t = 0
+    rcc.close()
+
+
+def test_context_may_be_destroyed_before_its_children(ra, orc, meshes):
+    """the context is reference counted: closing it first must not turn the later release of map / rcc /
+    pf handles into a use-after-free."""
+    from rmcl_amd import synthetic as syn, types as T
+    c2 = ra.Context(0)
+    v, f = meshes("cube")
+    hm = ra.import_hip_map(c2, v, f)
+    rcc = ra.RCCHipSpherical(hm)
+    upd = ra.PCDSensorUpdaterHip(hm)
+    upd.init()
+    c2.close()                                   # creator's reference gone; children keep the context alive
+    rcc.setTsb(T.identity())
+    rcc.setModel(syn.model_c1())
+    rcc.find(syn.pose_c2_truth())
+    ref = orc.Mesh(v, f).simulate_spherical(syn.model_c1(), T.identity(), syn.pose_c2_truth(), bvh=False)
+    _compare(rcc.modelView(), ref, "after ctx close")
+    upd.close()
+    rcc.close()
+    hm.release()

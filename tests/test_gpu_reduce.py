@@ -25,14 +25,23 @@ def _stats_close(s_gpu, ref64, scale=None):
 
 
 def _transform_close(a, b, tol=1e-5):
+    """pose deltas within 1e-5 RELATIVE (north_star): |ta - tb| <= tol * |tb| and the angle of the residual rotation
+    <= tol * the angle of b's rotation; the absolute floors (1e-6 m, 2e-7 rad) are the f32 resolution of the
+    metre-scale means / unit quaternions both sides round through, not slack on the deltas."""
     qa = np.array([a["R"][k] for k in "xyzw"], dtype=np.float64)
     qb = np.array([b["R"][k] for k in "xyzw"], dtype=np.float64)
+    qa, qb = qa / np.linalg.norm(qa), qb / np.linalg.norm(qb)
     if np.dot(qa, qb) < 0:
         qb = -qb
     ta = np.array([a["t"][k] for k in "xyz"], dtype=np.float64)
     tb = np.array([b["t"][k] for k in "xyz"], dtype=np.float64)
-    assert np.allclose(qa, qb, atol=tol), (qa, qb)
-    assert np.allclose(ta, tb, atol=tol * max(1.0, np.abs(tb).max())), (ta, tb)
+    ang_b = 2.0 * np.arctan2(np.linalg.norm(qb[:3]), abs(qb[3]))
+    # residual rotation qa^-1 * qb: its vector part has norm sin(angle / 2)
+    w = qa[3] * qb[3] + np.dot(qa[:3], qb[:3])
+    vec = qa[3] * qb[:3] - qb[3] * qa[:3] - np.cross(qa[:3], qb[:3])
+    ang_res = 2.0 * np.arctan2(np.linalg.norm(vec), abs(w))
+    assert ang_res <= tol * ang_b + 2e-7, (ang_res, ang_b, qa, qb)
+    assert np.linalg.norm(ta - tb) <= tol * np.linalg.norm(tb) + 1e-6, (ta, tb)
 
 
 def _setup(ra, orc, ctx, meshes, mesh_name, model, Tsb, truth, est):

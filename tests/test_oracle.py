@@ -91,6 +91,10 @@ def test_g1_ray_triangle_cases(orc):
     assert m.intersect((0.5, 0.0, 1), (0, 0, -1))[0] is True                 # on an edge: inclusive
     assert m.intersect((0.0, 0.0, 1), (0, 0, -1))[0] is True                 # on a vertex
     assert m.intersect((0.2, 0.2, 1), (np.nan, 0, -1), bvh=True)[0] is False  # NaN direction
+    # Embree's near side is strict (absDen * tnear < T): a ray that STARTS on the triangle does not hit it
+    assert m.intersect((0.2, 0.2, 0), (0, 0, -1))[0] is False
+    assert m.intersect((0.2, 0.2, 0), (0.3, 0.1, 1))[0] is False
+    assert m.intersect((0.2, 0.2, 1e-6), (0, 0, -1))[0] is True              # just in front of it: hit
 
 
 def test_tie_break_min_t_then_min_face(orc):
