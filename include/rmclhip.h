@@ -270,6 +270,11 @@ rmclhip_status rmclhip_rcc_find_variant(const rmclhip_rcc* rcc, uint32_t nposes,
 /* DIAGNOSTICS (tools/probe_find.py; not part of the reference interface): one spherical find() through an instrumented
  * copy of the one-lane-per-ray traversal that stamps s_memtime around every node / leaf step of every wave.
  * mode: bit 0 = one-round-trip leaves, bit 1 = LDS-resident top of the tree.  log_out: n_tiles x 512 dwords (host). */
+/* DIAGNOSTICS (tools/wave_timeline.py): one find() of the current variant whose waves record their entry / exit shader clock:
+ * out = n_waves x 8 dwords {s_memtime entry, exit (stores completed), s_memrealtime entry (100 MHz), tile | xcc << 24,
+ * s_memtime before the traversal, after it, stores issued, 0} (all zero = wave had no tile) */
+rmclhip_status rmclhip_debug_wave_clock(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est, uint32_t* out, size_t cap_dwords,
+                                        uint32_t* n_waves_out);
 rmclhip_status rmclhip_debug_probe_find(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est, int mode, uint32_t* log_out,
                                         size_t log_cap_dwords, uint32_t* n_tiles_out);
 /* rm::Simulator::simulate(Memory<Transform>, Bundle&) (batch form, lidar_corrector_embree_benchmark.cpp:117):

@@ -1477,3 +1477,143 @@ int orc_trace_bvh4_ordered(const uint32_t* nodes, const uint32_t* tris, orc_vec3
   if (found) { *t_out = best_t; *face_out = best_f; }
   return found;
 }
+
+/* ------------------------------------------------------------------------- */
+/* ANALYSIS (tools/wavesim.py): wave-level model of the product's one-lane-per-ray "while-while" traversal.  The     */
+/* single-scan find is bound by the slowest WAVE's chain of dependent steps, so what a builder / ordering change buys   */
+/* is measured here as wave-level node iterations and leaf rounds (a wave iterates while ANY of its lanes still has   */
+/* an inner node / a leaf), on the product's exported Node4 / TriRec arrays.                                          */
+/* mode bit0: cull popped entries whose entry distance exceeds best_t; bit1: (always) sort deferred children;         */
+/* bit2: entry-distance ties at 0 (origin inside several child boxes) are ordered by EXIT distance, farthest first.    */
+/* out[0] wave node iterations, out[1] wave leaf rounds, out[2] wave triangle iterations (sum over rounds of the       */
+/* longest leaf), out[3] sum of lane node visits, out[4] max lane node visits, out[5] sum lane leaf visits.            */
+/* ------------------------------------------------------------------------- */
+/* cost model of orc_wavesim_ww (cycles): per wave-level node iteration / triangle iteration, by the number of rays still
+ * walking at the start of the round: > t2 one lane per ray, <= t2 two lanes per ray, <= t4 four lanes per ray (a
+ * cooperative leaf step tests a whole leaf at once).  Set by orc_wavesim_costs; out[6] accumulates the estimate. */
+static struct { double n1, l1, n2, l2, n4, l4; uint32_t t2, t4; } g_ws_cost = {880, 300, 570, 400, 450, 400, 0, 0};
+void orc_wavesim_costs(double n1, double l1, double n2, double l2, double n4, double l4, uint32_t t2, uint32_t t4)
+{
+  g_ws_cost.n1 = n1; g_ws_cost.l1 = l1; g_ws_cost.n2 = n2; g_ws_cost.l2 = l2; g_ws_cost.n4 = n4; g_ws_cost.l4 = l4;
+  g_ws_cost.t2 = t2; g_ws_cost.t4 = t4;
+}
+
+typedef struct {
+  uint32_t cur; int sp; int done; float best_t; uint32_t best_f; int found;
+  float o[3], inv[3]; orc_vec3 O, D;
+  uint32_t stack[128]; float stack_t[128];
+  uint64_t nvisit, lvisit;
+} ws_lane;
+
+static int ws_box(const float* nd, uint32_t c, const float* o, const float* inv, float best_t, float* tn_out, float* tf_out)
+{
+  float tn = 0.0f, tf = best_t;
+  for (int k = 0; k < 3; ++k) {
+    const float lo = nd[8 * k + c], hi = nd[8 * k + 4 + c];
+    float t0 = (lo - o[k]) * inv[k], t1 = (hi - o[k]) * inv[k];
+    if (t0 > t1) { const float t = t0; t0 = t1; t1 = t; }
+    if (t0 > tn) tn = t0;
+    if (t1 < tf) tf = t1;
+  }
+  *tn_out = tn; *tf_out = tf;
+  return nd[c] < 1e29f && tn <= tf;
+}
+
+static void ws_pop(ws_lane* L, int mode)
+{
+  while (L->sp > 0) {
+    --L->sp;
+    if ((mode & 1) && L->stack_t[L->sp] > L->best_t) continue;
+    L->cur = L->stack[L->sp];
+    return;
+  }
+  L->done = 1;
+}
+
+int orc_wavesim_ww(const uint32_t* nodes, const uint32_t* tris, const float* O, const float* D, uint32_t nlanes,
+                   float tfar, int mode, uint64_t out[7], float* t_out, uint32_t* face_out)
+{
+  double est = 0.0;
+  if (nlanes > 64) return -1;
+  ws_lane* L = (ws_lane*)calloc(nlanes ? nlanes : 1, sizeof(ws_lane));
+  for (uint32_t i = 0; i < nlanes; ++i) {
+    L[i].O = v3(O[3 * i], O[3 * i + 1], O[3 * i + 2]); L[i].D = v3(D[3 * i], D[3 * i + 1], D[3 * i + 2]);
+    L[i].o[0] = L[i].O.x; L[i].o[1] = L[i].O.y; L[i].o[2] = L[i].O.z;
+    L[i].inv[0] = safe_inv(L[i].D.x); L[i].inv[1] = safe_inv(L[i].D.y); L[i].inv[2] = safe_inv(L[i].D.z);
+    L[i].best_t = tfar; L[i].best_f = 0xFFFFFFFFu;
+    L[i].done = !(L[i].D.x == L[i].D.x && L[i].D.y == L[i].D.y && L[i].D.z == L[i].D.z);
+  }
+  memset(out, 0, 7 * sizeof(uint64_t));
+  for (;;) {
+    int any = 0; uint32_t walking = 0;
+    for (uint32_t i = 0; i < nlanes; ++i) { any |= !L[i].done; walking += L[i].done ? 0u : 1u; }
+    if (!any) break;
+    const int coop = (walking <= g_ws_cost.t4) ? 4 : ((walking <= g_ws_cost.t2) ? 2 : 1);
+    const double cn = coop == 4 ? g_ws_cost.n4 : (coop == 2 ? g_ws_cost.n2 : g_ws_cost.n1);
+    const double cl = coop == 4 ? g_ws_cost.l4 : (coop == 2 ? g_ws_cost.l2 : g_ws_cost.l1);
+    /* phase 1: node iterations while any lane holds an inner node (policy, mode bits 8..15 = T > 0: the phase is also
+     * left as soon as at least T lanes hold a leaf) */
+    const uint32_t leaf_trigger = ((uint32_t)mode >> 8) & 0xFFu;
+    for (;;) {
+      int inner = 0; uint32_t holding = 0;
+      for (uint32_t i = 0; i < nlanes; ++i) {
+        inner |= (!L[i].done && !(L[i].cur & 0x80000000u));
+        holding += (!L[i].done && (L[i].cur & 0x80000000u)) ? 1u : 0u;
+      }
+      if (!inner) break;
+      if (leaf_trigger && holding >= leaf_trigger) break;
+      out[0]++;
+      est += cn;
+      for (uint32_t i = 0; i < nlanes; ++i) {
+        ws_lane* l = &L[i];
+        if (l->done || (l->cur & 0x80000000u)) continue;
+        l->nvisit++;
+        const float* nd = (const float*)(nodes + 32u * l->cur);
+        const uint32_t* ch = nodes + 32u * l->cur + 24u;
+        float key[4], key2[4]; uint32_t ref[4]; int nh = 0;
+        for (uint32_t c = 0; c < 4; ++c) {
+          float tn, tf;
+          if (ws_box(nd, c, l->o, l->inv, l->best_t, &tn, &tf)) { key[nh] = tn; key2[nh] = (mode & 4) ? -tf : 0.0f; ref[nh] = ch[c]; nh++; }
+        }
+        for (int a = 0; a < nh; ++a) for (int b = a + 1; b < nh; ++b)
+          if (key[b] < key[a] || (key[b] == key[a] && key2[b] < key2[a])) {
+            float t = key[a]; key[a] = key[b]; key[b] = t; t = key2[a]; key2[a] = key2[b]; key2[b] = t;
+            uint32_t r = ref[a]; ref[a] = ref[b]; ref[b] = r;
+          }
+        for (int a = nh - 1; a >= 1; --a) { if (l->sp < 128) { l->stack[l->sp] = ref[a]; l->stack_t[l->sp] = key[a]; l->sp++; } }
+        if (nh > 0) l->cur = ref[0]; else ws_pop(l, mode);
+      }
+    }
+    /* phase 2: one leaf round */
+    uint32_t maxcnt = 0; int anyleaf = 0;
+    for (uint32_t i = 0; i < nlanes; ++i) {
+      ws_lane* l = &L[i];
+      if (l->done || !(l->cur & 0x80000000u)) continue;
+      anyleaf = 1;
+      l->lvisit++;
+      const uint32_t first = l->cur & 0x0FFFFFFFu, cnt = ((l->cur >> 28) & 7u) + 1u;
+      if (cnt > maxcnt) maxcnt = cnt;
+      for (uint32_t k = 0; k < cnt; ++k) {
+        const float* r = (const float*)(tris + 16u * (first + k));
+        orc_tri T;
+        T.v0 = v3(r[0], r[1], r[2]); T.e1 = v3(r[3], r[4], r[5]); T.e2 = v3(r[6], r[7], r[8]);
+        T.Ng = v3(r[9], r[10], r[11]); T.n = v3(r[12], r[13], r[14]);
+        const uint32_t f = tris[16u * (first + k) + 15u];
+        float t;
+        if (tri_intersect(&T, l->O, l->D, 0.0f, tfar, &t)) {
+          if (!l->found || t < l->best_t || (t == l->best_t && f < l->best_f)) { l->best_t = t; l->best_f = f; l->found = 1; }
+        }
+      }
+      ws_pop(l, mode);
+    }
+    if (anyleaf) { out[1]++; out[2] += maxcnt; est += (coop == 1) ? cl * maxcnt : cl; }
+  }
+  out[6] = (uint64_t)est;
+  for (uint32_t i = 0; i < nlanes; ++i) {
+    out[3] += L[i].nvisit; if (L[i].nvisit > out[4]) out[4] = L[i].nvisit; out[5] += L[i].lvisit;
+    if (t_out) t_out[i] = L[i].found ? L[i].best_t : -1.0f;
+    if (face_out) face_out[i] = L[i].best_f;
+  }
+  free(L);
+  return 0;
+}

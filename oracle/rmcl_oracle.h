@@ -214,5 +214,11 @@ int orc_pointcloud2_unpack(const uint8_t* data, uint32_t width, uint32_t height,
 
 #ifdef __cplusplus
 }
+/* analysis only (tools/wavesim.py): wave-level step counts of the product's while-while traversal on its exported
+ * BVH4 arrays; see rmcl_oracle.c */
+int orc_wavesim_ww(const uint32_t* nodes, const uint32_t* tris, const float* O, const float* D, uint32_t nlanes,
+                   float tfar, int mode, uint64_t out[7], float* t_out, uint32_t* face_out);
+void orc_wavesim_costs(double n1, double l1, double n2, double l2, double n4, double l4, uint32_t t2, uint32_t t4);
+
 #endif
 #endif

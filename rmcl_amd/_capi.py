@@ -116,6 +116,7 @@ SIGNATURES = {
     "rmclhip_rcc_time_correct_once": (_i32, [_vp, _vp, _vp, _u32, _dbl, _i32, _u32, C.POINTER(_f32)]),
     "rmclhip_rcc_set_variant": (_i32, [_vp, _i32]),
     "rmclhip_rcc_find_variant": (_i32, [_vp, _u32, C.POINTER(_i32)]),
+    "rmclhip_debug_wave_clock": (_i32, [_vp, _vp, _vp, _sz, C.POINTER(_u32)]),
     "rmclhip_debug_probe_find": (_i32, [_vp, _vp, _i32, _vp, _sz, C.POINTER(_u32)]),
     "rmclhip_rcc_find_batch": (_i32, [_vp, _vp, _u32]),
     "rmclhip_rcc_time_find_batch": (_i32, [_vp, _vp, _u32, _u32, C.POINTER(_f32)]),

@@ -300,6 +300,8 @@ rmclhip_status rmclhip_map_create(rmclhip_ctx* ctx, const float* v, uint32_t nv,
   if (!err.empty()) return fail(RMCLHIP_ERR_INVALID, "map_create: " + err);
   if (bvh.info.stack_need > 64)
     return fail(RMCLHIP_ERR_UNSUPPORTED, "map_create: BVH needs a traversal stack deeper than 64 entries");
+  if (static_cast<uint64_t>(bvh.nodes.size()) * sizeof(Node4) >= (1ull << 32))
+    return fail(RMCLHIP_ERR_UNSUPPORTED, "map_create: node array exceeds 4 GB (the kernels address nodes with 32-bit byte offsets)");
   HIPCHK(hipSetDevice(ctx->device));
   rmclhip_map* m = new rmclhip_map();
   m->ctx = ctx;
@@ -1082,8 +1084,9 @@ rmclhip_status rmclhip_rcc_time_correct_once(rmclhip_rcc* r, const rmclhip_trans
 rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
   ApiGuard guard_("rmclhip_rcc_set_variant");
   if (!r || variant < 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: bad arguments");
-  const int kind = variant & 0xF, tile = (variant >> 4) & 0xF;
-  if ((kind > 10 && kind != 15) || kind == 3 || tile > 7 || (variant >> 13) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
+  // bit 13 adds 16 to the traversal kind (kinds 16..31)
+  const int kind = (variant & 0xF) | (((variant >> 13) & 1) << 4), tile = (variant >> 4) & 0xF;
+  if (kind == 3 || kind > 17 || tile > 7 || (variant >> 14) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
   r->variant = kind;
   r->tile_override = tile;
   r->fused_tail = ((variant >> 8) & 1) != 0;
@@ -1129,6 +1132,42 @@ rmclhip_status rmclhip_debug_probe_find(rmclhip_rcc* r, const rmclhip_transform*
   if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
   (void)hipFree(d_log);
   if (e != hipSuccess) return fail(RMCLHIP_ERR_HIP, std::string("debug_probe_find: ") + hipGetErrorString(e));
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_debug_wave_clock(rmclhip_rcc* r, const rmclhip_transform* Tbm_est, uint32_t* out, size_t cap_dwords,
+                                        uint32_t* n_waves_out) {
+  ApiGuard guard_("rmclhip_debug_wave_clock");
+  if (!r || !Tbm_est || !out) return fail(RMCLHIP_ERR_INVALID, "debug_wave_clock: null");
+  if (r->kind == kModelNone || r->W == 0 || r->H == 0) return fail(RMCLHIP_ERR_INVALID, "debug_wave_clock: no sensor model");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  const size_t n = static_cast<size_t>(r->W) * r->H;
+  r->n_model = static_cast<uint32_t>(n);
+  r->nposes_last = 1;
+  if (rmclhip_status st = ensure_model_buffers(r, n)) return st;
+  FindParams p;
+  fill_find_params(r, p, 1);
+  p.Tsm = xmul(to_x(Tbm_est), r->Tsb);
+  p.Tms = xinv(p.Tsm);
+  const int variant = find_variant(r, 1);
+  const uint32_t ntiles = p.tiles_x * p.tiles_y;
+  uint32_t nblocks = (variant == 2) ? ntiles : (ntiles + 3u) / 4u;
+  nblocks = (nblocks + 7u) & ~7u;
+  const size_t dwords = static_cast<size_t>(nblocks) * 4u * 8u;
+  if (n_waves_out) *n_waves_out = nblocks * 4u;
+  if (cap_dwords < dwords) return fail(RMCLHIP_ERR_INVALID, "debug_wave_clock: buffer too small");
+  uint32_t* d = nullptr;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&d), dwords * sizeof(uint32_t)));
+  hipError_t e = hipSuccess;
+  FindParams warm = p;
+  for (int i = 0; i < 5 && e == hipSuccess; ++i) e = launch_find(warm, r->kind, variant, r->stream);   // warm, un-instrumented
+  if (e == hipSuccess) e = hipMemsetAsync(d, 0, dwords * sizeof(uint32_t), r->stream);
+  p.wave_clock = d;
+  if (e == hipSuccess) e = launch_find(p, r->kind, variant, r->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d, dwords * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(RMCLHIP_ERR_HIP, std::string("debug_wave_clock: ") + hipGetErrorString(e));
   return RMCLHIP_OK;
 }
 

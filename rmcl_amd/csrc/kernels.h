@@ -40,6 +40,8 @@ struct FindParams {
   float* points;
   float* normals;
   uint32_t* face_ids;
+  // diagnostics (nullable): per physical wave {s_memtime at entry, at exit (low 32 bits), s_memrealtime at entry, tile | xcc << 24}
+  uint32_t* wave_clock;
 };
 
 struct MicpState;

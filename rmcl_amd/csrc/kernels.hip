@@ -34,9 +34,10 @@ typedef const __attribute__((address_space(4))) u32x16* cu32x16p;
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
+// closest hit of a ray: rec = index of the hit triangle's record, kNone (0xFFFFFFFF) for a miss; the ORIGINAL face id
+// lives in dword 15 of that record (the epilogues read it together with the unit normal)
 struct RayHit {
   float t;
-  uint32_t face;
   uint32_t rec;
 };
 
@@ -142,10 +143,13 @@ __device__ __forceinline__ const char* node_address(const uint32_t* __restrict__
   return ((cur < static_cast<uint32_t>(kTop)) ? l : g) + (static_cast<size_t>(cur) << 7);
 }
 
-// One triangle test of the per-lane traversals from the three dwordx4 of its record + its face id (same
-// arithmetic and acceptance as the loop bodies above: tri_accept, Tt > 0, t <= tfar, (min t, min face id)).
-__device__ __forceinline__ void tri_update(uint4 a, uint4 b, uint4 c, uint32_t face, uint32_t rec, f3 O, f3 D, float ray_tfar,
-                                           float& best_t, uint32_t& best_face, uint32_t& best_rec) {
+// One triangle test of the per-lane traversals from the first three dwordx4 of its record (same arithmetic and acceptance
+// as tri_accept's other callers: Tt > 0, t <= tfar, closest = (min t, then min face id)).  The face id is NOT read here:
+// it only decides exact ties in t, so the loop tracks the RECORD of the best hit and fetches the two face ids in the
+// (rare) tie branch; the caller's epilogue reads the winner's face id together with its normal.  One load fewer per
+// triangle, and no dependent load on the hit path.  best_rec == kNone <=> no hit yet.
+__device__ __forceinline__ void tri_update(uint4 a, uint4 b, uint4 c, uint32_t rec, const uint32_t* __restrict__ tris, f3 O, f3 D,
+                                           float ray_tfar, float& best_t, uint32_t& best_rec) {
   const f3 v0 = mk3(asf(a.x), asf(a.y), asf(a.z));
   const f3 e1 = mk3(asf(a.w), asf(b.x), asf(b.y));
   const f3 e2 = mk3(asf(b.z), asf(b.w), asf(c.x));
@@ -155,20 +159,24 @@ __device__ __forceinline__ void tri_update(uint4 a, uint4 b, uint4 c, uint32_t f
   if (ok) {
     const float t = Tt / aden;
     const bool acc = (Tt > 0.0f) && (t <= ray_tfar);
-    const bool closer = acc && ((t < best_t) || ((t == best_t) && (face < best_face)));
+    bool closer = acc && (t < best_t);
+    if (acc && (t == best_t) && (rec != best_rec)) {
+      // exact tie: the smaller ORIGINAL face id wins; a first hit at exactly t == tfar wins against "no hit"
+      closer = (best_rec == kNone) || (tris[static_cast<size_t>(rec) * 16u + 15u] < tris[static_cast<size_t>(best_rec) * 16u + 15u]);
+    }
     best_t = closer ? t : best_t;
-    best_face = closer ? face : best_face;
     best_rec = closer ? rec : best_rec;
   }
 }
 
-// A whole leaf (<= 4 records) in ONE memory round trip: the loop form above waits for triangle i before it requests
+// A whole leaf (<= 4 records) in ONE memory round trip: the loop form waits for triangle i before it requests
 // triangle i+1 -- up to four dependent round trips per leaf visit, and the wave runs as many as its fullest leaf has
-// triangles.  Here the records of all (wave-uniform maximum) slots are requested together; a lane whose leaf is
-// shorter re-requests its last record (same line, and a repeated test cannot change (best_t, best_face)), then the
-// tests run in record order: results identical to the loop.
+// triangles.  Here the records of all four slots are requested together, unconditionally (a load under a wave-uniform
+// branch makes the compiler wait for it at the end of the branch); a lane whose leaf is shorter re-requests its last
+// record (same cache line, and a repeated test cannot change (best_t, best_rec)); the tests run in record order and
+// skip slots no lane of the wave fills: results identical to the loop.
 __device__ __forceinline__ void leaf_batch(const uint32_t* __restrict__ tris, uint32_t cur, f3 O, f3 D, float ray_tfar,
-                                           float& best_t, uint32_t& best_face, uint32_t& best_rec) {
+                                           float& best_t, uint32_t& best_rec) {
   const uint32_t first = cur & 0x0FFFFFFFu;
   const uint32_t last = first + ((cur >> 28) & 7u);
   const bool w2 = __any(last > first), w3 = __any(last > first + 1u), w4 = __any(last > first + 2u);
@@ -178,16 +186,30 @@ __device__ __forceinline__ void leaf_batch(const uint32_t* __restrict__ tris, ui
   const uint4* t2 = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(i2) * 4u;
   const uint4* t3 = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(i3) * 4u;
   const uint4 a0 = t0[0], b0 = t0[1], c0 = t0[2];
-  const uint32_t f0 = reinterpret_cast<const uint32_t*>(t0)[15];
-  uint4 a1 = a0, b1 = b0, c1 = c0, a2 = a0, b2 = b0, c2 = c0, a3 = a0, b3 = b0, c3 = c0;
-  uint32_t f1 = f0, f2 = f0, f3_ = f0;
-  if (w2) { a1 = t1[0]; b1 = t1[1]; c1 = t1[2]; f1 = reinterpret_cast<const uint32_t*>(t1)[15]; }
-  if (w3) { a2 = t2[0]; b2 = t2[1]; c2 = t2[2]; f2 = reinterpret_cast<const uint32_t*>(t2)[15]; }
-  if (w4) { a3 = t3[0]; b3 = t3[1]; c3 = t3[2]; f3_ = reinterpret_cast<const uint32_t*>(t3)[15]; }
-  tri_update(a0, b0, c0, f0, first, O, D, ray_tfar, best_t, best_face, best_rec);
-  if (w2) tri_update(a1, b1, c1, f1, i1, O, D, ray_tfar, best_t, best_face, best_rec);
-  if (w3) tri_update(a2, b2, c2, f2, i2, O, D, ray_tfar, best_t, best_face, best_rec);
-  if (w4) tri_update(a3, b3, c3, f3_, i3, O, D, ray_tfar, best_t, best_face, best_rec);
+  const uint4 a1 = t1[0], b1 = t1[1], c1 = t1[2];
+  const uint4 a2 = t2[0], b2 = t2[1], c2 = t2[2];
+  const uint4 a3 = t3[0], b3 = t3[1], c3 = t3[2];
+  tri_update(a0, b0, c0, first, tris, O, D, ray_tfar, best_t, best_rec);
+  if (w2) tri_update(a1, b1, c1, i1, tris, O, D, ray_tfar, best_t, best_rec);
+  if (w3) tri_update(a2, b2, c2, i2, tris, O, D, ray_tfar, best_t, best_rec);
+  if (w4) tri_update(a3, b3, c3, i3, tris, O, D, ray_tfar, best_t, best_rec);
+}
+
+// the loop form of a leaf visit (one record per iteration), same rules
+__device__ __forceinline__ void leaf_loop(const uint32_t* __restrict__ tris, uint32_t cur, f3 O, f3 D, float ray_tfar,
+                                          float& best_t, uint32_t& best_rec) {
+  const uint32_t first = cur & 0x0FFFFFFFu;
+  const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
+  for (uint32_t i = 0; i < cnt; ++i) {
+    const uint4* tp = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(first + i) * 4u;
+    const uint4 a = tp[0], b = tp[1], c = tp[2];
+    tri_update(a, b, c, first + i, tris, O, D, ray_tfar, best_t, best_rec);
+  }
+}
+
+// face id of a record (kInvalidFace for "no hit"): one dword of the record's last 16 B
+__device__ __forceinline__ uint32_t record_face(const uint32_t* __restrict__ tris, uint32_t rec) {
+  return (rec != kNone) ? tris[static_cast<size_t>(rec) * 16u + 15u] : kInvalidFace;
 }
 
 // node_keys on the quantised twin of the node (layout.h: Node4Q): FOUR loads instead of seven.  The plane distance
@@ -308,8 +330,7 @@ __device__ __forceinline__ void trace_packet(cu32p nodes, cu32p tris, f3 O, f3 D
     cur = static_cast<uint32_t>(__builtin_amdgcn_readlane(stk, sp));
   }
   h.t = best_t;
-  h.face = best_face;
-  h.rec = best_rec;
+  h.rec = (best_face != kInvalidFace) ? best_rec : kNone;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -360,8 +381,7 @@ __device__ __forceinline__ void trace_lane(const uint32_t* __restrict__ nodes, c
     else { --sp; cur = lds_stack[sp * lds_stride]; }
   }
   h.t = best_t;
-  h.face = best_face;
-  h.rec = best_rec;
+  h.rec = (best_face != kInvalidFace) ? best_rec : kNone;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -373,13 +393,13 @@ __device__ __forceinline__ void trace_lane(const uint32_t* __restrict__ nodes, c
 // LDS entries (16 KB per block) catch almost every push.
 // ---------------------------------------------------------------------------------------------
 // kQuant: `nodes` points to the quantised Node4Q twins (four loads per node visit instead of seven)
-template <int kLdsEntries, bool kQuant = false>  // stack entries kept in LDS ([entry][lane]); the rest (up to 64 total) in scratch
+template <int kLdsEntries, bool kQuant = false, bool kLeafBatch = false>  // stack entries kept in LDS ([entry][lane]); the rest (up to 64 total) in scratch
 __device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris,
                                               f3 O, f3 D, float ray_tfar, uint32_t* __restrict__ lds_stack,
                                               uint32_t lds_stride, RayHit& h) {
   const RaySlab rs = make_ray_slab(O, D);
   float best_t = ray_tfar;
-  uint32_t best_face = kInvalidFace, best_rec = 0;
+  uint32_t best_rec = kNone;
   constexpr uint32_t kDone = 0x7FFFFFFFu;
   uint32_t priv[(kLdsEntries < 64) ? (64 - kLdsEntries) : 1];
   uint32_t sp = 0;
@@ -405,34 +425,170 @@ __device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes
     }
     // phase 2: this lane's leaf (if any)
     if (cur != kDone) {
-      const uint32_t first = cur & 0x0FFFFFFFu;
-      const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
-      for (uint32_t i = 0; i < cnt; ++i) {
-        const uint4* tp = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(first + i) * 4u;
-        const uint4 a = tp[0], b = tp[1], c = tp[2], d = tp[3];
-        const f3 v0 = mk3(asf(a.x), asf(a.y), asf(a.z));
-        const f3 e1 = mk3(asf(a.w), asf(b.x), asf(b.y));
-        const f3 e2 = mk3(asf(b.z), asf(b.w), asf(c.x));
-        const f3 Ng = mk3(asf(c.y), asf(c.z), asf(c.w));
-        const uint32_t face = d.w;
-        float Tt, aden;
-        const bool ok = tri_accept(v0, e1, e2, Ng, O, D, Tt, aden);
-        if (ok) {
-          const float t = Tt / aden;
-          const bool acc = (Tt > 0.0f) && (t <= ray_tfar);
-          const bool closer = acc && ((t < best_t) || ((t == best_t) && (face < best_face)));
-          best_t = closer ? t : best_t;
-          best_face = closer ? face : best_face;
-          best_rec = closer ? (first + i) : best_rec;
-        }
-      }
+      if (kLeafBatch) leaf_batch(tris, cur, O, D, ray_tfar, best_t, best_rec);
+      else leaf_loop(tris, cur, O, D, ray_tfar, best_t, best_rec);
       RMCL_POP()
     }
   }
 #undef RMCL_PUSH
 #undef RMCL_POP
   h.t = best_t;
-  h.face = best_face;
+  h.rec = best_rec;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-lane while-while traversal, BRANCH-FREE node step (the form every one-lane-per-ray kernel now uses).
+// In vivo a node step of trace_lane_ww costs ~1300 cycles on a chip full of C2 waves (tools/wave_timeline.py) and ~880 for
+// a lone wave (tools/probe_find.py: ~430 waiting for the node + ~450 of issue) -- and the ISSUE half was mostly control:
+// every conditional push is a v_cmp + s_and_saveexec + branch + (LDS-or-scratch test, another saveexec pair) + a 32-bit
+// multiply for `sp * stride`; the "nothing hit: pop" arm is another nest.  Here
+//   * the stack row stride is the compile-time block size (shift-add addressing, no v_mul_lo_u32),
+//   * the three deferred children are stored UNCONDITIONALLY at rows sp, sp', sp'' with sp advancing only past real hits
+//     (the children are sorted, misses last, so a miss is overwritten by the next store or lands above the top),
+//   * row 0 holds the sentinel kDone and the current top of the stack is fetched speculatively with the node, so
+//     "no child hit -> pop" is two selects; an empty stack ends the ray without a test,
+//   * node data is addressed as SGPR base + 32-bit lane offset (one v_lshl_add_u32 per load instead of 64-bit adds).
+// Rows >= kRows live in private scratch as before; a wave whose lanes might touch them in this step (wave-uniform
+// test) takes the general path.  Same visits, same arithmetic, same results as trace_lane_ww.
+// ---------------------------------------------------------------------------------------------
+// slab tests + keys of the four children from the seven 16-B groups of a node (near / far plane groups per axis + refs)
+__device__ __forceinline__ void node_keys_from(uint4 qnx, uint4 qfx, uint4 qny, uint4 qfy, uint4 qnz, uint4 qfz, uint4 qch,
+                                               const RaySlab& rs, float best_t, uint32_t (&key)[4], uint32_t (&ref)[4]) {
+  const f2 ix = {rs.inv.x, rs.inv.x}, iy = {rs.inv.y, rs.inv.y}, iz = {rs.inv.z, rs.inv.z};
+  const f2 nx = {rs.noi.x, rs.noi.x}, ny = {rs.noi.y, rs.noi.y}, nz = {rs.noi.z, rs.noi.z};
+  const f2 nx01 = __builtin_elementwise_fma(f2{asf(qnx.x), asf(qnx.y)}, ix, nx), nx23 = __builtin_elementwise_fma(f2{asf(qnx.z), asf(qnx.w)}, ix, nx);
+  const f2 fx01 = __builtin_elementwise_fma(f2{asf(qfx.x), asf(qfx.y)}, ix, nx), fx23 = __builtin_elementwise_fma(f2{asf(qfx.z), asf(qfx.w)}, ix, nx);
+  const f2 ny01 = __builtin_elementwise_fma(f2{asf(qny.x), asf(qny.y)}, iy, ny), ny23 = __builtin_elementwise_fma(f2{asf(qny.z), asf(qny.w)}, iy, ny);
+  const f2 fy01 = __builtin_elementwise_fma(f2{asf(qfy.x), asf(qfy.y)}, iy, ny), fy23 = __builtin_elementwise_fma(f2{asf(qfy.z), asf(qfy.w)}, iy, ny);
+  const f2 nz01 = __builtin_elementwise_fma(f2{asf(qnz.x), asf(qnz.y)}, iz, nz), nz23 = __builtin_elementwise_fma(f2{asf(qnz.z), asf(qnz.w)}, iz, nz);
+  const f2 fz01 = __builtin_elementwise_fma(f2{asf(qfz.x), asf(qfz.y)}, iz, nz), fz23 = __builtin_elementwise_fma(f2{asf(qfz.z), asf(qfz.w)}, iz, nz);
+  const float tnx[4] = {nx01.x, nx01.y, nx23.x, nx23.y}, tfx[4] = {fx01.x, fx01.y, fx23.x, fx23.y};
+  const float tny[4] = {ny01.x, ny01.y, ny23.x, ny23.y}, tfy[4] = {fy01.x, fy01.y, fy23.x, fy23.y};
+  const float tnz[4] = {nz01.x, nz01.y, nz23.x, nz23.y}, tfz[4] = {fz01.x, fz01.y, fz23.x, fz23.y};
+  ref[0] = qch.x; ref[1] = qch.y; ref[2] = qch.z; ref[3] = qch.w;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float tn = fmaxf(fmaxf(fmaxf(tnx[c], tny[c]), tnz[c]), 0.0f);
+    const float tf = fminf(fminf(fminf(tfx[c], tfy[c]), tfz[c]), best_t);
+    key[c] = (tn <= tf) ? __float_as_uint(tn) : kNone;
+  }
+}
+
+__device__ __forceinline__ void node_keys_off(const uint32_t* __restrict__ nodes, uint32_t byte_off, const RaySlab& rs, float best_t,
+                                              uint32_t (&key)[4], uint32_t (&ref)[4]) {
+  // uniform base + zero-extended 32-bit offsets (map_create bounds the node array below 4 GB)
+  const char* nb = reinterpret_cast<const char*>(nodes);
+  const uint4 qnx = *reinterpret_cast<const uint4*>(nb + (byte_off + rs.onx)), qfx = *reinterpret_cast<const uint4*>(nb + (byte_off + rs.ofx));
+  const uint4 qny = *reinterpret_cast<const uint4*>(nb + (byte_off + rs.ony)), qfy = *reinterpret_cast<const uint4*>(nb + (byte_off + rs.ofy));
+  const uint4 qnz = *reinterpret_cast<const uint4*>(nb + (byte_off + rs.onz)), qfz = *reinterpret_cast<const uint4*>(nb + (byte_off + rs.ofz));
+  const uint4 qch = *reinterpret_cast<const uint4*>(nb + (byte_off + 96u));
+  node_keys_from(qnx, qfx, qny, qfy, qnz, qfz, qch, rs, best_t, key, ref);
+}
+
+// WAVE-UNIFORM node (north_star: "wavefront ballot for packet traversal"): ~60 % of the node steps of a C2 scan are taken by
+// a wave whose active lanes all stand on the SAME node (the top of the tree, tools/probe_find.py).  A single scan is
+// bound by the vector memory pipeline -- 7 x 16 B x 64 lanes = 7 KB through the 64 B/clk texture path per wave and
+// step, 8 waves per CU -- so such a step fetches the node ONCE with scalar loads (scalar cache, not the vector path) into
+// SGPRs and the lanes read the planes as scalar operands.  When the wave's rays also share the sign octant of their
+// direction (every tile that does not straddle a coordinate plane) the near / far plane groups are selected by scalar
+// address arithmetic exactly like the per-lane offsets, so the arithmetic -- and therefore keys, order and results --
+// is identical to the vector path.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) u32x4* cu32x4p;
+
+__device__ __forceinline__ uint4 sload4(const uint32_t* __restrict__ base, uint32_t byte_off) {
+  const u32x4 v = *reinterpret_cast<cu32x4p>(reinterpret_cast<const __attribute__((address_space(4))) char*>((cu32p)(base)) + byte_off);
+  return uint4{v.x, v.y, v.z, v.w};
+}
+
+// octant offsets of the wave (uniform): same values as RaySlab's per-lane ones
+struct WaveOctant {
+  uint32_t onx, ofx, ony, ofy, onz, ofz;
+};
+
+__device__ __forceinline__ void node_keys_uniform(const uint32_t* __restrict__ nodes, uint32_t cur_uniform, const WaveOctant& wo,
+                                                  const RaySlab& rs, float best_t, uint32_t (&key)[4], uint32_t (&ref)[4]) {
+  const uint32_t b = cur_uniform << 7;
+  const uint4 qnx = sload4(nodes, b + wo.onx), qfx = sload4(nodes, b + wo.ofx);
+  const uint4 qny = sload4(nodes, b + wo.ony), qfy = sload4(nodes, b + wo.ofy);
+  const uint4 qnz = sload4(nodes, b + wo.onz), qfz = sload4(nodes, b + wo.ofz);
+  const uint4 qch = sload4(nodes, b + 96u);
+  node_keys_from(qnx, qfx, qny, qfy, qnz, qfz, qch, rs, best_t, key, ref);
+}
+
+constexpr uint32_t kBfStride = 256u;  // stack row stride in dwords = threads per block of every kernel that calls trace_lane_bf
+
+// kRows: stack rows in LDS per lane INCLUDING the sentinel row 0 (row r of this lane at lds_col[r * 256]); deeper entries
+// (up to 64 in total, the builder's bound) in scratch
+template <int kRows, bool kQuant = false, bool kLeafBatch = false, bool kUniform = false>
+__device__ __forceinline__ void trace_lane_bf(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris, f3 O, f3 D,
+                                              float ray_tfar, uint32_t* __restrict__ lds_col, RayHit& h) {
+  const RaySlab rs = make_ray_slab(O, D);
+  // do all rays of the wave share the sign octant of their direction?  (lanes without a ray do not vote)
+  WaveOctant wo = {0u, 0u, 0u, 0u, 0u, 0u};
+  bool uni_oct = false;
+  if (kUniform && !kQuant) {
+    const bool live = ray_tfar >= 0.0f;
+    const uint32_t oct = (rs.inv.x < 0.0f ? 1u : 0u) | (rs.inv.y < 0.0f ? 2u : 0u) | (rs.inv.z < 0.0f ? 4u : 0u);
+    const uint64_t m_live = __ballot(live);
+    if (m_live != 0) {
+      const uint32_t o0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(oct), __builtin_ctzll(m_live)));
+      uni_oct = __ballot(live && oct != o0) == 0;
+      wo.onx = (o0 & 1u) ? 16u : 0u;  wo.ofx = 16u - wo.onx;
+      wo.ony = (o0 & 2u) ? 48u : 32u; wo.ofy = 80u - wo.ony;
+      wo.onz = (o0 & 4u) ? 80u : 64u; wo.ofz = 144u - wo.onz;
+    }
+  }
+  float best_t = ray_tfar;
+  uint32_t best_rec = kNone;
+  constexpr uint32_t kDone = 0x7FFFFFFFu;
+  uint32_t priv[(kRows < 65) ? (65 - kRows) : 1];
+  lds_col[0] = kDone;  // sentinel
+  uint32_t sp = 1;     // first free row
+  uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
+  // general row access (rare path)
+#define RMCL_ROW_ST(r, v) { if ((r) < static_cast<uint32_t>(kRows)) lds_col[(r) * kBfStride] = (v); else priv[(r) - kRows] = (v); }
+#define RMCL_ROW_LD(r) (((r) < static_cast<uint32_t>(kRows)) ? lds_col[(r) * kBfStride] : priv[(r) - kRows])
+  while (__any(cur != kDone)) {
+    // phase 1: inner nodes (cur < kDone <=> inner node: leaf references have bit 31 set)
+    while (cur < kDone) {
+      uint32_t key[4], ref[4];
+      if (!__any(sp + 3u > static_cast<uint32_t>(kRows))) {
+        // ---- fast path: every row this step can touch is in LDS (wave-uniform) ----
+        const uint32_t top = lds_col[(sp - 1u) * kBfStride];
+        const uint32_t c0 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(cur)));
+        if (kUniform && !kQuant && uni_oct && !__any(cur != c0)) node_keys_uniform(nodes, c0, wo, rs, best_t, key, ref);
+        else if (kQuant) node_keys_q(nodes, cur, rs, best_t, key, ref);
+        else node_keys_off(nodes, cur << 7, rs, best_t, key, ref);
+        RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
+        lds_col[sp * kBfStride] = ref[3]; sp += (key[3] != kNone) ? 1u : 0u;
+        lds_col[sp * kBfStride] = ref[2]; sp += (key[2] != kNone) ? 1u : 0u;
+        lds_col[sp * kBfStride] = ref[1]; sp += (key[1] != kNone) ? 1u : 0u;
+        const bool any = key[0] != kNone;
+        cur = any ? ref[0] : top;
+        sp = any ? sp : (sp - 1u);
+      } else {
+        if (kQuant) node_keys_q(nodes, cur, rs, best_t, key, ref);
+        else node_keys_off(nodes, cur << 7, rs, best_t, key, ref);
+        RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
+        if (key[3] != kNone) { RMCL_ROW_ST(sp, ref[3]) ++sp; }
+        if (key[2] != kNone) { RMCL_ROW_ST(sp, ref[2]) ++sp; }
+        if (key[1] != kNone) { RMCL_ROW_ST(sp, ref[1]) ++sp; }
+        if (key[0] != kNone) cur = ref[0];
+        else { --sp; cur = RMCL_ROW_LD(sp); }
+      }
+    }
+    // phase 2: this lane's leaf (if any)
+    if (cur != kDone) {
+      if (kLeafBatch) leaf_batch(tris, cur, O, D, ray_tfar, best_t, best_rec);
+      else leaf_loop(tris, cur, O, D, ray_tfar, best_t, best_rec);
+      --sp;
+      cur = RMCL_ROW_LD(sp);
+    }
+  }
+#undef RMCL_ROW_ST
+#undef RMCL_ROW_LD
+  h.t = best_t;
   h.rec = best_rec;
 }
 
@@ -549,8 +705,7 @@ __device__ __forceinline__ void trace_quad(const uint32_t* __restrict__ nodes, c
     }
   }
   h.t = best_t;
-  h.face = best_face;
-  h.rec = best_rec;
+  h.rec = (best_face != kInvalidFace) ? best_rec : kNone;
 }
 
 // trace_lane_ww whose LAST rays are finished by quads.  A single scan ends when its slowest ray ends, and that ray sits
@@ -570,7 +725,7 @@ __device__ __forceinline__ void trace_lane_ww_tail(const uint32_t* __restrict__ 
                                                    RayHit& h, const uint32_t* lds_top = nullptr) {
   const RaySlab rs = make_ray_slab(O, D);
   float best_t = ray_tfar;
-  uint32_t best_face = kInvalidFace, best_rec = 0;
+  uint32_t best_rec = kNone;
   constexpr uint32_t kDone = 0x7FFFFFFFu;
   uint32_t priv[(kLdsEntries < 64) ? (64 - kLdsEntries) : 1];
   uint32_t sp = 0;
@@ -590,7 +745,9 @@ __device__ __forceinline__ void trace_lane_ww_tail(const uint32_t* __restrict__ 
         uint32_t* x = xfer_wave + j * kTailXferDwords;
         x[0] = __float_as_uint(O.x); x[1] = __float_as_uint(O.y); x[2] = __float_as_uint(O.z);
         x[3] = __float_as_uint(D.x); x[4] = __float_as_uint(D.y); x[5] = __float_as_uint(D.z);
-        x[6] = __float_as_uint(ray_tfar); x[7] = __float_as_uint(best_t); x[8] = best_face; x[9] = best_rec;
+        x[6] = __float_as_uint(ray_tfar); x[7] = __float_as_uint(best_t);
+        x[8] = record_face(tris, best_rec);  // the quad traversal carries (t, face id) pairs
+        x[9] = best_rec;
         x[10] = cur; x[11] = sp;
         // the stack, bottom to top, into rows 1..sp of column (wave*16 + j) of the quad-layout region
         uint32_t* col = qstack + (wave * kTailRays + j);
@@ -611,12 +768,12 @@ __device__ __forceinline__ void trace_lane_ww_tail(const uint32_t* __restrict__ 
       trace_quad<true>(cnodes, tris, Oq, Dq, tfq, c, wave * kTailRays + q, qstack, hq, &rsm);
       if (have && c == 0u) {
         uint32_t* y = xfer_wave + q * kTailXferDwords;
-        y[7] = __float_as_uint(hq.t); y[8] = hq.face; y[9] = hq.rec;
+        y[7] = __float_as_uint(hq.t); y[9] = hq.rec;
       }
       __builtin_amdgcn_wave_barrier();
       if (mine) {
         const uint32_t* y = xfer_wave + j * kTailXferDwords;
-        best_t = asf(y[7]); best_face = y[8]; best_rec = y[9];
+        best_t = asf(y[7]); best_rec = y[9];
       }
       break;
     }
@@ -632,41 +789,111 @@ __device__ __forceinline__ void trace_lane_ww_tail(const uint32_t* __restrict__ 
       else RMCL_POP()
     }
     // phase 2: this lane's leaf (if any)
-    if (kLeafBatch) {
-      if (cur != kDone) {
-        leaf_batch(tris, cur, O, D, ray_tfar, best_t, best_face, best_rec);
-        RMCL_POP()
-      }
-    } else
     if (cur != kDone) {
-      const uint32_t first = cur & 0x0FFFFFFFu;
-      const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
-      for (uint32_t i = 0; i < cnt; ++i) {
-        const uint4* tp = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(first + i) * 4u;
-        const uint4 a = tp[0], b = tp[1], c = tp[2], d = tp[3];
-        const f3 v0 = mk3(asf(a.x), asf(a.y), asf(a.z));
-        const f3 e1 = mk3(asf(a.w), asf(b.x), asf(b.y));
-        const f3 e2 = mk3(asf(b.z), asf(b.w), asf(c.x));
-        const f3 Ng = mk3(asf(c.y), asf(c.z), asf(c.w));
-        const uint32_t face = d.w;
-        float Tt, aden;
-        const bool ok = tri_accept(v0, e1, e2, Ng, O, D, Tt, aden);
-        if (ok) {
-          const float t = Tt / aden;
-          const bool acc = (Tt > 0.0f) && (t <= ray_tfar);
-          const bool closer = acc && ((t < best_t) || ((t == best_t) && (face < best_face)));
-          best_t = closer ? t : best_t;
-          best_face = closer ? face : best_face;
-          best_rec = closer ? (first + i) : best_rec;
-        }
-      }
+      if (kLeafBatch) leaf_batch(tris, cur, O, D, ray_tfar, best_t, best_rec);
+      else leaf_loop(tris, cur, O, D, ray_tfar, best_t, best_rec);
       RMCL_POP()
     }
   }
 #undef RMCL_PUSH
 #undef RMCL_POP
   h.t = best_t;
-  h.face = best_face;
+  h.rec = best_rec;
+}
+
+// trace_lane_bf whose LAST rays are finished by quads (see trace_lane_ww_tail): branch-free node steps and one-round-trip
+// leaves while more than kTailRays rays of the wave are walking, then each remaining ray gets four lanes.
+// LDS: lane stacks (kRows x 256) | quad-tail stacks (64 columns x kQuadStackEntries rows) | hand-over slots.
+template <int kRows, bool kLeafBatch>
+__device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ cnodes,
+                                                   const uint32_t* __restrict__ tris, f3 O, f3 D, float ray_tfar,
+                                                   uint32_t* __restrict__ lds_col, uint32_t* __restrict__ qstack,
+                                                   uint32_t* __restrict__ xfer_wave, RayHit& h) {
+  const RaySlab rs = make_ray_slab(O, D);
+  float best_t = ray_tfar;
+  uint32_t best_rec = kNone;
+  constexpr uint32_t kDone = 0x7FFFFFFFu;
+  uint32_t priv[(kRows < 65) ? (65 - kRows) : 1];
+  lds_col[0] = kDone;
+  uint32_t sp = 1;
+  uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#define RMCL_ROW_ST(r, v) { if ((r) < static_cast<uint32_t>(kRows)) lds_col[(r) * kBfStride] = (v); else priv[(r) - kRows] = (v); }
+#define RMCL_ROW_LD(r) (((r) < static_cast<uint32_t>(kRows)) ? lds_col[(r) * kBfStride] : priv[(r) - kRows])
+  for (;;) {
+    const uint64_t m_act = __ballot(cur != kDone);
+    if (m_act == 0) break;
+    const uint32_t na = static_cast<uint32_t>(__popcll(m_act));
+    if (na <= kTailRays) {
+      // ---- hand the remaining rays to quads ----
+      const bool mine = cur != kDone;
+      const uint32_t j = static_cast<uint32_t>(__popcll(m_act & ((1ull << lane) - 1ull)));
+      if (mine) {
+        uint32_t* x = xfer_wave + j * kTailXferDwords;
+        x[0] = __float_as_uint(O.x); x[1] = __float_as_uint(O.y); x[2] = __float_as_uint(O.z);
+        x[3] = __float_as_uint(D.x); x[4] = __float_as_uint(D.y); x[5] = __float_as_uint(D.z);
+        x[6] = __float_as_uint(ray_tfar); x[7] = __float_as_uint(best_t);
+        x[8] = record_face(tris, best_rec);  // the quad traversal carries (t, face id) pairs
+        x[9] = best_rec;
+        x[10] = cur; x[11] = sp - 1u;        // rows 1..sp-1 hold this ray's pending entries
+        uint32_t* col = qstack + (wave * kTailRays + j);
+        for (uint32_t e = 1; e < sp; ++e) col[e * 64u] = RMCL_ROW_LD(e);
+      }
+      __builtin_amdgcn_wave_barrier();  // the hand-over slots and stack columns are read by OTHER lanes of this wave
+      const uint32_t q = lane >> 2, c = lane & 3u;
+      const bool have = q < na;
+      const uint32_t* x = xfer_wave + (have ? q : 0u) * kTailXferDwords;
+      const f3 Oq = mk3(asf(x[0]), asf(x[1]), asf(x[2])), Dq = mk3(asf(x[3]), asf(x[4]), asf(x[5]));
+      QuadResume rsm;
+      rsm.cur = x[10]; rsm.n_stack = x[11]; rsm.best_t = asf(x[7]); rsm.best_face = x[8]; rsm.best_rec = x[9];
+      const float tfq = have ? asf(x[6]) : -1.0f;
+      RayHit hq;
+      trace_quad<true>(cnodes, tris, Oq, Dq, tfq, c, wave * kTailRays + q, qstack, hq, &rsm);
+      if (have && c == 0u) {
+        uint32_t* y = xfer_wave + q * kTailXferDwords;
+        y[7] = __float_as_uint(hq.t); y[9] = hq.rec;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (mine) {
+        const uint32_t* y = xfer_wave + j * kTailXferDwords;
+        best_t = asf(y[7]); best_rec = y[9];
+      }
+      break;
+    }
+    // phase 1: inner nodes
+    while (cur < kDone) {
+      uint32_t key[4], ref[4];
+      if (!__any(sp + 3u > static_cast<uint32_t>(kRows))) {
+        const uint32_t top = lds_col[(sp - 1u) * kBfStride];
+        node_keys_off(nodes, cur << 7, rs, best_t, key, ref);
+        RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
+        lds_col[sp * kBfStride] = ref[3]; sp += (key[3] != kNone) ? 1u : 0u;
+        lds_col[sp * kBfStride] = ref[2]; sp += (key[2] != kNone) ? 1u : 0u;
+        lds_col[sp * kBfStride] = ref[1]; sp += (key[1] != kNone) ? 1u : 0u;
+        const bool any = key[0] != kNone;
+        cur = any ? ref[0] : top;
+        sp = any ? sp : (sp - 1u);
+      } else {
+        node_keys_off(nodes, cur << 7, rs, best_t, key, ref);
+        RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
+        if (key[3] != kNone) { RMCL_ROW_ST(sp, ref[3]) ++sp; }
+        if (key[2] != kNone) { RMCL_ROW_ST(sp, ref[2]) ++sp; }
+        if (key[1] != kNone) { RMCL_ROW_ST(sp, ref[1]) ++sp; }
+        if (key[0] != kNone) cur = ref[0];
+        else { --sp; cur = RMCL_ROW_LD(sp); }
+      }
+    }
+    // phase 2: this lane's leaf (if any)
+    if (cur != kDone) {
+      if (kLeafBatch) leaf_batch(tris, cur, O, D, ray_tfar, best_t, best_rec);
+      else leaf_loop(tris, cur, O, D, ray_tfar, best_t, best_rec);
+      --sp;
+      cur = RMCL_ROW_LD(sp);
+    }
+  }
+#undef RMCL_ROW_ST
+#undef RMCL_ROW_LD
+  h.t = best_t;
   h.rec = best_rec;
 }
 
@@ -934,6 +1161,7 @@ __device__ __forceinline__ f3 pinhole_direction(float fx, float fy, float cx, fl
 // full BVH4), 8 adds the one-round-trip leaf, 9 / 10 both
 constexpr int find_top_nodes(int trav) { return (trav == 6 || trav == 9) ? 85 : ((trav == 7 || trav == 10) ? 341 : 0); }
 constexpr bool find_leaf_batch(int trav) { return trav >= 8 && trav <= 10; }
+constexpr int kFindBfRows = 24;  // LDS stack rows per lane (sentinel included) of the branch-free lane traversal in k_find
 constexpr uint32_t kFindTailLdsDwords = 16u * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords;
 
 template <uint32_t kModel, int kTrav>
@@ -943,6 +1171,13 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   constexpr int kTop = find_top_nodes(kTrav);
   const uint32_t lane = kQuad ? (threadIdx.x >> 2) : (threadIdx.x & 63u), wave = threadIdx.x >> 6;
   const uint32_t sub = threadIdx.x & 3u;  // quad mode: child slot / triangle slot / output role of this lane
+  uint32_t clk_begin = 0, clk_real = 0;
+  if (p.wave_clock != nullptr) {  // diagnostics (tools/wave_timeline.py)
+    uint64_t t, r;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "=s"(r) : : "memory");
+    clk_begin = static_cast<uint32_t>(t);
+    clk_real = static_cast<uint32_t>(r);
+  }
   if constexpr (kTop > 0) {
     // the block's copy of the top of the tree: coalesced 16-B pieces, all requested before the first LDS write
     uint4* dst = reinterpret_cast<uint4*>(lds_dyn + kFindTailLdsDwords);
@@ -1007,14 +1242,28 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   const bool finite = (dir_m.x == dir_m.x) && (dir_m.y == dir_m.y) && (dir_m.z == dir_m.z);
   const float ray_tfar = (valid && finite) ? p.tfar : -1.0f;
 
+  uint32_t clk_trace0 = 0, clk_trace1 = 0;
+  if (p.wave_clock != nullptr) {
+    uint64_t t;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    clk_trace0 = static_cast<uint32_t>(t);
+  }
   RayHit h;
   if (kPacket) {
     trace_packet((cu32p)(p.nodes), (cu32p)(p.tris), org_m, dir_m, ray_tfar, lane, h);
   } else if (kQuad) {
     trace_quad(p.cnodes, p.tris, org_m, dir_m, ray_tfar, sub, lane, lds_dyn, h);
   } else {
-    if (kTrav == 4) trace_lane_ww<16, true>(p.qnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
-    else if (kTrav >= 5)
+    if (kTrav == 4) trace_lane_bf<kFindBfRows, true>(p.qnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
+    else if (kTrav == 1) trace_lane_bf<kFindBfRows>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
+    else if (kTrav == 12) trace_lane_bf<kFindBfRows, false, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
+    else if (kTrav == 16 || kTrav == 17)
+      trace_lane_bf_tail<kFindBfRows, kTrav == 17>(p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x,
+                                                   lds_dyn + kFindBfRows * 256u,
+                                                   lds_dyn + kFindBfRows * 256u + kQuadStackEntries * 64u + (threadIdx.x >> 6) * (kTailRays * kTailXferDwords), h);
+    else if (kTrav == 13) trace_lane_bf<kFindBfRows, false, false, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
+    else if (kTrav == 14) trace_lane_bf<kFindBfRows, false, true, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
+    else if (kTrav >= 5 && kTrav <= 10)
       trace_lane_ww_tail<16, kTop, find_leaf_batch(kTrav)>(
           p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, lds_dyn + 16u * 256u,
           lds_dyn + 16u * 256u + kQuadStackEntries * 64u + (threadIdx.x >> 6) * (kTailRays * kTailXferDwords), h,
@@ -1022,9 +1271,14 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
     else trace_lane_ww<16>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
   }
 
-  if (!valid) return;
+  if (p.wave_clock != nullptr) {
+    uint64_t t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    clk_trace1 = static_cast<uint32_t>(t);
+  }
+  if (valid) {
   const size_t g = static_cast<size_t>(pose) * p.W * p.H + loc;
-  const bool found = (h.face != kInvalidFace);
+  const bool found = (h.rec != kNone);
   // quad mode: the four lanes of a ray hold the same result and share the stores (0: hits/ranges/face ids, 1: points,
   // 2: normals)
   const bool w0 = !kQuad || sub == 0u, w1 = !kQuad || sub == 1u, w2 = !kQuad || sub == 2u;
@@ -1036,13 +1290,16 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
       if (kModel == kModelO1Dn || kModel == kModelOnDn) pt = add3(pt, orig_s);
       p.points[3 * g] = pt.x; p.points[3 * g + 1] = pt.y; p.points[3 * g + 2] = pt.z;
     }
-    if (p.normals && w2) {
+    // the record's last 16 B: unit normal + the ORIGINAL face id
+    if ((p.normals && w2) || (p.face_ids && w0)) {
       const uint4 nrec = reinterpret_cast<const uint4*>(p.tris)[static_cast<size_t>(h.rec) * 4u + 3u];
-      f3 n = qrot(Tms.R, mk3(asf(nrec.x), asf(nrec.y), asf(nrec.z)));
-      if (dot_plain(dir_s, n) > 0.0f) n = neg3(n);  // flip towards the sensor
-      p.normals[3 * g] = n.x; p.normals[3 * g + 1] = n.y; p.normals[3 * g + 2] = n.z;
+      if (p.normals && w2) {
+        f3 n = qrot(Tms.R, mk3(asf(nrec.x), asf(nrec.y), asf(nrec.z)));
+        if (dot_plain(dir_s, n) > 0.0f) n = neg3(n);  // flip towards the sensor
+        p.normals[3 * g] = n.x; p.normals[3 * g + 1] = n.y; p.normals[3 * g + 2] = n.z;
+      }
+      if (p.face_ids && w0) p.face_ids[g] = nrec.w;
     }
-    if (p.face_ids && w0) p.face_ids[g] = h.face;
   } else {
     const float qn = __uint_as_float(0x7FC00000u);
     if (p.hits && w0) p.hits[g] = 0;
@@ -1050,6 +1307,20 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
     if (p.points && w1) { p.points[3 * g] = qn; p.points[3 * g + 1] = qn; p.points[3 * g + 2] = qn; }
     if (p.normals && w2) { p.normals[3 * g] = qn; p.normals[3 * g + 1] = qn; p.normals[3 * g + 2] = qn; }
     if (p.face_ids && w0) p.face_ids[g] = kInvalidFace;
+  }
+  }  // valid
+  if (p.wave_clock != nullptr) {
+    uint64_t t;
+    uint64_t t2;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2) : : "memory");   // stores issued
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");  // ... and completed
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if ((threadIdx.x & 63u) == 0u) {
+      uint32_t* w = p.wave_clock + 8u * ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + wave);
+      w[0] = clk_begin; w[1] = static_cast<uint32_t>(t); w[2] = clk_real; w[3] = (tile & 0xFFFFFFu) | (xcc << 24);
+      w[4] = clk_trace0; w[5] = clk_trace1; w[6] = static_cast<uint32_t>(t2); w[7] = 0u;
+    }
   }
 }
 
@@ -1116,7 +1387,7 @@ __global__ void __launch_bounds__(256) k_find_probe(const FindParams p, uint32_t
 
   const RaySlab rs = make_ray_slab(O, D);
   float best_t = ray_tfar;
-  uint32_t best_face = kInvalidFace, best_rec = 0;
+  uint32_t best_rec = kNone;
   constexpr uint32_t kDone = 0x7FFFFFFFu;
   uint32_t* lds_stack = lds_dyn + threadIdx.x;
   constexpr uint32_t lds_stride = 256u;
@@ -1126,6 +1397,9 @@ __global__ void __launch_bounds__(256) k_find_probe(const FindParams p, uint32_t
   uint32_t step = 0;
 #define RMCL_PUSH(v) { if (sp < 16u) lds_stack[sp * lds_stride] = (v); else priv[sp - 16u] = (v); ++sp; }
 #define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; if (sp < 16u) cur = lds_stack[sp * lds_stride]; else cur = priv[sp - 16u]; } }
+  // calibration: two stamps with nothing between them = the cost every interval below includes once
+  RMCL_PROBE(9u, true, __ballot(true), false, 0u)
+  RMCL_PROBE(10u, true, __ballot(true), false, 0u)
   while (__any(cur != kDone)) {
     for (;;) {
       const bool inner = (cur != kDone) && !(cur & kLeafBit);
@@ -1134,16 +1408,16 @@ __global__ void __launch_bounds__(256) k_find_probe(const FindParams p, uint32_t
       const uint32_t c0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cur), __builtin_ctzll(m)));
       const bool uni = __ballot(inner && cur != c0) == 0;
       RMCL_PROBE(1u, true, m, uni, step)
+      uint4 qnx = {0, 0, 0, 0}, qfx = qnx, qny = qnx, qfy = qnx, qnz = qnx, qfz = qnx, qch = qnx;
       if (inner) {
         const char* nb = node_address<kTop>(p.nodes, lds_dyn + 16u * 256u, cur);
-        const uint4 qnx = *reinterpret_cast<const uint4*>(nb + rs.onx), qfx = *reinterpret_cast<const uint4*>(nb + rs.ofx);
-        const uint4 qny = *reinterpret_cast<const uint4*>(nb + rs.ony), qfy = *reinterpret_cast<const uint4*>(nb + rs.ofy);
-        const uint4 qnz = *reinterpret_cast<const uint4*>(nb + rs.onz), qfz = *reinterpret_cast<const uint4*>(nb + rs.ofz);
-        const uint4 qch = *reinterpret_cast<const uint4*>(nb + 96);
-        // keep the loads above the stamp: the asm below has a memory clobber and waits for them
-        uint32_t sink = qnx.x ^ qfx.x ^ qny.x ^ qfy.x ^ qnz.x ^ qfz.x ^ qch.x;
-        asm volatile("" : "+v"(sink));
-        RMCL_PROBE(2u, true, m, uni, step)
+        qnx = *reinterpret_cast<const uint4*>(nb + rs.onx); qfx = *reinterpret_cast<const uint4*>(nb + rs.ofx);
+        qny = *reinterpret_cast<const uint4*>(nb + rs.ony); qfy = *reinterpret_cast<const uint4*>(nb + rs.ofy);
+        qnz = *reinterpret_cast<const uint4*>(nb + rs.onz); qfz = *reinterpret_cast<const uint4*>(nb + rs.ofz);
+        qch = *reinterpret_cast<const uint4*>(nb + 96);
+      }
+      RMCL_PROBE(2u, true, m, uni, step)   // the stamp drains vmcnt: node data arrived
+      if (inner) {
         const f2 ix = {rs.inv.x, rs.inv.x}, iy = {rs.inv.y, rs.inv.y}, iz = {rs.inv.z, rs.inv.z};
         const f2 nx = {rs.noi.x, rs.noi.x}, ny = {rs.noi.y, rs.noi.y}, nz = {rs.noi.z, rs.noi.z};
         const f2 nx01 = __builtin_elementwise_fma(f2{asf(qnx.x), asf(qnx.y)}, ix, nx), nx23 = __builtin_elementwise_fma(f2{asf(qnx.z), asf(qnx.w)}, ix, nx);
@@ -1179,7 +1453,7 @@ __global__ void __launch_bounds__(256) k_find_probe(const FindParams p, uint32_t
         if (kLeafBatch) {
           RMCL_PROBE(4u, true, m, false, step)
           if (leaf) {
-            leaf_batch(p.tris, cur, O, D, ray_tfar, best_t, best_face, best_rec);
+            leaf_batch(p.tris, cur, O, D, ray_tfar, best_t, best_rec);
             RMCL_POP()
           }
           RMCL_PROBE(6u, true, m, false, step)
@@ -1189,14 +1463,13 @@ __global__ void __launch_bounds__(256) k_find_probe(const FindParams p, uint32_t
           for (uint32_t i = 0; __any(i < cnt); ++i) {
             const uint64_t mi = __ballot(i < cnt);
             RMCL_PROBE(4u, true, mi, false, step)
+            uint4 a = {0, 0, 0, 0}, b = a, c = a;
             if (i < cnt) {
               const uint4* tp = reinterpret_cast<const uint4*>(p.tris) + static_cast<size_t>(first + i) * 4u;
-              const uint4 a = tp[0], b = tp[1], c = tp[2], d = tp[3];
-              uint32_t sink = a.x ^ b.x ^ c.x ^ d.x;
-              asm volatile("" : "+v"(sink));
-              RMCL_PROBE(5u, true, mi, false, step)
-              tri_update(a, b, c, d.w, first + i, O, D, ray_tfar, best_t, best_face, best_rec);
+              a = tp[0]; b = tp[1]; c = tp[2];
             }
+            RMCL_PROBE(5u, true, mi, false, step)
+            if (i < cnt) tri_update(a, b, c, first + i, p.tris, O, D, ray_tfar, best_t, best_rec);
             RMCL_PROBE(6u, true, mi, false, step)
           }
           if (leaf) RMCL_POP()
@@ -1210,7 +1483,7 @@ __global__ void __launch_bounds__(256) k_find_probe(const FindParams p, uint32_t
   RMCL_PROBE(7u, true, __ballot(true), false, step)
   if (valid) {
     const size_t g = loc;
-    const bool found = (best_face != kInvalidFace);
+    const bool found = (best_rec != kNone);
     if (found) {
       p.hits[g] = 1;
       p.ranges[g] = best_t;
@@ -1220,7 +1493,7 @@ __global__ void __launch_bounds__(256) k_find_probe(const FindParams p, uint32_t
       f3 n = qrot(Tms.R, mk3(asf(nrec.x), asf(nrec.y), asf(nrec.z)));
       if (dot_plain(dir_s, n) > 0.0f) n = neg3(n);
       p.normals[3 * g] = n.x; p.normals[3 * g + 1] = n.y; p.normals[3 * g + 2] = n.z;
-      p.face_ids[g] = best_face;
+      p.face_ids[g] = nrec.w;
     } else {
       const float qn = __uint_as_float(0x7FC00000u);
       p.hits[g] = 0;
@@ -1233,10 +1506,10 @@ __global__ void __launch_bounds__(256) k_find_probe(const FindParams p, uint32_t
   RMCL_PROBE(8u, true, __ballot(true), false, step)
 #undef RMCL_PROBE
   if (lane == 0u) {
-    log[0] = min(nlog, kProbeEntries);
     uint32_t xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    log[1] = xcc;
+    log[0] = min(nlog, kProbeEntries) | (xcc << 16);
+    log[1] = t_begin;   // absolute shader clock (low 32 bits) at wave start
   }
 }
 
@@ -1809,7 +2082,7 @@ __global__ void __launch_bounds__(256) k_pf_update(const PfParams p) {
     if (live) {
       // evaluate_rcc (PCDSensorUpdaterEmbree.cpp:18-86) with unit face normals (BeamEvaluateProgram.cu:104-113)
       const bool real_hit = (range >= p.range_min) && (range <= p.range_max);
-      const bool sim_hit = (h.face != kInvalidFace) && (h.t > p.range_min);
+      const bool sim_hit = (h.rec != kNone) && (h.t > p.range_min);
       float error;
       if (sim_hit) {
         if (real_hit) {
@@ -1881,7 +2154,7 @@ __global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
   f3 O = mk3(0.f, 0.f, 0.f), D = O;
   RaySlab rs = make_ray_slab(O, mk3(1.f, 1.f, 1.f));
   float range = 0.f, best_t = 0.f;
-  uint32_t best_face = kInvalidFace, best_rec = 0;
+  uint32_t best_rec = kNone;
   uint32_t priv[(kLdsEntries < 64) ? (64 - kLdsEntries) : 1];
   uint32_t sp = 0, cur = kDone;
 #define RMCL_PUSH(v) { if (kLdsEntries >= 64 || sp < kLdsEntries) lds_stack[sp * lds_stride] = (v); else priv[sp - kLdsEntries] = (v); ++sp; }
@@ -1897,7 +2170,7 @@ __global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
           // evaluate_rcc (PCDSensorUpdaterEmbree.cpp:18-86) with unit face normals (BeamEvaluateProgram.cu:104-113)
           const uint32_t pi = rr / p.n_beams, b = rr - pi * p.n_beams;
           const bool real_hit = (range >= p.range_min) && (range <= p.range_max);
-          const bool sim_hit = (best_face != kInvalidFace) && (best_t > p.range_min);
+          const bool sim_hit = (best_rec != kNone) && (best_t > p.range_min);
           float error;
           if (sim_hit) {
             if (real_hit) {
@@ -1939,8 +2212,7 @@ __global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
           range = bm[6];
           rs = make_ray_slab(O, D);
           best_t = __builtin_inff();
-          best_face = kInvalidFace;
-          best_rec = 0;
+          best_rec = kNone;
           sp = 0;
           has_ray = true;
           const bool finite = (D.x == D.x) && (D.y == D.y) && (D.z == D.z);
@@ -1971,29 +2243,9 @@ __global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
         else RMCL_POP()
       }
     }
-    // phase 2: this lane's leaf (if any)
+    // phase 2: this lane's leaf (if any); tfar = infinity
     if ((cur != kDone) && (cur & kLeafBit)) {
-      const uint32_t first = cur & 0x0FFFFFFFu;
-      const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
-      for (uint32_t i = 0; i < cnt; ++i) {
-        const uint4* tp = reinterpret_cast<const uint4*>(p.tris) + static_cast<size_t>(first + i) * 4u;
-        const uint4 a = tp[0], b = tp[1], c = tp[2], d = tp[3];
-        const f3 v0 = mk3(asf(a.x), asf(a.y), asf(a.z));
-        const f3 e1 = mk3(asf(a.w), asf(b.x), asf(b.y));
-        const f3 e2 = mk3(asf(b.z), asf(b.w), asf(c.x));
-        const f3 Ng = mk3(asf(c.y), asf(c.z), asf(c.w));
-        const uint32_t face = d.w;
-        float Tt, aden;
-        const bool ok = tri_accept(v0, e1, e2, Ng, O, D, Tt, aden);
-        if (ok) {
-          const float t = Tt / aden;
-          const bool acc = (Tt > 0.0f);  // tnear = 0 exclusive, tfar = infinity
-          const bool closer = acc && ((t < best_t) || ((t == best_t) && (face < best_face)));
-          best_t = closer ? t : best_t;
-          best_face = closer ? face : best_face;
-          best_rec = closer ? (first + i) : best_rec;
-        }
-      }
+      leaf_loop(p.tris, cur, O, D, __builtin_inff(), best_t, best_rec);
       RMCL_POP()
     }
   }
@@ -2037,7 +2289,7 @@ __global__ void __launch_bounds__(256) k_pf_motion(const uint32_t* __restrict__ 
     vec = mk3(vec.x / length, vec.y / length, vec.z / length);
     RayHit h;
     trace_lane_ww<16, true>(nodes, tris, pose_old.t, vec, (live && moving) ? length : -1.0f, lds_dyn + threadIdx.x, blockDim.x, h);
-    if (moving && h.face != kInvalidFace) { L.mean = 0.0f; L.sigma = 0.0f; L.n_meas = max_n_meas; }
+    if (moving && h.rec != kNone) { L.mean = 0.0f; L.sigma = 0.0f; L.n_meas = max_n_meas; }
   }
   if (live) {
     poses[i] = pose_new;
@@ -2197,7 +2449,7 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
   nblocks = (nblocks + 7u) & ~7u;  // the XCD remap in k_find needs gridDim.x % 8 == 0
   dim3 grid(nblocks, p.nposes, 1), block(256, 1, 1);
   // more than 64 KB of dynamic LDS per block must be granted once per kernel
-  static bool lds_granted[16][8] = {};
+  static bool lds_granted[32][8] = {};
 #define RMCL_FIND_ONE(KIND, TRAV, LDS)                                                                               \
   {                                                                                                                  \
     if ((LDS) > 65536u && !lds_granted[TRAV][KIND]) {                                                                \
@@ -2222,7 +2474,7 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
     const size_t lds = kQuadStackEntries * 64u * sizeof(uint32_t);
     RMCL_LAUNCH_FIND(2, lds)
   } else if (variant == 4) {  // one lane per ray on the 64-B quantised nodes
-    const size_t lds = 16u * 256u * sizeof(uint32_t);
+    const size_t lds = static_cast<size_t>(kFindBfRows) * 256u * sizeof(uint32_t);
     RMCL_LAUNCH_FIND(4, lds)
   } else if (variant >= 5 && variant <= 10) {  // one lane per ray, the last rays of every wave finished by quads
     const size_t lds = (kFindTailLdsDwords + static_cast<uint32_t>(find_top_nodes(variant)) * kNodeDwords) * sizeof(uint32_t);
@@ -2234,8 +2486,23 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
       case 9: RMCL_LAUNCH_FIND(9, lds) break;
       default: RMCL_LAUNCH_FIND(10, lds) break;
     }
-  } else {             // per-lane while-while traversal: 16 stack entries per lane in LDS, the rest in scratch
+  } else if (variant == 11) {  // A/B: the branchy while-while step (16 stack entries per lane in LDS, the rest in scratch)
     const size_t lds = 16u * 256u * sizeof(uint32_t);
+    RMCL_LAUNCH_FIND(11, lds)
+  } else if (variant == 12) {  // branch-free step + one-round-trip leaves
+    const size_t lds = static_cast<size_t>(kFindBfRows) * 256u * sizeof(uint32_t);
+    RMCL_LAUNCH_FIND(12, lds)
+  } else if (variant == 16 || variant == 17) {  // branch-free step (17: + one-round-trip leaves), tail of every wave finished by quads
+    const size_t lds = (static_cast<size_t>(kFindBfRows) * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords) * sizeof(uint32_t);
+    if (variant == 16) { RMCL_LAUNCH_FIND(16, lds) } else { RMCL_LAUNCH_FIND(17, lds) }
+  } else if (variant == 13) {  // branch-free step, wave-uniform nodes through the scalar cache
+    const size_t lds = static_cast<size_t>(kFindBfRows) * 256u * sizeof(uint32_t);
+    RMCL_LAUNCH_FIND(13, lds)
+  } else if (variant == 14) {  // 13 + one-round-trip leaves
+    const size_t lds = static_cast<size_t>(kFindBfRows) * 256u * sizeof(uint32_t);
+    RMCL_LAUNCH_FIND(14, lds)
+  } else {             // per-lane while-while traversal, branch-free node step
+    const size_t lds = static_cast<size_t>(kFindBfRows) * 256u * sizeof(uint32_t);
     RMCL_LAUNCH_FIND(1, lds)
   }
 #undef RMCL_LAUNCH_FIND

@@ -317,11 +317,26 @@ class CorrespondencesHIP:
     def set_variant(self, variant):
         _capi.check(_capi.lib().rmclhip_rcc_set_variant(self._h, int(variant)))
 
+    def set_traversal(self, kind):
+        """traversal kind 0..31 alone (kinds >= 16 travel in bit 13 of the variant word, see rmclhip.h)"""
+        self.set_variant((int(kind) & 15) | ((int(kind) >> 4) << 13))
+
     def find_variant(self, nposes=1):
         """the traversal the automatic rule (variant 15) launches for `nposes` scans of the current model"""
         v = C.c_int(0)
         _capi.check(_capi.lib().rmclhip_rcc_find_variant(self._h, int(nposes), C.byref(v)))
         return v.value
+
+    def debug_wave_clock(self, Tbm_est):
+        """diagnostics: uint32 [n_waves, 8] = {entry clock, exit clock, entry realtime (100 MHz), tile | xcc << 24, clock
+        before / after the traversal, clock at stores issued, 0}"""
+        T = np.ascontiguousarray(Tbm_est, dtype=TRANSFORM).reshape(1)
+        H, W = self._model_shape
+        buf = np.zeros((H * W + 8 * 64 * 64) * 8, np.uint32)
+        nw = C.c_uint32(0)
+        _capi.check(_capi.lib().rmclhip_debug_wave_clock(self._h, _ptr(T), _ptr(buf), buf.size, C.byref(nw)))
+        self._last_nposes = 1
+        return buf[: nw.value * 8].reshape(nw.value, 8)
 
     def debug_probe_find(self, Tbm_est, mode=0):
         """diagnostics: per-wave step timeline of one spherical scan -> uint32 array [n_tiles, 256, 2]"""

@@ -3,12 +3,16 @@ PCDSensorUpdaterHip through rmcl_amd.distributed.ShardedSensorUpdate / ShardedRe
 unsharded update bit for bit (the sharded classes had never executed on a GPU).
 World sizes 2 and 3 (ragged) run on CPU with gloo in tests/test_distributed_cpu.py; 8 GPUs are the driver's to launch."""
 import math
+import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -19,11 +23,23 @@ def _free_port():
     return p
 
 
-def test_rccl_world1_sharded_update_equals_unsharded(ra, ctx, meshes):
+def test_rccl_world1_sharded_update_equals_unsharded():
+    """runs in a fresh process: torch (which bundles its own HIP runtime) has to initialise the device BEFORE
+    librmclhip.so does -- the order bench.py uses -- and the pytest process has already created HIP contexts."""
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests")]))
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def _main():
     import torch
     import torch.distributed as dist
-    from rmcl_amd import distributed as D, synthetic as syn, types as T
     torch.cuda.set_device(0)
+    torch.cuda.init()
+    import rmcl_amd as ra
+    from rmcl_amd import distributed as D, synthetic as syn, types as T
+    ctx = ra.Context(0)
+    meshes = {"room30k": syn.noisy_room(30000)}.__getitem__
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
                             device_id=torch.device("cuda", 0))
     try:
@@ -58,5 +74,10 @@ def test_rccl_world1_sharded_update_equals_unsharded(ra, ctx, meshes):
         allp = D.allgather_records(rec, n)
         assert allp.shape == (n, 32) and allp.cpu().numpy().tobytes() == poses.tobytes()
         upd.close()
+        print("RCCL_WORLD1_OK", flush=True)
     finally:
         dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    _main()

@@ -33,7 +33,7 @@ def _poses(syn, T):
     ]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6, 8, 10])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6, 8, 10, 11, 12, 13, 14, 16, 17])
 def test_c1_cube_32x32(ra, orc, ctx, meshes, variant):
     """config C1: 32x32 scan, 972-triangle cube, every output attribute, 3 poses, Tsb != I."""
     from rmcl_amd import synthetic as syn, types as T
@@ -43,7 +43,7 @@ def test_c1_cube_32x32(ra, orc, ctx, meshes, variant):
     model = syn.model_c1()
     for Tsb in (T.identity(), syn.tsb_offset()):
         rcc = ra.RCCHipSpherical(hm)
-        rcc.set_variant(variant)
+        rcc.set_traversal(variant)
         rcc.setTsb(Tsb)
         rcc.setModel(model)
         for i, Tbm in enumerate(_poses(syn, T)):
@@ -73,7 +73,7 @@ def test_c1_matches_committed_golden(ra, ctx, meshes):
         _compare(gpu, ref, "golden pose %d" % i)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 7, 8, 9])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 7, 8, 9, 11, 12, 13, 14, 16, 17])
 def test_c2_sphere100k_full_size(ra, orc, ctx, meshes, variant):
     """config C2 at BASELINE.json's full size: 128x1024 rays, 100k triangles; oracle BVH on all rays,
     brute force on a sample, and the committed SHA-256 of the face-id array (G7)."""
@@ -83,7 +83,7 @@ def test_c2_sphere100k_full_size(ra, orc, ctx, meshes, variant):
     hm = ra.import_hip_map(ctx, v, f)
     model = syn.model_c2()
     rcc = ra.RCCHipSpherical(hm)
-    rcc.set_variant(variant)
+    rcc.set_traversal(variant)
     rcc.setTsb(T.identity())
     rcc.setModel(model)
     Tbm = syn.pose_c2_truth()
@@ -158,7 +158,7 @@ def test_misses_and_range_limit(ra, orc, ctx, meshes):
     assert np.isnan(gpu["points"][miss]).all() and np.isnan(gpu["normals"][miss]).all()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 9])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 9, 13, 14])
 def test_o1dn_model(ra, orc, ctx, meshes, variant):
     """RCCEmbreeO1Dn::find (RCCEmbree.cpp:89-99): one origin, N explicit directions, with NaN
     directions (invalid points of an organised cloud) which must come back as misses."""
@@ -177,7 +177,7 @@ def test_o1dn_model(ra, orc, ctx, meshes, variant):
     Tsb = syn.tsb_offset()
     Tbm = T.transform_from_rpy((-1.0, 0.7, 1.1), (0.02, 0.03, 1.9))
     rcc = ra.RCCHipO1Dn(hm)
-    rcc.set_variant(variant)
+    rcc.set_traversal(variant)
     rcc.setTsb(Tsb)
     rcc.setModel(W, H, 0.2, 40.0, orig, dirs)
     rcc.find(Tbm)
@@ -234,9 +234,9 @@ def test_c5_mesh_one_million_triangles(ra, orc, ctx):
     model = syn.model_c2()
     Tbm = syn.pose_c2_truth()
     ref = m.simulate_spherical(model, T.identity(), Tbm, bvh=True, nthreads=8)
-    for variant in (1, 0, 2, 4, 5, 10):
+    for variant in (1, 0, 2, 4, 5, 10, 12, 14):
         rcc = ra.RCCHipSpherical(hm)
-        rcc.set_variant(variant)
+        rcc.set_traversal(variant)
         rcc.setTsb(T.identity())
         rcc.setModel(model)
         rcc.find(Tbm)
@@ -259,7 +259,7 @@ def test_c5_mesh_one_million_triangles(ra, orc, ctx):
 ROOM_POSE_RPY = ((1.5, -2.0, 1.6), (0.02, -0.03, 0.4))   # the pose of tests/golden/make_golden.py:g7_digests
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6, 10, 15])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6, 10, 11, 12, 13, 14, 15, 16, 17])
 def test_c2_room100k_full_size(ra, orc, ctx, meshes, variant):
     """config C2's scan on a REALISTIC map (room-100k: occluders, vertex noise, open ceiling => misses): every
     traversal incl. the automatic one (15) vs the oracle on all 131 072 rays + the committed G7 digests
@@ -270,7 +270,7 @@ def test_c2_room100k_full_size(ra, orc, ctx, meshes, variant):
     hm = ra.import_hip_map(ctx, v, f)
     model = syn.model_c2()
     rcc = ra.RCCHipSpherical(hm)
-    rcc.set_variant(variant)
+    rcc.set_traversal(variant)
     rcc.setTsb(T.identity())
     rcc.setModel(model)
     Tbm = T.transform_from_rpy(*ROOM_POSE_RPY)
@@ -310,7 +310,7 @@ def test_o1dn_c2_size_single_pose(ra, orc, ctx, meshes, mesh, variant):
     Tsb = syn.tsb_offset()
     Tbm = syn.pose_c2_truth() if mesh == "sphere100k" else T.transform_from_rpy(*ROOM_POSE_RPY)
     rcc = ra.RCCHipO1Dn(hm)
-    rcc.set_variant(variant)
+    rcc.set_traversal(variant)
     rcc.setTsb(Tsb)
     rcc.setModel(W, H, float(model.range.min), float(model.range.max), orig, dirs)
     rcc.find(Tbm)
@@ -378,7 +378,7 @@ def test_automatic_variant_in_every_size_bracket(ra, orc, ctx, meshes, mesh):
         rcc.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6, 13, 14])
 def test_sensor_origin_on_a_face(ra, orc, ctx, meshes, variant):
     """Embree's depth test is strict on the near side (absDen * tnear < T with tnear = 0): a ray that starts exactly ON a
     wall triangle does not hit that triangle -- the sensor sees the room, not t = 0 everywhere."""
@@ -389,7 +389,7 @@ def test_sensor_origin_on_a_face(ra, orc, ctx, meshes, variant):
     model = syn.model_c1()
     Tbm = T.transform_from_rpy((5.0, 0.3, 0.2), (0.0, 0.0, 0.0))     # x = +5 is the wall plane of the side-10 cube
     rcc = ra.RCCHipSpherical(hm)
-    rcc.set_variant(variant)
+    rcc.set_traversal(variant)
     rcc.setTsb(T.identity())
     rcc.setModel(model)
     rcc.find(Tbm)

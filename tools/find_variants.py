@@ -30,7 +30,7 @@ for mesh in ("sphere", "room"):
             rcc = ra.RCCHipSpherical(hm)
             rcc.setTsb(T.identity())
             rcc.setModel(m)
-            rcc.set_variant(kind)
+            rcc.set_variant((kind & 15) | ((kind >> 4) << 13))
             ts = sorted(rcc.time_find(base, 30) for _ in range(7))
             row.append(ts[3] * 1e3)
             rcc.close()
