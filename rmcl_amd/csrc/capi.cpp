@@ -174,6 +174,16 @@ struct rmclhip_rcc {
   DevBuf<uint8_t> d_raw;           // staged PointCloud2 bytes (set_input_pointcloud2)
   DevBuf<xform> d_Tbm, d_Tsm, d_Tms, d_Tdelta;
   DevBuf<cstats> d_bstats;
+  // mixed launch (traversal 18): slow tiles of the previous scans run with four lanes per ray in helper blocks
+  DevBuf<uint8_t> d_tile_flags;    // per group of four tiles: 0 none, 1..4 delegated tile
+  DevBuf<uint32_t> d_tile_cost;    // per tile: most node visits of any of its rays (max over the calibration window)
+  std::vector<uint32_t> h_tile_cost;
+  std::vector<uint8_t> h_tile_flags;
+  uint32_t tiles_ngroups = 0, tiles_n = 0;
+  uint32_t finds_since_calib = 0;
+  bool tiles_fresh = true;         // no calibration since the model / variant changed
+  bool capturing = false;          // inside hipStreamBeginCapture: no synchronisation allowed
+  float mixed_frac = 0.25f;        // share of the groups whose slowest tile is delegated
   int variant = 15;       // traversal kind: 0 wave-packet, 1 one lane per ray (while-while), 2 four lanes per ray
                           // (quad-cooperative), 15 automatic: quad while the launch is bound by the slowest ray's
                           // chain of dependent fetches (few rays in flight), one lane per ray once the chip is full
@@ -409,6 +419,7 @@ void rmclhip_rcc_destroy(rmclhip_rcc* r) {
   r->d_partials.release(); r->d_Tbm.release(); r->d_Tsm.release(); r->d_Tms.release(); r->d_Tdelta.release();
   r->d_bstats.release();
   r->d_raw.release();
+  r->d_tile_flags.release(); r->d_tile_cost.release();
   DBG_STEP(hipPeekAtLastError());
   if (r->h_stats) DBG_STEP(hipHostFree(r->h_stats));
   if (r->h_state) DBG_STEP(hipHostFree(r->h_state));
@@ -443,6 +454,8 @@ rmclhip_status rmclhip_rcc_set_model_spherical(rmclhip_rcc* r, const rmclhip_sph
   const uint32_t H = m->phi.size, W = m->theta.size;
   r->kind = kModelSpherical;
   r->graph_dirty = true;
+  r->tiles_fresh = true;
+  r->finds_since_calib = 0;
   r->W = W; r->H = H;
   r->range = m->range;
   r->orig = mk3(0.f, 0.f, 0.f);
@@ -473,6 +486,8 @@ rmclhip_status rmclhip_rcc_set_model_o1dn(rmclhip_rcc* r, uint32_t width, uint32
   HIPCHK(hipStreamSynchronize(r->stream));
   r->kind = kModelO1Dn;
   r->graph_dirty = true;
+  r->tiles_fresh = true;
+  r->finds_since_calib = 0;
   r->W = width; r->H = height;
   r->range = range;
   r->orig = mk3(orig.x, orig.y, orig.z);
@@ -493,6 +508,8 @@ rmclhip_status rmclhip_rcc_set_model_pinhole(rmclhip_rcc* r, uint32_t width, uin
   HIPCHK(hipStreamSynchronize(r->stream));
   r->kind = kModelPinhole;
   r->graph_dirty = true;
+  r->tiles_fresh = true;
+  r->finds_since_calib = 0;
   r->W = width; r->H = height;
   r->range = range;
   r->orig = mk3(0.f, 0.f, 0.f);
@@ -508,6 +525,8 @@ rmclhip_status rmclhip_rcc_set_model_ondn(rmclhip_rcc* r, uint32_t width, uint32
   HIPCHK(hipStreamSynchronize(r->stream));
   r->kind = kModelOnDn;
   r->graph_dirty = true;
+  r->tiles_fresh = true;
+  r->finds_since_calib = 0;
   r->W = width; r->H = height;
   r->range = range;
   r->orig = mk3(0.f, 0.f, 0.f);
@@ -606,6 +625,8 @@ rmclhip_status rmclhip_rcc_set_input_pointcloud2(rmclhip_rcc* r, const uint8_t* 
   HIPCHK(hipStreamSynchronize(r->stream));
   r->kind = kModelO1Dn;
   r->graph_dirty = true;
+  r->tiles_fresh = true;
+  r->finds_since_calib = 0;
   r->W = ow; r->H = oh;
   r->range = range;
   r->orig = mk3(0.f, 0.f, 0.f);
@@ -658,7 +679,9 @@ static int find_variant(const rmclhip_rcc* r, uint32_t nposes) {
   if (r->variant != 15) return r->variant;
   const uint64_t rays = static_cast<uint64_t>(r->W) * r->H * nposes;
   if (rays <= 65536u) return 2;   // bound by the slowest ray's fetch chain: four lanes per ray
-  if (rays <= 262144u) return 5;  // one scan fills the chip once: one lane per ray, the tail of every wave finished by quads
+  if (rays <= 131072u) return 17;  // one scan fills the chip once: one lane per ray (branch-free step, one-round-trip leaves,
+                                  // quad-finished tails).  (The mixed launch, kind 18, measured slower here: A/B only.)
+  if (rays <= 262144u) return 5;  // larger: occupancy matters more than the leaf round trips (kind 17 needs 124 VGPRs)
   return 4;                       // batches are bound by L1 accesses: one lane per ray on the 64-B quantised nodes
 }
 
@@ -683,6 +706,69 @@ static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
   p.face_ids = r->d_face_ids.p;
 }
 
+// ---- mixed launch bookkeeping -------------------------------------------------------------------------
+// Which tiles are slow is a property of (pose, map) that changes slowly from scan to scan (MICP re-localises from nearly
+// the same pose), so it is LEARNED: every launch records per tile the largest number of node visits of any of its rays (a
+// measure that does not depend on how the tile was traced); every kCalibEvery launches the host reads the 8 KB back, picks
+// in each group of four tiles the slowest one, and delegates it to the group's quad helper block if it belongs to the
+// slowest `mixed_frac` of the groups.  Flags only ever change here, between launches, so the lane block and the helper of
+// a group always agree; a stale flag costs time, never correctness (results are identical for every assignment).
+constexpr uint32_t kCalibEvery = 256;
+
+static rmclhip_status tiles_prepare(rmclhip_rcc* r, const FindParams& p) {
+  const uint32_t ntiles = p.tiles_x * p.tiles_y;
+  const uint32_t ngroups = (((ntiles + 3u) / 4u) + 7u) & ~7u;
+  if (r->tiles_n == ntiles && r->tiles_ngroups == ngroups && r->d_tile_flags.p && !r->tiles_fresh) return RMCLHIP_OK;
+  if (r->tiles_n != ntiles || r->tiles_ngroups != ngroups || !r->d_tile_flags.p) {
+    HIPCHK(r->d_tile_flags.reserve(ngroups));
+    HIPCHK(r->d_tile_cost.reserve(static_cast<size_t>(ngroups) * 4u));
+    r->h_tile_cost.assign(static_cast<size_t>(ngroups) * 4u, 0u);
+    r->h_tile_flags.assign(ngroups, 0u);
+    r->tiles_n = ntiles;
+    r->tiles_ngroups = ngroups;
+    r->tiles_fresh = true;
+  }
+  if (r->tiles_fresh && r->finds_since_calib == 0) {
+    HIPCHK(hipMemsetAsync(r->d_tile_flags.p, 0, ngroups, r->stream));
+    HIPCHK(hipMemsetAsync(r->d_tile_cost.p, 0, static_cast<size_t>(ngroups) * 4u * sizeof(uint32_t), r->stream));
+  }
+  return RMCLHIP_OK;
+}
+
+static rmclhip_status tiles_calibrate(rmclhip_rcc* r) {
+  const uint32_t ng = r->tiles_ngroups;
+  HIPCHK(hipMemcpyAsync(r->h_tile_cost.data(), r->d_tile_cost.p, static_cast<size_t>(ng) * 4u * sizeof(uint32_t),
+                        hipMemcpyDeviceToHost, r->stream));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  std::vector<uint32_t> gmax(ng);
+  for (uint32_t g = 0; g < ng; ++g) {
+    uint32_t best = 0, arg = 0;
+    for (uint32_t k = 0; k < 4; ++k)
+      if (r->h_tile_cost[4u * g + k] > best) { best = r->h_tile_cost[4u * g + k]; arg = k; }
+    gmax[g] = best;
+    r->h_tile_flags[g] = static_cast<uint8_t>(best ? arg + 1u : 0u);
+  }
+  std::vector<uint32_t> sorted(gmax);
+  std::sort(sorted.begin(), sorted.end());
+  const uint32_t live = static_cast<uint32_t>(sorted.end() - std::upper_bound(sorted.begin(), sorted.end(), 0u));
+  uint32_t ndel = static_cast<uint32_t>(r->mixed_frac * static_cast<float>(live));
+  uint32_t thr = 0xFFFFFFFFu;
+  if (ndel > 0 && live > 0) thr = sorted[sorted.size() - ndel];
+  if (thr == 0u) thr = 1u;
+  // ties at the threshold: delegate at most ~ndel groups (first come)
+  uint32_t taken = 0;
+  for (uint32_t g = 0; g < ng; ++g) {
+    if (gmax[g] >= thr && taken < ndel + ndel / 4u + 1u) ++taken;
+    else r->h_tile_flags[g] = 0u;
+  }
+  HIPCHK(hipMemcpyAsync(r->d_tile_flags.p, r->h_tile_flags.data(), ng, hipMemcpyHostToDevice, r->stream));
+  HIPCHK(hipMemsetAsync(r->d_tile_cost.p, 0, static_cast<size_t>(ng) * 4u * sizeof(uint32_t), r->stream));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  r->finds_since_calib = 0;
+  r->tiles_fresh = false;
+  return RMCLHIP_OK;
+}
+
 static rmclhip_status find_enqueue(rmclhip_rcc* r, const xform& Tbm) {
   const size_t n = static_cast<size_t>(r->W) * r->H;
   r->n_model = static_cast<uint32_t>(n);
@@ -692,7 +778,19 @@ static rmclhip_status find_enqueue(rmclhip_rcc* r, const xform& Tbm) {
   fill_find_params(r, p, 1);
   p.Tsm = xmul(Tbm, r->Tsb);
   p.Tms = xinv(p.Tsm);
-  HIPCHK(launch_find(p, r->kind, find_variant(r, p.nposes), r->stream));
+  const int variant = find_variant(r, p.nposes);
+  if (variant == 18) {
+    // the first launches after a model change run undelegated and are measured; afterwards the flags are refreshed
+    // every kCalibEvery launches (one 8 KB read-back + one stream synchronisation, amortised)
+    if (!r->capturing && ((r->tiles_fresh && r->finds_since_calib >= 2u) || r->finds_since_calib >= kCalibEvery))
+      if (rmclhip_status st = tiles_calibrate(r)) return st;
+    if (!r->capturing)
+      if (rmclhip_status st = tiles_prepare(r, p)) return st;
+    p.tile_flags = r->d_tile_flags.p;
+    p.tile_cost = r->d_tile_cost.p;
+    ++r->finds_since_calib;
+  }
+  HIPCHK(launch_find(p, r->kind, variant, r->stream));
   return RMCLHIP_OK;
 }
 
@@ -891,6 +989,18 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
         r->tickets_cap = 1;
       }
     }
+    if (find_variant(r, 1) == 18) {
+      // mixed launch inside the (static) graph: the flag / cost buffers must exist before the capture; the flags are
+      // refreshed here, outside the graph, every kCalibEvery corrections
+      FindParams pt;
+      fill_find_params(r, pt, 1);
+      if ((r->tiles_fresh && r->finds_since_calib >= 2u) || r->finds_since_calib >= kCalibEvery)
+        if (rmclhip_status st = tiles_calibrate(r)) return st;
+      const uint8_t* before = r->d_tile_flags.p;
+      if (rmclhip_status st = tiles_prepare(r, pt)) return st;
+      if (before != r->d_tile_flags.p) r->graph_dirty = true;   // (re)allocated: the captured pointers are stale
+      ++r->finds_since_calib;
+    }
     r->h_call->Tsm = xmul(xmul(Tom, Tbo), r->Tsb);
     r->h_call->Tms = xinv(r->h_call->Tsm);
     r->h_call->Tsb = r->Tsb;
@@ -902,7 +1012,9 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
       fill_find_params(r, p, 1);
       p.Tsm_arr = &r->d_call->Tsm;
       p.Tms_arr = &r->d_call->Tms;
-      HIPCHK(launch_find(p, r->kind, find_variant(r, p.nposes), r->stream));
+      const int fvariant = find_variant(r, p.nposes);
+      if (fvariant == 18) { p.tile_flags = r->d_tile_flags.p; p.tile_cost = r->d_tile_cost.p; }
+      HIPCHK(launch_find(p, r->kind, fvariant, r->stream));
       const bool iter_form = r->loop_blocks == 0 && !r->fused_tail && n_iter > 0;
       if (!iter_form) HIPCHK(launch_micp_init(r->d_state, r->d_loop_barrier, r->stream));  // k_micp_iter initialises itself
       MicpState* final_state = r->d_state;
@@ -951,7 +1063,9 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
         if (r->micp_graph) { (void)hipGraphDestroy(r->micp_graph); r->micp_graph = nullptr; }
         HIPCHK(hipStreamSynchronize(r->stream));
         HIPCHK(hipStreamBeginCapture(r->stream, hipStreamCaptureModeThreadLocal));
+        r->capturing = true;
         const rmclhip_status cst = enqueue_chain();
+        r->capturing = false;
         hipGraph_t g = nullptr;
         const hipError_t ce = hipStreamEndCapture(r->stream, &g);
         if (cst != RMCLHIP_OK) { if (g) (void)hipGraphDestroy(g); return cst; }
@@ -1086,7 +1200,7 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
   if (!r || variant < 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: bad arguments");
   // bit 13 adds 16 to the traversal kind (kinds 16..31)
   const int kind = (variant & 0xF) | (((variant >> 13) & 1) << 4), tile = (variant >> 4) & 0xF;
-  if (kind == 3 || kind > 17 || tile > 7 || (variant >> 14) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
+  if (kind == 3 || kind > 18 || tile > 7 || (variant >> 14) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
   r->variant = kind;
   r->tile_override = tile;
   r->fused_tail = ((variant >> 8) & 1) != 0;
@@ -1097,6 +1211,8 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
     r->loop_blocks = kLoopBlocks[(variant >> 10) & 7];
   }
   r->graph_dirty = true;
+  r->tiles_fresh = true;
+  r->finds_since_calib = 0;
   return RMCLHIP_OK;
 }
 
@@ -1153,6 +1269,14 @@ rmclhip_status rmclhip_debug_wave_clock(rmclhip_rcc* r, const rmclhip_transform*
   const uint32_t ntiles = p.tiles_x * p.tiles_y;
   uint32_t nblocks = (variant == 2) ? ntiles : (ntiles + 3u) / 4u;
   nblocks = (nblocks + 7u) & ~7u;
+  if (variant == 18) {
+    for (int i = 0; i < 4; ++i)
+      if (rmclhip_status st = find_enqueue(r, to_x(Tbm_est))) return st;   // learn the slow tiles first
+    if (rmclhip_status st = tiles_calibrate(r)) return st;
+    p.tile_flags = r->d_tile_flags.p;
+    p.tile_cost = r->d_tile_cost.p;
+    nblocks *= 2u;
+  }
   const size_t dwords = static_cast<size_t>(nblocks) * 4u * 8u;
   if (n_waves_out) *n_waves_out = nblocks * 4u;
   if (cap_dwords < dwords) return fail(RMCLHIP_ERR_INVALID, "debug_wave_clock: buffer too small");
@@ -1184,7 +1308,8 @@ static rmclhip_status find_batch_enqueue(rmclhip_rcc* r, const rmclhip_transform
   fill_find_params(r, p, nposes);
   p.Tsm_arr = r->d_Tsm.p;
   p.Tms_arr = r->d_Tms.p;
-  HIPCHK(launch_find(p, r->kind, find_variant(r, p.nposes), r->stream));
+  const int bvariant = find_variant(r, p.nposes);
+  HIPCHK(launch_find(p, r->kind, bvariant == 18 ? 17 : bvariant, r->stream));   // the mixed launch is a single-scan form
   return RMCLHIP_OK;
 }
 
@@ -1211,7 +1336,8 @@ rmclhip_status rmclhip_rcc_time_find_batch(rmclhip_rcc* r, const rmclhip_transfo
   p.Tsm_arr = r->d_Tsm.p;
   p.Tms_arr = r->d_Tms.p;
   HIPCHK(hipEventRecord(r->ev0, r->stream));
-  for (uint32_t i = 0; i < iters; ++i) HIPCHK(launch_find(p, r->kind, find_variant(r, p.nposes), r->stream));
+  const int bvariant = (find_variant(r, p.nposes) == 18) ? 17 : find_variant(r, p.nposes);
+  for (uint32_t i = 0; i < iters; ++i) HIPCHK(launch_find(p, r->kind, bvariant, r->stream));
   HIPCHK(hipEventRecord(r->ev1, r->stream));
   HIPCHK(hipStreamSynchronize(r->stream));
   float total = 0.f;

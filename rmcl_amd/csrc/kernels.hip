@@ -207,6 +207,18 @@ __device__ __forceinline__ void leaf_loop(const uint32_t* __restrict__ tris, uin
   }
 }
 
+// maximum over the wave of a per-lane integer < 64, by six ballots (no cross-lane data movement)
+__device__ __forceinline__ uint32_t wave_max_6bit(uint32_t v) {
+  v = min(v, 63u);
+  uint32_t m = 0;
+#pragma unroll
+  for (int b = 5; b >= 0; --b) {
+    const uint32_t cand = m | (1u << b);
+    if (__any(v >= cand)) m = cand;
+  }
+  return m;
+}
+
 // face id of a record (kInvalidFace for "no hit"): one dword of the record's last 16 B
 __device__ __forceinline__ uint32_t record_face(const uint32_t* __restrict__ tris, uint32_t rec) {
   return (rec != kNone) ? tris[static_cast<size_t>(rec) * 16u + 15u] : kInvalidFace;
@@ -522,7 +534,8 @@ constexpr uint32_t kBfStride = 256u;  // stack row stride in dwords = threads pe
 // (up to 64 in total, the builder's bound) in scratch
 template <int kRows, bool kQuant = false, bool kLeafBatch = false, bool kUniform = false>
 __device__ __forceinline__ void trace_lane_bf(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris, f3 O, f3 D,
-                                              float ray_tfar, uint32_t* __restrict__ lds_col, RayHit& h) {
+                                              float ray_tfar, uint32_t* __restrict__ lds_col, RayHit& h, uint32_t* visits = nullptr) {
+  uint32_t nvis = 0;  // node visits of this ray
   const RaySlab rs = make_ray_slab(O, D);
   // do all rays of the wave share the sign octant of their direction?  (lanes without a ray do not vote)
   WaveOctant wo = {0u, 0u, 0u, 0u, 0u, 0u};
@@ -553,6 +566,7 @@ __device__ __forceinline__ void trace_lane_bf(const uint32_t* __restrict__ nodes
     // phase 1: inner nodes (cur < kDone <=> inner node: leaf references have bit 31 set)
     while (cur < kDone) {
       uint32_t key[4], ref[4];
+      ++nvis;
       if (!__any(sp + 3u > static_cast<uint32_t>(kRows))) {
         // ---- fast path: every row this step can touch is in LDS (wave-uniform) ----
         const uint32_t top = lds_col[(sp - 1u) * kBfStride];
@@ -590,6 +604,7 @@ __device__ __forceinline__ void trace_lane_bf(const uint32_t* __restrict__ nodes
 #undef RMCL_ROW_LD
   h.t = best_t;
   h.rec = best_rec;
+  if (visits) *visits = nvis;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -618,7 +633,8 @@ struct QuadResume {
 template <bool kResume = false>
 __device__ __forceinline__ void trace_quad(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris, f3 O,
                                            f3 D, float ray_tfar, uint32_t c, uint32_t ray, uint32_t* __restrict__ lds,
-                                           RayHit& h, const QuadResume* resume = nullptr) {
+                                           RayHit& h, const QuadResume* resume = nullptr, uint32_t* visits = nullptr) {
+  uint32_t nvis = 0;  // node visits of this ray (the mixed launch's cost measure)
   const RaySlab rs = make_ray_slab(O, D);
   float best_t = kResume ? resume->best_t : ray_tfar;
   uint32_t best_face = kResume ? resume->best_face : kInvalidFace, best_rec = kResume ? resume->best_rec : 0u;
@@ -640,6 +656,7 @@ __device__ __forceinline__ void trace_quad(const uint32_t* __restrict__ nodes, c
       const uint4* nd = reinterpret_cast<const uint4*>(nbase + (cur << 7) + coff);
       const uint4 q0 = nd[0], q1 = nd[1];  // lo.x lo.y lo.z hi.x | hi.y hi.z ref pad
       const uint32_t top = *reinterpret_cast<const uint32_t*>(sbase + (spb - 256u));
+      ++nvis;
       const float pnx = ngx ? asf(q0.w) : asf(q0.x), pfx = ngx ? asf(q0.x) : asf(q0.w);
       const float pny = ngy ? asf(q1.x) : asf(q0.y), pfy = ngy ? asf(q0.y) : asf(q1.x);
       const float pnz = ngz ? asf(q1.y) : asf(q0.z), pfz = ngz ? asf(q0.z) : asf(q1.y);
@@ -706,6 +723,7 @@ __device__ __forceinline__ void trace_quad(const uint32_t* __restrict__ nodes, c
   }
   h.t = best_t;
   h.rec = (best_face != kInvalidFace) ? best_rec : kNone;
+  if (visits) *visits = nvis;
 }
 
 // trace_lane_ww whose LAST rays are finished by quads.  A single scan ends when its slowest ray ends, and that ray sits
@@ -808,10 +826,11 @@ template <int kRows, bool kLeafBatch>
 __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ cnodes,
                                                    const uint32_t* __restrict__ tris, f3 O, f3 D, float ray_tfar,
                                                    uint32_t* __restrict__ lds_col, uint32_t* __restrict__ qstack,
-                                                   uint32_t* __restrict__ xfer_wave, RayHit& h) {
+                                                   uint32_t* __restrict__ xfer_wave, RayHit& h, uint32_t* visits = nullptr) {
   const RaySlab rs = make_ray_slab(O, D);
   float best_t = ray_tfar;
   uint32_t best_rec = kNone;
+  uint32_t nvis = 0;  // node visits of this ray
   constexpr uint32_t kDone = 0x7FFFFFFFu;
   uint32_t priv[(kRows < 65) ? (65 - kRows) : 1];
   lds_col[0] = kDone;
@@ -848,21 +867,23 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
       rsm.cur = x[10]; rsm.n_stack = x[11]; rsm.best_t = asf(x[7]); rsm.best_face = x[8]; rsm.best_rec = x[9];
       const float tfq = have ? asf(x[6]) : -1.0f;
       RayHit hq;
-      trace_quad<true>(cnodes, tris, Oq, Dq, tfq, c, wave * kTailRays + q, qstack, hq, &rsm);
+      uint32_t qvis = 0;
+      trace_quad<true>(cnodes, tris, Oq, Dq, tfq, c, wave * kTailRays + q, qstack, hq, &rsm, &qvis);
       if (have && c == 0u) {
         uint32_t* y = xfer_wave + q * kTailXferDwords;
-        y[7] = __float_as_uint(hq.t); y[9] = hq.rec;
+        y[7] = __float_as_uint(hq.t); y[9] = hq.rec; y[10] = qvis;
       }
       __builtin_amdgcn_wave_barrier();
       if (mine) {
         const uint32_t* y = xfer_wave + j * kTailXferDwords;
-        best_t = asf(y[7]); best_rec = y[9];
+        best_t = asf(y[7]); best_rec = y[9]; nvis += y[10];
       }
       break;
     }
     // phase 1: inner nodes
     while (cur < kDone) {
       uint32_t key[4], ref[4];
+      ++nvis;
       if (!__any(sp + 3u > static_cast<uint32_t>(kRows))) {
         const uint32_t top = lds_col[(sp - 1u) * kBfStride];
         node_keys_off(nodes, cur << 7, rs, best_t, key, ref);
@@ -895,6 +916,7 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
 #undef RMCL_ROW_LD
   h.t = best_t;
   h.rec = best_rec;
+  if (visits) *visits = nvis;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1167,7 +1189,13 @@ constexpr uint32_t kFindTailLdsDwords = 16u * 256u + kQuadStackEntries * 64u + 4
 template <uint32_t kModel, int kTrav>
 __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   extern __shared__ uint32_t lds_dyn[];
-  constexpr bool kPacket = (kTrav == 0), kQuad = (kTrav == 2);
+  constexpr bool kPacket = (kTrav == 0), kMixed = (kTrav == 18);
+  // mixed launch (kTrav 18): the second half of the grid are lane blocks (4 tiles each), the first half their helpers: a
+  // helper runs the ONE tile its group's flag delegates (the slow tile of the previous scans) with four lanes per ray
+  // (helpers come FIRST in the grid: most of them exit at once and free their slot; placed last they would queue behind
+  // the lane blocks -- 45 KB of LDS admit three blocks per CU -- and start when the scan is almost over)
+  const bool helper = kMixed && (blockIdx.x < (gridDim.x >> 1));
+  const bool kQuad = (kTrav == 2) || helper;
   constexpr int kTop = find_top_nodes(kTrav);
   const uint32_t lane = kQuad ? (threadIdx.x >> 2) : (threadIdx.x & 63u), wave = threadIdx.x >> 6;
   const uint32_t sub = threadIdx.x & 3u;  // quad mode: child slot / triangle slot / output role of this lane
@@ -1199,9 +1227,22 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   }
   // XCD-aware remap: the dispatcher places block b on XCD b%8; give every XCD a contiguous range of
   // tiles so neighbouring tiles (which walk the same subtrees) share one L2.  gridDim.x % 8 == 0.
-  const uint32_t chunk = gridDim.x >> 3;
-  const uint32_t vb = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
-  const uint32_t tile = kQuad ? vb : (vb * 4u + wave);
+  const uint32_t nblk = kMixed ? (gridDim.x >> 1) : gridDim.x;
+  const uint32_t bidx = (kMixed && !helper) ? (blockIdx.x - nblk) : blockIdx.x;
+  const uint32_t chunk = nblk >> 3;
+  const uint32_t vb = (bidx & 7u) * chunk + (bidx >> 3);
+  uint32_t tile = ((kTrav == 2) ? vb : (vb * 4u + wave));
+  if (kMixed) {
+    // flag of the group: 0 = nobody delegated, k = tile (group * 4 + k - 1) runs in the helper.  The flags are written by
+    // the host between launches only (capi.cpp: calibrate_tiles), so lane block and helper always agree.
+    const uint32_t f = p.tile_flags[vb];
+    if (helper) {
+      if (f == 0u) return;
+      tile = vb * 4u + (f - 1u);
+    } else if (f == wave + 1u) {
+      return;
+    }
+  }
   const uint32_t ntiles = p.tiles_x * p.tiles_y;
   if (tile >= ntiles) return;
   const uint32_t pose = blockIdx.y;
@@ -1252,7 +1293,21 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   if (kPacket) {
     trace_packet((cu32p)(p.nodes), (cu32p)(p.tris), org_m, dir_m, ray_tfar, lane, h);
   } else if (kQuad) {
-    trace_quad(p.cnodes, p.tris, org_m, dir_m, ray_tfar, sub, lane, lds_dyn, h);
+    uint32_t vis = 0;
+    trace_quad(p.cnodes, p.tris, org_m, dir_m, ray_tfar, sub, lane, lds_dyn, h, nullptr, &vis);
+    if (kMixed && p.tile_cost != nullptr) {
+      // cost of the tile = most node visits of any of its rays (independent of how the tile was traced)
+      const uint32_t m = wave_max_6bit(vis);
+      if ((threadIdx.x & 63u) == 0u) atomicMax(p.tile_cost + tile, m);
+    }
+  } else if (kMixed) {
+    uint32_t vis = 0;
+    // (no quad-finished tail here: its 18 KB of LDS per block are what decides whether lane blocks AND helpers are co-resident)
+    trace_lane_bf<kFindBfRows, false, true, false>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h, &vis);
+    if (p.tile_cost != nullptr) {
+      const uint32_t m = wave_max_6bit(vis);
+      if ((threadIdx.x & 63u) == 0u) p.tile_cost[tile] = m;
+    }
   } else {
     if (kTrav == 4) trace_lane_bf<kFindBfRows, true>(p.qnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
     else if (kTrav == 1) trace_lane_bf<kFindBfRows>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
@@ -2492,6 +2547,11 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
   } else if (variant == 12) {  // branch-free step + one-round-trip leaves
     const size_t lds = static_cast<size_t>(kFindBfRows) * 256u * sizeof(uint32_t);
     RMCL_LAUNCH_FIND(12, lds)
+  } else if (variant == 18) {  // mixed launch: lane blocks + one quad helper block per group of four tiles
+    const size_t lds = static_cast<size_t>(kFindBfRows) * 256u * sizeof(uint32_t);   // >= the helper's quad stack (17.6 KB)
+    if (p.tile_flags == nullptr || p.nposes != 1u) return hipErrorInvalidValue;
+    grid = dim3(2u * nblocks, 1, 1);
+    RMCL_LAUNCH_FIND(18, lds)
   } else if (variant == 16 || variant == 17) {  // branch-free step (17: + one-round-trip leaves), tail of every wave finished by quads
     const size_t lds = (static_cast<size_t>(kFindBfRows) * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords) * sizeof(uint32_t);
     if (variant == 16) { RMCL_LAUNCH_FIND(16, lds) } else { RMCL_LAUNCH_FIND(17, lds) }

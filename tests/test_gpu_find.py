@@ -33,7 +33,7 @@ def _poses(syn, T):
     ]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6, 8, 10, 11, 12, 13, 14, 16, 17])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6, 8, 10, 11, 12, 13, 14, 16, 17, 18])
 def test_c1_cube_32x32(ra, orc, ctx, meshes, variant):
     """config C1: 32x32 scan, 972-triangle cube, every output attribute, 3 poses, Tsb != I."""
     from rmcl_amd import synthetic as syn, types as T
@@ -73,7 +73,7 @@ def test_c1_matches_committed_golden(ra, ctx, meshes):
         _compare(gpu, ref, "golden pose %d" % i)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 7, 8, 9, 11, 12, 13, 14, 16, 17])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 7, 8, 9, 11, 12, 13, 14, 16, 17, 18])
 def test_c2_sphere100k_full_size(ra, orc, ctx, meshes, variant):
     """config C2 at BASELINE.json's full size: 128x1024 rays, 100k triangles; oracle BVH on all rays,
     brute force on a sample, and the committed SHA-256 of the face-id array (G7)."""
@@ -259,7 +259,7 @@ def test_c5_mesh_one_million_triangles(ra, orc, ctx):
 ROOM_POSE_RPY = ((1.5, -2.0, 1.6), (0.02, -0.03, 0.4))   # the pose of tests/golden/make_golden.py:g7_digests
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6, 10, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6, 10, 11, 12, 13, 14, 15, 16, 17, 18])
 def test_c2_room100k_full_size(ra, orc, ctx, meshes, variant):
     """config C2's scan on a REALISTIC map (room-100k: occluders, vertex noise, open ceiling => misses): every
     traversal incl. the automatic one (15) vs the oracle on all 131 072 rays + the committed G7 digests
@@ -421,3 +421,36 @@ def test_context_may_be_destroyed_before_its_children(ra, orc, meshes):
     upd.close()
     rcc.close()
     hm.release()
+
+
+@pytest.mark.parametrize("mesh", ["sphere100k", "room100k"])
+def test_mixed_launch_learns_and_stays_identical(ra, orc, ctx, meshes, mesh):
+    """traversal 18 (the automatic choice for one 128x1024 scan): the slow tiles of the previous scans are delegated to quad
+    helper blocks.  The flags are learned over the first launches and refreshed later; results must be bit-identical before
+    and after every calibration, for the learned pose and for a different one (stale flags)."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes(mesh)
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    model = syn.model_c2()
+    base = syn.pose_c2_truth() if mesh == "sphere100k" else T.transform_from_rpy(*ROOM_POSE_RPY)
+    other = T.mult(base, T.transform_from_rpy((0.7, -0.4, 0.1), (0.05, -0.02, 1.3)))
+    rcc = ra.RCCHipSpherical(hm)
+    rcc.set_traversal(18)
+    rcc.setTsb(T.identity())
+    rcc.setModel(model)
+    ref_a = m.simulate_spherical(model, T.identity(), base, bvh=True, nthreads=8)
+    ref_b = m.simulate_spherical(model, T.identity(), other, bvh=True, nthreads=8)
+    for i in range(6):                      # launches 1-2 undelegated, calibration before the 3rd, then delegated
+        rcc.find(base)
+        _compare(rcc.modelView(), ref_a, "mixed %s launch %d" % (mesh, i))
+    rcc.find(other)                         # flags learned for another pose: slower at worst, never different
+    _compare(rcc.modelView(), ref_b, "mixed %s stale flags" % mesh)
+    for i in range(300):                    # crosses the periodic recalibration (every 256 launches)
+        rcc.find_async(other)
+    rcc.sync()
+    rcc.find(other)
+    _compare(rcc.modelView(), ref_b, "mixed %s after recalibration" % mesh)
+    rcc.find(base)
+    _compare(rcc.modelView(), ref_a, "mixed %s back" % mesh)
+    rcc.close()
