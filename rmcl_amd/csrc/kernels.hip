@@ -2131,7 +2131,7 @@ __global__ void __launch_bounds__(256) k_pf_update(const PfParams p) {
     }
     RayHit h;
     const float rtf = (live && finite) ? __builtin_inff() : -1.0f;
-    if (kTrav == 0) trace_lane_ww<16>(p.nodes, p.tris, org, dir, rtf, stacks + threadIdx.x, 256u, h);
+    if (kTrav == 0) trace_lane_bf<16>(p.nodes, p.tris, org, dir, rtf, stacks + threadIdx.x, h);
     else if (kTrav == 1) trace_lane_ww<64>(p.nodes, p.tris, org, dir, rtf, stacks + threadIdx.x, 256u, h);
     else trace_lane(p.nodes, p.tris, org, dir, rtf, stacks + threadIdx.x, 256u, h);
     if (live) {
@@ -2181,13 +2181,14 @@ __global__ void __launch_bounds__(256) k_pf_update(const PfParams p) {
 // finished its ray takes the next one from the block's queue as soon as kRefill lanes of its wave are idle; every
 // result is stored under its ray index, so the outcome does not depend on the schedule.  Traversal, acceptance
 // rules and beam evaluation are those of trace_lane_ww / k_pf_update (bit-identical results).
+constexpr int kPfRows = 20;  // LDS stack rows per lane of the persistent particle-filter kernel (sentinel included)
+
 template <int kLdsEntries, int kRefill, bool kQuant>
 __global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
   // LDS: [ per-lane stacks kLdsEntries*256 | Tsm (PB xforms) | evals (PB*n_beams floats) ]
   extern __shared__ uint32_t lds_dyn[];
   __shared__ uint32_t s_next;
-  uint32_t* lds_stack = lds_dyn + threadIdx.x;
-  constexpr uint32_t lds_stride = 256u;
+  uint32_t* lds_col = lds_dyn + threadIdx.x;   // stack rows of this lane: row r at lds_col[r * 256], row 0 = sentinel
   xform* s_Tsm = reinterpret_cast<xform*>(lds_dyn + kLdsEntries * 256);
   float* s_eval = reinterpret_cast<float*>(s_Tsm + p.particles_per_block);
 
@@ -2210,10 +2211,13 @@ __global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
   RaySlab rs = make_ray_slab(O, mk3(1.f, 1.f, 1.f));
   float range = 0.f, best_t = 0.f;
   uint32_t best_rec = kNone;
-  uint32_t priv[(kLdsEntries < 64) ? (64 - kLdsEntries) : 1];
-  uint32_t sp = 0, cur = kDone;
-#define RMCL_PUSH(v) { if (kLdsEntries >= 64 || sp < kLdsEntries) lds_stack[sp * lds_stride] = (v); else priv[sp - kLdsEntries] = (v); ++sp; }
-#define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; if (kLdsEntries >= 64 || sp < kLdsEntries) cur = lds_stack[sp * lds_stride]; else cur = priv[sp - kLdsEntries]; } }
+  // branch-free node step of trace_lane_bf: kLdsEntries rows in LDS (row 0 = sentinel kDone), deeper rows in scratch
+  constexpr int kRows = kLdsEntries;
+  uint32_t priv[(kRows < 65) ? (65 - kRows) : 1];
+  lds_col[0] = kDone;
+  uint32_t sp = 1, cur = kDone;
+#define RMCL_ROW_ST(r, v) { if ((r) < static_cast<uint32_t>(kRows)) lds_col[(r) * kBfStride] = (v); else priv[(r) - kRows] = (v); }
+#define RMCL_ROW_LD(r) (((r) < static_cast<uint32_t>(kRows)) ? lds_col[(r) * kBfStride] : priv[(r) - kRows])
   for (;;) {
     const bool idle = (cur == kDone) && !exhausted;
     const uint64_t want = __ballot(idle);
@@ -2268,7 +2272,7 @@ __global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
           rs = make_ray_slab(O, D);
           best_t = __builtin_inff();
           best_rec = kNone;
-          sp = 0;
+          sp = 1;
           has_ray = true;
           const bool finite = (D.x == D.x) && (D.y == D.y) && (D.z == D.z);
           cur = finite ? 0u : kDone;  // a non-finite beam is a miss: evaluated at the next refill
@@ -2288,24 +2292,38 @@ __global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
       if (__popcll(m_inner) <= kTailLanes && __ballot((cur != kDone) && (cur & kLeafBit)) != 0) break;
       if (inner) {
         uint32_t key[4], ref[4];
-        if (kQuant) node_keys_q(p.qnodes, cur, rs, best_t, key, ref);
-        else node_keys(p.nodes, cur, rs, best_t, key, ref);
-        RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
-        if (key[3] != kNone) RMCL_PUSH(ref[3])
-        if (key[2] != kNone) RMCL_PUSH(ref[2])
-        if (key[1] != kNone) RMCL_PUSH(ref[1])
-        if (key[0] != kNone) cur = ref[0];
-        else RMCL_POP()
+        if (!__any(sp + 3u > static_cast<uint32_t>(kRows))) {
+          const uint32_t top = lds_col[(sp - 1u) * kBfStride];
+          if (kQuant) node_keys_q(p.qnodes, cur, rs, best_t, key, ref);
+          else node_keys_off(p.nodes, cur << 7, rs, best_t, key, ref);
+          RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
+          lds_col[sp * kBfStride] = ref[3]; sp += (key[3] != kNone) ? 1u : 0u;
+          lds_col[sp * kBfStride] = ref[2]; sp += (key[2] != kNone) ? 1u : 0u;
+          lds_col[sp * kBfStride] = ref[1]; sp += (key[1] != kNone) ? 1u : 0u;
+          const bool any = key[0] != kNone;
+          cur = any ? ref[0] : top;
+          sp = any ? sp : (sp - 1u);
+        } else {
+          if (kQuant) node_keys_q(p.qnodes, cur, rs, best_t, key, ref);
+          else node_keys_off(p.nodes, cur << 7, rs, best_t, key, ref);
+          RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
+          if (key[3] != kNone) { RMCL_ROW_ST(sp, ref[3]) ++sp; }
+          if (key[2] != kNone) { RMCL_ROW_ST(sp, ref[2]) ++sp; }
+          if (key[1] != kNone) { RMCL_ROW_ST(sp, ref[1]) ++sp; }
+          if (key[0] != kNone) cur = ref[0];
+          else { --sp; cur = RMCL_ROW_LD(sp); }
+        }
       }
     }
     // phase 2: this lane's leaf (if any); tfar = infinity
     if ((cur != kDone) && (cur & kLeafBit)) {
       leaf_loop(p.tris, cur, O, D, __builtin_inff(), best_t, best_rec);
-      RMCL_POP()
+      --sp;
+      cur = RMCL_ROW_LD(sp);
     }
   }
-#undef RMCL_PUSH
-#undef RMCL_POP
+#undef RMCL_ROW_ST
+#undef RMCL_ROW_LD
   __syncthreads();
   // in-order merge, one lane per particle (sequential semantics of sensorUpdate, :232-238)
   if (threadIdx.x < np) {
@@ -2343,7 +2361,7 @@ __global__ void __launch_bounds__(256) k_pf_motion(const uint32_t* __restrict__ 
     const bool moving = !(static_cast<double>(length) < 0.00001);
     vec = mk3(vec.x / length, vec.y / length, vec.z / length);
     RayHit h;
-    trace_lane_ww<16, true>(nodes, tris, pose_old.t, vec, (live && moving) ? length : -1.0f, lds_dyn + threadIdx.x, blockDim.x, h);
+    trace_lane_bf<16, true>(nodes, tris, pose_old.t, vec, (live && moving) ? length : -1.0f, lds_dyn + threadIdx.x, h);
     if (moving && h.rec != kNone) { L.mean = 0.0f; L.sigma = 0.0f; L.n_meas = max_n_meas; }
   }
   if (live) {
@@ -2682,20 +2700,21 @@ hipError_t launch_pf_update(const PfParams& p, int variant, hipStream_t s) {
   const bool deep = (variant & 4) != 0;  // 64-deep LDS stack instead of 32 (maps with stack_need > 32)
   const bool cpc = (variant & 8) != 0;   // correspondence_type 1
   const size_t stack_lds = ((trav == 0 || cpc) ? 16u : (deep ? 64u : 32u)) * 256u * sizeof(uint32_t);
-  const size_t lds = stack_lds + tail;
+  size_t lds = stack_lds + tail;
   const int refill = (variant >> 4) & 7;  // 0 = rounds of one ray per lane; 1..4 = persistent lanes, refill at 8/16/32/48 idle
   if (!cpc && trav == 0 && refill != 0) {
+    lds = static_cast<size_t>(kPfRows) * 256u * sizeof(uint32_t) + tail;
     const bool quant = ((variant >> 7) & 1) == 0 && p.qnodes != nullptr;  // bit 7: full-precision nodes (A/B)
     if (quant) {
-      if (refill == 1) hipLaunchKernelGGL((k_pf_update_persist<16, 8, true>), dim3(nblocks), dim3(256), lds, s, p);
-      else if (refill == 2) hipLaunchKernelGGL((k_pf_update_persist<16, 16, true>), dim3(nblocks), dim3(256), lds, s, p);
-      else if (refill == 3) hipLaunchKernelGGL((k_pf_update_persist<16, 32, true>), dim3(nblocks), dim3(256), lds, s, p);
-      else hipLaunchKernelGGL((k_pf_update_persist<16, 48, true>), dim3(nblocks), dim3(256), lds, s, p);
+      if (refill == 1) hipLaunchKernelGGL((k_pf_update_persist<kPfRows, 8, true>), dim3(nblocks), dim3(256), lds, s, p);
+      else if (refill == 2) hipLaunchKernelGGL((k_pf_update_persist<kPfRows, 16, true>), dim3(nblocks), dim3(256), lds, s, p);
+      else if (refill == 3) hipLaunchKernelGGL((k_pf_update_persist<kPfRows, 32, true>), dim3(nblocks), dim3(256), lds, s, p);
+      else hipLaunchKernelGGL((k_pf_update_persist<kPfRows, 48, true>), dim3(nblocks), dim3(256), lds, s, p);
     } else {
-      if (refill == 1) hipLaunchKernelGGL((k_pf_update_persist<16, 8, false>), dim3(nblocks), dim3(256), lds, s, p);
-      else if (refill == 2) hipLaunchKernelGGL((k_pf_update_persist<16, 16, false>), dim3(nblocks), dim3(256), lds, s, p);
-      else if (refill == 3) hipLaunchKernelGGL((k_pf_update_persist<16, 32, false>), dim3(nblocks), dim3(256), lds, s, p);
-      else hipLaunchKernelGGL((k_pf_update_persist<16, 48, false>), dim3(nblocks), dim3(256), lds, s, p);
+      if (refill == 1) hipLaunchKernelGGL((k_pf_update_persist<kPfRows, 8, false>), dim3(nblocks), dim3(256), lds, s, p);
+      else if (refill == 2) hipLaunchKernelGGL((k_pf_update_persist<kPfRows, 16, false>), dim3(nblocks), dim3(256), lds, s, p);
+      else if (refill == 3) hipLaunchKernelGGL((k_pf_update_persist<kPfRows, 32, false>), dim3(nblocks), dim3(256), lds, s, p);
+      else hipLaunchKernelGGL((k_pf_update_persist<kPfRows, 48, false>), dim3(nblocks), dim3(256), lds, s, p);
     }
     return hipGetLastError();
   }
