@@ -89,6 +89,38 @@ int main(int argc, char** argv) {
     std::printf("host_loop_n_meas %u\nhost_loop_t %.9g %.9g %.9g\nhost_loop_q %.9g %.9g %.9g %.9g\n", Cmerged.n_meas,
                 T_onew_oold.t.x, T_onew_oold.t.y, T_onew_oold.t.z, T_onew_oold.R.x, T_onew_oold.R.y, T_onew_oold.R.z,
                 T_onew_oold.R.w);
+    // Correspondences_::dataset filled the way the reference's device sensors fill it (MICPSphericalSensorCUDA.cpp:207-232):
+    // points / mask built on the host per measurement, then `dataset.points = host.points; dataset.mask = host.mask;`
+    {
+      RCCHipSpherical rcc2(map);
+      rcc2.setTsb(Tsb);
+      rcc2.setModel(model);
+      rcc2.params.max_dist = 1.0f;
+      rcc2.adaptive_max_dist_min = 0.15f;
+      PointCloud_<RAM> dataset_cpu;
+      dataset_cpu.points.resize(n);
+      dataset_cpu.mask.resize(n);
+      uint32_t valid2 = 0;
+      for (uint32_t vid = 0; vid < model.phi.size; ++vid)
+        for (uint32_t hid = 0; hid < model.theta.size; ++hid) {
+          const uint32_t loc_id = getBufferId(model, vid, hid);
+          const float real_range = ranges[loc_id];
+          const Vector d = getDirection(model, vid, hid);
+          dataset_cpu.points[loc_id] = Vector{d.x * real_range, d.y * real_range, d.z * real_range};
+          const bool out_of_range = real_range < model.range.min || real_range > model.range.max;
+          dataset_cpu.mask[loc_id] = out_of_range ? 0 : 1;
+          valid2 += out_of_range ? 0 : 1;
+        }
+      rcc2.dataset.points = dataset_cpu.points;   // upload
+      rcc2.dataset.mask = dataset_cpu.mask;
+      rcc2.find(Tom_est * Tbo);
+      const CrossStatistics a = rcc2.computeCrossStatistics(identity(), 0.0);
+      rcc.find(Tom_est * Tbo);
+      const CrossStatistics b = rcc.computeCrossStatistics(identity(), 0.0);
+      const auto dv = rcc2.datasetView();
+      std::printf("dataset_member_valid %u\ndataset_member_n_meas %u %u\ndataset_member_cov00 %.9g %.9g\ndataset_view %zu %zu\n", valid2,
+                  a.n_meas, b.n_meas, a.covariance[0], b.covariance[0], dv.points.size(), dv.mask.size());
+    }
     // the same loop resident on the device
     CrossStatistics sdev{};
     const Transform Tdev = rcc.correctOnce(Tom_est, Tbo, 5, 0.0, false, &sdev);
@@ -117,6 +149,23 @@ int main(int argc, char** argv) {
     check(rmclhip_memcpy_d2h(ctx->handle(), attrs.data(), d_attrs, attrs.size() * sizeof(ParticleAttributes)));
     for (size_t i = 0; i < attrs.size(); ++i)
       std::printf("pf_%zu %.9g %.9g %u\n", i, attrs[i].likelihood.mean, attrs[i].likelihood.sigma, attrs[i].likelihood.n_meas);
+    // beams drawn from a raw PointCloud2 (x y z float32 + one more float32 field, point_step 16) like
+    // PCDSensorUpdaterEmbree::update does: the simulated scan at the true pose, misses as NaN points
+    {
+      std::vector<float> pts3(3 * static_cast<size_t>(n));
+      rcc.find(truth * Tbo);
+      rcc.download(nullptr, nullptr, pts3.data(), nullptr, nullptr);
+      std::vector<float> cloud(4 * static_cast<size_t>(n), 0.0f);
+      for (uint32_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) cloud[4 * i + k] = pts3[3 * i + k];
+      rmclhip_pointcloud2_layout L{};
+      L.width = n; L.height = 1; L.point_step = 16; L.row_step = 16 * n; L.offset_x = 0; L.offset_y = 4; L.offset_z = 8; L.datatype = 7;
+      PCDSensorUpdaterHip upd2(map);
+      const size_t nb = upd2.setInput(reinterpret_cast<const uint8_t*>(cloud.data()), cloud.size() * 4, L, Tsb, 40, 1234);
+      double range_sum = 0;
+      for (const auto& bm : upd2.beams()) range_sum += bm.range;
+      std::printf("sampled_beams %zu %.9g\n", nb, range_sum);
+    }
     // motion update (30 cm forward, 1 % forgetting, wall-collision test) and one gladiator tournament
     TFMotionUpdaterHip motion(map);
     const DeviceView<Transform> vposes{static_cast<Transform*>(d_poses), poses.size()};

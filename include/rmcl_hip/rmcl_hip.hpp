@@ -13,6 +13,7 @@
 // (micp_localization.cpp:613, PCDSensorUpdaterOptix.cpp:179-192).
 #pragma once
 
+#include <cmath>
 #include <cstdint>
 #include <memory>
 #include <stdexcept>
@@ -115,6 +116,91 @@ struct DeviceView {
   size_t size() const { return n; }
 };
 
+// rmagine::Memory<T, MemT> for the two memory spaces the adapters need (rmcl_localization.cpp:408-421 uses resize / raw /
+// size / operator[] / cross-space assignment).  RAM = host, VRAM_HIP = device memory of one context.
+struct RAM {};
+template <typename T, typename MemT>
+class Memory;
+
+template <typename T>
+class Memory<T, RAM> {
+ public:
+  Memory() = default;
+  explicit Memory(size_t n) : v_(n) {}
+  void resize(size_t n) { v_.resize(n); }
+  size_t size() const { return v_.size(); }
+  T* raw() { return v_.data(); }
+  const T* raw() const { return v_.data(); }
+  T& operator[](size_t i) { return v_[i]; }
+  const T& operator[](size_t i) const { return v_[i]; }
+
+ private:
+  std::vector<T> v_;
+};
+
+template <typename T>
+class Memory<T, VRAM_HIP> {
+ public:
+  Memory() = default;
+  explicit Memory(ContextPtr ctx) : ctx_(std::move(ctx)) {}
+  ~Memory() { release(); }
+  Memory(const Memory&) = delete;
+  Memory& operator=(const Memory&) = delete;
+  void setContext(ContextPtr ctx) { ctx_ = std::move(ctx); }
+  // grow-only like rm::Memory::resize on the reference's device paths (contents are not preserved)
+  void resize(size_t n) {
+    if (n > cap_) {
+      release();
+      if (!ctx_) throw std::runtime_error("Memory<VRAM_HIP>: no context");
+      void* p = nullptr;
+      check(rmclhip_malloc(ctx_->handle(), n * sizeof(T), &p));
+      ptr_ = static_cast<T*>(p);
+      cap_ = n;
+    }
+    n_ = n;
+  }
+  size_t size() const { return n_; }
+  T* raw() { return ptr_; }
+  const T* raw() const { return ptr_; }
+  // cross-space assignment: `correspondences_->dataset.points = dataset_cpu_.points` (MICPSphericalSensorCUDA.cpp:231)
+  Memory& operator=(const Memory<T, RAM>& host) {
+    resize(host.size());
+    if (host.size()) check(rmclhip_memcpy_h2d(ctx_->handle(), ptr_, host.raw(), host.size() * sizeof(T)));
+    ++version_;
+    return *this;
+  }
+  void download(Memory<T, RAM>& host) const {
+    host.resize(n_);
+    if (n_) check(rmclhip_memcpy_d2h(ctx_->handle(), host.raw(), ptr_, n_ * sizeof(T)));
+  }
+  uint64_t version() const { return version_; }   // bumped by every upload (the operator rebinds its dataset view)
+  void touch() { ++version_; }                    // after writing through raw() with one's own kernel
+
+ private:
+  void release() {
+    if (ptr_ && ctx_) (void)rmclhip_free(ctx_->handle(), ptr_);
+    ptr_ = nullptr;
+    cap_ = n_ = 0;
+  }
+  ContextPtr ctx_;
+  T* ptr_ = nullptr;
+  size_t cap_ = 0, n_ = 0;
+  uint64_t version_ = 0;
+};
+
+// rmagine::PointCloud_<MemT> / PointCloudView_<MemT> (Correspondences.hpp:24,47-62): {points, mask} (+ normals in views)
+template <typename MemT>
+struct PointCloud_ {
+  Memory<Vector, MemT> points;
+  Memory<uint8_t, MemT> mask;
+};
+template <typename MemT>
+struct PointCloudView_ {
+  DeviceView<const Vector> points;
+  DeviceView<const uint8_t> mask;
+  DeviceView<const Vector> normals;
+};
+
 template <typename MemT>
 class Correspondences_;
 
@@ -125,11 +211,16 @@ class Correspondences_<VRAM_HIP> {
   // public attributes that have to be filled (Correspondences.hpp:19-29)
   UmeyamaReductionConstraints params;
   float adaptive_max_dist_min = 1.0f;
+  // Correspondences.hpp:24: sensors write `dataset.points = host_points; dataset.mask = host_mask;` (device memory owned
+  // here, borrowed by the library: rmclhip_rcc_set_dataset_view) -- reference sensor code compiles against this unchanged
+  PointCloud_<VRAM_HIP> dataset;
   bool outdated = true;
 
   explicit Correspondences_(HipMapPtr map) : map_(std::move(map)) {
     if (!map_) throw std::runtime_error("NO MAP");
     check(rmclhip_rcc_create(map_->context()->handle(), map_->handle(), &h_));
+    dataset.points.setContext(map_->context());
+    dataset.mask.setContext(map_->context());
   }
   virtual ~Correspondences_() { rmclhip_rcc_destroy(h_); }
   Correspondences_(const Correspondences_&) = delete;
@@ -142,6 +233,7 @@ class Correspondences_<VRAM_HIP> {
   // finds and fills the model buffers
   virtual void find(const Transform& Tbm_est) { check(rmclhip_rcc_find(h_, &Tbm_est)); }
   virtual CrossStatistics computeCrossStatistics(const Transform& T_snew_sold, double convergence_progress = 0.0) const {
+    bindDataset();
     check(rmclhip_rcc_set_params(h_, params.max_dist, adaptive_max_dist_min));
     CrossStatistics out;
     check(rmclhip_rcc_compute_cross_statistics(h_, &T_snew_sold, convergence_progress, &out));
@@ -151,13 +243,22 @@ class Correspondences_<VRAM_HIP> {
   // MICPSphericalSensorCUDA.cpp:231-232)
   void setDataset(const float* points_xyz, const uint8_t* mask, uint32_t n, bool src_is_device = false) {
     check(rmclhip_rcc_set_dataset(h_, points_xyz, mask, n, src_is_device ? 1 : 0));
+    bound_points_ = bound_mask_ = ~0ull;   // the library's own copy is current until `dataset` is written again
     outdated = true;
   }
   uint32_t setDatasetFromRanges(const float* ranges, uint32_t n) {
     uint32_t valid = 0;
     check(rmclhip_rcc_set_dataset_from_ranges(h_, ranges, n, &valid));
+    bound_points_ = bound_mask_ = ~0ull;
     outdated = true;
     return valid;
+  }
+  // datasetView() (Correspondences.hpp:55-62)
+  PointCloudView_<VRAM_HIP> datasetView() const {
+    PointCloudView_<VRAM_HIP> v;
+    v.points = {dataset.points.raw(), dataset.points.size()};
+    v.mask = {dataset.mask.raw(), dataset.mask.size()};
+    return v;
   }
   // modelView(): borrowed device views of {points, hits(mask), normals} (+ ranges, face ids)
   struct ModelView {
@@ -179,6 +280,7 @@ class Correspondences_<VRAM_HIP> {
   // device-resident MICP-L inner loop for this sensor (micp_localization.cpp:900-964)
   Transform correctOnce(const Transform& Tom, const Transform& Tbo, uint32_t iterations, double convergence_progress,
                         bool refind_each_iteration, CrossStatistics* stats_o = nullptr) {
+    bindDataset();
     check(rmclhip_rcc_set_params(h_, params.max_dist, adaptive_max_dist_min));
     Transform T;
     check(rmclhip_rcc_correct_once(h_, &Tom, &Tbo, iterations, convergence_progress, refind_each_iteration ? 1 : 0, &T,
@@ -187,6 +289,7 @@ class Correspondences_<VRAM_HIP> {
   }
   // v1 SphereCorrector::correct (lidar_corrector_embree_benchmark.cpp:127-135)
   std::vector<Transform> correctBatch(const std::vector<Transform>& Tbm, std::vector<CrossStatistics>* stats = nullptr) {
+    bindDataset();
     check(rmclhip_rcc_set_params(h_, params.max_dist, adaptive_max_dist_min));
     std::vector<Transform> out(Tbm.size());
     if (stats) stats->resize(Tbm.size());
@@ -197,9 +300,22 @@ class Correspondences_<VRAM_HIP> {
   rmclhip_rcc* handle() const { return h_; }
 
  protected:
+  // hand the current `dataset` memory to the library when it was (re)written since the last call
+  void bindDataset() const {
+    if (dataset.points.size() == 0) return;   // dataset handed over with setDataset*() instead
+    if (dataset.points.version() == bound_points_ && dataset.mask.version() == bound_mask_) return;
+    if (dataset.mask.size() != 0 && dataset.mask.size() != dataset.points.size())
+      throw std::runtime_error("Correspondences: dataset.mask.size() != dataset.points.size()");
+    check(rmclhip_rcc_set_dataset_view(h_, reinterpret_cast<const float*>(dataset.points.raw()),
+                                       dataset.mask.size() ? dataset.mask.raw() : nullptr,
+                                       static_cast<uint32_t>(dataset.points.size())));
+    bound_points_ = dataset.points.version();
+    bound_mask_ = dataset.mask.version();
+  }
   HipMapPtr map_;
   rmclhip_rcc* h_ = nullptr;
   Transform Tsb_ = identity();
+  mutable uint64_t bound_points_ = ~0ull, bound_mask_ = ~0ull;
 };
 using CorrespondencesHIP = Correspondences_<VRAM_HIP>;
 
@@ -217,6 +333,15 @@ struct O1DnModel {
   Vector orig{0.f, 0.f, 0.f};
   std::vector<Vector> dirs;
 };
+
+// rmagine::SphericalModel::getDirection / getBufferId (convention pinned by rmcl_ros/src/util/conversions.cpp:174-188):
+// what the reference's unpackMessage evaluates per measurement when it fills `dataset` (MICPSphericalSensorCPU.cpp:212-219)
+inline Vector getDirection(const SphericalModel& m, uint32_t vid, uint32_t hid) {
+  const float phi = m.phi.min + static_cast<float>(vid) * m.phi.inc;
+  const float theta = m.theta.min + static_cast<float>(hid) * m.theta.inc;
+  return Vector{std::cos(phi) * std::cos(theta), std::cos(phi) * std::sin(theta), std::sin(phi)};
+}
+inline uint32_t getBufferId(const SphericalModel& m, uint32_t vid, uint32_t hid) { return vid * m.theta.size + hid; }
 
 class RCCHipSpherical : public CorrespondencesHIP, public ModelSetter<SphericalModel> {
  public:
@@ -314,6 +439,19 @@ class PCDSensorUpdaterHip : public SensorUpdaterBase, public ParticleUpdater<VRA
     beams_ = std::move(beams);
     Tsb_ = Tsb;
   }
+  // Input<PointCloud2::ConstSharedPtr>::setInput (Input.hpp:7-15) for the raw message: `samples` beams are drawn from the
+  // cloud bytes like PCDSensorUpdaterEmbree::update does (:276-327; config_.samples, default 100, :124), with an explicit
+  // seed instead of the reference's function-static engine.  Returns the number of beams (< samples: "Point invalid").
+  size_t setInput(const uint8_t* cloud_data, size_t nbytes, const rmclhip_pointcloud2_layout& layout, const Transform& Tsb,
+                  uint32_t samples = 100, uint64_t seed = 0) {
+    beams_.resize(samples);
+    uint32_t n = 0;
+    check(rmclhip_pf_sample_beams_pointcloud2(cloud_data, nbytes, &layout, samples, seed, beams_.data(), &n));
+    beams_.resize(n);
+    Tsb_ = Tsb;
+    return n;
+  }
+  const std::vector<RangeMeasurement>& beams() const { return beams_; }
   ParticleUpdateResults update(DeviceView<Transform> poses, DeviceView<ParticleAttributes> attrs,
                                const ParticleUpdateConfig& = {}) override {
     init();

@@ -188,6 +188,11 @@ rmclhip_status rmclhip_rcc_set_params(rmclhip_rcc* rcc, float max_dist, float ad
  * mask may be NULL (all valid). */
 rmclhip_status rmclhip_rcc_set_dataset(rmclhip_rcc* rcc, const float* points_xyz, const uint8_t* mask,
                                        uint32_t n, int src_is_device);
+/* Correspondences_::dataset kept in the CALLER's device memory (rmagine::PointCloud_<VRAM_HIP>: Correspondences.hpp:24,
+ * written by `correspondences_->dataset.points = dataset_cpu_.points`, MICPSphericalSensorCUDA.cpp:231-232): the handle
+ * borrows the pointers -- no copy -- until the next set_dataset* call; the memory must stay valid meanwhile.
+ * mask_dev may be NULL (all valid). */
+rmclhip_status rmclhip_rcc_set_dataset_view(rmclhip_rcc* rcc, const float* points_xyz_dev, const uint8_t* mask_dev, uint32_t n);
 /* convenience mirror of unpackMessage: ranges -> dataset points = dir(vid,hid)*range (+orig for
  * O1Dn), mask = range in [range.min, range.max]; returns valid count */
 rmclhip_status rmclhip_rcc_set_dataset_from_ranges(rmclhip_rcc* rcc, const float* ranges, uint32_t n,
@@ -343,6 +348,14 @@ rmclhip_status rmclhip_pf_time_update(rmclhip_pf* pf, const rmclhip_transform* p
  * next ray when 8 / 16 / 32 / 48 lanes of their wave are idle); bit 7: persistent lanes on the 128-B nodes instead
  * of their 64-B quantised twins (A/B).  A fresh handle uses traversal 0, refill at 48, quantised nodes. */
 rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* pf, int variant);
+/* Beam sampling of PCDSensorUpdater{Embree,Optix}::update (PCDSensorUpdaterEmbree.cpp:276-327) on the raw
+ * sensor_msgs/PointCloud2 bytes (HOST function, no device needed): `samples` uniformly random points, each with up to 100
+ * retries for one without NaN, become RangeMeasurements {orig 0, dir = p / |p|, range = |p|, cov = 0.1 I}.  The reference
+ * draws from an unseeded function-static engine; here: std::mt19937(seed), index = draw % (width * height).  *n_out <
+ * samples iff a sample stayed invalid (the reference returns early there). */
+rmclhip_status rmclhip_pf_sample_beams_pointcloud2(const uint8_t* data, size_t nbytes, const rmclhip_pointcloud2_layout* layout,
+                                                   uint32_t samples, uint64_t seed, rmclhip_range_measurement* beams_out,
+                                                   uint32_t* n_out);
 
 
 /* ---- resampling: rmcl::GladiatorResamplerGPU (GladiatorResamplerGPU.cpp:46-81, resampling.cu:41-219) ----

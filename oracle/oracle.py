@@ -558,3 +558,24 @@ def pointcloud2_unpack(data, width, height, point_step, row_step, off_x, off_y, 
     lib().orc_pointcloud2_unpack(*args, C.byref(ow), C.byref(oh), _p(dirs), _p(rng), _p(pts), _p(mask), C.byref(nv))
     return {"width": ow.value, "height": oh.value, "dirs": dirs, "ranges": rng, "points": pts, "mask": mask,
             "n_valid": nv.value}
+
+
+def sample_beams_pointcloud2(data, width, height, point_step, row_step, off_x, off_y, off_z, samples, seed, datatype=7):
+    """PCDSensorUpdaterEmbree.cpp:276-327 with the pinned stream (MT19937(seed), index = draw % n_points)."""
+    buf = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8)) if isinstance(data, (bytes, bytearray, memoryview)) \
+        else np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+    out = np.zeros(int(samples), dtype=RANGE_MEASUREMENT)
+    n = C.c_uint32(0)
+    L = lib()
+    L.orc_sample_beams_pointcloud2.argtypes = [C.c_void_p] + [C.c_uint32] * 10 + [C.c_void_p, C.POINTER(C.c_uint32)]
+    rc = L.orc_sample_beams_pointcloud2(buf.ctypes.data, width, height, point_step, row_step, off_x, off_y, off_z, datatype,
+                                        samples, seed & 0xFFFFFFFF, out.ctypes.data, C.byref(n))
+    assert rc == 0
+    return out[: n.value].copy()
+
+
+def mt19937_draw(seed, n_skip=0):
+    L = lib()
+    L.orc_mt19937_draw.restype = C.c_uint32
+    L.orc_mt19937_draw.argtypes = [C.c_uint32, C.c_uint32]
+    return int(L.orc_mt19937_draw(seed & 0xFFFFFFFF, n_skip))

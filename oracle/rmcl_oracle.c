@@ -1617,3 +1617,65 @@ int orc_wavesim_ww(const uint32_t* nodes, const uint32_t* tris, const float* O, 
   free(L);
   return 0;
 }
+
+
+/* ------------------------------------------------------------------------- */
+/* beam sampling of PCDSensorUpdaterEmbree::update (PCDSensorUpdaterEmbree.cpp:276-327) with the pinned stream:   */
+/* MT19937 (Matsumoto & Nishimura 1998, the algorithm std::mt19937 is specified to be), index = draw % n_points.   */
+/* ------------------------------------------------------------------------- */
+typedef struct { uint32_t mt[624]; int idx; } orc_mt19937;
+static void mt_seed(orc_mt19937* g, uint32_t seed)
+{
+  g->mt[0] = seed;
+  for (int i = 1; i < 624; ++i) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+  g->idx = 624;
+}
+static uint32_t mt_next(orc_mt19937* g)
+{
+  if (g->idx >= 624) {
+    for (int i = 0; i < 624; ++i) {
+      const uint32_t y = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7FFFFFFFu);
+      g->mt[i] = g->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
+    }
+    g->idx = 0;
+  }
+  uint32_t y = g->mt[g->idx++];
+  y ^= y >> 11; y ^= (y << 7) & 0x9D2C5680u; y ^= (y << 15) & 0xEFC60000u; y ^= y >> 18;
+  return y;
+}
+uint32_t orc_mt19937_draw(uint32_t seed, uint32_t n_skip)
+{
+  orc_mt19937 g; mt_seed(&g, seed);
+  uint32_t v = 0;
+  for (uint32_t i = 0; i <= n_skip; ++i) v = mt_next(&g);
+  return v;
+}
+
+int orc_sample_beams_pointcloud2(const uint8_t* data, uint32_t width, uint32_t height, uint32_t point_step, uint32_t row_step,
+                                 uint32_t off_x, uint32_t off_y, uint32_t off_z, uint32_t datatype, uint32_t samples,
+                                 uint32_t seed, orc_range_measurement* out, uint32_t* n_out)
+{
+  *n_out = 0;
+  if (datatype != 7u && datatype != 8u) return -1;
+  const uint64_t n_points = (uint64_t)width * height;
+  if (n_points == 0) return samples ? -1 : 0;
+  orc_mt19937 g; mt_seed(&g, seed);
+  for (uint32_t s = 0; s < samples; ++s) {
+    int valid = 0; float x = 0, y = 0, z = 0;
+    for (int t = 0; t < 100 && !valid; ++t) {
+      const uint64_t id = (uint64_t)mt_next(&g) % n_points;
+      const uint8_t* ptr = data + (id / width) * row_step + (id % width) * point_step;
+      if (datatype == 8u) { double d; memcpy(&d, ptr + off_x, 8); x = (float)d; memcpy(&d, ptr + off_y, 8); y = (float)d; memcpy(&d, ptr + off_z, 8); z = (float)d; }
+      else { memcpy(&x, ptr + off_x, 4); memcpy(&y, ptr + off_y, 4); memcpy(&z, ptr + off_z, 4); }
+      valid = (x == x) && (y == y) && (z == z);
+    }
+    if (!valid) break;
+    orc_range_measurement m; memset(&m, 0, sizeof(m));
+    const float norm = sqrtf((x * x + y * y) + z * z);
+    m.dir = v3(x / norm, y / norm, z / norm);
+    m.range = norm;
+    m.cov[0] = m.cov[4] = m.cov[8] = 0.1f;
+    out[(*n_out)++] = m;
+  }
+  return 0;
+}

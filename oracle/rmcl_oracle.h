@@ -214,6 +214,13 @@ int orc_pointcloud2_unpack(const uint8_t* data, uint32_t width, uint32_t height,
 
 #ifdef __cplusplus
 }
+/* beam sampling (PCDSensorUpdaterEmbree.cpp:276-327): MT19937(seed), index = draw % (width * height), up to 100 retries
+ * for a point without NaN; returns 0, *n_out = beams written */
+int orc_sample_beams_pointcloud2(const uint8_t* data, uint32_t width, uint32_t height, uint32_t point_step, uint32_t row_step,
+                                 uint32_t off_x, uint32_t off_y, uint32_t off_z, uint32_t datatype, uint32_t samples,
+                                 uint32_t seed, orc_range_measurement* out, uint32_t* n_out);
+uint32_t orc_mt19937_draw(uint32_t seed, uint32_t n_skip);   /* the (n_skip+1)-th output of MT19937(seed): known-answer tests */
+
 /* analysis only (tools/wavesim.py): wave-level step counts of the product's while-while traversal on its exported
  * BVH4 arrays; see rmcl_oracle.c */
 int orc_wavesim_ww(const uint32_t* nodes, const uint32_t* tris, const float* O, const float* D, uint32_t nlanes,

@@ -97,6 +97,7 @@ SIGNATURES = {
     "rmclhip_rcc_set_model_ondn": (_i32, [_vp, _u32, _u32, Interval, _vp, _vp]),
     "rmclhip_rcc_set_params": (_i32, [_vp, _f32, _f32]),
     "rmclhip_rcc_set_dataset": (_i32, [_vp, _vp, _vp, _u32, _i32]),
+    "rmclhip_rcc_set_dataset_view": (_i32, [_vp, _vp, _vp, _u32]),
     "rmclhip_rcc_set_dataset_from_ranges": (_i32, [_vp, _vp, _u32, C.POINTER(_u32)]),
     "rmclhip_rcc_find": (_i32, [_vp, _vp]),
     "rmclhip_rcc_find_async": (_i32, [_vp, _vp]),
@@ -136,6 +137,7 @@ SIGNATURES = {
     "rmclhip_pf_extract_weights": (_i32, [_vp, _vp, _u32, _vp]),
     "rmclhip_pf_time_update": (_i32, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32, C.POINTER(_f32)]),
     "rmclhip_pf_set_variant": (_i32, [_vp, _i32]),
+    "rmclhip_pf_sample_beams_pointcloud2": (_i32, [_vp, _sz, C.POINTER(PointCloud2Layout), _u32, C.c_uint64, _vp, C.POINTER(_u32)]),
     "rmclhip_resampler_create": (_i32, [_vp, _pp]),
     "rmclhip_resampler_destroy": (None, [_vp]),
     "rmclhip_resampler_compute_stats": (_i32, [_vp, _vp, _u32, C.POINTER(LikelihoodStats)]),

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -135,6 +136,10 @@ struct rmclhip_rcc {
   // dataset
   DevBuf<float> d_ds_points;
   DevBuf<uint8_t> d_ds_mask;
+  // what the kernels read: the handle's own copies above, or device memory borrowed from the caller
+  // (rmclhip_rcc_set_dataset_view: Correspondences_::dataset lives in the caller's rm::Memory<.., VRAM_HIP>)
+  const float* ds_pts = nullptr;
+  const uint8_t* ds_msk = nullptr;
   uint32_t n_dataset = 0;
   bool ds_has_mask = false;
   // model buffers
@@ -563,6 +568,20 @@ rmclhip_status rmclhip_rcc_set_dataset(rmclhip_rcc* r, const float* pts, const u
     HIPCHK(r->d_ds_mask.reserve(n));
     HIPCHK(hipMemcpy(r->d_ds_mask.p, mask, n, kind));
   }
+  r->ds_pts = r->d_ds_points.p;
+  r->ds_msk = mask ? r->d_ds_mask.p : nullptr;
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_set_dataset_view(rmclhip_rcc* r, const float* pts_dev, const uint8_t* mask_dev, uint32_t n) {
+  ApiGuard guard_("rmclhip_rcc_set_dataset_view");
+  if (!r || (!pts_dev && n > 0)) return fail(RMCLHIP_ERR_INVALID, "rcc_set_dataset_view: null");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  r->n_dataset = n;
+  r->ds_has_mask = (mask_dev != nullptr);
+  r->ds_pts = pts_dev;
+  r->ds_msk = mask_dev;
   return RMCLHIP_OK;
 }
 
@@ -592,6 +611,8 @@ rmclhip_status rmclhip_rcc_set_dataset_from_ranges(rmclhip_rcc* r, const float* 
   if (e == hipSuccess) e = hipMemcpyAsync(&nv, r->d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
   d_r.release();
+  r->ds_pts = r->d_ds_points.p;
+  r->ds_msk = r->d_ds_mask.p;
   if (e != hipSuccess) return fail(RMCLHIP_ERR_HIP, std::string("dataset_from_ranges: ") + hipGetErrorString(e));
   if (n_valid_out) *n_valid_out = nv;
   return RMCLHIP_OK;
@@ -639,6 +660,8 @@ rmclhip_status rmclhip_rcc_set_input_pointcloud2(rmclhip_rcc* r, const uint8_t* 
   HIPCHK(r->d_model_tab.reserve(3 * n));
   HIPCHK(r->d_ds_points.reserve(3 * n));
   HIPCHK(r->d_ds_mask.reserve(n));
+  r->ds_pts = r->d_ds_points.p;
+  r->ds_msk = r->d_ds_mask.p;
   const uint8_t* d_data = data;
   if (!src_is_device) {
     HIPCHK(r->d_raw.reserve(nbytes));
@@ -828,7 +851,7 @@ rmclhip_status rmclhip_rcc_find_cpc(rmclhip_rcc* r, const rmclhip_transform* Tbm
   r->nposes_last = 1;
   const xform Tsm = xmul(to_x(Tbm_est), r->Tsb);
   const bool quad = (r->variant == 15) ? true : (r->variant == 2);  // four lanes per point read the child-major nodes
-  HIPCHK(launch_cpc_find(quad ? r->map->d_cnodes : r->map->d_nodes, r->map->d_tris, r->d_ds_points.p, r->n_dataset,
+  HIPCHK(launch_cpc_find(quad ? r->map->d_cnodes : r->map->d_nodes, r->map->d_tris, r->ds_pts, r->n_dataset,
                          r->max_dist, Tsm, xinv(Tsm), r->d_hits.p, r->d_ranges.p, r->d_points.p, r->d_normals.p,
                          r->d_face_ids.p, quad, r->stream));
   HIPCHK(hipStreamSynchronize(r->stream));
@@ -869,8 +892,8 @@ static rmclhip_status reduce_enqueue(rmclhip_rcc* r, const xform& Tpre, const xf
   }
   ReduceParams p;
   std::memset(&p, 0, sizeof(p));
-  p.dataset_points = r->d_ds_points.p;
-  p.dataset_mask = r->ds_has_mask ? r->d_ds_mask.p : nullptr;
+  p.dataset_points = r->ds_pts;
+  p.dataset_mask = r->ds_has_mask ? r->ds_msk : nullptr;
   p.model_points = r->d_points.p;
   p.model_normals = r->d_normals.p;
   p.model_mask = r->d_hits.p;
@@ -1018,11 +1041,11 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
       const bool iter_form = r->loop_blocks == 0 && !r->fused_tail && n_iter > 0;
       if (!iter_form) HIPCHK(launch_micp_init(r->d_state, r->d_loop_barrier, r->stream));  // k_micp_iter initialises itself
       MicpState* final_state = r->d_state;
-      const uint8_t* dmask = r->ds_has_mask ? r->d_ds_mask.p : nullptr;
+      const uint8_t* dmask = r->ds_has_mask ? r->ds_msk : nullptr;
       if (r->loop_blocks > 0) {
         // persistent loop: every iteration inside ONE launch (k_micp_loop); A/B only -- a device-wide barrier
         // across the 8 XCDs costs more than the launch boundaries it replaces
-        HIPCHK(launch_micp_loop(r->d_ds_points.p, dmask, r->d_points.p, r->d_normals.p, r->d_hits.p, nred, n_iter,
+        HIPCHK(launch_micp_loop(r->ds_pts, dmask, r->d_points.p, r->d_normals.p, r->d_hits.p, nred, n_iter,
                                 r->d_call, r->d_partials.p, r->d_loop_barrier, r->d_state,
                                 static_cast<uint32_t>(r->loop_blocks), r->stream));
       } else if (iter_form) {
@@ -1031,7 +1054,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
         const uint32_t nb = reduce_num_blocks(nred, 1);
         double* part[2] = {r->d_partials.p, r->d_partials.p + static_cast<size_t>(nb) * 16};
         for (uint32_t i = 0; i < n_iter; ++i)
-          HIPCHK(launch_micp_iter(r->d_ds_points.p, dmask, r->d_points.p, r->d_normals.p, r->d_hits.p, nred, nb, r->d_call,
+          HIPCHK(launch_micp_iter(r->ds_pts, dmask, r->d_points.p, r->d_normals.p, r->d_hits.p, nred, nb, r->d_call,
                                   part[(i + 1u) & 1u], part[i & 1u], r->d_state + (i & 1u), r->d_state + ((i + 1u) & 1u),
                                   i == 0, r->stream));
         // the closing step writes the result straight into host-mapped memory (no copy node)
@@ -1056,8 +1079,8 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
       key.n_iter = n_iter; key.W = r->W; key.H = r->H; key.n_dataset = r->n_dataset;
       key.kind = static_cast<int>(r->kind); key.variant = r->variant; key.tile = r->tile_override;
       key.fused = (r->fused_tail ? 1 : 0) | (r->loop_blocks << 1); key.has_mask = r->ds_has_mask ? 1 : 0;
-      key.ptrs[0] = r->d_points.p; key.ptrs[1] = r->d_ds_points.p; key.ptrs[2] = r->d_partials.p;
-      key.ptrs[3] = r->d_model_tab.p; key.ptrs[4] = r->d_ds_mask.p; key.ptrs[5] = r->d_hits.p;
+      key.ptrs[0] = r->d_points.p; key.ptrs[1] = r->ds_pts; key.ptrs[2] = r->d_partials.p;
+      key.ptrs[3] = r->d_model_tab.p; key.ptrs[4] = r->ds_msk; key.ptrs[5] = r->d_hits.p;
       if (!r->micp_exec || r->graph_dirty || !(key == r->micp_key)) {
         if (r->micp_exec) { (void)hipGraphExecDestroy(r->micp_exec); r->micp_exec = nullptr; }
         if (r->micp_graph) { (void)hipGraphDestroy(r->micp_graph); r->micp_graph = nullptr; }
@@ -1573,6 +1596,50 @@ rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* f, int variant) {
   return RMCLHIP_OK;
 }
 
+
+// PCDSensorUpdaterEmbree::update, beam sampling (PCDSensorUpdaterEmbree.cpp:276-327), on the raw message bytes (host).
+rmclhip_status rmclhip_pf_sample_beams_pointcloud2(const uint8_t* data, size_t nbytes, const rmclhip_pointcloud2_layout* L,
+                                                   uint32_t samples, uint64_t seed, rmclhip_range_measurement* beams_out,
+                                                   uint32_t* n_out) {
+  ApiGuard guard_("rmclhip_pf_sample_beams_pointcloud2");
+  if (!L || !n_out || (!beams_out && samples)) return fail(RMCLHIP_ERR_INVALID, "pf_sample_beams_pointcloud2: null");
+  *n_out = 0;
+  if (L->datatype != 7u && L->datatype != 8u)
+    return fail(RMCLHIP_ERR_UNSUPPORTED, "pf_sample_beams_pointcloud2: Field X has unknown DataType (FLOAT32 / FLOAT64 only)");
+  const uint64_t n_points = static_cast<uint64_t>(L->width) * L->height;
+  if (samples == 0) return RMCLHIP_OK;
+  if (n_points == 0 || !data) return fail(RMCLHIP_ERR_INVALID, "pf_sample_beams_pointcloud2: empty cloud");
+  const uint32_t fsz = (L->datatype == 8u) ? 8u : 4u;
+  const uint32_t max_off = std::max(L->offset_x, std::max(L->offset_y, L->offset_z));
+  const uint64_t last = static_cast<uint64_t>(L->height - 1u) * L->row_step + static_cast<uint64_t>(L->width - 1u) * L->point_step + max_off + fsz;
+  if (last > nbytes) return fail(RMCLHIP_ERR_INVALID, "pf_sample_beams_pointcloud2: cloud data shorter than its layout");
+  // the reference draws from a function-static std::mt19937 seeded by std::random_device through a
+  // std::uniform_int_distribution (implementation defined); pinned here: mt19937(seed), index = draw % n_points
+  std::mt19937 gen(static_cast<uint32_t>(seed));
+  auto load = [&](const uint8_t* p) -> float {
+    if (fsz == 8u) { double d; std::memcpy(&d, p, 8); return static_cast<float>(d); }
+    float f; std::memcpy(&f, p, 4); return f;
+  };
+  for (uint32_t sidx = 0; sidx < samples; ++sidx) {
+    bool valid = false;
+    float x = 0.f, y = 0.f, z = 0.f;
+    for (int t = 0; t < 100 && !valid; ++t) {
+      const uint64_t id = static_cast<uint64_t>(gen()) % n_points;
+      const uint8_t* ptr = data + (id / L->width) * L->row_step + (id % L->width) * L->point_step;
+      x = load(ptr + L->offset_x); y = load(ptr + L->offset_y); z = load(ptr + L->offset_z);
+      valid = (x == x) && (y == y) && (z == z);   // NaN only, like the reference (:303): +-inf passes
+    }
+    if (!valid) break;   // "Point invalid": the reference returns early (:306-311)
+    rmclhip_range_measurement m;
+    std::memset(&m, 0, sizeof(m));
+    const float norm = std::sqrt((x * x + y * y) + z * z);   // rm::Vector3::l2norm
+    m.dir = {x / norm, y / norm, z / norm};                  // rm::Vector3::normalize
+    m.range = norm;
+    m.cov[0] = m.cov[4] = m.cov[8] = 0.1f;                   // Rrs * (Identity * 0.1) * Rrs^T with Trs = Identity
+    beams_out[(*n_out)++] = m;
+  }
+  return RMCLHIP_OK;
+}
 
 // ---- resampling --------------------------------------------------------------------------------
 rmclhip_status rmclhip_resampler_create(rmclhip_ctx* ctx, rmclhip_resampler** out) {

@@ -26,21 +26,26 @@ def beams_from_points(points):
     return out
 
 
+def sample_beams_pointcloud2(data, width, height, point_step, row_step, offset_x, offset_y, offset_z, samples, seed,
+                             datatype=7):
+    """PCDSensorUpdaterEmbree.cpp:276-327 on the raw sensor_msgs/PointCloud2 bytes, through the C ABI
+    (rmclhip_pf_sample_beams_pointcloud2, a host function): `samples` uniformly random points -- std::mt19937(seed),
+    index = draw % (width * height), up to 100 retries for a point without NaN -- as RangeMeasurements."""
+    buf = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8)) if isinstance(data, (bytes, bytearray, memoryview)) \
+        else np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+    L = _capi.PointCloud2Layout(int(width), int(height), int(point_step), int(row_step), int(offset_x), int(offset_y),
+                                int(offset_z), int(datatype))
+    out = np.zeros(int(samples), dtype=RANGE_MEASUREMENT)
+    n = C.c_uint32(0)
+    _capi.check(_capi.lib().rmclhip_pf_sample_beams_pointcloud2(_ptr(buf), buf.size, C.byref(L), int(samples), int(seed),
+                                                               _ptr(out), C.byref(n)))
+    return out[: n.value].copy()
+
+
 def sample_beams(cloud_xyz, samples, seed):
-    """Beam sampling of PCDSensorUpdaterEmbree.cpp:290-311 with an explicit seed:
-    uniform random indices, up to 100 retries for a point without NaN."""
+    """the same sampling on an [n, 3] float32 array (an unorganised cloud: width n, height 1, point_step 12)"""
     pts = np.ascontiguousarray(cloud_xyz, dtype=np.float32).reshape(-1, 3)
-    rng = np.random.RandomState(seed)
-    chosen = []
-    for _ in range(samples):
-        for _try in range(100):
-            i = rng.randint(0, len(pts))
-            if not np.isnan(pts[i]).any():   # x==x && y==y && z==z (PCDSensorUpdaterEmbree.cpp:303): +-inf passes
-                chosen.append(i)
-                break
-        else:
-            break  # "Point invalid": the reference returns early
-    return beams_from_points(pts[chosen])
+    return sample_beams_pointcloud2(pts.view(np.uint8).reshape(-1), len(pts), 1, 12, 12 * len(pts), 0, 4, 8, samples, seed)
 
 
 def combined_forget_rate(forget_rate_per_meter, forget_rate_per_second, dist_travelled, dt):

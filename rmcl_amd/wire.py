@@ -60,17 +60,7 @@ def xyz_from_pointcloud2(data, n_points, point_step, offset_x, offset_y, offset_
 
 
 def sample_beams_pointcloud2(data, n_points, point_step, offset_x, offset_y, offset_z, samples, seed, datatype=FLOAT32):
-    """PCDSensorUpdaterEmbree.cpp:290-327 on the raw message bytes: `samples` uniformly random points (each with up
-    to 100 retries for one without NaN) become RangeMeasurements {orig 0, dir = p / |p|, range = |p|}."""
-    pts = xyz_from_pointcloud2(data, n_points, point_step, offset_x, offset_y, offset_z, datatype)
-    rng = np.random.RandomState(seed)
-    chosen = []
-    for _ in range(samples):
-        for _try in range(100):
-            i = rng.randint(0, n_points)
-            if not np.isnan(pts[i]).any():   # x==x && y==y && z==z (PCDSensorUpdaterEmbree.cpp:303): +-inf passes
-                chosen.append(i)
-                break
-        else:
-            break
-    return beams_from_points(pts[chosen])
+    """PCDSensorUpdaterEmbree.cpp:290-327 on the raw message bytes (cloud treated as n_points x 1 like the reference's
+    `random_point_id * point_step` addressing), through the C ABI sampler (rmclhip_pf_sample_beams_pointcloud2)."""
+    from .pf import sample_beams_pointcloud2 as _sample
+    return _sample(data, n_points, 1, point_step, point_step * n_points, offset_x, offset_y, offset_z, samples, seed, datatype)

@@ -72,6 +72,17 @@ def test_cpp_example_matches_python_and_oracle(ra, orc, ctx, meshes, tmp_path):
     q = np.array([float(x) for x in out["host_loop_q"]])
     q_ref = np.array([float(To["R"][k]) for k in "xyzw"])
     assert np.allclose(q, q_ref * np.sign(np.dot(q, q_ref)), atol=1e-5)
+    # Correspondences_::dataset written like the reference's device sensors write it == the setDataset*() hand-over
+    assert int(out["dataset_member_valid"][0]) == int(mask.sum())
+    assert out["dataset_member_n_meas"][0] == out["dataset_member_n_meas"][1] and int(out["dataset_member_n_meas"][0]) > 0
+    assert out["dataset_member_cov00"][0] == out["dataset_member_cov00"][1]
+    assert [int(x) for x in out["dataset_view"]] == [1024, 1024]
+    # beams sampled from the raw PointCloud2 bytes by the C ABI == the oracle's sampler on the same bytes
+    cloud = np.zeros((1024, 4), np.float32)
+    cloud[:, :3] = meas["points"]
+    ob = orc.sample_beams_pointcloud2(cloud.tobytes(), 1024, 1, 16, 16 * 1024, 0, 4, 8, 40, 1234)
+    assert int(out["sampled_beams"][0]) == len(ob) == 40
+    assert abs(float(out["sampled_beams"][1]) - float(ob["range"].astype(np.float64).sum())) < 1e-4
     # particle filter part
     poses = np.array([truth, est, T.transform_from_rpy((1, 1, 0), (0, 0, 1.0)), T.transform_from_rpy((-2, 0.5, 0.3), (0, 0, -2.0))],
                      dtype=T.TRANSFORM)

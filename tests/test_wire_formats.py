@@ -57,6 +57,11 @@ def test_wire_field_mappings(ra):
         assert len(beams) == 20 and np.isfinite(beams["range"]).all()
         ref = ra.sample_beams(xyz, 20, seed=3)
         assert beams.tobytes() == ref.tobytes()
+        # ... and the C-ABI sampler (librmclhip, std::mt19937) draws exactly what the oracle's own MT19937 restatement draws
+        import oracle as orc
+        oref = orc.sample_beams_pointcloud2(a.tobytes(), 36, 1, rec.itemsize, 36 * rec.itemsize, rec.fields["x"][1],
+                                            rec.fields["y"][1], rec.fields["z"][1], 20, 3, datatype=dt)
+        assert beams.tobytes() == oref.tobytes()
 
 
 @pytest.mark.gpu
@@ -105,3 +110,37 @@ def test_pointcloud2_input_equals_model_plus_dataset(ra, orc, ctx, meshes, rec, 
     assert a_rcc.modelView()["face_ids"].tobytes() == outs[1][0]["face_ids"].tobytes()
     with pytest.raises(ra.RmclHipError):
         a_rcc.setInputPointCloud2(a.tobytes()[:100], Wd, H, rec.itemsize, rec.itemsize * Wd, ox, oy, oz, dt)
+
+
+def test_beam_sampler_stream_and_edge_cases(ra):
+    """the pinned random stream of the C-ABI beam sampler: MT19937 known answers (the 10000th output of the default-seeded
+    engine is 4123659995, ISO C++ [rand.predef]), index = draw % n_points, retry on NaN only, early return when a sample
+    stays invalid, organised clouds with row padding."""
+    import oracle as orc
+    assert orc.mt19937_draw(5489, 9999) == 4123659995
+    assert orc.mt19937_draw(5489, 0) == 3499211612
+    W = ra.wire
+    # organised 3 x 5 cloud with 8 B of row padding and an intensity field before xyz
+    rec = np.dtype([("i", "<f4"), ("x", "<f4"), ("y", "<f4"), ("z", "<f4")])
+    rows = []
+    rng = np.random.RandomState(0)
+    a = np.zeros((3, 5), rec)
+    for k in "xyz":
+        a[k] = rng.uniform(-4, 4, (3, 5))
+    a["x"][1, 2] = np.inf                       # +-inf is NOT retried by the reference (x == x): it comes through
+    raw = b"".join(a[r].tobytes() + b"\0" * 8 for r in range(3))
+    row_step = 5 * rec.itemsize + 8
+    beams = ra.pf.sample_beams_pointcloud2(raw, 5, 3, rec.itemsize, row_step, 4, 8, 12, samples=200, seed=77)
+    oref = orc.sample_beams_pointcloud2(raw, 5, 3, rec.itemsize, row_step, 4, 8, 12, 200, 77)
+    assert len(beams) == 200 and beams.tobytes() == oref.tobytes()
+    ids = [orc.mt19937_draw(77, k) % 15 for k in range(200)]
+    pts = np.stack([a[k].reshape(-1) for k in "xyz"], 1)[ids]
+    exp = ra.beams_from_points(pts)
+    fin = np.isfinite(pts).all(1)
+    assert np.array_equal(beams["range"][fin], exp["range"][fin]) and np.isinf(beams["range"][~fin]).all() and (~fin).any()
+    # a cloud of NaNs: every retry fails, the sampler stops like the reference ("Point invalid", :306-311)
+    nan_cloud = np.full((10, 3), np.nan, np.float32)
+    assert len(ra.sample_beams(nan_cloud, 5, seed=1)) == 0
+    # short buffers are an error, not a read past the end
+    with pytest.raises(ra._capi.RmclHipError):
+        ra.pf.sample_beams_pointcloud2(raw[:40], 5, 3, rec.itemsize, row_step, 4, 8, 12, samples=3, seed=1)
