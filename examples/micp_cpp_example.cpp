@@ -166,6 +166,20 @@ int main(int argc, char** argv) {
       for (const auto& bm : upd2.beams()) range_sum += bm.range;
       std::printf("sampled_beams %zu %.9g\n", nb, range_sum);
     }
+    // the same update through the multi-device form (one process, here one device): weights, {sum, max}, pose estimate
+    {
+      std::vector<ParticleAttributes> attrs0(poses.size());
+      for (auto& a : attrs0) { a = ParticleAttributes{}; a.likelihood.mean = 1.0f; }
+      PCDSensorUpdaterHipSharded sharded({0}, verts.data(), nv, faces.data(), nf);
+      sharded.setParticles(poses, attrs0);
+      sharded.setInput(beams, Tsb);
+      sharded.update();
+      const std::vector<float> w = sharded.weights();
+      const rmclhip_likelihood_stats sst = sharded.computeStats();
+      const rmclhip_pose_estimate est = sharded.estimateStats(1000000);
+      std::printf("sharded_world %u\nsharded_w %.9g %.9g %.9g %.9g\nsharded_stats %.9g %.9g\nsharded_pose_t %.9g %.9g %.9g\n",
+                  sharded.worldSize(), w[0], w[1], w[2], w[3], sst.sum, sst.max, est.pose.t.x, est.pose.t.y, est.pose.t.z);
+    }
     // motion update (30 cm forward, 1 % forgetting, wall-collision test) and one gladiator tournament
     TFMotionUpdaterHip motion(map);
     const DeviceView<Transform> vposes{static_cast<Transform*>(d_poses), poses.size()};

@@ -469,6 +469,77 @@ class PCDSensorUpdaterHip : public SensorUpdaterBase, public ParticleUpdater<VRA
   Transform Tsb_ = identity();
 };
 
+// The particle filter of ONE process over several devices (rmclhip_comm + rmclhip_pf_sharded: RCCL ncclCommInitAll, weight
+// all-gather, moment all-reduces): sensor update, pose estimate (RmclNode::estimateStats, rmcl_localization.cpp:642-731) and
+// the distributed gladiator tournament for the single-process node (rmcl_localization.cpp:482-552).  The cloud lives in the
+// object (block-partitioned over the devices); setParticles / download move it from / to the node's host store.
+class PCDSensorUpdaterHipSharded : public SensorUpdaterBase {
+ public:
+  rmclhip_pf_params config_{2.0f, 100.0f, 100.0f, 0.0f, {0.05f, 80.0f}, 10000u, 0u};
+
+  PCDSensorUpdaterHipSharded(const std::vector<int>& devices, const float* vertices_xyz, uint32_t n_vertices,
+                             const uint32_t* faces_ijk, uint32_t n_faces) {
+    check(rmclhip_comm_create(devices.data(), static_cast<uint32_t>(devices.size()), &comm_));
+    const rmclhip_status st = rmclhip_pf_sharded_create(comm_, vertices_xyz, n_vertices, faces_ijk, n_faces, &h_);
+    if (st != RMCLHIP_OK) {
+      const std::string msg = rmclhip_last_error();
+      rmclhip_comm_destroy(comm_);
+      throw std::runtime_error(msg);
+    }
+  }
+  ~PCDSensorUpdaterHipSharded() override {
+    rmclhip_pf_sharded_destroy(h_);
+    rmclhip_comm_destroy(comm_);
+  }
+  PCDSensorUpdaterHipSharded(const PCDSensorUpdaterHipSharded&) = delete;
+  PCDSensorUpdaterHipSharded& operator=(const PCDSensorUpdaterHipSharded&) = delete;
+  void init() override {}
+  uint32_t worldSize() const { return rmclhip_comm_size(comm_); }
+  void setParticles(const std::vector<Transform>& poses, const std::vector<ParticleAttributes>& attrs) {
+    if (poses.size() != attrs.size()) throw std::runtime_error("setParticles: poses.size() != attrs.size()");
+    check(rmclhip_pf_sharded_set_particles(h_, poses.data(), attrs.data(), static_cast<uint32_t>(poses.size())));
+    n_ = poses.size();
+  }
+  void download(std::vector<Transform>& poses, std::vector<ParticleAttributes>& attrs) const {
+    poses.resize(n_);
+    attrs.resize(n_);
+    check(rmclhip_pf_sharded_download(h_, poses.data(), attrs.data()));
+  }
+  void setInput(std::vector<RangeMeasurement> beams, const Transform& Tsb) {
+    beams_ = std::move(beams);
+    Tsb_ = Tsb;
+  }
+  // sensor update on every device's block + ONE all-gather of the weights
+  ParticleUpdateResults update(const ParticleUpdateConfig& = {}) {
+    check(rmclhip_pf_sharded_set_params(h_, &config_));
+    check(rmclhip_pf_update_sharded(h_, beams_.data(), static_cast<uint32_t>(beams_.size()), &Tsb_));
+    return {};
+  }
+  std::vector<float> weights(uint32_t rank = 0) const {
+    std::vector<float> w(n_);
+    check(rmclhip_pf_sharded_get_weights(h_, rank, w.data()));
+    return w;
+  }
+  rmclhip_likelihood_stats computeStats() const {
+    rmclhip_likelihood_stats st{};
+    check(rmclhip_pf_allreduce_stats(h_, &st));
+    return st;
+  }
+  rmclhip_pose_estimate estimateStats(uint32_t max_induction_particles) const {
+    rmclhip_pose_estimate e{};
+    check(rmclhip_pf_allreduce_pose_estimate(h_, max_induction_particles, &e));
+    return e;
+  }
+  void resample(const rmclhip_gladiator_config& cfg, uint64_t seed, uint32_t step) { check(rmclhip_pf_sharded_resample(h_, &cfg, seed, step)); }
+
+ private:
+  rmclhip_comm* comm_ = nullptr;
+  rmclhip_pf_sharded* h_ = nullptr;
+  size_t n_ = 0;
+  std::vector<RangeMeasurement> beams_;
+  Transform Tsb_ = identity();
+};
+
 // rmcl::TFMotionUpdaterGPU (+ the wall-collision test of TFMotionUpdaterCPU) on gfx950: MotionUpdater<MemT>.
 // The odometry lookup (TF) and the forget rate (TFMotionUpdaterCPU.cpp:172-174) stay with the caller.
 class TFMotionUpdaterHip : public SensorUpdaterBase {

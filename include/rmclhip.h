@@ -106,6 +106,15 @@ typedef struct {
 } rmclhip_gladiator_config;
 /* rmcl::SimpleLikelihoodStats (resampling.cuh:26-30) */
 typedef struct { float sum, max; } rmclhip_likelihood_stats;
+/* rmcl_msgs/ParticleStats as RmclNode::estimateStats fills it (rmcl_localization.cpp:642-731) */
+typedef struct {
+  rmclhip_transform pose;           /* rm::markley_mean of the poses, weights likelihood.mean / sum (:703-705) */
+  double covariance[36];            /* rm::covariance around that mean (:716-718), row-major 6x6: x y z roll pitch yaw */
+  double likelihood_mean, likelihood_sigma, likelihood_min, likelihood_max;   /* :664-689 */
+  float trans_bb_min[3], trans_bb_max[3];
+  uint32_t n_particles;             /* min(n_particles, max_induction_particles) */
+  uint32_t reserved;
+} rmclhip_pose_estimate;
 
 typedef struct {
   uint32_t n_faces, n_vertices;
@@ -122,6 +131,8 @@ typedef struct rmclhip_map rmclhip_map;
 typedef struct rmclhip_rcc rmclhip_rcc;
 typedef struct rmclhip_pf rmclhip_pf;
 typedef struct rmclhip_resampler rmclhip_resampler;
+typedef struct rmclhip_comm rmclhip_comm;              /* RCCL communicators of one process driving several devices */
+typedef struct rmclhip_pf_sharded rmclhip_pf_sharded;  /* a particle cloud block-partitioned over those devices */
 
 /* ---- library ------------------------------------------------------------------ */
 const char* rmclhip_last_error(void);
@@ -374,6 +385,44 @@ rmclhip_status rmclhip_resampler_gladiator(rmclhip_resampler* rs, const rmclhip_
                                            rmclhip_transform* poses_new_dev, rmclhip_particle_attributes* attrs_new_dev,
                                            uint32_t first, uint32_t count, const rmclhip_gladiator_config* config,
                                            uint64_t seed, uint32_t step);
+
+/* ---- multi-GPU: ONE process drives several devices -------------------------------------------------------------
+ * (the reference's localisation node is one process: rmcl_localization.cpp:482-552; particle store rmcl_localization.hpp:65-77.
+ * The reference has no distributed code -- SURVEY.md 8(e) defines this part.)  Particles are block-partitioned over the
+ * devices, mesh + BVH are replicated (built once), beams are identical everywhere; exchanges are RCCL collectives over xGMI
+ * (librccl is loaded with dlopen by rmclhip_comm_create: single-GPU users never touch it). */
+/* devices: HIP device indices (NULL = 0 .. ndev-1).  ncclCommInitAll. */
+rmclhip_status rmclhip_comm_create(const int* devices, uint32_t ndev, rmclhip_comm** out);
+void rmclhip_comm_destroy(rmclhip_comm* comm);
+uint32_t rmclhip_comm_size(const rmclhip_comm* comm);
+/* contiguous block partition of [0, n): rank owns [lo, hi); the first n % world ranks own one extra element */
+void rmclhip_shard_bounds(uint32_t n, uint32_t rank, uint32_t world, uint32_t* lo, uint32_t* hi);
+/* one context + map replica + sensor updater + resampler per device of the communicator */
+rmclhip_status rmclhip_pf_sharded_create(rmclhip_comm* comm, const float* vertices_xyz, uint32_t n_vertices,
+                                         const uint32_t* faces_ijk, uint32_t n_faces, rmclhip_pf_sharded** out);
+void rmclhip_pf_sharded_destroy(rmclhip_pf_sharded* pf);
+rmclhip_status rmclhip_pf_sharded_set_params(rmclhip_pf_sharded* pf, const rmclhip_pf_params* params);
+/* scatter the (host) cloud: rank r receives particles [lo_r, hi_r) */
+rmclhip_status rmclhip_pf_sharded_set_particles(rmclhip_pf_sharded* pf, const rmclhip_transform* poses,
+                                                const rmclhip_particle_attributes* attrs, uint32_t n_total);
+rmclhip_status rmclhip_pf_sharded_download(rmclhip_pf_sharded* pf, rmclhip_transform* poses, rmclhip_particle_attributes* attrs);
+/* PCDSensorUpdater*::update on every device's block (concurrently), then rmclhip_pf_allgather_weights */
+rmclhip_status rmclhip_pf_update_sharded(rmclhip_pf_sharded* pf, const rmclhip_range_measurement* beams, uint32_t n_beams,
+                                         const rmclhip_transform* Tsb);
+/* ONE ncclAllGather of likelihood.mean (4 B x N on equal padded shards): afterwards every device holds the dense weight
+ * vector of the whole cloud; rmclhip_pf_sharded_get_weights copies rank's copy to the host */
+rmclhip_status rmclhip_pf_allgather_weights(rmclhip_pf_sharded* pf);
+rmclhip_status rmclhip_pf_sharded_get_weights(rmclhip_pf_sharded* pf, uint32_t rank, float* weights_host);
+/* global {sum, max}: simple_stats_kernel (resampling.cu:41-92) as an all-reduce of per-device partials */
+rmclhip_status rmclhip_pf_allreduce_stats(rmclhip_pf_sharded* pf, rmclhip_likelihood_stats* out);
+/* RmclNode::estimateStats (rmcl_localization.cpp:642-731) over the first n_induction particles: three passes of per-device
+ * moments (<= 24 doubles each: likelihood sums + bounding box, weighted quaternion outer products + translations for the
+ * Markley mean, 6x6 covariance around it), each followed by one ncclAllReduce */
+rmclhip_status rmclhip_pf_allreduce_pose_estimate(rmclhip_pf_sharded* pf, uint32_t n_induction, rmclhip_pose_estimate* out);
+/* distributed GladiatorResamplerGPU::update: all-gather of the 68-B particle records, then every device resamples its own
+ * champions against the gathered cloud (Philox counter = GLOBAL champion index => identical to one GPU).  n_total must
+ * be a multiple of the device count. */
+rmclhip_status rmclhip_pf_sharded_resample(rmclhip_pf_sharded* pf, const rmclhip_gladiator_config* config, uint64_t seed, uint32_t step);
 
 /* ---- device memory helpers for hosts without their own allocator ---------------------- */
 rmclhip_status rmclhip_malloc(rmclhip_ctx* ctx, size_t bytes, void** out_dev);

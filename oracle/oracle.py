@@ -579,3 +579,37 @@ def mt19937_draw(seed, n_skip=0):
     L.orc_mt19937_draw.restype = C.c_uint32
     L.orc_mt19937_draw.argtypes = [C.c_uint32, C.c_uint32]
     return int(L.orc_mt19937_draw(seed & 0xFFFFFFFF, n_skip))
+
+
+def estimate_stats(poses, attrs, max_induction_particles=None):
+    """RmclNode::estimateStats (rmcl_ros/src/nodes/rmcl_localization.cpp:642-731) restated in double precision numpy.
+    rm::markley_mean / rm::covariance are EXTERNAL (rmagine): restated as the published algorithms -- Markley et al. 2007:
+    the mean rotation is the eigenvector of the largest eigenvalue of sum w q q^T, the mean translation sum w t; the 6x6
+    covariance is sum w d d^T with d = (translation, roll, pitch, yaw) of ~Tbm * T_i (parity unpinned)."""
+    n = len(poses) if max_induction_particles is None else min(len(poses), int(max_induction_particles))
+    P, A = poses[:n], attrs[:n]
+    L = A["likelihood"]["mean"].astype(np.float64)
+    L_sum, L_n = L.sum(), float(n)
+    L_mean = L_sum / L_n
+    t = np.stack([P["t"][k] for k in "xyz"], 1).astype(np.float64)
+    q = np.stack([P["R"][k] for k in "xyzw"], 1).astype(np.float64)
+    out = {"likelihood": {"mean": L_mean, "sigma": float(np.sqrt(max((L * L).sum() / L_n - L_mean * L_mean, 0.0))),
+                          "min": float(L.min()), "max": float(max(L.max(), 0.0))},
+           "trans_bb_min": t.min(0), "trans_bb_max": t.max(0), "nparticles": n}
+    w = L / L_sum
+    M = (q * w[:, None]).T @ q
+    ev, evec = np.linalg.eigh(M)
+    qm = evec[:, -1]
+    if qm[3] < 0:
+        qm = -qm
+    tm = (t * w[:, None]).sum(0)
+    Tbm = transform(qm, tm)
+    out["pose"] = Tbm
+    Tmb = tinv(Tbm)
+    d = np.zeros((n, 6))
+    for i in range(n):
+        Td = tmult(Tmb, P[i])
+        d[i, :3] = [Td["t"][k] for k in "xyz"]
+        d[i, 3:] = quat_to_euler(Td["R"])
+    out["covariance"] = (d * w[:, None]).T @ d
+    return out

@@ -6,8 +6,9 @@ library is built, computing needs a HIP device.
 from . import _capi, types, synthetic, wire  # noqa: F401
 from ._capi import NoDeviceError, RmclHipError  # noqa: F401
 from .micp import MICPLocalization, MICPSensor  # noqa: F401
-from .pf import (GladiatorResamplerHip, PCDSensorUpdaterHip, TFMotionUpdaterHip, beams_from_points, combined_forget_rate,  # noqa: F401
-                 sample_beams)
+from . import pf  # noqa: F401
+from .pf import (GladiatorResamplerHip, PCDSensorUpdaterHip, ShardedParticleFilterHip, TFMotionUpdaterHip,  # noqa: F401
+                 beams_from_points, combined_forget_rate, sample_beams)
 from .registration import (CPCHip, Context, CorrespondencesHIP, DeviceArray, HipMap, MapMap, RCCHipO1Dn,  # noqa: F401
                            RCCHipOnDn, RCCHipPinhole, RCCHipSpherical, build_bvh_host, build_bvh_host_quantised,
                            import_hip_map)

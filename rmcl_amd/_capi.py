@@ -67,6 +67,13 @@ class LikelihoodStats(C.Structure):
     _fields_ = [("sum", C.c_float), ("max", C.c_float)]
 
 
+class PoseEstimate(C.Structure):
+    _fields_ = [("pose", C.c_float * 8), ("covariance", C.c_double * 36), ("likelihood_mean", C.c_double),
+                ("likelihood_sigma", C.c_double), ("likelihood_min", C.c_double), ("likelihood_max", C.c_double),
+                ("trans_bb_min", C.c_float * 3), ("trans_bb_max", C.c_float * 3), ("n_particles", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
 class MapInfo(C.Structure):
     _fields_ = [("n_faces", C.c_uint32), ("n_vertices", C.c_uint32), ("n_nodes", C.c_uint32),
                 ("n_tri_records", C.c_uint32), ("max_depth", C.c_uint32), ("stack_need", C.c_uint32),
@@ -143,6 +150,21 @@ SIGNATURES = {
     "rmclhip_resampler_compute_stats": (_i32, [_vp, _vp, _u32, C.POINTER(LikelihoodStats)]),
     "rmclhip_resampler_gladiator": (_i32, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, C.POINTER(GladiatorConfig),
                                             C.c_uint64, _u32]),
+    "rmclhip_comm_create": (_i32, [_vp, _u32, _pp]),
+    "rmclhip_comm_destroy": (None, [_vp]),
+    "rmclhip_comm_size": (_u32, [_vp]),
+    "rmclhip_shard_bounds": (None, [_u32, _u32, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
+    "rmclhip_pf_sharded_create": (_i32, [_vp, _vp, _u32, _vp, _u32, _pp]),
+    "rmclhip_pf_sharded_destroy": (None, [_vp]),
+    "rmclhip_pf_sharded_set_params": (_i32, [_vp, C.POINTER(PFParams)]),
+    "rmclhip_pf_sharded_set_particles": (_i32, [_vp, _vp, _vp, _u32]),
+    "rmclhip_pf_sharded_download": (_i32, [_vp, _vp, _vp]),
+    "rmclhip_pf_update_sharded": (_i32, [_vp, _vp, _u32, _vp]),
+    "rmclhip_pf_allgather_weights": (_i32, [_vp]),
+    "rmclhip_pf_sharded_get_weights": (_i32, [_vp, _u32, _vp]),
+    "rmclhip_pf_allreduce_stats": (_i32, [_vp, C.POINTER(LikelihoodStats)]),
+    "rmclhip_pf_allreduce_pose_estimate": (_i32, [_vp, _u32, C.POINTER(PoseEstimate)]),
+    "rmclhip_pf_sharded_resample": (_i32, [_vp, C.POINTER(GladiatorConfig), C.c_uint64, _u32]),
     "rmclhip_malloc": (_i32, [_vp, _sz, _pp]),
     "rmclhip_free": (_i32, [_vp, _vp]),
     "rmclhip_memcpy_h2d": (_i32, [_vp, _vp, _vp, _sz]),

@@ -2,6 +2,8 @@
 // Host-side orchestration only: device memory, streams, launches.  There is no CPU compute
 // path here: without a HIP device every compute entry point fails with RMCLHIP_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types only: the library is resolved with dlopen when the first communicator is created
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -224,6 +226,8 @@ struct rmclhip_resampler {
 
 extern "C" {
 
+static rmclhip_status map_upload(rmclhip_ctx* ctx, const BvhHost& bvh, rmclhip_map** out);
+
 const char* rmclhip_last_error(void) { return g_err.c_str(); }
 const char* rmclhip_version(void) { return "rmclhip 0.1 (gfx950)"; }
 
@@ -313,6 +317,11 @@ rmclhip_status rmclhip_map_create(rmclhip_ctx* ctx, const float* v, uint32_t nv,
   BvhHost bvh;
   const std::string err = build_bvh(v, nv, f, nf, bvh);
   if (!err.empty()) return fail(RMCLHIP_ERR_INVALID, "map_create: " + err);
+  return map_upload(ctx, bvh, out);
+}
+
+// device copy of a built BVH (one build can serve several devices: rmclhip_pf_sharded_create)
+static rmclhip_status map_upload(rmclhip_ctx* ctx, const BvhHost& bvh, rmclhip_map** out) {
   if (bvh.info.stack_need > 64)
     return fail(RMCLHIP_ERR_UNSUPPORTED, "map_create: BVH needs a traversal stack deeper than 64 entries");
   if (static_cast<uint64_t>(bvh.nodes.size()) * sizeof(Node4) >= (1ull << 32))
@@ -1714,6 +1723,444 @@ rmclhip_status rmclhip_resampler_gladiator(rmclhip_resampler* r, const rmclhip_t
                                    reinterpret_cast<xform*>(poses_new_dev), attrs_new_dev, first, count, c8,
                                    cfg->trans_dist_metric, seed, step, r->stream));
   HIPCHK(hipStreamSynchronize(r->stream));
+  return RMCLHIP_OK;
+}
+
+// ---- multi-GPU: one process drives ndev devices (the reference's localisation node is one process,
+// rmcl_localization.cpp:482-552); RCCL communicators of ncclCommInitAll, resolved with dlopen so that single-GPU users never
+// load the library ---------------------------------------------------------------------------------------------
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+
+static bool rccl_load(std::string& err) {
+  if (g_rccl.lib) return true;
+  void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) { err = std::string("dlopen(librccl.so.1): ") + dlerror(); return false; }
+#define RCCL_SYM(field, name)                                                       \
+  g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(lib, name));        \
+  if (!g_rccl.field) { err = std::string("librccl lacks ") + name; dlclose(lib); return false; }
+  RCCL_SYM(CommInitAll, "ncclCommInitAll") RCCL_SYM(CommDestroy, "ncclCommDestroy") RCCL_SYM(AllGather, "ncclAllGather")
+  RCCL_SYM(AllReduce, "ncclAllReduce") RCCL_SYM(GroupStart, "ncclGroupStart") RCCL_SYM(GroupEnd, "ncclGroupEnd")
+  RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef RCCL_SYM
+  g_rccl.lib = lib;
+  return true;
+}
+
+#define NCCLCHK(expr)                                                                                          \
+  do {                                                                                                         \
+    const ncclResult_t r_ = (expr);                                                                            \
+    if (r_ != ncclSuccess) return fail(RMCLHIP_ERR_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
+  } while (0)
+
+}  // extern "C" (the structs below are C++)
+
+struct rmclhip_comm {
+  std::vector<int> devices;
+  std::vector<ncclComm_t> comms;
+  std::vector<hipStream_t> streams;   // one collective stream per device
+};
+
+struct PfRank {
+  rmclhip_ctx* ctx = nullptr;
+  rmclhip_map* map = nullptr;
+  rmclhip_pf* pf = nullptr;
+  rmclhip_resampler* rs = nullptr;
+  uint32_t lo = 0, hi = 0;
+  xform* d_poses = nullptr; void* d_attrs = nullptr;          // this rank's shard (cap particles)
+  xform* d_poses_new = nullptr; void* d_attrs_new = nullptr;  // tournament output
+  xform* d_poses_all = nullptr; void* d_attrs_all = nullptr;  // gathered cloud (world * cap), distributed tournament
+  float* d_w_send = nullptr;   // cap
+  float* d_w_pad = nullptr;    // world * cap (all-gather layout)
+  float* d_w_all = nullptr;    // n_total, dense
+  double* d_mom_part = nullptr;  // 256 * 32
+  double* d_mom = nullptr;       // 32 (+ 32 reduced)
+  double* h_mom = nullptr;       // pinned 32
+};
+
+struct rmclhip_pf_sharded {
+  rmclhip_comm* comm = nullptr;
+  uint32_t n_total = 0, cap = 0;
+  std::vector<PfRank> ranks;
+  rmclhip_pf_params params{2.0f, 100.0f, 100.0f, 0.0f, {0.05f, 80.0f}, 10000u, 0u};
+};
+
+extern "C" {
+
+static void shard_bounds(uint32_t n, uint32_t rank, uint32_t world, uint32_t* lo, uint32_t* hi) {
+  const uint32_t base = n / world, rem = n % world;
+  *lo = rank * base + std::min(rank, rem);
+  *hi = *lo + base + (rank < rem ? 1u : 0u);
+}
+
+void rmclhip_shard_bounds(uint32_t n, uint32_t rank, uint32_t world, uint32_t* lo, uint32_t* hi) {
+  if (world == 0 || !lo || !hi) return;
+  shard_bounds(n, rank, world, lo, hi);
+}
+
+rmclhip_status rmclhip_comm_create(const int* devices, uint32_t ndev, rmclhip_comm** out) {
+  ApiGuard guard_("rmclhip_comm_create");
+  if (!out) return fail(RMCLHIP_ERR_INVALID, "comm_create: out is null");
+  *out = nullptr;
+  if (ndev == 0 || ndev > 64) return fail(RMCLHIP_ERR_INVALID, "comm_create: ndev must be 1..64");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(RMCLHIP_ERR_NO_DEVICE, "no HIP device available (librmclhip has no CPU fallback)");
+  std::vector<int> devs(ndev);
+  for (uint32_t i = 0; i < ndev; ++i) {
+    devs[i] = devices ? devices[i] : static_cast<int>(i);
+    if (devs[i] < 0 || devs[i] >= count) return fail(RMCLHIP_ERR_INVALID, "comm_create: device index out of range");
+    for (uint32_t j = 0; j < i; ++j)
+      if (devs[j] == devs[i]) return fail(RMCLHIP_ERR_INVALID, "comm_create: duplicate device");
+  }
+  std::string err;
+  if (!rccl_load(err)) return fail(RMCLHIP_ERR_UNSUPPORTED, "comm_create: " + err);
+  rmclhip_comm* c = new rmclhip_comm();
+  c->devices = devs;
+  c->comms.resize(ndev);
+  const ncclResult_t r = g_rccl.CommInitAll(c->comms.data(), static_cast<int>(ndev), devs.data());
+  if (r != ncclSuccess) {
+    delete c;
+    return fail(RMCLHIP_ERR_HIP, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
+  }
+  c->streams.resize(ndev);
+  for (uint32_t i = 0; i < ndev; ++i) {
+    (void)hipSetDevice(devs[i]);
+    if (hipStreamCreateWithFlags(&c->streams[i], hipStreamNonBlocking) != hipSuccess) {
+      rmclhip_comm_destroy(c);
+      return fail(RMCLHIP_ERR_HIP, "comm_create: hipStreamCreate failed");
+    }
+  }
+  *out = c;
+  return RMCLHIP_OK;
+}
+
+void rmclhip_comm_destroy(rmclhip_comm* c) {
+  if (!c) return;
+  for (size_t i = 0; i < c->devices.size(); ++i) {
+    (void)hipSetDevice(c->devices[i]);
+    if (i < c->streams.size() && c->streams[i]) { (void)hipStreamSynchronize(c->streams[i]); (void)hipStreamDestroy(c->streams[i]); }
+    if (i < c->comms.size() && c->comms[i] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comms[i]);
+  }
+  delete c;
+}
+
+uint32_t rmclhip_comm_size(const rmclhip_comm* c) { return c ? static_cast<uint32_t>(c->devices.size()) : 0u; }
+
+void rmclhip_pf_sharded_destroy(rmclhip_pf_sharded* h) {
+  if (!h) return;
+  for (PfRank& R : h->ranks) {
+    if (R.ctx) (void)hipSetDevice(R.ctx->device);
+    void* bufs[] = {R.d_poses, R.d_attrs, R.d_poses_new, R.d_attrs_new, R.d_poses_all, R.d_attrs_all, R.d_w_send, R.d_w_pad,
+                    R.d_w_all, R.d_mom_part, R.d_mom};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (R.h_mom) (void)hipHostFree(R.h_mom);
+    if (R.rs) rmclhip_resampler_destroy(R.rs);
+    if (R.pf) rmclhip_pf_destroy(R.pf);
+    if (R.map) rmclhip_map_release(R.map);
+    if (R.ctx) rmclhip_ctx_destroy(R.ctx);
+  }
+  delete h;
+}
+
+rmclhip_status rmclhip_pf_sharded_create(rmclhip_comm* comm, const float* v, uint32_t nv, const uint32_t* f, uint32_t nf,
+                                         rmclhip_pf_sharded** out) {
+  ApiGuard guard_("rmclhip_pf_sharded_create");
+  if (!out) return fail(RMCLHIP_ERR_INVALID, "pf_sharded_create: out is null");
+  *out = nullptr;
+  if (!comm) return fail(RMCLHIP_ERR_INVALID, "pf_sharded_create: null communicator");
+  BvhHost bvh;   // built ONCE, uploaded to every device (mesh + BVH replicated)
+  const std::string err = build_bvh(v, nv, f, nf, bvh);
+  if (!err.empty()) return fail(RMCLHIP_ERR_INVALID, "pf_sharded_create: " + err);
+  rmclhip_pf_sharded* h = new rmclhip_pf_sharded();
+  h->comm = comm;
+  h->ranks.resize(comm->devices.size());
+  for (size_t r = 0; r < h->ranks.size(); ++r) {
+    PfRank& R = h->ranks[r];
+    rmclhip_status st = rmclhip_ctx_create(comm->devices[r], &R.ctx);
+    if (st == RMCLHIP_OK) st = map_upload(R.ctx, bvh, &R.map);
+    if (st == RMCLHIP_OK) st = rmclhip_pf_create(R.ctx, R.map, &R.pf);
+    if (st == RMCLHIP_OK) st = rmclhip_resampler_create(R.ctx, &R.rs);
+    hipError_t e = hipSuccess;
+    if (st == RMCLHIP_OK) e = hipMalloc(reinterpret_cast<void**>(&R.d_mom_part), 256 * 32 * sizeof(double));
+    if (st == RMCLHIP_OK && e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&R.d_mom), 64 * sizeof(double));
+    if (st == RMCLHIP_OK && e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&R.h_mom), 64 * sizeof(double), hipHostMallocDefault);
+    if (st != RMCLHIP_OK || e != hipSuccess) {
+      const std::string msg = (st != RMCLHIP_OK) ? g_err : std::string(hipGetErrorString(e));
+      rmclhip_pf_sharded_destroy(h);
+      return fail(st != RMCLHIP_OK ? st : RMCLHIP_ERR_HIP, "pf_sharded_create: " + msg);
+    }
+  }
+  *out = h;
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_pf_sharded_set_params(rmclhip_pf_sharded* h, const rmclhip_pf_params* p) {
+  if (!h || !p) return fail(RMCLHIP_ERR_INVALID, "pf_sharded_set_params: null");
+  for (PfRank& R : h->ranks)
+    if (rmclhip_status st = rmclhip_pf_set_params(R.pf, p)) return st;
+  h->params = *p;
+  return RMCLHIP_OK;
+}
+
+// contiguous block partition of the particle range; shards are padded to `cap` so that the collectives
+// run on equal counts
+rmclhip_status rmclhip_pf_sharded_set_particles(rmclhip_pf_sharded* h, const rmclhip_transform* poses,
+                                                const rmclhip_particle_attributes* attrs, uint32_t n_total) {
+  ApiGuard guard_("rmclhip_pf_sharded_set_particles");
+  if (!h || (n_total && (!poses || !attrs))) return fail(RMCLHIP_ERR_INVALID, "pf_sharded_set_particles: null");
+  const uint32_t world = static_cast<uint32_t>(h->ranks.size());
+  const uint32_t cap = (n_total + world - 1u) / world;
+  for (uint32_t r = 0; r < world; ++r) {
+    PfRank& R = h->ranks[r];
+    HIPCHK(hipSetDevice(R.ctx->device));
+    if (cap > h->cap || !R.d_poses) {
+      void** bufs[] = {reinterpret_cast<void**>(&R.d_poses), &R.d_attrs, reinterpret_cast<void**>(&R.d_poses_new), &R.d_attrs_new,
+                       reinterpret_cast<void**>(&R.d_poses_all), &R.d_attrs_all, reinterpret_cast<void**>(&R.d_w_send),
+                       reinterpret_cast<void**>(&R.d_w_pad), reinterpret_cast<void**>(&R.d_w_all)};
+      for (void** b : bufs) if (*b) { (void)hipFree(*b); *b = nullptr; }
+      const size_t c = std::max<uint32_t>(cap, 1u);
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&R.d_poses), c * 32)); HIPCHK(hipMalloc(&R.d_attrs, c * 36));
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&R.d_poses_new), c * 32)); HIPCHK(hipMalloc(&R.d_attrs_new, c * 36));
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&R.d_poses_all), c * world * 32)); HIPCHK(hipMalloc(&R.d_attrs_all, c * world * 36));
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&R.d_w_send), c * 4)); HIPCHK(hipMalloc(reinterpret_cast<void**>(&R.d_w_pad), c * world * 4));
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&R.d_w_all), static_cast<size_t>(std::max(n_total, 1u)) * 4));
+    }
+    shard_bounds(n_total, r, world, &R.lo, &R.hi);
+    HIPCHK(hipMemset(R.d_poses, 0, static_cast<size_t>(std::max(cap, 1u)) * 32));
+    HIPCHK(hipMemset(R.d_attrs, 0, static_cast<size_t>(std::max(cap, 1u)) * 36));
+    HIPCHK(hipMemset(R.d_w_send, 0, static_cast<size_t>(std::max(cap, 1u)) * 4));
+    if (R.hi > R.lo) {
+      HIPCHK(hipMemcpy(R.d_poses, poses + R.lo, static_cast<size_t>(R.hi - R.lo) * 32, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(R.d_attrs, attrs + R.lo, static_cast<size_t>(R.hi - R.lo) * 36, hipMemcpyHostToDevice));
+    }
+  }
+  h->n_total = n_total;
+  h->cap = std::max(cap, h->cap);
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_pf_sharded_download(rmclhip_pf_sharded* h, rmclhip_transform* poses, rmclhip_particle_attributes* attrs) {
+  ApiGuard guard_("rmclhip_pf_sharded_download");
+  if (!h) return fail(RMCLHIP_ERR_INVALID, "pf_sharded_download: null");
+  for (PfRank& R : h->ranks) {
+    HIPCHK(hipSetDevice(R.ctx->device));
+    HIPCHK(hipDeviceSynchronize());
+    if (R.hi > R.lo) {
+      if (poses) HIPCHK(hipMemcpy(poses + R.lo, R.d_poses, static_cast<size_t>(R.hi - R.lo) * 32, hipMemcpyDeviceToHost));
+      if (attrs) HIPCHK(hipMemcpy(attrs + R.lo, R.d_attrs, static_cast<size_t>(R.hi - R.lo) * 36, hipMemcpyDeviceToHost));
+    }
+  }
+  return RMCLHIP_OK;
+}
+
+// all-gather of likelihood.mean (4 B x N; C5: 4 MB, one collective, never bucketed): afterwards EVERY device holds the dense
+// weight vector of the whole cloud (consumer: the tournament / {sum, max}, resampling.cu:108-199)
+rmclhip_status rmclhip_pf_allgather_weights(rmclhip_pf_sharded* h) {
+  ApiGuard guard_("rmclhip_pf_allgather_weights");
+  if (!h) return fail(RMCLHIP_ERR_INVALID, "pf_allgather_weights: null");
+  if (h->n_total == 0) return RMCLHIP_OK;
+  const uint32_t world = static_cast<uint32_t>(h->ranks.size()), cap = (h->n_total + world - 1u) / world;
+  for (uint32_t r = 0; r < world; ++r) {
+    PfRank& R = h->ranks[r];
+    HIPCHK(hipSetDevice(R.ctx->device));
+    HIPCHK(launch_pf_extract_weights(R.d_attrs, R.hi - R.lo, R.d_w_send, h->comm->streams[r]));
+  }
+  NCCLCHK(g_rccl.GroupStart());
+  for (uint32_t r = 0; r < world; ++r) {
+    PfRank& R = h->ranks[r];
+    (void)hipSetDevice(R.ctx->device);
+    const ncclResult_t nr = g_rccl.AllGather(R.d_w_send, R.d_w_pad, cap, ncclFloat, h->comm->comms[r], h->comm->streams[r]);
+    if (nr != ncclSuccess) { (void)g_rccl.GroupEnd(); return fail(RMCLHIP_ERR_HIP, std::string("ncclAllGather: ") + g_rccl.GetErrorString(nr)); }
+  }
+  NCCLCHK(g_rccl.GroupEnd());
+  for (uint32_t r = 0; r < world; ++r) {
+    PfRank& R = h->ranks[r];
+    HIPCHK(hipSetDevice(R.ctx->device));
+    HIPCHK(launch_compact_shards(R.d_w_pad, R.d_w_all, h->n_total, world, cap, h->comm->streams[r]));
+  }
+  for (uint32_t r = 0; r < world; ++r) {
+    HIPCHK(hipSetDevice(h->ranks[r].ctx->device));
+    HIPCHK(hipStreamSynchronize(h->comm->streams[r]));
+  }
+  return RMCLHIP_OK;
+}
+
+// PCDSensorUpdater*::update on every device's block of the particles (concurrently: one stream per device), then the
+// weight all-gather
+rmclhip_status rmclhip_pf_update_sharded(rmclhip_pf_sharded* h, const rmclhip_range_measurement* beams, uint32_t n_beams,
+                                         const rmclhip_transform* Tsb) {
+  ApiGuard guard_("rmclhip_pf_update_sharded");
+  if (!h || !Tsb || (n_beams && !beams)) return fail(RMCLHIP_ERR_INVALID, "pf_update_sharded: null");
+  for (PfRank& R : h->ranks) {
+    if (R.hi == R.lo) continue;
+    if (rmclhip_status st = rmclhip_pf_update_async(R.pf, reinterpret_cast<const rmclhip_transform*>(R.d_poses),
+                                                    static_cast<rmclhip_particle_attributes*>(R.d_attrs), R.hi - R.lo, beams, n_beams, Tsb))
+      return st;
+  }
+  for (PfRank& R : h->ranks)
+    if (rmclhip_status st = rmclhip_pf_sync(R.pf)) return st;
+  return rmclhip_pf_allgather_weights(h);
+}
+
+rmclhip_status rmclhip_pf_sharded_get_weights(rmclhip_pf_sharded* h, uint32_t rank, float* weights_host) {
+  ApiGuard guard_("rmclhip_pf_sharded_get_weights");
+  if (!h || !weights_host || rank >= h->ranks.size()) return fail(RMCLHIP_ERR_INVALID, "pf_sharded_get_weights: bad arguments");
+  PfRank& R = h->ranks[rank];
+  HIPCHK(hipSetDevice(R.ctx->device));
+  if (h->n_total) HIPCHK(hipMemcpy(weights_host, R.d_w_all, static_cast<size_t>(h->n_total) * 4, hipMemcpyDeviceToHost));
+  return RMCLHIP_OK;
+}
+
+// moments of one pass on every rank's overlap with [0, n_use), all-reduced (sums with ncclSum, maxima with ncclMax);
+// result (identical on every rank) in out32
+static rmclhip_status sharded_moments(rmclhip_pf_sharded* h, uint32_t n_use, int pass, double L_sum, const xform& Tbm, double* out32) {
+  const uint32_t world = static_cast<uint32_t>(h->ranks.size());
+  for (uint32_t r = 0; r < world; ++r) {
+    PfRank& R = h->ranks[r];
+    HIPCHK(hipSetDevice(R.ctx->device));
+    const uint32_t hi = std::min(R.hi, n_use);
+    const uint32_t n = (hi > R.lo) ? (hi - R.lo) : 0u;
+    HIPCHK(launch_pose_moments(R.d_poses, R.d_attrs, n, pass, L_sum, Tbm, R.d_mom_part, R.d_mom, h->comm->streams[r]));
+  }
+  NCCLCHK(g_rccl.GroupStart());
+  for (uint32_t r = 0; r < world; ++r) {
+    PfRank& R = h->ranks[r];
+    (void)hipSetDevice(R.ctx->device);
+    ncclResult_t nr = g_rccl.AllReduce(R.d_mom, R.d_mom + 32, 24, ncclDouble, ncclSum, h->comm->comms[r], h->comm->streams[r]);
+    if (nr == ncclSuccess) nr = g_rccl.AllReduce(R.d_mom + 24, R.d_mom + 32 + 24, 8, ncclDouble, ncclMax, h->comm->comms[r], h->comm->streams[r]);
+    if (nr != ncclSuccess) { (void)g_rccl.GroupEnd(); return fail(RMCLHIP_ERR_HIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(nr)); }
+  }
+  NCCLCHK(g_rccl.GroupEnd());
+  PfRank& R0 = h->ranks[0];
+  HIPCHK(hipSetDevice(R0.ctx->device));
+  HIPCHK(hipMemcpyAsync(R0.h_mom, R0.d_mom + 32, 32 * sizeof(double), hipMemcpyDeviceToHost, h->comm->streams[0]));
+  for (uint32_t r = 0; r < world; ++r) {
+    HIPCHK(hipSetDevice(h->ranks[r].ctx->device));
+    HIPCHK(hipStreamSynchronize(h->comm->streams[r]));
+  }
+  std::memcpy(out32, R0.h_mom, 32 * sizeof(double));
+  return RMCLHIP_OK;
+}
+
+// global {sum, max} of the likelihoods: the distributed form of simple_stats_kernel (resampling.cu:41-92)
+rmclhip_status rmclhip_pf_allreduce_stats(rmclhip_pf_sharded* h, rmclhip_likelihood_stats* out) {
+  ApiGuard guard_("rmclhip_pf_allreduce_stats");
+  if (!h || !out) return fail(RMCLHIP_ERR_INVALID, "pf_allreduce_stats: null");
+  double m[32];
+  if (rmclhip_status st = sharded_moments(h, h->n_total, 0, 1.0, xidentity(), m)) return st;
+  out->sum = static_cast<float>(m[0]);
+  out->max = static_cast<float>(std::max(m[24], 0.0));   // seeded with 0 like the reference's shared-memory init
+  return RMCLHIP_OK;
+}
+
+// largest eigenvector of a symmetric 4x4 matrix (cyclic Jacobi, double)
+static void sym4_largest_eigenvector(const double* M10, double* q) {
+  double A[4][4], V[4][4];
+  int k = 0;
+  for (int a = 0; a < 4; ++a) for (int b = a; b < 4; ++b) { A[a][b] = A[b][a] = M10[k++]; }
+  for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) V[a][b] = (a == b) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    double off = 0.0;
+    for (int a = 0; a < 4; ++a) for (int b = a + 1; b < 4; ++b) off += A[a][b] * A[a][b];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 3; ++p)
+      for (int qq = p + 1; qq < 4; ++qq) {
+        if (A[p][qq] == 0.0) continue;
+        const double theta = (A[qq][qq] - A[p][p]) / (2.0 * A[p][qq]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+        for (int i = 0; i < 4; ++i) { const double ip = A[i][p], iq = A[i][qq]; A[i][p] = c * ip - sn * iq; A[i][qq] = sn * ip + c * iq; }
+        for (int i = 0; i < 4; ++i) { const double pi_ = A[p][i], qi = A[qq][i]; A[p][i] = c * pi_ - sn * qi; A[qq][i] = sn * pi_ + c * qi; }
+        for (int i = 0; i < 4; ++i) { const double ip = V[i][p], iq = V[i][qq]; V[i][p] = c * ip - sn * iq; V[i][qq] = sn * ip + c * iq; }
+      }
+  }
+  int best = 0;
+  for (int a = 1; a < 4; ++a) if (A[a][a] > A[best][best]) best = a;
+  double n = 0.0;
+  for (int a = 0; a < 4; ++a) n += V[a][best] * V[a][best];
+  n = std::sqrt(n);
+  const double sgn = (V[3][best] < 0.0) ? -1.0 : 1.0;   // canonical sign: w >= 0
+  for (int a = 0; a < 4; ++a) q[a] = sgn * V[a][best] / n;
+}
+
+// RmclNode::estimateStats (rmcl_localization.cpp:642-731) over the first n_induction particles of the sharded cloud
+rmclhip_status rmclhip_pf_allreduce_pose_estimate(rmclhip_pf_sharded* h, uint32_t n_induction, rmclhip_pose_estimate* out) {
+  ApiGuard guard_("rmclhip_pf_allreduce_pose_estimate");
+  if (!h || !out) return fail(RMCLHIP_ERR_INVALID, "pf_allreduce_pose_estimate: null");
+  std::memset(out, 0, sizeof(*out));
+  const uint32_t n_use = std::min(n_induction, h->n_total);
+  if (n_use == 0) return fail(RMCLHIP_ERR_INVALID, "pf_allreduce_pose_estimate: no particles");
+  double m[32];
+  if (rmclhip_status st = sharded_moments(h, n_use, 0, 1.0, xidentity(), m)) return st;
+  const double L_sum = m[0], L_n = m[2];
+  const double L_mean = L_sum / L_n;
+  out->n_particles = n_use;
+  out->likelihood_mean = L_mean;
+  out->likelihood_sigma = std::sqrt(std::max(m[1] / L_n - L_mean * L_mean, 0.0));
+  out->likelihood_max = std::max(m[24], 0.0);   // L_max starts at 0.0 in the reference (:665)
+  out->likelihood_min = -m[25];
+  for (int k = 0; k < 3; ++k) { out->trans_bb_max[k] = static_cast<float>(m[26 + k]); out->trans_bb_min[k] = static_cast<float>(-m[29 + k]); }
+  // first pass: mean (rm::markley_mean with weights L_i / L_sum)
+  if (rmclhip_status st = sharded_moments(h, n_use, 1, L_sum, xidentity(), m)) return st;
+  double q[4];
+  sym4_largest_eigenvector(m, q);
+  xform Tbm = xidentity();
+  Tbm.R.x = static_cast<float>(q[0]); Tbm.R.y = static_cast<float>(q[1]); Tbm.R.z = static_cast<float>(q[2]); Tbm.R.w = static_cast<float>(q[3]);
+  Tbm.t = mk3(static_cast<float>(m[10]), static_cast<float>(m[11]), static_cast<float>(m[12]));
+  from_x(Tbm, &out->pose);
+  // second pass: covariance around the mean
+  if (rmclhip_status st = sharded_moments(h, n_use, 2, L_sum, Tbm, m)) return st;
+  int k = 0;
+  for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { out->covariance[6 * a + b] = out->covariance[6 * b + a] = m[k++]; }
+  return RMCLHIP_OK;
+}
+
+// distributed gladiator tournament: the enemy of a champion may live on any rank, so the cloud (68 B per
+// particle) is all-gathered once, then every rank resamples its own champions against the gathered copy; the Philox
+// stream is a function of the GLOBAL champion index, so the result equals the single-GPU tournament
+rmclhip_status rmclhip_pf_sharded_resample(rmclhip_pf_sharded* h, const rmclhip_gladiator_config* cfg, uint64_t seed, uint32_t step) {
+  ApiGuard guard_("rmclhip_pf_sharded_resample");
+  if (!h || !cfg) return fail(RMCLHIP_ERR_INVALID, "pf_sharded_resample: null");
+  if (h->n_total == 0) return RMCLHIP_OK;
+  const uint32_t world = static_cast<uint32_t>(h->ranks.size()), cap = (h->n_total + world - 1u) / world;
+  const bool ragged = (h->n_total % world) != 0u;
+  if (ragged && world > 1)
+    return fail(RMCLHIP_ERR_UNSUPPORTED, "pf_sharded_resample: n_total must be a multiple of the number of devices (padded shards "
+                                         "would shift the global particle indices of the gathered cloud)");
+  NCCLCHK(g_rccl.GroupStart());
+  for (uint32_t r = 0; r < world; ++r) {
+    PfRank& R = h->ranks[r];
+    (void)hipSetDevice(R.ctx->device);
+    ncclResult_t nr = g_rccl.AllGather(R.d_poses, R.d_poses_all, static_cast<size_t>(cap) * 32, ncclChar, h->comm->comms[r], h->comm->streams[r]);
+    if (nr == ncclSuccess) nr = g_rccl.AllGather(R.d_attrs, R.d_attrs_all, static_cast<size_t>(cap) * 36, ncclChar, h->comm->comms[r], h->comm->streams[r]);
+    if (nr != ncclSuccess) { (void)g_rccl.GroupEnd(); return fail(RMCLHIP_ERR_HIP, std::string("ncclAllGather: ") + g_rccl.GetErrorString(nr)); }
+  }
+  NCCLCHK(g_rccl.GroupEnd());
+  for (uint32_t r = 0; r < world; ++r) {
+    HIPCHK(hipSetDevice(h->ranks[r].ctx->device));
+    HIPCHK(hipStreamSynchronize(h->comm->streams[r]));
+  }
+  for (PfRank& R : h->ranks) {
+    if (R.hi == R.lo) continue;
+    if (rmclhip_status st = rmclhip_resampler_gladiator(R.rs, reinterpret_cast<const rmclhip_transform*>(R.d_poses_all),
+                                                        static_cast<const rmclhip_particle_attributes*>(R.d_attrs_all), h->n_total,
+                                                        reinterpret_cast<rmclhip_transform*>(R.d_poses_new),
+                                                        static_cast<rmclhip_particle_attributes*>(R.d_attrs_new), R.lo, R.hi - R.lo, cfg, seed, step))
+      return st;
+    std::swap(R.d_poses, R.d_poses_new);
+    std::swap(R.d_attrs, R.d_attrs_new);
+  }
   return RMCLHIP_OK;
 }
 

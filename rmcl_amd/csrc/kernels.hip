@@ -2511,6 +2511,111 @@ __global__ void __launch_bounds__(64) k_likelihood_stats_final(const double* __r
   if (threadIdx.x == 0) { out[0] = static_cast<float>(sum); out[1] = mx; }
 }
 
+// ---------------------------------------------------------------------------------------------
+// pose estimate of the particle cloud (RmclNode::estimateStats, rmcl_ros/src/nodes/rmcl_localization.cpp:642-731) as
+// three linear moment passes, so that it shards: every GPU reduces its block of the particles to <= 24 doubles and the
+// ranks all-reduce them ("Stats for pose estimate: all-reduce of ~32 floats").
+//   pass 0: sum L, sum L^2, count | max L, -min L, bb_max xyz, -bb_min xyz (max-reduced)           (:664-689)
+//   pass 1: sum w q q^T (10 unique entries, x y z w order), sum w t, with w = L / L_sum                  (:703-705)
+//           -- the Markley mean is the eigenvector of the largest eigenvalue of that 4x4 matrix
+//   pass 2: sum w d d^T (21 unique entries), d = (dt, roll, pitch, yaw) of ~Tbm * T_i                    (:716-718)
+// Partials per block: 24 sums (double) + 8 maxima (float as double).
+// ---------------------------------------------------------------------------------------------
+constexpr int kMomSums = 24, kMomMax = 8;
+
+__global__ void __launch_bounds__(256) k_pose_moments(const xform* __restrict__ poses, const pattrs* __restrict__ attrs, uint32_t n,
+                                                      int pass, double L_sum, xform Tbm, double* __restrict__ partials) {
+  __shared__ double red[4][kMomSums + kMomMax];
+  double acc[kMomSums];
+  float mx[kMomMax];
+#pragma unroll
+  for (int k = 0; k < kMomSums; ++k) acc[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < kMomMax; ++k) mx[k] = -3.402823466e38f;
+  const xform Tmb = xinv(Tbm);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const xform T = poses[i];
+    const float Lf = attrs[i].likelihood.mean;
+    const double L = static_cast<double>(Lf);
+    if (pass == 0) {
+      acc[0] += L; acc[1] += L * L; acc[2] += 1.0;
+      mx[0] = fmaxf(mx[0], Lf); mx[1] = fmaxf(mx[1], -Lf);
+      mx[2] = fmaxf(mx[2], T.t.x); mx[3] = fmaxf(mx[3], T.t.y); mx[4] = fmaxf(mx[4], T.t.z);
+      mx[5] = fmaxf(mx[5], -T.t.x); mx[6] = fmaxf(mx[6], -T.t.y); mx[7] = fmaxf(mx[7], -T.t.z);
+    } else if (pass == 1) {
+      const double w = L / L_sum;
+      const double q[4] = {T.R.x, T.R.y, T.R.z, T.R.w};
+      int k = 0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = a; b < 4; ++b) acc[k++] += w * q[a] * q[b];
+      acc[10] += w * T.t.x; acc[11] += w * T.t.y; acc[12] += w * T.t.z;
+    } else {
+      const double w = L / L_sum;
+      const xform Td = xmul(Tmb, T);
+      // EulerAngles <- Quaternion (textbook ZYX extraction, as in k_gladiator_resample)
+      const quat qd = Td.R;
+      const float sinr_cosp = 2.0f * (qd.w * qd.x + qd.y * qd.z), cosr_cosp = 1.0f - 2.0f * (qd.x * qd.x + qd.y * qd.y);
+      const float sinp = 2.0f * (qd.w * qd.y - qd.z * qd.x);
+      const float siny_cosp = 2.0f * (qd.w * qd.z + qd.x * qd.y), cosy_cosp = 1.0f - 2.0f * (qd.y * qd.y + qd.z * qd.z);
+      const double d[6] = {Td.t.x, Td.t.y, Td.t.z,
+                           atan2(static_cast<double>(sinr_cosp), static_cast<double>(cosr_cosp)),
+                           (fabsf(sinp) >= 1.0f) ? copysign(3.14159265358979323846 / 2.0, static_cast<double>(sinp)) : asin(static_cast<double>(sinp)),
+                           atan2(static_cast<double>(siny_cosp), static_cast<double>(cosy_cosp))};
+      int k = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b) acc[k++] += w * d[a] * d[b];
+    }
+  }
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < kMomSums; ++k) {
+    double v = acc[k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0u) red[wave][k] = v;
+  }
+#pragma unroll
+  for (int k = 0; k < kMomMax; ++k) {
+    float v = mx[k];
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    if (lane == 0u) red[wave][kMomSums + k] = static_cast<double>(v);
+  }
+  __syncthreads();
+  if (threadIdx.x < kMomSums + kMomMax) {
+    const int k = static_cast<int>(threadIdx.x);
+    double v;
+    if (k < kMomSums) v = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+    else v = fmax(fmax(red[0][k], red[1][k]), fmax(red[2][k], red[3][k]));
+    partials[static_cast<size_t>(blockIdx.x) * (kMomSums + kMomMax) + k] = v;
+  }
+}
+
+__global__ void __launch_bounds__(64) k_pose_moments_final(const double* __restrict__ partials, uint32_t nblocks, double* __restrict__ out) {
+  const int k = static_cast<int>(threadIdx.x);
+  if (k >= kMomSums + kMomMax) return;
+  double v = (k < kMomSums) ? 0.0 : -1.7976931348623157e308;
+  for (uint32_t b = 0; b < nblocks; ++b) {
+    const double x = partials[static_cast<size_t>(b) * (kMomSums + kMomMax) + k];
+    v = (k < kMomSums) ? (v + x) : fmax(v, x);
+  }
+  out[k] = v;
+}
+
+// dense weight vector from the padded all-gather layout: rank r's shard sits at r * cap
+__global__ void k_compact_shards(const float* __restrict__ padded, float* __restrict__ dense, uint32_t n_total, uint32_t world, uint32_t cap) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_total) return;
+  const uint32_t base = n_total / world, rem = n_total % world;
+  // owner of global index i under the block partition (the first `rem` ranks own base + 1)
+  const uint32_t split = rem * (base + 1u);
+  const uint32_t r = (i < split) ? (i / (base + 1u)) : (rem + (i - split) / max(base, 1u));
+  const uint32_t lo = r * base + min(r, rem);
+  dense[i] = padded[static_cast<size_t>(r) * cap + (i - lo)];
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -2778,6 +2883,23 @@ hipError_t launch_pointcloud2_unpack(const uint8_t* data, uint32_t point_step, u
   Pc2Params p{data, point_step, row_step, off_x, off_y, off_z, is_f64 ? 1u : 0u, h_skip, h_inc, w_skip, w_inc,
               out_w, out_h, range_min, range_max, dirs, points, mask, n_valid};
   hipLaunchKernelGGL(k_pointcloud2_unpack, dim3((n + 255u) / 256u), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_pose_moments(const xform* poses, const void* attrs, uint32_t n, int pass, double L_sum, xform Tbm,
+                               double* partials, double* out32, hipStream_t s) {
+  uint32_t nblocks = (n + 1023u) / 1024u;
+  if (nblocks < 1u) nblocks = 1u;
+  if (nblocks > 256u) nblocks = 256u;
+  hipLaunchKernelGGL(k_pose_moments, dim3(nblocks), dim3(256), 0, s, poses, reinterpret_cast<const pattrs*>(attrs), n, pass, L_sum, Tbm,
+                     partials);
+  hipLaunchKernelGGL(k_pose_moments_final, dim3(1), dim3(64), 0, s, partials, nblocks, out32);
+  return hipGetLastError();
+}
+
+hipError_t launch_compact_shards(const float* padded, float* dense, uint32_t n_total, uint32_t world, uint32_t cap, hipStream_t s) {
+  if (n_total == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_compact_shards, dim3((n_total + 255u) / 256u), dim3(256), 0, s, padded, dense, n_total, world, cap);
   return hipGetLastError();
 }
 

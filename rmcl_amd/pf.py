@@ -225,3 +225,83 @@ class GladiatorResamplerHip:
             self.close()
         except Exception:
             pass
+
+
+class ShardedParticleFilterHip:
+    """A particle cloud block-partitioned over the devices of ONE process (rmclhip_comm / rmclhip_pf_sharded: RCCL
+    ncclCommInitAll + all-gather / all-reduce over xGMI) -- the multi-GPU form of PCDSensorUpdater + GladiatorResampler +
+    RmclNode::estimateStats for the single-process node (rmcl_localization.cpp:482-552, 642-731)."""
+
+    def __init__(self, vertices, faces, devices=(0,)):
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self._comm = C.c_void_p()
+        _capi.check(_capi.lib().rmclhip_comm_create(devs, len(devices), C.byref(self._comm)))
+        v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+        f = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
+        self._h = C.c_void_p()
+        try:
+            _capi.check(_capi.lib().rmclhip_pf_sharded_create(self._comm, _ptr(v), len(v), _ptr(f), len(f), C.byref(self._h)))
+        except Exception:
+            _capi.lib().rmclhip_comm_destroy(self._comm)
+            self._comm = C.c_void_p()
+            raise
+        self.world = len(devices)
+        self.n_total = 0
+        self.config_ = pf_params()
+
+    def set_particles(self, poses, attrs):
+        p = np.ascontiguousarray(poses, dtype=TRANSFORM).reshape(-1)
+        a = np.ascontiguousarray(attrs).reshape(-1)
+        assert a.dtype.itemsize == 36 and len(a) == len(p)
+        _capi.check(_capi.lib().rmclhip_pf_sharded_set_particles(self._h, _ptr(p), _ptr(a), len(p)))
+        self.n_total = len(p)
+
+    def download(self):
+        from .types import PARTICLE_ATTRIBUTES
+        p, a = np.zeros(self.n_total, TRANSFORM), np.zeros(self.n_total, PARTICLE_ATTRIBUTES)
+        _capi.check(_capi.lib().rmclhip_pf_sharded_download(self._h, _ptr(p), _ptr(a)))
+        return p, a
+
+    def update(self, beams, Tsb):
+        """sensor update on every device's block + the weight all-gather; returns the dense weights as rank 0 holds them"""
+        b = np.ascontiguousarray(beams, dtype=RANGE_MEASUREMENT).reshape(-1)
+        T = np.ascontiguousarray(Tsb, dtype=TRANSFORM).reshape(1)
+        _capi.check(_capi.lib().rmclhip_pf_sharded_set_params(self._h, C.byref(self.config_)))
+        _capi.check(_capi.lib().rmclhip_pf_update_sharded(self._h, _ptr(b), len(b), _ptr(T)))
+        return self.weights(0)
+
+    def weights(self, rank=0):
+        w = np.zeros(self.n_total, np.float32)
+        _capi.check(_capi.lib().rmclhip_pf_sharded_get_weights(self._h, int(rank), _ptr(w)))
+        return w
+
+    def stats(self):
+        st = _capi.LikelihoodStats()
+        _capi.check(_capi.lib().rmclhip_pf_allreduce_stats(self._h, C.byref(st)))
+        return {"sum": st.sum, "max": st.max}
+
+    def pose_estimate(self, max_induction_particles=0xFFFFFFFF):
+        e = _capi.PoseEstimate()
+        _capi.check(_capi.lib().rmclhip_pf_allreduce_pose_estimate(self._h, int(min(max_induction_particles, 0xFFFFFFFF)), C.byref(e)))
+        pose = np.frombuffer(bytes(bytearray(memoryview(e.pose))), dtype=TRANSFORM)[0].copy()
+        return {"pose": pose, "covariance": np.array(e.covariance, dtype=np.float64).reshape(6, 6),
+                "likelihood": {"mean": e.likelihood_mean, "sigma": e.likelihood_sigma, "min": e.likelihood_min, "max": e.likelihood_max},
+                "trans_bb_min": np.array(e.trans_bb_min), "trans_bb_max": np.array(e.trans_bb_max), "nparticles": e.n_particles}
+
+    def resample(self, cfg=None, seed=42, step=0):
+        cfg = cfg if cfg is not None else gladiator_config()
+        _capi.check(_capi.lib().rmclhip_pf_sharded_resample(self._h, C.byref(cfg), int(seed), int(step)))
+
+    def close(self):
+        if self._h:
+            _capi.lib().rmclhip_pf_sharded_destroy(self._h)
+            self._h = C.c_void_p()
+        if self._comm:
+            _capi.lib().rmclhip_comm_destroy(self._comm)
+            self._comm = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -97,6 +97,13 @@ def test_cpp_example_matches_python_and_oracle(ra, orc, ctx, meshes, tmp_path):
         mean, sigma, n = out["pf_%d" % i]
         assert int(n) == int(attrs["likelihood"]["n_meas"][i])
         assert abs(float(mean) - float(attrs["likelihood"]["mean"][i])) <= 1e-5 * abs(float(attrs["likelihood"]["mean"][i])) + 1e-12
+    # the multi-device form at one device: same weights; pose estimate vs the oracle
+    assert int(out["sharded_world"][0]) == 1
+    for i in range(4):
+        assert abs(float(out["sharded_w"][i]) - float(attrs["likelihood"]["mean"][i])) <= 1e-5 * abs(float(attrs["likelihood"]["mean"][i])) + 1e-12
+    est = orc.estimate_stats(poses, attrs)
+    assert np.allclose([float(x) for x in out["sharded_pose_t"]], [float(est["pose"]["t"][k]) for k in "xyz"], rtol=1e-5, atol=1e-6)
+    assert abs(float(out["sharded_stats"][0]) - float(attrs["likelihood"]["mean"].astype(np.float64).sum())) < 1e-5
     # motion update + gladiator tournament on the updated cloud
     m.pf_motion_update(poses, attrs, T.transform_from_rpy((0.3, 0, 0), (0, 0, 0.05)), 0.01, collision=True, bvh=False)
     st = orc.likelihood_stats(attrs)

@@ -108,3 +108,24 @@ def test_shard_bounds_partition():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1 and max(sizes) <= shard_capacity(n, world)
+
+
+def test_c_abi_shard_bounds_and_comm_without_device(ra):
+    """the C ABI's block partition (rmclhip_shard_bounds, used by rmclhip_pf_sharded_*) is the Python one; without a HIP device
+    rmclhip_comm_create fails loudly (no CPU fallback, and librccl is not even loaded)."""
+    import ctypes as C
+    from rmcl_amd.distributed import shard_bounds
+    L = ra._capi.lib()
+    for n in (0, 1, 7, 8, 9, 100000, 1000003):
+        for world in (1, 2, 3, 8):
+            for rank in range(world):
+                lo, hi = C.c_uint32(), C.c_uint32()
+                L.rmclhip_shard_bounds(n, rank, world, C.byref(lo), C.byref(hi))
+                assert (lo.value, hi.value) == shard_bounds(n, rank, world)
+    import torch
+    if not torch.cuda.is_available():
+        comm = C.c_void_p()
+        assert L.rmclhip_comm_create(None, 1, C.byref(comm)) == ra._capi.ERR_NO_DEVICE and not comm
+        assert b"no HIP device" in L.rmclhip_last_error()
+    assert L.rmclhip_comm_create(None, 0, C.byref(C.c_void_p())) == ra._capi.ERR_INVALID
+    assert L.rmclhip_comm_size(None) == 0

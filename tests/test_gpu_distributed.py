@@ -81,3 +81,66 @@ def _main():
 
 if __name__ == "__main__":
     _main()
+
+
+def test_c_abi_sharded_particle_filter_on_one_device(ra, orc, ctx, meshes):
+    """multi-GPU behind the C ABI (rmclhip_comm_create = RCCL ncclCommInitAll in ONE process, the shape of the reference's
+    single-process node, rmcl_localization.cpp:482-552) at ndev = 1 on the GPU that is there: sharded sensor update + weight
+    all-gather == unsharded update; all-reduced {sum, max}; the pose estimate (Markley mean + 6x6 covariance,
+    rmcl_localization.cpp:642-731) vs the oracle's double-precision restatement; distributed tournament == single-GPU one."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room30k")
+    hm = ra.import_hip_map(ctx, v, f)
+    n = 4096
+    poses, attrs = syn.uniform_particles(n, seed=5, bb_min=(-8, -8, 0.2, 0, 0, -math.pi), bb_max=(8, 8, 3, 0, 0, math.pi))
+    # a cloud with some structure: half of the particles clustered around one pose (a converging filter)
+    rng = np.random.RandomState(2)
+    c = T.transform_from_rpy((1.0, -2.0, 1.2), (0.0, 0.0, 0.7))
+    for i in range(0, n, 2):
+        poses[i] = T.mult(c, T.transform_from_rpy(tuple(rng.normal(0, 0.15, 3)), (rng.normal(0, 0.02), rng.normal(0, 0.02), rng.normal(0, 0.1))))
+    beams = ra.beams_from_points(syn.model_directions(syn.model_pf16())[::8] * np.float32(4.0))
+    Tsb = syn.tsb_offset()
+    # unsharded reference on the product
+    upd = ra.PCDSensorUpdaterHip(hm)
+    upd.init()
+    upd.setInput(beams, Tsb)
+    d_p, d_a = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
+    upd.update(d_p, d_a)
+    ref_attrs = d_a.download()
+    upd.close()
+
+    sh = ra.ShardedParticleFilterHip(v, f, devices=(0,))
+    assert sh.world == 1
+    sh.set_particles(poses, attrs)
+    w = sh.update(beams, Tsb)
+    p2, a2 = sh.download()
+    assert a2.tobytes() == ref_attrs.tobytes() and p2.tobytes() == poses.tobytes()
+    assert np.array_equal(w, ref_attrs["likelihood"]["mean"])
+    st = sh.stats()
+    Lm = ref_attrs["likelihood"]["mean"].astype(np.float64)
+    assert abs(st["sum"] - Lm.sum()) <= 1e-6 * Lm.sum() and st["max"] == np.float32(Lm.max())
+    # pose estimate over all particles and over the first 1000 (max_induction_particles)
+    for n_ind in (n, 1000):
+        est = sh.pose_estimate(n_ind)
+        ref = orc.estimate_stats(poses, ref_attrs, n_ind)
+        assert est["nparticles"] == ref["nparticles"] == n_ind
+        for k in ("mean", "sigma", "min", "max"):
+            assert abs(est["likelihood"][k] - ref["likelihood"][k]) <= 1e-9 + 1e-9 * abs(ref["likelihood"][k]), k
+        assert np.array_equal(est["trans_bb_min"], ref["trans_bb_min"].astype(np.float32))
+        assert np.array_equal(est["trans_bb_max"], ref["trans_bb_max"].astype(np.float32))
+        qa = np.array([est["pose"]["R"][k] for k in "xyzw"], np.float64)
+        qb = np.array([ref["pose"]["R"][k] for k in "xyzw"], np.float64)
+        assert min(np.linalg.norm(qa - qb), np.linalg.norm(qa + qb)) < 1e-6
+        assert np.allclose([est["pose"]["t"][k] for k in "xyz"], [ref["pose"]["t"][k] for k in "xyz"], rtol=1e-6, atol=1e-6)
+        assert np.allclose(est["covariance"], ref["covariance"], rtol=1e-4, atol=1e-6 * np.abs(ref["covariance"]).max())
+    # distributed gladiator tournament == the single-GPU tournament on the same cloud
+    rs = ra.GladiatorResamplerHip(ctx)
+    d_p2, d_a2 = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, ref_attrs)
+    d_pn, d_an = ra.DeviceArray(ctx, T.TRANSFORM, n), ra.DeviceArray(ctx, T.PARTICLE_ATTRIBUTES, n)
+    rs.seed = 42
+    rs.update(d_p2, d_a2, d_pn, d_an, n)
+    sh.resample(seed=42, step=0)
+    p3, a3 = sh.download()
+    assert p3.tobytes() == d_pn.download().tobytes() and a3.tobytes() == d_an.download().tobytes()
+    rs.close()
+    sh.close()
