@@ -126,6 +126,13 @@ int main(int argc, char** argv) {
     const Transform Tdev = rcc.correctOnce(Tom_est, Tbo, 5, 0.0, false, &sdev);
     std::printf("device_loop_n_meas %u\ndevice_loop_t %.9g %.9g %.9g\n", sdev.n_meas, Tdev.t.x, Tdev.t.y, Tdev.t.z);
 
+    // the N-sensor entry point with this one sensor (the node's loop over sensors_vec_, micp_localization.cpp:921-938)
+    {
+      CrossStatistics sm{};
+      const Transform Tm = correctOnce({&rcc}, Tom_est, {Tbo}, {1.0}, 5, 0.0, &sm);
+      std::printf("multi_loop_n_meas %u\nmulti_loop_t %.9g %.9g %.9g\n", sm.n_meas, Tm.t.x, Tm.t.y, Tm.t.z);
+    }
+
     // particle filter: 4 hypotheses, 3 beams
     std::vector<Transform> poses = {truth, Tom_est, from_rpy(1, 1, 0, 0, 0, 1.0), from_rpy(-2, 0.5f, 0.3f, 0, 0, -2.0)};
     std::vector<ParticleAttributes> attrs(poses.size());

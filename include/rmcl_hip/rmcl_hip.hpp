@@ -298,6 +298,12 @@ class Correspondences_<VRAM_HIP> {
     return out;
   }
   rmclhip_rcc* handle() const { return h_; }
+  // bind `dataset` and push `params` before a device-resident loop reads them (correctOnce for several sensors)
+  void prepareForDeviceLoop() {
+    bindDataset();
+    check(rmclhip_rcc_set_params(h_, params.max_dist, adaptive_max_dist_min));
+    outdated = false;
+  }
 
  protected:
   // hand the current `dataset` memory to the library when it was (re)written since the last call
@@ -318,6 +324,25 @@ class Correspondences_<VRAM_HIP> {
   mutable uint64_t bound_points_ = ~0ull, bound_mask_ = ~0ull;
 };
 using CorrespondencesHIP = Correspondences_<VRAM_HIP>;
+
+// MICPLocalizationNode::correctOnce inner loop (micp_localization.cpp:900-964) for all sensors of the node, resident on the
+// device: `sensors[i]` is the correspondence operator of sensor i, Tbo[i] its odom frame at its stamp, weights[i] its
+// merge_weight_multiplier.  Returns T_onew_oold; merged (optional) receives the unweighted Cmerged_o of the last iteration.
+inline Transform correctOnce(const std::vector<CorrespondencesHIP*>& sensors, const Transform& Tom, const std::vector<Transform>& Tbo,
+                             const std::vector<double>& weights, uint32_t iterations, double convergence_progress,
+                             CrossStatistics* merged = nullptr) {
+  if (sensors.empty() || Tbo.size() != sensors.size() || (!weights.empty() && weights.size() != sensors.size()))
+    throw std::runtime_error("correctOnce: one Tbo (and weight) per sensor");
+  std::vector<rmclhip_rcc*> h(sensors.size());
+  for (size_t i = 0; i < sensors.size(); ++i) {
+    sensors[i]->prepareForDeviceLoop();
+    h[i] = sensors[i]->handle();
+  }
+  Transform T;
+  check(rmclhip_micp_correct_once(h.data(), static_cast<uint32_t>(h.size()), &Tom, Tbo.data(), weights.empty() ? nullptr : weights.data(),
+                                  iterations, convergence_progress, &T, merged));
+  return T;
+}
 
 // rmagine::ModelSetter<ModelT>
 template <typename ModelT>

@@ -252,6 +252,15 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* rcc, const rmclhip_transfor
                                         double convergence_progress, int refind_each_iteration,
                                         rmclhip_transform* T_onew_oold_out,
                                         rmclhip_cross_statistics* stats_o_out);
+/* MICPLocalizationNode::correctOnce inner loop for N <= 8 sensors of one device (micp_localization.cpp:900-964): one find per
+ * sensor at Tbm = Tom * Tbo[s], then n_iter x { per sensor statistics at T_snew_sold (MICPSensor.hpp:178) in its own frame,
+ * Cs_o = Tbo * (Tsb * stats_s), Cmerged_o += Cs_o, Cmerged_weighted_o += Cs_o with n_meas *= merge_weight_multiplier[s]
+ * (truncating, :934), T_onew_oold *= umeyama(Cmerged_weighted_o) } -- all on the device, one synchronisation at the end.
+ * merge_weight_multiplier may be NULL (all 1).  merged_out: the UNWEIGHTED statistics of the last iteration (:1010-1011). */
+rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n_sensors, const rmclhip_transform* Tom,
+                                         const rmclhip_transform* Tbo, const double* merge_weight_multiplier, uint32_t n_iter,
+                                         double convergence_progress, rmclhip_transform* T_onew_oold_out,
+                                         rmclhip_cross_statistics* merged_out);
 /* stale v1 SphereCorrector API (lidar_corrector_embree_benchmark.cpp:86-133): nposes hypotheses share
  * the dataset; one raycast + reduction + Umeyama per pose; Tdelta_out[i] such that
  * T_new[i] = Tbm[i] * Tdelta_out[i]. */

@@ -117,6 +117,7 @@ SIGNATURES = {
     "rmclhip_rcc_download": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "rmclhip_rcc_device_views": (_i32, [_vp, _pp, _pp, _pp, _pp, _pp, C.POINTER(_u32)]),
     "rmclhip_rcc_correct_once": (_i32, [_vp, _vp, _vp, _u32, _dbl, _i32, _vp, _vp]),
+    "rmclhip_micp_correct_once": (_i32, [_vp, _u32, _vp, _vp, _vp, _u32, _dbl, _vp, _vp]),
     "rmclhip_rcc_correct_batch": (_i32, [_vp, _vp, _u32, _vp, _vp]),
     "rmclhip_rcc_last_kernel_ms": (_i32, [_vp, C.POINTER(_f32), C.POINTER(_f32)]),
     "rmclhip_rcc_time_find": (_i32, [_vp, _vp, _u32, C.POINTER(_f32)]),

@@ -1138,6 +1138,96 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
 
 static rmclhip_status find_batch_enqueue(rmclhip_rcc* r, const rmclhip_transform* Tbm, uint32_t nposes);
 
+// MICPLocalizationNode::correctOnce inner loop for N sensors on one device (micp_localization.cpp:900-964): one find per
+// sensor, then per iteration one reduction per sensor and ONE step launch that merges, solves and hands out the next
+// pre-transforms; nothing returns to the host until the loop is over (the host form costs one synchronisation per sensor
+// and iteration).
+rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n_sensors, const rmclhip_transform* Tom_,
+                                         const rmclhip_transform* Tbo_, const double* merge_weight_multiplier, uint32_t n_iter,
+                                         double convergence_progress, rmclhip_transform* T_out,
+                                         rmclhip_cross_statistics* merged_out) {
+  ApiGuard guard_("rmclhip_micp_correct_once");
+  if (!sensors || !Tom_ || !Tbo_ || !T_out || n_sensors == 0) return fail(RMCLHIP_ERR_INVALID, "micp_correct_once: null");
+  if (n_sensors > kMaxMicpSensors) return fail(RMCLHIP_ERR_UNSUPPORTED, "micp_correct_once: at most 8 sensors");
+  rmclhip_rcc* r0 = sensors[0];
+  for (uint32_t s = 0; s < n_sensors; ++s) {
+    rmclhip_rcc* r = sensors[s];
+    if (!r) return fail(RMCLHIP_ERR_INVALID, "micp_correct_once: null sensor");
+    if (r->ctx->device != r0->ctx->device) return fail(RMCLHIP_ERR_INVALID, "micp_correct_once: sensors live on different devices");
+    if (r->kind == kModelNone || r->W == 0 || r->H == 0) return fail(RMCLHIP_ERR_INVALID, "micp_correct_once: sensor without a model");
+    if (r->n_dataset == 0) return fail(RMCLHIP_ERR_INVALID, "micp_correct_once: sensor without a dataset");
+  }
+  HIPCHK(hipSetDevice(r0->ctx->device));
+  hipStream_t st = r0->stream;
+  // per-call block + state live with the first sensor
+  struct Scratch { MicpMultiCall call; };
+  static thread_local MicpMultiCall h_call;
+  std::memset(&h_call, 0, sizeof(h_call));
+  const xform Tom = to_x(Tom_);
+  for (uint32_t s = 0; s < n_sensors; ++s) {
+    rmclhip_rcc* r = sensors[s];
+    HIPCHK(hipStreamSynchronize(r->stream));   // whatever the sensor's own stream still holds
+    const size_t n = static_cast<size_t>(r->W) * r->H;
+    r->n_model = static_cast<uint32_t>(n);
+    r->nposes_last = 1;
+    if (rmclhip_status e = ensure_model_buffers(r, n)) return e;
+    const uint32_t nred = (r->n_dataset < r->n_model) ? r->n_dataset : r->n_model;
+    const uint32_t nb = reduce_num_blocks(nred, 1);
+    HIPCHK(r->d_partials.reserve(std::max<size_t>(static_cast<size_t>(nb) * 32, 2u * 256u * 16u)));
+    h_call.Tsb[s] = r->Tsb;
+    h_call.Tbo[s] = to_x(Tbo_ + s);
+    h_call.weight[s] = merge_weight_multiplier ? merge_weight_multiplier[s] : 1.0;
+    h_call.partials[s] = r->d_partials.p;
+    h_call.nblocks[s] = nb;
+  }
+  h_call.n_sensors = n_sensors;
+  DevBuf<uint8_t> d_blob;   // call + state
+  HIPCHK(d_blob.reserve(sizeof(MicpMultiCall) + sizeof(MicpMultiState)));
+  MicpMultiCall* d_call = reinterpret_cast<MicpMultiCall*>(d_blob.p);
+  MicpMultiState* d_state = reinterpret_cast<MicpMultiState*>(d_blob.p + sizeof(MicpMultiCall));
+  hipError_t e = hipMemcpyAsync(d_call, &h_call, sizeof(h_call), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = launch_micp_multi_init(d_call, d_state, st);
+  // sensor->setTom(Tom); sensor->findCorrespondences()  (:900-909): Tbm = Tom * Tbo
+  for (uint32_t s = 0; s < n_sensors && e == hipSuccess; ++s) {
+    rmclhip_rcc* r = sensors[s];
+    FindParams p;
+    fill_find_params(r, p, 1);
+    p.Tsm = xmul(xmul(Tom, h_call.Tbo[s]), r->Tsb);
+    p.Tms = xinv(p.Tsm);
+    int v = find_variant(r, 1);
+    if (v == 18) v = 17;
+    e = launch_find(p, r->kind, v, st);
+  }
+  for (uint32_t it = 0; it < n_iter && e == hipSuccess; ++it) {
+    for (uint32_t s = 0; s < n_sensors && e == hipSuccess; ++s) {
+      rmclhip_rcc* r = sensors[s];
+      const uint32_t nred = (r->n_dataset < r->n_model) ? r->n_dataset : r->n_model;
+      ReduceParams rp;
+      std::memset(&rp, 0, sizeof(rp));
+      rp.dataset_points = r->ds_pts;
+      rp.dataset_mask = r->ds_has_mask ? r->ds_msk : nullptr;
+      rp.model_points = r->d_points.p; rp.model_normals = r->d_normals.p; rp.model_mask = r->d_hits.p;
+      rp.n = nred; rp.nposes = 1;
+      rp.max_dist = adaptive_max_dist(r, convergence_progress);
+      rp.Tpre = xidentity();
+      rp.Tpre_dev = &d_state->T_snew_sold[s];
+      rp.partials = r->d_partials.p;
+      rp.nblocks = h_call.nblocks[s];
+      rp.tail_mode = kTailNone;
+      e = launch_reduce_partials(rp, st);
+    }
+    if (e == hipSuccess) e = launch_micp_multi_step(d_call, d_state, st);
+  }
+  MicpMultiState h_state;
+  if (e == hipSuccess) e = hipMemcpyAsync(&h_state, d_state, sizeof(h_state), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  d_blob.release();
+  if (e != hipSuccess) return fail(RMCLHIP_ERR_HIP, std::string("micp_correct_once: ") + hipGetErrorString(e));
+  from_x(h_state.T_onew_oold, T_out);
+  if (merged_out) from_cs(h_state.merged_o, merged_out);
+  return RMCLHIP_OK;
+}
+
 rmclhip_status rmclhip_rcc_correct_batch(rmclhip_rcc* r, const rmclhip_transform* Tbm, uint32_t nposes,
                                          rmclhip_transform* Tdelta_out, rmclhip_cross_statistics* stats_out) {
   ApiGuard guard_("rmclhip_rcc_correct_batch");

@@ -107,6 +107,25 @@ struct MicpState {
   cstats stats_o;                // last merged statistics, odom frame
 };
 
+// N-sensor MICP loop on the device (micp_localization.cpp:900-964): per-call frames + per-sensor partials, one step launch per
+// iteration merges every sensor's statistics (weighted and unweighted), solves once and hands every sensor its next
+// pre-transform
+constexpr uint32_t kMaxMicpSensors = 8;
+struct MicpMultiCall {
+  xform Tsb[kMaxMicpSensors], Tbo[kMaxMicpSensors];
+  double weight[kMaxMicpSensors];              // merge_weight_multiplier
+  const double* partials[kMaxMicpSensors];     // [nblocks[s]][16]
+  uint32_t nblocks[kMaxMicpSensors];
+  uint32_t n_sensors, pad;
+};
+struct MicpMultiState {
+  xform T_onew_oold;
+  cstats merged_o, merged_weighted_o;
+  xform T_snew_sold[kMaxMicpSensors];
+};
+hipError_t launch_micp_multi_init(const MicpMultiCall* call, MicpMultiState* state, hipStream_t s);
+hipError_t launch_micp_multi_step(const MicpMultiCall* call, MicpMultiState* state, hipStream_t s);
+
 hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStream_t s);
 // diagnostics (tools/probe_find.py): per-wave step timeline of one spherical scan; probe_log: tiles x 512 dwords
 hipError_t launch_find_probe(const FindParams& p, int mode, uint32_t* probe_log, hipStream_t s);

@@ -1979,6 +1979,45 @@ __global__ void __launch_bounds__(64) k_micp_step(const double* __restrict__ par
   }
 }
 
+// N sensors, one iteration of MICPLocalizationNode::correctOnce (micp_localization.cpp:915-964), ONE wave:
+//   per sensor (in order): stats_s <- partials; Cs_b = Tsb * stats_s (MICPSensor.hpp:182); Cs_o = Tbo * Cs_b (:931);
+//   Cs_weighted_o = Cs_o with n_meas *= merge_weight_multiplier (truncating, :934); Cmerged_o += Cs_o; Cmerged_weighted_o += ...
+//   T_inner = umeyama(Cmerged_weighted_o) (:952); T_onew_oold *= T_inner (:963);
+//   next pre-transforms: T_bnew_bold = ~Tbo * T_onew_oold * Tbo (:926), T_snew_sold = ~Tsb * T_bnew_bold * Tsb (MICPSensor.hpp:178)
+__global__ void __launch_bounds__(64) k_micp_multi_step(const MicpMultiCall* __restrict__ call, MicpMultiState* __restrict__ st) {
+  const uint32_t ns = call->n_sensors;
+  cstats merged = cs_identity(), merged_w = cs_identity();
+  for (uint32_t s = 0; s < ns; ++s) {
+    const cstats stats_s = finalize_pose(call->partials[s], call->nblocks[s]);   // whole wave
+    if (threadIdx.x == 0) {
+      const cstats Cs_o = cs_transform(call->Tbo[s], cs_transform(call->Tsb[s], stats_s));
+      cstats Cs_w = Cs_o;
+      Cs_w.n_meas = static_cast<uint32_t>(static_cast<double>(Cs_w.n_meas) * call->weight[s]);
+      merged = cs_merge(merged, Cs_o);
+      merged_w = cs_merge(merged_w, Cs_w);
+    }
+  }
+  if (threadIdx.x == 0) {
+    const xform T_inner = umeyama(merged_w);
+    const xform T_onew_oold = xmul(st->T_onew_oold, T_inner);
+    st->T_onew_oold = T_onew_oold;
+    st->merged_o = merged;
+    st->merged_weighted_o = merged_w;
+    for (uint32_t s = 0; s < ns; ++s) {
+      const xform T_bnew_bold = xmul(xmul(xinv(call->Tbo[s]), T_onew_oold), call->Tbo[s]);
+      st->T_snew_sold[s] = xmul(xmul(xinv(call->Tsb[s]), T_bnew_bold), call->Tsb[s]);
+    }
+  }
+}
+
+__global__ void k_micp_multi_init(const MicpMultiCall* __restrict__ call, MicpMultiState* __restrict__ st) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  st->T_onew_oold = xidentity();
+  st->merged_o = cs_identity();
+  st->merged_weighted_o = cs_identity();
+  for (uint32_t s = 0; s < kMaxMicpSensors; ++s) st->T_snew_sold[s] = xidentity();
+}
+
 // stale v1 corrector (lidar_corrector_embree_benchmark.cpp:127-135): per pose, Tdelta_b = Tsb * T_s * ~Tsb
 __global__ void __launch_bounds__(64) k_batch_solve(const double* __restrict__ partials, uint32_t nblocks, xform Tsb,
                                                     xform* __restrict__ Tdelta, cstats* __restrict__ stats) {
@@ -2768,6 +2807,16 @@ hipError_t launch_micp_iter(const float* dataset_points, const uint8_t* dataset_
   MicpIterParams p{dataset_points, dataset_mask, model_points, model_normals, model_mask, n, nblocks, call,
                    partials_prev, partials_out, state_in, state_out, first ? 1u : 0u};
   hipLaunchKernelGGL(k_micp_iter, dim3(nblocks), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_micp_multi_init(const MicpMultiCall* call, MicpMultiState* state, hipStream_t s) {
+  hipLaunchKernelGGL(k_micp_multi_init, dim3(1), dim3(64), 0, s, call, state);
+  return hipGetLastError();
+}
+
+hipError_t launch_micp_multi_step(const MicpMultiCall* call, MicpMultiState* state, hipStream_t s) {
+  hipLaunchKernelGGL(k_micp_multi_step, dim3(1), dim3(64), 0, s, call, state);
   return hipGetLastError();
 }
 

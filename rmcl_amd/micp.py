@@ -56,10 +56,36 @@ class MICPLocalization:
         self.convergence_progress_ = 0.0
         self.correction_stats_latest_ = {}
 
-    def correctOnce(self, record=None):
-        """micp_localization.cpp:856-1016. `record`, if a list, receives T_onew_oold after each iteration."""
+    def _device_loop(self, Tom):
+        """the inner loop of correctOnce for all sensors resident on the device (rmclhip_micp_correct_once): finds, per-sensor
+        reductions, merges, solve and compositions without a host round trip per sensor and iteration"""
+        import ctypes as C
+        from . import _capi
+        from .types import CROSS_STATISTICS, TRANSFORM, _ptr
+        n = len(self.sensors_vec_)
+        handles = (C.c_void_p * n)(*[s.correspondences_._h for s in self.sensors_vec_])
+        Tbo = np.array([s.Tbo for s in self.sensors_vec_], dtype=TRANSFORM)
+        w = np.array([float(s.merge_weight_multiplier) for s in self.sensors_vec_], dtype=np.float64)
+        for s in self.sensors_vec_:
+            s.setTom(Tom)
+            s.correspondences_.setTsb(s.Tsb)
+            s.correspondences_._push_params()
+            s.correspondences_.outdated = False
+            s.correspondences_._last_nposes = 1
+        Tin = np.ascontiguousarray(Tom, dtype=TRANSFORM).reshape(1)
+        Tout, merged = np.zeros(1, TRANSFORM), np.zeros(1, CROSS_STATISTICS)
+        _capi.check(_capi.lib().rmclhip_micp_correct_once(handles, n, _ptr(Tin), _ptr(Tbo), _ptr(w), int(self.optimization_iterations_),
+                                                          float(self.convergence_progress_), _ptr(Tout), _ptr(merged)))
+        return Tout[0].copy(), merged[0].copy()
+
+    def correctOnce(self, record=None, device_loop=False):
+        """micp_localization.cpp:856-1016. `record`, if a list, receives T_onew_oold after each iteration.
+        device_loop=True runs the inner loop (finds + iterations) on the device for all sensors at once."""
         Tom = self.Tom_
         valid_measurements = sum(s.valid_dataset_measurements for s in self.sensors_vec_)
+        if device_loop and not self.disable_correction_ and self.optimization_iterations_ > 0:
+            T_onew_oold, Cmerged_o = self._device_loop(Tom)
+            return self._finish(Tom, T_onew_oold, Cmerged_o, valid_measurements)
         for s in self.sensors_vec_:
             s.setTom(Tom)
             s.findCorrespondences()
@@ -83,6 +109,9 @@ class MICPLocalization:
             T_onew_oold = T.mult(T_onew_oold, T_inner)                                    # :963
             if record is not None:
                 record.append(T_onew_oold.copy())
+        return self._finish(Tom, T_onew_oold, Cmerged_o, valid_measurements)
+
+    def _finish(self, Tom, T_onew_oold, Cmerged_o, valid_measurements):
         T_onew_map = T.mult(Tom, T_onew_oold)                                             # :972
         n_meas = int(Cmerged_o["n_meas"])
         if not self.disable_correction_ and n_meas > 0:

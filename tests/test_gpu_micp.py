@@ -213,3 +213,60 @@ def test_find_batch_o1dn_pose_major(ra, orc, ctx, meshes):
         ref = m.simulate_o1dn(16, 16, 0.05, 80.0, (0.01, 0.02, 0.03), dirs, syn.tsb_offset(), poses, bvh=True, nthreads=4)
         assert np.array_equal(mv["face_ids"], ref["face_ids"]) and np.array_equal(mv["hits"], ref["hits"])
         assert np.allclose(mv["ranges"], ref["ranges"], rtol=1e-5)
+
+
+def test_two_sensor_device_loop_equals_host_loop(ra, orc, ctx, meshes):
+    """MICPLocalizationNode::correctOnce with TWO sensors (micp_localization.cpp:921-938: per-sensor statistics, optimal +
+    weighted merge, one solve per iteration): the device-resident loop (rmclhip_micp_correct_once) must equal the host loop
+    that calls computeCrossStatistics per sensor and iteration -- different models, mounts, odometry stamps (Tbo) and merge
+    weights, including a weight that truncates (n_meas *= 0.37)."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room30k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    truth = T.transform_from_rpy((1.0, -2.0, 1.4), (0.02, -0.03, 0.4))
+    est = T.mult(truth, T.transform_from_rpy((0.15, -0.1, 0.04), (0.01, 0.0, 0.03)))
+    specs = [("lidar", syn.model_vlp16_900(0.3), syn.tsb_offset(), T.identity(), 1.0),
+             ("lidar2", syn.model_c1(), T.transform_from_rpy((-0.2, 0.1, 0.5), (0.0, 0.1, -1.0)),
+              T.transform_from_rpy((0.01, 0.0, 0.0), (0.0, 0.0, 0.002)), 0.37)]
+
+    def build():
+        sensors = []
+        for name, model, Tsb, Tbo, w in specs:
+            meas = m.simulate_spherical(model, Tsb, T.mult(truth, Tbo), bvh=True, nthreads=8)
+            ds, mask = om.dataset_from_ranges(model, meas["ranges"])
+            rcc = ra.RCCHipSpherical(hm)
+            rcc.setModel(model)
+            rcc.set_dataset(ds, mask)
+            rcc.params.max_dist, rcc.adaptive_max_dist_min = 0.8, 0.2
+            s = ra.MICPSensor(name, rcc, Tsb=Tsb, Tbo=Tbo, merge_weight_multiplier=w)
+            s.valid_dataset_measurements = int(mask.sum())
+            sensors.append(s)
+        return sensors
+
+    for n_iter, progress in ((5, 0.0), (10, 0.4)):
+        host = ra.MICPLocalization(build(), optimization_iterations=n_iter)
+        host.Tom_, host.convergence_progress_ = est, progress
+        rec = []
+        Th = host.correctOnce(record=rec)
+        dev = ra.MICPLocalization(build(), optimization_iterations=n_iter)
+        dev.Tom_, dev.convergence_progress_ = est, progress
+        Td = dev.correctOnce(device_loop=True)
+        _transform_close(Td, Th, 1e-5)
+        assert dev.correction_stats_latest_["valid_matches"] == host.correction_stats_latest_["valid_matches"] > 1000
+        assert abs(dev.convergence_progress_ - host.convergence_progress_) < 1e-6
+        _transform_close(dev.Tom_, host.Tom_, 1e-5)
+        # the correction really moves towards the truth
+        d0 = np.linalg.norm([est["t"][k] - truth["t"][k] for k in "xyz"])
+        d1 = np.linalg.norm([dev.Tom_["t"][k] - truth["t"][k] for k in "xyz"])
+        assert d1 < 0.5 * d0
+        for s in host.sensors_vec_ + dev.sensors_vec_:
+            s.correspondences_.close()
+    # one sensor through the N-sensor entry point == the single-sensor graph path
+    sensors = build()[:1]
+    loc = ra.MICPLocalization(sensors, optimization_iterations=7)
+    loc.Tom_ = est
+    Tm = loc.correctOnce(device_loop=True)
+    Tg, _ = sensors[0].correspondences_.correct_once(est, sensors[0].Tbo, 7, 0.0, False)
+    _transform_close(Tm, Tg, 1e-5)
+    sensors[0].correspondences_.close()
