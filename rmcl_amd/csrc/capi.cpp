@@ -1056,7 +1056,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
         // across the 8 XCDs costs more than the launch boundaries it replaces
         HIPCHK(launch_micp_loop(r->ds_pts, dmask, r->d_points.p, r->d_normals.p, r->d_hits.p, nred, n_iter,
                                 r->d_call, r->d_partials.p, r->d_loop_barrier, r->d_state,
-                                static_cast<uint32_t>(r->loop_blocks), r->stream));
+                                static_cast<uint32_t>(r->loop_blocks & 0xFFFF), (r->loop_blocks >> 16) != 0, r->stream));
       } else if (iter_form) {
         // default: ONE launch per iteration (k_micp_iter solves the previous iteration in its prologue) + one
         // closing solve: n_iter + 1 launches instead of 2 * n_iter
@@ -1329,7 +1329,8 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
   r->use_graph = ((variant >> 9) & 1) == 0;
   {  // bits 10..12: MICP loop form -- 0 default (one launch per iteration, solve in the prologue), 1 classic
      // (reduce + solve launches), 2..6 persistent loop kernel with 16..256 blocks
-    static const int kLoopBlocks[8] = {0, -1, 16, 32, 64, 128, 256, 0};
+    // 7: persistent loop with 32 blocks confined to one XCD (bit 16 of loop_blocks)
+    static const int kLoopBlocks[8] = {0, -1, 16, 32, 64, 128, 256, 32 | (1 << 16)};
     r->loop_blocks = kLoopBlocks[(variant >> 10) & 7];
   }
   r->graph_dirty = true;

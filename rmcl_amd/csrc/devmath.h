@@ -319,7 +319,10 @@ RM_HD bool horn_quaternion(const double* C, double* q) {
   const double c2 = -2.0 * ss;
   const double c1 = -8.0 * det3(C);
   const double c0 = sym4_det(sym4_sub(K));
-  const double lam0 = sqrt(4.0 * ss);  // sqrt(trace K^2) = sqrt(-2 c2) >= largest eigenvalue
+  // largest eigenvalue of K = sum of the singular values of S <= sqrt(3) * |S|_F (Cauchy-Schwarz); starting Newton's
+  // iteration at or above the largest root of the quartic keeps it monotone (P convex there), so this tighter bound
+  // (the classic one is sqrt(trace K^2) = 2 |S|_F) saves iterations without changing the limit
+  const double lam0 = sqrt(3.0 * ss) * (1.0 + 1e-12);
   double lam = lam0;
   bool converged = false;
   for (int it = 0; it < 60; ++it) {

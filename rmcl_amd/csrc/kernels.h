@@ -165,7 +165,7 @@ hipError_t launch_micp_iter(const float* dataset_points, const uint8_t* dataset_
 hipError_t launch_micp_loop(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
                             const float* model_normals, const uint8_t* model_mask, uint32_t n, uint32_t n_iter,
                             const MicpCall* call, double* partials, uint32_t* barrier, MicpState* state,
-                            uint32_t nblocks, hipStream_t s);
+                            uint32_t nblocks, bool one_xcd, hipStream_t s);
 // batch: per pose finalize + umeyama -> Tdelta (sensor->base conjugated), stats
 hipError_t launch_batch_solve(const double* partials, uint32_t nblocks, uint32_t nposes, xform Tsb,
                               xform* Tdelta_out, cstats* stats_out, hipStream_t s);

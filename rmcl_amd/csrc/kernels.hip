@@ -1776,11 +1776,16 @@ struct MicpLoopParams {
   MicpState* state;      // result, written by block 0
 };
 
+// kOneXcd: the grid is 8x larger and only the blocks the dispatcher places on XCD 0 (block id % 8 == 0: observed placement,
+// used for speed only -- the barrier protocol is valid wherever the blocks land) take part, so that partials, counter and
+// correspondences meet in ONE L2 instead of crossing the fabric between eight
+template <bool kOneXcd>
 __global__ void __launch_bounds__(512) k_micp_loop(const MicpLoopParams p) {
   __shared__ double red[8][kAcc];
   __shared__ MicpState s_state;
   __shared__ xform s_Tsb, s_Tbo;
-  const uint32_t G = gridDim.x, b = blockIdx.x;
+  if (kOneXcd && (blockIdx.x & 7u) != 0u) return;
+  const uint32_t G = kOneXcd ? (gridDim.x >> 3) : gridDim.x, b = kOneXcd ? (blockIdx.x >> 3) : blockIdx.x;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) {
     s_state.T_onew_oold = xidentity();
@@ -1885,6 +1890,29 @@ struct MicpIterParams {
 __global__ void __launch_bounds__(256) k_micp_iter(const MicpIterParams p) {
   __shared__ double red[4][kAcc];
   __shared__ xform s_Tpre;
+  // The correspondences of this thread do not depend on the pre-transform the prologue is about to compute: request the
+  // first two elements (all a thread gets at reduce_num_blocks' 512 elements per block) BEFORE the prologue, so that
+  // their load latency hides behind the finalize + solve of wave 0 instead of following it.
+  constexpr int kPre = 2;
+  float pd[kPre][3], pm[kPre][3], pn[kPre][3];
+  bool pok[kPre];
+#pragma unroll
+  for (int u = 0; u < kPre; ++u) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x + static_cast<uint32_t>(u) * gridDim.x * 256u;
+    pok[u] = false;
+    if (i < p.n) {
+      const bool dok = (p.dataset_mask == nullptr) || (p.dataset_mask[i] > 0);
+      pok[u] = dok && p.model_mask[i] > 0;
+      const float* dp = p.dataset_points + 3 * static_cast<size_t>(i);
+      const float* mp = p.model_points + 3 * static_cast<size_t>(i);
+      const float* mn = p.model_normals + 3 * static_cast<size_t>(i);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { pd[u][k] = dp[k]; pm[u][k] = mp[k]; pn[u][k] = mn[k]; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { pd[u][k] = 0.f; pm[u][k] = 0.f; pn[u][k] = 0.f; }
+    }
+  }
   if (threadIdx.x < 64u) {
     if (p.first) {
       if (threadIdx.x == 0) {
@@ -1913,29 +1941,34 @@ __global__ void __launch_bounds__(256) k_micp_iter(const MicpIterParams p) {
   double acc[kAcc];
 #pragma unroll
   for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < p.n; i += gridDim.x * 256u) {
+#define RMCL_P2L_ACCUMULATE(DX, DY, DZ, IX, IY, IZ, NX, NY, NZ)                      \
+  {                                                                                 \
+    const f3 Di = xapply(Tpre, mk3(DX, DY, DZ));                                    \
+    const f3 Ii = mk3(IX, IY, IZ);                                                  \
+    const f3 Ni = mk3(NX, NY, NZ);                                                  \
+    const float spd = dot_plain(sub3(Ii, Di), Ni);                                  \
+    if (fabsf(spd) < max_dist) {                                                    \
+      const f3 Mi = add3(Di, scale3(Ni, spd));                                      \
+      const double d[3] = {Di.x, Di.y, Di.z}, m[3] = {Mi.x, Mi.y, Mi.z};            \
+      _Pragma("unroll") for (int k = 0; k < 3; ++k) { acc[k] += d[k]; acc[3 + k] += m[k]; } \
+      _Pragma("unroll") for (int r = 0; r < 3; ++r)                                 \
+        _Pragma("unroll") for (int c = 0; c < 3; ++c) acc[6 + 3 * r + c] += m[r] * d[c]; \
+      acc[15] += 1.0;                                                               \
+    }                                                                               \
+  }
+#pragma unroll
+  for (int u = 0; u < kPre; ++u)
+    if (pok[u]) RMCL_P2L_ACCUMULATE(pd[u][0], pd[u][1], pd[u][2], pm[u][0], pm[u][1], pm[u][2], pn[u][0], pn[u][1], pn[u][2])
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x + static_cast<uint32_t>(kPre) * gridDim.x * 256u; i < p.n; i += gridDim.x * 256u) {
     const bool dok = (p.dataset_mask == nullptr) || (p.dataset_mask[i] > 0);
     if (dok && p.model_mask[i] > 0) {
       const float* dp = p.dataset_points + 3 * static_cast<size_t>(i);
       const float* mp = p.model_points + 3 * static_cast<size_t>(i);
       const float* mn = p.model_normals + 3 * static_cast<size_t>(i);
-      const f3 Di = xapply(Tpre, mk3(dp[0], dp[1], dp[2]));
-      const f3 Ii = mk3(mp[0], mp[1], mp[2]);
-      const f3 Ni = mk3(mn[0], mn[1], mn[2]);
-      const float spd = dot_plain(sub3(Ii, Di), Ni);
-      if (fabsf(spd) < max_dist) {
-        const f3 Mi = add3(Di, scale3(Ni, spd));
-        const double d[3] = {Di.x, Di.y, Di.z}, m[3] = {Mi.x, Mi.y, Mi.z};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { acc[k] += d[k]; acc[3 + k] += m[k]; }
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) acc[6 + 3 * r + c] += m[r] * d[c];
-        acc[15] += 1.0;
-      }
+      RMCL_P2L_ACCUMULATE(dp[0], dp[1], dp[2], mp[0], mp[1], mp[2], mn[0], mn[1], mn[2])
     }
   }
+#undef RMCL_P2L_ACCUMULATE
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int half = 8, off = 32; half >= 1; half >>= 1, off >>= 1) {
@@ -2793,10 +2826,11 @@ hipError_t launch_reduce_finalize(const double* partials, uint32_t nblocks, uint
 hipError_t launch_micp_loop(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
                             const float* model_normals, const uint8_t* model_mask, uint32_t n, uint32_t n_iter,
                             const MicpCall* call, double* partials, uint32_t* barrier, MicpState* state,
-                            uint32_t nblocks, hipStream_t s) {
+                            uint32_t nblocks, bool one_xcd, hipStream_t s) {
   MicpLoopParams p{dataset_points, dataset_mask, model_points, model_normals, model_mask, n, n_iter, call, partials,
                    barrier, state};
-  hipLaunchKernelGGL(k_micp_loop, dim3(nblocks), dim3(512), 0, s, p);
+  if (one_xcd) hipLaunchKernelGGL((k_micp_loop<true>), dim3(nblocks * 8u), dim3(512), 0, s, p);
+  else hipLaunchKernelGGL((k_micp_loop<false>), dim3(nblocks), dim3(512), 0, s, p);
   return hipGetLastError();
 }
 

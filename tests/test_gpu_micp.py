@@ -162,7 +162,7 @@ def test_correct_batch_v1_api(ra, orc, ctx, meshes):
 
 
 @pytest.mark.parametrize("variant_bits", [0, 1 << 8, 1 << 9, (1 << 8) | (1 << 9), 1 << 10, (1 << 10) | (1 << 9), 4 << 10,
-                                          (6 << 10) | (1 << 8)])
+                                          (6 << 10) | (1 << 8), 7 << 10])
 def test_loop_variants_agree(ra, orc, ctx, meshes, variant_bits):
     """A/B code paths of the MICP loop (fused last-block reduction tail, hipGraph replay on/off, loop form: one
     launch per iteration / reduce + solve launches / persistent kernel with a grid barrier) give the same
