@@ -46,14 +46,22 @@ def algorithmic_bytes_pf(n_particles, n_beams):
 
 def measured_traffic(kernel_key):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, produced by
-    tools/pmc_find.sh + tools/traffic_from_pmc.py: separate FETCH_SIZE / WRITE_SIZE passes, KiB -> bytes;
-    gfx950's 2x FETCH_SIZE under-count applies to wide 16 B/lane streams only and is noted there)."""
+    tools/pmc_traffic.sh + tools/traffic_from_pmc.py: separate FETCH_SIZE / WRITE_SIZE passes, KiB -> bytes;
+    gfx950's 2x FETCH_SIZE under-count applies to wide 16 B/lane streams only and is noted there).  Keyed by the
+    traversal kind that was profiled ("k_find_kind17", ...): a kind without a profile reports null, never another kind's."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(path):
         return None
     with open(path) as fh:
         d = json.load(fh)
     return d.get(kernel_key, {}).get("hbm_bytes_per_launch")
+
+
+def median_kernel_ms(fn, batches=9):
+    """median over `batches` of the mean launch-to-launch time of a batch of back-to-back launches (one noisy
+    launch moves a mean of 20 by 5 %; it does not move the median of batch means)"""
+    ts = sorted(fn() for _ in range(batches))
+    return ts[len(ts) // 2]
 
 
 def main():
@@ -135,11 +143,13 @@ def main():
         elapsed = max_over_ranks(time.perf_counter() - t0)
         units_per_step = n_rays
 
-        # dominant kernel, measured live: HIP events on the rcc's own stream around back-to-back launches
-        kernel_ms = rcc.time_find(Tbm, iters=max(50, min(args.steps, 500)))
+        # dominant kernel, measured live: HIP events on the rcc's own stream around back-to-back launches; median of 9
+        # batches of 40 launches
+        kernel_ms = median_kernel_ms(lambda: rcc.time_find(Tbm, iters=40))
         b_alg = algorithmic_bytes_raycast(n_rays, len(f), 1)
-        kname = "k_find<spherical,%s>" % ("packet" if (args.variant & 0xF) == 0 else "lane")  # 15 / 1 / 5: one lane per ray
-        traffic = measured_traffic("k_find_packet" if (args.variant & 0xF) == 0 else "k_find_lane")
+        kind = rcc.find_variant(1)   # the traversal the automatic rule (or --variant) launches for this scan
+        kname = "k_find<spherical, kind %d>" % kind
+        traffic = measured_traffic("k_find_kind%d" % kind)
 
         if rank == 0 and not args.no_extras:
             # C3: MICP-L inner loop: (R) 1 find + 10 x (reduce + solve), (B) 10 x (find + reduce + solve).
@@ -180,6 +190,28 @@ def main():
             extras["c4_particle_updates_per_s"] = round(100000 / (pms * 1e-3), 1)
             extras["c4_pf_algorithmic_GBps"] = round(algorithmic_bytes_pf(100000, 256) / (pms * 1e-3) / 1e9, 2)
             extras.update(_pf_cycle(ra, syn, T, np, ctx, hm, 100000))
+            # the same scan on a REALISTIC map (room-100k: occluders, vertex noise, open ceiling) and with the O1Dn model (the
+            # documented deployment model: directions are data, +12 B/ray read)
+            vr, fr = syn.noisy_room(100000)
+            hmr = ra.import_hip_map(ctx, vr, fr)
+            Troom = T.transform_from_rpy((1.5, -2.0, 1.6), (0.02, -0.03, 0.4))
+            rr = ra.RCCHipSpherical(hmr)
+            rr.setTsb(T.identity())
+            rr.setModel(model)
+            rms = median_kernel_ms(lambda: rr.time_find(Troom, iters=40), 5)
+            extras["find_room100k_ms"] = round(rms, 5)
+            extras["find_room100k_rays_per_s"] = round(n_rays / (rms * 1e-3), 1)
+            rr.close()
+            dirs_c2 = syn.model_directions(model)
+            for nm, hmx, Tx in (("sphere100k", hm, Tbm), ("room100k", hmr, Troom)):
+                ro = ra.RCCHipO1Dn(hmx)
+                ro.setTsb(T.identity())
+                ro.setModel(model.theta.size, model.phi.size, float(model.range.min), float(model.range.max), (0.0, 0.0, 0.0), dirs_c2)
+                oms = median_kernel_ms(lambda: ro.time_find(Tx, iters=40), 5)
+                extras["find_o1dn_%s_ms" % nm] = round(oms, 5)
+                extras["find_o1dn_%s_GBps" % nm] = round((algorithmic_bytes_raycast(n_rays, len(f), 1) + 12 * n_rays) / (oms * 1e-3) / 1e9, 1)
+                ro.close()
+            hmr.release()
             # closest-point correspondences on the C2 dataset, and a 16x900 scan (rays in flight below the chip's
             # width: the four-lanes-per-ray traversal is selected automatically)
             cpc = ra.CPCHip(hm)
@@ -220,35 +252,74 @@ def main():
             extras["v1_bench_rays_per_s"] = round(1000 * 16 * 900 / dt, 1)
             extras["v1_bench_pose_corrections_per_s"] = round(1000 / dt, 1)
             small.close()
+            # two sensors through the device-resident N-sensor loop (rmclhip_micp_correct_once): 128x1024 + 16x900, 10 iterations
+            sA, sB = ra.RCCHipSpherical(hm), ra.RCCHipSpherical(hm)
+            sens = []
+            for rc_, mdl in ((sA, model), (sB, syn.model_vlp16_900())):
+                rc_.setTsb(T.identity())
+                rc_.setModel(mdl)
+                rc_.find(syn.pose_c2_truth())
+                rc_.set_dataset_from_ranges(rc_.modelView()["ranges"])
+                rc_.params.max_dist, rc_.adaptive_max_dist_min = 1.0, 0.15
+                sens.append(ra.MICPSensor("s%d" % len(sens), rc_, Tsb=T.identity(), Tbo=T.identity()))
+            loc = ra.MICPLocalization(sens, optimization_iterations=10)
+            loc.Tom_ = est
+            extras["micp_two_sensors_device_loop_ms"] = round(_median_call_ms(lambda: (setattr(loc, "Tom_", est), loc.correctOnce(device_loop=True)), reps=15), 4)
+            extras["micp_two_sensors_host_loop_ms"] = round(_median_call_ms(lambda: (setattr(loc, "Tom_", est), loc.correctOnce()), reps=15), 4)
+            sA.close()
+            sB.close()
+            # the particle filter through the multi-GPU C ABI on this one GPU (RCCL ncclCommInitAll + all-gather + all-reduces)
+            shp = ra.ShardedParticleFilterHip(v, f, devices=(local_rank,))
+            pposes, pattrs = syn.uniform_particles(100000, seed=42, bb_min=(-5, -5, -1, 0, 0, -math.pi), bb_max=(5, 5, 1, 0, 0, math.pi))
+            shp.set_particles(pposes, pattrs)
+            pdirs = syn.model_directions(syn.model_pf16())
+            pbeams = ra.beams_from_points(pdirs * np.float32(6.0))
+            extras["pf_sharded_cabi_update_allgather_ms"] = round(_median_call_ms(lambda: shp.update(pbeams, T.identity()), reps=5, warm=1), 4)
+            extras["pf_sharded_cabi_pose_estimate_ms"] = round(_median_call_ms(lambda: shp.pose_estimate(), reps=9, warm=1), 4)
+            extras["pf_sharded_cabi_allreduce_stats_ms"] = round(_median_call_ms(lambda: shp.stats(), reps=9, warm=1), 4)
+            shp.close()
 
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle as orc  # cpu_baseline leg only: the oracle is the thing timed, never the product path
             m = orc.Mesh(v, f)
-            # 16 scans per call: the oracle spawns its worker threads per call (pthread_create x cores), which would
-            # otherwise dominate a single 131 072-ray scan on a many-core host
-            per_call = 16
+            # the oracle keeps ONE pool of worker threads alive across calls and deals the scan out in chunks of 512 rays,
+            # chunk c to worker c mod N (no shared counter): it runs on ALL host threads; 8 scans per call amortise the
+            # wake-up of the pool; output arrays are reused (fresh ones cost first-touch page faults in every worker)
+            per_call = 8
             Tb = np.array([Tbm] * per_call, dtype=T.TRANSFORM)
-            buf = m.simulate_spherical(model, T.identity(), Tb, bvh=True, nthreads=cores)   # outputs reused below
-            # the thread count that serves the oracle best on this host (it does not scale to every SMT thread of a
-            # two-socket box): short trial per candidate, then the 10 s sample with the winner
-            best_nt, best_rate = cores, 0.0
-            for nt in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8)}, reverse=True):
-                t1 = time.perf_counter()
-                for _ in range(2):
-                    m.simulate_spherical(model, T.identity(), Tb, bvh=True, nthreads=nt, out=buf)
-                rate = 2 * per_call * n_rays / (time.perf_counter() - t1)
-                if rate > best_rate:
-                    best_nt, best_rate = nt, rate
+            buf = m.simulate_spherical(model, T.identity(), Tb, bvh=True, nthreads=cores)
             reps, t1 = 0, time.perf_counter()
-            while time.perf_counter() - t1 < 10.0:
-                m.simulate_spherical(model, T.identity(), Tb, bvh=True, nthreads=best_nt, out=buf)
+            while time.perf_counter() - t1 < 8.0:
+                m.simulate_spherical(model, T.identity(), Tb, bvh=True, nthreads=cores, out=buf)
                 reps += per_call
             dt = time.perf_counter() - t1
-            cpu = {"value": round(reps * n_rays / dt, 1), "unit": "rays/s", "cores": best_nt, "kind": "port",
-                   "sample": "%d x the same 128x1024 / 100k-triangle scan (16 per call) in %.1f s, CPU oracle (BVH2, same "
-                             "intersector, five output attributes), %d threads (best of %d/%d/%d/%d on a %d-thread host)"
-                             % (reps, dt, best_nt, cores, cores // 2, cores // 4, cores // 8, cores)}
+            # 1-thread row: the same scan, one core, ~4 s
+            one = m.simulate_spherical(model, T.identity(), Tb[:1], bvh=True, nthreads=1)
+            r1, t2 = 0, time.perf_counter()
+            while time.perf_counter() - t2 < 4.0:
+                m.simulate_spherical(model, T.identity(), Tb[:1], bvh=True, nthreads=1, out=one)
+                r1 += 1
+            dt1 = time.perf_counter() - t2
+            cpu = {"value": round(reps * n_rays / dt, 1), "unit": "rays/s", "cores": cores, "kind": "port",
+                   "one_thread_value": round(r1 * n_rays / dt1, 1),
+                   "sample": "%d x the same 128x1024 / 100k-triangle scan (8 per call) in %.1f s on all %d host threads (persistent "
+                             "pool, static chunks of 512 rays) + %d scans in %.1f s on ONE thread; CPU oracle (scalar BVH2 walk, same "
+                             "intersector, five output attributes)" % (reps, dt, cores, r1, dt1)}
+            # traversal-traffic view of the roofline: B_trav = sum over rays of nodes_visited * 32 + triangles
+            # tested * 36, counted by the instrumented oracle on the identical rays and a BVH2 / one-triangle-per-leaf
+            # reference tree (deterministic), against the aggregate L2 rate of 34.5 TB/s
+            m1 = orc.Mesh(v, f, max_leaf=1)
+            cnt = m1.simulate_spherical(model, T.identity(), Tb[:1], bvh=True, nthreads=cores, counters=True,
+                                        want=("hits",))["counters"]
+            b_trav = cnt["nodes_visited"] * 32 + cnt["tris_tested"] * 36
+            extras["traversal_view"] = {
+                "B_trav_bytes_per_scan": int(b_trav), "B_trav_bytes_per_ray": round(b_trav / n_rays, 1),
+                "nodes_visited_per_ray": round(cnt["nodes_visited"] / n_rays, 2), "tris_tested_per_ray": round(cnt["tris_tested"] / n_rays, 2),
+                "achieved_TBps": round(b_trav / (kernel_ms * 1e-3) / 1e12, 3), "l2_aggregate_peak_TBps": 34.5,
+                "frac_of_l2": round(b_trav / (kernel_ms * 1e-3) / 1e12 / 34.5, 4),
+                "frac_of_hbm": round(b_trav / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "tree": "oracle BVH2, 1 triangle per leaf (reference tree of SURVEY.md 8(d)), same rays as the timed scan"}
         metric = "ray-mesh intersections/s (128x1024 scan, 100k-tri mesh)"
         unit = "rays/s"
         workload = ("C2: 1 pose x 128x1024 spherical LiDAR, UV-sphere 100k triangles, find() only, 5 output "

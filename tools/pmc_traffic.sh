@@ -1,16 +1,17 @@
 #!/bin/bash
-# HBM traffic passes (rocprofv3 PMC, one counter group per run, kernel-trace only) for the three hot kernels.
-# usage (on the GPU box, via gpurun): bash tools/pmc_traffic.sh <tag>
+# HBM traffic passes (rocprofv3 PMC, ONE counter per run, kernel-trace only -- never combined with sys / hip / hsa traces) for the
+# hot kernels, in the exact configuration bench.py times.  usage (on the GPU box, via gpurun): bash tools/pmc_traffic.sh <tag>
 set -u
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/traffic_$1
 mkdir -p $OUT
-run() { # name counters... -- cmd
+run() { # name counter cmd...
   name=$1; shift; ctr=$1; shift
   timeout 300 rocprofv3 --kernel-trace --pmc $ctr -d $OUT -o $name -- "$@" > $OUT/$name.stdout 2>&1 || echo "$name failed" >> $OUT/errors.txt
 }
-for v in 1 0; do
+# the automatic traversal (15 -> kind 17 for C2) and the main A/B kinds, each in its own pass pair
+for v in 15 1 2; do
   run find_v${v}_fetch FETCH_SIZE python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras --variant $v
   run find_v${v}_write WRITE_SIZE python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras --variant $v
 done

@@ -21,10 +21,19 @@ def avg(db, kernel_like, counter):
 
 def main(d, out):
     res = {}
-    for key, like, pre, wide in (("k_find_lane", "%k_find<1u, 1>%", "find_v1", False), ("k_find_packet", "%k_find<1u, 0>%", "find_v0", False),
-                                 ("k_pf_update", "%k_pf_update%", "pf", False), ("k_reduce_partials", "%k_reduce_partials%", "red", True)):
-        f, nf = avg("%s/%s_fetch_results.db" % (d, pre), like, "FETCH_SIZE")
-        w, nw = avg("%s/%s_write_results.db" % (d, pre), like, "WRITE_SIZE")
+    # key = the kernel as bench.py names it (traversal kind of k_find), like = its demangled template arguments
+    specs = (("k_find_kind17", "%k_find<1u, 17>%", "find_v15", False), ("k_find_kind1", "%k_find<1u, 1>%", "find_v1", False),
+             ("k_find_kind2", "%k_find<1u, 2>%", "find_v2", False), ("k_pf_update", "%k_pf_update%", "pf", False),
+             ("k_micp_iter", "%k_micp_iter%", "red", True), ("k_reduce_partials", "%k_reduce_partials%", "red", True))
+    for key, like, pre, wide in specs:
+        try:
+            f, nf = avg("%s/%s_fetch_results.db" % (d, pre), like, "FETCH_SIZE")
+            w, nw = avg("%s/%s_write_results.db" % (d, pre), like, "WRITE_SIZE")
+        except Exception as e:  # pass missing
+            print("skip", key, e)
+            continue
+        if nf == 0 and nw == 0:
+            continue
         fb, wb = f * 1024.0, w * 1024.0
         res[key] = {"fetch_bytes_measured": round(fb), "write_bytes_measured": round(wb),
                     "fetch_correction": 2.0 if wide else 1.0,
