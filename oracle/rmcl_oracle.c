@@ -1612,7 +1612,7 @@ int orc_wavesim_ww(const uint32_t* nodes, const uint32_t* tris, const float* O, 
   for (uint32_t i = 0; i < nlanes; ++i) {
     out[3] += L[i].nvisit; if (L[i].nvisit > out[4]) out[4] = L[i].nvisit; out[5] += L[i].lvisit;
     if (t_out) t_out[i] = L[i].found ? L[i].best_t : -1.0f;
-    if (face_out) face_out[i] = L[i].best_f;
+    if (face_out) face_out[i] = (mode & 0x10000) ? (uint32_t)L[i].nvisit : L[i].best_f;   /* analysis: per-lane node visits */
   }
   free(L);
   return 0;
