@@ -921,7 +921,8 @@ float orc_evaluate_rcc(const orc_mesh* m, const orc_range_measurement* meas, con
     if (real_hit) {
       const orc_vec3 preal = v_add(meas->orig, v_scale(meas->dir, meas->range));
       const orc_vec3 pint = v_add(meas->orig, v_scale(meas->dir, t));
-      error = fabsf(v_dot_plain(v_sub(pint, preal), m->tris[face].n));
+      /* correspondence_type 2: Embree's rayhit.hit.Ng, not normalised (PCDSensorUpdaterEmbree.cpp:56-66) */
+      error = fabsf(v_dot_plain(v_sub(pint, preal), p->correspondence_type == 2 ? m->tris[face].Ng : m->tris[face].n));
     } else error = p->real_miss_sim_hit_error;
   } else {
     error = real_hit ? p->real_hit_sim_miss_error : p->real_miss_sim_miss_error;

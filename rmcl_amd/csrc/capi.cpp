@@ -1549,7 +1549,8 @@ rmclhip_status rmclhip_pf_set_params(rmclhip_pf* f, const rmclhip_pf_params* p) 
   ApiGuard guard_("rmclhip_pf_set_params");
   if (!f || !p) return fail(RMCLHIP_ERR_INVALID, "pf_set_params: null");
   if (!(p->dist_sigma > 0.f)) return fail(RMCLHIP_ERR_INVALID, "pf_set_params: dist_sigma must be > 0");
-  if (p->correspondence_type > 1u) return fail(RMCLHIP_ERR_INVALID, "pf_set_params: correspondence_type must be 0 (RCC) or 1 (CPC)");
+  if (p->correspondence_type > 2u)
+    return fail(RMCLHIP_ERR_INVALID, "pf_set_params: correspondence_type must be 0 (RCC), 1 (CPC) or 2 (RCC, Embree Ng)");
   f->params = *p;
   return RMCLHIP_OK;
 }
@@ -1600,6 +1601,7 @@ static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, 
   p.range_max = f->params.sensor_range.max;
   p.max_n_meas = f->params.max_n_meas;
   p.errors = f->errors_dev;
+  p.raw_ng = (f->params.correspondence_type == 2u) ? 1u : 0u;
   // particles per workgroup: ~2048 rays per block (measured 4-6 % faster than 4096: shorter tail per block, more
   // blocks to balance), at most 64 particles, evals must fit 32 KB of LDS
   uint32_t pb = 2048u / n_beams;

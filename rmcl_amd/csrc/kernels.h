@@ -89,6 +89,7 @@ struct PfParams {
   uint32_t max_n_meas;
   float* errors;                 // nullable [n_particles*n_beams]
   uint32_t particles_per_block;
+  uint32_t raw_ng;               // correspondence_type 2: error against Embree's un-normalised Ng
 };
 
 // per-call inputs of the device-resident MICP loop: written by ONE H2D copy so that the whole loop can be a

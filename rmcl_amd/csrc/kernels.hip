@@ -2154,6 +2154,14 @@ __device__ __forceinline__ g1d g1d_add(g1d a, g1d b) {
   return r;
 }
 
+// Normal the point-to-plane error of evaluate_rcc is taken against: the unit face normal (OptiX program,
+// BeamEvaluateProgram.cu:104-113; dwords 12..14 of the record) or, for correspondence_type 2, Embree's un-normalised
+// rayhit.hit.Ng = cross(e2, e1) that the Embree updater reads (PCDSensorUpdaterEmbree.cpp:56-66; dwords 9..11).
+__device__ __forceinline__ f3 pf_error_normal(const uint32_t* tris, uint32_t rec, uint32_t raw_ng) {
+  const uint4 r = reinterpret_cast<const uint4*>(tris)[static_cast<size_t>(rec) * 4u + (raw_ng ? 2u : 3u)];
+  return raw_ng ? mk3(asf(r.y), asf(r.z), asf(r.w)) : mk3(asf(r.x), asf(r.y), asf(r.z));
+}
+
 // kTrav: 0 = while-while traversal, per-lane stack 16 entries in LDS + scratch overflow (default)
 //        1 = while-while traversal, per-lane stack entirely in LDS
 //        2 = original single-loop traversal, stack in LDS (A/B)
@@ -2213,8 +2221,7 @@ __global__ void __launch_bounds__(256) k_pf_update(const PfParams p) {
       float error;
       if (sim_hit) {
         if (real_hit) {
-          const uint4 nrec = reinterpret_cast<const uint4*>(p.tris)[static_cast<size_t>(h.rec) * 4u + 3u];
-          const f3 n = mk3(asf(nrec.x), asf(nrec.y), asf(nrec.z));
+          const f3 n = pf_error_normal(p.tris, h.rec, p.raw_ng);
           const f3 preal = add3(org, scale3(dir, range));
           const f3 pint = add3(org, scale3(dir, h.t));
           error = fabsf(dot_plain(sub3(pint, preal), n));
@@ -2305,8 +2312,7 @@ __global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
           float error;
           if (sim_hit) {
             if (real_hit) {
-              const uint4 nrec = reinterpret_cast<const uint4*>(p.tris)[static_cast<size_t>(best_rec) * 4u + 3u];
-              const f3 n = mk3(asf(nrec.x), asf(nrec.y), asf(nrec.z));
+              const f3 n = pf_error_normal(p.tris, best_rec, p.raw_ng);
               const f3 preal = add3(O, scale3(D, range));
               const f3 pint = add3(O, scale3(D, best_t));
               error = fabsf(dot_plain(sub3(pint, preal), n));

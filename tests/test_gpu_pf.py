@@ -129,6 +129,37 @@ def test_custom_parameters_and_empty_inputs(ra, orc, ctx, meshes):
     assert np.array_equal(d_attrs.download().view(np.uint8), attrs.view(np.uint8))
 
 
+@pytest.mark.parametrize("variant", [0, 2, 48])
+def test_embree_geometric_normal_mode(ra, orc, ctx, meshes, variant):
+    """correspondence_type 2: the error of evaluate_rcc against Embree's UN-normalised rayhit.hit.Ng
+    (PCDSensorUpdaterEmbree.cpp:56-66) instead of the OptiX program's unit normal: bit-for-bit the oracle's mode-2
+    errors, equal to |Ng| x the unit-normal errors wherever both sides hit, penalties unchanged."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room30k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    model = syn.model_c1()
+    truth = T.transform_from_rpy((1.0, -1.5, 1.2), (0.0, 0.0, 0.5))
+    cloud = m.simulate_spherical(model, T.identity(), truth, bvh=True)["points"]
+    beams = ra.sample_beams(cloud, 64, seed=3)
+    poses, attrs = syn.uniform_particles(777, seed=8, bb_min=(-9, -9, 0.2, 0, 0, -math.pi), bb_max=(9, 9, 3.0, 0, 0, math.pi))
+    Tsb = syn.tsb_offset()
+    a_gpu, e_gpu = _run(ra, ctx, hm, poses, attrs.copy(), beams, Tsb, params=T.pf_params(correspondence_type=2), variant=variant)
+    a_ref = attrs.copy()
+    e_ref = m.pf_update(poses, a_ref, beams, Tsb, orc.pf_params(correspondence_type=2), bvh=True, nthreads=8, want_errors=True)
+    _check(a_gpu, e_gpu, a_ref, e_ref, "embree Ng")
+    # against the unit-normal mode: same penalties, point-to-plane errors scaled by |Ng| = 2 * area (never equal on this map)
+    a_unit, e_unit = _run(ra, ctx, hm, poses, attrs.copy(), beams, Tsb, variant=variant)
+    pen = (e_unit == 100.0)
+    assert pen.any() and np.array_equal(e_gpu[pen], e_unit[pen])
+    geo = ~pen & (e_unit > 1e-3)
+    ratio = e_gpu[geo] / e_unit[geo]
+    tri = v[f]
+    two_area = np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
+    assert ratio.min() > 0.5 * two_area.min() and ratio.max() < 2.0 * two_area.max()
+    assert not np.allclose(ratio, 1.0, atol=1e-2)
+
+
 def test_c4_full_size_properties(ra, orc, ctx, meshes):
     """BASELINE config C4 at full size (100 000 particles x 256 beams, sphere-100k): far beyond what the oracle
     finishes in seconds, so size-independent properties are checked instead --

@@ -344,6 +344,28 @@ def test_evaluate_rcc_four_cases(orc, meshes):
     assert err((1, 0, 0), 90.0)[0] == 0.5            # real miss, sim miss
 
 
+def test_evaluate_rcc_embree_geometric_normal(orc, meshes):
+    """correspondence_type 2 reads Embree's un-normalised Ng (PCDSensorUpdaterEmbree.cpp:56-66): the cube's walls are two
+    10 x 10 right triangles each, |Ng| = 2 * area = 100, so the 1 m plane distance becomes 100; penalties are unchanged."""
+    v, f = meshes("cube")
+    m = orc.Mesh(v, f)
+    poses = np.array([orc.transform()], dtype=orc.TRANSFORM)
+    beams = np.zeros(2, dtype=orc.RANGE_MEASUREMENT)
+    beams["dir"]["x"] = 1.0
+    beams["range"] = (4.0, 90.0)
+    tri = v[f]
+    two_area = np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
+    assert np.allclose(two_area, two_area[0])
+    for bvh in (False, True):
+        e = {}
+        for ct in (0, 2):
+            attrs = np.zeros(1, dtype=orc.PARTICLE_ATTRIBUTES)
+            e[ct] = m.pf_update(poses, attrs, beams, orc.transform(), orc.pf_params(correspondence_type=ct), bvh=bvh,
+                                want_errors=True)[0]
+        assert abs(e[0][0] - 1.0) < 1e-6 and abs(e[2][0] - two_area[0]) < 1e-3 * two_area[0]
+        assert e[0][1] == e[2][1] == 100.0
+
+
 def test_golden_g6_reproduces(orc, meshes):
     from rmcl_amd import types as T
     g = np.load(golden_path("g6_pf_cube.npz"))
