@@ -139,8 +139,10 @@ def main():
             rcc.find_async(Tbm)
         rcc.sync()
         torch.cuda.synchronize()
+        t1 = time.perf_counter()   # this rank's K steps are complete; the closing barrier itself is not part of the K steps
         barrier()
-        elapsed = max_over_ranks(time.perf_counter() - t0)
+        torch.cuda.synchronize()
+        elapsed = max_over_ranks(t1 - t0)
         units_per_step = n_rays
 
         # dominant kernel, measured live: HIP events on the rcc's own stream around back-to-back launches; median of 9
@@ -358,8 +360,10 @@ def main():
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
+        t1 = time.perf_counter()
         barrier()
-        elapsed = max_over_ranks(time.perf_counter() - t0)
+        torch.cuda.synchronize()
+        elapsed = max_over_ranks(t1 - t0)
         units_per_step = n_local * n_beams
         kernel_ms = upd.time_update(d_poses, d_attrs, hi - lo, iters=5)
         b_alg = algorithmic_bytes_pf(hi - lo, n_beams)

@@ -84,10 +84,15 @@ typedef struct {
   float real_miss_sim_miss_error;   /* 0    */
   rmclhip_interval sensor_range;    /* [0.05, 80] */
   uint32_t max_n_meas;              /* MAX_N_MEAS = 10000, ParticleAttributes.hpp:34 */
-  uint32_t correspondence_type;     /* 0 = RCC with UNIT face normals (the OptiX program, BeamEvaluateProgram.cu:104-113),
-                                     * 1 = CPC (evaluate_cpc, :88-95),
-                                     * 2 = RCC with Embree's un-normalised rayhit.hit.Ng = cross(v2-v0, v0-v1), i.e. the
-                                     *     error of evaluate_rcc (:56-66) scales with twice the triangle's area */
+  uint32_t correspondence_type;     /* 0 = RCC, the hybrid SURVEY.md App. B.1 recommends: UNIT face normals (as the OptiX
+                                     *     program and rmagine's simulators) with the Embree updater's ray rules
+                                     *     (tfar = inf, sim hit needs t > sensor_range.min);
+                                     * 1 = CPC (evaluate_cpc, :88-95);
+                                     * 2 = RCC exactly as PCDSensorUpdaterEmbree.cpp:18-86: like 0 but the error is taken
+                                     *     against Embree's un-normalised rayhit.hit.Ng = cross(v2-v0, v0-v1), i.e. it scales
+                                     *     with twice the triangle's area;
+                                     * 3 = RCC exactly as optix/BeamEvaluateProgram.cu:15-130: unit normals, optixTrace
+                                     *     tmax = 1e4, every hit is a sim hit (no sensor_range.min test) */
 } rmclhip_pf_params;
 
 /* sensor_msgs/PointCloud2 layout of the fields this path reads (datatype: PointField FLOAT32 = 7, FLOAT64 = 8) and

@@ -913,9 +913,12 @@ float orc_evaluate_rcc(const orc_mesh* m, const orc_range_measurement* meas, con
   const int real_hit = (meas->range >= p->sensor_range.min && meas->range <= p->sensor_range.max);
   float t = 0; uint32_t face = 0;
   int hit;
-  if (use_bvh) hit = orc_intersect_bvh(m, meas->orig, meas->dir, 0.0f, INFINITY, &t, &face, NULL);
-  else hit = orc_intersect_brute(m, meas->orig, meas->dir, 0.0f, INFINITY, &t, &face);
-  const int sim_hit = (hit > 0) && (t > p->sensor_range.min);
+  /* correspondence_type 3 = the OptiX program's rules (BeamEvaluateProgram.cu:44-49,77-120): tmax 1e4, any hit counts */
+  const int optix = (p->correspondence_type == 3);
+  const float tfar = optix ? 1.0e4f : INFINITY;
+  if (use_bvh) hit = orc_intersect_bvh(m, meas->orig, meas->dir, 0.0f, tfar, &t, &face, NULL);
+  else hit = orc_intersect_brute(m, meas->orig, meas->dir, 0.0f, tfar, &t, &face);
+  const int sim_hit = (hit > 0) && (optix || t > p->sensor_range.min);
   float error;
   if (sim_hit) {
     if (real_hit) {
@@ -1504,6 +1507,7 @@ typedef struct {
   float o[3], inv[3]; orc_vec3 O, D;
   uint32_t stack[128]; float stack_t[128];
   uint64_t nvisit, lvisit;
+  uint32_t pend;   /* postponed leaf (mode 0x20000), 0 = none */
 } ws_lane;
 
 static int ws_box(const float* nd, uint32_t c, const float* o, const float* inv, float best_t, float* tn_out, float* tf_out)
@@ -1557,6 +1561,13 @@ int orc_wavesim_ww(const uint32_t* nodes, const uint32_t* tris, const float* O, 
     const uint32_t leaf_trigger = ((uint32_t)mode >> 8) & 0xFFu;
     for (;;) {
       int inner = 0; uint32_t holding = 0;
+      /* mode 0x20000, "speculative while-while" (Aila & Laine 2009): a lane that arrives at a leaf parks it (one slot)
+       * and keeps walking with the next stack entry instead of idling until the leaf phase */
+      if (mode & 0x20000)
+        for (uint32_t i = 0; i < nlanes; ++i) {
+          ws_lane* l = &L[i];
+          if (!l->done && (l->cur & 0x80000000u) && l->pend == 0 && l->sp > 0) { l->pend = l->cur; ws_pop(l, mode); if (l->done) { l->done = 0; l->cur = l->pend; l->pend = 0; } }
+        }
       for (uint32_t i = 0; i < nlanes; ++i) {
         inner |= (!L[i].done && !(L[i].cur & 0x80000000u));
         holding += (!L[i].done && (L[i].cur & 0x80000000u)) ? 1u : 0u;
@@ -1589,10 +1600,11 @@ int orc_wavesim_ww(const uint32_t* nodes, const uint32_t* tris, const float* O, 
     uint32_t maxcnt = 0; int anyleaf = 0;
     for (uint32_t i = 0; i < nlanes; ++i) {
       ws_lane* l = &L[i];
-      if (l->done || !(l->cur & 0x80000000u)) continue;
+      if (l->done || (!(l->cur & 0x80000000u) && l->pend == 0)) continue;
       anyleaf = 1;
       l->lvisit++;
-      const uint32_t first = l->cur & 0x0FFFFFFFu, cnt = ((l->cur >> 28) & 7u) + 1u;
+      const uint32_t leaf = l->pend ? l->pend : l->cur;
+      const uint32_t first = leaf & 0x0FFFFFFFu, cnt = ((leaf >> 28) & 7u) + 1u;
       if (cnt > maxcnt) maxcnt = cnt;
       for (uint32_t k = 0; k < cnt; ++k) {
         const float* r = (const float*)(tris + 16u * (first + k));
@@ -1605,7 +1617,7 @@ int orc_wavesim_ww(const uint32_t* nodes, const uint32_t* tris, const float* O, 
           if (!l->found || t < l->best_t || (t == l->best_t && f < l->best_f)) { l->best_t = t; l->best_f = f; l->found = 1; }
         }
       }
-      ws_pop(l, mode);
+      if (l->pend) l->pend = 0; else ws_pop(l, mode);
     }
     if (anyleaf) { out[1]++; out[2] += maxcnt; est += (coop == 1) ? cl * maxcnt : cl; }
   }

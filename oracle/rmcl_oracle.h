@@ -56,7 +56,7 @@ typedef struct {
   float real_miss_sim_miss_error;
   orc_interval sensor_range;
   uint32_t max_n_meas;          /* 10000, ParticleAttributes.hpp:34 */
-  uint32_t correspondence_type; /* 0 = evaluate_rcc (unit normals), 1 = evaluate_cpc (PCDSensorUpdaterEmbree.cpp:211-222), 2 = evaluate_rcc with Embree's raw Ng */
+  uint32_t correspondence_type; /* 0 = evaluate_rcc (unit normals), 1 = evaluate_cpc (PCDSensorUpdaterEmbree.cpp:211-222), 2 = evaluate_rcc with Embree's raw Ng, 3 = the OptiX program's rules (tmax 1e4, no range.min test) */
 } orc_pf_params;
 
 typedef struct {

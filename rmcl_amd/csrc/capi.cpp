@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <random>
 #include <string>
 #include <vector>
@@ -1549,8 +1550,8 @@ rmclhip_status rmclhip_pf_set_params(rmclhip_pf* f, const rmclhip_pf_params* p) 
   ApiGuard guard_("rmclhip_pf_set_params");
   if (!f || !p) return fail(RMCLHIP_ERR_INVALID, "pf_set_params: null");
   if (!(p->dist_sigma > 0.f)) return fail(RMCLHIP_ERR_INVALID, "pf_set_params: dist_sigma must be > 0");
-  if (p->correspondence_type > 2u)
-    return fail(RMCLHIP_ERR_INVALID, "pf_set_params: correspondence_type must be 0 (RCC), 1 (CPC) or 2 (RCC, Embree Ng)");
+  if (p->correspondence_type > 3u)
+    return fail(RMCLHIP_ERR_INVALID, "pf_set_params: correspondence_type must be 0 (RCC), 1 (CPC), 2 (RCC, Embree rules) or 3 (RCC, OptiX rules)");
   f->params = *p;
   return RMCLHIP_OK;
 }
@@ -1602,6 +1603,8 @@ static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, 
   p.max_n_meas = f->params.max_n_meas;
   p.errors = f->errors_dev;
   p.raw_ng = (f->params.correspondence_type == 2u) ? 1u : 0u;
+  p.sim_min_range = (f->params.correspondence_type == 3u) ? 0u : 1u;
+  p.ray_tfar = (f->params.correspondence_type == 3u) ? 1.0e4f : std::numeric_limits<float>::infinity();
   // particles per workgroup: ~2048 rays per block (measured 4-6 % faster than 4096: shorter tail per block, more
   // blocks to balance), at most 64 particles, evals must fit 32 KB of LDS
   uint32_t pb = 2048u / n_beams;

@@ -90,6 +90,8 @@ struct PfParams {
   float* errors;                 // nullable [n_particles*n_beams]
   uint32_t particles_per_block;
   uint32_t raw_ng;               // correspondence_type 2: error against Embree's un-normalised Ng
+  uint32_t sim_min_range;        // sim hit requires t > sensor_range.min (Embree updater :47; the OptiX program does not)
+  float ray_tfar;                // inf (Embree updater :27) or 1e4 (optixTrace tmax, BeamEvaluateProgram.cu:48)
 };
 
 // per-call inputs of the device-resident MICP loop: written by ONE H2D copy so that the whole loop can be a

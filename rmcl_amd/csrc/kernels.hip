@@ -2210,14 +2210,14 @@ __global__ void __launch_bounds__(256) k_pf_update(const PfParams p) {
       continue;
     }
     RayHit h;
-    const float rtf = (live && finite) ? __builtin_inff() : -1.0f;
+    const float rtf = (live && finite) ? p.ray_tfar : -1.0f;
     if (kTrav == 0) trace_lane_bf<16>(p.nodes, p.tris, org, dir, rtf, stacks + threadIdx.x, h);
     else if (kTrav == 1) trace_lane_ww<64>(p.nodes, p.tris, org, dir, rtf, stacks + threadIdx.x, 256u, h);
     else trace_lane(p.nodes, p.tris, org, dir, rtf, stacks + threadIdx.x, 256u, h);
     if (live) {
       // evaluate_rcc (PCDSensorUpdaterEmbree.cpp:18-86) with unit face normals (BeamEvaluateProgram.cu:104-113)
       const bool real_hit = (range >= p.range_min) && (range <= p.range_max);
-      const bool sim_hit = (h.rec != kNone) && (h.t > p.range_min);
+      const bool sim_hit = (h.rec != kNone) && (!p.sim_min_range || h.t > p.range_min);
       float error;
       if (sim_hit) {
         if (real_hit) {
@@ -2308,7 +2308,7 @@ __global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
           // evaluate_rcc (PCDSensorUpdaterEmbree.cpp:18-86) with unit face normals (BeamEvaluateProgram.cu:104-113)
           const uint32_t pi = rr / p.n_beams, b = rr - pi * p.n_beams;
           const bool real_hit = (range >= p.range_min) && (range <= p.range_max);
-          const bool sim_hit = (best_rec != kNone) && (best_t > p.range_min);
+          const bool sim_hit = (best_rec != kNone) && (!p.sim_min_range || best_t > p.range_min);
           float error;
           if (sim_hit) {
             if (real_hit) {
@@ -2348,7 +2348,7 @@ __global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
           O = xapply(Tsm, mk3(bm[0], bm[1], bm[2]));
           range = bm[6];
           rs = make_ray_slab(O, D);
-          best_t = __builtin_inff();
+          best_t = p.ray_tfar;
           best_rec = kNone;
           sp = 1;
           has_ray = true;
@@ -2395,7 +2395,7 @@ __global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
     }
     // phase 2: this lane's leaf (if any); tfar = infinity
     if ((cur != kDone) && (cur & kLeafBit)) {
-      leaf_loop(p.tris, cur, O, D, __builtin_inff(), best_t, best_rec);
+      leaf_loop(p.tris, cur, O, D, p.ray_tfar, best_t, best_rec);
       --sp;
       cur = RMCL_ROW_LD(sp);
     }

@@ -103,5 +103,5 @@ def test_pf_update_with_closest_point_errors(ra, orc, ctx, meshes, n_particles, 
     assert_close_rel(a_gpu["likelihood"]["sigma"], a_ref["likelihood"]["sigma"], 1e-4, 1e-10, "cpc sigma")
     assert e_ref.max() < 20 and e_ref.min() >= 0       # distances, never the 100 m miss penalty
     with pytest.raises(ra.RmclHipError):
-        upd.config = T.pf_params(correspondence_type=3)
+        upd.config = T.pf_params(correspondence_type=4)
         upd.update(d_poses, d_attrs)

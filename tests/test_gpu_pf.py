@@ -160,6 +160,32 @@ def test_embree_geometric_normal_mode(ra, orc, ctx, meshes, variant):
     assert not np.allclose(ratio, 1.0, atol=1e-2)
 
 
+@pytest.mark.parametrize("variant", [0, 48])
+def test_optix_program_rules_mode(ra, orc, ctx, meshes, variant):
+    """correspondence_type 3 = optix/BeamEvaluateProgram.cu:15-130 exactly: tmax 1e4 and EVERY hit is a sim hit (the Embree
+    updater also asks t > sensor_range.min, PCDSensorUpdaterEmbree.cpp:47).  Particles hugging a wall make the two rules
+    differ: hits closer than range.min are point-to-plane errors here and 'sim miss' penalties in mode 0."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("cube")                                   # walls at +-5
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    poses, attrs = syn.uniform_particles(600, seed=13, bb_min=(4.7, -4, -2, 0, 0, -math.pi), bb_max=(4.999, 4, 2, 0, 0, math.pi))
+    beams = ra.beams_from_points(syn.model_directions(syn.model_pf16())[::5] * np.float32(3.0))
+    kw = dict(range_min=0.5, range_max=80.0)
+    out = {}
+    for ct in (0, 3):
+        a_gpu, e_gpu = _run(ra, ctx, hm, poses, attrs.copy(), beams, T.identity(), params=T.pf_params(correspondence_type=ct, **kw),
+                            variant=variant)
+        a_ref = attrs.copy()
+        e_ref = m.pf_update(poses, a_ref, beams, T.identity(), orc.pf_params(correspondence_type=ct, **kw), bvh=True, nthreads=4,
+                            want_errors=True)
+        _check(a_gpu, e_gpu, a_ref, e_ref, "rules %d" % ct)
+        out[ct] = e_gpu
+    differ = out[0] != out[3]
+    assert differ.any()                                     # near-wall hits: penalty (mode 0) vs plane distance (mode 3)
+    assert np.all(out[0][differ] == 100.0) and np.all(out[3][differ] < 10.0)
+
+
 def test_c4_full_size_properties(ra, orc, ctx, meshes):
     """BASELINE config C4 at full size (100 000 particles x 256 beams, sphere-100k): far beyond what the oracle
     finishes in seconds, so size-independent properties are checked instead --
