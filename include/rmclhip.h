@@ -298,6 +298,24 @@ rmclhip_status rmclhip_rcc_time_correct_once(rmclhip_rcc* rcc, const rmclhip_tra
  * of the MICP loop (0 = one launch per iteration, the default; 1 = reduce + solve launches; 2..6 = persistent
  * kernel with 16..256 blocks and a grid barrier, A/B) */
 rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* rcc, int variant);
+/* Moment form of the schedule-(R) loop of rmclhip_rcc_correct_once (refind_each_iteration = 0; micp_localization.cpp:900-964
+ * iterates statistics_p2l + umeyama over FIXED correspondences): the gate |dist| < max_dist is the only part of the 16 raw
+ * sums that is not a polynomial in the pre-transform, so correspondences whose gate decision cannot change while the
+ * pre-transform stays within bounds learnt from the previous corrections are summarised ONCE as 82 moments, the few others
+ * are re-evaluated every iteration, and all iterations run in one single-workgroup launch.  When a pre-transform leaves the
+ * bounds, or too many correspondences are undecided, the library falls back to one streaming launch per iteration: the
+ * result never depends on the bounds (both forms agree to f64 summation order).  mode 0 = never, 1 = automatic (default). */
+typedef struct {
+  uint32_t attempts, done, cap_exits, overflows;   /* outcomes since the operator was created */
+  uint32_t last_code;                              /* 0 done, 1 pre-transform left the bounds, 2 > 4096 undecided */
+  uint32_t last_uncertain;                         /* undecided correspondences of the last attempt */
+  float last_rho, last_tau;                        /* largest |2 sin(theta/2)| and |t| of its pre-transforms */
+  float rho_cap, tau_cap;                          /* bounds the next attempt will use */
+  uint32_t last_setup_clocks, last_loop_clocks;    /* diagnostics: shader clocks the single-workgroup launch spent before /
+                                                    * in its iterations (last completed attempt) */
+} rmclhip_micp_fast_info;
+rmclhip_status rmclhip_rcc_set_micp_fast(rmclhip_rcc* rcc, int mode);
+rmclhip_status rmclhip_rcc_micp_fast_info(const rmclhip_rcc* rcc, rmclhip_micp_fast_info* out);
 /* the traversal (bits 0..3 above, never 15) a find of `nposes` scans of the current model would launch */
 rmclhip_status rmclhip_rcc_find_variant(const rmclhip_rcc* rcc, uint32_t nposes, int* variant_out);
 /* DIAGNOSTICS (tools/probe_find.py; not part of the reference interface): one spherical find() through an instrumented

@@ -47,6 +47,12 @@ class PFParams(C.Structure):
                 ("correspondence_type", C.c_uint32)]
 
 
+class MicpFastInfo(C.Structure):
+    _fields_ = [("attempts", C.c_uint32), ("done", C.c_uint32), ("cap_exits", C.c_uint32), ("overflows", C.c_uint32),
+                ("last_code", C.c_uint32), ("last_uncertain", C.c_uint32), ("last_rho", C.c_float), ("last_tau", C.c_float),
+                ("rho_cap", C.c_float), ("tau_cap", C.c_float), ("last_setup_clocks", C.c_uint32), ("last_loop_clocks", C.c_uint32)]
+
+
 class PointCloud2Layout(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("point_step", C.c_uint32), ("row_step", C.c_uint32),
                 ("offset_x", C.c_uint32), ("offset_y", C.c_uint32), ("offset_z", C.c_uint32), ("datatype", C.c_uint32)]
@@ -125,6 +131,8 @@ SIGNATURES = {
     "rmclhip_rcc_time_correct_once": (_i32, [_vp, _vp, _vp, _u32, _dbl, _i32, _u32, C.POINTER(_f32)]),
     "rmclhip_rcc_set_variant": (_i32, [_vp, _i32]),
     "rmclhip_rcc_find_variant": (_i32, [_vp, _u32, C.POINTER(_i32)]),
+    "rmclhip_rcc_set_micp_fast": (_i32, [_vp, _i32]),
+    "rmclhip_rcc_micp_fast_info": (_i32, [_vp, C.POINTER(MicpFastInfo)]),
     "rmclhip_debug_wave_clock": (_i32, [_vp, _vp, _vp, _sz, C.POINTER(_u32)]),
     "rmclhip_debug_probe_find": (_i32, [_vp, _vp, _i32, _vp, _sz, C.POINTER(_u32)]),
     "rmclhip_rcc_find_batch": (_i32, [_vp, _vp, _u32]),

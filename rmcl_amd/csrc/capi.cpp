@@ -171,13 +171,27 @@ struct rmclhip_rcc {
     int kind = 0, variant = 0, tile = 0, fused = 0, has_mask = 0;
     const void* ptrs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool operator==(const MicpKey& o) const { return std::memcmp(this, &o, sizeof(MicpKey)) == 0; }
-  } micp_key;
+  } micp_key, micp_fast_key;
   bool use_graph = true;
+  bool fast_graph_dirty = true;    // same, for the moment-form graph
   bool graph_dirty = true;         // set by setModel / set_variant: by-value launch arguments changed
   size_t tickets_cap = 0;
   int loop_blocks = 0;             // MICP loop form (schedule R): 0 one launch per iteration (k_micp_iter), -1 classic
                                    // reduce + solve launches, > 0 persistent k_micp_loop with this many blocks
   bool fused_tail = false;         // true: last-block tail inside the reduction kernel (measured slower, A/B only)
+  // moment form of the schedule-(R) loop (launch_micp_fast): tried first when the previous corrections say the gate
+  // decisions are stable; the per-iteration form above is the fallback and the reference for the result
+  int fast_mode = 1;               // 0 off, 1 automatic
+  DevBuf<double> d_fast_partials;
+  DevBuf<unsigned long long> d_fast_mask;
+  MicpFastStatus* h_fast_status = nullptr;      // pinned, host-mapped
+  MicpFastStatus* h_fast_status_dev = nullptr;
+  hipGraphExec_t micp_fast_exec = nullptr;
+  hipGraph_t micp_fast_graph = nullptr;
+  float fast_rho_cap = 0.02f, fast_tau_cap = 0.1f;   // bounds on |2 sin(theta/2)| and |t| of the pre-transforms
+  uint32_t fast_holdoff = 0;       // corrections to skip the attempt for (after repeated overflows)
+  uint32_t fast_overflows = 0;     // consecutive
+  rmclhip_micp_fast_info fast_info = {};
   // batch
   DevBuf<uint8_t> d_raw;           // staged PointCloud2 bytes (set_input_pointcloud2)
   DevBuf<xform> d_Tbm, d_Tsm, d_Tms, d_Tdelta;
@@ -408,6 +422,8 @@ rmclhip_status rmclhip_rcc_create(rmclhip_ctx* ctx, rmclhip_map* map, rmclhip_rc
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_state), sizeof(MicpState), hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&r->h_state_dev), r->h_state, 0);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->d_state), 2 * sizeof(MicpState));
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_fast_status), sizeof(MicpFastStatus), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&r->h_fast_status_dev), r->h_fast_status, 0);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->d_counter), sizeof(uint32_t));
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_call), sizeof(MicpCall), hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->d_call), sizeof(MicpCall));
@@ -444,6 +460,10 @@ void rmclhip_rcc_destroy(rmclhip_rcc* r) {
   if (r->d_tickets) DBG_STEP(hipFree(r->d_tickets));
   if (r->micp_exec) DBG_STEP(hipGraphExecDestroy(r->micp_exec));
   if (r->micp_graph) DBG_STEP(hipGraphDestroy(r->micp_graph));
+  if (r->micp_fast_exec) DBG_STEP(hipGraphExecDestroy(r->micp_fast_exec));
+  if (r->micp_fast_graph) DBG_STEP(hipGraphDestroy(r->micp_fast_graph));
+  if (r->h_fast_status) DBG_STEP(hipHostFree(r->h_fast_status));
+  r->d_fast_partials.release(); r->d_fast_mask.release();
   if (r->h_call) DBG_STEP(hipHostFree(r->h_call));
   if (r->d_call) DBG_STEP(hipFree(r->d_call));
   if (r->ev0) DBG_STEP(hipEventDestroy(r->ev0));
@@ -468,7 +488,7 @@ rmclhip_status rmclhip_rcc_set_model_spherical(rmclhip_rcc* r, const rmclhip_sph
   HIPCHK(hipStreamSynchronize(r->stream));
   const uint32_t H = m->phi.size, W = m->theta.size;
   r->kind = kModelSpherical;
-  r->graph_dirty = true;
+  r->graph_dirty = true; r->fast_graph_dirty = true;
   r->tiles_fresh = true;
   r->finds_since_calib = 0;
   r->W = W; r->H = H;
@@ -500,7 +520,7 @@ rmclhip_status rmclhip_rcc_set_model_o1dn(rmclhip_rcc* r, uint32_t width, uint32
   HIPCHK(hipSetDevice(r->ctx->device));
   HIPCHK(hipStreamSynchronize(r->stream));
   r->kind = kModelO1Dn;
-  r->graph_dirty = true;
+  r->graph_dirty = true; r->fast_graph_dirty = true;
   r->tiles_fresh = true;
   r->finds_since_calib = 0;
   r->W = width; r->H = height;
@@ -522,7 +542,7 @@ rmclhip_status rmclhip_rcc_set_model_pinhole(rmclhip_rcc* r, uint32_t width, uin
   HIPCHK(hipSetDevice(r->ctx->device));
   HIPCHK(hipStreamSynchronize(r->stream));
   r->kind = kModelPinhole;
-  r->graph_dirty = true;
+  r->graph_dirty = true; r->fast_graph_dirty = true;
   r->tiles_fresh = true;
   r->finds_since_calib = 0;
   r->W = width; r->H = height;
@@ -539,7 +559,7 @@ rmclhip_status rmclhip_rcc_set_model_ondn(rmclhip_rcc* r, uint32_t width, uint32
   HIPCHK(hipSetDevice(r->ctx->device));
   HIPCHK(hipStreamSynchronize(r->stream));
   r->kind = kModelOnDn;
-  r->graph_dirty = true;
+  r->graph_dirty = true; r->fast_graph_dirty = true;
   r->tiles_fresh = true;
   r->finds_since_calib = 0;
   r->W = width; r->H = height;
@@ -655,7 +675,7 @@ rmclhip_status rmclhip_rcc_set_input_pointcloud2(rmclhip_rcc* r, const uint8_t* 
   HIPCHK(hipSetDevice(r->ctx->device));
   HIPCHK(hipStreamSynchronize(r->stream));
   r->kind = kModelO1Dn;
-  r->graph_dirty = true;
+  r->graph_dirty = true; r->fast_graph_dirty = true;
   r->tiles_fresh = true;
   r->finds_since_calib = 0;
   r->W = ow; r->H = oh;
@@ -1031,7 +1051,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
         if (rmclhip_status st = tiles_calibrate(r)) return st;
       const uint8_t* before = r->d_tile_flags.p;
       if (rmclhip_status st = tiles_prepare(r, pt)) return st;
-      if (before != r->d_tile_flags.p) r->graph_dirty = true;   // (re)allocated: the captured pointers are stale
+      if (before != r->d_tile_flags.p) { r->graph_dirty = true; r->fast_graph_dirty = true; }   // (re)allocated: the captured pointers are stale
       ++r->finds_since_calib;
     }
     r->h_call->Tsm = xmul(xmul(Tom, Tbo), r->Tsb);
@@ -1039,6 +1059,78 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
     r->h_call->Tsb = r->Tsb;
     r->h_call->Tbo = Tbo;
     r->h_call->max_dist = maxd;
+    r->h_call->rho_cap = r->fast_rho_cap;
+    r->h_call->tau_cap = r->fast_tau_cap;
+    // ---- moment form first (kernels.hip "gate-stable moment form"); any outcome other than "done" falls through to the
+    // per-iteration form below, which recomputes the correction from scratch
+    const bool fast_eligible = r->fast_mode != 0 && r->use_graph && r->loop_blocks == 0 && !r->fused_tail && n_iter >= 2u &&
+                               find_variant(r, 1) != 18;
+    bool fast_tried = false;
+    if (fast_eligible && r->fast_holdoff > 0u) --r->fast_holdoff;
+    else if (fast_eligible) {
+      fast_tried = true;
+      HIPCHK(r->d_fast_partials.reserve(static_cast<size_t>(micp_fast_blocks(nred)) * kMicpFastMoments));
+      HIPCHK(r->d_fast_mask.reserve((static_cast<size_t>(nred) + 63u) / 64u));
+      rmclhip_rcc::MicpKey key;
+      std::memset(&key, 0, sizeof(key));
+      key.n_iter = n_iter; key.W = r->W; key.H = r->H; key.n_dataset = r->n_dataset;
+      key.kind = static_cast<int>(r->kind); key.variant = r->variant; key.tile = r->tile_override;
+      key.fused = 0; key.has_mask = r->ds_has_mask ? 1 : 0;
+      key.ptrs[0] = r->d_points.p; key.ptrs[1] = r->ds_pts; key.ptrs[2] = r->d_fast_partials.p;
+      key.ptrs[3] = r->d_model_tab.p; key.ptrs[4] = r->ds_msk; key.ptrs[5] = r->d_fast_mask.p;
+      if (!r->micp_fast_exec || r->fast_graph_dirty || !(key == r->micp_fast_key)) {
+        if (r->micp_fast_exec) { (void)hipGraphExecDestroy(r->micp_fast_exec); r->micp_fast_exec = nullptr; }
+        if (r->micp_fast_graph) { (void)hipGraphDestroy(r->micp_fast_graph); r->micp_fast_graph = nullptr; }
+        HIPCHK(hipStreamSynchronize(r->stream));
+        HIPCHK(hipStreamBeginCapture(r->stream, hipStreamCaptureModeThreadLocal));
+        r->capturing = true;
+        hipError_t le = hipMemcpyAsync(r->d_call, r->h_call, sizeof(MicpCall), hipMemcpyHostToDevice, r->stream);
+        if (le == hipSuccess) {
+          FindParams fp;
+          fill_find_params(r, fp, 1);
+          fp.Tsm_arr = &r->d_call->Tsm;
+          fp.Tms_arr = &r->d_call->Tms;
+          le = launch_find(fp, r->kind, find_variant(r, 1), r->stream);
+        }
+        if (le == hipSuccess)
+          le = launch_micp_fast(r->ds_pts, r->ds_has_mask ? r->ds_msk : nullptr, r->d_points.p, r->d_normals.p, r->d_hits.p, nred,
+                                r->d_call, r->d_fast_partials.p, r->d_fast_mask.p, n_iter, r->h_state_dev, r->h_fast_status_dev,
+                                r->stream);
+        r->capturing = false;
+        hipGraph_t g = nullptr;
+        const hipError_t ce = hipStreamEndCapture(r->stream, &g);
+        if (le != hipSuccess) { if (g) (void)hipGraphDestroy(g); return fail(RMCLHIP_ERR_HIP, std::string("micp fast capture: ") + hipGetErrorString(le)); }
+        if (ce != hipSuccess) return fail(RMCLHIP_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+        r->micp_fast_graph = g;
+        HIPCHK(hipGraphInstantiate(&r->micp_fast_exec, g, nullptr, nullptr, 0));
+        r->micp_fast_key = key;
+        r->fast_graph_dirty = false;
+      }
+      r->h_fast_status->code = 0xFFFFFFFFu;
+      HIPCHK(hipGraphLaunch(r->micp_fast_exec, r->stream));
+      HIPCHK(hipStreamSynchronize(r->stream));
+      const MicpFastStatus fs = *r->h_fast_status;
+      r->fast_info.attempts++;
+      r->fast_info.last_code = fs.code;
+      r->fast_info.last_uncertain = fs.n_uncertain;
+      r->fast_info.last_rho = fs.max_rho;
+      r->fast_info.last_tau = fs.max_tau;
+      r->fast_info.last_setup_clocks = fs.code == 0u ? fs.pad[0] : 0u;
+      r->fast_info.last_loop_clocks = fs.code == 0u ? fs.pad[1] : 0u;
+      if (fs.code == 0u) {
+        r->fast_info.done++;
+        r->fast_overflows = 0;
+        r->fast_rho_cap = std::max(0.002f, std::max(2.0f * fs.max_rho, 0.9f * r->fast_rho_cap));
+        r->fast_tau_cap = std::max(0.005f, std::max(2.0f * fs.max_tau, 0.9f * r->fast_tau_cap));
+        r->fast_info.rho_cap = r->fast_rho_cap;
+        r->fast_info.tau_cap = r->fast_tau_cap;
+        from_x(r->h_state->T_onew_oold, T_out);
+        if (stats_out) from_cs(r->h_state->stats_o, stats_out);
+        return RMCLHIP_OK;
+      }
+      if (fs.code != 1u && fs.code != 2u) return fail(RMCLHIP_ERR_HIP, "correct_once: the moment-form loop did not report a status");
+      if (fs.code == 2u) r->fast_info.overflows++; else r->fast_info.cap_exits++;
+    }
     auto enqueue_chain = [&]() -> rmclhip_status {
       HIPCHK(hipMemcpyAsync(r->d_call, r->h_call, sizeof(MicpCall), hipMemcpyHostToDevice, r->stream));
       FindParams p;
@@ -1068,8 +1160,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
                                   part[(i + 1u) & 1u], part[i & 1u], r->d_state + (i & 1u), r->d_state + ((i + 1u) & 1u),
                                   i == 0, r->stream));
         // the closing step writes the result straight into host-mapped memory (no copy node)
-        HIPCHK(launch_micp_step(part[(n_iter - 1u) & 1u], nb, r->Tsb, Tbo, r->d_call, r->d_state + (n_iter & 1u),
-                                r->h_state_dev, r->stream));
+        HIPCHK(launch_micp_close(part[(n_iter - 1u) & 1u], nb, r->d_call, r->d_state + (n_iter & 1u), r->h_state_dev, r->stream));
         final_state = nullptr;
       } else
       for (uint32_t i = 0; i < n_iter; ++i) {
@@ -1113,6 +1204,25 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
       if (rmclhip_status st = enqueue_chain()) return st;
     }
     HIPCHK(hipStreamSynchronize(r->stream));
+    if (fast_tried) {
+      // the pre-transform this correction ended with bounds the next attempt (iterates approach it monotonically in the
+      // usual case; an attempt that still leaves the caps costs one more fallback and doubles them)
+      const xform Tb = xmul(xmul(xinv(Tbo), r->h_state->T_onew_oold), Tbo);
+      const xform Ts = xmul(xmul(xinv(r->Tsb), Tb), r->Tsb);
+      const float rho = 2.0f * std::sqrt(Ts.R.x * Ts.R.x + Ts.R.y * Ts.R.y + Ts.R.z * Ts.R.z);
+      const float tau = std::sqrt(Ts.t.x * Ts.t.x + Ts.t.y * Ts.t.y + Ts.t.z * Ts.t.z);
+      if (r->h_fast_status->code == 2u) {
+        // too many uncertain correspondences: tighter caps, and stop trying when that does not help either
+        r->fast_rho_cap = std::max(0.002f, 1.25f * rho);
+        r->fast_tau_cap = std::max(0.005f, 1.25f * tau);
+        if (++r->fast_overflows >= 2u) { r->fast_holdoff = 32u; r->fast_overflows = 0; }
+      } else {
+        r->fast_rho_cap = std::max(0.002f, std::max(2.0f * rho, 2.0f * r->h_fast_status->max_rho));
+        r->fast_tau_cap = std::max(0.005f, std::max(2.0f * tau, 2.0f * r->h_fast_status->max_tau));
+      }
+      r->fast_info.rho_cap = r->fast_rho_cap;
+      r->fast_info.tau_cap = r->fast_tau_cap;
+    }
     from_x(r->h_state->T_onew_oold, T_out);
     if (stats_out) from_cs(r->h_state->stats_o, stats_out);
     return RMCLHIP_OK;
@@ -1334,9 +1444,26 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
     static const int kLoopBlocks[8] = {0, -1, 16, 32, 64, 128, 256, 32 | (1 << 16)};
     r->loop_blocks = kLoopBlocks[(variant >> 10) & 7];
   }
-  r->graph_dirty = true;
+  r->graph_dirty = true; r->fast_graph_dirty = true;
   r->tiles_fresh = true;
   r->finds_since_calib = 0;
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_set_micp_fast(rmclhip_rcc* r, int mode) {
+  ApiGuard guard_("rmclhip_rcc_set_micp_fast");
+  if (!r || mode < 0 || mode > 1) return fail(RMCLHIP_ERR_INVALID, "rcc_set_micp_fast: mode must be 0 (off) or 1 (automatic)");
+  r->fast_mode = mode;
+  r->fast_holdoff = 0;
+  r->fast_overflows = 0;
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_micp_fast_info(const rmclhip_rcc* r, rmclhip_micp_fast_info* out) {
+  if (!r || !out) return fail(RMCLHIP_ERR_INVALID, "rcc_micp_fast_info: null");
+  *out = r->fast_info;
+  out->rho_cap = r->fast_rho_cap;
+  out->tau_cap = r->fast_tau_cap;
   return RMCLHIP_OK;
 }
 

@@ -324,6 +324,18 @@ RM_HD bool horn_quaternion(const double* C, double* q) {
   // (the classic one is sqrt(trace K^2) = 2 |S|_F) saves iterations without changing the limit
   const double lam0 = sqrt(3.0 * ss) * (1.0 + 1e-12);
   double lam = lam0;
+  {
+    // A much closer start for the case this solver is called for (small corrections: S nearly symmetric, R nearly I):
+    // k00 = trace S is the Rayleigh quotient of q = (1, 0, 0, 0), hence a LOWER bound of the largest root, O(theta^2) below
+    // it.  Where the quartic is convex (3 l^2 > ss) and rising, one Newton step from a point left of the root lands right
+    // of it (the tangent of a convex function lies below it), from where the iteration is monotone as before.
+    const double a = K.k00, a2 = a * a;
+    const double Pa = (a2 + c2) * a2 + c1 * a + c0, dPa = (4.0 * a2 + 2.0 * c2) * a + c1;
+    if (a > 0.0 && 3.0 * a2 > ss && dPa > 0.0 && Pa <= 0.0) {
+      const double a1 = a - Pa / dPa;
+      if (a1 < lam0) lam = a1;
+    }
+  }
   bool converged = false;
   for (int it = 0; it < 60; ++it) {
     const double l2 = lam * lam;
@@ -355,7 +367,8 @@ RM_HD bool horn_quaternion(const double* C, double* q) {
   if (!(dbest > 1e-10 * lam0 * lam0 * lam0)) return false;  // repeated largest eigenvalue
   const double n = sqrt((v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3));
   if (!(n > 0.0)) return false;
-  double w = v0 / n, x = v1 / n, y = v2 / n, z = v3 / n;
+  const double rn = 1.0 / n;
+  double w = v0 * rn, x = v1 * rn, y = v2 * rn, z = v3 * rn;
   // sign convention of mat_to_quat (Shepperd): w > 0 when trace R > 0 (|w| > 1/2), else the largest of x, y, z positive
   double lead = w;
   if (!(fabs(w) > 0.5)) {

@@ -100,7 +100,8 @@ struct MicpCall {
   xform Tsm, Tms;   // find pose: Tom * Tbo * Tsb and its inverse
   xform Tsb, Tbo;
   float max_dist;
-  uint32_t pad[7];
+  float rho_cap, tau_cap;   // moment form of the loop (launch_micp_fast): bounds on the pre-transforms it may meet
+  uint32_t pad[5];
 };
 
 // MICP-L inner-loop state kept on the device between launches (correct_once)
@@ -109,6 +110,21 @@ struct MicpState {
   xform T_snew_sold;             // pre-transform for the next reduction
   cstats stats_o;                // last merged statistics, odom frame
 };
+
+// moment form of the schedule-(R) loop (kernels.hip: "gate-stable moment form"): one streaming pass + one single-workgroup
+// launch for all iterations.  status->code: 0 = done (state_out valid), 1 = a pre-transform left (rho_cap, tau_cap) at
+// iteration `iter`, 2 = more than 4096 uncertain correspondences; for 1 and 2 the caller runs the per-iteration form.
+struct MicpFastStatus { uint32_t code, iter, n_uncertain; float max_rho, max_tau; uint32_t pad[3]; };
+constexpr uint32_t kMicpFastMoments = 96;
+inline uint32_t micp_fast_blocks(uint32_t n) {
+  const uint32_t b = (n + 1023u) / 1024u;
+  return b < 1u ? 1u : (b > 128u ? 128u : b);
+}
+// partials: micp_fast_blocks(n) * 96 doubles; unc_mask: ceil(n / 64) words
+hipError_t launch_micp_fast(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
+                            const float* model_normals, const uint8_t* model_mask, uint32_t n, const MicpCall* call,
+                            double* partials, unsigned long long* unc_mask, uint32_t n_iter, MicpState* state_out,
+                            MicpFastStatus* status, hipStream_t s);
 
 // N-sensor MICP loop on the device (micp_localization.cpp:900-964): per-call frames + per-sensor partials, one step launch per
 // iteration merges every sensor's statistics (weighted and unweighted), solves once and hands every sensor its next
@@ -155,6 +171,10 @@ hipError_t launch_reduce_finalize(const double* partials, uint32_t nblocks, uint
 // finalize + (Tsb*, Tbo*) + umeyama + compose; advances MicpState on the device
 hipError_t launch_micp_step(const double* partials, uint32_t nblocks, xform Tsb, xform Tbo, const MicpCall* call,
                             const MicpState* state, MicpState* state_out, hipStream_t s);
+// closing launch of the launch_micp_iter chain: solve of the last iteration + T_onew_oold / stats_o (the chain itself works in
+// the sensor frame, kernels.hip micp_advance_sensor)
+hipError_t launch_micp_close(const double* partials, uint32_t nblocks, const MicpCall* call, const MicpState* state,
+                             MicpState* state_out, hipStream_t s);
 // state: TWO MicpState slots (ping-pong of k_micp_iter); both initialised
 hipError_t launch_micp_init(MicpState* state, uint32_t* barrier, hipStream_t s);
 // one launch per MICP iteration: finishes the previous iteration (finalize + solve, redundantly in every block)

@@ -1656,6 +1656,25 @@ __device__ __forceinline__ void micp_advance(const cstats& stats_s, const xform&
   st->stats_o = Cmerged;
 }
 
+// The same loop for ONE sensor, written in the sensor frame.  umeyama is equivariant under a rigid change of frame
+// (umeyama(T * C) = T o umeyama(C) o T^-1 for a transform T applied to both means and the covariance), so with
+// Tso = Tbo * Tsb:  T_inner = Tso U Tso^-1 with U = umeyama(stats_s), and
+//   T_snew_sold' = Tso^-1 (T_onew_oold T_inner) Tso = T_snew_sold * U.
+// The loop therefore only needs U and one product per iteration; T_onew_oold = Tso T_snew_sold Tso^-1 and
+// stats_o = Tbo * (Tsb * stats_s) are formed once, after the last iteration (micp_close_sensor).  Same mathematics as
+// micp_advance, ~700 instead of ~2500 dependent operations per iteration for the lone lane that runs it; the rounding
+// differs from the frame-by-frame order at the 1e-7 level (tests: 1e-5 against the oracle's frame-by-frame loop).
+__device__ __forceinline__ void micp_advance_sensor(const cstats& stats_s, xform* T_snew_sold) {
+  *T_snew_sold = xmul(*T_snew_sold, umeyama(stats_s));
+}
+__device__ __forceinline__ void micp_close_sensor(const cstats& stats_s_last, const xform& T_snew_sold, const xform& Tsb,
+                                                  const xform& Tbo, MicpState* st) {
+  const xform Tso = xmul(Tbo, Tsb);
+  st->T_snew_sold = T_snew_sold;
+  st->T_onew_oold = xmul(xmul(Tso, T_snew_sold), xinv(Tso));
+  st->stats_o = cs_merge(cs_identity(), cs_transform(Tbo, cs_transform(Tsb, stats_s_last)));
+}
+
 // kTail == kTailNone keeps the streaming kernel lean (the solve code of the fused tails costs registers and
 // scratch: with it compiled in, this kernel went from 96 to 192 VGPRs + 80 B scratch and 2.3x slower launches)
 template <uint32_t kTail>
@@ -1928,10 +1947,12 @@ __global__ void __launch_bounds__(256) k_micp_iter(const MicpIterParams p) {
     } else {
       const cstats st = finalize_pose(p.partials_prev, p.nblocks);
       if (threadIdx.x == 0) {
-        MicpState local = *p.state_in;
-        micp_advance(st, p.call->Tsb, p.call->Tbo, &local);
-        s_Tpre = local.T_snew_sold;
-        if (blockIdx.x == 0) *p.state_out = local;
+        // sensor-frame form of the iteration (micp_advance_sensor): the odom-frame quantities are formed by the closing
+        // launch (k_micp_close); between launches the state carries T_snew_sold only
+        xform T_s = p.state_in->T_snew_sold;
+        micp_advance_sensor(st, &T_s);
+        s_Tpre = T_s;
+        if (blockIdx.x == 0) p.state_out->T_snew_sold = T_s;
       }
     }
   }
@@ -2002,6 +2023,19 @@ __global__ void k_micp_init(MicpState* st, uint32_t* barrier) {
 // unfused form of the MICP step (kept for A/B against the fused tail of k_reduce_partials)
 // st_out may alias st (in place) or point to host-mapped memory: the closing step of a correction then delivers the
 // result without a device-to-host copy node
+// closing launch of the one-launch-per-iteration form: the last iteration's solve + the odom-frame results
+__global__ void __launch_bounds__(64) k_micp_close(const double* __restrict__ partials, uint32_t nblocks, const MicpCall* call,
+                                                   const MicpState* st, MicpState* st_out) {
+  const cstats stats_s = finalize_pose(partials, nblocks);
+  if (threadIdx.x == 0) {
+    xform T_s = st->T_snew_sold;
+    micp_advance_sensor(stats_s, &T_s);
+    MicpState out;
+    micp_close_sensor(stats_s, T_s, call->Tsb, call->Tbo, &out);
+    *st_out = out;
+  }
+}
+
 __global__ void __launch_bounds__(64) k_micp_step(const double* __restrict__ partials, uint32_t nblocks, xform Tsb,
                                                   xform Tbo, const MicpCall* call, const MicpState* st, MicpState* st_out) {
   const cstats stats_s = finalize_pose(partials, nblocks);
@@ -2011,6 +2045,424 @@ __global__ void __launch_bounds__(64) k_micp_step(const double* __restrict__ par
     *st_out = local;
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Gate-stable moment form of the MICP-L inner loop, schedule (R) (micp_localization.cpp:900-964: ONE find, then n_iter x
+// (statistics_p2l + umeyama) over the SAME correspondences).  Between iterations only the pre-transform T = (R, t) changes:
+//   D' = R D + t,  dist = N.I - N.D',  M = D' + N dist,  gate |dist| < max_dist           (MICPSensorCPU.cpp:70-84)
+// so for a FIXED set of gated-in correspondences the 16 raw sums of the reduction (sum D', sum M, sum M D'^T, n) are
+// polynomials in (R, t) whose coefficients are 82 moments of (D, N, s = N.I):
+//   sum D, sum D D^T, sum s N, sum s N D^T, sum N N^T, sum N_a N_b D_j, sum N_a N_b D_j D_k.
+// The gate is the only non-polynomial part.  A correspondence whose |dist| at the first pre-transform (identity) is
+// farther from max_dist than the farthest its point can move, |D' - D| <= rho |D| + tau (rho = 2 sin(theta/2), tau = |t|),
+// keeps its gate decision for every iteration whose pre-transform stays within (rho_cap, tau_cap): its contribution comes
+// from the moments.  The others ("uncertain", normally a few hundred) are re-evaluated every iteration with the reduction's
+// own f32 arithmetic.  One streaming pass (k_micp_moments) + ONE single-workgroup launch for all iterations
+// (k_micp_fast_loop) replace n_iter streaming launches.  If a pre-transform leaves the caps or more than
+// kFastMaxUncertain correspondences are uncertain, the loop reports it and the caller runs the per-iteration form instead:
+// the result never depends on the caps.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMom = 96;  // 82 used: n | D[3] | DD[6] | sN[3] | sND[9] | NN[6] | NND[18] | NNDD[36]
+constexpr uint32_t kFastMaxUncertain = 4096;
+constexpr uint32_t kFastThreads = 256;   // 1 wave per SIMD: the one-lane solve may use up to 512 VGPRs (no scratch)
+
+// wave64 sum of 16 doubles per lane by the halving butterfly of k_reduce_partials: afterwards lane L holds the wave total of
+// value L >> 2 in v[0]
+__device__ __forceinline__ void wave_reduce16(double (&v)[16], uint32_t lane) {
+#pragma unroll
+  for (int half = 8, off = 32; half >= 1; half >>= 1, off >>= 1) {
+    const bool hi = (lane & static_cast<uint32_t>(off)) != 0u;
+#pragma unroll
+    for (int j = 0; j < half; ++j) {
+      const double send = hi ? v[j] : v[j + half];
+      const double keep = hi ? v[j + half] : v[j];
+      v[j] = keep + __shfl_xor(send, off, 64);
+    }
+  }
+  v[0] += __shfl_xor(v[0], 2, 64);
+  v[0] += __shfl_xor(v[0], 1, 64);
+}
+
+// wave64 sum of 16 doubles per lane through LDS instead of cross-lane shuffles: every lane stores its 16 values (row = lane),
+// lane L adds column L & 15 over the 16 rows of slice L >> 4, two xor steps join the four slices.  The 17 shuffles of the
+// halving butterfly are a chain of dependent ds_bpermute round trips (~3.4k clocks measured for a lone wave); here all stores
+// and all loads are independent (~0.6k).  scratch: 64 x 17 doubles owned by this wave; LDS operations of one wave complete in
+// order, so no barrier is needed.  Afterwards lanes 0..15 hold the totals of values 0..15.
+__device__ __forceinline__ double wave_sum16_lds(const double (&v)[16], double* scratch, uint32_t lane) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) scratch[lane * 17u + static_cast<uint32_t>(k)] = v[k];
+  const uint32_t col = lane & 15u, row0 = (lane >> 4) * 16u;
+  double a[16];
+#pragma unroll
+  for (uint32_t r = 0; r < 16u; ++r) a[r] = scratch[(row0 + r) * 17u + col];
+  double t = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  t += ((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15]));
+  t += __shfl_xor(t, 16, 64);
+  t += __shfl_xor(t, 32, 64);
+  return t;
+}
+
+// raw sums of the reduction (sd[3] sm[3] smd[9] n) -> CrossStatistics, as finalize_pose does
+__device__ __forceinline__ cstats cstats_from_sums(const double* acc) {
+  cstats s = cs_identity();
+  const double n = acc[15];
+  if (n > 0.0) {
+    const double rn = 1.0 / n;   // one division (finalize_pose divides 15 times: same values to the last bit or two)
+    const double md[3] = {acc[0] * rn, acc[1] * rn, acc[2] * rn};
+    const double mm[3] = {acc[3] * rn, acc[4] * rn, acc[5] * rn};
+    s.dataset_mean = mk3(static_cast<float>(md[0]), static_cast<float>(md[1]), static_cast<float>(md[2]));
+    s.model_mean = mk3(static_cast<float>(mm[0]), static_cast<float>(mm[1]), static_cast<float>(mm[2]));
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) s.covariance[3 * r + c] = static_cast<float>(acc[6 + 3 * r + c] * rn - mm[r] * md[c]);
+    s.n_meas = static_cast<uint32_t>(n);
+  }
+  return s;
+}
+
+struct MicpFastParams {
+  const float* dataset_points;
+  const uint8_t* dataset_mask;  // nullable
+  const float* model_points;
+  const float* model_normals;
+  const uint8_t* model_mask;
+  uint32_t n, nblocks;          // nblocks: grid of k_micp_moments
+  const MicpCall* call;
+  double* partials;             // [nblocks][kMom]
+  unsigned long long* unc_mask; // [ceil(n / 64)]: bit i%64 of word i/64 = correspondence i is uncertain
+  uint32_t n_iter;
+  MicpState* state_out;         // may be host-mapped
+  MicpFastStatus* status;       // may be host-mapped
+};
+
+__global__ void __launch_bounds__(256) k_micp_moments(const MicpFastParams p) {
+  __shared__ double red[4][kMom];
+  __shared__ double s_scratch[4][2][64 * 17];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const float max_dist = p.call->max_dist, rho_cap = p.call->rho_cap, tau_cap = p.call->tau_cap;
+  double m[kMom];
+#pragma unroll
+  for (int k = 0; k < kMom; ++k) m[k] = 0.0;
+  // a wave takes 64 consecutive correspondences per step (one mask word); two steps are requested before the first is used
+  const uint32_t stride = gridDim.x * 256u;
+  const uint32_t nceil = (p.n + 63u) & ~63u;
+  for (uint32_t base = (blockIdx.x * 4u + wave) * 64u; base < nceil; base += 2u * stride) {
+    float d[2][3], q[2][3], nn[2][3];
+    bool ok[2], live[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t i = base + static_cast<uint32_t>(u) * stride + lane;
+      live[u] = (base + static_cast<uint32_t>(u) * stride) < nceil;
+      ok[u] = false;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { d[u][k] = 0.f; q[u][k] = 0.f; nn[u][k] = 0.f; }
+      if (i < p.n) {
+        const bool dok = (p.dataset_mask == nullptr) || (p.dataset_mask[i] > 0);
+        ok[u] = dok && p.model_mask[i] > 0;
+        const float* dp = p.dataset_points + 3 * static_cast<size_t>(i);
+        const float* mp = p.model_points + 3 * static_cast<size_t>(i);
+        const float* mn = p.model_normals + 3 * static_cast<size_t>(i);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { d[u][k] = dp[k]; q[u][k] = mp[k]; nn[u][k] = mn[k]; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!live[u]) continue;   // wave-uniform
+      const f3 Di = mk3(d[u][0], d[u][1], d[u][2]), Ii = mk3(q[u][0], q[u][1], q[u][2]), Ni = mk3(nn[u][0], nn[u][1], nn[u][2]);
+      // the reduction's own gate value at the identity pre-transform
+      const float spd0 = dot_plain(sub3(Ii, Di), Ni);
+      const float nd = sqrtf(dot_plain(Di, Di));
+      const float margin = (rho_cap * nd + tau_cap) + 1e-4f * (1.0f + nd);
+      const float slack = fabsf(fabsf(spd0) - max_dist);
+      const bool certain = ok[u] && (slack > margin);          // NaN anywhere => not certain
+      const bool uncertain = ok[u] && !certain;
+      const unsigned long long word = __ballot(uncertain);
+      if (lane == 0u) p.unc_mask[(base + static_cast<uint32_t>(u) * stride) >> 6] = word;
+      if (certain && fabsf(spd0) < max_dist) {
+        const double D[3] = {Di.x, Di.y, Di.z}, N[3] = {Ni.x, Ni.y, Ni.z};
+        const double sI = (N[0] * static_cast<double>(Ii.x) + N[1] * static_cast<double>(Ii.y)) + N[2] * static_cast<double>(Ii.z);
+        const double DD[6] = {D[0] * D[0], D[0] * D[1], D[0] * D[2], D[1] * D[1], D[1] * D[2], D[2] * D[2]};
+        const double NN[6] = {N[0] * N[0], N[0] * N[1], N[0] * N[2], N[1] * N[1], N[1] * N[2], N[2] * N[2]};
+        m[0] += 1.0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) m[1 + j] += D[j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) m[4 + k] += DD[k];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const double sn = sI * N[a];
+          m[10 + a] += sn;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) m[13 + 3 * a + j] += sn * D[j];
+        }
+#pragma unroll
+        for (int pq = 0; pq < 6; ++pq) {
+          m[22 + pq] += NN[pq];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) m[28 + 3 * pq + j] += NN[pq] * D[j];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) m[46 + 6 * pq + k] += NN[pq] * DD[k];
+        }
+      }
+    }
+  }
+  // six chunks of 16 moments, each with its own scratch area so that the chunks overlap
+#pragma unroll
+  for (int c = 0; c < kMom / 16; ++c) {
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = m[16 * c + k];
+    const double t = wave_sum16_lds(v, &s_scratch[wave][c & 1][0], lane);
+    if (lane < 16u) red[wave][16 * c + lane] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < kMom)
+    p.partials[static_cast<size_t>(blockIdx.x) * kMom + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// The 16 raw sums of the reduction over the CERTAIN correspondences at pre-transform (R row-major, t) from the moments, by
+// one wave.  With X ranging over the ten per-correspondence factors  N_aN_b (6, symmetric pairs) | 1 | s N_a (3)  the moments
+// are W(X) = sum X, P(X)_j = sum X D_j, Q(X)_jk = sum X D_j D_k, and every sum below is one of
+//   rP(X)_b = sum_j R_bj P(X)_j,   H(X)_bc = sum_jk R_bj R_ck Q(X)_jk   (X = "1": sum D'_b, sum D'_b D'_c up to the t terms).
+// Stage A (63 lanes) G(X)_cj = sum_k Q(X)_jk R_ck; stage B (63 + 30 lanes) H and rP; stage C (16 lanes) the outputs.
+// All operands live in LDS; LDS operations of one wave complete in order (no barrier between the stages).
+__device__ __forceinline__ int sym3(int a, int b) {
+  const int lo = min(a, b), hi = max(a, b);
+  return lo == 0 ? hi : (lo == 1 ? hi + 2 : 5);
+}
+__device__ __forceinline__ const double* mom_Q(const double* mom, int x) { return x < 6 ? mom + 46 + 6 * x : mom + 4; }
+__device__ __forceinline__ const double* mom_P(const double* mom, int x) { return x < 6 ? mom + 28 + 3 * x : (x == 6 ? mom + 1 : mom + 13 + 3 * (x - 7)); }
+__device__ __forceinline__ double mom_W(const double* mom, int x) { return x < 6 ? mom[22 + x] : (x == 6 ? mom[0] : mom[10 + (x - 7)]); }
+
+struct MomentScratch { double G[64], H[64], rP[32]; };
+
+__device__ __forceinline__ void micp_moment_sums_wave(uint32_t lane, const double* mom, const double* R, const double* t,
+                                                      MomentScratch* ws, double* tot) {
+  // stage A: lane = 9 x + 3 c + j, x = 0..6
+  if (lane < 63u) {
+    const int x = static_cast<int>(lane) / 9, c = (static_cast<int>(lane) % 9) / 3, j = static_cast<int>(lane) % 3;
+    const double* Q = mom_Q(mom, x);
+    ws->G[lane] = (Q[sym3(j, 0)] * R[3 * c] + Q[sym3(j, 1)] * R[3 * c + 1]) + Q[sym3(j, 2)] * R[3 * c + 2];
+  }
+  // stage B: lane = 9 x + 3 b + c -> H(x)_bc; lanes 0..29 also rP(x)_b with lane = 3 x + b, x = 0..9
+  if (lane < 63u) {
+    const int x = static_cast<int>(lane) / 9, b = (static_cast<int>(lane) % 9) / 3, c = static_cast<int>(lane) % 3;
+    const double* Gx = ws->G + 9 * x + 3 * c;
+    ws->H[lane] = (R[3 * b] * Gx[0] + R[3 * b + 1] * Gx[1]) + R[3 * b + 2] * Gx[2];
+  }
+  if (lane < 30u) {
+    const int x = static_cast<int>(lane) / 3, b = static_cast<int>(lane) % 3;
+    const double* P = mom_P(mom, x);
+    ws->rP[lane] = (R[3 * b] * P[0] + R[3 * b + 1] * P[1]) + R[3 * b + 2] * P[2];
+  }
+  // stage C
+  if (lane < 16u) {
+    const double n = mom[0];
+    double out;
+    if (lane == 15u) {
+      out = n;
+    } else if (lane < 3u) {
+      const int c = static_cast<int>(lane);
+      out = ws->rP[18 + c] + n * t[c];
+    } else if (lane < 6u) {
+      const int a = static_cast<int>(lane) - 3;
+      double ndp = 0.0;   // sum N_a (N . D')
+      for (int b = 0; b < 3; ++b) {
+        const int x = sym3(a, b);
+        ndp += ws->rP[3 * x + b] + t[b] * mom_W(mom, x);
+      }
+      out = (ws->rP[18 + a] + n * t[a]) + mom[10 + a] - ndp;
+    } else {
+      const int a = (static_cast<int>(lane) - 6) / 3, c = (static_cast<int>(lane) - 6) % 3;
+      const double ddp = ws->H[54 + 3 * a + c] + ws->rP[18 + a] * t[c] + t[a] * ws->rP[18 + c] + n * t[a] * t[c];   // sum D'_a D'_c
+      const double sndp = ws->rP[3 * (7 + a) + c] + mom[10 + a] * t[c];                                            // sum s N_a D'_c
+      double nndd = 0.0;                                                                                           // sum N_a (N . D') D'_c
+      for (int b = 0; b < 3; ++b) {
+        const int x = sym3(a, b);
+        nndd += ws->H[9 * x + 3 * b + c] + t[c] * ws->rP[3 * x + b] + t[b] * ws->rP[3 * x + c] + t[b] * t[c] * mom_W(mom, x);
+      }
+      out = ddp + sndp - nndd;
+    }
+    tot[lane] = out;
+  }
+}
+
+__global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastParams p) {
+  constexpr uint32_t kGroups = kFastThreads / kMom;
+  __shared__ double s_mom[kMom];
+  __shared__ double s_part[kGroups][kMom];
+  __shared__ double s_rows[kFastThreads][17];   // per-thread raw sums of the uncertain correspondences (+1: bank spread)
+  __shared__ double s_tot[16];
+  __shared__ double s_R[9], s_t[3];
+  __shared__ MomentScratch s_ws;
+  __shared__ uint32_t s_list[kFastMaxUncertain];
+  __shared__ uint32_t s_wave_cnt[kFastThreads / 64];
+  __shared__ xform s_Tpre;
+  __shared__ uint32_t s_flag;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const unsigned long long clk0 = __builtin_readcyclecounter();
+
+  // (1) moments = sum of the per-block partials: 16 loads in flight per thread
+  {
+    const uint32_t k = tid % kMom, g = tid / kMom;   // kGroups groups of 96 threads
+    if (g < kGroups) {
+      double a = 0.0;
+      uint32_t b = g;
+      for (; b + 15u * kGroups < p.nblocks; b += 16u * kGroups) {
+        double v[16];
+#pragma unroll
+        for (uint32_t u = 0; u < 16u; ++u) v[u] = p.partials[static_cast<size_t>(b + u * kGroups) * kMom + k];
+#pragma unroll
+        for (uint32_t u = 0; u < 16u; u += 4u) a += (v[u] + v[u + 1]) + (v[u + 2] + v[u + 3]);
+      }
+      for (; b < p.nblocks; b += kGroups) a += p.partials[static_cast<size_t>(b) * kMom + k];
+      s_part[g][k] = a;
+    }
+  }
+  // (2) the uncertain correspondences, in index order: count per thread over a contiguous range of mask words, block scan
+  const uint32_t nwords = (p.n + 63u) >> 6;
+  const uint32_t wpt = (nwords + kFastThreads - 1u) / kFastThreads;
+  const uint32_t w0 = min(tid * wpt, nwords), w1 = min(w0 + wpt, nwords);
+  uint32_t cnt = 0;
+  for (uint32_t w = w0; w < w1; ++w) cnt += static_cast<uint32_t>(__popcll(p.unc_mask[w]));
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = __shfl_up(incl, off, 64);
+    if (lane >= static_cast<uint32_t>(off)) incl += v;
+  }
+  if (lane == 63u) s_wave_cnt[wave] = incl;
+  if (tid == 0u) s_flag = 0u;
+  __syncthreads();
+  if (tid < kMom) {
+    double a = s_part[0][tid];
+#pragma unroll
+    for (uint32_t g = 1; g < kGroups; ++g) a += s_part[g][tid];
+    s_mom[tid] = a;
+  }
+  uint32_t wave_base = 0, total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < kFastThreads / 64; ++w) {
+    const uint32_t c = s_wave_cnt[w];
+    if (w < wave) wave_base += c;
+    total += c;
+  }
+  if (total > kFastMaxUncertain) {
+    if (tid == 0u) {
+      MicpFastStatus st;
+      st.code = 2u; st.iter = 0u; st.n_uncertain = total; st.max_rho = 0.f; st.max_tau = 0.f;
+      *p.status = st;
+    }
+    return;
+  }
+  if (cnt != 0u) {
+    uint32_t pos = wave_base + incl - cnt;
+    for (uint32_t w = w0; w < w1; ++w) {
+      unsigned long long bits = p.unc_mask[w];
+      while (bits) {
+        const int b = __builtin_ctzll(bits);
+        bits &= bits - 1ull;
+        s_list[pos++] = (w << 6) + static_cast<uint32_t>(b);
+      }
+    }
+  }
+  const float max_dist = p.call->max_dist, rho_cap = p.call->rho_cap, tau_cap = p.call->tau_cap;
+  const uint32_t nrows = min(total, kFastThreads);
+  // thread 0 owns the loop state (registers): the sensor-frame pre-transform and the statistics of the last iteration
+  xform T_s = xidentity();
+  cstats last = cs_identity();
+  float max_rho = 0.f, max_tau = 0.f;
+  const unsigned long long clk1 = __builtin_readcyclecounter();
+  for (uint32_t it = 0; it < p.n_iter; ++it) {
+    if (tid == 0u) {
+      const float rho = 2.0f * sqrtf((T_s.R.x * T_s.R.x + T_s.R.y * T_s.R.y) + T_s.R.z * T_s.R.z);
+      const float tau = sqrtf(dot_plain(T_s.t, T_s.t));
+      max_rho = fmaxf(max_rho, rho);
+      max_tau = fmaxf(max_tau, tau);
+      if (!(rho <= rho_cap) || !(tau <= tau_cap)) s_flag = 1u;
+      s_Tpre = T_s;
+      // the linear map of qrot (q v q*), in double from the f32 components
+      const double x = T_s.R.x, y = T_s.R.y, z = T_s.R.z, w = T_s.R.w;
+      const double ww = w * w, uu = (x * x + y * y) + z * z;
+      s_R[0] = (ww - uu) + 2.0 * x * x; s_R[1] = 2.0 * (x * y - w * z);   s_R[2] = 2.0 * (x * z + w * y);
+      s_R[3] = 2.0 * (x * y + w * z);   s_R[4] = (ww - uu) + 2.0 * y * y; s_R[5] = 2.0 * (y * z - w * x);
+      s_R[6] = 2.0 * (x * z - w * y);   s_R[7] = 2.0 * (y * z + w * x);   s_R[8] = (ww - uu) + 2.0 * z * z;
+      s_t[0] = T_s.t.x; s_t[1] = T_s.t.y; s_t[2] = T_s.t.z;
+    }
+    __syncthreads();   // (A) pre-transform published; also orders the previous iteration's reads of s_rows / s_tot
+    if (s_flag != 0u) {
+      if (tid == 0u) {
+        MicpFastStatus st;
+        st.code = 1u; st.iter = it; st.n_uncertain = total; st.max_rho = max_rho; st.max_tau = max_tau;
+        *p.status = st;
+      }
+      return;
+    }
+    if (tid < nrows) {
+      // the uncertain correspondences with the reduction's own arithmetic (k_micp_iter); re-read every iteration (L2 hits,
+      // normally a few hundred elements) so that nothing of them is live across the one-lane solve.  Thread t sums elements
+      // t, t + 256, ... into row t; the rows are added in index order below: no cross-lane butterfly, deterministic.
+      const xform Tpre = s_Tpre;
+      double acc[kAcc];
+#pragma unroll
+      for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
+      for (uint32_t e = tid; e < total; e += kFastThreads) {
+        const uint32_t i = s_list[e];
+        const float* dp = p.dataset_points + 3 * static_cast<size_t>(i);
+        const float* mp = p.model_points + 3 * static_cast<size_t>(i);
+        const float* mn = p.model_normals + 3 * static_cast<size_t>(i);
+        const f3 Di = xapply(Tpre, mk3(dp[0], dp[1], dp[2]));
+        const f3 Ii = mk3(mp[0], mp[1], mp[2]);
+        const f3 Ni = mk3(mn[0], mn[1], mn[2]);
+        const float spd = dot_plain(sub3(Ii, Di), Ni);
+        if (fabsf(spd) < max_dist) {
+          const f3 Mi = add3(Di, scale3(Ni, spd));
+          const double d[3] = {Di.x, Di.y, Di.z}, m[3] = {Mi.x, Mi.y, Mi.z};
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { acc[k] += d[k]; acc[3 + k] += m[k]; }
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[6 + 3 * r + c] += m[r] * d[c];
+          acc[15] += 1.0;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kAcc; ++k) s_rows[tid][k] = acc[k];
+    }
+    if (nrows > 64u) __syncthreads();   // (B) rows of other waves (block-uniform condition); wave 0's own rows are in order
+    if (wave == 0u) {
+      micp_moment_sums_wave(lane, s_mom, s_R, s_t, &s_ws, s_tot);
+      if (lane < 16u && nrows != 0u) {
+        double v = s_tot[lane];
+        for (uint32_t r = 0; r < nrows; ++r) v += s_rows[r][lane];
+        s_tot[lane] = v;
+      }
+    }
+    if (tid == 0u) {
+      // lanes 0..15 of this wave wrote s_tot just above (LDS operations of one wave complete in order)
+      double tot[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) tot[k] = s_tot[k];
+      last = cstats_from_sums(tot);
+      micp_advance_sensor(last, &T_s);
+    }
+  }
+  if (tid == 0u) {
+    MicpState out;
+    micp_close_sensor(last, T_s, p.call->Tsb, p.call->Tbo, &out);
+    *p.state_out = out;
+    MicpFastStatus st;
+    st.code = 0u; st.iter = p.n_iter; st.n_uncertain = total; st.max_rho = max_rho; st.max_tau = max_tau;
+    st.pad[0] = static_cast<uint32_t>(clk1 - clk0);                              // diagnostics: shader clocks of the set-up
+    st.pad[1] = static_cast<uint32_t>(__builtin_readcyclecounter() - clk1);      // ... and of all iterations
+    st.pad[2] = 0u;
+    __threadfence_system();
+    *p.status = st;
+  }
+}
+
 
 // N sensors, one iteration of MICPLocalizationNode::correctOnce (micp_localization.cpp:915-964), ONE wave:
 //   per sensor (in order): stats_s <- partials; Cs_b = Tsb * stats_s (MICPSensor.hpp:182); Cs_o = Tbo * Cs_b (:931);
@@ -2850,6 +3302,17 @@ hipError_t launch_micp_iter(const float* dataset_points, const uint8_t* dataset_
   return hipGetLastError();
 }
 
+hipError_t launch_micp_fast(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
+                            const float* model_normals, const uint8_t* model_mask, uint32_t n, const MicpCall* call,
+                            double* partials, unsigned long long* unc_mask, uint32_t n_iter, MicpState* state_out,
+                            MicpFastStatus* status, hipStream_t s) {
+  MicpFastParams p{dataset_points, dataset_mask, model_points, model_normals, model_mask, n, micp_fast_blocks(n), call,
+                   partials, unc_mask, n_iter, state_out, status};
+  hipLaunchKernelGGL(k_micp_moments, dim3(p.nblocks), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(k_micp_fast_loop, dim3(1), dim3(kFastThreads), 0, s, p);
+  return hipGetLastError();
+}
+
 hipError_t launch_micp_multi_init(const MicpMultiCall* call, MicpMultiState* state, hipStream_t s) {
   hipLaunchKernelGGL(k_micp_multi_init, dim3(1), dim3(64), 0, s, call, state);
   return hipGetLastError();
@@ -2862,6 +3325,12 @@ hipError_t launch_micp_multi_step(const MicpMultiCall* call, MicpMultiState* sta
 
 hipError_t launch_micp_init(MicpState* state, uint32_t* barrier, hipStream_t s) {
   hipLaunchKernelGGL(k_micp_init, dim3(1), dim3(64), 0, s, state, barrier);
+  return hipGetLastError();
+}
+
+hipError_t launch_micp_close(const double* partials, uint32_t nblocks, const MicpCall* call, const MicpState* state,
+                             MicpState* state_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_micp_close, dim3(1), dim3(64), 0, s, partials, nblocks, call, state, state_out);
   return hipGetLastError();
 }
 

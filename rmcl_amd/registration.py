@@ -321,6 +321,16 @@ class CorrespondencesHIP:
         """traversal kind 0..31 alone (kinds >= 16 travel in bit 13 of the variant word, see rmclhip.h)"""
         self.set_variant((int(kind) & 15) | ((int(kind) >> 4) << 13))
 
+    def set_micp_fast(self, mode):
+        """moment form of the schedule-(R) loop of correctOnce: 0 = never, 1 = automatic (rmclhip.h)"""
+        _capi.check(_capi.lib().rmclhip_rcc_set_micp_fast(self._h, int(mode)))
+
+    def micp_fast_info(self):
+        """outcomes of the moment-form attempts of this operator as a dict (rmclhip_micp_fast_info)"""
+        info = _capi.MicpFastInfo()
+        _capi.check(_capi.lib().rmclhip_rcc_micp_fast_info(self._h, C.byref(info)))
+        return {k: getattr(info, k) for k, _ in info._fields_}
+
     def find_variant(self, nposes=1):
         """the traversal the automatic rule (variant 15) launches for `nposes` scans of the current model"""
         v = C.c_int(0)
