@@ -164,10 +164,19 @@ def main():
             for name, refind in (("R", False), ("B", True)):
                 # complete synchronous corrections timed at the C ABI (host clock inside the library: what a C / C++
                 # caller sees); the same call through the Python harness costs ~15 us more
+                if not refind:
+                    rcc.correct_once(est, T.identity(), 10, 0.0, False)   # the moment form learns its bounds on the first call
                 dt = rcc.time_correct_once(est, T.identity(), 10, 0.0, refind, iters=50) * 1e-3
                 extras["c3_schedule_%s_ms" % name] = round(dt * 1e3, 4)
                 extras["c3_schedule_%s_pose_corrections_per_s" % name] = round(1.0 / dt, 1)
                 extras["c3_schedule_%s_icp_iterations_per_s" % name] = round(10.0 / dt, 1)
+            # (R) again with the moment form off: one streaming launch per iteration (the fallback of the default form)
+            info = rcc.micp_fast_info()
+            extras["c3_schedule_R_moment_form"] = {k: info[k] for k in ("attempts", "done", "cap_exits", "overflows", "last_uncertain")}
+            rcc.set_micp_fast(0)
+            extras["c3_schedule_R_per_iteration_form_ms"] = round(rcc.time_correct_once(est, T.identity(), 10, 0.0, False, iters=50), 4)
+            extras["c3_zero_iterations_ms"] = round(rcc.time_correct_once(est, T.identity(), 0, 0.0, False, iters=50), 4)
+            rcc.set_micp_fast(1)
             red_ms = rcc.time_reduce(T.identity(), iters=100)
             extras["reduce_ms"] = round(red_ms, 5)
             extras["reduce_GBps"] = round((n_rays * 38 + 64) / (red_ms * 1e-3) / 1e9, 1)

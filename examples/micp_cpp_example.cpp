@@ -125,6 +125,16 @@ int main(int argc, char** argv) {
     CrossStatistics sdev{};
     const Transform Tdev = rcc.correctOnce(Tom_est, Tbo, 5, 0.0, false, &sdev);
     std::printf("device_loop_n_meas %u\ndevice_loop_t %.9g %.9g %.9g\n", sdev.n_meas, Tdev.t.x, Tdev.t.y, Tdev.t.z);
+    // repeats of the same correction run in the moment form once the first call has learnt its bounds (rmclhip.h:
+    // rmclhip_rcc_set_micp_fast); the result is the same
+    {
+      Transform Trep = Tdev;
+      CrossStatistics srep{};
+      for (int k = 0; k < 3; ++k) Trep = rcc.correctOnce(Tom_est, Tbo, 5, 0.0, false, &srep);
+      const rmclhip_micp_fast_info info = rcc.micpFastInfo();
+      std::printf("moment_form_attempts_done %u %u\nmoment_form_n_meas %u\nmoment_form_t %.9g %.9g %.9g\n", info.attempts, info.done,
+                  srep.n_meas, Trep.t.x, Trep.t.y, Trep.t.z);
+    }
 
     // the N-sensor entry point with this one sensor (the node's loop over sensors_vec_, micp_localization.cpp:921-938)
     {

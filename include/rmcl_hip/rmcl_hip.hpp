@@ -298,6 +298,13 @@ class Correspondences_<VRAM_HIP> {
     return out;
   }
   rmclhip_rcc* handle() const { return h_; }
+  // moment form of correctOnce's fixed-correspondence loop (rmclhip.h: rmclhip_rcc_set_micp_fast): 0 never, 1 automatic
+  void setMicpFast(int mode) { check(rmclhip_rcc_set_micp_fast(h_, mode)); }
+  rmclhip_micp_fast_info micpFastInfo() const {
+    rmclhip_micp_fast_info info{};
+    check(rmclhip_rcc_micp_fast_info(h_, &info));
+    return info;
+  }
   // bind `dataset` and push `params` before a device-resident loop reads them (correctOnce for several sensors)
   void prepareForDeviceLoop() {
     bindDataset();

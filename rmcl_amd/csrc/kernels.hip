@@ -1582,6 +1582,26 @@ __global__ void k_compose_poses(const xform* __restrict__ Tbm, xform Tsb, xform*
 // ---------------------------------------------------------------------------------------------
 constexpr int kAcc = 16;  // sd[3] sm[3] smd[9] cnt
 
+// wave64 sum of 16 doubles per lane through LDS instead of cross-lane shuffles: every lane stores its 16 values (row = lane),
+// lane L adds column L & 15 over the 16 rows of slice L >> 4, two xor steps join the four slices.  The 17 shuffles of the
+// halving butterfly are a chain of dependent ds_bpermute round trips (~3.4k clocks measured for a lone wave); here all stores
+// and all loads are independent (~0.6k).  scratch: 64 x 17 doubles owned by this wave; LDS operations of one wave complete in
+// order, so no barrier is needed.  Afterwards lanes 0..15 hold the totals of values 0..15.
+__device__ __forceinline__ double wave_sum16_lds(const double (&v)[16], double* scratch, uint32_t lane) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) scratch[lane * 17u + static_cast<uint32_t>(k)] = v[k];
+  const uint32_t col = lane & 15u, row0 = (lane >> 4) * 16u;
+  double a[16];
+#pragma unroll
+  for (uint32_t r = 0; r < 16u; ++r) a[r] = scratch[(row0 + r) * 17u + col];
+  double t = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  t += ((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15]));
+  t += __shfl_xor(t, 16, 64);
+  t += __shfl_xor(t, 32, 64);
+  return t;
+}
+
+
 // sum the per-block partials of one pose (one wave) and turn the raw moments into CrossStatistics
 template <bool kAgentLoads = false>
 __device__ __forceinline__ cstats finalize_pose(const double* partials, uint32_t nblocks) {
@@ -1680,6 +1700,7 @@ __device__ __forceinline__ void micp_close_sensor(const cstats& stats_s_last, co
 template <uint32_t kTail>
 __global__ void __launch_bounds__(256) k_reduce_partials(const ReduceParams p) {
   __shared__ double red[4][kAcc];
+  __shared__ double s_wsum[4][64 * 17];
   const uint32_t pose = blockIdx.y;
   const xform Tpre = (p.Tpre_dev != nullptr) ? p.Tpre_dev[pose] : p.Tpre;
   const float max_dist = (p.call != nullptr) ? p.call->max_dist : p.max_dist;
@@ -1710,23 +1731,13 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const ReduceParams p) {
       }
     }
   }
-  // wave64 reduction of 16 moments: halving butterfly -- at xor distance 32/16/8/4 each lane hands the half of
-  // its moments it no longer owns to its partner (8+4+2+1 exchanges), then two plain steps: 17 double shuffles
-  // instead of 16 x 6 = 96.  Afterwards lane L holds the wave total of moment L >> 2.
+  // wave64 reduction of the 16 moments through LDS (wave_sum16_lds: round 1 used a halving butterfly of 17 dependent
+  // double shuffles, ~3.4k clocks for the last wave of a block; the transposed sum has no dependent round trips)
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int half = 8, off = 32; half >= 1; half >>= 1, off >>= 1) {
-    const bool hi = (lane & static_cast<uint32_t>(off)) != 0u;
-#pragma unroll
-    for (int j = 0; j < half; ++j) {
-      const double send = hi ? acc[j] : acc[j + half];
-      const double keep = hi ? acc[j + half] : acc[j];
-      acc[j] = keep + __shfl_xor(send, off, 64);
-    }
+  {
+    const double wsum = wave_sum16_lds(acc, &s_wsum[wave][0], lane);
+    if (lane < 16u) red[wave][lane] = wsum;
   }
-  acc[0] += __shfl_xor(acc[0], 2, 64);
-  acc[0] += __shfl_xor(acc[0], 1, 64);
-  if ((lane & 3u) == 0u) red[wave][lane >> 2] = acc[0];
   __syncthreads();
   if (threadIdx.x < kAcc) {
     const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
@@ -1908,6 +1919,7 @@ struct MicpIterParams {
 
 __global__ void __launch_bounds__(256) k_micp_iter(const MicpIterParams p) {
   __shared__ double red[4][kAcc];
+  __shared__ double s_wsum[4][64 * 17];
   __shared__ xform s_Tpre;
   // The correspondences of this thread do not depend on the pre-transform the prologue is about to compute: request the
   // first two elements (all a thread gets at reduce_num_blocks' 512 elements per block) BEFORE the prologue, so that
@@ -1991,19 +2003,10 @@ __global__ void __launch_bounds__(256) k_micp_iter(const MicpIterParams p) {
   }
 #undef RMCL_P2L_ACCUMULATE
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int half = 8, off = 32; half >= 1; half >>= 1, off >>= 1) {
-    const bool hi = (lane & static_cast<uint32_t>(off)) != 0u;
-#pragma unroll
-    for (int j = 0; j < half; ++j) {
-      const double send = hi ? acc[j] : acc[j + half];
-      const double keep = hi ? acc[j + half] : acc[j];
-      acc[j] = keep + __shfl_xor(send, off, 64);
-    }
+  {
+    const double wsum = wave_sum16_lds(acc, &s_wsum[wave][0], lane);
+    if (lane < 16u) red[wave][lane] = wsum;
   }
-  acc[0] += __shfl_xor(acc[0], 2, 64);
-  acc[0] += __shfl_xor(acc[0], 1, 64);
-  if ((lane & 3u) == 0u) red[wave][lane >> 2] = acc[0];
   __syncthreads();
   if (threadIdx.x < kAcc)
     p.partials_out[static_cast<size_t>(blockIdx.x) * kAcc + threadIdx.x] =
@@ -2081,25 +2084,6 @@ __device__ __forceinline__ void wave_reduce16(double (&v)[16], uint32_t lane) {
   }
   v[0] += __shfl_xor(v[0], 2, 64);
   v[0] += __shfl_xor(v[0], 1, 64);
-}
-
-// wave64 sum of 16 doubles per lane through LDS instead of cross-lane shuffles: every lane stores its 16 values (row = lane),
-// lane L adds column L & 15 over the 16 rows of slice L >> 4, two xor steps join the four slices.  The 17 shuffles of the
-// halving butterfly are a chain of dependent ds_bpermute round trips (~3.4k clocks measured for a lone wave); here all stores
-// and all loads are independent (~0.6k).  scratch: 64 x 17 doubles owned by this wave; LDS operations of one wave complete in
-// order, so no barrier is needed.  Afterwards lanes 0..15 hold the totals of values 0..15.
-__device__ __forceinline__ double wave_sum16_lds(const double (&v)[16], double* scratch, uint32_t lane) {
-#pragma unroll
-  for (int k = 0; k < 16; ++k) scratch[lane * 17u + static_cast<uint32_t>(k)] = v[k];
-  const uint32_t col = lane & 15u, row0 = (lane >> 4) * 16u;
-  double a[16];
-#pragma unroll
-  for (uint32_t r = 0; r < 16u; ++r) a[r] = scratch[(row0 + r) * 17u + col];
-  double t = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-  t += ((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15]));
-  t += __shfl_xor(t, 16, 64);
-  t += __shfl_xor(t, 32, 64);
-  return t;
 }
 
 // raw sums of the reduction (sd[3] sm[3] smd[9] n) -> CrossStatistics, as finalize_pose does

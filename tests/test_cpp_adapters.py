@@ -72,6 +72,9 @@ def test_cpp_example_matches_python_and_oracle(ra, orc, ctx, meshes, tmp_path):
     q = np.array([float(x) for x in out["host_loop_q"]])
     q_ref = np.array([float(To["R"][k]) for k in "xyzw"])
     assert np.allclose(q, q_ref * np.sign(np.dot(q, q_ref)), atol=1e-5)
+    assert int(out["moment_form_attempts_done"][0]) == 4 and int(out["moment_form_attempts_done"][1]) >= 2
+    assert int(out["moment_form_n_meas"][0]) == int(so["n_meas"])
+    assert np.allclose([float(x) for x in out["moment_form_t"]], [float(x) for x in out["device_loop_t"]], atol=1e-6)
     assert int(out["multi_loop_n_meas"][0]) == int(so["n_meas"])
     assert np.allclose([float(x) for x in out["multi_loop_t"]], t_ref, atol=1e-5)
     # Correspondences_::dataset written like the reference's device sensors write it == the setDataset*() hand-over

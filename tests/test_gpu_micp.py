@@ -293,7 +293,7 @@ def test_moment_form_equals_per_iteration_form(ra, orc, ctx, meshes):
     Tsb, Tbo = syn.tsb_offset(), T.transform_from_rpy((0.3, -0.1, 0.0), (0.0, 0.0, 0.2))
     meas = m.simulate_spherical(model, Tsb, T.mult(truth, T.identity()), bvh=True, nthreads=8)
     ds, mask = om.dataset_from_ranges(model, meas["ranges"])
-    done_total = 0
+    done_total, unc_seen = 0, 0
     for pert, rpy, prog in (((0.03, -0.02, 0.01), (0.0, 0.0, 0.01), 0.0), ((0.12, 0.08, -0.03), (0.01, -0.01, 0.03), 0.0),
                             ((0.01, 0.0, 0.0), (0.0, 0.0, 0.002), 0.9), ((0.3, -0.2, 0.1), (0.02, 0.0, -0.06), 0.2)):
         # the localisation state: Tom * Tbo = truth * perturbation
@@ -313,6 +313,8 @@ def test_moment_form_equals_per_iteration_form(ra, orc, ctx, meshes):
                 info = rcc.micp_fast_info()
                 assert info["attempts"] == 3
                 done_total += info["done"]
+                if info["last_code"] == 0:
+                    unc_seen = max(unc_seen, info["last_uncertain"])
             else:
                 assert rcc.micp_fast_info()["attempts"] == 0
             rcc.close()
@@ -325,6 +327,7 @@ def test_moment_form_equals_per_iteration_form(ra, orc, ctx, meshes):
             _transform_close(Tf, To, 1e-5)
             assert np.allclose(sf["covariance"], sc["covariance"], rtol=1e-5, atol=1e-6)
     assert done_total >= 4          # the moment form did run (not only its fallback)
+    assert unc_seen > 0             # ... including its per-iteration re-evaluation of undecided correspondences
 
 
 def test_moment_form_fallbacks_keep_the_result(ra, orc, ctx, meshes):
