@@ -166,15 +166,17 @@ hipError_t launch_compose_poses(const xform* Tbm_dev, xform Tsb, xform* Tsm_out,
 uint32_t reduce_num_blocks(uint32_t n, uint32_t nposes);
 hipError_t launch_reduce_partials(const ReduceParams& p, hipStream_t s);
 // finalize one pose's partials into CrossStatistics (writes to out, which may be host-mapped memory)
-hipError_t launch_reduce_finalize(const double* partials, uint32_t nblocks, uint32_t nposes, cstats* out,
+// done (nullable, host-mapped, single pose only): set to 1 after `out` is visible to the host
+hipError_t launch_reduce_finalize(const double* partials, uint32_t nblocks, uint32_t nposes, cstats* out, uint32_t* done,
                                   hipStream_t s);
 // finalize + (Tsb*, Tbo*) + umeyama + compose; advances MicpState on the device
 hipError_t launch_micp_step(const double* partials, uint32_t nblocks, xform Tsb, xform Tbo, const MicpCall* call,
                             const MicpState* state, MicpState* state_out, hipStream_t s);
 // closing launch of the launch_micp_iter chain: solve of the last iteration + T_onew_oold / stats_o (the chain itself works in
 // the sensor frame, kernels.hip micp_advance_sensor)
+// done (nullable, host-mapped): set to 1 after the results are visible to the host
 hipError_t launch_micp_close(const double* partials, uint32_t nblocks, const MicpCall* call, const MicpState* state,
-                             MicpState* state_out, hipStream_t s);
+                             MicpState* state_out, uint32_t* done, hipStream_t s);
 // state: TWO MicpState slots (ping-pong of k_micp_iter); both initialised
 hipError_t launch_micp_init(MicpState* state, uint32_t* barrier, hipStream_t s);
 // one launch per MICP iteration: finishes the previous iteration (finalize + solve, redundantly in every block)

@@ -1778,10 +1778,16 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const ReduceParams p) {
 }
 
 __global__ void __launch_bounds__(64) k_reduce_finalize(const double* __restrict__ partials, uint32_t nblocks,
-                                                       cstats* __restrict__ out) {
+                                                       cstats* __restrict__ out, uint32_t* done) {
   const uint32_t pose = blockIdx.x;
   const cstats s = finalize_pose(partials + static_cast<size_t>(pose) * nblocks * kAcc, nblocks);
-  if (threadIdx.x == 0) out[pose] = s;
+  if (threadIdx.x == 0) {
+    out[pose] = s;
+    if (done) {   // single-pose call with a host-mapped result: completion word polled by the host (capi.cpp wait_word)
+      __threadfence_system();
+      *done = 1u;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2028,7 +2034,7 @@ __global__ void k_micp_init(MicpState* st, uint32_t* barrier) {
 // result without a device-to-host copy node
 // closing launch of the one-launch-per-iteration form: the last iteration's solve + the odom-frame results
 __global__ void __launch_bounds__(64) k_micp_close(const double* __restrict__ partials, uint32_t nblocks, const MicpCall* call,
-                                                   const MicpState* st, MicpState* st_out) {
+                                                   const MicpState* st, MicpState* st_out, uint32_t* done) {
   const cstats stats_s = finalize_pose(partials, nblocks);
   if (threadIdx.x == 0) {
     xform T_s = st->T_snew_sold;
@@ -2036,6 +2042,10 @@ __global__ void __launch_bounds__(64) k_micp_close(const double* __restrict__ pa
     MicpState out;
     micp_close_sensor(stats_s, T_s, call->Tsb, call->Tbo, &out);
     *st_out = out;
+    if (done) {   // host-mapped completion word: the caller polls it instead of waiting for the stream's signal
+      __threadfence_system();
+      *done = 1u;
+    }
   }
 }
 
@@ -3259,9 +3269,9 @@ hipError_t launch_reduce_partials(const ReduceParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_reduce_finalize(const double* partials, uint32_t nblocks, uint32_t nposes, cstats* out,
+hipError_t launch_reduce_finalize(const double* partials, uint32_t nblocks, uint32_t nposes, cstats* out, uint32_t* done,
                                   hipStream_t s) {
-  hipLaunchKernelGGL(k_reduce_finalize, dim3(nposes), dim3(64), 0, s, partials, nblocks, out);
+  hipLaunchKernelGGL(k_reduce_finalize, dim3(nposes), dim3(64), 0, s, partials, nblocks, out, (nposes == 1u) ? done : nullptr);
   return hipGetLastError();
 }
 
@@ -3313,8 +3323,8 @@ hipError_t launch_micp_init(MicpState* state, uint32_t* barrier, hipStream_t s) 
 }
 
 hipError_t launch_micp_close(const double* partials, uint32_t nblocks, const MicpCall* call, const MicpState* state,
-                             MicpState* state_out, hipStream_t s) {
-  hipLaunchKernelGGL(k_micp_close, dim3(1), dim3(64), 0, s, partials, nblocks, call, state, state_out);
+                             MicpState* state_out, uint32_t* done, hipStream_t s) {
+  hipLaunchKernelGGL(k_micp_close, dim3(1), dim3(64), 0, s, partials, nblocks, call, state, state_out, done);
   return hipGetLastError();
 }
 
