@@ -2168,7 +2168,8 @@ __global__ void __launch_bounds__(256) k_micp_moments(const MicpFastParams p) {
       const float nd = sqrtf(dot_plain(Di, Di));
       const float margin = (rho_cap * nd + tau_cap) + 1e-4f * (1.0f + nd);
       const float slack = fabsf(fabsf(spd0) - max_dist);
-      const bool certain = ok[u] && (slack > margin);          // NaN anywhere => not certain
+      // NaN gate value (a NaN / inf dataset point without a mask): NaN under every pre-transform, gated out for good
+      const bool certain = ok[u] && ((slack > margin) || (spd0 != spd0));
       const bool uncertain = ok[u] && !certain;
       const unsigned long long word = __ballot(uncertain);
       if (lane == 0u) p.unc_mask[(base + static_cast<uint32_t>(u) * stride) >> 6] = word;

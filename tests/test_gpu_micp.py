@@ -369,3 +369,42 @@ def test_moment_form_fallbacks_keep_the_result(ra, orc, ctx, meshes):
     assert 2 in codes or info["overflows"] >= 0      # the tight gate may or may not overflow on this mesh: reported either way
     rcc.close()
     ref.close()
+
+
+def test_moment_form_o1dn_unmasked_dataset_and_short_dataset(ra, orc, ctx, meshes):
+    """The moment form behind the other entry conditions of correct_once: an O1Dn model with NaN directions (misses),
+    a dataset handed over WITHOUT a mask (NaN points stay in and are gated out by the reduction's own comparison), and a
+    dataset shorter than the model (the reduction runs over min(n_dataset, n_model)): equal to the per-iteration form."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room30k")
+    hm = ra.import_hip_map(ctx, v, f)
+    model = syn.model_c1()
+    dirs = syn.model_directions(model).copy()
+    dirs[5::97] = np.nan
+    H, W = model.phi.size, model.theta.size
+    truth = T.transform_from_rpy((1.0, -1.5, 1.2), (0.0, 0.0, 0.5))
+    est = T.mult(truth, T.transform_from_rpy((0.04, -0.03, 0.01), (0.0, 0.0, 0.012)))
+    res = {}
+    for mode in (0, 1):
+        rcc = ra.RCCHipO1Dn(hm)
+        rcc.setTsb(T.identity())
+        rcc.setModel(W, H, 0.1, 100.0, (0.0, 0.0, 0.0), dirs)
+        rcc.find(truth)
+        mv = rcc.modelView()
+        pts = (dirs * mv["ranges"].reshape(-1, 1)).astype(np.float32)     # NaN where the direction is NaN
+        pts[mv["hits"].reshape(-1) == 0] = np.nan                            # ... and where the scan missed
+        rcc.params.max_dist, rcc.adaptive_max_dist_min = 0.6, 0.2
+        rcc.set_micp_fast(mode)
+        out = []
+        rcc.set_dataset(pts, None)
+        out += [rcc.correct_once(est, T.identity(), 6, 0.1, False) for _ in range(3)]
+        rcc.set_dataset(pts[: (H * W) // 2 + 7], None)
+        out += [rcc.correct_once(est, T.identity(), 6, 0.1, False) for _ in range(3)]
+        res[mode] = out
+        if mode == 1:
+            assert rcc.micp_fast_info()["done"] >= 2
+        rcc.close()
+    for (Tf, sf), (Tc, sc) in zip(res[1], res[0]):
+        assert int(sf["n_meas"]) == int(sc["n_meas"]) > 100
+        _transform_close(Tf, Tc, 1e-6)
+    assert int(res[1][0][1]["n_meas"]) > int(res[1][3][1]["n_meas"])        # the short dataset really is shorter
