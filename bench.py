@@ -262,6 +262,11 @@ def main():
             extras["v1_bench_1000x16x900_ms"] = round(dt * 1e3, 4)
             extras["v1_bench_rays_per_s"] = round(1000 * 16 * 900 / dt, 1)
             extras["v1_bench_pose_corrections_per_s"] = round(1000 / dt, 1)
+            # stage split in the reference benchmark's terms (lidar_corrector_embree_benchmark.cpp:185-190 records Sim 96.8 %,
+            # Red 3.2 %, SVD 0.015 % on its CPU): sim = the batched find (HIP events), the rest = batched reduction + per-pose
+            # solve + result download (one launch each, host clock)
+            sim_ms = small.time_find_batch(v1poses, iters=5)
+            extras["v1_bench_stage_split_ms"] = {"sim": round(sim_ms, 4), "red_svd_download": round(dt * 1e3 - sim_ms, 4)}
             small.close()
             # two sensors through the device-resident N-sensor loop (rmclhip_micp_correct_once): 128x1024 + 16x900, 10 iterations
             sA, sB = ra.RCCHipSpherical(hm), ra.RCCHipSpherical(hm)

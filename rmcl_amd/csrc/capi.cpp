@@ -192,6 +192,13 @@ struct rmclhip_rcc {
   uint32_t fast_holdoff = 0;       // corrections to skip the attempt for (after repeated overflows)
   uint32_t fast_overflows = 0;     // consecutive
   rmclhip_micp_fast_info fast_info = {};
+  // N-sensor loop (rmclhip_micp_correct_once): call block + state of the first sensor, kept between calls
+  DevBuf<uint8_t> d_multi_blob;
+  MicpMultiState* h_multi_state = nullptr;          // pinned, host-mapped
+  MicpMultiState* h_multi_state_dev = nullptr;
+  MicpMultiFastStatus* h_multi_status = nullptr;    // pinned, host-mapped
+  MicpMultiFastStatus* h_multi_status_dev = nullptr;
+  uint32_t multi_holdoff = 0, multi_overflows = 0;
   // batch
   DevBuf<uint8_t> d_raw;           // staged PointCloud2 bytes (set_input_pointcloud2)
   DevBuf<xform> d_Tbm, d_Tsm, d_Tms, d_Tdelta;
@@ -465,6 +472,9 @@ void rmclhip_rcc_destroy(rmclhip_rcc* r) {
   if (r->micp_fast_graph) DBG_STEP(hipGraphDestroy(r->micp_fast_graph));
   if (r->h_fast_status) DBG_STEP(hipHostFree(r->h_fast_status));
   r->d_fast_partials.release(); r->d_fast_mask.release();
+  r->d_multi_blob.release();
+  if (r->h_multi_state) DBG_STEP(hipHostFree(r->h_multi_state));
+  if (r->h_multi_status) DBG_STEP(hipHostFree(r->h_multi_status));
   if (r->h_call) DBG_STEP(hipHostFree(r->h_call));
   if (r->d_call) DBG_STEP(hipFree(r->d_call));
   if (r->ev0) DBG_STEP(hipEventDestroy(r->ev0));
@@ -1325,12 +1335,17 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
     h_call.nblocks[s] = nb;
   }
   h_call.n_sensors = n_sensors;
-  DevBuf<uint8_t> d_blob;   // call + state
-  HIPCHK(d_blob.reserve(sizeof(MicpMultiCall) + sizeof(MicpMultiState)));
-  MicpMultiCall* d_call = reinterpret_cast<MicpMultiCall*>(d_blob.p);
-  MicpMultiState* d_state = reinterpret_cast<MicpMultiState*>(d_blob.p + sizeof(MicpMultiCall));
+  // call + state live with the first sensor and persist between calls (an allocation per call cost more than the loop)
+  HIPCHK(r0->d_multi_blob.reserve(sizeof(MicpMultiCall) + sizeof(MicpMultiState)));
+  if (!r0->h_multi_state) {
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&r0->h_multi_state), sizeof(MicpMultiState), hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&r0->h_multi_state_dev), r0->h_multi_state, 0));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&r0->h_multi_status), sizeof(MicpMultiFastStatus), hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&r0->h_multi_status_dev), r0->h_multi_status, 0));
+  }
+  MicpMultiCall* d_call = reinterpret_cast<MicpMultiCall*>(r0->d_multi_blob.p);
+  MicpMultiState* d_state = reinterpret_cast<MicpMultiState*>(r0->d_multi_blob.p + sizeof(MicpMultiCall));
   hipError_t e = hipMemcpyAsync(d_call, &h_call, sizeof(h_call), hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) e = launch_micp_multi_init(d_call, d_state, st);
   // sensor->setTom(Tom); sensor->findCorrespondences()  (:900-909): Tbm = Tom * Tbo
   for (uint32_t s = 0; s < n_sensors && e == hipSuccess; ++s) {
     rmclhip_rcc* r = sensors[s];
@@ -1342,6 +1357,66 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
     if (v == 18) v = 17;
     e = launch_find(p, r->kind, v, st);
   }
+  if (e != hipSuccess) return fail(RMCLHIP_ERR_HIP, std::string("micp_correct_once: ") + hipGetErrorString(e));
+  // ---- moment form first (kernels.hip k_micp_multi_fast_loop): every sensor's caps are the ones its own corrections learnt
+  bool fast_eligible = n_iter >= 2u;
+  for (uint32_t s = 0; s < n_sensors; ++s) fast_eligible = fast_eligible && sensors[s]->fast_mode != 0;
+  bool fast_tried = false;
+  if (fast_eligible && r0->multi_holdoff > 0u) --r0->multi_holdoff;
+  else if (fast_eligible) {
+    fast_tried = true;
+    MicpMultiFastParams fp;
+    std::memset(&fp, 0, sizeof(fp));
+    for (uint32_t s = 0; s < n_sensors; ++s) {
+      rmclhip_rcc* r = sensors[s];
+      const uint32_t nred = (r->n_dataset < r->n_model) ? r->n_dataset : r->n_model;
+      HIPCHK(r->d_fast_partials.reserve(static_cast<size_t>(micp_fast_blocks(nred)) * kMicpFastMoments));
+      HIPCHK(r->d_fast_mask.reserve((static_cast<size_t>(nred) + 63u) / 64u));
+      std::memset(r->h_call, 0, sizeof(MicpCall));
+      r->h_call->max_dist = adaptive_max_dist(r, convergence_progress);
+      r->h_call->rho_cap = r->fast_rho_cap;
+      r->h_call->tau_cap = r->fast_tau_cap;
+      HIPCHK(hipMemcpyAsync(r->d_call, r->h_call, sizeof(MicpCall), hipMemcpyHostToDevice, st));
+      HIPCHK(launch_micp_moments(r->ds_pts, r->ds_has_mask ? r->ds_msk : nullptr, r->d_points.p, r->d_normals.p, r->d_hits.p, nred,
+                                 r->d_call, r->d_fast_partials.p, r->d_fast_mask.p, st));
+      fp.dataset_points[s] = r->ds_pts; fp.model_points[s] = r->d_points.p; fp.model_normals[s] = r->d_normals.p;
+      fp.partials[s] = r->d_fast_partials.p; fp.unc_mask[s] = r->d_fast_mask.p; fp.sensor_call[s] = r->d_call;
+      fp.n[s] = nred; fp.nblocks[s] = micp_fast_blocks(nred);
+    }
+    fp.call = d_call;
+    fp.n_iter = n_iter;
+    fp.state_out = r0->h_multi_state_dev;
+    fp.status = r0->h_multi_status_dev;
+    r0->h_multi_status->code = 0xFFFFFFFFu;
+    HIPCHK(launch_micp_multi_fast_loop(fp, st));
+    HIPCHK(wait_word(&r0->h_multi_status->code, 0xFFFFFFFFu, st));
+    const MicpMultiFastStatus fs = *r0->h_multi_status;
+    for (uint32_t s = 0; s < n_sensors; ++s) {
+      rmclhip_rcc* r = sensors[s];
+      r->fast_info.attempts++;
+      r->fast_info.last_code = fs.code;
+      r->fast_info.last_uncertain = fs.n_uncertain;
+      r->fast_info.last_rho = fs.max_rho[s];
+      r->fast_info.last_tau = fs.max_tau[s];
+    }
+    if (fs.code == 0u) {
+      r0->multi_overflows = 0;
+      for (uint32_t s = 0; s < n_sensors; ++s) {
+        rmclhip_rcc* r = sensors[s];
+        r->fast_info.done++;
+        r->fast_rho_cap = std::max(0.002f, std::max(2.0f * fs.max_rho[s], 0.9f * r->fast_rho_cap));
+        r->fast_tau_cap = std::max(0.005f, std::max(2.0f * fs.max_tau[s], 0.9f * r->fast_tau_cap));
+      }
+      from_x(r0->h_multi_state->T_onew_oold, T_out);
+      if (merged_out) from_cs(r0->h_multi_state->merged_o, merged_out);
+      return RMCLHIP_OK;
+    }
+    if (fs.code != 1u && fs.code != 2u) return fail(RMCLHIP_ERR_HIP, "micp_correct_once: the moment-form loop did not report a status");
+    for (uint32_t s = 0; s < n_sensors; ++s) {
+      if (fs.code == 2u) sensors[s]->fast_info.overflows++; else sensors[s]->fast_info.cap_exits++;
+    }
+  }
+  e = launch_micp_multi_init(d_call, d_state, st);
   for (uint32_t it = 0; it < n_iter && e == hipSuccess; ++it) {
     for (uint32_t s = 0; s < n_sensors && e == hipSuccess; ++s) {
       rmclhip_rcc* r = sensors[s];
@@ -1365,8 +1440,25 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
   MicpMultiState h_state;
   if (e == hipSuccess) e = hipMemcpyAsync(&h_state, d_state, sizeof(h_state), hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  d_blob.release();
   if (e != hipSuccess) return fail(RMCLHIP_ERR_HIP, std::string("micp_correct_once: ") + hipGetErrorString(e));
+  if (fast_tried) {
+    // caps for the next attempt from the pre-transforms this correction ended with (see rmclhip_rcc_correct_once)
+    const bool overflow = r0->h_multi_status->code == 2u;
+    for (uint32_t s = 0; s < n_sensors; ++s) {
+      rmclhip_rcc* r = sensors[s];
+      const xform Ts = h_state.T_snew_sold[s];
+      const float rho = 2.0f * std::sqrt(Ts.R.x * Ts.R.x + Ts.R.y * Ts.R.y + Ts.R.z * Ts.R.z);
+      const float tau = std::sqrt(Ts.t.x * Ts.t.x + Ts.t.y * Ts.t.y + Ts.t.z * Ts.t.z);
+      if (overflow) {
+        r->fast_rho_cap = std::max(0.002f, 1.25f * rho);
+        r->fast_tau_cap = std::max(0.005f, 1.25f * tau);
+      } else {
+        r->fast_rho_cap = std::max(0.002f, std::max(2.0f * rho, 2.0f * r0->h_multi_status->max_rho[s]));
+        r->fast_tau_cap = std::max(0.005f, std::max(2.0f * tau, 2.0f * r0->h_multi_status->max_tau[s]));
+      }
+    }
+    if (overflow && ++r0->multi_overflows >= 2u) { r0->multi_holdoff = 32u; r0->multi_overflows = 0; }
+  }
   from_x(h_state.T_onew_oold, T_out);
   if (merged_out) from_cs(h_state.merged_o, merged_out);
   return RMCLHIP_OK;

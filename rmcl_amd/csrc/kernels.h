@@ -142,6 +142,30 @@ struct MicpMultiState {
   cstats merged_o, merged_weighted_o;
   xform T_snew_sold[kMaxMicpSensors];
 };
+// moment form of the N-sensor loop: launch_micp_moments once per sensor (its MicpCall carries max_dist and the caps), then ONE
+// single-workgroup launch for all iterations of all sensors; status->code as MicpFastStatus (0 done, 1 a pre-transform of
+// sensor `sensor` left its caps, 2 more than 4096 undecided correspondences in total)
+struct MicpMultiFastStatus {
+  uint32_t code, iter, n_uncertain, sensor;
+  float max_rho[kMaxMicpSensors], max_tau[kMaxMicpSensors];
+};
+struct MicpMultiFastParams {
+  const float* dataset_points[kMaxMicpSensors];
+  const float* model_points[kMaxMicpSensors];
+  const float* model_normals[kMaxMicpSensors];
+  const double* partials[kMaxMicpSensors];               // [nblocks][96] of launch_micp_moments
+  const unsigned long long* unc_mask[kMaxMicpSensors];
+  const MicpCall* sensor_call[kMaxMicpSensors];           // max_dist, rho_cap, tau_cap
+  uint32_t n[kMaxMicpSensors], nblocks[kMaxMicpSensors];
+  const MicpMultiCall* call;
+  uint32_t n_iter;
+  MicpMultiState* state_out;                              // may be host-mapped
+  MicpMultiFastStatus* status;                            // may be host-mapped
+};
+hipError_t launch_micp_moments(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
+                               const float* model_normals, const uint8_t* model_mask, uint32_t n, const MicpCall* call,
+                               double* partials, unsigned long long* unc_mask, hipStream_t s);
+hipError_t launch_micp_multi_fast_loop(const MicpMultiFastParams& p, hipStream_t s);
 hipError_t launch_micp_multi_init(const MicpMultiCall* call, MicpMultiState* state, hipStream_t s);
 hipError_t launch_micp_multi_step(const MicpMultiCall* call, MicpMultiState* state, hipStream_t s);
 

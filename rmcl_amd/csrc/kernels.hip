@@ -3270,6 +3270,219 @@ hipError_t launch_reduce_partials(const ReduceParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Moment form of the N-sensor loop (k_micp_multi_step's iteration, micp_localization.cpp:915-964): every sensor's statistics
+// come from its moments + its undecided correspondences at ITS pre-transform (see k_micp_fast_loop); the merge over the sensors
+// and the solve keep the frame-by-frame order of k_micp_multi_step.
+__global__ void __launch_bounds__(kFastThreads) k_micp_multi_fast_loop(const MicpMultiFastParams p) {
+  constexpr uint32_t kGroups = kFastThreads / kMom;
+  __shared__ double s_mom[kMaxMicpSensors][kMom];
+  __shared__ double s_part[kGroups][kMom];
+  __shared__ double s_rows[kFastThreads][17];
+  __shared__ double s_tot[kMaxMicpSensors][16];
+  __shared__ double s_R[kMaxMicpSensors][9], s_t[kMaxMicpSensors][3];
+  __shared__ MomentScratch s_ws;
+  __shared__ uint32_t s_list[kFastMaxUncertain];
+  __shared__ uint32_t s_seg[kMaxMicpSensors + 1];
+  __shared__ uint32_t s_wave_cnt[kFastThreads / 64];
+  __shared__ xform s_Ts[kMaxMicpSensors];
+  __shared__ uint32_t s_flag, s_flag_sensor;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t ns = p.call->n_sensors;
+
+  // set-up, sensor by sensor: moments and the index-ordered list segment of its undecided correspondences
+  uint32_t total = 0;
+  for (uint32_t s = 0; s < ns; ++s) {
+    {
+      const uint32_t k = tid % kMom, g = tid / kMom;
+      if (g < kGroups) {
+        double a = 0.0;
+        uint32_t b = g;
+        const double* part = p.partials[s];
+        for (; b + 15u * kGroups < p.nblocks[s]; b += 16u * kGroups) {
+          double v[16];
+#pragma unroll
+          for (uint32_t u = 0; u < 16u; ++u) v[u] = part[static_cast<size_t>(b + u * kGroups) * kMom + k];
+#pragma unroll
+          for (uint32_t u = 0; u < 16u; u += 4u) a += (v[u] + v[u + 1]) + (v[u + 2] + v[u + 3]);
+        }
+        for (; b < p.nblocks[s]; b += kGroups) a += part[static_cast<size_t>(b) * kMom + k];
+        s_part[g][k] = a;
+      }
+    }
+    const unsigned long long* mask = p.unc_mask[s];
+    const uint32_t nwords = (p.n[s] + 63u) >> 6;
+    const uint32_t wpt = (nwords + kFastThreads - 1u) / kFastThreads;
+    const uint32_t w0 = min(tid * wpt, nwords), w1 = min(w0 + wpt, nwords);
+    uint32_t cnt = 0;
+    for (uint32_t w = w0; w < w1; ++w) cnt += static_cast<uint32_t>(__popcll(mask[w]));
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t v = __shfl_up(incl, off, 64);
+      if (lane >= static_cast<uint32_t>(off)) incl += v;
+    }
+    if (lane == 63u) s_wave_cnt[wave] = incl;
+    __syncthreads();
+    if (tid < kMom) {
+      double a = s_part[0][tid];
+#pragma unroll
+      for (uint32_t g = 1; g < kGroups; ++g) a += s_part[g][tid];
+      s_mom[s][tid] = a;
+    }
+    uint32_t wave_base = 0, cnt_s = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kFastThreads / 64; ++w) {
+      const uint32_t c = s_wave_cnt[w];
+      if (w < wave) wave_base += c;
+      cnt_s += c;
+    }
+    if (tid == 0u) s_seg[s] = total;
+    if (total + cnt_s > kFastMaxUncertain) {
+      if (tid == 0u) {
+        MicpMultiFastStatus st;
+        st.code = 2u; st.iter = 0u; st.n_uncertain = total + cnt_s; st.sensor = s;
+        for (uint32_t q = 0; q < kMaxMicpSensors; ++q) { st.max_rho[q] = 0.f; st.max_tau[q] = 0.f; }
+        *p.status = st;
+      }
+      return;
+    }
+    if (cnt != 0u) {
+      uint32_t pos = total + wave_base + incl - cnt;
+      for (uint32_t w = w0; w < w1; ++w) {
+        unsigned long long bits = mask[w];
+        while (bits) {
+          const int b = __builtin_ctzll(bits);
+          bits &= bits - 1ull;
+          s_list[pos++] = (w << 6) + static_cast<uint32_t>(b);
+        }
+      }
+    }
+    total += cnt_s;
+    __syncthreads();   // s_part / s_wave_cnt are reused by the next sensor
+  }
+  if (tid == 0u) {
+    s_seg[ns] = total;
+    s_flag = 0u;
+    for (uint32_t s = 0; s < ns; ++s) s_Ts[s] = xidentity();
+  }
+  // loop state of thread 0
+  xform T_onew_oold = xidentity();
+  cstats merged = cs_identity(), merged_w = cs_identity();
+  float max_rho[kMaxMicpSensors], max_tau[kMaxMicpSensors];
+#pragma unroll
+  for (uint32_t q = 0; q < kMaxMicpSensors; ++q) { max_rho[q] = 0.f; max_tau[q] = 0.f; }
+  __syncthreads();
+  for (uint32_t it = 0; it < p.n_iter; ++it) {
+    if (tid == 0u) {
+      for (uint32_t s = 0; s < ns; ++s) {
+        const xform T = s_Ts[s];
+        const float rho = 2.0f * sqrtf((T.R.x * T.R.x + T.R.y * T.R.y) + T.R.z * T.R.z);
+        const float tau = sqrtf(dot_plain(T.t, T.t));
+        max_rho[s] = fmaxf(max_rho[s], rho);
+        max_tau[s] = fmaxf(max_tau[s], tau);
+        if ((!(rho <= p.sensor_call[s]->rho_cap) || !(tau <= p.sensor_call[s]->tau_cap)) && s_flag == 0u) { s_flag = 1u; s_flag_sensor = s; }
+        const double x = T.R.x, y = T.R.y, z = T.R.z, w = T.R.w;
+        const double ww = w * w, uu = (x * x + y * y) + z * z;
+        double* R = s_R[s];
+        R[0] = (ww - uu) + 2.0 * x * x; R[1] = 2.0 * (x * y - w * z);   R[2] = 2.0 * (x * z + w * y);
+        R[3] = 2.0 * (x * y + w * z);   R[4] = (ww - uu) + 2.0 * y * y; R[5] = 2.0 * (y * z - w * x);
+        R[6] = 2.0 * (x * z - w * y);   R[7] = 2.0 * (y * z + w * x);   R[8] = (ww - uu) + 2.0 * z * z;
+        s_t[s][0] = T.t.x; s_t[s][1] = T.t.y; s_t[s][2] = T.t.z;
+      }
+    }
+    __syncthreads();
+    if (s_flag != 0u) {
+      if (tid == 0u) {
+        MicpMultiFastStatus st;
+        st.code = 1u; st.iter = it; st.n_uncertain = total; st.sensor = s_flag_sensor;
+        for (uint32_t q = 0; q < kMaxMicpSensors; ++q) { st.max_rho[q] = max_rho[q]; st.max_tau[q] = max_tau[q]; }
+        *p.status = st;
+      }
+      return;
+    }
+    for (uint32_t s = 0; s < ns; ++s) {
+      const uint32_t seg0 = s_seg[s], seg1 = s_seg[s + 1];
+      const uint32_t nrows = min(seg1 - seg0, kFastThreads);
+      if (tid < nrows) {
+        const xform Tpre = s_Ts[s];
+        const float max_dist = p.sensor_call[s]->max_dist;
+        const float* dpts = p.dataset_points[s];
+        const float* mpts = p.model_points[s];
+        const float* mnrm = p.model_normals[s];
+        double acc[kAcc];
+#pragma unroll
+        for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
+        for (uint32_t e = seg0 + tid; e < seg1; e += kFastThreads) {
+          const uint32_t i = s_list[e];
+          const float* dp = dpts + 3 * static_cast<size_t>(i);
+          const float* mp = mpts + 3 * static_cast<size_t>(i);
+          const float* mn = mnrm + 3 * static_cast<size_t>(i);
+          const f3 Di = xapply(Tpre, mk3(dp[0], dp[1], dp[2]));
+          const f3 Ii = mk3(mp[0], mp[1], mp[2]);
+          const f3 Ni = mk3(mn[0], mn[1], mn[2]);
+          const float spd = dot_plain(sub3(Ii, Di), Ni);
+          if (fabsf(spd) < max_dist) {
+            const f3 Mi = add3(Di, scale3(Ni, spd));
+            const double d[3] = {Di.x, Di.y, Di.z}, m[3] = {Mi.x, Mi.y, Mi.z};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { acc[k] += d[k]; acc[3 + k] += m[k]; }
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+              for (int c = 0; c < 3; ++c) acc[6 + 3 * r + c] += m[r] * d[c];
+            acc[15] += 1.0;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kAcc; ++k) s_rows[tid][k] = acc[k];
+      }
+      __syncthreads();
+      if (wave == 0u) {
+        micp_moment_sums_wave(lane, s_mom[s], s_R[s], s_t[s], &s_ws, s_tot[s]);
+        if (lane < 16u && nrows != 0u) {
+          double v = s_tot[s][lane];
+          for (uint32_t r = 0; r < nrows; ++r) v += s_rows[r][lane];
+          s_tot[s][lane] = v;
+        }
+      }
+      __syncthreads();   // s_rows / s_ws are reused by the next sensor
+    }
+    if (tid == 0u) {
+      // k_micp_multi_step's merge and solve, frame by frame
+      merged = cs_identity();
+      merged_w = cs_identity();
+      for (uint32_t s = 0; s < ns; ++s) {
+        double tot[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot[k] = s_tot[s][k];
+        const cstats stats_s = cstats_from_sums(tot);
+        const cstats Cs_o = cs_transform(p.call->Tbo[s], cs_transform(p.call->Tsb[s], stats_s));
+        cstats Cs_w = Cs_o;
+        Cs_w.n_meas = static_cast<uint32_t>(static_cast<double>(Cs_w.n_meas) * p.call->weight[s]);
+        merged = cs_merge(merged, Cs_o);
+        merged_w = cs_merge(merged_w, Cs_w);
+      }
+      T_onew_oold = xmul(T_onew_oold, umeyama(merged_w));
+      for (uint32_t s = 0; s < ns; ++s) {
+        const xform T_bnew_bold = xmul(xmul(xinv(p.call->Tbo[s]), T_onew_oold), p.call->Tbo[s]);
+        s_Ts[s] = xmul(xmul(xinv(p.call->Tsb[s]), T_bnew_bold), p.call->Tsb[s]);
+      }
+    }
+  }
+  if (tid == 0u) {
+    MicpMultiState* out = p.state_out;
+    out->T_onew_oold = T_onew_oold;
+    out->merged_o = merged;
+    out->merged_weighted_o = merged_w;
+    for (uint32_t s = 0; s < ns; ++s) out->T_snew_sold[s] = s_Ts[s];
+    MicpMultiFastStatus st;
+    st.code = 0u; st.iter = p.n_iter; st.n_uncertain = total; st.sensor = 0u;
+    for (uint32_t q = 0; q < kMaxMicpSensors; ++q) { st.max_rho[q] = max_rho[q]; st.max_tau[q] = max_tau[q]; }
+    __threadfence_system();
+    *p.status = st;
+  }
+}
+
 hipError_t launch_reduce_finalize(const double* partials, uint32_t nblocks, uint32_t nposes, cstats* out, uint32_t* done,
                                   hipStream_t s) {
   hipLaunchKernelGGL(k_reduce_finalize, dim3(nposes), dim3(64), 0, s, partials, nblocks, out, (nposes == 1u) ? done : nullptr);
@@ -3294,6 +3507,20 @@ hipError_t launch_micp_iter(const float* dataset_points, const uint8_t* dataset_
   MicpIterParams p{dataset_points, dataset_mask, model_points, model_normals, model_mask, n, nblocks, call,
                    partials_prev, partials_out, state_in, state_out, first ? 1u : 0u};
   hipLaunchKernelGGL(k_micp_iter, dim3(nblocks), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_micp_moments(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
+                               const float* model_normals, const uint8_t* model_mask, uint32_t n, const MicpCall* call,
+                               double* partials, unsigned long long* unc_mask, hipStream_t s) {
+  MicpFastParams p{dataset_points, dataset_mask, model_points, model_normals, model_mask, n, micp_fast_blocks(n), call,
+                   partials, unc_mask, 0u, nullptr, nullptr};
+  hipLaunchKernelGGL(k_micp_moments, dim3(p.nblocks), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_micp_multi_fast_loop(const MicpMultiFastParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(k_micp_multi_fast_loop, dim3(1), dim3(kFastThreads), 0, s, p);
   return hipGetLastError();
 }
 

@@ -244,15 +244,30 @@ def test_two_sensor_device_loop_equals_host_loop(ra, orc, ctx, meshes):
             sensors.append(s)
         return sensors
 
-    for n_iter, progress in ((5, 0.0), (10, 0.4)):
+    est_far = est
+    est_near = T.mult(truth, T.transform_from_rpy((0.03, -0.02, 0.01), (0.002, 0.0, 0.006)))
+    for n_iter, progress, est, want_done in ((5, 0.0, est_far, False), (10, 0.4, est_far, False), (10, 0.1, est_near, True)):
         host = ra.MICPLocalization(build(), optimization_iterations=n_iter)
         host.Tom_, host.convergence_progress_ = est, progress
         rec = []
         Th = host.correctOnce(record=rec)
         dev = ra.MICPLocalization(build(), optimization_iterations=n_iter)
+        # the same correction three times: the first call of the moment form of the N-sensor loop learns its bounds (falls
+        # back to one streaming launch per sensor and iteration), the repeats run in the single-workgroup loop
+        for rep in range(3):
+            dev.Tom_, dev.convergence_progress_ = est, progress
+            Td = dev.correctOnce(device_loop=True)
+            _transform_close(Td, Th, 1e-5)
+        infos = [s.correspondences_.micp_fast_info() for s in dev.sensors_vec_]
+        # a correction that is large against the gate (est_far: the points move up to 0.9 m, max_dist is 0.8) leaves every
+        # correspondence undecided and always takes the fallback; the small one must complete in the moment form
+        assert all(i["attempts"] == 3 for i in infos) and (not want_done or all(i["done"] >= 1 for i in infos)), infos
+        # ... and with the moment form switched off on one sensor the whole loop takes the per-iteration form
+        dev.sensors_vec_[1].correspondences_.set_micp_fast(0)
         dev.Tom_, dev.convergence_progress_ = est, progress
         Td = dev.correctOnce(device_loop=True)
         _transform_close(Td, Th, 1e-5)
+        assert dev.sensors_vec_[0].correspondences_.micp_fast_info()["attempts"] == 3
         assert dev.correction_stats_latest_["valid_matches"] == host.correction_stats_latest_["valid_matches"] > 1000
         assert abs(dev.convergence_progress_ - host.convergence_progress_) < 1e-6
         _transform_close(dev.Tom_, host.Tom_, 1e-5)
