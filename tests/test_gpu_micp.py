@@ -423,3 +423,49 @@ def test_moment_form_o1dn_unmasked_dataset_and_short_dataset(ra, orc, ctx, meshe
         assert int(sf["n_meas"]) == int(sc["n_meas"]) > 100
         _transform_close(Tf, Tc, 1e-6)
     assert int(res[1][0][1]["n_meas"]) > int(res[1][3][1]["n_meas"])        # the short dataset really is shorter
+
+
+def test_moment_form_randomised_against_per_iteration_form(ra, orc, ctx, meshes):
+    """120 random corrections (mesh, mount, odometry frame, perturbation from millimetres to decimetres, gate from 5 cm to
+    2 m, 2..12 iterations, progress) through two operators that differ only in rmclhip_rcc_set_micp_fast: n_meas must be
+    IDENTICAL (a gate decision taken from the moments that the per-iteration arithmetic takes differently would show here)
+    and the pose equal to 1e-6 -- whichever exit the moment form takes."""
+    from rmcl_amd import synthetic as syn, types as T
+    rng = np.random.RandomState(2024)
+    model = syn.model_c1()
+    codes = {0: 0, 1: 0, 2: 0}
+    for mesh in ("cube", "room30k"):
+        v, f = meshes(mesh)
+        hm = ra.import_hip_map(ctx, v, f)
+        truth = T.transform_from_rpy((1.0, -1.5, 1.2), (0.0, 0.0, 0.5))
+        pair = []
+        for mode in (1, 0):
+            rcc = ra.RCCHipSpherical(hm)
+            rcc.setModel(model)
+            rcc.set_micp_fast(mode)
+            pair.append(rcc)
+        for case in range(60):
+            Tsb = T.transform_from_rpy(tuple(rng.uniform(-0.3, 0.3, 3)), tuple(rng.uniform(-0.5, 0.5, 3)))
+            Tbo = T.transform_from_rpy(tuple(rng.uniform(-0.2, 0.2, 3)), tuple(rng.uniform(-0.1, 0.1, 3)))
+            scale = 10.0 ** rng.uniform(-3.0, -0.5)
+            est = T.mult(truth, T.transform_from_rpy(tuple(rng.uniform(-1, 1, 3) * scale), tuple(rng.uniform(-1, 1, 3) * scale * 0.3)))
+            Tom = T.mult(est, T.inv(Tbo))
+            md = float(10.0 ** rng.uniform(-1.3, 0.3))
+            n_iter = int(rng.randint(2, 13))
+            prog = float(rng.uniform(0.0, 1.0))
+            out = []
+            for rcc in pair:
+                rcc.setTsb(Tsb)
+                if case % 7 == 0 or case == 0:
+                    # a fresh measured scan every few cases (taken at the truth through this mount)
+                    rcc.find(T.mult(truth, T.identity()))
+                    rcc.set_dataset_from_ranges(rcc.modelView()["ranges"])
+                rcc.params.max_dist, rcc.adaptive_max_dist_min = md, 0.5 * md
+                out.append(rcc.correct_once(Tom, Tbo, n_iter, prog, False))
+            (Tf, sf), (Tc, sc) = out
+            assert int(sf["n_meas"]) == int(sc["n_meas"]), (mesh, case, md, scale, pair[0].micp_fast_info())
+            _transform_close(Tf, Tc, 1e-6)
+            codes[pair[0].micp_fast_info()["last_code"]] += 1
+        for rcc in pair:
+            rcc.close()
+    assert codes[0] >= 30 and codes[1] >= 5, codes      # all the exits were taken
