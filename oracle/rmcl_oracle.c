@@ -1633,6 +1633,117 @@ int orc_wavesim_ww(const uint32_t* nodes, const uint32_t* tris, const float* O, 
 
 
 /* ------------------------------------------------------------------------- */
+/* block-level model of a work-sharing find: `nw` waves (tiles of 64 rays) run side by side with their own clocks;   */
+/* a wave that has finished takes half of the still-walking rays of the wave that holds the most (state moves with  */
+/* the ray: cur, stack, best hit), at a cost for both.  Analysis only (tools/blocksim.py): what could intra-CU ray    */
+/* stealing win over the static tile -> wave assignment?  costs[]: node iteration with > 16 / <= 16 rays, leaf round  */
+/* with > 16 / <= 16 rays, thief cost, victim cost; min_victim: rays a victim must hold.  out[0] = makespan without,  */
+/* out[1] = with stealing, out[2] = steals.                                                                           */
+/* ------------------------------------------------------------------------- */
+static void bs_init_lane(ws_lane* L, const float* O, const float* D, float tfar)
+{
+  memset(L, 0, sizeof(*L));
+  L->O = v3(O[0], O[1], O[2]); L->D = v3(D[0], D[1], D[2]);
+  L->o[0] = L->O.x; L->o[1] = L->O.y; L->o[2] = L->O.z;
+  L->inv[0] = safe_inv(L->D.x); L->inv[1] = safe_inv(L->D.y); L->inv[2] = safe_inv(L->D.z);
+  L->best_t = tfar; L->best_f = 0xFFFFFFFFu;
+  L->done = !(L->D.x == L->D.x && L->D.y == L->D.y && L->D.z == L->D.z);
+}
+/* one unit of work of a wave: a node iteration if any lane holds an inner node, else a leaf round; returns 0 node, 1 leaf, -1 idle */
+static int bs_unit(ws_lane* L, uint32_t n, const uint32_t* nodes, const uint32_t* tris, float tfar, uint32_t* active_out)
+{
+  uint32_t active = 0; int inner = 0;
+  for (uint32_t i = 0; i < n; ++i) { if (!L[i].done) { active++; inner |= !(L[i].cur & 0x80000000u); } }
+  *active_out = active;
+  if (!active) return -1;
+  if (inner) {
+    for (uint32_t i = 0; i < n; ++i) {
+      ws_lane* l = &L[i];
+      if (l->done || (l->cur & 0x80000000u)) continue;
+      const float* nd = (const float*)(nodes + 32u * l->cur);
+      const uint32_t* ch = nodes + 32u * l->cur + 24u;
+      float key[4]; uint32_t ref[4]; int nh = 0;
+      for (uint32_t c = 0; c < 4; ++c) { float tn, tf; if (ws_box(nd, c, l->o, l->inv, l->best_t, &tn, &tf)) { key[nh] = tn; ref[nh] = ch[c]; nh++; } }
+      for (int a = 0; a < nh; ++a) for (int b = a + 1; b < nh; ++b) if (key[b] < key[a]) { float t = key[a]; key[a] = key[b]; key[b] = t; uint32_t r = ref[a]; ref[a] = ref[b]; ref[b] = r; }
+      for (int a = nh - 1; a >= 1; --a) { if (l->sp < 128) { l->stack[l->sp] = ref[a]; l->stack_t[l->sp] = key[a]; l->sp++; } }
+      if (nh > 0) l->cur = ref[0]; else ws_pop(l, 0);
+    }
+    return 0;
+  }
+  for (uint32_t i = 0; i < n; ++i) {
+    ws_lane* l = &L[i];
+    if (l->done) continue;
+    const uint32_t first = l->cur & 0x0FFFFFFFu, cnt = ((l->cur >> 28) & 7u) + 1u;
+    for (uint32_t k = 0; k < cnt; ++k) {
+      const float* r = (const float*)(tris + 16u * (first + k));
+      orc_tri T;
+      T.v0 = v3(r[0], r[1], r[2]); T.e1 = v3(r[3], r[4], r[5]); T.e2 = v3(r[6], r[7], r[8]);
+      T.Ng = v3(r[9], r[10], r[11]); T.n = v3(r[12], r[13], r[14]);
+      const uint32_t f = tris[16u * (first + k) + 15u];
+      float t;
+      if (tri_intersect(&T, l->O, l->D, 0.0f, tfar, &t)) {
+        if (!l->found || t < l->best_t || (t == l->best_t && f < l->best_f)) { l->best_t = t; l->best_f = f; l->found = 1; }
+      }
+    }
+    ws_pop(l, 0);
+  }
+  return 1;
+}
+int orc_blocksim(const uint32_t* nodes, const uint32_t* tris, const float* O, const float* D, uint32_t nw, float tfar,
+                 const double* costs, uint32_t min_victim, double out[3])
+{
+  if (nw == 0 || nw > 16) return -1;
+  out[0] = out[1] = out[2] = 0.0;
+  for (int pass = 0; pass < 2; ++pass) {
+    ws_lane* L = (ws_lane*)calloc((size_t)nw * 64u, sizeof(ws_lane));
+    uint32_t cnt[16]; double clk[16]; int finished[16];
+    for (uint32_t w = 0; w < nw; ++w) {
+      cnt[w] = 64; clk[w] = 0.0; finished[w] = 0;
+      for (uint32_t i = 0; i < 64; ++i) bs_init_lane(&L[w * 64u + i], O + 3u * (w * 64u + i), D + 3u * (w * 64u + i), tfar);
+    }
+    for (;;) {
+      int w = -1;
+      for (uint32_t k = 0; k < nw; ++k) if (!finished[k] && (w < 0 || clk[k] < clk[w])) w = (int)k;
+      if (w < 0) break;
+      uint32_t active;
+      const int u = bs_unit(&L[(uint32_t)w * 64u], cnt[w], nodes, tris, tfar, &active);
+      if (u >= 0) { clk[w] += (u == 0) ? (active > 16 ? costs[0] : costs[1]) : (active > 16 ? costs[2] : costs[3]); continue; }
+      /* idle: steal (second pass only) */
+      int v = -1; uint32_t vact = 0;
+      if (pass == 1) {
+        for (uint32_t k = 0; k < nw; ++k) {
+          if ((int)k == w || finished[k]) continue;
+          uint32_t a = 0;
+          for (uint32_t i = 0; i < cnt[k]; ++i) a += L[k * 64u + i].done ? 0u : 1u;
+          if (a >= min_victim && a > vact) { vact = a; v = (int)k; }
+        }
+      }
+      if (v < 0) { finished[w] = 1; continue; }
+      /* every other walking ray of the victim moves to the thief */
+      uint32_t moved = 0, seen = 0;
+      for (uint32_t i = 0; i < cnt[v]; ++i) {
+        ws_lane* l = &L[(uint32_t)v * 64u + i];
+        if (l->done) continue;
+        if ((seen++ & 1u) == 0u) continue;
+        L[(uint32_t)w * 64u + moved] = *l;
+        l->done = 1;
+        moved++;
+      }
+      cnt[w] = moved;
+      const double t0 = clk[w] > clk[v] ? clk[w] : clk[v];
+      clk[w] = t0 + costs[4];
+      clk[v] += costs[5];
+      out[2] += 1.0;
+    }
+    double mk = 0.0;
+    for (uint32_t k = 0; k < nw; ++k) if (clk[k] > mk) mk = clk[k];
+    out[pass] = mk;
+    free(L);
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
 /* beam sampling of PCDSensorUpdaterEmbree::update (PCDSensorUpdaterEmbree.cpp:276-327) with the pinned stream:   */
 /* MT19937 (Matsumoto & Nishimura 1998, the algorithm std::mt19937 is specified to be), index = draw % n_points.   */
 /* ------------------------------------------------------------------------- */

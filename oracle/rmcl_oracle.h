@@ -225,6 +225,8 @@ uint32_t orc_mt19937_draw(uint32_t seed, uint32_t n_skip);   /* the (n_skip+1)-t
  * BVH4 arrays; see rmcl_oracle.c */
 int orc_wavesim_ww(const uint32_t* nodes, const uint32_t* tris, const float* O, const float* D, uint32_t nlanes,
                    float tfar, int mode, uint64_t out[7], float* t_out, uint32_t* face_out);
+int orc_blocksim(const uint32_t* nodes, const uint32_t* tris, const float* O, const float* D, uint32_t nw, float tfar,
+                 const double* costs, uint32_t min_victim, double out[3]);
 void orc_wavesim_costs(double n1, double l1, double n2, double l2, double n4, double l4, uint32_t t2, uint32_t t4);
 
 #endif
