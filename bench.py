@@ -65,6 +65,12 @@ def median_kernel_ms(fn, batches=9):
 
 
 def main():
+    # Libraries below us write to stdout on their own (RCCL prints a version banner when its first communicator is created):
+    # everything but the ONE result line goes to stderr -- fd 1 is pointed at fd 2 for the whole run and the JSON line is
+    # written to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -415,7 +421,8 @@ def main():
             "cpu_baseline": cpu,
             "extras": extras,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
