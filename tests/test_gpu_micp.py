@@ -469,3 +469,27 @@ def test_moment_form_randomised_against_per_iteration_form(ra, orc, ctx, meshes)
         for rcc in pair:
             rcc.close()
     assert codes[0] >= 30 and codes[1] >= 5, codes      # all the exits were taken
+
+
+def test_long_loops_stay_within_tolerance(ra, orc, ctx, meshes):
+    """40 iterations with non-trivial frames: the sensor-frame form of the iteration (one product per iteration instead of the
+    reference's frame-by-frame conjugations) and the moment form must not drift away from the oracle's frame-by-frame loop."""
+    from rmcl_amd import synthetic as syn, types as T
+    g = np.load(golden_path("g5_micp_sphere20k.npz"))
+    m, hm, model = _sphere_setup(ra, orc, ctx, meshes)
+    Tsb, Tbo, Tom2 = (g[k].view(T.TRANSFORM)[0] for k in ("Tsb", "Tbo", "Tom2"))
+    meas = m.simulate_spherical(model, Tsb, T.mult(T.identity(), Tbo), bvh=True, nthreads=8)
+    ds, mask = om.dataset_from_ranges(model, meas["ranges"])
+    To, so, _ = om.correct_once(m, model, Tsb, Tbo, Tom2, ds, mask, 40, 1.0, adaptive_min=0.15, convergence_progress=0.3, nthreads=8)
+    for mode in (0, 1):
+        rcc = ra.RCCHipSpherical(hm)
+        rcc.setTsb(Tsb)
+        rcc.setModel(model)
+        rcc.set_dataset(ds, mask)
+        rcc.params.max_dist, rcc.adaptive_max_dist_min = 1.0, 0.15
+        rcc.set_micp_fast(mode)
+        for _ in range(3):
+            Tg, sg = rcc.correct_once(Tom2, Tbo, 40, 0.3, False)
+            _transform_close(Tg, To, 1e-5)
+            assert int(sg["n_meas"]) == int(so["n_meas"])
+        rcc.close()
