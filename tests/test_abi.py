@@ -56,6 +56,13 @@ def test_no_device_is_a_loud_error_not_a_fallback(ra):
     assert b"NO MAP" in L.rmclhip_last_error()
     assert L.rmclhip_pf_create(None, None, C.byref(out)) == ra._capi.ERR_INVALID
     assert L.rmclhip_rcc_find(None, None) == ra._capi.ERR_INVALID
+    # round-2 entry points: null handles / arguments are rejected the same way
+    info = ra._capi.MicpFastInfo()
+    assert L.rmclhip_rcc_set_micp_fast(None, 1) == ra._capi.ERR_INVALID
+    assert L.rmclhip_rcc_micp_fast_info(None, C.byref(info)) == ra._capi.ERR_INVALID
+    assert L.rmclhip_micp_correct_once(None, 0, None, None, None, 1, 0.0, None, None) == ra._capi.ERR_INVALID
+    assert L.rmclhip_comm_create(None, 0, C.byref(out)) == ra._capi.ERR_INVALID
+    assert L.rmclhip_pf_update_sharded(None, None, 0, None) == ra._capi.ERR_INVALID
     assert L.rmclhip_version().startswith(b"rmclhip")
 
 
