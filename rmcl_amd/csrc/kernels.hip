@@ -2128,6 +2128,25 @@ struct MicpFastParams {
   MicpFastStatus* status;       // may be host-mapped
 };
 
+// Status blocks live in pinned host memory and the host polls `code`: every other field is written first, a system-scope fence
+// orders them, `code` goes last -- the host never sees a fresh code next to stale fields, and no late store of this launch can
+// land after the host has started to reuse the block.
+__device__ __forceinline__ void publish_status(MicpFastStatus* dst, const MicpFastStatus& st) {
+  MicpFastStatus body = st;
+  body.code = 0xFFFFFFFFu;          // "pending", what the host wrote before the launch
+  body.pad[2] = 0u;                 // the completion word of the per-iteration chains: not in use during this launch
+  *dst = body;                      // two 16-B stores
+  __threadfence_system();
+  *reinterpret_cast<volatile uint32_t*>(&dst->code) = st.code;
+}
+__device__ __forceinline__ void publish_status(MicpMultiFastStatus* dst, const MicpMultiFastStatus& st) {
+  MicpMultiFastStatus body = st;
+  body.code = 0xFFFFFFFFu;
+  *dst = body;
+  __threadfence_system();
+  *reinterpret_cast<volatile uint32_t*>(&dst->code) = st.code;
+}
+
 __global__ void __launch_bounds__(256) k_micp_moments(const MicpFastParams p) {
   __shared__ double red[4][kMom];
   __shared__ double s_scratch[4][2][64 * 17];
@@ -2346,8 +2365,8 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastP
   if (total > kFastMaxUncertain) {
     if (tid == 0u) {
       MicpFastStatus st;
-      st.code = 2u; st.iter = 0u; st.n_uncertain = total; st.max_rho = 0.f; st.max_tau = 0.f;
-      *p.status = st;
+      st.code = 2u; st.iter = 0u; st.n_uncertain = total; st.max_rho = 0.f; st.max_tau = 0.f; st.pad[0] = st.pad[1] = st.pad[2] = 0u;
+      publish_status(p.status, st);
     }
     return;
   }
@@ -2389,8 +2408,8 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastP
     if (s_flag != 0u) {
       if (tid == 0u) {
         MicpFastStatus st;
-        st.code = 1u; st.iter = it; st.n_uncertain = total; st.max_rho = max_rho; st.max_tau = max_tau;
-        *p.status = st;
+        st.code = 1u; st.iter = it; st.n_uncertain = total; st.max_rho = max_rho; st.max_tau = max_tau; st.pad[0] = st.pad[1] = st.pad[2] = 0u;
+        publish_status(p.status, st);
       }
       return;
     }
@@ -2454,7 +2473,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastP
     st.pad[1] = static_cast<uint32_t>(__builtin_readcyclecounter() - clk1);      // ... and of all iterations
     st.pad[2] = 0u;
     __threadfence_system();
-    *p.status = st;
+    publish_status(p.status, st);
   }
 }
 
@@ -3342,7 +3361,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_multi_fast_loop(const Mic
         MicpMultiFastStatus st;
         st.code = 2u; st.iter = 0u; st.n_uncertain = total + cnt_s; st.sensor = s;
         for (uint32_t q = 0; q < kMaxMicpSensors; ++q) { st.max_rho[q] = 0.f; st.max_tau[q] = 0.f; }
-        *p.status = st;
+        publish_status(p.status, st);
       }
       return;
     }
@@ -3396,7 +3415,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_multi_fast_loop(const Mic
         MicpMultiFastStatus st;
         st.code = 1u; st.iter = it; st.n_uncertain = total; st.sensor = s_flag_sensor;
         for (uint32_t q = 0; q < kMaxMicpSensors; ++q) { st.max_rho[q] = max_rho[q]; st.max_tau[q] = max_tau[q]; }
-        *p.status = st;
+        publish_status(p.status, st);
       }
       return;
     }
@@ -3479,7 +3498,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_multi_fast_loop(const Mic
     st.code = 0u; st.iter = p.n_iter; st.n_uncertain = total; st.sensor = 0u;
     for (uint32_t q = 0; q < kMaxMicpSensors; ++q) { st.max_rho[q] = max_rho[q]; st.max_tau[q] = max_tau[q]; }
     __threadfence_system();
-    *p.status = st;
+    publish_status(p.status, st);
   }
 }
 
