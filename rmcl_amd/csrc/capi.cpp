@@ -1313,8 +1313,6 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
   }
   HIPCHK(hipSetDevice(r0->ctx->device));
   hipStream_t st = r0->stream;
-  // per-call block + state live with the first sensor
-  struct Scratch { MicpMultiCall call; };
   static thread_local MicpMultiCall h_call;
   std::memset(&h_call, 0, sizeof(h_call));
   const xform Tom = to_x(Tom_);
