@@ -972,7 +972,9 @@ static rmclhip_status reduce_enqueue(rmclhip_rcc* r, const xform& Tpre, const xf
 static hipError_t wait_word(volatile const uint32_t* word, uint32_t pending, hipStream_t stream) {
   const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
   for (uint32_t spins = 0; *word == pending; ++spins) {
+#if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
+#endif
     if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() > t_end) return hipStreamSynchronize(stream);
   }
   std::atomic_thread_fence(std::memory_order_acquire);
