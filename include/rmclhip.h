@@ -288,11 +288,16 @@ rmclhip_status rmclhip_rcc_time_reduce(rmclhip_rcc* rcc, const rmclhip_transform
 rmclhip_status rmclhip_rcc_time_correct_once(rmclhip_rcc* rcc, const rmclhip_transform* Tom, const rmclhip_transform* Tbo,
                                              uint32_t n_iter, double convergence_progress, int refind_each_iteration,
                                              uint32_t iters, float* ms_per_call);
-/* kernel variant selection: bits 0..3 traversal (15 = automatic, the default: four lanes per ray
- * up to 65536 rays in flight, one lane per ray with a quad-finished tail up to 262144, one lane per ray on the 64-B
- * quantised nodes above; 0 = wave packet, 1 = one lane per ray, 2 = four lanes per ray, 4 = one lane per ray on
- * quantised nodes, 5 = one lane per ray whose last <= 16 rays per wave are handed to four lanes each; 6 / 7 = 5 with
- * the top 85 / 341 nodes of the tree resident in LDS, 8 = 5 with one-round-trip leaves, 9 / 10 = 8 with the LDS top),
+/* kernel variant selection: bits 0..3 (+ bit 13 = 16 more) traversal kind (15 = automatic, the default:
+ * four lanes per ray up to 65536 rays in flight (kind 2), one lane per ray with a quad-finished tail and the leaf trigger
+ * up to 262144 (kinds 19 / 21), one lane per ray on the 64-B quantised nodes with the leaf trigger above (kind 22);
+ * 0 = wave packet, 1 = one lane per ray, 2 = four lanes per ray, 4 = one lane per ray on quantised nodes, 5 = one lane
+ * per ray whose last <= 16 rays per wave are handed to four lanes each; 6 / 7 = 5 with the top 85 / 341 nodes of the tree
+ * resident in LDS, 8 = 5 with one-round-trip leaves, 9 / 10 = 8 with the LDS top, 11 = round-1 branchy step, 12 = branch-free
+ * step + one-round-trip leaves, 13 / 14 = wave-uniform nodes through the scalar cache, 16 / 17 = branch-free step with the
+ * quad-finished tail (17: + one-round-trip leaves), 18 = learned slow tiles in quad helper blocks, 19 / 20 = 17 with the
+ * leaf trigger -- a wave leaves its node phase once the lanes that wait with a leaf outnumber 1.5 x the lanes still
+ * descending (20: per-triangle leaf loop) --, 21 = 5 and 22 = 4 with the leaf trigger),
  * bits 4..7 = 1 + log2(tile width) of the wave's scan-image tile (0 = automatic, 8x8 for tall images),
  * bit 8 = fused last-block reduction tail (A/B), bit 9 = disable the hipGraph MICP loop (A/B), bits 10..12 = form
  * of the MICP loop (0 = one launch per iteration, the default; 1 = reduce + solve launches; 2..6 = persistent

@@ -743,10 +743,12 @@ static int find_variant(const rmclhip_rcc* r, uint32_t nposes) {
   if (r->variant != 15) return r->variant;
   const uint64_t rays = static_cast<uint64_t>(r->W) * r->H * nposes;
   if (rays <= 65536u) return 2;   // bound by the slowest ray's fetch chain: four lanes per ray
-  if (rays <= 131072u) return 17;  // one scan fills the chip once: one lane per ray (branch-free step, one-round-trip leaves,
-                                  // quad-finished tails).  (The mixed launch, kind 18, measured slower here: A/B only.)
-  if (rays <= 262144u) return 5;  // larger: occupancy matters more than the leaf round trips (kind 17 needs 124 VGPRs)
-  return 4;                       // batches are bound by L1 accesses: one lane per ray on the 64-B quantised nodes
+  // one lane per ray with the LEAF TRIGGER (kernels.hip trace_lane_bf_tail): the node phase of a wave ends as soon as the
+  // lanes that wait with a leaf outnumber 1.5 x the lanes still descending (kinds 19 / 21 / 22 = 17 / 5 / 4 with the trigger:
+  // sphere C2 21.2 -> 19.4 us, room-100k 36.7 -> 27.8 us, 64-pose batches 0.59 -> 0.56 ms)
+  if (rays <= 131072u) return 19;  // one scan fills the chip once: branch-free step, one-round-trip leaves, quad-finished tails
+  if (rays <= 262144u) return 21;  // larger: occupancy matters more than the leaf round trips (the branch-free kinds need 24 LDS rows)
+  return 22;                       // batches are bound by L1 accesses / VALU issue: the 64-B quantised nodes, 16 LDS rows
 }
 
 static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
@@ -1566,7 +1568,7 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
   if (!r || variant < 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: bad arguments");
   // bit 13 adds 16 to the traversal kind (kinds 16..31)
   const int kind = (variant & 0xF) | (((variant >> 13) & 1) << 4), tile = (variant >> 4) & 0xF;
-  if (kind == 3 || kind > 18 || tile > 7 || (variant >> 14) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
+  if (kind == 3 || kind > 22 || tile > 7 || (variant >> 14) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
   r->variant = kind;
   r->tile_override = tile;
   r->fused_tail = ((variant >> 8) & 1) != 0;

@@ -405,7 +405,7 @@ __device__ __forceinline__ void trace_lane(const uint32_t* __restrict__ nodes, c
 // LDS entries (16 KB per block) catch almost every push.
 // ---------------------------------------------------------------------------------------------
 // kQuant: `nodes` points to the quantised Node4Q twins (four loads per node visit instead of seven)
-template <int kLdsEntries, bool kQuant = false, bool kLeafBatch = false>  // stack entries kept in LDS ([entry][lane]); the rest (up to 64 total) in scratch
+template <int kLdsEntries, bool kQuant = false, bool kLeafBatch = false, bool kVote = false>  // stack entries kept in LDS ([entry][lane]); the rest (up to 64 total) in scratch
 __device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris,
                                               f3 O, f3 D, float ray_tfar, uint32_t* __restrict__ lds_stack,
                                               uint32_t lds_stride, RayHit& h) {
@@ -420,7 +420,10 @@ __device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes
 #define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; if (kLdsEntries >= 64 || sp < kLdsEntries) cur = lds_stack[sp * lds_stride]; else cur = priv[sp - kLdsEntries]; } }
   while (__any(cur != kDone)) {
     // phase 1: inner nodes
-    while ((cur != kDone) && !(cur & kLeafBit)) {
+    for (;;) {
+      const bool inner_ = (cur != kDone) && !(cur & kLeafBit);
+      if (!kVote && !inner_) break;
+      if (inner_) {
       uint32_t key[4], ref[4];
       if (kQuant) node_keys_q(nodes, cur, rs, best_t, key, ref);
       else node_keys(nodes, cur, rs, best_t, key, ref);
@@ -434,9 +437,16 @@ __device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes
       if (key[1] != kNone) RMCL_PUSH(ref[1])
       if (key[0] != kNone) cur = ref[0];
       else RMCL_POP()
+      }
+      if (kVote) {
+        const uint32_t n_in = static_cast<uint32_t>(__popcll(__ballot((cur != kDone) && !(cur & kLeafBit))));
+        if (n_in == 0u) break;
+        const uint32_t n_lf = static_cast<uint32_t>(__popcll(__ballot((cur != kDone) && (cur & kLeafBit))));
+        if (2u * n_lf >= 3u * n_in) break;
+      }
     }
     // phase 2: this lane's leaf (if any)
-    if (cur != kDone) {
+    if ((cur != kDone) && (cur & kLeafBit)) {
       if (kLeafBatch) leaf_batch(tris, cur, O, D, ray_tfar, best_t, best_rec);
       else leaf_loop(tris, cur, O, D, ray_tfar, best_t, best_rec);
       RMCL_POP()
@@ -735,7 +745,7 @@ __device__ __forceinline__ void trace_quad(const uint32_t* __restrict__ nodes, c
 constexpr uint32_t kTailRays = 16;
 constexpr uint32_t kTailXferDwords = 12;
 
-template <int kLdsEntries, int kTop = 0, bool kLeafBatch = false>
+template <int kLdsEntries, int kTop = 0, bool kLeafBatch = false, bool kVote = false>
 __device__ __forceinline__ void trace_lane_ww_tail(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ cnodes,
                                                    const uint32_t* __restrict__ tris, f3 O, f3 D, float ray_tfar,
                                                    uint32_t* __restrict__ lds_stack, uint32_t lds_stride,
@@ -795,19 +805,29 @@ __device__ __forceinline__ void trace_lane_ww_tail(const uint32_t* __restrict__ 
       }
       break;
     }
-    // phase 1: inner nodes
-    while ((cur != kDone) && !(cur & kLeafBit)) {
-      uint32_t key[4], ref[4];
-      node_keys_at(node_address<kTop>(nodes, lds_top, cur), rs, best_t, key, ref);
-      RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
-      if (key[3] != kNone) RMCL_PUSH(ref[3])
-      if (key[2] != kNone) RMCL_PUSH(ref[2])
-      if (key[1] != kNone) RMCL_PUSH(ref[1])
-      if (key[0] != kNone) cur = ref[0];
-      else RMCL_POP()
+    // phase 1: inner nodes (kVote: left early by the leaf trigger of trace_lane_bf_tail)
+    for (;;) {
+      const bool inner = (cur != kDone) && !(cur & kLeafBit);
+      if (!kVote && !inner) break;
+      if (inner) {
+        uint32_t key[4], ref[4];
+        node_keys_at(node_address<kTop>(nodes, lds_top, cur), rs, best_t, key, ref);
+        RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
+        if (key[3] != kNone) RMCL_PUSH(ref[3])
+        if (key[2] != kNone) RMCL_PUSH(ref[2])
+        if (key[1] != kNone) RMCL_PUSH(ref[1])
+        if (key[0] != kNone) cur = ref[0];
+        else RMCL_POP()
+      }
+      if (kVote) {
+        const uint32_t n_in = static_cast<uint32_t>(__popcll(__ballot((cur != kDone) && !(cur & kLeafBit))));
+        if (n_in == 0u) break;
+        const uint32_t n_lf = static_cast<uint32_t>(__popcll(__ballot((cur != kDone) && (cur & kLeafBit))));
+        if (2u * n_lf >= 3u * n_in) break;
+      }
     }
     // phase 2: this lane's leaf (if any)
-    if (cur != kDone) {
+    if ((cur != kDone) && (cur & kLeafBit)) {
       if (kLeafBatch) leaf_batch(tris, cur, O, D, ray_tfar, best_t, best_rec);
       else leaf_loop(tris, cur, O, D, ray_tfar, best_t, best_rec);
       RMCL_POP()
@@ -822,7 +842,7 @@ __device__ __forceinline__ void trace_lane_ww_tail(const uint32_t* __restrict__ 
 // trace_lane_bf whose LAST rays are finished by quads (see trace_lane_ww_tail): branch-free node steps and one-round-trip
 // leaves while more than kTailRays rays of the wave are walking, then each remaining ray gets four lanes.
 // LDS: lane stacks (kRows x 256) | quad-tail stacks (64 columns x kQuadStackEntries rows) | hand-over slots.
-template <int kRows, bool kLeafBatch>
+template <int kRows, bool kLeafBatch, int kLeafTrigger = 0>
 __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ cnodes,
                                                    const uint32_t* __restrict__ tris, f3 O, f3 D, float ray_tfar,
                                                    uint32_t* __restrict__ lds_col, uint32_t* __restrict__ qstack,
@@ -880,32 +900,56 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
       }
       break;
     }
-    // phase 1: inner nodes
-    while (cur < kDone) {
-      uint32_t key[4], ref[4];
-      ++nvis;
-      if (!__any(sp + 3u > static_cast<uint32_t>(kRows))) {
-        const uint32_t top = lds_col[(sp - 1u) * kBfStride];
-        node_keys_off(nodes, cur << 7, rs, best_t, key, ref);
-        RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
-        lds_col[sp * kBfStride] = ref[3]; sp += (key[3] != kNone) ? 1u : 0u;
-        lds_col[sp * kBfStride] = ref[2]; sp += (key[2] != kNone) ? 1u : 0u;
-        lds_col[sp * kBfStride] = ref[1]; sp += (key[1] != kNone) ? 1u : 0u;
-        const bool any = key[0] != kNone;
-        cur = any ? ref[0] : top;
-        sp = any ? sp : (sp - 1u);
-      } else {
-        node_keys_off(nodes, cur << 7, rs, best_t, key, ref);
-        RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
-        if (key[3] != kNone) { RMCL_ROW_ST(sp, ref[3]) ++sp; }
-        if (key[2] != kNone) { RMCL_ROW_ST(sp, ref[2]) ++sp; }
-        if (key[1] != kNone) { RMCL_ROW_ST(sp, ref[1]) ++sp; }
-        if (key[0] != kNone) cur = ref[0];
-        else { --sp; cur = RMCL_ROW_LD(sp); }
-      }
+    // phase 1: inner nodes.  kLeafTrigger > 0: the phase is also left as soon as that many lanes hold a leaf -- they would
+    // otherwise idle through the descents of the others (the wave model: 65 -> 45 node iterations for the slowest tile of
+    // the room, 32 -> 26 on the sphere, for one or two more leaf rounds); the stragglers resume in the next round.
+#define RMCL_BF_STEP                                                                                         \
+    {                                                                                                        \
+      uint32_t key[4], ref[4];                                                                               \
+      ++nvis;                                                                                                \
+      if (!__any(sp + 3u > static_cast<uint32_t>(kRows))) {                                                  \
+        const uint32_t top = lds_col[(sp - 1u) * kBfStride];                                                 \
+        node_keys_off(nodes, cur << 7, rs, best_t, key, ref);                                                \
+        RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)                 \
+        lds_col[sp * kBfStride] = ref[3]; sp += (key[3] != kNone) ? 1u : 0u;                                 \
+        lds_col[sp * kBfStride] = ref[2]; sp += (key[2] != kNone) ? 1u : 0u;                                 \
+        lds_col[sp * kBfStride] = ref[1]; sp += (key[1] != kNone) ? 1u : 0u;                                 \
+        const bool any = key[0] != kNone;                                                                    \
+        cur = any ? ref[0] : top;                                                                            \
+        sp = any ? sp : (sp - 1u);                                                                           \
+      } else {                                                                                               \
+        node_keys_off(nodes, cur << 7, rs, best_t, key, ref);                                                \
+        RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)                 \
+        if (key[3] != kNone) { RMCL_ROW_ST(sp, ref[3]) ++sp; }                                               \
+        if (key[2] != kNone) { RMCL_ROW_ST(sp, ref[2]) ++sp; }                                               \
+        if (key[1] != kNone) { RMCL_ROW_ST(sp, ref[1]) ++sp; }                                               \
+        if (key[0] != kNone) cur = ref[0];                                                                   \
+        else { --sp; cur = RMCL_ROW_LD(sp); }                                                                \
+      }                                                                                                      \
     }
-    // phase 2: this lane's leaf (if any)
-    if (cur != kDone) {
+    if constexpr (kLeafTrigger > 0) {
+      // at least one node step per round (a lane that keeps popping leaves must not starve the descending ones), then the vote:
+      // kLeafTrigger == 1 alternates node step and leaf round
+      for (;;) {
+        const bool inner = cur < kDone;
+        if (inner) RMCL_BF_STEP
+        const uint32_t n_in = static_cast<uint32_t>(__popcll(__ballot(cur < kDone)));
+        if (n_in == 0) break;
+        const uint32_t n_lf = static_cast<uint32_t>(__popcll(__ballot(cur > kDone)));
+        if (kLeafTrigger == 101) { if (n_lf >= n_in) break; }
+        else if (kLeafTrigger == 102) { if (2u * n_lf >= 3u * n_in) break; }
+        else if (kLeafTrigger == 103) { if (n_lf >= n_in || n_lf >= 20u) break; }
+        else if (kLeafTrigger == 104) { if (n_lf >= 2u * n_in) break; }
+        else if (kLeafTrigger == 105) { if (2u * n_lf >= 3u * n_in && n_lf >= 4u) break; }
+        else if (kLeafTrigger == 106) { if (4u * n_lf >= 5u * n_in) break; }
+        else if (n_lf >= static_cast<uint32_t>(kLeafTrigger)) break;
+      }
+    } else {
+      while (cur < kDone) RMCL_BF_STEP
+    }
+#undef RMCL_BF_STEP
+    // phase 2: this lane's leaf (if any; with a leaf trigger other lanes may still hold an inner node)
+    if (cur > kDone) {
       if (kLeafBatch) leaf_batch(tris, cur, O, D, ray_tfar, best_t, best_rec);
       else leaf_loop(tris, cur, O, D, ray_tfar, best_t, best_rec);
       --sp;
@@ -1186,6 +1230,9 @@ constexpr bool find_leaf_batch(int trav) { return trav >= 8 && trav <= 10; }
 constexpr int kFindBfRows = 24;  // LDS stack rows per lane (sentinel included) of the branch-free lane traversal in k_find
 constexpr uint32_t kFindTailLdsDwords = 16u * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords;
 
+// kinds 19..22: kind 17 + leaving the node phase when 32 / 24 / 16 / 8 lanes hold a leaf
+constexpr int find_leaf_trigger(int trav) { return (trav == 19 || trav == 20) ? 102 : 0; }
+
 template <uint32_t kModel, int kTrav>
 __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   extern __shared__ uint32_t lds_dyn[];
@@ -1312,10 +1359,16 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
     // kind 4 serves launches that fill the chip (pose batches): throughput, not the slowest wave's chain, is what counts there, and
     // the branchy step with its partial sort and 16 LDS rows (more resident waves) is 11 % faster than the branch-free one
     if (kTrav == 4) trace_lane_ww<16, true>(p.qnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
+    else if (kTrav == 22) trace_lane_ww<16, true, false, true>(p.qnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
+    else if (kTrav == 21)
+      trace_lane_ww_tail<16, 0, false, true>(
+          p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, lds_dyn + 16u * 256u,
+          lds_dyn + 16u * 256u + kQuadStackEntries * 64u + (threadIdx.x >> 6) * (kTailRays * kTailXferDwords), h,
+          lds_dyn + kFindTailLdsDwords);
     else if (kTrav == 1) trace_lane_bf<kFindBfRows>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
     else if (kTrav == 12) trace_lane_bf<kFindBfRows, false, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
-    else if (kTrav == 16 || kTrav == 17)
-      trace_lane_bf_tail<kFindBfRows, kTrav == 17>(p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x,
+    else if (kTrav == 16 || kTrav == 17 || kTrav == 19 || kTrav == 20)
+      trace_lane_bf_tail<kFindBfRows, kTrav != 16 && kTrav != 20, find_leaf_trigger(kTrav)>(p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x,
                                                    lds_dyn + kFindBfRows * 256u,
                                                    lds_dyn + kFindBfRows * 256u + kQuadStackEntries * 64u + (threadIdx.x >> 6) * (kTailRays * kTailXferDwords), h);
     else if (kTrav == 13) trace_lane_bf<kFindBfRows, false, false, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
@@ -3221,6 +3274,17 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
     if (p.tile_flags == nullptr || p.nposes != 1u) return hipErrorInvalidValue;
     grid = dim3(2u * nblocks, 1, 1);
     RMCL_LAUNCH_FIND(18, lds)
+  } else if (variant >= 19 && variant <= 22) {  // kind 17 with a leaf trigger (find_leaf_trigger)
+    const size_t lds = (static_cast<size_t>(kFindBfRows) * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords) * sizeof(uint32_t);
+    if (variant == 19) { RMCL_LAUNCH_FIND(19, lds) }
+    else if (variant == 20) { RMCL_LAUNCH_FIND(20, lds) }
+    else if (variant == 21) {   // kind 5 with the leaf trigger
+      const size_t lds5 = kFindTailLdsDwords * sizeof(uint32_t);
+      RMCL_LAUNCH_FIND(21, lds5)
+    } else {                    // kind 4 with the leaf trigger
+      const size_t lds4 = 16u * 256u * sizeof(uint32_t);
+      RMCL_LAUNCH_FIND(22, lds4)
+    }
   } else if (variant == 16 || variant == 17) {  // branch-free step (17: + one-round-trip leaves), tail of every wave finished by quads
     const size_t lds = (static_cast<size_t>(kFindBfRows) * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords) * sizeof(uint32_t);
     if (variant == 16) { RMCL_LAUNCH_FIND(16, lds) } else { RMCL_LAUNCH_FIND(17, lds) }

@@ -33,7 +33,7 @@ def _poses(syn, T):
     ]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6, 8, 10, 11, 12, 13, 14, 16, 17, 18])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6, 8, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 22])
 def test_c1_cube_32x32(ra, orc, ctx, meshes, variant):
     """config C1: 32x32 scan, 972-triangle cube, every output attribute, 3 poses, Tsb != I."""
     from rmcl_amd import synthetic as syn, types as T
@@ -73,7 +73,7 @@ def test_c1_matches_committed_golden(ra, ctx, meshes):
         _compare(gpu, ref, "golden pose %d" % i)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 7, 8, 9, 11, 12, 13, 14, 16, 17, 18])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 7, 8, 9, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 22])
 def test_c2_sphere100k_full_size(ra, orc, ctx, meshes, variant):
     """config C2 at BASELINE.json's full size: 128x1024 rays, 100k triangles; oracle BVH on all rays,
     brute force on a sample, and the committed SHA-256 of the face-id array (G7)."""
@@ -259,7 +259,7 @@ def test_c5_mesh_one_million_triangles(ra, orc, ctx):
 ROOM_POSE_RPY = ((1.5, -2.0, 1.6), (0.02, -0.03, 0.4))   # the pose of tests/golden/make_golden.py:g7_digests
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6, 10, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
 def test_c2_room100k_full_size(ra, orc, ctx, meshes, variant):
     """config C2's scan on a REALISTIC map (room-100k: occluders, vertex noise, open ceiling => misses): every
     traversal incl. the automatic one (15) vs the oracle on all 131 072 rays + the committed G7 digests
@@ -350,8 +350,9 @@ def test_o1dn_c2_size_pose_batch(ra, orc, ctx, meshes):
 @pytest.mark.parametrize("mesh", ["sphere100k", "room100k"])
 def test_automatic_variant_in_every_size_bracket(ra, orc, ctx, meshes, mesh):
     """variant 15 (the default) picks a different traversal per rays-in-flight bracket (capi.cpp:find_variant):
-    <= 65 536 four lanes per ray, <= 262 144 one lane per ray with the tail of every wave finished by quads,
-    larger: one lane per ray on the quantised nodes.  Each bracket is run explicitly with variant 15."""
+    <= 65 536 four lanes per ray (kind 2), <= 131 072 / 262 144 one lane per ray with the tail of every wave finished by
+    quads and the leaf trigger (kinds 19 / 21), larger: one lane per ray on the quantised nodes with the leaf trigger
+    (kind 22).  Each bracket is run explicitly with variant 15."""
     from rmcl_amd import synthetic as syn, types as T
     v, f = meshes(mesh)
     m = orc.Mesh(v, f)
@@ -368,6 +369,8 @@ def test_automatic_variant_in_every_size_bracket(ra, orc, ctx, meshes, mesh):
         rcc.set_variant(15)
         rcc.setTsb(T.identity())
         rcc.setModel(model)
+        rays = H * W * nposes
+        assert rcc.find_variant(nposes) == (2 if rays <= 65536 else 19 if rays <= 131072 else 21 if rays <= 262144 else 22)
         if nposes == 1:
             rcc.find(poses[0])
         else:

@@ -48,7 +48,7 @@ def test_find_all_traversals_vs_brute_force(ra, orc, ctx, case):
     Tsb = syn.tsb_offset()
     ref = m.simulate_spherical(model, Tsb, pose, bvh=False)          # brute force over all triangles
     assert 100 < int(ref["hits"].sum()) < 1024, int(ref["hits"].sum())   # hits and misses
-    for variant in (0, 1, 2, 4, 5, 7, 9, 11, 12, 13, 14, 16, 17, 18):
+    for variant in (0, 1, 2, 4, 5, 7, 9, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 22):
         rcc = ra.RCCHipSpherical(hm)
         rcc.set_traversal(variant)
         rcc.setTsb(Tsb)

@@ -22,7 +22,8 @@ def avg(db, kernel_like, counter):
 def main(d, out):
     res = {}
     # key = the kernel as bench.py names it (traversal kind of k_find), like = its demangled template arguments
-    specs = (("k_find_kind17", "%k_find<1u, 17>%", "find_v15", False), ("k_find_kind1", "%k_find<1u, 1>%", "find_v1", False),
+    specs = (("k_find_kind19", "%k_find<1u, 19>%", "find_v15", False), ("k_find_kind17", "%k_find<1u, 17>%", "find_v17", False),
+             ("k_find_kind1", "%k_find<1u, 1>%", "find_v1", False),
              ("k_find_kind2", "%k_find<1u, 2>%", "find_v2", False), ("k_pf_update", "%k_pf_update%", "pf", False),
              ("k_micp_iter", "%k_micp_iter%", "red", True), ("k_reduce_partials", "%k_reduce_partials%", "red", True))
     for key, like, pre, wide in specs:
@@ -39,6 +40,12 @@ def main(d, out):
                     "fetch_correction": 2.0 if wide else 1.0,
                     "hbm_bytes_per_launch": round(fb * (2.0 if wide else 1.0) + wb),
                     "hbm_bytes_per_launch_upper_bound_x2_fetch": round(2 * fb + wb), "dispatches": [nf, nw]}
+    try:   # keys that were not re-measured in this run keep their previous entry
+        old = json.load(open(out))
+    except Exception:
+        old = {}
+    old.update(res)
+    res = old
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1, sort_keys=True)
     print(json.dumps(res, indent=1))
