@@ -418,12 +418,12 @@ __device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes
   uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
 #define RMCL_PUSH(v) { if (kLdsEntries >= 64 || sp < kLdsEntries) lds_stack[sp * lds_stride] = (v); else priv[sp - kLdsEntries] = (v); ++sp; }
 #define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; if (kLdsEntries >= 64 || sp < kLdsEntries) cur = lds_stack[sp * lds_stride]; else cur = priv[sp - kLdsEntries]; } }
-  while (__any(cur != kDone)) {
-    // phase 1: inner nodes
-    for (;;) {
-      const bool inner_ = (cur != kDone) && !(cur & kLeafBit);
-      if (!kVote && !inner_) break;
-      if (inner_) {
+  for (;;) {
+    const uint64_t m_act = __ballot(cur != kDone);
+    if (m_act == 0) break;
+    const uint32_t na = static_cast<uint32_t>(__popcll(m_act));   // rays alive at the start of this round
+    // phase 1: inner nodes (kVote: the leaf trigger, see trace_lane_bf_tail)
+    while ((cur != kDone) && !(cur & kLeafBit)) {
       uint32_t key[4], ref[4];
       if (kQuant) node_keys_q(nodes, cur, rs, best_t, key, ref);
       else node_keys(nodes, cur, rs, best_t, key, ref);
@@ -437,12 +437,8 @@ __device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes
       if (key[1] != kNone) RMCL_PUSH(ref[1])
       if (key[0] != kNone) cur = ref[0];
       else RMCL_POP()
-      }
       if (kVote) {
-        const uint32_t n_in = static_cast<uint32_t>(__popcll(__ballot((cur != kDone) && !(cur & kLeafBit))));
-        if (n_in == 0u) break;
-        const uint32_t n_lf = static_cast<uint32_t>(__popcll(__ballot((cur != kDone) && (cur & kLeafBit))));
-        if (2u * n_lf >= 3u * n_in) break;
+        if (5u * static_cast<uint32_t>(__popcll(__ballot((cur != kDone) && !(cur & kLeafBit)))) <= 2u * na) break;
       }
     }
     // phase 2: this lane's leaf (if any)
@@ -805,25 +801,18 @@ __device__ __forceinline__ void trace_lane_ww_tail(const uint32_t* __restrict__ 
       }
       break;
     }
-    // phase 1: inner nodes (kVote: left early by the leaf trigger of trace_lane_bf_tail)
-    for (;;) {
-      const bool inner = (cur != kDone) && !(cur & kLeafBit);
-      if (!kVote && !inner) break;
-      if (inner) {
-        uint32_t key[4], ref[4];
-        node_keys_at(node_address<kTop>(nodes, lds_top, cur), rs, best_t, key, ref);
-        RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
-        if (key[3] != kNone) RMCL_PUSH(ref[3])
-        if (key[2] != kNone) RMCL_PUSH(ref[2])
-        if (key[1] != kNone) RMCL_PUSH(ref[1])
-        if (key[0] != kNone) cur = ref[0];
-        else RMCL_POP()
-      }
+    // phase 1: inner nodes (kVote: left early by the leaf trigger of trace_lane_bf_tail; `na` = rays alive in this round)
+    while ((cur != kDone) && !(cur & kLeafBit)) {
+      uint32_t key[4], ref[4];
+      node_keys_at(node_address<kTop>(nodes, lds_top, cur), rs, best_t, key, ref);
+      RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
+      if (key[3] != kNone) RMCL_PUSH(ref[3])
+      if (key[2] != kNone) RMCL_PUSH(ref[2])
+      if (key[1] != kNone) RMCL_PUSH(ref[1])
+      if (key[0] != kNone) cur = ref[0];
+      else RMCL_POP()
       if (kVote) {
-        const uint32_t n_in = static_cast<uint32_t>(__popcll(__ballot((cur != kDone) && !(cur & kLeafBit))));
-        if (n_in == 0u) break;
-        const uint32_t n_lf = static_cast<uint32_t>(__popcll(__ballot((cur != kDone) && (cur & kLeafBit))));
-        if (2u * n_lf >= 3u * n_in) break;
+        if (5u * static_cast<uint32_t>(__popcll(__ballot((cur != kDone) && !(cur & kLeafBit)))) <= 2u * na) break;
       }
     }
     // phase 2: this lane's leaf (if any)
@@ -928,21 +917,13 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
       }                                                                                                      \
     }
     if constexpr (kLeafTrigger > 0) {
-      // at least one node step per round (a lane that keeps popping leaves must not starve the descending ones), then the vote:
-      // kLeafTrigger == 1 alternates node step and leaf round
-      for (;;) {
-        const bool inner = cur < kDone;
-        if (inner) RMCL_BF_STEP
-        const uint32_t n_in = static_cast<uint32_t>(__popcll(__ballot(cur < kDone)));
-        if (n_in == 0) break;
-        const uint32_t n_lf = static_cast<uint32_t>(__popcll(__ballot(cur > kDone)));
-        if (kLeafTrigger == 101) { if (n_lf >= n_in) break; }
-        else if (kLeafTrigger == 102) { if (2u * n_lf >= 3u * n_in) break; }
-        else if (kLeafTrigger == 103) { if (n_lf >= n_in || n_lf >= 20u) break; }
-        else if (kLeafTrigger == 104) { if (n_lf >= 2u * n_in) break; }
-        else if (kLeafTrigger == 105) { if (2u * n_lf >= 3u * n_in && n_lf >= 4u) break; }
-        else if (kLeafTrigger == 106) { if (4u * n_lf >= 5u * n_in) break; }
-        else if (n_lf >= static_cast<uint32_t>(kLeafTrigger)) break;
+      // The loop stays the divergent per-lane while loop; the vote only needs the number of lanes still in it (the ballot of
+      // a divergent loop counts exactly those) against `na`, the rays alive when the round began: waiting >= 1.5 x descending
+      // <=> 5 x descending <= 2 x alive.  Checked after the step, so every round makes progress (a lane that keeps popping
+      // leaves cannot starve the descending ones).
+      while (cur < kDone) {
+        RMCL_BF_STEP
+        if (static_cast<uint32_t>(kLeafTrigger) * static_cast<uint32_t>(__popcll(__ballot(cur < kDone))) <= 4u * na) break;
       }
     } else {
       while (cur < kDone) RMCL_BF_STEP
@@ -1231,7 +1212,7 @@ constexpr int kFindBfRows = 24;  // LDS stack rows per lane (sentinel included) 
 constexpr uint32_t kFindTailLdsDwords = 16u * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords;
 
 // kinds 19..22: kind 17 + leaving the node phase when 32 / 24 / 16 / 8 lanes hold a leaf
-constexpr int find_leaf_trigger(int trav) { return (trav == 19 || trav == 20) ? 102 : 0; }
+constexpr int find_leaf_trigger(int trav) { return (trav == 19 || trav == 20) ? 10 : 0; }   // leave at <= 4/10 of the round's rays
 
 template <uint32_t kModel, int kTrav>
 __global__ void __launch_bounds__(256) k_find(const FindParams p) {
@@ -3274,7 +3255,7 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
     if (p.tile_flags == nullptr || p.nposes != 1u) return hipErrorInvalidValue;
     grid = dim3(2u * nblocks, 1, 1);
     RMCL_LAUNCH_FIND(18, lds)
-  } else if (variant >= 19 && variant <= 22) {  // kind 17 with a leaf trigger (find_leaf_trigger)
+  } else if (variant >= 19 && variant <= 22) {  // kinds 17 / 5 / 4 with the leaf trigger
     const size_t lds = (static_cast<size_t>(kFindBfRows) * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords) * sizeof(uint32_t);
     if (variant == 19) { RMCL_LAUNCH_FIND(19, lds) }
     else if (variant == 20) { RMCL_LAUNCH_FIND(20, lds) }
