@@ -1559,6 +1559,8 @@ int orc_wavesim_ww(const uint32_t* nodes, const uint32_t* tris, const float* O, 
     /* phase 1: node iterations while any lane holds an inner node (policy, mode bits 8..15 = T > 0: the phase is also
      * left as soon as at least T lanes hold a leaf) */
     const uint32_t leaf_trigger = ((uint32_t)mode >> 8) & 0xFFu;
+    uint32_t steps_this_round = 0;
+    const uint32_t alive_at_round_start = walking;
     for (;;) {
       int inner = 0; uint32_t holding = 0;
       /* mode 0x20000, "speculative while-while" (Aila & Laine 2009): a lane that arrives at a leaf parks it (one slot)
@@ -1574,6 +1576,14 @@ int orc_wavesim_ww(const uint32_t* nodes, const uint32_t* tris, const float* O, 
       }
       if (!inner) break;
       if (leaf_trigger && holding >= leaf_trigger) break;
+      /* mode 0x40000: the product's leaf trigger (kernels.hip trace_lane_bf_tail): after at least one step of the round,
+       * leave when the descending lanes are <= 40 % of the rays alive at the start of the round */
+      if ((mode & 0x40000) && steps_this_round > 0) {
+        uint32_t n_in = 0;
+        for (uint32_t i = 0; i < nlanes; ++i) n_in += (!L[i].done && !(L[i].cur & 0x80000000u)) ? 1u : 0u;
+        if (5u * n_in <= 2u * alive_at_round_start) break;
+      }
+      steps_this_round++;
       out[0]++;
       est += cn;
       for (uint32_t i = 0; i < nlanes; ++i) {
