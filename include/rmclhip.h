@@ -289,7 +289,7 @@ rmclhip_status rmclhip_rcc_time_correct_once(rmclhip_rcc* rcc, const rmclhip_tra
                                              uint32_t n_iter, double convergence_progress, int refind_each_iteration,
                                              uint32_t iters, float* ms_per_call);
 /* kernel variant selection: bits 0..3 (+ bit 13 = 16 more) traversal kind (15 = automatic, the default:
- * four lanes per ray up to 65536 rays in flight (kind 2), one lane per ray with a quad-finished tail and the leaf trigger
+ * four lanes per ray up to 57344 rays in flight (kind 2), one lane per ray with a quad-finished tail and the leaf trigger
  * up to 262144 (kinds 19 / 21), one lane per ray on the 64-B quantised nodes with the leaf trigger above (kind 22);
  * 0 = wave packet, 1 = one lane per ray, 2 = four lanes per ray, 4 = one lane per ray on quantised nodes, 5 = one lane
  * per ray whose last <= 16 rays per wave are handed to four lanes each; 6 / 7 = 5 with the top 85 / 341 nodes of the tree

@@ -742,7 +742,8 @@ static rmclhip_status ensure_model_buffers(rmclhip_rcc* r, size_t n_total) {
 static int find_variant(const rmclhip_rcc* r, uint32_t nposes) {
   if (r->variant != 15) return r->variant;
   const uint64_t rays = static_cast<uint64_t>(r->W) * r->H * nposes;
-  if (rays <= 65536u) return 2;   // bound by the slowest ray's fetch chain: four lanes per ray
+  if (rays <= 57344u) return 2;   // bound by the slowest ray's fetch chain: four lanes per ray (crossover measured between
+                                  // 49152 rays -- quads 13.6 / 20.8 us vs 16.4 / 23.4 -- and 65536 -- 15.9 / 26.3 vs 16.3 / 23.7)
   // one lane per ray with the LEAF TRIGGER (kernels.hip trace_lane_bf_tail): the node phase of a wave ends as soon as the
   // lanes that wait with a leaf outnumber 1.5 x the lanes still descending (kinds 19 / 21 / 22 = 17 / 5 / 4 with the trigger:
   // sphere C2 21.2 -> 19.4 us, room-100k 36.7 -> 27.8 us, 64-pose batches 0.59 -> 0.56 ms)

@@ -350,7 +350,7 @@ def test_o1dn_c2_size_pose_batch(ra, orc, ctx, meshes):
 @pytest.mark.parametrize("mesh", ["sphere100k", "room100k"])
 def test_automatic_variant_in_every_size_bracket(ra, orc, ctx, meshes, mesh):
     """variant 15 (the default) picks a different traversal per rays-in-flight bracket (capi.cpp:find_variant):
-    <= 65 536 four lanes per ray (kind 2), <= 131 072 / 262 144 one lane per ray with the tail of every wave finished by
+    <= 57 344 four lanes per ray (kind 2), <= 131 072 / 262 144 one lane per ray with the tail of every wave finished by
     quads and the leaf trigger (kinds 19 / 21), larger: one lane per ray on the quantised nodes with the leaf trigger
     (kind 22).  Each bracket is run explicitly with variant 15."""
     from rmcl_amd import synthetic as syn, types as T
@@ -370,7 +370,7 @@ def test_automatic_variant_in_every_size_bracket(ra, orc, ctx, meshes, mesh):
         rcc.setTsb(T.identity())
         rcc.setModel(model)
         rays = H * W * nposes
-        assert rcc.find_variant(nposes) == (2 if rays <= 65536 else 19 if rays <= 131072 else 21 if rays <= 262144 else 22)
+        assert rcc.find_variant(nposes) == (2 if rays <= 57344 else 19 if rays <= 131072 else 21 if rays <= 262144 else 22)
         if nposes == 1:
             rcc.find(poses[0])
         else:
