@@ -177,6 +177,15 @@ rmclhip_status rmclhip_bvh_build_host(const float* vertices_xyz, uint32_t n_vert
 rmclhip_status rmclhip_bvh_build_host_quantised(const float* vertices_xyz, uint32_t n_vertices, const uint32_t* faces_ijk,
                                                 uint32_t n_faces, uint32_t* qnodes_out, size_t qnodes_capacity_dwords);
 
+/* the particle filter's own tree of the same map: the builder splits ONE BVH2 down to leaves of <= 2 triangles; the map's
+ * tree (leaves <= 4, rmclhip_bvh_build_host) and this one are two cuts through it and share the leaf-ordered record
+ * array.  nodes_out: Node4 (32 dwords each), qnodes_out: Node4Q (16 dwords each, what k_pf_update_* reads); either may be
+ * null; info->n_nodes / max_depth / stack_need describe THIS tree.  Replaces nothing in the reference (Embree / OptiX
+ * build their own acceleration structures, PCDSensorUpdaterEmbree.cpp:158, PCDSensorUpdaterOptix.cpp:123-154). */
+rmclhip_status rmclhip_bvh_build_host_pf(const float* vertices_xyz, uint32_t n_vertices, const uint32_t* faces_ijk,
+                                         uint32_t n_faces, rmclhip_map_info* info, uint32_t* nodes_out,
+                                         size_t nodes_cap_dwords, uint32_t* qnodes_out, size_t qnodes_cap_dwords);
+
 /* ---- ray-casting correspondences (MICP-L) ------------------------------------------
  * rmcl::RCCEmbreeSpherical / RCCEmbreeO1Dn / RCCOptixSpherical
  * (rmcl/include/rmcl/registration/RCCEmbree.hpp:18-83, RCCOptix.hpp:18-93) on top of

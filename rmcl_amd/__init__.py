@@ -10,7 +10,7 @@ from . import pf  # noqa: F401
 from .pf import (GladiatorResamplerHip, PCDSensorUpdaterHip, ShardedParticleFilterHip, TFMotionUpdaterHip,  # noqa: F401
                  beams_from_points, combined_forget_rate, sample_beams)
 from .registration import (CPCHip, Context, CorrespondencesHIP, DeviceArray, HipMap, MapMap, RCCHipO1Dn,  # noqa: F401
-                           RCCHipOnDn, RCCHipPinhole, RCCHipSpherical, build_bvh_host, build_bvh_host_quantised,
+                           RCCHipOnDn, RCCHipPinhole, RCCHipSpherical, build_bvh_host, build_bvh_host_pf, build_bvh_host_quantised,
                            import_hip_map)
 
 __version__ = "0.1.0"

@@ -101,6 +101,7 @@ SIGNATURES = {
     "rmclhip_map_get_info": (_i32, [_vp, C.POINTER(MapInfo)]),
     "rmclhip_bvh_build_host": (_i32, [_vp, _u32, _vp, _u32, C.POINTER(MapInfo), _vp, _sz, _vp, _sz]),
     "rmclhip_bvh_build_host_quantised": (_i32, [_vp, _u32, _vp, _u32, _vp, _sz]),
+    "rmclhip_bvh_build_host_pf": (_i32, [_vp, _u32, _vp, _u32, C.POINTER(MapInfo), _vp, _sz, _vp, _sz]),
     "rmclhip_rcc_create": (_i32, [_vp, _vp, _pp]),
     "rmclhip_rcc_destroy": (None, [_vp]),
     "rmclhip_rcc_set_tsb": (_i32, [_vp, _vp]),

@@ -35,7 +35,7 @@ struct Prim { Box b; float c[3]; };
 struct Node2 {
   Box b;
   int32_t left = -1, right = -1;  // children (inner)
-  uint32_t first = 0, count = 0;  // prims (leaf)
+  uint32_t first = 0, count = 0;  // prims of the whole subtree (a contiguous range of `order`)
   bool leaf() const { return left < 0; }
 };
 
@@ -46,7 +46,9 @@ struct Builder {
   std::vector<uint32_t>& order;
   std::vector<Node2> nodes;
 
-  Builder(const std::vector<Prim>& p, std::vector<uint32_t>& o) : prims(p), order(o) {}
+  uint32_t max_leaf;
+
+  Builder(const std::vector<Prim>& p, std::vector<uint32_t>& o, uint32_t ml) : prims(p), order(o), max_leaf(ml) {}
 
   int bin_of(float c, float cmin, float scale) const {
     int b = static_cast<int>((c - cmin) * scale);
@@ -71,11 +73,9 @@ struct Builder {
         cb.grow(p.c);
       }
       nodes[t.node].b = nb;
-      if (t.count <= kMaxLeafTris) {
-        nodes[t.node].first = t.first;
-        nodes[t.node].count = t.count;
-        continue;
-      }
+      nodes[t.node].first = t.first;
+      nodes[t.node].count = t.count;
+      if (t.count <= max_leaf) continue;
       int best_axis = -1, best_bin = -1;
       float best_cost = FLT_MAX;
       for (int axis = 0; axis < 3; ++axis) {
@@ -136,72 +136,22 @@ inline void cross_fma(const float* a, const float* b, float* r) {
   r[2] = std::fmaf(a[0], b[1], -(a[1] * b[0]));
 }
 
-}  // namespace
+// collapse of the BVH2 into BVH4 nodes, breadth-first emission.  A BVH2 node whose subtree holds <= leaf_limit
+// primitives is a leaf of the emitted tree (the builder splits down to kPfLeafTris, so trees of different leaf sizes are
+// cuts through the SAME BVH2 and share the leaf-ordered record array).
+struct Collapsed {
+  std::vector<Node4> nodes;
+  uint32_t max_depth = 0, stack_need = 0;
+};
 
-std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, uint32_t nf, BvhHost& out) {
-  if (!verts || !faces) return "null mesh pointers";
-  if (nf == 0 || nv == 0) return "empty mesh";
-  if (nf > 0x0FFFFFFFu) return "too many faces (max 2^28-1)";
-  for (uint32_t i = 0; i < 3u * nf; ++i)
-    if (faces[i] >= nv) return "face index out of range";
-  for (size_t i = 0; i < 3 * static_cast<size_t>(nv); ++i)
-    if (!std::isfinite(verts[i])) return "non-finite vertex coordinate";
-
-  // triangle records (by face id) + primitive boxes
-  std::vector<TriRec> recs(nf);
-  std::vector<Prim> prims(nf);
-  Box scene;
-  scene.reset();
-  for (uint32_t f = 0; f < nf; ++f) {
-    const float* a = verts + 3 * static_cast<size_t>(faces[3 * f + 0]);
-    const float* b = verts + 3 * static_cast<size_t>(faces[3 * f + 1]);
-    const float* c = verts + 3 * static_cast<size_t>(faces[3 * f + 2]);
-    TriRec& r = recs[f];
-    for (int k = 0; k < 3; ++k) {
-      r.v0[k] = a[k];
-      r.e1[k] = a[k] - b[k];
-      r.e2[k] = c[k] - a[k];
-    }
-    cross_fma(r.e2, r.e1, r.Ng);
-    const float d = std::sqrt((r.Ng[0] * r.Ng[0] + r.Ng[1] * r.Ng[1]) + r.Ng[2] * r.Ng[2]);
-    for (int k = 0; k < 3; ++k) r.n[k] = (d > 0.f) ? r.Ng[k] / d : 0.f;
-    r.face_id = f;
-    Prim& p = prims[f];
-    p.b.reset();
-    p.b.grow(a);
-    p.b.grow(b);
-    p.b.grow(c);
-    for (int k = 0; k < 3; ++k) p.c[k] = 0.5f * (p.b.mn[k] + p.b.mx[k]);
-    scene.grow(p.b);
-  }
-
-  std::vector<uint32_t> order(nf);
-  for (uint32_t f = 0; f < nf; ++f) order[f] = f;
-  Builder bld(prims, order);
-  bld.build();
-  const std::vector<Node2>& n2 = bld.nodes;
-
-  // conservative padding of every stored box: the slab test runs in fp32 with fused ops and must
-  // never cull a box whose triangle the (exact-spec) intersector would accept.
-  float diag = 0.f, amax = 0.f;
-  for (int k = 0; k < 3; ++k) {
-    diag = std::max(diag, scene.mx[k] - scene.mn[k]);
-    amax = std::max(amax, std::max(std::fabs(scene.mn[k]), std::fabs(scene.mx[k])));
-  }
-  const float pad = 1e-4f * std::max(diag, amax) + 1e-6f;
-
-  // collapse BVH2 -> BVH4, breadth-first emission
-  out.nodes.clear();
-  out.tris.resize(nf);
-  for (uint32_t i = 0; i < nf; ++i) out.tris[i] = recs[order[i]];
-
+Collapsed collapse(const std::vector<Node2>& n2, uint32_t leaf_limit, float pad) {
+  Collapsed out;
+  auto is_leaf = [&](int32_t id) { return n2[id].leaf() || n2[id].count <= leaf_limit; };
   struct QItem { int32_t n2; uint32_t depth; uint32_t stack_before; };
   std::deque<QItem> queue;
   // the root is always an inner Node4, even for tiny meshes
   queue.push_back({0, 1, 0});
   std::vector<std::pair<uint32_t, int>> patch;  // (node4 index, slot) -> child n2 id to resolve later
-  std::vector<int32_t> n2_of_node4;
-  uint32_t max_depth = 0, stack_need = 0;
 
   // first pass: assign Node4 ids in BFS order
   while (!queue.empty()) {
@@ -211,11 +161,11 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
     out.nodes.emplace_back();
     Node4& nd = out.nodes.back();
     std::memset(&nd, 0, sizeof(nd));
-    max_depth = std::max(max_depth, it.depth);
+    out.max_depth = std::max(out.max_depth, it.depth);
 
     int32_t kids[4];
     int nk = 0;
-    if (n2[it.n2].leaf()) {
+    if (is_leaf(it.n2)) {
       kids[nk++] = it.n2;
     } else {
       kids[nk++] = n2[it.n2].left;
@@ -224,7 +174,7 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
         int best = -1;
         float best_area = -1.f;
         for (int i = 0; i < nk; ++i) {
-          if (n2[kids[i]].leaf()) continue;
+          if (is_leaf(kids[i])) continue;
           const float a = n2[kids[i]].b.area();
           if (a > best_area) { best_area = a; best = i; }
         }
@@ -235,7 +185,7 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
       }
     }
     const uint32_t stack_here = it.stack_before + static_cast<uint32_t>(nk - 1);
-    stack_need = std::max(stack_need, stack_here);
+    out.stack_need = std::max(out.stack_need, stack_here);
     nd.n_children = static_cast<uint32_t>(nk);
     for (int s = 0; s < 4; ++s) {
       if (s < nk) {
@@ -243,7 +193,7 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
         nd.x[s] = ch.b.mn[0] - pad; nd.x[4 + s] = ch.b.mx[0] + pad;
         nd.y[s] = ch.b.mn[1] - pad; nd.y[4 + s] = ch.b.mx[1] + pad;
         nd.z[s] = ch.b.mn[2] - pad; nd.z[4 + s] = ch.b.mx[2] + pad;
-        if (ch.leaf()) {
+        if (is_leaf(kids[s])) {
           nd.child[s] = make_leaf_ref(ch.first, ch.count);
         } else {
           // id resolved when the child is dequeued: BFS => ids are assigned in queue order
@@ -262,13 +212,17 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
   }
   // BFS: the i-th pushed inner child receives Node4 id (i+1)
   for (size_t i = 0; i < patch.size(); ++i) out.nodes[patch[i].first].child[patch[i].second] = static_cast<uint32_t>(i + 1);
+  out.stack_need += 1;
+  return out;
+}
 
-  // quantised twins (layout.h): per node, corner + step of an 8-bit grid that covers all (padded) child boxes; lower
-  // planes round down, upper planes up, checked in the arithmetic the decode uses
-  out.qnodes.resize(out.nodes.size());
-  for (size_t i = 0; i < out.nodes.size(); ++i) {
-    const Node4& nd = out.nodes[i];
-    Node4Q& q = out.qnodes[i];
+// quantised twins (layout.h): per node, corner + step of an 8-bit grid that covers all (padded) child boxes; lower
+// planes round down, upper planes up, checked in the arithmetic the decode uses
+void quantise(const std::vector<Node4>& nodes, std::vector<Node4Q>& qnodes) {
+  qnodes.resize(nodes.size());
+  for (size_t i = 0; i < nodes.size(); ++i) {
+    const Node4& nd = nodes[i];
+    Node4Q& q = qnodes[i];
     std::memset(&q, 0, sizeof(q));
     const float* lohi[3] = {nd.x, nd.y, nd.z};
     uint32_t* qlo[3] = {&q.qx_lo, &q.qy_lo, &q.qz_lo};
@@ -302,6 +256,89 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
     }
     for (int c = 0; c < 4; ++c) q.child[c] = nd.child[c];
   }
+}
+
+}  // namespace
+
+std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, uint32_t nf, BvhHost& out, uint32_t max_leaf) {
+  if (!verts || !faces) return "null mesh pointers";
+  if (nf == 0 || nv == 0) return "empty mesh";
+  if (nf > 0x0FFFFFFFu) return "too many faces (max 2^28-1)";
+  if (max_leaf < 1 || max_leaf > kMaxLeafTris) return "max_leaf must be 1..4";
+  for (uint32_t i = 0; i < 3u * nf; ++i)
+    if (faces[i] >= nv) return "face index out of range";
+  for (size_t i = 0; i < 3 * static_cast<size_t>(nv); ++i)
+    if (!std::isfinite(verts[i])) return "non-finite vertex coordinate";
+
+  // triangle records (by face id) + primitive boxes
+  std::vector<TriRec> recs(nf);
+  std::vector<Prim> prims(nf);
+  Box scene;
+  scene.reset();
+  for (uint32_t f = 0; f < nf; ++f) {
+    const float* a = verts + 3 * static_cast<size_t>(faces[3 * f + 0]);
+    const float* b = verts + 3 * static_cast<size_t>(faces[3 * f + 1]);
+    const float* c = verts + 3 * static_cast<size_t>(faces[3 * f + 2]);
+    TriRec& r = recs[f];
+    for (int k = 0; k < 3; ++k) {
+      r.v0[k] = a[k];
+      r.e1[k] = a[k] - b[k];
+      r.e2[k] = c[k] - a[k];
+    }
+    cross_fma(r.e2, r.e1, r.Ng);
+    const float d = std::sqrt((r.Ng[0] * r.Ng[0] + r.Ng[1] * r.Ng[1]) + r.Ng[2] * r.Ng[2]);
+    for (int k = 0; k < 3; ++k) r.n[k] = (d > 0.f) ? r.Ng[k] / d : 0.f;
+    r.face_id = f;
+    Prim& p = prims[f];
+    p.b.reset();
+    p.b.grow(a);
+    p.b.grow(b);
+    p.b.grow(c);
+    for (int k = 0; k < 3; ++k) p.c[k] = 0.5f * (p.b.mn[k] + p.b.mx[k]);
+    scene.grow(p.b);
+  }
+
+  // ONE BVH2, split down to the smallest leaf size any tree of the map uses
+  std::vector<uint32_t> order(nf);
+  for (uint32_t f = 0; f < nf; ++f) order[f] = f;
+  Builder bld(prims, order, std::min(max_leaf, kPfLeafTris));
+  bld.build();
+  const std::vector<Node2>& n2 = bld.nodes;
+
+  // conservative padding of every stored box: the slab test runs in fp32 with fused ops and must
+  // never cull a box whose triangle the (exact-spec) intersector would accept.
+  float diag = 0.f, amax = 0.f;
+  for (int k = 0; k < 3; ++k) {
+    diag = std::max(diag, scene.mx[k] - scene.mn[k]);
+    amax = std::max(amax, std::max(std::fabs(scene.mn[k]), std::fabs(scene.mx[k])));
+  }
+  const float pad = 1e-4f * std::max(diag, amax) + 1e-6f;
+
+  out.tris.resize(nf);
+  for (uint32_t i = 0; i < nf; ++i) out.tris[i] = recs[order[i]];
+
+  // the map's tree: leaves of <= max_leaf records
+  Collapsed main_tree = collapse(n2, max_leaf, pad);
+  out.nodes = std::move(main_tree.nodes);
+  quantise(out.nodes, out.qnodes);
+
+  // the particle filter's tree (quantised nodes only): leaves of <= kPfLeafTris records, same record array.  The
+  // filter's rays are incoherent and its kernel is bound by instruction issue with the lanes of a wave taking turns
+  // through the triangle loop: shorter leaves trade a few more (cheap, quantised) node steps for fewer loop trips.
+  if (max_leaf > kPfLeafTris) {
+    Collapsed pf_tree = collapse(n2, kPfLeafTris, pad);
+    quantise(pf_tree.nodes, out.qnodes_pf);
+    out.info.n_nodes_pf = static_cast<uint32_t>(pf_tree.nodes.size());
+    out.info.max_depth_pf = pf_tree.max_depth;
+    out.info.stack_need_pf = pf_tree.stack_need;
+    out.nodes_pf = std::move(pf_tree.nodes);
+  } else {
+    out.qnodes_pf = out.qnodes;
+    out.nodes_pf = out.nodes;
+    out.info.n_nodes_pf = static_cast<uint32_t>(out.nodes.size());
+    out.info.max_depth_pf = main_tree.max_depth;
+    out.info.stack_need_pf = main_tree.stack_need;
+  }
 
   out.cnodes.resize(out.nodes.size());
   for (size_t i = 0; i < out.nodes.size(); ++i) {
@@ -318,8 +355,8 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
   out.info.n_faces = nf;
   out.info.n_vertices = nv;
   out.info.n_nodes = static_cast<uint32_t>(out.nodes.size());
-  out.info.max_depth = max_depth;
-  out.info.stack_need = stack_need + 1;
+  out.info.max_depth = main_tree.max_depth;
+  out.info.stack_need = main_tree.stack_need;
   out.info.pad = pad;
   for (int k = 0; k < 3; ++k) { out.info.bbox_min[k] = scene.mn[k]; out.info.bbox_max[k] = scene.mx[k]; }
   return std::string();

@@ -13,6 +13,7 @@ namespace rmclhip {
 
 struct BvhInfo {
   uint32_t n_faces = 0, n_vertices = 0, n_nodes = 0, max_depth = 0, stack_need = 0;
+  uint32_t n_nodes_pf = 0, max_depth_pf = 0, stack_need_pf = 0;  // the particle filter's tree (leaves <= kPfLeafTris)
   float bbox_min[3] = {0, 0, 0}, bbox_max[3] = {0, 0, 0};
   float pad = 0.f;
 };
@@ -21,11 +22,15 @@ struct BvhHost {
   std::vector<Node4> nodes;
   std::vector<Node4Q> qnodes;  // quantised twins, same indices
   std::vector<Node4C> cnodes;  // child-major twins, same indices
-  std::vector<TriRec> tris;  // leaf order
+  std::vector<Node4> nodes_pf;    // the particle filter's cut of the same BVH2 (leaves <= kPfLeafTris): host-side only
+  std::vector<Node4Q> qnodes_pf;  // ... and its quantised form, what k_pf_update_* reads
+  std::vector<TriRec> tris;  // leaf order (shared by both trees)
   BvhInfo info;
 };
 
 // returns empty string on success, else an error message
-std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, uint32_t nf, BvhHost& out);
+// max_leaf: largest leaf of the map's tree (1..kMaxLeafTris)
+std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, uint32_t nf, BvhHost& out,
+                      uint32_t max_leaf = kMaxLeafTris);
 
 }  // namespace rmclhip

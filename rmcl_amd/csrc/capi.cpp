@@ -116,6 +116,7 @@ struct rmclhip_map {
   BvhInfo info;
   uint32_t* d_nodes = nullptr;
   uint32_t* d_qnodes = nullptr;  // Node4Q twins
+  uint32_t* d_qnodes_pf = nullptr;  // Node4Q array of the particle filter's own tree (leaves <= kPfLeafTris, same records)
   uint32_t* d_cnodes = nullptr;  // Node4C twins
   uint32_t* d_tris = nullptr;
   uint64_t bytes = 0;
@@ -232,6 +233,10 @@ struct rmclhip_pf {
   size_t h_beams_cap = 0;
   float* errors_dev = nullptr;
   int variant = 0;
+  bool beams_at_origin = false;  // of the beams uploaded last: all start at the sensor origin
+  bool legacy = false;      // A/B: the round-2 kernel (k_pf_update_persist)
+  bool big_blocks = false;  // A/B: 4096 rays per workgroup
+  bool pf_tree = true;      // quantised nodes of the filter's own tree (leaves <= kPfLeafTris); false: the map's tree (A/B)
   bool full_nodes = false;  // A/B: persistent lanes on the 128-B nodes instead of their 64-B quantised twins
   int refill = 4;  // 0: rounds of one ray per lane; 1..4: persistent lanes (dynamic ray fetch), refill when 8/16/32/48
                    // lanes of a wave are idle (default 48: the refill block also evaluates the finished beams, which
@@ -318,6 +323,31 @@ rmclhip_status rmclhip_bvh_build_host(const float* v, uint32_t nv, const uint32_
   return RMCLHIP_OK;
 }
 
+rmclhip_status rmclhip_bvh_build_host_pf(const float* v, uint32_t nv, const uint32_t* f, uint32_t nf,
+                                         rmclhip_map_info* info, uint32_t* nodes_out, size_t nodes_cap,
+                                         uint32_t* qnodes_out, size_t qnodes_cap) {
+  ApiGuard guard_("rmclhip_bvh_build_host_pf");
+  BvhHost bvh;
+  const std::string err = build_bvh(v, nv, f, nf, bvh);
+  if (!err.empty()) return fail(RMCLHIP_ERR_INVALID, "bvh_build_host_pf: " + err);
+  const size_t nd = bvh.nodes_pf.size() * kNodeDwords, qd = bvh.qnodes_pf.size() * (sizeof(Node4Q) / 4);
+  if (info) {
+    fill_info(bvh.info, (nd + bvh.tris.size() * kTriDwords) * 4, info);
+    info->n_nodes = bvh.info.n_nodes_pf;
+    info->max_depth = bvh.info.max_depth_pf;
+    info->stack_need = bvh.info.stack_need_pf;
+  }
+  if (nodes_out) {
+    if (nodes_cap < nd) return fail(RMCLHIP_ERR_INVALID, "bvh_build_host_pf: nodes buffer too small");
+    std::memcpy(nodes_out, bvh.nodes_pf.data(), nd * 4);
+  }
+  if (qnodes_out) {
+    if (qnodes_cap < qd) return fail(RMCLHIP_ERR_INVALID, "bvh_build_host_pf: qnodes buffer too small");
+    std::memcpy(qnodes_out, bvh.qnodes_pf.data(), qd * 4);
+  }
+  return RMCLHIP_OK;
+}
+
 rmclhip_status rmclhip_bvh_build_host_quantised(const float* v, uint32_t nv, const uint32_t* f, uint32_t nf,
                                                 uint32_t* qnodes_out, size_t qnodes_cap) {
   ApiGuard guard_("rmclhip_bvh_build_host_quantised");
@@ -345,7 +375,7 @@ rmclhip_status rmclhip_map_create(rmclhip_ctx* ctx, const float* v, uint32_t nv,
 
 // device copy of a built BVH (one build can serve several devices: rmclhip_pf_sharded_create)
 static rmclhip_status map_upload(rmclhip_ctx* ctx, const BvhHost& bvh, rmclhip_map** out) {
-  if (bvh.info.stack_need > 64)
+  if (bvh.info.stack_need > 64 || bvh.info.stack_need_pf > 64)
     return fail(RMCLHIP_ERR_UNSUPPORTED, "map_create: BVH needs a traversal stack deeper than 64 entries");
   if (static_cast<uint64_t>(bvh.nodes.size()) * sizeof(Node4) >= (1ull << 32))
     return fail(RMCLHIP_ERR_UNSUPPORTED, "map_create: node array exceeds 4 GB (the kernels address nodes with 32-bit byte offsets)");
@@ -363,6 +393,9 @@ static rmclhip_status map_upload(rmclhip_ctx* ctx, const BvhHost& bvh, rmclhip_m
   const size_t qb = bvh.qnodes.size() * sizeof(Node4Q);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_qnodes), qb);
   if (e == hipSuccess) e = hipMemcpy(m->d_qnodes, bvh.qnodes.data(), qb, hipMemcpyHostToDevice);
+  const size_t qpb = bvh.qnodes_pf.size() * sizeof(Node4Q);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_qnodes_pf), qpb);
+  if (e == hipSuccess) e = hipMemcpy(m->d_qnodes_pf, bvh.qnodes_pf.data(), qpb, hipMemcpyHostToDevice);
   const size_t cb = bvh.cnodes.size() * sizeof(Node4C);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_cnodes), cb);
   if (e == hipSuccess) e = hipMemcpy(m->d_cnodes, bvh.cnodes.data(), cb, hipMemcpyHostToDevice);
@@ -370,13 +403,14 @@ static rmclhip_status map_upload(rmclhip_ctx* ctx, const BvhHost& bvh, rmclhip_m
   if (e != hipSuccess) {
     if (m->d_nodes) (void)hipFree(m->d_nodes);
     if (m->d_qnodes) (void)hipFree(m->d_qnodes);
+    if (m->d_qnodes_pf) (void)hipFree(m->d_qnodes_pf);
     if (m->d_cnodes) (void)hipFree(m->d_cnodes);
     if (m->d_tris) (void)hipFree(m->d_tris);
     delete m;
     return fail(e == hipErrorOutOfMemory ? RMCLHIP_ERR_NOMEM : RMCLHIP_ERR_HIP,
                 std::string("map_create upload: ") + hipGetErrorString(e));
   }
-  m->bytes = nb + qb + cb + tb;
+  m->bytes = nb + qb + qpb + cb + tb;
   ctx_retain(ctx);
   *out = m;
   return RMCLHIP_OK;
@@ -396,6 +430,7 @@ void rmclhip_map_release(rmclhip_map* map) {
     (void)hipSetDevice(map->ctx->device);
     if (map->d_nodes) (void)hipFree(map->d_nodes);
     if (map->d_qnodes) (void)hipFree(map->d_qnodes);
+    if (map->d_qnodes_pf) (void)hipFree(map->d_qnodes_pf);
     if (map->d_cnodes) (void)hipFree(map->d_cnodes);
     if (map->d_tris) (void)hipFree(map->d_tris);
     ctx_release(map->ctx);
@@ -1841,6 +1876,9 @@ static rmclhip_status pf_upload_beams(rmclhip_pf* f, const rmclhip_range_measure
     HIPCHK(hipStreamSynchronize(f->stream));  // the staging buffer may still be in flight
   }
   std::memcpy(f->h_beams, beams, nf * sizeof(float));
+  f->beams_at_origin = true;
+  for (uint32_t b = 0; b < n_beams && f->beams_at_origin; ++b)
+    f->beams_at_origin = beams[b].orig.x == 0.0f && beams[b].orig.y == 0.0f && beams[b].orig.z == 0.0f;
   HIPCHK(hipMemcpyAsync(f->d_beams.p, f->h_beams, nf * sizeof(float), hipMemcpyHostToDevice, f->stream));
   return RMCLHIP_OK;
 }
@@ -1850,7 +1888,7 @@ static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, 
   PfParams p;
   std::memset(&p, 0, sizeof(p));
   p.nodes = f->map->d_nodes;
-  p.qnodes = f->map->d_qnodes;
+  p.qnodes = f->pf_tree ? f->map->d_qnodes_pf : f->map->d_qnodes;
   p.tris = f->map->d_tris;
   p.poses = reinterpret_cast<const xform*>(poses);
   p.attrs = attrs;
@@ -1871,13 +1909,15 @@ static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, 
   p.ray_tfar = (f->params.correspondence_type == 3u) ? 1.0e4f : std::numeric_limits<float>::infinity();
   // particles per workgroup: ~2048 rays per block (measured 4-6 % faster than 4096: shorter tail per block, more
   // blocks to balance), at most 64 particles, evals must fit 32 KB of LDS
-  uint32_t pb = 2048u / n_beams;
+  uint32_t pb = (f->big_blocks ? 4096u : 2048u) / n_beams;
   if (pb < 1u) pb = 1u;
   if (pb > 64u) pb = 64u;
   if (static_cast<size_t>(pb) * n_beams > 8192u) return fail(RMCLHIP_ERR_UNSUPPORTED, "pf_update: more than 8192 beams");
   p.particles_per_block = pb;
-  const int variant = (f->variant & 3) | ((f->map->info.stack_need > 32) ? 4 : 0) | (f->params.correspondence_type == 1u ? 8 : 0) |
-                      (f->refill << 4) | (f->full_nodes ? 128 : 0);
+  p.beams_at_origin = f->beams_at_origin ? 1u : 0u;
+  p.nb_magic = static_cast<uint32_t>((1ull << 32) / n_beams) + 1u;   // pb * n_beams <= 8192, n_beams <= 8192: exact
+  const int variant = (f->variant & 3) | ((std::max(f->map->info.stack_need, f->map->info.stack_need_pf) > 32) ? 4 : 0) | (f->params.correspondence_type == 1u ? 8 : 0) |
+                      (f->refill << 4) | (f->full_nodes ? 128 : 0) | (f->legacy ? 256 : 0) | (f->pf_tree ? 0 : 1024);
   HIPCHK(launch_pf_update(p, variant, f->stream));
   return RMCLHIP_OK;
 }
@@ -1958,10 +1998,13 @@ rmclhip_status rmclhip_pf_time_update(rmclhip_pf* f, const rmclhip_transform* po
 
 rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* f, int variant) {
   ApiGuard guard_("rmclhip_pf_set_variant");
-  if (!f || variant < 0 || (variant & 15) > 2 || ((variant >> 4) & 7) > 4 || (variant >> 8) != 0) return fail(RMCLHIP_ERR_INVALID, "pf_set_variant: bad arguments");
+  if (!f || variant < 0 || (variant & 15) > 2 || ((variant >> 4) & 7) > 4 || (variant >> 11) != 0) return fail(RMCLHIP_ERR_INVALID, "pf_set_variant: bad arguments");
   f->variant = variant & 15;
   f->refill = (variant >> 4) & 7;
   f->full_nodes = ((variant >> 7) & 1) != 0;
+  f->legacy = ((variant >> 8) & 1) != 0;      // the round-2 kernel
+  f->big_blocks = ((variant >> 9) & 1) != 0;  // 4096 instead of 2048 rays per workgroup
+  f->pf_tree = ((variant >> 10) & 1) == 0;    // bit 10: traverse the map's tree (leaves <= 4) instead of the filter's own
   return RMCLHIP_OK;
 }
 

@@ -92,6 +92,9 @@ struct PfParams {
   uint32_t raw_ng;               // correspondence_type 2: error against Embree's un-normalised Ng
   uint32_t sim_min_range;        // sim hit requires t > sensor_range.min (Embree updater :47; the OptiX program does not)
   float ray_tfar;                // inf (Embree updater :27) or 1e4 (optixTrace tmax, BeamEvaluateProgram.cu:48)
+  uint32_t beams_at_origin;      // every beam starts at (0,0,0) of the sensor frame (what PCDSensorUpdaterEmbree::update builds,
+                                 // :314-327): Tsm * orig is Tsm.t, the rotation of a zero vector is skipped
+  uint32_t nb_magic;             // floor(2^32 / n_beams) + 1: ray index / n_beams = umulhi(ray, nb_magic) for ray * n_beams < 2^32
 };
 
 // per-call inputs of the device-resident MICP loop: written by ONE H2D copy so that the whole loop can be a

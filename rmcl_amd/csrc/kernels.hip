@@ -2919,6 +2919,231 @@ __global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 3 form of the persistent-lane kernel (the default).  tools/pfsim.py -- a wave-level model of this schedule on the
+// product's own BVH arrays that reproduces the round-2 PMC figures (2.0 ms, ~60 % of the lanes active) -- says the kernel is
+// bound by VALU instruction ISSUES, and that what moves the issue count is (a) shorter leaves, (b) what the refill block and
+// the merge tail cost, not how many lanes sit in each issue:
+//   * the filter's OWN tree (bvh_build.h): leaves of <= 2 records, same record array; a leaf visit is ONE round trip for
+//     both records (leaf_pair) instead of a loop over up to four;
+//   * the refill block only derives the point-to-plane ERROR of a finished beam; the double-precision exp / divide of the
+//     likelihood runs afterwards as a dense pass over the block's beams (every lane busy) -- same operations, same result;
+//   * the in-order Gaussian1D merge (one lane per particle, sequential by the reference's semantics) no longer divides:
+//     the count sequence of a particle is known up front (n0 + k, clamped), so the two weights of every (particle, beam) are
+//     computed by all lanes into the LDS the traversal stacks have just vacated, and the chain is ~14 dependent flops;
+//   * ray set-up takes v_rcp_f32 for the slab reciprocals (the slab test is free-form and conservative: boxes are padded
+//     1000 x wider than the reciprocal's error).
+// Results are those of k_pf_update / k_pf_update_persist bit for bit (tests/test_gpu_pf.py runs all of them).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_inv(float d) {
+  const float ad = fabsf(d);
+  const float s = (ad < 1e-30f) ? copysignf(1e-30f, d) : d;
+  return __builtin_amdgcn_rcpf(s);
+}
+
+// a leaf of the filter's tree (<= kPfLeafTris = 2 records) in one memory round trip; a lane whose leaf holds one record
+// re-tests it (a repeated test cannot change (best_t, best_rec))
+__device__ __forceinline__ void leaf_pair(const uint32_t* __restrict__ tris, uint32_t cur, f3 O, f3 D, float ray_tfar,
+                                          float& best_t, uint32_t& best_rec) {
+  const uint32_t first = cur & 0x0FFFFFFFu;
+  const bool two = ((cur >> 28) & 7u) != 0u;
+  const uint32_t second = first + (two ? 1u : 0u);
+  const uint4* t0 = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(first) * 4u;
+  const uint4* t1 = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(second) * 4u;
+  const uint4 a0 = t0[0], b0 = t0[1], c0 = t0[2];
+  const uint4 a1 = t1[0], b1 = t1[1], c1 = t1[2];
+  tri_update(a0, b0, c0, first, tris, O, D, ray_tfar, best_t, best_rec);
+  if (__any(two)) tri_update(a1, b1, c1, second, tris, O, D, ray_tfar, best_t, best_rec);
+}
+
+template <int kRows, int kRefill, bool kLeaf2>
+__global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
+  // LDS: [ per-lane stacks kRows*256 (later: merge weights) | Tsm (PB xforms) | n0 (PB) | errors -> evals (PB*n_beams floats) ]
+  extern __shared__ uint32_t lds_dyn[];
+  __shared__ uint32_t s_next;
+  uint32_t* lds_col = lds_dyn + threadIdx.x;   // stack rows of this lane: row r at lds_col[r * 256], row 0 = sentinel
+  xform* s_Tsm = reinterpret_cast<xform*>(lds_dyn + kRows * 256);
+  uint32_t* s_n0 = reinterpret_cast<uint32_t*>(s_Tsm + p.particles_per_block);
+  float* s_eval = reinterpret_cast<float*>(s_n0 + p.particles_per_block);
+
+  const uint32_t PB = p.particles_per_block;
+  const uint32_t p0 = blockIdx.x * PB;
+  if (p0 >= p.n_particles) return;
+  const uint32_t np = min(PB, p.n_particles - p0);
+  pattrs* attrs = reinterpret_cast<pattrs*>(p.attrs);
+  if (threadIdx.x < np) {
+    s_Tsm[threadIdx.x] = xmul(p.poses[p0 + threadIdx.x], p.Tsb);
+    s_n0[threadIdx.x] = attrs[p0 + threadIdx.x].likelihood.n_meas;
+  }
+  if (threadIdx.x == 0) s_next = 0u;
+  __syncthreads();
+
+  const float sq = p.dist_sigma * p.dist_sigma;
+  const uint32_t nrays = np * p.n_beams;
+  const uint32_t lane = threadIdx.x & 63u;
+  constexpr uint32_t kDone = 0x7FFFFFFFu;
+  // per-lane ray state
+  uint32_t rr = 0;
+  bool has_ray = false, exhausted = false;
+  f3 O = mk3(0.f, 0.f, 0.f), D = O;
+  RaySlab rs = make_ray_slab(O, mk3(1.f, 1.f, 1.f));
+  float range = 0.f, best_t = 0.f;
+  uint32_t best_rec = kNone;
+  uint32_t priv[(kRows < 65) ? (65 - kRows) : 1];
+  lds_col[0] = kDone;
+  uint32_t sp = 1, cur = kDone;
+#define RMCL_ROW_ST(r, v) { if ((r) < static_cast<uint32_t>(kRows)) lds_col[(r) * kBfStride] = (v); else priv[(r) - kRows] = (v); }
+#define RMCL_ROW_LD(r) (((r) < static_cast<uint32_t>(kRows)) ? lds_col[(r) * kBfStride] : priv[(r) - kRows])
+  for (;;) {
+    const bool idle = (cur == kDone) && !exhausted;
+    const uint64_t want = __ballot(idle);
+    const uint64_t busy = __ballot(cur != kDone);
+    if (want == 0 && busy == 0) break;
+    if (want != 0 && (busy == 0 || __popcll(want) >= kRefill)) {
+      if (idle && has_ray) {
+        // evaluate_rcc (PCDSensorUpdaterEmbree.cpp:18-86) with unit face normals (BeamEvaluateProgram.cu:104-113): the error only
+        const bool real_hit = (range >= p.range_min) && (range <= p.range_max);
+        const bool sim_hit = (best_rec != kNone) && (!p.sim_min_range || best_t > p.range_min);
+        float error;
+        if (sim_hit) {
+          if (real_hit) {
+            const f3 n = pf_error_normal(p.tris, best_rec, p.raw_ng);
+            const f3 preal = add3(O, scale3(D, range));
+            const f3 pint = add3(O, scale3(D, best_t));
+            error = fabsf(dot_plain(sub3(pint, preal), n));
+          } else {
+            error = p.rmsh;
+          }
+        } else {
+          error = real_hit ? p.rhsm : p.rmsm;
+        }
+        s_eval[rr] = error;
+        has_ray = false;
+      }
+      // next rays for the idle lanes: one LDS atomic per wave and refill
+      const uint32_t nwant = static_cast<uint32_t>(__popcll(want));
+      const int leader = __builtin_ctzll(want);
+      uint32_t base = 0;
+      if (static_cast<int>(lane) == leader) base = atomicAdd(&s_next, nwant);
+      base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(base), leader));
+      if (idle) {
+        const uint32_t mine = base + static_cast<uint32_t>(__popcll(want & ((1ull << lane) - 1ull)));
+        if (mine < nrays) {
+          rr = mine;
+          const uint32_t pi = __umulhi(rr, p.nb_magic), b = rr - pi * p.n_beams;
+          const xform Tsm = s_Tsm[pi];
+          const float* bm = p.beams + 16u * b;
+          // meas_m = Tsm * meas_s (RangeMeasurement.hpp:28-42)
+          D = qrot(Tsm.R, mk3(bm[3], bm[4], bm[5]));
+          O = p.beams_at_origin ? Tsm.t : xapply(Tsm, mk3(bm[0], bm[1], bm[2]));
+          range = bm[6];
+          rs.inv = mk3(fast_inv(D.x), fast_inv(D.y), fast_inv(D.z));
+          rs.noi = mk3(-(O.x * rs.inv.x), -(O.y * rs.inv.y), -(O.z * rs.inv.z));
+          best_t = p.ray_tfar;
+          best_rec = kNone;
+          sp = 1;
+          has_ray = true;
+          const bool finite = (D.x == D.x) && (D.y == D.y) && (D.z == D.z);
+          cur = finite ? 0u : kDone;  // a non-finite beam is a miss: evaluated at the next refill
+        } else {
+          exhausted = true;
+        }
+      }
+    }
+    // phase 1: inner nodes -- left early once at most kTailLanes lanes are still descending while others hold a leaf
+    constexpr int kTailLanes = 8;
+    for (;;) {
+      const bool inner = (cur != kDone) && !(cur & kLeafBit);
+      const uint64_t m_inner = __ballot(inner);
+      if (m_inner == 0) break;
+      if (__popcll(m_inner) <= kTailLanes && __ballot((cur != kDone) && (cur & kLeafBit)) != 0) break;
+      if (inner) {
+        uint32_t key[4], ref[4];
+        if (!__any(sp + 3u > static_cast<uint32_t>(kRows))) {
+          const uint32_t top = lds_col[(sp - 1u) * kBfStride];
+          node_keys_q(p.qnodes, cur, rs, best_t, key, ref);
+          RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
+          lds_col[sp * kBfStride] = ref[3]; sp += (key[3] != kNone) ? 1u : 0u;
+          lds_col[sp * kBfStride] = ref[2]; sp += (key[2] != kNone) ? 1u : 0u;
+          lds_col[sp * kBfStride] = ref[1]; sp += (key[1] != kNone) ? 1u : 0u;
+          const bool any = key[0] != kNone;
+          cur = any ? ref[0] : top;
+          sp = any ? sp : (sp - 1u);
+        } else {
+          node_keys_q(p.qnodes, cur, rs, best_t, key, ref);
+          RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
+          if (key[3] != kNone) { RMCL_ROW_ST(sp, ref[3]) ++sp; }
+          if (key[2] != kNone) { RMCL_ROW_ST(sp, ref[2]) ++sp; }
+          if (key[1] != kNone) { RMCL_ROW_ST(sp, ref[1]) ++sp; }
+          if (key[0] != kNone) cur = ref[0];
+          else { --sp; cur = RMCL_ROW_LD(sp); }
+        }
+      }
+    }
+    // phase 2: this lane's leaf (if any); tfar = infinity
+    if ((cur != kDone) && (cur & kLeafBit)) {
+      if (kLeaf2) leaf_pair(p.tris, cur, O, D, p.ray_tfar, best_t, best_rec);
+      else leaf_loop(p.tris, cur, O, D, p.ray_tfar, best_t, best_rec);
+      --sp;
+      cur = RMCL_ROW_LD(sp);
+    }
+  }
+#undef RMCL_ROW_ST
+#undef RMCL_ROW_LD
+  __syncthreads();  // every beam of the block has its error in s_eval; the stack rows are free from here on
+
+  // dense pass: error -> likelihood (PCDSensorUpdaterEmbree.cpp:224: float argument, double exp / sqrt, float result)
+  const double den = sqrt(static_cast<double>(2 * sq) * 3.14159265358979323846);
+  for (uint32_t i = threadIdx.x; i < nrays; i += 256u) {
+    const float error = s_eval[i];
+    if (p.errors) p.errors[static_cast<size_t>(p0) * p.n_beams + i] = error;
+    const float arg = -(error * error) / sq / 2;
+    s_eval[i] = static_cast<float>(exp(static_cast<double>(arg)) / den);
+  }
+
+  // in-order merge (sequential semantics of sensorUpdate, :232-238): likelihood += Gaussian1D{eval, 0, 1}; n_meas = min(n_meas, max)
+  // after every beam.  The count a particle carries INTO beam k is a_k = n0 (k = 0), n0 + min(k, max - n0) (n0 < max), max
+  // (otherwise): both weights of rm::Gaussian1D::operator+= for every (particle, beam) come from all lanes, chunk by chunk,
+  // into the stack rows; the chain of one lane per particle is then the multiply-adds of g1d_add in g1d_add's order.
+  float* s_w = reinterpret_cast<float*>(lds_dyn);
+  const uint32_t chunk = min(p.n_beams, (static_cast<uint32_t>(kRows * 256) / np - 2u) / 2u);  // beams per chunk; np <= 64 => >= 39
+  const uint32_t wstride = 2u * chunk + 2u;
+  g1d L = {0.f, 0.f, 0u};
+  if (threadIdx.x < np) L = attrs[p0 + threadIdx.x].likelihood;
+  for (uint32_t b0 = 0; b0 < p.n_beams; b0 += chunk) {
+    const uint32_t nb = min(chunk, p.n_beams - b0);
+    __syncthreads();
+    for (uint32_t pi = 0; pi < np; ++pi) {
+      const uint32_t n0 = s_n0[pi];
+      for (uint32_t j = threadIdx.x; j < nb; j += 256u) {
+        const uint32_t k = b0 + j;
+        const uint32_t a = (k == 0u) ? n0 : ((n0 < p.max_n_meas) ? n0 + min(k, p.max_n_meas - n0) : p.max_n_meas);
+        const uint32_t n = a + 1u;
+        s_w[pi * wstride + 2u * j] = static_cast<float>(a) / static_cast<float>(n);
+        s_w[pi * wstride + 2u * j + 1u] = static_cast<float>(1u) / static_cast<float>(n);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < np) {
+      const float* ev = s_eval + threadIdx.x * p.n_beams + b0;
+      const float* w = s_w + threadIdx.x * wstride;
+      for (uint32_t j = 0; j < nb; ++j) {
+        const float w1 = w[2u * j], w2 = w[2u * j + 1u], e = ev[j];
+        const float mean = L.mean * w1 + e * w2;
+        const float P1 = L.sigma * w1 + 0.0f * w2;
+        const float P2 = ((L.mean - mean) * (L.mean - mean)) * w1 + ((e - mean) * (e - mean)) * w2;
+        L.mean = mean;
+        L.sigma = P1 + P2;
+      }
+    }
+  }
+  if (threadIdx.x < np) {
+    const uint32_t n0 = s_n0[threadIdx.x], k = p.n_beams;
+    L.n_meas = (n0 < p.max_n_meas) ? n0 + min(k, p.max_n_meas - n0) : p.max_n_meas;
+    attrs[p0 + threadIdx.x].likelihood = L;
+  }
+}
+
 // particle_move_and_forget_kernel (rmcl_ros/src/rmcl/particle_motion.cu:11-34) + the wall-collision test of the
 // CPU updater (collision_in_between, TFMotionUpdaterCPU.cpp:17-50,207-221): one lane per particle; the occlusion
 // ray runs from the old to the new particle position with tfar = segment length.
@@ -3653,6 +3878,20 @@ hipError_t launch_pf_update(const PfParams& p, int variant, hipStream_t s) {
   const size_t stack_lds = ((trav == 0 || cpc) ? 16u : (deep ? 64u : 32u)) * 256u * sizeof(uint32_t);
   size_t lds = stack_lds + tail;
   const int refill = (variant >> 4) & 7;  // 0 = rounds of one ray per lane; 1..4 = persistent lanes, refill at 8/16/32/48 idle
+  const bool legacy = ((variant >> 8) & 1) != 0;   // bit 8: the round-2 kernel (k_pf_update_persist), A/B
+  const bool leaf2 = ((variant >> 10) & 1) == 0;   // bit 10 set: p.qnodes is the MAP's tree (leaves <= 4) -> loop over the leaf
+  if (!cpc && trav == 0 && refill != 0 && !legacy && ((variant >> 7) & 1) == 0 && p.qnodes != nullptr) {
+    lds = static_cast<size_t>(kPfRows) * 256u * sizeof(uint32_t) + tail + sizeof(uint32_t) * p.particles_per_block;
+    if (leaf2) {
+      if (refill == 1) hipLaunchKernelGGL((k_pf_update_v3<kPfRows, 8, true>), dim3(nblocks), dim3(256), lds, s, p);
+      else if (refill == 2) hipLaunchKernelGGL((k_pf_update_v3<kPfRows, 16, true>), dim3(nblocks), dim3(256), lds, s, p);
+      else if (refill == 3) hipLaunchKernelGGL((k_pf_update_v3<kPfRows, 32, true>), dim3(nblocks), dim3(256), lds, s, p);
+      else hipLaunchKernelGGL((k_pf_update_v3<kPfRows, 48, true>), dim3(nblocks), dim3(256), lds, s, p);
+    } else {
+      hipLaunchKernelGGL((k_pf_update_v3<kPfRows, 48, false>), dim3(nblocks), dim3(256), lds, s, p);
+    }
+    return hipGetLastError();
+  }
   if (!cpc && trav == 0 && refill != 0) {
     lds = static_cast<size_t>(kPfRows) * 256u * sizeof(uint32_t) + tail;
     const bool quant = ((variant >> 7) & 1) == 0 && p.qnodes != nullptr;  // bit 7: full-precision nodes (A/B)

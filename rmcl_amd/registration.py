@@ -150,6 +150,22 @@ def build_bvh_host(vertices, faces):
     return info, nodes, tris
 
 
+def build_bvh_host_pf(vertices, faces):
+    """The particle filter's tree of the same map (leaves <= 2 triangles, same record array as build_bvh_host):
+    returns (info dict, nodes[n,32] u32, qnodes[n,16] u32)."""
+    v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+    f = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
+    mi = _capi.MapInfo()
+    L = _capi.lib()
+    _capi.check(L.rmclhip_bvh_build_host_pf(_ptr(v), len(v), _ptr(f), len(f), C.byref(mi), None, 0, None, 0))
+    nodes = np.zeros((mi.n_nodes, 32), dtype=np.uint32)
+    qnodes = np.zeros((mi.n_nodes, 16), dtype=np.uint32)
+    _capi.check(L.rmclhip_bvh_build_host_pf(_ptr(v), len(v), _ptr(f), len(f), C.byref(mi), _ptr(nodes), nodes.size,
+                                            _ptr(qnodes), qnodes.size))
+    info = {k: (list(getattr(mi, k)) if k.startswith("bbox") else getattr(mi, k)) for k, _ in mi._fields_}
+    return info, nodes, qnodes
+
+
 def build_bvh_host_quantised(vertices, faces, n_nodes):
     """the 64-B quantised twins of the nodes of build_bvh_host (host only): qnodes[n_nodes, 16] u32."""
     v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)

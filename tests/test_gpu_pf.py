@@ -38,7 +38,13 @@ def _check(a_gpu, e_gpu, a_ref, e_ref, what):
     assert np.array_equal(a_gpu["state_sigma"], a_ref["state_sigma"]), what + " state_sigma must be untouched"
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 16, 48, 48 | 128])
+# variant bits (rmclhip_pf_set_variant): 0-1 traversal of the round kernel, 4-6 persistent lanes (refill at 8/16/32/48 idle lanes),
+# 7 full 128-B nodes (round-2 kernel), 8 round-2 kernel on the quantised nodes, 9 4096 rays per workgroup, 10 the map's tree
+# (leaves <= 4) instead of the filter's own (leaves <= 2)
+LEGACY, BIG, MAPTREE = 256, 512, 1024
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 16, 48, 64, 48 | 128, 64 | LEGACY, 64 | BIG, 64 | MAPTREE])
 def test_golden_g6_cube(ra, ctx, meshes, variant):
     """committed fixture G6: 64 particles x 16 beams on the cube; beams outside the sensor range
     (real miss) and the MAX_N_MEAS clamp included."""
@@ -55,7 +61,7 @@ def test_golden_g6_cube(ra, ctx, meshes, variant):
 
 
 @pytest.mark.parametrize("n_particles,n_beams", [(1000, 100), (257, 7), (4099, 256)])
-@pytest.mark.parametrize("variant", [0, 2, 16, 32, 64, 48 | 128])
+@pytest.mark.parametrize("variant", [0, 2, 16, 32, 64, 48 | 128, 64 | LEGACY, 64 | BIG, 64 | MAPTREE, 64 | LEGACY | MAPTREE])
 def test_room_random_particles(ra, orc, ctx, meshes, n_particles, n_beams, variant):
     """random hypotheses in a room with occluders and an open ceiling (sim misses), reference default of
     100 random beams and ragged sizes; beams sampled from a simulated cloud like update() does."""
@@ -76,6 +82,32 @@ def test_room_random_particles(ra, orc, ctx, meshes, n_particles, n_beams, varia
     e_ref = m.pf_update(poses, a_ref, beams, Tsb, orc.pf_params(), bvh=True, nthreads=8, want_errors=True)
     _check(a_gpu, e_gpu, a_ref, e_ref, "room %dx%d" % (n_particles, n_beams))
     assert (e_ref == 100.0).any() and (e_ref < 1.0).any()
+
+
+@pytest.mark.parametrize("variant", [64, 64 | BIG, 64 | LEGACY, 0])
+def test_beams_with_their_own_origins_and_edge_counts(ra, orc, ctx, meshes, variant):
+    """RangeMeasurement.orig != 0 (the general Tsm * meas_s of RangeMeasurement.hpp:28-42; the kernel's shortcut for beams that
+    start at the sensor origin must not be taken) and every regime of the count sequence of the in-order merge: n_meas
+    below, at and above MAX_N_MEAS on entry (the weights of the merge are derived from the closed form of that sequence)."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room30k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    poses, attrs = syn.uniform_particles(600, seed=31, bb_min=(-9, -9, 0.2, 0, 0, -math.pi), bb_max=(9, 9, 3.0, 0, 0, math.pi))
+    counts = np.array([0, 1, 2, 40, 48, 49, 50, 51, 52, 1000, 0xFFFFFFF0], np.uint32)
+    attrs["likelihood"]["n_meas"] = counts[np.arange(len(attrs)) % len(counts)]
+    attrs["likelihood"]["sigma"] = 0.01
+    attrs["likelihood"]["mean"] = 0.3
+    beams = ra.beams_from_points(syn.model_directions(syn.model_pf16())[5::9] * np.float32(5.0))
+    rng = np.random.default_rng(3)
+    for k in "xyz":
+        beams["orig"][k] = rng.uniform(-0.2, 0.2, len(beams)).astype(np.float32)
+    kw = dict(max_n_meas=50)
+    a_gpu, e_gpu = _run(ra, ctx, hm, poses, attrs.copy(), beams, syn.tsb_offset(), params=T.pf_params(**kw), variant=variant)
+    a_ref = attrs.copy()
+    e_ref = m.pf_update(poses, a_ref, beams, syn.tsb_offset(), orc.pf_params(**kw), bvh=True, want_errors=True)
+    _check(a_gpu, e_gpu, a_ref, e_ref, "own origins / edge counts")
+    assert set(np.unique(a_ref["likelihood"]["n_meas"])) == {len(beams), len(beams) + 1, len(beams) + 2, 50}
 
 
 def test_repeated_updates_accumulate_and_clamp(ra, orc, ctx, meshes):
@@ -205,7 +237,7 @@ def test_c4_full_size_properties(ra, orc, ctx, meshes):
     beams = ra.beams_from_points(syn.model_directions(syn.model_pf16()) * np.float32(radius))
     assert len(beams) == 256
     results = []
-    for variant in (64, 16, 48 | 128, 0):
+    for variant in (64, 64 | 256, 64 | 512, 16, 48 | 128, 0):
         upd = ra.PCDSensorUpdaterHip(hm)
         upd.init()
         upd.set_variant(variant)

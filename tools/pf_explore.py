@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""GPU perf exploration of the particle-filter update (config C4 and smaller)."""
+"""GPU perf exploration of the particle-filter update (config C4): kernel generations and their knobs.
+usage: python tools/pf_explore.py [sphere|room] [variant ...]"""
 import math
 import os
 import sys
@@ -10,13 +11,19 @@ import numpy as np
 import rmcl_amd as ra
 from rmcl_amd import synthetic as syn, types as T
 
+LEGACY, BIG, MAPTREE = 256, 512, 1024
+NAMES = {64 | LEGACY | MAPTREE: "round-2 kernel, map tree (leaves<=4)", 64 | LEGACY: "round-2 kernel, filter tree (leaves<=2)",
+         64 | MAPTREE: "round-3 kernel, map tree", 64: "round-3 kernel (default)", 48: "round-3, refill at 32 idle",
+         32: "round-3, refill at 16 idle", 64 | BIG: "round-3, 4096 rays per workgroup"}
+
 mesh = sys.argv[1] if len(sys.argv) > 1 else "sphere"
+variants = [int(a) for a in sys.argv[2:]] or list(NAMES)
 ctx = ra.Context(0)
 v, f = syn.uv_sphere(100000) if mesh == "sphere" else syn.noisy_room(100000)
 hm = ra.import_hip_map(ctx, v, f)
 print("map", hm.info())
 dirs = syn.model_directions(syn.model_pf16())
-for n_particles, n_beams in ((100000, 100), (100000, 256)):
+for n_particles, n_beams in ((100000, 256), (100000, 100)):
     if mesh == "sphere":
         poses, attrs = syn.uniform_particles(n_particles, seed=42, bb_min=(-5, -5, -1, 0, 0, -math.pi), bb_max=(5, 5, 1, 0, 0, math.pi))
     else:
@@ -24,13 +31,13 @@ for n_particles, n_beams in ((100000, 100), (100000, 256)):
     sel = np.linspace(0, len(dirs) - 1, n_beams).astype(int)
     beams = ra.beams_from_points(dirs[sel] * np.float32(6.0))
     d_poses, d_attrs = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
-    for variant in (16, 32, 48, 64):
+    for variant in variants:
         upd = ra.PCDSensorUpdaterHip(hm)
         upd.init()
         upd.set_variant(variant)
         upd.setInput(beams, T.identity())
-        ms = upd.time_update(d_poses, d_attrs, n_particles, iters=3)
+        ms = min(upd.time_update(d_poses, d_attrs, n_particles, iters=4) for _ in range(3))
         rays = n_particles * n_beams
-        print("particles=%7d beams=%4d variant=%d: %9.3f ms  %7.3f Grays/s  %9.1f particle-updates/s" %
-              (n_particles, n_beams, variant, ms, rays / ms / 1e6, n_particles / ms * 1e3), flush=True)
+        print("%s particles=%7d beams=%4d variant=%4d %-42s %8.3f ms  %7.3f Grays/s" %
+              (mesh, n_particles, n_beams, variant, NAMES.get(variant, ""), ms, rays / ms / 1e6), flush=True)
         upd.close()
