@@ -13,8 +13,13 @@ process per GPU, a different pose per rank, no data-path collective ("replicas o
 the ranks (weak scaling: 100k per GPU) and ONE RCCL all-gather of the 4 B x N weights per step.
 
   python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus N ...          (launched plainly: spawns its own N ranks, one per GPU, and waits for them)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
+
+Every run (any N) also reports `extras.pf_sharded`: config C5's per-GPU term -- 125 000 particles x 256 beams per GPU on the
+1M-triangle sphere, particles block-partitioned over the ranks, sensor update + ONE all-gather of the weights (RCCL when
+N > 1) + the {sum, max} all-reduce; at N = 8 that block IS config C5.
 
 Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events on the stream the kernel runs on
 (rmclhip_rcc_time_find / rmclhip_pf_time_update); `cpu_baseline` times the CPU oracle (a port -- the
@@ -92,8 +97,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        os.dup2(real_stdout, 1)
+        sys.exit(_self_launch(args.gpus, sys.argv[1:]))
     dist = None
     if args.all_on_device0:
         local_rank = 0
@@ -301,6 +307,12 @@ def main():
             extras["pf_sharded_cabi_allreduce_stats_ms"] = round(_median_call_ms(lambda: shp.stats(), reps=9, warm=1), 4)
             shp.close()
 
+        # config C5's per-GPU term, on every rank and for every N (the only BASELINE config that shards)
+        if not args.no_extras:
+            blk = _pf_sharded_block(ra, syn, T, np, torch, dist, ctx, rank, world)
+            if rank == 0:
+                extras["pf_sharded"] = blk
+
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle as orc  # cpu_baseline leg only: the oracle is the thing timed, never the product path
@@ -310,12 +322,20 @@ def main():
             # wake-up of the pool; output arrays are reused (fresh ones cost first-touch page faults in every worker)
             per_call = 8
             Tb = np.array([Tbm] * per_call, dtype=T.TRANSFORM)
-            buf = m.simulate_spherical(model, T.identity(), Tb, bvh=True, nthreads=cores)
+            # threads: what the cgroup lets this process use (the GPU boxes show 256 hardware threads under a 16-CPU quota)
+            usable, visible, quota = _cpu_quota()
+            buf = m.simulate_spherical(model, T.identity(), Tb, bvh=True, nthreads=usable)
             reps, t1 = 0, time.perf_counter()
             while time.perf_counter() - t1 < 8.0:
-                m.simulate_spherical(model, T.identity(), Tb, bvh=True, nthreads=cores, out=buf)
+                m.simulate_spherical(model, T.identity(), Tb, bvh=True, nthreads=usable, out=buf)
                 reps += per_call
             dt = time.perf_counter() - t1
+            # all visible threads, for the record (round 2 reported this row: oversubscribed under the quota)
+            ra_, ta = 0, time.perf_counter()
+            while visible != usable and time.perf_counter() - ta < 3.0:
+                m.simulate_spherical(model, T.identity(), Tb, bvh=True, nthreads=visible, out=buf)
+                ra_ += per_call
+            dta = time.perf_counter() - ta
             # 1-thread row: the same scan, one core, ~4 s
             one = m.simulate_spherical(model, T.identity(), Tb[:1], bvh=True, nthreads=1)
             r1, t2 = 0, time.perf_counter()
@@ -323,16 +343,19 @@ def main():
                 m.simulate_spherical(model, T.identity(), Tb[:1], bvh=True, nthreads=1, out=one)
                 r1 += 1
             dt1 = time.perf_counter() - t2
-            cpu = {"value": round(reps * n_rays / dt, 1), "unit": "rays/s", "cores": cores, "kind": "port",
+            cpu = {"value": round(reps * n_rays / dt, 1), "unit": "rays/s", "cores": usable, "kind": "port",
                    "one_thread_value": round(r1 * n_rays / dt1, 1),
-                   "sample": "%d x the same 128x1024 / 100k-triangle scan (8 per call) in %.1f s on all %d host threads (persistent "
-                             "pool, static chunks of 512 rays) + %d scans in %.1f s on ONE thread; CPU oracle (scalar BVH2 walk, same "
-                             "intersector, five output attributes)" % (reps, dt, cores, r1, dt1)}
+                   "all_visible_threads_value": (round(ra_ * n_rays / dta, 1) if ra_ else None),
+                   "host": {"visible_threads": visible, "cgroup_cpu_quota": quota, "threads_used": usable},
+                   "sample": "%d x the same 128x1024 / 100k-triangle scan (8 per call) in %.1f s on %d threads = the CPUs this "
+                             "process may use (affinity %d, cgroup cpu.max quota %s; persistent pool, static chunks of 512 rays) + "
+                             "%d scans in %.1f s on ONE thread; CPU oracle (scalar BVH2 walk, same intersector, five output "
+                             "attributes)" % (reps, dt, usable, visible, ("%.1f CPUs" % quota) if quota else "none", r1, dt1)}
             # traversal-traffic view of the roofline: B_trav = sum over rays of nodes_visited * 32 + triangles
             # tested * 36, counted by the instrumented oracle on the identical rays and a BVH2 / one-triangle-per-leaf
             # reference tree (deterministic), against the aggregate L2 rate of 34.5 TB/s
             m1 = orc.Mesh(v, f, max_leaf=1)
-            cnt = m1.simulate_spherical(model, T.identity(), Tb[:1], bvh=True, nthreads=cores, counters=True,
+            cnt = m1.simulate_spherical(model, T.identity(), Tb[:1], bvh=True, nthreads=usable, counters=True,
                                         want=("hits",))["counters"]
             b_trav = cnt["nodes_visited"] * 32 + cnt["tris_tested"] * 36
             extras["traversal_view"] = {
@@ -387,8 +410,8 @@ def main():
         units_per_step = n_local * n_beams
         kernel_ms = upd.time_update(d_poses, d_attrs, hi - lo, iters=5)
         b_alg = algorithmic_bytes_pf(hi - lo, n_beams)
-        kname = "k_pf_update"
-        traffic = measured_traffic("k_pf_update")
+        kname = "k_pf_update_v3<20, leaves <= 2>"
+        traffic = measured_traffic("k_pf_update_v3")
         extras["particle_updates_per_s"] = round(world * args.steps * n_local / elapsed, 1)
         extras["allgather_bytes"] = 4 * n_total
         metric = "particle-beam evaluations/s (100k particles x 256 beams per GPU, 100k-tri mesh)"
@@ -426,6 +449,140 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the same environment
+    contract torch.distributed.run provides), pass rank 0's stdout through (the ONE JSON line), wait for all of them.  If a
+    rank dies the others are terminated (they would wait in a collective forever)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=(None if r == 0 else subprocess.DEVNULL)))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for pr in list(alive):
+            code = pr.poll()
+            if code is None:
+                continue
+            alive.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in alive:
+                    other.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def _cpu_quota():
+    """host threads this process may actually use: min(affinity mask, cgroup CPU quota).  The GPU boxes of this pool show
+    256 hardware threads but run the job in a cgroup with cpu.max = 1600000 100000, i.e. 16 CPUs: more threads than that
+    only add scheduling overhead (round 2 measured 7.5x on "256 threads")."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                parts = fh.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    quota = float(parts[0]) / float(parts[1])
+            else:
+                q = float(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh2:
+                        quota = q / float(fh2.read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    eff = n if quota is None else max(1, min(n, int(math.ceil(quota))))
+    return eff, n, quota
+
+
+def _pf_sharded_block(ra, syn, T, np, torch, dist, ctx, rank, world, n_local=125000, n_beams=256, n_tri=1000000):
+    """config C5's per-GPU term on every rank: n_local particles x n_beams beams on the 1M-triangle sphere; the cloud of
+    world x n_local particles is block-partitioned, the map replicated; per step: fused sensor update, extraction of the
+    weights, ONE all-gather of 4 B x N (RCCL for world > 1), and the {sum, max} all-reduce the resampler needs."""
+    from rmcl_amd import distributed as D
+    v, f = syn.uv_sphere(n_tri)
+    t0 = time.perf_counter()
+    hm = ra.import_hip_map(ctx, v, f)
+    build_s = time.perf_counter() - t0
+    n_total = n_local * world
+    lo, hi = D.shard_bounds(n_total, rank, world)
+    # the same cloud on every world size: particle i is drawn from seed (42, i // n_local)
+    poses, attrs = syn.uniform_particles(n_local, seed=42 + rank, bb_min=(-5, -5, -1, 0, 0, -math.pi), bb_max=(5, 5, 1, 0, 0, math.pi))
+    beams = ra.beams_from_points(syn.model_directions(syn.model_pf16()) * np.float32(6.0))
+    upd = ra.PCDSensorUpdaterHip(hm)
+    upd.init()
+    upd.setInput(beams, T.identity())
+    d_poses, d_attrs = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
+    w_local = torch.empty(hi - lo, dtype=torch.float32, device="cuda")
+    sharded = D.ShardedSensorUpdate(upd, n_total, rank, world)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def reduce_max(x):
+        if dist is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def step():
+        if dist is not None:
+            w = sharded.update(d_poses, d_attrs, w_local)
+            D.allreduce_sum_max(w_local)
+            return w
+        upd.update(d_poses, d_attrs, n_particles=hi - lo)
+        upd.extract_weights(d_attrs, hi - lo, w_local.data_ptr())
+        return w_local
+
+    for _ in range(2):
+        step()
+    sync_all()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    step_ms = reduce_max((time.perf_counter() - t0) / reps * 1e3)
+    sync_all()
+    update_ms = reduce_max(upd.time_update(d_poses, d_attrs, hi - lo, iters=3))
+    ag_ms = 0.0
+    if dist is not None:
+        for _ in range(3):
+            D.allgather_weights(w_local, n_total)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            D.allgather_weights(w_local, n_total)
+        torch.cuda.synchronize()
+        ag_ms = reduce_max((time.perf_counter() - t0) / 20 * 1e3)
+    upd.close()
+    hm.release()
+    return {"shape": "C5 per GPU: %d particles x %d beams, UV-sphere %d triangles, %d GPU(s), %d particles in total" %
+                     (n_local, n_beams, n_tri, world, n_total),
+            "c5_shard_update_ms": round(update_ms, 4), "c5_step_ms": round(step_ms, 4), "c5_allgather_ms": round(ag_ms, 4),
+            "allgather_bytes": 4 * n_total, "collective": ("RCCL all_gather_into_tensor + 2 all_reduce" if dist is not None else "none (1 GPU)"),
+            "particle_beam_evals_per_s": round(n_total * n_beams / (step_ms * 1e-3), 1),
+            "particle_updates_per_s": round(n_total / (step_ms * 1e-3), 1), "map_build_upload_s": round(build_s, 2)}
 
 
 def _pf_c4(ra, syn, T, np, ctx, hm, n_particles, n_beams, iters):

@@ -151,6 +151,16 @@ const char* rmclhip_version(void);
  * creator's, and the context is freed with its last holder -- destroy order does not matter. */
 rmclhip_status rmclhip_ctx_create(int device, rmclhip_ctx** out);
 void rmclhip_ctx_destroy(rmclhip_ctx* ctx);
+
+/* How the SYNCHRONOUS calls that return a result through host-mapped memory (computeCrossStatistics, correct_once,
+ * micp_correct_once) wait for it.  RMCLHIP_WAIT_SPIN (default): the calling thread polls a completion tag the last kernel
+ * of the call writes (sequence number + checksum of the result, verified by the host) -- ~9 us less latency per call, one
+ * busy host core while a call is in flight.  RMCLHIP_WAIT_BLOCK: hipStreamSynchronize -- the thread sleeps in the runtime.
+ * The reference's node has ONE correction thread per node (micp_localization.cpp:300-302); integrators who cannot spare a
+ * spinning core choose BLOCK.  Applies to every handle of the context, may be changed at any time. */
+#define RMCLHIP_WAIT_SPIN 0
+#define RMCLHIP_WAIT_BLOCK 1
+rmclhip_status rmclhip_ctx_set_wait_mode(rmclhip_ctx* ctx, int mode);
 rmclhip_status rmclhip_ctx_device_name(rmclhip_ctx* ctx, char* buf, size_t n);
 
 /* ---- map ------------------------------------------------------------------------
@@ -406,8 +416,15 @@ rmclhip_status rmclhip_pf_time_update(rmclhip_pf* pf, const rmclhip_transform* p
 /* bits 0..3: traversal (0 = while-while with the hybrid LDS + scratch stack, 1 = stack entirely in LDS, 2 = single
  * loop, A/B); bits 4..6: ray scheduling (0 = rounds of one ray per lane; 1..4 = persistent lanes that fetch the
  * next ray when 8 / 16 / 32 / 48 lanes of their wave are idle); bit 7: persistent lanes on the 128-B nodes instead
- * of their 64-B quantised twins (A/B).  A fresh handle uses traversal 0, refill at 48, quantised nodes. */
+ * of their 64-B quantised twins (A/B); bit 8: the round-2 kernel on the quantised nodes (A/B); bit 9: 4096 instead of
+ * 2048 rays per workgroup (A/B); bit 10: traverse the map's tree (leaves <= 4 triangles) instead of the filter's own
+ * (leaves <= 2, rmclhip_bvh_build_host_pf).  A fresh handle uses traversal 0, refill at 48, quantised nodes of the
+ * filter's tree, the round-3 kernel. */
 rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* pf, int variant);
+/* schedule of the persistent-lane kernel: a wave fetches new beams once `refill_idle_lanes` of its lanes are idle (0: the
+ * threshold selected by set_variant) and leaves its node phase when at most `tail_lanes` lanes still descend while
+ * another holds a leaf (default 8).  The result does not depend on either (tests/test_gpu_pf.py). */
+rmclhip_status rmclhip_pf_set_schedule(rmclhip_pf* pf, uint32_t refill_idle_lanes, uint32_t tail_lanes);
 /* Beam sampling of PCDSensorUpdater{Embree,Optix}::update (PCDSensorUpdaterEmbree.cpp:276-327) on the raw
  * sensor_msgs/PointCloud2 bytes (HOST function, no device needed): `samples` uniformly random points, each with up to 100
  * retries for one without NaN, become RangeMeasurements {orig 0, dir = p / |p|, range = |p|, cov = 0.1 I}.  The reference

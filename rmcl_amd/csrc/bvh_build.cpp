@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <limits>
@@ -39,7 +40,8 @@ struct Node2 {
   bool leaf() const { return left < 0; }
 };
 
-constexpr int kBins = 16;
+constexpr int kMaxBins = 64;
+static int kBins = 16;
 
 struct Builder {
   const std::vector<Prim>& prims;
@@ -81,8 +83,8 @@ struct Builder {
       for (int axis = 0; axis < 3; ++axis) {
         const float ext = cb.mx[axis] - cb.mn[axis];
         if (!(ext > 0.f)) continue;
-        Box bb[kBins];
-        uint32_t bc[kBins];
+        Box bb[kMaxBins];
+        uint32_t bc[kMaxBins];
         for (int b = 0; b < kBins; ++b) { bb[b].reset(); bc[b] = 0; }
         const float scale = static_cast<float>(kBins) / ext;
         for (uint32_t i = t.first; i < t.first + t.count; ++i) {
@@ -91,8 +93,8 @@ struct Builder {
           bc[b]++;
           bb[b].grow(p.b);
         }
-        float la[kBins - 1], ra[kBins - 1];
-        uint32_t lc[kBins - 1], rc[kBins - 1];
+        float la[kMaxBins - 1], ra[kMaxBins - 1];
+        uint32_t lc[kMaxBins - 1], rc[kMaxBins - 1];
         Box acc;
         acc.reset();
         uint32_t c = 0;
@@ -298,6 +300,7 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
     scene.grow(p.b);
   }
 
+  if (const char* e = std::getenv("RMCLHIP_BINS")) kBins = std::max(2, std::min(kMaxBins, std::atoi(e)));
   // ONE BVH2, split down to the smallest leaf size any tree of the map uses
   std::vector<uint32_t> order(nf);
   for (uint32_t f = 0; f < nf; ++f) order[f] = f;

@@ -95,12 +95,24 @@ struct DevBuf {
 
 }  // namespace
 
+// Upload on the handle's OWN stream, then wait for it.  A plain hipMemcpy runs on the null stream, which the handles'
+// hipStreamNonBlocking streams do not synchronise with: a copy from pageable memory may return once the data is staged,
+// and a kernel enqueued on the handle's stream right afterwards is then not ordered behind the DMA.  (Observed as a
+// 1-in-200 deviation of 5e-7 rad in a correction issued immediately after set_dataset, tools/flaky_g5.py.)
+static inline hipError_t upload_on(hipStream_t s, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  if (bytes == 0) return hipSuccess;
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  return e;
+}
+
 struct rmclhip_ctx {
   int device = 0;
   hipDeviceProp_t props;
   // map / rcc / pf / resampler handles keep a pointer to their context: each holds a reference, and
   // rmclhip_ctx_destroy only drops the creator's, so destroying the context before its children is safe
   std::atomic<int> refs{1};
+  std::atomic<int> wait_block{0};   // rmclhip_ctx_set_wait_mode: 0 = spin on the completion tag, 1 = block in hipStreamSynchronize
 };
 
 namespace {
@@ -187,6 +199,9 @@ struct rmclhip_rcc {
   DevBuf<unsigned long long> d_fast_mask;
   MicpFastStatus* h_fast_status = nullptr;      // pinned, host-mapped
   MicpFastStatus* h_fast_status_dev = nullptr;
+  unsigned long long* h_done = nullptr;         // pinned, host-mapped completion tags: [0] this handle's chains, [1] the N-sensor loop
+  unsigned long long* h_done_dev = nullptr;
+  uint32_t done_seq = 0;                        // sequence number of the last polled call (never 0 in a tag)
   hipGraphExec_t micp_fast_exec = nullptr;
   hipGraph_t micp_fast_graph = nullptr;
   float fast_rho_cap = 0.02f, fast_tau_cap = 0.1f;   // bounds on |2 sin(theta/2)| and |t| of the pre-transforms
@@ -233,6 +248,7 @@ struct rmclhip_pf {
   size_t h_beams_cap = 0;
   float* errors_dev = nullptr;
   int variant = 0;
+  uint32_t refill_thr = 0, tail_lanes = 8;  // schedule knobs of the round-3 kernel (0: from `refill`); rmclhip_pf_set_schedule
   bool beams_at_origin = false;  // of the beams uploaded last: all start at the sensor origin
   bool legacy = false;      // A/B: the round-2 kernel (k_pf_update_persist)
   bool big_blocks = false;  // A/B: 4096 rays per workgroup
@@ -282,6 +298,13 @@ rmclhip_status rmclhip_ctx_create(int device, rmclhip_ctx** out) {
 }
 
 void rmclhip_ctx_destroy(rmclhip_ctx* ctx) { ctx_release(ctx); }
+
+rmclhip_status rmclhip_ctx_set_wait_mode(rmclhip_ctx* ctx, int mode) {
+  ApiGuard guard_("rmclhip_ctx_set_wait_mode");
+  if (!ctx || (mode != RMCLHIP_WAIT_SPIN && mode != RMCLHIP_WAIT_BLOCK)) return fail(RMCLHIP_ERR_INVALID, "ctx_set_wait_mode: bad arguments");
+  ctx->wait_block.store(mode == RMCLHIP_WAIT_BLOCK ? 1 : 0);
+  return RMCLHIP_OK;
+}
 
 rmclhip_status rmclhip_ctx_device_name(rmclhip_ctx* ctx, char* buf, size_t n) {
   ApiGuard guard_("rmclhip_ctx_device_name");
@@ -400,6 +423,9 @@ static rmclhip_status map_upload(rmclhip_ctx* ctx, const BvhHost& bvh, rmclhip_m
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_cnodes), cb);
   if (e == hipSuccess) e = hipMemcpy(m->d_cnodes, bvh.cnodes.data(), cb, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(m->d_tris, bvh.tris.data(), tb, hipMemcpyHostToDevice);
+  // the map is read by kernels on the handles' non-blocking streams, which do not synchronise with the null stream these
+  // copies ran on: make sure every byte has landed before the handle is handed out
+  if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
     if (m->d_nodes) (void)hipFree(m->d_nodes);
     if (m->d_qnodes) (void)hipFree(m->d_qnodes);
@@ -467,6 +493,9 @@ rmclhip_status rmclhip_rcc_create(rmclhip_ctx* ctx, rmclhip_map* map, rmclhip_rc
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->d_state), 2 * sizeof(MicpState));
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_fast_status), sizeof(MicpFastStatus), hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&r->h_fast_status_dev), r->h_fast_status, 0);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_done), 2 * sizeof(unsigned long long), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&r->h_done_dev), r->h_done, 0);
+  if (e == hipSuccess) r->h_done[0] = r->h_done[1] = 0ull;
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->d_counter), sizeof(uint32_t));
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_call), sizeof(MicpCall), hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->d_call), sizeof(MicpCall));
@@ -506,6 +535,7 @@ void rmclhip_rcc_destroy(rmclhip_rcc* r) {
   if (r->micp_fast_exec) DBG_STEP(hipGraphExecDestroy(r->micp_fast_exec));
   if (r->micp_fast_graph) DBG_STEP(hipGraphDestroy(r->micp_fast_graph));
   if (r->h_fast_status) DBG_STEP(hipHostFree(r->h_fast_status));
+  if (r->h_done) DBG_STEP(hipHostFree(r->h_done));
   r->d_fast_partials.release(); r->d_fast_mask.release();
   r->d_multi_blob.release();
   if (r->h_multi_state) DBG_STEP(hipHostFree(r->h_multi_state));
@@ -555,7 +585,7 @@ rmclhip_status rmclhip_rcc_set_model_spherical(rmclhip_rcc* r, const rmclhip_sph
     tab[2 * H + W + h] = sinf(th);
   }
   HIPCHK(r->d_model_tab.reserve(tab.size()));
-  HIPCHK(hipMemcpy(r->d_model_tab.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(upload_on(r->stream, r->d_model_tab.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
   return RMCLHIP_OK;
 }
 
@@ -576,7 +606,7 @@ rmclhip_status rmclhip_rcc_set_model_o1dn(rmclhip_rcc* r, uint32_t width, uint32
   if (n == 0) return RMCLHIP_OK;
   if (!dirs) return fail(RMCLHIP_ERR_INVALID, "rcc_set_model_o1dn: dirs is null");
   HIPCHK(r->d_model_tab.reserve(3 * n));
-  HIPCHK(hipMemcpy(r->d_model_tab.p, dirs, 3 * n * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(upload_on(r->stream, r->d_model_tab.p, dirs, 3 * n * sizeof(float), hipMemcpyHostToDevice));
   return RMCLHIP_OK;
 }
 
@@ -615,8 +645,8 @@ rmclhip_status rmclhip_rcc_set_model_ondn(rmclhip_rcc* r, uint32_t width, uint32
   if (n == 0) return RMCLHIP_OK;
   if (!origs || !dirs) return fail(RMCLHIP_ERR_INVALID, "rcc_set_model_ondn: origs / dirs is null");
   HIPCHK(r->d_model_tab.reserve(6 * n));
-  HIPCHK(hipMemcpy(r->d_model_tab.p, origs, 3 * n * sizeof(float), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(r->d_model_tab.p + 3 * n, dirs, 3 * n * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(upload_on(r->stream, r->d_model_tab.p, origs, 3 * n * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(upload_on(r->stream, r->d_model_tab.p + 3 * n, dirs, 3 * n * sizeof(float), hipMemcpyHostToDevice));
   return RMCLHIP_OK;
 }
 
@@ -639,10 +669,10 @@ rmclhip_status rmclhip_rcc_set_dataset(rmclhip_rcc* r, const float* pts, const u
   if (n == 0) return RMCLHIP_OK;
   const hipMemcpyKind kind = src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   HIPCHK(r->d_ds_points.reserve(3 * static_cast<size_t>(n)));
-  HIPCHK(hipMemcpy(r->d_ds_points.p, pts, 3 * static_cast<size_t>(n) * sizeof(float), kind));
+  HIPCHK(upload_on(r->stream, r->d_ds_points.p, pts, 3 * static_cast<size_t>(n) * sizeof(float), kind));
   if (mask) {
     HIPCHK(r->d_ds_mask.reserve(n));
-    HIPCHK(hipMemcpy(r->d_ds_mask.p, mask, n, kind));
+    HIPCHK(upload_on(r->stream, r->d_ds_mask.p, mask, n, kind));
   }
   r->ds_pts = r->d_ds_points.p;
   r->ds_msk = mask ? r->d_ds_mask.p : nullptr;
@@ -678,7 +708,7 @@ rmclhip_status rmclhip_rcc_set_dataset_from_ranges(rmclhip_rcc* r, const float* 
   // stage the ranges in the (not yet used) ranges model buffer region of a scratch allocation
   DevBuf<float> d_r;
   HIPCHK(d_r.reserve(n));
-  hipError_t e = hipMemcpy(d_r.p, ranges, n * sizeof(float), hipMemcpyHostToDevice);
+  hipError_t e = upload_on(r->stream, d_r.p, ranges, n * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemsetAsync(r->d_counter, 0, sizeof(uint32_t), r->stream);
   if (e == hipSuccess)
     e = launch_dataset_from_ranges(d_r.p, r->d_model_tab.p, r->kind, r->W, r->H, r->orig, r->pin_fc, r->range.min, r->range.max,
@@ -953,7 +983,8 @@ struct ReduceTail {
   xform Tbo = xidentity();
   MicpState* state = nullptr;
   xform* Tdelta_out = nullptr;
-  uint32_t* done = nullptr;   // host-mapped completion word (kTailStats, one pose, unfused tail)
+  unsigned long long* done = nullptr;   // host-mapped completion tag (kTailStats, one pose, unfused tail)
+  uint32_t seq = 0;                     // ... and the sequence number it must carry
 };
 
 static rmclhip_status reduce_enqueue(rmclhip_rcc* r, const xform& Tpre, const xform* Tpre_dev, float max_dist,
@@ -995,7 +1026,7 @@ static rmclhip_status reduce_enqueue(rmclhip_rcc* r, const xform& Tpre, const xf
   p.tail_mode = r->fused_tail ? tail.mode : static_cast<uint32_t>(kTailNone);
   HIPCHK(launch_reduce_partials(p, r->stream));
   if (!r->fused_tail) {
-    if (tail.mode == kTailStats) HIPCHK(launch_reduce_finalize(r->d_partials.p, nb, nposes, tail.stats_out, tail.done, r->stream));
+    if (tail.mode == kTailStats) HIPCHK(launch_reduce_finalize(r->d_partials.p, nb, nposes, tail.stats_out, tail.done, tail.seq, r->stream));
     else if (tail.mode == kTailMicp) HIPCHK(launch_micp_step(r->d_partials.p, nb, r->Tsb, tail.Tbo, tail.call, tail.state, tail.state, r->stream));
     else if (tail.mode == kTailBatchSolve)
       HIPCHK(launch_batch_solve(r->d_partials.p, nb, nposes, r->Tsb, tail.Tdelta_out, tail.stats_out, r->stream));
@@ -1003,20 +1034,53 @@ static rmclhip_status reduce_enqueue(rmclhip_rcc* r, const xform& Tpre, const xf
   return RMCLHIP_OK;
 }
 
-// Wait for a completion word in host-mapped memory that the LAST kernel of a chain writes after its results (pinned host
-// writes + __threadfence_system), instead of hipStreamSynchronize: the word arrives ~9 us before the stream's completion
-// signal has made its way through the runtime (measured on the MICP loop: 84 -> 75 us per correction).  Everything the chain
-// wrote is complete when the word is seen (it is the chain's last store).  Falls back to the stream after 20 ms.
-static hipError_t wait_word(volatile const uint32_t* word, uint32_t pending, hipStream_t stream) {
+// Wait for the completion tag the LAST kernel of a chain stores in host-mapped memory after its results (kernels.hip
+// publish_tag), instead of hipStreamSynchronize: the tag arrives ~9 us before the stream's completion signal has made its way
+// through the runtime (measured on the MICP loop: 84 -> 75 us per correction).
+// A flag alone is NOT a sound hand-off here: round 3 measured (tools/determinism2.py, 1 in ~10^4 calls) the host seeing the
+// flag of the current call while the result block -- written before the kernel's __threadfence_system(), but to another host
+// allocation -- still held the previous call's values.  So the tag carries {sequence number of the call, xor of every
+// result word}: the result is accepted only when the sequence number is this call's AND the words the host reads add up to
+// the tag's sum; otherwise polling continues.  20 ms without an acceptable tag, or wait mode "block"
+// (rmclhip_ctx_set_wait_mode), falls back to the stream.
+static inline uint32_t xor_host(const void* p, size_t bytes) {
+  const volatile uint32_t* w = static_cast<const volatile uint32_t*>(p);
+  uint32_t x = 0;
+  for (size_t i = 0; i < bytes / 4; ++i) x ^= w[i];
+  return x;
+}
+static inline uint32_t next_seq(rmclhip_rcc* r) {
+  if (++r->done_seq == 0u) r->done_seq = 1u;
+  return r->done_seq;
+}
+// what the tag's sum covers: `base` always; the `extra` blocks only when *code == 0 (a status block's "done", the exits that
+// also wrote a state block) or when there is no code word
+struct DoneCheck {
+  const void* base = nullptr; size_t base_bytes = 0;
+  const volatile uint32_t* code = nullptr;
+  const void* extra[3] = {nullptr, nullptr, nullptr}; size_t extra_bytes[3] = {0, 0, 0};
+};
+static inline uint32_t done_sum(const DoneCheck& c) {
+  uint32_t x = xor_host(c.base, c.base_bytes);
+  if (c.code == nullptr || *c.code == 0u)
+    for (int k = 0; k < 3; ++k) if (c.extra[k]) x ^= xor_host(c.extra[k], c.extra_bytes[k]);
+  return x;
+}
+static hipError_t wait_done(const rmclhip_ctx* ctx, volatile const unsigned long long* tag, uint32_t seq, const DoneCheck& chk,
+                            hipStream_t stream) {
+  if (ctx->wait_block.load(std::memory_order_relaxed)) return hipStreamSynchronize(stream);
   const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
-  for (uint32_t spins = 0; *word == pending; ++spins) {
+  for (uint32_t spins = 0;; ++spins) {
+    const unsigned long long t = *tag;
+    if (static_cast<uint32_t>(t) == seq) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      if (done_sum(chk) == static_cast<uint32_t>(t >> 32)) return hipSuccess;
+    }
 #if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
 #endif
     if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() > t_end) return hipStreamSynchronize(stream);
   }
-  std::atomic_thread_fence(std::memory_order_acquire);
-  return hipSuccess;
 }
 
 static float adaptive_max_dist(const rmclhip_rcc* r, double p) {
@@ -1035,13 +1099,14 @@ rmclhip_status rmclhip_rcc_compute_cross_statistics(rmclhip_rcc* r, const rmclhi
   tail.mode = kTailStats;
   tail.stats_out = r->h_stats_dev;  // host-mapped: the finalize launch writes the 64-B result straight to the host
   const bool polled = !r->fused_tail;
-  if (polled) { tail.done = &r->h_fast_status_dev->pad[2]; r->h_fast_status->pad[2] = 0u; }
+  if (polled) { tail.done = r->h_done_dev; tail.seq = next_seq(r); }
   HIPCHK(hipEventRecord(r->ev0, r->stream));
   if (rmclhip_status st = reduce_enqueue(r, to_x(T_snew_sold), nullptr, adaptive_max_dist(r, convergence_progress), 1, tail))
     return st;
   HIPCHK(hipEventRecord(r->ev1, r->stream));
   if (polled) {
-    HIPCHK(wait_word(&r->h_fast_status->pad[2], 0u, r->stream));
+    DoneCheck chk; chk.base = &r->h_stats[0]; chk.base_bytes = sizeof(cstats);
+    HIPCHK(wait_done(r->ctx, r->h_done, tail.seq, chk, r->stream));
     r->reduce_timing_pending = true;   // the events are read when rmclhip_rcc_last_kernel_ms asks for them
   } else {
     HIPCHK(hipStreamSynchronize(r->stream));
@@ -1135,6 +1200,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
     r->h_call->max_dist = maxd;
     r->h_call->rho_cap = r->fast_rho_cap;
     r->h_call->tau_cap = r->fast_tau_cap;
+    r->h_call->seq = next_seq(r);
     // ---- moment form first (kernels.hip "gate-stable moment form"); any outcome other than "done" falls through to the
     // per-iteration form below, which recomputes the correction from scratch
     const bool fast_eligible = r->fast_mode != 0 && r->use_graph && r->loop_blocks == 0 && !r->fused_tail && n_iter >= 2u &&
@@ -1169,7 +1235,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
         if (le == hipSuccess)
           le = launch_micp_fast(r->ds_pts, r->ds_has_mask ? r->ds_msk : nullptr, r->d_points.p, r->d_normals.p, r->d_hits.p, nred,
                                 r->d_call, r->d_fast_partials.p, r->d_fast_mask.p, n_iter, r->h_state_dev, r->h_fast_status_dev,
-                                r->stream);
+                                r->h_done_dev, r->stream);
         r->capturing = false;
         hipGraph_t g = nullptr;
         const hipError_t ce = hipStreamEndCapture(r->stream, &g);
@@ -1180,9 +1246,11 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
         r->micp_fast_key = key;
         r->fast_graph_dirty = false;
       }
-      r->h_fast_status->code = 0xFFFFFFFFu;
       HIPCHK(hipGraphLaunch(r->micp_fast_exec, r->stream));
-      HIPCHK(wait_word(&r->h_fast_status->code, 0xFFFFFFFFu, r->stream));
+      // sum of the tag: the status block, plus the state block when the loop ran to its end (code 0)
+      DoneCheck chk; chk.base = r->h_fast_status; chk.base_bytes = sizeof(MicpFastStatus); chk.code = &r->h_fast_status->code;
+      chk.extra[0] = r->h_state; chk.extra_bytes[0] = sizeof(MicpState);
+      HIPCHK(wait_done(r->ctx, r->h_done, r->h_call->seq, chk, r->stream));
       const MicpFastStatus fs = *r->h_fast_status;
       r->fast_info.attempts++;
       r->fast_info.last_code = fs.code;
@@ -1205,8 +1273,10 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
       if (fs.code != 1u && fs.code != 2u) return fail(RMCLHIP_ERR_HIP, "correct_once: the moment-form loop did not report a status");
       if (fs.code == 2u) r->fast_info.overflows++; else r->fast_info.cap_exits++;
     }
-    // the one-launch-per-iteration chain ends with k_micp_close, which sets a completion word the host polls
+    // the one-launch-per-iteration chain ends with k_micp_close, which publishes a completion tag the host polls (a fresh
+    // sequence number: the moment-form attempt above may have published one for this call already)
     const bool polled = r->loop_blocks == 0 && !r->fused_tail && n_iter > 0;
+    r->h_call->seq = next_seq(r);
     auto enqueue_chain = [&]() -> rmclhip_status {
       HIPCHK(hipMemcpyAsync(r->d_call, r->h_call, sizeof(MicpCall), hipMemcpyHostToDevice, r->stream));
       FindParams p;
@@ -1237,7 +1307,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
                                   i == 0, r->stream));
         // the closing step writes the result straight into host-mapped memory (no copy node)
         HIPCHK(launch_micp_close(part[(n_iter - 1u) & 1u], nb, r->d_call, r->d_state + (n_iter & 1u), r->h_state_dev,
-                                 &r->h_fast_status_dev->pad[2], r->stream));
+                                 r->h_done_dev, r->stream));
         final_state = nullptr;
       } else
       for (uint32_t i = 0; i < n_iter; ++i) {
@@ -1276,13 +1346,14 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
         r->micp_key = key;
         r->graph_dirty = false;
       }
-      r->h_fast_status->pad[2] = 0u;
       HIPCHK(hipGraphLaunch(r->micp_exec, r->stream));
     } else {
-      r->h_fast_status->pad[2] = 0u;
       if (rmclhip_status st = enqueue_chain()) return st;
     }
-    if (polled) HIPCHK(wait_word(&r->h_fast_status->pad[2], 0u, r->stream));
+    if (polled) {
+      DoneCheck chk; chk.base = r->h_state; chk.base_bytes = sizeof(MicpState);
+      HIPCHK(wait_done(r->ctx, r->h_done, r->h_call->seq, chk, r->stream));
+    }
     else HIPCHK(hipStreamSynchronize(r->stream));
     if (fast_tried) {
       // the pre-transform this correction ended with bounds the next attempt (iterates approach it monotonically in the
@@ -1317,9 +1388,12 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
     tail.mode = kTailStats;
     tail.stats_out = r->h_stats_dev;
     const bool polled = !r->fused_tail;
-    if (polled) { tail.done = &r->h_fast_status_dev->pad[2]; r->h_fast_status->pad[2] = 0u; }
+    if (polled) { tail.done = r->h_done_dev; tail.seq = next_seq(r); }
     if (rmclhip_status st = reduce_enqueue(r, xidentity(), nullptr, maxd, 1, tail)) return st;
-    if (polled) HIPCHK(wait_word(&r->h_fast_status->pad[2], 0u, r->stream));
+    if (polled) {
+      DoneCheck chk; chk.base = &r->h_stats[0]; chk.base_bytes = sizeof(cstats);
+      HIPCHK(wait_done(r->ctx, r->h_done, tail.seq, chk, r->stream));
+    }
     else HIPCHK(hipStreamSynchronize(r->stream));
     const cstats Cs_o = cs_transform(Tbo, cs_transform(r->Tsb, r->h_stats[0]));
     last = cs_merge(cs_identity(), Cs_o);
@@ -1373,6 +1447,7 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
     h_call.nblocks[s] = nb;
   }
   h_call.n_sensors = n_sensors;
+  h_call.seq = next_seq(r0);
   // call + state live with the first sensor and persist between calls (an allocation per call cost more than the loop)
   HIPCHK(r0->d_multi_blob.reserve(sizeof(MicpMultiCall) + sizeof(MicpMultiState)));
   if (!r0->h_multi_state) {
@@ -1425,9 +1500,15 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
     fp.n_iter = n_iter;
     fp.state_out = r0->h_multi_state_dev;
     fp.status = r0->h_multi_status_dev;
-    r0->h_multi_status->code = 0xFFFFFFFFu;
+    fp.done = r0->h_done_dev + 1;
     HIPCHK(launch_micp_multi_fast_loop(fp, st));
-    HIPCHK(wait_word(&r0->h_multi_status->code, 0xFFFFFFFFu, st));
+    {
+      DoneCheck chk; chk.base = r0->h_multi_status; chk.base_bytes = sizeof(MicpMultiFastStatus); chk.code = &r0->h_multi_status->code;
+      chk.extra[0] = &r0->h_multi_state->T_onew_oold; chk.extra_bytes[0] = sizeof(xform);
+      chk.extra[1] = &r0->h_multi_state->merged_o; chk.extra_bytes[1] = sizeof(cstats);
+      chk.extra[2] = &r0->h_multi_state->merged_weighted_o; chk.extra_bytes[2] = sizeof(cstats);
+      HIPCHK(wait_done(r0->ctx, r0->h_done + 1, h_call.seq, chk, st));
+    }
     const MicpMultiFastStatus fs = *r0->h_multi_status;
     for (uint32_t s = 0; s < n_sensors; ++s) {
       rmclhip_rcc* r = sensors[s];
@@ -1915,6 +1996,9 @@ static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, 
   if (static_cast<size_t>(pb) * n_beams > 8192u) return fail(RMCLHIP_ERR_UNSUPPORTED, "pf_update: more than 8192 beams");
   p.particles_per_block = pb;
   p.beams_at_origin = f->beams_at_origin ? 1u : 0u;
+  static const uint32_t kRefillAt[5] = {48u, 8u, 16u, 32u, 48u};
+  p.refill_thr = f->refill_thr ? f->refill_thr : kRefillAt[f->refill];
+  p.tail_lanes = f->tail_lanes;
   p.nb_magic = static_cast<uint32_t>((1ull << 32) / n_beams) + 1u;   // pb * n_beams <= 8192, n_beams <= 8192: exact
   const int variant = (f->variant & 3) | ((std::max(f->map->info.stack_need, f->map->info.stack_need_pf) > 32) ? 4 : 0) | (f->params.correspondence_type == 1u ? 8 : 0) |
                       (f->refill << 4) | (f->full_nodes ? 128 : 0) | (f->legacy ? 256 : 0) | (f->pf_tree ? 0 : 1024);
@@ -1993,6 +2077,14 @@ rmclhip_status rmclhip_pf_time_update(rmclhip_pf* f, const rmclhip_transform* po
   float total = 0.f;
   HIPCHK(hipEventElapsedTime(&total, f->ev0, f->ev1));
   *ms = total / static_cast<float>(iters);
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_pf_set_schedule(rmclhip_pf* f, uint32_t refill_idle_lanes, uint32_t tail_lanes) {
+  ApiGuard guard_("rmclhip_pf_set_schedule");
+  if (!f || refill_idle_lanes > 64u || tail_lanes > 64u) return fail(RMCLHIP_ERR_INVALID, "pf_set_schedule: bad arguments");
+  f->refill_thr = refill_idle_lanes;
+  f->tail_lanes = tail_lanes;
   return RMCLHIP_OK;
 }
 
@@ -2346,6 +2438,7 @@ rmclhip_status rmclhip_pf_sharded_set_particles(rmclhip_pf_sharded* h, const rmc
     if (R.hi > R.lo) {
       HIPCHK(hipMemcpy(R.d_poses, poses + R.lo, static_cast<size_t>(R.hi - R.lo) * 32, hipMemcpyHostToDevice));
       HIPCHK(hipMemcpy(R.d_attrs, attrs + R.lo, static_cast<size_t>(R.hi - R.lo) * 36, hipMemcpyHostToDevice));
+      HIPCHK(hipDeviceSynchronize());   // consumers run on non-blocking streams (see upload_on)
     }
   }
   h->n_total = n_total;
@@ -2591,7 +2684,10 @@ rmclhip_status rmclhip_memcpy_h2d(rmclhip_ctx* ctx, void* dst, const void* src, 
   ApiGuard guard_("rmclhip_memcpy_h2d");
   if (!ctx || (bytes && (!dst || !src))) return fail(RMCLHIP_ERR_INVALID, "memcpy_h2d: null");
   HIPCHK(hipSetDevice(ctx->device));
-  if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  if (bytes) {
+    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipDeviceSynchronize());   // consumers run on non-blocking streams (see upload_on)
+  }
   return RMCLHIP_OK;
 }
 

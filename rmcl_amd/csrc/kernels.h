@@ -94,6 +94,8 @@ struct PfParams {
   float ray_tfar;                // inf (Embree updater :27) or 1e4 (optixTrace tmax, BeamEvaluateProgram.cu:48)
   uint32_t beams_at_origin;      // every beam starts at (0,0,0) of the sensor frame (what PCDSensorUpdaterEmbree::update builds,
                                  // :314-327): Tsm * orig is Tsm.t, the rotation of a zero vector is skipped
+  uint32_t refill_thr, tail_lanes;  // schedule of the persistent-lane kernel: refill when >= refill_thr lanes of a wave are idle;
+                                 // leave the node phase when <= tail_lanes lanes still descend and a lane holds a leaf
   uint32_t nb_magic;             // floor(2^32 / n_beams) + 1: ray index / n_beams = umulhi(ray, nb_magic) for ray * n_beams < 2^32
 };
 
@@ -104,7 +106,8 @@ struct MicpCall {
   xform Tsb, Tbo;
   float max_dist;
   float rho_cap, tau_cap;   // moment form of the loop (launch_micp_fast): bounds on the pre-transforms it may meet
-  uint32_t pad[5];
+  uint32_t seq;             // sequence number of this call: echoed in the completion tag the chain's last kernel publishes
+  uint32_t pad[4];
 };
 
 // MICP-L inner-loop state kept on the device between launches (correct_once)
@@ -127,7 +130,7 @@ inline uint32_t micp_fast_blocks(uint32_t n) {
 hipError_t launch_micp_fast(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
                             const float* model_normals, const uint8_t* model_mask, uint32_t n, const MicpCall* call,
                             double* partials, unsigned long long* unc_mask, uint32_t n_iter, MicpState* state_out,
-                            MicpFastStatus* status, hipStream_t s);
+                            MicpFastStatus* status, unsigned long long* done, hipStream_t s);
 
 // N-sensor MICP loop on the device (micp_localization.cpp:900-964): per-call frames + per-sensor partials, one step launch per
 // iteration merges every sensor's statistics (weighted and unweighted), solves once and hands every sensor its next
@@ -138,7 +141,7 @@ struct MicpMultiCall {
   double weight[kMaxMicpSensors];              // merge_weight_multiplier
   const double* partials[kMaxMicpSensors];     // [nblocks[s]][16]
   uint32_t nblocks[kMaxMicpSensors];
-  uint32_t n_sensors, pad;
+  uint32_t n_sensors, seq;                     // seq: echoed in the completion tag (see MicpCall)
 };
 struct MicpMultiState {
   xform T_onew_oold;
@@ -164,6 +167,7 @@ struct MicpMultiFastParams {
   uint32_t n_iter;
   MicpMultiState* state_out;                              // may be host-mapped
   MicpMultiFastStatus* status;                            // may be host-mapped
+  unsigned long long* done;                               // host-mapped completion tag (see kernels.hip publish_tag)
 };
 hipError_t launch_micp_moments(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
                                const float* model_normals, const uint8_t* model_mask, uint32_t n, const MicpCall* call,
@@ -193,17 +197,18 @@ hipError_t launch_compose_poses(const xform* Tbm_dev, xform Tsb, xform* Tsm_out,
 uint32_t reduce_num_blocks(uint32_t n, uint32_t nposes);
 hipError_t launch_reduce_partials(const ReduceParams& p, hipStream_t s);
 // finalize one pose's partials into CrossStatistics (writes to out, which may be host-mapped memory)
-// done (nullable, host-mapped, single pose only): set to 1 after `out` is visible to the host
-hipError_t launch_reduce_finalize(const double* partials, uint32_t nblocks, uint32_t nposes, cstats* out, uint32_t* done,
-                                  hipStream_t s);
+// done (nullable, host-mapped, single pose only): completion tag {seq, xor of the 16 result words}, one 8-byte store after
+// `out` (kernels.hip publish_tag): the host polls the tag and VERIFIES the sum -- a flag alone is not enough, see capi.cpp wait_done
+hipError_t launch_reduce_finalize(const double* partials, uint32_t nblocks, uint32_t nposes, cstats* out,
+                                  unsigned long long* done, uint32_t seq, hipStream_t s);
 // finalize + (Tsb*, Tbo*) + umeyama + compose; advances MicpState on the device
 hipError_t launch_micp_step(const double* partials, uint32_t nblocks, xform Tsb, xform Tbo, const MicpCall* call,
                             const MicpState* state, MicpState* state_out, hipStream_t s);
 // closing launch of the launch_micp_iter chain: solve of the last iteration + T_onew_oold / stats_o (the chain itself works in
 // the sensor frame, kernels.hip micp_advance_sensor)
-// done (nullable, host-mapped): set to 1 after the results are visible to the host
+// done (nullable, host-mapped): completion tag {call->seq, xor of the state's words}, stored after the results
 hipError_t launch_micp_close(const double* partials, uint32_t nblocks, const MicpCall* call, const MicpState* state,
-                             MicpState* state_out, uint32_t* done, hipStream_t s);
+                             MicpState* state_out, unsigned long long* done, hipStream_t s);
 // state: TWO MicpState slots (ping-pong of k_micp_iter); both initialised
 hipError_t launch_micp_init(MicpState* state, uint32_t* barrier, hipStream_t s);
 // one launch per MICP iteration: finishes the previous iteration (finalize + solve, redundantly in every block)

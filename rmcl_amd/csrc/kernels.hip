@@ -1813,16 +1813,36 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const ReduceParams p) {
   }  // kTail != kTailNone
 }
 
+// Completion tag of a launch chain whose results go to host-mapped memory and whose caller polls instead of waiting for the
+// stream: ONE 8-byte store {seq, xor of every result word}, issued after the results and a system-scope fence.  The sum is what
+// makes the hand-off sound: on this platform the host was observed (1 in ~10^4 calls, tools/determinism2.py) to see a flag
+// written AFTER `__threadfence_system()` while the 64 B of results written BEFORE it still showed the previous call's
+// values -- results and flag live in different host allocations and reach the host through different channels.  The host
+// therefore accepts a result only when the tag carries this call's sequence number AND the words it reads add up to the
+// tag's sum (capi.cpp wait_done), and keeps polling otherwise.
+template <typename Tp>
+__device__ __forceinline__ uint32_t xor_words(const Tp& v) {
+  static_assert(sizeof(Tp) % 4 == 0, "word-sized results only");
+  uint32_t w[sizeof(Tp) / 4];
+  __builtin_memcpy(w, &v, sizeof(Tp));
+  uint32_t x = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < sizeof(Tp) / 4; ++i) x ^= w[i];
+  return x;
+}
+__device__ __forceinline__ void publish_tag(unsigned long long* tag, uint32_t seq, uint32_t sum) {
+  __threadfence_system();
+  __hip_atomic_store(tag, (static_cast<unsigned long long>(sum) << 32) | static_cast<unsigned long long>(seq), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ void __launch_bounds__(64) k_reduce_finalize(const double* __restrict__ partials, uint32_t nblocks,
-                                                       cstats* __restrict__ out, uint32_t* done) {
+                                                       cstats* __restrict__ out, unsigned long long* done, uint32_t seq) {
   const uint32_t pose = blockIdx.x;
   const cstats s = finalize_pose(partials + static_cast<size_t>(pose) * nblocks * kAcc, nblocks);
   if (threadIdx.x == 0) {
     out[pose] = s;
-    if (done) {   // single-pose call with a host-mapped result: completion word polled by the host (capi.cpp wait_word)
-      __threadfence_system();
-      *done = 1u;
-    }
+    if (done) publish_tag(done, seq, xor_words(s));   // single-pose call with a host-mapped result (capi.cpp wait_done)
   }
 }
 
@@ -2070,7 +2090,7 @@ __global__ void k_micp_init(MicpState* st, uint32_t* barrier) {
 // result without a device-to-host copy node
 // closing launch of the one-launch-per-iteration form: the last iteration's solve + the odom-frame results
 __global__ void __launch_bounds__(64) k_micp_close(const double* __restrict__ partials, uint32_t nblocks, const MicpCall* call,
-                                                   const MicpState* st, MicpState* st_out, uint32_t* done) {
+                                                   const MicpState* st, MicpState* st_out, unsigned long long* done) {
   const cstats stats_s = finalize_pose(partials, nblocks);
   if (threadIdx.x == 0) {
     xform T_s = st->T_snew_sold;
@@ -2078,10 +2098,7 @@ __global__ void __launch_bounds__(64) k_micp_close(const double* __restrict__ pa
     MicpState out;
     micp_close_sensor(stats_s, T_s, call->Tsb, call->Tbo, &out);
     *st_out = out;
-    if (done) {   // host-mapped completion word: the caller polls it instead of waiting for the stream's signal
-      __threadfence_system();
-      *done = 1u;
-    }
+    if (done) publish_tag(done, call->seq, xor_words(out));   // the caller polls the tag instead of waiting for the stream's signal
   }
 }
 
@@ -2162,25 +2179,22 @@ struct MicpFastParams {
   uint32_t n_iter;
   MicpState* state_out;         // may be host-mapped
   MicpFastStatus* status;       // may be host-mapped
+  unsigned long long* done;     // host-mapped completion tag
 };
 
-// Status blocks live in pinned host memory and the host polls `code`: every other field is written first, a system-scope fence
-// orders them, `code` goes last -- the host never sees a fresh code next to stale fields, and no late store of this launch can
-// land after the host has started to reuse the block.
-__device__ __forceinline__ void publish_status(MicpFastStatus* dst, const MicpFastStatus& st) {
+// Status blocks live in pinned host memory: the block is written whole, then the completion tag (publish_tag) with the sum of
+// the block and of whatever else this exit wrote for the host (`extra`: the xor of the state block, 0 for the early exits).
+__device__ __forceinline__ void publish_status(MicpFastStatus* dst, const MicpFastStatus& st, unsigned long long* tag, uint32_t seq,
+                                               uint32_t extra) {
   MicpFastStatus body = st;
-  body.code = 0xFFFFFFFFu;          // "pending", what the host wrote before the launch
-  body.pad[2] = 0u;                 // the completion word of the per-iteration chains: not in use during this launch
+  body.pad[2] = 0u;
   *dst = body;                      // two 16-B stores
-  __threadfence_system();
-  *reinterpret_cast<volatile uint32_t*>(&dst->code) = st.code;
+  publish_tag(tag, seq, xor_words(body) ^ extra);
 }
-__device__ __forceinline__ void publish_status(MicpMultiFastStatus* dst, const MicpMultiFastStatus& st) {
-  MicpMultiFastStatus body = st;
-  body.code = 0xFFFFFFFFu;
-  *dst = body;
-  __threadfence_system();
-  *reinterpret_cast<volatile uint32_t*>(&dst->code) = st.code;
+__device__ __forceinline__ void publish_status(MicpMultiFastStatus* dst, const MicpMultiFastStatus& st, unsigned long long* tag,
+                                               uint32_t seq, uint32_t extra) {
+  *dst = st;
+  publish_tag(tag, seq, xor_words(st) ^ extra);
 }
 
 __global__ void __launch_bounds__(256) k_micp_moments(const MicpFastParams p) {
@@ -2402,7 +2416,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastP
     if (tid == 0u) {
       MicpFastStatus st;
       st.code = 2u; st.iter = 0u; st.n_uncertain = total; st.max_rho = 0.f; st.max_tau = 0.f; st.pad[0] = st.pad[1] = st.pad[2] = 0u;
-      publish_status(p.status, st);
+      publish_status(p.status, st, p.done, p.call->seq, 0u);
     }
     return;
   }
@@ -2445,7 +2459,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastP
       if (tid == 0u) {
         MicpFastStatus st;
         st.code = 1u; st.iter = it; st.n_uncertain = total; st.max_rho = max_rho; st.max_tau = max_tau; st.pad[0] = st.pad[1] = st.pad[2] = 0u;
-        publish_status(p.status, st);
+        publish_status(p.status, st, p.done, p.call->seq, 0u);
       }
       return;
     }
@@ -2508,8 +2522,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastP
     st.pad[0] = static_cast<uint32_t>(clk1 - clk0);                              // diagnostics: shader clocks of the set-up
     st.pad[1] = static_cast<uint32_t>(__builtin_readcyclecounter() - clk1);      // ... and of all iterations
     st.pad[2] = 0u;
-    __threadfence_system();
-    publish_status(p.status, st);
+    publish_status(p.status, st, p.done, p.call->seq, xor_words(out));
   }
 }
 
@@ -2956,7 +2969,7 @@ __device__ __forceinline__ void leaf_pair(const uint32_t* __restrict__ tris, uin
   if (__any(two)) tri_update(a1, b1, c1, second, tris, O, D, ray_tfar, best_t, best_rec);
 }
 
-template <int kRows, int kRefill, bool kLeaf2>
+template <int kRows, bool kLeaf2>
 __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
   // LDS: [ per-lane stacks kRows*256 (later: merge weights) | Tsm (PB xforms) | n0 (PB) | errors -> evals (PB*n_beams floats) ]
   extern __shared__ uint32_t lds_dyn[];
@@ -2999,7 +3012,7 @@ __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
     const uint64_t want = __ballot(idle);
     const uint64_t busy = __ballot(cur != kDone);
     if (want == 0 && busy == 0) break;
-    if (want != 0 && (busy == 0 || __popcll(want) >= kRefill)) {
+    if (want != 0 && (busy == 0 || __popcll(want) >= static_cast<int>(p.refill_thr))) {
       if (idle && has_ray) {
         // evaluate_rcc (PCDSensorUpdaterEmbree.cpp:18-86) with unit face normals (BeamEvaluateProgram.cu:104-113): the error only
         const bool real_hit = (range >= p.range_min) && (range <= p.range_max);
@@ -3051,12 +3064,11 @@ __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
       }
     }
     // phase 1: inner nodes -- left early once at most kTailLanes lanes are still descending while others hold a leaf
-    constexpr int kTailLanes = 8;
     for (;;) {
       const bool inner = (cur != kDone) && !(cur & kLeafBit);
       const uint64_t m_inner = __ballot(inner);
       if (m_inner == 0) break;
-      if (__popcll(m_inner) <= kTailLanes && __ballot((cur != kDone) && (cur & kLeafBit)) != 0) break;
+      if (__popcll(m_inner) <= static_cast<int>(p.tail_lanes) && __ballot((cur != kDone) && (cur & kLeafBit)) != 0) break;
       if (inner) {
         uint32_t key[4], ref[4];
         if (!__any(sp + 3u > static_cast<uint32_t>(kRows))) {
@@ -3633,7 +3645,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_multi_fast_loop(const Mic
         MicpMultiFastStatus st;
         st.code = 2u; st.iter = 0u; st.n_uncertain = total + cnt_s; st.sensor = s;
         for (uint32_t q = 0; q < kMaxMicpSensors; ++q) { st.max_rho[q] = 0.f; st.max_tau[q] = 0.f; }
-        publish_status(p.status, st);
+        publish_status(p.status, st, p.done, p.call->seq, 0u);
       }
       return;
     }
@@ -3687,7 +3699,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_multi_fast_loop(const Mic
         MicpMultiFastStatus st;
         st.code = 1u; st.iter = it; st.n_uncertain = total; st.sensor = s_flag_sensor;
         for (uint32_t q = 0; q < kMaxMicpSensors; ++q) { st.max_rho[q] = max_rho[q]; st.max_tau[q] = max_tau[q]; }
-        publish_status(p.status, st);
+        publish_status(p.status, st, p.done, p.call->seq, 0u);
       }
       return;
     }
@@ -3769,14 +3781,14 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_multi_fast_loop(const Mic
     MicpMultiFastStatus st;
     st.code = 0u; st.iter = p.n_iter; st.n_uncertain = total; st.sensor = 0u;
     for (uint32_t q = 0; q < kMaxMicpSensors; ++q) { st.max_rho[q] = max_rho[q]; st.max_tau[q] = max_tau[q]; }
-    __threadfence_system();
-    publish_status(p.status, st);
+    // the host reads T_onew_oold and the merged statistics of this block (rmclhip_micp_correct_once)
+    publish_status(p.status, st, p.done, p.call->seq, xor_words(T_onew_oold) ^ xor_words(merged) ^ xor_words(merged_w));
   }
 }
 
-hipError_t launch_reduce_finalize(const double* partials, uint32_t nblocks, uint32_t nposes, cstats* out, uint32_t* done,
-                                  hipStream_t s) {
-  hipLaunchKernelGGL(k_reduce_finalize, dim3(nposes), dim3(64), 0, s, partials, nblocks, out, (nposes == 1u) ? done : nullptr);
+hipError_t launch_reduce_finalize(const double* partials, uint32_t nblocks, uint32_t nposes, cstats* out,
+                                  unsigned long long* done, uint32_t seq, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_finalize, dim3(nposes), dim3(64), 0, s, partials, nblocks, out, (nposes == 1u) ? done : nullptr, seq);
   return hipGetLastError();
 }
 
@@ -3805,7 +3817,7 @@ hipError_t launch_micp_moments(const float* dataset_points, const uint8_t* datas
                                const float* model_normals, const uint8_t* model_mask, uint32_t n, const MicpCall* call,
                                double* partials, unsigned long long* unc_mask, hipStream_t s) {
   MicpFastParams p{dataset_points, dataset_mask, model_points, model_normals, model_mask, n, micp_fast_blocks(n), call,
-                   partials, unc_mask, 0u, nullptr, nullptr};
+                   partials, unc_mask, 0u, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(k_micp_moments, dim3(p.nblocks), dim3(256), 0, s, p);
   return hipGetLastError();
 }
@@ -3818,9 +3830,9 @@ hipError_t launch_micp_multi_fast_loop(const MicpMultiFastParams& p, hipStream_t
 hipError_t launch_micp_fast(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
                             const float* model_normals, const uint8_t* model_mask, uint32_t n, const MicpCall* call,
                             double* partials, unsigned long long* unc_mask, uint32_t n_iter, MicpState* state_out,
-                            MicpFastStatus* status, hipStream_t s) {
+                            MicpFastStatus* status, unsigned long long* done, hipStream_t s) {
   MicpFastParams p{dataset_points, dataset_mask, model_points, model_normals, model_mask, n, micp_fast_blocks(n), call,
-                   partials, unc_mask, n_iter, state_out, status};
+                   partials, unc_mask, n_iter, state_out, status, done};
   hipLaunchKernelGGL(k_micp_moments, dim3(p.nblocks), dim3(256), 0, s, p);
   hipLaunchKernelGGL(k_micp_fast_loop, dim3(1), dim3(kFastThreads), 0, s, p);
   return hipGetLastError();
@@ -3842,7 +3854,7 @@ hipError_t launch_micp_init(MicpState* state, uint32_t* barrier, hipStream_t s) 
 }
 
 hipError_t launch_micp_close(const double* partials, uint32_t nblocks, const MicpCall* call, const MicpState* state,
-                             MicpState* state_out, uint32_t* done, hipStream_t s) {
+                             MicpState* state_out, unsigned long long* done, hipStream_t s) {
   hipLaunchKernelGGL(k_micp_close, dim3(1), dim3(64), 0, s, partials, nblocks, call, state, state_out, done);
   return hipGetLastError();
 }
@@ -3882,14 +3894,8 @@ hipError_t launch_pf_update(const PfParams& p, int variant, hipStream_t s) {
   const bool leaf2 = ((variant >> 10) & 1) == 0;   // bit 10 set: p.qnodes is the MAP's tree (leaves <= 4) -> loop over the leaf
   if (!cpc && trav == 0 && refill != 0 && !legacy && ((variant >> 7) & 1) == 0 && p.qnodes != nullptr) {
     lds = static_cast<size_t>(kPfRows) * 256u * sizeof(uint32_t) + tail + sizeof(uint32_t) * p.particles_per_block;
-    if (leaf2) {
-      if (refill == 1) hipLaunchKernelGGL((k_pf_update_v3<kPfRows, 8, true>), dim3(nblocks), dim3(256), lds, s, p);
-      else if (refill == 2) hipLaunchKernelGGL((k_pf_update_v3<kPfRows, 16, true>), dim3(nblocks), dim3(256), lds, s, p);
-      else if (refill == 3) hipLaunchKernelGGL((k_pf_update_v3<kPfRows, 32, true>), dim3(nblocks), dim3(256), lds, s, p);
-      else hipLaunchKernelGGL((k_pf_update_v3<kPfRows, 48, true>), dim3(nblocks), dim3(256), lds, s, p);
-    } else {
-      hipLaunchKernelGGL((k_pf_update_v3<kPfRows, 48, false>), dim3(nblocks), dim3(256), lds, s, p);
-    }
+    if (leaf2) hipLaunchKernelGGL((k_pf_update_v3<kPfRows, true>), dim3(nblocks), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((k_pf_update_v3<kPfRows, false>), dim3(nblocks), dim3(256), lds, s, p);
     return hipGetLastError();
   }
   if (!cpc && trav == 0 && refill != 0) {

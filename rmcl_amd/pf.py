@@ -159,6 +159,11 @@ class PCDSensorUpdaterHip:
             self.init()
         _capi.check(_capi.lib().rmclhip_pf_set_variant(self._h, int(v)))
 
+    def set_schedule(self, refill_idle_lanes=0, tail_lanes=8):
+        if not self._h:
+            self.init()
+        _capi.check(_capi.lib().rmclhip_pf_set_schedule(self._h, int(refill_idle_lanes), int(tail_lanes)))
+
     def _push_params(self):
         _capi.check(_capi.lib().rmclhip_pf_set_params(self._h, C.byref(self.config)))
 

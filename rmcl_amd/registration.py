@@ -47,6 +47,11 @@ class Context:
         _capi.check(_capi.lib().rmclhip_ctx_device_name(self._h, buf, 256))
         return buf.value.decode()
 
+    def set_wait_mode(self, mode):
+        """how synchronous calls wait for results in host-mapped memory: "spin" (poll the completion tag, default) or "block"
+        (hipStreamSynchronize); rmclhip_ctx_set_wait_mode"""
+        _capi.check(_capi.lib().rmclhip_ctx_set_wait_mode(self._h, {"spin": 0, "block": 1}[mode]))
+
     def close(self):
         if self._h:
             _capi.lib().rmclhip_ctx_destroy(self._h)

@@ -32,6 +32,8 @@ typedef struct {
 static pfsim_cost g_cost = {125, 75, 12, 110, 200, 14, 14, 14};
 
 void pfsim_costs(const double* c) { memcpy(&g_cost, c, sizeof(g_cost)); }
+static int g_lds_rows = 20;
+void pfsim_lds_rows(int r) { g_lds_rows = r; }
 
 typedef struct {
   uint32_t cur;          /* DONE: no ray / finished */
@@ -118,6 +120,7 @@ typedef struct {
   double node_lane, leaf_lane, refill_lane;
   double makespan;      /* max wave clock of the block (issues) */
   double nvisit, lvisit, rays;
+  double deep_steps, node_steps, max_sp;   /* wave-level node steps in which a lane's stack reaches beyond the LDS rows */
 } pfsim_out;
 
 /* O, D: nrays x 3 floats (queue order); returns stats of ONE block */
@@ -173,6 +176,11 @@ int pfsim_block(const uint32_t* nodes, const uint32_t* tris, const float* O, con
         if (inner <= tail_lanes && holding) break;
         CHARGE(wv, node, g_cost.node, inner);
         out->node_lane += g_cost.node * inner / 64.0;
+        {
+          int deep = 0;
+          for (int l = 0; l < 64; ++l) { const slot_t* s = &wv->slot[l][0]; if (s->cur != DONE && !(s->cur & LEAF)) { if (s->sp + 1 + 3 > g_lds_rows) deep = 1; if (s->sp > out->max_sp) out->max_sp = s->sp; } }
+          out->deep_steps += deep; out->node_steps += 1;
+        }
         for (int l = 0; l < 64; ++l) { slot_t* s = &wv->slot[l][0]; if (s->cur != DONE && !(s->cur & LEAF)) node_step(s, nodes); }
       }
       {

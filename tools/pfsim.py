@@ -18,7 +18,7 @@ from rmcl_amd import synthetic as syn  # noqa: E402
 
 class Out(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("issue", "lane_issue", "node_issue", "leaf_issue", "refill_issue", "loop_issue",
-                                          "node_lane", "leaf_lane", "refill_lane", "makespan", "nvisit", "lvisit", "rays")]
+                                          "node_lane", "leaf_lane", "refill_lane", "makespan", "nvisit", "lvisit", "rays", "deep_steps", "node_steps", "max_sp")]
 
 
 def lib():
@@ -43,7 +43,7 @@ def block_rays(poses, dirs, order=None):
 
 
 def run(L, nodes, tris, poses, dirs, pb, nblocks, slots, thr, tail, order=None, nwaves=4):
-    tot = np.zeros(13)
+    tot = np.zeros(16)
     for b in range(nblocks):
         O, D = block_rays(poses[b * pb:(b + 1) * pb], dirs, order)
         o = Out()
@@ -100,6 +100,7 @@ if __name__ == "__main__":
         nb_total = 100000 / pb
         merge = 44.0 * 256 * pb / 8 / (pb * 256)   # issues per ray of the 8-lane in-order merge (one wave)
         ms = (r["issue"] / nb + merge * pb * 256) * nb_total * 4 / 1024 / 2.4e6
+        print("   wave node steps that leave the 20 LDS stack rows: %.2f %%  (max sp %d)" % (100 * r["deep_steps"] / max(r["node_steps"], 1), r["max_sp"] / nb))
         print("%-50s issues/ray %6.1f lanes %.3f | node %.3f(%4.1f%%) leaf %.3f(%4.1f%%) refill %.3f(%4.1f%%) | visits %5.2f | est %.2f ms (with merge)" % (
             tag, r["issue"] / r["rays"], r["lane_issue"] / r["issue"],
             r["node_lane"] / max(r["node_issue"], 1), 100 * r["node_issue"] / r["issue"],
