@@ -156,6 +156,7 @@ class Memory<T, VRAM_HIP> {
       check(rmclhip_malloc(ctx_->handle(), n * sizeof(T), &p));
       ptr_ = static_cast<T*>(p);
       cap_ = n;
+      ++version_;   // the buffer moved: an operator that borrowed the old pointer rebinds before its next use
     }
     n_ = n;
   }
@@ -260,8 +261,18 @@ class Correspondences_<VRAM_HIP> {
     v.mask = {dataset.mask.raw(), dataset.mask.size()};
     return v;
   }
-  // modelView(): borrowed device views of {points, hits(mask), normals} (+ ranges, face ids)
-  struct ModelView {
+  // modelView() (Correspondences.hpp:47-53): PointCloudView_ {points, mask = hits, normals} over the model buffers of the last
+  // find -- the shape MICPSensorCUDA.cpp:66-84 reads
+  PointCloudView_<VRAM_HIP> modelView() const {
+    const ModelBuffers b = modelBuffers();
+    PointCloudView_<VRAM_HIP> v;
+    v.points = {reinterpret_cast<const Vector*>(b.points), b.n};
+    v.mask = {b.mask, b.n};
+    v.normals = {reinterpret_cast<const Vector*>(b.normals), b.n};
+    return v;
+  }
+  // everything find() writes, as raw borrowed device pointers (+ ranges, face ids, which the reference's bundle does not carry)
+  struct ModelBuffers {
     const float* points;
     const uint8_t* mask;
     const float* normals;
@@ -269,8 +280,8 @@ class Correspondences_<VRAM_HIP> {
     const uint32_t* face_ids;
     uint32_t n;
   };
-  ModelView modelView() const {
-    ModelView v{};
+  ModelBuffers modelBuffers() const {
+    ModelBuffers v{};
     check(rmclhip_rcc_device_views(h_, &v.mask, &v.ranges, &v.points, &v.normals, &v.face_ids, &v.n));
     return v;
   }
@@ -429,6 +440,7 @@ class CPCHip : public CorrespondencesHIP {
  public:
   explicit CPCHip(HipMapPtr map) : CorrespondencesHIP(std::move(map)) {}
   void find(const Transform& Tbm_est) override {
+    bindDataset();   // the closest-point query READS the dataset (CPCEmbree.cpp:27-37), unlike the ray-casting find
     check(rmclhip_rcc_set_params(h_, params.max_dist, adaptive_max_dist_min));
     check(rmclhip_rcc_find_cpc(h_, &Tbm_est));
   }

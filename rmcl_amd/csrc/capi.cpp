@@ -486,14 +486,14 @@ rmclhip_status rmclhip_rcc_create(rmclhip_ctx* ctx, rmclhip_map* map, rmclhip_rc
   hipError_t e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&r->ev0);
   if (e == hipSuccess) e = hipEventCreate(&r->ev1);
-  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_stats), sizeof(cstats) * 2, hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_stats), sizeof(cstats) * 2, hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&r->h_stats_dev), r->h_stats, 0);
-  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_state), sizeof(MicpState), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_state), sizeof(MicpState), hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&r->h_state_dev), r->h_state, 0);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->d_state), 2 * sizeof(MicpState));
-  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_fast_status), sizeof(MicpFastStatus), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_fast_status), sizeof(MicpFastStatus), hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&r->h_fast_status_dev), r->h_fast_status, 0);
-  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_done), 2 * sizeof(unsigned long long), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_done), 2 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&r->h_done_dev), r->h_done, 0);
   if (e == hipSuccess) r->h_done[0] = r->h_done[1] = 0ull;
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->d_counter), sizeof(uint32_t));
@@ -1219,9 +1219,11 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
       key.ptrs[0] = r->d_points.p; key.ptrs[1] = r->ds_pts; key.ptrs[2] = r->d_fast_partials.p;
       key.ptrs[3] = r->d_model_tab.p; key.ptrs[4] = r->ds_msk; key.ptrs[5] = r->d_fast_mask.p;
       if (!r->micp_fast_exec || r->fast_graph_dirty || !(key == r->micp_fast_key)) {
+        // the previous call returned on its completion tag, which precedes the stream's own completion: let the last node
+        // retire before its executable graph is destroyed
+        HIPCHK(hipStreamSynchronize(r->stream));
         if (r->micp_fast_exec) { (void)hipGraphExecDestroy(r->micp_fast_exec); r->micp_fast_exec = nullptr; }
         if (r->micp_fast_graph) { (void)hipGraphDestroy(r->micp_fast_graph); r->micp_fast_graph = nullptr; }
-        HIPCHK(hipStreamSynchronize(r->stream));
         HIPCHK(hipStreamBeginCapture(r->stream, hipStreamCaptureModeThreadLocal));
         r->capturing = true;
         hipError_t le = hipMemcpyAsync(r->d_call, r->h_call, sizeof(MicpCall), hipMemcpyHostToDevice, r->stream);
@@ -1330,9 +1332,9 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
       key.ptrs[0] = r->d_points.p; key.ptrs[1] = r->ds_pts; key.ptrs[2] = r->d_partials.p;
       key.ptrs[3] = r->d_model_tab.p; key.ptrs[4] = r->ds_msk; key.ptrs[5] = r->d_hits.p;
       if (!r->micp_exec || r->graph_dirty || !(key == r->micp_key)) {
+        HIPCHK(hipStreamSynchronize(r->stream));   // see the moment-form graph above
         if (r->micp_exec) { (void)hipGraphExecDestroy(r->micp_exec); r->micp_exec = nullptr; }
         if (r->micp_graph) { (void)hipGraphDestroy(r->micp_graph); r->micp_graph = nullptr; }
-        HIPCHK(hipStreamSynchronize(r->stream));
         HIPCHK(hipStreamBeginCapture(r->stream, hipStreamCaptureModeThreadLocal));
         r->capturing = true;
         const rmclhip_status cst = enqueue_chain();
@@ -1451,9 +1453,9 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
   // call + state live with the first sensor and persist between calls (an allocation per call cost more than the loop)
   HIPCHK(r0->d_multi_blob.reserve(sizeof(MicpMultiCall) + sizeof(MicpMultiState)));
   if (!r0->h_multi_state) {
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&r0->h_multi_state), sizeof(MicpMultiState), hipHostMallocMapped));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&r0->h_multi_state), sizeof(MicpMultiState), hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&r0->h_multi_state_dev), r0->h_multi_state, 0));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&r0->h_multi_status), sizeof(MicpMultiFastStatus), hipHostMallocMapped));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&r0->h_multi_status), sizeof(MicpMultiFastStatus), hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&r0->h_multi_status_dev), r0->h_multi_status, 0));
   }
   MicpMultiCall* d_call = reinterpret_cast<MicpMultiCall*>(r0->d_multi_blob.p);
@@ -2425,11 +2427,17 @@ rmclhip_status rmclhip_pf_sharded_set_particles(rmclhip_pf_sharded* h, const rmc
                        reinterpret_cast<void**>(&R.d_w_pad), reinterpret_cast<void**>(&R.d_w_all)};
       for (void** b : bufs) if (*b) { (void)hipFree(*b); *b = nullptr; }
       const size_t c = std::max<uint32_t>(cap, 1u);
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&R.d_poses), c * 32)); HIPCHK(hipMalloc(&R.d_attrs, c * 36));
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&R.d_poses_new), c * 32)); HIPCHK(hipMalloc(&R.d_attrs_new, c * 36));
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&R.d_poses_all), c * world * 32)); HIPCHK(hipMalloc(&R.d_attrs_all, c * world * 36));
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&R.d_w_send), c * 4)); HIPCHK(hipMalloc(reinterpret_cast<void**>(&R.d_w_pad), c * world * 4));
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&R.d_w_all), static_cast<size_t>(std::max(n_total, 1u)) * 4));
+      // d_w_all holds the dense [n_total] weights: n_total <= cap * world for every cloud this capacity admits (sizing it
+      // by the n_total of the call that allocated let a later, larger cloud of the same capacity write past its end)
+      const size_t sizes[] = {c * 32, c * 36, c * 32, c * 36, c * world * 32, c * world * 36, c * 4, c * world * 4, c * world * 4};
+      hipError_t ae = hipSuccess;
+      for (size_t k = 0; k < sizeof(sizes) / sizeof(sizes[0]) && ae == hipSuccess; ++k) ae = hipMalloc(bufs[k], sizes[k]);
+      if (ae != hipSuccess) {
+        // leave no half-allocated rank behind: the next call must see "no buffers" and start over
+        for (void** b : bufs) if (*b) { (void)hipFree(*b); *b = nullptr; }
+        h->cap = 0;
+        return fail(ae == hipErrorOutOfMemory ? RMCLHIP_ERR_NOMEM : RMCLHIP_ERR_HIP, std::string("pf_sharded_set_particles: ") + hipGetErrorString(ae));
+      }
     }
     shard_bounds(n_total, r, world, &R.lo, &R.hi);
     HIPCHK(hipMemset(R.d_poses, 0, static_cast<size_t>(std::max(cap, 1u)) * 32));

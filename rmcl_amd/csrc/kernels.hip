@@ -3443,15 +3443,14 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
   uint32_t nblocks = (variant == 2) ? ntiles : (ntiles + 3u) / 4u;
   nblocks = (nblocks + 7u) & ~7u;  // the XCD remap in k_find needs gridDim.x % 8 == 0
   dim3 grid(nblocks, p.nposes, 1), block(256, 1, 1);
-  // more than 64 KB of dynamic LDS per block must be granted once per kernel
-  static bool lds_granted[32][8] = {};
+  // more than 64 KB of dynamic LDS per block must be granted per kernel AND per device (the attribute belongs to the device's
+  // copy of the function); launches that need it are rare A/B kinds, so the grant is simply repeated on every such launch
 #define RMCL_FIND_ONE(KIND, TRAV, LDS)                                                                               \
   {                                                                                                                  \
-    if ((LDS) > 65536u && !lds_granted[TRAV][KIND]) {                                                                \
+    if ((LDS) > 65536u) {                                                                                            \
       const hipError_t ge = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_find<KIND, TRAV>),                  \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(LDS)); \
       if (ge != hipSuccess) return ge;                                                                               \
-      lds_granted[TRAV][KIND] = true;                                                                                \
     }                                                                                                                \
     hipLaunchKernelGGL((k_find<KIND, TRAV>), grid, block, LDS, s, p);                                                \
   }

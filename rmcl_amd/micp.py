@@ -80,10 +80,19 @@ class MICPLocalization:
 
     def correctOnce(self, record=None, device_loop=False):
         """micp_localization.cpp:856-1016. `record`, if a list, receives T_onew_oold after each iteration.
-        device_loop=True runs the inner loop (finds + iterations) on the device for all sensors at once."""
+        device_loop=True runs the inner loop (finds + iterations) on the device for all sensors at once; it sets every
+        sensor's Tom and pushes its parameters, but does NOT call sensor.findCorrespondences() (sensor-side effects of that
+        method, e.g. visualisation hooks of a subclass, do not run) and cannot fill `record`."""
         Tom = self.Tom_
         valid_measurements = sum(s.valid_dataset_measurements for s in self.sensors_vec_)
         if device_loop and not self.disable_correction_ and self.optimization_iterations_ > 0:
+            # the device loop returns only the final transform and does not call sensor.findCorrespondences(): per-iteration
+            # records and more sensors than the device block holds need the host loop -- say so instead of returning less
+            if record is not None:
+                raise ValueError("correctOnce(record=..., device_loop=True): the device-resident loop does not return per-iteration "
+                                 "transforms; use the host loop (device_loop=False) to record them")
+            if len(self.sensors_vec_) > 8:
+                raise ValueError("correctOnce(device_loop=True): at most 8 sensors (rmclhip_micp_correct_once); use the host loop")
             T_onew_oold, Cmerged_o = self._device_loop(Tom)
             return self._finish(Tom, T_onew_oold, Cmerged_o, valid_measurements)
         for s in self.sensors_vec_:

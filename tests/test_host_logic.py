@@ -132,3 +132,24 @@ def test_synthetic_generators(ra):
     assert np.allclose(np.linalg.norm(q, axis=1), 1, atol=1e-6) and np.all(q[:, 0] == 0) and np.all(q[:, 1] == 0)
     assert np.all(attrs["likelihood"]["mean"] == 1.0) and np.all(attrs["likelihood"]["n_meas"] == 0)
     assert syn.uniform_particles(10, seed=42)[0].tobytes() == syn.uniform_particles(10, seed=42)[0].tobytes()
+
+
+def test_device_loop_refuses_what_it_cannot_deliver(ra):
+    """correctOnce(device_loop=True) returns only the final transform (rmclhip_micp_correct_once): a `record` list or more than
+    8 sensors must be an error, not a silently shorter answer"""
+    import pytest
+    from rmcl_amd import types as T
+
+    class _Corr:
+        outdated = True
+
+        def setTsb(self, Tsb):
+            pass
+
+    sensors = [ra.MICPSensor("s%d" % i, _Corr(), Tsb=T.identity(), Tbo=T.identity()) for i in range(9)]
+    loc = ra.MICPLocalization(sensors[:1], optimization_iterations=3)
+    with pytest.raises(ValueError, match="record"):
+        loc.correctOnce(record=[], device_loop=True)
+    loc9 = ra.MICPLocalization(sensors, optimization_iterations=3)
+    with pytest.raises(ValueError, match="8 sensors"):
+        loc9.correctOnce(device_loop=True)
