@@ -307,16 +307,12 @@ rmclhip_status rmclhip_rcc_time_reduce(rmclhip_rcc* rcc, const rmclhip_transform
 rmclhip_status rmclhip_rcc_time_correct_once(rmclhip_rcc* rcc, const rmclhip_transform* Tom, const rmclhip_transform* Tbo,
                                              uint32_t n_iter, double convergence_progress, int refind_each_iteration,
                                              uint32_t iters, float* ms_per_call);
-/* kernel variant selection: bits 0..3 (+ bit 13 = 16 more) traversal kind (15 = automatic, the default:
- * four lanes per ray up to 57344 rays in flight (kind 2), one lane per ray with a quad-finished tail and the leaf trigger
- * up to 262144 (kinds 19 / 21), one lane per ray on the 64-B quantised nodes with the leaf trigger above (kind 22);
- * 0 = wave packet, 1 = one lane per ray, 2 = four lanes per ray, 4 = one lane per ray on quantised nodes, 5 = one lane
- * per ray whose last <= 16 rays per wave are handed to four lanes each; 6 / 7 = 5 with the top 85 / 341 nodes of the tree
- * resident in LDS, 8 = 5 with one-round-trip leaves, 9 / 10 = 8 with the LDS top, 11 = round-1 branchy step, 12 = branch-free
- * step + one-round-trip leaves, 13 / 14 = wave-uniform nodes through the scalar cache, 16 / 17 = branch-free step with the
- * quad-finished tail (17: + one-round-trip leaves), 18 = learned slow tiles in quad helper blocks, 19 / 20 = 17 with the
- * leaf trigger -- a wave leaves its node phase once the lanes that wait with a leaf outnumber 1.5 x the lanes still
- * descending (20: per-triangle leaf loop) --, 21 = 5 and 22 = 4 with the leaf trigger),
+/* kernel variant selection: bits 0..3 (+ bit 13 = 16 more) traversal kind.  15 = automatic, the default: four
+ * lanes per ray up to 57344 rays in flight (kind 2), one lane per ray with a quad-finished tail and the leaf trigger up to 262144
+ * (kinds 19 / 21), one lane per ray on the 64-B quantised nodes with the leaf trigger above (kind 22).  librmclhip.so builds
+ * the kinds that rule can select plus 0 = wave packet and 4 = one lane per ray on quantised nodes; every other kind is a
+ * measured-and-rejected experiment that lives in librmclhip_lab.so (include/rmclhip_lab.h lists them) and is accepted here
+ * only while that library is loaded (RMCLHIP_ERR_UNSUPPORTED otherwise),
  * bits 4..7 = 1 + log2(tile width) of the wave's scan-image tile (0 = automatic, 8x8 for tall images),
  * bit 8 = fused last-block reduction tail (A/B), bit 9 = disable the hipGraph MICP loop (A/B), bits 10..12 = form
  * of the MICP loop (0 = one launch per iteration, the default; 1 = reduce + solve launches; 2..6 = persistent
@@ -342,16 +338,6 @@ rmclhip_status rmclhip_rcc_set_micp_fast(rmclhip_rcc* rcc, int mode);
 rmclhip_status rmclhip_rcc_micp_fast_info(const rmclhip_rcc* rcc, rmclhip_micp_fast_info* out);
 /* the traversal (bits 0..3 above, never 15) a find of `nposes` scans of the current model would launch */
 rmclhip_status rmclhip_rcc_find_variant(const rmclhip_rcc* rcc, uint32_t nposes, int* variant_out);
-/* DIAGNOSTICS (tools/probe_find.py; not part of the reference interface): one spherical find() through an instrumented
- * copy of the one-lane-per-ray traversal that stamps s_memtime around every node / leaf step of every wave.
- * mode: bit 0 = one-round-trip leaves, bit 1 = LDS-resident top of the tree.  log_out: n_tiles x 512 dwords (host). */
-/* DIAGNOSTICS (tools/wave_timeline.py): one find() of the current variant whose waves record their entry / exit shader clock:
- * out = n_waves x 8 dwords {s_memtime entry, exit (stores completed), s_memrealtime entry (100 MHz), tile | xcc << 24,
- * s_memtime before the traversal, after it, stores issued, 0} (all zero = wave had no tile) */
-rmclhip_status rmclhip_debug_wave_clock(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est, uint32_t* out, size_t cap_dwords,
-                                        uint32_t* n_waves_out);
-rmclhip_status rmclhip_debug_probe_find(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est, int mode, uint32_t* log_out,
-                                        size_t log_cap_dwords, uint32_t* n_tiles_out);
 /* rm::Simulator::simulate(Memory<Transform>, Bundle&) (batch form, lidar_corrector_embree_benchmark.cpp:117):
  * one launch for nposes x H x W rays; model buffers become pose-major [pose][vid][hid]. */
 rmclhip_status rmclhip_rcc_find_batch(rmclhip_rcc* rcc, const rmclhip_transform* Tbm, uint32_t nposes);
@@ -419,7 +405,8 @@ rmclhip_status rmclhip_pf_time_update(rmclhip_pf* pf, const rmclhip_transform* p
  * of their 64-B quantised twins (A/B); bit 8: the round-2 kernel on the quantised nodes (A/B); bit 9: 4096 instead of
  * 2048 rays per workgroup (A/B); bit 10: traverse the map's tree (leaves <= 4 triangles) instead of the filter's own
  * (leaves <= 2, rmclhip_bvh_build_host_pf).  A fresh handle uses traversal 0, refill at 48, quantised nodes of the
- * filter's tree, the round-3 kernel. */
+ * filter's tree, the round-3 kernel.  The round kernels (bits 4..6 = 0, bits 0..1) and the round-2 kernel (bits 7 / 8) are
+ * experiments: accepted only while librmclhip_lab.so is loaded. */
 rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* pf, int variant);
 /* schedule of the persistent-lane kernel: a wave fetches new beams once `refill_idle_lanes` of its lanes are idle (0: the
  * threshold selected by set_variant) and leaves its node phase when at most `tail_lanes` lanes still descend while

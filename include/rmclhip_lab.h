@@ -1,0 +1,45 @@
+/* rmclhip_lab.h -- EXPERIMENTS of librmclhip (librmclhip_lab.so): measured-and-rejected kernel variants and in-kernel
+ * instrumentation, kept buildable for A/B runs (tools/) and for the `lab` group of the GPU tests.  NOT part of the drop-in
+ * boundary: nothing here replaces a reference interface, and a product build never needs this header or that library.
+ *
+ * Loading librmclhip_lab.so (dlopen / ctypes.CDLL, after librmclhip.so) registers its launchers with the product; from then on
+ *   rmclhip_rcc_set_variant accepts the traversal kinds
+ *       1  one lane per ray, branch-free step                 5  while-while step, tails of every wave finished by quads
+ *       6 / 7   kind 5 + the top 85 / 341 nodes resident in LDS (north_star "LDS-staged node tiles"; flat loads)
+ *       8       kind 5 + one-round-trip leaves                 9 / 10  kind 8 + the LDS top
+ *       11 the round-1 branchy step                            12 branch-free step + one-round-trip leaves
+ *       13 / 14 wave-uniform nodes through the scalar cache ("wavefront ballot"; 14: + one-round-trip leaves)
+ *       16 / 17 branch-free step + quad-finished tails (17: + one-round-trip leaves)      20 kind 16 + the leaf trigger
+ *     (spherical model only; results are bit-identical to the product's kinds, tests/test_gpu_lab.py), and
+ *   rmclhip_pf_set_variant accepts the round kernels (bits 4..6 = 0) and the round-2 persistent kernel (bits 7 / 8).
+ * Measurements of every kind: profiles/r02_find_variants_ab.txt, profiles/r03_find_variants_ab.txt, DESIGN.md 4. */
+#ifndef RMCLHIP_LAB_H
+#define RMCLHIP_LAB_H
+
+#include "rmclhip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* exported by librmclhip_lab.so */
+const char* rmclhip_lab_version(void);
+
+/* The two entry points below are exported by librmclhip.so (they need the handle's internals) but work only while
+ * librmclhip_lab.so is loaded -- the instrumented kernels live there; RMCLHIP_ERR_UNSUPPORTED otherwise. */
+
+/* tools/wave_timeline.py: one spherical find() of the current variant whose waves record their entry / exit shader clock:
+ * out = n_waves x 8 dwords {s_memtime entry, exit (stores completed), s_memrealtime entry (100 MHz), tile | xcc << 24,
+ * s_memtime before the traversal, after it, stores issued, 0} (all zero = wave had no tile) */
+rmclhip_status rmclhip_debug_wave_clock(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est, uint32_t* out, size_t cap_dwords,
+                                        uint32_t* n_waves_out);
+/* tools/probe_find.py: one spherical find() through an instrumented copy of the one-lane-per-ray traversal that stamps
+ * s_memtime around every node / leaf step of every wave.  mode: bit 0 = one-round-trip leaves, bit 1 = LDS-resident top of the
+ * tree.  log_out: n_tiles x 512 dwords (host). */
+rmclhip_status rmclhip_debug_probe_find(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est, int mode, uint32_t* log_out,
+                                        size_t log_cap_dwords, uint32_t* n_tiles_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

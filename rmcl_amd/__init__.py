@@ -13,4 +13,6 @@ from .registration import (CPCHip, Context, CorrespondencesHIP, DeviceArray, Hip
                            RCCHipOnDn, RCCHipPinhole, RCCHipSpherical, build_bvh_host, build_bvh_host_pf, build_bvh_host_quantised,
                            import_hip_map)
 
+from ._capi import load_lab  # noqa: F401  (experiments library; tools/ and the `lab` tests only)
+
 __version__ = "0.1.0"

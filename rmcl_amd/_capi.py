@@ -204,6 +204,25 @@ def lib():
     return L
 
 
+LAB_PATH = os.path.join(os.path.dirname(LIB_PATH), "librmclhip_lab.so")
+_lab = None
+
+
+def load_lab():
+    """Load librmclhip_lab.so (EXPERIMENTS: rejected traversal kinds, probes, older particle-filter kernels; see
+    include/rmclhip_lab.h).  Its static initialiser registers the experiments' launchers with librmclhip.so.  Only tools/
+    and the `lab` test group call this; the product never does."""
+    global _lab
+    if _lab is not None:
+        return _lab
+    lib()
+    if not os.path.exists(LAB_PATH):
+        raise ImportError("librmclhip_lab.so is missing (%s): `make -C rmcl_amd/csrc`" % LAB_PATH)
+    _lab = C.CDLL(LAB_PATH, mode=C.RTLD_GLOBAL)
+    _lab.rmclhip_lab_version.restype = C.c_char_p
+    return _lab
+
+
 def check(status):
     if status == OK:
         return

@@ -18,9 +18,11 @@
 #include <vector>
 
 #include "../../include/rmclhip.h"
+#include "../../include/rmclhip_lab.h"
 #include "bvh_build.h"
 #include "devmath.h"
 #include "kernels.h"
+#include "lab_hooks.h"
 
 using namespace rmclhip;
 
@@ -42,6 +44,9 @@ rmclhip_status fail(rmclhip_status st, const std::string& msg) {
 #define HIPCHK(expr)                                                                              \
   do {                                                                                            \
     hipError_t e_ = (expr);                                                                       \
+    if (e_ == hipErrorNotSupported)                                                               \
+      return fail(RMCLHIP_ERR_UNSUPPORTED, std::string(#expr) + ": this kernel variant is an experiment that lives in " \
+                  "librmclhip_lab.so, which is not loaded (include/rmclhip_lab.h)");              \
     if (e_ != hipSuccess)                                                                         \
       return fail(RMCLHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
   } while (0)
@@ -219,16 +224,7 @@ struct rmclhip_rcc {
   DevBuf<uint8_t> d_raw;           // staged PointCloud2 bytes (set_input_pointcloud2)
   DevBuf<xform> d_Tbm, d_Tsm, d_Tms, d_Tdelta;
   DevBuf<cstats> d_bstats;
-  // mixed launch (traversal 18): slow tiles of the previous scans run with four lanes per ray in helper blocks
-  DevBuf<uint8_t> d_tile_flags;    // per group of four tiles: 0 none, 1..4 delegated tile
-  DevBuf<uint32_t> d_tile_cost;    // per tile: most node visits of any of its rays (max over the calibration window)
-  std::vector<uint32_t> h_tile_cost;
-  std::vector<uint8_t> h_tile_flags;
-  uint32_t tiles_ngroups = 0, tiles_n = 0;
-  uint32_t finds_since_calib = 0;
-  bool tiles_fresh = true;         // no calibration since the model / variant changed
   bool capturing = false;          // inside hipStreamBeginCapture: no synchronisation allowed
-  float mixed_frac = 0.25f;        // share of the groups whose slowest tile is delegated
   int variant = 15;       // traversal kind: 0 wave-packet, 1 one lane per ray (while-while), 2 four lanes per ray
                           // (quad-cooperative), 15 automatic: quad while the launch is bound by the slowest ray's
                           // chain of dependent fetches (few rays in flight), one lane per ray once the chip is full
@@ -522,7 +518,6 @@ void rmclhip_rcc_destroy(rmclhip_rcc* r) {
   r->d_partials.release(); r->d_Tbm.release(); r->d_Tsm.release(); r->d_Tms.release(); r->d_Tdelta.release();
   r->d_bstats.release();
   r->d_raw.release();
-  r->d_tile_flags.release(); r->d_tile_cost.release();
   DBG_STEP(hipPeekAtLastError());
   if (r->h_stats) DBG_STEP(hipHostFree(r->h_stats));
   if (r->h_state) DBG_STEP(hipHostFree(r->h_state));
@@ -565,8 +560,6 @@ rmclhip_status rmclhip_rcc_set_model_spherical(rmclhip_rcc* r, const rmclhip_sph
   const uint32_t H = m->phi.size, W = m->theta.size;
   r->kind = kModelSpherical;
   r->graph_dirty = true; r->fast_graph_dirty = true;
-  r->tiles_fresh = true;
-  r->finds_since_calib = 0;
   r->W = W; r->H = H;
   r->range = m->range;
   r->orig = mk3(0.f, 0.f, 0.f);
@@ -597,8 +590,6 @@ rmclhip_status rmclhip_rcc_set_model_o1dn(rmclhip_rcc* r, uint32_t width, uint32
   HIPCHK(hipStreamSynchronize(r->stream));
   r->kind = kModelO1Dn;
   r->graph_dirty = true; r->fast_graph_dirty = true;
-  r->tiles_fresh = true;
-  r->finds_since_calib = 0;
   r->W = width; r->H = height;
   r->range = range;
   r->orig = mk3(orig.x, orig.y, orig.z);
@@ -619,8 +610,6 @@ rmclhip_status rmclhip_rcc_set_model_pinhole(rmclhip_rcc* r, uint32_t width, uin
   HIPCHK(hipStreamSynchronize(r->stream));
   r->kind = kModelPinhole;
   r->graph_dirty = true; r->fast_graph_dirty = true;
-  r->tiles_fresh = true;
-  r->finds_since_calib = 0;
   r->W = width; r->H = height;
   r->range = range;
   r->orig = mk3(0.f, 0.f, 0.f);
@@ -636,8 +625,6 @@ rmclhip_status rmclhip_rcc_set_model_ondn(rmclhip_rcc* r, uint32_t width, uint32
   HIPCHK(hipStreamSynchronize(r->stream));
   r->kind = kModelOnDn;
   r->graph_dirty = true; r->fast_graph_dirty = true;
-  r->tiles_fresh = true;
-  r->finds_since_calib = 0;
   r->W = width; r->H = height;
   r->range = range;
   r->orig = mk3(0.f, 0.f, 0.f);
@@ -752,8 +739,6 @@ rmclhip_status rmclhip_rcc_set_input_pointcloud2(rmclhip_rcc* r, const uint8_t* 
   HIPCHK(hipStreamSynchronize(r->stream));
   r->kind = kModelO1Dn;
   r->graph_dirty = true; r->fast_graph_dirty = true;
-  r->tiles_fresh = true;
-  r->finds_since_calib = 0;
   r->W = ow; r->H = oh;
   r->range = range;
   r->orig = mk3(0.f, 0.f, 0.f);
@@ -838,69 +823,6 @@ static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
   p.face_ids = r->d_face_ids.p;
 }
 
-// ---- mixed launch bookkeeping -------------------------------------------------------------------------
-// Which tiles are slow is a property of (pose, map) that changes slowly from scan to scan (MICP re-localises from nearly
-// the same pose), so it is LEARNED: every launch records per tile the largest number of node visits of any of its rays (a
-// measure that does not depend on how the tile was traced); every kCalibEvery launches the host reads the 8 KB back, picks
-// in each group of four tiles the slowest one, and delegates it to the group's quad helper block if it belongs to the
-// slowest `mixed_frac` of the groups.  Flags only ever change here, between launches, so the lane block and the helper of
-// a group always agree; a stale flag costs time, never correctness (results are identical for every assignment).
-constexpr uint32_t kCalibEvery = 256;
-
-static rmclhip_status tiles_prepare(rmclhip_rcc* r, const FindParams& p) {
-  const uint32_t ntiles = p.tiles_x * p.tiles_y;
-  const uint32_t ngroups = (((ntiles + 3u) / 4u) + 7u) & ~7u;
-  if (r->tiles_n == ntiles && r->tiles_ngroups == ngroups && r->d_tile_flags.p && !r->tiles_fresh) return RMCLHIP_OK;
-  if (r->tiles_n != ntiles || r->tiles_ngroups != ngroups || !r->d_tile_flags.p) {
-    HIPCHK(r->d_tile_flags.reserve(ngroups));
-    HIPCHK(r->d_tile_cost.reserve(static_cast<size_t>(ngroups) * 4u));
-    r->h_tile_cost.assign(static_cast<size_t>(ngroups) * 4u, 0u);
-    r->h_tile_flags.assign(ngroups, 0u);
-    r->tiles_n = ntiles;
-    r->tiles_ngroups = ngroups;
-    r->tiles_fresh = true;
-  }
-  if (r->tiles_fresh && r->finds_since_calib == 0) {
-    HIPCHK(hipMemsetAsync(r->d_tile_flags.p, 0, ngroups, r->stream));
-    HIPCHK(hipMemsetAsync(r->d_tile_cost.p, 0, static_cast<size_t>(ngroups) * 4u * sizeof(uint32_t), r->stream));
-  }
-  return RMCLHIP_OK;
-}
-
-static rmclhip_status tiles_calibrate(rmclhip_rcc* r) {
-  const uint32_t ng = r->tiles_ngroups;
-  HIPCHK(hipMemcpyAsync(r->h_tile_cost.data(), r->d_tile_cost.p, static_cast<size_t>(ng) * 4u * sizeof(uint32_t),
-                        hipMemcpyDeviceToHost, r->stream));
-  HIPCHK(hipStreamSynchronize(r->stream));
-  std::vector<uint32_t> gmax(ng);
-  for (uint32_t g = 0; g < ng; ++g) {
-    uint32_t best = 0, arg = 0;
-    for (uint32_t k = 0; k < 4; ++k)
-      if (r->h_tile_cost[4u * g + k] > best) { best = r->h_tile_cost[4u * g + k]; arg = k; }
-    gmax[g] = best;
-    r->h_tile_flags[g] = static_cast<uint8_t>(best ? arg + 1u : 0u);
-  }
-  std::vector<uint32_t> sorted(gmax);
-  std::sort(sorted.begin(), sorted.end());
-  const uint32_t live = static_cast<uint32_t>(sorted.end() - std::upper_bound(sorted.begin(), sorted.end(), 0u));
-  uint32_t ndel = static_cast<uint32_t>(r->mixed_frac * static_cast<float>(live));
-  uint32_t thr = 0xFFFFFFFFu;
-  if (ndel > 0 && live > 0) thr = sorted[sorted.size() - ndel];
-  if (thr == 0u) thr = 1u;
-  // ties at the threshold: delegate at most ~ndel groups (first come)
-  uint32_t taken = 0;
-  for (uint32_t g = 0; g < ng; ++g) {
-    if (gmax[g] >= thr && taken < ndel + ndel / 4u + 1u) ++taken;
-    else r->h_tile_flags[g] = 0u;
-  }
-  HIPCHK(hipMemcpyAsync(r->d_tile_flags.p, r->h_tile_flags.data(), ng, hipMemcpyHostToDevice, r->stream));
-  HIPCHK(hipMemsetAsync(r->d_tile_cost.p, 0, static_cast<size_t>(ng) * 4u * sizeof(uint32_t), r->stream));
-  HIPCHK(hipStreamSynchronize(r->stream));
-  r->finds_since_calib = 0;
-  r->tiles_fresh = false;
-  return RMCLHIP_OK;
-}
-
 static rmclhip_status find_enqueue(rmclhip_rcc* r, const xform& Tbm) {
   const size_t n = static_cast<size_t>(r->W) * r->H;
   r->n_model = static_cast<uint32_t>(n);
@@ -911,17 +833,6 @@ static rmclhip_status find_enqueue(rmclhip_rcc* r, const xform& Tbm) {
   p.Tsm = xmul(Tbm, r->Tsb);
   p.Tms = xinv(p.Tsm);
   const int variant = find_variant(r, p.nposes);
-  if (variant == 18) {
-    // the first launches after a model change run undelegated and are measured; afterwards the flags are refreshed
-    // every kCalibEvery launches (one 8 KB read-back + one stream synchronisation, amortised)
-    if (!r->capturing && ((r->tiles_fresh && r->finds_since_calib >= 2u) || r->finds_since_calib >= kCalibEvery))
-      if (rmclhip_status st = tiles_calibrate(r)) return st;
-    if (!r->capturing)
-      if (rmclhip_status st = tiles_prepare(r, p)) return st;
-    p.tile_flags = r->d_tile_flags.p;
-    p.tile_cost = r->d_tile_cost.p;
-    ++r->finds_since_calib;
-  }
   HIPCHK(launch_find(p, r->kind, variant, r->stream));
   return RMCLHIP_OK;
 }
@@ -1181,18 +1092,6 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
         r->tickets_cap = 1;
       }
     }
-    if (find_variant(r, 1) == 18) {
-      // mixed launch inside the (static) graph: the flag / cost buffers must exist before the capture; the flags are
-      // refreshed here, outside the graph, every kCalibEvery corrections
-      FindParams pt;
-      fill_find_params(r, pt, 1);
-      if ((r->tiles_fresh && r->finds_since_calib >= 2u) || r->finds_since_calib >= kCalibEvery)
-        if (rmclhip_status st = tiles_calibrate(r)) return st;
-      const uint8_t* before = r->d_tile_flags.p;
-      if (rmclhip_status st = tiles_prepare(r, pt)) return st;
-      if (before != r->d_tile_flags.p) { r->graph_dirty = true; r->fast_graph_dirty = true; }   // (re)allocated: the captured pointers are stale
-      ++r->finds_since_calib;
-    }
     r->h_call->Tsm = xmul(xmul(Tom, Tbo), r->Tsb);
     r->h_call->Tms = xinv(r->h_call->Tsm);
     r->h_call->Tsb = r->Tsb;
@@ -1203,8 +1102,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
     r->h_call->seq = next_seq(r);
     // ---- moment form first (kernels.hip "gate-stable moment form"); any outcome other than "done" falls through to the
     // per-iteration form below, which recomputes the correction from scratch
-    const bool fast_eligible = r->fast_mode != 0 && r->use_graph && r->loop_blocks == 0 && !r->fused_tail && n_iter >= 2u &&
-                               find_variant(r, 1) != 18;
+    const bool fast_eligible = r->fast_mode != 0 && r->use_graph && r->loop_blocks == 0 && !r->fused_tail && n_iter >= 2u;
     bool fast_tried = false;
     if (fast_eligible && r->fast_holdoff > 0u) --r->fast_holdoff;
     else if (fast_eligible) {
@@ -1286,7 +1184,6 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
       p.Tsm_arr = &r->d_call->Tsm;
       p.Tms_arr = &r->d_call->Tms;
       const int fvariant = find_variant(r, p.nposes);
-      if (fvariant == 18) { p.tile_flags = r->d_tile_flags.p; p.tile_cost = r->d_tile_cost.p; }
       HIPCHK(launch_find(p, r->kind, fvariant, r->stream));
       const bool iter_form = r->loop_blocks == 0 && !r->fused_tail && n_iter > 0;
       if (!iter_form) HIPCHK(launch_micp_init(r->d_state, r->d_loop_barrier, r->stream));  // k_micp_iter initialises itself
@@ -1469,7 +1366,6 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
     p.Tsm = xmul(xmul(Tom, h_call.Tbo[s]), r->Tsb);
     p.Tms = xinv(p.Tsm);
     int v = find_variant(r, 1);
-    if (v == 18) v = 17;
     e = launch_find(p, r->kind, v, st);
   }
   if (e != hipSuccess) return fail(RMCLHIP_ERR_HIP, std::string("micp_correct_once: ") + hipGetErrorString(e));
@@ -1687,7 +1583,11 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
   if (!r || variant < 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: bad arguments");
   // bit 13 adds 16 to the traversal kind (kinds 16..31)
   const int kind = (variant & 0xF) | (((variant >> 13) & 1) << 4), tile = (variant >> 4) & 0xF;
-  if (kind == 3 || kind > 22 || tile > 7 || (variant >> 14) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
+  if (kind == 3 || kind == 18 || kind > 22 || tile > 7 || (variant >> 14) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
+  // (kind 1 also selects the one-lane-per-point form of the closest-point query, which the product owns)
+  if (kind != 15 && kind != 1 && !find_kind_in_product(kind) && lab_hooks() == nullptr)
+    return fail(RMCLHIP_ERR_UNSUPPORTED, "rcc_set_variant: this traversal kind is an experiment -- it lives in librmclhip_lab.so, "
+                                         "which is not loaded (the product builds kinds 0, 2, 4, 19, 21, 22 and the automatic rule 15)");
   r->variant = kind;
   r->tile_override = tile;
   r->fused_tail = ((variant >> 8) & 1) != 0;
@@ -1699,8 +1599,6 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
     r->loop_blocks = kLoopBlocks[(variant >> 10) & 7];
   }
   r->graph_dirty = true; r->fast_graph_dirty = true;
-  r->tiles_fresh = true;
-  r->finds_since_calib = 0;
   return RMCLHIP_OK;
 }
 
@@ -1732,6 +1630,7 @@ rmclhip_status rmclhip_debug_probe_find(rmclhip_rcc* r, const rmclhip_transform*
   ApiGuard guard_("rmclhip_debug_probe_find");
   if (!r || !Tbm_est || !log_out) return fail(RMCLHIP_ERR_INVALID, "debug_probe_find: null");
   if (r->kind != kModelSpherical || r->W == 0 || r->H == 0) return fail(RMCLHIP_ERR_INVALID, "debug_probe_find: spherical model only");
+  if (lab_hooks() == nullptr) return fail(RMCLHIP_ERR_UNSUPPORTED, "debug_probe_find: the probe kernel lives in librmclhip_lab.so, which is not loaded");
   HIPCHK(hipSetDevice(r->ctx->device));
   const size_t n = static_cast<size_t>(r->W) * r->H;
   r->n_model = static_cast<uint32_t>(n);
@@ -1760,7 +1659,8 @@ rmclhip_status rmclhip_debug_wave_clock(rmclhip_rcc* r, const rmclhip_transform*
                                         uint32_t* n_waves_out) {
   ApiGuard guard_("rmclhip_debug_wave_clock");
   if (!r || !Tbm_est || !out) return fail(RMCLHIP_ERR_INVALID, "debug_wave_clock: null");
-  if (r->kind == kModelNone || r->W == 0 || r->H == 0) return fail(RMCLHIP_ERR_INVALID, "debug_wave_clock: no sensor model");
+  if (r->kind != kModelSpherical || r->W == 0 || r->H == 0) return fail(RMCLHIP_ERR_INVALID, "debug_wave_clock: spherical model only");
+  if (lab_hooks() == nullptr) return fail(RMCLHIP_ERR_UNSUPPORTED, "debug_wave_clock: the clocked kernels live in librmclhip_lab.so, which is not loaded");
   HIPCHK(hipSetDevice(r->ctx->device));
   const size_t n = static_cast<size_t>(r->W) * r->H;
   r->n_model = static_cast<uint32_t>(n);
@@ -1774,14 +1674,6 @@ rmclhip_status rmclhip_debug_wave_clock(rmclhip_rcc* r, const rmclhip_transform*
   const uint32_t ntiles = p.tiles_x * p.tiles_y;
   uint32_t nblocks = (variant == 2) ? ntiles : (ntiles + 3u) / 4u;
   nblocks = (nblocks + 7u) & ~7u;
-  if (variant == 18) {
-    for (int i = 0; i < 4; ++i)
-      if (rmclhip_status st = find_enqueue(r, to_x(Tbm_est))) return st;   // learn the slow tiles first
-    if (rmclhip_status st = tiles_calibrate(r)) return st;
-    p.tile_flags = r->d_tile_flags.p;
-    p.tile_cost = r->d_tile_cost.p;
-    nblocks *= 2u;
-  }
   const size_t dwords = static_cast<size_t>(nblocks) * 4u * 8u;
   if (n_waves_out) *n_waves_out = nblocks * 4u;
   if (cap_dwords < dwords) return fail(RMCLHIP_ERR_INVALID, "debug_wave_clock: buffer too small");
@@ -1814,7 +1706,7 @@ static rmclhip_status find_batch_enqueue(rmclhip_rcc* r, const rmclhip_transform
   p.Tsm_arr = r->d_Tsm.p;
   p.Tms_arr = r->d_Tms.p;
   const int bvariant = find_variant(r, p.nposes);
-  HIPCHK(launch_find(p, r->kind, bvariant == 18 ? 17 : bvariant, r->stream));   // the mixed launch is a single-scan form
+  HIPCHK(launch_find(p, r->kind, bvariant, r->stream));
   return RMCLHIP_OK;
 }
 
@@ -2099,6 +1991,9 @@ rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* f, int variant) {
   f->legacy = ((variant >> 8) & 1) != 0;      // the round-2 kernel
   f->big_blocks = ((variant >> 9) & 1) != 0;  // 4096 instead of 2048 rays per workgroup
   f->pf_tree = ((variant >> 10) & 1) == 0;    // bit 10: traverse the map's tree (leaves <= 4) instead of the filter's own
+  if ((f->refill == 0 || f->legacy || f->full_nodes || f->variant != 0) && lab_hooks() == nullptr)
+    return fail(RMCLHIP_ERR_UNSUPPORTED, "pf_set_variant: the round kernels and the round-2 persistent kernel are experiments -- they live in "
+                                         "librmclhip_lab.so, which is not loaded");
   return RMCLHIP_OK;
 }
 

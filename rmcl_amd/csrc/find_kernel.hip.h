@@ -1,0 +1,200 @@
+// find_kernel.hip.h -- k_find<model, traversal kind, clocks>: ray-casting correspondences, rm::*Simulator*::simulate as called by
+// RCC*::find (rmcl/src/rmcl/registration/RCCEmbree.cpp:26-36,89-99).  One template, two homes: kernels.hip instantiates the kinds
+// the product can select (0 packet, 2 quad, 4 / 22 quantised, 19 / 21 leaf trigger) WITHOUT clocks; kernels_lab.hip instantiates
+// the measured-and-rejected kinds and the clocked variants for tools/wave_timeline.py.
+#pragma once
+#include "traverse.hip.h"
+
+namespace rmclhip {
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// find
+// ---------------------------------------------------------------------------------------------
+// kTrav: 0 = wave packet, 1 = one lane per ray (while-while), 4 = the same on the quantised 64-B nodes, 5 = one lane
+// per ray with the tail of every wave handed to quads,
+// 2 = four lanes per ray (quad-cooperative; the block
+// of 256 threads then covers ONE 64-ray tile instead of four)
+// kTrav 5..10 share the tail traversal: 6 / 7 add the LDS-resident top of the tree (85 / 341 nodes = levels 0-3 / 0-4 of a
+// full BVH4), 8 adds the one-round-trip leaf, 9 / 10 both
+constexpr int find_top_nodes(int trav) { return (trav == 6 || trav == 9) ? 85 : ((trav == 7 || trav == 10) ? 341 : 0); }
+constexpr bool find_leaf_batch(int trav) { return trav >= 8 && trav <= 10; }
+constexpr int kFindBfRows = 24;  // LDS stack rows per lane (sentinel included) of the branch-free lane traversal in k_find
+constexpr uint32_t kFindTailLdsDwords = 16u * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords;
+
+// kinds 19..22: kind 17 + leaving the node phase when 32 / 24 / 16 / 8 lanes hold a leaf
+constexpr int find_leaf_trigger(int trav) { return (trav == 19 || trav == 20) ? 10 : 0; }   // leave at <= 4/10 of the round's rays
+
+// kClock: entry / traversal / store clocks of every wave go to p.wave_clock (tools/wave_timeline.py); the production
+// instantiations are built with kClock = false and contain no s_memtime
+template <uint32_t kModel, int kTrav, bool kClock = false>
+__global__ void __launch_bounds__(256) k_find(const FindParams p) {
+  extern __shared__ uint32_t lds_dyn[];
+  constexpr bool kPacket = (kTrav == 0);
+  constexpr bool kQuad = (kTrav == 2);
+  constexpr int kTop = find_top_nodes(kTrav);
+  const uint32_t lane = kQuad ? (threadIdx.x >> 2) : (threadIdx.x & 63u), wave = threadIdx.x >> 6;
+  const uint32_t sub = threadIdx.x & 3u;  // quad mode: child slot / triangle slot / output role of this lane
+  uint32_t clk_begin = 0, clk_real = 0;
+  if (kClock && p.wave_clock != nullptr) {  // diagnostics (tools/wave_timeline.py)
+    uint64_t t, r;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "=s"(r) : : "memory");
+    clk_begin = static_cast<uint32_t>(t);
+    clk_real = static_cast<uint32_t>(r);
+  }
+  if constexpr (kTop > 0) {
+    // the block's copy of the top of the tree: coalesced 16-B pieces, all requested before the first LDS write
+    uint4* dst = reinterpret_cast<uint4*>(lds_dyn + kFindTailLdsDwords);
+    const uint4* src = reinterpret_cast<const uint4*>(p.nodes);
+    const uint32_t n16 = min(static_cast<uint32_t>(kTop), p.n_nodes) * 8u;
+    constexpr int kRounds = (kTop > 0) ? (kTop * 8 + 255) / 256 : 1;
+    uint4 v[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const uint32_t i = static_cast<uint32_t>(r) * 256u + threadIdx.x;
+      if (i < n16) v[r] = src[i];
+    }
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const uint32_t i = static_cast<uint32_t>(r) * 256u + threadIdx.x;
+      if (i < n16) dst[i] = v[r];
+    }
+    __syncthreads();
+  }
+  // XCD-aware remap: the dispatcher places block b on XCD b%8; give every XCD a contiguous range of
+  // tiles so neighbouring tiles (which walk the same subtrees) share one L2.  gridDim.x % 8 == 0.
+  const uint32_t chunk = gridDim.x >> 3;
+  const uint32_t vb = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+  const uint32_t tile = ((kTrav == 2) ? vb : (vb * 4u + wave));
+  const uint32_t ntiles = p.tiles_x * p.tiles_y;
+  if (tile >= ntiles) return;
+  const uint32_t pose = blockIdx.y;
+  const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+  const uint32_t twl = p.tile_w_log2;
+  const uint32_t lx = lane & ((1u << twl) - 1u), ly = lane >> twl;
+  const uint32_t vid = (ty << (6u - twl)) + ly, hid = (tx << twl) + lx;
+  const bool valid = (vid < p.H) && (hid < p.W);
+  const uint32_t cv = valid ? vid : 0u, ch = valid ? hid : 0u;
+  const uint32_t loc = cv * p.W + ch;
+
+  xform Tsm, Tms;
+  if (p.Tsm_arr != nullptr) { Tsm = p.Tsm_arr[pose]; Tms = p.Tms_arr[pose]; }
+  else { Tsm = p.Tsm; Tms = p.Tms; }
+
+  f3 dir_s, org_m, orig_s = p.orig_s;
+  if (kModel == kModelSpherical) {
+    // rmagine SphericalModel::getDirection (convention pinned by rmcl_ros/src/util/conversions.cpp:174-188);
+    // the four trig tables hold the host libm values of cos/sin(phi_v), cos/sin(theta_h)
+    const float cp = p.model_tab[cv], sp = p.model_tab[p.H + cv];
+    const float ct = p.model_tab[2u * p.H + ch], st = p.model_tab[2u * p.H + p.W + ch];
+    dir_s = mk3(cp * ct, cp * st, sp);
+    org_m = Tsm.t;
+  } else if (kModel == kModelPinhole) {
+    dir_s = pinhole_direction(p.pin_f[0], p.pin_f[1], p.pin_c[0], p.pin_c[1], cv, ch);
+    org_m = Tsm.t;
+  } else if (kModel == kModelOnDn) {
+    const float* og = p.model_tab + 3u * static_cast<size_t>(loc);
+    const float* dr = p.model_tab + 3u * (static_cast<size_t>(p.W) * p.H + loc);
+    orig_s = mk3(og[0], og[1], og[2]);
+    dir_s = mk3(dr[0], dr[1], dr[2]);
+    org_m = xapply(Tsm, orig_s);
+  } else {
+    dir_s = mk3(p.model_tab[3u * loc], p.model_tab[3u * loc + 1u], p.model_tab[3u * loc + 2u]);
+    org_m = xapply(Tsm, orig_s);
+  }
+  const f3 dir_m = qrot(Tsm.R, dir_s);
+  const bool finite = (dir_m.x == dir_m.x) && (dir_m.y == dir_m.y) && (dir_m.z == dir_m.z);
+  const float ray_tfar = (valid && finite) ? p.tfar : -1.0f;
+
+  uint32_t clk_trace0 = 0, clk_trace1 = 0;
+  if (kClock && p.wave_clock != nullptr) {
+    uint64_t t;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    clk_trace0 = static_cast<uint32_t>(t);
+  }
+  RayHit h;
+  if (kPacket) {
+    trace_packet((cu32p)(p.nodes), (cu32p)(p.tris), org_m, dir_m, ray_tfar, lane, h);
+  } else if (kQuad) {
+    trace_quad(p.cnodes, p.tris, org_m, dir_m, ray_tfar, sub, lane, lds_dyn, h);
+  } else {
+    // kind 4 serves launches that fill the chip (pose batches): throughput, not the slowest wave's chain, is what counts there, and
+    // the branchy step with its partial sort and 16 LDS rows (more resident waves) is 11 % faster than the branch-free one
+    if (kTrav == 4) trace_lane_ww<16, true>(p.qnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
+    else if (kTrav == 22) trace_lane_ww<16, true, false, true>(p.qnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
+    else if (kTrav == 21)
+      trace_lane_ww_tail<16, 0, false, true>(
+          p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, lds_dyn + 16u * 256u,
+          lds_dyn + 16u * 256u + kQuadStackEntries * 64u + (threadIdx.x >> 6) * (kTailRays * kTailXferDwords), h,
+          lds_dyn + kFindTailLdsDwords);
+    else if (kTrav == 1) trace_lane_bf<kFindBfRows>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
+    else if (kTrav == 12) trace_lane_bf<kFindBfRows, false, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
+    else if (kTrav == 16 || kTrav == 17 || kTrav == 19 || kTrav == 20)
+      trace_lane_bf_tail<kFindBfRows, kTrav != 16 && kTrav != 20, find_leaf_trigger(kTrav)>(p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x,
+                                                   lds_dyn + kFindBfRows * 256u,
+                                                   lds_dyn + kFindBfRows * 256u + kQuadStackEntries * 64u + (threadIdx.x >> 6) * (kTailRays * kTailXferDwords), h);
+    else if (kTrav == 13) trace_lane_bf<kFindBfRows, false, false, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
+    else if (kTrav == 14) trace_lane_bf<kFindBfRows, false, true, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
+    else if (kTrav >= 5 && kTrav <= 10)
+      trace_lane_ww_tail<16, kTop, find_leaf_batch(kTrav)>(
+          p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, lds_dyn + 16u * 256u,
+          lds_dyn + 16u * 256u + kQuadStackEntries * 64u + (threadIdx.x >> 6) * (kTailRays * kTailXferDwords), h,
+          lds_dyn + kFindTailLdsDwords);
+    else trace_lane_ww<16>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
+  }
+
+  if (kClock && p.wave_clock != nullptr) {
+    uint64_t t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    clk_trace1 = static_cast<uint32_t>(t);
+  }
+  if (valid) {
+  const size_t g = static_cast<size_t>(pose) * p.W * p.H + loc;
+  const bool found = (h.rec != kNone);
+  // quad mode: the four lanes of a ray hold the same result and share the stores (0: hits/ranges/face ids, 1: points,
+  // 2: normals)
+  const bool w0 = !kQuad || sub == 0u, w1 = !kQuad || sub == 1u, w2 = !kQuad || sub == 2u;
+  if (found) {
+    if (p.hits && w0) p.hits[g] = 1;
+    if (p.ranges && w0) p.ranges[g] = h.t;
+    if (p.points && w1) {
+      f3 pt = scale3(dir_s, h.t);
+      if (kModel == kModelO1Dn || kModel == kModelOnDn) pt = add3(pt, orig_s);
+      p.points[3 * g] = pt.x; p.points[3 * g + 1] = pt.y; p.points[3 * g + 2] = pt.z;
+    }
+    // the record's last 16 B: unit normal + the ORIGINAL face id
+    if ((p.normals && w2) || (p.face_ids && w0)) {
+      const uint4 nrec = reinterpret_cast<const uint4*>(p.tris)[static_cast<size_t>(h.rec) * 4u + 3u];
+      if (p.normals && w2) {
+        f3 n = qrot(Tms.R, mk3(asf(nrec.x), asf(nrec.y), asf(nrec.z)));
+        if (dot_plain(dir_s, n) > 0.0f) n = neg3(n);  // flip towards the sensor
+        p.normals[3 * g] = n.x; p.normals[3 * g + 1] = n.y; p.normals[3 * g + 2] = n.z;
+      }
+      if (p.face_ids && w0) p.face_ids[g] = nrec.w;
+    }
+  } else {
+    const float qn = __uint_as_float(0x7FC00000u);
+    if (p.hits && w0) p.hits[g] = 0;
+    if (p.ranges && w0) p.ranges[g] = p.tfar + 1.0f;
+    if (p.points && w1) { p.points[3 * g] = qn; p.points[3 * g + 1] = qn; p.points[3 * g + 2] = qn; }
+    if (p.normals && w2) { p.normals[3 * g] = qn; p.normals[3 * g + 1] = qn; p.normals[3 * g + 2] = qn; }
+    if (p.face_ids && w0) p.face_ids[g] = kInvalidFace;
+  }
+  }  // valid
+  if (kClock && p.wave_clock != nullptr) {
+    uint64_t t;
+    uint64_t t2;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2) : : "memory");   // stores issued
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");  // ... and completed
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if ((threadIdx.x & 63u) == 0u) {
+      uint32_t* w = p.wave_clock + 8u * ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + wave);
+      w[0] = clk_begin; w[1] = static_cast<uint32_t>(t); w[2] = clk_real; w[3] = (tile & 0xFFFFFFu) | (xcc << 24);
+      w[4] = clk_trace0; w[5] = clk_trace1; w[6] = static_cast<uint32_t>(t2); w[7] = 0u;
+    }
+  }
+}
+
+}  // namespace
+}  // namespace rmclhip

@@ -42,10 +42,6 @@ struct FindParams {
   uint32_t* face_ids;
   // diagnostics (nullable): per physical wave {s_memtime at entry, at exit (low 32 bits), s_memrealtime at entry, tile | xcc << 24}
   uint32_t* wave_clock;
-  // mixed launch (traversal 18): per group of four tiles the tile delegated to the quad helper (0 none, 1..4), written by
-  // the host only; per tile the largest number of node visits of any of its rays, written by the kernel (nullable)
-  const uint8_t* tile_flags;
-  uint32_t* tile_cost;
 };
 
 struct MicpState;

@@ -1,1608 +1,24 @@
-// kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the RMCL / MICP-L hot path.
+// kernels.hip -- PRODUCTION kernels of librmclhip.so (gfx950, MI355X, CDNA4) for the RMCL / MICP-L hot path.
 //
-//  k_find            ray-casting correspondences: rm::*Simulator*::simulate as called by
-//                    RCC*::find (rmcl/src/rmcl/registration/RCCEmbree.cpp:26-36,89-99)
+//  k_find            (find_kernel.hip.h) ray-casting correspondences, the kinds the product can select
+//  k_cpc_find        (traverse.hip.h) closest-point correspondences, CPCEmbree::find
 //  k_reduce_partials rm::statistics_p2l (CorrespondencesCPU.cpp:26-30; gate MICPSensorCPU.cpp:70-84)
-//  k_micp_step       one inner iteration of MICPLocalizationNode::correctOnce
+//  k_micp_*          the inner iterations of MICPLocalizationNode::correctOnce
 //                    (rmcl_ros/src/nodes/micp_localization.cpp:915-964) + rm::umeyama_transform
-//  k_pf_update       PCDSensorUpdater{Embree,Optix}::update, all beams fused
+//  k_pf_update_v3    PCDSensorUpdater{Embree,Optix}::update, all beams fused
 //                    (PCDSensorUpdaterEmbree.cpp:290-342, optix/BeamEvaluateProgram.cu:15-130)
+//  k_pf_motion, k_gladiator_resample, k_likelihood_stats_*, k_pose_moments*: the rest of a filter cycle
 //
-// Wave64 design notes (DESIGN.md has the long form):
-//  * packet traversal: one wave = one 8x8 (configurable) tile of the scan image.  The current
-//    BVH4 node is WAVE-UNIFORM, so its 128 B are fetched with scalar loads (s_load_dwordx*)
-//    into SGPRs and the per-lane slab tests read them as SGPR operands; triangles likewise.
-//    The traversal stack is wave-uniform too and lives in ONE VGPR, one entry per lane,
-//    pushed / popped with v_writelane / v_readlane.  Descent decisions are v_cmp ballots.
-//  * per-lane traversal (incoherent particle-filter rays): per-lane stack in LDS laid out
-//    [depth][lane] (bank-conflict free), nodes via global_load_dwordx4.
-//  * the ray/triangle arithmetic (tri_accept) is an exact-order fp32 spec shared with the
-//    parity oracle; the slab test is free-form but conservative (boxes are padded at build).
-#include "kernels.h"
+// Experiments (rejected traversal kinds, probes, the round-2 particle-filter kernels) live in kernels_lab.hip and ship in
+// librmclhip_lab.so; launch_find / launch_pf_update hand kinds they do not own to that library when it is loaded
+// (lab_hooks.h), and report hipErrorNotSupported otherwise.
+#include "find_kernel.hip.h"
+#include "lab_hooks.h"
+#include "pf_common.hip.h"
 
 namespace rmclhip {
 
 namespace {
-
-typedef const __attribute__((address_space(4))) uint32_t* cu32p;  // constant AS: uniform loads -> SMEM
-typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-typedef const __attribute__((address_space(4))) u32x16* cu32x16p;
-
-// full 5-comparator ordering of the 4 children; the 3-comparator "nearest only" variant measured neutral on the
-// sphere and 3-5 % slower on the occluded room / particle filter (profiles/r01d_*)
-#define RMCL_FULL_SORT 1
-
-constexpr uint32_t kNone = 0xFFFFFFFFu;
-
-// closest hit of a ray: rec = index of the hit triangle's record, kNone (0xFFFFFFFF) for a miss; the ORIGINAL face id
-// lives in dword 15 of that record (the epilogues read it together with the unit normal)
-struct RayHit {
-  float t;
-  uint32_t rec;
-};
-
-__device__ __forceinline__ float asf(uint32_t u) { return __uint_as_float(u); }
-
-__device__ __forceinline__ float safe_inv(float d) {
-  const float ad = fabsf(d);
-  const float s = (ad < 1e-30f) ? copysignf(1e-30f, d) : d;
-  return 1.0f / s;
-}
-
-// Moeller-Trumbore in Embree's formulation; must match oracle/rmcl_oracle.c:tri_intersect op for op.
-// Returns the barycentric acceptance; T/aden is left to the caller (so a packet can skip the divide).
-// Depth test of the callers: Embree's near side is STRICT (absDen * tnear < T, tnear = 0 => T > 0): a ray that starts
-// exactly on a triangle does not hit it; far side t <= tfar.
-__device__ __forceinline__ bool tri_accept(f3 v0, f3 e1, f3 e2, f3 Ng, f3 O, f3 D, float& Tt, float& aden) {
-  const f3 C = sub3(v0, O);
-  const f3 R = cross_fma(C, D);
-  const float den = dot_fma(Ng, D);
-  aden = fabsf(den);
-  float U = dot_fma(R, e2);
-  float V = dot_fma(R, e1);
-  Tt = dot_fma(Ng, C);
-  if (den < 0.0f) { U = -U; V = -V; Tt = -Tt; }
-  return (den != 0.0f) && (U >= 0.0f) && (V >= 0.0f) && ((U + V) <= aden);
-}
-
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-// One child's slab test.  px/py/pz = (min, max) plane pair of the child per axis; both plane distances of an
-// axis are ONE packed FMA (v_pk_fma_f32).  Free-form arithmetic: conservative because the boxes are padded.
-__device__ __forceinline__ void slab(f2 px, f2 py, f2 pz, f3 inv, f3 noi, float best_t, float& tn, float& tf) {
-  const f2 ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
-  const f2 nx = {noi.x, noi.x}, ny = {noi.y, noi.y}, nz = {noi.z, noi.z};
-  const f2 tx = __builtin_elementwise_fma(px, ix, nx);
-  const f2 ty = __builtin_elementwise_fma(py, iy, ny);
-  const f2 tz = __builtin_elementwise_fma(pz, iz, nz);
-  tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), 0.0f));
-  tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), best_t));
-}
-
-// Per-ray constants of the sign-selected node fetch (layout.h): byte offsets, inside a 128-B node, of the group of
-// four planes the ray ENTERS through and of the group it leaves through, per axis.
-struct RaySlab {
-  f3 inv, noi;
-  uint32_t onx, ofx, ony, ofy, onz, ofz;
-};
-
-__device__ __forceinline__ RaySlab make_ray_slab(f3 O, f3 D) {
-  RaySlab r;
-  r.inv = mk3(safe_inv(D.x), safe_inv(D.y), safe_inv(D.z));
-  r.noi = mk3(-(O.x * r.inv.x), -(O.y * r.inv.y), -(O.z * r.inv.z));
-  r.onx = (r.inv.x < 0.0f) ? 16u : 0u;  r.ofx = 16u - r.onx;
-  r.ony = (r.inv.y < 0.0f) ? 48u : 32u; r.ofy = 80u - r.ony;
-  r.onz = (r.inv.z < 0.0f) ? 80u : 64u; r.ofz = 144u - r.onz;
-  return r;
-}
-
-// The four children of inner node `cur` for one lane: seven global_load_dwordx4 (near / far plane groups of the
-// three axes + child references), twelve packed FMAs (two children per instruction), then per child one
-// max3 / min3 pair.  key = entry distance bits (>= 0, so they order like the floats) or kNone for a miss; unused
-// slots hold an unreachable box (layout.h).  Free-form arithmetic: conservative because the boxes are padded.
-__device__ __forceinline__ void node_keys_at(const char* nb, const RaySlab& rs, float best_t, uint32_t (&key)[4], uint32_t (&ref)[4]) {
-  const uint4 qnx = *reinterpret_cast<const uint4*>(nb + rs.onx), qfx = *reinterpret_cast<const uint4*>(nb + rs.ofx);
-  const uint4 qny = *reinterpret_cast<const uint4*>(nb + rs.ony), qfy = *reinterpret_cast<const uint4*>(nb + rs.ofy);
-  const uint4 qnz = *reinterpret_cast<const uint4*>(nb + rs.onz), qfz = *reinterpret_cast<const uint4*>(nb + rs.ofz);
-  const uint4 qch = *reinterpret_cast<const uint4*>(nb + 96);
-  const f2 ix = {rs.inv.x, rs.inv.x}, iy = {rs.inv.y, rs.inv.y}, iz = {rs.inv.z, rs.inv.z};
-  const f2 nx = {rs.noi.x, rs.noi.x}, ny = {rs.noi.y, rs.noi.y}, nz = {rs.noi.z, rs.noi.z};
-  const f2 nx01 = __builtin_elementwise_fma(f2{asf(qnx.x), asf(qnx.y)}, ix, nx), nx23 = __builtin_elementwise_fma(f2{asf(qnx.z), asf(qnx.w)}, ix, nx);
-  const f2 fx01 = __builtin_elementwise_fma(f2{asf(qfx.x), asf(qfx.y)}, ix, nx), fx23 = __builtin_elementwise_fma(f2{asf(qfx.z), asf(qfx.w)}, ix, nx);
-  const f2 ny01 = __builtin_elementwise_fma(f2{asf(qny.x), asf(qny.y)}, iy, ny), ny23 = __builtin_elementwise_fma(f2{asf(qny.z), asf(qny.w)}, iy, ny);
-  const f2 fy01 = __builtin_elementwise_fma(f2{asf(qfy.x), asf(qfy.y)}, iy, ny), fy23 = __builtin_elementwise_fma(f2{asf(qfy.z), asf(qfy.w)}, iy, ny);
-  const f2 nz01 = __builtin_elementwise_fma(f2{asf(qnz.x), asf(qnz.y)}, iz, nz), nz23 = __builtin_elementwise_fma(f2{asf(qnz.z), asf(qnz.w)}, iz, nz);
-  const f2 fz01 = __builtin_elementwise_fma(f2{asf(qfz.x), asf(qfz.y)}, iz, nz), fz23 = __builtin_elementwise_fma(f2{asf(qfz.z), asf(qfz.w)}, iz, nz);
-  const float tnx[4] = {nx01.x, nx01.y, nx23.x, nx23.y}, tfx[4] = {fx01.x, fx01.y, fx23.x, fx23.y};
-  const float tny[4] = {ny01.x, ny01.y, ny23.x, ny23.y}, tfy[4] = {fy01.x, fy01.y, fy23.x, fy23.y};
-  const float tnz[4] = {nz01.x, nz01.y, nz23.x, nz23.y}, tfz[4] = {fz01.x, fz01.y, fz23.x, fz23.y};
-  ref[0] = qch.x; ref[1] = qch.y; ref[2] = qch.z; ref[3] = qch.w;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const float tn = fmaxf(fmaxf(fmaxf(tnx[c], tny[c]), tnz[c]), 0.0f);
-    const float tf = fminf(fminf(fminf(tfx[c], tfy[c]), tfz[c]), best_t);
-    key[c] = (tn <= tf) ? __float_as_uint(tn) : kNone;
-  }
-}
-
-__device__ __forceinline__ void node_keys(const uint32_t* __restrict__ nodes, uint32_t cur, const RaySlab& rs, float best_t,
-                                          uint32_t (&key)[4], uint32_t (&ref)[4]) {
-  node_keys_at(reinterpret_cast<const char*>(nodes) + (static_cast<size_t>(cur) << 7), rs, best_t, key, ref);
-}
-
-// LDS-resident top of the tree (north_star: "LDS-staged node tiles"): the nodes are stored breadth-first, so the first
-// kTop of them ARE the top levels; every block copies that prefix into its LDS once, and a lane whose current node
-// index is below kTop reads it from there.  The choice is per lane and per step, so the node address is a FLAT
-// pointer -- LDS aperture or global -- and the seven plane-group loads become flat_load_dwordx4: lanes still in the
-// top levels are served by the LDS (~64 cycles), the others by L1/L2 as before, in one instruction stream.
-template <int kTop>
-__device__ __forceinline__ const char* node_address(const uint32_t* __restrict__ nodes, const uint32_t* lds_top, uint32_t cur) {
-  const char* g = reinterpret_cast<const char*>(nodes);
-  if (kTop == 0) return g + (static_cast<size_t>(cur) << 7);
-  const char* l = reinterpret_cast<const char*>(lds_top);
-  return ((cur < static_cast<uint32_t>(kTop)) ? l : g) + (static_cast<size_t>(cur) << 7);
-}
-
-// One triangle test of the per-lane traversals from the first three dwordx4 of its record (same arithmetic and acceptance
-// as tri_accept's other callers: Tt > 0, t <= tfar, closest = (min t, then min face id)).  The face id is NOT read here:
-// it only decides exact ties in t, so the loop tracks the RECORD of the best hit and fetches the two face ids in the
-// (rare) tie branch; the caller's epilogue reads the winner's face id together with its normal.  One load fewer per
-// triangle, and no dependent load on the hit path.  best_rec == kNone <=> no hit yet.
-__device__ __forceinline__ void tri_update(uint4 a, uint4 b, uint4 c, uint32_t rec, const uint32_t* __restrict__ tris, f3 O, f3 D,
-                                           float ray_tfar, float& best_t, uint32_t& best_rec) {
-  const f3 v0 = mk3(asf(a.x), asf(a.y), asf(a.z));
-  const f3 e1 = mk3(asf(a.w), asf(b.x), asf(b.y));
-  const f3 e2 = mk3(asf(b.z), asf(b.w), asf(c.x));
-  const f3 Ng = mk3(asf(c.y), asf(c.z), asf(c.w));
-  float Tt, aden;
-  const bool ok = tri_accept(v0, e1, e2, Ng, O, D, Tt, aden);
-  if (ok) {
-    const float t = Tt / aden;
-    const bool acc = (Tt > 0.0f) && (t <= ray_tfar);
-    bool closer = acc && (t < best_t);
-    if (acc && (t == best_t) && (rec != best_rec)) {
-      // exact tie: the smaller ORIGINAL face id wins; a first hit at exactly t == tfar wins against "no hit"
-      closer = (best_rec == kNone) || (tris[static_cast<size_t>(rec) * 16u + 15u] < tris[static_cast<size_t>(best_rec) * 16u + 15u]);
-    }
-    best_t = closer ? t : best_t;
-    best_rec = closer ? rec : best_rec;
-  }
-}
-
-// A whole leaf (<= 4 records) in ONE memory round trip: the loop form waits for triangle i before it requests
-// triangle i+1 -- up to four dependent round trips per leaf visit, and the wave runs as many as its fullest leaf has
-// triangles.  Here the records of all four slots are requested together, unconditionally (a load under a wave-uniform
-// branch makes the compiler wait for it at the end of the branch); a lane whose leaf is shorter re-requests its last
-// record (same cache line, and a repeated test cannot change (best_t, best_rec)); the tests run in record order and
-// skip slots no lane of the wave fills: results identical to the loop.
-__device__ __forceinline__ void leaf_batch(const uint32_t* __restrict__ tris, uint32_t cur, f3 O, f3 D, float ray_tfar,
-                                           float& best_t, uint32_t& best_rec) {
-  const uint32_t first = cur & 0x0FFFFFFFu;
-  const uint32_t last = first + ((cur >> 28) & 7u);
-  const bool w2 = __any(last > first), w3 = __any(last > first + 1u), w4 = __any(last > first + 2u);
-  const uint32_t i1 = min(first + 1u, last), i2 = min(first + 2u, last), i3 = min(first + 3u, last);
-  const uint4* t0 = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(first) * 4u;
-  const uint4* t1 = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(i1) * 4u;
-  const uint4* t2 = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(i2) * 4u;
-  const uint4* t3 = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(i3) * 4u;
-  const uint4 a0 = t0[0], b0 = t0[1], c0 = t0[2];
-  const uint4 a1 = t1[0], b1 = t1[1], c1 = t1[2];
-  const uint4 a2 = t2[0], b2 = t2[1], c2 = t2[2];
-  const uint4 a3 = t3[0], b3 = t3[1], c3 = t3[2];
-  tri_update(a0, b0, c0, first, tris, O, D, ray_tfar, best_t, best_rec);
-  if (w2) tri_update(a1, b1, c1, i1, tris, O, D, ray_tfar, best_t, best_rec);
-  if (w3) tri_update(a2, b2, c2, i2, tris, O, D, ray_tfar, best_t, best_rec);
-  if (w4) tri_update(a3, b3, c3, i3, tris, O, D, ray_tfar, best_t, best_rec);
-}
-
-// the loop form of a leaf visit (one record per iteration), same rules
-__device__ __forceinline__ void leaf_loop(const uint32_t* __restrict__ tris, uint32_t cur, f3 O, f3 D, float ray_tfar,
-                                          float& best_t, uint32_t& best_rec) {
-  const uint32_t first = cur & 0x0FFFFFFFu;
-  const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
-  for (uint32_t i = 0; i < cnt; ++i) {
-    const uint4* tp = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(first + i) * 4u;
-    const uint4 a = tp[0], b = tp[1], c = tp[2];
-    tri_update(a, b, c, first + i, tris, O, D, ray_tfar, best_t, best_rec);
-  }
-}
-
-// maximum over the wave of a per-lane integer < 64, by six ballots (no cross-lane data movement)
-__device__ __forceinline__ uint32_t wave_max_6bit(uint32_t v) {
-  v = min(v, 63u);
-  uint32_t m = 0;
-#pragma unroll
-  for (int b = 5; b >= 0; --b) {
-    const uint32_t cand = m | (1u << b);
-    if (__any(v >= cand)) m = cand;
-  }
-  return m;
-}
-
-// face id of a record (kInvalidFace for "no hit"): one dword of the record's last 16 B
-__device__ __forceinline__ uint32_t record_face(const uint32_t* __restrict__ tris, uint32_t rec) {
-  return (rec != kNone) ? tris[static_cast<size_t>(rec) * 16u + 15u] : kInvalidFace;
-}
-
-// node_keys on the quantised twin of the node (layout.h: Node4Q): FOUR loads instead of seven.  The plane distance
-// t = (origin + q*scale - O) * inv is evaluated as q * (scale*inv) + (origin*inv - O*inv): six per-node
-// instructions, then one (packed) FMA per plane as before; the bytes are widened with v_cvt_f32_ubyteN.
-__device__ __forceinline__ void node_keys_q(const uint32_t* __restrict__ qnodes, uint32_t cur, const RaySlab& rs, float best_t,
-                                            uint32_t (&key)[4], uint32_t (&ref)[4]) {
-  const uint4* nb = reinterpret_cast<const uint4*>(qnodes) + static_cast<size_t>(cur) * 4u;
-  const uint4 qa = nb[0], qb = nb[1], qc = nb[2], qch = nb[3];
-  const float sx = asf(qa.w) * rs.inv.x, sy = asf(qb.x) * rs.inv.y, sz = asf(qb.y) * rs.inv.z;
-  const float bx = fmaf(asf(qa.x), rs.inv.x, rs.noi.x), by = fmaf(asf(qa.y), rs.inv.y, rs.noi.y), bz = fmaf(asf(qa.z), rs.inv.z, rs.noi.z);
-  const bool ngx = rs.inv.x < 0.0f, ngy = rs.inv.y < 0.0f, ngz = rs.inv.z < 0.0f;
-  const uint32_t qnx = ngx ? qb.w : qb.z, qfx = ngx ? qb.z : qb.w;
-  const uint32_t qny = ngy ? qc.y : qc.x, qfy = ngy ? qc.x : qc.y;
-  const uint32_t qnz = ngz ? qc.w : qc.z, qfz = ngz ? qc.z : qc.w;
-  ref[0] = qch.x; ref[1] = qch.y; ref[2] = qch.z; ref[3] = qch.w;
-  // bytes -> floats (v_cvt_f32_ubyteN), two children per packed FMA
-#define RMCL_Q2(w, a, b) f2{static_cast<float>(((w) >> (8 * (a))) & 0xFFu), static_cast<float>(((w) >> (8 * (b))) & 0xFFu)}
-  const f2 sx2 = {sx, sx}, sy2 = {sy, sy}, sz2 = {sz, sz}, bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
-  const f2 nx01 = __builtin_elementwise_fma(RMCL_Q2(qnx, 0, 1), sx2, bx2), nx23 = __builtin_elementwise_fma(RMCL_Q2(qnx, 2, 3), sx2, bx2);
-  const f2 fx01 = __builtin_elementwise_fma(RMCL_Q2(qfx, 0, 1), sx2, bx2), fx23 = __builtin_elementwise_fma(RMCL_Q2(qfx, 2, 3), sx2, bx2);
-  const f2 ny01 = __builtin_elementwise_fma(RMCL_Q2(qny, 0, 1), sy2, by2), ny23 = __builtin_elementwise_fma(RMCL_Q2(qny, 2, 3), sy2, by2);
-  const f2 fy01 = __builtin_elementwise_fma(RMCL_Q2(qfy, 0, 1), sy2, by2), fy23 = __builtin_elementwise_fma(RMCL_Q2(qfy, 2, 3), sy2, by2);
-  const f2 nz01 = __builtin_elementwise_fma(RMCL_Q2(qnz, 0, 1), sz2, bz2), nz23 = __builtin_elementwise_fma(RMCL_Q2(qnz, 2, 3), sz2, bz2);
-  const f2 fz01 = __builtin_elementwise_fma(RMCL_Q2(qfz, 0, 1), sz2, bz2), fz23 = __builtin_elementwise_fma(RMCL_Q2(qfz, 2, 3), sz2, bz2);
-#undef RMCL_Q2
-  const float tnx[4] = {nx01.x, nx01.y, nx23.x, nx23.y}, tfx[4] = {fx01.x, fx01.y, fx23.x, fx23.y};
-  const float tny[4] = {ny01.x, ny01.y, ny23.x, ny23.y}, tfy[4] = {fy01.x, fy01.y, fy23.x, fy23.y};
-  const float tnz[4] = {nz01.x, nz01.y, nz23.x, nz23.y}, tfz[4] = {fz01.x, fz01.y, fz23.x, fz23.y};
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const float tn = fmaxf(fmaxf(fmaxf(tnx[c], tny[c]), tnz[c]), 0.0f);
-    const float tf = fminf(fminf(fminf(tfx[c], tfy[c]), tfz[c]), best_t);
-    key[c] = (tn <= tf) ? __float_as_uint(tn) : kNone;
-  }
-}
-
-#define RMCL_CSWAP(i, j)                                   \
-  {                                                        \
-    const bool sw_ = key[j] < key[i];                      \
-    const uint32_t ka_ = sw_ ? key[j] : key[i];            \
-    const uint32_t kb_ = sw_ ? key[i] : key[j];            \
-    const uint32_t ra_ = sw_ ? ref[j] : ref[i];            \
-    const uint32_t rb_ = sw_ ? ref[i] : ref[j];            \
-    key[i] = ka_; key[j] = kb_; ref[i] = ra_; ref[j] = rb_; \
-  }
-
-// ---------------------------------------------------------------------------------------------
-// packet traversal: wave-uniform node, scalar loads, stack in a VGPR (needs stack_need <= 64)
-// ray_tfar < 0 marks an inactive lane.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void trace_packet(cu32p nodes, cu32p tris, f3 O, f3 D, float ray_tfar, uint32_t lane, RayHit& h) {
-  const f3 inv = mk3(safe_inv(D.x), safe_inv(D.y), safe_inv(D.z));
-  const f3 noi = mk3(-(O.x * inv.x), -(O.y * inv.y), -(O.z * inv.z));
-  float best_t = ray_tfar;
-  uint32_t best_face = kInvalidFace, best_rec = 0;
-
-  int stk = 0;       // 64 wave-uniform entries, entry i in lane i
-  uint32_t sp = 0;   // uniform
-  uint32_t cur = 0;  // uniform; root is always an inner node
-  for (;;) {
-    if (!(cur & kLeafBit)) {
-      // whole node in two s_load_dwordx16: dwords 0..15 = x and y plane groups; 16..31 = z groups, child[4], count
-      const cu32x16p np = reinterpret_cast<cu32x16p>(nodes + cur * kNodeDwords);
-      const u32x16 lo = np[0], hi = np[1];
-      uint32_t key[4], ref[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float tn, tf;
-        const f2 px = {asf(lo[c]), asf(lo[4 + c])}, py = {asf(lo[8 + c]), asf(lo[12 + c])};
-        const f2 pz = {asf(hi[c]), asf(hi[4 + c])};
-        slab(px, py, pz, inv, noi, best_t, tn, tf);
-        ref[c] = hi[8 + c];
-        const uint64_t m = __ballot(tn <= tf);  // unused slots hold an unreachable box (layout.h)
-        uint32_t k = kNone;
-        if (m != 0) {
-          const int first = __builtin_ctzll(m);
-          k = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(__float_as_uint(tn)), first));
-        }
-        key[c] = k;
-      }
-      RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
-      if (key[3] != kNone) { stk = (lane == sp) ? static_cast<int>(ref[3]) : stk; ++sp; }
-      if (key[2] != kNone) { stk = (lane == sp) ? static_cast<int>(ref[2]) : stk; ++sp; }
-      if (key[1] != kNone) { stk = (lane == sp) ? static_cast<int>(ref[1]) : stk; ++sp; }
-      if (key[0] != kNone) { cur = ref[0]; continue; }
-    } else {
-      const uint32_t first = cur & 0x0FFFFFFFu;
-      const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
-      // the whole leaf (<= 4 records, 256 contiguous bytes) is requested at once: four s_load_dwordx16 in
-      // flight cost one scalar-cache round trip instead of four (the record array is padded by 3 records)
-      const cu32x16p tp = reinterpret_cast<cu32x16p>(tris + first * kTriDwords);
-      const u32x16 trs[4] = {tp[0], tp[1], tp[2], tp[3]};
-#pragma unroll
-      for (uint32_t i = 0; i < kMaxLeafTris; ++i) {
-        if (i < cnt) {
-          const u32x16 tr = trs[i];
-          const f3 v0 = mk3(asf(tr[0]), asf(tr[1]), asf(tr[2]));
-          const f3 e1 = mk3(asf(tr[3]), asf(tr[4]), asf(tr[5]));
-          const f3 e2 = mk3(asf(tr[6]), asf(tr[7]), asf(tr[8]));
-          const f3 Ng = mk3(asf(tr[9]), asf(tr[10]), asf(tr[11]));
-          const uint32_t face = tr[15];
-          float Tt, aden;
-          const bool ok = tri_accept(v0, e1, e2, Ng, O, D, Tt, aden);
-          if (__ballot(ok) != 0) {
-            const float t = Tt / aden;
-            const bool acc = ok && (Tt > 0.0f) && (t <= ray_tfar);
-            const bool closer = acc && ((t < best_t) || ((t == best_t) && (face < best_face)));
-            best_t = closer ? t : best_t;
-            best_face = closer ? face : best_face;
-            best_rec = closer ? (first + i) : best_rec;
-          }
-        }
-      }
-    }
-    if (sp == 0) break;
-    --sp;
-    cur = static_cast<uint32_t>(__builtin_amdgcn_readlane(stk, sp));
-  }
-  h.t = best_t;
-  h.rec = (best_face != kInvalidFace) ? best_rec : kNone;
-}
-
-// ---------------------------------------------------------------------------------------------
-// per-lane traversal: every lane walks its own path; stack in LDS [depth][blockDim]
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void trace_lane(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris,
-                                           f3 O, f3 D, float ray_tfar, uint32_t* __restrict__ lds_stack,
-                                           uint32_t lds_stride, RayHit& h) {
-  const RaySlab rs = make_ray_slab(O, D);
-  float best_t = ray_tfar;
-  uint32_t best_face = kInvalidFace, best_rec = 0;
-  constexpr uint32_t kDone = 0x7FFFFFFFu;
-  uint32_t sp = 0;
-  uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
-  while (cur != kDone) {
-    if (!(cur & kLeafBit)) {
-      uint32_t key[4], ref[4];
-      node_keys(nodes, cur, rs, best_t, key, ref);
-      RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
-      if (key[3] != kNone) { lds_stack[sp * lds_stride] = ref[3]; ++sp; }
-      if (key[2] != kNone) { lds_stack[sp * lds_stride] = ref[2]; ++sp; }
-      if (key[1] != kNone) { lds_stack[sp * lds_stride] = ref[1]; ++sp; }
-      if (key[0] != kNone) { cur = ref[0]; continue; }
-    } else {
-      const uint32_t first = cur & 0x0FFFFFFFu;
-      const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
-      for (uint32_t i = 0; i < cnt; ++i) {
-        const uint4* tp = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(first + i) * 4u;
-        const uint4 a = tp[0], b = tp[1], c = tp[2], d = tp[3];
-        const f3 v0 = mk3(asf(a.x), asf(a.y), asf(a.z));
-        const f3 e1 = mk3(asf(a.w), asf(b.x), asf(b.y));
-        const f3 e2 = mk3(asf(b.z), asf(b.w), asf(c.x));
-        const f3 Ng = mk3(asf(c.y), asf(c.z), asf(c.w));
-        const uint32_t face = d.w;
-        float Tt, aden;
-        const bool ok = tri_accept(v0, e1, e2, Ng, O, D, Tt, aden);
-        if (ok) {
-          const float t = Tt / aden;
-          const bool acc = (Tt > 0.0f) && (t <= ray_tfar);
-          const bool closer = acc && ((t < best_t) || ((t == best_t) && (face < best_face)));
-          best_t = closer ? t : best_t;
-          best_face = closer ? face : best_face;
-          best_rec = closer ? (first + i) : best_rec;
-        }
-      }
-    }
-    if (sp == 0) { cur = kDone; }
-    else { --sp; cur = lds_stack[sp * lds_stride]; }
-  }
-  h.t = best_t;
-  h.rec = (best_face != kInvalidFace) ? best_rec : kNone;
-}
-
-// ---------------------------------------------------------------------------------------------
-// per-lane traversal, "while-while" form (Aila & Laine): every lane first descends through inner nodes
-// until it holds a leaf; only then does the wave run the (expensive) triangle tests, with most lanes
-// active.  The per-lane stack is split: the first kLdsEntries live in LDS ([entry][lane], conflict free), deeper
-// entries spill to private (scratch) memory.  A full 64-deep LDS stack costs 64 KB per 256-thread block (2 blocks
-// per CU); a pure scratch stack keeps occupancy but measured 272 MB of HBM-side write traffic per C4 update; 16
-// LDS entries (16 KB per block) catch almost every push.
-// ---------------------------------------------------------------------------------------------
-// kQuant: `nodes` points to the quantised Node4Q twins (four loads per node visit instead of seven)
-template <int kLdsEntries, bool kQuant = false, bool kLeafBatch = false, bool kVote = false>  // stack entries kept in LDS ([entry][lane]); the rest (up to 64 total) in scratch
-__device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris,
-                                              f3 O, f3 D, float ray_tfar, uint32_t* __restrict__ lds_stack,
-                                              uint32_t lds_stride, RayHit& h) {
-  const RaySlab rs = make_ray_slab(O, D);
-  float best_t = ray_tfar;
-  uint32_t best_rec = kNone;
-  constexpr uint32_t kDone = 0x7FFFFFFFu;
-  uint32_t priv[(kLdsEntries < 64) ? (64 - kLdsEntries) : 1];
-  uint32_t sp = 0;
-  uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
-#define RMCL_PUSH(v) { if (kLdsEntries >= 64 || sp < kLdsEntries) lds_stack[sp * lds_stride] = (v); else priv[sp - kLdsEntries] = (v); ++sp; }
-#define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; if (kLdsEntries >= 64 || sp < kLdsEntries) cur = lds_stack[sp * lds_stride]; else cur = priv[sp - kLdsEntries]; } }
-  for (;;) {
-    const uint64_t m_act = __ballot(cur != kDone);
-    if (m_act == 0) break;
-    const uint32_t na = static_cast<uint32_t>(__popcll(m_act));   // rays alive at the start of this round
-    // phase 1: inner nodes (kVote: the leaf trigger, see trace_lane_bf_tail)
-    while ((cur != kDone) && !(cur & kLeafBit)) {
-      uint32_t key[4], ref[4];
-      if (kQuant) node_keys_q(nodes, cur, rs, best_t, key, ref);
-      else node_keys(nodes, cur, rs, best_t, key, ref);
-#ifdef RMCL_FULL_SORT
-      RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
-#else
-      RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2)  // nearest child to slot 0; the deferred ones stay unordered
-#endif
-      if (key[3] != kNone) RMCL_PUSH(ref[3])
-      if (key[2] != kNone) RMCL_PUSH(ref[2])
-      if (key[1] != kNone) RMCL_PUSH(ref[1])
-      if (key[0] != kNone) cur = ref[0];
-      else RMCL_POP()
-      if (kVote) {
-        if (5u * static_cast<uint32_t>(__popcll(__ballot((cur != kDone) && !(cur & kLeafBit)))) <= 2u * na) break;
-      }
-    }
-    // phase 2: this lane's leaf (if any)
-    if ((cur != kDone) && (cur & kLeafBit)) {
-      if (kLeafBatch) leaf_batch(tris, cur, O, D, ray_tfar, best_t, best_rec);
-      else leaf_loop(tris, cur, O, D, ray_tfar, best_t, best_rec);
-      RMCL_POP()
-    }
-  }
-#undef RMCL_PUSH
-#undef RMCL_POP
-  h.t = best_t;
-  h.rec = best_rec;
-}
-
-// ---------------------------------------------------------------------------------------------
-// per-lane while-while traversal, BRANCH-FREE node step (the form every one-lane-per-ray kernel now uses).
-// In vivo a node step of trace_lane_ww costs ~1300 cycles on a chip full of C2 waves (tools/wave_timeline.py) and ~880 for
-// a lone wave (tools/probe_find.py: ~430 waiting for the node + ~450 of issue) -- and the ISSUE half was mostly control:
-// every conditional push is a v_cmp + s_and_saveexec + branch + (LDS-or-scratch test, another saveexec pair) + a 32-bit
-// multiply for `sp * stride`; the "nothing hit: pop" arm is another nest.  Here
-//   * the stack row stride is the compile-time block size (shift-add addressing, no v_mul_lo_u32),
-//   * the three deferred children are stored UNCONDITIONALLY at rows sp, sp', sp'' with sp advancing only past real hits
-//     (the children are sorted, misses last, so a miss is overwritten by the next store or lands above the top),
-//   * row 0 holds the sentinel kDone and the current top of the stack is fetched speculatively with the node, so
-//     "no child hit -> pop" is two selects; an empty stack ends the ray without a test,
-//   * node data is addressed as SGPR base + 32-bit lane offset (one v_lshl_add_u32 per load instead of 64-bit adds).
-// Rows >= kRows live in private scratch as before; a wave whose lanes might touch them in this step (wave-uniform
-// test) takes the general path.  Same visits, same arithmetic, same results as trace_lane_ww.
-// ---------------------------------------------------------------------------------------------
-// slab tests + keys of the four children from the seven 16-B groups of a node (near / far plane groups per axis + refs)
-__device__ __forceinline__ void node_keys_from(uint4 qnx, uint4 qfx, uint4 qny, uint4 qfy, uint4 qnz, uint4 qfz, uint4 qch,
-                                               const RaySlab& rs, float best_t, uint32_t (&key)[4], uint32_t (&ref)[4]) {
-  const f2 ix = {rs.inv.x, rs.inv.x}, iy = {rs.inv.y, rs.inv.y}, iz = {rs.inv.z, rs.inv.z};
-  const f2 nx = {rs.noi.x, rs.noi.x}, ny = {rs.noi.y, rs.noi.y}, nz = {rs.noi.z, rs.noi.z};
-  const f2 nx01 = __builtin_elementwise_fma(f2{asf(qnx.x), asf(qnx.y)}, ix, nx), nx23 = __builtin_elementwise_fma(f2{asf(qnx.z), asf(qnx.w)}, ix, nx);
-  const f2 fx01 = __builtin_elementwise_fma(f2{asf(qfx.x), asf(qfx.y)}, ix, nx), fx23 = __builtin_elementwise_fma(f2{asf(qfx.z), asf(qfx.w)}, ix, nx);
-  const f2 ny01 = __builtin_elementwise_fma(f2{asf(qny.x), asf(qny.y)}, iy, ny), ny23 = __builtin_elementwise_fma(f2{asf(qny.z), asf(qny.w)}, iy, ny);
-  const f2 fy01 = __builtin_elementwise_fma(f2{asf(qfy.x), asf(qfy.y)}, iy, ny), fy23 = __builtin_elementwise_fma(f2{asf(qfy.z), asf(qfy.w)}, iy, ny);
-  const f2 nz01 = __builtin_elementwise_fma(f2{asf(qnz.x), asf(qnz.y)}, iz, nz), nz23 = __builtin_elementwise_fma(f2{asf(qnz.z), asf(qnz.w)}, iz, nz);
-  const f2 fz01 = __builtin_elementwise_fma(f2{asf(qfz.x), asf(qfz.y)}, iz, nz), fz23 = __builtin_elementwise_fma(f2{asf(qfz.z), asf(qfz.w)}, iz, nz);
-  const float tnx[4] = {nx01.x, nx01.y, nx23.x, nx23.y}, tfx[4] = {fx01.x, fx01.y, fx23.x, fx23.y};
-  const float tny[4] = {ny01.x, ny01.y, ny23.x, ny23.y}, tfy[4] = {fy01.x, fy01.y, fy23.x, fy23.y};
-  const float tnz[4] = {nz01.x, nz01.y, nz23.x, nz23.y}, tfz[4] = {fz01.x, fz01.y, fz23.x, fz23.y};
-  ref[0] = qch.x; ref[1] = qch.y; ref[2] = qch.z; ref[3] = qch.w;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const float tn = fmaxf(fmaxf(fmaxf(tnx[c], tny[c]), tnz[c]), 0.0f);
-    const float tf = fminf(fminf(fminf(tfx[c], tfy[c]), tfz[c]), best_t);
-    key[c] = (tn <= tf) ? __float_as_uint(tn) : kNone;
-  }
-}
-
-__device__ __forceinline__ void node_keys_off(const uint32_t* __restrict__ nodes, uint32_t byte_off, const RaySlab& rs, float best_t,
-                                              uint32_t (&key)[4], uint32_t (&ref)[4]) {
-  // uniform base + zero-extended 32-bit offsets (map_create bounds the node array below 4 GB)
-  const char* nb = reinterpret_cast<const char*>(nodes);
-  const uint4 qnx = *reinterpret_cast<const uint4*>(nb + (byte_off + rs.onx)), qfx = *reinterpret_cast<const uint4*>(nb + (byte_off + rs.ofx));
-  const uint4 qny = *reinterpret_cast<const uint4*>(nb + (byte_off + rs.ony)), qfy = *reinterpret_cast<const uint4*>(nb + (byte_off + rs.ofy));
-  const uint4 qnz = *reinterpret_cast<const uint4*>(nb + (byte_off + rs.onz)), qfz = *reinterpret_cast<const uint4*>(nb + (byte_off + rs.ofz));
-  const uint4 qch = *reinterpret_cast<const uint4*>(nb + (byte_off + 96u));
-  node_keys_from(qnx, qfx, qny, qfy, qnz, qfz, qch, rs, best_t, key, ref);
-}
-
-// WAVE-UNIFORM node (north_star: "wavefront ballot for packet traversal"): ~60 % of the node steps of a C2 scan are taken by
-// a wave whose active lanes all stand on the SAME node (the top of the tree, tools/probe_find.py).  A single scan is
-// bound by the vector memory pipeline -- 7 x 16 B x 64 lanes = 7 KB through the 64 B/clk texture path per wave and
-// step, 8 waves per CU -- so such a step fetches the node ONCE with scalar loads (scalar cache, not the vector path) into
-// SGPRs and the lanes read the planes as scalar operands.  When the wave's rays also share the sign octant of their
-// direction (every tile that does not straddle a coordinate plane) the near / far plane groups are selected by scalar
-// address arithmetic exactly like the per-lane offsets, so the arithmetic -- and therefore keys, order and results --
-// is identical to the vector path.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(4))) u32x4* cu32x4p;
-
-__device__ __forceinline__ uint4 sload4(const uint32_t* __restrict__ base, uint32_t byte_off) {
-  const u32x4 v = *reinterpret_cast<cu32x4p>(reinterpret_cast<const __attribute__((address_space(4))) char*>((cu32p)(base)) + byte_off);
-  return uint4{v.x, v.y, v.z, v.w};
-}
-
-// octant offsets of the wave (uniform): same values as RaySlab's per-lane ones
-struct WaveOctant {
-  uint32_t onx, ofx, ony, ofy, onz, ofz;
-};
-
-__device__ __forceinline__ void node_keys_uniform(const uint32_t* __restrict__ nodes, uint32_t cur_uniform, const WaveOctant& wo,
-                                                  const RaySlab& rs, float best_t, uint32_t (&key)[4], uint32_t (&ref)[4]) {
-  const uint32_t b = cur_uniform << 7;
-  const uint4 qnx = sload4(nodes, b + wo.onx), qfx = sload4(nodes, b + wo.ofx);
-  const uint4 qny = sload4(nodes, b + wo.ony), qfy = sload4(nodes, b + wo.ofy);
-  const uint4 qnz = sload4(nodes, b + wo.onz), qfz = sload4(nodes, b + wo.ofz);
-  const uint4 qch = sload4(nodes, b + 96u);
-  node_keys_from(qnx, qfx, qny, qfy, qnz, qfz, qch, rs, best_t, key, ref);
-}
-
-constexpr uint32_t kBfStride = 256u;  // stack row stride in dwords = threads per block of every kernel that calls trace_lane_bf
-
-// kRows: stack rows in LDS per lane INCLUDING the sentinel row 0 (row r of this lane at lds_col[r * 256]); deeper entries
-// (up to 64 in total, the builder's bound) in scratch
-template <int kRows, bool kQuant = false, bool kLeafBatch = false, bool kUniform = false>
-__device__ __forceinline__ void trace_lane_bf(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris, f3 O, f3 D,
-                                              float ray_tfar, uint32_t* __restrict__ lds_col, RayHit& h, uint32_t* visits = nullptr) {
-  uint32_t nvis = 0;  // node visits of this ray
-  const RaySlab rs = make_ray_slab(O, D);
-  // do all rays of the wave share the sign octant of their direction?  (lanes without a ray do not vote)
-  WaveOctant wo = {0u, 0u, 0u, 0u, 0u, 0u};
-  bool uni_oct = false;
-  if (kUniform && !kQuant) {
-    const bool live = ray_tfar >= 0.0f;
-    const uint32_t oct = (rs.inv.x < 0.0f ? 1u : 0u) | (rs.inv.y < 0.0f ? 2u : 0u) | (rs.inv.z < 0.0f ? 4u : 0u);
-    const uint64_t m_live = __ballot(live);
-    if (m_live != 0) {
-      const uint32_t o0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(oct), __builtin_ctzll(m_live)));
-      uni_oct = __ballot(live && oct != o0) == 0;
-      wo.onx = (o0 & 1u) ? 16u : 0u;  wo.ofx = 16u - wo.onx;
-      wo.ony = (o0 & 2u) ? 48u : 32u; wo.ofy = 80u - wo.ony;
-      wo.onz = (o0 & 4u) ? 80u : 64u; wo.ofz = 144u - wo.onz;
-    }
-  }
-  float best_t = ray_tfar;
-  uint32_t best_rec = kNone;
-  constexpr uint32_t kDone = 0x7FFFFFFFu;
-  uint32_t priv[(kRows < 65) ? (65 - kRows) : 1];
-  lds_col[0] = kDone;  // sentinel
-  uint32_t sp = 1;     // first free row
-  uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
-  // general row access (rare path)
-#define RMCL_ROW_ST(r, v) { if ((r) < static_cast<uint32_t>(kRows)) lds_col[(r) * kBfStride] = (v); else priv[(r) - kRows] = (v); }
-#define RMCL_ROW_LD(r) (((r) < static_cast<uint32_t>(kRows)) ? lds_col[(r) * kBfStride] : priv[(r) - kRows])
-  while (__any(cur != kDone)) {
-    // phase 1: inner nodes (cur < kDone <=> inner node: leaf references have bit 31 set)
-    while (cur < kDone) {
-      uint32_t key[4], ref[4];
-      ++nvis;
-      if (!__any(sp + 3u > static_cast<uint32_t>(kRows))) {
-        // ---- fast path: every row this step can touch is in LDS (wave-uniform) ----
-        const uint32_t top = lds_col[(sp - 1u) * kBfStride];
-        const uint32_t c0 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(cur)));
-        if (kUniform && !kQuant && uni_oct && !__any(cur != c0)) node_keys_uniform(nodes, c0, wo, rs, best_t, key, ref);
-        else if (kQuant) node_keys_q(nodes, cur, rs, best_t, key, ref);
-        else node_keys_off(nodes, cur << 7, rs, best_t, key, ref);
-        RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
-        lds_col[sp * kBfStride] = ref[3]; sp += (key[3] != kNone) ? 1u : 0u;
-        lds_col[sp * kBfStride] = ref[2]; sp += (key[2] != kNone) ? 1u : 0u;
-        lds_col[sp * kBfStride] = ref[1]; sp += (key[1] != kNone) ? 1u : 0u;
-        const bool any = key[0] != kNone;
-        cur = any ? ref[0] : top;
-        sp = any ? sp : (sp - 1u);
-      } else {
-        if (kQuant) node_keys_q(nodes, cur, rs, best_t, key, ref);
-        else node_keys_off(nodes, cur << 7, rs, best_t, key, ref);
-        RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
-        if (key[3] != kNone) { RMCL_ROW_ST(sp, ref[3]) ++sp; }
-        if (key[2] != kNone) { RMCL_ROW_ST(sp, ref[2]) ++sp; }
-        if (key[1] != kNone) { RMCL_ROW_ST(sp, ref[1]) ++sp; }
-        if (key[0] != kNone) cur = ref[0];
-        else { --sp; cur = RMCL_ROW_LD(sp); }
-      }
-    }
-    // phase 2: this lane's leaf (if any)
-    if (cur != kDone) {
-      if (kLeafBatch) leaf_batch(tris, cur, O, D, ray_tfar, best_t, best_rec);
-      else leaf_loop(tris, cur, O, D, ray_tfar, best_t, best_rec);
-      --sp;
-      cur = RMCL_ROW_LD(sp);
-    }
-  }
-#undef RMCL_ROW_ST
-#undef RMCL_ROW_LD
-  h.t = best_t;
-  h.rec = best_rec;
-  if (visits) *visits = nvis;
-}
-
-// ---------------------------------------------------------------------------------------------
-// quad-cooperative traversal: FOUR lanes per ray, lane c of the quad owns child slot c of the current node and
-// triangle c of the current leaf (leaves hold <= 4 triangles).  A single scan is bound by the slowest ray's chain
-// of dependent node fetches (tools/latency_explore.py: one wave alone takes 2/3 of the full scan's time), so the
-// work of one step is spread over four lanes: one slab test instead of four, a rank computation over DPP
-// quad_perm instead of a sorting network, up to four triangle tests at once.  The quad's stack (64 entries, the
-// builder's bound) lives in LDS.  Same acceptance rules and tie-break as trace_lane_ww: identical results.
-// ---------------------------------------------------------------------------------------------
-template <int kCtrl>
-__device__ __forceinline__ uint32_t quad_dpp(uint32_t v) {
-  return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), kCtrl, 0xF, 0xF, true));
-}
-constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kQuadXor3 = 0x1B;  // quad_perm [1,0,3,2] [2,3,0,1] [3,2,1,0]
-constexpr uint32_t kQuadStackEntries = 1u + 64u + 4u;            // sentinel + the builder's bound + scratch rows
-
-// A traversal in progress, handed from one lane to a quad (see trace_lane_ww_tail): current node, number of stack
-// entries already stored in rows 1..n_stack of the quad's column, and the best hit so far.
-struct QuadResume {
-  uint32_t cur, n_stack;
-  float best_t;
-  uint32_t best_face, best_rec;
-};
-
-template <bool kResume = false>
-__device__ __forceinline__ void trace_quad(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris, f3 O,
-                                           f3 D, float ray_tfar, uint32_t c, uint32_t ray, uint32_t* __restrict__ lds,
-                                           RayHit& h, const QuadResume* resume = nullptr, uint32_t* visits = nullptr) {
-  uint32_t nvis = 0;  // node visits of this ray (the mixed launch's cost measure)
-  const RaySlab rs = make_ray_slab(O, D);
-  float best_t = kResume ? resume->best_t : ray_tfar;
-  uint32_t best_face = kResume ? resume->best_face : kInvalidFace, best_rec = kResume ? resume->best_rec : 0u;
-  constexpr uint32_t kDone = 0x7FFFFFFFu;
-  // The quad's stack: entry e of ray r at byte (e*64 + r)*4 of `lds` (kQuadStackEntries rows).  Row 0 holds the
-  // sentinel kDone, so that popping an empty stack ends the ray without a test; rows above the top are scratch:
-  // every lane stores its child reference every step (deferred children below the new top, the rest above it)
-  // and the top of the stack is fetched speculatively together with the node -- no branch in a node step.
-  const char* nbase = reinterpret_cast<const char*>(nodes);
-  char* sbase = reinterpret_cast<char*>(lds) + ray * 4u;
-  if (c == 0u) *reinterpret_cast<uint32_t*>(sbase) = kDone;
-  uint32_t spb = kResume ? ((resume->n_stack + 1u) << 8) : 256u;  // byte offset of the first free row
-  uint32_t cur = (ray_tfar >= 0.0f) ? (kResume ? resume->cur : 0u) : kDone;
-  // this lane's child inside a child-major node (layout.h: Node4C): 32 B = two dwordx4
-  const uint32_t coff = c * 32u;
-  const bool ngx = rs.inv.x < 0.0f, ngy = rs.inv.y < 0.0f, ngz = rs.inv.z < 0.0f;
-  while (__any(cur != kDone)) {
-    while (cur < kDone) {  // inner node (leaf references have bit 31 set)
-      const uint4* nd = reinterpret_cast<const uint4*>(nbase + (cur << 7) + coff);
-      const uint4 q0 = nd[0], q1 = nd[1];  // lo.x lo.y lo.z hi.x | hi.y hi.z ref pad
-      const uint32_t top = *reinterpret_cast<const uint32_t*>(sbase + (spb - 256u));
-      ++nvis;
-      const float pnx = ngx ? asf(q0.w) : asf(q0.x), pfx = ngx ? asf(q0.x) : asf(q0.w);
-      const float pny = ngy ? asf(q1.x) : asf(q0.y), pfy = ngy ? asf(q0.y) : asf(q1.x);
-      const float pnz = ngz ? asf(q1.y) : asf(q0.z), pfz = ngz ? asf(q0.z) : asf(q1.y);
-      const uint32_t ref = q1.z;
-      const float tn = fmaxf(fmaxf(fmaxf(fmaf(pnx, rs.inv.x, rs.noi.x), fmaf(pny, rs.inv.y, rs.noi.y)), fmaf(pnz, rs.inv.z, rs.noi.z)), 0.0f);
-      const float tf = fminf(fminf(fminf(fmaf(pfx, rs.inv.x, rs.noi.x), fmaf(pfy, rs.inv.y, rs.noi.y)), fmaf(pfz, rs.inv.z, rs.noi.z)), best_t);
-      // unique keys: entry distance with the slot number in the two low mantissa bits; misses (unused slots hold
-      // an unreachable box, layout.h) sort last
-      const uint32_t key = ((tn <= tf) ? (__float_as_uint(tn) & ~3u) : 0xFFFFFFFCu) | c;
-      const uint32_t k1 = quad_dpp<kQuadXor1>(key), k2 = quad_dpp<kQuadXor2>(key), k3 = quad_dpp<kQuadXor3>(key);
-      const uint32_t rank = (k1 < key ? 1u : 0u) + (k2 < key ? 1u : 0u) + (k3 < key ? 1u : 0u);
-      const uint32_t kmin = min(min(key, k1), min(k2, k3));
-      // number of hits = 4 - misses; all four keys are known to every lane
-      const uint32_t nh = (key < 0xFFFFFFFCu ? 1u : 0u) + (k1 < 0xFFFFFFFCu ? 1u : 0u) + (k2 < 0xFFFFFFFCu ? 1u : 0u) +
-                          (k3 < 0xFFFFFFFCu ? 1u : 0u);
-      const uint32_t sel = (key == kmin) ? ref : 0u;
-      const uint32_t s1 = sel | quad_dpp<kQuadXor1>(sel);
-      const uint32_t nearest = s1 | quad_dpp<kQuadXor2>(s1);
-      // rows: deferred hits (rank 1..nh-1) at spb + (nh-1-rank), second nearest on top; rank 0 and the misses land
-      // in the scratch rows at or above the new top
-      const uint32_t row = (rank < nh) ? (nh - 1u - rank) : rank;
-      *reinterpret_cast<uint32_t*>(sbase + spb + (row << 8)) = ref;
-      const bool any = nh != 0u;
-      cur = any ? nearest : top;
-      spb = any ? (spb + ((nh - 1u) << 8)) : (spb - 256u);
-    }
-    if (cur != kDone) {
-      const uint32_t first = cur & 0x0FFFFFFFu;
-      const uint32_t cnt = ((cur >> 28) & 7u) + 1u;  // <= kMaxLeafTris = 4
-      const uint32_t idx = first + ((c < cnt) ? c : (cnt - 1u));
-      const uint4* tp = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(idx) * 4u;
-      const uint4 a = tp[0], b = tp[1], cc = tp[2], d = tp[3];
-      const uint32_t top = *reinterpret_cast<const uint32_t*>(sbase + (spb - 256u));
-      const f3 v0 = mk3(asf(a.x), asf(a.y), asf(a.z));
-      const f3 e1 = mk3(asf(a.w), asf(b.x), asf(b.y));
-      const f3 e2 = mk3(asf(b.z), asf(b.w), asf(cc.x));
-      const f3 Ng = mk3(asf(cc.y), asf(cc.z), asf(cc.w));
-      float Tt, aden;
-      const bool ok = tri_accept(v0, e1, e2, Ng, O, D, Tt, aden);
-      const float t = Tt / aden;
-      const bool acc = ok && (c < cnt) && (Tt > 0.0f) && (t <= ray_tfar);
-      // quad minimum of (t, face): candidates that fail carry (+inf, invalid face) and never win
-      float ct = acc ? t : __builtin_inff();
-      uint32_t cf = acc ? d.w : kInvalidFace, cr = idx;
-      {
-        const float ot = __uint_as_float(quad_dpp<kQuadXor1>(__float_as_uint(ct)));
-        const uint32_t of = quad_dpp<kQuadXor1>(cf), orr = quad_dpp<kQuadXor1>(cr);
-        const bool take = (ot < ct) || ((ot == ct) && (of < cf));
-        ct = take ? ot : ct; cf = take ? of : cf; cr = take ? orr : cr;
-      }
-      {
-        const float ot = __uint_as_float(quad_dpp<kQuadXor2>(__float_as_uint(ct)));
-        const uint32_t of = quad_dpp<kQuadXor2>(cf), orr = quad_dpp<kQuadXor2>(cr);
-        const bool take = (ot < ct) || ((ot == ct) && (of < cf));
-        ct = take ? ot : ct; cf = take ? of : cf; cr = take ? orr : cr;
-      }
-      const bool closer = (cf != kInvalidFace) && ((ct < best_t) || ((ct == best_t) && (cf < best_face)));
-      best_t = closer ? ct : best_t;
-      best_face = closer ? cf : best_face;
-      best_rec = closer ? cr : best_rec;
-      cur = top;
-      spb -= 256u;
-    }
-  }
-  h.t = best_t;
-  h.rec = (best_face != kInvalidFace) ? best_rec : kNone;
-  if (visits) *visits = nvis;
-}
-
-// trace_lane_ww whose LAST rays are finished by quads.  A single scan ends when its slowest ray ends, and that ray sits
-// in a wave whose other lanes have long been idle: once at most kTailRays rays of the wave are still walking, each of
-// them is handed to four lanes (state through LDS, its stack copied into a quad-layout column) and finishes with
-// trace_quad -- shorter node steps, four triangles per leaf step -- instead of crawling on alone.  Same visits per
-// ray up to ordering, same results.  LDS: lane stacks | quad-tail stacks (64 columns x kQuadStackEntries rows) | hand-over
-// slots (4 waves x kTailRays x 12 dwords).
-constexpr uint32_t kTailRays = 16;
-constexpr uint32_t kTailXferDwords = 12;
-
-template <int kLdsEntries, int kTop = 0, bool kLeafBatch = false, bool kVote = false>
-__device__ __forceinline__ void trace_lane_ww_tail(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ cnodes,
-                                                   const uint32_t* __restrict__ tris, f3 O, f3 D, float ray_tfar,
-                                                   uint32_t* __restrict__ lds_stack, uint32_t lds_stride,
-                                                   uint32_t* __restrict__ qstack, uint32_t* __restrict__ xfer_wave,
-                                                   RayHit& h, const uint32_t* lds_top = nullptr) {
-  const RaySlab rs = make_ray_slab(O, D);
-  float best_t = ray_tfar;
-  uint32_t best_rec = kNone;
-  constexpr uint32_t kDone = 0x7FFFFFFFu;
-  uint32_t priv[(kLdsEntries < 64) ? (64 - kLdsEntries) : 1];
-  uint32_t sp = 0;
-  uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-#define RMCL_PUSH(v) { if (kLdsEntries >= 64 || sp < kLdsEntries) lds_stack[sp * lds_stride] = (v); else priv[sp - kLdsEntries] = (v); ++sp; }
-#define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; if (kLdsEntries >= 64 || sp < kLdsEntries) cur = lds_stack[sp * lds_stride]; else cur = priv[sp - kLdsEntries]; } }
-  for (;;) {
-    const uint64_t m_act = __ballot(cur != kDone);
-    if (m_act == 0) break;
-    const uint32_t na = static_cast<uint32_t>(__popcll(m_act));
-    if (na <= kTailRays) {
-      // ---- hand the remaining rays to quads ----
-      const bool mine = cur != kDone;
-      const uint32_t j = static_cast<uint32_t>(__popcll(m_act & ((1ull << lane) - 1ull)));
-      if (mine) {
-        uint32_t* x = xfer_wave + j * kTailXferDwords;
-        x[0] = __float_as_uint(O.x); x[1] = __float_as_uint(O.y); x[2] = __float_as_uint(O.z);
-        x[3] = __float_as_uint(D.x); x[4] = __float_as_uint(D.y); x[5] = __float_as_uint(D.z);
-        x[6] = __float_as_uint(ray_tfar); x[7] = __float_as_uint(best_t);
-        x[8] = record_face(tris, best_rec);  // the quad traversal carries (t, face id) pairs
-        x[9] = best_rec;
-        x[10] = cur; x[11] = sp;
-        // the stack, bottom to top, into rows 1..sp of column (wave*16 + j) of the quad-layout region
-        uint32_t* col = qstack + (wave * kTailRays + j);
-        for (uint32_t e = 0; e < sp; ++e) {
-          const uint32_t v = (kLdsEntries >= 64 || e < kLdsEntries) ? lds_stack[e * lds_stride] : priv[e - kLdsEntries];
-          col[(e + 1u) * 64u] = v;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();  // the hand-over slots and stack columns are read by OTHER lanes of this wave
-      const uint32_t q = lane >> 2, c = lane & 3u;
-      const bool have = q < na;
-      const uint32_t* x = xfer_wave + (have ? q : 0u) * kTailXferDwords;
-      const f3 Oq = mk3(asf(x[0]), asf(x[1]), asf(x[2])), Dq = mk3(asf(x[3]), asf(x[4]), asf(x[5]));
-      QuadResume rsm;
-      rsm.cur = x[10]; rsm.n_stack = x[11]; rsm.best_t = asf(x[7]); rsm.best_face = x[8]; rsm.best_rec = x[9];
-      const float tfq = have ? asf(x[6]) : -1.0f;
-      RayHit hq;
-      trace_quad<true>(cnodes, tris, Oq, Dq, tfq, c, wave * kTailRays + q, qstack, hq, &rsm);
-      if (have && c == 0u) {
-        uint32_t* y = xfer_wave + q * kTailXferDwords;
-        y[7] = __float_as_uint(hq.t); y[9] = hq.rec;
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (mine) {
-        const uint32_t* y = xfer_wave + j * kTailXferDwords;
-        best_t = asf(y[7]); best_rec = y[9];
-      }
-      break;
-    }
-    // phase 1: inner nodes (kVote: left early by the leaf trigger of trace_lane_bf_tail; `na` = rays alive in this round)
-    while ((cur != kDone) && !(cur & kLeafBit)) {
-      uint32_t key[4], ref[4];
-      node_keys_at(node_address<kTop>(nodes, lds_top, cur), rs, best_t, key, ref);
-      RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
-      if (key[3] != kNone) RMCL_PUSH(ref[3])
-      if (key[2] != kNone) RMCL_PUSH(ref[2])
-      if (key[1] != kNone) RMCL_PUSH(ref[1])
-      if (key[0] != kNone) cur = ref[0];
-      else RMCL_POP()
-      if (kVote) {
-        if (5u * static_cast<uint32_t>(__popcll(__ballot((cur != kDone) && !(cur & kLeafBit)))) <= 2u * na) break;
-      }
-    }
-    // phase 2: this lane's leaf (if any)
-    if ((cur != kDone) && (cur & kLeafBit)) {
-      if (kLeafBatch) leaf_batch(tris, cur, O, D, ray_tfar, best_t, best_rec);
-      else leaf_loop(tris, cur, O, D, ray_tfar, best_t, best_rec);
-      RMCL_POP()
-    }
-  }
-#undef RMCL_PUSH
-#undef RMCL_POP
-  h.t = best_t;
-  h.rec = best_rec;
-}
-
-// trace_lane_bf whose LAST rays are finished by quads (see trace_lane_ww_tail): branch-free node steps and one-round-trip
-// leaves while more than kTailRays rays of the wave are walking, then each remaining ray gets four lanes.
-// LDS: lane stacks (kRows x 256) | quad-tail stacks (64 columns x kQuadStackEntries rows) | hand-over slots.
-template <int kRows, bool kLeafBatch, int kLeafTrigger = 0>
-__device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ cnodes,
-                                                   const uint32_t* __restrict__ tris, f3 O, f3 D, float ray_tfar,
-                                                   uint32_t* __restrict__ lds_col, uint32_t* __restrict__ qstack,
-                                                   uint32_t* __restrict__ xfer_wave, RayHit& h, uint32_t* visits = nullptr) {
-  const RaySlab rs = make_ray_slab(O, D);
-  float best_t = ray_tfar;
-  uint32_t best_rec = kNone;
-  uint32_t nvis = 0;  // node visits of this ray
-  constexpr uint32_t kDone = 0x7FFFFFFFu;
-  uint32_t priv[(kRows < 65) ? (65 - kRows) : 1];
-  lds_col[0] = kDone;
-  uint32_t sp = 1;
-  uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-#define RMCL_ROW_ST(r, v) { if ((r) < static_cast<uint32_t>(kRows)) lds_col[(r) * kBfStride] = (v); else priv[(r) - kRows] = (v); }
-#define RMCL_ROW_LD(r) (((r) < static_cast<uint32_t>(kRows)) ? lds_col[(r) * kBfStride] : priv[(r) - kRows])
-  for (;;) {
-    const uint64_t m_act = __ballot(cur != kDone);
-    if (m_act == 0) break;
-    const uint32_t na = static_cast<uint32_t>(__popcll(m_act));
-    if (na <= kTailRays) {
-      // ---- hand the remaining rays to quads ----
-      const bool mine = cur != kDone;
-      const uint32_t j = static_cast<uint32_t>(__popcll(m_act & ((1ull << lane) - 1ull)));
-      if (mine) {
-        uint32_t* x = xfer_wave + j * kTailXferDwords;
-        x[0] = __float_as_uint(O.x); x[1] = __float_as_uint(O.y); x[2] = __float_as_uint(O.z);
-        x[3] = __float_as_uint(D.x); x[4] = __float_as_uint(D.y); x[5] = __float_as_uint(D.z);
-        x[6] = __float_as_uint(ray_tfar); x[7] = __float_as_uint(best_t);
-        x[8] = record_face(tris, best_rec);  // the quad traversal carries (t, face id) pairs
-        x[9] = best_rec;
-        x[10] = cur; x[11] = sp - 1u;        // rows 1..sp-1 hold this ray's pending entries
-        uint32_t* col = qstack + (wave * kTailRays + j);
-        for (uint32_t e = 1; e < sp; ++e) col[e * 64u] = RMCL_ROW_LD(e);
-      }
-      __builtin_amdgcn_wave_barrier();  // the hand-over slots and stack columns are read by OTHER lanes of this wave
-      const uint32_t q = lane >> 2, c = lane & 3u;
-      const bool have = q < na;
-      const uint32_t* x = xfer_wave + (have ? q : 0u) * kTailXferDwords;
-      const f3 Oq = mk3(asf(x[0]), asf(x[1]), asf(x[2])), Dq = mk3(asf(x[3]), asf(x[4]), asf(x[5]));
-      QuadResume rsm;
-      rsm.cur = x[10]; rsm.n_stack = x[11]; rsm.best_t = asf(x[7]); rsm.best_face = x[8]; rsm.best_rec = x[9];
-      const float tfq = have ? asf(x[6]) : -1.0f;
-      RayHit hq;
-      uint32_t qvis = 0;
-      trace_quad<true>(cnodes, tris, Oq, Dq, tfq, c, wave * kTailRays + q, qstack, hq, &rsm, &qvis);
-      if (have && c == 0u) {
-        uint32_t* y = xfer_wave + q * kTailXferDwords;
-        y[7] = __float_as_uint(hq.t); y[9] = hq.rec; y[10] = qvis;
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (mine) {
-        const uint32_t* y = xfer_wave + j * kTailXferDwords;
-        best_t = asf(y[7]); best_rec = y[9]; nvis += y[10];
-      }
-      break;
-    }
-    // phase 1: inner nodes.  kLeafTrigger > 0: the phase is also left as soon as that many lanes hold a leaf -- they would
-    // otherwise idle through the descents of the others (the wave model: 65 -> 45 node iterations for the slowest tile of
-    // the room, 32 -> 26 on the sphere, for one or two more leaf rounds); the stragglers resume in the next round.
-#define RMCL_BF_STEP                                                                                         \
-    {                                                                                                        \
-      uint32_t key[4], ref[4];                                                                               \
-      ++nvis;                                                                                                \
-      if (!__any(sp + 3u > static_cast<uint32_t>(kRows))) {                                                  \
-        const uint32_t top = lds_col[(sp - 1u) * kBfStride];                                                 \
-        node_keys_off(nodes, cur << 7, rs, best_t, key, ref);                                                \
-        RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)                 \
-        lds_col[sp * kBfStride] = ref[3]; sp += (key[3] != kNone) ? 1u : 0u;                                 \
-        lds_col[sp * kBfStride] = ref[2]; sp += (key[2] != kNone) ? 1u : 0u;                                 \
-        lds_col[sp * kBfStride] = ref[1]; sp += (key[1] != kNone) ? 1u : 0u;                                 \
-        const bool any = key[0] != kNone;                                                                    \
-        cur = any ? ref[0] : top;                                                                            \
-        sp = any ? sp : (sp - 1u);                                                                           \
-      } else {                                                                                               \
-        node_keys_off(nodes, cur << 7, rs, best_t, key, ref);                                                \
-        RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)                 \
-        if (key[3] != kNone) { RMCL_ROW_ST(sp, ref[3]) ++sp; }                                               \
-        if (key[2] != kNone) { RMCL_ROW_ST(sp, ref[2]) ++sp; }                                               \
-        if (key[1] != kNone) { RMCL_ROW_ST(sp, ref[1]) ++sp; }                                               \
-        if (key[0] != kNone) cur = ref[0];                                                                   \
-        else { --sp; cur = RMCL_ROW_LD(sp); }                                                                \
-      }                                                                                                      \
-    }
-    if constexpr (kLeafTrigger > 0) {
-      // The loop stays the divergent per-lane while loop; the vote only needs the number of lanes still in it (the ballot of
-      // a divergent loop counts exactly those) against `na`, the rays alive when the round began: waiting >= 1.5 x descending
-      // <=> 5 x descending <= 2 x alive.  Checked after the step, so every round makes progress (a lane that keeps popping
-      // leaves cannot starve the descending ones).
-      while (cur < kDone) {
-        RMCL_BF_STEP
-        if (static_cast<uint32_t>(kLeafTrigger) * static_cast<uint32_t>(__popcll(__ballot(cur < kDone))) <= 4u * na) break;
-      }
-    } else {
-      while (cur < kDone) RMCL_BF_STEP
-    }
-#undef RMCL_BF_STEP
-    // phase 2: this lane's leaf (if any; with a leaf trigger other lanes may still hold an inner node)
-    if (cur > kDone) {
-      if (kLeafBatch) leaf_batch(tris, cur, O, D, ray_tfar, best_t, best_rec);
-      else leaf_loop(tris, cur, O, D, ray_tfar, best_t, best_rec);
-      --sp;
-      cur = RMCL_ROW_LD(sp);
-    }
-  }
-#undef RMCL_ROW_ST
-#undef RMCL_ROW_LD
-  h.t = best_t;
-  h.rec = best_rec;
-  if (visits) *visits = nvis;
-}
-
-// ---------------------------------------------------------------------------------------------
-// closest-point query (CPCEmbree::find -> rm::EmbreeMap::closestPoint): per-lane while-while traversal ordered
-// by box distance, closest point on triangle = Embree closest_point tutorial / Ericson RTCD 5.1.5, in the exact
-// operation order of oracle/rmcl_oracle.c:closest_point_triangle (a = v0, ab = -e1, ac = e2, b = a+ab, c = a+ac).
-// Equidistant triangles: min squared distance, then min face id.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ f3 closest_point_triangle(f3 a, f3 e1, f3 e2, f3 p) {
-  const f3 ab = neg3(e1), ac = e2;
-  const f3 b = add3(a, ab), c = add3(a, ac);
-  const f3 ap = sub3(p, a);
-  const float d1 = dot_plain(ab, ap), d2 = dot_plain(ac, ap);
-  if (d1 <= 0.f && d2 <= 0.f) return a;
-  const f3 bp = sub3(p, b);
-  const float d3 = dot_plain(ab, bp), d4 = dot_plain(ac, bp);
-  if (d3 >= 0.f && d4 <= d3) return b;
-  const f3 cp = sub3(p, c);
-  const float d5 = dot_plain(ab, cp), d6 = dot_plain(ac, cp);
-  if (d6 >= 0.f && d5 <= d6) return c;
-  const float vc = d1 * d4 - d3 * d2;
-  if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { const float v = d1 / (d1 - d3); return add3(a, scale3(ab, v)); }
-  const float vb = d5 * d2 - d1 * d6;
-  if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { const float v = d2 / (d2 - d6); return add3(a, scale3(ac, v)); }
-  const float va = d3 * d6 - d5 * d4;
-  if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {
-    const float v = (d4 - d3) / ((d4 - d3) + (d5 - d6));
-    return add3(b, scale3(sub3(c, b), v));
-  }
-  const float denom = 1.f / ((va + vb) + vc);
-  const float v = vb * denom, w = vc * denom;
-  return add3(add3(a, scale3(ab, v)), scale3(ac, w));
-}
-
-struct NearHit {
-  float d2;
-  uint32_t face;
-  uint32_t rec;
-  f3 p;
-};
-
-template <int kLdsEntries>
-__device__ __forceinline__ void nearest_lane_ww(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris,
-                                                f3 P, bool active, uint32_t* __restrict__ lds_stack,
-                                                uint32_t lds_stride, NearHit& h) {
-  float best = 3.0e38f;  // finite: unused node slots (box at 1e30 -> d2 = inf) never pass `d2 <= best`
-  uint32_t best_face = kInvalidFace, best_rec = 0;
-  f3 best_p = mk3(0.f, 0.f, 0.f);
-  constexpr uint32_t kDone = 0x7FFFFFFFu;
-  uint32_t priv[(kLdsEntries < 64) ? (64 - kLdsEntries) : 1];
-  uint32_t sp = 0;
-  uint32_t cur = active ? 0u : kDone;
-#define RMCL_PUSH(v) { if (kLdsEntries >= 64 || sp < kLdsEntries) lds_stack[sp * lds_stride] = (v); else priv[sp - kLdsEntries] = (v); ++sp; }
-#define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; if (kLdsEntries >= 64 || sp < kLdsEntries) cur = lds_stack[sp * lds_stride]; else cur = priv[sp - kLdsEntries]; } }
-  while (__any(cur != kDone)) {
-    while ((cur != kDone) && !(cur & kLeafBit)) {
-      const uint4* np = reinterpret_cast<const uint4*>(nodes) + static_cast<size_t>(cur) * 8u;
-      const uint4 qx0 = np[0], qx1 = np[1], qy0 = np[2], qy1 = np[3], qz0 = np[4], qz1 = np[5], qch = np[6];
-      // (lower, upper) plane of child c per axis: q*0 hold the four lower planes, q*1 the four upper planes
-      const f2 bx[4] = {{asf(qx0.x), asf(qx1.x)}, {asf(qx0.y), asf(qx1.y)}, {asf(qx0.z), asf(qx1.z)}, {asf(qx0.w), asf(qx1.w)}};
-      const f2 by[4] = {{asf(qy0.x), asf(qy1.x)}, {asf(qy0.y), asf(qy1.y)}, {asf(qy0.z), asf(qy1.z)}, {asf(qy0.w), asf(qy1.w)}};
-      const f2 bz[4] = {{asf(qz0.x), asf(qz1.x)}, {asf(qz0.y), asf(qz1.y)}, {asf(qz0.z), asf(qz1.z)}, {asf(qz0.w), asf(qz1.w)}};
-      uint32_t ref[4] = {qch.x, qch.y, qch.z, qch.w};
-      uint32_t key[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        // squared distance to the (padded) child box: a conservative lower bound of any triangle inside
-        const float dx = fmaxf(fmaxf(bx[c].x - P.x, P.x - bx[c].y), 0.f);
-        const float dy = fmaxf(fmaxf(by[c].x - P.y, P.y - by[c].y), 0.f);
-        const float dz = fmaxf(fmaxf(bz[c].x - P.z, P.z - bz[c].y), 0.f);
-        const float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-        key[c] = (d2 <= best) ? __float_as_uint(d2) : kNone;
-      }
-      RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
-      if (key[3] != kNone) RMCL_PUSH(ref[3])
-      if (key[2] != kNone) RMCL_PUSH(ref[2])
-      if (key[1] != kNone) RMCL_PUSH(ref[1])
-      if (key[0] != kNone) cur = ref[0];
-      else RMCL_POP()
-    }
-    if (cur != kDone) {
-      const uint32_t first = cur & 0x0FFFFFFFu;
-      const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
-      for (uint32_t i = 0; i < cnt; ++i) {
-        const uint4* tp = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(first + i) * 4u;
-        const uint4 a = tp[0], b = tp[1], c = tp[2], d = tp[3];
-        const f3 v0 = mk3(asf(a.x), asf(a.y), asf(a.z));
-        const f3 e1 = mk3(asf(a.w), asf(b.x), asf(b.y));
-        const f3 e2 = mk3(asf(b.z), asf(b.w), asf(c.x));
-        const uint32_t face = d.w;
-        const f3 q = closest_point_triangle(v0, e1, e2, P);
-        const f3 df = sub3(P, q);
-        const float d2 = (df.x * df.x + df.y * df.y) + df.z * df.z;
-        const bool closer = (d2 < best) || ((d2 == best) && (face < best_face));
-        if (closer) { best = d2; best_face = face; best_rec = first + i; best_p = q; }
-      }
-      RMCL_POP()
-    }
-  }
-#undef RMCL_PUSH
-#undef RMCL_POP
-  h.d2 = best;
-  h.face = best_face;
-  h.rec = best_rec;
-  h.p = best_p;
-}
-
-// closest-point query with FOUR lanes per point (see trace_quad): lane c measures the distance to child box c and
-// runs Ericson's closest-point-on-triangle for triangle c of a leaf -- the expensive, branchy part of this query is
-// done for up to four triangles at once; (d2, face id) ties resolve exactly like nearest_lane_ww.
-__device__ __forceinline__ void nearest_quad(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris, f3 P,
-                                             bool active, uint32_t c, uint32_t ray, uint32_t* __restrict__ lds, NearHit& h) {
-  float best = 3.0e38f;
-  uint32_t best_face = kInvalidFace, best_rec = 0;
-  f3 best_p = mk3(0.f, 0.f, 0.f);
-  constexpr uint32_t kDone = 0x7FFFFFFFu;
-  const char* nbase = reinterpret_cast<const char*>(nodes);
-  char* sbase = reinterpret_cast<char*>(lds) + ray * 4u;
-  if (c == 0u) *reinterpret_cast<uint32_t*>(sbase) = kDone;  // sentinel row (see trace_quad)
-  uint32_t spb = 256u;
-  uint32_t cur = active ? 0u : kDone;
-  const uint32_t coff = c * 32u;  // this lane's child inside a child-major node (layout.h: Node4C)
-  while (__any(cur != kDone)) {
-    while (cur < kDone) {
-      const uint4* nd = reinterpret_cast<const uint4*>(nbase + (cur << 7) + coff);
-      const uint4 q0 = nd[0], q1 = nd[1];  // lo.x lo.y lo.z hi.x | hi.y hi.z ref pad
-      const float lx = asf(q0.x), ly = asf(q0.y), lz = asf(q0.z), hx = asf(q0.w), hy = asf(q1.x), hz = asf(q1.y);
-      const uint32_t ref = q1.z;
-      const uint32_t top = *reinterpret_cast<const uint32_t*>(sbase + (spb - 256u));
-      const float dx = fmaxf(fmaxf(lx - P.x, P.x - hx), 0.f);
-      const float dy = fmaxf(fmaxf(ly - P.y, P.y - hy), 0.f);
-      const float dz = fmaxf(fmaxf(lz - P.z, P.z - hz), 0.f);
-      const float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-      const uint32_t key = ((d2 <= best) ? (__float_as_uint(d2) & ~3u) : 0xFFFFFFFCu) | c;
-      const uint32_t k1 = quad_dpp<kQuadXor1>(key), k2 = quad_dpp<kQuadXor2>(key), k3 = quad_dpp<kQuadXor3>(key);
-      const uint32_t rank = (k1 < key ? 1u : 0u) + (k2 < key ? 1u : 0u) + (k3 < key ? 1u : 0u);
-      const uint32_t kmin = min(min(key, k1), min(k2, k3));
-      const uint32_t nh = (key < 0xFFFFFFFCu ? 1u : 0u) + (k1 < 0xFFFFFFFCu ? 1u : 0u) + (k2 < 0xFFFFFFFCu ? 1u : 0u) +
-                          (k3 < 0xFFFFFFFCu ? 1u : 0u);
-      const uint32_t sel = (key == kmin) ? ref : 0u;
-      const uint32_t s1 = sel | quad_dpp<kQuadXor1>(sel);
-      const uint32_t nearest = s1 | quad_dpp<kQuadXor2>(s1);
-      const uint32_t row = (rank < nh) ? (nh - 1u - rank) : rank;
-      *reinterpret_cast<uint32_t*>(sbase + spb + (row << 8)) = ref;
-      const bool any = nh != 0u;
-      cur = any ? nearest : top;
-      spb = any ? (spb + ((nh - 1u) << 8)) : (spb - 256u);
-    }
-    if (cur != kDone) {
-      const uint32_t first = cur & 0x0FFFFFFFu;
-      const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
-      const uint32_t idx = first + ((c < cnt) ? c : (cnt - 1u));
-      const uint4* tp = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(idx) * 4u;
-      const uint4 a = tp[0], b = tp[1], cc = tp[2], d = tp[3];
-      const uint32_t top = *reinterpret_cast<const uint32_t*>(sbase + (spb - 256u));
-      const f3 v0 = mk3(asf(a.x), asf(a.y), asf(a.z));
-      const f3 e1 = mk3(asf(a.w), asf(b.x), asf(b.y));
-      const f3 e2 = mk3(asf(b.z), asf(b.w), asf(cc.x));
-      f3 cq = closest_point_triangle(v0, e1, e2, P);
-      const f3 df = sub3(P, cq);
-      const float d2 = (df.x * df.x + df.y * df.y) + df.z * df.z;
-      const bool valid = c < cnt;
-      float cd = valid ? d2 : __builtin_inff();
-      uint32_t cf = valid ? d.w : kInvalidFace, cr = idx;
-#define RMCL_QMIN(CTRL)                                                                               \
-      {                                                                                               \
-        const float od = __uint_as_float(quad_dpp<CTRL>(__float_as_uint(cd)));                        \
-        const uint32_t of = quad_dpp<CTRL>(cf), orr = quad_dpp<CTRL>(cr);                             \
-        const float ox = __uint_as_float(quad_dpp<CTRL>(__float_as_uint(cq.x)));                      \
-        const float oy = __uint_as_float(quad_dpp<CTRL>(__float_as_uint(cq.y)));                      \
-        const float oz = __uint_as_float(quad_dpp<CTRL>(__float_as_uint(cq.z)));                      \
-        const bool take = (od < cd) || ((od == cd) && (of < cf));                                     \
-        cd = take ? od : cd; cf = take ? of : cf; cr = take ? orr : cr;                               \
-        cq.x = take ? ox : cq.x; cq.y = take ? oy : cq.y; cq.z = take ? oz : cq.z;                    \
-      }
-      RMCL_QMIN(kQuadXor1)
-      RMCL_QMIN(kQuadXor2)
-#undef RMCL_QMIN
-      const bool closer = (cf != kInvalidFace) && ((cd < best) || ((cd == best) && (cf < best_face)));
-      if (closer) { best = cd; best_face = cf; best_rec = cr; best_p = cq; }
-      cur = top;
-      spb -= 256u;
-    }
-  }
-  h.d2 = best;
-  h.face = best_face;
-  h.rec = best_rec;
-  h.p = best_p;
-}
-
-struct CpcParams {
-  const uint32_t* nodes;
-  const uint32_t* tris;
-  const float* dataset_points;
-  uint32_t n;
-  float max_dist;
-  xform Tsm, Tms;
-  uint8_t* hits;
-  float* dists;
-  float* points;
-  float* normals;
-  uint32_t* face_ids;
-};
-
-// kQuad: four lanes per dataset point (64 points per block) instead of one
-template <bool kQuad>
-__global__ void __launch_bounds__(256) k_cpc_find(const CpcParams p) {
-  extern __shared__ uint32_t lds_dyn[];
-  const uint32_t sub = threadIdx.x & 3u;
-  const uint32_t i = kQuad ? (blockIdx.x * 64u + (threadIdx.x >> 2)) : (blockIdx.x * blockDim.x + threadIdx.x);
-  const bool live = i < p.n;
-  const uint32_t ii = live ? i : 0u;
-  const float* dp = p.dataset_points + 3 * static_cast<size_t>(ii);
-  const f3 Pm = xapply(p.Tsm, mk3(dp[0], dp[1], dp[2]));
-  const bool finite = (Pm.x == Pm.x) && (Pm.y == Pm.y) && (Pm.z == Pm.z);
-  NearHit h;
-  if (kQuad) nearest_quad(p.nodes, p.tris, Pm, live && finite, sub, threadIdx.x >> 2, lds_dyn, h);
-  else nearest_lane_ww<16>(p.nodes, p.tris, Pm, live && finite, lds_dyn + threadIdx.x, blockDim.x, h);
-  if (!live) return;
-  // quad: the four lanes of a point hold the same result and share the stores
-  const bool w0 = !kQuad || sub == 0u, w1 = !kQuad || sub == 1u, w2 = !kQuad || sub == 2u;
-  if (h.face != kInvalidFace) {
-    const float d = sqrtf(h.d2);
-    if (p.hits && w0) p.hits[i] = (d <= p.max_dist) ? 1 : 0;
-    if (p.dists && w0) p.dists[i] = d;
-    if (p.points && w1) {
-      const f3 ps = xapply(p.Tms, h.p);
-      p.points[3 * i] = ps.x; p.points[3 * i + 1] = ps.y; p.points[3 * i + 2] = ps.z;
-    }
-    if (p.normals && w2) {
-      const uint4 nrec = reinterpret_cast<const uint4*>(p.tris)[static_cast<size_t>(h.rec) * 4u + 3u];
-      const f3 ns = qrot(p.Tms.R, mk3(asf(nrec.x), asf(nrec.y), asf(nrec.z)));
-      p.normals[3 * i] = ns.x; p.normals[3 * i + 1] = ns.y; p.normals[3 * i + 2] = ns.z;
-    }
-    if (p.face_ids && w0) p.face_ids[i] = h.face;
-  } else {
-    const float qn = __uint_as_float(0x7FC00000u);
-    if (p.hits && w0) p.hits[i] = 0;
-    if (p.dists && w0) p.dists[i] = qn;
-    if (p.points && w1) { p.points[3 * i] = qn; p.points[3 * i + 1] = qn; p.points[3 * i + 2] = qn; }
-    if (p.normals && w2) { p.normals[3 * i] = qn; p.normals[3 * i + 1] = qn; p.normals[3 * i + 2] = qn; }
-    if (p.face_ids && w0) p.face_ids[i] = kInvalidFace;
-  }
-}
-
-// rmagine PinholeModel::getDirection: optical ray ((hid - cx)/fx, (vid - cy)/fy, 1) normalised (Vector::normalize
-// = divide by sqrt(x*x + y*y + z*z)), then optical (x right, y down, z forward) -> sensor (x forward, y left, z up).
-// Same operation order as oracle/rmcl_oracle.c:orc_pinhole_direction (IEEE division / sqrt on both sides).
-__device__ __forceinline__ f3 pinhole_direction(float fx, float fy, float cx, float cy, uint32_t vid, uint32_t hid) {
-  const float pX = (static_cast<float>(hid) - cx) / fx;
-  const float pY = (static_cast<float>(vid) - cy) / fy;
-  const float d = sqrtf((pX * pX + pY * pY) + 1.0f * 1.0f);
-  return mk3(1.0f / d, -(pX / d), -(pY / d));
-}
-
-// ---------------------------------------------------------------------------------------------
-// find
-// ---------------------------------------------------------------------------------------------
-// kTrav: 0 = wave packet, 1 = one lane per ray (while-while), 4 = the same on the quantised 64-B nodes, 5 = one lane
-// per ray with the tail of every wave handed to quads,
-// 2 = four lanes per ray (quad-cooperative; the block
-// of 256 threads then covers ONE 64-ray tile instead of four)
-// kTrav 5..10 share the tail traversal: 6 / 7 add the LDS-resident top of the tree (85 / 341 nodes = levels 0-3 / 0-4 of a
-// full BVH4), 8 adds the one-round-trip leaf, 9 / 10 both
-constexpr int find_top_nodes(int trav) { return (trav == 6 || trav == 9) ? 85 : ((trav == 7 || trav == 10) ? 341 : 0); }
-constexpr bool find_leaf_batch(int trav) { return trav >= 8 && trav <= 10; }
-constexpr int kFindBfRows = 24;  // LDS stack rows per lane (sentinel included) of the branch-free lane traversal in k_find
-constexpr uint32_t kFindTailLdsDwords = 16u * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords;
-
-// kinds 19..22: kind 17 + leaving the node phase when 32 / 24 / 16 / 8 lanes hold a leaf
-constexpr int find_leaf_trigger(int trav) { return (trav == 19 || trav == 20) ? 10 : 0; }   // leave at <= 4/10 of the round's rays
-
-template <uint32_t kModel, int kTrav>
-__global__ void __launch_bounds__(256) k_find(const FindParams p) {
-  extern __shared__ uint32_t lds_dyn[];
-  constexpr bool kPacket = (kTrav == 0), kMixed = (kTrav == 18);
-  // mixed launch (kTrav 18): the second half of the grid are lane blocks (4 tiles each), the first half their helpers: a
-  // helper runs the ONE tile its group's flag delegates (the slow tile of the previous scans) with four lanes per ray
-  // (helpers come FIRST in the grid: most of them exit at once and free their slot; placed last they would queue behind
-  // the lane blocks -- 45 KB of LDS admit three blocks per CU -- and start when the scan is almost over)
-  const bool helper = kMixed && (blockIdx.x < (gridDim.x >> 1));
-  const bool kQuad = (kTrav == 2) || helper;
-  constexpr int kTop = find_top_nodes(kTrav);
-  const uint32_t lane = kQuad ? (threadIdx.x >> 2) : (threadIdx.x & 63u), wave = threadIdx.x >> 6;
-  const uint32_t sub = threadIdx.x & 3u;  // quad mode: child slot / triangle slot / output role of this lane
-  uint32_t clk_begin = 0, clk_real = 0;
-  if (p.wave_clock != nullptr) {  // diagnostics (tools/wave_timeline.py)
-    uint64_t t, r;
-    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "=s"(r) : : "memory");
-    clk_begin = static_cast<uint32_t>(t);
-    clk_real = static_cast<uint32_t>(r);
-  }
-  if constexpr (kTop > 0) {
-    // the block's copy of the top of the tree: coalesced 16-B pieces, all requested before the first LDS write
-    uint4* dst = reinterpret_cast<uint4*>(lds_dyn + kFindTailLdsDwords);
-    const uint4* src = reinterpret_cast<const uint4*>(p.nodes);
-    const uint32_t n16 = min(static_cast<uint32_t>(kTop), p.n_nodes) * 8u;
-    constexpr int kRounds = (kTop > 0) ? (kTop * 8 + 255) / 256 : 1;
-    uint4 v[kRounds];
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-      const uint32_t i = static_cast<uint32_t>(r) * 256u + threadIdx.x;
-      if (i < n16) v[r] = src[i];
-    }
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-      const uint32_t i = static_cast<uint32_t>(r) * 256u + threadIdx.x;
-      if (i < n16) dst[i] = v[r];
-    }
-    __syncthreads();
-  }
-  // XCD-aware remap: the dispatcher places block b on XCD b%8; give every XCD a contiguous range of
-  // tiles so neighbouring tiles (which walk the same subtrees) share one L2.  gridDim.x % 8 == 0.
-  const uint32_t nblk = kMixed ? (gridDim.x >> 1) : gridDim.x;
-  const uint32_t bidx = (kMixed && !helper) ? (blockIdx.x - nblk) : blockIdx.x;
-  const uint32_t chunk = nblk >> 3;
-  const uint32_t vb = (bidx & 7u) * chunk + (bidx >> 3);
-  uint32_t tile = ((kTrav == 2) ? vb : (vb * 4u + wave));
-  if (kMixed) {
-    // flag of the group: 0 = nobody delegated, k = tile (group * 4 + k - 1) runs in the helper.  The flags are written by
-    // the host between launches only (capi.cpp: calibrate_tiles), so lane block and helper always agree.
-    const uint32_t f = p.tile_flags[vb];
-    if (helper) {
-      if (f == 0u) return;
-      tile = vb * 4u + (f - 1u);
-    } else if (f == wave + 1u) {
-      return;
-    }
-  }
-  const uint32_t ntiles = p.tiles_x * p.tiles_y;
-  if (tile >= ntiles) return;
-  const uint32_t pose = blockIdx.y;
-  const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-  const uint32_t twl = p.tile_w_log2;
-  const uint32_t lx = lane & ((1u << twl) - 1u), ly = lane >> twl;
-  const uint32_t vid = (ty << (6u - twl)) + ly, hid = (tx << twl) + lx;
-  const bool valid = (vid < p.H) && (hid < p.W);
-  const uint32_t cv = valid ? vid : 0u, ch = valid ? hid : 0u;
-  const uint32_t loc = cv * p.W + ch;
-
-  xform Tsm, Tms;
-  if (p.Tsm_arr != nullptr) { Tsm = p.Tsm_arr[pose]; Tms = p.Tms_arr[pose]; }
-  else { Tsm = p.Tsm; Tms = p.Tms; }
-
-  f3 dir_s, org_m, orig_s = p.orig_s;
-  if (kModel == kModelSpherical) {
-    // rmagine SphericalModel::getDirection (convention pinned by rmcl_ros/src/util/conversions.cpp:174-188);
-    // the four trig tables hold the host libm values of cos/sin(phi_v), cos/sin(theta_h)
-    const float cp = p.model_tab[cv], sp = p.model_tab[p.H + cv];
-    const float ct = p.model_tab[2u * p.H + ch], st = p.model_tab[2u * p.H + p.W + ch];
-    dir_s = mk3(cp * ct, cp * st, sp);
-    org_m = Tsm.t;
-  } else if (kModel == kModelPinhole) {
-    dir_s = pinhole_direction(p.pin_f[0], p.pin_f[1], p.pin_c[0], p.pin_c[1], cv, ch);
-    org_m = Tsm.t;
-  } else if (kModel == kModelOnDn) {
-    const float* og = p.model_tab + 3u * static_cast<size_t>(loc);
-    const float* dr = p.model_tab + 3u * (static_cast<size_t>(p.W) * p.H + loc);
-    orig_s = mk3(og[0], og[1], og[2]);
-    dir_s = mk3(dr[0], dr[1], dr[2]);
-    org_m = xapply(Tsm, orig_s);
-  } else {
-    dir_s = mk3(p.model_tab[3u * loc], p.model_tab[3u * loc + 1u], p.model_tab[3u * loc + 2u]);
-    org_m = xapply(Tsm, orig_s);
-  }
-  const f3 dir_m = qrot(Tsm.R, dir_s);
-  const bool finite = (dir_m.x == dir_m.x) && (dir_m.y == dir_m.y) && (dir_m.z == dir_m.z);
-  const float ray_tfar = (valid && finite) ? p.tfar : -1.0f;
-
-  uint32_t clk_trace0 = 0, clk_trace1 = 0;
-  if (p.wave_clock != nullptr) {
-    uint64_t t;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
-    clk_trace0 = static_cast<uint32_t>(t);
-  }
-  RayHit h;
-  if (kPacket) {
-    trace_packet((cu32p)(p.nodes), (cu32p)(p.tris), org_m, dir_m, ray_tfar, lane, h);
-  } else if (kQuad) {
-    uint32_t vis = 0;
-    trace_quad(p.cnodes, p.tris, org_m, dir_m, ray_tfar, sub, lane, lds_dyn, h, nullptr, &vis);
-    if (kMixed && p.tile_cost != nullptr) {
-      // cost of the tile = most node visits of any of its rays (independent of how the tile was traced)
-      const uint32_t m = wave_max_6bit(vis);
-      if ((threadIdx.x & 63u) == 0u) atomicMax(p.tile_cost + tile, m);
-    }
-  } else if (kMixed) {
-    uint32_t vis = 0;
-    // (no quad-finished tail here: its 18 KB of LDS per block are what decides whether lane blocks AND helpers are co-resident)
-    trace_lane_bf<kFindBfRows, false, true, false>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h, &vis);
-    if (p.tile_cost != nullptr) {
-      const uint32_t m = wave_max_6bit(vis);
-      if ((threadIdx.x & 63u) == 0u) p.tile_cost[tile] = m;
-    }
-  } else {
-    // kind 4 serves launches that fill the chip (pose batches): throughput, not the slowest wave's chain, is what counts there, and
-    // the branchy step with its partial sort and 16 LDS rows (more resident waves) is 11 % faster than the branch-free one
-    if (kTrav == 4) trace_lane_ww<16, true>(p.qnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
-    else if (kTrav == 22) trace_lane_ww<16, true, false, true>(p.qnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
-    else if (kTrav == 21)
-      trace_lane_ww_tail<16, 0, false, true>(
-          p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, lds_dyn + 16u * 256u,
-          lds_dyn + 16u * 256u + kQuadStackEntries * 64u + (threadIdx.x >> 6) * (kTailRays * kTailXferDwords), h,
-          lds_dyn + kFindTailLdsDwords);
-    else if (kTrav == 1) trace_lane_bf<kFindBfRows>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
-    else if (kTrav == 12) trace_lane_bf<kFindBfRows, false, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
-    else if (kTrav == 16 || kTrav == 17 || kTrav == 19 || kTrav == 20)
-      trace_lane_bf_tail<kFindBfRows, kTrav != 16 && kTrav != 20, find_leaf_trigger(kTrav)>(p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x,
-                                                   lds_dyn + kFindBfRows * 256u,
-                                                   lds_dyn + kFindBfRows * 256u + kQuadStackEntries * 64u + (threadIdx.x >> 6) * (kTailRays * kTailXferDwords), h);
-    else if (kTrav == 13) trace_lane_bf<kFindBfRows, false, false, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
-    else if (kTrav == 14) trace_lane_bf<kFindBfRows, false, true, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
-    else if (kTrav >= 5 && kTrav <= 10)
-      trace_lane_ww_tail<16, kTop, find_leaf_batch(kTrav)>(
-          p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, lds_dyn + 16u * 256u,
-          lds_dyn + 16u * 256u + kQuadStackEntries * 64u + (threadIdx.x >> 6) * (kTailRays * kTailXferDwords), h,
-          lds_dyn + kFindTailLdsDwords);
-    else trace_lane_ww<16>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
-  }
-
-  if (p.wave_clock != nullptr) {
-    uint64_t t;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
-    clk_trace1 = static_cast<uint32_t>(t);
-  }
-  if (valid) {
-  const size_t g = static_cast<size_t>(pose) * p.W * p.H + loc;
-  const bool found = (h.rec != kNone);
-  // quad mode: the four lanes of a ray hold the same result and share the stores (0: hits/ranges/face ids, 1: points,
-  // 2: normals)
-  const bool w0 = !kQuad || sub == 0u, w1 = !kQuad || sub == 1u, w2 = !kQuad || sub == 2u;
-  if (found) {
-    if (p.hits && w0) p.hits[g] = 1;
-    if (p.ranges && w0) p.ranges[g] = h.t;
-    if (p.points && w1) {
-      f3 pt = scale3(dir_s, h.t);
-      if (kModel == kModelO1Dn || kModel == kModelOnDn) pt = add3(pt, orig_s);
-      p.points[3 * g] = pt.x; p.points[3 * g + 1] = pt.y; p.points[3 * g + 2] = pt.z;
-    }
-    // the record's last 16 B: unit normal + the ORIGINAL face id
-    if ((p.normals && w2) || (p.face_ids && w0)) {
-      const uint4 nrec = reinterpret_cast<const uint4*>(p.tris)[static_cast<size_t>(h.rec) * 4u + 3u];
-      if (p.normals && w2) {
-        f3 n = qrot(Tms.R, mk3(asf(nrec.x), asf(nrec.y), asf(nrec.z)));
-        if (dot_plain(dir_s, n) > 0.0f) n = neg3(n);  // flip towards the sensor
-        p.normals[3 * g] = n.x; p.normals[3 * g + 1] = n.y; p.normals[3 * g + 2] = n.z;
-      }
-      if (p.face_ids && w0) p.face_ids[g] = nrec.w;
-    }
-  } else {
-    const float qn = __uint_as_float(0x7FC00000u);
-    if (p.hits && w0) p.hits[g] = 0;
-    if (p.ranges && w0) p.ranges[g] = p.tfar + 1.0f;
-    if (p.points && w1) { p.points[3 * g] = qn; p.points[3 * g + 1] = qn; p.points[3 * g + 2] = qn; }
-    if (p.normals && w2) { p.normals[3 * g] = qn; p.normals[3 * g + 1] = qn; p.normals[3 * g + 2] = qn; }
-    if (p.face_ids && w0) p.face_ids[g] = kInvalidFace;
-  }
-  }  // valid
-  if (p.wave_clock != nullptr) {
-    uint64_t t;
-    uint64_t t2;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2) : : "memory");   // stores issued
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");  // ... and completed
-    uint32_t xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    if ((threadIdx.x & 63u) == 0u) {
-      uint32_t* w = p.wave_clock + 8u * ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + wave);
-      w[0] = clk_begin; w[1] = static_cast<uint32_t>(t); w[2] = clk_real; w[3] = (tile & 0xFFFFFFu) | (xcc << 24);
-      w[4] = clk_trace0; w[5] = clk_trace1; w[6] = static_cast<uint32_t>(t2); w[7] = 0u;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// DIAGNOSTIC kernel (tools/probe_find.py; never on the product path): the per-lane while-while traversal of k_find<spherical>
-// with s_memtime stamps around every node step and every leaf step of every wave, so that the cost of a step can be
-// split into "loads issued -> data arrived" and "arithmetic + stack traffic" per tree depth.
-// Log entry (2 dwords): {cycles since wave start, kind | active lanes << 8 | uniform << 16 | step << 20}; kinds: 1 node step
-// begins, 2 its node data arrived, 3 it ends, 4 leaf step begins, 5 its records arrived, 6 it ends, 7 traversal done, 8 stores
-// issued.  probe_log[wave][0] = {number of entries, XCC id}.
-// ---------------------------------------------------------------------------------------------
-constexpr uint32_t kProbeEntries = 255;
-
-__device__ __forceinline__ uint32_t probe_clock(bool drain) {
-  uint64_t t;
-  if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
-  else asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
-  return static_cast<uint32_t>(t);
-}
-
-template <bool kLeafBatch, int kTop>
-__global__ void __launch_bounds__(256) k_find_probe(const FindParams p, uint32_t* __restrict__ probe_log) {
-  extern __shared__ uint32_t lds_dyn[];
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  if constexpr (kTop > 0) {
-    uint4* dst = reinterpret_cast<uint4*>(lds_dyn + 16u * 256u);
-    const uint4* src = reinterpret_cast<const uint4*>(p.nodes);
-    const uint32_t n16 = min(static_cast<uint32_t>(kTop), p.n_nodes) * 8u;
-    for (uint32_t i = threadIdx.x; i < n16; i += 256u) dst[i] = src[i];
-    __syncthreads();
-  }
-  const uint32_t chunk = gridDim.x >> 3;
-  const uint32_t vb = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
-  const uint32_t tile = vb * 4u + wave;
-  const uint32_t ntiles = p.tiles_x * p.tiles_y;
-  if (tile >= ntiles) return;
-  const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-  const uint32_t twl = p.tile_w_log2;
-  const uint32_t lx = lane & ((1u << twl) - 1u), ly = lane >> twl;
-  const uint32_t vid = (ty << (6u - twl)) + ly, hid = (tx << twl) + lx;
-  const bool valid = (vid < p.H) && (hid < p.W);
-  const uint32_t cv = valid ? vid : 0u, ch = valid ? hid : 0u;
-  const uint32_t loc = cv * p.W + ch;
-  const xform Tsm = p.Tsm, Tms = p.Tms;
-  uint32_t* log = probe_log + static_cast<size_t>(tile) * (2u * (kProbeEntries + 1u));
-  uint32_t nlog = 0;
-  const uint32_t t_begin = probe_clock(false);
-#define RMCL_PROBE(KIND, DRAIN, ACTIVE_MASK, UNIFORM, STEP)                                                              \
-  {                                                                                                                      \
-    const uint32_t tc_ = probe_clock(DRAIN) - t_begin;                                                                    \
-    if (nlog < kProbeEntries && lane == 0u) {                                                                            \
-      log[2u * (nlog + 1u)] = tc_;                                                                                       \
-      log[2u * (nlog + 1u) + 1u] = (KIND) | (static_cast<uint32_t>(__popcll(ACTIVE_MASK)) << 8) | ((UNIFORM) ? 0x10000u : 0u) | ((STEP) << 20); \
-    }                                                                                                                    \
-    ++nlog;                                                                                                              \
-  }
-  const float cp = p.model_tab[cv], sp_ = p.model_tab[p.H + cv];
-  const float ct = p.model_tab[2u * p.H + ch], st = p.model_tab[2u * p.H + p.W + ch];
-  const f3 dir_s = mk3(cp * ct, cp * st, sp_);
-  const f3 O = Tsm.t;
-  const f3 D = qrot(Tsm.R, dir_s);
-  const bool finite = (D.x == D.x) && (D.y == D.y) && (D.z == D.z);
-  const float ray_tfar = (valid && finite) ? p.tfar : -1.0f;
-
-  const RaySlab rs = make_ray_slab(O, D);
-  float best_t = ray_tfar;
-  uint32_t best_rec = kNone;
-  constexpr uint32_t kDone = 0x7FFFFFFFu;
-  uint32_t* lds_stack = lds_dyn + threadIdx.x;
-  constexpr uint32_t lds_stride = 256u;
-  uint32_t priv[48];
-  uint32_t sp = 0;
-  uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
-  uint32_t step = 0;
-#define RMCL_PUSH(v) { if (sp < 16u) lds_stack[sp * lds_stride] = (v); else priv[sp - 16u] = (v); ++sp; }
-#define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; if (sp < 16u) cur = lds_stack[sp * lds_stride]; else cur = priv[sp - 16u]; } }
-  // calibration: two stamps with nothing between them = the cost every interval below includes once
-  RMCL_PROBE(9u, true, __ballot(true), false, 0u)
-  RMCL_PROBE(10u, true, __ballot(true), false, 0u)
-  while (__any(cur != kDone)) {
-    for (;;) {
-      const bool inner = (cur != kDone) && !(cur & kLeafBit);
-      const uint64_t m = __ballot(inner);
-      if (m == 0) break;
-      const uint32_t c0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cur), __builtin_ctzll(m)));
-      const bool uni = __ballot(inner && cur != c0) == 0;
-      RMCL_PROBE(1u, true, m, uni, step)
-      uint4 qnx = {0, 0, 0, 0}, qfx = qnx, qny = qnx, qfy = qnx, qnz = qnx, qfz = qnx, qch = qnx;
-      if (inner) {
-        const char* nb = node_address<kTop>(p.nodes, lds_dyn + 16u * 256u, cur);
-        qnx = *reinterpret_cast<const uint4*>(nb + rs.onx); qfx = *reinterpret_cast<const uint4*>(nb + rs.ofx);
-        qny = *reinterpret_cast<const uint4*>(nb + rs.ony); qfy = *reinterpret_cast<const uint4*>(nb + rs.ofy);
-        qnz = *reinterpret_cast<const uint4*>(nb + rs.onz); qfz = *reinterpret_cast<const uint4*>(nb + rs.ofz);
-        qch = *reinterpret_cast<const uint4*>(nb + 96);
-      }
-      RMCL_PROBE(2u, true, m, uni, step)   // the stamp drains vmcnt: node data arrived
-      if (inner) {
-        const f2 ix = {rs.inv.x, rs.inv.x}, iy = {rs.inv.y, rs.inv.y}, iz = {rs.inv.z, rs.inv.z};
-        const f2 nx = {rs.noi.x, rs.noi.x}, ny = {rs.noi.y, rs.noi.y}, nz = {rs.noi.z, rs.noi.z};
-        const f2 nx01 = __builtin_elementwise_fma(f2{asf(qnx.x), asf(qnx.y)}, ix, nx), nx23 = __builtin_elementwise_fma(f2{asf(qnx.z), asf(qnx.w)}, ix, nx);
-        const f2 fx01 = __builtin_elementwise_fma(f2{asf(qfx.x), asf(qfx.y)}, ix, nx), fx23 = __builtin_elementwise_fma(f2{asf(qfx.z), asf(qfx.w)}, ix, nx);
-        const f2 ny01 = __builtin_elementwise_fma(f2{asf(qny.x), asf(qny.y)}, iy, ny), ny23 = __builtin_elementwise_fma(f2{asf(qny.z), asf(qny.w)}, iy, ny);
-        const f2 fy01 = __builtin_elementwise_fma(f2{asf(qfy.x), asf(qfy.y)}, iy, ny), fy23 = __builtin_elementwise_fma(f2{asf(qfy.z), asf(qfy.w)}, iy, ny);
-        const f2 nz01 = __builtin_elementwise_fma(f2{asf(qnz.x), asf(qnz.y)}, iz, nz), nz23 = __builtin_elementwise_fma(f2{asf(qnz.z), asf(qnz.w)}, iz, nz);
-        const f2 fz01 = __builtin_elementwise_fma(f2{asf(qfz.x), asf(qfz.y)}, iz, nz), fz23 = __builtin_elementwise_fma(f2{asf(qfz.z), asf(qfz.w)}, iz, nz);
-        const float tnx[4] = {nx01.x, nx01.y, nx23.x, nx23.y}, tfx[4] = {fx01.x, fx01.y, fx23.x, fx23.y};
-        const float tny[4] = {ny01.x, ny01.y, ny23.x, ny23.y}, tfy[4] = {fy01.x, fy01.y, fy23.x, fy23.y};
-        const float tnz[4] = {nz01.x, nz01.y, nz23.x, nz23.y}, tfz[4] = {fz01.x, fz01.y, fz23.x, fz23.y};
-        uint32_t key[4], ref[4] = {qch.x, qch.y, qch.z, qch.w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float tn = fmaxf(fmaxf(fmaxf(tnx[c], tny[c]), tnz[c]), 0.0f);
-          const float tf = fminf(fminf(fminf(tfx[c], tfy[c]), tfz[c]), best_t);
-          key[c] = (tn <= tf) ? __float_as_uint(tn) : kNone;
-        }
-        RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
-        if (key[3] != kNone) RMCL_PUSH(ref[3])
-        if (key[2] != kNone) RMCL_PUSH(ref[2])
-        if (key[1] != kNone) RMCL_PUSH(ref[1])
-        if (key[0] != kNone) cur = ref[0];
-        else RMCL_POP()
-      }
-      RMCL_PROBE(3u, true, m, uni, step)
-      ++step;
-    }
-    {
-      const bool leaf = (cur != kDone);
-      const uint64_t m = __ballot(leaf);
-      if (m != 0) {
-        if (kLeafBatch) {
-          RMCL_PROBE(4u, true, m, false, step)
-          if (leaf) {
-            leaf_batch(p.tris, cur, O, D, ray_tfar, best_t, best_rec);
-            RMCL_POP()
-          }
-          RMCL_PROBE(6u, true, m, false, step)
-        } else {
-          const uint32_t first = cur & 0x0FFFFFFFu;
-          const uint32_t cnt = leaf ? (((cur >> 28) & 7u) + 1u) : 0u;
-          for (uint32_t i = 0; __any(i < cnt); ++i) {
-            const uint64_t mi = __ballot(i < cnt);
-            RMCL_PROBE(4u, true, mi, false, step)
-            uint4 a = {0, 0, 0, 0}, b = a, c = a;
-            if (i < cnt) {
-              const uint4* tp = reinterpret_cast<const uint4*>(p.tris) + static_cast<size_t>(first + i) * 4u;
-              a = tp[0]; b = tp[1]; c = tp[2];
-            }
-            RMCL_PROBE(5u, true, mi, false, step)
-            if (i < cnt) tri_update(a, b, c, first + i, p.tris, O, D, ray_tfar, best_t, best_rec);
-            RMCL_PROBE(6u, true, mi, false, step)
-          }
-          if (leaf) RMCL_POP()
-        }
-        ++step;
-      }
-    }
-  }
-#undef RMCL_PUSH
-#undef RMCL_POP
-  RMCL_PROBE(7u, true, __ballot(true), false, step)
-  if (valid) {
-    const size_t g = loc;
-    const bool found = (best_rec != kNone);
-    if (found) {
-      p.hits[g] = 1;
-      p.ranges[g] = best_t;
-      const f3 pt = scale3(dir_s, best_t);
-      p.points[3 * g] = pt.x; p.points[3 * g + 1] = pt.y; p.points[3 * g + 2] = pt.z;
-      const uint4 nrec = reinterpret_cast<const uint4*>(p.tris)[static_cast<size_t>(best_rec) * 4u + 3u];
-      f3 n = qrot(Tms.R, mk3(asf(nrec.x), asf(nrec.y), asf(nrec.z)));
-      if (dot_plain(dir_s, n) > 0.0f) n = neg3(n);
-      p.normals[3 * g] = n.x; p.normals[3 * g + 1] = n.y; p.normals[3 * g + 2] = n.z;
-      p.face_ids[g] = nrec.w;
-    } else {
-      const float qn = __uint_as_float(0x7FC00000u);
-      p.hits[g] = 0;
-      p.ranges[g] = p.tfar + 1.0f;
-      p.points[3 * g] = qn; p.points[3 * g + 1] = qn; p.points[3 * g + 2] = qn;
-      p.normals[3 * g] = qn; p.normals[3 * g + 1] = qn; p.normals[3 * g + 2] = qn;
-      p.face_ids[g] = kInvalidFace;
-    }
-  }
-  RMCL_PROBE(8u, true, __ballot(true), false, step)
-#undef RMCL_PROBE
-  if (lane == 0u) {
-    uint32_t xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    log[0] = min(nlog, kProbeEntries) | (xcc << 16);
-    log[1] = t_begin;   // absolute shader clock (low 32 bits) at wave start
-  }
-}
 
 __global__ void k_compose_poses(const xform* __restrict__ Tbm, xform Tsb, xform* __restrict__ Tsm,
                                 xform* __restrict__ Tms, uint32_t n) {
@@ -2650,289 +1066,6 @@ __global__ void __launch_bounds__(256) k_pointcloud2_unpack(const Pc2Params p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// particle filter: all beams of all particles in one launch
-// ---------------------------------------------------------------------------------------------
-struct g1d { float mean, sigma; uint32_t n_meas; };
-struct pattrs { g1d likelihood; float state_sigma[6]; };
-static_assert(sizeof(pattrs) == 36, "ParticleAttributes must be 36 B");
-
-// rm::Gaussian1D::operator+= (1-D count-weighted merge)
-__device__ __forceinline__ g1d g1d_add(g1d a, g1d b) {
-  g1d r;
-  r.n_meas = a.n_meas + b.n_meas;
-  const float w1 = static_cast<float>(a.n_meas) / static_cast<float>(r.n_meas);
-  const float w2 = static_cast<float>(b.n_meas) / static_cast<float>(r.n_meas);
-  r.mean = a.mean * w1 + b.mean * w2;
-  const float P1 = a.sigma * w1 + b.sigma * w2;
-  const float P2 = ((a.mean - r.mean) * (a.mean - r.mean)) * w1 + ((b.mean - r.mean) * (b.mean - r.mean)) * w2;
-  r.sigma = P1 + P2;
-  return r;
-}
-
-// Normal the point-to-plane error of evaluate_rcc is taken against: the unit face normal (OptiX program,
-// BeamEvaluateProgram.cu:104-113; dwords 12..14 of the record) or, for correspondence_type 2, Embree's un-normalised
-// rayhit.hit.Ng = cross(e2, e1) that the Embree updater reads (PCDSensorUpdaterEmbree.cpp:56-66; dwords 9..11).
-__device__ __forceinline__ f3 pf_error_normal(const uint32_t* tris, uint32_t rec, uint32_t raw_ng) {
-  const uint4 r = reinterpret_cast<const uint4*>(tris)[static_cast<size_t>(rec) * 4u + (raw_ng ? 2u : 3u)];
-  return raw_ng ? mk3(asf(r.y), asf(r.z), asf(r.w)) : mk3(asf(r.x), asf(r.y), asf(r.z));
-}
-
-// kTrav: 0 = while-while traversal, per-lane stack 16 entries in LDS + scratch overflow (default)
-//        1 = while-while traversal, per-lane stack entirely in LDS
-//        2 = original single-loop traversal, stack in LDS (A/B)
-//        3 = closest-point correspondences (correspondence_type 1): nearest-point query instead of a ray
-template <int kStackDepth, int kTrav>
-__global__ void __launch_bounds__(256) k_pf_update(const PfParams p) {
-  // LDS: [ per-lane stacks kStackDepth*256 (kTrav != 0) | Tsm (PB xforms) | evals (PB*n_beams floats) ]
-  extern __shared__ uint32_t lds_dyn[];
-  uint32_t* stacks = lds_dyn;
-  xform* s_Tsm = reinterpret_cast<xform*>(lds_dyn + ((kTrav == 0 || kTrav == 3) ? 16 : kStackDepth) * 256);
-  float* s_eval = reinterpret_cast<float*>(s_Tsm + p.particles_per_block);
-
-  const uint32_t PB = p.particles_per_block;
-  const uint32_t p0 = blockIdx.x * PB;
-  if (p0 >= p.n_particles) return;
-  const uint32_t np = min(PB, p.n_particles - p0);
-  if (threadIdx.x < np) s_Tsm[threadIdx.x] = xmul(p.poses[p0 + threadIdx.x], p.Tsb);
-  __syncthreads();
-
-  const float sq = p.dist_sigma * p.dist_sigma;
-  const uint32_t nrays = np * p.n_beams;
-  for (uint32_t r = threadIdx.x; r < ((nrays + 255u) & ~255u); r += 256u) {
-    const bool live = r < nrays;
-    const uint32_t rr = live ? r : 0u;
-    const uint32_t pi = rr / p.n_beams, b = rr - pi * p.n_beams;
-    const xform Tsm = s_Tsm[pi];
-    const float* bm = p.beams + 16u * b;
-    // meas_m = Tsm * meas_s (RangeMeasurement.hpp:28-42)
-    const f3 dir = qrot(Tsm.R, mk3(bm[3], bm[4], bm[5]));
-    const f3 org = xapply(Tsm, mk3(bm[0], bm[1], bm[2]));
-    const float range = bm[6];
-    const bool finite = (dir.x == dir.x) && (dir.y == dir.y) && (dir.z == dir.z);
-    if (kTrav == 3) {
-      // evaluate_cpc (PCDSensorUpdaterEmbree.cpp:88-95): distance of meas_m.mean() = orig + dir * range to the surface
-      const f3 mean = add3(org, scale3(dir, range));
-      const bool ok = (mean.x == mean.x) && (mean.y == mean.y) && (mean.z == mean.z);
-      NearHit nh;
-      nearest_lane_ww<16>(p.nodes, p.tris, mean, live && ok, stacks + threadIdx.x, 256u, nh);
-      if (live) {
-        const float error = (nh.face != kInvalidFace) ? sqrtf(nh.d2) : __uint_as_float(0x7FC00000u);
-        if (p.errors) p.errors[static_cast<size_t>(p0 + pi) * p.n_beams + b] = error;
-        const float arg = -(error * error) / sq / 2;
-        s_eval[rr] = static_cast<float>(exp(static_cast<double>(arg)) /
-                                        sqrt(static_cast<double>(2 * sq) * 3.14159265358979323846));
-      }
-      continue;
-    }
-    RayHit h;
-    const float rtf = (live && finite) ? p.ray_tfar : -1.0f;
-    if (kTrav == 0) trace_lane_bf<16>(p.nodes, p.tris, org, dir, rtf, stacks + threadIdx.x, h);
-    else if (kTrav == 1) trace_lane_ww<64>(p.nodes, p.tris, org, dir, rtf, stacks + threadIdx.x, 256u, h);
-    else trace_lane(p.nodes, p.tris, org, dir, rtf, stacks + threadIdx.x, 256u, h);
-    if (live) {
-      // evaluate_rcc (PCDSensorUpdaterEmbree.cpp:18-86) with unit face normals (BeamEvaluateProgram.cu:104-113)
-      const bool real_hit = (range >= p.range_min) && (range <= p.range_max);
-      const bool sim_hit = (h.rec != kNone) && (!p.sim_min_range || h.t > p.range_min);
-      float error;
-      if (sim_hit) {
-        if (real_hit) {
-          const f3 n = pf_error_normal(p.tris, h.rec, p.raw_ng);
-          const f3 preal = add3(org, scale3(dir, range));
-          const f3 pint = add3(org, scale3(dir, h.t));
-          error = fabsf(dot_plain(sub3(pint, preal), n));
-        } else {
-          error = p.rmsh;
-        }
-      } else {
-        error = real_hit ? p.rhsm : p.rmsm;
-      }
-      if (p.errors) p.errors[static_cast<size_t>(p0 + pi) * p.n_beams + b] = error;
-      // PCDSensorUpdaterEmbree.cpp:224 : float argument, double exp / sqrt, float result
-      const float arg = -(error * error) / sq / 2;
-      const float eval = static_cast<float>(exp(static_cast<double>(arg)) /
-                                            sqrt(static_cast<double>(2 * sq) * 3.14159265358979323846));
-      s_eval[rr] = eval;
-    }
-  }
-  __syncthreads();
-  // in-order merge, one lane per particle (sequential semantics of sensorUpdate, :232-238)
-  if (threadIdx.x < np) {
-    pattrs* A = reinterpret_cast<pattrs*>(p.attrs) + (p0 + threadIdx.x);
-    g1d L = A->likelihood;
-    const float* ev = s_eval + threadIdx.x * p.n_beams;
-    for (uint32_t b = 0; b < p.n_beams; ++b) {
-      g1d m; m.mean = ev[b]; m.sigma = 0.0f; m.n_meas = 1;
-      L = g1d_add(L, m);
-      L.n_meas = min(L.n_meas, p.max_n_meas);
-    }
-    A->likelihood = L;
-  }
-}
-
-// Persistent-lane variant of k_pf_update ("dynamic ray fetch", Aila & Laine 2009).  The beams of a particle point in
-// all directions, so the 64 rays of a wave diverge almost immediately and with one ray per lane per round the
-// wave waits for its slowest ray: PMC showed 52 % of the lanes active in VALU instructions.  Here a lane that has
-// finished its ray takes the next one from the block's queue as soon as kRefill lanes of its wave are idle; every
-// result is stored under its ray index, so the outcome does not depend on the schedule.  Traversal, acceptance
-// rules and beam evaluation are those of trace_lane_ww / k_pf_update (bit-identical results).
-constexpr int kPfRows = 20;  // LDS stack rows per lane of the persistent particle-filter kernel (sentinel included)
-
-template <int kLdsEntries, int kRefill, bool kQuant>
-__global__ void __launch_bounds__(256) k_pf_update_persist(const PfParams p) {
-  // LDS: [ per-lane stacks kLdsEntries*256 | Tsm (PB xforms) | evals (PB*n_beams floats) ]
-  extern __shared__ uint32_t lds_dyn[];
-  __shared__ uint32_t s_next;
-  uint32_t* lds_col = lds_dyn + threadIdx.x;   // stack rows of this lane: row r at lds_col[r * 256], row 0 = sentinel
-  xform* s_Tsm = reinterpret_cast<xform*>(lds_dyn + kLdsEntries * 256);
-  float* s_eval = reinterpret_cast<float*>(s_Tsm + p.particles_per_block);
-
-  const uint32_t PB = p.particles_per_block;
-  const uint32_t p0 = blockIdx.x * PB;
-  if (p0 >= p.n_particles) return;
-  const uint32_t np = min(PB, p.n_particles - p0);
-  if (threadIdx.x < np) s_Tsm[threadIdx.x] = xmul(p.poses[p0 + threadIdx.x], p.Tsb);
-  if (threadIdx.x == 0) s_next = 0u;
-  __syncthreads();
-
-  const float sq = p.dist_sigma * p.dist_sigma;
-  const uint32_t nrays = np * p.n_beams;
-  const uint32_t lane = threadIdx.x & 63u;
-  constexpr uint32_t kDone = 0x7FFFFFFFu;
-  // per-lane ray state
-  uint32_t rr = 0;
-  bool has_ray = false, exhausted = false;
-  f3 O = mk3(0.f, 0.f, 0.f), D = O;
-  RaySlab rs = make_ray_slab(O, mk3(1.f, 1.f, 1.f));
-  float range = 0.f, best_t = 0.f;
-  uint32_t best_rec = kNone;
-  // branch-free node step of trace_lane_bf: kLdsEntries rows in LDS (row 0 = sentinel kDone), deeper rows in scratch
-  constexpr int kRows = kLdsEntries;
-  uint32_t priv[(kRows < 65) ? (65 - kRows) : 1];
-  lds_col[0] = kDone;
-  uint32_t sp = 1, cur = kDone;
-#define RMCL_ROW_ST(r, v) { if ((r) < static_cast<uint32_t>(kRows)) lds_col[(r) * kBfStride] = (v); else priv[(r) - kRows] = (v); }
-#define RMCL_ROW_LD(r) (((r) < static_cast<uint32_t>(kRows)) ? lds_col[(r) * kBfStride] : priv[(r) - kRows])
-  for (;;) {
-    const bool idle = (cur == kDone) && !exhausted;
-    const uint64_t want = __ballot(idle);
-    const uint64_t busy = __ballot(cur != kDone);
-    if (want == 0 && busy == 0) break;
-    if (want != 0 && (busy == 0 || __popcll(want) >= kRefill)) {
-      if (idle) {
-        if (has_ray) {
-          // evaluate_rcc (PCDSensorUpdaterEmbree.cpp:18-86) with unit face normals (BeamEvaluateProgram.cu:104-113)
-          const uint32_t pi = rr / p.n_beams, b = rr - pi * p.n_beams;
-          const bool real_hit = (range >= p.range_min) && (range <= p.range_max);
-          const bool sim_hit = (best_rec != kNone) && (!p.sim_min_range || best_t > p.range_min);
-          float error;
-          if (sim_hit) {
-            if (real_hit) {
-              const f3 n = pf_error_normal(p.tris, best_rec, p.raw_ng);
-              const f3 preal = add3(O, scale3(D, range));
-              const f3 pint = add3(O, scale3(D, best_t));
-              error = fabsf(dot_plain(sub3(pint, preal), n));
-            } else {
-              error = p.rmsh;
-            }
-          } else {
-            error = real_hit ? p.rhsm : p.rmsm;
-          }
-          if (p.errors) p.errors[static_cast<size_t>(p0 + pi) * p.n_beams + b] = error;
-          // PCDSensorUpdaterEmbree.cpp:224 : float argument, double exp / sqrt, float result
-          const float arg = -(error * error) / sq / 2;
-          s_eval[rr] = static_cast<float>(exp(static_cast<double>(arg)) /
-                                          sqrt(static_cast<double>(2 * sq) * 3.14159265358979323846));
-          has_ray = false;
-        }
-      }
-      // next rays for the idle lanes: one LDS atomic per wave and refill
-      const uint32_t nwant = static_cast<uint32_t>(__popcll(want));
-      const int leader = __builtin_ctzll(want);
-      uint32_t base = 0;
-      if (static_cast<int>(lane) == leader) base = atomicAdd(&s_next, nwant);
-      base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(base), leader));
-      if (idle) {
-        const uint32_t mine = base + static_cast<uint32_t>(__popcll(want & ((1ull << lane) - 1ull)));
-        if (mine < nrays) {
-          rr = mine;
-          const uint32_t pi = rr / p.n_beams, b = rr - pi * p.n_beams;
-          const xform Tsm = s_Tsm[pi];
-          const float* bm = p.beams + 16u * b;
-          // meas_m = Tsm * meas_s (RangeMeasurement.hpp:28-42)
-          D = qrot(Tsm.R, mk3(bm[3], bm[4], bm[5]));
-          O = xapply(Tsm, mk3(bm[0], bm[1], bm[2]));
-          range = bm[6];
-          rs = make_ray_slab(O, D);
-          best_t = p.ray_tfar;
-          best_rec = kNone;
-          sp = 1;
-          has_ray = true;
-          const bool finite = (D.x == D.x) && (D.y == D.y) && (D.z == D.z);
-          cur = finite ? 0u : kDone;  // a non-finite beam is a miss: evaluated at the next refill
-        } else {
-          exhausted = true;
-        }
-      }
-    }
-    // phase 1: inner nodes (see trace_lane_ww) -- left EARLY once at most kTailLanes lanes are still descending while
-    // others already hold a leaf: the stragglers resume in the next round and the leaf holders do not idle through
-    // the tail (measured 7 % / 5 % faster on sphere / room; for coherent scans the plain loop of trace_lane_ww wins)
-    constexpr int kTailLanes = 8;
-    for (;;) {
-      const bool inner = (cur != kDone) && !(cur & kLeafBit);
-      const uint64_t m_inner = __ballot(inner);
-      if (m_inner == 0) break;
-      if (__popcll(m_inner) <= kTailLanes && __ballot((cur != kDone) && (cur & kLeafBit)) != 0) break;
-      if (inner) {
-        uint32_t key[4], ref[4];
-        if (!__any(sp + 3u > static_cast<uint32_t>(kRows))) {
-          const uint32_t top = lds_col[(sp - 1u) * kBfStride];
-          if (kQuant) node_keys_q(p.qnodes, cur, rs, best_t, key, ref);
-          else node_keys_off(p.nodes, cur << 7, rs, best_t, key, ref);
-          RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
-          lds_col[sp * kBfStride] = ref[3]; sp += (key[3] != kNone) ? 1u : 0u;
-          lds_col[sp * kBfStride] = ref[2]; sp += (key[2] != kNone) ? 1u : 0u;
-          lds_col[sp * kBfStride] = ref[1]; sp += (key[1] != kNone) ? 1u : 0u;
-          const bool any = key[0] != kNone;
-          cur = any ? ref[0] : top;
-          sp = any ? sp : (sp - 1u);
-        } else {
-          if (kQuant) node_keys_q(p.qnodes, cur, rs, best_t, key, ref);
-          else node_keys_off(p.nodes, cur << 7, rs, best_t, key, ref);
-          RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)
-          if (key[3] != kNone) { RMCL_ROW_ST(sp, ref[3]) ++sp; }
-          if (key[2] != kNone) { RMCL_ROW_ST(sp, ref[2]) ++sp; }
-          if (key[1] != kNone) { RMCL_ROW_ST(sp, ref[1]) ++sp; }
-          if (key[0] != kNone) cur = ref[0];
-          else { --sp; cur = RMCL_ROW_LD(sp); }
-        }
-      }
-    }
-    // phase 2: this lane's leaf (if any); tfar = infinity
-    if ((cur != kDone) && (cur & kLeafBit)) {
-      leaf_loop(p.tris, cur, O, D, p.ray_tfar, best_t, best_rec);
-      --sp;
-      cur = RMCL_ROW_LD(sp);
-    }
-  }
-#undef RMCL_ROW_ST
-#undef RMCL_ROW_LD
-  __syncthreads();
-  // in-order merge, one lane per particle (sequential semantics of sensorUpdate, :232-238)
-  if (threadIdx.x < np) {
-    pattrs* A = reinterpret_cast<pattrs*>(p.attrs) + (p0 + threadIdx.x);
-    g1d L = A->likelihood;
-    const float* ev = s_eval + threadIdx.x * p.n_beams;
-    for (uint32_t b = 0; b < p.n_beams; ++b) {
-      g1d m; m.mean = ev[b]; m.sigma = 0.0f; m.n_meas = 1;
-      L = g1d_add(L, m);
-      L.n_meas = min(L.n_meas, p.max_n_meas);
-    }
-    A->likelihood = L;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Round 3 form of the persistent-lane kernel (the default).  tools/pfsim.py -- a wave-level model of this schedule on the
 // product's own BVH arrays that reproduces the round-2 PMC figures (2.0 ms, ~60 % of the lanes active) -- says the kernel is
 // bound by VALU instruction ISSUES, and that what moves the issue count is (a) shorter leaves, (b) what the refill block and
@@ -3438,29 +1571,28 @@ __global__ void k_compact_shards(const float* __restrict__ padded, float* __rest
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
+namespace {
+const LabHooks* g_lab = nullptr;
+}
+const LabHooks* lab_hooks() { return g_lab; }
+
 hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStream_t s) {
+  if (!find_kind_in_product(variant) || p.wave_clock != nullptr) {
+    // an experiment's kind, or a clocked launch of any kind (tools/wave_timeline.py): librmclhip_lab.so
+    if (g_lab && g_lab->find) return g_lab->find(p, kind, variant, p.wave_clock != nullptr, s);
+    return hipErrorNotSupported;
+  }
   const uint32_t ntiles = p.tiles_x * p.tiles_y;
   uint32_t nblocks = (variant == 2) ? ntiles : (ntiles + 3u) / 4u;
   nblocks = (nblocks + 7u) & ~7u;  // the XCD remap in k_find needs gridDim.x % 8 == 0
   dim3 grid(nblocks, p.nposes, 1), block(256, 1, 1);
-  // more than 64 KB of dynamic LDS per block must be granted per kernel AND per device (the attribute belongs to the device's
-  // copy of the function); launches that need it are rare A/B kinds, so the grant is simply repeated on every such launch
-#define RMCL_FIND_ONE(KIND, TRAV, LDS)                                                                               \
-  {                                                                                                                  \
-    if ((LDS) > 65536u) {                                                                                            \
-      const hipError_t ge = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_find<KIND, TRAV>),                  \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(LDS)); \
-      if (ge != hipSuccess) return ge;                                                                               \
-    }                                                                                                                \
-    hipLaunchKernelGGL((k_find<KIND, TRAV>), grid, block, LDS, s, p);                                                \
-  }
-#define RMCL_LAUNCH_FIND(TRAV, LDS)                             \
-  switch (kind) {                                               \
-    case kModelSpherical: RMCL_FIND_ONE(kModelSpherical, TRAV, LDS) break; \
-    case kModelO1Dn: RMCL_FIND_ONE(kModelO1Dn, TRAV, LDS) break;           \
-    case kModelPinhole: RMCL_FIND_ONE(kModelPinhole, TRAV, LDS) break;     \
-    case kModelOnDn: RMCL_FIND_ONE(kModelOnDn, TRAV, LDS) break;           \
-    default: return hipErrorInvalidValue;                       \
+#define RMCL_LAUNCH_FIND(TRAV, LDS)                                                                                   \
+  switch (kind) {                                                                                                     \
+    case kModelSpherical: hipLaunchKernelGGL((k_find<kModelSpherical, TRAV>), grid, block, LDS, s, p); break;         \
+    case kModelO1Dn: hipLaunchKernelGGL((k_find<kModelO1Dn, TRAV>), grid, block, LDS, s, p); break;                   \
+    case kModelPinhole: hipLaunchKernelGGL((k_find<kModelPinhole, TRAV>), grid, block, LDS, s, p); break;             \
+    case kModelOnDn: hipLaunchKernelGGL((k_find<kModelOnDn, TRAV>), grid, block, LDS, s, p); break;                   \
+    default: return hipErrorInvalidValue;                                                                             \
   }
   if (variant == 0) {  // wave-packet traversal (needs map stack_need <= 64, checked at map creation)
     RMCL_LAUNCH_FIND(0, 0)
@@ -3470,66 +1602,23 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
   } else if (variant == 4) {  // one lane per ray on the 64-B quantised nodes
     const size_t lds = 16u * 256u * sizeof(uint32_t);
     RMCL_LAUNCH_FIND(4, lds)
-  } else if (variant >= 5 && variant <= 10) {  // one lane per ray, the last rays of every wave finished by quads
-    const size_t lds = (kFindTailLdsDwords + static_cast<uint32_t>(find_top_nodes(variant)) * kNodeDwords) * sizeof(uint32_t);
-    switch (variant) {
-      case 5: RMCL_LAUNCH_FIND(5, lds) break;
-      case 6: RMCL_LAUNCH_FIND(6, lds) break;
-      case 7: RMCL_LAUNCH_FIND(7, lds) break;
-      case 8: RMCL_LAUNCH_FIND(8, lds) break;
-      case 9: RMCL_LAUNCH_FIND(9, lds) break;
-      default: RMCL_LAUNCH_FIND(10, lds) break;
-    }
-  } else if (variant == 11) {  // A/B: the branchy while-while step (16 stack entries per lane in LDS, the rest in scratch)
-    const size_t lds = 16u * 256u * sizeof(uint32_t);
-    RMCL_LAUNCH_FIND(11, lds)
-  } else if (variant == 12) {  // branch-free step + one-round-trip leaves
-    const size_t lds = static_cast<size_t>(kFindBfRows) * 256u * sizeof(uint32_t);
-    RMCL_LAUNCH_FIND(12, lds)
-  } else if (variant == 18) {  // mixed launch: lane blocks + one quad helper block per group of four tiles
-    const size_t lds = static_cast<size_t>(kFindBfRows) * 256u * sizeof(uint32_t);   // >= the helper's quad stack (17.6 KB)
-    if (p.tile_flags == nullptr || p.nposes != 1u) return hipErrorInvalidValue;
-    grid = dim3(2u * nblocks, 1, 1);
-    RMCL_LAUNCH_FIND(18, lds)
-  } else if (variant >= 19 && variant <= 22) {  // kinds 17 / 5 / 4 with the leaf trigger
+  } else if (variant == 19) {  // branch-free step, one-round-trip leaves, quad-finished tails, leaf trigger
     const size_t lds = (static_cast<size_t>(kFindBfRows) * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords) * sizeof(uint32_t);
-    if (variant == 19) { RMCL_LAUNCH_FIND(19, lds) }
-    else if (variant == 20) { RMCL_LAUNCH_FIND(20, lds) }
-    else if (variant == 21) {   // kind 5 with the leaf trigger
-      const size_t lds5 = kFindTailLdsDwords * sizeof(uint32_t);
-      RMCL_LAUNCH_FIND(21, lds5)
-    } else {                    // kind 4 with the leaf trigger
-      const size_t lds4 = 16u * 256u * sizeof(uint32_t);
-      RMCL_LAUNCH_FIND(22, lds4)
-    }
-  } else if (variant == 16 || variant == 17) {  // branch-free step (17: + one-round-trip leaves), tail of every wave finished by quads
-    const size_t lds = (static_cast<size_t>(kFindBfRows) * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords) * sizeof(uint32_t);
-    if (variant == 16) { RMCL_LAUNCH_FIND(16, lds) } else { RMCL_LAUNCH_FIND(17, lds) }
-  } else if (variant == 13) {  // branch-free step, wave-uniform nodes through the scalar cache
-    const size_t lds = static_cast<size_t>(kFindBfRows) * 256u * sizeof(uint32_t);
-    RMCL_LAUNCH_FIND(13, lds)
-  } else if (variant == 14) {  // 13 + one-round-trip leaves
-    const size_t lds = static_cast<size_t>(kFindBfRows) * 256u * sizeof(uint32_t);
-    RMCL_LAUNCH_FIND(14, lds)
-  } else {             // per-lane while-while traversal, branch-free node step
-    const size_t lds = static_cast<size_t>(kFindBfRows) * 256u * sizeof(uint32_t);
-    RMCL_LAUNCH_FIND(1, lds)
+    RMCL_LAUNCH_FIND(19, lds)
+  } else if (variant == 21) {  // while-while step with quad-finished tails and the leaf trigger
+    const size_t lds5 = kFindTailLdsDwords * sizeof(uint32_t);
+    RMCL_LAUNCH_FIND(21, lds5)
+  } else {                     // 22: kind 4 with the leaf trigger
+    const size_t lds4 = 16u * 256u * sizeof(uint32_t);
+    RMCL_LAUNCH_FIND(22, lds4)
   }
 #undef RMCL_LAUNCH_FIND
-#undef RMCL_FIND_ONE
   return hipGetLastError();
 }
 
 hipError_t launch_find_probe(const FindParams& p, int mode, uint32_t* probe_log, hipStream_t s) {
-  const uint32_t ntiles = p.tiles_x * p.tiles_y;
-  uint32_t nblocks = ((ntiles + 3u) / 4u + 7u) & ~7u;
-  const dim3 grid(nblocks, 1, 1), block(256, 1, 1);
-  const size_t lds0 = 16u * 256u * sizeof(uint32_t);
-  if (mode == 0) hipLaunchKernelGGL((k_find_probe<false, 0>), grid, block, lds0, s, p, probe_log);
-  else if (mode == 1) hipLaunchKernelGGL((k_find_probe<true, 0>), grid, block, lds0, s, p, probe_log);
-  else if (mode == 2) hipLaunchKernelGGL((k_find_probe<false, 85>), grid, block, lds0 + 85u * 128u, s, p, probe_log);
-  else hipLaunchKernelGGL((k_find_probe<true, 85>), grid, block, lds0 + 85u * 128u, s, p, probe_log);
-  return hipGetLastError();
+  if (g_lab && g_lab->find_probe) return g_lab->find_probe(p, mode, probe_log, s);
+  return hipErrorNotSupported;
 }
 
 hipError_t launch_cpc_find(const uint32_t* nodes, const uint32_t* tris, const float* dataset_points, uint32_t n,
@@ -3883,43 +1972,25 @@ hipError_t launch_pf_update(const PfParams& p, int variant, hipStream_t s) {
   const uint32_t nblocks = (p.n_particles + p.particles_per_block - 1u) / p.particles_per_block;
   const size_t tail = sizeof(xform) * p.particles_per_block +
                       sizeof(float) * static_cast<size_t>(p.particles_per_block) * p.n_beams;
-  const int trav = variant & 3;        // see k_pf_update
-  const bool deep = (variant & 4) != 0;  // 64-deep LDS stack instead of 32 (maps with stack_need > 32)
+  const int trav = variant & 3;          // traversal of the round kernels (lab)
   const bool cpc = (variant & 8) != 0;   // correspondence_type 1
-  const size_t stack_lds = ((trav == 0 || cpc) ? 16u : (deep ? 64u : 32u)) * 256u * sizeof(uint32_t);
-  size_t lds = stack_lds + tail;
-  const int refill = (variant >> 4) & 7;  // 0 = rounds of one ray per lane; 1..4 = persistent lanes, refill at 8/16/32/48 idle
-  const bool legacy = ((variant >> 8) & 1) != 0;   // bit 8: the round-2 kernel (k_pf_update_persist), A/B
+  const int refill = (variant >> 4) & 7;  // 0 = rounds of one ray per lane (lab); 1..4 = persistent lanes
+  const bool legacy = ((variant >> 8) & 1) != 0;   // bit 8: the round-2 kernel (k_pf_update_persist, lab), A/B
   const bool leaf2 = ((variant >> 10) & 1) == 0;   // bit 10 set: p.qnodes is the MAP's tree (leaves <= 4) -> loop over the leaf
-  if (!cpc && trav == 0 && refill != 0 && !legacy && ((variant >> 7) & 1) == 0 && p.qnodes != nullptr) {
-    lds = static_cast<size_t>(kPfRows) * 256u * sizeof(uint32_t) + tail + sizeof(uint32_t) * p.particles_per_block;
+  if (cpc) {
+    // closest-point correspondences (evaluate_cpc): rounds of one beam per lane on the full nodes
+    const size_t lds = 16u * 256u * sizeof(uint32_t) + tail;
+    hipLaunchKernelGGL((k_pf_update<64, 3>), dim3(nblocks), dim3(256), lds, s, p);
+    return hipGetLastError();
+  }
+  if (trav == 0 && refill != 0 && !legacy && ((variant >> 7) & 1) == 0 && p.qnodes != nullptr) {
+    const size_t lds = static_cast<size_t>(kPfRows) * 256u * sizeof(uint32_t) + tail + sizeof(uint32_t) * p.particles_per_block;
     if (leaf2) hipLaunchKernelGGL((k_pf_update_v3<kPfRows, true>), dim3(nblocks), dim3(256), lds, s, p);
     else hipLaunchKernelGGL((k_pf_update_v3<kPfRows, false>), dim3(nblocks), dim3(256), lds, s, p);
     return hipGetLastError();
   }
-  if (!cpc && trav == 0 && refill != 0) {
-    lds = static_cast<size_t>(kPfRows) * 256u * sizeof(uint32_t) + tail;
-    const bool quant = ((variant >> 7) & 1) == 0 && p.qnodes != nullptr;  // bit 7: full-precision nodes (A/B)
-    if (quant) {
-      if (refill == 1) hipLaunchKernelGGL((k_pf_update_persist<kPfRows, 8, true>), dim3(nblocks), dim3(256), lds, s, p);
-      else if (refill == 2) hipLaunchKernelGGL((k_pf_update_persist<kPfRows, 16, true>), dim3(nblocks), dim3(256), lds, s, p);
-      else if (refill == 3) hipLaunchKernelGGL((k_pf_update_persist<kPfRows, 32, true>), dim3(nblocks), dim3(256), lds, s, p);
-      else hipLaunchKernelGGL((k_pf_update_persist<kPfRows, 48, true>), dim3(nblocks), dim3(256), lds, s, p);
-    } else {
-      if (refill == 1) hipLaunchKernelGGL((k_pf_update_persist<kPfRows, 8, false>), dim3(nblocks), dim3(256), lds, s, p);
-      else if (refill == 2) hipLaunchKernelGGL((k_pf_update_persist<kPfRows, 16, false>), dim3(nblocks), dim3(256), lds, s, p);
-      else if (refill == 3) hipLaunchKernelGGL((k_pf_update_persist<kPfRows, 32, false>), dim3(nblocks), dim3(256), lds, s, p);
-      else hipLaunchKernelGGL((k_pf_update_persist<kPfRows, 48, false>), dim3(nblocks), dim3(256), lds, s, p);
-    }
-    return hipGetLastError();
-  }
-  if (cpc) hipLaunchKernelGGL((k_pf_update<64, 3>), dim3(nblocks), dim3(256), lds, s, p);
-  else if (trav == 0) hipLaunchKernelGGL((k_pf_update<64, 0>), dim3(nblocks), dim3(256), lds, s, p);
-  else if (trav == 1 && deep) hipLaunchKernelGGL((k_pf_update<64, 1>), dim3(nblocks), dim3(256), lds, s, p);
-  else if (trav == 1) hipLaunchKernelGGL((k_pf_update<32, 1>), dim3(nblocks), dim3(256), lds, s, p);
-  else if (deep) hipLaunchKernelGGL((k_pf_update<64, 2>), dim3(nblocks), dim3(256), lds, s, p);
-  else hipLaunchKernelGGL((k_pf_update<32, 2>), dim3(nblocks), dim3(256), lds, s, p);
-  return hipGetLastError();
+  if (g_lab && g_lab->pf_update) return g_lab->pf_update(p, variant, s);
+  return hipErrorNotSupported;
 }
 
 hipError_t launch_pf_motion(const uint32_t* nodes, const uint32_t* tris, xform* poses, void* attrs, uint32_t n,
@@ -3994,3 +2065,5 @@ hipError_t launch_compact_shards(const float* padded, float* dense, uint32_t n_t
 }
 
 }  // namespace rmclhip
+
+extern "C" void rmclhip_internal_register_lab(const rmclhip::LabHooks* hooks) { rmclhip::g_lab = hooks; }

@@ -20,6 +20,35 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a HIP device (MI355X); run with -m gpu")
+    config.addinivalue_line("markers", "lab: test drives an EXPERIMENT of librmclhip_lab.so (a rejected traversal kind, an older "
+                                       "particle-filter kernel); also marked gpu.  -m 'gpu and not lab' = the product alone")
+
+
+# traversal kinds librmclhip.so builds (lab_hooks.h: find_kind_in_product); 15 = the automatic rule
+PRODUCT_FIND_KINDS = (0, 2, 4, 15, 19, 21, 22)
+
+
+def find_kinds(*kinds):
+    """parametrize list of find traversal kinds: kinds of the experiments library carry the `lab` marker"""
+    return [k if k in PRODUCT_FIND_KINDS else pytest.param(k, marks=pytest.mark.lab) for k in kinds]
+
+
+def pf_variant_needs_lab(v):
+    """rmclhip_pf_set_variant: rounds (bits 4..6 = 0), the round kernels' traversals (bits 0..1), full nodes (bit 7) and the
+    round-2 kernel (bit 8) are experiments"""
+    return ((v >> 4) & 7) == 0 or (v & 3) != 0 or (v & 128) != 0 or (v & 256) != 0
+
+
+def pf_variants(*variants):
+    return [pytest.param(v, marks=pytest.mark.lab) if pf_variant_needs_lab(v) else v for v in variants]
+
+
+@pytest.fixture(autouse=True)
+def _experiments_library(request):
+    """tests marked `lab` get librmclhip_lab.so loaded (once per process); nothing else ever loads it"""
+    if request.node.get_closest_marker("lab") is not None:
+        import rmcl_amd
+        rmcl_amd.load_lab()
 
 
 @pytest.fixture(scope="session")

@@ -31,8 +31,10 @@ def _duplicate_faces(v, f, seed):
     return v, ff[rng.permutation(len(ff))]
 
 
+@pytest.mark.parametrize("kinds", [(0, 2, 4, 19, 21, 22), pytest.param((1, 5, 7, 9, 11, 12, 13, 14, 16, 17, 20), marks=pytest.mark.lab)],
+                         ids=["product", "experiments"])
 @pytest.mark.parametrize("case", ["soup", "duplicates", "far_from_origin"])
-def test_find_all_traversals_vs_brute_force(ra, orc, ctx, case):
+def test_find_all_traversals_vs_brute_force(ra, orc, ctx, case, kinds):
     from rmcl_amd import synthetic as syn, types as T
     if case == "soup":
         v, f = _soup(1, 3000)
@@ -48,7 +50,7 @@ def test_find_all_traversals_vs_brute_force(ra, orc, ctx, case):
     Tsb = syn.tsb_offset()
     ref = m.simulate_spherical(model, Tsb, pose, bvh=False)          # brute force over all triangles
     assert 100 < int(ref["hits"].sum()) < 1024, int(ref["hits"].sum())   # hits and misses
-    for variant in (0, 1, 2, 4, 5, 7, 9, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 22):
+    for variant in kinds:
         rcc = ra.RCCHipSpherical(hm)
         rcc.set_traversal(variant)
         rcc.setTsb(Tsb)
@@ -89,7 +91,7 @@ def test_cpc_and_pf_vs_brute_force_on_a_soup(ra, orc, ctx):
     beams = ra.beams_from_points(syn.model_directions(syn.model_pf16())[::5] * np.float32(2.5))
     a_ref = attrs.copy()
     e_ref = m.pf_update(poses, a_ref, beams, I, orc.pf_params(), bvh=False, want_errors=True)
-    for variant in (0, 64, 64 | 128):
+    for variant in (64, 48, 64 | 512, 64 | 1024):   # the product's kernel and its knobs (experiments: tests/test_gpu_pf.py, `lab`)
         upd = ra.PCDSensorUpdaterHip(hm)
         upd.init()
         upd.set_variant(variant)

@@ -174,7 +174,7 @@ def test_loop_variants_agree(ra, orc, ctx, meshes, variant_bits):
     meas = m.simulate_spherical(model, ident, ident, bvh=True, nthreads=8)
     ds, mask = om.dataset_from_ranges(model, meas["ranges"])
     rcc = ra.RCCHipSpherical(hm)
-    rcc.set_variant(1 | variant_bits)
+    rcc.set_variant(2 | variant_bits)   # 14 400 rays: the quad traversal, the automatic choice for this scan
     rcc.setTsb(ident)
     rcc.setModel(model)
     rcc.set_dataset(ds, mask)
@@ -206,8 +206,8 @@ def test_find_batch_o1dn_pose_major(ra, orc, ctx, meshes):
     rcc.setTsb(syn.tsb_offset())
     rcc.setModel(16, 16, 0.05, 80.0, (0.01, 0.02, 0.03), dirs)
     poses, _ = syn.uniform_particles(33, seed=9, bb_min=(-8, -8, 0.5, 0, 0, -3), bb_max=(8, 8, 2.5, 0, 0, 3))
-    for variant in (1, 0, 2, 4, 5):
-        rcc.set_variant(variant)
+    for variant in (19, 0, 2, 4, 21, 22):
+        rcc.set_traversal(variant)
         rcc.find_batch(poses)
         mv = rcc.modelView()
         ref = m.simulate_o1dn(16, 16, 0.05, 80.0, (0.01, 0.02, 0.03), dirs, syn.tsb_offset(), poses, bvh=True, nthreads=4)

@@ -11,7 +11,7 @@ from test_gpu_find import _compare
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant", [1, 0, 2, 4, 5])
+@pytest.mark.parametrize("variant", [19, 0, 2, 4, 21, 22])
 def test_pinhole_depth_camera(ra, orc, ctx, meshes, variant):
     from rmcl_amd import synthetic as syn, types as T
     v, f = meshes("room30k")
@@ -21,7 +21,7 @@ def test_pinhole_depth_camera(ra, orc, ctx, meshes, variant):
     Tsb = syn.tsb_offset()
     Tbm = T.transform_from_rpy((-2.0, 1.5, 1.4), (0.01, 0.1, 0.9))
     rcc = ra.RCCHipPinhole(hm)
-    rcc.set_variant(variant)
+    rcc.set_traversal(variant)
     rcc.setTsb(Tsb)
     rcc.setModel(W, H, 0.3, 12.0, fx, fy, cx, cy)
     rcc.find(Tbm)
@@ -44,7 +44,7 @@ def test_pinhole_depth_camera(ra, orc, ctx, meshes, variant):
     assert np.allclose(s["covariance"].reshape(3, 3), r64["covariance"], rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("variant", [1, 0, 2, 4, 5])
+@pytest.mark.parametrize("variant", [19, 0, 2, 4, 21, 22])
 def test_ondn_multi_origin(ra, orc, ctx, meshes, variant):
     from rmcl_amd import synthetic as syn, types as T
     v, f = meshes("room30k")
@@ -60,7 +60,7 @@ def test_ondn_multi_origin(ra, orc, ctx, meshes, variant):
     Tsb = syn.tsb_offset()
     Tbm = T.transform_from_rpy((3.0, -2.5, 1.0), (0.0, 0.0, -2.2))
     rcc = ra.RCCHipOnDn(hm)
-    rcc.set_variant(variant)
+    rcc.set_traversal(variant)
     rcc.setTsb(Tsb)
     rcc.setModel(W, H, 0.1, 25.0, origs, dirs)
     rcc.find(Tbm)

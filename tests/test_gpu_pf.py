@@ -8,7 +8,7 @@ import math
 import numpy as np
 import pytest
 
-from conftest import assert_close_rel, golden_path
+from conftest import assert_close_rel, golden_path, pf_variants
 
 pytestmark = pytest.mark.gpu
 
@@ -44,7 +44,7 @@ def _check(a_gpu, e_gpu, a_ref, e_ref, what):
 LEGACY, BIG, MAPTREE = 256, 512, 1024
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 16, 48, 64, 48 | 128, 64 | LEGACY, 64 | BIG, 64 | MAPTREE])
+@pytest.mark.parametrize("variant", pf_variants(0, 1, 2, 16, 48, 64, 48 | 128, 64 | LEGACY, 64 | BIG, 64 | MAPTREE))
 def test_golden_g6_cube(ra, ctx, meshes, variant):
     """committed fixture G6: 64 particles x 16 beams on the cube; beams outside the sensor range
     (real miss) and the MAX_N_MEAS clamp included."""
@@ -61,7 +61,7 @@ def test_golden_g6_cube(ra, ctx, meshes, variant):
 
 
 @pytest.mark.parametrize("n_particles,n_beams", [(1000, 100), (257, 7), (4099, 256)])
-@pytest.mark.parametrize("variant", [0, 2, 16, 32, 64, 48 | 128, 64 | LEGACY, 64 | BIG, 64 | MAPTREE, 64 | LEGACY | MAPTREE])
+@pytest.mark.parametrize("variant", pf_variants(0, 2, 16, 32, 64, 48 | 128, 64 | LEGACY, 64 | BIG, 64 | MAPTREE, 64 | LEGACY | MAPTREE))
 def test_room_random_particles(ra, orc, ctx, meshes, n_particles, n_beams, variant):
     """random hypotheses in a room with occluders and an open ceiling (sim misses), reference default of
     100 random beams and ragged sizes; beams sampled from a simulated cloud like update() does."""
@@ -84,7 +84,7 @@ def test_room_random_particles(ra, orc, ctx, meshes, n_particles, n_beams, varia
     assert (e_ref == 100.0).any() and (e_ref < 1.0).any()
 
 
-@pytest.mark.parametrize("variant", [64, 64 | BIG, 64 | LEGACY, 0])
+@pytest.mark.parametrize("variant", pf_variants(64, 64 | BIG, 64 | LEGACY, 0))
 def test_beams_with_their_own_origins_and_edge_counts(ra, orc, ctx, meshes, variant):
     """RangeMeasurement.orig != 0 (the general Tsm * meas_s of RangeMeasurement.hpp:28-42; the kernel's shortcut for beams that
     start at the sensor origin must not be taken) and every regime of the count sequence of the in-order merge: n_meas
@@ -161,7 +161,7 @@ def test_custom_parameters_and_empty_inputs(ra, orc, ctx, meshes):
     assert np.array_equal(d_attrs.download().view(np.uint8), attrs.view(np.uint8))
 
 
-@pytest.mark.parametrize("variant", [0, 2, 48])
+@pytest.mark.parametrize("variant", pf_variants(0, 2, 48, 64))
 def test_embree_geometric_normal_mode(ra, orc, ctx, meshes, variant):
     """correspondence_type 2: the error of evaluate_rcc against Embree's UN-normalised rayhit.hit.Ng
     (PCDSensorUpdaterEmbree.cpp:56-66) instead of the OptiX program's unit normal: bit-for-bit the oracle's mode-2
@@ -192,7 +192,7 @@ def test_embree_geometric_normal_mode(ra, orc, ctx, meshes, variant):
     assert not np.allclose(ratio, 1.0, atol=1e-2)
 
 
-@pytest.mark.parametrize("variant", [0, 48])
+@pytest.mark.parametrize("variant", pf_variants(0, 48, 64))
 def test_optix_program_rules_mode(ra, orc, ctx, meshes, variant):
     """correspondence_type 3 = optix/BeamEvaluateProgram.cu:15-130 exactly: tmax 1e4 and EVERY hit is a sim hit (the Embree
     updater also asks t > sensor_range.min, PCDSensorUpdaterEmbree.cpp:47).  Particles hugging a wall make the two rules
@@ -218,6 +218,7 @@ def test_optix_program_rules_mode(ra, orc, ctx, meshes, variant):
     assert np.all(out[0][differ] == 100.0) and np.all(out[3][differ] < 10.0)
 
 
+@pytest.mark.lab
 def test_c4_full_size_properties(ra, orc, ctx, meshes):
     """BASELINE config C4 at full size (100 000 particles x 256 beams, sphere-100k): far beyond what the oracle
     finishes in seconds, so size-independent properties are checked instead --
@@ -237,6 +238,7 @@ def test_c4_full_size_properties(ra, orc, ctx, meshes):
     beams = ra.beams_from_points(syn.model_directions(syn.model_pf16()) * np.float32(radius))
     assert len(beams) == 256
     results = []
+    ra.load_lab()   # the round-2 kernels are part of this schedule-independence check
     for variant in (64, 64 | 256, 64 | 512, 16, 48 | 128, 0):
         upd = ra.PCDSensorUpdaterHip(hm)
         upd.init()

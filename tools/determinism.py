@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import rmcl_amd as ra
+ra.load_lab()   # experiments library: the kinds / kernels this tool compares are not all in the product
 from rmcl_amd import synthetic as syn, types as T
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300

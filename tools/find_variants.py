@@ -9,6 +9,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rmcl_amd as ra
+ra.load_lab()   # experiments library: the kinds / kernels this tool compares are not all in the product
 from rmcl_amd import synthetic as syn, types as T
 
 kinds = [int(a) for a in sys.argv[1:]] or [1, 5, 6, 7, 8, 9, 10, 2]
