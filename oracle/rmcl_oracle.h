@@ -221,13 +221,6 @@ int orc_sample_beams_pointcloud2(const uint8_t* data, uint32_t width, uint32_t h
                                  uint32_t seed, orc_range_measurement* out, uint32_t* n_out);
 uint32_t orc_mt19937_draw(uint32_t seed, uint32_t n_skip);   /* the (n_skip+1)-th output of MT19937(seed): known-answer tests */
 
-/* analysis only (tools/wavesim.py): wave-level step counts of the product's while-while traversal on its exported
- * BVH4 arrays; see rmcl_oracle.c */
-int orc_wavesim_ww(const uint32_t* nodes, const uint32_t* tris, const float* O, const float* D, uint32_t nlanes,
-                   float tfar, int mode, uint64_t out[7], float* t_out, uint32_t* face_out);
-int orc_blocksim(const uint32_t* nodes, const uint32_t* tris, const float* O, const float* D, uint32_t nw, float tfar,
-                 const double* costs, uint32_t min_victim, double out[3]);
-void orc_wavesim_costs(double n1, double l1, double n2, double l2, double n4, double l4, uint32_t t2, uint32_t t4);
 
 #endif
 #endif

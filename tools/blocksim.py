@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""What could intra-CU ray stealing win for one find()?  Block-level model (oracle/rmcl_oracle.c: orc_blocksim): the 8 tiles a CU
+"""What could intra-CU ray stealing win for one find()?  Block-level model (tools/wavesim.c: orc_blocksim): the 8 tiles a CU
 receives at C2 run as 8 waves with their own clocks; a finished wave takes half of the walking rays of the busiest wave.
 Prints the slowest block with and without stealing.   usage: python tools/blocksim.py [sphere|room] [adjacent|strided]"""
 import ctypes as C
@@ -9,9 +9,8 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
+for p in (ROOT, os.path.join(ROOT, "tools")):
     sys.path.insert(0, p)
-import oracle as orc  # noqa: E402
 import rmcl_amd as ra  # noqa: E402
 import wavesim as ws  # noqa: E402
 from rmcl_amd import synthetic as syn  # noqa: E402
@@ -26,7 +25,7 @@ img = dm.reshape(H, W, 3)
 tiles = [np.ascontiguousarray(img[ty:ty + 8, tx:tx + 8].reshape(-1, 3)) for ty in range(0, H, 8) for tx in range(0, W, 8)]
 nt = len(tiles)
 order = np.arange(nt) if layout == "adjacent" else np.arange(nt).reshape(8, nt // 8).T.reshape(-1)
-L = orc.lib()
+L = ws.simlib()
 L.orc_blocksim.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_uint32, C.c_void_p]
 # clocks measured on the device: node iteration 730 (lane) / 600 (quad tail), leaf round 1400 / 800
 for thief, victim, minv in ((1500.0, 300.0, 8), (3000.0, 600.0, 8), (1500.0, 300.0, 24)):

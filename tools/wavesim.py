@@ -1,6 +1,5 @@
 #!/usr/bin/env python
-"""CPU model of what bounds a single-scan find: wave-level step counts of the product's traversal (oracle/rmcl_oracle.c:
-orc_wavesim_ww) for every 8x8 tile of the C2 scan.  The launch ends with its slowest wave, so the figure of merit is the
+"""CPU model of what bounds a single-scan find: wave-level step counts of the product's traversal (tools/wavesim.c: orc_wavesim_ww) for every 8x8 tile of the C2 scan.  The launch ends with its slowest wave, so the figure of merit is the
 MAX over waves of (node iterations, leaf rounds), not the mean per ray.   usage: python tools/wavesim.py [sphere|room] [modes]"""
 import ctypes as C
 import os
@@ -9,11 +8,17 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "oracle")):
-    sys.path.insert(0, p)
-import oracle as orc  # noqa: E402
+sys.path.insert(0, ROOT)
 import rmcl_amd as ra  # noqa: E402
 from rmcl_amd import synthetic as syn, types as T  # noqa: E402
+
+
+def simlib():
+    """tools/libwavesim.so (tools/wavesim.c: the models moved out of the parity oracle in round 3)"""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    subprocess.check_call(["make", "-s", "-C", here])
+    return C.CDLL(os.path.join(here, "libwavesim.so"))
 
 
 def rays_c2(mesh):
@@ -29,7 +34,7 @@ def rays_c2(mesh):
 
 
 def simulate(nodes, tris, model, O, dm, mode, tile=(8, 8), stride=1):
-    L = orc.lib()
+    L = simlib()
     L.orc_wavesim_ww.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p]
     H, W = model.phi.size, model.theta.size
