@@ -199,7 +199,7 @@ struct rmclhip_rcc {
   bool fused_tail = false;         // true: last-block tail inside the reduction kernel (measured slower, A/B only)
   // moment form of the schedule-(R) loop (launch_micp_fast): tried first when the previous corrections say the gate
   // decisions are stable; the per-iteration form above is the fallback and the reference for the result
-  int fast_mode = 1;               // 0 off, 1 automatic
+  int fast_mode = 1;               // 0 off, 1 automatic (direct launches), 2 automatic through a hipGraph (A/B)
   DevBuf<double> d_fast_partials;
   DevBuf<unsigned long long> d_fast_mask;
   MicpFastStatus* h_fast_status = nullptr;      // pinned, host-mapped
@@ -1102,7 +1102,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
     r->h_call->seq = next_seq(r);
     // ---- moment form first (kernels.hip "gate-stable moment form"); any outcome other than "done" falls through to the
     // per-iteration form below, which recomputes the correction from scratch
-    const bool fast_eligible = r->fast_mode != 0 && r->use_graph && r->loop_blocks == 0 && !r->fused_tail && n_iter >= 2u;
+    const bool fast_eligible = r->fast_mode != 0 && r->loop_blocks == 0 && !r->fused_tail && n_iter >= 2u;
     bool fast_tried = false;
     if (fast_eligible && r->fast_holdoff > 0u) --r->fast_holdoff;
     else if (fast_eligible) {
@@ -1116,7 +1116,21 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
       key.fused = 0; key.has_mask = r->ds_has_mask ? 1 : 0;
       key.ptrs[0] = r->d_points.p; key.ptrs[1] = r->ds_pts; key.ptrs[2] = r->d_fast_partials.p;
       key.ptrs[3] = r->d_model_tab.p; key.ptrs[4] = r->ds_msk; key.ptrs[5] = r->d_fast_mask.p;
-      if (!r->micp_fast_exec || r->fast_graph_dirty || !(key == r->micp_fast_key)) {
+      if (!r->use_graph || r->fast_mode == 1) {
+        // direct launches (the default form; fast_mode 2 replays the same chain from a hipGraph, A/B): three kernels with their per-call data BY VALUE -- no H2D copy node, no graph launch (a graph
+        // replay costs the host 10-16 us whatever it holds; three plain launches overlap with the kernels they start)
+        FindParams fp;
+        fill_find_params(r, fp, 1);
+        fp.Tsm = r->h_call->Tsm;
+        fp.Tms = r->h_call->Tms;
+        HIPCHK(launch_find(fp, r->kind, find_variant(r, 1), r->stream));
+        MicpCallLite cl;
+        cl.Tsb = r->Tsb; cl.Tbo = Tbo; cl.max_dist = maxd; cl.rho_cap = r->fast_rho_cap; cl.tau_cap = r->fast_tau_cap;
+        cl.seq = r->h_call->seq;
+        HIPCHK(launch_micp_fast(r->ds_pts, r->ds_has_mask ? r->ds_msk : nullptr, r->d_points.p, r->d_normals.p, r->d_hits.p, nred,
+                                nullptr, r->d_fast_partials.p, r->d_fast_mask.p, n_iter, r->h_state_dev, r->h_fast_status_dev,
+                                r->h_done_dev, r->stream, &cl));
+      } else if (!r->micp_fast_exec || r->fast_graph_dirty || !(key == r->micp_fast_key)) {
         // the previous call returned on its completion tag, which precedes the stream's own completion: let the last node
         // retire before its executable graph is destroyed
         HIPCHK(hipStreamSynchronize(r->stream));
@@ -1146,7 +1160,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
         r->micp_fast_key = key;
         r->fast_graph_dirty = false;
       }
-      HIPCHK(hipGraphLaunch(r->micp_fast_exec, r->stream));
+      if (r->use_graph && r->fast_mode != 1) HIPCHK(hipGraphLaunch(r->micp_fast_exec, r->stream));
       // sum of the tag: the status block, plus the state block when the loop ran to its end (code 0)
       DoneCheck chk; chk.base = r->h_fast_status; chk.base_bytes = sizeof(MicpFastStatus); chk.code = &r->h_fast_status->code;
       chk.extra[0] = r->h_state; chk.extra_bytes[0] = sizeof(MicpState);
@@ -1604,7 +1618,7 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
 
 rmclhip_status rmclhip_rcc_set_micp_fast(rmclhip_rcc* r, int mode) {
   ApiGuard guard_("rmclhip_rcc_set_micp_fast");
-  if (!r || mode < 0 || mode > 1) return fail(RMCLHIP_ERR_INVALID, "rcc_set_micp_fast: mode must be 0 (off) or 1 (automatic)");
+  if (!r || mode < 0 || mode > 2) return fail(RMCLHIP_ERR_INVALID, "rcc_set_micp_fast: mode must be 0 (off), 1 (automatic) or 2 (automatic, replayed from a hipGraph)");
   r->fast_mode = mode;
   r->fast_holdoff = 0;
   r->fast_overflows = 0;

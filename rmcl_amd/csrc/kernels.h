@@ -106,6 +106,14 @@ struct MicpCall {
   uint32_t pad[4];
 };
 
+// the part of MicpCall the moment-form kernels read, passed BY VALUE when the chain is launched directly (no hipGraph, no H2D
+// copy node: kernel arguments are fresh on every launch anyway)
+struct MicpCallLite {
+  xform Tsb, Tbo;
+  float max_dist, rho_cap, tau_cap;
+  uint32_t seq;
+};
+
 // MICP-L inner-loop state kept on the device between launches (correct_once)
 struct MicpState {
   xform T_onew_oold;
@@ -126,7 +134,8 @@ inline uint32_t micp_fast_blocks(uint32_t n) {
 hipError_t launch_micp_fast(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
                             const float* model_normals, const uint8_t* model_mask, uint32_t n, const MicpCall* call,
                             double* partials, unsigned long long* unc_mask, uint32_t n_iter, MicpState* state_out,
-                            MicpFastStatus* status, unsigned long long* done, hipStream_t s);
+                            MicpFastStatus* status, unsigned long long* done, hipStream_t s,
+                            const MicpCallLite* call_by_value = nullptr);   // non-null: `call` is ignored
 
 // N-sensor MICP loop on the device (micp_localization.cpp:900-964): per-call frames + per-sensor partials, one step launch per
 // iteration merges every sensor's statistics (weighted and unweighted), solves once and hands every sensor its next

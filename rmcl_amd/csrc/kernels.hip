@@ -566,11 +566,111 @@ __device__ __forceinline__ void wave_reduce16(double (&v)[16], uint32_t lane) {
 }
 
 // raw sums of the reduction (sd[3] sm[3] smd[9] n) -> CrossStatistics, as finalize_pose does
+// ---- cheaper reciprocals for the ONE lane that solves (moment-form loops): a lone lane retires one instruction per ~5-8 cycles,
+// so the solve costs what its instruction count costs, and an IEEE f64 division is ~25 instructions, a square root + division
+// ~50.  v_rcp_f64 / v_rsq_f64 with two Newton-Raphson refinements give 1/x and 1/sqrt(x) to ~1 ulp in 5 / 9 instructions.  Used
+// where the consumer is itself an iteration (Newton's step of the quartic) or is rounded to f32 afterwards (quaternion
+// normalisation, 1/n of the statistics); the generic umeyama() of devmath.h -- shared with the host and the oracle-facing
+// entry points -- keeps IEEE divisions.
+__device__ __forceinline__ double rcp_nr(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double rsq_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x, y * y, 1.5);
+  y = y * fma(-0.5 * x, y * y, 1.5);
+  return y;
+}
+
+// horn_quaternion (devmath.h) with rcp_nr / rsq_nr; same formulas, same fall-back condition (false -> the caller takes umeyama())
+__device__ __forceinline__ bool horn_quaternion_fast(const double* C, double* q) {
+  const double Sxx = C[0], Sxy = C[3], Sxz = C[6], Syx = C[1], Syy = C[4], Syz = C[7], Szx = C[2], Szy = C[5], Szz = C[8];
+  sym4 K;
+  K.k00 = Sxx + Syy + Szz; K.k01 = Syz - Szy; K.k02 = Szx - Sxz; K.k03 = Sxy - Syx;
+  K.k11 = Sxx - Syy - Szz; K.k12 = Sxy + Syx; K.k13 = Szx + Sxz;
+  K.k22 = -Sxx + Syy - Szz; K.k23 = Syz + Szy;
+  K.k33 = -Sxx - Syy + Szz;
+  const double ss = ((Sxx * Sxx + Sxy * Sxy + Sxz * Sxz) + (Syx * Syx + Syy * Syy + Syz * Syz)) + (Szx * Szx + Szy * Szy + Szz * Szz);
+  if (!(ss > 0.0)) return false;
+  const double c2 = -2.0 * ss;
+  const double c1 = -8.0 * det3(C);
+  const double c0 = sym4_det(sym4_sub(K));
+  const double lam0 = sqrt(3.0 * ss) * (1.0 + 1e-12);
+  double lam = lam0;
+  {
+    const double a = K.k00, a2 = a * a;
+    const double Pa = (a2 + c2) * a2 + c1 * a + c0, dPa = (4.0 * a2 + 2.0 * c2) * a + c1;
+    if (a > 0.0 && 3.0 * a2 > ss && dPa > 0.0 && Pa <= 0.0) {
+      const double a1 = a - Pa * rcp_nr(dPa);
+      if (a1 < lam0) lam = a1;
+    }
+  }
+  bool converged = false;
+  for (int it = 0; it < 60; ++it) {
+    const double l2 = lam * lam;
+    const double P = (l2 + c2) * l2 + c1 * lam + c0;
+    const double dP = (4.0 * l2 + 2.0 * c2) * lam + c1;
+    if (!(dP > 0.0)) break;
+    const double step = P * rcp_nr(dP);
+    lam -= step;
+    if (step <= 1e-14 * lam0) { converged = true; break; }
+  }
+  if (!converged) return false;
+  K.k00 -= lam; K.k11 -= lam; K.k22 -= lam; K.k33 -= lam;
+  const sym4_minors m = sym4_sub(K);
+  const double a00 = K.k11 * m.c5 - K.k12 * m.c4 + K.k13 * m.c3;
+  const double a11 = K.k00 * m.c5 - K.k02 * m.c2 + K.k03 * m.c1;
+  const double a22 = K.k03 * m.s4 - K.k13 * m.s2 + K.k33 * m.s0;
+  const double a33 = K.k02 * m.s3 - K.k12 * m.s1 + K.k22 * m.s0;
+  const double a01 = -K.k01 * m.c5 + K.k02 * m.c4 - K.k03 * m.c3;
+  const double a02 = K.k13 * m.s5 - K.k23 * m.s4 + K.k33 * m.s3;
+  const double a03 = -K.k12 * m.s5 + K.k22 * m.s4 - K.k23 * m.s3;
+  const double a12 = -K.k03 * m.s5 + K.k23 * m.s2 - K.k33 * m.s1;
+  const double a13 = K.k02 * m.s5 - K.k22 * m.s2 + K.k23 * m.s1;
+  const double a23 = -K.k02 * m.s4 + K.k12 * m.s2 - K.k23 * m.s0;
+  double v0 = a00, v1 = a01, v2 = a02, v3 = a03, dbest = fabs(a00);
+  if (fabs(a11) > dbest) { v0 = a01; v1 = a11; v2 = a12; v3 = a13; dbest = fabs(a11); }
+  if (fabs(a22) > dbest) { v0 = a02; v1 = a12; v2 = a22; v3 = a23; dbest = fabs(a22); }
+  if (fabs(a33) > dbest) { v0 = a03; v1 = a13; v2 = a23; v3 = a33; dbest = fabs(a33); }
+  if (!(dbest > 1e-10 * lam0 * lam0 * lam0)) return false;  // repeated largest eigenvalue
+  const double n2 = (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+  if (!(n2 > 0.0)) return false;
+  const double rn = rsq_nr(n2);
+  double w = v0 * rn, x = v1 * rn, y = v2 * rn, z = v3 * rn;
+  double lead = w;
+  if (!(fabs(w) > 0.5)) {
+    if (x * x > y * y && x * x > z * z) lead = x;
+    else if (y * y > z * z) lead = y;
+    else lead = z;
+  }
+  if (lead < 0.0) { w = -w; x = -x; y = -y; z = -z; }
+  q[0] = x; q[1] = y; q[2] = z; q[3] = w;
+  return true;
+}
+
+// umeyama() for the moment-form loops' one solving lane; degenerate inputs take the generic path
+__device__ __forceinline__ xform umeyama_fast(const cstats& s) {
+  if (s.n_meas == 0) return xidentity();
+  double C[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) C[i] = static_cast<double>(s.covariance[i]);
+  double q[4];
+  if (!horn_quaternion_fast(C, q)) return umeyama(s);
+  xform T = xidentity();
+  T.R.x = static_cast<float>(q[0]); T.R.y = static_cast<float>(q[1]);
+  T.R.z = static_cast<float>(q[2]); T.R.w = static_cast<float>(q[3]);
+  T.t = sub3(s.model_mean, qrot(T.R, s.dataset_mean));
+  return T;
+}
+
 __device__ __forceinline__ cstats cstats_from_sums(const double* acc) {
   cstats s = cs_identity();
   const double n = acc[15];
   if (n > 0.0) {
-    const double rn = 1.0 / n;   // one division (finalize_pose divides 15 times: same values to the last bit or two)
+    const double rn = rcp_nr(n);   // (finalize_pose divides 15 times: same values to the last bit or two)
     const double md[3] = {acc[0] * rn, acc[1] * rn, acc[2] * rn};
     const double mm[3] = {acc[3] * rn, acc[4] * rn, acc[5] * rn};
     s.dataset_mean = mk3(static_cast<float>(md[0]), static_cast<float>(md[1]), static_cast<float>(md[2]));
@@ -596,7 +696,9 @@ struct MicpFastParams {
   MicpState* state_out;         // may be host-mapped
   MicpFastStatus* status;       // may be host-mapped
   unsigned long long* done;     // host-mapped completion tag
+  MicpCallLite cv;              // used when call == nullptr (direct launches)
 };
+#define RMCL_FCALL(p, field) ((p).call != nullptr ? (p).call->field : (p).cv.field)
 
 // Status blocks live in pinned host memory: the block is written whole, then the completion tag (publish_tag) with the sum of
 // the block and of whatever else this exit wrote for the host (`extra`: the xor of the state block, 0 for the early exits).
@@ -617,7 +719,7 @@ __global__ void __launch_bounds__(256) k_micp_moments(const MicpFastParams p) {
   __shared__ double red[4][kMom];
   __shared__ double s_scratch[4][2][64 * 17];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const float max_dist = p.call->max_dist, rho_cap = p.call->rho_cap, tau_cap = p.call->tau_cap;
+  const float max_dist = RMCL_FCALL(p, max_dist), rho_cap = RMCL_FCALL(p, rho_cap), tau_cap = RMCL_FCALL(p, tau_cap);
   double m[kMom];
 #pragma unroll
   for (int k = 0; k < kMom; ++k) m[k] = 0.0;
@@ -832,7 +934,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastP
     if (tid == 0u) {
       MicpFastStatus st;
       st.code = 2u; st.iter = 0u; st.n_uncertain = total; st.max_rho = 0.f; st.max_tau = 0.f; st.pad[0] = st.pad[1] = st.pad[2] = 0u;
-      publish_status(p.status, st, p.done, p.call->seq, 0u);
+      publish_status(p.status, st, p.done, RMCL_FCALL(p, seq), 0u);
     }
     return;
   }
@@ -847,8 +949,16 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastP
       }
     }
   }
-  const float max_dist = p.call->max_dist, rho_cap = p.call->rho_cap, tau_cap = p.call->tau_cap;
+  const float max_dist = RMCL_FCALL(p, max_dist), rho_cap = RMCL_FCALL(p, rho_cap), tau_cap = RMCL_FCALL(p, tau_cap);
   const uint32_t nrows = min(total, kFastThreads);
+  // No undecided correspondence (the usual case of a tracking-size correction): everything the iterations need is the 82
+  // moments, and wave 0 alone runs them -- no workgroup barrier inside the loop (the LDS operations of ONE wave complete in
+  // program order); the other waves leave once the moments they summed are in LDS.
+  const bool lone = (total == 0u);
+  if (lone) {
+    __syncthreads();
+    if (wave != 0u) return;
+  }
   // thread 0 owns the loop state (registers): the sensor-frame pre-transform and the statistics of the last iteration
   xform T_s = xidentity();
   cstats last = cs_identity();
@@ -870,12 +980,13 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastP
       s_R[6] = 2.0 * (x * z - w * y);   s_R[7] = 2.0 * (y * z + w * x);   s_R[8] = (ww - uu) + 2.0 * z * z;
       s_t[0] = T_s.t.x; s_t[1] = T_s.t.y; s_t[2] = T_s.t.z;
     }
-    __syncthreads();   // (A) pre-transform published; also orders the previous iteration's reads of s_rows / s_tot
+    if (lone) __builtin_amdgcn_wave_barrier();
+    else __syncthreads();   // (A) pre-transform published; also orders the previous iteration's reads of s_rows / s_tot
     if (s_flag != 0u) {
       if (tid == 0u) {
         MicpFastStatus st;
         st.code = 1u; st.iter = it; st.n_uncertain = total; st.max_rho = max_rho; st.max_tau = max_tau; st.pad[0] = st.pad[1] = st.pad[2] = 0u;
-        publish_status(p.status, st, p.done, p.call->seq, 0u);
+        publish_status(p.status, st, p.done, RMCL_FCALL(p, seq), 0u);
       }
       return;
     }
@@ -926,19 +1037,19 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastP
 #pragma unroll
       for (int k = 0; k < 16; ++k) tot[k] = s_tot[k];
       last = cstats_from_sums(tot);
-      micp_advance_sensor(last, &T_s);
+      T_s = xmul(T_s, umeyama_fast(last));   // micp_advance_sensor with the cheaper reciprocals
     }
   }
   if (tid == 0u) {
     MicpState out;
-    micp_close_sensor(last, T_s, p.call->Tsb, p.call->Tbo, &out);
+    micp_close_sensor(last, T_s, RMCL_FCALL(p, Tsb), RMCL_FCALL(p, Tbo), &out);
     *p.state_out = out;
     MicpFastStatus st;
     st.code = 0u; st.iter = p.n_iter; st.n_uncertain = total; st.max_rho = max_rho; st.max_tau = max_tau;
     st.pad[0] = static_cast<uint32_t>(clk1 - clk0);                              // diagnostics: shader clocks of the set-up
     st.pad[1] = static_cast<uint32_t>(__builtin_readcyclecounter() - clk1);      // ... and of all iterations
     st.pad[2] = 0u;
-    publish_status(p.status, st, p.done, p.call->seq, xor_words(out));
+    publish_status(p.status, st, p.done, RMCL_FCALL(p, seq), xor_words(out));
   }
 }
 
@@ -1853,7 +1964,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_multi_fast_loop(const Mic
         merged = cs_merge(merged, Cs_o);
         merged_w = cs_merge(merged_w, Cs_w);
       }
-      T_onew_oold = xmul(T_onew_oold, umeyama(merged_w));
+      T_onew_oold = xmul(T_onew_oold, umeyama_fast(merged_w));
       for (uint32_t s = 0; s < ns; ++s) {
         const xform T_bnew_bold = xmul(xmul(xinv(p.call->Tbo[s]), T_onew_oold), p.call->Tbo[s]);
         s_Ts[s] = xmul(xmul(xinv(p.call->Tsb[s]), T_bnew_bold), p.call->Tsb[s]);
@@ -1905,7 +2016,7 @@ hipError_t launch_micp_moments(const float* dataset_points, const uint8_t* datas
                                const float* model_normals, const uint8_t* model_mask, uint32_t n, const MicpCall* call,
                                double* partials, unsigned long long* unc_mask, hipStream_t s) {
   MicpFastParams p{dataset_points, dataset_mask, model_points, model_normals, model_mask, n, micp_fast_blocks(n), call,
-                   partials, unc_mask, 0u, nullptr, nullptr, nullptr};
+                   partials, unc_mask, 0u, nullptr, nullptr, nullptr, {}};
   hipLaunchKernelGGL(k_micp_moments, dim3(p.nblocks), dim3(256), 0, s, p);
   return hipGetLastError();
 }
@@ -1918,9 +2029,10 @@ hipError_t launch_micp_multi_fast_loop(const MicpMultiFastParams& p, hipStream_t
 hipError_t launch_micp_fast(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
                             const float* model_normals, const uint8_t* model_mask, uint32_t n, const MicpCall* call,
                             double* partials, unsigned long long* unc_mask, uint32_t n_iter, MicpState* state_out,
-                            MicpFastStatus* status, unsigned long long* done, hipStream_t s) {
+                            MicpFastStatus* status, unsigned long long* done, hipStream_t s, const MicpCallLite* call_by_value) {
   MicpFastParams p{dataset_points, dataset_mask, model_points, model_normals, model_mask, n, micp_fast_blocks(n), call,
-                   partials, unc_mask, n_iter, state_out, status, done};
+                   partials, unc_mask, n_iter, state_out, status, done, {}};
+  if (call_by_value) { p.call = nullptr; p.cv = *call_by_value; }
   hipLaunchKernelGGL(k_micp_moments, dim3(p.nblocks), dim3(256), 0, s, p);
   hipLaunchKernelGGL(k_micp_fast_loop, dim3(1), dim3(kFastThreads), 0, s, p);
   return hipGetLastError();

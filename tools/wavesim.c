@@ -82,6 +82,10 @@ static void ws_pop(ws_lane* L, int mode)
   L->done = 1;
 }
 
+/* tracking mode (round 3): per-lane best_t seeds (the previous scan's hit distance); NULL = cold */
+static const float* g_seed_t = 0;
+void orc_wavesim_seed(const float* t) { g_seed_t = t; }
+
 int orc_wavesim_ww(const uint32_t* nodes, const uint32_t* tris, const float* O, const float* D, uint32_t nlanes,
                    float tfar, int mode, uint64_t out[7], float* t_out, uint32_t* face_out)
 {
@@ -92,7 +96,7 @@ int orc_wavesim_ww(const uint32_t* nodes, const uint32_t* tris, const float* O, 
     L[i].O = v3(O[3 * i], O[3 * i + 1], O[3 * i + 2]); L[i].D = v3(D[3 * i], D[3 * i + 1], D[3 * i + 2]);
     L[i].o[0] = L[i].O.x; L[i].o[1] = L[i].O.y; L[i].o[2] = L[i].O.z;
     L[i].inv[0] = safe_inv(L[i].D.x); L[i].inv[1] = safe_inv(L[i].D.y); L[i].inv[2] = safe_inv(L[i].D.z);
-    L[i].best_t = tfar; L[i].best_f = 0xFFFFFFFFu;
+    L[i].best_t = (g_seed_t && g_seed_t[i] > 0.0f) ? g_seed_t[i] : tfar; L[i].best_f = 0xFFFFFFFFu;
     L[i].done = !(L[i].D.x == L[i].D.x && L[i].D.y == L[i].D.y && L[i].D.z == L[i].D.z);
   }
   memset(out, 0, 7 * sizeof(uint64_t));

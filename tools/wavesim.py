@@ -33,8 +33,9 @@ def rays_c2(mesh):
     return model, O, dm
 
 
-def simulate(nodes, tris, model, O, dm, mode, tile=(8, 8), stride=1):
+def simulate(nodes, tris, model, O, dm, mode, tile=(8, 8), stride=1, seeded=False):
     L = simlib()
+    L.orc_wavesim_seed.argtypes = [C.c_void_p]
     L.orc_wavesim_ww.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p]
     H, W = model.phi.size, model.theta.size
@@ -50,8 +51,16 @@ def simulate(nodes, tris, model, O, dm, mode, tile=(8, 8), stride=1):
             d = np.ascontiguousarray(img[ty:ty + th, tx:tx + tw].reshape(-1, 3))
             o = np.ascontiguousarray(np.tile(O, (len(d), 1)))
             out = np.zeros(7, np.uint64)
+            if seeded:
+                # tracking mode: every ray starts with the hit distance of the previous (identical) scan as its best_t
+                t_prev = np.zeros(len(d), np.float32)
+                L.orc_wavesim_seed(None)
+                L.orc_wavesim_ww(nodes.ctypes.data, tris.ctypes.data, o.ctypes.data, d.ctypes.data, len(d), float(model.range.max),
+                                 mode, out.ctypes.data, t_prev.ctypes.data, None)
+                L.orc_wavesim_seed(t_prev.ctypes.data)
             L.orc_wavesim_ww(nodes.ctypes.data, tris.ctypes.data, o.ctypes.data, d.ctypes.data, len(d), float(model.range.max),
                              mode, out.ctypes.data, None, None)
+            L.orc_wavesim_seed(None)
             res.append(out.copy())
     return np.array(res, dtype=np.float64)
 
@@ -73,3 +82,4 @@ if __name__ == "__main__":
     model, O, dm = rays_c2(mesh)
     for mode in modes:
         report("mode %d" % mode, simulate(nodes, tris, model, O, dm, mode, stride=4))
+        report("mode %d seeded" % mode, simulate(nodes, tris, model, O, dm, mode, stride=4, seeded=True))
