@@ -308,10 +308,11 @@ rmclhip_status rmclhip_rcc_time_correct_once(rmclhip_rcc* rcc, const rmclhip_tra
                                              uint32_t n_iter, double convergence_progress, int refind_each_iteration,
                                              uint32_t iters, float* ms_per_call);
 /* kernel variant selection: bits 0..3 (+ bit 13 = 16 more) traversal kind.  15 = automatic, the default: four
- * lanes per ray up to 57344 rays in flight (kind 2), one lane per ray with a quad-finished tail and the leaf trigger up to 262144
- * (kinds 19 / 21), one lane per ray on the 64-B quantised nodes with the leaf trigger above (kind 22).  librmclhip.so builds
- * the kinds that rule can select plus 0 = wave packet and 4 = one lane per ray on quantised nodes; every other kind is a
- * measured-and-rejected experiment that lives in librmclhip_lab.so (include/rmclhip_lab.h lists them) and is accepted here
+ * lanes per ray up to 57344 rays in flight (kind 2); above that one lane per ray STARTING AT THE MAP'S FRONTIER (the wave culls
+ * the <= 256 references of BFS depth 4 against its tile's pyramid and every ray tests the few survivors: the top levels of
+ * the descent cost one cooperative pass) -- kind 23 on the full-precision nodes up to 524288 rays, kind 24 on the 64-B quantised
+ * nodes above (pose batches).  librmclhip.so builds those three plus 0 = wave packet; every other kind is a measured-and-
+ * rejected or superseded experiment that lives in librmclhip_lab.so (include/rmclhip_lab.h lists them) and is accepted here
  * only while that library is loaded (RMCLHIP_ERR_UNSUPPORTED otherwise),
  * bits 4..7 = 1 + log2(tile width) of the wave's scan-image tile (0 = automatic, 8x8 for tall images),
  * bit 8 = fused last-block reduction tail (A/B), bit 9 = disable the hipGraph MICP loop (A/B), bits 10..12 = form

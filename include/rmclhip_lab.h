@@ -4,12 +4,14 @@
  *
  * Loading librmclhip_lab.so (dlopen / ctypes.CDLL, after librmclhip.so) registers its launchers with the product; from then on
  *   rmclhip_rcc_set_variant accepts the traversal kinds
- *       1  one lane per ray, branch-free step                 5  while-while step, tails of every wave finished by quads
+ *       1  one lane per ray, branch-free step                 4  one lane per ray on the 64-B quantised nodes
+ *       5  while-while step, tails of every wave finished by quads
  *       6 / 7   kind 5 + the top 85 / 341 nodes resident in LDS (north_star "LDS-staged node tiles"; flat loads)
  *       8       kind 5 + one-round-trip leaves                 9 / 10  kind 8 + the LDS top
  *       11 the round-1 branchy step                            12 branch-free step + one-round-trip leaves
  *       13 / 14 wave-uniform nodes through the scalar cache ("wavefront ballot"; 14: + one-round-trip leaves)
  *       16 / 17 branch-free step + quad-finished tails (17: + one-round-trip leaves)      20 kind 16 + the leaf trigger
+ *       19 / 21 / 22  round 2's automatic choices (17 / 5 / 4 with the leaf trigger), superseded by 23 / 24 = 19 / 22 + frontier start
  *     (spherical model only; results are bit-identical to the product's kinds, tests/test_gpu_lab.py), and
  *   rmclhip_pf_set_variant accepts the round kernels (bits 4..6 = 0) and the round-2 persistent kernel (bits 7 / 8).
  * Measurements of every kind: profiles/r02_find_variants_ab.txt, profiles/r03_find_variants_ab.txt, DESIGN.md 4. */

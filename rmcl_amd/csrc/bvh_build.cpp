@@ -343,6 +343,29 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
     out.info.stack_need_pf = main_tree.stack_need;
   }
 
+  // frontier of the map's tree (layout.h: kFrontierDepth): every child reference found at BFS depth kFrontierDepth, and every
+  // leaf reference above it, with the (padded) box its parent stores for it.  A child's stored box lies inside its parent's,
+  // so "the ray hits this entry's box" is the exact condition under which the traversal from the root would reach it.
+  out.frontier.clear();
+  {
+    struct It { uint32_t node; uint32_t depth; };
+    std::vector<It> todo{{0u, 0u}};
+    while (!todo.empty()) {
+      const It it = todo.back();
+      todo.pop_back();
+      const Node4& nd = out.nodes[it.node];
+      for (uint32_t c = 0; c < nd.n_children; ++c) {
+        const uint32_t ref = nd.child[c];
+        if (!(ref & kLeafBit) && it.depth + 1u < kFrontierDepth) { todo.push_back({ref, it.depth + 1u}); continue; }
+        Node4C::Child e;
+        e.lo[0] = nd.x[c]; e.lo[1] = nd.y[c]; e.lo[2] = nd.z[c];
+        e.hix = nd.x[4 + c]; e.hiy = nd.y[4 + c]; e.hiz = nd.z[4 + c];
+        e.ref = ref; e.pad = 0;
+        out.frontier.push_back(e);
+      }
+    }
+  }
+
   out.cnodes.resize(out.nodes.size());
   for (size_t i = 0; i < out.nodes.size(); ++i) {
     const Node4& nd = out.nodes[i];

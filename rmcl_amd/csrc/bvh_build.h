@@ -24,6 +24,7 @@ struct BvhHost {
   std::vector<Node4C> cnodes;  // child-major twins, same indices
   std::vector<Node4> nodes_pf;    // the particle filter's cut of the same BVH2 (leaves <= kPfLeafTris): host-side only
   std::vector<Node4Q> qnodes_pf;  // ... and its quantised form, what k_pf_update_* reads
+  std::vector<Node4C::Child> frontier;  // <= 4^kFrontierDepth entries {box, ref}: where a scan's rays can start (layout.h)
   std::vector<TriRec> tris;  // leaf order (shared by both trees)
   BvhInfo info;
 };

@@ -133,6 +133,8 @@ struct rmclhip_map {
   BvhInfo info;
   uint32_t* d_nodes = nullptr;
   uint32_t* d_qnodes = nullptr;  // Node4Q twins
+  uint32_t* d_frontier = nullptr;   // frontier table (layout.h kFrontierDepth): n_frontier x 8 dwords {lo.xyz hi.x | hi.yz ref pad}
+  uint32_t n_frontier = 0;
   uint32_t* d_qnodes_pf = nullptr;  // Node4Q array of the particle filter's own tree (leaves <= kPfLeafTris, same records)
   uint32_t* d_cnodes = nullptr;  // Node4C twins
   uint32_t* d_tris = nullptr;
@@ -415,6 +417,10 @@ static rmclhip_status map_upload(rmclhip_ctx* ctx, const BvhHost& bvh, rmclhip_m
   const size_t qpb = bvh.qnodes_pf.size() * sizeof(Node4Q);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_qnodes_pf), qpb);
   if (e == hipSuccess) e = hipMemcpy(m->d_qnodes_pf, bvh.qnodes_pf.data(), qpb, hipMemcpyHostToDevice);
+  const size_t fb = bvh.frontier.size() * sizeof(Node4C::Child);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_frontier), std::max<size_t>(fb, 32));
+  if (e == hipSuccess && fb) e = hipMemcpy(m->d_frontier, bvh.frontier.data(), fb, hipMemcpyHostToDevice);
+  m->n_frontier = static_cast<uint32_t>(bvh.frontier.size());
   const size_t cb = bvh.cnodes.size() * sizeof(Node4C);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_cnodes), cb);
   if (e == hipSuccess) e = hipMemcpy(m->d_cnodes, bvh.cnodes.data(), cb, hipMemcpyHostToDevice);
@@ -426,13 +432,14 @@ static rmclhip_status map_upload(rmclhip_ctx* ctx, const BvhHost& bvh, rmclhip_m
     if (m->d_nodes) (void)hipFree(m->d_nodes);
     if (m->d_qnodes) (void)hipFree(m->d_qnodes);
     if (m->d_qnodes_pf) (void)hipFree(m->d_qnodes_pf);
+    if (m->d_frontier) (void)hipFree(m->d_frontier);
     if (m->d_cnodes) (void)hipFree(m->d_cnodes);
     if (m->d_tris) (void)hipFree(m->d_tris);
     delete m;
     return fail(e == hipErrorOutOfMemory ? RMCLHIP_ERR_NOMEM : RMCLHIP_ERR_HIP,
                 std::string("map_create upload: ") + hipGetErrorString(e));
   }
-  m->bytes = nb + qb + qpb + cb + tb;
+  m->bytes = nb + qb + qpb + cb + tb + fb;
   ctx_retain(ctx);
   *out = m;
   return RMCLHIP_OK;
@@ -453,6 +460,7 @@ void rmclhip_map_release(rmclhip_map* map) {
     if (map->d_nodes) (void)hipFree(map->d_nodes);
     if (map->d_qnodes) (void)hipFree(map->d_qnodes);
     if (map->d_qnodes_pf) (void)hipFree(map->d_qnodes_pf);
+    if (map->d_frontier) (void)hipFree(map->d_frontier);
     if (map->d_cnodes) (void)hipFree(map->d_cnodes);
     if (map->d_tris) (void)hipFree(map->d_tris);
     ctx_release(map->ctx);
@@ -794,12 +802,11 @@ static int find_variant(const rmclhip_rcc* r, uint32_t nposes) {
   const uint64_t rays = static_cast<uint64_t>(r->W) * r->H * nposes;
   if (rays <= 57344u) return 2;   // bound by the slowest ray's fetch chain: four lanes per ray (crossover measured between
                                   // 49152 rays -- quads 13.6 / 20.8 us vs 16.4 / 23.4 -- and 65536 -- 15.9 / 26.3 vs 16.3 / 23.7)
-  // one lane per ray with the LEAF TRIGGER (kernels.hip trace_lane_bf_tail): the node phase of a wave ends as soon as the
-  // lanes that wait with a leaf outnumber 1.5 x the lanes still descending (kinds 19 / 21 / 22 = 17 / 5 / 4 with the trigger:
-  // sphere C2 21.2 -> 19.4 us, room-100k 36.7 -> 27.8 us, 64-pose batches 0.59 -> 0.56 ms)
-  if (rays <= 131072u) return 19;  // one scan fills the chip once: branch-free step, one-round-trip leaves, quad-finished tails
-  if (rays <= 262144u) return 21;  // larger: occupancy matters more than the leaf round trips (the branch-free kinds need 24 LDS rows)
-  return 22;                       // batches are bound by L1 accesses / VALU issue: the 64-B quantised nodes, 16 LDS rows
+  // one lane per ray, starting at the map's FRONTIER instead of the root (traverse.hip.h frontier_start): from 65 536 to 524 288
+  // rays kind 23 is the fastest or within 3 % of it on both benchmark maps (profiles/r03_find_variants_ab.txt), which replaces
+  // round 2's three brackets (19 / 21 / 22) by one; pose batches are bound by cache-line accesses: the 64-B quantised nodes
+  if (rays <= 524288u) return 23;  // full-precision nodes, branch-free step, one-round-trip leaves, quad-finished tails, leaf trigger
+  return 24;                       // quantised nodes, 16 LDS rows, leaf trigger
 }
 
 static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
@@ -809,6 +816,14 @@ static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
   p.cnodes = r->map->d_cnodes;
   p.tris = r->map->d_tris;
   p.n_nodes = r->map->info.n_nodes;
+  p.frontier = r->map->d_frontier;
+  p.n_frontier = r->map->n_frontier;
+  {
+    const BvhInfo& bi = r->map->info;
+    p.scene_center = mk3(0.5f * (bi.bbox_min[0] + bi.bbox_max[0]), 0.5f * (bi.bbox_min[1] + bi.bbox_max[1]), 0.5f * (bi.bbox_min[2] + bi.bbox_max[2]));
+    const float dx = bi.bbox_max[0] - bi.bbox_min[0], dy = bi.bbox_max[1] - bi.bbox_min[1], dz = bi.bbox_max[2] - bi.bbox_min[2];
+    p.scene_half_diag = 0.5f * std::sqrt(dx * dx + dy * dy + dz * dz) + bi.pad;
+  }
   p.model_tab = r->d_model_tab.p;
   p.W = r->W; p.H = r->H;
   p.tile_w_log2 = (r->tile_override > 0) ? static_cast<uint32_t>(r->tile_override - 1) : pick_tile_w_log2(r->H);
@@ -1597,11 +1612,11 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
   if (!r || variant < 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: bad arguments");
   // bit 13 adds 16 to the traversal kind (kinds 16..31)
   const int kind = (variant & 0xF) | (((variant >> 13) & 1) << 4), tile = (variant >> 4) & 0xF;
-  if (kind == 3 || kind == 18 || kind > 22 || tile > 7 || (variant >> 14) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
+  if (kind == 3 || kind == 18 || kind > 24 || tile > 7 || (variant >> 14) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
   // (kind 1 also selects the one-lane-per-point form of the closest-point query, which the product owns)
   if (kind != 15 && kind != 1 && !find_kind_in_product(kind) && lab_hooks() == nullptr)
     return fail(RMCLHIP_ERR_UNSUPPORTED, "rcc_set_variant: this traversal kind is an experiment -- it lives in librmclhip_lab.so, "
-                                         "which is not loaded (the product builds kinds 0, 2, 4, 19, 21, 22 and the automatic rule 15)");
+                                         "which is not loaded (the product builds kinds 0, 2, 23, 24 and the automatic rule 15)");
   r->variant = kind;
   r->tile_override = tile;
   r->fused_tail = ((variant >> 8) & 1) != 0;

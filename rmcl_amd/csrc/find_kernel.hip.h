@@ -1,6 +1,6 @@
 // find_kernel.hip.h -- k_find<model, traversal kind, clocks>: ray-casting correspondences, rm::*Simulator*::simulate as called by
 // RCC*::find (rmcl/src/rmcl/registration/RCCEmbree.cpp:26-36,89-99).  One template, two homes: kernels.hip instantiates the kinds
-// the product can select (0 packet, 2 quad, 4 / 22 quantised, 19 / 21 leaf trigger) WITHOUT clocks; kernels_lab.hip instantiates
+// the product can select (0 packet, 2 quad, 23 / 24 one lane per ray with the frontier start) WITHOUT clocks; kernels_lab.hip instantiates
 // the measured-and-rejected kinds and the clocked variants for tools/wave_timeline.py.
 #pragma once
 #include "traverse.hip.h"
@@ -23,7 +23,9 @@ constexpr int kFindBfRows = 24;  // LDS stack rows per lane (sentinel included) 
 constexpr uint32_t kFindTailLdsDwords = 16u * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords;
 
 // kinds 19..22: kind 17 + leaving the node phase when 32 / 24 / 16 / 8 lanes hold a leaf
-constexpr int find_leaf_trigger(int trav) { return (trav == 19 || trav == 20) ? 10 : 0; }   // leave at <= 4/10 of the round's rays
+constexpr int find_leaf_trigger(int trav) { return (trav == 19 || trav == 20 || trav == 23) ? 10 : 0; }   // leave at <= 4/10 of the round's rays
+// kinds 23 / 24: kinds 19 / 22 whose rays start at the map's frontier (traverse.hip.h frontier_start) instead of the root
+constexpr bool find_frontier(int trav) { return trav == 23 || trav == 24; }
 
 // kClock: entry / traversal / store clocks of every wave go to p.wave_clock (tools/wave_timeline.py); the production
 // instantiations are built with kClock = false and contain no s_memtime
@@ -120,8 +122,20 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   } else {
     // kind 4 serves launches that fill the chip (pose batches): throughput, not the slowest wave's chain, is what counts there, and
     // the branchy step with its partial sort and 16 LDS rows (more resident waves) is 11 % faster than the branch-free one
+    TraceStart start;
+    const TraceStart* sp0 = nullptr;
+    if constexpr (find_frontier(kTrav) && kModel != kModelOnDn) {   // (OnDn: one origin per ray, no common pyramid)
+      if (kTrav == 23)
+        start = frontier_start<kFindBfRows, 1>(p.frontier, p.n_frontier, p.scene_center, p.scene_half_diag, org_m, dir_m, ray_tfar, lane,
+                                               p.tile_w_log2, lds_dyn + threadIdx.x, kBfStride);
+      else
+        start = frontier_start<16, 0>(p.frontier, p.n_frontier, p.scene_center, p.scene_half_diag, org_m, dir_m, ray_tfar, lane,
+                                      p.tile_w_log2, lds_dyn + threadIdx.x, blockDim.x);
+      sp0 = &start;
+    }
     if (kTrav == 4) trace_lane_ww<16, true>(p.qnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
-    else if (kTrav == 22) trace_lane_ww<16, true, false, true>(p.qnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
+    else if (kTrav == 22 || kTrav == 24)
+      trace_lane_ww<16, true, false, true>(p.qnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h, sp0);
     else if (kTrav == 21)
       trace_lane_ww_tail<16, 0, false, true>(
           p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, lds_dyn + 16u * 256u,
@@ -129,10 +143,11 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
           lds_dyn + kFindTailLdsDwords);
     else if (kTrav == 1) trace_lane_bf<kFindBfRows>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
     else if (kTrav == 12) trace_lane_bf<kFindBfRows, false, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
-    else if (kTrav == 16 || kTrav == 17 || kTrav == 19 || kTrav == 20)
+    else if (kTrav == 16 || kTrav == 17 || kTrav == 19 || kTrav == 20 || kTrav == 23)
       trace_lane_bf_tail<kFindBfRows, kTrav != 16 && kTrav != 20, find_leaf_trigger(kTrav)>(p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x,
                                                    lds_dyn + kFindBfRows * 256u,
-                                                   lds_dyn + kFindBfRows * 256u + kQuadStackEntries * 64u + (threadIdx.x >> 6) * (kTailRays * kTailXferDwords), h);
+                                                   lds_dyn + kFindBfRows * 256u + kQuadStackEntries * 64u + (threadIdx.x >> 6) * (kTailRays * kTailXferDwords), h,
+                                                   nullptr, sp0);
     else if (kTrav == 13) trace_lane_bf<kFindBfRows, false, false, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
     else if (kTrav == 14) trace_lane_bf<kFindBfRows, false, true, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
     else if (kTrav >= 5 && kTrav <= 10)

@@ -40,6 +40,11 @@ struct FindParams {
   float* points;
   float* normals;
   uint32_t* face_ids;
+  // frontier start (kinds 23 / 24): the map's frontier table and what bounds a hit's distance from any origin
+  const uint32_t* frontier;      // n_frontier x 8 dwords {lo.xyz hi.x | hi.yz ref pad} (layout.h kFrontierDepth)
+  uint32_t n_frontier;
+  f3 scene_center;
+  float scene_half_diag;
   // diagnostics (nullable): per physical wave {s_memtime at entry, at exit (low 32 bits), s_memrealtime at entry, tile | xcc << 24}
   uint32_t* wave_clock;
 };

@@ -1,6 +1,6 @@
 // kernels.hip -- PRODUCTION kernels of librmclhip.so (gfx950, MI355X, CDNA4) for the RMCL / MICP-L hot path.
 //
-//  k_find            (find_kernel.hip.h) ray-casting correspondences, the kinds the product can select
+//  k_find            (find_kernel.hip.h) ray-casting correspondences, the kinds the product can select (0, 2, 23, 24)
 //  k_cpc_find        (traverse.hip.h) closest-point correspondences, CPCEmbree::find
 //  k_reduce_partials rm::statistics_p2l (CorrespondencesCPU.cpp:26-30; gate MICPSensorCPU.cpp:70-84)
 //  k_micp_*          the inner iterations of MICPLocalizationNode::correctOnce
@@ -1710,18 +1710,12 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
   } else if (variant == 2) {  // quad-cooperative: 64 rays per block, 64 stack entries per ray in LDS
     const size_t lds = kQuadStackEntries * 64u * sizeof(uint32_t);
     RMCL_LAUNCH_FIND(2, lds)
-  } else if (variant == 4) {  // one lane per ray on the 64-B quantised nodes
-    const size_t lds = 16u * 256u * sizeof(uint32_t);
-    RMCL_LAUNCH_FIND(4, lds)
-  } else if (variant == 19) {  // branch-free step, one-round-trip leaves, quad-finished tails, leaf trigger
+  } else if (variant == 23) {  // one lane per ray: frontier start, branch-free step, one-round-trip leaves, quad-finished tails, leaf trigger
     const size_t lds = (static_cast<size_t>(kFindBfRows) * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords) * sizeof(uint32_t);
-    RMCL_LAUNCH_FIND(19, lds)
-  } else if (variant == 21) {  // while-while step with quad-finished tails and the leaf trigger
-    const size_t lds5 = kFindTailLdsDwords * sizeof(uint32_t);
-    RMCL_LAUNCH_FIND(21, lds5)
-  } else {                     // 22: kind 4 with the leaf trigger
+    RMCL_LAUNCH_FIND(23, lds)
+  } else {                     // 24: one lane per ray on the 64-B quantised nodes: frontier start, leaf trigger, 16 LDS rows
     const size_t lds4 = 16u * 256u * sizeof(uint32_t);
-    RMCL_LAUNCH_FIND(22, lds4)
+    RMCL_LAUNCH_FIND(24, lds4)
   }
 #undef RMCL_LAUNCH_FIND
   return hipGetLastError();

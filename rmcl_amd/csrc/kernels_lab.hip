@@ -413,6 +413,8 @@ hipError_t lab_find_kind(const FindParams& p, int variant, hipStream_t s) {
     case 20: return lab_find_one<20, kClock>(p, grid, lds_bf_tail, s);                         // 16 + leaf trigger
     case 21: return lab_find_one<21, kClock>(p, grid, kFindTailLdsDwords * sizeof(uint32_t), s);
     case 22: return lab_find_one<22, kClock>(p, grid, lds_ww, s);
+    case 23: return lab_find_one<23, kClock>(p, grid, lds_bf_tail, s);                         // 19 + frontier start
+    case 24: return lab_find_one<24, kClock>(p, grid, lds_ww, s);                              // 22 + frontier start
     default: return hipErrorNotSupported;
   }
 }

@@ -38,6 +38,7 @@ constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kNodeDwords = 32;
 constexpr uint32_t kTriDwords = 16;
 constexpr uint32_t kMaxLeafTris = 4;
+constexpr uint32_t kFrontierDepth = 4;   // BFS depth of the map's frontier table (bvh_build.h): <= 256 entries
 constexpr uint32_t kPfLeafTris = 2;   // leaf size of the particle filter's own tree (bvh_build.h)
 constexpr uint32_t kInvalidFace = 0xFFFFFFFFu;
 constexpr float kFarPoint[3] = {1.0e30f, 2.0e30f, 3.0e30f};

@@ -401,17 +401,23 @@ __device__ __forceinline__ void trace_lane(const uint32_t* __restrict__ nodes, c
 // LDS entries (16 KB per block) catch almost every push.
 // ---------------------------------------------------------------------------------------------
 // kQuant: `nodes` points to the quantised Node4Q twins (four loads per node visit instead of seven)
+// Where a ray starts when the top levels of its descent have been replaced by the frontier start (frontier_start below): the
+// node it enters first and the number of further entries already on its LDS stack.
+struct TraceStart {
+  uint32_t cur, sp;
+};
+
 template <int kLdsEntries, bool kQuant = false, bool kLeafBatch = false, bool kVote = false>  // stack entries kept in LDS ([entry][lane]); the rest (up to 64 total) in scratch
 __device__ __forceinline__ void trace_lane_ww(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris,
                                               f3 O, f3 D, float ray_tfar, uint32_t* __restrict__ lds_stack,
-                                              uint32_t lds_stride, RayHit& h) {
+                                              uint32_t lds_stride, RayHit& h, const TraceStart* start = nullptr) {
   const RaySlab rs = make_ray_slab(O, D);
   float best_t = ray_tfar;
   uint32_t best_rec = kNone;
   constexpr uint32_t kDone = 0x7FFFFFFFu;
   uint32_t priv[(kLdsEntries < 64) ? (64 - kLdsEntries) : 1];
-  uint32_t sp = 0;
-  uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
+  uint32_t sp = start ? start->sp : 0u;
+  uint32_t cur = start ? start->cur : ((ray_tfar >= 0.0f) ? 0u : kDone);
 #define RMCL_PUSH(v) { if (kLdsEntries >= 64 || sp < kLdsEntries) lds_stack[sp * lds_stride] = (v); else priv[sp - kLdsEntries] = (v); ++sp; }
 #define RMCL_POP() { if (sp == 0) cur = kDone; else { --sp; if (kLdsEntries >= 64 || sp < kLdsEntries) cur = lds_stack[sp * lds_stride]; else cur = priv[sp - kLdsEntries]; } }
   for (;;) {
@@ -831,7 +837,8 @@ template <int kRows, bool kLeafBatch, int kLeafTrigger = 0>
 __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ cnodes,
                                                    const uint32_t* __restrict__ tris, f3 O, f3 D, float ray_tfar,
                                                    uint32_t* __restrict__ lds_col, uint32_t* __restrict__ qstack,
-                                                   uint32_t* __restrict__ xfer_wave, RayHit& h, uint32_t* visits = nullptr) {
+                                                   uint32_t* __restrict__ xfer_wave, RayHit& h, uint32_t* visits = nullptr,
+                                                   const TraceStart* start = nullptr) {
   const RaySlab rs = make_ray_slab(O, D);
   float best_t = ray_tfar;
   uint32_t best_rec = kNone;
@@ -839,8 +846,8 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
   constexpr uint32_t kDone = 0x7FFFFFFFu;
   uint32_t priv[(kRows < 65) ? (65 - kRows) : 1];
   lds_col[0] = kDone;
-  uint32_t sp = 1;
-  uint32_t cur = (ray_tfar >= 0.0f) ? 0u : kDone;
+  uint32_t sp = start ? start->sp : 1u;   // a preset start: rows 1 .. sp-1 already hold this ray's pending entries
+  uint32_t cur = start ? start->cur : ((ray_tfar >= 0.0f) ? 0u : kDone);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 #define RMCL_ROW_ST(r, v) { if ((r) < static_cast<uint32_t>(kRows)) lds_col[(r) * kBfStride] = (v); else priv[(r) - kRows] = (v); }
 #define RMCL_ROW_LD(r) (((r) < static_cast<uint32_t>(kRows)) ? lds_col[(r) * kBfStride] : priv[(r) - kRows])
@@ -938,6 +945,147 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
   h.t = best_t;
   h.rec = best_rec;
   if (visits) *visits = nvis;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FRONTIER START (round 3).  The 64 rays of a wave leave ONE origin through one tile of the scan image, and every one of them
+// begins its traversal with the same few levels of the tree: ~45 % of all node visits of a C2 scan are spent above BFS depth 4
+// (tools/wavesim.py: 10.5 -> 4.6 visits per ray, 13.5 -> 7.3 node iterations per wave without them).  Here the wave replaces
+// those levels by ONE cooperative pass over the map's frontier table (<= 256 entries {box, reference} = every reference at BFS
+// depth 4 and every leaf above it, bvh_build.cpp):
+//   1. the tile's bounding pyramid: four planes through the origin spanned by the rays of the tile's corner lanes, each pushed
+//      outward until EVERY active ray of the wave lies inside (wave-min of n.d over the lanes -- exact for any ray set, spherical
+//      rows are small circles, O1Dn directions are data), times the farthest distance a hit can have;
+//   2. each lane tests <= 4 frontier boxes against the pyramid (positive-vertex test: conservative);
+//   3. the surviving entries are broadcast one by one (v_readlane) and every lane tests the box with ITS ray (the traversal's own
+//      slab test): hits go onto the lane's stack, the nearest becomes its first node.
+// A child's stored box lies inside its parent's, so "my ray hits this entry's box" is exactly the condition under which the
+// descent from the root would have reached that reference: the set of subtrees visited is the same, only their order can
+// differ -- and the closest hit (min t, then min face id) does not depend on the order.  Results are bit-identical
+// (tests/test_gpu_find.py digests).  If a lane would collect more entries than its LDS rows hold, the wave starts at the root.
+// kRow0: index of the first stack row (1 for the branch-free traversals whose row 0 is the sentinel, 0 for trace_lane_ww).
+// ---------------------------------------------------------------------------------------------
+// minimum over the 64 lanes, the same value in every lane: four DPP steps give every lane the minimum of its row of 16
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror -- one cycle each, no LDS crossbar), four v_readlane + three v_min
+// combine the rows
+template <int kCtrl>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), kCtrl, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_min_f32(float v) {
+  v = fminf(v, dpp_f32<0xB1>(v));
+  v = fminf(v, dpp_f32<0x4E>(v));
+  v = fminf(v, dpp_f32<0x141>(v));   // row_half_mirror
+  v = fminf(v, dpp_f32<0x140>(v));   // row_mirror
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return fminf(fminf(r0, r1), fminf(r2, r3));
+}
+__device__ __forceinline__ float lane_bcast(float v, uint32_t src_lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), static_cast<int>(src_lane)));
+}
+__device__ __forceinline__ uint32_t lane_bcast(uint32_t v, uint32_t src_lane) {
+  return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), static_cast<int>(src_lane)));
+}
+
+template <int kRows, int kRow0>
+__device__ __forceinline__ TraceStart frontier_start(const uint32_t* __restrict__ frontier, uint32_t n_frontier, f3 scene_center,
+                                                     float scene_half_diag, f3 O, f3 D, float ray_tfar, uint32_t lane,
+                                                     uint32_t tile_w_log2, uint32_t* __restrict__ lds_col, uint32_t lds_stride) {
+  constexpr uint32_t kDone = 0x7FFFFFFFu;
+  const bool active = ray_tfar >= 0.0f;
+  TraceStart root;
+  root.cur = active ? 0u : kDone;
+  root.sp = static_cast<uint32_t>(kRow0);
+  if (n_frontier == 0u) return root;
+  // my <= 4 entries of the table (coalesced: lane j takes entries j, j + 64, ...)
+  const uint4* F = reinterpret_cast<const uint4*>(frontier);
+  uint4 ea[4], eb[4];
+#pragma unroll
+  for (uint32_t k = 0; k < 4u; ++k) {
+    const uint32_t idx = min(lane + 64u * k, n_frontier - 1u);
+    ea[k] = F[2u * idx];
+    eb[k] = F[2u * idx + 1u];
+  }
+  // 1. the pyramid: corner lanes of the tile (row-major tile of width tw), centre = sum of the corners
+  const uint32_t tw = 1u << tile_w_log2;
+  const uint32_t c0 = 0u, c1 = tw - 1u, c2 = 64u - tw, c3 = 63u;
+  const f3 d0 = mk3(lane_bcast(D.x, c0), lane_bcast(D.y, c0), lane_bcast(D.z, c0));
+  const f3 d1 = mk3(lane_bcast(D.x, c1), lane_bcast(D.y, c1), lane_bcast(D.z, c1));
+  const f3 d2 = mk3(lane_bcast(D.x, c2), lane_bcast(D.y, c2), lane_bcast(D.z, c2));
+  const f3 d3 = mk3(lane_bcast(D.x, c3), lane_bcast(D.y, c3), lane_bcast(D.z, c3));
+  const f3 dc = add3(add3(d0, d1), add3(d2, d3));
+  f3 n[4] = {cross_fma(d0, d1), cross_fma(d1, d3), cross_fma(d3, d2), cross_fma(d2, d0)};
+  float off[4];
+  // the farthest a hit can be from this origin: inside the map's bounding sphere, and within the sensor's range
+  const f3 oc = sub3(O, scene_center);
+  const float reach = fminf(ray_tfar, sqrtf((oc.x * oc.x + oc.y * oc.y) + oc.z * oc.z) + scene_half_diag);
+  const float reach_u = wave_min_f32(active ? -reach : 0.0f);   // = -(largest reach of the wave's active rays)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float len2 = (n[k].x * n[k].x + n[k].y * n[k].y) + n[k].z * n[k].z;
+    const bool usable = len2 > 1e-12f;    // degenerate (1-D tiles, coincident corner rays) or NaN: the plane is dropped
+    float sc = usable ? __builtin_amdgcn_rsqf(len2) : 0.0f;
+    if (dot_plain(n[k], dc) < 0.0f) sc = -sc;   // inward
+    n[k] = scale3(n[k], sc);
+    // how far outside the plane the wave's worst active ray points (<= 0), per unit length along the ray
+    const float s_lane = active ? dot_plain(n[k], D) : 0.0f;
+    const float m = fminf(wave_min_f32(s_lane), 0.0f);
+    // offset in metres at the farthest possible hit + slack for the rounding of this test itself
+    off[k] = m * (-reach_u) - 1e-4f * (-reach_u) - 1e-6f;
+  }
+  // 2. my entries against the pyramid (positive vertex of the box per plane)
+  bool acc[4];
+#pragma unroll
+  for (uint32_t k = 0; k < 4u; ++k) {
+    const f3 lo = mk3(asf(ea[k].x) - O.x, asf(ea[k].y) - O.y, asf(ea[k].z) - O.z);
+    const f3 hi = mk3(asf(ea[k].w) - O.x, asf(eb[k].x) - O.y, asf(eb[k].y) - O.z);
+    bool ok = (lane + 64u * k) < n_frontier;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float v = ((n[q].x > 0.0f ? hi.x : lo.x) * n[q].x + (n[q].y > 0.0f ? hi.y : lo.y) * n[q].y) + (n[q].z > 0.0f ? hi.z : lo.z) * n[q].z;
+      ok = ok && !(v < off[q]);   // NaN -> keep
+    }
+    acc[k] = ok;
+  }
+  // 3. every surviving entry against every ray of the wave
+  const RaySlab rs = make_ray_slab(O, D);
+  uint32_t first_ref = kDone, first_key = 0xFFFFFFFFu, sp = static_cast<uint32_t>(kRow0);
+#pragma unroll
+  for (uint32_t k = 0; k < 4u; ++k) {
+    if (64u * k >= n_frontier) break;   // wave-uniform
+    uint64_t mask = __ballot(acc[k]);
+    while (mask != 0ull) {
+      const uint32_t j = static_cast<uint32_t>(__builtin_ctzll(mask));
+      mask &= mask - 1ull;
+      const float lx = lane_bcast(asf(ea[k].x), j), ly = lane_bcast(asf(ea[k].y), j), lz = lane_bcast(asf(ea[k].z), j);
+      const float hx = lane_bcast(asf(ea[k].w), j), hy = lane_bcast(asf(eb[k].x), j), hz = lane_bcast(asf(eb[k].y), j);
+      const uint32_t ref = lane_bcast(eb[k].z, j);
+      const float tx0 = fmaf(lx, rs.inv.x, rs.noi.x), tx1 = fmaf(hx, rs.inv.x, rs.noi.x);
+      const float ty0 = fmaf(ly, rs.inv.y, rs.noi.y), ty1 = fmaf(hy, rs.inv.y, rs.noi.y);
+      const float tz0 = fmaf(lz, rs.inv.z, rs.noi.z), tz1 = fmaf(hz, rs.inv.z, rs.noi.z);
+      const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
+      const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), ray_tfar));
+      if (active && tn <= tf) {
+        const uint32_t key = __float_as_uint(tn);
+        const bool nearer = key < first_key;
+        const uint32_t pushed = nearer ? first_ref : ref;
+        if (nearer) { first_ref = ref; first_key = key; }
+        if (pushed != kDone) {
+          if (sp < static_cast<uint32_t>(kRows)) lds_col[sp * lds_stride] = pushed;
+          ++sp;
+        }
+      }
+    }
+  }
+  // a lane that would need more rows than it has in LDS: the whole wave starts at the root instead
+  if (__any(sp > static_cast<uint32_t>(kRows - 4))) return root;
+  TraceStart st;
+  st.cur = first_ref;   // kDone: the ray misses every entry, i.e. the whole map
+  st.sp = sp;
+  return st;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -33,7 +33,7 @@ def _poses(syn, T):
     ]
 
 
-@pytest.mark.parametrize("variant", find_kinds(0, 1, 2, 4, 5, 6, 8, 10, 11, 12, 13, 14, 16, 17, 19, 20, 21, 22))
+@pytest.mark.parametrize("variant", find_kinds(0, 1, 2, 4, 5, 6, 8, 10, 11, 12, 13, 14, 16, 17, 19, 20, 21, 22, 23, 24))
 def test_c1_cube_32x32(ra, orc, ctx, meshes, variant):
     """config C1: 32x32 scan, 972-triangle cube, every output attribute, 3 poses, Tsb != I."""
     from rmcl_amd import synthetic as syn, types as T
@@ -73,7 +73,7 @@ def test_c1_matches_committed_golden(ra, ctx, meshes):
         _compare(gpu, ref, "golden pose %d" % i)
 
 
-@pytest.mark.parametrize("variant", find_kinds(0, 1, 2, 4, 5, 7, 8, 9, 11, 12, 13, 14, 16, 17, 19, 20, 21, 22))
+@pytest.mark.parametrize("variant", find_kinds(0, 1, 2, 4, 5, 7, 8, 9, 11, 12, 13, 14, 16, 17, 19, 20, 21, 22, 23, 24))
 def test_c2_sphere100k_full_size(ra, orc, ctx, meshes, variant):
     """config C2 at BASELINE.json's full size: 128x1024 rays, 100k triangles; oracle BVH on all rays,
     brute force on a sample, and the committed SHA-256 of the face-id array (G7)."""
@@ -106,7 +106,8 @@ def test_c2_sphere100k_full_size(ra, orc, ctx, meshes, variant):
     assert np.all(r <= 10.0 + 1e-4) and np.all(r >= 10.0 - 0.02)
 
 
-def test_ragged_and_tiny_models(ra, orc, ctx, meshes):
+@pytest.mark.parametrize("kinds", [(15, 23, 2, 24), pytest.param((19, 22), marks=pytest.mark.lab)], ids=["product", "round-2 kinds"])
+def test_ragged_and_tiny_models(ra, orc, ctx, meshes, kinds):
     """edge cases: 1x1, 1x360 (2-D scanner), 7x33 (ragged tiles), empty model (find is a no-op,
     RCCOptix.cpp:30-34)."""
     from rmcl_amd import types as T
@@ -119,14 +120,16 @@ def test_ragged_and_tiny_models(ra, orc, ctx, meshes):
     for (H, W) in [(1, 1), (1, 360), (7, 33), (65, 9)]:
         model = T.spherical_model(f32(-0.3), f32(0.6 / max(H - 1, 1)), H, f32(-math.pi), f32(2 * math.pi / W), W,
                                   f32(0.1), f32(30.0))
-        rcc = ra.RCCHipSpherical(hm)
-        rcc.setTsb(Tsb)
-        rcc.setModel(model)
-        rcc.find(Tbm)
-        gpu = rcc.modelView()
         ref = m.simulate_spherical(model, Tsb, Tbm, bvh=False)
-        _compare(gpu, ref, "ragged %dx%d" % (H, W))
-        rcc.close()
+        for kind in kinds:
+            rcc = ra.RCCHipSpherical(hm)
+            rcc.set_traversal(kind)
+            rcc.setTsb(Tsb)
+            rcc.setModel(model)
+            rcc.find(Tbm)
+            gpu = rcc.modelView()
+            _compare(gpu, ref, "ragged %dx%d kind %d" % (H, W, kind))
+            rcc.close()
     rcc = ra.RCCHipSpherical(hm)
     rcc.setTsb(Tsb)
     rcc.setModel(T.spherical_model(f32(0), f32(0), 0, f32(0), f32(0), 0, f32(0.1), f32(30.0)))
@@ -158,7 +161,7 @@ def test_misses_and_range_limit(ra, orc, ctx, meshes):
     assert np.isnan(gpu["points"][miss]).all() and np.isnan(gpu["normals"][miss]).all()
 
 
-@pytest.mark.parametrize("variant", find_kinds(0, 2, 4, 19, 21, 22))
+@pytest.mark.parametrize("variant", find_kinds(0, 2, 23, 24))
 def test_o1dn_model(ra, orc, ctx, meshes, variant):
     """RCCEmbreeO1Dn::find (RCCEmbree.cpp:89-99): one origin, N explicit directions, with NaN
     directions (invalid points of an organised cloud) which must come back as misses."""
@@ -234,7 +237,7 @@ def test_c5_mesh_one_million_triangles(ra, orc, ctx):
     model = syn.model_c2()
     Tbm = syn.pose_c2_truth()
     ref = m.simulate_spherical(model, T.identity(), Tbm, bvh=True, nthreads=8)
-    for variant in (0, 2, 4, 19, 21, 22):
+    for variant in (0, 2, 23, 24):
         rcc = ra.RCCHipSpherical(hm)
         rcc.set_traversal(variant)
         rcc.setTsb(T.identity())
@@ -259,7 +262,7 @@ def test_c5_mesh_one_million_triangles(ra, orc, ctx):
 ROOM_POSE_RPY = ((1.5, -2.0, 1.6), (0.02, -0.03, 0.4))   # the pose of tests/golden/make_golden.py:g7_digests
 
 
-@pytest.mark.parametrize("variant", find_kinds(0, 2, 4, 15, 19, 21, 22, 17))
+@pytest.mark.parametrize("variant", find_kinds(0, 2, 15, 23, 24, 19, 22))
 def test_c2_room100k_full_size(ra, orc, ctx, meshes, variant):
     """config C2's scan on a REALISTIC map (room-100k: occluders, vertex noise, open ceiling => misses): every
     traversal incl. the automatic one (15) vs the oracle on all 131 072 rays + the committed G7 digests
@@ -296,7 +299,7 @@ def _o1dn_c2(syn, n_nan=37, seed=11):
     return model, dirs
 
 
-@pytest.mark.parametrize("mesh,variant", [("sphere100k", 15), ("room100k", 15), ("room100k", 19), ("room100k", 2)])
+@pytest.mark.parametrize("mesh,variant", [("sphere100k", 15), ("room100k", 15), ("room100k", 24), ("room100k", 2)])
 def test_o1dn_c2_size_single_pose(ra, orc, ctx, meshes, mesh, variant):
     """RCCEmbreeO1Dn::find (RCCEmbree.cpp:89-99) at C2's full size: 131 072 explicit directions, sensor origin and
     Tsb != identity, NaN directions come back as misses."""
@@ -349,17 +352,16 @@ def test_o1dn_c2_size_pose_batch(ra, orc, ctx, meshes):
 
 @pytest.mark.parametrize("mesh", ["sphere100k", "room100k"])
 def test_automatic_variant_in_every_size_bracket(ra, orc, ctx, meshes, mesh):
-    """variant 15 (the default) picks a different traversal per rays-in-flight bracket (capi.cpp:find_variant):
-    <= 57 344 four lanes per ray (kind 2), <= 131 072 / 262 144 one lane per ray with the tail of every wave finished by
-    quads and the leaf trigger (kinds 19 / 21), larger: one lane per ray on the quantised nodes with the leaf trigger
-    (kind 22).  Each bracket is run explicitly with variant 15."""
+    """variant 15 (the default) picks a traversal per rays-in-flight bracket (capi.cpp:find_variant): <= 57 344 four lanes
+    per ray (kind 2); above, one lane per ray starting at the map's frontier -- kind 23 (full-precision nodes) up to 524 288
+    rays, kind 24 (quantised nodes) beyond.  Each bracket is run explicitly with variant 15."""
     from rmcl_amd import synthetic as syn, types as T
     v, f = meshes(mesh)
     m = orc.Mesh(v, f)
     hm = ra.import_hip_map(ctx, v, f)
     base = syn.pose_c2_truth() if mesh == "sphere100k" else T.transform_from_rpy(*ROOM_POSE_RPY)
     f32 = np.float32
-    brackets = [(16, 900, 1), (64, 1024, 1), (96, 1024, 1), (128, 1024, 1), (128, 2048, 1), (128, 1024, 3), (16, 900, 40)]
+    brackets = [(16, 900, 1), (64, 1024, 1), (96, 1024, 1), (128, 1024, 1), (128, 2048, 1), (128, 1024, 3), (128, 1024, 5), (16, 900, 40)]
     for (H, W, nposes) in brackets:
         model = T.spherical_model(f32(-0.39), f32(0.78 / (H - 1)), H, f32(-math.pi), f32(2 * math.pi / W), W, f32(0.3), f32(120.0))
         rng = np.random.RandomState(H + W + nposes)
@@ -370,7 +372,7 @@ def test_automatic_variant_in_every_size_bracket(ra, orc, ctx, meshes, mesh):
         rcc.setTsb(T.identity())
         rcc.setModel(model)
         rays = H * W * nposes
-        assert rcc.find_variant(nposes) == (2 if rays <= 57344 else 19 if rays <= 131072 else 21 if rays <= 262144 else 22)
+        assert rcc.find_variant(nposes) == (2 if rays <= 57344 else 23 if rays <= 524288 else 24)
         if nposes == 1:
             rcc.find(poses[0])
         else:
@@ -381,7 +383,7 @@ def test_automatic_variant_in_every_size_bracket(ra, orc, ctx, meshes, mesh):
         rcc.close()
 
 
-@pytest.mark.parametrize("variant", find_kinds(0, 2, 4, 19, 21, 22, 6, 13))
+@pytest.mark.parametrize("variant", find_kinds(0, 2, 23, 24, 6, 13, 19))
 def test_sensor_origin_on_a_face(ra, orc, ctx, meshes, variant):
     """Embree's depth test is strict on the near side (absDen * tnear < T with tnear = 0): a ray that starts exactly ON a
     wall triangle does not hit that triangle -- the sensor sees the room, not t = 0 everywhere."""

@@ -23,10 +23,10 @@ hm = ra.import_hip_map(ctx, v, f)
 rcc = ra.RCCHipSpherical(hm)
 rcc.setTsb(T.identity())
 rcc.setModel(syn.model_c1())
-for kind in (0, 2, 4, 15, 19, 21, 22):            # the product's own kinds
+for kind in (0, 2, 15, 23, 24):                  # the product's own kinds
     rcc.set_traversal(kind)
     rcc.find(syn.pose_c2_truth())
-for kind in (5, 6, 13, 17, 20):                  # experiments: refused at set_variant
+for kind in (4, 5, 6, 13, 17, 19, 20, 22):        # experiments: refused at set_variant
     try:
         rcc.set_traversal(kind)
         raise SystemExit("kind %%d accepted without the experiments library" %% kind)
@@ -67,10 +67,10 @@ def test_experiments_load_and_match_the_product(ra, ctx, meshes):
     rcc.setTsb(syn.tsb_offset())
     rcc.setModel(syn.model_c1())
     pose = T.transform_from_rpy((1.0, -1.5, 1.2), (0.0, 0.0, 0.5))
-    rcc.set_traversal(19)
+    rcc.set_traversal(23)
     rcc.find(pose)
     ref = rcc.modelView()
-    for kind in (1, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 20):
+    for kind in (1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 19, 20, 21, 22):
         rcc.set_traversal(kind)
         rcc.find(pose)
         mv = rcc.modelView()

@@ -206,7 +206,7 @@ def test_find_batch_o1dn_pose_major(ra, orc, ctx, meshes):
     rcc.setTsb(syn.tsb_offset())
     rcc.setModel(16, 16, 0.05, 80.0, (0.01, 0.02, 0.03), dirs)
     poses, _ = syn.uniform_particles(33, seed=9, bb_min=(-8, -8, 0.5, 0, 0, -3), bb_max=(8, 8, 2.5, 0, 0, 3))
-    for variant in (19, 0, 2, 4, 21, 22):
+    for variant in (23, 0, 2, 24):
         rcc.set_traversal(variant)
         rcc.find_batch(poses)
         mv = rcc.modelView()

@@ -12,9 +12,9 @@ import rmcl_amd as ra
 ra.load_lab()   # experiments library: the kinds / kernels this tool compares are not all in the product
 from rmcl_amd import synthetic as syn, types as T
 
-kinds = [int(a) for a in sys.argv[1:]] or [1, 5, 6, 7, 8, 9, 10, 2]
+kinds = [int(a) for a in sys.argv[1:]] or [19, 23, 22, 24, 2]
 ctx = ra.Context(0)
-sizes = ((128, 1024), (64, 1024), (128, 2048), (16, 900))
+sizes = ((128, 1024), (64, 1024), (128, 2048), (256, 2048), (16, 900))
 for mesh in ("sphere", "room"):
     v, f = syn.uv_sphere(100000) if mesh == "sphere" else syn.noisy_room(100000)
     hm = ra.import_hip_map(ctx, v, f)

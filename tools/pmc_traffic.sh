@@ -10,15 +10,14 @@ run() { # name counter cmd...
   name=$1; shift; ctr=$1; shift
   timeout 300 rocprofv3 --kernel-trace --pmc $ctr -d $OUT -o $name -- "$@" > $OUT/$name.stdout 2>&1 || echo "$name failed" >> $OUT/errors.txt
 }
-# the automatic traversal (15 -> kind 19 for C2) and the main A/B kinds, each in its own pass pair; `find` as 2nd argument: only these
-for v in 15 17 1 2; do
-  w=$v; [ $v -ge 16 ] && [ $v -ne 15 ] && w=$(( (v & 15) | 8192 ))   # kinds >= 16 travel in bit 13 of the variant word
-  run find_v${v}_fetch FETCH_SIZE python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras --variant $w
-  run find_v${v}_write WRITE_SIZE python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras --variant $w
+# the automatic traversal (15 -> kind 23 for C2) and the quad traversal, each in its own pass pair; `find` as 2nd argument: only these
+for v in 15 2; do
+  run find_v${v}_fetch FETCH_SIZE python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras --variant $v
+  run find_v${v}_write WRITE_SIZE python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras --variant $v
 done
 [ "${2:-all}" = find ] && { ls $OUT; exit 0; }
-run pf_fetch FETCH_SIZE python bench.py --workload pf --steps 3 --warmup 1
-run pf_write WRITE_SIZE python bench.py --workload pf --steps 3 --warmup 1
+run pf_fetch FETCH_SIZE python bench.py --workload pf --steps 3 --warmup 1 --no-extras
+run pf_write WRITE_SIZE python bench.py --workload pf --steps 3 --warmup 1 --no-extras
 run red_fetch FETCH_SIZE python bench.py --steps 5 --warmup 2 --no-cpu-baseline
 run red_write WRITE_SIZE python bench.py --steps 5 --warmup 2 --no-cpu-baseline
 ls $OUT

@@ -22,10 +22,9 @@ def avg(db, kernel_like, counter):
 def main(d, out):
     res = {}
     # key = the kernel as bench.py names it (traversal kind of k_find), like = its demangled template arguments
-    specs = (("k_find_kind19", "%k_find<1u, 19>%", "find_v15", False), ("k_find_kind17", "%k_find<1u, 17>%", "find_v17", False),
-             ("k_find_kind1", "%k_find<1u, 1>%", "find_v1", False),
-             ("k_find_kind2", "%k_find<1u, 2>%", "find_v2", False), ("k_pf_update", "%k_pf_update%", "pf", False),
-             ("k_micp_iter", "%k_micp_iter%", "red", True), ("k_reduce_partials", "%k_reduce_partials%", "red", True))
+    specs = (("k_find_kind23", "%k_find<1u, 23%", "find_v15", False), ("k_find_kind2", "%k_find<1u, 2,%", "find_v2", False),
+             ("k_pf_update_v3", "%k_pf_update_v3%", "pf", False),
+             ("k_micp_moments", "%k_micp_moments%", "red", True), ("k_reduce_partials", "%k_reduce_partials%", "red", True))
     for key, like, pre, wide in specs:
         try:
             f, nf = avg("%s/%s_fetch_results.db" % (d, pre), like, "FETCH_SIZE")

@@ -86,6 +86,27 @@ static void ws_pop(ws_lane* L, int mode)
 static const float* g_seed_t = 0;
 void orc_wavesim_seed(const float* t) { g_seed_t = t; }
 
+
+/* frontier start (round 3 idea): instead of descending from the root, a ray starts with the nodes of BFS depth `fd` (and the
+ * leaves above that depth) its own box tests accept, nearest first -- the top `fd` levels of per-ray descent are replaced by a
+ * wave-cooperative frustum culling of the (<= 4^fd) frontier entries plus one box test per surviving candidate.  Here: exact
+ * per-ray filter (what the kernel's per-lane filter computes), visits of the skipped levels are not counted. */
+static int g_frontier_depth = 0;
+static uint64_t g_frontier_cands = 0;
+uint64_t orc_wavesim_frontier_cands(void) { uint64_t v = g_frontier_cands; g_frontier_cands = 0; return v; }
+void orc_wavesim_frontier(int depth) { g_frontier_depth = depth; }
+static void ws_frontier(ws_lane* l, const uint32_t* nodes, uint32_t node, int depth, uint32_t* cand, float* ckey, int* nc)
+{
+  const float* nd = (const float*)(nodes + 32u * node);
+  const uint32_t* ch = nodes + 32u * node + 24u;
+  for (uint32_t c = 0; c < 4; ++c) {
+    float tn, tf;
+    if (!ws_box(nd, c, l->o, l->inv, l->best_t, &tn, &tf)) continue;
+    if (!(ch[c] & 0x80000000u) && depth + 1 < g_frontier_depth) ws_frontier(l, nodes, ch[c], depth + 1, cand, ckey, nc);
+    else if (*nc < 256) { cand[*nc] = ch[c]; ckey[*nc] = tn; (*nc)++; }
+  }
+}
+
 int orc_wavesim_ww(const uint32_t* nodes, const uint32_t* tris, const float* O, const float* D, uint32_t nlanes,
                    float tfar, int mode, uint64_t out[7], float* t_out, uint32_t* face_out)
 {
@@ -98,6 +119,15 @@ int orc_wavesim_ww(const uint32_t* nodes, const uint32_t* tris, const float* O, 
     L[i].inv[0] = safe_inv(L[i].D.x); L[i].inv[1] = safe_inv(L[i].D.y); L[i].inv[2] = safe_inv(L[i].D.z);
     L[i].best_t = (g_seed_t && g_seed_t[i] > 0.0f) ? g_seed_t[i] : tfar; L[i].best_f = 0xFFFFFFFFu;
     L[i].done = !(L[i].D.x == L[i].D.x && L[i].D.y == L[i].D.y && L[i].D.z == L[i].D.z);
+    if (g_frontier_depth > 0 && !L[i].done) {
+      uint32_t cand[256]; float ckey[256]; int nc = 0;
+      ws_frontier(&L[i], nodes, 0, 0, cand, ckey, &nc);
+      for (int a = 0; a < nc; ++a) for (int b = a + 1; b < nc; ++b)
+        if (ckey[b] < ckey[a]) { float t = ckey[a]; ckey[a] = ckey[b]; ckey[b] = t; uint32_t r = cand[a]; cand[a] = cand[b]; cand[b] = r; }
+      if (nc == 0) L[i].done = 1;
+      else { for (int a = nc - 1; a >= 1; --a) { L[i].stack[L[i].sp] = cand[a]; L[i].stack_t[L[i].sp] = ckey[a]; L[i].sp++; } L[i].cur = cand[0]; }
+      g_frontier_cands += (uint64_t)nc;
+    }
   }
   memset(out, 0, 7 * sizeof(uint64_t));
   for (;;) {

@@ -83,3 +83,11 @@ if __name__ == "__main__":
     for mode in modes:
         report("mode %d" % mode, simulate(nodes, tris, model, O, dm, mode, stride=4))
         report("mode %d seeded" % mode, simulate(nodes, tris, model, O, dm, mode, stride=4, seeded=True))
+        L = simlib()
+        L.orc_wavesim_frontier_cands.restype = C.c_uint64
+        for depth in (1, 2, 3, 4):
+            L.orc_wavesim_frontier(depth)
+            r = simulate(nodes, tris, model, O, dm, mode, stride=4)
+            report("mode %d frontier depth %d" % (mode, depth), r)
+            print("      candidates accepted per ray: %.2f" % (L.orc_wavesim_frontier_cands() / (64.0 * len(r))))
+        L.orc_wavesim_frontier(0)
