@@ -257,6 +257,11 @@ rmclhip_status rmclhip_rcc_set_input_pointcloud2(rmclhip_rcc* rcc, const uint8_t
  * dataset) receive hits = (distance <= params.max_dist), points = Tms * p_closest, normals = Tms.R * n_face
  * (+ ranges = distance, face ids).  computeCrossStatistics then works unchanged. */
 rmclhip_status rmclhip_rcc_find_cpc(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est);
+/* Tracking (default on): the operator remembers which triangle every dataset point was closest to and starts the next
+ * find_cpc of the SAME dataset with that triangle's distance as the search bound.  The triangle is a real candidate, so the
+ * answer -- min distance, then min face id -- is the same bit for bit; what changes is the number of leaves a query visits
+ * when the pose moved little between calls (an ICP loop).  A new dataset, or on = 0, starts cold. */
+rmclhip_status rmclhip_rcc_set_cpc_tracking(rmclhip_rcc* rcc, int on);
 /* Correspondences{CPU,CUDA}::computeCrossStatistics (CorrespondencesCPU.cpp:10-39):
  * max_dist' = max_dist (1-p) + adaptive_max_dist_min p; rm::statistics_p2l(T_snew_sold, ...) */
 rmclhip_status rmclhip_rcc_compute_cross_statistics(rmclhip_rcc* rcc, const rmclhip_transform* T_snew_sold,

@@ -209,6 +209,12 @@ struct rmclhip_rcc {
   unsigned long long* h_done = nullptr;         // pinned, host-mapped completion tags: [0] this handle's chains, [1] the N-sensor loop
   unsigned long long* h_done_dev = nullptr;
   uint32_t done_seq = 0;                        // sequence number of the last polled call (never 0 in a tag)
+  // closest-point correspondences, tracking: record index per dataset point of the previous find_cpc (see rmclhip_rcc_find_cpc)
+  DevBuf<uint32_t> d_cpc_rec;
+  const uint32_t* cpc_rec_ptr = nullptr;
+  const float* cpc_rec_pts = nullptr;           // the dataset the records were computed for
+  uint32_t cpc_rec_n = 0;
+  bool cpc_tracking = true;
   hipGraphExec_t micp_fast_exec = nullptr;
   hipGraph_t micp_fast_graph = nullptr;
   float fast_rho_cap = 0.02f, fast_tau_cap = 0.1f;   // bounds on |2 sin(theta/2)| and |t| of the pre-transforms
@@ -539,6 +545,7 @@ void rmclhip_rcc_destroy(rmclhip_rcc* r) {
   if (r->micp_fast_graph) DBG_STEP(hipGraphDestroy(r->micp_fast_graph));
   if (r->h_fast_status) DBG_STEP(hipHostFree(r->h_fast_status));
   if (r->h_done) DBG_STEP(hipHostFree(r->h_done));
+  r->d_cpc_rec.release();
   r->d_fast_partials.release(); r->d_fast_mask.release();
   r->d_multi_blob.release();
   if (r->h_multi_state) DBG_STEP(hipHostFree(r->h_multi_state));
@@ -660,6 +667,7 @@ rmclhip_status rmclhip_rcc_set_dataset(rmclhip_rcc* r, const float* pts, const u
   HIPCHK(hipSetDevice(r->ctx->device));
   HIPCHK(hipStreamSynchronize(r->stream));
   r->n_dataset = n;
+  r->cpc_rec_n = 0;   // a new dataset: the closest-point records of the old one mean nothing
   r->ds_has_mask = (mask != nullptr);
   if (n == 0) return RMCLHIP_OK;
   const hipMemcpyKind kind = src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -680,6 +688,7 @@ rmclhip_status rmclhip_rcc_set_dataset_view(rmclhip_rcc* r, const float* pts_dev
   HIPCHK(hipSetDevice(r->ctx->device));
   HIPCHK(hipStreamSynchronize(r->stream));
   r->n_dataset = n;
+  r->cpc_rec_n = 0;
   r->ds_has_mask = (mask_dev != nullptr);
   r->ds_pts = pts_dev;
   r->ds_msk = mask_dev;
@@ -695,6 +704,7 @@ rmclhip_status rmclhip_rcc_set_dataset_from_ranges(rmclhip_rcc* r, const float* 
   HIPCHK(hipSetDevice(r->ctx->device));
   HIPCHK(hipStreamSynchronize(r->stream));
   r->n_dataset = n;
+  r->cpc_rec_n = 0;
   r->ds_has_mask = true;
   if (n_valid_out) *n_valid_out = 0;
   if (n == 0) return RMCLHIP_OK;
@@ -751,6 +761,7 @@ rmclhip_status rmclhip_rcc_set_input_pointcloud2(rmclhip_rcc* r, const uint8_t* 
   r->range = range;
   r->orig = mk3(0.f, 0.f, 0.f);
   r->n_dataset = static_cast<uint32_t>(n);
+  r->cpc_rec_n = 0;
   r->ds_has_mask = true;
   if (out_width) *out_width = ow;
   if (out_height) *out_height = oh;
@@ -887,10 +898,27 @@ rmclhip_status rmclhip_rcc_find_cpc(rmclhip_rcc* r, const rmclhip_transform* Tbm
   r->nposes_last = 1;
   const xform Tsm = xmul(to_x(Tbm_est), r->Tsb);
   const bool quad = (r->variant == 15) ? true : (r->variant == 2);  // four lanes per point read the child-major nodes
+  // tracking: the record every point was closest to in the previous call of this operator bounds this call's search (same
+  // results; rmclhip_rcc_set_cpc_tracking).  The records belong to one dataset of one size: anything else starts cold.
+  const uint32_t* seed = nullptr;
+  if (r->cpc_tracking) {
+    HIPCHK(r->d_cpc_rec.reserve(n));
+    if (r->d_cpc_rec.p != r->cpc_rec_ptr) { r->cpc_rec_ptr = r->d_cpc_rec.p; r->cpc_rec_n = 0; }   // (re)allocated
+    if (r->cpc_rec_n == r->n_dataset && r->cpc_rec_pts == r->ds_pts) seed = r->d_cpc_rec.p;
+  }
   HIPCHK(launch_cpc_find(quad ? r->map->d_cnodes : r->map->d_nodes, r->map->d_tris, r->ds_pts, r->n_dataset,
                          r->max_dist, Tsm, xinv(Tsm), r->d_hits.p, r->d_ranges.p, r->d_points.p, r->d_normals.p,
-                         r->d_face_ids.p, quad, r->stream));
+                         r->d_face_ids.p, quad, r->stream, seed, r->cpc_tracking ? r->d_cpc_rec.p : nullptr, r->map->info.n_faces));
+  if (r->cpc_tracking) { r->cpc_rec_n = r->n_dataset; r->cpc_rec_pts = r->ds_pts; }
   HIPCHK(hipStreamSynchronize(r->stream));
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_set_cpc_tracking(rmclhip_rcc* r, int on) {
+  ApiGuard guard_("rmclhip_rcc_set_cpc_tracking");
+  if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_set_cpc_tracking: null");
+  r->cpc_tracking = on != 0;
+  r->cpc_rec_n = 0;
   return RMCLHIP_OK;
 }
 

@@ -1130,10 +1130,11 @@ struct NearHit {
 template <int kLdsEntries>
 __device__ __forceinline__ void nearest_lane_ww(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris,
                                                 f3 P, bool active, uint32_t* __restrict__ lds_stack,
-                                                uint32_t lds_stride, NearHit& h) {
+                                                uint32_t lds_stride, NearHit& h, const NearHit* seed = nullptr) {
   float best = 3.0e38f;  // finite: unused node slots (box at 1e30 -> d2 = inf) never pass `d2 <= best`
   uint32_t best_face = kInvalidFace, best_rec = 0;
   f3 best_p = mk3(0.f, 0.f, 0.f);
+  if (seed != nullptr && seed->face != kInvalidFace) { best = seed->d2; best_face = seed->face; best_rec = seed->rec; best_p = seed->p; }
   constexpr uint32_t kDone = 0x7FFFFFFFu;
   uint32_t priv[(kLdsEntries < 64) ? (64 - kLdsEntries) : 1];
   uint32_t sp = 0;
@@ -1197,10 +1198,12 @@ __device__ __forceinline__ void nearest_lane_ww(const uint32_t* __restrict__ nod
 // runs Ericson's closest-point-on-triangle for triangle c of a leaf -- the expensive, branchy part of this query is
 // done for up to four triangles at once; (d2, face id) ties resolve exactly like nearest_lane_ww.
 __device__ __forceinline__ void nearest_quad(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ tris, f3 P,
-                                             bool active, uint32_t c, uint32_t ray, uint32_t* __restrict__ lds, NearHit& h) {
+                                             bool active, uint32_t c, uint32_t ray, uint32_t* __restrict__ lds, NearHit& h,
+                                             const NearHit* seed = nullptr) {
   float best = 3.0e38f;
   uint32_t best_face = kInvalidFace, best_rec = 0;
   f3 best_p = mk3(0.f, 0.f, 0.f);
+  if (seed != nullptr && seed->face != kInvalidFace) { best = seed->d2; best_face = seed->face; best_rec = seed->rec; best_p = seed->p; }
   constexpr uint32_t kDone = 0x7FFFFFFFu;
   const char* nbase = reinterpret_cast<const char*>(nodes);
   char* sbase = reinterpret_cast<char*>(lds) + ray * 4u;
@@ -1288,6 +1291,13 @@ struct CpcParams {
   float* points;
   float* normals;
   uint32_t* face_ids;
+  // tracking: the record each point was closest to in the PREVIOUS call (nullable / kNone: none) and where this call's go.
+  // The previous triangle is an actual candidate, so its distance is an upper bound of the answer: the query starts with it
+  // and only visits boxes at most that far away -- the same result (min d2, then min face id), a fraction of the leaf visits
+  // when the pose changed little between the calls (the case of an ICP loop).
+  const uint32_t* seed_rec;
+  uint32_t* rec_out;
+  uint32_t n_tris;
 };
 
 // kQuad: four lanes per dataset point (64 points per block) instead of one
@@ -1301,10 +1311,24 @@ __global__ void __launch_bounds__(256) k_cpc_find(const CpcParams p) {
   const float* dp = p.dataset_points + 3 * static_cast<size_t>(ii);
   const f3 Pm = xapply(p.Tsm, mk3(dp[0], dp[1], dp[2]));
   const bool finite = (Pm.x == Pm.x) && (Pm.y == Pm.y) && (Pm.z == Pm.z);
-  NearHit h;
-  if (kQuad) nearest_quad(p.nodes, p.tris, Pm, live && finite, sub, threadIdx.x >> 2, lds_dyn, h);
-  else nearest_lane_ww<16>(p.nodes, p.tris, Pm, live && finite, lds_dyn + threadIdx.x, blockDim.x, h);
+  NearHit h, seed;
+  seed.d2 = 3.0e38f; seed.face = kInvalidFace; seed.rec = 0; seed.p = mk3(0.f, 0.f, 0.f);
+  if (p.seed_rec != nullptr) {
+    const uint32_t sr = p.seed_rec[ii];
+    if (live && finite && sr < p.n_tris) {
+      const uint4* tp = reinterpret_cast<const uint4*>(p.tris) + static_cast<size_t>(sr) * 4u;
+      const uint4 a = tp[0], b = tp[1], cc = tp[2], d = tp[3];
+      const f3 cq = closest_point_triangle(mk3(asf(a.x), asf(a.y), asf(a.z)), mk3(asf(a.w), asf(b.x), asf(b.y)),
+                                           mk3(asf(b.z), asf(b.w), asf(cc.x)), Pm);
+      const f3 df = sub3(Pm, cq);
+      seed.d2 = (df.x * df.x + df.y * df.y) + df.z * df.z;   // the query's own arithmetic: revisiting this record changes nothing
+      seed.face = d.w; seed.rec = sr; seed.p = cq;
+    }
+  }
+  if (kQuad) nearest_quad(p.nodes, p.tris, Pm, live && finite, sub, threadIdx.x >> 2, lds_dyn, h, &seed);
+  else nearest_lane_ww<16>(p.nodes, p.tris, Pm, live && finite, lds_dyn + threadIdx.x, blockDim.x, h, &seed);
   if (!live) return;
+  if (p.rec_out != nullptr && (!kQuad || sub == 0u)) p.rec_out[i] = (h.face != kInvalidFace) ? h.rec : kNone;
   // quad: the four lanes of a point hold the same result and share the stores
   const bool w0 = !kQuad || sub == 0u, w1 = !kQuad || sub == 1u, w2 = !kQuad || sub == 2u;
   if (h.face != kInvalidFace) {

@@ -471,6 +471,10 @@ class CPCHip(CorrespondencesHIP):
     """rmcl::CPCEmbree on gfx950 (CPCEmbree.cpp:11-44): closest-point correspondences; find() pairs every
     dataset point with the nearest surface point of the map (no sensor model needed)."""
 
+    def set_tracking(self, on=True):
+        """start every query from the triangle the point was closest to in the previous find (same results; rmclhip.h)"""
+        _capi.check(_capi.lib().rmclhip_rcc_set_cpc_tracking(self._h, 1 if on else 0))
+
     def find(self, Tbm_est):
         self._push_params()   # hits = (distance <= params.max_dist)
         T = np.ascontiguousarray(Tbm_est, dtype=TRANSFORM).reshape(1)

@@ -105,3 +105,36 @@ def test_pf_update_with_closest_point_errors(ra, orc, ctx, meshes, n_particles, 
     with pytest.raises(ra.RmclHipError):
         upd.config = T.pf_params(correspondence_type=4)
         upd.update(d_poses, d_attrs)
+
+
+def test_tracking_gives_the_cold_result_bit_for_bit(ra, orc, ctx, meshes):
+    """rmclhip_rcc_set_cpc_tracking: a query that starts from the triangle the point was closest to in the previous call returns
+    exactly what a cold query returns -- over a sequence of poses that drift (small steps, one large jump, a repeat), with
+    the dataset replaced in between (the records of the old dataset must not be used), four lanes and one lane per point."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room30k")
+    hm = ra.import_hip_map(ctx, v, f)
+    rng = np.random.RandomState(4)
+    pts_a = rng.uniform(-8, 8, (5000, 3)).astype(np.float32)
+    pts_a[:, 2] = rng.uniform(0.1, 3.0, 5000)
+    pts_b = (pts_a[::-1] * np.float32(0.9)).copy()
+    poses = [T.transform_from_rpy((0.02 * k, -0.015 * k, 0.01 * k), (0.0, 0.0, 0.004 * k)) for k in range(6)]
+    poses += [T.transform_from_rpy((2.0, -1.0, 0.5), (0.1, 0.0, 1.3)), poses[2], poses[2]]
+    for variant in (2, 1):
+        cold, warm = ra.CPCHip(hm), ra.CPCHip(hm)
+        for c in (cold, warm):
+            c.set_variant(variant)
+            c.setTsb(syn.tsb_offset())
+            c.params.max_dist = 0.4
+        cold.set_tracking(False)
+        for pts in (pts_a, pts_b, pts_a):
+            cold.set_dataset(pts, None)
+            warm.set_dataset(pts, None)
+            for P in poses:
+                cold.find(P)
+                warm.find(P)
+                a, b = cold.modelView(), warm.modelView()
+                for k in ("hits", "ranges", "face_ids", "points", "normals"):
+                    assert a[k].tobytes() == b[k].tobytes(), (variant, k)
+        cold.close()
+        warm.close()
