@@ -1654,15 +1654,34 @@ __global__ void __launch_bounds__(256) k_pose_moments(const xform* __restrict__ 
   }
 }
 
-__global__ void __launch_bounds__(64) k_pose_moments_final(const double* __restrict__ partials, uint32_t nblocks, double* __restrict__ out) {
-  const int k = static_cast<int>(threadIdx.x);
-  if (k >= kMomSums + kMomMax) return;
-  double v = (k < kMomSums) ? 0.0 : -1.7976931348623157e308;
-  for (uint32_t b = 0; b < nblocks; ++b) {
-    const double x = partials[static_cast<size_t>(b) * (kMomSums + kMomMax) + k];
-    v = (k < kMomSums) ? (v + x) : fmax(v, x);
+// One workgroup folds the per-block partials: thread = (moment k, group g of 8); a group takes every 8th block with four loads in
+// flight, the eight group sums are folded in a fixed order through LDS (deterministic).  Round 2's version -- one 64-lane wave,
+// one dependent load per block and lane -- took 23.7 us for 98 blocks, twice the streaming pass it finalizes.
+__global__ void __launch_bounds__(256) k_pose_moments_final(const double* __restrict__ partials, uint32_t nblocks, double* __restrict__ out) {
+  constexpr int kW = kMomSums + kMomMax;   // 32
+  __shared__ double s_g[8][kW];
+  const int k = static_cast<int>(threadIdx.x) & (kW - 1);
+  const uint32_t g = threadIdx.x >> 5;
+  const bool is_sum = k < kMomSums;
+  double v = is_sum ? 0.0 : -1.7976931348623157e308;
+  uint32_t b = g;
+  for (; b + 24u < nblocks; b += 32u) {
+    const double x0 = partials[static_cast<size_t>(b) * kW + k], x1 = partials[static_cast<size_t>(b + 8u) * kW + k];
+    const double x2 = partials[static_cast<size_t>(b + 16u) * kW + k], x3 = partials[static_cast<size_t>(b + 24u) * kW + k];
+    v = is_sum ? (v + ((x0 + x1) + (x2 + x3))) : fmax(fmax(v, fmax(x0, x1)), fmax(x2, x3));
   }
-  out[k] = v;
+  for (; b < nblocks; b += 8u) {
+    const double x = partials[static_cast<size_t>(b) * kW + k];
+    v = is_sum ? (v + x) : fmax(v, x);
+  }
+  s_g[g][k] = v;
+  __syncthreads();
+  if (threadIdx.x < static_cast<uint32_t>(kW)) {
+    double r = s_g[0][k];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) r = is_sum ? (r + s_g[q][k]) : fmax(r, s_g[q][k]);
+    out[k] = r;
+  }
 }
 
 // dense weight vector from the padded all-gather layout: rank r's shard sits at r * cap
@@ -2162,7 +2181,7 @@ hipError_t launch_pose_moments(const xform* poses, const void* attrs, uint32_t n
   if (nblocks > 256u) nblocks = 256u;
   hipLaunchKernelGGL(k_pose_moments, dim3(nblocks), dim3(256), 0, s, poses, reinterpret_cast<const pattrs*>(attrs), n, pass, L_sum, Tbm,
                      partials);
-  hipLaunchKernelGGL(k_pose_moments_final, dim3(1), dim3(64), 0, s, partials, nblocks, out32);
+  hipLaunchKernelGGL(k_pose_moments_final, dim3(1), dim3(256), 0, s, partials, nblocks, out32);
   return hipGetLastError();
 }
 
