@@ -121,6 +121,52 @@ int main(int argc, char** argv) {
       std::printf("dataset_member_valid %u\ndataset_member_n_meas %u %u\ndataset_member_cov00 %.9g %.9g\ndataset_view %zu %zu\n", valid2,
                   a.n_meas, b.n_meas, a.covariance[0], b.covariance[0], dv.points.size(), dv.mask.size());
     }
+    // modelView() (Correspondences.hpp:47-53) the way MICPSensorCUDA.cpp:66-84 reads it: {points, mask, normals} views on the device
+    {
+      rcc.find(truth * Tbo);
+      const auto mv = rcc.modelView();
+      Memory<uint8_t, RAM> mask_h;
+      Memory<Vector, RAM> points_h, normals_h;
+      download(*ctx, mv.mask, mask_h);
+      download(*ctx, mv.points, points_h);
+      download(*ctx, mv.normals, normals_h);
+      uint64_t mask_sum = 0;
+      double range_sum = 0, unit = 0;
+      for (size_t i = 0; i < mask_h.size(); ++i) {
+        if (!mask_h[i]) continue;
+        ++mask_sum;
+        range_sum += std::sqrt(points_h[i].x * points_h[i].x + points_h[i].y * points_h[i].y + points_h[i].z * points_h[i].z);
+        unit += normals_h[i].x * normals_h[i].x + normals_h[i].y * normals_h[i].y + normals_h[i].z * normals_h[i].z;
+      }
+      double ranges_sum = 0;
+      for (uint32_t i = 0; i < n; ++i) ranges_sum += hits[i] ? ranges[i] : 0.0;
+      std::printf("model_view %zu %llu %.9g %.9g %.9g\n", mv.points.size(), (unsigned long long)mask_sum, range_sum, ranges_sum, unit);
+    }
+    // a scene (rm::import_embree_map of a file with several nodes, micp_localization.cpp:187-195): the same mesh twice, the
+    // second copy scaled and out of sight 200 m away -- the scan must not change, face ids stay those of instance 0
+    {
+      const std::vector<rmclhip_mesh> scene_meshes = {rmclhip_mesh{verts.data(), faces.data(), nv, nf}};
+      const std::vector<rmclhip_instance> scene_instances = {
+          HipMap::instance(0, identity()), HipMap::instance(0, from_rpy(200.f, 0.f, 0.f, 0, 0, 0.5), Vector{2.f, 1.f, 0.5f})};
+      auto scene = std::make_shared<HipMap>(ctx, scene_meshes, scene_instances);
+      RCCHipSpherical rcc3(scene);
+      rcc3.setTsb(Tsb);
+      rcc3.setModel(model);
+      rcc3.find(truth * Tbo);
+      std::vector<uint32_t> fid3(n);
+      std::vector<uint8_t> hit3(n);
+      rcc3.download(hit3.data(), nullptr, nullptr, nullptr, fid3.data());
+      uint64_t fs3 = 0, hs3 = 0, inst_sum = 0;
+      for (uint32_t i = 0; i < n; ++i) {
+        if (!hit3[i]) continue;
+        fs3 += fid3[i];
+        ++hs3;
+        inst_sum += scene->locate(fid3[i]).instance;
+      }
+      const std::vector<uint32_t> first = scene->sceneInstances();
+      std::printf("scene %zu %u %u %u\nscene_hits %llu\nscene_face_sum %llu\nscene_instance_sum %llu\n", first.size() - 1, first[0],
+                  first[1], first[2], (unsigned long long)hs3, (unsigned long long)fs3, (unsigned long long)inst_sum);
+    }
     // the same loop resident on the device
     CrossStatistics sdev{};
     const Transform Tdev = rcc.correctOnce(Tom_est, Tbo, 5, 0.0, false, &sdev);

@@ -95,6 +95,43 @@ class HipMap {
       : ctx_(std::move(ctx)) {
     check(rmclhip_map_create(ctx_->handle(), vertices_xyz, n_vertices, faces_ijk, n_faces, &h_));
   }
+  // a whole scene -- what rm::import_embree_map / import_optix_map make of an assimp file (micp_localization.cpp:187-195):
+  // meshes placed (and possibly repeated) by instances; no instances = every mesh once, untransformed.  Face ids of find()
+  // are global, sceneInstances() / locate() translate them back.
+  HipMap(ContextPtr ctx, const std::vector<rmclhip_mesh>& meshes, const std::vector<rmclhip_instance>& instances = {})
+      : ctx_(std::move(ctx)) {
+    check(rmclhip_map_create_scene(ctx_->handle(), meshes.data(), static_cast<uint32_t>(meshes.size()),
+                                   instances.empty() ? nullptr : instances.data(), static_cast<uint32_t>(instances.size()), &h_));
+  }
+  // rmagine places an instance with a Transform and a per-axis scale (A = R diag(scale), t): the 3x4 the C ABI takes
+  static rmclhip_instance instance(uint32_t mesh, const Transform& T, const Vector& scale = Vector{1.f, 1.f, 1.f}) {
+    const float x = T.R.x, y = T.R.y, z = T.R.z, w = T.R.w;
+    const float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - z * w), 2.f * (x * z + y * w)},
+                           {2.f * (x * y + z * w), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - x * w)},
+                           {2.f * (x * z - y * w), 2.f * (y * z + x * w), 1.f - 2.f * (x * x + y * y)}};
+    const float sc[3] = {scale.x, scale.y, scale.z}, t[3] = {T.t.x, T.t.y, T.t.z};
+    rmclhip_instance I{};
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) I.transform[4 * r + c] = R[r][c] * sc[c];
+      I.transform[4 * r + 3] = t[r];
+    }
+    I.mesh = mesh;
+    return I;
+  }
+  // first global face id of every instance, + n_faces as the last entry
+  std::vector<uint32_t> sceneInstances() const {
+    uint32_t n = 0;
+    check(rmclhip_map_scene_instances(h_, nullptr, 0, &n));
+    std::vector<uint32_t> first(n + 1u);
+    check(rmclhip_map_scene_instances(h_, first.data(), first.size(), &n));
+    return first;
+  }
+  struct FaceLocation { uint32_t instance, face; };
+  FaceLocation locate(uint32_t face_id) const {
+    FaceLocation L{};
+    check(rmclhip_map_scene_locate(h_, face_id, &L.instance, &L.face));
+    return L;
+  }
   ~HipMap() { rmclhip_map_release(h_); }
   HipMap(const HipMap&) = delete;
   HipMap& operator=(const HipMap&) = delete;
@@ -188,6 +225,13 @@ class Memory<T, VRAM_HIP> {
   size_t cap_ = 0, n_ = 0;
   uint64_t version_ = 0;
 };
+
+// device view -> host memory (rmagine: `Memory<T, RAM> host = view;`), e.g. the members of modelView()
+template <typename T>
+inline void download(const Context& ctx, const DeviceView<const T>& view, Memory<T, RAM>& host) {
+  host.resize(view.size());
+  if (view.size()) check(rmclhip_memcpy_d2h(ctx.handle(), host.raw(), view.raw(), view.size() * sizeof(T)));
+}
 
 // rmagine::PointCloud_<MemT> / PointCloudView_<MemT> (Correspondences.hpp:24,47-62): {points, mask} (+ normals in views)
 template <typename MemT>

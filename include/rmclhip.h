@@ -174,6 +174,38 @@ rmclhip_status rmclhip_map_retain(rmclhip_map* map);
 void rmclhip_map_release(rmclhip_map* map);
 rmclhip_status rmclhip_map_get_info(const rmclhip_map* map, rmclhip_map_info* out);
 
+/* A whole scene: n_meshes indexed meshes, placed -- and possibly repeated -- by n_instances affine transforms.  This is what
+ * rm::import_embree_map / import_optix_map make of an assimp scene (micp_localization.cpp:187-195: one mesh per aiMesh, one
+ * instance per aiNode that references it).  The scene is flattened on the host into ONE world-space triangle soup and one
+ * tree (an instance costs its triangles again; RMCL's maps are a few static meshes).  instances == NULL: every mesh once,
+ * untransformed (n_instances is ignored).  transform: the first three rows of the row-major 4x4 node matrix (aiMatrix4x4's
+ * own layout, a1..c4), p_map = A p_mesh + t, applied in float row by row.  Face ids the find / download calls return are
+ * GLOBAL: instance i owns ids [first_face[i], first_face[i+1]), in the mesh's own face order. */
+typedef struct {
+  const float* vertices_xyz;
+  const uint32_t* faces_ijk;
+  uint32_t n_vertices, n_faces;
+} rmclhip_mesh;
+typedef struct {
+  float transform[12];   /* rows of [A | t] */
+  uint32_t mesh;         /* index into meshes[] */
+  uint32_t reserved[3];
+} rmclhip_instance;
+rmclhip_status rmclhip_map_create_scene(rmclhip_ctx* ctx, const rmclhip_mesh* meshes, uint32_t n_meshes,
+                                        const rmclhip_instance* instances, uint32_t n_instances, rmclhip_map** out);
+/* the face-id offset table of a map: first_face_out gets n_instances + 1 entries (the last = n_faces); a map made by
+ * rmclhip_map_create reports one instance.  first_face_out may be NULL to query n_instances. */
+rmclhip_status rmclhip_map_scene_instances(const rmclhip_map* map, uint32_t* first_face_out, size_t capacity,
+                                           uint32_t* n_instances);
+/* global face id -> (instance, face index within that instance's mesh) */
+rmclhip_status rmclhip_map_scene_locate(const rmclhip_map* map, uint32_t face_id, uint32_t* instance, uint32_t* local_face);
+/* the flattening alone, host only (no device): what rmclhip_map_create_scene hands to the BVH builder.  Output pointers may
+ * be NULL to query the sizes. */
+rmclhip_status rmclhip_scene_flatten_host(const rmclhip_mesh* meshes, uint32_t n_meshes, const rmclhip_instance* instances,
+                                          uint32_t n_instances, float* vertices_out, size_t vertices_cap_floats,
+                                          uint32_t* faces_out, size_t faces_cap_dwords, uint32_t* first_face_out,
+                                          size_t first_face_cap, uint32_t* n_vertices, uint32_t* n_faces);
+
 /* Host-only BVH build (no device needed): fills caller buffers with the exact
  * arrays map_create uploads.  nodes: n_nodes*32 dwords, tris: n_faces*16 dwords.
  * Pass NULL buffers to query sizes via info.  Used by the CPU tests to check the

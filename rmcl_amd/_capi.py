@@ -86,6 +86,14 @@ class MapInfo(C.Structure):
                 ("device_bytes", C.c_uint64), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3)]
 
 
+class Mesh(C.Structure):
+    _fields_ = [("vertices_xyz", C.c_void_p), ("faces_ijk", C.c_void_p), ("n_vertices", C.c_uint32), ("n_faces", C.c_uint32)]
+
+
+class Instance(C.Structure):
+    _fields_ = [("transform", C.c_float * 12), ("mesh", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/rmclhip.h
 _vp, _u32, _f32, _i32, _sz, _dbl = C.c_void_p, C.c_uint32, C.c_float, C.c_int, C.c_size_t, C.c_double
 _pp = C.POINTER(C.c_void_p)
@@ -96,6 +104,11 @@ SIGNATURES = {
     "rmclhip_ctx_destroy": (None, [_vp]),
     "rmclhip_ctx_device_name": (_i32, [_vp, C.c_char_p, _sz]),
     "rmclhip_map_create": (_i32, [_vp, _vp, _u32, _vp, _u32, _pp]),
+    "rmclhip_map_create_scene": (_i32, [_vp, _vp, _u32, _vp, _u32, _pp]),
+    "rmclhip_map_scene_instances": (_i32, [_vp, _vp, _sz, C.POINTER(_u32)]),
+    "rmclhip_map_scene_locate": (_i32, [_vp, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
+    "rmclhip_scene_flatten_host": (_i32, [_vp, _u32, _vp, _u32, _vp, _sz, _vp, _sz, _vp, _sz, C.POINTER(_u32),
+                                           C.POINTER(_u32)]),
     "rmclhip_map_retain": (_i32, [_vp]),
     "rmclhip_map_release": (None, [_vp]),
     "rmclhip_map_get_info": (_i32, [_vp, C.POINTER(MapInfo)]),

@@ -139,6 +139,7 @@ struct rmclhip_map {
   uint32_t* d_cnodes = nullptr;  // Node4C twins
   uint32_t* d_tris = nullptr;
   uint64_t bytes = 0;
+  std::vector<uint32_t> scene_first_face;  // map_create_scene: first global face id of every instance, + the total (else empty)
 };
 
 struct rmclhip_rcc {
@@ -472,6 +473,135 @@ void rmclhip_map_release(rmclhip_map* map) {
     ctx_release(map->ctx);
     delete map;
   }
+}
+
+// ---- scenes: several meshes, placed (and possibly repeated) by affine transforms -----------------
+// The reference hands a whole assimp scene to rm::import_embree_map / import_optix_map (micp_localization.cpp:187-195), which
+// instance every mesh under its node's transform.  The hot path only ever sees world-space triangles, so the scene is flattened
+// once on the host -- vertices transformed in float like Embree's / OptiX's instance transforms would at build time, faces
+// renumbered -- and ONE tree is built over it (no two-level traversal: an instance costs its triangles again, which for the
+// maps RMCL localises in -- a few static meshes -- is the cheaper side of the trade).
+extern "C++" {
+namespace {
+std::string scene_flatten(const rmclhip_mesh* meshes, uint32_t n_meshes, const rmclhip_instance* inst, uint32_t n_inst,
+                          std::vector<float>& v, std::vector<uint32_t>& f, std::vector<uint32_t>& first_face) {
+#pragma clang fp contract(off)
+  if (!meshes || n_meshes == 0) return "no meshes";
+  for (uint32_t m = 0; m < n_meshes; ++m) {
+    if ((meshes[m].n_vertices && !meshes[m].vertices_xyz) || (meshes[m].n_faces && !meshes[m].faces_ijk))
+      return "mesh " + std::to_string(m) + ": null array";
+    for (uint32_t k = 0; k < 3u * meshes[m].n_faces; ++k)
+      if (meshes[m].faces_ijk[k] >= meshes[m].n_vertices)
+        return "mesh " + std::to_string(m) + ": face " + std::to_string(k / 3u) + " references vertex " +
+               std::to_string(meshes[m].faces_ijk[k]) + " of " + std::to_string(meshes[m].n_vertices);
+  }
+  const uint32_t n = inst ? n_inst : n_meshes;
+  uint64_t nv = 0, nf = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t m = inst ? inst[i].mesh : i;
+    if (m >= n_meshes) return "instance " + std::to_string(i) + ": mesh index " + std::to_string(m) + " of " + std::to_string(n_meshes);
+    nv += meshes[m].n_vertices;
+    nf += meshes[m].n_faces;
+  }
+  if (nv >= (1ull << 32) || nf >= (1ull << 32)) return "scene exceeds 2^32 vertices or faces";
+  v.resize(3 * nv);
+  f.resize(3 * nf);
+  first_face.assign(n + 1u, 0u);
+  size_t vo = 0, fo = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const rmclhip_mesh& M = meshes[inst ? inst[i].mesh : i];
+    const float* A = inst ? inst[i].transform : nullptr;
+    first_face[i] = static_cast<uint32_t>(fo);
+    for (uint32_t k = 0; k < M.n_vertices; ++k) {
+      const float x = M.vertices_xyz[3 * k], y = M.vertices_xyz[3 * k + 1], z = M.vertices_xyz[3 * k + 2];
+      float* o = &v[3 * (vo + k)];
+      if (A) {
+        // row by row, left to right, no contraction: the flattening is part of the parity surface (tests restate it in numpy)
+        for (int r = 0; r < 3; ++r) {
+          float acc = A[4 * r] * x;
+          acc = acc + A[4 * r + 1] * y;
+          acc = acc + A[4 * r + 2] * z;
+          o[r] = acc + A[4 * r + 3];
+        }
+      } else {
+        o[0] = x; o[1] = y; o[2] = z;
+      }
+    }
+    for (uint32_t k = 0; k < 3u * M.n_faces; ++k) f[3 * fo + k] = M.faces_ijk[k] + static_cast<uint32_t>(vo);
+    vo += M.n_vertices;
+    fo += M.n_faces;
+  }
+  first_face[n] = static_cast<uint32_t>(fo);
+  return std::string();
+}
+}  // namespace
+}  // extern "C++"
+
+rmclhip_status rmclhip_scene_flatten_host(const rmclhip_mesh* meshes, uint32_t n_meshes, const rmclhip_instance* instances,
+                                          uint32_t n_instances, float* vertices_out, size_t vertices_cap_floats,
+                                          uint32_t* faces_out, size_t faces_cap_dwords, uint32_t* first_face_out,
+                                          size_t first_face_cap, uint32_t* n_vertices, uint32_t* n_faces) {
+  ApiGuard guard_("rmclhip_scene_flatten_host");
+  std::vector<float> v;
+  std::vector<uint32_t> f, ff;
+  const std::string err = scene_flatten(meshes, n_meshes, instances, n_instances, v, f, ff);
+  if (!err.empty()) return fail(RMCLHIP_ERR_INVALID, "scene_flatten_host: " + err);
+  if (n_vertices) *n_vertices = static_cast<uint32_t>(v.size() / 3);
+  if (n_faces) *n_faces = static_cast<uint32_t>(f.size() / 3);
+  if ((vertices_out && vertices_cap_floats < v.size()) || (faces_out && faces_cap_dwords < f.size()) ||
+      (first_face_out && first_face_cap < ff.size()))
+    return fail(RMCLHIP_ERR_INVALID, "scene_flatten_host: output buffer too small");
+  if (vertices_out) std::memcpy(vertices_out, v.data(), v.size() * sizeof(float));
+  if (faces_out) std::memcpy(faces_out, f.data(), f.size() * sizeof(uint32_t));
+  if (first_face_out) std::memcpy(first_face_out, ff.data(), ff.size() * sizeof(uint32_t));
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_map_create_scene(rmclhip_ctx* ctx, const rmclhip_mesh* meshes, uint32_t n_meshes,
+                                        const rmclhip_instance* instances, uint32_t n_instances, rmclhip_map** out) {
+  ApiGuard guard_("rmclhip_map_create_scene");
+  if (!out) return fail(RMCLHIP_ERR_INVALID, "map_create_scene: out is null");
+  *out = nullptr;
+  if (!ctx) return fail(RMCLHIP_ERR_INVALID, "map_create_scene: ctx is null");
+  std::vector<float> v;
+  std::vector<uint32_t> f, ff;
+  std::string err = scene_flatten(meshes, n_meshes, instances, n_instances, v, f, ff);
+  if (!err.empty()) return fail(RMCLHIP_ERR_INVALID, "map_create_scene: " + err);
+  BvhHost bvh;
+  err = build_bvh(v.data(), static_cast<uint32_t>(v.size() / 3), f.data(), static_cast<uint32_t>(f.size() / 3), bvh);
+  if (!err.empty()) return fail(RMCLHIP_ERR_INVALID, "map_create_scene: " + err);
+  const rmclhip_status st = map_upload(ctx, bvh, out);
+  if (st == RMCLHIP_OK) (*out)->scene_first_face = std::move(ff);
+  return st;
+}
+
+rmclhip_status rmclhip_map_scene_instances(const rmclhip_map* map, uint32_t* first_face_out, size_t cap, uint32_t* n_instances) {
+  ApiGuard guard_("rmclhip_map_scene_instances");
+  if (!map) return fail(RMCLHIP_ERR_INVALID, "map_scene_instances: map is null");
+  // a map made by rmclhip_map_create is one instance of one mesh
+  const std::vector<uint32_t> single{0u, map->info.n_faces};
+  const std::vector<uint32_t>& t = map->scene_first_face.empty() ? single : map->scene_first_face;
+  if (n_instances) *n_instances = static_cast<uint32_t>(t.size() - 1);
+  if (first_face_out) {
+    if (cap < t.size()) return fail(RMCLHIP_ERR_INVALID, "map_scene_instances: first_face_out needs n_instances + 1 entries");
+    std::memcpy(first_face_out, t.data(), t.size() * sizeof(uint32_t));
+  }
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_map_scene_locate(const rmclhip_map* map, uint32_t face_id, uint32_t* instance, uint32_t* local_face) {
+  ApiGuard guard_("rmclhip_map_scene_locate");
+  if (!map) return fail(RMCLHIP_ERR_INVALID, "map_scene_locate: map is null");
+  if (face_id >= map->info.n_faces) return fail(RMCLHIP_ERR_INVALID, "map_scene_locate: face id out of range");
+  uint32_t i = 0, first = 0;
+  if (!map->scene_first_face.empty()) {
+    const auto it = std::upper_bound(map->scene_first_face.begin(), map->scene_first_face.end(), face_id);
+    i = static_cast<uint32_t>(it - map->scene_first_face.begin()) - 1u;
+    first = map->scene_first_face[i];
+  }
+  if (instance) *instance = i;
+  if (local_face) *local_face = face_id - first;
+  return RMCLHIP_OK;
 }
 
 rmclhip_status rmclhip_map_get_info(const rmclhip_map* map, rmclhip_map_info* out) {

@@ -110,6 +110,33 @@ class HipMap:
         self._h = C.c_void_p()
         _capi.check(_capi.lib().rmclhip_map_create(ctx.handle, _ptr(v), len(v), _ptr(f), len(f), C.byref(self._h)))
 
+    @classmethod
+    def from_scene(cls, ctx, meshes, instances=None):
+        """A whole scene (what rm::import_embree_map makes of an assimp file, micp_localization.cpp:187-195):
+        meshes = [(vertices, faces), ...]; instances = [(mesh index, 3x4 or 4x4 row-major affine), ...] or None for every
+        mesh once, untransformed.  Face ids are global, see scene_instances()."""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        cm, ci, keep = _scene_arrays(meshes, instances)
+        _capi.check(_capi.lib().rmclhip_map_create_scene(ctx.handle, cm, len(meshes), ci, 0 if instances is None else len(instances),
+                                                         C.byref(self._h)))
+        return self
+
+    def scene_instances(self):
+        """first global face id of every instance, + n_faces as the last entry"""
+        n = C.c_uint32()
+        _capi.check(_capi.lib().rmclhip_map_scene_instances(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value + 1, np.uint32)
+        _capi.check(_capi.lib().rmclhip_map_scene_instances(self._h, _ptr(out), len(out), C.byref(n)))
+        return out
+
+    def scene_locate(self, face_id):
+        """global face id -> (instance, face index within that instance's mesh)"""
+        i, k = C.c_uint32(), C.c_uint32()
+        _capi.check(_capi.lib().rmclhip_map_scene_locate(self._h, int(face_id), C.byref(i), C.byref(k)))
+        return i.value, k.value
+
     @property
     def handle(self):
         return self._h
@@ -129,6 +156,47 @@ class HipMap:
             self.release()
         except Exception:
             pass
+
+
+def _scene_arrays(meshes, instances):
+    """ctypes arrays of rmclhip_mesh / rmclhip_instance (+ the numpy arrays they borrow, to be kept alive by the caller)"""
+    keep = []
+    cm = (_capi.Mesh * len(meshes))()
+    for k, (v, f) in enumerate(meshes):
+        v = np.ascontiguousarray(v, dtype=np.float32).reshape(-1, 3)
+        f = np.ascontiguousarray(f, dtype=np.uint32).reshape(-1, 3)
+        keep += [v, f]
+        cm[k].vertices_xyz, cm[k].faces_ijk, cm[k].n_vertices, cm[k].n_faces = v.ctypes.data, f.ctypes.data, len(v), len(f)
+    ci = None
+    if instances is not None:
+        ci = (_capi.Instance * max(len(instances), 1))()
+        for k, (mesh, A) in enumerate(instances):
+            A = np.asarray(A, dtype=np.float32)
+            if A.shape not in ((3, 4), (4, 4)):
+                raise ValueError("instance transform must be 3x4 or 4x4 (row-major), got %r" % (A.shape,))
+            ci[k].mesh = int(mesh)
+            ci[k].transform[:] = A[:3].reshape(-1).tolist()
+    return cm, ci, keep
+
+
+def flatten_scene_host(meshes, instances=None):
+    """the host-side flattening map_create_scene performs, without a device: (vertices, faces, first_face)"""
+    cm, ci, keep = _scene_arrays(meshes, instances)
+    ni = 0 if instances is None else len(instances)
+    nv, nf = C.c_uint32(), C.c_uint32()
+    L = _capi.lib()
+    _capi.check(L.rmclhip_scene_flatten_host(cm, len(meshes), ci, ni, None, 0, None, 0, None, 0, C.byref(nv), C.byref(nf)))
+    v = np.zeros((nv.value, 3), np.float32)
+    f = np.zeros((nf.value, 3), np.uint32)
+    ff = np.zeros((len(meshes) if instances is None else ni) + 1, np.uint32)
+    _capi.check(L.rmclhip_scene_flatten_host(cm, len(meshes), ci, ni, _ptr(v), v.size, _ptr(f), f.size, _ptr(ff), ff.size,
+                                             C.byref(nv), C.byref(nf)))
+    return v, f, ff
+
+
+def import_hip_scene(ctx, meshes, instances=None):
+    """rm::import_embree_map analogue for a scene of several (instanced) meshes"""
+    return HipMap.from_scene(ctx, meshes, instances)
 
 
 def import_hip_map(ctx, vertices, faces):

@@ -77,6 +77,14 @@ def test_cpp_example_matches_python_and_oracle(ra, orc, ctx, meshes, tmp_path):
     assert np.allclose([float(x) for x in out["moment_form_t"]], [float(x) for x in out["device_loop_t"]], atol=1e-6)
     assert int(out["multi_loop_n_meas"][0]) == int(so["n_meas"])
     assert np.allclose([float(x) for x in out["multi_loop_t"]], t_ref, atol=1e-5)
+    # modelView(): PointCloudView_ {points, mask, normals} of the last find, read back through the views
+    mv = out["model_view"]
+    assert int(mv[0]) == meas["hits"].size and int(mv[1]) == int(meas["hits"].sum())
+    assert math.isclose(float(mv[2]), float(mv[3]), rel_tol=1e-5)          # |point| == range, summed over the hits
+    assert math.isclose(float(mv[4]), float(mv[1]), rel_tol=1e-5)          # unit normals
+    # the scene of two instances answers like the single mesh (the second instance is out of sight)
+    assert [int(x) for x in out["scene"]] == [2, 0, len(f), 2 * len(f)]
+    assert out["scene_hits"] == out["hits"] and out["scene_face_sum"] == out["face_sum"] and int(out["scene_instance_sum"][0]) == 0
     # Correspondences_::dataset written like the reference's device sensors write it == the setDataset*() hand-over
     assert int(out["dataset_member_valid"][0]) == int(mask.sum())
     assert out["dataset_member_n_meas"][0] == out["dataset_member_n_meas"][1] and int(out["dataset_member_n_meas"][0]) > 0
