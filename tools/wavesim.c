@@ -95,6 +95,8 @@ static int g_frontier_depth = 0;
 static uint64_t g_frontier_cands = 0;
 uint64_t orc_wavesim_frontier_cands(void) { uint64_t v = g_frontier_cands; g_frontier_cands = 0; return v; }
 void orc_wavesim_frontier(int depth) { g_frontier_depth = depth; }
+static int g_frontier_order = 0;
+void orc_wavesim_frontier_order(int o) { g_frontier_order = o; }
 static void ws_frontier(ws_lane* l, const uint32_t* nodes, uint32_t node, int depth, uint32_t* cand, float* ckey, int* nc)
 {
   const float* nd = (const float*)(nodes + 32u * node);
@@ -122,8 +124,17 @@ int orc_wavesim_ww(const uint32_t* nodes, const uint32_t* tris, const float* O, 
     if (g_frontier_depth > 0 && !L[i].done) {
       uint32_t cand[256]; float ckey[256]; int nc = 0;
       ws_frontier(&L[i], nodes, 0, 0, cand, ckey, &nc);
-      for (int a = 0; a < nc; ++a) for (int b = a + 1; b < nc; ++b)
-        if (ckey[b] < ckey[a]) { float t = ckey[a]; ckey[a] = ckey[b]; ckey[b] = t; uint32_t r = cand[a]; cand[a] = cand[b]; cand[b] = r; }
+      if (g_frontier_order == 0) {   /* fully sorted: nearest first, then by entry distance */
+        for (int a = 0; a < nc; ++a) for (int b = a + 1; b < nc; ++b)
+          if (ckey[b] < ckey[a]) { float t = ckey[a]; ckey[a] = ckey[b]; ckey[b] = t; uint32_t r = cand[a]; cand[a] = cand[b]; cand[b] = r; }
+      } else {                       /* what round 3's first kernel did: only the nearest is found, the others stay in table order */
+        int best = 0;
+        for (int a = 1; a < nc; ++a) if (ckey[a] < ckey[best]) best = a;
+        if (nc > 0) { float t = ckey[0]; ckey[0] = ckey[best]; ckey[best] = t; uint32_t r = cand[0]; cand[0] = cand[best]; cand[best] = r; }
+        if (g_frontier_order == 2)   /* ... and the two nearest */
+          { int b2 = 1; for (int a = 2; a < nc; ++a) if (ckey[a] < ckey[b2]) b2 = a;
+            if (nc > 1) { float t = ckey[1]; ckey[1] = ckey[b2]; ckey[b2] = t; uint32_t r = cand[1]; cand[1] = cand[b2]; cand[b2] = r; } }
+      }
       if (nc == 0) L[i].done = 1;
       else { for (int a = nc - 1; a >= 1; --a) { L[i].stack[L[i].sp] = cand[a]; L[i].stack_t[L[i].sp] = ckey[a]; L[i].sp++; } L[i].cur = cand[0]; }
       g_frontier_cands += (uint64_t)nc;
