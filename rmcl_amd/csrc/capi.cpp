@@ -238,6 +238,8 @@ struct rmclhip_rcc {
                           // (quad-cooperative), 15 automatic: quad while the launch is bound by the slowest ray's
                           // chain of dependent fetches (few rays in flight), one lane per ray once the chip is full
   int tile_override = 0;  // 1 + log2(tile width), 0 = automatic
+  DevBuf<float> d_tile_planes;     // plane table of the frontier start for the current (model, tiling): 16 floats per tile
+  bool tile_planes_ok = false;
   float last_find_ms = 0.f, last_reduce_ms = 0.f;
   bool reduce_timing_pending = false;
 };
@@ -676,7 +678,7 @@ void rmclhip_rcc_destroy(rmclhip_rcc* r) {
   if (r->h_fast_status) DBG_STEP(hipHostFree(r->h_fast_status));
   if (r->h_done) DBG_STEP(hipHostFree(r->h_done));
   r->d_cpc_rec.release();
-  r->d_fast_partials.release(); r->d_fast_mask.release();
+  r->d_fast_partials.release(); r->d_fast_mask.release(); r->d_tile_planes.release();
   r->d_multi_blob.release();
   if (r->h_multi_state) DBG_STEP(hipHostFree(r->h_multi_state));
   if (r->h_multi_status) DBG_STEP(hipHostFree(r->h_multi_status));
@@ -697,6 +699,8 @@ rmclhip_status rmclhip_rcc_set_tsb(rmclhip_rcc* r, const rmclhip_transform* Tsb)
   return RMCLHIP_OK;
 }
 
+static rmclhip_status rebuild_tile_planes(rmclhip_rcc* r);
+
 rmclhip_status rmclhip_rcc_set_model_spherical(rmclhip_rcc* r, const rmclhip_spherical_model* m) {
   ApiGuard guard_("rmclhip_rcc_set_model_spherical");
   if (!r || !m) return fail(RMCLHIP_ERR_INVALID, "rcc_set_model_spherical: null");
@@ -708,6 +712,7 @@ rmclhip_status rmclhip_rcc_set_model_spherical(rmclhip_rcc* r, const rmclhip_sph
   r->W = W; r->H = H;
   r->range = m->range;
   r->orig = mk3(0.f, 0.f, 0.f);
+  r->tile_planes_ok = false;
   if (W == 0 || H == 0) return RMCLHIP_OK;
   // trig tables with the host libm, exactly what rmagine's getDirection evaluates per ray:
   // phi = phi.min + float(vid) * phi.inc, theta likewise
@@ -724,7 +729,7 @@ rmclhip_status rmclhip_rcc_set_model_spherical(rmclhip_rcc* r, const rmclhip_sph
   }
   HIPCHK(r->d_model_tab.reserve(tab.size()));
   HIPCHK(upload_on(r->stream, r->d_model_tab.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
-  return RMCLHIP_OK;
+  return rebuild_tile_planes(r);
 }
 
 rmclhip_status rmclhip_rcc_set_model_o1dn(rmclhip_rcc* r, uint32_t width, uint32_t height, rmclhip_interval range,
@@ -739,11 +744,12 @@ rmclhip_status rmclhip_rcc_set_model_o1dn(rmclhip_rcc* r, uint32_t width, uint32
   r->range = range;
   r->orig = mk3(orig.x, orig.y, orig.z);
   const size_t n = static_cast<size_t>(width) * height;
+  r->tile_planes_ok = false;
   if (n == 0) return RMCLHIP_OK;
   if (!dirs) return fail(RMCLHIP_ERR_INVALID, "rcc_set_model_o1dn: dirs is null");
   HIPCHK(r->d_model_tab.reserve(3 * n));
   HIPCHK(upload_on(r->stream, r->d_model_tab.p, dirs, 3 * n * sizeof(float), hipMemcpyHostToDevice));
-  return RMCLHIP_OK;
+  return rebuild_tile_planes(r);
 }
 
 rmclhip_status rmclhip_rcc_set_model_pinhole(rmclhip_rcc* r, uint32_t width, uint32_t height, rmclhip_interval range,
@@ -759,7 +765,7 @@ rmclhip_status rmclhip_rcc_set_model_pinhole(rmclhip_rcc* r, uint32_t width, uin
   r->range = range;
   r->orig = mk3(0.f, 0.f, 0.f);
   r->pin_fc[0] = fx; r->pin_fc[1] = fy; r->pin_fc[2] = cx; r->pin_fc[3] = cy;
-  return RMCLHIP_OK;
+  return rebuild_tile_planes(r);
 }
 
 rmclhip_status rmclhip_rcc_set_model_ondn(rmclhip_rcc* r, uint32_t width, uint32_t height, rmclhip_interval range,
@@ -769,6 +775,7 @@ rmclhip_status rmclhip_rcc_set_model_ondn(rmclhip_rcc* r, uint32_t width, uint32
   HIPCHK(hipSetDevice(r->ctx->device));
   HIPCHK(hipStreamSynchronize(r->stream));
   r->kind = kModelOnDn;
+  r->tile_planes_ok = false;
   r->graph_dirty = true; r->fast_graph_dirty = true;
   r->W = width; r->H = height;
   r->range = range;
@@ -896,6 +903,7 @@ rmclhip_status rmclhip_rcc_set_input_pointcloud2(rmclhip_rcc* r, const uint8_t* 
   if (out_width) *out_width = ow;
   if (out_height) *out_height = oh;
   if (n_valid_out) *n_valid_out = 0;
+  r->tile_planes_ok = false;
   if (n == 0) return RMCLHIP_OK;
   HIPCHK(r->d_model_tab.reserve(3 * n));
   HIPCHK(r->d_ds_points.reserve(3 * n));
@@ -912,6 +920,7 @@ rmclhip_status rmclhip_rcc_set_input_pointcloud2(rmclhip_rcc* r, const uint8_t* 
   HIPCHK(launch_pointcloud2_unpack(d_data, L->point_step, L->row_step, L->offset_x, L->offset_y, L->offset_z, L->datatype == 8u,
                                    h.skip_begin, h.increment, w.skip_begin, w.increment, ow, oh, range.min, range.max,
                                    r->d_model_tab.p, r->d_ds_points.p, r->d_ds_mask.p, r->d_counter, r->stream));
+  if (rmclhip_status st = rebuild_tile_planes(r)) return st;   // the directions just written are the O1Dn model
   uint32_t nv = 0;
   HIPCHK(hipMemcpyAsync(&nv, r->d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
   HIPCHK(hipStreamSynchronize(r->stream));
@@ -977,6 +986,21 @@ static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
   p.nposes = nposes;
   p.hits = r->d_hits.p; p.ranges = r->d_ranges.p; p.points = r->d_points.p; p.normals = r->d_normals.p;
   p.face_ids = r->d_face_ids.p;
+  p.tile_planes = r->tile_planes_ok ? r->d_tile_planes.p : nullptr;
+}
+
+// The frontier start's plane table belongs to (model, tiling): rebuilt -- one small launch on the handle's stream -- by whatever
+// changes either (the model setters, set_variant's tile shape), never inside a find (finds are captured into graphs).
+static rmclhip_status rebuild_tile_planes(rmclhip_rcc* r) {
+  r->tile_planes_ok = false;
+  if (r->kind == kModelOnDn || r->kind == kModelNone || r->W == 0 || r->H == 0) return RMCLHIP_OK;
+  FindParams p;
+  fill_find_params(r, p, 1);
+  HIPCHK(r->d_tile_planes.reserve(static_cast<size_t>(p.tiles_x) * p.tiles_y * 16u));
+  HIPCHK(launch_tile_planes(p, r->kind, r->d_tile_planes.p, r->stream));
+  r->tile_planes_ok = true;
+  r->graph_dirty = true; r->fast_graph_dirty = true;
+  return RMCLHIP_OK;
 }
 
 static rmclhip_status find_enqueue(rmclhip_rcc* r, const xform& Tbm) {
@@ -1776,6 +1800,7 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
     return fail(RMCLHIP_ERR_UNSUPPORTED, "rcc_set_variant: this traversal kind is an experiment -- it lives in librmclhip_lab.so, "
                                          "which is not loaded (the product builds kinds 0, 2, 23, 24 and the automatic rule 15)");
   r->variant = kind;
+  const bool tiling_changed = r->tile_override != tile;
   r->tile_override = tile;
   r->fused_tail = ((variant >> 8) & 1) != 0;
   r->use_graph = ((variant >> 9) & 1) == 0;
@@ -1786,6 +1811,11 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
     r->loop_blocks = kLoopBlocks[(variant >> 10) & 7];
   }
   r->graph_dirty = true; r->fast_graph_dirty = true;
+  if (tiling_changed) {
+    HIPCHK(hipSetDevice(r->ctx->device));
+    HIPCHK(hipStreamSynchronize(r->stream));
+    return rebuild_tile_planes(r);
+  }
   return RMCLHIP_OK;
 }
 

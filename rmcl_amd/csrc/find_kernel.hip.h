@@ -27,6 +27,52 @@ constexpr int find_leaf_trigger(int trav) { return (trav == 19 || trav == 20 || 
 // kinds 23 / 24: kinds 19 / 22 whose rays start at the map's frontier (traverse.hip.h frontier_start) instead of the root
 constexpr bool find_frontier(int trav) { return trav == 23 || trav == 24; }
 
+// the ray of image position (cv, ch) in the SENSOR frame (loc = cv * W + ch)
+template <uint32_t kModel>
+__device__ __forceinline__ void find_ray_s(const FindParams& p, uint32_t cv, uint32_t ch, uint32_t loc, f3& dir_s, f3& orig_s) {
+  if (kModel == kModelSpherical) {
+    // rmagine SphericalModel::getDirection (convention pinned by rmcl_ros/src/util/conversions.cpp:174-188);
+    // the four trig tables hold the host libm values of cos/sin(phi_v), cos/sin(theta_h)
+    const float cp = p.model_tab[cv], sp = p.model_tab[p.H + cv];
+    const float ct = p.model_tab[2u * p.H + ch], st = p.model_tab[2u * p.H + p.W + ch];
+    dir_s = mk3(cp * ct, cp * st, sp);
+  } else if (kModel == kModelPinhole) {
+    dir_s = pinhole_direction(p.pin_f[0], p.pin_f[1], p.pin_c[0], p.pin_c[1], cv, ch);
+  } else if (kModel == kModelOnDn) {
+    const float* og = p.model_tab + 3u * static_cast<size_t>(loc);
+    const float* dr = p.model_tab + 3u * (static_cast<size_t>(p.W) * p.H + loc);
+    orig_s = mk3(og[0], og[1], og[2]);
+    dir_s = mk3(dr[0], dr[1], dr[2]);
+  } else {
+    dir_s = mk3(p.model_tab[3u * loc], p.model_tab[3u * loc + 1u], p.model_tab[3u * loc + 2u]);
+  }
+}
+
+// The plane table of the frontier start (traverse.hip.h: tile_planes_wave): one wave per tile of the scan image, 16 floats per
+// tile, in the sensor frame.  Run once per (model, tiling), not per find.  grid = ceil(ntiles / 4) blocks of 256.
+template <uint32_t kModel>
+__global__ void __launch_bounds__(256) k_tile_planes(const FindParams p, float* __restrict__ planes) {
+  const uint32_t lane = threadIdx.x & 63u, tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (tile >= p.tiles_x * p.tiles_y) return;
+  const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+  const uint32_t twl = p.tile_w_log2;
+  const uint32_t lx = lane & ((1u << twl) - 1u), ly = lane >> twl;
+  const uint32_t vid = (ty << (6u - twl)) + ly, hid = (tx << twl) + lx;
+  const bool valid = (vid < p.H) && (hid < p.W);
+  const uint32_t cv = valid ? vid : 0u, ch = valid ? hid : 0u;
+  f3 dir_s, orig_s = p.orig_s;
+  find_ray_s<kModel>(p, cv, ch, cv * p.W + ch, dir_s, orig_s);
+  const bool finite = (dir_s.x == dir_s.x) && (dir_s.y == dir_s.y) && (dir_s.z == dir_s.z);
+  float out[16];
+  tile_planes_wave(dir_s, valid && finite, twl, out);
+  if (lane < 16u) {
+    float v = out[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v = (lane == static_cast<uint32_t>(k)) ? out[k] : v;
+    planes[static_cast<size_t>(tile) * 16u + lane] = v;
+  }
+}
+
 // kClock: entry / traversal / store clocks of every wave go to p.wave_clock (tools/wave_timeline.py); the production
 // instantiations are built with kClock = false and contain no s_memtime
 template <uint32_t kModel, int kTrav, bool kClock = false>
@@ -83,27 +129,9 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   if (p.Tsm_arr != nullptr) { Tsm = p.Tsm_arr[pose]; Tms = p.Tms_arr[pose]; }
   else { Tsm = p.Tsm; Tms = p.Tms; }
 
-  f3 dir_s, org_m, orig_s = p.orig_s;
-  if (kModel == kModelSpherical) {
-    // rmagine SphericalModel::getDirection (convention pinned by rmcl_ros/src/util/conversions.cpp:174-188);
-    // the four trig tables hold the host libm values of cos/sin(phi_v), cos/sin(theta_h)
-    const float cp = p.model_tab[cv], sp = p.model_tab[p.H + cv];
-    const float ct = p.model_tab[2u * p.H + ch], st = p.model_tab[2u * p.H + p.W + ch];
-    dir_s = mk3(cp * ct, cp * st, sp);
-    org_m = Tsm.t;
-  } else if (kModel == kModelPinhole) {
-    dir_s = pinhole_direction(p.pin_f[0], p.pin_f[1], p.pin_c[0], p.pin_c[1], cv, ch);
-    org_m = Tsm.t;
-  } else if (kModel == kModelOnDn) {
-    const float* og = p.model_tab + 3u * static_cast<size_t>(loc);
-    const float* dr = p.model_tab + 3u * (static_cast<size_t>(p.W) * p.H + loc);
-    orig_s = mk3(og[0], og[1], og[2]);
-    dir_s = mk3(dr[0], dr[1], dr[2]);
-    org_m = xapply(Tsm, orig_s);
-  } else {
-    dir_s = mk3(p.model_tab[3u * loc], p.model_tab[3u * loc + 1u], p.model_tab[3u * loc + 2u]);
-    org_m = xapply(Tsm, orig_s);
-  }
+  f3 dir_s, orig_s = p.orig_s;
+  find_ray_s<kModel>(p, cv, ch, loc, dir_s, orig_s);
+  const f3 org_m = (kModel == kModelSpherical || kModel == kModelPinhole) ? Tsm.t : xapply(Tsm, orig_s);
   const f3 dir_m = qrot(Tsm.R, dir_s);
   const bool finite = (dir_m.x == dir_m.x) && (dir_m.y == dir_m.y) && (dir_m.z == dir_m.z);
   const float ray_tfar = (valid && finite) ? p.tfar : -1.0f;
@@ -125,13 +153,16 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
     TraceStart start;
     const TraceStart* sp0 = nullptr;
     if constexpr (find_frontier(kTrav) && kModel != kModelOnDn) {   // (OnDn: one origin per ray, no common pyramid)
-      if (kTrav == 23)
-        start = frontier_start<kFindBfRows, 1>(p.frontier, p.n_frontier, p.scene_center, p.scene_half_diag, org_m, dir_m, ray_tfar, lane,
-                                               p.tile_w_log2, lds_dyn + threadIdx.x, kBfStride);
-      else
-        start = frontier_start<16, 0>(p.frontier, p.n_frontier, p.scene_center, p.scene_half_diag, org_m, dir_m, ray_tfar, lane,
-                                      p.tile_w_log2, lds_dyn + threadIdx.x, blockDim.x);
-      sp0 = &start;
+      if (p.tile_planes != nullptr) {     // (no table: the rays start at the root)
+        const float* planes = p.tile_planes + static_cast<size_t>(__builtin_amdgcn_readfirstlane(tile)) * 16u;
+        if (kTrav == 23)
+          start = frontier_start<kFindBfRows, 1>(p.frontier, p.n_frontier, p.scene_center, p.scene_half_diag, planes, Tsm.R, p.tfar, org_m,
+                                                 dir_m, ray_tfar, lane, lds_dyn + threadIdx.x, kBfStride);
+        else
+          start = frontier_start<16, 0>(p.frontier, p.n_frontier, p.scene_center, p.scene_half_diag, planes, Tsm.R, p.tfar, org_m, dir_m,
+                                        ray_tfar, lane, lds_dyn + threadIdx.x, blockDim.x);
+        sp0 = &start;
+      }
     }
     if (kTrav == 4) trace_lane_ww<16, true>(p.qnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
     else if (kTrav == 22 || kTrav == 24)

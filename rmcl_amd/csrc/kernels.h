@@ -45,6 +45,7 @@ struct FindParams {
   uint32_t n_frontier;
   f3 scene_center;
   float scene_half_diag;
+  const float* tile_planes;      // per tile of the scan image: the pyramid of its rays in the sensor frame (k_tile_planes), or null
   // diagnostics (nullable): per physical wave {s_memtime at entry, at exit (low 32 bits), s_memrealtime at entry, tile | xcc << 24}
   uint32_t* wave_clock;
 };
@@ -187,6 +188,8 @@ hipError_t launch_micp_multi_init(const MicpMultiCall* call, MicpMultiState* sta
 hipError_t launch_micp_multi_step(const MicpMultiCall* call, MicpMultiState* state, hipStream_t s);
 
 hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStream_t s);
+// the plane table of the frontier start (kinds 23 / 24): tiles_x * tiles_y * 16 floats for p's model and tiling
+hipError_t launch_tile_planes(const FindParams& p, ModelKind kind, float* planes, hipStream_t s);
 // diagnostics (tools/probe_find.py): per-wave step timeline of one spherical scan; probe_log: tiles x 512 dwords
 hipError_t launch_find_probe(const FindParams& p, int mode, uint32_t* probe_log, hipStream_t s);
 hipError_t launch_cpc_find(const uint32_t* nodes, const uint32_t* tris, const float* dataset_points, uint32_t n,

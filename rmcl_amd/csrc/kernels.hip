@@ -1740,6 +1740,19 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
   return hipGetLastError();
 }
 
+hipError_t launch_tile_planes(const FindParams& p, ModelKind kind, float* planes, hipStream_t s) {
+  const uint32_t ntiles = p.tiles_x * p.tiles_y;
+  if (ntiles == 0u) return hipSuccess;
+  const dim3 grid((ntiles + 3u) / 4u), block(256);
+  switch (kind) {
+    case kModelSpherical: hipLaunchKernelGGL((k_tile_planes<kModelSpherical>), grid, block, 0, s, p, planes); break;
+    case kModelO1Dn: hipLaunchKernelGGL((k_tile_planes<kModelO1Dn>), grid, block, 0, s, p, planes); break;
+    case kModelPinhole: hipLaunchKernelGGL((k_tile_planes<kModelPinhole>), grid, block, 0, s, p, planes); break;
+    default: return hipErrorInvalidValue;   // OnDn: one origin per ray, no pyramid
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_find_probe(const FindParams& p, int mode, uint32_t* probe_log, hipStream_t s) {
   if (g_lab && g_lab->find_probe) return g_lab->find_probe(p, mode, probe_log, s);
   return hipErrorNotSupported;

@@ -990,10 +990,42 @@ __device__ __forceinline__ uint32_t lane_bcast(uint32_t v, uint32_t src_lane) {
   return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), static_cast<int>(src_lane)));
 }
 
+// The pyramid of one tile (= one wave's rays), in the SENSOR frame: four planes through the origin spanned by the corner rays of
+// the tile, normals inward and unit length, and per plane how far outside it the tile's worst ray points per unit length
+// (m = min over the rays of n.D, <= 0).  Both are properties of the sensor model and the tiling alone -- n.D is invariant under
+// the pose's rotation -- so they are computed once per model (k_tile_planes) and a find only rotates four normals.
+// out: n0.xyz m0 | n1.xyz m1 | n2.xyz m2 | n3.xyz m3 (wave-uniform values)
+__device__ __forceinline__ void tile_planes_wave(f3 D, bool active, uint32_t tile_w_log2, float (&out)[16]) {
+  const uint32_t tw = 1u << tile_w_log2;
+  const uint32_t c0 = 0u, c1 = tw - 1u, c2 = 64u - tw, c3 = 63u;
+  const f3 d0 = mk3(lane_bcast(D.x, c0), lane_bcast(D.y, c0), lane_bcast(D.z, c0));
+  const f3 d1 = mk3(lane_bcast(D.x, c1), lane_bcast(D.y, c1), lane_bcast(D.z, c1));
+  const f3 d2 = mk3(lane_bcast(D.x, c2), lane_bcast(D.y, c2), lane_bcast(D.z, c2));
+  const f3 d3 = mk3(lane_bcast(D.x, c3), lane_bcast(D.y, c3), lane_bcast(D.z, c3));
+  const f3 dc = add3(add3(d0, d1), add3(d2, d3));
+  f3 n[4] = {cross_fma(d0, d1), cross_fma(d1, d3), cross_fma(d3, d2), cross_fma(d2, d0)};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float len2 = (n[k].x * n[k].x + n[k].y * n[k].y) + n[k].z * n[k].z;
+    const bool usable = len2 > 1e-12f;    // degenerate (1-D tiles, coincident corner rays) or NaN: the plane is dropped (n = 0 keeps every box)
+    float sc = usable ? __builtin_amdgcn_rsqf(len2) : 0.0f;
+    if (dot_plain(n[k], dc) < 0.0f) sc = -sc;   // inward
+    n[k] = usable ? scale3(n[k], sc) : mk3(0.f, 0.f, 0.f);
+    const float s_lane = active ? dot_plain(n[k], D) : 0.0f;
+    const float m = fminf(wave_min_f32(s_lane), 0.0f);
+    out[4 * k] = n[k].x; out[4 * k + 1] = n[k].y; out[4 * k + 2] = n[k].z; out[4 * k + 3] = m;
+  }
+}
+
+// Frontier start: instead of walking the top levels of the tree, the wave culls the map's frontier table (the <= 256 child
+// references of BFS depth kFrontierDepth with their boxes) against the pyramid of its tile, then every lane tests the few
+// survivors against its own ray and starts with the accepted ones on its stack, the two nearest on top.
+// planes: this tile's 16 floats of the model's plane table (uniform address); Rsm: the pose's rotation sensor -> map.
 template <int kRows, int kRow0>
 __device__ __forceinline__ TraceStart frontier_start(const uint32_t* __restrict__ frontier, uint32_t n_frontier, f3 scene_center,
-                                                     float scene_half_diag, f3 O, f3 D, float ray_tfar, uint32_t lane,
-                                                     uint32_t tile_w_log2, uint32_t* __restrict__ lds_col, uint32_t lds_stride) {
+                                                     float scene_half_diag, const float* __restrict__ planes, quat Rsm, float tfar,
+                                                     f3 O, f3 D, float ray_tfar, uint32_t lane, uint32_t* __restrict__ lds_col,
+                                                     uint32_t lds_stride) {
   constexpr uint32_t kDone = 0x7FFFFFFFu;
   const bool active = ray_tfar >= 0.0f;
   TraceStart root;
@@ -1009,33 +1041,19 @@ __device__ __forceinline__ TraceStart frontier_start(const uint32_t* __restrict_
     ea[k] = F[2u * idx];
     eb[k] = F[2u * idx + 1u];
   }
-  // 1. the pyramid: corner lanes of the tile (row-major tile of width tw), centre = sum of the corners
-  const uint32_t tw = 1u << tile_w_log2;
-  const uint32_t c0 = 0u, c1 = tw - 1u, c2 = 64u - tw, c3 = 63u;
-  const f3 d0 = mk3(lane_bcast(D.x, c0), lane_bcast(D.y, c0), lane_bcast(D.z, c0));
-  const f3 d1 = mk3(lane_bcast(D.x, c1), lane_bcast(D.y, c1), lane_bcast(D.z, c1));
-  const f3 d2 = mk3(lane_bcast(D.x, c2), lane_bcast(D.y, c2), lane_bcast(D.z, c2));
-  const f3 d3 = mk3(lane_bcast(D.x, c3), lane_bcast(D.y, c3), lane_bcast(D.z, c3));
-  const f3 dc = add3(add3(d0, d1), add3(d2, d3));
-  f3 n[4] = {cross_fma(d0, d1), cross_fma(d1, d3), cross_fma(d3, d2), cross_fma(d2, d0)};
-  float off[4];
+  // 1. the tile's pyramid in the map frame
+  const uint4 P0 = sload4(reinterpret_cast<const uint32_t*>(planes), 0u), P1 = sload4(reinterpret_cast<const uint32_t*>(planes), 16u);
+  const uint4 P2 = sload4(reinterpret_cast<const uint32_t*>(planes), 32u), P3 = sload4(reinterpret_cast<const uint32_t*>(planes), 48u);
+  f3 n[4] = {qrot(Rsm, mk3(asf(P0.x), asf(P0.y), asf(P0.z))), qrot(Rsm, mk3(asf(P1.x), asf(P1.y), asf(P1.z))),
+             qrot(Rsm, mk3(asf(P2.x), asf(P2.y), asf(P2.z))), qrot(Rsm, mk3(asf(P3.x), asf(P3.y), asf(P3.z)))};
+  const float mq[4] = {asf(P0.w), asf(P1.w), asf(P2.w), asf(P3.w)};
   // the farthest a hit can be from this origin: inside the map's bounding sphere, and within the sensor's range
   const f3 oc = sub3(O, scene_center);
-  const float reach = fminf(ray_tfar, sqrtf((oc.x * oc.x + oc.y * oc.y) + oc.z * oc.z) + scene_half_diag);
-  const float reach_u = wave_min_f32(active ? -reach : 0.0f);   // = -(largest reach of the wave's active rays)
+  const float reach = fminf(tfar, sqrtf((oc.x * oc.x + oc.y * oc.y) + oc.z * oc.z) + scene_half_diag);
+  float off[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float len2 = (n[k].x * n[k].x + n[k].y * n[k].y) + n[k].z * n[k].z;
-    const bool usable = len2 > 1e-12f;    // degenerate (1-D tiles, coincident corner rays) or NaN: the plane is dropped
-    float sc = usable ? __builtin_amdgcn_rsqf(len2) : 0.0f;
-    if (dot_plain(n[k], dc) < 0.0f) sc = -sc;   // inward
-    n[k] = scale3(n[k], sc);
-    // how far outside the plane the wave's worst active ray points (<= 0), per unit length along the ray
-    const float s_lane = active ? dot_plain(n[k], D) : 0.0f;
-    const float m = fminf(wave_min_f32(s_lane), 0.0f);
-    // offset in metres at the farthest possible hit + slack for the rounding of this test itself
-    off[k] = m * (-reach_u) - 1e-4f * (-reach_u) - 1e-6f;
-  }
+  for (int k = 0; k < 4; ++k)   // offset in metres at the farthest possible hit + slack for the rounding of the rotation and of this test
+    off[k] = mq[k] * reach - 1e-4f * reach - 1e-6f;
   // 2. my entries against the pyramid: the box's vertex farthest along n ("positive vertex") is at n.c + |n|.h from the origin
   // (c = centre - O, h = half extent); in doubled quantities (2c = lo + hi - 2 O, 2h = hi - lo) that is six FMAs per plane
   f3 an[4];
