@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   const bool finite = (dir_m.x == dir_m.x) && (dir_m.y == dir_m.y) && (dir_m.z == dir_m.z);
   const float ray_tfar = (valid && finite) ? p.tfar : -1.0f;
 
-  uint32_t clk_trace0 = 0, clk_trace1 = 0;
+  uint32_t clk_trace0 = 0, clk_trace1 = 0, clk_visits = 0, clk_dbg[3] = {0u, 0u, 0u};
   if (kClock && p.wave_clock != nullptr) {
     uint64_t t;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
       trace_lane_bf_tail<kFindBfRows, kTrav != 16 && kTrav != 20, find_leaf_trigger(kTrav)>(p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x,
                                                    lds_dyn + kFindBfRows * 256u,
                                                    lds_dyn + kFindBfRows * 256u + kQuadStackEntries * 64u + (threadIdx.x >> 6) * (kTailRays * kTailXferDwords), h,
-                                                   nullptr, sp0);
+                                                   kClock ? &clk_visits : nullptr, sp0, kClock ? clk_dbg : nullptr);
     else if (kTrav == 13) trace_lane_bf<kFindBfRows, false, false, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
     else if (kTrav == 14) trace_lane_bf<kFindBfRows, false, true, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
     else if (kTrav >= 5 && kTrav <= 10)
@@ -234,10 +234,16 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
     asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");  // ... and completed
     uint32_t xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    // diagnostics of the lane traversals with counters: hardest ray's node visits | rays handed to quads | steps on the general
+    // (scratch-capable) path | cycles inside the quad tail / 64
+    auto wmax = [](uint32_t v, int bits) { uint32_t m = 0; for (int b = bits - 1; b >= 0; --b) { const uint32_t c = m | (1u << b); if (__any(v >= c)) m = c; } return m; };
+    const uint32_t clk_w7 = wmax(min(clk_visits, 63u), 6) | (wmax(min(clk_dbg[1], 31u), 5) << 6) | (wmax(min(clk_dbg[0], 511u), 9) << 11) |
+                            (wmax(min(clk_dbg[2] >> 6, 4095u), 12) << 20);
     if ((threadIdx.x & 63u) == 0u) {
       uint32_t* w = p.wave_clock + 8u * ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + wave);
       w[0] = clk_begin; w[1] = static_cast<uint32_t>(t); w[2] = clk_real; w[3] = (tile & 0xFFFFFFu) | (xcc << 24);
-      w[4] = clk_trace0; w[5] = clk_trace1; w[6] = static_cast<uint32_t>(t2); w[7] = 0u;
+      w[4] = clk_trace0; w[5] = clk_trace1; w[6] = static_cast<uint32_t>(t2);
+      w[7] = clk_w7;
     }
   }
 }

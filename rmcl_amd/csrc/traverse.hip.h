@@ -838,11 +838,12 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
                                                    const uint32_t* __restrict__ tris, f3 O, f3 D, float ray_tfar,
                                                    uint32_t* __restrict__ lds_col, uint32_t* __restrict__ qstack,
                                                    uint32_t* __restrict__ xfer_wave, RayHit& h, uint32_t* visits = nullptr,
-                                                   const TraceStart* start = nullptr) {
+                                                   const TraceStart* start = nullptr, uint32_t* dbg = nullptr) {
   const RaySlab rs = make_ray_slab(O, D);
   float best_t = ray_tfar;
   uint32_t best_rec = kNone;
   uint32_t nvis = 0;  // node visits of this ray
+  uint32_t dbg_slow = 0, dbg_na = 0, dbg_tail = 0;
   constexpr uint32_t kDone = 0x7FFFFFFFu;
   uint32_t priv[(kRows < 65) ? (65 - kRows) : 1];
   lds_col[0] = kDone;
@@ -880,7 +881,10 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
       const float tfq = have ? asf(x[6]) : -1.0f;
       RayHit hq;
       uint32_t qvis = 0;
+      uint64_t tq0 = 0, tq1 = 0;
+      if (dbg) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq0) : : "memory");
       trace_quad<true>(cnodes, tris, Oq, Dq, tfq, c, wave * kTailRays + q, qstack, hq, &rsm, &qvis);
+      if (dbg) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq1) : : "memory"); dbg_tail = static_cast<uint32_t>(tq1 - tq0); dbg_na = na; }
       if (have && c == 0u) {
         uint32_t* y = xfer_wave + q * kTailXferDwords;
         y[7] = __float_as_uint(hq.t); y[9] = hq.rec; y[10] = qvis;
@@ -910,6 +914,7 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
         cur = any ? ref[0] : top;                                                                            \
         sp = any ? sp : (sp - 1u);                                                                           \
       } else {                                                                                               \
+        ++dbg_slow;                                                                                          \
         node_keys_off(nodes, cur << 7, rs, best_t, key, ref);                                                \
         RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)                 \
         if (key[3] != kNone) { RMCL_ROW_ST(sp, ref[3]) ++sp; }                                               \
@@ -945,6 +950,7 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
   h.t = best_t;
   h.rec = best_rec;
   if (visits) *visits = nvis;
+  if (dbg) { dbg[0] = dbg_slow; dbg[1] = dbg_na; dbg[2] = dbg_tail; }
 }
 
 // ---------------------------------------------------------------------------------------------

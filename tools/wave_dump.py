@@ -23,5 +23,5 @@ rcc.set_traversal(kind)
 rcc.time_find(pose, 20)
 w = rcc.debug_wave_clock(pose)
 w = w[w[:, 1] != 0].astype(np.int64)
-np.savez(out, tile=w[:, 3] & 0xFFFFFF, whole=(w[:, 1] - w[:, 0]) & 0xFFFFFFFF, trav=(w[:, 5] - w[:, 4]) & 0xFFFFFFFF)
+np.savez(out, tile=w[:, 3] & 0xFFFFFF, whole=(w[:, 1] - w[:, 0]) & 0xFFFFFFFF, trav=(w[:, 5] - w[:, 4]) & 0xFFFFFFFF, maxvis=w[:, 7] & 63, tail_rays=(w[:, 7] >> 6) & 31, slow_steps=(w[:, 7] >> 11) & 511, tail_cycles=((w[:, 7] >> 20) & 4095) * 64)
 print(mesh, kind, len(w), "waves; slowest", ((w[:, 1] - w[:, 0]) & 0xFFFFFFFF).max())
