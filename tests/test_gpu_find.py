@@ -206,6 +206,58 @@ def test_grow_only_buffers_and_refind(ra, orc, ctx, meshes):
         _compare(rcc.modelView(), m.simulate_spherical(model, T.identity(), Tbm, bvh=False), "regrow")
 
 
+@pytest.mark.parametrize("kind", [23, 24])
+def test_frontier_plane_table_follows_model_and_tiling(ra, orc, ctx, meshes, kind):
+    """The frontier start (kinds 23 / 24) reads the pyramid of every tile from a table that belongs to (model, tiling) and is
+    rebuilt by the model setters and by set_variant's tile shape.  One operator walks through spherical models of three sizes,
+    an O1Dn model with NaN directions, a pinhole model and three tile shapes; every scan must equal the scan of the packet
+    traversal (kind 0: no table, no frontier) bit for bit -- a stale table would cull boxes the new tiles' rays enter."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room30k")
+    hm = ra.import_hip_map(ctx, v, f)
+    Tbm = T.transform_from_rpy((1.5, -2.0, 1.6), (0.02, -0.03, 0.4))
+
+    def scan(op, tile_bits=0):
+        out = {}
+        for k in (kind, 0):
+            op.set_variant((k & 15) | ((k >> 4) << 13) | (tile_bits << 4))
+            op.find(Tbm)
+            out[k] = op.modelView()
+        for key in ("hits", "ranges", "points", "normals", "face_ids"):
+            assert np.array_equal(out[kind][key], out[0][key], equal_nan=True), key
+        return int(out[0]["hits"].sum())
+
+    rcc = ra.RCCHipSpherical(hm)
+    rcc.setTsb(syn.tsb_offset())
+    hits = []
+    for model in (syn.model_c2(), syn.model_c1(), syn.model_pf16(), syn.model_c2()):
+        rcc.setModel(model)
+        hits.append(scan(rcc))
+        for tile_bits in (1, 3, 5, 0):          # 1 + log2(tile width): 1x64, 4x16, 16x4 rays per wave, then automatic again
+            assert scan(rcc, tile_bits) == hits[-1]
+    assert hits[0] == hits[-1] and hits[0] > 100000
+    rcc.close()
+    # O1Dn on the same map: directions are data (every 7th one NaN), then a different size on the same operator
+    model = syn.model_c2()
+    dirs = syn.model_directions(model).reshape(-1, 3).copy()
+    dirs[::7] = np.nan
+    ro = ra.RCCHipO1Dn(hm)
+    ro.setTsb(T.identity())
+    ro.setModel(model.theta.size, model.phi.size, 0.3, 120.0, (0.1, 0.0, 0.2), dirs)
+    n1 = scan(ro)
+    half = (model.phi.size // 2) * model.theta.size
+    ro.setModel(model.theta.size, model.phi.size // 2, 0.3, 120.0, (0.1, 0.0, 0.2), dirs[:half])
+    n2 = scan(ro)
+    assert 0 < n2 < n1
+    ro.close()
+    rp = ra.RCCHipPinhole(hm)
+    rp.setTsb(T.identity())
+    for (w, h) in ((640, 480), (97, 33)):
+        rp.setModel(w, h, 0.1, 100.0, 0.8 * w, 0.8 * w, 0.5 * w, 0.5 * h)
+        assert scan(rp) > 0
+    rp.close()
+
+
 def test_far_from_origin_mesh(ra, orc, ctx):
     """conservative slab test: a mesh 5 km from the origin (large absolute coordinates) must still
     give brute-force-identical face ids."""
