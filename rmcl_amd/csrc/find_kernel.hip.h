@@ -25,7 +25,9 @@ constexpr uint32_t kFindTailLdsDwords = 16u * 256u + kQuadStackEntries * 64u + 4
 // kinds 19..22: kind 17 + leaving the node phase when 32 / 24 / 16 / 8 lanes hold a leaf
 constexpr int find_leaf_trigger(int trav) { return (trav == 19 || trav == 20 || trav == 23) ? 10 : 0; }   // leave at <= 4/10 of the round's rays
 // kinds 23 / 24: kinds 19 / 22 whose rays start at the map's frontier (traverse.hip.h frontier_start) instead of the root
-constexpr bool find_frontier(int trav) { return trav == 23 || trav == 24; }
+constexpr bool find_frontier(int trav) { return trav == 23 || trav == 24 || trav == 25; }
+// kind 25: kind 2 (four lanes per ray) with the frontier start
+constexpr bool find_quad(int trav) { return trav == 2 || trav == 25; }
 
 // the ray of image position (cv, ch) in the SENSOR frame (loc = cv * W + ch)
 template <uint32_t kModel>
@@ -79,7 +81,7 @@ template <uint32_t kModel, int kTrav, bool kClock = false>
 __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   extern __shared__ uint32_t lds_dyn[];
   constexpr bool kPacket = (kTrav == 0);
-  constexpr bool kQuad = (kTrav == 2);
+  constexpr bool kQuad = find_quad(kTrav);
   constexpr int kTop = find_top_nodes(kTrav);
   const uint32_t lane = kQuad ? (threadIdx.x >> 2) : (threadIdx.x & 63u), wave = threadIdx.x >> 6;
   const uint32_t sub = threadIdx.x & 3u;  // quad mode: child slot / triangle slot / output role of this lane
@@ -113,7 +115,7 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   // tiles so neighbouring tiles (which walk the same subtrees) share one L2.  gridDim.x % 8 == 0.
   const uint32_t chunk = gridDim.x >> 3;
   const uint32_t vb = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
-  const uint32_t tile = ((kTrav == 2) ? vb : (vb * 4u + wave));
+  const uint32_t tile = (kQuad ? vb : (vb * 4u + wave));
   const uint32_t ntiles = p.tiles_x * p.tiles_y;
   if (tile >= ntiles) return;
   const uint32_t pose = blockIdx.y;
@@ -146,7 +148,22 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   if (kPacket) {
     trace_packet((cu32p)(p.nodes), (cu32p)(p.tris), org_m, dir_m, ray_tfar, lane, h);
   } else if (kQuad) {
-    trace_quad(p.cnodes, p.tris, org_m, dir_m, ray_tfar, sub, lane, lds_dyn, h);
+    bool started = false;
+    if constexpr (kTrav == 25 && kModel != kModelOnDn) {
+      if (p.tile_planes != nullptr) {
+        // the block's 64-ray tile has ONE pyramid; each wave (16 rays x 4 lanes) culls the frontier against it with its 64 lanes
+        // and every lane filters the survivors with its ray (the four lanes of a ray agree and store the same rows)
+        const float* planes = p.tile_planes + static_cast<size_t>(__builtin_amdgcn_readfirstlane(tile)) * 16u;
+        const TraceStart st = frontier_start<static_cast<int>(kQuadStackEntries), 1>(
+            p.frontier, p.n_frontier, p.scene_center, p.scene_half_diag, planes, Tsm.R, p.tfar, org_m, dir_m, ray_tfar, threadIdx.x & 63u,
+            lds_dyn + lane, 64u);
+        QuadResume rsm;
+        rsm.cur = st.cur; rsm.n_stack = st.sp - 1u; rsm.best_t = ray_tfar; rsm.best_face = kInvalidFace; rsm.best_rec = 0u;
+        trace_quad<true>(p.cnodes, p.tris, org_m, dir_m, ray_tfar, sub, lane, lds_dyn, h, &rsm);
+        started = true;
+      }
+    }
+    if (!started) trace_quad(p.cnodes, p.tris, org_m, dir_m, ray_tfar, sub, lane, lds_dyn, h);
   } else {
     // kind 4 serves launches that fill the chip (pose batches): throughput, not the slowest wave's chain, is what counts there, and
     // the branchy step with its partial sort and 16 LDS rows (more resident waves) is 11 % faster than the branch-free one

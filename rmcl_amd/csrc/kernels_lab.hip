@@ -385,7 +385,7 @@ hipError_t lab_find_one(const FindParams& p, dim3 grid, size_t lds, hipStream_t 
 template <bool kClock>
 hipError_t lab_find_kind(const FindParams& p, int variant, hipStream_t s) {
   const uint32_t ntiles = p.tiles_x * p.tiles_y;
-  uint32_t nblocks = (variant == 2) ? ntiles : (ntiles + 3u) / 4u;
+  uint32_t nblocks = (variant == 2 || variant == 25) ? ntiles : (ntiles + 3u) / 4u;
   nblocks = (nblocks + 7u) & ~7u;  // the XCD remap in k_find needs gridDim.x % 8 == 0
   const dim3 grid(nblocks, p.nposes, 1);
   const size_t lds_bf = static_cast<size_t>(kFindBfRows) * 256u * sizeof(uint32_t);
@@ -415,6 +415,7 @@ hipError_t lab_find_kind(const FindParams& p, int variant, hipStream_t s) {
     case 22: return lab_find_one<22, kClock>(p, grid, lds_ww, s);
     case 23: return lab_find_one<23, kClock>(p, grid, lds_bf_tail, s);                         // 19 + frontier start
     case 24: return lab_find_one<24, kClock>(p, grid, lds_ww, s);                              // 22 + frontier start
+    case 25: return lab_find_one<25, kClock>(p, grid, kQuadStackEntries * 64u * sizeof(uint32_t), s);   // 2 + frontier start
     default: return hipErrorNotSupported;
   }
 }
