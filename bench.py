@@ -226,6 +226,8 @@ def main():
             rms = median_kernel_ms(lambda: rr.time_find(Troom, iters=40), 5)
             extras["find_room100k_ms"] = round(rms, 5)
             extras["find_room100k_rays_per_s"] = round(n_rays / (rms * 1e-3), 1)
+            k_t, ms_t = rr.autotune(Troom)
+            extras["find_room100k_autotuned"] = {"rule_kind": 23, "chosen_kind": k_t, "ms": round(ms_t, 5)}
             rr.close()
             rpms, _ = _pf_c4(ra, syn, T, np, ctx, hmr, 100000, 256, iters=3, bb=((-9, -9, 0.3), (9, 9, 3)))
             extras["c4_room100k_pf_update_ms"] = round(rpms, 4)
@@ -265,6 +267,9 @@ def main():
             sms = small.time_find(Tbm, iters=100)
             extras["find_16x900_ms"] = round(sms, 5)
             extras["find_16x900_rays_per_s"] = round(16 * 900 / (sms * 1e-3), 1)
+            # measurement-driven choice of the traversal on the operator's own map / model (rmclhip_rcc_autotune) instead of the rule
+            k_t, ms_t = small.autotune(Tbm)
+            extras["find_16x900_autotuned"] = {"rule_kind": 2, "chosen_kind": k_t, "ms": round(ms_t, 5)}
             # the reference's own (stale) benchmark shape: 1000 poses x vlp16_900 per correct() call, sphere with
             # 100k faces (lidar_corrector_{embree,optix}_benchmark.cpp; BASELINE.md: OptiX 73.7 k, Embree 5.5 k
             # corrections/s on the authors' hardware)

@@ -305,6 +305,12 @@ class Correspondences_<VRAM_HIP> {
     v.mask = {dataset.mask.raw(), dataset.mask.size()};
     return v;
   }
+  // measurement-driven choice of the single-scan traversal for this map and model (rmclhip.h: rmclhip_rcc_autotune); returns the kind
+  int autotune(const Transform& Tbm_est) {
+    int kind = 0;
+    check(rmclhip_rcc_autotune(h_, &Tbm_est, &kind, nullptr));
+    return kind;
+  }
   // modelView() (Correspondences.hpp:47-53): PointCloudView_ {points, mask = hits, normals} over the model buffers of the last
   // find -- the shape MICPSensorCUDA.cpp:66-84 reads
   PointCloudView_<VRAM_HIP> modelView() const {

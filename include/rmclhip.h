@@ -378,6 +378,13 @@ rmclhip_status rmclhip_rcc_set_micp_fast(rmclhip_rcc* rcc, int mode);
 rmclhip_status rmclhip_rcc_micp_fast_info(const rmclhip_rcc* rcc, rmclhip_micp_fast_info* out);
 /* the traversal (bits 0..3 above, never 15) a find of `nposes` scans of the current model would launch */
 rmclhip_status rmclhip_rcc_find_variant(const rmclhip_rcc* rcc, uint32_t nposes, int* variant_out);
+/* Measurement instead of brackets: the automatic rule above was tuned on two synthetic maps; which traversal is fastest for a
+ * single scan depends on the map (open / occluded), the model's size and shape, and where the sensor is.  This call times the
+ * product's single-scan kinds (2, 23, 24) on THIS operator's map and model at the given pose (15 short launches each, HIP
+ * events) and makes the fastest one the automatic choice for single scans until the model or the tiling changes.  Results do not
+ * depend on the kind (bit-identical); batches keep the rule.  Opt-in: never run behind the caller's back.
+ * chosen_kind / kernel_ms may be NULL. */
+rmclhip_status rmclhip_rcc_autotune(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est, int* chosen_kind, float* kernel_ms);
 /* rm::Simulator::simulate(Memory<Transform>, Bundle&) (batch form, lidar_corrector_embree_benchmark.cpp:117):
  * one launch for nposes x H x W rays; model buffers become pose-major [pose][vid][hid]. */
 rmclhip_status rmclhip_rcc_find_batch(rmclhip_rcc* rcc, const rmclhip_transform* Tbm, uint32_t nposes);

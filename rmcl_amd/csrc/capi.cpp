@@ -238,6 +238,7 @@ struct rmclhip_rcc {
                           // (quad-cooperative), 15 automatic: quad while the launch is bound by the slowest ray's
                           // chain of dependent fetches (few rays in flight), one lane per ray once the chip is full
   int tile_override = 0;  // 1 + log2(tile width), 0 = automatic
+  int tuned_kind = 0;              // rmclhip_rcc_autotune: the single-scan kind measured fastest for the current (map, model); 0 = none
   DevBuf<float> d_tile_planes;     // plane table of the frontier start for the current (model, tiling): 16 floats per tile
   bool tile_planes_ok = false;
   float last_find_ms = 0.f, last_reduce_ms = 0.f;
@@ -776,6 +777,7 @@ rmclhip_status rmclhip_rcc_set_model_ondn(rmclhip_rcc* r, uint32_t width, uint32
   HIPCHK(hipStreamSynchronize(r->stream));
   r->kind = kModelOnDn;
   r->tile_planes_ok = false;
+  r->tuned_kind = 0;
   r->graph_dirty = true; r->fast_graph_dirty = true;
   r->W = width; r->H = height;
   r->range = range;
@@ -949,6 +951,7 @@ static rmclhip_status ensure_model_buffers(rmclhip_rcc* r, size_t n_total) {
 // traversal kind of a launch of `nposes` scans (tools/latency_explore.py, tools/perf_explore.py)
 static int find_variant(const rmclhip_rcc* r, uint32_t nposes) {
   if (r->variant != 15) return r->variant;
+  if (nposes == 1u && r->tuned_kind != 0) return r->tuned_kind;   // measured on this operator's own map and model (rmclhip_rcc_autotune)
   const uint64_t rays = static_cast<uint64_t>(r->W) * r->H * nposes;
   if (rays <= 57344u) return 2;   // bound by the slowest ray's fetch chain: four lanes per ray (crossover measured between
                                   // 49152 rays -- quads 13.6 / 20.8 us vs 16.4 / 23.4 -- and 65536 -- 15.9 / 26.3 vs 16.3 / 23.7)
@@ -993,6 +996,7 @@ static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
 // changes either (the model setters, set_variant's tile shape), never inside a find (finds are captured into graphs).
 static rmclhip_status rebuild_tile_planes(rmclhip_rcc* r) {
   r->tile_planes_ok = false;
+  r->tuned_kind = 0;   // a measurement belongs to the model it was taken with
   if (r->kind == kModelOnDn || r->kind == kModelNone || r->W == 0 || r->H == 0) return RMCLHIP_OK;
   FindParams p;
   fill_find_params(r, p, 1);
@@ -1747,6 +1751,33 @@ rmclhip_status rmclhip_rcc_time_find(rmclhip_rcc* r, const rmclhip_transform* Tb
   float total = 0.f;
   HIPCHK(hipEventElapsedTime(&total, r->ev0, r->ev1));
   *ms = total / static_cast<float>(iters);
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_autotune(rmclhip_rcc* r, const rmclhip_transform* Tbm_est, int* chosen_kind, float* kernel_ms) {
+  ApiGuard guard_("rmclhip_rcc_autotune");
+  if (!r || !Tbm_est) return fail(RMCLHIP_ERR_INVALID, "rcc_autotune: bad arguments");
+  if (r->kind == kModelNone || r->W == 0 || r->H == 0) return fail(RMCLHIP_ERR_INVALID, "rcc_autotune: no sensor model");
+  if (r->variant != 15) return fail(RMCLHIP_ERR_INVALID, "rcc_autotune: a traversal kind is forced (set_variant); nothing to choose");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  // the product's single-scan kinds, each timed on THIS map, model and pose: median of 5 batches of 8 back-to-back launches
+  static const int kCandidates[3] = {2, 23, 24};
+  int best = 0;
+  float best_ms = 0.f;
+  const int saved = r->tuned_kind;
+  for (int k : kCandidates) {
+    r->tuned_kind = k;
+    float t[5];
+    for (float& x : t) {
+      if (rmclhip_status st = rmclhip_rcc_time_find(r, Tbm_est, 8, &x)) { r->tuned_kind = saved; return st; }
+    }
+    std::sort(t, t + 5);
+    if (best == 0 || t[2] < best_ms) { best = k; best_ms = t[2]; }
+  }
+  r->tuned_kind = best;
+  r->graph_dirty = true; r->fast_graph_dirty = true;
+  if (chosen_kind) *chosen_kind = best;
+  if (kernel_ms) *kernel_ms = best_ms;
   return RMCLHIP_OK;
 }
 

@@ -406,6 +406,14 @@ class CorrespondencesHIP:
     def set_variant(self, variant):
         _capi.check(_capi.lib().rmclhip_rcc_set_variant(self._h, int(variant)))
 
+    def autotune(self, Tbm_est):
+        """time the product's single-scan traversals on this map / model / pose and keep the fastest as the automatic choice
+        (rmclhip.h: rmclhip_rcc_autotune); returns (kind, kernel milliseconds)"""
+        T = np.ascontiguousarray(Tbm_est, dtype=TRANSFORM).reshape(1)
+        kind, ms = C.c_int(), C.c_float()
+        _capi.check(_capi.lib().rmclhip_rcc_autotune(self._h, _ptr(T), C.byref(kind), C.byref(ms)))
+        return kind.value, ms.value
+
     def set_traversal(self, kind):
         """traversal kind 0..31 alone (kinds >= 16 travel in bit 13 of the variant word, see rmclhip.h)"""
         self.set_variant((int(kind) & 15) | ((int(kind) >> 4) << 13))

@@ -258,6 +258,36 @@ def test_frontier_plane_table_follows_model_and_tiling(ra, orc, ctx, meshes, kin
     rp.close()
 
 
+def test_autotune_chooses_a_product_kind_and_changes_no_result(ra, orc, ctx, meshes):
+    """rmclhip_rcc_autotune: the single-scan traversal is MEASURED on the operator's own map and model; the choice is one of the
+    product's kinds, the scan is the same bit for bit, a new model forgets the measurement, a forced kind refuses it."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room30k")
+    hm = ra.import_hip_map(ctx, v, f)
+    Tbm = T.transform_from_rpy((1.5, -2.0, 1.6), (0.02, -0.03, 0.4))
+    rcc = ra.RCCHipSpherical(hm)
+    rcc.setTsb(T.identity())
+    for model in (syn.model_vlp16_900(), syn.model_c2()):
+        rcc.setModel(model)
+        rule = rcc.find_variant(1)
+        rcc.find(Tbm)
+        before = rcc.modelView()
+        kind, ms = rcc.autotune(Tbm)
+        assert kind in (2, 23, 24) and 0.0 < ms < 1.0
+        assert rcc.find_variant(1) == kind
+        assert rcc.find_variant(64) in (23, 24)           # batches keep the rule
+        rcc.find(Tbm)
+        after = rcc.modelView()
+        for key in ("hits", "ranges", "points", "normals", "face_ids"):
+            assert np.array_equal(before[key], after[key], equal_nan=True), key
+        rcc.setModel(model)                               # a (re)set model forgets the measurement
+        assert rcc.find_variant(1) == rule
+    rcc.set_traversal(23)
+    with pytest.raises(RuntimeError, match="forced"):
+        rcc.autotune(Tbm)
+    rcc.close()
+
+
 def test_far_from_origin_mesh(ra, orc, ctx):
     """conservative slab test: a mesh 5 km from the origin (large absolute coordinates) must still
     give brute-force-identical face ids."""
