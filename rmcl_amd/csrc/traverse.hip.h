@@ -833,7 +833,7 @@ __device__ __forceinline__ void trace_lane_ww_tail(const uint32_t* __restrict__ 
 // trace_lane_bf whose LAST rays are finished by quads (see trace_lane_ww_tail): branch-free node steps and one-round-trip
 // leaves while more than kTailRays rays of the wave are walking, then each remaining ray gets four lanes.
 // LDS: lane stacks (kRows x 256) | quad-tail stacks (64 columns x kQuadStackEntries rows) | hand-over slots.
-template <int kRows, bool kLeafBatch, int kLeafTrigger = 0>
+template <int kRows, bool kLeafBatch, int kLeafTrigger = 0, bool kQuant = false>   // kQuant: `nodes` are the 64-B quantised twins
 __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ cnodes,
                                                    const uint32_t* __restrict__ tris, f3 O, f3 D, float ray_tfar,
                                                    uint32_t* __restrict__ lds_col, uint32_t* __restrict__ qstack,
@@ -905,7 +905,7 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
       ++nvis;                                                                                                \
       if (!__any(sp + 3u > static_cast<uint32_t>(kRows))) {                                                  \
         const uint32_t top = lds_col[(sp - 1u) * kBfStride];                                                 \
-        node_keys_off(nodes, cur << 7, rs, best_t, key, ref);                                                \
+        if constexpr (kQuant) node_keys_q(nodes, cur, rs, best_t, key, ref); else node_keys_off(nodes, cur << 7, rs, best_t, key, ref);                                                \
         RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)                 \
         lds_col[sp * kBfStride] = ref[3]; sp += (key[3] != kNone) ? 1u : 0u;                                 \
         lds_col[sp * kBfStride] = ref[2]; sp += (key[2] != kNone) ? 1u : 0u;                                 \
@@ -915,7 +915,7 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
         sp = any ? sp : (sp - 1u);                                                                           \
       } else {                                                                                               \
         ++dbg_slow;                                                                                          \
-        node_keys_off(nodes, cur << 7, rs, best_t, key, ref);                                                \
+        if constexpr (kQuant) node_keys_q(nodes, cur, rs, best_t, key, ref); else node_keys_off(nodes, cur << 7, rs, best_t, key, ref);                                                \
         RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)                 \
         if (key[3] != kNone) { RMCL_ROW_ST(sp, ref[3]) ++sp; }                                               \
         if (key[2] != kNone) { RMCL_ROW_ST(sp, ref[2]) ++sp; }                                               \
