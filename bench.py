@@ -260,6 +260,14 @@ def main():
                 dt = (time.perf_counter() - t1) / 20
                 extras[key] = round(dt * 1e3, 4)
             extras["cpc_closest_points_per_s"] = round(n_rays / dt, 1)
+            # opt-in: search only within max_dist (hits and hit outputs unchanged; rmclhip_rcc_set_cpc_bounded), cold
+            cpc.set_tracking(False)
+            cpc.set_bounded(True)
+            cpc.find(est)
+            t1 = time.perf_counter()
+            for _ in range(20):
+                cpc.find(est)
+            extras["cpc_find_cold_bounded_ms"] = round((time.perf_counter() - t1) / 20 * 1e3, 4)
             cpc.close()
             small = ra.RCCHipSpherical(hm)
             small.setTsb(T.identity())

@@ -494,6 +494,10 @@ class CPCHip : public CorrespondencesHIP {
     check(rmclhip_rcc_set_params(h_, params.max_dist, adaptive_max_dist_min));
     check(rmclhip_rcc_find_cpc(h_, &Tbm_est));
   }
+  // both optional, neither changes a hit: start every query at the triangle it ended on in the previous find (default on) /
+  // search only within params.max_dist (default off: points beyond it then carry NaN instead of their gated-out closest point)
+  void setTracking(bool on) { check(rmclhip_rcc_set_cpc_tracking(h_, on ? 1 : 0)); }
+  void setBounded(bool on) { check(rmclhip_rcc_set_cpc_bounded(h_, on ? 1 : 0)); }
 };
 
 // ---- particle filter -----------------------------------------------------------------------------------

@@ -294,6 +294,12 @@ rmclhip_status rmclhip_rcc_find_cpc(rmclhip_rcc* rcc, const rmclhip_transform* T
  * answer -- min distance, then min face id -- is the same bit for bit; what changes is the number of leaves a query visits
  * when the pose moved little between calls (an ICP loop).  A new dataset, or on = 0, starts cold. */
 rmclhip_status rmclhip_rcc_set_cpc_tracking(rmclhip_rcc* rcc, int on);
+/* Bounded search (default off = the reference's semantics, CPCEmbree.cpp:36-41: the global closest point of EVERY dataset point,
+ * hits = (d <= params.max_dist)).  On: nothing farther than max_dist is looked for.  hits, and every output of a point that
+ * hits, are unchanged bit for bit; a point with no surface within max_dist gets hits = 0 and NaN point / normal / distance,
+ * face id 0xFFFFFFFF -- it is gated out of every statistic either way.  A first (cold) find then costs about what a tracked one
+ * does; the two options combine. */
+rmclhip_status rmclhip_rcc_set_cpc_bounded(rmclhip_rcc* rcc, int on);
 /* Correspondences{CPU,CUDA}::computeCrossStatistics (CorrespondencesCPU.cpp:10-39):
  * max_dist' = max_dist (1-p) + adaptive_max_dist_min p; rm::statistics_p2l(T_snew_sold, ...) */
 rmclhip_status rmclhip_rcc_compute_cross_statistics(rmclhip_rcc* rcc, const rmclhip_transform* T_snew_sold,

@@ -216,6 +216,7 @@ struct rmclhip_rcc {
   const float* cpc_rec_pts = nullptr;           // the dataset the records were computed for
   uint32_t cpc_rec_n = 0;
   bool cpc_tracking = true;
+  bool cpc_bounded = false;        // rmclhip_rcc_set_cpc_bounded: search only within max_dist
   hipGraphExec_t micp_fast_exec = nullptr;
   hipGraph_t micp_fast_graph = nullptr;
   float fast_rho_cap = 0.02f, fast_tau_cap = 0.1f;   // bounds on |2 sin(theta/2)| and |t| of the pre-transforms
@@ -1044,6 +1045,16 @@ rmclhip_status rmclhip_rcc_find(rmclhip_rcc* r, const rmclhip_transform* Tbm_est
   return RMCLHIP_OK;
 }
 
+// squared search radius of a bounded closest-point query: everything with sqrtf(d2) <= max_dist must stay inside it (sqrtf rounds
+// to nearest: d2 <= max_dist^2 (1 + 2^-22) covers every such d2), so hits -- and every output of a point that hits -- are those of
+// the unbounded search
+static float cpc_bound_d2(const rmclhip_rcc* r) {
+  if (!r->cpc_bounded || !(r->max_dist >= 0.0f)) return 3.0e38f;
+  const double m = static_cast<double>(r->max_dist);
+  const double b = m * m * (1.0 + 1.0 / 1048576.0) + 1e-30;
+  return b < 3.0e38 ? static_cast<float>(b) : 3.0e38f;
+}
+
 rmclhip_status rmclhip_rcc_find_cpc(rmclhip_rcc* r, const rmclhip_transform* Tbm_est) {
   ApiGuard guard_("rmclhip_rcc_find_cpc");
   if (!r || !Tbm_est) return fail(RMCLHIP_ERR_INVALID, "rcc_find_cpc: null");
@@ -1066,7 +1077,8 @@ rmclhip_status rmclhip_rcc_find_cpc(rmclhip_rcc* r, const rmclhip_transform* Tbm
   }
   HIPCHK(launch_cpc_find(quad ? r->map->d_cnodes : r->map->d_nodes, r->map->d_tris, r->ds_pts, r->n_dataset,
                          r->max_dist, Tsm, xinv(Tsm), r->d_hits.p, r->d_ranges.p, r->d_points.p, r->d_normals.p,
-                         r->d_face_ids.p, quad, r->stream, seed, r->cpc_tracking ? r->d_cpc_rec.p : nullptr, r->map->info.n_faces));
+                         r->d_face_ids.p, quad, r->stream, seed, r->cpc_tracking ? r->d_cpc_rec.p : nullptr, r->map->info.n_faces,
+                         cpc_bound_d2(r)));
   if (r->cpc_tracking) { r->cpc_rec_n = r->n_dataset; r->cpc_rec_pts = r->ds_pts; }
   HIPCHK(hipStreamSynchronize(r->stream));
   return RMCLHIP_OK;
@@ -1077,6 +1089,13 @@ rmclhip_status rmclhip_rcc_set_cpc_tracking(rmclhip_rcc* r, int on) {
   if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_set_cpc_tracking: null");
   r->cpc_tracking = on != 0;
   r->cpc_rec_n = 0;
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_set_cpc_bounded(rmclhip_rcc* r, int on) {
+  ApiGuard guard_("rmclhip_rcc_set_cpc_bounded");
+  if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_set_cpc_bounded: null");
+  r->cpc_bounded = on != 0;
   return RMCLHIP_OK;
 }
 

@@ -195,7 +195,7 @@ hipError_t launch_find_probe(const FindParams& p, int mode, uint32_t* probe_log,
 hipError_t launch_cpc_find(const uint32_t* nodes, const uint32_t* tris, const float* dataset_points, uint32_t n,
                            float max_dist, xform Tsm, xform Tms, uint8_t* hits, float* dists, float* points,
                            float* normals, uint32_t* face_ids, bool quad, hipStream_t s, const uint32_t* seed_rec = nullptr,
-                           uint32_t* rec_out = nullptr, uint32_t n_tris = 0);
+                           uint32_t* rec_out = nullptr, uint32_t n_tris = 0, float bound_d2 = 3.0e38f);
 hipError_t launch_gladiator_resample(const xform* poses, const void* attrs, uint32_t n, xform* poses_new, void* attrs_new,
                                      uint32_t first, uint32_t count, const float* cfg8, uint32_t trans_dist_metric,
                                      uint64_t seed, uint32_t step, hipStream_t s);

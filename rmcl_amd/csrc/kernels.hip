@@ -1761,12 +1761,12 @@ hipError_t launch_find_probe(const FindParams& p, int mode, uint32_t* probe_log,
 hipError_t launch_cpc_find(const uint32_t* nodes, const uint32_t* tris, const float* dataset_points, uint32_t n,
                            float max_dist, xform Tsm, xform Tms, uint8_t* hits, float* dists, float* points,
                            float* normals, uint32_t* face_ids, bool quad, hipStream_t s, const uint32_t* seed_rec, uint32_t* rec_out,
-                           uint32_t n_tris) {
+                           uint32_t n_tris, float bound_d2) {
   if (n == 0) return hipSuccess;
   CpcParams p;
   p.nodes = nodes; p.tris = tris; p.dataset_points = dataset_points; p.n = n; p.max_dist = max_dist;
   p.Tsm = Tsm; p.Tms = Tms; p.hits = hits; p.dists = dists; p.points = points; p.normals = normals; p.face_ids = face_ids;
-  p.seed_rec = seed_rec; p.rec_out = rec_out; p.n_tris = n_tris;
+  p.seed_rec = seed_rec; p.rec_out = rec_out; p.n_tris = n_tris; p.bound_d2 = bound_d2;
   if (quad) hipLaunchKernelGGL((k_cpc_find<true>), dim3((n + 63u) / 64u), dim3(256), kQuadStackEntries * 64u * sizeof(uint32_t), s, p);
   else hipLaunchKernelGGL((k_cpc_find<false>), dim3((n + 255u) / 256u), dim3(256), 16u * 256u * sizeof(uint32_t), s, p);
   return hipGetLastError();

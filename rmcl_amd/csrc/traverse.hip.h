@@ -1177,7 +1177,7 @@ __device__ __forceinline__ void nearest_lane_ww(const uint32_t* __restrict__ nod
   float best = 3.0e38f;  // finite: unused node slots (box at 1e30 -> d2 = inf) never pass `d2 <= best`
   uint32_t best_face = kInvalidFace, best_rec = 0;
   f3 best_p = mk3(0.f, 0.f, 0.f);
-  if (seed != nullptr && seed->face != kInvalidFace) { best = seed->d2; best_face = seed->face; best_rec = seed->rec; best_p = seed->p; }
+  if (seed != nullptr) { best = seed->d2; best_face = seed->face; best_rec = seed->rec; best_p = seed->p; }   // (a bound without a candidate has face == kInvalidFace: every face wins a tie against it)
   constexpr uint32_t kDone = 0x7FFFFFFFu;
   uint32_t priv[(kLdsEntries < 64) ? (64 - kLdsEntries) : 1];
   uint32_t sp = 0;
@@ -1246,7 +1246,7 @@ __device__ __forceinline__ void nearest_quad(const uint32_t* __restrict__ nodes,
   float best = 3.0e38f;
   uint32_t best_face = kInvalidFace, best_rec = 0;
   f3 best_p = mk3(0.f, 0.f, 0.f);
-  if (seed != nullptr && seed->face != kInvalidFace) { best = seed->d2; best_face = seed->face; best_rec = seed->rec; best_p = seed->p; }
+  if (seed != nullptr) { best = seed->d2; best_face = seed->face; best_rec = seed->rec; best_p = seed->p; }   // (a bound without a candidate has face == kInvalidFace: every face wins a tie against it)
   constexpr uint32_t kDone = 0x7FFFFFFFu;
   const char* nbase = reinterpret_cast<const char*>(nodes);
   char* sbase = reinterpret_cast<char*>(lds) + ray * 4u;
@@ -1341,6 +1341,9 @@ struct CpcParams {
   const uint32_t* seed_rec;
   uint32_t* rec_out;
   uint32_t n_tris;
+  // bounded search (opt-in, rmclhip_rcc_set_cpc_bounded): nothing farther than this squared distance is looked for; a point
+  // with no surface inside it gets the "not found" outputs.  3e38: unbounded (the reference's semantics).
+  float bound_d2;
 };
 
 // kQuad: four lanes per dataset point (64 points per block) instead of one
@@ -1367,6 +1370,9 @@ __global__ void __launch_bounds__(256) k_cpc_find(const CpcParams p) {
       seed.d2 = (df.x * df.x + df.y * df.y) + df.z * df.z;   // the query's own arithmetic: revisiting this record changes nothing
       seed.face = d.w; seed.rec = sr; seed.p = cq;
     }
+  }
+  if (!(seed.d2 <= p.bound_d2)) {   // bounded search: start from the bound itself (no candidate: every face wins a tie against it)
+    seed.d2 = p.bound_d2; seed.face = kInvalidFace; seed.rec = 0; seed.p = mk3(0.f, 0.f, 0.f);
   }
   if (kQuad) nearest_quad(p.nodes, p.tris, Pm, live && finite, sub, threadIdx.x >> 2, lds_dyn, h, &seed);
   else nearest_lane_ww<16>(p.nodes, p.tris, Pm, live && finite, lds_dyn + threadIdx.x, blockDim.x, h, &seed);

@@ -551,6 +551,11 @@ class CPCHip(CorrespondencesHIP):
         """start every query from the triangle the point was closest to in the previous find (same results; rmclhip.h)"""
         _capi.check(_capi.lib().rmclhip_rcc_set_cpc_tracking(self._h, 1 if on else 0))
 
+    def set_bounded(self, on=True):
+        """search only within params.max_dist: hits and every output of a point that hits are unchanged, points with no surface
+        within max_dist get NaN outputs instead of their (gated-out) global closest point (rmclhip.h)"""
+        _capi.check(_capi.lib().rmclhip_rcc_set_cpc_bounded(self._h, 1 if on else 0))
+
     def find(self, Tbm_est):
         self._push_params()   # hits = (distance <= params.max_dist)
         T = np.ascontiguousarray(Tbm_est, dtype=TRANSFORM).reshape(1)

@@ -138,3 +138,53 @@ def test_tracking_gives_the_cold_result_bit_for_bit(ra, orc, ctx, meshes):
                     assert a[k].tobytes() == b[k].tobytes(), (variant, k)
         cold.close()
         warm.close()
+
+
+def test_bounded_search_keeps_every_hit_bit_for_bit(ra, orc, ctx, meshes):
+    """rmclhip_rcc_set_cpc_bounded: with the search limited to params.max_dist the hit mask is the unbounded one and every hit
+    point carries the unbounded answer bit for bit; points with no surface within max_dist carry NaN / 0xFFFFFFFF.  Three
+    gates (most points out, half, all in), tracking on and off, four lanes and one lane per point, points exactly at
+    max_dist from a wall."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("cube")           # walls at +-5
+    hm = ra.import_hip_map(ctx, v, f)
+    rng = np.random.RandomState(9)
+    pts = rng.uniform(-4.9, 4.9, (6000, 3)).astype(np.float32)
+    pts[:64] = np.float32(0.0)
+    pts[:64, 0] = np.float32(5.0) - np.float32(0.25)      # exactly 0.25 from the wall x = 5 (before the pose)
+    Tsb = T.identity()
+    poses = [T.identity(), T.transform_from_rpy((0.01, -0.02, 0.015), (0.0, 0.0, 0.003)), T.identity()]
+    for variant in (2, 1):
+        for tracking in (True, False):
+            for md in (0.25, 1.0, 20.0):
+                ref, bnd = ra.CPCHip(hm), ra.CPCHip(hm)
+                for c in (ref, bnd):
+                    c.set_variant(variant)
+                    c.setTsb(Tsb)
+                    c.params.max_dist = md
+                    c.set_tracking(tracking)
+                    c.set_dataset(pts, None)
+                bnd.set_bounded(True)
+                for P in poses:
+                    ref.find(P)
+                    bnd.find(P)
+                    a, b = ref.modelView(), bnd.modelView()
+                    assert a["hits"].tobytes() == b["hits"].tobytes(), (variant, tracking, md)
+                    hit = a["hits"].reshape(-1) > 0
+                    for k in ("ranges", "face_ids", "points", "normals"):
+                        ak, bk = a[k].reshape(len(hit), -1), b[k].reshape(len(hit), -1)
+                        assert ak[hit].tobytes() == bk[hit].tobytes(), (variant, tracking, md, k)
+                    # beyond the gate: either the unbounded answer (found inside the slightly inflated bound) or "not found"
+                    out = ~hit
+                    nf = b["face_ids"].reshape(-1)[out] == 0xFFFFFFFF
+                    assert np.isnan(b["points"].reshape(-1, 3)[out][nf]).all() and np.isnan(b["ranges"].reshape(-1)[out][nf]).all()
+                    same = a["face_ids"].reshape(-1)[out][~nf] == b["face_ids"].reshape(-1)[out][~nf]
+                    assert same.all()
+                    if md == 0.25 and P is poses[0]:
+                        assert hit[:64].all()                       # d == max_dist is a hit (<=) in both forms
+                    if md == 20.0:
+                        assert hit.all() and not nf.any()
+                    if md == 0.25:
+                        assert nf.sum() > 0.5 * out.sum() > 0       # the bound really cut the search
+                ref.close()
+                bnd.close()
