@@ -652,6 +652,11 @@ def _pf_cycle(ra, syn, T, np, ctx, hm, n_particles):
     out["pf_resample_gladiator_ms"] = round(_median_call_ms(lambda: rs.update(d_p, d_a, d_pn, d_an, n_particles)), 4)
     out["pf_likelihood_stats_ms"] = round(_median_call_ms(lambda: rs.compute_stats(d_a, n_particles)), 4)
     rs.close()
+    # the node's other resampler plugin (ResidualResamplerCPU.cpp:55-203): the reference's sequential loop as three parallel passes
+    rr = ra.ResidualResamplerHip(ctx)
+    out["pf_resample_residual_ms"] = round(_median_call_ms(lambda: rr.update(d_p, d_a, d_pn, d_an, n_particles), reps=9), 4)
+    out["pf_resample_residual_loop_iterations"] = rr.last_draws
+    rr.close()
     return out
 
 

@@ -260,6 +260,23 @@ int main(int argc, char** argv) {
     check(rmclhip_memcpy_d2h(ctx->handle(), poses.data(), d_poses_new, poses.size() * sizeof(Transform)));
     check(rmclhip_memcpy_d2h(ctx->handle(), attrs.data(), d_attrs_new, attrs.size() * sizeof(ParticleAttributes)));
     std::printf("resampled %zu\n", res.n_particles);
+    {
+      // the node's other resampler plugin (rmcl_localization.cpp:567): residual resampling of the same cloud into a larger one
+      const size_t n_big = 3 * poses.size();
+      void *d_pr = nullptr, *d_ar = nullptr;
+      check(rmclhip_malloc(ctx->handle(), n_big * sizeof(Transform), &d_pr));
+      check(rmclhip_malloc(ctx->handle(), n_big * sizeof(ParticleAttributes), &d_ar));
+      ResidualResamplerHip residual(ctx);
+      residual.seed = 42;
+      const auto rr = residual.update(vposes, vattrs, {static_cast<Transform*>(d_pr), n_big}, {static_cast<ParticleAttributes*>(d_ar), n_big});
+      std::vector<ParticleAttributes> ar(n_big);
+      check(rmclhip_memcpy_d2h(ctx->handle(), ar.data(), d_ar, n_big * sizeof(ParticleAttributes)));
+      double lsum = 0;
+      for (const auto& a : ar) lsum += a.likelihood.mean;
+      std::printf("residual %zu %llu %.9g\n", rr.n_particles, (unsigned long long)residual.last_draws, lsum);
+      check(rmclhip_free(ctx->handle(), d_pr));
+      check(rmclhip_free(ctx->handle(), d_ar));
+    }
     for (size_t i = 0; i < attrs.size(); ++i)
       std::printf("rs_%zu %.9g %u %.9g %.9g %.9g\n", i, attrs[i].likelihood.mean, attrs[i].likelihood.n_meas, poses[i].t.x,
                   poses[i].t.y, poses[i].t.z);

@@ -702,4 +702,36 @@ class GladiatorResamplerHip : public SensorUpdaterBase {
   uint32_t step_ = 0;
 };
 
+// rmcl::ResidualResamplerCPU (ResidualResamplerCPU.cpp:55-203), the node's other Resampler plugin (rmcl_localization.cpp:567): same
+// interface and parameters as the gladiator; the new cloud may have a different size than the old one
+class ResidualResamplerHip : public SensorUpdaterBase {
+ public:
+  rmclhip_gladiator_config config_{0.03f, 0.03f, 0.0f, 0.0f, 0.0f, 0.01f, 0.3f, 0.2f, 1u};
+  uint64_t seed = 1234;
+  uint64_t last_draws = 0;   // iterations the reference's sequential loop would have run
+
+  explicit ResidualResamplerHip(ContextPtr ctx) : ctx_(std::move(ctx)) {
+    if (!ctx_) throw std::runtime_error("NO CONTEXT");
+  }
+  ~ResidualResamplerHip() override { rmclhip_resampler_destroy(h_); }
+  void init() override {
+    if (!h_) check(rmclhip_resampler_create(ctx_->handle(), &h_));
+  }
+  void reset() override { step_ = 0; }
+  ParticleUpdateDynamicResults update(DeviceView<Transform> poses, DeviceView<ParticleAttributes> attrs,
+                                      DeviceView<Transform> poses_new, DeviceView<ParticleAttributes> attrs_new,
+                                      const ParticleUpdateDynamicConfig& = {}) {
+    init();
+    const uint32_t n_new = static_cast<uint32_t>(poses_new.size());
+    check(rmclhip_resampler_residual(h_, poses.raw(), attrs.raw(), static_cast<uint32_t>(poses.size()), poses_new.raw(),
+                                     attrs_new.raw(), n_new, 0u, n_new, &config_, seed, step_++, &last_draws));
+    return {n_new};
+  }
+
+ private:
+  ContextPtr ctx_;
+  rmclhip_resampler* h_ = nullptr;
+  uint32_t step_ = 0;
+};
+
 }  // namespace rmcl_hip

@@ -492,6 +492,21 @@ rmclhip_status rmclhip_resampler_gladiator(rmclhip_resampler* rs, const rmclhip_
                                            uint32_t first, uint32_t count, const rmclhip_gladiator_config* config,
                                            uint64_t seed, uint32_t step);
 
+/* rmcl::ResidualResamplerCPU::update (ResidualResamplerCPU.cpp:55-203), the PF node's second resampler plugin: until the new
+ * cloud of n_new particles is full, draw a random particle and insert size_t(L / sum(L) * n_new) perturbed copies of it
+ * (Gaussians of width min_noise_* / (L / max(L)); n_meas *= forget_per_meter^|dt|^2 * forget_per_radian^l2norm(dR)).  The
+ * reference's loop is sequential; here the draws are a counter-based stream (draw k -> particle philox(k, step, 2)[0] % n; the
+ * Gaussians of slot j from philox(j, step, 3 / 4)), so their counts, a prefix sum and the slots are three data-parallel passes
+ * with the sequential loop's result.  Slots first .. first+count-1 land in poses_new_dev / attrs_new_dev [0 .. count) (a GPU
+ * can fill its shard of an all-gathered cloud).  config: the gladiator's struct (trans_dist_metric is ignored).
+ * n_draws_out (nullable): draws the sequential loop uses -- set when the call fills the LAST slot.  Errors: likelihoods that
+ * sum to zero; shares that all truncate to zero (the reference's loop would not terminate). */
+rmclhip_status rmclhip_resampler_residual(rmclhip_resampler* rs, const rmclhip_transform* poses_dev,
+                                          const rmclhip_particle_attributes* attrs_dev, uint32_t n_particles,
+                                          rmclhip_transform* poses_new_dev, rmclhip_particle_attributes* attrs_new_dev,
+                                          uint32_t n_new, uint32_t first, uint32_t count, const rmclhip_gladiator_config* config,
+                                          uint64_t seed, uint32_t step, uint64_t* n_draws_out);
+
 /* ---- multi-GPU: ONE process drives several devices -------------------------------------------------------------
  * (the reference's localisation node is one process: rmcl_localization.cpp:482-552; particle store rmcl_localization.hpp:65-77.
  * The reference has no distributed code -- SURVEY.md 8(e) defines this part.)  Particles are block-partitioned over the

@@ -175,6 +175,8 @@ def lib():
     L.orc_likelihood_stats_compute.argtypes = [vp, u32]
     L.orc_quat_to_euler.argtypes = [Quat, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32)]
     L.orc_gladiator_resample.argtypes = [vp, vp, u32, vp, vp, u32, u32, C.POINTER(GladiatorConfig), C.c_uint64, u32]
+    L.orc_residual_resample.restype = u32
+    L.orc_residual_resample.argtypes = [vp, vp, u32, vp, vp, u32, C.POINTER(GladiatorConfig), C.c_uint64, u32, C.c_uint64, C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -539,6 +541,17 @@ def gladiator_resample(poses, attrs, cfg, seed, step, first=0, count=None):
     lib().orc_gladiator_resample(_p(poses), _p(attrs), len(poses), _p(pn), _p(an), int(first), int(count),
                                  C.byref(cfg), int(seed), int(step))
     return pn, an
+
+
+def residual_resample(poses, attrs, cfg, seed, step, n_new=None, max_draws=None):
+    """ResidualResamplerCPU::update: (poses_new, attrs_new, n_filled, n_draws)"""
+    n_new = len(poses) if n_new is None else int(n_new)
+    max_draws = (1 << 40) if max_draws is None else int(max_draws)
+    pn, an = np.zeros(n_new, TRANSFORM), np.zeros(n_new, PARTICLE_ATTRIBUTES)
+    nd = C.c_uint64(0)
+    filled = lib().orc_residual_resample(_p(poses), _p(attrs), len(poses), _p(pn), _p(an), n_new, C.byref(cfg), int(seed), int(step),
+                                         max_draws, C.byref(nd))
+    return pn, an, int(filled), int(nd.value)
 
 
 # ------------------------------------------------------------ wire formats --

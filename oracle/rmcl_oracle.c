@@ -1376,6 +1376,86 @@ void orc_gladiator_resample(const orc_transform* poses, const orc_particle_attri
 }
 
 /* ------------------------------------------------------------------------- */
+/* residual resampling (ResidualResamplerCPU.cpp:55-203)                     */
+/* ------------------------------------------------------------------------- */
+/* The reference's loop, statement by statement: statistics {sum, max} of likelihood.mean in double (:72-85); then, until the new
+ * cloud is full (:104): draw a random particle (:106), insert n = size_t(L / sum * N_new) copies of it -- clamped to the room
+ * that is left (:115-121) --, each perturbed by Gaussians of width min_noise / (L / max) (:144-159) and with its n_meas reduced
+ * by forget_per_meter^|dt|^2 * forget_per_radian^l2norm(dR) (:163-168).
+ * Pinned where the reference is implementation-defined (mt19937 + uniform_int_distribution + normal_distribution<float>, all
+ * libstdc++ specific): draw k takes particle philox(k, step, 2, 0)[0] % n; the six Gaussians of OUTPUT SLOT j come from
+ * philox(j, step, 3, 0) / philox(j, step, 4, 0) by Box-Muller in double; pow() is evaluated in double and rounded to float
+ * (the reference's std::pow(float, float)); a non-positive or NaN share inserts nothing.  max_draws bounds the loop (the
+ * reference's does not terminate when every share truncates to 0).  Returns the number of slots filled; *n_draws = draws used. */
+uint32_t orc_residual_resample(const orc_transform* poses, const orc_particle_attributes* attrs, uint32_t n,
+                               orc_transform* poses_new, orc_particle_attributes* attrs_new, uint32_t n_new,
+                               const orc_gladiator_config* cfg, uint64_t seed, uint32_t step, uint64_t max_draws,
+                               uint64_t* n_draws)
+{
+  const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  double weight_sum = 0.0, weight_max = 0.0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const double v = (double)attrs[i].likelihood.mean;
+    weight_sum += v;
+    if (v > weight_max) weight_max = v;
+  }
+  uint32_t insertion_idx = 0;
+  uint64_t k = 0;
+  while (insertion_idx < n_new && k < max_draws && n > 0) {
+    uint32_t r[4];
+    const uint32_t ck[4] = {(uint32_t)k, step, 2u, (uint32_t)(k >> 32)};
+    orc_philox4x32_10(ck, key, r);
+    ++k;
+    const uint32_t random_index = r[0] % n;
+    const orc_transform pose = poses[random_index];
+    const orc_particle_attributes at = attrs[random_index];
+    const double L = (double)at.likelihood.mean;
+    const double L_sum_normed = L / weight_sum, L_max_normed = L / weight_max;
+    const double share = L_sum_normed * (double)n_new;
+    const uint32_t left = n_new - insertion_idx;
+    uint32_t n_ins = 0;
+    if (share > 0.0) n_ins = (share >= (double)left) ? left : (uint32_t)share;
+    for (uint32_t inner = 0; inner < n_ins; ++inner) {
+      const uint32_t j = insertion_idx + inner;
+      uint32_t ra[4], rb[4];
+      const uint32_t c3[4] = {j, step, 3u, 0u}, c4[4] = {j, step, 4u, 0u};
+      orc_philox4x32_10(c3, key, ra);
+      orc_philox4x32_10(c4, key, rb);
+      float Nd_tx, Nd_ty, Nd_tz, Nd_rx, Nd_ry, Nd_rz;
+      box_muller(ra[0], ra[1], &Nd_tx, &Nd_ty);
+      box_muller(ra[2], ra[3], &Nd_tz, &Nd_rx);
+      box_muller(rb[0], rb[1], &Nd_ry, &Nd_rz);
+      const float noise_tx = (float)((double)cfg->min_noise_tx / L_max_normed), noise_ty = (float)((double)cfg->min_noise_ty / L_max_normed);
+      const float noise_tz = (float)((double)cfg->min_noise_tz / L_max_normed);
+      const float noise_roll = (float)((double)cfg->min_noise_roll / L_max_normed), noise_pitch = (float)((double)cfg->min_noise_pitch / L_max_normed);
+      const float noise_yaw = (float)((double)cfg->min_noise_yaw / L_max_normed);
+      orc_transform pose_new = pose;
+      orc_particle_attributes attrs_n = at;
+      pose_new.t.x = pose_new.t.x + Nd_tx * noise_tx;
+      pose_new.t.y = pose_new.t.y + Nd_ty * noise_ty;
+      pose_new.t.z = pose_new.t.z + Nd_tz * noise_tz;
+      float roll, pitch, yaw;
+      orc_quat_to_euler(pose_new.R, &roll, &pitch, &yaw);
+      roll = roll + Nd_rx * noise_roll;
+      pitch = pitch + Nd_ry * noise_pitch;
+      yaw = yaw + Nd_rz * noise_yaw;
+      pose_new.R = euler_to_quat_d(roll, pitch, yaw);
+      const orc_transform diff = orc_transform_mult(orc_transform_inv(pose), pose_new);
+      const float trans_dist = (diff.t.x * diff.t.x + diff.t.y * diff.t.y) + diff.t.z * diff.t.z;   /* l2normSquared (:164) */
+      const float rot_dist = sqrtf(((diff.R.w * diff.R.w + diff.R.x * diff.R.x) + diff.R.y * diff.R.y) + diff.R.z * diff.R.z);
+      const float reduction_factor = (float)pow((double)cfg->likelihood_forget_per_meter, (double)trans_dist) *
+                                     (float)pow((double)cfg->likelihood_forget_per_radian, (double)rot_dist);
+      attrs_n.likelihood.n_meas = (uint32_t)((float)attrs_n.likelihood.n_meas * reduction_factor);
+      poses_new[j] = pose_new;
+      attrs_new[j] = attrs_n;
+    }
+    insertion_idx += n_ins;
+  }
+  if (n_draws) *n_draws = k;
+  return insertion_idx;
+}
+
+/* ------------------------------------------------------------------------- */
 /* PointCloud2 -> O1Dn model + dataset (conversions.cpp:869-1002 etc.)       */
 /* ------------------------------------------------------------------------- */
 int orc_pointcloud2_unpack(const uint8_t* data, uint32_t width, uint32_t height, uint32_t point_step, uint32_t row_step,

@@ -193,6 +193,13 @@ void orc_gladiator_resample(const orc_transform* poses, const orc_particle_attri
                             orc_transform* poses_new, orc_particle_attributes* attrs_new, uint32_t first,
                             uint32_t count, const orc_gladiator_config* cfg, uint64_t seed, uint32_t step);
 
+/* ---- residual resampling (ResidualResamplerCPU.cpp:55-203): see the restatement's header comment for what is pinned.
+ * cfg: the gladiator's struct (same parameters; trans_dist_metric is ignored -- the residual resampler uses |dt|^2). */
+uint32_t orc_residual_resample(const orc_transform* poses, const orc_particle_attributes* attrs, uint32_t n,
+                               orc_transform* poses_new, orc_particle_attributes* attrs_new, uint32_t n_new,
+                               const orc_gladiator_config* cfg, uint64_t seed, uint32_t step, uint64_t max_draws,
+                               uint64_t* n_draws);
+
 /* instrumented walk of the PRODUCT's BVH4 in the product's traversal order (nearest child first, deferred
  * children on a stack): counts inner-node visits, visits whose four children all fail, leaf visits, triangle
  * tests and the stack high-water mark.  mode bit0: cull popped entries with their stored entry distance;

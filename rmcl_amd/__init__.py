@@ -7,7 +7,7 @@ from . import _capi, types, synthetic, wire  # noqa: F401
 from ._capi import NoDeviceError, RmclHipError  # noqa: F401
 from .micp import MICPLocalization, MICPSensor  # noqa: F401
 from . import pf  # noqa: F401
-from .pf import (GladiatorResamplerHip, PCDSensorUpdaterHip, ShardedParticleFilterHip, TFMotionUpdaterHip,  # noqa: F401
+from .pf import (GladiatorResamplerHip, PCDSensorUpdaterHip, ResidualResamplerHip, ShardedParticleFilterHip, TFMotionUpdaterHip,  # noqa: F401
                  beams_from_points, combined_forget_rate, sample_beams)
 from .registration import (CPCHip, Context, CorrespondencesHIP, DeviceArray, HipMap, MapMap, RCCHipO1Dn,  # noqa: F401
                            RCCHipOnDn, RCCHipPinhole, RCCHipSpherical, build_bvh_host, build_bvh_host_pf, build_bvh_host_quantised,

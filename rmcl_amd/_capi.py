@@ -178,6 +178,8 @@ SIGNATURES = {
     "rmclhip_resampler_compute_stats": (_i32, [_vp, _vp, _u32, C.POINTER(LikelihoodStats)]),
     "rmclhip_resampler_gladiator": (_i32, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, C.POINTER(GladiatorConfig),
                                             C.c_uint64, _u32]),
+    "rmclhip_resampler_residual": (_i32, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, _u32, C.POINTER(GladiatorConfig),
+                                           C.c_uint64, _u32, C.POINTER(C.c_uint64)]),
     "rmclhip_comm_create": (_i32, [_vp, _u32, _pp]),
     "rmclhip_comm_destroy": (None, [_vp]),
     "rmclhip_comm_size": (_u32, [_vp]),

@@ -275,6 +275,9 @@ struct rmclhip_resampler {
   DevBuf<double> d_psum;
   DevBuf<float> d_pmax, d_out;
   float* h_out = nullptr;  // pinned {sum, max}
+  // residual resampling: {double sum, double max, u64 expect, u64 n_draws} on the device, the draws' particle / count / prefix sums
+  DevBuf<unsigned long long> d_res_stats, d_res_incl, d_res_btot;
+  DevBuf<uint32_t> d_res_idx, d_res_cnt;
 };
 
 extern "C" {
@@ -2340,6 +2343,7 @@ void rmclhip_resampler_destroy(rmclhip_resampler* r) {
   r->d_psum.release();
   r->d_pmax.release();
   r->d_out.release();
+  r->d_res_stats.release(); r->d_res_incl.release(); r->d_res_btot.release(); r->d_res_idx.release(); r->d_res_cnt.release();
   if (r->h_out) (void)hipHostFree(r->h_out);
   if (r->stream) (void)hipStreamDestroy(r->stream);
   ctx_release(r->ctx);
@@ -2382,6 +2386,69 @@ rmclhip_status rmclhip_resampler_gladiator(rmclhip_resampler* r, const rmclhip_t
                                    reinterpret_cast<xform*>(poses_new_dev), attrs_new_dev, first, count, c8,
                                    cfg->trans_dist_metric, seed, step, r->stream));
   HIPCHK(hipStreamSynchronize(r->stream));
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_resampler_residual(rmclhip_resampler* r, const rmclhip_transform* poses_dev,
+                                          const rmclhip_particle_attributes* attrs_dev, uint32_t n_particles,
+                                          rmclhip_transform* poses_new_dev, rmclhip_particle_attributes* attrs_new_dev,
+                                          uint32_t n_new, uint32_t first, uint32_t count, const rmclhip_gladiator_config* cfg,
+                                          uint64_t seed, uint32_t step, uint64_t* n_draws_out) {
+  ApiGuard guard_("rmclhip_resampler_residual");
+  if (!r || !cfg) return fail(RMCLHIP_ERR_INVALID, "resampler_residual: null");
+  if (n_draws_out) *n_draws_out = 0;
+  if (n_new == 0 || count == 0) return RMCLHIP_OK;
+  if (!poses_dev || !attrs_dev || !poses_new_dev || !attrs_new_dev || n_particles == 0)
+    return fail(RMCLHIP_ERR_INVALID, "resampler_residual: null particle buffers");
+  if (static_cast<uint64_t>(first) + count > n_new) return fail(RMCLHIP_ERR_INVALID, "resampler_residual: slot range exceeds the new cloud");
+  if (poses_new_dev == poses_dev || attrs_new_dev == attrs_dev)
+    return fail(RMCLHIP_ERR_INVALID, "resampler_residual: out of place (double buffers)");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  HIPCHK(r->d_res_stats.reserve(4));
+  // 1. statistics (ResidualResamplerCPU.cpp:72-85) and how many copies a draw inserts on average
+  HIPCHK(launch_residual_prepare(attrs_dev, n_particles, n_new, r->d_psum.p, r->d_pmax.p, r->d_res_stats.p, r->stream));
+  struct { double sum, max; unsigned long long expect, n_draws; } st;
+  HIPCHK(hipMemcpyAsync(&st, r->d_res_stats.p, sizeof(st), hipMemcpyDeviceToHost, r->stream));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  if (!(st.sum > 0.0)) return fail(RMCLHIP_ERR_INVALID, "resampler_residual: the likelihoods sum to zero (or NaN): nothing to resample from");
+  if (st.expect == 0ull)
+    return fail(RMCLHIP_ERR_INVALID, "resampler_residual: every particle's share L / sum * N_new truncates to 0 -- no draw would ever insert "
+                                     "a particle (the reference's loop, ResidualResamplerCPU.cpp:104, does not terminate on this input)");
+  // 2. a block of draws that fills the cloud with a margin: N_new / E[copies per draw] x 1.25 + 4096; doubled if it falls short
+  const double per_draw = static_cast<double>(st.expect) / static_cast<double>(n_particles);
+  double want = static_cast<double>(n_new) / per_draw * 1.25 + 4096.0;
+  const double kMaxDraws = 1073741824.0;   // 2^30 draws = 16 GB of scratch: far beyond any sane input
+  unsigned long long total = 0ull;
+  uint32_t n_draws = 0;
+  for (;;) {
+    if (want > kMaxDraws) return fail(RMCLHIP_ERR_UNSUPPORTED, "resampler_residual: more than 2^30 draws would be needed to fill the cloud");
+    n_draws = static_cast<uint32_t>(want);
+    const uint32_t nb = (n_draws + 1023u) / 1024u;
+    HIPCHK(r->d_res_idx.reserve(n_draws));
+    HIPCHK(r->d_res_cnt.reserve(n_draws));
+    HIPCHK(r->d_res_incl.reserve(n_draws));
+    HIPCHK(r->d_res_btot.reserve(nb));
+    HIPCHK(launch_residual_draws(attrs_dev, n_particles, n_new, r->d_res_stats.p, n_draws, seed, step, r->d_res_idx.p, r->d_res_cnt.p,
+                                 r->d_res_incl.p, r->d_res_btot.p, r->stream));
+    HIPCHK(hipMemcpyAsync(&total, r->d_res_incl.p + (n_draws - 1u), sizeof(total), hipMemcpyDeviceToHost, r->stream));
+    HIPCHK(hipStreamSynchronize(r->stream));
+    if (total >= n_new) break;
+    want *= 2.0;   // the same draws again plus as many more: the stream is a function of the draw index
+  }
+  // 3. the slots
+  const float c8[8] = {cfg->min_noise_tx, cfg->min_noise_ty, cfg->min_noise_tz, cfg->min_noise_roll,
+                       cfg->min_noise_pitch, cfg->min_noise_yaw, cfg->likelihood_forget_per_meter,
+                       cfg->likelihood_forget_per_radian};
+  HIPCHK(launch_residual_fill(reinterpret_cast<const xform*>(poses_dev), attrs_dev, r->d_res_idx.p, r->d_res_incl.p, n_draws,
+                              reinterpret_cast<xform*>(poses_new_dev), attrs_new_dev, n_new, first, count, c8, r->d_res_stats.p, seed,
+                              step, r->stream));
+  if (n_draws_out && static_cast<uint64_t>(first) + count == n_new) {
+    HIPCHK(hipMemcpyAsync(&st, r->d_res_stats.p, sizeof(st), hipMemcpyDeviceToHost, r->stream));
+    HIPCHK(hipStreamSynchronize(r->stream));
+    *n_draws_out = st.n_draws;
+  } else {
+    HIPCHK(hipStreamSynchronize(r->stream));
+  }
   return RMCLHIP_OK;
 }
 

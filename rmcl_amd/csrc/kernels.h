@@ -196,6 +196,15 @@ hipError_t launch_cpc_find(const uint32_t* nodes, const uint32_t* tris, const fl
                            float max_dist, xform Tsm, xform Tms, uint8_t* hits, float* dists, float* points,
                            float* normals, uint32_t* face_ids, bool quad, hipStream_t s, const uint32_t* seed_rec = nullptr,
                            uint32_t* rec_out = nullptr, uint32_t n_tris = 0, float bound_d2 = 3.0e38f);
+// residual resampling (ResidualResamplerCPU.cpp:55-203) in three steps; stats: 32 bytes on the device {double sum, double max,
+// u64 n * E[copies per draw], u64 draws used}
+hipError_t launch_residual_prepare(const void* attrs, uint32_t n, uint32_t n_new, double* psum, float* pmax, void* stats, hipStream_t s);
+hipError_t launch_residual_draws(const void* attrs, uint32_t n, uint32_t n_new, const void* stats, uint32_t n_draws, uint64_t seed,
+                                 uint32_t step, uint32_t* draw_idx, uint32_t* draw_cnt, unsigned long long* incl,
+                                 unsigned long long* block_tot, hipStream_t s);
+hipError_t launch_residual_fill(const xform* poses, const void* attrs, const uint32_t* draw_idx, const unsigned long long* incl,
+                                uint32_t n_draws, xform* poses_new, void* attrs_new, uint32_t n_new, uint32_t first, uint32_t count,
+                                const float* cfg8, void* stats, uint64_t seed, uint32_t step, hipStream_t s);
 hipError_t launch_gladiator_resample(const xform* poses, const void* attrs, uint32_t n, xform* poses_new, void* attrs_new,
                                      uint32_t first, uint32_t count, const float* cfg8, uint32_t trans_dist_metric,
                                      uint64_t seed, uint32_t step, hipStream_t s);

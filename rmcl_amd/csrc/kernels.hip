@@ -1531,6 +1531,191 @@ __global__ void __launch_bounds__(256) k_gladiator_resample(const xform* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// residual resampling (ResidualResamplerCPU.cpp:55-203) -- the reference's SEQUENTIAL loop "draw a particle, insert
+// size_t(L / sum * N_new) perturbed copies, until the new cloud is full" as four data-parallel passes over a block of draws:
+//   counts   c_k = copies draw k inserts (the draw's particle and its share; independent of every other draw),
+//   scan     inclusive prefix sums of c_k (64-bit): draw k fills slots [incl_k - c_k, incl_k),
+//   fill     slot j finds its draw by binary search, perturbs the copy with ITS Gaussians (Philox counter = slot index).
+// Same stream, same arithmetic as oracle/rmcl_oracle.c: orc_residual_resample (which restates the loop statement by statement):
+// particles, likelihoods and n_meas bit-exact, poses to float rounding of the double-evaluated transcendentals.
+// ---------------------------------------------------------------------------------------------
+struct ResidualStats {
+  double sum, max;
+  unsigned long long expect;   // sum over the particles of their share's integer part = n * E[c_k]
+  unsigned long long n_draws;  // written by k_residual_fill: draws the sequential loop would have used
+};
+
+__global__ void __launch_bounds__(64) k_residual_stats_final(const double* __restrict__ psum, const float* __restrict__ pmax,
+                                                            uint32_t nblocks, ResidualStats* __restrict__ out) {
+  // fixed order: lane l sums blocks l, l + 64, ...; then a fixed butterfly
+  double s = 0.0;
+  float m = 0.0f;
+  for (uint32_t b = threadIdx.x; b < nblocks; b += 64u) { s += psum[b]; m = fmaxf(m, pmax[b]); }
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_down(s, off);
+    m = fmaxf(m, __shfl_down(m, off));
+  }
+  if (threadIdx.x == 0) { out->sum = s; out->max = static_cast<double>(m); out->expect = 0ull; out->n_draws = 0ull; }
+}
+
+// copies a draw of particle likelihood L inserts when `left` slots are free: the reference's size_t(L / sum * N_new), clamped
+__device__ __forceinline__ uint32_t residual_share(float Lf, double weight_sum, uint32_t n_new) {
+  const double share = (static_cast<double>(Lf) / weight_sum) * static_cast<double>(n_new);
+  if (!(share > 0.0)) return 0u;
+  return (share >= static_cast<double>(n_new)) ? n_new : static_cast<uint32_t>(share);
+}
+
+__global__ void __launch_bounds__(256) k_residual_expect(const pattrs* __restrict__ attrs, uint32_t n, uint32_t n_new,
+                                                         ResidualStats* __restrict__ st) {
+  __shared__ unsigned long long s_part[4];
+  const double sum = st->sum;
+  unsigned long long acc = 0ull;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    acc += residual_share(attrs[i].likelihood.mean, sum, n_new);
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if ((threadIdx.x & 63u) == 0u) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&st->expect, (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));   // integers: order independent
+}
+
+__global__ void __launch_bounds__(256) k_residual_counts(const pattrs* __restrict__ attrs, uint32_t n, uint32_t n_new,
+                                                         const ResidualStats* __restrict__ st, uint32_t n_draws, uint32_t key0,
+                                                         uint32_t key1, uint32_t step, uint32_t* __restrict__ idx_out,
+                                                         uint32_t* __restrict__ cnt_out) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_draws) return;
+  uint32_t r[4];
+  philox4x32_10(k, step, 2u, 0u, key0, key1, r);
+  const uint32_t random_index = r[0] % n;
+  idx_out[k] = random_index;
+  cnt_out[k] = residual_share(attrs[random_index].likelihood.mean, st->sum, n_new);
+}
+
+// inclusive 64-bit prefix sums of 32-bit counts, three passes: 1024 elements per block -> block totals -> totals scanned by ONE
+// block -> added back.  (Counts are <= N_new each, so 32 bits would overflow for peaked weights.)
+__device__ __forceinline__ unsigned long long block_scan_256(unsigned long long v, unsigned long long* s_wave, unsigned long long& total) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  unsigned long long incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long o = __shfl_up(incl, off, 64);
+    if (lane >= static_cast<uint32_t>(off)) incl += o;
+  }
+  if (lane == 63u) s_wave[wave] = incl;
+  __syncthreads();
+  unsigned long long base = 0ull;
+  for (uint32_t w = 0; w < wave; ++w) base += s_wave[w];
+  total = ((s_wave[0] + s_wave[1]) + s_wave[2]) + s_wave[3];
+  __syncthreads();
+  return base + incl;
+}
+
+__global__ void __launch_bounds__(256) k_scan_blocks(const uint32_t* __restrict__ cnt, uint32_t n, unsigned long long* __restrict__ incl,
+                                                     unsigned long long* __restrict__ block_total) {
+  __shared__ unsigned long long s_wave[4];
+  const uint32_t base = blockIdx.x * 1024u + threadIdx.x * 4u;
+  unsigned long long c[4];
+#pragma unroll
+  for (uint32_t u = 0; u < 4u; ++u) c[u] = (base + u < n) ? cnt[base + u] : 0u;
+  const unsigned long long mine = (c[0] + c[1]) + (c[2] + c[3]);
+  unsigned long long total;
+  const unsigned long long end = block_scan_256(mine, s_wave, total);   // inclusive over the threads
+  unsigned long long run = end - mine;
+#pragma unroll
+  for (uint32_t u = 0; u < 4u; ++u) {
+    run += c[u];
+    if (base + u < n) incl[base + u] = run;
+  }
+  if (threadIdx.x == 0) block_total[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(256) k_scan_totals(unsigned long long* __restrict__ block_total, uint32_t nblocks) {
+  __shared__ unsigned long long s_wave[4];
+  unsigned long long carry = 0ull;
+  for (uint32_t b0 = 0; b0 < nblocks; b0 += 256u) {
+    const uint32_t b = b0 + threadIdx.x;
+    const unsigned long long v = (b < nblocks) ? block_total[b] : 0ull;
+    unsigned long long total;
+    const unsigned long long inc = block_scan_256(v, s_wave, total);
+    if (b < nblocks) block_total[b] = carry + inc - v;   // exclusive: what precedes block b
+    carry += total;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_scan_add(unsigned long long* __restrict__ incl, uint32_t n, const unsigned long long* __restrict__ block_excl) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) incl[i] += block_excl[i >> 10];
+}
+
+__global__ void __launch_bounds__(256) k_residual_fill(const xform* __restrict__ poses, const pattrs* __restrict__ attrs,
+                                                       const uint32_t* __restrict__ draw_idx, const unsigned long long* __restrict__ incl,
+                                                       uint32_t n_draws, xform* __restrict__ poses_new, pattrs* __restrict__ attrs_new,
+                                                       uint32_t n_new, uint32_t first, uint32_t count, GladiatorConfig cfg,
+                                                       ResidualStats* __restrict__ st, uint32_t key0, uint32_t key1, uint32_t step) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  const uint32_t j = first + t;                 // global output slot
+  // the draw that fills slot j: the first k with incl[k] > j (the host launches this only when incl[n_draws - 1] >= n_new)
+  uint32_t lo = 0u, hi = n_draws - 1u;
+  while (lo < hi) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (incl[mid] > static_cast<unsigned long long>(j)) hi = mid; else lo = mid + 1u;
+  }
+  const uint32_t k = lo;
+  if (j + 1u == n_new) st->n_draws = static_cast<unsigned long long>(k) + 1ull;   // the sequential loop stops after this draw
+  const uint32_t src = draw_idx[k];
+  const xform pose = poses[src];
+  pattrs an = attrs[src];
+  const double L_max_normed = static_cast<double>(an.likelihood.mean) / st->max;
+  uint32_t ra[4], rb[4];
+  philox4x32_10(j, step, 3u, 0u, key0, key1, ra);
+  philox4x32_10(j, step, 4u, 0u, key0, key1, rb);
+  float Nd_tx, Nd_ty, Nd_tz, Nd_rx, Nd_ry, Nd_rz;
+  box_muller(ra[0], ra[1], Nd_tx, Nd_ty);
+  box_muller(ra[2], ra[3], Nd_tz, Nd_rx);
+  box_muller(rb[0], rb[1], Nd_ry, Nd_rz);
+  const float noise_tx = static_cast<float>(static_cast<double>(cfg.min_noise_tx) / L_max_normed);
+  const float noise_ty = static_cast<float>(static_cast<double>(cfg.min_noise_ty) / L_max_normed);
+  const float noise_tz = static_cast<float>(static_cast<double>(cfg.min_noise_tz) / L_max_normed);
+  const float noise_roll = static_cast<float>(static_cast<double>(cfg.min_noise_roll) / L_max_normed);
+  const float noise_pitch = static_cast<float>(static_cast<double>(cfg.min_noise_pitch) / L_max_normed);
+  const float noise_yaw = static_cast<float>(static_cast<double>(cfg.min_noise_yaw) / L_max_normed);
+  xform pn = pose;
+  pn.t.x = pn.t.x + Nd_tx * noise_tx;
+  pn.t.y = pn.t.y + Nd_ty * noise_ty;
+  pn.t.z = pn.t.z + Nd_tz * noise_tz;
+  // EulerAngles <- Quaternion (textbook ZYX extraction, as in k_gladiator_resample)
+  const quat q = pn.R;
+  const float sinr_cosp = 2.0f * (q.w * q.x + q.y * q.z);
+  const float cosr_cosp = 1.0f - 2.0f * (q.x * q.x + q.y * q.y);
+  const float sinp = 2.0f * (q.w * q.y - q.z * q.x);
+  const float siny_cosp = 2.0f * (q.w * q.z + q.x * q.y);
+  const float cosy_cosp = 1.0f - 2.0f * (q.y * q.y + q.z * q.z);
+  float roll = static_cast<float>(atan2(static_cast<double>(sinr_cosp), static_cast<double>(cosr_cosp)));
+  float pitch = (fabsf(sinp) >= 1.0f) ? copysignf(static_cast<float>(3.14159265358979323846 / 2.0), sinp)
+                                      : static_cast<float>(asin(static_cast<double>(sinp)));
+  float yaw = static_cast<float>(atan2(static_cast<double>(siny_cosp), static_cast<double>(cosy_cosp)));
+  roll = roll + Nd_rx * noise_roll;
+  pitch = pitch + Nd_ry * noise_pitch;
+  yaw = yaw + Nd_rz * noise_yaw;
+  const float cr = static_cast<float>(cos(static_cast<double>(roll / 2.0f))), sr = static_cast<float>(sin(static_cast<double>(roll / 2.0f)));
+  const float cp = static_cast<float>(cos(static_cast<double>(pitch / 2.0f))), sp = static_cast<float>(sin(static_cast<double>(pitch / 2.0f)));
+  const float cy = static_cast<float>(cos(static_cast<double>(yaw / 2.0f))), sy = static_cast<float>(sin(static_cast<double>(yaw / 2.0f)));
+  pn.R.w = cr * cp * cy + sr * sp * sy;
+  pn.R.x = sr * cp * cy - cr * sp * sy;
+  pn.R.y = cr * sp * cy + sr * cp * sy;
+  pn.R.z = cr * cp * sy - sr * sp * cy;
+  const xform diff = xmul(xinv(pose), pn);
+  const float trans_dist = (diff.t.x * diff.t.x + diff.t.y * diff.t.y) + diff.t.z * diff.t.z;   // l2normSquared (:164)
+  const float rot_dist = sqrtf(((diff.R.w * diff.R.w + diff.R.x * diff.R.x) + diff.R.y * diff.R.y) + diff.R.z * diff.R.z);
+  const float reduction_factor = static_cast<float>(pow(static_cast<double>(cfg.likelihood_forget_per_meter), static_cast<double>(trans_dist))) *
+                                 static_cast<float>(pow(static_cast<double>(cfg.likelihood_forget_per_radian), static_cast<double>(rot_dist)));
+  an.likelihood.n_meas = static_cast<uint32_t>(static_cast<float>(an.likelihood.n_meas) * reduction_factor);
+  poses_new[t] = pn;
+  attrs_new[t] = an;
+}
+
 // simple_stats_kernel (resampling.cu:41-81): {sum, max} of likelihood.mean; max seeded with 0 like the reference's
 // shared-memory init, sum accumulated in double.  Stage 1: <=256 blocks of grid-stride partials; stage 2: one wave.
 __global__ void __launch_bounds__(256) k_likelihood_stats_partial(const pattrs* __restrict__ attrs, uint32_t n,
@@ -2161,6 +2346,45 @@ hipError_t launch_gladiator_resample(const xform* poses, const void* attrs, uint
   hipLaunchKernelGGL(k_gladiator_resample, dim3((count + 255u) / 256u), dim3(256), 0, s, poses,
                      reinterpret_cast<const pattrs*>(attrs), n, poses_new, reinterpret_cast<pattrs*>(attrs_new), first,
                      count, c, static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), step);
+  return hipGetLastError();
+}
+
+// residual resampling, step 1: {sum, max} in double + the expected number of copies per draw (x n) -> *stats (device)
+hipError_t launch_residual_prepare(const void* attrs, uint32_t n, uint32_t n_new, double* psum, float* pmax, void* stats, hipStream_t s) {
+  uint32_t nblocks = (n + 1023u) / 1024u;
+  if (nblocks < 1u) nblocks = 1u;
+  if (nblocks > 256u) nblocks = 256u;
+  hipLaunchKernelGGL(k_likelihood_stats_partial, dim3(nblocks), dim3(256), 0, s, reinterpret_cast<const pattrs*>(attrs), n, psum, pmax);
+  hipLaunchKernelGGL(k_residual_stats_final, dim3(1), dim3(64), 0, s, psum, pmax, nblocks, reinterpret_cast<ResidualStats*>(stats));
+  hipLaunchKernelGGL(k_residual_expect, dim3(nblocks), dim3(256), 0, s, reinterpret_cast<const pattrs*>(attrs), n, n_new,
+                     reinterpret_cast<ResidualStats*>(stats));
+  return hipGetLastError();
+}
+
+// step 2: the particle and the copy count of draws 0 .. n_draws-1 and the inclusive prefix sums of the counts
+hipError_t launch_residual_draws(const void* attrs, uint32_t n, uint32_t n_new, const void* stats, uint32_t n_draws, uint64_t seed,
+                                 uint32_t step, uint32_t* draw_idx, uint32_t* draw_cnt, unsigned long long* incl,
+                                 unsigned long long* block_tot, hipStream_t s) {
+  if (n_draws == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_residual_counts, dim3((n_draws + 255u) / 256u), dim3(256), 0, s, reinterpret_cast<const pattrs*>(attrs), n, n_new,
+                     reinterpret_cast<const ResidualStats*>(stats), n_draws, static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32),
+                     step, draw_idx, draw_cnt);
+  const uint32_t nb = (n_draws + 1023u) / 1024u;
+  hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(256), 0, s, draw_cnt, n_draws, incl, block_tot);
+  hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(256), 0, s, block_tot, nb);
+  hipLaunchKernelGGL(k_scan_add, dim3((n_draws + 255u) / 256u), dim3(256), 0, s, incl, n_draws, block_tot);
+  return hipGetLastError();
+}
+
+// step 3: slots first .. first+count-1 of the new cloud -> poses_new / attrs_new [0 .. count)
+hipError_t launch_residual_fill(const xform* poses, const void* attrs, const uint32_t* draw_idx, const unsigned long long* incl,
+                                uint32_t n_draws, xform* poses_new, void* attrs_new, uint32_t n_new, uint32_t first, uint32_t count,
+                                const float* cfg8, void* stats, uint64_t seed, uint32_t step, hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  GladiatorConfig c{cfg8[0], cfg8[1], cfg8[2], cfg8[3], cfg8[4], cfg8[5], cfg8[6], cfg8[7], 1u};
+  hipLaunchKernelGGL(k_residual_fill, dim3((count + 255u) / 256u), dim3(256), 0, s, poses, reinterpret_cast<const pattrs*>(attrs), draw_idx,
+                     incl, n_draws, poses_new, reinterpret_cast<pattrs*>(attrs_new), n_new, first, count, c,
+                     reinterpret_cast<ResidualStats*>(stats), static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), step);
   return hipGetLastError();
 }
 

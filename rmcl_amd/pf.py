@@ -232,6 +232,33 @@ class GladiatorResamplerHip:
             pass
 
 
+class ResidualResamplerHip(GladiatorResamplerHip):
+    """rmcl::ResidualResamplerCPU on gfx950 (ResidualResamplerCPU.cpp:55-203), the PF node's second resampler plugin: random
+    particles are inserted floor(L / sum(L) * N_new) times each, perturbed, until the new cloud is full.  Same interface and
+    parameters as the gladiator (`config.trans_dist_metric` is ignored: this resampler measures |dt|^2); `last_draws` = the
+    iterations the reference's sequential loop would have run."""
+
+    def __init__(self, ctx, seed=1234):
+        super().__init__(ctx, seed)
+        self.last_draws = 0
+
+    def update(self, particle_poses, particle_attrs, particle_poses_new, particle_attrs_new, n_particles, n_particles_new=None,
+               first=0, count=None):
+        """slots first..first+count-1 (default: all) of a new cloud of n_particles_new (default n_particles) particles; results in
+        particle_*_new[0..count)."""
+        self.init()
+        n_new = int(n_particles if n_particles_new is None else n_particles_new)
+        if count is None:
+            count = n_new - int(first)
+        nd = C.c_uint64(0)
+        _capi.check(_capi.lib().rmclhip_resampler_residual(
+            self._h, _as_ptr(particle_poses), _as_ptr(particle_attrs), int(n_particles), _as_ptr(particle_poses_new),
+            _as_ptr(particle_attrs_new), n_new, int(first), int(count), C.byref(self.config), self.seed, self.step, C.byref(nd)))
+        self.step += 1
+        self.last_draws = int(nd.value)
+        return {"n_particles": int(count)}
+
+
 class ShardedParticleFilterHip:
     """A particle cloud block-partitioned over the devices of ONE process (rmclhip_comm / rmclhip_pf_sharded: RCCL
     ncclCommInitAll + all-gather / all-reduce over xGMI) -- the multi-GPU form of PCDSensorUpdater + GladiatorResampler +

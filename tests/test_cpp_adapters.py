@@ -128,3 +128,7 @@ def test_cpp_example_matches_python_and_oracle(ra, orc, ctx, meshes, tmp_path):
         assert int(n) == int(an["likelihood"]["n_meas"][i])
         assert abs(float(mean) - float(an["likelihood"]["mean"][i])) <= 1e-5 * abs(float(an["likelihood"]["mean"][i])) + 1e-12
         assert np.allclose([float(x), float(y), float(z)], [float(pn["t"][k][i]) for k in "xyz"], atol=1e-5)
+    # the residual resampler (the node's other Resampler plugin) on the same 4 particles -> 12
+    _, anr, filled, draws = orc.residual_resample(poses, attrs, orc.gladiator_config(trans_dist_metric=1), seed=42, step=0, n_new=12)
+    assert [int(out["residual"][0]), int(out["residual"][1])] == [filled, draws] == [12, draws]
+    assert abs(float(out["residual"][2]) - float(anr["likelihood"]["mean"].astype(np.float64).sum())) < 1e-5
