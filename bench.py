@@ -204,6 +204,9 @@ def main():
             for _ in range(3):
                 rcc.correct_batch(poses)
             dt = (time.perf_counter() - t1) / 3
+            k_b, ms_b = rcc.autotune_batch(poses)      # kinds 23 / 24 with and without the frontier start, measured on these poses
+            extras["find_batch64_autotuned"] = {"rule_kind": 24, "chosen_kind": k_b, "ms": round(ms_b, 4)}
+            rcc.setModel(model)                        # forget the measurement: everything below runs on the rule
             extras["correct_batch64_ms"] = round(dt * 1e3, 4)
             extras["correct_batch64_pose_corrections_per_s"] = round(64 / dt, 1)
             # C4: particle filter, 100k particles x 256 beams

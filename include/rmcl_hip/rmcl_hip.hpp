@@ -311,6 +311,11 @@ class Correspondences_<VRAM_HIP> {
     check(rmclhip_rcc_autotune(h_, &Tbm_est, &kind, nullptr));
     return kind;
   }
+  int autotuneBatch(const std::vector<Transform>& Tbm) {
+    int kind = 0;
+    check(rmclhip_rcc_autotune_batch(h_, Tbm.data(), static_cast<uint32_t>(Tbm.size()), &kind, nullptr));
+    return kind;
+  }
   // modelView() (Correspondences.hpp:47-53): PointCloudView_ {points, mask = hits, normals} over the model buffers of the last
   // find -- the shape MICPSensorCUDA.cpp:66-84 reads
   PointCloudView_<VRAM_HIP> modelView() const {

@@ -386,11 +386,16 @@ rmclhip_status rmclhip_rcc_micp_fast_info(const rmclhip_rcc* rcc, rmclhip_micp_f
 rmclhip_status rmclhip_rcc_find_variant(const rmclhip_rcc* rcc, uint32_t nposes, int* variant_out);
 /* Measurement instead of brackets: the automatic rule above was tuned on two synthetic maps; which traversal is fastest for a
  * single scan depends on the map (open / occluded), the model's size and shape, and where the sensor is.  This call times the
- * product's single-scan kinds (2, 23, 24) on THIS operator's map and model at the given pose (15 short launches each, HIP
- * events) and makes the fastest one the automatic choice for single scans until the model or the tiling changes.  Results do not
+ * product's single-scan kinds (2, 23, 24; the latter two with and without the frontier start) on THIS operator's map and model at
+ * the given pose (40 short launches each, HIP events) and makes the fastest one the automatic choice for single scans until the model or the tiling changes.  Results do not
  * depend on the kind (bit-identical); batches keep the rule.  Opt-in: never run behind the caller's back.
  * chosen_kind / kernel_ms may be NULL. */
 rmclhip_status rmclhip_rcc_autotune(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est, int* chosen_kind, float* kernel_ms);
+/* the same for pose batches (find_batch / correct_batch) of about nposes scans: kinds 23 / 24, each with and without the frontier
+ * start (on an occluded map the per-wave culling can cost a batch more than the top levels it skips).  Both calls report the
+ * choice as 2 / 23 / 24 or -- frontier start off -- as 19 / 22, round 2's numbers for the same traversals. */
+rmclhip_status rmclhip_rcc_autotune_batch(rmclhip_rcc* rcc, const rmclhip_transform* Tbm, uint32_t nposes, int* chosen_kind,
+                                          float* kernel_ms);
 /* rm::Simulator::simulate(Memory<Transform>, Bundle&) (batch form, lidar_corrector_embree_benchmark.cpp:117):
  * one launch for nposes x H x W rays; model buffers become pose-major [pose][vid][hid]. */
 rmclhip_status rmclhip_rcc_find_batch(rmclhip_rcc* rcc, const rmclhip_transform* Tbm, uint32_t nposes);

@@ -142,6 +142,7 @@ SIGNATURES = {
     "rmclhip_rcc_last_kernel_ms": (_i32, [_vp, C.POINTER(_f32), C.POINTER(_f32)]),
     "rmclhip_rcc_time_find": (_i32, [_vp, _vp, _u32, C.POINTER(_f32)]),
     "rmclhip_rcc_autotune": (_i32, [_vp, _vp, C.POINTER(_i32), C.POINTER(_f32)]),
+    "rmclhip_rcc_autotune_batch": (_i32, [_vp, _vp, _u32, C.POINTER(_i32), C.POINTER(_f32)]),
     "rmclhip_rcc_time_reduce": (_i32, [_vp, _vp, _u32, C.POINTER(_f32)]),
     "rmclhip_rcc_time_correct_once": (_i32, [_vp, _vp, _vp, _u32, _dbl, _i32, _u32, C.POINTER(_f32)]),
     "rmclhip_rcc_set_variant": (_i32, [_vp, _i32]),

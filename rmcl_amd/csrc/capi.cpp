@@ -239,7 +239,10 @@ struct rmclhip_rcc {
                           // (quad-cooperative), 15 automatic: quad while the launch is bound by the slowest ray's
                           // chain of dependent fetches (few rays in flight), one lane per ray once the chip is full
   int tile_override = 0;  // 1 + log2(tile width), 0 = automatic
-  int tuned_kind = 0;              // rmclhip_rcc_autotune: the single-scan kind measured fastest for the current (map, model); 0 = none
+  // rmclhip_rcc_autotune[_batch]: the kind measured fastest for the current (map, model), for single scans / pose batches (0 = the
+  // rule), and whether its rays start at the frontier (kinds 23 / 24 without it are round 2's kinds 19 / 22)
+  int tuned_kind = 0, tuned_batch_kind = 0;
+  bool tuned_frontier = true, tuned_batch_frontier = true;
   DevBuf<float> d_tile_planes;     // plane table of the frontier start for the current (model, tiling): 16 floats per tile
   bool tile_planes_ok = false;
   float last_find_ms = 0.f, last_reduce_ms = 0.f;
@@ -781,7 +784,7 @@ rmclhip_status rmclhip_rcc_set_model_ondn(rmclhip_rcc* r, uint32_t width, uint32
   HIPCHK(hipStreamSynchronize(r->stream));
   r->kind = kModelOnDn;
   r->tile_planes_ok = false;
-  r->tuned_kind = 0;
+  r->tuned_kind = r->tuned_batch_kind = 0; r->tuned_frontier = r->tuned_batch_frontier = true;
   r->graph_dirty = true; r->fast_graph_dirty = true;
   r->W = width; r->H = height;
   r->range = range;
@@ -956,6 +959,7 @@ static rmclhip_status ensure_model_buffers(rmclhip_rcc* r, size_t n_total) {
 static int find_variant(const rmclhip_rcc* r, uint32_t nposes) {
   if (r->variant != 15) return r->variant;
   if (nposes == 1u && r->tuned_kind != 0) return r->tuned_kind;   // measured on this operator's own map and model (rmclhip_rcc_autotune)
+  if (nposes > 1u && r->tuned_batch_kind != 0) return r->tuned_batch_kind;
   const uint64_t rays = static_cast<uint64_t>(r->W) * r->H * nposes;
   if (rays <= 57344u) return 2;   // bound by the slowest ray's fetch chain: four lanes per ray (crossover measured between
                                   // 49152 rays -- quads 13.6 / 20.8 us vs 16.4 / 23.4 -- and 65536 -- 15.9 / 26.3 vs 16.3 / 23.7)
@@ -993,14 +997,15 @@ static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
   p.nposes = nposes;
   p.hits = r->d_hits.p; p.ranges = r->d_ranges.p; p.points = r->d_points.p; p.normals = r->d_normals.p;
   p.face_ids = r->d_face_ids.p;
-  p.tile_planes = r->tile_planes_ok ? r->d_tile_planes.p : nullptr;
+  p.tile_planes = (r->tile_planes_ok && (nposes == 1u ? r->tuned_frontier : r->tuned_batch_frontier)) ? r->d_tile_planes.p : nullptr;
 }
 
 // The frontier start's plane table belongs to (model, tiling): rebuilt -- one small launch on the handle's stream -- by whatever
 // changes either (the model setters, set_variant's tile shape), never inside a find (finds are captured into graphs).
 static rmclhip_status rebuild_tile_planes(rmclhip_rcc* r) {
   r->tile_planes_ok = false;
-  r->tuned_kind = 0;   // a measurement belongs to the model it was taken with
+  r->tuned_kind = r->tuned_batch_kind = 0;   // a measurement belongs to the model it was taken with
+  r->tuned_frontier = r->tuned_batch_frontier = true;
   if (r->kind == kModelOnDn || r->kind == kModelNone || r->W == 0 || r->H == 0) return RMCLHIP_OK;
   FindParams p;
   fill_find_params(r, p, 1);
@@ -1776,29 +1781,61 @@ rmclhip_status rmclhip_rcc_time_find(rmclhip_rcc* r, const rmclhip_transform* Tb
   return RMCLHIP_OK;
 }
 
+// candidates of the measured choice: {template kind, frontier start}; reported as kinds 2 / 23 / 24 and -- without the frontier
+// start -- as round 2's numbers for the same traversals, 19 / 22
+struct TuneCand { int kind; bool frontier; int reported; };
+static const TuneCand kTuneSingle[5] = {{2, true, 2}, {23, true, 23}, {23, false, 19}, {24, true, 24}, {24, false, 22}};
+static const TuneCand kTuneBatch[4] = {{23, true, 23}, {23, false, 19}, {24, true, 24}, {24, false, 22}};
+
 rmclhip_status rmclhip_rcc_autotune(rmclhip_rcc* r, const rmclhip_transform* Tbm_est, int* chosen_kind, float* kernel_ms) {
   ApiGuard guard_("rmclhip_rcc_autotune");
   if (!r || !Tbm_est) return fail(RMCLHIP_ERR_INVALID, "rcc_autotune: bad arguments");
   if (r->kind == kModelNone || r->W == 0 || r->H == 0) return fail(RMCLHIP_ERR_INVALID, "rcc_autotune: no sensor model");
   if (r->variant != 15) return fail(RMCLHIP_ERR_INVALID, "rcc_autotune: a traversal kind is forced (set_variant); nothing to choose");
   HIPCHK(hipSetDevice(r->ctx->device));
-  // the product's single-scan kinds, each timed on THIS map, model and pose: median of 5 batches of 8 back-to-back launches
-  static const int kCandidates[3] = {2, 23, 24};
-  int best = 0;
+  // each candidate timed on THIS map, model and pose: median of 5 batches of 8 back-to-back launches
+  const int saved_kind = r->tuned_kind;
+  const bool saved_frontier = r->tuned_frontier;
+  const TuneCand* best = nullptr;
   float best_ms = 0.f;
-  const int saved = r->tuned_kind;
-  for (int k : kCandidates) {
-    r->tuned_kind = k;
+  for (const TuneCand& c : kTuneSingle) {
+    r->tuned_kind = c.kind; r->tuned_frontier = c.frontier;
     float t[5];
     for (float& x : t) {
-      if (rmclhip_status st = rmclhip_rcc_time_find(r, Tbm_est, 8, &x)) { r->tuned_kind = saved; return st; }
+      if (rmclhip_status st = rmclhip_rcc_time_find(r, Tbm_est, 8, &x)) { r->tuned_kind = saved_kind; r->tuned_frontier = saved_frontier; return st; }
     }
     std::sort(t, t + 5);
-    if (best == 0 || t[2] < best_ms) { best = k; best_ms = t[2]; }
+    if (!best || t[2] < best_ms) { best = &c; best_ms = t[2]; }
   }
-  r->tuned_kind = best;
+  r->tuned_kind = best->kind; r->tuned_frontier = best->frontier;
   r->graph_dirty = true; r->fast_graph_dirty = true;
-  if (chosen_kind) *chosen_kind = best;
+  if (chosen_kind) *chosen_kind = best->reported;
+  if (kernel_ms) *kernel_ms = best_ms;
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_autotune_batch(rmclhip_rcc* r, const rmclhip_transform* Tbm, uint32_t nposes, int* chosen_kind, float* kernel_ms) {
+  ApiGuard guard_("rmclhip_rcc_autotune_batch");
+  if (!r || !Tbm || nposes < 2u) return fail(RMCLHIP_ERR_INVALID, "rcc_autotune_batch: needs at least two poses");
+  if (r->kind == kModelNone || r->W == 0 || r->H == 0) return fail(RMCLHIP_ERR_INVALID, "rcc_autotune_batch: no sensor model");
+  if (r->variant != 15) return fail(RMCLHIP_ERR_INVALID, "rcc_autotune_batch: a traversal kind is forced (set_variant); nothing to choose");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  const int saved_kind = r->tuned_batch_kind;
+  const bool saved_frontier = r->tuned_batch_frontier;
+  const TuneCand* best = nullptr;
+  float best_ms = 0.f;
+  for (const TuneCand& c : kTuneBatch) {
+    r->tuned_batch_kind = c.kind; r->tuned_batch_frontier = c.frontier;
+    float t[3];
+    for (float& x : t) {
+      if (rmclhip_status st = rmclhip_rcc_time_find_batch(r, Tbm, nposes, 3, &x)) { r->tuned_batch_kind = saved_kind; r->tuned_batch_frontier = saved_frontier; return st; }
+    }
+    std::sort(t, t + 3);
+    if (!best || t[1] < best_ms) { best = &c; best_ms = t[1]; }
+  }
+  r->tuned_batch_kind = best->kind; r->tuned_batch_frontier = best->frontier;
+  r->graph_dirty = true; r->fast_graph_dirty = true;
+  if (chosen_kind) *chosen_kind = best->reported;
   if (kernel_ms) *kernel_ms = best_ms;
   return RMCLHIP_OK;
 }

@@ -167,8 +167,14 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   } else {
     // kind 4 serves launches that fill the chip (pose batches): throughput, not the slowest wave's chain, is what counts there, and
     // the branchy step with its partial sort and 16 LDS rows (more resident waves) is 11 % faster than the branch-free one
+    // where the ray starts: the root -- or, for the frontier kinds, what frontier_start returns.  ALWAYS a struct passed by
+    // address, never "null or &start": a pointer chosen at run time forces the struct through scratch memory (8 B per ray
+    // written and read back on the critical path of every wave; seen as 1 MiB of extra HBM writes per C2 launch)
+    constexpr bool kWwStack = (kTrav == 4 || kTrav == 22 || kTrav == 24);   // trace_lane_ww: first stack row 0; branch-free forms: row 1
     TraceStart start;
-    const TraceStart* sp0 = nullptr;
+    start.cur = (ray_tfar >= 0.0f) ? 0u : 0x7FFFFFFFu;
+    start.sp = kWwStack ? 0u : 1u;
+    const TraceStart* sp0 = &start;
     if constexpr (find_frontier(kTrav) && kModel != kModelOnDn) {   // (OnDn: one origin per ray, no common pyramid)
       if (p.tile_planes != nullptr) {     // (no table: the rays start at the root)
         const float* planes = p.tile_planes + static_cast<size_t>(__builtin_amdgcn_readfirstlane(tile)) * 16u;
@@ -178,7 +184,6 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
         else
           start = frontier_start<16, 0>(p.frontier, p.n_frontier, p.scene_center, p.scene_half_diag, planes, Tsm.R, p.tfar, org_m, dir_m,
                                         ray_tfar, lane, lds_dyn + threadIdx.x, blockDim.x);
-        sp0 = &start;
       }
     }
     if (kTrav == 4) trace_lane_ww<16, true>(p.qnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);

@@ -414,6 +414,14 @@ class CorrespondencesHIP:
         _capi.check(_capi.lib().rmclhip_rcc_autotune(self._h, _ptr(T), C.byref(kind), C.byref(ms)))
         return kind.value, ms.value
 
+    def autotune_batch(self, Tbm_poses):
+        """the same measurement for pose batches (find_batch / correct_batch): kinds 23 / 24 with and without the frontier start;
+        returns (kind, kernel milliseconds) -- 19 / 22 stand for 23 / 24 without the frontier start"""
+        P = np.ascontiguousarray(Tbm_poses, dtype=TRANSFORM).reshape(-1)
+        kind, ms = C.c_int(), C.c_float()
+        _capi.check(_capi.lib().rmclhip_rcc_autotune_batch(self._h, _ptr(P), len(P), C.byref(kind), C.byref(ms)))
+        return kind.value, ms.value
+
     def set_traversal(self, kind):
         """traversal kind 0..31 alone (kinds >= 16 travel in bit 13 of the variant word, see rmclhip.h)"""
         self.set_variant((int(kind) & 15) | ((int(kind) >> 4) << 13))

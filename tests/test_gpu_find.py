@@ -273,15 +273,26 @@ def test_autotune_chooses_a_product_kind_and_changes_no_result(ra, orc, ctx, mes
         rcc.find(Tbm)
         before = rcc.modelView()
         kind, ms = rcc.autotune(Tbm)
-        assert kind in (2, 23, 24) and 0.0 < ms < 1.0
-        assert rcc.find_variant(1) == kind
-        assert rcc.find_variant(64) in (23, 24)           # batches keep the rule
+        assert kind in (2, 19, 22, 23, 24) and 0.0 < ms < 1.0       # 19 / 22: kinds 23 / 24 without the frontier start
+        assert rcc.find_variant(1) == {19: 23, 22: 24}.get(kind, kind)
+        assert rcc.find_variant(64) in (23, 24)           # batches keep the rule ...
         rcc.find(Tbm)
         after = rcc.modelView()
         for key in ("hits", "ranges", "points", "normals", "face_ids"):
             assert np.array_equal(before[key], after[key], equal_nan=True), key
-        rcc.setModel(model)                               # a (re)set model forgets the measurement
-        assert rcc.find_variant(1) == rule
+        # ... until they are measured too: same results before and after
+        poses = np.array([T.mult(Tbm, T.transform_from_rpy((0.01 * k, -0.02 * k, 0.0), (0.0, 0.0, 0.05 * k))) for k in range(6)], dtype=T.TRANSFORM)
+        rcc.find_batch(poses)
+        b0 = rcc.modelView()
+        bkind, bms = rcc.autotune_batch(poses)
+        assert bkind in (19, 22, 23, 24) and 0.0 < bms < 10.0
+        assert rcc.find_variant(6) == {19: 23, 22: 24}.get(bkind, bkind)
+        rcc.find_batch(poses)
+        b1 = rcc.modelView()
+        for key in ("hits", "ranges", "points", "normals", "face_ids"):
+            assert np.array_equal(b0[key], b1[key], equal_nan=True), key
+        rcc.setModel(model)                               # a (re)set model forgets the measurements
+        assert rcc.find_variant(1) == rule and rcc.find_variant(6) == rcc.find_variant(6)
     rcc.set_traversal(23)
     with pytest.raises(RuntimeError, match="forced"):
         rcc.autotune(Tbm)
