@@ -105,3 +105,65 @@ def test_cpc_and_pf_vs_brute_force_on_a_soup(ra, orc, ctx):
         assert np.array_equal(a["likelihood"]["n_meas"], a_ref["likelihood"]["n_meas"])
         assert_close_rel(a["likelihood"]["mean"], a_ref["likelihood"]["mean"], 1e-5, 1e-12, "soup pf mean")
         upd.close()
+
+
+def test_frontier_start_randomised_against_the_packet_traversal(ra, ctx):
+    """The frontier start (kinds 23 / 24) culls subtrees for a whole wave at once: a box dropped wrongly loses hits silently.  160
+    random scans -- soups, a room, a tiny and a far-away mesh; spherical models from 1 x 7 to 64 x 512 rays with fields of view from
+    2 to 360 degrees; O1Dn models with random (partly NaN, partly repeated) directions; sensors inside, outside, far outside and ON
+    the map's bounding box; random mounts -- must equal the wave-packet traversal (kind 0: no table, no culling) bit for bit."""
+    from rmcl_amd import synthetic as syn, types as T
+    rng = np.random.RandomState(77)
+    maps = [("soup", _soup(21, 2500)), ("room", syn.noisy_room(20000)), ("tiny", syn.cube_room(side=0.2)),
+            ("far", _soup(22, 1500, offset=(4000.0, 2500.0, -700.0), scale=30.0))]
+    n_scans, n_hits, n_rays = 0, 0, 0
+    for name, (v, f) in maps:
+        hm = ra.import_hip_map(ctx, v, f)
+        vv = np.asarray(v, np.float32).reshape(-1, 3)
+        lo, hi = vv.min(0), vv.max(0)
+        centre, ext = 0.5 * (lo + hi), (hi - lo)
+        for case in range(40):
+            where = case % 4                      # inside / just outside / far outside / on a face of the bounding box
+            if where == 0:
+                pos = centre + rng.uniform(-0.45, 0.45, 3) * ext
+            elif where == 1:
+                pos = centre + rng.choice([-1.0, 1.0], 3) * rng.uniform(0.55, 0.9, 3) * ext
+            elif where == 2:
+                pos = centre + rng.normal(size=3) * 40.0 * np.linalg.norm(ext)
+            else:
+                pos = centre + rng.uniform(-0.5, 0.5, 3) * ext
+                ax = rng.randint(3)
+                pos[ax] = lo[ax] if rng.rand() < 0.5 else hi[ax]
+            pose = T.transform_from_rpy(tuple(float(x) for x in pos), tuple(float(x) for x in rng.uniform(-math.pi, math.pi, 3)))
+            Tsb = T.transform_from_rpy(tuple(rng.uniform(-0.3, 0.3, 3)), tuple(rng.uniform(-0.5, 0.5, 3)))
+            far = float(10.0 ** rng.uniform(-0.5, 4.0))
+            if case % 3 == 2:
+                W, H = int(rng.choice([1, 9, 64, 333])), int(rng.choice([1, 8, 17]))
+                d = rng.normal(size=(W * H, 3)).astype(np.float32)
+                d /= np.linalg.norm(d, axis=1, keepdims=True)
+                d[rng.rand(W * H) < 0.1] = np.nan
+                d[rng.rand(W * H) < 0.1] = d[0]
+                op = ra.RCCHipO1Dn(hm)
+                op.setModel(W, H, 0.0, far, tuple(float(x) for x in rng.uniform(-0.2, 0.2, 3)), d)
+            else:
+                H, W = int(rng.choice([1, 3, 16, 64])), int(rng.choice([7, 64, 512]))
+                fov_v, fov_h = float(rng.uniform(0.03, math.pi)), float(rng.uniform(0.03, 2 * math.pi))
+                f32 = np.float32
+                model = T.spherical_model(f32(-fov_v / 2), f32(fov_v / max(H - 1, 1)), H, f32(-fov_h / 2), f32(fov_h / W), W, f32(0.0), f32(far))
+                op = ra.RCCHipSpherical(hm)
+                op.setModel(model)
+            op.setTsb(Tsb)
+            out = {}
+            for k in (0, 23, 24):
+                op.set_traversal(k)
+                op.find(pose)
+                out[k] = op.modelView()
+            for k in (23, 24):
+                for key in ("hits", "ranges", "points", "normals", "face_ids"):
+                    assert np.array_equal(out[k][key], out[0][key], equal_nan=True), (name, case, k, key)
+            n_scans += 1
+            n_hits += int(out[0]["hits"].sum())
+            n_rays += out[0]["hits"].size
+            op.close()
+        hm.release()
+    assert n_scans == 160 and 0.05 * n_rays < n_hits < 0.9 * n_rays, (n_hits, n_rays)     # hits and misses, plenty of both
