@@ -318,6 +318,15 @@ def main():
             loc.Tom_ = est
             extras["micp_two_sensors_device_loop_ms"] = round(_median_call_ms(lambda: (setattr(loc, "Tom_", est), loc.correctOnce(device_loop=True)), reps=15), 4)
             extras["micp_two_sensors_host_loop_ms"] = round(_median_call_ms(lambda: (setattr(loc, "Tom_", est), loc.correctOnce()), reps=15), 4)
+            # the same call at the C ABI, without the Python host class around it (arguments built once)
+            import ctypes as C
+            from rmcl_amd import _capi as _c
+            hnd = (C.c_void_p * 2)(sA._h, sB._h)
+            Tbo2, w2 = np.array([T.identity(), T.identity()], dtype=T.TRANSFORM), np.ones(2, np.float64)
+            Tin, Tout, mrg = np.ascontiguousarray(est, dtype=T.TRANSFORM).reshape(1), np.zeros(1, T.TRANSFORM), np.zeros(1, T.CROSS_STATISTICS)
+            vp = lambda a: a.ctypes.data_as(C.c_void_p)
+            extras["micp_two_sensors_device_loop_cabi_ms"] = round(_median_call_ms(
+                lambda: _c.check(_c.lib().rmclhip_micp_correct_once(hnd, 2, vp(Tin), vp(Tbo2), vp(w2), 10, 0.0, vp(Tout), vp(mrg))), reps=25), 4)
             sA.close()
             sB.close()
             # the particle filter through the multi-GPU C ABI on this one GPU (RCCL ncclCommInitAll + all-gather + all-reduces)

@@ -1599,7 +1599,7 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
   }
   MicpMultiCall* d_call = reinterpret_cast<MicpMultiCall*>(r0->d_multi_blob.p);
   MicpMultiState* d_state = reinterpret_cast<MicpMultiState*>(r0->d_multi_blob.p + sizeof(MicpMultiCall));
-  hipError_t e = hipMemcpyAsync(d_call, &h_call, sizeof(h_call), hipMemcpyHostToDevice, st);
+  hipError_t e = hipSuccess;
   // sensor->setTom(Tom); sensor->findCorrespondences()  (:900-909): Tbm = Tom * Tbo
   for (uint32_t s = 0; s < n_sensors && e == hipSuccess; ++s) {
     rmclhip_rcc* r = sensors[s];
@@ -1625,18 +1625,20 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
       const uint32_t nred = (r->n_dataset < r->n_model) ? r->n_dataset : r->n_model;
       HIPCHK(r->d_fast_partials.reserve(static_cast<size_t>(micp_fast_blocks(nred)) * kMicpFastMoments));
       HIPCHK(r->d_fast_mask.reserve((static_cast<size_t>(nred) + 63u) / 64u));
-      std::memset(r->h_call, 0, sizeof(MicpCall));
-      r->h_call->max_dist = adaptive_max_dist(r, convergence_progress);
-      r->h_call->rho_cap = r->fast_rho_cap;
-      r->h_call->tau_cap = r->fast_tau_cap;
-      HIPCHK(hipMemcpyAsync(r->d_call, r->h_call, sizeof(MicpCall), hipMemcpyHostToDevice, st));
+      // per-call data by value: no H2D copy node per sensor (4.4 us each in the kernel trace of round 2's chain)
+      MicpCallLite cl;
+      cl.Tsb = r->Tsb; cl.Tbo = h_call.Tbo[s]; cl.max_dist = adaptive_max_dist(r, convergence_progress);
+      cl.rho_cap = r->fast_rho_cap; cl.tau_cap = r->fast_tau_cap; cl.seq = h_call.seq;
       HIPCHK(launch_micp_moments(r->ds_pts, r->ds_has_mask ? r->ds_msk : nullptr, r->d_points.p, r->d_normals.p, r->d_hits.p, nred,
-                                 r->d_call, r->d_fast_partials.p, r->d_fast_mask.p, st));
+                                 nullptr, r->d_fast_partials.p, r->d_fast_mask.p, st, &cl));
       fp.dataset_points[s] = r->ds_pts; fp.model_points[s] = r->d_points.p; fp.model_normals[s] = r->d_normals.p;
-      fp.partials[s] = r->d_fast_partials.p; fp.unc_mask[s] = r->d_fast_mask.p; fp.sensor_call[s] = r->d_call;
+      fp.partials[s] = r->d_fast_partials.p; fp.unc_mask[s] = r->d_fast_mask.p;
       fp.n[s] = nred; fp.nblocks[s] = micp_fast_blocks(nred);
+      fp.Tsb[s] = cl.Tsb; fp.Tbo[s] = cl.Tbo; fp.weight[s] = h_call.weight[s];
+      fp.max_dist[s] = cl.max_dist; fp.rho_cap[s] = cl.rho_cap; fp.tau_cap[s] = cl.tau_cap;
     }
-    fp.call = d_call;
+    fp.n_sensors = n_sensors;
+    fp.seq = h_call.seq;
     fp.n_iter = n_iter;
     fp.state_out = r0->h_multi_state_dev;
     fp.status = r0->h_multi_status_dev;
@@ -1675,7 +1677,9 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
       if (fs.code == 2u) sensors[s]->fast_info.overflows++; else sensors[s]->fast_info.cap_exits++;
     }
   }
-  e = launch_micp_multi_init(d_call, d_state, st);
+  // per-iteration form (fallback, or the moment form is off): the call block goes to the device
+  e = hipMemcpyAsync(d_call, &h_call, sizeof(h_call), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = launch_micp_multi_init(d_call, d_state, st);
   for (uint32_t it = 0; it < n_iter && e == hipSuccess; ++it) {
     for (uint32_t s = 0; s < n_sensors && e == hipSuccess; ++s) {
       rmclhip_rcc* r = sensors[s];

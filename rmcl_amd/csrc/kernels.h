@@ -172,9 +172,13 @@ struct MicpMultiFastParams {
   const float* model_normals[kMaxMicpSensors];
   const double* partials[kMaxMicpSensors];               // [nblocks][96] of launch_micp_moments
   const unsigned long long* unc_mask[kMaxMicpSensors];
-  const MicpCall* sensor_call[kMaxMicpSensors];           // max_dist, rho_cap, tau_cap
   uint32_t n[kMaxMicpSensors], nblocks[kMaxMicpSensors];
-  const MicpMultiCall* call;
+  // per-call data BY VALUE (round 3: no H2D copy nodes in the chain, and nothing the one solving lane has to fetch from global
+  // memory inside the iterations): frames, merge weights, gates and caps of the sensors
+  xform Tsb[kMaxMicpSensors], Tbo[kMaxMicpSensors];
+  double weight[kMaxMicpSensors];
+  float max_dist[kMaxMicpSensors], rho_cap[kMaxMicpSensors], tau_cap[kMaxMicpSensors];
+  uint32_t n_sensors, seq;
   uint32_t n_iter;
   MicpMultiState* state_out;                              // may be host-mapped
   MicpMultiFastStatus* status;                            // may be host-mapped
@@ -182,7 +186,7 @@ struct MicpMultiFastParams {
 };
 hipError_t launch_micp_moments(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
                                const float* model_normals, const uint8_t* model_mask, uint32_t n, const MicpCall* call,
-                               double* partials, unsigned long long* unc_mask, hipStream_t s);
+                               double* partials, unsigned long long* unc_mask, hipStream_t s, const MicpCallLite* call_by_value = nullptr);
 hipError_t launch_micp_multi_fast_loop(const MicpMultiFastParams& p, hipStream_t s);
 hipError_t launch_micp_multi_init(const MicpMultiCall* call, MicpMultiState* state, hipStream_t s);
 hipError_t launch_micp_multi_step(const MicpMultiCall* call, MicpMultiState* state, hipStream_t s);

@@ -1995,14 +1995,18 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_multi_fast_loop(const Mic
   __shared__ double s_rows[kFastThreads][17];
   __shared__ double s_tot[kMaxMicpSensors][16];
   __shared__ double s_R[kMaxMicpSensors][9], s_t[kMaxMicpSensors][3];
-  __shared__ MomentScratch s_ws;
+  __shared__ MomentScratch s_ws[kFastThreads / 64];   // one per wave: without undecided correspondences wave w sums sensor w
   __shared__ uint32_t s_list[kFastMaxUncertain];
   __shared__ uint32_t s_seg[kMaxMicpSensors + 1];
   __shared__ uint32_t s_wave_cnt[kFastThreads / 64];
   __shared__ xform s_Ts[kMaxMicpSensors];
-  __shared__ uint32_t s_flag, s_flag_sensor;
+  __shared__ cstats s_Cs[kMaxMicpSensors];       // sensor statistics in the odom frame
+  __shared__ uint32_t s_wn[kMaxMicpSensors];     // ... and their weighted n_meas
+  __shared__ xform s_Tone;                       // T_onew_oold of this iteration, for the sensors' lanes
+  __shared__ float s_max_rho[kMaxMicpSensors], s_max_tau[kMaxMicpSensors];
+  __shared__ uint32_t s_bad;                     // smallest index of a sensor whose pre-transform left its caps
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t ns = p.call->n_sensors;
+  const uint32_t ns = p.n_sensors;
 
   // set-up, sensor by sensor: moments and the index-ordered list segment of its undecided correspondences
   uint32_t total = 0;
@@ -2057,7 +2061,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_multi_fast_loop(const Mic
         MicpMultiFastStatus st;
         st.code = 2u; st.iter = 0u; st.n_uncertain = total + cnt_s; st.sensor = s;
         for (uint32_t q = 0; q < kMaxMicpSensors; ++q) { st.max_rho[q] = 0.f; st.max_tau[q] = 0.f; }
-        publish_status(p.status, st, p.done, p.call->seq, 0u);
+        publish_status(p.status, st, p.done, p.seq, 0u);
       }
       return;
     }
@@ -2077,50 +2081,63 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_multi_fast_loop(const Mic
   }
   if (tid == 0u) {
     s_seg[ns] = total;
-    s_flag = 0u;
-    for (uint32_t s = 0; s < ns; ++s) s_Ts[s] = xidentity();
+    s_bad = 0xFFFFFFFFu;
   }
+  // Lane s of wave 0 OWNS sensor s (round 3): its frames, their inverses, its pre-transform and its caps live in that lane's
+  // registers, and everything that is per sensor -- the pre-transform's rotation matrix, the frame changes of its statistics, its
+  // next pre-transform -- runs in the ns lanes at once.  Lane 0 alone only merges and solves.  (Round 2 ran all of it on lane 0:
+  // ~2000 dependent instructions per iteration for two sensors, 9.4 us.)
+  const bool is_sensor = tid < ns;
+  const uint32_t sx = is_sensor ? tid : 0u;
+  const xform my_Tsb = p.Tsb[sx], my_Tbo = p.Tbo[sx];
+  const xform my_Tsb_inv = xinv(my_Tsb), my_Tbo_inv = xinv(my_Tbo);
+  const double my_weight = p.weight[sx];
+  const float my_rho_cap = p.rho_cap[sx], my_tau_cap = p.tau_cap[sx];
+  xform my_Ts = xidentity();
+  float my_max_rho = 0.f, my_max_tau = 0.f;
+  if (is_sensor) { s_Ts[tid] = my_Ts; s_max_rho[tid] = 0.f; s_max_tau[tid] = 0.f; }
   // loop state of thread 0
   xform T_onew_oold = xidentity();
   cstats merged = cs_identity(), merged_w = cs_identity();
-  float max_rho[kMaxMicpSensors], max_tau[kMaxMicpSensors];
-#pragma unroll
-  for (uint32_t q = 0; q < kMaxMicpSensors; ++q) { max_rho[q] = 0.f; max_tau[q] = 0.f; }
   __syncthreads();
   for (uint32_t it = 0; it < p.n_iter; ++it) {
-    if (tid == 0u) {
-      for (uint32_t s = 0; s < ns; ++s) {
-        const xform T = s_Ts[s];
-        const float rho = 2.0f * sqrtf((T.R.x * T.R.x + T.R.y * T.R.y) + T.R.z * T.R.z);
-        const float tau = sqrtf(dot_plain(T.t, T.t));
-        max_rho[s] = fmaxf(max_rho[s], rho);
-        max_tau[s] = fmaxf(max_tau[s], tau);
-        if ((!(rho <= p.sensor_call[s]->rho_cap) || !(tau <= p.sensor_call[s]->tau_cap)) && s_flag == 0u) { s_flag = 1u; s_flag_sensor = s; }
-        const double x = T.R.x, y = T.R.y, z = T.R.z, w = T.R.w;
-        const double ww = w * w, uu = (x * x + y * y) + z * z;
-        double* R = s_R[s];
-        R[0] = (ww - uu) + 2.0 * x * x; R[1] = 2.0 * (x * y - w * z);   R[2] = 2.0 * (x * z + w * y);
-        R[3] = 2.0 * (x * y + w * z);   R[4] = (ww - uu) + 2.0 * y * y; R[5] = 2.0 * (y * z - w * x);
-        R[6] = 2.0 * (x * z - w * y);   R[7] = 2.0 * (y * z + w * x);   R[8] = (ww - uu) + 2.0 * z * z;
-        s_t[s][0] = T.t.x; s_t[s][1] = T.t.y; s_t[s][2] = T.t.z;
-      }
+    if (is_sensor) {
+      const xform T = my_Ts;
+      const float rho = 2.0f * sqrtf((T.R.x * T.R.x + T.R.y * T.R.y) + T.R.z * T.R.z);
+      const float tau = sqrtf(dot_plain(T.t, T.t));
+      my_max_rho = fmaxf(my_max_rho, rho);
+      my_max_tau = fmaxf(my_max_tau, tau);
+      s_max_rho[tid] = my_max_rho; s_max_tau[tid] = my_max_tau;
+      if (!(rho <= my_rho_cap) || !(tau <= my_tau_cap)) atomicMin(&s_bad, tid);   // the FIRST sensor outside its caps is reported
+      const double x = T.R.x, y = T.R.y, z = T.R.z, w = T.R.w;
+      const double ww = w * w, uu = (x * x + y * y) + z * z;
+      double* R = s_R[tid];
+      R[0] = (ww - uu) + 2.0 * x * x; R[1] = 2.0 * (x * y - w * z);   R[2] = 2.0 * (x * z + w * y);
+      R[3] = 2.0 * (x * y + w * z);   R[4] = (ww - uu) + 2.0 * y * y; R[5] = 2.0 * (y * z - w * x);
+      R[6] = 2.0 * (x * z - w * y);   R[7] = 2.0 * (y * z + w * x);   R[8] = (ww - uu) + 2.0 * z * z;
+      s_t[tid][0] = T.t.x; s_t[tid][1] = T.t.y; s_t[tid][2] = T.t.z;
     }
     __syncthreads();
-    if (s_flag != 0u) {
+    if (s_bad != 0xFFFFFFFFu) {
       if (tid == 0u) {
         MicpMultiFastStatus st;
-        st.code = 1u; st.iter = it; st.n_uncertain = total; st.sensor = s_flag_sensor;
-        for (uint32_t q = 0; q < kMaxMicpSensors; ++q) { st.max_rho[q] = max_rho[q]; st.max_tau[q] = max_tau[q]; }
-        publish_status(p.status, st, p.done, p.call->seq, 0u);
+        st.code = 1u; st.iter = it; st.n_uncertain = total; st.sensor = s_bad;
+        for (uint32_t q = 0; q < kMaxMicpSensors; ++q) { st.max_rho[q] = (q < ns) ? s_max_rho[q] : 0.f; st.max_tau[q] = (q < ns) ? s_max_tau[q] : 0.f; }
+        publish_status(p.status, st, p.done, p.seq, 0u);
       }
       return;
     }
+    if (total == 0u) {
+      // nothing to re-evaluate (the usual tracking case): the sensors' 16 sums come from their moments alone, one sensor per wave
+      for (uint32_t s = wave; s < ns; s += kFastThreads / 64u) micp_moment_sums_wave(lane, s_mom[s], s_R[s], s_t[s], &s_ws[wave], s_tot[s]);
+      __syncthreads();
+    } else
     for (uint32_t s = 0; s < ns; ++s) {
       const uint32_t seg0 = s_seg[s], seg1 = s_seg[s + 1];
       const uint32_t nrows = min(seg1 - seg0, kFastThreads);
       if (tid < nrows) {
         const xform Tpre = s_Ts[s];
-        const float max_dist = p.sensor_call[s]->max_dist;
+        const float max_dist = p.max_dist[s];
         const float* dpts = p.dataset_points[s];
         const float* mpts = p.model_points[s];
         const float* mnrm = p.model_normals[s];
@@ -2153,7 +2170,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_multi_fast_loop(const Mic
       }
       __syncthreads();
       if (wave == 0u) {
-        micp_moment_sums_wave(lane, s_mom[s], s_R[s], s_t[s], &s_ws, s_tot[s]);
+        micp_moment_sums_wave(lane, s_mom[s], s_R[s], s_t[s], &s_ws[0], s_tot[s]);
         if (lane < 16u && nrows != 0u) {
           double v = s_tot[s][lane];
           for (uint32_t r = 0; r < nrows; ++r) v += s_rows[r][lane];
@@ -2162,28 +2179,39 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_multi_fast_loop(const Mic
       }
       __syncthreads();   // s_rows / s_ws are reused by the next sensor
     }
+    // k_micp_multi_step's merge and solve, frame by frame: the frame changes sensor-parallel, merge + solve on lane 0, the next
+    // pre-transforms sensor-parallel again.  All in wave 0, whose LDS operations complete in program order.
+    if (is_sensor) {
+      double tot[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) tot[k] = s_tot[tid][k];
+      const cstats stats_s = cstats_from_sums(tot);
+      s_Cs[tid] = cs_transform(my_Tbo, cs_transform(my_Tsb, stats_s));
+      s_wn[tid] = static_cast<uint32_t>(static_cast<double>(stats_s.n_meas) * my_weight);   // n_meas *= merge_weight_multiplier (:934)
+    }
+    if (wave == 0u) __builtin_amdgcn_wave_barrier();
     if (tid == 0u) {
-      // k_micp_multi_step's merge and solve, frame by frame
       merged = cs_identity();
       merged_w = cs_identity();
       for (uint32_t s = 0; s < ns; ++s) {
-        double tot[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) tot[k] = s_tot[s][k];
-        const cstats stats_s = cstats_from_sums(tot);
-        const cstats Cs_o = cs_transform(p.call->Tbo[s], cs_transform(p.call->Tsb[s], stats_s));
+        const cstats Cs_o = s_Cs[s];
         cstats Cs_w = Cs_o;
-        Cs_w.n_meas = static_cast<uint32_t>(static_cast<double>(Cs_w.n_meas) * p.call->weight[s]);
+        Cs_w.n_meas = s_wn[s];
         merged = cs_merge(merged, Cs_o);
         merged_w = cs_merge(merged_w, Cs_w);
       }
       T_onew_oold = xmul(T_onew_oold, umeyama_fast(merged_w));
-      for (uint32_t s = 0; s < ns; ++s) {
-        const xform T_bnew_bold = xmul(xmul(xinv(p.call->Tbo[s]), T_onew_oold), p.call->Tbo[s]);
-        s_Ts[s] = xmul(xmul(xinv(p.call->Tsb[s]), T_bnew_bold), p.call->Tsb[s]);
-      }
+      s_Tone = T_onew_oold;
+    }
+    if (wave == 0u) __builtin_amdgcn_wave_barrier();
+    if (is_sensor) {
+      const xform T1 = s_Tone;
+      const xform T_bnew_bold = xmul(xmul(my_Tbo_inv, T1), my_Tbo);
+      my_Ts = xmul(xmul(my_Tsb_inv, T_bnew_bold), my_Tsb);
+      s_Ts[tid] = my_Ts;
     }
   }
+  __syncthreads();
   if (tid == 0u) {
     MicpMultiState* out = p.state_out;
     out->T_onew_oold = T_onew_oold;
@@ -2192,9 +2220,9 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_multi_fast_loop(const Mic
     for (uint32_t s = 0; s < ns; ++s) out->T_snew_sold[s] = s_Ts[s];
     MicpMultiFastStatus st;
     st.code = 0u; st.iter = p.n_iter; st.n_uncertain = total; st.sensor = 0u;
-    for (uint32_t q = 0; q < kMaxMicpSensors; ++q) { st.max_rho[q] = max_rho[q]; st.max_tau[q] = max_tau[q]; }
+    for (uint32_t q = 0; q < kMaxMicpSensors; ++q) { st.max_rho[q] = (q < ns) ? s_max_rho[q] : 0.f; st.max_tau[q] = (q < ns) ? s_max_tau[q] : 0.f; }
     // the host reads T_onew_oold and the merged statistics of this block (rmclhip_micp_correct_once)
-    publish_status(p.status, st, p.done, p.call->seq, xor_words(T_onew_oold) ^ xor_words(merged) ^ xor_words(merged_w));
+    publish_status(p.status, st, p.done, p.seq, xor_words(T_onew_oold) ^ xor_words(merged) ^ xor_words(merged_w));
   }
 }
 
@@ -2227,9 +2255,10 @@ hipError_t launch_micp_iter(const float* dataset_points, const uint8_t* dataset_
 
 hipError_t launch_micp_moments(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
                                const float* model_normals, const uint8_t* model_mask, uint32_t n, const MicpCall* call,
-                               double* partials, unsigned long long* unc_mask, hipStream_t s) {
+                               double* partials, unsigned long long* unc_mask, hipStream_t s, const MicpCallLite* call_by_value) {
   MicpFastParams p{dataset_points, dataset_mask, model_points, model_normals, model_mask, n, micp_fast_blocks(n), call,
                    partials, unc_mask, 0u, nullptr, nullptr, nullptr, {}};
+  if (call_by_value) { p.call = nullptr; p.cv = *call_by_value; }
   hipLaunchKernelGGL(k_micp_moments, dim3(p.nblocks), dim3(256), 0, s, p);
   return hipGetLastError();
 }
