@@ -870,8 +870,31 @@ __device__ __forceinline__ void micp_moment_sums_wave(uint32_t lane, const doubl
   }
 }
 
+// Sum of the per-block moment partials [nblocks][kMom] into s_part[kFoldGroups][kMom] (the caller adds the groups after a barrier):
+// five groups of 48 threads, TWO moments (one 16-B load) per thread and row, 13 rows in flight -- 128 rows are two round trips
+// (round 2: two groups of 96 threads, one moment each, 16 in flight: four round trips, ~2 us of the loop kernel's set-up).
+constexpr uint32_t kFoldGroups = 5, kFoldLanes = kMom / 2, kFoldBatch = 13;
+__device__ __forceinline__ void fold_moment_partials(const double* __restrict__ partials, uint32_t nblocks, double (*s_part)[kMom], uint32_t tid) {
+  const uint32_t k2 = tid % kFoldLanes, g = tid / kFoldLanes;
+  if (g >= kFoldGroups) return;
+  const double2* base = reinterpret_cast<const double2*>(partials) + k2;
+  double a0 = 0.0, a1 = 0.0;
+  for (uint32_t b0 = g; b0 < nblocks; b0 += kFoldBatch * kFoldGroups) {
+    double2 v[kFoldBatch];
+#pragma unroll
+    for (uint32_t u = 0; u < kFoldBatch; ++u) {
+      const uint32_t b = b0 + u * kFoldGroups;
+      v[u] = (b < nblocks) ? base[static_cast<size_t>(b) * kFoldLanes] : double2{0.0, 0.0};
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < kFoldBatch; ++u) { a0 += v[u].x; a1 += v[u].y; }
+  }
+  s_part[g][2u * k2] = a0;
+  s_part[g][2u * k2 + 1u] = a1;
+}
+
 __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastParams p) {
-  constexpr uint32_t kGroups = kFastThreads / kMom;
+  constexpr uint32_t kGroups = kFoldGroups;
   __shared__ double s_mom[kMom];
   __shared__ double s_part[kGroups][kMom];
   __shared__ double s_rows[kFastThreads][17];   // per-thread raw sums of the uncertain correspondences (+1: bank spread)
@@ -885,29 +908,20 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastP
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const unsigned long long clk0 = __builtin_readcyclecounter();
 
-  // (1) moments = sum of the per-block partials: 16 loads in flight per thread
-  {
-    const uint32_t k = tid % kMom, g = tid / kMom;   // kGroups groups of 96 threads
-    if (g < kGroups) {
-      double a = 0.0;
-      uint32_t b = g;
-      for (; b + 15u * kGroups < p.nblocks; b += 16u * kGroups) {
-        double v[16];
-#pragma unroll
-        for (uint32_t u = 0; u < 16u; ++u) v[u] = p.partials[static_cast<size_t>(b + u * kGroups) * kMom + k];
-#pragma unroll
-        for (uint32_t u = 0; u < 16u; u += 4u) a += (v[u] + v[u + 1]) + (v[u + 2] + v[u + 3]);
-      }
-      for (; b < p.nblocks; b += kGroups) a += p.partials[static_cast<size_t>(b) * kMom + k];
-      s_part[g][k] = a;
-    }
-  }
+  // (1) moments = sum of the per-block partials
+  fold_moment_partials(p.partials, p.nblocks, s_part, tid);
   // (2) the uncertain correspondences, in index order: count per thread over a contiguous range of mask words, block scan
   const uint32_t nwords = (p.n + 63u) >> 6;
   const uint32_t wpt = (nwords + kFastThreads - 1u) / kFastThreads;
   const uint32_t w0 = min(tid * wpt, nwords), w1 = min(w0 + wpt, nwords);
   uint32_t cnt = 0;
-  for (uint32_t w = w0; w < w1; ++w) cnt += static_cast<uint32_t>(__popcll(p.unc_mask[w]));
+  for (uint32_t w = w0; w < w1; w += 8u) {   // eight words requested together (a word per iteration was one round trip per word)
+    unsigned long long m[8];
+#pragma unroll
+    for (uint32_t u = 0; u < 8u; ++u) m[u] = (w + u < w1) ? p.unc_mask[w + u] : 0ull;
+#pragma unroll
+    for (uint32_t u = 0; u < 8u; ++u) cnt += static_cast<uint32_t>(__popcll(m[u]));
+  }
   uint32_t incl = cnt;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -1989,7 +2003,7 @@ hipError_t launch_reduce_partials(const ReduceParams& p, hipStream_t s) {
 // come from its moments + its undecided correspondences at ITS pre-transform (see k_micp_fast_loop); the merge over the sensors
 // and the solve keep the frame-by-frame order of k_micp_multi_step.
 __global__ void __launch_bounds__(kFastThreads) k_micp_multi_fast_loop(const MicpMultiFastParams p) {
-  constexpr uint32_t kGroups = kFastThreads / kMom;
+  constexpr uint32_t kGroups = kFoldGroups;
   __shared__ double s_mom[kMaxMicpSensors][kMom];
   __shared__ double s_part[kGroups][kMom];
   __shared__ double s_rows[kFastThreads][17];
@@ -2011,29 +2025,19 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_multi_fast_loop(const Mic
   // set-up, sensor by sensor: moments and the index-ordered list segment of its undecided correspondences
   uint32_t total = 0;
   for (uint32_t s = 0; s < ns; ++s) {
-    {
-      const uint32_t k = tid % kMom, g = tid / kMom;
-      if (g < kGroups) {
-        double a = 0.0;
-        uint32_t b = g;
-        const double* part = p.partials[s];
-        for (; b + 15u * kGroups < p.nblocks[s]; b += 16u * kGroups) {
-          double v[16];
-#pragma unroll
-          for (uint32_t u = 0; u < 16u; ++u) v[u] = part[static_cast<size_t>(b + u * kGroups) * kMom + k];
-#pragma unroll
-          for (uint32_t u = 0; u < 16u; u += 4u) a += (v[u] + v[u + 1]) + (v[u + 2] + v[u + 3]);
-        }
-        for (; b < p.nblocks[s]; b += kGroups) a += part[static_cast<size_t>(b) * kMom + k];
-        s_part[g][k] = a;
-      }
-    }
+    fold_moment_partials(p.partials[s], p.nblocks[s], s_part, tid);
     const unsigned long long* mask = p.unc_mask[s];
     const uint32_t nwords = (p.n[s] + 63u) >> 6;
     const uint32_t wpt = (nwords + kFastThreads - 1u) / kFastThreads;
     const uint32_t w0 = min(tid * wpt, nwords), w1 = min(w0 + wpt, nwords);
     uint32_t cnt = 0;
-    for (uint32_t w = w0; w < w1; ++w) cnt += static_cast<uint32_t>(__popcll(mask[w]));
+    for (uint32_t w = w0; w < w1; w += 8u) {
+      unsigned long long m[8];
+#pragma unroll
+      for (uint32_t u = 0; u < 8u; ++u) m[u] = (w + u < w1) ? mask[w + u] : 0ull;
+#pragma unroll
+      for (uint32_t u = 0; u < 8u; ++u) cnt += static_cast<uint32_t>(__popcll(m[u]));
+    }
     uint32_t incl = cnt;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
