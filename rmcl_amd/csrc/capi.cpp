@@ -937,10 +937,15 @@ rmclhip_status rmclhip_rcc_set_input_pointcloud2(rmclhip_rcc* r, const uint8_t* 
   return RMCLHIP_OK;
 }
 
-static uint32_t pick_tile_w_log2(uint32_t H) {
-  // 8x8 tiles for images at least 8 rows tall; flatter tiles for 2-D scanners
+static uint32_t pick_tile_w_log2(uint32_t H, bool packet) {
+  // The 64 rays of a wave (kind 2: of a block) are a tile of the scan image.  The wave-packet traversal (kind 0), whose rays walk
+  // together, keeps round 1's square 8x8 tiles (images at least 8 rows tall; flatter tiles for 2-D scanners).  For the per-ray
+  // traversals round 3 re-measured the shapes with the frontier start in place (profiles/r03_find_tile_shapes.txt): 16 wide x 4 tall
+  // is faster or equal in 10 of 12 (size, map) cells of kinds 23 / 2 -- C2 16.9 -> 16.5 us (sphere), 25.3 -> 24.5 us (room) -- and
+  // neutral for pose batches (kind 24).
+  const uint32_t max_th = packet ? 8u : 4u;
   uint32_t th = 1;
-  while (th < H && th < 8) th <<= 1;
+  while (th < H && th < max_th) th <<= 1;
   uint32_t twl = 0;
   while ((64u >> twl) > th) ++twl;
   return twl;  // tile = 2^twl wide, 64 >> twl tall
@@ -987,7 +992,7 @@ static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
   }
   p.model_tab = r->d_model_tab.p;
   p.W = r->W; p.H = r->H;
-  p.tile_w_log2 = (r->tile_override > 0) ? static_cast<uint32_t>(r->tile_override - 1) : pick_tile_w_log2(r->H);
+  p.tile_w_log2 = (r->tile_override > 0) ? static_cast<uint32_t>(r->tile_override - 1) : pick_tile_w_log2(r->H, find_variant(r, nposes) == 0);
   const uint32_t tw = 1u << p.tile_w_log2, th = 64u >> p.tile_w_log2;
   p.tiles_x = (r->W + tw - 1) / tw;
   p.tiles_y = (r->H + th - 1) / th;
@@ -1905,12 +1910,11 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
     r->loop_blocks = kLoopBlocks[(variant >> 10) & 7];
   }
   r->graph_dirty = true; r->fast_graph_dirty = true;
-  if (tiling_changed) {
-    HIPCHK(hipSetDevice(r->ctx->device));
-    HIPCHK(hipStreamSynchronize(r->stream));
-    return rebuild_tile_planes(r);
-  }
-  return RMCLHIP_OK;
+  // the tile shape depends on the kind (packet: 8x8, per-ray: 16x4) and on the override: the plane table follows
+  (void)tiling_changed;
+  HIPCHK(hipSetDevice(r->ctx->device));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  return rebuild_tile_planes(r);
 }
 
 rmclhip_status rmclhip_rcc_set_micp_fast(rmclhip_rcc* r, int mode) {
