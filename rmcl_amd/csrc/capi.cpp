@@ -242,6 +242,7 @@ struct rmclhip_rcc {
   // rmclhip_rcc_autotune[_batch]: the kind measured fastest for the current (map, model), for single scans / pose batches (0 = the
   // rule), and whether its rays start at the frontier (kinds 23 / 24 without it are round 2's kinds 19 / 22)
   int tuned_kind = 0, tuned_batch_kind = 0;
+  int tuned_tile = 0;              // 1 + log2(tile width) measured best by rmclhip_rcc_autotune (0 = the rule's shape)
   bool tuned_frontier = true, tuned_batch_frontier = true;
   DevBuf<float> d_tile_planes;     // plane table of the frontier start for the current (model, tiling): 16 floats per tile
   bool tile_planes_ok = false;
@@ -707,7 +708,7 @@ rmclhip_status rmclhip_rcc_set_tsb(rmclhip_rcc* r, const rmclhip_transform* Tsb)
   return RMCLHIP_OK;
 }
 
-static rmclhip_status rebuild_tile_planes(rmclhip_rcc* r);
+static rmclhip_status rebuild_tile_planes(rmclhip_rcc* r, bool keep_tuning = false);
 
 rmclhip_status rmclhip_rcc_set_model_spherical(rmclhip_rcc* r, const rmclhip_spherical_model* m) {
   ApiGuard guard_("rmclhip_rcc_set_model_spherical");
@@ -784,7 +785,7 @@ rmclhip_status rmclhip_rcc_set_model_ondn(rmclhip_rcc* r, uint32_t width, uint32
   HIPCHK(hipStreamSynchronize(r->stream));
   r->kind = kModelOnDn;
   r->tile_planes_ok = false;
-  r->tuned_kind = r->tuned_batch_kind = 0; r->tuned_frontier = r->tuned_batch_frontier = true;
+  r->tuned_kind = r->tuned_batch_kind = 0; r->tuned_frontier = r->tuned_batch_frontier = true; r->tuned_tile = 0;
   r->graph_dirty = true; r->fast_graph_dirty = true;
   r->W = width; r->H = height;
   r->range = range;
@@ -992,7 +993,9 @@ static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
   }
   p.model_tab = r->d_model_tab.p;
   p.W = r->W; p.H = r->H;
-  p.tile_w_log2 = (r->tile_override > 0) ? static_cast<uint32_t>(r->tile_override - 1) : pick_tile_w_log2(r->H, find_variant(r, nposes) == 0);
+  p.tile_w_log2 = (r->tile_override > 0) ? static_cast<uint32_t>(r->tile_override - 1)
+                  : ((r->tuned_tile > 0 && find_variant(r, nposes) != 0) ? static_cast<uint32_t>(r->tuned_tile - 1)
+                                                                         : pick_tile_w_log2(r->H, find_variant(r, nposes) == 0));
   const uint32_t tw = 1u << p.tile_w_log2, th = 64u >> p.tile_w_log2;
   p.tiles_x = (r->W + tw - 1) / tw;
   p.tiles_y = (r->H + th - 1) / th;
@@ -1007,10 +1010,13 @@ static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
 
 // The frontier start's plane table belongs to (model, tiling): rebuilt -- one small launch on the handle's stream -- by whatever
 // changes either (the model setters, set_variant's tile shape), never inside a find (finds are captured into graphs).
-static rmclhip_status rebuild_tile_planes(rmclhip_rcc* r) {
+static rmclhip_status rebuild_tile_planes(rmclhip_rcc* r, bool keep_tuning) {
   r->tile_planes_ok = false;
-  r->tuned_kind = r->tuned_batch_kind = 0;   // a measurement belongs to the model it was taken with
-  r->tuned_frontier = r->tuned_batch_frontier = true;
+  if (!keep_tuning) {
+    r->tuned_kind = r->tuned_batch_kind = 0;   // a measurement belongs to the model it was taken with
+    r->tuned_frontier = r->tuned_batch_frontier = true;
+    r->tuned_tile = 0;
+  }
   if (r->kind == kModelOnDn || r->kind == kModelNone || r->W == 0 || r->H == 0) return RMCLHIP_OK;
   FindParams p;
   fill_find_params(r, p, 1);
@@ -1817,6 +1823,25 @@ rmclhip_status rmclhip_rcc_autotune(rmclhip_rcc* r, const rmclhip_transform* Tbm
     if (!best || t[2] < best_ms) { best = &c; best_ms = t[2]; }
   }
   r->tuned_kind = best->kind; r->tuned_frontier = best->frontier;
+  // ... then the tile shape of the winner (the rule: 16 wide x 4 tall; profiles/r03_find_tile_shapes.txt shows maps that prefer
+  // 4 x 16 or 32 x 2): widths 4, 8, 32 where the image is tall enough, the plane table rebuilt for each
+  if (r->tile_override == 0) {
+    int best_tile = 0;
+    for (int tile : {3, 4, 6}) {
+      const uint32_t th = 64u >> (tile - 1);
+      if (th > r->H && th > 1u) continue;            // taller than the image: lanes without rays
+      r->tuned_tile = tile;
+      if (rmclhip_status st = rebuild_tile_planes(r, true)) { r->tuned_tile = 0; (void)rebuild_tile_planes(r, true); return st; }
+      float t[5];
+      for (float& x : t) {
+        if (rmclhip_status st = rmclhip_rcc_time_find(r, Tbm_est, 8, &x)) { r->tuned_tile = 0; (void)rebuild_tile_planes(r, true); return st; }
+      }
+      std::sort(t, t + 5);
+      if (t[2] < 0.98f * best_ms) { best_tile = tile; best_ms = t[2]; }   // a 2 % margin: do not chase noise
+    }
+    r->tuned_tile = best_tile;
+    if (rmclhip_status st = rebuild_tile_planes(r, true)) return st;
+  }
   r->graph_dirty = true; r->fast_graph_dirty = true;
   if (chosen_kind) *chosen_kind = best->reported;
   if (kernel_ms) *kernel_ms = best_ms;
