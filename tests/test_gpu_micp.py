@@ -287,6 +287,58 @@ def test_two_sensor_device_loop_equals_host_loop(ra, orc, ctx, meshes):
     sensors[0].correspondences_.close()
 
 
+def test_six_sensor_device_loop_equals_host_loop(ra, orc, ctx, meshes):
+    """the N-sensor device loop with SIX sensors (more than the four waves of its workgroup: wave w evaluates sensors w and w + 4;
+    lanes 0..5 of wave 0 own one sensor each): different models, mounts, odometry offsets and merge weights (one of them 0:
+    the sensor counts in the optimal merge only).  Equal to the host loop -- per sensor and iteration one computeCrossStatistics --
+    in the moment form (small correction) and in its fallback (large correction)."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room30k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    truth = T.transform_from_rpy((1.0, -2.0, 1.4), (0.02, -0.03, 0.4))
+    rng = np.random.RandomState(5)
+    models = [syn.model_c1(), syn.model_vlp16_900(0.3), syn.model_pf16(), syn.model_c1(), syn.model_pf16(), syn.model_c1()]
+    weights = [1.0, 0.37, 2.0, 0.0, 1.0, 0.5]
+    specs = []
+    for k, (model, w) in enumerate(zip(models, weights)):
+        Tsb = T.transform_from_rpy(tuple(rng.uniform(-0.3, 0.3, 3)), tuple(rng.uniform(-0.5, 0.5, 3)))
+        Tbo = T.transform_from_rpy(tuple(rng.uniform(-0.01, 0.01, 3)), (0.0, 0.0, float(rng.uniform(-0.003, 0.003))))
+        specs.append(("s%d" % k, model, Tsb, Tbo, w))
+
+    def build():
+        sensors = []
+        for name, model, Tsb, Tbo, w in specs:
+            meas = m.simulate_spherical(model, Tsb, T.mult(truth, Tbo), bvh=True, nthreads=8)
+            ds, mask = om.dataset_from_ranges(model, meas["ranges"])
+            rcc = ra.RCCHipSpherical(hm)
+            rcc.setModel(model)
+            rcc.set_dataset(ds, mask)
+            rcc.params.max_dist, rcc.adaptive_max_dist_min = 0.8, 0.2
+            s = ra.MICPSensor(name, rcc, Tsb=Tsb, Tbo=Tbo, merge_weight_multiplier=w)
+            s.valid_dataset_measurements = int(mask.sum())
+            sensors.append(s)
+        return sensors
+
+    est_far = T.mult(truth, T.transform_from_rpy((0.15, -0.1, 0.04), (0.01, 0.0, 0.03)))
+    est_near = T.mult(truth, T.transform_from_rpy((0.02, -0.015, 0.01), (0.001, 0.0, 0.004)))
+    for n_iter, progress, est, want_done in ((6, 0.2, est_far, False), (9, 0.1, est_near, True)):
+        host = ra.MICPLocalization(build(), optimization_iterations=n_iter)
+        host.Tom_, host.convergence_progress_ = est, progress
+        Th = host.correctOnce()
+        dev = ra.MICPLocalization(build(), optimization_iterations=n_iter)
+        for rep in range(3):
+            dev.Tom_, dev.convergence_progress_ = est, progress
+            Td = dev.correctOnce(device_loop=True)
+            _transform_close(Td, Th, 1e-5)
+        infos = [s.correspondences_.micp_fast_info() for s in dev.sensors_vec_]
+        assert all(i["attempts"] == 3 for i in infos) and (not want_done or all(i["done"] >= 1 for i in infos)), infos
+        assert dev.correction_stats_latest_["valid_matches"] == host.correction_stats_latest_["valid_matches"] > 1000
+        _transform_close(dev.Tom_, host.Tom_, 1e-5)
+        for s in host.sensors_vec_ + dev.sensors_vec_:
+            s.correspondences_.close()
+
+
 def _room_case(ra, orc, ctx, meshes, model):
     from rmcl_amd import types as T
     v, f = meshes("room30k")
