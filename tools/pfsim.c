@@ -54,6 +54,9 @@ static void slot_start(slot_t* s, const float* O, const float* D, float tfar)
 
 static void slot_pop(slot_t* s) { if (s->sp > 0) s->cur = s->stack[--s->sp]; else s->cur = DONE; }
 
+static int g_tie_mode = 0;   /* 0: order children by entry distance alone; 1: ties at 0 (origin inside the box) by FARTHEST exit first; 2: nearest exit first */
+void pfsim_tie_mode(int m) { g_tie_mode = m; }
+static float g_last_tf;
 static int box(const float* nd, uint32_t c, const slot_t* s, float* tn_out)
 {
   float tn = 0.0f, tf = s->best_t;
@@ -65,6 +68,7 @@ static int box(const float* nd, uint32_t c, const slot_t* s, float* tn_out)
     if (t1 < tf) tf = t1;
   }
   *tn_out = tn;
+  g_last_tf = tf;
   return nd[c] < 1e29f && tn <= tf;
 }
 
@@ -74,7 +78,7 @@ static void node_step(slot_t* s, const uint32_t* nodes)
   const uint32_t* ch = nodes + 32u * s->cur + 24u;
   float key[4]; uint32_t ref[4]; int nh = 0;
   s->nvisit++;
-  for (uint32_t c = 0; c < 4; ++c) { float tn; if (box(nd, c, s, &tn)) { key[nh] = tn; ref[nh] = ch[c]; nh++; } }
+  for (uint32_t c = 0; c < 4; ++c) { float tn; if (box(nd, c, s, &tn)) { key[nh] = tn; if (g_tie_mode && tn == 0.0f) key[nh] = (g_tie_mode == 1) ? -g_last_tf * 1e-20f : -1e-20f / (g_last_tf + 1e-20f); ref[nh] = ch[c]; nh++; } }
   for (int a = 0; a < nh; ++a) for (int b = a + 1; b < nh; ++b)
     if (key[b] < key[a]) { float t = key[a]; key[a] = key[b]; key[b] = t; uint32_t r = ref[a]; ref[a] = ref[b]; ref[b] = r; }
   for (int a = nh - 1; a >= 1; --a) if (s->sp < 96) s->stack[s->sp++] = ref[a];
