@@ -2487,11 +2487,11 @@ rmclhip_status rmclhip_resampler_residual(rmclhip_resampler* r, const rmclhip_tr
   // 2. a block of draws that fills the cloud with a margin: N_new / E[copies per draw] x 1.25 + 4096; doubled if it falls short
   const double per_draw = static_cast<double>(st.expect) / static_cast<double>(n_particles);
   double want = static_cast<double>(n_new) / per_draw * 1.25 + 4096.0;
-  const double kMaxDraws = 1073741824.0;   // 2^30 draws = 16 GB of scratch: far beyond any sane input
+  const double kMaxDraws = 268435456.0;    // 2^28 draws = 4 GB of scratch: far beyond any sane input
   unsigned long long total = 0ull;
   uint32_t n_draws = 0;
   for (;;) {
-    if (want > kMaxDraws) return fail(RMCLHIP_ERR_UNSUPPORTED, "resampler_residual: more than 2^30 draws would be needed to fill the cloud");
+    if (want > kMaxDraws) return fail(RMCLHIP_ERR_UNSUPPORTED, "resampler_residual: more than 2^28 draws would be needed to fill the cloud");
     n_draws = static_cast<uint32_t>(want);
     const uint32_t nb = (n_draws + 1023u) / 1024u;
     HIPCHK(r->d_res_idx.reserve(n_draws));
