@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """GPU perf exploration of the particle-filter update (config C4): kernel generations and their knobs.
-usage: python tools/pf_explore.py [sphere|room] [variant ...]"""
+usage: python tools/pf_explore.py [sphere|room|sphere1m] [variant ...]   (sphere1m: the 1 M-triangle map of config C5, 125 k particles)"""
 import math
 import os
 import sys
@@ -20,12 +20,12 @@ NAMES = {64 | LEGACY | MAPTREE: "round-2 kernel, map tree (leaves<=4)", 64 | LEG
 mesh = sys.argv[1] if len(sys.argv) > 1 else "sphere"
 variants = [int(a) for a in sys.argv[2:]] or list(NAMES)
 ctx = ra.Context(0)
-v, f = syn.uv_sphere(100000) if mesh == "sphere" else syn.noisy_room(100000)
+v, f = syn.uv_sphere(1000000) if mesh == "sphere1m" else (syn.uv_sphere(100000) if mesh == "sphere" else syn.noisy_room(100000))
 hm = ra.import_hip_map(ctx, v, f)
 print("map", hm.info())
 dirs = syn.model_directions(syn.model_pf16())
-for n_particles, n_beams in ((100000, 256), (100000, 100)):
-    if mesh == "sphere":
+for n_particles, n_beams in (((125000, 256),) if mesh == "sphere1m" else ((100000, 256), (100000, 100))):
+    if mesh in ("sphere", "sphere1m"):
         poses, attrs = syn.uniform_particles(n_particles, seed=42, bb_min=(-5, -5, -1, 0, 0, -math.pi), bb_max=(5, 5, 1, 0, 0, math.pi))
     else:
         poses, attrs = syn.uniform_particles(n_particles, seed=42, bb_min=(-9, -9, 0.3, 0, 0, -math.pi), bb_max=(9, 9, 3, 0, 0, math.pi))
