@@ -634,6 +634,7 @@ class PCDSensorUpdaterHipSharded : public SensorUpdaterBase {
     return e;
   }
   void resample(const rmclhip_gladiator_config& cfg, uint64_t seed, uint32_t step) { check(rmclhip_pf_sharded_resample(h_, &cfg, seed, step)); }
+  void resampleResidual(const rmclhip_gladiator_config& cfg, uint64_t seed, uint32_t step) { check(rmclhip_pf_sharded_resample_residual(h_, &cfg, seed, step)); }
 
  private:
   rmclhip_comm* comm_ = nullptr;

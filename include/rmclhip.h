@@ -549,6 +549,9 @@ rmclhip_status rmclhip_pf_allreduce_pose_estimate(rmclhip_pf_sharded* pf, uint32
  * champions against the gathered cloud (Philox counter = GLOBAL champion index => identical to one GPU).  n_total must
  * be a multiple of the device count. */
 rmclhip_status rmclhip_pf_sharded_resample(rmclhip_pf_sharded* pf, const rmclhip_gladiator_config* config, uint64_t seed, uint32_t step);
+/* the same exchange with the residual resampler (rmclhip_resampler_residual): every device fills its slots of the new cloud from the
+ * gathered one -- identical to one GPU (draws and Gaussians are functions of global indices) */
+rmclhip_status rmclhip_pf_sharded_resample_residual(rmclhip_pf_sharded* pf, const rmclhip_gladiator_config* config, uint64_t seed, uint32_t step);
 
 /* ---- device memory helpers for hosts without their own allocator ---------------------- */
 rmclhip_status rmclhip_malloc(rmclhip_ctx* ctx, size_t bytes, void** out_dev);

@@ -196,6 +196,7 @@ SIGNATURES = {
     "rmclhip_pf_allreduce_stats": (_i32, [_vp, C.POINTER(LikelihoodStats)]),
     "rmclhip_pf_allreduce_pose_estimate": (_i32, [_vp, _u32, C.POINTER(PoseEstimate)]),
     "rmclhip_pf_sharded_resample": (_i32, [_vp, C.POINTER(GladiatorConfig), C.c_uint64, _u32]),
+    "rmclhip_pf_sharded_resample_residual": (_i32, [_vp, C.POINTER(GladiatorConfig), C.c_uint64, _u32]),
     "rmclhip_malloc": (_i32, [_vp, _sz, _pp]),
     "rmclhip_free": (_i32, [_vp, _vp]),
     "rmclhip_memcpy_h2d": (_i32, [_vp, _vp, _vp, _sz]),

@@ -2932,8 +2932,21 @@ rmclhip_status rmclhip_pf_allreduce_pose_estimate(rmclhip_pf_sharded* h, uint32_
 // distributed gladiator tournament: the enemy of a champion may live on any rank, so the cloud (68 B per
 // particle) is all-gathered once, then every rank resamples its own champions against the gathered copy; the Philox
 // stream is a function of the GLOBAL champion index, so the result equals the single-GPU tournament
+static rmclhip_status pf_sharded_resample_impl(rmclhip_pf_sharded* h, const rmclhip_gladiator_config* cfg, uint64_t seed, uint32_t step,
+                                              bool residual);
+
 rmclhip_status rmclhip_pf_sharded_resample(rmclhip_pf_sharded* h, const rmclhip_gladiator_config* cfg, uint64_t seed, uint32_t step) {
   ApiGuard guard_("rmclhip_pf_sharded_resample");
+  return pf_sharded_resample_impl(h, cfg, seed, step, false);
+}
+
+rmclhip_status rmclhip_pf_sharded_resample_residual(rmclhip_pf_sharded* h, const rmclhip_gladiator_config* cfg, uint64_t seed, uint32_t step) {
+  ApiGuard guard_("rmclhip_pf_sharded_resample_residual");
+  return pf_sharded_resample_impl(h, cfg, seed, step, true);
+}
+
+static rmclhip_status pf_sharded_resample_impl(rmclhip_pf_sharded* h, const rmclhip_gladiator_config* cfg, uint64_t seed, uint32_t step,
+                                              bool residual) {
   if (!h || !cfg) return fail(RMCLHIP_ERR_INVALID, "pf_sharded_resample: null");
   if (h->n_total == 0) return RMCLHIP_OK;
   const uint32_t world = static_cast<uint32_t>(h->ranks.size()), cap = (h->n_total + world - 1u) / world;
@@ -2956,11 +2969,18 @@ rmclhip_status rmclhip_pf_sharded_resample(rmclhip_pf_sharded* h, const rmclhip_
   }
   for (PfRank& R : h->ranks) {
     if (R.hi == R.lo) continue;
-    if (rmclhip_status st = rmclhip_resampler_gladiator(R.rs, reinterpret_cast<const rmclhip_transform*>(R.d_poses_all),
-                                                        static_cast<const rmclhip_particle_attributes*>(R.d_attrs_all), h->n_total,
-                                                        reinterpret_cast<rmclhip_transform*>(R.d_poses_new),
-                                                        static_cast<rmclhip_particle_attributes*>(R.d_attrs_new), R.lo, R.hi - R.lo, cfg, seed, step))
-      return st;
+    // every device resamples ITS slots / champions against the whole gathered cloud: both streams are functions of global indices
+    const rmclhip_status st =
+        residual ? rmclhip_resampler_residual(R.rs, reinterpret_cast<const rmclhip_transform*>(R.d_poses_all),
+                                              static_cast<const rmclhip_particle_attributes*>(R.d_attrs_all), h->n_total,
+                                              reinterpret_cast<rmclhip_transform*>(R.d_poses_new),
+                                              static_cast<rmclhip_particle_attributes*>(R.d_attrs_new), h->n_total, R.lo, R.hi - R.lo, cfg, seed,
+                                              step, nullptr)
+                 : rmclhip_resampler_gladiator(R.rs, reinterpret_cast<const rmclhip_transform*>(R.d_poses_all),
+                                               static_cast<const rmclhip_particle_attributes*>(R.d_attrs_all), h->n_total,
+                                               reinterpret_cast<rmclhip_transform*>(R.d_poses_new),
+                                               static_cast<rmclhip_particle_attributes*>(R.d_attrs_new), R.lo, R.hi - R.lo, cfg, seed, step);
+    if (st != RMCLHIP_OK) return st;
     std::swap(R.d_poses, R.d_poses_new);
     std::swap(R.d_attrs, R.d_attrs_new);
   }

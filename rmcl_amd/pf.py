@@ -320,9 +320,11 @@ class ShardedParticleFilterHip:
                 "likelihood": {"mean": e.likelihood_mean, "sigma": e.likelihood_sigma, "min": e.likelihood_min, "max": e.likelihood_max},
                 "trans_bb_min": np.array(e.trans_bb_min), "trans_bb_max": np.array(e.trans_bb_max), "nparticles": e.n_particles}
 
-    def resample(self, cfg=None, seed=42, step=0):
+    def resample(self, cfg=None, seed=42, step=0, residual=False):
+        """all-gather the cloud, then every device resamples its shard: the gladiator tournament (default) or the residual resampler"""
         cfg = cfg if cfg is not None else gladiator_config()
-        _capi.check(_capi.lib().rmclhip_pf_sharded_resample(self._h, C.byref(cfg), int(seed), int(step)))
+        fn = _capi.lib().rmclhip_pf_sharded_resample_residual if residual else _capi.lib().rmclhip_pf_sharded_resample
+        _capi.check(fn(self._h, C.byref(cfg), int(seed), int(step)))
 
     def close(self):
         if self._h:

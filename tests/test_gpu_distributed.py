@@ -143,4 +143,13 @@ def test_c_abi_sharded_particle_filter_on_one_device(ra, orc, ctx, meshes):
     p3, a3 = sh.download()
     assert p3.tobytes() == d_pn.download().tobytes() and a3.tobytes() == d_an.download().tobytes()
     rs.close()
+    # ... and the distributed residual resampling == the single-GPU one (on the cloud the tournament left behind)
+    rr = ra.ResidualResamplerHip(ctx, seed=43)
+    d_p4, d_a4 = ra.DeviceArray.from_host(ctx, p3), ra.DeviceArray.from_host(ctx, a3)
+    rr.update(d_p4, d_a4, d_pn, d_an, n)
+    sh.resample(seed=43, step=0, residual=True)
+    p5, a5 = sh.download()
+    assert p5.tobytes() == d_pn.download().tobytes() and a5.tobytes() == d_an.download().tobytes()
+    assert a5.tobytes() != a3.tobytes()
+    rr.close()
     sh.close()
