@@ -84,6 +84,18 @@ def _worker(rank, world, port, n_total, out_dir):
         pn, an = D.ShardedResample(resample, n_total, rank, world).update(lp, la)
         pn_ref, an_ref = orc.gladiator_resample(poses, full, cfg, seed=77, step=3)
         ok &= pn.tobytes() == pn_ref[lo:hi].tobytes() and an.tobytes() == an_ref[lo:hi].tobytes()
+        # the same exchange for the residual resampler: every rank fills its slots [lo, hi) of the new cloud from the gathered one
+        if float(full["likelihood"]["mean"].astype(np.float64).sum()) > 0 and n_total >= 100:
+            def resample_residual(poses_all, attrs_all, n, first, count):
+                pa = poses_all.numpy().reshape(-1).view(orc.TRANSFORM)
+                aa = attrs_all.numpy().reshape(-1).view(orc.PARTICLE_ATTRIBUTES)
+                pr, ar, filled, _ = orc.residual_resample(pa, aa, cfg, seed=78, step=1, max_draws=200 * n)
+                assert filled == n
+                return pr[first:first + count], ar[first:first + count]
+
+            pr, ar = D.ShardedResample(resample_residual, n_total, rank, world).update(lp, la)
+            pr_ref, ar_ref, filled, _ = orc.residual_resample(poses, full, cfg, seed=78, step=1, max_draws=200 * n_total)
+            ok &= filled == n_total and pr.tobytes() == pr_ref[lo:hi].tobytes() and ar.tobytes() == ar_ref[lo:hi].tobytes()
         with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as fh:
             fh.write("OK" if ok else "MISMATCH")
     finally:
