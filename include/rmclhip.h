@@ -353,11 +353,11 @@ rmclhip_status rmclhip_rcc_time_correct_once(rmclhip_rcc* rcc, const rmclhip_tra
 /* kernel variant selection: bits 0..3 (+ bit 13 = 16 more) traversal kind.  15 = automatic, the default: four
  * lanes per ray up to 57344 rays in flight (kind 2); above that one lane per ray STARTING AT THE MAP'S FRONTIER (the wave culls
  * the <= 256 references of BFS depth 4 against its tile's pyramid and every ray tests the few survivors: the top levels of
- * the descent cost one cooperative pass) -- kind 23 on the full-precision nodes up to 524288 rays, kind 24 on the 64-B quantised
- * nodes above (pose batches).  librmclhip.so builds those three plus 0 = wave packet; every other kind is a measured-and-
+ * the descent cost one cooperative pass) -- kind 23 on the full-precision nodes up to 262144 rays, kind 24 on the 64-B quantised
+ * nodes of the particle filter's tree (leaves <= 2 triangles) above (large scans, pose batches).  librmclhip.so builds those three plus 0 = wave packet; every other kind is a measured-and-
  * rejected or superseded experiment that lives in librmclhip_lab.so (include/rmclhip_lab.h lists them) and is accepted here
  * only while that library is loaded (RMCLHIP_ERR_UNSUPPORTED otherwise),
- * bits 4..7 = 1 + log2(tile width) of the wave's scan-image tile (0 = automatic, 8x8 for tall images),
+ * bits 4..7 = 1 + log2(tile width) of the wave's scan-image tile (0 = automatic: 16 wide x 4 tall, 8x8 for the wave packet),
  * bit 8 = fused last-block reduction tail (A/B), bit 9 = disable the hipGraph MICP loop (A/B), bits 10..12 = form
  * of the MICP loop (0 = one launch per iteration, the default; 1 = reduce + solve launches; 2..6 = persistent
  * kernel with 16..256 blocks and a grid barrier, A/B) */

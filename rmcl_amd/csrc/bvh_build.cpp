@@ -346,14 +346,14 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
   // frontier of the map's tree (layout.h: kFrontierDepth): every child reference found at BFS depth kFrontierDepth, and every
   // leaf reference above it, with the (padded) box its parent stores for it.  A child's stored box lies inside its parent's,
   // so "the ray hits this entry's box" is the exact condition under which the traversal from the root would reach it.
-  out.frontier.clear();
-  {
+  auto frontier_of = [](const std::vector<Node4>& tree, std::vector<Node4C::Child>& table) {
+    table.clear();
     struct It { uint32_t node; uint32_t depth; };
     std::vector<It> todo{{0u, 0u}};
     while (!todo.empty()) {
       const It it = todo.back();
       todo.pop_back();
-      const Node4& nd = out.nodes[it.node];
+      const Node4& nd = tree[it.node];
       for (uint32_t c = 0; c < nd.n_children; ++c) {
         const uint32_t ref = nd.child[c];
         if (!(ref & kLeafBit) && it.depth + 1u < kFrontierDepth) { todo.push_back({ref, it.depth + 1u}); continue; }
@@ -361,10 +361,14 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
         e.lo[0] = nd.x[c]; e.lo[1] = nd.y[c]; e.lo[2] = nd.z[c];
         e.hix = nd.x[4 + c]; e.hiy = nd.y[4 + c]; e.hiz = nd.z[4 + c];
         e.ref = ref; e.pad = 0;
-        out.frontier.push_back(e);
+        table.push_back(e);
       }
     }
-  }
+  };
+  frontier_of(out.nodes, out.frontier);
+  // ... and of the filter's tree: the batch traversal of find (kind 24) walks that tree (round 3: its two-triangle leaves make the
+  // per-lane triangle loop 6-10 % cheaper for pose batches), whose node indices differ from the map tree's below the top levels
+  frontier_of(out.nodes_pf, out.frontier_pf);
 
   out.cnodes.resize(out.nodes.size());
   for (size_t i = 0; i < out.nodes.size(); ++i) {

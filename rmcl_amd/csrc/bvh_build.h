@@ -25,6 +25,7 @@ struct BvhHost {
   std::vector<Node4> nodes_pf;    // the particle filter's cut of the same BVH2 (leaves <= kPfLeafTris): host-side only
   std::vector<Node4Q> qnodes_pf;  // ... and its quantised form, what k_pf_update_* reads
   std::vector<Node4C::Child> frontier;  // <= 4^kFrontierDepth entries {box, ref}: where a scan's rays can start (layout.h)
+  std::vector<Node4C::Child> frontier_pf;   // the same for the filter's tree (nodes_pf / qnodes_pf)
   std::vector<TriRec> tris;  // leaf order (shared by both trees)
   BvhInfo info;
 };

@@ -135,6 +135,8 @@ struct rmclhip_map {
   uint32_t* d_qnodes = nullptr;  // Node4Q twins
   uint32_t* d_frontier = nullptr;   // frontier table (layout.h kFrontierDepth): n_frontier x 8 dwords {lo.xyz hi.x | hi.yz ref pad}
   uint32_t n_frontier = 0;
+  uint32_t* d_frontier_pf = nullptr;   // ... of the filter's tree (find kind 24 walks d_qnodes_pf)
+  uint32_t n_frontier_pf = 0;
   uint32_t* d_qnodes_pf = nullptr;  // Node4Q array of the particle filter's own tree (leaves <= kPfLeafTris, same records)
   uint32_t* d_cnodes = nullptr;  // Node4C twins
   uint32_t* d_tris = nullptr;
@@ -439,6 +441,10 @@ static rmclhip_status map_upload(rmclhip_ctx* ctx, const BvhHost& bvh, rmclhip_m
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_frontier), std::max<size_t>(fb, 32));
   if (e == hipSuccess && fb) e = hipMemcpy(m->d_frontier, bvh.frontier.data(), fb, hipMemcpyHostToDevice);
   m->n_frontier = static_cast<uint32_t>(bvh.frontier.size());
+  const size_t fpb = bvh.frontier_pf.size() * sizeof(Node4C::Child);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_frontier_pf), std::max<size_t>(fpb, 32));
+  if (e == hipSuccess && fpb) e = hipMemcpy(m->d_frontier_pf, bvh.frontier_pf.data(), fpb, hipMemcpyHostToDevice);
+  m->n_frontier_pf = static_cast<uint32_t>(bvh.frontier_pf.size());
   const size_t cb = bvh.cnodes.size() * sizeof(Node4C);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_cnodes), cb);
   if (e == hipSuccess) e = hipMemcpy(m->d_cnodes, bvh.cnodes.data(), cb, hipMemcpyHostToDevice);
@@ -451,6 +457,7 @@ static rmclhip_status map_upload(rmclhip_ctx* ctx, const BvhHost& bvh, rmclhip_m
     if (m->d_qnodes) (void)hipFree(m->d_qnodes);
     if (m->d_qnodes_pf) (void)hipFree(m->d_qnodes_pf);
     if (m->d_frontier) (void)hipFree(m->d_frontier);
+    if (m->d_frontier_pf) (void)hipFree(m->d_frontier_pf);
     if (m->d_cnodes) (void)hipFree(m->d_cnodes);
     if (m->d_tris) (void)hipFree(m->d_tris);
     delete m;
@@ -479,6 +486,7 @@ void rmclhip_map_release(rmclhip_map* map) {
     if (map->d_qnodes) (void)hipFree(map->d_qnodes);
     if (map->d_qnodes_pf) (void)hipFree(map->d_qnodes_pf);
     if (map->d_frontier) (void)hipFree(map->d_frontier);
+    if (map->d_frontier_pf) (void)hipFree(map->d_frontier_pf);
     if (map->d_cnodes) (void)hipFree(map->d_cnodes);
     if (map->d_tris) (void)hipFree(map->d_tris);
     ctx_release(map->ctx);
@@ -969,11 +977,13 @@ static int find_variant(const rmclhip_rcc* r, uint32_t nposes) {
   const uint64_t rays = static_cast<uint64_t>(r->W) * r->H * nposes;
   if (rays <= 57344u) return 2;   // bound by the slowest ray's fetch chain: four lanes per ray (crossover measured between
                                   // 49152 rays -- quads 13.6 / 20.8 us vs 16.4 / 23.4 -- and 65536 -- 15.9 / 26.3 vs 16.3 / 23.7)
-  // one lane per ray, starting at the map's FRONTIER instead of the root (traverse.hip.h frontier_start): from 65 536 to 524 288
+  // one lane per ray, starting at the map's FRONTIER instead of the root (traverse.hip.h frontier_start): from 65 536 to 262 144
   // rays kind 23 is the fastest or within 3 % of it on both benchmark maps (profiles/r03_find_variants_ab.txt), which replaces
-  // round 2's three brackets (19 / 21 / 22) by one; pose batches are bound by cache-line accesses: the 64-B quantised nodes
-  if (rays <= 524288u) return 23;  // full-precision nodes, branch-free step, one-round-trip leaves, quad-finished tails, leaf trigger
-  return 24;                       // quantised nodes, 16 LDS rows, leaf trigger
+  // round 2's three brackets (19 / 21 / 22) by one; larger launches and pose batches are bound by cache-line accesses and issue
+  // slots: the 64-B quantised nodes of the FILTER's tree (leaves <= 2: the per-lane triangle loop is short).  At 262 144 rays the
+  // sphere prefers 24 (24.9 vs 28.1 us) and the room 23 (38.9 vs 41.1); at 524 288 both prefer 24 (40.5 / 57.8 vs 43.6 / 59.3)
+  if (rays <= 262144u) return 23;  // full-precision nodes, branch-free step, one-round-trip leaves, quad-finished tails, leaf trigger
+  return 24;                       // quantised nodes of the filter's tree, 16 LDS rows, leaf trigger
 }
 
 static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
@@ -1006,6 +1016,17 @@ static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
   p.hits = r->d_hits.p; p.ranges = r->d_ranges.p; p.points = r->d_points.p; p.normals = r->d_normals.p;
   p.face_ids = r->d_face_ids.p;
   p.tile_planes = (r->tile_planes_ok && (nposes == 1u ? r->tuned_frontier : r->tuned_batch_frontier)) ? r->d_tile_planes.p : nullptr;
+  {
+    // kind 24 (and its frontier-less twin 22: rays on the quantised nodes, triangles in a per-lane loop) walks the FILTER's tree --
+    // the same BVH2 cut at leaves of <= 2 instead of <= 4 triangles, the same record array (layout.h): pose batches 6-10 % faster
+    // (profiles/r03_find_variants_ab.txt).  That tree has its own node numbering, hence its own frontier table.
+    const int v = find_variant(r, nposes);
+    if ((v == 24 || v == 22) && r->map->d_qnodes_pf != nullptr) {
+      p.qnodes = r->map->d_qnodes_pf;
+      p.frontier = r->map->d_frontier_pf;
+      p.n_frontier = r->map->n_frontier_pf;
+    }
+  }
 }
 
 // The frontier start's plane table belongs to (model, tiling): rebuilt -- one small launch on the handle's stream -- by whatever

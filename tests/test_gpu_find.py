@@ -454,7 +454,7 @@ def test_automatic_variant_in_every_size_bracket(ra, orc, ctx, meshes, mesh):
     hm = ra.import_hip_map(ctx, v, f)
     base = syn.pose_c2_truth() if mesh == "sphere100k" else T.transform_from_rpy(*ROOM_POSE_RPY)
     f32 = np.float32
-    brackets = [(16, 900, 1), (64, 1024, 1), (96, 1024, 1), (128, 1024, 1), (128, 2048, 1), (128, 1024, 3), (128, 1024, 5), (16, 900, 40)]
+    brackets = [(16, 900, 1), (64, 1024, 1), (96, 1024, 1), (128, 1024, 1), (128, 2048, 1), (256, 2048, 1), (128, 1024, 3), (128, 1024, 5), (16, 900, 40)]
     for (H, W, nposes) in brackets:
         model = T.spherical_model(f32(-0.39), f32(0.78 / (H - 1)), H, f32(-math.pi), f32(2 * math.pi / W), W, f32(0.3), f32(120.0))
         rng = np.random.RandomState(H + W + nposes)
@@ -465,7 +465,7 @@ def test_automatic_variant_in_every_size_bracket(ra, orc, ctx, meshes, mesh):
         rcc.setTsb(T.identity())
         rcc.setModel(model)
         rays = H * W * nposes
-        assert rcc.find_variant(nposes) == (2 if rays <= 57344 else 23 if rays <= 524288 else 24)
+        assert rcc.find_variant(nposes) == (2 if rays <= 57344 else 23 if rays <= 262144 else 24)
         if nposes == 1:
             rcc.find(poses[0])
         else:
