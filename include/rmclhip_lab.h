@@ -12,7 +12,8 @@
  *       13 / 14 wave-uniform nodes through the scalar cache ("wavefront ballot"; 14: + one-round-trip leaves)
  *       16 / 17 branch-free step + quad-finished tails (17: + one-round-trip leaves)      20 kind 16 + the leaf trigger
  *       19 / 21 / 22  round 2's automatic choices (17 / 5 / 4 with the leaf trigger), superseded by 23 / 24 = 19 / 22 + frontier start
- *       25 kind 2 (four lanes per ray) + frontier start        26 kind 23 on the 64-B quantised nodes (round 3, both measured and not adopted)
+ *       25 kind 2 (four lanes per ray) + frontier start        26 kind 23 on the 64-B quantised nodes
+ *       27 kind 23 + prefetch of the hit record's normal / face id during the traversal   (round 3: 25 / 26 / 27 measured, not adopted)
  *     (spherical model only; results are bit-identical to the product's kinds, tests/test_gpu_lab.py), and
  *   rmclhip_pf_set_variant accepts the round kernels (bits 4..6 = 0) and the round-2 persistent kernel (bits 7 / 8).
  * Measurements of every kind: profiles/r02_find_variants_ab.txt, profiles/r03_find_variants_ab.txt, DESIGN.md 4. */

@@ -833,12 +833,17 @@ __device__ __forceinline__ void trace_lane_ww_tail(const uint32_t* __restrict__ 
 // trace_lane_bf whose LAST rays are finished by quads (see trace_lane_ww_tail): branch-free node steps and one-round-trip
 // leaves while more than kTailRays rays of the wave are walking, then each remaining ray gets four lanes.
 // LDS: lane stacks (kRows x 256) | quad-tail stacks (64 columns x kQuadStackEntries rows) | hand-over slots.
-template <int kRows, bool kLeafBatch, int kLeafTrigger = 0, bool kQuant = false>   // kQuant: `nodes` are the 64-B quantised twins
+// kPre (experiment iv): after every leaf visit the lane requests the last 16 B (unit normal + face id) of the record that is
+// its best hit so far into *pre (and remembers which record in *pre_rec): the epilogue of k_find then finds them in registers
+template <int kRows, bool kLeafBatch, int kLeafTrigger = 0, bool kQuant = false, bool kPre = false>   // kQuant: `nodes` are the 64-B quantised twins
 __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ cnodes,
                                                    const uint32_t* __restrict__ tris, f3 O, f3 D, float ray_tfar,
                                                    uint32_t* __restrict__ lds_col, uint32_t* __restrict__ qstack,
                                                    uint32_t* __restrict__ xfer_wave, RayHit& h, uint32_t* visits = nullptr,
-                                                   const TraceStart* start = nullptr, uint32_t* dbg = nullptr) {
+                                                   const TraceStart* start = nullptr, uint32_t* dbg = nullptr, uint4* pre = nullptr,
+                                                   uint32_t* pre_rec = nullptr) {
+  uint4 pre_v = uint4{0u, 0u, 0u, 0u};
+  uint32_t pre_r = kNone;
   const RaySlab rs = make_ray_slab(O, D);
   float best_t = ray_tfar;
   uint32_t best_rec = kNone;
@@ -941,6 +946,10 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
     if (cur > kDone) {
       if (kLeafBatch) leaf_batch(tris, cur, O, D, ray_tfar, best_t, best_rec);
       else leaf_loop(tris, cur, O, D, ray_tfar, best_t, best_rec);
+      if constexpr (kPre) {
+        pre_r = best_rec;
+        pre_v = reinterpret_cast<const uint4*>(tris)[static_cast<size_t>((best_rec != kNone) ? best_rec : 0u) * 4u + 3u];
+      }
       --sp;
       cur = RMCL_ROW_LD(sp);
     }
@@ -949,6 +958,7 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
 #undef RMCL_ROW_LD
   h.t = best_t;
   h.rec = best_rec;
+  if constexpr (kPre) { *pre = pre_v; *pre_rec = pre_r; }
   if (visits) *visits = nvis;
   if (dbg) { dbg[0] = dbg_slow; dbg[1] = dbg_na; dbg[2] = dbg_tail; }
 }
