@@ -1071,6 +1071,23 @@ rmclhip_status rmclhip_rcc_find_async(rmclhip_rcc* r, const rmclhip_transform* T
   return find_enqueue(r, to_x(Tbm_est));
 }
 
+// Wait for a handle's stream the way the context's wait mode says (rmclhip_ctx_set_wait_mode): SPIN polls hipStreamQuery -- the
+// thread learns of the completion ~10 us before an interrupt-driven hipStreamSynchronize would wake it, which is what a single
+// 17-us scan (find, find_async + sync) feels --, then one hipStreamSynchronize (immediate) keeps the runtime's own view in order;
+// BLOCK sleeps in the runtime.  20 ms of polling at most.
+static hipError_t stream_wait(const rmclhip_ctx* ctx, hipStream_t stream) {
+  if (!ctx->wait_block.load(std::memory_order_relaxed)) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; ++spins) {
+      const hipError_t q = hipStreamQuery(stream);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) return q;
+      if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+    }
+  }
+  return hipStreamSynchronize(stream);
+}
+
 rmclhip_status rmclhip_rcc_find(rmclhip_rcc* r, const rmclhip_transform* Tbm_est) {
   ApiGuard guard_("rmclhip_rcc_find");
   if (!r || !Tbm_est) return fail(RMCLHIP_ERR_INVALID, "rcc_find: null");
@@ -1080,7 +1097,7 @@ rmclhip_status rmclhip_rcc_find(rmclhip_rcc* r, const rmclhip_transform* Tbm_est
   HIPCHK(hipEventRecord(r->ev0, r->stream));
   if (rmclhip_status st = find_enqueue(r, to_x(Tbm_est))) return st;
   HIPCHK(hipEventRecord(r->ev1, r->stream));
-  HIPCHK(hipStreamSynchronize(r->stream));
+  HIPCHK(stream_wait(r->ctx, r->stream));
   HIPCHK(hipEventElapsedTime(&r->last_find_ms, r->ev0, r->ev1));
   return RMCLHIP_OK;
 }
@@ -1120,7 +1137,7 @@ rmclhip_status rmclhip_rcc_find_cpc(rmclhip_rcc* r, const rmclhip_transform* Tbm
                          r->d_face_ids.p, quad, r->stream, seed, r->cpc_tracking ? r->d_cpc_rec.p : nullptr, r->map->info.n_faces,
                          cpc_bound_d2(r)));
   if (r->cpc_tracking) { r->cpc_rec_n = r->n_dataset; r->cpc_rec_pts = r->ds_pts; }
-  HIPCHK(hipStreamSynchronize(r->stream));
+  HIPCHK(stream_wait(r->ctx, r->stream));
   return RMCLHIP_OK;
 }
 
@@ -1143,7 +1160,7 @@ rmclhip_status rmclhip_rcc_sync(rmclhip_rcc* r) {
   ApiGuard guard_("rmclhip_rcc_sync");
   if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_sync: null");
   HIPCHK(hipSetDevice(r->ctx->device));
-  HIPCHK(hipStreamSynchronize(r->stream));
+  HIPCHK(stream_wait(r->ctx, r->stream));
   return RMCLHIP_OK;
 }
 
