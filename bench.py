@@ -140,6 +140,11 @@ def main():
         rcc.setModel(model)
         # replicas: rank r localises a scan from a different pose inside the same map
         Tbm = T.mult(syn.pose_c2_truth(), T.transform_from_rpy((0.05 * rank, -0.03 * rank, 0.0), (0.0, 0.0, 0.11 * rank)))
+        # dominant kernel, measured live FIRST: HIP events on the rcc's own stream around back-to-back launches; median of 9
+        # batches of 40 launches.  (It runs before the W + K steps on purpose: a run with few steps -- the driver's K = 20 is
+        # 0.35 ms of GPU time -- would otherwise be timed on a device that has not left its idle clocks: 19.0 vs 18.2 us per
+        # step measured; the metric is steady-state rays/s.  DESIGN.md section 5.)
+        kernel_ms = median_kernel_ms(lambda: rcc.time_find(Tbm, iters=40))
         for _ in range(max(args.warmup, 1)):
             rcc.find_async(Tbm)
         rcc.sync()
@@ -157,9 +162,6 @@ def main():
         elapsed = max_over_ranks(t1 - t0)
         units_per_step = n_rays
 
-        # dominant kernel, measured live: HIP events on the rcc's own stream around back-to-back launches; median of 9
-        # batches of 40 launches
-        kernel_ms = median_kernel_ms(lambda: rcc.time_find(Tbm, iters=40))
         b_alg = algorithmic_bytes_raycast(n_rays, len(f), 1)
         kind = rcc.find_variant(1)   # the traversal the automatic rule (or --variant) launches for this scan
         kname = "k_find<spherical, kind %d>" % kind
