@@ -13,7 +13,9 @@
  *       16 / 17 branch-free step + quad-finished tails (17: + one-round-trip leaves)      20 kind 16 + the leaf trigger
  *       19 / 21 / 22  round 2's automatic choices (17 / 5 / 4 with the leaf trigger), superseded by 23 / 24 = 19 / 22 + frontier start
  *       25 kind 2 (four lanes per ray) + frontier start        26 kind 23 on the 64-B quantised nodes
- *       27 kind 23 + prefetch of the hit record's normal / face id during the traversal   (round 3: 25 / 26 / 27 measured, not adopted)
+ *       27 kind 23 + prefetch of the hit record's normal / face id during the traversal
+ *       28 kind 23 with a software-pipelined node step (next node requested after three of the five ordering steps, top of the stack in a register)
+ *       29 / 30 kind 23 with four / three of the five ordering steps of a node's children    (round 3: 25 ... 30 measured, not adopted)
  *     (spherical model only; results are bit-identical to the product's kinds, tests/test_gpu_lab.py), and
  *   rmclhip_pf_set_variant accepts the round kernels (bits 4..6 = 0) and the round-2 persistent kernel (bits 7 / 8).
  * Measurements of every kind: profiles/r02_find_variants_ab.txt, profiles/r03_find_variants_ab.txt, DESIGN.md 4. */

@@ -1956,7 +1956,7 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
   if (!r || variant < 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: bad arguments");
   // bit 13 adds 16 to the traversal kind (kinds 16..31)
   const int kind = (variant & 0xF) | (((variant >> 13) & 1) << 4), tile = (variant >> 4) & 0xF;
-  if (kind == 3 || kind == 18 || kind > 27 || tile > 7 || (variant >> 14) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
+  if (kind == 3 || kind == 18 || kind > 30 || tile > 7 || (variant >> 14) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
   // (kind 1 also selects the one-lane-per-point form of the closest-point query, which the product owns)
   if (kind != 15 && kind != 1 && !find_kind_in_product(kind) && lab_hooks() == nullptr)
     return fail(RMCLHIP_ERR_UNSUPPORTED, "rcc_set_variant: this traversal kind is an experiment -- it lives in librmclhip_lab.so, "

@@ -23,9 +23,9 @@ constexpr int kFindBfRows = 24;  // LDS stack rows per lane (sentinel included) 
 constexpr uint32_t kFindTailLdsDwords = 16u * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords;
 
 // kinds 19..22: kind 17 + leaving the node phase when 32 / 24 / 16 / 8 lanes hold a leaf
-constexpr int find_leaf_trigger(int trav) { return (trav == 19 || trav == 20 || trav == 23 || trav == 26 || trav == 27) ? 10 : 0; }   // leave at <= 4/10 of the round's rays
+constexpr int find_leaf_trigger(int trav) { return (trav == 19 || trav == 20 || trav == 23 || (trav >= 26 && trav <= 30)) ? 10 : 0; }   // leave at <= 4/10 of the round's rays
 // kinds 23 / 24: kinds 19 / 22 whose rays start at the map's frontier (traverse.hip.h frontier_start) instead of the root
-constexpr bool find_frontier(int trav) { return trav == 23 || trav == 24 || trav == 25 || trav == 26 || trav == 27; }   // 26: 23 on the quantised nodes; 27: 23 + record prefetch
+constexpr bool find_frontier(int trav) { return trav == 23 || trav == 24 || (trav >= 25 && trav <= 30); }   // 26: 23 on the quantised nodes; 27: 23 + record prefetch; 28: 23 with the pipelined node step; 29 / 30: 23 with four / three of the five ordering steps
 // kind 25: kind 2 (four lanes per ray) with the frontier start
 constexpr bool find_quad(int trav) { return trav == 2 || trav == 25; }
 
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
     if constexpr (find_frontier(kTrav) && kModel != kModelOnDn) {   // (OnDn: one origin per ray, no common pyramid)
       if (p.tile_planes != nullptr) {     // (no table: the rays start at the root)
         const float* planes = p.tile_planes + static_cast<size_t>(__builtin_amdgcn_readfirstlane(tile)) * 16u;
-        if (kTrav == 23 || kTrav == 26 || kTrav == 27)
+        if (kTrav == 23 || (kTrav >= 26 && kTrav <= 30))
           start = frontier_start<kFindBfRows, 1>(p.frontier, p.n_frontier, p.scene_center, p.scene_half_diag, planes, Tsm.R, p.tfar, org_m,
                                                  dir_m, ray_tfar, lane, lds_dyn + threadIdx.x, kBfStride);
         else
@@ -198,8 +198,8 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
           lds_dyn + kFindTailLdsDwords);
     else if (kTrav == 1) trace_lane_bf<kFindBfRows>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
     else if (kTrav == 12) trace_lane_bf<kFindBfRows, false, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
-    else if (kTrav == 16 || kTrav == 17 || kTrav == 19 || kTrav == 20 || kTrav == 23 || kTrav == 26 || kTrav == 27)
-      trace_lane_bf_tail<kFindBfRows, kTrav != 16 && kTrav != 20, find_leaf_trigger(kTrav), kTrav == 26, kTrav == 27>(kTrav == 26 ? p.qnodes : p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x,
+    else if (kTrav == 16 || kTrav == 17 || kTrav == 19 || kTrav == 20 || kTrav == 23 || (kTrav >= 26 && kTrav <= 30))
+      trace_lane_bf_tail<kFindBfRows, kTrav != 16 && kTrav != 20, find_leaf_trigger(kTrav), kTrav == 26, kTrav == 27, kTrav == 28, (kTrav == 29 ? 4 : (kTrav == 30 ? 3 : 5))>(kTrav == 26 ? p.qnodes : p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x,
                                                    lds_dyn + kFindBfRows * 256u,
                                                    lds_dyn + kFindBfRows * 256u + kQuadStackEntries * 64u + (threadIdx.x >> 6) * (kTailRays * kTailXferDwords), h,
                                                    kClock ? &clk_visits : nullptr, sp0, kClock ? clk_dbg : nullptr, &pre_nrec, &pre_rec);

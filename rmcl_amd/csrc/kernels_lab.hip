@@ -415,6 +415,9 @@ hipError_t lab_find_kind(const FindParams& p, int variant, hipStream_t s) {
     case 22: return lab_find_one<22, kClock>(p, grid, lds_ww, s);
     case 23: return lab_find_one<23, kClock>(p, grid, lds_bf_tail, s);                         // 19 + frontier start
     case 24: return lab_find_one<24, kClock>(p, grid, lds_ww, s);                              // 22 + frontier start
+    case 30: return lab_find_one<30, kClock>(p, grid, lds_bf_tail, s);                           // 23, only the nearest child found
+    case 29: return lab_find_one<29, kClock>(p, grid, lds_bf_tail, s);                           // 23, the middle two children unordered
+    case 28: return lab_find_one<28, kClock>(p, grid, lds_bf_tail, s);                           // 23 with the software-pipelined node step
     case 27: return lab_find_one<27, kClock>(p, grid, lds_bf_tail, s);                           // 23 + prefetch of the hit record's normal (experiment iv)
     case 26: return lab_find_one<26, kClock>(p, grid, lds_bf_tail, s);                           // 23 on the quantised nodes
     case 25: return lab_find_one<25, kClock>(p, grid, kQuadStackEntries * 64u * sizeof(uint32_t), s);   // 2 + frontier start

@@ -171,8 +171,11 @@ __device__ __forceinline__ void tri_update(uint4 a, uint4 b, uint4 c, uint32_t r
 // branch makes the compiler wait for it at the end of the branch); a lane whose leaf is shorter re-requests its last
 // record (same cache line, and a repeated test cannot change (best_t, best_rec)); the tests run in record order and
 // skip slots no lane of the wave fills: results identical to the loop.
-__device__ __forceinline__ void leaf_batch(const uint32_t* __restrict__ tris, uint32_t cur, f3 O, f3 D, float ray_tfar,
-                                           float& best_t, uint32_t& best_rec) {
+// `after_requests` runs between the record requests and the first test (kPipe: the lane's NEXT node is requested there, behind
+// the records, so the records' arrival is not held up by it and its latency is covered by the tests)
+template <class F>
+__device__ __forceinline__ void leaf_batch_then(const uint32_t* __restrict__ tris, uint32_t cur, f3 O, f3 D, float ray_tfar,
+                                                float& best_t, uint32_t& best_rec, F&& after_requests) {
   const uint32_t first = cur & 0x0FFFFFFFu;
   const uint32_t last = first + ((cur >> 28) & 7u);
   const bool w2 = __any(last > first), w3 = __any(last > first + 1u), w4 = __any(last > first + 2u);
@@ -185,10 +188,15 @@ __device__ __forceinline__ void leaf_batch(const uint32_t* __restrict__ tris, ui
   const uint4 a1 = t1[0], b1 = t1[1], c1 = t1[2];
   const uint4 a2 = t2[0], b2 = t2[1], c2 = t2[2];
   const uint4 a3 = t3[0], b3 = t3[1], c3 = t3[2];
+  after_requests();
   tri_update(a0, b0, c0, first, tris, O, D, ray_tfar, best_t, best_rec);
   if (w2) tri_update(a1, b1, c1, i1, tris, O, D, ray_tfar, best_t, best_rec);
   if (w3) tri_update(a2, b2, c2, i2, tris, O, D, ray_tfar, best_t, best_rec);
   if (w4) tri_update(a3, b3, c3, i3, tris, O, D, ray_tfar, best_t, best_rec);
+}
+__device__ __forceinline__ void leaf_batch(const uint32_t* __restrict__ tris, uint32_t cur, f3 O, f3 D, float ray_tfar,
+                                           float& best_t, uint32_t& best_rec) {
+  leaf_batch_then(tris, cur, O, D, ray_tfar, best_t, best_rec, [] {});
 }
 
 // the loop form of a leaf visit (one record per iteration), same rules
@@ -536,6 +544,18 @@ __device__ __forceinline__ void node_keys_uniform(const uint32_t* __restrict__ n
   node_keys_from(qnx, qfx, qny, qfy, qnz, qfz, qch, rs, best_t, key, ref);
 }
 
+// A node REQUESTED ahead of its use (kPipe of trace_lane_bf_tail): the seven sign-selected 16-B groups of node_keys_off in registers
+struct NodeRegs { uint4 qnx, qfx, qny, qfy, qnz, qfz, qch; };
+__device__ __forceinline__ NodeRegs node_req(const uint32_t* __restrict__ nodes, uint32_t byte_off, const RaySlab& rs) {
+  const char* nb = reinterpret_cast<const char*>(nodes);
+  NodeRegs r;
+  r.qnx = *reinterpret_cast<const uint4*>(nb + (byte_off + rs.onx)); r.qfx = *reinterpret_cast<const uint4*>(nb + (byte_off + rs.ofx));
+  r.qny = *reinterpret_cast<const uint4*>(nb + (byte_off + rs.ony)); r.qfy = *reinterpret_cast<const uint4*>(nb + (byte_off + rs.ofy));
+  r.qnz = *reinterpret_cast<const uint4*>(nb + (byte_off + rs.onz)); r.qfz = *reinterpret_cast<const uint4*>(nb + (byte_off + rs.ofz));
+  r.qch = *reinterpret_cast<const uint4*>(nb + (byte_off + 96u));
+  return r;
+}
+
 constexpr uint32_t kBfStride = 256u;  // stack row stride in dwords = threads per block of every kernel that calls trace_lane_bf
 
 // kRows: stack rows in LDS per lane INCLUDING the sentinel row 0 (row r of this lane at lds_col[r * 256]); deeper entries
@@ -835,7 +855,15 @@ __device__ __forceinline__ void trace_lane_ww_tail(const uint32_t* __restrict__ 
 // LDS: lane stacks (kRows x 256) | quad-tail stacks (64 columns x kQuadStackEntries rows) | hand-over slots.
 // kPre (experiment iv): after every leaf visit the lane requests the last 16 B (unit normal + face id) of the record that is
 // its best hit so far into *pre (and remembers which record in *pre_rec): the epilogue of k_find then finds them in registers
-template <int kRows, bool kLeafBatch, int kLeafTrigger = 0, bool kQuant = false, bool kPre = false>   // kQuant: `nodes` are the 64-B quantised twins
+// kPipe (round 3, kind 28): the node step is software-pipelined.  A lone wave's step is a dependent chain -- seven loads, ~130
+// VALU instructions, the next node's address --, so the lane requests its NEXT node as soon as the nearest child is known (after
+// three of the five compare-exchanges), finishes the ordering and the pushes under that request, keeps the top of its stack in
+// a register (a pop costs no LDS round trip) and, at a leaf, requests the node it will pop behind the leaf's records, before
+// the triangle tests.  Same visits in the same order: results and visit counts are those of the plain step.
+// kSortSteps (kinds 29 / 30): 5 = the four children fully ordered; 4 = nearest first, farthest last, the middle two as they come;
+// 3 = only the nearest found.  The visit ORDER changes (never the set of hits: min t, then min face id), a step is 5 / 10 VALU
+// instructions shorter.
+template <int kRows, bool kLeafBatch, int kLeafTrigger = 0, bool kQuant = false, bool kPre = false, bool kPipe = false, int kSortSteps = 5>   // kQuant: `nodes` are the 64-B quantised twins
 __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ cnodes,
                                                    const uint32_t* __restrict__ tris, f3 O, f3 D, float ray_tfar,
                                                    uint32_t* __restrict__ lds_col, uint32_t* __restrict__ qstack,
@@ -857,7 +885,24 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 #define RMCL_ROW_ST(r, v) { if ((r) < static_cast<uint32_t>(kRows)) lds_col[(r) * kBfStride] = (v); else priv[(r) - kRows] = (v); }
 #define RMCL_ROW_LD(r) (((r) < static_cast<uint32_t>(kRows)) ? lds_col[(r) * kBfStride] : priv[(r) - kRows])
+  static_assert(!(kPipe && kQuant), "the pipelined step reads the 128-B nodes");
+  // the pipelined loops touch LDS rows only (a row select between LDS and scratch would turn the re-read of the cached top into
+  // a flat load -- one more instruction through the texture path per step, measured +12 %): a wave whose stacks come within
+  // three rows of kRows leaves the pipelined form for good (`piped`, wave-uniform) and continues with the plain step
+#define RMCL_TOP_LD(dst, spv) { (dst) = lds_col[(max((spv), 1u) - 1u) * kBfStride]; }
+  // kPipe invariants at the top of every round: `nr` holds (a request for) node `cur` whenever cur < kDone, `top` = row sp - 1
+  NodeRegs nr = {};
+  uint32_t top = kDone;
+  bool piped = kPipe;
+  if constexpr (kPipe) {
+    piped = !__any(sp + 3u > static_cast<uint32_t>(kRows));
+    if (piped) {
+      if (cur < kDone) nr = node_req(nodes, cur << 7, rs);
+      RMCL_TOP_LD(top, sp)
+    }
+  }
   for (;;) {
+    if constexpr (kPipe) piped = __all(piped);   // lanes that had left the node loop when the wave gave up the pipelined form follow
     const uint64_t m_act = __ballot(cur != kDone);
     if (m_act == 0) break;
     const uint32_t na = static_cast<uint32_t>(__popcll(m_act));
@@ -904,6 +949,10 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
     // phase 1: inner nodes.  kLeafTrigger > 0: the phase is also left as soon as that many lanes hold a leaf -- they would
     // otherwise idle through the descents of the others (the wave model: 65 -> 45 node iterations for the slowest tile of
     // the room, 32 -> 26 on the sphere, for one or two more leaf rounds); the stragglers resume in the next round.
+#define RMCL_SORT4                                                                                           \
+        RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2)                                                   \
+        if constexpr (kSortSteps >= 4) RMCL_CSWAP(1, 3)                                                      \
+        if constexpr (kSortSteps >= 5) RMCL_CSWAP(1, 2)
 #define RMCL_BF_STEP                                                                                         \
     {                                                                                                        \
       uint32_t key[4], ref[4];                                                                               \
@@ -911,7 +960,7 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
       if (!__any(sp + 3u > static_cast<uint32_t>(kRows))) {                                                  \
         const uint32_t top = lds_col[(sp - 1u) * kBfStride];                                                 \
         if constexpr (kQuant) node_keys_q(nodes, cur, rs, best_t, key, ref); else node_keys_off(nodes, cur << 7, rs, best_t, key, ref);                                                \
-        RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)                 \
+        RMCL_SORT4                                                                                           \
         lds_col[sp * kBfStride] = ref[3]; sp += (key[3] != kNone) ? 1u : 0u;                                 \
         lds_col[sp * kBfStride] = ref[2]; sp += (key[2] != kNone) ? 1u : 0u;                                 \
         lds_col[sp * kBfStride] = ref[1]; sp += (key[1] != kNone) ? 1u : 0u;                                 \
@@ -921,7 +970,7 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
       } else {                                                                                               \
         ++dbg_slow;                                                                                          \
         if constexpr (kQuant) node_keys_q(nodes, cur, rs, best_t, key, ref); else node_keys_off(nodes, cur << 7, rs, best_t, key, ref);                                                \
-        RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2) RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)                 \
+        RMCL_SORT4                                                                                           \
         if (key[3] != kNone) { RMCL_ROW_ST(sp, ref[3]) ++sp; }                                               \
         if (key[2] != kNone) { RMCL_ROW_ST(sp, ref[2]) ++sp; }                                               \
         if (key[1] != kNone) { RMCL_ROW_ST(sp, ref[1]) ++sp; }                                               \
@@ -929,7 +978,31 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
         else { --sp; cur = RMCL_ROW_LD(sp); }                                                                \
       }                                                                                                      \
     }
-    if constexpr (kLeafTrigger > 0) {
+#define RMCL_BF_STEP_PIPE                                                                                    \
+    {                                                                                                        \
+      uint32_t key[4], ref[4];                                                                               \
+      ++nvis;                                                                                                \
+      node_keys_from(nr.qnx, nr.qfx, nr.qny, nr.qfy, nr.qnz, nr.qfz, nr.qch, rs, best_t, key, ref);          \
+      RMCL_CSWAP(0, 1) RMCL_CSWAP(2, 3) RMCL_CSWAP(0, 2)                                                     \
+      const bool any = key[0] != kNone;                                                                      \
+      const uint32_t nxt = any ? ref[0] : top;                                                               \
+      if (nxt < kDone) nr = node_req(nodes, nxt << 7, rs);                                                   \
+      RMCL_CSWAP(1, 3) RMCL_CSWAP(1, 2)                                                                      \
+      lds_col[sp * kBfStride] = ref[3]; sp += (key[3] != kNone) ? 1u : 0u;                                   \
+      lds_col[sp * kBfStride] = ref[2]; sp += (key[2] != kNone) ? 1u : 0u;                                   \
+      lds_col[sp * kBfStride] = ref[1]; sp += (key[1] != kNone) ? 1u : 0u;                                   \
+      sp = any ? sp : (sp - 1u);                                                                             \
+      RMCL_TOP_LD(top, sp)                                                                                   \
+      cur = nxt;                                                                                             \
+    }
+    if (kPipe && piped) {
+      while (cur < kDone) {
+        if (__any(sp + 3u > static_cast<uint32_t>(kRows))) { piped = false; break; }   // wave-uniform
+        RMCL_BF_STEP_PIPE
+        if constexpr (kLeafTrigger > 0)
+          if (static_cast<uint32_t>(kLeafTrigger) * static_cast<uint32_t>(__popcll(__ballot(cur < kDone))) <= 4u * na) break;
+      }
+    } else if constexpr (kLeafTrigger > 0) {
       // The loop stays the divergent per-lane while loop; the vote only needs the number of lanes still in it (the ballot of
       // a divergent loop counts exactly those) against `na`, the rays alive when the round began: waiting >= 1.5 x descending
       // <=> 5 x descending <= 2 x alive.  Checked after the step, so every round makes progress (a lane that keeps popping
@@ -942,7 +1015,21 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
       while (cur < kDone) RMCL_BF_STEP
     }
 #undef RMCL_BF_STEP
+#undef RMCL_SORT4
+#undef RMCL_BF_STEP_PIPE
     // phase 2: this lane's leaf (if any; with a leaf trigger other lanes may still hold an inner node)
+    if (kPipe && piped) {
+      if (cur > kDone) {
+        static_assert(!kPipe || kLeafBatch, "the pipelined step comes with the one-round-trip leaf");
+        const uint32_t leaf = cur;
+        --sp;
+        cur = top;   // == row sp
+        leaf_batch_then(tris, leaf, O, D, ray_tfar, best_t, best_rec, [&] {
+          if (cur < kDone) nr = node_req(nodes, cur << 7, rs);
+          RMCL_TOP_LD(top, sp)
+        });
+      }
+    } else
     if (cur > kDone) {
       if (kLeafBatch) leaf_batch(tris, cur, O, D, ray_tfar, best_t, best_rec);
       else leaf_loop(tris, cur, O, D, ray_tfar, best_t, best_rec);
@@ -956,6 +1043,7 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
   }
 #undef RMCL_ROW_ST
 #undef RMCL_ROW_LD
+#undef RMCL_TOP_LD
   h.t = best_t;
   h.rec = best_rec;
   if constexpr (kPre) { *pre = pre_v; *pre_rec = pre_r; }

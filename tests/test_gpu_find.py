@@ -33,7 +33,7 @@ def _poses(syn, T):
     ]
 
 
-@pytest.mark.parametrize("variant", find_kinds(0, 1, 2, 4, 5, 6, 8, 10, 11, 12, 13, 14, 16, 17, 19, 20, 21, 22, 23, 24, 25, 26, 27))
+@pytest.mark.parametrize("variant", find_kinds(0, 1, 2, 4, 5, 6, 8, 10, 11, 12, 13, 14, 16, 17, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30))
 def test_c1_cube_32x32(ra, orc, ctx, meshes, variant):
     """config C1: 32x32 scan, 972-triangle cube, every output attribute, 3 poses, Tsb != I."""
     from rmcl_amd import synthetic as syn, types as T
@@ -73,7 +73,7 @@ def test_c1_matches_committed_golden(ra, ctx, meshes):
         _compare(gpu, ref, "golden pose %d" % i)
 
 
-@pytest.mark.parametrize("variant", find_kinds(0, 1, 2, 4, 5, 7, 8, 9, 11, 12, 13, 14, 16, 17, 19, 20, 21, 22, 23, 24, 25, 26, 27))
+@pytest.mark.parametrize("variant", find_kinds(0, 1, 2, 4, 5, 7, 8, 9, 11, 12, 13, 14, 16, 17, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30))
 def test_c2_sphere100k_full_size(ra, orc, ctx, meshes, variant):
     """config C2 at BASELINE.json's full size: 128x1024 rays, 100k triangles; oracle BVH on all rays,
     brute force on a sample, and the committed SHA-256 of the face-id array (G7)."""
@@ -355,7 +355,7 @@ def test_c5_mesh_one_million_triangles(ra, orc, ctx):
 ROOM_POSE_RPY = ((1.5, -2.0, 1.6), (0.02, -0.03, 0.4))   # the pose of tests/golden/make_golden.py:g7_digests
 
 
-@pytest.mark.parametrize("variant", find_kinds(0, 2, 15, 23, 24, 19, 22, 25, 26, 27))
+@pytest.mark.parametrize("variant", find_kinds(0, 2, 15, 23, 24, 19, 22, 25, 26, 27, 28, 29, 30))
 def test_c2_room100k_full_size(ra, orc, ctx, meshes, variant):
     """config C2's scan on a REALISTIC map (room-100k: occluders, vertex noise, open ceiling => misses): every
     traversal incl. the automatic one (15) vs the oracle on all 131 072 rays + the committed G7 digests
