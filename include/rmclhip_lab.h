@@ -39,6 +39,10 @@ const char* rmclhip_lab_version(void);
  * s_memtime before the traversal, after it, stores issued, 0} (all zero = wave had no tile) */
 rmclhip_status rmclhip_debug_wave_clock(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est, uint32_t* out, size_t cap_dwords,
                                         uint32_t* n_waves_out);
+/* the moments the LAST moment-form attempt of rmclhip_rcc_correct_once worked from (rmclhip.h: rmclhip_rcc_set_micp_fast): the 96 sums
+ * of its partial rows (82 used; layout in kernels.hip) and the number of correspondences it left undecided.  Works without the
+ * experiments library. */
+rmclhip_status rmclhip_debug_micp_moments(rmclhip_rcc* rcc, double* totals96, uint32_t* n_rows_out, uint64_t* n_uncertain_out);
 /* tools/probe_find.py: one spherical find() through an instrumented copy of the one-lane-per-ray traversal that stamps
  * s_memtime around every node / leaf step of every wave.  mode: bit 0 = one-round-trip leaves, bit 1 = LDS-resident top of the
  * tree.  log_out: n_tiles x 512 dwords (host). */

@@ -150,6 +150,7 @@ SIGNATURES = {
     "rmclhip_rcc_set_micp_fast": (_i32, [_vp, _i32]),
     "rmclhip_rcc_micp_fast_info": (_i32, [_vp, C.POINTER(MicpFastInfo)]),
     "rmclhip_debug_wave_clock": (_i32, [_vp, _vp, _vp, _sz, C.POINTER(_u32)]),
+    "rmclhip_debug_micp_moments": (_i32, [_vp, _vp, C.POINTER(_u32), C.POINTER(C.c_uint64)]),
     "rmclhip_debug_probe_find": (_i32, [_vp, _vp, _i32, _vp, _sz, C.POINTER(_u32)]),
     "rmclhip_rcc_find_batch": (_i32, [_vp, _vp, _u32]),
     "rmclhip_rcc_time_find_batch": (_i32, [_vp, _vp, _u32, _u32, C.POINTER(_f32)]),

@@ -207,6 +207,9 @@ struct rmclhip_rcc {
   int fast_mode = 1;               // 0 off, 1 automatic (direct launches), 2 automatic through a hipGraph (A/B)
   DevBuf<double> d_fast_partials;
   DevBuf<unsigned long long> d_fast_mask;
+  double* d_fold_rows = nullptr;      // hand-over area of the loop launch's folding workgroups (kernels.h: kMicpFoldBlocks)
+  uint32_t* d_fold_flags = nullptr;
+  uint32_t last_fast_rows = 0, last_fast_words = 0;   // partial rows / mask words of the last moment-form attempt (diagnostics)
   MicpFastStatus* h_fast_status = nullptr;      // pinned, host-mapped
   MicpFastStatus* h_fast_status_dev = nullptr;
   unsigned long long* h_done = nullptr;         // pinned, host-mapped completion tags: [0] this handle's chains, [1] the N-sensor loop
@@ -696,6 +699,7 @@ void rmclhip_rcc_destroy(rmclhip_rcc* r) {
   if (r->h_done) DBG_STEP(hipHostFree(r->h_done));
   r->d_cpc_rec.release();
   r->d_fast_partials.release(); r->d_fast_mask.release(); r->d_tile_planes.release();
+  if (r->d_fold_rows) DBG_STEP(hipFree(r->d_fold_rows));
   r->d_multi_blob.release();
   if (r->h_multi_state) DBG_STEP(hipHostFree(r->h_multi_state));
   if (r->h_multi_status) DBG_STEP(hipHostFree(r->h_multi_status));
@@ -1393,20 +1397,47 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
       key.fused = 0; key.has_mask = r->ds_has_mask ? 1 : 0;
       key.ptrs[0] = r->d_points.p; key.ptrs[1] = r->ds_pts; key.ptrs[2] = r->d_fast_partials.p;
       key.ptrs[3] = r->d_model_tab.p; key.ptrs[4] = r->ds_msk; key.ptrs[5] = r->d_fast_mask.p;
-      if (!r->use_graph || r->fast_mode == 1) {
+      if (!r->use_graph || r->fast_mode == 1 || r->fast_mode == 3) {
         // direct launches (the default form; fast_mode 2 replays the same chain from a hipGraph, A/B): three kernels with their per-call data BY VALUE -- no H2D copy node, no graph launch (a graph
         // replay costs the host 10-16 us whatever it holds; three plain launches overlap with the kernels they start)
         FindParams fp;
         fill_find_params(r, fp, 1);
         fp.Tsm = r->h_call->Tsm;
         fp.Tms = r->h_call->Tms;
-        HIPCHK(launch_find(fp, r->kind, find_variant(r, 1), r->stream));
         MicpCallLite cl;
         cl.Tsb = r->Tsb; cl.Tbo = Tbo; cl.max_dist = maxd; cl.rho_cap = r->fast_rho_cap; cl.tau_cap = r->fast_tau_cap;
         cl.seq = r->h_call->seq;
-        HIPCHK(launch_micp_fast(r->ds_pts, r->ds_has_mask ? r->ds_msk : nullptr, r->d_points.p, r->d_normals.p, r->d_hits.p, nred,
-                                nullptr, r->d_fast_partials.p, r->d_fast_mask.p, n_iter, r->h_state_dev, r->h_fast_status_dev,
-                                r->h_done_dev, r->stream, &cl));
+        if (r->fast_mode != 3 && find_variant(r, 1) == 23) {
+          // TWO kernels: the find forms the moments in its epilogue (find_kernel.hip.h: the 10 x 10 factor products of its 64
+          // correspondences per wave through f64 MFMA), one partial row per workgroup; the second pass over the find's outputs is gone
+          // (fast_mode 3 keeps it for A/B; the other traversal kinds have no moment epilogue)
+          const uint32_t nb = find_moments_blocks(fp);
+          HIPCHK(r->d_fast_partials.reserve(static_cast<size_t>(nb) * kMicpFastMoments));
+          HIPCHK(r->d_fast_mask.reserve(static_cast<size_t>(nb) * 4u));
+          fp.mom_dataset_points = r->ds_pts;
+          fp.mom_dataset_mask = r->ds_has_mask ? r->ds_msk : nullptr;
+          fp.mom_n = nred;
+          fp.mom_max_dist = maxd; fp.mom_rho_cap = r->fast_rho_cap; fp.mom_tau_cap = r->fast_tau_cap;
+          fp.mom_partials = r->d_fast_partials.p;
+          fp.mom_unc_mask = r->d_fast_mask.p;
+          if (!r->d_fold_rows) {
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&r->d_fold_rows), kMicpFoldBlocks * kMicpFastMoments * sizeof(double) + kMicpFoldBlocks * sizeof(uint32_t)));
+            HIPCHK(hipMemset(r->d_fold_rows, 0, kMicpFoldBlocks * kMicpFastMoments * sizeof(double) + kMicpFoldBlocks * sizeof(uint32_t)));
+            HIPCHK(hipDeviceSynchronize());
+            r->d_fold_flags = reinterpret_cast<uint32_t*>(r->d_fold_rows + kMicpFoldBlocks * kMicpFastMoments);
+          }
+          r->last_fast_rows = nb; r->last_fast_words = 4u * nb;
+          HIPCHK(launch_find_moments(fp, r->kind, r->stream));
+          HIPCHK(launch_micp_fast_loop_tiled(r->ds_pts, r->ds_has_mask ? r->ds_msk : nullptr, r->d_points.p, r->d_normals.p, r->d_hits.p,
+                                             nred, nb, r->d_fast_partials.p, r->d_fast_mask.p, r->W, fp.tiles_x, fp.tile_w_log2, n_iter,
+                                             r->h_state_dev, r->h_fast_status_dev, r->h_done_dev, r->stream, cl, r->d_fold_rows, r->d_fold_flags));
+        } else {
+          r->last_fast_rows = micp_fast_blocks(nred); r->last_fast_words = (nred + 63u) / 64u;
+          HIPCHK(launch_find(fp, r->kind, find_variant(r, 1), r->stream));
+          HIPCHK(launch_micp_fast(r->ds_pts, r->ds_has_mask ? r->ds_msk : nullptr, r->d_points.p, r->d_normals.p, r->d_hits.p, nred,
+                                  nullptr, r->d_fast_partials.p, r->d_fast_mask.p, n_iter, r->h_state_dev, r->h_fast_status_dev,
+                                  r->h_done_dev, r->stream, &cl));
+        }
       } else if (!r->micp_fast_exec || r->fast_graph_dirty || !(key == r->micp_fast_key)) {
         // the previous call returned on its completion tag, which precedes the stream's own completion: let the last node
         // retire before its executable graph is destroyed
@@ -1437,7 +1468,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
         r->micp_fast_key = key;
         r->fast_graph_dirty = false;
       }
-      if (r->use_graph && r->fast_mode != 1) HIPCHK(hipGraphLaunch(r->micp_fast_exec, r->stream));
+      if (r->use_graph && r->fast_mode == 2) HIPCHK(hipGraphLaunch(r->micp_fast_exec, r->stream));
       // sum of the tag: the status block, plus the state block when the loop ran to its end (code 0)
       DoneCheck chk; chk.base = r->h_fast_status; chk.base_bytes = sizeof(MicpFastStatus); chk.code = &r->h_fast_status->code;
       chk.extra[0] = r->h_state; chk.extra_bytes[0] = sizeof(MicpState);
@@ -1982,7 +2013,9 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
 
 rmclhip_status rmclhip_rcc_set_micp_fast(rmclhip_rcc* r, int mode) {
   ApiGuard guard_("rmclhip_rcc_set_micp_fast");
-  if (!r || mode < 0 || mode > 2) return fail(RMCLHIP_ERR_INVALID, "rcc_set_micp_fast: mode must be 0 (off), 1 (automatic) or 2 (automatic, replayed from a hipGraph)");
+  if (!r || mode < 0 || mode > 3)
+    return fail(RMCLHIP_ERR_INVALID, "rcc_set_micp_fast: mode must be 0 (off), 1 (automatic), 2 (automatic, replayed from a hipGraph) or 3 (automatic, "
+                                     "moments in a pass of their own)");
   r->fast_mode = mode;
   r->fast_holdoff = 0;
   r->fast_overflows = 0;
@@ -2030,6 +2063,27 @@ rmclhip_status rmclhip_debug_probe_find(rmclhip_rcc* r, const rmclhip_transform*
   if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
   (void)hipFree(d_log);
   if (e != hipSuccess) return fail(RMCLHIP_ERR_HIP, std::string("debug_probe_find: ") + hipGetErrorString(e));
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_debug_micp_moments(rmclhip_rcc* r, double* totals96, uint32_t* n_rows_out, uint64_t* n_uncertain_out) {
+  ApiGuard guard_("rmclhip_debug_micp_moments");
+  if (!r || !totals96) return fail(RMCLHIP_ERR_INVALID, "debug_micp_moments: null");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  std::vector<double> rows(static_cast<size_t>(r->last_fast_rows) * kMicpFastMoments);
+  std::vector<unsigned long long> words(r->last_fast_words);
+  if (!rows.empty()) HIPCHK(hipMemcpy(rows.data(), r->d_fast_partials.p, rows.size() * sizeof(double), hipMemcpyDeviceToHost));
+  if (!words.empty()) HIPCHK(hipMemcpy(words.data(), r->d_fast_mask.p, words.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  for (uint32_t k = 0; k < kMicpFastMoments; ++k) {
+    double acc = 0.0;
+    for (uint32_t b = 0; b < r->last_fast_rows; ++b) acc += rows[static_cast<size_t>(b) * kMicpFastMoments + k];
+    totals96[k] = acc;
+  }
+  uint64_t bits = 0;
+  for (unsigned long long w : words) bits += static_cast<uint64_t>(__builtin_popcountll(w));
+  if (n_rows_out) *n_rows_out = r->last_fast_rows;
+  if (n_uncertain_out) *n_uncertain_out = bits;
   return RMCLHIP_OK;
 }
 

@@ -75,11 +75,140 @@ __global__ void __launch_bounds__(256) k_tile_planes(const FindParams p, float* 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MICP moment epilogue of k_find (kMoments; launch_find_moments).  The gate-stable moment form (kernels.hip k_micp_moments) needs,
+// per correspondence that is certainly gated in, the 82 sums  sum X_a Y_b  of the factor vectors
+//   X = (N0N0, N0N1, N0N2, N1N1, N1N2, N2N2 | 1 | sN0, sN1, sN2)      s = N . I
+//   Y = (1 | D0, D1, D2 | D0D0, D0D1, D0D2, D1D1, D1D2, D2D2)
+// of (dataset point D, model point I, model normal N): that IS a dense product X^T Y (10 x 10, 18 entries unused) over the
+// correspondences -- the one place on this path where the correspondence stack is tiled as a GEMM.  A wave holds 64 correspondences,
+// one per lane, right after its traversal; it stages the factors of 32 of them at a time in its OWN stack columns (free once the
+// traversal has returned; no other wave touches them) and feeds v_mfma_f64_16x16x4_f64: A[i][k] = X_i of correspondence k,
+// B[k][j] = Y_j of correspondence k, 16 instructions for the wave's 64 correspondences, f64 accumulation.  The four waves of a
+// workgroup add their tiles through a 3-KB array and write ONE partial row in k_micp_moments' layout; the loop kernel is unchanged
+// except that the mask words of the undecided correspondences arrive in the find's tile order.
+// ---------------------------------------------------------------------------------------------
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kMomRow = 96;          // == kMicpFastMoments
+
+// index in the 96-double partial row of sum X_x Y_y, or -1 (k_micp_moments: n | D[3] | DD[6] | sN[3] | sND[9] | NN[6] | NND[18] | NNDD[36])
+__device__ __forceinline__ int mom_row_index(uint32_t x, uint32_t y) {
+  if (x >= 10u || y >= 10u) return -1;
+  if (x < 6u) return (y == 0u) ? static_cast<int>(22u + x) : ((y < 4u) ? static_cast<int>(28u + 3u * x + (y - 1u)) : static_cast<int>(46u + 6u * x + (y - 4u)));
+  if (x == 6u) return (y == 0u) ? 0 : ((y < 4u) ? static_cast<int>(1u + (y - 1u)) : static_cast<int>(4u + (y - 4u)));
+  const uint32_t a = x - 7u;
+  return (y == 0u) ? static_cast<int>(10u + a) : ((y < 4u) ? static_cast<int>(13u + 3u * a + (y - 1u)) : -1);
+}
+
+// The wave's staging area = its 24 x 64 dwords of stack columns: row r of the wave is 256 contiguous bytes = 32 doubles, one per staged
+// correspondence.  Factor X_i of correspondence c sits in row i, factor Y_i in row 10 + i, both in column (c + 4 i) mod 32: the skew
+// spreads the 16 rows an MFMA operand fetch touches (a row stride of 1 KB would put them all in one bank) and keeps every access one
+// base register + an immediate: a row is 1024 B further, the Y row of the same i 10 240 B further, the next MFMA step 32 B.
+__device__ __forceinline__ char* mom_stage_base(uint32_t* lds_dyn, uint32_t wave) {
+  return reinterpret_cast<char*>(lds_dyn + wave * 64u);
+}
+
+// the workgroup's partial row: sum of the four waves' tiles (every wave of the workgroup calls this exactly once)
+__device__ __forceinline__ void find_moments_block_sum(const FindParams& p, double (*s_red)[kMomRow]) {
+  __syncthreads();
+  if (threadIdx.x < kMomRow)
+    p.mom_partials[static_cast<size_t>(blockIdx.x) * kMomRow + threadIdx.x] =
+        ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
+}
+
+// a wave without a tile (grid padding): no correspondences
+__device__ __forceinline__ void find_moments_idle_wave(const FindParams& p, double (*s_red)[kMomRow], uint32_t word_index, uint32_t wave, uint32_t lane) {
+  s_red[wave][lane] = 0.0;
+  if (lane < kMomRow - 64u) s_red[wave][64u + lane] = 0.0;
+  if (lane == 0u) p.mom_unc_mask[word_index] = 0ull;
+  find_moments_block_sum(p, s_red);
+}
+
+// the correspondence's dataset side, requested BEFORE the traversal (its latency would otherwise sit at the end of the slowest wave)
+struct MomDataset { f3 D; bool ok; };
+__device__ __forceinline__ MomDataset find_moments_dataset(const FindParams& p, bool valid, uint32_t loc) {
+  MomDataset d;
+  d.D = mk3(0.f, 0.f, 0.f);
+  d.ok = valid && (loc < p.mom_n);
+  if (d.ok) {
+    d.ok = (p.mom_dataset_mask == nullptr) || (p.mom_dataset_mask[loc] > 0);
+    const float* dp = p.mom_dataset_points + 3 * static_cast<size_t>(loc);
+    d.D = mk3(dp[0], dp[1], dp[2]);
+  }
+  return d;
+}
+
+__device__ __forceinline__ void find_moments_wave(const FindParams& p, uint32_t* lds_dyn, double (*s_red)[kMomRow], bool have, MomDataset ds,
+                                                  f3 Ii, f3 Ni, uint32_t word_index, uint32_t wave, uint32_t lane) {
+  // classification: k_micp_moments' own arithmetic at the identity pre-transform
+  const bool ok = have && ds.ok;
+  const f3 Di = ds.D;
+  const float spd0 = dot_plain(sub3(Ii, Di), Ni);
+  const float nd = sqrtf(dot_plain(Di, Di));
+  const float margin = (p.mom_rho_cap * nd + p.mom_tau_cap) + 1e-4f * (1.0f + nd);
+  const float slack = fabsf(fabsf(spd0) - p.mom_max_dist);
+  const bool certain = ok && ((slack > margin) || (spd0 != spd0));
+  const bool uncertain = ok && !certain;
+  const unsigned long long word = __ballot(uncertain);
+  if (lane == 0u) p.mom_unc_mask[word_index] = word;
+  const bool gate = certain && fabsf(spd0) < p.mom_max_dist;
+  double X[10], Y[10];
+  {
+    const double g = gate ? 1.0 : 0.0;   // a gated-out lane contributes zeros (its inputs may be NaN: select, do not multiply)
+    const double D0 = gate ? static_cast<double>(Di.x) : 0.0, D1 = gate ? static_cast<double>(Di.y) : 0.0, D2 = gate ? static_cast<double>(Di.z) : 0.0;
+    const double N0 = gate ? static_cast<double>(Ni.x) : 0.0, N1 = gate ? static_cast<double>(Ni.y) : 0.0, N2 = gate ? static_cast<double>(Ni.z) : 0.0;
+    const double I0 = gate ? static_cast<double>(Ii.x) : 0.0, I1 = gate ? static_cast<double>(Ii.y) : 0.0, I2 = gate ? static_cast<double>(Ii.z) : 0.0;
+    const double sI = (N0 * I0 + N1 * I1) + N2 * I2;
+    X[0] = N0 * N0; X[1] = N0 * N1; X[2] = N0 * N2; X[3] = N1 * N1; X[4] = N1 * N2; X[5] = N2 * N2;
+    X[6] = g; X[7] = sI * N0; X[8] = sI * N1; X[9] = sI * N2;
+    Y[0] = g; Y[1] = D0; Y[2] = D1; Y[3] = D2;
+    Y[4] = D0 * D0; Y[5] = D0 * D1; Y[6] = D0 * D2; Y[7] = D1 * D1; Y[8] = D1 * D2; Y[9] = D2 * D2;
+  }
+  v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+  const uint32_t i16 = lane & 15u, k4 = lane >> 4, ir = min(i16, 9u);
+  char* stage = mom_stage_base(lds_dyn, wave);
+  constexpr uint32_t kRowBytes = kBfStride * 4u;   // 1024
+#pragma unroll
+  for (uint32_t half = 0; half < 2u; ++half) {
+    if ((lane >> 5) == half) {
+      const uint32_t c = lane & 31u;
+#pragma unroll
+      for (uint32_t i = 0; i < 10u; ++i) {
+        char* at = stage + i * kRowBytes + ((c + 4u * i) & 31u) * 8u;
+        *reinterpret_cast<double*>(at) = X[i];
+        *reinterpret_cast<double*>(at + 10u * kRowBytes) = Y[i];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (uint32_t s = 0; s < 8u; ++s) {
+      const char* at = stage + ir * kRowBytes + ((4u * s + k4 + 4u * ir) & 31u) * 8u;
+      const double a = *reinterpret_cast<const double*>(at), b = *reinterpret_cast<const double*>(at + 10u * kRowBytes);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64((i16 < 10u) ? a : 0.0, (i16 < 10u) ? b : 0.0, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  // v_mfma_f64_16x16x4_f64 leaves D[x = 4 * v + lane / 16][y = lane % 16] in acc[v] (checked against k_micp_moments' sums: rmclhip_debug_micp_moments)
+  if (lane >= 50u) s_red[wave][32u + lane] = 0.0;   // entries 82 .. 95 are unused
+#pragma unroll
+  for (uint32_t v = 0; v < 4u; ++v) {
+    const int idx = mom_row_index(4u * v + k4, i16);
+    if (idx >= 0) s_red[wave][idx] = acc[v];
+  }
+  find_moments_block_sum(p, s_red);
+}
+
 // kClock: entry / traversal / store clocks of every wave go to p.wave_clock (tools/wave_timeline.py); the production
 // instantiations are built with kClock = false and contain no s_memtime
-template <uint32_t kModel, int kTrav, bool kClock = false>
+template <uint32_t kModel, int kTrav, bool kClock = false, bool kMoments = false>
 __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   extern __shared__ uint32_t lds_dyn[];
+  static_assert(!kMoments || (kTrav == 23 && !kClock), "the moment epilogue is built for kind 23");
+  __shared__ double s_mom_red[kMoments ? 4 : 1][kMomRow];
   constexpr bool kPacket = (kTrav == 0);
   constexpr bool kQuad = find_quad(kTrav);
   constexpr int kTop = find_top_nodes(kTrav);
@@ -117,7 +246,10 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   const uint32_t vb = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
   const uint32_t tile = (kQuad ? vb : (vb * 4u + wave));
   const uint32_t ntiles = p.tiles_x * p.tiles_y;
-  if (tile >= ntiles) return;
+  if (tile >= ntiles) {
+    if constexpr (kMoments) find_moments_idle_wave(p, s_mom_red, vb * 4u + wave, wave, lane);
+    return;
+  }
   const uint32_t pose = blockIdx.y;
   const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
   const uint32_t twl = p.tile_w_log2;
@@ -127,6 +259,8 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   const uint32_t cv = valid ? vid : 0u, ch = valid ? hid : 0u;
   const uint32_t loc = cv * p.W + ch;
 
+  MomDataset mom_ds = {mk3(0.f, 0.f, 0.f), false};
+  if constexpr (kMoments) mom_ds = find_moments_dataset(p, valid, loc);
   xform Tsm, Tms;
   if (p.Tsm_arr != nullptr) { Tsm = p.Tsm_arr[pose]; Tms = p.Tms_arr[pose]; }
   else { Tsm = p.Tsm; Tms = p.Tms; }
@@ -218,6 +352,7 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
     clk_trace1 = static_cast<uint32_t>(t);
   }
+  f3 mom_I = mk3(0.f, 0.f, 0.f), mom_N = mk3(0.f, 0.f, 0.f);   // kMoments: the correspondence as stored (sensor frame)
   if (valid) {
   const size_t g = static_cast<size_t>(pose) * p.W * p.H + loc;
   const bool found = (h.rec != kNone);
@@ -227,20 +362,22 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   if (found) {
     if (p.hits && w0) p.hits[g] = 1;
     if (p.ranges && w0) p.ranges[g] = h.t;
-    if (p.points && w1) {
+    if ((p.points && w1) || kMoments) {
       f3 pt = scale3(dir_s, h.t);
       if (kModel == kModelO1Dn || kModel == kModelOnDn) pt = add3(pt, orig_s);
-      p.points[3 * g] = pt.x; p.points[3 * g + 1] = pt.y; p.points[3 * g + 2] = pt.z;
+      if (p.points && w1) { p.points[3 * g] = pt.x; p.points[3 * g + 1] = pt.y; p.points[3 * g + 2] = pt.z; }
+      mom_I = pt;
     }
     // the record's last 16 B: unit normal + the ORIGINAL face id
-    if ((p.normals && w2) || (p.face_ids && w0)) {
+    if ((p.normals && w2) || (p.face_ids && w0) || kMoments) {
       uint4 nrec;
       if (kTrav == 27 && pre_rec == h.rec) nrec = pre_nrec;   // (rays finished by the quad tail fetch it here)
       else nrec = reinterpret_cast<const uint4*>(p.tris)[static_cast<size_t>(h.rec) * 4u + 3u];
-      if (p.normals && w2) {
+      if ((p.normals && w2) || kMoments) {
         f3 n = qrot(Tms.R, mk3(asf(nrec.x), asf(nrec.y), asf(nrec.z)));
         if (dot_plain(dir_s, n) > 0.0f) n = neg3(n);  // flip towards the sensor
-        p.normals[3 * g] = n.x; p.normals[3 * g + 1] = n.y; p.normals[3 * g + 2] = n.z;
+        if (p.normals && w2) { p.normals[3 * g] = n.x; p.normals[3 * g + 1] = n.y; p.normals[3 * g + 2] = n.z; }
+        mom_N = n;
       }
       if (p.face_ids && w0) p.face_ids[g] = nrec.w;
     }
@@ -253,6 +390,8 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
     if (p.face_ids && w0) p.face_ids[g] = kInvalidFace;
   }
   }  // valid
+  if constexpr (kMoments)   // (after the stores have been issued: they complete under it)
+    find_moments_wave(p, lds_dyn, s_mom_red, valid && (h.rec != kNone), mom_ds, mom_I, mom_N, vb * 4u + wave, wave, lane);
   if (kClock && p.wave_clock != nullptr) {
     uint64_t t;
     uint64_t t2;

@@ -48,6 +48,15 @@ struct FindParams {
   const float* tile_planes;      // per tile of the scan image: the pyramid of its rays in the sensor frame (k_tile_planes), or null
   // diagnostics (nullable): per physical wave {s_memtime at entry, at exit (low 32 bits), s_memrealtime at entry, tile | xcc << 24}
   uint32_t* wave_clock;
+  // MICP moment epilogue (launch_find_moments, k_find<..., kMom = true>): the moments of the gate-stable form (kernels.hip) are
+  // formed while the correspondences are still in registers -- classification as in k_micp_moments, the 10 x 10 products
+  // X^T Y of the factor vectors through v_mfma_f64_16x16x4_f64 -- instead of a second pass over the find's outputs
+  const float* mom_dataset_points;
+  const uint8_t* mom_dataset_mask;     // nullable
+  uint32_t mom_n;                      // correspondences: min(n_dataset, W * H)
+  float mom_max_dist, mom_rho_cap, mom_tau_cap;
+  double* mom_partials;                // [gridDim.x][kMicpFastMoments]
+  unsigned long long* mom_unc_mask;    // [4 * gridDim.x]: bit l of word t = lane l of (virtual) tile t holds an undecided correspondence
 };
 
 struct MicpState;
@@ -143,6 +152,16 @@ hipError_t launch_micp_fast(const float* dataset_points, const uint8_t* dataset_
                             MicpFastStatus* status, unsigned long long* done, hipStream_t s,
                             const MicpCallLite* call_by_value = nullptr);   // non-null: `call` is ignored
 
+// the loop launch alone, after launch_find_moments: `nblocks` partial rows, mask words in the find's tile order (decoded with
+// W / tiles_x / tile_w_log2 of that find)
+hipError_t launch_micp_fast_loop_tiled(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
+                                       const float* model_normals, const uint8_t* model_mask, uint32_t n, uint32_t nblocks,
+                                       const double* partials, const unsigned long long* unc_mask, uint32_t W, uint32_t tiles_x,
+                                       uint32_t tile_w_log2, uint32_t n_iter, MicpState* state_out, MicpFastStatus* status,
+                                       unsigned long long* done, hipStream_t s, const MicpCallLite& call_by_value,
+                                       double* fold_rows, uint32_t* fold_flags);   // [kMicpFoldBlocks][96] doubles / flags, zeroed once; null: one workgroup
+constexpr uint32_t kMicpFoldBlocks = 8;
+
 // N-sensor MICP loop on the device (micp_localization.cpp:900-964): per-call frames + per-sensor partials, one step launch per
 // iteration merges every sensor's statistics (weighted and unweighted), solves once and hands every sensor its next
 // pre-transform
@@ -192,6 +211,10 @@ hipError_t launch_micp_multi_init(const MicpMultiCall* call, MicpMultiState* sta
 hipError_t launch_micp_multi_step(const MicpMultiCall* call, MicpMultiState* state, hipStream_t s);
 
 hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStream_t s);
+// kind 23 with the MICP moment epilogue: grid of find_moments_blocks(p) workgroups, one partial row per workgroup, one mask word
+// per wave (p.mom_* set by the caller); followed by launch_micp_fast_loop_tiled
+uint32_t find_moments_blocks(const FindParams& p);
+hipError_t launch_find_moments(const FindParams& p, ModelKind kind, hipStream_t s);
 // the plane table of the frontier start (kinds 23 / 24): tiles_x * tiles_y * 16 floats for p's model and tiling
 hipError_t launch_tile_planes(const FindParams& p, ModelKind kind, float* planes, hipStream_t s);
 // diagnostics (tools/probe_find.py): per-wave step timeline of one spherical scan; probe_log: tiles x 512 dwords

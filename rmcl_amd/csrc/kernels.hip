@@ -697,7 +697,20 @@ struct MicpFastParams {
   MicpFastStatus* status;       // may be host-mapped
   unsigned long long* done;     // host-mapped completion tag
   MicpCallLite cv;              // used when call == nullptr (direct launches)
+  // mask words in the tile order of the find that produced them (launch_find_moments): word t = (virtual) tile t, bit l = lane l
+  uint32_t mask_tiled, mask_W, mask_tiles_x, mask_tile_w_log2, mask_nwords;
+  // k_micp_fast_loop launched as gridDim.x > 1 workgroups: workgroup b folds its share of the partial rows; b > 0 hands its 82 sums to
+  // workgroup 0 through fold_rows[b] / fold_flags[b] (= this call's sequence number) and leaves
+  double* fold_rows;            // [kMicpFoldBlocks][kMom]
+  uint32_t* fold_flags;         // [kMicpFoldBlocks]
 };
+// correspondence index of bit `b` of mask word `w`
+__device__ __forceinline__ uint32_t micp_mask_index(const MicpFastParams& p, uint32_t w, uint32_t b) {
+  if (p.mask_tiled == 0u) return (w << 6) + b;
+  const uint32_t ty = w / p.mask_tiles_x, tx = w - ty * p.mask_tiles_x, twl = p.mask_tile_w_log2;
+  const uint32_t vid = (ty << (6u - twl)) + (b >> twl), hid = (tx << twl) + (b & ((1u << twl) - 1u));
+  return vid * p.mask_W + hid;
+}
 #define RMCL_FCALL(p, field) ((p).call != nullptr ? (p).call->field : (p).cv.field)
 
 // Status blocks live in pinned host memory: the block is written whole, then the completion tag (publish_tag) with the sum of
@@ -873,7 +886,12 @@ __device__ __forceinline__ void micp_moment_sums_wave(uint32_t lane, const doubl
 // Sum of the per-block moment partials [nblocks][kMom] into s_part[kFoldGroups][kMom] (the caller adds the groups after a barrier):
 // five groups of 48 threads, TWO moments (one 16-B load) per thread and row, 13 rows in flight -- 128 rows are two round trips
 // (round 2: two groups of 96 threads, one moment each, 16 in flight: four round trips, ~2 us of the loop kernel's set-up).
-constexpr uint32_t kFoldGroups = 5, kFoldLanes = kMom / 2, kFoldBatch = 13;
+constexpr uint32_t kMomUsed = 82;   // columns of a partial row that carry a moment
+// Six groups of 41 lanes: a lane owns one 16-B column pair and every sixth row, 22 rows requested per round -- a fold is bound by what
+// ONE compute unit can pull from L2 (64 B per clock), so only the 82 used columns are read and enough requests are in flight to
+// keep that path busy: 128 rows (k_micp_moments) are one round, the 512 rows of a find with the moment epilogue four.
+constexpr uint32_t kFoldGroups = 6, kFoldLanes = kMomUsed / 2, kFoldBatch = 22;
+static_assert(kFoldGroups * kFoldLanes <= kFastThreads, "fold lanes");
 __device__ __forceinline__ void fold_moment_partials(const double* __restrict__ partials, uint32_t nblocks, double (*s_part)[kMom], uint32_t tid) {
   const uint32_t k2 = tid % kFoldLanes, g = tid / kFoldLanes;
   if (g >= kFoldGroups) return;
@@ -884,13 +902,14 @@ __device__ __forceinline__ void fold_moment_partials(const double* __restrict__ 
 #pragma unroll
     for (uint32_t u = 0; u < kFoldBatch; ++u) {
       const uint32_t b = b0 + u * kFoldGroups;
-      v[u] = (b < nblocks) ? base[static_cast<size_t>(b) * kFoldLanes] : double2{0.0, 0.0};
+      v[u] = (b < nblocks) ? base[static_cast<size_t>(b) * (kMom / 2)] : double2{0.0, 0.0};
     }
 #pragma unroll
     for (uint32_t u = 0; u < kFoldBatch; ++u) { a0 += v[u].x; a1 += v[u].y; }
   }
   s_part[g][2u * k2] = a0;
   s_part[g][2u * k2 + 1u] = a1;
+  if (k2 < (kMom - kMomUsed) / 2u) { s_part[g][kMomUsed + 2u * k2] = 0.0; s_part[g][kMomUsed + 2u * k2 + 1u] = 0.0; }
 }
 
 __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastParams p) {
@@ -908,10 +927,28 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastP
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const unsigned long long clk0 = __builtin_readcyclecounter();
 
-  // (1) moments = sum of the per-block partials
-  fold_moment_partials(p.partials, p.nblocks, s_part, tid);
+  // (1) moments = sum of the per-block partials.  One compute unit pulls 64 B per clock from L2: the 512 rows a find with the moment
+  // epilogue leaves (336 KB) would take it 4 us, so that launch comes as several workgroups -- each folds its share of the rows, the
+  // others hand their 82 sums to workgroup 0 (write-through stores, then a release of this call's sequence number) and leave
+  const uint32_t nfold = gridDim.x;
+  const uint32_t rows_per = (p.nblocks + nfold - 1u) / nfold;
+  const uint32_t row0 = min(blockIdx.x * rows_per, p.nblocks), row1 = min(row0 + rows_per, p.nblocks);
+  fold_moment_partials(p.partials + static_cast<size_t>(row0) * kMom, row1 - row0, s_part, tid);
+  if (blockIdx.x != 0u) {
+    __syncthreads();
+    if (tid < kMomUsed) {
+      double a = s_part[0][tid];
+#pragma unroll
+      for (uint32_t g = 1; g < kGroups; ++g) a += s_part[g][tid];
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(p.fold_rows) + blockIdx.x * kMom + tid,
+                         static_cast<unsigned long long>(__double_as_longlong(a)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (tid == 0u) __hip_atomic_store(p.fold_flags + blockIdx.x, RMCL_FCALL(p, seq), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   // (2) the uncertain correspondences, in index order: count per thread over a contiguous range of mask words, block scan
-  const uint32_t nwords = (p.n + 63u) >> 6;
+  const uint32_t nwords = (p.mask_tiled != 0u) ? p.mask_nwords : ((p.n + 63u) >> 6);
   const uint32_t wpt = (nwords + kFastThreads - 1u) / kFastThreads;
   const uint32_t w0 = min(tid * wpt, nwords), w1 = min(w0 + wpt, nwords);
   uint32_t cnt = 0;
@@ -935,6 +972,30 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastP
     double a = s_part[0][tid];
 #pragma unroll
     for (uint32_t g = 1; g < kGroups; ++g) a += s_part[g][tid];
+    if (nfold > 1u && tid < kMomUsed) {
+      // the other workgroups' sums, in workgroup order; every reading thread acquires the flag itself
+      // (all flags polled together, ONE acquire, all rows requested together: two memory round trips, not two per workgroup)
+      const uint32_t seq = RMCL_FCALL(p, seq);
+      bool ready;
+      do {
+        uint32_t f[kMicpFoldBlocks];
+#pragma unroll
+        for (uint32_t b = 1; b < kMicpFoldBlocks; ++b)
+          f[b] = (b < nfold) ? __hip_atomic_load(p.fold_flags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seq;
+        ready = true;
+#pragma unroll
+        for (uint32_t b = 1; b < kMicpFoldBlocks; ++b) ready = ready && (f[b] == seq);
+      } while (!ready);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      unsigned long long v[kMicpFoldBlocks];
+#pragma unroll
+      for (uint32_t b = 1; b < kMicpFoldBlocks; ++b)
+        v[b] = (b < nfold) ? __hip_atomic_load(reinterpret_cast<unsigned long long*>(p.fold_rows) + b * kMom + tid, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT)
+                           : 0ull;
+#pragma unroll
+      for (uint32_t b = 1; b < kMicpFoldBlocks; ++b) a += __longlong_as_double(static_cast<long long>(v[b]));
+    }
     s_mom[tid] = a;
   }
   uint32_t wave_base = 0, total = 0;
@@ -959,7 +1020,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastP
       while (bits) {
         const int b = __builtin_ctzll(bits);
         bits &= bits - 1ull;
-        s_list[pos++] = (w << 6) + static_cast<uint32_t>(b);
+        s_list[pos++] = micp_mask_index(p, w, static_cast<uint32_t>(b));
       }
     }
   }
@@ -1939,6 +2000,26 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
   return hipGetLastError();
 }
 
+uint32_t find_moments_blocks(const FindParams& p) {
+  const uint32_t ntiles = p.tiles_x * p.tiles_y;
+  return (((ntiles + 3u) / 4u) + 7u) & ~7u;
+}
+
+hipError_t launch_find_moments(const FindParams& p, ModelKind kind, hipStream_t s) {
+  static_assert(kMomRow == kMicpFastMoments && kMomRow == static_cast<uint32_t>(kMom), "one partial-row layout");
+  if (p.nposes != 1u || p.wave_clock != nullptr || p.mom_partials == nullptr || p.mom_unc_mask == nullptr) return hipErrorInvalidValue;
+  dim3 grid(find_moments_blocks(p), 1, 1), block(256, 1, 1);
+  const size_t lds = (static_cast<size_t>(kFindBfRows) * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords) * sizeof(uint32_t);
+  switch (kind) {
+    case kModelSpherical: hipLaunchKernelGGL((k_find<kModelSpherical, 23, false, true>), grid, block, lds, s, p); break;
+    case kModelO1Dn: hipLaunchKernelGGL((k_find<kModelO1Dn, 23, false, true>), grid, block, lds, s, p); break;
+    case kModelPinhole: hipLaunchKernelGGL((k_find<kModelPinhole, 23, false, true>), grid, block, lds, s, p); break;
+    case kModelOnDn: hipLaunchKernelGGL((k_find<kModelOnDn, 23, false, true>), grid, block, lds, s, p); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_tile_planes(const FindParams& p, ModelKind kind, float* planes, hipStream_t s) {
   const uint32_t ntiles = p.tiles_x * p.tiles_y;
   if (ntiles == 0u) return hipSuccess;
@@ -2281,6 +2362,20 @@ hipError_t launch_micp_fast(const float* dataset_points, const uint8_t* dataset_
   if (call_by_value) { p.call = nullptr; p.cv = *call_by_value; }
   hipLaunchKernelGGL(k_micp_moments, dim3(p.nblocks), dim3(256), 0, s, p);
   hipLaunchKernelGGL(k_micp_fast_loop, dim3(1), dim3(kFastThreads), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_micp_fast_loop_tiled(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
+                                       const float* model_normals, const uint8_t* model_mask, uint32_t n, uint32_t nblocks,
+                                       const double* partials, const unsigned long long* unc_mask, uint32_t W, uint32_t tiles_x,
+                                       uint32_t tile_w_log2, uint32_t n_iter, MicpState* state_out, MicpFastStatus* status,
+                                       unsigned long long* done, hipStream_t s, const MicpCallLite& call_by_value, double* fold_rows,
+                                       uint32_t* fold_flags) {
+  MicpFastParams p{dataset_points, dataset_mask, model_points, model_normals, model_mask, n, nblocks, nullptr,
+                   const_cast<double*>(partials), const_cast<unsigned long long*>(unc_mask), n_iter, state_out, status, done, call_by_value,
+                   1u, W, tiles_x, tile_w_log2, 4u * nblocks, fold_rows, fold_flags};
+  const uint32_t nfold = (fold_rows != nullptr && fold_flags != nullptr && nblocks >= 256u) ? kMicpFoldBlocks : 1u;
+  hipLaunchKernelGGL(k_micp_fast_loop, dim3(nfold), dim3(kFastThreads), 0, s, p);
   return hipGetLastError();
 }
 

@@ -453,6 +453,13 @@ class CorrespondencesHIP:
         self._last_nposes = 1
         return buf[: nw.value * 8].reshape(nw.value, 8)
 
+    def debug_micp_moments(self):
+        """diagnostics: (96 moment totals, partial rows, undecided correspondences) of the last moment-form attempt"""
+        tot = np.zeros(96, np.float64)
+        rows, unc = C.c_uint32(0), C.c_uint64(0)
+        _capi.check(_capi.lib().rmclhip_debug_micp_moments(self._h, _ptr(tot), C.byref(rows), C.byref(unc)))
+        return tot, rows.value, unc.value
+
     def debug_probe_find(self, Tbm_est, mode=0):
         """diagnostics: per-wave step timeline of one spherical scan -> uint32 array [n_tiles, 256, 2]"""
         T = np.ascontiguousarray(Tbm_est, dtype=TRANSFORM).reshape(1)

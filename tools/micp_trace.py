@@ -19,6 +19,8 @@ rcc.set_dataset_from_ranges(rcc.modelView()["ranges"])
 rcc.params.max_dist, rcc.adaptive_max_dist_min = 1.0, 0.15
 est = T.mult(syn.pose_c2_truth(), syn.pose_c2_perturbation())
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+if len(sys.argv) > 2:
+    rcc.set_micp_fast(int(sys.argv[2]))   # 1 = moments in the find's epilogue (default), 3 = in a pass of their own
 for _ in range(300):
     rcc.correct_once(est, T.identity(), n_iter, 0.0, False)
 print(rcc.micp_fast_info())
