@@ -184,6 +184,11 @@ def main():
                 extras["c3_schedule_%s_ms" % name] = round(dt * 1e3, 4)
                 extras["c3_schedule_%s_pose_corrections_per_s" % name] = round(1.0 / dt, 1)
                 extras["c3_schedule_%s_icp_iterations_per_s" % name] = round(10.0 / dt, 1)
+            # (R) with the moments in a pass of their own (round 3's first form, three launches: A/B of the find's moment epilogue)
+            rcc.set_micp_fast(3)
+            rcc.correct_once(est, T.identity(), 10, 0.0, False)
+            extras["c3_schedule_R_separate_moments_pass_ms"] = round(rcc.time_correct_once(est, T.identity(), 10, 0.0, False, iters=50), 4)
+            rcc.set_micp_fast(1)
             # (R) again with the moment form off: one streaming launch per iteration (the fallback of the default form)
             info = rcc.micp_fast_info()
             extras["c3_schedule_R_moment_form"] = {k: info[k] for k in ("attempts", "done", "cap_exits", "overflows", "last_uncertain")}

@@ -91,15 +91,6 @@ __global__ void __launch_bounds__(256) k_tile_planes(const FindParams p, float* 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr uint32_t kMomRow = 96;          // == kMicpFastMoments
 
-// index in the 96-double partial row of sum X_x Y_y, or -1 (k_micp_moments: n | D[3] | DD[6] | sN[3] | sND[9] | NN[6] | NND[18] | NNDD[36])
-__device__ __forceinline__ int mom_row_index(uint32_t x, uint32_t y) {
-  if (x >= 10u || y >= 10u) return -1;
-  if (x < 6u) return (y == 0u) ? static_cast<int>(22u + x) : ((y < 4u) ? static_cast<int>(28u + 3u * x + (y - 1u)) : static_cast<int>(46u + 6u * x + (y - 4u)));
-  if (x == 6u) return (y == 0u) ? 0 : ((y < 4u) ? static_cast<int>(1u + (y - 1u)) : static_cast<int>(4u + (y - 4u)));
-  const uint32_t a = x - 7u;
-  return (y == 0u) ? static_cast<int>(10u + a) : ((y < 4u) ? static_cast<int>(13u + 3u * a + (y - 1u)) : -1);
-}
-
 // The wave's staging area = its 24 x 64 dwords of stack columns: row r of the wave is 256 contiguous bytes = 32 doubles, one per staged
 // correspondence.  Factor X_i of correspondence c sits in row i, factor Y_i in row 10 + i, both in column (c + 4 i) mod 32: the skew
 // spreads the 16 rows an MFMA operand fetch touches (a row stride of 1 KB would put them all in one bank) and keeps every access one
@@ -108,18 +99,31 @@ __device__ __forceinline__ char* mom_stage_base(uint32_t* lds_dyn, uint32_t wave
   return reinterpret_cast<char*>(lds_dyn + wave * 64u);
 }
 
-// the workgroup's partial row: sum of the four waves' tiles (every wave of the workgroup calls this exactly once)
-__device__ __forceinline__ void find_moments_block_sum(const FindParams& p, double (*s_red)[kMomRow]) {
+// the workgroup's partial row: sum of the four waves' 16 x 16 tiles (every wave of the workgroup calls this exactly once); thread t
+// writes row entry t, which is tile element (x, y) = the inverse of k_micp_moments' layout
+constexpr uint32_t kMomTile = 256;
+__device__ __forceinline__ void find_moments_block_sum(const FindParams& p, double (*s_red)[kMomTile]) {
   __syncthreads();
-  if (threadIdx.x < kMomRow)
-    p.mom_partials[static_cast<size_t>(blockIdx.x) * kMomRow + threadIdx.x] =
-        ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
+  const uint32_t t = threadIdx.x;
+  if (t < kMomRow) {
+    // n | D[3] | DD[6] | sN[3] | sND[9] | NN[6] | NND[18] | NNDD[36]   <->   X = (NN[6] | 1 | sN[3]), Y = (1 | D[3] | DD[6])
+    uint32_t x = 16u, y = 0u;   // x = 16: an unused entry (82 .. 95)
+    if (t < 10u) { x = 6u; y = t; }
+    else if (t < 13u) { x = 7u + (t - 10u); y = 0u; }
+    else if (t < 22u) { x = 7u + (t - 13u) / 3u; y = 1u + (t - 13u) % 3u; }
+    else if (t < 28u) { x = t - 22u; y = 0u; }
+    else if (t < 46u) { x = (t - 28u) / 3u; y = 1u + (t - 28u) % 3u; }
+    else if (t < 82u) { x = (t - 46u) / 6u; y = 4u + (t - 46u) % 6u; }
+    const uint32_t e = (x & 15u) * 16u + y;
+    const double v = ((s_red[0][e] + s_red[1][e]) + s_red[2][e]) + s_red[3][e];
+    p.mom_partials[static_cast<size_t>(blockIdx.x) * kMomRow + t] = (x < 16u) ? v : 0.0;
+  }
 }
 
 // a wave without a tile (grid padding): no correspondences
-__device__ __forceinline__ void find_moments_idle_wave(const FindParams& p, double (*s_red)[kMomRow], uint32_t word_index, uint32_t wave, uint32_t lane) {
-  s_red[wave][lane] = 0.0;
-  if (lane < kMomRow - 64u) s_red[wave][64u + lane] = 0.0;
+__device__ __forceinline__ void find_moments_idle_wave(const FindParams& p, double (*s_red)[kMomTile], uint32_t word_index, uint32_t wave, uint32_t lane) {
+#pragma unroll
+  for (uint32_t v = 0; v < 4u; ++v) s_red[wave][v * 64u + lane] = 0.0;
   if (lane == 0u) p.mom_unc_mask[word_index] = 0ull;
   find_moments_block_sum(p, s_red);
 }
@@ -138,13 +142,12 @@ __device__ __forceinline__ MomDataset find_moments_dataset(const FindParams& p, 
   return d;
 }
 
-__device__ __forceinline__ void find_moments_wave(const FindParams& p, uint32_t* lds_dyn, double (*s_red)[kMomRow], bool have, MomDataset ds,
+__device__ __forceinline__ void find_moments_wave(const FindParams& p, uint32_t* lds_dyn, double (*s_red)[kMomTile], bool have, MomDataset ds,
                                                   f3 Ii, f3 Ni, uint32_t word_index, uint32_t wave, uint32_t lane) {
   // classification: k_micp_moments' own arithmetic at the identity pre-transform
   const bool ok = have && ds.ok;
-  const f3 Di = ds.D;
-  const float spd0 = dot_plain(sub3(Ii, Di), Ni);
-  const float nd = sqrtf(dot_plain(Di, Di));
+  const float spd0 = dot_plain(sub3(Ii, ds.D), Ni);
+  const float nd = sqrtf(dot_plain(ds.D, ds.D));
   const float margin = (p.mom_rho_cap * nd + p.mom_tau_cap) + 1e-4f * (1.0f + nd);
   const float slack = fabsf(fabsf(spd0) - p.mom_max_dist);
   const bool certain = ok && ((slack > margin) || (spd0 != spd0));
@@ -154,10 +157,10 @@ __device__ __forceinline__ void find_moments_wave(const FindParams& p, uint32_t*
   const bool gate = certain && fabsf(spd0) < p.mom_max_dist;
   double X[10], Y[10];
   {
-    const double g = gate ? 1.0 : 0.0;   // a gated-out lane contributes zeros (its inputs may be NaN: select, do not multiply)
-    const double D0 = gate ? static_cast<double>(Di.x) : 0.0, D1 = gate ? static_cast<double>(Di.y) : 0.0, D2 = gate ? static_cast<double>(Di.z) : 0.0;
-    const double N0 = gate ? static_cast<double>(Ni.x) : 0.0, N1 = gate ? static_cast<double>(Ni.y) : 0.0, N2 = gate ? static_cast<double>(Ni.z) : 0.0;
-    const double I0 = gate ? static_cast<double>(Ii.x) : 0.0, I1 = gate ? static_cast<double>(Ii.y) : 0.0, I2 = gate ? static_cast<double>(Ii.z) : 0.0;
+    // a gated-out lane contributes zeros (its inputs may be NaN: select, do not multiply)
+    const f3 Dz = gate ? ds.D : mk3(0.f, 0.f, 0.f), Nz = gate ? Ni : mk3(0.f, 0.f, 0.f), Iz = gate ? Ii : mk3(0.f, 0.f, 0.f);
+    const double g = gate ? 1.0 : 0.0;
+    const double D0 = Dz.x, D1 = Dz.y, D2 = Dz.z, N0 = Nz.x, N1 = Nz.y, N2 = Nz.z, I0 = Iz.x, I1 = Iz.y, I2 = Iz.z;
     const double sI = (N0 * I0 + N1 * I1) + N2 * I2;
     X[0] = N0 * N0; X[1] = N0 * N1; X[2] = N0 * N2; X[3] = N1 * N1; X[4] = N1 * N2; X[5] = N2 * N2;
     X[6] = g; X[7] = sI * N0; X[8] = sI * N1; X[9] = sI * N2;
@@ -165,9 +168,15 @@ __device__ __forceinline__ void find_moments_wave(const FindParams& p, uint32_t*
     Y[4] = D0 * D0; Y[5] = D0 * D1; Y[6] = D0 * D2; Y[7] = D1 * D1; Y[8] = D1 * D2; Y[9] = D2 * D2;
   }
   v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-  const uint32_t i16 = lane & 15u, k4 = lane >> 4, ir = min(i16, 9u);
+  const uint32_t i16 = lane & 15u, k4 = lane >> 4;
   char* stage = mom_stage_base(lds_dyn, wave);
   constexpr uint32_t kRowBytes = kBfStride * 4u;   // 1024
+  // operand lanes 10 .. 15 of an MFMA step (the tile is 16 wide, the factor vectors 10 long) read zeros: row 20 of the wave
+  if (lane < 32u) *reinterpret_cast<double*>(stage + 20u * kRowBytes + lane * 8u) = 0.0;
+  const bool opl = i16 < 10u;
+  const char* row_a = stage + (opl ? i16 : 20u) * kRowBytes;
+  const char* row_b = stage + (opl ? 10u + i16 : 20u) * kRowBytes;
+  const uint32_t col0 = k4 + 4u * i16;
 #pragma unroll
   for (uint32_t half = 0; half < 2u; ++half) {
     if ((lane >> 5) == half) {
@@ -184,21 +193,16 @@ __device__ __forceinline__ void find_moments_wave(const FindParams& p, uint32_t*
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (uint32_t s = 0; s < 8u; ++s) {
-      const char* at = stage + ir * kRowBytes + ((4u * s + k4 + 4u * ir) & 31u) * 8u;
-      const double a = *reinterpret_cast<const double*>(at), b = *reinterpret_cast<const double*>(at + 10u * kRowBytes);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64((i16 < 10u) ? a : 0.0, (i16 < 10u) ? b : 0.0, acc, 0, 0, 0);
+      const uint32_t cb = ((col0 + 4u * s) & 31u) * 8u;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(*reinterpret_cast<const double*>(row_a + cb), *reinterpret_cast<const double*>(row_b + cb), acc, 0, 0, 0);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   // v_mfma_f64_16x16x4_f64 leaves D[x = 4 * v + lane / 16][y = lane % 16] in acc[v] (checked against k_micp_moments' sums: rmclhip_debug_micp_moments)
-  if (lane >= 50u) s_red[wave][32u + lane] = 0.0;   // entries 82 .. 95 are unused
 #pragma unroll
-  for (uint32_t v = 0; v < 4u; ++v) {
-    const int idx = mom_row_index(4u * v + k4, i16);
-    if (idx >= 0) s_red[wave][idx] = acc[v];
-  }
+  for (uint32_t v = 0; v < 4u; ++v) s_red[wave][(4u * v + k4) * 16u + i16] = acc[v];
   find_moments_block_sum(p, s_red);
 }
 
@@ -208,7 +212,7 @@ template <uint32_t kModel, int kTrav, bool kClock = false, bool kMoments = false
 __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   extern __shared__ uint32_t lds_dyn[];
   static_assert(!kMoments || (kTrav == 23 && !kClock), "the moment epilogue is built for kind 23");
-  __shared__ double s_mom_red[kMoments ? 4 : 1][kMomRow];
+  __shared__ double s_mom_red[kMoments ? 4 : 1][kMoments ? kMomTile : 1];
   constexpr bool kPacket = (kTrav == 0);
   constexpr bool kQuad = find_quad(kTrav);
   constexpr int kTop = find_top_nodes(kTrav);

@@ -427,7 +427,8 @@ class CorrespondencesHIP:
         self.set_variant((int(kind) & 15) | ((int(kind) >> 4) << 13))
 
     def set_micp_fast(self, mode):
-        """moment form of the schedule-(R) loop of correctOnce: 0 = never, 1 = automatic (rmclhip.h)"""
+        """moment form of the schedule-(R) loop of correctOnce: 0 = never, 1 = automatic (moments formed in the find's epilogue where the
+        traversal allows), 2 = through a hipGraph, 3 = moments always in a pass of their own (rmclhip.h)"""
         _capi.check(_capi.lib().rmclhip_rcc_set_micp_fast(self._h, int(mode)))
 
     def micp_fast_info(self):

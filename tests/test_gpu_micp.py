@@ -477,6 +477,68 @@ def test_moment_form_o1dn_unmasked_dataset_and_short_dataset(ra, orc, ctx, meshe
     assert int(res[1][0][1]["n_meas"]) > int(res[1][3][1]["n_meas"])        # the short dataset really is shorter
 
 
+@pytest.mark.parametrize("shape", [(128, 1024), (100, 1000)])
+def test_moments_formed_in_the_find_epilogue_equal_the_separate_pass(ra, orc, ctx, meshes, shape):
+    """rmclhip_rcc_set_micp_fast 1 (the find of kind 23 forms the moments in its epilogue: f64 MFMA over the wave's 64 correspondences,
+    one partial row per workgroup, mask words in tile order, rows folded by eight workgroups) against mode 3 (k_micp_moments, a pass of
+    its own): the same 82 moments (1e-10 relative: the summation order differs), the same undecided correspondences, the same
+    statistics and pose.  100 x 1000 has ragged tiles, lanes without a ray and workgroups without a tile; the room leaves
+    correspondences undecided, the O1Dn model has NaN directions and an unmasked dataset."""
+    from rmcl_amd import synthetic as syn, types as T
+    H, W = shape
+    v, f = meshes("room100k")
+    hm = ra.import_hip_map(ctx, v, f)
+    model = syn.model_c2()
+    model.phi.inc = model.phi.inc * 128.0 / H
+    model.phi.size = H
+    model.theta.inc = model.theta.inc * 1024.0 / W
+    model.theta.size = W
+    truth = T.transform_from_rpy((1.5, -2.0, 1.6), (0.02, -0.03, 0.4))
+    est = T.mult(truth, T.transform_from_rpy((0.03, -0.02, 0.015), (0.004, -0.003, 0.008)))
+    dirs = syn.model_directions(model).copy()
+    dirs[11::131] = np.nan
+    for kind in ("spherical", "o1dn"):
+        res = {}
+        for mode in (3, 1):
+            if kind == "spherical":
+                rcc = ra.RCCHipSpherical(hm)
+                rcc.setTsb(T.identity())
+                rcc.setModel(model)
+                rcc.find(truth)
+                rcc.set_dataset_from_ranges(rcc.modelView()["ranges"])
+            else:
+                rcc = ra.RCCHipO1Dn(hm)
+                rcc.setTsb(T.identity())
+                rcc.setModel(W, H, 0.1, 100.0, (0.01, -0.02, 0.03), dirs)
+                rcc.find(truth)
+                mv = rcc.modelView()
+                pts = (dirs * mv["ranges"].reshape(-1, 1) + np.float32([0.01, -0.02, 0.03])).astype(np.float32)
+                pts[mv["hits"].reshape(-1) == 0] = np.nan
+                rcc.set_dataset(pts, None)
+            assert rcc.find_variant(1) == 23
+            rcc.params.max_dist, rcc.adaptive_max_dist_min = 0.5, 0.2
+            rcc.set_micp_fast(3)
+            for _ in range(3):
+                rcc.correct_once(est, T.identity(), 8, 0.0, False)       # the bounds are learnt with the separate pass in both runs
+            rcc.set_micp_fast(mode)
+            Tc, st = rcc.correct_once(est, T.identity(), 8, 0.0, False)
+            tot, rows, unc = rcc.debug_micp_moments()
+            info = rcc.micp_fast_info()
+            assert info["last_code"] == 0, info
+            res[mode] = (Tc, st, tot, rows, unc, info["last_uncertain"])
+            rcc.close()
+        (Ta, sa, ma, rows_a, unc_a, lu_a), (Tb, sb, mb, rows_b, unc_b, lu_b) = res[3], res[1]
+        assert rows_b > rows_a and rows_b % 8 == 0                       # one row per workgroup of the find
+        assert unc_a == unc_b == lu_a == lu_b
+        assert ma[0] > 1000 and ma[0] == mb[0]                           # the count of certainly gated-in correspondences: exact
+        assert np.allclose(ma[:82], mb[:82], rtol=1e-10, atol=1e-7)
+        assert np.all(mb[82:] == 0.0)
+        assert int(sa["n_meas"]) == int(sb["n_meas"])
+        _transform_close(Ta, Tb, 1e-6)
+        assert np.allclose(sa["covariance"], sb["covariance"], rtol=1e-6, atol=1e-8)
+    hm.release()
+
+
 def test_moment_form_randomised_against_per_iteration_form(ra, orc, ctx, meshes):
     """120 random corrections (mesh, mount, odometry frame, perturbation from millimetres to decimetres, gate from 5 cm to
     2 m, 2..12 iterations, progress) through two operators that differ only in rmclhip_rcc_set_micp_fast: n_meas must be
