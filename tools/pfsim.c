@@ -72,8 +72,27 @@ static int box(const float* nd, uint32_t c, const slot_t* s, float* tn_out)
   return nd[c] < 1e29f && tn <= tf;
 }
 
+static int g_sort_steps = 0;   /* 0: full order (insertion sort over the hits); 3 / 4 / 5: the kernel's compare-exchange network cut after that many steps */
+void pfsim_sort_steps(int n) { g_sort_steps = n; }
+static void node_step_network(slot_t* s, const uint32_t* nodes)
+{
+  const float* nd = (const float*)(nodes + 32u * s->cur);
+  const uint32_t* ch = nodes + 32u * s->cur + 24u;
+  float key[4]; uint32_t ref[4];
+  s->nvisit++;
+  for (uint32_t c = 0; c < 4; ++c) { float tn; key[c] = box(nd, c, s, &tn) ? tn : 3e38f; ref[c] = ch[c]; }
+#define CSW(i, j) if (key[j] < key[i]) { float t = key[i]; key[i] = key[j]; key[j] = t; uint32_t r = ref[i]; ref[i] = ref[j]; ref[j] = r; }
+  CSW(0, 1) CSW(2, 3) CSW(0, 2)
+  if (g_sort_steps >= 4) CSW(1, 3)
+  if (g_sort_steps >= 5) CSW(1, 2)
+#undef CSW
+  for (int a = 3; a >= 1; --a) if (key[a] < 3e38f && s->sp < 96) s->stack[s->sp++] = ref[a];
+  if (key[0] < 3e38f) s->cur = ref[0]; else slot_pop(s);
+}
+
 static void node_step(slot_t* s, const uint32_t* nodes)
 {
+  if (g_sort_steps) { node_step_network(s, nodes); return; }
   const float* nd = (const float*)(nodes + 32u * s->cur);
   const uint32_t* ch = nodes + 32u * s->cur + 24u;
   float key[4]; uint32_t ref[4]; int nh = 0;
