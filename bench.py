@@ -279,6 +279,34 @@ def main():
                 cpc.find(est)
             extras["cpc_find_cold_bounded_ms"] = round((time.perf_counter() - t1) / 20 * 1e3, 4)
             cpc.close()
+            # TWO operators (two sensors of one node, or two scans of a stream in flight): each has its own stream and buffers, their
+            # finds alternate without waiting for each other.  A single 128x1024 scan leaves the chip partly idle -- its launch ends
+            # with its slowest wave while the average wave takes two thirds of that, plus ~2.3 us between dependent launches --; this
+            # is the throughput when the next scan may start under the previous one's tail.  NOT the headline (one scan at a time).
+            pair = []
+            for k in range(2):
+                o = ra.RCCHipSpherical(hm)
+                o.setTsb(T.identity())
+                o.setModel(model)
+                o.find(Tbm)
+                pair.append(o)
+            reps = 100
+            ts = []
+            for _ in range(5):
+                for o in pair:
+                    o.sync()
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    for o in pair:
+                        o.find_async(Tbm)
+                for o in pair:
+                    o.sync()
+                ts.append((time.perf_counter() - t1) / (2 * reps))
+            two_ms = sorted(ts)[2] * 1e3
+            extras["find_two_operators_in_flight_ms_per_scan"] = round(two_ms, 5)
+            extras["find_two_operators_in_flight_rays_per_s"] = round(n_rays / (two_ms * 1e-3), 1)
+            for o in pair:
+                o.close()
             small = ra.RCCHipSpherical(hm)
             small.setTsb(T.identity())
             small.setModel(syn.model_vlp16_900())
