@@ -208,6 +208,8 @@ struct rmclhip_rcc {
   DevBuf<double> d_fast_partials;
   DevBuf<unsigned long long> d_fast_mask;
   double* d_fold_rows = nullptr;      // hand-over area of the loop launch's folding workgroups (kernels.h: kMicpFoldBlocks)
+  uint32_t* d_join_flags = nullptr;   // (first sensor of rmclhip_micp_correct_once) the other sensors' "my rows are complete" words
+  hipEvent_t ev_join = nullptr;       // rmclhip_micp_correct_once: this sensor's find (+ moment pass) ran on its own stream; the loop's stream waits for it
   uint32_t* d_fold_flags = nullptr;
   uint32_t last_fast_rows = 0, last_fast_words = 0;   // partial rows / mask words of the last moment-form attempt (diagnostics)
   MicpFastStatus* h_fast_status = nullptr;      // pinned, host-mapped
@@ -700,6 +702,8 @@ void rmclhip_rcc_destroy(rmclhip_rcc* r) {
   r->d_cpc_rec.release();
   r->d_fast_partials.release(); r->d_fast_mask.release(); r->d_tile_planes.release();
   if (r->d_fold_rows) DBG_STEP(hipFree(r->d_fold_rows));
+  if (r->ev_join) DBG_STEP(hipEventDestroy(r->ev_join));
+  if (r->d_join_flags) DBG_STEP(hipFree(r->d_join_flags));
   r->d_multi_blob.release();
   if (r->h_multi_state) DBG_STEP(hipHostFree(r->h_multi_state));
   if (r->h_multi_status) DBG_STEP(hipHostFree(r->h_multi_status));
@@ -1680,28 +1684,38 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
   MicpMultiCall* d_call = reinterpret_cast<MicpMultiCall*>(r0->d_multi_blob.p);
   MicpMultiState* d_state = reinterpret_cast<MicpMultiState*>(r0->d_multi_blob.p + sizeof(MicpMultiCall));
   hipError_t e = hipSuccess;
-  // sensor->setTom(Tom); sensor->findCorrespondences()  (:900-909): Tbm = Tom * Tbo
-  for (uint32_t s = 0; s < n_sensors && e == hipSuccess; ++s) {
-    rmclhip_rcc* r = sensors[s];
-    FindParams p;
-    fill_find_params(r, p, 1);
-    p.Tsm = xmul(xmul(Tom, h_call.Tbo[s]), r->Tsb);
-    p.Tms = xinv(p.Tsm);
-    int v = find_variant(r, 1);
-    e = launch_find(p, r->kind, v, st);
-  }
-  if (e != hipSuccess) return fail(RMCLHIP_ERR_HIP, std::string("micp_correct_once: ") + hipGetErrorString(e));
   // ---- moment form first (kernels.hip k_micp_multi_fast_loop): every sensor's caps are the ones its own corrections learnt
   bool fast_eligible = n_iter >= 2u;
   for (uint32_t s = 0; s < n_sensors; ++s) fast_eligible = fast_eligible && sensors[s]->fast_mode != 0;
   bool fast_tried = false;
   if (fast_eligible && r0->multi_holdoff > 0u) --r0->multi_holdoff;
-  else if (fast_eligible) {
-    fast_tried = true;
-    MicpMultiFastParams fp;
-    std::memset(&fp, 0, sizeof(fp));
-    for (uint32_t s = 0; s < n_sensors; ++s) {
-      rmclhip_rcc* r = sensors[s];
+  else if (fast_eligible) fast_tried = true;
+  // sensor->setTom(Tom); sensor->findCorrespondences()  (:900-909): Tbm = Tom * Tbo.  The sensors' finds (and moment passes) do not
+  // depend on each other: sensor 0's go to the stream the loop runs on, every other sensor's to ITS OWN stream, joined by an event
+  // before the loop -- one scan leaves the chip partly idle (bench.py extras.find_two_operators_in_flight_*), a second sensor's scan
+  // fills it (round 3: everything sat on one stream)
+  MicpMultiFastParams fp;
+  std::memset(&fp, 0, sizeof(fp));
+  // A cross-stream EVENT takes ~10 us to reach the waiting queue (measured: the loop started 10-12 us after its last input), so in the
+  // moment form the join is a flag: a one-lane kernel behind the sensor's moment pass stores the call's sequence number, the loop
+  // kernel -- launched without waiting -- polls it before it touches that sensor's rows.  Events are recorded all the same: the
+  // per-iteration form (fallback) waits for them on the stream.
+  if (n_sensors > 1u && !r0->d_join_flags) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&r0->d_join_flags), kMaxMicpSensors * sizeof(uint32_t)));
+    HIPCHK(hipMemset(r0->d_join_flags, 0, kMaxMicpSensors * sizeof(uint32_t)));
+    HIPCHK(hipDeviceSynchronize());
+  }
+  for (uint32_t s = 0; s < n_sensors && e == hipSuccess; ++s) {
+    rmclhip_rcc* r = sensors[s];
+    hipStream_t fs = (s == 0u) ? st : r->stream;
+    FindParams p;
+    fill_find_params(r, p, 1);
+    p.Tsm = xmul(xmul(Tom, h_call.Tbo[s]), r->Tsb);
+    p.Tms = xinv(p.Tsm);
+    int v = find_variant(r, 1);
+    e = launch_find(p, r->kind, v, fs);
+    if (e != hipSuccess) break;
+    if (fast_tried) {
       const uint32_t nred = (r->n_dataset < r->n_model) ? r->n_dataset : r->n_model;
       HIPCHK(r->d_fast_partials.reserve(static_cast<size_t>(micp_fast_blocks(nred)) * kMicpFastMoments));
       HIPCHK(r->d_fast_mask.reserve((static_cast<size_t>(nred) + 63u) / 64u));
@@ -1710,13 +1724,25 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
       cl.Tsb = r->Tsb; cl.Tbo = h_call.Tbo[s]; cl.max_dist = adaptive_max_dist(r, convergence_progress);
       cl.rho_cap = r->fast_rho_cap; cl.tau_cap = r->fast_tau_cap; cl.seq = h_call.seq;
       HIPCHK(launch_micp_moments(r->ds_pts, r->ds_has_mask ? r->ds_msk : nullptr, r->d_points.p, r->d_normals.p, r->d_hits.p, nred,
-                                 nullptr, r->d_fast_partials.p, r->d_fast_mask.p, st, &cl));
+                                 nullptr, r->d_fast_partials.p, r->d_fast_mask.p, fs, &cl));
       fp.dataset_points[s] = r->ds_pts; fp.model_points[s] = r->d_points.p; fp.model_normals[s] = r->d_normals.p;
       fp.partials[s] = r->d_fast_partials.p; fp.unc_mask[s] = r->d_fast_mask.p;
       fp.n[s] = nred; fp.nblocks[s] = micp_fast_blocks(nred);
       fp.Tsb[s] = cl.Tsb; fp.Tbo[s] = cl.Tbo; fp.weight[s] = h_call.weight[s];
       fp.max_dist[s] = cl.max_dist; fp.rho_cap[s] = cl.rho_cap; fp.tau_cap[s] = cl.tau_cap;
     }
+    if (s != 0u) {
+      if (fast_tried) {
+        HIPCHK(launch_signal_flag(r0->d_join_flags + s, h_call.seq, fs));
+        fp.join_mask |= 1u << s;
+      }
+      if (!r->ev_join) HIPCHK(hipEventCreateWithFlags(&r->ev_join, hipEventDisableTiming));
+      HIPCHK(hipEventRecord(r->ev_join, fs));
+    }
+  }
+  fp.join_flags = r0->d_join_flags;
+  if (e != hipSuccess) return fail(RMCLHIP_ERR_HIP, std::string("micp_correct_once: ") + hipGetErrorString(e));
+  if (fast_tried) {
     fp.n_sensors = n_sensors;
     fp.seq = h_call.seq;
     fp.n_iter = n_iter;
@@ -1757,7 +1783,9 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
       if (fs.code == 2u) sensors[s]->fast_info.overflows++; else sensors[s]->fast_info.cap_exits++;
     }
   }
-  // per-iteration form (fallback, or the moment form is off): the call block goes to the device
+  // per-iteration form (fallback, or the moment form is off): the call block goes to the device.  The other sensors' finds ran on
+  // their own streams: this stream waits for their events first.
+  for (uint32_t s = 1; s < n_sensors; ++s) HIPCHK(hipStreamWaitEvent(st, sensors[s]->ev_join, 0));
   e = hipMemcpyAsync(d_call, &h_call, sizeof(h_call), hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = launch_micp_multi_init(d_call, d_state, st);
   for (uint32_t it = 0; it < n_iter && e == hipSuccess; ++it) {

@@ -202,7 +202,13 @@ struct MicpMultiFastParams {
   MicpMultiState* state_out;                              // may be host-mapped
   MicpMultiFastStatus* status;                            // may be host-mapped
   unsigned long long* done;                               // host-mapped completion tag (see kernels.hip publish_tag)
+  // sensors whose find + moment pass ran on ANOTHER stream (bit s of join_mask): the loop waits for join_flags[s] == seq before it
+  // touches sensor s's rows -- an in-kernel wait of ~1 us where a cross-stream event takes ~10 us to reach the waiting queue
+  const uint32_t* join_flags;
+  uint32_t join_mask;
 };
+// one lane stores `seq` to *flag with release semantics at device scope: enqueued behind a sensor's moment pass on that sensor's stream
+hipError_t launch_signal_flag(uint32_t* flag, uint32_t seq, hipStream_t s);
 hipError_t launch_micp_moments(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
                                const float* model_normals, const uint8_t* model_mask, uint32_t n, const MicpCall* call,
                                double* partials, unsigned long long* unc_mask, hipStream_t s, const MicpCallLite* call_by_value = nullptr);

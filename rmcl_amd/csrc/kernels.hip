@@ -2106,6 +2106,13 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_multi_fast_loop(const Mic
   // set-up, sensor by sensor: moments and the index-ordered list segment of its undecided correspondences
   uint32_t total = 0;
   for (uint32_t s = 0; s < ns; ++s) {
+    if ((p.join_mask >> s) & 1u) {
+      // this sensor's rows and mask words come from another stream: its signal kernel (behind its moment pass) stores the call's
+      // sequence number; one lane acquires it, the barrier hands the visibility to the workgroup
+      if (tid == 0u)
+        while (__hip_atomic_load(p.join_flags + s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != p.seq) __builtin_amdgcn_s_sleep(2);
+      __syncthreads();
+    }
     fold_moment_partials(p.partials[s], p.nblocks[s], s_part, tid);
     const unsigned long long* mask = p.unc_mask[s];
     const uint32_t nwords = (p.n[s] + 63u) >> 6;
@@ -2345,6 +2352,16 @@ hipError_t launch_micp_moments(const float* dataset_points, const uint8_t* datas
                    partials, unc_mask, 0u, nullptr, nullptr, nullptr, {}};
   if (call_by_value) { p.call = nullptr; p.cv = *call_by_value; }
   hipLaunchKernelGGL(k_micp_moments, dim3(p.nblocks), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+namespace {
+__global__ void k_signal_flag(uint32_t* flag, uint32_t seq) {
+  if (threadIdx.x == 0u && blockIdx.x == 0u) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+}  // namespace
+hipError_t launch_signal_flag(uint32_t* flag, uint32_t seq, hipStream_t s) {
+  hipLaunchKernelGGL(k_signal_flag, dim3(1), dim3(64), 0, s, flag, seq);
   return hipGetLastError();
 }
 
