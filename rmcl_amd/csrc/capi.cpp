@@ -1657,7 +1657,8 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
   const xform Tom = to_x(Tom_);
   for (uint32_t s = 0; s < n_sensors; ++s) {
     rmclhip_rcc* r = sensors[s];
-    HIPCHK(hipStreamSynchronize(r->stream));   // whatever the sensor's own stream still holds
+    // (no synchronisation with the sensor's own stream: its find is enqueued ON that stream, behind whatever it still holds, and the
+    // loop touches the sensor only behind that find -- flag or event; a hipStreamSynchronize per sensor cost ~9 us each here)
     const size_t n = static_cast<size_t>(r->W) * r->H;
     r->n_model = static_cast<uint32_t>(n);
     r->nposes_last = 1;
@@ -1698,46 +1699,43 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
   std::memset(&fp, 0, sizeof(fp));
   // A cross-stream EVENT takes ~10 us to reach the waiting queue (measured: the loop started 10-12 us after its last input), so in the
   // moment form the join is a flag: a one-lane kernel behind the sensor's moment pass stores the call's sequence number, the loop
-  // kernel -- launched without waiting -- polls it before it touches that sensor's rows.  Events are recorded all the same: the
-  // per-iteration form (fallback) waits for them on the stream.
+  // kernel -- launched without waiting -- polls it before it touches that sensor's rows.  The per-iteration form (fallback) records
+  // an event on every other sensor's stream and waits for it.
   if (n_sensors > 1u && !r0->d_join_flags) {
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&r0->d_join_flags), kMaxMicpSensors * sizeof(uint32_t)));
     HIPCHK(hipMemset(r0->d_join_flags, 0, kMaxMicpSensors * sizeof(uint32_t)));
     HIPCHK(hipDeviceSynchronize());
   }
+  // every find first (the host needs ~4 us per launch: the second sensor's scan should not wait behind the first sensor's moment pass
+  // being enqueued), then the moment passes and the flags
   for (uint32_t s = 0; s < n_sensors && e == hipSuccess; ++s) {
     rmclhip_rcc* r = sensors[s];
-    hipStream_t fs = (s == 0u) ? st : r->stream;
     FindParams p;
     fill_find_params(r, p, 1);
     p.Tsm = xmul(xmul(Tom, h_call.Tbo[s]), r->Tsb);
     p.Tms = xinv(p.Tsm);
-    int v = find_variant(r, 1);
-    e = launch_find(p, r->kind, v, fs);
-    if (e != hipSuccess) break;
-    if (fast_tried) {
-      const uint32_t nred = (r->n_dataset < r->n_model) ? r->n_dataset : r->n_model;
-      HIPCHK(r->d_fast_partials.reserve(static_cast<size_t>(micp_fast_blocks(nred)) * kMicpFastMoments));
-      HIPCHK(r->d_fast_mask.reserve((static_cast<size_t>(nred) + 63u) / 64u));
-      // per-call data by value: no H2D copy node per sensor (4.4 us each in the kernel trace of round 2's chain)
-      MicpCallLite cl;
-      cl.Tsb = r->Tsb; cl.Tbo = h_call.Tbo[s]; cl.max_dist = adaptive_max_dist(r, convergence_progress);
-      cl.rho_cap = r->fast_rho_cap; cl.tau_cap = r->fast_tau_cap; cl.seq = h_call.seq;
-      HIPCHK(launch_micp_moments(r->ds_pts, r->ds_has_mask ? r->ds_msk : nullptr, r->d_points.p, r->d_normals.p, r->d_hits.p, nred,
-                                 nullptr, r->d_fast_partials.p, r->d_fast_mask.p, fs, &cl));
-      fp.dataset_points[s] = r->ds_pts; fp.model_points[s] = r->d_points.p; fp.model_normals[s] = r->d_normals.p;
-      fp.partials[s] = r->d_fast_partials.p; fp.unc_mask[s] = r->d_fast_mask.p;
-      fp.n[s] = nred; fp.nblocks[s] = micp_fast_blocks(nred);
-      fp.Tsb[s] = cl.Tsb; fp.Tbo[s] = cl.Tbo; fp.weight[s] = h_call.weight[s];
-      fp.max_dist[s] = cl.max_dist; fp.rho_cap[s] = cl.rho_cap; fp.tau_cap[s] = cl.tau_cap;
-    }
+    e = launch_find(p, r->kind, find_variant(r, 1), (s == 0u) ? st : r->stream);
+  }
+  for (uint32_t s = 0; s < n_sensors && e == hipSuccess && fast_tried; ++s) {
+    rmclhip_rcc* r = sensors[s];
+    hipStream_t fs = (s == 0u) ? st : r->stream;
+    const uint32_t nred = (r->n_dataset < r->n_model) ? r->n_dataset : r->n_model;
+    HIPCHK(r->d_fast_partials.reserve(static_cast<size_t>(micp_fast_blocks(nred)) * kMicpFastMoments));
+    HIPCHK(r->d_fast_mask.reserve((static_cast<size_t>(nred) + 63u) / 64u));
+    // per-call data by value: no H2D copy node per sensor (4.4 us each in the kernel trace of round 2's chain)
+    MicpCallLite cl;
+    cl.Tsb = r->Tsb; cl.Tbo = h_call.Tbo[s]; cl.max_dist = adaptive_max_dist(r, convergence_progress);
+    cl.rho_cap = r->fast_rho_cap; cl.tau_cap = r->fast_tau_cap; cl.seq = h_call.seq;
+    HIPCHK(launch_micp_moments(r->ds_pts, r->ds_has_mask ? r->ds_msk : nullptr, r->d_points.p, r->d_normals.p, r->d_hits.p, nred,
+                               nullptr, r->d_fast_partials.p, r->d_fast_mask.p, fs, &cl));
+    fp.dataset_points[s] = r->ds_pts; fp.model_points[s] = r->d_points.p; fp.model_normals[s] = r->d_normals.p;
+    fp.partials[s] = r->d_fast_partials.p; fp.unc_mask[s] = r->d_fast_mask.p;
+    fp.n[s] = nred; fp.nblocks[s] = micp_fast_blocks(nred);
+    fp.Tsb[s] = cl.Tsb; fp.Tbo[s] = cl.Tbo; fp.weight[s] = h_call.weight[s];
+    fp.max_dist[s] = cl.max_dist; fp.rho_cap[s] = cl.rho_cap; fp.tau_cap[s] = cl.tau_cap;
     if (s != 0u) {
-      if (fast_tried) {
-        HIPCHK(launch_signal_flag(r0->d_join_flags + s, h_call.seq, fs));
-        fp.join_mask |= 1u << s;
-      }
-      if (!r->ev_join) HIPCHK(hipEventCreateWithFlags(&r->ev_join, hipEventDisableTiming));
-      HIPCHK(hipEventRecord(r->ev_join, fs));
+      HIPCHK(launch_signal_flag(r0->d_join_flags + s, h_call.seq, fs));
+      fp.join_mask |= 1u << s;
     }
   }
   fp.join_flags = r0->d_join_flags;
@@ -1785,7 +1783,12 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
   }
   // per-iteration form (fallback, or the moment form is off): the call block goes to the device.  The other sensors' finds ran on
   // their own streams: this stream waits for their events first.
-  for (uint32_t s = 1; s < n_sensors; ++s) HIPCHK(hipStreamWaitEvent(st, sensors[s]->ev_join, 0));
+  for (uint32_t s = 1; s < n_sensors; ++s) {
+    rmclhip_rcc* r = sensors[s];
+    if (!r->ev_join) HIPCHK(hipEventCreateWithFlags(&r->ev_join, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(r->ev_join, r->stream));   // (recorded here, not per call: the moment form never needs it)
+    HIPCHK(hipStreamWaitEvent(st, r->ev_join, 0));
+  }
   e = hipMemcpyAsync(d_call, &h_call, sizeof(h_call), hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = launch_micp_multi_init(d_call, d_state, st);
   for (uint32_t it = 0; it < n_iter && e == hipSuccess; ++it) {
