@@ -1079,10 +1079,13 @@ rmclhip_status rmclhip_rcc_find_async(rmclhip_rcc* r, const rmclhip_transform* T
   return find_enqueue(r, to_x(Tbm_est));
 }
 
-// Wait for a handle's stream the way the context's wait mode says (rmclhip_ctx_set_wait_mode): SPIN polls hipStreamQuery -- the
-// thread learns of the completion ~10 us before an interrupt-driven hipStreamSynchronize would wake it, which is what a single
-// 17-us scan (find, find_async + sync) feels --, then one hipStreamSynchronize (immediate) keeps the runtime's own view in order;
-// BLOCK sleeps in the runtime.  20 ms of polling at most.
+// Wait for a handle's stream the way the context's wait mode says (rmclhip_ctx_set_wait_mode): SPIN polls hipStreamQuery, then one
+// hipStreamSynchronize (immediate) keeps the runtime's own view in order; BLOCK goes to hipStreamSynchronize at once.  20 ms of polling
+// at most.  Measured late in round 3 (a synchronous 128x1024 find at the C ABI, median of 200): 32.0 us either way -- on this runtime
+// hipStreamSynchronize spins for short waits itself, so for a find the mode only says whose loop burns the core; it is the polled
+// completion TAG of the calls that return results (wait_done: computeCrossStatistics 21.5 vs 27.3 us) that the mode really moves.
+// For the particle filter's short kernels the polling loop was SLOWER than hipStreamSynchronize (likelihood statistics 19 -> 31 us):
+// those entry points call hipStreamSynchronize directly.
 static hipError_t stream_wait(const rmclhip_ctx* ctx, hipStream_t stream) {
   if (!ctx->wait_block.load(std::memory_order_relaxed)) {
     const auto t0 = std::chrono::steady_clock::now();
