@@ -498,10 +498,31 @@ def test_moments_formed_in_the_find_epilogue_equal_the_separate_pass(ra, orc, ct
     est = T.mult(truth, T.transform_from_rpy((0.03, -0.02, 0.015), (0.004, -0.003, 0.008)))
     dirs = syn.model_directions(model).copy()
     dirs[11::131] = np.nan
-    for kind in ("spherical", "o1dn"):
+    kinds = ("spherical", "o1dn") if (H, W) != (128, 1024) else ("spherical", "o1dn", "pinhole", "ondn")
+    for kind in kinds:
         res = {}
         for mode in (3, 1):
-            if kind == "spherical":
+            if kind == "pinhole":
+                rcc = ra.RCCHipPinhole(hm)
+                rcc.setTsb(T.identity())
+                rcc.setModel(W, H, 0.1, 100.0, 600.0, 90.0, W / 2 - 0.5, H / 2 - 0.5)
+                rcc.find(truth)
+                mv = rcc.modelView()
+                pts = mv["points"].reshape(-1, 3).copy()
+                pts[mv["hits"].reshape(-1) == 0] = np.nan
+                rcc.set_dataset(pts, (mv["hits"].reshape(-1) > 0).astype(np.uint8))
+            elif kind == "ondn":
+                rcc = ra.RCCHipOnDn(hm)
+                rcc.setTsb(T.identity())
+                d2 = syn.model_directions(model).copy()
+                origs = (0.05 * np.stack([np.sin(np.arange(H * W) * 0.37), np.cos(np.arange(H * W) * 0.11), np.sin(np.arange(H * W) * 0.05)], -1)).astype(np.float32)
+                rcc.setModel(W, H, 0.1, 100.0, origs, d2)
+                rcc.find(truth)
+                mv = rcc.modelView()
+                pts = mv["points"].reshape(-1, 3).copy()
+                pts[mv["hits"].reshape(-1) == 0] = np.nan
+                rcc.set_dataset(pts, None)
+            elif kind == "spherical":
                 rcc = ra.RCCHipSpherical(hm)
                 rcc.setTsb(T.identity())
                 rcc.setModel(model)
