@@ -369,9 +369,9 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* rcc, int variant);
  * are re-evaluated every iteration, and all iterations run in one single-workgroup launch.  When a pre-transform leaves the
  * bounds, or too many correspondences are undecided, the library falls back to one streaming launch per iteration: the
  * result never depends on the bounds (both forms agree to f64 summation order).  mode 0 = never, 1 = automatic (default: TWO plain
- * launches with their per-call data by value -- when the scan is one the per-ray traversal (kind 23) serves, the find forms the
- * moments in its epilogue, a 10 x 10 product of factor vectors per correspondence through f64 MFMA, and the loop launch folds the
- * per-workgroup rows; other scans: find, moments pass, loop), 2 = automatic, find + moments pass + loop replayed from a hipGraph
+ * launches with their per-call data by value -- the find (per-ray kind 23 or quad kind 2: every single scan the rule serves) forms
+ * the moments in its epilogue, a 10 x 10 product of factor vectors per correspondence through f64 MFMA, and the loop launch folds
+ * the per-workgroup rows; a forced other kind: find, moments pass, loop), 2 = automatic, find + moments pass + loop replayed from a hipGraph
  * behind an H2D copy node (A/B: a graph replay costs the host more than three launches), 3 = automatic, three plain launches
  * (A/B: the moments always in a pass of their own). */
 typedef struct {

@@ -1414,13 +1414,14 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
         MicpCallLite cl;
         cl.Tsb = r->Tsb; cl.Tbo = Tbo; cl.max_dist = maxd; cl.rho_cap = r->fast_rho_cap; cl.tau_cap = r->fast_tau_cap;
         cl.seq = r->h_call->seq;
-        if (r->fast_mode != 3 && find_variant(r, 1) == 23) {
+        const int fv = find_variant(r, 1);
+        if (r->fast_mode != 3 && (fv == 23 || fv == 2)) {
           // TWO kernels: the find forms the moments in its epilogue (find_kernel.hip.h: the 10 x 10 factor products of its 64
           // correspondences per wave through f64 MFMA), one partial row per workgroup; the second pass over the find's outputs is gone
           // (fast_mode 3 keeps it for A/B; the other traversal kinds have no moment epilogue)
-          const uint32_t nb = find_moments_blocks(fp);
+          const uint32_t nb = find_moments_blocks(fp, fv), wpb = (fv == 2) ? 1u : 4u;   // mask words per workgroup
           HIPCHK(r->d_fast_partials.reserve(static_cast<size_t>(nb) * kMicpFastMoments));
-          HIPCHK(r->d_fast_mask.reserve(static_cast<size_t>(nb) * 4u));
+          HIPCHK(r->d_fast_mask.reserve(static_cast<size_t>(nb) * wpb));
           fp.mom_dataset_points = r->ds_pts;
           fp.mom_dataset_mask = r->ds_has_mask ? r->ds_msk : nullptr;
           fp.mom_n = nred;
@@ -1433,14 +1434,14 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
             HIPCHK(hipDeviceSynchronize());
             r->d_fold_flags = reinterpret_cast<uint32_t*>(r->d_fold_rows + kMicpFoldBlocks * kMicpFastMoments);
           }
-          r->last_fast_rows = nb; r->last_fast_words = 4u * nb;
-          HIPCHK(launch_find_moments(fp, r->kind, r->stream));
+          r->last_fast_rows = nb; r->last_fast_words = wpb * nb;
+          HIPCHK(launch_find_moments(fp, r->kind, fv, r->stream));
           HIPCHK(launch_micp_fast_loop_tiled(r->ds_pts, r->ds_has_mask ? r->ds_msk : nullptr, r->d_points.p, r->d_normals.p, r->d_hits.p,
-                                             nred, nb, r->d_fast_partials.p, r->d_fast_mask.p, r->W, fp.tiles_x, fp.tile_w_log2, n_iter,
+                                             nred, nb, r->d_fast_partials.p, r->d_fast_mask.p, r->W, fp.tiles_x, fp.tile_w_log2, wpb, n_iter,
                                              r->h_state_dev, r->h_fast_status_dev, r->h_done_dev, r->stream, cl, r->d_fold_rows, r->d_fold_flags));
         } else {
           r->last_fast_rows = micp_fast_blocks(nred); r->last_fast_words = (nred + 63u) / 64u;
-          HIPCHK(launch_find(fp, r->kind, find_variant(r, 1), r->stream));
+          HIPCHK(launch_find(fp, r->kind, fv, r->stream));
           HIPCHK(launch_micp_fast(r->ds_pts, r->ds_has_mask ? r->ds_msk : nullptr, r->d_points.p, r->d_normals.p, r->d_hits.p, nred,
                                   nullptr, r->d_fast_partials.p, r->d_fast_mask.p, n_iter, r->h_state_dev, r->h_fast_status_dev,
                                   r->h_done_dev, r->stream, &cl));

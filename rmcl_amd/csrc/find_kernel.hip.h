@@ -102,9 +102,14 @@ __device__ __forceinline__ char* mom_stage_base(uint32_t* lds_dyn, uint32_t wave
 // the workgroup's partial row: sum of the four waves' 16 x 16 tiles (every wave of the workgroup calls this exactly once); thread t
 // writes row entry t, which is tile element (x, y) = the inverse of k_micp_moments' layout
 constexpr uint32_t kMomTile = 256;
-__device__ __forceinline__ void find_moments_block_sum(const FindParams& p, double (*s_red)[kMomTile]) {
+__device__ __forceinline__ void find_moments_block_sum(const FindParams& p, double (*s_red)[kMomTile], const uint32_t* s_piece = nullptr,
+                                                       uint32_t tile_word = 0u) {
   __syncthreads();
   const uint32_t t = threadIdx.x;
+  // quad kind: the tile's 64 rays are spread over the four waves (16 each): their 16-bit pieces make the tile's mask word
+  if (s_piece != nullptr && t == 0u)
+    p.mom_unc_mask[tile_word] = static_cast<unsigned long long>(s_piece[0]) | (static_cast<unsigned long long>(s_piece[1]) << 16) |
+                                (static_cast<unsigned long long>(s_piece[2]) << 32) | (static_cast<unsigned long long>(s_piece[3]) << 48);
   if (t < kMomRow) {
     // n | D[3] | DD[6] | sN[3] | sND[9] | NN[6] | NND[18] | NNDD[36]   <->   X = (NN[6] | 1 | sN[3]), Y = (1 | D[3] | DD[6])
     uint32_t x = 16u, y = 0u;   // x = 16: an unused entry (82 .. 95)
@@ -121,11 +126,18 @@ __device__ __forceinline__ void find_moments_block_sum(const FindParams& p, doub
 }
 
 // a wave without a tile (grid padding): no correspondences
-__device__ __forceinline__ void find_moments_idle_wave(const FindParams& p, double (*s_red)[kMomTile], uint32_t word_index, uint32_t wave, uint32_t lane) {
+template <bool kQuadRays>
+__device__ __forceinline__ void find_moments_idle_wave(const FindParams& p, double (*s_red)[kMomTile], uint32_t* s_piece, uint32_t word_index,
+                                                       uint32_t wave, uint32_t lane) {
 #pragma unroll
   for (uint32_t v = 0; v < 4u; ++v) s_red[wave][v * 64u + lane] = 0.0;
-  if (lane == 0u) p.mom_unc_mask[word_index] = 0ull;
-  find_moments_block_sum(p, s_red);
+  if (kQuadRays) {
+    if (lane == 0u) s_piece[wave] = 0u;
+    find_moments_block_sum(p, s_red, s_piece, word_index);
+  } else {
+    if (lane == 0u) p.mom_unc_mask[word_index] = 0ull;
+    find_moments_block_sum(p, s_red);
+  }
 }
 
 // the correspondence's dataset side, requested BEFORE the traversal (its latency would otherwise sit at the end of the slowest wave)
@@ -142,8 +154,11 @@ __device__ __forceinline__ MomDataset find_moments_dataset(const FindParams& p, 
   return d;
 }
 
-__device__ __forceinline__ void find_moments_wave(const FindParams& p, uint32_t* lds_dyn, double (*s_red)[kMomTile], bool have, MomDataset ds,
-                                                  f3 Ii, f3 Ni, uint32_t word_index, uint32_t wave, uint32_t lane) {
+// kQuadRays: the quad traversal -- a ray is held by four lanes (the one with sub == 0 speaks for it: `have` is false in the others), a wave
+// has 16 of the tile's 64 rays: the MFMA passes run over 64 lanes of which 16 contribute, the mask word is assembled per workgroup
+template <bool kQuadRays>
+__device__ __forceinline__ void find_moments_wave(const FindParams& p, uint32_t* lds_dyn, double (*s_red)[kMomTile], uint32_t* s_piece, bool have,
+                                                  MomDataset ds, f3 Ii, f3 Ni, uint32_t word_index, uint32_t wave, uint32_t lane) {
   // classification: k_micp_moments' own arithmetic at the identity pre-transform
   const bool ok = have && ds.ok;
   const float spd0 = dot_plain(sub3(Ii, ds.D), Ni);
@@ -152,8 +167,15 @@ __device__ __forceinline__ void find_moments_wave(const FindParams& p, uint32_t*
   const float slack = fabsf(fabsf(spd0) - p.mom_max_dist);
   const bool certain = ok && ((slack > margin) || (spd0 != spd0));
   const bool uncertain = ok && !certain;
-  const unsigned long long word = __ballot(uncertain);
-  if (lane == 0u) p.mom_unc_mask[word_index] = word;
+  unsigned long long word = __ballot(uncertain);
+  if (kQuadRays) {
+    // bits sit at lanes 4 r (sub == 0): lane r < 16 fetches lane 4 r's flag, the ballot of those is the wave's 16-bit piece
+    const int u4 = __shfl(uncertain ? 1 : 0, static_cast<int>((lane & 15u) << 2), 64);
+    word = __ballot(lane < 16u && u4 != 0);
+    if (lane == 0u) s_piece[wave] = static_cast<uint32_t>(word);
+  } else if (lane == 0u) {
+    p.mom_unc_mask[word_index] = word;
+  }
   const bool gate = certain && fabsf(spd0) < p.mom_max_dist;
   double X[10], Y[10];
   {
@@ -203,7 +225,8 @@ __device__ __forceinline__ void find_moments_wave(const FindParams& p, uint32_t*
   // v_mfma_f64_16x16x4_f64 leaves D[x = 4 * v + lane / 16][y = lane % 16] in acc[v] (checked against k_micp_moments' sums: rmclhip_debug_micp_moments)
 #pragma unroll
   for (uint32_t v = 0; v < 4u; ++v) s_red[wave][(4u * v + k4) * 16u + i16] = acc[v];
-  find_moments_block_sum(p, s_red);
+  if (kQuadRays) find_moments_block_sum(p, s_red, s_piece, word_index);
+  else find_moments_block_sum(p, s_red);
 }
 
 // kClock: entry / traversal / store clocks of every wave go to p.wave_clock (tools/wave_timeline.py); the production
@@ -211,8 +234,9 @@ __device__ __forceinline__ void find_moments_wave(const FindParams& p, uint32_t*
 template <uint32_t kModel, int kTrav, bool kClock = false, bool kMoments = false>
 __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   extern __shared__ uint32_t lds_dyn[];
-  static_assert(!kMoments || (kTrav == 23 && !kClock), "the moment epilogue is built for kind 23");
+  static_assert(!kMoments || ((kTrav == 23 || kTrav == 2) && !kClock), "the moment epilogue is built for kinds 23 and 2");
   __shared__ double s_mom_red[kMoments ? 4 : 1][kMoments ? kMomTile : 1];
+  __shared__ uint32_t s_mom_piece[4];
   constexpr bool kPacket = (kTrav == 0);
   constexpr bool kQuad = find_quad(kTrav);
   constexpr int kTop = find_top_nodes(kTrav);
@@ -251,7 +275,7 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   const uint32_t tile = (kQuad ? vb : (vb * 4u + wave));
   const uint32_t ntiles = p.tiles_x * p.tiles_y;
   if (tile >= ntiles) {
-    if constexpr (kMoments) find_moments_idle_wave(p, s_mom_red, vb * 4u + wave, wave, lane);
+    if constexpr (kMoments) find_moments_idle_wave<kQuad>(p, s_mom_red, s_mom_piece, kQuad ? vb : (vb * 4u + wave), wave, threadIdx.x & 63u);
     return;
   }
   const uint32_t pose = blockIdx.y;
@@ -264,7 +288,7 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   const uint32_t loc = cv * p.W + ch;
 
   MomDataset mom_ds = {mk3(0.f, 0.f, 0.f), false};
-  if constexpr (kMoments) mom_ds = find_moments_dataset(p, valid, loc);
+  if constexpr (kMoments) mom_ds = find_moments_dataset(p, valid && (!kQuad || sub == 0u), loc);
   xform Tsm, Tms;
   if (p.Tsm_arr != nullptr) { Tsm = p.Tsm_arr[pose]; Tms = p.Tms_arr[pose]; }
   else { Tsm = p.Tsm; Tms = p.Tms; }
@@ -395,7 +419,8 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   }
   }  // valid
   if constexpr (kMoments)   // (after the stores have been issued: they complete under it)
-    find_moments_wave(p, lds_dyn, s_mom_red, valid && (h.rec != kNone), mom_ds, mom_I, mom_N, vb * 4u + wave, wave, lane);
+    find_moments_wave<kQuad>(p, lds_dyn + (kQuad ? kQuadStackEntries * 64u : 0u), s_mom_red, s_mom_piece, valid && (h.rec != kNone) && (!kQuad || sub == 0u),
+                             mom_ds, mom_I, mom_N, kQuad ? vb : (vb * 4u + wave), wave, threadIdx.x & 63u);
   if (kClock && p.wave_clock != nullptr) {
     uint64_t t;
     uint64_t t2;

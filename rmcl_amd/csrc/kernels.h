@@ -142,7 +142,7 @@ struct MicpState {
 struct MicpFastStatus { uint32_t code, iter, n_uncertain; float max_rho, max_tau; uint32_t pad[3]; };
 constexpr uint32_t kMicpFastMoments = 96;
 inline uint32_t micp_fast_blocks(uint32_t n) {
-  const uint32_t b = (n + 1023u) / 1024u;
+  const uint32_t b = (n + 255u) / 256u;   // one correspondence per thread for small scans, up to 128 rows
   return b < 1u ? 1u : (b > 128u ? 128u : b);
 }
 // partials: micp_fast_blocks(n) * 96 doubles; unc_mask: ceil(n / 64) words
@@ -157,8 +157,8 @@ hipError_t launch_micp_fast(const float* dataset_points, const uint8_t* dataset_
 hipError_t launch_micp_fast_loop_tiled(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
                                        const float* model_normals, const uint8_t* model_mask, uint32_t n, uint32_t nblocks,
                                        const double* partials, const unsigned long long* unc_mask, uint32_t W, uint32_t tiles_x,
-                                       uint32_t tile_w_log2, uint32_t n_iter, MicpState* state_out, MicpFastStatus* status,
-                                       unsigned long long* done, hipStream_t s, const MicpCallLite& call_by_value,
+                                       uint32_t tile_w_log2, uint32_t words_per_block, uint32_t n_iter, MicpState* state_out,
+                                       MicpFastStatus* status, unsigned long long* done, hipStream_t s, const MicpCallLite& call_by_value,
                                        double* fold_rows, uint32_t* fold_flags);   // [kMicpFoldBlocks][96] doubles / flags, zeroed once; null: one workgroup
 constexpr uint32_t kMicpFoldBlocks = 8;
 
@@ -217,10 +217,10 @@ hipError_t launch_micp_multi_init(const MicpMultiCall* call, MicpMultiState* sta
 hipError_t launch_micp_multi_step(const MicpMultiCall* call, MicpMultiState* state, hipStream_t s);
 
 hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStream_t s);
-// kind 23 with the MICP moment epilogue: grid of find_moments_blocks(p) workgroups, one partial row per workgroup, one mask word
-// per wave (p.mom_* set by the caller); followed by launch_micp_fast_loop_tiled
-uint32_t find_moments_blocks(const FindParams& p);
-hipError_t launch_find_moments(const FindParams& p, ModelKind kind, hipStream_t s);
+// kinds 23 / 2 with the MICP moment epilogue: grid of find_moments_blocks(p, kind) workgroups, one partial row per workgroup, one mask
+// word per wave (23) or per workgroup (2: a tile is a workgroup) (p.mom_* set by the caller); followed by launch_micp_fast_loop_tiled
+uint32_t find_moments_blocks(const FindParams& p, int variant);
+hipError_t launch_find_moments(const FindParams& p, ModelKind kind, int variant, hipStream_t s);   // variant 23 (a mask word per wave) or 2 (per workgroup)
 // the plane table of the frontier start (kinds 23 / 24): tiles_x * tiles_y * 16 floats for p's model and tiling
 hipError_t launch_tile_planes(const FindParams& p, ModelKind kind, float* planes, hipStream_t s);
 // diagnostics (tools/probe_find.py): per-wave step timeline of one spherical scan; probe_log: tiles x 512 dwords

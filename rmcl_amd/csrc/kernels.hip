@@ -2000,15 +2000,28 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
   return hipGetLastError();
 }
 
-uint32_t find_moments_blocks(const FindParams& p) {
+uint32_t find_moments_blocks(const FindParams& p, int variant) {
   const uint32_t ntiles = p.tiles_x * p.tiles_y;
-  return (((ntiles + 3u) / 4u) + 7u) & ~7u;
+  return (((variant == 2) ? ntiles : (ntiles + 3u) / 4u) + 7u) & ~7u;
 }
 
-hipError_t launch_find_moments(const FindParams& p, ModelKind kind, hipStream_t s) {
+hipError_t launch_find_moments(const FindParams& p, ModelKind kind, int variant, hipStream_t s) {
   static_assert(kMomRow == kMicpFastMoments && kMomRow == static_cast<uint32_t>(kMom), "one partial-row layout");
-  if (p.nposes != 1u || p.wave_clock != nullptr || p.mom_partials == nullptr || p.mom_unc_mask == nullptr) return hipErrorInvalidValue;
-  dim3 grid(find_moments_blocks(p), 1, 1), block(256, 1, 1);
+  if (p.nposes != 1u || p.wave_clock != nullptr || p.mom_partials == nullptr || p.mom_unc_mask == nullptr || (variant != 23 && variant != 2))
+    return hipErrorInvalidValue;
+  dim3 grid(find_moments_blocks(p, variant), 1, 1), block(256, 1, 1);
+  if (variant == 2) {
+    // quad kind: the ray stacks, then the four waves' staging rows (21 rows of 256 dwords, find_moments_wave)
+    const size_t lds = (static_cast<size_t>(kQuadStackEntries) * 64u + 21u * 256u) * sizeof(uint32_t);
+    switch (kind) {
+      case kModelSpherical: hipLaunchKernelGGL((k_find<kModelSpherical, 2, false, true>), grid, block, lds, s, p); break;
+      case kModelO1Dn: hipLaunchKernelGGL((k_find<kModelO1Dn, 2, false, true>), grid, block, lds, s, p); break;
+      case kModelPinhole: hipLaunchKernelGGL((k_find<kModelPinhole, 2, false, true>), grid, block, lds, s, p); break;
+      case kModelOnDn: hipLaunchKernelGGL((k_find<kModelOnDn, 2, false, true>), grid, block, lds, s, p); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   const size_t lds = (static_cast<size_t>(kFindBfRows) * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords) * sizeof(uint32_t);
   switch (kind) {
     case kModelSpherical: hipLaunchKernelGGL((k_find<kModelSpherical, 23, false, true>), grid, block, lds, s, p); break;
@@ -2385,12 +2398,12 @@ hipError_t launch_micp_fast(const float* dataset_points, const uint8_t* dataset_
 hipError_t launch_micp_fast_loop_tiled(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
                                        const float* model_normals, const uint8_t* model_mask, uint32_t n, uint32_t nblocks,
                                        const double* partials, const unsigned long long* unc_mask, uint32_t W, uint32_t tiles_x,
-                                       uint32_t tile_w_log2, uint32_t n_iter, MicpState* state_out, MicpFastStatus* status,
-                                       unsigned long long* done, hipStream_t s, const MicpCallLite& call_by_value, double* fold_rows,
-                                       uint32_t* fold_flags) {
+                                       uint32_t tile_w_log2, uint32_t words_per_block, uint32_t n_iter, MicpState* state_out,
+                                       MicpFastStatus* status, unsigned long long* done, hipStream_t s, const MicpCallLite& call_by_value,
+                                       double* fold_rows, uint32_t* fold_flags) {
   MicpFastParams p{dataset_points, dataset_mask, model_points, model_normals, model_mask, n, nblocks, nullptr,
                    const_cast<double*>(partials), const_cast<unsigned long long*>(unc_mask), n_iter, state_out, status, done, call_by_value,
-                   1u, W, tiles_x, tile_w_log2, 4u * nblocks, fold_rows, fold_flags};
+                   1u, W, tiles_x, tile_w_log2, words_per_block * nblocks, fold_rows, fold_flags};
   const uint32_t nfold = (fold_rows != nullptr && fold_flags != nullptr && nblocks >= 256u) ? kMicpFoldBlocks : 1u;
   hipLaunchKernelGGL(k_micp_fast_loop, dim3(nfold), dim3(kFastThreads), 0, s, p);
   return hipGetLastError();
