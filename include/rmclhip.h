@@ -326,7 +326,10 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* rcc, const rmclhip_transfor
  * sensor at Tbm = Tom * Tbo[s], then n_iter x { per sensor statistics at T_snew_sold (MICPSensor.hpp:178) in its own frame,
  * Cs_o = Tbo * (Tsb * stats_s), Cmerged_o += Cs_o, Cmerged_weighted_o += Cs_o with n_meas *= merge_weight_multiplier[s]
  * (truncating, :934), T_onew_oold *= umeyama(Cmerged_weighted_o) } -- all on the device, one synchronisation at the end.
- * merge_weight_multiplier may be NULL (all 1).  merged_out: the UNWEIGHTED statistics of the last iteration (:1010-1011). */
+ * merge_weight_multiplier may be NULL (all 1).  merged_out: the UNWEIGHTED statistics of the last iteration (:1010-1011).
+ * Every sensor's find (and moment pass) is enqueued on that sensor's OWN stream, so the scans run concurrently; the loop runs on
+ * sensor 0's stream behind all of them (an in-kernel flag per sensor; stream events in the per-iteration fallback).  When the call
+ * returns, all of it is complete and every sensor's model buffers hold its scan at Tom * Tbo[s]. */
 rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n_sensors, const rmclhip_transform* Tom,
                                          const rmclhip_transform* Tbo, const double* merge_weight_multiplier, uint32_t n_iter,
                                          double convergence_progress, rmclhip_transform* T_onew_oold_out,
