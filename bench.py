@@ -184,6 +184,19 @@ def main():
                 extras["c3_schedule_%s_ms" % name] = round(dt * 1e3, 4)
                 extras["c3_schedule_%s_pose_corrections_per_s" % name] = round(1.0 / dt, 1)
                 extras["c3_schedule_%s_icp_iterations_per_s" % name] = round(10.0 / dt, 1)
+            # the reference's UNCHANGED caller loop (micp_localization.cpp:900-964: find once, then per iteration computeCrossStatistics
+            # + the CrossStatistics algebra + umeyama_transform ON THE HOST) through the public C entry points, timed in C: round 4
+            # serves the per-iteration calls from the moments the find published (no launch); with the moment form off every call is a
+            # streaming reduction + a completion wait (round 3's behaviour)
+            ms, Tcl, scl = rcc.time_caller_loop(est, T.identity(), 10, 0.0, iters=50)
+            extras["c3_schedule_R_unchanged_caller_cabi_ms"] = round(ms, 4)
+            extras["c3_schedule_R_unchanged_caller_pose_corrections_per_s"] = round(1e3 / ms, 1)
+            extras["c3_schedule_R_unchanged_caller_served"] = rcc.ccs_info()
+            rcc.set_micp_fast(0)
+            extras["c3_schedule_R_unchanged_caller_streaming_reduce_cabi_ms"] = round(rcc.time_caller_loop(est, T.identity(), 10, 0.0, iters=30)[0], 4)
+            rcc.set_micp_fast(4)
+            rcc.correct_once(est, T.identity(), 10, 0.0, False)
+            extras["c3_schedule_R_device_loop_ms"] = round(rcc.time_correct_once(est, T.identity(), 10, 0.0, False, iters=50), 4)
             # (R) with the moments in a pass of their own (round 3's first form, three launches: A/B of the find's moment epilogue)
             rcc.set_micp_fast(3)
             rcc.correct_once(est, T.identity(), 10, 0.0, False)

@@ -353,6 +353,14 @@ rmclhip_status rmclhip_rcc_time_reduce(rmclhip_rcc* rcc, const rmclhip_transform
 rmclhip_status rmclhip_rcc_time_correct_once(rmclhip_rcc* rcc, const rmclhip_transform* Tom, const rmclhip_transform* Tbo,
                                              uint32_t n_iter, double convergence_progress, int refind_each_iteration,
                                              uint32_t iters, float* ms_per_call);
+/* host-clock time of the reference's UNCHANGED caller loop for one sensor (micp_localization.cpp:900-964: find once, then n_iter x
+ * { computeCrossStatistics, Tsb *, Tbo *, merge, umeyama_transform, compose } on the host) through the public entry points above,
+ * mean over `iters` corrections after two untimed ones; also returns the last T_onew_oold / merged statistics (nullable).  What an
+ * integrator measures who keeps the node's loop instead of calling rmclhip_rcc_correct_once. */
+rmclhip_status rmclhip_rcc_time_caller_loop(rmclhip_rcc* rcc, const rmclhip_transform* Tom, const rmclhip_transform* Tbo,
+                                            uint32_t n_iter, double convergence_progress, uint32_t iters,
+                                            rmclhip_transform* T_onew_oold_out, rmclhip_cross_statistics* merged_out,
+                                            float* ms_per_call);
 /* kernel variant selection: bits 0..3 (+ bit 13 = 16 more) traversal kind.  15 = automatic, the default: four
  * lanes per ray up to 57344 rays in flight (kind 2); above that one lane per ray STARTING AT THE MAP'S FRONTIER (the wave culls
  * the <= 256 references of BFS depth 4 against its tile's pyramid and every ray tests the few survivors: the top levels of
@@ -371,12 +379,14 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* rcc, int variant);
  * pre-transform stays within bounds learnt from the previous corrections are summarised ONCE as 82 moments, the few others
  * are re-evaluated every iteration, and all iterations run in one single-workgroup launch.  When a pre-transform leaves the
  * bounds, or too many correspondences are undecided, the library falls back to one streaming launch per iteration: the
- * result never depends on the bounds (both forms agree to f64 summation order).  mode 0 = never, 1 = automatic (default: TWO plain
- * launches with their per-call data by value -- the find (per-ray kind 23 or quad kind 2: every single scan the rule serves) forms
- * the moments in its epilogue, a 10 x 10 product of factor vectors per correspondence through f64 MFMA, and the loop launch folds
- * the per-workgroup rows; a forced other kind: find, moments pass, loop), 2 = automatic, find + moments pass + loop replayed from a hipGraph
- * behind an H2D copy node (A/B: a graph replay costs the host more than three launches), 3 = automatic, three plain launches
- * (A/B: the moments always in a pass of their own). */
+ * result never depends on the bounds (both forms agree to f64 summation order).  mode 0 = never; 1 = automatic (default): TWO plain
+ * launches -- the find (per-ray kind 23 or quad kind 2: every single scan the rule serves) forms the moments in its epilogue, a
+ * 10 x 10 product of factor vectors per correspondence through f64 MFMA; a fold launch sums the per-workgroup rows and publishes
+ * {82 moments, the undecided correspondences (<= 256)} to the host -- and the ITERATIONS RUN ON THE HOST (~0.5 us each; the same
+ * published set then also answers rmclhip_rcc_compute_cross_statistics without a launch, see rmclhip_ccs_info); more than 256
+ * undecided: the device loop of mode 4 on the same rows.  2 = device loop, find + moments pass + loop replayed from a hipGraph
+ * behind an H2D copy node (A/B); 3 = device loop, three plain launches (A/B: the moments always in a pass of their own); 4 = device
+ * loop behind a find with the moment epilogue (round 3's default, A/B: one lane of the GPU solves every iteration). */
 typedef struct {
   uint32_t attempts, done, cap_exits, overflows;   /* outcomes since the operator was created */
   uint32_t last_code;                              /* 0 done, 1 pre-transform left the bounds, 2 > 4096 undecided */
@@ -384,9 +394,34 @@ typedef struct {
   float last_rho, last_tau;                        /* largest |2 sin(theta/2)| and |t| of its pre-transforms */
   float rho_cap, tau_cap;                          /* bounds the next attempt will use */
   uint32_t last_setup_clocks, last_loop_clocks;    /* diagnostics: shader clocks the single-workgroup launch spent before /
-                                                    * in its iterations (last completed attempt) */
+                                                    * in its iterations (last completed attempt; 0 when the host ran them) */
+  uint32_t host_loops;                             /* attempts whose iterations ran on the host (mode 1) */
 } rmclhip_micp_fast_info;
 rmclhip_status rmclhip_rcc_set_micp_fast(rmclhip_rcc* rcc, int mode);
+/* How rmclhip_rcc_compute_cross_statistics was served since the operator was created.  With the moment form on (mode != 0) a call is
+ * answered ON THE HOST from the 82 moments + the undecided correspondences of the current find whenever a published set covers its
+ * (pre-transform, max_dist'): no launch, no wait (micp_localization.cpp:915-964 calls it once per sensor and iteration on fixed
+ * correspondences).  The set comes from the find itself when the previous find was followed by such calls (`speculative_finds`:
+ * moment epilogue + publish, classified for max_dist' within +-8 % of the last one), else from ONE moment pass the first call
+ * after a find pays (`passes`); everything else takes the streaming reduction (calls - from_moments). */
+typedef struct {
+  uint32_t calls;              /* computeCrossStatistics calls that were eligible (moment form on) */
+  uint32_t from_moments;       /* ... answered on the host without a launch */
+  uint32_t passes;             /* moment passes run by a call (no covering set yet) */
+  uint32_t speculative_finds;  /* finds that formed the moments in their epilogue */
+} rmclhip_ccs_info;
+rmclhip_status rmclhip_rcc_ccs_info(const rmclhip_rcc* rcc, rmclhip_ccs_info* out);
+/* The host half of the moment form on its own (no device): classifies the n correspondences (D = dataset point, I = model point,
+ * N = model normal, valid nullable) for every max_dist' in [gate_lo, gate_hi] and every pre-transform within (rho_cap = |2 sin
+ * theta/2|, tau_cap = |t|), accumulates the 82 moments of the certainly-gated-in ones, keeps the undecided ones (<= 256), and
+ * evaluates rm::statistics_p2l(Tpre, ..., max_dist) from them.  *covered = 0 (and Identity statistics) when (Tpre, max_dist) lies
+ * outside what the set was formed for or more than 256 correspondences are undecided: the library then uses the streaming
+ * reduction.  What the device publishes per find is this set; the entry point exists so that the arithmetic can be checked
+ * against the reference's per-element loop (MICPSensorCPU.cpp:70-84) without a GPU. */
+rmclhip_status rmclhip_host_moment_statistics(const float* dataset_points, const float* model_points, const float* model_normals,
+                                              const uint8_t* valid, uint32_t n, float gate_lo, float gate_hi, float rho_cap,
+                                              float tau_cap, const rmclhip_transform* Tpre, float max_dist,
+                                              rmclhip_cross_statistics* out, uint32_t* n_undecided, int* covered);
 rmclhip_status rmclhip_rcc_micp_fast_info(const rmclhip_rcc* rcc, rmclhip_micp_fast_info* out);
 /* the traversal (bits 0..3 above, never 15) a find of `nposes` scans of the current model would launch */
 rmclhip_status rmclhip_rcc_find_variant(const rmclhip_rcc* rcc, uint32_t nposes, int* variant_out);

@@ -50,7 +50,12 @@ class PFParams(C.Structure):
 class MicpFastInfo(C.Structure):
     _fields_ = [("attempts", C.c_uint32), ("done", C.c_uint32), ("cap_exits", C.c_uint32), ("overflows", C.c_uint32),
                 ("last_code", C.c_uint32), ("last_uncertain", C.c_uint32), ("last_rho", C.c_float), ("last_tau", C.c_float),
-                ("rho_cap", C.c_float), ("tau_cap", C.c_float), ("last_setup_clocks", C.c_uint32), ("last_loop_clocks", C.c_uint32)]
+                ("rho_cap", C.c_float), ("tau_cap", C.c_float), ("last_setup_clocks", C.c_uint32), ("last_loop_clocks", C.c_uint32),
+                ("host_loops", C.c_uint32)]
+
+
+class CcsInfo(C.Structure):
+    _fields_ = [("calls", C.c_uint32), ("from_moments", C.c_uint32), ("passes", C.c_uint32), ("speculative_finds", C.c_uint32)]
 
 
 class PointCloud2Layout(C.Structure):
@@ -145,10 +150,14 @@ SIGNATURES = {
     "rmclhip_rcc_autotune_batch": (_i32, [_vp, _vp, _u32, C.POINTER(_i32), C.POINTER(_f32)]),
     "rmclhip_rcc_time_reduce": (_i32, [_vp, _vp, _u32, C.POINTER(_f32)]),
     "rmclhip_rcc_time_correct_once": (_i32, [_vp, _vp, _vp, _u32, _dbl, _i32, _u32, C.POINTER(_f32)]),
+    "rmclhip_rcc_time_caller_loop": (_i32, [_vp, _vp, _vp, _u32, _dbl, _u32, _vp, _vp, C.POINTER(_f32)]),
     "rmclhip_rcc_set_variant": (_i32, [_vp, _i32]),
     "rmclhip_rcc_find_variant": (_i32, [_vp, _u32, C.POINTER(_i32)]),
     "rmclhip_rcc_set_micp_fast": (_i32, [_vp, _i32]),
     "rmclhip_rcc_micp_fast_info": (_i32, [_vp, C.POINTER(MicpFastInfo)]),
+    "rmclhip_rcc_ccs_info": (_i32, [_vp, C.POINTER(CcsInfo)]),
+    "rmclhip_host_moment_statistics": (_i32, [_vp, _vp, _vp, _vp, _u32, _f32, _f32, _f32, _f32, _vp, _f32, _vp, C.POINTER(_u32),
+                                               C.POINTER(_i32)]),
     "rmclhip_debug_wave_clock": (_i32, [_vp, _vp, _vp, _sz, C.POINTER(_u32)]),
     "rmclhip_debug_micp_moments": (_i32, [_vp, _vp, C.POINTER(_u32), C.POINTER(C.c_uint64)]),
     "rmclhip_debug_probe_find": (_i32, [_vp, _vp, _i32, _vp, _sz, C.POINTER(_u32)]),

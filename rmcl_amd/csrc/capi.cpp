@@ -204,7 +204,7 @@ struct rmclhip_rcc {
   bool fused_tail = false;         // true: last-block tail inside the reduction kernel (measured slower, A/B only)
   // moment form of the schedule-(R) loop (launch_micp_fast): tried first when the previous corrections say the gate
   // decisions are stable; the per-iteration form above is the fallback and the reference for the result
-  int fast_mode = 1;               // 0 off, 1 automatic (direct launches), 2 automatic through a hipGraph (A/B)
+  int fast_mode = 1;               // rmclhip_rcc_set_micp_fast: 0 off, 1 automatic with the iterations on the host (default), 2 / 3 / 4 device loops (A/B)
   DevBuf<double> d_fast_partials;
   DevBuf<unsigned long long> d_fast_mask;
   double* d_fold_rows = nullptr;      // hand-over area of the loop launch's folding workgroups (kernels.h: kMicpFoldBlocks)
@@ -230,6 +230,21 @@ struct rmclhip_rcc {
   uint32_t fast_holdoff = 0;       // corrections to skip the attempt for (after repeated overflows)
   uint32_t fast_overflows = 0;     // consecutive
   rmclhip_micp_fast_info fast_info = {};
+  // Round 4 -- iterations on the host (micp_host.h): what k_micp_publish hands over, and the host's verified copy of it
+  MicpHostBlock* h_mom = nullptr;      // pinned, host-mapped
+  MicpHostBlock* h_mom_dev = nullptr;
+  MicpMomentSet mset;                  // valid for the model buffers + dataset it was formed from; dropped by whatever changes either
+  bool mset_pending = false;           // a publish is in flight on the stream (speculating find): its tag carries mset_seq
+  uint32_t mset_seq = 0;
+  float pend_lo = 0.f, pend_hi = 0.f, pend_rho = 0.f, pend_tau = 0.f;   // band and caps the in-flight set is formed for
+  uint32_t mset_passes = 0;            // moment passes computeCrossStatistics ran since the last find (at most 2)
+  MicpFastStatus last_fast = {};       // outcome of the last moment-form attempt, whichever side ran the iterations
+  // the reference's unchanged caller loop (micp_localization.cpp:900-964): find(), then computeCrossStatistics() per iteration
+  uint32_t ccs_since_find = 0;         // computeCrossStatistics calls since the last find
+  bool ccs_loop = false;               // the last find was followed by such calls: the next find forms the moments in its epilogue
+  float ccs_last_maxd = 0.f;           // max_dist' of the last call (the band of the next speculation is centred on it)
+  float ccs_max_rho = 0.f, ccs_max_tau = 0.f;   // largest pre-transform since the last find
+  rmclhip_ccs_info ccs_info = {};
   // N-sensor loop (rmclhip_micp_correct_once): call block + state of the first sensor, kept between calls
   DevBuf<uint8_t> d_multi_blob;
   MicpMultiState* h_multi_state = nullptr;          // pinned, host-mapped
@@ -255,7 +270,15 @@ struct rmclhip_rcc {
   bool tile_planes_ok = false;
   float last_find_ms = 0.f, last_reduce_ms = 0.f;
   bool reduce_timing_pending = false;
+  bool find_timing_pending = false;   // a speculating find returned on its tag: ev0 / ev1 still hold its timing
 };
+
+// whatever is about to rewrite the model buffers or the dataset: the published moments summarise the old ones
+static inline void drop_moment_set(rmclhip_rcc* r) {
+  r->mset.valid = false;
+  r->mset_pending = false;
+  r->mset_passes = 0;
+}
 
 struct rmclhip_pf {
   rmclhip_ctx* ctx = nullptr;
@@ -660,6 +683,9 @@ rmclhip_status rmclhip_rcc_create(rmclhip_ctx* ctx, rmclhip_map* map, rmclhip_rc
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_done), 2 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&r->h_done_dev), r->h_done, 0);
   if (e == hipSuccess) r->h_done[0] = r->h_done[1] = 0ull;
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_mom), sizeof(MicpHostBlock), hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&r->h_mom_dev), r->h_mom, 0);
+  if (e == hipSuccess) std::memset(r->h_mom, 0, sizeof(MicpHostBlock));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->d_counter), sizeof(uint32_t));
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_call), sizeof(MicpCall), hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->d_call), sizeof(MicpCall));
@@ -699,6 +725,7 @@ void rmclhip_rcc_destroy(rmclhip_rcc* r) {
   if (r->micp_fast_graph) DBG_STEP(hipGraphDestroy(r->micp_fast_graph));
   if (r->h_fast_status) DBG_STEP(hipHostFree(r->h_fast_status));
   if (r->h_done) DBG_STEP(hipHostFree(r->h_done));
+  if (r->h_mom) DBG_STEP(hipHostFree(r->h_mom));
   r->d_cpc_rec.release();
   r->d_fast_partials.release(); r->d_fast_mask.release(); r->d_tile_planes.release();
   if (r->d_fold_rows) DBG_STEP(hipFree(r->d_fold_rows));
@@ -826,6 +853,7 @@ rmclhip_status rmclhip_rcc_set_params(rmclhip_rcc* r, float max_dist, float adap
 rmclhip_status rmclhip_rcc_set_dataset(rmclhip_rcc* r, const float* pts, const uint8_t* mask, uint32_t n,
                                        int src_is_device) {
   ApiGuard guard_("rmclhip_rcc_set_dataset");
+  if (r) drop_moment_set(r);
   if (!r || (!pts && n > 0)) return fail(RMCLHIP_ERR_INVALID, "rcc_set_dataset: null");
   HIPCHK(hipSetDevice(r->ctx->device));
   HIPCHK(hipStreamSynchronize(r->stream));
@@ -847,6 +875,7 @@ rmclhip_status rmclhip_rcc_set_dataset(rmclhip_rcc* r, const float* pts, const u
 
 rmclhip_status rmclhip_rcc_set_dataset_view(rmclhip_rcc* r, const float* pts_dev, const uint8_t* mask_dev, uint32_t n) {
   ApiGuard guard_("rmclhip_rcc_set_dataset_view");
+  if (r) drop_moment_set(r);
   if (!r || (!pts_dev && n > 0)) return fail(RMCLHIP_ERR_INVALID, "rcc_set_dataset_view: null");
   HIPCHK(hipSetDevice(r->ctx->device));
   HIPCHK(hipStreamSynchronize(r->stream));
@@ -861,6 +890,7 @@ rmclhip_status rmclhip_rcc_set_dataset_view(rmclhip_rcc* r, const float* pts_dev
 rmclhip_status rmclhip_rcc_set_dataset_from_ranges(rmclhip_rcc* r, const float* ranges, uint32_t n,
                                                    uint32_t* n_valid_out) {
   ApiGuard guard_("rmclhip_rcc_set_dataset_from_ranges");
+  if (r) drop_moment_set(r);
   if (!r || !ranges) return fail(RMCLHIP_ERR_INVALID, "rcc_set_dataset_from_ranges: null");
   if (r->kind == kModelNone) return fail(RMCLHIP_ERR_INVALID, "rcc_set_dataset_from_ranges: no sensor model set");
   if (n != r->W * r->H) return fail(RMCLHIP_ERR_INVALID, "rcc_set_dataset_from_ranges: n != model size");
@@ -897,6 +927,7 @@ rmclhip_status rmclhip_rcc_set_input_pointcloud2(rmclhip_rcc* r, const uint8_t* 
                                                  const rmclhip_filter1d* fw, rmclhip_interval range, int src_is_device,
                                                  uint32_t* out_width, uint32_t* out_height, uint32_t* n_valid_out) {
   ApiGuard guard_("rmclhip_rcc_set_input_pointcloud2");
+  if (r) drop_moment_set(r);
   if (!r || !L) return fail(RMCLHIP_ERR_INVALID, "rcc_set_input_pointcloud2: null");
   if (L->datatype != 7u && L->datatype != 8u)
     return fail(RMCLHIP_ERR_UNSUPPORTED, "rcc_set_input_pointcloud2: Field X has unknown DataType (FLOAT32 / FLOAT64 only)");
@@ -969,6 +1000,7 @@ static uint32_t pick_tile_w_log2(uint32_t H, bool packet) {
 }
 
 static rmclhip_status ensure_model_buffers(rmclhip_rcc* r, size_t n_total) {
+  drop_moment_set(r);   // every find form comes through here first
   HIPCHK(r->d_hits.reserve(n_total));
   HIPCHK(r->d_ranges.reserve(n_total));
   HIPCHK(r->d_points.reserve(3 * n_total));
@@ -1056,11 +1088,40 @@ static rmclhip_status rebuild_tile_planes(rmclhip_rcc* r, bool keep_tuning) {
   return RMCLHIP_OK;
 }
 
-static rmclhip_status find_enqueue(rmclhip_rcc* r, const xform& Tbm) {
+static rmclhip_status enqueue_find_with_moments(rmclhip_rcc* r, const xform& Tsm, float lo, float hi, float rho_cap, float tau_cap, uint32_t seq,
+                                                bool epilogue_allowed);
+static inline void learn_caps(rmclhip_rcc* r, float max_rho, float max_tau);
+static inline void gate_band(const rmclhip_rcc* r, float centre, float* lo, float* hi);
+static inline uint32_t next_seq(rmclhip_rcc* r);
+static hipError_t wait_moments(rmclhip_rcc* r, uint32_t seq, float lo, float hi, float rho_cap, float tau_cap);
+
+// `speculate` (out, nullable): set when the find was enqueued WITH the moment epilogue + publish for the computeCrossStatistics calls
+// that will follow it (r->mset_pending, r->mset_seq, r->pend_*): the reference's caller loop (micp_localization.cpp:900-964)
+// alternates find() and n x computeCrossStatistics(), so a find that was followed by such calls expects them again.
+static rmclhip_status find_enqueue(rmclhip_rcc* r, const xform& Tbm, bool* speculate = nullptr) {
   const size_t n = static_cast<size_t>(r->W) * r->H;
   r->n_model = static_cast<uint32_t>(n);
   r->nposes_last = 1;
   if (rmclhip_status st = ensure_model_buffers(r, n)) return st;
+  if (speculate) {
+    *speculate = false;
+    // what the last loop met bounds what this one may meet
+    if (r->ccs_since_find != 0u) learn_caps(r, r->ccs_max_rho, r->ccs_max_tau);
+    r->ccs_loop = r->ccs_since_find != 0u;
+    r->ccs_since_find = 0u; r->ccs_max_rho = 0.f; r->ccs_max_tau = 0.f;
+    const int fv = find_variant(r, 1);
+    if (r->ccs_loop && r->fast_mode == 1 && !r->fused_tail && r->n_dataset != 0u && (fv == 23 || fv == 2) && r->ccs_last_maxd == r->ccs_last_maxd) {
+      gate_band(r, r->ccs_last_maxd, &r->pend_lo, &r->pend_hi);
+      r->pend_rho = r->fast_rho_cap; r->pend_tau = r->fast_tau_cap;
+      r->mset_seq = next_seq(r);
+      if (rmclhip_status st = enqueue_find_with_moments(r, xmul(Tbm, r->Tsb), r->pend_lo, r->pend_hi, r->pend_rho, r->pend_tau, r->mset_seq, true))
+        return st;
+      r->mset_pending = true;
+      ++r->ccs_info.speculative_finds;
+      *speculate = true;
+      return RMCLHIP_OK;
+    }
+  }
   FindParams p;
   fill_find_params(r, p, 1);
   p.Tsm = xmul(Tbm, r->Tsb);
@@ -1076,7 +1137,8 @@ rmclhip_status rmclhip_rcc_find_async(rmclhip_rcc* r, const rmclhip_transform* T
   // RCCOptix.cpp:30-34: nothing to do for an empty model
   if (r->kind == kModelNone || r->W == 0 || r->H == 0) return RMCLHIP_OK;
   HIPCHK(hipSetDevice(r->ctx->device));
-  return find_enqueue(r, to_x(Tbm_est));
+  bool spec = false;
+  return find_enqueue(r, to_x(Tbm_est), &spec);   // (a speculating find's publish is awaited by the first computeCrossStatistics)
 }
 
 // Wait for a handle's stream the way the context's wait mode says (rmclhip_ctx_set_wait_mode): SPIN polls hipStreamQuery, then one
@@ -1106,10 +1168,19 @@ rmclhip_status rmclhip_rcc_find(rmclhip_rcc* r, const rmclhip_transform* Tbm_est
   HIPCHK(hipSetDevice(r->ctx->device));
   r->reduce_timing_pending = false;   // the events are reused below
   HIPCHK(hipEventRecord(r->ev0, r->stream));
-  if (rmclhip_status st = find_enqueue(r, to_x(Tbm_est))) return st;
+  bool spec = false;
+  if (rmclhip_status st = find_enqueue(r, to_x(Tbm_est), &spec)) return st;
   HIPCHK(hipEventRecord(r->ev1, r->stream));
+  if (spec) {
+    // the publish launch's tag says the find before it on this stream is complete as well -- and reaches the host sooner than the
+    // stream's own completion does (see wait_done); the events are read when rmclhip_rcc_last_kernel_ms asks for them
+    HIPCHK(wait_moments(r, r->mset_seq, r->pend_lo, r->pend_hi, r->pend_rho, r->pend_tau));
+    r->find_timing_pending = true;
+    return RMCLHIP_OK;
+  }
   HIPCHK(stream_wait(r->ctx, r->stream));
   HIPCHK(hipEventElapsedTime(&r->last_find_ms, r->ev0, r->ev1));
+  r->find_timing_pending = false;
   return RMCLHIP_OK;
 }
 
@@ -1288,17 +1359,161 @@ static float adaptive_max_dist(const rmclhip_rcc* r, double p) {
                             static_cast<double>(r->adaptive_max_dist_min) * p);
 }
 
+// ---- the gate-stable moments on the host (micp_host.h; kernels.hip k_micp_publish) -----------------------------------------------
+// The band of max_dist' values a speculating find classifies for: max_dist' = max_dist (1 - p) + adaptive_max_dist_min p moves with
+// the node's convergence_progress_ from one correction to the next (micp_localization.cpp:988-1007), the find does not know the
+// next value, so it takes +-8 % around the last one, clipped to what the two parameters allow.  A max_dist' outside the band
+// costs the first computeCrossStatistics of that correction one moment pass of its own (what every call cost before round 4).
+static inline void gate_band(const rmclhip_rcc* r, float centre, float* lo, float* hi) {
+  const float a = std::min(r->max_dist, r->adaptive_max_dist_min), b = std::max(r->max_dist, r->adaptive_max_dist_min);
+  *lo = std::max(a, 0.92f * centre);
+  *hi = std::min(b, 1.08f * centre);
+  if (!(*lo <= centre)) *lo = centre;   // (centre outside [a, b]: parameters changed since; also NaN-safe)
+  if (!(*hi >= centre)) *hi = centre;
+}
+
+// wait for the tag of a publish launch and take a verified copy of the block (see wait_done for why the sum is checked)
+static hipError_t wait_moments(rmclhip_rcc* r, uint32_t seq, float lo, float hi, float rho_cap, float tau_cap) {
+  const MicpHostBlock* hb = r->h_mom;
+  auto block_sum = [hb]() -> uint32_t {
+    uint32_t x = xor_host(hb->mom, sizeof(hb->mom));
+    const uint32_t code = *reinterpret_cast<const volatile uint32_t*>(&hb->code);
+    const uint32_t n = *reinterpret_cast<const volatile uint32_t*>(&hb->n_uncertain);
+    x ^= code ^ n;
+    if (code == 0u && n <= kMicpHostMaxUnc) x ^= xor_host(hb->unc, static_cast<size_t>(n) * 9u * sizeof(float));
+    return x;
+  };
+  hipError_t e = hipSuccess;
+  if (r->ctx->wait_block.load(std::memory_order_relaxed)) e = hipStreamSynchronize(r->stream);
+  else {
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+    volatile const unsigned long long* tag = r->h_done;
+    for (uint32_t spins = 0;; ++spins) {
+      const unsigned long long t = *tag;
+      if (static_cast<uint32_t>(t) == seq) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (block_sum() == static_cast<uint32_t>(t >> 32)) break;
+      }
+#if defined(__x86_64__) || defined(__i386__)
+      __builtin_ia32_pause();
+#endif
+      if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() > t_end) { e = hipStreamSynchronize(r->stream); break; }
+    }
+  }
+  r->mset_pending = false;
+  if (e != hipSuccess) { r->mset.valid = false; return e; }
+  MicpMomentSet& ms = r->mset;
+  std::memcpy(ms.mom, hb->mom, sizeof(ms.mom));
+  ms.gate_lo = lo; ms.gate_hi = hi; ms.rho_cap = rho_cap; ms.tau_cap = tau_cap;
+  ms.n_unc = hb->n_uncertain;
+  ms.valid = (hb->code == 0u && ms.n_unc <= kMicpHostMaxUnc);
+  if (ms.valid && ms.n_unc) std::memcpy(ms.unc, hb->unc, static_cast<size_t>(ms.n_unc) * 9u * sizeof(float));
+  return hipSuccess;
+}
+
+// caps of the next moment set from the pre-transforms the last loop met (as rmclhip_rcc_correct_once learns them)
+static inline void learn_caps(rmclhip_rcc* r, float max_rho, float max_tau) {
+  r->fast_rho_cap = std::max(0.002f, std::max(2.0f * max_rho, 0.9f * r->fast_rho_cap));
+  r->fast_tau_cap = std::max(0.005f, std::max(2.0f * max_tau, 0.9f * r->fast_tau_cap));
+  r->fast_info.rho_cap = r->fast_rho_cap;
+  r->fast_info.tau_cap = r->fast_tau_cap;
+}
+
+// find + moment epilogue + publish on the handle's stream (kinds 23 / 2), or find + moment pass + publish (any other kind);
+// the caller waits with wait_moments(seq, ...)
+static rmclhip_status enqueue_find_with_moments(rmclhip_rcc* r, const xform& Tsm, float lo, float hi, float rho_cap, float tau_cap, uint32_t seq,
+                                                bool epilogue_allowed) {
+  const uint32_t nred = (r->n_dataset < r->n_model) ? r->n_dataset : r->n_model;
+  FindParams fp;
+  fill_find_params(r, fp, 1);
+  fp.Tsm = Tsm;
+  fp.Tms = xinv(Tsm);
+  const int fv = find_variant(r, 1);
+  if (epilogue_allowed && (fv == 23 || fv == 2)) {
+    const uint32_t nb = find_moments_blocks(fp, fv), wpb = (fv == 2) ? 1u : 4u;   // mask words per workgroup
+    HIPCHK(r->d_fast_partials.reserve(static_cast<size_t>(nb) * kMicpFastMoments));
+    HIPCHK(r->d_fast_mask.reserve(static_cast<size_t>(nb) * wpb));
+    fp.mom_dataset_points = r->ds_pts;
+    fp.mom_dataset_mask = r->ds_has_mask ? r->ds_msk : nullptr;
+    fp.mom_n = nred;
+    fp.mom_gate_lo = lo; fp.mom_gate_hi = hi; fp.mom_rho_cap = rho_cap; fp.mom_tau_cap = tau_cap;
+    fp.mom_partials = r->d_fast_partials.p;
+    fp.mom_unc_mask = r->d_fast_mask.p;
+    if (!r->d_fold_rows) {
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&r->d_fold_rows), kMicpFoldBlocks * kMicpFastMoments * sizeof(double) + kMicpFoldBlocks * sizeof(uint32_t)));
+      HIPCHK(hipMemset(r->d_fold_rows, 0, kMicpFoldBlocks * kMicpFastMoments * sizeof(double) + kMicpFoldBlocks * sizeof(uint32_t)));
+      HIPCHK(hipDeviceSynchronize());
+      r->d_fold_flags = reinterpret_cast<uint32_t*>(r->d_fold_rows + kMicpFoldBlocks * kMicpFastMoments);
+    }
+    r->last_fast_rows = nb; r->last_fast_words = wpb * nb;
+    HIPCHK(launch_find_moments(fp, r->kind, fv, r->stream));
+    HIPCHK(launch_micp_publish_tiled(r->ds_pts, r->d_points.p, r->d_normals.p, nred, nb, r->d_fast_partials.p, r->d_fast_mask.p, r->W,
+                                     fp.tiles_x, fp.tile_w_log2, wpb, r->h_mom_dev, r->h_done_dev, seq, r->d_fold_rows, r->d_fold_flags,
+                                     r->stream));
+  } else {
+    HIPCHK(r->d_fast_partials.reserve(static_cast<size_t>(micp_fast_blocks(nred)) * kMicpFastMoments));
+    HIPCHK(r->d_fast_mask.reserve((static_cast<size_t>(nred) + 63u) / 64u));
+    r->last_fast_rows = micp_fast_blocks(nred); r->last_fast_words = (nred + 63u) / 64u;
+    MicpCallLite cl{};
+    cl.gate_lo = lo; cl.gate_hi = hi; cl.max_dist = hi; cl.rho_cap = rho_cap; cl.tau_cap = tau_cap; cl.seq = seq;
+    HIPCHK(launch_find(fp, r->kind, fv, r->stream));
+    HIPCHK(launch_micp_moments_publish(r->ds_pts, r->ds_has_mask ? r->ds_msk : nullptr, r->d_points.p, r->d_normals.p, r->d_hits.p, nred,
+                                       r->d_fast_partials.p, r->d_fast_mask.p, cl, r->h_mom_dev, r->h_done_dev, r->stream));
+  }
+  return RMCLHIP_OK;
+}
+
 rmclhip_status rmclhip_rcc_compute_cross_statistics(rmclhip_rcc* r, const rmclhip_transform* T_snew_sold,
                                                     double convergence_progress, rmclhip_cross_statistics* out) {
   ApiGuard guard_("rmclhip_rcc_compute_cross_statistics");
   if (!r || !T_snew_sold || !out) return fail(RMCLHIP_ERR_INVALID, "computeCrossStatistics: null");
   HIPCHK(hipSetDevice(r->ctx->device));
   if (r->nposes_last != 1) return fail(RMCLHIP_ERR_INVALID, "computeCrossStatistics: last find was a batch");
+  // ---- from the moments of this find's correspondences, when a set covers (pre-transform, max_dist'): no launch, no wait.
+  // The reference's caller (micp_localization.cpp:915-964) calls this once per sensor and iteration on FIXED correspondences.
+  {
+    const xform Tpre = to_x(T_snew_sold);
+    const float maxd = adaptive_max_dist(r, convergence_progress);
+    const float rho = micp_rho(Tpre), tau = micp_tau(Tpre);
+    ++r->ccs_since_find;
+    r->ccs_last_maxd = maxd;
+    r->ccs_max_rho = std::max(r->ccs_max_rho, rho);
+    r->ccs_max_tau = std::max(r->ccs_max_tau, tau);
+    const uint32_t nred = (r->n_dataset < r->n_model) ? r->n_dataset : r->n_model;
+    if (r->fast_mode != 0 && !r->fused_tail && nred != 0 && maxd == maxd) {
+      ++r->ccs_info.calls;
+      if (r->mset_pending) HIPCHK(wait_moments(r, r->mset_seq, r->pend_lo, r->pend_hi, r->pend_rho, r->pend_tau));
+      if (!micp_set_covers(r->mset, Tpre, maxd) && r->mset_passes < 2u && rho == rho && tau == tau) {
+        // no covering set (the find did not speculate, or max_dist' / the pre-transform left what it speculated for): ONE moment
+        // pass over the find's outputs now -- costs what the streaming reduction below costs -- serves the rest of the loop
+        ++r->mset_passes;
+        ++r->ccs_info.passes;
+        float lo, hi;
+        gate_band(r, maxd, &lo, &hi);
+        const float rho_cap = std::max(r->fast_rho_cap, 2.0f * rho), tau_cap = std::max(r->fast_tau_cap, 2.0f * tau);
+        HIPCHK(r->d_fast_partials.reserve(static_cast<size_t>(micp_fast_blocks(nred)) * kMicpFastMoments));
+        HIPCHK(r->d_fast_mask.reserve((static_cast<size_t>(nred) + 63u) / 64u));
+        r->last_fast_rows = micp_fast_blocks(nred); r->last_fast_words = (nred + 63u) / 64u;
+        MicpCallLite cl{};
+        cl.gate_lo = lo; cl.gate_hi = hi; cl.max_dist = maxd; cl.rho_cap = rho_cap; cl.tau_cap = tau_cap; cl.seq = next_seq(r);
+        HIPCHK(launch_micp_moments_publish(r->ds_pts, r->ds_has_mask ? r->ds_msk : nullptr, r->d_points.p, r->d_normals.p, r->d_hits.p, nred,
+                                           r->d_fast_partials.p, r->d_fast_mask.p, cl, r->h_mom_dev, r->h_done_dev, r->stream));
+        HIPCHK(wait_moments(r, cl.seq, lo, hi, rho_cap, tau_cap));
+        if (!r->mset.valid) r->mset_passes = 2u;   // too many undecided correspondences: a second pass would find as many
+      }
+      if (micp_set_covers(r->mset, Tpre, maxd)) {
+        ++r->ccs_info.from_moments;
+        from_cs(micp_statistics_from_set(r->mset, Tpre, maxd), out);
+        return RMCLHIP_OK;
+      }
+    }
+  }
   ReduceTail tail;
   tail.mode = kTailStats;
   tail.stats_out = r->h_stats_dev;  // host-mapped: the finalize launch writes the 64-B result straight to the host
   const bool polled = !r->fused_tail;
   if (polled) { tail.done = r->h_done_dev; tail.seq = next_seq(r); }
+  r->find_timing_pending = false;   // the events are reused
   HIPCHK(hipEventRecord(r->ev0, r->stream));
   if (rmclhip_status st = reduce_enqueue(r, to_x(T_snew_sold), nullptr, adaptive_max_dist(r, convergence_progress), 1, tail))
     return st;
@@ -1385,6 +1600,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
     r->h_call->Tsb = r->Tsb;
     r->h_call->Tbo = Tbo;
     r->h_call->max_dist = maxd;
+    r->h_call->gate_lo = maxd; r->h_call->gate_hi = maxd;
     r->h_call->rho_cap = r->fast_rho_cap;
     r->h_call->tau_cap = r->fast_tau_cap;
     r->h_call->seq = next_seq(r);
@@ -1404,28 +1620,73 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
       key.fused = 0; key.has_mask = r->ds_has_mask ? 1 : 0;
       key.ptrs[0] = r->d_points.p; key.ptrs[1] = r->ds_pts; key.ptrs[2] = r->d_fast_partials.p;
       key.ptrs[3] = r->d_model_tab.p; key.ptrs[4] = r->ds_msk; key.ptrs[5] = r->d_fast_mask.p;
-      if (!r->use_graph || r->fast_mode == 1 || r->fast_mode == 3) {
-        // direct launches (the default form; fast_mode 2 replays the same chain from a hipGraph, A/B): three kernels with their per-call data BY VALUE -- no H2D copy node, no graph launch (a graph
-        // replay costs the host 10-16 us whatever it holds; three plain launches overlap with the kernels they start)
+      MicpFastStatus fs{};
+      bool fs_ready = false;     // the host ran the iterations: `fs` (and r->h_state) are final, nothing to wait for
+      if (!r->use_graph || r->fast_mode != 2) {
+        // direct launches (fast_mode 2 replays find + moment pass + device loop from a hipGraph, A/B) with their per-call data BY VALUE --
+        // no H2D copy node, no graph launch (a graph replay costs the host 10-16 us whatever it holds)
         FindParams fp;
         fill_find_params(r, fp, 1);
         fp.Tsm = r->h_call->Tsm;
         fp.Tms = r->h_call->Tms;
         MicpCallLite cl;
         cl.Tsb = r->Tsb; cl.Tbo = Tbo; cl.max_dist = maxd; cl.rho_cap = r->fast_rho_cap; cl.tau_cap = r->fast_tau_cap;
+        cl.gate_lo = maxd; cl.gate_hi = maxd;
         cl.seq = r->h_call->seq;
         const int fv = find_variant(r, 1);
-        if (r->fast_mode != 3 && (fv == 23 || fv == 2)) {
-          // TWO kernels: the find forms the moments in its epilogue (find_kernel.hip.h: the 10 x 10 factor products of its 64
-          // correspondences per wave through f64 MFMA), one partial row per workgroup; the second pass over the find's outputs is gone
-          // (fast_mode 3 keeps it for A/B; the other traversal kinds have no moment epilogue)
-          const uint32_t nb = find_moments_blocks(fp, fv), wpb = (fv == 2) ? 1u : 4u;   // mask words per workgroup
+        const bool tiled = r->fast_mode != 3 && (fv == 23 || fv == 2);   // the find forms the moments in its epilogue
+        const uint32_t nb = tiled ? find_moments_blocks(fp, fv) : micp_fast_blocks(nred), wpb = (fv == 2) ? 1u : 4u;
+        bool device_loop = r->fast_mode != 1;
+        if (r->fast_mode == 1) {
+          // ---- round 4 default: TWO launches (find with the moment epilogue; fold + publish), the iterations on the HOST from the 82
+          // moments + the undecided correspondences (micp_host.h): ~0.5 us per iteration instead of ~2.7 us of one lane's f64 chain
+          if (rmclhip_status st = enqueue_find_with_moments(r, r->h_call->Tsm, maxd, maxd, r->fast_rho_cap, r->fast_tau_cap, cl.seq, true)) return st;
+          HIPCHK(wait_moments(r, cl.seq, maxd, maxd, r->fast_rho_cap, r->fast_tau_cap));
+          if (r->mset.valid) {
+            xform T_s = xidentity();
+            cstats last = cs_identity();
+            fs.code = 0u; fs.n_uncertain = r->mset.n_unc;
+            for (uint32_t it = 0; it < n_iter; ++it) {
+              const float rho = micp_rho(T_s), tau = micp_tau(T_s);
+              fs.max_rho = std::max(fs.max_rho, rho);
+              fs.max_tau = std::max(fs.max_tau, tau);
+              if (!(rho <= r->mset.rho_cap) || !(tau <= r->mset.tau_cap)) { fs.code = 1u; fs.iter = it; break; }
+              last = micp_statistics_from_set(r->mset, T_s, maxd);
+              T_s = xmul(T_s, umeyama(last));   // kernels.hip micp_advance_sensor
+            }
+            if (fs.code == 0u) {
+              // kernels.hip micp_close_sensor
+              fs.iter = n_iter;
+              const xform Tso = xmul(Tbo, r->Tsb);
+              r->h_state->T_snew_sold = T_s;
+              r->h_state->T_onew_oold = xmul(xmul(Tso, T_s), xinv(Tso));
+              r->h_state->stats_o = cs_merge(cs_identity(), cs_transform(Tbo, cs_transform(r->Tsb, last)));
+            }
+            fs_ready = true;
+          } else {
+            // more undecided correspondences than the host takes: the device loop on the rows the find left (a sequence number of its own:
+            // the publish launch used this one for its hand-over flags and its tag)
+            device_loop = true;
+            cl.seq = r->h_call->seq = next_seq(r);
+            if (tiled)
+              HIPCHK(launch_micp_fast_loop_tiled(r->ds_pts, r->ds_has_mask ? r->ds_msk : nullptr, r->d_points.p, r->d_normals.p, r->d_hits.p,
+                                                 nred, nb, r->d_fast_partials.p, r->d_fast_mask.p, r->W, fp.tiles_x, fp.tile_w_log2, wpb, n_iter,
+                                                 r->h_state_dev, r->h_fast_status_dev, r->h_done_dev, r->stream, cl, r->d_fold_rows, r->d_fold_flags));
+            else
+              HIPCHK(launch_micp_fast(r->ds_pts, r->ds_has_mask ? r->ds_msk : nullptr, r->d_points.p, r->d_normals.p, r->d_hits.p, nred,
+                                      nullptr, r->d_fast_partials.p, r->d_fast_mask.p, n_iter, r->h_state_dev, r->h_fast_status_dev,
+                                      r->h_done_dev, r->stream, &cl));
+          }
+        } else if (tiled) {
+          // (fast_mode 4, round 3's default) TWO kernels: the find forms the moments in its epilogue (find_kernel.hip.h: the 10 x 10 factor
+          // products of its 64 correspondences per wave through f64 MFMA), one partial row per workgroup; the loop launch folds them and runs
+          // every iteration on the device
           HIPCHK(r->d_fast_partials.reserve(static_cast<size_t>(nb) * kMicpFastMoments));
           HIPCHK(r->d_fast_mask.reserve(static_cast<size_t>(nb) * wpb));
           fp.mom_dataset_points = r->ds_pts;
           fp.mom_dataset_mask = r->ds_has_mask ? r->ds_msk : nullptr;
           fp.mom_n = nred;
-          fp.mom_max_dist = maxd; fp.mom_rho_cap = r->fast_rho_cap; fp.mom_tau_cap = r->fast_tau_cap;
+          fp.mom_gate_lo = maxd; fp.mom_gate_hi = maxd; fp.mom_rho_cap = r->fast_rho_cap; fp.mom_tau_cap = r->fast_tau_cap;
           fp.mom_partials = r->d_fast_partials.p;
           fp.mom_unc_mask = r->d_fast_mask.p;
           if (!r->d_fold_rows) {
@@ -1446,6 +1707,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
                                   nullptr, r->d_fast_partials.p, r->d_fast_mask.p, n_iter, r->h_state_dev, r->h_fast_status_dev,
                                   r->h_done_dev, r->stream, &cl));
         }
+        (void)device_loop;
       } else if (!r->micp_fast_exec || r->fast_graph_dirty || !(key == r->micp_fast_key)) {
         // the previous call returned on its completion tag, which precedes the stream's own completion: let the last node
         // retire before its executable graph is destroyed
@@ -1477,11 +1739,16 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
         r->fast_graph_dirty = false;
       }
       if (r->use_graph && r->fast_mode == 2) HIPCHK(hipGraphLaunch(r->micp_fast_exec, r->stream));
-      // sum of the tag: the status block, plus the state block when the loop ran to its end (code 0)
-      DoneCheck chk; chk.base = r->h_fast_status; chk.base_bytes = sizeof(MicpFastStatus); chk.code = &r->h_fast_status->code;
-      chk.extra[0] = r->h_state; chk.extra_bytes[0] = sizeof(MicpState);
-      HIPCHK(wait_done(r->ctx, r->h_done, r->h_call->seq, chk, r->stream));
-      const MicpFastStatus fs = *r->h_fast_status;
+      if (!fs_ready) {
+        // sum of the tag: the status block, plus the state block when the loop ran to its end (code 0)
+        DoneCheck chk; chk.base = r->h_fast_status; chk.base_bytes = sizeof(MicpFastStatus); chk.code = &r->h_fast_status->code;
+        chk.extra[0] = r->h_state; chk.extra_bytes[0] = sizeof(MicpState);
+        HIPCHK(wait_done(r->ctx, r->h_done, r->h_call->seq, chk, r->stream));
+        fs = *r->h_fast_status;
+      } else {
+        ++r->fast_info.host_loops;
+      }
+      r->last_fast = fs;
       r->fast_info.attempts++;
       r->fast_info.last_code = fs.code;
       r->fast_info.last_uncertain = fs.n_uncertain;
@@ -1591,14 +1858,14 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
       const xform Ts = xmul(xmul(xinv(r->Tsb), Tb), r->Tsb);
       const float rho = 2.0f * std::sqrt(Ts.R.x * Ts.R.x + Ts.R.y * Ts.R.y + Ts.R.z * Ts.R.z);
       const float tau = std::sqrt(Ts.t.x * Ts.t.x + Ts.t.y * Ts.t.y + Ts.t.z * Ts.t.z);
-      if (r->h_fast_status->code == 2u) {
+      if (r->last_fast.code == 2u) {
         // too many uncertain correspondences: tighter caps, and stop trying when that does not help either
         r->fast_rho_cap = std::max(0.002f, 1.25f * rho);
         r->fast_tau_cap = std::max(0.005f, 1.25f * tau);
         if (++r->fast_overflows >= 2u) { r->fast_holdoff = 32u; r->fast_overflows = 0; }
       } else {
-        r->fast_rho_cap = std::max(0.002f, std::max(2.0f * rho, 2.0f * r->h_fast_status->max_rho));
-        r->fast_tau_cap = std::max(0.005f, std::max(2.0f * tau, 2.0f * r->h_fast_status->max_tau));
+        r->fast_rho_cap = std::max(0.002f, std::max(2.0f * rho, 2.0f * r->last_fast.max_rho));
+        r->fast_tau_cap = std::max(0.005f, std::max(2.0f * tau, 2.0f * r->last_fast.max_tau));
       }
       r->fast_info.rho_cap = r->fast_rho_cap;
       r->fast_info.tau_cap = r->fast_tau_cap;
@@ -1695,6 +1962,91 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
   bool fast_tried = false;
   if (fast_eligible && r0->multi_holdoff > 0u) --r0->multi_holdoff;
   else if (fast_eligible) fast_tried = true;
+  // ---- round 4: every sensor's find forms its moments and publishes them to the host (its own stream, its own block and tag), the
+  // host merges and solves (micp_host.h; same frame-by-frame order as k_micp_multi_step).  Any sensor with too many undecided
+  // correspondences or a pre-transform outside its caps: the device forms below, from scratch.
+  bool device_fast = fast_tried;   // the device's moment loop is tried (after the host form, when that is on and did not finish)
+  bool host_form = fast_tried;
+  for (uint32_t s = 0; s < n_sensors; ++s) host_form = host_form && sensors[s]->fast_mode == 1 && !sensors[s]->fused_tail;
+  if (host_form) {
+    float maxd[kMaxMicpSensors];
+    uint32_t seqs[kMaxMicpSensors];
+    for (uint32_t s = 0; s < n_sensors; ++s) {
+      rmclhip_rcc* r = sensors[s];
+      maxd[s] = adaptive_max_dist(r, convergence_progress);
+      seqs[s] = (s == 0u) ? h_call.seq : next_seq(r);
+      if (rmclhip_status e2 = enqueue_find_with_moments(r, xmul(xmul(Tom, h_call.Tbo[s]), r->Tsb), maxd[s], maxd[s], r->fast_rho_cap, r->fast_tau_cap,
+                                                        seqs[s], true))
+        return e2;
+    }
+    bool all_valid = true;
+    for (uint32_t s = 0; s < n_sensors; ++s) {
+      rmclhip_rcc* r = sensors[s];
+      HIPCHK(wait_moments(r, seqs[s], maxd[s], maxd[s], r->fast_rho_cap, r->fast_tau_cap));
+      all_valid = all_valid && r->mset.valid;
+    }
+    MicpMultiFastStatus hs;
+    std::memset(&hs, 0, sizeof(hs));
+    hs.code = all_valid ? 0u : 2u;
+    xform T_onew_oold = xidentity(), T_s[kMaxMicpSensors];
+    cstats merged = cs_identity(), merged_w = cs_identity();
+    for (uint32_t s = 0; s < n_sensors; ++s) { T_s[s] = xidentity(); hs.n_uncertain += sensors[s]->mset.n_unc; }
+    for (uint32_t it = 0; it < n_iter && hs.code == 0u; ++it) {
+      merged = cs_identity(); merged_w = cs_identity();
+      for (uint32_t s = 0; s < n_sensors; ++s) {
+        const rmclhip_rcc* r = sensors[s];
+        const float rho = micp_rho(T_s[s]), tau = micp_tau(T_s[s]);
+        hs.max_rho[s] = std::max(hs.max_rho[s], rho);
+        hs.max_tau[s] = std::max(hs.max_tau[s], tau);
+        if (!(rho <= r->mset.rho_cap) || !(tau <= r->mset.tau_cap)) { hs.code = 1u; hs.iter = it; hs.sensor = s; break; }
+        // micp_localization.cpp:926-937 with MICPSensor.hpp:178-182
+        const cstats stats_s = micp_statistics_from_set(r->mset, T_s[s], maxd[s]);
+        const cstats Cs_o = cs_transform(h_call.Tbo[s], cs_transform(r->Tsb, stats_s));
+        cstats Cs_w = Cs_o;
+        Cs_w.n_meas = static_cast<uint32_t>(static_cast<double>(Cs_w.n_meas) * h_call.weight[s]);
+        merged = cs_merge(merged, Cs_o);
+        merged_w = cs_merge(merged_w, Cs_w);
+      }
+      if (hs.code != 0u) break;
+      T_onew_oold = xmul(T_onew_oold, umeyama(merged_w));   // :952-963
+      for (uint32_t s = 0; s < n_sensors; ++s) {
+        const xform T_bnew_bold = xmul(xmul(xinv(h_call.Tbo[s]), T_onew_oold), h_call.Tbo[s]);
+        T_s[s] = xmul(xmul(xinv(sensors[s]->Tsb), T_bnew_bold), sensors[s]->Tsb);
+      }
+    }
+    for (uint32_t s = 0; s < n_sensors && hs.code != 2u; ++s) {   // (code 2: the device loop below is this call's attempt)
+      rmclhip_rcc* r = sensors[s];
+      r->fast_info.attempts++;
+      r->fast_info.last_code = hs.code;
+      r->fast_info.last_uncertain = hs.n_uncertain;
+      r->fast_info.last_rho = hs.max_rho[s];
+      r->fast_info.last_tau = hs.max_tau[s];
+      r->fast_info.last_setup_clocks = r->fast_info.last_loop_clocks = 0u;
+    }
+    if (hs.code == 0u) {
+      r0->multi_overflows = 0;
+      for (uint32_t s = 0; s < n_sensors; ++s) {
+        rmclhip_rcc* r = sensors[s];
+        r->fast_info.done++;
+        r->fast_info.host_loops++;
+        learn_caps(r, hs.max_rho[s], hs.max_tau[s]);
+      }
+      from_x(T_onew_oold, T_out);
+      if (merged_out) from_cs(merged, merged_out);
+      return RMCLHIP_OK;
+    }
+    // not served on the host: the device forms take over, from scratch (the moment sets belong to finds that are about to be redone).
+    // A pre-transform that left its caps would leave them in the device's moment loop as well: straight to the per-iteration form,
+    // whose end learns the caps from this status; too many undecided correspondences for the host (> 256 in a sensor): the device's
+    // moment loop takes up to 4096.
+    if (hs.code == 1u) {
+      device_fast = false;
+      *r0->h_multi_status = hs;
+      for (uint32_t s = 0; s < n_sensors; ++s) sensors[s]->fast_info.cap_exits++;
+    }
+    for (uint32_t s = 0; s < n_sensors; ++s) drop_moment_set(sensors[s]);
+    h_call.seq = next_seq(r0);
+  }
   // sensor->setTom(Tom); sensor->findCorrespondences()  (:900-909): Tbm = Tom * Tbo.  The sensors' finds (and moment passes) do not
   // depend on each other: sensor 0's go to the stream the loop runs on, every other sensor's to ITS OWN stream, joined by an event
   // before the loop -- one scan leaves the chip partly idle (bench.py extras.find_two_operators_in_flight_*), a second sensor's scan
@@ -1720,7 +2072,7 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
     p.Tms = xinv(p.Tsm);
     e = launch_find(p, r->kind, find_variant(r, 1), (s == 0u) ? st : r->stream);
   }
-  for (uint32_t s = 0; s < n_sensors && e == hipSuccess && fast_tried; ++s) {
+  for (uint32_t s = 0; s < n_sensors && e == hipSuccess && device_fast; ++s) {
     rmclhip_rcc* r = sensors[s];
     hipStream_t fs = (s == 0u) ? st : r->stream;
     const uint32_t nred = (r->n_dataset < r->n_model) ? r->n_dataset : r->n_model;
@@ -1729,6 +2081,7 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
     // per-call data by value: no H2D copy node per sensor (4.4 us each in the kernel trace of round 2's chain)
     MicpCallLite cl;
     cl.Tsb = r->Tsb; cl.Tbo = h_call.Tbo[s]; cl.max_dist = adaptive_max_dist(r, convergence_progress);
+    cl.gate_lo = cl.max_dist; cl.gate_hi = cl.max_dist;
     cl.rho_cap = r->fast_rho_cap; cl.tau_cap = r->fast_tau_cap; cl.seq = h_call.seq;
     HIPCHK(launch_micp_moments(r->ds_pts, r->ds_has_mask ? r->ds_msk : nullptr, r->d_points.p, r->d_normals.p, r->d_hits.p, nred,
                                nullptr, r->d_fast_partials.p, r->d_fast_mask.p, fs, &cl));
@@ -1744,7 +2097,7 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
   }
   fp.join_flags = r0->d_join_flags;
   if (e != hipSuccess) return fail(RMCLHIP_ERR_HIP, std::string("micp_correct_once: ") + hipGetErrorString(e));
-  if (fast_tried) {
+  if (device_fast) {
     fp.n_sensors = n_sensors;
     fp.seq = h_call.seq;
     fp.n_iter = n_iter;
@@ -1874,6 +2227,12 @@ rmclhip_status rmclhip_rcc_last_kernel_ms(rmclhip_rcc* r, float* find_ms, float*
     HIPCHK(hipEventSynchronize(r->ev1));
     HIPCHK(hipEventElapsedTime(&r->last_reduce_ms, r->ev0, r->ev1));
     r->reduce_timing_pending = false;
+  }
+  if (r->find_timing_pending) {   // (find + moment epilogue + publish)
+    HIPCHK(hipSetDevice(r->ctx->device));
+    HIPCHK(hipEventSynchronize(r->ev1));
+    HIPCHK(hipEventElapsedTime(&r->last_find_ms, r->ev0, r->ev1));
+    r->find_timing_pending = false;
   }
   if (find_ms) *find_ms = r->last_find_ms;
   if (reduce_ms) *reduce_ms = r->last_reduce_ms;
@@ -2017,6 +2376,53 @@ rmclhip_status rmclhip_rcc_time_correct_once(rmclhip_rcc* r, const rmclhip_trans
   return RMCLHIP_OK;
 }
 
+// The reference's caller loop for one sensor, literally (micp_localization.cpp:900-964 with MICPSensor.hpp:146-184), through the
+// PUBLIC entry points a C caller has -- find once, then per iteration computeCrossStatistics + the CrossStatistics / Transform
+// algebra + umeyama_transform on the host -- on the host clock.  This is the flow an integrator gets WITHOUT replacing the node's
+// loop by rmclhip_rcc_correct_once.
+rmclhip_status rmclhip_rcc_time_caller_loop(rmclhip_rcc* r, const rmclhip_transform* Tom, const rmclhip_transform* Tbo, uint32_t n_iter,
+                                            double convergence_progress, uint32_t iters, rmclhip_transform* T_onew_oold_out,
+                                            rmclhip_cross_statistics* merged_out, float* ms_per_call) {
+  if (!r || !Tom || !Tbo || !ms_per_call || iters == 0) return fail(RMCLHIP_ERR_INVALID, "rcc_time_caller_loop: bad arguments");
+  rmclhip_transform Tsb, Tsb_inv, Tbo_inv, Tbm, T_onew_oold, T_bnew_bold, T_snew_sold, T_inner, tmp;
+  rmclhip_cross_statistics Cs_s, Cs_b, Cs_o, ident, merged;
+  from_x(r->Tsb, &Tsb);
+  from_cs(cs_identity(), &ident);
+  merged = ident;
+  auto once = [&]() -> rmclhip_status {
+    rmclhip_status st;
+    if ((st = rmclhip_transform_inv(&Tsb, &Tsb_inv))) return st;
+    if ((st = rmclhip_transform_inv(Tbo, &Tbo_inv))) return st;
+    if ((st = rmclhip_transform_mult(Tom, Tbo, &Tbm))) return st;             // MICPSensor.hpp:146-151
+    if ((st = rmclhip_rcc_find(r, &Tbm))) return st;
+    from_x(xidentity(), &T_onew_oold);
+    for (uint32_t i = 0; i < n_iter; ++i) {
+      if ((st = rmclhip_transform_mult(&Tbo_inv, &T_onew_oold, &tmp))) return st;      // :926
+      if ((st = rmclhip_transform_mult(&tmp, Tbo, &T_bnew_bold))) return st;
+      if ((st = rmclhip_transform_mult(&Tsb_inv, &T_bnew_bold, &tmp))) return st;      // MICPSensor.hpp:178
+      if ((st = rmclhip_transform_mult(&tmp, &Tsb, &T_snew_sold))) return st;
+      if ((st = rmclhip_rcc_compute_cross_statistics(r, &T_snew_sold, convergence_progress, &Cs_s))) return st;
+      if ((st = rmclhip_cross_statistics_transform(&Tsb, &Cs_s, &Cs_b))) return st;    // MICPSensor.hpp:182
+      if ((st = rmclhip_cross_statistics_transform(Tbo, &Cs_b, &Cs_o))) return st;     // :931
+      if ((st = rmclhip_cross_statistics_merge(&ident, &Cs_o, &merged))) return st;    // :936
+      if ((st = rmclhip_umeyama_transform(&merged, &T_inner))) return st;              // :952
+      if ((st = rmclhip_transform_mult(&T_onew_oold, &T_inner, &tmp))) return st;      // :963
+      T_onew_oold = tmp;
+    }
+    return RMCLHIP_OK;
+  };
+  for (int warm = 0; warm < 2; ++warm)   // (allocation; the second find learns that computeCrossStatistics calls follow a find)
+    if (rmclhip_status st = once()) return st;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t i = 0; i < iters; ++i)
+    if (rmclhip_status st = once()) return st;
+  const auto t1 = std::chrono::steady_clock::now();
+  *ms_per_call = static_cast<float>(std::chrono::duration<double, std::milli>(t1 - t0).count() / iters);
+  if (T_onew_oold_out) *T_onew_oold_out = T_onew_oold;
+  if (merged_out) *merged_out = merged;
+  return RMCLHIP_OK;
+}
+
 rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
   ApiGuard guard_("rmclhip_rcc_set_variant");
   if (!r || variant < 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: bad arguments");
@@ -2048,9 +2454,10 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
 
 rmclhip_status rmclhip_rcc_set_micp_fast(rmclhip_rcc* r, int mode) {
   ApiGuard guard_("rmclhip_rcc_set_micp_fast");
-  if (!r || mode < 0 || mode > 3)
-    return fail(RMCLHIP_ERR_INVALID, "rcc_set_micp_fast: mode must be 0 (off), 1 (automatic), 2 (automatic, replayed from a hipGraph) or 3 (automatic, "
-                                     "moments in a pass of their own)");
+  if (!r || mode < 0 || mode > 4)
+    return fail(RMCLHIP_ERR_INVALID, "rcc_set_micp_fast: mode must be 0 (off), 1 (automatic, iterations on the host), 2 (device loop replayed from a "
+                                     "hipGraph), 3 (device loop, moments in a pass of their own) or 4 (device loop, moments in the find's epilogue)");
+  drop_moment_set(r);
   r->fast_mode = mode;
   r->fast_holdoff = 0;
   r->fast_overflows = 0;
@@ -2062,6 +2469,31 @@ rmclhip_status rmclhip_rcc_micp_fast_info(const rmclhip_rcc* r, rmclhip_micp_fas
   *out = r->fast_info;
   out->rho_cap = r->fast_rho_cap;
   out->tau_cap = r->fast_tau_cap;
+  return RMCLHIP_OK;
+}
+
+// the host side of the moment form alone (micp_host.h), no device involved: classify + accumulate the moments of the given
+// correspondences exactly as k_micp_moments / the find's epilogue do, then evaluate statistics_p2l at (Tpre, max_dist) from them
+rmclhip_status rmclhip_host_moment_statistics(const float* dataset_points, const float* model_points, const float* model_normals,
+                                              const uint8_t* valid, uint32_t n, float gate_lo, float gate_hi, float rho_cap, float tau_cap,
+                                              const rmclhip_transform* Tpre_, float max_dist, rmclhip_cross_statistics* out,
+                                              uint32_t* n_undecided, int* covered) {
+  if ((n != 0 && (!dataset_points || !model_points || !model_normals)) || !Tpre_ || !out)
+    return fail(RMCLHIP_ERR_INVALID, "host_moment_statistics: null");
+  static thread_local MicpMomentSet ms;
+  uint32_t unc = 0;
+  const bool fits = micp_set_from_correspondences(dataset_points, model_points, model_normals, valid, n, gate_lo, gate_hi, rho_cap, tau_cap, &ms, &unc);
+  if (n_undecided) *n_undecided = unc;
+  const xform Tpre = to_x(Tpre_);
+  const bool cov = fits && micp_set_covers(ms, Tpre, max_dist);
+  if (covered) *covered = cov ? 1 : 0;
+  from_cs(cov ? micp_statistics_from_set(ms, Tpre, max_dist) : cs_identity(), out);
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_ccs_info(const rmclhip_rcc* r, rmclhip_ccs_info* out) {
+  if (!r || !out) return fail(RMCLHIP_ERR_INVALID, "rcc_ccs_info: null");
+  *out = r->ccs_info;
   return RMCLHIP_OK;
 }
 

@@ -408,4 +408,23 @@ RM_HD xform umeyama(const cstats& s) {
   return T;
 }
 
+
+// ---- gate-stable moment form of the MICP iterations (kernels.hip k_micp_moments, find_kernel.hip.h find_moments_wave, and the
+// host's evaluation in micp_host.h): classification of one correspondence at the identity pre-transform.  spd0 = (I - D) . N is
+// the reduction's own gate value, nd = |D|.  While the pre-transform stays within (rho_cap = |2 sin(theta/2)|, tau_cap = |t|) the
+// dataset point moves by at most rho_cap nd + tau_cap, and so does the gate value (|N| = 1; the 1e-4 (1 + nd) covers the f32
+// rounding of both evaluations).  The gate |spd| < max_dist is asked for every max_dist in [gate_lo, gate_hi] (one value when the
+// caller knows it; a band when the find speculates for the computeCrossStatistics calls that will follow it):
+//   1 = gated in under every such pre-transform and max_dist  -> its contribution comes from the moments
+//   0 = gated out under every one (also a NaN gate value)     -> contributes nothing
+//   2 = undecided                                             -> re-evaluated per call with the reduction's own f32 arithmetic
+RM_HD int micp_gate_class(float spd0, float nd, float gate_lo, float gate_hi, float rho_cap, float tau_cap) {
+  const float margin = (rho_cap * nd + tau_cap) + 1e-4f * (1.0f + nd);
+  const float a = fabsf(spd0);
+  if (spd0 != spd0) return 0;
+  if (gate_lo - a > margin) return 1;
+  if (a - gate_hi > margin) return 0;
+  return 2;
+}
+
 }  // namespace rmclhip

@@ -163,10 +163,8 @@ __device__ __forceinline__ void find_moments_wave(const FindParams& p, uint32_t*
   const bool ok = have && ds.ok;
   const float spd0 = dot_plain(sub3(Ii, ds.D), Ni);
   const float nd = sqrtf(dot_plain(ds.D, ds.D));
-  const float margin = (p.mom_rho_cap * nd + p.mom_tau_cap) + 1e-4f * (1.0f + nd);
-  const float slack = fabsf(fabsf(spd0) - p.mom_max_dist);
-  const bool certain = ok && ((slack > margin) || (spd0 != spd0));
-  const bool uncertain = ok && !certain;
+  const int cls = micp_gate_class(spd0, nd, p.mom_gate_lo, p.mom_gate_hi, p.mom_rho_cap, p.mom_tau_cap);
+  const bool uncertain = ok && cls == 2;
   unsigned long long word = __ballot(uncertain);
   if (kQuadRays) {
     // bits sit at lanes 4 r (sub == 0): lane r < 16 fetches lane 4 r's flag, the ballot of those is the wave's 16-bit piece
@@ -176,7 +174,7 @@ __device__ __forceinline__ void find_moments_wave(const FindParams& p, uint32_t*
   } else if (lane == 0u) {
     p.mom_unc_mask[word_index] = word;
   }
-  const bool gate = certain && fabsf(spd0) < p.mom_max_dist;
+  const bool gate = ok && cls == 1;
   double X[10], Y[10];
   {
     // a gated-out lane contributes zeros (its inputs may be NaN: select, do not multiply)

@@ -6,6 +6,7 @@
 
 #include "devmath.h"
 #include "layout.h"
+#include "micp_host.h"
 
 namespace rmclhip {
 
@@ -54,7 +55,7 @@ struct FindParams {
   const float* mom_dataset_points;
   const uint8_t* mom_dataset_mask;     // nullable
   uint32_t mom_n;                      // correspondences: min(n_dataset, W * H)
-  float mom_max_dist, mom_rho_cap, mom_tau_cap;
+  float mom_gate_lo, mom_gate_hi, mom_rho_cap, mom_tau_cap;   // devmath.h micp_gate_class
   double* mom_partials;                // [gridDim.x][kMicpFastMoments]
   unsigned long long* mom_unc_mask;    // [4 * gridDim.x]: bit l of word t = lane l of (virtual) tile t holds an undecided correspondence
 };
@@ -118,7 +119,8 @@ struct MicpCall {
   float max_dist;
   float rho_cap, tau_cap;   // moment form of the loop (launch_micp_fast): bounds on the pre-transforms it may meet
   uint32_t seq;             // sequence number of this call: echoed in the completion tag the chain's last kernel publishes
-  uint32_t pad[4];
+  float gate_lo, gate_hi;   // moment form: the classification holds for every max_dist in [gate_lo, gate_hi] (devmath.h micp_gate_class)
+  uint32_t pad[2];
 };
 
 // the part of MicpCall the moment-form kernels read, passed BY VALUE when the chain is launched directly (no hipGraph, no H2D
@@ -127,6 +129,7 @@ struct MicpCallLite {
   xform Tsb, Tbo;
   float max_dist, rho_cap, tau_cap;
   uint32_t seq;
+  float gate_lo, gate_hi;   // see MicpCall
 };
 
 // MICP-L inner-loop state kept on the device between launches (correct_once)
@@ -161,6 +164,17 @@ hipError_t launch_micp_fast_loop_tiled(const float* dataset_points, const uint8_
                                        MicpFastStatus* status, unsigned long long* done, hipStream_t s, const MicpCallLite& call_by_value,
                                        double* fold_rows, uint32_t* fold_flags);   // [kMicpFoldBlocks][96] doubles / flags, zeroed once; null: one workgroup
 constexpr uint32_t kMicpFoldBlocks = 8;
+// Round 4 -- the iterations on the host (micp_host.h): fold the rows like the loop launch does, then hand {82 moments, undecided
+// count, the undecided correspondences' D | I | N} to the host behind one completion tag {seq, xor of the written words}.
+// _tiled: after launch_find_moments (mask words in the find's tile order); _moments_publish: the separate pass + the publish.
+hipError_t launch_micp_publish_tiled(const float* dataset_points, const float* model_points, const float* model_normals, uint32_t n,
+                                     uint32_t nblocks, const double* partials, const unsigned long long* unc_mask, uint32_t W,
+                                     uint32_t tiles_x, uint32_t tile_w_log2, uint32_t words_per_block, MicpHostBlock* host_block,
+                                     unsigned long long* done, uint32_t seq, double* fold_rows, uint32_t* fold_flags, hipStream_t s);
+hipError_t launch_micp_moments_publish(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
+                                       const float* model_normals, const uint8_t* model_mask, uint32_t n, double* partials,
+                                       unsigned long long* unc_mask, const MicpCallLite& cv, MicpHostBlock* host_block,
+                                       unsigned long long* done, hipStream_t s);
 
 // N-sensor MICP loop on the device (micp_localization.cpp:900-964): per-call frames + per-sensor partials, one step launch per
 // iteration merges every sensor's statistics (weighted and unweighted), solves once and hands every sensor its next

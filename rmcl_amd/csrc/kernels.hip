@@ -703,6 +703,7 @@ struct MicpFastParams {
   // workgroup 0 through fold_rows[b] / fold_flags[b] (= this call's sequence number) and leaves
   double* fold_rows;            // [kMicpFoldBlocks][kMom]
   uint32_t* fold_flags;         // [kMicpFoldBlocks]
+  MicpHostBlock* host_block;    // k_micp_publish: pinned, host-mapped
 };
 // correspondence index of bit `b` of mask word `w`
 __device__ __forceinline__ uint32_t micp_mask_index(const MicpFastParams& p, uint32_t w, uint32_t b) {
@@ -732,7 +733,7 @@ __global__ void __launch_bounds__(256) k_micp_moments(const MicpFastParams p) {
   __shared__ double red[4][kMom];
   __shared__ double s_scratch[4][2][64 * 17];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const float max_dist = RMCL_FCALL(p, max_dist), rho_cap = RMCL_FCALL(p, rho_cap), tau_cap = RMCL_FCALL(p, tau_cap);
+  const float gate_lo = RMCL_FCALL(p, gate_lo), gate_hi = RMCL_FCALL(p, gate_hi), rho_cap = RMCL_FCALL(p, rho_cap), tau_cap = RMCL_FCALL(p, tau_cap);
   double m[kMom];
 #pragma unroll
   for (int k = 0; k < kMom; ++k) m[k] = 0.0;
@@ -766,14 +767,12 @@ __global__ void __launch_bounds__(256) k_micp_moments(const MicpFastParams p) {
       // the reduction's own gate value at the identity pre-transform
       const float spd0 = dot_plain(sub3(Ii, Di), Ni);
       const float nd = sqrtf(dot_plain(Di, Di));
-      const float margin = (rho_cap * nd + tau_cap) + 1e-4f * (1.0f + nd);
-      const float slack = fabsf(fabsf(spd0) - max_dist);
-      // NaN gate value (a NaN / inf dataset point without a mask): NaN under every pre-transform, gated out for good
-      const bool certain = ok[u] && ((slack > margin) || (spd0 != spd0));
-      const bool uncertain = ok[u] && !certain;
+      // (a NaN gate value -- a NaN / inf dataset point without a mask -- is NaN under every pre-transform: gated out for good)
+      const int cls = micp_gate_class(spd0, nd, gate_lo, gate_hi, rho_cap, tau_cap);
+      const bool uncertain = ok[u] && cls == 2;
       const unsigned long long word = __ballot(uncertain);
       if (lane == 0u) p.unc_mask[(base + static_cast<uint32_t>(u) * stride) >> 6] = word;
-      if (certain && fabsf(spd0) < max_dist) {
+      if (ok[u] && cls == 1) {
         const double D[3] = {Di.x, Di.y, Di.z}, N[3] = {Ni.x, Ni.y, Ni.z};
         const double sI = (N[0] * static_cast<double>(Ii.x) + N[1] * static_cast<double>(Ii.y)) + N[2] * static_cast<double>(Ii.z);
         const double DD[6] = {D[0] * D[0], D[0] * D[1], D[0] * D[2], D[1] * D[1], D[1] * D[2], D[2] * D[2]};
@@ -1125,6 +1124,141 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastP
     st.pad[1] = static_cast<uint32_t>(__builtin_readcyclecounter() - clk1);      // ... and of all iterations
     st.pad[2] = 0u;
     publish_status(p.status, st, p.done, RMCL_FCALL(p, seq), xor_words(out));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round 4: the iterations leave the device.  k_micp_fast_loop above spends ~4.4 k cycles per iteration in ONE lane's dependent f64
+// chain (Horn's quartic, the frame products) -- 34 of a correction's 60 us -- although an iteration is a closed-form function of
+// the 82 moments and the few undecided correspondences.  k_micp_publish folds the per-workgroup rows exactly as the loop kernel
+// does (same order, same sums) and writes {moments, undecided count, D | I | N of every undecided correspondence} into pinned
+// host memory behind one completion tag; the host (micp_host.h) then runs the iterations -- rmclhip_rcc_correct_once -- or
+// answers every computeCrossStatistics of the reference's unchanged caller loop (micp_localization.cpp:915-964) with no launch
+// at all.  More than kMicpHostMaxUnc undecided correspondences: code 2, the caller launches the device loop on the same rows.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kFastThreads) k_micp_publish(const MicpFastParams p) {
+  constexpr uint32_t kGroups = kFoldGroups;
+  __shared__ double s_part[kGroups][kMom];
+  __shared__ uint32_t s_list[kMicpHostMaxUnc];
+  __shared__ uint32_t s_wave_cnt[kFastThreads / 64];
+  __shared__ uint32_t s_xor[kFastThreads / 64];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t nfold = gridDim.x;
+  const uint32_t rows_per = (p.nblocks + nfold - 1u) / nfold;
+  const uint32_t row0 = min(blockIdx.x * rows_per, p.nblocks), row1 = min(row0 + rows_per, p.nblocks);
+  fold_moment_partials(p.partials + static_cast<size_t>(row0) * kMom, row1 - row0, s_part, tid);
+  if (blockIdx.x != 0u) {
+    __syncthreads();
+    if (tid < kMomUsed) {
+      double a = s_part[0][tid];
+#pragma unroll
+      for (uint32_t g = 1; g < kGroups; ++g) a += s_part[g][tid];
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(p.fold_rows) + blockIdx.x * kMom + tid,
+                         static_cast<unsigned long long>(__double_as_longlong(a)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (tid == 0u) __hip_atomic_store(p.fold_flags + blockIdx.x, p.cv.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  // the undecided correspondences, in index order (as k_micp_fast_loop counts them)
+  const uint32_t nwords = (p.mask_tiled != 0u) ? p.mask_nwords : ((p.n + 63u) >> 6);
+  const uint32_t wpt = (nwords + kFastThreads - 1u) / kFastThreads;
+  const uint32_t w0 = min(tid * wpt, nwords), w1 = min(w0 + wpt, nwords);
+  uint32_t cnt = 0;
+  for (uint32_t w = w0; w < w1; w += 8u) {
+    unsigned long long m[8];
+#pragma unroll
+    for (uint32_t u = 0; u < 8u; ++u) m[u] = (w + u < w1) ? p.unc_mask[w + u] : 0ull;
+#pragma unroll
+    for (uint32_t u = 0; u < 8u; ++u) cnt += static_cast<uint32_t>(__popcll(m[u]));
+  }
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = __shfl_up(incl, off, 64);
+    if (lane >= static_cast<uint32_t>(off)) incl += v;
+  }
+  if (lane == 63u) s_wave_cnt[wave] = incl;
+  __syncthreads();
+  uint32_t x = 0u;   // xor of the words this thread writes for the host
+  if (tid < kMom) {
+    double a = 0.0;
+    if (tid < kMomUsed) {
+      a = s_part[0][tid];
+#pragma unroll
+      for (uint32_t g = 1; g < kGroups; ++g) a += s_part[g][tid];
+      if (nfold > 1u) {
+        const uint32_t seq = p.cv.seq;
+        bool ready;
+        do {
+          uint32_t f[kMicpFoldBlocks];
+#pragma unroll
+          for (uint32_t b = 1; b < kMicpFoldBlocks; ++b)
+            f[b] = (b < nfold) ? __hip_atomic_load(p.fold_flags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seq;
+          ready = true;
+#pragma unroll
+          for (uint32_t b = 1; b < kMicpFoldBlocks; ++b) ready = ready && (f[b] == seq);
+        } while (!ready);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        unsigned long long v[kMicpFoldBlocks];
+#pragma unroll
+        for (uint32_t b = 1; b < kMicpFoldBlocks; ++b)
+          v[b] = (b < nfold) ? __hip_atomic_load(reinterpret_cast<unsigned long long*>(p.fold_rows) + b * kMom + tid, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT)
+                             : 0ull;
+#pragma unroll
+        for (uint32_t b = 1; b < kMicpFoldBlocks; ++b) a += __longlong_as_double(static_cast<long long>(v[b]));
+      }
+    }
+    p.host_block->mom[tid] = a;
+    const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(a));
+    x ^= static_cast<uint32_t>(bits) ^ static_cast<uint32_t>(bits >> 32);
+  }
+  uint32_t wave_base = 0, total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < kFastThreads / 64; ++w) {
+    const uint32_t c = s_wave_cnt[w];
+    if (w < wave) wave_base += c;
+    total += c;
+  }
+  const bool fits = total <= kMicpHostMaxUnc;   // block-uniform
+  if (fits && total != 0u) {
+    if (cnt != 0u) {
+      uint32_t pos = wave_base + incl - cnt;
+      for (uint32_t w = w0; w < w1; ++w) {
+        unsigned long long bits = p.unc_mask[w];
+        while (bits) {
+          const int b = __builtin_ctzll(bits);
+          bits &= bits - 1ull;
+          s_list[pos++] = micp_mask_index(p, w, static_cast<uint32_t>(b));
+        }
+      }
+    }
+    __syncthreads();
+    for (uint32_t e = tid; e < total; e += kFastThreads) {
+      const uint32_t i = s_list[e];
+      const float* dp = p.dataset_points + 3 * static_cast<size_t>(i);
+      const float* mp = p.model_points + 3 * static_cast<size_t>(i);
+      const float* mn = p.model_normals + 3 * static_cast<size_t>(i);
+      const float v[9] = {dp[0], dp[1], dp[2], mp[0], mp[1], mp[2], mn[0], mn[1], mn[2]};
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        p.host_block->unc[e][k] = v[k];
+        x ^= __float_as_uint(v[k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) x ^= __shfl_xor(x, off, 64);
+  if (lane == 0u) s_xor[wave] = x;
+  __threadfence_system();   // this thread's stores to the host block, before the tag below
+  __syncthreads();
+  if (tid == 0u) {
+    const uint32_t code = fits ? 0u : 2u;
+    p.host_block->code = code;
+    p.host_block->n_uncertain = total;
+    p.host_block->pad[0] = 0u; p.host_block->pad[1] = 0u;
+    publish_tag(p.done, p.cv.seq, ((s_xor[0] ^ s_xor[1]) ^ (s_xor[2] ^ s_xor[3])) ^ (code ^ total));
   }
 }
 
@@ -2406,6 +2540,32 @@ hipError_t launch_micp_fast_loop_tiled(const float* dataset_points, const uint8_
                    1u, W, tiles_x, tile_w_log2, words_per_block * nblocks, fold_rows, fold_flags};
   const uint32_t nfold = (fold_rows != nullptr && fold_flags != nullptr && nblocks >= 256u) ? kMicpFoldBlocks : 1u;
   hipLaunchKernelGGL(k_micp_fast_loop, dim3(nfold), dim3(kFastThreads), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_micp_publish_tiled(const float* dataset_points, const float* model_points, const float* model_normals, uint32_t n,
+                                     uint32_t nblocks, const double* partials, const unsigned long long* unc_mask, uint32_t W,
+                                     uint32_t tiles_x, uint32_t tile_w_log2, uint32_t words_per_block, MicpHostBlock* host_block,
+                                     unsigned long long* done, uint32_t seq, double* fold_rows, uint32_t* fold_flags, hipStream_t s) {
+  MicpCallLite cv{};
+  cv.seq = seq;
+  MicpFastParams p{dataset_points, nullptr, model_points, model_normals, nullptr, n, nblocks, nullptr,
+                   const_cast<double*>(partials), const_cast<unsigned long long*>(unc_mask), 0u, nullptr, nullptr, done, cv,
+                   1u, W, tiles_x, tile_w_log2, words_per_block * nblocks, fold_rows, fold_flags, host_block};
+  const uint32_t nfold = (fold_rows != nullptr && fold_flags != nullptr && nblocks >= 256u) ? kMicpFoldBlocks : 1u;
+  hipLaunchKernelGGL(k_micp_publish, dim3(nfold), dim3(kFastThreads), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_micp_moments_publish(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
+                                       const float* model_normals, const uint8_t* model_mask, uint32_t n, double* partials,
+                                       unsigned long long* unc_mask, const MicpCallLite& cv, MicpHostBlock* host_block,
+                                       unsigned long long* done, hipStream_t s) {
+  MicpFastParams p{dataset_points, dataset_mask, model_points, model_normals, model_mask, n, micp_fast_blocks(n), nullptr,
+                   partials, unc_mask, 0u, nullptr, nullptr, done, cv};
+  p.host_block = host_block;
+  hipLaunchKernelGGL(k_micp_moments, dim3(p.nblocks), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(k_micp_publish, dim3(1), dim3(kFastThreads), 0, s, p);
   return hipGetLastError();
 }
 

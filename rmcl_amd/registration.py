@@ -353,6 +353,20 @@ class CorrespondencesHIP:
         self._last_nposes = 1
         return ms.value
 
+    def time_caller_loop(self, Tom, Tbo, n_iter, convergence_progress=0.0, iters=20):
+        """mean host-clock ms of the reference's UNCHANGED caller loop (find once, then n_iter x computeCrossStatistics + the host
+        algebra + umeyama_transform: micp_localization.cpp:900-964) through the public C entry points; returns
+        (ms, T_onew_oold, merged statistics of the last iteration)"""
+        self._push_params()
+        a = np.ascontiguousarray(Tom, dtype=TRANSFORM).reshape(1)
+        b = np.ascontiguousarray(Tbo, dtype=TRANSFORM).reshape(1)
+        Tout, st = np.zeros(1, dtype=TRANSFORM), np.zeros(1, dtype=CROSS_STATISTICS)
+        ms = C.c_float(0)
+        _capi.check(_capi.lib().rmclhip_rcc_time_caller_loop(self._h, _ptr(a), _ptr(b), int(n_iter), float(convergence_progress),
+                                                             int(iters), _ptr(Tout), _ptr(st), C.byref(ms)))
+        self._last_nposes = 1
+        return ms.value, Tout[0].copy(), st[0].copy()
+
     def correct_batch(self, Tbm):
         """v1 SphereCorrector::correct (lidar_corrector_embree_benchmark.cpp:127-135): Tdelta per pose."""
         self._push_params()
@@ -427,9 +441,16 @@ class CorrespondencesHIP:
         self.set_variant((int(kind) & 15) | ((int(kind) >> 4) << 13))
 
     def set_micp_fast(self, mode):
-        """moment form of the schedule-(R) loop of correctOnce: 0 = never, 1 = automatic (moments formed in the find's epilogue where the
-        traversal allows), 2 = through a hipGraph, 3 = moments always in a pass of their own (rmclhip.h)"""
+        """moment form of the schedule-(R) loop of correctOnce: 0 = never, 1 = automatic, iterations on the host from the published
+        moments (default), 2 = device loop through a hipGraph, 3 = device loop, moments in a pass of their own, 4 = device loop behind
+        a find with the moment epilogue (rmclhip.h)"""
         _capi.check(_capi.lib().rmclhip_rcc_set_micp_fast(self._h, int(mode)))
+
+    def ccs_info(self):
+        """how computeCrossStatistics was served (rmclhip_ccs_info): calls, from_moments (host, no launch), passes, speculative_finds"""
+        info = _capi.CcsInfo()
+        _capi.check(_capi.lib().rmclhip_rcc_ccs_info(self._h, C.byref(info)))
+        return {k: getattr(info, k) for k, _ in info._fields_}
 
     def micp_fast_info(self):
         """outcomes of the moment-form attempts of this operator as a dict (rmclhip_micp_fast_info)"""

@@ -360,14 +360,14 @@ def test_moment_form_equals_per_iteration_form(ra, orc, ctx, meshes):
     Tsb, Tbo = syn.tsb_offset(), T.transform_from_rpy((0.3, -0.1, 0.0), (0.0, 0.0, 0.2))
     meas = m.simulate_spherical(model, Tsb, T.mult(truth, T.identity()), bvh=True, nthreads=8)
     ds, mask = om.dataset_from_ranges(model, meas["ranges"])
-    done_total, unc_seen = 0, 0
+    done_total, unc_seen, host_loops = 0, {1: 0, 4: 0}, 0
     for pert, rpy, prog in (((0.03, -0.02, 0.01), (0.0, 0.0, 0.01), 0.0), ((0.12, 0.08, -0.03), (0.01, -0.01, 0.03), 0.0),
                             ((0.01, 0.0, 0.0), (0.0, 0.0, 0.002), 0.9), ((0.3, -0.2, 0.1), (0.02, 0.0, -0.06), 0.2)):
         # the localisation state: Tom * Tbo = truth * perturbation
         est_bm = T.mult(truth, T.transform_from_rpy(pert, rpy))
         Tom = T.mult(est_bm, T.inv(Tbo))
         res = {}
-        for mode in (0, 1):
+        for mode in (0, 1, 4):      # 1: iterations on the host (default), 4: round 3's device loop
             rcc = ra.RCCHipSpherical(hm)
             rcc.setTsb(Tsb)
             rcc.setModel(model)
@@ -376,28 +376,35 @@ def test_moment_form_equals_per_iteration_form(ra, orc, ctx, meshes):
             rcc.set_micp_fast(mode)
             out = [rcc.correct_once(Tom, Tbo, 8, prog, False) for _ in range(3)]
             res[mode] = out
-            if mode == 1:
+            if mode != 0:
                 info = rcc.micp_fast_info()
                 assert info["attempts"] == 3
                 done_total += info["done"]
                 if info["last_code"] == 0:
-                    unc_seen = max(unc_seen, info["last_uncertain"])
+                    unc_seen[mode] = max(unc_seen[mode], info["last_uncertain"])
+                if mode == 1:
+                    host_loops += info["host_loops"]
+                else:
+                    assert info["host_loops"] == 0
             else:
                 assert rcc.micp_fast_info()["attempts"] == 0
             rcc.close()
         To, so, _ = om.correct_once(m, model, Tsb, Tbo, Tom, ds, mask, 8, 1.0, adaptive_min=0.15, convergence_progress=prog, nthreads=8)
         for k in range(3):
-            Tf, sf = res[1][k]
-            Tc, sc = res[0][k]
-            assert int(sf["n_meas"]) == int(sc["n_meas"]) == int(so["n_meas"])
-            _transform_close(Tf, Tc, 1e-6)
-            _transform_close(Tf, To, 1e-5)
-            assert np.allclose(sf["covariance"], sc["covariance"], rtol=1e-5, atol=1e-6)
-    assert done_total >= 4          # the moment form did run (not only its fallback)
-    assert unc_seen > 0             # ... including its per-iteration re-evaluation of undecided correspondences
+            for mode in (1, 4):
+                Tf, sf = res[mode][k]
+                Tc, sc = res[0][k]
+                assert int(sf["n_meas"]) == int(sc["n_meas"]) == int(so["n_meas"])
+                _transform_close(Tf, Tc, 1e-6)
+                _transform_close(Tf, To, 1e-5)
+                assert np.allclose(sf["covariance"], sc["covariance"], rtol=1e-5, atol=1e-6)
+    assert done_total >= 8          # the moment form did run (not only its fallback), in both forms
+    assert host_loops >= 4          # ... and in mode 1 the HOST ran the iterations
+    assert unc_seen[1] > 0 and unc_seen[4] > 0   # ... including the re-evaluation of undecided correspondences on either side
 
 
-def test_moment_form_fallbacks_keep_the_result(ra, orc, ctx, meshes):
+@pytest.mark.parametrize("fast", [1, 4])
+def test_moment_form_fallbacks_keep_the_result(ra, orc, ctx, meshes, fast):
     """Both exits of the moment form: (a) a correction far larger than the learnt bounds (pre-transform leaves the caps),
     (b) a gate so tight that most correspondences sit near it (more than 4096 undecided): the per-iteration form takes
     over and the result equals the one with the moment form switched off."""
@@ -416,6 +423,7 @@ def test_moment_form_fallbacks_keep_the_result(ra, orc, ctx, meshes):
     rcc.setTsb(ident)
     rcc.setModel(model)
     rcc.set_dataset(ds, mask)
+    rcc.set_micp_fast(fast)
     ref = ra.RCCHipSpherical(hm)
     ref.setTsb(ident)
     ref.setModel(model)
@@ -452,7 +460,7 @@ def test_moment_form_o1dn_unmasked_dataset_and_short_dataset(ra, orc, ctx, meshe
     truth = T.transform_from_rpy((1.0, -1.5, 1.2), (0.0, 0.0, 0.5))
     est = T.mult(truth, T.transform_from_rpy((0.04, -0.03, 0.01), (0.0, 0.0, 0.012)))
     res = {}
-    for mode in (0, 1):
+    for mode in (0, 1, 4):
         rcc = ra.RCCHipO1Dn(hm)
         rcc.setTsb(T.identity())
         rcc.setModel(W, H, 0.1, 100.0, (0.0, 0.0, 0.0), dirs)
@@ -468,12 +476,13 @@ def test_moment_form_o1dn_unmasked_dataset_and_short_dataset(ra, orc, ctx, meshe
         rcc.set_dataset(pts[: (H * W) // 2 + 7], None)
         out += [rcc.correct_once(est, T.identity(), 6, 0.1, False) for _ in range(3)]
         res[mode] = out
-        if mode == 1:
+        if mode != 0:
             assert rcc.micp_fast_info()["done"] >= 2
         rcc.close()
-    for (Tf, sf), (Tc, sc) in zip(res[1], res[0]):
-        assert int(sf["n_meas"]) == int(sc["n_meas"]) > 100
-        _transform_close(Tf, Tc, 1e-6)
+    for mode in (1, 4):
+        for (Tf, sf), (Tc, sc) in zip(res[mode], res[0]):
+            assert int(sf["n_meas"]) == int(sc["n_meas"]) > 100
+            _transform_close(Tf, Tc, 1e-6)
     assert int(res[1][0][1]["n_meas"]) > int(res[1][3][1]["n_meas"])        # the short dataset really is shorter
 
 
@@ -502,7 +511,7 @@ def test_moments_formed_in_the_find_epilogue_equal_the_separate_pass(ra, orc, ct
     kinds = ("spherical", "o1dn") if (H, W) not in ((128, 1024), (16, 900)) else ("spherical", "o1dn", "pinhole", "ondn")
     for kind in kinds:
         res = {}
-        for mode in (3, 1):
+        for mode in (3, 1, 4):
             if kind == "pinhole":
                 rcc = ra.RCCHipPinhole(hm)
                 rcc.setTsb(T.identity())
@@ -552,20 +561,22 @@ def test_moments_formed_in_the_find_epilogue_equal_the_separate_pass(ra, orc, ct
             assert info["last_code"] == 0, info
             res[mode] = (Tc, st, tot, rows, unc, info["last_uncertain"])
             rcc.close()
-        (Ta, sa, ma, rows_a, unc_a, lu_a), (Tb, sb, mb, rows_b, unc_b, lu_b) = res[3], res[1]
-        ntiles = -(-H // 4) * -(-W // 16)
-        assert rows_b % 8 == 0 and rows_b == ((ntiles if want_kind == 2 else -(-ntiles // 4)) + 7) // 8 * 8   # one row per workgroup of the find
-        assert unc_a == unc_b == lu_a == lu_b
-        assert ma[0] > 1000 and ma[0] == mb[0]                           # the count of certainly gated-in correspondences: exact
-        assert np.allclose(ma[:82], mb[:82], rtol=1e-10, atol=1e-7)
-        assert np.all(mb[82:] == 0.0)
-        assert int(sa["n_meas"]) == int(sb["n_meas"])
-        _transform_close(Ta, Tb, 1e-6)
-        assert np.allclose(sa["covariance"], sb["covariance"], rtol=1e-6, atol=1e-8)
+        for other in (1, 4):     # (the host's iterations and the device loop, both behind the find's epilogue)
+            (Ta, sa, ma, rows_a, unc_a, lu_a), (Tb, sb, mb, rows_b, unc_b, lu_b) = res[3], res[other]
+            ntiles = -(-H // 4) * -(-W // 16)
+            assert rows_b % 8 == 0 and rows_b == ((ntiles if want_kind == 2 else -(-ntiles // 4)) + 7) // 8 * 8   # one row per workgroup of the find
+            assert unc_a == unc_b == lu_a == lu_b
+            assert ma[0] > 1000 and ma[0] == mb[0]                           # the count of certainly gated-in correspondences: exact
+            assert np.allclose(ma[:82], mb[:82], rtol=1e-10, atol=1e-7)
+            assert np.all(mb[82:] == 0.0)
+            assert int(sa["n_meas"]) == int(sb["n_meas"])
+            _transform_close(Ta, Tb, 1e-6)
+            assert np.allclose(sa["covariance"], sb["covariance"], rtol=1e-6, atol=1e-8)
     hm.release()
 
 
-def test_moment_form_randomised_against_per_iteration_form(ra, orc, ctx, meshes):
+@pytest.mark.parametrize("fast", [1, 4])
+def test_moment_form_randomised_against_per_iteration_form(ra, orc, ctx, meshes, fast):
     """120 random corrections (mesh, mount, odometry frame, perturbation from millimetres to decimetres, gate from 5 cm to
     2 m, 2..12 iterations, progress) through two operators that differ only in rmclhip_rcc_set_micp_fast: n_meas must be
     IDENTICAL (a gate decision taken from the moments that the per-iteration arithmetic takes differently would show here)
@@ -579,7 +590,7 @@ def test_moment_form_randomised_against_per_iteration_form(ra, orc, ctx, meshes)
         hm = ra.import_hip_map(ctx, v, f)
         truth = T.transform_from_rpy((1.0, -1.5, 1.2), (0.0, 0.0, 0.5))
         pair = []
-        for mode in (1, 0):
+        for mode in (fast, 0):
             rcc = ra.RCCHipSpherical(hm)
             rcc.setModel(model)
             rcc.set_micp_fast(mode)
@@ -621,7 +632,7 @@ def test_long_loops_stay_within_tolerance(ra, orc, ctx, meshes):
     meas = m.simulate_spherical(model, Tsb, T.mult(T.identity(), Tbo), bvh=True, nthreads=8)
     ds, mask = om.dataset_from_ranges(model, meas["ranges"])
     To, so, _ = om.correct_once(m, model, Tsb, Tbo, Tom2, ds, mask, 40, 1.0, adaptive_min=0.15, convergence_progress=0.3, nthreads=8)
-    for mode in (0, 1):
+    for mode in (0, 1, 4):
         rcc = ra.RCCHipSpherical(hm)
         rcc.setTsb(Tsb)
         rcc.setModel(model)
@@ -633,3 +644,128 @@ def test_long_loops_stay_within_tolerance(ra, orc, ctx, meshes):
             _transform_close(Tg, To, 1e-5)
             assert int(sg["n_meas"]) == int(so["n_meas"])
         rcc.close()
+
+
+def _caller_loop_pair(ra, hm, model, Tsb, Tbo, ds, mask, modes=(1, 0), n_iter=10):
+    out = []
+    for mode in modes:
+        rcc = ra.RCCHipSpherical(hm)
+        rcc.setModel(model)
+        rcc.set_dataset(ds, mask)
+        rcc.params.max_dist, rcc.adaptive_max_dist_min = 1.0, 0.15
+        rcc.set_micp_fast(mode)
+        sensor = ra.MICPSensor("lidar", rcc, Tsb=Tsb, Tbo=Tbo)
+        sensor.valid_dataset_measurements = int(mask.sum())
+        sensor.total_dataset_measurements = len(mask)
+        out.append((rcc, ra.MICPLocalization([sensor], optimization_iterations=n_iter)))
+    return out
+
+
+def test_unchanged_caller_loop_is_served_from_the_moments(ra, orc, ctx, meshes):
+    """The reference's own loop -- find() once, then computeCrossStatistics() + umeyama_transform per iteration on the HOST
+    (micp_localization.cpp:900-964; rmcl_amd.micp.MICPLocalization.correctOnce restates it call for call) -- through the
+    unchanged entry points.  Round 4: the first correction's first computeCrossStatistics runs ONE moment pass, every later call of
+    that correction is answered on the host from the published moments; from the second correction on the find itself forms them
+    (speculating on max_dist' within +-8 % of the last one) and NO call launches anything.  Against the same loop with the moment
+    form off (a streaming reduction per call) and the oracle's frame-by-frame loop: every iteration's T_onew_oold within 1e-6 /
+    1e-5, valid_matches identical, on a room with occluders (undecided correspondences, gated-out ones, misses)."""
+    from rmcl_amd import synthetic as syn, types as T
+    model = syn.model_c1()
+    m, hm, truth, ds0, mask0 = _room_case(ra, orc, ctx, meshes, model)
+    Tsb, Tbo = syn.tsb_offset(), T.transform_from_rpy((0.3, -0.1, 0.0), (0.0, 0.0, 0.2))
+    meas = m.simulate_spherical(model, Tsb, T.mult(truth, T.identity()), bvh=True, nthreads=8)
+    ds, mask = om.dataset_from_ranges(model, meas["ranges"])
+    (rcc, loc), (rcc0, loc0) = _caller_loop_pair(ra, hm, model, Tsb, Tbo, ds, mask)
+    est_bm = T.mult(truth, T.transform_from_rpy((0.05, -0.03, 0.01), (0.0, 0.005, 0.02)))
+    loc.Tom_ = T.mult(est_bm, T.inv(Tbo))
+    loc0.Tom_ = loc.Tom_.copy()
+    unc = 0
+    for corr in range(6):
+        Tom_before, prog = loc.Tom_.copy(), loc.convergence_progress_
+        rec, rec0 = [], []
+        loc.correctOnce(record=rec)
+        loc0.correctOnce(record=rec0)
+        To, so, _ = om.correct_once(m, model, Tsb, Tbo, Tom_before, ds, mask, 10, 1.0, adaptive_min=0.15, convergence_progress=prog, nthreads=8)
+        assert loc.correction_stats_latest_["valid_matches"] == loc0.correction_stats_latest_["valid_matches"] == int(so["n_meas"])
+        for a, b in zip(rec, rec0):
+            _transform_close(a, b, 1e-6)
+        _transform_close(rec[-1], To, 1e-5)
+        assert abs(loc.convergence_progress_ - loc0.convergence_progress_) < 1e-6
+        # both localisations continue from the SAME state (the comparison is per correction, not of two diverging trajectories)
+        loc0.Tom_, loc0.convergence_progress_ = loc.Tom_.copy(), loc.convergence_progress_
+        unc = max(unc, rcc.micp_fast_info()["last_uncertain"])
+    info = rcc.ccs_info()
+    assert info["calls"] == 60
+    assert info["from_moments"] >= 55, info            # everything but what a band / cap miss sent to the streaming reduction
+    assert info["speculative_finds"] >= 3, info        # the finds of the later corrections formed the moments themselves
+    assert info["passes"] <= 4, info
+    assert rcc0.ccs_info()["from_moments"] == 0
+    rcc.close()
+    rcc0.close()
+
+
+def test_caller_loop_moment_cache_is_dropped_by_what_invalidates_it(ra, orc, ctx, meshes):
+    """The published moments belong to ONE find and ONE dataset: a new dataset, a new find, a max_dist' outside the band, a
+    pre-transform outside the caps and a gate so tight that more than 256 correspondences are undecided must all reach the same
+    numbers the streaming reduction gives."""
+    from rmcl_amd import synthetic as syn, types as T
+    model = syn.model_c1()
+    m, hm, truth, ds0, mask0 = _room_case(ra, orc, ctx, meshes, model)
+    ident = T.identity()
+    meas = m.simulate_spherical(model, ident, truth, bvh=True, nthreads=8)
+    ds, mask = om.dataset_from_ranges(model, meas["ranges"])
+    rcc, ref = ra.RCCHipSpherical(hm), ra.RCCHipSpherical(hm)
+    for r, mode in ((rcc, 1), (ref, 0)):
+        r.setTsb(ident)
+        r.setModel(model)
+        r.set_dataset(ds, mask)
+        r.params.max_dist, r.adaptive_max_dist_min = 1.0, 0.15
+        r.set_micp_fast(mode)
+    est = T.mult(truth, T.transform_from_rpy((0.04, -0.02, 0.01), (0.0, 0.0, 0.01)))
+    small = T.transform_from_rpy((0.002, 0.001, 0.0), (0.0, 0.0, 0.001))
+    big = T.transform_from_rpy((0.4, 0.0, 0.0), (0.0, 0.0, 0.1))
+
+    def both(Tpre, prog):
+        a, b = rcc.computeCrossStatistics(Tpre, prog), ref.computeCrossStatistics(Tpre, prog)
+        assert int(a["n_meas"]) == int(b["n_meas"]), (int(a["n_meas"]), int(b["n_meas"]), rcc.ccs_info())
+        assert np.allclose(a["covariance"], b["covariance"], rtol=2e-5, atol=2e-6)
+        for k in "xyz":
+            assert abs(float(a["model_mean"][k]) - float(b["model_mean"][k])) < 2e-5
+        return a
+
+    for r in (rcc, ref):
+        r.find(est)
+    both(ident, 0.0)                      # pass
+    both(small, 0.0)                      # from the moments
+    i0 = rcc.ccs_info()
+    assert i0["passes"] == 1 and i0["from_moments"] == 2
+    both(small, 0.5)                      # max_dist' 0.575: outside the band -> second pass
+    both(big, 0.5)                        # outside the caps and no pass left -> streaming
+    i1 = rcc.ccs_info()
+    assert i1["passes"] == 2 and i1["from_moments"] == 3, i1
+    # a new dataset (shifted points): the old moments must not answer
+    ds2 = (ds + np.float32([0.01, 0.0, 0.0])).astype(np.float32)
+    for r in (rcc, ref):
+        r.set_dataset(ds2, mask)
+    both(small, 0.5)
+    # a new find (speculating now: the last find was followed by calls) at another pose
+    est2 = T.mult(truth, T.transform_from_rpy((-0.03, 0.02, 0.0), (0.0, 0.0, -0.015)))
+    for r in (rcc, ref):
+        r.find(est2)
+    assert rcc.ccs_info()["speculative_finds"] == 1
+    before = rcc.ccs_info()["from_moments"]
+    both(ident, 0.5)
+    both(small, 0.52)                     # within the band of the speculation (centre 0.575 * ...)
+    assert rcc.ccs_info()["from_moments"] == before + 2 and rcc.ccs_info()["passes"] == i1["passes"] + 1
+    # a gate at 3 cm on a 4-6 cm perturbation: most correspondences are undecided -> streaming, same numbers
+    for r in (rcc, ref):
+        r.params.max_dist = r.adaptive_max_dist_min = 0.03
+        r.find(est)
+    both(ident, 0.0)
+    both(small, 0.0)
+    # modelView after a speculating find is the find's own output
+    mv, mv0 = rcc.modelView(), ref.modelView()
+    assert np.array_equal(mv["face_ids"], mv0["face_ids"]) and np.array_equal(mv["hits"], mv0["hits"])
+    assert np.array_equal(mv["points"], mv0["points"], equal_nan=True)
+    rcc.close()
+    ref.close()

@@ -153,3 +153,83 @@ def test_device_loop_refuses_what_it_cannot_deliver(ra):
     loc9 = ra.MICPLocalization(sensors, optimization_iterations=3)
     with pytest.raises(ValueError, match="8 sensors"):
         loc9.correctOnce(device_loop=True)
+
+
+# ---- round 4: the host half of the gate-stable moment form (rmcl_amd/csrc/micp_host.h) ---------------------------------------
+def _host_moment_stats(ra, D, I, N, valid, lo, hi, rho_cap, tau_cap, Tpre, maxd):
+    import ctypes as C
+    from rmcl_amd import types as T
+    L = ra._capi.lib()
+    out = np.zeros(1, dtype=T.CROSS_STATISTICS)
+    nu, cov = C.c_uint32(0), C.c_int(0)
+    Tp = np.ascontiguousarray(Tpre, dtype=T.TRANSFORM).reshape(1)
+    vp = None if valid is None else valid.ctypes.data
+    st = L.rmclhip_host_moment_statistics(D.ctypes.data, I.ctypes.data, N.ctypes.data, vp, len(D), lo, hi, rho_cap, tau_cap,
+                                          Tp.ctypes.data, maxd, out.ctypes.data, C.byref(nu), C.byref(cov))
+    assert st == 0
+    return out[0], nu.value, bool(cov.value)
+
+
+def _random_correspondences(n, seed, spread=1.0):
+    rng = np.random.default_rng(seed)
+    D = (rng.normal(size=(n, 3)) * 6.0).astype(np.float32)
+    N = rng.normal(size=(n, 3))
+    N = (N / np.linalg.norm(N, axis=1, keepdims=True)).astype(np.float32)
+    # model point = dataset point + an offset whose component along N is spread around the gate
+    off = rng.normal(size=(n, 3)) * 0.3 + N * (rng.uniform(-1.6, 1.6, size=(n, 1)) * spread)
+    I = (D + off).astype(np.float32)
+    valid = (rng.uniform(size=n) > 0.1).astype(np.uint8)
+    return np.ascontiguousarray(D), np.ascontiguousarray(I), np.ascontiguousarray(N), valid
+
+
+def test_host_moment_form_equals_the_per_element_loop(ra, orc):
+    """statistics_p2l evaluated from the 82 moments + the undecided correspondences == the oracle's per-element loop
+    (MICPSensorCPU.cpp:70-84) for pre-transforms inside the caps: identical n_meas, means / covariance to f32 rounding."""
+    from rmcl_amd import types as T
+    D, I, N, valid = _random_correspondences(6000, 7, spread=1.0)
+    rng = np.random.default_rng(11)
+    maxd = 1.0
+    hits = 0
+    for trial in range(12):
+        ang = rng.uniform(0, 0.0019)
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        tr = rng.normal(size=3)
+        tr = tr / np.linalg.norm(tr) * rng.uniform(0, 0.0019)
+        q = np.concatenate([axis * math.sin(ang / 2), [math.cos(ang / 2)]])
+        Tpre = T.transform(q=tuple(float(x) for x in q), t=tuple(float(x) for x in tr))
+        s, nu, cov = _host_moment_stats(ra, D, I, N, valid, maxd, maxd, 0.002, 0.002, Tpre, maxd)
+        assert cov and nu <= 256
+        ref = orc.statistics_p2l_f64(Tpre, D, valid, I, N, np.ones(len(D), np.uint8), maxd)
+        assert int(s["n_meas"]) == ref["n_meas"] and ref["n_meas"] > 1500
+        hits += nu
+        for i, k in enumerate("xyz"):
+            assert abs(float(s["dataset_mean"][k]) - ref["dataset_mean"][i]) < 2e-6 * (1 + abs(ref["dataset_mean"][i]))
+            assert abs(float(s["model_mean"][k]) - ref["model_mean"][i]) < 2e-6 * (1 + abs(ref["model_mean"][i]))
+        assert np.allclose(s["covariance"].reshape(3, 3), ref["covariance"], rtol=2e-6, atol=2e-5)
+    assert hits > 0   # the undecided path was exercised
+
+
+def test_host_moment_form_band_and_caps(ra, orc):
+    """a set formed for a BAND of max_dist' answers every value in the band exactly (n_meas identical to the per-element loop) and
+    refuses (covered = 0) values outside it and pre-transforms outside the caps; NaN / masked-out points contribute nothing."""
+    from rmcl_amd import types as T
+    D, I, N, valid = _random_correspondences(1200, 3, spread=0.4)
+    D[5] = np.nan
+    valid[5] = 1
+    Tpre = T.identity()
+    lo, hi = 0.5, 0.58
+    for maxd in (0.5, 0.53, 0.58):
+        s, nu, cov = _host_moment_stats(ra, D, I, N, valid, lo, hi, 0.001, 0.001, Tpre, maxd)
+        assert cov
+        ref = orc.statistics_p2l_f64(Tpre, D, valid, I, N, np.ones(len(D), np.uint8), maxd)
+        assert int(s["n_meas"]) == ref["n_meas"]
+        assert np.allclose(s["covariance"].reshape(3, 3), ref["covariance"], rtol=2e-6, atol=2e-5)
+    for maxd in (0.49, 0.6):
+        assert not _host_moment_stats(ra, D, I, N, valid, lo, hi, 0.001, 0.001, Tpre, maxd)[2]
+    far = T.transform(t=(0.05, 0.0, 0.0))
+    assert not _host_moment_stats(ra, D, I, N, valid, lo, hi, 0.001, 0.001, far, 0.53)[2]
+    # more undecided correspondences than the host takes: not covered
+    D2, I2, N2, v2 = _random_correspondences(20000, 5, spread=0.05)
+    s, nu, cov = _host_moment_stats(ra, D2, I2, N2, v2, 0.05, 0.08, 0.05, 0.05, Tpre, 0.06)
+    assert nu > 256 and not cov
