@@ -130,6 +130,7 @@ def main():
     cores = os.cpu_count() or 1
     extras = {}
     cpu = None
+    pose_batches = None
 
     if args.workload == "c2":
         model = syn.model_c2()
@@ -393,6 +394,10 @@ def main():
             blk = _pf_sharded_block(ra, syn, T, np, torch, dist, ctx, rank, world)
             if rank == 0:
                 extras["pf_sharded"] = blk
+            # pose batches over the ranks (no exchange): the N-GPU pose-corrections/s
+            pose_batches = _pose_batch_block(ra, syn, T, np, torch, dist, hm, rank, world)
+            if rank == 0:
+                extras["pose_batches"] = pose_batches
 
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -520,7 +525,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "units_per_step_per_gpu": units_per_step, "triangles": int(len(f)),
                        "parallelism": parallelism, "kernel_variant": args.variant},
-            "pose_corrections_per_s": extras.get("c3_schedule_R_pose_corrections_per_s"),
+            # whole-job pose-corrections/s (aggregate over the ranks, weak: a batch per GPU) for the reference's own batch shape and
+            # for full-size scans; the single-scan 10-iteration correction (C3 schedule R) does not shard: rank 0's figure, per rank
+            "pose_corrections_per_s": {
+                "batch_1000x16x900": (pose_batches or {}).get("batch_1000x16x900", {}).get("weak", {}).get("pose_corrections_per_s"),
+                "batch_64x128x1024": (pose_batches or {}).get("batch_64x128x1024", {}).get("weak", {}).get("pose_corrections_per_s"),
+                "n_gpus": world, "scaling": "weak (one batch per GPU, block-partitioned pose lists, no collective)",
+                "single_scan_10_iterations_per_rank": extras.get("c3_schedule_R_pose_corrections_per_s"),
+                "single_scan_unchanged_caller_loop_per_rank": extras.get("c3_schedule_R_unchanged_caller_pose_corrections_per_s")},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "extras": extras,
@@ -590,6 +602,63 @@ def _cpu_quota():
             continue
     eff = n if quota is None else max(1, min(n, int(math.ceil(quota))))
     return eff, n, quota
+
+
+def _pose_batch_block(ra, syn, T, np, torch, dist, hm, rank, world):
+    """pose-corrections/s over ranks (north_star: "at 1/2/4/8 GPUs"; SURVEY.md 8(e): pose batches shard by pose, no exchange): the
+    v1 corrector shape of the reference's own benchmark -- 1000 poses x one 16x900 scan per correct()
+    (lidar_corrector_optix_benchmark.cpp:86-133) -- and 64 poses x 128x1024, on the 100k-triangle sphere.
+    weak: every rank corrects a whole batch of its own (what bench.py's `scaling` says); strong: ONE batch block-partitioned over the
+    ranks with distributed.ShardedBatchCorrector.  Timed like the headline: barrier + synchronize on both sides, max over ranks."""
+    from rmcl_amd import distributed as D
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def reduce_max(x):
+        if dist is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    out = {"partition": "block partition of the pose list (rmcl_amd.distributed.shard_bounds), map replicated, NO collective on the data path",
+           "reference_shape": "lidar_corrector_optix_benchmark.cpp:86-133 (1000 poses per correct(), vlp16_900)"}
+    truth = syn.pose_c2_truth()
+    for key, model, nposes, reps in (("batch_1000x16x900", syn.model_vlp16_900(0.0), 1000, 5), ("batch_64x128x1024", syn.model_c2(), 64, 5)):
+        rcc = ra.RCCHipSpherical(hm)
+        rcc.setTsb(T.identity())
+        rcc.setModel(model)
+        rcc.find(truth)
+        rcc.set_dataset_from_ranges(rcc.modelView()["ranges"])
+        rcc.params.max_dist = rcc.adaptive_max_dist_min = 1.0
+        rng = np.random.RandomState(1000 + rank)          # weak: a batch of its own per rank
+        mine = np.array([T.mult(truth, T.transform_from_rpy(tuple(rng.uniform(-0.2, 0.2, 3)), (0, 0, rng.uniform(-0.05, 0.05))))
+                         for _ in range(nposes)], dtype=T.TRANSFORM)
+        rng0 = np.random.RandomState(999)                  # strong: the SAME list on every rank
+        shared = np.array([T.mult(truth, T.transform_from_rpy(tuple(rng0.uniform(-0.2, 0.2, 3)), (0, 0, rng0.uniform(-0.05, 0.05))))
+                           for _ in range(nposes)], dtype=T.TRANSFORM)
+        sh = D.ShardedBatchCorrector(lambda blk: rcc.correct_batch(blk), rank, world)
+        res = {}
+        for mode in ("weak", "strong"):
+            fn = (lambda: rcc.correct_batch(mine)) if mode == "weak" else (lambda: sh.correct(shared))
+            fn()
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            dt = reduce_max(time.perf_counter() - t0) / reps
+            total = nposes * (world if mode == "weak" else 1)
+            res[mode] = {"ms_per_batch": round(dt * 1e3, 4), "poses_per_batch_all_ranks": total,
+                         "pose_corrections_per_s": round(total / dt, 1)}
+            sync_all()
+        out[key] = res
+        rcc.close()
+    return out
 
 
 def _pf_sharded_block(ra, syn, T, np, torch, dist, ctx, rank, world, n_local=125000, n_beams=256, n_tri=1000000):

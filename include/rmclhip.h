@@ -141,6 +141,7 @@ typedef struct rmclhip_pf rmclhip_pf;
 typedef struct rmclhip_resampler rmclhip_resampler;
 typedef struct rmclhip_comm rmclhip_comm;              /* RCCL communicators of one process driving several devices */
 typedef struct rmclhip_pf_sharded rmclhip_pf_sharded;  /* a particle cloud block-partitioned over those devices */
+typedef struct rmclhip_rcc_sharded rmclhip_rcc_sharded; /* one correspondence operator per device: pose batches block-partitioned */
 
 /* ---- library ------------------------------------------------------------------ */
 const char* rmclhip_last_error(void);
@@ -339,6 +340,24 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
  * T_new[i] = Tbm[i] * Tdelta_out[i]. */
 rmclhip_status rmclhip_rcc_correct_batch(rmclhip_rcc* rcc, const rmclhip_transform* Tbm, uint32_t nposes,
                                          rmclhip_transform* Tdelta_out, rmclhip_cross_statistics* stats_out);
+
+/* ---- pose batches over several devices (north_star: "pose-corrections/s at 1/2/4/8 GPUs"; SURVEY 8(e): MICP pose batches shard
+ * by pose with NO exchange) -------------------------------------------------------------------------------------------------
+ * One process, one operator replica per entry of `devices` (NULL: devices 0 .. ndev-1) over ONE host BVH build.  No collective is
+ * involved, hence no RCCL communicator; an entry may repeat a device (two replicas on one GPU: of use to tests and to fill a GPU
+ * that a single stream of small batches leaves idle).  Configure every replica through its borrowed handle with the ordinary
+ * setters (rmclhip_rcc_set_tsb / _set_model_* / _set_params / _set_dataset*): the corrector does not care whether they agree.
+ * rmclhip_rcc_sharded_correct_batch = rmclhip_rcc_correct_batch (the v1 SphereCorrector::correct shape,
+ * lidar_corrector_optix_benchmark.cpp:86-133) with poses [lo, hi) = rmclhip_shard_bounds(nposes, rank, ndev) on replica `rank`:
+ * every replica's chain is enqueued before any is waited for, results arrive in pose order, bit-identical to the unsharded call
+ * (a pose's result does not depend on its neighbours in the batch). */
+rmclhip_status rmclhip_rcc_sharded_create(const int* devices, uint32_t ndev, const float* vertices_xyz, uint32_t n_vertices,
+                                          const uint32_t* faces_ijk, uint32_t n_faces, rmclhip_rcc_sharded** out);
+void rmclhip_rcc_sharded_destroy(rmclhip_rcc_sharded* h);
+uint32_t rmclhip_rcc_sharded_size(const rmclhip_rcc_sharded* h);
+rmclhip_status rmclhip_rcc_sharded_replica(rmclhip_rcc_sharded* h, uint32_t rank, rmclhip_rcc** rcc_borrowed);
+rmclhip_status rmclhip_rcc_sharded_correct_batch(rmclhip_rcc_sharded* h, const rmclhip_transform* Tbm, uint32_t nposes,
+                                                 rmclhip_transform* Tdelta_out, rmclhip_cross_statistics* stats_out);
 
 /* kernel timing of the last find / reduction on the handle's stream (hipEvent, ms) */
 rmclhip_status rmclhip_rcc_last_kernel_ms(rmclhip_rcc* rcc, float* find_ms, float* reduce_ms);

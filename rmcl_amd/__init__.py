@@ -10,7 +10,7 @@ from . import pf  # noqa: F401
 from .pf import (GladiatorResamplerHip, PCDSensorUpdaterHip, ResidualResamplerHip, ShardedParticleFilterHip, TFMotionUpdaterHip,  # noqa: F401
                  beams_from_points, combined_forget_rate, sample_beams)
 from .registration import (CPCHip, Context, CorrespondencesHIP, DeviceArray, HipMap, MapMap, RCCHipO1Dn,  # noqa: F401
-                           RCCHipOnDn, RCCHipPinhole, RCCHipSpherical, build_bvh_host, build_bvh_host_pf, build_bvh_host_quantised,
+                           RCCHipOnDn, RCCHipPinhole, RCCHipSpherical, ShardedCorrectorHip, build_bvh_host, build_bvh_host_pf, build_bvh_host_quantised,
                            flatten_scene_host, import_hip_map, import_hip_scene)
 
 from ._capi import load_lab  # noqa: F401  (experiments library; tools/ and the `lab` tests only)

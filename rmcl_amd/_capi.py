@@ -144,6 +144,11 @@ SIGNATURES = {
     "rmclhip_rcc_correct_once": (_i32, [_vp, _vp, _vp, _u32, _dbl, _i32, _vp, _vp]),
     "rmclhip_micp_correct_once": (_i32, [_vp, _u32, _vp, _vp, _vp, _u32, _dbl, _vp, _vp]),
     "rmclhip_rcc_correct_batch": (_i32, [_vp, _vp, _u32, _vp, _vp]),
+    "rmclhip_rcc_sharded_create": (_i32, [_vp, _u32, _vp, _u32, _vp, _u32, _pp]),
+    "rmclhip_rcc_sharded_destroy": (None, [_vp]),
+    "rmclhip_rcc_sharded_size": (_u32, [_vp]),
+    "rmclhip_rcc_sharded_replica": (_i32, [_vp, _u32, _pp]),
+    "rmclhip_rcc_sharded_correct_batch": (_i32, [_vp, _vp, _u32, _vp, _vp]),
     "rmclhip_rcc_last_kernel_ms": (_i32, [_vp, C.POINTER(_f32), C.POINTER(_f32)]),
     "rmclhip_rcc_time_find": (_i32, [_vp, _vp, _u32, C.POINTER(_f32)]),
     "rmclhip_rcc_autotune": (_i32, [_vp, _vp, C.POINTER(_i32), C.POINTER(_f32)]),

@@ -2219,6 +2219,136 @@ rmclhip_status rmclhip_rcc_correct_batch(rmclhip_rcc* r, const rmclhip_transform
   return RMCLHIP_OK;
 }
 
+// ---- pose batches sharded over devices (north_star: pose-corrections/s at 1/2/4/8 GPUs; SURVEY 8(e): "MICP pose batches: shard
+// poses, no exchange at all").  One process, one operator replica per device over ONE host BVH build (as rmclhip_pf_sharded_create
+// does for the filter); the poses of a batch are block-partitioned with shard_bounds, every replica's chain (pose upload, find over
+// its block, reduction, per-pose solve, results to pinned host memory) is ENQUEUED before any is waited for, so the devices run
+// concurrently; no collective, hence no RCCL.  Replaces the loop of lidar_corrector_optix_benchmark.cpp:86-133 (1000 poses per
+// correct()) when one GPU is not enough.
+}  // extern "C"
+
+extern "C" {
+static void shard_bounds(uint32_t n, uint32_t rank, uint32_t world, uint32_t* lo, uint32_t* hi);
+}
+
+struct RccRank {
+  rmclhip_ctx* ctx = nullptr;
+  rmclhip_map* map = nullptr;
+  rmclhip_rcc* rcc = nullptr;
+  xform* h_Tdelta = nullptr;   // pinned staging of this replica's block
+  cstats* h_stats = nullptr;
+  uint32_t cap = 0;
+};
+struct rmclhip_rcc_sharded {
+  std::vector<RccRank> ranks;
+};
+
+extern "C" {
+
+void rmclhip_rcc_sharded_destroy(rmclhip_rcc_sharded* h) {
+  if (!h) return;
+  for (RccRank& R : h->ranks) {
+    if (R.ctx) (void)hipSetDevice(R.ctx->device);
+    if (R.h_Tdelta) (void)hipHostFree(R.h_Tdelta);
+    if (R.h_stats) (void)hipHostFree(R.h_stats);
+    if (R.rcc) rmclhip_rcc_destroy(R.rcc);
+    if (R.map) rmclhip_map_release(R.map);
+    if (R.ctx) rmclhip_ctx_destroy(R.ctx);
+  }
+  delete h;
+}
+
+rmclhip_status rmclhip_rcc_sharded_create(const int* devices, uint32_t ndev, const float* v, uint32_t nv, const uint32_t* f, uint32_t nf,
+                                          rmclhip_rcc_sharded** out) {
+  ApiGuard guard_("rmclhip_rcc_sharded_create");
+  if (!out) return fail(RMCLHIP_ERR_INVALID, "rcc_sharded_create: out is null");
+  *out = nullptr;
+  if (ndev == 0 || ndev > 64) return fail(RMCLHIP_ERR_INVALID, "rcc_sharded_create: ndev must be 1..64");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(RMCLHIP_ERR_NO_DEVICE, "no HIP device available (librmclhip has no CPU fallback)");
+  for (uint32_t i = 0; i < ndev; ++i) {
+    const int d = devices ? devices[i] : static_cast<int>(i);
+    if (d < 0 || d >= count) return fail(RMCLHIP_ERR_INVALID, "rcc_sharded_create: device index out of range");
+  }
+  BvhHost bvh;   // built ONCE, uploaded to every device
+  const std::string err = build_bvh(v, nv, f, nf, bvh);
+  if (!err.empty()) return fail(RMCLHIP_ERR_INVALID, "rcc_sharded_create: " + err);
+  rmclhip_rcc_sharded* h = new rmclhip_rcc_sharded();
+  h->ranks.resize(ndev);
+  for (uint32_t r = 0; r < ndev; ++r) {
+    RccRank& R = h->ranks[r];
+    rmclhip_status st = rmclhip_ctx_create(devices ? devices[r] : static_cast<int>(r), &R.ctx);
+    if (st == RMCLHIP_OK) st = map_upload(R.ctx, bvh, &R.map);
+    if (st == RMCLHIP_OK) st = rmclhip_rcc_create(R.ctx, R.map, &R.rcc);
+    if (st != RMCLHIP_OK) {
+      const std::string msg = g_err;
+      rmclhip_rcc_sharded_destroy(h);
+      return fail(st, "rcc_sharded_create: " + msg);
+    }
+  }
+  *out = h;
+  return RMCLHIP_OK;
+}
+
+uint32_t rmclhip_rcc_sharded_size(const rmclhip_rcc_sharded* h) { return h ? static_cast<uint32_t>(h->ranks.size()) : 0u; }
+
+rmclhip_status rmclhip_rcc_sharded_replica(rmclhip_rcc_sharded* h, uint32_t rank, rmclhip_rcc** out) {
+  if (!h || !out || rank >= h->ranks.size()) return fail(RMCLHIP_ERR_INVALID, "rcc_sharded_replica: bad arguments");
+  *out = h->ranks[rank].rcc;
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_sharded_correct_batch(rmclhip_rcc_sharded* h, const rmclhip_transform* Tbm, uint32_t nposes,
+                                                 rmclhip_transform* Tdelta_out, rmclhip_cross_statistics* stats_out) {
+  ApiGuard guard_("rmclhip_rcc_sharded_correct_batch");
+  if (!h || !Tbm || !Tdelta_out) return fail(RMCLHIP_ERR_INVALID, "rcc_sharded_correct_batch: null");
+  if (nposes == 0) return RMCLHIP_OK;
+  const uint32_t world = static_cast<uint32_t>(h->ranks.size());
+  // phase 1: every replica's chain is enqueued (nothing here waits for a device)
+  for (uint32_t rk = 0; rk < world; ++rk) {
+    RccRank& R = h->ranks[rk];
+    rmclhip_rcc* r = R.rcc;
+    uint32_t lo, hi;
+    shard_bounds(nposes, rk, world, &lo, &hi);
+    const uint32_t cnt = hi - lo;
+    if (cnt == 0) continue;
+    if (r->kind == kModelNone || r->W == 0 || r->H == 0) return fail(RMCLHIP_ERR_INVALID, "rcc_sharded_correct_batch: a replica has no sensor model");
+    if (cnt > 32768) return fail(RMCLHIP_ERR_UNSUPPORTED, "rcc_sharded_correct_batch: at most 32768 poses per device and call");
+    if (r->n_dataset != static_cast<size_t>(r->W) * r->H) return fail(RMCLHIP_ERR_INVALID, "rcc_sharded_correct_batch: dataset size != model size");
+    HIPCHK(hipSetDevice(R.ctx->device));
+    if (cnt > R.cap) {
+      if (R.h_Tdelta) { (void)hipHostFree(R.h_Tdelta); R.h_Tdelta = nullptr; }
+      if (R.h_stats) { (void)hipHostFree(R.h_stats); R.h_stats = nullptr; }
+      R.cap = 0;
+      HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&R.h_Tdelta), sizeof(xform) * cnt, hipHostMallocDefault));
+      HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&R.h_stats), sizeof(cstats) * cnt, hipHostMallocDefault));
+      R.cap = cnt;
+    }
+    HIPCHK(r->d_Tdelta.reserve(cnt)); HIPCHK(r->d_bstats.reserve(cnt));
+    if (rmclhip_status st = find_batch_enqueue(r, Tbm + lo, cnt)) return st;
+    ReduceTail tail;
+    tail.mode = kTailBatchSolve;
+    tail.Tdelta_out = r->d_Tdelta.p;
+    tail.stats_out = r->d_bstats.p;
+    if (rmclhip_status st = reduce_enqueue(r, xidentity(), nullptr, r->max_dist, cnt, tail)) return st;
+    HIPCHK(hipMemcpyAsync(R.h_Tdelta, r->d_Tdelta.p, sizeof(xform) * cnt, hipMemcpyDeviceToHost, r->stream));
+    if (stats_out) HIPCHK(hipMemcpyAsync(R.h_stats, r->d_bstats.p, sizeof(cstats) * cnt, hipMemcpyDeviceToHost, r->stream));
+  }
+  // phase 2: wait for each and hand its block over
+  for (uint32_t rk = 0; rk < world; ++rk) {
+    RccRank& R = h->ranks[rk];
+    uint32_t lo, hi;
+    shard_bounds(nposes, rk, world, &lo, &hi);
+    if (hi == lo) continue;
+    HIPCHK(hipSetDevice(R.ctx->device));
+    HIPCHK(hipStreamSynchronize(R.rcc->stream));
+    std::memcpy(Tdelta_out + lo, R.h_Tdelta, sizeof(xform) * (hi - lo));
+    if (stats_out) std::memcpy(stats_out + lo, R.h_stats, sizeof(cstats) * (hi - lo));
+  }
+  return RMCLHIP_OK;
+}
+
 rmclhip_status rmclhip_rcc_last_kernel_ms(rmclhip_rcc* r, float* find_ms, float* reduce_ms) {
   ApiGuard guard_("rmclhip_rcc_last_kernel_ms");
   if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_last_kernel_ms: null");

@@ -130,3 +130,27 @@ class ShardedResample:
         poses_all = allgather_records(poses_local, self.n_total, group)
         attrs_all = allgather_records(attrs_local, self.n_total, group)
         return self.resample_fn(poses_all, attrs_all, self.n_total, self.lo, self.hi - self.lo)
+
+
+class ShardedBatchCorrector:
+    """MICP pose batches over ranks (north_star: pose-corrections/s at 1/2/4/8 GPUs; SURVEY.md 8(e): "shard poses, no exchange").
+    Every rank holds the same operator configuration (map replicated, same model / dataset / parameters) and the same pose list;
+    rank r corrects the block shard_bounds(nposes, r, world) with its own `correct_fn(Tbm_block) -> (Tdelta_block, stats_block)`
+    (RCCHip*.correct_batch on GPUs, the oracle in the CPU tests).  The data path has NO collective: a pose's correction does not
+    depend on any other pose.  `gather=True` adds ONE all-gather of the 32-B deltas (1000 poses: 32 kB) for callers that want the
+    whole vector on every rank (the v1 benchmark's T_curr = multNxN(T_curr, Tdelta) on one host)."""
+
+    def __init__(self, correct_fn, rank, world):
+        self.correct_fn = correct_fn
+        self.rank, self.world = int(rank), int(world)
+
+    def correct(self, Tbm_all, gather=False, group=None):
+        n = len(Tbm_all)
+        lo, hi = shard_bounds(n, self.rank, self.world)
+        Td, st = self.correct_fn(Tbm_all[lo:hi]) if hi > lo else (Tbm_all[:0].copy(), None)
+        if not gather:
+            return lo, hi, Td, st
+        import torch
+        rec = np.ascontiguousarray(Td).view(np.uint8).reshape(hi - lo, 32)
+        dense = allgather_records(torch.from_numpy(rec.copy()), n, group)
+        return lo, hi, dense.numpy().reshape(-1).view(Td.dtype).copy(), st

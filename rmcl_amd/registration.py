@@ -499,8 +499,72 @@ class CorrespondencesHIP:
                                                        float(self.adaptive_max_dist_min)))
 
     def close(self):
-        if self._h:
+        if self._h and not getattr(self, "_borrowed", False):
             _capi.lib().rmclhip_rcc_destroy(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @classmethod
+    def _borrow(cls, handle):
+        """wrap an operator handle owned by someone else (a replica of ShardedCorrectorHip): never destroyed from here"""
+        self = cls.__new__(cls)
+        self.map = self.ctx = None
+        self.params = UmeyamaReductionConstraints(1.0)
+        self.adaptive_max_dist_min = 1.0
+        self.outdated = True
+        self._h = C.c_void_p(handle)
+        self._borrowed = True
+        self._model_shape = (0, 0)
+        self._last_nposes = 1
+        return self
+
+
+class ShardedCorrectorHip:
+    """Pose batches of the v1 SphereCorrector::correct shape (lidar_corrector_optix_benchmark.cpp:86-133) over several devices of ONE
+    process (rmclhip_rcc_sharded_*): one operator replica per device over one host BVH build, poses block-partitioned with
+    distributed.shard_bounds, no exchange.  `replica_class` is the operator type of the replicas (RCCHipSpherical, RCCHipO1Dn, ...);
+    configure them through `.replicas` (or `.for_each`), then `.correct_batch(Tbm)` == the unsharded RCCHip*.correct_batch."""
+
+    def __init__(self, devices, vertices, faces, replica_class=None):
+        v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+        f = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self._h = C.c_void_p()
+        _capi.check(_capi.lib().rmclhip_rcc_sharded_create(devs, len(devices), _ptr(v), len(v), _ptr(f), len(f), C.byref(self._h)))
+        cls = replica_class or RCCHipSpherical
+        self.replicas = []
+        for r in range(len(devices)):
+            h = C.c_void_p()
+            _capi.check(_capi.lib().rmclhip_rcc_sharded_replica(self._h, r, C.byref(h)))
+            self.replicas.append(cls._borrow(h.value))
+
+    @property
+    def world(self):
+        return len(self.replicas)
+
+    def for_each(self, fn):
+        for r in self.replicas:
+            fn(r)
+
+    def correct_batch(self, Tbm, want_stats=True):
+        for r in self.replicas:
+            r._push_params()
+        T = np.ascontiguousarray(Tbm, dtype=TRANSFORM).reshape(-1)
+        out = np.zeros(len(T), dtype=TRANSFORM)
+        st = np.zeros(len(T), dtype=CROSS_STATISTICS)
+        _capi.check(_capi.lib().rmclhip_rcc_sharded_correct_batch(self._h, _ptr(T), len(T), _ptr(out), _ptr(st) if want_stats else None))
+        return out, st
+
+    def close(self):
+        if self._h:
+            for r in self.replicas:
+                r.close()
+            _capi.lib().rmclhip_rcc_sharded_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

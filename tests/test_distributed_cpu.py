@@ -141,3 +141,57 @@ def test_c_abi_shard_bounds_and_comm_without_device(ra):
         assert b"no HIP device" in L.rmclhip_last_error()
     assert L.rmclhip_comm_create(None, 0, C.byref(C.c_void_p())) == ra._capi.ERR_INVALID
     assert L.rmclhip_comm_size(None) == 0
+
+
+# ---- pose batches sharded over ranks (north_star: pose-corrections/s at 1/2/4/8 GPUs; SURVEY.md 8(e): no exchange) ----------------
+def _pose_worker(rank, world, port, nposes, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import oracle as orc
+    import oracle_micp as om
+    from rmcl_amd import distributed as D, synthetic as syn, types as T
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        v, f = syn.cube_room()
+        m = orc.Mesh(v, f)
+        model = syn.model_c1()
+        Tsb = syn.tsb_offset()
+        truth = T.transform_from_rpy((0.5, -0.3, 0.2), (0.0, 0.0, 0.3))
+        meas = m.simulate_spherical(model, Tsb, truth, bvh=True)
+        ds, mask = om.dataset_from_ranges(model, meas["ranges"])
+        rng = np.random.RandomState(5)
+        poses = np.array([T.mult(truth, T.transform_from_rpy(tuple(rng.uniform(-0.2, 0.2, 3)), (0.0, 0.0, rng.uniform(-0.05, 0.05))))
+                          for _ in range(nposes)], dtype=T.TRANSFORM)
+
+        def correct_fn(block):   # TEST STUB with RCCHip*.correct_batch's call surface, the CPU oracle inside
+            return om.correct_batch(m, model, Tsb, block, ds, mask, 1.0)
+
+        sh = D.ShardedBatchCorrector(correct_fn, rank, world)
+        lo, hi, Td_local, st_local = sh.correct(poses)
+        _, _, Td_all, _ = sh.correct(poses, gather=True)
+        Tr, sr = om.correct_batch(m, model, Tsb, poses, ds, mask, 1.0)      # unpartitioned, on every rank
+        ok = (lo, hi) == D.shard_bounds(nposes, rank, world)
+        ok &= np.asarray(Td_local).tobytes() == np.asarray(Tr[lo:hi]).tobytes()
+        ok &= np.asarray(Td_all).tobytes() == np.asarray(Tr).tobytes()
+        if hi > lo:
+            ok &= all(int(a["n_meas"]) == int(b["n_meas"]) for a, b in zip(st_local, sr[lo:hi]))
+        with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as fh:
+            fh.write("OK" if ok else "MISMATCH")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nposes", [(2, 10), (3, 7), (3, 2)])
+def test_sharded_pose_batch_equals_unpartitioned(tmp_path, world, nposes):
+    """the partitioned batch corrector (each rank its block of the pose list, no data-path collective; an optional all-gather of the
+    32-B deltas) returns exactly what the unpartitioned call returns -- ragged blocks and ranks without a pose included."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_pose_worker, args=(world, port, nposes, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert (tmp_path / ("rank%d.txt" % r)).read_text() == "OK"

@@ -153,3 +153,49 @@ def test_c_abi_sharded_particle_filter_on_one_device(ra, orc, ctx, meshes):
     assert a5.tobytes() != a3.tobytes()
     rr.close()
     sh.close()
+
+
+@pytest.mark.parametrize("devices", [(0,), (0, 0), (0, 0, 0)])
+def test_c_abi_sharded_pose_batch_equals_unsharded(ra, orc, ctx, meshes, devices):
+    """rmclhip_rcc_sharded_correct_batch: one operator replica per entry of `devices` over ONE host BVH build, the poses of the batch
+    block-partitioned, every replica's chain enqueued before any is waited for.  A one-GPU box runs the ndev > 1 branches with
+    several replicas on device 0 (allowed: no collective is involved): bit-identical to rmclhip_rcc_correct_batch of one operator,
+    ragged partitions and a batch smaller than the number of replicas included; against the oracle to 1e-5."""
+    import oracle_micp as om
+    from rmcl_amd import synthetic as syn, types as T
+    from test_gpu_reduce import _transform_close
+    v, f = meshes("sphere20k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    model = syn.model_vlp16_900(0.0)
+    Tsb = syn.tsb_offset()
+    ident = T.identity()
+    meas = m.simulate_spherical(model, Tsb, ident, bvh=True, nthreads=8)
+    ds, mask = om.dataset_from_ranges(model, meas["ranges"])
+    rng = np.random.RandomState(21)
+    poses = np.array([T.transform_from_rpy(tuple(rng.uniform(-0.3, 0.3, 3)), (0.0, 0.0, rng.uniform(-0.05, 0.05)))
+                      for _ in range(23)], dtype=T.TRANSFORM)
+
+    def configure(r):
+        r.setTsb(Tsb)
+        r.setModel(model)
+        r.set_dataset(ds, mask)
+        r.params.max_dist = r.adaptive_max_dist_min = 1.0
+
+    one = ra.RCCHipSpherical(hm)
+    configure(one)
+    sh = ra.ShardedCorrectorHip(devices, v, f)
+    assert sh.world == len(devices)
+    sh.for_each(configure)
+    for n in (23, 2, 1):
+        Td1, st1 = one.correct_batch(poses[:n])
+        for _ in range(2):    # twice: the staging buffers are reused
+            Td, st = sh.correct_batch(poses[:n])
+            assert Td.tobytes() == Td1.tobytes() and st.tobytes() == st1.tobytes()
+    Tr, sr = om.correct_batch(m, model, Tsb, poses, ds, mask, 1.0, nthreads=8)
+    Td, st = sh.correct_batch(poses)
+    for i in range(len(poses)):
+        assert int(st[i]["n_meas"]) == int(sr[i]["n_meas"])
+        _transform_close(Td[i], Tr[i], 1e-5)
+    sh.close()
+    one.close()

@@ -740,9 +740,11 @@ def test_caller_loop_moment_cache_is_dropped_by_what_invalidates_it(ra, orc, ctx
     i0 = rcc.ccs_info()
     assert i0["passes"] == 1 and i0["from_moments"] == 2
     both(small, 0.5)                      # max_dist' 0.575: outside the band -> second pass
-    both(big, 0.5)                        # outside the caps and no pass left -> streaming
+    both(small, 0.9)                      # max_dist' 0.235: outside the band again and no pass left -> streaming
     i1 = rcc.ccs_info()
     assert i1["passes"] == 2 and i1["from_moments"] == 3, i1
+    both(small, 0.5)                      # (the set of the second pass still answers its own band)
+    assert rcc.ccs_info()["from_moments"] == 4
     # a new dataset (shifted points): the old moments must not answer
     ds2 = (ds + np.float32([0.01, 0.0, 0.0])).astype(np.float32)
     for r in (rcc, ref):
@@ -757,6 +759,7 @@ def test_caller_loop_moment_cache_is_dropped_by_what_invalidates_it(ra, orc, ctx
     both(ident, 0.5)
     both(small, 0.52)                     # within the band of the speculation (centre 0.575 * ...)
     assert rcc.ccs_info()["from_moments"] == before + 2 and rcc.ccs_info()["passes"] == i1["passes"] + 1
+    both(big, 0.5)                        # a pre-transform outside the caps: a pass with wider caps (everything undecided) -> streaming
     # a gate at 3 cm on a 4-6 cm perturbation: most correspondences are undecided -> streaming, same numbers
     for r in (rcc, ref):
         r.params.max_dist = r.adaptive_max_dist_min = 0.03
