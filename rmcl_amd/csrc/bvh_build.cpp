@@ -41,7 +41,13 @@ struct Node2 {
 };
 
 constexpr int kMaxBins = 64;
-static int kBins = 16;
+// SAH bins per axis.  16 is the product's choice; RMCLHIP_BINS (2..64) is a STUDY knob of tools/ (tree quality vs build time), read
+// ONCE per process -- never written afterwards, so concurrent builds (rmclhip_*_sharded_create) see one constant
+static int bins_from_env() {
+  const char* e = std::getenv("RMCLHIP_BINS");
+  return e ? std::max(2, std::min(kMaxBins, std::atoi(e))) : 16;
+}
+static const int kBins = bins_from_env();
 
 struct Builder {
   const std::vector<Prim>& prims;
@@ -300,7 +306,6 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
     scene.grow(p.b);
   }
 
-  if (const char* e = std::getenv("RMCLHIP_BINS")) kBins = std::max(2, std::min(kMaxBins, std::atoi(e)));
   // ONE BVH2, split down to the smallest leaf size any tree of the map uses
   std::vector<uint32_t> order(nf);
   for (uint32_t f = 0; f < nf; ++f) order[f] = f;

@@ -44,7 +44,7 @@ rmclhip_status fail(rmclhip_status st, const std::string& msg) {
 #define HIPCHK(expr)                                                                              \
   do {                                                                                            \
     hipError_t e_ = (expr);                                                                       \
-    if (e_ == hipErrorNotSupported)                                                               \
+    if (e_ == kLabMissing)                                                                        \
       return fail(RMCLHIP_ERR_UNSUPPORTED, std::string(#expr) + ": this kernel variant is an experiment that lives in " \
                   "librmclhip_lab.so, which is not loaded (include/rmclhip_lab.h)");              \
     if (e_ != hipSuccess)                                                                         \
@@ -492,7 +492,7 @@ static rmclhip_status map_upload(rmclhip_ctx* ctx, const BvhHost& bvh, rmclhip_m
     return fail(e == hipErrorOutOfMemory ? RMCLHIP_ERR_NOMEM : RMCLHIP_ERR_HIP,
                 std::string("map_create upload: ") + hipGetErrorString(e));
   }
-  m->bytes = nb + qb + qpb + cb + tb + fb;
+  m->bytes = nb + qb + qpb + cb + tb + fb + fpb;
   ctx_retain(ctx);
   *out = m;
   return RMCLHIP_OK;
@@ -1061,11 +1061,19 @@ static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
     // the same BVH2 cut at leaves of <= 2 instead of <= 4 triangles, the same record array (layout.h): pose batches 6-10 % faster
     // (profiles/r03_find_variants_ab.txt).  That tree has its own node numbering, hence its own frontier table.
     const int v = find_variant(r, nposes);
+    uint32_t need = r->map->info.stack_need;
     if ((v == 24 || v == 22) && r->map->d_qnodes_pf != nullptr) {
       p.qnodes = r->map->d_qnodes_pf;
       p.frontier = r->map->d_frontier_pf;
       p.n_frontier = r->map->n_frontier_pf;
+      need = r->map->info.stack_need_pf;
     }
+    // The frontier start pre-loads a lane's stack (up to 19 entries for kind 23, 12 for kind 24, more for the quad kind); map_upload's
+    // stack_need <= 64 bounds a descent from the ROOT only.  From the frontier the descent may still push what the tree's deepest path
+    // pushes, so the start may leave at most 64 - stack_need entries (traverse.hip.h frontier_start returns the root beyond that); a
+    // tree that leaves no room for even two starts every ray at the root.
+    p.frontier_max_preload = (need < 64u) ? 64u - need : 0u;
+    if (p.frontier_max_preload < 2u) p.tile_planes = nullptr;
   }
 }
 
@@ -2922,7 +2930,8 @@ static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, 
   static const uint32_t kRefillAt[5] = {48u, 8u, 16u, 32u, 48u};
   p.refill_thr = f->refill_thr ? f->refill_thr : kRefillAt[f->refill];
   p.tail_lanes = f->tail_lanes;
-  p.nb_magic = static_cast<uint32_t>((1ull << 32) / n_beams) + 1u;   // pb * n_beams <= 8192, n_beams <= 8192: exact
+  // pb * n_beams <= 8192, n_beams <= 8192: exact.  n_beams == 1 has no 32-bit magic (2^32 + 1): the kernel takes pi = ray there
+  p.nb_magic = (n_beams == 1u) ? 0u : static_cast<uint32_t>((1ull << 32) / n_beams) + 1u;
   const int variant = (f->variant & 3) | ((std::max(f->map->info.stack_need, f->map->info.stack_need_pf) > 32) ? 4 : 0) | (f->params.correspondence_type == 1u ? 8 : 0) |
                       (f->refill << 4) | (f->full_nodes ? 128 : 0) | (f->legacy ? 256 : 0) | (f->pf_tree ? 0 : 1024);
   HIPCHK(launch_pf_update(p, variant, f->stream));
@@ -3014,15 +3023,18 @@ rmclhip_status rmclhip_pf_set_schedule(rmclhip_pf* f, uint32_t refill_idle_lanes
 rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* f, int variant) {
   ApiGuard guard_("rmclhip_pf_set_variant");
   if (!f || variant < 0 || (variant & 15) > 2 || ((variant >> 4) & 7) > 4 || (variant >> 11) != 0) return fail(RMCLHIP_ERR_INVALID, "pf_set_variant: bad arguments");
-  f->variant = variant & 15;
-  f->refill = (variant >> 4) & 7;
-  f->full_nodes = ((variant >> 7) & 1) != 0;
-  f->legacy = ((variant >> 8) & 1) != 0;      // the round-2 kernel
-  f->big_blocks = ((variant >> 9) & 1) != 0;  // 4096 instead of 2048 rays per workgroup
-  f->pf_tree = ((variant >> 10) & 1) == 0;    // bit 10: traverse the map's tree (leaves <= 4) instead of the filter's own
-  if ((f->refill == 0 || f->legacy || f->full_nodes || f->variant != 0) && lab_hooks() == nullptr)
+  const int kind = variant & 15, refill = (variant >> 4) & 7;
+  const bool full_nodes = ((variant >> 7) & 1) != 0, legacy = ((variant >> 8) & 1) != 0;
+  // validate BEFORE the handle is touched: a rejected configuration must not stay behind (every later update would fail)
+  if ((refill == 0 || legacy || full_nodes || kind != 0) && lab_hooks() == nullptr)
     return fail(RMCLHIP_ERR_UNSUPPORTED, "pf_set_variant: the round kernels and the round-2 persistent kernel are experiments -- they live in "
                                          "librmclhip_lab.so, which is not loaded");
+  f->variant = kind;
+  f->refill = refill;
+  f->full_nodes = full_nodes;
+  f->legacy = legacy;                         // the round-2 kernel
+  f->big_blocks = ((variant >> 9) & 1) != 0;  // 4096 instead of 2048 rays per workgroup
+  f->pf_tree = ((variant >> 10) & 1) == 0;    // bit 10: traverse the map's tree (leaves <= 4) instead of the filter's own
   return RMCLHIP_OK;
 }
 

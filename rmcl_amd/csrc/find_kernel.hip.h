@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
         const float* planes = p.tile_planes + static_cast<size_t>(__builtin_amdgcn_readfirstlane(tile)) * 16u;
         const TraceStart st = frontier_start<static_cast<int>(kQuadStackEntries), 1>(
             p.frontier, p.n_frontier, p.scene_center, p.scene_half_diag, planes, Tsm.R, p.tfar, org_m, dir_m, ray_tfar, threadIdx.x & 63u,
-            lds_dyn + lane, 64u);
+            lds_dyn + lane, 64u, p.frontier_max_preload);
         QuadResume rsm;
         rsm.cur = st.cur; rsm.n_stack = st.sp - 1u; rsm.best_t = ray_tfar; rsm.best_face = kInvalidFace; rsm.best_rec = 0u;
         trace_quad<true>(p.cnodes, p.tris, org_m, dir_m, ray_tfar, sub, lane, lds_dyn, h, &rsm);
@@ -342,10 +342,10 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
         const float* planes = p.tile_planes + static_cast<size_t>(__builtin_amdgcn_readfirstlane(tile)) * 16u;
         if (kTrav == 23 || (kTrav >= 26 && kTrav <= 30))
           start = frontier_start<kFindBfRows, 1>(p.frontier, p.n_frontier, p.scene_center, p.scene_half_diag, planes, Tsm.R, p.tfar, org_m,
-                                                 dir_m, ray_tfar, lane, lds_dyn + threadIdx.x, kBfStride);
+                                                 dir_m, ray_tfar, lane, lds_dyn + threadIdx.x, kBfStride, p.frontier_max_preload);
         else
           start = frontier_start<16, 0>(p.frontier, p.n_frontier, p.scene_center, p.scene_half_diag, planes, Tsm.R, p.tfar, org_m, dir_m,
-                                        ray_tfar, lane, lds_dyn + threadIdx.x, blockDim.x);
+                                        ray_tfar, lane, lds_dyn + threadIdx.x, blockDim.x, p.frontier_max_preload);
       }
     }
     if (kTrav == 4) trace_lane_ww<16, true>(p.qnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);

@@ -10,6 +10,11 @@
 
 namespace rmclhip {
 
+// what a launcher returns for a kernel variant that lives in librmclhip_lab.so while that library is not loaded: a value of its own,
+// NOT hipErrorNotSupported -- the runtime reports that for real failures (graph capture, host-allocation flags), which must stay
+// visible as what they are
+constexpr hipError_t kLabMissing = static_cast<hipError_t>(2040);
+
 enum ModelKind : uint32_t { kModelNone = 0, kModelSpherical = 1, kModelO1Dn = 2, kModelPinhole = 3, kModelOnDn = 4 };
 
 // one find() launch: every ray of (nposes x H x W)
@@ -47,6 +52,7 @@ struct FindParams {
   f3 scene_center;
   float scene_half_diag;
   const float* tile_planes;      // per tile of the scan image: the pyramid of its rays in the sensor frame (k_tile_planes), or null
+  uint32_t frontier_max_preload; // stack entries the frontier start may leave per lane: 64 - stack_need of the tree the kind walks
   // diagnostics (nullable): per physical wave {s_memtime at entry, at exit (low 32 bits), s_memrealtime at entry, tile | xcc << 24}
   uint32_t* wave_clock;
   // MICP moment epilogue (launch_find_moments, k_find<..., kMom = true>): the moments of the gate-stable form (kernels.hip) are

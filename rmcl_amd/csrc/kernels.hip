@@ -11,7 +11,7 @@
 //
 // Experiments (rejected traversal kinds, probes, the round-2 particle-filter kernels) live in kernels_lab.hip and ship in
 // librmclhip_lab.so; launch_find / launch_pf_update hand kinds they do not own to that library when it is loaded
-// (lab_hooks.h), and report hipErrorNotSupported otherwise.
+// (lab_hooks.h), and report kLabMissing (kernels.h) otherwise.
 #include "find_kernel.hip.h"
 #include "lab_hooks.h"
 #include "pf_common.hip.h"
@@ -1496,7 +1496,8 @@ __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
         const uint32_t mine = base + static_cast<uint32_t>(__popcll(want & ((1ull << lane) - 1ull)));
         if (mine < nrays) {
           rr = mine;
-          const uint32_t pi = __umulhi(rr, p.nb_magic), b = rr - pi * p.n_beams;
+          // (n_beams == 1: floor(2^32 / 1) + 1 does not fit the 32-bit magic -- every ray is its own particle)
+          const uint32_t pi = (p.n_beams == 1u) ? rr : __umulhi(rr, p.nb_magic), b = rr - pi * p.n_beams;
           const xform Tsm = s_Tsm[pi];
           const float* bm = p.beams + 16u * b;
           // meas_m = Tsm * meas_s (RangeMeasurement.hpp:28-42)
@@ -2104,7 +2105,7 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
   if (!find_kind_in_product(variant) || p.wave_clock != nullptr) {
     // an experiment's kind, or a clocked launch of any kind (tools/wave_timeline.py): librmclhip_lab.so
     if (g_lab && g_lab->find) return g_lab->find(p, kind, variant, p.wave_clock != nullptr, s);
-    return hipErrorNotSupported;
+    return kLabMissing;
   }
   const uint32_t ntiles = p.tiles_x * p.tiles_y;
   uint32_t nblocks = (variant == 2) ? ntiles : (ntiles + 3u) / 4u;
@@ -2182,7 +2183,7 @@ hipError_t launch_tile_planes(const FindParams& p, ModelKind kind, float* planes
 
 hipError_t launch_find_probe(const FindParams& p, int mode, uint32_t* probe_log, hipStream_t s) {
   if (g_lab && g_lab->find_probe) return g_lab->find_probe(p, mode, probe_log, s);
-  return hipErrorNotSupported;
+  return kLabMissing;
 }
 
 hipError_t launch_cpc_find(const uint32_t* nodes, const uint32_t* tris, const float* dataset_points, uint32_t n,
@@ -2633,7 +2634,7 @@ hipError_t launch_pf_update(const PfParams& p, int variant, hipStream_t s) {
     return hipGetLastError();
   }
   if (g_lab && g_lab->pf_update) return g_lab->pf_update(p, variant, s);
-  return hipErrorNotSupported;
+  return kLabMissing;
 }
 
 hipError_t launch_pf_motion(const uint32_t* nodes, const uint32_t* tris, xform* poses, void* attrs, uint32_t n,

@@ -421,12 +421,12 @@ hipError_t lab_find_kind(const FindParams& p, int variant, hipStream_t s) {
     case 27: return lab_find_one<27, kClock>(p, grid, lds_bf_tail, s);                           // 23 + prefetch of the hit record's normal (experiment iv)
     case 26: return lab_find_one<26, kClock>(p, grid, lds_bf_tail, s);                           // 23 on the quantised nodes
     case 25: return lab_find_one<25, kClock>(p, grid, kQuadStackEntries * 64u * sizeof(uint32_t), s);   // 2 + frontier start
-    default: return hipErrorNotSupported;
+    default: return kLabMissing;
   }
 }
 
 hipError_t lab_find(const FindParams& p, ModelKind kind, int variant, bool with_clock, hipStream_t s) {
-  if (kind != kModelSpherical) return hipErrorNotSupported;
+  if (kind != kModelSpherical) return kLabMissing;
   if (with_clock) return lab_find_kind<true>(p, variant, s);
   if (find_kind_in_product(variant)) return hipErrorInvalidValue;   // the product launches its own kinds
   return lab_find_kind<false>(p, variant, s);

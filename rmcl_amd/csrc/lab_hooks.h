@@ -1,7 +1,7 @@
 // lab_hooks.h -- the seam between librmclhip.so (product) and librmclhip_lab.so (experiments).  The product's launchers own
 // the traversal kinds the automatic rule can select and the round-3 particle-filter kernel; every other kind is handed to
 // the hooks below, which the experiments' library registers when it is loaded (a static initialiser calls
-// rmclhip_internal_register_lab).  Without that library those kinds report hipErrorNotSupported.  Not a public interface:
+// rmclhip_internal_register_lab).  Without that library those kinds report kLabMissing (kernels.h).  Not a public interface:
 // include/rmclhip.h does not mention it; include/rmclhip_lab.h declares what tools/ and the `lab` tests may call.
 #pragma once
 #include "kernels.h"

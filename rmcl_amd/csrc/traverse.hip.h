@@ -1129,7 +1129,10 @@ template <int kRows, int kRow0>
 __device__ __forceinline__ TraceStart frontier_start(const uint32_t* __restrict__ frontier, uint32_t n_frontier, f3 scene_center,
                                                      float scene_half_diag, const float* __restrict__ planes, quat Rsm, float tfar,
                                                      f3 O, f3 D, float ray_tfar, uint32_t lane, uint32_t* __restrict__ lds_col,
-                                                     uint32_t lds_stride) {
+                                                     uint32_t lds_stride, uint32_t max_preload) {
+  // max_preload (FindParams::frontier_max_preload, uniform): entries the start may leave on a lane's stack = the stack's 64 entries
+  // minus what the deepest descent of THIS map's tree can still push (the builder's stack_need bounds a descent from the root, hence
+  // from any frontier entry): a deep tree starts more waves at the root instead of overflowing the stack
   constexpr uint32_t kDone = 0x7FFFFFFFu;
   const bool active = ray_tfar >= 0.0f;
   TraceStart root;
@@ -1222,7 +1225,7 @@ __device__ __forceinline__ TraceStart frontier_start(const uint32_t* __restrict_
     ++sp;
   }
   // a lane that would need more rows than it has in LDS: the whole wave starts at the root instead
-  if (__any(sp > static_cast<uint32_t>(kRows - 4))) return root;
+  if (__any(sp > min(static_cast<uint32_t>(kRows - 4), static_cast<uint32_t>(kRow0) + max_preload))) return root;
   TraceStart st;
   st.cur = first_ref;   // kDone: the ray misses every entry, i.e. the whole map
   st.sp = sp;

@@ -25,6 +25,21 @@ def _compare(gpu, ref, what):
     assert_close_rel(gpu["normals"], ref["normals"], 1e-5, 1e-6, what + " normals")
 
 
+def _brute_force_sample(orc, m, model, Tbm, gpu, n_sample, seed=0):
+    """`n_sample` of the scan's OWN rays against every triangle of the map (no BVH at all: the authority the oracle's BVH walk is
+    itself checked against), face ids and hits bit-exact, ranges to 1e-5.  The rays go through the oracle's O1Dn entry with the
+    spherical model's own direction values and a zero origin: the same arithmetic as simulate_spherical."""
+    from rmcl_amd import types as T
+    dirs = orc.spherical_directions(model)
+    idx = np.sort(np.random.RandomState(1234 + int(seed)).choice(len(dirs), size=min(n_sample, len(dirs)), replace=False))
+    sub = m.simulate_o1dn(len(idx), 1, model.range.min, model.range.max, (0.0, 0.0, 0.0), dirs[idx], T.identity(), Tbm, bvh=False,
+                          nthreads=8, want=("hits", "ranges", "face_ids"))
+    assert np.array_equal(gpu["hits"][idx], sub["hits"]), "brute-force sample: hits differ"
+    bad = gpu["face_ids"][idx] != sub["face_ids"]
+    assert not bad.any(), "brute-force sample: %d of %d face ids differ from the exhaustive test" % (bad.sum(), bad.size)
+    assert_close_rel(gpu["ranges"][idx], sub["ranges"], 1e-5, 0, "brute-force sample ranges")
+
+
 def _poses(syn, T):
     return [
         syn.pose_c2_truth(),
@@ -73,7 +88,7 @@ def test_c1_matches_committed_golden(ra, ctx, meshes):
         _compare(gpu, ref, "golden pose %d" % i)
 
 
-@pytest.mark.parametrize("variant", find_kinds(0, 1, 2, 4, 5, 7, 8, 9, 11, 12, 13, 14, 16, 17, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30))
+@pytest.mark.parametrize("variant", find_kinds(0, 1, 2, 4, 5, 7, 8, 9, 11, 12, 13, 14, 15, 16, 17, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30))
 def test_c2_sphere100k_full_size(ra, orc, ctx, meshes, variant):
     """config C2 at BASELINE.json's full size: 128x1024 rays, 100k triangles; oracle BVH on all rays,
     brute force on a sample, and the committed SHA-256 of the face-id array (G7)."""
@@ -92,6 +107,8 @@ def test_c2_sphere100k_full_size(ra, orc, ctx, meshes, variant):
     ref = m.simulate_spherical(model, T.identity(), Tbm, bvh=True, nthreads=8)
     _compare(gpu, ref, "C2")
     assert gpu["hits"].all()
+    if variant in (0, 2, 15, 23, 24):     # (the product's kinds; the experiments of the lab library are pinned by _compare + the digest)
+        _brute_force_sample(orc, m, model, Tbm, gpu, 2048, seed=variant)
     with open(golden_path("g7_digests.json")) as fh:
         dig = json.load(fh)
     assert hashlib.sha256(gpu["face_ids"].tobytes()).hexdigest() == dig["c2_sphere100k_face_ids_sha256"]
@@ -519,3 +536,74 @@ def test_context_may_be_destroyed_before_its_children(ra, orc, meshes):
     upd.close()
     rcc.close()
     hm.release()
+
+
+def test_c2_room100k_brute_force_sample(ra, orc, ctx, meshes):
+    """C2's scan on the occluded room-100k map: the full scan against the oracle's BVH walk and 2 048 of its rays against every
+    triangle (no BVH), for the product's automatic kind."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room100k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    model = syn.model_c2()
+    rcc = ra.RCCHipSpherical(hm)
+    rcc.setTsb(T.identity())
+    rcc.setModel(model)
+    Tbm = T.transform_from_rpy((1.5, -2.0, 1.6), (0.02, -0.03, 0.4))
+    rcc.find(Tbm)
+    gpu = rcc.modelView()
+    ref = m.simulate_spherical(model, T.identity(), Tbm, bvh=True, nthreads=8)
+    _compare(gpu, ref, "C2 room")
+    _brute_force_sample(orc, m, model, Tbm, gpu, 2048)
+    rcc.close()
+
+
+def _nested_triangles(n, ratio, largest):
+    """n coaxial triangles of geometrically growing size stacked 1 cm apart: the SAH builder can only peel them off one by one, which
+    makes the DEEPEST trees map_upload accepts out of a few hundred triangles"""
+    vs, fs = [], []
+    for k in range(n):
+        s = largest * ratio ** (k - (n - 1))
+        vs += [[-s, -s, 0.01 * k], [s, -s, 0.01 * k], [0.0, s, 0.01 * k]]
+        fs.append([3 * k, 3 * k + 1, 3 * k + 2])
+    return np.array(vs, np.float32), np.array(fs, np.uint32)
+
+
+@pytest.mark.parametrize("shape", [(160, 1.22), (140, 1.25), (120, 1.3)])
+def test_deep_trees_do_not_overflow_the_frontier_start(ra, orc, ctx, shape):
+    """the frontier start pre-loads up to 19 (kind 23) / 12 (kind 24) / more (quad kind) stack entries per lane, while
+    map_upload's stack_need <= 64 only bounds a descent from the root.  Maps whose trees need 45..59 entries (stack_need of the main
+    tree / of the filter's tree) must still trace correctly: the start is bounded by 64 - stack_need and falls back to the root.
+    Rays from above the stack cross MANY of the nested boxes, so the frontier accepts as many entries as it can."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = _nested_triangles(shape[0], shape[1], 40.0)
+    info, _, _ = ra.build_bvh_host(v, f)
+    info_pf, _, _ = ra.build_bvh_host_pf(v, f)
+    assert max(info["stack_need"], info_pf["stack_need"]) > 45 and max(info["stack_need"], info_pf["stack_need"]) <= 64
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    model = syn.model_c1()
+    model.phi.size, model.theta.size = 64, 256
+    model.phi.inc, model.theta.inc = model.phi.inc * 32.0 / 64.0, model.theta.inc * 32.0 / 256.0
+    model.phi.min = -1.45                                   # looks DOWN through the stack as well as sideways
+    model.phi.inc = (1.45 + 0.4) / 63.0
+    poses = [T.transform_from_rpy((0.001, -0.002, 3.0), (0.0, 0.0, 0.3)), T.transform_from_rpy((0.8, 0.3, 2.5), (0.05, -0.1, 1.0))]
+    for kind in (23, 24, 2, 15):
+        rcc = ra.RCCHipSpherical(hm)
+        rcc.set_traversal(kind)
+        rcc.setTsb(T.identity())
+        rcc.setModel(model)
+        for i, Tbm in enumerate(poses):
+            rcc.find(Tbm)
+            gpu = rcc.modelView()
+            ref = m.simulate_spherical(model, T.identity(), Tbm, bvh=False, nthreads=8)
+            _compare(gpu, ref, "nested %s kind %d pose %d" % (shape, kind, i))
+            assert gpu["hits"].sum() > 1000
+        # the same map through a pose batch (kind 24 by rule)
+        rcc.find_batch(np.array(poses, dtype=T.TRANSFORM))
+        mvb = rcc.modelView()
+        n = 64 * 256
+        for i, Tbm in enumerate(poses):
+            ref = m.simulate_spherical(model, T.identity(), Tbm, bvh=False, nthreads=8)
+            assert np.array_equal(mvb["face_ids"][i * n:(i + 1) * n], ref["face_ids"])
+        rcc.close()

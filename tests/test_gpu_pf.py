@@ -60,7 +60,7 @@ def test_golden_g6_cube(ra, ctx, meshes, variant):
     _check(a_gpu, e_gpu, g["attrs_out"].view(T.PARTICLE_ATTRIBUTES), g["errors"], "G6")
 
 
-@pytest.mark.parametrize("n_particles,n_beams", [(1000, 100), (257, 7), (4099, 256)])
+@pytest.mark.parametrize("n_particles,n_beams", [(1000, 100), (257, 7), (4099, 256), (3001, 1), (130, 2)])   # (one beam: the magic division of the ray index has no 32-bit constant)
 @pytest.mark.parametrize("variant", pf_variants(0, 2, 16, 32, 64, 48 | 128, 64 | LEGACY, 64 | BIG, 64 | MAPTREE, 64 | LEGACY | MAPTREE))
 def test_room_random_particles(ra, orc, ctx, meshes, n_particles, n_beams, variant):
     """random hypotheses in a room with occluders and an open ceiling (sim misses), reference default of
@@ -303,3 +303,9 @@ def test_c5_shard_size_properties(ra, orc, ctx, meshes):
     ref = attrs[sub].copy()
     m.pf_update(poses[sub], ref, beams, T.identity(), orc.pf_params(), bvh=True, nthreads=8)
     assert_close_rel(shard["likelihood"]["mean"][sub], ref["likelihood"]["mean"], 1e-5, 1e-12, "C5 shard prefix mean")
+    # ... and one particle's 256 beams against EVERY one of the 1 000 000 triangles (no BVH at all)
+    for pi in (7, 124999):
+        bf = attrs[pi:pi + 1].copy()
+        m.pf_update(poses[pi:pi + 1], bf, beams, T.identity(), orc.pf_params(), bvh=False, nthreads=8)
+        assert int(bf["likelihood"]["n_meas"][0]) == int(shard["likelihood"]["n_meas"][pi])
+        assert_close_rel(shard["likelihood"]["mean"][pi:pi + 1], bf["likelihood"]["mean"], 1e-5, 1e-12, "C5 brute-force particle")
