@@ -558,12 +558,12 @@ def test_c2_room100k_brute_force_sample(ra, orc, ctx, meshes):
     rcc.close()
 
 
-def _nested_triangles(n, ratio, largest):
+def _nested_triangles(n, ratio, smallest):
     """n coaxial triangles of geometrically growing size stacked 1 cm apart: the SAH builder can only peel them off one by one, which
     makes the DEEPEST trees map_upload accepts out of a few hundred triangles"""
     vs, fs = [], []
     for k in range(n):
-        s = largest * ratio ** (k - (n - 1))
+        s = smallest * ratio ** k
         vs += [[-s, -s, 0.01 * k], [s, -s, 0.01 * k], [0.0, s, 0.01 * k]]
         fs.append([3 * k, 3 * k + 1, 3 * k + 2])
     return np.array(vs, np.float32), np.array(fs, np.uint32)
@@ -576,7 +576,7 @@ def test_deep_trees_do_not_overflow_the_frontier_start(ra, orc, ctx, shape):
     tree / of the filter's tree) must still trace correctly: the start is bounded by 64 - stack_need and falls back to the root.
     Rays from above the stack cross MANY of the nested boxes, so the frontier accepts as many entries as it can."""
     from rmcl_amd import synthetic as syn, types as T
-    v, f = _nested_triangles(shape[0], shape[1], 40.0)
+    v, f = _nested_triangles(shape[0], shape[1], 1e-3)
     info, _, _ = ra.build_bvh_host(v, f)
     info_pf, _, _ = ra.build_bvh_host_pf(v, f)
     assert max(info["stack_need"], info_pf["stack_need"]) > 45 and max(info["stack_need"], info_pf["stack_need"]) <= 64
@@ -585,9 +585,10 @@ def test_deep_trees_do_not_overflow_the_frontier_start(ra, orc, ctx, shape):
     model = syn.model_c1()
     model.phi.size, model.theta.size = 64, 256
     model.phi.inc, model.theta.inc = model.phi.inc * 32.0 / 64.0, model.theta.inc * 32.0 / 256.0
-    model.phi.min = -1.45                                   # looks DOWN through the stack as well as sideways
+    model.phi.min = -0.4                                    # looks UP through the stack (smallest triangle first) as well as sideways
     model.phi.inc = (1.45 + 0.4) / 63.0
-    poses = [T.transform_from_rpy((0.001, -0.002, 3.0), (0.0, 0.0, 0.3)), T.transform_from_rpy((0.8, 0.3, 2.5), (0.05, -0.1, 1.0))]
+    model.range.max = 1.0e12
+    poses = [T.transform_from_rpy((0.001, -0.002, -1.0), (0.0, 0.0, 0.3)), T.transform_from_rpy((0.8, 0.3, -2.5), (0.05, -0.1, 1.0))]
     for kind in (23, 24, 2, 15):
         rcc = ra.RCCHipSpherical(hm)
         rcc.set_traversal(kind)
@@ -598,7 +599,7 @@ def test_deep_trees_do_not_overflow_the_frontier_start(ra, orc, ctx, shape):
             gpu = rcc.modelView()
             ref = m.simulate_spherical(model, T.identity(), Tbm, bvh=False, nthreads=8)
             _compare(gpu, ref, "nested %s kind %d pose %d" % (shape, kind, i))
-            assert gpu["hits"].sum() > 1000
+            assert gpu["hits"].sum() > 1000 and len(np.unique(gpu["face_ids"][gpu["hits"] > 0])) > 20
         # the same map through a pose batch (kind 24 by rule)
         rcc.find_batch(np.array(poses, dtype=T.TRANSFORM))
         mvb = rcc.modelView()
