@@ -579,6 +579,12 @@ rmclhip_status rmclhip_resampler_residual(rmclhip_resampler* rs, const rmclhip_t
  * (librccl is loaded with dlopen by rmclhip_comm_create: single-GPU users never touch it). */
 /* devices: HIP device indices (NULL = 0 .. ndev-1).  ncclCommInitAll. */
 rmclhip_status rmclhip_comm_create(const int* devices, uint32_t ndev, rmclhip_comm** out);
+/* TEST INFRASTRUCTURE: an in-process stand-in for the RCCL communicator -- same handle type, accepted by every rmclhip_pf_sharded_*
+ * entry point; every "rank" is a stream of this process and `devices` may repeat a device; an all-gather is device-to-device
+ * copies, an all-reduce one small kernel, ordered with events.  It lets the ndev > 1 code paths (grouped all-gather of weights and of
+ * the cloud, the moment all-reduces, the per-rank tournament / residual fill) run, and be checked against the unsharded results,
+ * on a box with ONE GPU; it is not a transport (no xGMI, no peer access set-up). */
+rmclhip_status rmclhip_comm_create_loopback(const int* devices, uint32_t ndev, rmclhip_comm** out);
 void rmclhip_comm_destroy(rmclhip_comm* comm);
 uint32_t rmclhip_comm_size(const rmclhip_comm* comm);
 /* contiguous block partition of [0, n): rank owns [lo, hi); the first n % world ranks own one extra element */

@@ -49,6 +49,12 @@ rmclhip_status rmclhip_debug_micp_moments(rmclhip_rcc* rcc, double* totals96, ui
 rmclhip_status rmclhip_debug_probe_find(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est, int mode, uint32_t* log_out,
                                         size_t log_cap_dwords, uint32_t* n_tiles_out);
 
+/* debug trace of the sharded entry points (rmclhip_pf_update_sharded, _allgather_weights, _sharded_resample*): on = 1 starts (and
+ * clears) the recording, on = 0 stops it; buf (nullable) receives what was recorded before this call.  Tokens: "E<r>" rank r's part of
+ * a phase was enqueued, "W<r>" the host waited for rank r, "<phase>:" labels.  A phase that lets the devices run concurrently reads
+ * "E0 E1 ... W0 W1 ..."; tests/test_gpu_distributed.py asserts that.  Works without the experiments library. */
+rmclhip_status rmclhip_debug_trace(int on, char* buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

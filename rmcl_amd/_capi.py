@@ -197,6 +197,8 @@ SIGNATURES = {
     "rmclhip_resampler_residual": (_i32, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, _u32, C.POINTER(GladiatorConfig),
                                            C.c_uint64, _u32, C.POINTER(C.c_uint64)]),
     "rmclhip_comm_create": (_i32, [_vp, _u32, _pp]),
+    "rmclhip_comm_create_loopback": (_i32, [_vp, _u32, _pp]),
+    "rmclhip_debug_trace": (_i32, [_i32, _vp, _sz]),
     "rmclhip_comm_destroy": (None, [_vp]),
     "rmclhip_comm_size": (_u32, [_vp]),
     "rmclhip_shard_bounds": (None, [_u32, _u32, _u32, C.POINTER(_u32), C.POINTER(_u32)]),

@@ -309,6 +309,7 @@ struct rmclhip_resampler {
   DevBuf<double> d_psum;
   DevBuf<float> d_pmax, d_out;
   float* h_out = nullptr;  // pinned {sum, max}
+  unsigned long long* h_res = nullptr;   // pinned: residual resampling's {sum, max, expect, n_draws} + the draws' total (5 words)
   // residual resampling: {double sum, double max, u64 expect, u64 n_draws} on the device, the draws' particle / count / prefix sums
   DevBuf<unsigned long long> d_res_stats, d_res_incl, d_res_btot;
   DevBuf<uint32_t> d_res_idx, d_res_cnt;
@@ -3098,6 +3099,7 @@ rmclhip_status rmclhip_resampler_create(rmclhip_ctx* ctx, rmclhip_resampler** ou
   if (e == hipSuccess) e = r->d_pmax.reserve(256);
   if (e == hipSuccess) e = r->d_out.reserve(2);
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_out), 2 * sizeof(float), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_res), 8 * sizeof(unsigned long long), hipHostMallocDefault);
   if (e != hipSuccess) {
     rmclhip_resampler_destroy(r);
     return fail(RMCLHIP_ERR_HIP, std::string("resampler_create: ") + hipGetErrorString(e));
@@ -3116,6 +3118,7 @@ void rmclhip_resampler_destroy(rmclhip_resampler* r) {
   r->d_out.release();
   r->d_res_stats.release(); r->d_res_incl.release(); r->d_res_btot.release(); r->d_res_idx.release(); r->d_res_cnt.release();
   if (r->h_out) (void)hipHostFree(r->h_out);
+  if (r->h_res) (void)hipHostFree(r->h_res);
   if (r->stream) (void)hipStreamDestroy(r->stream);
   ctx_release(r->ctx);
   delete r;
@@ -3134,12 +3137,13 @@ rmclhip_status rmclhip_resampler_compute_stats(rmclhip_resampler* r, const rmclh
   return RMCLHIP_OK;
 }
 
-rmclhip_status rmclhip_resampler_gladiator(rmclhip_resampler* r, const rmclhip_transform* poses_dev,
-                                           const rmclhip_particle_attributes* attrs_dev, uint32_t n_particles,
-                                           rmclhip_transform* poses_new_dev, rmclhip_particle_attributes* attrs_new_dev,
-                                           uint32_t first, uint32_t count, const rmclhip_gladiator_config* cfg,
-                                           uint64_t seed, uint32_t step) {
-  ApiGuard guard_("rmclhip_resampler_gladiator");
+// The resamplers as ENQUEUE + WAIT (round 4): the sharded entry points enqueue every device's part before they wait for any
+// (pf_sharded_resample_impl); the public single-device calls are enqueue + one wait.  `st`: the stream the work goes to (the
+// resampler's own, or the communicator's stream of that device behind the all-gather of the cloud).
+static rmclhip_status gladiator_enqueue(rmclhip_resampler* r, const rmclhip_transform* poses_dev, const rmclhip_particle_attributes* attrs_dev,
+                                        uint32_t n_particles, rmclhip_transform* poses_new_dev, rmclhip_particle_attributes* attrs_new_dev,
+                                        uint32_t first, uint32_t count, const rmclhip_gladiator_config* cfg, uint64_t seed, uint32_t step,
+                                        hipStream_t st) {
   if (!r || !cfg) return fail(RMCLHIP_ERR_INVALID, "resampler_gladiator: null");
   if (count == 0) return RMCLHIP_OK;
   if (!poses_dev || !attrs_dev || !poses_new_dev || !attrs_new_dev || n_particles == 0)
@@ -3155,8 +3159,109 @@ rmclhip_status rmclhip_resampler_gladiator(rmclhip_resampler* r, const rmclhip_t
                        cfg->likelihood_forget_per_radian};
   HIPCHK(launch_gladiator_resample(reinterpret_cast<const xform*>(poses_dev), attrs_dev, n_particles,
                                    reinterpret_cast<xform*>(poses_new_dev), attrs_new_dev, first, count, c8,
-                                   cfg->trans_dist_metric, seed, step, r->stream));
+                                   cfg->trans_dist_metric, seed, step, st));
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_resampler_gladiator(rmclhip_resampler* r, const rmclhip_transform* poses_dev,
+                                           const rmclhip_particle_attributes* attrs_dev, uint32_t n_particles,
+                                           rmclhip_transform* poses_new_dev, rmclhip_particle_attributes* attrs_new_dev,
+                                           uint32_t first, uint32_t count, const rmclhip_gladiator_config* cfg,
+                                           uint64_t seed, uint32_t step) {
+  ApiGuard guard_("rmclhip_resampler_gladiator");
+  if (!r) return fail(RMCLHIP_ERR_INVALID, "resampler_gladiator: null");
+  if (rmclhip_status st = gladiator_enqueue(r, poses_dev, attrs_dev, n_particles, poses_new_dev, attrs_new_dev, first, count, cfg, seed, step,
+                                            r->stream))
+    return st;
+  if (count == 0) return RMCLHIP_OK;
   HIPCHK(hipStreamSynchronize(r->stream));
+  return RMCLHIP_OK;
+}
+
+// residual resampling (ResidualResamplerCPU.cpp:55-203) in three enqueue phases, each followed by ONE wait of the caller:
+//   A prepare: statistics + how many copies a draw inserts on average  -> h_res[0..3]
+//   B draws  : a block of draws that fills the cloud with a margin     -> h_res[4] = copies these draws insert (repeat doubled if short)
+//   C fill   : the slots [first, first + count) of the new cloud
+struct ResidualJob {
+  rmclhip_resampler* r = nullptr;
+  hipStream_t st = nullptr;
+  const rmclhip_transform* poses = nullptr; const rmclhip_particle_attributes* attrs = nullptr;
+  rmclhip_transform* poses_new = nullptr; rmclhip_particle_attributes* attrs_new = nullptr;
+  uint32_t n_particles = 0, n_new = 0, first = 0, count = 0;
+  const rmclhip_gladiator_config* cfg = nullptr;
+  uint64_t seed = 0; uint32_t step = 0;
+  double want = 0.0;
+  uint32_t n_draws = 0;
+  bool filled = false;     // phase B's draws cover the new cloud
+  bool active = false;     // count != 0 && n_new != 0
+};
+static rmclhip_status residual_check(ResidualJob& j) {
+  j.active = false;
+  if (!j.r || !j.cfg) return fail(RMCLHIP_ERR_INVALID, "resampler_residual: null");
+  if (j.n_new == 0 || j.count == 0) return RMCLHIP_OK;
+  if (!j.poses || !j.attrs || !j.poses_new || !j.attrs_new || j.n_particles == 0)
+    return fail(RMCLHIP_ERR_INVALID, "resampler_residual: null particle buffers");
+  if (static_cast<uint64_t>(j.first) + j.count > j.n_new) return fail(RMCLHIP_ERR_INVALID, "resampler_residual: slot range exceeds the new cloud");
+  if (j.poses_new == j.poses || j.attrs_new == j.attrs)
+    return fail(RMCLHIP_ERR_INVALID, "resampler_residual: out of place (double buffers)");
+  j.active = true;
+  return RMCLHIP_OK;
+}
+static rmclhip_status residual_prepare_enqueue(ResidualJob& j) {
+  if (!j.active) return RMCLHIP_OK;
+  rmclhip_resampler* r = j.r;
+  HIPCHK(hipSetDevice(r->ctx->device));
+  HIPCHK(r->d_res_stats.reserve(4));
+  // ResidualResamplerCPU.cpp:72-85
+  HIPCHK(launch_residual_prepare(j.attrs, j.n_particles, j.n_new, r->d_psum.p, r->d_pmax.p, r->d_res_stats.p, j.st));
+  HIPCHK(hipMemcpyAsync(r->h_res, r->d_res_stats.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, j.st));
+  return RMCLHIP_OK;
+}
+static rmclhip_status residual_draws_enqueue(ResidualJob& j, bool first_try) {
+  if (!j.active || j.filled) return RMCLHIP_OK;
+  rmclhip_resampler* r = j.r;
+  HIPCHK(hipSetDevice(r->ctx->device));
+  if (first_try) {
+    double sum; unsigned long long expect;
+    std::memcpy(&sum, &r->h_res[0], sizeof(double));
+    expect = r->h_res[2];
+    if (!(sum > 0.0)) return fail(RMCLHIP_ERR_INVALID, "resampler_residual: the likelihoods sum to zero (or NaN): nothing to resample from");
+    if (expect == 0ull)
+      return fail(RMCLHIP_ERR_INVALID, "resampler_residual: every particle's share L / sum * N_new truncates to 0 -- no draw would ever insert "
+                                       "a particle (the reference's loop, ResidualResamplerCPU.cpp:104, does not terminate on this input)");
+    // a block of draws that fills the cloud with a margin: N_new / E[copies per draw] x 1.25 + 4096; doubled if it falls short
+    const double per_draw = static_cast<double>(expect) / static_cast<double>(j.n_particles);
+    j.want = static_cast<double>(j.n_new) / per_draw * 1.25 + 4096.0;
+  } else {
+    j.want *= 2.0;   // the same draws again plus as many more: the stream is a function of the draw index
+  }
+  const double kMaxDraws = 268435456.0;    // 2^28 draws = 4 GB of scratch: far beyond any sane input
+  if (j.want > kMaxDraws) return fail(RMCLHIP_ERR_UNSUPPORTED, "resampler_residual: more than 2^28 draws would be needed to fill the cloud");
+  j.n_draws = static_cast<uint32_t>(j.want);
+  const uint32_t nb = (j.n_draws + 1023u) / 1024u;
+  HIPCHK(r->d_res_idx.reserve(j.n_draws));
+  HIPCHK(r->d_res_cnt.reserve(j.n_draws));
+  HIPCHK(r->d_res_incl.reserve(j.n_draws));
+  HIPCHK(r->d_res_btot.reserve(nb));
+  HIPCHK(launch_residual_draws(j.attrs, j.n_particles, j.n_new, r->d_res_stats.p, j.n_draws, j.seed, j.step, r->d_res_idx.p, r->d_res_cnt.p,
+                               r->d_res_incl.p, r->d_res_btot.p, j.st));
+  HIPCHK(hipMemcpyAsync(&r->h_res[4], r->d_res_incl.p + (j.n_draws - 1u), sizeof(unsigned long long), hipMemcpyDeviceToHost, j.st));
+  return RMCLHIP_OK;
+}
+static void residual_draws_done(ResidualJob& j) {   // after the wait that follows residual_draws_enqueue
+  if (j.active && !j.filled) j.filled = j.r->h_res[4] >= j.n_new;
+}
+static rmclhip_status residual_fill_enqueue(ResidualJob& j, bool want_n_draws) {
+  if (!j.active) return RMCLHIP_OK;
+  rmclhip_resampler* r = j.r;
+  HIPCHK(hipSetDevice(r->ctx->device));
+  const float c8[8] = {j.cfg->min_noise_tx, j.cfg->min_noise_ty, j.cfg->min_noise_tz, j.cfg->min_noise_roll,
+                       j.cfg->min_noise_pitch, j.cfg->min_noise_yaw, j.cfg->likelihood_forget_per_meter,
+                       j.cfg->likelihood_forget_per_radian};
+  HIPCHK(launch_residual_fill(reinterpret_cast<const xform*>(j.poses), j.attrs, r->d_res_idx.p, r->d_res_incl.p, j.n_draws,
+                              reinterpret_cast<xform*>(j.poses_new), j.attrs_new, j.n_new, j.first, j.count, c8, r->d_res_stats.p, j.seed,
+                              j.step, j.st));
+  if (want_n_draws) HIPCHK(hipMemcpyAsync(r->h_res, r->d_res_stats.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, j.st));
   return RMCLHIP_OK;
 }
 
@@ -3166,60 +3271,24 @@ rmclhip_status rmclhip_resampler_residual(rmclhip_resampler* r, const rmclhip_tr
                                           uint32_t n_new, uint32_t first, uint32_t count, const rmclhip_gladiator_config* cfg,
                                           uint64_t seed, uint32_t step, uint64_t* n_draws_out) {
   ApiGuard guard_("rmclhip_resampler_residual");
-  if (!r || !cfg) return fail(RMCLHIP_ERR_INVALID, "resampler_residual: null");
   if (n_draws_out) *n_draws_out = 0;
-  if (n_new == 0 || count == 0) return RMCLHIP_OK;
-  if (!poses_dev || !attrs_dev || !poses_new_dev || !attrs_new_dev || n_particles == 0)
-    return fail(RMCLHIP_ERR_INVALID, "resampler_residual: null particle buffers");
-  if (static_cast<uint64_t>(first) + count > n_new) return fail(RMCLHIP_ERR_INVALID, "resampler_residual: slot range exceeds the new cloud");
-  if (poses_new_dev == poses_dev || attrs_new_dev == attrs_dev)
-    return fail(RMCLHIP_ERR_INVALID, "resampler_residual: out of place (double buffers)");
-  HIPCHK(hipSetDevice(r->ctx->device));
-  HIPCHK(r->d_res_stats.reserve(4));
-  // 1. statistics (ResidualResamplerCPU.cpp:72-85) and how many copies a draw inserts on average
-  HIPCHK(launch_residual_prepare(attrs_dev, n_particles, n_new, r->d_psum.p, r->d_pmax.p, r->d_res_stats.p, r->stream));
-  struct { double sum, max; unsigned long long expect, n_draws; } st;
-  HIPCHK(hipMemcpyAsync(&st, r->d_res_stats.p, sizeof(st), hipMemcpyDeviceToHost, r->stream));
-  HIPCHK(hipStreamSynchronize(r->stream));
-  if (!(st.sum > 0.0)) return fail(RMCLHIP_ERR_INVALID, "resampler_residual: the likelihoods sum to zero (or NaN): nothing to resample from");
-  if (st.expect == 0ull)
-    return fail(RMCLHIP_ERR_INVALID, "resampler_residual: every particle's share L / sum * N_new truncates to 0 -- no draw would ever insert "
-                                     "a particle (the reference's loop, ResidualResamplerCPU.cpp:104, does not terminate on this input)");
-  // 2. a block of draws that fills the cloud with a margin: N_new / E[copies per draw] x 1.25 + 4096; doubled if it falls short
-  const double per_draw = static_cast<double>(st.expect) / static_cast<double>(n_particles);
-  double want = static_cast<double>(n_new) / per_draw * 1.25 + 4096.0;
-  const double kMaxDraws = 268435456.0;    // 2^28 draws = 4 GB of scratch: far beyond any sane input
-  unsigned long long total = 0ull;
-  uint32_t n_draws = 0;
-  for (;;) {
-    if (want > kMaxDraws) return fail(RMCLHIP_ERR_UNSUPPORTED, "resampler_residual: more than 2^28 draws would be needed to fill the cloud");
-    n_draws = static_cast<uint32_t>(want);
-    const uint32_t nb = (n_draws + 1023u) / 1024u;
-    HIPCHK(r->d_res_idx.reserve(n_draws));
-    HIPCHK(r->d_res_cnt.reserve(n_draws));
-    HIPCHK(r->d_res_incl.reserve(n_draws));
-    HIPCHK(r->d_res_btot.reserve(nb));
-    HIPCHK(launch_residual_draws(attrs_dev, n_particles, n_new, r->d_res_stats.p, n_draws, seed, step, r->d_res_idx.p, r->d_res_cnt.p,
-                                 r->d_res_incl.p, r->d_res_btot.p, r->stream));
-    HIPCHK(hipMemcpyAsync(&total, r->d_res_incl.p + (n_draws - 1u), sizeof(total), hipMemcpyDeviceToHost, r->stream));
-    HIPCHK(hipStreamSynchronize(r->stream));
-    if (total >= n_new) break;
-    want *= 2.0;   // the same draws again plus as many more: the stream is a function of the draw index
+  ResidualJob j;
+  j.r = r; j.st = r ? r->stream : nullptr;
+  j.poses = poses_dev; j.attrs = attrs_dev; j.poses_new = poses_new_dev; j.attrs_new = attrs_new_dev;
+  j.n_particles = n_particles; j.n_new = n_new; j.first = first; j.count = count; j.cfg = cfg; j.seed = seed; j.step = step;
+  if (rmclhip_status st = residual_check(j)) return st;
+  if (!j.active) return RMCLHIP_OK;
+  if (rmclhip_status st = residual_prepare_enqueue(j)) return st;
+  HIPCHK(hipStreamSynchronize(j.st));
+  for (bool first_try = true; !j.filled; first_try = false) {
+    if (rmclhip_status st = residual_draws_enqueue(j, first_try)) return st;
+    HIPCHK(hipStreamSynchronize(j.st));
+    residual_draws_done(j);
   }
-  // 3. the slots
-  const float c8[8] = {cfg->min_noise_tx, cfg->min_noise_ty, cfg->min_noise_tz, cfg->min_noise_roll,
-                       cfg->min_noise_pitch, cfg->min_noise_yaw, cfg->likelihood_forget_per_meter,
-                       cfg->likelihood_forget_per_radian};
-  HIPCHK(launch_residual_fill(reinterpret_cast<const xform*>(poses_dev), attrs_dev, r->d_res_idx.p, r->d_res_incl.p, n_draws,
-                              reinterpret_cast<xform*>(poses_new_dev), attrs_new_dev, n_new, first, count, c8, r->d_res_stats.p, seed,
-                              step, r->stream));
-  if (n_draws_out && static_cast<uint64_t>(first) + count == n_new) {
-    HIPCHK(hipMemcpyAsync(&st, r->d_res_stats.p, sizeof(st), hipMemcpyDeviceToHost, r->stream));
-    HIPCHK(hipStreamSynchronize(r->stream));
-    *n_draws_out = st.n_draws;
-  } else {
-    HIPCHK(hipStreamSynchronize(r->stream));
-  }
+  const bool want = n_draws_out && static_cast<uint64_t>(first) + count == n_new;
+  if (rmclhip_status st = residual_fill_enqueue(j, want)) return st;
+  HIPCHK(hipStreamSynchronize(j.st));
+  if (want) *n_draws_out = r->h_res[3];
   return RMCLHIP_OK;
 }
 
@@ -3266,7 +3335,45 @@ struct rmclhip_comm {
   std::vector<int> devices;
   std::vector<ncclComm_t> comms;
   std::vector<hipStream_t> streams;   // one collective stream per device
+  // rmclhip_comm_create_loopback: an in-process stand-in for RCCL (every "rank" is a stream of this process, ranks may share a
+  // device): collectives are device-to-device copies / one small kernel, ordered with events.  It exists so that the ndev > 1 code
+  // paths of the sharded entry points run -- and are checked against the unsharded results -- on a box with ONE GPU.
+  bool loopback = false;
+  std::vector<hipEvent_t> ev_in, ev_out;
 };
+
+// debug trace of the sharded entry points (rmclhip_debug_trace): "E<r>" = rank r's work of a phase enqueued, "W<r>" = the host waited
+// for rank r.  A phase that scales reads E0 E1 ... W0 W1 ...; E0 W0 E1 W1 serialises the devices.
+static bool g_trace_on = false;
+static std::string g_trace;
+static inline void trace(char what, uint32_t rank) {
+  if (!g_trace_on) return;
+  g_trace += what;
+  g_trace += std::to_string(rank);
+  g_trace += ' ';
+}
+static inline void trace_mark(const char* label) {
+  if (!g_trace_on) return;
+  g_trace += label;
+  g_trace += ' ';
+}
+
+// every rank's stream waits until all ranks' streams have reached this point (loopback collectives only)
+static hipError_t loopback_barrier(rmclhip_comm* c, std::vector<hipEvent_t>& evs) {
+  const size_t world = c->devices.size();
+  for (size_t r = 0; r < world; ++r) {
+    hipError_t e = hipSetDevice(c->devices[r]);
+    if (e == hipSuccess) e = hipEventRecord(evs[r], c->streams[r]);
+    if (e != hipSuccess) return e;
+  }
+  for (size_t r = 0; r < world; ++r) {
+    hipError_t e = hipSetDevice(c->devices[r]);
+    for (size_t s = 0; s < world && e == hipSuccess; ++s)
+      if (s != r) e = hipStreamWaitEvent(c->streams[r], evs[s], 0);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
 
 struct PfRank {
   rmclhip_ctx* ctx = nullptr;
@@ -3348,11 +3455,109 @@ void rmclhip_comm_destroy(rmclhip_comm* c) {
     (void)hipSetDevice(c->devices[i]);
     if (i < c->streams.size() && c->streams[i]) { (void)hipStreamSynchronize(c->streams[i]); (void)hipStreamDestroy(c->streams[i]); }
     if (i < c->comms.size() && c->comms[i] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comms[i]);
+    if (i < c->ev_in.size() && c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]);
+    if (i < c->ev_out.size() && c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]);
   }
   delete c;
 }
 
 uint32_t rmclhip_comm_size(const rmclhip_comm* c) { return c ? static_cast<uint32_t>(c->devices.size()) : 0u; }
+
+// The loopback communicator (see struct rmclhip_comm): same interface, no RCCL, ranks may share a device.
+rmclhip_status rmclhip_comm_create_loopback(const int* devices, uint32_t ndev, rmclhip_comm** out) {
+  ApiGuard guard_("rmclhip_comm_create_loopback");
+  if (!out) return fail(RMCLHIP_ERR_INVALID, "comm_create_loopback: out is null");
+  *out = nullptr;
+  if (ndev == 0 || ndev > 64) return fail(RMCLHIP_ERR_INVALID, "comm_create_loopback: ndev must be 1..64");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(RMCLHIP_ERR_NO_DEVICE, "no HIP device available (librmclhip has no CPU fallback)");
+  rmclhip_comm* c = new rmclhip_comm();
+  c->loopback = true;
+  c->devices.resize(ndev);
+  c->streams.assign(ndev, nullptr);
+  c->ev_in.assign(ndev, nullptr);
+  c->ev_out.assign(ndev, nullptr);
+  for (uint32_t i = 0; i < ndev; ++i) {
+    c->devices[i] = devices ? devices[i] : 0;
+    if (c->devices[i] < 0 || c->devices[i] >= count) { rmclhip_comm_destroy(c); return fail(RMCLHIP_ERR_INVALID, "comm_create_loopback: device index out of range"); }
+    hipError_t e = hipSetDevice(c->devices[i]);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->streams[i], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming);
+    if (e != hipSuccess) { rmclhip_comm_destroy(c); return fail(RMCLHIP_ERR_HIP, std::string("comm_create_loopback: ") + hipGetErrorString(e)); }
+  }
+  *out = c;
+  return RMCLHIP_OK;
+}
+
+// ---- the collectives the sharded entry points use, on every rank's collective stream (nothing here waits on the host) ----
+// all-gather of `bytes` per rank: recv[r][s * bytes ..] = send[s][0 .. bytes) for every rank r and s
+static rmclhip_status comm_allgather(rmclhip_comm* c, const void* const* send, void* const* recv, size_t bytes) {
+  const uint32_t world = static_cast<uint32_t>(c->devices.size());
+  if (bytes == 0) return RMCLHIP_OK;
+  if (!c->loopback) {
+    NCCLCHK(g_rccl.GroupStart());
+    for (uint32_t r = 0; r < world; ++r) {
+      (void)hipSetDevice(c->devices[r]);
+      const ncclResult_t nr = g_rccl.AllGather(send[r], recv[r], bytes, ncclChar, c->comms[r], c->streams[r]);
+      if (nr != ncclSuccess) { (void)g_rccl.GroupEnd(); return fail(RMCLHIP_ERR_HIP, std::string("ncclAllGather: ") + g_rccl.GetErrorString(nr)); }
+    }
+    NCCLCHK(g_rccl.GroupEnd());
+    return RMCLHIP_OK;
+  }
+  HIPCHK(loopback_barrier(c, c->ev_in));      // every rank's send buffer is complete
+  for (uint32_t r = 0; r < world; ++r) {
+    HIPCHK(hipSetDevice(c->devices[r]));
+    for (uint32_t sr = 0; sr < world; ++sr)
+      HIPCHK(hipMemcpyAsync(static_cast<char*>(recv[r]) + static_cast<size_t>(sr) * bytes, send[sr], bytes, hipMemcpyDefault, c->streams[r]));
+  }
+  HIPCHK(loopback_barrier(c, c->ev_out));     // ... and nobody overwrites it before every rank has read it
+  return RMCLHIP_OK;
+}
+// all-reduce of `count` doubles (sum or max): recv[r] = op over s of send[s], identical on every rank
+static rmclhip_status comm_allreduce_f64(rmclhip_comm* c, const double* const* send, double* const* recv, uint32_t count, bool is_max) {
+  const uint32_t world = static_cast<uint32_t>(c->devices.size());
+  if (count == 0) return RMCLHIP_OK;
+  if (!c->loopback) {
+    NCCLCHK(g_rccl.GroupStart());
+    for (uint32_t r = 0; r < world; ++r) {
+      (void)hipSetDevice(c->devices[r]);
+      const ncclResult_t nr = g_rccl.AllReduce(send[r], recv[r], count, ncclDouble, is_max ? ncclMax : ncclSum, c->comms[r], c->streams[r]);
+      if (nr != ncclSuccess) { (void)g_rccl.GroupEnd(); return fail(RMCLHIP_ERR_HIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(nr)); }
+    }
+    NCCLCHK(g_rccl.GroupEnd());
+    return RMCLHIP_OK;
+  }
+  HIPCHK(loopback_barrier(c, c->ev_in));
+  for (uint32_t r = 0; r < world; ++r) {
+    HIPCHK(hipSetDevice(c->devices[r]));
+    HIPCHK(launch_loopback_allreduce(send, world, recv[r], count, is_max, c->streams[r]));
+  }
+  HIPCHK(loopback_barrier(c, c->ev_out));
+  return RMCLHIP_OK;
+}
+// the host waits for every rank's collective stream (ONE wait per rank, after everything of a phase has been enqueued)
+static rmclhip_status comm_wait_all(rmclhip_comm* c) {
+  for (size_t r = 0; r < c->devices.size(); ++r) {
+    HIPCHK(hipSetDevice(c->devices[r]));
+    HIPCHK(hipStreamSynchronize(c->streams[r]));
+    trace('W', static_cast<uint32_t>(r));
+  }
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_debug_trace(int on, char* buf, size_t cap) {
+  // on = 1: start (clears), on = 0: stop; buf (nullable) receives what was recorded so far
+  if (buf && cap) {
+    const size_t n = std::min(cap - 1, g_trace.size());
+    std::memcpy(buf, g_trace.data(), n);
+    buf[n] = 0;
+  }
+  if (on) g_trace.clear();
+  g_trace_on = on != 0;
+  return RMCLHIP_OK;
+}
 
 void rmclhip_pf_sharded_destroy(rmclhip_pf_sharded* h) {
   if (!h) return;
@@ -3475,29 +3680,23 @@ rmclhip_status rmclhip_pf_allgather_weights(rmclhip_pf_sharded* h) {
   if (!h) return fail(RMCLHIP_ERR_INVALID, "pf_allgather_weights: null");
   if (h->n_total == 0) return RMCLHIP_OK;
   const uint32_t world = static_cast<uint32_t>(h->ranks.size()), cap = (h->n_total + world - 1u) / world;
+  // extract, gather, compact: three steps per rank on its collective stream, all enqueued before the ONE wait per rank
+  std::vector<const void*> send(world);
+  std::vector<void*> recv(world);
   for (uint32_t r = 0; r < world; ++r) {
     PfRank& R = h->ranks[r];
     HIPCHK(hipSetDevice(R.ctx->device));
     HIPCHK(launch_pf_extract_weights(R.d_attrs, R.hi - R.lo, R.d_w_send, h->comm->streams[r]));
+    send[r] = R.d_w_send; recv[r] = R.d_w_pad;
   }
-  NCCLCHK(g_rccl.GroupStart());
-  for (uint32_t r = 0; r < world; ++r) {
-    PfRank& R = h->ranks[r];
-    (void)hipSetDevice(R.ctx->device);
-    const ncclResult_t nr = g_rccl.AllGather(R.d_w_send, R.d_w_pad, cap, ncclFloat, h->comm->comms[r], h->comm->streams[r]);
-    if (nr != ncclSuccess) { (void)g_rccl.GroupEnd(); return fail(RMCLHIP_ERR_HIP, std::string("ncclAllGather: ") + g_rccl.GetErrorString(nr)); }
-  }
-  NCCLCHK(g_rccl.GroupEnd());
+  if (rmclhip_status st = comm_allgather(h->comm, send.data(), recv.data(), static_cast<size_t>(cap) * sizeof(float))) return st;
   for (uint32_t r = 0; r < world; ++r) {
     PfRank& R = h->ranks[r];
     HIPCHK(hipSetDevice(R.ctx->device));
     HIPCHK(launch_compact_shards(R.d_w_pad, R.d_w_all, h->n_total, world, cap, h->comm->streams[r]));
+    trace('E', r);
   }
-  for (uint32_t r = 0; r < world; ++r) {
-    HIPCHK(hipSetDevice(h->ranks[r].ctx->device));
-    HIPCHK(hipStreamSynchronize(h->comm->streams[r]));
-  }
-  return RMCLHIP_OK;
+  return comm_wait_all(h->comm);
 }
 
 // PCDSensorUpdater*::update on every device's block of the particles (concurrently: one stream per device), then the
@@ -3506,14 +3705,20 @@ rmclhip_status rmclhip_pf_update_sharded(rmclhip_pf_sharded* h, const rmclhip_ra
                                          const rmclhip_transform* Tsb) {
   ApiGuard guard_("rmclhip_pf_update_sharded");
   if (!h || !Tsb || (n_beams && !beams)) return fail(RMCLHIP_ERR_INVALID, "pf_update_sharded: null");
-  for (PfRank& R : h->ranks) {
+  trace_mark("update:");
+  for (size_t r = 0; r < h->ranks.size(); ++r) {
+    PfRank& R = h->ranks[r];
     if (R.hi == R.lo) continue;
     if (rmclhip_status st = rmclhip_pf_update_async(R.pf, reinterpret_cast<const rmclhip_transform*>(R.d_poses),
                                                     static_cast<rmclhip_particle_attributes*>(R.d_attrs), R.hi - R.lo, beams, n_beams, Tsb))
       return st;
+    // the gather runs on the communicator's stream of this device: it waits for the update on the DEVICE (an event), not on the host
+    HIPCHK(hipSetDevice(R.ctx->device));
+    HIPCHK(hipEventRecord(R.pf->ev1, R.pf->stream));
+    HIPCHK(hipStreamWaitEvent(h->comm->streams[r], R.pf->ev1, 0));
+    trace('E', static_cast<uint32_t>(r));
   }
-  for (PfRank& R : h->ranks)
-    if (rmclhip_status st = rmclhip_pf_sync(R.pf)) return st;
+  trace_mark("gather:");
   return rmclhip_pf_allgather_weights(h);
 }
 
@@ -3537,22 +3742,18 @@ static rmclhip_status sharded_moments(rmclhip_pf_sharded* h, uint32_t n_use, int
     const uint32_t n = (hi > R.lo) ? (hi - R.lo) : 0u;
     HIPCHK(launch_pose_moments(R.d_poses, R.d_attrs, n, pass, L_sum, Tbm, R.d_mom_part, R.d_mom, h->comm->streams[r]));
   }
-  NCCLCHK(g_rccl.GroupStart());
+  std::vector<const double*> s_sum(world), s_max(world);
+  std::vector<double*> r_sum(world), r_max(world);
   for (uint32_t r = 0; r < world; ++r) {
     PfRank& R = h->ranks[r];
-    (void)hipSetDevice(R.ctx->device);
-    ncclResult_t nr = g_rccl.AllReduce(R.d_mom, R.d_mom + 32, 24, ncclDouble, ncclSum, h->comm->comms[r], h->comm->streams[r]);
-    if (nr == ncclSuccess) nr = g_rccl.AllReduce(R.d_mom + 24, R.d_mom + 32 + 24, 8, ncclDouble, ncclMax, h->comm->comms[r], h->comm->streams[r]);
-    if (nr != ncclSuccess) { (void)g_rccl.GroupEnd(); return fail(RMCLHIP_ERR_HIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(nr)); }
+    s_sum[r] = R.d_mom; r_sum[r] = R.d_mom + 32; s_max[r] = R.d_mom + 24; r_max[r] = R.d_mom + 32 + 24;
   }
-  NCCLCHK(g_rccl.GroupEnd());
+  if (rmclhip_status st = comm_allreduce_f64(h->comm, s_sum.data(), r_sum.data(), 24, false)) return st;
+  if (rmclhip_status st = comm_allreduce_f64(h->comm, s_max.data(), r_max.data(), 8, true)) return st;
   PfRank& R0 = h->ranks[0];
   HIPCHK(hipSetDevice(R0.ctx->device));
   HIPCHK(hipMemcpyAsync(R0.h_mom, R0.d_mom + 32, 32 * sizeof(double), hipMemcpyDeviceToHost, h->comm->streams[0]));
-  for (uint32_t r = 0; r < world; ++r) {
-    HIPCHK(hipSetDevice(h->ranks[r].ctx->device));
-    HIPCHK(hipStreamSynchronize(h->comm->streams[r]));
-  }
+  if (rmclhip_status st = comm_wait_all(h->comm)) return st;
   std::memcpy(out32, R0.h_mom, 32 * sizeof(double));
   return RMCLHIP_OK;
 }
@@ -3655,33 +3856,66 @@ static rmclhip_status pf_sharded_resample_impl(rmclhip_pf_sharded* h, const rmcl
   if (ragged && world > 1)
     return fail(RMCLHIP_ERR_UNSUPPORTED, "pf_sharded_resample: n_total must be a multiple of the number of devices (padded shards "
                                          "would shift the global particle indices of the gathered cloud)");
-  NCCLCHK(g_rccl.GroupStart());
+  // (1) the cloud (68 B per particle) is all-gathered on every rank's collective stream; (2) BEHIND it, on the same stream, every
+  // rank's tournament / slot fill over its own champions -- enqueued for ALL ranks before the host waits for any (round 3 ran the N
+  // tournaments one after the other, each with its own launch + wait).  The tournament reads one enemy per champion; gathering the
+  // whole cloud instead of an indexed exchange of the winners costs 68 B x N x (world - 1) / world per rank: C5 = 59.5 MB per rank,
+  // ~0.2 ms at the ~300 GB/s an 8-GPU RCCL all-gather reaches over xGMI (an estimate: no node to measure on) against a 2.9 ms
+  // sensor update per resampling step -- accepted, stated, and the first thing to replace if a profile says otherwise.
+  trace_mark("resample:");
+  std::vector<const void*> sp(world), sa(world);
+  std::vector<void*> rp(world), ra_(world);
   for (uint32_t r = 0; r < world; ++r) {
     PfRank& R = h->ranks[r];
-    (void)hipSetDevice(R.ctx->device);
-    ncclResult_t nr = g_rccl.AllGather(R.d_poses, R.d_poses_all, static_cast<size_t>(cap) * 32, ncclChar, h->comm->comms[r], h->comm->streams[r]);
-    if (nr == ncclSuccess) nr = g_rccl.AllGather(R.d_attrs, R.d_attrs_all, static_cast<size_t>(cap) * 36, ncclChar, h->comm->comms[r], h->comm->streams[r]);
-    if (nr != ncclSuccess) { (void)g_rccl.GroupEnd(); return fail(RMCLHIP_ERR_HIP, std::string("ncclAllGather: ") + g_rccl.GetErrorString(nr)); }
+    sp[r] = R.d_poses; rp[r] = R.d_poses_all; sa[r] = R.d_attrs; ra_[r] = R.d_attrs_all;
   }
-  NCCLCHK(g_rccl.GroupEnd());
-  for (uint32_t r = 0; r < world; ++r) {
-    HIPCHK(hipSetDevice(h->ranks[r].ctx->device));
-    HIPCHK(hipStreamSynchronize(h->comm->streams[r]));
+  if (rmclhip_status st = comm_allgather(h->comm, sp.data(), rp.data(), static_cast<size_t>(cap) * 32)) return st;
+  if (rmclhip_status st = comm_allgather(h->comm, sa.data(), ra_.data(), static_cast<size_t>(cap) * 36)) return st;
+  if (!residual) {
+    for (uint32_t r = 0; r < world; ++r) {
+      PfRank& R = h->ranks[r];
+      if (R.hi == R.lo) continue;
+      // every device resamples ITS champions against the whole gathered cloud: the random stream is a function of the global index
+      if (rmclhip_status st = gladiator_enqueue(R.rs, reinterpret_cast<const rmclhip_transform*>(R.d_poses_all),
+                                                static_cast<const rmclhip_particle_attributes*>(R.d_attrs_all), h->n_total,
+                                                reinterpret_cast<rmclhip_transform*>(R.d_poses_new),
+                                                static_cast<rmclhip_particle_attributes*>(R.d_attrs_new), R.lo, R.hi - R.lo, cfg, seed, step,
+                                                h->comm->streams[r]))
+        return st;
+      trace('E', r);
+    }
+    if (rmclhip_status st = comm_wait_all(h->comm)) return st;
+  } else {
+    std::vector<ResidualJob> jobs(world);
+    for (uint32_t r = 0; r < world; ++r) {
+      PfRank& R = h->ranks[r];
+      ResidualJob& j = jobs[r];
+      j.r = R.rs; j.st = h->comm->streams[r];
+      j.poses = reinterpret_cast<const rmclhip_transform*>(R.d_poses_all); j.attrs = static_cast<const rmclhip_particle_attributes*>(R.d_attrs_all);
+      j.poses_new = reinterpret_cast<rmclhip_transform*>(R.d_poses_new); j.attrs_new = static_cast<rmclhip_particle_attributes*>(R.d_attrs_new);
+      j.n_particles = h->n_total; j.n_new = h->n_total; j.first = R.lo; j.count = R.hi - R.lo; j.cfg = cfg; j.seed = seed; j.step = step;
+      if (rmclhip_status st = residual_check(j)) return st;
+    }
+    // three phases, each enqueued on every rank before the one wait per rank (round 3: three waits per rank, rank after rank)
+    for (uint32_t r = 0; r < world; ++r) { if (rmclhip_status st = residual_prepare_enqueue(jobs[r])) return st; trace('E', r); }
+    if (rmclhip_status st = comm_wait_all(h->comm)) return st;
+    for (bool first_try = true;; first_try = false) {
+      bool any = false;
+      for (uint32_t r = 0; r < world; ++r) {
+        if (!jobs[r].active || jobs[r].filled) continue;
+        any = true;
+        if (rmclhip_status st = residual_draws_enqueue(jobs[r], first_try)) return st;
+        trace('E', r);
+      }
+      if (!any) break;
+      if (rmclhip_status st = comm_wait_all(h->comm)) return st;
+      for (uint32_t r = 0; r < world; ++r) residual_draws_done(jobs[r]);
+    }
+    for (uint32_t r = 0; r < world; ++r) { if (rmclhip_status st = residual_fill_enqueue(jobs[r], false)) return st; trace('E', r); }
+    if (rmclhip_status st = comm_wait_all(h->comm)) return st;
   }
   for (PfRank& R : h->ranks) {
     if (R.hi == R.lo) continue;
-    // every device resamples ITS slots / champions against the whole gathered cloud: both streams are functions of global indices
-    const rmclhip_status st =
-        residual ? rmclhip_resampler_residual(R.rs, reinterpret_cast<const rmclhip_transform*>(R.d_poses_all),
-                                              static_cast<const rmclhip_particle_attributes*>(R.d_attrs_all), h->n_total,
-                                              reinterpret_cast<rmclhip_transform*>(R.d_poses_new),
-                                              static_cast<rmclhip_particle_attributes*>(R.d_attrs_new), h->n_total, R.lo, R.hi - R.lo, cfg, seed,
-                                              step, nullptr)
-                 : rmclhip_resampler_gladiator(R.rs, reinterpret_cast<const rmclhip_transform*>(R.d_poses_all),
-                                               static_cast<const rmclhip_particle_attributes*>(R.d_attrs_all), h->n_total,
-                                               reinterpret_cast<rmclhip_transform*>(R.d_poses_new),
-                                               static_cast<rmclhip_particle_attributes*>(R.d_attrs_new), R.lo, R.hi - R.lo, cfg, seed, step);
-    if (st != RMCLHIP_OK) return st;
     std::swap(R.d_poses, R.d_poses_new);
     std::swap(R.d_attrs, R.d_attrs_new);
   }

@@ -313,6 +313,7 @@ hipError_t launch_pf_motion(const uint32_t* nodes, const uint32_t* tris, xform* 
 // pose-estimate moments (RmclNode::estimateStats): partials = 256 * 32 doubles of scratch, out32 = 24 sums + 8 maxima (device)
 hipError_t launch_pose_moments(const xform* poses, const void* attrs, uint32_t n, int pass, double L_sum, xform Tbm,
                                double* partials, double* out32, hipStream_t s);
+hipError_t launch_loopback_allreduce(const double* const* send, uint32_t world, double* recv, uint32_t count, bool is_max, hipStream_t s);
 hipError_t launch_compact_shards(const float* padded, float* dense, uint32_t n_total, uint32_t world, uint32_t cap, hipStream_t s);
 
 }  // namespace rmclhip

@@ -2741,6 +2741,24 @@ hipError_t launch_pose_moments(const xform* poses, const void* attrs, uint32_t n
   return hipGetLastError();
 }
 
+// in-process stand-in for ncclAllReduce on doubles (the loopback communicator of the tests, capi.cpp): every "rank" runs this on its own
+// stream over the send buffers of all of them, in rank order (deterministic)
+struct LoopbackPtrs { const double* p[64]; };
+__global__ void k_loopback_allreduce(LoopbackPtrs send, uint32_t world, double* __restrict__ recv, uint32_t count, uint32_t is_max) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double a = send.p[0][i];
+  for (uint32_t r = 1; r < world; ++r) { const double b = send.p[r][i]; a = is_max ? fmax(a, b) : a + b; }
+  recv[i] = a;
+}
+hipError_t launch_loopback_allreduce(const double* const* send, uint32_t world, double* recv, uint32_t count, bool is_max, hipStream_t s) {
+  if (count == 0 || world == 0 || world > 64) return world > 64 ? hipErrorInvalidValue : hipSuccess;
+  LoopbackPtrs lp;
+  for (uint32_t r = 0; r < 64; ++r) lp.p[r] = send[r < world ? r : 0];
+  hipLaunchKernelGGL(k_loopback_allreduce, dim3((count + 63u) / 64u), dim3(64), 0, s, lp, world, recv, count, is_max ? 1u : 0u);
+  return hipGetLastError();
+}
+
 hipError_t launch_compact_shards(const float* padded, float* dense, uint32_t n_total, uint32_t world, uint32_t cap, hipStream_t s) {
   if (n_total == 0) return hipSuccess;
   hipLaunchKernelGGL(k_compact_shards, dim3((n_total + 255u) / 256u), dim3(256), 0, s, padded, dense, n_total, world, cap);

@@ -264,10 +264,13 @@ class ShardedParticleFilterHip:
     ncclCommInitAll + all-gather / all-reduce over xGMI) -- the multi-GPU form of PCDSensorUpdater + GladiatorResampler +
     RmclNode::estimateStats for the single-process node (rmcl_localization.cpp:482-552, 642-731)."""
 
-    def __init__(self, vertices, faces, devices=(0,)):
+    def __init__(self, vertices, faces, devices=(0,), loopback=False):
+        """loopback=True: the in-process stand-in for RCCL (rmclhip_comm_create_loopback) -- `devices` may then repeat a device, which
+        lets a one-GPU box run and check the ndev > 1 code paths; never a production configuration."""
         devs = (C.c_int * len(devices))(*[int(d) for d in devices])
         self._comm = C.c_void_p()
-        _capi.check(_capi.lib().rmclhip_comm_create(devs, len(devices), C.byref(self._comm)))
+        create = _capi.lib().rmclhip_comm_create_loopback if loopback else _capi.lib().rmclhip_comm_create
+        _capi.check(create(devs, len(devices), C.byref(self._comm)))
         v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
         f = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
         self._h = C.c_void_p()

@@ -83,8 +83,49 @@ if __name__ == "__main__":
     _main()
 
 
-def test_c_abi_sharded_particle_filter_on_one_device(ra, orc, ctx, meshes):
-    """multi-GPU behind the C ABI (rmclhip_comm_create = RCCL ncclCommInitAll in ONE process, the shape of the reference's
+def _trace(ra, on):
+    import ctypes as C
+    buf = C.create_string_buffer(1 << 16)
+    ra._capi.check(ra._capi.lib().rmclhip_debug_trace(int(on), buf, len(buf)))
+    return buf.value.decode()
+
+
+def _phases(trace):
+    """{label: [tokens]} of a rmclhip_debug_trace recording"""
+    out, cur = {}, None
+    for tok in trace.split():
+        if tok.endswith(":"):
+            cur = tok[:-1]
+            out.setdefault(cur, [])
+        elif cur is not None:
+            out[cur].append(tok)
+    return out
+
+
+def _enqueues_precede_waits(tokens, world):
+    """every maximal run of E tokens covers all ranks before the first W of the run that follows it: E0 E1 .. W0 W1 .., never E0 W0 E1 W1"""
+    i, ok, seen_block = 0, True, False
+    while i < len(tokens):
+        es = []
+        while i < len(tokens) and tokens[i][0] == "E":
+            es.append(tokens[i]); i += 1
+        ws = []
+        while i < len(tokens) and tokens[i][0] == "W":
+            ws.append(tokens[i]); i += 1
+        if es:
+            seen_block = True
+            ok &= len(ws) == world            # one wait per rank, after the enqueues
+            ok &= len(set(es)) == len(es)     # a rank is enqueued once per phase
+    return ok and seen_block
+
+
+@pytest.mark.parametrize("devices,loopback", [((0,), False), ((0,), True), ((0, 0), True), ((0, 0, 0, 0), True)],
+                         ids=["rccl-1", "loopback-1", "loopback-2", "loopback-4"])
+def test_c_abi_sharded_particle_filter_on_one_device(ra, orc, ctx, meshes, devices, loopback):
+    """(round 4: also with the in-process LOOPBACK communicator at 2 and 4 ranks on device 0 -- rmclhip_comm_create_loopback -- so that
+    the ndev > 1 branches of every sharded entry point execute on this box and are held to the same results; the recorded call
+    sequence must enqueue every rank's part of a phase before the host waits for any.)
+    multi-GPU behind the C ABI (rmclhip_comm_create = RCCL ncclCommInitAll in ONE process, the shape of the reference's
     single-process node, rmcl_localization.cpp:482-552) at ndev = 1 on the GPU that is there: sharded sensor update + weight
     all-gather == unsharded update; all-reduced {sum, max}; the pose estimate (Markley mean + 6x6 covariance,
     rmcl_localization.cpp:642-731) vs the oracle's double-precision restatement; distributed tournament == single-GPU one."""
@@ -109,10 +150,16 @@ def test_c_abi_sharded_particle_filter_on_one_device(ra, orc, ctx, meshes):
     ref_attrs = d_a.download()
     upd.close()
 
-    sh = ra.ShardedParticleFilterHip(v, f, devices=(0,))
-    assert sh.world == 1
+    sh = ra.ShardedParticleFilterHip(v, f, devices=devices, loopback=loopback)
+    world = len(devices)
+    assert sh.world == world
     sh.set_particles(poses, attrs)
+    _trace(ra, 1)
     w = sh.update(beams, Tsb)
+    tr = _phases(_trace(ra, 0))
+    assert _enqueues_precede_waits(tr["update"] + tr["gather"], world), tr
+    for rk in range(world):
+        assert np.array_equal(sh.weights(rk), w)      # every rank holds the same dense vector
     p2, a2 = sh.download()
     assert a2.tobytes() == ref_attrs.tobytes() and p2.tobytes() == poses.tobytes()
     assert np.array_equal(w, ref_attrs["likelihood"]["mean"])
@@ -139,7 +186,9 @@ def test_c_abi_sharded_particle_filter_on_one_device(ra, orc, ctx, meshes):
     d_pn, d_an = ra.DeviceArray(ctx, T.TRANSFORM, n), ra.DeviceArray(ctx, T.PARTICLE_ATTRIBUTES, n)
     rs.seed = 42
     rs.update(d_p2, d_a2, d_pn, d_an, n)
+    _trace(ra, 1)
     sh.resample(seed=42, step=0)
+    assert _enqueues_precede_waits(_phases(_trace(ra, 0))["resample"], world)
     p3, a3 = sh.download()
     assert p3.tobytes() == d_pn.download().tobytes() and a3.tobytes() == d_an.download().tobytes()
     rs.close()
@@ -147,7 +196,9 @@ def test_c_abi_sharded_particle_filter_on_one_device(ra, orc, ctx, meshes):
     rr = ra.ResidualResamplerHip(ctx, seed=43)
     d_p4, d_a4 = ra.DeviceArray.from_host(ctx, p3), ra.DeviceArray.from_host(ctx, a3)
     rr.update(d_p4, d_a4, d_pn, d_an, n)
+    _trace(ra, 1)
     sh.resample(seed=43, step=0, residual=True)
+    assert _enqueues_precede_waits(_phases(_trace(ra, 0))["resample"], world)
     p5, a5 = sh.download()
     assert p5.tobytes() == d_pn.download().tobytes() and a5.tobytes() == d_an.download().tobytes()
     assert a5.tobytes() != a3.tobytes()
@@ -199,3 +250,26 @@ def test_c_abi_sharded_pose_batch_equals_unsharded(ra, orc, ctx, meshes, devices
         _transform_close(Td[i], Tr[i], 1e-5)
     sh.close()
     one.close()
+
+
+def test_loopback_ragged_three_ranks(ra, orc, ctx, meshes):
+    """1001 particles over three loopback ranks on device 0 (334 + 334 + 333, padded shards in the gather): update + all-gather ==
+    unsharded update, {sum, max} and the pose estimate from the all-reduced moments == the one-rank results."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room30k")
+    n = 1001
+    poses, attrs = syn.uniform_particles(n, seed=9, bb_min=(-8, -8, 0.2, 0, 0, -math.pi), bb_max=(8, 8, 3, 0, 0, math.pi))
+    beams = ra.beams_from_points(syn.model_directions(syn.model_pf16())[::8] * np.float32(4.0))
+    Tsb = syn.tsb_offset()
+    res = {}
+    for devices in ((0,), (0, 0, 0)):
+        sh = ra.ShardedParticleFilterHip(v, f, devices=devices, loopback=True)
+        sh.set_particles(poses, attrs)
+        w = sh.update(beams, Tsb)
+        res[len(devices)] = (w.copy(), sh.download()[1], sh.stats(), sh.pose_estimate(n))
+        sh.close()
+    (w1, a1, s1, e1), (w3, a3, s3, e3) = res[1], res[3]
+    assert np.array_equal(w1, w3) and a1.tobytes() == a3.tobytes()
+    assert abs(s1["sum"] - s3["sum"]) <= 1e-6 * abs(s1["sum"]) and s1["max"] == s3["max"]
+    assert np.allclose([e1["pose"]["t"][k] for k in "xyz"], [e3["pose"]["t"][k] for k in "xyz"], rtol=1e-6, atol=1e-7)
+    assert np.allclose(e1["covariance"], e3["covariance"], rtol=1e-6, atol=1e-9)

@@ -110,7 +110,7 @@ static void ws_frontier(ws_lane* l, const uint32_t* nodes, uint32_t node, int de
 }
 
 int orc_wavesim_ww(const uint32_t* nodes, const uint32_t* tris, const float* O, const float* D, uint32_t nlanes,
-                   float tfar, int mode, uint64_t out[7], float* t_out, uint32_t* face_out)
+                   float tfar, int mode, uint64_t out[8], float* t_out, uint32_t* face_out)
 {
   double est = 0.0;
   if (nlanes > 64) return -1;
@@ -140,7 +140,7 @@ int orc_wavesim_ww(const uint32_t* nodes, const uint32_t* tris, const float* O, 
       g_frontier_cands += (uint64_t)nc;
     }
   }
-  memset(out, 0, 7 * sizeof(uint64_t));
+  memset(out, 0, 8 * sizeof(uint64_t));
   for (;;) {
     int any = 0; uint32_t walking = 0;
     for (uint32_t i = 0; i < nlanes; ++i) { any |= !L[i].done; walking += L[i].done ? 0u : 1u; }
@@ -207,6 +207,7 @@ int orc_wavesim_ww(const uint32_t* nodes, const uint32_t* tris, const float* O, 
       l->lvisit++;
       const uint32_t leaf = l->pend ? l->pend : l->cur;
       const uint32_t first = leaf & 0x0FFFFFFFu, cnt = ((leaf >> 28) & 7u) + 1u;
+      out[7] += cnt;   /* triangle records fetched by lanes (64 B each) */
       if (cnt > maxcnt) maxcnt = cnt;
       for (uint32_t k = 0; k < cnt; ++k) {
         const float* r = (const float*)(tris + 16u * (first + k));

@@ -50,7 +50,7 @@ def simulate(nodes, tris, model, O, dm, mode, tile=(8, 8), stride=1, seeded=Fals
                 continue
             d = np.ascontiguousarray(img[ty:ty + th, tx:tx + tw].reshape(-1, 3))
             o = np.ascontiguousarray(np.tile(O, (len(d), 1)))
-            out = np.zeros(7, np.uint64)
+            out = np.zeros(8, np.uint64)
             if seeded:
                 # tracking mode: every ray starts with the hit distance of the previous (identical) scan as its best_t
                 t_prev = np.zeros(len(d), np.float32)
