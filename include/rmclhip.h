@@ -529,6 +529,16 @@ rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* pf, int variant);
 /* schedule of the persistent-lane kernel: a wave fetches new beams once `refill_idle_lanes` of its lanes are idle (0: the
  * threshold selected by set_variant) and leaves its node phase when at most `tail_lanes` lanes still descend while
  * another holds a leaf (default 8).  The result does not depend on either (tests/test_gpu_pf.py). */
+/* Ray dealing of the sensor update.  mapping 0 (default): beam-minor -- a workgroup takes ~2048 rays of a few particles, a wave's lanes
+ * hold DIFFERENT beams (uniform clouds: nothing is coherent anyway).  mapping 1: particle-minor -- a workgroup takes
+ * `particles_per_block` (0 = 32, at most 64) consecutive SLOTS and deals their rays out so that the 64 lanes of a wave hold the same
+ * beam of consecutive slots: nearly the same ray when the cloud has converged, so the lanes walk the tree together (one cache line per
+ * node step instead of up to 64, no masked lanes).  order_dev (nullable, borrowed device memory, n_order = the particle count it is
+ * for): slot -> particle index, e.g. sorted by a Morton key of (x, y, yaw) once per resampling step (rmclhip_pf_spatial_order);
+ * null = slot i is particle i.  The rays, every beam's error and the in-order Gaussian1D merge per particle are those of mapping 0:
+ * results do not depend on the mapping or the order. */
+rmclhip_status rmclhip_pf_set_mapping(rmclhip_pf* pf, int mapping, uint32_t particles_per_block, const uint32_t* order_dev,
+                                      uint32_t n_order);
 rmclhip_status rmclhip_pf_set_schedule(rmclhip_pf* pf, uint32_t refill_idle_lanes, uint32_t tail_lanes);
 /* Beam sampling of PCDSensorUpdater{Embree,Optix}::update (PCDSensorUpdaterEmbree.cpp:276-327) on the raw
  * sensor_msgs/PointCloud2 bytes (HOST function, no device needed): `samples` uniformly random points, each with up to 100

@@ -185,6 +185,7 @@ SIGNATURES = {
     "rmclhip_pf_time_update": (_i32, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32, C.POINTER(_f32)]),
     "rmclhip_pf_set_variant": (_i32, [_vp, _i32]),
     "rmclhip_pf_set_schedule": (_i32, [_vp, _u32, _u32]),
+    "rmclhip_pf_set_mapping": (_i32, [_vp, _i32, _u32, _vp, _u32]),
     "rmclhip_ctx_set_wait_mode": (_i32, [_vp, _i32]),
     "rmclhip_rcc_set_cpc_tracking": (_i32, [_vp, _i32]),
     "rmclhip_rcc_set_cpc_bounded": (_i32, [_vp, _i32]),

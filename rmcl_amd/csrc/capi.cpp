@@ -292,6 +292,12 @@ struct rmclhip_pf {
   float* errors_dev = nullptr;
   int variant = 0;
   uint32_t refill_thr = 0, tail_lanes = 8;  // schedule knobs of the round-3 kernel (0: from `refill`); rmclhip_pf_set_schedule
+  // rmclhip_pf_set_mapping: 0 beam-minor blocks of ~2048 rays (uniform clouds), 1 particle-minor blocks (converged clouds), 2 automatic
+  int mapping = 0;
+  uint32_t map_ppb = 0;            // particles per workgroup of the particle-minor mapping (0: 32)
+  const uint32_t* order = nullptr; // slot -> particle (device), borrowed or d_order
+  uint32_t order_n = 0;
+  DevBuf<uint32_t> d_order;
   bool beams_at_origin = false;  // of the beams uploaded last: all start at the sensor origin
   bool legacy = false;      // A/B: the round-2 kernel (k_pf_update_persist)
   bool big_blocks = false;  // A/B: 4096 rays per workgroup
@@ -2925,7 +2931,16 @@ static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, 
   uint32_t pb = (f->big_blocks ? 4096u : 2048u) / n_beams;
   if (pb < 1u) pb = 1u;
   if (pb > 64u) pb = 64u;
-  if (static_cast<size_t>(pb) * n_beams > 8192u) return fail(RMCLHIP_ERR_UNSUPPORTED, "pf_update: more than 8192 beams");
+  p.particle_minor = 0u;
+  p.order = nullptr;
+  if (f->mapping == 1) {
+    // particle-minor dealing: a wave's lanes hold the same beam of `pb` consecutive slots; errors of pb x n_beams beams stay in LDS
+    p.particle_minor = 1u;
+    pb = f->map_ppb ? f->map_ppb : 32u;
+    while (pb > 1u && static_cast<size_t>(pb) * n_beams * 4u > 96u * 1024u) pb >>= 1;
+    if (f->order && f->order_n == n) p.order = f->order;
+  }
+  if (static_cast<size_t>(pb) * n_beams > (p.particle_minor ? 24576u : 8192u)) return fail(RMCLHIP_ERR_UNSUPPORTED, "pf_update: more than 8192 beams");
   p.particles_per_block = pb;
   p.beams_at_origin = f->beams_at_origin ? 1u : 0u;
   static const uint32_t kRefillAt[5] = {48u, 8u, 16u, 32u, 48u};
@@ -3018,6 +3033,16 @@ rmclhip_status rmclhip_pf_set_schedule(rmclhip_pf* f, uint32_t refill_idle_lanes
   if (!f || refill_idle_lanes > 64u || tail_lanes > 64u) return fail(RMCLHIP_ERR_INVALID, "pf_set_schedule: bad arguments");
   f->refill_thr = refill_idle_lanes;
   f->tail_lanes = tail_lanes;
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_pf_set_mapping(rmclhip_pf* f, int mapping, uint32_t particles_per_block, const uint32_t* order_dev, uint32_t n_order) {
+  ApiGuard guard_("rmclhip_pf_set_mapping");
+  if (!f || mapping < 0 || mapping > 1 || particles_per_block > 64u) return fail(RMCLHIP_ERR_INVALID, "pf_set_mapping: bad arguments");
+  f->mapping = mapping;
+  f->map_ppb = particles_per_block;
+  f->order = order_dev;
+  f->order_n = order_dev ? n_order : 0u;
   return RMCLHIP_OK;
 }
 

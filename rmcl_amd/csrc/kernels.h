@@ -115,6 +115,12 @@ struct PfParams {
   uint32_t refill_thr, tail_lanes;  // schedule of the persistent-lane kernel: refill when >= refill_thr lanes of a wave are idle;
                                  // leave the node phase when <= tail_lanes lanes still descend and a lane holds a leaf
   uint32_t nb_magic;             // floor(2^32 / n_beams) + 1: ray index / n_beams = umulhi(ray, nb_magic) for ray * n_beams < 2^32
+  // Round 4 -- particle-coherent mapping (rmclhip_pf_set_mapping): the block's rays are dealt out PARTICLE-minor (ray j = beam j / np
+  // of particle j % np), so the 64 lanes of a wave hold the SAME beam of 64 particles -- nearly the same ray when the cloud has
+  // converged and neighbouring slots hold neighbouring particles (order: slot -> particle index, sorted by a Morton key of x, y, yaw;
+  // null = identity).  Same rays, same per-particle merge order: results do not depend on the mapping.
+  uint32_t particle_minor;
+  const uint32_t* order;         // nullable [n_particles]
 };
 
 // per-call inputs of the device-resident MICP loop: written by ONE H2D copy so that the whole loop can be a

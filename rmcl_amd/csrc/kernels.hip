@@ -1437,15 +1437,18 @@ __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
   if (p0 >= p.n_particles) return;
   const uint32_t np = min(PB, p.n_particles - p0);
   pattrs* attrs = reinterpret_cast<pattrs*>(p.attrs);
+  // slot j of the block = particle `mine` (identity, or the caller's spatial order)
+  const uint32_t mine_p = (threadIdx.x < np) ? (p.order ? p.order[p0 + threadIdx.x] : p0 + threadIdx.x) : 0u;
   if (threadIdx.x < np) {
-    s_Tsm[threadIdx.x] = xmul(p.poses[p0 + threadIdx.x], p.Tsb);
-    s_n0[threadIdx.x] = attrs[p0 + threadIdx.x].likelihood.n_meas;
+    s_Tsm[threadIdx.x] = xmul(p.poses[mine_p], p.Tsb);
+    s_n0[threadIdx.x] = attrs[mine_p].likelihood.n_meas;
   }
   if (threadIdx.x == 0) s_next = 0u;
   __syncthreads();
 
   const float sq = p.dist_sigma * p.dist_sigma;
   const uint32_t nrays = np * p.n_beams;
+  const uint32_t np_magic = (np == 1u) ? 0u : static_cast<uint32_t>(0x100000000ull / np) + 1u;   // ray / np (particle-minor order)
   const uint32_t lane = threadIdx.x & 63u;
   constexpr uint32_t kDone = 0x7FFFFFFFu;
   // per-lane ray state
@@ -1495,9 +1498,11 @@ __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
       if (idle) {
         const uint32_t mine = base + static_cast<uint32_t>(__popcll(want & ((1ull << lane) - 1ull)));
         if (mine < nrays) {
-          rr = mine;
           // (n_beams == 1: floor(2^32 / 1) + 1 does not fit the 32-bit magic -- every ray is its own particle)
-          const uint32_t pi = (p.n_beams == 1u) ? rr : __umulhi(rr, p.nb_magic), b = rr - pi * p.n_beams;
+          uint32_t pi, b;
+          if (p.particle_minor) { b = (np == 1u) ? mine : __umulhi(mine, np_magic); pi = mine - b * np; }
+          else { pi = (p.n_beams == 1u) ? mine : __umulhi(mine, p.nb_magic); b = mine - pi * p.n_beams; }
+          rr = pi * p.n_beams + b;     // the beam's slot in s_eval (particle-major whatever the dealing order)
           const xform Tsm = s_Tsm[pi];
           const float* bm = p.beams + 16u * b;
           // meas_m = Tsm * meas_s (RangeMeasurement.hpp:28-42)
@@ -1562,7 +1567,10 @@ __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
   const double den = sqrt(static_cast<double>(2 * sq) * 3.14159265358979323846);
   for (uint32_t i = threadIdx.x; i < nrays; i += 256u) {
     const float error = s_eval[i];
-    if (p.errors) p.errors[static_cast<size_t>(p0) * p.n_beams + i] = error;
+    if (p.errors) {
+      if (p.order) { const uint32_t pi = i / p.n_beams; p.errors[static_cast<size_t>(p.order[p0 + pi]) * p.n_beams + (i - pi * p.n_beams)] = error; }
+      else p.errors[static_cast<size_t>(p0) * p.n_beams + i] = error;
+    }
     const float arg = -(error * error) / sq / 2;
     s_eval[i] = static_cast<float>(exp(static_cast<double>(arg)) / den);
   }
@@ -1575,7 +1583,7 @@ __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
   const uint32_t chunk = min(p.n_beams, (static_cast<uint32_t>(kRows * 256) / np - 2u) / 2u);  // beams per chunk; np <= 64 => >= 39
   const uint32_t wstride = 2u * chunk + 2u;
   g1d L = {0.f, 0.f, 0u};
-  if (threadIdx.x < np) L = attrs[p0 + threadIdx.x].likelihood;
+  if (threadIdx.x < np) L = attrs[mine_p].likelihood;
   for (uint32_t b0 = 0; b0 < p.n_beams; b0 += chunk) {
     const uint32_t nb = min(chunk, p.n_beams - b0);
     __syncthreads();
@@ -1606,7 +1614,7 @@ __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
   if (threadIdx.x < np) {
     const uint32_t n0 = s_n0[threadIdx.x], k = p.n_beams;
     L.n_meas = (n0 < p.max_n_meas) ? n0 + min(k, p.max_n_meas - n0) : p.max_n_meas;
-    attrs[p0 + threadIdx.x].likelihood = L;
+    attrs[mine_p].likelihood = L;
   }
 }
 
@@ -2629,6 +2637,17 @@ hipError_t launch_pf_update(const PfParams& p, int variant, hipStream_t s) {
   }
   if (trav == 0 && refill != 0 && !legacy && ((variant >> 7) & 1) == 0 && p.qnodes != nullptr) {
     const size_t lds = static_cast<size_t>(kPfRows) * 256u * sizeof(uint32_t) + tail + sizeof(uint32_t) * p.particles_per_block;
+    if (lds > 65536u) {   // (particle-minor blocks of 64 particles x 256 beams keep 64 KB of beam errors)
+      static bool raised[2] = {false, false};
+      if (!raised[leaf2 ? 1 : 0]) {
+        const hipError_t ae = leaf2 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pf_update_v3<kPfRows, true>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)
+                                    : hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pf_update_v3<kPfRows, false>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        if (ae != hipSuccess) return ae;
+        raised[leaf2 ? 1 : 0] = true;
+      }
+    }
     if (leaf2) hipLaunchKernelGGL((k_pf_update_v3<kPfRows, true>), dim3(nblocks), dim3(256), lds, s, p);
     else hipLaunchKernelGGL((k_pf_update_v3<kPfRows, false>), dim3(nblocks), dim3(256), lds, s, p);
     return hipGetLastError();

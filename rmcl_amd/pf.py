@@ -164,6 +164,15 @@ class PCDSensorUpdaterHip:
             self.init()
         _capi.check(_capi.lib().rmclhip_pf_set_schedule(self._h, int(refill_idle_lanes), int(tail_lanes)))
 
+    def set_mapping(self, mapping, particles_per_block=0, order=None):
+        """ray dealing of the update (rmclhip_pf_set_mapping): 0 beam-minor (default), 1 particle-minor (converged clouds); order: a
+        DeviceArray of uint32 slot -> particle indices (kept alive by this object) or None"""
+        if not self._h:
+            self.init()
+        self._order = order
+        _capi.check(_capi.lib().rmclhip_pf_set_mapping(self._h, int(mapping), int(particles_per_block),
+                                                       order.ptr if order is not None else None, order.count if order is not None else 0))
+
     def _push_params(self):
         _capi.check(_capi.lib().rmclhip_pf_set_params(self._h, C.byref(self.config)))
 

@@ -193,5 +193,64 @@ def uniform_particles(n, seed=42, bb_min=(-8, -8, -1, 0, 0, -math.pi), bb_max=(8
     return poses, attrs
 
 
+def converged_particles(n, centre, sigma_t=0.25, sigma_yaw_deg=5.0, seed=42):
+    """a converged particle cloud: poses ~ centre o N(0, sigma_t) in x / y (z: sigma_t / 4), yaw ~ N(0, sigma_yaw), roll = pitch = 0 in
+    the centre's frame -- the filter's steady state (the reference resamples around the mode: GladiatorResamplerGPU noise terms);
+    attrs as uniform_particles.  Seeded, order random (as a tournament leaves it)."""
+    from . import types as T
+    rng = np.random.RandomState(seed)
+    d = np.zeros(n, dtype=TRANSFORM)
+    yaw = rng.normal(0.0, math.radians(sigma_yaw_deg), n)
+    d["R"]["z"], d["R"]["w"] = np.sin(yaw / 2), np.cos(yaw / 2)
+    d["t"]["x"], d["t"]["y"], d["t"]["z"] = rng.normal(0, sigma_t, n), rng.normal(0, sigma_t, n), rng.normal(0, sigma_t / 4, n)
+    # pose_i = centre * d_i, with the library's own arithmetic (vectorised restatement of Transform::operator*)
+    c = np.ascontiguousarray(centre, dtype=TRANSFORM).reshape(1)[0]
+    cq = np.array([c["R"][k] for k in "xyzw"], np.float64)
+    ct = np.array([c["t"][k] for k in "xyz"], np.float64)
+    dq = np.stack([d["R"][k].astype(np.float64) for k in "xyzw"], -1)
+    dt = np.stack([d["t"][k].astype(np.float64) for k in "xyz"], -1)
+
+    def qmul(a, b):
+        ax, ay, az, aw = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+        bx, by, bz, bw = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+        return np.stack([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                         aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz], -1)
+
+    q = qmul(cq[None, :], dq)
+    pv = np.concatenate([dt, np.zeros((n, 1))], -1)
+    cinv = cq * np.array([-1, -1, -1, 1.0])
+    rt = qmul(qmul(cq[None, :], pv), cinv[None, :])[:, :3] + ct
+    poses = np.zeros(n, dtype=TRANSFORM)
+    for i, k in enumerate("xyzw"):
+        poses["R"][k] = q[:, i]
+    for i, k in enumerate("xyz"):
+        poses["t"][k] = rt[:, i]
+    attrs = np.zeros(n, dtype=PARTICLE_ATTRIBUTES)
+    attrs["likelihood"]["mean"] = 1.0
+    _ = T
+    return poses, attrs
+
+
+def morton_order_xy_yaw(poses, bits=10):
+    """slot -> particle index sorted by a Morton key of (x, y, yaw), `bits` bits each over the cloud's own bounding box: what
+    rmclhip_pf_spatial_order computes on the device (the host form serves tests and tools)"""
+    x, y = poses["t"]["x"].astype(np.float64), poses["t"]["y"].astype(np.float64)
+    yaw = 2.0 * np.arctan2(poses["R"]["z"].astype(np.float64), poses["R"]["w"].astype(np.float64))
+
+    def quant(v):
+        lo, hi = v.min(), v.max()
+        s = (2 ** bits - 1) / (hi - lo) if hi > lo else 0.0
+        return np.clip(((v - lo) * s), 0, 2 ** bits - 1).astype(np.uint64)
+
+    def spread(v):
+        out = np.zeros_like(v)
+        for b in range(bits):
+            out |= ((v >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b)
+        return out
+
+    key = spread(quant(yaw)) << np.uint64(2) | spread(quant(x)) << np.uint64(1) | spread(quant(y))
+    return np.argsort(key, kind="stable").astype(np.uint32)
+
+
 __all__ = [n for n in dir() if not n.startswith("_")]
 _ = euler_to_quat  # re-exported for callers
