@@ -293,6 +293,15 @@ def main():
                 dt = (time.perf_counter() - t1) / 20
                 extras[key] = round(dt * 1e3, 4)
             extras["cpc_closest_points_per_s"] = round(n_rays / dt, 1)
+            # the cold query WITHOUT the map's near grid (round 3's cold; rmclhip_rcc_set_cpc_grid 0): no seed at all, as rtcPointQuery
+            cpc.set_tracking(False)
+            cpc.set_grid(False)
+            cpc.find(est)
+            t1 = time.perf_counter()
+            for _ in range(20):
+                cpc.find(est)
+            extras["cpc_find_cold_no_grid_ms"] = round((time.perf_counter() - t1) / 20 * 1e3, 4)
+            cpc.set_grid(True)
             # opt-in: search only within max_dist (hits and hit outputs unchanged; rmclhip_rcc_set_cpc_bounded), cold
             cpc.set_tracking(False)
             cpc.set_bounded(True)

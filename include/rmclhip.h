@@ -301,6 +301,12 @@ rmclhip_status rmclhip_rcc_set_cpc_tracking(rmclhip_rcc* rcc, int on);
  * face id 0xFFFFFFFF -- it is gated out of every statistic either way.  A first (cold) find then costs about what a tracked one
  * does; the two options combine. */
 rmclhip_status rmclhip_rcc_set_cpc_bounded(rmclhip_rcc* rcc, int on);
+/* The map's near grid (default on): ~2 M cubic cells over the map's box, each holding the triangle closest to its centre, built on the
+ * first closest-point query of any operator of the map (one launch, a few ms, 4 B per cell).  A point without a tracking seed --
+ * every point of a COLD query: first scan, new dataset, tracking off -- starts from the record of its cell: an actual candidate,
+ * hence a bound within about a cell of the answer, so the cold query prunes like a tracked one (CPCEmbree.cpp:18-44 has no such
+ * state: Embree's rtcPointQuery starts unbounded every time).  Results do not depend on it.  on = 0: A/B. */
+rmclhip_status rmclhip_rcc_set_cpc_grid(rmclhip_rcc* rcc, int on);
 /* Correspondences{CPU,CUDA}::computeCrossStatistics (CorrespondencesCPU.cpp:10-39):
  * max_dist' = max_dist (1-p) + adaptive_max_dist_min p; rm::statistics_p2l(T_snew_sold, ...) */
 rmclhip_status rmclhip_rcc_compute_cross_statistics(rmclhip_rcc* rcc, const rmclhip_transform* T_snew_sold,

@@ -189,6 +189,7 @@ SIGNATURES = {
     "rmclhip_ctx_set_wait_mode": (_i32, [_vp, _i32]),
     "rmclhip_rcc_set_cpc_tracking": (_i32, [_vp, _i32]),
     "rmclhip_rcc_set_cpc_bounded": (_i32, [_vp, _i32]),
+    "rmclhip_rcc_set_cpc_grid": (_i32, [_vp, _i32]),
     "rmclhip_pf_sample_beams_pointcloud2": (_i32, [_vp, _sz, C.POINTER(PointCloud2Layout), _u32, C.c_uint64, _vp, C.POINTER(_u32)]),
     "rmclhip_resampler_create": (_i32, [_vp, _pp]),
     "rmclhip_resampler_destroy": (None, [_vp]),

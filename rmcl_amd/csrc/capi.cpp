@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -141,6 +142,11 @@ struct rmclhip_map {
   uint32_t* d_cnodes = nullptr;  // Node4C twins
   uint32_t* d_tris = nullptr;
   uint64_t bytes = 0;
+  // near grid of the closest-point queries (kernels.h NearGrid): built on the first rmclhip_rcc_find_cpc of any operator of this map
+  std::mutex grid_mtx;
+  bool grid_ready = false, grid_failed = false;
+  uint32_t* d_near_grid = nullptr;
+  NearGrid grid = {};
   std::vector<uint32_t> scene_first_face;  // map_create_scene: first global face id of every instance, + the total (else empty)
 };
 
@@ -224,6 +230,7 @@ struct rmclhip_rcc {
   uint32_t cpc_rec_n = 0;
   bool cpc_tracking = true;
   bool cpc_bounded = false;        // rmclhip_rcc_set_cpc_bounded: search only within max_dist
+  bool cpc_grid = true;            // rmclhip_rcc_set_cpc_grid: points without a tracking seed start from the map's near grid
   hipGraphExec_t micp_fast_exec = nullptr;
   hipGraph_t micp_fast_graph = nullptr;
   float fast_rho_cap = 0.02f, fast_tau_cap = 0.1f;   // bounds on |2 sin(theta/2)| and |t| of the pre-transforms
@@ -524,6 +531,7 @@ void rmclhip_map_release(rmclhip_map* map) {
     if (map->d_frontier_pf) (void)hipFree(map->d_frontier_pf);
     if (map->d_cnodes) (void)hipFree(map->d_cnodes);
     if (map->d_tris) (void)hipFree(map->d_tris);
+    if (map->d_near_grid) (void)hipFree(map->d_near_grid);
     ctx_release(map->ctx);
     delete map;
   }
@@ -1209,6 +1217,62 @@ static float cpc_bound_d2(const rmclhip_rcc* r) {
   return b < 3.0e38 ? static_cast<float>(b) : 3.0e38f;
 }
 
+// The map's near grid: ~2 M cubic cells over the map's box (at most 256 per axis), each holding the record closest to its centre --
+// one cold closest-point launch over the cell centres, once per map (a few ms; 8 MB), under the map's mutex: operators of one map may
+// be used from different threads.
+static rmclhip_status ensure_near_grid(rmclhip_rcc* r) {
+  rmclhip_map* m = r->map;
+  std::lock_guard<std::mutex> lock(m->grid_mtx);
+  if (m->grid_ready || m->grid_failed) return RMCLHIP_OK;
+  float ext[3];
+  double vol = 1.0;
+  for (int k = 0; k < 3; ++k) {
+    ext[k] = std::max(m->info.bbox_max[k] - m->info.bbox_min[k], 1e-3f);
+    ext[k] *= 1.02f;   // a thin margin: points of a scan lie ON the surface, i.e. on the box's faces
+    vol *= ext[k];
+  }
+  if (!(vol > 0.0) || !std::isfinite(vol)) { m->grid_failed = true; return RMCLHIP_OK; }
+  const float cell = static_cast<float>(std::cbrt(vol / 2.0e6));
+  NearGrid g = {};
+  size_t total = 1;
+  for (int k = 0; k < 3; ++k) {
+    g.n[k] = std::max(1u, std::min(256u, static_cast<uint32_t>(std::ceil(ext[k] / cell))));
+    g.org[k] = 0.5f * (m->info.bbox_min[k] + m->info.bbox_max[k]) - 0.5f * ext[k];
+    g.inv[k] = static_cast<float>(g.n[k]) / ext[k];
+    total *= g.n[k];
+  }
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->d_near_grid), total * sizeof(uint32_t));
+  if (e != hipSuccess) { m->d_near_grid = nullptr; m->grid_failed = true; (void)hipGetLastError(); return RMCLHIP_OK; }   // (a map too large for the table simply runs without it)
+  // coarse to fine: a grid of a quarter of the resolution first (its cells far from any surface are the expensive, unbounded queries:
+  // 64 x fewer of them), then the full grid with every cell seeded from its coarse parent
+  // (cells farther than two coarse cell diagonals from the surface get no record: a query point there runs unseeded, as before)
+  const float cdiag = 4.0f * cell * 1.7320508f;
+  const float skip_d2 = (2.0f * cdiag) * (2.0f * cdiag);
+  NearGrid c = g;
+  size_t ctotal = 1;
+  for (int k = 0; k < 3; ++k) { c.n[k] = (g.n[k] + 3u) / 4u; c.inv[k] = g.inv[k] * static_cast<float>(c.n[k]) / static_cast<float>(g.n[k]); ctotal *= c.n[k]; }
+  uint32_t* d_coarse = nullptr;
+  e = hipMalloc(reinterpret_cast<void**>(&d_coarse), ctotal * sizeof(uint32_t));
+  if (e == hipSuccess)
+    e = launch_cpc_find(m->d_nodes, m->d_tris, nullptr, static_cast<uint32_t>(ctotal), 0.f, xidentity(), xidentity(), nullptr, nullptr, nullptr, nullptr,
+                        nullptr, false, r->stream, nullptr, d_coarse, m->info.n_faces, 3.0e38f, nullptr, &c);
+  c.cells = d_coarse;
+  if (e == hipSuccess)
+    e = launch_cpc_find(m->d_nodes, m->d_tris, nullptr, static_cast<uint32_t>(total), 0.f, xidentity(), xidentity(), nullptr, nullptr, nullptr, nullptr,
+                        nullptr, false, r->stream, nullptr, m->d_near_grid, m->info.n_faces, 3.0e38f, &c, &g, skip_d2);
+  if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+  if (d_coarse) (void)hipFree(d_coarse);
+  if (e != hipSuccess) {
+    (void)hipFree(m->d_near_grid); m->d_near_grid = nullptr; m->grid_failed = true;
+    return fail(RMCLHIP_ERR_HIP, std::string("near grid: ") + hipGetErrorString(e));
+  }
+  g.cells = m->d_near_grid;
+  m->grid = g;
+  m->bytes += total * sizeof(uint32_t);
+  m->grid_ready = true;
+  return RMCLHIP_OK;
+}
+
 rmclhip_status rmclhip_rcc_find_cpc(rmclhip_rcc* r, const rmclhip_transform* Tbm_est) {
   ApiGuard guard_("rmclhip_rcc_find_cpc");
   if (!r || !Tbm_est) return fail(RMCLHIP_ERR_INVALID, "rcc_find_cpc: null");
@@ -1229,10 +1293,12 @@ rmclhip_status rmclhip_rcc_find_cpc(rmclhip_rcc* r, const rmclhip_transform* Tbm
     if (r->d_cpc_rec.p != r->cpc_rec_ptr) { r->cpc_rec_ptr = r->d_cpc_rec.p; r->cpc_rec_n = 0; }   // (re)allocated
     if (r->cpc_rec_n == r->n_dataset && r->cpc_rec_pts == r->ds_pts) seed = r->d_cpc_rec.p;
   }
+  if (r->cpc_grid) { if (rmclhip_status gst = ensure_near_grid(r)) return gst; }
+  const NearGrid* grid = (r->cpc_grid && r->map->grid_ready) ? &r->map->grid : nullptr;
   HIPCHK(launch_cpc_find(quad ? r->map->d_cnodes : r->map->d_nodes, r->map->d_tris, r->ds_pts, r->n_dataset,
                          r->max_dist, Tsm, xinv(Tsm), r->d_hits.p, r->d_ranges.p, r->d_points.p, r->d_normals.p,
                          r->d_face_ids.p, quad, r->stream, seed, r->cpc_tracking ? r->d_cpc_rec.p : nullptr, r->map->info.n_faces,
-                         cpc_bound_d2(r)));
+                         cpc_bound_d2(r), grid));
   if (r->cpc_tracking) { r->cpc_rec_n = r->n_dataset; r->cpc_rec_pts = r->ds_pts; }
   HIPCHK(stream_wait(r->ctx, r->stream));
   return RMCLHIP_OK;
@@ -1243,6 +1309,13 @@ rmclhip_status rmclhip_rcc_set_cpc_tracking(rmclhip_rcc* r, int on) {
   if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_set_cpc_tracking: null");
   r->cpc_tracking = on != 0;
   r->cpc_rec_n = 0;
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_set_cpc_grid(rmclhip_rcc* r, int on) {
+  ApiGuard guard_("rmclhip_rcc_set_cpc_grid");
+  if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_set_cpc_grid: null");
+  r->cpc_grid = on != 0;
   return RMCLHIP_OK;
 }
 

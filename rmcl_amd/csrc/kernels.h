@@ -251,10 +251,20 @@ hipError_t launch_find_moments(const FindParams& p, ModelKind kind, int variant,
 hipError_t launch_tile_planes(const FindParams& p, ModelKind kind, float* planes, hipStream_t s);
 // diagnostics (tools/probe_find.py): per-wave step timeline of one spherical scan; probe_log: tiles x 512 dwords
 hipError_t launch_find_probe(const FindParams& p, int mode, uint32_t* probe_log, hipStream_t s);
+// the map's near grid (traverse.hip.h CpcParams): `cells` = one record index per cell, x fastest; org / inv = the box's corner and
+// cells per metre per axis
+struct NearGrid {
+  const uint32_t* cells;
+  uint32_t n[3];
+  float org[3], inv[3];
+};
+// grid (nullable): seeds points without a tracking seed; cells (nullable): BUILD a grid -- the query points are the centres of cells
+// [0, n) of `cells` (whose records are not read), rec_out receives their records
 hipError_t launch_cpc_find(const uint32_t* nodes, const uint32_t* tris, const float* dataset_points, uint32_t n,
                            float max_dist, xform Tsm, xform Tms, uint8_t* hits, float* dists, float* points,
                            float* normals, uint32_t* face_ids, bool quad, hipStream_t s, const uint32_t* seed_rec = nullptr,
-                           uint32_t* rec_out = nullptr, uint32_t n_tris = 0, float bound_d2 = 3.0e38f);
+                           uint32_t* rec_out = nullptr, uint32_t n_tris = 0, float bound_d2 = 3.0e38f, const NearGrid* grid = nullptr,
+                           const NearGrid* cells = nullptr, float skip_d2 = 3.0e38f);
 // residual resampling (ResidualResamplerCPU.cpp:55-203) in three steps; stats: 32 bytes on the device {double sum, double max,
 // u64 n * E[copies per draw], u64 draws used}
 hipError_t launch_residual_prepare(const void* attrs, uint32_t n, uint32_t n_new, double* psum, float* pmax, void* stats, hipStream_t s);

@@ -2197,12 +2197,20 @@ hipError_t launch_find_probe(const FindParams& p, int mode, uint32_t* probe_log,
 hipError_t launch_cpc_find(const uint32_t* nodes, const uint32_t* tris, const float* dataset_points, uint32_t n,
                            float max_dist, xform Tsm, xform Tms, uint8_t* hits, float* dists, float* points,
                            float* normals, uint32_t* face_ids, bool quad, hipStream_t s, const uint32_t* seed_rec, uint32_t* rec_out,
-                           uint32_t n_tris, float bound_d2) {
+                           uint32_t n_tris, float bound_d2, const NearGrid* grid, const NearGrid* cells, float skip_d2) {
   if (n == 0) return hipSuccess;
   CpcParams p;
   p.nodes = nodes; p.tris = tris; p.dataset_points = dataset_points; p.n = n; p.max_dist = max_dist;
   p.Tsm = Tsm; p.Tms = Tms; p.hits = hits; p.dists = dists; p.points = points; p.normals = normals; p.face_ids = face_ids;
   p.seed_rec = seed_rec; p.rec_out = rec_out; p.n_tris = n_tris; p.bound_d2 = bound_d2;
+  p.near_grid = nullptr; p.from_cells = (cells != nullptr) ? 1u : 0u; p.skip_d2 = skip_d2;
+  for (int k = 0; k < 3; ++k) { p.gn[k] = 1u; p.gorg[k] = 0.f; p.ginv[k] = 1.f; p.cn[k] = 1u; p.corg[k] = 0.f; p.cinv[k] = 1.f; }
+  if (grid != nullptr) {
+    p.near_grid = grid->cells;
+    for (int k = 0; k < 3; ++k) { p.gn[k] = grid->n[k]; p.gorg[k] = grid->org[k]; p.ginv[k] = grid->inv[k]; }
+  }
+  if (cells != nullptr)
+    for (int k = 0; k < 3; ++k) { p.cn[k] = cells->n[k]; p.corg[k] = cells->org[k]; p.cinv[k] = cells->inv[k]; }
   if (quad) hipLaunchKernelGGL((k_cpc_find<true>), dim3((n + 63u) / 64u), dim3(256), kQuadStackEntries * 64u * sizeof(uint32_t), s, p);
   else hipLaunchKernelGGL((k_cpc_find<false>), dim3((n + 255u) / 256u), dim3(256), 16u * 256u * sizeof(uint32_t), s, p);
   return hipGetLastError();

@@ -1445,6 +1445,19 @@ struct CpcParams {
   // bounded search (opt-in, rmclhip_rcc_set_cpc_bounded): nothing farther than this squared distance is looked for; a point
   // with no surface inside it gets the "not found" outputs.  3e38: unbounded (the reference's semantics).
   float bound_d2;
+  // Round 4 -- the map's NEAR GRID (nullable): one triangle record per cell of a uniform grid over the map's box, the record closest
+  // to the cell's centre (built once per map, on the first closest-point query).  A point without a tracking seed starts from the
+  // record of its cell: an actual candidate, hence an upper bound of the answer within about a cell diagonal of it -- a COLD query
+  // (first scan, new pose, no previous call) prunes like a tracked one.  Same results by construction.
+  const uint32_t* near_grid;
+  uint32_t gn[3];
+  float gorg[3], ginv[3];
+  // (grid build only) the query points are the centres of cells [0, n) of THIS grid instead of dataset_points
+  uint32_t from_cells;
+  uint32_t cn[3];
+  float corg[3], cinv[3];
+  float skip_d2;   // (grid build) a cell whose seed is farther than this gets NO record: query points live near the surface, and cells
+                   // deep inside free space -- the centre of a hollow sphere: everything equidistant -- are the searches that cannot prune
 };
 
 // kQuad: four lanes per dataset point (64 points per block) instead of one
@@ -1455,13 +1468,27 @@ __global__ void __launch_bounds__(256) k_cpc_find(const CpcParams p) {
   const uint32_t i = kQuad ? (blockIdx.x * 64u + (threadIdx.x >> 2)) : (blockIdx.x * blockDim.x + threadIdx.x);
   const bool live = i < p.n;
   const uint32_t ii = live ? i : 0u;
-  const float* dp = p.dataset_points + 3 * static_cast<size_t>(ii);
-  const f3 Pm = xapply(p.Tsm, mk3(dp[0], dp[1], dp[2]));
+  f3 Pm;
+  if (p.from_cells) {
+    const uint32_t cx = ii % p.cn[0], cyz = ii / p.cn[0], cy = cyz % p.cn[1], cz = cyz / p.cn[1];
+    Pm = mk3(p.corg[0] + (static_cast<float>(cx) + 0.5f) / p.cinv[0], p.corg[1] + (static_cast<float>(cy) + 0.5f) / p.cinv[1],
+             p.corg[2] + (static_cast<float>(cz) + 0.5f) / p.cinv[2]);
+  } else {
+    const float* dp = p.dataset_points + 3 * static_cast<size_t>(ii);
+    Pm = xapply(p.Tsm, mk3(dp[0], dp[1], dp[2]));
+  }
   const bool finite = (Pm.x == Pm.x) && (Pm.y == Pm.y) && (Pm.z == Pm.z);
   NearHit h, seed;
   seed.d2 = 3.0e38f; seed.face = kInvalidFace; seed.rec = 0; seed.p = mk3(0.f, 0.f, 0.f);
-  if (p.seed_rec != nullptr) {
-    const uint32_t sr = p.seed_rec[ii];
+  {
+    uint32_t sr = (p.seed_rec != nullptr) ? p.seed_rec[ii] : kNone;
+    if (sr >= p.n_tris && p.near_grid != nullptr && live && finite) {
+      // no tracking seed: the record of the point's cell (points outside the grid take the nearest cell: any record is a candidate)
+      const float fx = fminf(fmaxf((Pm.x - p.gorg[0]) * p.ginv[0], 0.0f), static_cast<float>(p.gn[0] - 1u));
+      const float fy = fminf(fmaxf((Pm.y - p.gorg[1]) * p.ginv[1], 0.0f), static_cast<float>(p.gn[1] - 1u));
+      const float fz = fminf(fmaxf((Pm.z - p.gorg[2]) * p.ginv[2], 0.0f), static_cast<float>(p.gn[2] - 1u));
+      sr = p.near_grid[(static_cast<uint32_t>(fz) * p.gn[1] + static_cast<uint32_t>(fy)) * p.gn[0] + static_cast<uint32_t>(fx)];
+    }
     if (live && finite && sr < p.n_tris) {
       const uint4* tp = reinterpret_cast<const uint4*>(p.tris) + static_cast<size_t>(sr) * 4u;
       const uint4 a = tp[0], b = tp[1], cc = tp[2], d = tp[3];
@@ -1471,6 +1498,10 @@ __global__ void __launch_bounds__(256) k_cpc_find(const CpcParams p) {
       seed.d2 = (df.x * df.x + df.y * df.y) + df.z * df.z;   // the query's own arithmetic: revisiting this record changes nothing
       seed.face = d.w; seed.rec = sr; seed.p = cq;
     }
+  }
+  if (p.from_cells && seed.d2 > p.skip_d2) {
+    if (live && p.rec_out != nullptr && (!kQuad || sub == 0u)) p.rec_out[i] = kNone;
+    return;   // (no barrier follows in this kernel)
   }
   if (!(seed.d2 <= p.bound_d2)) {   // bounded search: start from the bound itself (no candidate: every face wins a tie against it)
     seed.d2 = p.bound_d2; seed.face = kInvalidFace; seed.rec = 0; seed.p = mk3(0.f, 0.f, 0.f);

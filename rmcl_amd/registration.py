@@ -657,6 +657,10 @@ class CPCHip(CorrespondencesHIP):
         within max_dist get NaN outputs instead of their (gated-out) global closest point (rmclhip.h)"""
         _capi.check(_capi.lib().rmclhip_rcc_set_cpc_bounded(self._h, 1 if on else 0))
 
+    def set_grid(self, on):
+        """the map's near grid seeds points that have no tracking seed (default on; results do not depend on it): rmclhip_rcc_set_cpc_grid"""
+        _capi.check(_capi.lib().rmclhip_rcc_set_cpc_grid(self._h, 1 if on else 0))
+
     def find(self, Tbm_est):
         self._push_params()   # hits = (distance <= params.max_dist)
         T = np.ascontiguousarray(Tbm_est, dtype=TRANSFORM).reshape(1)

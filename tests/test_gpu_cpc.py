@@ -121,23 +121,43 @@ def test_tracking_gives_the_cold_result_bit_for_bit(ra, orc, ctx, meshes):
     poses = [T.transform_from_rpy((0.02 * k, -0.015 * k, 0.01 * k), (0.0, 0.0, 0.004 * k)) for k in range(6)]
     poses += [T.transform_from_rpy((2.0, -1.0, 0.5), (0.1, 0.0, 1.3)), poses[2], poses[2]]
     for variant in (2, 1):
-        cold, warm = ra.CPCHip(hm), ra.CPCHip(hm)
-        for c in (cold, warm):
+        # cold: no tracking, seeded from the map's near grid (round 4 default); bare: no seed at all (the reference's rtcPointQuery);
+        # warm: tracking (+ the grid for the points a previous call left without a record)
+        cold, warm, bare = ra.CPCHip(hm), ra.CPCHip(hm), ra.CPCHip(hm)
+        for c in (cold, warm, bare):
             c.set_variant(variant)
             c.setTsb(syn.tsb_offset())
             c.params.max_dist = 0.4
         cold.set_tracking(False)
+        bare.set_tracking(False)
+        bare.set_grid(False)
         for pts in (pts_a, pts_b, pts_a):
-            cold.set_dataset(pts, None)
-            warm.set_dataset(pts, None)
+            for c in (cold, warm, bare):
+                c.set_dataset(pts, None)
             for P in poses:
-                cold.find(P)
-                warm.find(P)
-                a, b = cold.modelView(), warm.modelView()
+                for c in (cold, warm, bare):
+                    c.find(P)
+                a, b, z = cold.modelView(), warm.modelView(), bare.modelView()
                 for k in ("hits", "ranges", "face_ids", "points", "normals"):
-                    assert a[k].tobytes() == b[k].tobytes(), (variant, k)
-        cold.close()
-        warm.close()
+                    assert a[k].tobytes() == b[k].tobytes() == z[k].tobytes(), (variant, k)
+        for c in (cold, warm, bare):
+            c.close()
+    # points far outside the map's box (clamped to the nearest cell) and NaN points through the grid seed
+    far = (pts_a * np.float32(40.0)).astype(np.float32)
+    far[::7] = np.nan
+    cold, bare = ra.CPCHip(hm), ra.CPCHip(hm)
+    bare.set_grid(False)
+    for c in (cold, bare):
+        c.set_tracking(False)
+        c.setTsb(syn.tsb_offset())
+        c.params.max_dist = 0.4
+        c.set_dataset(far, None)
+        c.find(poses[3])
+    a, z = cold.modelView(), bare.modelView()
+    for k in ("hits", "ranges", "face_ids", "points", "normals"):
+        assert a[k].tobytes() == z[k].tobytes(), k
+    cold.close()
+    bare.close()
 
 
 def test_bounded_search_keeps_every_hit_bit_for_bit(ra, orc, ctx, meshes):
