@@ -1425,6 +1425,9 @@ __device__ __forceinline__ void leaf_pair(const uint32_t* __restrict__ tris, uin
 template <int kRows, bool kLeaf2>
 __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
   // LDS: [ per-lane stacks kRows*256 (later: merge weights) | Tsm (PB xforms) | n0 (PB) | errors -> evals (PB*n_beams floats) ]
+  // (round 4 A/B, removed: the top 85 / 341 nodes of the tree in LDS -- the TD / TA units read 94 % / 82 % busy, but those are
+  // "non-idle" counters, not bandwidth: 14 % / 33 % SLOWER, profiles/r04_pf_lds_top.txt.  The kernel is VALU-issue bound at the
+  // per-class issue costs of profiles/r04_valu_issue_rate.txt: DESIGN.md, particle filter.)
   extern __shared__ uint32_t lds_dyn[];
   __shared__ uint32_t s_next;
   uint32_t* lds_col = lds_dyn + threadIdx.x;   // stack rows of this lane: row r at lds_col[r * 256], row 0 = sentinel

@@ -231,10 +231,15 @@ __device__ __forceinline__ uint32_t record_face(const uint32_t* __restrict__ tri
 // node_keys on the quantised twin of the node (layout.h: Node4Q): FOUR loads instead of seven.  The plane distance
 // t = (origin + q*scale - O) * inv is evaluated as q * (scale*inv) + (origin*inv - O*inv): six per-node
 // instructions, then one (packed) FMA per plane as before; the bytes are widened with v_cvt_f32_ubyteN.
+__device__ __forceinline__ void node_keys_q4(uint4 qa, uint4 qb, uint4 qc, uint4 qch, const RaySlab& rs, float best_t,
+                                             uint32_t (&key)[4], uint32_t (&ref)[4]);
 __device__ __forceinline__ void node_keys_q(const uint32_t* __restrict__ qnodes, uint32_t cur, const RaySlab& rs, float best_t,
                                             uint32_t (&key)[4], uint32_t (&ref)[4]) {
   const uint4* nb = reinterpret_cast<const uint4*>(qnodes) + static_cast<size_t>(cur) * 4u;
-  const uint4 qa = nb[0], qb = nb[1], qc = nb[2], qch = nb[3];
+  node_keys_q4(nb[0], nb[1], nb[2], nb[3], rs, best_t, key, ref);
+}
+__device__ __forceinline__ void node_keys_q4(uint4 qa, uint4 qb, uint4 qc, uint4 qch, const RaySlab& rs, float best_t,
+                                             uint32_t (&key)[4], uint32_t (&ref)[4]) {
   const float sx = asf(qa.w) * rs.inv.x, sy = asf(qb.x) * rs.inv.y, sz = asf(qb.y) * rs.inv.z;
   const float bx = fmaf(asf(qa.x), rs.inv.x, rs.noi.x), by = fmaf(asf(qa.y), rs.inv.y, rs.noi.y), bz = fmaf(asf(qa.z), rs.inv.z, rs.noi.z);
   const bool ngx = rs.inv.x < 0.0f, ngy = rs.inv.y < 0.0f, ngz = rs.inv.z < 0.0f;
