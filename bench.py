@@ -247,6 +247,15 @@ def main():
             extras["c4_particle_beam_evals_per_s"] = round(prays / (pms * 1e-3), 1)
             extras["c4_particle_updates_per_s"] = round(100000 / (pms * 1e-3), 1)
             extras["c4_pf_algorithmic_GBps"] = round(algorithmic_bytes_pf(100000, 256) / (pms * 1e-3) / 1e9, 2)
+            # the filter's steady state: a CONVERGED cloud (100k particles ~ N(pose, 0.25 m, 5 deg yaw)), round 3's dealing and the
+            # particle-coherent one (a wave's lanes = the same beam of 16 Morton-neighbouring particles x 4 beams); measured neutral:
+            # the kernel is VALU-issue bound, coherence removes cache lines, not instructions (profiles/r04_pf_converged_mapping.txt)
+            cms, _ = _pf_c4(ra, syn, T, np, ctx, hm, 100000, 256, iters=3, converged_at=T.transform_from_rpy((0.4, -0.3, 0.1), (0, 0, 0.4)))
+            cms1, _ = _pf_c4(ra, syn, T, np, ctx, hm, 100000, 256, iters=3, converged_at=T.transform_from_rpy((0.4, -0.3, 0.1), (0, 0, 0.4)),
+                             particle_minor=True)
+            extras["c4_converged_pf_update_ms"] = round(cms, 4)
+            extras["c4_converged_particle_beam_evals_per_s"] = round(prays / (cms * 1e-3), 1)
+            extras["c4_converged_particle_minor_morton_ms"] = round(cms1, 4)
             extras.update(_pf_cycle(ra, syn, T, np, ctx, hm, 100000))
             # the same scan on a REALISTIC map (room-100k: occluders, vertex noise, open ceiling) and with the O1Dn model (the
             # documented deployment model: directions are data, +12 B/ray read)
@@ -265,6 +274,9 @@ def main():
             rpms, _ = _pf_c4(ra, syn, T, np, ctx, hmr, 100000, 256, iters=3, bb=((-9, -9, 0.3), (9, 9, 3)))
             extras["c4_room100k_pf_update_ms"] = round(rpms, 4)
             extras["c4_room100k_particle_beam_evals_per_s"] = round(prays / (rpms * 1e-3), 1)
+            rcms, _ = _pf_c4(ra, syn, T, np, ctx, hmr, 100000, 256, iters=3, converged_at=T.transform_from_rpy((1.5, -2.0, 1.6), (0, 0, 0.4)))
+            extras["c4_converged_room100k_pf_update_ms"] = round(rcms, 4)
+            extras["c4_converged_room100k_particle_beam_evals_per_s"] = round(prays / (rcms * 1e-3), 1)
             dirs_c2 = syn.model_directions(model)
             for nm, hmx, Tx in (("sphere100k", hm, Tbm), ("room100k", hmr, Troom)):
                 ro = ra.RCCHipO1Dn(hmx)
@@ -770,8 +782,13 @@ def _pf_sharded_block(ra, syn, T, np, torch, dist, ctx, rank, world, n_local=125
             "particle_updates_per_s": round(n_total / (step_ms * 1e-3), 1), "map_build_upload_s": round(build_s, 2)}
 
 
-def _pf_c4(ra, syn, T, np, ctx, hm, n_particles, n_beams, iters, bb=((-5, -5, -1), (5, 5, 1))):
-    poses, attrs = syn.uniform_particles(n_particles, seed=42, bb_min=bb[0] + (0, 0, -math.pi), bb_max=bb[1] + (0, 0, math.pi))
+def _pf_c4(ra, syn, T, np, ctx, hm, n_particles, n_beams, iters, bb=((-5, -5, -1), (5, 5, 1)), converged_at=None, particle_minor=False):
+    """config C4's sensor update; converged_at: a converged cloud ~ N(that pose, 0.25 m, 5 deg yaw) instead of the uniform one;
+    particle_minor: the particle-coherent dealing (rmclhip_pf_set_mapping 1, 16 slots per workgroup, Morton order of x / y / yaw)"""
+    if converged_at is None:
+        poses, attrs = syn.uniform_particles(n_particles, seed=42, bb_min=bb[0] + (0, 0, -math.pi), bb_max=bb[1] + (0, 0, math.pi))
+    else:
+        poses, attrs = syn.converged_particles(n_particles, converged_at, 0.25, 5.0, seed=42)
     dirs = syn.model_directions(syn.model_pf16())
     sel = np.linspace(0, len(dirs) - 1, n_beams).astype(int)
     beams = ra.beams_from_points(dirs[sel] * np.float32(6.0))
@@ -779,6 +796,8 @@ def _pf_c4(ra, syn, T, np, ctx, hm, n_particles, n_beams, iters, bb=((-5, -5, -1
     upd.init()
     upd.setInput(beams, T.identity())
     d_poses, d_attrs = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
+    if particle_minor:
+        upd.set_mapping(1, 16, ra.DeviceArray.from_host(ctx, syn.morton_order_xy_yaw(poses)))
     upd.time_update(d_poses, d_attrs, n_particles, iters=1)
     ms = sorted(upd.time_update(d_poses, d_attrs, n_particles, iters=iters) for _ in range(5))[2]
     upd.close()

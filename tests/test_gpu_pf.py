@@ -309,3 +309,46 @@ def test_c5_shard_size_properties(ra, orc, ctx, meshes):
         m.pf_update(poses[pi:pi + 1], bf, beams, T.identity(), orc.pf_params(), bvh=False, nthreads=8)
         assert int(bf["likelihood"]["n_meas"][0]) == int(shard["likelihood"]["n_meas"][pi])
         assert_close_rel(shard["likelihood"]["mean"][pi:pi + 1], bf["likelihood"]["mean"], 1e-5, 1e-12, "C5 brute-force particle")
+
+
+@pytest.mark.parametrize("ppb", [0, 16, 64])
+def test_particle_minor_mapping_and_slot_order_keep_the_result(ra, orc, ctx, meshes, ppb):
+    """rmclhip_pf_set_mapping 1 (round 4): the block's rays dealt out particle-minor -- a wave's lanes hold the SAME beam of consecutive
+    slots -- with the slots in the Morton order of (x, y, yaw), on a converged cloud (the filter's steady state) and on a uniform one:
+    attributes and per-beam errors are those of the default dealing bit for bit (same rays, same in-order merge per particle), and
+    both equal the oracle.  Ragged particle count, 100 beams (the reference's default), repeated updates."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room30k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    centre = T.transform_from_rpy((1.0, -1.5, 1.2), (0.0, 0.0, 0.5))
+    beams = ra.sample_beams(m.simulate_spherical(syn.model_c1(), T.identity(), centre, bvh=True)["points"], 100, seed=7)
+    Tsb = syn.tsb_offset()
+    n = 3001
+    for cloud in ("converged", "uniform"):
+        if cloud == "converged":
+            poses, attrs = syn.converged_particles(n, centre, 0.25, 5.0, seed=3)
+        else:
+            poses, attrs = syn.uniform_particles(n, seed=5, bb_min=(-9, -9, 0.2, 0, 0, -math.pi), bb_max=(9, 9, 3.0, 0, 0, math.pi))
+        order = syn.morton_order_xy_yaw(poses)
+        assert sorted(order.tolist()) == list(range(n))
+        res = []
+        for mapping, od in ((0, None), (1, None), (1, order)):
+            upd = ra.PCDSensorUpdaterHip(hm)
+            upd.init()
+            upd.setInput(beams, Tsb)
+            d_order = ra.DeviceArray.from_host(ctx, od) if od is not None else None
+            upd.set_mapping(mapping, ppb, d_order)
+            d_p, d_a = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
+            d_err = ra.DeviceArray(ctx, np.float32, n * len(beams))
+            upd.set_error_output(d_err)
+            upd.update(d_p, d_a)
+            upd.update(d_p, d_a)          # a second update accumulates on the first (n_meas 100 -> 200)
+            res.append((d_a.download(), d_err.download()))
+            upd.close()
+        for a, e in res[1:]:
+            assert a.tobytes() == res[0][0].tobytes() and e.tobytes() == res[0][1].tobytes(), cloud
+        a_ref = attrs.copy()
+        m.pf_update(poses, a_ref, beams, Tsb, orc.pf_params(), bvh=True, nthreads=8)
+        e_ref = m.pf_update(poses, a_ref, beams, Tsb, orc.pf_params(), bvh=True, nthreads=8, want_errors=True)
+        _check(res[0][0], res[0][1].reshape(n, len(beams)), a_ref, e_ref, "mapping " + cloud)
