@@ -536,13 +536,15 @@ rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* pf, int variant);
  * threshold selected by set_variant) and leaves its node phase when at most `tail_lanes` lanes still descend while
  * another holds a leaf (default 8).  The result does not depend on either (tests/test_gpu_pf.py). */
 /* Ray dealing of the sensor update.  mapping 0 (default): beam-minor -- a workgroup takes ~2048 rays of a few particles, a wave's lanes
- * hold DIFFERENT beams (uniform clouds: nothing is coherent anyway).  mapping 1: particle-minor -- a workgroup takes
- * `particles_per_block` (0 = 32, at most 64) consecutive SLOTS and deals their rays out so that the 64 lanes of a wave hold the same
- * beam of consecutive slots: nearly the same ray when the cloud has converged, so the lanes walk the tree together (one cache line per
- * node step instead of up to 64, no masked lanes).  order_dev (nullable, borrowed device memory, n_order = the particle count it is
- * for): slot -> particle index, e.g. sorted by a Morton key of (x, y, yaw) once per resampling step (rmclhip_pf_spatial_order);
- * null = slot i is particle i.  The rays, every beam's error and the in-order Gaussian1D merge per particle are those of mapping 0:
- * results do not depend on the mapping or the order. */
+ * hold DIFFERENT beams.  mapping 1: particle-minor -- a workgroup takes `particles_per_block` (0 = 32, at most 64) consecutive SLOTS
+ * and deals their rays out so that the lanes of a wave hold the same beam of consecutive slots: nearly the same ray when the cloud has
+ * converged and neighbouring slots hold neighbouring particles.  order_dev (nullable, borrowed device memory, n_order = the particle
+ * count it is for): slot -> particle index, e.g. the Morton order of (x, y, yaw) (rmcl_amd.synthetic.morton_order_xy_yaw is the host
+ * form tests and bench.py use); null = slot i is particle i.  The rays, every beam's error and the in-order Gaussian1D merge per
+ * particle are those of mapping 0: results do not depend on the mapping or the order.
+ * MEASURED NEUTRAL (round 4, profiles/r04_pf_converged_mapping.txt): on a converged cloud (sigma 0.25 m / 5 deg) mapping 1 with 16
+ * slots per workgroup and the Morton order is 3 % faster than mapping 0, with larger workgroups slower -- the kernel is bound by
+ * VALU issue, and coherent lanes save cache lines, not instructions.  Kept as an option; nothing selects it automatically. */
 rmclhip_status rmclhip_pf_set_mapping(rmclhip_pf* pf, int mapping, uint32_t particles_per_block, const uint32_t* order_dev,
                                       uint32_t n_order);
 rmclhip_status rmclhip_pf_set_schedule(rmclhip_pf* pf, uint32_t refill_idle_lanes, uint32_t tail_lanes);

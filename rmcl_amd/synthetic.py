@@ -232,8 +232,8 @@ def converged_particles(n, centre, sigma_t=0.25, sigma_yaw_deg=5.0, seed=42):
 
 
 def morton_order_xy_yaw(poses, bits=10):
-    """slot -> particle index sorted by a Morton key of (x, y, yaw), `bits` bits each over the cloud's own bounding box: what
-    rmclhip_pf_spatial_order computes on the device (the host form serves tests and tools)"""
+    """slot -> particle index sorted by a Morton key of (x, y, yaw), `bits` bits each over the cloud's own bounding box (the slot order
+    rmclhip_pf_set_mapping accepts; a host form: the mapping measured neutral, profiles/r04_pf_converged_mapping.txt, so no device sort was built)"""
     x, y = poses["t"]["x"].astype(np.float64), poses["t"]["y"].astype(np.float64)
     yaw = 2.0 * np.arctan2(poses["R"]["z"].astype(np.float64), poses["R"]["w"].astype(np.float64))
 
