@@ -1694,7 +1694,8 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
     r->h_call->seq = next_seq(r);
     // ---- moment form first (kernels.hip "gate-stable moment form"); any outcome other than "done" falls through to the
     // per-iteration form below, which recomputes the correction from scratch
-    const bool fast_eligible = r->fast_mode != 0 && r->loop_blocks == 0 && !r->fused_tail && n_iter >= 2u;
+    // (the device loops need >= 2 iterations to pay for their moment pass; the host form -- two launches, no reduction launch at all -- serves 1 as well)
+    const bool fast_eligible = r->fast_mode != 0 && r->loop_blocks == 0 && !r->fused_tail && n_iter >= ((r->fast_mode == 1) ? 1u : 2u);
     bool fast_tried = false;
     if (fast_eligible && r->fast_holdoff > 0u) --r->fast_holdoff;
     else if (fast_eligible) {
