@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "rmcl_hip/rmcl_hip.hpp"
@@ -89,6 +90,20 @@ int main(int argc, char** argv) {
     std::printf("host_loop_n_meas %u\nhost_loop_t %.9g %.9g %.9g\nhost_loop_q %.9g %.9g %.9g %.9g\n", Cmerged.n_meas,
                 T_onew_oold.t.x, T_onew_oold.t.y, T_onew_oold.t.z, T_onew_oold.R.x, T_onew_oold.R.y, T_onew_oold.R.z,
                 T_onew_oold.R.w);
+    {
+      // round 4: the five calls above were answered from the moments of the find's correspondences -- one moment pass at the first
+      // call, the other four on the host without a launch (rmclhip_rcc_ccs_info); the same unchanged loop timed in C
+      const rmclhip_ccs_info ci = rcc.ccsInfo();
+      float ms = 0.f;
+      Transform Tcl{};
+      CrossStatistics scl{};
+      check(rmclhip_rcc_time_caller_loop(rcc.handle(), &Tom_est, &Tbo, 5, 0.0, 20, &Tcl, &scl, &ms));
+      const rmclhip_ccs_info c2 = rcc.ccsInfo();
+      std::printf("caller_loop_served %u %u %u\ncaller_loop_timed %u %u %u %u\ncaller_loop_t %.9g %.9g %.9g\ncaller_loop_n_meas %u\n", ci.calls,
+                  ci.from_moments, ci.passes, c2.calls - ci.calls, c2.from_moments - ci.from_moments, c2.passes - ci.passes,
+                  c2.speculative_finds, Tcl.t.x, Tcl.t.y, Tcl.t.z, scl.n_meas);
+      std::fprintf(stderr, "unchanged caller loop: %.4f ms per 5-iteration correction\n", ms);
+    }
     // Correspondences_::dataset filled the way the reference's device sensors fill it (MICPSphericalSensorCUDA.cpp:207-232):
     // points / mask built on the host per measurement, then `dataset.points = host.points; dataset.mask = host.mask;`
     {
@@ -187,6 +202,37 @@ int main(int argc, char** argv) {
       CrossStatistics sm{};
       const Transform Tm = correctOnce({&rcc}, Tom_est, {Tbo}, {1.0}, 5, 0.0, &sm);
       std::printf("multi_loop_n_meas %u\nmulti_loop_t %.9g %.9g %.9g\n", sm.n_meas, Tm.t.x, Tm.t.y, Tm.t.z);
+    }
+
+    // v1 pose batch (lidar_corrector_optix_benchmark.cpp:86-133) through one operator and through TWO replicas on device 0
+    // (rmclhip_rcc_sharded_*: poses block-partitioned, no exchange): identical deltas
+    {
+      std::vector<Transform> batch;
+      for (int k = 0; k < 7; ++k) batch.push_back(truth * from_rpy(0.05f * k, -0.03f * k, 0.01f * k, 0, 0, 0.01f * k));
+      rcc.params.max_dist = rcc.adaptive_max_dist_min = 1.0f;
+      const std::vector<Transform> one = rcc.correctBatch(batch);
+      ShardedCorrectorHip sh({0, 0}, verts.data(), nv, faces.data(), nf);
+      std::vector<Vector> pts(n);
+      std::vector<uint8_t> msk(n);
+      for (uint32_t vid = 0; vid < model.phi.size; ++vid)
+        for (uint32_t hid = 0; hid < model.theta.size; ++hid) {
+          const uint32_t id = getBufferId(model, vid, hid);
+          const Vector d = getDirection(model, vid, hid);
+          pts[id] = Vector{d.x * ranges[id], d.y * ranges[id], d.z * ranges[id]};
+          msk[id] = (ranges[id] < model.range.min || ranges[id] > model.range.max) ? 0 : 1;
+        }
+      sh.forEach([&](rmclhip_rcc* r) {
+        check(rmclhip_rcc_set_tsb(r, &Tsb));
+        check(rmclhip_rcc_set_model_spherical(r, &model));
+        check(rmclhip_rcc_set_params(r, 1.0f, 1.0f));
+        check(rmclhip_rcc_set_dataset(r, &pts[0].x, msk.data(), n, 0));
+      });
+      const std::vector<Transform> two = sh.correctBatch(batch);
+      uint32_t same = 0;
+      for (size_t k = 0; k < batch.size(); ++k) same += std::memcmp(&one[k], &two[k], sizeof(Transform)) == 0 ? 1u : 0u;
+      std::printf("sharded_batch %u %zu %u\n", sh.size(), batch.size(), same);
+      rcc.params.max_dist = 1.0f;
+      rcc.adaptive_max_dist_min = 0.15f;
     }
 
     // particle filter: 4 hypotheses, 3 beams

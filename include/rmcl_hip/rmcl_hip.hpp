@@ -371,6 +371,12 @@ class Correspondences_<VRAM_HIP> {
     check(rmclhip_rcc_micp_fast_info(h_, &info));
     return info;
   }
+  // how computeCrossStatistics was served: from the find's published moments on the host (no launch) or by a streaming reduction
+  rmclhip_ccs_info ccsInfo() const {
+    rmclhip_ccs_info info{};
+    check(rmclhip_rcc_ccs_info(h_, &info));
+    return info;
+  }
   // bind `dataset` and push `params` before a device-resident loop reads them (correctOnce for several sensors)
   void prepareForDeviceLoop() {
     bindDataset();
@@ -503,6 +509,41 @@ class CPCHip : public CorrespondencesHIP {
   // search only within params.max_dist (default off: points beyond it then carry NaN instead of their gated-out closest point)
   void setTracking(bool on) { check(rmclhip_rcc_set_cpc_tracking(h_, on ? 1 : 0)); }
   void setBounded(bool on) { check(rmclhip_rcc_set_cpc_bounded(h_, on ? 1 : 0)); }
+  // the map's near grid seeds points without a tracking seed (default on; a cold query then costs what a tracked one does)
+  void setGrid(bool on) { check(rmclhip_rcc_set_cpc_grid(h_, on ? 1 : 0)); }
+};
+
+// ---- pose batches over several devices (v1 SphereCorrector::correct shape, lidar_corrector_optix_benchmark.cpp:86-133) ------
+// One operator replica per device over one host BVH build; the poses of a batch are block-partitioned, no exchange.  The replicas
+// are plain rmclhip_rcc handles (borrowed): configure them with forEach and the C setters, then correctBatch == the unsharded one.
+class ShardedCorrectorHip {
+ public:
+  ShardedCorrectorHip(const std::vector<int>& devices, const float* vertices_xyz, uint32_t n_vertices, const uint32_t* faces_ijk,
+                      uint32_t n_faces) {
+    check(rmclhip_rcc_sharded_create(devices.data(), static_cast<uint32_t>(devices.size()), vertices_xyz, n_vertices, faces_ijk, n_faces, &h_));
+  }
+  ~ShardedCorrectorHip() { rmclhip_rcc_sharded_destroy(h_); }
+  ShardedCorrectorHip(const ShardedCorrectorHip&) = delete;
+  ShardedCorrectorHip& operator=(const ShardedCorrectorHip&) = delete;
+  uint32_t size() const { return rmclhip_rcc_sharded_size(h_); }
+  rmclhip_rcc* replica(uint32_t rank) const {
+    rmclhip_rcc* r = nullptr;
+    check(rmclhip_rcc_sharded_replica(h_, rank, &r));
+    return r;
+  }
+  template <typename Fn>
+  void forEach(Fn&& fn) const {   // fn(rmclhip_rcc*): e.g. rmclhip_rcc_set_tsb / _set_model_spherical / _set_params / _set_dataset
+    for (uint32_t r = 0; r < size(); ++r) fn(replica(r));
+  }
+  std::vector<Transform> correctBatch(const std::vector<Transform>& Tbm, std::vector<CrossStatistics>* stats = nullptr) {
+    std::vector<Transform> out(Tbm.size());
+    if (stats) stats->resize(Tbm.size());
+    check(rmclhip_rcc_sharded_correct_batch(h_, Tbm.data(), static_cast<uint32_t>(Tbm.size()), out.data(), stats ? stats->data() : nullptr));
+    return out;
+  }
+
+ private:
+  rmclhip_rcc_sharded* h_ = nullptr;
 };
 
 // ---- particle filter -----------------------------------------------------------------------------------

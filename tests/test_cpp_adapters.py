@@ -72,6 +72,14 @@ def test_cpp_example_matches_python_and_oracle(ra, orc, ctx, meshes, tmp_path):
     q = np.array([float(x) for x in out["host_loop_q"]])
     q_ref = np.array([float(To["R"][k]) for k in "xyzw"])
     assert np.allclose(q, q_ref * np.sign(np.dot(q, q_ref)), atol=1e-5)
+    # round 4: the host loop's computeCrossStatistics calls were served from the find's moments (5 calls: one pass, then no launch),
+    # and the SAME unchanged loop timed in C (22 corrections of 5 calls) ran on speculating finds, every call from the moments
+    assert [int(x) for x in out["caller_loop_served"]] == [5, 5, 1]
+    timed = [int(x) for x in out["caller_loop_timed"]]
+    assert timed[0] == 110 and timed[1] >= 105 and timed[2] <= 2 and timed[3] >= 20, timed
+    assert int(out["caller_loop_n_meas"][0]) == int(so["n_meas"])
+    assert np.allclose([float(x) for x in out["caller_loop_t"]], t_ref, atol=1e-5)
+    assert [int(x) for x in out["sharded_batch"]] == [2, 7, 7]       # two replicas, seven poses, seven identical deltas
     assert int(out["moment_form_attempts_done"][0]) == 4 and int(out["moment_form_attempts_done"][1]) >= 2
     assert int(out["moment_form_n_meas"][0]) == int(so["n_meas"])
     assert np.allclose([float(x) for x in out["moment_form_t"]], [float(x) for x in out["device_loop_t"]], atol=1e-6)
