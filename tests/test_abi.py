@@ -72,6 +72,29 @@ def test_no_device_is_a_loud_error_not_a_fallback(ra):
     assert L.rmclhip_micp_correct_once(None, 0, None, None, None, 1, 0.0, None, None) == ra._capi.ERR_INVALID
     assert L.rmclhip_comm_create(None, 0, C.byref(out)) == ra._capi.ERR_INVALID
     assert L.rmclhip_pf_update_sharded(None, None, 0, None) == ra._capi.ERR_INVALID
+    # round-4 entry points
+    ci = ra._capi.CcsInfo()
+    assert L.rmclhip_rcc_ccs_info(None, C.byref(ci)) == ra._capi.ERR_INVALID
+    assert L.rmclhip_rcc_set_cpc_grid(None, 1) == ra._capi.ERR_INVALID
+    assert L.rmclhip_pf_set_mapping(None, 1, 16, None, 0) == ra._capi.ERR_INVALID
+    ms = C.c_float(0)
+    assert L.rmclhip_rcc_time_caller_loop(None, None, None, 5, 0.0, 1, None, None, C.byref(ms)) == ra._capi.ERR_INVALID
+    assert L.rmclhip_rcc_sharded_create(None, 0, None, 0, None, 0, C.byref(out)) == ra._capi.ERR_INVALID
+    assert L.rmclhip_rcc_sharded_correct_batch(None, None, 0, None, None) == ra._capi.ERR_INVALID
+    assert L.rmclhip_rcc_sharded_size(None) == 0
+    assert L.rmclhip_comm_create_loopback(None, 0, C.byref(out)) == ra._capi.ERR_INVALID
+    if st != ra._capi.OK:   # no device: the multi-device constructors fail loudly too
+        assert L.rmclhip_comm_create_loopback(None, 2, C.byref(out)) == ra._capi.ERR_NO_DEVICE
+        one = (C.c_int * 1)(0)
+        assert L.rmclhip_rcc_sharded_create(one, 1, None, 0, None, 0, C.byref(out)) == ra._capi.ERR_NO_DEVICE
+    tr = ra.types.identity().reshape(1) if hasattr(ra.types.identity(), "reshape") else None
+    cs = np.zeros(1, ra.types.CROSS_STATISTICS)
+    assert L.rmclhip_host_moment_statistics(None, None, None, None, 3, 1.0, 1.0, 0.0, 0.0, None, 1.0, cs.ctypes.data, None, None) == ra._capi.ERR_INVALID
+    # ... and an empty correspondence set is Identity statistics, covered
+    Tid = np.ascontiguousarray(ra.types.identity(), dtype=ra.types.TRANSFORM).reshape(1)
+    cov = C.c_int(0)
+    assert L.rmclhip_host_moment_statistics(None, None, None, None, 0, 1.0, 1.0, 0.01, 0.01, Tid.ctypes.data, 1.0, cs.ctypes.data, None, C.byref(cov)) == ra._capi.OK
+    assert cov.value == 1 and int(cs[0]["n_meas"]) == 0
     assert L.rmclhip_version().startswith(b"rmclhip")
 
 
