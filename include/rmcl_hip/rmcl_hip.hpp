@@ -276,7 +276,13 @@ class Correspondences_<VRAM_HIP> {
     check(rmclhip_rcc_set_tsb(h_, &Tsb));
   }
   // finds and fills the model buffers
-  virtual void find(const Transform& Tbm_est) { check(rmclhip_rcc_find(h_, &Tbm_est)); }
+  // (binds `dataset` and pushes `params` first: since round 4 a find that is followed by computeCrossStatistics calls forms the
+  // moments of ITS correspondences in its epilogue -- it reads the dataset, so a re-assigned `dataset` member must be bound before)
+  virtual void find(const Transform& Tbm_est) {
+    bindDataset();
+    check(rmclhip_rcc_set_params(h_, params.max_dist, adaptive_max_dist_min));
+    check(rmclhip_rcc_find(h_, &Tbm_est));
+  }
   virtual CrossStatistics computeCrossStatistics(const Transform& T_snew_sold, double convergence_progress = 0.0) const {
     bindDataset();
     check(rmclhip_rcc_set_params(h_, params.max_dist, adaptive_max_dist_min));

@@ -308,7 +308,13 @@ rmclhip_status rmclhip_rcc_set_cpc_bounded(rmclhip_rcc* rcc, int on);
  * state: Embree's rtcPointQuery starts unbounded every time).  Results do not depend on it.  on = 0: A/B. */
 rmclhip_status rmclhip_rcc_set_cpc_grid(rmclhip_rcc* rcc, int on);
 /* Correspondences{CPU,CUDA}::computeCrossStatistics (CorrespondencesCPU.cpp:10-39):
- * max_dist' = max_dist (1-p) + adaptive_max_dist_min p; rm::statistics_p2l(T_snew_sold, ...) */
+ * max_dist' = max_dist (1-p) + adaptive_max_dist_min p; rm::statistics_p2l(T_snew_sold, ...)
+ * Round 4: answered on the host from the moments of the current find's correspondences when a published set covers the call
+ * (rmclhip_ccs_info below), by a streaming reduction otherwise -- same result.  CONTRACT that makes this sound: the dataset's
+ * CONTENTS do not change between a find and the computeCrossStatistics calls that follow it unless one of the rmclhip_rcc_set_dataset*
+ * calls announces it (they drop the set); the reference holds data_correction_mutex_ over both (micp_localization.cpp:868,968).
+ * For the same reason rmclhip_rcc_find[_async] may READ the dataset (a find that was followed by such calls last time forms the
+ * moments in its epilogue): a view handed over with rmclhip_rcc_set_dataset_view must stay valid until it is replaced. */
 rmclhip_status rmclhip_rcc_compute_cross_statistics(rmclhip_rcc* rcc, const rmclhip_transform* T_snew_sold,
                                                     double convergence_progress,
                                                     rmclhip_cross_statistics* out);
