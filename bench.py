@@ -198,6 +198,11 @@ def main():
             # + the CrossStatistics algebra + umeyama_transform ON THE HOST) through the public C entry points, timed in C: round 4
             # serves the per-iteration calls from the moments the find published (no launch); with the moment form off every call is a
             # streaming reduction + a completion wait (round 3's behaviour)
+            rcc.find(est)      # (a find not followed by computeCrossStatistics: the next ones are plain finds)
+            extras["find_sync_call_cabi_ms"] = round(rcc.time_find_sync(est, iters=100), 5)
+            rcc.set_kernel_timing(True)
+            extras["find_sync_call_with_event_timing_cabi_ms"] = round(rcc.time_find_sync(est, iters=100), 5)
+            rcc.set_kernel_timing(False)
             ms, Tcl, scl = rcc.time_caller_loop(est, T.identity(), 10, 0.0, iters=50)
             extras["c3_schedule_R_unchanged_caller_cabi_ms"] = round(ms, 4)
             extras["c3_schedule_R_unchanged_caller_pose_corrections_per_s"] = round(1e3 / ms, 1)

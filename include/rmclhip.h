@@ -371,7 +371,12 @@ rmclhip_status rmclhip_rcc_sharded_replica(rmclhip_rcc_sharded* h, uint32_t rank
 rmclhip_status rmclhip_rcc_sharded_correct_batch(rmclhip_rcc_sharded* h, const rmclhip_transform* Tbm, uint32_t nposes,
                                                  rmclhip_transform* Tdelta_out, rmclhip_cross_statistics* stats_out);
 
-/* kernel timing of the last find / reduction on the handle's stream (hipEvent, ms) */
+/* kernel timing of the last synchronous find / streaming reduction on the handle's stream (hipEvent, ms).  OPT-IN since round 4
+ * (rmclhip_rcc_set_kernel_timing 1): the two hipEventRecord + hipEventElapsedTime per call cost the caller microseconds on calls
+ * that take tens; without it the values stay at what the last timed call left (0 initially). */
+rmclhip_status rmclhip_rcc_set_kernel_timing(rmclhip_rcc* rcc, int on);
+/* host-clock time of one synchronous rmclhip_rcc_find as a C caller sees it (mean over `iters` calls after one untimed call) */
+rmclhip_status rmclhip_rcc_time_find_sync(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est, uint32_t iters, float* ms_per_call);
 rmclhip_status rmclhip_rcc_last_kernel_ms(rmclhip_rcc* rcc, float* find_ms, float* reduce_ms);
 /* benchmarking hook: run `iters` back-to-back find launches on the handle's stream bracketed by
  * hipEvents on THAT stream; returns the mean kernel-to-kernel time per launch in ms */

@@ -150,6 +150,8 @@ SIGNATURES = {
     "rmclhip_rcc_sharded_replica": (_i32, [_vp, _u32, _pp]),
     "rmclhip_rcc_sharded_correct_batch": (_i32, [_vp, _vp, _u32, _vp, _vp]),
     "rmclhip_rcc_last_kernel_ms": (_i32, [_vp, C.POINTER(_f32), C.POINTER(_f32)]),
+    "rmclhip_rcc_set_kernel_timing": (_i32, [_vp, _i32]),
+    "rmclhip_rcc_time_find_sync": (_i32, [_vp, _vp, _u32, C.POINTER(_f32)]),
     "rmclhip_rcc_time_find": (_i32, [_vp, _vp, _u32, C.POINTER(_f32)]),
     "rmclhip_rcc_autotune": (_i32, [_vp, _vp, C.POINTER(_i32), C.POINTER(_f32)]),
     "rmclhip_rcc_autotune_batch": (_i32, [_vp, _vp, _u32, C.POINTER(_i32), C.POINTER(_f32)]),

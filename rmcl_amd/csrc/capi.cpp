@@ -278,6 +278,8 @@ struct rmclhip_rcc {
   float last_find_ms = 0.f, last_reduce_ms = 0.f;
   bool reduce_timing_pending = false;
   bool find_timing_pending = false;   // a speculating find returned on its tag: ev0 / ev1 still hold its timing
+  bool kernel_timing = false;         // rmclhip_rcc_set_kernel_timing: bracket find / computeCrossStatistics with HIP events (two
+                                      // hipEventRecord + one hipEventElapsedTime per call: opt-in since round 4)
 };
 
 // whatever is about to rewrite the model buffers or the dataset: the published moments summarise the old ones
@@ -1189,21 +1191,22 @@ rmclhip_status rmclhip_rcc_find(rmclhip_rcc* r, const rmclhip_transform* Tbm_est
   if (!r || !Tbm_est) return fail(RMCLHIP_ERR_INVALID, "rcc_find: null");
   if (r->kind == kModelNone || r->W == 0 || r->H == 0) return RMCLHIP_OK;
   HIPCHK(hipSetDevice(r->ctx->device));
+  const bool timed = r->kernel_timing;
   r->reduce_timing_pending = false;   // the events are reused below
-  HIPCHK(hipEventRecord(r->ev0, r->stream));
+  r->find_timing_pending = false;
+  if (timed) HIPCHK(hipEventRecord(r->ev0, r->stream));
   bool spec = false;
   if (rmclhip_status st = find_enqueue(r, to_x(Tbm_est), &spec)) return st;
-  HIPCHK(hipEventRecord(r->ev1, r->stream));
+  if (timed) HIPCHK(hipEventRecord(r->ev1, r->stream));
   if (spec) {
     // the publish launch's tag says the find before it on this stream is complete as well -- and reaches the host sooner than the
     // stream's own completion does (see wait_done); the events are read when rmclhip_rcc_last_kernel_ms asks for them
     HIPCHK(wait_moments(r, r->mset_seq, r->pend_lo, r->pend_hi, r->pend_rho, r->pend_tau));
-    r->find_timing_pending = true;
+    r->find_timing_pending = timed;
     return RMCLHIP_OK;
   }
   HIPCHK(stream_wait(r->ctx, r->stream));
-  HIPCHK(hipEventElapsedTime(&r->last_find_ms, r->ev0, r->ev1));
-  r->find_timing_pending = false;
+  if (timed) HIPCHK(hipEventElapsedTime(&r->last_find_ms, r->ev0, r->ev1));
   return RMCLHIP_OK;
 }
 
@@ -1601,18 +1604,20 @@ rmclhip_status rmclhip_rcc_compute_cross_statistics(rmclhip_rcc* r, const rmclhi
   tail.stats_out = r->h_stats_dev;  // host-mapped: the finalize launch writes the 64-B result straight to the host
   const bool polled = !r->fused_tail;
   if (polled) { tail.done = r->h_done_dev; tail.seq = next_seq(r); }
+  const bool timed = r->kernel_timing;
   r->find_timing_pending = false;   // the events are reused
-  HIPCHK(hipEventRecord(r->ev0, r->stream));
+  r->reduce_timing_pending = false;
+  if (timed) HIPCHK(hipEventRecord(r->ev0, r->stream));
   if (rmclhip_status st = reduce_enqueue(r, to_x(T_snew_sold), nullptr, adaptive_max_dist(r, convergence_progress), 1, tail))
     return st;
-  HIPCHK(hipEventRecord(r->ev1, r->stream));
+  if (timed) HIPCHK(hipEventRecord(r->ev1, r->stream));
   if (polled) {
     DoneCheck chk; chk.base = &r->h_stats[0]; chk.base_bytes = sizeof(cstats);
     HIPCHK(wait_done(r->ctx, r->h_done, tail.seq, chk, r->stream));
-    r->reduce_timing_pending = true;   // the events are read when rmclhip_rcc_last_kernel_ms asks for them
+    r->reduce_timing_pending = timed;   // the events are read when rmclhip_rcc_last_kernel_ms asks for them
   } else {
     HIPCHK(hipStreamSynchronize(r->stream));
-    HIPCHK(hipEventElapsedTime(&r->last_reduce_ms, r->ev0, r->ev1));
+    if (timed) HIPCHK(hipEventElapsedTime(&r->last_reduce_ms, r->ev0, r->ev1));
   }
   from_cs(r->h_stats[0], out);
   return RMCLHIP_OK;
@@ -2435,6 +2440,26 @@ rmclhip_status rmclhip_rcc_sharded_correct_batch(rmclhip_rcc_sharded* h, const r
     std::memcpy(Tdelta_out + lo, R.h_Tdelta, sizeof(xform) * (hi - lo));
     if (stats_out) std::memcpy(stats_out + lo, R.h_stats, sizeof(cstats) * (hi - lo));
   }
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_set_kernel_timing(rmclhip_rcc* r, int on) {
+  ApiGuard guard_("rmclhip_rcc_set_kernel_timing");
+  if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_set_kernel_timing: null");
+  r->kernel_timing = on != 0;
+  r->find_timing_pending = r->reduce_timing_pending = false;
+  return RMCLHIP_OK;
+}
+
+// host-clock time of one synchronous rmclhip_rcc_find as a C caller sees it (mean over `iters` calls after one untimed call)
+rmclhip_status rmclhip_rcc_time_find_sync(rmclhip_rcc* r, const rmclhip_transform* Tbm_est, uint32_t iters, float* ms_per_call) {
+  if (!r || !Tbm_est || !ms_per_call || iters == 0) return fail(RMCLHIP_ERR_INVALID, "rcc_time_find_sync: bad arguments");
+  if (rmclhip_status st = rmclhip_rcc_find(r, Tbm_est)) return st;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t i = 0; i < iters; ++i)
+    if (rmclhip_status st = rmclhip_rcc_find(r, Tbm_est)) return st;
+  const auto t1 = std::chrono::steady_clock::now();
+  *ms_per_call = static_cast<float>(std::chrono::duration<double, std::milli>(t1 - t0).count() / iters);
   return RMCLHIP_OK;
 }
 

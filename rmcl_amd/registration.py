@@ -412,6 +412,18 @@ class CorrespondencesHIP:
     def sync(self):
         _capi.check(_capi.lib().rmclhip_rcc_sync(self._h))
 
+    def set_kernel_timing(self, on):
+        """bracket synchronous find / computeCrossStatistics calls with HIP events so that last_kernel_ms() has values (opt-in)"""
+        _capi.check(_capi.lib().rmclhip_rcc_set_kernel_timing(self._h, 1 if on else 0))
+
+    def time_find_sync(self, Tbm_est, iters=50):
+        """mean host-clock ms of one synchronous find at the C ABI"""
+        T = np.ascontiguousarray(Tbm_est, dtype=TRANSFORM).reshape(1)
+        ms = C.c_float(0)
+        _capi.check(_capi.lib().rmclhip_rcc_time_find_sync(self._h, _ptr(T), int(iters), C.byref(ms)))
+        self._last_nposes = 1
+        return ms.value
+
     def last_kernel_ms(self):
         a, b = C.c_float(0), C.c_float(0)
         _capi.check(_capi.lib().rmclhip_rcc_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
