@@ -772,3 +772,50 @@ def test_caller_loop_moment_cache_is_dropped_by_what_invalidates_it(ra, orc, ctx
     assert np.array_equal(mv["points"], mv0["points"], equal_nan=True)
     rcc.close()
     ref.close()
+
+
+def test_c3_full_size_room_host_forms_with_undecided_correspondences(ra, orc, ctx, meshes):
+    """C3 at full size (128 x 1024, 100 000 triangles) on the occluded room: a tracking-size correction leaves a handful of
+    correspondences undecided, which the HOST re-evaluates per iteration -- rmclhip_rcc_correct_once (iterations on the host) and the
+    reference's unchanged caller loop (find + 10 x computeCrossStatistics, served from the published moments) against the oracle's
+    frame-by-frame loop to 1e-5 and against the streaming form (moment form off) to 1e-6; n_meas identical everywhere."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room100k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    model = syn.model_c2()
+    truth = T.transform_from_rpy((1.5, -2.0, 1.6), (0.02, -0.03, 0.4))
+    Tsb, Tbo = syn.tsb_offset(), T.transform_from_rpy((0.3, -0.1, 0.0), (0.0, 0.0, 0.2))
+    meas = m.simulate_spherical(model, Tsb, truth, bvh=True, nthreads=8)
+    ds, mask = om.dataset_from_ranges(model, meas["ranges"])
+    est_bm = T.mult(truth, T.transform_from_rpy((0.02, -0.015, 0.005), (0.0, 0.001, 0.005)))
+    Tom = T.mult(est_bm, T.inv(Tbo))
+    To, so, _ = om.correct_once(m, model, Tsb, Tbo, Tom, ds, mask, 10, 1.0, adaptive_min=0.15, convergence_progress=0.2, nthreads=8)
+    (rcc, loc), (rcc0, loc0) = _caller_loop_pair(ra, hm, model, Tsb, Tbo, ds, mask)
+    unc = []
+    for rep in range(3):       # (the first correction learns the caps; the repeats run on speculating finds)
+        for L in (loc, loc0):
+            L.Tom_, L.convergence_progress_ = Tom, 0.2
+        rec, rec0 = [], []
+        loc.correctOnce(record=rec)
+        loc0.correctOnce(record=rec0)
+        assert loc.correction_stats_latest_["valid_matches"] == loc0.correction_stats_latest_["valid_matches"] == int(so["n_meas"])
+        for a, b in zip(rec, rec0):
+            _transform_close(a, b, 1e-6)
+        _transform_close(rec[-1], To, 1e-5)
+    info = rcc.ccs_info()
+    assert info["from_moments"] >= 28 and info["speculative_finds"] >= 2, info
+    # the one-call form on the same operator
+    for rep in range(3):
+        Tg, sg = rcc.correct_once(Tom, Tbo, 10, 0.2, False)
+        T0, s0 = rcc0.correct_once(Tom, Tbo, 10, 0.2, False)
+        assert int(sg["n_meas"]) == int(s0["n_meas"]) == int(so["n_meas"])
+        _transform_close(Tg, T0, 1e-6)
+        _transform_close(Tg, To, 1e-5)
+        fi = rcc.micp_fast_info()
+        if fi["last_code"] == 0:
+            unc.append(fi["last_uncertain"])
+    assert unc and 0 < max(unc) <= 256, unc      # undecided correspondences were present and the host took them
+    assert rcc.micp_fast_info()["host_loops"] >= 2
+    rcc.close()
+    rcc0.close()
