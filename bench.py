@@ -414,7 +414,10 @@ def main():
             sA.close()
             sB.close()
             # the particle filter through the multi-GPU C ABI on this one GPU (RCCL ncclCommInitAll + all-gather + all-reduces)
-            shp = ra.ShardedParticleFilterHip(v, f, devices=(local_rank,))
+            # (under a multi-rank launch torch's own RCCL process group is live in this process: the in-library communicator is then the
+            # in-process loopback one, so that two RCCL instances never meet; at N = 1 it is RCCL's ncclCommInitAll)
+            shp = ra.ShardedParticleFilterHip(v, f, devices=(local_rank,), loopback=(world > 1))
+            extras["pf_sharded_cabi_communicator"] = "loopback (in-process)" if world > 1 else "rccl ncclCommInitAll"
             pposes, pattrs = syn.uniform_particles(100000, seed=42, bb_min=(-5, -5, -1, 0, 0, -math.pi), bb_max=(5, 5, 1, 0, 0, math.pi))
             shp.set_particles(pposes, pattrs)
             pdirs = syn.model_directions(syn.model_pf16())
