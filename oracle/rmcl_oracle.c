@@ -131,6 +131,9 @@ struct orc_mesh {
   uint32_t n_nodes;
   uint32_t max_leaf;
   float pad;
+  struct orc_node4* nodes4;   /* 4-wide collapse of `nodes` for the SSE walk (use_bvh = 2: the CPU-baseline path), built on first use */
+  uint32_t n_nodes4;
+  int bvh4_ready;             /* set (release) once nodes4 is complete */
 };
 
 static void tri_setup(orc_tri* T, orc_vec3 a, orc_vec3 b, orc_vec3 c)
@@ -305,7 +308,7 @@ orc_mesh* orc_mesh_create(const float* verts, uint32_t nv, const uint32_t* faces
 void orc_mesh_destroy(orc_mesh* m)
 {
   if (!m) return;
-  free(m->tris); free(m->prim); free(m->nodes); free(m);
+  free(m->tris); free(m->prim); free(m->nodes); free(m->nodes4); free(m);
 }
 
 uint32_t orc_mesh_num_nodes(const orc_mesh* m) { return m->n_nodes; }
@@ -391,6 +394,121 @@ done:
   return found;
 }
 
+/* ------------------------------------------------------------------------- */
+/* use_bvh = 2: the same closest hit through a 4-wide collapse of the BVH2 with the four children's slab tests in one  */
+/* SSE register -- what a CPU ray caster of Embree's class does per ray (bvh4 + single-ray traversal), so that the      */
+/* `cpu_baseline` of bench.py is not a strawman.  Same triangle test, same (min t, min face id) rule: the result is    */
+/* the BVH2 walk's and the brute-force loop's bit for bit (tests/test_oracle.py).  Box test per child = box_hit's       */
+/* arithmetic, lane-wise.                                                                                               */
+/* ------------------------------------------------------------------------- */
+#include <immintrin.h>
+typedef struct orc_node4 {
+  float lo[3][4], hi[3][4];
+  int32_t child[4];   /* >= 0: orc_node4 index; < 0: ~(index of a BVH2 LEAF node); empty slot: inverted box, child = INT32_MIN */
+} orc_node4;
+
+static float n2_area(const orc_node* n) { return box_area(n->bmin, n->bmax); }
+
+static uint32_t build_node4(orc_mesh* m, uint32_t n2)
+{
+  /* collapse: start with the two children of BVH2 node n2, open the inner candidate of largest area until four */
+  uint32_t cand[4]; int nc = 0;
+  cand[nc++] = m->nodes[n2].left_first; cand[nc++] = m->nodes[n2].left_first + 1;
+  while (nc < 4) {
+    int best = -1; float ba = -1.0f;
+    for (int i = 0; i < nc; ++i)
+      if (m->nodes[cand[i]].count == 0) { const float a = n2_area(&m->nodes[cand[i]]); if (a > ba) { ba = a; best = i; } }
+    if (best < 0) break;
+    const uint32_t l = m->nodes[cand[best]].left_first;
+    cand[best] = l; cand[nc++] = l + 1;
+  }
+  const uint32_t me = m->n_nodes4++;
+  for (int i = 0; i < 4; ++i) {
+    orc_node4* N = &m->nodes4[me];
+    if (i < nc) {
+      const orc_node* c = &m->nodes[cand[i]];
+      for (int k = 0; k < 3; ++k) { N->lo[k][i] = c->bmin[k]; N->hi[k][i] = c->bmax[k]; }
+    } else {
+      for (int k = 0; k < 3; ++k) { N->lo[k][i] = 1.0f; N->hi[k][i] = -1.0f; }   /* never entered */
+      N->child[i] = INT32_MIN;
+    }
+  }
+  for (int i = 0; i < nc; ++i) {
+    const int32_t ref = (m->nodes[cand[i]].count > 0) ? ~(int32_t)cand[i] : (int32_t)build_node4(m, cand[i]);
+    m->nodes4[me].child[i] = ref;   /* (re-index: nodes4 may have moved? no -- allocated once, below) */
+  }
+  return me;
+}
+
+static pthread_mutex_t g_bvh4_mtx = PTHREAD_MUTEX_INITIALIZER;
+static void ensure_bvh4(orc_mesh* m)
+{
+  pthread_mutex_lock(&g_bvh4_mtx);
+  if (!__atomic_load_n(&m->bvh4_ready, __ATOMIC_ACQUIRE)) {
+    m->nodes4 = (orc_node4*)malloc(sizeof(orc_node4) * (size_t)(m->n_nodes ? m->n_nodes : 1));   /* <= one per BVH2 inner node */
+    m->n_nodes4 = 0;
+    if (m->nodes[0].count == 0) build_node4(m, 0);
+    __atomic_store_n(&m->bvh4_ready, 1, __ATOMIC_RELEASE);
+  }
+  pthread_mutex_unlock(&g_bvh4_mtx);
+}
+
+int orc_intersect_bvh4(const orc_mesh* mc, orc_vec3 O, orc_vec3 D, float tnear, float tfar, float* t_out, uint32_t* face_out)
+{
+  orc_mesh* m = (orc_mesh*)mc;
+  if (!__atomic_load_n(&m->bvh4_ready, __ATOMIC_ACQUIRE)) ensure_bvh4(m);
+  if (m->nodes[0].count > 0) return orc_intersect_bvh(mc, O, D, tnear, tfar, t_out, face_out, NULL);   /* a single leaf */
+  if (!(D.x == D.x && D.y == D.y && D.z == D.z)) return 0;
+  const float inv3[3] = {safe_inv(D.x), safe_inv(D.y), safe_inv(D.z)};
+  const __m128 ox = _mm_set1_ps(O.x), oy = _mm_set1_ps(O.y), oz = _mm_set1_ps(O.z);
+  const __m128 ix = _mm_set1_ps(inv3[0]), iy = _mm_set1_ps(inv3[1]), iz = _mm_set1_ps(inv3[2]);
+  const __m128 vnear = _mm_set1_ps(tnear), slack = _mm_set1_ps(1.0000004f);
+  float best_t = tfar; uint32_t best_f = 0xFFFFFFFFu; int found = 0;
+  int32_t stack[256]; float stack_t[256]; int sp = 0;
+  stack[sp] = 0; stack_t[sp] = tnear; ++sp;
+  while (sp > 0) {
+    --sp;
+    const int32_t ref = stack[sp];
+    if (stack_t[sp] > best_t * 1.0000004f) continue;
+    if (ref < 0) {
+      const orc_node* n = &m->nodes[~ref];
+      for (uint32_t i = 0; i < n->count; ++i) {
+        const uint32_t f = m->prim[n->left_first + i];
+        float t;
+        if (tri_intersect(&m->tris[f], O, D, tnear, tfar, &t)) {
+          if (!found || t < best_t || (t == best_t && f < best_f)) { best_t = t; best_f = f; found = 1; }
+        }
+      }
+      continue;
+    }
+    const orc_node4* N = &m->nodes4[ref];
+    /* box_hit, four children at once: t0 = (bmin - o) * inv, t1 = (bmax - o) * inv, ordered, intersected with [tnear, best_t] */
+    const __m128 ax = _mm_mul_ps(_mm_sub_ps(_mm_loadu_ps(N->lo[0]), ox), ix), bx = _mm_mul_ps(_mm_sub_ps(_mm_loadu_ps(N->hi[0]), ox), ix);
+    const __m128 ay = _mm_mul_ps(_mm_sub_ps(_mm_loadu_ps(N->lo[1]), oy), iy), by = _mm_mul_ps(_mm_sub_ps(_mm_loadu_ps(N->hi[1]), oy), iy);
+    const __m128 az = _mm_mul_ps(_mm_sub_ps(_mm_loadu_ps(N->lo[2]), oz), iz), bz = _mm_mul_ps(_mm_sub_ps(_mm_loadu_ps(N->hi[2]), oz), iz);
+    const __m128 tn = _mm_max_ps(_mm_max_ps(_mm_min_ps(ax, bx), _mm_min_ps(ay, by)), _mm_max_ps(_mm_min_ps(az, bz), vnear));
+    const __m128 tf = _mm_min_ps(_mm_min_ps(_mm_max_ps(ax, bx), _mm_max_ps(ay, by)), _mm_min_ps(_mm_max_ps(az, bz), _mm_set1_ps(best_t)));
+    int mask = _mm_movemask_ps(_mm_cmple_ps(tn, _mm_mul_ps(tf, slack)));
+    if (!mask) continue;
+    float tns[4];
+    _mm_storeu_ps(tns, tn);
+    /* push the hit children far to near (insertion into a sorted run of <= 4) */
+    int order[4], no = 0;
+    while (mask) {
+      const int c = __builtin_ctz((unsigned)mask);
+      mask &= mask - 1;
+      if (N->child[c] == INT32_MIN) continue;
+      int pos = no++;
+      while (pos > 0 && tns[order[pos - 1]] < tns[c]) { order[pos] = order[pos - 1]; --pos; }
+      order[pos] = c;
+    }
+    if (sp + no > 256) return -1;
+    for (int i = 0; i < no; ++i) { stack[sp] = N->child[order[i]]; stack_t[sp] = tns[order[i]]; ++sp; }   /* nearest on top */
+  }
+  if (found) { *t_out = best_t; *face_out = best_f; }
+  return found;
+}
+
 /* rmagine PinholeModel::getDirection (external; fields f = {fx, fy}, c = {cx, cy} pinned by
  * rmcl_ros/src/util/conversions.cpp:36-60): optical ray ((hid - cx)/fx, (vid - cy)/fy, 1) normalised, then
  * optical (x right, y down, z forward) -> sensor frame (x forward, y left, z up). */
@@ -421,6 +539,7 @@ typedef struct {
   const orc_transform* Tbm;
   uint32_t nposes;
   int use_bvh;
+  const float* trig;   /* spherical, use_bvh = 2: cos(phi_v)[H] | sin(phi_v)[H] | cos(theta_h)[W] | sin(theta_h)[W] */
   uint8_t* hits; float* ranges; float* points; float* normals; uint32_t* face_ids;
   /* work distribution */
   volatile uint64_t next;
@@ -449,9 +568,14 @@ static void sim_range(sim_job* J, uint64_t begin, uint64_t end, orc_counters* cn
     if (J->kind == 0) {
       /* rmagine SphericalModel::getDirection = polar2cartesian(phi, theta)
        * (convention pinned by rmcl_ros/src/util/conversions.cpp:174-188) */
-      const float phi = J->sph->phi.min + (float)vid * J->sph->phi.inc;
-      const float theta = J->sph->theta.min + (float)hid * J->sph->theta.inc;
-      const float cp = cosf(phi), sp = sinf(phi), ct = cosf(theta), st = sinf(theta);
+      float cp, sp, ct, st;
+      if (J->trig) {   /* the same four libm values, computed once per row / column of the scan instead of once per ray */
+        cp = J->trig[vid]; sp = J->trig[J->height + vid]; ct = J->trig[2 * J->height + hid]; st = J->trig[2 * J->height + J->width + hid];
+      } else {
+        const float phi = J->sph->phi.min + (float)vid * J->sph->phi.inc;
+        const float theta = J->sph->theta.min + (float)hid * J->sph->theta.inc;
+        cp = cosf(phi); sp = sinf(phi); ct = cosf(theta); st = sinf(theta);
+      }
       dir_s = v3(cp * ct, cp * st, sp);
       orig_s = v3(0, 0, 0);
       org_m = Tsm.t;
@@ -472,7 +596,8 @@ static void sim_range(sim_job* J, uint64_t begin, uint64_t end, orc_counters* cn
     const orc_vec3 dir_m = orc_quat_rotate(Tsm.R, dir_s);
     float t = 0; uint32_t face = 0xFFFFFFFFu;
     int hit;
-    if (J->use_bvh) hit = orc_intersect_bvh(J->m, org_m, dir_m, 0.0f, J->range.max, &t, &face, cnt);
+    if (J->use_bvh == 2) hit = orc_intersect_bvh4(J->m, org_m, dir_m, 0.0f, J->range.max, &t, &face);
+    else if (J->use_bvh) hit = orc_intersect_bvh(J->m, org_m, dir_m, 0.0f, J->range.max, &t, &face, cnt);
     else hit = orc_intersect_brute(J->m, org_m, dir_m, 0.0f, J->range.max, &t, &face);
     if (hit > 0) {
       if (J->hits) J->hits[g] = 1;
@@ -608,7 +733,19 @@ int orc_simulate_spherical(const orc_mesh* m, const orc_spherical_model* model, 
   J.m = m; J.kind = 0; J.sph = model; J.width = model->theta.size; J.height = model->phi.size;
   J.range = model->range; J.Tsb = Tsb; J.Tbm = Tbm; J.nposes = nposes; J.use_bvh = use_bvh;
   J.hits = hits; J.ranges = ranges; J.points = points; J.normals = normals; J.face_ids = face_ids;
-  return run_sim(&J, nthreads, cnt);
+  float* trig = NULL;
+  if (use_bvh == 2) {
+    /* the baseline path: the per-ray libm values, hoisted per row / column (identical values, hence identical rays) */
+    const uint32_t H = J.height, W = J.width;
+    trig = (float*)malloc(sizeof(float) * (2u * (size_t)H + 2u * (size_t)W + 1u));
+    for (uint32_t v = 0; v < H; ++v) { const float phi = model->phi.min + (float)v * model->phi.inc; trig[v] = cosf(phi); trig[H + v] = sinf(phi); }
+    for (uint32_t h = 0; h < W; ++h) { const float th = model->theta.min + (float)h * model->theta.inc; trig[2 * H + h] = cosf(th); trig[2 * H + W + h] = sinf(th); }
+    J.trig = trig;
+    if (!__atomic_load_n(&((orc_mesh*)m)->bvh4_ready, __ATOMIC_ACQUIRE)) ensure_bvh4((orc_mesh*)m);
+  }
+  const int rc = run_sim(&J, nthreads, cnt);
+  free(trig);
+  return rc;
 }
 
 int orc_simulate_o1dn(const orc_mesh* m, uint32_t width, uint32_t height, orc_interval range, orc_vec3 orig,

@@ -161,6 +161,9 @@ int orc_pf_update(const orc_mesh* m, const orc_transform* poses, orc_particle_at
                   float* errors_out /* nullable, n*nbeams */);
 
 /* ---- closest-point correspondences (CPCEmbree.cpp:18-44; rm::EmbreeMap::closestPoint) ---- */
+/* use_bvh = 2 (accepted by orc_simulate_spherical / _o1dn / ...): the closest hit through a 4-wide collapse of the BVH2 with SSE slab
+ * tests -- the CPU-baseline path of bench.py; bit-identical results (same triangle test, same tie-break) */
+int orc_intersect_bvh4(const orc_mesh* m, orc_vec3 O, orc_vec3 D, float tnear, float tfar, float* t_out, uint32_t* face_out);
 int orc_closest_point(const orc_mesh* m, orc_vec3 P, int use_bvh, float* d_out, orc_vec3* cp_out, uint32_t* face_out);
 void orc_cpc_find(const orc_mesh* m, const orc_transform* Tsb, const orc_transform* Tbm, const float* dataset_points,
                   uint32_t n, float max_dist, int use_bvh, uint8_t* hits, float* dists, float* points, float* normals,

@@ -396,3 +396,35 @@ def test_golden_g5_reproduces(orc, meshes):
     assert np.array_equal(np.array(traj, dtype=T.TRANSFORM).view(np.uint8), g["traj_R"])
     z = [float(T.mult(Tom, t)["t"]["z"]) for t in traj]
     assert all(z[i + 1] <= z[i] + 1e-6 for i in range(9)) and z[-1] < 0.2   # moves towards the truth
+
+
+@pytest.mark.parametrize("name", ["cube", "sphere20k", "room30k"])
+def test_bvh4_sse_walk_equals_brute_force_and_bvh2(orc, meshes, name):
+    """use_bvh = 2 -- the 4-wide collapse of the BVH2 walked with SSE slab tests, the path bench.py times as `cpu_baseline` -- returns
+    what the exhaustive loop and the scalar BVH2 walk return, bit for bit, for every model (spherical with hoisted trig tables, O1Dn
+    with NaN directions, pinhole, OnDn), tiny and ragged scans, several poses and threads."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes(name)
+    m = orc.Mesh(v, f)
+    model = syn.model_c1()
+    poses = [syn.pose_c2_truth(), T.transform_from_rpy((-2.1, 1.3, 0.7), (0.3, -0.2, 2.5))]
+    Tsb = syn.tsb_offset()
+    for Tbm in poses:
+        ref = m.simulate_spherical(model, Tsb, Tbm, bvh=False, nthreads=4)
+        for mode, nt in ((True, 1), (2, 1), (2, 4)):
+            out = m.simulate_spherical(model, Tsb, Tbm, bvh=mode, nthreads=nt)
+            for k in ("hits", "ranges", "points", "normals", "face_ids"):
+                assert np.array_equal(out[k], ref[k], equal_nan=True), (name, mode, k)
+    dirs = syn.model_directions(model).copy()
+    dirs[3::17] = np.nan
+    H, W = model.phi.size, model.theta.size
+    a = m.simulate_o1dn(W, H, 0.1, 100.0, (0.01, -0.02, 0.03), dirs, Tsb, poses[1], bvh=False, nthreads=4)
+    b = m.simulate_o1dn(W, H, 0.1, 100.0, (0.01, -0.02, 0.03), dirs, Tsb, poses[1], bvh=2, nthreads=4)
+    c = m.simulate_pinhole(40, 30, 0.1, 100.0, (35.0, 35.0), (19.5, 14.5), Tsb, poses[0], bvh=False, nthreads=4)
+    d = m.simulate_pinhole(40, 30, 0.1, 100.0, (35.0, 35.0), (19.5, 14.5), Tsb, poses[0], bvh=2, nthreads=4)
+    for x, y in ((a, b), (c, d)):
+        for k in ("hits", "ranges", "face_ids"):
+            assert np.array_equal(x[k], y[k], equal_nan=True), k
+    one = orc.Mesh(v[f[0]].reshape(3, 3), np.array([[0, 1, 2]], np.uint32))      # a map of ONE triangle: the BVH2 root is a leaf
+    assert np.array_equal(one.simulate_spherical(model, T.identity(), poses[0], bvh=2)["face_ids"],
+                          one.simulate_spherical(model, T.identity(), poses[0], bvh=False)["face_ids"])
