@@ -144,7 +144,8 @@ struct rmclhip_map {
   uint64_t bytes = 0;
   // near grid of the closest-point queries (kernels.h NearGrid): built on the first rmclhip_rcc_find_cpc of any operator of this map
   std::mutex grid_mtx;
-  bool grid_ready = false, grid_failed = false;
+  bool grid_ready = false, grid_failed = false, grid_full = false;
+  uint64_t grid_bytes = 0;
   uint32_t* d_near_grid = nullptr;
   NearGrid grid = {};
   std::vector<uint32_t> scene_first_face;  // map_create_scene: first global face id of every instance, + the total (else empty)
@@ -302,6 +303,7 @@ struct rmclhip_pf {
   int variant = 0;
   uint32_t refill_thr = 0, tail_lanes = 8;  // schedule knobs of the round-3 kernel (0: from `refill`); rmclhip_pf_set_schedule
   // rmclhip_pf_set_mapping: 0 beam-minor blocks of ~2048 rays (uniform clouds), 1 particle-minor blocks (converged clouds), 2 automatic
+  bool cpc_grid = true;            // correspondence_type 1: seed every closest-point query from the map's near grid (A/B: rmclhip_pf_set_mapping bit 8 clears it)
   int mapping = 0;
   uint32_t map_ppb = 0;            // particles per workgroup of the particle-minor mapping (0: 32)
   const uint32_t* order = nullptr; // slot -> particle (device), borrowed or d_order
@@ -1223,10 +1225,16 @@ static float cpc_bound_d2(const rmclhip_rcc* r) {
 // The map's near grid: ~2 M cubic cells over the map's box (at most 256 per axis), each holding the record closest to its centre --
 // one cold closest-point launch over the cell centres, once per map (a few ms; 8 MB), under the map's mutex: operators of one map may
 // be used from different threads.
-static rmclhip_status ensure_near_grid(rmclhip_rcc* r) {
-  rmclhip_map* m = r->map;
+// `full`: every cell gets a record (the particle filter's closest-point mode queries beam END points, metres from any surface);
+// otherwise cells farther than two coarse cell diagonals from the surface get none (scan points lie near it) -- the cheap build.
+static rmclhip_status ensure_near_grid(rmclhip_map* m, hipStream_t stream, bool full) {
   std::lock_guard<std::mutex> lock(m->grid_mtx);
-  if (m->grid_ready || m->grid_failed) return RMCLHIP_OK;
+  if (m->grid_failed || (m->grid_ready && (m->grid_full || !full))) return RMCLHIP_OK;
+  if (m->grid_ready) {   // upgrade a near-surface grid to a full one: rebuilt
+    m->grid_ready = false;
+    (void)hipFree(m->d_near_grid); m->d_near_grid = nullptr;
+    m->bytes -= m->grid_bytes; m->grid_bytes = 0;
+  }
   float ext[3];
   double vol = 1.0;
   for (int k = 0; k < 3; ++k) {
@@ -1250,7 +1258,7 @@ static rmclhip_status ensure_near_grid(rmclhip_rcc* r) {
   // 64 x fewer of them), then the full grid with every cell seeded from its coarse parent
   // (cells farther than two coarse cell diagonals from the surface get no record: a query point there runs unseeded, as before)
   const float cdiag = 4.0f * cell * 1.7320508f;
-  const float skip_d2 = (2.0f * cdiag) * (2.0f * cdiag);
+  const float skip_d2 = full ? 3.0e38f : (2.0f * cdiag) * (2.0f * cdiag);
   NearGrid c = g;
   size_t ctotal = 1;
   for (int k = 0; k < 3; ++k) { c.n[k] = (g.n[k] + 3u) / 4u; c.inv[k] = g.inv[k] * static_cast<float>(c.n[k]) / static_cast<float>(g.n[k]); ctotal *= c.n[k]; }
@@ -1258,12 +1266,12 @@ static rmclhip_status ensure_near_grid(rmclhip_rcc* r) {
   e = hipMalloc(reinterpret_cast<void**>(&d_coarse), ctotal * sizeof(uint32_t));
   if (e == hipSuccess)
     e = launch_cpc_find(m->d_nodes, m->d_tris, nullptr, static_cast<uint32_t>(ctotal), 0.f, xidentity(), xidentity(), nullptr, nullptr, nullptr, nullptr,
-                        nullptr, false, r->stream, nullptr, d_coarse, m->info.n_faces, 3.0e38f, nullptr, &c);
+                        nullptr, false, stream, nullptr, d_coarse, m->info.n_faces, 3.0e38f, nullptr, &c);
   c.cells = d_coarse;
   if (e == hipSuccess)
     e = launch_cpc_find(m->d_nodes, m->d_tris, nullptr, static_cast<uint32_t>(total), 0.f, xidentity(), xidentity(), nullptr, nullptr, nullptr, nullptr,
-                        nullptr, false, r->stream, nullptr, m->d_near_grid, m->info.n_faces, 3.0e38f, &c, &g, skip_d2);
-  if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+                        nullptr, false, stream, nullptr, m->d_near_grid, m->info.n_faces, 3.0e38f, &c, &g, skip_d2);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
   if (d_coarse) (void)hipFree(d_coarse);
   if (e != hipSuccess) {
     (void)hipFree(m->d_near_grid); m->d_near_grid = nullptr; m->grid_failed = true;
@@ -1271,7 +1279,9 @@ static rmclhip_status ensure_near_grid(rmclhip_rcc* r) {
   }
   g.cells = m->d_near_grid;
   m->grid = g;
-  m->bytes += total * sizeof(uint32_t);
+  m->grid_bytes = total * sizeof(uint32_t);
+  m->bytes += m->grid_bytes;
+  m->grid_full = full;
   m->grid_ready = true;
   return RMCLHIP_OK;
 }
@@ -1296,7 +1306,7 @@ rmclhip_status rmclhip_rcc_find_cpc(rmclhip_rcc* r, const rmclhip_transform* Tbm
     if (r->d_cpc_rec.p != r->cpc_rec_ptr) { r->cpc_rec_ptr = r->d_cpc_rec.p; r->cpc_rec_n = 0; }   // (re)allocated
     if (r->cpc_rec_n == r->n_dataset && r->cpc_rec_pts == r->ds_pts) seed = r->d_cpc_rec.p;
   }
-  if (r->cpc_grid) { if (rmclhip_status gst = ensure_near_grid(r)) return gst; }
+  if (r->cpc_grid) { if (rmclhip_status gst = ensure_near_grid(r->map, r->stream, false)) return gst; }
   const NearGrid* grid = (r->cpc_grid && r->map->grid_ready) ? &r->map->grid : nullptr;
   HIPCHK(launch_cpc_find(quad ? r->map->d_cnodes : r->map->d_nodes, r->map->d_tris, r->ds_pts, r->n_dataset,
                          r->max_dist, Tsm, xinv(Tsm), r->d_hits.p, r->d_ranges.p, r->d_points.p, r->d_normals.p,
@@ -3032,6 +3042,17 @@ static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, 
   if (pb > 64u) pb = 64u;
   p.particle_minor = 0u;
   p.order = nullptr;
+  p.near_grid = nullptr;
+  p.n_tris = f->map->info.n_faces;
+  for (int k = 0; k < 3; ++k) { p.gn[k] = 1u; p.gorg[k] = 0.f; p.ginv[k] = 1.f; }
+  if (f->params.correspondence_type == 1u && f->cpc_grid) {
+    // closest-point errors: every query starts from the near grid's record of its cell (the FULL grid: beam end points are anywhere)
+    if (rmclhip_status gst = ensure_near_grid(f->map, f->stream, true)) return gst;
+    if (f->map->grid_ready) {
+      p.near_grid = f->map->grid.cells;
+      for (int k = 0; k < 3; ++k) { p.gn[k] = f->map->grid.n[k]; p.gorg[k] = f->map->grid.org[k]; p.ginv[k] = f->map->grid.inv[k]; }
+    }
+  }
   if (f->mapping == 1) {
     // particle-minor dealing: a wave's lanes hold the same beam of `pb` consecutive slots; errors of pb x n_beams beams stay in LDS
     p.particle_minor = 1u;
@@ -3137,7 +3158,9 @@ rmclhip_status rmclhip_pf_set_schedule(rmclhip_pf* f, uint32_t refill_idle_lanes
 
 rmclhip_status rmclhip_pf_set_mapping(rmclhip_pf* f, int mapping, uint32_t particles_per_block, const uint32_t* order_dev, uint32_t n_order) {
   ApiGuard guard_("rmclhip_pf_set_mapping");
-  if (!f || mapping < 0 || mapping > 1 || particles_per_block > 64u) return fail(RMCLHIP_ERR_INVALID, "pf_set_mapping: bad arguments");
+  if (!f || mapping < 0 || (mapping & 0xFF) > 1 || (mapping >> 9) != 0 || particles_per_block > 64u) return fail(RMCLHIP_ERR_INVALID, "pf_set_mapping: bad arguments");
+  f->cpc_grid = ((mapping >> 8) & 1) == 0;   // bit 8 (A/B): closest-point errors WITHOUT the near-grid seed
+  mapping &= 0xFF;
   f->mapping = mapping;
   f->map_ppb = particles_per_block;
   f->order = order_dev;

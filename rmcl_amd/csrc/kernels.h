@@ -121,6 +121,11 @@ struct PfParams {
   // null = identity).  Same rays, same per-particle merge order: results do not depend on the mapping.
   uint32_t particle_minor;
   const uint32_t* order;         // nullable [n_particles]
+  // correspondence_type 1 (closest point): the map's near grid (kernels.h NearGrid; null: unseeded queries) and the record count
+  const uint32_t* near_grid;
+  uint32_t gn[3];
+  float gorg[3], ginv[3];
+  uint32_t n_tris;
 };
 
 // per-call inputs of the device-resident MICP loop: written by ONE H2D copy so that the whole loop can be a

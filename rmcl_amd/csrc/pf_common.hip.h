@@ -71,7 +71,15 @@ __global__ void __launch_bounds__(256) k_pf_update(const PfParams p) {
       const f3 mean = add3(org, scale3(dir, range));
       const bool ok = (mean.x == mean.x) && (mean.y == mean.y) && (mean.z == mean.z);
       NearHit nh;
-      nearest_lane_ww<16>(p.nodes, p.tris, mean, live && ok, stacks + threadIdx.x, 256u, nh);
+      if (p.near_grid != nullptr) {
+        // round 4: the query starts from the record of the map's near-grid cell the point falls into -- an actual candidate, so the
+        // result is unchanged; beam end points are often metres from any surface, where an unseeded query cannot prune
+        const uint32_t sr = (live && ok) ? near_grid_record(p.near_grid, p.gn, p.gorg, p.ginv, mean) : kNone;
+        const NearHit seed = near_seed_from_record(p.tris, sr, p.n_tris, mean, live && ok);
+        nearest_lane_ww<16>(p.nodes, p.tris, mean, live && ok, stacks + threadIdx.x, 256u, nh, &seed);
+      } else {
+        nearest_lane_ww<16>(p.nodes, p.tris, mean, live && ok, stacks + threadIdx.x, 256u, nh);
+      }
       if (live) {
         const float error = (nh.face != kInvalidFace) ? sqrtf(nh.d2) : __uint_as_float(0x7FC00000u);
         if (p.errors) p.errors[static_cast<size_t>(p0 + pi) * p.n_beams + b] = error;

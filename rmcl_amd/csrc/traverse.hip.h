@@ -1465,6 +1465,30 @@ struct CpcParams {
                    // deep inside free space -- the centre of a hollow sphere: everything equidistant -- are the searches that cannot prune
 };
 
+// seed of a closest-point query from a record index: the record's own closest point (the query's arithmetic: revisiting the record
+// changes nothing); sr >= n_tris: no seed
+__device__ __forceinline__ NearHit near_seed_from_record(const uint32_t* __restrict__ tris, uint32_t sr, uint32_t n_tris, f3 Pm, bool usable) {
+  NearHit seed;
+  seed.d2 = 3.0e38f; seed.face = kInvalidFace; seed.rec = 0; seed.p = mk3(0.f, 0.f, 0.f);
+  if (usable && sr < n_tris) {
+    const uint4* tp = reinterpret_cast<const uint4*>(tris) + static_cast<size_t>(sr) * 4u;
+    const uint4 a = tp[0], b = tp[1], cc = tp[2], d = tp[3];
+    const f3 cq = closest_point_triangle(mk3(asf(a.x), asf(a.y), asf(a.z)), mk3(asf(a.w), asf(b.x), asf(b.y)),
+                                         mk3(asf(b.z), asf(b.w), asf(cc.x)), Pm);
+    const f3 df = sub3(Pm, cq);
+    seed.d2 = (df.x * df.x + df.y * df.y) + df.z * df.z;
+    seed.face = d.w; seed.rec = sr; seed.p = cq;
+  }
+  return seed;
+}
+// the record of the near-grid cell a point falls into (points outside the grid take the nearest cell: any record is a candidate)
+__device__ __forceinline__ uint32_t near_grid_record(const uint32_t* __restrict__ cells, const uint32_t* gn, const float* gorg, const float* ginv, f3 Pm) {
+  const float fx = fminf(fmaxf((Pm.x - gorg[0]) * ginv[0], 0.0f), static_cast<float>(gn[0] - 1u));
+  const float fy = fminf(fmaxf((Pm.y - gorg[1]) * ginv[1], 0.0f), static_cast<float>(gn[1] - 1u));
+  const float fz = fminf(fmaxf((Pm.z - gorg[2]) * ginv[2], 0.0f), static_cast<float>(gn[2] - 1u));
+  return cells[(static_cast<uint32_t>(fz) * gn[1] + static_cast<uint32_t>(fy)) * gn[0] + static_cast<uint32_t>(fx)];
+}
+
 // kQuad: four lanes per dataset point (64 points per block) instead of one
 template <bool kQuad>
 __global__ void __launch_bounds__(256) k_cpc_find(const CpcParams p) {
@@ -1484,25 +1508,11 @@ __global__ void __launch_bounds__(256) k_cpc_find(const CpcParams p) {
   }
   const bool finite = (Pm.x == Pm.x) && (Pm.y == Pm.y) && (Pm.z == Pm.z);
   NearHit h, seed;
-  seed.d2 = 3.0e38f; seed.face = kInvalidFace; seed.rec = 0; seed.p = mk3(0.f, 0.f, 0.f);
   {
     uint32_t sr = (p.seed_rec != nullptr) ? p.seed_rec[ii] : kNone;
-    if (sr >= p.n_tris && p.near_grid != nullptr && live && finite) {
-      // no tracking seed: the record of the point's cell (points outside the grid take the nearest cell: any record is a candidate)
-      const float fx = fminf(fmaxf((Pm.x - p.gorg[0]) * p.ginv[0], 0.0f), static_cast<float>(p.gn[0] - 1u));
-      const float fy = fminf(fmaxf((Pm.y - p.gorg[1]) * p.ginv[1], 0.0f), static_cast<float>(p.gn[1] - 1u));
-      const float fz = fminf(fmaxf((Pm.z - p.gorg[2]) * p.ginv[2], 0.0f), static_cast<float>(p.gn[2] - 1u));
-      sr = p.near_grid[(static_cast<uint32_t>(fz) * p.gn[1] + static_cast<uint32_t>(fy)) * p.gn[0] + static_cast<uint32_t>(fx)];
-    }
-    if (live && finite && sr < p.n_tris) {
-      const uint4* tp = reinterpret_cast<const uint4*>(p.tris) + static_cast<size_t>(sr) * 4u;
-      const uint4 a = tp[0], b = tp[1], cc = tp[2], d = tp[3];
-      const f3 cq = closest_point_triangle(mk3(asf(a.x), asf(a.y), asf(a.z)), mk3(asf(a.w), asf(b.x), asf(b.y)),
-                                           mk3(asf(b.z), asf(b.w), asf(cc.x)), Pm);
-      const f3 df = sub3(Pm, cq);
-      seed.d2 = (df.x * df.x + df.y * df.y) + df.z * df.z;   // the query's own arithmetic: revisiting this record changes nothing
-      seed.face = d.w; seed.rec = sr; seed.p = cq;
-    }
+    // no tracking seed: the record of the point's cell
+    if (sr >= p.n_tris && p.near_grid != nullptr && live && finite) sr = near_grid_record(p.near_grid, p.gn, p.gorg, p.ginv, Pm);
+    seed = near_seed_from_record(p.tris, sr, p.n_tris, Pm, live && finite);
   }
   if (p.from_cells && seed.d2 > p.skip_d2) {
     if (live && p.rec_out != nullptr && (!kQuad || sub == 0u)) p.rec_out[i] = kNone;

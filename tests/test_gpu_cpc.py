@@ -102,6 +102,16 @@ def test_pf_update_with_closest_point_errors(ra, orc, ctx, meshes, n_particles, 
     assert_close_rel(a_gpu["likelihood"]["mean"], a_ref["likelihood"]["mean"], 1e-5, 1e-12, "cpc mean")
     assert_close_rel(a_gpu["likelihood"]["sigma"], a_ref["likelihood"]["sigma"], 1e-4, 1e-10, "cpc sigma")
     assert e_ref.max() < 20 and e_ref.min() >= 0       # distances, never the 100 m miss penalty
+    # round 4: the queries above started from the map's near grid (the default); without the seed (rmclhip_pf_set_mapping bit 8)
+    # attributes and errors are the same bit for bit -- a seed only bounds the search
+    upd.set_mapping(256, 0, None)
+    d_attrs2 = ra.DeviceArray.from_host(ctx, attrs)
+    d_err2 = ra.DeviceArray(ctx, np.float32, n_particles * n_beams)
+    upd.set_error_output(d_err2)
+    upd.update(d_poses, d_attrs2)
+    assert d_attrs2.download().tobytes() == a_gpu.tobytes()
+    assert d_err2.download().tobytes() == e_gpu.tobytes()
+    upd.close()
     with pytest.raises(ra.RmclHipError):
         upd.config = T.pf_params(correspondence_type=4)
         upd.update(d_poses, d_attrs)
