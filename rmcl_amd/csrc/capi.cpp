@@ -1481,7 +1481,7 @@ static hipError_t wait_moments(rmclhip_rcc* r, uint32_t seq, float lo, float hi,
     const uint32_t code = *reinterpret_cast<const volatile uint32_t*>(&hb->code);
     const uint32_t n = *reinterpret_cast<const volatile uint32_t*>(&hb->n_uncertain);
     x ^= code ^ n;
-    if (code == 0u && n <= kMicpHostMaxUnc) x ^= xor_host(hb->unc, static_cast<size_t>(n) * 9u * sizeof(float));
+    if (n <= kMicpHostMaxUnc) x ^= xor_host(hb->unc, static_cast<size_t>(n) * 9u * sizeof(float));   // (written whenever they fit)
     return x;
   };
   hipError_t e = hipSuccess;

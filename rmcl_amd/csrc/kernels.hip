@@ -546,6 +546,10 @@ __global__ void __launch_bounds__(64) k_micp_step(const double* __restrict__ par
 // ---------------------------------------------------------------------------------------------
 constexpr int kMom = 96;  // 82 used: n | D[3] | DD[6] | sN[3] | sND[9] | NN[6] | NND[18] | NNDD[36]
 constexpr uint32_t kFastMaxUncertain = 4096;
+// Bound of the device-side polls below (fold flags of sibling workgroups, join flags of another stream's signal kernel): a poll is
+// one L2 round trip (~1 us), so ~2 s.  A producer that never arrives ends the launch with status code 2 -- the host then takes the
+// per-iteration form, which joins with stream events -- instead of a kernel the 20 ms host fallback could never get past.
+constexpr uint32_t kDevicePollBound = 1u << 21;
 constexpr uint32_t kFastThreads = 256;   // 1 wave per SIMD: the one-lane solve may use up to 512 VGPRs (no scratch)
 
 // wave64 sum of 16 doubles per lane by the halving butterfly of k_reduce_partials: afterwards lane L holds the wave total of
@@ -923,6 +927,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastP
   __shared__ uint32_t s_wave_cnt[kFastThreads / 64];
   __shared__ xform s_Tpre;
   __shared__ uint32_t s_flag;
+  __shared__ uint32_t s_abort;   // a sibling workgroup's sums did not arrive within kDevicePollBound polls
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const unsigned long long clk0 = __builtin_readcyclecounter();
 
@@ -965,7 +970,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastP
     if (lane >= static_cast<uint32_t>(off)) incl += v;
   }
   if (lane == 63u) s_wave_cnt[wave] = incl;
-  if (tid == 0u) s_flag = 0u;
+  if (tid == 0u) { s_flag = 0u; s_abort = 0u; }
   __syncthreads();
   if (tid < kMom) {
     double a = s_part[0][tid];
@@ -976,6 +981,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastP
       // (all flags polled together, ONE acquire, all rows requested together: two memory round trips, not two per workgroup)
       const uint32_t seq = RMCL_FCALL(p, seq);
       bool ready;
+      uint32_t polls = 0;
       do {
         uint32_t f[kMicpFoldBlocks];
 #pragma unroll
@@ -984,7 +990,8 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastP
         ready = true;
 #pragma unroll
         for (uint32_t b = 1; b < kMicpFoldBlocks; ++b) ready = ready && (f[b] == seq);
-      } while (!ready);
+      } while (!ready && ++polls < kDevicePollBound);
+      if (!ready) s_abort = 1u;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       unsigned long long v[kMicpFoldBlocks];
 #pragma unroll
@@ -1003,6 +1010,10 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_fast_loop(const MicpFastP
     const uint32_t c = s_wave_cnt[w];
     if (w < wave) wave_base += c;
     total += c;
+  }
+  if (nfold > 1u) {   // (launch-uniform) did every sibling's row arrive?
+    __syncthreads();
+    if (s_abort != 0u) total = kFastMaxUncertain + 1u;
   }
   if (total > kFastMaxUncertain) {
     if (tid == 0u) {
@@ -1142,6 +1153,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_publish(const MicpFastPar
   __shared__ uint32_t s_list[kMicpHostMaxUnc];
   __shared__ uint32_t s_wave_cnt[kFastThreads / 64];
   __shared__ uint32_t s_xor[kFastThreads / 64];
+  __shared__ uint32_t s_abort;   // a sibling workgroup's sums did not arrive within kDevicePollBound polls: code 2
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t nfold = gridDim.x;
   const uint32_t rows_per = (p.nblocks + nfold - 1u) / nfold;
@@ -1179,6 +1191,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_publish(const MicpFastPar
     if (lane >= static_cast<uint32_t>(off)) incl += v;
   }
   if (lane == 63u) s_wave_cnt[wave] = incl;
+  if (tid == 0u) s_abort = 0u;
   __syncthreads();
   uint32_t x = 0u;   // xor of the words this thread writes for the host
   if (tid < kMom) {
@@ -1190,6 +1203,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_publish(const MicpFastPar
       if (nfold > 1u) {
         const uint32_t seq = p.cv.seq;
         bool ready;
+        uint32_t polls = 0;
         do {
           uint32_t f[kMicpFoldBlocks];
 #pragma unroll
@@ -1198,7 +1212,8 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_publish(const MicpFastPar
           ready = true;
 #pragma unroll
           for (uint32_t b = 1; b < kMicpFoldBlocks; ++b) ready = ready && (f[b] == seq);
-        } while (!ready);
+        } while (!ready && ++polls < kDevicePollBound);
+        if (!ready) s_abort = 1u;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         unsigned long long v[kMicpFoldBlocks];
 #pragma unroll
@@ -1254,7 +1269,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_publish(const MicpFastPar
   __threadfence_system();   // this thread's stores to the host block, before the tag below
   __syncthreads();
   if (tid == 0u) {
-    const uint32_t code = fits ? 0u : 2u;
+    const uint32_t code = (fits && s_abort == 0u) ? 0u : 2u;
     p.host_block->code = code;
     p.host_block->n_uncertain = total;
     p.host_block->pad[0] = 0u; p.host_block->pad[1] = 0u;
@@ -2267,6 +2282,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_multi_fast_loop(const Mic
   __shared__ xform s_Tone;                       // T_onew_oold of this iteration, for the sensors' lanes
   __shared__ float s_max_rho[kMaxMicpSensors], s_max_tau[kMaxMicpSensors];
   __shared__ uint32_t s_bad;                     // smallest index of a sensor whose pre-transform left its caps
+  __shared__ uint32_t s_join_lost;               // a joined stream's signal did not arrive within kDevicePollBound polls
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t ns = p.n_sensors;
 
@@ -2276,9 +2292,22 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_multi_fast_loop(const Mic
     if ((p.join_mask >> s) & 1u) {
       // this sensor's rows and mask words come from another stream: its signal kernel (behind its moment pass) stores the call's
       // sequence number; one lane acquires it, the barrier hands the visibility to the workgroup
-      if (tid == 0u)
-        while (__hip_atomic_load(p.join_flags + s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != p.seq) __builtin_amdgcn_s_sleep(2);
+      if (tid == 0u) {
+        uint32_t polls = 0;
+        while (__hip_atomic_load(p.join_flags + s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != p.seq && ++polls < kDevicePollBound)
+          __builtin_amdgcn_s_sleep(2);
+        s_join_lost = (polls >= kDevicePollBound) ? 1u : 0u;
+      }
       __syncthreads();
+      if (s_join_lost != 0u) {   // the other stream's signal never came: code 2, the host takes the per-iteration form
+        if (tid == 0u) {
+          MicpMultiFastStatus st;
+          st.code = 2u; st.iter = 0u; st.n_uncertain = 0xffffffffu; st.sensor = s;
+          for (uint32_t q = 0; q < kMaxMicpSensors; ++q) { st.max_rho[q] = 0.f; st.max_tau[q] = 0.f; }
+          publish_status(p.status, st, p.done, p.seq, 0u);
+        }
+        return;
+      }
     }
     fold_moment_partials(p.partials[s], p.nblocks[s], s_part, tid);
     const unsigned long long* mask = p.unc_mask[s];
