@@ -819,3 +819,70 @@ def test_c3_full_size_room_host_forms_with_undecided_correspondences(ra, orc, ct
     assert rcc.micp_fast_info()["host_loops"] >= 2
     rcc.close()
     rcc0.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_caller_calls_in_random_order_match_the_streaming_reduction(ra, orc, ctx, meshes, seed):
+    """The moment sets of round 4 live across calls (a find speculates on what the calls after the LAST find looked like), so the
+    state machine is fuzzed: a seeded random sequence of find / computeCrossStatistics / new dataset / new mask / new max_dist /
+    new adaptive_max_dist_min / find at far poses on two operators -- one with the moment form (default), one answering every call
+    with the streaming reduction -- must give the same statistics call for call, whatever answered them."""
+    from rmcl_amd import synthetic as syn, types as T
+    model = syn.model_c1()
+    m, hm, truth, ds, mask = _room_case(ra, orc, ctx, meshes, model)
+    ident = T.identity()
+    rng = np.random.RandomState(seed)
+    rcc, ref = ra.RCCHipSpherical(hm), ra.RCCHipSpherical(hm)
+    for r, mode in ((rcc, 1), (ref, 0)):
+        r.setTsb(ident)
+        r.setModel(model)
+        r.set_dataset(ds, mask)
+        r.params.max_dist, r.adaptive_max_dist_min = 1.0, 0.15
+        r.set_micp_fast(mode)
+
+    def small_pose(scale):
+        return T.transform_from_rpy(tuple(rng.normal(0, 0.03 * scale, 3)), tuple(rng.normal(0, 0.01 * scale, 3)))
+
+    est = T.mult(truth, small_pose(1.0))
+    for r in (rcc, ref):
+        r.find(est)
+    prog, n_ccs = 0.0, 0
+    for step in range(70):
+        op = rng.choice(["ccs", "ccs", "ccs", "ccs", "find", "find_far", "dataset", "mask", "maxd", "amin", "progress"])
+        if op == "ccs":
+            Tpre = small_pose(rng.choice([0.02, 0.2, 1.0, 6.0]))
+            a, b = rcc.computeCrossStatistics(Tpre, prog), ref.computeCrossStatistics(Tpre, prog)
+            assert int(a["n_meas"]) == int(b["n_meas"]), (step, int(a["n_meas"]), int(b["n_meas"]), rcc.ccs_info())
+            assert np.allclose(a["covariance"], b["covariance"], rtol=2e-5, atol=2e-6), (step, rcc.ccs_info())
+            for k in "xyz":
+                assert abs(float(a["model_mean"][k]) - float(b["model_mean"][k])) < 2e-5
+                assert abs(float(a["dataset_mean"][k]) - float(b["dataset_mean"][k])) < 2e-5
+            n_ccs += 1
+        elif op in ("find", "find_far"):
+            est = T.mult(truth, small_pose(1.0 if op == "find" else 8.0))
+            for r in (rcc, ref):
+                r.find(est)
+        elif op == "dataset":
+            ds = (ds + rng.normal(0, 0.004, 3).astype(np.float32)).astype(np.float32)
+            for r in (rcc, ref):
+                r.set_dataset(ds, mask)
+        elif op == "mask":
+            mask = (mask & (rng.rand(mask.size) > 0.05).astype(mask.dtype).reshape(mask.shape)).astype(mask.dtype)
+            for r in (rcc, ref):
+                r.set_dataset(ds, mask)
+        elif op == "maxd":
+            v = float(rng.choice([0.05, 0.3, 1.0, 2.5]))
+            for r in (rcc, ref):
+                r.params.max_dist = v
+        elif op == "amin":
+            v = float(rng.choice([0.02, 0.15, 0.5]))
+            for r in (rcc, ref):
+                r.adaptive_max_dist_min = v
+        else:
+            prog = float(rng.choice([0.0, 0.3, 0.5, 0.52, 0.9, 1.0]))
+    info = rcc.ccs_info()
+    assert info["calls"] == n_ccs and n_ccs > 10
+    assert info["from_moments"] > 0, info          # the fuzz does exercise the moment path
+    assert ref.ccs_info()["from_moments"] == 0
+    rcc.close()
+    ref.close()
