@@ -143,11 +143,12 @@ struct rmclhip_map {
   uint32_t* d_tris = nullptr;
   uint64_t bytes = 0;
   // near grid of the closest-point queries (kernels.h NearGrid): built on the first rmclhip_rcc_find_cpc of any operator of this map
+  // near grids (ensure_near_grid): slot 0 = cells near the surface only (scan points), slot 1 = every cell (the filter's beam ends).
+  // A slot is built once under the mutex and never changes or moves afterwards -- other operators' launches may be reading it --
+  // and both live until the map is released.
   std::mutex grid_mtx;
-  bool grid_ready = false, grid_failed = false, grid_full = false;
-  uint64_t grid_bytes = 0;
-  uint32_t* d_near_grid = nullptr;
-  NearGrid grid = {};
+  struct GridSlot { bool ready = false, failed = false; NearGrid g = {}; };
+  GridSlot grid_slot[2];
   std::vector<uint32_t> scene_first_face;  // map_create_scene: first global face id of every instance, + the total (else empty)
 };
 
@@ -535,7 +536,8 @@ void rmclhip_map_release(rmclhip_map* map) {
     if (map->d_frontier_pf) (void)hipFree(map->d_frontier_pf);
     if (map->d_cnodes) (void)hipFree(map->d_cnodes);
     if (map->d_tris) (void)hipFree(map->d_tris);
-    if (map->d_near_grid) (void)hipFree(map->d_near_grid);
+    for (auto& gs : map->grid_slot)
+      if (gs.g.cells) (void)hipFree(const_cast<uint32_t*>(gs.g.cells));
     ctx_release(map->ctx);
     delete map;
   }
@@ -1227,14 +1229,13 @@ static float cpc_bound_d2(const rmclhip_rcc* r) {
 // be used from different threads.
 // `full`: every cell gets a record (the particle filter's closest-point mode queries beam END points, metres from any surface);
 // otherwise cells farther than two coarse cell diagonals from the surface get none (scan points lie near it) -- the cheap build.
-static rmclhip_status ensure_near_grid(rmclhip_map* m, hipStream_t stream, bool full) {
+static rmclhip_status ensure_near_grid(rmclhip_map* m, hipStream_t stream, bool full, const NearGrid** out) {
+  *out = nullptr;
   std::lock_guard<std::mutex> lock(m->grid_mtx);
-  if (m->grid_failed || (m->grid_ready && (m->grid_full || !full))) return RMCLHIP_OK;
-  if (m->grid_ready) {   // upgrade a near-surface grid to a full one: rebuilt
-    m->grid_ready = false;
-    (void)hipFree(m->d_near_grid); m->d_near_grid = nullptr;
-    m->bytes -= m->grid_bytes; m->grid_bytes = 0;
-  }
+  if (m->grid_slot[1].ready) { *out = &m->grid_slot[1].g; return RMCLHIP_OK; }   // the full grid serves every caller
+  rmclhip_map::GridSlot& slot = m->grid_slot[full ? 1 : 0];
+  if (slot.ready) { *out = &slot.g; return RMCLHIP_OK; }
+  if (slot.failed) return RMCLHIP_OK;
   float ext[3];
   double vol = 1.0;
   for (int k = 0; k < 3; ++k) {
@@ -1242,7 +1243,7 @@ static rmclhip_status ensure_near_grid(rmclhip_map* m, hipStream_t stream, bool 
     ext[k] *= 1.02f;   // a thin margin: points of a scan lie ON the surface, i.e. on the box's faces
     vol *= ext[k];
   }
-  if (!(vol > 0.0) || !std::isfinite(vol)) { m->grid_failed = true; return RMCLHIP_OK; }
+  if (!(vol > 0.0) || !std::isfinite(vol)) { slot.failed = true; return RMCLHIP_OK; }
   const float cell = static_cast<float>(std::cbrt(vol / 2.0e6));
   NearGrid g = {};
   size_t total = 1;
@@ -1252,11 +1253,12 @@ static rmclhip_status ensure_near_grid(rmclhip_map* m, hipStream_t stream, bool 
     g.inv[k] = static_cast<float>(g.n[k]) / ext[k];
     total *= g.n[k];
   }
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->d_near_grid), total * sizeof(uint32_t));
-  if (e != hipSuccess) { m->d_near_grid = nullptr; m->grid_failed = true; (void)hipGetLastError(); return RMCLHIP_OK; }   // (a map too large for the table simply runs without it)
+  uint32_t* d_cells = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_cells), total * sizeof(uint32_t));
+  if (e != hipSuccess) { slot.failed = true; (void)hipGetLastError(); return RMCLHIP_OK; }   // (a map too large for the table simply runs without it)
   // coarse to fine: a grid of a quarter of the resolution first (its cells far from any surface are the expensive, unbounded queries:
   // 64 x fewer of them), then the full grid with every cell seeded from its coarse parent
-  // (cells farther than two coarse cell diagonals from the surface get no record: a query point there runs unseeded, as before)
+  // (slot 0: cells farther than two coarse cell diagonals from the surface get no record: a query point there runs unseeded, as before)
   const float cdiag = 4.0f * cell * 1.7320508f;
   const float skip_d2 = full ? 3.0e38f : (2.0f * cdiag) * (2.0f * cdiag);
   NearGrid c = g;
@@ -1270,19 +1272,19 @@ static rmclhip_status ensure_near_grid(rmclhip_map* m, hipStream_t stream, bool 
   c.cells = d_coarse;
   if (e == hipSuccess)
     e = launch_cpc_find(m->d_nodes, m->d_tris, nullptr, static_cast<uint32_t>(total), 0.f, xidentity(), xidentity(), nullptr, nullptr, nullptr, nullptr,
-                        nullptr, false, stream, nullptr, m->d_near_grid, m->info.n_faces, 3.0e38f, &c, &g, skip_d2);
+                        nullptr, false, stream, nullptr, d_cells, m->info.n_faces, 3.0e38f, &c, &g, skip_d2);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   if (d_coarse) (void)hipFree(d_coarse);
   if (e != hipSuccess) {
-    (void)hipFree(m->d_near_grid); m->d_near_grid = nullptr; m->grid_failed = true;
+    (void)hipFree(d_cells);
+    slot.failed = true;
     return fail(RMCLHIP_ERR_HIP, std::string("near grid: ") + hipGetErrorString(e));
   }
-  g.cells = m->d_near_grid;
-  m->grid = g;
-  m->grid_bytes = total * sizeof(uint32_t);
-  m->bytes += m->grid_bytes;
-  m->grid_full = full;
-  m->grid_ready = true;
+  g.cells = d_cells;
+  slot.g = g;
+  slot.ready = true;
+  m->bytes += total * sizeof(uint32_t);
+  *out = &slot.g;
   return RMCLHIP_OK;
 }
 
@@ -1306,8 +1308,8 @@ rmclhip_status rmclhip_rcc_find_cpc(rmclhip_rcc* r, const rmclhip_transform* Tbm
     if (r->d_cpc_rec.p != r->cpc_rec_ptr) { r->cpc_rec_ptr = r->d_cpc_rec.p; r->cpc_rec_n = 0; }   // (re)allocated
     if (r->cpc_rec_n == r->n_dataset && r->cpc_rec_pts == r->ds_pts) seed = r->d_cpc_rec.p;
   }
-  if (r->cpc_grid) { if (rmclhip_status gst = ensure_near_grid(r->map, r->stream, false)) return gst; }
-  const NearGrid* grid = (r->cpc_grid && r->map->grid_ready) ? &r->map->grid : nullptr;
+  const NearGrid* grid = nullptr;
+  if (r->cpc_grid) { if (rmclhip_status gst = ensure_near_grid(r->map, r->stream, false, &grid)) return gst; }
   HIPCHK(launch_cpc_find(quad ? r->map->d_cnodes : r->map->d_nodes, r->map->d_tris, r->ds_pts, r->n_dataset,
                          r->max_dist, Tsm, xinv(Tsm), r->d_hits.p, r->d_ranges.p, r->d_points.p, r->d_normals.p,
                          r->d_face_ids.p, quad, r->stream, seed, r->cpc_tracking ? r->d_cpc_rec.p : nullptr, r->map->info.n_faces,
@@ -3047,10 +3049,11 @@ static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, 
   for (int k = 0; k < 3; ++k) { p.gn[k] = 1u; p.gorg[k] = 0.f; p.ginv[k] = 1.f; }
   if (f->params.correspondence_type == 1u && f->cpc_grid) {
     // closest-point errors: every query starts from the near grid's record of its cell (the FULL grid: beam end points are anywhere)
-    if (rmclhip_status gst = ensure_near_grid(f->map, f->stream, true)) return gst;
-    if (f->map->grid_ready) {
-      p.near_grid = f->map->grid.cells;
-      for (int k = 0; k < 3; ++k) { p.gn[k] = f->map->grid.n[k]; p.gorg[k] = f->map->grid.org[k]; p.ginv[k] = f->map->grid.inv[k]; }
+    const NearGrid* grid = nullptr;
+    if (rmclhip_status gst = ensure_near_grid(f->map, f->stream, true, &grid)) return gst;
+    if (grid) {
+      p.near_grid = grid->cells;
+      for (int k = 0; k < 3; ++k) { p.gn[k] = grid->n[k]; p.gorg[k] = grid->org[k]; p.ginv[k] = grid->inv[k]; }
     }
   }
   if (f->mapping == 1) {
@@ -3455,6 +3458,8 @@ struct RcclApi {
 static RcclApi g_rccl;
 
 static bool rccl_load(std::string& err) {
+  static std::mutex mtx;   // two threads may create their first communicator at the same time
+  std::lock_guard<std::mutex> lock(mtx);
   if (g_rccl.lib) return true;
   void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
   if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
@@ -3491,16 +3496,19 @@ struct rmclhip_comm {
 
 // debug trace of the sharded entry points (rmclhip_debug_trace): "E<r>" = rank r's work of a phase enqueued, "W<r>" = the host waited
 // for rank r.  A phase that scales reads E0 E1 ... W0 W1 ...; E0 W0 E1 W1 serialises the devices.
-static bool g_trace_on = false;
+static std::atomic<bool> g_trace_on{false};
+static std::mutex g_trace_mtx;
 static std::string g_trace;
 static inline void trace(char what, uint32_t rank) {
-  if (!g_trace_on) return;
+  if (!g_trace_on.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lock(g_trace_mtx);
   g_trace += what;
   g_trace += std::to_string(rank);
   g_trace += ' ';
 }
 static inline void trace_mark(const char* label) {
-  if (!g_trace_on) return;
+  if (!g_trace_on.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lock(g_trace_mtx);
   g_trace += label;
   g_trace += ' ';
 }
@@ -3696,6 +3704,7 @@ static rmclhip_status comm_wait_all(rmclhip_comm* c) {
 
 rmclhip_status rmclhip_debug_trace(int on, char* buf, size_t cap) {
   // on = 1: start (clears), on = 0: stop; buf (nullable) receives what was recorded so far
+  std::lock_guard<std::mutex> lock(g_trace_mtx);
   if (buf && cap) {
     const size_t n = std::min(cap - 1, g_trace.size());
     std::memcpy(buf, g_trace.data(), n);

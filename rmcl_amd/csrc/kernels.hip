@@ -2672,21 +2672,25 @@ hipError_t launch_pf_update(const PfParams& p, int variant, hipStream_t s) {
   if (cpc) {
     // closest-point correspondences (evaluate_cpc): rounds of one beam per lane on the full nodes
     const size_t lds = 16u * 256u * sizeof(uint32_t) + tail;
+    if (lds > 160u * 1024u - 64u) return hipErrorInvalidValue;
+    if (lds > 65536u) {
+      const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pf_update<64, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                160 * 1024 - 64);
+      if (ae != hipSuccess) return ae;
+    }
     hipLaunchKernelGGL((k_pf_update<64, 3>), dim3(nblocks), dim3(256), lds, s, p);
     return hipGetLastError();
   }
   if (trav == 0 && refill != 0 && !legacy && ((variant >> 7) & 1) == 0 && p.qnodes != nullptr) {
     const size_t lds = static_cast<size_t>(kPfRows) * 256u * sizeof(uint32_t) + tail + sizeof(uint32_t) * p.particles_per_block;
+    if (lds > 160u * 1024u - 64u) return hipErrorInvalidValue;   // more beams per particle than one workgroup's LDS holds
     if (lds > 65536u) {   // (particle-minor blocks of 64 particles x 256 beams keep 64 KB of beam errors)
-      static bool raised[2] = {false, false};
-      if (!raised[leaf2 ? 1 : 0]) {
-        const hipError_t ae = leaf2 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pf_update_v3<kPfRows, true>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)
-                                    : hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pf_update_v3<kPfRows, false>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-        if (ae != hipSuccess) return ae;
-        raised[leaf2 ? 1 : 0] = true;
-      }
+      // per launch, not once per process: the attribute belongs to the function ON THE CURRENT DEVICE (sharded filters launch on several)
+      const hipError_t ae = leaf2 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pf_update_v3<kPfRows, true>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)
+                                  : hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pf_update_v3<kPfRows, false>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+      if (ae != hipSuccess) return ae;
     }
     if (leaf2) hipLaunchKernelGGL((k_pf_update_v3<kPfRows, true>), dim3(nblocks), dim3(256), lds, s, p);
     else hipLaunchKernelGGL((k_pf_update_v3<kPfRows, false>), dim3(nblocks), dim3(256), lds, s, p);
