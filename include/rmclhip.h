@@ -643,8 +643,8 @@ rmclhip_status rmclhip_pf_allreduce_stats(rmclhip_pf_sharded* pf, rmclhip_likeli
  * Markley mean, 6x6 covariance around it), each followed by one ncclAllReduce */
 rmclhip_status rmclhip_pf_allreduce_pose_estimate(rmclhip_pf_sharded* pf, uint32_t n_induction, rmclhip_pose_estimate* out);
 /* distributed GladiatorResamplerGPU::update: all-gather of the 68-B particle records, then every device resamples its own
- * champions against the gathered cloud (Philox counter = GLOBAL champion index => identical to one GPU).  n_total must
- * be a multiple of the device count. */
+ * champions against the gathered cloud (Philox counter = GLOBAL champion index => identical to one GPU).  A particle count
+ * that is not a multiple of the device count gathers padded shards and squeezes them dense on every device first. */
 rmclhip_status rmclhip_pf_sharded_resample(rmclhip_pf_sharded* pf, const rmclhip_gladiator_config* config, uint64_t seed, uint32_t step);
 /* the same exchange with the residual resampler (rmclhip_resampler_residual): every device fills its slots of the new cloud from the
  * gathered one -- identical to one GPU (draws and Gaussians are functions of global indices) */

@@ -3539,6 +3539,8 @@ struct PfRank {
   xform* d_poses = nullptr; void* d_attrs = nullptr;          // this rank's shard (cap particles)
   xform* d_poses_new = nullptr; void* d_attrs_new = nullptr;  // tournament output
   xform* d_poses_all = nullptr; void* d_attrs_all = nullptr;  // gathered cloud (world * cap), distributed tournament
+  void* d_poses_pad = nullptr; void* d_attrs_pad = nullptr;   // ragged partitions only: the padded all-gather lands here, *_all is its dense form
+  uint32_t pad_cap = 0;                                        // capacity (records per rank) the pad buffers were sized for
   float* d_w_send = nullptr;   // cap
   float* d_w_pad = nullptr;    // world * cap (all-gather layout)
   float* d_w_all = nullptr;    // n_total, dense
@@ -3720,7 +3722,7 @@ void rmclhip_pf_sharded_destroy(rmclhip_pf_sharded* h) {
   for (PfRank& R : h->ranks) {
     if (R.ctx) (void)hipSetDevice(R.ctx->device);
     void* bufs[] = {R.d_poses, R.d_attrs, R.d_poses_new, R.d_attrs_new, R.d_poses_all, R.d_attrs_all, R.d_w_send, R.d_w_pad,
-                    R.d_w_all, R.d_mom_part, R.d_mom};
+                    R.d_w_all, R.d_mom_part, R.d_mom, R.d_poses_pad, R.d_attrs_pad};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (R.h_mom) (void)hipHostFree(R.h_mom);
     if (R.rs) rmclhip_resampler_destroy(R.rs);
@@ -4008,10 +4010,26 @@ static rmclhip_status pf_sharded_resample_impl(rmclhip_pf_sharded* h, const rmcl
   if (!h || !cfg) return fail(RMCLHIP_ERR_INVALID, "pf_sharded_resample: null");
   if (h->n_total == 0) return RMCLHIP_OK;
   const uint32_t world = static_cast<uint32_t>(h->ranks.size()), cap = (h->n_total + world - 1u) / world;
-  const bool ragged = (h->n_total % world) != 0u;
-  if (ragged && world > 1)
-    return fail(RMCLHIP_ERR_UNSUPPORTED, "pf_sharded_resample: n_total must be a multiple of the number of devices (padded shards "
-                                         "would shift the global particle indices of the gathered cloud)");
+  // a ragged partition (n_total not a multiple of the number of devices): the all-gather needs equal counts, so the padded shards
+  // land in a second buffer and one kernel per record type squeezes the padding out (68 B x N read + written once more per rank)
+  const bool ragged = (h->n_total % world) != 0u && world > 1u;
+  if (ragged) {
+    for (PfRank& R : h->ranks) {
+      if (R.d_poses_pad && R.pad_cap >= cap) continue;
+      HIPCHK(hipSetDevice(R.ctx->device));
+      if (R.d_poses_pad) { (void)hipFree(R.d_poses_pad); R.d_poses_pad = nullptr; }
+      if (R.d_attrs_pad) { (void)hipFree(R.d_attrs_pad); R.d_attrs_pad = nullptr; }
+      R.pad_cap = 0;
+      const size_t c = static_cast<size_t>(std::max(cap, h->cap)) * world;
+      hipError_t ae = hipMalloc(&R.d_poses_pad, c * 32);
+      if (ae == hipSuccess) ae = hipMalloc(&R.d_attrs_pad, c * 36);
+      if (ae != hipSuccess) {
+        if (R.d_poses_pad) { (void)hipFree(R.d_poses_pad); R.d_poses_pad = nullptr; }
+        return fail(ae == hipErrorOutOfMemory ? RMCLHIP_ERR_NOMEM : RMCLHIP_ERR_HIP, std::string("pf_sharded_resample: ") + hipGetErrorString(ae));
+      }
+      R.pad_cap = std::max(cap, h->cap);
+    }
+  }
   // (1) the cloud (68 B per particle) is all-gathered on every rank's collective stream; (2) BEHIND it, on the same stream, every
   // rank's tournament / slot fill over its own champions -- enqueued for ALL ranks before the host waits for any (round 3 ran the N
   // tournaments one after the other, each with its own launch + wait).  The tournament reads one enemy per champion; gathering the
@@ -4023,10 +4041,19 @@ static rmclhip_status pf_sharded_resample_impl(rmclhip_pf_sharded* h, const rmcl
   std::vector<void*> rp(world), ra_(world);
   for (uint32_t r = 0; r < world; ++r) {
     PfRank& R = h->ranks[r];
-    sp[r] = R.d_poses; rp[r] = R.d_poses_all; sa[r] = R.d_attrs; ra_[r] = R.d_attrs_all;
+    sp[r] = R.d_poses; rp[r] = ragged ? R.d_poses_pad : static_cast<void*>(R.d_poses_all);
+    sa[r] = R.d_attrs; ra_[r] = ragged ? R.d_attrs_pad : R.d_attrs_all;
   }
   if (rmclhip_status st = comm_allgather(h->comm, sp.data(), rp.data(), static_cast<size_t>(cap) * 32)) return st;
   if (rmclhip_status st = comm_allgather(h->comm, sa.data(), ra_.data(), static_cast<size_t>(cap) * 36)) return st;
+  if (ragged) {
+    for (uint32_t r = 0; r < world; ++r) {
+      PfRank& R = h->ranks[r];
+      HIPCHK(hipSetDevice(R.ctx->device));
+      HIPCHK(launch_compact_records(R.d_poses_pad, R.d_poses_all, h->n_total, world, cap, 32u, h->comm->streams[r]));
+      HIPCHK(launch_compact_records(R.d_attrs_pad, R.d_attrs_all, h->n_total, world, cap, 36u, h->comm->streams[r]));
+    }
+  }
   if (!residual) {
     for (uint32_t r = 0; r < world; ++r) {
       PfRank& R = h->ranks[r];

@@ -336,5 +336,8 @@ hipError_t launch_pose_moments(const xform* poses, const void* attrs, uint32_t n
                                double* partials, double* out32, hipStream_t s);
 hipError_t launch_loopback_allreduce(const double* const* send, uint32_t world, double* recv, uint32_t count, bool is_max, hipStream_t s);
 hipError_t launch_compact_shards(const float* padded, float* dense, uint32_t n_total, uint32_t world, uint32_t cap, hipStream_t s);
+// the same for records of record_bytes (a multiple of 4): the padded all-gather layout of a ragged partition -> the dense cloud
+hipError_t launch_compact_records(const void* padded, void* dense, uint32_t n_total, uint32_t world, uint32_t cap, uint32_t record_bytes,
+                                  hipStream_t s);
 
 }  // namespace rmclhip

@@ -2117,6 +2117,19 @@ __global__ void k_compact_shards(const float* __restrict__ padded, float* __rest
   dense[i] = padded[static_cast<size_t>(r) * cap + (i - lo)];
 }
 
+// the same for records of `wpr` dwords (poses: 8, attributes: 9): one thread per dword
+__global__ void k_compact_records(const uint32_t* __restrict__ padded, uint32_t* __restrict__ dense, uint32_t n_total, uint32_t world, uint32_t cap,
+                                  uint32_t wpr) {
+  const size_t g = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= static_cast<size_t>(n_total) * wpr) return;
+  const uint32_t i = static_cast<uint32_t>(g / wpr), w = static_cast<uint32_t>(g - static_cast<size_t>(i) * wpr);
+  const uint32_t base = n_total / world, rem = n_total % world;
+  const uint32_t split = rem * (base + 1u);
+  const uint32_t r = (i < split) ? (i / (base + 1u)) : (rem + (i - split) / max(base, 1u));
+  const uint32_t lo = r * base + min(r, rem);
+  dense[g] = padded[(static_cast<size_t>(r) * cap + (i - lo)) * wpr + w];
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -2825,6 +2838,17 @@ hipError_t launch_loopback_allreduce(const double* const* send, uint32_t world, 
 hipError_t launch_compact_shards(const float* padded, float* dense, uint32_t n_total, uint32_t world, uint32_t cap, hipStream_t s) {
   if (n_total == 0) return hipSuccess;
   hipLaunchKernelGGL(k_compact_shards, dim3((n_total + 255u) / 256u), dim3(256), 0, s, padded, dense, n_total, world, cap);
+  return hipGetLastError();
+}
+
+hipError_t launch_compact_records(const void* padded, void* dense, uint32_t n_total, uint32_t world, uint32_t cap, uint32_t record_bytes,
+                                  hipStream_t s) {
+  if (n_total == 0) return hipSuccess;
+  if (record_bytes % 4u != 0u) return hipErrorInvalidValue;
+  const uint32_t wpr = record_bytes / 4u;
+  const size_t threads = static_cast<size_t>(n_total) * wpr;
+  hipLaunchKernelGGL(k_compact_records, dim3(static_cast<uint32_t>((threads + 255u) / 256u)), dim3(256), 0, s, static_cast<const uint32_t*>(padded),
+                     static_cast<uint32_t*>(dense), n_total, world, cap, wpr);
   return hipGetLastError();
 }
 

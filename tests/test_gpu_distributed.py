@@ -256,7 +256,8 @@ def test_c_abi_sharded_pose_batch_equals_unsharded(ra, orc, ctx, meshes, devices
 
 def test_loopback_ragged_three_ranks(ra, orc, ctx, meshes):
     """1001 particles over three loopback ranks on device 0 (334 + 334 + 333, padded shards in the gather): update + all-gather ==
-    unsharded update, {sum, max} and the pose estimate from the all-reduced moments == the one-rank results."""
+    unsharded update, {sum, max} and the pose estimate from the all-reduced moments == the one-rank results; gladiator and residual
+    resampling of the ragged partition == the one-rank cloud, particle for particle."""
     from rmcl_amd import synthetic as syn, types as T
     v, f = meshes("room30k")
     n = 1001
@@ -264,12 +265,26 @@ def test_loopback_ragged_three_ranks(ra, orc, ctx, meshes):
     beams = ra.beams_from_points(syn.model_directions(syn.model_pf16())[::8] * np.float32(4.0))
     Tsb = syn.tsb_offset()
     res = {}
+    clouds = {}
     for devices in ((0,), (0, 0, 0)):
         sh = ra.ShardedParticleFilterHip(v, f, devices=devices, loopback=True)
         sh.set_particles(poses, attrs)
         w = sh.update(beams, Tsb)
         res[len(devices)] = (w.copy(), sh.download()[1], sh.stats(), sh.pose_estimate(n))
+        # both resamplers on the ragged partition (round 4: the padded gather is squeezed dense before the tournament / the fill),
+        # twice each (the second call runs on the first one's output and on reused buffers), then another update on the new cloud
+        out = []
+        for residual in (False, True):
+            for step in (0, 1):
+                sh.resample(seed=7, step=step, residual=residual)
+                out.append(tuple(x.copy() for x in sh.download()))
+        w2 = sh.update(beams, Tsb)
+        out.append((w2.copy(),))
+        clouds[len(devices)] = out
         sh.close()
+    for a, b in zip(clouds[1], clouds[3]):
+        for x, y in zip(a, b):
+            assert x.tobytes() == y.tobytes()
     (w1, a1, s1, e1), (w3, a3, s3, e3) = res[1], res[3]
     assert np.array_equal(w1, w3) and a1.tobytes() == a3.tobytes()
     assert abs(s1["sum"] - s3["sum"]) <= 1e-6 * abs(s1["sum"]) and s1["max"] == s3["max"]
