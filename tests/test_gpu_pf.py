@@ -13,12 +13,13 @@ from conftest import assert_close_rel, golden_path, pf_variants
 pytestmark = pytest.mark.gpu
 
 
-def _run(ra, ctx, hm, poses, attrs, beams, Tsb, params=None, variant=0):
+def _run(ra, ctx, hm, poses, attrs, beams, Tsb, params=None, variant=None):
     upd = ra.PCDSensorUpdaterHip(hm)
     if params is not None:
         upd.config = params
     upd.init()
-    upd.set_variant(variant)
+    if variant is not None:    # (None: the product's default kernel; 0 would be the round kernel of the experiments library)
+        upd.set_variant(variant)
     upd.setInput(beams, Tsb)
     d_poses = ra.DeviceArray.from_host(ctx, poses)
     d_attrs = ra.DeviceArray.from_host(ctx, attrs)
