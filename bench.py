@@ -385,6 +385,9 @@ def main():
             extras["v1_bench_1000x16x900_ms"] = round(dt * 1e3, 4)
             extras["v1_bench_rays_per_s"] = round(1000 * 16 * 900 / dt, 1)
             extras["v1_bench_pose_corrections_per_s"] = round(1000 / dt, 1)
+            # the only figures the reference records for this shape (source comments, the authors' own machines, NOT this hardware):
+            extras["v1_bench_reference_source_comments"] = {"optix_gpu_100k_faces_pose_corrections_per_s": 73700, "embree_cpu_100k_faces_pose_corrections_per_s": 5464,
+                                                            "where": "rmcl_ros/src/benchmarks/lidar_corrector_{optix,embree}_benchmark.cpp:161 / :144 (BASELINE.md)"}
             # stage split in the reference benchmark's terms (lidar_corrector_embree_benchmark.cpp:185-190 records Sim 96.8 %,
             # Red 3.2 %, SVD 0.015 % on its CPU): sim = the batched find (HIP events), the rest = batched reduction + per-pose
             # solve + result download (one launch each, host clock)
