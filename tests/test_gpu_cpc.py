@@ -218,3 +218,60 @@ def test_bounded_search_keeps_every_hit_bit_for_bit(ra, orc, ctx, meshes):
                         assert nf.sum() > 0.5 * out.sum() > 0       # the bound really cut the search
                 ref.close()
                 bnd.close()
+
+
+def test_operators_of_one_map_from_several_threads(ra, orc, ctx, meshes):
+    """include/rmclhip.h: a handle is thread-compatible, operators of ONE map may be used from different threads at the same time.
+    Six threads, each with its own ray-casting operator, closest-point operator and particle-filter updater (closest-point mode) on
+    a shared map whose near grids do not exist yet -- so the first queries of several threads race for the grid build (slot 0 for
+    the scan points, slot 1 for the filter) -- must each reproduce what the same calls give one after the other."""
+    import threading
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room30k")
+    model = syn.model_c1()
+    truth = T.transform_from_rpy((1.0, -1.5, 1.2), (0.01, -0.02, 0.5))
+    beams = ra.beams_from_points(syn.model_directions(syn.model_pf16())[::16] * np.float32(3.0))
+    poses, attrs = syn.uniform_particles(200, seed=5, bb_min=(-8, -8, 0.3, 0, 0, -3.14), bb_max=(8, 8, 2.5, 0, 0, 3.14))
+
+    def work(hm, k, out):
+        est = T.mult(truth, T.transform_from_rpy((0.02 * k, -0.01 * k, 0.0), (0.0, 0.0, 0.01 * k)))
+        rcc = ra.RCCHipSpherical(hm); rcc.setTsb(T.identity()); rcc.setModel(model)
+        res = []
+        for _ in range(3):
+            rcc.find(est)
+            mv = rcc.modelView()
+            cpc = ra.CPCHip(hm); cpc.setTsb(T.identity()); cpc.params.max_dist = 1.0
+            cpc.set_dataset(mv["points"].reshape(-1, 3), mv["hits"].reshape(-1))
+            cpc.find(T.mult(est, T.transform_from_rpy((0.05, 0.0, 0.0), (0.0, 0.0, 0.02))))
+            cv = cpc.modelView()
+            upd = ra.PCDSensorUpdaterHip(hm)
+            upd.config = T.pf_params(correspondence_type=1)
+            upd.init(); upd.setInput(beams, T.identity())
+            d_p, d_a = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
+            upd.update(d_p, d_a)
+            res.append((mv["face_ids"].tobytes(), mv["ranges"].tobytes(), cv["face_ids"].tobytes(), cv["points"].tobytes(), d_a.download().tobytes()))
+            upd.close(); cpc.close()
+        rcc.close()
+        out[k] = res
+
+    serial, threaded = {}, {}
+    hm1 = ra.import_hip_map(ctx, v, f)
+    for k in range(6):
+        work(hm1, k, serial)
+    hm2 = ra.import_hip_map(ctx, v, f)      # a fresh map: no grid yet
+    errs = []
+
+    def guarded(k):
+        try:
+            work(hm2, k, threaded)
+        except Exception as e:   # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    ts = [threading.Thread(target=guarded, args=(k,)) for k in range(6)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for k in range(6):
+        assert threaded[k] == serial[k], k
