@@ -556,6 +556,8 @@ rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* pf, int variant);
  * MEASURED NEUTRAL (round 4, profiles/r04_pf_converged_mapping.txt): on a converged cloud (sigma 0.25 m / 5 deg) mapping 1 with 16
  * slots per workgroup and the Morton order is 3 % faster than mapping 0, with larger workgroups slower -- the kernel is bound by
  * VALU issue, and coherent lanes save cache lines, not instructions.  Kept as an option; nothing selects it automatically.
+ * Bit 9 of `mapping` (A/B): a workgroup's beam errors wait in LDS (rounds 3) instead of the updater's global scratch (round 4: 16 KB
+ * less LDS per workgroup, 3-5 % faster, identical results; profiles/r04_pf_occupancy.txt).
  * Bit 8 of `mapping` (A/B): correspondence_type 1 (closest-point errors) WITHOUT the near-grid seed its queries start from by
  * default (room-100k: 11.7 ms seeded vs 29.7 ms; identical results). */
 rmclhip_status rmclhip_pf_set_mapping(rmclhip_pf* pf, int mapping, uint32_t particles_per_block, const uint32_t* order_dev,

@@ -305,6 +305,8 @@ struct rmclhip_pf {
   uint32_t refill_thr = 0, tail_lanes = 8;  // schedule knobs of the round-3 kernel (0: from `refill`); rmclhip_pf_set_schedule
   // rmclhip_pf_set_mapping: 0 beam-minor blocks of ~2048 rays (uniform clouds), 1 particle-minor blocks (converged clouds), 2 automatic
   bool cpc_grid = true;            // correspondence_type 1: seed every closest-point query from the map's near grid (A/B: rmclhip_pf_set_mapping bit 8 clears it)
+  bool evals_global = true;        // k_pf_update_v3 keeps a workgroup's beam errors in global scratch, not LDS (A/B: rmclhip_pf_set_mapping bit 9 clears it)
+  DevBuf<float> d_evals;           // [n_particles * n_beams], grow-only
   int mapping = 0;
   uint32_t map_ppb = 0;            // particles per workgroup of the particle-minor mapping (0: 32)
   const uint32_t* order = nullptr; // slot -> particle (device), borrowed or d_order
@@ -2965,7 +2967,7 @@ void rmclhip_pf_destroy(rmclhip_pf* f) {
   if (!f) return;
   (void)hipSetDevice(f->ctx->device);
   if (f->stream) (void)hipStreamSynchronize(f->stream);
-  f->d_beams.release();
+  f->d_beams.release(); f->d_evals.release(); f->d_order.release();
   if (f->h_beams) (void)hipHostFree(f->h_beams);
   if (f->ev0) (void)hipEventDestroy(f->ev0);
   if (f->ev1) (void)hipEventDestroy(f->ev1);
@@ -3065,6 +3067,13 @@ static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, 
   }
   if (static_cast<size_t>(pb) * n_beams > (p.particle_minor ? 24576u : 8192u)) return fail(RMCLHIP_ERR_UNSUPPORTED, "pf_update: more than 8192 beams");
   p.particles_per_block = pb;
+  p.evals = nullptr;
+  if (f->evals_global && f->params.correspondence_type != 1u) {
+    // (the blocks of the last, partial workgroup included: slots are addressed from the workgroup's first particle)
+    const size_t slots = (static_cast<size_t>(n) + pb - 1u) / pb * pb;
+    HIPCHK(f->d_evals.reserve(slots * n_beams));
+    p.evals = f->d_evals.p;
+  }
   p.beams_at_origin = f->beams_at_origin ? 1u : 0u;
   static const uint32_t kRefillAt[5] = {48u, 8u, 16u, 32u, 48u};
   p.refill_thr = f->refill_thr ? f->refill_thr : kRefillAt[f->refill];
@@ -3161,8 +3170,9 @@ rmclhip_status rmclhip_pf_set_schedule(rmclhip_pf* f, uint32_t refill_idle_lanes
 
 rmclhip_status rmclhip_pf_set_mapping(rmclhip_pf* f, int mapping, uint32_t particles_per_block, const uint32_t* order_dev, uint32_t n_order) {
   ApiGuard guard_("rmclhip_pf_set_mapping");
-  if (!f || mapping < 0 || (mapping & 0xFF) > 1 || (mapping >> 9) != 0 || particles_per_block > 64u) return fail(RMCLHIP_ERR_INVALID, "pf_set_mapping: bad arguments");
+  if (!f || mapping < 0 || (mapping & 0xFF) > 1 || (mapping >> 10) != 0 || particles_per_block > 64u) return fail(RMCLHIP_ERR_INVALID, "pf_set_mapping: bad arguments");
   f->cpc_grid = ((mapping >> 8) & 1) == 0;   // bit 8 (A/B): closest-point errors WITHOUT the near-grid seed
+  f->evals_global = ((mapping >> 9) & 1) == 0;   // bit 9 (A/B): beam errors in LDS (rounds 3) instead of global scratch
   mapping &= 0xFF;
   f->mapping = mapping;
   f->map_ppb = particles_per_block;

@@ -126,6 +126,10 @@ struct PfParams {
   uint32_t gn[3];
   float gorg[3], ginv[3];
   uint32_t n_tris;
+  // k_pf_update_v3: the beam errors of a workgroup wait for the dense pass in GLOBAL scratch ([n_particles * n_beams] floats, written
+  // and read back by the same workgroup: L2) instead of LDS -- 16 KB less LDS per workgroup, 7 instead of 4 workgroups per CU
+  // (profiles/r04_pf_occupancy.txt).  null: the LDS form of rounds 3.
+  float* evals;
 };
 
 // per-call inputs of the device-resident MICP loop: written by ONE H2D copy so that the whole loop can be a

@@ -1502,11 +1502,13 @@ __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
   uint32_t* lds_col = lds_dyn + threadIdx.x;   // stack rows of this lane: row r at lds_col[r * 256], row 0 = sentinel
   xform* s_Tsm = reinterpret_cast<xform*>(lds_dyn + kRows * 256);
   uint32_t* s_n0 = reinterpret_cast<uint32_t*>(s_Tsm + p.particles_per_block);
-  float* s_eval = reinterpret_cast<float*>(s_n0 + p.particles_per_block);
 
   const uint32_t PB = p.particles_per_block;
   const uint32_t p0 = blockIdx.x * PB;
   if (p0 >= p.n_particles) return;
+  // the workgroup's beam errors: LDS behind n0 (rounds 3), or its slice of the global scratch (round 4: see PfParams::evals)
+  const bool evals_global = p.evals != nullptr;
+  float* s_eval = evals_global ? (p.evals + static_cast<size_t>(p0) * p.n_beams) : reinterpret_cast<float*>(s_n0 + p.particles_per_block);
   const uint32_t np = min(PB, p.n_particles - p0);
   pattrs* attrs = reinterpret_cast<pattrs*>(p.attrs);
   // slot j of the block = particle `mine` (identity, or the caller's spatial order)
@@ -1635,8 +1637,12 @@ __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
 #undef RMCL_ROW_LD
   __syncthreads();  // every beam of the block has its error in s_eval; the stack rows are free from here on
 
-  // dense pass: error -> likelihood (PCDSensorUpdaterEmbree.cpp:224: float argument, double exp / sqrt, float result)
   const double den = sqrt(static_cast<double>(2 * sq) * 3.14159265358979323846);
+  float* s_w = reinterpret_cast<float*>(lds_dyn);
+  g1d L = {0.f, 0.f, 0u};
+  if (threadIdx.x < np) L = attrs[mine_p].likelihood;
+  if (!evals_global) {
+  // dense pass: error -> likelihood (PCDSensorUpdaterEmbree.cpp:224: float argument, double exp / sqrt, float result)
   for (uint32_t i = threadIdx.x; i < nrays; i += 256u) {
     const float error = s_eval[i];
     if (p.errors) {
@@ -1651,11 +1657,8 @@ __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
   // after every beam.  The count a particle carries INTO beam k is a_k = n0 (k = 0), n0 + min(k, max - n0) (n0 < max), max
   // (otherwise): both weights of rm::Gaussian1D::operator+= for every (particle, beam) come from all lanes, chunk by chunk,
   // into the stack rows; the chain of one lane per particle is then the multiply-adds of g1d_add in g1d_add's order.
-  float* s_w = reinterpret_cast<float*>(lds_dyn);
   const uint32_t chunk = min(p.n_beams, (static_cast<uint32_t>(kRows * 256) / np - 2u) / 2u);  // beams per chunk; np <= 64 => >= 39
   const uint32_t wstride = 2u * chunk + 2u;
-  g1d L = {0.f, 0.f, 0u};
-  if (threadIdx.x < np) L = attrs[mine_p].likelihood;
   for (uint32_t b0 = 0; b0 < p.n_beams; b0 += chunk) {
     const uint32_t nb = min(chunk, p.n_beams - b0);
     __syncthreads();
@@ -1682,6 +1685,47 @@ __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
         L.sigma = P1 + P2;
       }
     }
+  }
+  } else {
+  // The same two steps with the errors in global scratch: chunk by chunk, ALL lanes turn the chunk's errors into likelihoods
+  // (same operations, same result) and the two merge weights, three floats per (particle, beam) in the vacated stack rows
+  // [ w1 | w2 | likelihood ]; then one lane per particle runs the chain over the chunk from LDS as before.
+  const uint32_t chunk = min(p.n_beams, (static_cast<uint32_t>(kRows * 256) / np) / 3u);   // np <= 64, kRows >= 16 => >= 21
+  const uint32_t cstride = 3u * chunk;
+  for (uint32_t b0 = 0; b0 < p.n_beams; b0 += chunk) {
+    const uint32_t nb = min(chunk, p.n_beams - b0);
+    const uint32_t cells = np * nb;
+    const uint32_t nb_m = (nb == 1u) ? 0u : static_cast<uint32_t>(0x100000000ull / nb) + 1u;   // cell / nb (cells < 2^16 * 2^8)
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < cells; c += 256u) {
+      const uint32_t pi = (nb == 1u) ? c : __umulhi(c, nb_m), j = c - pi * nb, k = b0 + j;
+      const float error = s_eval[pi * p.n_beams + k];
+      if (p.errors) {
+        const uint32_t dst = p.order ? p.order[p0 + pi] : (p0 + pi);
+        p.errors[static_cast<size_t>(dst) * p.n_beams + k] = error;
+      }
+      const float arg = -(error * error) / sq / 2;
+      const uint32_t n0 = s_n0[pi];
+      const uint32_t a = (k == 0u) ? n0 : ((n0 < p.max_n_meas) ? n0 + min(k, p.max_n_meas - n0) : p.max_n_meas);
+      const uint32_t n = a + 1u;
+      float* cell = s_w + pi * cstride + 3u * j;
+      cell[0] = static_cast<float>(a) / static_cast<float>(n);
+      cell[1] = static_cast<float>(1u) / static_cast<float>(n);
+      cell[2] = static_cast<float>(exp(static_cast<double>(arg)) / den);
+    }
+    __syncthreads();
+    if (threadIdx.x < np) {
+      const float* w = s_w + threadIdx.x * cstride;
+      for (uint32_t j = 0; j < nb; ++j) {
+        const float w1 = w[3u * j], w2 = w[3u * j + 1u], e = w[3u * j + 2u];
+        const float mean = L.mean * w1 + e * w2;
+        const float P1 = L.sigma * w1 + 0.0f * w2;
+        const float P2 = ((L.mean - mean) * (L.mean - mean)) * w1 + ((e - mean) * (e - mean)) * w2;
+        L.mean = mean;
+        L.sigma = P1 + P2;
+      }
+    }
+  }
   }
   if (threadIdx.x < np) {
     const uint32_t n0 = s_n0[threadIdx.x], k = p.n_beams;
@@ -2729,8 +2773,8 @@ hipError_t launch_dataset_from_ranges(const float* ranges, const float* model_ta
 
 hipError_t launch_pf_update(const PfParams& p, int variant, hipStream_t s) {
   const uint32_t nblocks = (p.n_particles + p.particles_per_block - 1u) / p.particles_per_block;
-  const size_t tail = sizeof(xform) * p.particles_per_block +
-                      sizeof(float) * static_cast<size_t>(p.particles_per_block) * p.n_beams;
+  const size_t tail_fixed = sizeof(xform) * p.particles_per_block;
+  const size_t tail = tail_fixed + sizeof(float) * static_cast<size_t>(p.particles_per_block) * p.n_beams;
   const int trav = variant & 3;          // traversal of the round kernels (lab)
   const bool cpc = (variant & 8) != 0;   // correspondence_type 1
   const int refill = (variant >> 4) & 7;  // 0 = rounds of one ray per lane (lab); 1..4 = persistent lanes
@@ -2749,7 +2793,7 @@ hipError_t launch_pf_update(const PfParams& p, int variant, hipStream_t s) {
     return hipGetLastError();
   }
   if (trav == 0 && refill != 0 && !legacy && ((variant >> 7) & 1) == 0 && p.qnodes != nullptr) {
-    const size_t lds = static_cast<size_t>(kPfRows) * 256u * sizeof(uint32_t) + tail + sizeof(uint32_t) * p.particles_per_block;
+    const size_t lds = static_cast<size_t>(kPfRows) * 256u * sizeof(uint32_t) + (p.evals != nullptr ? tail_fixed : tail) + sizeof(uint32_t) * p.particles_per_block;
     if (lds > 160u * 1024u - 64u) return hipErrorInvalidValue;   // more beams per particle than one workgroup's LDS holds
     if (lds > 65536u) {   // (particle-minor blocks of 64 particles x 256 beams keep 64 KB of beam errors)
       // per launch, not once per process: the attribute belongs to the function ON THE CURRENT DEVICE (sharded filters launch on several)

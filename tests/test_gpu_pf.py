@@ -353,3 +353,39 @@ def test_particle_minor_mapping_and_slot_order_keep_the_result(ra, orc, ctx, mes
         m.pf_update(poses, a_ref, beams, Tsb, orc.pf_params(), bvh=True, nthreads=8)
         e_ref = m.pf_update(poses, a_ref, beams, Tsb, orc.pf_params(), bvh=True, nthreads=8, want_errors=True)
         _check(res[0][0], res[0][1].reshape(n, len(beams)), a_ref, e_ref, "mapping " + cloud)
+
+
+@pytest.mark.parametrize("n_beams", [1, 7, 64, 256, 700])
+def test_beam_errors_in_global_scratch_equal_the_lds_form(ra, orc, ctx, meshes, n_beams):
+    """round 4: a workgroup's beam errors wait for the likelihood pass in the updater's global scratch (default) instead of LDS
+    (rmclhip_pf_set_mapping bit 9 = round 3's form): attributes and the optional error output must be the same bytes, for beam
+    counts that are one chunk, several chunks and not a multiple of anything, with a partial last workgroup (1003 particles),
+    repeated updates on reused scratch, and against the oracle."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room30k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    n = 1003
+    poses, attrs = syn.uniform_particles(n, seed=31, bb_min=(-8, -8, 0.2, 0, 0, -math.pi), bb_max=(8, 8, 3, 0, 0, math.pi))
+    attrs["likelihood"]["n_meas"][::3] = 9990          # the clamp at max_n_meas is reached inside the beam loop
+    dirs = syn.model_directions(syn.model_c1()).reshape(-1, 3)
+    beams = ra.beams_from_points(dirs[np.linspace(0, len(dirs) - 1, n_beams).astype(int)] * np.float32(5.0))
+    out = {}
+    for bits in (1 << 9, 0):
+        upd = ra.PCDSensorUpdaterHip(hm)
+        upd.init()
+        upd.setInput(beams, syn.tsb_offset())
+        upd.set_mapping(bits, 0, None)
+        d_p, d_a = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
+        d_err = ra.DeviceArray(ctx, np.float32, n * n_beams)
+        upd.set_error_output(d_err)
+        upd.update(d_p, d_a)
+        upd.update(d_p, d_a)
+        out[bits] = (d_a.download(), d_err.download())
+        upd.close()
+    assert out[0][0].tobytes() == out[1 << 9][0].tobytes()
+    assert out[0][1].tobytes() == out[1 << 9][1].tobytes()
+    a_ref = attrs.copy()
+    for _ in range(2):
+        e_ref = m.pf_update(poses, a_ref, beams, syn.tsb_offset(), orc.pf_params(), bvh=True, nthreads=8, want_errors=True)
+    _check(out[0][0], out[0][1].reshape(n, n_beams), a_ref, e_ref, "global scratch, %d beams" % n_beams)
