@@ -576,8 +576,9 @@ def main():
 
     achieved = b_alg / (kernel_ms * 1e-3) / 1e9
     # `frac` is the contract's figure (algorithmic bytes / kernel time against the HBM peak).  It is NOT what bounds these kernels:
-    # measured HBM traffic is 0.44x (find) / 1.76x (particle filter) the algorithmic bytes at < 1 TB/s -- the map is served from
-    # L2 / MALL and the launch ends with its slowest wave's chain of dependent fetches (DESIGN.md "what bounds a scan")
+    # measured HBM traffic is 0.44x the algorithmic bytes for the find (the map is served from L2 / MALL; the launch ends with its
+    # slowest wave's chain of dependent fetches) and ~20x for the particle filter since round 4 -- deliberately: a workgroup's beam errors
+    # wait in global scratch instead of LDS (more workgroups per CU, 3-5 % faster), ~0.1 TB/s of otherwise idle bandwidth
     roofline = {"bound": "latency / issue (frac = the contract's HBM fraction)", "contract_bound": "hbm",
                 "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
