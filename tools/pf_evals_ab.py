@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """profiles/r04_pf_occupancy.txt: config C4's sensor update with a workgroup's beam errors in LDS (rounds 3: rmclhip_pf_set_mapping
 bit 9) and in global scratch (round 4 default: 16 KB less LDS, 7 instead of 4 workgroups per CU); results must be identical.
-usage: python tools/pf_evals_ab.py"""
+usage: python tools/pf_evals_ab.py [lds|global]"""
 import math
 import os
 import sys
@@ -25,7 +25,10 @@ for mesh, bb, centre in (("sphere100k", ((-5, -5, -1), (5, 5, 1)), T.transform_f
     for cname, (poses, attrs) in clouds.items():
         d_p = ra.DeviceArray.from_host(ctx, poses)
         ref = None
-        for label, bits in (("errors in LDS (round 3)", 1 << 9), ("errors in global scratch", 0)):
+        forms = (("errors in LDS (round 3)", 1 << 9), ("errors in global scratch", 0))
+        if len(sys.argv) > 1:      # `lds` / `global`: one form only (PMC passes: both forms are the same kernel name)
+            forms = tuple(x for x in forms if (x[1] != 0) == (sys.argv[1] == "lds"))
+        for label, bits in forms:
             upd = ra.PCDSensorUpdaterHip(hm)
             upd.init()
             upd.setInput(beams, T.identity())
