@@ -3071,8 +3071,10 @@ static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, 
   if (f->evals_global && f->params.correspondence_type != 1u) {
     // (the blocks of the last, partial workgroup included: slots are addressed from the workgroup's first particle)
     const size_t slots = (static_cast<size_t>(n) + pb - 1u) / pb * pb;
-    HIPCHK(f->d_evals.reserve(slots * n_beams));
-    p.evals = f->d_evals.p;
+    const hipError_t re = f->d_evals.reserve(slots * n_beams);
+    if (re == hipSuccess) p.evals = f->d_evals.p;
+    else if (re == hipErrorOutOfMemory) (void)hipGetLastError();   // no room for the scratch: the LDS form of rounds 3, same results
+    else HIPCHK(re);
   }
   p.beams_at_origin = f->beams_at_origin ? 1u : 0u;
   static const uint32_t kRefillAt[5] = {48u, 8u, 16u, 32u, 48u};
