@@ -119,8 +119,8 @@ def _enqueues_precede_waits(tokens, world):
     return ok and seen_block
 
 
-@pytest.mark.parametrize("devices,loopback", [((0,), False), ((0,), True), ((0, 0), True), ((0, 0, 0, 0), True)],
-                         ids=["rccl-1", "loopback-1", "loopback-2", "loopback-4"])
+@pytest.mark.parametrize("devices,loopback", [((0,), False), ((0,), True), ((0, 0), True), ((0, 0, 0, 0), True), ((0,) * 8, True)],
+                         ids=["rccl-1", "loopback-1", "loopback-2", "loopback-4", "loopback-8"])
 def test_c_abi_sharded_particle_filter_on_one_device(ra, orc, ctx, meshes, devices, loopback):
     """(round 4: also with the in-process LOOPBACK communicator at 2 and 4 ranks on device 0 -- rmclhip_comm_create_loopback -- so that
     the ndev > 1 branches of every sharded entry point execute on this box and are held to the same results; the recorded call
