@@ -385,6 +385,15 @@ def main():
             extras["v1_bench_1000x16x900_ms"] = round(dt * 1e3, 4)
             extras["v1_bench_rays_per_s"] = round(1000 * 16 * 900 / dt, 1)
             extras["v1_bench_pose_corrections_per_s"] = round(1000 / dt, 1)
+            extras["v1_bench_poses"] = "1000 DIFFERENT poses (+-1 m, any yaw); the reference's benchmark passes 1000 copies of ONE pose (z + 0.2 m): v1_bench_identical_poses_*"
+            same = np.array([T.transform_from_rpy((0.0, 0.0, 0.2), (0, 0, 0))] * 1000, dtype=T.TRANSFORM)
+            small.correct_batch(same)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                small.correct_batch(same)
+            dts = (time.perf_counter() - t1) / 3
+            extras["v1_bench_identical_poses_ms"] = round(dts * 1e3, 4)
+            extras["v1_bench_identical_poses_pose_corrections_per_s"] = round(1000 / dts, 1)
             # the only figures the reference records for this shape (source comments, the authors' own machines, NOT this hardware):
             extras["v1_bench_reference_source_comments"] = {"optix_gpu_100k_faces_pose_corrections_per_s": 73700, "embree_cpu_100k_faces_pose_corrections_per_s": 5464,
                                                             "where": "rmcl_ros/src/benchmarks/lidar_corrector_{optix,embree}_benchmark.cpp:161 / :144 (BASELINE.md)"}
