@@ -278,6 +278,19 @@ def main():
             extras["find_room100k_rays_per_s"] = round(n_rays / (rms * 1e-3), 1)
             k_t, ms_t = rr.autotune(Troom)
             extras["find_room100k_autotuned"] = {"rule_kind": 23, "chosen_kind": k_t, "ms": round(ms_t, 5)}
+            rr.setModel(model)
+            # C3 on the room, over the size of the initial error (the sphere has no correspondence near the gate; a room has): the
+            # undecided correspondences go to the host up to 1024 of them, beyond that the device loop takes the call
+            # (profiles/r04_c3_regimes.txt)
+            rr.find(Troom)
+            rr.set_dataset_from_ranges(rr.modelView()["ranges"])
+            rr.params.max_dist, rr.adaptive_max_dist_min = 1.0, 0.15
+            for tag, sc in (("2cm_0.2deg", 0.1), ("10cm_1deg", 0.5), ("20cm_2deg", 1.0)):
+                est_r = T.mult(Troom, T.transform_from_rpy((0.2 * sc, 0.0, 0.0), (0.0, 0.0, 0.0349 * sc)))
+                for _ in range(3):
+                    rr.correct_once(est_r, T.identity(), 10, 0.0, False)
+                extras["c3_schedule_R_room100k_%s_ms" % tag] = round(rr.time_correct_once(est_r, T.identity(), 10, 0.0, False, iters=50), 4)
+                extras["c3_schedule_R_room100k_%s_undecided" % tag] = rr.micp_fast_info()["last_uncertain"]
             rr.close()
             rpms, _ = _pf_c4(ra, syn, T, np, ctx, hmr, 100000, 256, iters=3, bb=((-9, -9, 0.3), (9, 9, 3)))
             extras["c4_room100k_pf_update_ms"] = round(rpms, 4)

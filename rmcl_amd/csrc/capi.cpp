@@ -1512,7 +1512,7 @@ static hipError_t wait_moments(rmclhip_rcc* r, uint32_t seq, float lo, float hi,
   ms.gate_lo = lo; ms.gate_hi = hi; ms.rho_cap = rho_cap; ms.tau_cap = tau_cap;
   ms.n_unc = hb->n_uncertain;
   ms.valid = (hb->code == 0u && ms.n_unc <= kMicpHostMaxUnc);
-  if (ms.valid && ms.n_unc) std::memcpy(ms.unc, hb->unc, static_cast<size_t>(ms.n_unc) * 9u * sizeof(float));
+  if (ms.valid) ms.set_undecided(hb->unc, ms.n_unc);   // (component-major copy, padded for the eight-lane sums)
   return hipSuccess;
 }
 

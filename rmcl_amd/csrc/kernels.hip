@@ -1205,6 +1205,7 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_publish(const MicpFastPar
   constexpr uint32_t kGroups = kFoldGroups;
   __shared__ double s_part[kGroups][kMom];
   __shared__ uint32_t s_list[kMicpHostMaxUnc];
+  __shared__ float s_stage[9u * kMicpHostMaxUnc];
   __shared__ uint32_t s_wave_cnt[kFastThreads / 64];
   __shared__ uint32_t s_xor[kFastThreads / 64];
   __shared__ uint32_t s_abort;   // a sibling workgroup's sums did not arrive within kDevicePollBound polls: code 2
@@ -1304,6 +1305,8 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_publish(const MicpFastPar
       }
     }
     __syncthreads();
+    // gather D | I | N of the listed correspondences into LDS, then write the block to the host in address order (consecutive lanes,
+    // consecutive dwords: a thread storing its own 36-B record put nine narrow writes per correspondence on the bus)
     for (uint32_t e = tid; e < total; e += kFastThreads) {
       const uint32_t i = s_list[e];
       const float* dp = p.dataset_points + 3 * static_cast<size_t>(i);
@@ -1311,10 +1314,14 @@ __global__ void __launch_bounds__(kFastThreads) k_micp_publish(const MicpFastPar
       const float* mn = p.model_normals + 3 * static_cast<size_t>(i);
       const float v[9] = {dp[0], dp[1], dp[2], mp[0], mp[1], mp[2], mn[0], mn[1], mn[2]};
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        p.host_block->unc[e][k] = v[k];
-        x ^= __float_as_uint(v[k]);
-      }
+      for (int k = 0; k < 9; ++k) s_stage[9u * e + static_cast<uint32_t>(k)] = v[k];
+    }
+    __syncthreads();
+    float* dst = &p.host_block->unc[0][0];
+    for (uint32_t w = tid; w < 9u * total; w += kFastThreads) {
+      const float v = s_stage[w];
+      dst[w] = v;
+      x ^= __float_as_uint(v);
     }
   }
 #pragma unroll

@@ -233,3 +233,37 @@ def test_host_moment_form_band_and_caps(ra, orc):
     D2, I2, N2, v2 = _random_correspondences(20000, 5, spread=0.05)
     s, nu, cov = _host_moment_stats(ra, D2, I2, N2, v2, 0.05, 0.08, 0.05, 0.05, Tpre, 0.06)
     assert nu > 256 and not cov
+
+
+def test_undecided_sums_do_not_depend_on_the_cpu():
+    """micp_host.h sums the undecided correspondences in eight interleaved partial sums -- one AVX2 register of floats -- and compiles
+    the SAME body twice (target avx2 / portable).  The two must agree bit for bit (RMCLHIP_NO_AVX2 selects the portable one in a fresh
+    process), with several hundred undecided correspondences, a count that is not a multiple of eight, and gated-out ones among them."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np, ctypes as C
+sys.path.insert(0, %r)
+import rmcl_amd as ra
+from rmcl_amd import types as T
+rng = np.random.RandomState(5)
+n = 1500
+D = rng.uniform(-8, 8, (n, 3)).astype(np.float32)
+N = rng.normal(size=(n, 3)); N = (N / np.linalg.norm(N, axis=1, keepdims=True)).astype(np.float32)
+I = (D + N * rng.uniform(-1.6, 1.6, (n, 1))).astype(np.float32)
+ok = (rng.rand(n) > 0.1).astype(np.uint8)
+Tp = np.ascontiguousarray(T.transform_from_rpy((0.05, -0.02, 0.01), (0.004, -0.003, 0.01)), dtype=T.TRANSFORM).reshape(1)
+out = np.zeros(1, dtype=T.CROSS_STATISTICS); nu, cov = C.c_uint32(0), C.c_int(0)
+st = ra._capi.lib().rmclhip_host_moment_statistics(D.ctypes.data, I.ctypes.data, N.ctypes.data, ok.ctypes.data, n, 0.95, 1.05, 0.03, 0.08,
+                                                   Tp.ctypes.data, 1.0, out.ctypes.data, C.byref(nu), C.byref(cov))
+print(st, nu.value, cov.value, out.tobytes().hex())
+""" % root
+    res = []
+    for env_extra in ({}, {"RMCLHIP_NO_AVX2": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(r.stdout.strip().split())
+    assert res[0] == res[1], (res[0][:3], res[1][:3])
+    assert res[0][0] == "0" and res[0][2] == "1" and 200 < int(res[0][1]) <= 1024, res[0][:3]   # a few hundred undecided ones, covered
