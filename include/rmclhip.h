@@ -419,7 +419,7 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* rcc, int variant);
  * launches -- the find (per-ray kind 23 or quad kind 2: every single scan the rule serves) forms the moments in its epilogue, a
  * 10 x 10 product of factor vectors per correspondence through f64 MFMA; a fold launch sums the per-workgroup rows and publishes
  * {82 moments, the undecided correspondences (<= 256)} to the host -- and the ITERATIONS RUN ON THE HOST (~0.5 us each; the same
- * published set then also answers rmclhip_rcc_compute_cross_statistics without a launch, see rmclhip_ccs_info); more than 256
+ * published set then also answers rmclhip_rcc_compute_cross_statistics without a launch, see rmclhip_ccs_info); more than 1024
  * undecided: the device loop of mode 4 on the same rows.  2 = device loop, find + moments pass + loop replayed from a hipGraph
  * behind an H2D copy node (A/B); 3 = device loop, three plain launches (A/B: the moments always in a pass of their own); 4 = device
  * loop behind a find with the moment epilogue (round 3's default, A/B: one lane of the GPU solves every iteration). */
@@ -451,7 +451,7 @@ rmclhip_status rmclhip_rcc_ccs_info(const rmclhip_rcc* rcc, rmclhip_ccs_info* ou
  * N = model normal, valid nullable) for every max_dist' in [gate_lo, gate_hi] and every pre-transform within (rho_cap = |2 sin
  * theta/2|, tau_cap = |t|), accumulates the 82 moments of the certainly-gated-in ones, keeps the undecided ones (<= 256), and
  * evaluates rm::statistics_p2l(Tpre, ..., max_dist) from them.  *covered = 0 (and Identity statistics) when (Tpre, max_dist) lies
- * outside what the set was formed for or more than 256 correspondences are undecided: the library then uses the streaming
+ * outside what the set was formed for or more than 1024 correspondences are undecided: the library then uses the streaming
  * reduction.  What the device publishes per find is this set; the entry point exists so that the arithmetic can be checked
  * against the reference's per-element loop (MICPSensorCPU.cpp:70-84) without a GPU. */
 rmclhip_status rmclhip_host_moment_statistics(const float* dataset_points, const float* model_points, const float* model_normals,
