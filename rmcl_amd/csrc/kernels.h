@@ -244,6 +244,8 @@ struct MicpMultiFastParams {
 };
 // one lane stores `seq` to *flag with release semantics at device scope: enqueued behind a sensor's moment pass on that sensor's stream
 hipError_t launch_signal_flag(uint32_t* flag, uint32_t seq, hipStream_t s);
+// {seq, 0} to a pinned completion tag, behind whatever the stream holds
+hipError_t launch_host_tag(unsigned long long* done, uint32_t seq, hipStream_t s);
 hipError_t launch_micp_moments(const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
                                const float* model_normals, const uint8_t* model_mask, uint32_t n, const MicpCall* call,
                                double* partials, unsigned long long* unc_mask, hipStream_t s, const MicpCallLite* call_by_value = nullptr);

@@ -2674,6 +2674,17 @@ __global__ void k_signal_flag(uint32_t* flag, uint32_t seq) {
   if (threadIdx.x == 0u && blockIdx.x == 0u) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 }  // namespace
+namespace {
+// completion tag of a launch chain that returns nothing to the host but its own end: {seq, sum 0} to pinned memory, behind the chain
+// on its stream (the kernel boundary before this launch is what makes the chain's results visible)
+__global__ void k_host_tag(unsigned long long* done, uint32_t seq) {
+  if (threadIdx.x == 0u && blockIdx.x == 0u) publish_tag(done, seq, 0u);
+}
+}  // namespace
+hipError_t launch_host_tag(unsigned long long* done, uint32_t seq, hipStream_t s) {
+  hipLaunchKernelGGL(k_host_tag, dim3(1), dim3(64), 0, s, done, seq);
+  return hipGetLastError();
+}
 hipError_t launch_signal_flag(uint32_t* flag, uint32_t seq, hipStream_t s) {
   hipLaunchKernelGGL(k_signal_flag, dim3(1), dim3(64), 0, s, flag, seq);
   return hipGetLastError();
