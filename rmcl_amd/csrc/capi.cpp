@@ -284,6 +284,37 @@ struct rmclhip_rcc {
                                       // hipEventRecord + one hipEventElapsedTime per call: opt-in since round 4)
 };
 
+// A pinned, host-mapped completion tag of a handle whose synchronous calls launch kernels and return nothing through the host (the
+// filter's update / motion update, the tournament): a one-thread launch behind the chain stores {seq, 0}, the host polls it -- ~7 us
+// sooner than the stream's own completion signal reaches hipStreamSynchronize (measured on the synchronous find, round 4).
+struct ChainTag {
+  unsigned long long* h = nullptr;
+  unsigned long long* d = nullptr;
+  uint32_t seq = 0;
+  hipError_t create() {
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&h), sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&d), h, 0);
+    if (e == hipSuccess) *h = 0ull;
+    return e;
+  }
+  void destroy() { if (h) (void)hipHostFree(h); h = nullptr; d = nullptr; }
+  // wait for the end of what `stream` holds (BLOCK wait mode, or no tag: hipStreamSynchronize)
+  hipError_t wait_chain_end(const rmclhip_ctx* ctx, hipStream_t stream) {
+    if (h == nullptr || ctx->wait_block.load(std::memory_order_relaxed)) return hipStreamSynchronize(stream);
+    seq = (seq == 0xFFFFFFFFu) ? 1u : seq + 1u;
+    if (const hipError_t e = launch_host_tag(d, seq, stream)) return e;
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+    volatile const unsigned long long* tag = h;
+    for (uint32_t spins = 0;; ++spins) {
+      if (*tag == static_cast<unsigned long long>(seq)) { std::atomic_thread_fence(std::memory_order_acquire); return hipSuccess; }
+#if defined(__x86_64__) || defined(__i386__)
+      __builtin_ia32_pause();
+#endif
+      if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() > t_end) return hipStreamSynchronize(stream);
+    }
+  }
+};
+
 // whatever is about to rewrite the model buffers or the dataset: the published moments summarise the old ones
 static inline void drop_moment_set(rmclhip_rcc* r) {
   r->mset.valid = false;
@@ -305,6 +336,7 @@ struct rmclhip_pf {
   uint32_t refill_thr = 0, tail_lanes = 8;  // schedule knobs of the round-3 kernel (0: from `refill`); rmclhip_pf_set_schedule
   // rmclhip_pf_set_mapping: 0 beam-minor blocks of ~2048 rays (uniform clouds), 1 particle-minor blocks (converged clouds), 2 automatic
   bool cpc_grid = true;            // correspondence_type 1: seed every closest-point query from the map's near grid (A/B: rmclhip_pf_set_mapping bit 8 clears it)
+  ChainTag tag;                    // completion tag of the synchronous kernel-only calls (update, motion update, extract_weights)
   bool evals_global = true;        // k_pf_update_v3 keeps a workgroup's beam errors in global scratch, not LDS (A/B: rmclhip_pf_set_mapping bit 9 clears it)
   DevBuf<float> d_evals;           // [n_particles * n_beams], grow-only
   int mapping = 0;
@@ -329,6 +361,7 @@ struct rmclhip_resampler {
   DevBuf<double> d_psum;
   DevBuf<float> d_pmax, d_out;
   float* h_out = nullptr;  // pinned {sum, max}
+  ChainTag tag;            // completion tag of the tournament (a kernel-only synchronous call)
   unsigned long long* h_res = nullptr;   // pinned: residual resampling's {sum, max, expect, n_draws} + the draws' total (5 words)
   // residual resampling: {double sum, double max, u64 expect, u64 n_draws} on the device, the draws' particle / count / prefix sums
   DevBuf<unsigned long long> d_res_stats, d_res_incl, d_res_btot;
@@ -2971,6 +3004,7 @@ rmclhip_status rmclhip_pf_create(rmclhip_ctx* ctx, rmclhip_map* map, rmclhip_pf*
   hipError_t e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&f->ev0);
   if (e == hipSuccess) e = hipEventCreate(&f->ev1);
+  if (e == hipSuccess) e = f->tag.create();
   if (e != hipSuccess) {
     rmclhip_pf_destroy(f);
     return fail(RMCLHIP_ERR_HIP, std::string("pf_create: ") + hipGetErrorString(e));
@@ -2984,7 +3018,7 @@ void rmclhip_pf_destroy(rmclhip_pf* f) {
   if (!f) return;
   (void)hipSetDevice(f->ctx->device);
   if (f->stream) (void)hipStreamSynchronize(f->stream);
-  f->d_beams.release(); f->d_evals.release(); f->d_order.release();
+  f->d_beams.release(); f->d_evals.release(); f->d_order.release(); f->tag.destroy();
   if (f->h_beams) (void)hipHostFree(f->h_beams);
   if (f->ev0) (void)hipEventDestroy(f->ev0);
   if (f->ev1) (void)hipEventDestroy(f->ev1);
@@ -3122,7 +3156,8 @@ rmclhip_status rmclhip_pf_update(rmclhip_pf* f, const rmclhip_transform* poses, 
                                  const rmclhip_transform* Tsb) {
   ApiGuard guard_("rmclhip_pf_update");
   if (rmclhip_status st = rmclhip_pf_update_async(f, poses, attrs, n, beams, n_beams, Tsb)) return st;
-  HIPCHK(hipStreamSynchronize(f->stream));
+  if (n == 0 || n_beams == 0) return RMCLHIP_OK;
+  HIPCHK(f->tag.wait_chain_end(f->ctx, f->stream));
   return RMCLHIP_OK;
 }
 
@@ -3144,7 +3179,7 @@ rmclhip_status rmclhip_pf_motion_update(rmclhip_pf* f, rmclhip_transform* poses_
   HIPCHK(hipSetDevice(f->ctx->device));
   HIPCHK(launch_pf_motion(f->map->d_qnodes, f->map->d_tris, reinterpret_cast<xform*>(poses_dev), attrs_dev, n,
                           to_x(T_bnew_bold), forget_rate, f->params.max_n_meas, check_collision != 0, f->stream));
-  HIPCHK(hipStreamSynchronize(f->stream));
+  HIPCHK(f->tag.wait_chain_end(f->ctx, f->stream));
   return RMCLHIP_OK;
 }
 
@@ -3154,7 +3189,7 @@ rmclhip_status rmclhip_pf_extract_weights(rmclhip_pf* f, const rmclhip_particle_
   if (!f || (!attrs && n) || (!weights_dev && n)) return fail(RMCLHIP_ERR_INVALID, "pf_extract_weights: null");
   HIPCHK(hipSetDevice(f->ctx->device));
   HIPCHK(launch_pf_extract_weights(attrs, n, weights_dev, f->stream));
-  HIPCHK(hipStreamSynchronize(f->stream));
+  HIPCHK(f->tag.wait_chain_end(f->ctx, f->stream));
   return RMCLHIP_OK;
 }
 
@@ -3279,6 +3314,7 @@ rmclhip_status rmclhip_resampler_create(rmclhip_ctx* ctx, rmclhip_resampler** ou
   if (e == hipSuccess) e = r->d_out.reserve(2);
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_out), 2 * sizeof(float), hipHostMallocDefault);
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&r->h_res), 8 * sizeof(unsigned long long), hipHostMallocDefault);
+  if (e == hipSuccess) e = r->tag.create();
   if (e != hipSuccess) {
     rmclhip_resampler_destroy(r);
     return fail(RMCLHIP_ERR_HIP, std::string("resampler_create: ") + hipGetErrorString(e));
@@ -3298,6 +3334,7 @@ void rmclhip_resampler_destroy(rmclhip_resampler* r) {
   r->d_res_stats.release(); r->d_res_incl.release(); r->d_res_btot.release(); r->d_res_idx.release(); r->d_res_cnt.release();
   if (r->h_out) (void)hipHostFree(r->h_out);
   if (r->h_res) (void)hipHostFree(r->h_res);
+  r->tag.destroy();
   if (r->stream) (void)hipStreamDestroy(r->stream);
   ctx_release(r->ctx);
   delete r;
@@ -3353,7 +3390,7 @@ rmclhip_status rmclhip_resampler_gladiator(rmclhip_resampler* r, const rmclhip_t
                                             r->stream))
     return st;
   if (count == 0) return RMCLHIP_OK;
-  HIPCHK(hipStreamSynchronize(r->stream));
+  HIPCHK(r->tag.wait_chain_end(r->ctx, r->stream));
   return RMCLHIP_OK;
 }
 
