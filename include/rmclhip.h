@@ -158,7 +158,10 @@ void rmclhip_ctx_destroy(rmclhip_ctx* ctx);
  * of the call writes (sequence number + checksum of the result, verified by the host) -- ~9 us less latency per call, one
  * busy host core while a call is in flight.  RMCLHIP_WAIT_BLOCK: hipStreamSynchronize -- the thread sleeps in the runtime.
  * The reference's node has ONE correction thread per node (micp_localization.cpp:300-302); integrators who cannot spare a
- * spinning core choose BLOCK.  Applies to every handle of the context, may be changed at any time. */
+ * spinning core choose BLOCK.  Applies to every handle of the context, may be changed at any time.
+ * Since round 4 the synchronous calls that return NOTHING through the host (find, find_cpc, pf_update, pf_motion_update,
+ * pf_extract_weights, resampler_gladiator) wait the same way in SPIN mode: a one-thread launch behind the call's kernels stores
+ * the tag (a 128x1024 find returns after 24.5 instead of 31.6 us); the call's results are complete when it returns either way. */
 #define RMCLHIP_WAIT_SPIN 0
 #define RMCLHIP_WAIT_BLOCK 1
 rmclhip_status rmclhip_ctx_set_wait_mode(rmclhip_ctx* ctx, int mode);
