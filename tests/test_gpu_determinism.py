@@ -68,3 +68,61 @@ def test_correct_once_repeats_bit_identically(ra, ctx, meshes):
         assert bad == 0, (refind, fast, bad)
     rcc.set_micp_fast(1)
     rcc.close()
+
+
+@pytest.mark.parametrize("mode", ["spin", "block"])
+def test_kernel_only_calls_are_complete_when_they_return(ra, ctx, meshes, mode):
+    """Round 4: the synchronous calls that return nothing through the host (find, the closest-point find, the filter's update and
+    motion update, the tournament) come back on a polled completion tag stored by a one-thread launch BEHIND their kernels.  What
+    they wrote must be complete at that moment: outputs downloaded right after the call (plain device-to-host copies of the device
+    arrays, alternating inputs so that a stale result is recognisable) must equal the reference every time, in both wait modes."""
+    import math
+    from rmcl_amd import synthetic as syn, types as T
+    ctx.set_wait_mode(mode)
+    try:
+        v, f = meshes("sphere20k")
+        hm = ra.import_hip_map(ctx, v, f)
+        rcc = ra.RCCHipSpherical(hm)
+        rcc.setTsb(T.identity())
+        rcc.setModel(syn.model_c1())
+        poses = [T.transform((0, 0, 0, 1), (0.0, 0.0, 0.2)), T.transform_from_rpy((0.3, -0.2, 0.1), (0.0, 0.0, 0.5))]
+        ref = []
+        for P in poses:
+            rcc.find(P)
+            ref.append(rcc.modelView()["ranges"].tobytes())
+        assert ref[0] != ref[1]
+        bad = 0
+        for i in range(1500):
+            rcc.find(poses[i & 1])
+            bad += rcc.modelView()["ranges"].tobytes() != ref[i & 1]
+        assert bad == 0
+        # the filter: motion update (in place) + sensor update + tournament, two alternating clouds
+        beams = ra.beams_from_points(syn.model_directions(syn.model_pf16())[::8] * np.float32(4.0))
+        clouds = [syn.uniform_particles(600, seed=s, bb_min=(-4, -4, -1, 0, 0, -math.pi), bb_max=(4, 4, 1, 0, 0, math.pi)) for s in (1, 2)]
+        upd = ra.PCDSensorUpdaterHip(hm)
+        upd.init()
+        upd.setInput(beams, T.identity())
+        mot = ra.TFMotionUpdaterHip(hm)
+        rs = ra.GladiatorResamplerHip(ctx)
+        step = T.transform_from_rpy((0.02, 0.0, 0.0), (0.0, 0.0, 0.01))
+
+        def one(k):
+            poses_k, attrs_k = clouds[k]
+            n_p = len(poses_k)
+            d_p, d_a = ra.DeviceArray.from_host(ctx, poses_k), ra.DeviceArray.from_host(ctx, attrs_k)
+            d_p2, d_a2 = ra.DeviceArray.from_host(ctx, poses_k), ra.DeviceArray.from_host(ctx, attrs_k)
+            mot.update(d_p, d_a, n_p, step, 0.01)
+            upd.update(d_p, d_a)
+            rs.step = k          # (the tournament's random stream is a function of (seed, step, champion index))
+            rs.update(d_p, d_a, d_p2, d_a2, n_p)
+            return d_p.download().tobytes() + d_a.download().tobytes() + d_p2.download().tobytes() + d_a2.download().tobytes()
+
+        pref = [one(0), one(1)]
+        assert pref[0] != pref[1]
+        assert sum(one(i & 1) != pref[i & 1] for i in range(200)) == 0
+        upd.close()
+        mot.close()
+        rs.close()
+        rcc.close()
+    finally:
+        ctx.set_wait_mode("spin")
