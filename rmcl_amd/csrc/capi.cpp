@@ -265,6 +265,9 @@ struct rmclhip_rcc {
   DevBuf<uint8_t> d_raw;           // staged PointCloud2 bytes (set_input_pointcloud2)
   DevBuf<xform> d_Tbm, d_Tsm, d_Tms, d_Tdelta;
   DevBuf<cstats> d_bstats;
+  // correct_batch's results leave through pinned, host-mapped staging (grow-only): the solve launch writes them there, the call
+  // returns on its completion tag and copies them out -- no device-to-host copy launches, no stream synchronisation
+  xform* h_bT = nullptr; xform* h_bT_dev = nullptr; cstats* h_bS = nullptr; cstats* h_bS_dev = nullptr; uint32_t h_batch_cap = 0;
   bool capturing = false;          // inside hipStreamBeginCapture: no synchronisation allowed
   int variant = 15;       // traversal kind: 0 wave-packet, 1 one lane per ray (while-while), 2 four lanes per ray
                           // (quad-cooperative), 15 automatic: quad while the launch is bound by the slowest ray's
@@ -767,6 +770,8 @@ void rmclhip_rcc_destroy(rmclhip_rcc* r) {
   r->d_hits.release(); r->d_ranges.release(); r->d_points.release(); r->d_normals.release(); r->d_face_ids.release();
   r->d_partials.release(); r->d_Tbm.release(); r->d_Tsm.release(); r->d_Tms.release(); r->d_Tdelta.release();
   r->d_bstats.release();
+  if (r->h_bT) DBG_STEP(hipHostFree(r->h_bT));
+  if (r->h_bS) DBG_STEP(hipHostFree(r->h_bS));
   r->d_raw.release();
   DBG_STEP(hipPeekAtLastError());
   if (r->h_stats) DBG_STEP(hipHostFree(r->h_stats));
@@ -2363,17 +2368,27 @@ rmclhip_status rmclhip_rcc_correct_batch(rmclhip_rcc* r, const rmclhip_transform
   HIPCHK(hipSetDevice(r->ctx->device));
   const size_t n = static_cast<size_t>(r->W) * r->H;
   if (r->n_dataset != n) return fail(RMCLHIP_ERR_INVALID, "correct_batch: dataset size != model size");
-  HIPCHK(r->d_Tdelta.reserve(nposes)); HIPCHK(r->d_bstats.reserve(nposes));
+  if (nposes > r->h_batch_cap) {
+    HIPCHK(hipStreamSynchronize(r->stream));
+    if (r->h_bT) (void)hipHostFree(r->h_bT);
+    if (r->h_bS) (void)hipHostFree(r->h_bS);
+    r->h_bT = nullptr; r->h_bS = nullptr; r->h_batch_cap = 0;
+    const uint32_t cap = std::max(nposes, 64u);
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&r->h_bT), sizeof(xform) * cap, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&r->h_bT_dev), r->h_bT, 0));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&r->h_bS), sizeof(cstats) * cap, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&r->h_bS_dev), r->h_bS, 0));
+    r->h_batch_cap = cap;
+  }
   if (rmclhip_status st = find_batch_enqueue(r, Tbm, nposes)) return st;
   ReduceTail tail;
   tail.mode = kTailBatchSolve;
-  tail.Tdelta_out = r->d_Tdelta.p;
-  tail.stats_out = r->d_bstats.p;
+  tail.Tdelta_out = r->h_bT_dev;
+  tail.stats_out = r->h_bS_dev;
   if (rmclhip_status st = reduce_enqueue(r, xidentity(), nullptr, r->max_dist, nposes, tail)) return st;
-  HIPCHK(hipMemcpyAsync(Tdelta_out, r->d_Tdelta.p, sizeof(xform) * nposes, hipMemcpyDeviceToHost, r->stream));
-  if (stats_out)
-    HIPCHK(hipMemcpyAsync(stats_out, r->d_bstats.p, sizeof(cstats) * nposes, hipMemcpyDeviceToHost, r->stream));
-  HIPCHK(hipStreamSynchronize(r->stream));
+  HIPCHK(wait_chain_end(r));
+  std::memcpy(Tdelta_out, r->h_bT, sizeof(xform) * nposes);
+  if (stats_out) std::memcpy(stats_out, r->h_bS, sizeof(cstats) * nposes);
   return RMCLHIP_OK;
 }
 
