@@ -280,6 +280,7 @@ struct rmclhip_rcc {
   bool tuned_frontier = true, tuned_batch_frontier = true;
   DevBuf<float> d_tile_planes;     // plane table of the frontier start for the current (model, tiling): 16 floats per tile
   bool tile_planes_ok = false;
+  float ang_aspect = 0.0f;         // spherical models: |row spacing / column spacing| in angle (0: unknown -- the other models)
   float last_find_ms = 0.f, last_reduce_ms = 0.f;
   bool reduce_timing_pending = false;
   bool find_timing_pending = false;   // a speculating find returned on its tag: ev0 / ev1 still hold its timing
@@ -826,6 +827,7 @@ rmclhip_status rmclhip_rcc_set_model_spherical(rmclhip_rcc* r, const rmclhip_sph
   r->range = m->range;
   r->orig = mk3(0.f, 0.f, 0.f);
   r->tile_planes_ok = false;
+  r->ang_aspect = (H > 1u && W > 1u && m->theta.inc != 0.0f && std::isfinite(m->phi.inc / m->theta.inc)) ? std::fabs(m->phi.inc / m->theta.inc) : 0.0f;
   if (W == 0 || H == 0) return RMCLHIP_OK;
   // trig tables with the host libm, exactly what rmagine's getDirection evaluates per ray:
   // phi = phi.min + float(vid) * phi.inc, theta likewise
@@ -852,6 +854,7 @@ rmclhip_status rmclhip_rcc_set_model_o1dn(rmclhip_rcc* r, uint32_t width, uint32
   HIPCHK(hipSetDevice(r->ctx->device));
   HIPCHK(hipStreamSynchronize(r->stream));
   r->kind = kModelO1Dn;
+  r->ang_aspect = 0.0f;
   r->graph_dirty = true; r->fast_graph_dirty = true;
   r->W = width; r->H = height;
   r->range = range;
@@ -873,6 +876,7 @@ rmclhip_status rmclhip_rcc_set_model_pinhole(rmclhip_rcc* r, uint32_t width, uin
   HIPCHK(hipSetDevice(r->ctx->device));
   HIPCHK(hipStreamSynchronize(r->stream));
   r->kind = kModelPinhole;
+  r->ang_aspect = 0.0f;
   r->graph_dirty = true; r->fast_graph_dirty = true;
   r->W = width; r->H = height;
   r->range = range;
@@ -888,6 +892,7 @@ rmclhip_status rmclhip_rcc_set_model_ondn(rmclhip_rcc* r, uint32_t width, uint32
   HIPCHK(hipSetDevice(r->ctx->device));
   HIPCHK(hipStreamSynchronize(r->stream));
   r->kind = kModelOnDn;
+  r->ang_aspect = 0.0f;
   r->tile_planes_ok = false;
   r->tuned_kind = r->tuned_batch_kind = 0; r->tuned_frontier = r->tuned_batch_frontier = true; r->tuned_tile = 0;
   r->graph_dirty = true; r->fast_graph_dirty = true;
@@ -1011,6 +1016,7 @@ rmclhip_status rmclhip_rcc_set_input_pointcloud2(rmclhip_rcc* r, const uint8_t* 
   HIPCHK(hipSetDevice(r->ctx->device));
   HIPCHK(hipStreamSynchronize(r->stream));
   r->kind = kModelO1Dn;
+  r->ang_aspect = 0.0f;
   r->graph_dirty = true; r->fast_graph_dirty = true;
   r->W = ow; r->H = oh;
   r->range = range;
@@ -1046,7 +1052,21 @@ rmclhip_status rmclhip_rcc_set_input_pointcloud2(rmclhip_rcc* r, const uint8_t* 
   return RMCLHIP_OK;
 }
 
-static uint32_t pick_tile_w_log2(uint32_t H, bool packet) {
+static uint32_t pick_tile_w_log2(uint32_t H, bool packet, float ang_aspect = 0.0f) {
+  // Spherical models whose COLUMNS are much sparser than their rows (row spacing / column spacing < 0.5: a 32 x 32 or 16 x 16 model
+  // over the full circle) get tall tiles, as square in angle as 64 rays allow: 16 wide x 4 tall tiles of such a model span half the
+  // horizon, and the rays of a wave share nothing (round 4, 2000 poses x 32x32: 0.47 -> 0.27 ms; profiles/r04_v1_batch_breakdown.txt).
+  if (!packet && ang_aspect > 0.0f && ang_aspect < 0.5f) {
+    uint32_t hp = 1;
+    while (hp < H && hp < 64u) hp <<= 1;                         // tile height <= the model's (rounded up to a power of two)
+    uint32_t min_twl = 0;
+    while ((64u >> min_twl) > hp) ++min_twl;
+    const float want = 0.5f * std::log2(64.0f * ang_aspect);     // log2 of the width that makes the tile square in angle
+    int twl = static_cast<int>(std::lround(want));
+    twl = std::max(twl, static_cast<int>(min_twl));
+    twl = std::min(std::max(twl, 0), 4);                         // (never wider than the general rule below)
+    return static_cast<uint32_t>(twl);
+  }
   // The 64 rays of a wave (kind 2: of a block) are a tile of the scan image.  The wave-packet traversal (kind 0), whose rays walk
   // together, keeps round 1's square 8x8 tiles (images at least 8 rows tall; flatter tiles for 2-D scanners).  For the per-ray
   // traversals round 3 re-measured the shapes with the frontier start in place (profiles/r03_find_tile_shapes.txt): 16 wide x 4 tall
@@ -1106,7 +1126,7 @@ static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
   p.W = r->W; p.H = r->H;
   p.tile_w_log2 = (r->tile_override > 0) ? static_cast<uint32_t>(r->tile_override - 1)
                   : ((r->tuned_tile > 0 && find_variant(r, nposes) != 0) ? static_cast<uint32_t>(r->tuned_tile - 1)
-                                                                         : pick_tile_w_log2(r->H, find_variant(r, nposes) == 0));
+                                                                         : pick_tile_w_log2(r->H, find_variant(r, nposes) == 0, r->ang_aspect));
   const uint32_t tw = 1u << p.tile_w_log2, th = 64u >> p.tile_w_log2;
   p.tiles_x = (r->W + tw - 1) / tw;
   p.tiles_y = (r->H + th - 1) / th;

@@ -268,8 +268,12 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   }
   // XCD-aware remap: the dispatcher places block b on XCD b%8; give every XCD a contiguous range of
   // tiles so neighbouring tiles (which walk the same subtrees) share one L2.  gridDim.x % 8 == 0.
+  // Pose batches (gridDim.y > 1) rotate the assignment by the pose: a model of a few tiles fills only the first of the eight
+  // ranges, and without the rotation every pose's occupied range sat on the SAME XCD (round 4: 2000 poses x 32x32 rays ran on an
+  // eighth of the chip, 0.80 ms; rotated 0.2x ms -- profiles/r04_v1_batch_breakdown.txt).
   const uint32_t chunk = gridDim.x >> 3;
-  const uint32_t vb = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+  const uint32_t xr = (gridDim.y > 1u) ? ((blockIdx.x + blockIdx.y) & 7u) : (blockIdx.x & 7u);
+  const uint32_t vb = xr * chunk + (blockIdx.x >> 3);
   const uint32_t tile = (kQuad ? vb : (vb * 4u + wave));
   const uint32_t ntiles = p.tiles_x * p.tiles_y;
   if (tile >= ntiles) {
