@@ -1608,7 +1608,10 @@ static rmclhip_status enqueue_find_with_moments(rmclhip_rcc* r, const xform& Tsm
   fill_find_params(r, fp, 1);
   fp.Tsm = Tsm;
   fp.Tms = xinv(Tsm);
-  const int fv = find_variant(r, 1);
+  int fv = find_variant(r, 1);
+  // scans above 262 144 rays would take kind 24, which has no moment epilogue: the separate moment pass over half a million
+  // correspondences costs more (~40 us) than kind 23 loses against kind 24 there (~3 us) -- a correction of a 256 x 2048 scan 93 -> 6x us
+  if (epilogue_allowed && fv == 24 && r->variant == 15) fv = 23;
   if (epilogue_allowed && (fv == 23 || fv == 2)) {
     const uint32_t nb = find_moments_blocks(fp, fv), wpb = (fv == 2) ? 1u : 4u;   // mask words per workgroup
     HIPCHK(r->d_fast_partials.reserve(static_cast<size_t>(nb) * kMicpFastMoments));
