@@ -1549,7 +1549,7 @@ __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
     const uint64_t want = __ballot(idle);
     const uint64_t busy = __ballot(cur != kDone);
     if (want == 0 && busy == 0) break;
-    if (want != 0 && (busy == 0 || __popcll(want) >= static_cast<int>(p.refill_thr))) {
+    if (want != 0 && (busy == 0 || static_cast<uint32_t>(__popcll(want)) >= p.refill_thr)) {
       if (idle && has_ray) {
         // evaluate_rcc (PCDSensorUpdaterEmbree.cpp:18-86) with unit face normals (BeamEvaluateProgram.cu:104-113): the error only
         const bool real_hit = (range >= p.range_min) && (range <= p.range_max);
@@ -1608,7 +1608,7 @@ __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
       const bool inner = (cur != kDone) && !(cur & kLeafBit);
       const uint64_t m_inner = __ballot(inner);
       if (m_inner == 0) break;
-      if (__popcll(m_inner) <= static_cast<int>(p.tail_lanes) && __ballot((cur != kDone) && (cur & kLeafBit)) != 0) break;
+      if (static_cast<uint32_t>(__popcll(m_inner)) <= p.tail_lanes && __ballot((cur != kDone) && (cur & kLeafBit)) != 0) break;
       if (inner) {
         uint32_t key[4], ref[4];
         if (!__any(sp + 3u > static_cast<uint32_t>(kRows))) {
