@@ -132,6 +132,10 @@ typedef struct {
   uint32_t stack_need;     /* worst-case traversal stack entries */
   uint64_t device_bytes;
   float bbox_min[3], bbox_max[3];
+  /* round 5: stack_need <= 64 holds for EVERY mesh (no mesh is refused for its shape; rm::import_embree_map takes any Assimp mesh,
+     micp_localization.cpp:187-195).  These two count how often the bound had to be enforced -- 0 on ordinary meshes: object-median
+     splits forced by the height budget of the binary tree, and BVH4 nodes expanded tallest-child-first instead of largest-area-first */
+  uint32_t height_fallbacks, guarded_nodes;
 } rmclhip_map_info;
 
 typedef struct rmclhip_ctx rmclhip_ctx;
@@ -421,14 +425,14 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* rcc, int variant);
  * result never depends on the bounds (both forms agree to f64 summation order).  mode 0 = never; 1 = automatic (default): TWO plain
  * launches -- the find (per-ray kind 23 or quad kind 2: every single scan the rule serves) forms the moments in its epilogue, a
  * 10 x 10 product of factor vectors per correspondence through f64 MFMA; a fold launch sums the per-workgroup rows and publishes
- * {82 moments, the undecided correspondences (<= 256)} to the host -- and the ITERATIONS RUN ON THE HOST (~0.5 us each; the same
+ * {82 moments, the undecided correspondences (<= 1024)} to the host -- and the ITERATIONS RUN ON THE HOST (~0.5 us each; the same
  * published set then also answers rmclhip_rcc_compute_cross_statistics without a launch, see rmclhip_ccs_info); more than 1024
  * undecided: the device loop of mode 4 on the same rows.  2 = device loop, find + moments pass + loop replayed from a hipGraph
  * behind an H2D copy node (A/B); 3 = device loop, three plain launches (A/B: the moments always in a pass of their own); 4 = device
  * loop behind a find with the moment epilogue (round 3's default, A/B: one lane of the GPU solves every iteration). */
 typedef struct {
   uint32_t attempts, done, cap_exits, overflows;   /* outcomes since the operator was created */
-  uint32_t last_code;                              /* 0 done, 1 pre-transform left the bounds, 2 > 4096 undecided */
+  uint32_t last_code;                              /* 0 done, 1 pre-transform left the bounds, 2 too many undecided: > 1024 leaves the host form for the device loop, > 4096 the moment form altogether */
   uint32_t last_uncertain;                         /* undecided correspondences of the last attempt */
   float last_rho, last_tau;                        /* largest |2 sin(theta/2)| and |t| of its pre-transforms */
   float rho_cap, tau_cap;                          /* bounds the next attempt will use */
@@ -452,7 +456,7 @@ typedef struct {
 rmclhip_status rmclhip_rcc_ccs_info(const rmclhip_rcc* rcc, rmclhip_ccs_info* out);
 /* The host half of the moment form on its own (no device): classifies the n correspondences (D = dataset point, I = model point,
  * N = model normal, valid nullable) for every max_dist' in [gate_lo, gate_hi] and every pre-transform within (rho_cap = |2 sin
- * theta/2|, tau_cap = |t|), accumulates the 82 moments of the certainly-gated-in ones, keeps the undecided ones (<= 256), and
+ * theta/2|, tau_cap = |t|), accumulates the 82 moments of the certainly-gated-in ones, keeps the undecided ones (<= 1024 for the host, <= 4096 for the device loop), and
  * evaluates rm::statistics_p2l(Tpre, ..., max_dist) from them.  *covered = 0 (and Identity statistics) when (Tpre, max_dist) lies
  * outside what the set was formed for or more than 1024 correspondences are undecided: the library then uses the streaming
  * reduction.  What the device publishes per find is this set; the entry point exists so that the arithmetic can be checked

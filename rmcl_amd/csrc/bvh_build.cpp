@@ -2,13 +2,19 @@
 // records must be bit-identical to what the parity oracle derives from the same mesh.
 #include "bvh_build.h"
 
+#include <sched.h>
+
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <limits>
+#include <thread>
 
 namespace rmclhip {
 namespace {
@@ -35,7 +41,7 @@ struct Prim { Box b; float c[3]; };
 
 struct Node2 {
   Box b;
-  int32_t left = -1, right = -1;  // children (inner)
+  int32_t left = -1, right = -1;  // children (inner); a child's index is always larger than its parent's
   uint32_t first = 0, count = 0;  // prims of the whole subtree (a contiguous range of `order`)
   bool leaf() const { return left < 0; }
 };
@@ -49,92 +55,326 @@ static int bins_from_env() {
 }
 static const int kBins = bins_from_env();
 
+// Height budget of the BVH2 (round 5; VERDICT r4 "never refuse a valid mesh").  A node at depth d may only carry a subtree of
+// height <= kMaxHeight2 - d; a SAH split that would leave a child with more primitives than a balanced subtree of the remaining
+// height can hold is replaced by an object-median split (which halves the count, so the budget holds by induction).  With the
+// height-first collapse below, a BVH2 of height h becomes a BVH4 whose traversal stack needs <= 3 * ceil(h / 2) + 1 entries:
+// 42 -> 64 = kStackEntries of the kernels (traverse.hip.h), for ANY mesh of <= 2^28 - 1 faces.
+constexpr uint32_t kMaxHeight2 = 42;
+constexpr uint32_t kStackEntries = 64;
+
+// threads of one build: the CPUs this process may run on (affinity mask, cgroup quota), at most 16; RMCLHIP_BUILD_THREADS overrides.
+// The tree does not depend on it: every split is a function of the SET of primitives of its node, and partitions are stable.
+static int build_threads() {
+  if (const char* e = std::getenv("RMCLHIP_BUILD_THREADS")) return std::max(1, std::min(64, std::atoi(e)));
+  int n = static_cast<int>(std::thread::hardware_concurrency());
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n > 0 ? n : 1 << 20, CPU_COUNT(&set));
+  if (FILE* fh = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    long long quota = 0, period = 0;
+    if (std::fscanf(fh, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+      n = std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period));
+    std::fclose(fh);
+  }
+  return std::max(1, std::min(16, n));
+}
+
+// RMCLHIP_BUILD_TRACE=1: phase times of every build on stderr (tools/, never set by the product)
+struct PhaseTimer {
+  bool on = std::getenv("RMCLHIP_BUILD_TRACE") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void mark(const char* what) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[bvh_build] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+
+// f(thread, begin, end) over [0, n) in `nt` contiguous chunks (chunk k belongs to thread k: deterministic ownership)
+template <class F>
+static void parallel_chunks(size_t n, int nt, F&& f) {
+  if (nt <= 1 || n < 2) { f(0, size_t{0}, n); return; }
+  std::vector<std::thread> th;
+  th.reserve(nt - 1);
+  for (int k = 1; k < nt; ++k) th.emplace_back([&, k] { f(k, n * k / nt, n * (k + 1) / nt); });
+  f(0, size_t{0}, n / nt);
+  for (auto& t : th) t.join();
+}
+
+struct Bins {
+  uint32_t cnt[3][kMaxBins];
+  Box box[3][kMaxBins];   // primitive boxes per bin
+  Box cen[3][kMaxBins];   // centroid boxes per bin (the children's centroid bounds come out of the same pass)
+  void reset(int nb) {
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < nb; ++b) { cnt[a][b] = 0; box[a][b].reset(); cen[a][b].reset(); }
+  }
+  void merge(const Bins& o, int nb) {
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < nb; ++b) { cnt[a][b] += o.cnt[a][b]; box[a][b].grow(o.box[a][b]); cen[a][b].grow(o.cen[a][b]); }
+  }
+};
+
+struct Task {
+  int32_t node;
+  uint32_t first, count, depth;
+  bool have_bounds;
+  Box nb, cb;   // bounds of the primitives / of their centroids, when the parent's bins already hold them
+};
+
+// Binned-SAH top-down builder.  One pass bins a node's primitives on all three axes at once (boxes AND centroid boxes per bin, so the
+// children's bounds need no pass of their own), one stable partition moves them: `order` stays sorted by face id inside every node,
+// whatever the number of threads.  Large nodes are processed one at a time with the passes spread over the threads; subtrees below
+// `grain` primitives are handed out whole.
 struct Builder {
   const std::vector<Prim>& prims;
   std::vector<uint32_t>& order;
   std::vector<Node2> nodes;
-
   uint32_t max_leaf;
+  int nthreads;
+  uint32_t height_fallbacks = 0;   // median splits forced by the height budget (0 on every mesh of the test-suite's benchmarks)
 
-  Builder(const std::vector<Prim>& p, std::vector<uint32_t>& o, uint32_t ml) : prims(p), order(o), max_leaf(ml) {}
+  Builder(const std::vector<Prim>& p, std::vector<uint32_t>& o, uint32_t ml, int nt) : prims(p), order(o), max_leaf(ml), nthreads(nt) {}
 
-  int bin_of(float c, float cmin, float scale) const {
+  static int bin_of(float c, float cmin, float scale) {
     int b = static_cast<int>((c - cmin) * scale);
     return std::min(kBins - 1, std::max(0, b));
   }
+  // primitives a subtree of height h can hold
+  uint64_t cap(uint32_t h) const { return h >= 40 ? ~uint64_t{0} : static_cast<uint64_t>(max_leaf) << h; }
 
-  // iterative top-down build
-  void build() {
-    struct Task { int32_t node; uint32_t first, count; };
-    nodes.reserve(order.size() * 2);
-    nodes.emplace_back();
-    std::vector<Task> stack;
-    stack.push_back({0, 0, static_cast<uint32_t>(order.size())});
-    while (!stack.empty()) {
-      const Task t = stack.back();
-      stack.pop_back();
-      Box nb, cb;
-      nb.reset(); cb.reset();
-      for (uint32_t i = t.first; i < t.first + t.count; ++i) {
-        const Prim& p = prims[order[i]];
-        nb.grow(p.b);
-        cb.grow(p.c);
+  void bounds_of(uint32_t first, uint32_t count, Box& nb, Box& cb, int nt) const {
+    std::vector<Box> pn(nt), pc(nt);
+    parallel_chunks(count, nt, [&](int k, size_t a, size_t b) {
+      Box n, c;
+      n.reset(); c.reset();
+      for (size_t i = first + a; i < first + b; ++i) { const Prim& p = prims[order[i]]; n.grow(p.b); c.grow(p.c); }
+      pn[k] = n; pc[k] = c;
+    });
+    nb = pn[0]; cb = pc[0];
+    for (int k = 1; k < nt; ++k) { nb.grow(pn[k]); cb.grow(pc[k]); }
+  }
+
+  // splits one node: fills nodes[t.node], partitions order[first, first+count), returns false for a leaf, else the two child tasks
+  // (their node indices are NOT assigned here).  `tmp` is scratch of >= count entries, `nt` the threads this call may use.
+  bool split(const Task& t_in, Task& lt, Task& rt, uint32_t* tmp, int nt, Node2& node, uint32_t& fallbacks) {
+    Task t = t_in;
+    if (!t.have_bounds) bounds_of(t.first, t.count, t.nb, t.cb, nt);
+    node.b = t.nb;
+    node.first = t.first;
+    node.count = t.count;
+    if (t.count <= max_leaf) return false;
+    const Box& cb = t.cb;
+    float scale[3];
+    bool use[3];
+    for (int a = 0; a < 3; ++a) {
+      const float ext = cb.mx[a] - cb.mn[a];
+      use[a] = ext > 0.f;
+      scale[a] = use[a] ? static_cast<float>(kBins) / ext : 0.f;
+    }
+    int best_axis = -1, best_bin = -1;
+    Bins bins;
+    if (use[0] || use[1] || use[2]) {
+      std::vector<Bins> part(nt > 1 ? nt : 0);
+      bins.reset(kBins);
+      auto bin_range = [&](Bins& B, size_t a, size_t b) {
+        for (size_t i = t.first + a; i < t.first + b; ++i) {
+          const Prim& p = prims[order[i]];
+          for (int ax = 0; ax < 3; ++ax) {
+            if (!use[ax]) continue;
+            const int k = bin_of(p.c[ax], cb.mn[ax], scale[ax]);
+            B.cnt[ax][k]++;
+            B.box[ax][k].grow(p.b);
+            B.cen[ax][k].grow(p.c);
+          }
+        }
+      };
+      if (nt > 1) {
+        parallel_chunks(t.count, nt, [&](int k, size_t a, size_t b) { part[k].reset(kBins); bin_range(part[k], a, b); });
+        for (int k = 0; k < nt; ++k) bins.merge(part[k], kBins);
+      } else {
+        bin_range(bins, 0, t.count);
       }
-      nodes[t.node].b = nb;
-      nodes[t.node].first = t.first;
-      nodes[t.node].count = t.count;
-      if (t.count <= max_leaf) continue;
-      int best_axis = -1, best_bin = -1;
       float best_cost = FLT_MAX;
       for (int axis = 0; axis < 3; ++axis) {
-        const float ext = cb.mx[axis] - cb.mn[axis];
-        if (!(ext > 0.f)) continue;
-        Box bb[kMaxBins];
-        uint32_t bc[kMaxBins];
-        for (int b = 0; b < kBins; ++b) { bb[b].reset(); bc[b] = 0; }
-        const float scale = static_cast<float>(kBins) / ext;
-        for (uint32_t i = t.first; i < t.first + t.count; ++i) {
-          const Prim& p = prims[order[i]];
-          const int b = bin_of(p.c[axis], cb.mn[axis], scale);
-          bc[b]++;
-          bb[b].grow(p.b);
-        }
+        if (!use[axis]) continue;
         float la[kMaxBins - 1], ra[kMaxBins - 1];
         uint32_t lc[kMaxBins - 1], rc[kMaxBins - 1];
         Box acc;
         acc.reset();
         uint32_t c = 0;
-        for (int b = 0; b < kBins - 1; ++b) { acc.grow(bb[b]); c += bc[b]; la[b] = acc.area(); lc[b] = c; }
+        for (int b = 0; b < kBins - 1; ++b) { acc.grow(bins.box[axis][b]); c += bins.cnt[axis][b]; la[b] = acc.area(); lc[b] = c; }
         acc.reset();
         c = 0;
-        for (int b = kBins - 1; b > 0; --b) { acc.grow(bb[b]); c += bc[b]; ra[b - 1] = acc.area(); rc[b - 1] = c; }
+        for (int b = kBins - 1; b > 0; --b) { acc.grow(bins.box[axis][b]); c += bins.cnt[axis][b]; ra[b - 1] = acc.area(); rc[b - 1] = c; }
         for (int b = 0; b < kBins - 1; ++b) {
           if (lc[b] == 0 || rc[b] == 0) continue;
           const float cost = la[b] * static_cast<float>(lc[b]) + ra[b] * static_cast<float>(rc[b]);
           if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
         }
       }
-      uint32_t mid;
-      if (best_axis < 0) {
-        mid = t.first + t.count / 2;
-      } else {
-        const float ext = cb.mx[best_axis] - cb.mn[best_axis];
-        const float scale = static_cast<float>(kBins) / ext;
-        const float cmin = cb.mn[best_axis];
-        auto it = std::partition(order.begin() + t.first, order.begin() + t.first + t.count, [&](uint32_t id) {
-          return bin_of(prims[id].c[best_axis], cmin, scale) <= best_bin;
-        });
-        mid = static_cast<uint32_t>(it - order.begin());
-        if (mid == t.first || mid == t.first + t.count) mid = t.first + t.count / 2;
-      }
-      const int32_t l = static_cast<int32_t>(nodes.size());
-      nodes.emplace_back();
-      nodes.emplace_back();
-      nodes[t.node].left = l;
-      nodes[t.node].right = l + 1;
-      stack.push_back({l + 1, mid, t.first + t.count - mid});
-      stack.push_back({l, t.first, mid - t.first});
     }
+    const uint32_t height_left = kMaxHeight2 - t.depth;   // >= 1 here: count > max_leaf and count <= cap(height_left)
+    uint32_t nl = 0;
+    if (best_axis >= 0) {
+      for (int b = 0; b <= best_bin; ++b) nl += bins.cnt[best_axis][b];
+      const uint64_t child_cap = cap(height_left - 1);
+      if (nl > child_cap || t.count - nl > child_cap) { best_axis = -1; nl = 0; ++fallbacks; }   // height budget: median instead
+      else if (nl == 0 || nl == t.count) { best_axis = -1; nl = 0; }
+    }
+    lt.have_bounds = rt.have_bounds = false;
+    if (best_axis >= 0) {
+      const float cmin = cb.mn[best_axis], sc = scale[best_axis];
+      const int ax = best_axis, bb = best_bin;
+      uint32_t* o = order.data() + t.first;
+      if (nt > 1) {
+        std::vector<uint32_t> lcount(nt + 1, 0);
+        parallel_chunks(t.count, nt, [&](int k, size_t a, size_t b) {
+          uint32_t c = 0;
+          for (size_t i = a; i < b; ++i) c += bin_of(prims[o[i]].c[ax], cmin, sc) <= bb;
+          lcount[k + 1] = c;
+        });
+        for (int k = 0; k < nt; ++k) lcount[k + 1] += lcount[k];
+        parallel_chunks(t.count, nt, [&](int k, size_t a, size_t b) {
+          uint32_t li = lcount[k], ri = nl + static_cast<uint32_t>(a) - lcount[k];
+          for (size_t i = a; i < b; ++i) {
+            const uint32_t id = o[i];
+            if (bin_of(prims[id].c[ax], cmin, sc) <= bb) tmp[li++] = id; else tmp[ri++] = id;
+          }
+        });
+        parallel_chunks(t.count, nt, [&](int, size_t a, size_t b) { std::memcpy(o + a, tmp + a, (b - a) * sizeof(uint32_t)); });
+      } else {
+        uint32_t li = 0, ri = 0;
+        for (uint32_t i = 0; i < t.count; ++i) {
+          const uint32_t id = o[i];
+          if (bin_of(prims[id].c[ax], cmin, sc) <= bb) o[li++] = id; else tmp[ri++] = id;
+        }
+        std::memcpy(o + li, tmp, ri * sizeof(uint32_t));
+      }
+      lt.nb.reset(); lt.cb.reset(); rt.nb.reset(); rt.cb.reset();
+      for (int b = 0; b < kBins; ++b) {
+        Task& side = b <= best_bin ? lt : rt;
+        if (bins.cnt[ax][b] == 0) continue;
+        side.nb.grow(bins.box[ax][b]);
+        side.cb.grow(bins.cen[ax][b]);
+      }
+      lt.have_bounds = rt.have_bounds = true;
+    } else {
+      // no SAH split (all centroids coincide: halve the face-id order) or the height budget refused it (object median on the
+      // widest centroid axis, ties by face id: the set of the lower half is unique, so the split does not depend on the input order)
+      nl = t.count - t.count / 2;
+      int ax = 0;
+      float ext = -1.f;
+      for (int a = 0; a < 3; ++a) if (cb.mx[a] - cb.mn[a] > ext) { ext = cb.mx[a] - cb.mn[a]; ax = a; }
+      if (ext > 0.f) {
+        uint32_t* o = order.data() + t.first;
+        auto less = [&](uint32_t x, uint32_t y) {
+          const float cx = prims[x].c[ax], cy = prims[y].c[ax];
+          return cx < cy || (cx == cy && x < y);
+        };
+        std::nth_element(o, o + nl, o + t.count, less);
+        std::sort(o, o + nl);               // back to face-id order inside each half
+        std::sort(o + nl, o + t.count);
+      } else {
+        nl = t.count / 2;                    // (the split rule of rounds 1-4 for coincident centroids)
+      }
+    }
+    lt.first = t.first; lt.count = nl; lt.depth = t.depth + 1;
+    rt.first = t.first + nl; rt.count = t.count - nl; rt.depth = t.depth + 1;
+    return true;
+  }
+
+  void build() {
+    const uint32_t n = static_cast<uint32_t>(order.size());
+    const uint32_t grain = nthreads > 1 ? std::max<uint32_t>(4096u, n / (static_cast<uint32_t>(nthreads) * 16u)) : 0xFFFFFFFFu;
+    std::vector<uint32_t> tmp(nthreads > 1 ? n : 0);
+    nodes.clear();
+    nodes.emplace_back();
+    Task root{};
+    root.node = 0; root.first = 0; root.count = n; root.depth = 0; root.have_bounds = false;
+    PhaseTimer pa;
+    // phase A: nodes above the grain, one at a time, every pass spread over the threads
+    std::vector<Task> big{root}, small;
+    if (n <= grain) { small.swap(big); }
+    while (!big.empty()) {
+      const Task t = big.back();
+      big.pop_back();
+      Task lt, rt;
+      Node2 nd;
+      if (!split(t, lt, rt, tmp.data(), nthreads, nd, height_fallbacks)) { nodes[t.node] = nd; continue; }
+      const int32_t l = static_cast<int32_t>(nodes.size());
+      nd.left = l; nd.right = l + 1;
+      nodes[t.node] = nd;
+      nodes.emplace_back();
+      nodes.emplace_back();
+      lt.node = l; rt.node = l + 1;
+      (rt.count > grain ? big : small).push_back(rt);
+      (lt.count > grain ? big : small).push_back(lt);
+    }
+    pa.mark("  phase A (large nodes)");
+    PhaseTimer pt;
+    // phase B: whole subtrees, one thread each, into local node arrays (local index 0 = the subtree's root, which already has a slot)
+    std::sort(small.begin(), small.end(), [](const Task& a, const Task& b) { return a.count != b.count ? a.count > b.count : a.first < b.first; });
+    std::vector<std::vector<Node2>> local(small.size());
+    std::vector<uint32_t> fb(small.size(), 0);
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+      std::vector<uint32_t> scratch;
+      std::vector<Task> stack;
+      for (;;) {
+        const size_t k = next.fetch_add(1);
+        if (k >= small.size()) break;
+        std::vector<Node2>& ln = local[k];
+        ln.reserve(2 * static_cast<size_t>(small[k].count) / std::max(1u, max_leaf) + 2);
+        if (scratch.size() < small[k].count) scratch.resize(small[k].count);
+        ln.emplace_back();
+        Task r = small[k];
+        r.node = 0;
+        stack.assign(1, r);
+        while (!stack.empty()) {
+          const Task t = stack.back();
+          stack.pop_back();
+          Task lt, rt;
+          Node2 nd;
+          if (!split(t, lt, rt, scratch.data(), 1, nd, fb[k])) { ln[t.node] = nd; continue; }
+          const int32_t l = static_cast<int32_t>(ln.size());
+          nd.left = l; nd.right = l + 1;
+          ln[t.node] = nd;
+          ln.emplace_back();
+          ln.emplace_back();
+          lt.node = l; rt.node = l + 1;
+          stack.push_back(rt);
+          stack.push_back(lt);
+        }
+      }
+    };
+    {
+      const int nt = static_cast<int>(std::min<size_t>(nthreads, small.size()));
+      std::vector<std::thread> th;
+      for (int k = 1; k < nt; ++k) th.emplace_back(worker);
+      worker();
+      for (auto& t : th) t.join();
+    }
+    pt.mark("  phase B (subtrees)");
+    // splice: subtree k's local nodes 1.. go to [off[k], ...) of the global array
+    std::vector<size_t> off(small.size() + 1, nodes.size());
+    for (size_t k = 0; k < small.size(); ++k) off[k + 1] = off[k] + local[k].size() - 1;
+    nodes.resize(off[small.size()]);
+    parallel_chunks(small.size(), nthreads, [&](int, size_t a, size_t b) {
+      for (size_t k = a; k < b; ++k) {
+        const std::vector<Node2>& ln = local[k];
+        const int32_t shift = static_cast<int32_t>(off[k]) - 1;
+        for (size_t i = 0; i < ln.size(); ++i) {
+          Node2 nd = ln[i];
+          if (!nd.leaf()) { nd.left += shift; nd.right += shift; }
+          nodes[i == 0 ? static_cast<size_t>(small[k].node) : off[k] + i - 1] = nd;
+        }
+      }
+    });
+    for (uint32_t f : fb) height_fallbacks += f;
+    pt.mark("  splice");
   }
 };
 
@@ -150,16 +390,70 @@ inline void cross_fma(const float* a, const float* b, float* r) {
 struct Collapsed {
   std::vector<Node4> nodes;
   uint32_t max_depth = 0, stack_need = 0;
+  uint32_t guarded = 0;   // nodes expanded tallest-first to keep stack_need <= kStackEntries
 };
 
-Collapsed collapse(const std::vector<Node2>& n2, uint32_t leaf_limit, float pad) {
+// `guard` (collapse_guard below) is null for the plain collapse: children are expanded largest-area first, the rule of rounds 1-4.
+// With a guard, a node whose area-first subtree would need more than kStackEntries stack entries expands tallest-first instead:
+// both children of a BVH2 node of height h have height <= h-1, and expanding the taller one first leaves four grandchildren of
+// height <= h-2, so from a node that holds `s` entries the descent needs <= s + 3 * ceil(h / 2).
+struct CollapseGuard {
+  std::vector<uint8_t> height;    // of every BVH2 node in THIS cut (0 = leaf of the cut)
+  std::vector<uint8_t> area_need; // stack entries below a BVH4 node rooted here under area-first expansion (saturating at 255)
+};
+
+// `before(a, b)`: inner child a is expanded rather than b (a strict order; among equals the first slot wins)
+template <class IsLeaf, class Before>
+static int expand_children(const std::vector<Node2>& n2, int32_t root, IsLeaf is_leaf, Before before, int32_t kids[4]) {
+  int nk = 0;
+  if (is_leaf(root)) { kids[nk++] = root; return nk; }
+  kids[nk++] = n2[root].left;
+  kids[nk++] = n2[root].right;
+  while (nk < 4) {
+    int best = -1;
+    for (int i = 0; i < nk; ++i) {
+      if (is_leaf(kids[i])) continue;
+      if (best < 0 || before(kids[i], kids[best])) best = i;
+    }
+    if (best < 0) break;
+    const int32_t k = kids[best];
+    kids[best] = n2[k].left;
+    kids[nk++] = n2[k].right;
+  }
+  return nk;
+}
+
+static CollapseGuard collapse_guard(const std::vector<Node2>& n2, uint32_t leaf_limit) {
+  CollapseGuard g;
+  g.height.assign(n2.size(), 0);
+  g.area_need.assign(n2.size(), 0);
+  auto is_leaf = [&](int32_t id) { return n2[id].leaf() || n2[id].count <= leaf_limit; };
+  auto area = [&](int32_t a, int32_t b) { return n2[a].b.area() > n2[b].b.area(); };
+  for (size_t i = n2.size(); i-- > 0;) {   // children have larger indices than their parents
+    const int32_t id = static_cast<int32_t>(i);
+    if (is_leaf(id)) continue;
+    g.height[i] = static_cast<uint8_t>(1 + std::max(g.height[n2[i].left], g.height[n2[i].right]));
+    int32_t kids[4];
+    const int nk = expand_children(n2, id, is_leaf, area, kids);
+    uint32_t below = 0;
+    for (int k = 0; k < nk; ++k) below = std::max<uint32_t>(below, g.area_need[kids[k]]);
+    g.area_need[i] = static_cast<uint8_t>(std::min<uint32_t>(255u, below + static_cast<uint32_t>(nk - 1)));
+  }
+  return g;
+}
+
+Collapsed collapse(const std::vector<Node2>& n2, uint32_t leaf_limit, float pad, const CollapseGuard* guard = nullptr) {
   Collapsed out;
   auto is_leaf = [&](int32_t id) { return n2[id].leaf() || n2[id].count <= leaf_limit; };
+  auto area = [&](int32_t a, int32_t b) { return n2[a].b.area() > n2[b].b.area(); };
   struct QItem { int32_t n2; uint32_t depth; uint32_t stack_before; };
   std::deque<QItem> queue;
   // the root is always an inner Node4, even for tiny meshes
   queue.push_back({0, 1, 0});
   std::vector<std::pair<uint32_t, int>> patch;  // (node4 index, slot) -> child n2 id to resolve later
+  // every Node4 but a leaf-only root absorbs at least one inner BVH2 node: no reallocation while the tree grows
+  out.nodes.reserve(n2.size() / 2 + 2);
+  patch.reserve(n2.size() / 2 + 2);
 
   // first pass: assign Node4 ids in BFS order
   while (!queue.empty()) {
@@ -172,25 +466,15 @@ Collapsed collapse(const std::vector<Node2>& n2, uint32_t leaf_limit, float pad)
     out.max_depth = std::max(out.max_depth, it.depth);
 
     int32_t kids[4];
-    int nk = 0;
-    if (is_leaf(it.n2)) {
-      kids[nk++] = it.n2;
+    int nk;
+    if (guard && it.stack_before + guard->area_need[it.n2] > kStackEntries - 1) {
+      // tallest first; equal heights by area, so the choice stays a function of the tree alone
+      nk = expand_children(n2, it.n2, is_leaf, [&](int32_t a, int32_t b) {
+        return guard->height[a] != guard->height[b] ? guard->height[a] > guard->height[b] : area(a, b);
+      }, kids);
+      ++out.guarded;
     } else {
-      kids[nk++] = n2[it.n2].left;
-      kids[nk++] = n2[it.n2].right;
-      while (nk < 4) {
-        int best = -1;
-        float best_area = -1.f;
-        for (int i = 0; i < nk; ++i) {
-          if (is_leaf(kids[i])) continue;
-          const float a = n2[kids[i]].b.area();
-          if (a > best_area) { best_area = a; best = i; }
-        }
-        if (best < 0) break;
-        const int32_t k = kids[best];
-        kids[best] = n2[k].left;
-        kids[nk++] = n2[k].right;
-      }
+      nk = expand_children(n2, it.n2, is_leaf, area, kids);
     }
     const uint32_t stack_here = it.stack_before + static_cast<uint32_t>(nk - 1);
     out.stack_need = std::max(out.stack_need, stack_here);
@@ -226,9 +510,10 @@ Collapsed collapse(const std::vector<Node2>& n2, uint32_t leaf_limit, float pad)
 
 // quantised twins (layout.h): per node, corner + step of an 8-bit grid that covers all (padded) child boxes; lower
 // planes round down, upper planes up, checked in the arithmetic the decode uses
-void quantise(const std::vector<Node4>& nodes, std::vector<Node4Q>& qnodes) {
+void quantise(const std::vector<Node4>& nodes, std::vector<Node4Q>& qnodes, int nt) {
   qnodes.resize(nodes.size());
-  for (size_t i = 0; i < nodes.size(); ++i) {
+  parallel_chunks(nodes.size(), nt, [&](int, size_t lo_i, size_t hi_i) {
+  for (size_t i = lo_i; i < hi_i; ++i) {
     const Node4& nd = nodes[i];
     Node4Q& q = qnodes[i];
     std::memset(&q, 0, sizeof(q));
@@ -264,6 +549,7 @@ void quantise(const std::vector<Node4>& nodes, std::vector<Node4Q>& qnodes) {
     }
     for (int c = 0; c < 4; ++c) q.child[c] = nd.child[c];
   }
+  });
 }
 
 }  // namespace
@@ -273,45 +559,52 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
   if (nf == 0 || nv == 0) return "empty mesh";
   if (nf > 0x0FFFFFFFu) return "too many faces (max 2^28-1)";
   if (max_leaf < 1 || max_leaf > kMaxLeafTris) return "max_leaf must be 1..4";
-  for (uint32_t i = 0; i < 3u * nf; ++i)
-    if (faces[i] >= nv) return "face index out of range";
-  for (size_t i = 0; i < 3 * static_cast<size_t>(nv); ++i)
-    if (!std::isfinite(verts[i])) return "non-finite vertex coordinate";
+  const int nt = build_threads();
+  PhaseTimer timer;
+  {
+    std::atomic<int> bad{0};
+    parallel_chunks(3 * static_cast<size_t>(nf), nt, [&](int, size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; ++i)
+        if (faces[i] >= nv) { bad.fetch_or(1); return; }
+    });
+    parallel_chunks(3 * static_cast<size_t>(nv), nt, [&](int, size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; ++i)
+        if (!std::isfinite(verts[i])) { bad.fetch_or(2); return; }
+    });
+    if (bad.load() & 1) return "face index out of range";
+    if (bad.load() & 2) return "non-finite vertex coordinate";
+  }
 
-  // triangle records (by face id) + primitive boxes
-  std::vector<TriRec> recs(nf);
+  // primitive boxes (by face id)
   std::vector<Prim> prims(nf);
   Box scene;
   scene.reset();
-  for (uint32_t f = 0; f < nf; ++f) {
-    const float* a = verts + 3 * static_cast<size_t>(faces[3 * f + 0]);
-    const float* b = verts + 3 * static_cast<size_t>(faces[3 * f + 1]);
-    const float* c = verts + 3 * static_cast<size_t>(faces[3 * f + 2]);
-    TriRec& r = recs[f];
-    for (int k = 0; k < 3; ++k) {
-      r.v0[k] = a[k];
-      r.e1[k] = a[k] - b[k];
-      r.e2[k] = c[k] - a[k];
-    }
-    cross_fma(r.e2, r.e1, r.Ng);
-    const float d = std::sqrt((r.Ng[0] * r.Ng[0] + r.Ng[1] * r.Ng[1]) + r.Ng[2] * r.Ng[2]);
-    for (int k = 0; k < 3; ++k) r.n[k] = (d > 0.f) ? r.Ng[k] / d : 0.f;
-    r.face_id = f;
-    Prim& p = prims[f];
-    p.b.reset();
-    p.b.grow(a);
-    p.b.grow(b);
-    p.b.grow(c);
-    for (int k = 0; k < 3; ++k) p.c[k] = 0.5f * (p.b.mn[k] + p.b.mx[k]);
-    scene.grow(p.b);
+  {
+    std::vector<Box> part(nt);
+    parallel_chunks(nf, nt, [&](int k, size_t lo, size_t hi) {
+      Box sb;
+      sb.reset();
+      for (size_t f = lo; f < hi; ++f) {
+        Prim& p = prims[f];
+        p.b.reset();
+        for (int c = 0; c < 3; ++c) p.b.grow(verts + 3 * static_cast<size_t>(faces[3 * f + c]));
+        for (int c = 0; c < 3; ++c) p.c[c] = 0.5f * (p.b.mn[c] + p.b.mx[c]);
+        sb.grow(p.b);
+      }
+      part[k] = sb;
+    });
+    for (int k = 0; k < nt; ++k) scene.grow(part[k]);
   }
 
+  timer.mark("validate + primitive boxes");
   // ONE BVH2, split down to the smallest leaf size any tree of the map uses
   std::vector<uint32_t> order(nf);
   for (uint32_t f = 0; f < nf; ++f) order[f] = f;
-  Builder bld(prims, order, std::min(max_leaf, kPfLeafTris));
+  Builder bld(prims, order, std::min(max_leaf, kPfLeafTris), nt);
   bld.build();
   const std::vector<Node2>& n2 = bld.nodes;
+  std::vector<Prim>().swap(prims);
+  timer.mark("BVH2 (binned SAH)");
 
   // conservative padding of every stored box: the slab test runs in fp32 with fused ops and must
   // never cull a box whose triangle the (exact-spec) intersector would accept.
@@ -322,20 +615,58 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
   }
   const float pad = 1e-4f * std::max(diag, amax) + 1e-6f;
 
+  // triangle records, written in leaf order
   out.tris.resize(nf);
-  for (uint32_t i = 0; i < nf; ++i) out.tris[i] = recs[order[i]];
+  parallel_chunks(nf, nt, [&](int, size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) {
+      const uint32_t f = order[i];
+      const float* a = verts + 3 * static_cast<size_t>(faces[3 * static_cast<size_t>(f) + 0]);
+      const float* b = verts + 3 * static_cast<size_t>(faces[3 * static_cast<size_t>(f) + 1]);
+      const float* c = verts + 3 * static_cast<size_t>(faces[3 * static_cast<size_t>(f) + 2]);
+      TriRec& r = out.tris[i];
+      for (int k = 0; k < 3; ++k) {
+        r.v0[k] = a[k];
+        r.e1[k] = a[k] - b[k];
+        r.e2[k] = c[k] - a[k];
+      }
+      cross_fma(r.e2, r.e1, r.Ng);
+      const float d = std::sqrt((r.Ng[0] * r.Ng[0] + r.Ng[1] * r.Ng[1]) + r.Ng[2] * r.Ng[2]);
+      for (int k = 0; k < 3; ++k) r.n[k] = (d > 0.f) ? r.Ng[k] / d : 0.f;
+      r.face_id = f;
+    }
+  });
 
-  // the map's tree: leaves of <= max_leaf records
-  Collapsed main_tree = collapse(n2, max_leaf, pad);
+  timer.mark("triangle records");
+  // The two cuts of the BVH2 (collapsed concurrently): the map's tree, leaves of <= max_leaf records, and the particle filter's tree
+  // (quantised nodes only), leaves of <= kPfLeafTris records over the same record array.  The filter's rays are incoherent and its
+  // kernel is bound by instruction issue with the lanes of a wave taking turns through the triangle loop: shorter leaves trade a
+  // few more (cheap, quantised) node steps for fewer loop trips.
+  // A cut whose area-first collapse would need more than kStackEntries stack entries is collapsed again under the guard (tallest
+  // child first where the budget is short): stack_need <= kStackEntries holds for every mesh, map_upload only asserts it.
+  auto collapse_bounded = [&](uint32_t leaf_limit) {
+    Collapsed t = collapse(n2, leaf_limit, pad);
+    if (t.stack_need > kStackEntries) {
+      const CollapseGuard g = collapse_guard(n2, leaf_limit);
+      t = collapse(n2, leaf_limit, pad, &g);
+    }
+    return t;
+  };
+  Collapsed main_tree, pf_tree;
+  const bool own_pf_tree = max_leaf > kPfLeafTris;
+  {
+    std::thread side;
+    if (own_pf_tree && nt > 1) side = std::thread([&] { pf_tree = collapse_bounded(kPfLeafTris); });
+    main_tree = collapse_bounded(max_leaf);
+    if (side.joinable()) side.join();
+    else if (own_pf_tree) pf_tree = collapse_bounded(kPfLeafTris);
+  }
+  timer.mark("collapse (both cuts)");
   out.nodes = std::move(main_tree.nodes);
-  quantise(out.nodes, out.qnodes);
-
-  // the particle filter's tree (quantised nodes only): leaves of <= kPfLeafTris records, same record array.  The
-  // filter's rays are incoherent and its kernel is bound by instruction issue with the lanes of a wave taking turns
-  // through the triangle loop: shorter leaves trade a few more (cheap, quantised) node steps for fewer loop trips.
-  if (max_leaf > kPfLeafTris) {
-    Collapsed pf_tree = collapse(n2, kPfLeafTris, pad);
-    quantise(pf_tree.nodes, out.qnodes_pf);
+  quantise(out.nodes, out.qnodes, nt);
+  out.info.height_fallbacks = bld.height_fallbacks;
+  out.info.guarded_nodes = main_tree.guarded + pf_tree.guarded;
+  if (own_pf_tree) {
+    quantise(pf_tree.nodes, out.qnodes_pf, nt);
     out.info.n_nodes_pf = static_cast<uint32_t>(pf_tree.nodes.size());
     out.info.max_depth_pf = pf_tree.max_depth;
     out.info.stack_need_pf = pf_tree.stack_need;
@@ -370,13 +701,15 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
       }
     }
   };
+  timer.mark("quantise");
   frontier_of(out.nodes, out.frontier);
   // ... and of the filter's tree: the batch traversal of find (kind 24) walks that tree (round 3: its two-triangle leaves make the
   // per-lane triangle loop 6-10 % cheaper for pose batches), whose node indices differ from the map tree's below the top levels
   frontier_of(out.nodes_pf, out.frontier_pf);
 
   out.cnodes.resize(out.nodes.size());
-  for (size_t i = 0; i < out.nodes.size(); ++i) {
+  parallel_chunks(out.nodes.size(), nt, [&](int, size_t lo_i, size_t hi_i) {
+  for (size_t i = lo_i; i < hi_i; ++i) {
     const Node4& nd = out.nodes[i];
     Node4C& cn = out.cnodes[i];
     for (int c = 0; c < 4; ++c) {
@@ -386,7 +719,9 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
       cn.c[c].pad = 0;
     }
   }
+  });
 
+  timer.mark("frontier, child-major twins");
   out.info.n_faces = nf;
   out.info.n_vertices = nv;
   out.info.n_nodes = static_cast<uint32_t>(out.nodes.size());

@@ -16,6 +16,9 @@ struct BvhInfo {
   uint32_t n_nodes_pf = 0, max_depth_pf = 0, stack_need_pf = 0;  // the particle filter's tree (leaves <= kPfLeafTris)
   float bbox_min[3] = {0, 0, 0}, bbox_max[3] = {0, 0, 0};
   float pad = 0.f;
+  // round 5: how often the stack bound had to be enforced (0 on ordinary meshes): object-median splits the height budget of the BVH2
+  // forced, and BVH4 nodes expanded tallest-child-first; stack_need <= 64 holds for every mesh by construction
+  uint32_t height_fallbacks = 0, guarded_nodes = 0;
 };
 
 struct BvhHost {

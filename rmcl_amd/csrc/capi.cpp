@@ -277,6 +277,8 @@ struct rmclhip_rcc {
   // rule), and whether its rays start at the frontier (kinds 23 / 24 without it are round 2's kinds 19 / 22)
   int tuned_kind = 0, tuned_batch_kind = 0;
   int tuned_tile = 0;              // 1 + log2(tile width) measured best by rmclhip_rcc_autotune (0 = the rule's shape)
+  int last_moment_find_kind = 0;   // what enqueue_find_with_moments launched last (it may replace the rule's 24 by 23) ...
+  bool last_moment_find_tiled = false;   // ... and whether it left one moment row per workgroup (epilogue) or per 1024 elements (pass)
   bool tuned_frontier = true, tuned_batch_frontier = true;
   DevBuf<float> d_tile_planes;     // plane table of the frontier start for the current (model, tiling): 16 floats per tile
   bool tile_planes_ok = false;
@@ -338,7 +340,7 @@ struct rmclhip_pf {
   float* errors_dev = nullptr;
   int variant = 0;
   uint32_t refill_thr = 0, tail_lanes = 8;  // schedule knobs of the round-3 kernel (0: from `refill`); rmclhip_pf_set_schedule
-  // rmclhip_pf_set_mapping: 0 beam-minor blocks of ~2048 rays (uniform clouds), 1 particle-minor blocks (converged clouds), 2 automatic
+  // rmclhip_pf_set_mapping: 0 beam-minor blocks of ~2048 rays (default), 1 particle-minor blocks (measured neutral, kept for A/B); nothing else is accepted
   bool cpc_grid = true;            // correspondence_type 1: seed every closest-point query from the map's near grid (A/B: rmclhip_pf_set_mapping bit 8 clears it)
   ChainTag tag;                    // completion tag of the synchronous kernel-only calls (update, motion update, extract_weights)
   bool evals_global = true;        // k_pf_update_v3 keeps a workgroup's beam errors in global scratch, not LDS (A/B: rmclhip_pf_set_mapping bit 9 clears it)
@@ -428,6 +430,8 @@ static void fill_info(const BvhInfo& bi, uint64_t bytes, rmclhip_map_info* out) 
   out->stack_need = bi.stack_need;
   out->device_bytes = bytes;
   for (int k = 0; k < 3; ++k) { out->bbox_min[k] = bi.bbox_min[k]; out->bbox_max[k] = bi.bbox_max[k]; }
+  out->height_fallbacks = bi.height_fallbacks;
+  out->guarded_nodes = bi.guarded_nodes;
 }
 
 rmclhip_status rmclhip_bvh_build_host(const float* v, uint32_t nv, const uint32_t* f, uint32_t nf,
@@ -502,8 +506,10 @@ rmclhip_status rmclhip_map_create(rmclhip_ctx* ctx, const float* v, uint32_t nv,
 
 // device copy of a built BVH (one build can serve several devices: rmclhip_pf_sharded_create)
 static rmclhip_status map_upload(rmclhip_ctx* ctx, const BvhHost& bvh, rmclhip_map** out) {
+  // an assertion since round 5: build_bvh bounds the height of the binary tree and collapses tallest-first where needed, so no mesh
+  // can produce a deeper stack (bvh_build.cpp: kMaxHeight2)
   if (bvh.info.stack_need > 64 || bvh.info.stack_need_pf > 64)
-    return fail(RMCLHIP_ERR_UNSUPPORTED, "map_create: BVH needs a traversal stack deeper than 64 entries");
+    return fail(RMCLHIP_ERR_INVALID, "map_create: internal error, the BVH builder exceeded its own 64-entry stack bound");
   if (static_cast<uint64_t>(bvh.nodes.size()) * sizeof(Node4) >= (1ull << 32))
     return fail(RMCLHIP_ERR_UNSUPPORTED, "map_create: node array exceeds 4 GB (the kernels address nodes with 32-bit byte offsets)");
   HIPCHK(hipSetDevice(ctx->device));
@@ -1107,7 +1113,11 @@ static int find_variant(const rmclhip_rcc* r, uint32_t nposes) {
   return 24;                       // quantised nodes of the filter's tree, 16 LDS rows, leaf trigger
 }
 
-static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
+// `kind`: the traversal the caller is about to launch when it is not the automatic rule's (enqueue_find_with_moments replaces 24 by
+// 23); tree, frontier table, tile shape and pre-load bound all follow THAT kind (the tables of the filter's tree under a
+// walk of the map's tree start rays at wrong nodes)
+static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes, int kind = -1) {
+  const int v = kind >= 0 ? kind : find_variant(r, nposes);
   std::memset(&p, 0, sizeof(p));
   p.nodes = r->map->d_nodes;
   p.qnodes = r->map->d_qnodes;
@@ -1125,8 +1135,7 @@ static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
   p.model_tab = r->d_model_tab.p;
   p.W = r->W; p.H = r->H;
   p.tile_w_log2 = (r->tile_override > 0) ? static_cast<uint32_t>(r->tile_override - 1)
-                  : ((r->tuned_tile > 0 && find_variant(r, nposes) != 0) ? static_cast<uint32_t>(r->tuned_tile - 1)
-                                                                         : pick_tile_w_log2(r->H, find_variant(r, nposes) == 0, r->ang_aspect));
+                  : ((r->tuned_tile > 0 && v != 0) ? static_cast<uint32_t>(r->tuned_tile - 1) : pick_tile_w_log2(r->H, v == 0, r->ang_aspect));
   const uint32_t tw = 1u << p.tile_w_log2, th = 64u >> p.tile_w_log2;
   p.tiles_x = (r->W + tw - 1) / tw;
   p.tiles_y = (r->H + th - 1) / th;
@@ -1141,7 +1150,6 @@ static void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t nposes) {
     // kind 24 (and its frontier-less twin 22: rays on the quantised nodes, triangles in a per-lane loop) walks the FILTER's tree --
     // the same BVH2 cut at leaves of <= 2 instead of <= 4 triangles, the same record array (layout.h): pose batches 6-10 % faster
     // (profiles/r03_find_variants_ab.txt).  That tree has its own node numbering, hence its own frontier table.
-    const int v = find_variant(r, nposes);
     uint32_t need = r->map->info.stack_need;
     if ((v == 24 || v == 22) && r->map->d_qnodes_pf != nullptr) {
       p.qnodes = r->map->d_qnodes_pf;
@@ -1564,6 +1572,7 @@ static hipError_t wait_moments(rmclhip_rcc* r, uint32_t seq, float lo, float hi,
     return x;
   };
   hipError_t e = hipSuccess;
+  bool unverified = false;
   if (r->ctx->wait_block.load(std::memory_order_relaxed)) e = hipStreamSynchronize(r->stream);
   else {
     const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
@@ -1577,11 +1586,20 @@ static hipError_t wait_moments(rmclhip_rcc* r, uint32_t seq, float lo, float hi,
 #if defined(__x86_64__) || defined(__i386__)
       __builtin_ia32_pause();
 #endif
-      if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() > t_end) { e = hipStreamSynchronize(r->stream); break; }
+      if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() > t_end) {
+        // 20 ms without this sequence number: either the device is that slow, or a later launch of this handle has already
+        // replaced the tag (h_done is shared by every tagged launch).  Drain the stream, then accept the block only if the tag
+        // still is this publish's and its sum matches; otherwise the caller takes the streaming reduction
+        e = hipStreamSynchronize(r->stream);
+        const unsigned long long t2 = *tag;
+        std::atomic_thread_fence(std::memory_order_acquire);
+        unverified = !(static_cast<uint32_t>(t2) == seq && block_sum() == static_cast<uint32_t>(t2 >> 32));
+        break;
+      }
     }
   }
   r->mset_pending = false;
-  if (e != hipSuccess) { r->mset.valid = false; return e; }
+  if (e != hipSuccess || unverified) { r->mset.valid = false; return e; }
   MicpMomentSet& ms = r->mset;
   std::memcpy(ms.mom, hb->mom, sizeof(ms.mom));
   ms.gate_lo = lo; ms.gate_hi = hi; ms.rho_cap = rho_cap; ms.tau_cap = tau_cap;
@@ -1604,14 +1622,16 @@ static inline void learn_caps(rmclhip_rcc* r, float max_rho, float max_tau) {
 static rmclhip_status enqueue_find_with_moments(rmclhip_rcc* r, const xform& Tsm, float lo, float hi, float rho_cap, float tau_cap, uint32_t seq,
                                                 bool epilogue_allowed) {
   const uint32_t nred = (r->n_dataset < r->n_model) ? r->n_dataset : r->n_model;
-  FindParams fp;
-  fill_find_params(r, fp, 1);
-  fp.Tsm = Tsm;
-  fp.Tms = xinv(Tsm);
   int fv = find_variant(r, 1);
   // scans above 262 144 rays would take kind 24, which has no moment epilogue: the separate moment pass over half a million
   // correspondences costs more (~40 us) than kind 23 loses against kind 24 there (~3 us) -- a correction of a 256 x 2048 scan 93 -> 6x us
   if (epilogue_allowed && fv == 24 && r->variant == 15) fv = 23;
+  FindParams fp;
+  fill_find_params(r, fp, 1, fv);   // the tree and tables of the kind that RUNS
+  fp.Tsm = Tsm;
+  fp.Tms = xinv(Tsm);
+  r->last_moment_find_kind = fv;
+  r->last_moment_find_tiled = epilogue_allowed && (fv == 23 || fv == 2);
   if (epilogue_allowed && (fv == 23 || fv == 2)) {
     const uint32_t nb = find_moments_blocks(fp, fv), wpb = (fv == 2) ? 1u : 4u;   // mask words per workgroup
     HIPCHK(r->d_fast_partials.reserve(static_cast<size_t>(nb) * kMicpFastMoments));
@@ -1854,9 +1874,15 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
             // the publish launch used this one for its hand-over flags and its tag)
             device_loop = true;
             cl.seq = r->h_call->seq = next_seq(r);
-            if (tiled)
+            // kind and row layout are the ones enqueue_find_with_moments actually ran (it replaces kind 24 by 23 to get the epilogue):
+            // the loop folds THOSE rows instead of paying a moment pass of its own
+            const int ufv = r->last_moment_find_kind;
+            FindParams ufp;
+            fill_find_params(r, ufp, 1, ufv);
+            const uint32_t unb = find_moments_blocks(ufp, ufv), uwpb = (ufv == 2) ? 1u : 4u;
+            if (r->last_moment_find_tiled)
               HIPCHK(launch_micp_fast_loop_tiled(r->ds_pts, r->ds_has_mask ? r->ds_msk : nullptr, r->d_points.p, r->d_normals.p, r->d_hits.p,
-                                                 nred, nb, r->d_fast_partials.p, r->d_fast_mask.p, r->W, fp.tiles_x, fp.tile_w_log2, wpb, n_iter,
+                                                 nred, unb, r->d_fast_partials.p, r->d_fast_mask.p, r->W, ufp.tiles_x, ufp.tile_w_log2, uwpb, n_iter,
                                                  r->h_state_dev, r->h_fast_status_dev, r->h_done_dev, r->stream, cl, r->d_fold_rows, r->d_fold_flags));
             else
               HIPCHK(launch_micp_fast(r->ds_pts, r->ds_has_mask ? r->ds_msk : nullptr, r->d_points.p, r->d_normals.p, r->d_hits.p, nred,
@@ -2223,7 +2249,7 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
     }
     // not served on the host: the device forms take over, from scratch (the moment sets belong to finds that are about to be redone).
     // A pre-transform that left its caps would leave them in the device's moment loop as well: straight to the per-iteration form,
-    // whose end learns the caps from this status; too many undecided correspondences for the host (> 256 in a sensor): the device's
+    // whose end learns the caps from this status; too many undecided correspondences for the host (> kMicpHostMaxUnc = 1024 in a sensor): the device's
     // moment loop takes up to 4096.
     if (hs.code == 1u) {
       device_fast = false;

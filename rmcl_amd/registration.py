@@ -553,7 +553,9 @@ class ShardedCorrectorHip:
         for r in range(len(devices)):
             h = C.c_void_p()
             _capi.check(_capi.lib().rmclhip_rcc_sharded_replica(self._h, r, C.byref(h)))
-            self.replicas.append(cls._borrow(h.value))
+            rep = cls._borrow(h.value)
+            rep._owner = self   # a replica in use keeps its owner (and so its handle) alive; close() below nulls the replicas first
+            self.replicas.append(rep)
 
     @property
     def world(self):
@@ -575,7 +577,8 @@ class ShardedCorrectorHip:
     def close(self):
         if self._h:
             for r in self.replicas:
-                r.close()
+                r.close()          # borrowed: only forgets the handle -- a later call on the replica raises instead of touching freed memory
+                r._owner = None
             _capi.lib().rmclhip_rcc_sharded_destroy(self._h)
             self._h = C.c_void_p()
 

@@ -115,6 +115,37 @@ def noisy_room(n_faces_target=100000, side=20.0, height=6.0, noise=0.02, seed=12
     return verts.astype(np.float32), np.asarray(faces, dtype=np.uint32)
 
 
+def nested_triangles(n, ratio, smallest):
+    """n coaxial triangles of geometrically growing size stacked 1 cm apart: the SAH builder peels them off in thin groups, which
+    makes deep trees out of a few hundred triangles"""
+    k = np.arange(n, dtype=np.float64)
+    s = smallest * ratio ** k
+    z = 0.01 * k
+    v = np.stack([np.stack([-s, -s, z], -1), np.stack([s, -s, z], -1), np.stack([np.zeros(n), s, z], -1)], 1).reshape(-1, 3)
+    return v.astype(np.float32), np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+
+
+def exp_chain(n, ratio=2.0, k0=None):
+    """n triangles whose position AND size grow geometrically along x (sizes from ratio^k0 to ratio^(k0+n-1)): the cheapest SAH split
+    always separates the few largest from all the rest, i.e. the binary tree wants to be a chain about n / 4 deep -- far beyond what
+    a 64-entry traversal stack serves.  The builder's height budget (bvh_build.cpp: kMaxHeight2) must step in."""
+    k0 = -(n // 2) if k0 is None else k0
+    s = float(ratio) ** (k0 + np.arange(n, dtype=np.float64))
+    z = np.zeros(n)
+    v = np.stack([np.stack([s, z, z], -1), np.stack([1.5 * s, 0.1 * s, z], -1), np.stack([s, 0.1 * s, 0.1 * s], -1)], 1).reshape(-1, 3)
+    return v.astype(np.float32), np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+
+
+def sliver_fan(n, radius=10.0):
+    """n long thin triangles that all share the apex at the origin (a disc cut like a pie, rim height wobbling): every triangle's box
+    reaches the centre, the boxes overlap massively -- the classic bad case of an object-split BVH"""
+    a = np.linspace(0.0, 2.0 * np.pi, n + 1)
+    rim = np.stack([radius * np.cos(a), radius * np.sin(a), 0.3 * np.sin(7.0 * a)], -1)
+    v = np.concatenate([np.zeros((1, 3)), rim]).astype(np.float32)
+    f = np.stack([np.zeros(n, np.uint32), 1 + np.arange(n, dtype=np.uint32), 2 + np.arange(n, dtype=np.uint32)], -1)
+    return v, f.astype(np.uint32)
+
+
 # ---- sensor models (SURVEY.md 8(d)) -----------------------------------------------------------
 def model_c1():
     """32x32, phi in [-45,45] deg, theta full circle, range [0.1, 100]."""

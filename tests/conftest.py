@@ -108,6 +108,18 @@ def meshes():
                 cache[name] = syn.noisy_room(100000)
             elif name == "sphere1m":
                 cache[name] = syn.uv_sphere(1000000)
+            elif name == "sphere10m":
+                cache[name] = syn.uv_sphere(10000000)
+            elif name == "chain200":
+                cache[name] = syn.exp_chain(200, 1.5)
+            elif name == "chain2000":
+                cache[name] = syn.exp_chain(2000, 1.05)
+            elif name == "nested200":
+                cache[name] = syn.nested_triangles(200, 1.2, 1e-3)
+            elif name == "fan200k":
+                cache[name] = syn.sliver_fan(200000)
+            elif name == "fan20k":
+                cache[name] = syn.sliver_fan(20000)
             else:
                 raise KeyError(name)
         return cache[name]

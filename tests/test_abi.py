@@ -123,13 +123,18 @@ def test_host_algebra_bit_exact_with_oracle(ra, orc):
     assert int(ident["n_meas"]) == 0 and not np.isnan(ident["covariance"]).any()
 
 
-@pytest.mark.parametrize("name", ["cube", "sphere20k", "room30k"])
+@pytest.mark.parametrize("name", ["cube", "sphere20k", "room30k", "chain200", "chain2000", "nested200", "fan20k"])
 def test_bvh_builder_invariants(ra, orc, meshes, name):
     """Host-only build (rmclhip_bvh_build_host): every face in exactly one leaf, triangle records bit-equal
     to the oracle's, every child box contains its subtree, BFS node order, stack bound respected, and the
-    oracle's intersector walking THESE arrays reproduces brute force."""
+    oracle's intersector walking THESE arrays reproduces brute force.  chain* / nested200 are meshes whose SAH tree is far deeper
+    than the kernels' 64-entry stack (round 5: the builder bounds the stack by construction instead of refusing the mesh)."""
     v, f = meshes(name)
     info, nodes, tris = ra.build_bvh_host(v, f)
+    if name.startswith("chain"):
+        assert info["height_fallbacks"] + info["guarded_nodes"] > 0, "this mesh was meant to exercise the stack bound"
+    elif name in ("cube", "sphere20k", "room30k"):
+        assert info["height_fallbacks"] == 0 and info["guarded_nodes"] == 0
     m = orc.Mesh(v, f)
     nf = len(f)
     assert info["n_faces"] == nf and nodes.shape == (info["n_nodes"], 32) and tris.shape == (nf, 16)
@@ -174,12 +179,39 @@ def test_bvh_builder_invariants(ra, orc, meshes, name):
     assert smax + 1 <= info["stack_need"] <= 64
     assert np.allclose(lo, info["bbox_min"], atol=1e-5) and np.allclose(hi, info["bbox_max"], atol=1e-5)
     rng = np.random.RandomState(1)
-    for _ in range(200):
+    n_hit = 0
+    for k in range(200):
         O = rng.uniform(-3, 3, 3).astype(np.float32)
         O[2] = abs(O[2]) + 0.1
         D = rng.normal(size=3).astype(np.float32)
+        if name.startswith(("chain", "nested", "fan")) and k % 2:   # aim at a triangle: these meshes fill little of the view
+            tri = rng.randint(nf)
+            w = rng.dirichlet((1, 1, 1))
+            D = (w[0] * v0[tri] + w[1] * v1[tri] + w[2] * v2[tri] - O).astype(np.float32)
         D /= np.linalg.norm(D)
-        assert orc.trace_bvh4(nodes, tris, O, D, 0.0, 1e4) == m.intersect(O, D, 0.0, 1e4)
+        got = orc.trace_bvh4(nodes, tris, O, D, 0.0, 1e30)
+        assert got == m.intersect(O, D, 0.0, 1e30)
+        n_hit += bool(got[0])
+    assert n_hit >= 20
+
+
+def test_bvh_builder_is_independent_of_the_thread_count(ra, meshes):
+    """the threaded build (bvh_build.cpp: large nodes with the passes spread over the threads, subtrees handed out whole, stable
+    partitions) returns the same bytes for 1, 3 and the default number of threads -- checked in child processes, the thread count is
+    read once per build from RMCLHIP_BUILD_THREADS"""
+    import hashlib, os, subprocess, sys
+    code = ("import sys, hashlib; sys.path.insert(0, %r); import rmcl_amd as ra; from rmcl_amd import synthetic as syn\n"
+            "for v, f in (syn.uv_sphere(200000), syn.noisy_room(30000), syn.exp_chain(200, 1.5)):\n"
+            "    i, n, t = ra.build_bvh_host(v, f); ip, npf, q = ra.build_bvh_host_pf(v, f)\n"
+            "    print(hashlib.sha256(n.tobytes() + t.tobytes() + npf.tobytes() + q.tobytes()).hexdigest())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for nt in ("1", "3", None):
+        env = dict(os.environ)
+        env.pop("RMCLHIP_BUILD_THREADS", None)
+        if nt:
+            env["RMCLHIP_BUILD_THREADS"] = nt
+        outs.append(subprocess.check_output([sys.executable, "-c", code], env=env).decode().split())
+    assert len(outs[0]) == 3 and outs[0] == outs[1] == outs[2]
 
 
 @pytest.mark.parametrize("name", ["cube", "sphere20k", "room30k"])

@@ -889,3 +889,42 @@ def test_caller_calls_in_random_order_match_the_streaming_reduction(ra, orc, ctx
     assert ref.ccs_info()["from_moments"] == 0
     rcc.close()
     ref.close()
+
+
+@pytest.mark.parametrize("mesh", ["cube", "room30k"])
+def test_correct_once_above_262144_rays_walks_the_tree_its_tables_belong_to(ra, orc, ctx, meshes, mesh):
+    """for scans above 262 144 rays the automatic rule picks kind 24 (the FILTER's tree), while the correction's find
+    with the moment epilogue runs kind 23 on the MAP's tree.  The frontier table / stack bound handed to it must be those of the tree it
+    walks: on a small map the two cuts number their nodes differently right below the root, so tables of the wrong tree start rays at
+    wrong nodes and the correspondences are silently wrong.  256 x 2048 rays: the moment form (default) against the per-iteration form
+    (plain kind-24 find + streaming reductions) and against the oracle's correspondences."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes(mesh)
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    f32 = np.float32
+    H, W = 256, 2048
+    model = T.spherical_model(f32(-0.6), f32(1.2 / (H - 1)), H, f32(-math.pi), f32(2 * math.pi / W), W, f32(0.1), f32(60.0))
+    truth = T.transform_from_rpy((0.4, -0.3, 0.8 if mesh == "cube" else 1.4), (0.01, -0.02, 0.3))
+    est = T.mult(truth, T.transform_from_rpy((0.05, -0.04, 0.03), (0.0, 0.0, 0.01)))
+    ident = T.identity()
+    meas = m.simulate_spherical(model, ident, truth, bvh=True, nthreads=8)
+    ds, mask = om.dataset_from_ranges(model, meas["ranges"])
+    rcc = ra.RCCHipSpherical(hm)
+    rcc.setTsb(ident)
+    rcc.setModel(model)
+    rcc.set_dataset(ds, mask)
+    rcc.params.max_dist, rcc.adaptive_max_dist_min = 0.5, 0.5
+    assert rcc.find_variant(1) == 24
+    ref = m.simulate_spherical(model, ident, est, bvh=True, nthreads=8)
+    out = {}
+    for mode in (1, 0):
+        rcc.set_micp_fast(mode)
+        out[mode] = rcc.correct_once(est, ident, 5, 0.0, False)
+        mv = rcc.modelView()    # the correspondences the correction's own find left
+        assert np.array_equal(mv["hits"], ref["hits"]) and np.array_equal(mv["face_ids"], ref["face_ids"]), "mode %d" % mode
+    _transform_close(out[1][0], out[0][0], 1e-5)
+    assert int(out[1][1]["n_meas"]) == int(out[0][1]["n_meas"]) > 100000
+    To, so, _ = om.correct_once(m, model, ident, ident, est, ds, mask, 5, 0.5, adaptive_min=0.5, nthreads=8)
+    _transform_close(out[1][0], To, 1e-5)
+    rcc.close()
