@@ -458,6 +458,14 @@ def main():
             extras["pf_sharded_cabi_allreduce_stats_ms"] = round(_median_call_ms(lambda: shp.stats(), reps=9, warm=1), 4)
             shp.close()
 
+        if rank == 0 and not args.no_extras:
+            # the reference's own 1 M- and 10 M-face rows (lidar_corrector_{optix,embree}_benchmark.cpp:144-152, :161-169): maps that leave
+            # the L2s (1 M: 128 MB) and the MALL (10 M: 1.29 GB)
+            extras["large_maps"] = _large_maps(ra, syn, T, np, ctx)
+            # config C5 at FULL size as one run on this ONE GPU: eight loopback ranks (the ndev = 8 code of the C ABI, in-process copies
+            # instead of RCCL), 1 M particles x 256 beams, 1 M-triangle sphere: update + gather + {sum, max}; NOT a multi-GPU figure
+            extras["c5_full_loopback8"] = _c5_full_loopback(ra, syn, T, np)
+
         # config C5's per-GPU term, on every rank and for every N (the only BASELINE config that shards)
         if not args.no_extras:
             blk = _pf_sharded_block(ra, syn, T, np, torch, dist, ctx, rank, world)
@@ -517,6 +525,10 @@ def main():
                              "%d scans in %.1f s on ONE thread; CPU oracle, BVH4 walk with SSE slab tests + scalar Moeller-Trumbore "
                              "(same intersector and tie-break as the checker's scalar BVH2 walk, whose rate on the same threads is "
                              "scalar_bvh2_walk_value), five output attributes" % (reps, dt, usable, visible, ("%.1f CPUs" % quota) if quota else "none", r1, dt1)}
+            # ---- round 5: stated CPU baselines for the other two metrics -- never targets.  The oracle's loops, timed on the
+            # same host CPUs: the find (BVH4 + SSE walk) and the p2l reduction (one pass of raw double sums) on `usable` threads, the 3x3
+            # solve on one; the reference's CorrespondencesCPU::computeCrossStatistics is one call per iteration as well.
+            cpu.update(_cpu_baselines_c3_c4_v1(orc, m, np, syn, T, model, ra, usable))
             # traversal-traffic view of the roofline: B_trav = sum over rays of nodes_visited * 32 + triangles
             # tested * 36, counted by the instrumented oracle on the identical rays and a BVH2 / one-triangle-per-leaf
             # reference tree (deterministic), against the aggregate L2 rate of 34.5 TB/s
@@ -831,6 +843,177 @@ def _pf_sharded_block(ra, syn, T, np, torch, dist, ctx, rank, world, n_local=125
             "allgather_bytes": 4 * n_total, "collective": ("RCCL all_gather_into_tensor + 2 all_reduce" if dist is not None else "none (1 GPU)"),
             "particle_beam_evals_per_s": round(n_total * n_beams / (step_ms * 1e-3), 1),
             "particle_updates_per_s": round(n_total / (step_ms * 1e-3), 1), "map_build_upload_s": round(build_s, 2)}
+
+
+def _large_maps(ra, syn, T, np, ctx):
+    """C2 find, the v1 batch (1000 x 16x900) and C3 schedule (R) on the 1 M- and 10 M-face spheres.  `find_*_rotating_poses`: 16
+    different poses in turn -- the same scan repeated would live on what the previous launch left in the 256 MB MALL."""
+    out = {}
+    ref = {1000000: {"optix_rays_per_s": 852e6, "optix_pose_corrections_per_s": 59.2e3, "embree_rays_per_s": 71.6e6},
+           10000000: {"optix_rays_per_s": 462e6, "optix_pose_corrections_per_s": 32.1e3, "embree_rays_per_s": 31.6e6}}
+    model = syn.model_c2()
+    n_rays = model.phi.size * model.theta.size
+    rng = np.random.RandomState(7)
+    poses = [syn.pose_c2_truth()] + [T.transform_from_rpy(tuple(rng.uniform(-3.0, 3.0, 3)), tuple(rng.uniform(-0.4, 0.4, 2)) + (rng.uniform(-3.1, 3.1),))
+                                     for _ in range(15)]
+    for tag, nf in (("1m", 1000000), ("10m", 10000000)):
+        v, f = syn.uv_sphere(nf)
+        t0 = time.perf_counter()
+        hm = ra.import_hip_map(ctx, v, f)
+        r = {"map_build_s": round(time.perf_counter() - t0, 3)}
+        info = hm.info()
+        r["map"] = {k: info[k] for k in ("n_faces", "n_nodes", "stack_need", "device_bytes")}
+        rcc = ra.RCCHipSpherical(hm)
+        rcc.setTsb(T.identity())
+        rcc.setModel(model)
+        Tbm = poses[0]
+        ms = median_kernel_ms(lambda: rcc.time_find(Tbm, iters=20), 5)
+        r["find_sphere%s_ms" % tag] = round(ms, 5)
+        r["find_sphere%s_rays_per_s" % tag] = round(n_rays / (ms * 1e-3), 1)
+        for P in poses:
+            rcc.find(P)
+
+        def rot():
+            rcc.sync()
+            t1 = time.perf_counter()
+            for _ in range(4):
+                for P in poses:
+                    rcc.find_async(P)
+            rcc.sync()
+            return (time.perf_counter() - t1) / (4 * len(poses)) * 1e3
+        msr = median_kernel_ms(rot, 5)
+        r["find_sphere%s_rotating_poses_ms" % tag] = round(msr, 5)
+        r["find_sphere%s_rotating_poses_rays_per_s" % tag] = round(n_rays / (msr * 1e-3), 1)
+        r["find_kind"] = rcc.find_variant(1)
+        tr = measured_traffic("k_find_kind23_c2_scan_16_poses_in_turn_sphere%s" % tag)
+        if tr is not None:
+            r["find_sphere%s_rotating_poses_measured_traffic_bytes" % tag] = tr
+            r["find_sphere%s_rotating_poses_measured_TBps" % tag] = round(tr / (msr * 1e-3) / 1e12, 3)
+        rcc.find(Tbm)
+        rcc.set_dataset_from_ranges(rcc.modelView()["ranges"])
+        rcc.params.max_dist, rcc.adaptive_max_dist_min = 1.0, 0.15
+        est = T.mult(Tbm, syn.pose_c2_perturbation())
+        rcc.correct_once(est, T.identity(), 10, 0.0, False)
+        cms = rcc.time_correct_once(est, T.identity(), 10, 0.0, False, iters=30)
+        r["c3_schedule_R_%s_ms" % tag] = round(cms, 4)
+        r["c3_schedule_R_%s_pose_corrections_per_s" % tag] = round(1e3 / cms, 1)
+        rcc.close()
+        small = ra.RCCHipSpherical(hm)
+        small.setTsb(T.identity())
+        small.setModel(syn.model_vlp16_900())
+        rng1 = np.random.RandomState(1)
+        v1poses = np.array([T.transform_from_rpy(tuple(rng1.uniform(-1.0, 1.0, 3) * (1, 1, 0.3)), (0, 0, rng1.uniform(-3, 3)))
+                            for _ in range(1000)], dtype=T.TRANSFORM)
+        small.find(T.identity())
+        small.set_dataset_from_ranges(small.modelView()["ranges"])
+        small.params.max_dist = 1.0
+        small.correct_batch(v1poses)
+        dt = _median_call_ms(lambda: small.correct_batch(v1poses), reps=5, warm=1)
+        r["v1_bench_1000x16x900_%s_ms" % tag] = round(dt, 4)
+        r["v1_bench_1000x16x900_%s_rays_per_s" % tag] = round(1000 * 16 * 900 / (dt * 1e-3), 1)
+        r["v1_bench_1000x16x900_%s_pose_corrections_per_s" % tag] = round(1e6 / dt, 1)
+        r["v1_bench_1000x16x900_%s_find_ms" % tag] = round(small.time_find_batch(v1poses, iters=3), 4)
+        tr = measured_traffic("k_find_kind24_v1_batch_1000x16x900_sphere%s" % tag)
+        if tr is not None:
+            r["v1_bench_1000x16x900_%s_find_measured_traffic_bytes" % tag] = tr
+            r["v1_bench_1000x16x900_%s_find_measured_TBps" % tag] = round(tr / (r["v1_bench_1000x16x900_%s_find_ms" % tag] * 1e-3) / 1e12, 3)
+        small.close()
+        r["reference_source_comments_other_hardware"] = ref[nf]
+        hm.release()
+        out["sphere" + tag] = r
+        del v, f
+    out["note"] = ("the reference records these rows for 1000 copies of ONE pose on its authors' machines (BASELINE.md); here 1000 DIFFERENT poses. "
+                   "measured_traffic = L2-side FETCH_SIZE + WRITE_SIZE of profiles/traffic.json (tools/pmc_large_maps.sh); FETCH_SIZE tallies 64 B per "
+                   "128-B line request (profiles/r05_fetch_size_calibration.txt): exact for 64-B nodes / records, a lower bound otherwise")
+    return out
+
+
+def _c5_full_loopback(ra, syn, T, np):
+    v, f = syn.uv_sphere(1000000)
+    n = 1000000
+    poses, attrs = syn.uniform_particles(n, seed=5, bb_min=(-5, -5, -1, 0, 0, -math.pi), bb_max=(5, 5, 1, 0, 0, math.pi))
+    beams = ra.beams_from_points(syn.model_directions(syn.model_pf16()) * np.float32(6.0))
+    sh = ra.ShardedParticleFilterHip(v, f, devices=(0,) * 8, loopback=True)
+    sh.set_particles(poses, attrs)
+    ms = _median_call_ms(lambda: sh.step(beams, T.identity()), reps=3, warm=1)
+    msr = _median_call_ms(lambda: sh.step(beams, T.identity(), T_bnew_bold=T.transform_from_rpy((0.01, 0.0, 0.0), (0, 0, 0.001)), forget_rate=0.05,
+                                          resample="gladiator", seed=3), reps=3, warm=1)
+    sh.close()
+    return {"label": "ONE GPU, eight LOOPBACK ranks (in-process copies, no RCCL, no xGMI): the ndev = 8 code path at C5's full size, not a multi-GPU measurement",
+            "shape": "1 000 000 particles x 256 beams, UV-sphere 1 000 000 triangles",
+            "c5_full_loopback8_step_ms": round(ms, 3), "c5_full_loopback8_step_with_motion_and_tournament_ms": round(msr, 3),
+            "particle_beam_evals_per_s": round(n * 256 / (ms * 1e-3), 1)}
+
+
+def _cpu_baselines_c3_c4_v1(orc, m, np, syn, T, model, ra, usable):
+    """the same host CPUs, the other two metrics.  The oracle's find (BVH4 + SSE walk) and its one-pass threaded reduction
+    (orc_statistics_p2l_fast: what a tuned CPU reduction does; the checker's element-by-element forms are 10x slower and are not timed):
+    oracle-side C3 (find + 10 x statistics_p2l + umeyama: micp_localization.cpp:900-964), C4 sensor update (PCDSensorUpdaterEmbree.cpp:
+    290-342, grain 128 like :330-331) and the v1 batch (1000 x 16x900: lidar_corrector_embree_benchmark.cpp:127-135) on the host CPUs"""
+    out = {}
+    ident = T.identity()
+    truth = syn.pose_c2_truth()
+    est = T.mult(truth, syn.pose_c2_perturbation())
+    meas = m.simulate_spherical(model, ident, truth, bvh=2, nthreads=usable, want=("ranges",))
+    dirs = orc.spherical_directions(model)
+    ds = (dirs * meas["ranges"][:, None]).astype(np.float32)
+    mask = np.where((meas["ranges"] < np.float32(model.range.min)) | (meas["ranges"] > np.float32(model.range.max)), 0, 1).astype(np.uint8)
+
+    def c3(nthreads, buf):
+        sim = m.simulate_spherical(model, ident, est, bvh=2, nthreads=nthreads, want=("hits", "points", "normals"), out=buf)
+        T_delta = ident
+        for _ in range(10):
+            s_ = orc.statistics_p2l_fast(T_delta, ds, mask, sim["points"], sim["normals"], sim["hits"], 1.0, nthreads)
+            T_delta = orc.tmult(T_delta, orc.umeyama(orc.cs_merge(orc.cs_identity(), s_)))
+        return T_delta
+
+    for key, nt, budget in (("c3_pose_corrections_per_s", usable, 2.5), ("c3_pose_corrections_per_s_one_thread", 1, 2.5)):
+        buf = m.simulate_spherical(model, ident, est, bvh=2, nthreads=nt, want=("hits", "points", "normals"))
+        c3(nt, buf)
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget:
+            c3(nt, buf)
+            reps += 1
+        out[key] = round(reps / (time.perf_counter() - t0), 2)
+    out["c3_sample"] = ("C3 = 1 find (128x1024, sphere-100k, BVH4 + SSE walk) + 10 x (statistics_p2l as one pass of raw double sums + Umeyama) per "
+                        "correction; find and reduction on the usable threads (resp. one), the 3x3 solve on one; ~2.5 s each")
+    # C4: sensor update of a bounded sample of the 100 000 x 256 workload (20 000 particles), static chunks of <= 128 particles per fetch
+    n_s = 20000
+    poses, attrs = syn.uniform_particles(n_s, seed=42, bb_min=(-5, -5, -1, 0, 0, -math.pi), bb_max=(5, 5, 1, 0, 0, math.pi))
+    beams = ra.beams_from_points(syn.model_directions(syn.model_pf16()) * np.float32(6.0))
+    a = attrs.copy()
+    m.pf_update(poses[:2000], a[:2000], beams, ident, orc.pf_params(), bvh=2, nthreads=usable)
+    reps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 2.5:
+        a = attrs.copy()
+        m.pf_update(poses, a, beams, ident, orc.pf_params(), bvh=2, nthreads=usable)
+        reps += 1
+    dt = time.perf_counter() - t0
+    out["c4_particle_beam_evals_per_s"] = round(reps * n_s * len(beams) / dt, 1)
+    out["c4_particle_updates_per_s"] = round(reps * n_s / dt, 1)
+    out["c4_sample"] = "%d x (20 000 particles x 256 beams, sphere-100k) in %.1f s on %d threads: the oracle's sensorUpdate (BVH4 + SSE walk, double exp, in-order Gaussian1D merge)" % (reps, dt, usable)
+    # v1 batch: 1000 poses x 16x900, per pose raycast + reduce (Tpre = I) + Umeyama
+    small = syn.model_vlp16_900()
+    rng = np.random.RandomState(1)
+    v1poses = np.array([T.transform_from_rpy(tuple(rng.uniform(-1.0, 1.0, 3) * (1, 1, 0.3)), (0, 0, rng.uniform(-3, 3))) for _ in range(1000)], dtype=T.TRANSFORM)
+    meas = m.simulate_spherical(small, ident, ident, bvh=2, nthreads=usable, want=("ranges",))
+    sdirs = orc.spherical_directions(small)
+    sds = (sdirs * meas["ranges"][:, None]).astype(np.float32)
+    smask = np.ones(len(sds), np.uint8)
+    nray = len(sds)
+    buf = m.simulate_spherical(small, ident, v1poses, bvh=2, nthreads=usable, want=("hits", "points", "normals"))
+    t0 = time.perf_counter()
+    sim = m.simulate_spherical(small, ident, v1poses, bvh=2, nthreads=usable, want=("hits", "points", "normals"), out=buf)
+    t_sim = time.perf_counter() - t0
+    for i in range(len(v1poses)):
+        sl = slice(i * nray, (i + 1) * nray)
+        orc.umeyama(orc.statistics_p2l_fast(ident, sds, smask, sim["points"][sl], sim["normals"][sl], sim["hits"][sl], 1.0, 1))
+    dt = time.perf_counter() - t0
+    out["v1_batch_pose_corrections_per_s"] = round(len(v1poses) / dt, 1)
+    out["v1_batch_rays_per_s"] = round(len(v1poses) * nray / dt, 1)
+    out["v1_sample"] = ("one batch of 1000 poses x 16x900 rays, sphere-100k: raycast of all poses on %d threads (%.2f s) + per pose statistics_p2l (one pass) + Umeyama on "
+                        "one thread (%.2f s); the reference's source comments record 5 464 corrections/s (Embree, its authors' desktop)" % (usable, t_sim, dt - t_sim))
+    return out
 
 
 def _pf_c4(ra, syn, T, np, ctx, hm, n_particles, n_beams, iters, bb=((-5, -5, -1), (5, 5, 1)), converged_at=None, particle_minor=False):

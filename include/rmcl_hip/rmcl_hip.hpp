@@ -680,6 +680,22 @@ class PCDSensorUpdaterHipSharded : public SensorUpdaterBase {
     check(rmclhip_pf_allreduce_pose_estimate(h_, max_induction_particles, &e));
     return e;
   }
+  // MotionUpdater<MemT>::update on every device's block, in place (rmcl_localization.cpp:432-480; particle_motion.cu:11-46 + the collision
+  // ray of TFMotionUpdaterCPU.cpp:17-50): the odometry lookup and the combined forget rate stay with the caller, as for TFMotionUpdaterHip
+  void motionUpdate(const Transform& T_bnew_bold, double forget_rate, bool check_collision = true) {
+    check(rmclhip_pf_sharded_set_params(h_, &config_));
+    check(rmclhip_pf_sharded_motion_update(h_, &T_bnew_bold, forget_rate, check_collision ? 1 : 0));
+  }
+  // one cycle of the node (rmcl_localization.cpp:84, 432-552) in ONE call: motion (T_bnew_bold == nullptr: none) -> sensor update -> weight
+  // all-gather -> {sum, max} -> resampling (0 none, 1 gladiator, 2 residual); returns the {sum, max} the resampler normalises with
+  rmclhip_likelihood_stats step(const Transform* T_bnew_bold, double forget_rate, bool check_collision, int resample,
+                                const rmclhip_gladiator_config& cfg, uint64_t seed, uint32_t step_index) {
+    rmclhip_likelihood_stats st{};
+    check(rmclhip_pf_sharded_set_params(h_, &config_));
+    check(rmclhip_pf_sharded_step(h_, T_bnew_bold, forget_rate, check_collision ? 1 : 0, beams_.data(), static_cast<uint32_t>(beams_.size()), &Tsb_,
+                                  resample, &cfg, seed, step_index, &st));
+    return st;
+  }
   void resample(const rmclhip_gladiator_config& cfg, uint64_t seed, uint32_t step) { check(rmclhip_pf_sharded_resample(h_, &cfg, seed, step)); }
   void resampleResidual(const rmclhip_gladiator_config& cfg, uint64_t seed, uint32_t step) { check(rmclhip_pf_sharded_resample_residual(h_, &cfg, seed, step)); }
 

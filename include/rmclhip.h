@@ -641,6 +641,22 @@ rmclhip_status rmclhip_pf_sharded_download(rmclhip_pf_sharded* pf, rmclhip_trans
 /* PCDSensorUpdater*::update on every device's block (concurrently), then rmclhip_pf_allgather_weights */
 rmclhip_status rmclhip_pf_update_sharded(rmclhip_pf_sharded* pf, const rmclhip_range_measurement* beams, uint32_t n_beams,
                                          const rmclhip_transform* Tsb);
+/* MotionUpdater<MemT>::update on every device's block (rmcl_localization.cpp:432-480; particle_move_and_forget_kernel,
+ * rmcl_ros/src/rmcl/particle_motion.cu:11-46, with check_collision != 0 also the wall-collision ray of TFMotionUpdaterCPU.cpp:17-50,
+ * 207-221): the arguments of rmclhip_pf_motion_update, applied to the whole sharded cloud in place -- one launch per device, all
+ * enqueued before the host waits for any.  Identical to rmclhip_pf_motion_update on the unsharded cloud (a particle's result depends on
+ * that particle alone). */
+rmclhip_status rmclhip_pf_sharded_motion_update(rmclhip_pf_sharded* pf, const rmclhip_transform* T_bnew_bold, double forget_rate,
+                                                int check_collision);
+/* One cycle of the filter node on the sharded cloud (rmcl_localization.cpp:84, 432-552): motion update (T_bnew_bold NULL: skipped) ->
+ * sensor update -> weight all-gather -> {sum, max} all-reduce (stats_out, nullable) -> resampling (resample: 0 none, 1 gladiator
+ * tournament, 2 residual; config / seed / step as rmclhip_pf_sharded_resample).  A device's motion and sensor-update launches share a
+ * stream: the host never waits between them.  Equal, bit for bit, to the single-device sequence rmclhip_pf_motion_update,
+ * rmclhip_pf_update, rmclhip_resampler_compute_stats, rmclhip_resampler_gladiator / _residual. */
+rmclhip_status rmclhip_pf_sharded_step(rmclhip_pf_sharded* pf, const rmclhip_transform* T_bnew_bold, double forget_rate, int check_collision,
+                                       const rmclhip_range_measurement* beams, uint32_t n_beams, const rmclhip_transform* Tsb,
+                                       int resample, const rmclhip_gladiator_config* config, uint64_t seed, uint32_t step,
+                                       rmclhip_likelihood_stats* stats_out);
 /* ONE ncclAllGather of likelihood.mean (4 B x N on equal padded shards): afterwards every device holds the dense weight
  * vector of the whole cloud; rmclhip_pf_sharded_get_weights copies rank's copy to the host */
 rmclhip_status rmclhip_pf_allgather_weights(rmclhip_pf_sharded* pf);

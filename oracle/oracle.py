@@ -149,6 +149,8 @@ def lib():
                                     vp, vp, vp, vp, vp, vp]
     L.orc_statistics_p2l_f32.argtypes = [vp, vp, vp, vp, vp, vp, u32, f32, vp]
     L.orc_statistics_p2l_f64.argtypes = [vp, vp, vp, vp, vp, vp, u32, f32, vp, vp]
+    L.orc_statistics_p2l_fast.restype = None
+    L.orc_statistics_p2l_fast.argtypes = [vp, vp, vp, vp, vp, vp, u32, f32, C.c_int, vp]
     L.orc_adaptive_max_dist.restype = f32
     L.orc_adaptive_max_dist.argtypes = [f32, f32, C.c_double]
     L.orc_cross_statistics_merge.restype = CrossStatistics
@@ -285,10 +287,13 @@ def pf_params(dist_sigma=2.0, real_hit_sim_miss_error=100.0, real_miss_sim_hit_e
 
 
 class Mesh:
-    def __init__(self, verts, faces, max_leaf=4):
+    def __init__(self, verts, faces, max_leaf=4, build_bvh=True):
+        """build_bvh=False: records only (ORC_MESH_NO_BVH) -- every query is brute force whatever `bvh=` says; for 10^7-face maps
+        that are checked on a sample of rays against every triangle"""
         self.verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
         self.faces = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
-        self.h = lib().orc_mesh_create(_p(self.verts), len(self.verts), _p(self.faces), len(self.faces), max_leaf)
+        self.h = lib().orc_mesh_create(_p(self.verts), len(self.verts), _p(self.faces), len(self.faces),
+                                       int(max_leaf) | (0 if build_bvh else 0x80000000))
         if not self.h:
             raise ValueError("orc_mesh_create failed")
 
@@ -436,6 +441,20 @@ def statistics_p2l(Tpre, dataset_points, dataset_mask, model_points, model_norma
     mm = None if model_mask is None else np.ascontiguousarray(model_mask, dtype=np.uint8)
     out = np.zeros(1, dtype=CROSS_STATISTICS)
     lib().orc_statistics_p2l_f32(_p(Tpre), _p(dp), _p(dm), _p(mp), _p(mn), _p(mm), len(dp), max_dist, _p(out))
+    return out[0].copy()
+
+
+def statistics_p2l_fast(Tpre, dataset_points, dataset_mask, model_points, model_normals, model_mask, max_dist, nthreads=1):
+    """one pass of raw double sums on `nthreads` workers (bench.py's cpu_baseline form; inputs are used as they are when already
+    contiguous float32 / uint8)"""
+    Tpre = np.ascontiguousarray(Tpre, dtype=TRANSFORM).reshape(1)
+    dp = np.ascontiguousarray(dataset_points, dtype=np.float32).reshape(-1, 3)
+    mp = np.ascontiguousarray(model_points, dtype=np.float32).reshape(-1, 3)
+    mn = np.ascontiguousarray(model_normals, dtype=np.float32).reshape(-1, 3)
+    dm = None if dataset_mask is None else np.ascontiguousarray(dataset_mask, dtype=np.uint8)
+    mm = None if model_mask is None else np.ascontiguousarray(model_mask, dtype=np.uint8)
+    out = np.zeros(1, dtype=CROSS_STATISTICS)
+    lib().orc_statistics_p2l_fast(_p(Tpre), _p(dp), _p(dm), _p(mp), _p(mn), _p(mm), len(dp), max_dist, int(nthreads), _p(out))
     return out[0].copy()
 
 

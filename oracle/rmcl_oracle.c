@@ -265,14 +265,18 @@ static void build_rec(build_ctx* bc, uint32_t node_id, uint32_t first, uint32_t 
   build_rec(bc, left + 1, mid, first + count - mid);
 }
 
+/* max_leaf bit 31 (ORC_MESH_NO_BVH): records only, no tree -- for maps of 10^7 faces that are only ever traced by brute force (the
+ * recursive single-threaded build below would take longer than the check it serves); use_bvh != 0 on such a mesh is refused */
 orc_mesh* orc_mesh_create(const float* verts, uint32_t nv, const uint32_t* faces, uint32_t nf, uint32_t max_leaf)
 {
+  const int no_bvh = (max_leaf & 0x80000000u) != 0;
+  max_leaf &= 0x7FFFFFFFu;
   if (nf == 0 || max_leaf == 0) return NULL;
   orc_mesh* m = (orc_mesh*)calloc(1, sizeof(orc_mesh));
   m->nf = nf; m->max_leaf = max_leaf;
   m->tris = (orc_tri*)malloc(sizeof(orc_tri) * nf);
   m->prim = (uint32_t*)malloc(sizeof(uint32_t) * nf);
-  m->nodes = (orc_node*)malloc(sizeof(orc_node) * (2 * (size_t)nf));
+  m->nodes = (orc_node*)malloc(sizeof(orc_node) * (no_bvh ? 1 : 2 * (size_t)nf));
   prim_info* info = (prim_info*)malloc(sizeof(prim_info) * nf);
   float smin[3], smax[3]; box_init(smin, smax);
   for (uint32_t f = 0; f < nf; ++f) {
@@ -298,6 +302,7 @@ orc_mesh* orc_mesh_create(const float* verts, uint32_t nv, const uint32_t* faces
   float amax = 0.0f;
   for (int k = 0; k < 3; ++k) { if (fabsf(smin[k]) > amax) amax = fabsf(smin[k]); if (fabsf(smax[k]) > amax) amax = fabsf(smax[k]); }
   m->pad = 1e-4f * (diag > amax ? diag : amax) + 1e-6f;
+  if (no_bvh) { m->n_nodes = 0; free(info); return m; }
   build_ctx bc = {m, info, 0};
   m->n_nodes = 1;
   build_rec(&bc, 0, 0, nf);
@@ -355,6 +360,7 @@ static inline int box_hit(const orc_node* n, const float* o, const float* inv, f
 
 int orc_intersect_bvh(const orc_mesh* m, orc_vec3 O, orc_vec3 D, float tnear, float tfar, float* t_out, uint32_t* face_out, orc_counters* cnt)
 {
+  if (m->n_nodes == 0) return orc_intersect_brute(m, O, D, tnear, tfar, t_out, face_out);   /* ORC_MESH_NO_BVH: same result, no tree */
   const float o[3] = {O.x, O.y, O.z};
   const float inv[3] = {safe_inv(D.x), safe_inv(D.y), safe_inv(D.z)};
   float best_t = tfar; uint32_t best_f = 0xFFFFFFFFu; int found = 0;
@@ -455,6 +461,7 @@ static void ensure_bvh4(orc_mesh* m)
 
 int orc_intersect_bvh4(const orc_mesh* mc, orc_vec3 O, orc_vec3 D, float tnear, float tfar, float* t_out, uint32_t* face_out)
 {
+  if (mc->n_nodes == 0) return orc_intersect_brute(mc, O, D, tnear, tfar, t_out, face_out);   /* ORC_MESH_NO_BVH */
   orc_mesh* m = (orc_mesh*)mc;
   if (!__atomic_load_n(&m->bvh4_ready, __ATOMIC_ACQUIRE)) ensure_bvh4(m);
   if (m->nodes[0].count > 0) return orc_intersect_bvh(mc, O, D, tnear, tfar, t_out, face_out, NULL);   /* a single leaf */
@@ -895,6 +902,59 @@ void orc_statistics_p2l_f64(const orc_transform* Tpre, const float* dp, const ui
   for (int k = 0; k < 9; ++k) out15[6 + k] = C[k] / cnt;
 }
 
+/* The same statistics in ONE pass of raw double sums over static chunks on the worker pool -- what a tuned CPU reduction does (the
+ * reference calls rm::statistics_p2l, whose CPU form is an OpenMP reduction).  Only bench.py's cpu_baseline leg times this form; the
+ * checker uses the two forms above.  tests/test_oracle.py holds it to the two-pass value. */
+typedef struct {
+  const orc_transform* Tpre; const float* dp; const uint8_t* dm; const float* mp; const float* mn; const uint8_t* mm;
+  uint32_t n; float max_dist;
+  double (*part)[16];   /* per worker: sum d[3], sum m[3], sum m d^T [9], count */
+} p2l_fast_job;
+
+static void p2l_fast_worker(void* arg, int worker, int nworkers)
+{
+  const p2l_fast_job* J = (const p2l_fast_job*)arg;
+  const uint32_t lo = (uint32_t)((uint64_t)J->n * (uint64_t)worker / (uint64_t)nworkers);
+  const uint32_t hi = (uint32_t)((uint64_t)J->n * (uint64_t)(worker + 1) / (uint64_t)nworkers);
+  double a[16];
+  for (int k = 0; k < 16; ++k) a[k] = 0.0;
+  const orc_transform T = *J->Tpre;
+  for (uint32_t i = lo; i < hi; ++i) {
+    if ((J->dm == NULL || J->dm[i] > 0) && (J->mm == NULL || J->mm[i] > 0)) {
+      orc_vec3 Di, Mi;
+      if (p2l_element(&T, J->dp + 3 * i, J->mp + 3 * i, J->mn + 3 * i, J->max_dist, &Di, &Mi)) {
+        const double d[3] = {Di.x, Di.y, Di.z}, m_[3] = {Mi.x, Mi.y, Mi.z};
+        for (int k = 0; k < 3; ++k) { a[k] += d[k]; a[3 + k] += m_[k]; }
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) a[6 + 3 * r + c] += m_[r] * d[c];
+        a[15] += 1.0;
+      }
+    }
+  }
+  for (int k = 0; k < 16; ++k) J->part[worker][k] = a[k];
+}
+
+void orc_statistics_p2l_fast(const orc_transform* Tpre, const float* dp, const uint8_t* dm, const float* mp,
+                             const float* mn, const uint8_t* mm, uint32_t n, float max_dist, int nthreads, orc_cross_statistics* out)
+{
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 256) nthreads = 256;
+  double part[256][16];
+  p2l_fast_job J = {Tpre, dp, dm, mp, mn, mm, n, max_dist, part};
+  pool_run(p2l_fast_worker, &J, nthreads);
+  double a[16];
+  for (int k = 0; k < 16; ++k) { a[k] = 0.0; for (int w = 0; w < nthreads; ++w) a[k] += part[w][k]; }
+  orc_cross_statistics s = orc_cross_statistics_identity();
+  const double cnt = a[15];
+  if (cnt > 0.0) {
+    const double md[3] = {a[0] / cnt, a[1] / cnt, a[2] / cnt}, mm_[3] = {a[3] / cnt, a[4] / cnt, a[5] / cnt};
+    s.dataset_mean = v3((float)md[0], (float)md[1], (float)md[2]);
+    s.model_mean = v3((float)mm_[0], (float)mm_[1], (float)mm_[2]);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) s.covariance[3 * r + c] = (float)(a[6 + 3 * r + c] / cnt - mm_[r] * md[c]);
+    s.n_meas = (uint32_t)cnt;
+  }
+  *out = s;
+}
+
 /* symmetric 3x3 Jacobi eigen-decomposition (double). A = V diag(e) V^T */
 static void jacobi_eig3(const double* Ain, double* V, double* e)
 {
@@ -1053,7 +1113,10 @@ float orc_evaluate_rcc(const orc_mesh* m, const orc_range_measurement* meas, con
   /* correspondence_type 3 = the OptiX program's rules (BeamEvaluateProgram.cu:44-49,77-120): tmax 1e4, any hit counts */
   const int optix = (p->correspondence_type == 3);
   const float tfar = optix ? 1.0e4f : INFINITY;
-  if (use_bvh) hit = orc_intersect_bvh(m, meas->orig, meas->dir, 0.0f, tfar, &t, &face, NULL);
+  /* use_bvh 2: the BVH4 walk with SSE slab tests (same intersector, same tie rule: identical (t, face) -- tests/test_oracle.py);
+   * it makes the FULL-size checks of C4 / C5 (25.6 M and 32 M rays) a matter of seconds */
+  if (use_bvh == 2) hit = orc_intersect_bvh4(m, meas->orig, meas->dir, 0.0f, tfar, &t, &face);
+  else if (use_bvh) hit = orc_intersect_bvh(m, meas->orig, meas->dir, 0.0f, tfar, &t, &face, NULL);
   else hit = orc_intersect_brute(m, meas->orig, meas->dir, 0.0f, tfar, &t, &face);
   const int sim_hit = (hit > 0) && (optix || t > p->sensor_range.min);
   float error;
@@ -1336,7 +1399,7 @@ int orc_closest_point(const orc_mesh* m, orc_vec3 P, int use_bvh, float* d_out, 
 {
   float best = INFINITY; uint32_t best_f = 0xFFFFFFFFu; orc_vec3 best_p = v3(0, 0, 0);
   if (!(P.x == P.x && P.y == P.y && P.z == P.z)) return 0;
-  if (!use_bvh) {
+  if (!use_bvh || m->n_nodes == 0) {
     for (uint32_t f = 0; f < m->nf; ++f) {
       const orc_vec3 q = closest_point_triangle(&m->tris[f], P);
       const float d2 = dist2(P, q);

@@ -139,6 +139,10 @@ void orc_statistics_p2l_f64(const orc_transform* Tpre,
                             const float* model_points, const float* model_normals,
                             const uint8_t* model_mask, uint32_t n, float max_dist,
                             double* out15, uint32_t* n_out);
+/* the same statistics as ONE pass of raw double sums on `nthreads` workers: bench.py's cpu_baseline form (a tuned CPU reduction), never the checker's */
+void orc_statistics_p2l_fast(const orc_transform* Tpre, const float* dataset_points, const uint8_t* dataset_mask, const float* model_points,
+                             const float* model_normals, const uint8_t* model_mask, uint32_t n, float max_dist, int nthreads,
+                             orc_cross_statistics* out);
 /* CorrespondencesCPU.cpp:21-23 */
 float orc_adaptive_max_dist(float max_dist, float adaptive_max_dist_min, double convergence_progress);
 

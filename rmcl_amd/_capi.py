@@ -213,6 +213,9 @@ SIGNATURES = {
     "rmclhip_pf_sharded_set_particles": (_i32, [_vp, _vp, _vp, _u32]),
     "rmclhip_pf_sharded_download": (_i32, [_vp, _vp, _vp]),
     "rmclhip_pf_update_sharded": (_i32, [_vp, _vp, _u32, _vp]),
+    "rmclhip_pf_sharded_motion_update": (_i32, [_vp, _vp, _dbl, _i32]),
+    "rmclhip_pf_sharded_step": (_i32, [_vp, _vp, _dbl, _i32, _vp, _u32, _vp, _i32, C.POINTER(GladiatorConfig), C.c_uint64, _u32,
+                                       C.POINTER(LikelihoodStats)]),
     "rmclhip_pf_allgather_weights": (_i32, [_vp]),
     "rmclhip_pf_sharded_get_weights": (_i32, [_vp, _u32, _vp]),
     "rmclhip_pf_allreduce_stats": (_i32, [_vp, C.POINTER(LikelihoodStats)]),

@@ -4014,6 +4014,67 @@ rmclhip_status rmclhip_pf_update_sharded(rmclhip_pf_sharded* h, const rmclhip_ra
   return rmclhip_pf_allgather_weights(h);
 }
 
+static rmclhip_status pf_sharded_resample_impl(rmclhip_pf_sharded* h, const rmclhip_gladiator_config* cfg, uint64_t seed, uint32_t step,
+                                              bool residual);
+rmclhip_status rmclhip_pf_allreduce_stats(rmclhip_pf_sharded* h, rmclhip_likelihood_stats* out);
+// MotionUpdater<MemT>::update on every device's block (particle_motion.cu:11-46 + the collision ray of TFMotionUpdaterCPU.cpp:17-50,
+// 207-221): one k_pf_motion per rank on that rank's update stream.  `wait`: false leaves the launches in flight -- the sensor update of
+// the same cycle is enqueued behind them on the same streams (rmclhip_pf_sharded_step).
+static rmclhip_status pf_sharded_motion_enqueue(rmclhip_pf_sharded* h, const rmclhip_transform* T_bnew_bold, double forget_rate, int check_collision) {
+  for (size_t r = 0; r < h->ranks.size(); ++r) {
+    PfRank& R = h->ranks[r];
+    if (R.hi == R.lo) continue;
+    HIPCHK(hipSetDevice(R.ctx->device));
+    HIPCHK(launch_pf_motion(R.map->d_qnodes, R.map->d_tris, R.d_poses, static_cast<rmclhip_particle_attributes*>(R.d_attrs), R.hi - R.lo,
+                            to_x(T_bnew_bold), forget_rate, h->params.max_n_meas, check_collision != 0, R.pf->stream));
+    trace('E', static_cast<uint32_t>(r));
+  }
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_pf_sharded_motion_update(rmclhip_pf_sharded* h, const rmclhip_transform* T_bnew_bold, double forget_rate,
+                                                int check_collision) {
+  ApiGuard guard_("rmclhip_pf_sharded_motion_update");
+  if (!h || !T_bnew_bold) return fail(RMCLHIP_ERR_INVALID, "pf_sharded_motion_update: null");
+  if (h->n_total == 0) return RMCLHIP_OK;
+  trace_mark("motion:");
+  if (rmclhip_status st = pf_sharded_motion_enqueue(h, T_bnew_bold, forget_rate, check_collision)) return st;
+  for (size_t r = 0; r < h->ranks.size(); ++r) {   // every rank's launch is in flight before the host waits for any
+    PfRank& R = h->ranks[r];
+    if (R.hi == R.lo) continue;
+    HIPCHK(hipSetDevice(R.ctx->device));
+    HIPCHK(R.pf->tag.wait_chain_end(R.ctx, R.pf->stream));
+    trace('W', static_cast<uint32_t>(r));
+  }
+  return RMCLHIP_OK;
+}
+
+// One cycle of the filter node (rmcl_localization.cpp:84, 432-552: motionUpdate, sensorUpdate, resampling with its {sum, max}) on the
+// sharded cloud: motion (nullable T_bnew_bold: skipped) -> sensor update -> weight all-gather -> {sum, max} all-reduce -> resampling
+// (resample: 0 none, 1 gladiator tournament, 2 residual).  Motion and sensor update of a rank share its stream, so the host waits
+// once for the gather, once for the statistics and once inside the resampler -- never between motion and update.
+rmclhip_status rmclhip_pf_sharded_step(rmclhip_pf_sharded* h, const rmclhip_transform* T_bnew_bold, double forget_rate, int check_collision,
+                                       const rmclhip_range_measurement* beams, uint32_t n_beams, const rmclhip_transform* Tsb,
+                                       int resample, const rmclhip_gladiator_config* cfg, uint64_t seed, uint32_t step,
+                                       rmclhip_likelihood_stats* stats_out) {
+  ApiGuard guard_("rmclhip_pf_sharded_step");
+  if (!h || !Tsb || (n_beams && !beams)) return fail(RMCLHIP_ERR_INVALID, "pf_sharded_step: null");
+  if (resample < 0 || resample > 2 || (resample != 0 && !cfg)) return fail(RMCLHIP_ERR_INVALID, "pf_sharded_step: bad resampling arguments");
+  if (h->n_total == 0) { if (stats_out) { stats_out->sum = 0.f; stats_out->max = 0.f; } return RMCLHIP_OK; }
+  if (T_bnew_bold) {
+    trace_mark("motion:");
+    if (rmclhip_status st = pf_sharded_motion_enqueue(h, T_bnew_bold, forget_rate, check_collision)) return st;
+  }
+  if (rmclhip_status st = rmclhip_pf_update_sharded(h, beams, n_beams, Tsb)) return st;
+  rmclhip_likelihood_stats st_local;
+  trace_mark("stats:");
+  if (rmclhip_status st = rmclhip_pf_allreduce_stats(h, stats_out ? stats_out : &st_local)) return st;
+  if (resample != 0) {
+    if (rmclhip_status st = pf_sharded_resample_impl(h, cfg, seed, step, resample == 2)) return st;
+  }
+  return RMCLHIP_OK;
+}
+
 rmclhip_status rmclhip_pf_sharded_get_weights(rmclhip_pf_sharded* h, uint32_t rank, float* weights_host) {
   ApiGuard guard_("rmclhip_pf_sharded_get_weights");
   if (!h || !weights_host || rank >= h->ranks.size()) return fail(RMCLHIP_ERR_INVALID, "pf_sharded_get_weights: bad arguments");
@@ -4126,8 +4187,6 @@ rmclhip_status rmclhip_pf_allreduce_pose_estimate(rmclhip_pf_sharded* h, uint32_
 // distributed gladiator tournament: the enemy of a champion may live on any rank, so the cloud (68 B per
 // particle) is all-gathered once, then every rank resamples its own champions against the gathered copy; the Philox
 // stream is a function of the GLOBAL champion index, so the result equals the single-GPU tournament
-static rmclhip_status pf_sharded_resample_impl(rmclhip_pf_sharded* h, const rmclhip_gladiator_config* cfg, uint64_t seed, uint32_t step,
-                                              bool residual);
 
 rmclhip_status rmclhip_pf_sharded_resample(rmclhip_pf_sharded* h, const rmclhip_gladiator_config* cfg, uint64_t seed, uint32_t step) {
   ApiGuard guard_("rmclhip_pf_sharded_resample");

@@ -314,6 +314,28 @@ class ShardedParticleFilterHip:
         _capi.check(_capi.lib().rmclhip_pf_update_sharded(self._h, _ptr(b), len(b), _ptr(T)))
         return self.weights(0)
 
+    def motion_update(self, T_bnew_bold, forget_rate, check_collision=True):
+        """TFMotionUpdater*::update on every device's block, in place (rmclhip_pf_sharded_motion_update): pose <- pose * T_bnew_bold,
+        n_meas -= forget_rate * n_meas, and with check_collision the wall-collision ray of the CPU updater"""
+        T = np.ascontiguousarray(T_bnew_bold, dtype=TRANSFORM).reshape(1)
+        _capi.check(_capi.lib().rmclhip_pf_sharded_set_params(self._h, C.byref(self.config_)))   # (max_n_meas of a collided particle)
+        _capi.check(_capi.lib().rmclhip_pf_sharded_motion_update(self._h, _ptr(T), float(forget_rate), int(bool(check_collision))))
+
+    def step(self, beams, Tsb, T_bnew_bold=None, forget_rate=0.0, check_collision=True, resample=None, cfg=None, seed=42, step=0):
+        """one cycle of the filter node (rmcl_localization.cpp:84, 432-552) behind ONE C call: motion (skipped when T_bnew_bold is None)
+        -> sensor update -> weight all-gather -> {sum, max} -> resampling (None, "gladiator" or "residual"); returns {sum, max} of the
+        likelihoods after the sensor update"""
+        b = np.ascontiguousarray(beams, dtype=RANGE_MEASUREMENT).reshape(-1)
+        T = np.ascontiguousarray(Tsb, dtype=TRANSFORM).reshape(1)
+        Tm = None if T_bnew_bold is None else np.ascontiguousarray(T_bnew_bold, dtype=TRANSFORM).reshape(1)
+        cfg = cfg if cfg is not None else gladiator_config()
+        st = _capi.LikelihoodStats()
+        _capi.check(_capi.lib().rmclhip_pf_sharded_set_params(self._h, C.byref(self.config_)))
+        _capi.check(_capi.lib().rmclhip_pf_sharded_step(self._h, None if Tm is None else _ptr(Tm), float(forget_rate), int(bool(check_collision)),
+                                                       _ptr(b), len(b), _ptr(T), {None: 0, "gladiator": 1, "residual": 2}[resample],
+                                                       C.byref(cfg), int(seed), int(step), C.byref(st)))
+        return {"sum": st.sum, "max": st.max}
+
     def weights(self, rank=0):
         w = np.zeros(self.n_total, np.float32)
         _capi.check(_capi.lib().rmclhip_pf_sharded_get_weights(self._h, int(rank), _ptr(w)))

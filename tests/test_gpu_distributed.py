@@ -11,6 +11,8 @@ import sys
 import numpy as np
 import pytest
 
+from conftest import assert_close_rel
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -290,3 +292,121 @@ def test_loopback_ragged_three_ranks(ra, orc, ctx, meshes):
     assert abs(s1["sum"] - s3["sum"]) <= 1e-6 * abs(s1["sum"]) and s1["max"] == s3["max"]
     assert np.allclose([e1["pose"]["t"][k] for k in "xyz"], [e3["pose"]["t"][k] for k in "xyz"], rtol=1e-6, atol=1e-7)
     assert np.allclose(e1["covariance"], e3["covariance"], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("world,resample", [(1, "gladiator"), (3, "residual"), (8, "gladiator")])
+def test_sharded_cycle_motion_update_resample_equals_the_single_device_cycle(ra, orc, ctx, meshes, world, resample):
+    """the whole cycle of the filter node (rmcl_localization.cpp:84, 432-552) behind the one-process ABI --
+    rmclhip_pf_sharded_motion_update (k_pf_motion per rank, collision ray included) and rmclhip_pf_sharded_step (motion -> sensor update
+    -> weight all-gather -> {sum, max} -> resampling) -- on loopback ranks of device 0: particle for particle, bit for bit, the cloud the
+    single-device sequence TFMotionUpdaterHip / PCDSensorUpdaterHip / resampler leaves; three cycles, a ragged particle count, particles
+    that cross a wall (collision -> likelihood {0, 0, MAX_N_MEAS}); and the recorded call sequence enqueues every rank's launch of a
+    phase before the host waits for any."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room30k")
+    hm = ra.import_hip_map(ctx, v, f)
+    n = 5003
+    poses, attrs = syn.uniform_particles(n, seed=15, bb_min=(-9.5, -9.5, 0.2, 0, 0, -math.pi), bb_max=(9.5, 9.5, 3, 0, 0, math.pi))
+    attrs["likelihood"]["n_meas"] = np.random.RandomState(1).randint(0, 300, n)
+    beams = ra.beams_from_points(syn.model_directions(syn.model_pf16())[::4] * np.float32(4.0))
+    Tsb = syn.tsb_offset()
+    steps = [T.transform_from_rpy((0.9, 0.1, 0.0), (0.0, 0.0, 0.05)), T.transform_from_rpy((0.4, -0.3, 0.02), (0.0, 0.0, -0.2)),
+             T.transform_from_rpy((1.5, 0.0, 0.0), (0.0, 0.0, 0.0))]
+    # ---- the single-device cycle
+    mot = ra.TFMotionUpdaterHip(hm, check_collision=True)
+    mot.init()
+    upd = ra.PCDSensorUpdaterHip(hm)
+    upd.init()
+    upd.setInput(beams, Tsb)
+    rs = ra.ResidualResamplerHip(ctx, seed=77) if resample == "residual" else ra.GladiatorResamplerHip(ctx, seed=77)
+    d_p, d_a = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
+    d_pn, d_an = ra.DeviceArray(ctx, T.TRANSFORM, n), ra.DeviceArray(ctx, T.PARTICLE_ATTRIBUTES, n)
+    ref = []
+    for k, Tm in enumerate(steps):
+        mot.update(d_p, d_a, n, Tm, 0.1)
+        after_motion = d_a.download()
+        upd.update(d_p, d_a)
+        st = rs.compute_stats(d_a, n)
+        rs.step = k
+        rs.update(d_p, d_a, d_pn, d_an, n)
+        d_p, d_pn, d_a, d_an = d_pn, d_p, d_an, d_a
+        ref.append((d_p.download(), d_a.download(), st, after_motion))
+    assert (ref[0][3]["likelihood"]["n_meas"] == 10000).sum() > 20      # some particles did cross a wall
+    # ---- the sharded cycle, phase by phase (cycle 0) and through the one-call step (cycles 1, 2)
+    sh = ra.ShardedParticleFilterHip(v, f, devices=(0,) * world, loopback=True)
+    sh.set_particles(poses, attrs)
+    _trace(ra, 1)
+    sh.motion_update(steps[0], 0.1, check_collision=True)
+    tr = _phases(_trace(ra, 0))
+    assert _enqueues_precede_waits(tr["motion"], world), tr
+    assert sh.download()[1].tobytes() == ref[0][3].tobytes()
+    sh.update(beams, Tsb)
+    st0 = sh.stats()
+    sh.resample(seed=77, step=0, residual=(resample == "residual"))
+    p, a = sh.download()
+    assert p.tobytes() == ref[0][0].tobytes() and a.tobytes() == ref[0][1].tobytes()
+    assert st0["max"] == ref[0][2]["max"] and abs(st0["sum"] - ref[0][2]["sum"]) <= 1e-6 * abs(ref[0][2]["sum"])
+    for k in (1, 2):
+        _trace(ra, 1)
+        st = sh.step(beams, Tsb, T_bnew_bold=steps[k], forget_rate=0.1, check_collision=True, resample=resample, seed=77, step=k)
+        tr = _phases(_trace(ra, 0))
+        # motion and update are enqueued on every rank without a host wait in between; the first wait belongs to the gather
+        assert tr["motion"] == ["E%d" % r for r in range(world)] and tr["update"] == ["E%d" % r for r in range(world)], tr
+        assert _enqueues_precede_waits(tr["gather"], world) and _enqueues_precede_waits(tr["resample"], world), tr
+        p, a = sh.download()
+        assert p.tobytes() == ref[k][0].tobytes() and a.tobytes() == ref[k][1].tobytes(), "cycle %d" % k
+        assert st["max"] == ref[k][2]["max"] and abs(st["sum"] - ref[k][2]["sum"]) <= 1e-6 * abs(ref[k][2]["sum"])
+    sh.close()
+    for o in (mot, upd, rs):
+        o.close()
+
+
+def test_c5_full_size_one_run_on_eight_loopback_ranks(ra, orc, ctx, meshes):
+    """BASELINE config C5 at FULL size as one run: 1 000 000 particles x 256 beams on the 1 M-triangle sphere through
+    rmclhip_pf_update_sharded + weight all-gather + {sum, max} + pose estimate + the distributed tournament, on eight LOOPBACK ranks of
+    this one GPU (RCCL itself needs eight GPUs; the loopback communicator runs the same ndev = 8 code on one).  Checked against the eight
+    single-shard updates (each rank's block == PCDSensorUpdaterHip on that block alone), the gathered weights, an oracle sample from
+    every shard, and ONE unsharded tournament over the whole cloud."""
+    from rmcl_amd import distributed as D, synthetic as syn, types as T
+    v, f = meshes("sphere1m")
+    world, n = 8, 1000000
+    poses, attrs = syn.uniform_particles(n, seed=5, bb_min=(-5, -5, -1, 0, 0, -math.pi), bb_max=(5, 5, 1, 0, 0, math.pi))
+    beams = ra.beams_from_points(syn.model_directions(syn.model_pf16()) * np.float32(10.0))
+    assert len(beams) == 256
+    sh = ra.ShardedParticleFilterHip(v, f, devices=(0,) * world, loopback=True)
+    sh.set_particles(poses, attrs)
+    st = sh.step(beams, T.identity())                       # update + gather + {sum, max}, no motion, no resampling
+    w = sh.weights(3)
+    p1, a1 = sh.download()
+    assert p1.tobytes() == poses.tobytes()
+    assert np.array_equal(w, a1["likelihood"]["mean"]) and np.all(a1["likelihood"]["n_meas"] == 256)
+    # the eight single-shard updates on one plain updater
+    hm = ra.import_hip_map(ctx, v, f)
+    upd = ra.PCDSensorUpdaterHip(hm)
+    upd.init()
+    upd.setInput(beams, T.identity())
+    m = orc.Mesh(v, f)
+    for r in range(world):
+        lo, hi = D.shard_bounds(n, r, world)
+        d_p, d_a = ra.DeviceArray.from_host(ctx, poses[lo:hi]), ra.DeviceArray.from_host(ctx, attrs[lo:hi])
+        upd.update(d_p, d_a)
+        assert d_a.download().tobytes() == a1[lo:hi].tobytes(), "shard %d" % r
+        sub = slice(lo + 17 * r, lo + 17 * r + 2000)        # 2 000 particles of every shard against the oracle
+        ref = attrs[sub].copy()
+        m.pf_update(poses[sub], ref, beams, T.identity(), orc.pf_params(), bvh=2, nthreads=16)
+        assert_close_rel(a1["likelihood"]["mean"][sub], ref["likelihood"]["mean"], 1e-5, 1e-12, "C5 shard %d mean" % r)
+        d_p.free(); d_a.free()
+    Lm = a1["likelihood"]["mean"].astype(np.float64)
+    assert abs(st["sum"] - Lm.sum()) <= 1e-6 * Lm.sum() and st["max"] == np.float32(Lm.max())
+    est = sh.pose_estimate(10000)
+    ref_e = orc.estimate_stats(poses, a1, 10000)
+    assert np.allclose([est["pose"]["t"][k] for k in "xyz"], [ref_e["pose"]["t"][k] for k in "xyz"], rtol=1e-6, atol=1e-6)
+    # ONE unsharded tournament over the million particles == the distributed one
+    rs = ra.GladiatorResamplerHip(ctx, seed=9)
+    d_p, d_a = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, a1)
+    d_pn, d_an = ra.DeviceArray(ctx, T.TRANSFORM, n), ra.DeviceArray(ctx, T.PARTICLE_ATTRIBUTES, n)
+    rs.update(d_p, d_a, d_pn, d_an, n)
+    sh.resample(seed=9, step=0)
+    p2, a2 = sh.download()
+    assert p2.tobytes() == d_pn.download().tobytes() and a2.tobytes() == d_an.download().tobytes()
+    rs.close(); upd.close(); sh.close()

@@ -389,3 +389,57 @@ def test_beam_errors_in_global_scratch_equal_the_lds_form(ra, orc, ctx, meshes, 
     for _ in range(2):
         e_ref = m.pf_update(poses, a_ref, beams, syn.tsb_offset(), orc.pf_params(), bvh=True, nthreads=8, want_errors=True)
     _check(out[0][0], out[0][1].reshape(n, n_beams), a_ref, e_ref, "global scratch, %d beams" % n_beams)
+
+
+def _check_all_particles(a_gpu, a_ref, what):
+    """every particle: n_meas bit-exact, likelihood mean AND sigma within the bar of _check"""
+    assert np.array_equal(a_gpu["likelihood"]["n_meas"], a_ref["likelihood"]["n_meas"]), what + " n_meas"
+    assert_close_rel(a_gpu["likelihood"]["mean"], a_ref["likelihood"]["mean"], 1e-5, 1e-12, what + " mean")
+    assert_close_rel(a_gpu["likelihood"]["sigma"], a_ref["likelihood"]["sigma"], 1e-4, 1e-10, what + " sigma")
+    assert np.array_equal(a_gpu["state_sigma"], a_ref["state_sigma"])
+
+
+def test_c4_full_size_every_particle_against_the_oracle(ra, orc, ctx, meshes):
+    """VERDICT r4 'close the sampling holes': config C4 at full size, ALL 100 000 particles x 256 beams against the oracle's sequential
+    sensorUpdate (its BVH4 + SSE walk, bvh=2: 25.6 M rays in a second or two on the box's CPUs) -- n_meas, likelihood mean and sigma of
+    every particle; then a SECOND update on the result (n_meas 256 -> 512: the merge weights of a non-empty history)."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("sphere100k")
+    hm = ra.import_hip_map(ctx, v, f)
+    m = orc.Mesh(v, f)
+    n = 100000
+    poses, attrs = syn.uniform_particles(n, seed=42, bb_min=(-5, -5, -1, 0, 0, -math.pi), bb_max=(5, 5, 1, 0, 0, math.pi))
+    beams = ra.beams_from_points(syn.model_directions(syn.model_pf16()) * np.float32(6.0))
+    assert len(beams) == 256
+    upd = ra.PCDSensorUpdaterHip(hm)
+    upd.init()
+    upd.setInput(beams, T.identity())
+    d_poses, d_attrs = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
+    ref = attrs.copy()
+    for rnd in range(2):
+        upd.update(d_poses, d_attrs)
+        m.pf_update(poses, ref, beams, T.identity(), orc.pf_params(), bvh=2, nthreads=16)
+        _check_all_particles(d_attrs.download(), ref, "C4 update %d" % rnd)
+    assert np.all(ref["likelihood"]["n_meas"] == 512)
+    upd.close()
+
+
+def test_c5_shard_every_particle_against_the_oracle(ra, orc, ctx, meshes):
+    """one GPU's share of config C5 -- 125 000 particles x 256 beams on the 1 M-triangle sphere -- ALL particles against the oracle
+    (n_meas, mean, sigma), not a prefix"""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("sphere1m")
+    hm = ra.import_hip_map(ctx, v, f)
+    m = orc.Mesh(v, f)
+    n = 125000
+    poses, attrs = syn.uniform_particles(n, seed=11, bb_min=(-5, -5, -1, 0, 0, -math.pi), bb_max=(5, 5, 1, 0, 0, math.pi))
+    beams = ra.beams_from_points(syn.model_directions(syn.model_pf16()) * np.float32(10.0))
+    upd = ra.PCDSensorUpdaterHip(hm)
+    upd.init()
+    upd.setInput(beams, T.identity())
+    d_poses, d_attrs = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
+    upd.update(d_poses, d_attrs)
+    ref = attrs.copy()
+    m.pf_update(poses, ref, beams, T.identity(), orc.pf_params(), bvh=2, nthreads=16)
+    _check_all_particles(d_attrs.download(), ref, "C5 shard")
+    upd.close()

@@ -428,3 +428,31 @@ def test_bvh4_sse_walk_equals_brute_force_and_bvh2(orc, meshes, name):
     one = orc.Mesh(v[f[0]].reshape(3, 3), np.array([[0, 1, 2]], np.uint32))      # a map of ONE triangle: the BVH2 root is a leaf
     assert np.array_equal(one.simulate_spherical(model, T.identity(), poses[0], bvh=2)["face_ids"],
                           one.simulate_spherical(model, T.identity(), poses[0], bvh=False)["face_ids"])
+
+
+def test_one_pass_threaded_reduction_equals_the_two_pass_value(orc):
+    """orc_statistics_p2l_fast (bench.py's cpu_baseline form: one pass of raw double sums on a worker pool) against the two-pass f64
+    authority, with a pre-transform, masks, a gate that rejects a third of the pairs, points 40 m from the origin (where the raw-sum form
+    loses digits: it must stay within 1e-9 relative of the spread) and 1 / 3 / 8 threads; an empty selection gives Identity."""
+    rng = np.random.RandomState(3)
+    n = 50001
+    d = (rng.normal(size=(n, 3)) * 3 + np.array([40.0, -25.0, 5.0])).astype(np.float32)
+    nrm = rng.normal(size=(n, 3))
+    nrm = (nrm / np.linalg.norm(nrm, axis=1)[:, None]).astype(np.float32)
+    mp = (d + nrm * rng.normal(scale=0.4, size=(n, 1))).astype(np.float32)
+    dm = (rng.uniform(size=n) > 0.1).astype(np.uint8)
+    mm = (rng.uniform(size=n) > 0.1).astype(np.uint8)
+    Tpre = orc.transform((0.0005, -0.0003, 0.0008, 1.0), (0.05, -0.02, 0.01))     # (a few cm at 40 m: most pairs stay inside the gate)
+    q = np.array([Tpre["R"][k] for k in "xyzw"], np.float64)
+    for i, k in enumerate("xyzw"):
+        Tpre["R"][k] = q[i] / np.linalg.norm(q)
+    ref = orc.statistics_p2l_f64(Tpre, d, dm, mp, nrm, mm, 0.5)
+    assert 0.3 * n < ref["n_meas"] < 0.8 * n
+    for nt in (1, 3, 8):
+        s = orc.statistics_p2l_fast(Tpre, d, dm, mp, nrm, mm, 0.5, nthreads=nt)
+        assert int(s["n_meas"]) == ref["n_meas"]
+        assert np.allclose([s["dataset_mean"][k] for k in "xyz"], ref["dataset_mean"], rtol=1e-6, atol=1e-6)
+        assert np.allclose([s["model_mean"][k] for k in "xyz"], ref["model_mean"], rtol=1e-6, atol=1e-6)
+        assert np.allclose(s["covariance"].reshape(3, 3), ref["covariance"], rtol=1e-5, atol=1e-5)
+    e = orc.statistics_p2l_fast(Tpre, d, np.zeros(n, np.uint8), mp, nrm, mm, 0.5, nthreads=4)
+    assert int(e["n_meas"]) == 0
