@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "rmcl_hip/rmcl_hip.hpp"
+#include "rmclhip_bench.h"   // rmclhip_rcc_time_caller_loop: a measurement aid, not part of the boundary
 
 using namespace rmcl_hip;
 

@@ -378,32 +378,6 @@ rmclhip_status rmclhip_rcc_sharded_replica(rmclhip_rcc_sharded* h, uint32_t rank
 rmclhip_status rmclhip_rcc_sharded_correct_batch(rmclhip_rcc_sharded* h, const rmclhip_transform* Tbm, uint32_t nposes,
                                                  rmclhip_transform* Tdelta_out, rmclhip_cross_statistics* stats_out);
 
-/* kernel timing of the last synchronous find / streaming reduction on the handle's stream (hipEvent, ms).  OPT-IN since round 4
- * (rmclhip_rcc_set_kernel_timing 1): the two hipEventRecord + hipEventElapsedTime per call cost the caller microseconds on calls
- * that take tens; without it the values stay at what the last timed call left (0 initially). */
-rmclhip_status rmclhip_rcc_set_kernel_timing(rmclhip_rcc* rcc, int on);
-/* host-clock time of one synchronous rmclhip_rcc_find as a C caller sees it (mean over `iters` calls after one untimed call) */
-rmclhip_status rmclhip_rcc_time_find_sync(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est, uint32_t iters, float* ms_per_call);
-rmclhip_status rmclhip_rcc_last_kernel_ms(rmclhip_rcc* rcc, float* find_ms, float* reduce_ms);
-/* benchmarking hook: run `iters` back-to-back find launches on the handle's stream bracketed by
- * hipEvents on THAT stream; returns the mean kernel-to-kernel time per launch in ms */
-rmclhip_status rmclhip_rcc_time_find(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est, uint32_t iters,
-                                     float* ms_per_launch);
-rmclhip_status rmclhip_rcc_time_reduce(rmclhip_rcc* rcc, const rmclhip_transform* T_snew_sold, uint32_t iters,
-                                       float* ms_per_launch);
-/* host-clock time of one complete synchronous rmclhip_rcc_correct_once as a C caller sees it (mean over `iters` calls
- * after one untimed call); measurement aid like time_find / time_reduce */
-rmclhip_status rmclhip_rcc_time_correct_once(rmclhip_rcc* rcc, const rmclhip_transform* Tom, const rmclhip_transform* Tbo,
-                                             uint32_t n_iter, double convergence_progress, int refind_each_iteration,
-                                             uint32_t iters, float* ms_per_call);
-/* host-clock time of the reference's UNCHANGED caller loop for one sensor (micp_localization.cpp:900-964: find once, then n_iter x
- * { computeCrossStatistics, Tsb *, Tbo *, merge, umeyama_transform, compose } on the host) through the public entry points above,
- * mean over `iters` corrections after two untimed ones; also returns the last T_onew_oold / merged statistics (nullable).  What an
- * integrator measures who keeps the node's loop instead of calling rmclhip_rcc_correct_once. */
-rmclhip_status rmclhip_rcc_time_caller_loop(rmclhip_rcc* rcc, const rmclhip_transform* Tom, const rmclhip_transform* Tbo,
-                                            uint32_t n_iter, double convergence_progress, uint32_t iters,
-                                            rmclhip_transform* T_onew_oold_out, rmclhip_cross_statistics* merged_out,
-                                            float* ms_per_call);
 /* kernel variant selection: bits 0..3 (+ bit 13 = 16 more) traversal kind.  15 = automatic, the default: four
  * lanes per ray up to 57344 rays in flight (kind 2); above that one lane per ray STARTING AT THE MAP'S FRONTIER (the wave culls
  * the <= 256 references of BFS depth 4 against its tile's pyramid and every ray tests the few survivors: the top levels of
@@ -483,8 +457,6 @@ rmclhip_status rmclhip_rcc_autotune_batch(rmclhip_rcc* rcc, const rmclhip_transf
 /* rm::Simulator::simulate(Memory<Transform>, Bundle&) (batch form, lidar_corrector_embree_benchmark.cpp:117):
  * one launch for nposes x H x W rays; model buffers become pose-major [pose][vid][hid]. */
 rmclhip_status rmclhip_rcc_find_batch(rmclhip_rcc* rcc, const rmclhip_transform* Tbm, uint32_t nposes);
-rmclhip_status rmclhip_rcc_time_find_batch(rmclhip_rcc* rcc, const rmclhip_transform* Tbm, uint32_t nposes,
-                                           uint32_t iters, float* ms_per_launch);
 
 /* ---- host-side algebra (rmagine math the callers of the hot path use) -------------- */
 /* rm::umeyama_transform(CrossStatistics) (micp_localization.cpp:952-953) */
@@ -537,10 +509,6 @@ rmclhip_status rmclhip_pf_motion_update(rmclhip_pf* pf, rmclhip_transform* poses
  * multi-GPU all-gather) */
 rmclhip_status rmclhip_pf_extract_weights(rmclhip_pf* pf, const rmclhip_particle_attributes* attrs_dev,
                                           uint32_t n_particles, float* weights_dev);
-rmclhip_status rmclhip_pf_time_update(rmclhip_pf* pf, const rmclhip_transform* poses_dev,
-                                      rmclhip_particle_attributes* attrs_dev, uint32_t n_particles,
-                                      const rmclhip_range_measurement* beams, uint32_t n_beams,
-                                      const rmclhip_transform* Tsb, uint32_t iters, float* ms_per_launch);
 /* bits 0..3: traversal (0 = while-while with the hybrid LDS + scratch stack, 1 = stack entirely in LDS, 2 = single
  * loop, A/B); bits 4..6: ray scheduling (0 = rounds of one ray per lane; 1..4 = persistent lanes that fetch the
  * next ray when 8 / 16 / 32 / 48 lanes of their wave are idle); bit 7: persistent lanes on the 128-B nodes instead

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/rmclhip.h"
+#include "../../include/rmclhip_bench.h"
 #include "../../include/rmclhip_lab.h"
 #include "bvh_build.h"
 #include "devmath.h"
