@@ -1016,7 +1016,7 @@ def _cpu_baselines_c3_c4_v1(orc, m, np, syn, T, model, ra, usable):
     return out
 
 
-def _pf_c4(ra, syn, T, np, ctx, hm, n_particles, n_beams, iters, bb=((-5, -5, -1), (5, 5, 1)), converged_at=None, particle_minor=False):
+def _pf_c4(ra, syn, T, np, ctx, hm, n_particles, n_beams, iters, bb=((-5, -5, -1), (5, 5, 1)), converged_at=None, particle_minor=False, variant=None):
     """config C4's sensor update; converged_at: a converged cloud ~ N(that pose, 0.25 m, 5 deg yaw) instead of the uniform one;
     particle_minor: the particle-coherent dealing (rmclhip_pf_set_mapping 1, 16 slots per workgroup, Morton order of x / y / yaw)"""
     if converged_at is None:
@@ -1032,6 +1032,8 @@ def _pf_c4(ra, syn, T, np, ctx, hm, n_particles, n_beams, iters, bb=((-5, -5, -1
     d_poses, d_attrs = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
     if particle_minor:
         upd.set_mapping(1, 16, ra.DeviceArray.from_host(ctx, syn.morton_order_xy_yaw(poses)))
+    if variant is not None:
+        upd.set_variant(variant)
     upd.time_update(d_poses, d_attrs, n_particles, iters=1)
     ms = sorted(upd.time_update(d_poses, d_attrs, n_particles, iters=iters) for _ in range(5))[2]
     upd.close()

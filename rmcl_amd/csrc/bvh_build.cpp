@@ -476,6 +476,28 @@ Collapsed collapse(const std::vector<Node2>& n2, uint32_t leaf_limit, float pad,
     } else {
       nk = expand_children(n2, it.n2, is_leaf, area, kids);
     }
+    // Slot order (round 5): the children sorted by box centre along the axis on which their centres spread most (ties: expansion
+    // order).  A ray whose direction is positive on that axis meets the slots roughly near-to-far in slot order, a negative one in
+    // reverse: the particle filter's walk takes that order instead of sorting the entry distances (traverse.hip.h node_step_so).
+    // Every other traversal orders the children itself, so only their node numbering moves.  axis -> reserved[0] and, for the
+    // quantised twin, the low two mantissa bits of its x scale (quantise()).
+    {
+      float c[4][3], lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+      for (int i = 0; i < nk; ++i)
+        for (int a = 0; a < 3; ++a) {
+          c[i][a] = 0.5f * (n2[kids[i]].b.mn[a] + n2[kids[i]].b.mx[a]);
+          lo[a] = std::min(lo[a], c[i][a]);
+          hi[a] = std::max(hi[a], c[i][a]);
+        }
+      int ax = 0;
+      for (int a = 1; a < 3; ++a) if (hi[a] - lo[a] > hi[ax] - lo[ax]) ax = a;
+      int idx[4] = {0, 1, 2, 3};
+      std::stable_sort(idx, idx + nk, [&](int x, int y) { return c[x][ax] < c[y][ax]; });
+      int32_t sorted[4];
+      for (int i = 0; i < nk; ++i) sorted[i] = kids[idx[i]];
+      for (int i = 0; i < nk; ++i) kids[i] = sorted[i];
+      nd.reserved[0] = static_cast<uint32_t>(ax);
+    }
     const uint32_t stack_here = it.stack_before + static_cast<uint32_t>(nk - 1);
     out.stack_need = std::max(out.stack_need, stack_here);
     nd.n_children = static_cast<uint32_t>(nk);
@@ -526,6 +548,15 @@ void quantise(const std::vector<Node4>& nodes, std::vector<Node4Q>& qnodes, int 
       float sc = (mx - mn) / 255.0f;
       if (!(sc > 1e-30f)) sc = 1e-30f;
       while (mn + 255.0f * sc < mx) sc = std::nextafter(sc, std::numeric_limits<float>::infinity());
+      if (a == 0) {
+        // the node's slot-order axis rides in the low two mantissa bits of the x scale: the next float >= sc that ends in those bits
+        // (a larger step still covers the boxes; the bytes below are computed with the final value)
+        uint32_t bits;
+        std::memcpy(&bits, &sc, 4);
+        const uint32_t want = nd.reserved[0] & 3u;
+        bits += (want - (bits & 3u)) & 3u;
+        std::memcpy(&sc, &bits, 4);
+      }
       q.origin[a] = mn;
       q.scale[a] = sc;
       uint32_t lo_word = 0, hi_word = 0;

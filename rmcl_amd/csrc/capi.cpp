@@ -344,6 +344,10 @@ struct rmclhip_pf {
   // rmclhip_pf_set_mapping: 0 beam-minor blocks of ~2048 rays (default), 1 particle-minor blocks (measured neutral, kept for A/B); nothing else is accepted
   bool cpc_grid = true;            // correspondence_type 1: seed every closest-point query from the map's near grid (A/B: rmclhip_pf_set_mapping bit 8 clears it)
   ChainTag tag;                    // completion tag of the synchronous kernel-only calls (update, motion update, extract_weights)
+  bool slot_order = false;         // rmclhip_pf_set_variant bit 11
+  bool accum = true;               // order-independent likelihood accumulation (round 5 default: no error scratch, no in-order chain); rmclhip_pf_set_variant bit 12 clears it (A/B: rounds 3 / 4)
+  DevBuf<double> d_gpow;           // g^i, i = 0 .. n_beams, g = max_n_meas / (max_n_meas + 1): its merge weights
+  uint32_t gpow_beams = 0, gpow_max = 0;
   bool evals_global = true;        // k_pf_update_v3 keeps a workgroup's beam errors in global scratch, not LDS (A/B: rmclhip_pf_set_mapping bit 9 clears it)
   DevBuf<float> d_evals;           // [n_particles * n_beams], grow-only
   int mapping = 0;
@@ -3083,7 +3087,7 @@ void rmclhip_pf_destroy(rmclhip_pf* f) {
   if (!f) return;
   (void)hipSetDevice(f->ctx->device);
   if (f->stream) (void)hipStreamSynchronize(f->stream);
-  f->d_beams.release(); f->d_evals.release(); f->d_order.release(); f->tag.destroy();
+  f->d_beams.release(); f->d_evals.release(); f->d_gpow.release(); f->d_order.release(); f->tag.destroy();
   if (f->h_beams) (void)hipHostFree(f->h_beams);
   if (f->ev0) (void)hipEventDestroy(f->ev0);
   if (f->ev1) (void)hipEventDestroy(f->ev1);
@@ -3188,7 +3192,23 @@ static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, 
   if (static_cast<size_t>(pb) * n_beams > (p.particle_minor ? 24576u : 8192u)) return fail(RMCLHIP_ERR_UNSUPPORTED, "pf_update: more than 8192 beams");
   p.particles_per_block = pb;
   p.evals = nullptr;
-  if (f->evals_global && f->params.correspondence_type != 1u) {
+  p.gpow = nullptr;
+  p.inv_max1 = 0.0;
+  const bool accum = f->accum && f->params.correspondence_type != 1u;
+  if (accum) {
+    if (f->gpow_beams != n_beams || f->gpow_max != f->params.max_n_meas || f->d_gpow.p == nullptr) {
+      std::vector<double> g(static_cast<size_t>(n_beams) + 1u);
+      const double base = static_cast<double>(f->params.max_n_meas) / (static_cast<double>(f->params.max_n_meas) + 1.0);
+      for (uint32_t i = 0; i <= n_beams; ++i) g[i] = std::pow(base, static_cast<double>(i));
+      HIPCHK(hipStreamSynchronize(f->stream));   // an update in flight may still read the old table
+      HIPCHK(f->d_gpow.reserve(g.size()));
+      HIPCHK(upload_on(f->stream, f->d_gpow.p, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice));
+      f->gpow_beams = n_beams; f->gpow_max = f->params.max_n_meas;
+    }
+    p.gpow = f->d_gpow.p;
+    p.inv_max1 = 1.0 / (static_cast<double>(f->params.max_n_meas) + 1.0);
+  }
+  if (!accum && f->evals_global && f->params.correspondence_type != 1u) {
     // (the blocks of the last, partial workgroup included: slots are addressed from the workgroup's first particle)
     const size_t slots = (static_cast<size_t>(n) + pb - 1u) / pb * pb;
     const hipError_t re = f->d_evals.reserve(slots * n_beams);
@@ -3203,7 +3223,7 @@ static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, 
   // pb * n_beams <= 8192, n_beams <= 8192: exact.  n_beams == 1 has no 32-bit magic (2^32 + 1): the kernel takes pi = ray there
   p.nb_magic = (n_beams == 1u) ? 0u : static_cast<uint32_t>((1ull << 32) / n_beams) + 1u;
   const int variant = (f->variant & 3) | ((std::max(f->map->info.stack_need, f->map->info.stack_need_pf) > 32) ? 4 : 0) | (f->params.correspondence_type == 1u ? 8 : 0) |
-                      (f->refill << 4) | (f->full_nodes ? 128 : 0) | (f->legacy ? 256 : 0) | (f->pf_tree ? 0 : 1024);
+                      (f->refill << 4) | (f->full_nodes ? 128 : 0) | (f->legacy ? 256 : 0) | (f->pf_tree ? 0 : 1024) | (f->slot_order ? 2048 : 0) | (accum ? 4096 : 0);
   HIPCHK(launch_pf_update(p, variant, f->stream));
   return RMCLHIP_OK;
 }
@@ -3306,7 +3326,7 @@ rmclhip_status rmclhip_pf_set_mapping(rmclhip_pf* f, int mapping, uint32_t parti
 
 rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* f, int variant) {
   ApiGuard guard_("rmclhip_pf_set_variant");
-  if (!f || variant < 0 || (variant & 15) > 2 || ((variant >> 4) & 7) > 4 || (variant >> 11) != 0) return fail(RMCLHIP_ERR_INVALID, "pf_set_variant: bad arguments");
+  if (!f || variant < 0 || (variant & 15) > 2 || ((variant >> 4) & 7) > 4 || (variant >> 13) != 0) return fail(RMCLHIP_ERR_INVALID, "pf_set_variant: bad arguments");
   const int kind = variant & 15, refill = (variant >> 4) & 7;
   const bool full_nodes = ((variant >> 7) & 1) != 0, legacy = ((variant >> 8) & 1) != 0;
   // validate BEFORE the handle is touched: a rejected configuration must not stay behind (every later update would fail)
@@ -3319,6 +3339,8 @@ rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* f, int variant) {
   f->legacy = legacy;                         // the round-2 kernel
   f->big_blocks = ((variant >> 9) & 1) != 0;  // 4096 instead of 2048 rays per workgroup
   f->pf_tree = ((variant >> 10) & 1) == 0;    // bit 10: traverse the map's tree (leaves <= 4) instead of the filter's own
+  f->slot_order = ((variant >> 11) & 1) != 0; // bit 11 (round 5, A/B): children in the ray's slot order instead of sorted by entry distance
+  f->accum = ((variant >> 12) & 1) == 0;      // bit 12 (A/B): the stored form of rounds 3 / 4 (errors in scratch, dense pass, in-order chain) instead of the round-5 accumulation
   return RMCLHIP_OK;
 }
 

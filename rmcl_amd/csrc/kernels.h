@@ -130,6 +130,10 @@ struct PfParams {
   // and read back by the same workgroup: L2) instead of LDS -- 16 KB less LDS per workgroup, 7 instead of 4 workgroups per CU
   // (profiles/r04_pf_occupancy.txt).  null: the LDS form of rounds 3.
   float* evals;
+  // k_pf_update_v3<..., kAccum> (round 5): g^i for i = 0 .. n_beams, g = max_n_meas / (max_n_meas + 1), and 1 / (max_n_meas + 1) -- the
+  // closed-form merge weights of a particle's beams (kernels.hip "order-independent likelihood accumulation"); null: the forms of rounds 3 / 4
+  const double* gpow;
+  double inv_max1;
 };
 
 // per-call inputs of the device-resident MICP loop: written by ONE H2D copy so that the whole loop can be a

@@ -1498,7 +1498,57 @@ __device__ __forceinline__ void leaf_pair(const uint32_t* __restrict__ tris, uin
   if (__any(two)) tri_update(a1, b1, c1, second, tris, O, D, ray_tfar, best_t, best_rec);
 }
 
-template <int kRows, bool kLeaf2>
+// ---------------------------------------------------------------------------------------------
+// Round 5: ORDER-INDEPENDENT likelihood accumulation (kAccum).  The reference merges a particle's beams one by one,
+//   likelihood += Gaussian1D{eval, 0, 1};  n_meas = min(n_meas, MAX_N_MEAS)             (PCDSensorUpdaterEmbree.cpp:232-238)
+// which is a linear recurrence with weights that depend on the COUNTS alone: with S = sigma + mean^2,
+//   mean' = w1 mean + w2 e,   S' = w1 S + w2 e^2,   w1 = a / (a + 1),  w2 = 1 / (a + 1),  a = the count before the beam.
+// So   mean_K = P0 mean_0 + sum_k W_k e_k,   S_K = P0 S_0 + sum_k W_k e_k^2,   W_k = w2_k prod_{j > k} w1_j,  P0 = prod_j w1_j,
+// and the counts are a_k = min(n0 + k, MAX) (a_0 = n0 whatever it is): W_k is the SAME for every beam merged before the clamp
+// (g^(K - Kc) / (n0 + Kc), Kc = min(MAX - n0, K), g = MAX / (MAX + 1)) and g^(K - 1 - k) / (MAX + 1) for the beams after it.
+// Rounds 3 / 4 kept every beam's error (LDS, then 100 MB of global scratch written and read back) for a dense pass and ONE lane per
+// particle walking the chain.  Here a finished ray adds W_k e and W_k e^2 straight into its particle's accumulators and is forgotten.
+// The sums must not depend on the order the rays finish in (results are compared bit for bit across schedules, shards and runs):
+// the accumulators are FIXED-POINT -- per quantity a row of 64-bit integers, one per 16 binades ("bin"), a term t = m 2^e going to
+// bin (e - e_min) / 16 as m shifted so that the bin's top is 2^48 units: integer adds commute, a term keeps >= 32 significant bits
+// (the eval is a float: 24), 2^16 terms fit.  Final value = the bins added in ascending order in double.
+// Differences to the sequential float chain: ~1e-7 relative (its own rounding); sigma = S - mean^2 in double resolves a variance
+// down to 1e-16 of mean^2.  n_meas is the closed form as before, bit-exact.
+// ---------------------------------------------------------------------------------------------
+// exp(arg) * inv_den for arg <= 0 in float arithmetic: arg log2(e) split Cody-Waite style into an integer n and a residual r in
+// [-0.5, 0.5] (one fused multiply-add against each half of log2 e: |error of r| ~ 1e-8), 2^r by v_exp_f32 (1 ulp), the scale before
+// the exponent so that results below 2^-126 round like any other denormal.  NaN in, NaN out; below 2^-149 the result is 0.
+__device__ __forceinline__ float pf_eval_fast(float arg, float inv_den) {
+  const float kL2eHi = 1.44269502162933349609375f, kL2eLo = 1.925963033500011e-08f;
+  const float n = fmaxf(rintf(arg * kL2eHi), -400.0f);
+  float r = fmaf(arg, kL2eHi, -n);
+  r = fmaf(arg, kL2eLo, r);
+  return ldexpf(__builtin_amdgcn_exp2f(fmaxf(r, -2.0f)) * inv_den, static_cast<int>(n));
+}
+
+constexpr int kAccBins1 = 17, kAccEmin1 = -256;   // sum W e:   terms in [2^-256, 2^16)
+constexpr int kAccBins2 = 28, kAccEmin2 = -416;   // sum W e^2: terms in [2^-416, 2^32)
+constexpr int kAccWords = kAccBins1 + kAccBins2;  // 64-bit words per particle
+
+// returns false when t lies above the row's range (the caller poisons the particle: NaN, as an infinite term would make the chain)
+__device__ __forceinline__ bool acc_add(unsigned long long* row, int nbins, int e_min, double t) {
+  const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(t));
+  const int e = static_cast<int>((b >> 52) & 0x7FFull) - 1023;   // floor(log2 t) of a positive normal double
+  const int j = (e - e_min) >> 4;
+  if (j < 0) return true;                                         // below 2^e_min: cannot reach a float result
+  if (j >= nbins) return false;
+  const int shift = 4 + (e_min + 16 * (j + 1) - e);               // 5..20: the bin's top 2^E is 2^48 units
+  const unsigned long long mant = (b & 0xFFFFFFFFFFFFFull) | (1ull << 52);
+  atomicAdd(row + j, mant >> shift);
+  return true;
+}
+__device__ __forceinline__ double acc_value(const unsigned long long* row, int nbins, int e_min) {
+  double v = 0.0;
+  for (int j = 0; j < nbins; ++j) v += ldexp(static_cast<double>(row[j]), e_min + 16 * (j + 1) - 48);
+  return v;
+}
+
+template <int kRows, bool kLeaf2, bool kSlotOrder = false, bool kAccum = false>
 __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
   // LDS: [ per-lane stacks kRows*256 (later: merge weights) | Tsm (PB xforms) | n0 (PB) | errors -> evals (PB*n_beams floats) ]
   // (round 4 A/B, removed: the top 85 / 341 nodes of the tree in LDS -- the TD / TA units read 94 % / 82 % busy, but those are
@@ -1518,16 +1568,36 @@ __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
   float* s_eval = evals_global ? (p.evals + static_cast<size_t>(p0) * p.n_beams) : reinterpret_cast<float*>(s_n0 + p.particles_per_block);
   const uint32_t np = min(PB, p.n_particles - p0);
   pattrs* attrs = reinterpret_cast<pattrs*>(p.attrs);
+  // kAccum: behind n0 (8-byte aligned) per particle { W of an unclamped beam (double) | first clamped beam | poison } and the bins
+  // (the dynamic segment starts behind the 4 bytes of s_next: 8-byte alignment is taken from the ADDRESS, not from the offset -- 64-bit LDS
+  // atomics fault on a misaligned word; the launcher reserves the dword this may skip)
+  const uint32_t acc_dw = kRows * 256u + 8u * PB + PB;
+  double* s_wu = reinterpret_cast<double*>(lds_dyn + acc_dw + (((static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_dyn)) >> 2) + acc_dw) & 1u));
+  uint32_t* s_kc = reinterpret_cast<uint32_t*>(s_wu + PB);
+  uint32_t* s_bad = s_kc + PB;
+  unsigned long long* s_acc = reinterpret_cast<unsigned long long*>(s_bad + PB);
   // slot j of the block = particle `mine` (identity, or the caller's spatial order)
   const uint32_t mine_p = (threadIdx.x < np) ? (p.order ? p.order[p0 + threadIdx.x] : p0 + threadIdx.x) : 0u;
   if (threadIdx.x < np) {
     s_Tsm[threadIdx.x] = xmul(p.poses[mine_p], p.Tsb);
-    s_n0[threadIdx.x] = attrs[mine_p].likelihood.n_meas;
+    const uint32_t n0 = attrs[mine_p].likelihood.n_meas;
+    s_n0[threadIdx.x] = n0;
+    if (kAccum) {
+      const uint32_t K = p.n_beams;
+      // beams 0 .. kc-1 are merged before the count clamps (n0 >= MAX: beam 0 alone, with a = n0)
+      const uint32_t kc = (n0 < p.max_n_meas) ? min(p.max_n_meas - n0, K) : 1u;
+      s_wu[threadIdx.x] = p.gpow[K - kc] / (static_cast<double>(n0) + static_cast<double>(kc));
+      s_kc[threadIdx.x] = kc;
+      s_bad[threadIdx.x] = 0u;
+    }
   }
+  if (kAccum)
+    for (uint32_t i = threadIdx.x; i < np * static_cast<uint32_t>(kAccWords); i += 256u) s_acc[i] = 0ull;
   if (threadIdx.x == 0) s_next = 0u;
   __syncthreads();
 
   const float sq = p.dist_sigma * p.dist_sigma;
+  const float inv_den_f = static_cast<float>(1.0 / sqrt(static_cast<double>(2 * sq) * 3.14159265358979323846));
   const uint32_t nrays = np * p.n_beams;
   const uint32_t np_magic = (np == 1u) ? 0u : static_cast<uint32_t>(0x100000000ull / np) + 1u;   // ray / np (particle-minor order)
   const uint32_t lane = threadIdx.x & 63u;
@@ -1539,6 +1609,7 @@ __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
   RaySlab rs = make_ray_slab(O, mk3(1.f, 1.f, 1.f));
   float range = 0.f, best_t = 0.f;
   uint32_t best_rec = kNone;
+  uint32_t rev_mask = 0u;   // kSlotOrder: bit a = the ray runs towards negative `a`
   uint32_t priv[(kRows < 65) ? (65 - kRows) : 1];
   lds_col[0] = kDone;
   uint32_t sp = 1, cur = kDone;
@@ -1567,7 +1638,25 @@ __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
         } else {
           error = real_hit ? p.rhsm : p.rmsm;
         }
-        s_eval[rr] = error;
+        if (kAccum) {
+          const uint32_t pi = (p.n_beams == 1u) ? rr : __umulhi(rr, p.nb_magic), k = rr - pi * p.n_beams;
+          if (p.errors) p.errors[static_cast<size_t>(p.order ? p.order[p0 + pi] : (p0 + pi)) * p.n_beams + k] = error;
+          // PCDSensorUpdaterEmbree.cpp:224 evaluates exp(-e^2 / sigma^2 / 2) / sqrt(2 sigma^2 pi) with a float argument, double exp /
+          // sqrt and a float result; here the same float argument through pf_eval_fast: <= 2e-7 relative from that value
+          const float arg = -(error * error) / sq / 2;
+          const float ev = pf_eval_fast(arg, inv_den_f);
+          const double e1 = static_cast<double>(ev);
+          const double w = (k < s_kc[pi]) ? s_wu[pi] : p.gpow[p.n_beams - 1u - k] * p.inv_max1;
+          unsigned long long* row = s_acc + pi * static_cast<uint32_t>(kAccWords);
+          bool ok = e1 < __builtin_inf();                // false for NaN and +inf
+          if (ok && e1 > 0.0) {
+            const double t1 = w * e1;
+            ok = acc_add(row, kAccBins1, kAccEmin1, t1) && acc_add(row + kAccBins1, kAccBins2, kAccEmin2, t1 * e1);
+          }
+          if (!ok) atomicOr(&s_bad[pi], 1u);
+        } else {
+          s_eval[rr] = error;
+        }
         has_ray = false;
       }
       // next rays for the idle lanes: one LDS atomic per wave and refill
@@ -1592,6 +1681,7 @@ __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
           range = bm[6];
           rs.inv = mk3(fast_inv(D.x), fast_inv(D.y), fast_inv(D.z));
           rs.noi = mk3(-(O.x * rs.inv.x), -(O.y * rs.inv.y), -(O.z * rs.inv.z));
+          if (kSlotOrder) rev_mask = (D.x < 0.0f ? 1u : 0u) | (D.y < 0.0f ? 2u : 0u) | (D.z < 0.0f ? 4u : 0u);
           best_t = p.ray_tfar;
           best_rec = kNone;
           sp = 1;
@@ -1609,7 +1699,31 @@ __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
       const uint64_t m_inner = __ballot(inner);
       if (m_inner == 0) break;
       if (static_cast<uint32_t>(__popcll(m_inner)) <= p.tail_lanes && __ballot((cur != kDone) && (cur & kLeafBit)) != 0) break;
-      if (inner) {
+      if (inner && kSlotOrder) {
+        // children in the ray's slot order (node_hits_q4_so): the first one hit is entered, the later ones wait on the stack, nearest
+        // on top; three unconditional stores as in the sorted form
+        bool hit[4];
+        uint32_t ref[4];
+        if (!__any(sp + 3u > static_cast<uint32_t>(kRows))) {
+          const uint32_t top = lds_col[(sp - 1u) * kBfStride];
+          node_hits_q_so(p.qnodes, cur, rs, best_t, rev_mask, hit, ref);
+          const bool h01 = hit[0] || hit[1], h012 = h01 || hit[2];
+          lds_col[sp * kBfStride] = ref[3]; sp += (hit[3] && h012) ? 1u : 0u;
+          lds_col[sp * kBfStride] = ref[2]; sp += (hit[2] && h01) ? 1u : 0u;
+          lds_col[sp * kBfStride] = ref[1]; sp += (hit[1] && hit[0]) ? 1u : 0u;
+          const bool any = h012 || hit[3];
+          cur = hit[0] ? ref[0] : (hit[1] ? ref[1] : (hit[2] ? ref[2] : (hit[3] ? ref[3] : top)));
+          sp = any ? sp : (sp - 1u);
+        } else {
+          node_hits_q_so(p.qnodes, cur, rs, best_t, rev_mask, hit, ref);
+          const bool h01 = hit[0] || hit[1], h012 = h01 || hit[2];
+          if (hit[3] && h012) { RMCL_ROW_ST(sp, ref[3]) ++sp; }
+          if (hit[2] && h01) { RMCL_ROW_ST(sp, ref[2]) ++sp; }
+          if (hit[1] && hit[0]) { RMCL_ROW_ST(sp, ref[1]) ++sp; }
+          if (h012 || hit[3]) cur = hit[0] ? ref[0] : (hit[1] ? ref[1] : (hit[2] ? ref[2] : ref[3]));
+          else { --sp; cur = RMCL_ROW_LD(sp); }
+        }
+      } else if (inner) {
         uint32_t key[4], ref[4];
         if (!__any(sp + 3u > static_cast<uint32_t>(kRows))) {
           const uint32_t top = lds_col[(sp - 1u) * kBfStride];
@@ -1648,7 +1762,18 @@ __global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
   float* s_w = reinterpret_cast<float*>(lds_dyn);
   g1d L = {0.f, 0.f, 0u};
   if (threadIdx.x < np) L = attrs[mine_p].likelihood;
-  if (!evals_global) {
+  if (kAccum) {
+    if (threadIdx.x < np) {
+      const unsigned long long* row = s_acc + threadIdx.x * static_cast<uint32_t>(kAccWords);
+      const double p0w = static_cast<double>(s_n0[threadIdx.x]) * s_wu[threadIdx.x];   // prod of every w1: the weight of the history
+      const double m0 = static_cast<double>(L.mean);
+      const double mean = p0w * m0 + acc_value(row, kAccBins1, kAccEmin1);
+      const double S = p0w * (static_cast<double>(L.sigma) + m0 * m0) + acc_value(row + kAccBins1, kAccBins2, kAccEmin2);
+      const bool bad = s_bad[threadIdx.x] != 0u;
+      L.mean = bad ? __uint_as_float(0x7FC00000u) : static_cast<float>(mean);
+      L.sigma = bad ? __uint_as_float(0x7FC00000u) : static_cast<float>(S - mean * mean);
+    }
+  } else if (!evals_global) {
   // dense pass: error -> likelihood (PCDSensorUpdaterEmbree.cpp:224: float argument, double exp / sqrt, float result)
   for (uint32_t i = threadIdx.x; i < nrays; i += 256u) {
     const float error = s_eval[i];
@@ -2811,19 +2936,36 @@ hipError_t launch_pf_update(const PfParams& p, int variant, hipStream_t s) {
     return hipGetLastError();
   }
   if (trav == 0 && refill != 0 && !legacy && ((variant >> 7) & 1) == 0 && p.qnodes != nullptr) {
-    const size_t lds = static_cast<size_t>(kPfRows) * 256u * sizeof(uint32_t) + (p.evals != nullptr ? tail_fixed : tail) + sizeof(uint32_t) * p.particles_per_block;
+    // bit 11: the children of a node in the ray's SLOT order (round 5) instead of sorted by entry distance; bit 12: order-independent
+    // likelihood accumulation (round 5: no per-beam storage; 19 stack rows so that the accumulators fit beside them at 7 workgroups per CU)
+    const bool slot_order = ((variant >> 11) & 1) != 0, accum = ((variant >> 12) & 1) != 0 && p.gpow != nullptr;
+    constexpr int kAccRows = kPfRows - 1;
+    const uint32_t PB = p.particles_per_block;
+    const size_t acc_off = (static_cast<size_t>(kAccRows) * 256u + 8u * PB + PB + 1u) * sizeof(uint32_t);   // + 1: the kernel's alignment skip
+    const size_t lds = accum ? acc_off + static_cast<size_t>(PB) * (sizeof(double) + 2u * sizeof(uint32_t) + static_cast<size_t>(kAccWords) * 8u)
+                             : static_cast<size_t>(kPfRows) * 256u * sizeof(uint32_t) + (p.evals != nullptr ? tail_fixed : tail) + sizeof(uint32_t) * PB;
     if (lds > 160u * 1024u - 64u) return hipErrorInvalidValue;   // more beams per particle than one workgroup's LDS holds
-    if (lds > 65536u) {   // (particle-minor blocks of 64 particles x 256 beams keep 64 KB of beam errors)
-      // per launch, not once per process: the attribute belongs to the function ON THE CURRENT DEVICE (sharded filters launch on several)
-      const hipError_t ae = leaf2 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pf_update_v3<kPfRows, true>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)
-                                  : hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pf_update_v3<kPfRows, false>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-      if (ae != hipSuccess) return ae;
+#define RMCL_PF_V3(ROWS, L2, SO, AC)                                                                                           \
+    {                                                                                                                          \
+      if (lds > 65536u) {   /* per launch: the attribute belongs to the function ON THE CURRENT DEVICE (sharded filters) */   \
+        const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pf_update_v3<ROWS, L2, SO, AC>),            \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);                \
+        if (ae != hipSuccess) return ae;                                                                                       \
+      }                                                                                                                        \
+      hipLaunchKernelGGL((k_pf_update_v3<ROWS, L2, SO, AC>), dim3(nblocks), dim3(256), lds, s, p);                              \
+      return hipGetLastError();                                                                                                \
     }
-    if (leaf2) hipLaunchKernelGGL((k_pf_update_v3<kPfRows, true>), dim3(nblocks), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((k_pf_update_v3<kPfRows, false>), dim3(nblocks), dim3(256), lds, s, p);
-    return hipGetLastError();
+    if (accum) {
+      if (leaf2 && slot_order) RMCL_PF_V3(kAccRows, true, true, true)
+      if (leaf2) RMCL_PF_V3(kAccRows, true, false, true)
+      if (slot_order) RMCL_PF_V3(kAccRows, false, true, true)
+      RMCL_PF_V3(kAccRows, false, false, true)
+    }
+    if (leaf2 && slot_order) RMCL_PF_V3(kPfRows, true, true, false)
+    if (leaf2) RMCL_PF_V3(kPfRows, true, false, false)
+    if (slot_order) RMCL_PF_V3(kPfRows, false, true, false)
+    RMCL_PF_V3(kPfRows, false, false, false)
+#undef RMCL_PF_V3
   }
   if (g_lab && g_lab->pf_update) return g_lab->pf_update(p, variant, s);
   return kLabMissing;

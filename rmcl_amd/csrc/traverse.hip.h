@@ -268,6 +268,48 @@ __device__ __forceinline__ void node_keys_q4(uint4 qa, uint4 qb, uint4 qc, uint4
   }
 }
 
+// The quantised node in SLOT ORDER (round 5; bvh_build.cpp sorts a node's children along the axis their centres spread most and
+// leaves that axis in the low two mantissa bits of the x scale): hit[c] / ref[c] come back in the order THIS ray should visit them --
+// slots 0..3 when its direction is positive on the node's axis, 3..0 otherwise (`rev_mask` bit a = direction negative on axis a).
+// Nearest-first is only a heuristic here (the closest hit follows from the t bound alone), and this order costs one bit test and four
+// selects where the sorting network of five compare-exchanges costs twenty-five instructions.
+__device__ __forceinline__ void node_hits_q4_so(uint4 qa, uint4 qb, uint4 qc, uint4 qch, const RaySlab& rs, float best_t, uint32_t rev_mask,
+                                                bool (&hit)[4], uint32_t (&ref)[4]) {
+  const float sx = asf(qa.w) * rs.inv.x, sy = asf(qb.x) * rs.inv.y, sz = asf(qb.y) * rs.inv.z;
+  const float bx = fmaf(asf(qa.x), rs.inv.x, rs.noi.x), by = fmaf(asf(qa.y), rs.inv.y, rs.noi.y), bz = fmaf(asf(qa.z), rs.inv.z, rs.noi.z);
+  const bool ngx = rs.inv.x < 0.0f, ngy = rs.inv.y < 0.0f, ngz = rs.inv.z < 0.0f;
+  const uint32_t qnx = ngx ? qb.w : qb.z, qfx = ngx ? qb.z : qb.w;
+  const uint32_t qny = ngy ? qc.y : qc.x, qfy = ngy ? qc.x : qc.y;
+  const uint32_t qnz = ngz ? qc.w : qc.z, qfz = ngz ? qc.z : qc.w;
+#define RMCL_Q2(w, a, b) f2{static_cast<float>(((w) >> (8 * (a))) & 0xFFu), static_cast<float>(((w) >> (8 * (b))) & 0xFFu)}
+  const f2 sx2 = {sx, sx}, sy2 = {sy, sy}, sz2 = {sz, sz}, bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
+  const f2 nx01 = __builtin_elementwise_fma(RMCL_Q2(qnx, 0, 1), sx2, bx2), nx23 = __builtin_elementwise_fma(RMCL_Q2(qnx, 2, 3), sx2, bx2);
+  const f2 fx01 = __builtin_elementwise_fma(RMCL_Q2(qfx, 0, 1), sx2, bx2), fx23 = __builtin_elementwise_fma(RMCL_Q2(qfx, 2, 3), sx2, bx2);
+  const f2 ny01 = __builtin_elementwise_fma(RMCL_Q2(qny, 0, 1), sy2, by2), ny23 = __builtin_elementwise_fma(RMCL_Q2(qny, 2, 3), sy2, by2);
+  const f2 fy01 = __builtin_elementwise_fma(RMCL_Q2(qfy, 0, 1), sy2, by2), fy23 = __builtin_elementwise_fma(RMCL_Q2(qfy, 2, 3), sy2, by2);
+  const f2 nz01 = __builtin_elementwise_fma(RMCL_Q2(qnz, 0, 1), sz2, bz2), nz23 = __builtin_elementwise_fma(RMCL_Q2(qnz, 2, 3), sz2, bz2);
+  const f2 fz01 = __builtin_elementwise_fma(RMCL_Q2(qfz, 0, 1), sz2, bz2), fz23 = __builtin_elementwise_fma(RMCL_Q2(qfz, 2, 3), sz2, bz2);
+#undef RMCL_Q2
+  const float tnx[4] = {nx01.x, nx01.y, nx23.x, nx23.y}, tfx[4] = {fx01.x, fx01.y, fx23.x, fx23.y};
+  const float tny[4] = {ny01.x, ny01.y, ny23.x, ny23.y}, tfy[4] = {fy01.x, fy01.y, fy23.x, fy23.y};
+  const float tnz[4] = {nz01.x, nz01.y, nz23.x, nz23.y}, tfz[4] = {fz01.x, fz01.y, fz23.x, fz23.y};
+  bool h[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float tn = fmaxf(fmaxf(fmaxf(tnx[c], tny[c]), tnz[c]), 0.0f);
+    const float tf = fminf(fminf(fminf(tfx[c], tfy[c]), tfz[c]), best_t);
+    h[c] = tn <= tf;
+  }
+  const bool rev = ((rev_mask >> (qa.w & 3u)) & 1u) != 0u;
+  hit[0] = rev ? h[3] : h[0]; hit[1] = rev ? h[2] : h[1]; hit[2] = rev ? h[1] : h[2]; hit[3] = rev ? h[0] : h[3];
+  ref[0] = rev ? qch.w : qch.x; ref[1] = rev ? qch.z : qch.y; ref[2] = rev ? qch.y : qch.z; ref[3] = rev ? qch.x : qch.w;
+}
+__device__ __forceinline__ void node_hits_q_so(const uint32_t* __restrict__ qnodes, uint32_t cur, const RaySlab& rs, float best_t, uint32_t rev_mask,
+                                               bool (&hit)[4], uint32_t (&ref)[4]) {
+  const uint4* nb = reinterpret_cast<const uint4*>(qnodes) + static_cast<size_t>(cur) * 4u;
+  node_hits_q4_so(nb[0], nb[1], nb[2], nb[3], rs, best_t, rev_mask, hit, ref);
+}
+
 #define RMCL_CSWAP(i, j)                                   \
   {                                                        \
     const bool sw_ = key[j] < key[i];                      \

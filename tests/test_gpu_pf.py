@@ -42,10 +42,10 @@ def _check(a_gpu, e_gpu, a_ref, e_ref, what):
 # variant bits (rmclhip_pf_set_variant): 0-1 traversal of the round kernel, 4-6 persistent lanes (refill at 8/16/32/48 idle lanes),
 # 7 full 128-B nodes (round-2 kernel), 8 round-2 kernel on the quantised nodes, 9 4096 rays per workgroup, 10 the map's tree
 # (leaves <= 4) instead of the filter's own (leaves <= 2)
-LEGACY, BIG, MAPTREE = 256, 512, 1024
+LEGACY, BIG, MAPTREE, SLOT, STORED = 256, 512, 1024, 2048, 4096   # round 5: SLOT = children in the ray's slot order; STORED = the stored-error form of rounds 3 / 4 (the default accumulates order-independently)
 
 
-@pytest.mark.parametrize("variant", pf_variants(0, 1, 2, 16, 48, 64, 48 | 128, 64 | LEGACY, 64 | BIG, 64 | MAPTREE))
+@pytest.mark.parametrize("variant", pf_variants(0, 1, 2, 16, 48, 64, 48 | 128, 64 | LEGACY, 64 | BIG, 64 | MAPTREE, 64 | SLOT, 64 | SLOT | MAPTREE, 48 | SLOT | BIG, 64 | STORED, 16 | STORED | BIG, 64 | STORED | SLOT | MAPTREE))
 def test_golden_g6_cube(ra, ctx, meshes, variant):
     """committed fixture G6: 64 particles x 16 beams on the cube; beams outside the sensor range
     (real miss) and the MAX_N_MEAS clamp included."""
@@ -62,7 +62,7 @@ def test_golden_g6_cube(ra, ctx, meshes, variant):
 
 
 @pytest.mark.parametrize("n_particles,n_beams", [(1000, 100), (257, 7), (4099, 256), (3001, 1), (130, 2)])   # (one beam: the magic division of the ray index has no 32-bit constant)
-@pytest.mark.parametrize("variant", pf_variants(0, 2, 16, 32, 64, 48 | 128, 64 | LEGACY, 64 | BIG, 64 | MAPTREE, 64 | LEGACY | MAPTREE))
+@pytest.mark.parametrize("variant", pf_variants(0, 2, 16, 32, 64, 48 | 128, 64 | LEGACY, 64 | BIG, 64 | MAPTREE, 64 | LEGACY | MAPTREE, 64 | SLOT, 32 | SLOT | MAPTREE, 64 | STORED, 32 | STORED | SLOT))
 def test_room_random_particles(ra, orc, ctx, meshes, n_particles, n_beams, variant):
     """random hypotheses in a room with occluders and an open ceiling (sim misses), reference default of
     100 random beams and ragged sizes; beams sampled from a simulated cloud like update() does."""
@@ -85,7 +85,7 @@ def test_room_random_particles(ra, orc, ctx, meshes, n_particles, n_beams, varia
     assert (e_ref == 100.0).any() and (e_ref < 1.0).any()
 
 
-@pytest.mark.parametrize("variant", pf_variants(64, 64 | BIG, 64 | LEGACY, 0))
+@pytest.mark.parametrize("variant", pf_variants(64, 64 | BIG, 64 | LEGACY, 0, 64 | SLOT, 64 | STORED))
 def test_beams_with_their_own_origins_and_edge_counts(ra, orc, ctx, meshes, variant):
     """RangeMeasurement.orig != 0 (the general Tsm * meas_s of RangeMeasurement.hpp:28-42; the kernel's shortcut for beams that
     start at the sensor origin must not be taken) and every regime of the count sequence of the in-order merge: n_meas
@@ -162,7 +162,7 @@ def test_custom_parameters_and_empty_inputs(ra, orc, ctx, meshes):
     assert np.array_equal(d_attrs.download().view(np.uint8), attrs.view(np.uint8))
 
 
-@pytest.mark.parametrize("variant", pf_variants(0, 2, 48, 64))
+@pytest.mark.parametrize("variant", pf_variants(0, 2, 48, 64, 64 | SLOT, 64 | STORED))
 def test_embree_geometric_normal_mode(ra, orc, ctx, meshes, variant):
     """correspondence_type 2: the error of evaluate_rcc against Embree's UN-normalised rayhit.hit.Ng
     (PCDSensorUpdaterEmbree.cpp:56-66) instead of the OptiX program's unit normal: bit-for-bit the oracle's mode-2
@@ -193,7 +193,7 @@ def test_embree_geometric_normal_mode(ra, orc, ctx, meshes, variant):
     assert not np.allclose(ratio, 1.0, atol=1e-2)
 
 
-@pytest.mark.parametrize("variant", pf_variants(0, 48, 64))
+@pytest.mark.parametrize("variant", pf_variants(0, 48, 64, 64 | STORED))
 def test_optix_program_rules_mode(ra, orc, ctx, meshes, variant):
     """correspondence_type 3 = optix/BeamEvaluateProgram.cu:15-130 exactly: tmax 1e4 and EVERY hit is a sim hit (the Embree
     updater also asks t > sensor_range.min, PCDSensorUpdaterEmbree.cpp:47).  Particles hugging a wall make the two rules
@@ -240,7 +240,7 @@ def test_c4_full_size_properties(ra, orc, ctx, meshes):
     assert len(beams) == 256
     results = []
     ra.load_lab()   # the round-2 kernels are part of this schedule-independence check
-    for variant in (64, 64 | 256, 64 | 512, 16, 48 | 128, 0):
+    for variant in (64 | 4096, 64 | 256, 64 | 512 | 4096, 16 | 4096, 48 | 128, 0):   # (the stored forms: bit for bit with the round kernels)
         upd = ra.PCDSensorUpdaterHip(hm)
         upd.init()
         upd.set_variant(variant)
@@ -375,6 +375,7 @@ def test_beam_errors_in_global_scratch_equal_the_lds_form(ra, orc, ctx, meshes, 
         upd = ra.PCDSensorUpdaterHip(hm)
         upd.init()
         upd.setInput(beams, syn.tsb_offset())
+        upd.set_variant(64 | STORED)      # (both are forms of the stored-error kernel of rounds 3 / 4; the round-5 default stores nothing)
         upd.set_mapping(bits, 0, None)
         d_p, d_a = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
         d_err = ra.DeviceArray(ctx, np.float32, n * n_beams)
@@ -442,4 +443,44 @@ def test_c5_shard_every_particle_against_the_oracle(ra, orc, ctx, meshes):
     ref = attrs.copy()
     m.pf_update(poses, ref, beams, T.identity(), orc.pf_params(), bvh=2, nthreads=16)
     _check_all_particles(d_attrs.download(), ref, "C5 shard")
+    upd.close()
+
+
+def test_order_independent_accumulation_is_schedule_independent(ra, orc, ctx, meshes):
+    """round 5 (the default; rmclhip_pf_set_variant bit 12 selects the stored form of rounds 3 / 4): a finished ray adds W_k e and W_k e^2 into fixed-point accumulators of its particle and
+    is forgotten -- no per-beam storage, no in-order chain.  Integer adds commute: the attributes are the SAME BITS whatever the refill
+    threshold, the workgroup size, the child order, the ray dealing (particle-minor, Morton order) or the run; the per-beam errors are
+    those of the stored form bit for bit; mean / sigma / n_meas against the oracle's sequential chain within the bar of _check, on a
+    cloud whose histories differ (n_meas 0 .. above the clamp)."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("room30k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    n = 6007
+    poses, attrs = syn.uniform_particles(n, seed=77, bb_min=(-9, -9, 0.2, 0, 0, -math.pi), bb_max=(9, 9, 3.0, 0, 0, math.pi))
+    rng = np.random.RandomState(5)
+    attrs["likelihood"]["n_meas"] = rng.choice([0, 1, 7, 150, 9900, 9999, 10000, 20000], n)
+    attrs["likelihood"]["mean"] = rng.uniform(0.0, 0.3, n).astype(np.float32)
+    attrs["likelihood"]["sigma"] = rng.uniform(0.0, 0.01, n).astype(np.float32)
+    beams = ra.beams_from_points(syn.model_directions(syn.model_pf16())[::2] * np.float32(5.0))
+    Tsb = syn.tsb_offset()
+    a_ref = attrs.copy()
+    e_ref = m.pf_update(poses, a_ref, beams, Tsb, orc.pf_params(), bvh=True, nthreads=8, want_errors=True)
+    a0, e0 = _run(ra, ctx, hm, poses, attrs.copy(), beams, Tsb, variant=64 | STORED)          # the stored form
+    outs = []
+    for variant in (64, 16, 32 | BIG, 64 | SLOT, 64 | MAPTREE, None):
+        a, e = _run(ra, ctx, hm, poses, attrs.copy(), beams, Tsb, variant=variant)
+        assert np.array_equal(e, e0)
+        outs.append(a)
+    for a in outs[1:]:
+        assert a.tobytes() == outs[0].tobytes()
+    _check(outs[0], e0, a_ref, e_ref, "accumulated")
+    # particle-minor dealing in Morton order
+    upd = ra.PCDSensorUpdaterHip(hm)
+    upd.init()
+    upd.set_mapping(1, 16, ra.DeviceArray.from_host(ctx, syn.morton_order_xy_yaw(poses)))
+    upd.setInput(beams, Tsb)
+    d_p, d_a = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
+    upd.update(d_p, d_a)
+    assert d_a.download().tobytes() == outs[0].tobytes()
     upd.close()

@@ -14,7 +14,7 @@ mkdir -p $OUT
 i=0
 for set in "${SETS[@]}"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $set -d $OUT -o pass$i --output-format csv -- "$@" > $OUT/pass$i.stdout 2>&1 || echo "pass $i failed: $set" >> $OUT/errors.txt
+  timeout 120 rocprofv3 --kernel-trace --pmc $set -d $OUT -o pass$i --output-format csv -- "$@" > $OUT/pass$i.stdout 2>&1 || echo "pass $i failed: $set" >> $OUT/errors.txt
 done
 echo "== $TAG ($KF): $*"
 [ -f $OUT/errors.txt ] && cat $OUT/errors.txt
