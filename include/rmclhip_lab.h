@@ -54,6 +54,9 @@ rmclhip_status rmclhip_debug_probe_find(rmclhip_rcc* rcc, const rmclhip_transfor
  * a phase was enqueued, "W<r>" the host waited for rank r, "<phase>:" labels.  A phase that lets the devices run concurrently reads
  * "E0 E1 ... W0 W1 ..."; tests/test_gpu_distributed.py asserts that.  Works without the experiments library. */
 rmclhip_status rmclhip_debug_trace(int on, char* buf, size_t cap);
+/* how often, in this process, a host poller found ITS sequence number in a completion tag while the result words it read did not yet add
+ * up to the tag's checksum -- the event the {sequence, xor} tag guards against (tools/tag_retries.py, profiles/r05_tag_handoff.txt) */
+rmclhip_status rmclhip_debug_tag_retries(unsigned long long* retries_out);
 
 #ifdef __cplusplus
 }

@@ -203,6 +203,7 @@ SIGNATURES = {
                                            C.c_uint64, _u32, C.POINTER(C.c_uint64)]),
     "rmclhip_comm_create": (_i32, [_vp, _u32, _pp]),
     "rmclhip_comm_create_loopback": (_i32, [_vp, _u32, _pp]),
+    "rmclhip_debug_tag_retries": (_i32, [C.POINTER(C.c_ulonglong)]),
     "rmclhip_debug_trace": (_i32, [_i32, _vp, _sz]),
     "rmclhip_comm_destroy": (None, [_vp]),
     "rmclhip_comm_size": (_u32, [_vp]),

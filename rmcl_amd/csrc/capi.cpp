@@ -1504,6 +1504,10 @@ static inline uint32_t xor_host(const void* p, size_t bytes) {
   for (size_t i = 0; i < bytes / 4; ++i) x ^= w[i];
   return x;
 }
+// how often a poller saw ITS sequence number in the tag while the result words did not (yet) add up to the tag's sum: the event the
+// checksum exists for (rmclhip_debug_tag_retries; profiles/r05_tag_handoff.txt)
+static std::atomic<unsigned long long> g_tag_sum_retries{0};
+
 static inline uint32_t next_seq(rmclhip_rcc* r) {
   if (++r->done_seq == 0u) r->done_seq = 1u;
   return r->done_seq;
@@ -1530,6 +1534,7 @@ static hipError_t wait_done(const rmclhip_ctx* ctx, volatile const unsigned long
     if (static_cast<uint32_t>(t) == seq) {
       std::atomic_thread_fence(std::memory_order_acquire);
       if (done_sum(chk) == static_cast<uint32_t>(t >> 32)) return hipSuccess;
+      g_tag_sum_retries.fetch_add(1, std::memory_order_relaxed);   // this call's tag, but the words read do not add up to it (yet)
     }
 #if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
@@ -1587,6 +1592,7 @@ static hipError_t wait_moments(rmclhip_rcc* r, uint32_t seq, float lo, float hi,
       if (static_cast<uint32_t>(t) == seq) {
         std::atomic_thread_fence(std::memory_order_acquire);
         if (block_sum() == static_cast<uint32_t>(t >> 32)) break;
+        g_tag_sum_retries.fetch_add(1, std::memory_order_relaxed);
       }
 #if defined(__x86_64__) || defined(__i386__)
       __builtin_ia32_pause();
@@ -3858,6 +3864,12 @@ static rmclhip_status comm_wait_all(rmclhip_comm* c) {
     HIPCHK(hipStreamSynchronize(c->streams[r]));
     trace('W', static_cast<uint32_t>(r));
   }
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_debug_tag_retries(unsigned long long* retries_out) {
+  if (!retries_out) return fail(RMCLHIP_ERR_INVALID, "debug_tag_retries: null");
+  *retries_out = g_tag_sum_retries.load();
   return RMCLHIP_OK;
 }
 

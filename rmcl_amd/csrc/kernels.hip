@@ -1549,7 +1549,9 @@ __device__ __forceinline__ double acc_value(const unsigned long long* row, int n
 }
 
 template <int kRows, bool kLeaf2, bool kSlotOrder = false, bool kAccum = false>
-__global__ void __launch_bounds__(256) k_pf_update_v3(const PfParams p) {
+// (kAccum: 72 instead of 78 registers = 7 instead of 6 waves per SIMD, which is also what the LDS admits: the C5 shard -5 %, room-100k -2 %,
+//  sphere-100k unchanged -- profiles/r05_pf_forms_ab.txt; the stored forms keep the 6 they were measured with)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kAccum ? 7 : 6, kAccum ? 7 : 6))) k_pf_update_v3(const PfParams p) {
   // LDS: [ per-lane stacks kRows*256 (later: merge weights) | Tsm (PB xforms) | n0 (PB) | errors -> evals (PB*n_beams floats) ]
   // (round 4 A/B, removed: the top 85 / 341 nodes of the tree in LDS -- the TD / TA units read 94 % / 82 % busy, but those are
   // "non-idle" counters, not bandwidth: 14 % / 33 % SLOWER, profiles/r04_pf_lds_top.txt.  The kernel is VALU-issue bound at the
