@@ -1,4 +1,4 @@
-// kernels.h -- launch interface between the C ABI (capi.cpp) and the HIP kernels (kernels.hip).
+// kernels.h -- launch interface between the C ABI (capi_*.cpp) and the HIP kernels (kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -305,7 +305,7 @@ uint32_t reduce_num_blocks(uint32_t n, uint32_t nposes);
 hipError_t launch_reduce_partials(const ReduceParams& p, hipStream_t s);
 // finalize one pose's partials into CrossStatistics (writes to out, which may be host-mapped memory)
 // done (nullable, host-mapped, single pose only): completion tag {seq, xor of the 16 result words}, one 8-byte store after
-// `out` (kernels.hip publish_tag): the host polls the tag and VERIFIES the sum -- a flag alone is not enough, see capi.cpp wait_done
+// `out` (kernels.hip publish_tag): the host polls the tag and VERIFIES the sum -- a flag alone is not enough, see capi_rcc.cpp wait_done
 hipError_t launch_reduce_finalize(const double* partials, uint32_t nblocks, uint32_t nposes, cstats* out,
                                   unsigned long long* done, uint32_t seq, hipStream_t s);
 // finalize + (Tsb*, Tbo*) + umeyama + compose; advances MicpState on the device

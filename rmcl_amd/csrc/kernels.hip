@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const ReduceParams p) {
 // written AFTER `__threadfence_system()` while the 64 B of results written BEFORE it still showed the previous call's
 // values -- results and flag live in different host allocations and reach the host through different channels.  The host
 // therefore accepts a result only when the tag carries this call's sequence number AND the words it reads add up to the
-// tag's sum (capi.cpp wait_done), and keeps polling otherwise.
+// tag's sum (capi_rcc.cpp wait_done), and keeps polling otherwise.
 template <typename Tp>
 __device__ __forceinline__ uint32_t xor_words(const Tp& v) {
   static_assert(sizeof(Tp) % 4 == 0, "word-sized results only");
@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(64) k_reduce_finalize(const double* __restrict
   const cstats s = finalize_pose(partials + static_cast<size_t>(pose) * nblocks * kAcc, nblocks);
   if (threadIdx.x == 0) {
     out[pose] = s;
-    if (done) publish_tag(done, seq, xor_words(s));   // single-pose call with a host-mapped result (capi.cpp wait_done)
+    if (done) publish_tag(done, seq, xor_words(s));   // single-pose call with a host-mapped result (capi_rcc.cpp wait_done)
   }
 }
 
@@ -3077,7 +3077,7 @@ hipError_t launch_pose_moments(const xform* poses, const void* attrs, uint32_t n
   return hipGetLastError();
 }
 
-// in-process stand-in for ncclAllReduce on doubles (the loopback communicator of the tests, capi.cpp): every "rank" runs this on its own
+// in-process stand-in for ncclAllReduce on doubles (the loopback communicator of the tests, capi_multi.cpp): every "rank" runs this on its own
 // stream over the send buffers of all of them, in rank order (deterministic)
 struct LoopbackPtrs { const double* p[64]; };
 __global__ void k_loopback_allreduce(LoopbackPtrs send, uint32_t world, double* __restrict__ recv, uint32_t count, uint32_t is_max) {

@@ -1,7 +1,7 @@
 """Run-to-run determinism of the synchronous result paths.  A parity test that passes once says nothing about a 1-in-10^4 race:
 round 3 found one -- the host polled a completion FLAG in host-mapped memory and occasionally read the previous call's
 result block next to the current call's flag (tools/determinism2.py).  The hand-off now carries a sequence number and a checksum
-of the result (capi.cpp wait_done); these tests repeat the calls that exposed it and demand bit-identical results every time,
+of the result (capi_rcc.cpp wait_done); these tests repeat the calls that exposed it and demand bit-identical results every time,
 in both wait modes (rmclhip_ctx_set_wait_mode)."""
 import numpy as np
 import pytest

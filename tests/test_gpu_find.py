@@ -462,7 +462,7 @@ def test_o1dn_c2_size_pose_batch(ra, orc, ctx, meshes):
 
 @pytest.mark.parametrize("mesh", ["sphere100k", "room100k"])
 def test_automatic_variant_in_every_size_bracket(ra, orc, ctx, meshes, mesh):
-    """variant 15 (the default) picks a traversal per rays-in-flight bracket (capi.cpp:find_variant): <= 57 344 four lanes
+    """variant 15 (the default) picks a traversal per rays-in-flight bracket (capi_rcc.cpp:find_variant): <= 57 344 four lanes
     per ray (kind 2); above, one lane per ray starting at the map's frontier -- kind 23 (full-precision nodes) up to 524 288
     rays, kind 24 (quantised nodes) beyond.  Each bracket is run explicitly with variant 15."""
     from rmcl_amd import synthetic as syn, types as T
