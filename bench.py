@@ -465,6 +465,9 @@ def main():
             # config C5 at FULL size as one run on this ONE GPU: eight loopback ranks (the ndev = 8 code of the C ABI, in-process copies
             # instead of RCCL), 1 M particles x 256 beams, 1 M-triangle sphere: update + gather + {sum, max}; NOT a multi-GPU figure
             extras["c5_full_loopback8"] = _c5_full_loopback(ra, syn, T, np)
+            # meshes whose SAH tree is deeper than the kernels' 64-entry stack (rounds 1-4 refused them with RMCLHIP_ERR_UNSUPPORTED): the
+            # builder bounds the stack by construction since round 5 (bvh_build.cpp: height budget + tallest-first collapse)
+            extras["stack_bounded_maps"] = _stack_bounded_maps(ra, syn, T, np, ctx)
 
         # config C5's per-GPU term, on every rank and for every N (the only BASELINE config that shards)
         if not args.no_extras:
@@ -925,6 +928,32 @@ def _large_maps(ra, syn, T, np, ctx):
     out["note"] = ("the reference records these rows for 1000 copies of ONE pose on its authors' machines (BASELINE.md); here 1000 DIFFERENT poses. "
                    "measured_traffic = L2-side FETCH_SIZE + WRITE_SIZE of profiles/traffic.json (tools/pmc_large_maps.sh); FETCH_SIZE tallies 64 B per "
                    "128-B line request (profiles/r05_fetch_size_calibration.txt): exact for 64-B nodes / records, a lower bound otherwise")
+    return out
+
+
+def _stack_bounded_maps(ra, syn, T, np, ctx):
+    out = {}
+    f32 = np.float32
+    H, W = 64, 512
+    for name, (v, f), model, Tbm in (
+            ("exp_chain_2000", syn.exp_chain(2000, 1.05), T.spherical_model(f32(-0.2), f32(0.4 / (H - 1)), H, f32(-0.3), f32(0.6 / W), W, f32(0.0), f32(1e30)),
+             T.transform_from_rpy((-1.0, 0.04, 0.03), (0.0, 0.0, 0.0))),
+            ("nested_triangles_200", syn.nested_triangles(200, 1.2, 1e-3), T.spherical_model(f32(-0.4), f32(1.85 / (H - 1)), H, f32(-math.pi), f32(2 * math.pi / W), W, f32(0.0), f32(1e12)),
+             T.transform_from_rpy((0.001, -0.002, -1.0), (0.0, 0.0, 0.3))),
+            ("sliver_fan_200k", syn.sliver_fan(200000), T.spherical_model(f32(-1.5), f32(3.0 / (H - 1)), H, f32(-math.pi), f32(2 * math.pi / W), W, f32(0.01), f32(1e6)),
+             T.transform_from_rpy((1.0, 2.0, 3.0), (0.1, 0.2, 0.3)))):
+        hm = ra.import_hip_map(ctx, v, f)
+        info = hm.info()
+        rcc = ra.RCCHipSpherical(hm)
+        rcc.setTsb(T.identity())
+        rcc.setModel(model)
+        ms = median_kernel_ms(lambda: rcc.time_find(Tbm, iters=20), 5)
+        rcc.find(Tbm)
+        nh = int(rcc.modelView()["hits"].sum())
+        out[name] = {"n_faces": info["n_faces"], "stack_need": info["stack_need"], "height_fallbacks": info["height_fallbacks"],
+                     "guarded_nodes": info["guarded_nodes"], "find_%dx%d_us" % (H, W): round(ms * 1e3, 2), "rays_hit": nh}
+        rcc.close()
+        hm.release()
     return out
 
 

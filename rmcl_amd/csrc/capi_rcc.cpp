@@ -563,6 +563,8 @@ rmclhip_status rmclhip_rcc_find(rmclhip_rcc* r, const rmclhip_transform* Tbm_est
     HIPCHK(hipEventElapsedTime(&r->last_find_ms, r->ev0, r->ev1));
     return RMCLHIP_OK;
   }
+  // (round 5, built, measured and removed: the find storing its own completion tag from its last wave instead of the one-thread kernel
+  // behind it -- 39 to 70 us per call against 24: profiles/r05_sync_find_tag.txt)
   HIPCHK(wait_chain_end(r));
   return RMCLHIP_OK;
 }
@@ -753,12 +755,11 @@ RMCL_INTERNAL rmclhip_status reduce_enqueue(rmclhip_rcc* r, const xform& Tpre, c
 // Wait for the completion tag the LAST kernel of a chain stores in host-mapped memory after its results (kernels.hip
 // publish_tag), instead of hipStreamSynchronize: the tag arrives ~9 us before the stream's completion signal has made its way
 // through the runtime (measured on the MICP loop: 84 -> 75 us per correction).
-// A flag alone is NOT a sound hand-off here: round 3 measured (tools/determinism2.py, 1 in ~10^4 calls) the host seeing the
-// flag of the current call while the result block -- written before the kernel's __threadfence_system(), but to another host
-// allocation -- still held the previous call's values.  So the tag carries {sequence number of the call, xor of every
-// result word}: the result is accepted only when the sequence number is this call's AND the words the host reads add up to
-// the tag's sum; otherwise polling continues.  20 ms without an acceptable tag, or wait mode "block"
-// (rmclhip_ctx_set_wait_mode), falls back to the stream.
+// The tag carries {sequence number of the call, xor of every result word}: the result is accepted only when the sequence number is
+// this call's AND the words the host reads add up to the tag's sum; otherwise polling continues.  (Round 2 polled a flag of constant
+// value that the host cleared before each launch and read a stale result 1 call in ~10^4; the per-call sequence number is what cured
+// it -- the checksum has not rejected a block since, profiles/r05_tag_handoff.txt -- and the xor remains as a belt.)  20 ms without an
+// acceptable tag, or wait mode "block" (rmclhip_ctx_set_wait_mode), falls back to the stream.
 static inline uint32_t xor_host(const void* p, size_t bytes) {
   const volatile uint32_t* w = static_cast<const volatile uint32_t*>(p);
   uint32_t x = 0;

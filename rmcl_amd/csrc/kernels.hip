@@ -284,12 +284,14 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const ReduceParams p) {
 }
 
 // Completion tag of a launch chain whose results go to host-mapped memory and whose caller polls instead of waiting for the
-// stream: ONE 8-byte store {seq, xor of every result word}, issued after the results and a system-scope fence.  The sum is what
-// makes the hand-off sound: on this platform the host was observed (1 in ~10^4 calls, tools/determinism2.py) to see a flag
-// written AFTER `__threadfence_system()` while the 64 B of results written BEFORE it still showed the previous call's
-// values -- results and flag live in different host allocations and reach the host through different channels.  The host
-// therefore accepts a result only when the tag carries this call's sequence number AND the words it reads add up to the
-// tag's sum (capi_rcc.cpp wait_done), and keeps polling otherwise.
+// stream: ONE 8-byte store {seq, xor of every result word}, issued after the results and a system-scope fence.  The SEQUENCE NUMBER
+// is what makes the hand-off sound: round 2's form polled a flag the host itself had cleared before the launch -- the same value
+// every call -- and about 1 call in 10^4 took the previous call's results (tools/determinism2.py).  Round 5 isolated the mechanism
+// (tools/ubench/tag_handoff.hip, tools/tag_retries.py, profiles/r05_tag_handoff.txt): with a per-call value the device's
+// "results, __threadfence_system(), tag" order has never been seen violated (6 x 10^6 isolated hand-offs across allocations and
+// pinning flags, 9 x 10^5 product calls, not one checksum rejection) -- the failure belonged to the reused flag, not to the store
+// order.  The xor stays as a belt: the host accepts a result only when the tag carries this call's sequence number AND the words it
+// reads add up to the tag's sum (capi_rcc.cpp wait_done), and keeps polling otherwise.
 template <typename Tp>
 __device__ __forceinline__ uint32_t xor_words(const Tp& v) {
   static_assert(sizeof(Tp) % 4 == 0, "word-sized results only");
