@@ -947,13 +947,17 @@ def _stack_bounded_maps(ra, syn, T, np, ctx):
         rcc = ra.RCCHipSpherical(hm)
         rcc.setTsb(T.identity())
         rcc.setModel(model)
-        ms = median_kernel_ms(lambda: rcc.time_find(Tbm, iters=20), 5)
+        first = rcc.time_find(Tbm, iters=1)
+        ms = median_kernel_ms(lambda: rcc.time_find(Tbm, iters=20), 5) if first < 1.0 else min(first, rcc.time_find(Tbm, iters=2))
         rcc.find(Tbm)
         nh = int(rcc.modelView()["hits"].sum())
         out[name] = {"n_faces": info["n_faces"], "stack_need": info["stack_need"], "height_fallbacks": info["height_fallbacks"],
                      "guarded_nodes": info["guarded_nodes"], "find_%dx%d_us" % (H, W): round(ms * 1e3, 2), "rays_hit": nh}
         rcc.close()
         hm.release()
+    out["note"] = ("adversarial meshes, reported because they load at all now; the sliver fan (every triangle's box reaches the shared apex) is the classic "
+                   "worst case of an object-split BVH -- rays near the disc's plane visit thousands of overlapping boxes (tens of ms per 32 k rays); "
+                   "spatial splits are not built")
     return out
 
 
