@@ -514,9 +514,14 @@ rmclhip_status rmclhip_pf_extract_weights(rmclhip_pf* pf, const rmclhip_particle
  * next ray when 8 / 16 / 32 / 48 lanes of their wave are idle); bit 7: persistent lanes on the 128-B nodes instead
  * of their 64-B quantised twins (A/B); bit 8: the round-2 kernel on the quantised nodes (A/B); bit 9: 4096 instead of
  * 2048 rays per workgroup (A/B); bit 10: traverse the map's tree (leaves <= 4 triangles) instead of the filter's own
- * (leaves <= 2, rmclhip_bvh_build_host_pf).  A fresh handle uses traversal 0, refill at 48, quantised nodes of the
- * filter's tree, the round-3 kernel.  The round kernels (bits 4..6 = 0, bits 0..1) and the round-2 kernel (bits 7 / 8) are
- * experiments: accepted only while librmclhip_lab.so is loaded. */
+ * (leaves <= 2, rmclhip_bvh_build_host_pf); bit 11 (A/B, round 5): a node's children in the ray's slot order instead of sorted by
+ * entry distance (measured slower: more node visits than instructions saved); bit 12 (A/B): the STORED form of rounds 3 / 4 -- every
+ * beam's error kept (global scratch), a dense likelihood pass and one lane per particle walking the reference's in-order
+ * Gaussian1D += chain, bit-identical to the oracle's float chain -- instead of the round-5 default, the order-independent
+ * accumulation (closed-form merge weights, fixed-point accumulators: no per-beam storage, the same bits for every schedule and shard,
+ * mean / sigma within 2e-6 / 5e-6 relative of the sequential chain, n_meas exact).  A fresh handle uses traversal 0,
+ * refill at 48, quantised nodes of the filter's tree, sorted children, the accumulation.  The round kernels (bits 4..6 = 0,
+ * bits 0..1) and the round-2 kernel (bits 7 / 8) are experiments: accepted only while librmclhip_lab.so is loaded. */
 rmclhip_status rmclhip_pf_set_variant(rmclhip_pf* pf, int variant);
 /* schedule of the persistent-lane kernel: a wave fetches new beams once `refill_idle_lanes` of its lanes are idle (0: the
  * threshold selected by set_variant) and leaves its node phase when at most `tail_lanes` lanes still descend while
