@@ -107,7 +107,7 @@ static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, 
   uint32_t pb = (f->big_blocks ? 4096u : 2048u) / n_beams;
   if (pb < 1u) pb = 1u;
   if (pb > 64u) pb = 64u;
-  // the accumulation form keeps 360 B of accumulators per particle of the workgroup in LDS: at most 16 particles (few beams per particle
+  // the accumulation form keeps 384 B of accumulators per particle of the workgroup in LDS: at most 16 particles (few beams per particle
   // would otherwise put 64 of them, 23 KB, into a workgroup: 100 000 x 16 beams 0.189 -> 0.157 ms, x 32 0.338 -> 0.273, x 64 0.522 -> 0.485;
   // the stored form 0.169 / 0.295 / 0.491 -- tools/pf_shapes_ab.py, profiles/r05_pf_forms_ab.txt)
   if (f->accum && f->params.correspondence_type != 1u && pb > 16u) pb = 16u;

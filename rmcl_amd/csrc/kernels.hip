@@ -1528,8 +1528,8 @@ __device__ __forceinline__ float pf_eval_fast(float arg, float inv_den) {
   return ldexpf(__builtin_amdgcn_exp2f(fmaxf(r, -2.0f)) * inv_den, static_cast<int>(n));
 }
 
-constexpr int kAccBins1 = 17, kAccEmin1 = -256;   // sum W e:   terms in [2^-256, 2^16)
-constexpr int kAccBins2 = 28, kAccEmin2 = -416;   // sum W e^2: terms in [2^-416, 2^32)
+constexpr int kAccBins1 = 18, kAccEmin1 = -256;   // sum W e:   terms in [2^-256, 2^32): evals up to 4e9, i.e. dist_sigma down to 1e-10
+constexpr int kAccBins2 = 30, kAccEmin2 = -416;   // sum W e^2: terms in [2^-416, 2^64)
 constexpr int kAccWords = kAccBins1 + kAccBins2;  // 64-bit words per particle
 
 // returns false when t lies above the row's range (the caller poisons the particle: NaN, as an infinite term would make the chain)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""The two forms of the sensor update over cloud SHAPES (particles x beams): the order-independent accumulation keeps 360 B of accumulators per
+"""The two forms of the sensor update over cloud SHAPES (particles x beams): the order-independent accumulation keeps 384 B of accumulators per
 particle of a workgroup in LDS, and a workgroup takes 2048 / n_beams particles -- few beams per particle mean many particles per workgroup.
    usage: python tools/pf_shapes_ab.py"""
 import math
