@@ -604,7 +604,7 @@ def main():
         units_per_step = n_local * n_beams
         kernel_ms = upd.time_update(d_poses, d_attrs, hi - lo, iters=5)
         b_alg = algorithmic_bytes_pf(hi - lo, n_beams)
-        kname = "k_pf_update_v3<20, leaves <= 2>"
+        kname = "k_pf_update_v3<19 rows, leaves <= 2, accumulate>"
         traffic = measured_traffic("k_pf_update_v3")
         extras["particle_updates_per_s"] = round(world * args.steps * n_local / elapsed, 1)
         extras["allgather_bytes"] = 4 * n_total
@@ -617,8 +617,8 @@ def main():
     achieved = b_alg / (kernel_ms * 1e-3) / 1e9
     # `frac` is the contract's figure (algorithmic bytes / kernel time against the HBM peak).  It is NOT what bounds these kernels:
     # measured HBM traffic is 0.44x the algorithmic bytes for the find (the map is served from L2 / MALL; the launch ends with its
-    # slowest wave's chain of dependent fetches) and ~20x for the particle filter since round 4 -- deliberately: a workgroup's beam errors
-    # wait in global scratch instead of LDS (more workgroups per CU, 3-5 % faster), ~0.1 TB/s of otherwise idle bandwidth
+    # slowest wave's chain of dependent fetches) and 1.8x for the particle filter (round 5: the order-independent accumulation keeps no
+    # per-beam storage; round 4's error scratch made it ~20x) -- that kernel is bound by VALU issue and occupancy
     roofline = {"bound": "latency / issue (frac = the contract's HBM fraction)", "contract_bound": "hbm",
                 "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
@@ -646,6 +646,12 @@ def main():
                 "n_gpus": world, "scaling": "weak (one batch per GPU, block-partitioned pose lists, no collective)",
                 "single_scan_10_iterations_per_rank": extras.get("c3_schedule_R_pose_corrections_per_s"),
                 "single_scan_unchanged_caller_loop_per_rank": extras.get("c3_schedule_R_unchanged_caller_pose_corrections_per_s")},
+            # the one BASELINE configuration that shards (C5: particles block-partitioned, one weight all-gather per step); at N = 1 the
+            # per-GPU term.  At N > 1 `value` above is N independent replicas of C2 -- THIS block and pose_corrections_per_s are the
+            # informative multi-GPU figures
+            "particle_filter_sharded": ({k: extras["pf_sharded"].get(k) for k in ("shape", "c5_step_ms", "c5_shard_update_ms", "c5_allgather_ms",
+                                                                               "particle_beam_evals_per_s", "collective")}
+                                        if isinstance(extras.get("pf_sharded"), dict) else None),
             "roofline": roofline,
             "cpu_baseline": cpu,
             "extras": extras,
