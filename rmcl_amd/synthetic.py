@@ -136,6 +136,35 @@ def exp_chain(n, ratio=2.0, k0=None):
     return v.astype(np.float32), np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
 
 
+def cad_mix(n_detail=100000, room=40.0):
+    """what a CAD export next to scanned detail looks like: a 40 m hall of TWELVE triangles (two per wall), eight 30 m beams of twelve
+    triangles each crossing it, and a finely tessellated object (a UV sphere of radius 3) in the middle -- a few hundred-metre-scale
+    triangles among 10^5 centimetre-scale ones"""
+    h = room / 2.0
+    vs, fs = [], []
+
+    def box(lo, hi):
+        base = len(vs)
+        for z in (lo[2], hi[2]):
+            for y in (lo[1], hi[1]):
+                for x in (lo[0], hi[0]):
+                    vs.append([x, y, z])
+        quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+        for a, b, c, d in quads:
+            fs.append([base + a, base + b, base + c])
+            fs.append([base + a, base + c, base + d])
+
+    box((-h, -h, -3.5), (h, h, 8.0))
+    for k in range(8):
+        y = -14.0 + 4.0 * k
+        box((-15.0, y, 5.0 + 0.1 * k), (15.0, y + 0.2, 5.3 + 0.1 * k))
+    sv, sf = uv_sphere(n_detail, radius=3.0)
+    base = len(vs)
+    verts = np.concatenate([np.asarray(vs, np.float32), sv])
+    faces = np.concatenate([np.asarray(fs, np.uint32), sf + np.uint32(base)])
+    return verts, faces
+
+
 def sliver_fan(n, radius=10.0):
     """n long thin triangles that all share the apex at the origin (a disc cut like a pie, rim height wobbling): every triangle's box
     reaches the centre, the boxes overlap massively -- the classic bad case of an object-split BVH"""

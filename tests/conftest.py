@@ -120,6 +120,8 @@ def meshes():
                 cache[name] = syn.sliver_fan(200000)
             elif name == "fan20k":
                 cache[name] = syn.sliver_fan(20000)
+            elif name == "cadmix20k":
+                cache[name] = syn.cad_mix(20000)
             else:
                 raise KeyError(name)
         return cache[name]

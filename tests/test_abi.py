@@ -126,7 +126,7 @@ def test_host_algebra_bit_exact_with_oracle(ra, orc):
     assert int(ident["n_meas"]) == 0 and not np.isnan(ident["covariance"]).any()
 
 
-@pytest.mark.parametrize("name", ["cube", "sphere20k", "room30k", "chain200", "chain2000", "nested200", "fan20k"])
+@pytest.mark.parametrize("name", ["cube", "sphere20k", "room30k", "chain200", "chain2000", "nested200", "fan20k", "cadmix20k"])
 def test_bvh_builder_invariants(ra, orc, meshes, name):
     """Host-only build (rmclhip_bvh_build_host): every face in exactly one leaf, triangle records bit-equal
     to the oracle's, every child box contains its subtree, BFS node order, stack bound respected, and the

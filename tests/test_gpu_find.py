@@ -726,3 +726,32 @@ def test_meshes_beyond_the_old_stack_limit_upload_and_trace(ra, orc, ctx, meshes
                   % (name, len(f), info["stack_need"], info["height_fallbacks"], info["guarded_nodes"], H, W, ms * 1e3))
         rcc.close()
     assert n_hits > 500
+
+
+def test_mixed_scale_map_hall_beams_and_a_fine_object(ra, orc, ctx, meshes):
+    """a map whose triangles span four decades of size (a 40 m hall of twelve triangles, eight 30 m beams, a 20 k-triangle object of
+    radius 3: what a CAD export next to scanned detail looks like): every product kind against the oracle's own tree on all rays and
+    against brute force on a sample -- the hall's triangles sit in leaves near the root, beside subtrees five levels deep"""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("cadmix20k")
+    hm = ra.import_hip_map(ctx, v, f)
+    m = orc.Mesh(v, f)
+    model = syn.model_c2()
+    dirs = orc.spherical_directions(model)
+    idx = np.sort(np.random.RandomState(5).choice(len(dirs), size=1024, replace=False))
+    for Tbm in (T.transform_from_rpy((9.0, -7.0, 0.5), (0.02, -0.03, 2.5)), T.transform_from_rpy((-6.0, 0.5, 1.5), (0.3, 0.1, -1.0))):
+        ref = m.simulate_spherical(model, T.identity(), Tbm, bvh=2, nthreads=16)
+        sub = m.simulate_o1dn(len(idx), 1, model.range.min, model.range.max, (0.0, 0.0, 0.0), dirs[idx], T.identity(), Tbm, bvh=False,
+                              nthreads=16, want=("hits", "ranges", "face_ids"))
+        assert np.array_equal(ref["face_ids"][idx], sub["face_ids"])
+        assert ref["hits"].all(), "a closed hall: every ray ends on something"
+        for kind in (15, 23, 24, 2, 0):
+            rcc = ra.RCCHipSpherical(hm)
+            rcc.set_traversal(kind)
+            rcc.setTsb(T.identity())
+            rcc.setModel(model)
+            rcc.find(Tbm)
+            _compare(rcc.modelView(), ref, "cad mix kind %d" % kind)
+            rcc.close()
+        small = ref["face_ids"] >= 108   # the hall and the beams are faces 0..107
+        assert 1000 < small.sum() < small.size - 1000, "both poses see the object AND the hall"
