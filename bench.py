@@ -291,6 +291,12 @@ def main():
                     rr.correct_once(est_r, T.identity(), 10, 0.0, False)
                 extras["c3_schedule_R_room100k_%s_ms" % tag] = round(rr.time_correct_once(est_r, T.identity(), 10, 0.0, False, iters=50), 4)
                 extras["c3_schedule_R_room100k_%s_undecided" % tag] = rr.micp_fast_info()["last_uncertain"]
+                # the reference's unchanged caller loop in the same regime (find + 10 x computeCrossStatistics through the C entry points)
+                served0 = rr.ccs_info()
+                rr.time_caller_loop(est_r, T.identity(), 10, 0.0, iters=3)
+                extras["c3_unchanged_caller_room100k_%s_cabi_ms" % tag] = round(rr.time_caller_loop(est_r, T.identity(), 10, 0.0, iters=50)[0], 4)
+                served1 = rr.ccs_info()
+                extras["c3_unchanged_caller_room100k_%s_served" % tag] = {k: served1[k] - served0[k] for k in served1}
             rr.close()
             rpms, _ = _pf_c4(ra, syn, T, np, ctx, hmr, 100000, 256, iters=3, bb=((-9, -9, 0.3), (9, 9, 3)))
             extras["c4_room100k_pf_update_ms"] = round(rpms, 4)
