@@ -342,6 +342,8 @@ struct rmclhip_pf {
   rmclhip_pf_params params{2.0f, 100.0f, 100.0f, 0.0f, {0.05f, 80.0f}, 10000u, 0u};
   DevBuf<float> d_beams;
   float* h_beams = nullptr;  // pinned staging
+  hipEvent_t ev_beams = nullptr;      // behind the last copy out of h_beams
+  bool beams_copy_pending = false;
   size_t h_beams_cap = 0;
   float* errors_dev = nullptr;
   int variant = 0;

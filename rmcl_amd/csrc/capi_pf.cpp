@@ -16,6 +16,7 @@ rmclhip_status rmclhip_pf_create(rmclhip_ctx* ctx, rmclhip_map* map, rmclhip_pf*
   hipError_t e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&f->ev0);
   if (e == hipSuccess) e = hipEventCreate(&f->ev1);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_beams, hipEventDisableTiming);
   if (e == hipSuccess) e = f->tag.create();
   if (e != hipSuccess) {
     rmclhip_pf_destroy(f);
@@ -34,6 +35,7 @@ void rmclhip_pf_destroy(rmclhip_pf* f) {
   if (f->h_beams) (void)hipHostFree(f->h_beams);
   if (f->ev0) (void)hipEventDestroy(f->ev0);
   if (f->ev1) (void)hipEventDestroy(f->ev1);
+  if (f->ev_beams) (void)hipEventDestroy(f->ev_beams);
   if (f->stream) (void)hipStreamDestroy(f->stream);
   rmclhip_map_release(f->map);
   ctx_release(f->ctx);
@@ -60,21 +62,23 @@ rmclhip_status rmclhip_pf_set_error_output(rmclhip_pf* f, float* errors_dev) {
 static rmclhip_status pf_upload_beams(rmclhip_pf* f, const rmclhip_range_measurement* beams, uint32_t n_beams) {
   const size_t nf = static_cast<size_t>(n_beams) * 16;
   HIPCHK(f->d_beams.reserve(nf));
+  // the staging buffer may still be the source of the PREVIOUS call's copy: wait for that copy alone (its event), not for whatever else
+  // the stream holds -- a motion update enqueued just before this call keeps running (rmclhip_pf_sharded_step)
+  if (f->beams_copy_pending) { HIPCHK(hipEventSynchronize(f->ev_beams)); f->beams_copy_pending = false; }
   if (f->h_beams_cap < nf) {
-    HIPCHK(hipStreamSynchronize(f->stream));
     if (f->h_beams) (void)hipHostFree(f->h_beams);
     f->h_beams = nullptr;
     f->h_beams_cap = 0;
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&f->h_beams), nf * sizeof(float), hipHostMallocDefault));
     f->h_beams_cap = nf;
-  } else {
-    HIPCHK(hipStreamSynchronize(f->stream));  // the staging buffer may still be in flight
   }
   std::memcpy(f->h_beams, beams, nf * sizeof(float));
   f->beams_at_origin = true;
   for (uint32_t b = 0; b < n_beams && f->beams_at_origin; ++b)
     f->beams_at_origin = beams[b].orig.x == 0.0f && beams[b].orig.y == 0.0f && beams[b].orig.z == 0.0f;
   HIPCHK(hipMemcpyAsync(f->d_beams.p, f->h_beams, nf * sizeof(float), hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipEventRecord(f->ev_beams, f->stream));
+  f->beams_copy_pending = true;
   return RMCLHIP_OK;
 }
 
