@@ -155,15 +155,16 @@ def main():
         # 0.35 ms of GPU time -- would otherwise be timed on a device that has not left its idle clocks: 19.0 vs 18.2 us per
         # step measured; the metric is steady-state rays/s.  DESIGN.md section 5.)
         kernel_ms = median_kernel_ms(lambda: rcc.time_find(Tbm, iters=40))
+        step = rcc.find_async_fn(Tbm)   # rmclhip_rcc_find_async(handle, pose) with the pose converted once: one C call per step
         for _ in range(max(args.warmup, 1)):
-            rcc.find_async(Tbm)
+            step()
         rcc.sync()
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            rcc.find_async(Tbm)
+            step()
         rcc.sync()
         torch.cuda.synchronize()
         t1 = time.perf_counter()   # this rank's K steps are complete; the closing barrier itself is not part of the K steps

