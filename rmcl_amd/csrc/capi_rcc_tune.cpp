@@ -126,7 +126,7 @@ rmclhip_status rmclhip_rcc_autotune_batch(rmclhip_rcc* r, const rmclhip_transfor
   float best_ms = 0.f;
   for (const TuneCand& c : kTuneBatch) {
     r->tuned_batch_kind = c.kind; r->tuned_batch_frontier = c.frontier;
-    float t[3];
+    float t[3] = {0.f, 0.f, 0.f};
     for (float& x : t) {
       if (rmclhip_status st = rmclhip_rcc_time_find_batch(r, Tbm, nposes, 3, &x)) { r->tuned_batch_kind = saved_kind; r->tuned_batch_frontier = saved_frontier; return st; }
     }
