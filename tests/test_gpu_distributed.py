@@ -410,3 +410,49 @@ def test_c5_full_size_one_run_on_eight_loopback_ranks(ra, orc, ctx, meshes):
     p2, a2 = sh.download()
     assert p2.tobytes() == d_pn.download().tobytes() and a2.tobytes() == d_an.download().tobytes()
     rs.close(); upd.close(); sh.close()
+
+
+def test_allgather_alone_map_refcount_and_kernel_clock(ra, orc, ctx, meshes):
+    """three entry points nothing else calls directly: rmclhip_pf_allgather_weights on its own (after a motion update changed nothing the
+    weights depend on, a second gather returns the same dense vector on every rank), rmclhip_map_retain / _release (a map that a
+    registry retained outlives its creator's release: an operator built afterwards still traces), rmclhip_rcc_last_kernel_ms (HIP-event
+    time of the last synchronous find with kernel timing on: positive, below the call's host time)."""
+    import ctypes as C
+    import time
+    from rmcl_amd import _capi, synthetic as syn, types as T
+    v, f = meshes("room30k")
+    n = 777
+    poses, attrs = syn.uniform_particles(n, seed=4, bb_min=(-8, -8, 0.2, 0, 0, -math.pi), bb_max=(8, 8, 3, 0, 0, math.pi))
+    beams = ra.beams_from_points(syn.model_directions(syn.model_pf16())[::8] * np.float32(4.0))
+    sh = ra.ShardedParticleFilterHip(v, f, devices=(0, 0, 0), loopback=True)
+    sh.set_particles(poses, attrs)
+    w = sh.update(beams, syn.tsb_offset()).copy()
+    _capi.check(_capi.lib().rmclhip_pf_allgather_weights(sh._h))
+    for rank in range(3):
+        again = np.zeros(n, np.float32)
+        _capi.check(_capi.lib().rmclhip_pf_sharded_get_weights(sh._h, rank, again.ctypes.data_as(C.c_void_p)))
+        assert np.array_equal(again, w), rank
+    sh.close()
+
+    hm = ra.import_hip_map(ctx, v, f)
+    handle = C.c_void_p(hm.handle.value)
+    _capi.check(_capi.lib().rmclhip_map_retain(handle))     # the registry's reference ("<name>.hip" in an rm::MapMap)
+    hm.release()                                            # the creator lets go
+    borrowed = ra.HipMap.__new__(ra.HipMap)
+    borrowed.ctx, borrowed._h = ctx, handle
+    model = syn.model_c1()
+    rcc = ra.RCCHipSpherical(borrowed)
+    rcc.setTsb(T.identity())
+    rcc.setModel(model)
+    Tbm = T.transform_from_rpy((1.0, -1.5, 1.2), (0.01, -0.02, 0.5))
+    rcc.find(Tbm)
+    ref = orc.Mesh(v, f).simulate_spherical(model, T.identity(), Tbm, bvh=True, nthreads=8)
+    assert np.array_equal(rcc.modelView()["face_ids"], ref["face_ids"])
+    rcc.set_kernel_timing(True)
+    t0 = time.perf_counter()
+    rcc.find(Tbm)
+    host_ms = (time.perf_counter() - t0) * 1e3
+    find_ms, _ = rcc.last_kernel_ms()
+    assert 0.0 < find_ms < host_ms, (find_ms, host_ms)
+    rcc.close()
+    borrowed.release()                                      # the last reference
