@@ -289,6 +289,18 @@ int main(int argc, char** argv) {
       const rmclhip_pose_estimate est = sharded.estimateStats(1000000);
       std::printf("sharded_world %u\nsharded_w %.9g %.9g %.9g %.9g\nsharded_stats %.9g %.9g\nsharded_pose_t %.9g %.9g %.9g\n",
                   sharded.worldSize(), w[0], w[1], w[2], w[3], sst.sum, sst.max, est.pose.t.x, est.pose.t.y, est.pose.t.z);
+      // the node's cycle on the sharded cloud (rmcl_localization.cpp:84, 432-552): a motion update on its own, then motion -> sensor
+      // update -> weight all-gather -> {sum, max} in ONE call (no resampling here: the clouds below are compared particle by particle)
+      const Transform T_bnew_bold = from_rpy(0.3f, 0, 0, 0, 0, 0.05f);
+      sharded.motionUpdate(T_bnew_bold, 0.01, true);
+      rmclhip_gladiator_config no_cfg{};
+      const rmclhip_likelihood_stats cst = sharded.step(&T_bnew_bold, 0.01, true, 0, no_cfg, 42, 0);
+      std::vector<Transform> pc;
+      std::vector<ParticleAttributes> ac;
+      sharded.download(pc, ac);
+      std::printf("sharded_cycle_stats %.9g %.9g\n", cst.sum, cst.max);
+      for (size_t i = 0; i < ac.size(); ++i)
+        std::printf("sharded_cycle_%zu %.9g %u %.9g %.9g %.9g\n", i, ac[i].likelihood.mean, ac[i].likelihood.n_meas, pc[i].t.x, pc[i].t.y, pc[i].t.z);
     }
     // motion update (30 cm forward, 1 % forgetting, wall-collision test) and one gladiator tournament
     TFMotionUpdaterHip motion(map);

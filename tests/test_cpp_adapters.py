@@ -126,6 +126,19 @@ def test_cpp_example_matches_python_and_oracle(ra, orc, ctx, meshes, tmp_path):
     est = orc.estimate_stats(poses, attrs)
     assert np.allclose([float(x) for x in out["sharded_pose_t"]], [float(est["pose"]["t"][k]) for k in "xyz"], rtol=1e-5, atol=1e-6)
     assert abs(float(out["sharded_stats"][0]) - float(attrs["likelihood"]["mean"].astype(np.float64).sum())) < 1e-5
+    # the sharded cycle from the C++ adapter (round 5): motion, then {motion -> update -> gather -> stats} in one call
+    pc, ac = poses.copy(), attrs.copy()
+    Tm = T.transform_from_rpy((0.3, 0, 0), (0, 0, 0.05))
+    for _ in range(2):
+        m.pf_motion_update(pc, ac, Tm, 0.01, collision=True, bvh=False)
+    m.pf_update(pc, ac, beams, Tsb, orc.pf_params(), bvh=False)
+    stc = orc.likelihood_stats(ac)
+    assert abs(float(out["sharded_cycle_stats"][0]) - stc["sum"]) <= 1e-5 * stc["sum"] and abs(float(out["sharded_cycle_stats"][1]) - stc["max"]) <= 1e-5 * stc["max"]
+    for i in range(4):
+        mean, n, x, y, z = out["sharded_cycle_%d" % i]
+        assert int(n) == int(ac["likelihood"]["n_meas"][i])
+        assert abs(float(mean) - float(ac["likelihood"]["mean"][i])) <= 1e-5 * abs(float(ac["likelihood"]["mean"][i])) + 1e-12
+        assert np.allclose([float(x), float(y), float(z)], [float(pc["t"][k][i]) for k in "xyz"], atol=1e-5)
     # motion update + gladiator tournament on the updated cloud
     m.pf_motion_update(poses, attrs, T.transform_from_rpy((0.3, 0, 0), (0, 0, 0.05)), 0.01, collision=True, bvh=False)
     st = orc.likelihood_stats(attrs)
