@@ -105,6 +105,58 @@ int main(int argc, char** argv) {
                   c2.speculative_finds, Tcl.t.x, Tcl.t.y, Tcl.t.z, scl.n_meas);
       std::fprintf(stderr, "unchanged caller loop: %.4f ms per 5-iteration correction\n", ms);
     }
+    // the other model adapters (RCCEmbree.cpp:57-68, 89-99, 120-130) and the closest-point operator (CPCEmbree.cpp:18-44) on the same scan:
+    // O1Dn / OnDn fed with the spherical model's own directions must answer like the spherical operator; the pinhole operator and CPCHip
+    // are compared with the oracle by tests/test_cpp_adapters.py
+    {
+      auto tally = [n](const CorrespondencesHIP& op, const char* key) {
+        std::vector<uint8_t> h(n);
+        std::vector<uint32_t> ids(n);
+        op.download(h.data(), nullptr, nullptr, nullptr, ids.data());
+        uint64_t fs = 0, hs = 0;
+        for (uint32_t i = 0; i < n; ++i) { fs += h[i] ? ids[i] : 0; hs += h[i]; }
+        std::printf("%s %llu %llu\n", key, (unsigned long long)hs, (unsigned long long)fs);
+      };
+      O1DnModel o1;
+      o1.width = model.theta.size; o1.height = model.phi.size; o1.range = model.range; o1.orig = Vector{0.f, 0.f, 0.f};
+      OnDnModel on;
+      on.width = o1.width; on.height = o1.height; on.range = model.range;
+      for (uint32_t vid = 0; vid < model.phi.size; ++vid)
+        for (uint32_t hid = 0; hid < model.theta.size; ++hid) {
+          o1.dirs.push_back(getDirection(model, vid, hid));
+          on.dirs.push_back(getDirection(model, vid, hid));
+          on.origs.push_back(Vector{0.f, 0.f, 0.f});
+        }
+      RCCHipO1Dn r1(map);
+      r1.setTsb(Tsb); r1.setModel(o1); r1.find(truth * Tbo);
+      tally(r1, "o1dn");
+      RCCHipOnDn rn(map);
+      rn.setTsb(Tsb); rn.setModel(on); rn.find(truth * Tbo);
+      tally(rn, "ondn");
+      PinholeModel ph;
+      ph.width = 32; ph.height = 32; ph.range = model.range; ph.f[0] = 20.f; ph.f[1] = 20.f; ph.c[0] = 15.5f; ph.c[1] = 15.5f;
+      RCCHipPinhole rp(map);
+      rp.setTsb(Tsb); rp.setModel(ph); rp.find(truth * Tbo);
+      tally(rp, "pinhole");
+      CPCHip cpc(map);
+      cpc.setTsb(Tsb);
+      cpc.params.max_dist = 1.0f;
+      cpc.adaptive_max_dist_min = 1.0f;
+      std::vector<float> pts(3 * static_cast<size_t>(n));
+      std::vector<uint8_t> msk(n);
+      for (uint32_t vid = 0; vid < model.phi.size; ++vid)
+        for (uint32_t hid = 0; hid < model.theta.size; ++hid) {
+          const uint32_t i = getBufferId(model, vid, hid);
+          const Vector d = getDirection(model, vid, hid);
+          pts[3 * i] = d.x * ranges[i]; pts[3 * i + 1] = d.y * ranges[i]; pts[3 * i + 2] = d.z * ranges[i];
+          msk[i] = (ranges[i] >= model.range.min && ranges[i] <= model.range.max) ? 1 : 0;
+        }
+      cpc.setDataset(pts.data(), msk.data(), n);
+      cpc.find(Tom_est * Tbo);
+      tally(cpc, "cpc");
+      const CrossStatistics cs = cpc.computeCrossStatistics(identity(), 0.0);
+      std::printf("cpc_n_meas %u\n", cs.n_meas);
+    }
     // Correspondences_::dataset filled the way the reference's device sensors fill it (MICPSphericalSensorCUDA.cpp:207-232):
     // points / mask built on the host per measurement, then `dataset.points = host.points; dataset.mask = host.mask;`
     {

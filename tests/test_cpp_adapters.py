@@ -64,6 +64,16 @@ def test_cpp_example_matches_python_and_oracle(ra, orc, ctx, meshes, tmp_path):
     assert int(out["face_sum"][0]) == int(meas["face_ids"][meas["hits"] > 0].astype(np.uint64).sum())
     ds, mask = om.dataset_from_ranges(model, meas["ranges"])
     assert int(out["valid"][0]) == int(mask.sum())
+    # the O1Dn / OnDn adapters fed with the spherical model's directions answer like the spherical operator; pinhole and closest-point
+    # adapters against the oracle
+    assert out["o1dn"] == [out["hits"][0], out["face_sum"][0]] and out["ondn"] == out["o1dn"]
+    ph = m.simulate_pinhole(32, 32, 0.1, 100.0, (20.0, 20.0), (15.5, 15.5), Tsb, truth, bvh=False)
+    assert [int(x) for x in out["pinhole"]] == [int(ph["hits"].sum()), int(ph["face_ids"][ph["hits"] > 0].astype(np.uint64).sum())]
+    assert int(out["pinhole"][0]) > 500
+    cp = m.cpc_find(Tsb, est, ds, 1.0, bvh=False)
+    assert [int(x) for x in out["cpc"]] == [int(cp["hits"].sum()), int(cp["face_ids"][cp["hits"] > 0].astype(np.uint64).sum())]
+    rcp = orc.statistics_p2l_f64(T.identity(), ds, mask, cp["points"], cp["normals"], cp["hits"], 1.0)
+    assert int(out["cpc_n_meas"][0]) == rcp["n_meas"] > 500
     To, so, _ = om.correct_once(m, model, Tsb, T.identity(), est, ds, mask, 5, 1.0, adaptive_min=0.15)
     assert int(out["host_loop_n_meas"][0]) == int(so["n_meas"]) == int(out["device_loop_n_meas"][0])
     t_ref = [float(To["t"][k]) for k in "xyz"]
