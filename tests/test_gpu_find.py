@@ -755,3 +755,27 @@ def test_mixed_scale_map_hall_beams_and_a_fine_object(ra, orc, ctx, meshes):
             rcc.close()
         small = ref["face_ids"] >= 108   # the hall and the beams are faces 0..107
         assert 1000 < small.sum() < small.size - 1000, "both poses see the object AND the hall"
+
+
+def test_prebound_find_callable_equals_find(ra, orc, ctx, meshes):
+    """registration.find_async_fn (bench.py's timed step: the pose converted once, one C call per step) launches the same find as
+    find() -- also when the caller's pose array is changed or dropped after the callable was made (it keeps its own copy)."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = meshes("sphere20k")
+    hm = ra.import_hip_map(ctx, v, f)
+    rcc = ra.RCCHipSpherical(hm)
+    rcc.setTsb(T.identity())
+    rcc.setModel(syn.model_c1())
+    Tbm = np.array([T.transform_from_rpy((0.4, -0.2, 0.1), (0.02, -0.03, 0.4))], dtype=T.TRANSFORM)
+    rcc.find(Tbm[0])
+    want = {k: x.copy() for k, x in rcc.modelView().items()}
+    step = rcc.find_async_fn(Tbm[0])
+    Tbm["t"]["x"] = 5.0          # the caller's array changes afterwards
+    rcc.find(T.transform_from_rpy((2.0, 1.0, 0.0), (0, 0, 1.0)))   # something else in between
+    for _ in range(3):
+        step()
+    rcc.sync()
+    got = rcc.modelView()
+    for k in want:
+        assert np.array_equal(got[k], want[k], equal_nan=True), k
+    rcc.close()
