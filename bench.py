@@ -856,7 +856,8 @@ def _pf_sharded_block(ra, syn, T, np, torch, dist, ctx, rank, world, n_local=125
     return {"shape": "C5 per GPU: %d particles x %d beams, UV-sphere %d triangles, %d GPU(s), %d particles in total" %
                      (n_local, n_beams, n_tri, world, n_total),
             "c5_shard_update_ms": round(update_ms, 4), "c5_step_ms": round(step_ms, 4), "c5_allgather_ms": round(ag_ms, 4),
-            "allgather_bytes": 4 * n_total, "collective": ("RCCL all_gather_into_tensor + 2 all_reduce" if dist is not None else "none (1 GPU)"),
+            "allgather_bytes": 4 * n_total, "collective": ((("RCCL" if str(dist.get_backend()) == "nccl" else str(dist.get_backend()) + " (plumbing test, not RCCL)") +
+                                                            " all_gather_into_tensor + 2 all_reduce") if dist is not None else "none (1 GPU)"),
             "particle_beam_evals_per_s": round(n_total * n_beams / (step_ms * 1e-3), 1),
             "particle_updates_per_s": round(n_total / (step_ms * 1e-3), 1), "map_build_upload_s": round(build_s, 2)}
 
