@@ -60,6 +60,9 @@ int main(int argc, char** argv) {
     RCCHipSpherical rcc(map);
     rcc.setTsb(Tsb);
     rcc.setModel(model);
+    // the operator's bundle is {points, normals, hits} like Correspondences_::model_buffers_ (Correspondences.hpp:81-85); this example
+    // also reads ranges and face ids back
+    rcc.setOutputs(RMCLHIP_OUT_ALL);
     rcc.params.max_dist = 1.0f;
     rcc.adaptive_max_dist_min = 0.15f;
 
@@ -128,15 +131,15 @@ int main(int argc, char** argv) {
           on.origs.push_back(Vector{0.f, 0.f, 0.f});
         }
       RCCHipO1Dn r1(map);
-      r1.setTsb(Tsb); r1.setModel(o1); r1.find(truth * Tbo);
+      r1.setOutputs(RMCLHIP_OUT_ALL); r1.setTsb(Tsb); r1.setModel(o1); r1.find(truth * Tbo);
       tally(r1, "o1dn");
       RCCHipOnDn rn(map);
-      rn.setTsb(Tsb); rn.setModel(on); rn.find(truth * Tbo);
+      rn.setOutputs(RMCLHIP_OUT_ALL); rn.setTsb(Tsb); rn.setModel(on); rn.find(truth * Tbo);
       tally(rn, "ondn");
       PinholeModel ph;
       ph.width = 32; ph.height = 32; ph.range = model.range; ph.f[0] = 20.f; ph.f[1] = 20.f; ph.c[0] = 15.5f; ph.c[1] = 15.5f;
       RCCHipPinhole rp(map);
-      rp.setTsb(Tsb); rp.setModel(ph); rp.find(truth * Tbo);
+      rp.setOutputs(RMCLHIP_OUT_ALL); rp.setTsb(Tsb); rp.setModel(ph); rp.find(truth * Tbo);
       tally(rp, "pinhole");
       CPCHip cpc(map);
       cpc.setTsb(Tsb);
@@ -218,6 +221,7 @@ int main(int argc, char** argv) {
           HipMap::instance(0, identity()), HipMap::instance(0, from_rpy(200.f, 0.f, 0.f, 0, 0, 0.5), Vector{2.f, 1.f, 0.5f})};
       auto scene = std::make_shared<HipMap>(ctx, scene_meshes, scene_instances);
       RCCHipSpherical rcc3(scene);
+      rcc3.setOutputs(RMCLHIP_OUT_HITS | RMCLHIP_OUT_FACE_IDS);
       rcc3.setTsb(Tsb);
       rcc3.setModel(model);
       rcc3.find(truth * Tbo);
@@ -276,7 +280,7 @@ int main(int argc, char** argv) {
         }
       sh.forEach([&](rmclhip_rcc* r) {
         check(rmclhip_rcc_set_tsb(r, &Tsb));
-        check(rmclhip_rcc_set_model_spherical(r, &model));
+        check(rmclhip_rcc_set_model_spherical(r, model.c_model()));
         check(rmclhip_rcc_set_params(r, 1.0f, 1.0f));
         check(rmclhip_rcc_set_dataset(r, &pts[0].x, msk.data(), n, 0));
       });

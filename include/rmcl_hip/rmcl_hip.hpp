@@ -4,6 +4,10 @@
 //   rmcl::Correspondences_<MemT>            rmcl/include/rmcl/registration/Correspondences.hpp:16-88
 //   rmcl::CorrespondencesCUDA               rmcl/include/rmcl/registration/CorrespondencesCUDA.hpp:10-17
 //   rmcl::RCCOptixSpherical / RCCEmbreeO1Dn rmcl/include/rmcl/registration/RCCOptix.hpp:18-93, RCCEmbree.hpp:60-83
+//   rmagine::SphereSimulator* / O1Dn / Pinhole / OnDn, Bundle<...>   as used by RCCEmbree.hpp:18-83 (protected bases of the RCC classes),
+//                                           rmcl_ros/src/nodes/filter/scan_map_segmentation_embree.cpp:38-39,76-87 and
+//                                           rmcl_ros/src/benchmarks/lidar_corrector_embree_benchmark.cpp:117
+//   rmagine::statistics_p2l (free function) rmcl/src/rmcl/registration/CorrespondencesCUDA.cpp:28
 //   rmcl::SensorUpdater<MemT>               rmcl_ros/include/rmcl_ros/rmcl/SensorUpdater.hpp:18-42
 //   rmcl::ParticleUpdater<MemT>::update     rmcl_ros/include/rmcl_ros/rmcl/ParticleUpdater.hpp:24-44
 //
@@ -18,6 +22,8 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../rmclhip.h"
@@ -29,41 +35,87 @@ struct VRAM_HIP {};  // memory-space tag, sibling of rmagine::RAM / VRAM_CUDA
 using Vector = rmclhip_vec3;
 using Quaternion = rmclhip_quat;
 using Transform = rmclhip_transform;
-using SphericalModel = rmclhip_spherical_model;
 using CrossStatistics = rmclhip_cross_statistics;
 using ParticleAttributes = rmclhip_particle_attributes;
 using RangeMeasurement = rmclhip_range_measurement;
-using Interval = rmclhip_interval;
+
+// rmagine::Interval / DiscreteInterval / SphericalModel: the C ABI's PODs (same members, same layout) with the member functions the
+// reference's callers use -- model.range.inside(r), model.getHeight() / getWidth() / getBufferId(vid, hid) / getDirection(vid, hid) /
+// getOrigin(vid, hid) / size() (scan_map_segmentation_embree.cpp:108-125, MICPSphericalSensorCPU.cpp:212-219)
+struct Interval {
+  float min, max;
+  bool inside(float v) const { return v >= min && v <= max; }
+  operator rmclhip_interval() const { return rmclhip_interval{min, max}; }
+};
+struct DiscreteInterval {
+  float min, inc;
+  uint32_t size;
+};
+struct SphericalModel {
+  DiscreteInterval phi;     // vertical: rows, height (conversions.cpp:22-34)
+  DiscreteInterval theta;   // horizontal: columns, width
+  Interval range;
+  uint32_t getWidth() const { return theta.size; }
+  uint32_t getHeight() const { return phi.size; }
+  size_t size() const { return static_cast<size_t>(phi.size) * theta.size; }
+  uint32_t getBufferId(uint32_t vid, uint32_t hid) const { return vid * theta.size + hid; }
+  // direction convention pinned by rmcl_ros/src/util/conversions.cpp:174-188
+  Vector getDirection(uint32_t vid, uint32_t hid) const {
+    const float p = phi.min + static_cast<float>(vid) * phi.inc;
+    const float t = theta.min + static_cast<float>(hid) * theta.inc;
+    return Vector{std::cos(p) * std::cos(t), std::cos(p) * std::sin(t), std::sin(p)};
+  }
+  Vector getOrigin(uint32_t, uint32_t) const { return Vector{0.f, 0.f, 0.f}; }
+  const rmclhip_spherical_model* c_model() const { return reinterpret_cast<const rmclhip_spherical_model*>(this); }
+};
+static_assert(sizeof(Interval) == sizeof(rmclhip_interval) && sizeof(DiscreteInterval) == sizeof(rmclhip_discrete_interval) &&
+                  sizeof(SphericalModel) == sizeof(rmclhip_spherical_model) && std::is_standard_layout<SphericalModel>::value,
+              "SphericalModel must keep the C ABI's layout");
 
 inline void check(rmclhip_status st) {
   if (st != RMCLHIP_OK) throw std::runtime_error(std::string("rmclhip: ") + rmclhip_last_error());
 }
 
 inline Transform identity() { return Transform{{0.f, 0.f, 0.f, 1.f}, {0.f, 0.f, 0.f}, 0u}; }
+
+}  // namespace rmcl_hip
+
+// The PODs are the C ABI's structs, which live in the GLOBAL namespace: their operators must live there too, or argument-dependent
+// lookup does not find them from a caller's namespace (`namespace rm = rmcl_hip;` as the reference writes `rm::`).
 // Transform::operator* / operator~ (micp_localization.cpp:926,963)
-inline Transform operator*(const Transform& a, const Transform& b) {
-  Transform r;
-  check(rmclhip_transform_mult(&a, &b, &r));
+inline rmclhip_transform operator*(const rmclhip_transform& a, const rmclhip_transform& b) {
+  rmclhip_transform r;
+  rmcl_hip::check(rmclhip_transform_mult(&a, &b, &r));
   return r;
 }
-inline Transform operator~(const Transform& a) {
-  Transform r;
-  check(rmclhip_transform_inv(&a, &r));
+inline rmclhip_transform operator~(const rmclhip_transform& a) {
+  rmclhip_transform r;
+  rmcl_hip::check(rmclhip_transform_inv(&a, &r));
   return r;
 }
 // Transform * CrossStatistics (MICPSensor.hpp:182)
-inline CrossStatistics operator*(const Transform& T, const CrossStatistics& s) {
-  CrossStatistics r;
-  check(rmclhip_cross_statistics_transform(&T, &s, &r));
+inline rmclhip_cross_statistics operator*(const rmclhip_transform& T, const rmclhip_cross_statistics& s) {
+  rmclhip_cross_statistics r;
+  rmcl_hip::check(rmclhip_cross_statistics_transform(&T, &s, &r));
   return r;
 }
 // CrossStatistics::operator+= (micp_localization.cpp:936-937)
-inline CrossStatistics& operator+=(CrossStatistics& a, const CrossStatistics& b) {
-  CrossStatistics r;
-  check(rmclhip_cross_statistics_merge(&a, &b, &r));
+inline rmclhip_cross_statistics& operator+=(rmclhip_cross_statistics& a, const rmclhip_cross_statistics& b) {
+  rmclhip_cross_statistics r;
+  rmcl_hip::check(rmclhip_cross_statistics_merge(&a, &b, &r));
   a = r;
   return a;
 }
+// rmagine::Vector arithmetic the callers of simulate() use on its results (scan_map_segmentation_embree.cpp:125-135)
+inline rmclhip_vec3 operator*(const rmclhip_vec3& a, float s) { return rmclhip_vec3{a.x * s, a.y * s, a.z * s}; }
+inline rmclhip_vec3 operator+(const rmclhip_vec3& a, const rmclhip_vec3& b) { return rmclhip_vec3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline rmclhip_vec3 operator-(const rmclhip_vec3& a, const rmclhip_vec3& b) { return rmclhip_vec3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+
+namespace rmcl_hip {
+
+inline float dot(const Vector& a, const Vector& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline float l2norm(const Vector& a) { return std::sqrt(dot(a, a)); }
+
 inline CrossStatistics cross_statistics_identity() { return CrossStatistics{}; }
 // rm::umeyama_transform (micp_localization.cpp:952-953)
 inline Transform umeyama_transform(const CrossStatistics& s) {
@@ -159,6 +211,25 @@ struct RAM {};
 template <typename T, typename MemT>
 class Memory;
 
+// rmagine::MemoryView<T, RAM>: non-owning host view (`const rm::MemoryView<float, rm::RAM> ranges = res.ranges;`,
+// scan_map_segmentation_embree.cpp:89-90); MemoryView<T, VRAM_HIP> is DeviceView<T>
+template <typename T, typename MemT>
+struct MemoryView;
+template <typename T>
+struct MemoryView<T, RAM> {
+  T* ptr = nullptr;
+  size_t n = 0;
+  MemoryView() = default;
+  MemoryView(T* p, size_t count) : ptr(p), n(count) {}
+  template <typename U, typename = typename std::enable_if<std::is_same<typename std::remove_const<T>::type, U>::value>::type>
+  MemoryView(const Memory<U, RAM>& m) : ptr(const_cast<T*>(m.raw())), n(m.size()) {}   // (T is const-qualified for a const Memory)
+  T* raw() const { return ptr; }
+  size_t size() const { return n; }
+  T& operator[](size_t i) const { return ptr[i]; }
+};
+template <typename T>
+struct MemoryView<T, VRAM_HIP> : DeviceView<T> {};
+
 template <typename T>
 class Memory<T, RAM> {
  public:
@@ -183,7 +254,24 @@ class Memory<T, VRAM_HIP> {
   ~Memory() { release(); }
   Memory(const Memory&) = delete;
   Memory& operator=(const Memory&) = delete;
+  // movable: `ResultT res = sim->simulate<ResultT>(T)` returns a bundle of these by value (scan_map_segmentation_embree.cpp:87)
+  Memory(Memory&& o) noexcept : ctx_(std::move(o.ctx_)), ptr_(o.ptr_), cap_(o.cap_), n_(o.n_), version_(o.version_ + 1u) {
+    o.ptr_ = nullptr;
+    o.cap_ = o.n_ = 0;
+  }
+  Memory& operator=(Memory&& o) noexcept {
+    if (this != &o) {
+      release();
+      ctx_ = std::move(o.ctx_);
+      ptr_ = o.ptr_; cap_ = o.cap_; n_ = o.n_;
+      o.ptr_ = nullptr;
+      o.cap_ = o.n_ = 0;
+      ++version_;
+    }
+    return *this;
+  }
   void setContext(ContextPtr ctx) { ctx_ = std::move(ctx); }
+  const ContextPtr& context() const { return ctx_; }
   // grow-only like rm::Memory::resize on the reference's device paths (contents are not preserved)
   void resize(size_t n) {
     if (n > cap_) {
@@ -244,7 +332,72 @@ struct PointCloudView_ {
   DeviceView<const Vector> points;
   DeviceView<const uint8_t> mask;
   DeviceView<const Vector> normals;
+  rmclhip_ctx* ctx = nullptr;   // the device the views live on (filled by watch() / modelView() / datasetView()): statistics_p2l runs there
 };
+// rm::watch(dataset) (CorrespondencesCUDA.cpp:13): a view of an owning point cloud
+inline PointCloudView_<VRAM_HIP> watch(const PointCloud_<VRAM_HIP>& cloud) {
+  PointCloudView_<VRAM_HIP> v;
+  v.points = {cloud.points.raw(), cloud.points.size()};
+  v.mask = {cloud.mask.raw(), cloud.mask.size()};
+  v.ctx = cloud.points.context() ? cloud.points.context()->handle() : nullptr;
+  return v;
+}
+// rm::statistics_p2l(Tpre, dataset, model, params) -> CrossStatistics on device views (CorrespondencesCUDA.cpp:28; gate and projection
+// as MICPSensorCPU.cpp:70-84): what CorrespondencesCUDA::computeCrossStatistics calls after its max_dist interpolation.  A view
+// without a mask counts every element as valid; the views must live on one device.
+inline CrossStatistics statistics_p2l(const Transform& Tpre, const PointCloudView_<VRAM_HIP>& dataset, const PointCloudView_<VRAM_HIP>& model,
+                                      const UmeyamaReductionConstraints& params) {
+  rmclhip_ctx* ctx = dataset.ctx ? dataset.ctx : model.ctx;
+  if (!ctx) throw std::runtime_error("statistics_p2l: views without a context (use watch() / modelView())");
+  if (dataset.ctx && model.ctx && dataset.ctx != model.ctx) throw std::runtime_error("statistics_p2l: dataset and model live on different contexts");
+  if (model.normals.size() < model.points.size()) throw std::runtime_error("statistics_p2l: the model view needs normals");
+  if ((dataset.mask.size() && dataset.mask.size() < dataset.points.size()) || (model.mask.size() && model.mask.size() < model.points.size()))
+    throw std::runtime_error("statistics_p2l: mask shorter than its points");
+  const size_t n = dataset.points.size() < model.points.size() ? dataset.points.size() : model.points.size();
+  CrossStatistics out;
+  check(rmclhip_statistics_p2l(ctx, &Tpre, reinterpret_cast<const float*>(dataset.points.raw()), dataset.mask.size() ? dataset.mask.raw() : nullptr,
+                               reinterpret_cast<const float*>(model.points.raw()), reinterpret_cast<const float*>(model.normals.raw()),
+                               model.mask.size() ? model.mask.raw() : nullptr, static_cast<uint32_t>(n), params.max_dist, &out));
+  return out;
+}
+
+// ---- rmagine::Bundle and its attributes (rmagine/simulation/SimulationResults.hpp as used by Correspondences.hpp:81-85,
+// scan_map_segmentation_embree.cpp:82-85, lidar_corrector_embree_benchmark.cpp:95-100) -------------------------------------------
+// An attribute is a struct with ONE Memory member of rmagine's name; a Bundle derives from the attributes it carries; simulate()
+// writes exactly those.  MemT = VRAM_HIP: the kernel writes the caller's device memory; MemT = RAM: results are staged on the device
+// and copied to the host (the Embree callers' code, unchanged).
+template <typename MemT> struct Hits { Memory<uint8_t, MemT> hits; Memory<uint8_t, MemT>& attr_memory_() { return hits; } };
+template <typename MemT> struct Ranges { Memory<float, MemT> ranges; Memory<float, MemT>& attr_memory_() { return ranges; } };
+template <typename MemT> struct Points { Memory<Vector, MemT> points; Memory<Vector, MemT>& attr_memory_() { return points; } };
+template <typename MemT> struct Normals { Memory<Vector, MemT> normals; Memory<Vector, MemT>& attr_memory_() { return normals; } };
+template <typename MemT> struct FaceIds { Memory<uint32_t, MemT> face_ids; Memory<uint32_t, MemT>& attr_memory_() { return face_ids; } };
+template <typename... Attrs>
+struct Bundle : public Attrs... {};
+
+namespace detail {
+template <template <typename> class Attr, typename BundleT>
+constexpr bool has_attr() { return std::is_base_of<Attr<RAM>, BundleT>::value || std::is_base_of<Attr<VRAM_HIP>, BundleT>::value; }
+// resize one attribute of a bundle if it carries it in MemT
+template <typename MemT, template <typename> class Attr, typename BundleT>
+inline void resize_attr(BundleT& b, size_t n, const ContextPtr& ctx) {
+  if constexpr (std::is_base_of<Attr<MemT>, BundleT>::value) {
+    auto& m = static_cast<Attr<MemT>&>(b).attr_memory_();
+    if constexpr (std::is_same<MemT, VRAM_HIP>::value) { if (!m.context()) m.setContext(ctx); }
+    m.resize(n);
+  }
+}
+}  // namespace detail
+// rm::resize_memory_bundle<MemT>(bundle, H, W, N) (RCCEmbree.cpp:32): every attribute the bundle carries in MemT gets H * W * N elements
+// (device attributes without a context yet take `ctx`)
+template <typename MemT, typename BundleT>
+inline void resize_memory_bundle(BundleT& b, size_t H, size_t W, size_t N, const ContextPtr& ctx = nullptr) {
+  const size_t n = H * W * N;
+  detail::resize_attr<MemT, Hits>(b, n, ctx);
+  detail::resize_attr<MemT, Ranges>(b, n, ctx);
+  detail::resize_attr<MemT, Points>(b, n, ctx);
+  detail::resize_attr<MemT, Normals>(b, n, ctx);
+  detail::resize_attr<MemT, FaceIds>(b, n, ctx);
+}
 
 template <typename MemT>
 class Correspondences_;
@@ -309,7 +462,16 @@ class Correspondences_<VRAM_HIP> {
     PointCloudView_<VRAM_HIP> v;
     v.points = {dataset.points.raw(), dataset.points.size()};
     v.mask = {dataset.mask.raw(), dataset.mask.size()};
+    v.ctx = map_->context()->handle();
     return v;
+  }
+  // Bundle attribute selection of find() (rmclhip.h: rmclhip_rcc_set_outputs).  The C ABI's default is all five; the reference's
+  // model_buffers_ is Bundle<Points, Normals, Hits> (Correspondences.hpp:81-85) = RMCLHIP_OUT_MICP, 25 instead of 33 B per ray.
+  void setOutputs(uint32_t mask) { check(rmclhip_rcc_set_outputs(h_, mask)); }
+  uint32_t outputs() const {
+    uint32_t m = 0;
+    check(rmclhip_rcc_get_outputs(h_, &m));
+    return m;
   }
   // measurement-driven choice of the single-scan traversal for this map and model (rmclhip.h: rmclhip_rcc_autotune); returns the kind
   int autotune(const Transform& Tbm_est) {
@@ -327,9 +489,10 @@ class Correspondences_<VRAM_HIP> {
   PointCloudView_<VRAM_HIP> modelView() const {
     const ModelBuffers b = modelBuffers();
     PointCloudView_<VRAM_HIP> v;
-    v.points = {reinterpret_cast<const Vector*>(b.points), b.n};
-    v.mask = {b.mask, b.n};
-    v.normals = {reinterpret_cast<const Vector*>(b.normals), b.n};
+    v.points = {reinterpret_cast<const Vector*>(b.points), b.points ? b.n : 0u};
+    v.mask = {b.mask, b.mask ? b.n : 0u};
+    v.normals = {reinterpret_cast<const Vector*>(b.normals), b.normals ? b.n : 0u};
+    v.ctx = map_->context()->handle();
     return v;
   }
   // everything find() writes, as raw borrowed device pointers (+ ranges, face ids, which the reference's bundle does not carry)
@@ -436,37 +599,24 @@ struct ModelSetter {
   virtual void setModel(const ModelT&) = 0;
 };
 
-// rmagine::O1DnModel (fields: rmcl_ros/src/util/conversions.cpp:74-94)
+// rmagine::O1DnModel (fields: rmcl_ros/src/util/conversions.cpp:74-94; buffer id = vid * width + hid: conversions.cpp:974)
 struct O1DnModel {
   uint32_t width = 0, height = 0;
   Interval range{0.f, 0.f};
   Vector orig{0.f, 0.f, 0.f};
   std::vector<Vector> dirs;
+  uint32_t getWidth() const { return width; }
+  uint32_t getHeight() const { return height; }
+  size_t size() const { return static_cast<size_t>(width) * height; }
+  uint32_t getBufferId(uint32_t vid, uint32_t hid) const { return vid * width + hid; }
+  Vector getDirection(uint32_t vid, uint32_t hid) const { return dirs[getBufferId(vid, hid)]; }
+  Vector getOrigin(uint32_t, uint32_t) const { return orig; }
 };
 
 // rmagine::SphericalModel::getDirection / getBufferId (convention pinned by rmcl_ros/src/util/conversions.cpp:174-188):
 // what the reference's unpackMessage evaluates per measurement when it fills `dataset` (MICPSphericalSensorCPU.cpp:212-219)
-inline Vector getDirection(const SphericalModel& m, uint32_t vid, uint32_t hid) {
-  const float phi = m.phi.min + static_cast<float>(vid) * m.phi.inc;
-  const float theta = m.theta.min + static_cast<float>(hid) * m.theta.inc;
-  return Vector{std::cos(phi) * std::cos(theta), std::cos(phi) * std::sin(theta), std::sin(phi)};
-}
-inline uint32_t getBufferId(const SphericalModel& m, uint32_t vid, uint32_t hid) { return vid * m.theta.size + hid; }
-
-class RCCHipSpherical : public CorrespondencesHIP, public ModelSetter<SphericalModel> {
- public:
-  explicit RCCHipSpherical(HipMapPtr map) : CorrespondencesHIP(std::move(map)) {}
-  void setModel(const SphericalModel& m) override { check(rmclhip_rcc_set_model_spherical(h_, &m)); }
-};
-
-class RCCHipO1Dn : public CorrespondencesHIP, public ModelSetter<O1DnModel> {
- public:
-  explicit RCCHipO1Dn(HipMapPtr map) : CorrespondencesHIP(std::move(map)) {}
-  void setModel(const O1DnModel& m) override {
-    if (m.dirs.size() != static_cast<size_t>(m.width) * m.height) throw std::runtime_error("O1DnModel: dirs.size() != width*height");
-    check(rmclhip_rcc_set_model_o1dn(h_, m.width, m.height, m.range, m.orig, reinterpret_cast<const float*>(m.dirs.data())));
-  }
-};
+inline Vector getDirection(const SphericalModel& m, uint32_t vid, uint32_t hid) { return m.getDirection(vid, hid); }
+inline uint32_t getBufferId(const SphericalModel& m, uint32_t vid, uint32_t hid) { return m.getBufferId(vid, hid); }
 
 // rmagine::PinholeModel (fields: rmcl_ros/src/util/conversions.cpp:36-60)
 struct PinholeModel {
@@ -474,6 +624,10 @@ struct PinholeModel {
   Interval range{0.f, 0.f};
   float f[2] = {1.f, 1.f};
   float c[2] = {0.f, 0.f};
+  uint32_t getWidth() const { return width; }
+  uint32_t getHeight() const { return height; }
+  size_t size() const { return static_cast<size_t>(width) * height; }
+  uint32_t getBufferId(uint32_t vid, uint32_t hid) const { return vid * width + hid; }
 };
 
 // rmagine::OnDnModel (fields: rmcl_ros/src/util/conversions.cpp:96-120)
@@ -481,26 +635,184 @@ struct OnDnModel {
   uint32_t width = 0, height = 0;
   Interval range{0.f, 0.f};
   std::vector<Vector> origs, dirs;
+  uint32_t getWidth() const { return width; }
+  uint32_t getHeight() const { return height; }
+  size_t size() const { return static_cast<size_t>(width) * height; }
+  uint32_t getBufferId(uint32_t vid, uint32_t hid) const { return vid * width + hid; }
+  Vector getDirection(uint32_t vid, uint32_t hid) const { return dirs[getBufferId(vid, hid)]; }
+  Vector getOrigin(uint32_t vid, uint32_t hid) const { return origs[getBufferId(vid, hid)]; }
 };
 
-class RCCHipPinhole : public CorrespondencesHIP, public ModelSetter<PinholeModel> {
- public:
-  explicit RCCHipPinhole(HipMapPtr map) : CorrespondencesHIP(std::move(map)) {}
-  void setModel(const PinholeModel& m) override {
-    check(rmclhip_rcc_set_model_pinhole(h_, m.width, m.height, m.range, m.f[0], m.f[1], m.c[0], m.c[1]));
-  }
-};
+namespace detail {
+// Simulator::setModel per model type -> the C ABI's setter
+inline void set_model(rmclhip_rcc* h, const SphericalModel& m) { check(rmclhip_rcc_set_model_spherical(h, m.c_model())); }
+inline void set_model(rmclhip_rcc* h, const O1DnModel& m) {
+  if (m.dirs.size() != m.size()) throw std::runtime_error("O1DnModel: dirs.size() != width*height");
+  check(rmclhip_rcc_set_model_o1dn(h, m.width, m.height, m.range, m.orig, reinterpret_cast<const float*>(m.dirs.data())));
+}
+inline void set_model(rmclhip_rcc* h, const PinholeModel& m) {
+  check(rmclhip_rcc_set_model_pinhole(h, m.width, m.height, m.range, m.f[0], m.f[1], m.c[0], m.c[1]));
+}
+inline void set_model(rmclhip_rcc* h, const OnDnModel& m) {
+  if (m.dirs.size() != m.size() || m.origs.size() != m.size()) throw std::runtime_error("OnDnModel: origs/dirs size != width*height");
+  check(rmclhip_rcc_set_model_ondn(h, m.width, m.height, m.range, reinterpret_cast<const float*>(m.origs.data()),
+                                   reinterpret_cast<const float*>(m.dirs.data())));
+}
+}  // namespace detail
 
-class RCCHipOnDn : public CorrespondencesHIP, public ModelSetter<OnDnModel> {
+// rmagine::SphereSimulatorEmbree / O1DnSimulatorEmbree / PinholeSimulatorEmbree / OnDnSimulatorEmbree (and their Optix twins) on gfx950:
+//   setTsb, setModel, simulate(const Transform&, BundleT&), simulate<BundleT>(Transform), simulate(Memory<Transform>&, BundleT&)
+// (scan_map_segmentation_embree.cpp:38-39,78,87; lidar_corrector_embree_benchmark.cpp:117; lidar_corrector_optix_benchmark.cpp:119 with
+// the poses in device memory).  Results are in the SENSOR frame; a bundle receives exactly the attributes it carries
+// (rmclhip_rcc_simulate): the kernel skips the stores of the others.  Standalone (`SphereSimulatorHip sim(map)`) it owns its engine
+// handle; as the protected base of an RCCHip* class it borrows the operator's (RCCEmbree.hpp:18-22).
+template <typename ModelT>
+class SimulatorHip {
  public:
-  explicit RCCHipOnDn(HipMapPtr map) : CorrespondencesHIP(std::move(map)) {}
-  void setModel(const OnDnModel& m) override {
-    const size_t n = static_cast<size_t>(m.width) * m.height;
-    if (m.dirs.size() != n || m.origs.size() != n) throw std::runtime_error("OnDnModel: origs/dirs size != width*height");
-    check(rmclhip_rcc_set_model_ondn(h_, m.width, m.height, m.range, reinterpret_cast<const float*>(m.origs.data()),
-                                     reinterpret_cast<const float*>(m.dirs.data())));
+  explicit SimulatorHip(HipMapPtr map) : sim_map_(std::move(map)), sim_owns_(true) {
+    if (!sim_map_) throw std::runtime_error("NO MAP");
+    check(rmclhip_rcc_create(sim_map_->context()->handle(), sim_map_->handle(), &sim_));
+  }
+  virtual ~SimulatorHip() {
+    if (sim_owns_) rmclhip_rcc_destroy(sim_);
+  }
+  SimulatorHip(const SimulatorHip&) = delete;
+  SimulatorHip& operator=(const SimulatorHip&) = delete;
+
+  void setTsb(const Transform& Tsb) { check(rmclhip_rcc_set_tsb(sim_, &Tsb)); }
+  void setModel(const ModelT& model) {
+    detail::set_model(sim_, model);
+    m_model = std::make_shared<ModelT>(model);
+  }
+  // rmagine keeps the model as `m_model` (RCCEmbree.cpp:29: m_model->size())
+  std::shared_ptr<ModelT> model() const { return m_model; }
+
+  // simulate(Tbm, res): every attribute of `res` must already hold model.size() elements (lidar_corrector_embree_benchmark.cpp:99-100)
+  template <typename BundleT>
+  void simulate(const Transform& Tbm, BundleT& res) { run(&Tbm, 1u, false, res); }
+  // simulate<BundleT>(Tbm): allocates the bundle (scan_map_segmentation_embree.cpp:87)
+  template <typename BundleT>
+  BundleT simulate(const Transform& Tbm) {
+    BundleT res;
+    resize_bundle(res, 1u);
+    run(&Tbm, 1u, false, res);
+    return res;
+  }
+  // batch forms: results pose-major, index pose * size() + getBufferId(vid, hid)
+  template <typename BundleT>
+  void simulate(const Memory<Transform, RAM>& Tbm, BundleT& res) { run(Tbm.raw(), static_cast<uint32_t>(Tbm.size()), false, res); }
+  template <typename BundleT>
+  void simulate(const Memory<Transform, VRAM_HIP>& Tbm, BundleT& res) { run(Tbm.raw(), static_cast<uint32_t>(Tbm.size()), true, res); }
+  template <typename BundleT>
+  BundleT simulate(const Memory<Transform, RAM>& Tbm) {
+    BundleT res;
+    resize_bundle(res, Tbm.size());
+    run(Tbm.raw(), static_cast<uint32_t>(Tbm.size()), false, res);
+    return res;
+  }
+  template <typename BundleT>
+  BundleT simulate(const Memory<Transform, VRAM_HIP>& Tbm) {
+    BundleT res;
+    resize_bundle(res, Tbm.size());
+    run(Tbm.raw(), static_cast<uint32_t>(Tbm.size()), true, res);
+    return res;
+  }
+
+ protected:
+  // the protected-base form: the engine is the operator's handle
+  struct Borrowed { rmclhip_rcc* h; HipMapPtr map; };
+  explicit SimulatorHip(Borrowed b) : sim_map_(std::move(b.map)), sim_(b.h), sim_owns_(false) {}
+  std::shared_ptr<ModelT> m_model;
+
+ private:
+  template <typename BundleT>
+  void resize_bundle(BundleT& res, size_t nposes) {
+    if (!m_model) throw std::runtime_error("simulate: no sensor model (setModel first)");
+    resize_memory_bundle<RAM>(res, m_model->getHeight(), m_model->getWidth(), nposes);
+    resize_memory_bundle<VRAM_HIP>(res, m_model->getHeight(), m_model->getWidth(), nposes, sim_map_->context());
+  }
+  // one attribute: the device pointer the kernel writes -- the caller's own memory (VRAM_HIP) or this simulator's staging buffer (RAM)
+  template <template <typename> class Attr, typename T, typename BundleT>
+  T* bind(BundleT& res, size_t n, Memory<T, VRAM_HIP>& stage) {
+    if constexpr (std::is_base_of<Attr<VRAM_HIP>, BundleT>::value) {
+      auto& m = static_cast<Attr<VRAM_HIP>&>(res).attr_memory_();
+      if (m.size() < n) throw std::runtime_error("simulate: a bundle attribute is smaller than poses * model.size()");
+      return m.raw();
+    } else if constexpr (std::is_base_of<Attr<RAM>, BundleT>::value) {
+      if (static_cast<Attr<RAM>&>(res).attr_memory_().size() < n) throw std::runtime_error("simulate: a bundle attribute is smaller than poses * model.size()");
+      if (!stage.context()) stage.setContext(sim_map_->context());
+      stage.resize(n);
+      return stage.raw();
+    } else {
+      (void)res; (void)n; (void)stage;
+      return nullptr;
+    }
+  }
+  template <template <typename> class Attr, typename T, typename BundleT>
+  void fetch(BundleT& res, size_t n, const Memory<T, VRAM_HIP>& stage) {
+    if constexpr (!std::is_base_of<Attr<VRAM_HIP>, BundleT>::value && std::is_base_of<Attr<RAM>, BundleT>::value) {
+      if (n) check(rmclhip_memcpy_d2h(sim_map_->context()->handle(), static_cast<Attr<RAM>&>(res).attr_memory_().raw(), stage.raw(), n * sizeof(T)));
+    } else {
+      (void)res; (void)n; (void)stage;
+    }
+  }
+  template <typename BundleT>
+  void run(const Transform* Tbm, uint32_t nposes, bool poses_on_device, BundleT& res) {
+    static_assert(detail::has_attr<Hits, BundleT>() || detail::has_attr<Ranges, BundleT>() || detail::has_attr<Points, BundleT>() ||
+                      detail::has_attr<Normals, BundleT>() || detail::has_attr<FaceIds, BundleT>(),
+                  "simulate: the bundle carries none of Hits / Ranges / Points / Normals / FaceIds");
+    if (!m_model) throw std::runtime_error("simulate: no sensor model (setModel first)");
+    if (nposes == 0u) return;
+    const size_t n = m_model->size() * nposes;
+    rmclhip_bundle_views v{};
+    v.hits_dev = bind<Hits>(res, n, st_hits_);
+    v.ranges_dev = bind<Ranges>(res, n, st_ranges_);
+    v.points_xyz_dev = reinterpret_cast<float*>(bind<Points>(res, n, st_points_));
+    v.normals_xyz_dev = reinterpret_cast<float*>(bind<Normals>(res, n, st_normals_));
+    v.face_ids_dev = bind<FaceIds>(res, n, st_face_ids_);
+    check(rmclhip_rcc_simulate(sim_, Tbm, nposes, poses_on_device ? 1 : 0, &v));
+    fetch<Hits>(res, n, st_hits_);
+    fetch<Ranges>(res, n, st_ranges_);
+    fetch<Points>(res, n, st_points_);
+    fetch<Normals>(res, n, st_normals_);
+    fetch<FaceIds>(res, n, st_face_ids_);
+  }
+  HipMapPtr sim_map_;
+  rmclhip_rcc* sim_ = nullptr;
+  bool sim_owns_ = false;
+  Memory<uint8_t, VRAM_HIP> st_hits_;       // staging of RAM bundles (grow-only)
+  Memory<float, VRAM_HIP> st_ranges_;
+  Memory<Vector, VRAM_HIP> st_points_, st_normals_;
+  Memory<uint32_t, VRAM_HIP> st_face_ids_;
+};
+using SphereSimulatorHip = SimulatorHip<SphericalModel>;
+using O1DnSimulatorHip = SimulatorHip<O1DnModel>;
+using PinholeSimulatorHip = SimulatorHip<PinholeModel>;
+using OnDnSimulatorHip = SimulatorHip<OnDnModel>;
+using SphereSimulatorHipPtr = std::shared_ptr<SphereSimulatorHip>;
+using O1DnSimulatorHipPtr = std::shared_ptr<O1DnSimulatorHip>;
+
+// rmcl::RCCEmbree{Spherical, Pinhole, O1Dn, OnDn} (RCCEmbree.hpp:18-83): the correspondence operator + ModelSetter + -- protected --
+// the simulator of its model.  find() is the reference's `simulate(Tbm_est, model_buffers_)` (RCCEmbree.cpp:35) on the operator's own
+// buffers, which live behind the C handle (rmclhip_rcc_find); like Correspondences_::model_buffers_ they carry {points, normals, hits}
+// unless setOutputs() widens the bundle.
+template <typename ModelT>
+class RCCHip_ : public CorrespondencesHIP, public ModelSetter<ModelT>, protected SimulatorHip<ModelT> {
+ public:
+  explicit RCCHip_(HipMapPtr map) : CorrespondencesHIP(map), SimulatorHip<ModelT>(typename SimulatorHip<ModelT>::Borrowed{h_, map}) {
+    setOutputs(RMCLHIP_OUT_MICP);
+  }
+  void setModel(const ModelT& sensor_model) override { SimulatorHip<ModelT>::setModel(sensor_model); }
+  // RCCEmbree.cpp:15-19: both bases learn Tsb (here they share the engine, so once is enough for it)
+  void setTsb(const Transform& Tsb) override {
+    CorrespondencesHIP::setTsb(Tsb);
+    SimulatorHip<ModelT>::setTsb(Tsb);
   }
 };
+using RCCHipSpherical = RCCHip_<SphericalModel>;
+using RCCHipO1Dn = RCCHip_<O1DnModel>;
+using RCCHipPinhole = RCCHip_<PinholeModel>;
+using RCCHipOnDn = RCCHip_<OnDnModel>;
 
 // rmcl::CPCEmbree (rmcl/include/rmcl/registration/CPCEmbree.hpp): closest-point correspondences
 class CPCHip : public CorrespondencesHIP {

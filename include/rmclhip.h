@@ -458,6 +458,61 @@ rmclhip_status rmclhip_rcc_autotune_batch(rmclhip_rcc* rcc, const rmclhip_transf
  * one launch for nposes x H x W rays; model buffers become pose-major [pose][vid][hid]. */
 rmclhip_status rmclhip_rcc_find_batch(rmclhip_rcc* rcc, const rmclhip_transform* Tbm, uint32_t nposes);
 
+/* ---- the rmagine-level Simulator interface ---------------------------------------------------------------
+ * The reference's RCC classes ARE simulators: `class RCCEmbreeSpherical : public CorrespondencesCPU, public
+ * rmagine::ModelSetter<SphericalModel>, protected rmagine::SphereSimulatorEmbree` (rmcl/include/rmcl/registration/RCCEmbree.hpp:18-22),
+ * find() is `simulate(Tbm_est, model_buffers_)` (RCCEmbree.cpp:35), and the simulators are also used on their own
+ * (rmcl_ros/src/nodes/filter/scan_map_segmentation_embree.cpp:38-39,76-87; lidar_corrector_embree_benchmark.cpp:117).  Here the
+ * rmclhip_rcc handle is that simulator: rmclhip_rcc_set_tsb / rmclhip_rcc_set_model_* are Simulator::setTsb / ::setModel, and
+ * rmclhip_rcc_simulate is Simulator::simulate(const Transform&, BundleT&) / simulate(Memory<Transform>&, BundleT&).
+ *
+ * Bundle attribute selection.  rmagine's simulate<Bundle<Ranges, Normals>> writes only the attributes the bundle names
+ * (scan_map_segmentation_embree.cpp:80-87); MICP's own bundle is {Points, Normals, Hits} = 25 B/ray (Correspondences.hpp:81-85).
+ * An attribute is selected by a bit; the kernel skips the stores of the others. */
+#define RMCLHIP_OUT_HITS 1u      /* rmagine::Hits     uint8  per ray */
+#define RMCLHIP_OUT_RANGES 2u    /* rmagine::Ranges   float  per ray (miss: range.max + 1) */
+#define RMCLHIP_OUT_POINTS 4u    /* rmagine::Points   3 floats, sensor frame (miss: NaN) */
+#define RMCLHIP_OUT_NORMALS 8u   /* rmagine::Normals  3 floats, sensor frame, facing the ray (miss: NaN) */
+#define RMCLHIP_OUT_FACE_IDS 16u /* rmagine::FaceIds  uint32 (miss: 0xFFFFFFFF) */
+#define RMCLHIP_OUT_ALL 31u
+#define RMCLHIP_OUT_MICP (RMCLHIP_OUT_HITS | RMCLHIP_OUT_POINTS | RMCLHIP_OUT_NORMALS) /* Correspondences_::model_buffers_ */
+/* Which of the operator's OWN model buffers find / find_batch write (default RMCLHIP_OUT_ALL).  A deselected buffer is not written --
+ * it keeps what the last find that selected it left there (nothing, if none did: download / device_views of it then fail / return
+ * NULL).  computeCrossStatistics and the corrections read {hits, points, normals}: they fail with RMCLHIP_ERR_INVALID while one of
+ * those is deselected.  mask == 0 or bits beyond RMCLHIP_OUT_ALL: RMCLHIP_ERR_INVALID. */
+rmclhip_status rmclhip_rcc_set_outputs(rmclhip_rcc* rcc, uint32_t mask);
+rmclhip_status rmclhip_rcc_get_outputs(const rmclhip_rcc* rcc, uint32_t* mask);
+/* a rmagine Bundle over CALLER-owned device memory: one nullable pointer per attribute (NULL = the bundle does not carry it);
+ * every non-null buffer holds nposes * width * height elements, index pose * W * H + vid * W + hid */
+typedef struct {
+  uint8_t* hits_dev;
+  float* ranges_dev;
+  float* points_xyz_dev;
+  float* normals_xyz_dev;
+  uint32_t* face_ids_dev;
+} rmclhip_bundle_views;
+/* rm::Simulator::simulate(const Transform& Tbm, BundleT& res) (nposes == 1; scan_map_segmentation_embree.cpp:87) and its batch form
+ * simulate(const Memory<Transform>& Tbm, BundleT& res) (lidar_corrector_embree_benchmark.cpp:117, _optix_benchmark.cpp:119 -- there the
+ * poses are device memory: Tbm_is_device != 0).  One launch for nposes x H x W rays with Tsm = Tbm[i] * Tsb, results in the sensor
+ * frame into the caller's bundle.  The operator's own model buffers, its dataset and whatever computeCrossStatistics has cached of them
+ * are NOT touched.  No-op on an empty model or nposes == 0.  The _async form returns once the launch is enqueued on the handle's stream
+ * (rmclhip_rcc_sync waits); Tbm is copied before it returns. */
+rmclhip_status rmclhip_rcc_simulate(rmclhip_rcc* rcc, const rmclhip_transform* Tbm, uint32_t nposes, int Tbm_is_device,
+                                    const rmclhip_bundle_views* out);
+rmclhip_status rmclhip_rcc_simulate_async(rmclhip_rcc* rcc, const rmclhip_transform* Tbm, uint32_t nposes, int Tbm_is_device,
+                                          const rmclhip_bundle_views* out);
+/* rm::statistics_p2l(const Transform& Tpre, const PointCloudView_<MemT>& dataset, const PointCloudView_<MemT>& model,
+ * const UmeyamaReductionConstraints& params) -> CrossStatistics, as a free function on CALLER-owned device views
+ * (rmcl/src/rmcl/registration/CorrespondencesCUDA.cpp:28; gate and projection pinned by rmcl_ros/src/micpl/MICPSensorCPU.cpp:70-84):
+ * for i < n with dataset_mask[i] > 0 && model_mask[i] > 0: Di = Tpre * dataset_points[i], d = (Ii - Di) . Ni, kept iff |d| < max_dist,
+ * Mi = Di + Ni d; means of D and M, covariance 1/n sum (M - mean_M)(D - mean_D)^T, count.  Either mask may be NULL (all valid).
+ * The streaming reduction of rmclhip_rcc_compute_cross_statistics (k_reduce_partials + finalize) on the context's own stream;
+ * synchronous, thread-safe per context (calls on one context serialise). */
+rmclhip_status rmclhip_statistics_p2l(rmclhip_ctx* ctx, const rmclhip_transform* Tpre, const float* dataset_points_xyz_dev,
+                                      const uint8_t* dataset_mask_dev, const float* model_points_xyz_dev,
+                                      const float* model_normals_xyz_dev, const uint8_t* model_mask_dev, uint32_t n, float max_dist,
+                                      rmclhip_cross_statistics* out);
+
 /* ---- host-side algebra (rmagine math the callers of the hot path use) -------------- */
 /* rm::umeyama_transform(CrossStatistics) (micp_localization.cpp:952-953) */
 rmclhip_status rmclhip_umeyama_transform(const rmclhip_cross_statistics* stats, rmclhip_transform* out);

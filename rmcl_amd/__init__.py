@@ -11,7 +11,7 @@ from .pf import (GladiatorResamplerHip, PCDSensorUpdaterHip, ResidualResamplerHi
                  beams_from_points, combined_forget_rate, sample_beams)
 from .registration import (CPCHip, Context, CorrespondencesHIP, DeviceArray, HipMap, MapMap, RCCHipO1Dn,  # noqa: F401
                            RCCHipOnDn, RCCHipPinhole, RCCHipSpherical, ShardedCorrectorHip, build_bvh_host, build_bvh_host_pf, build_bvh_host_quantised,
-                           flatten_scene_host, import_hip_map, import_hip_scene)
+                           flatten_scene_host, import_hip_map, import_hip_scene, statistics_p2l)
 
 from ._capi import load_lab  # noqa: F401  (experiments library; tools/ and the `lab` tests only)
 

@@ -92,6 +92,17 @@ class MapInfo(C.Structure):
                 ("height_fallbacks", C.c_uint32), ("guarded_nodes", C.c_uint32)]
 
 
+class BundleViews(C.Structure):
+    """rmclhip_bundle_views: a rmagine Bundle over caller-owned device memory, one nullable pointer per attribute"""
+    _fields_ = [("hits_dev", C.c_void_p), ("ranges_dev", C.c_void_p), ("points_xyz_dev", C.c_void_p),
+                ("normals_xyz_dev", C.c_void_p), ("face_ids_dev", C.c_void_p)]
+
+
+OUT_HITS, OUT_RANGES, OUT_POINTS, OUT_NORMALS, OUT_FACE_IDS = 1, 2, 4, 8, 16
+OUT_ALL = 31
+OUT_MICP = OUT_HITS | OUT_POINTS | OUT_NORMALS   # Correspondences_::model_buffers_ (Correspondences.hpp:81-85)
+
+
 class Mesh(C.Structure):
     _fields_ = [("vertices_xyz", C.c_void_p), ("faces_ijk", C.c_void_p), ("n_vertices", C.c_uint32), ("n_faces", C.c_uint32)]
 
@@ -142,6 +153,11 @@ SIGNATURES = {
     "rmclhip_rcc_compute_cross_statistics": (_i32, [_vp, _vp, _dbl, _vp]),
     "rmclhip_rcc_download": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "rmclhip_rcc_device_views": (_i32, [_vp, _pp, _pp, _pp, _pp, _pp, C.POINTER(_u32)]),
+    "rmclhip_rcc_set_outputs": (_i32, [_vp, _u32]),
+    "rmclhip_rcc_get_outputs": (_i32, [_vp, C.POINTER(_u32)]),
+    "rmclhip_rcc_simulate": (_i32, [_vp, _vp, _u32, _i32, C.POINTER(BundleViews)]),
+    "rmclhip_rcc_simulate_async": (_i32, [_vp, _vp, _u32, _i32, C.POINTER(BundleViews)]),
+    "rmclhip_statistics_p2l": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _f32, _vp]),
     "rmclhip_rcc_correct_once": (_i32, [_vp, _vp, _vp, _u32, _dbl, _i32, _vp, _vp]),
     "rmclhip_micp_correct_once": (_i32, [_vp, _u32, _vp, _vp, _vp, _u32, _dbl, _vp, _vp]),
     "rmclhip_rcc_correct_batch": (_i32, [_vp, _vp, _u32, _vp, _vp]),

@@ -14,6 +14,8 @@
 #include <cstring>
 #include <deque>
 #include <limits>
+#include <exception>
+#include <system_error>
 #include <thread>
 
 namespace rmclhip {
@@ -93,14 +95,27 @@ struct PhaseTimer {
 };
 
 // f(thread, begin, end) over [0, n) in `nt` contiguous chunks (chunk k belongs to thread k: deterministic ownership)
+// Nothing may escape a std::thread or leave joinable threads behind (either ends the process, and this code runs under extern-"C"
+// entry points): a worker hands its exception over, a thread that cannot be created (EAGAIN under a pid limit) has its chunk run by the
+// caller, and everything started is joined before the first exception continues to build_bvh, which turns it into an error string.
 template <class F>
 static void parallel_chunks(size_t n, int nt, F&& f) {
   if (nt <= 1 || n < 2) { f(0, size_t{0}, n); return; }
   std::vector<std::thread> th;
   th.reserve(nt - 1);
-  for (int k = 1; k < nt; ++k) th.emplace_back([&, k] { f(k, n * k / nt, n * (k + 1) / nt); });
-  f(0, size_t{0}, n / nt);
+  std::vector<std::exception_ptr> err(static_cast<size_t>(nt));
+  auto run = [&](int k) noexcept {
+    try { f(k, n * k / nt, n * (k + 1) / nt); } catch (...) { err[static_cast<size_t>(k)] = std::current_exception(); }
+  };
+  int started = 1;
+  for (int k = 1; k < nt; ++k) {
+    try { th.emplace_back(run, k); } catch (const std::system_error&) { break; }
+    ++started;
+  }
+  run(0);
+  for (int k = started; k < nt; ++k) run(k);   // chunks whose thread could not be created
   for (auto& t : th) t.join();
+  for (const auto& e : err) if (e) std::rethrow_exception(e);
 }
 
 struct Bins {
@@ -350,13 +365,9 @@ struct Builder {
         }
       }
     };
-    {
-      const int nt = static_cast<int>(std::min<size_t>(nthreads, small.size()));
-      std::vector<std::thread> th;
-      for (int k = 1; k < nt; ++k) th.emplace_back(worker);
-      worker();
-      for (auto& t : th) t.join();
-    }
+    // (the workers pull subtrees from a shared counter: any number of them, down to the caller alone, completes the list)
+    parallel_chunks(static_cast<size_t>(std::max<size_t>(std::min<size_t>(nthreads, small.size()), 1)),
+                    static_cast<int>(std::min<size_t>(nthreads, small.size())), [&](int, size_t, size_t) { worker(); });
     pt.mark("  phase B (subtrees)");
     // splice: subtree k's local nodes 1.. go to [off[k], ...) of the global array
     std::vector<size_t> off(small.size() + 1, nodes.size());
@@ -585,7 +596,23 @@ void quantise(const std::vector<Node4>& nodes, std::vector<Node4Q>& qnodes, int 
 
 }  // namespace
 
+static std::string build_bvh_impl(const float* verts, uint32_t nv, const uint32_t* faces, uint32_t nf, BvhHost& out, uint32_t max_leaf);
+
+// the boundary of the builder: an allocation that fails on a 10 M-face build, or a thread the system refuses, becomes an error string
+// for the C entry points (which never throw) instead of crossing them
 std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, uint32_t nf, BvhHost& out, uint32_t max_leaf) {
+  try {
+    return build_bvh_impl(verts, nv, faces, nf, out, max_leaf);
+  } catch (const std::bad_alloc&) {
+    return "BVH build: out of host memory";
+  } catch (const std::exception& e) {
+    return std::string("BVH build: ") + e.what();
+  } catch (...) {
+    return "BVH build: unknown failure";
+  }
+}
+
+static std::string build_bvh_impl(const float* verts, uint32_t nv, const uint32_t* faces, uint32_t nf, BvhHost& out, uint32_t max_leaf) {
   if (!verts || !faces) return "null mesh pointers";
   if (nf == 0 || nv == 0) return "empty mesh";
   if (nf > 0x0FFFFFFFu) return "too many faces (max 2^28-1)";
@@ -685,11 +712,16 @@ std::string build_bvh(const float* verts, uint32_t nv, const uint32_t* faces, ui
   Collapsed main_tree, pf_tree;
   const bool own_pf_tree = max_leaf > kPfLeafTris;
   {
-    std::thread side;
-    if (own_pf_tree && nt > 1) side = std::thread([&] { pf_tree = collapse_bounded(kPfLeafTris); });
-    main_tree = collapse_bounded(max_leaf);
-    if (side.joinable()) side.join();
-    else if (own_pf_tree) pf_tree = collapse_bounded(kPfLeafTris);
+    // the two cuts side by side; chunk 0 (the caller) takes the map's, chunk 1 the filter's (parallel_chunks: exception- and EAGAIN-safe)
+    if (own_pf_tree && nt > 1) {
+      parallel_chunks(2, 2, [&](int k, size_t, size_t) {
+        if (k == 0) main_tree = collapse_bounded(max_leaf);
+        else pf_tree = collapse_bounded(kPfLeafTris);
+      });
+    } else {
+      main_tree = collapse_bounded(max_leaf);
+      if (own_pf_tree) pf_tree = collapse_bounded(kPfLeafTris);
+    }
   }
   timer.mark("collapse (both cuts)");
   out.nodes = std::move(main_tree.nodes);

@@ -127,6 +127,19 @@ struct rmclhip_ctx {
   // rmclhip_ctx_destroy only drops the creator's, so destroying the context before its children is safe
   std::atomic<int> refs{1};
   std::atomic<int> wait_block{0};   // rmclhip_ctx_set_wait_mode: 0 = spin on the completion tag, 1 = block in hipStreamSynchronize
+  // rmclhip_statistics_p2l (the free function on caller-owned views): stream, partial rows, host-mapped result + tag, created by the
+  // first call under the mutex, which also serialises the calls of one context
+  std::mutex p2l_mtx;
+  hipStream_t p2l_stream = nullptr;
+  double* p2l_partials = nullptr;
+  size_t p2l_partials_cap = 0;          // doubles
+  cstats* p2l_h_stats = nullptr;        // pinned, host-mapped: [0] the result
+  cstats* p2l_h_stats_dev = nullptr;
+  unsigned long long* p2l_h_done = nullptr;
+  unsigned long long* p2l_h_done_dev = nullptr;
+  uint32_t* p2l_tickets = nullptr;      // (the fused tail's arrival counter: unused by this path, the kernel's parameter block wants one)
+  uint32_t p2l_seq = 0;
+  ~rmclhip_ctx();                       // capi_map.cpp
 };
 
 inline void ctx_retain(rmclhip_ctx* c) { c->refs.fetch_add(1); }
@@ -188,6 +201,7 @@ struct rmclhip_rcc {
   DevBuf<uint32_t> d_face_ids;
   uint32_t n_model = 0;      // per pose
   uint32_t nposes_last = 0;
+  uint32_t out_mask = RMCLHIP_OUT_ALL;   // rmclhip_rcc_set_outputs: which model buffers find / find_batch write
   // reduction
   DevBuf<double> d_partials;
   cstats* h_stats = nullptr;       // pinned, host-mapped
@@ -326,6 +340,11 @@ struct ChainTag {
     }
   }
 };
+
+// computeCrossStatistics and every correction read {hits, points, normals} of the operator's model buffers (Correspondences.hpp:81-85)
+inline bool micp_outputs_selected(const rmclhip_rcc* r) { return (r->out_mask & RMCLHIP_OUT_MICP) == RMCLHIP_OUT_MICP; }
+constexpr const char* kNeedMicpOutputs =
+    "the operator's {hits, points, normals} outputs are deselected (rmclhip_rcc_set_outputs): nothing to reduce";
 
 // whatever is about to rewrite the model buffers or the dataset: the published moments summarise the old ones
 static inline void drop_moment_set(rmclhip_rcc* r) {

@@ -32,6 +32,18 @@ rmclhip_status rmclhip_ctx_create(int device, rmclhip_ctx** out) {
 
 void rmclhip_ctx_destroy(rmclhip_ctx* ctx) { ctx_release(ctx); }
 
+// the scratch of rmclhip_statistics_p2l (capi_rcc.cpp) belongs to the context and goes with its last holder
+rmclhip_ctx::~rmclhip_ctx() {
+  if (p2l_stream == nullptr) return;
+  (void)hipSetDevice(device);
+  (void)hipStreamSynchronize(p2l_stream);
+  if (p2l_partials) (void)hipFree(p2l_partials);
+  if (p2l_tickets) (void)hipFree(p2l_tickets);
+  if (p2l_h_stats) (void)hipHostFree(p2l_h_stats);
+  if (p2l_h_done) (void)hipHostFree(p2l_h_done);
+  (void)hipStreamDestroy(p2l_stream);
+}
+
 rmclhip_status rmclhip_ctx_set_wait_mode(rmclhip_ctx* ctx, int mode) {
   ApiGuard guard_("rmclhip_ctx_set_wait_mode");
   if (!ctx || (mode != RMCLHIP_WAIT_SPIN && mode != RMCLHIP_WAIT_BLOCK)) return fail(RMCLHIP_ERR_INVALID, "ctx_set_wait_mode: bad arguments");

@@ -46,6 +46,11 @@ rmclhip_status rmclhip_pf_set_params(rmclhip_pf* f, const rmclhip_pf_params* p) 
   ApiGuard guard_("rmclhip_pf_set_params");
   if (!f || !p) return fail(RMCLHIP_ERR_INVALID, "pf_set_params: null");
   if (!(p->dist_sigma > 0.f)) return fail(RMCLHIP_ERR_INVALID, "pf_set_params: dist_sigma must be > 0");
+  // a NaN penalty would become a NaN beam error; the default (accumulating) update evaluates exp through fmaxf, which swallows NaN
+  // into a zero likelihood where the reference's exp(NaN) poisons the particle: refuse the parameter instead
+  if (p->real_hit_sim_miss_error != p->real_hit_sim_miss_error || p->real_miss_sim_hit_error != p->real_miss_sim_hit_error ||
+      p->real_miss_sim_miss_error != p->real_miss_sim_miss_error || p->dist_sigma != p->dist_sigma)
+    return fail(RMCLHIP_ERR_INVALID, "pf_set_params: NaN parameter");
   if (p->correspondence_type > 3u)
     return fail(RMCLHIP_ERR_INVALID, "pf_set_params: correspondence_type must be 0 (RCC), 1 (CPC), 2 (RCC, Embree rules) or 3 (RCC, OptiX rules)");
   f->params = *p;
@@ -111,7 +116,9 @@ static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, 
   uint32_t pb = (f->big_blocks ? 4096u : 2048u) / n_beams;
   if (pb < 1u) pb = 1u;
   if (pb > 64u) pb = 64u;
-  // the accumulation form keeps 384 B of accumulators per particle of the workgroup in LDS: at most 16 particles (few beams per particle
+  // the accumulation form keeps 384 B of accumulators per particle of the workgroup in LDS: at most 16 particles in the default
+  // (beam-minor) dealing; the particle-minor mapping below chooses its own count (32 or the caller's, <= 64: 24 KB of accumulators --
+  // results do not depend on it, the accumulators are order-independent) (few beams per particle
   // would otherwise put 64 of them, 23 KB, into a workgroup: 100 000 x 16 beams 0.189 -> 0.157 ms, x 32 0.338 -> 0.273, x 64 0.522 -> 0.485;
   // the stored form 0.169 / 0.295 / 0.491 -- tools/pf_shapes_ab.py, profiles/r05_pf_forms_ab.txt)
   if (f->accum && f->params.correspondence_type != 1u && pb > 16u) pb = 16u;

@@ -364,11 +364,12 @@ static uint32_t pick_tile_w_log2(uint32_t H, bool packet, float ang_aspect = 0.0
 
 RMCL_INTERNAL rmclhip_status ensure_model_buffers(rmclhip_rcc* r, size_t n_total) {
   drop_moment_set(r);   // every find form comes through here first
-  HIPCHK(r->d_hits.reserve(n_total));
-  HIPCHK(r->d_ranges.reserve(n_total));
-  HIPCHK(r->d_points.reserve(3 * n_total));
-  HIPCHK(r->d_normals.reserve(3 * n_total));
-  HIPCHK(r->d_face_ids.reserve(n_total));
+  // only what the selected bundle carries (rmclhip_rcc_set_outputs); a deselected buffer keeps what it has
+  if (r->out_mask & RMCLHIP_OUT_HITS) HIPCHK(r->d_hits.reserve(n_total));
+  if (r->out_mask & RMCLHIP_OUT_RANGES) HIPCHK(r->d_ranges.reserve(n_total));
+  if (r->out_mask & RMCLHIP_OUT_POINTS) HIPCHK(r->d_points.reserve(3 * n_total));
+  if (r->out_mask & RMCLHIP_OUT_NORMALS) HIPCHK(r->d_normals.reserve(3 * n_total));
+  if (r->out_mask & RMCLHIP_OUT_FACE_IDS) HIPCHK(r->d_face_ids.reserve(n_total));
   return RMCLHIP_OK;
 }
 
@@ -419,8 +420,12 @@ RMCL_INTERNAL void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t npos
   p.orig_s = r->orig;
   p.pin_f[0] = r->pin_fc[0]; p.pin_f[1] = r->pin_fc[1]; p.pin_c[0] = r->pin_fc[2]; p.pin_c[1] = r->pin_fc[3];
   p.nposes = nposes;
-  p.hits = r->d_hits.p; p.ranges = r->d_ranges.p; p.points = r->d_points.p; p.normals = r->d_normals.p;
-  p.face_ids = r->d_face_ids.p;
+  // bundle attribute selection (rmclhip_rcc_set_outputs): the kernel skips the stores of a null output
+  p.hits = (r->out_mask & RMCLHIP_OUT_HITS) ? r->d_hits.p : nullptr;
+  p.ranges = (r->out_mask & RMCLHIP_OUT_RANGES) ? r->d_ranges.p : nullptr;
+  p.points = (r->out_mask & RMCLHIP_OUT_POINTS) ? r->d_points.p : nullptr;
+  p.normals = (r->out_mask & RMCLHIP_OUT_NORMALS) ? r->d_normals.p : nullptr;
+  p.face_ids = (r->out_mask & RMCLHIP_OUT_FACE_IDS) ? r->d_face_ids.p : nullptr;
   p.tile_planes = (r->tile_planes_ok && (nposes == 1u ? r->tuned_frontier : r->tuned_batch_frontier)) ? r->d_tile_planes.p : nullptr;
   {
     // kind 24 (and its frontier-less twin 22: rays on the quantised nodes, triangles in a per-lane loop) walks the FILTER's tree --
@@ -483,7 +488,8 @@ RMCL_INTERNAL rmclhip_status find_enqueue(rmclhip_rcc* r, const xform& Tbm, bool
     r->ccs_loop = r->ccs_since_find != 0u;
     r->ccs_since_find = 0u; r->ccs_max_rho = 0.f; r->ccs_max_tau = 0.f;
     const int fv = find_variant(r, 1);
-    if (r->ccs_loop && r->fast_mode == 1 && !r->fused_tail && r->n_dataset != 0u && (fv == 23 || fv == 2) && r->ccs_last_maxd == r->ccs_last_maxd) {
+    if (r->ccs_loop && r->fast_mode == 1 && !r->fused_tail && r->n_dataset != 0u && (fv == 23 || fv == 2) && r->ccs_last_maxd == r->ccs_last_maxd &&
+        micp_outputs_selected(r)) {
       gate_band(r, r->ccs_last_maxd, &r->pend_lo, &r->pend_hi);
       r->pend_rho = r->fast_rho_cap; r->pend_tau = r->fast_tau_cap;
       r->mset_seq = next_seq(r);
@@ -666,8 +672,10 @@ rmclhip_status rmclhip_rcc_find_cpc(rmclhip_rcc* r, const rmclhip_transform* Tbm
   const NearGrid* grid = nullptr;
   if (r->cpc_grid) { if (rmclhip_status gst = ensure_near_grid(r->map, r->stream, false, &grid)) return gst; }
   HIPCHK(launch_cpc_find(quad ? r->map->d_cnodes : r->map->d_nodes, r->map->d_tris, r->ds_pts, r->n_dataset,
-                         r->max_dist, Tsm, xinv(Tsm), r->d_hits.p, r->d_ranges.p, r->d_points.p, r->d_normals.p,
-                         r->d_face_ids.p, quad, r->stream, seed, r->cpc_tracking ? r->d_cpc_rec.p : nullptr, r->map->info.n_faces,
+                         r->max_dist, Tsm, xinv(Tsm), (r->out_mask & RMCLHIP_OUT_HITS) ? r->d_hits.p : nullptr,
+                         (r->out_mask & RMCLHIP_OUT_RANGES) ? r->d_ranges.p : nullptr, (r->out_mask & RMCLHIP_OUT_POINTS) ? r->d_points.p : nullptr,
+                         (r->out_mask & RMCLHIP_OUT_NORMALS) ? r->d_normals.p : nullptr,
+                         (r->out_mask & RMCLHIP_OUT_FACE_IDS) ? r->d_face_ids.p : nullptr, quad, r->stream, seed, r->cpc_tracking ? r->d_cpc_rec.p : nullptr, r->map->info.n_faces,
                          cpc_bound_d2(r), grid));
   if (r->cpc_tracking) { r->cpc_rec_n = r->n_dataset; r->cpc_rec_pts = r->ds_pts; }
   HIPCHK(wait_chain_end(r));
@@ -707,6 +715,7 @@ rmclhip_status rmclhip_rcc_sync(rmclhip_rcc* r) {
 
 RMCL_INTERNAL rmclhip_status reduce_enqueue(rmclhip_rcc* r, const xform& Tpre, const xform* Tpre_dev, float max_dist,
                                      uint32_t nposes, const ReduceTail& tail) {
+  if (!micp_outputs_selected(r)) return fail(RMCLHIP_ERR_INVALID, kNeedMicpOutputs);
   const uint32_t n = (r->n_dataset < r->n_model) ? r->n_dataset : r->n_model;
   if (n == 0) return fail(RMCLHIP_ERR_INVALID, "computeCrossStatistics: empty dataset or model (call find first)");
   if (r->n_model != n && nposes > 1) return fail(RMCLHIP_ERR_INVALID, "batch reduction needs dataset size == model size");
@@ -938,6 +947,7 @@ rmclhip_status rmclhip_rcc_compute_cross_statistics(rmclhip_rcc* r, const rmclhi
   if (!r || !T_snew_sold || !out) return fail(RMCLHIP_ERR_INVALID, "computeCrossStatistics: null");
   HIPCHK(hipSetDevice(r->ctx->device));
   if (r->nposes_last != 1) return fail(RMCLHIP_ERR_INVALID, "computeCrossStatistics: last find was a batch");
+  if (!micp_outputs_selected(r)) return fail(RMCLHIP_ERR_INVALID, kNeedMicpOutputs);
   // ---- from the moments of this find's correspondences, when a set covers (pre-transform, max_dist'): no launch, no wait.
   // The reference's caller (micp_localization.cpp:915-964) calls this once per sensor and iteration on FIXED correspondences.
   {
@@ -1009,6 +1019,10 @@ rmclhip_status rmclhip_rcc_download(rmclhip_rcc* r, uint8_t* hits, float* ranges
   HIPCHK(hipStreamSynchronize(r->stream));
   const size_t n = static_cast<size_t>(r->n_model) * (r->nposes_last ? r->nposes_last : 1);
   if (n == 0) return RMCLHIP_OK;
+  // an attribute that no find of this size has written yet (deselected all along: rmclhip_rcc_set_outputs) has nothing to hand out
+  if ((hits && r->d_hits.cap < n) || (ranges && r->d_ranges.cap < n) || (points && r->d_points.cap < 3 * n) ||
+      (normals && r->d_normals.cap < 3 * n) || (face_ids && r->d_face_ids.cap < n))
+    return fail(RMCLHIP_ERR_INVALID, "rcc_download: a requested attribute was never selected for a find of this size (rmclhip_rcc_set_outputs)");
   if (hits) HIPCHK(hipMemcpy(hits, r->d_hits.p, n, hipMemcpyDeviceToHost));
   if (ranges) HIPCHK(hipMemcpy(ranges, r->d_ranges.p, n * sizeof(float), hipMemcpyDeviceToHost));
   if (points) HIPCHK(hipMemcpy(points, r->d_points.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
@@ -1022,12 +1036,151 @@ rmclhip_status rmclhip_rcc_device_views(rmclhip_rcc* r, const uint8_t** hits, co
                                         uint32_t* n) {
   ApiGuard guard_("rmclhip_rcc_device_views");
   if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_device_views: null");
-  if (hits) *hits = r->d_hits.p;
-  if (ranges) *ranges = r->d_ranges.p;
-  if (points) *points = r->d_points.p;
-  if (normals) *normals = r->d_normals.p;
-  if (face_ids) *face_ids = r->d_face_ids.p;
-  if (n) *n = r->n_model * (r->nposes_last ? r->nposes_last : 1);
+  // (a buffer too small for the last find belongs to an attribute no find of that size selected: no view of it)
+  const size_t nt = static_cast<size_t>(r->n_model) * (r->nposes_last ? r->nposes_last : 1);
+  if (hits) *hits = (r->d_hits.cap >= nt) ? r->d_hits.p : nullptr;
+  if (ranges) *ranges = (r->d_ranges.cap >= nt) ? r->d_ranges.p : nullptr;
+  if (points) *points = (r->d_points.cap >= 3 * nt) ? r->d_points.p : nullptr;
+  if (normals) *normals = (r->d_normals.cap >= 3 * nt) ? r->d_normals.p : nullptr;
+  if (face_ids) *face_ids = (r->d_face_ids.cap >= nt) ? r->d_face_ids.p : nullptr;
+  if (n) *n = static_cast<uint32_t>(nt);
+  return RMCLHIP_OK;
+}
+
+// ---- the rmagine-level Simulator interface (rmclhip.h) ----------------------------------------------------------------------
+rmclhip_status rmclhip_rcc_set_outputs(rmclhip_rcc* r, uint32_t mask) {
+  ApiGuard guard_("rmclhip_rcc_set_outputs");
+  if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_set_outputs: null");
+  if (mask == 0u || (mask & ~RMCLHIP_OUT_ALL) != 0u) return fail(RMCLHIP_ERR_INVALID, "rcc_set_outputs: mask must name at least one of the five attributes and nothing else");
+  if (mask != r->out_mask) {
+    r->out_mask = mask;
+    drop_moment_set(r);   // (the set summarises buffers the next find may no longer write)
+    r->graph_dirty = true; r->fast_graph_dirty = true;   // the captured chains hold the find's output pointers by value
+  }
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_get_outputs(const rmclhip_rcc* r, uint32_t* mask) {
+  if (!r || !mask) return fail(RMCLHIP_ERR_INVALID, "rcc_get_outputs: null");
+  *mask = r->out_mask;
+  return RMCLHIP_OK;
+}
+
+// Simulator::simulate into the caller's bundle: the find kernel with the caller's pointers as its outputs.  One pose from the host goes by
+// value (no copy, no compose launch: what rmclhip_rcc_find does); batches and device-resident poses are composed with Tsb on the device.
+static rmclhip_status simulate_enqueue(rmclhip_rcc* r, const rmclhip_transform* Tbm, uint32_t nposes, int Tbm_is_device,
+                                       const rmclhip_bundle_views* out) {
+  if (nposes > 32768) return fail(RMCLHIP_ERR_UNSUPPORTED, "simulate: at most 32768 poses per call");
+  FindParams p;
+  fill_find_params(r, p, nposes);
+  p.hits = out->hits_dev; p.ranges = out->ranges_dev; p.points = out->points_xyz_dev; p.normals = out->normals_xyz_dev;
+  p.face_ids = out->face_ids_dev;
+  if (nposes == 1u && !Tbm_is_device) {
+    p.Tsm = xmul(to_x(Tbm), r->Tsb);
+    p.Tms = xinv(p.Tsm);
+  } else {
+    HIPCHK(r->d_Tsm.reserve(nposes)); HIPCHK(r->d_Tms.reserve(nposes));
+    const xform* src = reinterpret_cast<const xform*>(Tbm);
+    if (!Tbm_is_device) {
+      HIPCHK(r->d_Tbm.reserve(nposes));
+      // (pageable source: the copy has staged the caller's poses when it returns; the stream orders the launches behind the DMA)
+      HIPCHK(hipMemcpyAsync(r->d_Tbm.p, Tbm, sizeof(xform) * nposes, hipMemcpyHostToDevice, r->stream));
+      src = r->d_Tbm.p;
+    }
+    HIPCHK(launch_compose_poses(src, r->Tsb, r->d_Tsm.p, r->d_Tms.p, nposes, r->stream));
+    p.Tsm_arr = r->d_Tsm.p;
+    p.Tms_arr = r->d_Tms.p;
+  }
+  HIPCHK(launch_find(p, r->kind, find_variant(r, nposes), r->stream));
+  return RMCLHIP_OK;
+}
+
+static rmclhip_status simulate_check(const char* who, rmclhip_rcc* r, const rmclhip_transform* Tbm, uint32_t nposes,
+                                     const rmclhip_bundle_views* out, bool* nothing_to_do) {
+  *nothing_to_do = false;
+  if (!r || !out || (!Tbm && nposes)) return fail(RMCLHIP_ERR_INVALID, std::string(who) + ": null");
+  if (nposes == 0 || r->kind == kModelNone || r->W == 0 || r->H == 0) { *nothing_to_do = true; return RMCLHIP_OK; }
+  if (!out->hits_dev && !out->ranges_dev && !out->points_xyz_dev && !out->normals_xyz_dev && !out->face_ids_dev)
+    return fail(RMCLHIP_ERR_INVALID, std::string(who) + ": the bundle carries no attribute");
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_simulate_async(rmclhip_rcc* r, const rmclhip_transform* Tbm, uint32_t nposes, int Tbm_is_device,
+                                          const rmclhip_bundle_views* out) {
+  ApiGuard guard_("rmclhip_rcc_simulate_async");
+  bool nothing = false;
+  if (rmclhip_status st = simulate_check("simulate_async", r, Tbm, nposes, out, &nothing)) return st;
+  if (nothing) return RMCLHIP_OK;
+  HIPCHK(hipSetDevice(r->ctx->device));
+  return simulate_enqueue(r, Tbm, nposes, Tbm_is_device, out);
+}
+
+rmclhip_status rmclhip_rcc_simulate(rmclhip_rcc* r, const rmclhip_transform* Tbm, uint32_t nposes, int Tbm_is_device,
+                                    const rmclhip_bundle_views* out) {
+  ApiGuard guard_("rmclhip_rcc_simulate");
+  bool nothing = false;
+  if (rmclhip_status st = simulate_check("simulate", r, Tbm, nposes, out, &nothing)) return st;
+  if (nothing) return RMCLHIP_OK;
+  HIPCHK(hipSetDevice(r->ctx->device));
+  if (rmclhip_status st = simulate_enqueue(r, Tbm, nposes, Tbm_is_device, out)) return st;
+  HIPCHK(wait_chain_end(r));
+  return RMCLHIP_OK;
+}
+
+// rm::statistics_p2l on caller-owned device views: the operator's streaming reduction with the context's own scratch
+rmclhip_status rmclhip_statistics_p2l(rmclhip_ctx* ctx, const rmclhip_transform* Tpre, const float* dataset_points,
+                                      const uint8_t* dataset_mask, const float* model_points, const float* model_normals,
+                                      const uint8_t* model_mask, uint32_t n, float max_dist, rmclhip_cross_statistics* out) {
+  ApiGuard guard_("rmclhip_statistics_p2l");
+  if (!ctx || !Tpre || !out) return fail(RMCLHIP_ERR_INVALID, "statistics_p2l: null");
+  if (n == 0) { from_cs(cs_identity(), out); return RMCLHIP_OK; }   // CrossStatistics::Identity(): nothing measured
+  if (!dataset_points || !model_points || !model_normals) return fail(RMCLHIP_ERR_INVALID, "statistics_p2l: null view");
+  std::lock_guard<std::mutex> lock(ctx->p2l_mtx);
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->p2l_stream == nullptr) {
+    hipStream_t s = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&ctx->p2l_h_stats), sizeof(cstats), hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->p2l_h_stats_dev), ctx->p2l_h_stats, 0);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&ctx->p2l_h_done), sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->p2l_h_done_dev), ctx->p2l_h_done, 0);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->p2l_tickets), sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(ctx->p2l_tickets, 0, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+      if (ctx->p2l_h_stats) (void)hipHostFree(ctx->p2l_h_stats);
+      if (ctx->p2l_h_done) (void)hipHostFree(ctx->p2l_h_done);
+      if (ctx->p2l_tickets) (void)hipFree(ctx->p2l_tickets);
+      ctx->p2l_h_stats = nullptr; ctx->p2l_h_done = nullptr; ctx->p2l_tickets = nullptr;
+      (void)hipStreamDestroy(s);
+      return fail(RMCLHIP_ERR_HIP, std::string("statistics_p2l: ") + hipGetErrorString(e));
+    }
+    *ctx->p2l_h_done = 0ull;
+    ctx->p2l_stream = s;   // last: the destructor frees the scratch iff the stream exists
+  }
+  const uint32_t nb = reduce_num_blocks(n, 1);
+  if (ctx->p2l_partials_cap < static_cast<size_t>(nb) * 16u) {
+    if (ctx->p2l_partials) (void)hipFree(ctx->p2l_partials);
+    ctx->p2l_partials = nullptr; ctx->p2l_partials_cap = 0;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&ctx->p2l_partials), static_cast<size_t>(nb) * 16u * sizeof(double)));
+    ctx->p2l_partials_cap = static_cast<size_t>(nb) * 16u;
+  }
+  ReduceParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.dataset_points = dataset_points; p.dataset_mask = dataset_mask;
+  p.model_points = model_points; p.model_normals = model_normals; p.model_mask = model_mask;
+  p.n = n; p.nposes = 1; p.max_dist = max_dist;
+  p.Tpre = to_x(Tpre);
+  p.partials = ctx->p2l_partials; p.nblocks = nb;
+  p.tickets = ctx->p2l_tickets;
+  p.Tsb = xidentity(); p.Tbo = xidentity();
+  p.tail_mode = static_cast<uint32_t>(kTailNone);
+  if (++ctx->p2l_seq == 0u) ctx->p2l_seq = 1u;
+  HIPCHK(launch_reduce_partials(p, ctx->p2l_stream));
+  HIPCHK(launch_reduce_finalize(ctx->p2l_partials, nb, 1, ctx->p2l_h_stats_dev, ctx->p2l_h_done_dev, ctx->p2l_seq, ctx->p2l_stream));
+  DoneCheck chk; chk.base = ctx->p2l_h_stats; chk.base_bytes = sizeof(cstats);
+  HIPCHK(wait_done(ctx, ctx->p2l_h_done, ctx->p2l_seq, chk, ctx->p2l_stream));
+  from_cs(*ctx->p2l_h_stats, out);
   return RMCLHIP_OK;
 }
 
@@ -1037,6 +1190,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
   ApiGuard guard_("rmclhip_rcc_correct_once");
   if (!r || !Tom_ || !Tbo_ || !T_out) return fail(RMCLHIP_ERR_INVALID, "correct_once: null");
   if (r->kind == kModelNone || r->W == 0 || r->H == 0) return fail(RMCLHIP_ERR_INVALID, "correct_once: no sensor model");
+  if (!micp_outputs_selected(r)) return fail(RMCLHIP_ERR_INVALID, kNeedMicpOutputs);
   HIPCHK(hipSetDevice(r->ctx->device));
   const xform Tom = to_x(Tom_), Tbo = to_x(Tbo_);
   const float maxd = adaptive_max_dist(r, convergence_progress);
@@ -1397,6 +1551,7 @@ rmclhip_status rmclhip_micp_correct_once(rmclhip_rcc* const* sensors, uint32_t n
     if (r->ctx->device != r0->ctx->device) return fail(RMCLHIP_ERR_INVALID, "micp_correct_once: sensors live on different devices");
     if (r->kind == kModelNone || r->W == 0 || r->H == 0) return fail(RMCLHIP_ERR_INVALID, "micp_correct_once: sensor without a model");
     if (r->n_dataset == 0) return fail(RMCLHIP_ERR_INVALID, "micp_correct_once: sensor without a dataset");
+    if (!micp_outputs_selected(r)) return fail(RMCLHIP_ERR_INVALID, kNeedMicpOutputs);
   }
   HIPCHK(hipSetDevice(r0->ctx->device));
   hipStream_t st = r0->stream;
@@ -1679,6 +1834,7 @@ rmclhip_status rmclhip_rcc_correct_batch(rmclhip_rcc* r, const rmclhip_transform
   if (nposes == 0) return RMCLHIP_OK;
   if (r->kind == kModelNone || r->W == 0 || r->H == 0) return fail(RMCLHIP_ERR_INVALID, "correct_batch: no sensor model");
   if (nposes > 32768) return fail(RMCLHIP_ERR_UNSUPPORTED, "correct_batch: at most 32768 poses per call");
+  if (!micp_outputs_selected(r)) return fail(RMCLHIP_ERR_INVALID, kNeedMicpOutputs);
   HIPCHK(hipSetDevice(r->ctx->device));
   const size_t n = static_cast<size_t>(r->W) * r->H;
   if (r->n_dataset != n) return fail(RMCLHIP_ERR_INVALID, "correct_batch: dataset size != model size");

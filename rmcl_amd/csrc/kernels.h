@@ -75,7 +75,7 @@ struct ReduceParams {
   const uint8_t* dataset_mask;   // nullable
   const float* model_points;
   const float* model_normals;
-  const uint8_t* model_mask;
+  const uint8_t* model_mask;     // nullable (k_reduce_partials only: a caller-owned view without a mask)
   uint32_t n;                    // elements per pose
   uint32_t nposes;               // model buffers hold nposes*n elements; dataset is shared
   float max_dist;

@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const ReduceParams p) {
   const size_t mbase = static_cast<size_t>(pose) * p.n;
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < p.n; i += gridDim.x * 256u) {
     const bool dok = (p.dataset_mask == nullptr) || (p.dataset_mask[i] > 0);
-    if (dok && p.model_mask[mbase + i] > 0) {
+    if (dok && (p.model_mask == nullptr || p.model_mask[mbase + i] > 0)) {   // (null: rmclhip_statistics_p2l on a view without a mask)
       const float* dp = p.dataset_points + 3 * static_cast<size_t>(i);
       const float* mp = p.model_points + 3 * (mbase + i);
       const float* mn = p.model_normals + 3 * (mbase + i);
@@ -1514,12 +1514,16 @@ __device__ __forceinline__ void leaf_pair(const uint32_t* __restrict__ tris, uin
 // the accumulators are FIXED-POINT -- per quantity a row of 64-bit integers, one per 16 binades ("bin"), a term t = m 2^e going to
 // bin (e - e_min) / 16 as m shifted so that the bin's top is 2^48 units: integer adds commute, a term keeps >= 32 significant bits
 // (the eval is a float: 24), 2^16 terms fit.  Final value = the bins added in ascending order in double.
-// Differences to the sequential float chain: ~1e-7 relative (its own rounding); sigma = S - mean^2 in double resolves a variance
-// down to 1e-16 of mean^2.  n_meas is the closed form as before, bit-exact.
+// Differences to the sequential float chain: ~1e-7 relative (its own rounding).  sigma = max(S - mean^2, 0): every term keeps >= 32
+// significant bits (rounded to nearest into its bin, so the error has no sign), hence S and mean^2 each carry ~2^-33 relative and a
+// variance below ~1e-10 mean^2 is noise of either sign -- clamped at 0, which is what the reference's chain of non-negative terms
+// (P1 + P2 >= 0 in Gaussian1D::operator+=) can reach at the least (the unclamped difference went negative for particles
+// whose beams all evaluate alike, and a downstream sqrt(sigma) would have been NaN).  n_meas is the closed form as before, bit-exact.
 // ---------------------------------------------------------------------------------------------
 // exp(arg) * inv_den for arg <= 0 in float arithmetic: arg log2(e) split Cody-Waite style into an integer n and a residual r in
 // [-0.5, 0.5] (one fused multiply-add against each half of log2 e: |error of r| ~ 1e-8), 2^r by v_exp_f32 (1 ulp), the scale before
-// the exponent so that results below 2^-126 round like any other denormal.  NaN in, NaN out; below 2^-149 the result is 0.
+// the exponent so that results below 2^-126 round like any other denormal.  Below 2^-149 the result is 0.  A NaN argument gives 0, not
+// NaN (fmaxf is maxnum): it can only come from NaN penalty parameters, which rmclhip_pf_set_params rejects.
 __device__ __forceinline__ float pf_eval_fast(float arg, float inv_den) {
   const float kL2eHi = 1.44269502162933349609375f, kL2eLo = 1.925963033500011e-08f;
   const float n = fmaxf(rintf(arg * kL2eHi), -400.0f);
@@ -1541,7 +1545,7 @@ __device__ __forceinline__ bool acc_add(unsigned long long* row, int nbins, int 
   if (j >= nbins) return false;
   const int shift = 4 + (e_min + 16 * (j + 1) - e);               // 5..20: the bin's top 2^E is 2^48 units
   const unsigned long long mant = (b & 0xFFFFFFFFFFFFFull) | (1ull << 52);
-  atomicAdd(row + j, mant >> shift);
+  atomicAdd(row + j, (mant + (1ull << (shift - 1))) >> shift);   // round to nearest: truncation biased every sum downwards
   return true;
 }
 __device__ __forceinline__ double acc_value(const unsigned long long* row, int nbins, int e_min) {
@@ -1775,7 +1779,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kAccum
       const double S = p0w * (static_cast<double>(L.sigma) + m0 * m0) + acc_value(row + kAccBins1, kAccBins2, kAccEmin2);
       const bool bad = s_bad[threadIdx.x] != 0u;
       L.mean = bad ? __uint_as_float(0x7FC00000u) : static_cast<float>(mean);
-      L.sigma = bad ? __uint_as_float(0x7FC00000u) : static_cast<float>(S - mean * mean);
+      L.sigma = bad ? __uint_as_float(0x7FC00000u) : static_cast<float>(fmax(S - mean * mean, 0.0));   // never negative: see above
     }
   } else if (!evals_global) {
   // dense pass: error -> likelihood (PCDSensorUpdaterEmbree.cpp:224: float argument, double exp / sqrt, float result)

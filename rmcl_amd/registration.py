@@ -248,6 +248,25 @@ def build_bvh_host_quantised(vertices, faces, n_nodes):
     return q
 
 
+# the five bundle attributes in the C ABI's argument order (rmclhip_rcc_download, rmclhip_bundle_views)
+_ATTRS = ("hits", "ranges", "points", "normals", "face_ids")
+_ATTR_BIT = dict(hits=_capi.OUT_HITS, ranges=_capi.OUT_RANGES, points=_capi.OUT_POINTS, normals=_capi.OUT_NORMALS, face_ids=_capi.OUT_FACE_IDS)
+_ATTR_DTYPE = dict(hits=np.uint8, ranges=np.float32, points=np.float32, normals=np.float32, face_ids=np.uint32)
+_ATTR_SHAPE = dict(hits=(), ranges=(), points=(3,), normals=(3,), face_ids=())
+
+
+def statistics_p2l(ctx, Tpre, dataset_points, dataset_mask, model_points, model_normals, model_mask, n, max_dist):
+    """rm::statistics_p2l(Tpre, dataset, model, params) as a free function on caller-owned DEVICE views
+    (CorrespondencesCUDA.cpp:28): DeviceArrays / torch tensors / raw device pointers; either mask may be None.
+    Returns CrossStatistics by value on the host."""
+    T = np.ascontiguousarray(Tpre, dtype=TRANSFORM).reshape(1)
+    out = np.zeros(1, dtype=CROSS_STATISTICS)
+    _capi.check(_capi.lib().rmclhip_statistics_p2l(ctx.handle, _ptr(T), _as_ptr(dataset_points), _as_ptr(dataset_mask),
+                                                   _as_ptr(model_points), _as_ptr(model_normals), _as_ptr(model_mask), int(n),
+                                                   float(max_dist), _ptr(out)))
+    return out[0].copy()
+
+
 class UmeyamaReductionConstraints:
     """rmagine::UmeyamaReductionConstraints (only max_dist is used, micp_localization.cpp:525-526)."""
 
@@ -295,17 +314,68 @@ class CorrespondencesHIP:
                                                                      _ptr(out)))
         return out[0].copy()
 
-    def modelView(self):
-        """host copy of {points, mask(hits), normals} (+ ranges, face_ids) of the last find"""
+    def modelView(self, attributes=None):
+        """host copy of {points, mask(hits), normals} (+ ranges, face_ids) of the last find; `attributes`: a subset of the five names
+        to read back (default: the ones set_outputs() selected -- all five unless it was called)"""
         H, W = self._model_shape
         n = H * W * self._last_nposes
-        out = dict(hits=np.zeros(n, np.uint8), ranges=np.zeros(n, np.float32), points=np.zeros((n, 3), np.float32),
-                   normals=np.zeros((n, 3), np.float32), face_ids=np.zeros(n, np.uint32))
+        names = _ATTRS if attributes is None else tuple(attributes)
+        if attributes is None:
+            sel = self.outputs()
+            names = tuple(a for a in _ATTRS if sel & _ATTR_BIT[a])
+        out = {a: np.zeros((n,) + _ATTR_SHAPE[a], _ATTR_DTYPE[a]) for a in names}
         if n:
-            _capi.check(_capi.lib().rmclhip_rcc_download(self._h, _ptr(out["hits"]), _ptr(out["ranges"]),
-                                                         _ptr(out["points"]), _ptr(out["normals"]),
-                                                         _ptr(out["face_ids"])))
-        out["mask"] = out["hits"]
+            _capi.check(_capi.lib().rmclhip_rcc_download(self._h, *[_ptr(out[a]) if a in out else None for a in _ATTRS]))
+        if "hits" in out:
+            out["mask"] = out["hits"]
+        return out
+
+    # -- the rmagine-level Simulator interface (RCCEmbree.hpp:18-22: the RCC classes are simulators by protected inheritance) --------
+    def set_outputs(self, mask):
+        """bundle attribute selection of find / find_batch: an OR of _capi.OUT_* (rmclhip_rcc_set_outputs); a string list works too"""
+        if not isinstance(mask, int):
+            mask = sum(_ATTR_BIT[a] for a in mask)
+        _capi.check(_capi.lib().rmclhip_rcc_set_outputs(self._h, int(mask)))
+
+    def outputs(self):
+        m = C.c_uint32(0)
+        _capi.check(_capi.lib().rmclhip_rcc_get_outputs(self._h, C.byref(m)))
+        return m.value
+
+    def simulate(self, Tbm, attributes=("ranges",), into=None, poses_dev=None):
+        """rm::Simulator::simulate(Tbm, Bundle&) / simulate<Bundle>(Tbm) / the batch form with an array of poses
+        (scan_map_segmentation_embree.cpp:87, lidar_corrector_embree_benchmark.cpp:117): only the named attributes are written.
+        into: {attribute: DeviceArray / torch tensor} of caller-owned device memory (the bundle); None: a fresh bundle of DeviceArrays
+        is allocated.  poses_dev: device memory holding the poses instead of `Tbm` (lidar_corrector_optix_benchmark.cpp:119), `Tbm` is
+        then the pose count.  Returns the bundle (dict of device buffers); `download_bundle` brings it to the host.  The operator's own
+        model buffers and cached statistics are not touched."""
+        H, W = self._model_shape
+        if poses_dev is not None:
+            nposes, tptr, on_dev = int(Tbm), _as_ptr(poses_dev), 1
+        else:
+            T = np.ascontiguousarray(Tbm, dtype=TRANSFORM).reshape(-1)
+            nposes, tptr, on_dev = len(T), _ptr(T), 0
+        n = H * W * nposes
+        bundle = {} if into is None else dict(into)
+        for a in attributes:
+            if a not in _ATTRS:
+                raise ValueError("unknown bundle attribute %r" % (a,))
+            if a not in bundle:
+                bundle[a] = DeviceArray(self.ctx, _ATTR_DTYPE[a], max(n, 1) * (3 if _ATTR_SHAPE[a] else 1))
+        v = _capi.BundleViews()
+        for a, field in zip(_ATTRS, ("hits_dev", "ranges_dev", "points_xyz_dev", "normals_xyz_dev", "face_ids_dev")):
+            if a in bundle:
+                setattr(v, field, _as_ptr(bundle[a]))
+        _capi.check(_capi.lib().rmclhip_rcc_simulate(self._h, tptr, nposes, on_dev, C.byref(v)))
+        return bundle
+
+    @staticmethod
+    def download_bundle(bundle):
+        """host copies of a simulate() bundle of DeviceArrays: {attribute: ndarray} with points / normals as (n, 3)"""
+        out = {}
+        for a, d in bundle.items():
+            h = d.download()
+            out[a] = h.reshape(-1, 3) if _ATTR_SHAPE[a] else h
         return out
 
     # -- dataset ------------------------------------------------------------------------------
@@ -411,15 +481,19 @@ class CorrespondencesHIP:
 
     def find_async_fn(self, Tbm_est):
         """find_async(Tbm_est) as a zero-argument callable with the argument conversion done ONCE (a loop of identical finds then pays
-        one ctypes call per step: bench.py's timed region)"""
+        one ctypes call per step: bench.py's timed region).  The callable keeps this operator alive and reads its handle on every
+        call: after close() it raises instead of handing a freed handle to the library."""
         T = np.ascontiguousarray(Tbm_est, dtype=TRANSFORM).reshape(1).copy()
-        fn, h, ptr, check = _capi.lib().rmclhip_rcc_find_async, self._h, _ptr(T), _capi.check
+        fn, ptr, check, owner = _capi.lib().rmclhip_rcc_find_async, _ptr(T), _capi.check, self
 
         def call(_keep=T):
+            h = owner._h
+            if not h:
+                raise RuntimeError("find_async_fn: the operator was closed")
             rc = fn(h, ptr)
             if rc:
                 check(rc)
-        self._last_nposes = 1
+            owner._last_nposes = 1
         return call
 
     def sync(self):

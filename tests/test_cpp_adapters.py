@@ -12,20 +12,53 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(tmp_path):
-    exe = str(tmp_path / "micp_example")
+def _build(tmp_path, source="micp_cpp_example.cpp"):
+    exe = str(tmp_path / source.replace(".cpp", ""))
     libdir = os.path.join(ROOT, "rmcl_amd")
     cmd = ["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "examples", "micp_cpp_example.cpp"), "-L" + libdir, "-lrmclhip",
+           os.path.join(ROOT, "examples", source), "-L" + libdir, "-lrmclhip",
            "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
     subprocess.check_call(cmd)
     return exe
 
 
-def test_adapters_compile_and_link_without_gpu(ra, tmp_path):
-    exe = _build(tmp_path)
+@pytest.mark.parametrize("source", ["micp_cpp_example.cpp", "simulator_cpp_example.cpp"])
+def test_adapters_compile_and_link_without_gpu(ra, tmp_path, source):
+    exe = _build(tmp_path, source)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr
+
+
+def test_rcc_classes_have_the_reference_shape(tmp_path):
+    """RCCEmbree.hpp:18-22: `class RCCEmbreeSpherical : public CorrespondencesCPU, public ModelSetter<SphericalModel>, protected
+    SphereSimulatorEmbree` -- checked at compile time: public operator + ModelSetter bases (the node discovers the latter with a
+    dynamic_pointer_cast, MICPSphericalSensorCPU.cpp:155-160), the simulator base NOT reachable from outside, reachable from a subclass;
+    Bundle carries exactly the attributes it names."""
+    src = tmp_path / "shape.cpp"
+    src.write_text(r'''
+#include <type_traits>
+#include "rmcl_hip/rmcl_hip.hpp"
+using namespace rmcl_hip;
+template <typename T, typename = void> struct can_simulate : std::false_type {};
+template <typename T>
+struct can_simulate<T, std::void_t<decltype(std::declval<T&>().template simulate<Bundle<Ranges<RAM>>>(std::declval<const Transform&>()))>> : std::true_type {};
+struct Opened : RCCHipSpherical { using RCCHipSpherical::RCCHipSpherical; using SimulatorHip<SphericalModel>::simulate; };
+static_assert(std::is_base_of<CorrespondencesHIP, RCCHipSpherical>::value && std::is_convertible<RCCHipSpherical*, CorrespondencesHIP*>::value, "");
+static_assert(std::is_convertible<RCCHipSpherical*, ModelSetter<SphericalModel>*>::value, "");
+static_assert(std::is_convertible<RCCHipO1Dn*, ModelSetter<O1DnModel>*>::value && std::is_convertible<RCCHipPinhole*, ModelSetter<PinholeModel>*>::value &&
+              std::is_convertible<RCCHipOnDn*, ModelSetter<OnDnModel>*>::value, "");
+static_assert(std::is_base_of<SphereSimulatorHip, RCCHipSpherical>::value && !std::is_convertible<RCCHipSpherical*, SphereSimulatorHip*>::value,
+              "the simulator is a PROTECTED base");
+static_assert(std::is_base_of<O1DnSimulatorHip, RCCHipO1Dn>::value && !std::is_convertible<RCCHipO1Dn*, O1DnSimulatorHip*>::value, "");
+static_assert(can_simulate<SphereSimulatorHip>::value && !can_simulate<RCCHipSpherical>::value && can_simulate<Opened>::value, "");
+using B = Bundle<Ranges<RAM>, Normals<VRAM_HIP>>;
+static_assert(detail::has_attr<Ranges, B>() && detail::has_attr<Normals, B>() && !detail::has_attr<Hits, B>() && !detail::has_attr<Points, B>() &&
+              !detail::has_attr<FaceIds, B>(), "");
+static_assert(std::is_same<decltype(B::ranges), Memory<float, RAM>>::value && std::is_same<decltype(B::normals), Memory<Vector, VRAM_HIP>>::value, "");
+static_assert(sizeof(SphericalModel) == 32 && sizeof(Transform) == 32 && sizeof(CrossStatistics) == 64, "");
+int main() { return 0; }
+''')
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), str(src)])
 
 
 def test_c_header_is_plain_c(tmp_path):
@@ -164,3 +197,92 @@ def test_cpp_example_matches_python_and_oracle(ra, orc, ctx, meshes, tmp_path):
     _, anr, filled, draws = orc.residual_resample(poses, attrs, orc.gladiator_config(trans_dist_metric=1), seed=42, step=0, n_new=12)
     assert [int(out["residual"][0]), int(out["residual"][1])] == [filled, draws] == [12, draws]
     assert abs(float(out["residual"][2]) - float(anr["likelihood"]["mean"].astype(np.float64).sum())) < 1e-5
+
+
+@pytest.mark.gpu
+def test_simulator_example_matches_oracle(ra, orc, ctx, meshes, tmp_path):
+    """examples/simulator_cpp_example.cpp: the segmentation node's body (scan_map_segmentation_embree.cpp:76-185) on SphereSimulatorHip,
+    the v1 benchmarks' batch simulate on host and device poses, CorrespondencesCUDA::computeCrossStatistics written out with the free
+    statistics_p2l -- every printed figure against the oracle"""
+    import math
+    from rmcl_amd import synthetic as syn, types as T
+    exe = _build(tmp_path, "simulator_cpp_example.cpp")
+    v, f = meshes("cube")
+    mesh_bin = tmp_path / "mesh.bin"
+    with open(mesh_bin, "wb") as fh:
+        fh.write(struct.pack("<II", len(v), len(f)))
+        fh.write(np.ascontiguousarray(v, np.float32).tobytes())
+        fh.write(np.ascontiguousarray(f, np.uint32).tobytes())
+    m = orc.Mesh(v, f)
+    model = syn.model_c1()
+    T_sensor_map = T.transform_from_rpy((0.5, -0.3, 0.2), (0.02, -0.03, 0.4))
+    # the "real" scan: the map seen from that pose, with an obstacle (a block of beams 40 % shorter), a hole in the map (a block 1.5 m
+    # longer), a block of invalid returns and a few beams beyond the range
+    sim0 = m.simulate_spherical(model, T.identity(), T_sensor_map, bvh=False)
+    real = sim0["ranges"].copy().reshape(32, 32)
+    real[4:9, 3:12] *= np.float32(0.6)
+    real[20:24, 16:25] += np.float32(1.5)
+    real[12:14, :] = np.float32(0.0)
+    real[30, 5:9] = np.float32(150.0)
+    real = real.reshape(-1)
+    scan_bin = tmp_path / "scan.bin"
+    real.astype(np.float32).tofile(scan_bin)
+    r = subprocess.run([exe, str(mesh_bin), str(scan_bin)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.strip().splitlines()}
+
+    # the node's classification restated on the oracle's simulation
+    dirs = orc.spherical_directions(model).astype(np.float32)
+    rs, nrm = sim0["ranges"], sim0["normals"]
+    real_ok = (real >= np.float32(0.1)) & (real <= np.float32(100.0))
+    sim_ok = (rs >= np.float32(0.1)) & (rs <= np.float32(100.0))
+    preal = dirs * real[:, None]
+    pint = dirs * rs[:, None]
+    n_unit = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+    with np.errstate(invalid="ignore"):
+        spd = np.einsum("ij,ij->i", preal - pint, n_unit)
+    plane = np.abs(spd)
+    both = real_ok & sim_ok
+    scan_out = (both & (real < rs) & (plane > 0.15)) | (real_ok & ~sim_ok)
+    map_out = (both & ~(real < rs) & (plane > 0.15)) | (~real_ok & sim_ok)
+    # beams whose plane distance sits within float noise of the threshold may fall either way: none in this scene
+    assert not (both & (np.abs(plane - 0.15) < 1e-4)).any()
+    assert int(out["seg_outlier_scan"][0]) == int(scan_out.sum()) > 30
+    assert int(out["seg_outlier_map"][0]) == int(map_out.sum()) > 30
+    assert np.allclose([float(x) for x in out["seg_outlier_scan"][1:]], preal[scan_out].astype(np.float64).sum(axis=0), rtol=1e-5, atol=1e-3)
+    assert np.allclose([float(x) for x in out["seg_outlier_map"][1:]], pint[map_out].astype(np.float64).sum(axis=0), rtol=1e-5, atol=1e-3)
+
+    # batch simulate
+    Tsb = syn.tsb_offset()
+    for i in range(3):
+        Ti = T_sensor_map.copy()
+        Ti["t"]["z"] = np.float32(Ti["t"]["z"]) + np.float32(0.2) * np.float32(i)
+        ref = m.simulate_spherical(model, Tsb, Ti, bvh=False)
+        assert math.isclose(float(out["batch_ranges_%d" % i][0]), float(ref["ranges"].astype(np.float64).sum()), rel_tol=1e-6)
+    assert out["batch_device_equal"] == ["3072", "3072"]
+
+    # the free statistics_p2l == the operator == the oracle
+    est = T.mult(T_sensor_map, T.transform_from_rpy((0.2, 0.1, 0.05), (0, 0, 2.0 * math.pi / 180)))
+    mod = m.simulate_spherical(model, Tsb, est, bvh=False)
+    ds = (dirs * real[:, None]).astype(np.float32)
+    Tpre = T.transform_from_rpy((0.01, -0.02, 0.005), (0.001, 0.002, -0.003))
+    maxd = np.float32(np.float64(np.float32(1.0)) * 0.75 + np.float64(np.float32(0.15)) * 0.25)
+    ref = orc.statistics_p2l_f64(Tpre, ds, real_ok.astype(np.uint8), mod["points"], mod["normals"], mod["hits"], float(maxd))
+    assert out["p2l_free"][0] == out["p2l_operator"][0] == str(ref["n_meas"]) and ref["n_meas"] > 300
+    for key in ("p2l_free", "p2l_operator"):
+        got = [float(x) for x in out[key][1:]]
+        want = [ref["dataset_mean"][0], ref["model_mean"][2], ref["covariance"][0, 0], ref["covariance"][1, 2]]
+        assert np.allclose(got, want, rtol=1e-5, atol=1e-6), key
+    assert out["operator_bundle"] == ["13", "1", "1", "1", "0", "0"]
+    assert out["p2l_after_simulate"][0] == out["p2l_operator"][0] and math.isclose(float(out["p2l_after_simulate"][1]), float(out["p2l_operator"][3]), rel_tol=1e-6)
+    tru = m.simulate_spherical(model, Tsb, T_sensor_map, bvh=False)
+    reft = orc.statistics_p2l_f64(T.identity(), ds, real_ok.astype(np.uint8), tru["points"], tru["normals"], tru["hits"], float(maxd))
+    assert int(out["p2l_truth_pose"][0]) == reft["n_meas"]
+    assert math.isclose(float(out["p2l_truth_pose"][1]), float(np.trace(reft["covariance"])), rel_tol=1e-4)
+
+    # the four simulators
+    ref_s = m.simulate_spherical(model, Tsb, T_sensor_map, bvh=False)
+    want = [int(ref_s["hits"].sum()), int(ref_s["face_ids"][ref_s["hits"] > 0].astype(np.uint64).sum())]
+    assert [int(x) for x in out["sim_sphere"]] == want == [int(x) for x in out["sim_o1dn"]] == [int(x) for x in out["sim_ondn"]]
+    ph = m.simulate_pinhole(32, 32, 0.1, 100.0, (20.0, 20.0), (15.5, 15.5), Tsb, T_sensor_map, bvh=False)
+    assert [int(x) for x in out["sim_pinhole"]] == [int(ph["hits"].sum()), int(ph["face_ids"][ph["hits"] > 0].astype(np.uint64).sum())]
