@@ -16,59 +16,6 @@
 #include "lab_hooks.h"
 #include "pf_common.hip.h"
 
-#ifdef RMCL_ASAN_LOG
-// `make asan` only (tools/asan_gpu_tests.sh).  ROCm's device sanitizer reports through a host service this image does not install, so
-// the process would die with "Hostcall: no handler found" and no address.  These definitions take the place of the device library's
-// report functions: the FIRST bad access of the process is recorded (address, kind = 100 x is_load + bytes, workgroup, thread), the
-// offending wave ends; rmclhip_asan_log() hands the record to the host.
-__device__ unsigned long long g_rmcl_asan_log[8];
-static __device__ __attribute__((noinline)) void rmcl_asan_note(unsigned long long addr, unsigned long long kind, unsigned long long ra);
-#define RMCL_ASAN_RA() reinterpret_cast<unsigned long long>(__builtin_return_address(0))
-static __device__ __attribute__((noinline)) void rmcl_asan_note(unsigned long long addr, unsigned long long kind, unsigned long long ra) {
-  if (atomicAdd(&g_rmcl_asan_log[0], 1ull) == 0ull) {
-    // where: the report function's return address, and this function's own address to subtract (the code object's load address is
-    // not known here): offset from the symbol rmcl_asan_note in the extracted code object -> llvm-objdump -d -l
-    g_rmcl_asan_log[6] = ra;
-    g_rmcl_asan_log[7] = reinterpret_cast<unsigned long long>(&rmcl_asan_note);
-    g_rmcl_asan_log[1] = addr;
-    g_rmcl_asan_log[2] = kind;
-    g_rmcl_asan_log[3] = static_cast<unsigned long long>(blockIdx.x) | (static_cast<unsigned long long>(blockIdx.y) << 32);
-    g_rmcl_asan_log[4] = threadIdx.x;
-    g_rmcl_asan_log[5] = static_cast<unsigned long long>(gridDim.x) | (static_cast<unsigned long long>(blockDim.x) << 32);
-  }
-  // the instrumentation treats the report as the end of the road (what follows the call is unreachable): the wave ends here, cleanly
-  // -- its record is written, the rest of the launch runs on, the host reads the record instead of a dead process
-  __threadfence();
-  __builtin_amdgcn_endpgm();
-}
-#define RMCL_ASAN_REPORT(n)                                                                                              \
-  extern "C" __device__ void __asan_report_load##n(unsigned long long a) { rmcl_asan_note(a, 100ull + n, RMCL_ASAN_RA()); }              \
-  extern "C" __device__ void __asan_report_store##n(unsigned long long a) { rmcl_asan_note(a, n, RMCL_ASAN_RA()); }                      \
-  extern "C" __device__ void __asan_report_load##n##_noabort(unsigned long long a) { rmcl_asan_note(a, 100ull + n, RMCL_ASAN_RA()); }    \
-  extern "C" __device__ void __asan_report_store##n##_noabort(unsigned long long a) { rmcl_asan_note(a, n, RMCL_ASAN_RA()); }
-RMCL_ASAN_REPORT(1) RMCL_ASAN_REPORT(2) RMCL_ASAN_REPORT(4) RMCL_ASAN_REPORT(8) RMCL_ASAN_REPORT(16)
-#undef RMCL_ASAN_REPORT
-// (functions with very many accesses are instrumented with calls to the device library's __asan_load / __asan_store, which report
-// through this entry of the library instead)
-extern "C" __device__ void __ockl_sanitizer_report(unsigned long long addr, unsigned long long pc, unsigned long long, unsigned long long,
-                                                   unsigned long long, unsigned long long, unsigned long long is_read, unsigned long long size) {
-  rmcl_asan_note(addr, (is_read ? 100ull : 0ull) + size, pc);
-}
-extern "C" __device__ void __asan_report_load_n(unsigned long long a, unsigned long long n) { rmcl_asan_note(a, 100ull + n, RMCL_ASAN_RA()); }
-extern "C" __device__ void __asan_report_store_n(unsigned long long a, unsigned long long n) { rmcl_asan_note(a, n, RMCL_ASAN_RA()); }
-extern "C" __device__ void __asan_report_load_n_noabort(unsigned long long a, unsigned long long n) { rmcl_asan_note(a, 100ull + n, RMCL_ASAN_RA()); }
-extern "C" __device__ void __asan_report_store_n_noabort(unsigned long long a, unsigned long long n) { rmcl_asan_note(a, n, RMCL_ASAN_RA()); }
-// out[0] = number of bad accesses so far, out[1..5] = the first one; reset != 0 clears the record
-extern "C" int rmclhip_asan_log(unsigned long long* out8, int reset) {
-  if (hipDeviceSynchronize() != hipSuccess) return 1;
-  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_rmcl_asan_log), sizeof(g_rmcl_asan_log)) != hipSuccess) return 2;
-  if (reset) {
-    const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_rmcl_asan_log), z, sizeof(z)) != hipSuccess) return 3;
-  }
-  return 0;
-}
-#endif
 
 namespace rmclhip {
 

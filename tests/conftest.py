@@ -51,24 +51,6 @@ def _experiments_library(request):
         rmcl_amd.load_lab()
 
 
-@pytest.fixture(autouse=True)
-def _device_sanitizer_record(request):
-    """tools/asan_gpu_tests.sh (RMCLHIP_ASAN_LOG=1, the `make asan` build of the library): a test whose kernels touched memory they
-    must not touch fails with the first bad access (address, 100 x is_load + bytes, workgroup, thread); a no-op otherwise"""
-    yield
-    if os.environ.get("RMCLHIP_ASAN_LOG") != "1" or request.node.get_closest_marker("gpu") is None:
-        return
-    import ctypes as C
-    import rmcl_amd
-    lib = rmcl_amd._capi.lib()
-    out = (C.c_ulonglong * 8)()
-    rc = lib.rmclhip_asan_log(out, 1)
-    assert rc == 0 and out[0] == 0, ("device sanitizer: %d bad accesses; first: address %#x kind %d workgroup (%d, %d) thread %d grid %d x %d; "
-                                     "return address = rmcl_asan_note %+d"
-                                     % (out[0], out[1], out[2], out[3] & 0xffffffff, out[3] >> 32, out[4], out[5] & 0xffffffff, out[5] >> 32,
-                                        int(out[6]) - int(out[7])))
-
-
 @pytest.fixture(scope="session")
 def orc():
     import oracle
