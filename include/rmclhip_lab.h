@@ -49,6 +49,11 @@ rmclhip_status rmclhip_debug_micp_moments(rmclhip_rcc* rcc, double* totals96, ui
 rmclhip_status rmclhip_debug_probe_find(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est, int mode, uint32_t* log_out,
                                         size_t log_cap_dwords, uint32_t* n_tiles_out);
 
+/* A/B knobs of the cooperative descent of find kind 31 (traverse.hip.h frontier_descent_start): the wave stops descending when a level
+ * would leave more than final_cap entries (<= 64, default 64) or after max_levels levels (default 24; 0 = kind 23's frontier start with
+ * kind 31's bookkeeping).  Results do not depend on either.  Exported by librmclhip.so. */
+rmclhip_status rmclhip_rcc_set_descent(rmclhip_rcc* rcc, uint32_t final_cap, uint32_t max_levels);
+
 /* debug trace of the sharded entry points (rmclhip_pf_update_sharded, _allgather_weights, _sharded_resample*): on = 1 starts (and
  * clears) the recording, on = 0 stops it; buf (nullable) receives what was recorded before this call.  Tokens: "E<r>" rank r's part of
  * a phase was enqueued, "W<r>" the host waited for rank r, "<phase>:" labels.  A phase that lets the devices run concurrently reads

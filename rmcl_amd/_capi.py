@@ -177,6 +177,7 @@ SIGNATURES = {
     "rmclhip_rcc_time_caller_loop": (_i32, [_vp, _vp, _vp, _u32, _dbl, _u32, _vp, _vp, C.POINTER(_f32)]),
     "rmclhip_rcc_set_variant": (_i32, [_vp, _i32]),
     "rmclhip_rcc_find_variant": (_i32, [_vp, _u32, C.POINTER(_i32)]),
+    "rmclhip_rcc_set_descent": (_i32, [_vp, _u32, _u32]),
     "rmclhip_rcc_set_micp_fast": (_i32, [_vp, _i32]),
     "rmclhip_rcc_micp_fast_info": (_i32, [_vp, C.POINTER(MicpFastInfo)]),
     "rmclhip_rcc_ccs_info": (_i32, [_vp, C.POINTER(CcsInfo)]),

@@ -201,6 +201,7 @@ struct rmclhip_rcc {
   DevBuf<uint32_t> d_face_ids;
   uint32_t n_model = 0;      // per pose
   uint32_t nposes_last = 0;
+  uint32_t descent_final_cap = 64, descent_levels = 24;   // kind 31's cooperative descent (rmclhip_rcc_set_descent, include/rmclhip_lab.h)
   uint32_t out_mask = RMCLHIP_OUT_ALL;   // rmclhip_rcc_set_outputs: which model buffers find / find_batch write
   // reduction
   DevBuf<double> d_partials;

@@ -64,9 +64,12 @@ rmclhip_status rmclhip_rcc_time_find(rmclhip_rcc* r, const rmclhip_transform* Tb
 
 // candidates of the measured choice: {template kind, frontier start}; reported as kinds 2 / 23 / 24 and -- without the frontier
 // start -- as round 2's numbers for the same traversals, 19 / 22
-struct TuneCand { int kind; bool frontier; int reported; };
-static const TuneCand kTuneSingle[5] = {{2, true, 2}, {23, true, 23}, {23, false, 19}, {24, true, 24}, {24, false, 22}};
-static const TuneCand kTuneBatch[4] = {{23, true, 23}, {23, false, 19}, {24, true, 24}, {24, false, 22}};
+struct TuneCand { int kind; bool frontier; int reported; uint32_t descent_cap; };   // descent_cap: kind 31 only (rmclhip_rcc_set_descent), 0 otherwise
+// (kind 31 = kind 23 behind the cooperative descent, with the wave's final list capped at 12 or at 64 entries: open maps want the
+// long list, rooms the short one or none -- profiles/r06_descent_maps_ab.txt)
+static const TuneCand kTuneSingle[7] = {{2, true, 2, 0}, {23, true, 23, 0}, {23, false, 19, 0}, {24, true, 24, 0}, {24, false, 22, 0},
+                                        {31, true, 31, 12}, {31, true, 31, 64}};
+static const TuneCand kTuneBatch[4] = {{23, true, 23, 0}, {23, false, 19, 0}, {24, true, 24, 0}, {24, false, 22, 0}};
 
 rmclhip_status rmclhip_rcc_autotune(rmclhip_rcc* r, const rmclhip_transform* Tbm_est, int* chosen_kind, float* kernel_ms) {
   ApiGuard guard_("rmclhip_rcc_autotune");
@@ -77,18 +80,22 @@ rmclhip_status rmclhip_rcc_autotune(rmclhip_rcc* r, const rmclhip_transform* Tbm
   // each candidate timed on THIS map, model and pose: median of 5 batches of 8 back-to-back launches
   const int saved_kind = r->tuned_kind;
   const bool saved_frontier = r->tuned_frontier;
+  const uint32_t saved_cap = r->descent_final_cap;
   const TuneCand* best = nullptr;
   float best_ms = 0.f;
   for (const TuneCand& c : kTuneSingle) {
+    if (c.kind == 31 && (r->kind == kModelOnDn || r->map->d_cnodes == nullptr)) continue;   // (no common pyramid / no child-major nodes: kind 23)
     r->tuned_kind = c.kind; r->tuned_frontier = c.frontier;
+    if (c.descent_cap != 0u) r->descent_final_cap = c.descent_cap;
     float t[5];
     for (float& x : t) {
-      if (rmclhip_status st = rmclhip_rcc_time_find(r, Tbm_est, 8, &x)) { r->tuned_kind = saved_kind; r->tuned_frontier = saved_frontier; return st; }
+      if (rmclhip_status st = rmclhip_rcc_time_find(r, Tbm_est, 8, &x)) { r->tuned_kind = saved_kind; r->tuned_frontier = saved_frontier; r->descent_final_cap = saved_cap; return st; }
     }
     std::sort(t, t + 5);
     if (!best || t[2] < best_ms) { best = &c; best_ms = t[2]; }
   }
   r->tuned_kind = best->kind; r->tuned_frontier = best->frontier;
+  r->descent_final_cap = best->descent_cap != 0u ? best->descent_cap : saved_cap;
   // ... then the tile shape of the winner (the rule: 16 wide x 4 tall; profiles/r03_find_tile_shapes.txt shows maps that prefer
   // 4 x 16 or 32 x 2): widths 4, 8, 32 where the image is tall enough, the plane table rebuilt for each
   if (r->tile_override == 0) {
@@ -231,7 +238,7 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
   if (!r || variant < 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: bad arguments");
   // bit 13 adds 16 to the traversal kind (kinds 16..31)
   const int kind = (variant & 0xF) | (((variant >> 13) & 1) << 4), tile = (variant >> 4) & 0xF;
-  if (kind == 3 || kind == 18 || kind > 30 || tile > 7 || (variant >> 14) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
+  if (kind == 3 || kind == 18 || kind > 31 || tile > 7 || (variant >> 14) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
   // (kind 1 also selects the one-lane-per-point form of the closest-point query, which the product owns)
   if (kind != 15 && kind != 1 && !find_kind_in_product(kind) && lab_hooks() == nullptr)
     return fail(RMCLHIP_ERR_UNSUPPORTED, "rcc_set_variant: this traversal kind is an experiment -- it lives in librmclhip_lab.so, "
@@ -253,6 +260,15 @@ rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
   HIPCHK(hipSetDevice(r->ctx->device));
   HIPCHK(hipStreamSynchronize(r->stream));
   return rebuild_tile_planes(r);
+}
+
+rmclhip_status rmclhip_rcc_set_descent(rmclhip_rcc* r, uint32_t final_cap, uint32_t max_levels) {
+  ApiGuard guard_("rmclhip_rcc_set_descent");
+  if (!r || final_cap > 64u) return fail(RMCLHIP_ERR_INVALID, "rcc_set_descent: final_cap <= 64");
+  r->descent_final_cap = final_cap;
+  r->descent_levels = max_levels;
+  r->graph_dirty = true; r->fast_graph_dirty = true;
+  return RMCLHIP_OK;
 }
 
 rmclhip_status rmclhip_rcc_set_micp_fast(rmclhip_rcc* r, int mode) {

@@ -23,9 +23,13 @@ constexpr int kFindBfRows = 24;  // LDS stack rows per lane (sentinel included) 
 constexpr uint32_t kFindTailLdsDwords = 16u * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords;
 
 // kinds 19..22: kind 17 + leaving the node phase when 32 / 24 / 16 / 8 lanes hold a leaf
-constexpr int find_leaf_trigger(int trav) { return (trav == 19 || trav == 20 || trav == 23 || (trav >= 26 && trav <= 30)) ? 10 : 0; }   // leave at <= 4/10 of the round's rays
+constexpr int find_leaf_trigger(int trav) { return (trav == 19 || trav == 20 || trav == 23 || (trav >= 26 && trav <= 31)) ? 10 : 0; }   // leave at <= 4/10 of the round's rays
 // kinds 23 / 24: kinds 19 / 22 whose rays start at the map's frontier (traverse.hip.h frontier_start) instead of the root
-constexpr bool find_frontier(int trav) { return trav == 23 || trav == 24 || (trav >= 25 && trav <= 30); }   // 26: 23 on the quantised nodes; 27: 23 + record prefetch; 28: 23 with the pipelined node step; 29 / 30: 23 with four / three of the five ordering steps
+// kind 31 (round 6): kind 23 whose wave keeps descending cooperatively below the frontier (traverse.hip.h frontier_descent_start)
+constexpr bool find_frontier(int trav) { return trav == 23 || trav == 24 || (trav >= 25 && trav <= 31); }
+// LDS of the one-lane-per-ray kinds with quad-finished tails (23, 31, ...), in dwords; kind 31 appends its waves' descent lists
+constexpr uint32_t kFindBfTailLdsDwords = static_cast<uint32_t>(kFindBfRows) * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords;
+static_assert(kFindBfTailLdsDwords % 4u == 0u, "the descent lists behind it are read and written 16 B at a time");   // 26: 23 on the quantised nodes; 27: 23 + record prefetch; 28: 23 with the pipelined node step; 29 / 30: 23 with four / three of the five ordering steps
 // kind 25: kind 2 (four lanes per ray) with the frontier start
 constexpr bool find_quad(int trav) { return trav == 2 || trav == 25; }
 
@@ -231,8 +235,8 @@ __device__ __forceinline__ void find_moments_wave(const FindParams& p, uint32_t*
 // instantiations are built with kClock = false and contain no s_memtime
 template <uint32_t kModel, int kTrav, bool kClock = false, bool kMoments = false>
 __global__ void __launch_bounds__(256) k_find(const FindParams p) {
-  extern __shared__ uint32_t lds_dyn[];
-  static_assert(!kMoments || ((kTrav == 23 || kTrav == 2) && !kClock), "the moment epilogue is built for kinds 23 and 2");
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  static_assert(!kMoments || ((kTrav == 23 || kTrav == 31 || kTrav == 2) && !kClock), "the moment epilogue is built for kinds 23, 31 and 2");
   __shared__ double s_mom_red[kMoments ? 4 : 1][kMoments ? kMomTile : 1];
   __shared__ uint32_t s_mom_piece[4];
   constexpr bool kPacket = (kTrav == 0);
@@ -302,7 +306,7 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   const bool finite = (dir_m.x == dir_m.x) && (dir_m.y == dir_m.y) && (dir_m.z == dir_m.z);
   const float ray_tfar = (valid && finite) ? p.tfar : -1.0f;
 
-  uint32_t clk_trace0 = 0, clk_trace1 = 0, clk_visits = 0, clk_dbg[3] = {0u, 0u, 0u};
+  uint32_t clk_trace0 = 0, clk_trace1 = 0, clk_visits = 0, clk_dbg[4] = {0u, 0u, 0u, 0u}, clk_descent = 0, clk_start = 0;
   if (kClock && p.wave_clock != nullptr) {
     uint64_t t;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
@@ -344,13 +348,22 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
     if constexpr (find_frontier(kTrav) && kModel != kModelOnDn) {   // (OnDn: one origin per ray, no common pyramid)
       if (p.tile_planes != nullptr) {     // (no table: the rays start at the root)
         const float* planes = p.tile_planes + static_cast<size_t>(__builtin_amdgcn_readfirstlane(tile)) * 16u;
-        if (kTrav == 23 || (kTrav >= 26 && kTrav <= 30))
+        if (kTrav == 31)
+          start = frontier_descent_start<kFindBfRows, 1>(p.frontier, p.n_frontier, p.cnodes, p.scene_center, p.scene_half_diag, planes, Tsm.R, p.tfar,
+                                                         org_m, dir_m, ray_tfar, lane, lds_dyn + threadIdx.x, kBfStride, p.frontier_max_preload,
+                                                         lds_dyn + kFindBfTailLdsDwords + wave * kDescentWaveDwords, min(p.descent_final_cap, kDescentCap), p.descent_levels, kClock ? &clk_descent : nullptr);
+        else if (kTrav == 23 || (kTrav >= 26 && kTrav <= 30))
           start = frontier_start<kFindBfRows, 1>(p.frontier, p.n_frontier, p.scene_center, p.scene_half_diag, planes, Tsm.R, p.tfar, org_m,
                                                  dir_m, ray_tfar, lane, lds_dyn + threadIdx.x, kBfStride, p.frontier_max_preload);
         else
           start = frontier_start<16, 0>(p.frontier, p.n_frontier, p.scene_center, p.scene_half_diag, planes, Tsm.R, p.tfar, org_m, dir_m,
                                         ray_tfar, lane, lds_dyn + threadIdx.x, blockDim.x, p.frontier_max_preload);
       }
+    }
+    if (kClock && p.wave_clock != nullptr) {   // the start (frontier cull / cooperative descent) ends here
+      uint64_t t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+      clk_start = static_cast<uint32_t>(t);
     }
     if (kTrav == 4) trace_lane_ww<16, true>(p.qnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, blockDim.x, h);
     else if (kTrav == 22 || kTrav == 24)
@@ -362,7 +375,7 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
           lds_dyn + kFindTailLdsDwords);
     else if (kTrav == 1) trace_lane_bf<kFindBfRows>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
     else if (kTrav == 12) trace_lane_bf<kFindBfRows, false, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
-    else if (kTrav == 16 || kTrav == 17 || kTrav == 19 || kTrav == 20 || kTrav == 23 || (kTrav >= 26 && kTrav <= 30))
+    else if (kTrav == 16 || kTrav == 17 || kTrav == 19 || kTrav == 20 || kTrav == 23 || (kTrav >= 26 && kTrav <= 31))
       trace_lane_bf_tail<kFindBfRows, kTrav != 16 && kTrav != 20, find_leaf_trigger(kTrav), kTrav == 26, kTrav == 27, kTrav == 28, (kTrav == 29 ? 4 : (kTrav == 30 ? 3 : 5))>(kTrav == 26 ? p.qnodes : p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x,
                                                    lds_dyn + kFindBfRows * 256u,
                                                    lds_dyn + kFindBfRows * 256u + kQuadStackEntries * 64u + (threadIdx.x >> 6) * (kTailRays * kTailXferDwords), h,
@@ -437,9 +450,11 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
                             (wmax(min(clk_dbg[2] >> 6, 4095u), 12) << 20);
     if ((threadIdx.x & 63u) == 0u) {
       uint32_t* w = p.wave_clock + 8u * ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + wave);
-      w[0] = clk_begin; w[1] = static_cast<uint32_t>(t); w[2] = clk_real; w[3] = (tile & 0xFFFFFFu) | (xcc << 24);
+      // kinds 23 / 31: w[2] = cycles of the start (>> 4, 16 bits) | the wave's most leaf visits of a lane << 16 | most node visits << 24 instead of the realtime clock
+      const uint32_t w2 = (kTrav == 23 || kTrav == 31) ? (min((clk_start - clk_trace0) >> 4, 0xFFFFu) | (wmax(min(clk_dbg[3], 255u), 8) << 16) | (wmax(min(clk_visits, 255u), 8) << 24)) : clk_real;
+      w[0] = clk_begin; w[1] = static_cast<uint32_t>(t); w[2] = w2; w[3] = (tile & 0xFFFFFFu) | (xcc << 24);
       w[4] = clk_trace0; w[5] = clk_trace1; w[6] = static_cast<uint32_t>(t2);
-      w[7] = clk_w7;
+      w[7] = (kTrav == 31) ? clk_descent : clk_w7;   // kind 31: what its cooperative descent did (traverse.hip.h frontier_descent_start)
     }
   }
 }

@@ -53,6 +53,9 @@ struct FindParams {
   float scene_half_diag;
   const float* tile_planes;      // per tile of the scan image: the pyramid of its rays in the sensor frame (k_tile_planes), or null
   uint32_t frontier_max_preload; // stack entries the frontier start may leave per lane: 64 - stack_need of the tree the kind walks
+  // kind 31 (traverse.hip.h frontier_descent_start): the wave stops descending when a level would leave more than descent_final_cap
+  // entries (<= 64) or after descent_levels levels
+  uint32_t descent_final_cap, descent_levels;
   // diagnostics (nullable): per physical wave {s_memtime at entry, at exit (low 32 bits), s_memrealtime at entry, tile | xcc << 24}
   uint32_t* wave_clock;
   // MICP moment epilogue (launch_find_moments, k_find<..., kMom = true>): the moments of the gate-stable form (kernels.hip) are

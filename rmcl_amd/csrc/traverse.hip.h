@@ -923,7 +923,7 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
   float best_t = ray_tfar;
   uint32_t best_rec = kNone;
   uint32_t nvis = 0;  // node visits of this ray
-  uint32_t dbg_slow = 0, dbg_na = 0, dbg_tail = 0;
+  uint32_t dbg_slow = 0, dbg_na = 0, dbg_tail = 0, dbg_leaf = 0;
   constexpr uint32_t kDone = 0x7FFFFFFFu;
   uint32_t priv[(kRows < 65) ? (65 - kRows) : 1];
   lds_col[0] = kDone;
@@ -1078,6 +1078,7 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
       }
     } else
     if (cur > kDone) {
+      ++dbg_leaf;
       if (kLeafBatch) leaf_batch(tris, cur, O, D, ray_tfar, best_t, best_rec);
       else leaf_loop(tris, cur, O, D, ray_tfar, best_t, best_rec);
       if constexpr (kPre) {
@@ -1095,7 +1096,7 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
   h.rec = best_rec;
   if constexpr (kPre) { *pre = pre_v; *pre_rec = pre_r; }
   if (visits) *visits = nvis;
-  if (dbg) { dbg[0] = dbg_slow; dbg[1] = dbg_na; dbg[2] = dbg_tail; }
+  if (dbg) { dbg[0] = dbg_slow; dbg[1] = dbg_na; dbg[2] = dbg_tail; dbg[3] = dbg_leaf; }   // dbg[3]: leaf visits of this lane before the quad tail
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1275,6 +1276,225 @@ __device__ __forceinline__ TraceStart frontier_start(const uint32_t* __restrict_
   if (__any(sp > min(static_cast<uint32_t>(kRows - 4), static_cast<uint32_t>(kRow0) + max_preload))) return root;
   TraceStart st;
   st.cur = first_ref;   // kDone: the ray misses every entry, i.e. the whole map
+  st.sp = sp;
+  return st;
+}
+
+// ---------------------------------------------------------------------------------------------
+// COOPERATIVE DESCENT below the frontier (round 6, kind 31).  The frontier start replaces the top four levels of every ray's descent
+// by one cooperative pass; what remains on a resident map is still a chain of dependent, divergent node fetches (~4.6 node visits per
+// ray of a C2 scan, 10 - 16 wave steps of ~1.3 k cycles each at two waves per SIMD).  But the 64 rays of a tile keep walking the SAME
+// few subtrees below the frontier too: a 16 x 4 tile of a C2 scan sees about a dozen leaves.  So the wave keeps descending TOGETHER:
+// the frontier's survivors are a list in LDS; per level, lane l tests child (l & 3) of survivor (l >> 2) -- one coalesced 32-B fetch per
+// lane from the child-major nodes, the pyramid test of the frontier pass -- and the children inside the tile's pyramid become the next
+// list (16 nodes per pass, up to two passes per level).  Leaves met on the way collect in a second list.  When no inner node is left
+// (or the lists would outgrow 64 entries: a tile that sees a lot of the map, or a deep scene -- the level is then not expanded) every
+// lane tests the final entries against ITS ray, exactly as the frontier start does with the frontier's survivors, and starts the
+// ordinary per-lane traversal with the accepted ones on its stack: on the benchmark maps these are leaves only, so the divergent
+// phase is a few leaf rounds.  One round trip per LEVEL and wave instead of one per node visit and ray.
+// Same argument as the frontier start for the results: a stored child box lies inside its parent's, an entry is dropped only when its
+// box lies outside the pyramid that contains every ray of the wave (up to the farthest possible hit), hence every subtree a ray's own
+// descent would enter is entered; the closest hit (min t, then min face id) does not depend on the order.  Bit-identical to kind 23.
+// ws: this wave's scratch, kDescentWaveDwords dwords, 16-B aligned.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kDescentCap = 64u, kDescentInnerCap = 32u;       // entries ({box, ref} = 8 dwords each) of the final list / of an inner list
+constexpr uint32_t kDescentWaveDwords = (kDescentCap + 2u * kDescentInnerCap) * 8u;   // final list | inner list A | inner list B: 4 KB per wave
+#define RMCL_WAVE_LDS_SYNC()                                   \
+  {                                                            \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
+    __builtin_amdgcn_wave_barrier();                           \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
+  }
+
+template <int kRows, int kRow0>
+__device__ __forceinline__ TraceStart frontier_descent_start(const uint32_t* __restrict__ frontier, uint32_t n_frontier,
+                                                             const uint32_t* __restrict__ cnodes, f3 scene_center, float scene_half_diag,
+                                                             const float* __restrict__ planes, quat Rsm, float tfar, f3 O, f3 D,
+                                                             float ray_tfar, uint32_t lane, uint32_t* __restrict__ lds_col,
+                                                             uint32_t lds_stride, uint32_t max_preload, uint32_t* __restrict__ ws,
+                                                             uint32_t final_cap, uint32_t max_levels, uint32_t* dbg_levels = nullptr) {
+  constexpr uint32_t kDone = 0x7FFFFFFFu;
+  const bool active = ray_tfar >= 0.0f;
+  TraceStart root;
+  root.cur = active ? 0u : kDone;
+  root.sp = static_cast<uint32_t>(kRow0);
+  if (n_frontier == 0u) return root;
+  const uint4* Ft = reinterpret_cast<const uint4*>(frontier);
+  uint4 ea[4], eb[4];
+#pragma unroll
+  for (uint32_t k = 0; k < 4u; ++k) {
+    const uint32_t idx = min(lane + 64u * k, n_frontier - 1u);
+    ea[k] = Ft[2u * idx];
+    eb[k] = Ft[2u * idx + 1u];
+  }
+  // the tile's pyramid in the map frame (frontier_start, steps 1 and 2)
+  const uint4 P0 = sload4(reinterpret_cast<const uint32_t*>(planes), 0u), P1 = sload4(reinterpret_cast<const uint32_t*>(planes), 16u);
+  const uint4 P2 = sload4(reinterpret_cast<const uint32_t*>(planes), 32u), P3 = sload4(reinterpret_cast<const uint32_t*>(planes), 48u);
+  f3 n[4] = {qrot(Rsm, mk3(asf(P0.x), asf(P0.y), asf(P0.z))), qrot(Rsm, mk3(asf(P1.x), asf(P1.y), asf(P1.z))),
+             qrot(Rsm, mk3(asf(P2.x), asf(P2.y), asf(P2.z))), qrot(Rsm, mk3(asf(P3.x), asf(P3.y), asf(P3.z)))};
+  const float mq[4] = {asf(P0.w), asf(P1.w), asf(P2.w), asf(P3.w)};
+  const f3 oc = sub3(O, scene_center);
+  const float reach = fminf(tfar, sqrtf((oc.x * oc.x + oc.y * oc.y) + oc.z * oc.z) + scene_half_diag);
+  f3 an[4];
+  float off2[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    an[q] = mk3(fabsf(n[q].x), fabsf(n[q].y), fabsf(n[q].z));
+    off2[q] = 2.0f * (mq[q] * reach - 1e-4f * reach - 1e-6f);
+  }
+  const f3 O2 = mk3(2.0f * O.x, 2.0f * O.y, 2.0f * O.z);
+  // a box {a.xyz = lo, a.w b.x b.y = hi} against the pyramid: its vertex farthest along every plane normal (conservative; NaN keeps)
+  auto in_pyramid = [&](const uint4& a, const uint4& b) -> bool {
+    const f3 lo = mk3(asf(a.x), asf(a.y), asf(a.z)), hi = mk3(asf(a.w), asf(b.x), asf(b.y));
+    const f3 c2 = mk3((lo.x + hi.x) - O2.x, (lo.y + hi.y) - O2.y, (lo.z + hi.z) - O2.z);
+    const f3 h2 = mk3(hi.x - lo.x, hi.y - lo.y, hi.z - lo.z);
+    bool ok = true;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float v = fmaf(an[q].z, h2.z, fmaf(an[q].y, h2.y, fmaf(an[q].x, h2.x, fmaf(n[q].z, c2.z, fmaf(n[q].y, c2.y, n[q].x * c2.x)))));
+      ok = ok && !(v < off2[q]);
+    }
+    return ok;
+  };
+  bool acc[4];
+#pragma unroll
+  for (uint32_t k = 0; k < 4u; ++k) acc[k] = ((lane + 64u * k) < n_frontier) && in_pyramid(ea[k], eb[k]);
+
+  const RaySlab rs = make_ray_slab(O, D);
+  uint32_t first_ref = kDone, first_key = 0xFFFFFFFFu, second_ref = kDone, second_key = 0xFFFFFFFFu, sp = static_cast<uint32_t>(kRow0);
+  // one entry {box, ref} (wave-uniform values) against this lane's ray: the traversal's own slab test; the two nearest accepted entries
+  // stay in registers (entered first / on top of the stack), the others go below them in list order
+  auto offer = [&](float lx, float ly, float lz, float hx, float hy, float hz, uint32_t ref) {
+    const float tx0 = fmaf(lx, rs.inv.x, rs.noi.x), tx1 = fmaf(hx, rs.inv.x, rs.noi.x);
+    const float ty0 = fmaf(ly, rs.inv.y, rs.noi.y), ty1 = fmaf(hy, rs.inv.y, rs.noi.y);
+    const float tz0 = fmaf(lz, rs.inv.z, rs.noi.z), tz1 = fmaf(hz, rs.inv.z, rs.noi.z);
+    const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
+    const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), ray_tfar));
+    if (active && tn <= tf) {
+      const uint32_t key = __float_as_uint(tn);
+      const bool n1 = key < first_key, n2 = key < second_key;
+      const uint32_t pushed = n2 ? second_ref : ref;
+      second_ref = n1 ? first_ref : (n2 ? ref : second_ref);
+      second_key = n1 ? first_key : (n2 ? key : second_key);
+      first_ref = n1 ? ref : first_ref;
+      first_key = n1 ? key : first_key;
+      if (pushed != kDone) {
+        if (sp < static_cast<uint32_t>(kRows)) lds_col[sp * lds_stride] = pushed;
+        ++sp;
+      }
+    }
+  };
+
+  // how many entries survive, how many of them are inner nodes (wave-uniform)
+  uint64_t m_all[4], m_in[4];
+  uint32_t n_surv = 0, n_inner = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 4u; ++k) {
+    m_all[k] = __ballot(acc[k]);
+    m_in[k] = __ballot(acc[k] && !(eb[k].z & kLeafBit));
+    n_surv += static_cast<uint32_t>(__popcll(m_all[k]));
+    n_inner += static_cast<uint32_t>(__popcll(m_in[k]));
+  }
+  uint32_t levels = 0;
+  if (dbg_levels) *dbg_levels = min(n_surv, 63u);   // diagnostics: survivors of the frontier | entries after level 1 << 6 | 2 << 12 | 3 << 18 | final entries << 24
+  if (cnodes != nullptr && n_inner != 0u && n_inner <= kDescentInnerCap && n_surv <= kDescentCap) {
+    // ---- the descent: lists in this wave's scratch ----
+    uint4* Fl = reinterpret_cast<uint4*>(ws);
+    uint4* Acur = Fl + 2u * kDescentCap;
+    uint4* Anext = Acur + 2u * kDescentInnerCap;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t nF = 0, nA = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+      const uint64_t m_lf = m_all[k] & ~m_in[k];
+      if (acc[k]) {
+        const bool inner = !(eb[k].z & kLeafBit);
+        const uint32_t idx = inner ? nA + static_cast<uint32_t>(__popcll(m_in[k] & lt)) : nF + static_cast<uint32_t>(__popcll(m_lf & lt));
+        uint4* dst = inner ? Acur : Fl;
+        dst[2u * idx] = ea[k];
+        dst[2u * idx + 1u] = eb[k];
+      }
+      nF += static_cast<uint32_t>(__popcll(m_lf));
+      nA += static_cast<uint32_t>(__popcll(m_in[k]));
+    }
+    RMCL_WAVE_LDS_SYNC()
+    const uint32_t s_in = lane >> 2, c_in = lane & 3u;
+    // A level that turns out not to fit costs a round trip for nothing, so the wave predicts before it fetches: the list grew by
+    // g = total / previous total at the last level (at least 5/4); the next level is fetched only if total * g <= final_cap
+    uint32_t prev_total = max(n_surv, 1u);
+    while (nA != 0u && levels < max_levels) {
+      {
+        const uint32_t total = nF + nA;
+        const uint32_t g_num = max(4u * total, 5u * prev_total);   // g = g_num / (4 prev_total)
+        if (total * g_num > final_cap * 4u * prev_total) break;
+        prev_total = total;
+      }
+      // expand every node of the current list: 16 nodes (x 4 children) per pass
+      uint32_t nFn = nF, nAn = 0;
+      for (uint32_t base = 0; base < nA; base += 16u) {
+        const uint32_t s = base + s_in;
+        const bool have = s < nA;
+        const uint32_t nref = have ? reinterpret_cast<const uint32_t*>(Acur)[8u * s + 6u] : 0u;
+        const uint4* cn = reinterpret_cast<const uint4*>(cnodes) + (static_cast<size_t>(nref) * 8u + 2u * c_in);
+        const uint4 ca = cn[0], cb = cn[1];
+        // (an unused child slot holds the far point, layout.h: never inside a scene -- but possibly inside an unbounded pyramid)
+        const bool ok = have && (asf(ca.x) < 1.0e29f) && in_pyramid(ca, cb);
+        const bool inner = !(cb.z & kLeafBit);
+        const uint64_t mi = __ballot(ok && inner), ml = __ballot(ok && !inner);
+        if (ok) {
+          const uint32_t idx = inner ? nAn + static_cast<uint32_t>(__popcll(mi & lt)) : nFn + static_cast<uint32_t>(__popcll(ml & lt));
+          if (idx < (inner ? kDescentInnerCap : kDescentCap)) {
+            uint4* dst = inner ? Anext : Fl;
+            dst[2u * idx] = ca;
+            dst[2u * idx + 1u] = cb;
+          }
+        }
+        nAn += static_cast<uint32_t>(__popcll(mi));
+        nFn += static_cast<uint32_t>(__popcll(ml));
+      }
+      RMCL_WAVE_LDS_SYNC()
+      if (nFn + nAn > final_cap || nAn > kDescentInnerCap) break;   // this level does not fit: it stays unexpanded (its leaves, written above nF, are forgotten)
+      nF = nFn;
+      nA = nAn;
+      uint4* t = Acur; Acur = Anext; Anext = t;
+      ++levels;
+      if (dbg_levels && levels <= 3u) *dbg_levels |= min(nF + nA, 63u) << (6u * levels);
+    }
+    if (dbg_levels) *dbg_levels |= (nF + nA) << 24;
+    // the inner nodes left unexpanded join the final list (nF + nA <= kDescentCap by construction)
+    if (lane < nA) {
+      Fl[2u * (nF + lane)] = Acur[2u * lane];
+      Fl[2u * (nF + lane) + 1u] = Acur[2u * lane + 1u];
+    }
+    nF += nA;
+    RMCL_WAVE_LDS_SYNC()
+    // final entries lane-resident, then each against every ray of the wave
+    const uint32_t jl = min(lane, max(nF, 1u) - 1u);
+    const uint4 fa = Fl[2u * jl], fb = Fl[2u * jl + 1u];
+    for (uint32_t j = 0; j < nF; ++j)
+      offer(lane_bcast(asf(fa.x), j), lane_bcast(asf(fa.y), j), lane_bcast(asf(fa.z), j), lane_bcast(asf(fa.w), j), lane_bcast(asf(fb.x), j),
+            lane_bcast(asf(fb.y), j), lane_bcast(fb.z, j));
+  } else {
+    // no descent (nothing but leaves survived, too many survivors, no child-major nodes): the frontier start's own third step
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+      if (64u * k >= n_frontier) break;   // wave-uniform
+      uint64_t mask = m_all[k];
+      while (mask != 0ull) {
+        const uint32_t j = static_cast<uint32_t>(__builtin_ctzll(mask));
+        mask &= mask - 1ull;
+        offer(lane_bcast(asf(ea[k].x), j), lane_bcast(asf(ea[k].y), j), lane_bcast(asf(ea[k].z), j), lane_bcast(asf(ea[k].w), j),
+              lane_bcast(asf(eb[k].x), j), lane_bcast(asf(eb[k].y), j), lane_bcast(eb[k].z, j));
+      }
+    }
+  }
+  if (second_ref != kDone) {
+    if (sp < static_cast<uint32_t>(kRows)) lds_col[sp * lds_stride] = second_ref;
+    ++sp;
+  }
+  if (__any(sp > min(static_cast<uint32_t>(kRows - 4), static_cast<uint32_t>(kRow0) + max_preload))) return root;
+  TraceStart st;
+  st.cur = first_ref;
   st.sp = sp;
   return st;
 }
