@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--workload", choices=("c2", "pf"), default="c2")
     ap.add_argument("--variant", type=int, default=15,
                     help="find traversal: 15 automatic (default), 1 one lane per ray, 2 four lanes per ray, 0 wave packet")
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="time the headline scan on the automatic RULE's traversal instead of the one rmclhip_rcc_autotune measures fastest "
+                         "on this map / model / pose (INTEGRATION.md: the sensor set-up calls it once; results are bit-identical either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing tests)")
@@ -154,7 +157,16 @@ def main():
         # batches of 40 launches.  (It runs before the W + K steps on purpose: a run with few steps -- the driver's K = 20 is
         # 0.35 ms of GPU time -- would otherwise be timed on a device that has not left its idle clocks: 19.0 vs 18.2 us per
         # step measured; the metric is steady-state rays/s.  DESIGN.md section 5.)
-        kernel_ms = median_kernel_ms(lambda: rcc.time_find(Tbm, iters=40))
+        rule_kind = rcc.find_variant(1)
+        rule_kernel_ms = median_kernel_ms(lambda: rcc.time_find(Tbm, iters=40))
+        tuned = None
+        if args.variant == 15 and not args.no_autotune:
+            # what INTEGRATION.md's sensor set-up does once per (map, model): the operator measures its own single-scan traversals here
+            # (kinds 2 / 23 / 24 with and without the frontier start, kind 31 = the cooperative descent with a short and a long list, then
+            # the tile shape) and keeps the fastest.  The step below is the same rmclhip_rcc_find_async either way.
+            k_t, ms_t = rcc.autotune(Tbm)
+            tuned = {"rule_kind": rule_kind, "rule_kernel_ms": round(rule_kernel_ms, 5), "chosen_kind": k_t, "autotune_kernel_ms": round(ms_t, 5)}
+        kernel_ms = median_kernel_ms(lambda: rcc.time_find(Tbm, iters=40)) if tuned else rule_kernel_ms
         step = rcc.find_async_fn(Tbm)   # rmclhip_rcc_find_async(handle, pose) with the pose converted once: one C call per step
         for _ in range(max(args.warmup, 1)):
             step()
@@ -174,11 +186,31 @@ def main():
         units_per_step = n_rays
 
         b_alg = algorithmic_bytes_raycast(n_rays, len(f), 1)
-        kind = rcc.find_variant(1)   # the traversal the automatic rule (or --variant) launches for this scan
+        kind = rcc.find_variant(1)   # the traversal that was timed: the autotuned one, the rule's (--no-autotune) or --variant's
         kname = "k_find<spherical, kind %d>" % kind
         traffic = measured_traffic("k_find_kind%d" % kind)
+        if tuned is not None:
+            extras["headline_traversal"] = dict(tuned, timed_kind=kind, rule_rays_per_s=round(n_rays / (rule_kernel_ms * 1e-3), 1),
+                                                note="rmclhip_rcc_autotune ran once before the timed steps (a product call, INTEGRATION.md); "
+                                                     "--no-autotune times the automatic rule's kind; results are bit-identical")
 
         if rank == 0 and not args.no_extras:
+            # the boundary's Simulator surface (round 6): the MICP bundle {points, normals, hits} = 25 B/ray that Correspondences_::model_buffers_
+            # carries (Correspondences.hpp:81-85) beside the five-output headline (33 B/ray); simulate() into a caller-owned
+            # Bundle<Ranges, Normals> (scan_map_segmentation_embree.cpp:80-87); the free statistics_p2l on caller-owned views
+            from rmcl_amd import _capi as _cb
+            rcc.set_outputs(_cb.OUT_MICP)
+            mb_ms = median_kernel_ms(lambda: rcc.time_find(Tbm, iters=40), 5)
+            extras["find_micp_bundle_ms"] = round(mb_ms, 5)
+            extras["find_micp_bundle_rays_per_s"] = round(n_rays / (mb_ms * 1e-3), 1)
+            extras["find_micp_bundle_algorithmic_GBps"] = round((algorithmic_bytes_raycast(n_rays, len(f), 1) - 8 * n_rays) / (mb_ms * 1e-3) / 1e9, 1)
+            rcc.set_outputs(_cb.OUT_ALL)
+            bundle = rcc.simulate(Tbm, attributes=("ranges", "normals"))
+            extras["simulate_ranges_normals_sync_call_ms"] = round(_median_call_ms(lambda: rcc.simulate(Tbm, attributes=("ranges", "normals"), into=bundle), reps=50), 5)
+            rcc.find(Tbm)
+            mvd = rcc.simulate(Tbm, attributes=("points", "normals", "hits"))
+            extras["statistics_p2l_free_function_sync_call_ms"] = round(_median_call_ms(
+                lambda: ra.statistics_p2l(ctx, T.identity(), mvd["points"], mvd["hits"], mvd["points"], mvd["normals"], mvd["hits"], n_rays, 1.0), reps=50), 5)
             # C3: MICP-L inner loop: (R) 1 find + 10 x (reduce + solve), (B) 10 x (find + reduce + solve).
             # The measured scan is the product's own simulation at the ground-truth pose (no oracle involved).
             rcc.find(syn.pose_c2_truth())
@@ -255,6 +287,17 @@ def main():
             sms, _ = _pf_c4(ra, syn, T, np, ctx, hm, 100000, 256, iters=3, bb=((-8, -8, -1), (8, 8, 1)))
             extras["c4_pf_update_survey_box_ms"] = round(sms, 4)
             extras["c4_particle_updates_per_s"] = round(100000 / (pms * 1e-3), 1)
+            # the REFERENCE's GPU schedule as a comparator (PCDSensorUpdaterOptix.cpp:319-338): one launch per beam, attributes re-read and
+            # re-written per beam (B_pf unfused = 256 x 100 000 x 104 B = 2.66 GB), the stream synchronised after every beam (:337)
+            ums, ums_async = _pf_c4_unfused(ra, syn, T, np, ctx, hm, 100000, 256)
+            extras["c4_unfused_reference_schedule_ms"] = round(ums, 3)
+            extras["c4_unfused_reference_schedule_no_sync_between_beams_ms"] = round(ums_async, 3)
+            b_unf = 256 * 100000 * 104
+            extras["c4_unfused_reference_schedule_roofline"] = {
+                "algorithmic_bytes": b_unf, "achieved_GBps": round(b_unf / (ums_async * 1e-3) / 1e9, 1),
+                "frac_of_hbm_peak": round(b_unf / (ums_async * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "fused_algorithmic_bytes": algorithmic_bytes_pf(100000, 256), "fused_ms": round(pms, 4),
+                "fused_over_unfused_speedup": round(ums / pms, 1)}
             extras["c4_pf_algorithmic_GBps"] = round(algorithmic_bytes_pf(100000, 256) / (pms * 1e-3) / 1e9, 2)
             # the filter's steady state: a CONVERGED cloud (100k particles ~ N(pose, 0.25 m, 5 deg yaw)), round 3's dealing and the
             # particle-coherent one (a wave's lanes = the same beam of 16 Morton-neighbouring particles x 4 beams); measured neutral:
@@ -456,12 +499,14 @@ def main():
             # in-process loopback one, so that two RCCL instances never meet; at N = 1 it is RCCL's ncclCommInitAll)
             shp = ra.ShardedParticleFilterHip(v, f, devices=(local_rank,), loopback=(world > 1))
             extras["pf_sharded_cabi_communicator"] = "loopback (in-process)" if world > 1 else "rccl ncclCommInitAll"
+            extras["pf_sharded_cabi_collective_ranks"] = list(shp.collective_ranks())   # ncclCommCount of the C-ABI communicator
             pposes, pattrs = syn.uniform_particles(100000, seed=42, bb_min=(-5, -5, -1, 0, 0, -math.pi), bb_max=(5, 5, 1, 0, 0, math.pi))
             shp.set_particles(pposes, pattrs)
             pdirs = syn.model_directions(syn.model_pf16())
             pbeams = ra.beams_from_points(pdirs * np.float32(6.0))
             extras["pf_sharded_cabi_update_allgather_ms"] = round(_median_call_ms(lambda: shp.update(pbeams, T.identity()), reps=5, warm=1), 4)
             extras["pf_sharded_cabi_pose_estimate_ms"] = round(_median_call_ms(lambda: shp.pose_estimate(), reps=9, warm=1), 4)
+            # (round 6: no all-reduce behind this call any more -- every device reduces its copy of the gathered weights; the key keeps its name)
             extras["pf_sharded_cabi_allreduce_stats_ms"] = round(_median_call_ms(lambda: shp.stats(), reps=9, warm=1), 4)
             shp.close()
 
@@ -644,7 +689,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "units_per_step_per_gpu": units_per_step, "triangles": int(len(f)),
-                       "parallelism": parallelism, "kernel_variant": args.variant},
+                       "parallelism": parallelism, "kernel_variant": args.variant,
+                       "traversal": (("autotuned (rmclhip_rcc_autotune): kind %d" % extras["headline_traversal"]["timed_kind"])
+                                     if "headline_traversal" in extras else "automatic rule / --variant")},
             # whole-job pose-corrections/s (aggregate over the ranks, weak: a batch per GPU) for the reference's own batch shape and
             # for full-size scans; the single-scan 10-iteration correction (C3 schedule R) does not shard: rank 0's figure, per rank
             "pose_corrections_per_s": {
@@ -657,7 +704,9 @@ def main():
             # per-GPU term.  At N > 1 `value` above is N independent replicas of C2 -- THIS block and pose_corrections_per_s are the
             # informative multi-GPU figures
             "particle_filter_sharded": ({k: extras["pf_sharded"].get(k) for k in ("shape", "c5_step_ms", "c5_shard_update_ms", "c5_allgather_ms",
-                                                                               "particle_beam_evals_per_s", "collective")}
+                                                                               "particle_beam_evals_per_s", "collective", "collective_ranks",
+                                                                               "collective_backend", "gathered_vector_length",
+                                                                               "gathered_vector_complete_on_every_rank")}
                                         if isinstance(extras.get("pf_sharded"), dict) else None),
             "roofline": roofline,
             "cpu_baseline": cpu,
@@ -821,14 +870,21 @@ def _pf_sharded_block(ra, syn, T, np, torch, dist, ctx, rank, world, n_local=125
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
+    rsm = ra.GladiatorResamplerHip(ctx)
+    gathered_len = {"n": None}
+
     def step():
+        # sensor update -> ONE all-gather of the weights -> {sum, max} on this rank's own copy of the gathered vector (round 6: no
+        # second collective; rmclhip_resampler_compute_stats_weights = the single-GPU kernel and order)
         if dist is not None:
             w = sharded.update(d_poses, d_attrs, w_local)
-            D.allreduce_sum_max(w_local)
-            return w
-        upd.update(d_poses, d_attrs, n_particles=hi - lo)
-        upd.extract_weights(d_attrs, hi - lo, w_local.data_ptr())
-        return w_local
+        else:
+            upd.update(d_poses, d_attrs, n_particles=hi - lo)
+            upd.extract_weights(d_attrs, hi - lo, w_local.data_ptr())
+            w = w_local
+        gathered_len["n"] = int(w.shape[0])
+        D.gathered_sum_max(w[:n_total], rsm.compute_stats_weights)
+        return w
 
     for _ in range(2):
         step()
@@ -851,13 +907,24 @@ def _pf_sharded_block(ra, syn, T, np, torch, dist, ctx, rank, world, n_local=125
             D.allgather_weights(w_local, n_total)
         torch.cuda.synchronize()
         ag_ms = reduce_max((time.perf_counter() - t0) / 20 * 1e3)
+    # what the collective itself saw: the process group's size and backend, and the gathered vector's length CHECKED ON EVERY RANK
+    # (a scaling run then shows that RCCL moved N ranks' shards, not that N processes ran side by side)
+    len_ok = 1.0 if (gathered_len["n"] is not None and gathered_len["n"] >= n_total) else 0.0
+    if dist is not None:
+        tt = torch.tensor([len_ok], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+        len_ok = float(tt.item())
+    rsm.close()
     upd.close()
     hm.release()
     return {"shape": "C5 per GPU: %d particles x %d beams, UV-sphere %d triangles, %d GPU(s), %d particles in total" %
                      (n_local, n_beams, n_tri, world, n_total),
             "c5_shard_update_ms": round(update_ms, 4), "c5_step_ms": round(step_ms, 4), "c5_allgather_ms": round(ag_ms, 4),
             "allgather_bytes": 4 * n_total, "collective": ((("RCCL" if str(dist.get_backend()) == "nccl" else str(dist.get_backend()) + " (plumbing test, not RCCL)") +
-                                                            " all_gather_into_tensor + 2 all_reduce") if dist is not None else "none (1 GPU)"),
+                                                            " all_gather_into_tensor; {sum, max} from the gathered vector on every rank (no all-reduce)") if dist is not None else "none (1 GPU)"),
+            "collective_ranks": (dist.get_world_size() if dist is not None else 1),
+            "collective_backend": (str(dist.get_backend()) if dist is not None else "none"),
+            "gathered_vector_length": gathered_len["n"], "gathered_vector_complete_on_every_rank": bool(len_ok == 1.0),
             "particle_beam_evals_per_s": round(n_total * n_beams / (step_ms * 1e-3), 1),
             "particle_updates_per_s": round(n_total / (step_ms * 1e-3), 1), "map_build_upload_s": round(build_s, 2)}
 
@@ -1085,6 +1152,23 @@ def _pf_c4(ra, syn, T, np, ctx, hm, n_particles, n_beams, iters, bb=((-5, -5, -1
     ms = sorted(upd.time_update(d_poses, d_attrs, n_particles, iters=iters) for _ in range(5))[2]
     upd.close()
     return ms, n_particles * n_beams
+
+
+def _pf_c4_unfused(ra, syn, T, np, ctx, hm, n_particles, n_beams):
+    """config C4 in the reference's GPU schedule (one single-beam update per beam): (ms with a host wait after every beam, ms with one wait
+    at the end) -- rmclhip_pf_time_update_unfused, host clock inside the library"""
+    poses, attrs = syn.uniform_particles(n_particles, seed=42, bb_min=(-5, -5, -1, 0, 0, -math.pi), bb_max=(5, 5, 1, 0, 0, math.pi))
+    dirs = syn.model_directions(syn.model_pf16())
+    sel = np.linspace(0, len(dirs) - 1, n_beams).astype(int)
+    beams = ra.beams_from_points(dirs[sel] * np.float32(6.0))
+    upd = ra.PCDSensorUpdaterHip(hm)
+    upd.init()
+    upd.setInput(beams, T.identity())
+    d_poses, d_attrs = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
+    a = upd.time_update_unfused(d_poses, d_attrs, n_particles, sync_each_beam=True, iters=2)
+    b = upd.time_update_unfused(d_poses, d_attrs, n_particles, sync_each_beam=False, iters=2)
+    upd.close()
+    return a, b
 
 
 def _median_call_ms(fn, reps=25, warm=3):

@@ -624,6 +624,11 @@ rmclhip_status rmclhip_resampler_create(rmclhip_ctx* ctx, rmclhip_resampler** ou
 void rmclhip_resampler_destroy(rmclhip_resampler* rs);
 rmclhip_status rmclhip_resampler_compute_stats(rmclhip_resampler* rs, const rmclhip_particle_attributes* attrs_dev,
                                                uint32_t n, rmclhip_likelihood_stats* out);
+/* the same {sum, max} of a DENSE weight vector on the device -- the all-gathered likelihood.mean of a sharded cloud (every
+ * rank holds all N weights after the gather and computes the statistics locally, no second collective): the kernel and the order of
+ * rmclhip_resampler_compute_stats, hence the same bits as that call on attributes holding the same values, on every rank */
+rmclhip_status rmclhip_resampler_compute_stats_weights(rmclhip_resampler* rs, const float* weights_dev, uint32_t n,
+                                                       rmclhip_likelihood_stats* out);
 rmclhip_status rmclhip_resampler_gladiator(rmclhip_resampler* rs, const rmclhip_transform* poses_dev,
                                            const rmclhip_particle_attributes* attrs_dev, uint32_t n_particles,
                                            rmclhip_transform* poses_new_dev, rmclhip_particle_attributes* attrs_new_dev,
@@ -682,7 +687,7 @@ rmclhip_status rmclhip_pf_update_sharded(rmclhip_pf_sharded* pf, const rmclhip_r
 rmclhip_status rmclhip_pf_sharded_motion_update(rmclhip_pf_sharded* pf, const rmclhip_transform* T_bnew_bold, double forget_rate,
                                                 int check_collision);
 /* One cycle of the filter node on the sharded cloud (rmcl_localization.cpp:84, 432-552): motion update (T_bnew_bold NULL: skipped) ->
- * sensor update -> weight all-gather -> {sum, max} all-reduce (stats_out, nullable) -> resampling (resample: 0 none, 1 gladiator
+ * sensor update -> weight all-gather -> {sum, max} of the gathered weights on every device (stats_out, nullable; no collective) -> resampling (resample: 0 none, 1 gladiator
  * tournament, 2 residual; config / seed / step as rmclhip_pf_sharded_resample).  A device's motion and sensor-update launches share a
  * stream: the host never waits between them.  Equal, bit for bit, to the single-device sequence rmclhip_pf_motion_update,
  * rmclhip_pf_update, rmclhip_resampler_compute_stats, rmclhip_resampler_gladiator / _residual. */
@@ -694,8 +699,14 @@ rmclhip_status rmclhip_pf_sharded_step(rmclhip_pf_sharded* pf, const rmclhip_tra
  * vector of the whole cloud; rmclhip_pf_sharded_get_weights copies rank's copy to the host */
 rmclhip_status rmclhip_pf_allgather_weights(rmclhip_pf_sharded* pf);
 rmclhip_status rmclhip_pf_sharded_get_weights(rmclhip_pf_sharded* pf, uint32_t rank, float* weights_host);
-/* global {sum, max}: simple_stats_kernel (resampling.cu:41-92) as an all-reduce of per-device partials */
+/* global {sum, max} (simple_stats_kernel, resampling.cu:41-92).  Since round 6 NOT a collective, the name notwithstanding: after the
+ * weight all-gather every device holds all N likelihoods and reduces its own copy with the single-device kernel in that kernel's fixed
+ * order -- the single-device value bit for bit, independent of the order in which a collective library would have added per-device
+ * partials (the value feeds size_t(L / sum * N) in the residual resampler).  Gathers first if the attributes changed since the last gather. */
 rmclhip_status rmclhip_pf_allreduce_stats(rmclhip_pf_sharded* pf, rmclhip_likelihood_stats* out);
+/* ranks the communicator's collectives span, as the collective library itself reports them (ncclCommCount; the loopback stand-in: its
+ * rank list) and whether it is RCCL (1) or the stand-in (0) */
+rmclhip_status rmclhip_comm_collective_ranks(rmclhip_comm* comm, uint32_t* n_ranks, int* is_rccl);
 /* RmclNode::estimateStats (rmcl_localization.cpp:642-731) over the first n_induction particles: three passes of per-device
  * moments (<= 24 doubles each: likelihood sums + bounding box, weighted quaternion outer products + translations for the
  * Markley mean, 6x6 covariance around it), each followed by one ncclAllReduce */

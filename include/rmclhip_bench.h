@@ -46,6 +46,17 @@ rmclhip_status rmclhip_pf_time_update(rmclhip_pf* pf, const rmclhip_transform* p
                                       const rmclhip_range_measurement* beams, uint32_t n_beams,
                                       const rmclhip_transform* Tsb, uint32_t iters, float* ms_per_launch);
 
+/* The REFERENCE's GPU schedule of the sensor update as a comparator (PCDSensorUpdaterOptix.cpp:319-338: one launch per beam, the
+ * particle attributes read and written by every launch, the stream synchronised after every beam, :337): n_beams synchronous
+ * rmclhip_pf_update calls of ONE beam each (sync_each_beam != 0), or the same launches enqueued back to back with one wait at the end
+ * (sync_each_beam == 0: what the schedule costs the device alone).  Host clock around the whole sequence, mean over `iters` sequences
+ * after one untimed one.  Results equal the fused update's (the beams are applied in order); particle traffic is
+ * n_beams x n_particles x 104 B instead of n_particles x 104 B (SURVEY 8(d) B_pf unfused). */
+rmclhip_status rmclhip_pf_time_update_unfused(rmclhip_pf* pf, const rmclhip_transform* poses_dev,
+                                              rmclhip_particle_attributes* attrs_dev, uint32_t n_particles,
+                                              const rmclhip_range_measurement* beams, uint32_t n_beams,
+                                              const rmclhip_transform* Tsb, int sync_each_beam, uint32_t iters, float* ms_per_sequence);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,11 @@ rmclhip_status rmclhip_debug_probe_find(rmclhip_rcc* rcc, const rmclhip_transfor
  * kind 31's bookkeeping).  Results do not depend on either.  Exported by librmclhip.so. */
 rmclhip_status rmclhip_rcc_set_descent(rmclhip_rcc* rcc, uint32_t final_cap, uint32_t max_levels);
 
+/* TEST knob of the loopback communicator (rmclhip_comm_create_loopback): its all-reduce adds the ranks' contributions starting at
+ * `first_rank` instead of rank 0 -- the freedom a real collective library has.  Whatever must not depend on the library's order of
+ * summation is tested under several rotations (tests/test_gpu_distributed.py).  Exported by librmclhip.so. */
+rmclhip_status rmclhip_comm_loopback_set_reduce_rotation(rmclhip_comm* comm, uint32_t first_rank);
+
 /* debug trace of the sharded entry points (rmclhip_pf_update_sharded, _allgather_weights, _sharded_resample*): on = 1 starts (and
  * clears) the recording, on = 0 stops it; buf (nullable) receives what was recorded before this call.  Tokens: "E<r>" rank r's part of
  * a phase was enqueued, "W<r>" the host waited for rank r, "<phase>:" labels.  A phase that lets the devices run concurrently reads

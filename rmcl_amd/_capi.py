@@ -203,6 +203,7 @@ SIGNATURES = {
     "rmclhip_pf_motion_update": (_i32, [_vp, _vp, _vp, _u32, _vp, _dbl, _i32]),
     "rmclhip_pf_extract_weights": (_i32, [_vp, _vp, _u32, _vp]),
     "rmclhip_pf_time_update": (_i32, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32, C.POINTER(_f32)]),
+    "rmclhip_pf_time_update_unfused": (_i32, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _i32, _u32, C.POINTER(_f32)]),
     "rmclhip_pf_set_variant": (_i32, [_vp, _i32]),
     "rmclhip_pf_set_schedule": (_i32, [_vp, _u32, _u32]),
     "rmclhip_pf_set_mapping": (_i32, [_vp, _i32, _u32, _vp, _u32]),
@@ -214,12 +215,15 @@ SIGNATURES = {
     "rmclhip_resampler_create": (_i32, [_vp, _pp]),
     "rmclhip_resampler_destroy": (None, [_vp]),
     "rmclhip_resampler_compute_stats": (_i32, [_vp, _vp, _u32, C.POINTER(LikelihoodStats)]),
+    "rmclhip_resampler_compute_stats_weights": (_i32, [_vp, _vp, _u32, C.POINTER(LikelihoodStats)]),
     "rmclhip_resampler_gladiator": (_i32, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, C.POINTER(GladiatorConfig),
                                             C.c_uint64, _u32]),
     "rmclhip_resampler_residual": (_i32, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, _u32, C.POINTER(GladiatorConfig),
                                            C.c_uint64, _u32, C.POINTER(C.c_uint64)]),
     "rmclhip_comm_create": (_i32, [_vp, _u32, _pp]),
     "rmclhip_comm_create_loopback": (_i32, [_vp, _u32, _pp]),
+    "rmclhip_comm_collective_ranks": (_i32, [_vp, C.POINTER(_u32), C.POINTER(_i32)]),
+    "rmclhip_comm_loopback_set_reduce_rotation": (_i32, [_vp, _u32]),
     "rmclhip_debug_tag_retries": (_i32, [C.POINTER(C.c_ulonglong)]),
     "rmclhip_debug_trace": (_i32, [_i32, _vp, _sz]),
     "rmclhip_comm_destroy": (None, [_vp]),

@@ -138,6 +138,7 @@ struct RcclApi {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
 };
 static RcclApi g_rccl;
 
@@ -153,7 +154,7 @@ static bool rccl_load(std::string& err) {
   if (!g_rccl.field) { err = std::string("librccl lacks ") + name; dlclose(lib); return false; }
   RCCL_SYM(CommInitAll, "ncclCommInitAll") RCCL_SYM(CommDestroy, "ncclCommDestroy") RCCL_SYM(AllGather, "ncclAllGather")
   RCCL_SYM(AllReduce, "ncclAllReduce") RCCL_SYM(GroupStart, "ncclGroupStart") RCCL_SYM(GroupEnd, "ncclGroupEnd")
-  RCCL_SYM(GetErrorString, "ncclGetErrorString")
+  RCCL_SYM(GetErrorString, "ncclGetErrorString") RCCL_SYM(CommCount, "ncclCommCount")
 #undef RCCL_SYM
   g_rccl.lib = lib;
   return true;
@@ -175,6 +176,7 @@ struct rmclhip_comm {
   // paths of the sharded entry points run -- and are checked against the unsharded results -- on a box with ONE GPU.
   bool loopback = false;
   std::vector<hipEvent_t> ev_in, ev_out;
+  uint32_t reduce_rotation = 0;   // loopback only (rmclhip_comm_loopback_set_reduce_rotation): the all-reduce adds the ranks starting at this one
 };
 
 // debug trace of the sharded entry points (rmclhip_debug_trace): "E<r>" = rank r's work of a phase enqueued, "W<r>" = the host waited
@@ -237,6 +239,7 @@ struct rmclhip_pf_sharded {
   uint32_t n_total = 0, cap = 0;
   std::vector<PfRank> ranks;
   rmclhip_pf_params params{2.0f, 100.0f, 100.0f, 0.0f, {0.05f, 80.0f}, 10000u, 0u};
+  bool weights_fresh = false;   // every rank's d_w_all holds the likelihoods of the cloud as it is (set by the all-gather, cleared by whatever rewrites attributes)
 };
 
 
@@ -369,9 +372,13 @@ static rmclhip_status comm_allreduce_f64(rmclhip_comm* c, const double* const* s
     return RMCLHIP_OK;
   }
   HIPCHK(loopback_barrier(c, c->ev_in));
+  // (RCCL chooses its own order of summation; the stand-in can be told to choose another one -- a result that must not depend on the
+  // library's order is tested by rotating it)
+  std::vector<const double*> rot(world);
+  for (uint32_t k = 0; k < world; ++k) rot[k] = send[(k + c->reduce_rotation) % world];
   for (uint32_t r = 0; r < world; ++r) {
     HIPCHK(hipSetDevice(c->devices[r]));
-    HIPCHK(launch_loopback_allreduce(send, world, recv[r], count, is_max, c->streams[r]));
+    HIPCHK(launch_loopback_allreduce(rot.data(), world, recv[r], count, is_max, c->streams[r]));
   }
   HIPCHK(loopback_barrier(c, c->ev_out));
   return RMCLHIP_OK;
@@ -383,6 +390,25 @@ static rmclhip_status comm_wait_all(rmclhip_comm* c) {
     HIPCHK(hipStreamSynchronize(c->streams[r]));
     trace('W', static_cast<uint32_t>(r));
   }
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_comm_loopback_set_reduce_rotation(rmclhip_comm* c, uint32_t first_rank) {
+  if (!c || !c->loopback) return fail(RMCLHIP_ERR_INVALID, "comm_loopback_set_reduce_rotation: a loopback communicator is needed");
+  c->reduce_rotation = first_rank % static_cast<uint32_t>(c->devices.size());
+  return RMCLHIP_OK;
+}
+
+/* how many ranks the communicator's collectives span: ncclCommCount of the first rank's communicator for RCCL, the rank list's size for
+ * the loopback stand-in (bench.py records it beside its sharded figures: a scaling run shows that RCCL saw N ranks) */
+rmclhip_status rmclhip_comm_collective_ranks(rmclhip_comm* c, uint32_t* n_ranks, int* is_rccl) {
+  if (!c || !n_ranks) return fail(RMCLHIP_ERR_INVALID, "comm_collective_ranks: null");
+  if (is_rccl) *is_rccl = c->loopback ? 0 : 1;
+  if (c->loopback) { *n_ranks = static_cast<uint32_t>(c->devices.size()); return RMCLHIP_OK; }
+  int cnt = 0;
+  if (g_rccl.CommCount == nullptr) return fail(RMCLHIP_ERR_UNSUPPORTED, "comm_collective_ranks: ncclCommCount not resolved");
+  NCCLCHK(g_rccl.CommCount(c->comms[0], &cnt));
+  *n_ranks = static_cast<uint32_t>(cnt);
   return RMCLHIP_OK;
 }
 
@@ -467,6 +493,7 @@ rmclhip_status rmclhip_pf_sharded_set_particles(rmclhip_pf_sharded* h, const rmc
                                                 const rmclhip_particle_attributes* attrs, uint32_t n_total) {
   ApiGuard guard_("rmclhip_pf_sharded_set_particles");
   if (!h || (n_total && (!poses || !attrs))) return fail(RMCLHIP_ERR_INVALID, "pf_sharded_set_particles: null");
+  h->weights_fresh = false;
   const uint32_t world = static_cast<uint32_t>(h->ranks.size());
   const uint32_t cap = (n_total + world - 1u) / world;
   for (uint32_t r = 0; r < world; ++r) {
@@ -542,7 +569,9 @@ rmclhip_status rmclhip_pf_allgather_weights(rmclhip_pf_sharded* h) {
     HIPCHK(launch_compact_shards(R.d_w_pad, R.d_w_all, h->n_total, world, cap, h->comm->streams[r]));
     trace('E', r);
   }
-  return comm_wait_all(h->comm);
+  if (rmclhip_status st = comm_wait_all(h->comm)) return st;
+  h->weights_fresh = true;
+  return RMCLHIP_OK;
 }
 
 // PCDSensorUpdater*::update on every device's block of the particles (concurrently: one stream per device), then the
@@ -551,6 +580,7 @@ rmclhip_status rmclhip_pf_update_sharded(rmclhip_pf_sharded* h, const rmclhip_ra
                                          const rmclhip_transform* Tsb) {
   ApiGuard guard_("rmclhip_pf_update_sharded");
   if (!h || !Tsb || (n_beams && !beams)) return fail(RMCLHIP_ERR_INVALID, "pf_update_sharded: null");
+  h->weights_fresh = false;
   trace_mark("update:");
   for (size_t r = 0; r < h->ranks.size(); ++r) {
     PfRank& R = h->ranks[r];
@@ -575,6 +605,7 @@ rmclhip_status rmclhip_pf_allreduce_stats(rmclhip_pf_sharded* h, rmclhip_likelih
 // 207-221): one k_pf_motion per rank on that rank's update stream.  `wait`: false leaves the launches in flight -- the sensor update of
 // the same cycle is enqueued behind them on the same streams (rmclhip_pf_sharded_step).
 static rmclhip_status pf_sharded_motion_enqueue(rmclhip_pf_sharded* h, const rmclhip_transform* T_bnew_bold, double forget_rate, int check_collision) {
+  h->weights_fresh = false;   // (a particle that crosses a wall gets likelihood {0, 0, MAX})
   for (size_t r = 0; r < h->ranks.size(); ++r) {
     PfRank& R = h->ranks[r];
     if (R.hi == R.lo) continue;
@@ -665,14 +696,32 @@ static rmclhip_status sharded_moments(rmclhip_pf_sharded* h, uint32_t n_use, int
   return RMCLHIP_OK;
 }
 
-// global {sum, max} of the likelihoods: the distributed form of simple_stats_kernel (resampling.cu:41-92)
+// global {sum, max} of the likelihoods (simple_stats_kernel, resampling.cu:41-92; consumer rmcl_localization.cpp:664-689 and the residual
+// resampler's size_t(L / sum * N)).  Round 6: NO collective -- after the weight all-gather every rank holds all N likelihoods, so every
+// rank reduces its own copy with the single-device kernel (same blocks, same order: the value is the single-device value bit for bit
+// whatever library moved the weights, and does not depend on a reduction order RCCL is free to choose).  The name is kept for the ABI.
+// A cloud whose attributes changed since the last gather (set_particles, motion update, resampling) is gathered first.
 rmclhip_status rmclhip_pf_allreduce_stats(rmclhip_pf_sharded* h, rmclhip_likelihood_stats* out) {
   ApiGuard guard_("rmclhip_pf_allreduce_stats");
   if (!h || !out) return fail(RMCLHIP_ERR_INVALID, "pf_allreduce_stats: null");
-  double m[32];
-  if (rmclhip_status st = sharded_moments(h, h->n_total, 0, 1.0, xidentity(), m)) return st;
-  out->sum = static_cast<float>(m[0]);
-  out->max = static_cast<float>(std::max(m[24], 0.0));   // seeded with 0 like the reference's shared-memory init
+  if (h->n_total == 0) { out->sum = 0.f; out->max = 0.f; return RMCLHIP_OK; }
+  if (!h->weights_fresh)
+    if (rmclhip_status st = rmclhip_pf_allgather_weights(h)) return st;
+  const uint32_t world = static_cast<uint32_t>(h->ranks.size());
+  for (uint32_t r = 0; r < world; ++r) {
+    PfRank& R = h->ranks[r];
+    HIPCHK(hipSetDevice(R.ctx->device));
+    HIPCHK(launch_likelihood_stats_dense(R.d_w_all, h->n_total, R.rs->d_psum.p, R.rs->d_pmax.p, R.rs->d_out.p, h->comm->streams[r]));
+    trace('E', r);
+  }
+  // the host needs ONE copy: rank 0's (the other ranks keep theirs on the device, ordered on their streams)
+  PfRank& R0 = h->ranks[0];
+  HIPCHK(hipSetDevice(R0.ctx->device));
+  HIPCHK(hipMemcpyAsync(R0.rs->h_out, R0.rs->d_out.p, 2 * sizeof(float), hipMemcpyDeviceToHost, h->comm->streams[0]));
+  HIPCHK(hipStreamSynchronize(h->comm->streams[0]));
+  trace('W', 0u);
+  out->sum = R0.rs->h_out[0];
+  out->max = R0.rs->h_out[1];
   return RMCLHIP_OK;
 }
 
@@ -756,6 +805,7 @@ static rmclhip_status pf_sharded_resample_impl(rmclhip_pf_sharded* h, const rmcl
                                               bool residual) {
   if (!h || !cfg) return fail(RMCLHIP_ERR_INVALID, "pf_sharded_resample: null");
   if (h->n_total == 0) return RMCLHIP_OK;
+  h->weights_fresh = false;   // the cloud is about to be replaced
   const uint32_t world = static_cast<uint32_t>(h->ranks.size()), cap = (h->n_total + world - 1u) / world;
   // a ragged partition (n_total not a multiple of the number of devices): the all-gather needs equal counts, so the padded shards
   // land in a second buffer and one kernel per record type squeezes the padding out (68 B x N read + written once more per rank)

@@ -261,6 +261,28 @@ rmclhip_status rmclhip_pf_time_update(rmclhip_pf* f, const rmclhip_transform* po
   return RMCLHIP_OK;
 }
 
+rmclhip_status rmclhip_pf_time_update_unfused(rmclhip_pf* f, const rmclhip_transform* poses, rmclhip_particle_attributes* attrs, uint32_t n,
+                                              const rmclhip_range_measurement* beams, uint32_t n_beams, const rmclhip_transform* Tsb,
+                                              int sync_each_beam, uint32_t iters, float* ms) {
+  ApiGuard guard_("rmclhip_pf_time_update_unfused");
+  if (!f || !ms || iters == 0 || !Tsb || !poses || !attrs || !beams || n == 0 || n_beams == 0)
+    return fail(RMCLHIP_ERR_INVALID, "pf_time_update_unfused: bad arguments");
+  auto sequence = [&]() -> rmclhip_status {
+    for (uint32_t b = 0; b < n_beams; ++b) {
+      const rmclhip_status st = sync_each_beam ? rmclhip_pf_update(f, poses, attrs, n, beams + b, 1u, Tsb)
+                                               : rmclhip_pf_update_async(f, poses, attrs, n, beams + b, 1u, Tsb);
+      if (st) return st;
+    }
+    return sync_each_beam ? RMCLHIP_OK : rmclhip_pf_sync(f);
+  };
+  if (rmclhip_status st = sequence()) return st;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t i = 0; i < iters; ++i)
+    if (rmclhip_status st = sequence()) return st;
+  *ms = static_cast<float>(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / iters);
+  return RMCLHIP_OK;
+}
+
 rmclhip_status rmclhip_pf_set_schedule(rmclhip_pf* f, uint32_t refill_idle_lanes, uint32_t tail_lanes) {
   ApiGuard guard_("rmclhip_pf_set_schedule");
   if (!f || refill_idle_lanes > 64u || tail_lanes > 64u) return fail(RMCLHIP_ERR_INVALID, "pf_set_schedule: bad arguments");
@@ -395,6 +417,18 @@ rmclhip_status rmclhip_resampler_compute_stats(rmclhip_resampler* r, const rmclh
   if (!r || !out || (!attrs_dev && n)) return fail(RMCLHIP_ERR_INVALID, "resampler_compute_stats: null");
   HIPCHK(hipSetDevice(r->ctx->device));
   HIPCHK(launch_likelihood_stats(attrs_dev, n, r->d_psum.p, r->d_pmax.p, r->d_out.p, r->stream));
+  HIPCHK(hipMemcpyAsync(r->h_out, r->d_out.p, 2 * sizeof(float), hipMemcpyDeviceToHost, r->stream));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  out->sum = r->h_out[0];
+  out->max = r->h_out[1];
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_resampler_compute_stats_weights(rmclhip_resampler* r, const float* weights_dev, uint32_t n, rmclhip_likelihood_stats* out) {
+  ApiGuard guard_("rmclhip_resampler_compute_stats_weights");
+  if (!r || !out || (!weights_dev && n)) return fail(RMCLHIP_ERR_INVALID, "resampler_compute_stats_weights: null");
+  HIPCHK(hipSetDevice(r->ctx->device));
+  HIPCHK(launch_likelihood_stats_dense(weights_dev, n, r->d_psum.p, r->d_pmax.p, r->d_out.p, r->stream));
   HIPCHK(hipMemcpyAsync(r->h_out, r->d_out.p, 2 * sizeof(float), hipMemcpyDeviceToHost, r->stream));
   HIPCHK(hipStreamSynchronize(r->stream));
   out->sum = r->h_out[0];

@@ -297,6 +297,9 @@ hipError_t launch_gladiator_resample(const xform* poses, const void* attrs, uint
                                      uint64_t seed, uint32_t step, hipStream_t s);
 // psum / pmax: scratch of 256 entries each; out2: {sum, max} (device)
 hipError_t launch_likelihood_stats(const void* attrs, uint32_t n, double* psum, float* pmax, float* out2, hipStream_t s);
+// the same {sum, max} of a DENSE weight vector (the gathered likelihood.mean of a sharded cloud): bit-identical to the call above on
+// attributes that hold the same n values
+hipError_t launch_likelihood_stats_dense(const float* weights, uint32_t n, double* psum, float* pmax, float* out2, hipStream_t s);
 hipError_t launch_pointcloud2_unpack(const uint8_t* data, uint32_t point_step, uint32_t row_step, uint32_t off_x,
                                      uint32_t off_y, uint32_t off_z, bool is_f64, uint32_t h_skip, uint32_t h_inc,
                                      uint32_t w_skip, uint32_t w_inc, uint32_t out_w, uint32_t out_h, float range_min,

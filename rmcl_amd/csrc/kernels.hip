@@ -2139,14 +2139,17 @@ __global__ void __launch_bounds__(256) k_residual_fill(const xform* __restrict__
 
 // simple_stats_kernel (resampling.cu:41-81): {sum, max} of likelihood.mean; max seeded with 0 like the reference's
 // shared-memory init, sum accumulated in double.  Stage 1: <=256 blocks of grid-stride partials; stage 2: one wave.
-__global__ void __launch_bounds__(256) k_likelihood_stats_partial(const pattrs* __restrict__ attrs, uint32_t n,
+// likelihoods: `first` + i * stride floats -- the likelihood.mean members of an attribute array (stride 9) or a dense weight vector
+// (stride 1: what the sharded filter's all-gather leaves on every rank); the summation order depends on n alone, so both forms of the
+// same n values give the same bits
+__global__ void __launch_bounds__(256) k_likelihood_stats_partial(const float* __restrict__ first, uint32_t stride, uint32_t n,
                                                                   double* __restrict__ psum, float* __restrict__ pmax) {
   __shared__ double s_sum[4];
   __shared__ float s_max[4];
   double sum = 0.0;
   float mx = 0.0f;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const float L = attrs[i].likelihood.mean;
+    const float L = first[static_cast<size_t>(i) * stride];
     sum += static_cast<double>(L);
     mx = (L > mx) ? L : mx;
   }
@@ -2976,7 +2979,7 @@ hipError_t launch_residual_prepare(const void* attrs, uint32_t n, uint32_t n_new
   uint32_t nblocks = (n + 1023u) / 1024u;
   if (nblocks < 1u) nblocks = 1u;
   if (nblocks > 256u) nblocks = 256u;
-  hipLaunchKernelGGL(k_likelihood_stats_partial, dim3(nblocks), dim3(256), 0, s, reinterpret_cast<const pattrs*>(attrs), n, psum, pmax);
+  hipLaunchKernelGGL(k_likelihood_stats_partial, dim3(nblocks), dim3(256), 0, s, reinterpret_cast<const float*>(attrs), 9u, n, psum, pmax);
   hipLaunchKernelGGL(k_residual_stats_final, dim3(1), dim3(64), 0, s, psum, pmax, nblocks, reinterpret_cast<ResidualStats*>(stats));
   hipLaunchKernelGGL(k_residual_expect, dim3(nblocks), dim3(256), 0, s, reinterpret_cast<const pattrs*>(attrs), n, n_new,
                      reinterpret_cast<ResidualStats*>(stats));
@@ -3014,8 +3017,17 @@ hipError_t launch_likelihood_stats(const void* attrs, uint32_t n, double* psum, 
   uint32_t nblocks = (n + 1023u) / 1024u;
   if (nblocks < 1u) nblocks = 1u;
   if (nblocks > 256u) nblocks = 256u;
-  hipLaunchKernelGGL(k_likelihood_stats_partial, dim3(nblocks), dim3(256), 0, s, reinterpret_cast<const pattrs*>(attrs), n,
-                     psum, pmax);
+  static_assert(sizeof(pattrs) == 36 && offsetof(pattrs, likelihood) == 0, "likelihood.mean is the first float of a 9-float record");
+  hipLaunchKernelGGL(k_likelihood_stats_partial, dim3(nblocks), dim3(256), 0, s, reinterpret_cast<const float*>(attrs), 9u, n, psum, pmax);
+  hipLaunchKernelGGL(k_likelihood_stats_final, dim3(1), dim3(64), 0, s, psum, pmax, nblocks, out2);
+  return hipGetLastError();
+}
+
+hipError_t launch_likelihood_stats_dense(const float* weights, uint32_t n, double* psum, float* pmax, float* out2, hipStream_t s) {
+  uint32_t nblocks = (n + 1023u) / 1024u;   // the rule of launch_likelihood_stats: same blocks, same order, same bits
+  if (nblocks < 1u) nblocks = 1u;
+  if (nblocks > 256u) nblocks = 256u;
+  hipLaunchKernelGGL(k_likelihood_stats_partial, dim3(nblocks), dim3(256), 0, s, weights, 1u, n, psum, pmax);
   hipLaunchKernelGGL(k_likelihood_stats_final, dim3(1), dim3(64), 0, s, psum, pmax, nblocks, out2);
   return hipGetLastError();
 }

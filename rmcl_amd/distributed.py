@@ -69,9 +69,24 @@ def allgather_weights(local_weights, n_total, group=None):
     return _GatherBuffers.get(n_total, world, local_weights.device, torch.float32).gather(local_weights, group)
 
 
+def gathered_sum_max(weights_all, stats_fn=None):
+    """global {sum, max} of the weights WITHOUT a second collective (round 6): after the all-gather every rank holds the whole
+    vector and reduces it itself, in a fixed order -- every rank gets the same bits, and they do not depend on the order in which a
+    collective library would have added per-rank partials (the value feeds size_t(L / sum * N) in the residual resampler,
+    resampling.cu:41-92, ResidualResamplerCPU.cpp:112-118).  stats_fn(weights_all, n) -> {"sum", "max"}: the device kernel
+    (GladiatorResamplerHip.compute_stats_weights: the single-GPU statistics bit for bit); None: numpy on the host (CPU tests)."""
+    n = int(weights_all.shape[0])
+    if stats_fn is not None:
+        st = stats_fn(weights_all, n)
+        return float(st["sum"]), float(st["max"])
+    w = weights_all.detach().cpu().numpy() if hasattr(weights_all, "detach") else np.asarray(weights_all)
+    return float(np.float32(w.astype(np.float64).sum())), float(max(np.float32(0.0), w.max())) if n else (0.0, 0.0)
+
+
 def allreduce_sum_max(local_weights, group=None):
-    """global {sum, max} of the weights: the distributed form of the reference's simple_stats_kernel
-    (rmcl_ros/src/rmcl/resampling.cu:41-92), two tiny all-reduces."""
+    """(rounds 2-5, kept for A/B) global {sum, max} as two tiny all-reduces of per-rank partials: the sum then depends on the
+    collective library's order of summation -- gathered_sum_max does not.
+    The distributed form of the reference's simple_stats_kernel (rmcl_ros/src/rmcl/resampling.cu:41-92)."""
     import torch
     import torch.distributed as dist
     s = local_weights.to(torch.float64).sum().reshape(1)

@@ -154,6 +154,18 @@ class PCDSensorUpdaterHip:
                                                        _ptr(self._Tsb), int(iters), C.byref(ms)))
         return ms.value
 
+    def time_update_unfused(self, particle_poses, particle_attrs, n_particles, sync_each_beam=True, iters=2):
+        """the reference's GPU schedule as a comparator (PCDSensorUpdaterOptix.cpp:319-338): one single-beam update per beam, synchronised
+        after each (or only at the end); host-clock ms per sequence of all beams (rmclhip_pf_time_update_unfused)"""
+        if not self._h:
+            self.init()
+        self._push_params()
+        ms = C.c_float(0)
+        _capi.check(_capi.lib().rmclhip_pf_time_update_unfused(self._h, _as_ptr(particle_poses), _as_ptr(particle_attrs), int(n_particles),
+                                                               _ptr(self._beams), len(self._beams), _ptr(self._Tsb),
+                                                               1 if sync_each_beam else 0, int(iters), C.byref(ms)))
+        return ms.value
+
     def set_variant(self, v):
         if not self._h:
             self.init()
@@ -214,6 +226,14 @@ class GladiatorResamplerHip:
         out = _capi.LikelihoodStats()
         _capi.check(_capi.lib().rmclhip_resampler_compute_stats(self._h, _as_ptr(particle_attrs), int(n_particles),
                                                                 C.byref(out)))
+        return {"sum": out.sum, "max": out.max}
+
+    def compute_stats_weights(self, weights, n):
+        """{sum, max} of a dense float32 weight vector on the device (the all-gathered likelihood.mean of a sharded cloud): the bits
+        compute_stats gives for attributes holding the same values (rmclhip_resampler_compute_stats_weights)"""
+        self.init()
+        out = _capi.LikelihoodStats()
+        _capi.check(_capi.lib().rmclhip_resampler_compute_stats_weights(self._h, _as_ptr(weights), int(n), C.byref(out)))
         return {"sum": out.sum, "max": out.max}
 
     def update(self, particle_poses, particle_attrs, particle_poses_new, particle_attrs_new, n_particles,
@@ -342,9 +362,21 @@ class ShardedParticleFilterHip:
         return w
 
     def stats(self):
+        """{sum, max} of the likelihoods: every device reduces ITS copy of the gathered weights in the single-device kernel's order
+        (no collective since round 6: rmclhip_pf_allreduce_stats)"""
         st = _capi.LikelihoodStats()
         _capi.check(_capi.lib().rmclhip_pf_allreduce_stats(self._h, C.byref(st)))
         return {"sum": st.sum, "max": st.max}
+
+    def collective_ranks(self):
+        """(ranks the collective library itself reports for this communicator -- ncclCommCount --, "rccl" | "loopback")"""
+        n, is_rccl = C.c_uint32(0), C.c_int(0)
+        _capi.check(_capi.lib().rmclhip_comm_collective_ranks(self._comm, C.byref(n), C.byref(is_rccl)))
+        return n.value, ("rccl" if is_rccl.value else "loopback")
+
+    def set_loopback_reduce_rotation(self, first_rank):
+        """TEST knob (loopback communicators): the all-reduce adds the ranks starting at first_rank (include/rmclhip_lab.h)"""
+        _capi.check(_capi.lib().rmclhip_comm_loopback_set_reduce_rotation(self._comm, int(first_rank)))
 
     def pose_estimate(self, max_induction_particles=0xFFFFFFFF):
         e = _capi.PoseEstimate()

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(ra):
     # the public header carries no diagnostics, experiments or measurement loops (round 5: the timing entry points moved to rmclhip_bench.h)
     assert not [n for n in names if "debug" in n or "lab" in n or "_time_" in n or "kernel_ms" in n or "kernel_timing" in n]
     bench_names = _declared_symbols("rmclhip_bench.h")
-    assert "rmclhip_rcc_time_find" in bench_names and "rmclhip_pf_time_update" in bench_names and len(bench_names) == 9
+    assert "rmclhip_rcc_time_find" in bench_names and "rmclhip_pf_time_update" in bench_names and "rmclhip_pf_time_update_unfused" in bench_names and len(bench_names) == 10
     assert not [n for n in bench_names if not hasattr(L, n)]
     # the experiments' header: its two instrumentation entry points are exported by the product library (they need the handle's
     # internals; they report UNSUPPORTED until librmclhip_lab.so is loaded), the rest by the experiments library itself

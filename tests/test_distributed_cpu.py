@@ -62,12 +62,16 @@ def _worker(rank, world, port, n_total, out_dir):
             local_attrs = attrs[lo:hi].copy()
             gathered = sharded.update(poses[lo:hi], local_attrs, w_local)
         ssum, smax = D.allreduce_sum_max(w_local)
+        # round 6: the statistics every rank computes ITSELF from the gathered vector (no second collective): identical on every rank by
+        # construction, equal to the unsharded cloud's
+        gsum, gmax = D.gathered_sum_max(gathered[:n_total])
         # unsharded reference on every rank
         ref = attrs.copy()
         m.pf_update(poses, ref, beams, Tsb, orc.pf_params(), bvh=True)
         ok = np.array_equal(gathered.numpy(), ref["likelihood"]["mean"])
         ok &= abs(ssum - float(ref["likelihood"]["mean"].astype(np.float64).sum())) < 1e-6
         ok &= smax == float(ref["likelihood"]["mean"].max())
+        ok &= gsum == float(np.float32(ref["likelihood"]["mean"].astype(np.float64).sum())) and gmax == float(max(np.float32(0), ref["likelihood"]["mean"].max()))
         ok &= gathered.numel() == n_total
         # distributed gladiator tournament == the unsharded one (Philox counter = global champion index)
         cfg = orc.gladiator_config(min_noise_roll=0.01)
