@@ -19,6 +19,7 @@ stats workload_pf_c4 python bench.py --workload pf --steps 20 --warmup 3 --no-ex
 stats workload_pf_c5_shard python tools/pf_c5_shard.py 20
 stats workload_room100k_find python tools/find_variants.py 23
 stats full_bench python bench.py --no-cpu-baseline
+cp profiles/traffic.json $O/traffic_r06.json
 bash tools/pmc_traffic.sh r06 > $O/traffic_passes.log 2>&1
 python tools/traffic_from_pmc.py gpurun_out/traffic_r06 $O/traffic_r06.json > $O/traffic_summary.txt 2>&1
 rm -rf gpurun_out/traffic_r06
