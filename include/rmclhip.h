@@ -127,7 +127,8 @@ typedef struct {
 typedef struct {
   uint32_t n_faces, n_vertices;
   uint32_t n_nodes;        /* BVH4 nodes (128 B each) */
-  uint32_t n_tri_records;  /* == n_faces (64 B each, leaf order) */
+  uint32_t n_tri_records;  /* 64 B each, leaf order; >= n_faces: a face that the builder's spatial splits reference from k leaves has k
+                            * identical records (round 6; == n_faces for maps no spatial split touched) */
   uint32_t max_depth;      /* BVH4 depth */
   uint32_t stack_need;     /* worst-case traversal stack entries */
   uint64_t device_bytes;
@@ -136,6 +137,10 @@ typedef struct {
      micp_localization.cpp:187-195).  These two count how often the bound had to be enforced -- 0 on ordinary meshes: object-median
      splits forced by the height budget of the binary tree, and BVH4 nodes expanded tallest-child-first instead of largest-area-first */
   uint32_t height_fallbacks, guarded_nodes;
+  /* round 6: spatial splits (SBVH) the builder took: nodes cut by a plane, a straddling triangle referenced from both sides with the box
+   * of its part there.  0 on regular meshes (the object split is kept unless the spatial one is >= 10 % cheaper); CAD-like mixes of
+   * huge and tiny triangles and slivers get them, within a budget of extra records (n_tri_records - n_faces). */
+  uint32_t spatial_splits, reserved;
 } rmclhip_map_info;
 
 typedef struct rmclhip_ctx rmclhip_ctx;
@@ -215,7 +220,7 @@ rmclhip_status rmclhip_scene_flatten_host(const rmclhip_mesh* meshes, uint32_t n
                                           size_t first_face_cap, uint32_t* n_vertices, uint32_t* n_faces);
 
 /* Host-only BVH build (no device needed): fills caller buffers with the exact
- * arrays map_create uploads.  nodes: n_nodes*32 dwords, tris: n_faces*16 dwords.
+ * arrays map_create uploads.  nodes: n_nodes*32 dwords, tris: n_tri_records*16 dwords.
  * Pass NULL buffers to query sizes via info.  Used by the CPU tests to check the
  * builder's invariants without a GPU. */
 rmclhip_status rmclhip_bvh_build_host(const float* vertices_xyz, uint32_t n_vertices,

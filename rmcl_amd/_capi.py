@@ -89,7 +89,7 @@ class MapInfo(C.Structure):
     _fields_ = [("n_faces", C.c_uint32), ("n_vertices", C.c_uint32), ("n_nodes", C.c_uint32),
                 ("n_tri_records", C.c_uint32), ("max_depth", C.c_uint32), ("stack_need", C.c_uint32),
                 ("device_bytes", C.c_uint64), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3),
-                ("height_fallbacks", C.c_uint32), ("guarded_nodes", C.c_uint32)]
+                ("height_fallbacks", C.c_uint32), ("guarded_nodes", C.c_uint32), ("spatial_splits", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class BundleViews(C.Structure):

@@ -389,6 +389,488 @@ struct Builder {
   }
 };
 
+// RMCLHIP_SBVH_ALPHA (study knob, read once per process): extra references the spatial splits may create, as a multiple of the face
+// count; 0 = object splits only (the builder of rounds 1-5)
+static double sbvh_alpha_from_env() {
+  const char* e = std::getenv("RMCLHIP_SBVH_ALPHA");
+  return e ? std::max(0.0, std::min(64.0, std::atof(e))) : 1.0;
+}
+static double sbvh_alpha() {
+  static const double a = sbvh_alpha_from_env();
+  return a;
+}
+constexpr uint32_t kSbvhMaxFaces = 4000000u;   // larger maps: the in-place builder, object splits only
+constexpr int64_t kSbvhFloor = 0;              // (an absolute floor of extra references for small maps was tried: a 20 k sliver fan took 37 x its records for 1.8 x; RMCLHIP_SBVH_ALPHA is the knob for such maps)
+
+// ---------------------------------------------------------------------------------------------
+// SBVH (round 6): the same top-down builder with SPATIAL splits (Stich, Friedrich, Dietrich: "Spatial splits in bounding volume
+// hierarchies", HPG 2009).  An object split puts every primitive whole into one child: triangles that are long against their
+// neighbours (CAD walls among scanned detail, slivers) give children whose boxes overlap, and a ray through the overlap walks both.
+// A spatial split cuts the node's box by a plane and REFERENCES a straddling triangle from both children, each with the box of its
+// part on that side: tighter boxes for more references.  Per node:
+//   * the object split of Builder::split, decision for decision (same bins over the centroid bounds, same cost loop, same fallbacks),
+//     so that a node which takes no spatial split has the children the plain builder gives it;
+//   * if that split's children overlap by more than kSbvhOverlap of the root's area: kBins spatial bins per axis over the NODE's box;
+//     every reference is chopped into the bins it spans (the triangle clipped to the bin's slab, intersected with the reference's
+//     own box), entering the bin it starts in and leaving the bin it ends in; the cheapest plane by the same SAH;
+//   * the spatial split is taken when it is cheaper than kSbvhGain x the object split, fits the node's share of the reference budget
+//     and makes progress; a straddling reference is then split, or -- "unsplitting" -- put whole into one child when that is cheaper.
+// Reference budget: alpha x n_faces extra references for the whole tree (at least kSbvhFloor: small maps may afford what their worst
+// triangles need), handed down the tree in proportion to the children's reference counts, so that the result does not depend on the
+// order in which subtrees are built (threads).  Leaves reference RECORDS: a face that is referenced k times has k identical 64-B
+// records (the kernels' tie rule -- min t, then min face id -- makes duplicates invisible).
+// ---------------------------------------------------------------------------------------------
+struct Ref { Box b; float c[3]; uint32_t face; };
+
+constexpr float kSbvhOverlap = 1.0e-5f;   // Stich et al.'s alpha: spatial splits only where the object split's children overlap noticeably
+constexpr float kSbvhGain = 0.90f;        // ... and only when they are at least 10 % cheaper: regular meshes keep the plain builder's tree
+
+struct SplitTask {
+  std::vector<Ref> refs;
+  int32_t node = 0;
+  uint32_t depth = 0;
+  int64_t budget = 0;       // extra references this subtree may still create
+  bool have_bounds = false;
+  Box nb, cb;
+};
+
+struct SplitBuilder {
+  const float* verts;
+  const uint32_t* faces;
+  uint32_t max_leaf;
+  int nthreads;
+  float root_area = 0.f;
+  std::vector<Node2> nodes;                       // leaves: first = index into `leaves` until finish() assigns the record ranges
+  std::vector<std::vector<uint32_t>> leaves;      // faces of every leaf, in face-id order
+  uint32_t height_fallbacks = 0;
+  uint64_t spatial_splits = 0, duplicates = 0;
+
+  SplitBuilder(const float* v, const uint32_t* f, uint32_t ml, int nt) : verts(v), faces(f), max_leaf(ml), nthreads(nt) {}
+
+  static int bin_of(float c, float cmin, float scale) {
+    int b = static_cast<int>((c - cmin) * scale);
+    return std::min(kBins - 1, std::max(0, b));
+  }
+  uint64_t cap(uint32_t h) const { return h >= 40 ? ~uint64_t{0} : static_cast<uint64_t>(max_leaf) << h; }
+
+  // bounds of the part of triangle `face` between the planes x_axis = lo and x_axis = hi (Sutherland-Hodgman on the two planes),
+  // intersected with `within`; empty (mn > mx) when nothing of the triangle lies there
+  Box clipped(uint32_t face, int axis, float lo, float hi, const Box& within) const {
+    float poly[8][3], tmp[8][3];
+    int n = 3;
+    for (int k = 0; k < 3; ++k) {
+      const float* p = verts + 3 * static_cast<size_t>(faces[3 * static_cast<size_t>(face) + k]);
+      poly[k][0] = p[0]; poly[k][1] = p[1]; poly[k][2] = p[2];
+    }
+    for (int side = 0; side < 2 && n > 0; ++side) {
+      const float plane = side == 0 ? lo : hi;
+      const float sgn = side == 0 ? 1.f : -1.f;      // keep sgn * (x - plane) >= 0
+      int m = 0;
+      for (int i = 0; i < n; ++i) {
+        const float* a = poly[i];
+        const float* b = poly[(i + 1) % n];
+        const float da = sgn * (a[axis] - plane), db = sgn * (b[axis] - plane);
+        if (da >= 0.f) { tmp[m][0] = a[0]; tmp[m][1] = a[1]; tmp[m][2] = a[2]; ++m; }
+        if ((da > 0.f && db < 0.f) || (da < 0.f && db > 0.f)) {
+          const float t = da / (da - db);
+          for (int k = 0; k < 3; ++k) tmp[m][k] = a[k] + t * (b[k] - a[k]);
+          tmp[m][axis] = plane;
+          ++m;
+        }
+      }
+      n = m;
+      for (int i = 0; i < n; ++i) { poly[i][0] = tmp[i][0]; poly[i][1] = tmp[i][1]; poly[i][2] = tmp[i][2]; }
+    }
+    Box r;
+    r.reset();
+    for (int i = 0; i < n; ++i) r.grow(poly[i]);
+    if (n > 0) {
+      // the interpolated vertices are rounded: widen by a few units in the last place of the coordinates involved before the
+      // intersection (the stored boxes get the scene's padding on top, bvh_build_impl); the cut itself stays exact
+      for (int k = 0; k < 3; ++k) {
+        if (k == axis) continue;
+        const float e = 4.f * FLT_EPSILON * std::max(std::fabs(r.mn[k]), std::fabs(r.mx[k]));
+        r.mn[k] -= e; r.mx[k] += e;
+      }
+      for (int k = 0; k < 3; ++k) { r.mn[k] = std::max(r.mn[k], within.mn[k]); r.mx[k] = std::min(r.mx[k], within.mx[k]); }
+      r.mn[axis] = std::max(r.mn[axis], std::max(lo, within.mn[axis]));
+      r.mx[axis] = std::min(r.mx[axis], std::min(hi, within.mx[axis]));
+    }
+    return r;
+  }
+  static bool empty(const Box& b) { return b.mn[0] > b.mx[0] || b.mn[1] > b.mx[1] || b.mn[2] > b.mx[2]; }
+  static void set_centre(Ref& r) { for (int k = 0; k < 3; ++k) r.c[k] = 0.5f * (r.b.mn[k] + r.b.mx[k]); }
+
+  struct Leaf { std::vector<uint32_t> faces; };
+
+  // splits one node: fills `node` (box), returns false for a leaf (its faces in leaf_out), else fills lt / rt (refs, bounds, budgets)
+  bool split(SplitTask& t, SplitTask& lt, SplitTask& rt, int nt, Node2& node, std::vector<uint32_t>& leaf_out, uint32_t& fallbacks,
+             uint64_t& n_spatial, uint64_t& n_dup) {
+    std::vector<Ref>& R = t.refs;
+    const uint32_t count = static_cast<uint32_t>(R.size());
+    if (!t.have_bounds) {
+      t.nb.reset(); t.cb.reset();
+      for (const Ref& r : R) { t.nb.grow(r.b); t.cb.grow(r.c); }
+    }
+    node.b = t.nb;
+    node.count = count;
+    if (count <= max_leaf) {
+      leaf_out.resize(count);
+      for (uint32_t i = 0; i < count; ++i) leaf_out[i] = R[i].face;
+      return false;
+    }
+    // ---- the object split (Builder::split) ----
+    const Box& cb = t.cb;
+    float scale[3];
+    bool use[3];
+    for (int a = 0; a < 3; ++a) {
+      const float ext = cb.mx[a] - cb.mn[a];
+      use[a] = ext > 0.f;
+      scale[a] = use[a] ? static_cast<float>(kBins) / ext : 0.f;
+    }
+    int best_axis = -1, best_bin = -1;
+    float best_cost = FLT_MAX;
+    Bins bins;
+    if (use[0] || use[1] || use[2]) {
+      bins.reset(kBins);
+      auto bin_range = [&](Bins& B, size_t a, size_t b) {
+        for (size_t i = a; i < b; ++i) {
+          const Ref& p = R[i];
+          for (int ax = 0; ax < 3; ++ax) {
+            if (!use[ax]) continue;
+            const int k = bin_of(p.c[ax], cb.mn[ax], scale[ax]);
+            B.cnt[ax][k]++;
+            B.box[ax][k].grow(p.b);
+            B.cen[ax][k].grow(p.c);
+          }
+        }
+      };
+      if (nt > 1) {
+        std::vector<Bins> part(nt);
+        parallel_chunks(count, nt, [&](int k, size_t a, size_t b) { part[k].reset(kBins); bin_range(part[k], a, b); });
+        for (int k = 0; k < nt; ++k) bins.merge(part[k], kBins);
+      } else {
+        bin_range(bins, 0, count);
+      }
+      for (int axis = 0; axis < 3; ++axis) {
+        if (!use[axis]) continue;
+        float la[kMaxBins - 1], ra[kMaxBins - 1];
+        uint32_t lc[kMaxBins - 1], rc[kMaxBins - 1];
+        Box acc;
+        acc.reset();
+        uint32_t c = 0;
+        for (int b = 0; b < kBins - 1; ++b) { acc.grow(bins.box[axis][b]); c += bins.cnt[axis][b]; la[b] = acc.area(); lc[b] = c; }
+        acc.reset();
+        c = 0;
+        for (int b = kBins - 1; b > 0; --b) { acc.grow(bins.box[axis][b]); c += bins.cnt[axis][b]; ra[b - 1] = acc.area(); rc[b - 1] = c; }
+        for (int b = 0; b < kBins - 1; ++b) {
+          if (lc[b] == 0 || rc[b] == 0) continue;
+          const float cost = la[b] * static_cast<float>(lc[b]) + ra[b] * static_cast<float>(rc[b]);
+          if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+        }
+      }
+    }
+    const uint32_t height_left = kMaxHeight2 - t.depth;
+    const uint64_t child_cap = cap(height_left - 1);
+    uint32_t nl = 0;
+    bool height_refused = false;
+    if (best_axis >= 0) {
+      for (int b = 0; b <= best_bin; ++b) nl += bins.cnt[best_axis][b];
+      if (nl > child_cap || count - nl > child_cap) { best_axis = -1; nl = 0; ++fallbacks; height_refused = true; }
+      else if (nl == 0 || nl == count) { best_axis = -1; nl = 0; }
+    }
+    // ---- a spatial split, where the object split's children overlap (or there is no object split at all) ----
+    bool spatial = false;
+    int s_axis = -1;
+    float s_plane = 0.f;
+    if (!height_refused && t.budget > 0 && root_area > 0.f) {
+      float overlap = FLT_MAX;
+      if (best_axis >= 0) {
+        Box lb, rb;
+        lb.reset(); rb.reset();
+        for (int b = 0; b < kBins; ++b) { if (bins.cnt[best_axis][b]) (b <= best_bin ? lb : rb).grow(bins.box[best_axis][b]); }
+        Box ov;
+        for (int k = 0; k < 3; ++k) { ov.mn[k] = std::max(lb.mn[k], rb.mn[k]); ov.mx[k] = std::min(lb.mx[k], rb.mx[k]); }
+        overlap = ov.area();
+      }
+      if (overlap > kSbvhOverlap * root_area) {
+        float sp_cost = FLT_MAX;
+        uint32_t sp_nl = 0, sp_nr = 0;
+        for (int axis = 0; axis < 3; ++axis) {
+          const float lo = t.nb.mn[axis], ext = t.nb.mx[axis] - lo;
+          if (!(ext > 0.f)) continue;
+          const float sc = static_cast<float>(kBins) / ext, width = ext / static_cast<float>(kBins);
+          struct SBins { Box bb[kMaxBins]; uint32_t en[kMaxBins], ex[kMaxBins]; };
+          auto sbin_range = [&](SBins& S, size_t i0, size_t i1) {
+            for (int b = 0; b < kBins; ++b) { S.bb[b].reset(); S.en[b] = S.ex[b] = 0; }
+            for (size_t i = i0; i < i1; ++i) {
+              const Ref& r = R[i];
+              const int b0 = bin_of(r.b.mn[axis], lo, sc), b1 = bin_of(r.b.mx[axis], lo, sc);
+              S.en[b0]++; S.ex[b1]++;
+              if (b0 == b1) { S.bb[b0].grow(r.b); continue; }
+              for (int b = b0; b <= b1; ++b) {
+                const float p0 = (b == 0) ? -FLT_MAX : lo + width * static_cast<float>(b);
+                const float p1 = (b == kBins - 1) ? FLT_MAX : lo + width * static_cast<float>(b + 1);
+                const Box part = clipped(r.face, axis, p0, p1, r.b);
+                if (!empty(part)) S.bb[b].grow(part);
+              }
+            }
+          };
+          SBins tot;
+          if (nt > 1) {
+            std::vector<SBins> part(nt);
+            parallel_chunks(count, nt, [&](int k, size_t a, size_t b) { sbin_range(part[k], a, b); });
+            tot = part[0];
+            for (int k = 1; k < nt; ++k)
+              for (int b = 0; b < kBins; ++b) { tot.bb[b].grow(part[k].bb[b]); tot.en[b] += part[k].en[b]; tot.ex[b] += part[k].ex[b]; }
+          } else {
+            sbin_range(tot, 0, count);
+          }
+          const Box* bb = tot.bb;
+          const uint32_t* en = tot.en;
+          const uint32_t* ex = tot.ex;
+          float la[kMaxBins - 1], ra[kMaxBins - 1];
+          uint32_t lc[kMaxBins - 1], rc[kMaxBins - 1];
+          Box acc;
+          acc.reset();
+          uint32_t c = 0;
+          for (int b = 0; b < kBins - 1; ++b) { acc.grow(bb[b]); c += en[b]; la[b] = acc.area(); lc[b] = c; }
+          acc.reset();
+          c = 0;
+          for (int b = kBins - 1; b > 0; --b) { acc.grow(bb[b]); c += ex[b]; ra[b - 1] = acc.area(); rc[b - 1] = c; }
+          for (int b = 0; b < kBins - 1; ++b) {
+            if (lc[b] == 0 || rc[b] == 0) continue;
+            const float cost = la[b] * static_cast<float>(lc[b]) + ra[b] * static_cast<float>(rc[b]);
+            if (cost < sp_cost) { sp_cost = cost; s_axis = axis; s_plane = lo + width * static_cast<float>(b + 1); sp_nl = lc[b]; sp_nr = rc[b]; }
+          }
+        }
+        const uint64_t dup = (s_axis >= 0 && static_cast<uint64_t>(sp_nl) + sp_nr > count) ? static_cast<uint64_t>(sp_nl) + sp_nr - count : 0u;
+        // (a child may be as large as its parent -- every reference straddling the plane: what chops a bundle of slivers --; the split
+        // then costs `count` references of the budget, which is what ends such a chain)
+        spatial = s_axis >= 0 && (best_axis < 0 || sp_cost < kSbvhGain * best_cost) && static_cast<int64_t>(dup) <= t.budget &&
+                  (dup > 0u || (sp_nl < count && sp_nr < count)) && sp_nl <= child_cap && sp_nr <= child_cap;
+      }
+    }
+    lt.have_bounds = rt.have_bounds = false;
+    lt.depth = rt.depth = t.depth + 1;
+    int64_t budget_left = t.budget;
+    if (spatial) {
+      // ---- perform it: references wholly on one side go there; a straddler is split -- or kept whole in one child when that is cheaper
+      Box lb, rb;
+      lb.reset(); rb.reset();
+      uint32_t n1 = 0, n2 = 0;
+      std::vector<uint8_t> where(count);   // 0 left, 1 right, 2 straddles
+      for (uint32_t i = 0; i < count; ++i) {
+        const Ref& r = R[i];
+        if (r.b.mx[s_axis] <= s_plane) { where[i] = 0; lb.grow(r.b); ++n1; }
+        else if (r.b.mn[s_axis] >= s_plane) { where[i] = 1; rb.grow(r.b); ++n2; }
+        else { where[i] = 2; ++n1; ++n2; }
+      }
+      // bounds of the halves of the straddlers first (their boxes enter both sides' bounds unless unsplit below)
+      std::vector<Box> lpart(count), rpart(count);
+      for (uint32_t i = 0; i < count; ++i) {
+        if (where[i] != 2) continue;
+        lpart[i] = clipped(R[i].face, s_axis, -FLT_MAX, s_plane, R[i].b);
+        rpart[i] = clipped(R[i].face, s_axis, s_plane, FLT_MAX, R[i].b);
+        if (empty(lpart[i]) && empty(rpart[i])) { lpart[i] = R[i].b; lpart[i].mx[s_axis] = s_plane; rpart[i] = R[i].b; rpart[i].mn[s_axis] = s_plane; }
+        if (empty(lpart[i])) { where[i] = 1; --n1; rb.grow(R[i].b); continue; }
+        if (empty(rpart[i])) { where[i] = 0; --n2; lb.grow(R[i].b); continue; }
+        lb.grow(lpart[i]); rb.grow(rpart[i]);
+      }
+      lt.refs.clear(); rt.refs.clear();
+      lt.refs.reserve(n1); rt.refs.reserve(n2);
+      for (uint32_t i = 0; i < count; ++i) {
+        const Ref& r = R[i];
+        if (where[i] == 0) { lt.refs.push_back(r); continue; }
+        if (where[i] == 1) { rt.refs.push_back(r); continue; }
+        // unsplitting (Stich et al., section 4.4), in list order: whole left / whole right / split
+        Box lu = lb, ru = rb;
+        lu.grow(r.b); ru.grow(r.b);
+        const float c_split = lb.area() * static_cast<float>(n1) + rb.area() * static_cast<float>(n2);
+        const float c_left = lu.area() * static_cast<float>(n1) + rb.area() * static_cast<float>(n2 - 1u);
+        const float c_right = lb.area() * static_cast<float>(n1 - 1u) + ru.area() * static_cast<float>(n2);
+        if (c_left < c_split && c_left <= c_right && n2 > 1u) { lb = lu; --n2; lt.refs.push_back(r); continue; }
+        if (c_right < c_split && n1 > 1u) { rb = ru; --n1; rt.refs.push_back(r); continue; }
+        Ref a = r, b = r;
+        a.b = lpart[i]; b.b = rpart[i];
+        set_centre(a); set_centre(b);
+        lt.refs.push_back(a); rt.refs.push_back(b);
+      }
+      const uint32_t a1 = static_cast<uint32_t>(lt.refs.size()), a2 = static_cast<uint32_t>(rt.refs.size());
+      const uint64_t dup_now = static_cast<uint64_t>(a1) + a2 > count ? static_cast<uint64_t>(a1) + a2 - count : 0u;
+      if (a1 == 0 || a2 == 0 || (dup_now == 0u && (a1 >= count || a2 >= count)) || static_cast<int64_t>(dup_now) > t.budget) {
+        spatial = false;   // no progress (unsplitting emptied a side): the object split instead
+      } else {
+        const uint64_t dup = static_cast<uint64_t>(a1) + a2 > count ? static_cast<uint64_t>(a1) + a2 - count : 0u;
+        budget_left -= static_cast<int64_t>(dup);
+        n_dup += dup;
+        ++n_spatial;
+      }
+    }
+    if (!spatial && best_axis >= 0) {
+      const float cmin = cb.mn[best_axis], sc = scale[best_axis];
+      lt.refs.clear(); rt.refs.clear();
+      lt.refs.reserve(nl); rt.refs.reserve(count - nl);
+      for (const Ref& r : R) (bin_of(r.c[best_axis], cmin, sc) <= best_bin ? lt.refs : rt.refs).push_back(r);
+      lt.nb.reset(); lt.cb.reset(); rt.nb.reset(); rt.cb.reset();
+      for (int b = 0; b < kBins; ++b) {
+        SplitTask& side = b <= best_bin ? lt : rt;
+        if (bins.cnt[best_axis][b] == 0) continue;
+        side.nb.grow(bins.box[best_axis][b]);
+        side.cb.grow(bins.cen[best_axis][b]);
+      }
+      lt.have_bounds = rt.have_bounds = true;
+    } else if (!spatial) {
+      // no SAH split at all, or the height budget refused it: object median (Builder::split's rule)
+      nl = count - count / 2;
+      int ax = 0;
+      float ext = -1.f;
+      for (int a = 0; a < 3; ++a) if (cb.mx[a] - cb.mn[a] > ext) { ext = cb.mx[a] - cb.mn[a]; ax = a; }
+      if (ext > 0.f) {
+        auto less = [&](const Ref& x, const Ref& y) { return x.c[ax] < y.c[ax] || (x.c[ax] == y.c[ax] && x.face < y.face); };
+        std::nth_element(R.begin(), R.begin() + nl, R.end(), less);
+        auto by_face = [](const Ref& x, const Ref& y) { return x.face < y.face; };
+        std::sort(R.begin(), R.begin() + nl, by_face);
+        std::sort(R.begin() + nl, R.end(), by_face);
+      } else {
+        nl = count / 2;
+      }
+      lt.refs.assign(R.begin(), R.begin() + nl);
+      rt.refs.assign(R.begin() + nl, R.end());
+    }
+    std::vector<Ref>().swap(R);
+    // the rest of the budget goes down in proportion to the children's reference counts
+    {
+      const uint64_t a1 = lt.refs.size(), a2 = rt.refs.size();
+      const int64_t bl = (a1 + a2) ? static_cast<int64_t>(static_cast<unsigned __int128>(static_cast<uint64_t>(std::max<int64_t>(budget_left, 0))) * a1 / (a1 + a2)) : 0;
+      lt.budget = bl;
+      rt.budget = std::max<int64_t>(budget_left, 0) - bl;
+    }
+    return true;
+  }
+
+  void build(std::vector<Ref>&& refs, int64_t budget) {
+    const uint32_t n = static_cast<uint32_t>(refs.size());
+    const uint32_t grain = nthreads > 1 ? std::max<uint32_t>(4096u, n / (static_cast<uint32_t>(nthreads) * 16u)) : 0xFFFFFFFFu;
+    nodes.clear();
+    nodes.emplace_back();
+    leaves.clear();
+    {
+      Box nb;
+      nb.reset();
+      for (const Ref& r : refs) nb.grow(r.b);
+      root_area = nb.area();
+    }
+    std::vector<SplitTask> big, small;
+    {
+      SplitTask root;
+      root.refs = std::move(refs);
+      root.node = 0; root.depth = 0; root.budget = budget;
+      (n > grain ? big : small).push_back(std::move(root));
+    }
+    auto store_leaf = [](std::vector<std::vector<uint32_t>>& store, Node2& nd, std::vector<uint32_t>& lf) {
+      nd.left = nd.right = -1;
+      nd.first = static_cast<uint32_t>(store.size());
+      store.push_back(std::move(lf));
+    };
+    // phase A: nodes above the grain, one at a time (the binning pass spread over the threads)
+    while (!big.empty()) {
+      SplitTask t = std::move(big.back());
+      big.pop_back();
+      SplitTask lt, rt;
+      Node2 nd;
+      std::vector<uint32_t> lf;
+      if (!split(t, lt, rt, nthreads, nd, lf, height_fallbacks, spatial_splits, duplicates)) { store_leaf(leaves, nd, lf); nodes[t.node] = nd; continue; }
+      const int32_t l = static_cast<int32_t>(nodes.size());
+      nd.left = l; nd.right = l + 1;
+      nodes[t.node] = nd;
+      nodes.emplace_back();
+      nodes.emplace_back();
+      lt.node = l; rt.node = l + 1;
+      const bool rbig = rt.refs.size() > grain, lbig = lt.refs.size() > grain;
+      (rbig ? big : small).push_back(std::move(rt));
+      (lbig ? big : small).push_back(std::move(lt));
+    }
+    // phase B: whole subtrees, one thread each, into local node arrays and local leaf stores
+    struct Local { std::vector<Node2> nodes; std::vector<std::vector<uint32_t>> leaves; uint32_t fb = 0; uint64_t sp = 0, dup = 0; };
+    std::vector<Local> local(small.size());
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+      for (;;) {
+        const size_t k = next.fetch_add(1);
+        if (k >= small.size()) break;
+        Local& L = local[k];
+        L.nodes.emplace_back();
+        std::vector<SplitTask> stack;
+        small[k].node = 0;
+        stack.push_back(std::move(small[k]));
+        while (!stack.empty()) {
+          SplitTask t = std::move(stack.back());
+          stack.pop_back();
+          SplitTask lt, rt;
+          Node2 nd;
+          std::vector<uint32_t> lf;
+          const int32_t me = t.node;
+          if (!split(t, lt, rt, 1, nd, lf, L.fb, L.sp, L.dup)) { store_leaf(L.leaves, nd, lf); L.nodes[me] = nd; continue; }
+          const int32_t l = static_cast<int32_t>(L.nodes.size());
+          nd.left = l; nd.right = l + 1;
+          L.nodes[me] = nd;
+          L.nodes.emplace_back();
+          L.nodes.emplace_back();
+          lt.node = l; rt.node = l + 1;
+          stack.push_back(std::move(rt));
+          stack.push_back(std::move(lt));
+        }
+      }
+    };
+    std::vector<int32_t> small_root(small.size());
+    for (size_t k = 0; k < small.size(); ++k) small_root[k] = small[k].node;
+    parallel_chunks(static_cast<size_t>(std::max<size_t>(std::min<size_t>(nthreads, small.size()), 1)),
+                    static_cast<int>(std::min<size_t>(nthreads, small.size())), [&](int, size_t, size_t) { worker(); });
+    // splice (serial: node and leaf indices are offset per subtree)
+    for (size_t k = 0; k < small.size(); ++k) {
+      const Local& L = local[k];
+      const int32_t shift = static_cast<int32_t>(nodes.size()) - 1;
+      const uint32_t lshift = static_cast<uint32_t>(leaves.size());
+      for (size_t i = 0; i < L.nodes.size(); ++i) {
+        Node2 nd = L.nodes[i];
+        if (nd.leaf()) nd.first += lshift;
+        else { nd.left += shift; nd.right += shift; }
+        if (i == 0) nodes[small_root[k]] = nd; else nodes.push_back(nd);
+      }
+      for (const auto& lf : L.leaves) leaves.push_back(lf);
+      height_fallbacks += L.fb; spatial_splits += L.sp; duplicates += L.dup;
+    }
+  }
+
+  // record order: the leaves left to right; every node's (first, count) = the contiguous record range of its subtree
+  void finish(std::vector<uint32_t>& record_face) {
+    record_face.clear();
+    struct It { int32_t node; bool done; };
+    std::vector<It> st{{0, false}};
+    while (!st.empty()) {
+      It it = st.back();
+      st.pop_back();
+      Node2& nd = nodes[it.node];
+      if (nd.leaf()) {
+        const std::vector<uint32_t>& lf = leaves[nd.first];
+        nd.first = static_cast<uint32_t>(record_face.size());
+        nd.count = static_cast<uint32_t>(lf.size());
+        record_face.insert(record_face.end(), lf.begin(), lf.end());
+        continue;
+      }
+      if (!it.done) {
+        st.push_back({it.node, true});
+        st.push_back({nd.right, false});
+        st.push_back({nd.left, false});
+      } else {
+        nd.first = nodes[nd.left].first;
+        nd.count = nodes[nd.left].count + nodes[nd.right].count;
+      }
+    }
+  }
+};
+
 inline void cross_fma(const float* a, const float* b, float* r) {
   r[0] = std::fmaf(a[1], b[2], -(a[2] * b[1]));
   r[1] = std::fmaf(a[2], b[0], -(a[0] * b[2]));
@@ -655,13 +1137,42 @@ static std::string build_bvh_impl(const float* verts, uint32_t nv, const uint32_
   }
 
   timer.mark("validate + primitive boxes");
-  // ONE BVH2, split down to the smallest leaf size any tree of the map uses
-  std::vector<uint32_t> order(nf);
-  for (uint32_t f = 0; f < nf; ++f) order[f] = f;
-  Builder bld(prims, order, std::min(max_leaf, kPfLeafTris), nt);
-  bld.build();
-  const std::vector<Node2>& n2 = bld.nodes;
-  std::vector<Prim>().swap(prims);
+  // ONE BVH2, split down to the smallest leaf size any tree of the map uses.  `order`: the face of every record, in leaf order.
+  // Maps of up to kSbvhMaxFaces faces are built with spatial splits (SplitBuilder above; RMCLHIP_SBVH_ALPHA = 0 switches them off);
+  // larger ones by the in-place builder (object splits only: its passes are spread over the threads, 10 M faces in ~2 s).
+  std::vector<uint32_t> order;
+  std::vector<Node2> n2_store;
+  uint32_t height_fallbacks = 0;
+  const double alpha = sbvh_alpha();
+  if (alpha > 0.0 && nf <= kSbvhMaxFaces) {
+    std::vector<Ref> refs(nf);
+    parallel_chunks(nf, nt, [&](int, size_t lo, size_t hi) {
+      for (size_t f = lo; f < hi; ++f) {
+        refs[f].b = prims[f].b;
+        for (int c = 0; c < 3; ++c) refs[f].c[c] = prims[f].c[c];
+        refs[f].face = static_cast<uint32_t>(f);
+      }
+    });
+    std::vector<Prim>().swap(prims);
+    SplitBuilder sb(verts, faces, std::min(max_leaf, kPfLeafTris), nt);
+    const int64_t budget = std::min<int64_t>(std::max<int64_t>(static_cast<int64_t>(alpha * static_cast<double>(nf)), kSbvhFloor),
+                                             static_cast<int64_t>(0x0FFFFFFF) - static_cast<int64_t>(nf));
+    sb.build(std::move(refs), budget);
+    sb.finish(order);
+    n2_store = std::move(sb.nodes);
+    height_fallbacks = sb.height_fallbacks;
+    out.info.spatial_splits = static_cast<uint32_t>(std::min<uint64_t>(sb.spatial_splits, 0xFFFFFFFFu));
+  } else {
+    order.resize(nf);
+    for (uint32_t f = 0; f < nf; ++f) order[f] = f;
+    Builder bld(prims, order, std::min(max_leaf, kPfLeafTris), nt);
+    bld.build();
+    n2_store = std::move(bld.nodes);
+    height_fallbacks = bld.height_fallbacks;
+    std::vector<Prim>().swap(prims);
+  }
+  const std::vector<Node2>& n2 = n2_store;
+  const size_t n_records = order.size();
   timer.mark("BVH2 (binned SAH)");
 
   // conservative padding of every stored box: the slab test runs in fp32 with fused ops and must
@@ -674,8 +1185,8 @@ static std::string build_bvh_impl(const float* verts, uint32_t nv, const uint32_
   const float pad = 1e-4f * std::max(diag, amax) + 1e-6f;
 
   // triangle records, written in leaf order
-  out.tris.resize(nf);
-  parallel_chunks(nf, nt, [&](int, size_t lo, size_t hi) {
+  out.tris.resize(n_records);
+  parallel_chunks(n_records, nt, [&](int, size_t lo, size_t hi) {
     for (size_t i = lo; i < hi; ++i) {
       const uint32_t f = order[i];
       const float* a = verts + 3 * static_cast<size_t>(faces[3 * static_cast<size_t>(f) + 0]);
@@ -726,7 +1237,7 @@ static std::string build_bvh_impl(const float* verts, uint32_t nv, const uint32_
   timer.mark("collapse (both cuts)");
   out.nodes = std::move(main_tree.nodes);
   quantise(out.nodes, out.qnodes, nt);
-  out.info.height_fallbacks = bld.height_fallbacks;
+  out.info.height_fallbacks = height_fallbacks;
   out.info.guarded_nodes = main_tree.guarded + pf_tree.guarded;
   if (own_pf_tree) {
     quantise(pf_tree.nodes, out.qnodes_pf, nt);
@@ -786,6 +1297,7 @@ static std::string build_bvh_impl(const float* verts, uint32_t nv, const uint32_
 
   timer.mark("frontier, child-major twins");
   out.info.n_faces = nf;
+  out.info.n_records = static_cast<uint32_t>(n_records);
   out.info.n_vertices = nv;
   out.info.n_nodes = static_cast<uint32_t>(out.nodes.size());
   out.info.max_depth = main_tree.max_depth;

@@ -19,6 +19,9 @@ struct BvhInfo {
   // round 5: how often the stack bound had to be enforced (0 on ordinary meshes): object-median splits the height budget of the BVH2
   // forced, and BVH4 nodes expanded tallest-child-first; stack_need <= 64 holds for every mesh by construction
   uint32_t height_fallbacks = 0, guarded_nodes = 0;
+  // round 6: spatial splits the builder took, and the triangle RECORDS they left (>= n_faces: a face referenced by k leaves has k
+  // identical records; leaf references and every record index of the kernels count records)
+  uint32_t spatial_splits = 0, n_records = 0;
 };
 
 struct BvhHost {

@@ -64,7 +64,9 @@ static void fill_info(const BvhInfo& bi, uint64_t bytes, rmclhip_map_info* out) 
   out->n_faces = bi.n_faces;
   out->n_vertices = bi.n_vertices;
   out->n_nodes = bi.n_nodes;
-  out->n_tri_records = bi.n_faces;
+  out->n_tri_records = bi.n_records;
+  out->spatial_splits = bi.spatial_splits;
+  out->reserved = 0;
   out->max_depth = bi.max_depth;
   out->stack_need = bi.stack_need;
   out->device_bytes = bytes;

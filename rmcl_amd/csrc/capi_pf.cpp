@@ -129,7 +129,7 @@ static rmclhip_status pf_enqueue(rmclhip_pf* f, const rmclhip_transform* poses, 
   p.particle_minor = 0u;
   p.order = nullptr;
   p.near_grid = nullptr;
-  p.n_tris = f->map->info.n_faces;
+  p.n_tris = f->map->info.n_records;   // record indices (a face that spatial splits reference k times has k records)
   for (int k = 0; k < 3; ++k) { p.gn[k] = 1u; p.gorg[k] = 0.f; p.ginv[k] = 1.f; }
   if (f->params.correspondence_type == 1u && f->cpc_grid) {
     // closest-point errors: every query starts from the near grid's record of its cell (the FULL grid: beam end points are anywhere)

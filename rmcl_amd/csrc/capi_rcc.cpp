@@ -630,11 +630,11 @@ RMCL_INTERNAL rmclhip_status ensure_near_grid(rmclhip_map* m, hipStream_t stream
   e = hipMalloc(reinterpret_cast<void**>(&d_coarse), ctotal * sizeof(uint32_t));
   if (e == hipSuccess)
     e = launch_cpc_find(m->d_nodes, m->d_tris, nullptr, static_cast<uint32_t>(ctotal), 0.f, xidentity(), xidentity(), nullptr, nullptr, nullptr, nullptr,
-                        nullptr, false, stream, nullptr, d_coarse, m->info.n_faces, 3.0e38f, nullptr, &c);
+                        nullptr, false, stream, nullptr, d_coarse, m->info.n_records, 3.0e38f, nullptr, &c);
   c.cells = d_coarse;
   if (e == hipSuccess)
     e = launch_cpc_find(m->d_nodes, m->d_tris, nullptr, static_cast<uint32_t>(total), 0.f, xidentity(), xidentity(), nullptr, nullptr, nullptr, nullptr,
-                        nullptr, false, stream, nullptr, d_cells, m->info.n_faces, 3.0e38f, &c, &g, skip_d2);
+                        nullptr, false, stream, nullptr, d_cells, m->info.n_records, 3.0e38f, &c, &g, skip_d2);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   if (d_coarse) (void)hipFree(d_coarse);
   if (e != hipSuccess) {
@@ -676,7 +676,7 @@ rmclhip_status rmclhip_rcc_find_cpc(rmclhip_rcc* r, const rmclhip_transform* Tbm
                          r->max_dist, Tsm, xinv(Tsm), (r->out_mask & RMCLHIP_OUT_HITS) ? r->d_hits.p : nullptr,
                          (r->out_mask & RMCLHIP_OUT_RANGES) ? r->d_ranges.p : nullptr, (r->out_mask & RMCLHIP_OUT_POINTS) ? r->d_points.p : nullptr,
                          (r->out_mask & RMCLHIP_OUT_NORMALS) ? r->d_normals.p : nullptr,
-                         (r->out_mask & RMCLHIP_OUT_FACE_IDS) ? r->d_face_ids.p : nullptr, quad, r->stream, seed, r->cpc_tracking ? r->d_cpc_rec.p : nullptr, r->map->info.n_faces,
+                         (r->out_mask & RMCLHIP_OUT_FACE_IDS) ? r->d_face_ids.p : nullptr, quad, r->stream, seed, r->cpc_tracking ? r->d_cpc_rec.p : nullptr, r->map->info.n_records,
                          cpc_bound_d2(r), grid));
   if (r->cpc_tracking) { r->cpc_rec_n = r->n_dataset; r->cpc_rec_pts = r->ds_pts; }
   HIPCHK(wait_chain_end(r));

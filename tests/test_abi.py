@@ -128,10 +128,13 @@ def test_host_algebra_bit_exact_with_oracle(ra, orc):
 
 @pytest.mark.parametrize("name", ["cube", "sphere20k", "room30k", "chain200", "chain2000", "nested200", "fan20k", "cadmix20k"])
 def test_bvh_builder_invariants(ra, orc, meshes, name):
-    """Host-only build (rmclhip_bvh_build_host): every face in exactly one leaf, triangle records bit-equal
-    to the oracle's, every child box contains its subtree, BFS node order, stack bound respected, and the
-    oracle's intersector walking THESE arrays reproduces brute force.  chain* / nested200 are meshes whose SAH tree is far deeper
-    than the kernels' 64-entry stack (round 5: the builder bounds the stack by construction instead of refusing the mesh)."""
+    """Host-only build (rmclhip_bvh_build_host): every record in exactly one leaf and every face in at least one (round 6: a face the
+    builder's SPATIAL splits cut is referenced from several leaves, each with the box of its part there, through identical records),
+    triangle records bit-equal to the oracle's, every child box contains its subtree (a cut face: the union of the leaf boxes that
+    reference it covers the triangle -- sampled), BFS node order, stack bound respected, and the oracle's intersector walking THESE
+    arrays reproduces brute force.  chain* / nested200 are meshes whose SAH tree is far deeper than the kernels' 64-entry stack (round 5:
+    the builder bounds the stack by construction instead of refusing the mesh); fan20k / cadmix20k / sphere20k's polar slivers take
+    spatial splits."""
     v, f = meshes(name)
     info, nodes, tris = ra.build_bvh_host(v, f)
     if name.startswith("chain"):
@@ -140,23 +143,40 @@ def test_bvh_builder_invariants(ra, orc, meshes, name):
         assert info["height_fallbacks"] == 0 and info["guarded_nodes"] == 0
     m = orc.Mesh(v, f)
     nf = len(f)
-    assert info["n_faces"] == nf and nodes.shape == (info["n_nodes"], 32) and tris.shape == (nf, 16)
+    nrec = info["n_tri_records"]
+    assert info["n_faces"] == nf and nodes.shape == (info["n_nodes"], 32) and tris.shape == (nrec, 16) and nrec >= nf
     fid = tris[:, 15]
-    assert np.array_equal(np.sort(fid), np.arange(nf, dtype=np.uint32))
+    refs_of = np.bincount(fid, minlength=nf)
+    assert len(refs_of) == nf and refs_of.min() >= 1                   # every face is referenced, no record names a face that does not exist
+    assert (nrec > nf) == (info["spatial_splits"] > 0)
+    if name in ("cube", "room30k", "chain200", "chain2000", "nested200"):
+        assert nrec == nf                                               # regular meshes / chains: the plain builder's tree
+    if name in ("fan20k", "sphere20k"):
+        assert info["spatial_splits"] > 0 and nrec <= 2 * nf            # the reference budget: at most alpha = 1 extra records per face
     assert np.array_equal(tris.view(np.float32)[:, :15].view(np.uint32), m.tri_records()[fid].view(np.uint32))
     fl = nodes.view(np.float32)
-    leaf_seen = np.zeros(nf, dtype=np.int32)
+    leaf_seen = np.zeros(nrec, dtype=np.int32)
+    cut_boxes = {}                                                      # face -> [(lo, hi)] of the leaf boxes that reference a cut face
     v0 = tris.view(np.float32)[:, 0:3]
     v1 = v0 - tris.view(np.float32)[:, 3:6]
     v2 = v0 + tris.view(np.float32)[:, 6:9]
 
-    def subtree_bounds(ref, depth, stack):
+    def subtree_bounds(ref, depth, stack, box=None):
         if ref & 0x80000000:
             first, cnt = ref & 0x0FFFFFFF, ((ref >> 28) & 7) + 1
             assert cnt <= 4
             leaf_seen[first:first + cnt] += 1
-            pts = np.concatenate([v0[first:first + cnt], v1[first:first + cnt], v2[first:first + cnt]])
-            return pts.min(0), pts.max(0), depth, stack
+            whole = [r for r in range(first, first + cnt) if refs_of[fid[r]] == 1]
+            for r in range(first, first + cnt):
+                if refs_of[fid[r]] > 1:
+                    cut_boxes.setdefault(int(fid[r]), []).append(box)
+            if not whole:                       # only parts of cut faces: the stored box is all there is to say
+                return box[0], box[1], depth, stack
+            pts = np.concatenate([v0[whole], v1[whole], v2[whole]])
+            lo_, hi_ = pts.min(0), pts.max(0)
+            if len(whole) < cnt:
+                lo_, hi_ = np.minimum(lo_, box[0]), np.maximum(hi_, box[1])
+            return lo_, hi_, depth, stack
         assert ref < info["n_nodes"]
         lo, hi, dmax, smax = np.full(3, np.inf), np.full(3, -np.inf), depth, stack
         nk = int(nodes[ref, 28])
@@ -168,9 +188,9 @@ def test_bvh_builder_invariants(ra, orc, meshes, name):
             child = int(nodes[ref, 24 + c])
             if not child & 0x80000000:
                 assert child > ref  # breadth-first order: children come later
-            clo, chi, d, s = subtree_bounds(child, depth + 1, stack + len(kids) - 1)
             bmin = np.array([fl[ref, 0 + c], fl[ref, 8 + c], fl[ref, 16 + c]])
             bmax = np.array([fl[ref, 4 + c], fl[ref, 12 + c], fl[ref, 20 + c]])
+            clo, chi, d, s = subtree_bounds(child, depth + 1, stack + len(kids) - 1, (bmin, bmax))
             assert np.all(bmin <= clo) and np.all(bmax >= chi)       # (padded) box contains the subtree
             lo, hi, dmax, smax = np.minimum(lo, clo), np.maximum(hi, chi), max(dmax, d), max(smax, s)
         return lo, hi, dmax, smax
@@ -179,8 +199,21 @@ def test_bvh_builder_invariants(ra, orc, meshes, name):
     sys.setrecursionlimit(10000)
     lo, hi, dmax, smax = subtree_bounds(0, 1, 0)
     assert np.all(leaf_seen == 1)
+    # a cut face: every point of the triangle lies in a leaf box that references the face (random barycentric samples + the corners)
+    rs = np.random.RandomState(7)
+    for face in list(cut_boxes)[:400]:
+        r = int(np.nonzero(fid == face)[0][0])
+        assert len(cut_boxes[face]) == refs_of[face]
+        w = np.concatenate([rs.dirichlet((1, 1, 1), 24), np.eye(3)])
+        pts = w[:, :1] * v0[r].astype(np.float64) + w[:, 1:2] * v1[r].astype(np.float64) + w[:, 2:3] * v2[r].astype(np.float64)
+        inside = np.zeros(len(pts), bool)
+        for blo, bhi in cut_boxes[face]:
+            inside |= np.all(pts >= blo - 1e-6, axis=1) & np.all(pts <= bhi + 1e-6, axis=1)
+        assert inside.all(), "face %d: part of the triangle lies in none of the %d leaf boxes that reference it" % (face, len(cut_boxes[face]))
     assert smax + 1 <= info["stack_need"] <= 64
-    assert np.allclose(lo, info["bbox_min"], atol=1e-5) and np.allclose(hi, info["bbox_max"], atol=1e-5)
+    # (a leaf that holds only parts of cut faces contributes its STORED, padded box: the scene's padding is 1e-4 of its extent)
+    slack = (2e-4 * float(np.max(np.abs(np.array(info["bbox_max"]) - np.array(info["bbox_min"])) + np.abs(info["bbox_max"]))) + 1e-5) if nrec > nf else 1e-5
+    assert np.allclose(lo, info["bbox_min"], atol=slack) and np.allclose(hi, info["bbox_max"], atol=slack)
     rng = np.random.RandomState(1)
     n_hit = 0
     for k in range(200):
@@ -204,7 +237,7 @@ def test_bvh_builder_is_independent_of_the_thread_count(ra, meshes):
     read once per build from RMCLHIP_BUILD_THREADS"""
     import hashlib, os, subprocess, sys
     code = ("import sys, hashlib; sys.path.insert(0, %r); import rmcl_amd as ra; from rmcl_amd import synthetic as syn\n"
-            "for v, f in (syn.uv_sphere(200000), syn.noisy_room(30000), syn.exp_chain(200, 1.5)):\n"
+            "for v, f in (syn.uv_sphere(200000), syn.noisy_room(30000), syn.exp_chain(200, 1.5), syn.sliver_fan(6000), syn.cad_mix(20000)):\n"
             "    i, n, t = ra.build_bvh_host(v, f); ip, npf, q = ra.build_bvh_host_pf(v, f)\n"
             "    print(hashlib.sha256(n.tobytes() + t.tobytes() + npf.tobytes() + q.tobytes()).hexdigest())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
@@ -214,7 +247,7 @@ def test_bvh_builder_is_independent_of_the_thread_count(ra, meshes):
         if nt:
             env["RMCLHIP_BUILD_THREADS"] = nt
         outs.append(subprocess.check_output([sys.executable, "-c", code], env=env).decode().split())
-    assert len(outs[0]) == 3 and outs[0] == outs[1] == outs[2]
+    assert len(outs[0]) == 5 and outs[0] == outs[1] == outs[2]   # (the fan and the CAD mix take spatial splits: their reference budget is handed down the tree, not drawn from a shared counter)
 
 
 @pytest.mark.parametrize("name", ["cube", "sphere20k", "room30k"])
