@@ -136,12 +136,14 @@ def exp_chain(n, ratio=2.0, k0=None):
     return v.astype(np.float32), np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
 
 
-def cad_mix(n_detail=100000, room=40.0):
+def cad_mix(n_detail=100000, room=40.0, beam_yaw_deg=0.0, beam_tilt_deg=0.0, n_beams=8):
     """what a CAD export next to scanned detail looks like: a 40 m hall of TWELVE triangles (two per wall), eight 30 m beams of twelve
     triangles each crossing it, and a finely tessellated object (a UV sphere of radius 3) in the middle -- a few hundred-metre-scale
-    triangles among 10^5 centimetre-scale ones"""
+    triangles among 10^5 centimetre-scale ones.  beam_yaw_deg / beam_tilt_deg turn the beams out of the axes (about z, then about the
+    turned y): long thin DIAGONAL triangles, whose boxes cover most of the hall -- the case spatial splits are for."""
     h = room / 2.0
     vs, fs = [], []
+    first_beam_vertex = [None]
 
     def box(lo, hi):
         base = len(vs)
@@ -155,9 +157,19 @@ def cad_mix(n_detail=100000, room=40.0):
             fs.append([base + a, base + c, base + d])
 
     box((-h, -h, -3.5), (h, h, 8.0))
-    for k in range(8):
-        y = -14.0 + 4.0 * k
-        box((-15.0, y, 5.0 + 0.1 * k), (15.0, y + 0.2, 5.3 + 0.1 * k))
+    first_beam_vertex[0] = len(vs)
+    for k in range(n_beams):
+        y = -14.0 + 28.0 * k / max(n_beams - 1, 1)
+        box((-15.0, y, 5.0 + 0.1 * (k % 8)), (15.0, y + 0.2, 5.3 + 0.1 * (k % 8)))
+    if beam_yaw_deg != 0.0 or beam_tilt_deg != 0.0:
+        cz, sz = math.cos(math.radians(beam_yaw_deg)), math.sin(math.radians(beam_yaw_deg))
+        cy, sy = math.cos(math.radians(beam_tilt_deg)), math.sin(math.radians(beam_tilt_deg))
+        Rz = np.array([[cz, -sz, 0.0], [sz, cz, 0.0], [0.0, 0.0, 1.0]])
+        Ry = np.array([[cy, 0.0, sy], [0.0, 1.0, 0.0], [-sy, 0.0, cy]])
+        R = Rz @ Ry
+        c = np.array([0.0, 0.0, 5.0])
+        for i in range(first_beam_vertex[0], len(vs)):
+            vs[i] = (R @ (np.asarray(vs[i]) - c) + c).tolist()
     sv, sf = uv_sphere(n_detail, radius=3.0)
     base = len(vs)
     verts = np.concatenate([np.asarray(vs, np.float32), sv])

@@ -757,6 +757,61 @@ def test_mixed_scale_map_hall_beams_and_a_fine_object(ra, orc, ctx, meshes):
         assert 1000 < small.sum() < small.size - 1000, "both poses see the object AND the hall"
 
 
+def test_spatial_splits_leave_every_result_unchanged(ra, orc, ctx, meshes):
+    """round 6 (SBVH): a CAD mix whose 60 beams are turned out of the axes -- long thin DIAGONAL triangles over scanned detail -- takes
+    hundreds of spatial splits: faces referenced from several leaves through identical records.  Every product kind (and the cooperative
+    descent) against the oracle's OWN tree (no spatial splits) on all rays and brute force on a sample: hits, face ids and ranges bit for
+    bit; the particle filter's update and the closest-point query on the same map (they index records too) against the oracle."""
+    from rmcl_amd import synthetic as syn, types as T
+    v, f = syn.cad_mix(20000, beam_yaw_deg=35.0, beam_tilt_deg=12.0, n_beams=60)
+    hm = ra.import_hip_map(ctx, v, f)
+    info = hm.info()
+    assert info["spatial_splits"] > 50 and info["n_faces"] < info["n_tri_records"] <= 2 * info["n_faces"] and info["stack_need"] <= 64
+    m = orc.Mesh(v, f)
+    model = syn.model_c2()
+    dirs = orc.spherical_directions(model)
+    idx = np.sort(np.random.RandomState(6).choice(len(dirs), size=1024, replace=False))
+    Tbm = T.transform_from_rpy((-6.0, 0.5, 1.5), (0.3, 0.1, -1.0))
+    ref = m.simulate_spherical(model, T.identity(), Tbm, bvh=2, nthreads=16)
+    sub = m.simulate_o1dn(len(idx), 1, model.range.min, model.range.max, (0.0, 0.0, 0.0), dirs[idx], T.identity(), Tbm, bvh=False,
+                          nthreads=16, want=("hits", "ranges", "face_ids"))
+    assert np.array_equal(ref["face_ids"][idx], sub["face_ids"])
+    beam_faces = (ref["face_ids"] >= 12) & (ref["face_ids"] < 12 + 60 * 12)
+    assert beam_faces.sum() > 2000, "the scan must see the turned beams"
+    for kind in (15, 23, 31, 24, 2, 0):
+        rcc = ra.RCCHipSpherical(hm)
+        rcc.set_traversal(kind)
+        rcc.setTsb(T.identity())
+        rcc.setModel(model)
+        rcc.find(Tbm)
+        _compare(rcc.modelView(), ref, "turned beams kind %d" % kind)
+        rcc.close()
+    # the filter's tree is a cut of the same BVH2, its records the same array
+    poses, attrs = syn.uniform_particles(300, seed=8, bb_min=(-8, -8, 0.0, 0, 0, -math.pi), bb_max=(8, 8, 3.0, 0, 0, math.pi))
+    beams = ra.beams_from_points(syn.model_directions(syn.model_pf16())[::4] * np.float32(6.0))
+    upd = ra.PCDSensorUpdaterHip(hm)
+    upd.init()
+    upd.setInput(beams, T.identity())
+    d_p, d_a = ra.DeviceArray.from_host(ctx, poses), ra.DeviceArray.from_host(ctx, attrs)
+    upd.update(d_p, d_a)
+    a_gpu, a_ref = d_a.download(), attrs.copy()
+    m.pf_update(poses, a_ref, beams, T.identity(), orc.pf_params(), bvh=True)
+    assert np.array_equal(a_gpu["likelihood"]["n_meas"], a_ref["likelihood"]["n_meas"])
+    assert np.allclose(a_gpu["likelihood"]["mean"], a_ref["likelihood"]["mean"], rtol=1e-5, atol=1e-12)
+    upd.close()
+    # closest point: ties go to the smaller face id -- a face's duplicate records tie with themselves
+    cpc = ra.CPCHip(hm)
+    cpc.setTsb(T.identity())
+    cpc.params.max_dist = 2.0
+    pts = (np.random.RandomState(3).uniform(-6, 6, (4000, 3)) + np.array([0, 0, 4.0])).astype(np.float32)
+    cpc.set_dataset(pts, None)
+    cpc.find(T.identity())
+    got = cpc.modelView()
+    want = m.cpc_find(T.identity(), T.identity(), pts, 2.0, bvh=False)
+    assert np.array_equal(got["hits"], want["hits"]) and np.array_equal(got["face_ids"], want["face_ids"])
+    cpc.close()
+
+
 def test_prebound_find_callable_equals_find(ra, orc, ctx, meshes):
     """registration.find_async_fn (bench.py's timed step: the pose converted once, one C call per step) launches the same find as
     find() -- also when the caller's pose array is changed or dropped after the callable was made (it keeps its own copy)."""

@@ -20,8 +20,11 @@ H, W = 64, 512
 cases = (
   ("sliver_fan_200k", lambda: syn.sliver_fan(200000), T.spherical_model(f32(-1.5), f32(3.0 / (H - 1)), H, f32(-math.pi), f32(2 * math.pi / W), W, f32(0.01), f32(1e6)), T.transform_from_rpy((1.0, 2.0, 3.0), (0.1, 0.2, 0.3))),
   ("sliver_fan_20k", lambda: syn.sliver_fan(20000), T.spherical_model(f32(-1.5), f32(3.0 / (H - 1)), H, f32(-math.pi), f32(2 * math.pi / W), W, f32(0.01), f32(1e6)), T.transform_from_rpy((1.0, 2.0, 3.0), (0.1, 0.2, 0.3))),
-  ("cadmix_100k", lambda: syn.cad_mix(100000), syn.model_c2(), T.transform_from_rpy((0.5, 0.3, 1.0), (0, 0, 0.3))),
-  ("cadmix_20k", lambda: syn.cad_mix(20000), syn.model_c2(), T.transform_from_rpy((0.5, 0.3, 1.0), (0, 0, 0.3))),
+  ("cadmix_100k", lambda: syn.cad_mix(100000), syn.model_c2(), T.transform_from_rpy((-6.0, 0.5, 1.5), (0.3, 0.1, -1.0))),
+  ("cadmix_100k_8_beams_turned", lambda: syn.cad_mix(100000, beam_yaw_deg=35.0, beam_tilt_deg=12.0), syn.model_c2(), T.transform_from_rpy((-6.0, 0.5, 1.5), (0.3, 0.1, -1.0))),
+  ("cadmix_100k_200_beams_turned", lambda: syn.cad_mix(100000, beam_yaw_deg=35.0, beam_tilt_deg=12.0, n_beams=200), syn.model_c2(), T.transform_from_rpy((-6.0, 0.5, 1.5), (0.3, 0.1, -1.0))),
+  ("cadmix_100k_2000_beams_turned", lambda: syn.cad_mix(100000, beam_yaw_deg=35.0, beam_tilt_deg=12.0, n_beams=2000), syn.model_c2(), T.transform_from_rpy((-6.0, 0.5, 1.5), (0.3, 0.1, -1.0))),
+  ("cadmix_20k", lambda: syn.cad_mix(20000), syn.model_c2(), T.transform_from_rpy((-6.0, 0.5, 1.5), (0.3, 0.1, -1.0))),
   ("sphere_100k", lambda: syn.uv_sphere(100000), syn.model_c2(), syn.pose_c2_truth()),
   ("room_100k", lambda: syn.noisy_room(100000), syn.model_c2(), T.transform_from_rpy((1.5, -2.0, 1.6), (0.02, -0.03, 0.4))),
 )
