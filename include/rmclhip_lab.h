@@ -51,7 +51,8 @@ rmclhip_status rmclhip_debug_probe_find(rmclhip_rcc* rcc, const rmclhip_transfor
 
 /* A/B knobs of the cooperative descent of find kind 31 (traverse.hip.h frontier_descent_start): the wave stops descending when a level
  * would leave more than final_cap entries (<= 64, default 64) or after max_levels levels (default 24; 0 = kind 23's frontier start with
- * kind 31's bookkeeping).  Results do not depend on either.  Exported by librmclhip.so. */
+ * kind 31's bookkeeping; bit 31 set: descend on the four-wide nodes even where the map carries the 16-wide twins -- two tree levels per pass
+ * -- A/B).  Results do not depend on any of them.  Exported by librmclhip.so. */
 rmclhip_status rmclhip_rcc_set_descent(rmclhip_rcc* rcc, uint32_t final_cap, uint32_t max_levels);
 
 /* TEST knob of the loopback communicator (rmclhip_comm_create_loopback): its all-reduce adds the ranks' contributions starting at

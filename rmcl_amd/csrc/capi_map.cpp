@@ -182,6 +182,15 @@ RMCL_INTERNAL rmclhip_status map_upload(rmclhip_ctx* ctx, const BvhHost& bvh, rm
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_cnodes), cb);
   if (e == hipSuccess) e = hipMemcpy(m->d_cnodes, bvh.cnodes.data(), cb, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(m->d_tris, bvh.tris.data(), tb, hipMemcpyHostToDevice);
+  // the 16-wide twins for the cooperative descent of find kind 31 (512 B per node: 8 MB for a 100 k-triangle map), derived on the device;
+  // maps beyond kMaxNodes16 nodes (~4 M triangles) go without -- the descent then walks the four-wide nodes
+  constexpr size_t kMaxNodes16 = 600000;
+  size_t c16b = 0;
+  if (e == hipSuccess && bvh.cnodes.size() <= kMaxNodes16) {
+    c16b = bvh.cnodes.size() * sizeof(Node16C);
+    e = hipMalloc(reinterpret_cast<void**>(&m->d_cnodes16), c16b);
+    if (e == hipSuccess) e = launch_build_cnodes16(m->d_cnodes, static_cast<uint32_t>(bvh.cnodes.size()), m->d_cnodes16, nullptr);
+  }
   // the map is read by kernels on the handles' non-blocking streams, which do not synchronise with the null stream these
   // copies ran on: make sure every byte has landed before the handle is handed out
   if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -192,12 +201,13 @@ RMCL_INTERNAL rmclhip_status map_upload(rmclhip_ctx* ctx, const BvhHost& bvh, rm
     if (m->d_frontier) (void)hipFree(m->d_frontier);
     if (m->d_frontier_pf) (void)hipFree(m->d_frontier_pf);
     if (m->d_cnodes) (void)hipFree(m->d_cnodes);
+    if (m->d_cnodes16) (void)hipFree(m->d_cnodes16);
     if (m->d_tris) (void)hipFree(m->d_tris);
     delete m;
     return fail(e == hipErrorOutOfMemory ? RMCLHIP_ERR_NOMEM : RMCLHIP_ERR_HIP,
                 std::string("map_create upload: ") + hipGetErrorString(e));
   }
-  m->bytes = nb + qb + qpb + cb + tb + fb + fpb;
+  m->bytes = nb + qb + qpb + cb + c16b + tb + fb + fpb;
   ctx_retain(ctx);
   *out = m;
   return RMCLHIP_OK;
@@ -221,6 +231,7 @@ void rmclhip_map_release(rmclhip_map* map) {
     if (map->d_frontier) (void)hipFree(map->d_frontier);
     if (map->d_frontier_pf) (void)hipFree(map->d_frontier_pf);
     if (map->d_cnodes) (void)hipFree(map->d_cnodes);
+    if (map->d_cnodes16) (void)hipFree(map->d_cnodes16);
     if (map->d_tris) (void)hipFree(map->d_tris);
     for (auto& gs : map->grid_slot)
       if (gs.g.cells) (void)hipFree(const_cast<uint32_t*>(gs.g.cells));

@@ -399,6 +399,7 @@ RMCL_INTERNAL void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t npos
   p.nodes = r->map->d_nodes;
   p.qnodes = r->map->d_qnodes;
   p.cnodes = r->map->d_cnodes;
+  p.cnodes16 = r->descent_wide ? r->map->d_cnodes16 : nullptr;
   p.tris = r->map->d_tris;
   p.n_nodes = r->map->info.n_nodes;
   p.frontier = r->map->d_frontier;

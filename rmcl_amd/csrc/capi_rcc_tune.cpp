@@ -65,10 +65,10 @@ rmclhip_status rmclhip_rcc_time_find(rmclhip_rcc* r, const rmclhip_transform* Tb
 // candidates of the measured choice: {template kind, frontier start}; reported as kinds 2 / 23 / 24 and -- without the frontier
 // start -- as round 2's numbers for the same traversals, 19 / 22
 struct TuneCand { int kind; bool frontier; int reported; uint32_t descent_cap; };   // descent_cap: kind 31 only (rmclhip_rcc_set_descent), 0 otherwise
-// (kind 31 = kind 23 behind the cooperative descent, with the wave's final list capped at 12 or at 64 entries: open maps want the
+// (kind 31 = kind 23 behind the cooperative descent, with the wave's final list capped at 12, 32 or 64 entries: open maps want the
 // long list, rooms the short one or none -- profiles/r06_descent_maps_ab.txt)
-static const TuneCand kTuneSingle[7] = {{2, true, 2, 0}, {23, true, 23, 0}, {23, false, 19, 0}, {24, true, 24, 0}, {24, false, 22, 0},
-                                        {31, true, 31, 12}, {31, true, 31, 64}};
+static const TuneCand kTuneSingle[8] = {{2, true, 2, 0}, {23, true, 23, 0}, {23, false, 19, 0}, {24, true, 24, 0}, {24, false, 22, 0},
+                                        {31, true, 31, 12}, {31, true, 31, 32}, {31, true, 31, 64}};
 static const TuneCand kTuneBatch[4] = {{23, true, 23, 0}, {23, false, 19, 0}, {24, true, 24, 0}, {24, false, 22, 0}};
 
 rmclhip_status rmclhip_rcc_autotune(rmclhip_rcc* r, const rmclhip_transform* Tbm_est, int* chosen_kind, float* kernel_ms) {
@@ -266,7 +266,8 @@ rmclhip_status rmclhip_rcc_set_descent(rmclhip_rcc* r, uint32_t final_cap, uint3
   ApiGuard guard_("rmclhip_rcc_set_descent");
   if (!r || final_cap > 64u) return fail(RMCLHIP_ERR_INVALID, "rcc_set_descent: final_cap <= 64");
   r->descent_final_cap = final_cap;
-  r->descent_levels = max_levels;
+  r->descent_levels = max_levels & 0x7FFFFFFFu;
+  r->descent_wide = (max_levels >> 31) == 0u;   // bit 31 (A/B): the four-wide nodes even where the map has the 16-wide twins
   r->graph_dirty = true; r->fast_graph_dirty = true;
   return RMCLHIP_OK;
 }

@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
       if (p.tile_planes != nullptr) {     // (no table: the rays start at the root)
         const float* planes = p.tile_planes + static_cast<size_t>(__builtin_amdgcn_readfirstlane(tile)) * 16u;
         if (kTrav == 31)
-          start = frontier_descent_start<kFindBfRows, 1>(p.frontier, p.n_frontier, p.cnodes, p.scene_center, p.scene_half_diag, planes, Tsm.R, p.tfar,
+          start = frontier_descent_start<kFindBfRows, 1>(p.frontier, p.n_frontier, p.cnodes, p.cnodes16, p.scene_center, p.scene_half_diag, planes, Tsm.R, p.tfar,
                                                          org_m, dir_m, ray_tfar, lane, lds_dyn + threadIdx.x, kBfStride, p.frontier_max_preload,
                                                          lds_dyn + kFindBfTailLdsDwords + wave * kDescentWaveDwords, min(p.descent_final_cap, kDescentCap), p.descent_levels, kClock ? &clk_descent : nullptr);
         else if (kTrav == 23 || (kTrav >= 26 && kTrav <= 30))

@@ -22,6 +22,7 @@ struct FindParams {
   const uint32_t* nodes;   // Node4[]
   const uint32_t* qnodes;  // Node4Q[] (quantised twins)
   const uint32_t* cnodes;  // Node4C[] (child-major twins)
+  const uint32_t* cnodes16;  // Node16C[] (a node's grandchildren, child-major; kind 31's two-levels-per-pass descent), nullable
   const uint32_t* tris;    // TriRec[]
   uint32_t n_nodes;        // number of Node4 (the LDS-resident top of the tree copies min(kTop, n_nodes) of them)
   // spherical: [cos(phi_v) (H) | sin(phi_v) (H) | cos(theta_h) (W) | sin(theta_h) (W)], host libm values
@@ -305,6 +306,8 @@ hipError_t launch_pointcloud2_unpack(const uint8_t* data, uint32_t point_step, u
                                      uint32_t w_skip, uint32_t w_inc, uint32_t out_w, uint32_t out_h, float range_min,
                                      float range_max, float* dirs, float* points, uint8_t* mask, uint32_t* n_valid,
                                      hipStream_t s);
+// the 16-wide twins of the child-major nodes (layout.h Node16C), built on the device from them: one thread per (node, entry)
+hipError_t launch_build_cnodes16(const uint32_t* cnodes, uint32_t n_nodes, uint32_t* cnodes16, hipStream_t s);
 hipError_t launch_compose_poses(const xform* Tbm_dev, xform Tsb, xform* Tsm_out, xform* Tms_out, uint32_t n,
                                 hipStream_t s);
 uint32_t reduce_num_blocks(uint32_t n, uint32_t nposes);

@@ -21,6 +21,28 @@ namespace rmclhip {
 
 namespace {
 
+// Node16C twins (layout.h): thread = (node, entry)
+__global__ void __launch_bounds__(256) k_build_cnodes16(const uint4* __restrict__ cn, uint32_t n_nodes, uint4* __restrict__ out) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t node = t >> 4, e = t & 15u, c = e >> 2, g = e & 3u;
+  if (node >= n_nodes) return;
+  const uint4 ca = cn[static_cast<size_t>(node) * 8u + 2u * c], cb = cn[static_cast<size_t>(node) * 8u + 2u * c + 1u];
+  const uint4 far_a = uint4{__float_as_uint(kFarPoint[0]), __float_as_uint(kFarPoint[1]), __float_as_uint(kFarPoint[2]), __float_as_uint(kFarPoint[0])};
+  const uint4 far_b = uint4{__float_as_uint(kFarPoint[1]), __float_as_uint(kFarPoint[2]), kLeafBit, 0u};
+  uint4 oa = far_a, ob = far_b;
+  const bool unused = __uint_as_float(ca.x) >= 1.0e29f;
+  if (!unused) {
+    if (cb.z & kLeafBit) {
+      if (g == 0u) { oa = ca; ob = cb; }
+    } else {
+      oa = cn[static_cast<size_t>(cb.z) * 8u + 2u * g];
+      ob = cn[static_cast<size_t>(cb.z) * 8u + 2u * g + 1u];
+    }
+  }
+  out[static_cast<size_t>(node) * 32u + 2u * e] = oa;
+  out[static_cast<size_t>(node) * 32u + 2u * e + 1u] = ob;
+}
+
 __global__ void k_compose_poses(const xform* __restrict__ Tbm, xform Tsb, xform* __restrict__ Tsm,
                                 xform* __restrict__ Tms, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3010,6 +3032,13 @@ hipError_t launch_residual_fill(const xform* poses, const void* attrs, const uin
   hipLaunchKernelGGL(k_residual_fill, dim3((count + 255u) / 256u), dim3(256), 0, s, poses, reinterpret_cast<const pattrs*>(attrs), draw_idx,
                      incl, n_draws, poses_new, reinterpret_cast<pattrs*>(attrs_new), n_new, first, count, c,
                      reinterpret_cast<ResidualStats*>(stats), static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), step);
+  return hipGetLastError();
+}
+
+hipError_t launch_build_cnodes16(const uint32_t* cnodes, uint32_t n_nodes, uint32_t* cnodes16, hipStream_t s) {
+  if (n_nodes == 0u) return hipSuccess;
+  const uint32_t nb = (n_nodes * 16u + 255u) / 256u;
+  hipLaunchKernelGGL(k_build_cnodes16, dim3(nb), dim3(256), 0, s, reinterpret_cast<const uint4*>(cnodes), n_nodes, reinterpret_cast<uint4*>(cnodes16));
   return hipGetLastError();
 }
 

@@ -1308,7 +1308,8 @@ constexpr uint32_t kDescentWaveDwords = (kDescentCap + 2u * kDescentInnerCap) * 
 
 template <int kRows, int kRow0>
 __device__ __forceinline__ TraceStart frontier_descent_start(const uint32_t* __restrict__ frontier, uint32_t n_frontier,
-                                                             const uint32_t* __restrict__ cnodes, f3 scene_center, float scene_half_diag,
+                                                             const uint32_t* __restrict__ cnodes, const uint32_t* __restrict__ cnodes16,
+                                                             f3 scene_center, float scene_half_diag,
                                                              const float* __restrict__ planes, quat Rsm, float tfar, f3 O, f3 D,
                                                              float ray_tfar, uint32_t lane, uint32_t* __restrict__ lds_col,
                                                              uint32_t lds_stride, uint32_t max_preload, uint32_t* __restrict__ ws,
@@ -1418,7 +1419,12 @@ __device__ __forceinline__ TraceStart frontier_descent_start(const uint32_t* __r
       nA += static_cast<uint32_t>(__popcll(m_in[k]));
     }
     RMCL_WAVE_LDS_SYNC()
-    const uint32_t s_in = lane >> 2, c_in = lane & 3u;
+    // two levels per round trip where the map carries the 16-wide twins (layout.h Node16C: a node's GRANDCHILDREN, child-major): lane l
+    // tests entry (l & 15) of survivor (l >> 4), four nodes per pass -- the first levels below the frontier barely branch (2.8 -> 3.0 ->
+    // 3.6 survivors per tile of a C2 scan on sphere-100k), so a level of four-wide nodes buys little for its round trip
+    const bool wide = cnodes16 != nullptr;
+    const uint32_t lsh = wide ? 4u : 2u, per_pass = wide ? 4u : 16u;
+    const uint32_t s_in = lane >> lsh, c_in = lane & ((1u << lsh) - 1u);
     // A level that turns out not to fit costs a round trip for nothing, so the wave predicts before it fetches: the list grew by
     // g = total / previous total at the last level (at least 5/4); the next level is fetched only if total * g <= final_cap
     uint32_t prev_total = max(n_surv, 1u);
@@ -1429,13 +1435,14 @@ __device__ __forceinline__ TraceStart frontier_descent_start(const uint32_t* __r
         if (total * g_num > final_cap * 4u * prev_total) break;
         prev_total = total;
       }
-      // expand every node of the current list: 16 nodes (x 4 children) per pass
+      // expand every node of the current list: 16 nodes (x 4 children) or 4 nodes (x 16 grandchildren) per pass
       uint32_t nFn = nF, nAn = 0;
-      for (uint32_t base = 0; base < nA; base += 16u) {
+      for (uint32_t base = 0; base < nA; base += per_pass) {
         const uint32_t s = base + s_in;
         const bool have = s < nA;
         const uint32_t nref = have ? reinterpret_cast<const uint32_t*>(Acur)[8u * s + 6u] : 0u;
-        const uint4* cn = reinterpret_cast<const uint4*>(cnodes) + (static_cast<size_t>(nref) * 8u + 2u * c_in);
+        const uint4* cn = wide ? reinterpret_cast<const uint4*>(cnodes16) + (static_cast<size_t>(nref) * 32u + 2u * c_in)
+                               : reinterpret_cast<const uint4*>(cnodes) + (static_cast<size_t>(nref) * 8u + 2u * c_in);
         const uint4 ca = cn[0], cb = cn[1];
         // (an unused child slot holds the far point, layout.h: never inside a scene -- but possibly inside an unbounded pyramid)
         const bool ok = have && (asf(ca.x) < 1.0e29f) && in_pyramid(ca, cb);
