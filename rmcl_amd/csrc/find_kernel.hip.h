@@ -29,7 +29,10 @@ constexpr int find_leaf_trigger(int trav) { return (trav == 19 || trav == 20 || 
 constexpr bool find_frontier(int trav) { return trav == 23 || trav == 24 || (trav >= 25 && trav <= 31); }
 // LDS of the one-lane-per-ray kinds with quad-finished tails (23, 31, ...), in dwords; kind 31 appends its waves' descent lists
 constexpr uint32_t kFindBfTailLdsDwords = static_cast<uint32_t>(kFindBfRows) * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords;
-static_assert(kFindBfTailLdsDwords % 4u == 0u, "the descent lists behind it are read and written 16 B at a time");   // 26: 23 on the quantised nodes; 27: 23 + record prefetch; 28: 23 with the pipelined node step; 29 / 30: 23 with four / three of the five ordering steps
+// kind 31 has no quad tail: its LDS is the lane stacks, then the four waves' descent lists
+constexpr uint32_t kFind31ListsAt = static_cast<uint32_t>(kFindBfRows) * 256u;
+constexpr uint32_t kFind31LdsDwords = kFind31ListsAt + 4u * kDescentWaveDwords;
+static_assert(kFind31ListsAt % 4u == 0u, "the descent lists are read and written 16 B at a time");   // 26: 23 on the quantised nodes; 27: 23 + record prefetch; 28: 23 with the pipelined node step; 29 / 30: 23 with four / three of the five ordering steps
 // kind 25: kind 2 (four lanes per ray) with the frontier start
 constexpr bool find_quad(int trav) { return trav == 2 || trav == 25; }
 
@@ -351,7 +354,7 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
         if (kTrav == 31)
           start = frontier_descent_start<kFindBfRows, 1>(p.frontier, p.n_frontier, p.cnodes, p.cnodes16, p.scene_center, p.scene_half_diag, planes, Tsm.R, p.tfar,
                                                          org_m, dir_m, ray_tfar, lane, lds_dyn + threadIdx.x, kBfStride, p.frontier_max_preload,
-                                                         lds_dyn + kFindBfTailLdsDwords + wave * kDescentWaveDwords, min(p.descent_final_cap, kDescentCap), p.descent_levels, kClock ? &clk_descent : nullptr);
+                                                         lds_dyn + kFind31ListsAt + wave * kDescentWaveDwords, min(p.descent_final_cap, kDescentCap), p.descent_levels, kClock ? &clk_descent : nullptr);
         else if (kTrav == 23 || (kTrav >= 26 && kTrav <= 30))
           start = frontier_start<kFindBfRows, 1>(p.frontier, p.n_frontier, p.scene_center, p.scene_half_diag, planes, Tsm.R, p.tfar, org_m,
                                                  dir_m, ray_tfar, lane, lds_dyn + threadIdx.x, kBfStride, p.frontier_max_preload);
@@ -376,7 +379,7 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
     else if (kTrav == 1) trace_lane_bf<kFindBfRows>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
     else if (kTrav == 12) trace_lane_bf<kFindBfRows, false, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
     else if (kTrav == 16 || kTrav == 17 || kTrav == 19 || kTrav == 20 || kTrav == 23 || (kTrav >= 26 && kTrav <= 31))
-      trace_lane_bf_tail<kFindBfRows, kTrav != 16 && kTrav != 20, find_leaf_trigger(kTrav), kTrav == 26, kTrav == 27, kTrav == 28, (kTrav == 29 ? 4 : (kTrav == 30 ? 3 : 5))>(kTrav == 26 ? p.qnodes : p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x,
+      trace_lane_bf_tail<kFindBfRows, kTrav != 16 && kTrav != 20, find_leaf_trigger(kTrav), kTrav == 26, kTrav == 27, kTrav == 28, (kTrav == 29 ? 4 : (kTrav == 30 ? 3 : 5)), kTrav != 31>(kTrav == 26 ? p.qnodes : p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x,
                                                    lds_dyn + kFindBfRows * 256u,
                                                    lds_dyn + kFindBfRows * 256u + kQuadStackEntries * 64u + (threadIdx.x >> 6) * (kTailRays * kTailXferDwords), h,
                                                    kClock ? &clk_visits : nullptr, sp0, kClock ? clk_dbg : nullptr, &pre_nrec, &pre_rec);

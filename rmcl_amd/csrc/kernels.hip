@@ -2377,7 +2377,7 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
     const size_t lds = (static_cast<size_t>(kFindBfRows) * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords) * sizeof(uint32_t);
     RMCL_LAUNCH_FIND(23, lds)
   } else if (variant == 31) {  // kind 23 behind the cooperative descent: + the four waves' lists
-    const size_t lds = (static_cast<size_t>(kFindBfTailLdsDwords) + 4u * kDescentWaveDwords) * sizeof(uint32_t);
+    const size_t lds = static_cast<size_t>(kFind31LdsDwords) * sizeof(uint32_t);
     RMCL_LAUNCH_FIND(31, lds)
   } else {                     // 24: one lane per ray on the 64-B quantised nodes: frontier start, leaf trigger, 16 LDS rows
     const size_t lds4 = 16u * 256u * sizeof(uint32_t);
@@ -2410,7 +2410,7 @@ hipError_t launch_find_moments(const FindParams& p, ModelKind kind, int variant,
     return hipGetLastError();
   }
   if (variant == 31) {   // kind 23's epilogue behind the cooperative descent (+ the four waves' lists)
-    const size_t lds31 = (static_cast<size_t>(kFindBfTailLdsDwords) + 4u * kDescentWaveDwords) * sizeof(uint32_t);
+    const size_t lds31 = static_cast<size_t>(kFind31LdsDwords) * sizeof(uint32_t);
     switch (kind) {
       case kModelSpherical: hipLaunchKernelGGL((k_find<kModelSpherical, 31, false, true>), grid, block, lds31, s, p); break;
       case kModelO1Dn: hipLaunchKernelGGL((k_find<kModelO1Dn, 31, false, true>), grid, block, lds31, s, p); break;

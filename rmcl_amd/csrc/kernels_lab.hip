@@ -421,7 +421,7 @@ hipError_t lab_find_kind(const FindParams& p, int variant, hipStream_t s) {
     case 27: return lab_find_one<27, kClock>(p, grid, lds_bf_tail, s);                           // 23 + prefetch of the hit record's normal (experiment iv)
     case 26: return lab_find_one<26, kClock>(p, grid, lds_bf_tail, s);                           // 23 on the quantised nodes
     case 25: return lab_find_one<25, kClock>(p, grid, kQuadStackEntries * 64u * sizeof(uint32_t), s);   // 2 + frontier start
-    case 31: return lab_find_one<31, kClock>(p, grid, lds_bf_tail + 4u * kDescentWaveDwords * sizeof(uint32_t), s);   // (clocked only) 23 + cooperative descent
+    case 31: return lab_find_one<31, kClock>(p, grid, kFind31LdsDwords * sizeof(uint32_t), s);   // (clocked only) 23 + cooperative descent
     default: return kLabMissing;
   }
 }

@@ -910,7 +910,7 @@ __device__ __forceinline__ void trace_lane_ww_tail(const uint32_t* __restrict__ 
 // kSortSteps (kinds 29 / 30): 5 = the four children fully ordered; 4 = nearest first, farthest last, the middle two as they come;
 // 3 = only the nearest found.  The visit ORDER changes (never the set of hits: min t, then min face id), a step is 5 / 10 VALU
 // instructions shorter.
-template <int kRows, bool kLeafBatch, int kLeafTrigger = 0, bool kQuant = false, bool kPre = false, bool kPipe = false, int kSortSteps = 5>   // kQuant: `nodes` are the 64-B quantised twins
+template <int kRows, bool kLeafBatch, int kLeafTrigger = 0, bool kQuant = false, bool kPre = false, bool kPipe = false, int kSortSteps = 5, bool kTail = true>   // kQuant: `nodes` are the 64-B quantised twins; kTail = false: no hand-over of the last rays to quads (qstack / xfer_wave unused)
 __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ cnodes,
                                                    const uint32_t* __restrict__ tris, f3 O, f3 D, float ray_tfar,
                                                    uint32_t* __restrict__ lds_col, uint32_t* __restrict__ qstack,
@@ -953,7 +953,11 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
     const uint64_t m_act = __ballot(cur != kDone);
     if (m_act == 0) break;
     const uint32_t na = static_cast<uint32_t>(__popcll(m_act));
-    if (na <= kTailRays) {
+    // kTail = false (kind 31, whose rays mostly start with nothing but the leaves their tile sees): no hand-over -- rays that only hold
+    // leaves finish in a round or two of the lane loop, and the kernel is better off without the quad traversal's code and LDS
+    // (C2 sphere-100k 13.4 -> 12.8 us; where stragglers still descend, as on the room, that costs 9 %: kind 23 is the kind for those maps)
+    const bool hand_over = kTail && na <= kTailRays;
+    if (hand_over) {
       // ---- hand the remaining rays to quads ----
       const bool mine = cur != kDone;
       const uint32_t j = static_cast<uint32_t>(__popcll(m_act & ((1ull << lane) - 1ull)));
