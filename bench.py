@@ -1038,7 +1038,8 @@ def _stack_bounded_maps(ra, syn, T, np, ctx):
         hm.release()
     out["note"] = ("adversarial meshes, reported because they load at all now; the sliver fan (every triangle's box reaches the shared apex) is the classic "
                    "worst case of an object-split BVH -- rays near the disc's plane visit thousands of overlapping boxes (tens of ms per 32 k rays); "
-                   "spatial splits are not built")
+                   "round 6's spatial splits help CAD-like mixes (profiles/r06_sbvh_ab.txt), not this fan: every sliver crosses every plane through the "
+                   "apex, so a split duplicates all of them (DESIGN.md section 3)")
     return out
 
 

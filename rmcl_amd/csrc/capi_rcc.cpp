@@ -710,7 +710,10 @@ rmclhip_status rmclhip_rcc_sync(rmclhip_rcc* r) {
   ApiGuard guard_("rmclhip_rcc_sync");
   if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_sync: null");
   HIPCHK(hipSetDevice(r->ctx->device));
-  HIPCHK(stream_wait(r->ctx, r->stream));
+  // SPIN mode: a one-thread launch behind whatever the stream holds stores a completion tag that the host sees several microseconds
+  // before the stream's own completion signal (what the synchronous find does since round 4); BLOCK mode: hipStreamSynchronize
+  if (hipStreamQuery(r->stream) == hipSuccess) return RMCLHIP_OK;
+  HIPCHK(wait_chain_end(r));
   return RMCLHIP_OK;
 }
 
