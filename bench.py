@@ -162,7 +162,7 @@ def main():
         tuned = None
         if args.variant == 15 and not args.no_autotune:
             # what INTEGRATION.md's sensor set-up does once per (map, model): the operator measures its own single-scan traversals here
-            # (kinds 2 / 23 / 24 with and without the frontier start, kind 31 = the cooperative descent with a short and a long list, then
+            # (kinds 2 / 23 / 24 with and without the frontier start, kind 32 = the cooperative descent with a short and a long list, then
             # the tile shape) and keeps the fastest.  The step below is the same rmclhip_rcc_find_async either way.
             k_t, ms_t = rcc.autotune(Tbm)
             tuned = {"rule_kind": rule_kind, "rule_kernel_ms": round(rule_kernel_ms, 5), "chosen_kind": k_t, "autotune_kernel_ms": round(ms_t, 5)}

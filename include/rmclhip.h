@@ -383,18 +383,19 @@ rmclhip_status rmclhip_rcc_sharded_replica(rmclhip_rcc_sharded* h, uint32_t rank
 rmclhip_status rmclhip_rcc_sharded_correct_batch(rmclhip_rcc_sharded* h, const rmclhip_transform* Tbm, uint32_t nposes,
                                                  rmclhip_transform* Tdelta_out, rmclhip_cross_statistics* stats_out);
 
-/* kernel variant selection: bits 0..3 (+ bit 13 = 16 more) traversal kind.  15 = automatic, the default: four
- * lanes per ray up to 57344 rays in flight (kind 2); above that one lane per ray STARTING AT THE MAP'S FRONTIER (the wave culls
- * the <= 256 references of BFS depth 4 against its tile's pyramid and every ray tests the few survivors: the top levels of
+/* kernel variant selection: bits 0..3 (+ bit 13 = 16 more, bit 14 = 32 more) traversal kind.  15 = automatic, the
+ * default: four lanes per ray up to 57344 rays in flight (kind 2); above that one lane per ray STARTING AT THE MAP'S FRONTIER (the
+ * wave culls the <= 256 references of BFS depth 4 against its tile's pyramid and every ray tests the few survivors: the top levels of
  * the descent cost one cooperative pass) -- kind 23 on the full-precision nodes up to 262144 rays, kind 24 on the 64-B quantised
- * nodes of the particle filter's tree (leaves <= 2 triangles) above (large scans, pose batches).  librmclhip.so builds those three plus 0 = wave packet
- * and 31 (round 6) = kind 23 whose wave keeps descending COOPERATIVELY below the frontier: per level, lane l tests child (l & 3) of the
- * wave's surviving node (l >> 2) against the tile's pyramid, so the levels below the frontier cost one round trip per level and wave
- * instead of one per node visit and ray; the rays start with the few leaves their tile sees.  17 % faster than 23 on the open benchmark
- * map (C2 sphere-100k 17.3 -> 14.3 us), slower on rooms whose grazing tiles see long strips of the map (room-100k 25.1 -> 25.6 ... 29.7 us
- * depending on how long the wave's list may grow): the rule does not select it, rmclhip_rcc_autotune measures it on the caller's map; every other kind is a measured-and-
- * rejected or superseded experiment that lives in librmclhip_lab.so (include/rmclhip_lab.h lists them) and is accepted here
- * only while that library is loaded (RMCLHIP_ERR_UNSUPPORTED otherwise),
+ * nodes of the particle filter's tree (leaves <= 2 triangles) above (large scans, pose batches).  librmclhip.so builds those three plus
+ * 0 = wave packet and 32 (round 6) = the wave keeps descending COOPERATIVELY below the frontier: lane l tests entry (l & 15) of the
+ * 16-wide twin of surviving node (l >> 4) against the tile's pyramid (two tree levels per round trip and wave instead of one round
+ * trip per node visit and ray), then every ray marks the final leaves whose box it enters in a 64-bit mask and tests just those -- no
+ * ordered hand-over, no stack.  29 % faster than 23 on the open benchmark map (C2 sphere-100k 17.2 -> 12.2 us, sphere-1M 22.3 -> 19.6),
+ * slower on rooms whose grazing tiles see long strips of the map (room-100k 25.4 -> 30.8 us): the rule does not select it,
+ * rmclhip_rcc_autotune measures it on the caller's map.  Every other kind (31 = round 6's first form of 32 with the sorted
+ * hand-over among them) is a measured-and-rejected or superseded experiment that lives in librmclhip_lab.so (include/rmclhip_lab.h lists
+ * them) and is accepted here only while that library is loaded (RMCLHIP_ERR_UNSUPPORTED otherwise),
  * bits 4..7 = 1 + log2(tile width) of the wave's scan-image tile (0 = automatic: 16 wide x 4 tall, 8x8 for the wave packet),
  * bit 8 = fused last-block reduction tail (A/B), bit 9 = disable the hipGraph MICP loop (A/B), bits 10..12 = form
  * of the MICP loop (0 = one launch per iteration, the default; 1 = reduce + solve launches; 2..6 = persistent
@@ -454,14 +455,14 @@ rmclhip_status rmclhip_rcc_micp_fast_info(const rmclhip_rcc* rcc, rmclhip_micp_f
 rmclhip_status rmclhip_rcc_find_variant(const rmclhip_rcc* rcc, uint32_t nposes, int* variant_out);
 /* Measurement instead of brackets: the automatic rule above was tuned on two synthetic maps; which traversal is fastest for a
  * single scan depends on the map (open / occluded), the model's size and shape, and where the sensor is.  This call times the
- * product's single-scan kinds (2, 23, 24 -- the latter two with and without the frontier start -- and 31 with a short and a long list) on THIS operator's map and model at
+ * product's single-scan kinds (2, 23, 24 -- the latter two with and without the frontier start -- and 32 with a short and a long list) on THIS operator's map and model at
  * the given pose (40 short launches each, HIP events), then the winner's tile shape (4, 8, 16 or 32 rays wide) and makes the fastest one the automatic choice for single scans until the model or the tiling changes.  Results do not
  * depend on the kind (bit-identical); batches keep the rule.  Opt-in: never run behind the caller's back.
  * chosen_kind / kernel_ms may be NULL. */
 rmclhip_status rmclhip_rcc_autotune(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est, int* chosen_kind, float* kernel_ms);
 /* the same for pose batches (find_batch / correct_batch) of about nposes scans: kinds 23 / 24, each with and without the frontier
  * start (on an occluded map the per-wave culling can cost a batch more than the top levels it skips).  Both calls report the
- * choice as 2 / 23 / 24 / 31 or -- frontier start off -- as 19 / 22, round 2's numbers for the same traversals. */
+ * choice as 2 / 23 / 24 / 32 or -- frontier start off -- as 19 / 22, round 2's numbers for the same traversals. */
 rmclhip_status rmclhip_rcc_autotune_batch(rmclhip_rcc* rcc, const rmclhip_transform* Tbm, uint32_t nposes, int* chosen_kind,
                                           float* kernel_ms);
 /* rm::Simulator::simulate(Memory<Transform>, Bundle&) (batch form, lidar_corrector_embree_benchmark.cpp:117):

@@ -49,10 +49,11 @@ rmclhip_status rmclhip_debug_micp_moments(rmclhip_rcc* rcc, double* totals96, ui
 rmclhip_status rmclhip_debug_probe_find(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est, int mode, uint32_t* log_out,
                                         size_t log_cap_dwords, uint32_t* n_tiles_out);
 
-/* A/B knobs of the cooperative descent of find kind 31 (traverse.hip.h frontier_descent_start): the wave stops descending when a level
- * would leave more than final_cap entries (<= 64, default 64) or after max_levels levels (default 24; 0 = kind 23's frontier start with
- * kind 31's bookkeeping; bit 31 set: descend on the four-wide nodes even where the map carries the 16-wide twins -- two tree levels per pass
- * -- A/B).  Results do not depend on any of them.  Exported by librmclhip.so. */
+/* A/B knobs of the cooperative descent of find kinds 32 / 31 (traverse.hip.h frontier_descent_start): the wave stops descending when a
+ * level would leave more than final_cap entries (<= 64, default 64) or after (max_levels & 255) levels (default 24; 0 = kind 23's
+ * frontier start with the descent's bookkeeping); bits 8..15 of max_levels, when not 0: kind 32's bound on the final leaves one ray may
+ * enter before its wave starts at the root instead (default 24); bit 31 set: descend on the four-wide nodes even where the map carries
+ * the 16-wide twins (A/B).  Results do not depend on any of them.  Exported by librmclhip.so. */
 rmclhip_status rmclhip_rcc_set_descent(rmclhip_rcc* rcc, uint32_t final_cap, uint32_t max_levels);
 
 /* TEST knob of the loopback communicator (rmclhip_comm_create_loopback): its all-reduce adds the ranks' contributions starting at

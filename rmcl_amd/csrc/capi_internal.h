@@ -159,7 +159,7 @@ struct rmclhip_map {
   uint32_t n_frontier_pf = 0;
   uint32_t* d_qnodes_pf = nullptr;  // Node4Q array of the particle filter's own tree (leaves <= kPfLeafTris, same records)
   uint32_t* d_cnodes = nullptr;  // Node4C twins
-  uint32_t* d_cnodes16 = nullptr;  // Node16C twins (maps of up to kMaxNodes16 nodes; find kind 31 descends two levels per pass on them), else null
+  uint32_t* d_cnodes16 = nullptr;  // Node16C twins (maps of up to kMaxNodes16 nodes; find kind 32 descends two levels per pass on them), else null
   uint32_t* d_tris = nullptr;
   uint64_t bytes = 0;
   // near grid of the closest-point queries (kernels.h NearGrid): built on the first rmclhip_rcc_find_cpc of any operator of this map
@@ -203,7 +203,8 @@ struct rmclhip_rcc {
   uint32_t n_model = 0;      // per pose
   uint32_t nposes_last = 0;
   bool descent_wide = true;   // ... on the 16-wide twins when the map has them (A/B: rmclhip_rcc_set_descent's max_levels bit 31 clears it)
-  uint32_t descent_final_cap = 64, descent_levels = 24;   // kind 31's cooperative descent (rmclhip_rcc_set_descent, include/rmclhip_lab.h)
+  uint32_t descent_final_cap = 64, descent_levels = 24;   // kind 32's cooperative descent (rmclhip_rcc_set_descent, include/rmclhip_lab.h)
+  uint32_t descent_leaf_cap = 24;   // kind 32: a wave one of whose rays enters more final leaves than this starts at the root (lab: rmclhip_rcc_set_descent)
   uint32_t out_mask = RMCLHIP_OUT_ALL;   // rmclhip_rcc_set_outputs: which model buffers find / find_batch write
   // reduction
   DevBuf<double> d_partials;

@@ -182,7 +182,7 @@ RMCL_INTERNAL rmclhip_status map_upload(rmclhip_ctx* ctx, const BvhHost& bvh, rm
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_cnodes), cb);
   if (e == hipSuccess) e = hipMemcpy(m->d_cnodes, bvh.cnodes.data(), cb, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(m->d_tris, bvh.tris.data(), tb, hipMemcpyHostToDevice);
-  // the 16-wide twins for the cooperative descent of find kind 31 (512 B per node: 8 MB for a 100 k-triangle map), derived on the device;
+  // the 16-wide twins for the cooperative descent of find kind 32 (512 B per node: 8 MB for a 100 k-triangle map), derived on the device;
   // maps beyond kMaxNodes16 nodes (~4 M triangles) go without -- the descent then walks the four-wide nodes
   constexpr size_t kMaxNodes16 = 600000;
   size_t c16b = 0;

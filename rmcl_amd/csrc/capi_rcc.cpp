@@ -443,7 +443,8 @@ RMCL_INTERNAL void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t npos
     // stack_need <= 64 bounds a descent from the ROOT only.  From the frontier the descent may still push what the tree's deepest path
     // pushes, so the start may leave at most 64 - stack_need entries (traverse.hip.h frontier_start returns the root beyond that); a
     // tree that leaves no room for even two starts every ray at the root.
-    p.descent_final_cap = r->descent_final_cap; p.descent_levels = r->descent_levels;
+    p.descent_final_cap = r->descent_final_cap;
+    p.descent_levels = (r->descent_levels & 0xFFu) | (r->descent_leaf_cap << 8);   // (traverse.hip.h frontier_descent_start: levels | most leaves per ray << 8)
     p.frontier_max_preload = (need < 64u) ? 64u - need : 0u;
     if (p.frontier_max_preload < 2u) p.tile_planes = nullptr;
   }
@@ -490,7 +491,7 @@ RMCL_INTERNAL rmclhip_status find_enqueue(rmclhip_rcc* r, const xform& Tbm, bool
     r->ccs_loop = r->ccs_since_find != 0u;
     r->ccs_since_find = 0u; r->ccs_max_rho = 0.f; r->ccs_max_tau = 0.f;
     const int fv = find_variant(r, 1);
-    if (r->ccs_loop && r->fast_mode == 1 && !r->fused_tail && r->n_dataset != 0u && (fv == 23 || fv == 31 || fv == 2) && r->ccs_last_maxd == r->ccs_last_maxd &&
+    if (r->ccs_loop && r->fast_mode == 1 && !r->fused_tail && r->n_dataset != 0u && (fv == 23 || fv == 32 || fv == 2) && r->ccs_last_maxd == r->ccs_last_maxd &&
         micp_outputs_selected(r)) {
       gate_band(r, r->ccs_last_maxd, &r->pend_lo, &r->pend_hi);
       r->pend_rho = r->fast_rho_cap; r->pend_tau = r->fast_tau_cap;
@@ -911,8 +912,8 @@ static rmclhip_status enqueue_find_with_moments(rmclhip_rcc* r, const xform& Tsm
   fp.Tsm = Tsm;
   fp.Tms = xinv(Tsm);
   r->last_moment_find_kind = fv;
-  r->last_moment_find_tiled = epilogue_allowed && (fv == 23 || fv == 31 || fv == 2);
-  if (epilogue_allowed && (fv == 23 || fv == 31 || fv == 2)) {
+  r->last_moment_find_tiled = epilogue_allowed && (fv == 23 || fv == 32 || fv == 2);
+  if (epilogue_allowed && (fv == 23 || fv == 32 || fv == 2)) {
     const uint32_t nb = find_moments_blocks(fp, fv), wpb = (fv == 2) ? 1u : 4u;   // mask words per workgroup
     HIPCHK(r->d_fast_partials.reserve(static_cast<size_t>(nb) * kMicpFastMoments));
     HIPCHK(r->d_fast_mask.reserve(static_cast<size_t>(nb) * wpb));
@@ -1265,7 +1266,7 @@ rmclhip_status rmclhip_rcc_correct_once(rmclhip_rcc* r, const rmclhip_transform*
         cl.gate_lo = maxd; cl.gate_hi = maxd;
         cl.seq = r->h_call->seq;
         const int fv = find_variant(r, 1);
-        const bool tiled = r->fast_mode != 3 && (fv == 23 || fv == 31 || fv == 2);   // the find forms the moments in its epilogue
+        const bool tiled = r->fast_mode != 3 && (fv == 23 || fv == 32 || fv == 2);   // the find forms the moments in its epilogue
         const uint32_t nb = tiled ? find_moments_blocks(fp, fv) : micp_fast_blocks(nred), wpb = (fv == 2) ? 1u : 4u;
         bool device_loop = r->fast_mode != 1;
         if (r->fast_mode == 1) {

@@ -64,11 +64,11 @@ rmclhip_status rmclhip_rcc_time_find(rmclhip_rcc* r, const rmclhip_transform* Tb
 
 // candidates of the measured choice: {template kind, frontier start}; reported as kinds 2 / 23 / 24 and -- without the frontier
 // start -- as round 2's numbers for the same traversals, 19 / 22
-struct TuneCand { int kind; bool frontier; int reported; uint32_t descent_cap; };   // descent_cap: kind 31 only (rmclhip_rcc_set_descent), 0 otherwise
-// (kind 31 = kind 23 behind the cooperative descent, with the wave's final list capped at 12, 32 or 64 entries: open maps want the
+struct TuneCand { int kind; bool frontier; int reported; uint32_t descent_cap; };   // descent_cap: kind 32 only (rmclhip_rcc_set_descent), 0 otherwise
+// (kind 32 = the cooperative descent below the frontier, with the wave's final list capped at 12, 32 or 64 entries: open maps want the
 // long list, rooms the short one or none -- profiles/r06_descent_maps_ab.txt)
 static const TuneCand kTuneSingle[8] = {{2, true, 2, 0}, {23, true, 23, 0}, {23, false, 19, 0}, {24, true, 24, 0}, {24, false, 22, 0},
-                                        {31, true, 31, 12}, {31, true, 31, 32}, {31, true, 31, 64}};
+                                        {32, true, 32, 12}, {32, true, 32, 32}, {32, true, 32, 64}};
 static const TuneCand kTuneBatch[4] = {{23, true, 23, 0}, {23, false, 19, 0}, {24, true, 24, 0}, {24, false, 22, 0}};
 
 rmclhip_status rmclhip_rcc_autotune(rmclhip_rcc* r, const rmclhip_transform* Tbm_est, int* chosen_kind, float* kernel_ms) {
@@ -84,7 +84,7 @@ rmclhip_status rmclhip_rcc_autotune(rmclhip_rcc* r, const rmclhip_transform* Tbm
   const TuneCand* best = nullptr;
   float best_ms = 0.f;
   for (const TuneCand& c : kTuneSingle) {
-    if (c.kind == 31 && (r->kind == kModelOnDn || r->map->d_cnodes == nullptr)) continue;   // (no common pyramid / no child-major nodes: kind 23)
+    if (c.kind == 32 && (r->kind == kModelOnDn || r->map->d_cnodes == nullptr)) continue;   // (no common pyramid / no child-major nodes: kind 23)
     r->tuned_kind = c.kind; r->tuned_frontier = c.frontier;
     if (c.descent_cap != 0u) r->descent_final_cap = c.descent_cap;
     float t[5];
@@ -236,13 +236,13 @@ rmclhip_status rmclhip_rcc_time_caller_loop(rmclhip_rcc* r, const rmclhip_transf
 rmclhip_status rmclhip_rcc_set_variant(rmclhip_rcc* r, int variant) {
   ApiGuard guard_("rmclhip_rcc_set_variant");
   if (!r || variant < 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: bad arguments");
-  // bit 13 adds 16 to the traversal kind (kinds 16..31)
-  const int kind = (variant & 0xF) | (((variant >> 13) & 1) << 4), tile = (variant >> 4) & 0xF;
-  if (kind == 3 || kind == 18 || kind > 31 || tile > 7 || (variant >> 14) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
+  // bit 13 adds 16 to the traversal kind (kinds 16..31), bit 14 adds 32
+  const int kind = (variant & 0xF) | (((variant >> 13) & 1) << 4) | (((variant >> 14) & 1) << 5), tile = (variant >> 4) & 0xF;
+  if (kind == 3 || kind == 18 || kind > 32 || tile > 7 || (variant >> 15) != 0) return fail(RMCLHIP_ERR_INVALID, "rcc_set_variant: unknown variant");
   // (kind 1 also selects the one-lane-per-point form of the closest-point query, which the product owns)
   if (kind != 15 && kind != 1 && !find_kind_in_product(kind) && lab_hooks() == nullptr)
     return fail(RMCLHIP_ERR_UNSUPPORTED, "rcc_set_variant: this traversal kind is an experiment -- it lives in librmclhip_lab.so, "
-                                         "which is not loaded (the product builds kinds 0, 2, 23, 24 and the automatic rule 15)");
+                                         "which is not loaded (the product builds kinds 0, 2, 23, 24, 32 and the automatic rule 15)");
   r->variant = kind;
   const bool tiling_changed = r->tile_override != tile;
   r->tile_override = tile;
@@ -266,7 +266,8 @@ rmclhip_status rmclhip_rcc_set_descent(rmclhip_rcc* r, uint32_t final_cap, uint3
   ApiGuard guard_("rmclhip_rcc_set_descent");
   if (!r || final_cap > 64u) return fail(RMCLHIP_ERR_INVALID, "rcc_set_descent: final_cap <= 64");
   r->descent_final_cap = final_cap;
-  r->descent_levels = max_levels & 0x7FFFFFFFu;
+  r->descent_levels = max_levels & 0xFFu;
+  if ((max_levels >> 8) & 0xFFu) r->descent_leaf_cap = (max_levels >> 8) & 0xFFu;   // bits 8..15 (A/B): kind 32's leaves-per-ray bound, 0 = keep
   r->descent_wide = (max_levels >> 31) == 0u;   // bit 31 (A/B): the four-wide nodes even where the map has the 16-wide twins
   r->graph_dirty = true; r->fast_graph_dirty = true;
   return RMCLHIP_OK;
@@ -393,7 +394,8 @@ rmclhip_status rmclhip_debug_wave_clock(rmclhip_rcc* r, const rmclhip_transform*
   const uint32_t ntiles = p.tiles_x * p.tiles_y;
   uint32_t nblocks = (variant == 2) ? ntiles : (ntiles + 3u) / 4u;
   nblocks = (nblocks + 7u) & ~7u;
-  const size_t dwords = static_cast<size_t>(nblocks) * 4u * 8u;
+  // kind 31: 16 more words per wave (the descent's phase stamps) behind the [n_waves][8] table
+  const size_t dwords = static_cast<size_t>(nblocks) * 4u * ((variant == 31 || variant == 32) ? 24u : 8u);
   if (n_waves_out) *n_waves_out = nblocks * 4u;
   if (cap_dwords < dwords) return fail(RMCLHIP_ERR_INVALID, "debug_wave_clock: buffer too small");
   uint32_t* d = nullptr;

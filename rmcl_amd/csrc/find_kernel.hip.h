@@ -23,13 +23,13 @@ constexpr int kFindBfRows = 24;  // LDS stack rows per lane (sentinel included) 
 constexpr uint32_t kFindTailLdsDwords = 16u * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords;
 
 // kinds 19..22: kind 17 + leaving the node phase when 32 / 24 / 16 / 8 lanes hold a leaf
-constexpr int find_leaf_trigger(int trav) { return (trav == 19 || trav == 20 || trav == 23 || (trav >= 26 && trav <= 31)) ? 10 : 0; }   // leave at <= 4/10 of the round's rays
+constexpr int find_leaf_trigger(int trav) { return (trav == 19 || trav == 20 || trav == 23 || (trav >= 26 && trav <= 32)) ? 10 : 0; }   // leave at <= 4/10 of the round's rays
 // kinds 23 / 24: kinds 19 / 22 whose rays start at the map's frontier (traverse.hip.h frontier_start) instead of the root
-// kind 31 (round 6): kind 23 whose wave keeps descending cooperatively below the frontier (traverse.hip.h frontier_descent_start)
-constexpr bool find_frontier(int trav) { return trav == 23 || trav == 24 || (trav >= 25 && trav <= 31); }
-// LDS of the one-lane-per-ray kinds with quad-finished tails (23, 31, ...), in dwords; kind 31 appends its waves' descent lists
+// kinds 31 / 32 (round 6): the wave keeps descending cooperatively below the frontier (traverse.hip.h frontier_descent_start); 32 = the product's form (one bit per final leaf and ray), 31 = the first form (sorted hand-over), kept in the lab for A/B
+constexpr bool find_frontier(int trav) { return trav == 23 || trav == 24 || (trav >= 25 && trav <= 32); }
+// LDS of the one-lane-per-ray kinds with quad-finished tails (23, 31, ...), in dwords; kinds 31 and 32 append their waves' descent lists
 constexpr uint32_t kFindBfTailLdsDwords = static_cast<uint32_t>(kFindBfRows) * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords;
-// kind 31 has no quad tail: its LDS is the lane stacks, then the four waves' descent lists
+// kinds 31 and 32 have no quad tail: its LDS is the lane stacks, then the four waves' descent lists
 constexpr uint32_t kFind31ListsAt = static_cast<uint32_t>(kFindBfRows) * 256u;
 constexpr uint32_t kFind31LdsDwords = kFind31ListsAt + 4u * kDescentWaveDwords;
 static_assert(kFind31ListsAt % 4u == 0u, "the descent lists are read and written 16 B at a time");   // 26: 23 on the quantised nodes; 27: 23 + record prefetch; 28: 23 with the pipelined node step; 29 / 30: 23 with four / three of the five ordering steps
@@ -239,7 +239,7 @@ __device__ __forceinline__ void find_moments_wave(const FindParams& p, uint32_t*
 template <uint32_t kModel, int kTrav, bool kClock = false, bool kMoments = false>
 __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
-  static_assert(!kMoments || ((kTrav == 23 || kTrav == 31 || kTrav == 2) && !kClock), "the moment epilogue is built for kinds 23, 31 and 2");
+  static_assert(!kMoments || ((kTrav == 23 || kTrav == 31 || kTrav == 32 || kTrav == 2) && !kClock), "the moment epilogue is built for kinds 23, 31, 32 and 2");
   __shared__ double s_mom_red[kMoments ? 4 : 1][kMoments ? kMomTile : 1];
   __shared__ uint32_t s_mom_piece[4];
   constexpr bool kPacket = (kTrav == 0);
@@ -310,6 +310,7 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   const float ray_tfar = (valid && finite) ? p.tfar : -1.0f;
 
   uint32_t clk_trace0 = 0, clk_trace1 = 0, clk_visits = 0, clk_dbg[4] = {0u, 0u, 0u, 0u}, clk_descent = 0, clk_start = 0;
+  uint32_t clk_stamps[16] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // kinds 31 and 32, clocked: frontier_descent_start's phase boundaries
   if (kClock && p.wave_clock != nullptr) {
     uint64_t t;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
@@ -345,16 +346,18 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
     // written and read back on the critical path of every wave; seen as 1 MiB of extra HBM writes per C2 launch)
     constexpr bool kWwStack = (kTrav == 4 || kTrav == 22 || kTrav == 24);   // trace_lane_ww: first stack row 0; branch-free forms: row 1
     TraceStart start;
+    RayHit coop_seed = {ray_tfar, kNone};   // kind 32: the closest hit among the leaves the wave tested together (frontier_descent_start)
     start.cur = (ray_tfar >= 0.0f) ? 0u : 0x7FFFFFFFu;
     start.sp = kWwStack ? 0u : 1u;
     const TraceStart* sp0 = &start;
     if constexpr (find_frontier(kTrav) && kModel != kModelOnDn) {   // (OnDn: one origin per ray, no common pyramid)
       if (p.tile_planes != nullptr) {     // (no table: the rays start at the root)
         const float* planes = p.tile_planes + static_cast<size_t>(__builtin_amdgcn_readfirstlane(tile)) * 16u;
-        if (kTrav == 31)
-          start = frontier_descent_start<kFindBfRows, 1>(p.frontier, p.n_frontier, p.cnodes, p.cnodes16, p.scene_center, p.scene_half_diag, planes, Tsm.R, p.tfar,
+        if (kTrav == 31 || kTrav == 32)
+          start = frontier_descent_start<kFindBfRows, 1, kTrav == 32>(p.frontier, p.n_frontier, p.cnodes, p.cnodes16, p.scene_center, p.scene_half_diag, planes, Tsm.R, p.tfar,
                                                          org_m, dir_m, ray_tfar, lane, lds_dyn + threadIdx.x, kBfStride, p.frontier_max_preload,
-                                                         lds_dyn + kFind31ListsAt + wave * kDescentWaveDwords, min(p.descent_final_cap, kDescentCap), p.descent_levels, kClock ? &clk_descent : nullptr);
+                                                         lds_dyn + kFind31ListsAt + wave * kDescentWaveDwords, min(p.descent_final_cap, kDescentCap), p.descent_levels, kClock ? &clk_descent : nullptr,
+                                                         kClock ? clk_stamps : nullptr, p.tris, &coop_seed);
         else if (kTrav == 23 || (kTrav >= 26 && kTrav <= 30))
           start = frontier_start<kFindBfRows, 1>(p.frontier, p.n_frontier, p.scene_center, p.scene_half_diag, planes, Tsm.R, p.tfar, org_m,
                                                  dir_m, ray_tfar, lane, lds_dyn + threadIdx.x, kBfStride, p.frontier_max_preload);
@@ -378,11 +381,11 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
           lds_dyn + kFindTailLdsDwords);
     else if (kTrav == 1) trace_lane_bf<kFindBfRows>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
     else if (kTrav == 12) trace_lane_bf<kFindBfRows, false, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
-    else if (kTrav == 16 || kTrav == 17 || kTrav == 19 || kTrav == 20 || kTrav == 23 || (kTrav >= 26 && kTrav <= 31))
-      trace_lane_bf_tail<kFindBfRows, kTrav != 16 && kTrav != 20, find_leaf_trigger(kTrav), kTrav == 26, kTrav == 27, kTrav == 28, (kTrav == 29 ? 4 : (kTrav == 30 ? 3 : 5)), kTrav != 31>(kTrav == 26 ? p.qnodes : p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x,
+    else if (kTrav == 16 || kTrav == 17 || kTrav == 19 || kTrav == 20 || kTrav == 23 || (kTrav >= 26 && kTrav <= 32))
+      trace_lane_bf_tail<kFindBfRows, kTrav != 16 && kTrav != 20, find_leaf_trigger(kTrav), kTrav == 26, kTrav == 27, kTrav == 28, (kTrav == 29 ? 4 : (kTrav == 30 ? 3 : 5)), kTrav < 31>(kTrav == 26 ? p.qnodes : p.nodes, p.cnodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x,
                                                    lds_dyn + kFindBfRows * 256u,
                                                    lds_dyn + kFindBfRows * 256u + kQuadStackEntries * 64u + (threadIdx.x >> 6) * (kTailRays * kTailXferDwords), h,
-                                                   kClock ? &clk_visits : nullptr, sp0, kClock ? clk_dbg : nullptr, &pre_nrec, &pre_rec);
+                                                   kClock ? &clk_visits : nullptr, sp0, kClock ? clk_dbg : nullptr, &pre_nrec, &pre_rec, (kTrav == 32) ? &coop_seed : nullptr);
     else if (kTrav == 13) trace_lane_bf<kFindBfRows, false, false, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
     else if (kTrav == 14) trace_lane_bf<kFindBfRows, false, true, true>(p.nodes, p.tris, org_m, dir_m, ray_tfar, lds_dyn + threadIdx.x, h);
     else if (kTrav >= 5 && kTrav <= 10)
@@ -454,10 +457,15 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
     if ((threadIdx.x & 63u) == 0u) {
       uint32_t* w = p.wave_clock + 8u * ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + wave);
       // kinds 23 / 31: w[2] = cycles of the start (>> 4, 16 bits) | the wave's most leaf visits of a lane << 16 | most node visits << 24 instead of the realtime clock
-      const uint32_t w2 = (kTrav == 23 || kTrav == 31) ? (min((clk_start - clk_trace0) >> 4, 0xFFFFu) | (wmax(min(clk_dbg[3], 255u), 8) << 16) | (wmax(min(clk_visits, 255u), 8) << 24)) : clk_real;
+      const uint32_t w2 = (kTrav == 23 || kTrav == 31 || kTrav == 32) ? (min((clk_start - clk_trace0) >> 4, 0xFFFFu) | (wmax(min(clk_dbg[3], 255u), 8) << 16) | (wmax(min(clk_visits, 255u), 8) << 24)) : clk_real;
       w[0] = clk_begin; w[1] = static_cast<uint32_t>(t); w[2] = w2; w[3] = (tile & 0xFFFFFFu) | (xcc << 24);
       w[4] = clk_trace0; w[5] = clk_trace1; w[6] = static_cast<uint32_t>(t2);
-      w[7] = (kTrav == 31) ? clk_descent : clk_w7;   // kind 31: what its cooperative descent did (traverse.hip.h frontier_descent_start)
+      w[7] = (kTrav == 31 || kTrav == 32) ? clk_descent : clk_w7;   // kinds 31 and 32: what its cooperative descent did (traverse.hip.h frontier_descent_start)
+      if (kTrav == 31 || kTrav == 32) {   // ... and when: 16 more words per wave behind the table of all waves
+        uint32_t* ws = p.wave_clock + 8u * (gridDim.y * gridDim.x * 4u) + 16u * ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + wave);
+#pragma unroll
+        for (uint32_t i = 0; i < 16u; ++i) ws[i] = clk_stamps[i];
+      }
     }
   }
 }

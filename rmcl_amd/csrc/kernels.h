@@ -22,7 +22,7 @@ struct FindParams {
   const uint32_t* nodes;   // Node4[]
   const uint32_t* qnodes;  // Node4Q[] (quantised twins)
   const uint32_t* cnodes;  // Node4C[] (child-major twins)
-  const uint32_t* cnodes16;  // Node16C[] (a node's grandchildren, child-major; kind 31's two-levels-per-pass descent), nullable
+  const uint32_t* cnodes16;  // Node16C[] (a node's grandchildren, child-major; kind 32's two-levels-per-pass descent), nullable
   const uint32_t* tris;    // TriRec[]
   uint32_t n_nodes;        // number of Node4 (the LDS-resident top of the tree copies min(kTop, n_nodes) of them)
   // spherical: [cos(phi_v) (H) | sin(phi_v) (H) | cos(theta_h) (W) | sin(theta_h) (W)], host libm values
@@ -54,7 +54,7 @@ struct FindParams {
   float scene_half_diag;
   const float* tile_planes;      // per tile of the scan image: the pyramid of its rays in the sensor frame (k_tile_planes), or null
   uint32_t frontier_max_preload; // stack entries the frontier start may leave per lane: 64 - stack_need of the tree the kind walks
-  // kind 31 (traverse.hip.h frontier_descent_start): the wave stops descending when a level would leave more than descent_final_cap
+  // kind 32 (traverse.hip.h frontier_descent_start): the wave stops descending when a level would leave more than descent_final_cap
   // entries (<= 64) or after descent_levels levels
   uint32_t descent_final_cap, descent_levels;
   // diagnostics (nullable): per physical wave {s_memtime at entry, at exit (low 32 bits), s_memrealtime at entry, tile | xcc << 24}

@@ -2376,9 +2376,9 @@ hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStre
   } else if (variant == 23) {  // one lane per ray: frontier start, branch-free step, one-round-trip leaves, quad-finished tails, leaf trigger
     const size_t lds = (static_cast<size_t>(kFindBfRows) * 256u + kQuadStackEntries * 64u + 4u * kTailRays * kTailXferDwords) * sizeof(uint32_t);
     RMCL_LAUNCH_FIND(23, lds)
-  } else if (variant == 31) {  // kind 23 behind the cooperative descent: + the four waves' lists
+  } else if (variant == 32) {  // the cooperative descent below the frontier, one bit per final leaf and ray: + the four waves' lists
     const size_t lds = static_cast<size_t>(kFind31LdsDwords) * sizeof(uint32_t);
-    RMCL_LAUNCH_FIND(31, lds)
+    RMCL_LAUNCH_FIND(32, lds)
   } else {                     // 24: one lane per ray on the 64-B quantised nodes: frontier start, leaf trigger, 16 LDS rows
     const size_t lds4 = 16u * 256u * sizeof(uint32_t);
     RMCL_LAUNCH_FIND(24, lds4)
@@ -2394,7 +2394,7 @@ uint32_t find_moments_blocks(const FindParams& p, int variant) {
 
 hipError_t launch_find_moments(const FindParams& p, ModelKind kind, int variant, hipStream_t s) {
   static_assert(kMomRow == kMicpFastMoments && kMomRow == static_cast<uint32_t>(kMom), "one partial-row layout");
-  if (p.nposes != 1u || p.wave_clock != nullptr || p.mom_partials == nullptr || p.mom_unc_mask == nullptr || (variant != 23 && variant != 31 && variant != 2))
+  if (p.nposes != 1u || p.wave_clock != nullptr || p.mom_partials == nullptr || p.mom_unc_mask == nullptr || (variant != 23 && variant != 32 && variant != 2))
     return hipErrorInvalidValue;
   dim3 grid(find_moments_blocks(p, variant), 1, 1), block(256, 1, 1);
   if (variant == 2) {
@@ -2409,13 +2409,13 @@ hipError_t launch_find_moments(const FindParams& p, ModelKind kind, int variant,
     }
     return hipGetLastError();
   }
-  if (variant == 31) {   // kind 23's epilogue behind the cooperative descent (+ the four waves' lists)
+  if (variant == 32) {   // kind 23's epilogue behind the cooperative descent (+ the four waves' lists)
     const size_t lds31 = static_cast<size_t>(kFind31LdsDwords) * sizeof(uint32_t);
     switch (kind) {
-      case kModelSpherical: hipLaunchKernelGGL((k_find<kModelSpherical, 31, false, true>), grid, block, lds31, s, p); break;
-      case kModelO1Dn: hipLaunchKernelGGL((k_find<kModelO1Dn, 31, false, true>), grid, block, lds31, s, p); break;
-      case kModelPinhole: hipLaunchKernelGGL((k_find<kModelPinhole, 31, false, true>), grid, block, lds31, s, p); break;
-      case kModelOnDn: hipLaunchKernelGGL((k_find<kModelOnDn, 31, false, true>), grid, block, lds31, s, p); break;
+      case kModelSpherical: hipLaunchKernelGGL((k_find<kModelSpherical, 32, false, true>), grid, block, lds31, s, p); break;
+      case kModelO1Dn: hipLaunchKernelGGL((k_find<kModelO1Dn, 32, false, true>), grid, block, lds31, s, p); break;
+      case kModelPinhole: hipLaunchKernelGGL((k_find<kModelPinhole, 32, false, true>), grid, block, lds31, s, p); break;
+      case kModelOnDn: hipLaunchKernelGGL((k_find<kModelOnDn, 32, false, true>), grid, block, lds31, s, p); break;
       default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -421,7 +421,8 @@ hipError_t lab_find_kind(const FindParams& p, int variant, hipStream_t s) {
     case 27: return lab_find_one<27, kClock>(p, grid, lds_bf_tail, s);                           // 23 + prefetch of the hit record's normal (experiment iv)
     case 26: return lab_find_one<26, kClock>(p, grid, lds_bf_tail, s);                           // 23 on the quantised nodes
     case 25: return lab_find_one<25, kClock>(p, grid, kQuadStackEntries * 64u * sizeof(uint32_t), s);   // 2 + frontier start
-    case 31: return lab_find_one<31, kClock>(p, grid, kFind31LdsDwords * sizeof(uint32_t), s);   // (clocked only) 23 + cooperative descent
+    case 31: return lab_find_one<31, kClock>(p, grid, kFind31LdsDwords * sizeof(uint32_t), s);   // 23 + cooperative descent, sorted hand-over of the final entries (round 6's first form)
+    case 32: return lab_find_one<32, kClock>(p, grid, kFind31LdsDwords * sizeof(uint32_t), s);   // (clocked only) 31 with one bit per final leaf and ray instead of the sorted hand-over
     default: return kLabMissing;
   }
 }

@@ -9,7 +9,7 @@
 namespace rmclhip {
 
 struct LabHooks {
-  // k_find kinds outside {0, 2, 23, 24, 31}; with_clock: the clocked instantiation of ANY kind (p.wave_clock != nullptr)
+  // k_find kinds outside {0, 2, 23, 24, 32}; with_clock: the clocked instantiation of ANY kind (p.wave_clock != nullptr)
   hipError_t (*find)(const FindParams& p, ModelKind kind, int variant, bool with_clock, hipStream_t s);
   hipError_t (*find_probe)(const FindParams& p, int mode, uint32_t* probe_log, hipStream_t s);
   // particle filter: the round kernels (refill 0) and the round-2 persistent kernel
@@ -18,7 +18,7 @@ struct LabHooks {
 
 // traversal kinds compiled into the product
 constexpr bool find_kind_in_product(int variant) {
-  return variant == 0 || variant == 2 || variant == 23 || variant == 24 || variant == 31;
+  return variant == 0 || variant == 2 || variant == 23 || variant == 24 || variant == 32;
 }
 
 const LabHooks* lab_hooks();   // nullptr until librmclhip_lab.so is loaded

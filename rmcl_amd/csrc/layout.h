@@ -78,7 +78,7 @@ static_assert(sizeof(Node4C) == 128, "Node4C must be 128 B");
 
 // 16-wide twin of a node, 512 B, same index (round 6, built on the device from the Node4C array): entry 4 c + g = grandchild g of child
 // c with the box child c's node stores for it; a child that is a leaf sits in entry 4 c itself; everything else is the far point.
-// The cooperative descent of find kind 31 tests one entry per lane: two levels of the tree per round trip.
+// The cooperative descent of find kind 32 tests one entry per lane: two levels of the tree per round trip.
 struct alignas(128) Node16C {
   Node4C::Child e[16];
 };

@@ -916,12 +916,12 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
                                                    uint32_t* __restrict__ lds_col, uint32_t* __restrict__ qstack,
                                                    uint32_t* __restrict__ xfer_wave, RayHit& h, uint32_t* visits = nullptr,
                                                    const TraceStart* start = nullptr, uint32_t* dbg = nullptr, uint4* pre = nullptr,
-                                                   uint32_t* pre_rec = nullptr) {
+                                                   uint32_t* pre_rec = nullptr, const RayHit* seed = nullptr) {
   uint4 pre_v = uint4{0u, 0u, 0u, 0u};
   uint32_t pre_r = kNone;
   const RaySlab rs = make_ray_slab(O, D);
-  float best_t = ray_tfar;
-  uint32_t best_rec = kNone;
+  float best_t = seed ? seed->t : ray_tfar;          // (kind 32: the closest hit among the leaves the wave tested together)
+  uint32_t best_rec = seed ? seed->rec : kNone;
   uint32_t nvis = 0;  // node visits of this ray
   uint32_t dbg_slow = 0, dbg_na = 0, dbg_tail = 0, dbg_leaf = 0;
   constexpr uint32_t kDone = 0x7FFFFFFFu;
@@ -953,7 +953,7 @@ __device__ __forceinline__ void trace_lane_bf_tail(const uint32_t* __restrict__ 
     const uint64_t m_act = __ballot(cur != kDone);
     if (m_act == 0) break;
     const uint32_t na = static_cast<uint32_t>(__popcll(m_act));
-    // kTail = false (kind 31, whose rays mostly start with nothing but the leaves their tile sees): no hand-over -- rays that only hold
+    // kTail = false (kinds 31 and 32, whose rays mostly start with nothing but the leaves their tile sees): no hand-over -- rays that only hold
     // leaves finish in a round or two of the lane loop, and the kernel is better off without the quad traversal's code and LDS
     // (C2 sphere-100k 13.4 -> 12.8 us; where stragglers still descend, as on the room, that costs 9 %: kind 23 is the kind for those maps)
     const bool hand_over = kTail && na <= kTailRays;
@@ -1285,7 +1285,7 @@ __device__ __forceinline__ TraceStart frontier_start(const uint32_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// COOPERATIVE DESCENT below the frontier (round 6, kind 31).  The frontier start replaces the top four levels of every ray's descent
+// COOPERATIVE DESCENT below the frontier (round 6, kinds 31 and 32).  The frontier start replaces the top four levels of every ray's descent
 // by one cooperative pass; what remains on a resident map is still a chain of dependent, divergent node fetches (~4.6 node visits per
 // ray of a C2 scan, 10 - 16 wave steps of ~1.3 k cycles each at two waves per SIMD).  But the 64 rays of a tile keep walking the SAME
 // few subtrees below the frontier too: a 16 x 4 tile of a C2 scan sees about a dozen leaves.  So the wave keeps descending TOGETHER:
@@ -1310,16 +1310,28 @@ constexpr uint32_t kDescentWaveDwords = (kDescentCap + 2u * kDescentInnerCap) * 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
   }
 
-template <int kRows, int kRow0>
+// kCoop (kind 32): the per-ray part without the sorted hand-over -- see the comment at the final list below.  `seed` receives the closest hit
+// among the final LEAVES; the per-lane traversal that follows starts from it and only sees what the descent left unexpanded.
+template <int kRows, int kRow0, bool kCoop = false>
 __device__ __forceinline__ TraceStart frontier_descent_start(const uint32_t* __restrict__ frontier, uint32_t n_frontier,
                                                              const uint32_t* __restrict__ cnodes, const uint32_t* __restrict__ cnodes16,
                                                              f3 scene_center, float scene_half_diag,
                                                              const float* __restrict__ planes, quat Rsm, float tfar, f3 O, f3 D,
                                                              float ray_tfar, uint32_t lane, uint32_t* __restrict__ lds_col,
                                                              uint32_t lds_stride, uint32_t max_preload, uint32_t* __restrict__ ws,
-                                                             uint32_t final_cap, uint32_t max_levels, uint32_t* dbg_levels = nullptr) {
+                                                             uint32_t final_cap, uint32_t max_levels, uint32_t* dbg_levels = nullptr,
+                                                             uint32_t* stamps = nullptr, const uint32_t* __restrict__ tris = nullptr,
+                                                             RayHit* seed = nullptr) {
   constexpr uint32_t kDone = 0x7FFFFFFFu;
   const bool active = ray_tfar >= 0.0f;
+  // diagnostics (clocked lab instantiation only; stamps == nullptr folds all of it away): shader clock at the phase boundaries, after
+  // everything in flight has arrived -- 0 entry, 1 frontier + planes here, 2 culled, 3 lists written, 4 + 2 L nodes of level L here,
+  // 5 + 2 L level L compacted (L < 3), 10 final list lane-resident, 11 every ray has seen every entry
+#define RMCL_STAMP(i) { if (stamps != nullptr) { uint64_t t_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory"); stamps[i] = static_cast<uint32_t>(t_); } }
+  RMCL_STAMP(0)
+  if constexpr (kCoop) { seed->t = ray_tfar; seed->rec = kNone; }
+  const uint32_t mask_leaf_cap = (max_levels >> 8) & 0xFFu;   // kCoop: most final leaves a ray may enter (bits 8..15 of the level word)
+  max_levels &= 0xFFu;
   TraceStart root;
   root.cur = active ? 0u : kDone;
   root.sp = static_cast<uint32_t>(kRow0);
@@ -1338,6 +1350,7 @@ __device__ __forceinline__ TraceStart frontier_descent_start(const uint32_t* __r
   f3 n[4] = {qrot(Rsm, mk3(asf(P0.x), asf(P0.y), asf(P0.z))), qrot(Rsm, mk3(asf(P1.x), asf(P1.y), asf(P1.z))),
              qrot(Rsm, mk3(asf(P2.x), asf(P2.y), asf(P2.z))), qrot(Rsm, mk3(asf(P3.x), asf(P3.y), asf(P3.z)))};
   const float mq[4] = {asf(P0.w), asf(P1.w), asf(P2.w), asf(P3.w)};
+  RMCL_STAMP(1)
   const f3 oc = sub3(O, scene_center);
   const float reach = fminf(tfar, sqrtf((oc.x * oc.x + oc.y * oc.y) + oc.z * oc.z) + scene_half_diag);
   f3 an[4];
@@ -1401,6 +1414,7 @@ __device__ __forceinline__ TraceStart frontier_descent_start(const uint32_t* __r
     n_inner += static_cast<uint32_t>(__popcll(m_in[k]));
   }
   uint32_t levels = 0;
+  RMCL_STAMP(2)
   if (dbg_levels) *dbg_levels = min(n_surv, 63u);   // diagnostics: survivors of the frontier | entries after level 1 << 6 | 2 << 12 | 3 << 18 | final entries << 24
   if (cnodes != nullptr && n_inner != 0u && n_inner <= kDescentInnerCap && n_surv <= kDescentCap) {
     // ---- the descent: lists in this wave's scratch ----
@@ -1423,6 +1437,7 @@ __device__ __forceinline__ TraceStart frontier_descent_start(const uint32_t* __r
       nA += static_cast<uint32_t>(__popcll(m_in[k]));
     }
     RMCL_WAVE_LDS_SYNC()
+    RMCL_STAMP(3)
     // two levels per round trip where the map carries the 16-wide twins (layout.h Node16C: a node's GRANDCHILDREN, child-major): lane l
     // tests entry (l & 15) of survivor (l >> 4), four nodes per pass -- the first levels below the frontier barely branch (2.8 -> 3.0 ->
     // 3.6 survivors per tile of a C2 scan on sphere-100k), so a level of four-wide nodes buys little for its round trip
@@ -1448,6 +1463,7 @@ __device__ __forceinline__ TraceStart frontier_descent_start(const uint32_t* __r
         const uint4* cn = wide ? reinterpret_cast<const uint4*>(cnodes16) + (static_cast<size_t>(nref) * 32u + 2u * c_in)
                                : reinterpret_cast<const uint4*>(cnodes) + (static_cast<size_t>(nref) * 8u + 2u * c_in);
         const uint4 ca = cn[0], cb = cn[1];
+        if (base == 0u) { if (levels == 0u) RMCL_STAMP(4) else if (levels == 1u) RMCL_STAMP(6) else if (levels == 2u) RMCL_STAMP(8) }
         // (an unused child slot holds the far point, layout.h: never inside a scene -- but possibly inside an unbounded pyramid)
         const bool ok = have && (asf(ca.x) < 1.0e29f) && in_pyramid(ca, cb);
         const bool inner = !(cb.z & kLeafBit);
@@ -1464,6 +1480,7 @@ __device__ __forceinline__ TraceStart frontier_descent_start(const uint32_t* __r
         nFn += static_cast<uint32_t>(__popcll(ml));
       }
       RMCL_WAVE_LDS_SYNC()
+      if (levels == 0u) RMCL_STAMP(5) else if (levels == 1u) RMCL_STAMP(7) else if (levels == 2u) RMCL_STAMP(9)
       if (nFn + nAn > final_cap || nAn > kDescentInnerCap) break;   // this level does not fit: it stays unexpanded (its leaves, written above nF, are forgotten)
       nF = nFn;
       nA = nAn;
@@ -1477,14 +1494,76 @@ __device__ __forceinline__ TraceStart frontier_descent_start(const uint32_t* __r
       Fl[2u * (nF + lane)] = Acur[2u * lane];
       Fl[2u * (nF + lane) + 1u] = Acur[2u * lane + 1u];
     }
+    const uint32_t n_leaves = nF;   // final entries [0, n_leaves) are leaves, [n_leaves, nF) inner nodes
     nF += nA;
     RMCL_WAVE_LDS_SYNC()
     // final entries lane-resident, then each against every ray of the wave
     const uint32_t jl = min(lane, max(nF, 1u) - 1u);
     const uint4 fa = Fl[2u * jl], fb = Fl[2u * jl + 1u];
-    for (uint32_t j = 0; j < nF; ++j)
-      offer(lane_bcast(asf(fa.x), j), lane_bcast(asf(fa.y), j), lane_bcast(asf(fa.z), j), lane_bcast(asf(fa.w), j), lane_bcast(asf(fb.x), j),
-            lane_bcast(asf(fb.y), j), lane_bcast(fb.z, j));
+    RMCL_STAMP(10)
+    if constexpr (!kCoop) {
+      for (uint32_t j = 0; j < nF; ++j)
+        offer(lane_bcast(asf(fa.x), j), lane_bcast(asf(fa.y), j), lane_bcast(asf(fa.z), j), lane_bcast(asf(fa.w), j), lane_bcast(asf(fb.x), j),
+              lane_bcast(asf(fb.y), j), lane_bcast(fb.z, j));
+    } else {
+      // Every closest hit is (min t, then min face id) whatever the order of the tests, and a leaf that reaches a ray's stack is tested
+      // whatever its distance -- so the per-ray filter needs neither the entry distances in order nor a stack: one bit per final entry
+      // (the list holds at most 64), the boxes read back from the list as broadcasts, and the ray then tests the leaves of its set bits
+      // in list order.  Only inner nodes the descent left unexpanded (rare) go to the ray's stack for the ordinary traversal.
+      uint32_t m_lo = 0u, m_hi = 0u;
+      float e_tn = 0.0f;
+      auto box_hit = [&](uint32_t j) -> bool {
+        const uint4 a = Fl[2u * j], b = Fl[2u * j + 1u];   // (wave-uniform address: a broadcast read)
+        const float tx0 = fmaf(asf(a.x), rs.inv.x, rs.noi.x), tx1 = fmaf(asf(a.w), rs.inv.x, rs.noi.x);
+        const float ty0 = fmaf(asf(a.y), rs.inv.y, rs.noi.y), ty1 = fmaf(asf(b.x), rs.inv.y, rs.noi.y);
+        const float tz0 = fmaf(asf(a.z), rs.inv.z, rs.noi.z), tz1 = fmaf(asf(b.y), rs.inv.z, rs.noi.z);
+        e_tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
+        const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), ray_tfar));
+        return e_tn <= tf;   // (an inactive ray has ray_tfar < 0: never)
+      };
+      const uint32_t n_lo = min(n_leaves, 32u);
+      for (uint32_t j = 0; j < n_lo; ++j) m_lo |= box_hit(j) ? (1u << j) : 0u;
+      for (uint32_t j = 32u; j < n_leaves; ++j) m_hi |= box_hit(j) ? (1u << (j - 32u)) : 0u;
+      // the unexpanded inner nodes (behind the leaves in the list; none on most tiles) are the ordinary traversal's business: nearest
+      // first as in the sorted form -- a far subtree entered before the near one is walked without a bound
+      for (uint32_t j = n_leaves; j < nF; ++j) {
+        if (box_hit(j)) {
+          const uint32_t key = __float_as_uint(e_tn), ref = lane_bcast(fb.z, j);
+          const bool n1 = key < first_key, n2 = key < second_key;
+          const uint32_t pushed = n2 ? second_ref : ref;
+          second_ref = n1 ? first_ref : (n2 ? ref : second_ref);
+          second_key = n1 ? first_key : (n2 ? key : second_key);
+          first_ref = n1 ? ref : first_ref;
+          first_key = n1 ? key : first_key;
+          if (pushed != kDone) {
+            if (sp < static_cast<uint32_t>(kRows)) lds_col[sp * lds_stride] = pushed;
+            ++sp;
+          }
+        }
+      }
+      // A ray that enters many of the boxes (a grazing ray along a wall) would test every one of their leaves here, where its own
+      // ordered traversal stops at the first few: such a wave starts at the root like a wave whose stacks the sorted form overfills
+      if (__any(static_cast<uint32_t>(__popc(m_lo) + __popc(m_hi)) > mask_leaf_cap)) return root;
+      float best_t = ray_tfar;
+      uint32_t best_rec = kNone;
+      const uint32_t* Fw = reinterpret_cast<const uint32_t*>(Fl);
+      while (__any((m_lo | m_hi) != 0u)) {
+        uint32_t ref = kDone;
+        if ((m_lo | m_hi) != 0u) {
+          const bool lo = m_lo != 0u;
+          const uint32_t w = lo ? m_lo : m_hi;
+          const uint32_t bit = static_cast<uint32_t>(__builtin_ctz(w));
+          m_lo = lo ? (m_lo & (m_lo - 1u)) : m_lo;
+          m_hi = lo ? m_hi : (m_hi & (m_hi - 1u));
+          ref = Fw[8u * (bit + (lo ? 0u : 32u)) + 6u];
+        }
+        if (ref > kDone) leaf_batch(tris, ref, O, D, ray_tfar, best_t, best_rec);
+      }
+      seed->t = best_t;
+      seed->rec = best_rec;
+    }
+    RMCL_STAMP(11)
+    if (stamps != nullptr) stamps[12] = levels;
   } else {
     // no descent (nothing but leaves survived, too many survivors, no child-major nodes): the frontier start's own third step
 #pragma unroll
@@ -1508,6 +1587,7 @@ __device__ __forceinline__ TraceStart frontier_descent_start(const uint32_t* __r
   st.cur = first_ref;
   st.sp = sp;
   return st;
+#undef RMCL_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------

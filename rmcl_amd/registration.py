@@ -536,8 +536,8 @@ class CorrespondencesHIP:
         return kind.value, ms.value
 
     def set_traversal(self, kind):
-        """traversal kind 0..31 alone (kinds >= 16 travel in bit 13 of the variant word, see rmclhip.h)"""
-        self.set_variant((int(kind) & 15) | ((int(kind) >> 4) << 13))
+        """traversal kind 0..32 alone (bits 4 and 5 of the kind travel in bits 13 and 14 of the variant word, see rmclhip.h)"""
+        self.set_variant((int(kind) & 15) | (((int(kind) >> 4) & 1) << 13) | (((int(kind) >> 5) & 1) << 14))
 
     def set_micp_fast(self, mode):
         """moment form of the schedule-(R) loop of correctOnce: 0 = never, 1 = automatic, iterations on the host from the published
@@ -572,6 +572,8 @@ class CorrespondencesHIP:
         nw = C.c_uint32(0)
         _capi.check(_capi.lib().rmclhip_debug_wave_clock(self._h, _ptr(T), _ptr(buf), buf.size, C.byref(nw)))
         self._last_nposes = 1
+        # kind 31 also leaves [n_waves, 16] phase stamps of its cooperative descent behind the table (traverse.hip.h RMCL_STAMP)
+        self._last_descent_stamps = buf[nw.value * 8: nw.value * 24].reshape(nw.value, 16).copy()
         return buf[: nw.value * 8].reshape(nw.value, 8)
 
     def debug_micp_moments(self):

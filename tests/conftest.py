@@ -25,7 +25,7 @@ def pytest_configure(config):
 
 
 # traversal kinds librmclhip.so builds (lab_hooks.h: find_kind_in_product); 15 = the automatic rule
-PRODUCT_FIND_KINDS = (0, 2, 15, 23, 24, 31)
+PRODUCT_FIND_KINDS = (0, 2, 15, 23, 24, 32)
 
 
 def find_kinds(*kinds):

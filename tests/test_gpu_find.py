@@ -48,7 +48,7 @@ def _poses(syn, T):
     ]
 
 
-@pytest.mark.parametrize("variant", find_kinds(0, 1, 2, 4, 5, 6, 8, 10, 11, 12, 13, 14, 16, 17, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31))
+@pytest.mark.parametrize("variant", find_kinds(0, 1, 2, 4, 5, 6, 8, 10, 11, 12, 13, 14, 16, 17, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32))
 def test_c1_cube_32x32(ra, orc, ctx, meshes, variant):
     """config C1: 32x32 scan, 972-triangle cube, every output attribute, 3 poses, Tsb != I."""
     from rmcl_amd import synthetic as syn, types as T
@@ -88,7 +88,7 @@ def test_c1_matches_committed_golden(ra, ctx, meshes):
         _compare(gpu, ref, "golden pose %d" % i)
 
 
-@pytest.mark.parametrize("variant", find_kinds(0, 1, 2, 4, 5, 7, 8, 9, 11, 12, 13, 14, 15, 16, 17, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31))
+@pytest.mark.parametrize("variant", find_kinds(0, 1, 2, 4, 5, 7, 8, 9, 11, 12, 13, 14, 15, 16, 17, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32))
 def test_c2_sphere100k_full_size(ra, orc, ctx, meshes, variant):
     """config C2 at BASELINE.json's full size: 128x1024 rays, 100k triangles; oracle BVH on all rays,
     brute force on a sample, and the committed SHA-256 of the face-id array (G7)."""
@@ -178,7 +178,7 @@ def test_misses_and_range_limit(ra, orc, ctx, meshes):
     assert np.isnan(gpu["points"][miss]).all() and np.isnan(gpu["normals"][miss]).all()
 
 
-@pytest.mark.parametrize("variant", find_kinds(0, 2, 23, 24, 31))
+@pytest.mark.parametrize("variant", find_kinds(0, 2, 23, 24, 32))
 def test_o1dn_model(ra, orc, ctx, meshes, variant):
     """RCCEmbreeO1Dn::find (RCCEmbree.cpp:89-99): one origin, N explicit directions, with NaN
     directions (invalid points of an organised cloud) which must come back as misses."""
@@ -237,7 +237,7 @@ def test_frontier_plane_table_follows_model_and_tiling(ra, orc, ctx, meshes, kin
     def scan(op, tile_bits=0):
         out = {}
         for k in (kind, 0):
-            op.set_variant((k & 15) | ((k >> 4) << 13) | (tile_bits << 4))
+            op.set_variant((k & 15) | (((k >> 4) & 1) << 13) | (((k >> 5) & 1) << 14) | (tile_bits << 4))
             op.find(Tbm)
             out[k] = op.modelView()
         for key in ("hits", "ranges", "points", "normals", "face_ids"):
@@ -290,7 +290,7 @@ def test_autotune_chooses_a_product_kind_and_changes_no_result(ra, orc, ctx, mes
         rcc.find(Tbm)
         before = rcc.modelView()
         kind, ms = rcc.autotune(Tbm)
-        assert kind in (2, 19, 22, 23, 24, 31) and 0.0 < ms < 1.0       # 19 / 22: kinds 23 / 24 without the frontier start
+        assert kind in (2, 19, 22, 23, 24, 32) and 0.0 < ms < 1.0       # 19 / 22: kinds 23 / 24 without the frontier start
         assert rcc.find_variant(1) == {19: 23, 22: 24}.get(kind, kind)
         assert rcc.find_variant(64) in (23, 24)           # batches keep the rule ...
         rcc.find(Tbm)
@@ -372,7 +372,7 @@ def test_c5_mesh_one_million_triangles(ra, orc, ctx):
 ROOM_POSE_RPY = ((1.5, -2.0, 1.6), (0.02, -0.03, 0.4))   # the pose of tests/golden/make_golden.py:g7_digests
 
 
-@pytest.mark.parametrize("variant", find_kinds(0, 2, 15, 23, 24, 19, 22, 25, 26, 27, 28, 29, 30, 31))
+@pytest.mark.parametrize("variant", find_kinds(0, 2, 15, 23, 24, 19, 22, 25, 26, 27, 28, 29, 30, 31, 32))
 def test_c2_room100k_full_size(ra, orc, ctx, meshes, variant):
     """config C2's scan on a REALISTIC map (room-100k: occluders, vertex noise, open ceiling => misses): every
     traversal incl. the automatic one (15) vs the oracle on all 131 072 rays + the committed G7 digests
@@ -493,7 +493,7 @@ def test_automatic_variant_in_every_size_bracket(ra, orc, ctx, meshes, mesh):
         rcc.close()
 
 
-@pytest.mark.parametrize("variant", find_kinds(0, 2, 23, 24, 31, 6, 13, 19))
+@pytest.mark.parametrize("variant", find_kinds(0, 2, 23, 24, 32, 6, 13, 19))
 def test_sensor_origin_on_a_face(ra, orc, ctx, meshes, variant):
     """Embree's depth test is strict on the near side (absDen * tnear < T with tnear = 0): a ray that starts exactly ON a
     wall triangle does not hit that triangle -- the sensor sees the room, not t = 0 everywhere."""
@@ -778,7 +778,7 @@ def test_spatial_splits_leave_every_result_unchanged(ra, orc, ctx, meshes):
     assert np.array_equal(ref["face_ids"][idx], sub["face_ids"])
     beam_faces = (ref["face_ids"] >= 12) & (ref["face_ids"] < 12 + 60 * 12)
     assert beam_faces.sum() > 2000, "the scan must see the turned beams"
-    for kind in (15, 23, 31, 24, 2, 0):
+    for kind in (15, 23, 32, 24, 2, 0):
         rcc = ra.RCCHipSpherical(hm)
         rcc.set_traversal(kind)
         rcc.setTsb(T.identity())

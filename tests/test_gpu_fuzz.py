@@ -31,7 +31,7 @@ def _duplicate_faces(v, f, seed):
     return v, ff[rng.permutation(len(ff))]
 
 
-@pytest.mark.parametrize("kinds", [(0, 2, 23, 24), pytest.param((1, 4, 5, 7, 9, 11, 12, 13, 14, 16, 17, 19, 20, 21, 22), marks=pytest.mark.lab)],
+@pytest.mark.parametrize("kinds", [(0, 2, 23, 24, 32), pytest.param((1, 4, 5, 7, 9, 11, 12, 13, 14, 16, 17, 19, 20, 21, 22), marks=pytest.mark.lab)],
                          ids=["product", "experiments"])
 @pytest.mark.parametrize("case", ["soup", "duplicates", "far_from_origin"])
 def test_find_all_traversals_vs_brute_force(ra, orc, ctx, case, kinds):

@@ -23,10 +23,10 @@ hm = ra.import_hip_map(ctx, v, f)
 rcc = ra.RCCHipSpherical(hm)
 rcc.setTsb(T.identity())
 rcc.setModel(syn.model_c1())
-for kind in (0, 2, 15, 23, 24):                  # the product's own kinds
+for kind in (0, 2, 15, 23, 24, 32):              # the product's own kinds
     rcc.set_traversal(kind)
     rcc.find(syn.pose_c2_truth())
-for kind in (4, 5, 6, 13, 17, 19, 20, 22):        # experiments: refused at set_variant
+for kind in (4, 5, 6, 13, 17, 19, 20, 22, 31):    # experiments: refused at set_variant
     try:
         rcc.set_traversal(kind)
         raise SystemExit("kind %%d accepted without the experiments library" %% kind)

@@ -486,7 +486,7 @@ def test_moment_form_o1dn_unmasked_dataset_and_short_dataset(ra, orc, ctx, meshe
     assert int(res[1][0][1]["n_meas"]) > int(res[1][3][1]["n_meas"])        # the short dataset really is shorter
 
 
-@pytest.mark.parametrize("shape", [(128, 1024, 23), (100, 1000, 23), (64, 512, 23), (64, 512, 2), (16, 900, 2), (30, 500, 2), (128, 1024, 31), (100, 1000, 31)])
+@pytest.mark.parametrize("shape", [(128, 1024, 23), (100, 1000, 23), (64, 512, 23), (64, 512, 2), (16, 900, 2), (30, 500, 2), (128, 1024, 32), (100, 1000, 32)])
 def test_moments_formed_in_the_find_epilogue_equal_the_separate_pass(ra, orc, ctx, meshes, shape):
     """rmclhip_rcc_set_micp_fast 1 (the find of kind 23 forms the moments in its epilogue: f64 MFMA over the wave's 64 correspondences,
     one partial row per workgroup, mask words in tile order, rows folded by eight workgroups) against mode 3 (k_micp_moments, a pass of
@@ -547,7 +547,7 @@ def test_moments_formed_in_the_find_epilogue_equal_the_separate_pass(ra, orc, ct
                 pts = (dirs * mv["ranges"].reshape(-1, 1) + np.float32([0.01, -0.02, 0.03])).astype(np.float32)
                 pts[mv["hits"].reshape(-1) == 0] = np.nan
                 rcc.set_dataset(pts, None)
-            if want_kind == 31 or (H * W <= 57344 and want_kind == 23):   # (31: kind 23 behind the cooperative descent, what autotune may choose)
+            if want_kind == 32 or (H * W <= 57344 and want_kind == 23):   # (32: the cooperative descent below the frontier, what autotune may choose)
                 rcc.set_traversal(want_kind)
             assert rcc.find_variant(1) == want_kind
             rcc.params.max_dist, rcc.adaptive_max_dist_min = 0.5, 0.2

@@ -11,7 +11,7 @@ from test_gpu_find import _compare
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant", [23, 0, 2, 24])
+@pytest.mark.parametrize("variant", [23, 0, 2, 24, 32])
 def test_pinhole_depth_camera(ra, orc, ctx, meshes, variant):
     from rmcl_amd import synthetic as syn, types as T
     v, f = meshes("room30k")
@@ -44,7 +44,7 @@ def test_pinhole_depth_camera(ra, orc, ctx, meshes, variant):
     assert np.allclose(s["covariance"].reshape(3, 3), r64["covariance"], rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("variant", [23, 0, 2, 24])
+@pytest.mark.parametrize("variant", [23, 0, 2, 24, 32])
 def test_ondn_multi_origin(ra, orc, ctx, meshes, variant):
     from rmcl_amd import synthetic as syn, types as T
     v, f = meshes("room30k")

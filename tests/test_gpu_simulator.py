@@ -68,7 +68,7 @@ def test_find_writes_only_the_selected_bundle(ra, orc, ctx, meshes, config, bund
     rcc.close()
 
 
-@pytest.mark.parametrize("variant", find_kinds(0, 2, 23, 24, 31))
+@pytest.mark.parametrize("variant", find_kinds(0, 2, 23, 24, 32))
 def test_selection_holds_for_every_product_kind(ra, orc, ctx, meshes, variant):
     from rmcl_amd import synthetic as syn, types as T
     v, f = meshes("cube")

@@ -15,7 +15,7 @@ for v in 15 2; do
   run find_v${v}_fetch FETCH_SIZE python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras --variant $v
   run find_v${v}_write WRITE_SIZE python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras --variant $v
 done
-# round 6: variant 15 autotunes (kind 31 on the sphere); the rule's kind 23 in a pass pair of its own
+# round 6: variant 15 autotunes (kind 32 on the sphere); the rule's kind 23 in a pass pair of its own
 run find_v15rule_fetch FETCH_SIZE python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras --no-autotune
 run find_v15rule_write WRITE_SIZE python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras --no-autotune
 [ "${2:-all}" = find ] && { ls $OUT; exit 0; }

@@ -24,7 +24,7 @@ def main(d, out):
     # key = the kernel as bench.py names it (traversal kind of k_find), like = its demangled template arguments
     # (round 6: bench.py's default run autotunes -- the autotune's own trial launches of other kinds land in the same pass and are told
     # apart by the kernel name; the rule's kind 23 is profiled with --no-autotune)
-    specs = (("k_find_kind31", "%k_find<1u, 31%", "find_v15", False), ("k_find_kind23", "%k_find<1u, 23%", "find_v15rule", False),
+    specs = (("k_find_kind32", "%k_find<1u, 32%", "find_v15", False), ("k_find_kind23", "%k_find<1u, 23%", "find_v15rule", False),
              ("k_find_kind2", "%k_find<1u, 2,%", "find_v2", False), ("k_pf_update_v3_c5_shard_sphere1m", "%k_pf_update_v3%", "pfc5", False),
              ("k_pf_update_v3", "%k_pf_update_v3%", "pf", False),
              ("k_micp_moments", "%k_micp_moments%", "red", True), ("k_reduce_partials", "%k_reduce_partials%", "red", True))
