@@ -56,6 +56,15 @@ rmclhip_status rmclhip_debug_probe_find(rmclhip_rcc* rcc, const rmclhip_transfor
  * the 16-wide twins (A/B).  Results do not depend on any of them.  Exported by librmclhip.so. */
 rmclhip_status rmclhip_rcc_set_descent(rmclhip_rcc* rcc, uint32_t final_cap, uint32_t max_levels);
 
+/* A/B knob (round 6, VERDICT r5 #7b): pose batches in WORLD ORDER (the default; on = 0 restores the pose-major launch).  Every batch launch
+ * (find_batch, correct_batch, simulate with several poses, the sharded forms) of this operator makes one
+ * key per workgroup of the launch (four neighbouring tiles of one pose; Morton code of the point where their central ray leaves the map's
+ * bounding box), sorts the
+ * tiles by key (counting sort over 4096 cells) and walks them in that order, `on` workgroups of consecutive tiles per XCD turn (1 = the
+ * default, 64), so that what runs on an XCD at a time -- one L2 -- sees one region of the map instead of one pose's whole scan.
+ * Results do not depend on it.  Exported by librmclhip.so. */
+rmclhip_status rmclhip_rcc_set_batch_order(rmclhip_rcc* rcc, int on);
+
 /* TEST knob of the loopback communicator (rmclhip_comm_create_loopback): its all-reduce adds the ranks' contributions starting at
  * `first_rank` instead of rank 0 -- the freedom a real collective library has.  Whatever must not depend on the library's order of
  * summation is tested under several rotations (tests/test_gpu_distributed.py).  Exported by librmclhip.so. */

@@ -178,6 +178,7 @@ SIGNATURES = {
     "rmclhip_rcc_set_variant": (_i32, [_vp, _i32]),
     "rmclhip_rcc_find_variant": (_i32, [_vp, _u32, C.POINTER(_i32)]),
     "rmclhip_rcc_set_descent": (_i32, [_vp, _u32, _u32]),
+    "rmclhip_rcc_set_batch_order": (_i32, [_vp, C.c_int]),
     "rmclhip_rcc_set_micp_fast": (_i32, [_vp, _i32]),
     "rmclhip_rcc_micp_fast_info": (_i32, [_vp, C.POINTER(MicpFastInfo)]),
     "rmclhip_rcc_ccs_info": (_i32, [_vp, C.POINTER(CcsInfo)]),

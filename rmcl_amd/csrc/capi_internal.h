@@ -204,6 +204,9 @@ struct rmclhip_rcc {
   uint32_t nposes_last = 0;
   bool descent_wide = true;   // ... on the 16-wide twins when the map has them (A/B: rmclhip_rcc_set_descent's max_levels bit 31 clears it)
   uint32_t descent_final_cap = 64, descent_levels = 24;   // kind 32's cooperative descent (rmclhip_rcc_set_descent, include/rmclhip_lab.h)
+  // pose batches in world order (kernels.hip launch_batch_tile_order; A/B knob rmclhip_rcc_set_batch_order): keys | sorted keys, values | sorted values, sort scratch
+  uint32_t batch_order = 64;   // 0 = pose-major; else the granule (workgroups per XCD turn)
+  DevBuf<uint32_t> d_ord_scratch, d_ord_vals;
   uint32_t descent_leaf_cap = 24;   // kind 32: a wave one of whose rays enters more final leaves than this starts at the root (lab: rmclhip_rcc_set_descent)
   uint32_t out_mask = RMCLHIP_OUT_ALL;   // rmclhip_rcc_set_outputs: which model buffers find / find_batch write
   // reduction
@@ -455,6 +458,7 @@ RMCL_INTERNAL rmclhip_status ensure_model_buffers(rmclhip_rcc* r, size_t n_total
 RMCL_INTERNAL rmclhip_status find_enqueue(rmclhip_rcc* r, const xform& Tbm, bool* speculate = nullptr);
 RMCL_INTERNAL rmclhip_status reduce_enqueue(rmclhip_rcc* r, const xform& Tpre, const xform* Tpre_dev, float max_dist, uint32_t nposes, const ReduceTail& tail);
 RMCL_INTERNAL rmclhip_status find_batch_enqueue(rmclhip_rcc* r, const rmclhip_transform* Tbm, uint32_t nposes);
+RMCL_INTERNAL rmclhip_status batch_order_enqueue(rmclhip_rcc* r, FindParams& p, int variant);   // pose batches in world order (capi_rcc_tune.cpp)
 RMCL_INTERNAL rmclhip_status ensure_near_grid(rmclhip_map* m, hipStream_t stream, bool full, const NearGrid** out);
 RMCL_INTERNAL rmclhip_status map_upload(rmclhip_ctx* ctx, const BvhHost& bvh, rmclhip_map** out);
 RMCL_INTERNAL rmclhip_status gladiator_enqueue(rmclhip_resampler* r, const rmclhip_transform* poses_dev, const rmclhip_particle_attributes* attrs_dev, uint32_t n_particles, rmclhip_transform* poses_new_dev, rmclhip_particle_attributes* attrs_new_dev, uint32_t first, uint32_t count, const rmclhip_gladiator_config* cfg, uint64_t seed, uint32_t step, hipStream_t st);

@@ -1097,6 +1097,7 @@ static rmclhip_status simulate_enqueue(rmclhip_rcc* r, const rmclhip_transform* 
     p.Tsm_arr = r->d_Tsm.p;
     p.Tms_arr = r->d_Tms.p;
   }
+  if (rmclhip_status st = batch_order_enqueue(r, p, find_variant(r, nposes))) return st;   // (batches: world order)
   HIPCHK(launch_find(p, r->kind, find_variant(r, nposes), r->stream));
   return RMCLHIP_OK;
 }

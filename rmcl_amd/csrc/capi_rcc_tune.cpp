@@ -413,6 +413,31 @@ rmclhip_status rmclhip_debug_wave_clock(rmclhip_rcc* r, const rmclhip_transform*
   return RMCLHIP_OK;
 }
 
+// A pose batch in world order (VERDICT r5 #7b): one key per wave-tile of the launch (where its central ray leaves the map's bounding
+// box), a counting sort, and k_find walks the sorted list -- consecutive blocks, hence one XCD's L2, then see one region of the map.
+// Three small launches per batch (~15 us); the v1 batch of the reference's benchmark gains 1 % (100 k faces) / 8 % (1 M) / 15 % (10 M) / 6 % (room),
+// all included (profiles/r06_batch_order_ab.txt).  On by default; rmclhip_rcc_set_batch_order(rcc, 0) restores the pose-major launch (A/B).
+RMCL_INTERNAL rmclhip_status batch_order_enqueue(rmclhip_rcc* r, FindParams& p, int variant) {
+  const uint32_t ntiles = p.tiles_x * p.tiles_y, group = (variant == 2) ? 1u : 4u, ngroups = (ntiles + group - 1u) / group;
+  if (r->batch_order == 0u || p.nposes < 2u || ngroups > 65535u || p.nposes > 32768u || p.Tsm_arr == nullptr) return RMCLHIP_OK;
+  const uint32_t n = ngroups * p.nposes;
+  HIPCHK(r->d_ord_scratch.reserve(batch_order_scratch_dwords(n))); HIPCHK(r->d_ord_vals.reserve(n));
+  const BvhInfo& bi = r->map->info;
+  HIPCHK(launch_batch_tile_order(p, r->kind, group, mk3(bi.bbox_min[0], bi.bbox_min[1], bi.bbox_min[2]),
+                                 mk3(bi.bbox_max[0], bi.bbox_max[1], bi.bbox_max[2]), r->d_ord_scratch.p, r->d_ord_vals.p, r->stream));
+  p.tile_order = r->d_ord_vals.p;
+  p.n_tile_order = n;
+  p.tile_order_granule = r->batch_order;
+  return RMCLHIP_OK;
+}
+
+rmclhip_status rmclhip_rcc_set_batch_order(rmclhip_rcc* r, int on) {
+  ApiGuard guard_("rmclhip_rcc_set_batch_order");
+  if (!r) return fail(RMCLHIP_ERR_INVALID, "rcc_set_batch_order: null");
+  r->batch_order = (on <= 0) ? 0u : (on == 1 ? 64u : static_cast<uint32_t>(on));   // 1: the default granule
+  return RMCLHIP_OK;
+}
+
 RMCL_INTERNAL rmclhip_status find_batch_enqueue(rmclhip_rcc* r, const rmclhip_transform* Tbm, uint32_t nposes) {
   if (nposes > 32768) return fail(RMCLHIP_ERR_UNSUPPORTED, "find_batch: at most 32768 poses per call");
   const size_t n = static_cast<size_t>(r->W) * r->H;
@@ -427,6 +452,7 @@ RMCL_INTERNAL rmclhip_status find_batch_enqueue(rmclhip_rcc* r, const rmclhip_tr
   p.Tsm_arr = r->d_Tsm.p;
   p.Tms_arr = r->d_Tms.p;
   const int bvariant = find_variant(r, p.nposes);
+  if (rmclhip_status st = batch_order_enqueue(r, p, bvariant)) return st;
   HIPCHK(launch_find(p, r->kind, bvariant, r->stream));
   return RMCLHIP_OK;
 }
@@ -456,7 +482,10 @@ rmclhip_status rmclhip_rcc_time_find_batch(rmclhip_rcc* r, const rmclhip_transfo
   r->reduce_timing_pending = false;
   HIPCHK(hipEventRecord(r->ev0, r->stream));
   const int bvariant = (find_variant(r, p.nposes) == 18) ? 17 : find_variant(r, p.nposes);
-  for (uint32_t i = 0; i < iters; ++i) HIPCHK(launch_find(p, r->kind, bvariant, r->stream));
+  for (uint32_t i = 0; i < iters; ++i) {
+    if (rmclhip_status st = batch_order_enqueue(r, p, bvariant)) return st;   // (world order on: its keys and sort are part of every batch)
+    HIPCHK(launch_find(p, r->kind, bvariant, r->stream));
+  }
   HIPCHK(hipEventRecord(r->ev1, r->stream));
   HIPCHK(hipStreamSynchronize(r->stream));
   float total = 0.f;

@@ -281,13 +281,26 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
   const uint32_t chunk = gridDim.x >> 3;
   const uint32_t xr = (gridDim.y > 1u) ? ((blockIdx.x + blockIdx.y) & 7u) : (blockIdx.x & 7u);
   const uint32_t vb = xr * chunk + (blockIdx.x >> 3);
-  const uint32_t tile = (kQuad ? vb : (vb * 4u + wave));
+  uint32_t tile = (kQuad ? vb : (vb * 4u + wave));
+  uint32_t pose = blockIdx.y;
   const uint32_t ntiles = p.tiles_x * p.tiles_y;
+  if constexpr (!kMoments) {
+    if (p.tile_order != nullptr) {   // a pose batch in world order: slot -> (pose, tile)
+      // XCD x takes `granule` consecutive workgroups' worth of slots, then XCD x + 1 the next: what runs on an XCD at a time sees one
+      // region of the map (its L2), and a hard region is shared by all eight (an eighth of the sorted list per XCD left the room
+      // 7 % slower: its grazing tiles ended up on one XCD)
+      const uint32_t G = p.tile_order_granule, li = blockIdx.x >> 3;
+      const uint32_t sb = ((li / G) * 8u + (blockIdx.x & 7u)) * G + (li % G);
+      if (sb >= p.n_tile_order) return;
+      const uint32_t e = __builtin_amdgcn_readfirstlane(p.tile_order[sb]);   // one entry per workgroup: its pose and its (four) tiles
+      pose = e >> 16;
+      tile = kQuad ? (e & 0xFFFFu) : ((e & 0xFFFFu) * 4u + wave);
+    }
+  }
   if (tile >= ntiles) {
     if constexpr (kMoments) find_moments_idle_wave<kQuad>(p, s_mom_red, s_mom_piece, kQuad ? vb : (vb * 4u + wave), wave, threadIdx.x & 63u);
     return;
   }
-  const uint32_t pose = blockIdx.y;
   const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
   const uint32_t twl = p.tile_w_log2;
   const uint32_t lx = lane & ((1u << twl) - 1u), ly = lane >> twl;

@@ -57,6 +57,11 @@ struct FindParams {
   // kind 32 (traverse.hip.h frontier_descent_start): the wave stops descending when a level would leave more than descent_final_cap
   // entries (<= 64) or after descent_levels levels
   uint32_t descent_final_cap, descent_levels;
+  // pose batches in world order (kernels.hip launch_batch_tile_order; nullable = pose-major): entry s = pose << 16 | (first tile / tiles per workgroup) of the s-th workgroup,
+  // sorted by where the tile's central ray leaves the map's bounding box -- the launch is then ONE row of blocks (gridDim.y == 1)
+  const uint32_t* tile_order;
+  uint32_t n_tile_order;
+  uint32_t tile_order_granule;   // workgroups of consecutive slots one XCD takes before the next XCD's turn (load balance across the XCDs)
   // diagnostics (nullable): per physical wave {s_memtime at entry, at exit (low 32 bits), s_memrealtime at entry, tile | xcc << 24}
   uint32_t* wave_clock;
   // MICP moment epilogue (launch_find_moments, k_find<..., kMom = true>): the moments of the gate-stable form (kernels.hip) are
@@ -261,6 +266,10 @@ hipError_t launch_micp_multi_fast_loop(const MicpMultiFastParams& p, hipStream_t
 hipError_t launch_micp_multi_init(const MicpMultiCall* call, MicpMultiState* state, hipStream_t s);
 hipError_t launch_micp_multi_step(const MicpMultiCall* call, MicpMultiState* state, hipStream_t s);
 
+// pose batches in world order (kernels.hip: keys + counting sort over 4096 cells of the map's bounding box)
+uint32_t batch_order_scratch_dwords(uint32_t n);
+hipError_t launch_batch_tile_order(const FindParams& p, ModelKind kind, uint32_t group, f3 bb_min, f3 bb_max, uint32_t* scratch, uint32_t* order,
+                                   hipStream_t s);
 hipError_t launch_find(const FindParams& p, ModelKind kind, int variant, hipStream_t s);
 // kinds 23 / 2 with the MICP moment epilogue: grid of find_moments_blocks(p, kind) workgroups, one partial row per workgroup, one mask
 // word per wave (23) or per workgroup (2: a tile is a workgroup) (p.mom_* set by the caller); followed by launch_micp_fast_loop_tiled

@@ -460,6 +460,46 @@ def test_o1dn_c2_size_pose_batch(ra, orc, ctx, meshes):
     rcc.close()
 
 
+@pytest.mark.parametrize("variant", find_kinds(0, 2, 23, 24, 32))
+def test_pose_batch_in_world_order_equals_the_pose_major_launch_and_the_oracle(ra, orc, ctx, meshes, variant):
+    """Round 6: a pose batch is launched in WORLD ORDER -- one key per workgroup (where the central ray of its tiles leaves the map's
+    bounding box), a counting sort, k_find walks the sorted list (kernels.hip launch_batch_tile_order).  The order decides which
+    workgroup computes a tile, never what is computed: 37 poses x a ragged 30 x 500 scan (a last workgroup with one tile, lanes
+    without a ray) in both orders and with two granules, every output bit-equal, and equal to the oracle; the same for two poses (fewer
+    workgroups than one turn of the XCDs)."""
+    from rmcl_amd import synthetic as syn, types as T, _capi
+    v, f = meshes("room100k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    model = syn.model_c2()
+    model.phi.inc = model.phi.inc * 128.0 / 30
+    model.phi.size = 30
+    model.theta.inc = model.theta.inc * 1024.0 / 500
+    model.theta.size = 500
+    rng = np.random.RandomState(17)
+    base = T.transform_from_rpy(*ROOM_POSE_RPY)
+    poses = np.array([T.mult(base, T.transform_from_rpy(tuple(rng.uniform(-1.5, 1.5, 3) * (1, 1, 0.2)), (0.0, 0.0, rng.uniform(-3, 3))))
+                      for _ in range(37)], dtype=T.TRANSFORM)
+    rcc = ra.RCCHipSpherical(hm)
+    rcc.setTsb(syn.tsb_offset())
+    rcc.setModel(model)
+    rcc.set_traversal(variant)
+    out = {}
+    for on in (0, 1, 3):     # pose-major, the default granule, three workgroups per XCD turn
+        _capi.check(_capi.lib().rmclhip_rcc_set_batch_order(rcc._h, on))
+        for P in (poses, poses[:2]):
+            rcc.find_batch(P)
+            mv = rcc.modelView()
+            out[(on, len(P))] = {k: np.array(mv[k]) for k in ("hits", "ranges", "points", "normals", "face_ids")}
+    for n in (37, 2):
+        for on in (1, 3):
+            for k in out[(0, n)]:
+                assert np.array_equal(out[(0, n)][k], out[(on, n)][k], equal_nan=True), (on, n, k)
+    ref = m.simulate_spherical(model, syn.tsb_offset(), poses, bvh=True, nthreads=8)
+    _compare(out[(1, 37)], ref, "world-order batch, kind %d" % variant)
+    rcc.close()
+
+
 @pytest.mark.parametrize("mesh", ["sphere100k", "room100k"])
 def test_automatic_variant_in_every_size_bracket(ra, orc, ctx, meshes, mesh):
     """variant 15 (the default) picks a traversal per rays-in-flight bracket (capi_rcc.cpp:find_variant): <= 57 344 four lanes
