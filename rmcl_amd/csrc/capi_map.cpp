@@ -183,8 +183,8 @@ RMCL_INTERNAL rmclhip_status map_upload(rmclhip_ctx* ctx, const BvhHost& bvh, rm
   if (e == hipSuccess) e = hipMemcpy(m->d_cnodes, bvh.cnodes.data(), cb, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(m->d_tris, bvh.tris.data(), tb, hipMemcpyHostToDevice);
   // the 16-wide twins for the cooperative descent of find kind 32 (512 B per node: 8 MB for a 100 k-triangle map), derived on the device;
-  // maps beyond kMaxNodes16 nodes (~4 M triangles) go without -- the descent then walks the four-wide nodes
-  constexpr size_t kMaxNodes16 = 600000;
+  // maps beyond kMaxNodes16 nodes (~18 M triangles) go without -- the descent then walks the four-wide nodes
+  constexpr size_t kMaxNodes16 = 6000000;   // (3 GB of twins for the largest: a 10 M-triangle map carries 1.7 GB, of 288)
   size_t c16b = 0;
   if (e == hipSuccess && bvh.cnodes.size() <= kMaxNodes16) {
     c16b = bvh.cnodes.size() * sizeof(Node16C);

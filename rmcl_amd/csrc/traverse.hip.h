@@ -1522,7 +1522,7 @@ __device__ __forceinline__ TraceStart frontier_descent_start(const uint32_t* __r
         return e_tn <= tf;   // (an inactive ray has ray_tfar < 0: never)
       };
       const uint32_t n_lo = min(n_leaves, 32u);
-      for (uint32_t j = 0; j < n_lo; ++j) m_lo |= box_hit(j) ? (1u << j) : 0u;
+      for (uint32_t j = 0; j < n_lo; ++j) m_lo |= box_hit(j) ? (1u << j) : 0u;   // (unrolling by four measured 5 % slower: registers)
       for (uint32_t j = 32u; j < n_leaves; ++j) m_hi |= box_hit(j) ? (1u << (j - 32u)) : 0u;
       // the unexpanded inner nodes (behind the leaves in the list; none on most tiles) are the ordinary traversal's business: nearest
       // first as in the sorted form -- a far subtree entered before the near one is walked without a bound

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""find kind 31 (cooperative descent, several final caps) against kind 23 beyond the two benchmark maps: spheres of 1 M / 10 M faces (the same
+"""find kind 32 (cooperative descent, several final caps) against kind 23 beyond the two benchmark maps: spheres of 1 M / 10 M faces (the same
 pose, and 16 poses in turn: nothing of the previous launch's lines in the MALL helps), other scan sizes, the mixed-scale and sliver maps.
 Kernel time: HIP events around back-to-back launches, median of 5 batches.
 usage (GPU box): python tools/descent_maps_ab.py [--big]"""
@@ -41,7 +41,7 @@ def row(name, hm, m, poses, iters=30):
                 ts.append(float(np.mean([rcc.time_find(p, 1) for p in poses])))
         return sorted(ts)[2] * 1e3
     base = t(23, 64)
-    print("%-44s kind 23 %8.2f us | kind 31: %s" % (name, base, "  ".join("cap %2d %8.2f (%+5.1f %%)" % (c, x, 100.0 * (x / base - 1.0)) for c, x in ((c, t(31, c)) for c in CAPS))), flush=True)
+    print("%-44s kind 23 %8.2f us | kind 32: %s" % (name, base, "  ".join("cap %2d %8.2f (%+5.1f %%)" % (c, x, 100.0 * (x / base - 1.0)) for c, x in ((c, t(32, c)) for c in CAPS))), flush=True)
     rcc.close()
 
 
