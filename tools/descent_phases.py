@@ -56,7 +56,7 @@ for L in range(3):
 last = np.where(s[:, 9] != 0, s[:, 9], np.where(s[:, 7] != 0, s[:, 7], np.where(s[:, 5] != 0, s[:, 5], s[:, 3])))
 phase("leftover inner nodes appended, final list lane-resident", s[:, 10], last)
 if kind == 32:
-    phase("every ray x every triangle of the final leaves (records via LDS)", s[:, 11], s[:, 10])
+    phase("every ray: a bit per final leaf it enters, then those leaves", s[:, 11], s[:, 10])
     phase("per-ray traversal of the unexpanded inner nodes", w[:, 5], s[:, 11])
 else:
     phase("every ray against every final entry (slab test, LDS pushes)", s[:, 11], s[:, 10])
