@@ -52,8 +52,9 @@ rmclhip_status rmclhip_debug_probe_find(rmclhip_rcc* rcc, const rmclhip_transfor
 /* A/B knobs of the cooperative descent of find kinds 32 / 31 (traverse.hip.h frontier_descent_start): the wave stops descending when a
  * level would leave more than final_cap entries (<= 64, default 64) or after (max_levels & 255) levels (default 24; 0 = kind 23's
  * frontier start with the descent's bookkeeping); bits 8..15 of max_levels, when not 0: kind 32's bound on the final leaves one ray may
- * enter before its wave starts at the root instead (default 24); bit 31 set: descend on the four-wide nodes even where the map carries
- * the 16-wide twins (A/B).  Results do not depend on any of them.  Exported by librmclhip.so. */
+ * enter before its wave starts at the root instead (default 24); bits 29..30, when not 0: 1 + the tile mapping of single scans (0 as
+ * dealt, 1 an eighth of the image per XCD, 2 a CU's two workgroups from the image's halves; find_kernel.hip.h) instead of the tuned /
+ * default one; bit 31 set: descend on the four-wide nodes even where the map carries the 16-wide twins (A/B).  Results do not depend on any of them.  Exported by librmclhip.so. */
 rmclhip_status rmclhip_rcc_set_descent(rmclhip_rcc* rcc, uint32_t final_cap, uint32_t max_levels);
 
 /* A/B knob (round 6, VERDICT r5 #7b): pose batches in WORLD ORDER (the default; on = 0 restores the pose-major launch).  Every batch launch

@@ -205,6 +205,8 @@ struct rmclhip_rcc {
   bool descent_wide = true;   // ... on the 16-wide twins when the map has them (A/B: rmclhip_rcc_set_descent's max_levels bit 31 clears it)
   uint32_t descent_final_cap = 64, descent_levels = 24;   // kind 32's cooperative descent (rmclhip_rcc_set_descent, include/rmclhip_lab.h)
   // pose batches in world order (kernels.hip launch_batch_tile_order; A/B knob rmclhip_rcc_set_batch_order): keys | sorted keys, values | sorted values, sort scratch
+  int xcd_mapping_override = -1;   // A/B knob (rmclhip_rcc_set_descent bits 29..30): -1 = the tuned / default mapping
+  uint32_t tuned_xcd_mapping = 0;  // rmclhip_rcc_autotune's choice among 0 / 1 / 2 (FindParams::xcd_mapping); 0 = the default
   uint32_t batch_order = 64;   // 0 = pose-major; else the granule (workgroups per XCD turn)
   DevBuf<uint32_t> d_ord_scratch, d_ord_vals;
   uint32_t descent_leaf_cap = 24;   // kind 32: a wave one of whose rays enters more final leaves than this starts at the root (lab: rmclhip_rcc_set_descent)

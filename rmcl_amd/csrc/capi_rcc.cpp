@@ -176,7 +176,7 @@ rmclhip_status rmclhip_rcc_set_model_ondn(rmclhip_rcc* r, uint32_t width, uint32
   r->kind = kModelOnDn;
   r->ang_aspect = 0.0f;
   r->tile_planes_ok = false;
-  r->tuned_kind = r->tuned_batch_kind = 0; r->tuned_frontier = r->tuned_batch_frontier = true; r->tuned_tile = 0;
+  r->tuned_kind = r->tuned_batch_kind = 0; r->tuned_frontier = r->tuned_batch_frontier = true; r->tuned_tile = 0; r->tuned_xcd_mapping = 0;
   r->graph_dirty = true; r->fast_graph_dirty = true;
   r->W = width; r->H = height;
   r->range = range;
@@ -444,6 +444,7 @@ RMCL_INTERNAL void fill_find_params(rmclhip_rcc* r, FindParams& p, uint32_t npos
     // pushes, so the start may leave at most 64 - stack_need entries (traverse.hip.h frontier_start returns the root beyond that); a
     // tree that leaves no room for even two starts every ray at the root.
     p.descent_final_cap = r->descent_final_cap;
+    p.xcd_mapping = (r->xcd_mapping_override >= 0) ? static_cast<uint32_t>(r->xcd_mapping_override) : r->tuned_xcd_mapping;
     p.descent_levels = (r->descent_levels & 0xFFu) | (r->descent_leaf_cap << 8);   // (traverse.hip.h frontier_descent_start: levels | most leaves per ray << 8)
     p.frontier_max_preload = (need < 64u) ? 64u - need : 0u;
     if (p.frontier_max_preload < 2u) p.tile_planes = nullptr;
@@ -458,6 +459,7 @@ RMCL_INTERNAL rmclhip_status rebuild_tile_planes(rmclhip_rcc* r, bool keep_tunin
     r->tuned_kind = r->tuned_batch_kind = 0;   // a measurement belongs to the model it was taken with
     r->tuned_frontier = r->tuned_batch_frontier = true;
     r->tuned_tile = 0;
+    r->tuned_xcd_mapping = 0;
   }
   if (r->kind == kModelOnDn || r->kind == kModelNone || r->W == 0 || r->H == 0) return RMCLHIP_OK;
   FindParams p;

@@ -115,6 +115,24 @@ rmclhip_status rmclhip_rcc_autotune(rmclhip_rcc* r, const rmclhip_transform* Tbm
     r->tuned_tile = best_tile;
     if (rmclhip_status st = rebuild_tile_planes(r, true)) return st;
   }
+  // ... and which workgroup computes which tile (find_kernel.hip.h: 0 = as dealt, the default; 1 = an eighth of the image per XCD;
+  // 2 = a CU's two workgroups from the two halves of the image)
+  if (r->xcd_mapping_override < 0) {
+    uint32_t best_map = r->tuned_xcd_mapping;
+    for (uint32_t m = 0; m < 3u; ++m) {
+      if (m == best_map) continue;
+      const uint32_t keep = r->tuned_xcd_mapping;
+      r->tuned_xcd_mapping = m;
+      float t[5];
+      for (float& x : t) {
+        if (rmclhip_status st = rmclhip_rcc_time_find(r, Tbm_est, 8, &x)) { r->tuned_xcd_mapping = keep; return st; }
+      }
+      std::sort(t, t + 5);
+      if (t[2] < 0.98f * best_ms) { best_map = m; best_ms = t[2]; }
+      r->tuned_xcd_mapping = keep;
+    }
+    r->tuned_xcd_mapping = best_map;
+  }
   r->graph_dirty = true; r->fast_graph_dirty = true;
   if (chosen_kind) *chosen_kind = best->reported;
   if (kernel_ms) *kernel_ms = best_ms;
@@ -268,6 +286,7 @@ rmclhip_status rmclhip_rcc_set_descent(rmclhip_rcc* r, uint32_t final_cap, uint3
   r->descent_final_cap = final_cap;
   r->descent_levels = max_levels & 0xFFu;
   if ((max_levels >> 8) & 0xFFu) r->descent_leaf_cap = (max_levels >> 8) & 0xFFu;   // bits 8..15 (A/B): kind 32's leaves-per-ray bound, 0 = keep
+  r->xcd_mapping_override = static_cast<int>((max_levels >> 29) & 3u) - 1;   // bits 29..30 (A/B): 1 + FindParams::xcd_mapping, 0 = the tuned / default one
   r->descent_wide = (max_levels >> 31) == 0u;   // bit 31 (A/B): the four-wide nodes even where the map has the 16-wide twins
   r->graph_dirty = true; r->fast_graph_dirty = true;
   return RMCLHIP_OK;

@@ -273,14 +273,27 @@ __global__ void __launch_bounds__(256) k_find(const FindParams p) {
     }
     __syncthreads();
   }
-  // XCD-aware remap: the dispatcher places block b on XCD b%8; give every XCD a contiguous range of
-  // tiles so neighbouring tiles (which walk the same subtrees) share one L2.  gridDim.x % 8 == 0.
-  // Pose batches (gridDim.y > 1) rotate the assignment by the pose: a model of a few tiles fills only the first of the eight
-  // ranges, and without the rotation every pose's occupied range sat on the SAME XCD (round 4: 2000 poses x 32x32 rays ran on an
-  // eighth of the chip, 0.80 ms; rotated 0.2x ms -- profiles/r04_v1_batch_breakdown.txt).
+  // Which workgroup computes which tile.  The dispatcher places workgroup b on XCD b % 8 and deals an XCD's workgroups round-robin over
+  // its 32 CUs.  Rounds 1-5 gave every XCD a contiguous range of tiles (neighbouring tiles walk the same subtrees: one L2) -- but a
+  // single scan is bound by issue slots and by its slowest waves, not by L2 misses, and a scan's hard tiles are neighbours (a room's
+  // grazing rows): contiguous ranges put them on ONE or two XCDs and, two tile rows apart, on the same SIMDs.  Round 6
+  // (profiles/r06_tile_mapping_ab.txt): single scans are dealt as the hardware deals them -- workgroup b = tiles 4b .. 4b+3, so that
+  // every XCD sees every eighth workgroup of every tile row (room-100k kind 23: 25.3 -> 22.2 us, sphere-100k 17.4 -> 16.4, 1 M faces
+  // 22.3 -> 21.3).  p.xcd_mapping: 0 = that; 1 = contiguous ranges; 2 = the two workgroups of a CU from the two halves of the image
+  // (rmclhip_rcc_autotune measures the three).  gridDim.x % 8 == 0.
+  // Pose batches launched pose-major (gridDim.y > 1; world order off) keep the contiguous ranges, rotated by the pose: a model of a few
+  // tiles fills only the first of the eight ranges, and without the rotation every pose's occupied range sat on the SAME XCD (round 4:
+  // 2000 poses x 32x32 rays ran on an eighth of the chip, 0.80 ms; rotated 0.2x ms -- profiles/r04_v1_batch_breakdown.txt).
   const uint32_t chunk = gridDim.x >> 3;
   const uint32_t xr = (gridDim.y > 1u) ? ((blockIdx.x + blockIdx.y) & 7u) : (blockIdx.x & 7u);
-  const uint32_t vb = xr * chunk + (blockIdx.x >> 3);
+  uint32_t vb = xr * chunk + (blockIdx.x >> 3);
+  if (gridDim.y == 1u) {
+    if (p.xcd_mapping == 0u) vb = blockIdx.x;
+    else if (p.xcd_mapping == 2u && (chunk & 63u) == 0u) {
+      const uint32_t li = blockIdx.x >> 3, band = (li >> 5) & 1u, in_band = (li >> 6) * 32u + (li & 31u);
+      vb = band * (gridDim.x >> 1) + xr * (chunk >> 1) + in_band;
+    }
+  }
   uint32_t tile = (kQuad ? vb : (vb * 4u + wave));
   uint32_t pose = blockIdx.y;
   const uint32_t ntiles = p.tiles_x * p.tiles_y;

@@ -61,7 +61,8 @@ struct FindParams {
   // sorted by where the tile's central ray leaves the map's bounding box -- the launch is then ONE row of blocks (gridDim.y == 1)
   const uint32_t* tile_order;
   uint32_t n_tile_order;
-  uint32_t tile_order_granule;   // workgroups of consecutive slots one XCD takes before the next XCD's turn (load balance across the XCDs)
+  uint32_t tile_order_granule;
+  uint32_t xcd_mapping;    // single scans: 0 = workgroup b computes tiles 4b.. (every XCD sees all of the image), 1 = an eighth of the image per XCD, 2 = a CU's two workgroups from the image's two halves (find_kernel.hip.h)   // workgroups of consecutive slots one XCD takes before the next XCD's turn (load balance across the XCDs)
   // diagnostics (nullable): per physical wave {s_memtime at entry, at exit (low 32 bits), s_memrealtime at entry, tile | xcc << 24}
   uint32_t* wave_clock;
   // MICP moment epilogue (launch_find_moments, k_find<..., kMom = true>): the moments of the gate-stable form (kernels.hip) are
