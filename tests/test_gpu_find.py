@@ -461,6 +461,51 @@ def test_o1dn_c2_size_pose_batch(ra, orc, ctx, meshes):
 
 
 @pytest.mark.parametrize("variant", find_kinds(0, 2, 23, 24, 32))
+def test_every_dealing_of_the_tiles_gives_the_same_scan_and_the_same_correction(ra, orc, ctx, meshes, variant):
+    """Round 6: which workgroup computes which tile of a single scan (FindParams::xcd_mapping: 0 as the hardware deals workgroups --
+    the default --, 1 an eighth of the image per XCD as in rounds 1-5, 2 a CU's two workgroups from the image's halves) decides
+    where a tile runs, never what it computes: 128 x 1024 (mapping 2's own shape: 64 workgroups per XCD), a ragged 100 x 1000 and
+    64 x 512, every output bit-equal across the three, the default equal to the oracle; and a correction whose find forms the
+    moments in its epilogue (partial rows and mask words follow the dealing) counts the same correspondences and returns the same
+    pose to 1e-6 (the f64 partial rows are summed in workgroup order, which is what the dealing changes: last bits only)."""
+    from rmcl_amd import synthetic as syn, types as T, _capi
+    v, f = meshes("room100k")
+    m = orc.Mesh(v, f)
+    hm = ra.import_hip_map(ctx, v, f)
+    Tbm = T.transform_from_rpy(*ROOM_POSE_RPY)
+    est = T.mult(Tbm, T.transform_from_rpy((0.03, -0.02, 0.015), (0.004, -0.003, 0.008)))
+    for H, W in ((128, 1024), (100, 1000), (64, 512)):
+        model = syn.model_c2()
+        model.phi.inc = model.phi.inc * 128.0 / H
+        model.phi.size = H
+        model.theta.inc = model.theta.inc * 1024.0 / W
+        model.theta.size = W
+        rcc = ra.RCCHipSpherical(hm)
+        rcc.setTsb(syn.tsb_offset())
+        rcc.setModel(model)
+        rcc.set_traversal(variant)
+        rcc.find(Tbm)
+        rcc.set_dataset_from_ranges(rcc.modelView()["ranges"])
+        rcc.params.max_dist = 0.5
+        out, corr = {}, {}
+        for mapping in (0, 1, 2):
+            _capi.check(_capi.lib().rmclhip_rcc_set_descent(rcc._h, 64, 24 | (24 << 8) | ((mapping + 1) << 29)))
+            rcc.find(Tbm)
+            mv = rcc.modelView()
+            out[mapping] = {k: np.array(mv[k]) for k in ("hits", "ranges", "points", "normals", "face_ids")}
+            Tc, st = rcc.correct_once(est, T.identity(), 4, 0.0, False)
+            corr[mapping] = (np.frombuffer(np.array(Tc).tobytes()[:28], dtype=np.float32).astype(np.float64), int(st["n_meas"]))   # quaternion + translation
+        for mapping in (1, 2):
+            for k in out[0]:
+                assert np.array_equal(out[0][k], out[mapping][k], equal_nan=True), (H, W, mapping, k)
+            assert corr[mapping][1] == corr[0][1], (H, W, mapping)
+            assert np.allclose(corr[mapping][0], corr[0][0], rtol=0.0, atol=1e-6), (H, W, mapping)
+        if (H, W) == (100, 1000):
+            _compare(out[0], m.simulate_spherical(model, syn.tsb_offset(), Tbm, bvh=True, nthreads=8), "dealing 0, kind %d" % variant)
+        rcc.close()
+
+
+@pytest.mark.parametrize("variant", find_kinds(0, 2, 23, 24, 32))
 def test_pose_batch_in_world_order_equals_the_pose_major_launch_and_the_oracle(ra, orc, ctx, meshes, variant):
     """Round 6: a pose batch is launched in WORLD ORDER -- one key per workgroup (where the central ray of its tiles leaves the map's
     bounding box), a counting sort, k_find walks the sorted list (kernels.hip launch_batch_tile_order).  The order decides which
