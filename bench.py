@@ -656,7 +656,9 @@ def main():
         units_per_step = n_local * n_beams
         kernel_ms = upd.time_update(d_poses, d_attrs, hi - lo, iters=5)
         b_alg = algorithmic_bytes_pf(hi - lo, n_beams)
-        kname = "k_pf_update_v3<19 rows, leaves <= 2, accumulate>"
+        # (the updater runs on the library's default variant -- this workload sets none --, which launches the accumulation form:
+        # capi_pf.cpp / kernels.hip launch_pf_update; a run under rmclhip_pf_set_variant would need the label re-derived)
+        kname = "k_pf_update_v3<19 rows, leaves <= 2, accumulate> (library default variant)"
         traffic = measured_traffic("k_pf_update_v3")
         extras["particle_updates_per_s"] = round(world * args.steps * n_local / elapsed, 1)
         extras["allgather_bytes"] = 4 * n_total
