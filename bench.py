@@ -32,6 +32,10 @@ import os
 import sys
 import time
 
+# several operators = several streams: ask the HIP runtime for eight hardware queues BEFORE anything initialises it (torch does, below);
+# with the default four, a fifth stream shares a queue with another and the two no longer overlap (rmclhip_ctx_create)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

@@ -1,6 +1,8 @@
 // capi_map.cpp -- see capi_internal.h
 #include "capi_internal.h"
 
+#include <cstdlib>
+
 
 
 RMCL_INTERNAL thread_local std::string g_err;
@@ -13,6 +15,14 @@ rmclhip_status rmclhip_ctx_create(int device, rmclhip_ctx** out) {
   ApiGuard guard_("rmclhip_ctx_create");
   if (!out) return fail(RMCLHIP_ERR_INVALID, "ctx_create: out is null");
   *out = nullptr;
+  // Every operator (and the free statistics_p2l) runs on a stream of its own, and the sensors of one MICP correction -- or two operators
+  // a node keeps in flight -- count on those streams running CONCURRENTLY.  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware
+  // queues (default 4) in turn: with a fifth stream in the process two of them share a queue and their kernels run one after the other
+  // (round 6, measured: a two-sensor correction 46 -> 63 us, two scans in flight 11.4 -> 7.8 G rays/s, once the bench held five
+  // streams).  The runtime reads the variable when it initialises, i.e. at the process's first HIP call: if that is this one and the
+  // caller has not chosen a value, ask for eight queues.  A process that has initialised HIP before (another library) sets
+  // GPU_MAX_HW_QUEUES itself -- INTEGRATION.md.
+  if (std::getenv("GPU_MAX_HW_QUEUES") == nullptr) (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0)

@@ -7,6 +7,7 @@ normals within 1e-5 relative (BASELINE.json north_star).
 import hashlib
 import json
 import math
+import os
 
 import numpy as np
 import pytest
@@ -458,6 +459,19 @@ def test_o1dn_c2_size_pose_batch(ra, orc, ctx, meshes):
     ref = m.simulate_o1dn(W, H, float(model.range.min), float(model.range.max), orig, dirs, Tsb, poses, bvh=True, nthreads=8)
     _compare(gpu, ref, "o1dn C2 batch")
     rcc.close()
+
+
+def test_context_creation_asks_for_eight_hardware_queues(ra, ctx):
+    """Round 6: operators run on streams of their own and count on overlapping; the HIP runtime deals streams onto GPU_MAX_HW_QUEUES
+    hardware queues (default 4) and a fifth stream shares one (a two-sensor correction 46 -> 63 us).  rmclhip_ctx_create sets the
+    variable to 8 unless the caller chose a value (the C environment: os.environ is Python's copy)."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    libc.getenv.restype = ctypes.c_char_p
+    v = libc.getenv(b"GPU_MAX_HW_QUEUES")
+    assert v is not None and int(v) >= 1
+    if "GPU_MAX_HW_QUEUES" not in os.environ:
+        assert int(v) == 8
 
 
 @pytest.mark.parametrize("variant", find_kinds(0, 2, 23, 24, 32))
