@@ -456,7 +456,10 @@ rmclhip_status rmclhip_rcc_find_variant(const rmclhip_rcc* rcc, uint32_t nposes,
 /* Measurement instead of brackets: the automatic rule above was tuned on two synthetic maps; which traversal is fastest for a
  * single scan depends on the map (open / occluded), the model's size and shape, and where the sensor is.  This call times the
  * product's single-scan kinds (2, 23, 24 -- the latter two with and without the frontier start -- and 32 with a short and a long list) on THIS operator's map and model at
- * the given pose (40 short launches each, HIP events), then the winner's tile shape (4, 8, 16 or 32 rays wide) and makes the fastest one the automatic choice for single scans until the model or the tiling changes.  Results do not
+ * the given pose (40 short launches each, HIP events), then the winner's tile shape (4, 8, 16 or 32 rays wide), then which workgroup
+ * computes which tile (as the hardware deals workgroups over the XCDs -- the default --, an eighth of the image per XCD, or a CU's two
+ * workgroups from the image's two halves), and makes the fastest combination the automatic choice for single scans until the model
+ * or the tiling changes (~10 ms in all).  Results do not
  * depend on the kind (bit-identical); batches keep the rule.  Opt-in: never run behind the caller's back.
  * chosen_kind / kernel_ms may be NULL. */
 rmclhip_status rmclhip_rcc_autotune(rmclhip_rcc* rcc, const rmclhip_transform* Tbm_est, int* chosen_kind, float* kernel_ms);
